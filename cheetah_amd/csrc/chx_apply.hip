@@ -1,0 +1,280 @@
+// chx_apply.hip — linear (affine 7x7) tracking kernels for gfx950.
+//
+// Replaces `new_particles = incoming.particles @ tm.mT` (cheetah/accelerator/element.py:182),
+// the element-by-element loop of Segment.track (segment.py:571-572) and the per-particle part of
+// Cavity.track (cavity.py:112-151,220-226).
+//
+// Design (HBM-bound, 56 B/particle fp32, 112 B fp64):
+//  * the reference's AoS layout particles[B][N][7] is kept (28-byte rows are not 16-B aligned),
+//    so a workgroup streams a TILE of rows as contiguous 16-byte vectors (global_load_dwordx4,
+//    fully coalesced) into LDS, every lane then picks its own rows at dword stride 7
+//    (gcd(7,32)=1 -> conflict-free ds_read_b32), the results go back through the same LDS tile and
+//    leave as 16-byte vector stores;
+//  * the 7x7 map is wave-uniform for a tile that lies inside one batch row -> read through the
+//    scalar cache (s_load), only tiles straddling a batch boundary fall back to per-lane loads;
+//  * fp32 rows are evaluated as an fmaf chain in the order j=0..6 (same sequence in the single
+//    pass, element-wise and fused kernels, so those agree bit for bit).
+#include "chx_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ T chx_fma(T a, T b, T c);
+template <> __device__ __forceinline__ float chx_fma<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double chx_fma<double>(double a, double b, double c) { return fma(a, b, c); }
+
+// y = R x with R row-major 7x7 (49 values). R may live in SGPRs (uniform pointer).
+template <typename T>
+__device__ __forceinline__ void apply7(const T* __restrict__ R, const T (&x)[7], T (&y)[7]) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        T acc = R[i * 7] * x[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) acc = chx_fma<T>(R[i * 7 + j], x[j], acc);
+        y[i] = acc;
+    }
+}
+
+// Cavity per-particle epilogue (cavity.py:135-151, 220-226), evaluated in fp64.
+// c = [a, b, kbeta0, phi, cosphi, T566, T556, T555]; tau/delta are the INCOMING coordinates.
+template <typename T>
+__device__ __forceinline__ void cavity_epilogue(const double* __restrict__ c, const T (&x)[7], T (&y)[7]) {
+    const double tau = (double)x[4], delta = (double)x[5];
+    const double dnew = delta * c[0] + c[1] * (cos(-tau * c[2] + c[3]) - c[4]);
+    const double tnew = (double)y[4] + (c[5] * delta * delta + c[6] * tau * delta + c[7] * tau * tau);
+    y[5] = (T)dnew;
+    y[4] = (T)tnew;
+}
+
+// ---- generic multi-map kernel -------------------------------------------------------------
+// MODE 0: x_out = R[0] x_in                      (single pass)
+// MODE 1: x_out = R[E-1] ... R[0] x_in           (fused run, particle stays in registers)
+// MODE 2: single pass + cavity epilogue
+// Output rows are flat over B*N. Input is flat too (Bx == B) or shared (Bx == 1, handled by
+// indexing with n only). TP = particles per tile, PPT = TP / CHX_BLOCK.
+template <typename T, int PPT, int MODE>
+__global__ __launch_bounds__(CHX_BLOCK) void apply_tile_kernel(
+    const T* __restrict__ x_in, const T* __restrict__ R, T* __restrict__ x_out,
+    const double* __restrict__ coeffs, int64_t B, int64_t Bx, int64_t BR, int64_t N, int E,
+    int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = PPT * CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+
+    // tiles are laid out per batch row so that a tile never straddles two rows:
+    // tiles_per_row = ceil(N / TP); blockIdx.x = b * tiles_per_row + t
+    const int64_t tiles_per_row = (N + TP - 1) / TP;
+    const int64_t b = blockIdx.x / tiles_per_row;
+    const int64_t t = blockIdx.x - b * tiles_per_row;
+    const int64_t n0 = t * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+
+    const int64_t in_row = (Bx == 1) ? 0 : b;
+    const T* gin = x_in + (in_row * N + n0) * 7;
+    T* gout = x_out + (b * N + n0) * 7;
+    // vector path needs the tile start 16-B aligned: base aligned (checked on host) and
+    // (row*N + n0)*7*sizeof(T) % 16 == 0. n0*7*sizeof(T) is a multiple of 16 by construction.
+    const bool in_vec = in_vec_ok && (((in_row * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
+    const bool out_vec = out_vec_ok && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
+
+    tile_load<T>(gin, lds, np * 7, in_vec);
+    __syncthreads();
+
+    const int64_t rb = (BR == 1) ? 0 : b;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + k * CHX_BLOCK;
+        if (p < np) {
+            T x[7], y[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) x[j] = lds[p * 7 + j];
+            if (MODE == 1) {
+                for (int e = 0; e < E; ++e) {
+                    const T* __restrict__ Re = R + ((int64_t)e * BR + rb) * 49;
+                    apply7<T>(Re, x, y);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) x[j] = y[j];
+                }
+            } else {
+                const T* __restrict__ Rb = R + rb * 49;
+                apply7<T>(Rb, x, y);
+                if (MODE == 2) cavity_epilogue<T>(coeffs + b * CHX_CAV_NCOEF, x, y);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = y[j];
+        }
+    }
+    __syncthreads();
+    tile_store<T>(gout, lds, np * 7, out_vec);
+}
+
+// ---- shared-input kernel (Bx == 1, B > 1): one x tile, many maps ---------------------------
+// grid = (tiles over N, batch chunks). Each block keeps its particles in registers and loops
+// over its chunk of batch rows; writes dominate (28 B per (batch, particle) in fp32).
+template <typename T, int PPT>
+__global__ __launch_bounds__(CHX_BLOCK) void apply_shared_kernel(
+    const T* __restrict__ x_in, const T* __restrict__ R, T* __restrict__ x_out, int64_t B,
+    int64_t N, int64_t rows_per_chunk, int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = PPT * CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t b1 = (b0 + rows_per_chunk < B) ? b0 + rows_per_chunk : B;
+
+    tile_load<T>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0);
+    __syncthreads();
+    T x[PPT][7];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + k * CHX_BLOCK;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? lds[p * 7 + j] : (T)0;
+    }
+    for (int64_t b = b0; b < b1; ++b) {
+        const T* __restrict__ Rb = R + b * 49;
+        __syncthreads();  // previous store finished reading lds
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * CHX_BLOCK;
+            if (p < np) {
+                T y[7];
+                apply7<T>(Rb, x[k], y);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = y[j];
+            }
+        }
+        __syncthreads();
+        const bool out_vec = out_vec_ok && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
+        tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec);
+    }
+}
+
+template <typename T> struct tile_cfg;
+template <> struct tile_cfg<float> { static constexpr int PPT = 2; };   // 512 rows, 14 KiB LDS
+template <> struct tile_cfg<double> { static constexpr int PPT = 1; };  // 256 rows, 14 KiB LDS
+
+template <typename T, int MODE>
+int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coeffs, int64_t B,
+                 int64_t Bx, int64_t BR, int64_t N, int E, hipStream_t s) {
+    constexpr int PPT = tile_cfg<T>::PPT;
+    constexpr int TP = PPT * CHX_BLOCK;
+    const int64_t tiles = ((N + TP - 1) / TP) * B;
+    if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL((apply_tile_kernel<T, PPT, MODE>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s,
+                       (const T*)x_in, (const T*)R, (T*)x_out, coeffs, B, Bx, BR, N, E,
+                       (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+template <typename T>
+int launch_shared(const void* x_in, const void* R, void* x_out, int64_t B, int64_t N, hipStream_t s) {
+    constexpr int PPT = tile_cfg<T>::PPT;
+    constexpr int TP = PPT * CHX_BLOCK;
+    const int64_t tiles = (N + TP - 1) / TP;
+    // enough blocks to fill 256 CUs x ~8 blocks, but keep >= 8 rows per chunk for x reuse
+    int64_t chunks = (2048 + tiles - 1) / tiles;
+    if (chunks < 1) chunks = 1;
+    if (chunks > B) chunks = B;
+    int64_t rows = (B + chunks - 1) / chunks;
+    if (rows < 8 && B >= 8) rows = 8;
+    chunks = (B + rows - 1) / rows;
+    if (tiles > 0x7fffffffLL || chunks > 65535) return CHX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL((apply_shared_kernel<T, PPT>), dim3((unsigned)tiles, (unsigned)chunks),
+                       dim3(CHX_BLOCK), 0, s, (const T*)x_in, (const T*)R, (T*)x_out, B, N, rows,
+                       (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+int check_common(const void* x_in, const void* R, const void* x_out, int64_t B, int64_t Bx,
+                 int64_t BR, int64_t N, int dtype) {
+    if (!x_in || !R || !x_out || B < 1 || N < 1) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    if ((reinterpret_cast<uintptr_t>(x_in) % esz) || (reinterpret_cast<uintptr_t>(x_out) % esz) ||
+        (reinterpret_cast<uintptr_t>(R) % esz))
+        return CHX_ERR_MISALIGNED;
+    return CHX_OK;
+}
+
+}  // namespace
+
+extern "C" int chx_apply_affine7(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
+                                 int64_t BR, int64_t N, int dtype, void* stream) {
+    int st = check_common(x_in, R, x_out, B, Bx, BR, N, dtype);
+    if (st != CHX_OK) return st;
+    hipStream_t s = (hipStream_t)stream;
+    if (Bx == 1 && B > 1 && BR == B) {
+        return dtype == CHX_F32 ? launch_shared<float>(x_in, R, x_out, B, N, s)
+                                : launch_shared<double>(x_in, R, x_out, B, N, s);
+    }
+    return dtype == CHX_F32 ? launch_tiles<float, 0>(x_in, R, x_out, nullptr, B, Bx, BR, N, 1, s)
+                            : launch_tiles<double, 0>(x_in, R, x_out, nullptr, B, Bx, BR, N, 1, s);
+}
+
+extern "C" int chx_track_fused(const void* x_in, const void* R, void* x_out, int64_t E, int64_t B,
+                               int64_t Bx, int64_t BR, int64_t N, int dtype, void* stream) {
+    int st = check_common(x_in, R, x_out, B, Bx, BR, N, dtype);
+    if (st != CHX_OK) return st;
+    if (E < 1 || E > 0x7fffffff) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == CHX_F32 ? launch_tiles<float, 1>(x_in, R, x_out, nullptr, B, Bx, BR, N, (int)E, s)
+                            : launch_tiles<double, 1>(x_in, R, x_out, nullptr, B, Bx, BR, N, (int)E, s);
+}
+
+extern "C" int chx_track_elementwise(const void* x_in, const void* R, void* x_out, void* scratch,
+                                     int64_t E, int64_t B, int64_t Bx, int64_t BR, int64_t N,
+                                     int dtype, void* stream) {
+    int st = check_common(x_in, R, x_out, B, Bx, BR, N, dtype);
+    if (st != CHX_OK) return st;
+    if (E < 1) return CHX_ERR_INVALID_ARG;
+    if (E > 1 && !scratch) return CHX_ERR_WORKSPACE;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    const char* Rp = (const char*)R;
+    // ping-pong so that pass E-1 lands in x_out
+    const void* src = x_in;
+    int64_t src_B = Bx;
+    for (int64_t e = 0; e < E; ++e) {
+        void* dst = (((E - 1 - e) & 1) == 0) ? x_out : scratch;
+        st = chx_apply_affine7(src, Rp + (size_t)e * (size_t)BR * 49 * esz, dst, B, src_B, BR, N,
+                               dtype, stream);
+        if (st != CHX_OK) return st;
+        src = dst;
+        src_B = B;
+    }
+    return CHX_OK;
+}
+
+extern "C" int chx_cavity_track(const void* x_in, const void* R, const double* coeffs, void* x_out,
+                                int64_t B, int64_t Bx, int64_t N, int dtype, void* stream) {
+    int st = check_common(x_in, R, x_out, B, Bx, B, N, dtype);
+    if (st != CHX_OK) return st;
+    if (!coeffs) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == CHX_F32 ? launch_tiles<float, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s)
+                            : launch_tiles<double, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s);
+}
+
+extern "C" int chx_time_apply_ms(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
+                                 int64_t BR, int64_t N, int dtype, int iters, void* stream,
+                                 double* ms_out) {
+    if (!ms_out || iters < 1) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CHX_ERR_LAUNCH;
+    int st = chx_apply_affine7(x_in, R, x_out, B, Bx, BR, N, dtype, stream);  // warm
+    if (st == CHX_OK) {
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters && st == CHX_OK; ++i)
+            st = chx_apply_affine7(x_in, R, x_out, B, Bx, BR, N, dtype, stream);
+        hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) st = CHX_ERR_LAUNCH;
+        float ms = 0.f;
+        if (st == CHX_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *ms_out = (double)ms / iters;
+        else if (st == CHX_OK) st = CHX_ERR_LAUNCH;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return st;
+}

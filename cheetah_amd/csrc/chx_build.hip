@@ -1,0 +1,608 @@
+// chx_build.hip — per-element 7x7 first-order transfer maps, segment composition and cavity
+// coefficients, built on device in fp64 (one thread per batch row; B is small, this is latency-
+// not bandwidth-work) so that a parameter change never costs a host round trip.
+//
+// Reference arithmetic being replaced (all under cheetah/):
+//   drift_matrix            track_methods.py:284-299
+//   base_rmatrix            track_methods.py:17-77   (complex sqrt/cos/sinc -> real branches here)
+//   rotation / misalignment track_methods.py:302-382
+//   Quadrupole              accelerator/quadrupole.py:93-110
+//   Dipole + edge maps      accelerator/dipole.py:372-394, 430-466
+//   correctors              accelerator/{horizontal,vertical,combined}_corrector.py
+//   Cavity R                accelerator/cavity.py:253-358 ; track coefficients cavity.py:100-226
+//   si1mdiv / log1pdiv      utils/autograd.py:77-146
+//   Segment composition     accelerator/segment.py:534-543
+//
+// All builders are templates over a scalar S that is either `double` or a forward-mode dual
+// number; chx_build_rmatrix_vjp seeds one input at a time and contracts dR/dtheta with the
+// incoming cotangent, which replaces torch autograd through ~40 tiny ops per element.
+#include "chx_common.h"
+
+namespace {
+
+constexpr double kSpeedOfLight = 299792458.0;  // scipy.constants.speed_of_light (cavity.py:7)
+constexpr double kPi = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------------------------
+struct Dual {
+    double v, d;
+};
+__device__ __forceinline__ Dual mk(double v, double d) { Dual r; r.v = v; r.d = d; return r; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return mk(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return mk(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return mk(a.v * b.v, a.d * b.v + a.v * b.d); }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+    const double q = a.v / b.v;
+    return mk(q, (a.d - q * b.d) / b.v);
+}
+__device__ __forceinline__ Dual operator-(Dual a) { return mk(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return mk(a.v + b, a.d); }
+__device__ __forceinline__ Dual operator+(double a, Dual b) { return mk(a + b.v, b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return mk(a.v - b, a.d); }
+__device__ __forceinline__ Dual operator-(double a, Dual b) { return mk(a - b.v, -b.d); }
+__device__ __forceinline__ Dual operator*(Dual a, double b) { return mk(a.v * b, a.d * b); }
+__device__ __forceinline__ Dual operator*(double a, Dual b) { return mk(a * b.v, a * b.d); }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { return mk(a.v / b, a.d / b); }
+__device__ __forceinline__ Dual operator/(double a, Dual b) {
+    const double q = a / b.v;
+    return mk(q, -q * b.d / b.v);
+}
+
+__device__ __forceinline__ double val(double x) { return x; }
+__device__ __forceinline__ double val(Dual x) { return x.v; }
+__device__ __forceinline__ double tan_of(double x) { return 0.0 * x; }
+__device__ __forceinline__ double tan_of(Dual x) { return x.d; }
+
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+__device__ __forceinline__ double m_tan(double x) { return tan(x); }
+__device__ __forceinline__ double m_sinh(double x) { return sinh(x); }
+__device__ __forceinline__ double m_cosh(double x) { return cosh(x); }
+__device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ Dual m_sqrt(Dual x) { const double s = sqrt(x.v); return mk(s, 0.5 * x.d / s); }
+__device__ __forceinline__ Dual m_sin(Dual x) { return mk(sin(x.v), cos(x.v) * x.d); }
+__device__ __forceinline__ Dual m_cos(Dual x) { return mk(cos(x.v), -sin(x.v) * x.d); }
+__device__ __forceinline__ Dual m_tan(Dual x) { const double t = tan(x.v); return mk(t, (1.0 + t * t) * x.d); }
+__device__ __forceinline__ Dual m_sinh(Dual x) { return mk(sinh(x.v), cosh(x.v) * x.d); }
+__device__ __forceinline__ Dual m_cosh(Dual x) { return mk(cosh(x.v), sinh(x.v) * x.d); }
+__device__ __forceinline__ Dual m_log1p(Dual x) { return mk(log1p(x.v), x.d / (1.0 + x.v)); }
+
+template <typename S> __device__ __forceinline__ S cst(double c);
+template <> __device__ __forceinline__ double cst<double>(double c) { return c; }
+template <> __device__ __forceinline__ Dual cst<Dual>(double c) { return mk(c, 0.0); }
+
+// ---- singularity-free "sinc family" as functions of u = k^2 L^2 (any sign) --------------------
+// C(u) = cos(sqrt u), S(u) = sin(sqrt u)/sqrt u, G(u) = (1-cos sqrt u)/u, F(u) = (1-S(u))/u.
+// |u| < kSeries uses the Taylor series (exact limits 1, 1, 1/2, 1/6 at u = 0 and correct
+// derivatives there; F is utils/autograd.py:108-146 `si1mdiv`), otherwise trig (u>0) or
+// hyperbolic (u<0) closed forms — the real restatement of the reference's complex sqrt.
+constexpr double kSeries = 0.05;
+
+template <typename S>
+__device__ __forceinline__ void sinc_family(S u, S& C, S& Sn, S& G, S& F) {
+    const double uv = val(u);
+    if (fabs(uv) < kSeries) {
+        // Horner in u; coefficients (-1)^n / (2n+m)!
+        C = 1.0 + u * (-1.0 / 2 + u * (1.0 / 24 + u * (-1.0 / 720 + u * (1.0 / 40320 + u * (-1.0 / 3628800 + u * (1.0 / 479001600))))));
+        Sn = 1.0 + u * (-1.0 / 6 + u * (1.0 / 120 + u * (-1.0 / 5040 + u * (1.0 / 362880 + u * (-1.0 / 39916800 + u * (1.0 / 6227020800.0))))));
+        G = 1.0 / 2 + u * (-1.0 / 24 + u * (1.0 / 720 + u * (-1.0 / 40320 + u * (1.0 / 3628800 + u * (-1.0 / 479001600 + u * (1.0 / 87178291200.0))))));
+        F = 1.0 / 6 + u * (-1.0 / 120 + u * (1.0 / 5040 + u * (-1.0 / 362880 + u * (1.0 / 39916800 + u * (-1.0 / 6227020800.0 + u * (1.0 / 1307674368000.0))))));
+    } else if (uv > 0) {
+        const S a = m_sqrt(u);
+        C = m_cos(a);
+        Sn = m_sin(a) / a;
+        const S sh = m_sin(0.5 * a);
+        G = 2.0 * sh * sh / u;
+        F = (1.0 - Sn) / u;
+    } else {
+        const S a = m_sqrt(-u);
+        C = m_cosh(a);
+        Sn = m_sinh(a) / a;
+        const S sh = m_sinh(0.5 * a);
+        G = 2.0 * sh * sh / (-u);  // (1 - cosh a)/u = (cosh a - 1)/a^2
+        F = (1.0 - Sn) / u;
+    }
+}
+
+// log(1+x)/x with its limit (utils/autograd.py:77-105)
+template <typename S>
+__device__ __forceinline__ S log1pdiv(S x) {
+    const double xv = val(x);
+    if (fabs(xv) < 1e-4) return 1.0 + x * (-1.0 / 2 + x * (1.0 / 3 + x * (-1.0 / 4 + x * (1.0 / 5))));
+    return m_log1p(x) / x;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename S>
+struct Mat7 {
+    S m[49];
+    __device__ __forceinline__ S& operator()(int i, int j) { return m[i * 7 + j]; }
+    __device__ __forceinline__ const S& operator()(int i, int j) const { return m[i * 7 + j]; }
+};
+
+template <typename S>
+__device__ void eye7(Mat7<S>& M) {
+    for (int k = 0; k < 49; ++k) M.m[k] = cst<S>(0.0);
+    for (int i = 0; i < 7; ++i) M(i, i) = cst<S>(1.0);
+}
+
+template <typename S>
+__device__ void matmul7(const Mat7<S>& A, const Mat7<S>& Bm, Mat7<S>& Cm) {
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) {
+            S acc = A(i, 0) * Bm(0, j);
+            for (int k = 1; k < 7; ++k) acc = acc + A(i, k) * Bm(k, j);
+            Cm(i, j) = acc;
+        }
+}
+
+template <typename S>
+__device__ __forceinline__ void rel_factors(S energy, double mass, S& gamma, S& igamma2, S& beta) {
+    gamma = energy / mass;                 // utils/physics.py:15-17
+    igamma2 = 1.0 / (gamma * gamma);
+    beta = m_sqrt(1.0 - igamma2);
+}
+
+// track_methods.py:284-299 (+ corrector kicks in column 6)
+template <typename S>
+__device__ void drift_map(S L, S energy, double mass, Mat7<S>& R) {
+    S g, ig2, beta;
+    rel_factors(energy, mass, g, ig2, beta);
+    eye7(R);
+    R(0, 1) = L;
+    R(2, 3) = L;
+    R(4, 5) = -L / (beta * beta) * ig2;
+}
+
+// track_methods.py:17-77
+template <typename S>
+__device__ void base_rmatrix(S L, S k1, S hx, S energy, double mass, Mat7<S>& R) {
+    S g, ig2, beta;
+    rel_factors(energy, mass, g, ig2, beta);
+    const S kx2 = k1 + hx * hx;
+    const S ky2 = -k1;
+    const S L2 = L * L;
+    S Cx, Sx, Gx, Fx, Cy, Sy, Gy, Fy;
+    sinc_family<S>(kx2 * L2, Cx, Sx, Gx, Fx);
+    sinc_family<S>(ky2 * L2, Cy, Sy, Gy, Fy);
+    const S sx = Sx * L, sy = Sy * L;
+    const S dx = hx * L2 * Gx;  // = hx * 0.5 L^2 sinc^2(kx L / 2)
+    const S b2 = beta * beta;
+    const S r56 = hx * hx * L2 * L * Fx / b2 - L / b2 * ig2;
+    eye7(R);
+    R(0, 0) = Cx;
+    R(0, 1) = sx;
+    R(0, 5) = dx / beta;
+    R(1, 0) = -kx2 * sx;
+    R(1, 1) = Cx;
+    R(1, 5) = sx * hx / beta;
+    R(2, 2) = Cy;
+    R(2, 3) = sy;
+    R(3, 2) = -ky2 * sy;
+    R(3, 3) = Cy;
+    R(4, 0) = sx * hx / beta;
+    R(4, 1) = dx / beta;
+    R(4, 5) = r56;
+}
+
+// track_methods.py:302-323
+template <typename S>
+__device__ void rotation_map(S angle, Mat7<S>& R) {
+    const S cs = m_cos(angle), sn = m_sin(angle);
+    eye7(R);
+    R(0, 0) = cs; R(0, 2) = sn; R(1, 1) = cs; R(1, 3) = sn;
+    R(2, 0) = -sn; R(2, 2) = cs; R(3, 1) = -sn; R(3, 3) = cs;
+}
+
+template <typename S>
+__device__ void transpose7(const Mat7<S>& A, Mat7<S>& At) {
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) At(i, j) = A(j, i);
+}
+
+// quadrupole.py:93-110 with track_methods.py:345-382
+template <typename S>
+__device__ void quadrupole_map(const S* p, S energy, double mass, Mat7<S>& R) {
+    const S L = p[0], k1 = p[1], tilt = p[2], mx = p[3], my = p[4];
+    Mat7<S> base, entry, exitm, tmp;
+    base_rmatrix<S>(L, k1, cst<S>(0.0), energy, mass, base);
+    rotation_map<S>(tilt, entry);
+    transpose7(entry, exitm);  // tm_exit = tm_entry.clone().mT (before the misalignment is added)
+    const S cs = m_cos(tilt), sn = m_sin(tilt);
+    entry(0, 6) = -mx * cs - my * sn;
+    entry(2, 6) = mx * sn - my * cs;
+    exitm(0, 6) = mx;
+    exitm(2, 6) = my;
+    matmul7(base, entry, tmp);
+    matmul7(exitm, tmp, R);
+}
+
+// dipole.py:372-394, 430-466 ; hx = angle / length (dipole.py:133-135)
+template <typename S>
+__device__ void dipole_map(const S* p, S energy, double mass, Mat7<S>& R) {
+    const S L = p[0], angle = p[1], k1 = p[2], e1 = p[3], e2 = p[4], tilt = p[5], fint = p[6],
+            fint_exit = p[7], gap = p[8];
+    const S hx = angle / L;
+    Mat7<S> base, enter, exitm, rot, rotT, t1, t2;
+    base_rmatrix<S>(L, k1, hx, energy, mass, base);
+    {
+        const S sec = 1.0 / m_cos(e1), s1 = m_sin(e1);
+        const S phi = fint * hx * gap * sec * (1.0 + s1 * s1);
+        eye7(enter);
+        enter(1, 0) = hx * m_tan(e1);
+        enter(3, 2) = -hx * m_tan(e1 - phi);
+    }
+    {
+        const S sec = 1.0 / m_cos(e2), s2 = m_sin(e2);
+        const S phi = fint_exit * hx * gap * sec * (1.0 + s2 * s2);  // NB: reference uses `gap` here too
+        eye7(exitm);
+        exitm(1, 0) = hx * m_tan(e2);
+        exitm(3, 2) = -hx * m_tan(e2 - phi);
+    }
+    matmul7(base, enter, t1);
+    matmul7(exitm, t1, t2);
+    rotation_map<S>(tilt, rot);
+    transpose7(rot, rotT);
+    matmul7(t2, rot, t1);
+    matmul7(rotT, t1, R);
+}
+
+// cavity.py:253-358
+template <typename S>
+__device__ void cavity_map(const S* p, S energy, double mass, double nq, bool standing, Mat7<S>& R) {
+    const S L = p[0], V = p[1], phase = p[2], freq = p[3];
+    const S phi = phase * (kPi / 180.0);
+    const S veff = -V * nq;
+    const S cphi = m_cos(phi), sphi = m_sin(phi);
+    const S dEn = veff * cphi;  // delta_energy
+    const S Ei = energy / mass;
+    const S dE = dEn / mass;
+    const S Ef = Ei + dE;
+    const S k = 2.0 * kPi * freq / kSpeedOfLight;
+    S r11, r12, r21, r22, r55, r56, r65, r66;
+    if (standing) {
+        const S l1p = log1pdiv<S>(dEn / energy);
+        const S alpha = 0.35355339059327378 /* sqrt(1/8) */ * veff / energy * l1p;
+        const S beta0 = m_sqrt(1.0 - 1.0 / (Ei * Ei));
+        const S beta1 = m_sqrt(1.0 - 1.0 / (Ef * Ef));
+        const S ca = m_cos(alpha), sa = m_sin(alpha);
+        S Ca, Sa, Ga, Fa;
+        sinc_family<S>(alpha * alpha, Ca, Sa, Ga, Fa);  // Sa = sin(alpha)/alpha
+        const double rt2 = 1.4142135623730951;
+        r11 = ca - rt2 * cphi * sa;
+        r12 = Sa * l1p * L;
+        r21 = -(veff / ((energy + dEn) * rt2 * L) * (0.5 + cphi * cphi) * sa);
+        r22 = Ei / Ef * (ca + rt2 * cphi * sa);
+        if (val(dE) != 0.0) {
+            r55 = 1.0 + k * L * beta0 * (sphi / cphi) * (Ei * Ef * (beta0 * beta1 - 1.0) + 1.0) / (beta1 * Ef * dE);
+        } else {
+            r55 = cst<S>(1.0);
+        }
+        r56 = -L / (Ef * Ef * Ei * beta1) * (Ef + Ei) / (beta1 + beta0);
+        r65 = k * sphi * veff / (beta1 * (energy + dEn));
+        r66 = Ei / Ef * beta0 / beta1;
+    } else {
+        const S Ep = dE / L;
+        // M = F_exit * Body * F_entry (2x2)
+        const S b01 = L * log1pdiv<S>(dE / Ei), b11 = Ei / Ef;
+        const S fe = -Ep / (2.0 * Ei), fx = Ep / (2.0 * Ef);
+        // Body * F_entry
+        const S m00 = 1.0 + b01 * fe, m01 = b01, m10 = b11 * fe, m11 = b11;
+        r11 = m00;
+        r12 = m01;
+        r21 = fx * m00 + m10;
+        r22 = fx * m01 + m11;
+        r55 = cst<S>(1.0);
+        r56 = cst<S>(0.0);
+        r65 = k * sphi * veff / (energy + dEn);
+        r66 = r22;
+    }
+    eye7(R);
+    R(0, 0) = r11; R(0, 1) = r12; R(1, 0) = r21; R(1, 1) = r22;
+    R(2, 2) = r11; R(2, 3) = r12; R(3, 2) = r21; R(3, 3) = r22;
+    R(4, 4) = r55; R(4, 5) = r56; R(5, 4) = r65; R(5, 5) = r66;
+}
+
+template <typename S>
+__device__ void build_kind(int kind, const S* p, S energy, double mass, double nq, Mat7<S>& R) {
+    switch (kind) {
+        case CHX_IDENTITY: eye7(R); break;
+        case CHX_DRIFT: drift_map<S>(p[0], energy, mass, R); break;
+        case CHX_QUADRUPOLE: quadrupole_map<S>(p, energy, mass, R); break;
+        case CHX_DIPOLE: dipole_map<S>(p, energy, mass, R); break;
+        case CHX_HCOR: drift_map<S>(p[0], energy, mass, R); R(1, 6) = p[1]; break;
+        case CHX_VCOR: drift_map<S>(p[0], energy, mass, R); R(3, 6) = p[1]; break;
+        case CHX_CCOR: drift_map<S>(p[0], energy, mass, R); R(1, 6) = p[1]; R(3, 6) = p[2]; break;
+        case CHX_CAVITY_SW: cavity_map<S>(p, energy, mass, nq, true, R); break;
+        case CHX_CAVITY_TW: cavity_map<S>(p, energy, mass, nq, false, R); break;
+        default: eye7(R); break;
+    }
+}
+
+__host__ __device__ inline int kind_num_params(int kind) {
+    switch (kind) {
+        case CHX_IDENTITY: return 0;
+        case CHX_DRIFT: return 1;
+        case CHX_QUADRUPOLE: return 5;
+        case CHX_DIPOLE: return 9;
+        case CHX_HCOR: return 2;
+        case CHX_VCOR: return 2;
+        case CHX_CCOR: return 3;
+        case CHX_CAVITY_SW: return 4;
+        case CHX_CAVITY_TW: return 4;
+        default: return -1;
+    }
+}
+
+template <typename T>
+__global__ void build_kernel(int kind, const T* __restrict__ params, const T* __restrict__ energy,
+                             double mass, double nq, int64_t B, int64_t Bp, int64_t Be, int P,
+                             T* __restrict__ R_out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double p[CHX_MAX_PARAMS];
+    for (int k = 0; k < P; ++k) p[k] = (double)params[(Bp == 1 ? 0 : b) * P + k];
+    const double en = (double)energy[Be == 1 ? 0 : b];
+    Mat7<double> R;
+    build_kind<double>(kind, p, en, mass, nq, R);
+    for (int k = 0; k < 49; ++k) R_out[b * 49 + k] = (T)R.m[k];
+}
+
+// one thread per (b, input k) with k in [0, P] (k == P is the energy)
+template <typename T>
+__global__ void build_vjp_kernel(int kind, const T* __restrict__ params, const T* __restrict__ energy,
+                                 double mass, double nq, const T* __restrict__ dR, int64_t B,
+                                 int64_t Bp, int64_t Be, int P, T* __restrict__ dparams,
+                                 T* __restrict__ denergy) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * (P + 1)) return;
+    const int64_t b = idx / (P + 1);
+    const int k = (int)(idx - b * (P + 1));
+    Dual p[CHX_MAX_PARAMS];
+    for (int q = 0; q < P; ++q) p[q] = mk((double)params[(Bp == 1 ? 0 : b) * P + q], q == k ? 1.0 : 0.0);
+    const Dual en = mk((double)energy[Be == 1 ? 0 : b], k == P ? 1.0 : 0.0);
+    Mat7<Dual> R;
+    build_kind<Dual>(kind, p, en, mass, nq, R);
+    double acc = 0.0;
+    for (int q = 0; q < 49; ++q) acc += (double)dR[b * 49 + q] * R.m[q].d;
+    if (k < P) dparams[b * P + k] = (T)acc;
+    else denergy[b] = (T)acc;
+}
+
+// ---- composition (segment.py:534-543): tm = R_e @ tm for e = 0..E-1 -------------------------
+// One workgroup (4 waves) per batch row. Wave w composes its contiguous chunk of elements
+// sequentially (49 lanes = 49 matrix entries, operands exchanged through LDS), then wave 0
+// multiplies the four partial products together: sequential depth E/4 + 4 instead of E.
+// The per-element device pointers travel BY VALUE in the kernel arguments (<= 192 per launch,
+// longer lattices chain launches through R_out): no pointer table in device memory, no H2D copy.
+constexpr int kComposeChunk = 192;
+struct ComposeArgs {
+    const void* ptr[kComposeChunk];
+    uint8_t bcast[kComposeChunk];
+};
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void compose_kernel(ComposeArgs args, int E, int has_init,
+                                                           T* __restrict__ R_out) {
+    __shared__ double cur[4][49];
+    __shared__ double nxt[4][49];
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane / 7, j = lane - 7 * i;
+    const int per = (E + 3) / 4;
+    const int e0 = wave * per, e1 = (e0 + per < E) ? e0 + per : E;
+    double acc = (lane < 49) ? ((i == j) ? 1.0 : 0.0) : 0.0;
+    // a follow-up launch continues from the product accumulated so far (wave 0 only)
+    if (has_init && wave == 0 && lane < 49) acc = (double)R_out[b * 49 + lane];
+    if (lane < 49) cur[wave][lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = e0; e < e1; ++e) {
+        const T* Re = (const T*)args.ptr[e] + (args.bcast[e] ? 0 : b * 49);
+        if (lane < 49) nxt[wave][lane] = (double)Re[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 49) {
+            double s = nxt[wave][i * 7] * cur[wave][j];
+            for (int k = 1; k < 7; ++k) s = fma(nxt[wave][i * 7 + k], cur[wave][k * 7 + j], s);
+            acc = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 49) cur[wave][lane] = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // total = P3 P2 P1 P0 ; start from P0 held in cur[0]
+        for (int w = 1; w < 4; ++w) {
+            if (lane < 49) {
+                double s = cur[w][i * 7] * cur[0][j];
+                for (int k = 1; k < 7; ++k) s = fma(cur[w][i * 7 + k], cur[0][k * 7 + j], s);
+                acc = s;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 49) cur[0][lane] = acc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane < 49) R_out[b * 49 + lane] = (T)acc;
+    }
+}
+
+// ---- cavity track coefficients (cavity.py:100-226) -------------------------------------------
+// Single workgroup; pass 1 evaluates `any(delta_energy > 0)` over the batch (cavity.py:157),
+// pass 2 writes [a, b, k*beta0, phi, cos phi, T566, T556, T555] and the outgoing energy.
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void cavity_coeff_kernel(const T* __restrict__ params,
+                                                                const T* __restrict__ energy,
+                                                                double mass, double nq, int64_t B,
+                                                                int64_t Bp, int64_t Be,
+                                                                double* __restrict__ coeffs,
+                                                                T* __restrict__ energy_out) {
+    __shared__ int any_gain;
+    if (threadIdx.x == 0) any_gain = 0;
+    __syncthreads();
+    int local = 0;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        const T* p = params + (Bp == 1 ? 0 : b) * 4;
+        const double V = (double)p[1], phi = (double)p[2] * (kPi / 180.0);
+        const double dEn = V * cos(phi) * nq * -1.0;
+        if (dEn > 0.0) local = 1;
+    }
+    if (local) atomicOr(&any_gain, 1);
+    __syncthreads();
+    const bool gain = any_gain != 0;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        const T* p = params + (Bp == 1 ? 0 : b) * 4;
+        const double L = (double)p[0], V = (double)p[1], phi = (double)p[2] * (kPi / 180.0),
+                     freq = (double)p[3];
+        const double E0 = (double)energy[Be == 1 ? 0 : b];
+        const double g0 = E0 / mass, ig2 = 1.0 / (g0 * g0), b0 = sqrt(1.0 - ig2);
+        const double cphi = cos(phi), sphi = sin(phi);
+        const double dEn = V * cphi * nq * -1.0;
+        const double E1 = E0 + dEn;
+        const double g1 = E1 / mass, b1 = sqrt(1.0 - 1.0 / (g1 * g1));
+        const double k = 2.0 * kPi * freq / kSpeedOfLight;
+        double T566 = 1.5 * L * ig2 / (b0 * b0 * b0), T556 = 0.0, T555 = 0.0;
+        if (gain) {
+            const double dg = V / mass;
+            const double b03 = b0 * b0 * b0, b13 = b1 * b1 * b1, g03 = g0 * g0 * g0, g13 = g1 * g1 * g1;
+            const double gd = g0 - g1;
+            T566 = L * (b03 * g03 - b13 * g13) / (2.0 * b0 * b13 * g0 * gd * g13);
+            T556 = b0 * k * L * dg * g0 * (b13 * g13 + b0 * (g0 - g13)) * sphi / (b13 * g13 * gd * gd);
+            T555 = b0 * b0 * k * k * L * dg / 2.0 *
+                   (dg * (2.0 * g0 * g13 * (b0 * b13 - 1.0) + g0 * g0 + 3.0 * g1 * g1 - 2.0) /
+                        (b13 * g13 * gd * gd * gd) * sphi * sphi -
+                    (g1 * g0 * (b1 * b0 - 1.0) + 1.0) / (b1 * g1 * gd * gd) * cphi);
+        }
+        double* c = coeffs + b * CHX_CAV_NCOEF;
+        c[0] = E0 * b0 / (E1 * b1);
+        c[1] = V * b0 / (E1 * b1);
+        c[2] = b0 * k;
+        c[3] = phi;
+        c[4] = cphi;
+        c[5] = T566;
+        c[6] = T556;
+        c[7] = T555;
+        energy_out[b] = (T)E1;
+    }
+}
+
+}  // namespace
+
+extern "C" int chx_kind_num_params(int kind) { return kind_num_params(kind); }
+extern "C" int chx_abi_version(void) { return CHX_ABI_VERSION; }
+extern "C" const char* chx_status_string(int status) {
+    switch (status) {
+        case CHX_OK: return "ok";
+        case CHX_ERR_INVALID_ARG: return "invalid argument";
+        case CHX_ERR_DTYPE: return "unsupported dtype";
+        case CHX_ERR_MISALIGNED: return "misaligned buffer";
+        case CHX_ERR_LAUNCH: return "kernel launch failed";
+        case CHX_ERR_WORKSPACE: return "workspace missing or too small";
+        case CHX_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int chx_build_rmatrix(int kind, const void* params, const void* energy, double mass_eV,
+                                 double n_charges, int64_t B, int64_t Bp, int64_t Be, int dtype,
+                                 void* R_out, void* stream) {
+    const int P = kind_num_params(kind);
+    if (P < 0 || B < 1 || !energy || !R_out || (P > 0 && !params)) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    const int grid = (int)((B + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(build_kernel<float>, dim3(grid), dim3(64), 0, s, kind, (const float*)params,
+                           (const float*)energy, mass_eV, n_charges, B, Bp, Be, P, (float*)R_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(build_kernel<double>, dim3(grid), dim3(64), 0, s, kind, (const double*)params,
+                           (const double*)energy, mass_eV, n_charges, B, Bp, Be, P, (double*)R_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_build_rmatrix_vjp(int kind, const void* params, const void* energy, double mass_eV,
+                                     double n_charges, const void* dR, int64_t B, int64_t Bp,
+                                     int64_t Be, int dtype, void* dparams, void* denergy,
+                                     void* stream) {
+    const int P = kind_num_params(kind);
+    if (P < 0 || B < 1 || !energy || !dR || !denergy || (P > 0 && (!params || !dparams)))
+        return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    const int64_t work = B * (P + 1);
+    const int grid = (int)((work + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(build_vjp_kernel<float>, dim3(grid), dim3(64), 0, s, kind,
+                           (const float*)params, (const float*)energy, mass_eV, n_charges,
+                           (const float*)dR, B, Bp, Be, P, (float*)dparams, (float*)denergy);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(build_vjp_kernel<double>, dim3(grid), dim3(64), 0, s, kind,
+                           (const double*)params, (const double*)energy, mass_eV, n_charges,
+                           (const double*)dR, B, Bp, Be, P, (double*)dparams, (double*)denergy);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_cavity_coeffs(const void* params, const void* energy, double mass_eV,
+                                 double n_charges, int64_t B, int64_t Bp, int64_t Be, int dtype,
+                                 double* coeffs, void* energy_out, void* stream) {
+    if (!params || !energy || !coeffs || !energy_out || B < 1) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(cavity_coeff_kernel<float>, dim3(1), dim3(CHX_BLOCK), 0, s,
+                           (const float*)params, (const float*)energy, mass_eV, n_charges, B, Bp, Be,
+                           coeffs, (float*)energy_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(cavity_coeff_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s,
+                           (const double*)params, (const double*)energy, mass_eV, n_charges, B, Bp,
+                           Be, coeffs, (double*)energy_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_compose_maps(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B,
+                                int dtype, void* R_out, void* stream) {
+    if (!R_ptrs || !bcast || !R_out || E < 1 || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t done = 0;
+    while (done < E) {
+        ComposeArgs a;
+        const int n = (int)((E - done < kComposeChunk) ? (E - done) : kComposeChunk);
+        for (int e = 0; e < n; ++e) {
+            if (!R_ptrs[done + e]) return CHX_ERR_INVALID_ARG;
+            a.ptr[e] = R_ptrs[done + e];
+            a.bcast[e] = bcast[done + e];
+        }
+        for (int e = n; e < kComposeChunk; ++e) { a.ptr[e] = nullptr; a.bcast[e] = 1; }
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(compose_kernel<float>, dim3((unsigned)B), dim3(CHX_BLOCK), 0, s, a, n,
+                               (int)(done > 0), (float*)R_out);
+        else
+            hipLaunchKernelGGL(compose_kernel<double>, dim3((unsigned)B), dim3(CHX_BLOCK), 0, s, a, n,
+                               (int)(done > 0), (double*)R_out);
+        CHX_CHECK_LAUNCH();
+        done += n;
+    }
+    return CHX_OK;
+}

@@ -1,0 +1,89 @@
+// chx_common.h — shared device/host helpers for the libchx HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "chx.h"
+
+#define CHX_WAVE 64
+#define CHX_BLOCK 256
+
+#define CHX_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return CHX_ERR_LAUNCH;        \
+    } while (0)
+
+static inline bool chx_bcast_ok(int64_t b, int64_t B) { return b == 1 || b == B; }
+static __host__ __device__ inline bool chx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// 16-byte vector type per element type: float -> 4 lanes, double -> 2 lanes.
+template <typename T> struct chx_vec16;
+template <> struct chx_vec16<float> { using type = float4; static constexpr int n = 4; };
+template <> struct chx_vec16<double> { using type = double2; static constexpr int n = 2; };
+
+// Sum over the 64 lanes of a wavefront (all lanes receive the total).
+__device__ __forceinline__ double chx_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum of K doubles per thread (CHX_BLOCK threads = 4 waves). Result valid in thread 0.
+template <int K>
+__device__ __forceinline__ void chx_block_sum(double (&v)[K], double* smem /* [4*K] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = chx_wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) smem[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            v[k] = smem[k] + smem[K + k] + smem[2 * K + k] + smem[3 * K + k];
+    }
+    __syncthreads();
+}
+
+// ---- LDS tile staging: contiguous 16-byte vector transfers between global memory and an LDS
+// tile (coalesced global_load/store_dwordx4); scalar fallback when the tile start is unaligned.
+template <typename T>
+__device__ __forceinline__ void tile_load(const T* __restrict__ g, T* __restrict__ lds, int n_elem,
+                                          bool vec_ok) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    if (vec_ok) {
+        const int nvec = n_elem / VN;
+        const V* __restrict__ gv = reinterpret_cast<const V*>(g);
+        V* lv = reinterpret_cast<V*>(lds);
+        for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) lv[v] = gv[v];
+        for (int e = nvec * VN + threadIdx.x; e < n_elem; e += CHX_BLOCK) lds[e] = g[e];
+    } else {
+        for (int e = threadIdx.x; e < n_elem; e += CHX_BLOCK) lds[e] = g[e];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void tile_store(T* __restrict__ g, const T* __restrict__ lds, int n_elem,
+                                           bool vec_ok) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    if (vec_ok) {
+        const int nvec = n_elem / VN;
+        V* __restrict__ gv = reinterpret_cast<V*>(g);
+        const V* lv = reinterpret_cast<const V*>(lds);
+        for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) gv[v] = lv[v];
+        for (int e = nvec * VN + threadIdx.x; e < n_elem; e += CHX_BLOCK) g[e] = lds[e];
+    } else {
+        for (int e = threadIdx.x; e < n_elem; e += CHX_BLOCK) g[e] = lds[e];
+    }
+}
+
+static inline int chx_grid_for(int64_t work_items, int per_block, int cap) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}

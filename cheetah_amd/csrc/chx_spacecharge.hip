@@ -1,0 +1,387 @@
+// chx_spacecharge.hip — grid and particle kernels of SpaceChargeKick.
+//
+// Replaces cheetah/accelerator/space_charge_kick.py:103-586 and the SI coordinate conversions
+// cheetah/particles/particle_beam.py:1262-1346. The 3-D FFTs stay in hipFFT (called through
+// torch.fft by the host layer); everything else is here:
+//   * chx_sc_igf        integrated Green function on the doubled (Hockney) grid, fp64 inside.
+//                       The reference evaluates the 6-transcendental primitive F eight times per
+//                       cell (space_charge_kick.py:195-236); neighbouring cells share corner points,
+//                       so F is tabulated once on the (g+1)^3 corner lattice and G is the signed
+//                       8-term difference of table entries (8x fewer asinh/atan), then mirrored into
+//                       the other seven octants (space_charge_kick.py:249-289).
+//   * chx_sc_spectral_mul   rho_hat *= G_hat * scale (space_charge_kick.py:313-316)
+//   * chx_sc_gradient   central differences of the cropped potential, x(-1/gamma^2), packed as
+//                       float4 (Fx,Fy,Fz,0) per node so the gather is one 16-byte load per corner
+//   * chx_sc_gather_kick    to_xyz_pxpypz -> node-based trilinear gather -> p += F dt ->
+//                       from_xyz_pxpypz fused per particle in registers (fp64 inside: the SI
+//                       momenta ~1e-20 kg m/s square to denormals in fp32).
+#include "chx_common.h"
+
+namespace {
+
+// scipy.constants (CODATA 2022, scipy 1.15.3) as used by the reference
+constexpr double kC = 299792458.0;
+constexpr double kElementaryCharge = 1.602176634e-19;
+constexpr double kEvToKg = 1.7826619216278975e-36;  // physical_constants["electron volt-kilogram relationship"]
+
+// space_charge_kick.py:103-123
+__device__ __forceinline__ double igf_primitive(double x, double y, double t) {
+    const double r = sqrt(x * x + y * y + t * t);
+    return -0.5 * t * t * atan(x * y / (t * r)) - 0.5 * y * y * atan(x * t / (y * r)) -
+           0.5 * x * x * atan(y * t / (x * r)) + y * t * asinh(x / sqrt(y * y + t * t)) +
+           x * t * asinh(y / sqrt(x * x + t * t)) + x * y * asinh(t / sqrt(x * x + y * y));
+}
+
+// table[b][i][j][k] = F((i-1/2) dx, (j-1/2) dy, (k-1/2) dt), i in [0, gx] etc.
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void igf_table_kernel(const T* __restrict__ cell,
+                                                             const T* __restrict__ gamma, int gx,
+                                                             int gy, int gz,
+                                                             double* __restrict__ table) {
+    const int64_t b = blockIdx.y;
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    const double dx = (double)cell[b * 3 + 0], dy = (double)cell[b * 3 + 1];
+    // longitudinal cell scaled by gamma (space_charge_kick.py:170-176); the product is formed in
+    // the working dtype like the reference's `cell_size[..., 2] * beam.relativistic_gamma`
+    const double dt = (double)(T)(cell[b * 3 + 2] * gamma[b]);
+    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < npts;
+         idx += (int64_t)gridDim.x * CHX_BLOCK) {
+        const int k = (int)(idx % (gz + 1));
+        const int j = (int)((idx / (gz + 1)) % (gy + 1));
+        const int i = (int)(idx / ((int64_t)(gz + 1) * (gy + 1)));
+        table[b * npts + idx] = igf_primitive((i - 0.5) * dx, (j - 0.5) * dy, (k - 0.5) * dt);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void igf_fill_kernel(const double* __restrict__ table, int gx,
+                                                            int gy, int gz, T* __restrict__ G) {
+    const int64_t b = blockIdx.y;
+    const int64_t ncell = (int64_t)gx * gy * gz;
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    const double* tb = table + b * npts;
+    const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
+    const int64_t GX = 2 * gx, GY = 2 * gy, GZ = 2 * gz;
+    T* Gb = G + b * GX * GY * GZ;
+    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ncell;
+         idx += (int64_t)gridDim.x * CHX_BLOCK) {
+        const int k = (int)(idx % gz);
+        const int j = (int)((idx / gz) % gy);
+        const int i = (int)(idx / ((int64_t)gz * gy));
+        const double* p = tb + i * sx + j * sy + k;
+        // +F(+,+,+) -F(-,+,+) -F(+,-,+) -F(+,+,-) +F(+,-,-) +F(-,+,-) +F(-,-,+) -F(-,-,-)
+        const double g = p[sx + sy + 1] - p[sy + 1] - p[sx + 1] - p[sx + sy] + p[sx] + p[sy] + p[1] - p[0];
+        const T gv = (T)g;
+        const int64_t i2 = GX - i, j2 = GY - j, k2 = GZ - k;
+        Gb[((int64_t)i * GY + j) * GZ + k] = gv;
+        if (i > 0) Gb[(i2 * GY + j) * GZ + k] = gv;
+        if (j > 0) Gb[((int64_t)i * GY + j2) * GZ + k] = gv;
+        if (k > 0) Gb[((int64_t)i * GY + j) * GZ + k2] = gv;
+        if (i > 0 && j > 0) Gb[(i2 * GY + j2) * GZ + k] = gv;
+        if (j > 0 && k > 0) Gb[((int64_t)i * GY + j2) * GZ + k2] = gv;
+        if (i > 0 && k > 0) Gb[(i2 * GY + j) * GZ + k2] = gv;
+        if (i > 0 && j > 0 && k > 0) Gb[(i2 * GY + j2) * GZ + k2] = gv;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void spectral_mul_kernel(T* __restrict__ a /*complex*/,
+                                                                const T* __restrict__ g,
+                                                                const double* __restrict__ scale,
+                                                                int64_t n) {
+    const int64_t b = blockIdx.y;
+    const T sc = (T)scale[b];
+    T* ab = a + b * n * 2;
+    const T* gb = g + b * n * 2;
+    for (int64_t i = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * CHX_BLOCK) {
+        const T ar = ab[2 * i], ai = ab[2 * i + 1], gr = gb[2 * i], gi = gb[2 * i + 1];
+        ab[2 * i] = (ar * gr - ai * gi) * sc;
+        ab[2 * i + 1] = (ar * gi + ai * gr) * sc;
+    }
+}
+
+// space_charge_kick.py:324-365
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void gradient_kernel(const T* __restrict__ phi,
+                                                            const T* __restrict__ cell,
+                                                            const T* __restrict__ gamma, int gx,
+                                                            int gy, int gz, T* __restrict__ F) {
+    const int64_t b = blockIdx.y;
+    const int64_t GY = 2 * gy, GZ = 2 * gz;
+    const T* pb = phi + b * (int64_t)(2 * gx) * GY * GZ;
+    const int64_t ncell = (int64_t)gx * gy * gz;
+    const T gm = gamma[b];
+    const T ig2 = (gm != (T)0) ? (T)1 / (gm * gm) : (T)0;
+    const T hx = (T)0.5 * ((T)1 / cell[b * 3 + 0]);
+    const T hy = (T)0.5 * ((T)1 / cell[b * 3 + 1]);
+    const T hz = (T)0.5 * ((T)1 / cell[b * 3 + 2]);
+    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ncell;
+         idx += (int64_t)gridDim.x * CHX_BLOCK) {
+        const int k = (int)(idx % gz);
+        const int j = (int)((idx / gz) % gy);
+        const int i = (int)(idx / ((int64_t)gz * gy));
+        const int64_t c = ((int64_t)i * GY + j) * GZ + k;
+        T fx = (T)0, fy = (T)0, fz = (T)0;
+        if (i > 0 && i < gx - 1) fx = (pb[c + GY * GZ] - pb[c - GY * GZ]) * hx;
+        if (j > 0 && j < gy - 1) fy = (pb[c + GZ] - pb[c - GZ]) * hy;
+        if (k > 0 && k < gz - 1) fz = (pb[c + 1] - pb[c - 1]) * hz;
+        T* o = F + (b * ncell + idx) * 4;
+        o[0] = -ig2 * fx;
+        o[1] = -ig2 * fy;
+        o[2] = -ig2 * fz;
+        o[3] = (T)0;
+    }
+}
+
+struct RefFrame {
+    double gamma, beta, p0, mc;  // reference gamma/beta, p0 = gamma beta m c, mc = m c
+};
+
+__device__ __forceinline__ RefFrame ref_frame(double energy, double mass_eV) {
+    RefFrame r;
+    r.gamma = energy / mass_eV;                                            // beam.py:323-326
+    r.beta = (fabs(r.gamma) > 0.0) ? sqrt(1.0 - 1.0 / (r.gamma * r.gamma)) : 1.0;  // beam.py:328-336
+    r.mc = mass_eV * kEvToKg * kC;
+    r.p0 = r.gamma * r.beta * r.mc;
+    return r;
+}
+
+// particle_beam.py:1316-1346
+__device__ __forceinline__ void to_si(const RefFrame& r, const double (&v)[7], double (&s)[7]) {
+    const double gi = r.gamma * (1.0 + v[5] * r.beta);
+    const double bi = sqrt(1.0 - 1.0 / (gi * gi));
+    const double P = gi * bi * r.mc;
+    const double px = v[1] * r.p0, py = v[3] * r.p0;
+    s[0] = v[0];
+    s[1] = px;
+    s[2] = v[2];
+    s[3] = py;
+    s[4] = v[4] * -r.beta;
+    s[5] = sqrt(P * P - px * px - py * py);
+    s[6] = v[6];
+}
+
+// particle_beam.py:1262-1314
+__device__ __forceinline__ void from_si(const RefFrame& r, const double (&s)[7], double (&v)[7]) {
+    const double p = sqrt(s[1] * s[1] + s[3] * s[3] + s[5] * s[5]);
+    const double q = p / r.mc;
+    const double g = sqrt(1.0 + q * q);
+    v[0] = s[0];
+    v[1] = s[1] / r.p0;
+    v[2] = s[2];
+    v[3] = s[3] / r.p0;
+    v[4] = -s[4] / r.beta;
+    v[5] = (g - r.gamma) / (r.beta * r.gamma);
+    v[6] = s[6];
+}
+
+// MODE 0: gather + kick (full SpaceChargeKick particle step); 1: to_xyz only; 2: from_xyz only
+template <typename T, int MODE>
+__global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
+    const T* __restrict__ x_in, const T* __restrict__ F, const T* __restrict__ half,
+    const T* __restrict__ cell, const T* __restrict__ energy, const T* __restrict__ dt,
+    double mass_eV, int64_t Bx, int64_t Be, int64_t N, int gx, int gy, int gz,
+    T* __restrict__ x_out) {
+    constexpr int PPT = 1;
+    constexpr int TP = PPT * CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    const int64_t b = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const int64_t xrow = (Bx == 1) ? 0 : b;
+    const bool vin = chx_aligned16(x_in) && (((xrow * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
+    const bool vout = chx_aligned16(x_out) && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
+    tile_load<T>(x_in + (xrow * N + n0) * 7, lds, np * 7, vin);
+    __syncthreads();
+    const RefFrame rf = ref_frame((double)energy[Be == 1 ? 0 : b], mass_eV);
+    const int p = threadIdx.x;
+    if (p < np) {
+        double v[7], s[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[j] = (double)lds[p * 7 + j];
+        if (MODE == 2) {
+            from_si(rf, v, s);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)s[j];
+        } else {
+            to_si(rf, v, s);
+            if (MODE == 0) {
+                // node-based trilinear gather (space_charge_kick.py:387-473)
+                const double pos[3] = {s[0], s[2], s[4]};
+                const int g[3] = {gx, gy, gz};
+                double u[3];
+                int i0[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    u[d] = (pos[d] + (double)half[b * 3 + d]) / (double)cell[b * 3 + d];
+                    double fl = floor(u[d]);
+                    fl = fl > 2.0e9 ? 2.0e9 : (fl < -2.0e9 ? -2.0e9 : fl);
+                    i0[d] = (int)fl;
+                }
+                double fx = 0.0, fy = 0.0, fz = 0.0;
+                const T* Fb = F + b * (int64_t)gx * gy * gz * 4;
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                        for (int oz = 0; oz < 2; ++oz) {
+                            const int ix = i0[0] + ox, iy = i0[1] + oy, iz = i0[2] + oz;
+                            const bool valid = ix >= 0 && ix < g[0] && iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2];
+                            if (valid) {
+                                const double w = (1.0 - fabs(u[0] - ix)) * (1.0 - fabs(u[1] - iy)) *
+                                                 (1.0 - fabs(u[2] - iz)) * kElementaryCharge;
+                                const T* f4 = Fb + (((int64_t)ix * g[1] + iy) * g[2] + iz) * 4;
+                                fx += w * (double)f4[0];
+                                fy += w * (double)f4[1];
+                                fz += w * (double)f4[2];
+                            }
+                        }
+                const double dtb = (double)dt[b];
+                s[1] += fx * dtb;
+                s[3] += fy * dtb;
+                s[5] += fz * dtb;
+                from_si(rf, s, v);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)s[j];
+            }
+        }
+    }
+    __syncthreads();
+    tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, vout);
+}
+
+inline dim3 cell_grid(int64_t n, int64_t B) {
+    int64_t g = (n + CHX_BLOCK - 1) / CHX_BLOCK;
+    int64_t cap = 16384 / B;
+    if (cap < 1) cap = 1;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g, (unsigned)B);
+}
+
+bool bins_ok(const int32_t* bins) {
+    return bins && bins[0] >= 2 && bins[1] >= 2 && bins[2] >= 2 && bins[0] <= 1024 && bins[1] <= 1024 &&
+           bins[2] <= 1024;
+}
+
+}  // namespace
+
+extern "C" size_t chx_sc_igf_workspace_bytes(int64_t B, const int32_t* bins) {
+    if (B < 1 || !bins_ok(bins)) return 0;
+    return (size_t)B * (size_t)(bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1) * sizeof(double);
+}
+
+extern "C" int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
+                          void* G_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!cell || !gamma || !G_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!workspace || workspace_bytes < chx_sc_igf_workspace_bytes(B, bins)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = bins[0], gy = bins[1], gz = bins[2];
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    const size_t gbytes = (size_t)B * 8 * (size_t)gx * gy * gz * esz;
+    if (hipMemsetAsync(G_out, 0, gbytes, s) != hipSuccess) return CHX_ERR_LAUNCH;  // index-g planes stay 0
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    double* table = (double*)workspace;
+    if (dtype == CHX_F32) {
+        hipLaunchKernelGGL(igf_table_kernel<float>, cell_grid(npts, B), dim3(CHX_BLOCK), 0, s,
+                           (const float*)cell, (const float*)gamma, gx, gy, gz, table);
+        CHX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(igf_fill_kernel<float>, cell_grid((int64_t)gx * gy * gz, B), dim3(CHX_BLOCK), 0, s,
+                           table, gx, gy, gz, (float*)G_out);
+    } else {
+        hipLaunchKernelGGL(igf_table_kernel<double>, cell_grid(npts, B), dim3(CHX_BLOCK), 0, s,
+                           (const double*)cell, (const double*)gamma, gx, gy, gz, table);
+        CHX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(igf_fill_kernel<double>, cell_grid((int64_t)gx * gy * gz, B), dim3(CHX_BLOCK), 0, s,
+                           table, gx, gy, gz, (double*)G_out);
+    }
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const double* scale, int64_t B,
+                                   int64_t n_complex, int dtype, void* stream) {
+    if (!rho_hat || !G_hat || !scale || B < 1 || B > 65535 || n_complex < 1) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(spectral_mul_kernel<float>, cell_grid(n_complex, B), dim3(CHX_BLOCK), 0, s,
+                           (float*)rho_hat, (const float*)G_hat, scale, n_complex);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(spectral_mul_kernel<double>, cell_grid(n_complex, B), dim3(CHX_BLOCK), 0, s,
+                           (double*)rho_hat, (const double*)G_hat, scale, n_complex);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_sc_gradient(const void* phi, const void* cell, const void* gamma, int64_t B,
+                               const int32_t* bins, int dtype, void* F_out, void* stream) {
+    if (!phi || !cell || !gamma || !F_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ncell = (int64_t)bins[0] * bins[1] * bins[2];
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(gradient_kernel<float>, cell_grid(ncell, B), dim3(CHX_BLOCK), 0, s,
+                           (const float*)phi, (const float*)cell, (const float*)gamma, bins[0], bins[1],
+                           bins[2], (float*)F_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(gradient_kernel<double>, cell_grid(ncell, B), dim3(CHX_BLOCK), 0, s,
+                           (const double*)phi, (const double*)cell, (const double*)gamma, bins[0], bins[1],
+                           bins[2], (double*)F_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+template <int MODE>
+static int launch_particle(const void* x_in, const void* F, const void* half, const void* cell,
+                           const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
+                           int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
+                           void* stream) {
+    if (!x_in || !x_out || !energy || B < 1 || N < 1 || B > 65535) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = (N + CHX_BLOCK - 1) / CHX_BLOCK;
+    if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    dim3 grid((unsigned)tiles, (unsigned)B);
+    const int gx = bins ? bins[0] : 0, gy = bins ? bins[1] : 0, gz = bins ? bins[2] : 0;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL((sc_particle_kernel<float, MODE>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+                           (const float*)F, (const float*)half, (const float*)cell, (const float*)energy,
+                           (const float*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (float*)x_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL((sc_particle_kernel<double, MODE>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
+                           (const double*)F, (const double*)half, (const double*)cell, (const double*)energy,
+                           (const double*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (double*)x_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_sc_gather_kick(const void* x_in, const void* F, const void* half, const void* cell,
+                                  const void* energy, const void* dt, double mass_eV, int64_t B,
+                                  int64_t Bx, int64_t Be, int64_t N, const int32_t* bins, int dtype,
+                                  void* x_out, void* stream) {
+    if (!F || !half || !cell || !dt || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    return launch_particle<0>(x_in, F, half, cell, energy, dt, mass_eV, B, Bx, Be, N, bins, dtype, x_out, stream);
+}
+
+extern "C" int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B,
+                                 int64_t Bx, int64_t Be, int64_t N, int dtype, void* xp_out, void* stream) {
+    return launch_particle<1>(x_in, nullptr, nullptr, nullptr, energy, nullptr, mass_eV, B, Bx, Be, N,
+                              nullptr, dtype, xp_out, stream);
+}
+
+extern "C" int chx_from_xyz_pxpypz(const void* xp_in, const void* energy, double mass_eV, int64_t B,
+                                   int64_t Bx, int64_t Be, int64_t N, int dtype, void* x_out, void* stream) {
+    return launch_particle<2>(xp_in, nullptr, nullptr, nullptr, energy, nullptr, mass_eV, B, Bx, Be, N,
+                              nullptr, dtype, x_out, stream);
+}

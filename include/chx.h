@@ -1,0 +1,243 @@
+/* chx.h — C-ABI of libchx, the MI355X (gfx950) beam-dynamics tracking engine.
+ *
+ * This is the drop-in boundary of the `Segment.track(ParticleBeam)` hot path of
+ * desy-ml/cheetah. The reference has no FFI of its own (it is pure Python on
+ * PyTorch); its operator interface is `Element.track` /
+ * `Element.first_order_transfer_map` / `Segment.track` / `ParticleBeam`
+ * (cheetah/accelerator/element.py:104-193, cheetah/accelerator/segment.py:534-574,
+ * cheetah/particles/particle_beam.py:60-106). Every entry point below names the
+ * reference function (file:line under /root/reference/cheetah) whose arithmetic it
+ * replaces. `cheetah_amd/_lib.py` binds them with ctypes; INTEGRATION.md shows the
+ * stub a Cheetah maintainer would add.
+ *
+ * Conventions (all entry points)
+ *  - return CHX_OK (0) or a negative chx_status; nothing throws across the ABI;
+ *  - every pointer is a DEVICE pointer owned by the caller, except `const int32_t*`
+ *    / struct arguments which are HOST memory read before the call returns;
+ *  - no allocation, no host synchronisation, no global state: work is enqueued on
+ *    the caller's HIP stream (`stream` = hipStream_t, NULL = default stream) and the
+ *    call returns immediately; calls on different streams are re-entrant;
+ *  - dtype: CHX_F32 / CHX_F64 selects the element type of all `void*` floating
+ *    buffers of that call; `double*` buffers are always fp64;
+ *  - phase-space layout is the reference's: particles[B][N][7] row-major, row =
+ *    (x, px, y, py, tau, delta, 1) (element.py:104-131), transfer maps [B][7][7]
+ *    row-major with out_i = sum_j R[i][j] * in_j (element.py:182);
+ *  - "B?" arguments (Bx, BR, Bw, ...) are broadcast extents: each must be 1 or B.
+ *  - particle buffers must be 16-byte aligned (CHX_ERR_MISALIGNED otherwise).
+ */
+#ifndef CHX_H
+#define CHX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHX_ABI_VERSION 1
+
+typedef enum chx_status {
+    CHX_OK = 0,
+    CHX_ERR_INVALID_ARG = -1,
+    CHX_ERR_DTYPE = -2,
+    CHX_ERR_MISALIGNED = -3,
+    CHX_ERR_LAUNCH = -4,
+    CHX_ERR_WORKSPACE = -5,
+    CHX_ERR_NO_DEVICE = -6
+} chx_status;
+
+typedef enum chx_dtype { CHX_F32 = 0, CHX_F64 = 1 } chx_dtype;
+
+/* Element kinds understood by chx_build_rmatrix; params layout [P] per batch row. */
+typedef enum chx_kind {
+    CHX_IDENTITY = 0,   /* P=0  Marker / inactive Screen, BPM, Aperture (marker.py:45-57) */
+    CHX_DRIFT = 1,      /* P=1  [L]                                  track_methods.py:284-299 */
+    CHX_QUADRUPOLE = 2, /* P=5  [L,k1,tilt,mis_x,mis_y]              quadrupole.py:93-110     */
+    CHX_DIPOLE = 3,     /* P=9  [L,angle,k1,e1,e2,tilt,fint,fint_exit,gap]  dipole.py:372-394,430-466 */
+    CHX_HCOR = 4,       /* P=2  [L,angle]                            horizontal_corrector.py:60-78 */
+    CHX_VCOR = 5,       /* P=2  [L,angle]                            vertical_corrector.py:61-78 */
+    CHX_CCOR = 6,       /* P=3  [L,hangle,vangle]                    combined_corrector.py:77-98 */
+    CHX_CAVITY_SW = 7,  /* P=4  [L,voltage,phase_deg,frequency]      cavity.py:253-358 (standing wave) */
+    CHX_CAVITY_TW = 8,  /* P=4  same, traveling wave                 cavity.py:310-335 */
+    CHX_KIND_COUNT = 9
+} chx_kind;
+
+#define CHX_MAX_PARAMS 9
+/* number of params of a kind, or -1 */
+int chx_kind_num_params(int kind);
+int chx_abi_version(void);
+/* human-readable status */
+const char* chx_status_string(int status);
+
+/* ---- map builders (a3-a8; track_methods.py:17-77,284-382; dipole.py:430-466; cavity.py:253-358)
+ * Builds R_out[B][7][7] (dtype) from params[Bp][P] and energy[Be] (dtype). Arithmetic is
+ * carried out in fp64 on device and rounded once. mass_eV / n_charges describe the Species
+ * (species.py:30-36). */
+int chx_build_rmatrix(int kind, const void* params, const void* energy, double mass_eV,
+                      double n_charges, int64_t B, int64_t Bp, int64_t Be, int dtype,
+                      void* R_out, void* stream);
+
+/* Vector-Jacobian product of chx_build_rmatrix: given dR[B][7][7] (dtype) returns
+ * dparams[B][P] and denergy[B] (dtype), d(sum dR*R)/d(param). Forward-mode dual numbers
+ * inside the kernel; replaces autograd through track_methods.py / utils/autograd.py:77-146. */
+int chx_build_rmatrix_vjp(int kind, const void* params, const void* energy, double mass_eV,
+                          double n_charges, const void* dR, int64_t B, int64_t Bp, int64_t Be,
+                          int dtype, void* dparams, void* denergy, void* stream);
+
+/* ---- segment composition (a2; segment.py:534-543): R_out[b] = R_{E-1}[b] ... R_1[b] R_0[b].
+ * R_ptrs is a HOST array of E device pointers, one map buffer per element (each element owns
+ * its cached map); buffer e is [1][7][7] if bcast[e] (HOST array) else [B][7][7]. The pointers are
+ * forwarded by value in the kernel arguments (no device-side table, no copy). fp64 accumulation,
+ * rounded once to dtype. */
+int chx_compose_maps(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B,
+                     int dtype, void* R_out, void* stream);
+
+/* ---- linear apply (a1; element.py:180-191): x_out[b][n][:] = R[b] . x_in[b][n][:]. */
+int chx_apply_affine7(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
+                      int64_t BR, int64_t N, int dtype, void* stream);
+
+/* Backward of the apply: dX[b][n][j] = sum_i dY[b][n][i] R[b][i][j]  (dX may be NULL) and
+ * dR[b][i][j] = sum_n dY[b][n][i] X[b][n][j] (double dR[B][49]; may be NULL; needs workspace
+ * of chx_apply_bwd_workspace_bytes(B,N)). */
+size_t chx_apply_bwd_workspace_bytes(int64_t B, int64_t N);
+int chx_apply_affine7_bwd(const void* dY, const void* R, const void* X, void* dX, double* dR,
+                          int64_t B, int64_t Bx, int64_t BR, int64_t N, int dtype,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Element-by-element tracking of a run of E linear elements WITHOUT merging the maps
+ * (`for e in elements: beam = e.track(beam)`, segment.py:571-572): E apply passes
+ * ping-ponging between x_out and scratch ([B][N][7]); the final result is in x_out. */
+int chx_track_elementwise(const void* x_in, const void* R /*[E][BR][7][7]*/, void* x_out,
+                          void* scratch, int64_t E, int64_t B, int64_t Bx, int64_t BR,
+                          int64_t N, int dtype, void* stream);
+
+/* Same result as chx_track_elementwise (bit-identical per-element rounding) but one pass
+ * over HBM: each particle stays in registers while the E maps are applied in order. */
+int chx_track_fused(const void* x_in, const void* R /*[E][BR][7][7]*/, void* x_out, int64_t E,
+                    int64_t B, int64_t Bx, int64_t BR, int64_t N, int dtype, void* stream);
+
+/* ---- cavity (a8; cavity.py:100-251).
+ * coefficients per batch row, computed on device (no host branch: the reference's
+ * `if (delta_energy > 0).any()` (cavity.py:157) is evaluated over the batch in-kernel). */
+#define CHX_CAV_NCOEF 8 /* [a, b, kbeta0, phi, cosphi, T566, T556, T555] */
+int chx_cavity_coeffs(const void* params /*[Bp][4]*/, const void* energy /*[Be]*/, double mass_eV,
+                      double n_charges, int64_t B, int64_t Bp, int64_t Be, int dtype,
+                      double* coeffs /*[B][CHX_CAV_NCOEF]*/, void* energy_out /*[B] dtype*/,
+                      void* stream);
+/* x_out = R.x_in, then delta' and tau' per particle (cavity.py:135-151,220-226). */
+int chx_cavity_track(const void* x_in, const void* R, const double* coeffs, void* x_out,
+                     int64_t B, int64_t Bx, int64_t N, int dtype, void* stream);
+
+/* ---- weighted beam moments (a10; particle_beam.py:1672-1943, utils/statistics.py:4-62).
+ * sums[b] = { W=sum w, sum w^2, sum w x_0..5 }  (8 doubles)
+ * m2[b]   = upper triangle (a<=b, row-major, 21 doubles) of sum w (x_a-mu_a)(x_b-mu_b),
+ *           mu = sums[2..7]/sums[0] read from `sums` on device (multi-GPU: all-reduce sums first)
+ * out[b]  = { W, W2, mu[6], cov[21] } with cov = m2 / (W - W2/W)          (29 doubles)
+ * w may be NULL (all ones). Deterministic two-stage reductions (no float atomics). */
+#define CHX_MOM_NSUMS 8
+#define CHX_MOM_NM2 21
+#define CHX_MOM_NOUT 29
+size_t chx_moments_workspace_bytes(int64_t B, int64_t N);
+int chx_moment_sums(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
+                    int dtype, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int chx_moment_centred(const void* x, const void* w, const double* sums, int64_t B, int64_t Bx,
+                       int64_t Bw, int64_t N, int dtype, double* m2, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int chx_moment_finalize(const double* sums, const double* m2, int64_t B, double* out, void* stream);
+/* convenience: the three calls above on one stream */
+int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
+                int dtype, double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* backward of chx_moments wrt x: given d_out[B][29] (double; entries 0,1 ignored) */
+int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,
+                    int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX, void* stream);
+
+/* ---- cloud-in-cell deposition (a12; utils/cloud_in_cell.py:8-451) and Screen images
+ * (a11; screen.py:241-344). Positions are read straight out of the particle array:
+ * pos_d = (x[b][n][col[d]] * scale[b][d]) - shift[b][d], each step rounded in `dtype`
+ * exactly like the reference's tensor ops (screen.py:200-212 misalignment subtraction,
+ * particle_beam.py:1333 z = tau * -beta). Weight = charge * survival (|charge| if abs_charge).
+ * Index arithmetic follows cloud_in_cell.py:150-211 in `dtype`, bit-exact. */
+typedef struct chx_cic_args {
+    int32_t ndim;            /* 1..3 */
+    int32_t cols[3];         /* column of the 7-vector used for each axis */
+    int32_t bins[3];         /* grid shape */
+    int64_t grid_strides[3]; /* element strides of the output grid per axis (row-major default if 0) */
+    int64_t grid_batch_stride;
+    int64_t B, Bx, Bq, Bs, Be, Bsc, Bsh, N;
+    int32_t dtype;
+    int32_t abs_charge;
+    const void* x;        /* [Bx][N][7] */
+    const void* charge;   /* [Bq][N] or NULL (=1) */
+    const void* survival; /* [Bs][N] or NULL (=1) */
+    const void* extent;   /* [Be][ndim][2] (left,right) */
+    const void* scale;    /* [Bsc][ndim] or NULL */
+    const void* shift;    /* [Bsh][ndim] or NULL */
+    void* grid;           /* [B] grids, dtype, accumulated into (caller zeroes) */
+} chx_cic_args;
+int chx_cic_deposit(const chx_cic_args* args, void* stream);
+/* Test/diagnostic twin: writes the integer cell index i_d=floor(p_d) (int32 [B][N][ndim])
+ * and fractional part f_d (dtype [B][N][ndim]) instead of depositing. */
+int chx_cic_indices(const chx_cic_args* args, int32_t* idx_out, void* frac_out, void* stream);
+/* Backward of the deposit wrt charges and positions (cloud_in_cell.py is differentiable):
+ * dq[b][n] = sum_corners dgrid*weight ; dpos[b][n][d] via d(weight)/d(f_d) / bin_width. */
+int chx_cic_deposit_bwd(const chx_cic_args* args, const void* dgrid, void* dweight /*[B][N]*/,
+                        void* dpos /*[B][N][ndim]*/, void* stream);
+
+/* Screen "histogram" method (screen.py:292-311 -> torch.histogramdd): bin j iff
+ * e_j <= v < e_{j+1}, last bin right-inclusive, outside dropped; edges from torch.linspace. */
+typedef struct chx_hist2d_args {
+    int64_t B, Bx, Bq, Bs, Bsh, N;
+    int32_t nx, ny; /* number of bins; edges have nx+1 / ny+1 entries */
+    int32_t dtype;
+    const void* x;        /* [Bx][N][7]; x = col 0, y = col 2 */
+    const void* charge;   /* |charge| * survival is the weight */
+    const void* survival;
+    const void* shift;    /* [Bsh][2] screen misalignment or NULL */
+    const void* edges_x;  /* [nx+1] dtype */
+    const void* edges_y;  /* [ny+1] dtype */
+    void* image;          /* [B][ny][nx] dtype (already transposed like screen.py:311), caller zeroes */
+} chx_hist2d_args;
+int chx_hist2d(const chx_hist2d_args* args, void* stream);
+int chx_hist2d_indices(const chx_hist2d_args* args, int32_t* ij_out /*[B][N][2], -1 = dropped*/,
+                       void* stream);
+
+/* ---- space charge (a13; space_charge_kick.py:103-586, particle_beam.py:1262-1346) */
+/* Integrated Green function on the doubled grid (space_charge_kick.py:163-291).
+ * cell[B][3] (dtype) = cell sizes (hx,hy,htau); gamma[B] (dtype). fp64 inside; the workspace
+ * holds the (gx+1)(gy+1)(gz+1) corner table of the primitive per batch row. */
+size_t chx_sc_igf_workspace_bytes(int64_t B, const int32_t* bins);
+int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
+               void* G_out /*[B][2gx][2gy][2gz]*/, void* workspace, size_t workspace_bytes,
+               void* stream);
+/* rho_hat *= G_hat * scale[b]  (complex multiply; space_charge_kick.py:313-316);
+ * n_complex = complex elements per batch row; scale (double[B]) folds 1/(4 pi eps0) and 1/cell volume. */
+int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const double* scale, int64_t B,
+                        int64_t n_complex, int dtype, void* stream);
+/* E+vxB force field from the potential (space_charge_kick.py:324-365): central differences
+ * on the cropped [g]^3 part of phi[B][2gx][2gy][2gz], x -1/gamma^2; F_out[B][gx][gy][gz][4]. */
+int chx_sc_gradient(const void* phi, const void* cell, const void* gamma, int64_t B,
+                    const int32_t* bins, int dtype, void* F_out, void* stream);
+/* Fused: to_xyz_pxpypz -> trilinear node-based gather -> p += F*dt -> from_xyz_pxpypz
+ * (space_charge_kick.py:387-475,548-584; particle_beam.py:1262-1346).
+ * half[B][3] grid half-widths, cell[B][3], energy[Be], dt[B] (all dtype). */
+int chx_sc_gather_kick(const void* x_in, const void* F, const void* half, const void* cell,
+                       const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
+                       int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
+                       void* stream);
+/* SI conversion on its own (particle_beam.py:1262-1346), used by to_xyz_pxpypz/from_xyz_pxpypz */
+int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B, int64_t Bx,
+                      int64_t Be, int64_t N, int dtype, void* xp_out, void* stream);
+int chx_from_xyz_pxpypz(const void* xp_in, const void* energy, double mass_eV, int64_t B,
+                        int64_t Bx, int64_t Be, int64_t N, int dtype, void* x_out, void* stream);
+
+/* ---- instrumentation: average duration (ms) of `iters` back-to-back launches of the apply
+ * kernel on `stream`, measured with hipEvents recorded on that stream. Used by bench.py for
+ * roofline.achieved. Synchronises the stream (the only entry point that does). */
+int chx_time_apply_ms(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
+                      int64_t BR, int64_t N, int dtype, int iters, void* stream, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHX_H */
