@@ -1,0 +1,30 @@
+"""cheetah_amd — MI355X-native tracking engine behind Cheetah's Segment / Element / ParticleBeam API.
+
+The hot path `Segment.track(ParticleBeam)` (map builders, linear apply, cavity, beam moments, screen
+images, space-charge kick) runs in hand-written HIP kernels for gfx950 exposed through the C-ABI of
+`libchx.so` (include/chx.h). There is no CPU or eager fallback: tensors must live on a ROCm device.
+"""
+
+from . import _lib  # noqa: F401
+from .accelerator import (  # noqa: F401
+    BPM,
+    Aperture,
+    Cavity,
+    CombinedCorrector,
+    CustomTransferMap,
+    Dipole,
+    Drift,
+    Element,
+    HorizontalCorrector,
+    Marker,
+    PhysicsWarning,
+    Quadrupole,
+    RBend,
+    Screen,
+    Segment,
+    SpaceChargeKick,
+    VerticalCorrector,
+)
+from .particles import ParticleBeam, Species  # noqa: F401
+
+__version__ = "0.1.0"

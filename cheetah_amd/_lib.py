@@ -1,0 +1,130 @@
+"""ctypes binding of libchx.so (include/chx.h).
+
+The library is the ONLY compute backend of this package: if it is missing or cannot be loaded the
+import of any tracking entry point fails loudly — there is no CPU / eager fallback.
+
+PyTorch is imported first on purpose: libchx.so needs ``libamdhip64.so.7``; PyTorch-ROCm ships and
+loads its own copy with the same soname, and the dynamic loader then binds libchx to that copy, so
+streams and device pointers handed over from torch are valid inside the kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede loading libchx.so, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchx.so")
+
+c_void_p, c_int, c_i64, c_double, c_size_t = (
+    ctypes.c_void_p,
+    ctypes.c_int,
+    ctypes.c_int64,
+    ctypes.c_double,
+    ctypes.c_size_t,
+)
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_u8_p = ctypes.POINTER(ctypes.c_uint8)
+c_vpp = ctypes.POINTER(ctypes.c_void_p)
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class ChxError(RuntimeError):
+    """A libchx entry point returned a negative chx_status."""
+
+
+class CicArgs(ctypes.Structure):
+    """struct chx_cic_args (include/chx.h)."""
+
+    _fields_ = [
+        ("ndim", ctypes.c_int32),
+        ("cols", ctypes.c_int32 * 3),
+        ("bins", ctypes.c_int32 * 3),
+        ("grid_strides", ctypes.c_int64 * 3),
+        ("grid_batch_stride", ctypes.c_int64),
+        ("B", c_i64), ("Bx", c_i64), ("Bq", c_i64), ("Bs", c_i64), ("Be", c_i64),
+        ("Bsc", c_i64), ("Bsh", c_i64), ("N", c_i64),
+        ("dtype", ctypes.c_int32),
+        ("abs_charge", ctypes.c_int32),
+        ("x", c_void_p), ("charge", c_void_p), ("survival", c_void_p), ("extent", c_void_p),
+        ("scale", c_void_p), ("shift", c_void_p), ("grid", c_void_p),
+    ]
+
+
+class Hist2dArgs(ctypes.Structure):
+    """struct chx_hist2d_args (include/chx.h)."""
+
+    _fields_ = [
+        ("B", c_i64), ("Bx", c_i64), ("Bq", c_i64), ("Bs", c_i64), ("Bsh", c_i64), ("N", c_i64),
+        ("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("x", c_void_p), ("charge", c_void_p), ("survival", c_void_p), ("shift", c_void_p),
+        ("edges_x", c_void_p), ("edges_y", c_void_p), ("image", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/chx.h declares
+SIGNATURES = {
+    "chx_kind_num_params": (c_int, [c_int]),
+    "chx_abi_version": (c_int, []),
+    "chx_status_string": (ctypes.c_char_p, [c_int]),
+    "chx_build_rmatrix": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_build_rmatrix_vjp": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_compose_maps": (c_int, [c_vpp, c_u8_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_apply_affine7": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
+    "chx_apply_bwd_workspace_bytes": (c_size_t, [c_i64, c_i64]),
+    "chx_apply_affine7_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_size_t, c_void_p]),
+    "chx_track_elementwise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
+    "chx_track_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
+    "chx_cavity_coeffs": (c_int, [c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_cavity_track": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]),
+    "chx_moments_workspace_bytes": (c_size_t, [c_i64, c_i64]),
+    "chx_moment_sums": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_moment_centred": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_moment_finalize": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "chx_moments": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_moments_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_cic_deposit": (c_int, [ctypes.POINTER(CicArgs), c_void_p]),
+    "chx_cic_indices": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_void_p, c_void_p]),
+    "chx_cic_deposit_bwd": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_hist2d": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p]),
+    "chx_hist2d_indices": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p, c_void_p]),
+    "chx_sc_igf_workspace_bytes": (c_size_t, [c_i64, c_i32_p]),
+    "chx_sc_igf": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_sc_spectral_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_sc_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_time_apply_ms": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_void_p, c_double_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libchx.so (once). Raises ImportError with build instructions when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP library is the only backend of cheetah_amd. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C cheetah_amd/csrc` (needs hipcc, --offload-arch=gfx950)."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.chx_abi_version() != 1:
+            raise ImportError("libchx.so ABI version mismatch; rebuild the library")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "libchx") -> None:
+    if status != 0:
+        msg = lib().chx_status_string(status).decode()
+        raise ChxError(f"{what} failed: {msg} (status {status})")

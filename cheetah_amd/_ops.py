@@ -1,0 +1,554 @@
+"""Tensor-level wrappers of the libchx C-ABI (device pointers + current HIP stream) and the
+``torch.autograd.Function``s whose backward passes are HIP kernels as well.
+
+PyTorch is plumbing here: it owns the device memory (caching allocator) and the stream. All
+arithmetic on particle-sized or map-sized data happens inside libchx.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CicArgs, Hist2dArgs, check
+
+KIND = {
+    "identity": 0, "drift": 1, "quadrupole": 2, "dipole": 3, "hcor": 4, "vcor": 5, "ccor": 6,
+    "cavity_sw": 7, "cavity_tw": 8,
+}
+NUM_PARAMS = [0, 1, 5, 9, 2, 2, 3, 4, 4]
+MOM_NOUT = 29
+CAV_NCOEF = 8
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.float64:
+        return 1
+    raise TypeError(f"cheetah_amd supports float32 and float64 beams, got {dtype}")
+
+
+def require_device(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "cheetah_amd tracks on the GPU only (HIP kernels, no CPU fallback): move the beam "
+                "and the lattice to a ROCm device first, e.g. `.to('cuda')`."
+            )
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+def aligned(t: torch.Tensor) -> torch.Tensor:
+    """Contiguous and 16-byte aligned view/copy of `t`."""
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+def flat_bcast(t: torch.Tensor, batch_shape, n_tail: int):
+    """Flatten the leading (vector) dims of `t` against `batch_shape`.
+
+    Returns (tensor of shape (Bt, *tail), Bt) with Bt in {1, B}; data is only materialised when the
+    vector dims are a genuine partial broadcast.
+    """
+    tail = t.shape[t.dim() - n_tail:] if n_tail else ()
+    lead = t.shape[: t.dim() - n_tail]
+    B = numel(batch_shape)
+    if numel(lead) == 1:
+        return t.reshape(1, *tail), 1
+    if tuple(lead) == tuple(batch_shape):
+        return t.reshape(B, *tail), B
+    return t.expand(*batch_shape, *tail).reshape(B, *tail), B
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# map builders
+def build_rmatrix_raw(kind: int, params, energy, mass_eV: float, n_charges: float, B: int) -> torch.Tensor:
+    """params (Bp,P) / energy (Be,) device tensors of one dtype -> R (B,7,7)."""
+    require_device(energy)
+    dt = dtype_code(energy.dtype)
+    R = torch.empty((B, 7, 7), dtype=energy.dtype, device=energy.device)
+    Bp = params.shape[0] if params is not None else 1
+    check(_lib.lib().chx_build_rmatrix(kind, ptr(params), ptr(energy), mass_eV, n_charges, B, Bp,
+                                       energy.shape[0], dt, ptr(R), stream_ptr()), "chx_build_rmatrix")
+    return R
+
+
+class BuildMap(torch.autograd.Function):
+    """R = builder(params, energy); backward = chx_build_rmatrix_vjp (dual numbers on device)."""
+
+    @staticmethod
+    def forward(ctx, params, energy, kind, mass_eV, n_charges, B):
+        params = params.contiguous()
+        energy = energy.contiguous()
+        ctx.save_for_backward(params, energy)
+        ctx.meta = (kind, mass_eV, n_charges, B)
+        return build_rmatrix_raw(kind, params, energy, mass_eV, n_charges, B)
+
+    @staticmethod
+    def backward(ctx, dR):
+        params, energy = ctx.saved_tensors
+        kind, mass_eV, n_charges, B = ctx.meta
+        P = NUM_PARAMS[kind]
+        dR = dR.contiguous()
+        dparams = torch.empty((B, max(P, 1)), dtype=energy.dtype, device=energy.device)
+        denergy = torch.empty((B,), dtype=energy.dtype, device=energy.device)
+        check(_lib.lib().chx_build_rmatrix_vjp(kind, ptr(params), ptr(energy), mass_eV, n_charges, ptr(dR),
+                                               B, params.shape[0], energy.shape[0], dtype_code(energy.dtype),
+                                               ptr(dparams), ptr(denergy), stream_ptr()), "chx_build_rmatrix_vjp")
+        dparams = dparams[:, :P]
+        if params.shape[0] == 1 and B > 1:
+            dparams = dparams.sum(dim=0, keepdim=True)
+        if energy.shape[0] == 1 and B > 1:
+            denergy = denergy.sum(dim=0, keepdim=True)
+        return dparams, denergy, None, None, None, None
+
+
+def build_rmatrix(kind: int, params, energy, mass_eV, n_charges, B) -> torch.Tensor:
+    if (params is not None and params.requires_grad) or energy.requires_grad:
+        if params is None:
+            params = energy.new_zeros((1, 0))
+        return BuildMap.apply(params, energy, kind, mass_eV, n_charges, B)
+    with torch.no_grad():
+        return build_rmatrix_raw(kind, None if params is None else params.contiguous(), energy.contiguous(),
+                                 mass_eV, n_charges, B)
+
+
+def compose_maps(maps: list[torch.Tensor], batch_shape, dtype, device) -> torch.Tensor:
+    """maps: per-element (…,7,7) tensors -> composed (*batch_shape,7,7) = R_E … R_1 (segment.py:534-543)."""
+    B = numel(batch_shape)
+    if any(m.requires_grad for m in maps):
+        # gradient path: a handful of 7x7 products, let autograd see them
+        tm = torch.eye(7, dtype=dtype, device=device)
+        for m in maps:
+            tm = m.to(dtype) @ tm
+        return tm.expand(*batch_shape, 7, 7)
+    E = len(maps)
+    flat = []
+    bc = (ctypes.c_uint8 * E)()
+    ptrs = (ctypes.c_void_p * E)()
+    for e, m in enumerate(maps):
+        f, Bm = flat_bcast(m if m.dtype == dtype else m.to(dtype), batch_shape, 2)
+        f = f.contiguous()
+        flat.append(f)  # keep alive until the launch is enqueued
+        bc[e] = 1 if Bm == 1 else 0
+        ptrs[e] = f.data_ptr()
+    out = torch.empty((B, 7, 7), dtype=dtype, device=device)
+    check(_lib.lib().chx_compose_maps(ptrs, bc, E, B, dtype_code(dtype), ptr(out), stream_ptr()),
+          "chx_compose_maps")
+    return out.reshape(*batch_shape, 7, 7)
+
+
+# ---------------------------------------------------------------------------------------------
+# linear apply
+def _apply_raw(x, R, B, Bx, BR, N):
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_apply_affine7(ptr(x), ptr(R), ptr(out), B, Bx, BR, N, dtype_code(x.dtype), stream_ptr()),
+          "chx_apply_affine7")
+    return out
+
+
+class Apply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, R, B):
+        ctx.save_for_backward(x, R)
+        ctx.B = B
+        return _apply_raw(x, R, B, x.shape[0], R.shape[0], x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, R = ctx.saved_tensors
+        B, Bx, BR, N = ctx.B, x.shape[0], R.shape[0], x.shape[1]
+        dY = aligned(dY)
+        need_dx, need_dr = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        lib = _lib.lib()
+        ws_bytes = lib.chx_apply_bwd_workspace_bytes(B, N)
+        ws = workspace(ws_bytes, x.device)
+        dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_dx else None
+        dR = torch.empty((B, 49), dtype=torch.float64, device=x.device) if need_dr else None
+        check(lib.chx_apply_affine7_bwd(ptr(dY), ptr(R), ptr(x), ptr(dX), ptr(dR), B, Bx, BR, N,
+                                        dtype_code(x.dtype), ptr(ws), ws_bytes, stream_ptr()),
+              "chx_apply_affine7_bwd")
+        if need_dx and Bx == 1 and B > 1:
+            dX = dX.sum(dim=0, keepdim=True)
+        if need_dr:
+            dR = dR.reshape(B, 7, 7)
+            if BR == 1 and B > 1:
+                dR = dR.sum(dim=0, keepdim=True)
+            dR = dR.to(R.dtype)
+        return dX, dR, None
+
+
+def apply_map(particles: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
+    """`particles @ tm.mT` (element.py:182) with torch broadcasting of the vector dims."""
+    require_device(particles, tm)
+    if tm.dtype != particles.dtype:
+        raise RuntimeError(f"transfer map dtype {tm.dtype} does not match particle dtype {particles.dtype}")
+    N = particles.shape[-2]
+    batch_shape = torch.broadcast_shapes(particles.shape[:-2], tm.shape[:-2])
+    B = numel(batch_shape)
+    x, _ = flat_bcast(particles, batch_shape, 2)
+    R, _ = flat_bcast(tm, batch_shape, 2)
+    x, R = aligned(x), R.contiguous()
+    if x.requires_grad or R.requires_grad:
+        out = Apply.apply(x, R, B)
+    else:
+        out = _apply_raw(x, R, B, x.shape[0], R.shape[0], N)
+    return out.reshape(*batch_shape, N, 7)
+
+
+def track_elementwise(particles, maps: torch.Tensor, fused: bool = False) -> torch.Tensor:
+    """Apply E maps ([E][BR][7][7]) one after the other without merging them."""
+    require_device(particles, maps)
+    E, BR = maps.shape[0], maps.shape[1]
+    N = particles.shape[-2]
+    batch_shape = torch.broadcast_shapes(particles.shape[:-2], (BR,) if BR > 1 else ())
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    x, maps = aligned(x), maps.contiguous()
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    lib = _lib.lib()
+    if fused:
+        check(lib.chx_track_fused(ptr(x), ptr(maps), ptr(out), E, B, Bx, BR, N, dtype_code(x.dtype), stream_ptr()),
+              "chx_track_fused")
+    else:
+        scratch = torch.empty_like(out) if E > 1 else None
+        check(lib.chx_track_elementwise(ptr(x), ptr(maps), ptr(out), ptr(scratch), E, B, Bx, BR, N,
+                                        dtype_code(x.dtype), stream_ptr()), "chx_track_elementwise")
+    return out.reshape(*batch_shape, N, 7)
+
+
+# ---------------------------------------------------------------------------------------------
+# cavity
+def cavity_coeffs(params, energy, mass_eV, n_charges, B):
+    coeffs = torch.empty((B, CAV_NCOEF), dtype=torch.float64, device=energy.device)
+    e_out = torch.empty((B,), dtype=energy.dtype, device=energy.device)
+    check(_lib.lib().chx_cavity_coeffs(ptr(params), ptr(energy), mass_eV, n_charges, B, params.shape[0],
+                                       energy.shape[0], dtype_code(energy.dtype), ptr(coeffs), ptr(e_out),
+                                       stream_ptr()), "chx_cavity_coeffs")
+    return coeffs, e_out
+
+
+def cavity_track(x, R, coeffs, B, N):
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_cavity_track(ptr(x), ptr(R), ptr(coeffs), ptr(out), B, x.shape[0], N,
+                                      dtype_code(x.dtype), stream_ptr()), "chx_cavity_track")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# moments
+def _moments_raw(x, w, B, N):
+    lib = _lib.lib()
+    ws_bytes = lib.chx_moments_workspace_bytes(B, N)
+    ws = workspace(ws_bytes, x.device)
+    out = torch.empty((B, MOM_NOUT), dtype=torch.float64, device=x.device)
+    check(lib.chx_moments(ptr(x), ptr(w), B, x.shape[0], 1 if w is None else w.shape[0], N, dtype_code(x.dtype),
+                          ptr(out), ptr(ws), ws_bytes, stream_ptr()), "chx_moments")
+    return out
+
+
+class Moments(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, B):
+        out = _moments_raw(x, w, B, x.shape[1])
+        ctx.save_for_backward(x, w, out)
+        ctx.B = B
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, w, out = ctx.saved_tensors
+        B, N = ctx.B, x.shape[1]
+        d_out = d_out.contiguous().to(torch.float64)
+        dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+        check(_lib.lib().chx_moments_bwd(ptr(x), ptr(w), ptr(out), ptr(d_out), B, x.shape[0],
+                                         1 if w is None else w.shape[0], N, dtype_code(x.dtype), ptr(dX),
+                                         stream_ptr()), "chx_moments_bwd")
+        if x.shape[0] == 1 and B > 1:
+            dX = dX.sum(dim=0, keepdim=True)
+        return dX, None, None
+
+
+def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Tensor:
+    """(…,29) float64: [W, W2, mu(6), cov upper triangle (21)] for every vector entry."""
+    require_device(particles)
+    N = particles.shape[-2]
+    sshape = survival.shape[:-1] if survival is not None else ()
+    batch_shape = torch.broadcast_shapes(particles.shape[:-2], sshape)
+    B = numel(batch_shape)
+    x, _ = flat_bcast(particles, batch_shape, 2)
+    x = aligned(x)
+    w = None
+    if survival is not None:
+        w, _ = flat_bcast(survival.to(particles.dtype), batch_shape, 1)
+        w = w.contiguous()
+    if x.requires_grad:
+        out = Moments.apply(x, w, B)
+    else:
+        out = _moments_raw(x, w, B, N)
+    return out.reshape(*batch_shape, MOM_NOUT)
+
+
+# ---------------------------------------------------------------------------------------------
+# cloud in cell / histogram
+def _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge, grid=None,
+              grid_strides=None, grid_batch_stride=0):
+    require_device(particles, extent)
+    dt = particles.dtype
+    N = particles.shape[-2]
+    nd = len(cols)
+    shapes = [particles.shape[:-2], extent.shape[:-2]]
+    for t, k in ((charge, 1), (survival, 1), (scale, 1), (shift, 1)):
+        if t is not None:
+            shapes.append(t.shape[:-1])
+    batch_shape = torch.broadcast_shapes(*shapes)
+    B = numel(batch_shape)
+    keep = []
+
+    def prep(t, n_tail):
+        if t is None:
+            return None, 1
+        f, Bt = flat_bcast(t.to(dt), batch_shape, n_tail)
+        f = f.contiguous()
+        keep.append(f)
+        return f, Bt
+
+    x, Bx = prep(particles, 2)
+    ext, Be = prep(extent, 2)
+    q, Bq = prep(charge, 1)
+    s, Bs = prep(survival, 1)
+    sc, Bsc = prep(scale, 1)
+    sh, Bsh = prep(shift, 1)
+    a = CicArgs()
+    a.ndim = nd
+    for d in range(nd):
+        a.cols[d] = int(cols[d])
+        a.bins[d] = int(bins[d])
+        a.grid_strides[d] = 0 if grid_strides is None else int(grid_strides[d])
+    a.grid_batch_stride = int(grid_batch_stride)
+    a.B, a.Bx, a.Bq, a.Bs, a.Be, a.Bsc, a.Bsh, a.N = B, Bx, Bq, Bs, Be, Bsc, Bsh, N
+    a.dtype = dtype_code(dt)
+    a.abs_charge = int(bool(abs_charge))
+    a.x, a.charge, a.survival, a.extent = ptr(x), ptr(q), ptr(s), ptr(ext)
+    a.scale, a.shift = ptr(sc), ptr(sh)
+    a.grid = ptr(grid)
+    return a, keep, batch_shape, B, N
+
+
+def cic_deposit(particles, cols, bins, extent, charge=None, survival=None, scale=None, shift=None,
+                abs_charge=False, transpose_2d=False) -> torch.Tensor:
+    """Cloud-in-cell deposition (utils/cloud_in_cell.py:8-451) of columns `cols` of the 7-vectors.
+
+    Returns (*batch, *bins); with transpose_2d the 2-D image is written directly as (bins[1], bins[0])
+    (the `.mT` of screen.py:339).
+    """
+    bins = [int(b) for b in bins]
+    a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge)
+    total = numel(bins)
+    grid = torch.zeros((B, total), dtype=particles.dtype, device=particles.device)
+    a.grid = ptr(grid)
+    if transpose_2d:
+        assert len(bins) == 2
+        a.grid_strides[0], a.grid_strides[1] = 1, bins[0]
+        a.grid_batch_stride = total
+        out_shape = (bins[1], bins[0])
+    else:
+        out_shape = tuple(bins)
+    check(_lib.lib().chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
+    return grid.reshape(*batch_shape, *out_shape)
+
+
+def cic_deposit_into(grid: torch.Tensor, grid_strides, grid_batch_stride, particles, cols, bins, extent,
+                     charge=None, survival=None, scale=None, shift=None) -> None:
+    """Deposit into a caller-provided (zeroed) strided grid, e.g. the doubled Hockney array."""
+    a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, False,
+                                           grid=grid, grid_strides=grid_strides,
+                                           grid_batch_stride=grid_batch_stride)
+    check(_lib.lib().chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
+
+
+def cic_indices(particles, cols, bins, extent, scale=None, shift=None):
+    a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, None, None, scale, shift, False)
+    idx = torch.empty((B, N, len(cols)), dtype=torch.int32, device=particles.device)
+    frac = torch.empty((B, N, len(cols)), dtype=particles.dtype, device=particles.device)
+    check(_lib.lib().chx_cic_indices(ctypes.byref(a), ptr(idx), ptr(frac), stream_ptr()), "chx_cic_indices")
+    return idx.reshape(*batch_shape, N, len(cols)), frac.reshape(*batch_shape, N, len(cols))
+
+
+def _hist_args(particles, edges_x, edges_y, charge, survival, shift):
+    require_device(particles, edges_x, edges_y)
+    dt = particles.dtype
+    N = particles.shape[-2]
+    shapes = [particles.shape[:-2]]
+    for t in (charge, survival, shift):
+        if t is not None:
+            shapes.append(t.shape[:-1])
+    batch_shape = torch.broadcast_shapes(*shapes)
+    B = numel(batch_shape)
+    keep = []
+
+    def prep(t, n_tail):
+        if t is None:
+            return None, 1
+        f, Bt = flat_bcast(t.to(dt), batch_shape, n_tail)
+        f = f.contiguous()
+        keep.append(f)
+        return f, Bt
+
+    x, Bx = prep(particles, 2)
+    q, Bq = prep(charge, 1)
+    s, Bs = prep(survival, 1)
+    sh, Bsh = prep(shift, 1)
+    ex, ey = edges_x.to(dt).contiguous(), edges_y.to(dt).contiguous()
+    keep += [ex, ey]
+    a = Hist2dArgs()
+    a.B, a.Bx, a.Bq, a.Bs, a.Bsh, a.N = B, Bx, Bq, Bs, Bsh, N
+    a.nx, a.ny = ex.shape[0] - 1, ey.shape[0] - 1
+    a.dtype = dtype_code(dt)
+    a.x, a.charge, a.survival, a.shift = ptr(x), ptr(q), ptr(s), ptr(sh)
+    a.edges_x, a.edges_y = ptr(ex), ptr(ey)
+    return a, keep, batch_shape, B, N
+
+
+def hist2d(particles, edges_x, edges_y, charge=None, survival=None, shift=None) -> torch.Tensor:
+    """Screen "histogram" image (…, ny, nx) (screen.py:292-311)."""
+    a, keep, batch_shape, B, N = _hist_args(particles, edges_x, edges_y, charge, survival, shift)
+    img = torch.zeros((B, a.ny, a.nx), dtype=particles.dtype, device=particles.device)
+    a.image = ptr(img)
+    check(_lib.lib().chx_hist2d(ctypes.byref(a), stream_ptr()), "chx_hist2d")
+    return img.reshape(*batch_shape, a.ny, a.nx)
+
+
+def hist2d_indices(particles, edges_x, edges_y, shift=None) -> torch.Tensor:
+    a, keep, batch_shape, B, N = _hist_args(particles, edges_x, edges_y, None, None, shift)
+    ij = torch.empty((B, N, 2), dtype=torch.int32, device=particles.device)
+    check(_lib.lib().chx_hist2d_indices(ctypes.byref(a), ptr(ij), stream_ptr()), "chx_hist2d_indices")
+    return ij.reshape(*batch_shape, N, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# space charge + SI conversions
+def _bins3(bins):
+    return (ctypes.c_int32 * 3)(*[int(b) for b in bins])
+
+
+def sc_igf(cell, gamma, bins) -> torch.Tensor:
+    B = cell.shape[0]
+    lib = _lib.lib()
+    b3 = _bins3(bins)
+    ws_bytes = lib.chx_sc_igf_workspace_bytes(B, b3)
+    ws = workspace(ws_bytes, cell.device)
+    G = torch.empty((B, 2 * bins[0], 2 * bins[1], 2 * bins[2]), dtype=cell.dtype, device=cell.device)
+    check(lib.chx_sc_igf(ptr(cell), ptr(gamma), B, b3, dtype_code(cell.dtype), ptr(G), ptr(ws), ws_bytes,
+                         stream_ptr()), "chx_sc_igf")
+    return G
+
+
+def sc_spectral_mul(rho_hat, G_hat, scale) -> None:
+    B = rho_hat.shape[0]
+    n = numel(rho_hat.shape[1:])
+    real_dtype = torch.float32 if rho_hat.dtype == torch.complex64 else torch.float64
+    check(_lib.lib().chx_sc_spectral_mul(ptr(rho_hat), ptr(G_hat), ptr(scale), B, n, dtype_code(real_dtype),
+                                         stream_ptr()), "chx_sc_spectral_mul")
+
+
+def sc_gradient(phi, cell, gamma, bins) -> torch.Tensor:
+    B = phi.shape[0]
+    F = torch.empty((B, bins[0], bins[1], bins[2], 4), dtype=phi.dtype, device=phi.device)
+    check(_lib.lib().chx_sc_gradient(ptr(phi), ptr(cell), ptr(gamma), B, _bins3(bins), dtype_code(phi.dtype),
+                                     ptr(F), stream_ptr()), "chx_sc_gradient")
+    return F
+
+
+def sc_gather_kick(x, F, half, cell, energy, dt, mass_eV, B, N, bins) -> torch.Tensor:
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_sc_gather_kick(ptr(x), ptr(F), ptr(half), ptr(cell), ptr(energy), ptr(dt), mass_eV, B,
+                                        x.shape[0], energy.shape[0], N, _bins3(bins), dtype_code(x.dtype),
+                                        ptr(out), stream_ptr()), "chx_sc_gather_kick")
+    return out
+
+
+def _si(fn_name, particles, energy, mass_eV):
+    require_device(particles, energy)
+    N = particles.shape[-2]
+    batch_shape = torch.broadcast_shapes(particles.shape[:-2], energy.shape)
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    e, Be = flat_bcast(energy.to(particles.dtype), batch_shape, 0)
+    x, e = aligned(x), e.contiguous()
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(getattr(_lib.lib(), fn_name)(ptr(x), ptr(e), mass_eV, B, Bx, Be, N, dtype_code(x.dtype), ptr(out),
+                                       stream_ptr()), fn_name)
+    return out.reshape(*batch_shape, N, 7)
+
+
+def to_xyz_pxpypz(particles, energy, mass_eV):
+    return _si("chx_to_xyz_pxpypz", particles, energy, mass_eV)
+
+
+def from_xyz_pxpypz(xp, energy, mass_eV):
+    return _si("chx_from_xyz_pxpypz", xp, energy, mass_eV)
+
+
+def time_apply_ms(x, R, out, B, Bx, BR, N, iters) -> float:
+    ms = ctypes.c_double(0.0)
+    check(_lib.lib().chx_time_apply_ms(ptr(x), ptr(R), ptr(out), B, Bx, BR, N, dtype_code(x.dtype), iters,
+                                       stream_ptr(), ctypes.byref(ms)), "chx_time_apply_ms")
+    return ms.value
+
+
+# ---------------------------------------------------------------------------------------------
+# split moment passes (multi-GPU: all-reduce the partials between the passes)
+def moment_sums(x, w, B):
+    """Pass 1: (B,8) float64 [sum w, sum w^2, sum w x_0..5] of the LOCAL particles."""
+    lib = _lib.lib()
+    N = x.shape[1]
+    ws_bytes = lib.chx_moments_workspace_bytes(B, N)
+    ws = workspace(ws_bytes, x.device)
+    sums = torch.empty((B, 8), dtype=torch.float64, device=x.device)
+    check(lib.chx_moment_sums(ptr(x), ptr(w), B, x.shape[0], 1 if w is None else w.shape[0], N,
+                              dtype_code(x.dtype), ptr(sums), ptr(ws), ws_bytes, stream_ptr()), "chx_moment_sums")
+    return sums
+
+
+def moment_centred(x, w, sums, B):
+    """Pass 2: (B,21) float64 centred second-moment sums of the LOCAL particles about the GLOBAL mean
+    encoded in `sums` (already all-reduced)."""
+    lib = _lib.lib()
+    N = x.shape[1]
+    ws_bytes = lib.chx_moments_workspace_bytes(B, N)
+    ws = workspace(ws_bytes, x.device)
+    m2 = torch.empty((B, 21), dtype=torch.float64, device=x.device)
+    check(lib.chx_moment_centred(ptr(x), ptr(w), ptr(sums), B, x.shape[0], 1 if w is None else w.shape[0], N,
+                                 dtype_code(x.dtype), ptr(m2), ptr(ws), ws_bytes, stream_ptr()), "chx_moment_centred")
+    return m2
+
+
+def moment_finalize(sums, m2):
+    B = sums.shape[0]
+    out = torch.empty((B, MOM_NOUT), dtype=torch.float64, device=sums.device)
+    check(_lib.lib().chx_moment_finalize(ptr(sums), ptr(m2), B, ptr(out), stream_ptr()), "chx_moment_finalize")
+    return out

@@ -1,0 +1,93 @@
+"""Cavity (mirror of cheetah/accelerator/cavity.py:51-358).
+
+The first-order map comes from the `chx_build_rmatrix` kernel (kinds CAVITY_SW / CAVITY_TW), the
+per-batch track coefficients from `chx_cavity_coeffs` (including the reference's data-dependent
+`if (delta_energy > 0).any()` branch, evaluated on device) and the particle update is ONE fused
+kernel, `chx_cavity_track`: matrix apply + delta / tau rewrite (the reference makes ~25 elementwise
+passes over the particle array, cavity.py:112-226).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _ops
+from ..particles.particle_beam import ParticleBeam
+from .element import Element
+
+
+class Cavity(Element):
+    """Accelerating RF cavity (standing or traveling wave)."""
+
+    supported_tracking_methods = ["linear"]
+
+    def __init__(self, length, voltage=None, phase=None, frequency=None, cavity_type="standing_wave", name=None,
+                 sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        z = lambda v: v if v is not None else torch.tensor(0.0, **fk)  # noqa: E731
+        self.length = length
+        self.register_buffer_or_parameter("voltage", z(voltage))
+        self.register_buffer_or_parameter("phase", z(phase))
+        self.register_buffer_or_parameter("frequency", z(frequency))
+        if cavity_type not in ("standing_wave", "traveling_wave"):
+            raise ValueError(f"Invalid cavity type: {cavity_type}")
+        self.cavity_type = cavity_type
+
+    @property
+    def _chx_kind(self) -> int:
+        return _ops.KIND["cavity_sw" if self.cavity_type == "standing_wave" else "cavity_tw"]
+
+    def _builder_params(self):
+        return [self.length, self.voltage, self.phase, self.frequency]
+
+    @property
+    def is_active(self) -> bool:
+        # host-side flag, refreshed only when the voltage tensor changes (one sync per change)
+        key = (id(self.voltage), self.voltage._version)
+        cached = self.__dict__.get("_active_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, bool((self.voltage != 0).any().item()))
+            self.__dict__["_active_cache"] = cached
+        return cached[1]
+
+    @property
+    def is_skippable(self) -> bool:
+        return not self.is_active
+
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if not isinstance(incoming, ParticleBeam):
+            raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+        dtype = incoming.particles.dtype
+        tm = self.first_order_transfer_map(incoming.energy, incoming.species)
+        tensors = [t.to(dtype) for t in self._builder_params()]
+        energy = incoming.energy.to(dtype)
+        _ops.require_device(incoming.particles, energy, *tensors)
+        pshape = torch.broadcast_shapes(*[t.shape for t in tensors])
+        vshape = torch.broadcast_shapes(pshape, energy.shape)  # shape of the outgoing energy (cavity.py:122)
+        batch_shape = torch.broadcast_shapes(vshape, incoming.particles.shape[:-2])
+        B, N = _ops.numel(batch_shape), incoming.particles.shape[-2]
+        if len(pshape) == 0:
+            params = torch.stack(tensors).reshape(1, 4)
+        else:
+            params = torch.stack([t.expand(batch_shape) for t in tensors], dim=-1).reshape(B, 4)
+        e = energy.reshape(1) if energy.dim() == 0 else energy.expand(batch_shape).reshape(B).contiguous()
+        sp = incoming.species
+        coeffs, e_out = _ops.cavity_coeffs(params.contiguous(), e, sp.mass_eV_float,
+                                           sp.num_elementary_charges_float, B)
+        x, _ = _ops.flat_bcast(incoming.particles, batch_shape, 2)
+        R, _ = _ops.flat_bcast(tm, batch_shape, 2)
+        R = R.expand(B, 7, 7).contiguous()
+        out = _ops.cavity_track(_ops.aligned(x), R, coeffs, B, N)
+        # outgoing energy has the broadcast shape of (voltage, phase, energy), not of the particles
+        e_out = e_out.reshape(batch_shape)
+        if tuple(vshape) != tuple(batch_shape):
+            idx = tuple(0 for _ in range(len(batch_shape) - len(vshape)))
+            e_out = e_out[idx].reshape(vshape) if idx else e_out.reshape(vshape)
+        return ParticleBeam(out.reshape(*batch_shape, N, 7), e_out, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length,
+                            species=incoming.species)
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length", "voltage", "phase", "frequency", "cavity_type"]

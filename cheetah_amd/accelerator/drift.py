@@ -1,0 +1,36 @@
+"""Drift (mirror of cheetah/accelerator/drift.py:40-65,156-158; linear tracking only)."""
+
+from __future__ import annotations
+
+from .. import _ops
+from .element import Element
+
+
+class Drift(Element):
+    """Drift section in a particle accelerator."""
+
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["drift"]
+
+    def __init__(self, length, tracking_method="linear", name=None, sanitize_name=None, metadata=None,
+                 device=None, dtype=None) -> None:
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, device=device, dtype=dtype)
+        self.length = length
+        self.tracking_method = tracking_method
+
+    def _builder_params(self):
+        return [self.length]
+
+    @property
+    def is_skippable(self) -> bool:
+        return self.tracking_method == "linear"
+
+    def split(self, resolution):
+        import torch
+
+        n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
+        return [Drift(self.length / n, dtype=self.length.dtype, device=self.length.device) for _ in range(n)]
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length"]

@@ -1,0 +1,182 @@
+"""Element base class (mirror of cheetah/accelerator/element.py:17-490 for the linear hot path).
+
+`first_order_transfer_map` is produced by the `chx_build_rmatrix` HIP kernel from the element's
+parameter tensors (no host round trip) and memoised with the reference's cache rules
+(cheetah/utils/cache.py:6-68): key = (id, _version, requires_grad) of every defining tensor plus
+the non-tensor features; bypass when energy / species require grad. `track` applies the map with
+the `chx_apply_affine7` kernel (element.py:180-191).
+"""
+
+from __future__ import annotations
+
+import warnings
+from copy import deepcopy
+from typing import Any
+
+import torch
+from torch import nn
+
+from .. import _ops
+from ..particles.particle_beam import ParticleBeam
+from ..particles.species import Species
+
+
+class PhysicsWarning(UserWarning):
+    """Mirror of cheetah.utils.warnings.PhysicsWarning."""
+
+
+_name_counter = 0
+
+
+def _unique_name() -> str:
+    global _name_counter
+    _name_counter += 1
+    return f"unnamed_element_{_name_counter}"
+
+
+class Element(nn.Module):
+    """Base class of all beamline elements."""
+
+    supported_tracking_methods = ["linear"]
+    #: libchx map-builder kind (include/chx.h `chx_kind`); None for elements with explicit maps
+    _chx_kind: int | None = None
+
+    def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
+        super().__init__()
+        self.__dict__["_revision"] = 0
+        self.name = name if name is not None else _unique_name()
+        self.metadata = metadata if metadata is not None else {}
+        self.register_buffer("length", torch.zeros((), device=device, dtype=dtype))
+        self._tracking_method = "linear"
+
+    # ---- parameters packed for the builder kernel, in include/chx.h order ------------------------
+    def _builder_params(self) -> list[torch.Tensor]:
+        return []
+
+    def _work_dtype(self) -> torch.dtype:
+        return self.length.dtype
+
+    def _build_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
+        """Evaluate the element's 7x7 map on device for `energy` (…) -> (…, 7, 7)."""
+        kind = self._chx_kind
+        dtype = self._work_dtype()
+        tensors = [t.to(dtype) if t.dtype != dtype else t for t in self._builder_params()]
+        energy = energy.to(dtype) if energy.dtype != dtype else energy
+        _ops.require_device(energy, *tensors)
+        pshape = torch.broadcast_shapes(*[t.shape for t in tensors]) if tensors else ()
+        shape = torch.broadcast_shapes(pshape, energy.shape)
+        B = _ops.numel(shape)
+        if not tensors:
+            params = None
+        elif len(pshape) == 0:
+            params = torch.stack(tensors).reshape(1, -1)
+        else:
+            params = torch.stack([t.expand(shape) for t in tensors], dim=-1).reshape(B, len(tensors))
+        e = energy.reshape(1) if energy.dim() == 0 else energy.expand(shape).reshape(B)
+        R = _ops.build_rmatrix(kind, params, e, species.mass_eV_float, species.num_elementary_charges_float, B)
+        return R.reshape(*shape, 7, 7)
+
+    # ---- cache (utils/cache.py) -----------------------------------------------------------------
+    def _feature_key(self):
+        key = []
+        for name in self.defining_features:
+            f = getattr(self, name)
+            if isinstance(f, torch.Tensor):
+                key.append((id(f), f._version, f.requires_grad))
+            else:
+                key.append(f if not isinstance(f, (list, dict)) else repr(f))
+        return tuple(key)
+
+    def first_order_transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
+        if energy.requires_grad or species.mass_eV.requires_grad or species.num_elementary_charges.requires_grad:
+            return self._build_map(energy, species)
+        cache = self.__dict__.get("_map_cache")
+        fkey = self._feature_key()
+        if cache is not None and cache["fkey"] == fkey and cache["mass"] == species.mass_eV_float \
+                and cache["nq"] == species.num_elementary_charges_float:
+            ce = cache["energy_ref"]
+            if (ce is energy and cache["energy_version"] == energy._version) or (
+                ce.dtype == energy.dtype and ce.device == energy.device and ce.shape == energy.shape
+                and torch.equal(cache["energy_copy"], energy)
+            ):
+                return cache["result"]
+        result = self._build_map(energy, species)
+        self.__dict__["_map_cache"] = {
+            "fkey": fkey, "mass": species.mass_eV_float, "nq": species.num_elementary_charges_float,
+            "energy_ref": energy, "energy_version": energy._version, "energy_copy": energy.detach().clone(),
+            "result": result,
+        }
+        return result
+
+    # ---- tracking ---------------------------------------------------------------------------------
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        return self._track_first_order(incoming)
+
+    def _track_first_order(self, incoming: ParticleBeam) -> ParticleBeam:
+        if not isinstance(incoming, ParticleBeam):
+            raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+        tm = self.first_order_transfer_map(incoming.energy, incoming.species)
+        new_particles = _ops.apply_map(incoming.particles, tm)
+        return ParticleBeam(
+            new_particles,
+            incoming.energy,
+            particle_charges=incoming.particle_charges,
+            survival_probabilities=incoming.survival_probabilities,
+            s=incoming.s + self.length,
+            species=incoming.species,
+        )
+
+    def forward(self, incoming: ParticleBeam) -> ParticleBeam:
+        return self.track(incoming)
+
+    # ---- misc API -----------------------------------------------------------------------------------
+    @property
+    def tracking_method(self) -> str:
+        return self._tracking_method
+
+    @tracking_method.setter
+    def tracking_method(self, value: str) -> None:
+        if value in self.supported_tracking_methods:
+            self._tracking_method = value
+        else:
+            warnings.warn(
+                f"Invalid tracking method '{value}' for element {self.name} of type {self.__class__.__name__}, "
+                f"supported methods are {self.supported_tracking_methods}. Keeping the previous tracking method "
+                f"{self._tracking_method}.", PhysicsWarning, stacklevel=2)
+
+    @property
+    def is_skippable(self) -> bool:
+        raise NotImplementedError
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        if "_revision" in self.__dict__ and not name.startswith("_"):
+            self.__dict__["_revision"] += 1
+            self.__dict__["_map_cache"] = None
+        return super().__setattr__(name, value)
+
+    def register_buffer_or_parameter(self, name: str, value, persistent: bool = True) -> None:
+        if isinstance(value, nn.Parameter):
+            self.register_parameter(name, value)
+        else:
+            self.register_buffer(name, value, persistent)
+
+    @property
+    def defining_features(self) -> list[str]:
+        return ["name"] if len(self.supported_tracking_methods) == 1 else ["name", "tracking_method"]
+
+    @property
+    def defining_tensors(self) -> list[str]:
+        return [f for f in self.defining_features if isinstance(getattr(self, f), torch.Tensor)]
+
+    def clone(self) -> "Element":
+        return self.__class__(
+            **{f: (getattr(self, f).clone() if isinstance(getattr(self, f), torch.Tensor)
+                   else deepcopy(getattr(self, f))) for f in self.defining_features},
+            metadata=deepcopy(self.metadata), sanitize_name=False)
+
+    def split(self, resolution: torch.Tensor) -> list["Element"]:
+        return [self]
+
+    def __repr__(self) -> str:
+        feats = ", ".join(f"{f}={getattr(self, f)!r}" for f in self.defining_features)
+        return f"{self.__class__.__name__}({feats})"

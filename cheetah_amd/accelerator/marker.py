@@ -1,0 +1,85 @@
+"""Pass-through elements (mirror of cheetah/accelerator/marker.py:45-57, bpm.py:66-87,
+aperture.py:79-135): identity map, skippable unless active."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _ops
+from ..particles.particle_beam import ParticleBeam
+from .element import Element
+
+
+class Marker(Element):
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["identity"]
+
+    def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, device=device, dtype=dtype)
+
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        return incoming._view()
+
+    @property
+    def is_skippable(self) -> bool:
+        return True
+
+
+class BPM(Marker):
+    """Beam position monitor: reads (mu_x, mu_y) of the passing beam when active (bpm.py:77-87)."""
+
+    def __init__(self, is_active=False, name=None, sanitize_name=None, metadata=None, device=None, dtype=None):
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, device=device, dtype=dtype)
+        self.is_active = is_active
+        self.reading = None
+
+    @property
+    def is_skippable(self) -> bool:
+        return not self.is_active
+
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if self.is_active:
+            self.reading = torch.stack([incoming.mu_x, incoming.mu_y], dim=-1)  # one fused chx_moments call
+        return incoming._view()
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["is_active"]
+
+
+class Aperture(Marker):
+    """Aperture: when active, zeroes the survival probability of particles outside
+    (aperture.py:90-135). The mask is a per-particle elementwise torch op on the device."""
+
+    def __init__(self, x_max=None, y_max=None, shape="rectangular", is_active=True, name=None, sanitize_name=None,
+                 metadata=None, device=None, dtype=None):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        inf = lambda v: v if v is not None else torch.tensor(float("inf"), **fk)  # noqa: E731
+        self.register_buffer_or_parameter("x_max", inf(x_max))
+        self.register_buffer_or_parameter("y_max", inf(y_max))
+        self.shape = shape
+        self.is_active = is_active
+
+    @property
+    def is_skippable(self) -> bool:
+        return not self.is_active
+
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if not self.is_active:
+            return incoming._view()
+        x, y = incoming.particles[..., 0], incoming.particles[..., 2]
+        xm, ym = self.x_max.unsqueeze(-1), self.y_max.unsqueeze(-1)
+        if self.shape == "rectangular":
+            inside = (x.abs() <= xm) & (y.abs() <= ym)
+        elif self.shape == "elliptical":
+            inside = (x.square() / xm.square() + y.square() / ym.square()) <= 1.0
+        else:
+            raise ValueError(f"Invalid aperture shape {self.shape}")
+        return ParticleBeam(incoming.particles, incoming.energy, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities * inside, s=incoming.s,
+                            species=incoming.species)
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["x_max", "y_max", "shape", "is_active"]

@@ -1,0 +1,48 @@
+"""Quadrupole (mirror of cheetah/accelerator/quadrupole.py:52-110; linear tracking)."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _ops
+from .element import Element
+
+
+class Quadrupole(Element):
+    """Quadrupole magnet: R = R_exit @ base_rmatrix(L, k1, 0) @ R_entry (tilt + misalignment)."""
+
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["quadrupole"]
+
+    def __init__(self, length, k1=None, misalignment=None, tilt=None, num_steps=1, tracking_method="linear",
+                 name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        self.length = length
+        self.register_buffer_or_parameter("k1", k1 if k1 is not None else torch.tensor(0.0, **fk))
+        self.register_buffer_or_parameter(
+            "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+        self.register_buffer_or_parameter("tilt", tilt if tilt is not None else torch.tensor(0.0, **fk))
+        self.num_steps = num_steps
+        self.tracking_method = tracking_method
+
+    def _builder_params(self):
+        return [self.length, self.k1, self.tilt, self.misalignment[..., 0], self.misalignment[..., 1]]
+
+    @property
+    def is_skippable(self) -> bool:
+        return self.tracking_method == "linear"
+
+    @property
+    def is_active(self) -> bool:
+        return bool((self.k1 != 0).any().item())
+
+    def split(self, resolution):
+        n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
+        fk = {"dtype": self.length.dtype, "device": self.length.device}
+        return [Quadrupole(self.length / n, self.k1, misalignment=self.misalignment, tilt=self.tilt, **fk)
+                for _ in range(n)]
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length", "k1", "misalignment", "tilt", "num_steps"]

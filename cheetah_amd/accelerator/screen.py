@@ -1,0 +1,137 @@
+"""Screen (mirror of cheetah/accelerator/screen.py:63-357).
+
+`reading` is produced by HIP kernels reading x / y straight out of the 7-vector rows:
+`chx_hist2d` (torch.histogramdd semantics on `torch.linspace` edges) or `chx_cic_deposit`
+(2-D cloud-in-cell written directly in the transposed (H, W) layout). The screen misalignment is
+subtracted inside the kernels (screen.py:200-212) — no cloned, shifted copy of the beam is made
+unless the caller asks for the read beam.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _ops
+from ..particles.particle_beam import ParticleBeam
+from .element import Element
+
+
+class Screen(Element):
+    """Diagnostic screen."""
+
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["identity"]
+
+    def __init__(self, resolution=(1024, 1024), pixel_size=None, binning=1, misalignment=None,
+                 method="cloud-in-cell", kde_bandwidth=None, is_blocking=False, is_active=False, name=None,
+                 sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        if method not in ("histogram", "cloud-in-cell"):
+            raise ValueError(f"Screen method {method!r} is not provided by cheetah_amd "
+                             "(the dense 'kde' method is out of scope; use 'cloud-in-cell').")
+        self.register_buffer_or_parameter(
+            "pixel_size", pixel_size if pixel_size is not None else torch.tensor((1e-3, 1e-3), **fk))
+        self.register_buffer_or_parameter(
+            "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+        self.resolution = tuple(resolution)
+        self.binning = binning
+        self.method = method
+        self.is_blocking = is_blocking
+        self.is_active = is_active
+        self.__dict__["_read_beam"] = None
+        self.__dict__["_cached_reading"] = None
+
+    @property
+    def is_skippable(self) -> bool:
+        return not self.is_active
+
+    @property
+    def effective_resolution(self) -> tuple[int, int]:
+        return (self.resolution[0] // self.binning, self.resolution[1] // self.binning)
+
+    @property
+    def effective_pixel_size(self) -> torch.Tensor:
+        return self.pixel_size * self.binning
+
+    @property
+    def extent(self) -> torch.Tensor:
+        return torch.stack([
+            -self.resolution[0] * self.pixel_size[0] / 2, self.resolution[0] * self.pixel_size[0] / 2,
+            -self.resolution[1] * self.pixel_size[1] / 2, self.resolution[1] * self.pixel_size[1] / 2,
+        ])
+
+    @property
+    def pixel_bin_edges(self) -> tuple[torch.Tensor, torch.Tensor]:
+        fk = {"device": self.pixel_size.device, "dtype": self.pixel_size.dtype}
+        return (
+            torch.linspace(-self.resolution[0] * self.pixel_size[0] / 2, self.resolution[0] * self.pixel_size[0] / 2,
+                           int(self.effective_resolution[0]) + 1, **fk),
+            torch.linspace(-self.resolution[1] * self.pixel_size[1] / 2, self.resolution[1] * self.pixel_size[1] / 2,
+                           int(self.effective_resolution[1]) + 1, **fk),
+        )
+
+    @property
+    def pixel_bin_centers(self) -> tuple[torch.Tensor, torch.Tensor]:
+        ex, ey = self.pixel_bin_edges
+        return ((ex[1:] + ex[:-1]) / 2, (ey[1:] + ey[:-1]) / 2)
+
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if self.is_active:
+            # the unshifted beam is recorded; the misalignment is applied inside the image kernels and
+            # lazily in get_read_beam()
+            self.__dict__["_incoming"] = incoming
+            self.__dict__["_read_beam"] = None
+            self.__dict__["_cached_reading"] = None
+        if self.is_active and self.is_blocking:
+            return ParticleBeam(incoming.particles, incoming.energy, particle_charges=incoming.particle_charges,
+                                survival_probabilities=torch.zeros_like(incoming.survival_probabilities),
+                                s=incoming.s, species=incoming.species)
+        return incoming._view()
+
+    @property
+    def reading(self) -> torch.Tensor:
+        """Image of shape (…, height, width)."""
+        if self.__dict__.get("_cached_reading") is not None:
+            return self._cached_reading
+        beam = self.__dict__.get("_incoming")
+        w, h = self.effective_resolution
+        if beam is None:
+            image = self.misalignment.new_zeros((int(h), int(w)))
+        elif self.method == "histogram":
+            if beam.particles.dim() > 2 or beam.particle_charges.dim() > 1 or beam.energy.dim() > 0:
+                raise NotImplementedError("The 'histogram' method of Screen does not support vectorization. "
+                                          "Use 'cloud-in-cell' instead.")
+            ex, ey = self.pixel_bin_edges
+            image = _ops.hist2d(beam.particles, ex, ey, charge=beam.particle_charges,
+                                survival=beam.survival_probabilities, shift=self.misalignment)
+        else:
+            image = _ops.cic_deposit(beam.particles, (0, 2), (w, h), self.extent.reshape(2, 2),
+                                     charge=beam.particle_charges, survival=beam.survival_probabilities,
+                                     shift=self.misalignment, abs_charge=True, transpose_2d=True)
+        self.__dict__["_cached_reading"] = image
+        return image
+
+    def get_read_beam(self) -> ParticleBeam | None:
+        """The beam as seen by the screen, i.e. with x, y relative to the screen centre (screen.py:196-214)."""
+        if self.__dict__.get("_read_beam") is None and self.__dict__.get("_incoming") is not None:
+            inc = self.__dict__["_incoming"]
+            tm = torch.eye(7, dtype=inc.particles.dtype, device=inc.particles.device).repeat(
+                *self.misalignment.shape[:-1], 1, 1)
+            tm[..., 0, 6] = -self.misalignment[..., 0]
+            tm[..., 2, 6] = -self.misalignment[..., 1]
+            shifted = _ops.apply_map(inc.particles, tm)  # x -= mx, y -= my through the apply kernel
+            self.__dict__["_read_beam"] = ParticleBeam(
+                shifted, inc.energy, particle_charges=inc.particle_charges,
+                survival_probabilities=inc.survival_probabilities, s=inc.s, species=inc.species)
+        return self.__dict__.get("_read_beam")
+
+    def set_read_beam(self, value) -> None:
+        self.__dict__["_incoming"] = value
+        self.__dict__["_read_beam"] = value
+        self.__dict__["_cached_reading"] = None
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["resolution", "pixel_size", "binning", "misalignment", "method",
+                                            "is_blocking", "is_active"]

@@ -1,0 +1,327 @@
+"""ParticleBeam (mirror of cheetah/particles/particle_beam.py:60-106, :1262-1346, :1672-2001 and the
+derived optics of cheetah/particles/beam.py:323-556).
+
+State layout is the reference's: ``particles (…, N, 7)``, ``energy (…)``, ``particle_charges (…, N)``,
+``survival_probabilities (…, N)``, ``s``, ``species``. All beam moments come from ONE fused HIP
+reduction (`chx_moments`: 6 means + 21 covariances in two passes over the particle array) and are
+cached per (tensor identity, version); the reference re-reads a strided column 3-4 times for every
+single property.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .. import _ops
+from .species import Species
+
+_COORDS = ["x", "px", "y", "py", "tau", "p"]
+speed_of_light = 299792458.0
+
+
+def _tri(i: int, j: int) -> int:
+    if i > j:
+        i, j = j, i
+    return 8 + i * 6 - (i * (i - 1)) // 2 + (j - i)
+
+
+class ParticleBeam(nn.Module):
+    """Beam of macro-particles, each a 7-vector (x, px, y, py, tau, p, 1)."""
+
+    def __init__(self, particles, energy, particle_charges=None, survival_probabilities=None, s=None,
+                 species=None, device=None, dtype=None) -> None:
+        super().__init__()
+        assert particles.shape[-2] > 0 and particles.shape[-1] == 7, "Particle vectors must be 7-dimensional."
+        # NOTE: like the reference, device/dtype only apply to tensors created here
+        device = device if device is not None else particles.device
+        dtype = dtype if dtype is not None else particles.dtype
+        factory_kwargs = {"device": device, "dtype": dtype}
+        self.species = species if species is not None else Species("electron", **factory_kwargs)
+        self.register_buffer("particles", particles)
+        self.register_buffer("energy", energy)
+        self.register_buffer(
+            "particle_charges",
+            particle_charges if particle_charges is not None
+            else torch.full((particles.shape[-2],), self.species.num_elementary_charges_float * 1.602176634e-19,
+                            **factory_kwargs),
+        )
+        self.register_buffer(
+            "survival_probabilities",
+            survival_probabilities if survival_probabilities is not None
+            else torch.ones(particles.shape[-2], **factory_kwargs),
+        )
+        self.register_buffer("s", s if s is not None else torch.tensor(0.0, **factory_kwargs))
+
+    # ------------------------------------------------------------------ factories (input generation)
+    @classmethod
+    def from_distribution(cls, mu, cov, num_particles=100_000, energy=None, total_charge=None, s=None,
+                          species=None, device=None, dtype=None) -> "ParticleBeam":
+        """Random particles matched to (mu, cov) (particle_beam.py:355-432). Input factory: generated
+        with torch's RNG on `device`; not part of the tracking hot path."""
+        factory_kwargs = {"device": device, "dtype": dtype}
+        species = species.to(**factory_kwargs) if species is not None else Species("electron", **factory_kwargs)
+        energy = energy if energy is not None else torch.tensor(1e8, **factory_kwargs)
+        total_charge = total_charge if total_charge is not None else species.charge_coulomb * num_particles
+        particle_charges = (torch.ones((*total_charge.shape, num_particles), **factory_kwargs)
+                            * total_charge.unsqueeze(-1) / num_particles)
+        z = torch.randn(num_particles, 6, **factory_kwargs)
+        # whiten the sample, then colour it with chol(cov) and shift to mu (utils/statistics.py:91-143)
+        z = z - z.mean(dim=0, keepdim=True)
+        c = (z.mT @ z) / (num_particles - 1)
+        z = torch.linalg.solve_triangular(torch.linalg.cholesky(c), z.mT, upper=False).mT
+        chol = torch.linalg.cholesky(cov + torch.eye(6, **factory_kwargs) * torch.finfo(cov.dtype).tiny)
+        p6 = z @ chol.mT + mu.unsqueeze(-2)
+        p7 = torch.cat([p6, torch.ones_like(p6[..., :1])], dim=-1)
+        return cls(p7, energy, particle_charges=particle_charges, s=s, species=species, device=device, dtype=dtype)
+
+    @classmethod
+    def from_parameters(cls, num_particles=100_000, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None,
+                        mu_p=None, sigma_x=None, sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None,
+                        sigma_p=None, cov_xpx=None, cov_ypy=None, cov_taup=None, cov_xp=None, cov_pxp=None,
+                        cov_yp=None, cov_pyp=None, energy=None, total_charge=None, s=None, species=None,
+                        device=None, dtype=None) -> "ParticleBeam":
+        """Gaussian beam from moments; defaults as particle_beam.py:193-216."""
+        fk = {"device": device, "dtype": dtype}
+        d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
+        mus = torch.broadcast_tensors(d(mu_x, 0.0), d(mu_px, 0.0), d(mu_y, 0.0), d(mu_py, 0.0), d(mu_tau, 0.0),
+                                      d(mu_p, 0.0))
+        mean = torch.stack(mus, dim=-1)
+        (sx, spx, sy, spy, st, sp, cxpx, cypy, ctp, cxp, cpxp, cyp, cpyp) = torch.broadcast_tensors(
+            d(sigma_x, 175e-6), d(sigma_px, 4e-6), d(sigma_y, 175e-6), d(sigma_py, 4e-6), d(sigma_tau, 8e-6),
+            d(sigma_p, 2e-3), d(cov_xpx, 0.0), d(cov_ypy, 0.0), d(cov_taup, 0.0), d(cov_xp, 0.0), d(cov_pxp, 0.0),
+            d(cov_yp, 0.0), d(cov_pyp, 0.0))
+        cov = torch.zeros(*sx.shape, 6, 6, **fk)
+        for i, sg in enumerate((sx, spx, sy, spy, st, sp)):
+            cov[..., i, i] = sg.square()
+        for (i, j, c) in ((0, 1, cxpx), (2, 3, cypy), (4, 5, ctp), (0, 5, cxp), (1, 5, cpxp), (2, 5, cyp), (3, 5, cpyp)):
+            cov[..., i, j] = c
+            cov[..., j, i] = c
+        return cls.from_distribution(mean, cov, num_particles=num_particles, energy=energy,
+                                     total_charge=total_charge, s=s, species=species, device=device, dtype=dtype)
+
+    @classmethod
+    def from_twiss(cls, num_particles=100_000, beta_x=None, alpha_x=None, emittance_x=None, beta_y=None,
+                   alpha_y=None, emittance_y=None, energy=None, sigma_tau=None, sigma_p=None, cov_taup=None,
+                   total_charge=None, s=None, species=None, device=None, dtype=None) -> "ParticleBeam":
+        """particle_beam.py:434-560 (without dispersion arguments)."""
+        fk = {"device": device, "dtype": dtype}
+        d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
+        beta_x, alpha_x, emittance_x = d(beta_x, 0.0), d(alpha_x, 0.0), d(emittance_x, 7.1971891e-13)
+        beta_y, alpha_y, emittance_y = d(beta_y, 0.0), d(alpha_y, 0.0), d(emittance_y, 7.1971891e-13)
+        return cls.from_parameters(
+            num_particles=num_particles,
+            sigma_x=(beta_x * emittance_x).sqrt(), sigma_px=(emittance_x * (1 + alpha_x.square()) / beta_x).sqrt(),
+            sigma_y=(beta_y * emittance_y).sqrt(), sigma_py=(emittance_y * (1 + alpha_y.square()) / beta_y).sqrt(),
+            sigma_tau=d(sigma_tau, 1e-6), sigma_p=d(sigma_p, 1e-6), cov_xpx=-emittance_x * alpha_x,
+            cov_ypy=-emittance_y * alpha_y, cov_taup=d(cov_taup, 0.0), energy=d(energy, 1e8),
+            total_charge=total_charge, s=s, species=species, device=device, dtype=dtype)
+
+    @classmethod
+    def uniform_3d_ellipsoid(cls, num_particles=100_000, radius_x=None, radius_y=None, radius_tau=None,
+                             sigma_px=None, sigma_py=None, sigma_p=None, energy=None, total_charge=None, s=None,
+                             species=None, device=None, dtype=None) -> "ParticleBeam":
+        """Water-bag ellipsoid (particle_beam.py:562-662)."""
+        fk = {"device": device, "dtype": dtype}
+        d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
+        radius_x, radius_y, radius_tau = d(radius_x, 1e-3), d(radius_y, 1e-3), d(radius_tau, 1e-3)
+        beam = cls.from_parameters(num_particles=num_particles, sigma_x=radius_x, sigma_px=sigma_px,
+                                   sigma_y=radius_y, sigma_py=sigma_py, sigma_tau=radius_tau, sigma_p=sigma_p,
+                                   energy=energy, total_charge=total_charge, s=s, species=species, device=device,
+                                   dtype=dtype)
+        vs = beam.particles.shape[:-2]
+        r = torch.rand(*vs, num_particles, **fk).pow(1 / 3)
+        theta = (2 * torch.rand(*vs, num_particles, **fk) - 1).arccos()
+        phi = torch.rand(*vs, num_particles, **fk) * 2 * math.pi
+        parts = beam.particles.clone()
+        parts[..., 0] = r * theta.sin() * phi.cos() * radius_x.unsqueeze(-1)
+        parts[..., 2] = r * theta.sin() * phi.sin() * radius_y.unsqueeze(-1)
+        parts[..., 4] = r * theta.cos() * radius_tau.unsqueeze(-1)
+        beam.particles = parts
+        return beam
+
+    # ------------------------------------------------------------------ SI conversion (HIP)
+    def to_xyz_pxpypz(self) -> torch.Tensor:
+        """(x, Px, y, Py, z, Pz, 1) in SI units (particle_beam.py:1316-1346) via `chx_to_xyz_pxpypz`."""
+        return _ops.to_xyz_pxpypz(self.particles, self.energy, self.species.mass_eV_float)
+
+    @classmethod
+    def from_xyz_pxpypz(cls, xp_coordinates, energy, particle_charges=None, survival_probabilities=None, s=None,
+                        species=None, device=None, dtype=None) -> "ParticleBeam":
+        """particle_beam.py:1262-1314 via `chx_from_xyz_pxpypz`."""
+        sp = species if species is not None else Species("electron", device=xp_coordinates.device,
+                                                         dtype=xp_coordinates.dtype)
+        parts = _ops.from_xyz_pxpypz(xp_coordinates, energy, sp.mass_eV_float)
+        return cls(parts, energy, particle_charges=particle_charges, survival_probabilities=survival_probabilities,
+                   s=s, species=sp, device=device, dtype=dtype)
+
+    # ------------------------------------------------------------------ moments (HIP, cached)
+    def _moments(self) -> torch.Tensor:
+        p, w = self.particles, self.survival_probabilities
+        key = (id(p), p._version, id(w), w._version)
+        cached = self.__dict__.get("_moment_cache")
+        if cached is not None and cached[0] == key and not p.requires_grad:
+            return cached[1]
+        out = _ops.moments(p, w)
+        self.__dict__["_moment_cache"] = (key, out)
+        return out
+
+    def _mu(self, i: int) -> torch.Tensor:
+        return self._moments()[..., 2 + i].to(self.particles.dtype)
+
+    def _cov(self, i: int, j: int) -> torch.Tensor:
+        return self._moments()[..., _tri(i, j)].to(self.particles.dtype)
+
+    def _sigma(self, i: int) -> torch.Tensor:
+        return self._moments()[..., _tri(i, i)].sqrt().to(self.particles.dtype)
+
+    @property
+    def total_charge(self) -> torch.Tensor:
+        return (self.particle_charges * self.survival_probabilities).sum(dim=-1)
+
+    @property
+    def num_particles(self) -> int:
+        return self.particles.shape[-2]
+
+    def __len__(self) -> int:
+        return int(self.num_particles)
+
+    @property
+    def num_particles_survived(self) -> torch.Tensor:
+        return self.survival_probabilities.sum(dim=-1)
+
+    # reference frame (beam.py:323-341)
+    @property
+    def relativistic_gamma(self) -> torch.Tensor:
+        return self.energy / self.species.mass_eV
+
+    @property
+    def relativistic_beta(self) -> torch.Tensor:
+        g = self.relativistic_gamma
+        return torch.where(g.abs() > 0, (1 - g.square().reciprocal()).clamp_min(0).sqrt(), torch.ones_like(g))
+
+    @property
+    def p0c(self) -> torch.Tensor:
+        return self.relativistic_beta * self.relativistic_gamma * self.species.mass_eV
+
+    @property
+    def energies(self) -> torch.Tensor:
+        return self.p * self.p0c.unsqueeze(-1) + self.energy.unsqueeze(-1)
+
+    @property
+    def momenta(self) -> torch.Tensor:
+        return (self.energies.square() - self.species.mass_eV.square()).sqrt()
+
+    # derived optics (beam.py:431-556)
+    @property
+    def emittance_x(self) -> torch.Tensor:
+        sp2 = self.sigma_p.square()
+        v = ((self.sigma_x.square() - self.cov_xp.square() / sp2) * (self.sigma_px.square() - self.cov_pxp.square() / sp2)
+             - (self.cov_xpx - self.cov_xp * self.cov_pxp / sp2).square())
+        return v.clamp_min(torch.finfo(v.dtype).tiny).sqrt()
+
+    @property
+    def emittance_y(self) -> torch.Tensor:
+        sp2 = self.sigma_p.square()
+        v = ((self.sigma_y.square() - self.cov_yp.square() / sp2) * (self.sigma_py.square() - self.cov_pyp.square() / sp2)
+             - (self.cov_ypy - self.cov_yp * self.cov_pyp / sp2).square())
+        return v.clamp_min(torch.finfo(v.dtype).tiny).sqrt()
+
+    @property
+    def normalized_emittance_x(self) -> torch.Tensor:
+        return self.emittance_x * self.relativistic_beta * self.relativistic_gamma
+
+    @property
+    def normalized_emittance_y(self) -> torch.Tensor:
+        return self.emittance_y * self.relativistic_beta * self.relativistic_gamma
+
+    @property
+    def projected_emittance_x(self) -> torch.Tensor:
+        return (self.sigma_x.square() * self.sigma_px.square() - self.cov_xpx.square()).sqrt()
+
+    @property
+    def projected_emittance_y(self) -> torch.Tensor:
+        return (self.sigma_y.square() * self.sigma_py.square() - self.cov_ypy.square()).sqrt()
+
+    @property
+    def beta_x(self) -> torch.Tensor:
+        return (self.sigma_x.square() - self.cov_xp.square() / self.sigma_p.square()) / self.emittance_x
+
+    @property
+    def beta_y(self) -> torch.Tensor:
+        return (self.sigma_y.square() - self.cov_yp.square() / self.sigma_p.square()) / self.emittance_y
+
+    @property
+    def alpha_x(self) -> torch.Tensor:
+        return -(self.cov_xpx - self.cov_xp * self.cov_pxp / self.sigma_p.square()) / self.emittance_x
+
+    @property
+    def alpha_y(self) -> torch.Tensor:
+        return -(self.cov_ypy - self.cov_yp * self.cov_pyp / self.sigma_p.square()) / self.emittance_y
+
+    @property
+    def dispersion_x(self) -> torch.Tensor:
+        return self.cov_xp / self.sigma_p.square()
+
+    @property
+    def dispersion_px(self) -> torch.Tensor:
+        return self.cov_pxp / self.sigma_p.square()
+
+    @property
+    def dispersion_y(self) -> torch.Tensor:
+        return self.cov_yp / self.sigma_p.square()
+
+    @property
+    def dispersion_py(self) -> torch.Tensor:
+        return self.cov_pyp / self.sigma_p.square()
+
+    # ------------------------------------------------------------------ housekeeping
+    def clone(self) -> "ParticleBeam":
+        return self.__class__(particles=self.particles.clone(), energy=self.energy.clone(),
+                              particle_charges=self.particle_charges.clone(),
+                              survival_probabilities=self.survival_probabilities.clone(), s=self.s.clone(),
+                              species=self.species.clone())
+
+    def _view(self) -> "ParticleBeam":
+        """New beam object sharing this beam's tensors (zero-copy). Pass-through elements return this
+        instead of the reference's deep `clone()` (marker.py:52-53): beams are treated as immutable
+        values on the tracking path, so no 56-byte-per-particle copy is made for an identity map."""
+        return self.__class__(particles=self.particles, energy=self.energy, particle_charges=self.particle_charges,
+                              survival_probabilities=self.survival_probabilities, s=self.s, species=self.species)
+
+    def __getitem__(self, item) -> "ParticleBeam":
+        vs = torch.broadcast_shapes(self.particles.shape[:-2], self.energy.shape, self.particle_charges.shape[:-1],
+                                    self.survival_probabilities.shape[:-1])
+        n = self.num_particles
+        return self.__class__(
+            particles=torch.broadcast_to(self.particles, (*vs, n, 7))[item],
+            energy=torch.broadcast_to(self.energy, vs)[item],
+            particle_charges=torch.broadcast_to(self.particle_charges, (*vs, n))[item],
+            survival_probabilities=torch.broadcast_to(self.survival_probabilities, (*vs, n))[item],
+            species=self.species)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(particles={self.particles}, energy={self.energy}, "
+                f"particle_charges={self.particle_charges}, "
+                f"survival_probabilities={self.survival_probabilities}, s={self.s}, species={self.species!r})")
+
+
+def _install_coordinate_properties() -> None:
+    for i, name in enumerate(_COORDS):
+        def getter(self, i=i):
+            return self.particles[..., i]
+
+        def setter(self, value, i=i):
+            self.particles[..., i] = value
+
+        setattr(ParticleBeam, name, property(getter, setter))
+        setattr(ParticleBeam, f"mu_{name}", property(lambda self, i=i: self._mu(i)))
+        setattr(ParticleBeam, f"sigma_{name}", property(lambda self, i=i: self._sigma(i)))
+    for i in range(6):
+        for j in range(i + 1, 6):
+            setattr(ParticleBeam, f"cov_{_COORDS[i]}{_COORDS[j]}", property(lambda self, i=i, j=j: self._cov(i, j)))
+
+
+_install_coordinate_properties()

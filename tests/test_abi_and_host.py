@@ -1,0 +1,136 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol include/chx.h declares;
+host-side logic (segment partitioning, caches, broadcasting helpers, fail-loud behaviour)."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "chx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    import cheetah_amd._lib as L
+
+    lib = L.lib()  # raises if libchx.so is missing or a declared symbol cannot be bound
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (chx_[a-z0-9_]+)", out))
+    assert set(syms) <= exported, sorted(set(syms) - exported)
+    assert set(syms) == set(L.SIGNATURES), (sorted(set(syms) ^ set(L.SIGNATURES)))
+    assert lib.chx_abi_version() == 1
+    assert lib.chx_kind_num_params(2) == 5 and lib.chx_kind_num_params(3) == 9 and lib.chx_kind_num_params(99) == -1
+    assert lib.chx_status_string(-3) == b"misaligned buffer"
+    # pure host-side queries (no device needed)
+    assert lib.chx_moments_workspace_bytes(1, 1_000_000) > 0
+    assert lib.chx_apply_bwd_workspace_bytes(4, 1000) > 0
+
+
+def test_library_targets_gfx950_only():
+    import cheetah_amd._lib as L
+
+    blob = open(L.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_product_has_no_cpu_fallback():
+    """Tracking a CPU beam must fail loudly instead of silently running elsewhere."""
+    import cheetah_amd as ca
+
+    seg = ca.Segment([ca.Drift(torch.tensor(1.0)), ca.Quadrupole(torch.tensor(0.2), k1=torch.tensor(4.2))])
+    beam = ca.ParticleBeam.from_parameters(num_particles=100)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        seg.track(beam)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        _ = beam.sigma_x
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cheetah_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("chx_oracle", "oracle") or f == "__none__", (dirpath, f)
+
+
+def test_segment_partitioning_and_names():
+    import cheetah_amd as ca
+
+    t = torch.tensor
+    seg = ca.Segment([
+        ca.Drift(t(1.0)), ca.Quadrupole(t(0.2), k1=t(1.0), name="q"), ca.Cavity(t(1.0), voltage=t(1e6), name="cav"),
+        ca.Drift(t(0.5), name="d"), ca.Screen(is_active=True, name="scr"), ca.Drift(t(0.5), name="d"), ca.Marker(name="m"),
+    ])
+    assert not seg.is_skippable
+    assert seg.q.k1.item() == 1.0
+    assert isinstance(seg.d, list) and len(seg.d) == 2
+    assert seg.cav.is_active and not seg.cav.is_skippable
+    assert seg.scr.is_active and not seg.scr.is_skippable
+    seg.scr.is_active = False
+    assert seg.scr.is_skippable
+    seg.cav.voltage = t(0.0)
+    assert seg.cav.is_skippable and seg.is_skippable
+    assert float(seg.length) == pytest.approx(3.2)
+    assert ca.Segment([ca.Drift(t(1.0))]).first_order_transfer_map is not None
+
+
+def test_revision_and_feature_keys_track_changes():
+    import cheetah_amd as ca
+
+    q = ca.Quadrupole(torch.tensor(0.2), k1=torch.tensor(4.2))
+    r0, k0 = q.__dict__["_revision"], q._feature_key()
+    q.k1 = torch.tensor(1.0)
+    assert q.__dict__["_revision"] > r0 and q._feature_key() != k0
+    k1 = q._feature_key()
+    q.k1.add_(1.0)
+    assert q._feature_key() != k1
+    q.k1 = torch.nn.Parameter(torch.tensor(2.0))
+    assert any(f[2] for f in q._feature_key() if isinstance(f, tuple))
+    assert [n for n, _ in q.named_parameters()] == ["k1"]
+
+
+def test_flat_bcast_helper():
+    from cheetah_amd import _ops
+
+    x = torch.zeros(5, 7)
+    f, B = _ops.flat_bcast(x, (3, 2), 2)
+    assert f.shape == (1, 5, 7) and B == 1
+    x = torch.zeros(3, 2, 5, 7)
+    f, B = _ops.flat_bcast(x, (3, 2), 2)
+    assert f.shape == (6, 5, 7) and B == 6
+    x = torch.zeros(3, 1, 5, 7)
+    f, B = _ops.flat_bcast(x, (3, 2), 2)
+    assert f.shape == (6, 5, 7) and B == 6
+    assert _ops.dtype_code(torch.float32) == 0 and _ops.dtype_code(torch.float64) == 1
+    with pytest.raises(TypeError):
+        _ops.dtype_code(torch.float16)
+
+
+def test_beam_factories_shapes_and_defaults():
+    import cheetah_amd as ca
+
+    torch.manual_seed(0)
+    b = ca.ParticleBeam.from_parameters(num_particles=20000)
+    assert b.particles.shape == (20000, 7) and torch.all(b.particles[:, 6] == 1)
+    s = b.particles[:, :6].std(dim=0)
+    assert torch.allclose(s, torch.tensor([175e-6, 4e-6, 175e-6, 4e-6, 8e-6, 2e-3]), rtol=1e-3)
+    assert float(b.energy) == 1e8 and b.particle_charges.shape == (20000,)
+    b = ca.ParticleBeam.from_twiss(beta_x=torch.tensor(3.14), beta_y=torch.tensor(42.0), num_particles=5000)
+    sx = (3.14 * 7.1971891e-13) ** 0.5
+    assert float(b.particles[:, 0].std()) == pytest.approx(sx, rel=1e-3)
+    b = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=5000, radius_x=torch.tensor(1e-3),
+                                             radius_y=torch.tensor(2e-3), radius_tau=torch.tensor(1e-4))
+    r2 = (b.particles[:, 0] / 1e-3) ** 2 + (b.particles[:, 2] / 2e-3) ** 2 + (b.particles[:, 4] / 1e-4) ** 2
+    assert float(r2.max()) <= 1.0 + 1e-5
+    sp = ca.Species("proton")
+    assert sp.mass_eV_float == pytest.approx(938272089.43) and sp.num_elementary_charges_float == 1.0

@@ -1,0 +1,592 @@
+"""Parity of the HIP path (through the C-ABI, via cheetah_amd) against the CPU oracle and the golden
+vectors generated from the reference.  Every test needs a real MI355X: run with `-m gpu`.
+
+Tolerances (stated per test):
+ * integer / index results (CIC cell indices, histogram pixel indices): bit-exact;
+ * fp32 / fp64 linear apply: bit-exact against the oracle's fma-chain restatement, and within
+   4 ulp of the row scale against the fp64-accumulated truth;
+ * transfer maps: 1e-12 (fp64), 2e-6 (fp32) relative to max(|entry|, 1e-3 max|R|);
+ * images / grids (float atomics, order dependent): rtol 1e-5 fp32, 1e-11 fp64.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    import cheetah_amd
+
+    cheetah_amd._lib.lib()  # fail loudly if libchx.so is missing
+    return cheetah_amd
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def tdt(tag):
+    return torch.float64 if tag == "f64" else torch.float32
+
+
+def ndt(tag):
+    return np.float64 if tag == "f64" else np.float32
+
+
+def relmax(a, b, axis=None):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+# ------------------------------------------------------------------------------------------------ apply
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("N", [1, 3, 255, 256, 257, 511, 512, 513, 1000, 4097, 100003])
+def test_apply_bit_exact_vs_oracle(ca, oracle, tag, N):
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((1, N, 7)).astype(ndt(tag)) * 1e-3
+    x[..., 6] = 1.0
+    R = rng.standard_normal((1, 7, 7)).astype(ndt(tag))
+    R[:, 6, :] = 0
+    R[:, 6, 6] = 1
+    out = _ops.apply_map(dev(x), dev(R)).cpu().numpy()
+    exact = oracle.apply(x, R, mode=1)
+    assert np.array_equal(out, exact)
+    truth = oracle.apply(x.astype(np.float64), R.astype(np.float64), mode=0)
+    eps = np.finfo(ndt(tag)).eps
+    scale = np.max(np.abs(truth), axis=(0, 1), keepdims=True)
+    assert np.max(np.abs(out - truth) / scale) < 8 * eps
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("shape", [((4,), (4,)), ((), (5,)), ((3,), ()), ((2, 3), (3,)), ((1,), (6,))])
+@pytest.mark.parametrize("N", [1001, 2048])
+def test_apply_broadcast_shapes(ca, oracle, tag, shape, N):
+    from cheetah_amd import _ops
+
+    xs, rs = shape
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((*xs, N, 7)).astype(ndt(tag))
+    R = rng.standard_normal((*rs, 7, 7)).astype(ndt(tag))
+    out = _ops.apply_map(dev(x), dev(R))
+    bshape = np.broadcast_shapes(xs, rs)
+    assert tuple(out.shape) == (*bshape, N, 7)
+    xb = np.broadcast_to(x, (*bshape, N, 7)).reshape(-1, N, 7)
+    Rb = np.broadcast_to(R, (*bshape, 7, 7)).reshape(-1, 7, 7)
+    exact = oracle.apply(np.ascontiguousarray(xb), np.ascontiguousarray(Rb), mode=1).reshape(*bshape, N, 7)
+    assert np.array_equal(out.cpu().numpy(), exact)
+
+
+def test_apply_rejects_cpu_tensors(ca):
+    from cheetah_amd import _ops
+
+    with pytest.raises(RuntimeError, match="GPU only"):
+        _ops.apply_map(torch.zeros(4, 7), torch.eye(7))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_elementwise_and_fused_agree_bitwise(ca, oracle, tag):
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(3)
+    N, E = 5000, 17
+    x = (rng.standard_normal((N, 7)) * 1e-3).astype(ndt(tag))
+    x[:, 6] = 1
+    maps = np.tile(np.eye(7), (E, 1, 1, 1)).astype(ndt(tag))
+    maps[:, 0, :6, :6] += (rng.standard_normal((E, 6, 6)) * 0.1).astype(ndt(tag))
+    a = _ops.track_elementwise(dev(x), dev(maps), fused=False).cpu().numpy()
+    b = _ops.track_elementwise(dev(x), dev(maps), fused=True).cpu().numpy()
+    assert np.array_equal(a, b)
+    y = x[None]
+    for e in range(E):
+        y = oracle.apply(y, maps[e], mode=1)
+    assert np.array_equal(a, y[0])
+
+
+# ------------------------------------------------------------------------------------------------ maps
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_map_builders_vs_reference_goldens(ca, golden, tag):
+    from cheetah_amd import _ops
+
+    g = golden("maps.npz")
+    n = int(g["n_cases"])
+    tol = 1e-12 if tag == "f64" else 2e-6
+    worst = 0.0
+    for i in range(n):
+        kind = _ops.KIND[str(g[f"kind_{i}"])]
+        mass, nq = g[f"species_{i}"]
+        P = _ops.NUM_PARAMS[kind]
+        params = g[f"params_{i}"].reshape(-1, P) if P else None
+        energy = g[f"energy_{i}"].reshape(-1)
+        Rref = g[f"R_{i}"].reshape(-1, 7, 7)
+        B = Rref.shape[0]
+        R = _ops.build_rmatrix(kind, None if params is None else dev(params, tdt(tag)), dev(energy, tdt(tag)),
+                               float(mass), float(nq), B).cpu().numpy()
+        denom = np.maximum(np.abs(Rref), 1e-3 * np.max(np.abs(Rref)))
+        err = np.max(np.abs(R - Rref) / denom)
+        worst = max(worst, err)
+        # fp32: the reference value is for fp64 inputs; inputs rounded to fp32 move entries by ~1e-7
+        assert err < (tol if tag == "f64" else 5e-5), (i, str(g[f"kind_{i}"]), err)
+    print("worst", tag, worst)
+
+
+def test_map_builder_fp32_equals_fp64_of_rounded_inputs(ca, oracle):
+    """fp32 maps are computed in fp64 on device from the fp32 parameters and rounded once."""
+    from cheetah_amd import _ops
+
+    p = np.array([[0.2, 4.2, 0.3, 1e-3, -2e-3]], dtype=np.float32)
+    e = np.array([1e8], dtype=np.float32)
+    R32 = _ops.build_rmatrix(_ops.KIND["quadrupole"], dev(p), dev(e), oracle.ELECTRON_MASS_EV, -1.0, 1).cpu().numpy()
+    Ro = oracle.build_rmatrix("quadrupole", p.astype(np.float64), e.astype(np.float64))
+    assert np.max(np.abs(R32 - Ro.astype(np.float32))) <= 2 * np.finfo(np.float32).eps * np.max(np.abs(Ro))
+
+
+def test_compose_vs_oracle(ca, oracle):
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(5)
+    for E, B in ((1, 1), (3, 1), (100, 1), (13, 7), (250, 3)):
+        maps = [np.eye(7) + 0.05 * rng.standard_normal((B if e % 3 == 0 else 1, 7, 7)) for e in range(E)]
+        ref = oracle.compose(maps)
+        tm = _ops.compose_maps([dev(m) for m in maps], (B,), torch.float64, "cuda").cpu().numpy()
+        assert relmax(tm, ref) < 1e-13, (E, B)
+
+
+# ------------------------------------------------------------------------------------------------ API level
+def _incoming(ca, g, dtype):
+    sp = ca.Species("electron", dtype=dtype, device="cuda")
+    return ca.ParticleBeam(dev(g["incoming_particles_f32"], dtype), dev(g["incoming_energy"], dtype),
+                           particle_charges=dev(g["incoming_charges_f32"], dtype),
+                           survival_probabilities=dev(g["incoming_survival_f32"], dtype), species=sp)
+
+
+def _t(v, dtype=torch.float64):
+    # reference tests create fp32 tensors and then call .to(float64)
+    return torch.tensor(v, dtype=torch.float32).to(dtype).cuda()
+
+
+def test_reference_consistency_goldens(ca, golden):
+    """tests/test_elements.py:356-431 of the reference, re-run against cheetah_amd (fp64)."""
+    g = golden("consistency.npz")
+    keep = int(g["keep"])
+    f64 = torch.float64
+    elements = {
+        "Drift_ParticleBeam_linear": ca.Drift(length=_t([1.0, -1.0])),
+        "Quadrupole_ParticleBeam_linear": ca.Quadrupole(length=_t(1.0), k1=_t([1.0, -2.0]), tilt=_t(0.42),
+                                                        misalignment=_t([0.01, -0.02])),
+        "Dipole_ParticleBeam_linear": ca.Dipole(length=_t(1.0), angle=_t([1.0, -2.0]), tilt=_t(0.42), dtype=f64,
+                                                device="cuda"),
+        "RBend_ParticleBeam_linear": ca.RBend(length=_t(1.0), angle=_t([1.0, -2.0]), tilt=_t(0.42), dtype=f64,
+                                              device="cuda"),
+        "HorizontalCorrector_ParticleBeam_default": ca.HorizontalCorrector(length=_t(1.0), angle=_t([1.0, -2.0])),
+        "VerticalCorrector_ParticleBeam_default": ca.VerticalCorrector(length=_t(1.0), angle=_t([1.0, -2.0])),
+        "CombinedCorrector_ParticleBeam_default": ca.CombinedCorrector(length=_t(1.0), horizontal_angle=_t([1.0, -2.0]),
+                                                                       vertical_angle=_t([1.0, -2.0])),
+        "Cavity_ParticleBeam_default": ca.Cavity(length=_t(1.0), dtype=f64, device="cuda"),
+        "CustomTransferMap_ParticleBeam_identity": ca.CustomTransferMap(torch.eye(7, dtype=f64, device="cuda")),
+        "Marker_ParticleBeam_default": ca.Marker(dtype=f64, device="cuda"),
+        "Screen_ParticleBeam_default": ca.Screen(dtype=f64, device="cuda"),
+        "Segment_ParticleBeam_default": ca.Segment([ca.Drift(length=_t(1.0))]),
+        "BPM_ParticleBeam_inactive": ca.BPM(is_active=False, dtype=f64, device="cuda"),
+        "Aperture_ParticleBeam_inactive": ca.Aperture(is_active=False, dtype=f64, device="cuda"),
+    }
+    for name, element in elements.items():
+        beam = _incoming(ca, g, f64)
+        out = element.track(beam)
+        exp = g[f"{name}__particles"]
+        got = out.particles.cpu().numpy()[..., :keep, :]
+        assert got.shape == exp.shape, name
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8), name  # the reference's own tolerance
+        assert relmax(got, exp) < 1e-12, (name, relmax(got, exp))   # ours
+        assert np.allclose(out.energy.cpu().numpy(), g[f"{name}__energy"]), name
+        assert np.allclose(out.s.cpu().numpy(), g[f"{name}__s"]), name
+        # inputs are never mutated
+        assert np.array_equal(beam.particles.cpu().numpy(), g["incoming_particles_f32"].astype(np.float64))
+
+
+def _readme_segment(ca, dtype):
+    t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+    kw = {"dtype": dtype, "device": "cuda"}
+    seg = ca.Segment([
+        ca.Drift(length=t(0.175)), ca.Quadrupole(length=t(0.122), name="AREAMQZM1", **kw), ca.Drift(length=t(0.428)),
+        ca.Quadrupole(length=t(0.122), name="AREAMQZM2", **kw), ca.Drift(length=t(0.204)),
+        ca.VerticalCorrector(length=t(0.02), name="AREAMCVM1", **kw), ca.Drift(length=t(0.204)),
+        ca.Quadrupole(length=t(0.122), name="AREAMQZM3", **kw), ca.Drift(length=t(0.179)),
+        ca.HorizontalCorrector(length=t(0.02), name="AREAMCHM1", **kw), ca.Drift(length=t(0.45)),
+        ca.Screen(name="AREABSCR1", **kw),
+    ])
+    seg.AREAMQZM1.k1 = t(8.2)
+    seg.AREAMQZM2.k1 = t(-14.3)
+    seg.AREAMCVM1.angle = t(9e-5)
+    seg.AREAMQZM3.k1 = t(3.142)
+    seg.AREAMCHM1.angle = t(-1e-4)
+    return seg
+
+
+def test_c1_readme_segment(ca, golden):
+    g = golden("segment_readme.npz")
+    f64 = torch.float64
+    seg = _readme_segment(ca, f64)
+    beam = ca.ParticleBeam(dev(g["in_particles"]), dev(g["energy"]), particle_charges=dev(g["charges"]),
+                           survival_probabilities=dev(g["survival"]),
+                           species=ca.Species("electron", dtype=f64, device="cuda"))
+    # inactive screen: whole segment merges into one map
+    R = seg.first_order_transfer_map(beam.energy, beam.species)
+    assert relmax(R.cpu().numpy(), g["R_merged"]) < 1e-13
+    seg.AREABSCR1.is_active = True
+    seg.AREABSCR1.pixel_size = torch.tensor([1e-5, 1e-5], dtype=f64, device="cuda")
+    seg.AREABSCR1.resolution = (512, 256)
+    out = seg.track(beam)
+    assert relmax(out.particles.cpu().numpy(), g["out_particles"]) < 1e-12
+    assert np.allclose(out.s.cpu().numpy(), g["out_s"])
+    for n in ["mu_x", "mu_px", "mu_y", "mu_py", "mu_tau", "mu_p", "sigma_x", "sigma_px", "sigma_y", "sigma_py",
+              "sigma_tau", "sigma_p", "cov_xpx", "cov_ypy", "cov_taup", "total_charge"]:
+        got, exp = float(getattr(out, n)), float(g["mom_" + n])
+        if n.startswith("mu_"):
+            assert abs(got - exp) < 1e-10 * float(g["mom_sigma_" + n[3:]]), n
+        else:
+            assert got == pytest.approx(exp, rel=1e-9), n
+    img = seg.AREABSCR1.reading.cpu().numpy()
+    ref = np.zeros(tuple(g["img_shape"]))
+    ref[g["img_idx"][:, 0], g["img_idx"][:, 1]] = g["img_val"]
+    assert img.shape == ref.shape
+    assert np.array_equal(img != 0, ref != 0)
+    assert np.allclose(img, ref, rtol=1e-11, atol=0)
+
+
+def _fodo(ca, dtype, cells=25):
+    t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+    kw = {"dtype": dtype, "device": "cuda"}
+    els = []
+    for _ in range(cells):
+        els += [ca.Quadrupole(length=t(0.2), k1=t(4.2), **kw), ca.Drift(length=t(0.8)),
+                ca.Quadrupole(length=t(0.2), k1=t(-4.2), **kw), ca.Drift(length=t(0.8))]
+    return ca.Segment(els)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_c2_fodo100(ca, golden, tag):
+    g = golden("fodo100.npz")
+    dt = tdt(tag)
+    seg = _fodo(ca, dt)
+    mass, nq = g[f"species_{tag}"]
+    sp = ca.Species("custom_electron", num_elementary_charges=torch.tensor(nq, dtype=dt, device="cuda"),
+                    mass_eV=torch.tensor(mass, dtype=torch.float64, device="cuda"))
+    beam = ca.ParticleBeam(dev(g[f"in_{tag}"]), dev(g[f"energy_{tag}"]), species=sp)
+    R = seg.first_order_transfer_map(beam.energy, beam.species).cpu().numpy()
+    assert relmax(R, g[f"R_{tag}"]) < (1e-10 if tag == "f64" else 2e-4)
+    out = seg.track(beam).particles.cpu().numpy()
+    scale = np.max(np.abs(g[f"out_merged_{tag}"]), axis=0)
+    assert np.max(np.abs(out - g[f"out_merged_{tag}"]) / scale) < (1e-11 if tag == "f64" else 5e-4)
+    tol = np.full(7, 1e-11 if tag == "f64" else 5e-4)
+    tol[4] = max(tol[4], 1e-7)  # reference species.clone() quirk, see tests/test_oracle_golden.py
+    for fused in (False, True):
+        ew = seg.track_elementwise(beam, fused=fused).particles.cpu().numpy()
+        assert (np.max(np.abs(ew - g[f"out_elementwise_{tag}"]) / scale, axis=0) < tol).all()
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_c3_k1_scan_vectorised(ca, golden, tag):
+    g = golden("k1scan.npz")
+    dt = tdt(tag)
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    k1 = dev(g[f"k1_{tag}"])
+    seg = ca.Segment([
+        ca.Marker(name="AREASOLA1", **kw), ca.Drift(length=t(0.17504)),
+        ca.Quadrupole(length=t(0.122), k1=k1, name="AREAMQZM1", **kw), ca.Drift(length=t(0.428)),
+        ca.Quadrupole(length=t(0.122), k1=t(-14.3), name="AREAMQZM2", **kw), ca.Drift(length=t(0.204)),
+        ca.VerticalCorrector(length=t(0.02), angle=t(9e-5), name="AREAMCVM1", **kw), ca.Drift(length=t(0.204)),
+        ca.Quadrupole(length=t(0.122), k1=t(3.142), name="AREAMQZM3", **kw), ca.Drift(length=t(0.179)),
+        ca.HorizontalCorrector(length=t(0.02), angle=t(-1e-4), name="AREAMCHM1", **kw), ca.Drift(length=t(0.45)),
+        ca.Screen(resolution=(2448, 2040), pixel_size=t([3.5488e-6, 2.5003e-6]), name="AREABSCR1", **kw),
+    ])
+    mass, nq = g[f"species_{tag}"]
+    sp = ca.Species("custom_electron", num_elementary_charges=torch.tensor(nq, dtype=dt, device="cuda"),
+                    mass_eV=torch.tensor(mass, dtype=torch.float64, device="cuda"))
+    beam = ca.ParticleBeam(dev(g[f"in_{tag}"]), dev(g[f"energy_{tag}"]), species=sp)
+    out = seg.track(beam)
+    assert tuple(out.particles.shape) == (len(k1), beam.num_particles, 7)
+    assert relmax(out.particles[:, :256].cpu().numpy(), g[f"out_{tag}"]) < (1e-12 if tag == "f64" else 5e-5)
+    rt = 1e-10 if tag == "f64" else 2e-4
+    assert np.allclose(out.sigma_x.cpu().numpy(), g[f"sigma_x_{tag}"], rtol=rt)
+    assert np.allclose(out.sigma_y.cpu().numpy(), g[f"sigma_y_{tag}"], rtol=rt)
+
+
+def test_cache_semantics(ca):
+    """utils/cache.py + tests/test_elements.py:234-353: same object until a defining feature changes."""
+    f32 = torch.float32
+    q = ca.Quadrupole(length=torch.tensor(0.2, device="cuda"), k1=torch.tensor(4.2, device="cuda"), device="cuda")
+    e = torch.tensor(1e8, device="cuda")
+    sp = ca.Species("electron", device="cuda", dtype=f32)
+    a = q.first_order_transfer_map(e, sp)
+    assert q.first_order_transfer_map(e, sp) is a
+    assert q.first_order_transfer_map(e.clone(), sp) is a          # equal energy, different object
+    q.k1 = torch.tensor(-4.2, device="cuda")
+    b = q.first_order_transfer_map(e, sp)
+    assert b is not a and not torch.equal(a, b)
+    q.k1.add_(1.0)                                                  # in-place -> _version bump
+    c = q.first_order_transfer_map(e, sp)
+    assert c is not b and not torch.equal(b, c)
+    assert q.first_order_transfer_map(torch.tensor(2e8, device="cuda"), sp) is not c
+
+
+# ------------------------------------------------------------------------------------------------ cavity
+def test_cavity_track_vs_reference(ca, golden):
+    g = golden("cavity.npz")
+    for i in range(int(g["n_cases"])):
+        meta = json.loads(str(g[f"c{i}_meta"]))
+        dt = tdt(meta["dtype"])
+        p = g[f"c{i}_params"]
+        t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+        V = p[:, 1] if p.shape[0] > 1 else p[0, 1]
+        cav = ca.Cavity(length=t(p[0, 0]), voltage=t(V), phase=t(p[0, 2]), frequency=t(p[0, 3]),
+                        cavity_type=meta["type"], dtype=dt, device="cuda")
+        beam = ca.ParticleBeam(dev(g[f"c{i}_in"]), t(meta["E"]), species=ca.Species("electron", dtype=dt, device="cuda"))
+        out = cav.track(beam)
+        exp = g[f"c{i}_out"]
+        got = out.particles.cpu().numpy()
+        assert got.shape == exp.shape, (i, meta)
+        scale = np.max(np.abs(exp).reshape(-1, 7), axis=0)
+        err = np.max(np.abs(got - exp).reshape(-1, 7) / scale)
+        assert err < (1e-10 if dt == torch.float64 else 2e-3), (i, meta, err)
+        assert np.allclose(out.energy.cpu().numpy(), g[f"c{i}_energy_out"], rtol=1e-13 if dt == torch.float64 else 1e-6)
+        assert out.energy.shape == torch.Size(g[f"c{i}_energy_out"].shape)
+
+
+# ------------------------------------------------------------------------------------------------ moments
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_moments_vs_reference(ca, golden, oracle, tag):
+    g = golden("moments.npz")
+    dt = tdt(tag)
+    beam = ca.ParticleBeam(dev(g[f"particles_{tag}"]), torch.tensor(1e8, dtype=dt, device="cuda"),
+                           particle_charges=dev(g[f"charges_{tag}"]), survival_probabilities=dev(g[f"survival_{tag}"]),
+                           species=ca.Species("electron", dtype=dt, device="cuda"))
+    rt = 1e-10 if tag == "f64" else 2e-3
+    sig = {}
+    for n in ["x", "px", "y", "py", "tau", "p"]:
+        sig[n] = getattr(beam, f"sigma_{n}").cpu().numpy()
+        assert np.allclose(sig[n], g[f"sigma_{n}_{tag}"], rtol=rt), n
+        assert np.allclose(getattr(beam, f"mu_{n}").cpu().numpy(), g[f"mu_{n}_{tag}"], rtol=rt, atol=rt * sig[n].max()), n
+    names = [k[:-4] for k in g.files if k.startswith("cov_") and k.endswith(tag)]
+    assert len(names) == 15
+    coords = ["x", "px", "y", "py", "tau", "p"]
+    for n in names:
+        got = getattr(beam, n).cpu().numpy()
+        a = [c for c in coords if n[4:].startswith(c)]
+        a = max(a, key=len)
+        b = n[4 + len(a):]
+        bound = sig[a] * sig[b]
+        assert np.all(np.abs(got - g[f"{n}_{tag}"]) <= rt * bound + 1e-300), n
+    for n in ["emittance_x", "emittance_y", "beta_x", "beta_y", "alpha_x", "alpha_y", "normalized_emittance_x",
+              "relativistic_gamma", "relativistic_beta", "total_charge"]:
+        assert np.allclose(getattr(beam, n).cpu().numpy(), g[f"{n}_{tag}"], rtol=1e-8 if tag == "f64" else 5e-3,
+                           atol=1e-12 if n.startswith("alpha") else 0), n
+    # device result vs the oracle (both fp64 accumulation): tight even for fp32 inputs
+    m = oracle.moments(g[f"particles_{tag}"], g[f"survival_{tag}"])
+    raw = beam._moments().cpu().numpy()
+    assert np.allclose(raw[:, :8], m["raw"][:, :8], rtol=1e-13, atol=1e-20)
+    assert np.allclose(raw[:, 8:], m["raw"][:, 8:], rtol=1e-9, atol=1e-30)
+
+
+# ------------------------------------------------------------------------------------------------ CIC / screen
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_cic_indices_bit_exact_and_grids(ca, golden, oracle, tag):
+    from cheetah_amd import _ops
+
+    g = golden("cic.npz")
+    pos, q, ext = g[f"pos_{tag}"], g[f"q_{tag}"], g[f"ext_{tag}"]
+    B, N = pos.shape[:2]
+    x = np.zeros((B, N, 7), dtype=pos.dtype)
+    x[..., 0], x[..., 2], x[..., 4] = pos[..., 0], pos[..., 1], pos[..., 2]
+    rt = 1e-11 if tag == "f64" else 2e-5
+    for nd, bins, cols in ((1, (17,), (0,)), (2, (16, 12), (0, 2)), (3, (8, 6, 10), (0, 2, 4))):
+        idx, frac = _ops.cic_indices(dev(x), cols, bins, dev(ext[:nd]))
+        oidx, ofrac = oracle.cic_indices(x, cols, bins, ext[:nd])
+        assert np.array_equal(idx.cpu().numpy(), oidx)             # bit-exact integer cell indices
+        assert np.array_equal(frac.cpu().numpy(), ofrac)           # and fractional parts
+        grid = _ops.cic_deposit(dev(x), cols, bins, dev(ext[:nd]), charge=dev(q)).cpu().numpy()
+        ref = g[f"grid{nd}d_{tag}"]
+        assert grid.shape == ref.shape
+        assert np.allclose(grid, ref, rtol=rt, atol=rt * np.abs(ref).max() * 1e-3)
+        assert np.isclose(grid.sum(), ref.sum(), rtol=rt)
+    grid = _ops.cic_deposit(dev(x), (0, 2), (9, 7), dev(g[f"ext_v_{tag}"]), charge=dev(q)).cpu().numpy()
+    assert np.allclose(grid, g[f"grid2d_v_{tag}"], rtol=rt, atol=rt * np.abs(grid).max() * 1e-3)
+
+
+def test_screen_pixel_indices_bit_exact_and_images(ca, golden):
+    from cheetah_amd import _ops
+
+    g = golden("screen.npz")
+    for i in range(int(g["n_cases"])):
+        meta = json.loads(str(g[f"s{i}_meta"]))
+        dt = tdt(meta["dtype"])
+        scr = ca.Screen(resolution=tuple(meta["resolution"]), pixel_size=torch.tensor(meta["pixel_size"], dtype=dt, device="cuda"),
+                        binning=meta["binning"], misalignment=torch.tensor(meta["misalignment"], dtype=dt, device="cuda"),
+                        method=meta["method"], is_active=True, dtype=dt, device="cuda")
+        beam = ca.ParticleBeam(dev(g[f"s{i}_particles"]), torch.tensor(1e8, dtype=dt, device="cuda"),
+                               particle_charges=dev(g[f"s{i}_q"]), survival_probabilities=dev(g[f"s{i}_surv"]),
+                               species=ca.Species("electron", dtype=dt, device="cuda"))
+        scr.track(beam)
+        img = scr.reading.cpu().numpy()
+        ref = np.zeros(tuple(g[f"s{i}_img_shape"]), dtype=img.dtype)
+        ref[g[f"s{i}_img_idx"][:, 0], g[f"s{i}_img_idx"][:, 1]] = g[f"s{i}_img_val"]
+        assert img.shape == ref.shape, (i, meta)
+        assert np.array_equal(img != 0, ref != 0), (i, meta)       # exactly the same pixels are hit
+        assert np.allclose(img, ref, rtol=2e-5 if dt == torch.float32 else 1e-11, atol=0), (i, meta)
+        if meta["method"] == "histogram":
+            ex, ey = scr.pixel_bin_edges
+            assert np.array_equal(ex.cpu().numpy(), g[f"s{i}_edges_x"])  # torch.linspace edges, same bits
+            assert np.array_equal(ey.cpu().numpy(), g[f"s{i}_edges_y"])
+            ij = _ops.hist2d_indices(beam.particles, ex, ey, shift=scr.misalignment).cpu().numpy()
+            assert np.array_equal(ij, g[f"s{i}_ij"]), (i, meta)    # bit-exact pixel indices
+        # read beam = incoming shifted by the misalignment
+        rb = scr.get_read_beam()
+        exp_x = g[f"s{i}_particles"][:, 0] - np.asarray(meta["misalignment"][0], dtype=img.dtype)
+        assert np.allclose(rb.particles[:, 0].cpu().numpy(), exp_x, rtol=0, atol=np.finfo(img.dtype).eps * 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ space charge
+@pytest.mark.parametrize("gi", [0, 1])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_space_charge_kick_vs_reference(ca, golden, gi, tag):
+    g = golden("space_charge.npz")
+    k = f"g{gi}_{tag}"
+    dt = tdt(tag)
+    grid = tuple(int(v) for v in g[f"{k}_grid"])
+    beam = ca.ParticleBeam(dev(g[f"{k}_in"]), torch.tensor(float(g["energy"]), dtype=dt, device="cuda"),
+                           particle_charges=dev(g[f"{k}_charges"]), survival_probabilities=dev(g[f"{k}_survival"]),
+                           species=ca.Species("electron", dtype=dt, device="cuda"))
+    sc = ca.SpaceChargeKick(effect_length=torch.tensor(float(g["effect_length"]), dtype=dt, device="cuda"),
+                            grid_shape=grid, dtype=dt, device="cuda")
+    before = beam.particles.clone()
+    out = sc.track(beam)
+    assert torch.equal(beam.particles, before)                      # input untouched
+    exp64 = g[f"g{gi}_f64_out"]
+    inp = g[f"{k}_in"].astype(np.float64)
+    got = out.particles.cpu().numpy().astype(np.float64)
+    kick = np.max(np.abs(exp64 - g[f"g{gi}_f64_in"]), axis=0)
+    err = np.max(np.abs(got - exp64 + (g[f"g{gi}_f64_in"] - inp)), axis=0)  # compare the KICK, inputs differ by rounding
+    tol = 1e-6 if tag == "f64" else 2e-2  # fraction of the kick amplitude; fp32 grid solve vs fp64 truth
+    for c in (1, 3, 5):
+        assert err[c] < tol * kick[c] + np.finfo(ndt(tag)).eps * np.max(np.abs(exp64[:, c])), (c, err[c], kick[c])
+    assert np.array_equal(got[:, 0], inp[:, 0]) and np.array_equal(got[:, 2], inp[:, 2])
+    assert np.allclose(got[:, 4], inp[:, 4], rtol=4 * np.finfo(ndt(tag)).eps, atol=0)
+
+
+def test_si_conversion_roundtrip(ca, golden, oracle):
+    g = golden("space_charge.npz")
+    f64 = torch.float64
+    beam = ca.ParticleBeam(dev(g["g0_f64_in"]), torch.tensor(float(g["energy"]), dtype=f64, device="cuda"),
+                           species=ca.Species("electron", dtype=f64, device="cuda"))
+    xp = beam.to_xyz_pxpypz()
+    assert relmax(xp[:256].cpu().numpy(), g["g0_f64_xp"]) < 1e-14
+    back = ca.ParticleBeam.from_xyz_pxpypz(xp, beam.energy, species=beam.species)
+    assert np.allclose(back.particles.cpu().numpy(), g["g0_f64_in"], rtol=1e-9, atol=1e-14)
+
+
+# ------------------------------------------------------------------------------------------------ autograd
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_c5_gradients_through_hip_kernels(ca, golden, tag):
+    g = golden("grad_k1.npz")
+    dt = tdt(tag)
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    k1 = torch.nn.Parameter(t(3.142))
+    L = torch.nn.Parameter(t(0.2))
+    seg = ca.Segment([ca.Drift(length=t(1.0)), ca.Quadrupole(length=L, k1=k1, dtype=dt, device="cuda"),
+                      ca.Drift(length=t(1.0)), ca.Screen(is_active=True, name="scr", dtype=dt, device="cuda")])
+    parts = dev(g[f"in_{tag}"]).requires_grad_(True)
+    mass, nq = g[f"species_{tag}"]
+    sp = ca.Species("custom_electron", num_elementary_charges=torch.tensor(nq, dtype=dt, device="cuda"),
+                    mass_eV=torch.tensor(mass, dtype=torch.float64, device="cuda"))
+    beam = ca.ParticleBeam(parts, dev(g[f"energy_{tag}"]), particle_charges=dev(g[f"charges_{tag}"]), species=sp)
+    seg.track(beam)
+    rb = seg.scr.get_read_beam()
+    loss = rb.sigma_x + 0.5 * rb.mu_y + 3.0 * rb.cov_xpx
+    loss.backward()
+    rt = 1e-9 if tag == "f64" else 2e-3
+    assert float(loss) == pytest.approx(float(g[f"loss_{tag}"]), rel=rt)
+    assert float(k1.grad) == pytest.approx(float(g[f"dk1_{tag}"]), rel=rt)
+    assert float(L.grad) == pytest.approx(float(g[f"dL_{tag}"]), rel=rt)
+    dp = parts.grad[:256].cpu().numpy()
+    ref = g[f"dparticles_{tag}"]
+    scale = np.max(np.abs(ref), axis=0)
+    scale[scale == 0] = 1.0
+    assert np.max(np.abs(dp - ref) / scale) < rt
+
+
+def test_builder_vjp_matches_finite_differences(ca, oracle):
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(0)
+    cases = {"drift": [0.7], "quadrupole": [0.3, 2.5, 0.2, 1e-3, -2e-3], "quadrupole0": [0.3, 0.0, 0.0, 0.0, 0.0],
+             "dipole": [0.8, 0.3, 0.5, 0.05, -0.02, 0.1, 0.4, 0.3, 0.02], "hcor": [0.1, 1e-3], "ccor": [0.1, 1e-3, 2e-3],
+             "cavity_sw": [1.0377, 18.15975e6, 30.0, 1.3e9], "cavity_tw": [1.0377, 18.15975e6, 30.0, 1.3e9]}
+    for name, p in cases.items():
+        kind = name.rstrip("0")
+        k = _ops.KIND[kind]
+        E = 6e6 if kind.startswith("cav") else 1e8
+        params = torch.tensor([p], dtype=torch.float64, device="cuda", requires_grad=True)
+        energy = torch.tensor([E], dtype=torch.float64, device="cuda", requires_grad=True)
+        W = rng.standard_normal((1, 7, 7))
+        R = _ops.build_rmatrix(k, params, energy, oracle.ELECTRON_MASS_EV, -1.0, 1)
+        (R * dev(W)).sum().backward()
+        for j in range(len(p) + 1):
+            h = 1e-6 * max(abs(p[j]) if j < len(p) else E, 1e-3)
+            pp, pm, Ep, Em = list(p), list(p), E, E
+            if j < len(p):
+                pp[j] += h
+                pm[j] -= h
+            else:
+                Ep, Em = E + h, E - h
+            fd = ((oracle.build_rmatrix(kind, pp, Ep) - oracle.build_rmatrix(kind, pm, Em)) * W).sum() / (2 * h)
+            got = float(params.grad[0, j]) if j < len(p) else float(energy.grad[0])
+            assert got == pytest.approx(fd, rel=2e-5, abs=1e-9 * (1 + abs(fd))), (name, j, got, fd)
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_c2_full_size_properties(ca):
+    """N = 1e6, fp32, 100-element FODO: size-independent properties instead of an oracle run."""
+    torch.manual_seed(0)
+    f32 = torch.float32
+    seg = _fodo(ca, f32)
+    beam = ca.ParticleBeam.from_parameters(num_particles=1_000_000, dtype=f32, device="cuda")
+    out = seg.track(beam)
+    assert out.particles.shape == (1_000_000, 7) and torch.isfinite(out.particles).all()
+    assert torch.equal(out.particles[:, 6], torch.ones_like(out.particles[:, 6]))
+    # linearity: track(a x) == a track(x) for the homogeneous part (power-of-two scale -> exact)
+    scaled = beam.particles.clone()
+    scaled[:, :6] *= 0.5
+    out2 = seg.track(ca.ParticleBeam(scaled, beam.energy, species=beam.species))
+    assert torch.equal(out2.particles[:, :6] * 2, out.particles[:, :6])
+    # merged == element by element within fp32 round-off of 100 steps; fused == elementwise bitwise
+    ew = seg.track_elementwise(beam, fused=False).particles
+    fu = seg.track_elementwise(beam, fused=True).particles
+    assert torch.equal(ew, fu)
+    scale = out.particles.abs().amax(dim=0)
+    assert ((ew - out.particles).abs().amax(dim=0) / scale).max() < 2e-4
+    # drift followed by negative drift is the identity map (tests/test_drift.py:95-115)
+    t = lambda v: torch.tensor(v, dtype=f32, device="cuda")  # noqa: E731
+    back = ca.Segment([ca.Drift(t(1.3)), ca.Drift(t(-1.3))]).track(beam)
+    assert torch.allclose(back.particles, beam.particles, rtol=1e-6, atol=1e-12)
+    # moments of the tracked beam obey sigma' = sqrt(R Sigma R^T)
+    R = seg.first_order_transfer_map(beam.energy, beam.species).double()[:6, :6]
+    m = beam._moments()
+    cov = torch.zeros(6, 6, dtype=torch.float64, device="cuda")
+    k = 8
+    for i in range(6):
+        for j in range(i, 6):
+            cov[i, j] = cov[j, i] = m[k]
+            k += 1
+    pred = (R @ cov @ R.T).diagonal().sqrt()
+    got = torch.stack([out.sigma_x, out.sigma_px, out.sigma_y, out.sigma_py, out.sigma_tau, out.sigma_p]).double()
+    assert torch.allclose(got, pred, rtol=1e-4)

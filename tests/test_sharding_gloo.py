@@ -1,0 +1,93 @@
+"""world_size-2 gloo test of the multi-GPU collective logic (cheetah_amd/sharding.py) on CPU.
+
+The per-rank partial reductions come from the CPU oracle here (on the GPU box they come from the
+chx_moment_* kernels); what is under test is the sharding arithmetic and the two all-reduces."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partials(x, w):
+    """numpy restatement of chx_moment_sums / chx_moment_centred for one shard."""
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    sums = np.concatenate([[w64.sum(), (w64 * w64).sum()], (w64[:, None] * x64[:, :6]).sum(0)])[None]
+
+    def centred(gs):
+        mu = gs[0, 2:8] / gs[0, 0]
+        d = x64[:, :6] - mu
+        out = []
+        for i in range(6):
+            for j in range(i, 6):
+                out.append((w64 * d[:, i] * d[:, j]).sum())
+        return np.asarray(out)[None]
+
+    return sums, centred
+
+
+def _finalize(sums, m2):
+    W, W2 = sums[:, 0], sums[:, 1]
+    out = torch.zeros(sums.shape[0], 29, dtype=torch.float64)
+    out[:, 0], out[:, 1] = W, W2
+    out[:, 2:8] = sums[:, 2:8] / W[:, None]
+    out[:, 8:] = m2 / (W - W2 / W)[:, None]
+    return out
+
+
+def _worker(rank, world, port, x, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cheetah_amd.sharding import allreduce_grid, allreduce_moments, shard_range
+
+    lo, hi = shard_range(x.shape[0], rank, world)
+    sums, centred = _partials(x[lo:hi], w[lo:hi])
+    out = allreduce_moments(torch.from_numpy(sums), lambda gs: torch.from_numpy(centred(gs.numpy())), _finalize)
+    grid = torch.full((4, 4), float(rank + 1), dtype=torch.float64)
+    allreduce_grid(grid)
+    if rank == 0:
+        q.put((out.numpy(), grid.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from cheetah_amd.sharding import shard_range
+
+    for n, world in ((10, 3), (4096, 8), (7, 8), (1_000_003, 8)):
+        cuts = [shard_range(n, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_global_moments_two_ranks_gloo(oracle):
+    rng = np.random.default_rng(5)
+    N = 20001  # odd on purpose: unequal shards
+    x = (rng.standard_normal((N, 7)) * [1e-3, 1e-5, 2e-3, 1e-5, 1e-4, 1e-3, 0] + [5e-3, 0, -1e-3, 0, 0, 0, 1]).astype(np.float32)
+    w = rng.random(N).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, x, w, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out, grid = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = oracle.moments(x[None], w[None])["raw"]
+    assert np.allclose(out[:, :8], ref[:, :8], rtol=1e-12, atol=1e-18)
+    assert np.allclose(out[:, 8:], ref[:, 8:], rtol=1e-9, atol=1e-24)
+    assert np.array_equal(grid, np.full((4, 4), 3.0))
