@@ -20,6 +20,7 @@ class Cavity(Element):
     """Accelerating RF cavity (standing or traveling wave)."""
 
     supported_tracking_methods = ["linear"]
+    _static_skippable = False  # `voltage != 0` is a tensor-value dependent flag
 
     def __init__(self, length, voltage=None, phase=None, frequency=None, cavity_type="standing_wave", name=None,
                  sanitize_name=None, metadata=None, device=None, dtype=None) -> None:

@@ -40,6 +40,8 @@ class Element(nn.Module):
     supported_tracking_methods = ["linear"]
     #: libchx map-builder kind (include/chx.h `chx_kind`); None for elements with explicit maps
     _chx_kind: int | None = None
+    #: True when `is_skippable` depends on non-tensor attributes only (those bump `_revision` when set)
+    _static_skippable = True
 
     def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         super().__init__()

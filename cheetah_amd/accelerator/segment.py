@@ -4,8 +4,15 @@
 (`chx_compose_maps`, fp64 accumulation) and applied in one pass over the particles; otherwise the
 element list is partitioned into maximal skippable runs (each composed and applied once) and the
 non-skippable elements (active Cavity / Screen / SpaceChargeKick / BPM / Aperture) are tracked one by
-one. Unlike the reference no nn.Module sub-segments are built per call, and the composed map of a run
-is cached against the (revision, tensor version) token of its elements.
+one.
+
+Host-side cost matters here (the merged pass is a ~10 us kernel), so unlike the reference
+ * no nn.Module sub-segments are built per call (segment.py:558-569);
+ * the partition into runs is planned once per lattice *revision* (any `setattr` on an element bumps
+   its revision counter) and re-used;
+ * per run, the composed map, the stacked per-element map table and the summed length are cached
+   against a token made of the `_version` counters of the run's tensors (in-place updates), the
+   `requires_grad` flags of its parameters and the identity/version of the beam energy.
 
 `track_elementwise` is the merge-free variant (`for e in elements: beam = e.track(beam)`): the E maps
 are applied back to back by `chx_track_elementwise` / `chx_track_fused` from a single C call.
@@ -24,10 +31,36 @@ from ..particles.species import Species
 from .element import Element
 
 
+class _Run:
+    """A maximal run of consecutive skippable elements plus its caches."""
+
+    __slots__ = ("elements", "tensors", "params", "token", "tm", "stack", "length", "energy_ref")
+
+    def __init__(self, elements):
+        self.elements = elements
+        self.tensors = []  # every buffer / parameter tensor of the run (for _version scans)
+        self.params = []
+        for e in elements:
+            for m in e.modules():
+                self.tensors += [t for t in m._buffers.values() if t is not None]
+                self.params += [p for p in m._parameters.values() if p is not None]
+        self.tensors += self.params
+        self.token = None
+        self.tm = None
+        self.stack = None
+        self.length = None
+        self.energy_ref = None
+
+    def current_token(self, energy, species):
+        return (id(energy), energy._version, species.mass_eV_float, species.num_elementary_charges_float,
+                tuple([t._version for t in self.tensors]), tuple([p.requires_grad for p in self.params]))
+
+
 class Segment(Element):
     """Ordered sequence of elements."""
 
     supported_tracking_methods = ["linear"]
+    _static_skippable = False  # depends on the children
 
     def __init__(self, elements: list[Element], name=None, sanitize_name=None, metadata=None, device=None,
                  dtype=None) -> None:
@@ -38,7 +71,7 @@ class Segment(Element):
         for e in elements:
             by_name.setdefault(e.name, []).append(e)
         self.__dict__["_by_name"] = by_name
-        self.__dict__["_run_cache"] = {}
+        self.__dict__["_plan_cache"] = None
 
     def __getattr__(self, name: str):
         by_name = self.__dict__.get("_by_name")
@@ -58,74 +91,108 @@ class Segment(Element):
             total = e.length if total is None else total + e.length
         return total
 
-    # ---- composition ---------------------------------------------------------------------------------
-    @staticmethod
-    def _run_token(elements, energy, species):
-        tok = [id(energy), energy._version, species.mass_eV_float, species.num_elementary_charges_float]
-        for e in elements:
-            tok.append(e.__dict__["_revision"])
-            for t in e._buffers.values():
-                if t is not None:
-                    tok.append(t._version)
-            for t in e._parameters.values():
-                if t is not None:
-                    tok.append(t._version)
-                    tok.append(t.requires_grad)
-            if isinstance(e, Segment):
-                tok.append(Segment._run_token(list(e.elements), energy, species))
-        return tuple(tok)
+    # ---- planning ------------------------------------------------------------------------------------
+    def _revision_key(self):
+        flat = self.__dict__.get("_flat_elements")
+        if flat is None or flat[0] != len(self.elements):
+            flat = (len(self.elements), [m for m in self.modules() if isinstance(m, Element)])
+            self.__dict__["_flat_elements"] = flat
+        return tuple([m.__dict__["_revision"] for m in flat[1]])
 
-    def _compose_run(self, key, elements, energy: torch.Tensor, species: Species) -> torch.Tensor:
-        """Composed map of a run of skippable elements, cached per run."""
-        cacheable = not (energy.requires_grad or species.mass_eV.requires_grad)
-        token = self._run_token(elements, energy, species) if cacheable else None
-        cache = self.__dict__["_run_cache"]
-        hit = cache.get(key)
-        if cacheable and hit is not None and hit[0] == token and not hit[1].requires_grad:
-            return hit[1]
-        maps = [e.first_order_transfer_map(energy, species) for e in elements]
-        dtype, device = maps[0].dtype, maps[0].device
-        batch_shape = torch.broadcast_shapes(energy.shape, *[m.shape[:-2] for m in maps])
-        tm = _ops.compose_maps(maps, batch_shape, dtype, device)
-        if cacheable:
-            cache[key] = (token, tm, energy)  # `energy` kept alive so its id cannot be recycled
-        return tm
-
-    def first_order_transfer_map(self, energy: torch.Tensor, species: Species):
-        if self.is_skippable:
-            return self._compose_run(("all",), list(self.elements), energy, species)
-        return None
-
-    # ---- tracking ---------------------------------------------------------------------------------------
-    def _apply_run(self, key, run, incoming: ParticleBeam) -> ParticleBeam:
-        tm = self._compose_run(key, run, incoming.energy, incoming.species)
-        new_particles = _ops.apply_map(incoming.particles, tm)
-        length = None
-        for e in run:
-            length = e.length if length is None else length + e.length
-        return ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities, s=incoming.s + length,
-                            species=incoming.species)
-
-    def track(self, incoming: ParticleBeam) -> ParticleBeam:
-        if not isinstance(incoming, ParticleBeam):
-            raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+    def _plan(self):
+        """[(kind, payload)] with kind 'run' (payload _Run) or 'element' (payload Element)."""
         elements = list(self.elements)
-        if all(e.is_skippable for e in elements):
-            return self._apply_run(("all",), elements, incoming)
-        run, start = [], 0
-        for i, e in enumerate(elements):
+        # skippability can depend on tensor VALUES for cavities (voltage != 0): fold their flag in
+        dyn = tuple([e.is_skippable for e in elements if not type(e)._static_skippable])
+        key = (self._revision_key(), dyn)
+        cached = self.__dict__["_plan_cache"]
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        plan, run = [], []
+        for e in elements:
             if e.is_skippable:
-                if not run:
-                    start = i
                 run.append(e)
             else:
                 if run:
-                    incoming = self._apply_run((start, i), run, incoming)
+                    plan.append(("run", _Run(run)))
                     run = []
-                incoming = e.track(incoming)
+                plan.append(("element", e))
         if run:
-            incoming = self._apply_run((start, len(elements)), run, incoming)
+            plan.append(("run", _Run(run)))
+        self.__dict__["_plan_cache"] = (key, plan)
+        return plan
+
+    # ---- per-run products ------------------------------------------------------------------------------
+    @staticmethod
+    def _refresh(run: _Run, energy, species) -> bool:
+        """Invalidate the run's caches when its token changed. Returns whether caching is allowed."""
+        if energy.requires_grad or species.mass_eV.requires_grad:
+            run.token = run.tm = run.stack = run.length = None
+            return False
+        token = run.current_token(energy, species)
+        if token != run.token:
+            run.token, run.tm, run.stack, run.length = token, None, None, None
+            run.energy_ref = energy  # kept alive so that its id cannot be recycled
+        return True
+
+    @staticmethod
+    def _run_length(run: _Run):
+        if run.length is None:
+            total = None
+            for e in run.elements:
+                total = e.length if total is None else total + e.length
+            run.length = total
+        return run.length
+
+    @staticmethod
+    def _run_map(run: _Run, energy, species) -> torch.Tensor:
+        cacheable = Segment._refresh(run, energy, species)
+        if cacheable and run.tm is not None:
+            return run.tm
+        maps = [e.first_order_transfer_map(energy, species) for e in run.elements]
+        batch_shape = torch.broadcast_shapes(energy.shape, *[m.shape[:-2] for m in maps])
+        tm = _ops.compose_maps(maps, batch_shape, maps[0].dtype, maps[0].device)
+        if cacheable and not tm.requires_grad:
+            run.tm = tm
+        return tm
+
+    @staticmethod
+    def _run_stack(run: _Run, energy, species) -> torch.Tensor:
+        cacheable = Segment._refresh(run, energy, species)
+        if cacheable and run.stack is not None:
+            return run.stack
+        maps = []
+        for e in run.elements:
+            m = e.first_order_transfer_map(energy, species)
+            maps.append(m)
+        bshape = torch.broadcast_shapes(energy.shape, *[m.shape[:-2] for m in maps])
+        Bm = _ops.numel(bshape)
+        stack = torch.stack([m.expand(*bshape, 7, 7).reshape(Bm, 7, 7) for m in maps])
+        if cacheable and not stack.requires_grad:
+            run.stack = stack
+        return stack
+
+    def first_order_transfer_map(self, energy: torch.Tensor, species: Species):
+        plan = self._plan()
+        if len(plan) == 1 and plan[0][0] == "run":
+            return self._run_map(plan[0][1], energy, species)
+        if not plan:
+            return torch.eye(7, dtype=energy.dtype, device=energy.device).repeat(*energy.shape, 1, 1)
+        return None
+
+    # ---- tracking ---------------------------------------------------------------------------------------
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if not isinstance(incoming, ParticleBeam):
+            raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+        for kind, item in self._plan():
+            if kind == "run":
+                tm = self._run_map(item, incoming.energy, incoming.species)
+                new_particles = _ops.apply_map(incoming.particles, tm)
+                incoming = ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
+                                        survival_probabilities=incoming.survival_probabilities,
+                                        s=incoming.s + self._run_length(item), species=incoming.species)
+            else:
+                incoming = item.track(incoming)
         return incoming
 
     def track_elementwise(self, incoming: ParticleBeam, fused: bool = False) -> ParticleBeam:
@@ -133,43 +200,20 @@ class Segment(Element):
         the particles, results identical to `for e in elements: beam = e.track(beam)`). Runs of linear
         elements are dispatched as one `chx_track_elementwise` (E passes over HBM) or, with
         `fused=True`, one `chx_track_fused` call (one pass, particle kept in registers)."""
-        elements = list(self.elements)
-        run: list[Element] = []
-        cache = self.__dict__["_run_cache"]
-
-        def flush(beam):
-            if not run:
-                return beam
-            # the stacked [E][B][7][7] map table of a run is cached like the composed map
-            key = ("stack", id(run[0]), len(run))
-            cacheable = not (beam.energy.requires_grad or beam.species.mass_eV.requires_grad)
-            token = self._run_token(run, beam.energy, beam.species) if cacheable else None
-            hit = cache.get(key)
-            if cacheable and hit is not None and hit[0] == token:
-                stack = hit[1]
+        for kind, item in self._plan():
+            if kind == "run":
+                if any(isinstance(e, Segment) for e in item.elements):
+                    for e in item.elements:
+                        incoming = e.track_elementwise(incoming, fused) if isinstance(e, Segment) else e.track(incoming)
+                    continue
+                stack = self._run_stack(item, incoming.energy, incoming.species)
+                out = _ops.track_elementwise(incoming.particles, stack, fused=fused)
+                incoming = ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
+                                        survival_probabilities=incoming.survival_probabilities,
+                                        s=incoming.s + self._run_length(item), species=incoming.species)
             else:
-                maps = [e.first_order_transfer_map(beam.energy, beam.species) for e in run]
-                bshape = torch.broadcast_shapes(beam.energy.shape, *[m.shape[:-2] for m in maps])
-                Bm = _ops.numel(bshape)
-                stack = torch.stack([m.expand(*bshape, 7, 7).reshape(Bm, 7, 7) for m in maps])
-                if cacheable and not stack.requires_grad:
-                    cache[key] = (token, stack, beam.energy)
-            out = _ops.track_elementwise(beam.particles, stack, fused=fused)
-            length = None
-            for e in run:
-                length = e.length if length is None else length + e.length
-            run.clear()
-            return ParticleBeam(out, beam.energy, particle_charges=beam.particle_charges,
-                                survival_probabilities=beam.survival_probabilities, s=beam.s + length,
-                                species=beam.species)
-
-        for e in elements:
-            if e.is_skippable and not isinstance(e, Segment):
-                run.append(e)
-            else:
-                incoming = flush(incoming)
-                incoming = e.track_elementwise(incoming, fused) if isinstance(e, Segment) else e.track(incoming)
-        return flush(incoming)
+                incoming = item.track_elementwise(incoming, fused) if isinstance(item, Segment) else item.track(incoming)
+        return incoming
 
     def get_beam_attrs_along_segment(self, attr_names, incoming: ParticleBeam, resolution=None):
         """Beam attributes after every element (segment.py:658-700)."""

@@ -293,6 +293,23 @@ CHXO_API int chxo_apply(const void* x_in, const void* R, void* x_out, int64_t B,
     return 0;
 }
 
+/* segment.py:571-572 `for e in elements: beam = e.track(beam)` for E linear elements, fp32 or fp64
+ * fma-chain arithmetic (mode 1 of chxo_apply), ping-ponging between two caller buffers so that no
+ * allocation or first-touch page fault falls into the timed region of the CPU baseline.
+ * R is [E][49] of the working dtype; the result ends in `buf_a` if E is even, else in `buf_b`...
+ * to keep it simple the function returns 0 and ALWAYS leaves the result in buf_out. */
+CHXO_API int chxo_track_elementwise(const void* x_in, const void* R, void* buf_out, void* buf_tmp, int64_t E,
+                                    int64_t N, int dtype) {
+    const void* src = x_in;
+    for (int64_t e = 0; e < E; ++e) {
+        void* dst = (((E - 1 - e) & 1) == 0) ? buf_out : buf_tmp;
+        const size_t esz = dtype == 0 ? 4 : 8;
+        chxo_apply(src, (const char*)R + (size_t)e * 49 * esz, dst, 1, 1, 1, N, dtype, 1);
+        src = dst;
+    }
+    return 0;
+}
+
 /* cavity.py:100-226: per-batch coefficients [a, b, k*beta0, phi, cos phi, T566, T556, T555] + E' */
 CHXO_API int chxo_cavity_coeffs(const double* params, const double* energy, double mass, double nq,
                                 int64_t B, int64_t Bp, int64_t Be, double* coeffs, double* energy_out) {

@@ -45,7 +45,9 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "chx_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(
-            ["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-fvisibility=hidden",
+            # -mavx2 -mfma: fmaf()/fma() become single instructions (x86-64-v3, any EPYC/Xeon host);
+            # -ffp-contract=off: no implicit contraction, the index arithmetic rounds op by op
+            ["gcc", "-O3", "-mavx2", "-mfma", "-fPIC", "-shared", "-fopenmp", "-fvisibility=hidden",
              "-ffp-contract=off", "-o", _SO, src, "-lm"]
         )
     return _SO
@@ -116,6 +118,18 @@ def apply(x, R, mode: int = 0) -> np.ndarray:
     B = max(Bx, BR)
     out = np.empty((B, x.shape[1], 7), dtype=x.dtype)
     st = lib().chxo_apply(_p(x), _p(R), _p(out), i64(B), i64(Bx), i64(BR), i64(x.shape[1]), _dt(x), mode)
+    assert st == 0
+    return out
+
+
+def track_elementwise(x, maps, out=None, tmp=None) -> np.ndarray:
+    """E linear elements one after the other, no merging (segment.py:571-572); x (N,7), maps (E,7,7)
+    of the same dtype. `out` / `tmp` may be passed to keep allocations out of a timed region."""
+    x = _c(x).reshape(-1, 7)
+    maps = _c(np.asarray(maps, dtype=x.dtype)).reshape(-1, 7, 7)
+    out = np.empty_like(x) if out is None else out
+    tmp = np.empty_like(x) if tmp is None else tmp
+    st = lib().chxo_track_elementwise(_p(x), _p(maps), _p(out), _p(tmp), i64(maps.shape[0]), i64(x.shape[0]), _dt(x))
     assert st == 0
     return out
 

@@ -27,7 +27,8 @@ def ca():
 
 
 def dev(a, dtype=None):
-    t = torch.as_tensor(np.ascontiguousarray(a))
+    a = np.asarray(a)
+    t = torch.as_tensor(np.ascontiguousarray(a)).reshape(a.shape)  # ascontiguousarray makes 0-d -> (1,)
     if dtype is not None:
         t = t.to(dtype)
     return t.cuda()
