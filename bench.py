@@ -85,7 +85,10 @@ def cpu_baseline(n_elements):
     x = (rng.standard_normal((N_PARTICLES, 7)) * [175e-6, 4e-6, 175e-6, 4e-6, 8e-6, 2e-3, 0]).astype(np.float32)
     x[..., 6] = 1.0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    out, tmp = np.empty_like(x), np.empty_like(x)
+    out, tmp, x_par = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    # first touch of every buffer happens inside the OpenMP loops (NUMA-local pages on a multi-socket host)
+    oracle.track_elementwise(x, np.eye(7, dtype=np.float32)[None], x_par, tmp)
+    x = x_par
     oracle.track_elementwise(x, maps, out, tmp)  # warm-up: page faults, OpenMP pool
     reps, t0 = 0, time.perf_counter()
     while True:

@@ -395,8 +395,14 @@ def test_moments_vs_reference(ca, golden, oracle, tag):
     # device result vs the oracle (both fp64 accumulation): tight even for fp32 inputs
     m = oracle.moments(g[f"particles_{tag}"], g[f"survival_{tag}"])
     raw = beam._moments().cpu().numpy()
-    assert np.allclose(raw[:, :8], m["raw"][:, :8], rtol=1e-13, atol=1e-20)
-    assert np.allclose(raw[:, 8:], m["raw"][:, 8:], rtol=1e-9, atol=1e-30)
+    assert np.allclose(raw[:, :2], m["raw"][:, :2], rtol=1e-13, atol=0)
+    sig6 = np.sqrt(np.stack([m["cov"][:, j, j] for j in range(6)], axis=-1))
+    assert np.all(np.abs(raw[:, 2:8] - m["raw"][:, 2:8]) <= 1e-13 * sig6)  # means: error relative to sigma
+    k = 8
+    for i in range(6):
+        for j in range(i, 6):
+            assert np.all(np.abs(raw[:, k] - m["raw"][:, k]) <= 1e-11 * sig6[:, i] * sig6[:, j]), (i, j)
+            k += 1
 
 
 # ------------------------------------------------------------------------------------------------ CIC / screen
