@@ -117,18 +117,25 @@ __global__ __launch_bounds__(CHX_BLOCK) void moment_centred_kernel(const T* __re
                                    partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 21);
 }
 
-// out[b][k] = sum over blk of partials[b][blk][k], fixed order: lane-strided then wave tree.
+// out[b][k] = sum over blk of partials[b][blk][k]. One wavefront per (k, b): lane-strided partial
+// sums in a fixed order, then the wave tree -> deterministic for a given launch geometry.
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const double* __restrict__ partials,
                                                             int nblk, int K,
                                                             double* __restrict__ out) {
-    const int64_t b = blockIdx.x;
-    const double* p = partials + b * nblk * K;
-    for (int k = 0; k < K; ++k) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += 64) s += p[(int64_t)i * K + k];
-        s = chx_wave_sum(s);
-        if (threadIdx.x == 0) out[b * K + k] = s;
+    const int64_t b = blockIdx.y;
+    const int k = blockIdx.x;
+    const double* p = partials + b * nblk * K + k;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // 4 independent chains hide the load latency
+    int i = threadIdx.x;
+    for (; i + 192 < nblk; i += 256) {
+        s0 += p[(int64_t)i * K];
+        s1 += p[(int64_t)(i + 64) * K];
+        s2 += p[(int64_t)(i + 128) * K];
+        s3 += p[(int64_t)(i + 192) * K];
     }
+    for (; i < nblk; i += 64) s0 += p[(int64_t)i * K];
+    const double s = chx_wave_sum((s0 + s1) + (s2 + s3));
+    if (threadIdx.x == 0) out[b * K + k] = s;
 }
 
 __global__ void moment_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ m2,
@@ -298,7 +305,7 @@ extern "C" int chx_moment_sums(const void* x, const void* w, int64_t B, int64_t 
         hipLaunchKernelGGL(moment_sums_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
                            (const double*)w, Bx, Bw, N, part);
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)B), dim3(64), 0, s, part, (int)nblk, 8, sums);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(8, (unsigned)B), dim3(64), 0, s, part, (int)nblk, 8, sums);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -321,7 +328,7 @@ extern "C" int chx_moment_centred(const void* x, const void* w, const double* su
         hipLaunchKernelGGL(moment_centred_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
                            (const double*)w, sums, Bx, Bw, N, part);
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)B), dim3(64), 0, s, part, (int)nblk, 21, m2);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(21, (unsigned)B), dim3(64), 0, s, part, (int)nblk, 21, m2);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -412,7 +419,7 @@ extern "C" int chx_apply_affine7_bwd(const void* dY, const void* R, const void* 
             hipLaunchKernelGGL(apply_bwd_dR_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)dY,
                                (const double*)X, Bx, N, part);
         CHX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)B), dim3(64), 0, s, part, (int)nblk, 49, dR);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(49, (unsigned)B), dim3(64), 0, s, part, (int)nblk, 49, dR);
         CHX_CHECK_LAUNCH();
     }
     return CHX_OK;

@@ -397,7 +397,9 @@ def test_moments_vs_reference(ca, golden, oracle, tag):
     raw = beam._moments().cpu().numpy()
     assert np.allclose(raw[:, :2], m["raw"][:, :2], rtol=1e-13, atol=0)
     sig6 = np.sqrt(np.stack([m["cov"][:, j, j] for j in range(6)], axis=-1))
-    assert np.all(np.abs(raw[:, 2:8] - m["raw"][:, 2:8]) <= 1e-13 * sig6)  # means: error relative to sigma
+    mu_err = np.abs(raw[:, 2:8] - m["raw"][:, 2:8])
+    mu_bound = 1e-12 * (sig6 + np.abs(m["raw"][:, 2:8]))  # summation-order differences only
+    assert np.all(mu_err <= mu_bound), (mu_err / mu_bound).max()
     k = 8
     for i in range(6):
         for j in range(i, 6):
@@ -478,14 +480,30 @@ def test_space_charge_kick_vs_reference(ca, golden, gi, tag):
     before = beam.particles.clone()
     out = sc.track(beam)
     assert torch.equal(beam.particles, before)                      # input untouched
-    exp64 = g[f"g{gi}_f64_out"]
     inp = g[f"{k}_in"].astype(np.float64)
     got = out.particles.cpu().numpy().astype(np.float64)
-    kick = np.max(np.abs(exp64 - g[f"g{gi}_f64_in"]), axis=0)
-    err = np.max(np.abs(got - exp64 + (g[f"g{gi}_f64_in"] - inp)), axis=0)  # compare the KICK, inputs differ by rounding
-    tol = 1e-6 if tag == "f64" else 2e-2  # fraction of the kick amplitude; fp32 grid solve vs fp64 truth
+    if tag == "f64":
+        truth = g[f"{k}_out"]          # the reference itself, fp64
+        tol = 1e-6                     # fraction of the kick amplitude
+    else:
+        # fp32: the reference's own fp32 result is noisy (IGF cancellation, denormal SI momenta), so the
+        # truth is the fp64 oracle evaluated on the SAME fp32 inputs (oracle pinned to the fp64 reference
+        # in tests/test_oracle_golden.py::test_space_charge_fp64)
+        from oracle import chx_oracle as oracle
+
+        truth = oracle.space_charge_kick(inp[None], float(g["energy"]), g[f"{k}_charges"].astype(np.float64),
+                                         g[f"{k}_survival"].astype(np.float64), float(g["effect_length"]),
+                                         grid_shape=grid)[0]
+        tol = 2e-2
+    kick = np.max(np.abs(truth - inp), axis=0)
+    err = np.max(np.abs(got - truth), axis=0)
     for c in (1, 3, 5):
-        assert err[c] < tol * kick[c] + np.finfo(ndt(tag)).eps * np.max(np.abs(exp64[:, c])), (c, err[c], kick[c])
+        assert err[c] < tol * kick[c] + 2 * np.finfo(ndt(tag)).eps * np.max(np.abs(truth[:, c])), (c, err[c], kick[c])
+    if tag == "f32":
+        # and the reference's fp32 output agrees with ours at the level of its own noise
+        ref32 = g[f"{k}_out"].astype(np.float64)
+        for c in (1, 3, 5):
+            assert np.max(np.abs(got[:, c] - ref32[:, c])) < 0.2 * kick[c] + 4 * np.finfo(np.float32).eps * np.max(np.abs(truth[:, c]))
     assert np.array_equal(got[:, 0], inp[:, 0]) and np.array_equal(got[:, 2], inp[:, 2])
     assert np.allclose(got[:, 4], inp[:, 4], rtol=4 * np.finfo(ndt(tag)).eps, atol=0)
 
