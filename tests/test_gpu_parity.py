@@ -391,7 +391,7 @@ def test_moments_vs_reference(ca, golden, oracle, tag):
     for n in ["emittance_x", "emittance_y", "beta_x", "beta_y", "alpha_x", "alpha_y", "normalized_emittance_x",
               "relativistic_gamma", "relativistic_beta", "total_charge"]:
         assert np.allclose(getattr(beam, n).cpu().numpy(), g[f"{n}_{tag}"], rtol=1e-8 if tag == "f64" else 5e-3,
-                           atol=1e-12 if n.startswith("alpha") else 0), n
+                           atol=(1e-12 if tag == "f64" else 1e-6) if n.startswith("alpha") else 0), n
     # device result vs the oracle (both fp64 accumulation): tight even for fp32 inputs
     m = oracle.moments(g[f"particles_{tag}"], g[f"survival_{tag}"])
     raw = beam._moments().cpu().numpy()
