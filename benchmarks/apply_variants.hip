@@ -1,0 +1,221 @@
+// apply_variants.hip — micro-benchmark harness for the affine-7 apply kernel (fp32), used to pick the
+// production tiling. Build & run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off benchmarks/apply_variants.hip -o /tmp/av && /tmp/av
+// Every variant computes y = R x for N particles (AoS rows of 7 floats) and is checked against variant 0.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ void apply7(const float* __restrict__ R, const float (&x)[7], float (&y)[7]) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        float acc = R[i * 7] * x[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) acc = fmaf(R[i * 7 + j], x[j], acc);
+        y[i] = acc;
+    }
+}
+
+// ---- V_tile<PPT>: one tile per block through LDS (production structure) -------------------------
+template <int PPT>
+__global__ __launch_bounds__(256) void k_tile(const float* __restrict__ x, const float* __restrict__ R,
+                                              float* __restrict__ y, long N) {
+    constexpr int TP = PPT * 256;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const long n0 = (long)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const float4* gv = reinterpret_cast<const float4*>(x + n0 * 7);
+    float4* lv = reinterpret_cast<float4*>(lds);
+    const int nvec = np * 7 / 4;
+    for (int v = threadIdx.x; v < nvec; v += 256) lv[v] = gv[v];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + k * 256;
+        if (p < np) {
+            float a[7], b[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a[j] = lds[p * 7 + j];
+            apply7(R, a, b);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = b[j];
+        }
+    }
+    __syncthreads();
+    float4* ov = reinterpret_cast<float4*>(y + n0 * 7);
+    for (int v = threadIdx.x; v < nvec; v += 256) ov[v] = lv[v];
+}
+
+// ---- V_pipe<PPT>: persistent blocks, register prefetch of the next tile ------------------------------
+template <int PPT>
+__global__ __launch_bounds__(256) void k_pipe(const float* __restrict__ x, const float* __restrict__ R,
+                                              float* __restrict__ y, long N) {
+    constexpr int TP = PPT * 256;
+    constexpr int VPT = (TP * 7 / 4 + 255) / 256;  // float4 per thread per tile
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const long tiles = (N + TP - 1) / TP;
+    float4 pre[VPT];
+    long t = blockIdx.x;
+    auto prefetch = [&](long tt) {
+        const long n0 = tt * TP;
+        const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+        const int nvec = np * 7 / 4;
+        const float4* gv = reinterpret_cast<const float4*>(x + n0 * 7);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * 256;
+            if (v < nvec) pre[i] = gv[v];
+        }
+    };
+    if (t < tiles) prefetch(t);
+    float4* lv = reinterpret_cast<float4*>(lds);
+    for (; t < tiles; t += gridDim.x) {
+        const long n0 = t * TP;
+        const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+        const int nvec = np * 7 / 4;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * 256;
+            if (v < nvec) lv[v] = pre[i];
+        }
+        __syncthreads();
+        if (t + gridDim.x < tiles) prefetch(t + gridDim.x);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * 256;
+            if (p < np) {
+                float a[7], b[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = lds[p * 7 + j];
+                apply7(R, a, b);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = b[j];
+            }
+        }
+        __syncthreads();
+        float4* ov = reinterpret_cast<float4*>(y + n0 * 7);
+        for (int v = threadIdx.x; v < nvec; v += 256) ov[v] = lv[v];
+        __syncthreads();
+    }
+}
+
+// ---- V_direct: no LDS, every lane moves its own 28-byte row with dword accesses -----------------------
+__global__ __launch_bounds__(256) void k_direct(const float* __restrict__ x, const float* __restrict__ R,
+                                                float* __restrict__ y, long N) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    float a[7], b[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) a[j] = x[p * 7 + j];
+    apply7(R, a, b);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) y[p * 7 + j] = b[j];
+}
+
+// ---- V_quad: a lane handles 4 consecutive particles = 7 float4 (112 contiguous bytes), no LDS ---------
+__global__ __launch_bounds__(256) void k_quad(const float* __restrict__ x, const float* __restrict__ R,
+                                              float* __restrict__ y, long N) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;  // group of 4 particles
+    if (q * 4 + 3 >= N) {
+        for (long p = q * 4; p < N; ++p) {
+            float a[7], b[7];
+            for (int j = 0; j < 7; ++j) a[j] = x[p * 7 + j];
+            apply7(R, a, b);
+            for (int j = 0; j < 7; ++j) y[p * 7 + j] = b[j];
+        }
+        return;
+    }
+    const float4* gv = reinterpret_cast<const float4*>(x + q * 28);
+    float v[28];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float4 t = gv[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+    float o[28];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a[7], b[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a[j] = v[k * 7 + j];
+        apply7(R, a, b);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o[k * 7 + j] = b[j];
+    }
+    float4* ov = reinterpret_cast<float4*>(y + q * 28);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ov[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+}
+
+// plain float4 copy of the same bytes: the practical ceiling
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ x, float4* __restrict__ y, long nvec) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) y[v] = x[v];
+}
+
+template <typename F>
+float time_it(F launch, int iters) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    for (long N : {1000000L, 16000000L}) {
+        std::vector<float> hx(N * 7), hR(49, 0.f);
+        for (long i = 0; i < N * 7; ++i) hx[i] = (float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
+        for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) hR[i * 7 + j] = (i == j) ? 1.f : 0.01f * (i + j);
+        float *x, *y, *y0, *R;
+        CK(hipMalloc(&x, N * 28)); CK(hipMalloc(&y, N * 28)); CK(hipMalloc(&y0, N * 28)); CK(hipMalloc(&R, 196));
+        CK(hipMemcpy(x, hx.data(), N * 28, hipMemcpyHostToDevice));
+        CK(hipMemcpy(R, hR.data(), 196, hipMemcpyHostToDevice));
+        const int iters = N > 2000000 ? 50 : 300;
+        auto report = [&](const char* name, float ms, bool check) {
+            int bad = 0;
+            if (check) {
+                std::vector<float> a(7000), b(7000);
+                CK(hipMemcpy(a.data(), y0 + (N - 1000) * 7, 28000, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(b.data(), y + (N - 1000) * 7, 28000, hipMemcpyDeviceToHost));
+                for (int i = 0; i < 7000; ++i) if (a[i] != b[i]) ++bad;
+            }
+            printf("N=%ld %-28s %8.3f us  %7.1f GB/s  mismatches=%d\n", N, name, ms * 1e3, 56.0 * N / (ms * 1e-3) / 1e9, bad);
+        };
+        float ms;
+        ms = time_it([&] { hipLaunchKernelGGL(k_tile<2>, dim3((N + 511) / 512), dim3(256), 0, 0, x, R, y0, N); }, iters);
+        report("tile PPT=2 (production)", ms, false);
+        ms = time_it([&] { hipLaunchKernelGGL(k_tile<1>, dim3((N + 255) / 256), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=1", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL(k_tile<4>, dim3((N + 1023) / 1024), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=4", ms, true);
+        for (int g : {256, 512, 1024, 2048}) {
+            char name[64];
+            snprintf(name, 64, "pipe PPT=2 grid=%d", g);
+            ms = time_it([&] { hipLaunchKernelGGL(k_pipe<2>, dim3(g), dim3(256), 0, 0, x, R, y, N); }, iters);
+            report(name, ms, true);
+            snprintf(name, 64, "pipe PPT=4 grid=%d", g);
+            ms = time_it([&] { hipLaunchKernelGGL(k_pipe<4>, dim3(g), dim3(256), 0, 0, x, R, y, N); }, iters);
+            report(name, ms, true);
+        }
+        ms = time_it([&] { hipLaunchKernelGGL(k_direct, dim3((N + 255) / 256), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("direct dword", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL(k_quad, dim3((N / 4 + 256) / 256), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("quad (4 rows/lane, float4)", ms, true);
+        for (int g : {1024, 2048, 4096, 8192}) {
+            char name[64];
+            snprintf(name, 64, "float4 copy grid=%d", g);
+            ms = time_it([&] { hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, 0, (const float4*)x, (float4*)y, N * 7 / 4); }, iters);
+            report(name, ms, false);
+        }
+        CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(y0)); CK(hipFree(R));
+    }
+    return 0;
+}

@@ -152,10 +152,9 @@ template <typename T> struct tile_cfg;
 template <> struct tile_cfg<float> { static constexpr int PPT = 2; };   // 512 rows, 14 KiB LDS
 template <> struct tile_cfg<double> { static constexpr int PPT = 1; };  // 256 rows, 14 KiB LDS
 
-template <typename T, int MODE>
-int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coeffs, int64_t B,
-                 int64_t Bx, int64_t BR, int64_t N, int E, hipStream_t s) {
-    constexpr int PPT = tile_cfg<T>::PPT;
+template <typename T, int PPT, int MODE>
+int launch_tiles_ppt(const void* x_in, const void* R, void* x_out, const double* coeffs, int64_t B,
+                     int64_t Bx, int64_t BR, int64_t N, int E, hipStream_t s) {
     constexpr int TP = PPT * CHX_BLOCK;
     const int64_t tiles = ((N + TP - 1) / TP) * B;
     if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
@@ -164,6 +163,18 @@ int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coe
                        (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
     CHX_CHECK_LAUNCH();
     return CHX_OK;
+}
+
+// Tile size: measured on MI355X (benchmarks/apply_variants.hip, fp32): 512-row tiles win while the
+// working set is Infinity-Cache resident (5.76 vs 5.71 TB/s at N = 1e6), 256-row tiles win once the
+// launch streams from HBM (5.74 vs 5.42 TB/s at N = 1.6e7; a float4 copy of the same bytes: 5.83 TB/s).
+template <typename T, int MODE>
+int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coeffs, int64_t B,
+                 int64_t Bx, int64_t BR, int64_t N, int E, hipStream_t s) {
+    constexpr int PPT = tile_cfg<T>::PPT;
+    if (PPT > 1 && MODE == 0 && B * N * 7 * (int64_t)sizeof(T) > (int64_t)96 * 1024 * 1024)
+        return launch_tiles_ppt<T, 1, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
+    return launch_tiles_ppt<T, PPT, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
 }
 
 template <typename T>

@@ -19,46 +19,48 @@ constexpr int kTileRows = 512;  // rows per tile used for sizing (max over dtype
 
 __host__ __device__ inline int64_t red_nblk(int64_t B, int64_t N, int tile_rows) {
     int64_t tiles = (N + tile_rows - 1) / tile_rows;
-    int64_t cap = 2048 / B;
+    int64_t cap = 1024 / B;  // ~4 workgroups per CU in total; each loops over many rows
     if (cap < 1) cap = 1;
     return tiles < cap ? tiles : cap;
 }
 
-// Generic tiled reduction over the particles of batch row b = blockIdx.y.
-// F::accumulate(x[7], w, acc[K]) is called once per particle.
+// Generic reduction over the particles of batch row b = blockIdx.y. Each lane streams its own 28-/56-byte
+// rows straight from global memory (measured on MI355X: dword-strided row reads reach the same bandwidth as
+// LDS-staged float4 tiles, benchmarks/apply_variants.hip "direct dword"), 2 rows in flight per lane and
+// iteration, no barrier inside the loop; one block reduction at the end.
+// F::accumulate(x[7], w, n, acc[K]) is called once per particle.
 template <typename T, int K, typename F>
 __device__ __forceinline__ void tiled_reduce(const T* __restrict__ x, const T* __restrict__ w,
                                              int64_t Bx, int64_t Bw, int64_t N, F& f,
                                              double* __restrict__ partial_out /*[K]*/) {
-    constexpr int PPT = red_cfg<T>::PPT;
-    constexpr int TP = PPT * CHX_BLOCK;
-    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     __shared__ double red[4 * K];
     const int64_t b = blockIdx.y;
     const int64_t xrow = (Bx == 1) ? 0 : b, wrow = (Bw == 1) ? 0 : b;
-    const T* xb = x + xrow * N * 7;
-    const bool vec = chx_aligned16(x) && (((xrow * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
-    const int64_t tiles = (N + TP - 1) / TP;
+    const T* __restrict__ xb = x + xrow * N * 7;
+    const T* __restrict__ wb = w ? w + wrow * N : nullptr;
     double acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.0;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t n0 = t * TP;
-        const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
-        __syncthreads();
-        tile_load<T>(xb + n0 * 7, lds, np * 7, vec);
-        __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * CHX_BLOCK;
+    int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x;
+    for (; n + stride < N; n += 2 * stride) {
+        T r0[7], r1[7];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int p = threadIdx.x + k * CHX_BLOCK;
-            if (p < np) {
-                double xv[7];
+        for (int j = 0; j < 7; ++j) { r0[j] = xb[n * 7 + j]; r1[j] = xb[(n + stride) * 7 + j]; }
+        const double w0 = wb ? (double)wb[n] : 1.0, w1 = wb ? (double)wb[n + stride] : 1.0;
+        double xv[7];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) xv[j] = (double)lds[p * 7 + j];
-                const double wv = w ? (double)w[wrow * N + n0 + p] : 1.0;
-                f.accumulate(xv, wv, n0 + p, acc);
-            }
-        }
+        for (int j = 0; j < 7; ++j) xv[j] = (double)r0[j];
+        f.accumulate(xv, w0, n, acc);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xv[j] = (double)r1[j];
+        f.accumulate(xv, w1, n + stride, acc);
+    }
+    if (n < N) {
+        double xv[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xv[j] = (double)xb[n * 7 + j];
+        f.accumulate(xv, wb ? (double)wb[n] : 1.0, n, acc);
     }
     chx_block_sum<K>(acc, red);
     if (threadIdx.x == 0) {
