@@ -34,7 +34,7 @@ from .element import Element
 class _Run:
     """A maximal run of consecutive skippable elements plus its caches."""
 
-    __slots__ = ("elements", "tensors", "params", "token", "tm", "stack", "length", "energy_ref")
+    __slots__ = ("elements", "tensors", "params", "token", "tm", "stack", "length", "energy_ref", "s_cache")
 
     def __init__(self, elements):
         self.elements = elements
@@ -50,6 +50,7 @@ class _Run:
         self.stack = None
         self.length = None
         self.energy_ref = None
+        self.s_cache = None
 
     def current_token(self, energy, species):
         return (id(energy), energy._version, species.mass_eV_float, species.num_elementary_charges_float,
@@ -131,7 +132,7 @@ class Segment(Element):
             return False
         token = run.current_token(energy, species)
         if token != run.token:
-            run.token, run.tm, run.stack, run.length = token, None, None, None
+            run.token, run.tm, run.stack, run.length, run.s_cache = token, None, None, None, None
             run.energy_ref = energy  # kept alive so that its id cannot be recycled
         return True
 
@@ -143,6 +144,18 @@ class Segment(Element):
                 total = e.length if total is None else total + e.length
             run.length = total
         return run.length
+
+    @staticmethod
+    def _run_s(run: _Run, s_in: torch.Tensor) -> torch.Tensor:
+        """`incoming.s + length` of the run; the sum is reused while the same incoming `s` tensor is
+        tracked again (the usual RL loop re-tracks one incoming beam), saving a device op per track."""
+        c = run.s_cache
+        if c is not None and c[0] is s_in and c[1] == s_in._version and not s_in.requires_grad:
+            return c[2]
+        s_out = s_in + Segment._run_length(run)
+        if not s_out.requires_grad:
+            run.s_cache = (s_in, s_in._version, s_out)
+        return s_out
 
     @staticmethod
     def _run_map(run: _Run, energy, species) -> torch.Tensor:
@@ -190,7 +203,7 @@ class Segment(Element):
                 new_particles = _ops.apply_map(incoming.particles, tm)
                 incoming = ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
                                         survival_probabilities=incoming.survival_probabilities,
-                                        s=incoming.s + self._run_length(item), species=incoming.species)
+                                        s=self._run_s(item, incoming.s), species=incoming.species)
             else:
                 incoming = item.track(incoming)
         return incoming
@@ -210,7 +223,7 @@ class Segment(Element):
                 out = _ops.track_elementwise(incoming.particles, stack, fused=fused)
                 incoming = ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
                                         survival_probabilities=incoming.survival_probabilities,
-                                        s=incoming.s + self._run_length(item), species=incoming.species)
+                                        s=self._run_s(item, incoming.s), species=incoming.species)
             else:
                 incoming = item.track_elementwise(incoming, fused) if isinstance(item, Segment) else item.track(incoming)
         return incoming

@@ -39,21 +39,22 @@ class ParticleBeam(nn.Module):
         device = device if device is not None else particles.device
         dtype = dtype if dtype is not None else particles.dtype
         factory_kwargs = {"device": device, "dtype": dtype}
-        self.species = species if species is not None else Species("electron", **factory_kwargs)
-        self.register_buffer("particles", particles)
-        self.register_buffer("energy", energy)
-        self.register_buffer(
-            "particle_charges",
+        species = species if species is not None else Species("electron", **factory_kwargs)
+        self._modules["species"] = species
+        # A new beam object is created for every tracked element: the buffers are entered directly
+        # (same result as five `register_buffer` calls, ~10 us cheaper) and read back through class-level
+        # properties below instead of nn.Module.__getattr__.
+        buffers = self._buffers
+        buffers["particles"] = particles
+        buffers["energy"] = energy
+        buffers["particle_charges"] = (
             particle_charges if particle_charges is not None
-            else torch.full((particles.shape[-2],), self.species.num_elementary_charges_float * 1.602176634e-19,
-                            **factory_kwargs),
-        )
-        self.register_buffer(
-            "survival_probabilities",
+            else torch.full((particles.shape[-2],), species.num_elementary_charges_float * 1.602176634e-19,
+                            **factory_kwargs))
+        buffers["survival_probabilities"] = (
             survival_probabilities if survival_probabilities is not None
-            else torch.ones(particles.shape[-2], **factory_kwargs),
-        )
-        self.register_buffer("s", s if s is not None else torch.tensor(0.0, **factory_kwargs))
+            else torch.ones(particles.shape[-2], **factory_kwargs))
+        buffers["s"] = s if s is not None else torch.tensor(0.0, **factory_kwargs)
 
     # ------------------------------------------------------------------ factories (input generation)
     @classmethod
@@ -324,4 +325,27 @@ def _install_coordinate_properties() -> None:
             setattr(ParticleBeam, f"cov_{_COORDS[i]}{_COORDS[j]}", property(lambda self, i=i, j=j: self._cov(i, j)))
 
 
+def _install_buffer_accessors() -> None:
+    """Class-level data descriptors for the five state tensors and the species: attribute reads hit the
+    descriptor (one dict lookup) instead of falling through to nn.Module.__getattr__; writes still go
+    through nn.Module.__setattr__, which stores tensors into `_buffers`."""
+    for name in ("particles", "energy", "particle_charges", "survival_probabilities", "s"):
+        def getter(self, name=name):
+            return self._buffers[name]
+
+        def setter(self, value, name=name):
+            self._buffers[name] = value
+
+        setattr(ParticleBeam, name, property(getter, setter))
+
+    def get_species(self):
+        return self._modules["species"]
+
+    def set_species(self, value):
+        self._modules["species"] = value
+
+    ParticleBeam.species = property(get_species, set_species)
+
+
+_install_buffer_accessors()
 _install_coordinate_properties()

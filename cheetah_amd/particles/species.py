@@ -60,12 +60,14 @@ class Species(nn.Module):
 
     # ---- host-side scalars for the C-ABI (refreshed when the tensors are replaced / moved) ----
     def _scalars(self):
-        key = (id(self.mass_eV), self.mass_eV._version, id(self.num_elementary_charges),
-               self.num_elementary_charges._version)
+        buffers, params = self._buffers, self._parameters
+        m = buffers["mass_eV"] if "mass_eV" in buffers else params["mass_eV"]
+        q = buffers["num_elementary_charges"] if "num_elementary_charges" in buffers else params["num_elementary_charges"]
+        key = (id(m), m._version, id(q), q._version)
         cached = self.__dict__.get("_scalar_cache")
         if cached is None or cached[0] != key:
-            cached = (key, float(self.mass_eV.detach().double().reshape(-1)[0].item()),
-                      float(self.num_elementary_charges.detach().double().reshape(-1)[0].item()))
+            cached = (key, float(m.detach().double().reshape(-1)[0].item()),
+                      float(q.detach().double().reshape(-1)[0].item()))
             self.__dict__["_scalar_cache"] = cached
         return cached[1], cached[2]
 
