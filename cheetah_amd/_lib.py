@@ -86,6 +86,8 @@ SIGNATURES = {
     "chx_moments": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_moments_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_cic_deposit": (c_int, [ctypes.POINTER(CicArgs), c_void_p]),
+    "chx_cic_sorted_workspace_bytes": (c_size_t, [ctypes.POINTER(CicArgs)]),
+    "chx_cic_deposit_sorted": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_size_t, c_void_p]),
     "chx_cic_indices": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_void_p, c_void_p]),
     "chx_cic_deposit_bwd": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_hist2d": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p]),

@@ -372,8 +372,29 @@ def _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs
     return a, keep, batch_shape, B, N
 
 
+SORTED_CIC_MIN_PARTICLES = 65536  # below this the 2^d global atomics per particle are cheaper than 5 launches
+
+
+def _launch_cic(a: CicArgs, N: int, ndim: int, device, mode: str = "auto") -> None:
+    """Direct (global float atomics) or sorted / LDS-privatised deposit (chx_cic_deposit_sorted)."""
+    lib = _lib.lib()
+    use_sorted = mode == "sorted" or (mode == "auto" and ndim >= 2 and N >= SORTED_CIC_MIN_PARTICLES)
+    if use_sorted:
+        nbytes = lib.chx_cic_sorted_workspace_bytes(ctypes.byref(a))
+        if nbytes > 0:
+            ws = workspace(nbytes, device)
+            st = lib.chx_cic_deposit_sorted(ctypes.byref(a), ptr(ws), nbytes, stream_ptr())
+            if st == 0:
+                return
+            if mode == "sorted":
+                check(st, "chx_cic_deposit_sorted")
+        elif mode == "sorted":
+            raise _lib.ChxError("sorted deposit needs ndim >= 2")
+    check(lib.chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
+
+
 def cic_deposit(particles, cols, bins, extent, charge=None, survival=None, scale=None, shift=None,
-                abs_charge=False, transpose_2d=False) -> torch.Tensor:
+                abs_charge=False, transpose_2d=False, mode: str = "auto") -> torch.Tensor:
     """Cloud-in-cell deposition (utils/cloud_in_cell.py:8-451) of columns `cols` of the 7-vectors.
 
     Returns (*batch, *bins); with transpose_2d the 2-D image is written directly as (bins[1], bins[0])
@@ -391,17 +412,17 @@ def cic_deposit(particles, cols, bins, extent, charge=None, survival=None, scale
         out_shape = (bins[1], bins[0])
     else:
         out_shape = tuple(bins)
-    check(_lib.lib().chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
+    _launch_cic(a, N, len(bins), particles.device, mode)
     return grid.reshape(*batch_shape, *out_shape)
 
 
 def cic_deposit_into(grid: torch.Tensor, grid_strides, grid_batch_stride, particles, cols, bins, extent,
-                     charge=None, survival=None, scale=None, shift=None) -> None:
+                     charge=None, survival=None, scale=None, shift=None, mode: str = "auto") -> None:
     """Deposit into a caller-provided (zeroed) strided grid, e.g. the doubled Hockney array."""
     a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, False,
                                            grid=grid, grid_strides=grid_strides,
                                            grid_batch_stride=grid_batch_stride)
-    check(_lib.lib().chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
+    _launch_cic(a, N, len(bins), particles.device, mode)
 
 
 def cic_indices(particles, cols, bins, extent, scale=None, shift=None):

@@ -176,6 +176,11 @@ typedef struct chx_cic_args {
     void* grid;           /* [B] grids, dtype, accumulated into (caller zeroes) */
 } chx_cic_args;
 int chx_cic_deposit(const chx_cic_args* args, void* stream);
+/* Same result as chx_cic_deposit (identical addends, different summation order) for ndim 2 or 3 and large
+ * N: particles are counting-sorted by grid tile, accumulated in LDS (ds_add) and flushed once per tile,
+ * instead of 2^ndim global float atomics per particle (which saturate at ~21 G atomics/s on MI355X). */
+size_t chx_cic_sorted_workspace_bytes(const chx_cic_args* args);
+int chx_cic_deposit_sorted(const chx_cic_args* args, void* workspace, size_t workspace_bytes, void* stream);
 /* Test/diagnostic twin: writes the integer cell index i_d=floor(p_d) (int32 [B][N][ndim])
  * and fractional part f_d (dtype [B][N][ndim]) instead of depositing. */
 int chx_cic_indices(const chx_cic_args* args, int32_t* idx_out, void* frac_out, void* stream);
