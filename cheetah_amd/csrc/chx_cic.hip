@@ -331,13 +331,22 @@ struct TileGeom {
     int nt;        // total tiles
 };
 
+// Small tiles balance the load (the hottest 8^3 brick of a Gaussian beam on a +-3 sigma 128^3 grid holds
+// 0.3 % of the particles, the hottest 16^3 brick 2.6 %); tile edges are doubled until the per-workgroup
+// histogram of tile ids fits 32 KiB of LDS (<= 8192 tiles).
 __host__ __device__ inline TileGeom tile_geom(int ndim, const int* bins) {
     TileGeom g;
-    g.nt = 1;
-    for (int d = 0; d < 3; ++d) {
-        g.tdim[d] = d < ndim ? (ndim == 2 ? 32 : 16) : 1;
-        g.ntile[d] = d < ndim ? (bins[d] + g.tdim[d] - 1) / g.tdim[d] : 1;
-        g.nt *= g.ntile[d];
+    for (int d = 0; d < 3; ++d) g.tdim[d] = d < ndim ? (ndim == 2 ? 16 : 8) : 1;
+    for (;;) {
+        g.nt = 1;
+        int widest = 0;
+        for (int d = 0; d < 3; ++d) {
+            g.ntile[d] = d < ndim ? (bins[d] + g.tdim[d] - 1) / g.tdim[d] : 1;
+            g.nt *= g.ntile[d];
+            if (g.ntile[d] > g.ntile[widest]) widest = d;
+        }
+        if (g.nt <= 8192 || g.tdim[widest] >= 64) break;
+        g.tdim[widest] *= 2;
     }
     return g;
 }
