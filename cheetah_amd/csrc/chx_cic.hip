@@ -306,17 +306,17 @@ inline dim3 particle_grid(int64_t N, int64_t B) {
 
 
 // =============================================================================================
-// Sorted, LDS-privatised deposit (2-D / 3-D, large N).
+// Sorted, LDS-privatised deposit (2-D / 3-D, large N) — "owner computes".
 // Measured on MI355X (benchmarks/atomic_scope.hip): global float atomics saturate at ~21 G/s chip-wide
-// whatever the scope or the grid size (L2 atomic units), i.e. 1e6 particles x 8 corners cost ~390 us.
-// LDS atomics are ~3 orders of magnitude more plentiful, so particles are first counting-sorted by the
-// TILE of their lower-corner cell (tile = 32x32 pixels or 16^3 cells), then one workgroup per tile
-// accumulates its particles into an LDS tile (+1 halo) with ds_add and flushes it once:
-//   pass 1  count     per-workgroup LDS histogram of tile ids              -> counts[tile][wg]
-//   pass 2  scan      exclusive prefix over (tile-major, wg-minor)          -> deterministic slot ranges
-//   pass 3  scatter   records {i_d, f_d, charge} to their slot (LDS cursors, no global atomics)
-//   pass 4  accumulate LDS tile per tile; interior cells are owned by exactly one tile (plain +=),
-//                      cells on tile borders receive from two or more tiles (global atomics, ~1/6 of cells)
+// whatever their scope or the grid size (L2 atomic units), i.e. 1e6 particles x 8 corners cost ~390 us.
+// LDS atomics are orders of magnitude more plentiful, so the grid is cut into small tiles (16x16 pixels /
+// 8^3 cells, doubled until <= 8192 tiles) and every tile is OWNED by one workgroup:
+//   pass 1  count     every particle is assigned to each tile its 2^d-corner footprint touches (1 tile for
+//                     most particles, up to 2^d at tile corners); per-workgroup LDS histogram -> counts[tile][wg]
+//   pass 2  scan      exclusive prefix over (tile-major, wg-minor): deterministic slot ranges, no atomics
+//   pass 3  scatter   records {i_d, f_d, charge} into their tile's slot range (LDS cursors)
+//   pass 4  accumulate one workgroup per tile: ds_add of the corners that fall into the OWNED cells, then a
+//                     plain, coalesced `grid += tile` (no global atomics anywhere, no halo exchange)
 // The index / weight arithmetic is the one of cic_locate / cic_deposit_kernel above (bit-identical addends).
 template <typename T, int ND>
 struct CicRec {
@@ -332,8 +332,7 @@ struct TileGeom {
 };
 
 // Small tiles balance the load (the hottest 8^3 brick of a Gaussian beam on a +-3 sigma 128^3 grid holds
-// 0.3 % of the particles, the hottest 16^3 brick 2.6 %); tile edges are doubled until the per-workgroup
-// histogram of tile ids fits 32 KiB of LDS (<= 8192 tiles).
+// 0.3 % of the particles); edges are doubled until the per-workgroup histogram fits 32 KiB of LDS.
 __host__ __device__ inline TileGeom tile_geom(int ndim, const int* bins) {
     TileGeom g;
     for (int d = 0; d < 3; ++d) g.tdim[d] = d < ndim ? (ndim == 2 ? 16 : 8) : 1;
@@ -351,55 +350,72 @@ __host__ __device__ inline TileGeom tile_geom(int ndim, const int* bins) {
     return g;
 }
 
-template <typename T, int ND>
-__device__ __forceinline__ int tile_of(const CicDev& a, const TileGeom& g, const CicPoint<T>& pt) {
-    int tile = 0;
-#pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        long long i = pt.i[d];
-        i = i < 0 ? 0 : (i > a.bins[d] - 1 ? a.bins[d] - 1 : i);
-        tile = tile * g.ntile[d] + (int)(i / g.tdim[d]);
-    }
-    return tile;
-}
+constexpr int kSortWG = 256;       // workgroups of the count / scatter passes (per batch row)
+constexpr int kSortThreads = 1024;  // threads of those workgroups (latency-bound loops: many waves)
 
-constexpr int kSortWG = 128;  // workgroups of the count / scatter passes (per batch row)
+// tiles touched per axis: [t0, t1] with t1 in {t0, t0 + 1}; cells outside the grid are never deposited
+template <typename T, int ND>
+__device__ __forceinline__ void tile_range(const CicDev& a, const TileGeom& g, const CicPoint<T>& pt,
+                                           int (&t0)[3], int (&t1)[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d < ND) {
+            long long lo = pt.i[d], hi = pt.i[d] + 1;
+            lo = lo < 0 ? 0 : lo;                               // corner -1 is invalid -> only cell 0 counts
+            hi = hi > a.bins[d] - 1 ? a.bins[d] - 1 : hi;       // corner n is invalid
+            if (lo > hi) lo = hi;
+            t0[d] = (int)(lo / g.tdim[d]);
+            t1[d] = (int)(hi / g.tdim[d]);
+        } else {
+            t0[d] = t1[d] = 0;
+        }
+    }
+}
 
 // pass 1 (SCATTER = false) and pass 3 (SCATTER = true) share the particle loop
 template <typename T, int ND, bool SCATTER>
-__global__ __launch_bounds__(CHX_BLOCK) void cic_sort_kernel(CicDev a, TileGeom g, const T* __restrict__ x,
-                                                            const T* __restrict__ q, const T* __restrict__ s,
-                                                            const T* __restrict__ extent,
-                                                            const T* __restrict__ scale,
-                                                            const T* __restrict__ shift,
-                                                            int* __restrict__ counts /*[B][nt][kSortWG]*/,
-                                                            const int* __restrict__ tile_start /*[B][nt+1]*/,
-                                                            CicRec<T, ND>* __restrict__ recs /*[B][N]*/) {
+__global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGeom g, const T* __restrict__ x,
+                                                               const T* __restrict__ q, const T* __restrict__ s,
+                                                               const T* __restrict__ extent,
+                                                               const T* __restrict__ scale,
+                                                               const T* __restrict__ shift,
+                                                               int* __restrict__ counts /*[B][nt][kSortWG]*/,
+                                                               const int* __restrict__ tile_start /*[B][nt+1]*/,
+                                                               CicRec<T, ND>* __restrict__ recs, int64_t rec_cap) {
     extern __shared__ int hist[];  // [nt]
     const int64_t b = blockIdx.y;
     const int wg = blockIdx.x;
-    for (int t = threadIdx.x; t < g.nt; t += CHX_BLOCK) hist[t] = 0;
+    for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] = 0;
     __syncthreads();
     const int64_t per = (a.N + kSortWG - 1) / kSortWG;
     const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
     int* cnt = counts + b * (int64_t)g.nt * kSortWG;
-    for (int64_t n = n0 + threadIdx.x; n < n1; n += CHX_BLOCK) {
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += kSortThreads) {
         const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n);
         if (!pt.inside) continue;
-        const int tile = tile_of<T, ND>(a, g, pt);
-        const int slot = atomicAdd(&hist[tile], 1);
+        int t0[3], t1[3];
+        tile_range<T, ND>(a, g, pt, t0, t1);
+        CicRec<T, ND> r;
         if (SCATTER) {
-            const int64_t pos = (int64_t)tile_start[b * (g.nt + 1) + tile] + cnt[(int64_t)tile * kSortWG + wg] + slot;
-            CicRec<T, ND> r;
 #pragma unroll
             for (int d = 0; d < ND; ++d) { r.i[d] = (int32_t)pt.i[d]; r.f[d] = pt.f[d]; }
             r.c = cic_charge<T>(a, q, s, b, n);
-            recs[b * a.N + pos] = r;
         }
+        for (int tx = t0[0]; tx <= t1[0]; ++tx)
+            for (int ty = t0[1]; ty <= t1[1]; ++ty)
+                for (int tz = t0[2]; tz <= t1[2]; ++tz) {
+                    const int tile = (tx * g.ntile[1] + ty) * g.ntile[2] + tz;
+                    const int slot = atomicAdd(&hist[tile], 1);
+                    if (SCATTER) {
+                        const int64_t pos = (int64_t)tile_start[b * (g.nt + 1) + tile] +
+                                            cnt[(int64_t)tile * kSortWG + wg] + slot;
+                        if (pos < rec_cap) recs[b * rec_cap + pos] = r;
+                    }
+                }
     }
     if (!SCATTER) {
         __syncthreads();
-        for (int t = threadIdx.x; t < g.nt; t += CHX_BLOCK) cnt[(int64_t)t * kSortWG + wg] = hist[t];
+        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) cnt[(int64_t)t * kSortWG + wg] = hist[t];
     }
 }
 
@@ -438,31 +454,34 @@ __global__ __launch_bounds__(1024) void cic_scan_totals_kernel(int* __restrict__
     for (int i = lo; i < hi; ++i) { const int t = v[i]; v[i] = run; run += t; }
 }
 
-// pass 4: one workgroup per (tile, batch row)
+// pass 4: one workgroup per (tile, batch row); LDS tile = exactly the owned cells
 template <typename T, int ND>
 __global__ __launch_bounds__(CHX_BLOCK) void cic_accumulate_kernel(CicDev a, TileGeom g,
                                                                   const int* __restrict__ tile_start,
                                                                   const CicRec<T, ND>* __restrict__ recs,
-                                                                  T* __restrict__ grid) {
+                                                                  int64_t rec_cap, T* __restrict__ grid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* tile = reinterpret_cast<T*>(smem);
     const int64_t b = blockIdx.y;
     const int t = blockIdx.x;
-    const int beg = tile_start[b * (g.nt + 1) + t], end = tile_start[b * (g.nt + 1) + t + 1];
-    if (beg == end) return;  // empty tile: nothing to add (caller zeroed the grid)
-    int tc[3], ld[3], org[3];  // tile coordinates, LDS extents (tdim+1), cell origin
+    const int beg = tile_start[b * (g.nt + 1) + t];
+    int end = tile_start[b * (g.nt + 1) + t + 1];
+    if (end > rec_cap) end = (int)rec_cap;
+    if (beg >= end) return;  // empty tile: nothing to add
+    int ld[3], org[3];       // owned extents and cell origin
     {
         int rem = t;
         for (int d = 2; d >= 0; --d) {
-            if (d < ND) { tc[d] = rem % g.ntile[d]; rem /= g.ntile[d]; } else tc[d] = 0;
-            ld[d] = d < ND ? g.tdim[d] + 1 : 1;
-            org[d] = tc[d] * g.tdim[d];
+            int tc = 0;
+            if (d < ND) { tc = rem % g.ntile[d]; rem /= g.ntile[d]; }
+            ld[d] = d < ND ? g.tdim[d] : 1;
+            org[d] = tc * ld[d];
         }
     }
     const int lcells = ld[0] * ld[1] * ld[2];
     for (int i = threadIdx.x; i < lcells; i += CHX_BLOCK) tile[i] = (T)0;
     __syncthreads();
-    const CicRec<T, ND>* rb = recs + b * a.N;
+    const CicRec<T, ND>* rb = recs + b * rec_cap;
     for (int r = beg + threadIdx.x; r < end; r += CHX_BLOCK) {
         const CicRec<T, ND> rec = rb[r];
         T wf[3][2];
@@ -474,8 +493,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_accumulate_kernel(CicDev a, Til
             for (int o = 0; o < 2; ++o) {
                 if (d < ND) {
                     const int id = rec.i[d] + o;
-                    ok[d][o] = (id >= 0) && (id < a.bins[d]);
-                    li[d][o] = id - org[d];
+                    const int l = id - org[d];
+                    // valid grid cell AND owned by this tile
+                    ok[d][o] = (id >= 0) && (id < a.bins[d]) && (l >= 0) && (l < ld[d]);
+                    li[d][o] = l;
                     wf[d][o] = o ? rec.f[d] : ((T)1.0 - rec.f[d]);
                 } else {
                     ok[d][o] = (o == 0); li[d][o] = 0; wf[d][o] = (T)1;
@@ -501,7 +522,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_accumulate_kernel(CicDev a, Til
         }
     }
     __syncthreads();
-    // flush: a cell whose local index is 0 or tdim on some axis is shared with a neighbouring tile
+    // flush the owned cells: exclusive owner -> plain read-modify-write, last axis fastest (coalesced)
     T* gb = grid + b * a.gbatch;
     for (int i = threadIdx.x; i < lcells; i += CHX_BLOCK) {
         const T v = tile[i];
@@ -511,29 +532,31 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_accumulate_kernel(CicDev a, Til
         l[2] = rem % ld[2]; rem /= ld[2];
         l[1] = rem % ld[1]; rem /= ld[1];
         l[0] = rem;
-        bool shared_cell = false, in_grid = true;
+        bool in_grid = true;
         int64_t off = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             if (d < ND) {
                 const int cell = org[d] + l[d];
                 in_grid = in_grid && cell < a.bins[d];
-                shared_cell = shared_cell || l[d] == 0 || l[d] == g.tdim[d];
                 off += (int64_t)cell * a.gstride[d];
             }
         }
-        if (!in_grid) continue;
-        if (shared_cell) unsafeAtomicAdd(gb + off, v);
-        else gb[off] += v;
+        if (in_grid) gb[off] += v;
     }
 }
+
+// record capacity per batch row: every particle can touch up to 2^ND tiles (only at tile corners); the
+// expected multiplicity is prod(1 + 1/tdim) ~ 1.13 (2-D, 16 px) .. 1.42 (3-D, 8 cells)
+template <int ND>
+int64_t rec_capacity(int64_t N) { return N * (1 << ND); }
 
 template <typename T, int ND>
 size_t sorted_ws_bytes(const CicDev& a, const TileGeom& g) {
     size_t bytes = (size_t)a.B * g.nt * kSortWG * sizeof(int);          // counts
     bytes += (size_t)a.B * (g.nt + 1) * sizeof(int);                    // tile starts
     bytes = (bytes + 255) & ~(size_t)255;
-    bytes += (size_t)a.B * a.N * sizeof(CicRec<T, ND>);                 // sorted records
+    bytes += (size_t)a.B * (size_t)rec_capacity<ND>(a.N) * sizeof(CicRec<T, ND>);  // sorted records
     return bytes;
 }
 
@@ -542,29 +565,31 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
     const TileGeom g = tile_geom(a.ndim, a.bins);
     if (workspace_bytes < sorted_ws_bytes<T, ND>(a, g)) return CHX_ERR_WORKSPACE;
     if ((size_t)g.nt * sizeof(int) > 64 * 1024) return CHX_ERR_INVALID_ARG;
+    if (rec_capacity<ND>(a.N) > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
     int* counts = (int*)workspace;
     int* starts = counts + (size_t)a.B * g.nt * kSortWG;
     size_t off = ((size_t)a.B * g.nt * kSortWG + (size_t)a.B * (g.nt + 1)) * sizeof(int);
     off = (off + 255) & ~(size_t)255;
     CicRec<T, ND>* recs = (CicRec<T, ND>*)((char*)workspace + off);
+    const int64_t cap = rec_capacity<ND>(a.N);
     const dim3 sgrid(kSortWG, (unsigned)a.B);
     const size_t hist_bytes = (size_t)g.nt * sizeof(int);
-    hipLaunchKernelGGL((cic_sort_kernel<T, ND, false>), sgrid, dim3(CHX_BLOCK), hist_bytes, s, a, g, (const T*)p->x,
+    hipLaunchKernelGGL((cic_sort_kernel<T, ND, false>), sgrid, dim3(kSortThreads), hist_bytes, s, a, g, (const T*)p->x,
                        (const T*)p->charge, (const T*)p->survival, (const T*)p->extent, (const T*)p->scale,
-                       (const T*)p->shift, counts, (const int*)starts, recs);
+                       (const T*)p->shift, counts, (const int*)starts, recs, cap);
     CHX_CHECK_LAUNCH();
     hipLaunchKernelGGL(cic_scan_tiles_kernel, dim3((g.nt + 255) / 256, (unsigned)a.B), dim3(256), 0, s, counts, starts, g.nt);
     CHX_CHECK_LAUNCH();
     hipLaunchKernelGGL(cic_scan_totals_kernel, dim3((unsigned)a.B), dim3(1024), 0, s, starts, g.nt);
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL((cic_sort_kernel<T, ND, true>), sgrid, dim3(CHX_BLOCK), hist_bytes, s, a, g, (const T*)p->x,
+    hipLaunchKernelGGL((cic_sort_kernel<T, ND, true>), sgrid, dim3(kSortThreads), hist_bytes, s, a, g, (const T*)p->x,
                        (const T*)p->charge, (const T*)p->survival, (const T*)p->extent, (const T*)p->scale,
-                       (const T*)p->shift, counts, (const int*)starts, recs);
+                       (const T*)p->shift, counts, (const int*)starts, recs, cap);
     CHX_CHECK_LAUNCH();
     size_t tile_bytes = sizeof(T);
-    for (int d = 0; d < ND; ++d) tile_bytes *= (size_t)(g.tdim[d] + 1);
+    for (int d = 0; d < ND; ++d) tile_bytes *= (size_t)g.tdim[d];
     hipLaunchKernelGGL((cic_accumulate_kernel<T, ND>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(CHX_BLOCK), tile_bytes, s,
-                       a, g, (const int*)starts, (const CicRec<T, ND>*)recs, (T*)p->grid);
+                       a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
