@@ -79,6 +79,38 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_tile_kernel(
     __syncthreads();
 
     const int64_t rb = (BR == 1) ? 0 : b;
+    if (MODE == 1) {
+        // fused run: all PPT rows of the lane stay in registers; the element loop is OUTSIDE the row loop so
+        // that every map is fetched into SGPRs once per lane and reused for PPT x 49 FMAs
+        T xs[PPT][7];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * CHX_BLOCK;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xs[k][j] = (p < np) ? lds[p * 7 + j] : (T)0;
+        }
+        for (int e = 0; e < E; ++e) {
+            const T* __restrict__ Re = R + ((int64_t)e * BR + rb) * 49;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                T y[7];
+                apply7<T>(Re, xs[k], y);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) xs[k][j] = y[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * CHX_BLOCK;
+            if (p < np) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = xs[k][j];
+            }
+        }
+        __syncthreads();
+        tile_store<T>(gout, lds, np * 7, out_vec);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = threadIdx.x + k * CHX_BLOCK;
@@ -174,6 +206,9 @@ int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coe
     constexpr int PPT = tile_cfg<T>::PPT;
     if (PPT > 1 && MODE == 0 && B * N * 7 * (int64_t)sizeof(T) > (int64_t)96 * 1024 * 1024)
         return launch_tiles_ppt<T, 1, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
+    // fused run: VALU-bound; 4 rows per lane amortise each map's scalar loads over 4 x 49 FMAs
+    if (MODE == 1 && E >= 4 && N >= 4 * CHX_BLOCK * 64)
+        return launch_tiles_ppt<T, 2 * PPT, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
     return launch_tiles_ppt<T, PPT, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
 }
 
@@ -276,16 +311,16 @@ extern "C" int chx_time_apply_ms(const void* x_in, const void* R, void* x_out, i
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CHX_ERR_LAUNCH;
     int st = chx_apply_affine7(x_in, R, x_out, B, Bx, BR, N, dtype, stream);  // warm
     if (st == CHX_OK) {
-        hipEventRecord(e0, s);
+        (void)hipEventRecord(e0, s);
         for (int i = 0; i < iters && st == CHX_OK; ++i)
             st = chx_apply_affine7(x_in, R, x_out, B, Bx, BR, N, dtype, stream);
-        hipEventRecord(e1, s);
+        (void)hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess) st = CHX_ERR_LAUNCH;
         float ms = 0.f;
         if (st == CHX_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *ms_out = (double)ms / iters;
         else if (st == CHX_OK) st = CHX_ERR_LAUNCH;
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return st;
 }

@@ -15,7 +15,6 @@ namespace {
 template <typename T> struct red_cfg;
 template <> struct red_cfg<float> { static constexpr int PPT = 2; };
 template <> struct red_cfg<double> { static constexpr int PPT = 1; };
-constexpr int kTileRows = 512;  // rows per tile used for sizing (max over dtypes)
 
 __host__ __device__ inline int64_t red_nblk(int64_t B, int64_t N, int tile_rows) {
     int64_t tiles = (N + tile_rows - 1) / tile_rows;
