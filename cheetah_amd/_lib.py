@@ -95,7 +95,7 @@ SIGNATURES = {
     "chx_sc_igf_workspace_bytes": (c_size_t, [c_i64, c_i32_p]),
     "chx_sc_igf": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_sc_spectral_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
-    "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_int, c_void_p, c_void_p]),
     "chx_sc_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),

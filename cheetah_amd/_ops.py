@@ -511,10 +511,12 @@ def sc_spectral_mul(rho_hat, G_hat, scale) -> None:
 
 
 def sc_gradient(phi, cell, gamma, bins) -> torch.Tensor:
+    """phi: doubled (B,2gx,2gy,2gz) or compact (B,gx,gy,gz) potential -> packed force grid (B,gx,gy,gz,4)."""
     B = phi.shape[0]
+    doubled = int(phi.shape[1] == 2 * bins[0])
     F = torch.empty((B, bins[0], bins[1], bins[2], 4), dtype=phi.dtype, device=phi.device)
-    check(_lib.lib().chx_sc_gradient(ptr(phi), ptr(cell), ptr(gamma), B, _bins3(bins), dtype_code(phi.dtype),
-                                     ptr(F), stream_ptr()), "chx_sc_gradient")
+    check(_lib.lib().chx_sc_gradient(ptr(phi), ptr(cell), ptr(gamma), B, _bins3(bins), doubled,
+                                     dtype_code(phi.dtype), ptr(F), stream_ptr()), "chx_sc_gradient")
     return F
 
 

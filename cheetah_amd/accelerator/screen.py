@@ -54,15 +54,38 @@ class Screen(Element):
     def effective_pixel_size(self) -> torch.Tensor:
         return self.pixel_size * self.binning
 
-    @property
-    def extent(self) -> torch.Tensor:
+    def _geometry(self, what: str):
+        """`extent` / `pixel_bin_edges` are a dozen tiny tensor ops (~100 us of launches): memoised against
+        the pixel-size tensor (identity, version), the resolution and the binning."""
+        ps = self.pixel_size
+        key = (id(ps), ps._version, self.resolution, self.binning)
+        cache = self.__dict__.get("_geom_cache")
+        if cache is None or cache["key"] != key:
+            cache = {"key": key, "pixel_size_ref": ps}
+            self.__dict__["_geom_cache"] = cache
+        if what not in cache:
+            cache[what] = self._compute_extent() if what == "extent" else self._compute_edges()
+        return cache[what]
+
+    def _compute_extent(self) -> torch.Tensor:
         return torch.stack([
             -self.resolution[0] * self.pixel_size[0] / 2, self.resolution[0] * self.pixel_size[0] / 2,
             -self.resolution[1] * self.pixel_size[1] / 2, self.resolution[1] * self.pixel_size[1] / 2,
         ])
 
     @property
+    def extent(self) -> torch.Tensor:
+        if self.pixel_size.requires_grad:
+            return self._compute_extent()
+        return self._geometry("extent")
+
+    @property
     def pixel_bin_edges(self) -> tuple[torch.Tensor, torch.Tensor]:
+        if self.pixel_size.requires_grad:
+            return self._compute_edges()
+        return self._geometry("edges")
+
+    def _compute_edges(self) -> tuple[torch.Tensor, torch.Tensor]:
         fk = {"device": self.pixel_size.device, "dtype": self.pixel_size.dtype}
         return (
             torch.linspace(-self.resolution[0] * self.pixel_size[0] / 2, self.resolution[0] * self.pixel_size[0] / 2,

@@ -31,6 +31,8 @@ class SpaceChargeKick(Element):
     """Applies the effect of space charge over `effect_length` as an instantaneous momentum kick."""
 
     supported_tracking_methods = ["linear"]
+    #: use the axis-by-axis pruned FFTs (class-level switch so both variants can be timed and compared)
+    pruned_fft = True
 
     def __init__(self, effect_length, grid_shape=(32, 32, 32), grid_extent_x=None, grid_extent_y=None,
                  grid_extent_tau=None, name=None, sanitize_name=None, metadata=None, device=None, dtype=None):
@@ -85,20 +87,36 @@ class SpaceChargeKick(Element):
 
         # charge deposition straight into the doubled array
         G2 = (2 * g[0], 2 * g[1], 2 * g[2])
-        rho = torch.zeros((B, *G2), dtype=dtype, device=device)
         scale = torch.stack([torch.ones_like(beta), torch.ones_like(beta), -beta], dim=-1).contiguous()
         extent = torch.stack([-half, half], dim=-1).contiguous()  # (B,3,2)
-        _ops.cic_deposit_into(rho, (G2[1] * G2[2], G2[2], 1), G2[0] * G2[1] * G2[2], x, (0, 2, 4), g, extent,
-                              charge=q, survival=w, scale=scale)
-
-        # Poisson solve by FFT convolution with the integrated Green function (space_charge_kick.py:293-322)
         green = _ops.sc_igf(cell, gamma, g)
-        rho_hat = torch.fft.rfftn(rho, dim=[1, 2, 3])
         green_hat = torch.fft.rfftn(green, dim=[1, 2, 3])
         inv_vol = cell.to(torch.float64).prod(dim=-1).reciprocal()
         pot_scale = (inv_vol / (4 * math.pi * epsilon_0)).contiguous()
-        _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
-        phi = torch.fft.irfftn(rho_hat, s=G2, dim=[1, 2, 3]).contiguous()
+
+        # Poisson solve by FFT convolution with the integrated Green function (space_charge_kick.py:293-322)
+        if self.pruned_fft:
+            # Hockney zero padding, pruned: the charge only occupies the first octant of the doubled array, so
+            # the forward transform pads one axis at a time (z lines of the g x g block, then y, then x) and the
+            # inverse crops one axis at a time — 58 % of the butterflies of the two full (2g)^3 transforms and no
+            # 8x zero-filled copy of rho.
+            rho = torch.zeros((B, *g), dtype=dtype, device=device)
+            _ops.cic_deposit_into(rho, (g[1] * g[2], g[2], 1), g[0] * g[1] * g[2], x, (0, 2, 4), g, extent,
+                                  charge=q, survival=w, scale=scale)
+            rho_hat = torch.fft.rfft(rho, n=G2[2], dim=3)
+            rho_hat = torch.fft.fft(rho_hat, n=G2[1], dim=2)
+            rho_hat = torch.fft.fft(rho_hat, n=G2[0], dim=1).contiguous()
+            _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
+            phi = torch.fft.ifft(rho_hat, dim=1)[:, : g[0]]
+            phi = torch.fft.ifft(phi, dim=2)[:, :, : g[1]]
+            phi = torch.fft.irfft(phi, n=G2[2], dim=3)[..., : g[2]].contiguous()
+        else:
+            rho = torch.zeros((B, *G2), dtype=dtype, device=device)
+            _ops.cic_deposit_into(rho, (G2[1] * G2[2], G2[2], 1), G2[0] * G2[1] * G2[2], x, (0, 2, 4), g, extent,
+                                  charge=q, survival=w, scale=scale)
+            rho_hat = torch.fft.rfftn(rho, dim=[1, 2, 3])
+            _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
+            phi = torch.fft.irfftn(rho_hat, s=G2, dim=[1, 2, 3]).contiguous()
 
         force = _ops.sc_gradient(phi, cell, gamma, g)
         out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)

@@ -106,10 +106,11 @@ template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void gradient_kernel(const T* __restrict__ phi,
                                                             const T* __restrict__ cell,
                                                             const T* __restrict__ gamma, int gx,
-                                                            int gy, int gz, T* __restrict__ F) {
+                                                            int gy, int gz, int doubled, T* __restrict__ F) {
     const int64_t b = blockIdx.y;
-    const int64_t GY = 2 * gy, GZ = 2 * gz;
-    const T* pb = phi + b * (int64_t)(2 * gx) * GY * GZ;
+    // phi is either the doubled Hockney array [2gx][2gy][2gz] (cropped on the fly) or already compact
+    const int64_t GY = doubled ? 2 * gy : gy, GZ = doubled ? 2 * gz : gz;
+    const T* pb = phi + b * (int64_t)(doubled ? 2 * gx : gx) * GY * GZ;
     const int64_t ncell = (int64_t)gx * gy * gz;
     const T gm = gamma[b];
     const T ig2 = (gm != (T)0) ? (T)1 / (gm * gm) : (T)0;
@@ -322,18 +323,18 @@ extern "C" int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const doubl
 }
 
 extern "C" int chx_sc_gradient(const void* phi, const void* cell, const void* gamma, int64_t B,
-                               const int32_t* bins, int dtype, void* F_out, void* stream) {
+                               const int32_t* bins, int phi_doubled, int dtype, void* F_out, void* stream) {
     if (!phi || !cell || !gamma || !F_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t ncell = (int64_t)bins[0] * bins[1] * bins[2];
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(gradient_kernel<float>, cell_grid(ncell, B), dim3(CHX_BLOCK), 0, s,
                            (const float*)phi, (const float*)cell, (const float*)gamma, bins[0], bins[1],
-                           bins[2], (float*)F_out);
+                           bins[2], phi_doubled, (float*)F_out);
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL(gradient_kernel<double>, cell_grid(ncell, B), dim3(CHX_BLOCK), 0, s,
                            (const double*)phi, (const double*)cell, (const double*)gamma, bins[0], bins[1],
-                           bins[2], (double*)F_out);
+                           bins[2], phi_doubled, (double*)F_out);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

@@ -219,10 +219,11 @@ int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bi
  * n_complex = complex elements per batch row; scale (double[B]) folds 1/(4 pi eps0) and 1/cell volume. */
 int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const double* scale, int64_t B,
                         int64_t n_complex, int dtype, void* stream);
-/* E+vxB force field from the potential (space_charge_kick.py:324-365): central differences
- * on the cropped [g]^3 part of phi[B][2gx][2gy][2gz], x -1/gamma^2; F_out[B][gx][gy][gz][4]. */
+/* E+vxB force field from the potential (space_charge_kick.py:324-365): central differences, x -1/gamma^2;
+ * phi is the doubled array phi[B][2gx][2gy][2gz] (cropped on the fly, phi_doubled = 1) or the compact
+ * phi[B][gx][gy][gz] (phi_doubled = 0); F_out[B][gx][gy][gz][4]. */
 int chx_sc_gradient(const void* phi, const void* cell, const void* gamma, int64_t B,
-                    const int32_t* bins, int dtype, void* F_out, void* stream);
+                    const int32_t* bins, int phi_doubled, int dtype, void* F_out, void* stream);
 /* Fused: to_xyz_pxpypz -> trilinear node-based gather -> p += F*dt -> from_xyz_pxpypz
  * (space_charge_kick.py:387-475,548-584; particle_beam.py:1262-1346).
  * half[B][3] grid half-widths, cell[B][3], energy[Be], dt[B] (all dtype). */
