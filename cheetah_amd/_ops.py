@@ -393,13 +393,70 @@ def _launch_cic(a: CicArgs, N: int, ndim: int, device, mode: str = "auto") -> No
     check(lib.chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
 
 
+class CicDeposit(torch.autograd.Function):
+    """Differentiable deposit (the reference's CIC is differentiable through torch ops,
+    utils/cloud_in_cell.py:14); backward = chx_cic_deposit_bwd: gradient wrt the particle coordinates
+    (through the corner weights) and wrt charges / survival probabilities."""
+
+    @staticmethod
+    def forward(ctx, particles, charge, survival, cols, bins, extent, scale, shift, abs_charge, transpose_2d, mode):
+        ctx.save_for_backward(particles, charge, survival, extent, scale, shift)
+        ctx.meta = (tuple(cols), tuple(bins), abs_charge, transpose_2d)
+        return _cic_deposit_raw(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge,
+                                transpose_2d, mode)
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        particles, charge, survival, extent, scale, shift = ctx.saved_tensors
+        cols, bins, abs_charge, transpose_2d = ctx.meta
+        nd = len(cols)
+        a, keep, batch_shape, B, N = _cic_args(particles.detach(), cols, bins, extent, charge, survival, scale, shift,
+                                               abs_charge)
+        total = numel(bins)
+        if transpose_2d:
+            a.grid_strides[0], a.grid_strides[1] = 1, bins[0]
+        a.grid_batch_stride = total
+        dg = dgrid.to(particles.dtype).reshape(B, total).contiguous()
+        dweight = torch.empty((B, N), dtype=particles.dtype, device=particles.device)
+        dpos = torch.empty((B, N, nd), dtype=particles.dtype, device=particles.device)
+        check(_lib.lib().chx_cic_deposit_bwd(ctypes.byref(a), ptr(dg), ptr(dweight), ptr(dpos), stream_ptr()),
+              "chx_cic_deposit_bwd")
+        dweight = dweight.reshape(*batch_shape, N)
+        dpos = dpos.reshape(*batch_shape, N, nd)
+        d_particles = d_charge = d_survival = None
+        if ctx.needs_input_grad[0]:
+            if scale is not None:
+                dpos = dpos * scale.unsqueeze(-2)
+            full = torch.zeros((*batch_shape, N, 7), dtype=particles.dtype, device=particles.device)
+            for d, c in enumerate(cols):
+                full[..., c] = dpos[..., d]
+            d_particles = full.sum_to_size(particles.shape)
+        if charge is not None and ctx.needs_input_grad[1]:
+            s_ = survival if survival is not None else 1.0
+            d_charge = (dweight * s_ * (charge.sign() if abs_charge else 1.0)).sum_to_size(charge.shape)
+        if survival is not None and ctx.needs_input_grad[2]:
+            c_ = (charge.abs() if abs_charge else charge) if charge is not None else 1.0
+            d_survival = (dweight * c_).sum_to_size(survival.shape)
+        return d_particles, d_charge, d_survival, None, None, None, None, None, None, None, None
+
+
 def cic_deposit(particles, cols, bins, extent, charge=None, survival=None, scale=None, shift=None,
                 abs_charge=False, transpose_2d=False, mode: str = "auto") -> torch.Tensor:
     """Cloud-in-cell deposition (utils/cloud_in_cell.py:8-451) of columns `cols` of the 7-vectors.
 
     Returns (*batch, *bins); with transpose_2d the 2-D image is written directly as (bins[1], bins[0])
-    (the `.mT` of screen.py:339).
+    (the `.mT` of screen.py:339). Differentiable wrt particles / charge / survival.
     """
+    if particles.requires_grad or (charge is not None and charge.requires_grad) or (
+            survival is not None and survival.requires_grad):
+        return CicDeposit.apply(particles, charge, survival, cols, bins, extent, scale, shift, abs_charge,
+                                transpose_2d, mode)
+    return _cic_deposit_raw(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge, transpose_2d,
+                            mode)
+
+
+def _cic_deposit_raw(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge, transpose_2d,
+                     mode) -> torch.Tensor:
     bins = [int(b) for b in bins]
     a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge)
     total = numel(bins)

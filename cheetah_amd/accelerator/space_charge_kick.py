@@ -31,8 +31,11 @@ class SpaceChargeKick(Element):
     """Applies the effect of space charge over `effect_length` as an instantaneous momentum kick."""
 
     supported_tracking_methods = ["linear"]
-    #: use the axis-by-axis pruned FFTs (class-level switch so both variants can be timed and compared)
-    pruned_fft = True
+    #: axis-by-axis pruned FFTs (class-level switch so both variants can be timed, benchmarks/sc_fft_ab.py).
+    #: Measured on MI355X: SLOWER than the two full (2g)^3 hipFFT transforms (1.44 vs 1.16 ms per kick at
+    #: 128^3, 0.64 vs 0.60 ms at 32^3) — the strided 1-D passes through torch.fft cost more than the pruned
+    #: butterflies save — so the full transforms stay the default.
+    pruned_fft = False
 
     def __init__(self, effect_length, grid_shape=(32, 32, 32), grid_extent_x=None, grid_extent_y=None,
                  grid_extent_tau=None, name=None, sanitize_name=None, metadata=None, device=None, dtype=None):

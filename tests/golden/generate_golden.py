@@ -539,8 +539,42 @@ def gen_grad():
     save("grad_k1.npz", **arrays)
 
 
+def gen_screen_grad():
+    """Gradient of a weighted Screen.reading (cloud-in-cell) wrt quadrupole k1, particles and charges."""
+    torch.manual_seed(77)
+    arrays = {}
+    N = 2000
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        t = lambda v: torch.tensor(v, dtype=dt)  # noqa: E731
+        torch.manual_seed(77)
+        beam = cheetah.ParticleBeam.from_parameters(num_particles=N, sigma_x=t(2e-4), sigma_y=t(3e-4), dtype=torch.float64).to(dt)
+        k1 = torch.nn.Parameter(t(2.5))
+        seg = cheetah.Segment(elements=[cheetah.Quadrupole(length=t(0.3), k1=k1, dtype=dt), cheetah.Drift(length=t(0.5), dtype=dt),
+                                        cheetah.Screen(resolution=(40, 30), pixel_size=t([5e-5, 6e-5]), misalignment=t([1e-4, -5e-5]),
+                                                       is_active=True, method="cloud-in-cell", name="scr", dtype=dt)])
+        parts = beam.particles.clone().requires_grad_(True)
+        q = beam.particle_charges.clone().requires_grad_(True)
+        b = cheetah.ParticleBeam(parts, beam.energy, particle_charges=q, dtype=dt)
+        seg.track(b)
+        img = seg.scr.reading
+        W = torch.linspace(0.5, 1.5, 40 * 30, dtype=dt).reshape(30, 40).sin()
+        loss = (img * W).sum() * 1e15
+        loss.backward()
+        arrays[f"in_{tag}"] = npy(beam.particles)
+        arrays[f"q_{tag}"] = npy(beam.particle_charges)
+        arrays[f"W_{tag}"] = npy(W)
+        arrays[f"loss_{tag}"] = npy(loss)
+        arrays[f"img_{tag}"] = npy(img)
+        arrays[f"dk1_{tag}"] = npy(k1.grad)
+        arrays[f"dparticles_{tag}"] = npy(parts.grad)
+        arrays[f"dq_{tag}"] = npy(q.grad)
+        arrays[f"species_{tag}"] = np.asarray(species_meta(b.species))
+        arrays[f"energy_{tag}"] = npy(b.energy)
+    save("screen_grad.npz", **arrays)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["maps", "consistency", "segment_readme", "fodo100", "k1scan", "cavity", "moments",
-                             "cic", "screen", "space_charge", "grad"]
+                             "cic", "screen", "space_charge", "grad", "screen_grad"]
     for w in which:
         globals()["gen_" + w]()
