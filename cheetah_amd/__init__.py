@@ -25,6 +25,6 @@ from .accelerator import (  # noqa: F401
     SpaceChargeKick,
     VerticalCorrector,
 )
-from .particles import ParticleBeam, Species  # noqa: F401
+from .particles import ParameterBeam, ParticleBeam, Species  # noqa: F401
 
 __version__ = "0.1.0"

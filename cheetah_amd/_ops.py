@@ -607,6 +607,45 @@ def from_xyz_pxpypz(xp, energy, mass_eV):
     return _si("chx_from_xyz_pxpypz", xp, energy, mass_eV)
 
 
+# ---------------------------------------------------------------------------------------------
+# ParameterBeam path
+def parameter_track(mu, cov, tm, cavity_coeffs=None, batch_shape=None):
+    """mu (…,7), cov (…,7,7), tm (…,7,7) -> (mu', cov') = (tm mu, tm cov tm^T) (element.py:167-179)."""
+    require_device(mu, cov, tm)
+    if batch_shape is None:
+        batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], tm.shape[:-2])
+    B = numel(batch_shape)
+    m, Bm = flat_bcast(mu, batch_shape, 1)
+    c, Bc = flat_bcast(cov, batch_shape, 2)
+    R, BR = flat_bcast(tm.to(mu.dtype), batch_shape, 2)
+    m, c, R = m.contiguous(), c.contiguous(), R.contiguous()
+    mu_out = torch.empty((B, 7), dtype=mu.dtype, device=mu.device)
+    cov_out = torch.empty((B, 7, 7), dtype=mu.dtype, device=mu.device)
+    check(_lib.lib().chx_parameter_track(ptr(m), ptr(c), ptr(R), ptr(cavity_coeffs), B, Bm, Bc, BR,
+                                         dtype_code(mu.dtype), ptr(mu_out), ptr(cov_out), stream_ptr()),
+          "chx_parameter_track")
+    return mu_out.reshape(*batch_shape, 7), cov_out.reshape(*batch_shape, 7, 7)
+
+
+def screen_gaussian(mu, cov, shift, geom, width: int, height: int) -> torch.Tensor:
+    """Bivariate-normal screen image (…, height, width) of a ParameterBeam (screen.py:255-291)."""
+    require_device(mu, cov, geom)
+    batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], shift.shape[:-1] if shift is not None else ())
+    B = numel(batch_shape)
+    m, Bm = flat_bcast(mu, batch_shape, 1)
+    c, Bc = flat_bcast(cov, batch_shape, 2)
+    m, c = m.contiguous(), c.contiguous()
+    sh, Bsh = (None, 1)
+    if shift is not None:
+        sh, Bsh = flat_bcast(shift.to(mu.dtype), batch_shape, 1)
+        sh = sh.contiguous()
+    geom = geom.to(mu.dtype).contiguous()
+    img = torch.empty((B, height, width), dtype=mu.dtype, device=mu.device)
+    check(_lib.lib().chx_screen_gaussian(ptr(m), ptr(c), ptr(sh), ptr(geom), B, Bm, Bc, Bsh, width, height,
+                                         dtype_code(mu.dtype), ptr(img), stream_ptr()), "chx_screen_gaussian")
+    return img.reshape(*batch_shape, height, width)
+
+
 def time_apply_ms(x, R, out, B, Bx, BR, N, iters) -> float:
     ms = ctypes.c_double(0.0)
     check(_lib.lib().chx_time_apply_ms(ptr(x), ptr(R), ptr(out), B, Bx, BR, N, dtype_code(x.dtype), iters,

@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from .. import _ops
+from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from .element import Element
 
@@ -56,7 +57,33 @@ class Cavity(Element):
     def is_skippable(self) -> bool:
         return not self.is_active
 
+    def _track_parameter_beam(self, incoming):
+        """cavity.py:108-110,127-133,202-218,229-239: matrix part plus the reference's moment updates, one kernel."""
+        dtype = incoming.mu.dtype
+        tm = self.first_order_transfer_map(incoming.energy, incoming.species)
+        tensors = [t.to(dtype) for t in self._builder_params()]
+        energy = incoming.energy.to(dtype)
+        _ops.require_device(incoming.mu, energy, *tensors)
+        pshape = torch.broadcast_shapes(*[t.shape for t in tensors])
+        batch_shape = torch.broadcast_shapes(pshape, energy.shape, incoming.mu.shape[:-1], incoming.cov.shape[:-2])
+        B = _ops.numel(batch_shape)
+        if len(pshape) == 0:
+            params = torch.stack(tensors).reshape(1, 4)
+        else:
+            params = torch.stack([t.expand(batch_shape) for t in tensors], dim=-1).reshape(B, 4)
+        e = energy.reshape(1) if energy.dim() == 0 else energy.expand(batch_shape).reshape(B).contiguous()
+        sp = incoming.species
+        coeffs, e_out = _ops.cavity_coeffs(params.contiguous(), e, sp.mass_eV_float, sp.num_elementary_charges_float, B)
+        vshape = torch.broadcast_shapes(pshape, energy.shape)
+        e_out = e_out.reshape(batch_shape)
+        if tuple(vshape) != tuple(batch_shape):
+            idx = tuple(0 for _ in range(len(batch_shape) - len(vshape)))
+            e_out = e_out[idx].reshape(vshape) if idx else e_out.reshape(vshape)
+        return incoming._tracked(tm, self.length, cavity_coeffs=coeffs, energy=e_out, batch_shape=batch_shape)
+
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if isinstance(incoming, ParameterBeam):
+            return self._track_parameter_beam(incoming)
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
         dtype = incoming.particles.dtype

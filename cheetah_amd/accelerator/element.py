@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import _ops
+from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
 
@@ -115,6 +116,9 @@ class Element(nn.Module):
         return self._track_first_order(incoming)
 
     def _track_first_order(self, incoming: ParticleBeam) -> ParticleBeam:
+        if isinstance(incoming, ParameterBeam):  # element.py:167-179
+            tm = self.first_order_transfer_map(incoming.energy, incoming.species)
+            return incoming._tracked(tm, self.length)
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
         tm = self.first_order_transfer_map(incoming.energy, incoming.species)

@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from .. import _ops
+from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from .element import Element
 
@@ -107,6 +108,10 @@ class Screen(Element):
             self.__dict__["_read_beam"] = None
             self.__dict__["_cached_reading"] = None
         if self.is_active and self.is_blocking:
+            if isinstance(incoming, ParameterBeam):
+                return ParameterBeam(incoming.mu, incoming.cov, incoming.energy,
+                                     total_charge=torch.zeros_like(incoming.total_charge), s=incoming.s,
+                                     species=incoming.species)
             return ParticleBeam(incoming.particles, incoming.energy, particle_charges=incoming.particle_charges,
                                 survival_probabilities=torch.zeros_like(incoming.survival_probabilities),
                                 s=incoming.s, species=incoming.species)
@@ -121,6 +126,11 @@ class Screen(Element):
         w, h = self.effective_resolution
         if beam is None:
             image = self.misalignment.new_zeros((int(h), int(w)))
+        elif isinstance(beam, ParameterBeam):
+            # bivariate normal density sampled at the pixel origins (screen.py:255-291)
+            ext = self.extent
+            geom = torch.stack([ext[0], self.pixel_size[0] * self.binning, ext[2], self.pixel_size[1] * self.binning])
+            image = _ops.screen_gaussian(beam.mu, beam.cov, self.misalignment, geom, int(w), int(h))
         elif self.method == "histogram":
             if beam.particles.dim() > 2 or beam.particle_charges.dim() > 1 or beam.energy.dim() > 0:
                 raise NotImplementedError("The 'histogram' method of Screen does not support vectorization. "
@@ -139,10 +149,13 @@ class Screen(Element):
         """The beam as seen by the screen, i.e. with x, y relative to the screen centre (screen.py:196-214)."""
         if self.__dict__.get("_read_beam") is None and self.__dict__.get("_incoming") is not None:
             inc = self.__dict__["_incoming"]
-            tm = torch.eye(7, dtype=inc.particles.dtype, device=inc.particles.device).repeat(
-                *self.misalignment.shape[:-1], 1, 1)
+            ref = inc.mu if isinstance(inc, ParameterBeam) else inc.particles
+            tm = torch.eye(7, dtype=ref.dtype, device=ref.device).repeat(*self.misalignment.shape[:-1], 1, 1)
             tm[..., 0, 6] = -self.misalignment[..., 0]
             tm[..., 2, 6] = -self.misalignment[..., 1]
+            if isinstance(inc, ParameterBeam):
+                self.__dict__["_read_beam"] = inc._tracked(tm, None)  # mu_x -= mx, mu_y -= my; cov unchanged
+                return self.__dict__["_read_beam"]
             shifted = _ops.apply_map(inc.particles, tm)  # x -= mx, y -= my through the apply kernel
             self.__dict__["_read_beam"] = ParticleBeam(
                 shifted, inc.energy, particle_charges=inc.particle_charges,

@@ -26,6 +26,7 @@ import torch
 from torch import nn
 
 from .. import _ops
+from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
 from .element import Element
@@ -195,6 +196,16 @@ class Segment(Element):
 
     # ---- tracking ---------------------------------------------------------------------------------------
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if isinstance(incoming, ParameterBeam):
+            for kind, item in self._plan():
+                if kind == "run":
+                    tm = self._run_map(item, incoming.energy, incoming.species)
+                    mu, cov = _ops.parameter_track(incoming.mu, incoming.cov, tm)
+                    incoming = ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge,
+                                             s=self._run_s(item, incoming.s), species=incoming.species)
+                else:
+                    incoming = item.track(incoming)
+            return incoming
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
         for kind, item in self._plan():

@@ -1,0 +1,123 @@
+// chx_parameter.hip — ParameterBeam path: a beam described by its mean vector and
+// covariance matrix is tracked as  mu' = R mu,  cov' = R cov R^T  (cheetah/accelerator/element.py:167-179),
+// the cavity applies the reference's moment updates (cavity.py:127-133, 202-218), and a Screen reads the beam
+// as a bivariate normal density on the pixel grid (screen.py:255-291). All of it is O(49) work per batch row:
+// these kernels exist so that a vectorised ParameterBeam scan (thousands of lattice settings, the usual RL
+// workload) stays on the device without a chain of tiny torch ops per element.
+#include "chx_common.h"
+
+namespace {
+
+// one wavefront per batch row; lane (i, j) owns one entry of the 7x7 result
+template <typename T>
+__global__ __launch_bounds__(64) void parameter_track_kernel(const T* __restrict__ mu, const T* __restrict__ cov,
+                                                            const T* __restrict__ R,
+                                                            const double* __restrict__ coeffs, int64_t Bmu,
+                                                            int64_t Bcov, int64_t BR, T* __restrict__ mu_out,
+                                                            T* __restrict__ cov_out) {
+    __shared__ double r[49], c[49], m[7], tmp[49];
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = lane / 7, j = lane - 7 * i;
+    if (lane < 49) {
+        r[lane] = (double)R[(BR == 1 ? 0 : b) * 49 + lane];
+        c[lane] = (double)cov[(Bcov == 1 ? 0 : b) * 49 + lane];
+    }
+    if (lane < 7) m[lane] = (double)mu[(Bmu == 1 ? 0 : b) * 7 + lane];
+    __syncthreads();
+    if (lane < 49) {  // tmp = R cov
+        double s = 0.0;
+        for (int k = 0; k < 7; ++k) s = fma(r[i * 7 + k], c[k * 7 + j], s);
+        tmp[lane] = s;
+    }
+    __syncthreads();
+    double cov_ij = 0.0, mu_i = 0.0;
+    if (lane < 49) {  // cov' = tmp R^T
+        for (int k = 0; k < 7; ++k) cov_ij = fma(tmp[i * 7 + k], r[j * 7 + k], cov_ij);
+    }
+    if (lane < 7) {
+        for (int k = 0; k < 7; ++k) mu_i = fma(r[lane * 7 + k], m[k], mu_i);
+    }
+    if (coeffs) {
+        // cavity moment updates with the INCOMING moments (cavity.py:127-133, 202-218);
+        // cf = [a, b, k*beta0, phi, cos phi, T566, T556, T555]
+        const double* cf = coeffs + b * CHX_CAV_NCOEF;
+        const double mu4 = m[4], mu5 = m[5], c44 = c[4 * 7 + 4], c45 = c[4 * 7 + 5], c55 = c[5 * 7 + 5];
+        if (lane == 5) mu_i = mu5 * cf[0] + cf[1] * (cos(-mu4 * cf[2] + cf[3]) - cf[4]);
+        if (lane == 4) mu_i = mu_i + (cf[5] * mu5 * mu5 + cf[6] * mu4 * mu5 + cf[7] * mu4 * mu4);
+        const double q = cf[5] * c55 * c55 + cf[6] * c45 * c55 + cf[7] * c44 * c44;
+        if (lane == 5 * 7 + 5) cov_ij = c55;
+        if (lane == 4 * 7 + 4 || lane == 4 * 7 + 5 || lane == 5 * 7 + 4) cov_ij = q;
+    }
+    if (lane < 49) cov_out[b * 49 + lane] = (T)cov_ij;
+    if (lane < 7) mu_out[b * 7 + lane] = (T)mu_i;
+}
+
+// image[b][iy][ix] = N2(pos; mu_xy, cov_xy) at pos = (left + ix hstep, bottom + iy vstep)  (screen.py:277-291)
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __restrict__ mu, const T* __restrict__ cov,
+                                                                   const T* __restrict__ shift,
+                                                                   const T* __restrict__ geom /*[left,hstep,bottom,vstep]*/,
+                                                                   int64_t Bmu, int64_t Bcov, int64_t Bsh, int W,
+                                                                   int H, T* __restrict__ image) {
+    const int64_t b = blockIdx.y;
+    const T* m = mu + (Bmu == 1 ? 0 : b) * 7;
+    const T* c = cov + (Bcov == 1 ? 0 : b) * 49;
+    const double sx = shift ? (double)shift[(Bsh == 1 ? 0 : b) * 2] : 0.0;
+    const double sy = shift ? (double)shift[(Bsh == 1 ? 0 : b) * 2 + 1] : 0.0;
+    const double mx = (double)m[0] - sx, my = (double)m[2] - sy;
+    const double cxx = (double)c[0], cxy = (double)c[2], cyy = (double)c[2 * 7 + 2];
+    const double det = cxx * cyy - cxy * cxy;
+    const double norm = 1.0 / (2.0 * 3.14159265358979323846 * sqrt(det));
+    const double left = (double)geom[0], hstep = (double)geom[1], bottom = (double)geom[2], vstep = (double)geom[3];
+    const int64_t npx = (int64_t)W * H;
+    for (int64_t p = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; p < npx; p += (int64_t)gridDim.x * CHX_BLOCK) {
+        const int iy = (int)(p / W), ix = (int)(p - (int64_t)iy * W);
+        const double dx = left + ix * hstep - mx, dy = bottom + iy * vstep - my;
+        const double quad = (cyy * dx * dx - 2.0 * cxy * dx * dy + cxx * dy * dy) / det;
+        image[b * npx + p] = (T)(norm * exp(-0.5 * quad));
+    }
+}
+
+}  // namespace
+
+extern "C" int chx_parameter_track(const void* mu, const void* cov, const void* R, const double* cavity_coeffs,
+                                   int64_t B, int64_t Bmu, int64_t Bcov, int64_t BR, int dtype, void* mu_out,
+                                   void* cov_out, void* stream) {
+    if (!mu || !cov || !R || !mu_out || !cov_out || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B) || !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(parameter_track_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, (const float*)mu,
+                           (const float*)cov, (const float*)R, cavity_coeffs, Bmu, Bcov, BR, (float*)mu_out,
+                           (float*)cov_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(parameter_track_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)mu,
+                           (const double*)cov, (const double*)R, cavity_coeffs, Bmu, Bcov, BR, (double*)mu_out,
+                           (double*)cov_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_screen_gaussian(const void* mu, const void* cov, const void* shift, const void* geom, int64_t B,
+                                   int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height, int dtype,
+                                   void* image, void* stream) {
+    if (!mu || !cov || !geom || !image || B < 1 || B > 65535 || width < 1 || height < 1) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B) || (shift && !chx_bcast_ok(Bsh, B))) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t g = ((int64_t)width * height + CHX_BLOCK - 1) / CHX_BLOCK;
+    if (g > 4096) g = 4096;
+    dim3 grid((unsigned)g, (unsigned)B);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(screen_gaussian_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)mu, (const float*)cov,
+                           (const float*)shift, (const float*)geom, Bmu, Bcov, Bsh, width, height, (float*)image);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(screen_gaussian_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)mu, (const double*)cov,
+                           (const double*)shift, (const double*)geom, Bmu, Bcov, Bsh, width, height, (double*)image);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}

@@ -1,2 +1,3 @@
+from .parameter_beam import ParameterBeam  # noqa: F401
 from .particle_beam import ParticleBeam  # noqa: F401
 from .species import Species  # noqa: F401

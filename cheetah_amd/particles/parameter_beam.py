@@ -1,0 +1,143 @@
+"""ParameterBeam (mirror of cheetah/particles/parameter_beam.py:8-779): a beam described by its 7-vector of means
+`mu (…, 7)` (last entry 1) and its covariance matrix `cov (…, 7, 7)` (last row / column 0).
+
+Tracking is `mu' = R mu`, `cov' = R cov R^T` through the `chx_parameter_track` kernel
+(cheetah/accelerator/element.py:167-179); this is the representation most RL environments track.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _ops
+from .beam import Beam
+from .species import Species
+
+_COORDS = ["x", "px", "y", "py", "tau", "p"]
+
+
+class ParameterBeam(Beam):
+    """Gaussian beam given by `mu` and `cov`."""
+
+    def __init__(self, mu, cov, energy, total_charge=None, s=None, species=None, device=None, dtype=None) -> None:
+        super().__init__()
+        device = device if device is not None else mu.device
+        dtype = dtype if dtype is not None else mu.dtype
+        fk = {"device": device, "dtype": dtype}
+        assert mu.shape[-1] == 7 and cov.shape[-2:] == (7, 7), "mu must be (…, 7) and cov (…, 7, 7)"
+        self.species = species if species is not None else Species("electron", **fk)
+        for name, value in (("mu", mu), ("cov", cov), ("energy", energy),
+                            ("total_charge", total_charge if total_charge is not None else torch.tensor(0.0, **fk)),
+                            ("s", s if s is not None else torch.tensor(0.0, **fk))):
+            if isinstance(value, torch.nn.Parameter):
+                self.register_parameter(name, value)
+            else:
+                self.register_buffer(name, value)
+
+    # ------------------------------------------------------------------ factories
+    @classmethod
+    def from_parameters(cls, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None, mu_p=None, sigma_x=None,
+                        sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None, sigma_p=None, cov_xpx=None,
+                        cov_ypy=None, cov_taup=None, cov_xp=None, cov_pxp=None, cov_yp=None, cov_pyp=None,
+                        cov_xy=None, cov_xpy=None, cov_xtau=None, cov_pxy=None, cov_pxpy=None, cov_pxtau=None,
+                        cov_ytau=None, cov_pytau=None, energy=None, total_charge=None, s=None, species=None,
+                        device=None, dtype=None) -> "ParameterBeam":
+        """parameter_beam.py:61-280 (same defaults)."""
+        fk = {"device": device, "dtype": dtype}
+        d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
+        mus = torch.broadcast_tensors(d(mu_x, 0.0), d(mu_px, 0.0), d(mu_y, 0.0), d(mu_py, 0.0), d(mu_tau, 0.0),
+                                      d(mu_p, 0.0))
+        mu = torch.stack([*mus, torch.ones_like(mus[0])], dim=-1)
+        entries = {
+            (0, 0): d(sigma_x, 175e-6).square(), (1, 1): d(sigma_px, 4e-6).square(), (2, 2): d(sigma_y, 175e-6).square(),
+            (3, 3): d(sigma_py, 4e-6).square(), (4, 4): d(sigma_tau, 8e-6).square(), (5, 5): d(sigma_p, 2e-3).square(),
+            (0, 1): d(cov_xpx, 0.0), (2, 3): d(cov_ypy, 0.0), (4, 5): d(cov_taup, 0.0), (0, 5): d(cov_xp, 0.0),
+            (1, 5): d(cov_pxp, 0.0), (2, 5): d(cov_yp, 0.0), (3, 5): d(cov_pyp, 0.0), (0, 2): d(cov_xy, 0.0),
+            (0, 3): d(cov_xpy, 0.0), (0, 4): d(cov_xtau, 0.0), (1, 2): d(cov_pxy, 0.0), (1, 3): d(cov_pxpy, 0.0),
+            (1, 4): d(cov_pxtau, 0.0), (2, 4): d(cov_ytau, 0.0), (3, 4): d(cov_pytau, 0.0),
+        }
+        shape = torch.broadcast_shapes(*[v.shape for v in entries.values()])
+        cov = torch.zeros(*shape, 7, 7, **fk)
+        for (i, j), v in entries.items():
+            cov[..., i, j] = v
+            cov[..., j, i] = v
+        try:
+            torch.linalg.cholesky(cov[..., :6, :6])
+        except RuntimeError as e:
+            raise ValueError("The covariance matrix of the beam must be positive definite. Please check the input "
+                             "parameters to ensure that they are consistent.") from e
+        energy = energy if energy is not None else torch.tensor(1e8, **fk)
+        return cls(mu=mu, cov=cov, energy=energy, total_charge=total_charge, s=s, species=species, device=device,
+                   dtype=dtype)
+
+    @classmethod
+    def from_twiss(cls, beta_x=None, alpha_x=None, emittance_x=None, beta_y=None, alpha_y=None, emittance_y=None,
+                   energy=None, sigma_tau=None, sigma_p=None, cov_taup=None, total_charge=None, s=None, species=None,
+                   device=None, dtype=None) -> "ParameterBeam":
+        """parameter_beam.py:282-414 (without dispersion arguments)."""
+        fk = {"device": device, "dtype": dtype}
+        d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
+        beta_x, alpha_x, emittance_x = d(beta_x, 1.0), d(alpha_x, 0.0), d(emittance_x, 7.1971891e-13)
+        beta_y, alpha_y, emittance_y = d(beta_y, 1.0), d(alpha_y, 0.0), d(emittance_y, 7.1971891e-13)
+        return cls.from_parameters(
+            sigma_x=(emittance_x * beta_x).sqrt(), sigma_px=(emittance_x * (1 + alpha_x.square()) / beta_x).sqrt(),
+            sigma_y=(emittance_y * beta_y).sqrt(), sigma_py=(emittance_y * (1 + alpha_y.square()) / beta_y).sqrt(),
+            sigma_tau=d(sigma_tau, 1e-6), sigma_p=d(sigma_p, 1e-6), cov_xpx=-emittance_x * alpha_x,
+            cov_ypy=-emittance_y * alpha_y, cov_taup=d(cov_taup, 0.0), energy=d(energy, 1e8),
+            total_charge=total_charge, s=s, species=species, device=device, dtype=dtype)
+
+    def transformed_to(self, energy=None, total_charge=None, species=None, **moments) -> "ParameterBeam":
+        """New beam with some moments replaced (parameter_beam.py:476-586): unspecified mu_* / sigma_* / cov_* keep
+        their current value."""
+        current = {f"mu_{c}": getattr(self, f"mu_{c}") for c in _COORDS}
+        current.update({f"sigma_{c}": getattr(self, f"sigma_{c}") for c in _COORDS})
+        for i in range(6):
+            for j in range(i + 1, 6):
+                name = f"cov_{_COORDS[i]}{_COORDS[j]}"
+                current[name] = getattr(self, name)
+        unknown = set(moments) - set(current)
+        if unknown:
+            raise TypeError(f"unknown beam parameters {sorted(unknown)}")
+        current.update({k: v for k, v in moments.items() if v is not None})
+        return self.__class__.from_parameters(
+            **current, energy=energy if energy is not None else self.energy,
+            total_charge=total_charge if total_charge is not None else self.total_charge, s=self.s,
+            species=species if species is not None else self.species, device=self.mu.device, dtype=self.mu.dtype)
+
+    def as_particle_beam(self, num_particles: int):
+        """parameter_beam.py:588-608."""
+        from .particle_beam import ParticleBeam
+
+        return ParticleBeam.from_distribution(num_particles=num_particles, mu=self.mu[..., :6], cov=self.cov[..., :6, :6],
+                                              energy=self.energy, total_charge=self.total_charge, s=self.s,
+                                              species=self.species, device=self.mu.device, dtype=self.mu.dtype)
+
+    # ------------------------------------------------------------------ tracking primitive
+    def _tracked(self, tm: torch.Tensor, length, cavity_coeffs=None, energy=None, batch_shape=None) -> "ParameterBeam":
+        mu, cov = _ops.parameter_track(self.mu, self.cov, tm, cavity_coeffs, batch_shape)
+        return self.__class__(mu, cov, self.energy if energy is None else energy, total_charge=self.total_charge,
+                              s=self.s + length if length is not None else self.s, species=self.species)
+
+    def _view(self) -> "ParameterBeam":
+        return self.__class__(self.mu, self.cov, self.energy, total_charge=self.total_charge, s=self.s,
+                              species=self.species)
+
+    def clone(self) -> "ParameterBeam":
+        return self.__class__(mu=self.mu.clone(), cov=self.cov.clone(), energy=self.energy.clone(),
+                              total_charge=self.total_charge.clone(), s=self.s.clone(), species=self.species.clone())
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(mu={self.mu!r}, cov={self.cov!r}, energy={self.energy!r}, "
+                f"total_charge={self.total_charge!r}, s={self.s!r}, species={self.species!r})")
+
+
+def _install_moment_properties() -> None:
+    for i, name in enumerate(_COORDS):
+        setattr(ParameterBeam, f"mu_{name}", property(lambda self, i=i: self.mu[..., i]))
+        setattr(ParameterBeam, f"sigma_{name}", property(lambda self, i=i: self.cov[..., i, i].clamp_min(0).sqrt()))
+    for i in range(6):
+        for j in range(i + 1, 6):
+            setattr(ParameterBeam, f"cov_{_COORDS[i]}{_COORDS[j]}", property(lambda self, i=i, j=j: self.cov[..., i, j]))
+
+
+_install_moment_properties()

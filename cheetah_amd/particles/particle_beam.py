@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from .. import _ops
+from .beam import Beam
 from .species import Species
 
 _COORDS = ["x", "px", "y", "py", "tau", "p"]
@@ -28,7 +29,7 @@ def _tri(i: int, j: int) -> int:
     return 8 + i * 6 - (i * (i - 1)) // 2 + (j - i)
 
 
-class ParticleBeam(nn.Module):
+class ParticleBeam(Beam):
     """Beam of macro-particles, each a 7-vector (x, px, y, py, tau, p, 1)."""
 
     def __init__(self, particles, energy, particle_charges=None, survival_probabilities=None, s=None,

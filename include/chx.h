@@ -237,6 +237,20 @@ int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int6
 int chx_from_xyz_pxpypz(const void* xp_in, const void* energy, double mass_eV, int64_t B,
                         int64_t Bx, int64_t Be, int64_t N, int dtype, void* x_out, void* stream);
 
+/* ---- ParameterBeam path (element.py:167-179, cavity.py:127-133,202-218,
+ * screen.py:255-291). mu[Bmu][7], cov[Bcov][7][7], R[BR][7][7]: mu' = R mu, cov' = R cov R^T (fp64 inside).
+ * With cavity_coeffs (double [B][CHX_CAV_NCOEF] from chx_cavity_coeffs) the reference's cavity moment
+ * updates are applied on top (mu_tau, mu_delta, cov_tautau, cov_taudelta, cov_deltadelta). */
+int chx_parameter_track(const void* mu, const void* cov, const void* R, const double* cavity_coeffs, int64_t B,
+                        int64_t Bmu, int64_t Bcov, int64_t BR, int dtype, void* mu_out, void* cov_out,
+                        void* stream);
+/* Screen reading of a ParameterBeam: bivariate normal density of (x - shift_x, y - shift_y) sampled at
+ * (left + ix*hstep, bottom + iy*vstep); geom = [left, hstep, bottom, vstep] (dtype, device);
+ * image[B][height][width]. */
+int chx_screen_gaussian(const void* mu, const void* cov, const void* shift, const void* geom, int64_t B,
+                        int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height, int dtype,
+                        void* image, void* stream);
+
 /* ---- instrumentation: average duration (ms) of `iters` back-to-back launches of the apply
  * kernel on `stream`, measured with hipEvents recorded on that stream. Used by bench.py for
  * roofline.achieved. Synchronises the stream (the only entry point that does). */

@@ -573,8 +573,58 @@ def gen_screen_grad():
     save("screen_grad.npz", **arrays)
 
 
+def gen_parameter_beam():
+    """Row f2: ParameterBeam tracking — the reference's own ParameterBeam consistency goldens re-exported, plus
+    an active-cavity / screen-reading segment and a vectorised scan (fp64)."""
+    incoming32 = load_incoming()
+    incoming = incoming32.to(torch.float64).as_parameter_beam()
+    arrays = {"mu": npy(incoming.mu), "cov": npy(incoming.cov), "energy": npy(incoming.energy),
+              "total_charge": npy(incoming.total_charge), "species": np.asarray(species_meta(incoming.species))}
+    wanted = ["Drift_ParameterBeam_linear", "Quadrupole_ParameterBeam_linear", "Dipole_ParameterBeam_linear",
+              "RBend_ParameterBeam_linear", "HorizontalCorrector_ParameterBeam_default",
+              "VerticalCorrector_ParameterBeam_default", "CombinedCorrector_ParameterBeam_default",
+              "Cavity_ParameterBeam_default", "CustomTransferMap_ParameterBeam_identity",
+              "Marker_ParameterBeam_default", "Screen_ParameterBeam_default", "Segment_ParameterBeam_default"]
+    for name in wanted:
+        with open(os.path.join(REF, "tests/resources/consistency_expected_outgoing", name + ".pkl"), "rb") as f:
+            exp = pickle.load(f)
+        arrays[f"{name}__mu"] = npy(exp.mu)
+        arrays[f"{name}__cov"] = npy(exp.cov)
+        arrays[f"{name}__energy"] = npy(exp.energy)
+        arrays[f"{name}__s"] = npy(exp.s)
+    # active cavities (SW / TW, vectorised voltage) + README segment with screen reading
+    f64 = torch.float64
+    t = lambda v: torch.tensor(v, dtype=f64)  # noqa: E731
+    beam = cheetah.ParameterBeam.from_parameters(mu_x=t(1e-4), mu_py=t(-2e-6), sigma_tau=t(1e-4), sigma_p=t(1e-3),
+                                                 cov_xpx=t(2e-10), energy=t(6e6), total_charge=t(1e-10), dtype=f64)
+    arrays["b_mu"], arrays["b_cov"] = npy(beam.mu), npy(beam.cov)
+    for i, (ctype, V) in enumerate((("standing_wave", 18.15975e6), ("traveling_wave", 18.15975e6),
+                                    ("standing_wave", [18.15975e6, -1.0e6, 5e6]))):
+        cav = cheetah.Cavity(length=t(1.0377), voltage=t(V), phase=t(30.0), frequency=t(1.3e9), cavity_type=ctype, dtype=f64)
+        out = cav.track(beam)
+        arrays[f"cav{i}_mu"], arrays[f"cav{i}_cov"], arrays[f"cav{i}_energy"] = npy(out.mu), npy(out.cov), npy(out.energy)
+    seg = readme_segment(f64)
+    seg.AREABSCR1.is_active = True
+    seg.AREABSCR1.resolution = (200, 160)
+    seg.AREABSCR1.pixel_size = t([2e-5, 3e-5])
+    seg.AREABSCR1.misalignment = t([1e-4, -2e-4])
+    b2 = cheetah.ParameterBeam.from_twiss(beta_x=t(3.14), beta_y=t(42.0), energy=t(1e8), dtype=f64)
+    out = seg.track(b2)
+    arrays["seg_in_mu"], arrays["seg_in_cov"] = npy(b2.mu), npy(b2.cov)
+    arrays["seg_out_mu"], arrays["seg_out_cov"], arrays["seg_out_s"] = npy(out.mu), npy(out.cov), npy(out.s)
+    arrays["seg_reading"] = npy(seg.AREABSCR1.reading)
+    for n in ("sigma_x", "sigma_y", "beta_x", "alpha_x", "emittance_x", "emittance_y"):
+        arrays["seg_" + n] = npy(getattr(out, n))
+    # vectorised k1 scan
+    k1 = torch.linspace(-30, 30, 64, dtype=f64)
+    seg2 = ares_subcell(f64, k1)
+    out2 = seg2.track(b2)
+    arrays["scan_k1"], arrays["scan_mu"], arrays["scan_cov"] = npy(k1), npy(out2.mu), npy(out2.cov)
+    save("parameter_beam.npz", **arrays)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["maps", "consistency", "segment_readme", "fodo100", "k1scan", "cavity", "moments",
-                             "cic", "screen", "space_charge", "grad", "screen_grad"]
+                             "cic", "screen", "space_charge", "grad", "screen_grad", "parameter_beam"]
     for w in which:
         globals()["gen_" + w]()
