@@ -100,7 +100,7 @@ SIGNATURES = {
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_parameter_track": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
-    "chx_screen_gaussian": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, ctypes.c_int32, c_int, c_void_p, c_void_p]),
+    "chx_screen_gaussian": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, ctypes.c_int32, c_int, c_int, c_void_p, c_void_p]),
     "chx_time_apply_ms": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_void_p, c_double_p]),
 }
 

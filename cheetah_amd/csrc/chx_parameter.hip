@@ -59,7 +59,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __r
                                                                    const T* __restrict__ shift,
                                                                    const T* __restrict__ geom /*[left,hstep,bottom,vstep]*/,
                                                                    int64_t Bmu, int64_t Bcov, int64_t Bsh, int W,
-                                                                   int H, T* __restrict__ image) {
+                                                                   int H, int pos_f32, T* __restrict__ image) {
     const int64_t b = blockIdx.y;
     const T* m = mu + (Bmu == 1 ? 0 : b) * 7;
     const T* c = cov + (Bcov == 1 ? 0 : b) * 49;
@@ -73,7 +73,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __r
     const int64_t npx = (int64_t)W * H;
     for (int64_t p = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; p < npx; p += (int64_t)gridDim.x * CHX_BLOCK) {
         const int iy = (int)(p / W), ix = (int)(p - (int64_t)iy * W);
-        const double dx = left + ix * hstep - mx, dy = bottom + iy * vstep - my;
+        // The reference builds the pixel grid with torch.arange(left, right, hstep) WITHOUT a dtype, i.e. in
+        // torch's default dtype (screen.py:284-287): with the usual float32 default the sample positions are
+        // fp32-rounded even for an fp64 screen. ATen evaluates start + i*step in double and rounds once.
+        double px = left + ix * hstep, py = bottom + iy * vstep;
+        if (pos_f32) { px = (double)(float)px; py = (double)(float)py; }
+        const double dx = px - mx, dy = py - my;
         const double quad = (cyy * dx * dx - 2.0 * cxy * dx * dy + cxx * dy * dy) / det;
         image[b * npx + p] = (T)(norm * exp(-0.5 * quad));
     }
@@ -102,8 +107,8 @@ extern "C" int chx_parameter_track(const void* mu, const void* cov, const void* 
 }
 
 extern "C" int chx_screen_gaussian(const void* mu, const void* cov, const void* shift, const void* geom, int64_t B,
-                                   int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height, int dtype,
-                                   void* image, void* stream) {
+                                   int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height,
+                                   int positions_fp32, int dtype, void* image, void* stream) {
     if (!mu || !cov || !geom || !image || B < 1 || B > 65535 || width < 1 || height < 1) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B) || (shift && !chx_bcast_ok(Bsh, B))) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -112,10 +117,10 @@ extern "C" int chx_screen_gaussian(const void* mu, const void* cov, const void* 
     dim3 grid((unsigned)g, (unsigned)B);
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(screen_gaussian_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)mu, (const float*)cov,
-                           (const float*)shift, (const float*)geom, Bmu, Bcov, Bsh, width, height, (float*)image);
+                           (const float*)shift, (const float*)geom, Bmu, Bcov, Bsh, width, height, positions_fp32, (float*)image);
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL(screen_gaussian_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)mu, (const double*)cov,
-                           (const double*)shift, (const double*)geom, Bmu, Bcov, Bsh, width, height, (double*)image);
+                           (const double*)shift, (const double*)geom, Bmu, Bcov, Bsh, width, height, positions_fp32, (double*)image);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

@@ -246,10 +246,11 @@ int chx_parameter_track(const void* mu, const void* cov, const void* R, const do
                         void* stream);
 /* Screen reading of a ParameterBeam: bivariate normal density of (x - shift_x, y - shift_y) sampled at
  * (left + ix*hstep, bottom + iy*vstep); geom = [left, hstep, bottom, vstep] (dtype, device);
- * image[B][height][width]. */
+ * positions_fp32 != 0 rounds the sample positions to fp32 (the reference's torch.arange grid is created in
+ * torch's default dtype, screen.py:284-287); image[B][height][width]. */
 int chx_screen_gaussian(const void* mu, const void* cov, const void* shift, const void* geom, int64_t B,
-                        int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height, int dtype,
-                        void* image, void* stream);
+                        int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height,
+                        int positions_fp32, int dtype, void* image, void* stream);
 
 /* ---- instrumentation: average duration (ms) of `iters` back-to-back launches of the apply
  * kernel on `stream`, measured with hipEvents recorded on that stream. Used by bench.py for
