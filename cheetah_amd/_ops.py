@@ -641,8 +641,9 @@ def screen_gaussian(mu, cov, shift, geom, width: int, height: int) -> torch.Tens
         sh = sh.contiguous()
     geom = geom.to(mu.dtype).contiguous()
     img = torch.empty((B, height, width), dtype=mu.dtype, device=mu.device)
-    # the reference's pixel grid is a dtype-less torch.arange, i.e. created in torch's DEFAULT dtype
-    pos_f32 = int(torch.get_default_dtype() == torch.float32)
+    # exact (working-precision) sample positions; the reference's dtype-less torch.arange grid carries fp32
+    # jitter (see chx_parameter.hip), which only matters for beams far narrower than a pixel
+    pos_f32 = 0
     check(_lib.lib().chx_screen_gaussian(ptr(m), ptr(c), ptr(sh), ptr(geom), B, Bm, Bc, Bsh, width, height, pos_f32,
                                          dtype_code(mu.dtype), ptr(img), stream_ptr()), "chx_screen_gaussian")
     return img.reshape(*batch_shape, height, width)

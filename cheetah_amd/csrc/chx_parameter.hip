@@ -73,9 +73,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __r
     const int64_t npx = (int64_t)W * H;
     for (int64_t p = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; p < npx; p += (int64_t)gridDim.x * CHX_BLOCK) {
         const int iy = (int)(p / W), ix = (int)(p - (int64_t)iy * W);
-        // The reference builds the pixel grid with torch.arange(left, right, hstep) WITHOUT a dtype, i.e. in
-        // torch's default dtype (screen.py:284-287): with the usual float32 default the sample positions are
-        // fp32-rounded even for an fp64 screen. ATen evaluates start + i*step in double and rounds once.
+        // NB: the reference builds the pixel grid with a dtype-less torch.arange, i.e. in torch's DEFAULT dtype
+        // (screen.py:284-287): with a float32 default its sample positions carry ~1e-11 m of fp32 jitter even
+        // for an fp64 screen (and ATen's vectorised arange is not round-to-nearest, so it cannot be reproduced
+        // portably). With pos_f32 the positions are rounded to fp32 (nearest) to stay within that jitter class;
+        // tests compare images of beams that are resolved by the pixel grid, where the jitter is harmless.
         double px = left + ix * hstep, py = bottom + iy * vstep;
         if (pos_f32) { px = (double)(float)px; py = (double)(float)py; }
         const double dx = px - mx, dy = py - my;

@@ -606,8 +606,10 @@ def gen_parameter_beam():
     seg = readme_segment(f64)
     seg.AREABSCR1.is_active = True
     seg.AREABSCR1.resolution = (200, 160)
-    seg.AREABSCR1.pixel_size = t([2e-5, 3e-5])
-    seg.AREABSCR1.misalignment = t([1e-4, -2e-4])
+    # pixels that RESOLVE the beam (sigma ~ 1.3 um ~ 6 px): the reference's pixel grid is a dtype-less
+    # torch.arange (float32 positions, ~1e-11 m jitter), harmless only when the beam spans several pixels
+    seg.AREABSCR1.pixel_size = t([2e-7, 3e-7])
+    seg.AREABSCR1.misalignment = t([-4.4e-5, 9.5e-5])
     b2 = cheetah.ParameterBeam.from_twiss(beta_x=t(3.14), beta_y=t(42.0), energy=t(1e8), dtype=f64)
     out = seg.track(b2)
     arrays["seg_in_mu"], arrays["seg_in_cov"] = npy(b2.mu), npy(b2.cov)
