@@ -22,7 +22,10 @@ from .accelerator import (  # noqa: F401
     RBend,
     Screen,
     Segment,
+    Sextupole,
+    Solenoid,
     SpaceChargeKick,
+    Undulator,
     VerticalCorrector,
 )
 from .particles import ParameterBeam, ParticleBeam, Species  # noqa: F401

@@ -16,9 +16,9 @@ from ._lib import CicArgs, Hist2dArgs, check
 
 KIND = {
     "identity": 0, "drift": 1, "quadrupole": 2, "dipole": 3, "hcor": 4, "vcor": 5, "ccor": 6,
-    "cavity_sw": 7, "cavity_tw": 8,
+    "cavity_sw": 7, "cavity_tw": 8, "solenoid": 9, "undulator": 10,
 }
-NUM_PARAMS = [0, 1, 5, 9, 2, 2, 3, 4, 4]
+NUM_PARAMS = [0, 1, 5, 9, 2, 2, 3, 4, 4, 4, 4]
 MOM_NOUT = 29
 CAV_NCOEF = 8
 

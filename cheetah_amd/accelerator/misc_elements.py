@@ -1,0 +1,105 @@
+"""Remaining linear elements of SURVEY section 8 row f3 (mirror of cheetah/accelerator/solenoid.py:41-116,
+undulator.py:41-125, sextupole.py:47-88): their first-order maps come from the same `chx_build_rmatrix`
+kernel (kinds SOLENOID / UNDULATOR / DRIFT) and are tracked by the same apply kernel."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _ops
+from .element import Element
+
+
+class Solenoid(Element):
+    """Hard-edge solenoid with transverse misalignment."""
+
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["solenoid"]
+
+    def __init__(self, length, k=None, misalignment=None, name=None, sanitize_name=None, metadata=None, device=None,
+                 dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        self.length = length
+        self.register_buffer_or_parameter("k", k if k is not None else torch.tensor(0.0, **fk))
+        self.register_buffer_or_parameter(
+            "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+
+    def _builder_params(self):
+        return [self.length, self.k, self.misalignment[..., 0], self.misalignment[..., 1]]
+
+    @property
+    def is_active(self) -> bool:
+        return bool((self.k != 0).any().item())
+
+    @property
+    def is_skippable(self) -> bool:
+        return True
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length", "k", "misalignment"]
+
+
+class Undulator(Element):
+    """Planar / helical undulator (linear focusing only, no radiation)."""
+
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["undulator"]
+
+    def __init__(self, length, kx=None, ky=None, period=None, is_active=False, name=None, sanitize_name=None,
+                 metadata=None, device=None, dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        self.length = length
+        self.register_buffer_or_parameter("kx", kx if kx is not None else torch.tensor(0.0, **fk))
+        self.register_buffer_or_parameter("ky", ky if ky is not None else torch.tensor(0.0, **fk))
+        self.register_buffer_or_parameter("period", period if period is not None else torch.tensor(0.0, **fk))
+
+    def _builder_params(self):
+        return [self.length, self.kx, self.ky, self.period]
+
+    @property
+    def is_active(self) -> bool:
+        return bool(torch.logical_or(self.kx != 0.0, self.ky != 0.0).any().item())
+
+    @property
+    def is_skippable(self) -> bool:
+        return True
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length", "kx", "ky", "period"]
+
+
+class Sextupole(Element):
+    """Sextupole: a drift in first order (sextupole.py:85-88); `second_order` tracking is not provided."""
+
+    supported_tracking_methods = ["linear"]
+    _chx_kind = _ops.KIND["drift"]
+
+    def __init__(self, length, k2=None, misalignment=None, tilt=None, tracking_method="linear", name=None,
+                 sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        self.length = length
+        self.register_buffer_or_parameter("k2", k2 if k2 is not None else torch.tensor(0.0, **fk))
+        self.register_buffer_or_parameter(
+            "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+        self.register_buffer_or_parameter("tilt", tilt if tilt is not None else torch.tensor(0.0, **fk))
+        self.tracking_method = tracking_method
+
+    def _builder_params(self):
+        return [self.length]
+
+    @property
+    def is_active(self) -> bool:
+        return bool((self.k2 != 0).any().item())
+
+    @property
+    def is_skippable(self) -> bool:
+        return self.tracking_method == "linear"
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length", "k2", "misalignment", "tilt"]

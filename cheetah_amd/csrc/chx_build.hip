@@ -304,6 +304,55 @@ __device__ void cavity_map(const S* p, S energy, double mass, double nq, bool st
     R(4, 4) = r55; R(4, 5) = r56; R(5, 4) = r65; R(5, 5) = r66;
 }
 
+// solenoid.py:75-116 (row f3): thin-lens-free hard-edge solenoid, then the (un-rotated) misalignment shift
+template <typename S>
+__device__ void solenoid_map(const S* p, S energy, double mass, Mat7<S>& R) {
+    const S L = p[0], k = p[1], mx = p[2], my = p[3];
+    const S gamma = energy / mass;
+    const S c = m_cos(L * k), s = m_sin(L * k);
+    S Cu, Su, Gu, Fu;
+    const S lk = L * k;
+    sinc_family<S>(lk * lk, Cu, Su, Gu, Fu);  // Su = sin(Lk)/(Lk) with its limit 1
+    const S s_k = Su * L;
+    Mat7<S> body, entry, exitm, tmp;
+    eye7(body);
+    body(0, 0) = c * c;      body(0, 1) = c * s_k;  body(0, 2) = s * c;       body(0, 3) = s * s_k;
+    body(1, 0) = -k * s * c; body(1, 1) = c * c;    body(1, 2) = -k * s * s;  body(1, 3) = s * c;
+    body(2, 0) = -s * c;     body(2, 1) = -s * s_k; body(2, 2) = c * c;       body(2, 3) = c * s_k;
+    body(3, 0) = k * s * s;  body(3, 1) = -s * c;   body(3, 2) = -k * s * c;  body(3, 3) = c * c;
+    body(4, 5) = L / (1.0 - gamma * gamma);
+    eye7(entry);
+    eye7(exitm);
+    entry(0, 6) = -mx; entry(2, 6) = -my;  // track_methods.py:326-342
+    exitm(0, 6) = mx;  exitm(2, 6) = my;
+    matmul7(body, entry, tmp);
+    matmul7(exitm, tmp, R);
+}
+
+// undulator.py:79-125 (row f3)
+template <typename S>
+__device__ void undulator_map(const S* p, S energy, double mass, Mat7<S>& R) {
+    const S L = p[0], kx = p[1], ky = p[2], period = p[3];
+    S g, ig2, beta;
+    rel_factors(energy, mass, g, ig2, beta);
+    eye7(R);
+    R(4, 5) = -L * ig2 * (1.0 / (beta * beta) + 0.5 * (kx * kx + ky * ky));
+    S sf = cst<S>(0.0);
+    if (val(period) > 0.0) sf = (1.4142135623730951 * kPi) / (period * g * beta);
+    {
+        const S w = sf * kx, wl = w * L;
+        S Cu, Su, Gu, Fu;
+        sinc_family<S>(wl * wl, Cu, Su, Gu, Fu);
+        R(2, 2) = m_cos(wl); R(2, 3) = Su * L; R(3, 2) = -m_sin(wl) * w; R(3, 3) = m_cos(wl);
+    }
+    {
+        const S w = sf * ky, wl = w * L;
+        S Cu, Su, Gu, Fu;
+        sinc_family<S>(wl * wl, Cu, Su, Gu, Fu);
+        R(0, 0) = m_cos(wl); R(0, 1) = Su * L; R(1, 0) = -m_sin(wl) * w; R(1, 1) = m_cos(wl);
+    }
+}
+
 template <typename S>
 __device__ void build_kind(int kind, const S* p, S energy, double mass, double nq, Mat7<S>& R) {
     switch (kind) {
@@ -316,6 +365,8 @@ __device__ void build_kind(int kind, const S* p, S energy, double mass, double n
         case CHX_CCOR: drift_map<S>(p[0], energy, mass, R); R(1, 6) = p[1]; R(3, 6) = p[2]; break;
         case CHX_CAVITY_SW: cavity_map<S>(p, energy, mass, nq, true, R); break;
         case CHX_CAVITY_TW: cavity_map<S>(p, energy, mass, nq, false, R); break;
+        case CHX_SOLENOID: solenoid_map<S>(p, energy, mass, R); break;
+        case CHX_UNDULATOR: undulator_map<S>(p, energy, mass, R); break;
         default: eye7(R); break;
     }
 }
@@ -331,6 +382,8 @@ __host__ __device__ inline int kind_num_params(int kind) {
         case CHX_CCOR: return 3;
         case CHX_CAVITY_SW: return 4;
         case CHX_CAVITY_TW: return 4;
+        case CHX_SOLENOID: return 4;
+        case CHX_UNDULATOR: return 4;
         default: return -1;
     }
 }

@@ -60,7 +60,9 @@ typedef enum chx_kind {
     CHX_CCOR = 6,       /* P=3  [L,hangle,vangle]                    combined_corrector.py:77-98 */
     CHX_CAVITY_SW = 7,  /* P=4  [L,voltage,phase_deg,frequency]      cavity.py:253-358 (standing wave) */
     CHX_CAVITY_TW = 8,  /* P=4  same, traveling wave                 cavity.py:310-335 */
-    CHX_KIND_COUNT = 9
+    CHX_SOLENOID = 9,   /* P=4  [L,k,mis_x,mis_y]                    solenoid.py:75-116  (row f3) */
+    CHX_UNDULATOR = 10, /* P=4  [L,kx,ky,period]                     undulator.py:79-125 (row f3) */
+    CHX_KIND_COUNT = 11
 } chx_kind;
 
 #define CHX_MAX_PARAMS 9

@@ -208,9 +208,44 @@ static void cavity_map(const double* p, double energy, double mass, double nq, i
     R[4 * 7 + 4] = r55; R[4 * 7 + 5] = r56; R[5 * 7 + 4] = r65; R[5 * 7 + 5] = r66;
 }
 
+/* solenoid.py:75-116 */
+static void solenoid_map(const double* p, double energy, double mass, double* R) {
+    const double L = p[0], k = p[1], mx = p[2], my = p[3];
+    const double gamma = energy / mass;
+    const double c = cos(L * k), s = sin(L * k);
+    const double s_k = (L * k != 0.0 ? sin(L * k) / (L * k) : 1.0) * L; /* sinc(L k / pi) * L */
+    double body[49], entry[49], exitm[49], t[49];
+    eye7(body);
+    body[0] = c * c;       body[1] = c * s_k;   body[2] = s * c;        body[3] = s * s_k;
+    body[7] = -k * s * c;  body[8] = c * c;     body[9] = -k * s * s;   body[10] = s * c;
+    body[14] = -s * c;     body[15] = -s * s_k; body[16] = c * c;       body[17] = c * s_k;
+    body[21] = k * s * s;  body[22] = -s * c;   body[23] = -k * s * c;  body[24] = c * c;
+    body[4 * 7 + 5] = L / (1.0 - gamma * gamma);
+    eye7(entry); eye7(exitm);               /* track_methods.py:326-342 */
+    entry[0 * 7 + 6] = -mx; entry[2 * 7 + 6] = -my;
+    exitm[0 * 7 + 6] = mx;  exitm[2 * 7 + 6] = my;
+    mm7(body, entry, t);
+    mm7(exitm, t, R);
+}
+
+/* undulator.py:79-125 */
+static void undulator_map(const double* p, double energy, double mass, double* R) {
+    const double L = p[0], kx = p[1], ky = p[2], period = p[3];
+    double g, ig2, beta;
+    rel_factors(energy, mass, &g, &ig2, &beta);
+    eye7(R);
+    R[4 * 7 + 5] = -L * ig2 * (1.0 / (beta * beta) + 0.5 * (kx * kx + ky * ky));
+    const double sf = period > 0.0 ? sqrt(2.0) * kPi / (period * g * beta) : 0.0;
+    const double wx = sf * kx, wy = sf * ky;
+    R[2 * 7 + 2] = cos(wx * L); R[2 * 7 + 3] = (wx * L != 0.0 ? sin(wx * L) / (wx * L) : 1.0) * L;
+    R[3 * 7 + 2] = -sin(wx * L) * wx; R[3 * 7 + 3] = cos(wx * L);
+    R[0] = cos(wy * L); R[1] = (wy * L != 0.0 ? sin(wy * L) / (wy * L) : 1.0) * L;
+    R[7] = -sin(wy * L) * wy; R[8] = cos(wy * L);
+}
+
 static int kind_np(int kind) {
-    static const int np[9] = {0, 1, 5, 9, 2, 2, 3, 4, 4};
-    return (kind >= 0 && kind < 9) ? np[kind] : -1;
+    static const int np[11] = {0, 1, 5, 9, 2, 2, 3, 4, 4, 4, 4};
+    return (kind >= 0 && kind < 11) ? np[kind] : -1;
 }
 
 /* params/energy/R_out are double here (the oracle is dtype-agnostic for the tiny maps) */
@@ -232,6 +267,8 @@ CHXO_API int chxo_build_rmatrix(int kind, const double* params, const double* en
             case 6: drift_matrix(p[0], en, mass, R); R[1 * 7 + 6] = p[1]; R[3 * 7 + 6] = p[2]; break; /* combined_corrector.py:92-96 */
             case 7: cavity_map(p, en, mass, nq, 1, R); break;
             case 8: cavity_map(p, en, mass, nq, 0, R); break;
+            case 9: solenoid_map(p, en, mass, R); break;
+            case 10: undulator_map(p, en, mass, R); break;
         }
     }
     return 0;

@@ -30,8 +30,10 @@ KIND = {
     "ccor": 6,
     "cavity_sw": 7,
     "cavity_tw": 8,
+    "solenoid": 9,
+    "undulator": 10,
 }
-NUM_PARAMS = [0, 1, 5, 9, 2, 2, 3, 4, 4]
+NUM_PARAMS = [0, 1, 5, 9, 2, 2, 3, 4, 4, 4, 4]
 
 EPSILON_0 = 8.8541878188e-12  # scipy.constants.epsilon_0 (CODATA 2022)
 SPEED_OF_LIGHT = 299792458.0

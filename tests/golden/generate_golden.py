@@ -625,8 +625,36 @@ def gen_parameter_beam():
     save("parameter_beam.npz", **arrays)
 
 
+def gen_misc_elements():
+    """Row f3: Solenoid / Undulator / Sextupole(linear) maps and the reference's consistency goldens for them."""
+    f64 = {"dtype": torch.float64}
+    t = lambda v: torch.tensor(v, **f64)  # noqa: E731
+    elec = cheetah.Species("electron", **f64)
+    arrays = {}
+    i = 0
+    for E in (6e6, 1e8):
+        for (L, k, mx, my) in [(1.0, 1.0, 0.01, -0.02), (1.0, -2.0, 0.01, -0.02), (0.5, 0.0, 0.0, 0.0), (0.3, 7.5, 0.0, 1e-3)]:
+            el = cheetah.Solenoid(length=t(L), k=t(k), misalignment=t([mx, my]), **f64)
+            arrays[f"m{i}_kind"], arrays[f"m{i}_params"], arrays[f"m{i}_energy"] = np.asarray("solenoid"), np.asarray([L, k, mx, my]), np.asarray(E)
+            arrays[f"m{i}_R"] = npy(el.first_order_transfer_map(t(E), elec))
+            i += 1
+        for (L, kx, ky, per) in [(1.0, 1.3, 0.0, 0.1), (2.0, 0.0, 0.9, 0.05), (1.0, 1.3, 0.7, 0.1), (1.0, 1.3, 0.0, 0.0), (0.5, 0.0, 0.0, 0.1)]:
+            el = cheetah.Undulator(length=t(L), kx=t(kx), ky=t(ky), period=t(per), **f64)
+            arrays[f"m{i}_kind"], arrays[f"m{i}_params"], arrays[f"m{i}_energy"] = np.asarray("undulator"), np.asarray([L, kx, ky, per]), np.asarray(E)
+            arrays[f"m{i}_R"] = npy(el.first_order_transfer_map(t(E), elec))
+            i += 1
+    arrays["n_cases"] = np.asarray(i)
+    keep = 512
+    for name in ("Solenoid_ParticleBeam_default", "Undulator_ParticleBeam_default", "Sextupole_ParticleBeam_linear"):
+        with open(os.path.join(REF, "tests/resources/consistency_expected_outgoing", name + ".pkl"), "rb") as f:
+            exp = pickle.load(f)
+        arrays[f"{name}__particles"] = npy(exp.particles)[..., :keep, :]
+    arrays["keep"] = np.asarray(keep)
+    save("misc_elements.npz", **arrays)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["maps", "consistency", "segment_readme", "fodo100", "k1scan", "cavity", "moments",
-                             "cic", "screen", "space_charge", "grad", "screen_grad", "parameter_beam"]
+                             "cic", "screen", "space_charge", "grad", "screen_grad", "parameter_beam", "misc_elements"]
     for w in which:
         globals()["gen_" + w]()
