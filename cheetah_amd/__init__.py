@@ -23,6 +23,7 @@ from .accelerator import (  # noqa: F401
     Screen,
     Segment,
     Sextupole,
+    TransverseDeflectingCavity,
     Solenoid,
     SpaceChargeKick,
     Undulator,

@@ -101,6 +101,12 @@ SIGNATURES = {
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_parameter_track": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_screen_gaussian": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, ctypes.c_int32, c_int, c_int, c_void_p, c_void_p]),
+    "chx_dkd_num_params": (c_int, [c_int]),
+    "chx_dkd_track": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_double, ctypes.c_int32, ctypes.c_int32,
+                              c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_t_num_params": (c_int, [c_int]),
+    "chx_build_ttensor": (c_int, [c_int, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_apply_second_order": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "chx_time_apply_ms": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_void_p, c_double_p]),
 }
 

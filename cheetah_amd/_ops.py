@@ -273,6 +273,88 @@ def cavity_track(x, R, coeffs, B, N):
 
 
 # ---------------------------------------------------------------------------------------------
+# non-linear tracking (drift_kick_drift, second_order)
+DKD_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "tdc": 3}
+DKD_NUM_PARAMS = [1, 5, 9, 7]
+T_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "sextupole": 3}
+T_NUM_PARAMS = [1, 5, 9, 5]
+FRINGE_AT = {"neither": 0, "entrance": 1, "exit": 2, "both": 3}
+
+
+def stack_params(values, dtype, device) -> tuple[torch.Tensor, torch.Size]:
+    """Element parameters (0-d or vector tensors) -> ((Bp, P) tensor, their common vector shape)."""
+    shape = bshapes(*[v.shape for v in values])
+    if len(shape) == 0:
+        return torch.stack([v.to(dtype) for v in values]).reshape(1, len(values)), shape
+    return torch.stack([v.to(dtype).expand(shape) for v in values], dim=-1).reshape(-1, len(values)), shape
+
+
+def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float, n_charges: float, num_steps: int = 1,
+              fringe_at: int = 3):
+    """One drift-kick-drift element (chx_dkd_track): particles (..., N, 7), params (Bp, P) with vector shape
+    `param_shape`, energy (...). Returns (particles_out (*batch, N, 7), ref_energy (*energy/param batch))."""
+    require_device(particles, params, energy)
+    if particles.requires_grad or params.requires_grad or energy.requires_grad:
+        raise NotImplementedError("drift_kick_drift tracking is not differentiable in this build (forward only)")
+    N = particles.shape[-2]
+    eb_shape = bshapes(param_shape, energy.shape)           # batch shape of the outgoing energy
+    batch_shape = bshapes(particles.shape[:-2], eb_shape)
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    p, Bp = flat_bcast(params.reshape(*param_shape, params.shape[-1]), batch_shape, 1)
+    e, Be = flat_bcast(energy, batch_shape, 0)
+    x, p, e = aligned(x), p.contiguous(), e.contiguous()
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    e_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_dkd_track(kind, ptr(x), ptr(p), ptr(e), mass_eV, n_charges, num_steps, fringe_at, B, Bx, Bp,
+                                   Be, N, dtype_code(x.dtype), ptr(out), ptr(e_out), stream_ptr()), "chx_dkd_track")
+    # the outgoing reference energy has the INCOMING energy's shape (bmadx.py:49: it only depends on p0c)
+    if energy.numel() == 1:
+        e_out = e_out[:1].reshape(energy.shape)
+    elif tuple(energy.shape) == tuple(batch_shape):
+        e_out = e_out.reshape(batch_shape)
+    else:  # energy broadcast against other vector dims: pick one representative per energy entry
+        idx = torch.arange(energy.numel(), device=x.device).reshape(energy.shape).expand(batch_shape).reshape(-1)
+        e_out = torch.zeros(energy.numel(), dtype=x.dtype, device=x.device).index_copy_(0, idx, e_out).reshape(energy.shape)
+    return out.reshape(*batch_shape, N, 7), e_out
+
+
+def build_ttensor(kind: int, params, param_shape, energy, mass_eV: float) -> torch.Tensor:
+    """Second-order transfer tensor (*batch, 7, 7, 7) of one element (chx_build_ttensor)."""
+    require_device(params, energy)
+    if params.requires_grad or energy.requires_grad:
+        raise NotImplementedError("second_order transfer maps are not differentiable in this build (forward only)")
+    batch_shape = bshapes(param_shape, energy.shape)
+    B = max(numel(batch_shape), 1)
+    p, Bp = flat_bcast(params.reshape(*param_shape, params.shape[-1]), batch_shape, 1)
+    e, Be = flat_bcast(energy, batch_shape, 0)
+    p, e = p.contiguous(), e.contiguous()
+    T = torch.empty((B, 7, 7, 7), dtype=energy.dtype, device=energy.device)
+    check(_lib.lib().chx_build_ttensor(kind, ptr(p), ptr(e), mass_eV, B, Bp, Be, dtype_code(energy.dtype), ptr(T),
+                                       stream_ptr()), "chx_build_ttensor")
+    return T.reshape(*batch_shape, 7, 7, 7)
+
+
+def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+    """einsum("...ijk,...j,...k->...i", T, x, x) over the particle axis (element.py:211-216)."""
+    require_device(particles, T)
+    if particles.requires_grad or T.requires_grad:
+        raise NotImplementedError("second_order tracking is not differentiable in this build (forward only)")
+    if T.dtype != particles.dtype:
+        raise RuntimeError(f"transfer map dtype {T.dtype} does not match particle dtype {particles.dtype}")
+    N = particles.shape[-2]
+    batch_shape = bshapes(particles.shape[:-2], T.shape[:-3])
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    Tt, BT = flat_bcast(T, batch_shape, 3)
+    x, Tt = aligned(x), Tt.contiguous()
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_apply_second_order(ptr(x), ptr(Tt), ptr(out), B, Bx, BT, N, dtype_code(x.dtype), stream_ptr()),
+          "chx_apply_second_order")
+    return out.reshape(*batch_shape, N, 7)
+
+
+# ---------------------------------------------------------------------------------------------
 # moments
 def _moments_raw(x, w, B, N):
     lib = _lib.lib()

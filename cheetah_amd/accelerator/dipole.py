@@ -11,8 +11,10 @@ from .element import Element
 class Dipole(Element):
     """Sector bend: R = rot^T (R_exit_face @ base_rmatrix(L, k1, angle/L) @ R_enter_face) rot."""
 
-    supported_tracking_methods = ["linear"]
+    supported_tracking_methods = ["linear", "second_order", "drift_kick_drift"]
     _chx_kind = _ops.KIND["dipole"]
+    _dkd_kind = _ops.DKD_KIND["dipole"]
+    _t_kind = _ops.T_KIND["dipole"]
 
     def __init__(self, length, angle=None, k1=None, dipole_e1=None, dipole_e2=None, tilt=None, gap=None,
                  gap_exit=None, fringe_integral=None, fringe_integral_exit=None, fringe_at="both",
@@ -64,6 +66,14 @@ class Dipole(Element):
         # NB: like the reference (dipole.py:453-459) the exit face uses `gap`, not `gap_exit`
         return [self.length, self.angle, self.k1, self._e1, self._e2, self.tilt, self.fringe_integral,
                 self.fringe_integral_exit, self.gap]
+
+    def _dkd_params(self):
+        # dipole.py:183-370 (Bmad-X body + linear_edge fringes); unlike the linear map the exit face uses gap_exit
+        return [self.length, self.angle, self._e1, self._e2, self.tilt, self.fringe_integral,
+                self.fringe_integral_exit, self.gap, self.gap_exit]
+
+    def _dkd_options(self):
+        return 1, _ops.FRINGE_AT[self.fringe_at]
 
     @property
     def is_skippable(self) -> bool:

@@ -1,4 +1,4 @@
-"""Drift (mirror of cheetah/accelerator/drift.py:40-65,156-158; linear tracking only)."""
+"""Drift (mirror of cheetah/accelerator/drift.py:40-158: linear, second_order and drift_kick_drift tracking)."""
 
 from __future__ import annotations
 
@@ -9,8 +9,10 @@ from .element import Element
 class Drift(Element):
     """Drift section in a particle accelerator."""
 
-    supported_tracking_methods = ["linear"]
+    supported_tracking_methods = ["linear", "second_order", "drift_kick_drift"]
     _chx_kind = _ops.KIND["drift"]
+    _dkd_kind = _ops.DKD_KIND["drift"]
+    _t_kind = _ops.T_KIND["drift"]
 
     def __init__(self, length, tracking_method="linear", name=None, sanitize_name=None, metadata=None,
                  device=None, dtype=None) -> None:
@@ -29,7 +31,8 @@ class Drift(Element):
         import torch
 
         n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
-        return [Drift(self.length / n, dtype=self.length.dtype, device=self.length.device) for _ in range(n)]
+        return [Drift(self.length / n, tracking_method=self.tracking_method, dtype=self.length.dtype,
+                      device=self.length.device) for _ in range(n)]
 
     @property
     def defining_features(self) -> list[str]:

@@ -91,9 +91,27 @@ class Element(nn.Module):
         return tuple(key)
 
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
+        return self._cached_map("_map_cache", self._build_map, energy, species)
+
+    def second_order_transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
+        """T_ijk with x_out_i = sum_jk T_ijk x_j x_k (element.py:134-148), built on device by chx_build_ttensor."""
+        if self._t_kind is None:
+            raise NotImplementedError
+        return self._cached_map("_tmap_cache", self._build_ttensor, energy, species)
+
+    def _t_params(self) -> list[torch.Tensor]:
+        return self._builder_params()
+
+    def _build_ttensor(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
+        dtype = self._work_dtype()
+        energy = energy.to(dtype) if energy.dtype != dtype else energy
+        params, pshape = _ops.stack_params(self._t_params(), dtype, energy.device)
+        return _ops.build_ttensor(self._t_kind, params, pshape, energy, species.mass_eV_float)
+
+    def _cached_map(self, slot: str, build, energy: torch.Tensor, species: Species) -> torch.Tensor:
         if energy.requires_grad or species.mass_eV.requires_grad or species.num_elementary_charges.requires_grad:
-            return self._build_map(energy, species)
-        cache = self.__dict__.get("_map_cache")
+            return build(energy, species)
+        cache = self.__dict__.get(slot)
         fkey = self._feature_key()
         if cache is not None and cache["fkey"] == fkey and cache["mass"] == species.mass_eV_float \
                 and cache["nq"] == species.num_elementary_charges_float:
@@ -103,8 +121,8 @@ class Element(nn.Module):
                 and torch.equal(cache["energy_copy"], energy)
             ):
                 return cache["result"]
-        result = self._build_map(energy, species)
-        self.__dict__["_map_cache"] = {
+        result = build(energy, species)
+        self.__dict__[slot] = {
             "fkey": fkey, "mass": species.mass_eV_float, "nq": species.num_elementary_charges_float,
             "energy_ref": energy, "energy_version": energy._version, "energy_copy": energy.detach().clone(),
             "result": result,
@@ -113,7 +131,61 @@ class Element(nn.Module):
 
     # ---- tracking ---------------------------------------------------------------------------------
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
-        return self._track_first_order(incoming)
+        method = self._tracking_method
+        if method == "linear":
+            return self._track_first_order(incoming)
+        if method == "second_order":
+            return self._track_second_order(incoming)
+        if method == "drift_kick_drift":
+            return self._track_drift_kick_drift(incoming)
+        raise ValueError(f"Invalid tracking method {method}. For element of type {self.__class__.__name__}, supported "
+                         f"methods are {self.supported_tracking_methods}.")
+
+    def _track_second_order(self, incoming: ParticleBeam) -> ParticleBeam:
+        """element.py:195-228: one pass of chx_apply_second_order with the element's T tensor."""
+        assert isinstance(incoming, ParticleBeam), "Second-order tracking is currently only supported for `ParticleBeam`."
+        T = self.second_order_transfer_map(incoming.energy, incoming.species)
+        return ParticleBeam(
+            _ops.apply_second_order(incoming.particles, T),
+            incoming.energy,
+            particle_charges=incoming.particle_charges,
+            survival_probabilities=incoming.survival_probabilities,
+            s=incoming.s + self.length,
+            species=incoming.species,
+        )
+
+    #: chx_dkd_kind / chx_t_kind of the element (include/chx.h); None = method not available
+    _dkd_kind: int | None = None
+    _t_kind: int | None = None
+
+    def _dkd_params(self) -> list[torch.Tensor]:
+        return self._builder_params()
+
+    def _dkd_options(self) -> tuple[int, int]:
+        """(num_steps, fringe_at bits) for chx_dkd_track."""
+        return 1, 3
+
+    def _track_drift_kick_drift(self, incoming: ParticleBeam) -> ParticleBeam:
+        """Bmad-X tracking (e.g. drift.py:106-154): Cheetah -> Bmad coordinates, the element's map and back in one
+        kernel pass (chx_dkd_track); the outgoing energy is the reference energy recomputed from p0c."""
+        assert isinstance(incoming, ParticleBeam), \
+            "Drift-kick-drift tracking is currently only supported for `ParticleBeam`."
+        dtype = incoming.particles.dtype
+        params, pshape = _ops.stack_params(self._dkd_params(), dtype, incoming.particles.device)
+        energy = incoming.energy.to(dtype) if incoming.energy.dtype != dtype else incoming.energy
+        num_steps, fringe = self._dkd_options()
+        species = incoming.species
+        particles, ref_energy = _ops.dkd_track(self._dkd_kind, incoming.particles, params, pshape, energy,
+                                               species.mass_eV_float, species.num_elementary_charges_float, num_steps,
+                                               fringe)
+        return ParticleBeam(
+            particles,
+            ref_energy,
+            particle_charges=incoming.particle_charges,
+            survival_probabilities=incoming.survival_probabilities,
+            s=incoming.s + self.length,
+            species=incoming.species,
+        )
 
     def _track_first_order(self, incoming: ParticleBeam) -> ParticleBeam:
         if isinstance(incoming, ParameterBeam):  # element.py:167-179

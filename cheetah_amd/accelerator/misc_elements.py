@@ -73,12 +73,13 @@ class Undulator(Element):
 
 
 class Sextupole(Element):
-    """Sextupole: a drift in first order (sextupole.py:85-88); `second_order` tracking is not provided."""
+    """Sextupole (sextupole.py:45-132): a drift in first order, the k2 kick through the second-order tensor."""
 
-    supported_tracking_methods = ["linear"]
+    supported_tracking_methods = ["linear", "second_order"]
     _chx_kind = _ops.KIND["drift"]
+    _t_kind = _ops.T_KIND["sextupole"]
 
-    def __init__(self, length, k2=None, misalignment=None, tilt=None, tracking_method="linear", name=None,
+    def __init__(self, length, k2=None, misalignment=None, tilt=None, tracking_method="second_order", name=None,
                  sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         fk = {"device": device, "dtype": dtype}
         super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
@@ -92,6 +93,9 @@ class Sextupole(Element):
     def _builder_params(self):
         return [self.length]
 
+    def _t_params(self):
+        return [self.length, self.k2, self.tilt, self.misalignment[..., 0], self.misalignment[..., 1]]
+
     @property
     def is_active(self) -> bool:
         return bool((self.k2 != 0).any().item())
@@ -103,3 +107,45 @@ class Sextupole(Element):
     @property
     def defining_features(self) -> list[str]:
         return super().defining_features + ["length", "k2", "misalignment", "tilt"]
+
+
+class TransverseDeflectingCavity(Element):
+    """Transverse deflecting cavity (transverse_deflecting_cavity.py:44-209): half drift, transverse RF kick with the
+    matching energy change, half drift, tracked per particle by chx_dkd_track (drift_kick_drift only)."""
+
+    supported_tracking_methods = ["drift_kick_drift"]
+    _dkd_kind = _ops.DKD_KIND["tdc"]
+
+    def __init__(self, length, voltage=None, phase=None, frequency=None, misalignment=None, tilt=None, num_steps=1,
+                 tracking_method="drift_kick_drift", name=None, sanitize_name=None, metadata=None, device=None,
+                 dtype=None) -> None:
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
+        z = lambda v: v if v is not None else torch.tensor(0.0, **fk)  # noqa: E731
+        self.length = length
+        self.register_buffer_or_parameter("voltage", z(voltage))
+        self.register_buffer_or_parameter("phase", z(phase))
+        self.register_buffer_or_parameter("frequency", z(frequency))
+        self.register_buffer_or_parameter(
+            "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+        self.register_buffer_or_parameter("tilt", z(tilt))
+        self.num_steps = num_steps
+        self._tracking_method = "drift_kick_drift"
+        self.tracking_method = tracking_method
+
+    def _dkd_params(self):
+        return [self.length, self.voltage, self.phase, self.frequency, self.tilt, self.misalignment[..., 0],
+                self.misalignment[..., 1]]
+
+    @property
+    def is_active(self) -> bool:
+        return bool((self.voltage != 0).any().item())
+
+    @property
+    def is_skippable(self) -> bool:
+        return False
+
+    @property
+    def defining_features(self) -> list[str]:
+        return super().defining_features + ["length", "voltage", "phase", "frequency", "misalignment", "tilt",
+                                            "num_steps"]

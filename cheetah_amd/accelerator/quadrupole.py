@@ -1,4 +1,4 @@
-"""Quadrupole (mirror of cheetah/accelerator/quadrupole.py:52-110; linear tracking)."""
+"""Quadrupole (mirror of cheetah/accelerator/quadrupole.py:52-255: linear, second_order, drift_kick_drift)."""
 
 from __future__ import annotations
 
@@ -11,8 +11,10 @@ from .element import Element
 class Quadrupole(Element):
     """Quadrupole magnet: R = R_exit @ base_rmatrix(L, k1, 0) @ R_entry (tilt + misalignment)."""
 
-    supported_tracking_methods = ["linear"]
+    supported_tracking_methods = ["linear", "second_order", "drift_kick_drift"]
     _chx_kind = _ops.KIND["quadrupole"]
+    _dkd_kind = _ops.DKD_KIND["quadrupole"]
+    _t_kind = _ops.T_KIND["quadrupole"]
 
     def __init__(self, length, k1=None, misalignment=None, tilt=None, num_steps=1, tracking_method="linear",
                  name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
@@ -29,6 +31,9 @@ class Quadrupole(Element):
     def _builder_params(self):
         return [self.length, self.k1, self.tilt, self.misalignment[..., 0], self.misalignment[..., 1]]
 
+    def _dkd_options(self):
+        return int(self.num_steps), 3
+
     @property
     def is_skippable(self) -> bool:
         return self.tracking_method == "linear"
@@ -40,8 +45,8 @@ class Quadrupole(Element):
     def split(self, resolution):
         n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
         fk = {"dtype": self.length.dtype, "device": self.length.device}
-        return [Quadrupole(self.length / n, self.k1, misalignment=self.misalignment, tilt=self.tilt, **fk)
-                for _ in range(n)]
+        return [Quadrupole(self.length / n, self.k1, misalignment=self.misalignment, tilt=self.tilt,
+                           num_steps=self.num_steps, tracking_method=self.tracking_method, **fk) for _ in range(n)]
 
     @property
     def defining_features(self) -> list[str]:

@@ -551,7 +551,243 @@ __global__ __launch_bounds__(CHX_BLOCK) void cavity_coeff_kernel(const T* __rest
     }
 }
 
+// ---- second-order transfer tensors (track_methods.py:80-296, MAD convention) ------------------
+// E(u) = (3 - 4 S + S C) / (2u)                              (utils/autograd.py:227-234, `sipsicos3mdiv`)
+// H(u) = (15 - 22.5 S + 9 S C - 1.5 S C^2 + u S^3) / u^3     (j3 of track_methods.py:134-143, = 6 j3 / L^7)
+// with S = sin(sqrt u)/sqrt u, C = cos(sqrt u). The closed form of E cancels like u^2 near u = 0, so
+// |u| < 1 is evaluated from its Taylor series (Horner, 12 terms, truncation < 1e-17).
+__device__ double ttensor_E(double u, double C, double S) {
+    if (fabs(u) < 1.0) {
+        const double c[12] = {0.0, 1.0 / 20, -1.0 / 168, 1.0 / 2880, -17.0 / 1330560, 31.0 / 94348800, -1.0 / 159667200,
+                              5461.0 / 59281238016000.0, -257.0 / 238519804723200.0, 73.0 / 7113748561920000.0,
+                              -1271.0 / 15667888932657561600.0, 60787.0 / 112400072777760768000000.0};
+        double r = c[11];
+        for (int k = 10; k >= 0; --k) r = r * u + c[k];
+        return r;
+    }
+    return (3.0 - 4.0 * S + S * C) / (2.0 * u);
+}
+// NB: the numerator of H does NOT vanish like u^3 (it starts at order u), so j3 has no finite limit at u = 0 —
+// the reference says so itself (track_methods.py:130-133) and substitutes L^7/56 at exactly kx2 == 0. Parity with
+// the reference means evaluating its closed form as written; there is no cancellation to protect against.
+__device__ double ttensor_H(double u, double C, double S) {
+    return (15.0 - 22.5 * S + 9.0 * S * C - 1.5 * S * C * C + u * S * S * S) / (u * u * u);
+}
+
+#define TT(i, j, k) T[((i) * 7 + (j)) * 7 + (k)]
+// T must be zero-filled by the caller. Every jc/js/jd/jf term below carries a factor k2, and the reference's
+// elements only combine k2 != 0 with k1 = hx = 0 (Sextupole), where the divided differences sit at their
+// a == b == 0 limits; elsewhere they are multiplied by zero, so the plain difference quotients suffice.
+__device__ void base_ttensor(double L, double k1, double k2, double hx, double energy, double mass, double* T) {
+    double g, ig2, beta;
+    rel_factors<double>(energy, mass, g, ig2, beta);
+    const double kx2 = k1 + hx * hx, ky2 = -k1;
+    const double L2 = L * L, L3 = L2 * L;
+    const double a = kx2 * L2, b = ky2 * L2;
+    double cx, Sx, Gx, Fx, cy, Sy, Gy, Fy, C4, S4, G4, F4;
+    sinc_family<double>(a, cx, Sx, Gx, Fx);
+    sinc_family<double>(b, cy, Sy, Gy, Fy);
+    sinc_family<double>(4.0 * b, C4, S4, G4, F4);
+    const double sx = Sx * L, sy = Sy * L;
+    const double dx = L2 * Gx;                 // 0.5 L^2 sinc^2(kx L / 2), no hx factor here (track_methods.py:120)
+    const double fx = L3 * Fx;                 // si1mdiv
+    const double f2y = L3 * 4.0 * F4;          // sicos1mdiv(v) = (1 - S(v) C(v)) / v = 4 F(4v)
+    const double j1 = fx;
+    const double j2 = L3 * ttensor_E(a, cx, Sx);
+    const double L7 = L3 * L3 * L;
+    const double j3 = (kx2 != 0.0) ? L7 * ttensor_H(a, cx, Sx) / 6.0 : L7 / 56.0;
+    const double jden = kx2 - 4.0 * ky2;
+    const double jc = L2 * ((a != b) ? (cy - cx) / (a - b) : 0.5 * Sx);
+    const double js = L3 * ((a != b) ? (Sx - Sy) / (b - a) : ((b != 0.0) ? 0.5 * (Sy - cy) / b : 1.0 / 6.0));
+    const double jd =
+        L2 * L2 * ((a != b) ? (Sy * Sy - Sx * Sx) / (a - b) : ((b != 0.0) ? (1.0 - cy * cy - b * Sy * cy) / (b * b) : 1.0 / 3.0));
+    const double jf = (jden != 0.0) ? (f2y - fx) / jden : L2 * L3 / 120.0;
+    const double khk = k2 + 2.0 * hx * k1;
+    const double b2 = beta * beta, b3 = b2 * beta, hx2 = hx * hx, hx3 = hx2 * hx, dx2 = dx * dx;
+
+    TT(0, 0, 0) = -khk * (sx * sx + dx) / 6.0 - 0.5 * hx * kx2 * sx * sx;
+    TT(0, 0, 1) = 2.0 * (-khk * sx * dx / 6.0 + 0.5 * hx * sx * cx);
+    TT(0, 1, 1) = -khk * dx2 / 6.0 + 0.5 * hx * dx * cx;
+    TT(0, 0, 5) = 2.0 * (-hx / 12.0 / beta * khk * (3.0 * sx * j1 - dx2) + 0.5 * hx2 / beta * sx * sx +
+                         0.25 / beta * k1 * L * sx);
+    TT(0, 1, 5) = 2.0 * (-hx / 12.0 / beta * khk * (sx * dx2 - 2.0 * cx * j2) + 0.25 * hx2 / beta * (sx * dx + cx * j1) -
+                         0.25 / beta * (sx + L * cx));
+    TT(0, 5, 5) = -hx2 / 6.0 / b2 * khk * (dx2 * dx - 2.0 * sx * j2) + 0.5 * hx3 / b2 * sx * j1 - 0.5 * hx / b2 * L * sx -
+                  0.5 * hx / b2 * ig2 * dx;
+    TT(0, 2, 2) = k1 * k2 * jd + 0.5 * (k2 + hx * k1) * dx;
+    TT(0, 2, 3) = 2.0 * (0.5 * k2 * js);
+    TT(0, 3, 3) = k2 * jd - 0.5 * hx * dx;
+    TT(1, 0, 0) = -khk * sx * (1.0 + 2.0 * cx) / 6.0;
+    TT(1, 0, 1) = -2.0 * khk * dx * (1.0 + 2.0 * cx) / 6.0;
+    TT(1, 1, 1) = -khk * sx * dx / 3.0 - 0.5 * hx * sx;
+    TT(1, 0, 5) = 2.0 * (-hx / 12.0 / beta * khk * (3.0 * cx * j1 + sx * dx) - 0.25 / beta * k1 * (sx - L * cx));
+    TT(1, 1, 5) = 2.0 * (-hx / 12.0 / beta * khk * (3.0 * sx * j1 + dx2) + 0.25 / beta * k1 * L * sx);
+    TT(1, 5, 5) = -hx2 / 6.0 / b2 * khk * (sx * dx2 - 2.0 * cx * j2) - 0.5 * hx / b2 * k1 * (cx * j1 - sx * dx) -
+                  0.5 * hx / b2 * ig2 * sx;
+    TT(1, 2, 2) = k1 * k2 * js + 0.5 * (k2 + hx * k1) * sx;
+    TT(1, 2, 3) = 2.0 * (0.5 * k2 * jc);
+    TT(1, 3, 3) = k2 * js - 0.5 * hx * sx;
+    TT(2, 0, 2) = 2.0 * (0.5 * k2 * (cy * jc - 2.0 * k1 * sy * js) + 0.5 * hx * k1 * sx * sy);
+    TT(2, 0, 3) = 2.0 * (0.5 * k2 * (sy * jc - 2.0 * cy * js) + 0.5 * hx * sx * cy);
+    TT(2, 1, 2) = 2.0 * (0.5 * k2 * (cy * js - 2.0 * k1 * sy * jd) + 0.5 * hx * k1 * dx * sy);
+    TT(2, 1, 3) = 2.0 * (0.5 * k2 * (sy * js - 2.0 * cy * jd) + 0.5 * hx * dx * cy);
+    TT(2, 2, 5) = 2.0 * (0.5 * hx / beta * k2 * (cy * jd - 2.0 * k1 * sy * jf) + 0.5 * hx2 / beta * k1 * j1 * sy -
+                         0.25 / beta * k1 * L * sy);
+    TT(2, 3, 5) = 2.0 * (0.5 * hx / beta * k2 * (sy * jd - 2.0 * cy * jf) + 0.5 * hx2 / beta * j1 * cy -
+                         0.25 / beta * (sy + L * cy));
+    TT(3, 0, 2) = 2.0 * (0.5 * k1 * k2 * (2.0 * cy * js - sy * jc) + 0.5 * (k2 + hx * k1) * sx * cy);
+    TT(3, 0, 3) = 2.0 * (0.5 * k2 * (2.0 * k1 * sy * js - cy * jc) + 0.5 * (k2 + hx * k1) * sx * sy);
+    TT(3, 1, 2) = 2.0 * (0.5 * k1 * k2 * (2.0 * cy * jd - sy * js) + 0.5 * (k2 + hx * k1) * dx * cy);
+    TT(3, 1, 3) = 2.0 * (0.5 * k2 * (2.0 * k1 * sy * jd - cy * js) + 0.5 * (k2 + hx * k1) * dx * sy);
+    TT(3, 2, 5) = 2.0 * (0.5 * hx / beta * k1 * k2 * (2.0 * cy * jf - sy * jd) + 0.5 * hx / beta * (k2 + hx * k1) * j1 * cy +
+                         0.25 / beta * k1 * (sy - L * cy));
+    TT(3, 3, 5) = 2.0 * (0.5 * hx / beta * k2 * (2.0 * k1 * sy * jf - cy * jd) + 0.5 * hx / beta * (k2 + hx * k1) * j1 * sy -
+                         0.25 / beta * k1 * L * sy);
+    TT(4, 0, 0) = -(hx / 12.0 / beta * khk * (sx * dx + 3.0 * j1) - 0.25 / beta * k1 * (L - sx * cx));
+    TT(4, 0, 1) = -2.0 * (hx / 12.0 / beta * khk * dx2 + 0.25 / beta * k1 * sx * sx);
+    TT(4, 1, 1) = -(hx / 6.0 / beta * khk * j2 - 0.5 / beta * sx - 0.25 / beta * k1 * (j1 - sx * dx));
+    TT(4, 0, 5) = -2.0 * (hx2 / 12.0 / b2 * khk * (3.0 * dx * j1 - 4.0 * j2) + 0.25 * hx / b2 * k1 * j1 * (1.0 + cx) +
+                          0.5 * hx / b2 * ig2 * sx);
+    TT(4, 1, 5) = -2.0 * (hx2 / 12.0 / b2 * khk * (dx * dx2 - 2.0 * sx * j2) + 0.25 * hx / b2 * k1 * sx * j1 +
+                          0.5 * hx / b2 * ig2 * dx);
+    TT(4, 5, 5) = -(hx3 / 6.0 / b3 * khk * (3.0 * j3 - 2.0 * dx * j2) +
+                    hx2 / 6.0 / b3 * k1 * (sx * dx2 - j2 * (1.0 + 2.0 * cx)) + 1.5 / b3 * ig2 * (hx2 * j1 - L));
+    TT(4, 2, 2) = -(-hx / beta * k1 * k2 * jf - 0.5 * hx / beta * (k2 + hx * k1) * j1 + 0.25 / beta * k1 * (L - cy * sy));
+    TT(4, 2, 3) = -2.0 * (-0.5 * hx / beta * k2 * jd - 0.25 / beta * k1 * sy * sy);
+    TT(4, 3, 3) = -(-hx / beta * k2 * jf + 0.5 * hx2 / beta * j1 - 0.25 / beta * (L + cy * sy));
+}
+#undef TT
+
+// One workgroup per batch row: lane 0 evaluates the closed forms into LDS, then 343 lanes carry out
+// T'_inm = sum_jkl X_ij T_jkl E_kn E_lm (quadrupole.py:140-144) as three 7-term contractions.
+constexpr int kTBlock = 384;
+
+__device__ void ttensor_contract(double* Ts, double* As, const double* X, const double* En) {
+    const int id = threadIdx.x;
+    const int i = id / 49, n = (id / 7) % 7, m = id % 7;
+    __syncthreads();
+    if (id < 343) {  // As[j=i][k=n][m] = sum_l Ts[j][k][l] En[l][m]
+        double acc = 0.0;
+        for (int l = 0; l < 7; ++l) acc += Ts[(i * 7 + n) * 7 + l] * En[l * 7 + m];
+        As[id] = acc;
+    }
+    __syncthreads();
+    if (id < 343) {  // Ts[j=i][n][m] = sum_k As[j][k][m] En[k][n]
+        double acc = 0.0;
+        for (int k = 0; k < 7; ++k) acc += As[(i * 7 + k) * 7 + m] * En[k * 7 + n];
+        Ts[id] = acc;
+    }
+    __syncthreads();
+    if (id < 343) {  // As[i][n][m] = sum_j X[i][j] Ts[j][n][m]
+        double acc = 0.0;
+        for (int j = 0; j < 7; ++j) acc += X[i * 7 + j] * Ts[(j * 7 + n) * 7 + m];
+        As[id] = acc;
+    }
+    __syncthreads();
+    if (id < 343) Ts[id] = As[id];
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kTBlock) void ttensor_kernel(int kind, const T* __restrict__ params,
+                                                          const T* __restrict__ energy, double mass, int64_t Bp,
+                                                          int64_t Be, int P, T* __restrict__ T_out) {
+    __shared__ double Ts[343], As[343], X1[49], E1[49], X2[49], E2[49];
+    const int64_t b = blockIdx.x;
+    const int id = threadIdx.x;
+    if (id < 343) Ts[id] = 0.0;
+    __syncthreads();
+    if (id == 0) {
+        double p[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) p[k] = (double)params[(Bp == 1 ? 0 : b) * P + k];
+        const double en = (double)energy[Be == 1 ? 0 : b];
+        Mat7<double> R;
+        if (kind == CHX_T_DRIFT) {
+            base_ttensor(p[0], 0.0, 0.0, 0.0, en, mass, Ts);
+            drift_map<double>(p[0], en, mass, R);
+        } else if (kind == CHX_T_QUADRUPOLE) {
+            base_ttensor(p[0], p[1], 0.0, 0.0, en, mass, Ts);
+            base_rmatrix<double>(p[0], p[1], 0.0, en, mass, R);
+        } else if (kind == CHX_T_SEXTUPOLE) {
+            base_ttensor(p[0], 0.0, p[1], 0.0, en, mass, Ts);
+            drift_map<double>(p[0], en, mass, R);
+        } else {  // CHX_T_DIPOLE: [L, angle, k1, e1, e2, tilt, fint, fint_exit, gap]
+            const double hx = p[1] / p[0];
+            base_ttensor(p[0], p[2], 0.0, hx, en, mass, Ts);
+            base_rmatrix<double>(p[0], p[2], hx, en, mass, R);
+        }
+        // first-order map into T[:, 6, :] (drift.py:79-82)
+        for (int i = 0; i < 7; ++i)
+            for (int k = 0; k < 7; ++k) Ts[(i * 7 + 6) * 7 + k] = R(i, k);
+        if (kind == CHX_T_QUADRUPOLE || kind == CHX_T_SEXTUPOLE) {
+            // combined_rotation_misalignment_matrix (track_methods.py:345-382)
+            const double tilt = p[2], mx = p[3], my = p[4];
+            Mat7<double> entry, exitm;
+            rotation_map<double>(tilt, entry);
+            transpose7(entry, exitm);
+            const double cs = cos(tilt), sn = sin(tilt);
+            entry(0, 6) = -mx * cs - my * sn;
+            entry(2, 6) = mx * sn - my * cs;
+            exitm(0, 6) = mx;
+            exitm(2, 6) = my;
+            for (int k = 0; k < 49; ++k) { E1[k] = entry.m[k]; X1[k] = exitm.m[k]; }
+        } else if (kind == CHX_T_DIPOLE) {
+            const double hx = p[1] / p[0], e1 = p[3], e2 = p[4], tilt = p[5], fint = p[6], fint_exit = p[7], gap = p[8];
+            Mat7<double> enter, exitm, rot, rotT;
+            {
+                const double sec = 1.0 / cos(e1), s1 = sin(e1);
+                const double phi = fint * hx * gap * sec * (1.0 + s1 * s1);
+                eye7(enter);
+                enter(1, 0) = hx * tan(e1);
+                enter(3, 2) = -hx * tan(e1 - phi);
+            }
+            {
+                const double sec = 1.0 / cos(e2), s2 = sin(e2);
+                const double phi = fint_exit * hx * gap * sec * (1.0 + s2 * s2);
+                eye7(exitm);
+                exitm(1, 0) = hx * tan(e2);
+                exitm(3, 2) = -hx * tan(e2 - phi);
+            }
+            rotation_map<double>(tilt, rot);
+            transpose7(rot, rotT);
+            for (int k = 0; k < 49; ++k) { E1[k] = enter.m[k]; X1[k] = exitm.m[k]; E2[k] = rot.m[k]; X2[k] = rotT.m[k]; }
+        }
+    }
+    if (kind != CHX_T_DRIFT) ttensor_contract(Ts, As, X1, E1);
+    if (kind == CHX_T_DIPOLE) ttensor_contract(Ts, As, X2, E2);
+    __syncthreads();
+    if (id < 343) T_out[b * 343 + id] = (T)Ts[id];
+}
+
 }  // namespace
+
+extern "C" int chx_t_num_params(int kind) {
+    switch (kind) {
+        case CHX_T_DRIFT: return 1;
+        case CHX_T_QUADRUPOLE: return 5;
+        case CHX_T_DIPOLE: return 9;
+        case CHX_T_SEXTUPOLE: return 5;
+    }
+    return -1;
+}
+
+extern "C" int chx_build_ttensor(int kind, const void* params, const void* energy, double mass_eV, int64_t B,
+                                 int64_t Bp, int64_t Be, int dtype, void* T_out, void* stream) {
+    const int P = chx_t_num_params(kind);
+    if (P < 0 || !params || !energy || !T_out || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(ttensor_kernel<float>, dim3((unsigned)B), dim3(kTBlock), 0, s, kind, (const float*)params,
+                           (const float*)energy, mass_eV, Bp, Be, P, (float*)T_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(ttensor_kernel<double>, dim3((unsigned)B), dim3(kTBlock), 0, s, kind, (const double*)params,
+                           (const double*)energy, mass_eV, Bp, Be, P, (double*)T_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
 
 extern "C" int chx_kind_num_params(int kind) { return kind_num_params(kind); }
 extern "C" int chx_abi_version(void) { return CHX_ABI_VERSION; }

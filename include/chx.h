@@ -254,6 +254,37 @@ int chx_screen_gaussian(const void* mu, const void* cov, const void* shift, cons
                         int64_t Bmu, int64_t Bcov, int64_t Bsh, int32_t width, int32_t height,
                         int positions_fp32, int dtype, void* image, void* stream);
 
+/* ---- non-linear per-particle tracking.
+ * Drift-kick-drift (Bmad-X) tracking: drift.py:106-154, quadrupole.py:168-251, dipole.py:183-370,
+ * transverse_deflecting_cavity.py:122-209 over utils/bmadx.py. Cheetah -> Bmad canonical coordinates,
+ * the element's exact/symplectic map, and back, in one pass; column 6 of x_out is 1.
+ * params[Bp][P] (dtype):
+ *   CHX_DKD_DRIFT       [length]
+ *   CHX_DKD_QUADRUPOLE  [length, k1, tilt, misalignment_x, misalignment_y]   (+ num_steps)
+ *   CHX_DKD_DIPOLE      [length, angle, e1, e2, tilt, fint, fint_exit, gap, gap_exit]
+ *                       (+ fringe_at: bit 0 = entrance, bit 1 = exit; linear_edge fringe)
+ *   CHX_DKD_TDC         [length, voltage, phase, frequency, tilt, misalignment_x, misalignment_y]
+ * energy_out[B] (may be NULL) receives the reference energy recomputed from p0c (bmadx.py:49). */
+enum chx_dkd_kind { CHX_DKD_DRIFT = 0, CHX_DKD_QUADRUPOLE = 1, CHX_DKD_DIPOLE = 2, CHX_DKD_TDC = 3 };
+int chx_dkd_num_params(int kind);
+int chx_dkd_track(int kind, const void* x_in, const void* params, const void* energy, double mass_eV,
+                  double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp,
+                  int64_t Be, int64_t N, int dtype, void* x_out, void* energy_out, void* stream);
+
+/* Second-order tracking (element.py:195-228): x_out_i = sum_jk T_ijk x_j x_k with the MAD-convention
+ * tensors of track_methods.py:80-296 (base_ttensor), the first-order map filled into T[:, 6, :] and the
+ * element's rotations / misalignments / fringes folded in (drift.py:68-84, quadrupole.py:113-146,
+ * dipole.py:397-428, sextupole.py:91-116). params[Bp][P] (dtype):
+ *   CHX_T_DRIFT [length]   CHX_T_QUADRUPOLE [length, k1, tilt, mx, my]   CHX_T_SEXTUPOLE [length, k2, tilt, mx, my]
+ *   CHX_T_DIPOLE = the CHX_DIPOLE vector [length, angle, k1, e1, e2, tilt, fint, fint_exit, gap]
+ * T_out[B][7][7][7] (dtype). */
+enum chx_t_kind { CHX_T_DRIFT = 0, CHX_T_QUADRUPOLE = 1, CHX_T_DIPOLE = 2, CHX_T_SEXTUPOLE = 3 };
+int chx_t_num_params(int kind);
+int chx_build_ttensor(int kind, const void* params, const void* energy, double mass_eV, int64_t B, int64_t Bp,
+                      int64_t Be, int dtype, void* T_out, void* stream);
+int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t B, int64_t Bx, int64_t BT,
+                           int64_t N, int dtype, void* stream);
+
 /* ---- instrumentation: average duration (ms) of `iters` back-to-back launches of the apply
  * kernel on `stream`, measured with hipEvents recorded on that stream. Used by bench.py for
  * roofline.achieved. Synchronises the stream (the only entry point that does). */

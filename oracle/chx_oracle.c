@@ -759,3 +759,6 @@ CHXO_API int chxo_sc_gather_kick(const void* x_in, const double* F, const double
     }
     return 0;
 }
+
+/* non-linear tracking (drift_kick_drift, second_order) */
+#include "chx_oracle_nonlinear.inc"

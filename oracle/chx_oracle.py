@@ -45,7 +45,8 @@ PROTON_MASS_EV = 938272089.4300001
 def build(force: bool = False) -> str:
     """Compile the C oracle next to its source (gcc, OpenMP)."""
     src = os.path.join(_HERE, "chx_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "chx_oracle_nonlinear.inc")))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(
             # -mavx2 -mfma: fmaf()/fma() become single instructions (x86-64-v3, any EPYC/Xeon host);
             # -ffp-contract=off: no implicit contraction, the index arithmetic rounds op by op
@@ -300,6 +301,60 @@ def igf(cell_scaled, bins) -> np.ndarray:
     G = np.empty((B, 2 * bins[0], 2 * bins[1], 2 * bins[2]), dtype=np.float64)
     lib().chxo_sc_igf(_p(cell_scaled), i64(B), b, _p(G))
     return G
+
+
+DKD_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "tdc": 3}
+DKD_NUM_PARAMS = {0: 1, 1: 5, 2: 9, 3: 7}
+T_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "sextupole": 3}
+T_NUM_PARAMS = {0: 1, 1: 5, 2: 9, 3: 5}
+
+
+def dkd_track(kind, x, params, energy, mass_eV=ELECTRON_MASS_EV, n_charges=-1.0, num_steps=1, fringe_at=3):
+    """Drift-kick-drift (Bmad-X) tracking of one element; x (Bx,N,7); params (Bp,P) and energy (Be,) are cast to
+    x.dtype like the reference's element buffers. Returns (x_out (B,N,7), ref_energy (B,) float64)."""
+    k = DKD_KIND[kind] if isinstance(kind, str) else int(kind)
+    x = _c(x)
+    x = x.reshape(-1, x.shape[-2], 7)
+    params = _c(np.asarray(params, dtype=x.dtype).reshape(-1, DKD_NUM_PARAMS[k]))
+    energy = _c(np.asarray(energy, dtype=x.dtype).reshape(-1))
+    Bx, Bp, Be = x.shape[0], params.shape[0], energy.shape[0]
+    B = max(Bx, Bp, Be)
+    assert Bx in (1, B) and Bp in (1, B) and Be in (1, B)
+    out = np.empty((B, x.shape[1], 7), dtype=x.dtype)
+    e_out = np.empty((B,), dtype=np.float64)
+    st = lib().chxo_dkd_track(k, _p(x), _p(params), _p(energy), ctypes.c_double(mass_eV), ctypes.c_double(n_charges),
+                              int(num_steps), int(fringe_at), i64(B), i64(Bx), i64(Bp), i64(Be), i64(x.shape[1]),
+                              _dt(x), _p(out), _p(e_out))
+    assert st == 0
+    return out, e_out
+
+
+def build_ttensor(kind, params, energy, mass_eV=ELECTRON_MASS_EV) -> np.ndarray:
+    """Second-order transfer tensor (B,7,7,7), float64 (track_methods.py:80-296 + element dressing)."""
+    k = T_KIND[kind] if isinstance(kind, str) else int(kind)
+    params = _c(np.asarray(params, dtype=np.float64).reshape(-1, T_NUM_PARAMS[k]))
+    energy = _c(np.asarray(energy, dtype=np.float64).reshape(-1))
+    Bp, Be = params.shape[0], energy.shape[0]
+    B = max(Bp, Be)
+    assert Bp in (1, B) and Be in (1, B)
+    out = np.empty((B, 7, 7, 7), dtype=np.float64)
+    st = lib().chxo_build_ttensor(k, _p(params), _p(energy), ctypes.c_double(mass_eV), i64(B), i64(Bp), i64(Be),
+                                  _p(out))
+    assert st == 0
+    return out
+
+
+def apply_second_order(x, T) -> np.ndarray:
+    """x_out_i = sum_jk T_ijk x_j x_k (element.py:207-217); x (Bx,N,7), T (BT,7,7,7)."""
+    x = _c(x)
+    x = x.reshape(-1, x.shape[-2], 7)
+    T = _c(np.asarray(T, dtype=np.float64).reshape(-1, 343))
+    Bx, BT = x.shape[0], T.shape[0]
+    B = max(Bx, BT)
+    out = np.empty((B, x.shape[1], 7), dtype=x.dtype)
+    st = lib().chxo_apply_second_order(_p(x), _p(T), _p(out), i64(B), i64(Bx), i64(BT), i64(x.shape[1]), _dt(x))
+    assert st == 0
+    return out
 
 
 def space_charge_kick(x, energy, charge, survival, effect_length, grid_shape=(32, 32, 32),

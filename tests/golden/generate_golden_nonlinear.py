@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Golden vectors for the non-linear tracking methods: tests/golden/dkd.npz and
+tests/golden/second_order.npz.
+
+Run in the build container only (imports /root/reference read-only through generate_golden.py):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_golden_nonlinear.py
+
+Contents are DATA only:
+  * the Bmad-X results the reference's tests compare against (tests/resources/bmadx/*.pt, used by
+    tests/test_drift.py:41-70, test_quadrupole.py:172-207, test_dipole.py:103-150,
+    test_transverse_deflecting_cavity.py:10-41), first KEEP particles, as arrays;
+  * the Bmad/Tao single-particle results for six species (tests/resources/bmad/x_tao_*.pt, test_compare_bmad.py);
+  * the reference's consistency goldens for drift_kick_drift / second_order / TDC (test_elements.py:356-431);
+  * outputs of the reference itself for extra cases (fp64 and fp32, vectorised, other species, fringe variants,
+    second-order tensors).
+"""
+
+import copy
+import os
+import pickle
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from generate_golden import REF, cheetah, load_incoming, np, npy, save, species_meta, torch  # noqa: E402
+
+from cheetah.utils.bmadx import bmad_to_cheetah_z_pz  # noqa: E402
+from scipy.constants import physical_constants  # noqa: E402
+
+KEEP = 2048
+F64 = {"dtype": torch.float64}
+
+
+def t64(v):
+    return torch.tensor(v, **F64)
+
+
+def bmadx_elements(dtype):
+    """The four elements of the reference's Bmad-X comparison tests, as (name, element, kind, params, steps, fringe)."""
+    kw = {"dtype": dtype}
+    angle = torch.tensor(20 * torch.pi / 180, **kw)
+    e1 = angle / 2
+    e2 = angle - e1
+    drift = cheetah.Drift(length=torch.tensor(1.0), tracking_method="drift_kick_drift", **kw)
+    quad = cheetah.Quadrupole(length=torch.tensor(1.0, **kw), k1=torch.tensor(10.0, **kw),
+                              misalignment=torch.tensor([0.01, -0.02], **kw), tilt=torch.tensor(0.5, **kw), num_steps=10,
+                              tracking_method="drift_kick_drift", **kw)
+    dip = cheetah.Dipole(length=torch.tensor(0.5), angle=angle, dipole_e1=e1, dipole_e2=e2, tilt=torch.tensor(0.1, **kw),
+                         fringe_integral=torch.tensor(0.5), fringe_integral_exit=torch.tensor(0.5),
+                         gap=torch.tensor(0.05, **kw), gap_exit=torch.tensor(0.05, **kw), fringe_at="both",
+                         fringe_type="linear_edge", tracking_method="drift_kick_drift", **kw)
+    tdc = cheetah.TransverseDeflectingCavity(length=torch.tensor(1.0, **kw), voltage=torch.tensor(1e7, **kw),
+                                             phase=torch.tensor(0.2, **kw), frequency=torch.tensor(1e9, **kw),
+                                             tracking_method="drift_kick_drift", **kw)
+    return {"drift": drift, "quadrupole": quad, "dipole": dip, "tdc": tdc}
+
+
+def dkd_params(el):
+    """Parameter vector of the C-ABI for a reference element (include/chx.h, chx_dkd_track)."""
+    f = lambda v: npy(v.to(torch.float64))  # noqa: E731
+    if isinstance(el, cheetah.TransverseDeflectingCavity):
+        b = torch.broadcast_tensors(el.length, el.voltage, el.phase, el.frequency, el.tilt, el.misalignment[..., 0],
+                                    el.misalignment[..., 1])
+        return "tdc", np.stack([f(v) for v in b], axis=-1), 1, 3
+    if isinstance(el, cheetah.Dipole):
+        b = torch.broadcast_tensors(el.length, el.angle, el.dipole_e1, el.dipole_e2, el.tilt, el.fringe_integral,
+                                    el.fringe_integral_exit, el.gap, el.gap_exit)
+        fr = {"neither": 0, "entrance": 1, "exit": 2, "both": 3}[el.fringe_at]
+        return "dipole", np.stack([f(v) for v in b], axis=-1), 1, fr
+    if isinstance(el, cheetah.Quadrupole):
+        b = torch.broadcast_tensors(el.length, el.k1, el.tilt, el.misalignment[..., 0], el.misalignment[..., 1])
+        return "quadrupole", np.stack([f(v) for v in b], axis=-1), el.num_steps, 3
+    return "drift", f(el.length)[..., None], 1, 3
+
+
+def gen_dkd():
+    arrays = {}
+    inc = torch.load(os.path.join(REF, "tests/resources/bmadx/incoming.pt"), weights_only=False)
+    arrays["incoming"] = npy(inc.particles)[:KEEP]
+    arrays["energy"] = npy(inc.energy)
+    arrays["species"] = np.asarray(species_meta(inc.species))
+    files = {"drift": "outgoing_drift.pt", "quadrupole": "outgoing_quadrupole.pt", "dipole": "outgoing_dipole.pt",
+             "tdc": "outgoing_transverse_deflecting_cavity.pt"}
+    els = bmadx_elements(torch.float64)
+    els32 = bmadx_elements(torch.float32)
+    for name, fn in files.items():
+        out = torch.load(os.path.join(REF, "tests/resources/bmadx", fn), weights_only=False)
+        arrays[f"bmadx_{name}"] = npy(out).reshape(-1, 7)[:KEEP]
+        kind, params, steps, fringe = dkd_params(els[name])
+        arrays[f"bmadx_{name}_params"] = params
+        arrays[f"bmadx_{name}_steps"] = np.asarray(steps)
+        arrays[f"bmadx_{name}_fringe"] = np.asarray(fringe)
+        # the reference's own fp64 / fp32 results on the same particles
+        o64 = els[name].track(inc)
+        arrays[f"ref64_{name}"] = npy(o64.particles).reshape(-1, 7)[:KEEP]
+        arrays[f"ref64_{name}_energy"] = npy(o64.energy)
+        o32 = els32[name].track(copy.deepcopy(inc).to(torch.float32))  # Module.to() works in place
+        arrays[f"ref32_{name}"] = npy(o32.particles).reshape(-1, 7)[:KEEP]
+
+    # Bmad / Tao single-particle comparison (tests/test_compare_bmad.py)
+    atomic_mass_eV = physical_constants["atomic mass constant energy equivalent in MeV"][0] * 1e6
+    species = {
+        "proton": cheetah.Species("proton", **F64), "electron": cheetah.Species("electron", **F64),
+        "positron": cheetah.Species("positron", **F64), "antiproton": cheetah.Species("antiproton", **F64),
+        "deuteron": cheetah.Species("deuteron", **F64),
+        "#12C+3": cheetah.Species("#12C+3", num_elementary_charges=t64(3.0), mass_eV=t64(12.0) * atomic_mass_eV, **F64),
+    }
+    tao_els = {
+        "Drift": cheetah.Drift(length=torch.tensor(1.0), tracking_method="drift_kick_drift", **F64),
+        "Dipole": cheetah.Dipole(length=torch.tensor(0.5), angle=torch.tensor(0.2), dipole_e1=torch.tensor(0.1),
+                                 dipole_e2=torch.tensor(0.1), tilt=torch.tensor(0.1), fringe_integral=torch.tensor(0.5),
+                                 fringe_integral_exit=torch.tensor(0.5), gap=torch.tensor(0.06), gap_exit=torch.tensor(0.06),
+                                 fringe_at="both", fringe_type="linear_edge", tracking_method="drift_kick_drift", **F64),
+        "Quadrupole": cheetah.Quadrupole(length=torch.tensor(0.5), k1=torch.tensor(1.0), tracking_method="drift_kick_drift",
+                                         **F64),
+    }
+    coords = t64([1e-3, 2e-3, -3e-3, -1e-3, 2e-3, -1e-3])
+    p0c = t64(5.0e7)
+    arrays["tao_coords"] = npy(coords)
+    arrays["tao_p0c"] = npy(p0c)
+    arrays["tao_species_names"] = np.asarray(["proton", "electron", "positron", "antiproton", "deuteron", "12C+3"])
+    for ename, el in tao_els.items():
+        _, params, steps, fringe = dkd_params(el)
+        arrays[f"tao_{ename}_params"] = params
+        arrays[f"tao_{ename}_fringe"] = np.asarray(fringe)
+    for sname, sp in species.items():
+        tau, delta, ref_energy = bmad_to_cheetah_z_pz(coords[4], coords[5], p0c, sp.mass_eV)
+        key = sname.replace("#", "")
+        arrays[f"tao_{key}_species"] = np.asarray(species_meta(sp))
+        arrays[f"tao_{key}_tau_delta_energy"] = np.asarray([float(tau), float(delta), float(ref_energy)])
+        for ename in tao_els:
+            arrays[f"tao_{key}_{ename}"] = npy(torch.load(os.path.join(REF, "tests/resources/bmad", f"x_tao_{sname}_{ename}.pt")))
+
+    # extra cases run through the reference (fp64): vectorised elements / energies, fringe variants, zero angle,
+    # negative k1, protons at low energy (low_energy_z_correction's other branch), misaligned + tilted TDC
+    sub = cheetah.ParticleBeam(particles=inc.particles[:512], energy=inc.energy, species=inc.species, **F64)
+    prot = cheetah.Species("proton", **F64)
+    sub_p = cheetah.ParticleBeam(particles=inc.particles[:512] * t64([1, 1, 1, 1, 1, 0.01, 1]), energy=t64(9.6e8), species=prot, **F64)
+    sub_e = cheetah.ParticleBeam(particles=inc.particles[:512], energy=t64([[5e7], [2e8]]), species=inc.species, **F64)
+    sub_e1 = cheetah.ParticleBeam(particles=inc.particles[:512], energy=t64([5e7, 2e8]), species=inc.species, **F64)
+    dk = {"tracking_method": "drift_kick_drift", **F64}
+    extra = [
+        ("drift_vec", cheetah.Drift(length=t64([1.0, -1.0, 0.3]), **dk), sub),
+        ("drift_proton", cheetah.Drift(length=t64(2.0), **dk), sub_p),
+        ("quad_vec", cheetah.Quadrupole(length=t64(1.0), k1=t64([1.0, -2.0, 0.0]), tilt=t64(0.42),
+                                        misalignment=t64([0.01, -0.02]), **dk), sub),
+        ("quad_steps5_proton", cheetah.Quadrupole(length=t64(0.4), k1=t64(-3.0), num_steps=5, **dk), sub_p),
+        ("quad_energy_vec", cheetah.Quadrupole(length=t64(0.2), k1=t64([4.2, -4.2]), num_steps=3, **dk), sub_e),
+        ("dipole_vec", cheetah.Dipole(length=t64(1.0), angle=t64([1.0, -2.0]), tilt=t64(0.42), **dk), sub),
+        ("dipole_zero", cheetah.Dipole(length=t64(1.0), angle=t64(0.0), **dk), sub),
+        ("dipole_entrance", cheetah.Dipole(length=t64(0.7), angle=t64(0.3), dipole_e1=t64(0.1), dipole_e2=t64(0.2),
+                                           fringe_integral=t64(0.4), fringe_integral_exit=t64(0.6), gap=t64(0.03),
+                                           gap_exit=t64(0.05), fringe_at="entrance", **dk), sub),
+        ("dipole_exit_proton", cheetah.Dipole(length=t64(0.7), angle=t64(-0.3), dipole_e1=t64(0.1), dipole_e2=t64(0.2),
+                                              fringe_integral=t64(0.4), fringe_integral_exit=t64(0.6), gap=t64(0.03),
+                                              gap_exit=t64(0.05), fringe_at="exit", **dk), sub_p),
+        ("dipole_neither", cheetah.Dipole(length=t64(0.7), angle=t64(0.3), dipole_e1=t64(0.1), fringe_at="neither", **dk), sub),
+        ("rbend", cheetah.RBend(length=t64(1.0), angle=t64([1.0, -2.0]), tilt=t64(0.42), **dk), sub),
+        ("tdc_vec", cheetah.TransverseDeflectingCavity(length=t64(1.0), voltage=t64([[1e7], [2e7], [0.0]]), phase=t64(0.4),
+                                                       frequency=t64(1e9), **dk), sub_e1),
+        ("tdc_misaligned", cheetah.TransverseDeflectingCavity(length=t64(0.8), voltage=t64(5e6), phase=t64(-0.1),
+                                                              frequency=t64(2.856e9), tilt=t64(0.3),
+                                                              misalignment=t64([1e-3, -2e-3]), **dk), sub_p),
+    ]
+    names = []
+    for name, el, beam in extra:
+        out = el.track(beam)
+        kind, params, steps, fringe = dkd_params(el)
+        arrays[f"x_{name}_kind"] = np.asarray(kind)
+        arrays[f"x_{name}_params"] = params
+        arrays[f"x_{name}_steps"] = np.asarray(steps)
+        arrays[f"x_{name}_fringe"] = np.asarray(fringe)
+        arrays[f"x_{name}_in"] = npy(beam.particles)
+        arrays[f"x_{name}_energy"] = npy(beam.energy)
+        arrays[f"x_{name}_species"] = np.asarray(species_meta(beam.species))
+        arrays[f"x_{name}_out"] = npy(out.particles)
+        arrays[f"x_{name}_energy_out"] = npy(out.energy)
+        names.append(name)
+    arrays["extra_names"] = np.asarray(names)
+
+    # consistency goldens (incoming = tests/golden/consistency.npz's beam)
+    for cname in ("Drift_ParticleBeam_drift_kick_drift", "Quadrupole_ParticleBeam_drift_kick_drift",
+                  "Dipole_ParticleBeam_drift_kick_drift", "RBend_ParticleBeam_drift_kick_drift",
+                  "TransverseDeflectingCavity_ParticleBeam_active", "TransverseDeflectingCavity_ParticleBeam_inactive"):
+        with open(os.path.join(REF, "tests/resources/consistency_expected_outgoing", cname + ".pkl"), "rb") as f:
+            exp = pickle.load(f)
+        arrays[f"{cname}__particles"] = npy(exp.particles)[..., :512, :]
+        arrays[f"{cname}__energy"] = npy(exp.energy)
+    save("dkd.npz", **arrays)
+
+
+def t_params(el):
+    f = lambda v: npy(v.to(torch.float64))  # noqa: E731
+    if isinstance(el, cheetah.Dipole):
+        b = torch.broadcast_tensors(el.length, el.angle, el.k1, el.dipole_e1, el.dipole_e2, el.tilt, el.fringe_integral,
+                                    el.fringe_integral_exit, el.gap)
+        return "dipole", np.stack([f(v) for v in b], axis=-1)
+    if isinstance(el, cheetah.Quadrupole):
+        b = torch.broadcast_tensors(el.length, el.k1, el.tilt, el.misalignment[..., 0], el.misalignment[..., 1])
+        return "quadrupole", np.stack([f(v) for v in b], axis=-1)
+    if isinstance(el, cheetah.Sextupole):
+        b = torch.broadcast_tensors(el.length, el.k2, el.tilt, el.misalignment[..., 0], el.misalignment[..., 1])
+        return "sextupole", np.stack([f(v) for v in b], axis=-1)
+    return "drift", f(el.length)[..., None]
+
+
+def gen_second_order():
+    arrays = {}
+    incoming = load_incoming().to(torch.float64)
+    elec = incoming.species
+    prot = cheetah.Species("proton", **F64)
+    so = {"tracking_method": "second_order", **F64}
+    cases = [
+        ("drift", cheetah.Drift(length=t64([1.0, -1.0, 0.25]), **so), t64(1e8), elec),
+        ("drift_lowE", cheetah.Drift(length=t64(0.7), **so), t64([6e6, 2e7]), elec),
+        ("quad", cheetah.Quadrupole(length=t64(1.0), k1=t64([1.0, -2.0, 0.0, 30.0]), tilt=t64(0.42),
+                                    misalignment=t64([0.01, -0.02]), **so), t64(1.0732e8), elec),
+        ("quad_small", cheetah.Quadrupole(length=t64(0.2), k1=t64([4.2, -4.2, 1e-3, -1e-6]), **so), t64(1e8), elec),
+        ("quad_proton", cheetah.Quadrupole(length=t64(0.5), k1=t64(1.5), tilt=t64(-0.2), **so), t64(1.5e9), prot),
+        ("dipole", cheetah.Dipole(length=t64(1.0), angle=t64([1.0, -2.0, 1e-3, 0.0]), tilt=t64(0.42), **so), t64(1e8), elec),
+        ("dipole_full", cheetah.Dipole(length=t64(0.5), angle=t64(0.2), k1=t64([0.0, 1.3, -0.8]), dipole_e1=t64(0.1),
+                                       dipole_e2=t64(0.05), tilt=t64(0.1), fringe_integral=t64(0.5),
+                                       fringe_integral_exit=t64(0.4), gap=t64(0.06), **so), t64(6e6), elec),
+        ("rbend", cheetah.RBend(length=t64(1.0), angle=t64([1.0, -2.0]), tilt=t64(0.42), **so), t64(1e8), elec),
+        ("sextupole", cheetah.Sextupole(length=t64(1.0), k2=t64([1.0, -2.0, 0.0]), tilt=t64(0.42),
+                                        misalignment=t64([0.01, -0.02]), **so), t64(1e8), elec),
+    ]
+    names = []
+    x = incoming.particles[:512]
+    arrays["incoming"] = npy(x)
+    arrays["incoming_f32"] = npy(x.to(torch.float32))
+    for name, el, energy, sp in cases:
+        kind, params = t_params(el)
+        T = el.second_order_transfer_map(energy, sp)
+        beam = cheetah.ParticleBeam(particles=x, energy=energy, species=sp, **F64)
+        out = el.track(beam)
+        arrays[f"{name}_kind"] = np.asarray(kind)
+        arrays[f"{name}_params"] = params
+        arrays[f"{name}_energy"] = npy(energy)
+        arrays[f"{name}_species"] = np.asarray(species_meta(sp))
+        arrays[f"{name}_T"] = npy(T)
+        arrays[f"{name}_out"] = npy(out.particles)
+        # the same in fp32 (element, beam and tensors in fp32)
+        el32 = el.clone().to(torch.float32) if hasattr(el, "clone") else el.to(torch.float32)
+        beam32 = cheetah.ParticleBeam(particles=x.to(torch.float32), energy=energy.to(torch.float32),
+                                      species=cheetah.Species(sp.name, dtype=torch.float32), dtype=torch.float32)
+        arrays[f"{name}_out_f32"] = npy(el32.track(beam32).particles)
+        names.append(name)
+    arrays["names"] = np.asarray(names)
+    for cname in ("Drift_ParticleBeam_second_order", "Quadrupole_ParticleBeam_second_order",
+                  "Dipole_ParticleBeam_second_order", "RBend_ParticleBeam_second_order",
+                  "Sextupole_ParticleBeam_second_order"):
+        with open(os.path.join(REF, "tests/resources/consistency_expected_outgoing", cname + ".pkl"), "rb") as f:
+            exp = pickle.load(f)
+        arrays[f"{cname}__particles"] = npy(exp.particles)[..., :512, :]
+    save("second_order.npz", **arrays)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dkd", "second_order"]
+    for w in which:
+        globals()["gen_" + w]()

@@ -48,7 +48,7 @@ def test_reference_consistency_goldens_misc(golden):
     elements = {
         "Solenoid_ParticleBeam_default": ca.Solenoid(length=t(1.0), k=t([1.0, -2.0]), misalignment=t([0.01, -0.02])),
         "Undulator_ParticleBeam_default": ca.Undulator(length=t(1.0), period=t(0.1), kx=t(1.3), **kw),
-        "Sextupole_ParticleBeam_linear": ca.Sextupole(length=t(1.0), k2=t([1.0, -2.0]), tilt=t(0.42), misalignment=t([0.01, -0.02])),
+        "Sextupole_ParticleBeam_linear": ca.Sextupole(length=t(1.0), k2=t([1.0, -2.0]), tilt=t(0.42), misalignment=t([0.01, -0.02]), tracking_method="linear"),
     }
     keep = int(g["keep"])
     for name, el in elements.items():
