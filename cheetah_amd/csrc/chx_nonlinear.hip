@@ -375,9 +375,12 @@ extern "C" int chx_dkd_track(int kind, const void* x_in, const void* params, con
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+__device__ __forceinline__ float nl_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double nl_fma(double a, double b, double c) { return fma(a, b, c); }
+
 // The quadratic form is symmetric in (j,k): the 343 coefficients of a batch row are folded once per
 // workgroup into U[i][j<=k] = T_ijk + T_ikj (196 doubles in LDS, read wave-uniformly), so a particle costs
-// 28 products + 196 fp64 FMAs instead of 343 + 49.
+// 28 products + 196 FMAs instead of 343 + 49.
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __restrict__ x_in, const T* __restrict__ Tt,
                                                                  T* __restrict__ x_out, int64_t B, int64_t Bx,
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
                                                                  int out_vec_ok) {
     constexpr int TP = CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
-    __shared__ double U[7 * 28];
+    __shared__ T U[7 * 28];  // arithmetic in the storage dtype, like the reference's einsum
 
     const int64_t tiles_per_row = (N + TP - 1) / TP;
     const int64_t b = blockIdx.x / tiles_per_row;
@@ -402,16 +405,16 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
         while (r >= 7 - j) { r -= 7 - j; ++j; }
         const int k = j + r;
         const T* Tb = Tt + ((BT == 1) ? 0 : b) * 343 + i * 49;
-        U[threadIdx.x] = (j == k) ? (double)Tb[j * 7 + k] : (double)Tb[j * 7 + k] + (double)Tb[k * 7 + j];
+        U[threadIdx.x] = (j == k) ? Tb[j * 7 + k] : Tb[j * 7 + k] + Tb[k * 7 + j];
     }
     tile_load<T>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec);
     __syncthreads();
 
     const int p = threadIdx.x;
     if (p < np) {
-        double x[7], q[28], y[7];
+        T x[7], q[28], y[7];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) x[j] = (double)lds[p * 7 + j];
+        for (int j = 0; j < 7; ++j) x[j] = lds[p * 7 + j];
         {
             int c = 0;
 #pragma unroll
@@ -421,13 +424,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            double acc = U[i * 28] * q[0];
+            T acc = U[i * 28] * q[0];
 #pragma unroll
-            for (int c = 1; c < 28; ++c) acc = fma(U[i * 28 + c], q[c], acc);
+            for (int c = 1; c < 28; ++c) acc = nl_fma(U[i * 28 + c], q[c], acc);
             y[i] = acc;
         }
 #pragma unroll
-        for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)y[j];
+        for (int j = 0; j < 7; ++j) lds[p * 7 + j] = y[j];
     }
     __syncthreads();
     tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec);

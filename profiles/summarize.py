@@ -33,12 +33,14 @@ for which in ("fetch", "write"):
     for r in csv.DictReader(open(os.path.join(src, f"pmc_{which}", "probe_counter_collection.csv"))):
         if "apply_tile_kernel" in r["Kernel_Name"]:
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-            agg[(int(r["Grid_Size"]), r["Counter_Name"])].append((float(r["Counter_Value"]), dur))
+            # rows per lane = PPT template argument: apply_tile_kernel<T, PPT, MODE>
+            ppt = int(r["Kernel_Name"].split("<")[1].split(",")[1])
+            agg[(int(r["Grid_Size"]), r["Counter_Name"], ppt)].append((float(r["Counter_Value"]), dur))
 lines = ["| grid (threads) | particles | counter | raw per launch (KiB) | corrected bytes per launch | algorithmic bytes | ratio |",
          "|---|---|---|---|---|---|---|"]
 traffic = {}
-for (grid, cname), vals in sorted(agg.items()):
-    n_part = {500224: 1_000_000, 8000000: 16_000_000}.get(grid, grid * 2)
+for (grid, cname, ppt), vals in sorted(agg.items()):
+    n_part = {(500224, 2): 1_000_000}.get((grid, ppt), grid * ppt)  # 1e6 rows fill 1954 tiles of 512 (last partial)
     raw = sum(v for v, _ in vals) / len(vals)
     corr = raw * 1024 * (2.0 if cname == "FETCH_SIZE" else 1.0)
     algo = 28.0 * n_part

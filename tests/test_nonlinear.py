@@ -223,7 +223,7 @@ def test_hip_second_order_tensors_and_tracking(golden, oracle, tag):
         ref = g[f"{name}_out" if tag == "f64" else f"{name}_out_f32"].reshape(out.shape)
         for j in range(6):
             # same T, same x: only the summation order differs from the oracle
-            assert _relerr(out[..., j], ora[..., j]) < (1e-13 if tag == "f64" else 3e-7), (name, j)
+            assert _relerr(out[..., j], ora[..., j]) < (1e-13 if tag == "f64" else 2e-6), (name, j)
             assert _relerr(out[..., j], ref[..., j]) < (1e-11 if tag == "f64" else 2e-5), (name, j)
         assert np.all(out[..., 6] == 1.0), name
 
