@@ -68,8 +68,11 @@ def c3(B=4096, N=100_000):
     o = out["b"]
     ms_sig = timeit(lambda: ca._ops.moments(o.particles, o.survival_probabilities), 5, 2)
     gbytes = B * N * 28 / 1e9
+    del o, out["b"]
+    ms_fused = timeit(lambda: seg.track_moments(beam), 5, 2)  # chx_track_moments: no (B, N, 7) output at all
     return {"config": f"C3 k1 scan B={B} x N={N}, fp32, shared beam", "track_ms": ms, "all_moments_ms": ms_sig,
-            "output_GB": gbytes, "write_GBps": gbytes / (ms * 1e-3), "steps_per_s": B * N * 13 / (ms * 1e-3)}
+            "fused_track_moments_ms": ms_fused, "output_GB": gbytes, "write_GBps": gbytes / (ms * 1e-3),
+            "steps_per_s": B * N * 13 / (ms * 1e-3), "fused_steps_per_s": B * N * 13 / (ms_fused * 1e-3)}
 
 
 def c4(N=1_000_000, g=128):

@@ -408,6 +408,37 @@ def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Ten
     return out.reshape(*batch_shape, MOM_NOUT)
 
 
+def track_moments(particles: torch.Tensor, survival: torch.Tensor | None, tm: torch.Tensor) -> torch.Tensor:
+    """Moments (…,29) of `particles @ tm.mT` without materialising the tracked particles (chx_track_moments)."""
+    require_device(particles, tm)
+    if particles.requires_grad or tm.requires_grad:
+        return moments(apply_map(particles, tm), survival)  # differentiable path: track, then reduce
+    if tm.dtype != particles.dtype:
+        raise RuntimeError(f"transfer map dtype {tm.dtype} does not match particle dtype {particles.dtype}")
+    N = particles.shape[-2]
+    sshape = survival.shape[:-1] if survival is not None else ()
+    in_shape = bshapes(particles.shape[:-2], sshape)
+    batch_shape = bshapes(in_shape, tm.shape[:-2])
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    R, BR = flat_bcast(tm, batch_shape, 2)
+    x, R = aligned(x), R.contiguous()
+    w, Bw = None, 1
+    if survival is not None:
+        w, Bw = flat_bcast(survival.to(particles.dtype), batch_shape, 1)
+        w = w.contiguous()
+    # shift point of the one-pass second moments: the incoming means (one cheap pass over the input rows)
+    sums = moment_sums(x, w if (Bw == 1 or Bw == Bx) else None, Bx)
+    centre = (sums[:, 2:8] / sums[:, 0:1]).contiguous()
+    lib = _lib.lib()
+    ws_bytes = lib.chx_track_moments_workspace_bytes(B, N)
+    ws = workspace(ws_bytes, x.device)
+    out = torch.empty((B, MOM_NOUT), dtype=torch.float64, device=x.device)
+    check(lib.chx_track_moments(ptr(x), ptr(w), ptr(R), ptr(centre), B, Bx, BR, Bw, N, dtype_code(x.dtype), ptr(out),
+                                ptr(ws), ws_bytes, stream_ptr()), "chx_track_moments")
+    return out.reshape(*batch_shape, MOM_NOUT)
+
+
 # ---------------------------------------------------------------------------------------------
 # cloud in cell / histogram
 def _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge, grid=None,

@@ -265,6 +265,157 @@ __global__ void transpose_maps_kernel(const T* __restrict__ R, int64_t B, T* __r
     Rt[b * 49 + j * 7 + i] = R[idx];
 }
 
+// ---- fused observables: moments of R_b x without writing the tracked particles --------------------------------
+// (element.py:180-191 followed by particle_beam.py:1672-1943, e.g. a k1 scan that only
+// reads sigma_x / sigma_y of the outgoing beams.) Shifted single pass: with d = R_b x - c_b,
+//   acc = { sum w, sum w^2, sum w d_a (6), sum w d_a d_b (21, a<=b) }
+// where c_b = R_b centre is the image of a point near the incoming mean, so |mean(d)| << sigma and the one-pass
+// second moments do not cancel. The apply runs in the storage dtype with the same fma chain as chx_apply_affine7
+// (bit-identical y), the accumulation in fp64.
+constexpr int kTM = 29;
+
+template <typename T> __device__ __forceinline__ T tm_fma(T a, T b, T c);
+template <> __device__ __forceinline__ float tm_fma<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double tm_fma<double>(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ void tm_accumulate(const T (&R)[42], const T (&x)[7], double w, const double (&c)[6],
+                                              double (&a)[kTM]) {
+    double d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        T y = R[i * 7] * x[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) y = tm_fma<T>(R[i * 7 + j], x[j], y);
+        d[i] = (double)y - c[i];
+    }
+    a[0] += w;
+    a[1] += w * w;
+    int k = 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double wd = w * d[i];
+        a[2 + i] += wd;
+#pragma unroll
+        for (int j = i; j < 6; ++j) a[k++] = fma(wd, d[j], a[k]);
+    }
+}
+
+// c = R centre (fp64; centre[6] with the affine 1 appended); NULL centre -> no shift
+template <typename T>
+__device__ __forceinline__ void tm_centre(const T (&R)[42], const double* __restrict__ centre, double (&c)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = 0.0;
+        if (centre) {
+            s = (double)R[i * 7 + 6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s += (double)R[i * 7 + j] * centre[j];
+        }
+        c[i] = s;
+    }
+}
+
+// Shared input beam, many maps: ONE LANE PER BATCH ROW. The lane keeps its map (42 values) and its 29 fp64
+// accumulators in registers and walks over a chunk of particles staged in LDS; every lane reads the same LDS
+// address (broadcast, conflict-free), and there is no cross-lane reduction at all.
+template <typename T> struct tm_cfg { static constexpr int chunk = sizeof(T) == 4 ? 1024 : 512; };  // 28 KiB of LDS
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void track_moments_rows_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                      const T* __restrict__ Rm,
+                                                                      const double* __restrict__ centre, int64_t B,
+                                                                      int64_t N, int64_t per_chunk,
+                                                                      double* __restrict__ partials) {
+    constexpr int kTMChunk = tm_cfg<T>::chunk;
+    __shared__ __attribute__((aligned(16))) T xs[kTMChunk * 7];
+    __shared__ T ws[kTMChunk];
+    const int64_t b = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x;
+    const int64_t bb = b < B ? b : B - 1;
+    T R[42];
+#pragma unroll
+    for (int k = 0; k < 42; ++k) R[k] = Rm[bb * 49 + k];
+    double c[6], acc[kTM];
+    tm_centre<T>(R, centre, c);
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) acc[k] = 0.0;
+    const int64_t n_begin = (int64_t)blockIdx.y * per_chunk;
+    const int64_t n_end = (n_begin + per_chunk < N) ? n_begin + per_chunk : N;
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += kTMChunk) {
+        const int np = (int)((n_end - n0 < kTMChunk) ? (n_end - n0) : kTMChunk);
+        __syncthreads();
+        tile_load<T>(x + n0 * 7, xs, np * 7, chx_aligned16(x) && ((n0 * 7 * (int64_t)sizeof(T)) & 15) == 0);
+        for (int i = threadIdx.x; i < np; i += CHX_BLOCK) ws[i] = w ? w[n0 + i] : (T)1;
+        __syncthreads();
+        for (int i = 0; i < np; ++i) {
+            T xv[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xv[j] = xs[i * 7 + j];
+            tm_accumulate<T>(R, xv, (double)ws[i], c, acc);
+        }
+    }
+    if (b < B) {
+        double* p = partials + ((int64_t)blockIdx.y * B + b) * kTM;
+#pragma unroll
+        for (int k = 0; k < kTM; ++k) p[k] = acc[k];
+    }
+}
+
+// General case (per-row inputs or few rows): lane per particle, block reduction per workgroup (tiled_reduce).
+template <typename T>
+struct TrackMomFn {
+    T R[42];
+    double c[6];
+    __device__ __forceinline__ void accumulate(const double (&xd)[7], double w, int64_t, double (&a)[kTM]) {
+        T xv[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xv[j] = (T)xd[j];  // exact: xd came from T
+        tm_accumulate<T>(R, xv, w, c, a);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void track_moments_particles_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                           const T* __restrict__ Rm,
+                                                                           const double* __restrict__ centre, int64_t Bx,
+                                                                           int64_t BR, int64_t Bw, int64_t N,
+                                                                           double* __restrict__ partials) {
+    TrackMomFn<T> f;
+    const int64_t b = blockIdx.y;
+    const T* Rb = Rm + ((BR == 1) ? 0 : b) * 49;
+#pragma unroll
+    for (int k = 0; k < 42; ++k) f.R[k] = Rb[k];
+    tm_centre<T>(f.R, centre ? centre + ((Bx == 1) ? 0 : b) * 6 : nullptr, f.c);
+    tiled_reduce<T, kTM, TrackMomFn<T>>(x, w, Bx, Bw, N, f, partials + ((int64_t)blockIdx.x * gridDim.y + b) * kTM);
+}
+
+// out[b] from partials[chunk][b][29]: sum the chunks in order, undo the shift, normalise (statistics.py:41-46)
+template <typename T>
+__global__ void track_moments_finalize_kernel(const double* __restrict__ partials, int nchunk, const T* __restrict__ Rm,
+                                              const double* __restrict__ centre, int64_t B, int64_t Bx, int64_t BR,
+                                              double* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double a[kTM];
+    for (int k = 0; k < kTM; ++k) a[k] = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int k = 0; k < kTM; ++k) a[k] += partials[((int64_t)ch * B + b) * kTM + k];
+    T R[42];
+    for (int k = 0; k < 42; ++k) R[k] = Rm[((BR == 1) ? 0 : b) * 49 + k];
+    double c[6];
+    tm_centre<T>(R, centre ? centre + ((Bx == 1) ? 0 : b) * 6 : nullptr, c);
+    const double W = a[0], W2 = a[1];
+    double* o = out + b * CHX_MOM_NOUT;
+    o[0] = W;
+    o[1] = W2;
+    double m[6];
+    for (int j = 0; j < 6; ++j) { m[j] = a[2 + j] / W; o[2 + j] = c[j] + m[j]; }
+    const double cf = W - W2 / W;
+    int k = 8;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j, ++k) o[k] = (a[k] - W * m[i] * m[j]) / cf;
+}
+
 int check_red(const void* x, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype) {
     if (!x || B < 1 || N < 1 || B > 65535) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bw, B)) return CHX_ERR_INVALID_ARG;
@@ -360,6 +511,71 @@ extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, 
     st = chx_moment_centred(x, w, sums, B, Bx, Bw, N, dtype, m2, workspace, need, stream);
     if (st != CHX_OK) return st;
     return chx_moment_finalize(sums, m2, B, out, stream);
+}
+
+// ---- fused track + moments ------------------------------------------------------------------------------------
+static int64_t tm_chunks(int64_t B, int64_t N, bool rows_path, int dtype) {
+    if (rows_path) {
+        // ~1024 workgroups in total; each chunk at least one LDS fill
+        const int64_t row_blocks = (B + CHX_BLOCK - 1) / CHX_BLOCK;
+        int64_t chunks = (1024 + row_blocks - 1) / row_blocks;
+        const int64_t fill = dtype == CHX_F32 ? 1024 : 512;
+        const int64_t max_chunks = (N + fill - 1) / fill;
+        if (chunks > max_chunks) chunks = max_chunks;
+        return chunks < 1 ? 1 : chunks;
+    }
+    return red_nblk(B, N, tile_rows(dtype));
+}
+static bool tm_rows_path(int64_t B, int64_t Bx, int64_t BR, int64_t Bw) { return Bx == 1 && Bw == 1 && BR == B && B >= 64; }
+
+extern "C" size_t chx_track_moments_workspace_bytes(int64_t B, int64_t N) {
+    if (B < 1 || N < 1) return 0;
+    int64_t c = tm_chunks(B, N, true, CHX_F64);
+    const int64_t c2 = tm_chunks(B, N, false, CHX_F64);
+    if (c2 > c) c = c2;
+    return (size_t)(c * B * kTM * sizeof(double));
+}
+
+extern "C" int chx_track_moments(const void* x_in, const void* w, const void* R, const double* centre, int64_t B,
+                                 int64_t Bx, int64_t BR, int64_t Bw, int64_t N, int dtype, double* out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    int st = check_red(x_in, B, Bx, w ? Bw : 1, N, dtype);
+    if (st != CHX_OK) return st;
+    if (!R || !out || !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    if (!w) Bw = 1;
+    const bool rows = tm_rows_path(B, Bx, BR, Bw);
+    const int64_t chunks = tm_chunks(B, N, rows, dtype);
+    if (!workspace || workspace_bytes < (size_t)(chunks * B * kTM * sizeof(double))) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    if (rows) {
+        const int64_t per_chunk = (N + chunks - 1) / chunks;
+        dim3 grid((unsigned)((B + CHX_BLOCK - 1) / CHX_BLOCK), (unsigned)chunks);
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(track_moments_rows_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+                               (const float*)w, (const float*)R, centre, B, N, per_chunk, part);
+        else
+            hipLaunchKernelGGL(track_moments_rows_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
+                               (const double*)w, (const double*)R, centre, B, N, per_chunk, part);
+    } else {
+        dim3 grid((unsigned)chunks, (unsigned)B);
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(track_moments_particles_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+                               (const float*)w, (const float*)R, centre, Bx, BR, Bw, N, part);
+        else
+            hipLaunchKernelGGL(track_moments_particles_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
+                               (const double*)w, (const double*)R, centre, Bx, BR, Bw, N, part);
+    }
+    CHX_CHECK_LAUNCH();
+    const unsigned fb = (unsigned)((B + 63) / 64);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(track_moments_finalize_kernel<float>, dim3(fb), dim3(64), 0, s, part, (int)chunks,
+                           (const float*)R, centre, B, Bx, BR, out);
+    else
+        hipLaunchKernelGGL(track_moments_finalize_kernel<double>, dim3(fb), dim3(64), 0, s, part, (int)chunks,
+                           (const double*)R, centre, B, Bx, BR, out);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
 }
 
 extern "C" int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,

@@ -118,6 +118,17 @@ class ParameterBeam(Beam):
         return self.__class__(mu, cov, self.energy if energy is None else energy, total_charge=self.total_charge,
                               s=self.s + length if length is not None else self.s, species=self.species)
 
+    @classmethod
+    def _from_moment_vector(cls, mom: torch.Tensor, dtype, energy, total_charge=None, s=None, species=None):
+        """(…,29) [W, W2, mu(6), cov upper triangle(21)] (chx_moments layout) -> ParameterBeam with the affine 7th
+        coordinate (mu_6 = 1, zero covariance), like particle_beam.py `as_parameter_beam`."""
+        iu = torch.triu_indices(6, 6, device=mom.device)
+        cov = torch.zeros((*mom.shape[:-1], 7, 7), dtype=mom.dtype, device=mom.device)
+        cov[..., iu[0], iu[1]] = mom[..., 8:29]
+        cov[..., iu[1], iu[0]] = mom[..., 8:29]
+        mu = torch.cat([mom[..., 2:8], torch.ones_like(mom[..., :1])], dim=-1)
+        return cls(mu.to(dtype), cov.to(dtype), energy, total_charge=total_charge, s=s, species=species)
+
     def _view(self) -> "ParameterBeam":
         return self.__class__(self.mu, self.cov, self.energy, total_charge=self.total_charge, s=self.s,
                               species=self.species)

@@ -170,6 +170,15 @@ class ParticleBeam(Beam):
         self.__dict__["_moment_cache"] = (key, out)
         return out
 
+    def as_parameter_beam(self):
+        """ParameterBeam with this beam's means and covariances (particle_beam.py `as_parameter_beam`): one fused
+        chx_moments call instead of 27 separate reductions."""
+        from .parameter_beam import ParameterBeam
+
+        # like the reference (particle_beam.py:1168-1178) `s` restarts at 0; the species is kept
+        return ParameterBeam._from_moment_vector(self._moments(), self.particles.dtype, self.energy,
+                                                 total_charge=self.total_charge, species=self.species)
+
     def _mu(self, i: int) -> torch.Tensor:
         return self._moments()[..., 2 + i].to(self.particles.dtype)
 

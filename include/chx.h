@@ -153,6 +153,16 @@ int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw,
 /* backward of chx_moments wrt x: given d_out[B][29] (double; entries 0,1 ignored) */
 int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,
                     int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX, void* stream);
+/* Fused observables: out[b] = chx_moments of the tracked beam R[b] x without ever
+ * writing it (element.py:180-191 followed by particle_beam.py:1672-1943), e.g. sigma_x(k1) over a scan of B
+ * settings on one shared beam. One pass; second moments are accumulated about c_b = R[b] centre, where
+ * centre[Bx][6] (double, device; e.g. the incoming means from chx_moment_sums) must lie within a few sigma of the
+ * incoming mean (NULL = origin). y = R x is evaluated exactly like chx_apply_affine7 (same fma chain).
+ * With a shared beam (Bx == Bw == 1, BR == B >= 64) each lane owns one batch row: no reduction across lanes. */
+size_t chx_track_moments_workspace_bytes(int64_t B, int64_t N);
+int chx_track_moments(const void* x_in, const void* w, const void* R, const double* centre, int64_t B, int64_t Bx,
+                      int64_t BR, int64_t Bw, int64_t N, int dtype, double* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ---- cloud-in-cell deposition (a12; utils/cloud_in_cell.py:8-451) and Screen images
  * (a11; screen.py:241-344). Positions are read straight out of the particle array:
