@@ -26,6 +26,7 @@ from .accelerator import (  # noqa: F401
     TransverseDeflectingCavity,
     Solenoid,
     SpaceChargeKick,
+    Superimposed,
     Undulator,
     VerticalCorrector,
 )

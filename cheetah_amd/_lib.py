@@ -104,6 +104,8 @@ SIGNATURES = {
     "chx_track_moments_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "chx_track_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int,
                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_aperture_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p,
+                                  c_void_p]),
     "chx_dkd_num_params": (c_int, [c_int]),
     "chx_dkd_track": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_double, ctypes.c_int32, ctypes.c_int32,
                               c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -408,6 +408,28 @@ def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Ten
     return out.reshape(*batch_shape, MOM_NOUT)
 
 
+def aperture_mask(particles: torch.Tensor, survival: torch.Tensor, x_max: torch.Tensor, y_max: torch.Tensor,
+                  shape: str) -> torch.Tensor:
+    """survival * inside(x, y) (aperture.py:104-128, chx_aperture_mask) with torch broadcasting of the vector dims."""
+    require_device(particles, survival, x_max, y_max)
+    if shape not in ("rectangular", "elliptical"):
+        raise AssertionError(f"Unknown aperture shape {shape}")
+    dt = particles.dtype
+    N = particles.shape[-2]
+    lim_shape = bshapes(x_max.shape, y_max.shape)
+    batch_shape = bshapes(particles.shape[:-2], survival.shape[:-1], lim_shape)
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    s, Bs = flat_bcast(survival.to(dt), batch_shape, 1)
+    limits = torch.stack(torch.broadcast_tensors(x_max.to(dt), y_max.to(dt)), dim=-1)
+    lim, Bl = flat_bcast(limits, batch_shape, 1)
+    x, s, lim = x.contiguous(), s.contiguous(), lim.contiguous()
+    out = torch.empty((B, N), dtype=dt, device=x.device)
+    check(_lib.lib().chx_aperture_mask(ptr(x), ptr(s), ptr(lim), 0 if shape == "rectangular" else 1, B, Bx, Bs, Bl, N,
+                                       dtype_code(dt), ptr(out), stream_ptr()), "chx_aperture_mask")
+    return out.reshape(*batch_shape, N)
+
+
 def track_moments(particles: torch.Tensor, survival: torch.Tensor | None, tm: torch.Tensor) -> torch.Tensor:
     """Moments (…,29) of `particles @ tm.mT` without materialising the tracked particles (chx_track_moments)."""
     require_device(particles, tm)

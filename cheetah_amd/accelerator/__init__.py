@@ -10,3 +10,4 @@ from .quadrupole import Quadrupole  # noqa: F401
 from .screen import Screen  # noqa: F401
 from .segment import Segment  # noqa: F401
 from .space_charge_kick import SpaceChargeKick  # noqa: F401
+from .superimposed import Superimposed  # noqa: F401

@@ -27,12 +27,10 @@ class Drift(Element):
     def is_skippable(self) -> bool:
         return self.tracking_method == "linear"
 
-    def split(self, resolution):
-        import torch
+    _merge_equal = ("tracking_method",)
 
-        n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
-        return [Drift(self.length / n, tracking_method=self.tracking_method, dtype=self.length.dtype,
-                      device=self.length.device) for _ in range(n)]
+    def split(self, resolution):
+        return self._split_evenly(resolution)
 
     @property
     def defining_features(self) -> list[str]:

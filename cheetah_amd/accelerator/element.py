@@ -29,6 +29,15 @@ class PhysicsWarning(UserWarning):
 _name_counter = 0
 
 
+def merge_element_names(*names: str, use_shared_prefix: bool = True) -> str:
+    """Name of a merged element (utils/names.py:17-38): the shared prefix if there is one, else the names joined."""
+    import os
+
+    assert len(names) > 0, "At least one name must be provided."
+    common_prefix = os.path.commonprefix(list(names))
+    return common_prefix if use_shared_prefix and len(common_prefix) > 0 else "_".join(names)
+
+
 def _unique_name() -> str:
     global _name_counter
     _name_counter += 1
@@ -253,7 +262,46 @@ class Element(nn.Module):
             metadata=deepcopy(self.metadata), sanitize_name=False)
 
     def split(self, resolution: torch.Tensor) -> list["Element"]:
+        """Slices no longer than `resolution` (element.py:338-347); elements that cannot be split return [self]."""
         return [self]
+
+    def _split_evenly(self, resolution) -> list["Element"]:
+        """`num_splits = ceil(max|length| / resolution)` equal slices, everything else unchanged (drift.py:160-173,
+        quadrupole.py:261-278, solenoid.py:126-141)."""
+        n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
+        parts = []
+        for i in range(n):
+            part = self.clone()
+            part.length = self.length / n
+            part.name = f"{self.name}_split_{i}"
+            part.metadata = self.metadata
+            parts.append(part)
+        return parts
+
+    #: merge rules (drift.py:175-187, quadrupole.py:280-301, sextupole.py:133-153, solenoid.py:143-157):
+    #: attributes that must be equal, attributes averaged with the lengths as weights, attributes summed
+    _merge_equal: tuple[str, ...] | None = None
+    _merge_weighted: tuple[str, ...] = ()
+    _merge_summed: tuple[str, ...] = ()
+
+    def merge(self, other: "Element") -> "Element | None":
+        """Merged element, or None when the two cannot be merged / the type does not support it (element.py:349-358)."""
+        if self._merge_equal is None or type(self) is not type(other):
+            return None
+        for attr in self._merge_equal:
+            a, b = getattr(self, attr), getattr(other, attr)
+            if not (a.equal(b) if isinstance(a, torch.Tensor) else a == b):
+                return None
+        merged = self.clone()
+        total = self.length + other.length
+        for attr in self._merge_weighted:
+            setattr(merged, attr, (getattr(self, attr) * self.length + getattr(other, attr) * other.length) / total)
+        for attr in self._merge_summed:
+            setattr(merged, attr, getattr(self, attr) + getattr(other, attr))
+        merged.length = total
+        merged.name = merge_element_names(self.name, other.name)
+        merged.metadata = {**other.metadata, **self.metadata}
+        return merged
 
     def __repr__(self) -> str:
         feats = ", ".join(f"{f}={getattr(self, f)!r}" for f in self.defining_features)

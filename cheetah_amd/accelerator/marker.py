@@ -68,17 +68,21 @@ class Aperture(Marker):
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         if not self.is_active:
             return incoming._view()
-        x, y = incoming.particles[..., 0], incoming.particles[..., 2]
-        xm, ym = self.x_max.unsqueeze(-1), self.y_max.unsqueeze(-1)
-        if self.shape == "rectangular":
-            inside = (x.abs() <= xm) & (y.abs() <= ym)
-        elif self.shape == "elliptical":
-            inside = (x.square() / xm.square() + y.square() / ym.square()) <= 1.0
-        else:
-            raise ValueError(f"Invalid aperture shape {self.shape}")
+        if not isinstance(incoming, ParticleBeam):  # aperture.py:94-100
+            import warnings
+
+            from .element import PhysicsWarning
+
+            warnings.warn("Aperture tracking is currently only supported for `ParticleBeam`.", PhysicsWarning,
+                          stacklevel=2)
+            return incoming
+        assert bool((self.x_max >= 0).all()) and bool((self.y_max >= 0).all())
+        assert self.shape in ["rectangular", "elliptical"], f"Unknown aperture shape {self.shape}"
+        # one streaming kernel (chx_aperture_mask): strict `<` for the rectangle, `<= 1` for the ellipse
+        survival = _ops.aperture_mask(incoming.particles, incoming.survival_probabilities, self.x_max, self.y_max,
+                                      self.shape)
         return ParticleBeam(incoming.particles, incoming.energy, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities * inside, s=incoming.s,
-                            species=incoming.species)
+                            survival_probabilities=survival, s=incoming.s, species=incoming.species)
 
     @property
     def defining_features(self) -> list[str]:

@@ -28,6 +28,12 @@ class Solenoid(Element):
     def _builder_params(self):
         return [self.length, self.k, self.misalignment[..., 0], self.misalignment[..., 1]]
 
+    _merge_equal = ("misalignment",)
+    _merge_weighted = ("k",)
+
+    def split(self, resolution):
+        return self._split_evenly(resolution)
+
     @property
     def is_active(self) -> bool:
         return bool((self.k != 0).any().item())
@@ -95,6 +101,8 @@ class Sextupole(Element):
 
     def _t_params(self):
         return [self.length, self.k2, self.tilt, self.misalignment[..., 0], self.misalignment[..., 1]]
+
+    _merge_equal = ("tracking_method", "k2", "misalignment", "tilt")
 
     @property
     def is_active(self) -> bool:

@@ -42,11 +42,12 @@ class Quadrupole(Element):
     def is_active(self) -> bool:
         return bool((self.k1 != 0).any().item())
 
+    _merge_equal = ("tracking_method", "misalignment", "tilt")
+    _merge_weighted = ("k1",)
+    _merge_summed = ("num_steps",)
+
     def split(self, resolution):
-        n = max(int(torch.ceil(self.length.abs().max() / resolution).item()), 1)
-        fk = {"dtype": self.length.dtype, "device": self.length.device}
-        return [Quadrupole(self.length / n, self.k1, misalignment=self.misalignment, tilt=self.tilt,
-                           num_steps=self.num_steps, tracking_method=self.tracking_method, **fk) for _ in range(n)]
+        return self._split_evenly(resolution)
 
     @property
     def defining_features(self) -> list[str]:

@@ -268,22 +268,146 @@ class Segment(Element):
                 incoming = item.track_elementwise(incoming, fused) if isinstance(item, Segment) else item.track(incoming)
         return incoming
 
-    def get_beam_attrs_along_segment(self, attr_names, incoming: ParticleBeam, resolution=None):
-        """Beam attributes after every element (segment.py:658-700)."""
-        single = isinstance(attr_names, str)
-        names = (attr_names,) if single else tuple(attr_names)
-        beams = [incoming]
-        for e in self.elements:
-            beams.append(e.track(beams[-1]))
-        results = tuple(torch.stack(torch.broadcast_tensors(*[getattr(b, n) for b in beams]), dim=-1) for n in names)
-        return results[0] if single else results
+    def beam_along_segment_generator(self, incoming, resolution=None):
+        """Beams at the end of every element, or every `resolution` metres (segment.py:631-656)."""
+        if resolution is not None:
+            yield from self.__class__(elements=self.split(resolution),
+                                      name=f"{self.name}_split").beam_along_segment_generator(incoming)
+        else:
+            yield incoming
+            for element in self.elements:
+                incoming = element.track(incoming)
+                yield incoming
 
-    # ---- lattice utilities (segment.py:179-367) -------------------------------------------------------------
+    #: trailing dims of non-scalar beam attributes (beam.py `UNVECTORIZED_NUM_ATTR_DIMS`)
+    _ATTR_DIMS = {"particles": 2, "particle_charges": 1, "survival_probabilities": 1, "mu": 1, "cov": 2, "x": 1, "px": 1,
+                  "y": 1, "py": 1, "tau": 1, "p": 1, "energies": 1, "momenta": 1}
+
+    def get_beam_attrs_along_segment(self, attr_names, incoming, resolution=None):
+        """Beam attributes (every moment of a beam comes out of one fused `chx_moments` call per position) along the
+        segment, stacked on a new axis in front of the attribute's own dims (segment.py:658-700)."""
+        names = attr_names if isinstance(attr_names, tuple) else (attr_names,)
+        per_beam = [tuple(getattr(beam, n) for n in names)
+                    for beam in self.beam_along_segment_generator(incoming, resolution=resolution)]
+        results = tuple(torch.stack(torch.broadcast_tensors(*[vals[i] for vals in per_beam]),
+                                    dim=-(self._ATTR_DIMS.get(n, 0) + 1)) for i, n in enumerate(names))
+        return results if isinstance(attr_names, tuple) else results[0]
+
+    def set_attrs_on_every_element(self, filter_type=None, is_recursive: bool = True, **kwargs) -> None:
+        """segment.py:702-724"""
+        for element in self.elements:
+            if filter_type is None or isinstance(element, filter_type):
+                for key, value in kwargs.items():
+                    setattr(element, key, value)
+            elif is_recursive and isinstance(element, Segment):
+                element.set_attrs_on_every_element(filter_type=filter_type, is_recursive=True, **kwargs)
+
+    # ---- lattice utilities (segment.py:73-367, 584-629) -----------------------------------------------------
+    @property
+    def element_names(self) -> list[str]:
+        return [element.name for element in self.elements]
+
+    def element_index(self, element_name: str) -> int:
+        try:
+            return self.element_names.index(element_name)
+        except ValueError:
+            raise ValueError(f"Element '{element_name}' not found in segment.")
+
+    def subcell(self, start=None, end=None, include_start: bool = True, include_end: bool = True) -> "Segment":
+        """Elements from `start` to `end` (names; None = the segment's own ends), segment.py:94-141."""
+        names = self.__dict__["_by_name"]
+        if start is not None and start not in names:
+            raise ValueError(f"Element {start} is not part of the segment.")
+        if end is not None and end not in names:
+            raise ValueError(f"Element {end} is not part of the segment.")
+        subcell = []
+        is_in_subcell = start is None
+        for element in self.elements:
+            if element.name == start:
+                is_in_subcell = True
+                if include_start:
+                    subcell.append(element)
+                continue
+            if element.name == end:
+                if include_end and is_in_subcell:
+                    subcell.append(element)
+                break
+            if is_in_subcell:
+                subcell.append(element)
+        return self.__class__(subcell)
+
     def flattened(self) -> "Segment":
         flat = []
         for e in self.elements:
             flat += list(e.flattened().elements) if isinstance(e, Segment) else [e]
         return Segment(flat, name=self.name)
+
+    def reversed(self) -> "Segment":
+        elements = [e.reversed() if isinstance(e, Segment) else e for e in self.elements][::-1]
+        return self.__class__(elements=elements, name=f"{self.name}_reversed")
+
+    def without_inactive_markers(self, except_for=None) -> "Segment":
+        """All Markers dropped (the reference has no `is_active` for them either, segment.py:231-257)."""
+        from .marker import Marker
+
+        except_for = except_for or []
+        return self.__class__(elements=[e for e in self.elements
+                                        if not type(e) is Marker or e.name in except_for], name=self.name)
+
+    def without_inactive_zero_length_elements(self, except_for=None) -> "Segment":
+        except_for = except_for or []
+        return self.__class__(
+            elements=[e for e in self.elements
+                      if bool((e.length != 0.0).any()) or getattr(e, "is_active", False) or e.name in except_for],
+            name=self.name)
+
+    def inactive_elements_as_drifts(self, except_for=None) -> "Segment":
+        """Inactive elements with a length become Drifts of the same name (segment.py:288-324)."""
+        from .drift import Drift
+
+        except_for = except_for or []
+        return self.__class__(
+            elements=[e if getattr(e, "is_active", False) or bool((e.length == 0.0).all()) or e.name in except_for
+                      else Drift(e.length, name=e.name, device=e.length.device, dtype=e.length.dtype)
+                      for e in self.elements],
+            name=self.name)
+
+    def with_consecutive_elements_merged(self, except_for=None) -> "Segment":
+        """Consecutive mergeable elements of one type combined (segment.py:326-367)."""
+        except_for = except_for or []
+        merged_elements = []
+        current = self.elements[0]
+        for next_element in list(self.elements)[1:]:
+            if current.name not in except_for:
+                if type(current) is Segment:
+                    current = current.with_consecutive_elements_merged(except_for=except_for)
+                elif type(current) is type(next_element) and next_element.name not in except_for:
+                    merged = current.merge(next_element)
+                    if merged is not None:
+                        current = merged
+                        continue
+            merged_elements.append(current)
+            current = next_element
+        merged_elements.append(current)
+        return self.__class__(elements=merged_elements, name=self.name, metadata=deepcopy(self.metadata))
+
+    def split(self, resolution) -> list[Element]:
+        return [part for element in self.elements for part in element.split(resolution)]
+
+    def merge(self, other: "Segment") -> "Segment":
+        from .element import merge_element_names
+
+        return self.__class__(elements=list(self.elements) + list(other.elements),
+                              name=merge_element_names(self.name, other.name),
+                              metadata={**other.metadata, **self.metadata})
+
+    def partition_at(self, element_name: str, mode: str = "both"):
+        """(pre, element, post) / (pre, post) around a named element (segment.py:599-629)."""
+        index = self.element_index(element_name)
+        elements = list(self.elements)
+        pre_cell = self.__class__(elements[: index + 1]) if mode == "after" else self.__class__(elements[:index])
+        post_cell = self.__class__(elements[index:]) if mode == "before" else self.__class__(elements[index + 1:])
+        return (pre_cell, elements[index], post_cell) if mode == "both" else (pre_cell, post_cell)
 
     def transfer_maps_merged(self, incoming_beam: ParticleBeam, except_for=None) -> "Segment":
         """Merge runs of skippable elements into CustomTransferMaps (segment.py:179-229)."""

@@ -295,6 +295,13 @@ int chx_build_ttensor(int kind, const void* params, const void* energy, double m
 int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t B, int64_t Bx, int64_t BT,
                            int64_t N, int dtype, void* stream);
 
+/* ---- Aperture (aperture.py:90-135): survival_out[B][N] = survival_in * inside, with
+ * limits[Bl][2] = (x_max, y_max); rectangular uses strict inequalities, elliptical x^2/x_max^2 + y^2/y_max^2 <= 1,
+ * both evaluated in `dtype`. survival_in may be NULL (all ones). */
+enum chx_aperture_shape { CHX_APERTURE_RECTANGULAR = 0, CHX_APERTURE_ELLIPTICAL = 1 };
+int chx_aperture_mask(const void* x_in, const void* survival_in, const void* limits, int shape, int64_t B, int64_t Bx,
+                      int64_t Bs, int64_t Bl, int64_t N, int dtype, void* survival_out, void* stream);
+
 /* ---- instrumentation: average duration (ms) of `iters` back-to-back launches of the apply
  * kernel on `stream`, measured with hipEvents recorded on that stream. Used by bench.py for
  * roofline.achieved. Synchronises the stream (the only entry point that does). */

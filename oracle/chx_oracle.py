@@ -303,6 +303,23 @@ def igf(cell_scaled, bins) -> np.ndarray:
     return G
 
 
+def aperture_mask(x, survival, x_max, y_max, shape="rectangular") -> np.ndarray:
+    """aperture.py:104-128 in numpy, every operation rounded in x.dtype like the reference's tensor ops:
+    rectangular -x_max < x < x_max and -y_max < y < y_max (strict); elliptical x^2/x_max^2 + y^2/y_max^2 <= 1."""
+    x = np.asarray(x)
+    dt = x.dtype
+    px, py = x[..., 0], x[..., 2]
+    xm = np.asarray(x_max, dtype=dt)[..., None]
+    ym = np.asarray(y_max, dtype=dt)[..., None]
+    if shape == "rectangular":
+        inside = np.logical_and(np.logical_and(px > -xm, px < xm), np.logical_and(py > -ym, py < ym))
+    elif shape == "elliptical":
+        inside = (np.square(px) / np.square(xm) + np.square(py) / np.square(ym)) <= dt.type(1.0)
+    else:
+        raise AssertionError(f"Unknown aperture shape {shape}")
+    return (np.asarray(survival, dtype=dt) * inside).astype(dt)
+
+
 DKD_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "tdc": 3}
 DKD_NUM_PARAMS = {0: 1, 1: 5, 2: 9, 3: 7}
 T_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "sextupole": 3}

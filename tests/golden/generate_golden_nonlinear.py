@@ -256,7 +256,82 @@ def gen_second_order():
     save("second_order.npz", **arrays)
 
 
+def gen_aperture():
+    """Row f3: Aperture survival masks (aperture.py:90-135) incl. particles exactly on / one ulp off the boundary,
+    both shapes, fp32 and fp64, vectorised limits, pre-existing survival probabilities; plus the lattice utilities
+    (split / merge / Superimposed / inactive_elements_as_drifts) as tracked outputs of the edited lattices."""
+    arrays = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        g = torch.Generator().manual_seed(7)
+        N = 4096
+        x = torch.randn(N, 7, generator=g, dtype=torch.float64) * torch.tensor([2e-4, 4e-6, 2e-4, 4e-6, 8e-6, 2e-3, 0.0], dtype=torch.float64)
+        x = x.to(dt)
+        x[:, 6] = 1.0
+        xm, ym = torch.tensor(2.5e-4, dtype=dt), torch.tensor(1.5e-4, dtype=dt)
+        # boundary cases: exactly on the rectangle edges, one ulp inside / outside, on the ellipse
+        eps = torch.finfo(dt).eps
+        edge = [xm, -xm, xm * (1 - eps), xm * (1 + eps), -xm * (1 - eps), -xm * (1 + eps)]
+        for i, v in enumerate(edge):
+            x[i, 0], x[i, 2] = v, 0.0
+            x[8 + i, 0], x[8 + i, 2] = 0.0, v / xm * ym
+        th = torch.linspace(0, 6.283, 64, dtype=dt)
+        x[32:96, 0], x[32:96, 2] = xm * th.cos(), ym * th.sin()
+        surv = torch.rand(N, generator=g, dtype=torch.float64).to(dt)
+        surv[::7] = 0.0
+        arrays[f"x_{tag}"], arrays[f"surv_{tag}"] = npy(x), npy(surv)
+        sp = cheetah.Species("electron", dtype=dt)
+        for shape in ("rectangular", "elliptical"):
+            beam = cheetah.ParticleBeam(x, torch.tensor(1e8, dtype=dt), survival_probabilities=surv, species=sp, dtype=dt)
+            out = cheetah.Aperture(x_max=xm, y_max=ym, shape=shape, dtype=dt).track(beam)
+            arrays[f"{shape}_{tag}"] = npy(out.survival_probabilities)
+            xv = torch.tensor([2.5e-4, 1e-4, float("inf")], dtype=dt)
+            yv = torch.tensor([[1.5e-4], [3e-4]], dtype=dt)
+            outv = cheetah.Aperture(x_max=xv, y_max=yv, shape=shape, dtype=dt).track(beam)
+            arrays[f"{shape}_vec_{tag}"] = npy(outv.survival_probabilities)
+        arrays[f"limits_{tag}"] = np.asarray([float(xm), float(ym)])
+    # lattice utilities, fp64, on the consistency beam
+    inc = load_incoming().to(torch.float64)
+    # a fresh fp64 species: the pickled beam's species carries an fp32-rounded mass that the reference silently
+    # replaces by the full-precision one in the first `species.clone()` (element.py:190)
+    beam = cheetah.ParticleBeam(inc.particles[:512], inc.energy, species=cheetah.Species("electron", **F64), **F64)
+    seg = cheetah.Segment([
+        cheetah.Drift(t64(0.3), name="d1", **F64), cheetah.Drift(t64(0.2), name="d2", **F64),
+        cheetah.Quadrupole(t64(0.1), k1=t64(4.2), name="q1a", **F64), cheetah.Quadrupole(t64(0.15), k1=t64(-2.0), name="q1b", **F64),
+        cheetah.Marker(name="m", **F64),
+        cheetah.HorizontalCorrector(t64(0.05), angle=t64(0.0), name="hc", **F64),
+        cheetah.Solenoid(t64(0.2), k=t64(0.8), name="s1", **F64), cheetah.Solenoid(t64(0.1), k=t64(0.4), name="s2", **F64),
+        cheetah.Superimposed(cheetah.Quadrupole(t64(0.4), k1=t64(1.1), name="qs", **F64),
+                             cheetah.Aperture(x_max=t64(1e-4), y_max=t64(2e-4), name="ap", **F64), name="sup", **F64),
+        cheetah.Drift(t64(0.5), name="d3", **F64),
+    ])
+    out = seg.track(beam)
+    arrays["lat_in"], arrays["lat_energy"] = npy(beam.particles), npy(beam.energy)
+    arrays["lat_species"] = np.asarray(species_meta(beam.species))  # the pickled beam carries an fp32-rounded mass
+    arrays["lat_out"], arrays["lat_out_survival"] = npy(out.particles), npy(out.survival_probabilities)
+    merged = seg.with_consecutive_elements_merged()
+    arrays["lat_merged_names"] = np.asarray(merged.element_names)
+    arrays["lat_merged_lengths"] = np.asarray([float(e.length) for e in merged.elements])
+    arrays["lat_merged_out"] = npy(merged.track(beam).particles)
+    arrays["lat_merged_q_k1"] = np.asarray(float(merged.elements[1].k1))
+    arrays["lat_merged_s_k"] = np.asarray(float(merged.elements[4].k))
+    drifts = seg.inactive_elements_as_drifts()
+    arrays["lat_drifts_types"] = np.asarray([type(e).__name__ for e in drifts.elements])
+    arrays["lat_drifts_out"] = npy(drifts.track(beam).particles)
+    split = cheetah.Segment(seg.split(t64(0.12)))
+    arrays["lat_split_names"] = np.asarray(split.element_names)
+    arrays["lat_split_out"] = npy(split.track(beam).particles)
+    arrays["lat_sigma_x_along"] = npy(seg.get_beam_attrs_along_segment("sigma_x", beam))
+    mu_x, s = seg.get_beam_attrs_along_segment(("mu_x", "s"), beam, resolution=0.25)
+    arrays["lat_mu_x_res"], arrays["lat_s_res"] = npy(mu_x), npy(s)
+    sub = seg.subcell("q1a", "s1", include_end=False)
+    arrays["lat_subcell_names"] = np.asarray(sub.element_names)
+    arrays["lat_nomarkers_names"] = np.asarray(seg.without_inactive_markers().element_names)
+    arrays["lat_nozero_names"] = np.asarray(seg.without_inactive_zero_length_elements().element_names)
+    arrays["lat_reversed_names"] = np.asarray(seg.reversed().element_names)
+    save("aperture_lattice.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture"]
     for w in which:
         globals()["gen_" + w]()
