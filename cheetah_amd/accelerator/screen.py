@@ -35,6 +35,9 @@ class Screen(Element):
             "pixel_size", pixel_size if pixel_size is not None else torch.tensor((1e-3, 1e-3), **fk))
         self.register_buffer_or_parameter(
             "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+        # carried for file compatibility only (screen.py:106-113): the KDE method itself is not provided
+        self.register_buffer_or_parameter(
+            "kde_bandwidth", kde_bandwidth if kde_bandwidth is not None else self.pixel_size[0].clone().detach())
         self.resolution = tuple(resolution)
         self.binning = binning
         self.method = method
@@ -170,4 +173,4 @@ class Screen(Element):
     @property
     def defining_features(self) -> list[str]:
         return super().defining_features + ["resolution", "pixel_size", "binning", "misalignment", "method",
-                                            "is_blocking", "is_active"]
+                                            "kde_bandwidth", "is_active"]

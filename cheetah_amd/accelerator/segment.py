@@ -437,6 +437,20 @@ class Segment(Element):
         flush()
         return Segment(merged, name=self.name)
 
+    @classmethod
+    def from_lattice_json(cls, filepath: str, device=None, dtype=None) -> "Segment":
+        """Load a LatticeJSON file (segment.py:369-384)."""
+        from ..latticejson import load_cheetah_model
+
+        return load_cheetah_model(filepath, device=device, dtype=dtype)
+
+    def to_lattice_json(self, filepath: str, title: str | None = None, info: str | None = None) -> None:
+        """Save as LatticeJSON (segment.py:386-402)."""
+        from ..latticejson import save_cheetah_model
+
+        kwargs = {} if info is None else {"info": info}
+        save_cheetah_model(self, filepath, title, **kwargs)
+
     def clone(self) -> "Segment":
         return self.__class__(elements=[e.clone() for e in self.elements], name=self.name,
                               metadata=deepcopy(self.metadata))

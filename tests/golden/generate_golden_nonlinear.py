@@ -331,7 +331,45 @@ def gen_aperture():
     save("aperture_lattice.npz", **arrays)
 
 
+def gen_ares():
+    """Row f4: the ARES lattice (docs/examples/ARESlatticeStage3v1_9.json, 195 elements) re-exported through the
+    reference's own LatticeJSON writer -> tests/golden/ares_lattice.json, and the reference's tracking result through
+    it with a working point set (quadrupoles, correctors, two accelerating cavities, the EA screen active)."""
+    import json
+
+    src = os.path.join(REF, "docs/examples/ARESlatticeStage3v1_9.json")
+    seg = cheetah.Segment.from_lattice_json(src, **F64)
+    out_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ares_lattice.json")
+    seg.to_lattice_json(out_json, title="ARES (re-exported)", info="docs/examples/ARESlatticeStage3v1_9.json via cheetah.Segment.to_lattice_json")
+    print("wrote ares_lattice.json:", os.path.getsize(out_json) // 1024, "KiB")
+    with open(out_json) as f:
+        d = json.load(f)
+    settings = {"AREAMQZM1": ("k1", 8.2), "AREAMQZM2": ("k1", -14.3), "AREAMQZM3": ("k1", 3.142), "AREAMCVM1": ("angle", 9e-5),
+                "AREAMCHM1": ("angle", -1e-4), "ARLIRSBL1": ("voltage", 2.0e7), "ARLIRSBL2": ("voltage", 1.5e7),
+                "ARLIMSOG1A": ("k", 0.3)}
+    names = [n for n in settings if n in d["elements"]]
+    for n in names:
+        setattr(getattr(seg, n), settings[n][0], t64(settings[n][1]))
+    seg.ARLIRSBL2.phase = t64(-10.0)
+    seg.AREABSCR1.is_active = True
+    seg.AREABSCR1.method = "cloud-in-cell"
+    torch.manual_seed(11)
+    beam = cheetah.ParticleBeam.from_parameters(num_particles=2000, energy=t64(6e6), sigma_p=t64(1e-3), **F64)
+    out = seg.track(beam)
+    arrays = {"names": np.asarray(names), "values": np.asarray([settings[n][1] for n in names]),
+              "attrs": np.asarray([settings[n][0] for n in names]),
+              "incoming": npy(beam.particles), "energy_in": npy(beam.energy), "charges": npy(beam.particle_charges),
+              "outgoing": npy(out.particles), "energy_out": npy(out.energy), "s_out": npy(out.s),
+              "length": npy(seg.length)}
+    img = npy(seg.AREABSCR1.reading)
+    nz = np.nonzero(img)
+    arrays["screen_idx"] = np.stack(nz, -1).astype(np.int32)
+    arrays["screen_val"] = img[nz]
+    arrays["screen_shape"] = np.asarray(img.shape)
+    save("ares_track.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares"]
     for w in which:
         globals()["gen_" + w]()
