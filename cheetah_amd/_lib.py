@@ -104,6 +104,9 @@ SIGNATURES = {
     "chx_track_moments_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "chx_track_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int,
                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_sc_geometry": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                c_i32_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
     "chx_aperture_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p,
                                   c_void_p]),
     "chx_dkd_num_params": (c_int, [c_int]),

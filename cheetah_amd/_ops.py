@@ -682,6 +682,22 @@ def _bins3(bins):
     return (ctypes.c_int32 * 3)(*[int(b) for b in bins])
 
 
+def sc_geometry(mom, grid_extent, energy, length, mass_eV: float, pot_factor: float, B: int, bins):
+    """One launch for the grid geometry of a kick (chx_sc_geometry): returns half (B,3), cell (B,3), gamma (B,),
+    dt (B,), scale (B,3), extent (B,3,2) in the beam dtype and pot_scale (B,) float64."""
+    dt_, dev = energy.dtype, energy.device
+    buf = torch.empty(17 * B, dtype=dt_, device=dev)
+    half, cell = buf[: 3 * B].view(B, 3), buf[3 * B: 6 * B].view(B, 3)
+    gamma, dt = buf[6 * B: 7 * B], buf[7 * B: 8 * B]
+    scale, extent = buf[8 * B: 11 * B].view(B, 3), buf[11 * B: 17 * B].view(B, 3, 2)
+    pot_scale = torch.empty(B, dtype=torch.float64, device=dev)
+    check(_lib.lib().chx_sc_geometry(ptr(mom), ptr(grid_extent), ptr(energy), ptr(length), mass_eV, pot_factor, B,
+                                     mom.shape[0], grid_extent.shape[0], energy.shape[0], length.shape[0], _bins3(bins),
+                                     dtype_code(dt_), ptr(half), ptr(cell), ptr(gamma), ptr(dt), ptr(scale), ptr(extent),
+                                     ptr(pot_scale), stream_ptr()), "chx_sc_geometry")
+    return half, cell, gamma, dt, scale, extent, pot_scale
+
+
 def sc_igf(cell, gamma, bins) -> torch.Tensor:
     B = cell.shape[0]
     lib = _lib.lib()

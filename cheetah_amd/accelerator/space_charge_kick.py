@@ -55,6 +55,17 @@ class SpaceChargeKick(Element):
     def first_order_transfer_map(self, energy, species):
         raise NotImplementedError("SpaceChargeKick has no linear transfer map")
 
+    def _grid_extent(self, dtype) -> torch.Tensor:
+        """(Bext, 3) grid extents in sigmas, cached against the three buffers' identity / version."""
+        parts = (self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau)
+        key = (dtype, tuple((id(p), p._version) for p in parts))
+        cached = self.__dict__.get("_ext_cache")
+        if cached is None or cached[0] != key or any(p.requires_grad for p in parts):
+            ext = torch.stack(torch.broadcast_tensors(*parts), dim=-1).to(dtype).reshape(-1, 3).contiguous()
+            cached = (key, ext)
+            self.__dict__["_ext_cache"] = cached
+        return cached[1]
+
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         assert isinstance(incoming, ParticleBeam), \
             "SpaceChargeKick tracking is currently only supported for `ParticleBeam`."
@@ -75,27 +86,16 @@ class SpaceChargeKick(Element):
         w, _ = _ops.flat_bcast(incoming.survival_probabilities, out_shape, 1)
         L = self.effect_length.to(dtype).expand(out_shape).reshape(B)
 
-        # beam sizes -> grid geometry (space_charge_kick.py:531-550), tiny (B,) / (B,3) tensors
-        mom = _ops.moments(x, w.contiguous())                     # (B or 1, 29)
-        mom = mom.expand(B, -1) if mom.shape[0] != B else mom
-        sig = torch.stack([mom[:, 8], mom[:, 8 + 11], mom[:, 8 + 18]], dim=-1).sqrt().to(dtype)  # xx, yy, tautau
-        ext = torch.stack([self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau], dim=-1).to(dtype)
-        half = (ext * sig).contiguous()                           # (B,3)
-        cell = (2 * half / torch.tensor(g, dtype=dtype, device=device)).contiguous()
-        mass = incoming.species.mass_eV.to(dtype)
-        gamma = (energy / mass).contiguous()
-        beta = torch.where(gamma.abs() > 0, (1 - gamma.square().reciprocal()).clamp_min(0).sqrt(),
-                           torch.ones_like(gamma))
-        dt = (L / (speed_of_light * beta)).contiguous()
-
-        # charge deposition straight into the doubled array
+        # beam sizes -> grid geometry (space_charge_kick.py:531-550): one moments call + one geometry kernel
+        mom = _ops.moments(x, w.contiguous())                     # (B or 1, 29) float64
         G2 = (2 * g[0], 2 * g[1], 2 * g[2])
-        scale = torch.stack([torch.ones_like(beta), torch.ones_like(beta), -beta], dim=-1).contiguous()
-        extent = torch.stack([-half, half], dim=-1).contiguous()  # (B,3,2)
+        # the inverse FFT below runs unnormalised (norm="forward"): its 1/(8 g^3) goes into the spectral factor
+        pot_factor = 1.0 / (4 * math.pi * epsilon_0) / float(G2[0] * G2[1] * G2[2])
+        half, cell, gamma, dt, scale, extent, pot_scale = _ops.sc_geometry(
+            mom, self._grid_extent(dtype), energy, L.contiguous(), incoming.species.mass_eV_float, pot_factor, B, g)
+
         green = _ops.sc_igf(cell, gamma, g)
         green_hat = torch.fft.rfftn(green, dim=[1, 2, 3])
-        inv_vol = cell.to(torch.float64).prod(dim=-1).reciprocal()
-        pot_scale = (inv_vol / (4 * math.pi * epsilon_0)).contiguous()
 
         # Poisson solve by FFT convolution with the integrated Green function (space_charge_kick.py:293-322)
         if self.pruned_fft:
@@ -110,16 +110,16 @@ class SpaceChargeKick(Element):
             rho_hat = torch.fft.fft(rho_hat, n=G2[1], dim=2)
             rho_hat = torch.fft.fft(rho_hat, n=G2[0], dim=1).contiguous()
             _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
-            phi = torch.fft.ifft(rho_hat, dim=1)[:, : g[0]]
-            phi = torch.fft.ifft(phi, dim=2)[:, :, : g[1]]
-            phi = torch.fft.irfft(phi, n=G2[2], dim=3)[..., : g[2]].contiguous()
+            phi = torch.fft.ifft(rho_hat, dim=1, norm="forward")[:, : g[0]]
+            phi = torch.fft.ifft(phi, dim=2, norm="forward")[:, :, : g[1]]
+            phi = torch.fft.irfft(phi, n=G2[2], dim=3, norm="forward")[..., : g[2]].contiguous()
         else:
             rho = torch.zeros((B, *G2), dtype=dtype, device=device)
             _ops.cic_deposit_into(rho, (G2[1] * G2[2], G2[2], 1), G2[0] * G2[1] * G2[2], x, (0, 2, 4), g, extent,
                                   charge=q, survival=w, scale=scale)
             rho_hat = torch.fft.rfftn(rho, dim=[1, 2, 3])
             _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
-            phi = torch.fft.irfftn(rho_hat, s=G2, dim=[1, 2, 3]).contiguous()
+            phi = torch.fft.irfftn(rho_hat, s=G2, dim=[1, 2, 3], norm="forward")
 
         force = _ops.sc_gradient(phi, cell, gamma, g)
         out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)

@@ -265,12 +265,77 @@ inline dim3 cell_grid(int64_t n, int64_t B) {
     return dim3((unsigned)g, (unsigned)B);
 }
 
+// Grid geometry of one kick from the beam moments (space_charge_kick.py:531-550, 110-130): replaces ~25 tiny tensor
+// ops (each a kernel launch) by one. Every step is rounded in T in the order the reference's tensor expressions
+// round (sigma = sqrt(cov) cast to T, half = extent * sigma, cell = 2 half / g, gamma = E / m, beta, dt = L / (c beta)).
+template <typename T>
+__global__ void sc_geometry_kernel(const double* __restrict__ mom, const T* __restrict__ ext, const T* __restrict__ energy,
+                                   const T* __restrict__ length, double mass, double pot_factor, int64_t B, int64_t Bm,
+                                   int64_t Bext, int64_t Be, int64_t Bl, int gx, int gy, int gz, T* __restrict__ half,
+                                   T* __restrict__ cell, T* __restrict__ gamma_out, T* __restrict__ dt,
+                                   T* __restrict__ scale, T* __restrict__ extent, double* __restrict__ pot_scale) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* m = mom + ((Bm == 1) ? 0 : b) * CHX_MOM_NOUT;
+    const double var[3] = {m[8], m[8 + 11], m[8 + 18]};  // cov_xx, cov_yy, cov_tautau
+    const T g[3] = {(T)gx, (T)gy, (T)gz};
+    double vol = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const T sig = (T)sqrt(var[d]);
+        const T h = ext[((Bext == 1) ? 0 : b) * 3 + d] * sig;
+        const T c = ((T)2 * h) / g[d];
+        half[b * 3 + d] = h;
+        cell[b * 3 + d] = c;
+        extent[(b * 3 + d) * 2 + 0] = -h;
+        extent[(b * 3 + d) * 2 + 1] = h;
+        vol *= (double)c;
+    }
+    const T gam = energy[(Be == 1) ? 0 : b] / (T)mass;
+    const T ig2 = (T)1 / (gam * gam);
+    T one_minus = (T)1 - ig2;
+    if (one_minus < (T)0) one_minus = (T)0;
+    const T beta = (fabs((double)gam) > 0.0) ? (T)sqrt(one_minus) : (T)1;
+    gamma_out[b] = gam;
+    dt[b] = length[(Bl == 1) ? 0 : b] / ((T)299792458.0 * beta);
+    scale[b * 3 + 0] = (T)1;
+    scale[b * 3 + 1] = (T)1;
+    scale[b * 3 + 2] = -beta;
+    pot_scale[b] = (1.0 / vol) * pot_factor;
+}
+
 bool bins_ok(const int32_t* bins) {
     return bins && bins[0] >= 2 && bins[1] >= 2 && bins[2] >= 2 && bins[0] <= 1024 && bins[1] <= 1024 &&
            bins[2] <= 1024;
 }
 
 }  // namespace
+
+extern "C" int chx_sc_geometry(const double* moments, const void* grid_extent, const void* energy, const void* length,
+                               double mass_eV, double pot_factor, int64_t B, int64_t Bm, int64_t Bext, int64_t Be,
+                               int64_t Bl, const int32_t* bins, int dtype, void* half, void* cell, void* gamma,
+                               void* dt, void* scale, void* extent, double* pot_scale, void* stream) {
+    if (!moments || !grid_extent || !energy || !length || !half || !cell || !gamma || !dt || !scale || !extent ||
+        !pot_scale || B < 1 || !bins_ok(bins))
+        return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bm, B) || !chx_bcast_ok(Bext, B) || !chx_bcast_ok(Be, B) || !chx_bcast_ok(Bl, B))
+        return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = (unsigned)((B + 63) / 64);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(sc_geometry_kernel<float>, dim3(nb), dim3(64), 0, s, moments, (const float*)grid_extent,
+                           (const float*)energy, (const float*)length, mass_eV, pot_factor, B, Bm, Bext, Be, Bl, bins[0],
+                           bins[1], bins[2], (float*)half, (float*)cell, (float*)gamma, (float*)dt, (float*)scale,
+                           (float*)extent, pot_scale);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(sc_geometry_kernel<double>, dim3(nb), dim3(64), 0, s, moments, (const double*)grid_extent,
+                           (const double*)energy, (const double*)length, mass_eV, pot_factor, B, Bm, Bext, Be, Bl, bins[0],
+                           bins[1], bins[2], (double*)half, (double*)cell, (double*)gamma, (double*)dt, (double*)scale,
+                           (double*)extent, pot_scale);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
 
 extern "C" size_t chx_sc_igf_workspace_bytes(int64_t B, const int32_t* bins) {
     if (B < 1 || !bins_ok(bins)) return 0;

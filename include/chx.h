@@ -229,6 +229,15 @@ int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bi
                void* stream);
 /* rho_hat *= G_hat * scale[b]  (complex multiply; space_charge_kick.py:313-316);
  * n_complex = complex elements per batch row; scale (double[B]) folds 1/(4 pi eps0) and 1/cell volume. */
+/* Grid geometry of a kick from the beam moments (space_charge_kick.py:531-550,110-130), one launch instead of ~25
+ * tensor ops: moments[Bm][29] (chx_moments layout), grid_extent[Bext][3] (in sigmas), energy[Be], length[Bl] ->
+ * half[B][3] = extent*sigma, cell[B][3] = 2 half / bins, gamma[B], dt[B] = L/(c beta), scale[B][3] = (1, 1, -beta),
+ * extent[B][3][2] = (-half, half) (all `dtype`, rounded step by step like the reference's tensor expressions) and
+ * pot_scale[B] (double) = pot_factor / prod(cell). */
+int chx_sc_geometry(const double* moments, const void* grid_extent, const void* energy, const void* length,
+                    double mass_eV, double pot_factor, int64_t B, int64_t Bm, int64_t Bext, int64_t Be, int64_t Bl,
+                    const int32_t* bins, int dtype, void* half, void* cell, void* gamma, void* dt, void* scale,
+                    void* extent, double* pot_scale, void* stream);
 int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const double* scale, int64_t B,
                         int64_t n_complex, int dtype, void* stream);
 /* E+vxB force field from the potential (space_charge_kick.py:324-365): central differences, x -1/gamma^2;

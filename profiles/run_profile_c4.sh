@@ -1,0 +1,9 @@
+#!/bin/bash
+# Kernel trace + stats of config C4 (50-element linac with 10 SpaceChargeKicks at 128^3, 1e6 particles)
+set -x
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_${1:-r01}_c4
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c4 -- \
+    python $REPO/benchmarks/run_configs.py c4 > $OUT/bench.log 2> $OUT/trace.log
