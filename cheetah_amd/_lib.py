@@ -93,9 +93,12 @@ SIGNATURES = {
     "chx_hist2d": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p]),
     "chx_hist2d_indices": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p, c_void_p]),
     "chx_sc_igf_workspace_bytes": (c_size_t, [c_i64, c_i32_p]),
-    "chx_sc_igf": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_sc_igf": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
+    "chx_sc_fft_plan_create": (c_int, [c_i64, c_i32_p, c_int, c_vpp]),
+    "chx_sc_fft_plan_destroy": (c_int, [c_void_p]),
+    "chx_sc_fft_exec": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "chx_sc_spectral_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
-    "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_int, c_void_p, c_void_p]),
+    "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_i64, c_int, c_void_p, c_void_p]),
     "chx_sc_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
@@ -136,7 +139,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 1:
+        if handle.chx_abi_version() != 2:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib

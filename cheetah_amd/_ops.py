@@ -698,22 +698,55 @@ def sc_geometry(mom, grid_extent, energy, length, mass_eV: float, pot_factor: fl
     return half, cell, gamma, dt, scale, extent, pot_scale
 
 
-def sc_igf(cell, gamma, bins) -> torch.Tensor:
+def sc_igf(cell, gamma, bins, padded: bool = False) -> torch.Tensor:
+    """Integrated Green function on the doubled grid, (B,2gx,2gy,2gz); `padded=True` returns the in-place R2C layout
+    (B,2gx,2gy,2gz+2) (the two extra values per row are don't-care)."""
     B = cell.shape[0]
     lib = _lib.lib()
     b3 = _bins3(bins)
     ws_bytes = lib.chx_sc_igf_workspace_bytes(B, b3)
     ws = workspace(ws_bytes, cell.device)
-    G = torch.empty((B, 2 * bins[0], 2 * bins[1], 2 * bins[2]), dtype=cell.dtype, device=cell.device)
-    check(lib.chx_sc_igf(ptr(cell), ptr(gamma), B, b3, dtype_code(cell.dtype), ptr(G), ptr(ws), ws_bytes,
+    ldz = 2 * bins[2] + (2 if padded else 0)
+    G = torch.empty((B, 2 * bins[0], 2 * bins[1], ldz), dtype=cell.dtype, device=cell.device)
+    check(lib.chx_sc_igf(ptr(cell), ptr(gamma), B, b3, dtype_code(cell.dtype), ptr(G), ldz, ptr(ws), ws_bytes,
                          stream_ptr()), "chx_sc_igf")
     return G
 
 
+class ScFftPlan:
+    """hipFFT plans of the Hockney convolution for one (B, grid, dtype) (chx_sc_fft_plan_*): in-place, unnormalised
+    real <-> complex 3-D transforms on the padded layout (B,2gx,2gy,2gz+2)."""
+
+    def __init__(self, B: int, bins, dtype: torch.dtype):
+        handle = ctypes.c_void_p()
+        check(_lib.lib().chx_sc_fft_plan_create(B, _bins3(bins), dtype_code(dtype), ctypes.byref(handle)),
+              "chx_sc_fft_plan_create")
+        self._handle = handle
+        self.key = (B, tuple(bins), dtype)
+
+    def forward(self, data: torch.Tensor, which: int = 0) -> None:
+        check(_lib.lib().chx_sc_fft_exec(self._handle, which, ptr(data), stream_ptr()), "chx_sc_fft_exec")
+
+    def inverse(self, data: torch.Tensor) -> None:
+        check(_lib.lib().chx_sc_fft_exec(self._handle, 2, ptr(data), stream_ptr()), "chx_sc_fft_exec")
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.lib().chx_sc_fft_plan_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
 def sc_spectral_mul(rho_hat, G_hat, scale) -> None:
+    """rho_hat *= G_hat * scale; complex tensors, or real tensors holding interleaved (re, im) pairs in the last dim."""
     B = rho_hat.shape[0]
     n = numel(rho_hat.shape[1:])
-    real_dtype = torch.float32 if rho_hat.dtype == torch.complex64 else torch.float64
+    if rho_hat.is_complex():
+        real_dtype = torch.float32 if rho_hat.dtype == torch.complex64 else torch.float64
+    else:
+        real_dtype, n = rho_hat.dtype, n // 2
     check(_lib.lib().chx_sc_spectral_mul(ptr(rho_hat), ptr(G_hat), ptr(scale), B, n, dtype_code(real_dtype),
                                          stream_ptr()), "chx_sc_spectral_mul")
 
@@ -722,8 +755,9 @@ def sc_gradient(phi, cell, gamma, bins) -> torch.Tensor:
     """phi: doubled (B,2gx,2gy,2gz) or compact (B,gx,gy,gz) potential -> packed force grid (B,gx,gy,gz,4)."""
     B = phi.shape[0]
     doubled = int(phi.shape[1] == 2 * bins[0])
+    ldz = phi.shape[3] if doubled else 0  # 2gz, or 2gz + 2 after an in-place inverse transform
     F = torch.empty((B, bins[0], bins[1], bins[2], 4), dtype=phi.dtype, device=phi.device)
-    check(_lib.lib().chx_sc_gradient(ptr(phi), ptr(cell), ptr(gamma), B, _bins3(bins), doubled,
+    check(_lib.lib().chx_sc_gradient(ptr(phi), ptr(cell), ptr(gamma), B, _bins3(bins), doubled, ldz,
                                      dtype_code(phi.dtype), ptr(F), stream_ptr()), "chx_sc_gradient")
     return F
 

@@ -36,6 +36,29 @@ class SpaceChargeKick(Element):
     #: 128^3, 0.64 vs 0.60 ms at 32^3) — the strided 1-D passes through torch.fft cost more than the pruned
     #: butterflies save — so the full transforms stay the default.
     pruned_fft = False
+    #: "hipfft": in-place hipFFT plans owned by libchx (chx_sc_fft_*), Green-function chain on a side stream;
+    #: "torch": torch.fft.rfftn / irfftn (out of place, defensive copies around every transform) — kept for A/B timing
+    fft_backend = "hipfft"
+    _plans: dict = {}
+    _side_streams: dict = {}
+
+    @classmethod
+    def _fft_plan(cls, B, g, dtype):
+        key = (B, tuple(g), dtype)
+        plan = cls._plans.get(key)
+        if plan is None:
+            if len(cls._plans) >= 8:  # bounded: every plan holds hipFFT work areas
+                cls._plans.pop(next(iter(cls._plans)))
+            plan = cls._plans[key] = _ops.ScFftPlan(B, g, dtype)
+        return plan
+
+    @classmethod
+    def _side_stream(cls, device):
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        s = cls._side_streams.get(key)
+        if s is None:
+            s = cls._side_streams[key] = torch.cuda.Stream(device=device)
+        return s
 
     def __init__(self, effect_length, grid_shape=(32, 32, 32), grid_extent_x=None, grid_extent_y=None,
                  grid_extent_tau=None, name=None, sanitize_name=None, metadata=None, device=None, dtype=None):
@@ -94,10 +117,40 @@ class SpaceChargeKick(Element):
         half, cell, gamma, dt, scale, extent, pot_scale = _ops.sc_geometry(
             mom, self._grid_extent(dtype), energy, L.contiguous(), incoming.species.mass_eV_float, pot_factor, B, g)
 
+        # Poisson solve by FFT convolution with the integrated Green function (space_charge_kick.py:293-322)
+        if self.fft_backend == "hipfft":
+            # in-place hipFFT on the padded layout [2gx][2gy][2gz+2]; the Green-function chain (fp64-bound table,
+            # fill, forward FFT) runs on a side stream while the main stream deposits and transforms the charge
+            plan = self._fft_plan(B, g, dtype)
+            ldz = G2[2] + 2
+            main = torch.cuda.current_stream(device)
+            side = self._side_stream(device)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                green = _ops.sc_igf(cell, gamma, g, padded=True)
+                plan.forward(green, which=1)
+                join = torch.cuda.Event()
+                join.record(side)
+            rho = torch.zeros((B, G2[0], G2[1], ldz), dtype=dtype, device=device)
+            _ops.cic_deposit_into(rho, (G2[1] * ldz, ldz, 1), G2[0] * G2[1] * ldz, x, (0, 2, 4), g, extent,
+                                  charge=q, survival=w, scale=scale)
+            plan.forward(rho, which=0)
+            main.wait_event(join)
+            green.record_stream(main)
+            _ops.sc_spectral_mul(rho, green, pot_scale)
+            plan.inverse(rho)
+            phi = rho
+            force = _ops.sc_gradient(phi, cell, gamma, g)
+            out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
+            return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,
+                                particle_charges=incoming.particle_charges,
+                                survival_probabilities=incoming.survival_probabilities, s=incoming.s,
+                                species=incoming.species)
+
         green = _ops.sc_igf(cell, gamma, g)
         green_hat = torch.fft.rfftn(green, dim=[1, 2, 3])
-
-        # Poisson solve by FFT convolution with the integrated Green function (space_charge_kick.py:293-322)
         if self.pruned_fft:
             # Hockney zero padding, pruned: the charge only occupies the first octant of the doubled array, so
             # the forward transform pads one axis at a time (z lines of the g x g block, then y, then x) and the

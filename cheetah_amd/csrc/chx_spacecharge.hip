@@ -15,6 +15,10 @@
 //   * chx_sc_gather_kick    to_xyz_pxpypz -> node-based trilinear gather -> p += F dt ->
 //                       from_xyz_pxpypz fused per particle in registers (fp64 inside: the SI
 //                       momenta ~1e-20 kg m/s square to denormals in fp32).
+#include <hipfft/hipfft.h>
+
+#include <new>
+
 #include "chx_common.h"
 
 namespace {
@@ -55,13 +59,15 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_table_kernel(const T* __restric
 
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void igf_fill_kernel(const double* __restrict__ table, int gx,
-                                                            int gy, int gz, T* __restrict__ G) {
+                                                            int gy, int gz, int64_t ldz, T* __restrict__ G) {
     const int64_t b = blockIdx.y;
     const int64_t ncell = (int64_t)gx * gy * gz;
     const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
     const double* tb = table + b * npts;
     const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
-    const int64_t GX = 2 * gx, GY = 2 * gy, GZ = 2 * gz;
+    // logical size (2gx, 2gy, 2gz); rows of the last axis are `ldz` apart (2gz, or 2gz + 2 for in-place R2C)
+    const int64_t GX = 2 * gx, GY = 2 * gy, GZ = ldz;
+    const int64_t GZlog = 2 * gz;
     T* Gb = G + b * GX * GY * GZ;
     for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ncell;
          idx += (int64_t)gridDim.x * CHX_BLOCK) {
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_fill_kernel(const double* __res
         // +F(+,+,+) -F(-,+,+) -F(+,-,+) -F(+,+,-) +F(+,-,-) +F(-,+,-) +F(-,-,+) -F(-,-,-)
         const double g = p[sx + sy + 1] - p[sy + 1] - p[sx + 1] - p[sx + sy] + p[sx] + p[sy] + p[1] - p[0];
         const T gv = (T)g;
-        const int64_t i2 = GX - i, j2 = GY - j, k2 = GZ - k;
+        const int64_t i2 = GX - i, j2 = GY - j, k2 = GZlog - k;
         Gb[((int64_t)i * GY + j) * GZ + k] = gv;
         if (i > 0) Gb[(i2 * GY + j) * GZ + k] = gv;
         if (j > 0) Gb[((int64_t)i * GY + j2) * GZ + k] = gv;
@@ -106,10 +112,12 @@ template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void gradient_kernel(const T* __restrict__ phi,
                                                             const T* __restrict__ cell,
                                                             const T* __restrict__ gamma, int gx,
-                                                            int gy, int gz, int doubled, T* __restrict__ F) {
+                                                            int gy, int gz, int doubled, int64_t ldz,
+                                                            T* __restrict__ F) {
     const int64_t b = blockIdx.y;
-    // phi is either the doubled Hockney array [2gx][2gy][2gz] (cropped on the fly) or already compact
-    const int64_t GY = doubled ? 2 * gy : gy, GZ = doubled ? 2 * gz : gz;
+    // phi is either the doubled Hockney array [2gx][2gy][ldz] (cropped on the fly; ldz = 2gz, or 2gz + 2 when the
+    // inverse FFT ran in place) or already compact [gx][gy][gz]
+    const int64_t GY = doubled ? 2 * gy : gy, GZ = doubled ? ldz : gz;
     const T* pb = phi + b * (int64_t)(doubled ? 2 * gx : gx) * GY * GZ;
     const int64_t ncell = (int64_t)gx * gy * gz;
     const T gm = gamma[b];
@@ -343,14 +351,16 @@ extern "C" size_t chx_sc_igf_workspace_bytes(int64_t B, const int32_t* bins) {
 }
 
 extern "C" int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
-                          void* G_out, void* workspace, size_t workspace_bytes, void* stream) {
+                          void* G_out, int64_t ldz, void* workspace, size_t workspace_bytes, void* stream) {
     if (!cell || !gamma || !G_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (!workspace || workspace_bytes < chx_sc_igf_workspace_bytes(B, bins)) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int gx = bins[0], gy = bins[1], gz = bins[2];
+    if (ldz == 0) ldz = 2 * gz;
+    if (ldz < 2 * gz) return CHX_ERR_INVALID_ARG;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    const size_t gbytes = (size_t)B * 8 * (size_t)gx * gy * gz * esz;
+    const size_t gbytes = (size_t)B * 4 * (size_t)gx * gy * (size_t)ldz * esz;
     if (hipMemsetAsync(G_out, 0, gbytes, s) != hipSuccess) return CHX_ERR_LAUNCH;  // index-g planes stay 0
     const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
     double* table = (double*)workspace;
@@ -359,13 +369,13 @@ extern "C" int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const 
                            (const float*)cell, (const float*)gamma, gx, gy, gz, table);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(igf_fill_kernel<float>, cell_grid((int64_t)gx * gy * gz, B), dim3(CHX_BLOCK), 0, s,
-                           table, gx, gy, gz, (float*)G_out);
+                           table, gx, gy, gz, ldz, (float*)G_out);
     } else {
         hipLaunchKernelGGL(igf_table_kernel<double>, cell_grid(npts, B), dim3(CHX_BLOCK), 0, s,
                            (const double*)cell, (const double*)gamma, gx, gy, gz, table);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(igf_fill_kernel<double>, cell_grid((int64_t)gx * gy * gz, B), dim3(CHX_BLOCK), 0, s,
-                           table, gx, gy, gz, (double*)G_out);
+                           table, gx, gy, gz, ldz, (double*)G_out);
     }
     CHX_CHECK_LAUNCH();
     return CHX_OK;
@@ -388,22 +398,96 @@ extern "C" int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const doubl
 }
 
 extern "C" int chx_sc_gradient(const void* phi, const void* cell, const void* gamma, int64_t B,
-                               const int32_t* bins, int phi_doubled, int dtype, void* F_out, void* stream) {
+                               const int32_t* bins, int phi_doubled, int64_t ldz, int dtype, void* F_out,
+                               void* stream) {
     if (!phi || !cell || !gamma || !F_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    if (ldz == 0) ldz = 2 * bins[2];
+    if (phi_doubled && ldz < 2 * bins[2]) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t ncell = (int64_t)bins[0] * bins[1] * bins[2];
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(gradient_kernel<float>, cell_grid(ncell, B), dim3(CHX_BLOCK), 0, s,
                            (const float*)phi, (const float*)cell, (const float*)gamma, bins[0], bins[1],
-                           bins[2], phi_doubled, (float*)F_out);
+                           bins[2], phi_doubled, ldz, (float*)F_out);
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL(gradient_kernel<double>, cell_grid(ncell, B), dim3(CHX_BLOCK), 0, s,
                            (const double*)phi, (const double*)cell, (const double*)gamma, bins[0], bins[1],
-                           bins[2], phi_doubled, (double*)F_out);
+                           bins[2], phi_doubled, ldz, (double*)F_out);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();
     return CHX_OK;
+}
+
+// ---- hipFFT plans for the Hockney convolution (space_charge_kick.py:306-314) ------------------------------------
+// Real-to-complex / complex-to-real 3-D transforms of the (2gx, 2gy, 2gz) arrays, IN PLACE in the padded layout
+// [B][2gx][2gy][2gz + 2] (complex view [B][2gx][2gy][gz + 1]), unnormalised. Going through hipFFT directly instead of
+// torch.fft removes the defensive input copies around every transform (~20 us each at 256^3), the separate complex
+// output arrays and the 1/N scaling pass. Two forward plans so that rho and the Green function can be transformed on
+// different streams at the same time.
+struct chx_sc_fft_plan {
+    hipfftHandle fwd[2];
+    hipfftHandle inv;
+    int dtype;
+    int64_t B;
+    int32_t bins[3];
+};
+
+extern "C" int chx_sc_fft_plan_create(int64_t B, const int32_t* bins, int dtype, void** plan_out) {
+    if (!plan_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (8.0 * bins[0] * bins[1] * (bins[2] + 1.0) > 2147483647.0) return CHX_ERR_INVALID_ARG;  // hipFFT int distances
+    chx_sc_fft_plan* p = new (std::nothrow) chx_sc_fft_plan();
+    if (!p) return CHX_ERR_WORKSPACE;
+    p->dtype = dtype;
+    p->B = B;
+    for (int d = 0; d < 3; ++d) p->bins[d] = bins[d];
+    int n[3] = {2 * bins[0], 2 * bins[1], 2 * bins[2]};
+    int rembed[3] = {n[0], n[1], n[2] + 2};        // padded real layout
+    int cembed[3] = {n[0], n[1], n[2] / 2 + 1};    // complex layout in the same bytes
+    const int rdist = n[0] * n[1] * (n[2] + 2), cdist = n[0] * n[1] * (n[2] / 2 + 1);
+    const hipfftType tf = dtype == CHX_F32 ? HIPFFT_R2C : HIPFFT_D2Z, ti = dtype == CHX_F32 ? HIPFFT_C2R : HIPFFT_Z2D;
+    bool ok = true;
+    int made = 0;
+    for (int k = 0; k < 2 && ok; ++k, ++made)
+        ok = hipfftPlanMany(&p->fwd[k], 3, n, rembed, 1, rdist, cembed, 1, cdist, tf, (int)B) == HIPFFT_SUCCESS;
+    if (ok) {
+        ok = hipfftPlanMany(&p->inv, 3, n, cembed, 1, cdist, rembed, 1, rdist, ti, (int)B) == HIPFFT_SUCCESS;
+        if (ok) ++made;
+    }
+    if (!ok) {
+        for (int k = 0; k < made && k < 2; ++k) hipfftDestroy(p->fwd[k]);
+        delete p;
+        return CHX_ERR_LAUNCH;
+    }
+    *plan_out = p;
+    return CHX_OK;
+}
+
+extern "C" int chx_sc_fft_plan_destroy(void* plan) {
+    if (!plan) return CHX_ERR_INVALID_ARG;
+    chx_sc_fft_plan* p = (chx_sc_fft_plan*)plan;
+    hipfftDestroy(p->fwd[0]);
+    hipfftDestroy(p->fwd[1]);
+    hipfftDestroy(p->inv);
+    delete p;
+    return CHX_OK;
+}
+
+// direction: 0 / 1 = forward with plan 0 / 1 (real padded -> complex), 2 = inverse (complex -> real padded)
+extern "C" int chx_sc_fft_exec(void* plan, int direction, void* data, void* stream) {
+    if (!plan || !data || direction < 0 || direction > 2) return CHX_ERR_INVALID_ARG;
+    chx_sc_fft_plan* p = (chx_sc_fft_plan*)plan;
+    hipfftHandle h = direction == 2 ? p->inv : p->fwd[direction];
+    if (hipfftSetStream(h, (hipStream_t)stream) != HIPFFT_SUCCESS) return CHX_ERR_LAUNCH;
+    hipfftResult r;
+    if (p->dtype == CHX_F32)
+        r = direction == 2 ? hipfftExecC2R(h, (hipfftComplex*)data, (hipfftReal*)data)
+                           : hipfftExecR2C(h, (hipfftReal*)data, (hipfftComplex*)data);
+    else
+        r = direction == 2 ? hipfftExecZ2D(h, (hipfftDoubleComplex*)data, (hipfftDoubleReal*)data)
+                           : hipfftExecD2Z(h, (hipfftDoubleReal*)data, (hipfftDoubleComplex*)data);
+    return r == HIPFFT_SUCCESS ? CHX_OK : CHX_ERR_LAUNCH;
 }
 
 template <int MODE>

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 1
+#define CHX_ABI_VERSION 2 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient */
 
 typedef enum chx_status {
     CHX_OK = 0,
@@ -224,11 +224,18 @@ int chx_hist2d_indices(const chx_hist2d_args* args, int32_t* ij_out /*[B][N][2],
  * cell[B][3] (dtype) = cell sizes (hx,hy,htau); gamma[B] (dtype). fp64 inside; the workspace
  * holds the (gx+1)(gy+1)(gz+1) corner table of the primitive per batch row. */
 size_t chx_sc_igf_workspace_bytes(int64_t B, const int32_t* bins);
+/* ldz = distance between rows of the last axis of G_out: 2gz (0 = default), or 2gz + 2 for the padded layout of
+ * an in-place real-to-complex transform (chx_sc_fft_exec). */
 int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
-               void* G_out /*[B][2gx][2gy][2gz]*/, void* workspace, size_t workspace_bytes,
+               void* G_out /*[B][2gx][2gy][ldz]*/, int64_t ldz, void* workspace, size_t workspace_bytes,
                void* stream);
-/* rho_hat *= G_hat * scale[b]  (complex multiply; space_charge_kick.py:313-316);
- * n_complex = complex elements per batch row; scale (double[B]) folds 1/(4 pi eps0) and 1/cell volume. */
+/* 3-D FFTs of the Hockney convolution (space_charge_kick.py:306-314) through hipFFT, in place on the padded real
+ * layout [B][2gx][2gy][2gz + 2] (= complex [B][2gx][2gy][gz + 1]), unnormalised. direction 0 / 1: forward with
+ * plan 0 / 1 (two plans, so rho and the Green function can be transformed concurrently on two streams),
+ * 2: inverse. Plan creation is a host-side call that may allocate hipFFT work areas; exec only enqueues. */
+int chx_sc_fft_plan_create(int64_t B, const int32_t* bins, int dtype, void** plan_out);
+int chx_sc_fft_plan_destroy(void* plan);
+int chx_sc_fft_exec(void* plan, int direction, void* data, void* stream);
 /* Grid geometry of a kick from the beam moments (space_charge_kick.py:531-550,110-130), one launch instead of ~25
  * tensor ops: moments[Bm][29] (chx_moments layout), grid_extent[Bext][3] (in sigmas), energy[Be], length[Bl] ->
  * half[B][3] = extent*sigma, cell[B][3] = 2 half / bins, gamma[B], dt[B] = L/(c beta), scale[B][3] = (1, 1, -beta),
@@ -238,13 +245,16 @@ int chx_sc_geometry(const double* moments, const void* grid_extent, const void* 
                     double mass_eV, double pot_factor, int64_t B, int64_t Bm, int64_t Bext, int64_t Be, int64_t Bl,
                     const int32_t* bins, int dtype, void* half, void* cell, void* gamma, void* dt, void* scale,
                     void* extent, double* pot_scale, void* stream);
+/* rho_hat *= G_hat * scale[b]  (complex multiply; space_charge_kick.py:313-316);
+ * n_complex = complex elements per batch row; scale (double[B]) folds 1/(4 pi eps0), 1/cell volume and the FFT
+ * normalisation. */
 int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const double* scale, int64_t B,
                         int64_t n_complex, int dtype, void* stream);
 /* E+vxB force field from the potential (space_charge_kick.py:324-365): central differences, x -1/gamma^2;
- * phi is the doubled array phi[B][2gx][2gy][2gz] (cropped on the fly, phi_doubled = 1) or the compact
- * phi[B][gx][gy][gz] (phi_doubled = 0); F_out[B][gx][gy][gz][4]. */
+ * phi is the doubled array phi[B][2gx][2gy][ldz] (cropped on the fly, phi_doubled = 1; ldz = 0 means 2gz) or the
+ * compact phi[B][gx][gy][gz] (phi_doubled = 0); F_out[B][gx][gy][gz][4]. */
 int chx_sc_gradient(const void* phi, const void* cell, const void* gamma, int64_t B,
-                    const int32_t* bins, int phi_doubled, int dtype, void* F_out, void* stream);
+                    const int32_t* bins, int phi_doubled, int64_t ldz, int dtype, void* F_out, void* stream);
 /* Fused: to_xyz_pxpypz -> trilinear node-based gather -> p += F*dt -> from_xyz_pxpypz
  * (space_charge_kick.py:387-475,548-584; particle_beam.py:1262-1346).
  * half[B][3] grid half-widths, cell[B][3], energy[Be], dt[B] (all dtype). */
