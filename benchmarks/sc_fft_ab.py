@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B: full (2g)^3 FFTs vs axis-by-axis pruned FFTs in SpaceChargeKick (same result, different cost)."""
+"""A/B/C of the Poisson solve in SpaceChargeKick (same result, different cost): in-place hipFFT plans inside libchx with
+the Green-function chain on a side stream (default), torch.fft full (2g)^3 transforms, torch.fft axis-by-axis pruned."""
 import os
 import sys
 import time
@@ -18,8 +19,9 @@ beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=1_000_000, total_charg
 for g in (32, 64, 128):
     sc = ca.SpaceChargeKick(t(0.2), grid_shape=(g, g, g), dtype=dt, device="cuda")
     outs = {}
-    for pruned in (False, True):
-        ca.SpaceChargeKick.pruned_fft = pruned
+    for pruned in ("hipfft", False, True):
+        ca.SpaceChargeKick.fft_backend = "hipfft" if pruned == "hipfft" else "torch"
+        ca.SpaceChargeKick.pruned_fft = pruned is True
         for _ in range(3):
             o = sc.track(beam)
         torch.cuda.synchronize()
@@ -28,7 +30,9 @@ for g in (32, 64, 128):
             o = sc.track(beam)
         torch.cuda.synchronize()
         outs[pruned] = o.particles
-        print(f"g={g:4d} pruned={pruned!s:5s} {(time.perf_counter() - t0) / 10 * 1e3:8.3f} ms")
+        label = {"hipfft": "libchx hipFFT in-place + side stream", False: "torch.fft full", True: "torch.fft pruned"}[pruned]
+        print(f"g={g:4d} {label:38s} {(time.perf_counter() - t0) / 10 * 1e3:8.3f} ms")
     kick = (outs[False] - beam.particles).abs().amax(dim=0)
-    diff = (outs[True] - outs[False]).abs().amax(dim=0)
-    print("   max |pruned - full| / kick amplitude:", [f"{float(d / k):.1e}" for d, k in zip(diff[[1, 3, 5]], kick[[1, 3, 5]])])
+    for other in (True, "hipfft"):
+        diff = (outs[other] - outs[False]).abs().amax(dim=0)
+        print(f"   max |{other} - torch full| / kick amplitude:", [f"{float(d / k):.1e}" for d, k in zip(diff[[1, 3, 5]], kick[[1, 3, 5]])])

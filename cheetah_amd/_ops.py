@@ -40,7 +40,16 @@ def require_device(*tensors: torch.Tensor) -> None:
             )
 
 
+try:  # raw C accessors: ~0.3 us instead of ~4 us for torch.cuda.current_stream().cuda_stream (called per launch)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _current_device = torch._C._cuda_getDevice
+except AttributeError:  # pragma: no cover - torch build without the private accessors
+    _raw_stream = None
+
+
 def stream_ptr() -> int:
+    if _raw_stream is not None:
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -96,10 +96,8 @@ class SpaceChargeKick(Element):
         dtype, device = parts.dtype, parts.device
         N = parts.shape[-2]
         g = self.grid_shape
-        flat_shape = torch.broadcast_shapes(parts.shape[:-2], incoming.energy.shape,
-                                            incoming.particle_charges.shape[:-1],
-                                            incoming.survival_probabilities.shape[:-1])
-        out_shape = torch.broadcast_shapes(flat_shape, self.effect_length.shape)
+        out_shape = _ops.bshapes(parts.shape[:-2], incoming.energy.shape, incoming.particle_charges.shape[:-1],
+                                 incoming.survival_probabilities.shape[:-1], self.effect_length.shape)
         B = _ops.numel(out_shape)
 
         x, _ = _ops.flat_bcast(parts, out_shape, 2)
