@@ -288,6 +288,77 @@ class ParticleBeam(Beam):
     def dispersion_py(self) -> torch.Tensor:
         return self.cov_pyp / self.sigma_p.square()
 
+    # ------------------------------------------------------------------ derived beams (host-side plumbing)
+    @classmethod
+    def make_linspaced(cls, num_particles=10, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None, mu_p=None,
+                       sigma_x=None, sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None, sigma_p=None,
+                       energy=None, total_charge=None, s=None, species=None, device=None, dtype=None) -> "ParticleBeam":
+        """`num_particles` particles spaced evenly over mu ± sigma in every coordinate (particle_beam.py:668-800)."""
+        fk = {"device": device, "dtype": dtype}
+        species = species if species is not None else Species("electron", **fk)
+        d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
+        mus = [d(mu_x, 0.0), d(mu_px, 0.0), d(mu_y, 0.0), d(mu_py, 0.0), d(mu_tau, 0.0), d(mu_p, 0.0)]
+        sigmas = [d(sigma_x, 175e-9), d(sigma_px, 2e-7), d(sigma_y, 175e-9), d(sigma_py, 2e-7), d(sigma_tau, 1e-6),
+                  d(sigma_p, 1e-6)]
+        energy = d(energy, 1e8)
+        total_charge = total_charge if total_charge is not None else species.charge_coulomb * num_particles
+        charges = torch.ones((*total_charge.shape, num_particles), **fk) * total_charge.unsqueeze(-1) / num_particles
+        vector_shape = torch.broadcast_shapes(*[t.shape for t in mus + sigmas])
+        particles = torch.ones((*vector_shape, num_particles, 7), **fk)
+        ramp = torch.linspace(0.0, 1.0, num_particles, **fk)
+        for i, (mu, sigma) in enumerate(zip(mus, sigmas)):
+            lo, hi = (mu - sigma).expand(vector_shape).unsqueeze(-1), (mu + sigma).expand(vector_shape).unsqueeze(-1)
+            particles[..., i] = lo + (hi - lo) * ramp
+        return cls(particles=particles, energy=energy, particle_charges=charges, s=s, species=species, **fk)
+
+    def linspaced(self, num_particles: int) -> "ParticleBeam":
+        """Evenly spaced beam with this beam's means, sigmas, energy and total charge (particle_beam.py:1180-1210)."""
+        return self.make_linspaced(
+            num_particles=num_particles, mu_x=self.mu_x, mu_px=self.mu_px, mu_y=self.mu_y, mu_py=self.mu_py,
+            mu_tau=self.mu_tau, mu_p=self.mu_p, sigma_x=self.sigma_x, sigma_px=self.sigma_px, sigma_y=self.sigma_y,
+            sigma_py=self.sigma_py, sigma_tau=self.sigma_tau, sigma_p=self.sigma_p, energy=self.energy,
+            total_charge=self.total_charge, s=self.s, species=self.species, device=self.particles.device,
+            dtype=self.particles.dtype)
+
+    def randomly_subsampled(self, num_particles: int, adjust_particle_charges: bool = True,
+                            random_state=None) -> "ParticleBeam":
+        """Random subset of the particles, charges rescaled to keep the total charge (particle_beam.py:1212-1262)."""
+        assert num_particles <= self.num_particles, (
+            "Number of particles to sample must be less than or equal to the number of particles in the original beam.")
+        idx = torch.randperm(self.num_particles, generator=random_state, device=self.particles.device)[:num_particles]
+        sub = self.__class__(particles=self.particles[..., idx, :], energy=self.energy,
+                             particle_charges=self.particle_charges[..., idx],
+                             survival_probabilities=self.survival_probabilities[..., idx], species=self.species)
+        if adjust_particle_charges:
+            sub.particle_charges = sub.particle_charges * (self.total_charge / sub.total_charge).unsqueeze(-1)
+        return sub
+
+    def transformed_to(self, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None, mu_p=None, sigma_x=None,
+                       sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None, sigma_p=None, energy=None,
+                       total_charge=None, species=None) -> "ParticleBeam":
+        """Shift and scale every coordinate to new means / sigmas (particle_beam.py:1034-1158); the current moments
+        come from one fused `chx_moments` call."""
+        names = ("x", "px", "y", "py", "tau", "p")
+        given_mu = (mu_x, mu_px, mu_y, mu_py, mu_tau, mu_p)
+        given_sigma = (sigma_x, sigma_px, sigma_y, sigma_py, sigma_tau, sigma_p)
+        old_mu = torch.stack(torch.broadcast_tensors(*[getattr(self, f"mu_{n}") for n in names]), dim=-1)
+        old_sigma = torch.stack(torch.broadcast_tensors(*[getattr(self, f"sigma_{n}") for n in names]), dim=-1)
+        new_mu = torch.stack(torch.broadcast_tensors(
+            *[g if g is not None else getattr(self, f"mu_{n}") for g, n in zip(given_mu, names)]), dim=-1)
+        new_sigma = torch.stack(torch.broadcast_tensors(
+            *[g if g is not None else getattr(self, f"sigma_{n}") for g, n in zip(given_sigma, names)]), dim=-1)
+        if total_charge is None:
+            charges = self.particle_charges
+        else:
+            charges = (torch.ones_like(self.particle_charges) * total_charge.unsqueeze(-1)
+                       / self.particle_charges.shape[-1])
+        phase_space = ((self.particles[..., :6] - old_mu.unsqueeze(-2)) / old_sigma.unsqueeze(-2)
+                       * new_sigma.unsqueeze(-2) + new_mu.unsqueeze(-2))
+        particles = torch.cat([phase_space, torch.ones_like(phase_space[..., :1])], dim=-1)
+        return self.__class__(particles=particles, energy=energy if energy is not None else self.energy,
+                              particle_charges=charges, survival_probabilities=self.survival_probabilities, s=self.s,
+                              species=species if species is not None else self.species)
+
     # ------------------------------------------------------------------ housekeeping
     def clone(self) -> "ParticleBeam":
         return self.__class__(particles=self.particles.clone(), energy=self.energy.clone(),

@@ -369,7 +369,28 @@ def gen_ares():
     save("ares_track.npz", **arrays)
 
 
+def gen_beam_utils():
+    """Derived-beam helpers of ParticleBeam (particle_beam.py:668-800, 1034-1262): make_linspaced, linspaced,
+    transformed_to, as_parameter_beam on a fixed beam (fp64)."""
+    arrays = {}
+    inc = load_incoming().to(torch.float64)
+    beam = cheetah.ParticleBeam(inc.particles[:1024], inc.energy, particle_charges=inc.particle_charges[:1024],
+                                species=cheetah.Species("electron", **F64), **F64)
+    arrays["in"], arrays["energy"], arrays["charges"] = npy(beam.particles), npy(beam.energy), npy(beam.particle_charges)
+    tr = beam.transformed_to(mu_x=t64(1e-3), sigma_y=t64([1e-4, 2e-4]), sigma_p=t64(5e-4), total_charge=t64(2e-12),
+                             energy=t64(2e8))
+    arrays["transformed"], arrays["transformed_charges"] = npy(tr.particles), npy(tr.particle_charges)
+    arrays["transformed_energy"] = npy(tr.energy)
+    lin = cheetah.ParticleBeam.make_linspaced(num_particles=17, mu_x=t64([1e-3, -1e-3]), sigma_px=t64(3e-6),
+                                              energy=t64(1.5e8), total_charge=t64(1e-10), **F64)
+    arrays["linspaced"], arrays["linspaced_charges"] = npy(lin.particles), npy(lin.particle_charges)
+    # (ParticleBeam.linspaced of the reference raises TypeError — it passes particle_charges to make_linspaced)
+    pb = beam.as_parameter_beam()
+    arrays["pb_mu"], arrays["pb_cov"], arrays["pb_total_charge"] = npy(pb.mu), npy(pb.cov), npy(pb.total_charge)
+    save("beam_utils.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils"]
     for w in which:
         globals()["gen_" + w]()
