@@ -79,6 +79,8 @@ SIGNATURES = {
     "chx_track_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "chx_cavity_coeffs": (c_int, [c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_cavity_track": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]),
+    "chx_cavity_track_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p,
+                                     c_size_t, c_void_p]),
     "chx_moments_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "chx_moment_sums": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_moment_centred": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -53,6 +53,13 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def forward_only(what: str, *tensors) -> None:
+    """Kernels without a backward pass must not silently detach: raise when an input carries gradients."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(f"{what} is forward-only in this build (no backward kernel); detach the inputs or "
+                                  "run under torch.no_grad()")
+
+
 def ptr(t: torch.Tensor | None):
     return None if t is None else t.data_ptr()
 
@@ -245,6 +252,7 @@ def apply_map(particles: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
 def track_elementwise(particles, maps: torch.Tensor, fused: bool = False) -> torch.Tensor:
     """Apply E maps ([E][BR][7][7]) one after the other without merging them."""
     require_device(particles, maps)
+    forward_only("element-wise (unmerged) tracking", particles, maps)
     E, BR = maps.shape[0], maps.shape[1]
     N = particles.shape[-2]
     batch_shape = torch.broadcast_shapes(particles.shape[:-2], (BR,) if BR > 1 else ())
@@ -265,7 +273,45 @@ def track_elementwise(particles, maps: torch.Tensor, fused: bool = False) -> tor
 
 # ---------------------------------------------------------------------------------------------
 # cavity
+def _cavity_coeffs_autograd(params, energy, mass_eV, n_charges, B):
+    """The closed forms of chx_cavity_coeffs (cavity.py:113-122,135-226) as (B,)-sized fp64 tensor expressions, used
+    only when voltage / phase / frequency / length / energy carry gradients: autograd differentiates them, the
+    particle-sized work stays in the kernels (CavityTrack)."""
+    import math
+
+    p = params.to(torch.float64).expand(B, 4)
+    L, V, phi, freq = p[:, 0], p[:, 1], p[:, 2] * (math.pi / 180.0), p[:, 3]
+    E0 = energy.to(torch.float64).expand(B)
+    g0 = E0 / mass_eV
+    ig2 = 1.0 / (g0 * g0)
+    b0 = (1.0 - ig2).sqrt()
+    cphi, sphi = phi.cos(), phi.sin()
+    dEn = V * cphi * n_charges * -1.0
+    E1 = E0 + dEn
+    g1 = E1 / mass_eV
+    b1 = (1.0 - 1.0 / (g1 * g1)).sqrt()
+    k = 2.0 * math.pi * freq / 299792458.0
+    gain = (dEn > 0).any()
+    dg = V / mass_eV
+    b03, b13, g03, g13 = b0**3, b1**3, g0**3, g1**3
+    gd = g0 - g1
+    gd = torch.where(gd == 0, torch.ones_like(gd), gd)  # only reached in rows the `gain` branch does not use
+    T566_gain = L * (b03 * g03 - b13 * g13) / (2.0 * b0 * b13 * g0 * gd * g13)
+    T556_gain = b0 * k * L * dg * g0 * (b13 * g13 + b0 * (g0 - g13)) * sphi / (b13 * g13 * gd * gd)
+    T555_gain = b0 * b0 * k * k * L * dg / 2.0 * (
+        dg * (2.0 * g0 * g13 * (b0 * b13 - 1.0) + g0 * g0 + 3.0 * g1 * g1 - 2.0) / (b13 * g13 * gd**3) * sphi * sphi
+        - (g1 * g0 * (b1 * b0 - 1.0) + 1.0) / (b1 * g1 * gd * gd) * cphi)
+    zero = torch.zeros_like(L)
+    T566 = torch.where(gain, T566_gain, 1.5 * L * ig2 / b03)
+    T556 = torch.where(gain, T556_gain, zero)
+    T555 = torch.where(gain, T555_gain, zero)
+    coeffs = torch.stack([E0 * b0 / (E1 * b1), V * b0 / (E1 * b1), b0 * k, phi, cphi, T566, T556, T555], dim=-1)
+    return coeffs, E1.to(energy.dtype)
+
+
 def cavity_coeffs(params, energy, mass_eV, n_charges, B):
+    if params.requires_grad or energy.requires_grad:
+        return _cavity_coeffs_autograd(params, energy, mass_eV, n_charges, B)
     coeffs = torch.empty((B, CAV_NCOEF), dtype=torch.float64, device=energy.device)
     e_out = torch.empty((B,), dtype=energy.dtype, device=energy.device)
     check(_lib.lib().chx_cavity_coeffs(ptr(params), ptr(energy), mass_eV, n_charges, B, params.shape[0],
@@ -274,11 +320,61 @@ def cavity_coeffs(params, energy, mass_eV, n_charges, B):
     return coeffs, e_out
 
 
-def cavity_track(x, R, coeffs, B, N):
+def _cavity_track_raw(x, R, coeffs, B, N):
     out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
     check(_lib.lib().chx_cavity_track(ptr(x), ptr(R), ptr(coeffs), ptr(out), B, x.shape[0], N,
                                       dtype_code(x.dtype), stream_ptr()), "chx_cavity_track")
     return out
+
+
+class CavityTrack(torch.autograd.Function):
+    """y = chx_cavity_track(x, R, coeffs); backward = chx_apply_affine7_bwd on the matrix part (row 5 of R does not
+    reach the output: delta' is rewritten from the incoming tau, delta) + chx_cavity_track_bwd for the rewrite."""
+
+    @staticmethod
+    def forward(ctx, x, R, coeffs, B):
+        ctx.save_for_backward(x, R, coeffs)
+        ctx.B = B
+        return _cavity_track_raw(x, R, coeffs, B, x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, R, coeffs = ctx.saved_tensors
+        B, Bx, N = ctx.B, x.shape[0], x.shape[1]
+        dY = aligned(dY)
+        need_dx, need_dr, need_dc = ctx.needs_input_grad[:3]
+        lib = _lib.lib()
+        dt = dtype_code(x.dtype)
+        dX = dR = None
+        if need_dx or need_dr:
+            R0 = R.clone()
+            R0[:, 5, :] = 0
+            ws_bytes = lib.chx_apply_bwd_workspace_bytes(B, N)
+            ws = workspace(ws_bytes, x.device)
+            dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_dx else None
+            dR = torch.empty((B, 49), dtype=torch.float64, device=x.device) if need_dr else None
+            check(lib.chx_apply_affine7_bwd(ptr(dY), ptr(R0), ptr(x), ptr(dX), ptr(dR), B, Bx, B, N, dt, ptr(ws),
+                                            ws_bytes, stream_ptr()), "chx_apply_affine7_bwd")
+        dC = None
+        if need_dx or need_dc:
+            ws_bytes = lib.chx_moments_workspace_bytes(B, N)
+            ws = workspace(ws_bytes, x.device)
+            dC = torch.empty((B, CAV_NCOEF), dtype=torch.float64, device=x.device)
+            check(lib.chx_cavity_track_bwd(ptr(dY), ptr(x), ptr(coeffs), ptr(dX), ptr(dC), B, Bx, N, dt, ptr(ws), ws_bytes,
+                                           stream_ptr()), "chx_cavity_track_bwd")
+        if need_dx and Bx == 1 and B > 1:
+            dX = dX.sum(dim=0, keepdim=True)
+        if need_dr:
+            dR = dR.reshape(B, 7, 7).clone()
+            dR[:, 5, :] = 0
+            dR = dR.to(R.dtype)
+        return dX, dR, (dC if need_dc else None), None
+
+
+def cavity_track(x, R, coeffs, B, N):
+    if x.requires_grad or R.requires_grad or coeffs.requires_grad:
+        return CavityTrack.apply(x, R, coeffs.contiguous(), B)
+    return _cavity_track_raw(x, R, coeffs, B, N)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -303,8 +399,7 @@ def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float,
     """One drift-kick-drift element (chx_dkd_track): particles (..., N, 7), params (Bp, P) with vector shape
     `param_shape`, energy (...). Returns (particles_out (*batch, N, 7), ref_energy (*energy/param batch))."""
     require_device(particles, params, energy)
-    if particles.requires_grad or params.requires_grad or energy.requires_grad:
-        raise NotImplementedError("drift_kick_drift tracking is not differentiable in this build (forward only)")
+    forward_only("drift_kick_drift tracking", particles, params, energy)
     N = particles.shape[-2]
     eb_shape = bshapes(param_shape, energy.shape)           # batch shape of the outgoing energy
     batch_shape = bshapes(particles.shape[:-2], eb_shape)
@@ -331,8 +426,7 @@ def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float,
 def build_ttensor(kind: int, params, param_shape, energy, mass_eV: float) -> torch.Tensor:
     """Second-order transfer tensor (*batch, 7, 7, 7) of one element (chx_build_ttensor)."""
     require_device(params, energy)
-    if params.requires_grad or energy.requires_grad:
-        raise NotImplementedError("second_order transfer maps are not differentiable in this build (forward only)")
+    forward_only("second_order transfer maps", params, energy)
     batch_shape = bshapes(param_shape, energy.shape)
     B = max(numel(batch_shape), 1)
     p, Bp = flat_bcast(params.reshape(*param_shape, params.shape[-1]), batch_shape, 1)
@@ -347,8 +441,7 @@ def build_ttensor(kind: int, params, param_shape, energy, mass_eV: float) -> tor
 def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     """einsum("...ijk,...j,...k->...i", T, x, x) over the particle axis (element.py:211-216)."""
     require_device(particles, T)
-    if particles.requires_grad or T.requires_grad:
-        raise NotImplementedError("second_order tracking is not differentiable in this build (forward only)")
+    forward_only("second_order tracking", particles, T)
     if T.dtype != particles.dtype:
         raise RuntimeError(f"transfer map dtype {T.dtype} does not match particle dtype {particles.dtype}")
     N = particles.shape[-2]
@@ -806,6 +899,12 @@ def from_xyz_pxpypz(xp, energy, mass_eV):
 def parameter_track(mu, cov, tm, cavity_coeffs=None, batch_shape=None):
     """mu (…,7), cov (…,7,7), tm (…,7,7) -> (mu', cov') = (tm mu, tm cov tm^T) (element.py:167-179)."""
     require_device(mu, cov, tm)
+    if mu.requires_grad or cov.requires_grad or tm.requires_grad:
+        # gradient path (tests/test_differentiable.py:58-75): B tiny 7x7 products, left to autograd like compose_maps
+        if cavity_coeffs is not None:
+            forward_only("ParameterBeam tracking through an active Cavity", mu, cov, tm)
+        tm_ = tm.to(mu.dtype)
+        return (tm_ @ mu.unsqueeze(-1)).squeeze(-1), tm_ @ cov @ tm_.mT
     if batch_shape is None:
         batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], tm.shape[:-2])
     B = numel(batch_shape)

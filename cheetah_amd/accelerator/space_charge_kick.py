@@ -93,6 +93,8 @@ class SpaceChargeKick(Element):
         assert isinstance(incoming, ParticleBeam), \
             "SpaceChargeKick tracking is currently only supported for `ParticleBeam`."
         parts = incoming.particles
+        _ops.forward_only("SpaceChargeKick", parts, incoming.particle_charges, incoming.survival_probabilities,
+                          incoming.energy, self.effect_length)
         dtype, device = parts.dtype, parts.device
         N = parts.shape[-2]
         g = self.grid_shape

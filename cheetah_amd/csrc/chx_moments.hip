@@ -416,6 +416,50 @@ __global__ void track_moments_finalize_kernel(const double* __restrict__ partial
         for (int j = i; j < 6; ++j, ++k) o[k] = (a[k] - W * m[i] * m[j]) / cf;
 }
 
+// ---- backward of the cavity epilogue (chx_apply.hip cavity_epilogue; cavity.py:135-151,220-226) ---------------------
+// delta' = a delta + b (cos(theta) - cos phi), theta = -tau kb0 + phi;  tau' = (R x)_tau + T566 d^2 + T556 tau d + T555 tau^2
+// with c = [a, b, kb0, phi, cos phi, T566, T556, T555]. Given g = dL/dy: adds the epilogue's contribution to
+// dL/dx (columns tau, delta) and reduces dL/dc over the particles of each batch row (8 sums, deterministic).
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void cavity_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+                                                              const double* __restrict__ coeffs, T* __restrict__ dX,
+                                                              int64_t Bx, int64_t N, double* __restrict__ partials) {
+    __shared__ double red[4 * 8];
+    const int64_t b = blockIdx.y;
+    const double* c = coeffs + b * CHX_CAV_NCOEF;
+    const double a = c[0], bb = c[1], kb0 = c[2], phi = c[3], cphi = c[4], T566 = c[5], T556 = c[6], T555 = c[7];
+    const T* __restrict__ gy = dY + b * N * 7;
+    const T* __restrict__ xb = X + ((Bx == 1) ? 0 : b) * N * 7;
+    T* __restrict__ dx = dX ? dX + b * N * 7 : nullptr;
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * CHX_BLOCK) {
+        const double g4 = (double)gy[n * 7 + 4], g5 = (double)gy[n * 7 + 5];
+        const double tau = (double)xb[n * 7 + 4], delta = (double)xb[n * 7 + 5];
+        const double theta = -tau * kb0 + phi;
+        const double s = sin(theta), co = cos(theta);
+        if (dx) {
+            dx[n * 7 + 4] = (T)((double)dx[n * 7 + 4] + g5 * bb * s * kb0 + g4 * (T556 * delta + 2.0 * T555 * tau));
+            dx[n * 7 + 5] = (T)((double)dx[n * 7 + 5] + g5 * a + g4 * (2.0 * T566 * delta + T556 * tau));
+        }
+        acc[0] += g5 * delta;
+        acc[1] += g5 * (co - cphi);
+        acc[2] += g5 * bb * s * tau;
+        acc[3] -= g5 * bb * s;
+        acc[4] -= g5 * bb;
+        acc[5] += g4 * delta * delta;
+        acc[6] += g4 * tau * delta;
+        acc[7] += g4 * tau * tau;
+    }
+    chx_block_sum<8>(acc, red);
+    if (threadIdx.x == 0) {
+        double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = acc[k];
+    }
+}
+
 int check_red(const void* x, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype) {
     if (!x || B < 1 || N < 1 || B > 65535) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bw, B)) return CHX_ERR_INVALID_ARG;
@@ -511,6 +555,29 @@ extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, 
     st = chx_moment_centred(x, w, sums, B, Bx, Bw, N, dtype, m2, workspace, need, stream);
     if (st != CHX_OK) return st;
     return chx_moment_finalize(sums, m2, B, out, stream);
+}
+
+extern "C" int chx_cavity_track_bwd(const void* dY, const void* X, const double* coeffs, void* dX, double* dcoeffs,
+                                    int64_t B, int64_t Bx, int64_t N, int dtype, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    int st = check_red(X, B, Bx, 1, N, dtype);
+    if (st != CHX_OK) return st;
+    if (!dY || !coeffs || !dcoeffs) return CHX_ERR_INVALID_ARG;
+    const int64_t nblk = red_nblk(B, N, tile_rows(dtype));
+    if (!workspace || workspace_bytes < (size_t)(B * nblk * 8 * sizeof(double))) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    dim3 grid((unsigned)nblk, (unsigned)B);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(cavity_bwd_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)dY, (const float*)X,
+                           coeffs, (float*)dX, Bx, N, part);
+    else
+        hipLaunchKernelGGL(cavity_bwd_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)dY, (const double*)X,
+                           coeffs, (double*)dX, Bx, N, part);
+    CHX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(8, (unsigned)B), dim3(64), 0, s, part, (int)nblk, 8, dcoeffs);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
 }
 
 // ---- fused track + moments ------------------------------------------------------------------------------------

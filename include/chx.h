@@ -131,6 +131,13 @@ int chx_cavity_coeffs(const void* params /*[Bp][4]*/, const void* energy /*[Be]*
 int chx_cavity_track(const void* x_in, const void* R, const double* coeffs, void* x_out,
                      int64_t B, int64_t Bx, int64_t N, int dtype, void* stream);
 
+/* Backward of the per-particle part of chx_cavity_track that is not the matrix apply: given dY = dL/d(x_out), adds
+ * the delta' / tau' rewrite's contribution to dX[B][N][7] (columns tau, delta; dX may be NULL) and writes
+ * dcoeffs[B][CHX_CAV_NCOEF] = dL/d(coeffs). The matrix part is chx_apply_affine7_bwd with row 5 of R zeroed.
+ * workspace: chx_moments_workspace_bytes(B, N). */
+int chx_cavity_track_bwd(const void* dY, const void* X, const double* coeffs, void* dX, double* dcoeffs, int64_t B,
+                         int64_t Bx, int64_t N, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- weighted beam moments (a10; particle_beam.py:1672-1943, utils/statistics.py:4-62).
  * sums[b] = { W=sum w, sum w^2, sum w x_0..5 }  (8 doubles)
  * m2[b]   = upper triangle (a<=b, row-major, 21 doubles) of sum w (x_a-mu_a)(x_b-mu_b),

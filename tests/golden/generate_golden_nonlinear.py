@@ -390,7 +390,42 @@ def gen_beam_utils():
     save("beam_utils.npz", **arrays)
 
 
+def gen_cavity_grad():
+    """Gradients through Cavity.track (cavity.py:100-251) for a ParticleBeam: d loss / d (voltage, phase, frequency,
+    length, incoming energy, incoming particles) with loss = sum(W * outgoing particles) + 1e-9 * outgoing energy,
+    standing- and travelling-wave, accelerating and decelerating, fp64."""
+    arrays = {}
+    g = torch.Generator().manual_seed(5)
+    N = 2000
+    x = torch.randn(N, 7, generator=g, **F64) * t64([2e-4, 4e-6, 2e-4, 4e-6, 8e-6, 2e-3, 0.0])
+    x[:, 6] = 1.0
+    W = torch.randn(N, 7, generator=g, **F64)
+    arrays["x"], arrays["W"] = npy(x), npy(W)
+    cases = [("sw_acc", "standing_wave", 1.0377, 18.15975e6, 30.0, 1.3e9, 6e6),
+             ("tw_acc", "traveling_wave", 4.139, 2.0e7, -12.0, 2.998e9, 1e8),
+             ("sw_dec", "standing_wave", 1.0377, 5.0e6, 170.0, 1.3e9, 5e7)]
+    for name, ctype, L, V, ph, f, E in cases:
+        length = torch.nn.Parameter(t64(L))
+        voltage, phase, freq = torch.nn.Parameter(t64(V)), torch.nn.Parameter(t64(ph)), torch.nn.Parameter(t64(f))
+        energy = t64(E).requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        cav = cheetah.Cavity(length=length, voltage=voltage, phase=phase, frequency=freq, cavity_type=ctype, **F64)
+        beam = cheetah.ParticleBeam(xin, energy, species=cheetah.Species("electron", **F64), **F64)
+        out = cav.track(beam)
+        loss = (out.particles * W).sum() + 1e-9 * out.energy
+        loss.backward()
+        arrays[f"{name}_params"] = np.asarray([L, V, ph, f, E])
+        arrays[f"{name}_type"] = np.asarray(ctype)
+        arrays[f"{name}_loss"] = npy(loss)
+        arrays[f"{name}_out"] = npy(out.particles)
+        arrays[f"{name}_grads"] = np.asarray([float(length.grad), float(voltage.grad), float(phase.grad), float(freq.grad),
+                                              float(energy.grad)])
+        arrays[f"{name}_dx"] = npy(xin.grad)
+    arrays["names"] = np.asarray([c[0] for c in cases])
+    save("cavity_grad.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad"]
     for w in which:
         globals()["gen_" + w]()
