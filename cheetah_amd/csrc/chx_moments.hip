@@ -416,6 +416,74 @@ __global__ void track_moments_finalize_kernel(const double* __restrict__ partial
         for (int j = i; j < 6; ++j, ++k) o[k] = (a[k] - W * m[i] * m[j]) / cf;
 }
 
+// ---- one-pass moments (chx_moments): same statistics as the two-pass pair above from ONE sweep over the particles.
+// Second moments are accumulated about c = the first particle of the row (a point of the distribution, so
+// |mean - c| is a few sigma at most and sum w d d^T does not cancel), then re-centred exactly:
+//   mu = c + s / W,  M = m - s s^T / W,  cov = M / (W - W2 / W).
+struct OnePassFn {
+    double c[6];
+    __device__ __forceinline__ void accumulate(const double (&x)[7], double w, int64_t, double (&a)[kTM]) {
+        double d[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[j] = x[j] - c[j];
+        a[0] += w;
+        a[1] += w * w;
+        int k = 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double wd = w * d[i];
+            a[2 + i] += wd;
+#pragma unroll
+            for (int j = i; j < 6; ++j) { a[k] = fma(wd, d[j], a[k]); ++k; }
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                   int64_t Bx, int64_t Bw, int64_t N,
+                                                                   double* __restrict__ partials) {
+    OnePassFn f;
+    const T* x0 = x + ((Bx == 1) ? 0 : (int64_t)blockIdx.y) * N * 7;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) f.c[j] = (double)x0[j];
+    tiled_reduce<T, kTM, OnePassFn>(x, w, Bx, Bw, N, f, partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kTM);
+}
+
+// One workgroup per batch row: wave k sums partial k over the blocks in a fixed order, then lanes 0..28 of wave 0
+// re-centre and normalise -> out[b][29]. Replaces reduce_partials x2 + finalize of the two-pass path.
+template <typename T>
+__global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const double* __restrict__ partials, int nblk,
+                                                                      const T* __restrict__ x, int64_t Bx, int64_t N,
+                                                                      double* __restrict__ out) {
+    __shared__ double tot[32];
+    const int64_t b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < kTM; k += 16) {
+        const double* p = partials + b * nblk * kTM + k;
+        double s0 = 0.0, s1 = 0.0;
+        int i = lane;
+        for (; i + 64 < nblk; i += 128) { s0 += p[(int64_t)i * kTM]; s1 += p[(int64_t)(i + 64) * kTM]; }
+        for (; i < nblk; i += 64) s0 += p[(int64_t)i * kTM];
+        const double s = chx_wave_sum(s0 + s1);
+        if (lane == 0) tot[k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const T* x0 = x + ((Bx == 1) ? 0 : b) * N * 7;
+        const double W = tot[0], W2 = tot[1];
+        double* o = out + b * CHX_MOM_NOUT;
+        o[0] = W;
+        o[1] = W2;
+        double m[6];
+        for (int j = 0; j < 6; ++j) { m[j] = tot[2 + j] / W; o[2 + j] = (double)x0[j] + m[j]; }
+        const double cf = W - W2 / W;
+        int k = 8;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j, ++k) o[k] = (tot[k] - W * m[i] * m[j]) / cf;
+    }
+}
+
 // ---- backward of the cavity epilogue (chx_apply.hip cavity_epilogue; cavity.py:135-151,220-226) ---------------------
 // delta' = a delta + b (cos(theta) - cos phi), theta = -tau kb0 + phi;  tau' = (R x)_tau + T566 d^2 + T556 tau d + T555 tau^2
 // with c = [a, b, kb0, phi, cos phi, T566, T556, T555]. Given g = dL/dy: adds the epilogue's contribution to
@@ -474,7 +542,7 @@ inline int tile_rows(int dtype) { return dtype == CHX_F32 ? 512 : 256; }
 static size_t partials_bytes(int64_t B, int64_t N) {
     // worst case over dtypes (fp64 tiles are 256 rows -> more tiles)
     const int64_t nblk = red_nblk(B, N, 256);
-    return (size_t)(B * nblk * 21 * sizeof(double));
+    return (size_t)(B * nblk * 29 * sizeof(double));  // 29 = one-pass accumulators (two-pass passes need 8 / 21)
 }
 
 extern "C" size_t chx_moments_workspace_bytes(int64_t B, int64_t N) {
@@ -548,13 +616,30 @@ extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, 
     const size_t need = partials_bytes(B, N);
     const size_t tail = (size_t)B * (CHX_MOM_NSUMS + CHX_MOM_NM2) * sizeof(double);
     if (!workspace || workspace_bytes < need + tail) return CHX_ERR_WORKSPACE;
-    double* sums = (double*)((char*)workspace + need);
-    double* m2 = sums + B * CHX_MOM_NSUMS;
-    int st = chx_moment_sums(x, w, B, Bx, Bw, N, dtype, sums, workspace, need, stream);
+    int st = check_red(x, B, Bx, w ? Bw : 1, N, dtype);
     if (st != CHX_OK) return st;
-    st = chx_moment_centred(x, w, sums, B, Bx, Bw, N, dtype, m2, workspace, need, stream);
-    if (st != CHX_OK) return st;
-    return chx_moment_finalize(sums, m2, B, out, stream);
+    if (!w) Bw = 1;
+    // one sweep over the particles + one reduce/finalize launch (the split two-pass entry points above remain for
+    // the multi-GPU path, where the means are all-reduced between the passes)
+    const int64_t nblk = red_nblk(B, N, tile_rows(dtype));
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    dim3 grid((unsigned)nblk, (unsigned)B);
+    if (dtype == CHX_F32) {
+        hipLaunchKernelGGL(moments_onepass_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x, (const float*)w,
+                           Bx, Bw, N, part);
+        CHX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(moments_reduce_finalize_kernel<float>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
+                           (const float*)x, Bx, N, out);
+    } else {
+        hipLaunchKernelGGL(moments_onepass_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
+                           (const double*)w, Bx, Bw, N, part);
+        CHX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(moments_reduce_finalize_kernel<double>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
+                           (const double*)x, Bx, N, out);
+    }
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
 }
 
 extern "C" int chx_cavity_track_bwd(const void* dY, const void* X, const double* coeffs, void* dX, double* dcoeffs,

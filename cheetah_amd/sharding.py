@@ -4,10 +4,12 @@ The path shards on two independent axes and needs NO data-path collective for tr
   * vector (batch) axis: independent lattice settings  -> `shard_range(B, rank, world)` per rank;
   * particle axis: particles are independent under linear maps and cavities -> each rank tracks its
     own slice of the beam.
-Only *global beam moments* need communication: two all-reduces of tiny fp64 buffers per query
-(8 sums, then 21 centred sums about the global mean), i.e. the reference's two-pass statistics
-(cheetah/utils/statistics.py:30-48) distributed over ranks. Space charge additionally all-reduces the
-g^3 charge grid (one exchange per kick).
+Only *global beam moments* need communication: every rank reduces its own particles with the one-pass
+`chx_moments` kernel, ONE all-gather moves 29 doubles per rank and batch row, and the per-rank moments are
+merged exactly (Chan et al.: M = sum_r [M_r + W_r (mu_r - mu)(mu_r - mu)^T]) — the reference's weighted
+statistics (cheetah/utils/statistics.py:30-48) distributed over ranks. (`allreduce_moments` is the older
+two-all-reduce formulation of the same result.) Space charge additionally all-reduces the g^3 charge grid
+(one exchange per kick).
 
 The collective logic is written against `torch.distributed` only, so it runs over RCCL on GPUs and
 over gloo in the CPU tests (tests/test_sharding_gloo.py, world_size 2, partials from the oracle).
@@ -45,20 +47,43 @@ def allreduce_moments(local_sums: torch.Tensor, centred_fn: Callable[[torch.Tens
     return finalize_fn(sums, m2)
 
 
+_TRI = [(i, j) for i in range(6) for j in range(i, 6)]
+
+
+def merge_moments(per_rank: torch.Tensor) -> torch.Tensor:
+    """(R, B, 29) per-rank [W, W2, mu(6), unbiased cov upper triangle(21)] -> (B, 29) of the union of the shards.
+    Ranks without weight (W = 0) contribute nothing."""
+    W_r, W2_r = per_rank[..., 0], per_rank[..., 1]
+    has = W_r > 0
+    safe_W = torch.where(has, W_r, torch.ones_like(W_r))
+    mu_r = torch.where(has.unsqueeze(-1), per_rank[..., 2:8], torch.zeros_like(per_rank[..., 2:8]))
+    cf_r = W_r - W2_r / safe_W
+    M_r = torch.where(has.unsqueeze(-1), per_rank[..., 8:29] * cf_r.unsqueeze(-1), torch.zeros_like(per_rank[..., 8:29]))
+    W, W2 = W_r.sum(0), W2_r.sum(0)
+    mu = (W_r.unsqueeze(-1) * mu_r).sum(0) / W.unsqueeze(-1)
+    d = mu_r - mu.unsqueeze(0)
+    dd = torch.stack([d[..., i] * d[..., j] for i, j in _TRI], dim=-1)
+    M = (M_r + W_r.unsqueeze(-1) * dd).sum(0)
+    cov = M / (W - W2 / W).unsqueeze(-1)
+    return torch.cat([W.unsqueeze(-1), W2.unsqueeze(-1), mu, cov], dim=-1)
+
+
+def gather_merge_moments(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Global moments from this rank's local (B,29) moments: one all-gather + exact merge."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return local
+    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    return merge_moments(torch.stack(parts, dim=0))
+
+
 def global_moments(beam, group=None) -> torch.Tensor:
-    """(…,29) global moments of a particle-sharded beam (HIP partial reductions + RCCL all-reduce)."""
+    """(…,29) global moments of a particle-sharded beam: local one-pass HIP reduction (chx_moments) + one
+    all-gather over RCCL + exact merge."""
     from . import _ops
 
-    p, w = beam.particles, beam.survival_probabilities
-    batch_shape = torch.broadcast_shapes(p.shape[:-2], w.shape[:-1])
-    B = _ops.numel(batch_shape)
-    x, _ = _ops.flat_bcast(p, batch_shape, 2)
-    x = _ops.aligned(x)
-    wf, _ = _ops.flat_bcast(w.to(p.dtype), batch_shape, 1)
-    wf = wf.contiguous()
-    out = allreduce_moments(_ops.moment_sums(x, wf, B), lambda s: _ops.moment_centred(x, wf, s, B),
-                            _ops.moment_finalize, group)
-    return out.reshape(*batch_shape, _ops.MOM_NOUT)
+    local = _ops.moments(beam.particles, beam.survival_probabilities)
+    return gather_merge_moments(local.reshape(-1, _ops.MOM_NOUT), group).reshape(local.shape)
 
 
 def allreduce_grid(grid: torch.Tensor, group=None) -> torch.Tensor:

@@ -91,3 +91,51 @@ def test_global_moments_two_ranks_gloo(oracle):
     assert np.allclose(out[:, :8], ref[:, :8], rtol=1e-12, atol=1e-18)
     assert np.allclose(out[:, 8:], ref[:, 8:], rtol=1e-9, atol=1e-24)
     assert np.array_equal(grid, np.full((4, 4), 3.0))
+
+
+def _worker_merge(rank, world, port, x, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cheetah_amd.sharding import gather_merge_moments, shard_range
+    from oracle import chx_oracle
+
+    lo, hi = shard_range(x.shape[1], rank, world)
+    if rank == world - 1:
+        w = w.copy()
+        w[1, lo:hi] = 0.0  # batch row 1: this rank's shard carries no weight at all
+    local = chx_oracle.moments(x[:, lo:hi], w[:, lo:hi])["raw"]  # on the GPU box: chx_moments of the local shard
+    out = gather_merge_moments(torch.from_numpy(np.nan_to_num(local, nan=0.0)))
+    if rank == 0:
+        q.put(out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_merge_moments_three_ranks_gloo(oracle):
+    """The one-collective formulation used by sharding.global_moments: per-rank moments, all-gather, exact merge."""
+    rng = np.random.default_rng(9)
+    B, N, world = 2, 9001, 3
+    x = (rng.standard_normal((B, N, 7)) * [1e-3, 1e-5, 2e-3, 1e-5, 1e-4, 1e-3, 0] + [5e-3, 0, -1e-3, 0, 0, 2e-2, 1]).astype(np.float64)
+    x[:, 6000:, 0] += 3e-3  # shards with different means: the merge term matters
+    w = rng.random((B, N))
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_merge, args=(r, world, port, x, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    w_ref = w.copy()
+    w_ref[1, 6001:] = 0.0  # shard_range(9001, 2, 3) = [6001, 9001)
+    ref = oracle.moments(x, w_ref)["raw"]
+    assert np.allclose(out[:, :2], ref[:, :2], rtol=1e-13)
+    sig = np.sqrt(ref[:, [8, 14, 19, 23, 26, 28]])
+    assert np.all(np.abs(out[:, 2:8] - ref[:, 2:8]) <= 1e-12 * (sig + np.abs(ref[:, 2:8])))
+    k = 8
+    for i in range(6):
+        for j in range(i, 6):
+            assert np.all(np.abs(out[:, k] - ref[:, k]) <= 1e-11 * sig[:, i] * sig[:, j]), (i, j)
+            k += 1
