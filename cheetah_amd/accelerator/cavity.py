@@ -17,6 +17,18 @@ from ..particles.particle_beam import ParticleBeam
 from .element import Element
 
 
+def _narrow_to(t: torch.Tensor, shape) -> torch.Tensor:
+    """Pick the representative entries of a broadcast tensor `t` so that it has `shape` (right-aligned, every dim of
+    `shape` equals the matching dim of `t` or is 1): the values do not depend on the dropped dims."""
+    lead = t.dim() - len(shape)
+    if lead:
+        t = t[(0,) * lead]
+    for d, s in enumerate(shape):
+        if s == 1 and t.shape[d] != 1:
+            t = t.narrow(d, 0, 1)
+    return t.reshape(shape)
+
+
 class Cavity(Element):
     """Accelerating RF cavity (standing or traveling wave)."""
 
@@ -42,6 +54,10 @@ class Cavity(Element):
 
     def _builder_params(self):
         return [self.length, self.voltage, self.phase, self.frequency]
+
+    def _energy_shape(self, energy: torch.Tensor):
+        """Shape of the outgoing energy: `incoming.energy + voltage * cos(phase) * ...` (cavity.py:113-122)."""
+        return torch.broadcast_shapes(self.voltage.shape, self.phase.shape, energy.shape)
 
     @property
     def is_active(self) -> bool:
@@ -74,11 +90,7 @@ class Cavity(Element):
         e = energy.reshape(1) if energy.dim() == 0 else energy.expand(batch_shape).reshape(B).contiguous()
         sp = incoming.species
         coeffs, e_out = _ops.cavity_coeffs(params.contiguous(), e, sp.mass_eV_float, sp.num_elementary_charges_float, B)
-        vshape = torch.broadcast_shapes(pshape, energy.shape)
-        e_out = e_out.reshape(batch_shape)
-        if tuple(vshape) != tuple(batch_shape):
-            idx = tuple(0 for _ in range(len(batch_shape) - len(vshape)))
-            e_out = e_out[idx].reshape(vshape) if idx else e_out.reshape(vshape)
+        e_out = _narrow_to(e_out.reshape(batch_shape), self._energy_shape(energy))
         return incoming._tracked(tm, self.length, cavity_coeffs=coeffs, energy=e_out, batch_shape=batch_shape)
 
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
@@ -107,11 +119,8 @@ class Cavity(Element):
         R, _ = _ops.flat_bcast(tm, batch_shape, 2)
         R = R.expand(B, 7, 7).contiguous()
         out = _ops.cavity_track(_ops.aligned(x), R, coeffs, B, N)
-        # outgoing energy has the broadcast shape of (voltage, phase, energy), not of the particles
-        e_out = e_out.reshape(batch_shape)
-        if tuple(vshape) != tuple(batch_shape):
-            idx = tuple(0 for _ in range(len(batch_shape) - len(vshape)))
-            e_out = e_out[idx].reshape(vshape) if idx else e_out.reshape(vshape)
+        # outgoing energy has the broadcast shape of (voltage, phase, energy) — not of the length or the particles
+        e_out = _narrow_to(e_out.reshape(batch_shape), self._energy_shape(energy))
         return ParticleBeam(out.reshape(*batch_shape, N, 7), e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length,
                             species=incoming.species)
