@@ -72,19 +72,30 @@ class ParameterBeam(Beam):
 
     @classmethod
     def from_twiss(cls, beta_x=None, alpha_x=None, emittance_x=None, beta_y=None, alpha_y=None, emittance_y=None,
-                   energy=None, sigma_tau=None, sigma_p=None, cov_taup=None, total_charge=None, s=None, species=None,
-                   device=None, dtype=None) -> "ParameterBeam":
-        """parameter_beam.py:282-414 (without dispersion arguments)."""
+                   dispersion_x=None, dispersion_px=None, dispersion_y=None, dispersion_py=None, energy=None,
+                   sigma_tau=None, sigma_p=None, cov_taup=None, total_charge=None, s=None, species=None, device=None,
+                   dtype=None) -> "ParameterBeam":
+        """Twiss parameters and dispersion -> moments (parameter_beam.py:282-414)."""
         fk = {"device": device, "dtype": dtype}
         d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
         beta_x, alpha_x, emittance_x = d(beta_x, 1.0), d(alpha_x, 0.0), d(emittance_x, 7.1971891e-13)
         beta_y, alpha_y, emittance_y = d(beta_y, 1.0), d(alpha_y, 0.0), d(emittance_y, 7.1971891e-13)
+        dx, dpx, dy, dpy = d(dispersion_x, 0.0), d(dispersion_px, 0.0), d(dispersion_y, 0.0), d(dispersion_py, 0.0)
+        sigma_p = d(sigma_p, 1e-6)
+        sp2 = sigma_p.square()
         return cls.from_parameters(
-            sigma_x=(emittance_x * beta_x).sqrt(), sigma_px=(emittance_x * (1 + alpha_x.square()) / beta_x).sqrt(),
-            sigma_y=(emittance_y * beta_y).sqrt(), sigma_py=(emittance_y * (1 + alpha_y.square()) / beta_y).sqrt(),
-            sigma_tau=d(sigma_tau, 1e-6), sigma_p=d(sigma_p, 1e-6), cov_xpx=-emittance_x * alpha_x,
-            cov_ypy=-emittance_y * alpha_y, cov_taup=d(cov_taup, 0.0), energy=d(energy, 1e8),
-            total_charge=total_charge, s=s, species=species, device=device, dtype=dtype)
+            sigma_x=(emittance_x * beta_x + dx.square() * sp2).sqrt(),
+            sigma_px=(emittance_x * (1 + alpha_x.square()) / beta_x + dpx.square() * sp2).sqrt(),
+            sigma_y=(emittance_y * beta_y + dy.square() * sp2).sqrt(),
+            sigma_py=(emittance_y * (1 + alpha_y.square()) / beta_y + dpy.square() * sp2).sqrt(),
+            sigma_tau=d(sigma_tau, 1e-6), sigma_p=sigma_p, cov_xpx=-emittance_x * alpha_x + dx * dpx * sp2,
+            cov_ypy=-emittance_y * alpha_y + dy * dpy * sp2, cov_taup=d(cov_taup, 0.0), cov_xp=dx * sp2, cov_pxp=dpx * sp2,
+            cov_yp=dy * sp2, cov_pyp=dpy * sp2, energy=d(energy, 1e8), total_charge=total_charge, s=s, species=species,
+            device=device, dtype=dtype)
+
+    @property
+    def defining_features(self) -> list[str]:
+        return ["mu", "cov", "energy", "total_charge", "s", "species"]
 
     def transformed_to(self, energy=None, total_charge=None, species=None, **moments) -> "ParameterBeam":
         """New beam with some moments replaced (parameter_beam.py:476-586): unspecified mu_* / sigma_* / cov_* keep

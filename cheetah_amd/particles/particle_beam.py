@@ -82,23 +82,27 @@ class ParticleBeam(Beam):
     @classmethod
     def from_parameters(cls, num_particles=100_000, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None,
                         mu_p=None, sigma_x=None, sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None,
-                        sigma_p=None, cov_xpx=None, cov_ypy=None, cov_taup=None, cov_xp=None, cov_pxp=None,
-                        cov_yp=None, cov_pyp=None, energy=None, total_charge=None, s=None, species=None,
-                        device=None, dtype=None) -> "ParticleBeam":
-        """Gaussian beam from moments; defaults as particle_beam.py:193-216."""
+                        sigma_p=None, cov_xpx=None, cov_xy=None, cov_xpy=None, cov_xtau=None, cov_xp=None, cov_pxy=None,
+                        cov_pxpy=None, cov_pxtau=None, cov_pxp=None, cov_ypy=None, cov_ytau=None, cov_yp=None,
+                        cov_pytau=None, cov_pyp=None, cov_taup=None, energy=None, total_charge=None, s=None,
+                        species=None, device=None, dtype=None) -> "ParticleBeam":
+        """Gaussian beam from its means, sigmas and any of the 15 covariances; defaults as particle_beam.py:108-353."""
         fk = {"device": device, "dtype": dtype}
         d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
         mus = torch.broadcast_tensors(d(mu_x, 0.0), d(mu_px, 0.0), d(mu_y, 0.0), d(mu_py, 0.0), d(mu_tau, 0.0),
                                       d(mu_p, 0.0))
         mean = torch.stack(mus, dim=-1)
-        (sx, spx, sy, spy, st, sp, cxpx, cypy, ctp, cxp, cpxp, cyp, cpyp) = torch.broadcast_tensors(
-            d(sigma_x, 175e-6), d(sigma_px, 4e-6), d(sigma_y, 175e-6), d(sigma_py, 4e-6), d(sigma_tau, 8e-6),
-            d(sigma_p, 2e-3), d(cov_xpx, 0.0), d(cov_ypy, 0.0), d(cov_taup, 0.0), d(cov_xp, 0.0), d(cov_pxp, 0.0),
-            d(cov_yp, 0.0), d(cov_pyp, 0.0))
-        cov = torch.zeros(*sx.shape, 6, 6, **fk)
-        for i, sg in enumerate((sx, spx, sy, spy, st, sp)):
+        offdiag = {(0, 1): cov_xpx, (0, 2): cov_xy, (0, 3): cov_xpy, (0, 4): cov_xtau, (0, 5): cov_xp, (1, 2): cov_pxy,
+                   (1, 3): cov_pxpy, (1, 4): cov_pxtau, (1, 5): cov_pxp, (2, 3): cov_ypy, (2, 4): cov_ytau, (2, 5): cov_yp,
+                   (3, 4): cov_pytau, (3, 5): cov_pyp, (4, 5): cov_taup}
+        sigmas = [d(sigma_x, 175e-6), d(sigma_px, 4e-6), d(sigma_y, 175e-6), d(sigma_py, 4e-6), d(sigma_tau, 8e-6),
+                  d(sigma_p, 2e-3)]
+        given = {k: v for k, v in offdiag.items() if v is not None}
+        shape = torch.broadcast_shapes(*[t.shape for t in sigmas], *[v.shape for v in given.values()])
+        cov = torch.zeros(*shape, 6, 6, **fk)
+        for i, sg in enumerate(sigmas):
             cov[..., i, i] = sg.square()
-        for (i, j, c) in ((0, 1, cxpx), (2, 3, cypy), (4, 5, ctp), (0, 5, cxp), (1, 5, cpxp), (2, 5, cyp), (3, 5, cpyp)):
+        for (i, j), c in given.items():
             cov[..., i, j] = c
             cov[..., j, i] = c
         return cls.from_distribution(mean, cov, num_particles=num_particles, energy=energy,
@@ -106,20 +110,27 @@ class ParticleBeam(Beam):
 
     @classmethod
     def from_twiss(cls, num_particles=100_000, beta_x=None, alpha_x=None, emittance_x=None, beta_y=None,
-                   alpha_y=None, emittance_y=None, energy=None, sigma_tau=None, sigma_p=None, cov_taup=None,
-                   total_charge=None, s=None, species=None, device=None, dtype=None) -> "ParticleBeam":
-        """particle_beam.py:434-560 (without dispersion arguments)."""
+                   alpha_y=None, emittance_y=None, dispersion_x=None, dispersion_px=None, dispersion_y=None,
+                   dispersion_py=None, energy=None, sigma_tau=None, sigma_p=None, cov_taup=None, total_charge=None,
+                   s=None, species=None, device=None, dtype=None) -> "ParticleBeam":
+        """Gaussian beam from Twiss parameters and dispersion (particle_beam.py:434-560)."""
         fk = {"device": device, "dtype": dtype}
         d = lambda v, default: v if v is not None else torch.tensor(default, **fk)  # noqa: E731
         beta_x, alpha_x, emittance_x = d(beta_x, 0.0), d(alpha_x, 0.0), d(emittance_x, 7.1971891e-13)
         beta_y, alpha_y, emittance_y = d(beta_y, 0.0), d(alpha_y, 0.0), d(emittance_y, 7.1971891e-13)
+        dx, dpx, dy, dpy = d(dispersion_x, 0.0), d(dispersion_px, 0.0), d(dispersion_y, 0.0), d(dispersion_py, 0.0)
+        sigma_tau, sigma_p, cov_taup = d(sigma_tau, 1e-6), d(sigma_p, 1e-6), d(cov_taup, 0.0)
+        sp2 = sigma_p.square()
         return cls.from_parameters(
             num_particles=num_particles,
-            sigma_x=(beta_x * emittance_x).sqrt(), sigma_px=(emittance_x * (1 + alpha_x.square()) / beta_x).sqrt(),
-            sigma_y=(beta_y * emittance_y).sqrt(), sigma_py=(emittance_y * (1 + alpha_y.square()) / beta_y).sqrt(),
-            sigma_tau=d(sigma_tau, 1e-6), sigma_p=d(sigma_p, 1e-6), cov_xpx=-emittance_x * alpha_x,
-            cov_ypy=-emittance_y * alpha_y, cov_taup=d(cov_taup, 0.0), energy=d(energy, 1e8),
-            total_charge=total_charge, s=s, species=species, device=device, dtype=dtype)
+            sigma_x=(beta_x * emittance_x + dx.square() * sp2).sqrt(),
+            sigma_px=(emittance_x * (1 + alpha_x.square()) / beta_x + dpx.square() * sp2).sqrt(),
+            sigma_y=(beta_y * emittance_y + dy.square() * sp2).sqrt(),
+            sigma_py=(emittance_y * (1 + alpha_y.square()) / beta_y + dpy.square() * sp2).sqrt(),
+            sigma_tau=sigma_tau, sigma_p=sigma_p, cov_xpx=-emittance_x * alpha_x + dx * dpx * sp2,
+            cov_ypy=-emittance_y * alpha_y + dy * dpy * sp2, cov_taup=cov_taup, cov_xp=dx * sp2, cov_pxp=dpx * sp2,
+            cov_yp=dy * sp2, cov_pyp=dpy * sp2, energy=d(energy, 1e8), total_charge=total_charge, s=s, species=species,
+            device=device, dtype=dtype)
 
     @classmethod
     def uniform_3d_ellipsoid(cls, num_particles=100_000, radius_x=None, radius_y=None, radius_tau=None,
@@ -360,6 +371,11 @@ class ParticleBeam(Beam):
                               species=species if species is not None else self.species)
 
     # ------------------------------------------------------------------ housekeeping
+    @property
+    def defining_features(self) -> list[str]:
+        """particle_beam.py `defining_features`: what makes two beams equal / what `.to()` converts."""
+        return ["particles", "energy", "particle_charges", "survival_probabilities", "s", "species"]
+
     def clone(self) -> "ParticleBeam":
         return self.__class__(particles=self.particles.clone(), energy=self.energy.clone(),
                               particle_charges=self.particle_charges.clone(),
