@@ -32,7 +32,6 @@ def _narrow_to(t: torch.Tensor, shape) -> torch.Tensor:
 class Cavity(Element):
     """Accelerating RF cavity (standing or traveling wave)."""
 
-    supported_tracking_methods = ["linear"]
     _static_skippable = False  # `voltage != 0` is a tensor-value dependent flag
 
     def __init__(self, length, voltage=None, phase=None, frequency=None, cavity_type="standing_wave", name=None,

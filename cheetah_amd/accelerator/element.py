@@ -47,7 +47,8 @@ def _unique_name() -> str:
 class Element(nn.Module):
     """Base class of all beamline elements."""
 
-    supported_tracking_methods = ["linear"]
+    #: declared by the elements that offer a choice; all others get `[<class name>.lower()]` in __init__, like the
+    #: reference (element.py:63-65) — e.g. a Marker does not "support" the linear method, it has none to choose from
     #: libchx map-builder kind (include/chx.h `chx_kind`); None for elements with explicit maps
     _chx_kind: int | None = None
     #: True when `is_skippable` depends on non-tensor attributes only (those bump `_revision` when set)
@@ -59,7 +60,9 @@ class Element(nn.Module):
         self.name = name if name is not None else _unique_name()
         self.metadata = metadata if metadata is not None else {}
         self.register_buffer("length", torch.zeros((), device=device, dtype=dtype))
-        self._tracking_method = "linear"
+        if not hasattr(self, "supported_tracking_methods"):
+            self.supported_tracking_methods = [self.__class__.__name__.lower()]
+        self._tracking_method = self.supported_tracking_methods[0]
 
     # ---- parameters packed for the builder kernel, in include/chx.h order ------------------------
     def _builder_params(self) -> list[torch.Tensor]:

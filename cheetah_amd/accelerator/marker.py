@@ -11,7 +11,6 @@ from .element import Element
 
 
 class Marker(Element):
-    supported_tracking_methods = ["linear"]
     _chx_kind = _ops.KIND["identity"]
 
     def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
@@ -28,10 +27,15 @@ class Marker(Element):
 class BPM(Marker):
     """Beam position monitor: reads (mu_x, mu_y) of the passing beam when active (bpm.py:77-87)."""
 
-    def __init__(self, is_active=False, name=None, sanitize_name=None, metadata=None, device=None, dtype=None):
-        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, device=device, dtype=dtype)
+    def __init__(self, is_active=False, name=None, misalignment=None, sanitize_name=None, metadata=None, device=None,
+                 dtype=None):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
         self.is_active = is_active
-        self.reading = None
+        self.register_buffer_or_parameter("misalignment",
+                                          misalignment if misalignment is not None else torch.zeros(2, **fk))
+        # (x, y) of the last tracked beam relative to the monitor; NaN until a beam has been read (bpm.py:57-61)
+        self.register_buffer("reading", torch.tensor((float("nan"), float("nan")), **fk), persistent=False)
 
     @property
     def is_skippable(self) -> bool:
@@ -39,7 +43,9 @@ class BPM(Marker):
 
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         if self.is_active:
-            self.reading = torch.stack([incoming.mu_x, incoming.mu_y], dim=-1)  # one fused chx_moments call
+            # both means come out of one fused chx_moments call (bpm.py:77-85)
+            self.reading = torch.stack([incoming.mu_x - self.misalignment[..., 0],
+                                        incoming.mu_y - self.misalignment[..., 1]], dim=-1)
         return incoming._view()
 
     @property

@@ -20,7 +20,6 @@ from .element import Element
 class Screen(Element):
     """Diagnostic screen."""
 
-    supported_tracking_methods = ["linear"]
     _chx_kind = _ops.KIND["identity"]
 
     def __init__(self, resolution=(1024, 1024), pixel_size=None, binning=1, misalignment=None,
@@ -105,9 +104,10 @@ class Screen(Element):
 
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         if self.is_active:
-            # the unshifted beam is recorded; the misalignment is applied inside the image kernels and
-            # lazily in get_read_beam()
-            self.__dict__["_incoming"] = incoming
+            # a snapshot of the unshifted beam is recorded (screen.py:190: later in-place edits of the incoming or
+            # outgoing beam must not change the reading); the misalignment is applied inside the image kernels
+            # and lazily in get_read_beam()
+            self.__dict__["_incoming"] = incoming.clone()
             self.__dict__["_read_beam"] = None
             self.__dict__["_cached_reading"] = None
         if self.is_active and self.is_blocking:
@@ -123,9 +123,22 @@ class Screen(Element):
     @property
     def reading(self) -> torch.Tensor:
         """Image of shape (…, height, width)."""
-        if self.__dict__.get("_cached_reading") is not None:
-            return self._cached_reading
+        cached = self.__dict__.get("_cached_reading")
+        if cached is not None:
+            if cached.dtype != self.misalignment.dtype or cached.device != self.misalignment.device:
+                # the element was moved with .to() / .double() after the image was made (test_screen.py:137-159)
+                cached = cached.to(device=self.misalignment.device, dtype=self.misalignment.dtype)
+                self.__dict__["_cached_reading"] = cached
+            return cached
         beam = self.__dict__.get("_incoming")
+        if beam is not None:
+            ref = beam.mu if isinstance(beam, ParameterBeam) else beam.particles
+            if ref.dtype != self.misalignment.dtype or ref.device != self.misalignment.device:
+                # the screen was moved with .to() / .double() after tracking: the recorded beam follows it, like the
+                # reference's read beam, which is a sub-module of the screen
+                beam = beam.to(device=self.misalignment.device, dtype=self.misalignment.dtype)
+                self.__dict__["_incoming"] = beam
+                self.__dict__["_read_beam"] = None
         w, h = self.effective_resolution
         if beam is None:
             image = self.misalignment.new_zeros((int(h), int(w)))

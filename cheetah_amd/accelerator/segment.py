@@ -61,7 +61,6 @@ class _Run:
 class Segment(Element):
     """Ordered sequence of elements."""
 
-    supported_tracking_methods = ["linear"]
     _static_skippable = False  # depends on the children
 
     def __init__(self, elements: list[Element], name=None, sanitize_name=None, metadata=None, device=None,

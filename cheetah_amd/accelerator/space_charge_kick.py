@@ -30,7 +30,6 @@ speed_of_light = 299792458.0
 class SpaceChargeKick(Element):
     """Applies the effect of space charge over `effect_length` as an instantaneous momentum kick."""
 
-    supported_tracking_methods = ["linear"]
     #: axis-by-axis pruned FFTs (class-level switch so both variants can be timed, benchmarks/sc_fft_ab.py).
     #: Measured on MI355X: SLOWER than the two full (2g)^3 hipFFT transforms (1.44 vs 1.16 ms per kick at
     #: 128^3, 0.64 vs 0.60 ms at 32^3) — the strided 1-D passes through torch.fft cost more than the pruned
