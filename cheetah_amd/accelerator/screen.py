@@ -107,7 +107,7 @@ class Screen(Element):
             # a snapshot of the unshifted beam is recorded (screen.py:190: later in-place edits of the incoming or
             # outgoing beam must not change the reading); the misalignment is applied inside the image kernels
             # and lazily in get_read_beam()
-            self.__dict__["_incoming"] = incoming.clone()
+            self.__dict__["_incoming"] = incoming._snapshot()
             self.__dict__["_read_beam"] = None
             self.__dict__["_cached_reading"] = None
         if self.is_active and self.is_blocking:

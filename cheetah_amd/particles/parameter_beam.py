@@ -140,6 +140,10 @@ class ParameterBeam(Beam):
         mu = torch.cat([mom[..., 2:8], torch.ones_like(mom[..., :1])], dim=-1)
         return cls(mu.to(dtype), cov.to(dtype), energy, total_charge=total_charge, s=s, species=species)
 
+    def _snapshot(self) -> "ParameterBeam":
+        return self.__class__(self.mu.clone(), self.cov.clone(), self.energy.clone(), total_charge=self.total_charge.clone(),
+                              s=self.s.clone(), species=self.species)
+
     def _view(self) -> "ParameterBeam":
         return self.__class__(self.mu, self.cov, self.energy, total_charge=self.total_charge, s=self.s,
                               species=self.species)

@@ -382,6 +382,14 @@ class ParticleBeam(Beam):
                               survival_probabilities=self.survival_probabilities.clone(), s=self.s.clone(),
                               species=self.species.clone())
 
+    def _snapshot(self) -> "ParticleBeam":
+        """Copy of the tensor state (autograd-connected) sharing the species object: what a Screen records, so that
+        later in-place edits of this beam do not reach the reading. Cheaper than `clone()` (no new Species tensors)."""
+        return self.__class__(particles=self.particles.clone(), energy=self.energy.clone(),
+                              particle_charges=self.particle_charges.clone(),
+                              survival_probabilities=self.survival_probabilities.clone(), s=self.s.clone(),
+                              species=self.species)
+
     def _view(self) -> "ParticleBeam":
         """New beam object sharing this beam's tensors (zero-copy). Pass-through elements return this
         instead of the reference's deep `clone()` (marker.py:52-53): beams are treated as immutable
