@@ -19,8 +19,8 @@ beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=1_000_000, total_charg
 for g in (32, 64, 128):
     sc = ca.SpaceChargeKick(t(0.2), grid_shape=(g, g, g), dtype=dt, device="cuda")
     outs = {}
-    for pruned in ("hipfft", False, True):
-        ca.SpaceChargeKick.fft_backend = "hipfft" if pruned == "hipfft" else "torch"
+    for pruned in ("pruned", "hipfft", False, True):
+        ca.SpaceChargeKick.fft_backend = pruned if isinstance(pruned, str) else "torch"
         ca.SpaceChargeKick.pruned_fft = pruned is True
         for _ in range(3):
             o = sc.track(beam)
@@ -30,9 +30,10 @@ for g in (32, 64, 128):
             o = sc.track(beam)
         torch.cuda.synchronize()
         outs[pruned] = o.particles
-        label = {"hipfft": "libchx hipFFT in-place + side stream", False: "torch.fft full", True: "torch.fft pruned"}[pruned]
+        label = {"pruned": "libchx pruned line FFTs + side stream", "hipfft": "libchx hipFFT in-place + side stream",
+                 False: "torch.fft full", True: "torch.fft pruned"}[pruned]
         print(f"g={g:4d} {label:38s} {(time.perf_counter() - t0) / 10 * 1e3:8.3f} ms")
     kick = (outs[False] - beam.particles).abs().amax(dim=0)
-    for other in (True, "hipfft"):
+    for other in (True, "hipfft", "pruned"):
         diff = (outs[other] - outs[False]).abs().amax(dim=0)
         print(f"   max |{other} - torch full| / kick amplitude:", [f"{float(d / k):.1e}" for d, k in zip(diff[[1, 3, 5]], kick[[1, 3, 5]])])

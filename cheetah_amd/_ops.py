@@ -815,6 +815,42 @@ def sc_igf(cell, gamma, bins, padded: bool = False) -> torch.Tensor:
     return G
 
 
+def sc_pruned_supported(bins, dtype) -> bool:
+    return bool(_lib.lib().chx_sc_pruned_supported(_bins3(bins), dtype_code(dtype)))
+
+
+def sc_green_spectrum(cell, gamma, bins) -> torch.Tensor:
+    """Real, even spectrum of the integrated Green function, (B, gx+1, gy+1, gz+1) (chx_sc_igf_table +
+    chx_sc_green_spectrum)."""
+    B = cell.shape[0]
+    lib = _lib.lib()
+    b3 = _bins3(bins)
+    dt = dtype_code(cell.dtype)
+    n1 = (bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1)
+    table = torch.empty((B, n1), dtype=torch.float64, device=cell.device)
+    check(lib.chx_sc_igf_table(ptr(cell), ptr(gamma), B, b3, dt, ptr(table), stream_ptr()), "chx_sc_igf_table")
+    ws_bytes = lib.chx_sc_green_workspace_bytes(B, b3, dt)
+    ws = workspace(ws_bytes, cell.device)
+    Ghat = torch.empty((B, bins[0] + 1, bins[1] + 1, bins[2] + 1), dtype=cell.dtype, device=cell.device)
+    check(lib.chx_sc_green_spectrum(ptr(table), B, b3, dt, ptr(Ghat), ptr(ws), ws_bytes, stream_ptr()),
+          "chx_sc_green_spectrum")
+    return Ghat
+
+
+def sc_convolve(rho, Ghat, scale, bins) -> torch.Tensor:
+    """phi (B,gx,gy,gz) from the compact charge grid rho (B,gx,gy,gz) (chx_sc_convolve)."""
+    B = rho.shape[0]
+    lib = _lib.lib()
+    b3 = _bins3(bins)
+    dt = dtype_code(rho.dtype)
+    ws_bytes = lib.chx_sc_convolve_workspace_bytes(B, b3, dt)
+    ws = workspace(ws_bytes, rho.device)
+    phi = torch.empty_like(rho)
+    check(lib.chx_sc_convolve(ptr(rho), ptr(Ghat), ptr(scale), B, b3, dt, ptr(phi), ptr(ws), ws_bytes, stream_ptr()),
+          "chx_sc_convolve")
+    return phi
+
+
 class ScFftPlan:
     """hipFFT plans of the Hockney convolution for one (B, grid, dtype) (chx_sc_fft_plan_*): in-place, unnormalised
     real <-> complex 3-D transforms on the padded layout (B,2gx,2gy,2gz+2)."""

@@ -1,0 +1,331 @@
+// chx_fft.hip — Poisson solve of SpaceChargeKick by pruned, symmetry-aware FFTs for gfx950
+// (space_charge_kick.py:293-322: phi = irfftn(rfftn(rho_padded) * rfftn(G)) cropped to the first octant).
+//
+// The reference (and chx_sc_fft_exec) transforms three dense (2g)^3 arrays. Here the structure of the Hockney
+// convolution is used instead, with one batched line-FFT kernel that stages tiles of lines through LDS:
+//   * rho is non-zero only in [0,g)^3 of the doubled array: the forward transform runs z lines on the g x g
+//     non-zero columns, then y lines on g x (g+1), then x lines on 2g x (g+1); the upper half of every input line
+//     is an implicit zero (never read). 177 MB of traffic per transform at g = 128 instead of ~400 MB.
+//   * only phi in [0,g)^3 is needed: the inverse runs the same three passes backwards and never writes the rest.
+//   * the integrated Green function is real and even in every axis, so its spectrum is real and even:
+//     it is computed from the compact (g+1)^3 table by three passes of even-extension transforms and stored as
+//     (g+1)^3 reals (8.6 MB instead of a 67 MB complex array); the spectral multiply looks it up by |k|.
+// Line lengths n = 2g must be powers of two (64 ... 1024); other grids use the hipFFT path (chx_sc_fft_exec).
+#include "chx_common.h"
+
+namespace {
+
+constexpr int kTL = 16;        // lines per tile
+constexpr int kPad = kTL + 1;  // LDS row pitch (complex elements): breaks the power-of-two bank pattern
+
+enum LoadMode { LOAD_COMPLEX = 0, LOAD_REAL = 1, LOAD_HERMITIAN = 2, LOAD_EVEN_REAL = 3 };
+enum StoreMode { STORE_COMPLEX = 0, STORE_REAL = 1 };
+
+struct LineLayout {
+    int64_t point_stride;   // elements between consecutive points of a line
+    int64_t inner_stride;   // elements between consecutive lines of the inner index
+    int64_t outer_stride;   // elements between consecutive outer indices
+    int64_t batch_stride;   // elements between batch rows
+};
+
+template <typename T> struct cplx { T re, im; };
+
+template <typename T>
+__device__ __forceinline__ void sincos_2pi(int k, int n, T& s, T& c);
+template <>
+__device__ __forceinline__ void sincos_2pi<float>(int k, int n, float& s, float& c) {
+    sincospif(2.0f * (float)k / (float)n, &s, &c);
+}
+template <>
+__device__ __forceinline__ void sincos_2pi<double>(int k, int n, double& s, double& c) {
+    sincospi(2.0 * (double)k / (double)n, &s, &c);
+}
+
+// One workgroup transforms kTL lines of length n (power of two) that are adjacent in the line index.
+//   lines: l = outer * inner_count + inner, l in [0, L)
+//   n_valid: leading input points that exist (the rest are zeros that are not read)
+//   n_keep:  leading output points that are written
+//   POINT_FAST: consecutive lanes walk along a line (point_stride == 1 passes), else across lines
+template <typename T, int LOADM, int STOREM, bool POINT_FAST>
+__global__ __launch_bounds__(CHX_BLOCK) void fft_lines_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int log2n,
+                                                             int n_valid, int n_keep, int64_t L, int64_t inner_count,
+                                                             LineLayout li, LineLayout lo, int inverse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem_raw);          // [n][kPad]
+    cplx<T>* tw = buf + (size_t)n * kPad;                         // [n/2] twiddles exp(-+2 pi i k / n)
+
+    const int tid = threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.x * kTL;
+    const int nl = (int)((L - l0 < kTL) ? (L - l0) : kTL);
+    const int64_t b = blockIdx.y;
+    // strides are in elements of the array's own type (real or complex): complex arrays are addressed as T pairs
+    const T* inb = in + b * li.batch_stride * ((LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN) ? 2 : 1);
+    T* outb = out + b * lo.batch_stride * ((STOREM == STORE_COMPLEX) ? 2 : 1);
+
+    __shared__ int64_t in_base[kTL], out_base[kTL];
+    if (tid < kTL) {
+        const int64_t l = l0 + (tid < nl ? tid : 0);
+        const int64_t outer = l / inner_count, inner = l - outer * inner_count;
+        in_base[tid] = outer * li.outer_stride + inner * li.inner_stride;
+        out_base[tid] = outer * lo.outer_stride + inner * lo.inner_stride;
+    }
+    for (int k = tid; k < n / 2; k += CHX_BLOCK) {
+        T s, c;
+        sincos_2pi<T>(k, n, s, c);
+        tw[k].re = c;
+        tw[k].im = inverse ? s : -s;
+    }
+    __syncthreads();
+    // ---- load (bit-reversed point index) --------------------------------------------------------------------
+    const int total = n * kTL;
+    for (int e = tid; e < total; e += CHX_BLOCK) {
+        int line, p;
+        if (POINT_FAST) { p = e & (n - 1); line = e >> log2n; } else { line = e & (kTL - 1); p = e / kTL; }
+        cplx<T> v;
+        v.re = (T)0;
+        v.im = (T)0;
+        if (line < nl) {
+            const int64_t base = in_base[line];
+            if (LOADM == LOAD_COMPLEX) {
+                if (p < n_valid) {
+                    const T* q = inb + 2 * (base + (int64_t)p * li.point_stride);
+                    v.re = q[0];
+                    v.im = q[1];
+                }
+            } else if (LOADM == LOAD_REAL) {
+                if (p < n_valid) v.re = inb[base + (int64_t)p * li.point_stride];
+            } else if (LOADM == LOAD_HERMITIAN) {  // half spectrum 0..n/2 given: X[n-k] = conj X[k]
+                const int ps = (p <= n / 2) ? p : n - p;
+                const T* q = inb + 2 * (base + (int64_t)ps * li.point_stride);
+                v.re = q[0];
+                v.im = (p <= n / 2) ? q[1] : -q[1];
+            } else {  // LOAD_EVEN_REAL: x[n-p] = x[p], values 0..n/2 given
+                const int ps = (p <= n / 2) ? p : n - p;
+                v.re = inb[base + (int64_t)ps * li.point_stride];
+            }
+        }
+        const int pr = (int)(__brev((unsigned)p) >> (32 - log2n));
+        buf[pr * kPad + line] = v;
+    }
+    __syncthreads();
+    // ---- radix-2 decimation-in-time stages, in place ----------------------------------------------------------
+    const int half_total = (n / 2) * kTL;
+    for (int s = 0; s < log2n; ++s) {
+        const int half = 1 << s;
+        for (int e = tid; e < half_total; e += CHX_BLOCK) {
+            const int line = e & (kTL - 1), bf = e / kTL;  // butterfly index 0 .. n/2-1
+            const int j = bf & (half - 1);
+            const int i0 = ((bf >> s) << (s + 1)) + j;
+            const int i1 = i0 + half;
+            const cplx<T> w = tw[j << (log2n - 1 - s)];
+            const cplx<T> a = buf[i0 * kPad + line];
+            const cplx<T> c = buf[i1 * kPad + line];
+            cplx<T> t;
+            t.re = c.re * w.re - c.im * w.im;
+            t.im = c.re * w.im + c.im * w.re;
+            cplx<T> u, d;
+            u.re = a.re + t.re; u.im = a.im + t.im;
+            d.re = a.re - t.re; d.im = a.im - t.im;
+            buf[i0 * kPad + line] = u;
+            buf[i1 * kPad + line] = d;
+        }
+        __syncthreads();
+    }
+    // ---- store ------------------------------------------------------------------------------------------------
+    const int total_out = n_keep * kTL;
+    for (int e = tid; e < total_out; e += CHX_BLOCK) {
+        int line, p;
+        if (POINT_FAST) { p = e % n_keep; line = e / n_keep; } else { line = e % kTL; p = e / kTL; }
+        if (line >= nl) continue;
+        const int64_t base = out_base[line];
+        const cplx<T> v = buf[p * kPad + line];
+        if (STOREM == STORE_COMPLEX) {
+            T* q = outb + 2 * (base + (int64_t)p * lo.point_stride);
+            q[0] = v.re;
+            q[1] = v.im;
+        } else {
+            outb[base + (int64_t)p * lo.point_stride] = v.re;
+        }
+    }
+}
+
+template <typename T, int LOADM, int STOREM, bool POINT_FAST>
+int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
+                 LineLayout lo, int inverse, int64_t B, hipStream_t s) {
+    int log2n = 0;
+    while ((1 << log2n) < n) ++log2n;
+    const size_t shmem = ((size_t)n * kPad + n / 2) * sizeof(cplx<T>);
+    auto kern = fft_lines_kernel<T, LOADM, STOREM, POINT_FAST>;
+    if (shmem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
+            hipSuccess)
+            return CHX_ERR_LAUNCH;
+    }
+    dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n, log2n, n_valid, n_keep, L, inner_count,
+                       li, lo, inverse);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+// Compact Green function Gc[b][i][j][k], i, j, k in [0, g]: the signed 8-term difference of the primitive table
+// (chx_spacecharge.hip igf_fill_kernel) for indices < g and 0 on the index-g planes (space_charge_kick.py:249-289).
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void igf_compact_kernel(const double* __restrict__ table, int gx, int gy, int gz,
+                                                               T* __restrict__ Gc) {
+    const int64_t b = blockIdx.y;
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    const double* tb = table + b * npts;
+    const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
+    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < npts; idx += (int64_t)gridDim.x * CHX_BLOCK) {
+        const int k = (int)(idx % (gz + 1));
+        const int j = (int)((idx / (gz + 1)) % (gy + 1));
+        const int i = (int)(idx / sx);
+        double g = 0.0;
+        if (i < gx && j < gy && k < gz) {
+            const double* p = tb + i * sx + j * sy + k;
+            g = p[sx + sy + 1] - p[sy + 1] - p[sx + 1] - p[sx + sy] + p[sx] + p[sy] + p[1] - p[0];
+        }
+        Gc[b * npts + idx] = (T)g;
+    }
+}
+
+// rho_hat[b][kx][ky][kz] *= Ghat[b][min(kx, nx-kx)][min(ky, ny-ky)][kz] * scale[b]
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void spectral_mul_sym_kernel(T* __restrict__ a, const T* __restrict__ gh,
+                                                                    const double* __restrict__ scale, int nx, int ny, int nzc) {
+    const int64_t b = blockIdx.y;
+    const int64_t ntot = (int64_t)nx * ny * nzc;
+    const T sc = (T)scale[b];
+    T* ab = a + b * ntot * 2;
+    const int gx1 = nx / 2 + 1, gy1 = ny / 2 + 1;
+    const T* gb = gh + b * (int64_t)gx1 * gy1 * nzc;
+    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ntot; idx += (int64_t)gridDim.x * CHX_BLOCK) {
+        const int kz = (int)(idx % nzc);
+        const int ky = (int)((idx / nzc) % ny);
+        const int kx = (int)(idx / ((int64_t)nzc * ny));
+        const int sxk = (kx <= nx / 2) ? kx : nx - kx, syk = (ky <= ny / 2) ? ky : ny - ky;
+        const T g = gb[((int64_t)sxk * gy1 + syk) * nzc + kz] * sc;
+        ab[2 * idx] *= g;
+        ab[2 * idx + 1] *= g;
+    }
+}
+
+// the tile [2g][17] complex + twiddles must fit the 160 KB of LDS of a CU: 2g <= 1024 (fp32) / 512 (fp64)
+bool pow2_ok(int g, int dtype) { return g >= 16 && g <= (dtype == CHX_F32 ? 512 : 256) && (g & (g - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int chx_sc_pruned_supported(const int32_t* bins, int dtype) {
+    return (dtype == CHX_F32 || dtype == CHX_F64) && bins && pow2_ok(bins[0], dtype) && pow2_ok(bins[1], dtype) &&
+           pow2_ok(bins[2], dtype);
+}
+
+// workspace layout of chx_sc_green_spectrum: [Gc (g+1)^3 T][H (g+1)^3 T] per batch row
+extern "C" size_t chx_sc_green_workspace_bytes(int64_t B, const int32_t* bins, int dtype) {
+    if (B < 1 || !chx_sc_pruned_supported(bins, dtype)) return 0;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    return (size_t)B * 2 * (size_t)(bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1) * esz;
+}
+
+template <typename T>
+static int green_spectrum_impl(const double* table, int64_t B, const int32_t* bins, T* Ghat, T* ws, hipStream_t s) {
+    const int gx = bins[0], gy = bins[1], gz = bins[2];
+    const int64_t n1 = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    T* Gc = ws;
+    T* H = ws + B * n1;
+    int grid = chx_grid_for(n1, CHX_BLOCK, 4096);
+    hipLaunchKernelGGL(igf_compact_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, gx, gy, gz, Gc);
+    CHX_CHECK_LAUNCH();
+    const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
+    // z: lines (x, y), points contiguous; even extension in, real out (kz <= gz)           Gc -> H
+    LineLayout lz{1, sy, sx, n1};
+    int st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, true>(Gc, H, 2 * gz, gz + 1, gz + 1, (int64_t)(gx + 1) * (gy + 1), gy + 1,
+                                                               lz, lz, 0, B, s);
+    if (st != CHX_OK) return st;
+    // y: lines (x, kz), point stride sy                                                    H -> Gc
+    LineLayout ly{sy, 1, sx, n1};
+    st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false>(H, Gc, 2 * gy, gy + 1, gy + 1, (int64_t)(gx + 1) * (gz + 1), gz + 1, ly,
+                                                            ly, 0, B, s);
+    if (st != CHX_OK) return st;
+    // x: lines (ky, kz) = one contiguous index, point stride sx                            Gc -> Ghat
+    LineLayout lx{sx, 1, 0, n1};
+    return launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false>(Gc, Ghat, 2 * gx, gx + 1, gx + 1, sx, sx, lx, lx, 0, B, s);
+}
+
+// Real, even spectrum of the integrated Green function on the doubled grid, stored on (gx+1)(gy+1)(gz+1) points.
+// `table` is the corner table written by chx_sc_igf_table (double [B][(gx+1)(gy+1)(gz+1)]).
+extern "C" int chx_sc_green_spectrum(const double* table, int64_t B, const int32_t* bins, int dtype, void* Ghat,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!table || !Ghat || B < 1 || B > 65535 || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!workspace || workspace_bytes < chx_sc_green_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == CHX_F32 ? green_spectrum_impl<float>(table, B, bins, (float*)Ghat, (float*)workspace, s)
+                            : green_spectrum_impl<double>(table, B, bins, (double*)Ghat, (double*)workspace, s);
+}
+
+// workspace of chx_sc_convolve per batch row: A [gx][gy][gz+1], Bf [gx][2gy][gz+1], C [2gx][2gy][gz+1] complex
+extern "C" size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins, int dtype) {
+    if (B < 1 || !chx_sc_pruned_supported(bins, dtype)) return 0;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    const size_t gx = bins[0], gy = bins[1], nzc = bins[2] + 1;
+    return (size_t)B * 2 * esz * (gx * gy * nzc + gx * 2 * gy * nzc + 2 * gx * 2 * gy * nzc);
+}
+
+template <typename T>
+static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64_t B, const int32_t* bins, T* phi, T* ws,
+                         hipStream_t s) {
+    const int gx = bins[0], gy = bins[1], gz = bins[2];
+    const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nzc = gz + 1;
+    const int64_t nA = (int64_t)gx * gy * nzc, nB = (int64_t)gx * ny * nzc, nC = (int64_t)nx * ny * nzc;  // complex elements
+    T* A = ws;
+    T* Bf = A + 2 * B * nA;
+    T* C = Bf + 2 * B * nB;
+    const int64_t g3 = (int64_t)gx * gy * gz;
+    // forward z: rho[x][y][z<gz] real -> A[x][y][kz<=gz]
+    LineLayout rz{1, gz, (int64_t)gy * gz, g3};
+    LineLayout az{1, nzc, (int64_t)gy * nzc, nA};
+    int st = launch_lines<T, LOAD_REAL, STORE_COMPLEX, true>(rho, A, nz, gz, nzc, (int64_t)gx * gy, gy, rz, az, 0, B, s);
+    if (st != CHX_OK) return st;
+    // forward y: A lines (x, kz), y < gy valid -> Bf[x][ky < ny][kz]
+    LineLayout ay{nzc, 1, (int64_t)gy * nzc, nA};
+    LineLayout by{nzc, 1, (int64_t)ny * nzc, nB};
+    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(A, Bf, ny, gy, ny, (int64_t)gx * nzc, nzc, ay, by, 0, B, s);
+    if (st != CHX_OK) return st;
+    // forward x: Bf lines (ky, kz), x < gx valid -> C[kx < nx][ky][kz]
+    const int64_t plane = (int64_t)ny * nzc;
+    LineLayout bx{plane, 1, 0, nB};
+    LineLayout cx{plane, 1, 0, nC};
+    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, C, nx, gx, nx, plane, plane, bx, cx, 0, B, s);
+    if (st != CHX_OK) return st;
+    // spectral multiply with the real, even Green spectrum
+    {
+        int grid = chx_grid_for(nC, CHX_BLOCK * 4, 8192);
+        hipLaunchKernelGGL(spectral_mul_sym_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, C, Ghat, scale, nx,
+                           ny, nzc);
+        CHX_CHECK_LAUNCH();
+    }
+    // inverse x: C -> Bf[x < gx][ky][kz]
+    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(C, Bf, nx, nx, gx, plane, plane, cx, bx, 1, B, s);
+    if (st != CHX_OK) return st;
+    // inverse y: Bf -> A[x][y < gy][kz]
+    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, A, ny, ny, gy, (int64_t)gx * nzc, nzc, by, ay, 1, B, s);
+    if (st != CHX_OK) return st;
+    // inverse z: A half spectra -> phi[x][y][z < gz] real
+    return launch_lines<T, LOAD_HERMITIAN, STORE_REAL, true>(A, phi, nz, nzc, gz, (int64_t)gx * gy, gy, az, rz, 1, B, s);
+}
+
+// phi[B][gx][gy][gz] = crop( ifft( fft(pad(rho)) * Ghat * scale ) ), unnormalised transforms (fold 1/(8 gx gy gz) into
+// scale). rho[B][gx][gy][gz] compact (not padded), Ghat from chx_sc_green_spectrum.
+extern "C" int chx_sc_convolve(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,
+                               int dtype, void* phi, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!rho || !Ghat || !scale || !phi || B < 1 || B > 65535 || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!workspace || workspace_bytes < chx_sc_convolve_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == CHX_F32 ? convolve_impl<float>((const float*)rho, (const float*)Ghat, scale, B, bins, (float*)phi,
+                                                   (float*)workspace, s)
+                            : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi,
+                                                    (double*)workspace, s);
+}

@@ -381,6 +381,25 @@ extern "C" int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const 
     return CHX_OK;
 }
 
+// Only the corner table of the primitive (the input of chx_sc_green_spectrum, chx_fft.hip).
+extern "C" int chx_sc_igf_table(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
+                                double* table, void* stream) {
+    if (!cell || !gamma || !table || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = bins[0], gy = bins[1], gz = bins[2];
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(igf_table_kernel<float>, cell_grid(npts, B), dim3(CHX_BLOCK), 0, s, (const float*)cell,
+                           (const float*)gamma, gx, gy, gz, table);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(igf_table_kernel<double>, cell_grid(npts, B), dim3(CHX_BLOCK), 0, s, (const double*)cell,
+                           (const double*)gamma, gx, gy, gz, table);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 extern "C" int chx_sc_spectral_mul(void* rho_hat, const void* G_hat, const double* scale, int64_t B,
                                    int64_t n_complex, int dtype, void* stream) {
     if (!rho_hat || !G_hat || !scale || B < 1 || B > 65535 || n_complex < 1) return CHX_ERR_INVALID_ARG;

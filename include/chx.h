@@ -243,6 +243,22 @@ int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bi
 int chx_sc_fft_plan_create(int64_t B, const int32_t* bins, int dtype, void** plan_out);
 int chx_sc_fft_plan_destroy(void* plan);
 int chx_sc_fft_exec(void* plan, int direction, void* data, void* stream);
+/* Pruned, symmetry-aware Poisson solve (csrc/chx_fft.hip) for power-of-two grids (chx_sc_pruned_supported):
+ *  - chx_sc_igf_table: the (gx+1)(gy+1)(gz+1) corner table of the Green-function primitive (double);
+ *  - chx_sc_green_spectrum: real, even spectrum of the integrated Green function on the doubled grid, stored on
+ *    (gx+1)(gy+1)(gz+1) points (the spectrum at index k and 2g-k is the same number);
+ *  - chx_sc_convolve: phi[B][gx][gy][gz] = crop(ifft(fft(pad(rho)) * Ghat * scale[b])) from the COMPACT rho[B][gx][gy][gz]:
+ *    the zero padding is implicit (the zero halves of the lines are never read) and only the first octant of the
+ *    result is ever written; transforms unnormalised (fold 1/(8 gx gy gz) into scale). */
+int chx_sc_pruned_supported(const int32_t* bins, int dtype);
+int chx_sc_igf_table(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype, double* table,
+                     void* stream);
+size_t chx_sc_green_workspace_bytes(int64_t B, const int32_t* bins, int dtype);
+int chx_sc_green_spectrum(const double* table, int64_t B, const int32_t* bins, int dtype, void* Ghat, void* workspace,
+                          size_t workspace_bytes, void* stream);
+size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins, int dtype);
+int chx_sc_convolve(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
+                    void* phi, void* workspace, size_t workspace_bytes, void* stream);
 /* Grid geometry of a kick from the beam moments (space_charge_kick.py:531-550,110-130), one launch instead of ~25
  * tensor ops: moments[Bm][29] (chx_moments layout), grid_extent[Bext][3] (in sigmas), energy[Be], length[Bl] ->
  * half[B][3] = extent*sigma, cell[B][3] = 2 half / bins, gamma[B], dt[B] = L/(c beta), scale[B][3] = (1, 1, -beta),
