@@ -149,9 +149,174 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_kernel(const T* __restric
     }
 }
 
+// ---- register-resident variant for n = 16 * M, M in {2, 4, 8, 16} ------------------------------------------------
+// Cooley-Tukey split n = 16 x M: a thread runs a whole 16-point FFT in registers on the points (c + M j1), multiplies
+// by W_n^(c k1), and after one exchange through LDS a thread runs the M-point FFT over c for its k1 and stores
+// X[k1 + 16 k2]. 256 threads = 16 lines x 16 columns: one barrier instead of log2(n), ~3x fewer instructions than the
+// LDS radix-2 kernel above (which stays for n = 512, 1024).
+template <typename T, int R>
+__device__ __forceinline__ void fft_reg(cplx<T> (&x)[R], int inverse) {
+    // bit-reversal permutation (compile-time indices after unrolling)
+    constexpr int LOG = (R == 2) ? 1 : (R == 4) ? 2 : (R == 8) ? 3 : 4;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        int r = 0;
+#pragma unroll
+        for (int b = 0; b < LOG; ++b) r |= ((i >> b) & 1) << (LOG - 1 - b);
+        if (r > i) { const cplx<T> t = x[i]; x[i] = x[r]; x[r] = t; }
+    }
+    // cos / sin of 2 pi k / 16, k = 0..7
+    constexpr double C16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                               0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
+    constexpr double S16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+                               1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
+#pragma unroll
+    for (int s = 0; s < LOG; ++s) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int bf = 0; bf < R / 2; ++bf) {
+            const int j = bf & (half - 1);
+            const int i0 = ((bf >> s) << (s + 1)) + j, i1 = i0 + half;
+            const int tk = (j * (R / 2 / half)) * (16 / R);  // index into the 16-point table
+            const T wr = (T)C16[tk];
+            const T wi = inverse ? (T)S16[tk] : (T)(-S16[tk]);
+            cplx<T> t;
+            t.re = x[i1].re * wr - x[i1].im * wi;
+            t.im = x[i1].re * wi + x[i1].im * wr;
+            const cplx<T> a = x[i0];
+            x[i0].re = a.re + t.re; x[i0].im = a.im + t.im;
+            x[i1].re = a.re - t.re; x[i1].im = a.im - t.im;
+        }
+    }
+}
+
+template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M>
+__global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __restrict__ in, T* __restrict__ out, int n_valid,
+                                                                 int n_keep, int64_t L, int64_t inner_count, LineLayout li,
+                                                                 LineLayout lo, int inverse) {
+    constexpr int n = 16 * M;
+    constexpr int LP = kTL + 1;                 // line pitch
+    constexpr int KP = M * LP + 1;              // pitch between k1 slabs (odd: spreads the banks)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx<T>* xch = reinterpret_cast<cplx<T>*>(smem_raw);  // [k1][c][line], 16 * KP elements
+    cplx<T>* tw = xch + 16 * KP;                           // exp(-+2 pi i k / n), n elements
+    __shared__ int64_t in_base[kTL], out_base[kTL];
+
+    const int tid = threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.x * kTL;
+    const int nl = (int)((L - l0 < kTL) ? (L - l0) : kTL);
+    const int64_t b = blockIdx.y;
+    const T* inb = in + b * li.batch_stride * ((LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN) ? 2 : 1);
+    T* outb = out + b * lo.batch_stride * ((STOREM == STORE_COMPLEX) ? 2 : 1);
+    if (tid < kTL) {
+        const int64_t l = l0 + (tid < nl ? tid : 0);
+        const int64_t outer = l / inner_count, inner = l - outer * inner_count;
+        in_base[tid] = outer * li.outer_stride + inner * li.inner_stride;
+        out_base[tid] = outer * lo.outer_stride + inner * lo.inner_stride;
+    }
+    for (int k = tid; k < n; k += CHX_BLOCK) {
+        T s, c;
+        sincos_2pi<T>(k, n, s, c);
+        tw[k].re = c;
+        tw[k].im = inverse ? s : -s;
+    }
+    __syncthreads();
+    const int line = POINT_FAST ? (tid >> 4) : (tid & 15);
+    const int c = POINT_FAST ? (tid & 15) : (tid >> 4);
+    // ---- pass 1: 16-point FFTs over j1 for column c (< M), then the twiddle W_n^(c k1) --------------------------
+    if (c < M) {
+        cplx<T> x[16];
+        const bool live = line < nl;
+        const int64_t base = in_base[line];
+#pragma unroll
+        for (int j1 = 0; j1 < 16; ++j1) {
+            const int p = c + M * j1;
+            x[j1].re = (T)0;
+            x[j1].im = (T)0;
+            if (live) {
+                if (LOADM == LOAD_COMPLEX) {
+                    if (p < n_valid) {
+                        const T* q = inb + 2 * (base + (int64_t)p * li.point_stride);
+                        x[j1].re = q[0];
+                        x[j1].im = q[1];
+                    }
+                } else if (LOADM == LOAD_REAL) {
+                    if (p < n_valid) x[j1].re = inb[base + (int64_t)p * li.point_stride];
+                } else if (LOADM == LOAD_HERMITIAN) {
+                    const int ps = (p <= n / 2) ? p : n - p;
+                    const T* q = inb + 2 * (base + (int64_t)ps * li.point_stride);
+                    x[j1].re = q[0];
+                    x[j1].im = (p <= n / 2) ? q[1] : -q[1];
+                } else {
+                    const int ps = (p <= n / 2) ? p : n - p;
+                    x[j1].re = inb[base + (int64_t)ps * li.point_stride];
+                }
+            }
+        }
+        fft_reg<T, 16>(x, inverse);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const cplx<T> w = tw[(c * k1) & (n - 1)];
+            cplx<T> y;
+            y.re = x[k1].re * w.re - x[k1].im * w.im;
+            y.im = x[k1].re * w.im + x[k1].im * w.re;
+            xch[k1 * KP + c * LP + line] = y;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: M-point FFT over c for k1 = c (16 of them), output index k1 + 16 k2 ----------------------------
+    {
+        const int k1 = c;
+        cplx<T> y[M];
+#pragma unroll
+        for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * KP + j2 * LP + line];
+        fft_reg<T, M>(y, inverse);
+        if (line < nl) {
+            const int64_t base = out_base[line];
+#pragma unroll
+            for (int k2 = 0; k2 < M; ++k2) {
+                const int p = k1 + 16 * k2;
+                if (p < n_keep) {
+                    if (STOREM == STORE_COMPLEX) {
+                        T* q = outb + 2 * (base + (int64_t)p * lo.point_stride);
+                        q[0] = y[k2].re;
+                        q[1] = y[k2].im;
+                    } else {
+                        outb[base + (int64_t)p * lo.point_stride] = y[k2].re;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M>
+int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
+                     LineLayout lo, int inverse, int64_t B, hipStream_t s) {
+    dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
+    constexpr size_t shmem = ((size_t)16 * (M * (kTL + 1) + 1) + 16 * M) * sizeof(cplx<T>);
+    auto kern = fft_lines_reg_kernel<T, LOADM, STOREM, POINT_FAST, M>;
+    if (shmem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
+            hipSuccess)
+            return CHX_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n_valid, n_keep, L, inner_count, li, lo,
+                       inverse);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 template <typename T, int LOADM, int STOREM, bool POINT_FAST>
 int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
                  LineLayout lo, int inverse, int64_t B, hipStream_t s) {
+    switch (n) {
+        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
+        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
+        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
+        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
+        default: break;
+    }
     int log2n = 0;
     while ((1 << log2n) < n) ++log2n;
     const size_t shmem = ((size_t)n * kPad + n / 2) * sizeof(cplx<T>);

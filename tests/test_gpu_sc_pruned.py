@@ -25,11 +25,12 @@ def _dense(rho, cell, gamma, scale, g):
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-@pytest.mark.parametrize("g", [(32, 32, 32), (16, 32, 64), (64, 64, 64)])
+@pytest.mark.parametrize("g", [(32, 32, 32), (16, 32, 64), (64, 64, 64), (128, 128, 128), (256, 16, 32)])
 def test_pruned_convolution_matches_dense_fft(tag, g):
     from cheetah_amd import _ops
 
     dt = torch.float32 if tag == "f32" else torch.float64
+    # line lengths 32 ... 256 run the register-resident kernel, 512 the LDS radix-2 kernel
     assert _ops.sc_pruned_supported(g, dt)
     B = 2
     torch.manual_seed(0)
