@@ -394,12 +394,60 @@ def stack_params(values, dtype, device) -> tuple[torch.Tensor, torch.Size]:
     return torch.stack([v.to(dtype).expand(shape) for v in values], dim=-1).reshape(-1, len(values)), shape
 
 
+def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N):
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    e_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_dkd_track(kind, ptr(x), ptr(p), ptr(e), mass_eV, n_charges, num_steps, fringe_at, B, x.shape[0],
+                                   p.shape[0], e.shape[0], N, dtype_code(x.dtype), ptr(out), ptr(e_out), stream_ptr()),
+          "chx_dkd_track")
+    return out, e_out
+
+
+class DkdTrack(torch.autograd.Function):
+    """(x_out, ref_energy) = chx_dkd_track(x, params, energy); backward = chx_dkd_track_bwd (dual numbers on device)."""
+
+    @staticmethod
+    def forward(ctx, x, p, e, kind, mass_eV, n_charges, num_steps, fringe_at, B, N):
+        ctx.save_for_backward(x, p, e)
+        ctx.meta = (kind, mass_eV, n_charges, num_steps, fringe_at, B, N)
+        return _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N)
+
+    @staticmethod
+    def backward(ctx, dY, dE):
+        x, p, e = ctx.saved_tensors
+        kind, mass_eV, n_charges, num_steps, fringe_at, B, N = ctx.meta
+        P = DKD_NUM_PARAMS[kind]
+        need_x = ctx.needs_input_grad[0]
+        need_theta = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dY = aligned(dY.contiguous())
+        dx = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_x else None
+        partials = None
+        if need_theta:
+            count = _lib.lib().chx_dkd_bwd_partials_count(kind, B, N)
+            partials = torch.empty((count,), dtype=torch.float64, device=x.device)
+        if need_x or need_theta:
+            check(_lib.lib().chx_dkd_track_bwd(kind, ptr(x), ptr(p), ptr(e), ptr(dY), mass_eV, n_charges, num_steps,
+                                               fringe_at, B, x.shape[0], p.shape[0], e.shape[0], N, dtype_code(x.dtype),
+                                               ptr(dx), ptr(partials), stream_ptr()), "chx_dkd_track_bwd")
+        dp = de = None
+        if need_theta:
+            tot = partials.view(B, -1, P + 1).sum(dim=1)  # (B, P + 1) fp64
+            if ctx.needs_input_grad[1]:
+                dp = tot[:, :P]
+                dp = (dp.sum(dim=0, keepdim=True) if p.shape[0] == 1 and B > 1 else dp).to(p.dtype)
+            if ctx.needs_input_grad[2]:
+                de = tot[:, P] + dE.to(torch.float64)  # d ref_energy / d energy = 1 (bmadx.py:49)
+                de = (de.sum(dim=0, keepdim=True) if e.shape[0] == 1 and B > 1 else de).to(e.dtype)
+        if need_x and x.shape[0] == 1 and B > 1:
+            dx = dx.sum(dim=0, keepdim=True)
+        return dx, dp, de, None, None, None, None, None, None, None
+
+
 def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float, n_charges: float, num_steps: int = 1,
               fringe_at: int = 3):
     """One drift-kick-drift element (chx_dkd_track): particles (..., N, 7), params (Bp, P) with vector shape
     `param_shape`, energy (...). Returns (particles_out (*batch, N, 7), ref_energy (*energy/param batch))."""
     require_device(particles, params, energy)
-    forward_only("drift_kick_drift tracking", particles, params, energy)
     N = particles.shape[-2]
     eb_shape = bshapes(param_shape, energy.shape)           # batch shape of the outgoing energy
     batch_shape = bshapes(particles.shape[:-2], eb_shape)
@@ -408,10 +456,10 @@ def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float,
     p, Bp = flat_bcast(params.reshape(*param_shape, params.shape[-1]), batch_shape, 1)
     e, Be = flat_bcast(energy, batch_shape, 0)
     x, p, e = aligned(x), p.contiguous(), e.contiguous()
-    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
-    e_out = torch.empty((B,), dtype=x.dtype, device=x.device)
-    check(_lib.lib().chx_dkd_track(kind, ptr(x), ptr(p), ptr(e), mass_eV, n_charges, num_steps, fringe_at, B, Bx, Bp,
-                                   Be, N, dtype_code(x.dtype), ptr(out), ptr(e_out), stream_ptr()), "chx_dkd_track")
+    if torch.is_grad_enabled() and (x.requires_grad or p.requires_grad or e.requires_grad):
+        out, e_out = DkdTrack.apply(x, p, e, kind, mass_eV, n_charges, num_steps, fringe_at, B, N)
+    else:
+        out, e_out = _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N)
     # the outgoing reference energy has the INCOMING energy's shape (bmadx.py:49: it only depends on p0c)
     if energy.numel() == 1:
         e_out = e_out[:1].reshape(energy.shape)
@@ -419,29 +467,114 @@ def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float,
         e_out = e_out.reshape(batch_shape)
     else:  # energy broadcast against other vector dims: pick one representative per energy entry
         idx = torch.arange(energy.numel(), device=x.device).reshape(energy.shape).expand(batch_shape).reshape(-1)
-        e_out = torch.zeros(energy.numel(), dtype=x.dtype, device=x.device).index_copy_(0, idx, e_out).reshape(energy.shape)
+        e_out = torch.zeros(energy.numel(), dtype=x.dtype, device=x.device).index_copy(0, idx, e_out).reshape(energy.shape)
     return out.reshape(*batch_shape, N, 7), e_out
+
+
+def _build_ttensor_raw(kind, p, e, mass_eV, B):
+    T = torch.empty((B, 7, 7, 7), dtype=e.dtype, device=e.device)
+    check(_lib.lib().chx_build_ttensor(kind, ptr(p), ptr(e), mass_eV, B, p.shape[0], e.shape[0], dtype_code(e.dtype), ptr(T),
+                                       stream_ptr()), "chx_build_ttensor")
+    return T
+
+
+class BuildTTensor(torch.autograd.Function):
+    """T = chx_build_ttensor(params, energy); backward = chx_build_ttensor_vjp (dual numbers on device)."""
+
+    @staticmethod
+    def forward(ctx, p, e, kind, mass_eV, B):
+        ctx.save_for_backward(p, e)
+        ctx.meta = (kind, mass_eV, B)
+        return _build_ttensor_raw(kind, p, e, mass_eV, B)
+
+    @staticmethod
+    def backward(ctx, dT):
+        p, e = ctx.saved_tensors
+        kind, mass_eV, B = ctx.meta
+        P = T_NUM_PARAMS[kind]
+        dT = dT.contiguous()
+        dp = torch.empty((B, P), dtype=e.dtype, device=e.device)
+        de = torch.empty((B,), dtype=e.dtype, device=e.device)
+        check(_lib.lib().chx_build_ttensor_vjp(kind, ptr(p), ptr(e), mass_eV, ptr(dT), B, p.shape[0], e.shape[0],
+                                               dtype_code(e.dtype), ptr(dp), ptr(de), stream_ptr()), "chx_build_ttensor_vjp")
+        if p.shape[0] == 1 and B > 1:
+            dp = dp.sum(dim=0, keepdim=True)
+        if e.shape[0] == 1 and B > 1:
+            de = de.sum(dim=0, keepdim=True)
+        return dp, de, None, None, None
 
 
 def build_ttensor(kind: int, params, param_shape, energy, mass_eV: float) -> torch.Tensor:
     """Second-order transfer tensor (*batch, 7, 7, 7) of one element (chx_build_ttensor)."""
     require_device(params, energy)
-    forward_only("second_order transfer maps", params, energy)
     batch_shape = bshapes(param_shape, energy.shape)
     B = max(numel(batch_shape), 1)
     p, Bp = flat_bcast(params.reshape(*param_shape, params.shape[-1]), batch_shape, 1)
     e, Be = flat_bcast(energy, batch_shape, 0)
     p, e = p.contiguous(), e.contiguous()
-    T = torch.empty((B, 7, 7, 7), dtype=energy.dtype, device=energy.device)
-    check(_lib.lib().chx_build_ttensor(kind, ptr(p), ptr(e), mass_eV, B, Bp, Be, dtype_code(energy.dtype), ptr(T),
-                                       stream_ptr()), "chx_build_ttensor")
+    if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad):
+        T = BuildTTensor.apply(p, e, kind, mass_eV, B)
+    else:
+        T = _build_ttensor_raw(kind, p, e, mass_eV, B)
     return T.reshape(*batch_shape, 7, 7, 7)
+
+
+def _apply_second_order_raw(x, Tt, B, N):
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_apply_second_order(ptr(x), ptr(Tt), ptr(out), B, x.shape[0], Tt.shape[0], N, dtype_code(x.dtype),
+                                            stream_ptr()), "chx_apply_second_order")
+    return out
+
+
+_UNFOLD_INDEX: dict = {}
+
+
+def _unfold_index(device) -> torch.Tensor:
+    """(343,) index of (i, j, k) into the folded (i, j <= k) order of chx_apply_second_order_bwd."""
+    idx = _UNFOLD_INDEX.get(device)
+    if idx is None:
+        start = [sum(7 - a for a in range(j)) for j in range(7)]
+        flat = [i * 28 + start[min(j, k)] + abs(k - j) for i in range(7) for j in range(7) for k in range(7)]
+        idx = _UNFOLD_INDEX[device] = torch.tensor(flat, dtype=torch.int64, device=device)
+    return idx
+
+
+class ApplySecondOrder(torch.autograd.Function):
+    """y = T x x (chx_apply_second_order); backward = chx_apply_second_order_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, Tt, B, N):
+        ctx.save_for_backward(x, Tt)
+        ctx.meta = (B, N)
+        return _apply_second_order_raw(x, Tt, B, N)
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, Tt = ctx.saved_tensors
+        B, N = ctx.meta
+        need_x, need_T = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dY = aligned(dY.contiguous())
+        dx = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_x else None
+        partials = None
+        if need_T:
+            count = _lib.lib().chx_second_order_bwd_partials_count(B)
+            partials = torch.empty((count,), dtype=torch.float64, device=x.device)
+        check(_lib.lib().chx_apply_second_order_bwd(ptr(x), ptr(Tt), ptr(dY), ptr(dx), ptr(partials), B, x.shape[0],
+                                                    Tt.shape[0], N, dtype_code(x.dtype), stream_ptr()),
+              "chx_apply_second_order_bwd")
+        dT = None
+        if need_T:
+            dU = partials.view(B, -1, 196).sum(dim=1)
+            dT = dU.index_select(1, _unfold_index(x.device))
+            dT = (dT.sum(dim=0, keepdim=True) if Tt.shape[0] == 1 and B > 1 else dT).to(Tt.dtype).reshape(-1, 7, 7, 7)
+        if need_x and x.shape[0] == 1 and B > 1:
+            dx = dx.sum(dim=0, keepdim=True)
+        return dx, dT, None, None
 
 
 def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     """einsum("...ijk,...j,...k->...i", T, x, x) over the particle axis (element.py:211-216)."""
     require_device(particles, T)
-    forward_only("second_order tracking", particles, T)
     if T.dtype != particles.dtype:
         raise RuntimeError(f"transfer map dtype {T.dtype} does not match particle dtype {particles.dtype}")
     N = particles.shape[-2]
@@ -450,9 +583,10 @@ def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor
     x, Bx = flat_bcast(particles, batch_shape, 2)
     Tt, BT = flat_bcast(T, batch_shape, 3)
     x, Tt = aligned(x), Tt.contiguous()
-    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
-    check(_lib.lib().chx_apply_second_order(ptr(x), ptr(Tt), ptr(out), B, Bx, BT, N, dtype_code(x.dtype), stream_ptr()),
-          "chx_apply_second_order")
+    if torch.is_grad_enabled() and (x.requires_grad or Tt.requires_grad):
+        out = ApplySecondOrder.apply(x, Tt, B, N)
+    else:
+        out = _apply_second_order_raw(x, Tt, B, N)
     return out.reshape(*batch_shape, N, 7)
 
 

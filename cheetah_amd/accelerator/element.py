@@ -134,6 +134,8 @@ class Element(nn.Module):
             ):
                 return cache["result"]
         result = build(energy, species)
+        if result.requires_grad:  # a graph-attached map must not outlive its backward pass
+            return result
         self.__dict__[slot] = {
             "fkey": fkey, "mass": species.mass_eV_float, "nq": species.num_elementary_charges_float,
             "energy_ref": energy, "energy_version": energy._version, "energy_copy": energy.detach().clone(),

@@ -17,60 +17,12 @@
 // number; chx_build_rmatrix_vjp seeds one input at a time and contracts dR/dtheta with the
 // incoming cotangent, which replaces torch autograd through ~40 tiny ops per element.
 #include "chx_common.h"
+#include "chx_dual.h"
 
 namespace {
 
 constexpr double kSpeedOfLight = 299792458.0;  // scipy.constants.speed_of_light (cavity.py:7)
 constexpr double kPi = 3.14159265358979323846;
-
-// ---------------------------------------------------------------------------------------------
-struct Dual {
-    double v, d;
-};
-__device__ __forceinline__ Dual mk(double v, double d) { Dual r; r.v = v; r.d = d; return r; }
-__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return mk(a.v + b.v, a.d + b.d); }
-__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return mk(a.v - b.v, a.d - b.d); }
-__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return mk(a.v * b.v, a.d * b.v + a.v * b.d); }
-__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
-    const double q = a.v / b.v;
-    return mk(q, (a.d - q * b.d) / b.v);
-}
-__device__ __forceinline__ Dual operator-(Dual a) { return mk(-a.v, -a.d); }
-__device__ __forceinline__ Dual operator+(Dual a, double b) { return mk(a.v + b, a.d); }
-__device__ __forceinline__ Dual operator+(double a, Dual b) { return mk(a + b.v, b.d); }
-__device__ __forceinline__ Dual operator-(Dual a, double b) { return mk(a.v - b, a.d); }
-__device__ __forceinline__ Dual operator-(double a, Dual b) { return mk(a - b.v, -b.d); }
-__device__ __forceinline__ Dual operator*(Dual a, double b) { return mk(a.v * b, a.d * b); }
-__device__ __forceinline__ Dual operator*(double a, Dual b) { return mk(a * b.v, a * b.d); }
-__device__ __forceinline__ Dual operator/(Dual a, double b) { return mk(a.v / b, a.d / b); }
-__device__ __forceinline__ Dual operator/(double a, Dual b) {
-    const double q = a / b.v;
-    return mk(q, -q * b.d / b.v);
-}
-
-__device__ __forceinline__ double val(double x) { return x; }
-__device__ __forceinline__ double val(Dual x) { return x.v; }
-__device__ __forceinline__ double tan_of(double x) { return 0.0 * x; }
-__device__ __forceinline__ double tan_of(Dual x) { return x.d; }
-
-__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ double m_sin(double x) { return sin(x); }
-__device__ __forceinline__ double m_cos(double x) { return cos(x); }
-__device__ __forceinline__ double m_tan(double x) { return tan(x); }
-__device__ __forceinline__ double m_sinh(double x) { return sinh(x); }
-__device__ __forceinline__ double m_cosh(double x) { return cosh(x); }
-__device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
-__device__ __forceinline__ Dual m_sqrt(Dual x) { const double s = sqrt(x.v); return mk(s, 0.5 * x.d / s); }
-__device__ __forceinline__ Dual m_sin(Dual x) { return mk(sin(x.v), cos(x.v) * x.d); }
-__device__ __forceinline__ Dual m_cos(Dual x) { return mk(cos(x.v), -sin(x.v) * x.d); }
-__device__ __forceinline__ Dual m_tan(Dual x) { const double t = tan(x.v); return mk(t, (1.0 + t * t) * x.d); }
-__device__ __forceinline__ Dual m_sinh(Dual x) { return mk(sinh(x.v), cosh(x.v) * x.d); }
-__device__ __forceinline__ Dual m_cosh(Dual x) { return mk(cosh(x.v), sinh(x.v) * x.d); }
-__device__ __forceinline__ Dual m_log1p(Dual x) { return mk(log1p(x.v), x.d / (1.0 + x.v)); }
-
-template <typename S> __device__ __forceinline__ S cst(double c);
-template <> __device__ __forceinline__ double cst<double>(double c) { return c; }
-template <> __device__ __forceinline__ Dual cst<Dual>(double c) { return mk(c, 0.0); }
 
 // ---- singularity-free "sinc family" as functions of u = k^2 L^2 (any sign) --------------------
 // C(u) = cos(sqrt u), S(u) = sin(sqrt u)/sqrt u, G(u) = (1-cos sqrt u)/u, F(u) = (1-S(u))/u.
@@ -556,54 +508,58 @@ __global__ __launch_bounds__(CHX_BLOCK) void cavity_coeff_kernel(const T* __rest
 // H(u) = (15 - 22.5 S + 9 S C - 1.5 S C^2 + u S^3) / u^3     (j3 of track_methods.py:134-143, = 6 j3 / L^7)
 // with S = sin(sqrt u)/sqrt u, C = cos(sqrt u). The closed form of E cancels like u^2 near u = 0, so
 // |u| < 1 is evaluated from its Taylor series (Horner, 12 terms, truncation < 1e-17).
-__device__ double ttensor_E(double u, double C, double S) {
-    if (fabs(u) < 1.0) {
+template <typename S>
+__device__ S ttensor_E(S u, S C, S Sn) {
+    if (fabs(val(u)) < 1.0) {
         const double c[12] = {0.0, 1.0 / 20, -1.0 / 168, 1.0 / 2880, -17.0 / 1330560, 31.0 / 94348800, -1.0 / 159667200,
                               5461.0 / 59281238016000.0, -257.0 / 238519804723200.0, 73.0 / 7113748561920000.0,
                               -1271.0 / 15667888932657561600.0, 60787.0 / 112400072777760768000000.0};
-        double r = c[11];
+        S r = cst<S>(c[11]);
         for (int k = 10; k >= 0; --k) r = r * u + c[k];
         return r;
     }
-    return (3.0 - 4.0 * S + S * C) / (2.0 * u);
+    return (3.0 - 4.0 * Sn + Sn * C) / (2.0 * u);
 }
 // NB: the numerator of H does NOT vanish like u^3 (it starts at order u), so j3 has no finite limit at u = 0 —
 // the reference says so itself (track_methods.py:130-133) and substitutes L^7/56 at exactly kx2 == 0. Parity with
 // the reference means evaluating its closed form as written; there is no cancellation to protect against.
-__device__ double ttensor_H(double u, double C, double S) {
-    return (15.0 - 22.5 * S + 9.0 * S * C - 1.5 * S * C * C + u * S * S * S) / (u * u * u);
+template <typename S>
+__device__ S ttensor_H(S u, S C, S Sn) {
+    return (15.0 - 22.5 * Sn + 9.0 * Sn * C - 1.5 * Sn * C * C + u * Sn * Sn * Sn) / (u * u * u);
 }
 
 #define TT(i, j, k) T[((i) * 7 + (j)) * 7 + (k)]
 // T must be zero-filled by the caller. Every jc/js/jd/jf term below carries a factor k2, and the reference's
 // elements only combine k2 != 0 with k1 = hx = 0 (Sextupole), where the divided differences sit at their
 // a == b == 0 limits; elsewhere they are multiplied by zero, so the plain difference quotients suffice.
-__device__ void base_ttensor(double L, double k1, double k2, double hx, double energy, double mass, double* T) {
-    double g, ig2, beta;
-    rel_factors<double>(energy, mass, g, ig2, beta);
-    const double kx2 = k1 + hx * hx, ky2 = -k1;
-    const double L2 = L * L, L3 = L2 * L;
-    const double a = kx2 * L2, b = ky2 * L2;
-    double cx, Sx, Gx, Fx, cy, Sy, Gy, Fy, C4, S4, G4, F4;
-    sinc_family<double>(a, cx, Sx, Gx, Fx);
-    sinc_family<double>(b, cy, Sy, Gy, Fy);
-    sinc_family<double>(4.0 * b, C4, S4, G4, F4);
-    const double sx = Sx * L, sy = Sy * L;
-    const double dx = L2 * Gx;                 // 0.5 L^2 sinc^2(kx L / 2), no hx factor here (track_methods.py:120)
-    const double fx = L3 * Fx;                 // si1mdiv
-    const double f2y = L3 * 4.0 * F4;          // sicos1mdiv(v) = (1 - S(v) C(v)) / v = 4 F(4v)
-    const double j1 = fx;
-    const double j2 = L3 * ttensor_E(a, cx, Sx);
-    const double L7 = L3 * L3 * L;
-    const double j3 = (kx2 != 0.0) ? L7 * ttensor_H(a, cx, Sx) / 6.0 : L7 / 56.0;
-    const double jden = kx2 - 4.0 * ky2;
-    const double jc = L2 * ((a != b) ? (cy - cx) / (a - b) : 0.5 * Sx);
-    const double js = L3 * ((a != b) ? (Sx - Sy) / (b - a) : ((b != 0.0) ? 0.5 * (Sy - cy) / b : 1.0 / 6.0));
-    const double jd =
-        L2 * L2 * ((a != b) ? (Sy * Sy - Sx * Sx) / (a - b) : ((b != 0.0) ? (1.0 - cy * cy - b * Sy * cy) / (b * b) : 1.0 / 3.0));
-    const double jf = (jden != 0.0) ? (f2y - fx) / jden : L2 * L3 / 120.0;
-    const double khk = k2 + 2.0 * hx * k1;
-    const double b2 = beta * beta, b3 = b2 * beta, hx2 = hx * hx, hx3 = hx2 * hx, dx2 = dx * dx;
+template <typename S>
+__device__ void base_ttensor(S L, S k1, S k2, S hx, S energy, double mass, S* T) {
+    S g, ig2, beta;
+    rel_factors<S>(energy, mass, g, ig2, beta);
+    const S kx2 = k1 + hx * hx, ky2 = -k1;
+    const S L2 = L * L, L3 = L2 * L;
+    const S a = kx2 * L2, b = ky2 * L2;
+    S cx, Sx, Gx, Fx, cy, Sy, Gy, Fy, C4, S4, G4, F4;
+    sinc_family<S>(a, cx, Sx, Gx, Fx);
+    sinc_family<S>(b, cy, Sy, Gy, Fy);
+    sinc_family<S>(4.0 * b, C4, S4, G4, F4);
+    const S sx = Sx * L, sy = Sy * L;
+    const S dx = L2 * Gx;                 // 0.5 L^2 sinc^2(kx L / 2), no hx factor here (track_methods.py:120)
+    const S fx = L3 * Fx;                 // si1mdiv
+    const S f2y = L3 * 4.0 * F4;          // sicos1mdiv(v) = (1 - S(v) C(v)) / v = 4 F(4v)
+    const S j1 = fx;
+    const S j2 = L3 * ttensor_E<S>(a, cx, Sx);
+    const S L7 = L3 * L3 * L;
+    const S j3 = (val(kx2) != 0.0) ? L7 * ttensor_H<S>(a, cx, Sx) / 6.0 : L7 / 56.0;
+    const S jden = kx2 - 4.0 * ky2;
+    const bool same = val(a) == val(b), bzero = val(b) == 0.0;
+    const S jc = L2 * (!same ? (cy - cx) / (a - b) : 0.5 * Sx);
+    const S js = L3 * (!same ? (Sx - Sy) / (b - a) : (!bzero ? 0.5 * (Sy - cy) / b : cst<S>(1.0 / 6.0)));
+    const S jd =
+        L2 * L2 * (!same ? (Sy * Sy - Sx * Sx) / (a - b) : (!bzero ? (1.0 - cy * cy - b * Sy * cy) / (b * b) : cst<S>(1.0 / 3.0)));
+    const S jf = (val(jden) != 0.0) ? (f2y - fx) / jden : L2 * L3 / 120.0;
+    const S khk = k2 + 2.0 * hx * k1;
+    const S b2 = beta * beta, b3 = b2 * beta, hx2 = hx * hx, hx3 = hx2 * hx, dx2 = dx * dx;
 
     TT(0, 0, 0) = -khk * (sx * sx + dx) / 6.0 - 0.5 * hx * kx2 * sx * sx;
     TT(0, 0, 1) = 2.0 * (-khk * sx * dx / 6.0 + 0.5 * hx * sx * cx);
@@ -662,30 +618,92 @@ __device__ void base_ttensor(double L, double k1, double k2, double hx, double e
 // T'_inm = sum_jkl X_ij T_jkl E_kn E_lm (quadrupole.py:140-144) as three 7-term contractions.
 constexpr int kTBlock = 384;
 
-__device__ void ttensor_contract(double* Ts, double* As, const double* X, const double* En) {
+template <typename S>
+__device__ __forceinline__ S s_zero() { return cst<S>(0.0); }
+
+template <typename S>
+__device__ void ttensor_contract(S* Ts, S* As, const S* X, const S* En) {
     const int id = threadIdx.x;
     const int i = id / 49, n = (id / 7) % 7, m = id % 7;
     __syncthreads();
     if (id < 343) {  // As[j=i][k=n][m] = sum_l Ts[j][k][l] En[l][m]
-        double acc = 0.0;
-        for (int l = 0; l < 7; ++l) acc += Ts[(i * 7 + n) * 7 + l] * En[l * 7 + m];
+        S acc = s_zero<S>();
+        for (int l = 0; l < 7; ++l) acc = acc + Ts[(i * 7 + n) * 7 + l] * En[l * 7 + m];
         As[id] = acc;
     }
     __syncthreads();
     if (id < 343) {  // Ts[j=i][n][m] = sum_k As[j][k][m] En[k][n]
-        double acc = 0.0;
-        for (int k = 0; k < 7; ++k) acc += As[(i * 7 + k) * 7 + m] * En[k * 7 + n];
+        S acc = s_zero<S>();
+        for (int k = 0; k < 7; ++k) acc = acc + As[(i * 7 + k) * 7 + m] * En[k * 7 + n];
         Ts[id] = acc;
     }
     __syncthreads();
     if (id < 343) {  // As[i][n][m] = sum_j X[i][j] Ts[j][n][m]
-        double acc = 0.0;
-        for (int j = 0; j < 7; ++j) acc += X[i * 7 + j] * Ts[(j * 7 + n) * 7 + m];
+        S acc = s_zero<S>();
+        for (int j = 0; j < 7; ++j) acc = acc + X[i * 7 + j] * Ts[(j * 7 + n) * 7 + m];
         As[id] = acc;
     }
     __syncthreads();
     if (id < 343) Ts[id] = As[id];
     __syncthreads();
+}
+
+// closed forms of one batch row (a single lane): the bare tensor + first-order map in Ts, the dressing matrices in
+// X1/E1 (misalignment or dipole faces) and X2/E2 (dipole tilt)
+template <typename S>
+__device__ void ttensor_fill(int kind, const S* p, S en, double mass, S* Ts, S* X1, S* E1, S* X2, S* E2) {
+    const S zero = s_zero<S>();
+    Mat7<S> R;
+    if (kind == CHX_T_DRIFT) {
+        base_ttensor<S>(p[0], zero, zero, zero, en, mass, Ts);
+        drift_map<S>(p[0], en, mass, R);
+    } else if (kind == CHX_T_QUADRUPOLE) {
+        base_ttensor<S>(p[0], p[1], zero, zero, en, mass, Ts);
+        base_rmatrix<S>(p[0], p[1], zero, en, mass, R);
+    } else if (kind == CHX_T_SEXTUPOLE) {
+        base_ttensor<S>(p[0], zero, p[1], zero, en, mass, Ts);
+        drift_map<S>(p[0], en, mass, R);
+    } else {  // CHX_T_DIPOLE: [L, angle, k1, e1, e2, tilt, fint, fint_exit, gap]
+        const S hx = p[1] / p[0];
+        base_ttensor<S>(p[0], p[2], zero, hx, en, mass, Ts);
+        base_rmatrix<S>(p[0], p[2], hx, en, mass, R);
+    }
+    // first-order map into T[:, 6, :] (drift.py:79-82)
+    for (int i = 0; i < 7; ++i)
+        for (int k = 0; k < 7; ++k) Ts[(i * 7 + 6) * 7 + k] = R(i, k);
+    if (kind == CHX_T_QUADRUPOLE || kind == CHX_T_SEXTUPOLE) {
+        // combined_rotation_misalignment_matrix (track_methods.py:345-382)
+        const S tilt = p[2], mx = p[3], my = p[4];
+        Mat7<S> entry, exitm;
+        rotation_map<S>(tilt, entry);
+        transpose7(entry, exitm);
+        const S cs = m_cos(tilt), sn = m_sin(tilt);
+        entry(0, 6) = -mx * cs - my * sn;
+        entry(2, 6) = mx * sn - my * cs;
+        exitm(0, 6) = mx;
+        exitm(2, 6) = my;
+        for (int k = 0; k < 49; ++k) { E1[k] = entry.m[k]; X1[k] = exitm.m[k]; }
+    } else if (kind == CHX_T_DIPOLE) {
+        const S hx = p[1] / p[0], e1 = p[3], e2 = p[4], tilt = p[5], fint = p[6], fint_exit = p[7], gap = p[8];
+        Mat7<S> enter, exitm, rot, rotT;
+        {
+            const S sec = 1.0 / m_cos(e1), s1 = m_sin(e1);
+            const S phi = fint * hx * gap * sec * (1.0 + s1 * s1);
+            eye7(enter);
+            enter(1, 0) = hx * m_tan(e1);
+            enter(3, 2) = -hx * m_tan(e1 - phi);
+        }
+        {
+            const S sec = 1.0 / m_cos(e2), s2 = m_sin(e2);
+            const S phi = fint_exit * hx * gap * sec * (1.0 + s2 * s2);
+            eye7(exitm);
+            exitm(1, 0) = hx * m_tan(e2);
+            exitm(3, 2) = -hx * m_tan(e2 - phi);
+        }
+        rotation_map<S>(tilt, rot);
+        transpose7(rot, rotT);
+        for (int k = 0; k < 49; ++k) { E1[k] = enter.m[k]; X1[k] = exitm.m[k]; E2[k] = rot.m[k]; X2[k] = rotT.m[k]; }
+    }
 }
 
 template <typename T>
@@ -700,63 +718,47 @@ __global__ __launch_bounds__(kTBlock) void ttensor_kernel(int kind, const T* __r
     if (id == 0) {
         double p[CHX_MAX_PARAMS];
         for (int k = 0; k < P; ++k) p[k] = (double)params[(Bp == 1 ? 0 : b) * P + k];
-        const double en = (double)energy[Be == 1 ? 0 : b];
-        Mat7<double> R;
-        if (kind == CHX_T_DRIFT) {
-            base_ttensor(p[0], 0.0, 0.0, 0.0, en, mass, Ts);
-            drift_map<double>(p[0], en, mass, R);
-        } else if (kind == CHX_T_QUADRUPOLE) {
-            base_ttensor(p[0], p[1], 0.0, 0.0, en, mass, Ts);
-            base_rmatrix<double>(p[0], p[1], 0.0, en, mass, R);
-        } else if (kind == CHX_T_SEXTUPOLE) {
-            base_ttensor(p[0], 0.0, p[1], 0.0, en, mass, Ts);
-            drift_map<double>(p[0], en, mass, R);
-        } else {  // CHX_T_DIPOLE: [L, angle, k1, e1, e2, tilt, fint, fint_exit, gap]
-            const double hx = p[1] / p[0];
-            base_ttensor(p[0], p[2], 0.0, hx, en, mass, Ts);
-            base_rmatrix<double>(p[0], p[2], hx, en, mass, R);
-        }
-        // first-order map into T[:, 6, :] (drift.py:79-82)
-        for (int i = 0; i < 7; ++i)
-            for (int k = 0; k < 7; ++k) Ts[(i * 7 + 6) * 7 + k] = R(i, k);
-        if (kind == CHX_T_QUADRUPOLE || kind == CHX_T_SEXTUPOLE) {
-            // combined_rotation_misalignment_matrix (track_methods.py:345-382)
-            const double tilt = p[2], mx = p[3], my = p[4];
-            Mat7<double> entry, exitm;
-            rotation_map<double>(tilt, entry);
-            transpose7(entry, exitm);
-            const double cs = cos(tilt), sn = sin(tilt);
-            entry(0, 6) = -mx * cs - my * sn;
-            entry(2, 6) = mx * sn - my * cs;
-            exitm(0, 6) = mx;
-            exitm(2, 6) = my;
-            for (int k = 0; k < 49; ++k) { E1[k] = entry.m[k]; X1[k] = exitm.m[k]; }
-        } else if (kind == CHX_T_DIPOLE) {
-            const double hx = p[1] / p[0], e1 = p[3], e2 = p[4], tilt = p[5], fint = p[6], fint_exit = p[7], gap = p[8];
-            Mat7<double> enter, exitm, rot, rotT;
-            {
-                const double sec = 1.0 / cos(e1), s1 = sin(e1);
-                const double phi = fint * hx * gap * sec * (1.0 + s1 * s1);
-                eye7(enter);
-                enter(1, 0) = hx * tan(e1);
-                enter(3, 2) = -hx * tan(e1 - phi);
-            }
-            {
-                const double sec = 1.0 / cos(e2), s2 = sin(e2);
-                const double phi = fint_exit * hx * gap * sec * (1.0 + s2 * s2);
-                eye7(exitm);
-                exitm(1, 0) = hx * tan(e2);
-                exitm(3, 2) = -hx * tan(e2 - phi);
-            }
-            rotation_map<double>(tilt, rot);
-            transpose7(rot, rotT);
-            for (int k = 0; k < 49; ++k) { E1[k] = enter.m[k]; X1[k] = exitm.m[k]; E2[k] = rot.m[k]; X2[k] = rotT.m[k]; }
-        }
+        ttensor_fill<double>(kind, p, (double)energy[Be == 1 ? 0 : b], mass, Ts, X1, E1, X2, E2);
     }
-    if (kind != CHX_T_DRIFT) ttensor_contract(Ts, As, X1, E1);
-    if (kind == CHX_T_DIPOLE) ttensor_contract(Ts, As, X2, E2);
+    if (kind != CHX_T_DRIFT) ttensor_contract<double>(Ts, As, X1, E1);
+    if (kind == CHX_T_DIPOLE) ttensor_contract<double>(Ts, As, X2, E2);
     __syncthreads();
     if (id < 343) T_out[b * 343 + id] = (T)Ts[id];
+}
+
+// vector-Jacobian product of the builder: workgroup (b, k) seeds input k (the parameters, then the energy), pushes
+// the tangent through the closed forms and the dressing, and contracts dT/dtheta_k with the incoming cotangent
+template <typename T>
+__global__ __launch_bounds__(kTBlock) void ttensor_vjp_kernel(int kind, const T* __restrict__ params,
+                                                              const T* __restrict__ energy, double mass,
+                                                              const T* __restrict__ dT, int64_t Bp, int64_t Be, int P,
+                                                              T* __restrict__ dparams, T* __restrict__ denergy) {
+    __shared__ Dual Ts[343], As[343], X1[49], E1[49], X2[49], E2[49];
+    __shared__ double red[kTBlock / 64];
+    const int64_t b = blockIdx.x;
+    const int k = blockIdx.y;  // 0..P-1: parameter, P: energy
+    const int id = threadIdx.x;
+    if (id < 343) Ts[id] = mk(0.0, 0.0);
+    __syncthreads();
+    if (id == 0) {
+        Dual p[CHX_MAX_PARAMS];
+        for (int j = 0; j < P; ++j) p[j] = mk((double)params[(Bp == 1 ? 0 : b) * P + j], j == k ? 1.0 : 0.0);
+        const Dual en = mk((double)energy[Be == 1 ? 0 : b], k == P ? 1.0 : 0.0);
+        ttensor_fill<Dual>(kind, p, en, mass, Ts, X1, E1, X2, E2);
+    }
+    if (kind != CHX_T_DRIFT) ttensor_contract<Dual>(Ts, As, X1, E1);
+    if (kind == CHX_T_DIPOLE) ttensor_contract<Dual>(Ts, As, X2, E2);
+    __syncthreads();
+    double acc = (id < 343) ? (double)dT[b * 343 + id] * Ts[id].d : 0.0;
+    acc = chx_wave_sum(acc);
+    if ((id & 63) == 0) red[id >> 6] = acc;
+    __syncthreads();
+    if (id == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < kTBlock / 64; ++w) tot += red[w];
+        if (k < P) dparams[b * P + k] = (T)tot;
+        else denergy[b] = (T)tot;
+    }
 }
 
 }  // namespace
@@ -783,6 +785,27 @@ extern "C" int chx_build_ttensor(int kind, const void* params, const void* energ
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL(ttensor_kernel<double>, dim3((unsigned)B), dim3(kTBlock), 0, s, kind, (const double*)params,
                            (const double*)energy, mass_eV, Bp, Be, P, (double*)T_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_build_ttensor_vjp(int kind, const void* params, const void* energy, double mass_eV,
+                                     const void* dT, int64_t B, int64_t Bp, int64_t Be, int dtype, void* dparams,
+                                     void* denergy, void* stream) {
+    const int P = chx_t_num_params(kind);
+    if (P < 0 || !params || !energy || !dT || !dparams || !denergy || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)B, (unsigned)(P + 1));
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(ttensor_vjp_kernel<float>, grid, dim3(kTBlock), 0, s, kind, (const float*)params,
+                           (const float*)energy, mass_eV, (const float*)dT, Bp, Be, P, (float*)dparams, (float*)denergy);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(ttensor_vjp_kernel<double>, grid, dim3(kTBlock), 0, s, kind, (const double*)params,
+                           (const double*)energy, mass_eV, (const double*)dT, Bp, Be, P, (double*)dparams,
+                           (double*)denergy);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

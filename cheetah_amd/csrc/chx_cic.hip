@@ -314,6 +314,8 @@ inline dim3 particle_grid(int64_t N, int64_t B) {
 //   pass 1  count     every particle is assigned to each tile its 2^d-corner footprint touches (1 tile for
 //                     most particles, up to 2^d at tile corners); per-workgroup LDS histogram -> counts[tile][wg]
 //   pass 2  scan      exclusive prefix over (tile-major, wg-minor): deterministic slot ranges, no atomics
+//                     (per-tile scan over the workgroups in its own kernel; the scan of the tile totals is redone
+//                     in LDS by every workgroup of pass 3, which saves a launch)
 //   pass 3  scatter   records {i_d, f_d, charge} into their tile's slot range (LDS cursors)
 //   pass 4  accumulate one workgroup per tile: ds_add of the corners that fall into the OWNED cells, then a
 //                     plain, coalesced `grid += tile` (no global atomics anywhere, no halo exchange)
@@ -372,6 +374,34 @@ __device__ __forceinline__ void tile_range(const CicDev& a, const TileGeom& g, c
     }
 }
 
+// exclusive prefix sum of v[0..n) in LDS by one workgroup of kSortThreads lanes; returns the total
+__device__ __forceinline__ int block_exclusive_scan(int* v, int n) {
+    __shared__ int wave_sum[kSortThreads / 64];
+    const int per = (n + kSortThreads - 1) / kSortThreads;
+    const int lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += v[i];
+    int incl = sum;  // inclusive scan across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if ((threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSortThreads / 64; ++w) {
+        const int ws = wave_sum[w];
+        if (w < (int)(threadIdx.x >> 6)) base += ws;
+        total += ws;
+    }
+    int run = base + incl - sum;
+    for (int i = lo; i < hi; ++i) { const int t = v[i]; v[i] = run; run += t; }
+    __syncthreads();
+    return total;
+}
+
 // pass 1 (SCATTER = false) and pass 3 (SCATTER = true) share the particle loop
 template <typename T, int ND, bool SCATTER>
 __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGeom g, const T* __restrict__ x,
@@ -379,17 +409,31 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
                                                                const T* __restrict__ extent,
                                                                const T* __restrict__ scale,
                                                                const T* __restrict__ shift,
-                                                               int* __restrict__ counts /*[B][nt][kSortWG]*/,
-                                                               const int* __restrict__ tile_start /*[B][nt+1]*/,
+                                                               int* __restrict__ counts /*[B][kSortWG][nt]*/,
+                                                               const int* __restrict__ totals /*[B][nt]*/,
+                                                               int* __restrict__ tile_start /*[B][nt+1]*/,
                                                                CicRec<T, ND>* __restrict__ recs, int64_t rec_cap) {
-    extern __shared__ int hist[];  // [nt]
+    extern __shared__ int hist[];  // [nt] — pass 1: per-tile counters; pass 3: absolute write cursors
     const int64_t b = blockIdx.y;
     const int wg = blockIdx.x;
-    for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] = 0;
+    int* cnt = counts + (b * kSortWG + wg) * (int64_t)g.nt;
+    if (!SCATTER) {
+        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] = 0;
+    } else {
+        // pass 2b folded in: every workgroup scans the tile totals itself (nt <= 16k ints in LDS), workgroup 0
+        // publishes the tile starts for pass 4; cursor = tile start + this workgroup's offset inside the tile
+        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] = totals[b * g.nt + t];
+        __syncthreads();
+        const int sum = block_exclusive_scan(hist, g.nt);
+        if (wg == 0) {
+            for (int t = threadIdx.x; t < g.nt; t += kSortThreads) tile_start[b * (g.nt + 1) + t] = hist[t];
+            if (threadIdx.x == 0) tile_start[b * (g.nt + 1) + g.nt] = sum;
+        }
+        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] += cnt[t];
+    }
     __syncthreads();
     const int64_t per = (a.N + kSortWG - 1) / kSortWG;
     const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
-    int* cnt = counts + b * (int64_t)g.nt * kSortWG;
     for (int64_t n = n0 + threadIdx.x; n < n1; n += kSortThreads) {
         const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n);
         if (!pt.inside) continue;
@@ -405,53 +449,46 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
             for (int ty = t0[1]; ty <= t1[1]; ++ty)
                 for (int tz = t0[2]; tz <= t1[2]; ++tz) {
                     const int tile = (tx * g.ntile[1] + ty) * g.ntile[2] + tz;
-                    const int slot = atomicAdd(&hist[tile], 1);
+                    const int pos = atomicAdd(&hist[tile], 1);
                     if (SCATTER) {
-                        const int64_t pos = (int64_t)tile_start[b * (g.nt + 1) + tile] +
-                                            cnt[(int64_t)tile * kSortWG + wg] + slot;
                         if (pos < rec_cap) recs[b * rec_cap + pos] = r;
                     }
                 }
     }
     if (!SCATTER) {
         __syncthreads();
-        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) cnt[(int64_t)t * kSortWG + wg] = hist[t];
+        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) cnt[t] = hist[t];
     }
 }
 
-// pass 2a: per tile, exclusive prefix over the workgroups (in place) and the tile total
-__global__ void cic_scan_tiles_kernel(int* __restrict__ counts, int* __restrict__ totals, int nt) {
+// pass 2a: per tile, exclusive prefix over the workgroups (in place) and the tile total. counts is wg-major
+// ([wg][tile]) so every access below is coalesced across the 64 tiles of a workgroup; the 256 workgroup counts of
+// a tile are cut into 16 chunks of 16 (one lane each, 16 loads in flight) that meet through LDS.
+constexpr int kScanChunk = 16;
+static_assert(kSortWG == kScanChunk * 16, "scan decomposition");
+__global__ __launch_bounds__(1024) void cic_scan_tiles_kernel(int* __restrict__ counts, int* __restrict__ totals, int nt) {
+    __shared__ int part[16][64];
     const int64_t b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
-    int* c = counts + (b * nt + t) * (int64_t)kSortWG;
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    int* cb = counts + b * kSortWG * (int64_t)nt;
+    int v[kScanChunk];
     int run = 0;
-    for (int w = 0; w < kSortWG; ++w) {
-        const int v = c[w];
-        c[w] = run;
-        run += v;
+    if (t < nt) {
+#pragma unroll
+        for (int i = 0; i < kScanChunk; ++i) v[i] = cb[(int64_t)(c * kScanChunk + i) * nt + t];
+#pragma unroll
+        for (int i = 0; i < kScanChunk; ++i) { const int x = v[i]; v[i] = run; run += x; }
     }
-    totals[b * (nt + 1) + t] = run;
-}
-
-// pass 2b: exclusive scan of the tile totals (single workgroup per batch row), in place; entry nt = sum
-__global__ __launch_bounds__(1024) void cic_scan_totals_kernel(int* __restrict__ totals, int nt) {
-    __shared__ int part[1024];
-    int* v = totals + (int64_t)blockIdx.x * (nt + 1);
-    const int per = (nt + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = (lo + per < nt) ? lo + per : nt;
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += v[i];
-    part[threadIdx.x] = sum;
+    part[c][lane] = run;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; ++i) { const int t = part[i]; part[i] = run; run += t; }
-        v[nt] = run;
+    int off = 0;
+    for (int cc = 0; cc < c; ++cc) off += part[cc][lane];
+    if (t < nt) {
+#pragma unroll
+        for (int i = 0; i < kScanChunk; ++i) cb[(int64_t)(c * kScanChunk + i) * nt + t] = v[i] + off;
+        if (c == 15) totals[b * nt + t] = off + run;
     }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int i = lo; i < hi; ++i) { const int t = v[i]; v[i] = run; run += t; }
 }
 
 // pass 4: one workgroup per (tile, batch row); LDS tile = exactly the owned cells
@@ -564,7 +601,7 @@ int64_t rec_capacity(int64_t N) { return N * (1 << ND); }
 template <typename T, int ND>
 size_t sorted_ws_bytes(const CicDev& a, const TileGeom& g) {
     size_t bytes = (size_t)a.B * g.nt * kSortWG * sizeof(int);          // counts
-    bytes += (size_t)a.B * (g.nt + 1) * sizeof(int);                    // tile starts
+    bytes += (size_t)a.B * (2 * g.nt + 1) * sizeof(int);                // tile totals, tile starts
     bytes = (bytes + 255) & ~(size_t)255;
     bytes += (size_t)a.B * (size_t)rec_capacity<ND>(a.N) * sizeof(CicRec<T, ND>);  // sorted records
     return bytes;
@@ -574,11 +611,12 @@ template <typename T, int ND>
 int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const TileGeom g = tile_geom(a.ndim, a.bins);
     if (workspace_bytes < sorted_ws_bytes<T, ND>(a, g)) return CHX_ERR_WORKSPACE;
-    if ((size_t)g.nt * sizeof(int) > 64 * 1024) return CHX_ERR_INVALID_ARG;
+    if ((size_t)g.nt * sizeof(int) > 60 * 1024) return CHX_ERR_INVALID_ARG;
     if (rec_capacity<ND>(a.N) > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
     int* counts = (int*)workspace;
-    int* starts = counts + (size_t)a.B * g.nt * kSortWG;
-    size_t off = ((size_t)a.B * g.nt * kSortWG + (size_t)a.B * (g.nt + 1)) * sizeof(int);
+    int* totals = counts + (size_t)a.B * g.nt * kSortWG;
+    int* starts = totals + (size_t)a.B * g.nt;
+    size_t off = ((size_t)a.B * g.nt * kSortWG + (size_t)a.B * (2 * g.nt + 1)) * sizeof(int);
     off = (off + 255) & ~(size_t)255;
     CicRec<T, ND>* recs = (CicRec<T, ND>*)((char*)workspace + off);
     const int64_t cap = rec_capacity<ND>(a.N);
@@ -586,15 +624,13 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
     const size_t hist_bytes = (size_t)g.nt * sizeof(int);
     hipLaunchKernelGGL((cic_sort_kernel<T, ND, false>), sgrid, dim3(kSortThreads), hist_bytes, s, a, g, (const T*)p->x,
                        (const T*)p->charge, (const T*)p->survival, (const T*)p->extent, (const T*)p->scale,
-                       (const T*)p->shift, counts, (const int*)starts, recs, cap);
+                       (const T*)p->shift, counts, (const int*)totals, starts, recs, cap);
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cic_scan_tiles_kernel, dim3((g.nt + 255) / 256, (unsigned)a.B), dim3(256), 0, s, counts, starts, g.nt);
-    CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cic_scan_totals_kernel, dim3((unsigned)a.B), dim3(1024), 0, s, starts, g.nt);
+    hipLaunchKernelGGL(cic_scan_tiles_kernel, dim3((g.nt + 63) / 64, (unsigned)a.B), dim3(1024), 0, s, counts, totals, g.nt);
     CHX_CHECK_LAUNCH();
     hipLaunchKernelGGL((cic_sort_kernel<T, ND, true>), sgrid, dim3(kSortThreads), hist_bytes, s, a, g, (const T*)p->x,
                        (const T*)p->charge, (const T*)p->survival, (const T*)p->extent, (const T*)p->scale,
-                       (const T*)p->shift, counts, (const int*)starts, recs, cap);
+                       (const T*)p->shift, counts, (const int*)totals, starts, recs, cap);
     CHX_CHECK_LAUNCH();
     size_t tile_bytes = sizeof(double);
     for (int d = 0; d < ND; ++d) tile_bytes *= (size_t)g.tdim[d];

@@ -11,6 +11,7 @@
 // LDS tile staging as chx_apply.hip; the per-particle arithmetic runs in fp64 whatever the storage
 // dtype is (transcendental-heavy but far below the HBM time of the pass on 256 CUs).
 #include "chx_common.h"
+#include "chx_dual.h"
 
 namespace {
 
@@ -18,92 +19,100 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kC = 299792458.0;  // scipy.constants.speed_of_light
 
 // ---------------------------------------------------------------------------------------------
-// Bmad-X helpers (utils/bmadx.py)
+// Bmad-X helpers (utils/bmadx.py). Templates over S = double (tracking) or Dual (chx_dkd_track_bwd).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sinc1(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }      // bmadx.py:318
-__device__ __forceinline__ double cosc1(double x) { const double s = sinc1(0.5 * x); return -0.5 * s * s; }  // :323
-__device__ __forceinline__ double sqrt_one(double x) { return x / (sqrt(1.0 + x) + 1.0); }     // :255
+template <typename S> __device__ __forceinline__ S sinc1(S x) { return val(x) == 0.0 ? cst<S>(1.0) : m_sin(x) / x; }  // bmadx.py:318
+template <typename S> __device__ __forceinline__ S cosc1(S x) { const S s = sinc1<S>(0.5 * x); return -0.5 * s * s; }  // :323
+template <typename S> __device__ __forceinline__ S sqrt_one(S x) { return x / (m_sqrt(1.0 + x) + 1.0); }              // :255
 
+template <typename S>
 struct Bmad {
-    double x, px, y, py, z, pz;
+    S x, px, y, py, z, pz;
 };
 
 // bmadx.py:7-31
-__device__ __forceinline__ void to_bmad(double tau, double delta, double E, double mc2, double p0c, double& z,
-                                        double& pz) {
-    const double en = E + delta * p0c;
-    const double p = sqrt(en * en - mc2 * mc2);
-    const double beta = p / en;
+template <typename S>
+__device__ __forceinline__ void to_bmad(S tau, S delta, S E, double mc2, S p0c, S& z, S& pz) {
+    const S en = E + delta * p0c;
+    const S p = m_sqrt(en * en - mc2 * mc2);
+    const S beta = p / en;
     z = -beta * tau;
     pz = (p - p0c) / p0c;
 }
 // bmadx.py:34-56
-__device__ __forceinline__ void from_bmad(double z, double pz, double p0c, double mc2, double& tau, double& delta) {
-    const double ref = sqrt(p0c * p0c + mc2 * mc2);
-    const double p = (1.0 + pz) * p0c;
-    const double en = sqrt(p * p + mc2 * mc2);
-    const double beta = p / en;
+template <typename S>
+__device__ __forceinline__ void from_bmad(S z, S pz, S p0c, double mc2, S& tau, S& delta) {
+    const S ref = m_sqrt(p0c * p0c + mc2 * mc2);
+    const S p = (1.0 + pz) * p0c;
+    const S en = m_sqrt(p * p + mc2 * mc2);
+    const S beta = p / en;
     tau = -z / beta;
     delta = (en - ref) / p0c;
 }
 // bmadx.py:117-147 / 150-181
-__device__ __forceinline__ void offset_set(double xo, double yo, double s, double c, Bmad& q) {
-    const double xi = q.x - xo, yi = q.y - yo;
-    const double x = xi * c + yi * s, y = -xi * s + yi * c;
-    const double px = q.px * c + q.py * s, py = -q.px * s + q.py * c;
+template <typename S>
+__device__ __forceinline__ void offset_set(S xo, S yo, S s, S c, Bmad<S>& q) {
+    const S xi = q.x - xo, yi = q.y - yo;
+    const S x = xi * c + yi * s, y = -xi * s + yi * c;
+    const S px = q.px * c + q.py * s, py = -q.px * s + q.py * c;
     q.x = x; q.y = y; q.px = px; q.py = py;
 }
-__device__ __forceinline__ void offset_unset(double xo, double yo, double s, double c, Bmad& q) {
-    const double xi = q.x * c - q.y * s, yi = q.x * s + q.y * c;
-    const double px = q.px * c - q.py * s, py = q.px * s + q.py * c;
+template <typename S>
+__device__ __forceinline__ void offset_unset(S xo, S yo, S s, S c, Bmad<S>& q) {
+    const S xi = q.x * c - q.y * s, yi = q.x * s + q.y * c;
+    const S px = q.px * c - q.py * s, py = q.px * s + q.py * c;
     q.x = xi + xo; q.y = yi + yo; q.px = px; q.py = py;
 }
 // bmadx.py:263-298
-__device__ __forceinline__ void track_a_drift(double L, Bmad& q, double p0c, double mc2) {
-    const double P = 1.0 + q.pz;
-    const double Px = q.px / P, Py = q.py / P;
-    const double Pxy2 = Px * Px + Py * Py;
-    const double Pl = sqrt(1.0 - Pxy2);
-    const double pc = p0c * P;
-    const double dz =
-        L * (sqrt_one((mc2 * mc2 * (2.0 * q.pz + q.pz * q.pz)) / (pc * pc + mc2 * mc2)) + sqrt_one(-Pxy2) / Pl);
+template <typename S>
+__device__ __forceinline__ void track_a_drift(S L, Bmad<S>& q, S p0c, double mc2) {
+    const S P = 1.0 + q.pz;
+    const S Px = q.px / P, Py = q.py / P;
+    const S Pxy2 = Px * Px + Py * Py;
+    const S Pl = m_sqrt(1.0 - Pxy2);
+    const S pc = p0c * P;
+    const S dz =
+        L * (sqrt_one<S>((mc2 * mc2 * (2.0 * q.pz + q.pz * q.pz)) / (pc * pc + mc2 * mc2)) + sqrt_one<S>(-Pxy2) / Pl);
     q.x = q.x + L * Px / Pl;
     q.y = q.y + L * Py / Pl;
     q.z = q.z + dz;
 }
 // bmadx.py:184-216
-__device__ __forceinline__ double low_energy_z_correction(double pz, double p0c, double mc2, double ds) {
-    const double pc = (1.0 + pz) * p0c;
-    const double beta = pc / sqrt(pc * pc + mc2 * mc2);
-    const double e_tot = sqrt(p0c * p0c + mc2 * mc2);
-    const double beta0 = p0c / e_tot;
-    const double b0pz = beta0 * pz;
-    const double evaluation = mc2 * (b0pz * b0pz);
-    const double me = mc2 / e_tot, me2 = me * me, b02 = beta0 * beta0;
-    if (evaluation < 3e-7 * e_tot)
+template <typename S>
+__device__ __forceinline__ S low_energy_z_correction(S pz, S p0c, double mc2, S ds) {
+    const S pc = (1.0 + pz) * p0c;
+    const S beta = pc / m_sqrt(pc * pc + mc2 * mc2);
+    const S e_tot = m_sqrt(p0c * p0c + mc2 * mc2);
+    const S beta0 = p0c / e_tot;
+    const S b0pz = beta0 * pz;
+    const S evaluation = mc2 * (b0pz * b0pz);
+    const S me = mc2 / e_tot, me2 = me * me, b02 = beta0 * beta0;
+    if (val(evaluation) < 3e-7 * val(e_tot))
         return ds * pz * (1.0 - 3.0 * (pz * b02) / 2.0 + pz * pz * b02 * (2.0 * b02 - me2 / 2.0)) * me2;
     return ds * (beta - beta0) / beta0;
 }
 // bmadx.py:219-252 with k1 real: kx = sqrt(-k1) is real (k1 < 0), imaginary (k1 > 0) or zero
+template <typename S>
 struct QuadCoef {
-    double a11, a12, a21, a22, c1, c2, c3;
+    S a11, a12, a21, a22, c1, c2, c3;
 };
-__device__ __forceinline__ QuadCoef quad_coefficients(double k1, double len, double rel_p) {
-    double cx, sx;
-    const double w = -k1;
-    if (w > 0.0) {
-        const double k = sqrt(w);
-        cx = cos(k * len);
-        sx = sin(k * len) / k;
-    } else if (w < 0.0) {
-        const double k = sqrt(-w);
-        cx = cosh(k * len);
-        sx = sinh(k * len) / k;
+template <typename S>
+__device__ __forceinline__ QuadCoef<S> quad_coefficients(S k1, S len, S rel_p) {
+    S cx, sx;
+    const S w = -k1;
+    if (val(w) > 0.0) {
+        const S k = m_sqrt(w);
+        cx = m_cos(k * len);
+        sx = m_sin(k * len) / k;
+    } else if (val(w) < 0.0) {
+        const S k = m_sqrt(-w);
+        cx = m_cosh(k * len);
+        sx = m_sinh(k * len) / k;
     } else {
-        cx = 1.0;
+        cx = cst<S>(1.0);
         sx = len;
     }
-    QuadCoef q;
+    QuadCoef<S> q;
     q.a11 = cx;
     q.a12 = sx / rel_p;
     q.a21 = k1 * sx * rel_p;
@@ -113,9 +122,13 @@ __device__ __forceinline__ QuadCoef quad_coefficients(double k1, double len, dou
     q.c3 = -(cx * sx + len) / (4.0 * (rel_p * rel_p));
     return q;
 }
-// utils/autograd.py:669-670
+// utils/autograd.py:669-670 (value) and :672-700 (derivatives, with the b == 0 limits -1/(2a^2), -1/(8a^3))
 __device__ __forceinline__ double sqrta2minusbdiva(double a, double b) {
     return b != 0.0 ? (sqrt(a * a + b) - a) / b : 1.0 / (2.0 * a);
+}
+__device__ __forceinline__ Dual sqrta2minusbdiva(Dual a, Dual b) {
+    if (b.v != 0.0) return (m_sqrt(a * a + b) - a) / b;
+    return mk(1.0 / (2.0 * a.v), -a.d / (2.0 * a.v * a.v) - b.d / (8.0 * a.v * a.v * a.v));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -123,41 +136,41 @@ __device__ __forceinline__ double sqrta2minusbdiva(double a, double b) {
 // ---------------------------------------------------------------------------------------------
 enum { C_E = 0, C_P0C, C_SIN, C_COS, C_XO, C_YO, C_A, C_B, C_C, C_D, C_E2, C_F, C_G, C_H, C_I, C_J, C_N };
 
-template <typename T>
-__device__ void dkd_constants(int kind, const T* __restrict__ par, double E, double mc2, double nq, int fringe,
-                              double* c) {
+template <typename S>
+__device__ void dkd_constants(int kind, const S* par, S E, double mc2, double nq, int fringe, S* c) {
+    const S zero = cst<S>(0.0), one = cst<S>(1.0);
     c[C_E] = E;
-    const double p0c = sqrt(E * E - mc2 * mc2);
+    const S p0c = m_sqrt(E * E - mc2 * mc2);
     c[C_P0C] = p0c;
-    c[C_SIN] = 0.0; c[C_COS] = 1.0; c[C_XO] = 0.0; c[C_YO] = 0.0;
+    c[C_SIN] = zero; c[C_COS] = one; c[C_XO] = zero; c[C_YO] = zero;
     if (kind == CHX_DKD_DRIFT) {
-        c[C_A] = (double)par[0];
+        c[C_A] = par[0];
     } else if (kind == CHX_DKD_QUADRUPOLE) {
-        const double L = (double)par[0], k1 = (double)par[1], tilt = (double)par[2];
-        c[C_SIN] = sin(tilt); c[C_COS] = cos(tilt);
-        c[C_XO] = (double)par[3]; c[C_YO] = (double)par[4];
+        const S L = par[0], k1 = par[1], tilt = par[2];
+        c[C_SIN] = m_sin(tilt); c[C_COS] = m_cos(tilt);
+        c[C_XO] = par[3]; c[C_YO] = par[4];
         c[C_A] = L;
         c[C_B] = k1 * L;  // b1 (quadrupole.py:199)
     } else if (kind == CHX_DKD_DIPOLE) {
-        const double L = (double)par[0], angle = (double)par[1], e1 = (double)par[2], e2 = (double)par[3];
-        const double tilt = (double)par[4], fint = (double)par[5], fintx = (double)par[6];
-        const double gap = (double)par[7], gapx = (double)par[8];
-        c[C_SIN] = sin(tilt); c[C_COS] = cos(tilt);
-        const double g = angle / L;
+        const S L = par[0], angle = par[1], e1 = par[2], e2 = par[3];
+        const S tilt = par[4], fint = par[5], fintx = par[6];
+        const S gap = par[7], gapx = par[8];
+        c[C_SIN] = m_sin(tilt); c[C_COS] = m_cos(tilt);
+        const S g = angle / L;
         c[C_A] = L; c[C_B] = angle; c[C_C] = g;
-        c[C_D] = sinc1(angle); c[C_E2] = cosc1(angle); c[C_F] = cos(angle); c[C_G] = sin(angle);
+        c[C_D] = sinc1<S>(angle); c[C_E2] = cosc1<S>(angle); c[C_F] = m_cos(angle); c[C_G] = m_sin(angle);
         // linear fringe kicks (dipole.py:355-366): hx, hy at entrance and exit
-        const double hg1 = 0.5 * gap, hg2 = 0.5 * gapx;
-        const double s1 = sin(e1), s2 = sin(e2);
-        c[C_H] = (fringe & 1) ? g * tan(e1) : 0.0;
-        c[C_I] = (fringe & 1) ? -g * tan(e1 - 2.0 * fint * hg1 * g * (1.0 + s1 * s1) / cos(e1)) : 0.0;
-        c[C_J] = (fringe & 2) ? g * tan(e2) : 0.0;
-        c[C_N] = (fringe & 2) ? -g * tan(e2 - 2.0 * fintx * hg2 * g * (1.0 + s2 * s2) / cos(e2)) : 0.0;
+        const S hg1 = 0.5 * gap, hg2 = 0.5 * gapx;
+        const S s1 = m_sin(e1), s2 = m_sin(e2);
+        c[C_H] = (fringe & 1) ? g * m_tan(e1) : zero;
+        c[C_I] = (fringe & 1) ? -g * m_tan(e1 - 2.0 * fint * hg1 * g * (1.0 + s1 * s1) / m_cos(e1)) : zero;
+        c[C_J] = (fringe & 2) ? g * m_tan(e2) : zero;
+        c[C_N] = (fringe & 2) ? -g * m_tan(e2 - 2.0 * fintx * hg2 * g * (1.0 + s2 * s2) / m_cos(e2)) : zero;
     } else {  // CHX_DKD_TDC
-        const double L = (double)par[0], V = (double)par[1], phase = (double)par[2], freq = (double)par[3];
-        const double tilt = (double)par[4];
-        c[C_SIN] = sin(tilt); c[C_COS] = cos(tilt);
-        c[C_XO] = (double)par[5]; c[C_YO] = (double)par[6];
+        const S L = par[0], V = par[1], phase = par[2], freq = par[3];
+        const S tilt = par[4];
+        c[C_SIN] = m_sin(tilt); c[C_COS] = m_cos(tilt);
+        c[C_XO] = par[5]; c[C_YO] = par[6];
         c[C_A] = L;
         c[C_B] = V * -1.0 * nq / p0c;        // transverse_deflecting_cavity.py:156
         c[C_C] = 2.0 * kPi * freq / kC;      // k_rf
@@ -166,86 +179,99 @@ __device__ void dkd_constants(int kind, const T* __restrict__ par, double E, dou
 }
 
 // dipole.py:246-336
-__device__ __forceinline__ void dipole_body(const double* c, Bmad& q, double p0c, double mc2) {
-    const double L = c[C_A], angle = c[C_B], g = c[C_C], sinc_a = c[C_D], cosc_a = c[C_E2];
-    const double cos_a = c[C_F], sin_a = c[C_G];
-    const double px_norm = sqrt((1.0 + q.pz) * (1.0 + q.pz) - q.py * q.py);
-    const double phi1 = asin(q.px / px_norm);
-    const double gp = g / px_norm;
-    const double gx1 = 1.0 + g * q.x;
-    const double sap = sin(angle + phi1), cap = cos(angle + phi1);
-    const double t = gx1 * L * sinc_a;
-    const double alpha = 2.0 * gx1 * sap * L * sinc_a - gp * (t * t);
-    const double x2_t1 = q.x * cos_a + L * L * g * cosc_a;
-    const double x2_t2 = sqrt(cap * cap + gp * alpha);
-    const double x2_t3 = cap;
-    const double x2 = (fabs(angle + phi1) < kPi / 2.0) ? x2_t1 + alpha / (x2_t2 + x2_t3)
-                                                     : x2_t1 + alpha * sqrta2minusbdiva(x2_t3, gp * alpha);
-    const double Lcu = x2 - L * L * g * cosc_a - q.x * cos_a;
-    const double Lcv = -L * sinc_a - q.x * sin_a;
-    const double theta_p = 2.0 * (angle + phi1 - kPi / 2.0 - atan2(Lcv, Lcu));
-    const double Lc = sqrt(Lcu * Lcu + Lcv * Lcv);
-    const double Lp = Lc / sinc1(theta_p / 2.0);
-    const double P = p0c * (1.0 + q.pz);
-    const double E = sqrt(P * P + mc2 * mc2);
-    const double E0 = sqrt(p0c * p0c + mc2 * mc2);
-    const double beta = P / E, beta0 = p0c / E0;
+template <typename S>
+__device__ __forceinline__ void dipole_body(const S* c, Bmad<S>& q, S p0c, double mc2) {
+    const S L = c[C_A], angle = c[C_B], g = c[C_C], sinc_a = c[C_D], cosc_a = c[C_E2];
+    const S cos_a = c[C_F], sin_a = c[C_G];
+    const S px_norm = m_sqrt((1.0 + q.pz) * (1.0 + q.pz) - q.py * q.py);
+    const S phi1 = m_asin(q.px / px_norm);
+    const S gp = g / px_norm;
+    const S gx1 = 1.0 + g * q.x;
+    const S sap = m_sin(angle + phi1), cap = m_cos(angle + phi1);
+    const S t = gx1 * L * sinc_a;
+    const S alpha = 2.0 * gx1 * sap * L * sinc_a - gp * (t * t);
+    const S x2_t1 = q.x * cos_a + L * L * g * cosc_a;
+    const S x2_t2 = m_sqrt(cap * cap + gp * alpha);
+    const S x2_t3 = cap;
+    const S x2 = (fabs(val(angle) + val(phi1)) < kPi / 2.0) ? x2_t1 + alpha / (x2_t2 + x2_t3)
+                                                            : x2_t1 + alpha * sqrta2minusbdiva(x2_t3, gp * alpha);
+    const S Lcu = x2 - L * L * g * cosc_a - q.x * cos_a;
+    const S Lcv = -L * sinc_a - q.x * sin_a;
+    const S theta_p = 2.0 * (angle + phi1 - kPi / 2.0 - m_atan2(Lcv, Lcu));
+    const S Lc = m_sqrt(Lcu * Lcu + Lcv * Lcv);
+    const S Lp = Lc / sinc1<S>(theta_p / 2.0);
+    const S P = p0c * (1.0 + q.pz);
+    const S E = m_sqrt(P * P + mc2 * mc2);
+    const S E0 = m_sqrt(p0c * p0c + mc2 * mc2);
+    const S beta = P / E, beta0 = p0c / E0;
     q.x = x2;
-    q.px = px_norm * sin(angle + phi1 - theta_p);
+    q.px = px_norm * m_sin(angle + phi1 - theta_p);
     q.y = q.y + q.py * Lp / px_norm;
     q.z = q.z + (beta * L / beta0) - ((1.0 + q.pz) * Lp / px_norm);
 }
 
-template <int KIND>
-__device__ __forceinline__ void dkd_particle(const double* c, Bmad& q, double mc2, int num_steps) {
-    const double p0c = c[C_P0C];
+template <int KIND, typename S>
+__device__ __forceinline__ void dkd_particle(const S* c, Bmad<S>& q, double mc2, int num_steps) {
+    const S p0c = c[C_P0C];
     if (KIND == CHX_DKD_DRIFT) {
-        track_a_drift(c[C_A], q, p0c, mc2);
+        track_a_drift<S>(c[C_A], q, p0c, mc2);
     } else if (KIND == CHX_DKD_QUADRUPOLE) {
-        const double L = c[C_A], b1 = c[C_B];
-        const double step = L / (double)num_steps;
-        offset_set(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
+        const S L = c[C_A], b1 = c[C_B];
+        const S step = L / (double)num_steps;
+        offset_set<S>(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
         // pz does not change inside the magnet, so the per-step coefficients are the same for every step
-        const double rel_p = 1.0 + q.pz;
-        const double k1 = b1 / (L * rel_p);
-        const QuadCoef tx = quad_coefficients(-k1, step, rel_p);
-        const QuadCoef ty = quad_coefficients(k1, step, rel_p);
-        const double dzc = low_energy_z_correction(q.pz, p0c, mc2, step);
+        const S rel_p = 1.0 + q.pz;
+        const S k1 = b1 / (L * rel_p);
+        const QuadCoef<S> tx = quad_coefficients<S>(-k1, step, rel_p);
+        const QuadCoef<S> ty = quad_coefficients<S>(k1, step, rel_p);
+        const S dzc = low_energy_z_correction<S>(q.pz, p0c, mc2, step);
         for (int s = 0; s < num_steps; ++s) {
             q.z = q.z + tx.c1 * (q.x * q.x) + tx.c2 * q.x * q.px + tx.c3 * (q.px * q.px) + ty.c1 * (q.y * q.y) +
                   ty.c2 * q.y * q.py + ty.c3 * (q.py * q.py);
-            const double xn = tx.a11 * q.x + tx.a12 * q.px, pxn = tx.a21 * q.x + tx.a22 * q.px;
-            const double yn = ty.a11 * q.y + ty.a12 * q.py, pyn = ty.a21 * q.y + ty.a22 * q.py;
+            const S xn = tx.a11 * q.x + tx.a12 * q.px, pxn = tx.a21 * q.x + tx.a22 * q.px;
+            const S yn = ty.a11 * q.y + ty.a12 * q.py, pyn = ty.a21 * q.y + ty.a22 * q.py;
             q.x = xn; q.px = pxn; q.y = yn; q.py = pyn;
             q.z = q.z + dzc;
         }
-        offset_unset(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
+        offset_unset<S>(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
     } else if (KIND == CHX_DKD_DIPOLE) {
-        offset_set(0.0, 0.0, c[C_SIN], c[C_COS], q);
+        const S zero = cst<S>(0.0);
+        offset_set<S>(zero, zero, c[C_SIN], c[C_COS], q);
         q.px = q.px + q.x * c[C_H];
         q.py = q.py + q.y * c[C_I];
-        dipole_body(c, q, p0c, mc2);
+        dipole_body<S>(c, q, p0c, mc2);
         q.px = q.px + q.x * c[C_J];
         q.py = q.py + q.y * c[C_N];
-        offset_unset(0.0, 0.0, c[C_SIN], c[C_COS], q);
+        offset_unset<S>(zero, zero, c[C_SIN], c[C_COS], q);
     } else {  // TDC, transverse_deflecting_cavity.py:147-193
-        const double half = c[C_A] / 2.0, volt = c[C_B], k_rf = c[C_C], phase0 = c[C_D], freq = c[C_E2];
-        offset_set(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
-        track_a_drift(half, q, p0c, mc2);
-        const double pc_old = (1.0 + q.pz) * p0c;
-        const double beta_old = pc_old / sqrt(pc_old * pc_old + mc2 * mc2);
-        const double time = -q.z / (beta_old * kC);  // bmadx.py:301-310
-        const double phase = 2.0 * kPi * (phase0 - time * freq);
-        q.px = q.px + volt * sin(phase);
-        const double E_old = pc_old / beta_old;
-        const double E_new = E_old + volt * cos(phase) * k_rf * q.x * p0c;
-        const double pc = sqrt(E_new * E_new - mc2 * mc2);
-        const double beta = pc / E_new;
+        const S half = c[C_A] / 2.0, volt = c[C_B], k_rf = c[C_C], phase0 = c[C_D], freq = c[C_E2];
+        offset_set<S>(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
+        track_a_drift<S>(half, q, p0c, mc2);
+        const S pc_old = (1.0 + q.pz) * p0c;
+        const S beta_old = pc_old / m_sqrt(pc_old * pc_old + mc2 * mc2);
+        const S time = -q.z / (beta_old * kC);  // bmadx.py:301-310
+        const S phase = 2.0 * kPi * (phase0 - time * freq);
+        q.px = q.px + volt * m_sin(phase);
+        const S E_old = pc_old / beta_old;
+        const S E_new = E_old + volt * m_cos(phase) * k_rf * q.x * p0c;
+        const S pc = m_sqrt(E_new * E_new - mc2 * mc2);
+        const S beta = pc / E_new;
         q.pz = (pc - p0c) / p0c;
         q.z = q.z * beta / beta_old;
-        track_a_drift(half, q, p0c, mc2);
-        offset_unset(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
+        track_a_drift<S>(half, q, p0c, mc2);
+        offset_unset<S>(c[C_XO], c[C_YO], c[C_SIN], c[C_COS], q);
     }
+}
+
+// cheetah coordinates -> Bmad -> element -> cheetah (out[0..5])
+template <int KIND, typename S>
+__device__ __forceinline__ void dkd_map(const S* c, const S (&in)[6], double mc2, int num_steps, S (&out)[6]) {
+    Bmad<S> q;
+    q.x = in[0]; q.px = in[1]; q.y = in[2]; q.py = in[3];
+    to_bmad<S>(in[4], in[5], c[C_E], mc2, c[C_P0C], q.z, q.pz);
+    dkd_particle<KIND, S>(c, q, mc2, num_steps);
+    out[0] = q.x; out[1] = q.px; out[2] = q.y; out[3] = q.py;
+    from_bmad<S>(q.z, q.pz, c[C_P0C], mc2, out[4], out[5]);
 }
 
 template <typename T, int KIND>
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
                                                         T* __restrict__ energy_out, int in_vec_ok, int out_vec_ok) {
     constexpr int TP = CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
-    __shared__ double cst[C_N + 1];
+    __shared__ double cst_[C_N + 1];
 
     const int64_t tiles_per_row = (N + TP - 1) / TP;
     const int64_t b = blockIdx.x / tiles_per_row;
@@ -269,7 +295,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
 
     if (threadIdx.x == 0) {
         const T Eb = energy[(Be == 1) ? 0 : b];
-        dkd_constants<T>(KIND, params + ((Bp == 1) ? 0 : b) * P, (double)Eb, mc2, nq, fringe, cst);
+        double par[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) par[k] = (double)params[((Bp == 1) ? 0 : b) * P + k];
+        dkd_constants<double>(KIND, par, (double)Eb, mc2, nq, fringe, cst_);
         if (t == 0 && energy_out) {
             // ref_energy of bmad_to_cheetah_z_pz (bmadx.py:49), in the storage dtype like the reference
             const T m = (T)mc2;
@@ -282,26 +310,100 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
 
     const int p = threadIdx.x;
     if (p < np) {
-        Bmad q;
-        q.x = (double)lds[p * 7 + 0];
-        q.px = (double)lds[p * 7 + 1];
-        q.y = (double)lds[p * 7 + 2];
-        q.py = (double)lds[p * 7 + 3];
-        const double tau = (double)lds[p * 7 + 4], delta = (double)lds[p * 7 + 5];
-        to_bmad(tau, delta, cst[C_E], mc2, cst[C_P0C], q.z, q.pz);
-        dkd_particle<KIND>(cst, q, mc2, num_steps);
-        double tau_o, delta_o;
-        from_bmad(q.z, q.pz, cst[C_P0C], mc2, tau_o, delta_o);
-        lds[p * 7 + 0] = (T)q.x;
-        lds[p * 7 + 1] = (T)q.px;
-        lds[p * 7 + 2] = (T)q.y;
-        lds[p * 7 + 3] = (T)q.py;
-        lds[p * 7 + 4] = (T)tau_o;
-        lds[p * 7 + 5] = (T)delta_o;
+        double in[6], out[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) in[j] = (double)lds[p * 7 + j];
+        dkd_map<KIND, double>(cst_, in, mc2, num_steps, out);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) lds[p * 7 + j] = (T)out[j];
         lds[p * 7 + 6] = (T)1;
     }
     __syncthreads();
     tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec);
+}
+
+// Backward of the above. dx[n][m] = sum_i dY[n][i] d out_i / d in_m (six passes, coordinate m seeded), and per
+// parameter k (then the energy) the workgroup's sum over its particles of dY . d out / d theta_k, written to
+// partials[b][tile][k] — summed by the caller (no atomics: deterministic, and 10 same-address atomics per workgroup
+// would serialise). Forward-mode costs (6 + P + 1) evaluations per particle; the pass stays far cheaper than the
+// reference's autograd graph through ~100 tensor ops per element.
+template <typename T, int KIND>
+__global__ __launch_bounds__(CHX_BLOCK) void dkd_bwd_kernel(const T* __restrict__ x_in, const T* __restrict__ params,
+                                                            const T* __restrict__ energy, const T* __restrict__ dY,
+                                                            double mc2, double nq, int num_steps, int fringe, int P,
+                                                            int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N,
+                                                            T* __restrict__ dx, double* __restrict__ partials) {
+    constexpr int TP = CHX_BLOCK;
+    __shared__ Dual cd[C_N + 1];
+    __shared__ double red[CHX_BLOCK / 64];
+
+    const int64_t tiles_per_row = (N + TP - 1) / TP;
+    const int64_t b = blockIdx.x / tiles_per_row;
+    const int64_t t = blockIdx.x - b * tiles_per_row;
+    const int64_t n = t * TP + threadIdx.x;
+    const bool live = n < N;
+    const int64_t in_row = (Bx == 1) ? 0 : b;
+    const T Eb = energy[(Be == 1) ? 0 : b];
+    const T* par = params + ((Bp == 1) ? 0 : b) * P;
+
+    double xv[6], g[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        xv[j] = live ? (double)x_in[(in_row * N + n) * 7 + j] : 0.0;
+        g[j] = live ? (double)dY[(b * N + n) * 7 + j] : 0.0;
+    }
+
+    auto constants = [&](int seed) {  // seed in [0, P): parameter, P: energy, -1: none
+        if (threadIdx.x == 0) {
+            Dual pd[CHX_MAX_PARAMS];
+            for (int k = 0; k < P; ++k) pd[k] = mk((double)par[k], k == seed ? 1.0 : 0.0);
+            dkd_constants<Dual>(KIND, pd, mk((double)Eb, seed == P ? 1.0 : 0.0), mc2, nq, fringe, cd);
+        }
+        __syncthreads();
+    };
+
+    if (dx) {
+        constants(-1);
+        if (live) {
+#pragma unroll 1
+            for (int m = 0; m < 6; ++m) {
+                Dual in[6], out[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) in[j] = mk(xv[j], j == m ? 1.0 : 0.0);
+                dkd_map<KIND, Dual>(cd, in, mc2, num_steps, out);
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc += g[j] * out[j].d;
+                dx[(b * N + n) * 7 + m] = (T)acc;
+            }
+            dx[(b * N + n) * 7 + 6] = (T)0;
+        }
+        __syncthreads();
+    }
+    if (partials) {
+#pragma unroll 1
+        for (int k = 0; k <= P; ++k) {
+            constants(k);
+            double acc = 0.0;
+            if (live) {
+                Dual in[6], out[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) in[j] = mk(xv[j], 0.0);
+                dkd_map<KIND, Dual>(cd, in, mc2, num_steps, out);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc += g[j] * out[j].d;
+            }
+            acc = chx_wave_sum(acc);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < CHX_BLOCK / 64; ++w) tot += red[w];
+                partials[(b * tiles_per_row + t) * (P + 1) + k] = tot;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 template <typename T, int KIND>
@@ -370,6 +472,68 @@ extern "C" int chx_dkd_track(int kind, const void* x_in, const void* params, con
                                                    fringe_at, B, Bx, Bp, Be, N, x_out, energy_out, s);
 }
 
+namespace {
+template <typename T, int KIND>
+int launch_dkd_bwd(const void* x_in, const void* params, const void* energy, const void* dY, double mc2, double nq,
+                   int num_steps, int fringe, int P, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N, void* dx,
+                   double* partials, hipStream_t s) {
+    const int64_t tiles = ((N + CHX_BLOCK - 1) / CHX_BLOCK) * B;
+    if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL((dkd_bwd_kernel<T, KIND>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const T*)x_in,
+                       (const T*)params, (const T*)energy, (const T*)dY, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be, N,
+                       (T*)dx, partials);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+template <typename T>
+int dispatch_dkd_bwd(int kind, const void* x_in, const void* params, const void* energy, const void* dY, double mc2,
+                     double nq, int num_steps, int fringe, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N,
+                     void* dx, double* partials, hipStream_t s) {
+    const int P = chx_dkd_num_params(kind);
+    switch (kind) {
+        case CHX_DKD_DRIFT:
+            return launch_dkd_bwd<T, CHX_DKD_DRIFT>(x_in, params, energy, dY, mc2, nq, num_steps, fringe, P, B, Bx, Bp,
+                                                    Be, N, dx, partials, s);
+        case CHX_DKD_QUADRUPOLE:
+            return launch_dkd_bwd<T, CHX_DKD_QUADRUPOLE>(x_in, params, energy, dY, mc2, nq, num_steps, fringe, P, B, Bx,
+                                                         Bp, Be, N, dx, partials, s);
+        case CHX_DKD_DIPOLE:
+            return launch_dkd_bwd<T, CHX_DKD_DIPOLE>(x_in, params, energy, dY, mc2, nq, num_steps, fringe, P, B, Bx, Bp,
+                                                     Be, N, dx, partials, s);
+        case CHX_DKD_TDC:
+            return launch_dkd_bwd<T, CHX_DKD_TDC>(x_in, params, energy, dY, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be,
+                                                  N, dx, partials, s);
+    }
+    return CHX_ERR_INVALID_ARG;
+}
+}  // namespace
+
+extern "C" int64_t chx_dkd_bwd_partials_count(int kind, int64_t B, int64_t N) {
+    const int P = chx_dkd_num_params(kind);
+    if (P < 0 || B < 0 || N < 0) return 0;
+    return B * ((N + CHX_BLOCK - 1) / CHX_BLOCK) * (P + 1);
+}
+
+extern "C" int chx_dkd_track_bwd(int kind, const void* x_in, const void* params, const void* energy, const void* dY,
+                                 double mass_eV, double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B,
+                                 int64_t Bx, int64_t Bp, int64_t Be, int64_t N, int dtype, void* dx, double* partials,
+                                 void* stream) {
+    if (chx_dkd_num_params(kind) < 0) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (B < 0 || N < 0) return CHX_ERR_INVALID_ARG;
+    if (B == 0 || N == 0) return CHX_OK;
+    if (!x_in || !params || !energy || !dY || (!dx && !partials)) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    if (kind == CHX_DKD_QUADRUPOLE && num_steps < 1) return CHX_ERR_INVALID_ARG;
+    if (fringe_at < 0 || fringe_at > 3) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == CHX_F32 ? dispatch_dkd_bwd<float>(kind, x_in, params, energy, dY, mass_eV, n_charges, num_steps,
+                                                      fringe_at, B, Bx, Bp, Be, N, dx, partials, s)
+                            : dispatch_dkd_bwd<double>(kind, x_in, params, energy, dY, mass_eV, n_charges, num_steps,
+                                                       fringe_at, B, Bx, Bp, Be, N, dx, partials, s);
+}
+
 // ---------------------------------------------------------------------------------------------
 // second-order tracking: x_out_i = sum_jk T_ijk x_j x_k (element.py:207-217)
 // ---------------------------------------------------------------------------------------------
@@ -436,6 +600,78 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
     tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec);
 }
 
+
+// Backward of second_order_kernel (arithmetic in fp64). With h_c = sum_i dY_i U_ic (28 values per particle)
+//   dx_m = sum_{k >= m} h_(m,k) x_k + sum_{j <= m} h_(j,m) x_j
+// and dU_ic = sum_n dY_i x_j x_k: 196 lanes each own one (i, c) and walk the tile's particles in LDS; a workgroup
+// strides over the tiles of its batch row and writes one 196-vector of partial sums (the caller adds them up and
+// unfolds dT_ijk = dT_ikj = dU_i(jk)).
+constexpr int kSoBwdBlocks = 256;
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void second_order_bwd_kernel(const T* __restrict__ x_in, const T* __restrict__ Tt,
+                                                                     const T* __restrict__ dY, T* __restrict__ dx,
+                                                                     double* __restrict__ dU_partials, int64_t B,
+                                                                     int64_t Bx, int64_t BT, int64_t N) {
+    constexpr int TP = CHX_BLOCK;
+    __shared__ double xs[TP * 7], gs[TP * 7];
+    __shared__ double U[7 * 28];
+    const int64_t b = blockIdx.y;
+    const int64_t in_row = (Bx == 1) ? 0 : b;
+    int ui = 0, uj = 0, uk = 0;
+    if (threadIdx.x < 7 * 28) {
+        ui = threadIdx.x / 28;
+        int r = threadIdx.x - ui * 28;
+        while (r >= 7 - uj) { r -= 7 - uj; ++uj; }
+        uk = uj + r;
+        const T* Tb = Tt + ((BT == 1) ? 0 : b) * 343 + ui * 49;
+        U[threadIdx.x] = (uj == uk) ? (double)Tb[uj * 7 + uk] : (double)Tb[uj * 7 + uk] + (double)Tb[uk * 7 + uj];
+    }
+    double dU = 0.0;
+    const int64_t tiles = (N + TP - 1) / TP;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t n0 = t * TP;
+        const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * 7; e += TP) {
+            xs[e] = (double)x_in[(in_row * N + n0) * 7 + e];
+            gs[e] = (double)dY[(b * N + n0) * 7 + e];
+        }
+        __syncthreads();
+        const int p = threadIdx.x;
+        if (dx && p < np) {
+            double x[7], g[7], h[28];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { x[j] = xs[p * 7 + j]; g[j] = gs[p * 7 + j]; }
+#pragma unroll
+            for (int c = 0; c < 28; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc = fma(g[i], U[i * 28 + c], acc);
+                h[c] = acc;
+            }
+            double d[7] = {0, 0, 0, 0, 0, 0, 0};
+            {
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+#pragma unroll
+                    for (int k = j; k < 7; ++k) {
+                        d[j] = fma(h[c], x[k], d[j]);
+                        d[k] = fma(h[c], x[j], d[k]);
+                        ++c;
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) dx[(b * N + n0 + p) * 7 + j] = (T)d[j];
+        }
+        if (dU_partials && threadIdx.x < 7 * 28) {
+            for (int q = 0; q < np; ++q) dU = fma(gs[q * 7 + ui], xs[q * 7 + uj] * xs[q * 7 + uk], dU);
+        }
+    }
+    if (dU_partials && threadIdx.x < 7 * 28) dU_partials[(b * gridDim.x + blockIdx.x) * 196 + threadIdx.x] = dU;
+}
+
 }  // namespace
 
 extern "C" int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t B, int64_t Bx,
@@ -456,6 +692,27 @@ extern "C" int chx_apply_second_order(const void* x_in, const void* T, void* x_o
         hipLaunchKernelGGL(second_order_kernel<double>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s,
                            (const double*)x_in, (const double*)T, (double*)x_out, B, Bx, BT, N,
                            (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int64_t chx_second_order_bwd_partials_count(int64_t B) { return B * kSoBwdBlocks * 196; }
+
+extern "C" int chx_apply_second_order_bwd(const void* x_in, const void* T, const void* dY, void* dx, double* dU_partials,
+                                          int64_t B, int64_t Bx, int64_t BT, int64_t N, int dtype, void* stream) {
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (B < 0 || N < 0 || B > 65535) return CHX_ERR_INVALID_ARG;
+    if (B == 0 || N == 0) return CHX_OK;
+    if (!x_in || !T || !dY || (!dx && !dU_partials)) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(BT, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(kSoBwdBlocks, (unsigned)B);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(second_order_bwd_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const float*)T,
+                           (const float*)dY, (float*)dx, dU_partials, B, Bx, BT, N);
+    else
+        hipLaunchKernelGGL(second_order_bwd_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
+                           (const double*)T, (const double*)dY, (double*)dx, dU_partials, B, Bx, BT, N);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

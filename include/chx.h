@@ -322,6 +322,15 @@ int chx_dkd_num_params(int kind);
 int chx_dkd_track(int kind, const void* x_in, const void* params, const void* energy, double mass_eV,
                   double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp,
                   int64_t Be, int64_t N, int dtype, void* x_out, void* energy_out, void* stream);
+/* Backward of chx_dkd_track (the reference gets it from torch autograd through utils/bmadx.py): forward-mode dual
+ * numbers on device, one seeded evaluation per input. dx[B][N][7] (dtype, may be NULL) = dY . d x_out / d x_in;
+ * partials (may be NULL) = chx_dkd_bwd_partials_count() doubles laid out [B][ceil(N/256)][P + 1]: per workgroup
+ * sums of dY . d x_out / d theta_k (k < P: params, k = P: energy) — the caller sums axis 1 (deterministic; no
+ * atomics). The gradient of energy_out with respect to energy is the identity. */
+int64_t chx_dkd_bwd_partials_count(int kind, int64_t B, int64_t N);
+int chx_dkd_track_bwd(int kind, const void* x_in, const void* params, const void* energy, const void* dY,
+                      double mass_eV, double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx,
+                      int64_t Bp, int64_t Be, int64_t N, int dtype, void* dx, double* partials, void* stream);
 
 /* Second-order tracking (element.py:195-228): x_out_i = sum_jk T_ijk x_j x_k with the MAD-convention
  * tensors of track_methods.py:80-296 (base_ttensor), the first-order map filled into T[:, 6, :] and the
@@ -336,6 +345,17 @@ int chx_build_ttensor(int kind, const void* params, const void* energy, double m
                       int64_t Be, int dtype, void* T_out, void* stream);
 int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t B, int64_t Bx, int64_t BT,
                            int64_t N, int dtype, void* stream);
+/* Derivatives of the two calls above (reference: torch autograd through track_methods.py:80-296 and the einsum).
+ * chx_build_ttensor_vjp: dparams[B][P], denergy[B] (dtype) = dT[B][343] . dT/dtheta (dual numbers, one workgroup
+ * per (row, input)); rows are NOT reduced when params / energy are broadcast (Bp or Be = 1) — the caller sums.
+ * chx_apply_second_order_bwd: dx[B][N][7] (dtype, may be NULL) and dU_partials (may be NULL) =
+ * chx_second_order_bwd_partials_count(B) doubles [B][256][196]: partial sums of dY_i x_j x_k over particles for
+ * j <= k in the order (i, (0,0),(0,1)..(0,6),(1,1)..(6,6)); dT_ijk = dT_ikj = sum over axis 1. */
+int chx_build_ttensor_vjp(int kind, const void* params, const void* energy, double mass_eV, const void* dT, int64_t B,
+                          int64_t Bp, int64_t Be, int dtype, void* dparams, void* denergy, void* stream);
+int64_t chx_second_order_bwd_partials_count(int64_t B);
+int chx_apply_second_order_bwd(const void* x_in, const void* T, const void* dY, void* dx, double* dU_partials,
+                               int64_t B, int64_t Bx, int64_t BT, int64_t N, int dtype, void* stream);
 
 /* ---- Aperture (aperture.py:90-135): survival_out[B][N] = survival_in * inside, with
  * limits[Bl][2] = (x_max, y_max); rectangular uses strict inequalities, elliptical x^2/x_max^2 + y^2/y_max^2 <= 1,

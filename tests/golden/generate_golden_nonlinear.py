@@ -425,7 +425,65 @@ def gen_cavity_grad():
     save("cavity_grad.npz", **arrays)
 
 
+def gen_nonlinear_grad():
+    """Gradients through drift_kick_drift and second_order tracking (the reference differentiates them with torch
+    autograd through utils/bmadx.py / track_methods.py:80-296): d loss / d (every element parameter, incoming energy,
+    incoming particles) with loss = sum(W * outgoing particles) + 1e-9 * outgoing energy, fp64.
+    NB the reference's second-order gradients are NaN wherever kx2 = k1 + hx^2 is exactly 0 (Drift, Sextupole): the
+    unselected branch of `torch.where(kx2 != 0, ...)` in track_methods.py:134-143 evaluates 0/0 and poisons autograd.
+    Those NaNs are stored as they come; the tests check such entries against finite differences instead."""
+    arrays = {}
+    g = torch.Generator().manual_seed(11)
+    N = 600
+    x = torch.randn(N, 7, generator=g, **F64) * t64([3e-4, 5e-5, 3e-4, 5e-5, 2e-5, 2e-3, 0.0])
+    x[:, 6] = 1.0
+    W = torch.randn(N, 7, generator=g, **F64)
+    arrays["x"], arrays["W"] = npy(x), npy(W)
+    dip = dict(length=0.5, angle=0.2, dipole_e1=0.08, dipole_e2=0.05, tilt=0.1, fringe_integral=0.5,
+               fringe_integral_exit=0.4, gap=0.05)
+    cases = [
+        ("dkd_drift", "Drift", "drift_kick_drift", dict(length=0.8), {}, 1e8),
+        ("dkd_drift_lowE", "Drift", "drift_kick_drift", dict(length=0.8), {}, 4e6),
+        ("dkd_quad", "Quadrupole", "drift_kick_drift", dict(length=0.3, k1=4.2, tilt=0.3, misalignment=[1e-3, -2e-3]),
+         dict(num_steps=5), 1e8),
+        ("dkd_quad_defocus", "Quadrupole", "drift_kick_drift", dict(length=0.2, k1=-7.0), dict(num_steps=1), 2e7),
+        ("dkd_dipole", "Dipole", "drift_kick_drift", dict(gap_exit=0.04, **dip), dict(fringe_at="both"), 6e7),
+        ("dkd_dipole_entrance", "Dipole", "drift_kick_drift", dict(gap_exit=0.04, **dip), dict(fringe_at="entrance"), 6e7),
+        ("dkd_tdc", "TransverseDeflectingCavity", "drift_kick_drift",
+         dict(length=1.0, voltage=1e7, phase=0.2, frequency=1e9, tilt=0.05, misalignment=[2e-4, -1e-4]), {}, 1e8),
+        ("so_drift", "Drift", "second_order", dict(length=0.8), {}, 1e8),
+        ("so_quad", "Quadrupole", "second_order", dict(length=0.3, k1=4.2, tilt=0.3, misalignment=[1e-3, -2e-3]), {}, 1e8),
+        ("so_quad_defocus", "Quadrupole", "second_order", dict(length=0.2, k1=-7.0), {}, 2e7),
+        ("so_dipole", "Dipole", "second_order", dict(k1=0.7, **dip), {}, 6e7),
+        ("so_sextupole", "Sextupole", "second_order", dict(length=0.4, k2=12.0, tilt=0.2, misalignment=[1e-3, 5e-4]), {}, 1e8),
+    ]
+    for name, cls, method, params, opts, E in cases:
+        tensors = {k: torch.nn.Parameter(t64(v)) for k, v in params.items()}
+        energy = t64(E).requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        el = getattr(cheetah, cls)(**tensors, **opts, tracking_method=method, **F64)
+        beam = cheetah.ParticleBeam(xin, energy, species=cheetah.Species("electron", **F64), **F64)
+        out = el.track(beam)
+        loss = (out.particles * W).sum() + 1e-9 * out.energy.sum()
+        loss.backward()
+        arrays[f"{name}__class"] = np.asarray(cls)
+        arrays[f"{name}__method"] = np.asarray(method)
+        arrays[f"{name}__opts"] = np.asarray(repr(opts))
+        arrays[f"{name}__energy"] = np.asarray(E)
+        arrays[f"{name}__pnames"] = np.asarray(list(params))
+        for k, tns in tensors.items():
+            arrays[f"{name}__p__{k}"] = npy(tns.detach())
+            arrays[f"{name}__g__{k}"] = npy(tns.grad)
+        arrays[f"{name}__g_energy"] = npy(energy.grad)
+        arrays[f"{name}__dx"] = npy(xin.grad)
+        arrays[f"{name}__out"] = npy(out.particles.detach())
+        arrays[f"{name}__loss"] = npy(loss.detach())
+        print(name, float(loss), {k: npy(v.grad).tolist() for k, v in tensors.items()}, float(energy.grad))
+    arrays["names"] = np.asarray([c[0] for c in cases])
+    save("nonlinear_grad.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad"]
     for w in which:
         globals()["gen_" + w]()

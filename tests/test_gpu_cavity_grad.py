@@ -92,8 +92,8 @@ def test_forward_only_kernels_refuse_gradients_instead_of_detaching():
     x[:, 6] = 1
     x[:, 0] = torch.linspace(-1e-4, 1e-4, 64, **kw)
     beam = ca.ParticleBeam(x.requires_grad_(True), t(1e8), species=ca.Species("electron", **kw))
-    for el in (ca.Drift(t(1.0), tracking_method="drift_kick_drift", **kw), ca.Sextupole(t(0.2), k2=t(3.0), **kw),
-               ca.SpaceChargeKick(t(0.1), **kw), ca.TransverseDeflectingCavity(t(1.0), voltage=t(1e6), **kw)):
+    # (drift_kick_drift and second_order tracking are differentiable: tests/test_gpu_nonlinear_grad.py)
+    for el in (ca.SpaceChargeKick(t(0.1), **kw),):
         with pytest.raises(NotImplementedError):
             el.track(beam)
         with torch.no_grad():
