@@ -134,6 +134,11 @@ SIGNATURES = {
     "chx_second_order_bwd_partials_count": (c_i64, [c_i64]),
     "chx_apply_second_order_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64,
                                            c_int, c_void_p]),
+    "chx_sc_igf_table_grad": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_sc_gradient_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_sc_gather_kick_bwd_partials_count": (c_i64, [c_i64, c_i64]),
+    "chx_sc_gather_kick_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64,
+                                       c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_time_apply_ms": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_void_p, c_double_p]),
 }
 

@@ -252,7 +252,12 @@ def apply_map(particles: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
 def track_elementwise(particles, maps: torch.Tensor, fused: bool = False) -> torch.Tensor:
     """Apply E maps ([E][BR][7][7]) one after the other without merging them."""
     require_device(particles, maps)
-    forward_only("element-wise (unmerged) tracking", particles, maps)
+    if torch.is_grad_enabled() and (particles.requires_grad or maps.requires_grad):
+        # gradient path: E differentiable passes (Apply); the one-launch kernels below keep no intermediates
+        x = particles
+        for e in range(maps.shape[0]):
+            x = apply_map(x, maps[e] if maps.shape[1] > 1 else maps[e, 0])
+        return x
     E, BR = maps.shape[0], maps.shape[1]
     N = particles.shape[-2]
     batch_shape = torch.broadcast_shapes(particles.shape[:-2], (BR,) if BR > 1 else ())
@@ -794,7 +799,21 @@ class CicDeposit(torch.autograd.Function):
               "chx_cic_deposit_bwd")
         dweight = dweight.reshape(*batch_shape, N)
         dpos = dpos.reshape(*batch_shape, N, nd)
-        d_particles = d_charge = d_survival = None
+        d_particles = d_charge = d_survival = d_extent = d_scale = None
+        if ctx.needs_input_grad[5] or ctx.needs_input_grad[6]:
+            # bin-space position pb = (v - l) / (r - l) * bins - 0.5 with v = scale * x - shift, and dpos = dL/dv:
+            #   dL/dl = -sum dpos (r - v) / (r - l),  dL/dr = -sum dpos (v - l) / (r - l),  dL/dscale = sum dpos x
+            xc = particles.detach()[..., list(cols)]
+            v = xc * scale.unsqueeze(-2) if scale is not None else xc
+            if shift is not None:
+                v = v - shift.unsqueeze(-2)
+            if ctx.needs_input_grad[5]:
+                lo, hi = extent[..., 0].unsqueeze(-2), extent[..., 1].unsqueeze(-2)
+                d_lo = -(dpos * (hi - v) / (hi - lo)).sum(dim=-2)
+                d_hi = -(dpos * (v - lo) / (hi - lo)).sum(dim=-2)
+                d_extent = torch.stack([d_lo, d_hi], dim=-1).sum_to_size(extent.shape)
+            if scale is not None and ctx.needs_input_grad[6]:
+                d_scale = (dpos * xc).sum(dim=-2).sum_to_size(scale.shape)
         if ctx.needs_input_grad[0]:
             if scale is not None:
                 dpos = dpos * scale.unsqueeze(-2)
@@ -808,7 +827,7 @@ class CicDeposit(torch.autograd.Function):
         if survival is not None and ctx.needs_input_grad[2]:
             c_ = (charge.abs() if abs_charge else charge) if charge is not None else 1.0
             d_survival = (dweight * c_).sum_to_size(survival.shape)
-        return d_particles, d_charge, d_survival, None, None, None, None, None, None, None, None
+        return d_particles, d_charge, d_survival, None, None, d_extent, d_scale, None, None, None, None
 
 
 def cic_deposit(particles, cols, bins, extent, charge=None, survival=None, scale=None, shift=None,
@@ -819,7 +838,8 @@ def cic_deposit(particles, cols, bins, extent, charge=None, survival=None, scale
     (the `.mT` of screen.py:339). Differentiable wrt particles / charge / survival.
     """
     if particles.requires_grad or (charge is not None and charge.requires_grad) or (
-            survival is not None and survival.requires_grad):
+            survival is not None and survival.requires_grad) or extent.requires_grad or (
+            scale is not None and scale.requires_grad):
         return CicDeposit.apply(particles, charge, survival, cols, bins, extent, scale, shift, abs_charge,
                                 transpose_2d, mode)
     return _cic_deposit_raw(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge, transpose_2d,
@@ -1042,6 +1062,124 @@ def sc_gather_kick(x, F, half, cell, energy, dt, mass_eV, B, N, bins) -> torch.T
     return out
 
 
+class ScPoisson(torch.autograd.Function):
+    """phi = pot_scale * (G(cell, gamma) * rho) on a power-of-two grid (chx_sc_igf_table + chx_sc_green_spectrum +
+    chx_sc_convolve). The operator is self-adjoint (G is even), so d rho = the same convolution of d phi; the cell /
+    gamma derivatives come from convolving rho with the derivative tables of chx_sc_igf_table_grad."""
+
+    @staticmethod
+    def forward(ctx, rho, cell, gamma, pot_scale, bins):
+        Ghat = sc_green_spectrum(cell, gamma, bins)
+        phi = sc_convolve(rho, Ghat, pot_scale, bins)
+        ctx.save_for_backward(rho, cell, gamma, pot_scale, Ghat, phi)
+        ctx.bins = tuple(bins)
+        return phi
+
+    @staticmethod
+    def backward(ctx, dphi):
+        rho, cell, gamma, pot_scale, Ghat, phi = ctx.saved_tensors
+        bins = ctx.bins
+        B = rho.shape[0]
+        dphi = dphi.contiguous()
+        d_rho = d_cell = d_gamma = d_scale = None
+        if ctx.needs_input_grad[0]:
+            d_rho = sc_convolve(dphi, Ghat, pot_scale, bins)
+        if ctx.needs_input_grad[3]:
+            d_scale = (dphi.double() * phi.double()).sum(dim=(1, 2, 3)) / pot_scale
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            lib = _lib.lib()
+            b3 = _bins3(bins)
+            dt = dtype_code(cell.dtype)
+            n1 = (bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1)
+            tables = torch.empty((3, B, n1), dtype=torch.float64, device=cell.device)
+            check(lib.chx_sc_igf_table_grad(ptr(cell), ptr(gamma), B, b3, dt, ptr(tables), stream_ptr()),
+                  "chx_sc_igf_table_grad")
+            ws_bytes = lib.chx_sc_green_workspace_bytes(B, b3, dt)
+            ws = workspace(ws_bytes, cell.device)
+            sens = []
+            for d in range(3):
+                Gd = torch.empty_like(Ghat)
+                check(lib.chx_sc_green_spectrum(ptr(tables[d]), B, b3, dt, ptr(Gd), ptr(ws), ws_bytes, stream_ptr()),
+                      "chx_sc_green_spectrum")
+                phi_d = sc_convolve(rho, Gd, pot_scale, bins)
+                sens.append((dphi.double() * phi_d.double()).sum(dim=(1, 2, 3)))
+            # third table is the derivative with respect to cell_z * gamma
+            if ctx.needs_input_grad[1]:
+                d_cell = torch.stack([sens[0], sens[1], sens[2] * gamma.double()], dim=-1).to(cell.dtype)
+            if ctx.needs_input_grad[2]:
+                d_gamma = (sens[2] * cell[:, 2].double()).to(gamma.dtype)
+        return d_rho, d_cell, d_gamma, d_scale, None
+
+
+class ScGradient(torch.autograd.Function):
+    """F = -(1/gamma^2) grad phi, packed (B, gx, gy, gz, 4) (chx_sc_gradient / chx_sc_gradient_bwd)."""
+
+    @staticmethod
+    def forward(ctx, phi, cell, gamma, bins):
+        F = sc_gradient(phi, cell, gamma, bins)
+        ctx.save_for_backward(cell, gamma, F)
+        ctx.bins = tuple(bins)
+        return F
+
+    @staticmethod
+    def backward(ctx, dF):
+        cell, gamma, F = ctx.saved_tensors
+        bins = ctx.bins
+        B = F.shape[0]
+        dF = dF.contiguous()
+        d_phi = d_cell = d_gamma = None
+        if ctx.needs_input_grad[0]:
+            d_phi = torch.empty((B, *bins), dtype=F.dtype, device=F.device)
+            check(_lib.lib().chx_sc_gradient_bwd(ptr(dF), ptr(cell), ptr(gamma), B, _bins3(bins), dtype_code(F.dtype),
+                                                 ptr(d_phi), stream_ptr()), "chx_sc_gradient_bwd")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # F_d = -(1/gamma^2) (0.5 / cell_d) (difference): homogeneous of degree -1 in cell_d and -2 in gamma
+            dot = (dF.double() * F.double()).sum(dim=(1, 2, 3))[:, :3]      # (B, 3)
+            if ctx.needs_input_grad[1]:
+                d_cell = (-dot / cell.double()).to(cell.dtype)
+            if ctx.needs_input_grad[2]:
+                d_gamma = (-2.0 * dot.sum(dim=-1) / gamma.double()).to(gamma.dtype)
+        return d_phi, d_cell, d_gamma, None
+
+
+class ScGatherKick(torch.autograd.Function):
+    """Fused SI conversion + trilinear gather + kick (chx_sc_gather_kick); backward = chx_sc_gather_kick_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, F, half, cell, energy, dt, mass_eV, B, N, bins):
+        ctx.save_for_backward(x, F, half, cell, energy, dt)
+        ctx.meta = (mass_eV, B, N, tuple(bins))
+        return sc_gather_kick(x, F, half, cell, energy, dt, mass_eV, B, N, bins)
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, F, half, cell, energy, dt = ctx.saved_tensors
+        mass_eV, B, N, bins = ctx.meta
+        need = ctx.needs_input_grad
+        dY = aligned(dY.contiguous())
+        lib = _lib.lib()
+        dx = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need[0] else None
+        dF = torch.zeros_like(F) if need[1] else None
+        partials = None
+        if need[2] or need[3] or need[4] or need[5]:
+            partials = torch.empty((lib.chx_sc_gather_kick_bwd_partials_count(B, N),), dtype=torch.float64, device=x.device)
+        check(lib.chx_sc_gather_kick_bwd(ptr(x), ptr(F), ptr(half), ptr(cell), ptr(energy), ptr(dt), ptr(dY), mass_eV, B,
+                                         x.shape[0], energy.shape[0], N, _bins3(bins), dtype_code(x.dtype), ptr(dx), ptr(dF),
+                                         ptr(partials), stream_ptr()), "chx_sc_gather_kick_bwd")
+        d_half = d_cell = d_energy = d_dt = None
+        if partials is not None:
+            tot = partials.view(B, -1, 8).sum(dim=1)
+            d_half = tot[:, 0:3].to(half.dtype) if need[2] else None
+            d_cell = tot[:, 3:6].to(cell.dtype) if need[3] else None
+            d_dt = tot[:, 6].to(dt.dtype) if need[5] else None
+            if need[4]:
+                d_energy = tot[:, 7]
+                d_energy = (d_energy.sum(dim=0, keepdim=True) if energy.shape[0] == 1 and B > 1 else d_energy).to(energy.dtype)
+        if dx is not None and x.shape[0] == 1 and B > 1:
+            dx = dx.sum(dim=0, keepdim=True)
+        return dx, dF, d_half, d_cell, d_energy, d_dt, None, None, None, None
+
+
 def _si(fn_name, particles, energy, mass_eV):
     require_device(particles, energy)
     N = particles.shape[-2]
@@ -1069,12 +1207,33 @@ def from_xyz_pxpypz(xp, energy, mass_eV):
 def parameter_track(mu, cov, tm, cavity_coeffs=None, batch_shape=None):
     """mu (…,7), cov (…,7,7), tm (…,7,7) -> (mu', cov') = (tm mu, tm cov tm^T) (element.py:167-179)."""
     require_device(mu, cov, tm)
-    if mu.requires_grad or cov.requires_grad or tm.requires_grad:
+    if mu.requires_grad or cov.requires_grad or tm.requires_grad or (
+            cavity_coeffs is not None and cavity_coeffs.requires_grad):
         # gradient path (tests/test_differentiable.py:58-75): B tiny 7x7 products, left to autograd like compose_maps
-        if cavity_coeffs is not None:
-            forward_only("ParameterBeam tracking through an active Cavity", mu, cov, tm)
         tm_ = tm.to(mu.dtype)
-        return (tm_ @ mu.unsqueeze(-1)).squeeze(-1), tm_ @ cov @ tm_.mT
+        mu_out, cov_out = (tm_ @ mu.unsqueeze(-1)).squeeze(-1), tm_ @ cov @ tm_.mT
+        if cavity_coeffs is None:
+            return mu_out, cov_out
+        # active cavity: the moment updates of parameter_track_kernel as (B,)-sized tensor expressions
+        # (cavity.py:127-133, 202-218); cf = [a, b, k beta0, phi, cos phi, T566, T556, T555] in fp64
+        if batch_shape is None:
+            batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], tm.shape[:-2])
+        cf = cavity_coeffs.reshape(*batch_shape, cavity_coeffs.shape[-1])
+        dt = mu.dtype
+        mu4, mu5 = mu[..., 4].double(), mu[..., 5].double()
+        c44, c45, c55 = cov[..., 4, 4].double(), cov[..., 4, 5].double(), cov[..., 5, 5].double()
+        new5 = mu5 * cf[..., 0] + cf[..., 1] * (torch.cos(-mu4 * cf[..., 2] + cf[..., 3]) - cf[..., 4])
+        add4 = cf[..., 5] * mu5 * mu5 + cf[..., 6] * mu4 * mu5 + cf[..., 7] * mu4 * mu4
+        q = (cf[..., 5] * c55 * c55 + cf[..., 6] * c45 * c55 + cf[..., 7] * c44 * c44).to(dt)
+        mu_out = mu_out.expand(*batch_shape, 7)
+        mu_out = torch.cat([mu_out[..., :4], (mu_out[..., 4].double() + add4).to(dt).unsqueeze(-1),
+                            new5.to(dt).expand(batch_shape).unsqueeze(-1), mu_out[..., 6:]], dim=-1)
+        cov_out = cov_out.expand(*batch_shape, 7, 7).clone()
+        cov_out[..., 5, 5] = c55.to(dt)
+        cov_out[..., 4, 4] = q
+        cov_out[..., 4, 5] = q
+        cov_out[..., 5, 4] = q
+        return mu_out, cov_out
     if batch_shape is None:
         batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], tm.shape[:-2])
     B = numel(batch_shape)

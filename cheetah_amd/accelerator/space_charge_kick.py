@@ -94,8 +94,10 @@ class SpaceChargeKick(Element):
         assert isinstance(incoming, ParticleBeam), \
             "SpaceChargeKick tracking is currently only supported for `ParticleBeam`."
         parts = incoming.particles
-        _ops.forward_only("SpaceChargeKick", parts, incoming.particle_charges, incoming.survival_probabilities,
-                          incoming.energy, self.effect_length)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (
+                parts, incoming.particle_charges, incoming.survival_probabilities, incoming.energy, self.effect_length,
+                self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau)):
+            return self._track_differentiable(incoming)
         dtype, device = parts.dtype, parts.device
         N = parts.shape[-2]
         g = self.grid_shape
@@ -204,6 +206,49 @@ class SpaceChargeKick(Element):
         out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
         return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,
                             particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=incoming.s,
+                            species=incoming.species)
+
+    def _track_differentiable(self, incoming: ParticleBeam) -> ParticleBeam:
+        """The same pipeline as `track`, assembled from differentiable stages (Moments, CicDeposit, ScPoisson,
+        ScGradient, ScGatherKick); the (B,)-sized grid geometry is written as tensor expressions so that autograd links
+        the stages exactly like the reference's tensor code does (space_charge_kick.py:531-575)."""
+        parts = incoming.particles
+        dtype, device = parts.dtype, parts.device
+        g = self.grid_shape
+        if not _ops.sc_pruned_supported(g, dtype):
+            raise NotImplementedError(f"gradients through SpaceChargeKick need a power-of-two grid (16..512), got {g}")
+        N = parts.shape[-2]
+        out_shape = _ops.bshapes(parts.shape[:-2], incoming.energy.shape, incoming.particle_charges.shape[:-1],
+                                 incoming.survival_probabilities.shape[:-1], self.effect_length.shape)
+        B = _ops.numel(out_shape)
+        x = parts.expand(*out_shape, N, 7).reshape(B, N, 7).contiguous()
+        energy = incoming.energy.to(dtype).expand(out_shape).reshape(B).contiguous()
+        q = incoming.particle_charges.expand(*out_shape, N).reshape(B, N)
+        w = incoming.survival_probabilities.expand(*out_shape, N).reshape(B, N)
+        L = self.effect_length.to(dtype).expand(out_shape).reshape(B)
+
+        mom = _ops.moments(x, w.contiguous())                                   # (B, 29) float64, differentiable
+        sigma = mom[:, [8, 19, 26]].sqrt().to(dtype)                            # sigma_x, sigma_y, sigma_tau
+        half = self._grid_extent(dtype) * sigma                                 # (B, 3)
+        gt = torch.tensor([float(v) for v in g], dtype=dtype, device=device)
+        cell = 2 * half / gt
+        gamma = energy / incoming.species.mass_eV_float
+        ig2 = 1 / (gamma * gamma)
+        beta = torch.where(gamma.abs() > 0, (1 - ig2).clamp_min(0).sqrt(), torch.ones_like(gamma))
+        dt = L / (speed_of_light * beta)
+        scale = torch.stack([torch.ones_like(beta), torch.ones_like(beta), -beta], dim=-1)
+        extent = torch.stack([-half, half], dim=-1)
+        G2 = (2 * g[0], 2 * g[1], 2 * g[2])
+        pot_factor = 1.0 / (4 * math.pi * epsilon_0) / float(G2[0] * G2[1] * G2[2])
+        pot_scale = pot_factor / cell.double().prod(dim=-1)
+
+        rho = _ops.cic_deposit(x, (0, 2, 4), g, extent, charge=q, survival=w, scale=scale)
+        phi = _ops.ScPoisson.apply(rho.reshape(B, *g).contiguous(), cell.contiguous(), gamma.contiguous(), pot_scale, g)
+        force = _ops.ScGradient.apply(phi, cell.contiguous(), gamma.contiguous(), g)
+        out = _ops.ScGatherKick.apply(_ops.aligned(x), force, half.contiguous(), cell.contiguous(), energy, dt.contiguous(),
+                                      incoming.species.mass_eV_float, B, N, g)
+        return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s,
                             species=incoming.species)
 

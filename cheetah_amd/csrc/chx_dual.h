@@ -60,3 +60,10 @@ __device__ __forceinline__ Dual m_asin(Dual x) { return mk(asin(x.v), x.d / sqrt
 __device__ __forceinline__ Dual m_atan2(Dual y, Dual x) {
     return mk(atan2(y.v, x.v), (x.v * y.d - y.v * x.d) / (x.v * x.v + y.v * y.v));
 }
+
+__device__ __forceinline__ double m_atan(double x) { return atan(x); }
+__device__ __forceinline__ double m_asinh(double x) { return asinh(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ Dual m_atan(Dual x) { return mk(atan(x.v), x.d / (1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual m_asinh(Dual x) { return mk(asinh(x.v), x.d / sqrt(1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual m_abs(Dual x) { return x.v < 0.0 ? mk(-x.v, -x.d) : x; }

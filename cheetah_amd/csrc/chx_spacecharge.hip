@@ -20,21 +20,9 @@
 #include <new>
 
 #include "chx_common.h"
+#include "chx_sc_math.h"
 
 namespace {
-
-// scipy.constants (CODATA 2022, scipy 1.15.3) as used by the reference
-constexpr double kC = 299792458.0;
-constexpr double kElementaryCharge = 1.602176634e-19;
-constexpr double kEvToKg = 1.7826619216278975e-36;  // physical_constants["electron volt-kilogram relationship"]
-
-// space_charge_kick.py:103-123
-__device__ __forceinline__ double igf_primitive(double x, double y, double t) {
-    const double r = sqrt(x * x + y * y + t * t);
-    return -0.5 * t * t * atan(x * y / (t * r)) - 0.5 * y * y * atan(x * t / (y * r)) -
-           0.5 * x * x * atan(y * t / (x * r)) + y * t * asinh(x / sqrt(y * y + t * t)) +
-           x * t * asinh(y / sqrt(x * x + t * t)) + x * y * asinh(t / sqrt(x * x + y * y));
-}
 
 // table[b][i][j][k] = F((i-1/2) dx, (j-1/2) dy, (k-1/2) dt), i in [0, gx] etc.
 template <typename T>
@@ -53,7 +41,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_table_kernel(const T* __restric
         const int k = (int)(idx % (gz + 1));
         const int j = (int)((idx / (gz + 1)) % (gy + 1));
         const int i = (int)(idx / ((int64_t)(gz + 1) * (gy + 1)));
-        table[b * npts + idx] = igf_primitive((i - 0.5) * dx, (j - 0.5) * dy, (k - 0.5) * dt);
+        table[b * npts + idx] = igf_primitive<double>((i - 0.5) * dx, (j - 0.5) * dy, (k - 0.5) * dt);
     }
 }
 
@@ -143,48 +131,6 @@ __global__ __launch_bounds__(CHX_BLOCK) void gradient_kernel(const T* __restrict
     }
 }
 
-struct RefFrame {
-    double gamma, beta, p0, mc;  // reference gamma/beta, p0 = gamma beta m c, mc = m c
-};
-
-__device__ __forceinline__ RefFrame ref_frame(double energy, double mass_eV) {
-    RefFrame r;
-    r.gamma = energy / mass_eV;                                            // beam.py:323-326
-    r.beta = (fabs(r.gamma) > 0.0) ? sqrt(1.0 - 1.0 / (r.gamma * r.gamma)) : 1.0;  // beam.py:328-336
-    r.mc = mass_eV * kEvToKg * kC;
-    r.p0 = r.gamma * r.beta * r.mc;
-    return r;
-}
-
-// particle_beam.py:1316-1346
-__device__ __forceinline__ void to_si(const RefFrame& r, const double (&v)[7], double (&s)[7]) {
-    const double gi = r.gamma * (1.0 + v[5] * r.beta);
-    const double bi = sqrt(1.0 - 1.0 / (gi * gi));
-    const double P = gi * bi * r.mc;
-    const double px = v[1] * r.p0, py = v[3] * r.p0;
-    s[0] = v[0];
-    s[1] = px;
-    s[2] = v[2];
-    s[3] = py;
-    s[4] = v[4] * -r.beta;
-    s[5] = sqrt(P * P - px * px - py * py);
-    s[6] = v[6];
-}
-
-// particle_beam.py:1262-1314
-__device__ __forceinline__ void from_si(const RefFrame& r, const double (&s)[7], double (&v)[7]) {
-    const double p = sqrt(s[1] * s[1] + s[3] * s[3] + s[5] * s[5]);
-    const double q = p / r.mc;
-    const double g = sqrt(1.0 + q * q);
-    v[0] = s[0];
-    v[1] = s[1] / r.p0;
-    v[2] = s[2];
-    v[3] = s[3] / r.p0;
-    v[4] = -s[4] / r.beta;
-    v[5] = (g - r.gamma) / (r.beta * r.gamma);
-    v[6] = s[6];
-}
-
 // MODE 0: gather + kick (full SpaceChargeKick particle step); 1: to_xyz only; 2: from_xyz only
 template <typename T, int MODE>
 __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
@@ -203,7 +149,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
     const bool vout = chx_aligned16(x_out) && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
     tile_load<T>(x_in + (xrow * N + n0) * 7, lds, np * 7, vin);
     __syncthreads();
-    const RefFrame rf = ref_frame((double)energy[Be == 1 ? 0 : b], mass_eV);
+    const RefFrame<double> rf = ref_frame<double>((double)energy[Be == 1 ? 0 : b], mass_eV);
     const int p = threadIdx.x;
     if (p < np) {
         double v[7], s[7];

@@ -226,6 +226,25 @@ int chx_hist2d(const chx_hist2d_args* args, void* stream);
 int chx_hist2d_indices(const chx_hist2d_args* args, int32_t* ij_out /*[B][N][2], -1 = dropped*/,
                        void* stream);
 
+/* Derivatives of the space-charge kick (the reference differentiates space_charge_kick.py with torch autograd;
+ * tests/test_space_charge_kick.py:202-327). Together with chx_cic_deposit_bwd, chx_moments' backward and the
+ * self-adjoint chx_sc_convolve they make SpaceChargeKick.track differentiable on power-of-two grids.
+ *  - chx_sc_igf_table_grad: tables[3][B][(gx+1)(gy+1)(gz+1)] (double) = d(corner table of chx_sc_igf_table) /
+ *    d(cell_x, cell_y, cell_z * gamma); feeding each through chx_sc_green_spectrum + chx_sc_convolve gives
+ *    d phi / d(that cell size), so dL/dcell = sum(dphi * that).
+ *  - chx_sc_gradient_bwd: dphi[B][gx][gy][gz] = adjoint of chx_sc_gradient (compact phi) applied to dF[B][g^3][4].
+ *  - chx_sc_gather_kick_bwd: dx[B][N][7] (may be NULL); dF[B][g^3][4] (may be NULL; ACCUMULATED with atomics — the
+ *    caller zero-fills); partials (may be NULL) = chx_sc_gather_kick_bwd_partials_count() doubles
+ *    [B][ceil(N/256)][8] = per-workgroup sums of dY . d x_out / d (half[3], cell[3], dt, energy). */
+int chx_sc_igf_table_grad(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype, double* tables,
+                          void* stream);
+int chx_sc_gradient_bwd(const void* dF, const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
+                        void* dphi, void* stream);
+int64_t chx_sc_gather_kick_bwd_partials_count(int64_t B, int64_t N);
+int chx_sc_gather_kick_bwd(const void* x_in, const void* F, const void* half, const void* cell, const void* energy,
+                           const void* dt, const void* dY, double mass_eV, int64_t B, int64_t Bx, int64_t Be, int64_t N,
+                           const int32_t* bins, int dtype, void* dx, void* dF, double* partials, void* stream);
+
 /* ---- space charge (a13; space_charge_kick.py:103-586, particle_beam.py:1262-1346) */
 /* Integrated Green function on the doubled grid (space_charge_kick.py:163-291).
  * cell[B][3] (dtype) = cell sizes (hx,hy,htau); gamma[B] (dtype). fp64 inside; the workspace

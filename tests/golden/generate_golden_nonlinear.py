@@ -483,7 +483,80 @@ def gen_nonlinear_grad():
     save("nonlinear_grad.npz", **arrays)
 
 
+def gen_parameter_cavity_grad():
+    """Gradients through Cavity.track for a ParameterBeam (cavity.py:108-110, 127-133, 202-218): d loss / d (voltage,
+    phase, frequency, length, incoming energy, mu, cov), loss = sum(Wm * mu') + 1e6 sum(Wc * cov') + 1e-15 * energy', fp64."""
+    arrays = {}
+    g = torch.Generator().manual_seed(17)
+    Wm, Wc = torch.randn(7, generator=g, **F64), torch.randn(7, 7, generator=g, **F64)
+    arrays["Wm"], arrays["Wc"] = npy(Wm), npy(Wc)
+    base = cheetah.ParameterBeam.from_parameters(sigma_x=t64(2e-4), sigma_px=t64(4e-6), sigma_y=t64(3e-4),
+                                                 sigma_py=t64(5e-6), sigma_tau=t64(8e-6), sigma_p=t64(2e-3),
+                                                 mu_x=t64(1e-5), mu_tau=t64(2e-6), mu_p=t64(1e-4), cov_taup=t64(3e-9),
+                                                 energy=t64(6e6), **F64)
+    arrays["mu"], arrays["cov"] = npy(base.mu), npy(base.cov)
+    cases = [("sw_acc", "standing_wave", 1.0377, 18.15975e6, 30.0, 1.3e9, 6e6),
+             ("tw_acc", "traveling_wave", 4.139, 2.0e7, -12.0, 2.998e9, 1e8),
+             ("sw_dec", "standing_wave", 1.0377, 5.0e6, 170.0, 1.3e9, 5e7)]
+    for name, ctype, L, V, ph, f, E in cases:
+        length = torch.nn.Parameter(t64(L))
+        voltage, phase, freq = torch.nn.Parameter(t64(V)), torch.nn.Parameter(t64(ph)), torch.nn.Parameter(t64(f))
+        energy = t64(E).requires_grad_(True)
+        mu = base.mu.clone().requires_grad_(True)
+        cov = base.cov.clone().requires_grad_(True)
+        cav = cheetah.Cavity(length=length, voltage=voltage, phase=phase, frequency=freq, cavity_type=ctype, **F64)
+        beam = cheetah.ParameterBeam(mu, cov, energy, species=cheetah.Species("electron", **F64), **F64)
+        out = cav.track(beam)
+        loss = (out.mu * Wm).sum() + 1e6 * (out.cov * Wc).sum() + 1e-15 * out.energy
+        loss.backward()
+        arrays[f"{name}_params"] = np.asarray([L, V, ph, f, E])
+        arrays[f"{name}_type"] = np.asarray(ctype)
+        arrays[f"{name}_loss"] = npy(loss.detach())
+        arrays[f"{name}_mu_out"], arrays[f"{name}_cov_out"] = npy(out.mu.detach()), npy(out.cov.detach())
+        arrays[f"{name}_grads"] = np.asarray([float(length.grad), float(voltage.grad), float(phase.grad), float(freq.grad),
+                                              float(energy.grad)])
+        arrays[f"{name}_dmu"], arrays[f"{name}_dcov"] = npy(mu.grad), npy(cov.grad)
+        print(name, float(loss.detach()), arrays[f"{name}_grads"])
+    arrays["names"] = np.asarray([c[0] for c in cases])
+    save("parameter_cavity_grad.npz", **arrays)
+
+
+def gen_sc_grad():
+    """Gradients through SpaceChargeKick.track (space_charge_kick.py:497-590, differentiated by torch autograd; the
+    reference's own tests/test_space_charge_kick.py:202-327 rely on it): d loss / d (effect_length, incoming energy,
+    incoming particles, particle charges), loss = sum(W * outgoing particles), fp64, 16^3 grid."""
+    arrays = {}
+    g = torch.Generator().manual_seed(23)
+    N = 3000
+    x = torch.randn(N, 7, generator=g, **F64) * t64([3e-4, 2e-5, 2e-4, 3e-5, 1e-5, 1e-3, 0.0])
+    x[:, 6] = 1.0
+    W = torch.randn(N, 7, generator=g, **F64)
+    q0 = torch.full((N,), 2e-9 / N, **F64) * (1.0 + 0.2 * torch.rand(N, generator=g, **F64))
+    arrays["x"], arrays["W"], arrays["q"] = npy(x), npy(W), npy(q0)
+    cases = [("e50MeV", 0.3, 5e7, (16, 16, 16), 3.0), ("e8MeV_anis", 0.1, 8e6, (16, 32, 16), 2.5)]
+    for name, L, E, grid, ext in cases:
+        length = torch.nn.Parameter(t64(L))
+        energy = t64(E).requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        q = q0.clone().requires_grad_(True)
+        sc = cheetah.SpaceChargeKick(effect_length=length, grid_shape=grid, grid_extent_x=t64(ext), grid_extent_y=t64(ext),
+                                     grid_extent_tau=t64(ext), **F64)
+        beam = cheetah.ParticleBeam(xin, energy, particle_charges=q, species=cheetah.Species("electron", **F64), **F64)
+        out = sc.track(beam)
+        loss = (out.particles * W).sum()
+        loss.backward()
+        arrays[f"{name}_meta"] = np.asarray([L, E, ext, *grid])
+        arrays[f"{name}_out"] = npy(out.particles.detach())
+        arrays[f"{name}_loss"] = npy(loss.detach())
+        arrays[f"{name}_grads"] = np.asarray([float(length.grad), float(energy.grad)])
+        arrays[f"{name}_dx"] = npy(xin.grad)
+        arrays[f"{name}_dq"] = npy(q.grad)
+        print(name, float(loss.detach()), arrays[f"{name}_grads"], float(xin.grad.abs().max()), float(q.grad.abs().max()))
+    arrays["names"] = np.asarray([c[0] for c in cases])
+    save("sc_grad.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad", "parameter_cavity_grad", "sc_grad"]
     for w in which:
         globals()["gen_" + w]()

@@ -81,20 +81,3 @@ def test_parameter_beam_gradients_flow():
     assert torch.allclose(out.mu, ref.mu, rtol=1e-13, atol=1e-20) and torch.allclose(out.cov, ref.cov, rtol=1e-12, atol=1e-30)
     out.sigma_x.backward()
     assert beam.cov.grad is not None and float(beam.cov.grad[0, 0]) > 0
-
-
-def test_forward_only_kernels_refuse_gradients_instead_of_detaching():
-    import cheetah_amd as ca
-
-    kw = {"dtype": torch.float64, "device": "cuda"}
-    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
-    x = torch.zeros(64, 7, **kw)
-    x[:, 6] = 1
-    x[:, 0] = torch.linspace(-1e-4, 1e-4, 64, **kw)
-    beam = ca.ParticleBeam(x.requires_grad_(True), t(1e8), species=ca.Species("electron", **kw))
-    # (drift_kick_drift and second_order tracking are differentiable: tests/test_gpu_nonlinear_grad.py)
-    for el in (ca.SpaceChargeKick(t(0.1), **kw),):
-        with pytest.raises(NotImplementedError):
-            el.track(beam)
-        with torch.no_grad():
-            el.track(beam)   # fine without gradient tracking

@@ -1,0 +1,99 @@
+"""Gradients through SpaceChargeKick.track: Moments + CicDeposit + ScPoisson + ScGradient + ScGatherKick (the
+backward kernels of csrc/chx_spacecharge_bwd.hip) against the reference's autograd results (tests/golden/sc_grad.npz,
+fp64) and against the physics check of the reference's own tests (tests/test_space_charge_kick.py:202-261)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KW = {"dtype": torch.float64, "device": "cuda"}
+
+
+def t(v):
+    return torch.tensor(np.asarray(v), **KW)
+
+
+@pytest.mark.parametrize("name", ["e50MeV", "e8MeV_anis"])
+def test_space_charge_gradients_match_reference(golden, name):
+    import cheetah_amd as ca
+
+    g = golden("sc_grad.npz")
+    L, E, ext, gx, gy, gz = g[f"{name}_meta"]
+    length = torch.nn.Parameter(t(L))
+    energy = t(E).requires_grad_(True)
+    xin = t(g["x"]).requires_grad_(True)
+    q = t(g["q"]).requires_grad_(True)
+    W = t(g["W"])
+    sc = ca.SpaceChargeKick(effect_length=length, grid_shape=(int(gx), int(gy), int(gz)), grid_extent_x=t(ext),
+                            grid_extent_y=t(ext), grid_extent_tau=t(ext), **KW)
+    beam = ca.ParticleBeam(xin, energy, particle_charges=q, species=ca.Species("electron", **KW))
+    out = sc.track(beam)
+    assert out.particles.grad_fn is not None
+    ref_out = g[f"{name}_out"]
+    assert np.allclose(out.particles.detach().cpu().numpy(), ref_out, rtol=1e-8, atol=1e-10 * np.abs(ref_out).max(axis=0))
+    # the differentiable pipeline and the fused forward-only pipeline agree
+    with torch.no_grad():
+        fused = sc.track(ca.ParticleBeam(xin.detach(), energy.detach(), particle_charges=q.detach(),
+                                         species=ca.Species("electron", **KW)))
+    assert torch.allclose(fused.particles, out.particles.detach(), rtol=1e-9, atol=1e-14)
+    loss = (out.particles * W).sum()
+    assert float(loss.detach()) == pytest.approx(float(g[f"{name}_loss"]), rel=1e-9)
+    loss.backward()
+    got = np.array([float(length.grad), float(energy.grad)])
+    ref = g[f"{name}_grads"]
+    assert np.allclose(got, ref, rtol=1e-6), (got, ref)
+    dx, dx_ref = xin.grad.cpu().numpy(), g[f"{name}_dx"]
+    scale = np.abs(dx_ref).max(axis=0)
+    assert np.allclose(dx, dx_ref, rtol=1e-6, atol=1e-8 * scale), np.abs(dx - dx_ref).max(axis=0) / scale
+    dq, dq_ref = q.grad.cpu().numpy(), g[f"{name}_dq"]
+    assert np.allclose(dq, dq_ref, rtol=1e-6, atol=1e-8 * np.abs(dq_ref).max())
+
+
+def test_gradient_value_backward_ad():
+    """tests/test_space_charge_kick.py:202-261: d(beam radius)/d(section length) of a cold uniform sphere against the
+    analytic expansion rate, through three kicks and four drifts (default dtype fp32)."""
+    import cheetah_amd as ca
+    from scipy import constants
+    from scipy.constants import physical_constants
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    R0 = tt(0.001)
+    energy = tt(2.5e8)
+    species = ca.Species("electron", **kw)
+    gamma = energy / species.mass_eV
+    beta = (1 - 1 / gamma**2).sqrt()
+    torch.manual_seed(0)
+    incoming = ca.ParticleBeam.uniform_3d_ellipsoid(
+        num_particles=100_000, total_charge=tt(1e-8), energy=energy, radius_x=R0, radius_y=R0,
+        radius_tau=R0 / gamma / beta, sigma_px=tt(1e-15), sigma_py=tt(1e-15), sigma_p=tt(1e-15), species=species, **kw)
+    electron_radius = tt(physical_constants["classical electron radius"][0])
+    kappa = 1 + (tt(2.0).sqrt() / 4) * (3 + 2 * tt(2.0).sqrt()).log()
+    Nb = incoming.total_charge / constants.elementary_charge
+    segment_length = torch.nn.Parameter((beta * gamma * kappa * (R0.pow(3) / (Nb * electron_radius)).sqrt()).detach())
+    segment = ca.Segment(elements=[
+        ca.Drift(segment_length / 6, **kw), ca.SpaceChargeKick(segment_length / 3, **kw),
+        ca.Drift(segment_length / 3, **kw), ca.SpaceChargeKick(segment_length / 3, **kw),
+        ca.Drift(segment_length / 3, **kw), ca.SpaceChargeKick(segment_length / 3, **kw),
+        ca.Drift(segment_length / 6, **kw)])
+    outgoing = segment.track(incoming)
+    # the beam doubles in size over this length (forward check of the same test file, :19-71)
+    assert float(outgoing.sigma_x.detach()) == pytest.approx(2 * float(incoming.sigma_x), rel=0.02)
+    outgoing.sigma_x.backward()
+    dradius_dlength = 5**0.5 * segment_length.grad
+    expected = (Nb * electron_radius / R0).sqrt() / gamma
+    assert float(dradius_dlength) == pytest.approx(float(expected), rel=0.1)
+
+
+def test_non_power_of_two_grid_refuses_gradients():
+    import cheetah_amd as ca
+
+    x = torch.randn(1000, 7, **KW) * 1e-4
+    x[:, 6] = 1.0
+    beam = ca.ParticleBeam(x.requires_grad_(True), t(1e8), species=ca.Species("electron", **KW))
+    sc = ca.SpaceChargeKick(t(0.1), grid_shape=(24, 24, 24), **KW)
+    with pytest.raises(NotImplementedError):
+        sc.track(beam)
+    with torch.no_grad():
+        sc.track(beam)
