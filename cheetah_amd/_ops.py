@@ -53,13 +53,6 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def forward_only(what: str, *tensors) -> None:
-    """Kernels without a backward pass must not silently detach: raise when an input carries gradients."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError(f"{what} is forward-only in this build (no backward kernel); detach the inputs or "
-                                  "run under torch.no_grad()")
-
-
 def ptr(t: torch.Tensor | None):
     return None if t is None else t.data_ptr()
 
