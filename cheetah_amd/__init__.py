@@ -31,5 +31,13 @@ from .accelerator import (  # noqa: F401
     VerticalCorrector,
 )
 from .particles import ParameterBeam, ParticleBeam, Species  # noqa: F401
+from . import converters  # noqa: F401,E402
+from .warnings import (  # noqa: F401,E402
+    DefaultParameterWarning,
+    DirtyNameWarning,
+    NoBeamPropertiesInLatticeWarning,
+    NotUnderstoodPropertyWarning,
+    UnknownElementWarning,
+)
 
 __version__ = "0.1.0"

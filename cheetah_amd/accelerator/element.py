@@ -22,8 +22,7 @@ from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
 
 
-class PhysicsWarning(UserWarning):
-    """Mirror of cheetah.utils.warnings.PhysicsWarning."""
+from ..warnings import DirtyNameWarning, PhysicsWarning  # noqa: E402,F401
 
 
 _name_counter = 0
@@ -58,11 +57,25 @@ class Element(nn.Module):
         super().__init__()
         self.__dict__["_revision"] = 0
         self.name = name if name is not None else _unique_name()
+        if not self.name.isidentifier():  # element.py:44-57
+            if sanitize_name:
+                self.sanitize_name()
+            elif sanitize_name is None:
+                warnings.warn(
+                    f"Dirty element name {self.name} is not a valid Python variable name. You will not be able to use "
+                    "the `segment.element_name` syntax to access this element. Set `sanitize_name=True` to change the "
+                    "name to a valid one, or `sanitize_name=False` to silence this warning.",
+                    category=DirtyNameWarning, stacklevel=2)
         self.metadata = metadata if metadata is not None else {}
         self.register_buffer("length", torch.zeros((), device=device, dtype=dtype))
         if not hasattr(self, "supported_tracking_methods"):
             self.supported_tracking_methods = [self.__class__.__name__.lower()]
         self._tracking_method = self.supported_tracking_methods[0]
+
+    def sanitize_name(self) -> None:
+        """Make the name a valid Python identifier: other characters -> '_', leading digit -> '_' prefix."""
+        clean = "".join(c if c.isalnum() or c == "_" else "_" for c in self.name)
+        self.name = "_" + clean if clean[0].isdigit() else clean
 
     # ---- parameters packed for the builder kernel, in include/chx.h order ------------------------
     def _builder_params(self) -> list[torch.Tensor]:

@@ -53,14 +53,14 @@ class Undulator(Element):
     supported_tracking_methods = ["linear"]
     _chx_kind = _ops.KIND["undulator"]
 
-    def __init__(self, length, kx=None, ky=None, period=None, is_active=False, name=None, sanitize_name=None,
-                 metadata=None, device=None, dtype=None) -> None:
+    def __init__(self, length, period=None, kx=None, ky=None, name=None, sanitize_name=None, metadata=None, device=None,
+                 dtype=None) -> None:
         fk = {"device": device, "dtype": dtype}
         super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
         self.length = length
         self.register_buffer_or_parameter("kx", kx if kx is not None else torch.tensor(0.0, **fk))
         self.register_buffer_or_parameter("ky", ky if ky is not None else torch.tensor(0.0, **fk))
-        self.register_buffer_or_parameter("period", period if period is not None else torch.tensor(0.0, **fk))
+        self.register_buffer_or_parameter("period", period if period is not None else torch.tensor(1.0, **fk))
 
     def _builder_params(self):
         return [self.length, self.kx, self.ky, self.period]
@@ -75,7 +75,7 @@ class Undulator(Element):
 
     @property
     def defining_features(self) -> list[str]:
-        return super().defining_features + ["length", "kx", "ky", "period"]
+        return super().defining_features + ["length", "period", "kx", "ky"]
 
 
 class Sextupole(Element):

@@ -437,6 +437,43 @@ class Segment(Element):
         return Segment(merged, name=self.name)
 
     @classmethod
+    def from_ocelot(cls, cell, name=None, sanitize_names=None, device=None, dtype=None, **kwargs) -> "Segment":
+        """Translate an Ocelot cell (a list of Ocelot elements) element by element (segment.py:404-445)."""
+        from ..converters import ocelot
+
+        converted = [ocelot.convert_element(el, sanitize_name=sanitize_names, device=device, dtype=dtype) for el in cell]
+        return cls(converted, name=name, sanitize_name=sanitize_names, **kwargs)
+
+    @classmethod
+    def from_bmad(cls, bmad_lattice_file_path: str, environment_variables=None, sanitize_names=None, device=None,
+                  dtype=None) -> "Segment":
+        """Read a Bmad lattice file; the line named by its `use` statement is built (segment.py:447-479)."""
+        from pathlib import Path
+
+        from ..converters import bmad
+
+        return bmad.convert_lattice(Path(bmad_lattice_file_path), environment_variables, sanitize_names, device, dtype)
+
+    @classmethod
+    def from_elegant(cls, elegant_lattice_file_path: str, name: str, sanitize_names=None, device=None,
+                     dtype=None) -> "Segment":
+        """Read the beam line `name` of an Elegant lattice file (segment.py:481-507)."""
+        from pathlib import Path
+
+        from ..converters import elegant
+
+        return elegant.convert_lattice(Path(elegant_lattice_file_path), name, sanitize_names, device, dtype)
+
+    @classmethod
+    def from_nx_tables(cls, filepath) -> "Segment":
+        """Read the NX-tables export of the ARES lattice (segment.py:509-523)."""
+        from pathlib import Path
+
+        from ..converters import nxtables
+
+        return nxtables.convert_lattice(Path(filepath))
+
+    @classmethod
     def from_lattice_json(cls, filepath: str, device=None, dtype=None) -> "Segment":
         """Load a LatticeJSON file (segment.py:369-384)."""
         from ..latticejson import load_cheetah_model

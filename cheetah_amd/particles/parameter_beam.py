@@ -92,6 +92,20 @@ class ParameterBeam(Beam):
             cov_ypy=-emittance_y * alpha_y + dy * dpy * sp2, cov_taup=d(cov_taup, 0.0), cov_xp=dx * sp2, cov_pxp=dpx * sp2,
             cov_yp=dy * sp2, cov_pyp=dpy * sp2, energy=d(energy, 1e8), total_charge=total_charge, s=s, species=species,
             device=device, dtype=dtype)
+    @classmethod
+    def from_astra(cls, path: str, device=None, dtype=None) -> "ParameterBeam":
+        """Moments of an Astra particle distribution (parameter_beam.py:444-474, converters/astra.py)."""
+        from ..converters.astra import from_astrabeam
+
+        kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
+        coordinates, energy, charges = from_astrabeam(path)
+        mu = torch.ones(7, **kw)
+        mu[:6] = torch.as_tensor(coordinates.mean(axis=0), **kw)
+        cov = torch.zeros(7, 7, **kw)
+        cov[:6, :6] = torch.as_tensor(coordinates, **kw).T.cov()
+        return cls(mu=mu, cov=cov, energy=torch.as_tensor(energy, **kw), total_charge=torch.as_tensor(charges, **kw).sum(),
+                   species=Species("electron"), **kw)
+
 
     @property
     def defining_features(self) -> list[str]:

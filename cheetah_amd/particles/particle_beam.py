@@ -156,6 +156,78 @@ class ParticleBeam(Beam):
         return beam
 
     # ------------------------------------------------------------------ SI conversion (HIP)
+    # ---- import / export of other codes' particle files (particle_beam.py:834-1033) --------------------------
+    @classmethod
+    def from_astra(cls, path: str, device=None, dtype=None) -> "ParticleBeam":
+        """Load an Astra particle distribution (converters/astra.py)."""
+        from ..converters.astra import from_astrabeam
+
+        kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
+        coordinates, energy, charges = from_astrabeam(path)
+        particles = torch.ones((coordinates.shape[0], 7), **kw)
+        particles[:, :6] = torch.as_tensor(coordinates, **kw)
+        return cls(particles=particles, energy=torch.as_tensor(energy, **kw), particle_charges=torch.as_tensor(charges, **kw),
+                   species=Species("electron", **kw), **kw)
+
+    @classmethod
+    def from_elegant(cls, file_path, device=None, dtype=None) -> "ParticleBeam":
+        """Load an Elegant SDDS particle file (needs the `sdds` package, like the reference)."""
+        from pathlib import Path
+
+        from ..converters import elegant
+
+        kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
+        particles, energy, charges = elegant.convert_beam(Path(file_path), **kw)
+        return cls(particles=particles, energy=energy, particle_charges=charges, species=Species("electron", **kw), **kw)
+
+    @classmethod
+    def from_openpmd_file(cls, path: str, energy: torch.Tensor, device=None, dtype=None) -> "ParticleBeam":
+        """Load an openPMD particle-group HDF5 file (needs openPMD-beamphysics, like the reference)."""
+        try:
+            import pmd_beamphysics as openpmd
+        except ImportError:
+            raise ImportError("To use the openPMD beam import, openPMD-beamphysics must be installed.")
+        return cls.from_openpmd_particlegroup(openpmd.ParticleGroup(path), energy, device=device, dtype=dtype)
+
+    @classmethod
+    def from_openpmd_particlegroup(cls, particle_group, energy: torch.Tensor, device=None, dtype=None) -> "ParticleBeam":
+        """From an openPMD `ParticleGroup` — or any object with its attributes x, y, px, py [eV/c], t [s], energy [eV],
+        weight [C], status, species (particle_beam.py:918-962)."""
+        kw = {"device": device, "dtype": dtype}
+        species = Species(particle_group.species, **kw)
+        energy = torch.as_tensor(energy, **kw)
+        p0c = (energy.square() - species.mass_eV.square()).sqrt()
+        col = lambda v: torch.as_tensor(v, **kw)  # noqa: E731
+        x, y = col(particle_group.x), col(particle_group.y)
+        particles = torch.stack([x, col(particle_group.px) / p0c, y, col(particle_group.py) / p0c,
+                                 col(particle_group.t) * 299792458.0, (col(particle_group.energy) - energy) / p0c,
+                                 torch.ones_like(x)], dim=-1)
+        return cls(particles=particles, energy=energy, particle_charges=col(particle_group.weight),
+                   survival_probabilities=col(particle_group.status), species=species, **kw)
+
+    def openpmd_data(self) -> dict:
+        """The dictionary the reference hands to `pmd_beamphysics.ParticleGroup(data=...)` (particle_beam.py:1009-1031):
+        momenta in eV/c, t = tau / c, boolean status from survival_probabilities > 0.5."""
+        if self.particles.dim() != 2:
+            raise ValueError("Only non-vectorised particle distributions are supported.")
+        px, py = self.px * self.p0c, self.py * self.p0c
+        p_total = (self.energies.square() - self.species.mass_eV.square()).sqrt()
+        pz = (p_total.square() - px.square() - py.square()).sqrt()
+        host = lambda v: v.detach().cpu().numpy()  # noqa: E731
+        return {"x": host(self.x), "y": host(self.y), "z": host(self.tau), "px": host(px), "py": host(py), "pz": host(pz),
+                "t": host(self.tau / 299792458.0), "weight": host(self.particle_charges),
+                "status": host((self.survival_probabilities > 0.5).int()), "species": self.species.name}
+
+    def to_openpmd_particlegroup(self):
+        try:
+            import pmd_beamphysics as openpmd
+        except ImportError:
+            raise ImportError("To use the openPMD beam export, openPMD-beamphysics must be installed.")
+        return openpmd.ParticleGroup(data=self.openpmd_data())
+
+    def save_as_openpmd_h5(self, path: str) -> None:
+        self.to_openpmd_particlegroup().write(path)
+
     def to_xyz_pxpypz(self) -> torch.Tensor:
         """(x, Px, y, Py, z, Pz, 1) in SI units (particle_beam.py:1316-1346) via `chx_to_xyz_pxpypz`."""
         return _ops.to_xyz_pxpypz(self.particles, self.energy, self.species.mass_eV_float)
