@@ -118,6 +118,12 @@ class Element(nn.Module):
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
         return self._cached_map("_map_cache", self._build_map, energy, species)
 
+    def transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
+        """Deprecated name of `first_order_transfer_map` (element.py:67-104)."""
+        warnings.warn("The `transfer_map` method is deprecated and will be removed in a future version. Use "
+                      "`first_order_transfer_map` instead.", DeprecationWarning, stacklevel=2)
+        return self.first_order_transfer_map(energy, species)
+
     def second_order_transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
         """T_ijk with x_out_i = sum_jk T_ijk x_j x_k (element.py:134-148), built on device by chx_build_ttensor."""
         if self._t_kind is None:

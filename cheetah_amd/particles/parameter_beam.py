@@ -93,6 +93,28 @@ class ParameterBeam(Beam):
             cov_yp=dy * sp2, cov_pyp=dpy * sp2, energy=d(energy, 1e8), total_charge=total_charge, s=s, species=species,
             device=device, dtype=dtype)
     @classmethod
+    def from_ocelot(cls, parray, device=None, dtype=None) -> "ParameterBeam":
+        """Moments of an Ocelot `ParticleArray` (parameter_beam.py:416-442)."""
+        kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
+        mu = torch.ones(7, **kw)
+        mu[:6] = torch.as_tensor(parray.rparticles.mean(axis=1), **kw)
+        cov = torch.zeros(7, 7, **kw)
+        cov[:6, :6] = torch.as_tensor(parray.rparticles, **kw).cov()
+        return cls(mu=mu, cov=cov, energy=1e9 * torch.as_tensor(parray.E, **kw),
+                   total_charge=torch.as_tensor(parray.q_array, **kw).sum(), species=Species("electron", **kw), **kw)
+
+    def linspaced(self, num_particles: int):
+        """ParticleBeam with `num_particles` evenly spaced particles and this beam's parameters
+        (parameter_beam.py:566-600)."""
+        from .particle_beam import ParticleBeam
+
+        return ParticleBeam.make_linspaced(
+            num_particles=num_particles, mu_x=self.mu_x, mu_y=self.mu_y, mu_px=self.mu_px, mu_py=self.mu_py,
+            sigma_x=self.sigma_x, sigma_y=self.sigma_y, sigma_px=self.sigma_px, sigma_py=self.sigma_py,
+            sigma_tau=self.sigma_tau, sigma_p=self.sigma_p, energy=self.energy, total_charge=self.total_charge,
+            species=self.species, device=self.mu.device, dtype=self.mu.dtype)
+
+    @classmethod
     def from_astra(cls, path: str, device=None, dtype=None) -> "ParameterBeam":
         """Moments of an Astra particle distribution (parameter_beam.py:444-474, converters/astra.py)."""
         from ..converters.astra import from_astrabeam

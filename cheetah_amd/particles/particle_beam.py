@@ -170,6 +170,16 @@ class ParticleBeam(Beam):
                    species=Species("electron", **kw), **kw)
 
     @classmethod
+    def from_ocelot(cls, parray, device=None, dtype=None) -> "ParticleBeam":
+        """From an Ocelot `ParticleArray` — any object with `rparticles` (6, N), `E` [GeV] and `q_array` [C]
+        (particle_beam.py:804-832)."""
+        kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
+        particles = torch.ones((parray.rparticles.shape[1], 7), **kw)
+        particles[:, :6] = torch.as_tensor(parray.rparticles.transpose(), **kw)
+        return cls(particles=particles, energy=1e9 * torch.as_tensor(parray.E, **kw),
+                   particle_charges=torch.as_tensor(parray.q_array, **kw), species=Species("electron", **kw), **kw)
+
+    @classmethod
     def from_elegant(cls, file_path, device=None, dtype=None) -> "ParticleBeam":
         """Load an Elegant SDDS particle file (needs the `sdds` package, like the reference)."""
         from pathlib import Path
