@@ -151,6 +151,83 @@ __global__ __launch_bounds__(256) void k_quad(const float* __restrict__ x, const
     for (int i = 0; i < 7; ++i) ov[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store(float4 v, float4* p) {
+    v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<v4f*>(p));
+}
+
+// ---- V_wave<PPL>: one WAVE per block (64 lanes), tile = 64 * PPL particles: the barrier only ever waits for the
+// wave's own loads, so waves of a CU drift apart and keep loads, FMAs and stores of different tiles in flight together
+template <int PPL, bool NT>
+__global__ __launch_bounds__(64) void k_wave(const float* __restrict__ x, const float* __restrict__ R,
+                                             float* __restrict__ y, long N) {
+    constexpr int TP = PPL * 64;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const long n0 = (long)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const float4* gv = reinterpret_cast<const float4*>(x + n0 * 7);
+    float4* lv = reinterpret_cast<float4*>(lds);
+    const int nvec = np * 7 / 4;
+    for (int v = threadIdx.x; v < nvec; v += 64) lv[v] = NT ? nt_load(gv + v) : gv[v];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        const int p = threadIdx.x + k * 64;
+        if (p < np) {
+            float a[7], b[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a[j] = lds[p * 7 + j];
+            apply7(R, a, b);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = b[j];
+        }
+    }
+    __syncthreads();
+    float4* ov = reinterpret_cast<float4*>(y + n0 * 7);
+    for (int v = threadIdx.x; v < nvec; v += 64) {
+        if (NT) nt_store(lv[v], ov + v);
+        else ov[v] = lv[v];
+    }
+}
+
+// production tile with non-temporal loads / stores
+template <int PPT, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_tile_nt(const float* __restrict__ x, const float* __restrict__ R,
+                                                 float* __restrict__ y, long N) {
+    constexpr int TP = PPT * 256;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const long n0 = (long)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const float4* gv = reinterpret_cast<const float4*>(x + n0 * 7);
+    float4* lv = reinterpret_cast<float4*>(lds);
+    const int nvec = np * 7 / 4;
+    for (int v = threadIdx.x; v < nvec; v += 256) lv[v] = NTL ? nt_load(gv + v) : gv[v];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + k * 256;
+        if (p < np) {
+            float a[7], b[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a[j] = lds[p * 7 + j];
+            apply7(R, a, b);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = b[j];
+        }
+    }
+    __syncthreads();
+    float4* ov = reinterpret_cast<float4*>(y + n0 * 7);
+    for (int v = threadIdx.x; v < nvec; v += 256) {
+        if (NTS) nt_store(lv[v], ov + v);
+        else ov[v] = lv[v];
+    }
+}
+
 // plain float4 copy of the same bytes: the practical ceiling
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ x, float4* __restrict__ y, long nvec) {
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) y[v] = x[v];
@@ -204,6 +281,38 @@ int main(int argc, char** argv) {
             snprintf(name, 64, "pipe PPT=4 grid=%d", g);
             ms = time_it([&] { hipLaunchKernelGGL(k_pipe<4>, dim3(g), dim3(256), 0, 0, x, R, y, N); }, iters);
             report(name, ms, true);
+        }
+        ms = time_it([&] { hipLaunchKernelGGL((k_wave<2, false>), dim3((N + 127) / 128), dim3(64), 0, 0, x, R, y, N); }, iters);
+        report("wave tile PPL=2", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_wave<4, false>), dim3((N + 255) / 256), dim3(64), 0, 0, x, R, y, N); }, iters);
+        report("wave tile PPL=4", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_wave<8, false>), dim3((N + 511) / 512), dim3(64), 0, 0, x, R, y, N); }, iters);
+        report("wave tile PPL=8", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_wave<4, true>), dim3((N + 255) / 256), dim3(64), 0, 0, x, R, y, N); }, iters);
+        report("wave tile PPL=4 nontemporal", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_tile_nt<2, true, true>), dim3((N + 511) / 512), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=2 nt load+store", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_tile_nt<2, true, false>), dim3((N + 511) / 512), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=2 nt load", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_tile_nt<2, false, true>), dim3((N + 511) / 512), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=2 nt store", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_tile_nt<1, true, true>), dim3((N + 255) / 256), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=1 nt load+store", ms, true);
+        ms = time_it([&] { hipLaunchKernelGGL((k_wave<2, true>), dim3((N + 127) / 128), dim3(64), 0, 0, x, R, y, N); }, iters);
+        report("wave tile PPL=2 nontemporal", ms, true);
+        {   // the way a lattice is tracked: the output of one pass is the input of the next (two buffers)
+            float* a = x; float* b = y;
+            auto pp = [&](auto kernel, dim3 grid, dim3 block) {
+                return time_it([&] { hipLaunchKernelGGL(kernel, grid, block, 0, 0, a, R, b, N); std::swap(a, b); }, iters % 2 ? iters + 1 : iters);
+            };
+            CK(hipMemcpy(y, x, N * 28, hipMemcpyDeviceToDevice));
+            ms = pp(k_tile<2>, dim3((N + 511) / 512), dim3(256)); report("PING-PONG tile PPT=2", ms, false);
+            ms = pp(k_tile_nt<2, true, true>, dim3((N + 511) / 512), dim3(256)); report("PING-PONG tile nt load+store", ms, false);
+            ms = pp(k_tile_nt<2, true, false>, dim3((N + 511) / 512), dim3(256)); report("PING-PONG tile nt load", ms, false);
+            ms = pp(k_tile_nt<2, false, true>, dim3((N + 511) / 512), dim3(256)); report("PING-PONG tile nt store", ms, false);
+            ms = pp(k_wave<2, false>, dim3((N + 127) / 128), dim3(64)); report("PING-PONG wave PPL=2", ms, false);
+            ms = pp(k_wave<2, true>, dim3((N + 127) / 128), dim3(64)); report("PING-PONG wave PPL=2 nt", ms, false);
+            CK(hipMemcpy(x, hx.data(), N * 28, hipMemcpyHostToDevice));
         }
         ms = time_it([&] { hipLaunchKernelGGL(k_direct, dim3((N + 255) / 256), dim3(256), 0, 0, x, R, y, N); }, iters);
         report("direct dword", ms, true);

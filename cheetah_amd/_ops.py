@@ -263,8 +263,7 @@ def track_elementwise(particles, maps: torch.Tensor, fused: bool = False) -> tor
         check(lib.chx_track_fused(ptr(x), ptr(maps), ptr(out), E, B, Bx, BR, N, dtype_code(x.dtype), stream_ptr()),
               "chx_track_fused")
     else:
-        scratch = torch.empty_like(out) if E > 1 else None
-        check(lib.chx_track_elementwise(ptr(x), ptr(maps), ptr(out), ptr(scratch), E, B, Bx, BR, N,
+        check(lib.chx_track_elementwise(ptr(x), ptr(maps), ptr(out), None, E, B, Bx, BR, N,
                                         dtype_code(x.dtype), stream_ptr()), "chx_track_elementwise")
     return out.reshape(*batch_shape, N, 7)
 

@@ -49,32 +49,67 @@ __device__ __forceinline__ void chx_block_sum(double (&v)[K], double* smem /* [4
 
 // ---- LDS tile staging: contiguous 16-byte vector transfers between global memory and an LDS
 // tile (coalesced global_load/store_dwordx4); scalar fallback when the tile start is unaligned.
-template <typename T>
+// Non-temporal 16-byte accesses (the `nt` cache policy of global_load/store_dwordx4): a streaming pass reads every
+// byte once and writes every byte once, so nothing is gained by allocating the lines in L2. Measured on MI355X
+// (benchmarks/apply_variants.hip, two buffers ping-ponged like a tracked lattice): 5.69 -> 6.71 TB/s at 1e6 particles,
+// 5.44 -> 5.90 TB/s at 1.6e7. Not used where other workgroups re-read the same input (a beam shared by a batch).
+typedef float chx_v4f __attribute__((ext_vector_type(4)));
+typedef double chx_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 chx_nt_load(const float4* p) {
+    const chx_v4f v = __builtin_nontemporal_load(reinterpret_cast<const chx_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 chx_nt_load(const double2* p) {
+    const chx_v2d v = __builtin_nontemporal_load(reinterpret_cast<const chx_v2d*>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void chx_nt_store(float4 v, float4* p) {
+    const chx_v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<chx_v4f*>(p));
+}
+__device__ __forceinline__ void chx_nt_store(double2 v, double2* p) {
+    const chx_v2d w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<chx_v2d*>(p));
+}
+
+// TP = particles per tile (compile time, for documentation of the call sites). The copy loops are deliberately left
+// rolled: issuing all ceil(TP * 7 / (VN * 256)) = 4 loads of a lane before the first wait was measured SLOWER on MI355X
+// (apply at 1e6 particles: 8.4 -> 9.4 us repeated, 9.3 -> 11.3 us ping-ponged) — with 8 workgroups per CU the memory
+// system is already oversubscribed and the extra 16 VGPRs cost occupancy.
+template <typename T, int TP>
 __device__ __forceinline__ void tile_load(const T* __restrict__ g, T* __restrict__ lds, int n_elem,
-                                          bool vec_ok) {
+                                          bool vec_ok, bool nt = false) {
     using V = typename chx_vec16<T>::type;
     constexpr int VN = chx_vec16<T>::n;
     if (vec_ok) {
         const int nvec = n_elem / VN;
         const V* __restrict__ gv = reinterpret_cast<const V*>(g);
         V* lv = reinterpret_cast<V*>(lds);
-        for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) lv[v] = gv[v];
+        if (nt) {
+            for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) lv[v] = chx_nt_load(gv + v);
+        } else {
+            for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) lv[v] = gv[v];
+        }
         for (int e = nvec * VN + threadIdx.x; e < n_elem; e += CHX_BLOCK) lds[e] = g[e];
     } else {
         for (int e = threadIdx.x; e < n_elem; e += CHX_BLOCK) lds[e] = g[e];
     }
 }
 
-template <typename T>
+template <typename T, int TP>
 __device__ __forceinline__ void tile_store(T* __restrict__ g, const T* __restrict__ lds, int n_elem,
-                                           bool vec_ok) {
+                                           bool vec_ok, bool nt = false) {
     using V = typename chx_vec16<T>::type;
     constexpr int VN = chx_vec16<T>::n;
     if (vec_ok) {
         const int nvec = n_elem / VN;
         V* __restrict__ gv = reinterpret_cast<V*>(g);
         const V* lv = reinterpret_cast<const V*>(lds);
-        for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) gv[v] = lv[v];
+        if (nt) {
+            for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) chx_nt_store(lv[v], gv + v);
+        } else {
+            for (int v = threadIdx.x; v < nvec; v += CHX_BLOCK) gv[v] = lv[v];
+        }
         for (int e = nvec * VN + threadIdx.x; e < n_elem; e += CHX_BLOCK) g[e] = lds[e];
     } else {
         for (int e = threadIdx.x; e < n_elem; e += CHX_BLOCK) g[e] = lds[e];

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
             energy_out[b] = sqrt(p0 * p0 + m * m);
         }
     }
-    tile_load<T>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec);
+    tile_load<T, TP>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec, !(Bx == 1 && B > 1));
     __syncthreads();
 
     const int p = threadIdx.x;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
         lds[p * 7 + 6] = (T)1;
     }
     __syncthreads();
-    tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec);
+    tile_store<T, TP>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec, true);
 }
 
 // Backward of the above. dx[n][m] = sum_i dY[n][i] d out_i / d in_m (six passes, coordinate m seeded), and per
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
         const T* Tb = Tt + ((BT == 1) ? 0 : b) * 343 + i * 49;
         U[threadIdx.x] = (j == k) ? Tb[j * 7 + k] : Tb[j * 7 + k] + Tb[k * 7 + j];
     }
-    tile_load<T>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec);
+    tile_load<T, TP>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec, !(Bx == 1 && B > 1));
     __syncthreads();
 
     const int p = threadIdx.x;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
         for (int j = 0; j < 7; ++j) lds[p * 7 + j] = y[j];
     }
     __syncthreads();
-    tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec);
+    tile_store<T, TP>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec, true);
 }
 
 

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
     const int64_t xrow = (Bx == 1) ? 0 : b;
     const bool vin = chx_aligned16(x_in) && (((xrow * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
     const bool vout = chx_aligned16(x_out) && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
-    tile_load<T>(x_in + (xrow * N + n0) * 7, lds, np * 7, vin);
+    tile_load<T, TP>(x_in + (xrow * N + n0) * 7, lds, np * 7, vin, Bx != 1 || gridDim.y == 1);
     __syncthreads();
     const RefFrame<double> rf = ref_frame<double>((double)energy[Be == 1 ? 0 : b], mass_eV);
     const int p = threadIdx.x;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
         }
     }
     __syncthreads();
-    tile_store<T>(x_out + (b * N + n0) * 7, lds, np * 7, vout);
+    tile_store<T, TP>(x_out + (b * N + n0) * 7, lds, np * 7, vout, true);
 }
 
 inline dim3 cell_grid(int64_t n, int64_t B) {

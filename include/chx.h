@@ -109,7 +109,8 @@ int chx_apply_affine7_bwd(const void* dY, const void* R, const void* X, void* dX
 
 /* Element-by-element tracking of a run of E linear elements WITHOUT merging the maps
  * (`for e in elements: beam = e.track(beam)`, segment.py:571-572): E apply passes
- * ping-ponging between x_out and scratch ([B][N][7]); the final result is in x_out. */
+ * pass 0 writes x_out, later passes update x_out in place (tile-local read-then-write); `scratch` is ignored (kept for
+ * ABI stability, may be NULL). x_out must not alias x_in. */
 int chx_track_elementwise(const void* x_in, const void* R /*[E][BR][7][7]*/, void* x_out,
                           void* scratch, int64_t E, int64_t B, int64_t Bx, int64_t BR,
                           int64_t N, int dtype, void* stream);
