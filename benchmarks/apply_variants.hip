@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256) void k_tile_nt(const float* __restrict__ x, co
     }
 }
 
+__global__ __launch_bounds__(256) void k_copy_nt(const float4* __restrict__ x, float4* __restrict__ y, long nvec) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) nt_store(nt_load(x + v), y + v);
+}
+
 // plain float4 copy of the same bytes: the practical ceiling
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ x, float4* __restrict__ y, long nvec) {
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) y[v] = x[v];
@@ -318,6 +322,14 @@ int main(int argc, char** argv) {
         report("direct dword", ms, true);
         ms = time_it([&] { hipLaunchKernelGGL(k_quad, dim3((N / 4 + 256) / 256), dim3(256), 0, 0, x, R, y, N); }, iters);
         report("quad (4 rows/lane, float4)", ms, true);
+        for (int g : {1024, 2048, 4096, 8192}) {
+            char name[64];
+            snprintf(name, 64, "float4 copy NT grid=%d", g);
+            ms = time_it([&] { hipLaunchKernelGGL(k_copy_nt, dim3(g), dim3(256), 0, 0, (const float4*)x, (float4*)y, N * 7 / 4); }, iters);
+            report(name, ms, false);
+        }
+        ms = time_it([&] { hipLaunchKernelGGL((k_tile_nt<4, true, true>), dim3((N + 1023) / 1024), dim3(256), 0, 0, x, R, y, N); }, iters);
+        report("tile PPT=4 nt load+store", ms, true);
         for (int g : {1024, 2048, 4096, 8192}) {
             char name[64];
             snprintf(name, 64, "float4 copy grid=%d", g);

@@ -337,9 +337,9 @@ class Segment(Element):
 
     def flattened(self) -> "Segment":
         flat = []
-        for e in self.elements:
-            flat += list(e.flattened().elements) if isinstance(e, Segment) else [e]
-        return Segment(flat, name=self.name)
+        for e in self.elements:   # anything that can flatten itself does (sub-segments, Superimposed): segment.py:143-157
+            flat += list(e.flattened().elements) if hasattr(e, "flattened") else [e]
+        return self.__class__(elements=flat, name=self.name, sanitize_name=False)
 
     def reversed(self) -> "Segment":
         elements = [e.reversed() if isinstance(e, Segment) else e for e in self.elements][::-1]
