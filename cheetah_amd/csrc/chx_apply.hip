@@ -14,6 +14,8 @@
 //    scalar cache (s_load), only tiles straddling a batch boundary fall back to per-lane loads;
 //  * fp32 rows are evaluated as an fmaf chain in the order j=0..6 (same sequence in the single
 //    pass, element-wise and fused kernels, so those agree bit for bit).
+#include <type_traits>
+
 #include "chx_common.h"
 
 namespace {
@@ -84,6 +86,52 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_tile_kernel(
     if (MODE == 1) {
         // fused run: all PPT rows of the lane stay in registers; the element loop is OUTSIDE the row loop so
         // that every map is fetched into SGPRs once per lane and reused for PPT x 49 FMAs
+        if constexpr (std::is_same<T, float>::value && (PPT % 2 == 0)) {
+            // fp32: two particles of the lane share one 64-bit register pair, so every step of the fmaf chain is ONE
+            // v_pk_fma_f32 for both (the map entry is a scalar operand): 49 packed FMAs per pair and element, the
+            // same per-particle operation order as apply7 -> bit-identical results, twice the FMA issue rate
+            chx_v2f xp[PPT / 2][7];
+#pragma unroll
+            for (int q = 0; q < PPT / 2; ++q) {
+                const int p0 = threadIdx.x + (2 * q) * CHX_BLOCK, p1 = p0 + CHX_BLOCK;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    xp[q][j].x = (p0 < np) ? lds[p0 * 7 + j] : 0.f;
+                    xp[q][j].y = (p1 < np) ? lds[p1 * 7 + j] : 0.f;
+                }
+            }
+            for (int e = 0; e < E; ++e) {
+                const float* __restrict__ Re = R + ((int64_t)e * BR + rb) * 49;
+#pragma unroll
+                for (int q = 0; q < PPT / 2; ++q) {
+                    chx_v2f y[7];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        chx_v2f acc = xp[q][0] * Re[i * 7];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) {
+                            const chx_v2f r = {Re[i * 7 + j], Re[i * 7 + j]};
+                            acc = __builtin_elementwise_fma(r, xp[q][j], acc);
+                        }
+                        y[i] = acc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) xp[q][j] = y[j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PPT / 2; ++q) {
+                const int p0 = threadIdx.x + (2 * q) * CHX_BLOCK, p1 = p0 + CHX_BLOCK;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    if (p0 < np) lds[p0 * 7 + j] = xp[q][j].x;
+                    if (p1 < np) lds[p1 * 7 + j] = xp[q][j].y;
+                }
+            }
+            __syncthreads();
+            tile_store<T, TP>(gout, lds, np * 7, out_vec, true);
+            return;
+        }
         T xs[PPT][7];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {

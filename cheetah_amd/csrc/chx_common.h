@@ -53,6 +53,7 @@ __device__ __forceinline__ void chx_block_sum(double (&v)[K], double* smem /* [4
 // byte once and writes every byte once, so nothing is gained by allocating the lines in L2. Measured on MI355X
 // (benchmarks/apply_variants.hip, two buffers ping-ponged like a tracked lattice): 5.69 -> 6.71 TB/s at 1e6 particles,
 // 5.44 -> 5.90 TB/s at 1.6e7. Not used where other workgroups re-read the same input (a beam shared by a batch).
+typedef float chx_v2f __attribute__((ext_vector_type(2)));
 typedef float chx_v4f __attribute__((ext_vector_type(4)));
 typedef double chx_v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 chx_nt_load(const float4* p) {
