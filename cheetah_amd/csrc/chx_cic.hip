@@ -76,6 +76,9 @@ __device__ __forceinline__ T cic_charge(const CicDev& a, const T* __restrict__ q
     return c;
 }
 
+constexpr int kCombSlots = 2048;  // 32 KiB of LDS per workgroup
+constexpr int kCombProbes = 4;
+
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const T* __restrict__ x,
                                                                const T* __restrict__ q,
@@ -84,13 +87,36 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
                                                                const T* __restrict__ scale,
                                                                const T* __restrict__ shift,
                                                                T* __restrict__ grid) {
+    // Per-workgroup combining table in LDS: a focused beam puts thousands of particles on a handful of pixels, and
+    // same-address global atomics serialise in L2 (measured: 159 us for 1e4 particles of the ARES example on its screen).
+    // Contributions are first summed per cell in an open-addressed LDS table (fp64 values, ds_add_f64 is the fast LDS
+    // atomic on gfx950), one global atomic per occupied slot at the end; a cell that finds no slot within kCombProbes
+    // goes to global memory directly, so a diffuse beam loses nothing.
+    __shared__ long long keys[kCombSlots];
+    __shared__ double vals[kCombSlots];
+    for (int i = threadIdx.x; i < kCombSlots; i += CHX_BLOCK) { keys[i] = -1; vals[i] = 0.0; }
+    __syncthreads();
     const int64_t b = blockIdx.y;
+    T* g = grid + b * a.gbatch;
+    auto add = [&](int64_t off, T v) {
+        unsigned h = (unsigned)((unsigned long long)off * 0x9E3779B97F4A7C15ull >> 40) & (kCombSlots - 1);
+#pragma unroll
+        for (int probe = 0; probe < kCombProbes; ++probe) {
+            const long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), (unsigned long long)-1LL,
+                                             (unsigned long long)off);
+            if (prev == -1LL || prev == (long long)off) {
+                unsafeAtomicAdd(&vals[h], (double)v);
+                return;
+            }
+            h = (h + 1) & (kCombSlots - 1);
+        }
+        unsafeAtomicAdd(g + off, v);
+    };
     for (int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; n < a.N;
          n += (int64_t)gridDim.x * CHX_BLOCK) {
         const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n);
         if (!pt.inside) continue;  // masked_charges == 0 (cloud_in_cell.py:150-156)
         const T c = cic_charge<T>(a, q, s, b, n);
-        T* g = grid + b * a.gbatch;
         T wf[3][2];
         int64_t off[3][2];
         bool ok[3][2];
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
         if (a.ndim == 1) {
 #pragma unroll
             for (int ox = 0; ox < 2; ++ox)
-                if (ok[0][ox]) unsafeAtomicAdd(g + off[0][ox], c * wf[0][ox]);
+                if (ok[0][ox]) add(off[0][ox], c * wf[0][ox]);
         } else if (a.ndim == 2) {
             // src = masked_charges * wx * wy  (cloud_in_cell.py:216-239), y outer / x inner order
 #pragma unroll
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
 #pragma unroll
                 for (int ox = 0; ox < 2; ++ox)
                     if (ok[0][ox] && ok[1][oy])
-                        unsafeAtomicAdd(g + off[0][ox] + off[1][oy], c * wf[0][ox] * wf[1][oy]);
+                        add(off[0][ox] + off[1][oy], c * wf[0][ox] * wf[1][oy]);
         } else {
             // weight = wx * wy * wz ; src = masked_charges * weight (cloud_in_cell.py:368-382)
 #pragma unroll
@@ -132,10 +158,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
 #pragma unroll
                     for (int oz = 0; oz < 2; ++oz)
                         if (ok[0][ox] && ok[1][oy] && ok[2][oz])
-                            unsafeAtomicAdd(g + off[0][ox] + off[1][oy] + off[2][oz],
-                                            c * (wf[0][ox] * wf[1][oy] * wf[2][oz]));
+                            add(off[0][ox] + off[1][oy] + off[2][oz], c * (wf[0][ox] * wf[1][oy] * wf[2][oz]));
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kCombSlots; i += CHX_BLOCK)
+        if (keys[i] != -1) unsafeAtomicAdd(g + keys[i], (T)vals[i]);
 }
 
 template <typename T>
