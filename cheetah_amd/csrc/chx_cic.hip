@@ -76,8 +76,44 @@ __device__ __forceinline__ T cic_charge(const CicDev& a, const T* __restrict__ q
     return c;
 }
 
+// Per-workgroup combining table in LDS: a focused beam puts thousands of particles on a handful of cells, and
+// same-address global atomics serialise in L2 (measured: 159 us for 1e4 particles of the ARES example on its screen,
+// 3-4 ms for 1e6 particles focused to half a pixel). Contributions are first summed per cell in an open-addressed LDS
+// table (fp64 values: ds_add_f64 is the fast LDS atomic on gfx950), one global atomic per occupied slot at the end; a
+// cell that finds no slot within kCombProbes goes to global memory directly, so a diffuse beam loses nothing.
 constexpr int kCombSlots = 2048;  // 32 KiB of LDS per workgroup
 constexpr int kCombProbes = 4;
+
+template <typename T>
+struct CombTable {
+    long long* keys;
+    double* vals;
+    T* g;
+    __device__ __forceinline__ void init(long long* k, double* v, T* grid) {
+        keys = k; vals = v; g = grid;
+        for (int i = threadIdx.x; i < kCombSlots; i += blockDim.x) { keys[i] = -1; vals[i] = 0.0; }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void add(int64_t off, T v) {
+        unsigned h = (unsigned)((unsigned long long)off * 0x9E3779B97F4A7C15ull >> 40) & (kCombSlots - 1);
+#pragma unroll
+        for (int probe = 0; probe < kCombProbes; ++probe) {
+            const long long prev = (long long)atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]),
+                                                        (unsigned long long)-1LL, (unsigned long long)off);
+            if (prev == -1LL || prev == (long long)off) {
+                unsafeAtomicAdd(&vals[h], (double)v);
+                return;
+            }
+            h = (h + 1) & (kCombSlots - 1);
+        }
+        unsafeAtomicAdd(g + off, v);
+    }
+    __device__ __forceinline__ void flush() {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kCombSlots; i += blockDim.x)
+            if (keys[i] != -1) unsafeAtomicAdd(g + keys[i], (T)vals[i]);
+    }
+};
 
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const T* __restrict__ x,
@@ -87,31 +123,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
                                                                const T* __restrict__ scale,
                                                                const T* __restrict__ shift,
                                                                T* __restrict__ grid) {
-    // Per-workgroup combining table in LDS: a focused beam puts thousands of particles on a handful of pixels, and
-    // same-address global atomics serialise in L2 (measured: 159 us for 1e4 particles of the ARES example on its screen).
-    // Contributions are first summed per cell in an open-addressed LDS table (fp64 values, ds_add_f64 is the fast LDS
-    // atomic on gfx950), one global atomic per occupied slot at the end; a cell that finds no slot within kCombProbes
-    // goes to global memory directly, so a diffuse beam loses nothing.
     __shared__ long long keys[kCombSlots];
     __shared__ double vals[kCombSlots];
-    for (int i = threadIdx.x; i < kCombSlots; i += CHX_BLOCK) { keys[i] = -1; vals[i] = 0.0; }
-    __syncthreads();
     const int64_t b = blockIdx.y;
-    T* g = grid + b * a.gbatch;
-    auto add = [&](int64_t off, T v) {
-        unsigned h = (unsigned)((unsigned long long)off * 0x9E3779B97F4A7C15ull >> 40) & (kCombSlots - 1);
-#pragma unroll
-        for (int probe = 0; probe < kCombProbes; ++probe) {
-            const long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), (unsigned long long)-1LL,
-                                             (unsigned long long)off);
-            if (prev == -1LL || prev == (long long)off) {
-                unsafeAtomicAdd(&vals[h], (double)v);
-                return;
-            }
-            h = (h + 1) & (kCombSlots - 1);
-        }
-        unsafeAtomicAdd(g + off, v);
-    };
+    CombTable<T> table;
+    table.init(keys, vals, grid + b * a.gbatch);
+    auto add = [&](int64_t off, T v) { table.add(off, v); };
     for (int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; n < a.N;
          n += (int64_t)gridDim.x * CHX_BLOCK) {
         const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n);
@@ -161,9 +178,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
                             add(off[0][ox] + off[1][oy] + off[2][oz], c * (wf[0][ox] * wf[1][oy] * wf[2][oz]));
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kCombSlots; i += CHX_BLOCK)
-        if (keys[i] != -1) unsafeAtomicAdd(g + keys[i], (T)vals[i]);
+    table.flush();
 }
 
 template <typename T>
@@ -266,7 +281,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void hist2d_kernel(HistDev a, const T* _
                                                           const T* __restrict__ ey,
                                                           T* __restrict__ image,
                                                           int32_t* __restrict__ ij) {
+    __shared__ long long keys[INDICES ? 1 : kCombSlots];
+    __shared__ double vals[INDICES ? 1 : kCombSlots];
     const int64_t b = blockIdx.y;
+    CombTable<T> table;
+    if (!INDICES) table.init(keys, vals, image + b * (int64_t)a.ny * a.nx);
     for (int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; n < a.N;
          n += (int64_t)gridDim.x * CHX_BLOCK) {
         const int64_t xrow = (a.Bx == 1 ? 0 : b) * a.N + n;
@@ -284,9 +303,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void hist2d_kernel(HistDev a, const T* _
         } else if (jx >= 0) {
             T c = q ? fabs(q[(a.Bq == 1 ? 0 : b) * a.N + n]) : (T)1;
             if (s) c = c * s[(a.Bs == 1 ? 0 : b) * a.N + n];
-            unsafeAtomicAdd(image + (b * a.ny + jy) * (int64_t)a.nx + jx, c);
+            table.add((int64_t)jy * a.nx + jx, c);
         }
     }
+    if (!INDICES) table.flush();
 }
 
 int cic_prepare(const chx_cic_args* p, CicDev& a) {
@@ -323,6 +343,17 @@ int cic_prepare(const chx_cic_args* p, CicDev& a) {
     return CHX_OK;
 }
 
+// grid of the kernels that combine in LDS first: ~1024 workgroups in total, each strides over many particles so that
+// its table absorbs as much as possible before the flush
+inline dim3 combine_grid(int64_t N, int64_t B) {
+    int64_t g = (N + CHX_BLOCK - 1) / CHX_BLOCK;
+    int64_t cap = 1024 / B;
+    if (cap < 1) cap = 1;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g, (unsigned)B);
+}
+
 inline dim3 particle_grid(int64_t N, int64_t B) {
     int64_t g = (N + CHX_BLOCK - 1) / CHX_BLOCK;
     int64_t cap = 8192 / B;  // grid-stride beyond ~8k workgroups in total
@@ -346,7 +377,8 @@ inline dim3 particle_grid(int64_t N, int64_t B) {
 //                     in LDS by every workgroup of pass 3, which saves a launch)
 //   pass 3  scatter   records {i_d, f_d, charge} into their tile's slot range (LDS cursors)
 //   pass 4  accumulate one workgroup per tile: ds_add of the corners that fall into the OWNED cells, then a
-//                     plain, coalesced `grid += tile` (no global atomics anywhere, no halo exchange)
+//                     plain, coalesced `grid += tile` (no halo exchange); the overflow of hot tiles (beams focused
+//                     into a few cells) is load-balanced over chunks of the record array by pass 4b
 // The index / weight arithmetic is the one of cic_locate / cic_deposit_kernel above (bit-identical addends).
 template <typename T, int ND>
 struct CicRec {
@@ -380,6 +412,7 @@ __host__ __device__ inline TileGeom tile_geom(int ndim, const int* bins) {
     return g;
 }
 
+constexpr int kAccTileCap = 8192;   // records of a tile handled by its owner workgroup (a +-3 sigma Gaussian stays below)
 constexpr int kSortWG = 256;       // workgroups of the count / scatter passes (per batch row)
 constexpr int kSortThreads = 1024;  // threads of those workgroups (latency-bound loops: many waves)
 
@@ -450,12 +483,25 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
     } else {
         // pass 2b folded in: every workgroup scans the tile totals itself (nt <= 16k ints in LDS), workgroup 0
         // publishes the tile starts for pass 4; cursor = tile start + this workgroup's offset inside the tile
-        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] = totals[b * g.nt + t];
+        __shared__ int fullest;
+        if (threadIdx.x == 0) fullest = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int t = threadIdx.x; t < g.nt; t += kSortThreads) {
+            const int c = totals[b * g.nt + t];
+            hist[t] = c;
+            mine = c > mine ? c : mine;
+        }
+        if (wg == 0 && mine > kAccTileCap) atomicMax(&fullest, mine);
         __syncthreads();
         const int sum = block_exclusive_scan(hist, g.nt);
         if (wg == 0) {
             for (int t = threadIdx.x; t < g.nt; t += kSortThreads) tile_start[b * (g.nt + 1) + t] = hist[t];
-            if (threadIdx.x == 0) tile_start[b * (g.nt + 1) + g.nt] = sum;
+            if (threadIdx.x == 0) {
+                tile_start[b * (g.nt + 1) + g.nt] = sum;
+                // one flag per batch row behind the starts: does any tile overflow into pass 4b?
+                tile_start[(int64_t)gridDim.y * (g.nt + 1) + b] = fullest > kAccTileCap ? 1 : 0;
+            }
         }
         for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] += cnt[t];
     }
@@ -519,7 +565,8 @@ __global__ __launch_bounds__(1024) void cic_scan_tiles_kernel(int* __restrict__ 
     }
 }
 
-// pass 4: one workgroup per (tile, batch row); LDS tile = exactly the owned cells
+// pass 4a: one workgroup per (tile, batch row); LDS tile = exactly the owned cells. Takes the first kAccTileCap records
+// of its tile; what a hot tile holds beyond that is spread over many workgroups by pass 4b.
 constexpr int kAccThreads = 1024;  // a hot tile is latency-bound on its record stream: many waves per tile
 
 template <typename T, int ND>
@@ -536,6 +583,7 @@ __global__ __launch_bounds__(kAccThreads) void cic_accumulate_kernel(CicDev a, T
     const int beg = tile_start[b * (g.nt + 1) + t];
     int end = tile_start[b * (g.nt + 1) + t + 1];
     if (end > rec_cap) end = (int)rec_cap;
+    if (end > beg + kAccTileCap) end = beg + kAccTileCap;
     if (beg >= end) return;  // empty tile: nothing to add
     int ld[3], org[3];       // owned extents and cell origin
     {
@@ -621,6 +669,139 @@ __global__ __launch_bounds__(kAccThreads) void cic_accumulate_kernel(CicDev a, T
     }
 }
 
+// pass 4b: hot tiles. The sorted record array is cut into chunks of kAccChunk records, one workgroup per (chunk, batch
+// row); it handles, for every tile overlapping its chunk, the records BEYOND the first kAccTileCap of that tile (those
+// belong to pass 4a) and adds its LDS tile to the grid with atomics. For a +-3 sigma beam no tile is that full and every
+// workgroup leaves after a binary search; a beam focused into one tile (1e6 particles inside 16 x 16 pixels) is spread
+// over 500 workgroups instead of serialising in one (measured: 3.0 ms -> 0.1 ms for a Screen reading).
+constexpr int kAccChunk = 2048;    // records per workgroup of pass 4b
+
+template <typename T, int ND>
+__global__ __launch_bounds__(kAccThreads) void cic_accumulate_hot_kernel(CicDev a, TileGeom g,
+                                                                  const int* __restrict__ tile_start,
+                                                                  const CicRec<T, ND>* __restrict__ recs,
+                                                                  int64_t rec_cap, T* __restrict__ grid) {
+    // The LDS tile is fp64 for both dtypes: measured on MI355X (benchmarks/lds_atomic_rate.hip) ds_add_f64
+    // sustains 5.7 G lane-atomics/s per CU, ds_add_f32 only 0.78 G/s — and the sums are more accurate.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tile = reinterpret_cast<double*>(smem);
+    const int64_t b = blockIdx.y;
+    if (!tile_start[(int64_t)gridDim.y * (g.nt + 1) + b]) return;  // no tile of this row is hot (flag from pass 3)
+    const int* ts = tile_start + b * (g.nt + 1);
+    int total = ts[g.nt];
+    if (total > rec_cap) total = (int)rec_cap;
+    const CicRec<T, ND>* rb = recs + b * rec_cap;
+    T* gb = grid + b * a.gbatch;
+    for (int r0 = blockIdx.x * kAccChunk; r0 < total; r0 += gridDim.x * kAccChunk) {
+    const int r1 = (r0 + kAccChunk < total) ? r0 + kAccChunk : total;
+    // last tile whose start is <= r0 (empty tiles share their start with the next non-empty one, so this is the tile
+    // that holds record r0)
+    int lo = 0, hi = g.nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ts[mid] <= r0) lo = mid; else hi = mid - 1;
+    }
+    {   // quick reject (the normal case): 64 lanes look at the next 64 tiles at once
+        const int t = lo + (threadIdx.x & 63);
+        bool hot_here = false;
+        if (t < g.nt) {
+            const int tb = ts[t], te = ts[t + 1];
+            hot_here = tb < r1 && te > r0 && te - tb > kAccTileCap;
+        }
+        const int tl = lo + 64 < g.nt ? lo + 64 : g.nt;
+        if (!__any(hot_here) && ts[tl] >= r1) continue;
+    }
+    for (int t = lo; t < g.nt && ts[t] < r1; ++t) {
+        const int tbeg = ts[t], tend = ts[t + 1];
+        const int hot = tbeg + kAccTileCap;  // first record of this tile that pass 4a leaves behind
+        const int beg = hot > r0 ? hot : r0, end = tend < r1 ? tend : r1;
+        if (beg >= end) continue;
+        int ld[3], org[3];       // owned extents and cell origin
+        {
+            int rem = t;
+            for (int d = 2; d >= 0; --d) {
+                int tc = 0;
+                if (d < ND) { tc = rem % g.ntile[d]; rem /= g.ntile[d]; }
+                ld[d] = d < ND ? g.tdim[d] : 1;
+                org[d] = tc * ld[d];
+            }
+        }
+        const int lcells = ld[0] * ld[1] * ld[2];
+        for (int i = threadIdx.x; i < lcells; i += kAccThreads) tile[i] = 0.0;
+        __syncthreads();
+        auto deposit = [&](const CicRec<T, ND>& rec) {
+            T wf[3][2];
+            int li[3][2];
+            bool ok[3][2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    if (d < ND) {
+                        const int id = rec.i[d] + o;
+                        const int l = id - org[d];
+                        // valid grid cell AND owned by this tile
+                        ok[d][o] = (id >= 0) && (id < a.bins[d]) && (l >= 0) && (l < ld[d]);
+                        li[d][o] = l;
+                        wf[d][o] = o ? rec.f[d] : ((T)1.0 - rec.f[d]);
+                    } else {
+                        ok[d][o] = (o == 0); li[d][o] = 0; wf[d][o] = (T)1;
+                    }
+                }
+            if (ND == 2) {
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox)
+                        if (ok[0][ox] && ok[1][oy])
+                            unsafeAtomicAdd(&tile[li[0][ox] * ld[1] + li[1][oy]], (double)(rec.c * wf[0][ox] * wf[1][oy]));
+            } else {
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                        for (int oz = 0; oz < 2; ++oz)
+                            if (ok[0][ox] && ok[1][oy] && ok[2][oz])
+                                unsafeAtomicAdd(&tile[(li[0][ox] * ld[1] + li[1][oy]) * ld[2] + li[2][oz]],
+                                                (double)(rec.c * (wf[0][ox] * wf[1][oy] * wf[2][oz])));
+            }
+        };
+        int r = beg + threadIdx.x;
+        // two record loads in flight per lane before the first ds_add depends on them
+        for (; r + kAccThreads < end; r += 2 * kAccThreads) {
+            const CicRec<T, ND> ra = rb[r], rc = rb[r + kAccThreads];
+            deposit(ra); deposit(rc);
+        }
+        for (; r < end; r += kAccThreads) deposit(rb[r]);
+        __syncthreads();
+        // add the tile to the grid (pass 4a may be writing the same cells: atomics)
+        for (int i = threadIdx.x; i < lcells; i += kAccThreads) {
+            const double v = tile[i];
+            if (v == 0.0) continue;
+            int l[3];
+            int rem = i;
+            l[2] = rem % ld[2]; rem /= ld[2];
+            l[1] = rem % ld[1]; rem /= ld[1];
+            l[0] = rem;
+            bool in_grid = true;
+            int64_t off = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (d < ND) {
+                    const int cell = org[d] + l[d];
+                    in_grid = in_grid && cell < a.bins[d];
+                    off += (int64_t)cell * a.gstride[d];
+                }
+            }
+            if (!in_grid) continue;
+            unsafeAtomicAdd(gb + off, (T)v);
+        }
+        __syncthreads();
+    }
+    }
+}
+
 // record capacity per batch row: every particle can touch up to 2^ND tiles (only at tile corners); the
 // expected multiplicity is prod(1 + 1/tdim) ~ 1.13 (2-D, 16 px) .. 1.42 (3-D, 8 cells)
 template <int ND>
@@ -629,7 +810,7 @@ int64_t rec_capacity(int64_t N) { return N * (1 << ND); }
 template <typename T, int ND>
 size_t sorted_ws_bytes(const CicDev& a, const TileGeom& g) {
     size_t bytes = (size_t)a.B * g.nt * kSortWG * sizeof(int);          // counts
-    bytes += (size_t)a.B * (2 * g.nt + 1) * sizeof(int);                // tile totals, tile starts
+    bytes += (size_t)a.B * (2 * g.nt + 2) * sizeof(int);                // tile totals, tile starts, hot flag
     bytes = (bytes + 255) & ~(size_t)255;
     bytes += (size_t)a.B * (size_t)rec_capacity<ND>(a.N) * sizeof(CicRec<T, ND>);  // sorted records
     return bytes;
@@ -644,7 +825,7 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
     int* counts = (int*)workspace;
     int* totals = counts + (size_t)a.B * g.nt * kSortWG;
     int* starts = totals + (size_t)a.B * g.nt;
-    size_t off = ((size_t)a.B * g.nt * kSortWG + (size_t)a.B * (2 * g.nt + 1)) * sizeof(int);
+    size_t off = ((size_t)a.B * g.nt * kSortWG + (size_t)a.B * (2 * g.nt + 2)) * sizeof(int);
     off = (off + 255) & ~(size_t)255;
     CicRec<T, ND>* recs = (CicRec<T, ND>*)((char*)workspace + off);
     const int64_t cap = rec_capacity<ND>(a.N);
@@ -665,6 +846,11 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
     hipLaunchKernelGGL((cic_accumulate_kernel<T, ND>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(kAccThreads), tile_bytes, s,
                        a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
     CHX_CHECK_LAUNCH();
+    unsigned nchunks = (unsigned)((cap + kAccChunk - 1) / kAccChunk);
+    if (nchunks > 1024) nchunks = 1024;  // chunk-strided inside the kernel
+    hipLaunchKernelGGL((cic_accumulate_hot_kernel<T, ND>), dim3(nchunks, (unsigned)a.B), dim3(kAccThreads), tile_bytes, s,
+                       a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
+    CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
 
@@ -676,7 +862,7 @@ extern "C" int chx_cic_deposit(const chx_cic_args* p, void* stream) {
     if (st != CHX_OK) return st;
     if (!p->grid) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid = particle_grid(a.N, a.B);
+    const dim3 grid = combine_grid(a.N, a.B);
     if (p->dtype == CHX_F32)
         hipLaunchKernelGGL(cic_deposit_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, a, (const float*)p->x,
                            (const float*)p->charge, (const float*)p->survival, (const float*)p->extent,
@@ -749,7 +935,7 @@ extern "C" int chx_hist2d(const chx_hist2d_args* p, void* stream) {
     if (st != CHX_OK) return st;
     if (!p->image) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid = particle_grid(a.N, a.B);
+    const dim3 grid = combine_grid(a.N, a.B);
     if (p->dtype == CHX_F32)
         hipLaunchKernelGGL((hist2d_kernel<float, false>), grid, dim3(CHX_BLOCK), 0, s, a, (const float*)p->x,
                            (const float*)p->charge, (const float*)p->survival, (const float*)p->shift,

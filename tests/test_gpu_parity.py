@@ -670,3 +670,53 @@ def test_sorted_deposit_full_size_conserves_charge(ca):
     assert float(a.sum()) == pytest.approx(float(b.sum()), rel=1e-5)
     assert float(a.double().sum()) <= inside * 1e-15 * (1 + 1e-5)
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.max()))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("nd", [2, 3])
+def test_focused_beam_deposit_hot_tiles(ca, oracle, tag, nd):
+    """A beam focused into a fraction of one tile (every particle on the same few cells): the LDS combining table of
+    the direct kernel and the hot-tile pass of the sorted deposit (tile count >> 8192 records) against the oracle."""
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(5)
+    N = 150_000
+    x = np.zeros((1, N, 7), dtype=ndt(tag))
+    x[..., 0] = 1.03e-3 + rng.standard_normal((1, N)) * 2e-6       # sigma = 0.04 cells of 5e-5
+    x[..., 2] = -0.52e-3 + rng.standard_normal((1, N)) * 3e-6
+    x[..., 4] = 0.11e-3 + rng.standard_normal((1, N)) * 2e-6
+    x[0, : N // 3, 0] += 4.0e-4                                     # a second spot, in another tile
+    q = (rng.random((1, N)) * 1e-15 + 1e-16).astype(ndt(tag))
+    if nd == 2:
+        cols, bins = (0, 2), (100, 80)
+        ext = np.array([[-2.5e-3, 2.5e-3], [-2e-3, 2e-3]], dtype=ndt(tag))
+    else:
+        cols, bins = (0, 2, 4), (100, 80, 40)
+        ext = np.array([[-2.5e-3, 2.5e-3], [-2e-3, 2e-3], [-1e-3, 1e-3]], dtype=ndt(tag))
+    ref = oracle.cic_deposit(x, cols, bins, ext, charge=q)
+    assert (ref != 0).sum() < 200                                   # really focused
+    rt = 2e-5 if tag == "f32" else 1e-11
+    scale = np.abs(ref).max()
+    for mode in ("direct", "sorted"):
+        got = _ops.cic_deposit(dev(x), cols, bins, dev(ext), charge=dev(q), mode=mode).cpu().numpy()
+        assert np.array_equal(got != 0, ref != 0), mode
+        assert np.allclose(got, ref, rtol=rt, atol=rt * scale * 1e-2), mode
+        assert np.isclose(got.sum(), ref.sum(), rtol=rt), mode
+
+
+def test_focused_beam_histogram(ca, oracle):
+    """All particles inside two pixels of a 2448 x 2040 screen (chx_hist2d through its LDS combining table)."""
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(9)
+    N = 200_000
+    x = np.zeros((1, N, 7), dtype=np.float32)
+    x[..., 0] = 1.0e-4 + rng.standard_normal((1, N)) * 2e-7
+    x[..., 2] = -3.0e-4 + rng.standard_normal((1, N)) * 2e-7
+    q = np.full((1, N), 1e-15, dtype=np.float32)
+    ex = torch.linspace(-2448 * 3.5488e-6 / 2, 2448 * 3.5488e-6 / 2, 2449).numpy()
+    ey = torch.linspace(-2040 * 2.5003e-6 / 2, 2040 * 2.5003e-6 / 2, 2041).numpy()
+    ref, _ = oracle.hist2d(x, ex, ey, charge=q)
+    got = _ops.hist2d(dev(x), dev(ex), dev(ey), charge=dev(q)).cpu().numpy()
+    assert (ref != 0).sum() <= 9 and np.array_equal(got != 0, ref != 0)
+    assert np.allclose(got, ref, rtol=2e-5) and np.isclose(got.sum(), N * 1e-15, rtol=1e-5)
