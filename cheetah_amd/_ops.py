@@ -1046,6 +1046,20 @@ def sc_gradient(phi, cell, gamma, bins) -> torch.Tensor:
     return F
 
 
+def sc_kick(x, q, w, energy, length, grid_extent, mass_eV, B, N, bins, side_stream=None) -> torch.Tensor:
+    """One chx_sc_kick call: x (Bx,N,7), q (Bq,N), w (Bs,N), energy (B,), length (B,), grid_extent (Bext,3) -> (B,N,7)."""
+    lib = _lib.lib()
+    b3 = _bins3(bins)
+    dt = dtype_code(x.dtype)
+    ws_bytes = lib.chx_sc_kick_workspace_bytes(B, N, b3, dt)
+    ws = workspace(ws_bytes, x.device)
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(lib.chx_sc_kick(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, B, x.shape[0],
+                          q.shape[0], w.shape[0], grid_extent.shape[0], N, b3, dt, ptr(out), ptr(ws), ws_bytes, stream_ptr(),
+                          side_stream.cuda_stream if side_stream is not None else None), "chx_sc_kick")
+    return out
+
+
 def sc_gather_kick(x, F, half, cell, energy, dt, mass_eV, B, N, bins) -> torch.Tensor:
     out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
     check(_lib.lib().chx_sc_gather_kick(ptr(x), ptr(F), ptr(half), ptr(cell), ptr(energy), ptr(dt), mass_eV, B,

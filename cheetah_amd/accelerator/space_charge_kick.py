@@ -112,6 +112,17 @@ class SpaceChargeKick(Element):
         w, _ = _ops.flat_bcast(incoming.survival_probabilities, out_shape, 1)
         L = self.effect_length.to(dtype).expand(out_shape).reshape(B)
 
+        if self.fft_backend == "pruned" and _ops.sc_pruned_supported(g, dtype):
+            # the whole kick in one C call (chx_sc_kick): moments, geometry, deposit, libchx's own pruned line FFTs with
+            # the Green-function chain on a side stream, gradient, gather + kick
+            out = _ops.sc_kick(x, q.to(dtype).contiguous(), w.to(dtype).contiguous(), energy, L.contiguous(),
+                               self._grid_extent(dtype),
+                               incoming.species.mass_eV_float, B, N, g, side_stream=self._side_stream(device))
+            return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,
+                                particle_charges=incoming.particle_charges,
+                                survival_probabilities=incoming.survival_probabilities, s=incoming.s,
+                                species=incoming.species)
+
         # beam sizes -> grid geometry (space_charge_kick.py:531-550): one moments call + one geometry kernel
         mom = _ops.moments(x, w.contiguous())                     # (B or 1, 29) float64
         G2 = (2 * g[0], 2 * g[1], 2 * g[2])
@@ -120,32 +131,6 @@ class SpaceChargeKick(Element):
         half, cell, gamma, dt, scale, extent, pot_scale = _ops.sc_geometry(
             mom, self._grid_extent(dtype), energy, L.contiguous(), incoming.species.mass_eV_float, pot_factor, B, g)
 
-        # Poisson solve by FFT convolution with the integrated Green function (space_charge_kick.py:293-322)
-        if self.fft_backend == "pruned" and _ops.sc_pruned_supported(g, dtype):
-            # libchx's own line FFTs (csrc/chx_fft.hip): compact charge grid with implicit zero padding, only the
-            # first octant of phi is produced, the Green spectrum is real / even and lives on (g+1)^3 points.
-            # The Green-function chain runs on a side stream while the main stream deposits the charge.
-            main = torch.cuda.current_stream(device)
-            side = self._side_stream(device)
-            fork = torch.cuda.Event()
-            fork.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(fork)
-                green_hat = _ops.sc_green_spectrum(cell, gamma, g)
-                join = torch.cuda.Event()
-                join.record(side)
-            rho = torch.zeros((B, *g), dtype=dtype, device=device)
-            _ops.cic_deposit_into(rho, (g[1] * g[2], g[2], 1), g[0] * g[1] * g[2], x, (0, 2, 4), g, extent,
-                                  charge=q, survival=w, scale=scale)
-            main.wait_event(join)
-            green_hat.record_stream(main)
-            phi = _ops.sc_convolve(rho, green_hat, pot_scale, g)
-            force = _ops.sc_gradient(phi, cell, gamma, g)
-            out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
-            return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,
-                                particle_charges=incoming.particle_charges,
-                                survival_probabilities=incoming.survival_probabilities, s=incoming.s,
-                                species=incoming.species)
         if self.fft_backend in ("hipfft", "pruned"):
             # in-place hipFFT on the padded layout [2gx][2gy][2gz+2]; the Green-function chain (fp64-bound table,
             # fill, forward FFT) runs on a side stream while the main stream deposits and transforms the charge

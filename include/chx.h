@@ -305,6 +305,18 @@ int chx_sc_gather_kick(const void* x_in, const void* F, const void* half, const 
                        const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
                        int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
                        void* stream);
+/* A whole SpaceChargeKick.track in ONE call (space_charge_kick.py:477-586) for grids chx_sc_pruned_supported() accepts:
+ * chx_moments -> chx_sc_geometry -> [side stream: chx_sc_igf_table, chx_sc_green_spectrum] -> zero + chx_cic_deposit
+ * (sorted for N >= 65536) -> chx_sc_convolve -> chx_sc_gradient -> chx_sc_gather_kick, all intermediates in `workspace`
+ * (chx_sc_kick_workspace_bytes). x_in[Bx][N][7], charge[Bq][N], survival[Bs][N], energy[B], length[B],
+ * grid_extent[Bext][3] (in sigmas) -> x_out[B][N][7]. `side_stream` may be NULL (everything on `stream`); two events are
+ * created and destroyed per call, nothing else is allocated. Saves ~20 foreign-function calls per kick: at the
+ * reference's default 32^3 grid the host, not the GPU, was the limit. */
+size_t chx_sc_kick_workspace_bytes(int64_t B, int64_t N, const int32_t* bins, int dtype);
+int chx_sc_kick(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext,
+                int64_t N, const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes,
+                void* stream, void* side_stream);
 /* SI conversion on its own (particle_beam.py:1262-1346), used by to_xyz_pxpypz/from_xyz_pxpypz */
 int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B, int64_t Bx,
                       int64_t Be, int64_t N, int dtype, void* xp_out, void* stream);
