@@ -136,7 +136,6 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_bwd_kernel(
     const int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x;
     const bool live = n < N;
     const int64_t xrow = (Bx == 1) ? 0 : b;
-    const int g[3] = {gx, gy, gz};
     const double E = (double)energy[Be == 1 ? 0 : b];
     const double hv[3] = {(double)half[b * 3], (double)half[b * 3 + 1], (double)half[b * 3 + 2]};
     const double cv[3] = {(double)cell[b * 3], (double)cell[b * 3 + 1], (double)cell[b * 3 + 2]};
