@@ -97,3 +97,36 @@ def test_non_power_of_two_grid_refuses_gradients():
         sc.track(beam)
     with torch.no_grad():
         sc.track(beam)
+
+
+def test_vectorised_space_charge_gradients_equal_separate_runs():
+    """Two effect lengths and two beams as one vectorised call: every gradient equals the one of the separate runs."""
+    import cheetah_amd as ca
+
+    torch.manual_seed(2)
+    N = 4000
+    xs = torch.randn(2, N, 7, **KW) * t([3e-4, 2e-5, 2e-4, 3e-5, 1e-5, 1e-3, 0.0])
+    xs[..., 6] = 1.0
+    W = torch.randn(2, N, 7, **KW)
+    lengths = [0.2, 0.35]
+    q = torch.full((N,), 1e-12, **KW)
+
+    def run(x, L):
+        x = x.clone().requires_grad_(True)
+        length = torch.nn.Parameter(t(L))
+        energy = t(3e7).requires_grad_(True) if not isinstance(L, list) else t([3e7, 3e7]).requires_grad_(True)
+        sc = ca.SpaceChargeKick(effect_length=length, grid_shape=(16, 16, 16), **KW)
+        out = sc.track(ca.ParticleBeam(x, energy, particle_charges=q, species=ca.Species("electron", **KW)))
+        return x, length, energy, out
+
+    x2, l2, e2, out2 = run(xs, lengths)
+    assert out2.particles.shape == (2, N, 7)
+    (out2.particles * W).sum().backward()
+    for b in range(2):
+        x1, l1, e1, out1 = run(xs[b], lengths[b])
+        assert torch.allclose(out1.particles, out2.particles[b].detach(), rtol=1e-10, atol=1e-16)
+        (out1.particles * W[b]).sum().backward()
+        assert float(l2.grad[b]) == pytest.approx(float(l1.grad), rel=1e-8)
+        assert float(e2.grad[b]) == pytest.approx(float(e1.grad), rel=1e-7)
+        scale = x1.grad.abs().max(dim=0).values
+        assert torch.all((x2.grad[b] - x1.grad).abs() <= 1e-7 * scale + 1e-30)
