@@ -196,7 +196,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_shared_kernel(
     const T* __restrict__ x_in, const T* __restrict__ R, T* __restrict__ x_out, int64_t B,
     int64_t N, int64_t rows_per_chunk, int in_vec_ok, int out_vec_ok) {
     constexpr int TP = PPT * CHX_BLOCK;
-    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    // two output tiles: row b is written to one while row b - 1 still leaves from the other -> one barrier per row
+    __shared__ __attribute__((aligned(16))) T lds2[2][TP * 7];
+    T* lds = lds2[0];
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
     const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk;
@@ -211,9 +213,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_shared_kernel(
 #pragma unroll
         for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? lds[p * 7 + j] : (T)0;
     }
+    __syncthreads();  // everyone has its rows in registers before tile 0 is overwritten
     for (int64_t b = b0; b < b1; ++b) {
         const T* __restrict__ Rb = R + b * 49;
-        __syncthreads();  // previous store finished reading lds
+        T* tile = lds2[(b - b0) & 1];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int p = threadIdx.x + k * CHX_BLOCK;
@@ -221,12 +224,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_shared_kernel(
                 T y[7];
                 apply7<T>(Rb, x[k], y);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = y[j];
+                for (int j = 0; j < 7; ++j) tile[p * 7 + j] = y[j];
             }
         }
         __syncthreads();
         const bool out_vec = out_vec_ok && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
-        tile_store<T, TP>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec, true);
+        tile_store<T, TP>(x_out + (b * N + n0) * 7, tile, np * 7, out_vec, true);
     }
 }
 

@@ -72,8 +72,8 @@ class ParameterBeam(Beam):
 
     @classmethod
     def from_twiss(cls, beta_x=None, alpha_x=None, emittance_x=None, beta_y=None, alpha_y=None, emittance_y=None,
-                   dispersion_x=None, dispersion_px=None, dispersion_y=None, dispersion_py=None, energy=None,
-                   sigma_tau=None, sigma_p=None, cov_taup=None, total_charge=None, s=None, species=None, device=None,
+                   sigma_tau=None, sigma_p=None, cov_taup=None, dispersion_x=None, dispersion_px=None, dispersion_y=None,
+                   dispersion_py=None, energy=None, total_charge=None, s=None, species=None, device=None,
                    dtype=None) -> "ParameterBeam":
         """Twiss parameters and dispersion -> moments (parameter_beam.py:282-414)."""
         fk = {"device": device, "dtype": dtype}
@@ -133,9 +133,14 @@ class ParameterBeam(Beam):
     def defining_features(self) -> list[str]:
         return ["mu", "cov", "energy", "total_charge", "s", "species"]
 
-    def transformed_to(self, energy=None, total_charge=None, species=None, **moments) -> "ParameterBeam":
+    def transformed_to(self, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None, mu_p=None, sigma_x=None,
+                       sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None, sigma_p=None, cov_xpx=None, cov_ypy=None, cov_taup=None, cov_xp=None, cov_pxp=None, cov_yp=None, cov_pyp=None, cov_xy=None, cov_xpy=None, cov_xtau=None,
+                       cov_pxy=None, cov_pxpy=None, cov_pxtau=None, cov_ytau=None, cov_pytau=None,
+                       energy=None, total_charge=None, species=None, device=None, dtype=None) -> "ParameterBeam":
         """New beam with some moments replaced (parameter_beam.py:476-586): unspecified mu_* / sigma_* / cov_* keep
         their current value."""
+        given = dict(locals())
+        moments = {k: v for k, v in given.items() if k.startswith(("mu_", "sigma_", "cov_"))}
         current = {f"mu_{c}": getattr(self, f"mu_{c}") for c in _COORDS}
         current.update({f"sigma_{c}": getattr(self, f"sigma_{c}") for c in _COORDS})
         for i in range(6):
@@ -149,7 +154,8 @@ class ParameterBeam(Beam):
         return self.__class__.from_parameters(
             **current, energy=energy if energy is not None else self.energy,
             total_charge=total_charge if total_charge is not None else self.total_charge, s=self.s,
-            species=species if species is not None else self.species, device=self.mu.device, dtype=self.mu.dtype)
+            species=species if species is not None else self.species,
+            device=device if device is not None else self.mu.device, dtype=dtype if dtype is not None else self.mu.dtype)
 
     def as_particle_beam(self, num_particles: int):
         """parameter_beam.py:588-608."""

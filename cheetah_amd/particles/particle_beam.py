@@ -82,9 +82,9 @@ class ParticleBeam(Beam):
     @classmethod
     def from_parameters(cls, num_particles=100_000, mu_x=None, mu_px=None, mu_y=None, mu_py=None, mu_tau=None,
                         mu_p=None, sigma_x=None, sigma_px=None, sigma_y=None, sigma_py=None, sigma_tau=None,
-                        sigma_p=None, cov_xpx=None, cov_xy=None, cov_xpy=None, cov_xtau=None, cov_xp=None, cov_pxy=None,
-                        cov_pxpy=None, cov_pxtau=None, cov_pxp=None, cov_ypy=None, cov_ytau=None, cov_yp=None,
-                        cov_pytau=None, cov_pyp=None, cov_taup=None, energy=None, total_charge=None, s=None,
+                        sigma_p=None, cov_xpx=None, cov_ypy=None, cov_taup=None, cov_xp=None, cov_pxp=None, cov_yp=None,
+                        cov_pyp=None, cov_xy=None, cov_xpy=None, cov_xtau=None, cov_pxy=None, cov_pxpy=None,
+                        cov_pxtau=None, cov_ytau=None, cov_pytau=None, energy=None, total_charge=None, s=None,
                         species=None, device=None, dtype=None) -> "ParticleBeam":
         """Gaussian beam from its means, sigmas and any of the 15 covariances; defaults as particle_beam.py:108-353."""
         fk = {"device": device, "dtype": dtype}
