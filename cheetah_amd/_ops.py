@@ -926,6 +926,61 @@ def hist2d_indices(particles, edges_x, edges_y, shift=None) -> torch.Tensor:
 
 # ---------------------------------------------------------------------------------------------
 # space charge + SI conversions
+KDE_CHUNK = 131072  # particles per GEMM slab: bounds the (N, bins) kernel-value arrays at ~1 GiB each
+
+
+def kde_histogram_2d(particles, centres_x, centres_y, bandwidth, charge=None, survival=None, shift=None) -> torch.Tensor:
+    """Screen "kde" image (…, H, W) (utils/kde.py:137-204 + the `.mT` of screen.py:326): chx_kde_values for the two
+    sets of Gaussian kernel values, their GEMM over the particle axis (rocBLAS through torch.matmul), normalised to a
+    pdf. With gradient tracking the kernel values are tensor expressions instead, so autograd sees them."""
+    require_device(particles, centres_x, centres_y, bandwidth)
+    dt = particles.dtype
+    N = particles.shape[-2]
+    shapes = [particles.shape[:-2]] + [t.shape[:-1] for t in (charge, survival, shift) if t is not None]
+    batch_shape = torch.broadcast_shapes(*shapes)
+    B = numel(batch_shape)
+    flat = lambda t, k: (None, 1) if t is None else flat_bcast(t.to(dt), batch_shape, k)  # noqa: E731
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    q, Bq = flat(charge, 1)
+    w, Bs = flat(survival, 1)
+    sh, Bsh = flat(shift, 1)
+    x = x.contiguous()
+    q, w, sh = (None if t is None else t.contiguous() for t in (q, w, sh))
+    cx, cy, sg = centres_x.to(dt).contiguous(), centres_y.to(dt).contiguous(), bandwidth.to(dt).reshape(1).contiguous()
+    W_, H_ = cx.shape[0], cy.shape[0]
+    differentiable = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, q, w, sh, sg))
+    joint = torch.zeros((B, W_, H_), dtype=dt, device=x.device)
+    tiny = torch.finfo(dt).tiny
+    for n0 in range(0, N, KDE_CHUNK):
+        nc = min(KDE_CHUNK, N - n0)
+        if differentiable:
+            def values(col, centres, weighted):
+                v = x[:, n0:n0 + nc, col].expand(B, nc)
+                if sh is not None:
+                    v = v - sh[:, 0 if col == 0 else 1].reshape(-1, 1)
+                k = (-0.5 * ((v.unsqueeze(-1) - centres) / sg).square()).exp() / (2 * torch.pi * sg.square()).sqrt()
+                if weighted:
+                    wt = torch.ones((), dtype=dt, device=x.device)
+                    if q is not None:
+                        wt = wt * q[:, n0:n0 + nc].abs()
+                    if w is not None:
+                        wt = wt * w[:, n0:n0 + nc]
+                    k = wt.expand(B, nc).unsqueeze(-1) * k
+                return k.clamp_min(tiny)
+            k1, k2 = values(0, cx, True), values(2, cy, False)
+        else:
+            k1 = torch.empty((B, nc, W_), dtype=dt, device=x.device)
+            k2 = torch.empty((B, nc, H_), dtype=dt, device=x.device)
+            lib = _lib.lib()
+            check(lib.chx_kde_values(ptr(x), ptr(q), ptr(w), ptr(sh), ptr(cx), ptr(sg), 0, B, Bx, Bq, Bs, Bsh, N, n0, nc, W_,
+                                     dtype_code(dt), ptr(k1), stream_ptr()), "chx_kde_values")
+            check(lib.chx_kde_values(ptr(x), None, None, ptr(sh), ptr(cy), ptr(sg), 2, B, Bx, 1, 1, Bsh, N, n0, nc, H_,
+                                     dtype_code(dt), ptr(k2), stream_ptr()), "chx_kde_values")
+        joint = joint + k1.mT @ k2
+    pdf = joint / (joint.sum(dim=(-2, -1), keepdim=True) + 1e-10)
+    return pdf.mT.reshape(*batch_shape, H_, W_)
+
+
 def _bins3(bins):
     return (ctypes.c_int32 * 3)(*[int(b) for b in bins])
 

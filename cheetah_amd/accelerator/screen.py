@@ -27,14 +27,12 @@ class Screen(Element):
                  sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         fk = {"device": device, "dtype": dtype}
         super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
-        if method not in ("histogram", "cloud-in-cell"):
-            raise ValueError(f"Screen method {method!r} is not provided by cheetah_amd "
-                             "(the dense 'kde' method is out of scope; use 'cloud-in-cell').")
+        if method not in ("histogram", "kde", "cloud-in-cell"):   # screen.py:84-87
+            raise ValueError(f"Invalid method {method}. Must be either 'histogram', 'kde' or 'cloud-in-cell'.")
         self.register_buffer_or_parameter(
             "pixel_size", pixel_size if pixel_size is not None else torch.tensor((1e-3, 1e-3), **fk))
         self.register_buffer_or_parameter(
             "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
-        # carried for file compatibility only (screen.py:106-113): the KDE method itself is not provided
         self.register_buffer_or_parameter(
             "kde_bandwidth", kde_bandwidth if kde_bandwidth is not None else self.pixel_size[0].clone().detach())
         self.resolution = tuple(resolution)
@@ -154,6 +152,10 @@ class Screen(Element):
             ex, ey = self.pixel_bin_edges
             image = _ops.hist2d(beam.particles, ex, ey, charge=beam.particle_charges,
                                 survival=beam.survival_probabilities, shift=self.misalignment)
+        elif self.method == "kde":
+            cx, cy = self.pixel_bin_centers
+            image = _ops.kde_histogram_2d(beam.particles, cx, cy, self.kde_bandwidth, charge=beam.particle_charges,
+                                          survival=beam.survival_probabilities, shift=self.misalignment)
         else:
             image = _ops.cic_deposit(beam.particles, (0, 2), (w, h), self.extent.reshape(2, 2),
                                      charge=beam.particle_charges, survival=beam.survival_probabilities,

@@ -246,6 +246,14 @@ int chx_sc_gather_kick_bwd(const void* x_in, const void* F, const void* half, co
                            const void* dt, const void* dY, double mass_eV, int64_t B, int64_t Bx, int64_t Be, int64_t N,
                            const int32_t* bins, int dtype, void* dx, void* dF, double* partials, void* stream);
 
+/* Screen "kde" method (screen.py:312-326, utils/kde.py:4-77): Gaussian kernel values of particles n0 .. n0 + nchunk - 1
+ * against the bin centres,  out[B][nchunk][nbins] = max(w exp(-((v - c_i) / sigma)^2 / 2) / sqrt(2 pi sigma^2), tiny),
+ * v = x[..][col] - shift (col 0: x, col 2: y), w = |charge| * survival (either may be NULL = 1). The joint density is
+ * the GEMM of two such arrays over the particle axis, left to the BLAS library by the host layer. */
+int chx_kde_values(const void* x, const void* charge, const void* survival, const void* shift, const void* centres,
+                   const void* sigma, int col, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bsh, int64_t N,
+                   int64_t n0, int64_t nchunk, int32_t nbins, int dtype, void* out, void* stream);
+
 /* ---- space charge (a13; space_charge_kick.py:103-586, particle_beam.py:1262-1346) */
 /* Integrated Green function on the doubled grid (space_charge_kick.py:163-291).
  * cell[B][3] (dtype) = cell sizes (hx,hy,htau); gamma[B] (dtype). fp64 inside; the workspace

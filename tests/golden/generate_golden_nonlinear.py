@@ -556,7 +556,38 @@ def gen_sc_grad():
     save("sc_grad.npz", **arrays)
 
 
+def gen_kde():
+    """Screen(method="kde") images (screen.py:312-326, utils/kde.py): scalar and vectorised beams, misalignment,
+    survival weights; fp64 and fp32; plus d(image)/d(particles) through a weighted sum for the fp64 scalar case."""
+    arrays = {}
+    g = torch.Generator().manual_seed(31)
+    N = 1500
+    x = torch.randn(2, N, 7, generator=g, **F64) * t64([4e-4, 1e-5, 3e-4, 1e-5, 1e-5, 1e-3, 0.0])
+    x[..., 6] = 1.0
+    q = (torch.rand(N, generator=g, **F64) + 0.5) * 1e-15 * torch.where(torch.rand(N, generator=g, **F64) < 0.3, -1.0, 1.0)
+    surv = torch.rand(N, generator=g, **F64)
+    W = torch.randn(48, 64, generator=g, **F64)
+    arrays.update(x=npy(x), q=npy(q), surv=npy(surv), W=npy(W))
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        kw = {"dtype": dtype}
+        scr = cheetah.Screen(resolution=(64, 48), pixel_size=torch.tensor([4e-5, 5e-5], **kw), method="kde",
+                             kde_bandwidth=torch.tensor(6e-5, **kw), misalignment=torch.tensor([1e-4, -5e-5], **kw),
+                             is_active=True, **kw)
+        for name, parts in (("scalar", x[0]), ("vector", x)):
+            xin = parts.to(dtype).clone().requires_grad_(dtype == torch.float64 and name == "scalar")
+            beam = cheetah.ParticleBeam(xin, torch.tensor(1e8, **kw), particle_charges=q.to(dtype),
+                                        survival_probabilities=surv.to(dtype), **kw)
+            scr.track(beam)
+            img = scr.reading
+            arrays[f"{name}_{tag}"] = npy(img.detach())
+            if xin.requires_grad:
+                (img * W).sum().backward()
+                arrays["scalar_f64_dx"] = npy(xin.grad)
+            print(name, tag, tuple(img.shape), float(img.sum()))
+    save("kde.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad", "parameter_cavity_grad", "sc_grad"]
+    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad", "parameter_cavity_grad", "sc_grad", "kde"]
     for w in which:
         globals()["gen_" + w]()
