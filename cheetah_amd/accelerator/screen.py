@@ -160,6 +160,14 @@ class Screen(Element):
             image = _ops.cic_deposit(beam.particles, (0, 2), (w, h), self.extent.reshape(2, 2),
                                      charge=beam.particle_charges, survival=beam.survival_probabilities,
                                      shift=self.misalignment, abs_charge=True, transpose_2d=True)
+        from .. import sharding
+
+        group = sharding.active_group()
+        if group is not None and beam is not None and not isinstance(beam, ParameterBeam):
+            if self.method == "kde":
+                raise NotImplementedError("the 'kde' image is normalised per process; use 'cloud-in-cell' or 'histogram' "
+                                          "for a particle-sharded beam")
+            image = sharding.allreduce_grid(image.contiguous(), group)   # every rank deposited its own particles
         self.__dict__["_cached_reading"] = image
         return image
 

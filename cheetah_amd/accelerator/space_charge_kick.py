@@ -112,6 +112,11 @@ class SpaceChargeKick(Element):
         w, _ = _ops.flat_bcast(incoming.survival_probabilities, out_shape, 1)
         L = self.effect_length.to(dtype).expand(out_shape).reshape(B)
 
+        from .. import sharding
+
+        group = sharding.active_group()
+        if group is not None:
+            return self._track_particle_sharded(incoming, group, x, q, w, energy, L, out_shape, B, N)
         if self.fft_backend == "pruned" and _ops.sc_pruned_supported(g, dtype):
             # the whole kick in one C call (chx_sc_kick): moments, geometry, deposit, libchx's own pruned line FFTs with
             # the Green-function chain on a side stream, gradient, gather + kick
@@ -191,6 +196,34 @@ class SpaceChargeKick(Element):
         out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
         return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,
                             particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=incoming.s,
+                            species=incoming.species)
+
+    def _track_particle_sharded(self, incoming, group, x, q, w, energy, L, out_shape, B, N) -> ParticleBeam:
+        """The kick for a beam whose particles are spread over the ranks of `group` (sharding.particle_sharded): the same
+        stages as `chx_sc_kick`, issued one by one so that the two exchanges fit in between — the beam moments (grid
+        geometry from the GLOBAL sigmas) and the charge grid (sum over the shards). Every rank then solves the same
+        Poisson problem and kicks its own particles."""
+        from .. import sharding
+
+        dtype, device = x.dtype, x.device
+        g = self.grid_shape
+        if not _ops.sc_pruned_supported(g, dtype):
+            raise NotImplementedError(f"a particle-sharded SpaceChargeKick needs a power-of-two grid (16..512), got {g}")
+        mom = _ops.moments(x, w.to(dtype).contiguous()).reshape(-1, _ops.MOM_NOUT)
+        mom = sharding.gather_merge_moments(mom, group).contiguous()
+        pot_factor = 1.0 / (4 * math.pi * epsilon_0) / float(8 * g[0] * g[1] * g[2])
+        half, cell, gamma, dt, scale, extent, pot_scale = _ops.sc_geometry(
+            mom, self._grid_extent(dtype), energy, L.contiguous(), incoming.species.mass_eV_float, pot_factor, B, g)
+        green_hat = _ops.sc_green_spectrum(cell, gamma, g)
+        rho = torch.zeros((B, *g), dtype=dtype, device=device)
+        _ops.cic_deposit_into(rho, (g[1] * g[2], g[2], 1), g[0] * g[1] * g[2], x, (0, 2, 4), g, extent, charge=q, survival=w,
+                              scale=scale)
+        sharding.allreduce_grid(rho, group)
+        phi = _ops.sc_convolve(rho, green_hat, pot_scale, g)
+        force = _ops.sc_gradient(phi, cell, gamma, g)
+        out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
+        return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s,
                             species=incoming.species)
 

@@ -17,10 +17,34 @@ over gloo in the CPU tests (tests/test_sharding_gloo.py, world_size 2, partials 
 
 from __future__ import annotations
 
+import contextlib
 from typing import Callable
 
 import torch
 import torch.distributed as dist
+
+_ACTIVE_GROUP: list = []   # stack of process groups inside `particle_sharded(...)`
+
+
+@contextlib.contextmanager
+def particle_sharded(group=None):
+    """Inside this context every rank of `group` holds a SLICE of the particles of one beam. Elements whose physics couples
+    the particles exchange what they need: a `SpaceChargeKick` takes its grid from the global beam moments (one
+    all-gather of 29 doubles per rank) and sums the deposited charge over the ranks (one all-reduce of the g^3 grid), a
+    `Screen` sums its image. Linear maps, cavities and apertures need nothing."""
+    _ACTIVE_GROUP.append(group if group is not None else (dist.group.WORLD if dist.is_initialized() else None))
+    try:
+        yield
+    finally:
+        _ACTIVE_GROUP.pop()
+
+
+def active_group():
+    """The process group of the innermost `particle_sharded` context, or None outside / without more than one rank."""
+    if not _ACTIVE_GROUP or not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = _ACTIVE_GROUP[-1]
+    return group if dist.get_world_size(group) > 1 else None
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -72,9 +96,12 @@ def gather_merge_moments(local: torch.Tensor, group=None) -> torch.Tensor:
     """Global moments from this rank's local (B,29) moments: one all-gather + exact merge."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return local
-    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(parts, local.contiguous(), group=group)
-    return merge_moments(torch.stack(parts, dim=0))
+    staged = local.contiguous()
+    if staged.is_cuda and dist.get_backend(group) == "gloo":
+        staged = staged.cpu()   # gloo has no device all-gather (29 doubles per row: the detour costs nothing)
+    parts = [torch.empty_like(staged) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, staged, group=group)
+    return merge_moments(torch.stack(parts, dim=0)).to(local.device)
 
 
 def global_moments(beam, group=None) -> torch.Tensor:

@@ -1,0 +1,89 @@
+"""A beam whose particles are spread over two processes (sharding.particle_sharded): the SpaceChargeKick takes its grid
+from the global moments and sums the charge grid over the ranks, so the union of the two outgoing slices equals the
+single-process result. Both ranks share the one GPU of the test box, hence the gloo backend (RCCL needs one device per
+rank); the collectives are the ones RCCL runs on a multi-GPU node."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make(ca, x, q, dtype):
+    kw = {"dtype": dtype, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    seg = ca.Segment([ca.Drift(t(0.1), **kw), ca.SpaceChargeKick(t(0.3), grid_shape=(32, 32, 32), **kw), ca.Drift(t(0.2), **kw),
+                      ca.Quadrupole(t(0.1), k1=t(3.0), **kw), ca.SpaceChargeKick(t(0.3), grid_shape=(32, 32, 32), **kw)])
+    beam = ca.ParticleBeam(x.to("cuda"), t(2e7), particle_charges=q.to("cuda"), species=ca.Species("electron", **kw))
+    return seg, beam
+
+
+def _worker(rank, world, port, x, q, queue):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cheetah_amd as ca
+    from cheetah_amd import sharding
+
+    lo, hi = sharding.shard_range(x.shape[0], rank, world)
+    seg, beam = _make(ca, x[lo:hi], q[lo:hi], x.dtype)
+    kw = {"dtype": x.dtype, "device": "cuda"}
+    screen = ca.Screen(resolution=(64, 48), pixel_size=torch.tensor([4e-5, 5e-5], **kw), is_active=True, **kw)
+    with sharding.particle_sharded():
+        out = seg.track(beam)
+        sigma = sharding.global_moments(out)[8].sqrt()
+        screen.track(out)
+        image_sum = float(screen.reading.sum())       # summed over the ranks inside the context
+    queue.put((rank, out.particles.cpu().numpy(), float(sigma), image_sum))   # by value: the process may be gone when it is read
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_particle_sharded_space_charge_equals_single_process(dtype):
+    import cheetah_amd as ca
+
+    torch.manual_seed(12)
+    N = 60_000 if dtype == torch.float64 else 150_001       # direct and sorted deposit; an odd split
+    x = torch.randn(N, 7, dtype=dtype) * torch.tensor([3e-4, 2e-5, 2e-4, 3e-5, 2e-5, 1e-3, 0.0], dtype=dtype)
+    x[:, 6] = 1.0
+    q = torch.full((N,), 2e-9 / N, dtype=dtype)
+    seg, beam = _make(ca, x, q, dtype)
+    whole = seg.track(beam)
+    ref, sigma_ref = whole.particles.cpu(), float(whole.sigma_x)
+
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, x, q, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in range(2):
+        rank, parts, sigma, image_sum = queue.get(timeout=300)
+        results[rank] = (parts, sigma, image_sum)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    joined = torch.cat([torch.from_numpy(results[0][0]), torch.from_numpy(results[1][0])], dim=0)
+    kick = (ref - x).abs().max(dim=0).values                   # size of the effect per coordinate
+    tol = 1e-9 if dtype == torch.float64 else 2e-3             # fp32: the charge sum order differs between the runs
+    assert torch.all((joined - ref).abs() <= tol * kick + 1e-30), ((joined - ref).abs().max(dim=0).values / kick)
+    kw = {"dtype": dtype, "device": "cuda"}
+    screen = ca.Screen(resolution=(64, 48), pixel_size=torch.tensor([4e-5, 5e-5], **kw), is_active=True, **kw)
+    screen.track(whole)
+    total = float(screen.reading.sum())
+    for r in range(2):
+        assert results[r][1] == pytest.approx(sigma_ref, rel=1e-6 if dtype == torch.float64 else 1e-4)
+        assert results[r][2] == pytest.approx(total, rel=1e-5)
