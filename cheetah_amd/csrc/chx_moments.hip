@@ -799,3 +799,49 @@ extern "C" int chx_apply_affine7_bwd(const void* dY, const void* R, const void* 
     }
     return CHX_OK;
 }
+
+// ---- exact merge of per-rank moments (multi-GPU; cheetah_amd/sharding.py merge_moments) ---------------------------------
+// per_rank[R][B][29] = [W, W2, mu(6), unbiased cov upper triangle(21)] of every shard -> out[B][29] of their union
+// (Chan et al.: M = sum_r [M_r + W_r (mu_r - mu)(mu_r - mu)^T]); shards without weight contribute nothing. One thread per
+// batch row: R is the number of GPUs, this replaces ~30 tiny tensor kernels per merge.
+namespace {
+__global__ void merge_moments_kernel(const double* __restrict__ per_rank, int R, int64_t B, double* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double W = 0.0, W2 = 0.0, mu[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) {
+        const double* p = per_rank + ((int64_t)r * B + b) * CHX_MOM_NOUT;
+        if (!(p[0] > 0.0)) continue;
+        W += p[0];
+        W2 += p[1];
+        for (int j = 0; j < 6; ++j) mu[j] += p[0] * p[2 + j];
+    }
+    for (int j = 0; j < 6; ++j) mu[j] /= W;
+    double M[21];
+    for (int k = 0; k < 21; ++k) M[k] = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const double* p = per_rank + ((int64_t)r * B + b) * CHX_MOM_NOUT;
+        if (!(p[0] > 0.0)) continue;
+        const double cf = p[0] - p[1] / p[0];
+        double d[6];
+        for (int j = 0; j < 6; ++j) d[j] = p[2 + j] - mu[j];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j, ++k) M[k] += p[8 + k] * cf + p[0] * d[i] * d[j];
+    }
+    double* o = out + b * CHX_MOM_NOUT;
+    o[0] = W;
+    o[1] = W2;
+    for (int j = 0; j < 6; ++j) o[2 + j] = mu[j];
+    const double cf = W - W2 / W;
+    for (int k = 0; k < 21; ++k) o[8 + k] = M[k] / cf;
+}
+}  // namespace
+
+extern "C" int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, double* out, void* stream) {
+    if (!per_rank || !out || R < 1 || B < 1) return CHX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(merge_moments_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, per_rank,
+                       (int)R, B, out);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}

@@ -99,9 +99,22 @@ def gather_merge_moments(local: torch.Tensor, group=None) -> torch.Tensor:
     staged = local.contiguous()
     if staged.is_cuda and dist.get_backend(group) == "gloo":
         staged = staged.cpu()   # gloo has no device all-gather (29 doubles per row: the detour costs nothing)
-    parts = [torch.empty_like(staged) for _ in range(dist.get_world_size(group))]
+    world = dist.get_world_size(group)
+    if staged.is_cuda:   # RCCL: one all-gather into a (R, B, 29) buffer, merged by one kernel
+        from . import _lib, _ops
+
+        gathered = torch.empty((world, *staged.shape), dtype=staged.dtype, device=staged.device)
+        dist.all_gather_into_tensor(gathered, staged, group=group)
+        out = torch.empty_like(staged)
+        _ops.check(_lib.lib().chx_merge_moments(gathered.data_ptr(), world, staged.shape[0], out.data_ptr(), _ops.stream_ptr()),
+                   "chx_merge_moments")
+        return out
+    parts = [torch.empty_like(staged) for _ in range(world)]
     dist.all_gather(parts, staged, group=group)
-    return merge_moments(torch.stack(parts, dim=0)).to(local.device)
+    merged = merge_moments(torch.stack(parts, dim=0))
+    if local.is_cuda:    # came through the gloo detour: merge on the device with the kernel as well
+        return merged.to(local.device)
+    return merged
 
 
 def global_moments(beam, group=None) -> torch.Tensor:

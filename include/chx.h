@@ -158,6 +158,9 @@ int chx_moment_finalize(const double* sums, const double* m2, int64_t B, double*
 /* convenience: the three calls above on one stream */
 int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
                 int dtype, double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* Multi-GPU: exact merge of the chx_moments outputs of R particle shards, per_rank[R][B][29] -> out[B][29] (the reference's
+ * weighted statistics over the union of the shards, utils/statistics.py:30-48; shards with zero weight are skipped). */
+int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, double* out, void* stream);
 /* backward of chx_moments wrt x: given d_out[B][29] (double; entries 0,1 ignored) */
 int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,
                     int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX, void* stream);

@@ -87,3 +87,25 @@ def test_particle_sharded_space_charge_equals_single_process(dtype):
     for r in range(2):
         assert results[r][1] == pytest.approx(sigma_ref, rel=1e-6 if dtype == torch.float64 else 1e-4)
         assert results[r][2] == pytest.approx(total, rel=1e-5)
+
+
+def test_merge_moments_kernel_equals_tensor_formula():
+    """chx_merge_moments (what the RCCL path runs after its all-gather) against sharding.merge_moments."""
+    import cheetah_amd as ca  # noqa: F401
+    from cheetah_amd import _lib, _ops, sharding
+
+    torch.manual_seed(1)
+    R, B, N = 3, 5, 4000
+    shards = []
+    for r in range(R):
+        x = torch.randn(B, N + 100 * r, 7, dtype=torch.float64, device="cuda") * (1 + r) + 0.1 * r
+        w = torch.rand(B, N + 100 * r, dtype=torch.float64, device="cuda")
+        if r == 1:
+            w[2] = 0.0                                           # a shard without weight in one batch row
+        shards.append(_ops.moments(x, w))
+    per_rank = torch.stack(shards, dim=0).contiguous()
+    per_rank[1, 2] = 0.0                                         # (its moments are NaN / undefined: they must be ignored)
+    ref = sharding.merge_moments(per_rank)
+    out = torch.empty((B, 29), dtype=torch.float64, device="cuda")
+    _ops.check(_lib.lib().chx_merge_moments(per_rank.data_ptr(), R, B, out.data_ptr(), _ops.stream_ptr()), "chx_merge_moments")
+    assert torch.allclose(out, ref, rtol=1e-12, atol=1e-300)
