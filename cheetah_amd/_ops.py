@@ -159,6 +159,52 @@ def build_rmatrix(kind: int, params, energy, mass_eV, n_charges, B) -> torch.Ten
                                  mass_eV, n_charges, B)
 
 
+MAX_PARAMS = 9  # CHX_MAX_PARAMS
+
+
+def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_charges: float):
+    """Composed (7,7) map of a run of elements whose builder parameters are all device scalars of the energy's dtype
+    (chx_build_rmatrix_scalars + chx_compose_maps: two C calls whatever the number of elements). Returns None when the
+    run does not qualify (vectorised or mixed-dtype parameters, gradients, elements without a builder kind) and the
+    caller takes the general per-element path; the result is bit-identical either way."""
+    dtype, device = energy.dtype, energy.device
+    if energy.dim() != 0 or not energy.is_cuda or energy.requires_grad:
+        return None
+    kinds, pointers, keep = [], [], []
+    identity = KIND["identity"]
+    for e in elements:
+        kind = e._chx_kind
+        if kind is None:
+            return None
+        if kind == identity:
+            continue
+        params = e._builder_params()
+        row = [None] * MAX_PARAMS
+        for k, t in enumerate(params):
+            if t.dim() != 0 or t.dtype != dtype or t.requires_grad or t.device != device:
+                return None
+            row[k] = t.data_ptr()
+        kinds.append(kind)
+        pointers += row
+        keep.append(params)   # views such as misalignment[..., 0] must outlive the launch
+    E = len(kinds)
+    if E == 0:
+        return torch.eye(7, dtype=dtype, device=device)
+    lib = _lib.lib()
+    code = dtype_code(dtype)
+    maps = torch.empty((E, 7, 7), dtype=dtype, device=device)
+    check(lib.chx_build_rmatrix_scalars((ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * MAX_PARAMS))(*pointers), E,
+                                        ptr(energy), mass_eV, n_charges, code, ptr(maps), stream_ptr()),
+          "chx_build_rmatrix_scalars")
+    if E == 1:
+        return maps[0]
+    base, step = maps.data_ptr(), 49 * maps.element_size()
+    out = torch.empty((7, 7), dtype=dtype, device=device)
+    check(lib.chx_compose_maps((ctypes.c_void_p * E)(*[base + e * step for e in range(E)]), (ctypes.c_uint8 * E)(*([1] * E)),
+                               E, 1, code, ptr(out), stream_ptr()), "chx_compose_maps")
+    return out
+
+
 def compose_maps(maps: list[torch.Tensor], batch_shape, dtype, device) -> torch.Tensor:
     """maps: per-element (…,7,7) tensors -> composed (*batch_shape,7,7) = R_E … R_1 (segment.py:534-543)."""
     B = numel(batch_shape)

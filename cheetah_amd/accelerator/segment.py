@@ -33,28 +33,49 @@ from .element import Element
 
 
 class _Run:
-    """A maximal run of consecutive skippable elements plus its caches."""
+    """A maximal run of consecutive skippable elements plus its caches. The run object survives changes of element
+    SETTINGS (only a change of the element list or of skippability re-plans the segment), so what does not depend on the
+    settings that changed — the tensor lists of the untouched elements, the summed length — is not redone."""
 
-    __slots__ = ("elements", "tensors", "params", "token", "tm", "stack", "length", "energy_ref", "s_cache")
+    __slots__ = ("elements", "modules", "rev", "per_module", "tensors", "params", "token", "tm", "stack", "length",
+                 "length_key", "energy_ref", "s_cache")
 
     def __init__(self, elements):
         self.elements = elements
+        self.modules = [m for e in elements for m in e.modules() if isinstance(m, Element)]
+        self.rev = None
+        self.per_module = [None] * len(self.modules)   # (revision, buffers + parameters, parameters) per module
         self.tensors = []  # every buffer / parameter tensor of the run (for _version scans)
         self.params = []
-        for e in elements:
-            for m in e.modules():
-                self.tensors += [t for t in m._buffers.values() if t is not None]
-                self.params += [p for p in m._parameters.values() if p is not None]
-        self.tensors += self.params
         self.token = None
         self.tm = None
         self.stack = None
         self.length = None
+        self.length_key = None
         self.energy_ref = None
         self.s_cache = None
+        self._collect()
+
+    def _collect(self):
+        """Refresh the tensor lists of the modules whose revision moved (an attribute was assigned)."""
+        rev = tuple([m.__dict__["_revision"] for m in self.modules])
+        if rev == self.rev:
+            return
+        self.rev = rev
+        tensors, params = [], []
+        for i, m in enumerate(self.modules):
+            cached = self.per_module[i]
+            if cached is None or cached[0] != rev[i]:
+                own_params = [p for p in m._parameters.values() if p is not None]
+                cached = (rev[i], [t for t in m._buffers.values() if t is not None] + own_params, own_params)
+                self.per_module[i] = cached
+            tensors += cached[1]
+            params += cached[2]
+        self.tensors, self.params = tensors, params
 
     def current_token(self, energy, species):
-        return (id(energy), energy._version, species.mass_eV_float, species.num_elementary_charges_float,
+        self._collect()
+        return (id(energy), energy._version, species.mass_eV_float, species.num_elementary_charges_float, self.rev,
                 tuple([t._version for t in self.tensors]), tuple([p.requires_grad for p in self.params]))
 
 
@@ -101,11 +122,10 @@ class Segment(Element):
         return tuple([m.__dict__["_revision"] for m in flat[1]])
 
     def _plan(self):
-        """[(kind, payload)] with kind 'run' (payload _Run) or 'element' (payload Element)."""
+        """[(kind, payload)] with kind 'run' (payload _Run) or 'element' (payload Element). Depends on the element list
+        and on which elements are skippable — not on their settings."""
         elements = list(self.elements)
-        # skippability can depend on tensor VALUES for cavities (voltage != 0): fold their flag in
-        dyn = tuple([e.is_skippable for e in elements if not type(e)._static_skippable])
-        key = (self._revision_key(), dyn)
+        key = (tuple([id(e) for e in elements]), tuple([e.is_skippable for e in elements]))
         cached = self.__dict__["_plan_cache"]
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -128,21 +148,30 @@ class Segment(Element):
     def _refresh(run: _Run, energy, species) -> bool:
         """Invalidate the run's caches when its token changed. Returns whether caching is allowed."""
         if energy.requires_grad or species.mass_eV.requires_grad:
-            run.token = run.tm = run.stack = run.length = None
+            run.token = run.tm = run.stack = None
             return False
         token = run.current_token(energy, species)
         if token != run.token:
-            run.token, run.tm, run.stack, run.length, run.s_cache = token, None, None, None, None
+            run.token, run.tm, run.stack, run.s_cache = token, None, None, None
             run.energy_ref = energy  # kept alive so that its id cannot be recycled
         return True
 
     @staticmethod
     def _run_length(run: _Run):
-        if run.length is None:
+        """Summed length of the run, redone only when a length tensor was replaced or modified. The previous tensors are
+        kept referenced by the key, so that an `is` comparison cannot be fooled by a recycled object id."""
+        lengths = [e.length for e in run.elements]
+        key = run.length_key
+        same = (key is not None and run.length is not None and not run.length.requires_grad
+                and all(a is b and a._version == v for a, (b, v) in zip(lengths, key)))
+        if not same:
             total = None
-            for e in run.elements:
-                total = e.length if total is None else total + e.length
+            for t in lengths:
+                total = t if total is None else total + t
             run.length = total
+            # derived lengths (a sub-segment's sum is a fresh tensor every time) never compare identical: recomputed
+            run.length_key = [(t, t._version) for t in lengths]
+            run.s_cache = None
         return run.length
 
     @staticmethod
@@ -162,9 +191,14 @@ class Segment(Element):
         cacheable = Segment._refresh(run, energy, species)
         if cacheable and run.tm is not None:
             return run.tm
-        maps = [e.first_order_transfer_map(energy, species) for e in run.elements]
-        batch_shape = torch.broadcast_shapes(energy.shape, *[m.shape[:-2] for m in maps])
-        tm = _ops.compose_maps(maps, batch_shape, maps[0].dtype, maps[0].device)
+        tm = None
+        if cacheable:
+            # all-scalar runs (the usual control loop): every element's map and their product in two C calls
+            tm = _ops.build_compose_scalars(run.elements, energy, species.mass_eV_float, species.num_elementary_charges_float)
+        if tm is None:
+            maps = [e.first_order_transfer_map(energy, species) for e in run.elements]
+            batch_shape = torch.broadcast_shapes(energy.shape, *[m.shape[:-2] for m in maps])
+            tm = _ops.compose_maps(maps, batch_shape, maps[0].dtype, maps[0].device)
         if cacheable and not tm.requires_grad:
             run.tm = tm
         return tm

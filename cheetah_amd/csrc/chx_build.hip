@@ -892,6 +892,66 @@ extern "C" int chx_cavity_coeffs(const void* params, const void* energy, double 
     return CHX_OK;
 }
 
+// ---- maps of a whole run of elements with SCALAR parameters, one launch per kBuildChunk elements ----------------------
+// The usual control loop (change a few magnet settings, track, read a screen) rebuilds the maps of every element whose
+// setting changed. Through chx_build_rmatrix that is one packed-parameter tensor (a torch.stack), one output allocation
+// and one launch PER ELEMENT; here the host only collects device pointers to the scalars where they already live, and one
+// thread per element evaluates its builder. Kinds and pointers travel by value in the kernel arguments.
+constexpr int kBuildChunk = 40;  // 40 x (9 pointers + 1 kind byte) = 2.9 KiB of kernel arguments
+struct BuildScalarsArgs {
+    const void* par[kBuildChunk][CHX_MAX_PARAMS];
+    uint8_t kind[kBuildChunk];
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void build_scalars_kernel(BuildScalarsArgs args, int n, const T* __restrict__ energy,
+                                                           double mass, double nq, T* __restrict__ R_out) {
+    const int e = threadIdx.x;
+    if (e >= n) return;
+    const int kind = args.kind[e];
+    const int P = kind_num_params(kind);
+    double p[CHX_MAX_PARAMS];
+    for (int k = 0; k < P; ++k) p[k] = (double)*(const T*)args.par[e][k];
+    Mat7<double> R;
+    build_kind<double>(kind, p, (double)energy[0], mass, nq, R);
+    for (int q = 0; q < 49; ++q) R_out[e * 49 + q] = (T)R.m[q];
+}
+
+extern "C" int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                                         double mass_eV, double n_charges, int dtype, void* R_out, void* stream) {
+    if (!kinds || !param_ptrs || !energy || !R_out || E < 1) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    for (int64_t done = 0; done < E; done += kBuildChunk) {
+        BuildScalarsArgs a;
+        const int n = (int)((E - done < kBuildChunk) ? (E - done) : kBuildChunk);
+        for (int e = 0; e < n; ++e) {
+            const int kind = kinds[done + e];
+            const int P = kind_num_params(kind);
+            if (P < 0) return CHX_ERR_INVALID_ARG;
+            a.kind[e] = (uint8_t)kind;
+            for (int k = 0; k < CHX_MAX_PARAMS; ++k) {
+                a.par[e][k] = k < P ? param_ptrs[(done + e) * CHX_MAX_PARAMS + k] : nullptr;
+                if (k < P && !a.par[e][k]) return CHX_ERR_INVALID_ARG;
+            }
+        }
+        for (int e = n; e < kBuildChunk; ++e) {
+            a.kind[e] = 0;
+            for (int k = 0; k < CHX_MAX_PARAMS; ++k) a.par[e][k] = nullptr;
+        }
+        char* out = (char*)R_out + (size_t)done * 49 * esz;
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(build_scalars_kernel<float>, dim3(1), dim3(64), 0, s, a, n, (const float*)energy, mass_eV,
+                               n_charges, (float*)out);
+        else
+            hipLaunchKernelGGL(build_scalars_kernel<double>, dim3(1), dim3(64), 0, s, a, n, (const double*)energy, mass_eV,
+                               n_charges, (double*)out);
+        CHX_CHECK_LAUNCH();
+    }
+    return CHX_OK;
+}
+
 extern "C" int chx_compose_maps(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B,
                                 int dtype, void* R_out, void* stream) {
     if (!R_ptrs || !bcast || !R_out || E < 1 || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;

@@ -87,6 +87,13 @@ int chx_build_rmatrix_vjp(int kind, const void* params, const void* energy, doub
                           double n_charges, const void* dR, int64_t B, int64_t Bp, int64_t Be,
                           int dtype, void* dparams, void* denergy, void* stream);
 
+/* Maps of E elements whose parameters are SCALARS, read where they live: kinds[E] and param_ptrs[E][CHX_MAX_PARAMS]
+ * (host arrays; entry k of element e is a DEVICE pointer to one `dtype` value, in the order chx_build_rmatrix documents;
+ * unused entries NULL), energy = device pointer to one value -> R_out[E][7][7]. Same arithmetic and rounding as E calls
+ * of chx_build_rmatrix with B = 1; made for control loops that change a few settings and re-track (one call instead of a
+ * packed tensor, an allocation and a launch per element). */
+int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                              double mass_eV, double n_charges, int dtype, void* R_out, void* stream);
 /* ---- segment composition (a2; segment.py:534-543): R_out[b] = R_{E-1}[b] ... R_1[b] R_0[b].
  * R_ptrs is a HOST array of E device pointers, one map buffer per element (each element owns
  * its cached map); buffer e is [1][7][7] if bcast[e] (HOST array) else [B][7][7]. The pointers are
