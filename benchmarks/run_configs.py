@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timings of the five BASELINE.json configs on one MI355X (secondary to bench.py; numbers go to DESIGN.md).
-usage: python benchmarks/run_configs.py [c1 c2 c3 c4 c5 screen]   -> one JSON line per config"""
+usage: python benchmarks/run_configs.py [c1 rl c3 c4 c5 screen]   -> one JSON line per config"""
 import json
 import os
 import sys
@@ -57,6 +57,31 @@ def c1():
     ms2 = timeit(f, 100)
     return {"config": "C1 ARES 13-element segment, 1e4 particles, fp64", "track_ms": ms, "track_plus_cic_reading_ms": ms2,
             "steps_per_s": 1e4 * 13 / (ms * 1e-3)}
+
+
+def rl():
+    """The control loop the reference's README is about: change five magnet settings, track, read the screen."""
+    dt = torch.float32
+    seg = ares_subcell(dt, t(8.2, dt))
+    seg.AREABSCR1.is_active = True
+    beams = {"ParticleBeam": ca.ParticleBeam.from_twiss(beta_x=t(3.14, dt), beta_y=t(42.0, dt), num_particles=10_000, dtype=dt,
+                                                        device=DEV),
+             "ParameterBeam": ca.ParameterBeam.from_twiss(beta_x=t(3.14, dt), beta_y=t(42.0, dt), dtype=dt, device=DEV)}
+    actions = torch.randn(300, 5, device=DEV, dtype=dt)
+    res = {"config": "control loop on the ARES section: 5 settings + track + screen reading, 1e4 particles, fp32"}
+    for name, beam in beams.items():
+        counter = [0]
+
+        def step():
+            a = actions[counter[0] % 300]
+            counter[0] += 1
+            seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle = a[0] * 10, a[1] * 10, a[2] * 1e-4
+            seg.AREAMQZM3.k1, seg.AREAMCHM1.angle = a[3] * 10, a[4] * 1e-4
+            seg.track(beam)
+            return seg.AREABSCR1.reading
+
+        res[f"{name}_ms_per_step"] = timeit(step, 500, 20)
+    return res
 
 
 def c3(B=4096, N=100_000):
@@ -132,6 +157,6 @@ def screen(N=1_000_000):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "c3", "c4", "c5", "screen"]
+    which = sys.argv[1:] or ["c1", "rl", "c3", "c4", "c5", "screen"]
     for w in which:
         print(json.dumps(globals()[w]()), flush=True)

@@ -178,15 +178,22 @@ def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_char
             return None
         if kind == identity:
             continue
-        params = e._builder_params()
+        refs = e._builder_scalar_refs()
         row = [None] * MAX_PARAMS
-        for k, t in enumerate(params):
-            if t.dim() != 0 or t.dtype != dtype or t.requires_grad or t.device != device:
+        for k, (t, index) in enumerate(refs):
+            if t.dtype != dtype or t.requires_grad or t.device != device:
                 return None
-            row[k] = t.data_ptr()
+            if index is None:
+                if t.dim() != 0:
+                    return None
+                row[k] = t.data_ptr()
+            else:
+                if t.dim() != 1 or not t.is_contiguous():
+                    return None
+                row[k] = t.data_ptr() + index * t.element_size()
         kinds.append(kind)
         pointers += row
-        keep.append(params)   # views such as misalignment[..., 0] must outlive the launch
+        keep.append(refs)     # the tensors must outlive the launch
     E = len(kinds)
     if E == 0:
         return torch.eye(7, dtype=dtype, device=device)

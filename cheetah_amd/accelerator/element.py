@@ -81,6 +81,11 @@ class Element(nn.Module):
     def _builder_params(self) -> list[torch.Tensor]:
         return []
 
+    def _builder_scalar_refs(self):
+        """The builder parameters as (tensor, index) pairs for the all-scalar fast path (`_ops.build_compose_scalars`):
+        index None = the 0-d tensor itself, an integer = that entry of a 1-d tensor (no view object is created)."""
+        return [(t, None) for t in self._builder_params()]
+
     def _work_dtype(self) -> torch.dtype:
         return self.length.dtype
 

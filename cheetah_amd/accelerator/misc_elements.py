@@ -28,6 +28,10 @@ class Solenoid(Element):
     def _builder_params(self):
         return [self.length, self.k, self.misalignment[..., 0], self.misalignment[..., 1]]
 
+    def _builder_scalar_refs(self):
+        m = self.misalignment
+        return [(self.length, None), (self.k, None), (m, 0), (m, 1)]
+
     _merge_equal = ("misalignment",)
     _merge_weighted = ("k",)
 
