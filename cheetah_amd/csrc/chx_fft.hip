@@ -307,6 +307,139 @@ int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t
     return CHX_OK;
 }
 
+// ---- x pass of the convolution, fused: forward FFT -> multiply by the Green spectrum -> inverse FFT, in place -------------
+// The x lines of the half-transformed charge (x < g valid, implicit zeros above) are transformed, multiplied by the real,
+// even Green spectrum and transformed back without leaving the CU: the [2g][2g][g+1] complex array C of the three-kernel
+// form (forward x, multiply, inverse x: 34 MB written + 68 MB read-modify-written + 34 MB read at g = 128) never exists.
+// The inverse runs the forward factorisation backwards — inverse M-point FFTs over k2 in the thread that holds
+// X[k1 + 16 k2], conjugate twiddle, one LDS exchange, inverse 16-point FFTs — so no re-ordering pass is needed:
+//   X[k1 + 16 k2] = sum_c W_M^(c k2) W_n^(c k1) sum_j1 x[c + M j1] W_16^(j1 k1)
+//   x[c + M j1]   = sum_k1 W_16^(-j1 k1) W_n^(-c k1) sum_k2 X[k1 + 16 k2] W_M^(-c k2)
+template <typename T, int M>
+__global__ __launch_bounds__(CHX_BLOCK) void fft_x_fused_kernel(T* __restrict__ data, const T* __restrict__ gh,
+                                                               const double* __restrict__ scale, int n_valid, int64_t L,
+                                                               int ny, int nzc, int64_t point_stride, int64_t batch_stride) {
+    constexpr int n = 16 * M;
+    constexpr int LP = kTL + 1;
+    constexpr int KP = M * LP + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx<T>* xch = reinterpret_cast<cplx<T>*>(smem_raw);  // [k1][c][line]
+    cplx<T>* tw = xch + 16 * KP;                           // exp(-2 pi i k / n)
+    __shared__ int64_t g_base[kTL];
+
+    const int tid = threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.x * kTL;
+    const int nl = (int)((L - l0 < kTL) ? (L - l0) : kTL);
+    const int64_t b = blockIdx.y;
+    T* db = data + 2 * b * batch_stride;
+    const int gx1 = n / 2 + 1, gy1 = ny / 2 + 1;
+    const T* gb = gh + b * (int64_t)gx1 * gy1 * nzc;
+    const T sc = (T)scale[b];
+    if (tid < kTL) {
+        const int64_t l = l0 + (tid < nl ? tid : 0);     // l = ky * nzc + kz
+        const int ky = (int)(l / nzc), kz = (int)(l - (int64_t)ky * nzc);
+        const int syk = (ky <= ny / 2) ? ky : ny - ky;
+        g_base[tid] = (int64_t)syk * nzc + kz;
+    }
+    for (int k = tid; k < n; k += CHX_BLOCK) {
+        T sn, cs;
+        sincos_2pi<T>(k, n, sn, cs);
+        tw[k].re = cs;
+        tw[k].im = -sn;
+    }
+    __syncthreads();
+    const int line = tid & 15, c = tid >> 4;
+    const bool live = line < nl;
+    const int64_t base = l0 + line;                       // element (complex) offset of point 0 of this line
+    // ---- forward, pass 1
+    if (c < M) {
+        cplx<T> x[16];
+#pragma unroll
+        for (int j1 = 0; j1 < 16; ++j1) {
+            const int p = c + M * j1;
+            x[j1].re = (T)0;
+            x[j1].im = (T)0;
+            if (live && p < n_valid) {
+                const T* q = db + 2 * (base + (int64_t)p * point_stride);
+                x[j1].re = q[0];
+                x[j1].im = q[1];
+            }
+        }
+        fft_reg<T, 16>(x, 0);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const cplx<T> w = tw[(c * k1) & (n - 1)];
+            cplx<T> y;
+            y.re = x[k1].re * w.re - x[k1].im * w.im;
+            y.im = x[k1].re * w.im + x[k1].im * w.re;
+            xch[k1 * KP + c * LP + line] = y;
+        }
+    }
+    __syncthreads();
+    // ---- forward pass 2, multiply, inverse pass 1 (all in the registers of the thread that owns k1)
+    {
+        const int k1 = c;
+        cplx<T> y[M];
+#pragma unroll
+        for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * KP + j2 * LP + line];
+        fft_reg<T, M>(y, 0);
+        const int64_t gl = g_base[line];
+#pragma unroll
+        for (int k2 = 0; k2 < M; ++k2) {
+            const int p = k1 + 16 * k2;
+            const int sxk = (p <= n / 2) ? p : n - p;
+            const T g = live ? gb[(int64_t)sxk * gy1 * nzc + gl] * sc : (T)0;
+            y[k2].re *= g;
+            y[k2].im *= g;
+        }
+        fft_reg<T, M>(y, 1);
+#pragma unroll
+        for (int cc = 0; cc < M; ++cc) {
+            const cplx<T> w = tw[(cc * k1) & (n - 1)];   // conjugate twiddle W_n^(-c k1)
+            cplx<T> z;
+            z.re = y[cc].re * w.re + y[cc].im * w.im;
+            z.im = y[cc].im * w.re - y[cc].re * w.im;
+            xch[k1 * KP + cc * LP + line] = z;            // this thread's own slab: nobody else reads or writes it
+        }
+    }
+    __syncthreads();
+    // ---- inverse pass 2: 16-point inverse FFTs over k1, outputs x[c + M j1] for the points that are kept
+    if (c < M) {
+        cplx<T> x[16];
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) x[k1] = xch[k1 * KP + c * LP + line];
+        fft_reg<T, 16>(x, 1);
+        if (live) {
+#pragma unroll
+            for (int j1 = 0; j1 < 16; ++j1) {
+                const int p = c + M * j1;
+                if (p < n_valid) {
+                    T* q = db + 2 * (base + (int64_t)p * point_stride);
+                    q[0] = x[j1].re;
+                    q[1] = x[j1].im;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int M>
+int launch_x_fused(void* data, const void* gh, const double* scale, int n_valid, int64_t L, int ny, int nzc, int64_t point_stride,
+                   int64_t batch_stride, int64_t B, hipStream_t s) {
+    dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
+    constexpr size_t shmem = ((size_t)16 * (M * (kTL + 1) + 1) + 16 * M) * sizeof(cplx<T>);
+    auto kern = fft_x_fused_kernel<T, M>;
+    if (shmem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
+            hipSuccess)
+            return CHX_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (T*)data, (const T*)gh, scale, n_valid, L, ny, nzc, point_stride,
+                       batch_stride);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 template <typename T, int LOADM, int STOREM, bool POINT_FAST>
 int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
                  LineLayout lo, int inverse, int64_t B, hipStream_t s) {
@@ -458,22 +591,33 @@ static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64
     LineLayout by{nzc, 1, (int64_t)ny * nzc, nB};
     st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(A, Bf, ny, gy, ny, (int64_t)gx * nzc, nzc, ay, by, 0, B, s);
     if (st != CHX_OK) return st;
-    // forward x: Bf lines (ky, kz), x < gx valid -> C[kx < nx][ky][kz]
     const int64_t plane = (int64_t)ny * nzc;
-    LineLayout bx{plane, 1, 0, nB};
-    LineLayout cx{plane, 1, 0, nC};
-    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, C, nx, gx, nx, plane, plane, bx, cx, 0, B, s);
-    if (st != CHX_OK) return st;
-    // spectral multiply with the real, even Green spectrum
-    {
-        int grid = chx_grid_for(nC, CHX_BLOCK * 4, 8192);
-        hipLaunchKernelGGL(spectral_mul_sym_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, C, Ghat, scale, nx,
-                           ny, nzc);
-        CHX_CHECK_LAUNCH();
+    int fused = CHX_ERR_INVALID_ARG;
+    switch (nx) {   // x pass fused with the spectral multiply, in place on Bf (register-resident line FFTs)
+        case 32: fused = launch_x_fused<T, 2>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
+        case 64: fused = launch_x_fused<T, 4>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
+        case 128: fused = launch_x_fused<T, 8>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
+        case 256: fused = launch_x_fused<T, 16>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
+        default: break;
     }
-    // inverse x: C -> Bf[x < gx][ky][kz]
-    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(C, Bf, nx, nx, gx, plane, plane, cx, bx, 1, B, s);
-    if (st != CHX_OK) return st;
+    if (fused == CHX_ERR_LAUNCH) return fused;
+    if (fused != CHX_OK) {
+        // forward x: Bf lines (ky, kz), x < gx valid -> C[kx < nx][ky][kz]
+        LineLayout bx{plane, 1, 0, nB};
+        LineLayout cx{plane, 1, 0, nC};
+        st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, C, nx, gx, nx, plane, plane, bx, cx, 0, B, s);
+        if (st != CHX_OK) return st;
+        // spectral multiply with the real, even Green spectrum
+        {
+            int grid = chx_grid_for(nC, CHX_BLOCK * 4, 8192);
+            hipLaunchKernelGGL(spectral_mul_sym_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, C, Ghat, scale,
+                               nx, ny, nzc);
+            CHX_CHECK_LAUNCH();
+        }
+        // inverse x: C -> Bf[x < gx][ky][kz]
+        st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(C, Bf, nx, nx, gx, plane, plane, cx, bx, 1, B, s);
+        if (st != CHX_OK) return st;
+    }
     // inverse y: Bf -> A[x][y < gy][kz]
     st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, A, ny, ny, gy, (int64_t)gx * nzc, nzc, by, ay, 1, B, s);
     if (st != CHX_OK) return st;
