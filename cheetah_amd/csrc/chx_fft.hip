@@ -28,7 +28,7 @@ struct LineLayout {
     int64_t batch_stride;   // elements between batch rows
 };
 
-template <typename T> struct cplx { T re, im; };
+template <typename T> struct alignas(2 * sizeof(T)) cplx { T re, im; };   // one 8/16-byte access per complex number
 
 template <typename T>
 __device__ __forceinline__ void sincos_2pi(int k, int n, T& s, T& c);
@@ -235,18 +235,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
             x[j1].im = (T)0;
             if (live) {
                 if (LOADM == LOAD_COMPLEX) {
-                    if (p < n_valid) {
-                        const T* q = inb + 2 * (base + (int64_t)p * li.point_stride);
-                        x[j1].re = q[0];
-                        x[j1].im = q[1];
-                    }
+                    if (p < n_valid) x[j1] = reinterpret_cast<const cplx<T>*>(inb)[base + (int64_t)p * li.point_stride];
                 } else if (LOADM == LOAD_REAL) {
                     if (p < n_valid) x[j1].re = inb[base + (int64_t)p * li.point_stride];
                 } else if (LOADM == LOAD_HERMITIAN) {
                     const int ps = (p <= n / 2) ? p : n - p;
-                    const T* q = inb + 2 * (base + (int64_t)ps * li.point_stride);
-                    x[j1].re = q[0];
-                    x[j1].im = (p <= n / 2) ? q[1] : -q[1];
+                    x[j1] = reinterpret_cast<const cplx<T>*>(inb)[base + (int64_t)ps * li.point_stride];
+                    if (p > n / 2) x[j1].im = -x[j1].im;
                 } else {
                     const int ps = (p <= n / 2) ? p : n - p;
                     x[j1].re = inb[base + (int64_t)ps * li.point_stride];
@@ -278,9 +273,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
                 const int p = k1 + 16 * k2;
                 if (p < n_keep) {
                     if (STOREM == STORE_COMPLEX) {
-                        T* q = outb + 2 * (base + (int64_t)p * lo.point_stride);
-                        q[0] = y[k2].re;
-                        q[1] = y[k2].im;
+                        reinterpret_cast<cplx<T>*>(outb)[base + (int64_t)p * lo.point_stride] = y[k2];
                     } else {
                         outb[base + (int64_t)p * lo.point_stride] = y[k2].re;
                     }
@@ -359,11 +352,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_x_fused_kernel(T* __restrict__ 
             const int p = c + M * j1;
             x[j1].re = (T)0;
             x[j1].im = (T)0;
-            if (live && p < n_valid) {
-                const T* q = db + 2 * (base + (int64_t)p * point_stride);
-                x[j1].re = q[0];
-                x[j1].im = q[1];
-            }
+            if (live && p < n_valid) x[j1] = reinterpret_cast<const cplx<T>*>(db)[base + (int64_t)p * point_stride];
         }
         fft_reg<T, 16>(x, 0);
 #pragma unroll
@@ -413,11 +402,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_x_fused_kernel(T* __restrict__ 
 #pragma unroll
             for (int j1 = 0; j1 < 16; ++j1) {
                 const int p = c + M * j1;
-                if (p < n_valid) {
-                    T* q = db + 2 * (base + (int64_t)p * point_stride);
-                    q[0] = x[j1].re;
-                    q[1] = x[j1].im;
-                }
+                if (p < n_valid) reinterpret_cast<cplx<T>*>(db)[base + (int64_t)p * point_stride] = x[j1];
             }
         }
     }
