@@ -131,6 +131,7 @@ SIGNATURES = {
                                   ctypes.c_int32, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_build_ttensor_vjp": (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "chx_special": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_second_order_bwd_partials_count": (c_i64, [c_i64]),
     "chx_apply_second_order_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64,
                                            c_int, c_void_p]),

@@ -979,10 +979,32 @@ def hist2d_indices(particles, edges_x, edges_y, shift=None) -> torch.Tensor:
 
 # ---------------------------------------------------------------------------------------------
 # space charge + SI conversions
+SPECIAL_KINDS = {"log1pdiv": 0, "si1mdiv": 1, "sicos1mdiv": 2, "sipsicos3mdiv": 3, "sicoskuddelmuddel15mdiv": 4,
+                 "cossqrtmcosdivdiff": 5, "simsidivdiff": 6, "si2msi2divdiff": 7, "sqrta2minusbdiva": 8}
+
+
+def special(kind: str, a: torch.Tensor, b: torch.Tensor | None = None):
+    """(f, df/da[, df/db]) of one of the reference's special functions (utils/autograd.py:4-74) element-wise, chx_special."""
+    code = SPECIAL_KINDS[kind]
+    if b is not None:
+        a, b = torch.broadcast_tensors(a, b)
+        require_device(a, b)
+        b = b.contiguous()
+    else:
+        require_device(a)
+    a = a.contiguous()
+    out, da = torch.empty_like(a), torch.empty_like(a)
+    db = torch.empty_like(a) if b is not None else None
+    check(_lib.lib().chx_special(code, ptr(a), ptr(b), a.numel(), dtype_code(a.dtype), ptr(out), ptr(da), ptr(db),
+                                 stream_ptr()), "chx_special")
+    return (out, da) if b is None else (out, da, db)
+
+
 KDE_CHUNK = 131072  # particles per GEMM slab: bounds the (N, bins) kernel-value arrays at ~1 GiB each
 
 
-def kde_histogram_2d(particles, centres_x, centres_y, bandwidth, charge=None, survival=None, shift=None) -> torch.Tensor:
+def kde_histogram_2d(particles, centres_x, centres_y, bandwidth, charge=None, survival=None, shift=None,
+                     epsilon: float = 1e-10) -> torch.Tensor:
     """Screen "kde" image (…, H, W) (utils/kde.py:137-204 + the `.mT` of screen.py:326): chx_kde_values for the two
     sets of Gaussian kernel values, their GEMM over the particle axis (rocBLAS through torch.matmul), normalised to a
     pdf. With gradient tracking the kernel values are tensor expressions instead, so autograd sees them."""
@@ -1030,8 +1052,31 @@ def kde_histogram_2d(particles, centres_x, centres_y, bandwidth, charge=None, su
             check(lib.chx_kde_values(ptr(x), None, None, ptr(sh), ptr(cy), ptr(sg), 2, B, Bx, 1, 1, Bsh, N, n0, nc, H_,
                                      dtype_code(dt), ptr(k2), stream_ptr()), "chx_kde_values")
         joint = joint + k1.mT @ k2
-    pdf = joint / (joint.sum(dim=(-2, -1), keepdim=True) + 1e-10)
+    pdf = joint / (joint.sum(dim=(-2, -1), keepdim=True) + epsilon)
     return pdf.mT.reshape(*batch_shape, H_, W_)
+
+
+def kde_histogram_1d(particles, centres, bandwidth, survival=None, epsilon: float = 1e-10) -> torch.Tensor:
+    """Normalised 1-D kernel density (…, len(centres)) of column 0 of `particles` (utils/kde.py:6-76,116-152):
+    chx_kde_values for the Gaussian kernel values, summed over the particle axis slab by slab."""
+    require_device(particles, centres, bandwidth)
+    dt = particles.dtype
+    N = particles.shape[-2]
+    batch_shape = torch.broadcast_shapes(particles.shape[:-2], *([survival.shape[:-1]] if survival is not None else []))
+    B = numel(batch_shape)
+    x, Bx = flat_bcast(particles, batch_shape, 2)
+    x = x.contiguous()
+    w, Bs = (None, 1) if survival is None else flat_bcast(survival.to(dt), batch_shape, 1)
+    w = None if w is None else w.contiguous()
+    c, sg = centres.to(dt).contiguous(), bandwidth.to(dt).reshape(1).contiguous()
+    mass = torch.zeros((B, c.shape[0]), dtype=dt, device=x.device)
+    for n0 in range(0, N, KDE_CHUNK):
+        nc = min(KDE_CHUNK, N - n0)
+        k = torch.empty((B, nc, c.shape[0]), dtype=dt, device=x.device)
+        check(_lib.lib().chx_kde_values(ptr(x), None, ptr(w), None, ptr(c), ptr(sg), 0, B, Bx, 1, Bs, 1, N, n0, nc, c.shape[0],
+                                        dtype_code(dt), ptr(k), stream_ptr()), "chx_kde_values")
+        mass = mass + k.sum(dim=1)
+    return (mass / (mass.sum(dim=-1, keepdim=True) + epsilon)).reshape(*batch_shape, c.shape[0])
 
 
 def _bins3(bins):

@@ -231,6 +231,7 @@ def _evaluate_rpn(text: str, context: dict):
     binary = {"+": lambda a, b: a + b, "-": lambda a, b: a - b, "*": lambda a, b: a * b, "/": lambda a, b: a / b,
               "^": lambda a, b: a**b}
     unary = {k: FUNCTIONS[k] for k in ("sqrt", "sin", "cos", "tan", "asin")}
+    text = text.split("#", 1)[0]   # trailing comment
     for token in [t for t in re.split(r"(\+|\-|\*|/|\^)|\s", text.strip().strip('"')) if t]:
         if token in binary:
             if len(stack) < 2:

@@ -761,7 +761,99 @@ __global__ __launch_bounds__(kTBlock) void ttensor_vjp_kernel(int kind, const T*
     }
 }
 
+// ---- the reference's singularity-free special functions as element-wise ops (utils/autograd.py:4-74) -----------------
+// The map builders above use these inline; chx_special evaluates one of them over an array together with its partial
+// derivatives (what the reference's torch.autograd.Function pairs provide: forward :77-700, backward/jvp ibid.).
+// The reference takes the closed form everywhere except exactly at the singular point; the series used here near it
+// agree to rounding.
+template <typename S>
+__device__ S special_one(int kind, S x) {
+    if (kind == CHX_SP_LOG1PDIV) return log1pdiv<S>(x);
+    S C, Sn, G, F;
+    if (kind == CHX_SP_SICOS1MDIV) {      // (1 - S C)(u) / u = 4 F(4u): sin(2a) = 2 sin a cos a
+        sinc_family<S>(4.0 * x, C, Sn, G, F);
+        return 4.0 * F;
+    }
+    sinc_family<S>(x, C, Sn, G, F);
+    if (kind == CHX_SP_SI1MDIV) return F;
+    if (kind == CHX_SP_SIPSICOS3MDIV) return ttensor_E<S>(x, C, Sn);
+    // CHX_SP_SICOSKUDDELMUDDEL15MDIV: the reference substitutes 1/56 at exactly 0 (utils/autograd.py:305-308); its
+    // derivative there is not finite (:323-335); special_kernel writes NaN for it
+    if (val(x) == 0.0) return cst<S>(1.0 / 56.0);
+    return ttensor_H<S>(x, C, Sn);
+}
+
+// a == b limits of the symmetric divided differences (utils/autograd.py:392,470,588): -C'(a), -S'(a), -(S^2)'(a)
+template <typename S>
+__device__ S special_diag(int kind, S a) {
+    S C, Sn, G, F;
+    sinc_family<S>(a, C, Sn, G, F);
+    if (kind == CHX_SP_COSSQRTMCOSDIVDIFF) return 0.5 * Sn;
+    if (kind == CHX_SP_SIMSIDIVDIFF) return 0.5 * (G - F);   // (S - C) / (2a)
+    return Sn * (G - F);                                      // (1 - C^2 - a S C) / a^2
+}
+
+template <typename S>
+__device__ S special_two(int kind, S a, S b) {
+    if (kind == CHX_SP_SQRTA2MINUSBDIVA) {
+        if (val(b) != 0.0) return (m_sqrt(a * a + b) - a) / b;
+        // b == 0: value 1/(2a), partials -1/(2a^2) and -1/(8a^3) (utils/autograd.py:672-700)
+        const S ia = 1.0 / a;
+        return 0.5 * ia - 0.125 * ia * ia * ia * b;
+    }
+    S Ca, Sa, Ga, Fa, Cb, Sb, Gb, Fb;
+    sinc_family<S>(a, Ca, Sa, Ga, Fa);
+    sinc_family<S>(b, Cb, Sb, Gb, Fb);
+    if (kind == CHX_SP_COSSQRTMCOSDIVDIFF) return (Cb - Ca) / (a - b);
+    if (kind == CHX_SP_SIMSIDIVDIFF) return (Sa - Sb) / (b - a);
+    return (Sb * Sb - Sa * Sa) / (a - b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void special_kernel(int kind, const T* __restrict__ a, const T* __restrict__ b, int64_t n,
+                                                           T* __restrict__ out, T* __restrict__ da, T* __restrict__ db) {
+    for (int64_t i = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CHX_BLOCK) {
+        const double av = (double)a[i];
+        if (kind < CHX_SP_COSSQRTMCOSDIVDIFF) {
+            const Dual r = special_one<Dual>(kind, mk(av, 1.0));
+            out[i] = (T)r.v;
+            if (da) da[i] = (kind == CHX_SP_SICOSKUDDELMUDDEL15MDIV && av == 0.0) ? (T)NAN : (T)r.d;
+            continue;
+        }
+        const double bv = (double)b[i];
+        if (kind != CHX_SP_SQRTA2MINUSBDIVA && av == bv) {
+            const Dual r = special_diag<Dual>(kind, mk(av, 1.0));   // symmetric in (a, b): each partial is half of d/dt f(t, t)
+            out[i] = (T)r.v;
+            if (da) da[i] = (T)(0.5 * r.d);
+            if (db) db[i] = (T)(0.5 * r.d);
+            continue;
+        }
+        const Dual ra = special_two<Dual>(kind, mk(av, 1.0), mk(bv, 0.0));
+        out[i] = (T)ra.v;
+        if (da) da[i] = (T)ra.d;
+        if (db) db[i] = (T)special_two<Dual>(kind, mk(av, 0.0), mk(bv, 1.0)).d;
+    }
+}
+
 }  // namespace
+
+extern "C" int chx_special(int kind, const void* a, const void* b, int64_t n, int dtype, void* out, void* da, void* db,
+                           void* stream) {
+    if (kind < 0 || kind > CHX_SP_SQRTA2MINUSBDIVA || !a || !out || n < 0) return CHX_ERR_INVALID_ARG;
+    if (kind >= CHX_SP_COSSQRTMCOSDIVDIFF && !b) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (n == 0) return CHX_OK;
+    const int grid = chx_grid_for(n, CHX_BLOCK, 4096);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(special_kernel<float>, dim3(grid), dim3(CHX_BLOCK), 0, s, kind, (const float*)a, (const float*)b, n,
+                           (float*)out, (float*)da, (float*)db);
+    else
+        hipLaunchKernelGGL(special_kernel<double>, dim3(grid), dim3(CHX_BLOCK), 0, s, kind, (const double*)a, (const double*)b,
+                           n, (double*)out, (double*)da, (double*)db);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
 
 extern "C" int chx_t_num_params(int kind) {
     switch (kind) {

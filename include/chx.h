@@ -382,6 +382,23 @@ int chx_dkd_track_bwd(int kind, const void* x_in, const void* params, const void
                       double mass_eV, double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx,
                       int64_t Bp, int64_t Be, int64_t N, int dtype, void* dx, double* partials, void* stream);
 
+/* The reference's singularity-free special functions (utils/autograd.py:4-74, the torch.autograd.Function pairs at
+ * :77-700) element-wise over n values, with their partial derivatives: out[i] = f(a[i] (, b[i])), da[i] = df/da,
+ * db[i] = df/db (da / db may be NULL; b is ignored by the one-argument kinds). Evaluated in double, stored as dtype.
+ *   LOG1PDIV log(1+x)/x            SI1MDIV (1 - si sqrt x)/x           SICOS1MDIV (1 - si sqrt x cos sqrt x)/x
+ *   SIPSICOS3MDIV (3 - 4 si + si cos)/(2x)                             SICOSKUDDELMUDDEL15MDIV (utils/autograd.py:305-308)
+ *   COSSQRTMCOSDIVDIFF (cos sqrt b - cos sqrt a)/(a - b)               SIMSIDIVDIFF (si sqrt a - si sqrt b)/(b - a)
+ *   SI2MSI2DIVDIFF (si^2 sqrt b - si^2 sqrt a)/(a - b)                 SQRTA2MINUSBDIVA (sqrt(a^2 + b) - a)/b
+ * with si x = sin x / x, negative arguments continued through the hyperbolic forms, and the limits at x = 0, a = b,
+ * b = 0 the reference substitutes. */
+enum chx_special_kind {
+    CHX_SP_LOG1PDIV = 0, CHX_SP_SI1MDIV = 1, CHX_SP_SICOS1MDIV = 2, CHX_SP_SIPSICOS3MDIV = 3,
+    CHX_SP_SICOSKUDDELMUDDEL15MDIV = 4, CHX_SP_COSSQRTMCOSDIVDIFF = 5, CHX_SP_SIMSIDIVDIFF = 6,
+    CHX_SP_SI2MSI2DIVDIFF = 7, CHX_SP_SQRTA2MINUSBDIVA = 8
+};
+int chx_special(int kind, const void* a, const void* b, int64_t n, int dtype, void* out, void* da, void* db,
+                void* stream);
+
 /* Second-order tracking (element.py:195-228): x_out_i = sum_jk T_ijk x_j x_k with the MAD-convention
  * tensors of track_methods.py:80-296 (base_ttensor), the first-order map filled into T[:, 6, :] and the
  * element's rotations / misalignments / fringes folded in (drift.py:68-84, quadrupole.py:113-146,

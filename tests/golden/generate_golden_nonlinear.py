@@ -587,7 +587,57 @@ def gen_kde():
     save("kde.npz", **arrays)
 
 
+def gen_special():
+    """Values and gradients of the reference's special functions (utils/autograd.py) at regular points, at the removed
+    singularities (0, a == b, b == 0) and for negative arguments, plus utils.kde / utils.bmadx round-trip data."""
+    from cheetah.utils import autograd as ag
+    from cheetah.utils import bmadx, kde_histogram_1d, kde_histogram_2d
+
+    arrays = {}
+    x = torch.tensor([-30.0, -2.5, -0.5, -1e-3, 0.0, 1e-3, 0.3, 1.0, 9.8696, 42.0], dtype=torch.float64)
+    arrays["x"] = npy(x)
+    for name in ("log1pdiv", "si1mdiv", "sicos1mdiv", "sipsicos3mdiv", "sicoskuddelmuddel15mdiv"):
+        xin = (x.clamp_min(-0.9) if name == "log1pdiv" else x).clone().requires_grad_(True)
+        y = getattr(ag, name)(xin)
+        (g,) = torch.autograd.grad(y.sum(), xin)
+        arrays[name + "_x"], arrays[name], arrays[name + "_grad"] = npy(xin.detach()), npy(y.detach()), npy(g)
+    a = torch.tensor([-3.0, -0.5, 0.0, 0.0, 0.7, 0.7, 2.0, 5.0, 12.0, -1.5, 4.0], dtype=torch.float64)
+    b = torch.tensor([-3.0, 0.25, 0.0, 1.5, 0.7, -0.7, 3.0, 5.0, 1.0, -1.5, 0.0], dtype=torch.float64)
+    arrays["a"], arrays["b"] = npy(a), npy(b)
+    for name in ("cossqrtmcosdivdiff", "simsidivdiff", "si2msi2divdiff"):
+        ain, bin_ = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = getattr(ag, name)(ain, bin_)
+        ga, gb = torch.autograd.grad(y.sum(), (ain, bin_))
+        arrays[name], arrays[name + "_ga"], arrays[name + "_gb"] = npy(y.detach()), npy(ga), npy(gb)
+    a2 = torch.tensor([0.5, 1.0, 2.0, 3.0, 1.5], dtype=torch.float64, requires_grad=True)
+    b2 = torch.tensor([0.0, 0.3, -1.0, 0.0, 10.0], dtype=torch.float64, requires_grad=True)
+    y = ag.sqrta2minusbdiva(a2, b2)
+    ga, gb = torch.autograd.grad(y.sum(), (a2, b2))
+    arrays.update(sq_a=npy(a2.detach()), sq_b=npy(b2.detach()), sqrta2minusbdiva=npy(y.detach()), sqrta2minusbdiva_ga=npy(ga),
+                  sqrta2minusbdiva_gb=npy(gb))
+    # utils.kde with the reference's call signatures
+    torch.manual_seed(5)
+    s1, s2 = torch.randn(2, 300, dtype=torch.float64), 0.5 * torch.randn(2, 300, dtype=torch.float64) + 0.2
+    wts = torch.rand(2, 300, dtype=torch.float64)
+    bins1, bins2 = torch.linspace(-3, 3, 40, dtype=torch.float64), torch.linspace(-2, 2, 25, dtype=torch.float64)
+    bw = torch.tensor(0.15, dtype=torch.float64)
+    arrays.update(kde_s1=npy(s1), kde_s2=npy(s2), kde_w=npy(wts), kde_bins1=npy(bins1), kde_bins2=npy(bins2),
+                  kde_1d=npy(kde_histogram_1d(s1, bins1, bw)), kde_1d_w=npy(kde_histogram_1d(s1, bins1, bw, weights=wts)),
+                  kde_2d=npy(kde_histogram_2d(s1, s2, bins1, bins2, bw)),
+                  kde_2d_w=npy(kde_histogram_2d(s1, s2, bins1, bins2, bw, weights=wts)))
+    # utils.bmadx coordinate conversions
+    coords = torch.randn(2, 50, 7, dtype=torch.float64) * torch.tensor([1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3, 0.0], dtype=torch.float64)
+    coords[..., 6] = 1.0
+    ref_energy, mc2 = torch.tensor([5e6, 1e8], dtype=torch.float64), torch.tensor(510998.95, dtype=torch.float64)
+    bm, p0c = bmadx.cheetah_to_bmad_coords(coords, ref_energy, mc2)
+    back, e_back = bmadx.bmad_to_cheetah_coords(bm, p0c, mc2)
+    arrays.update(bx_coords=npy(coords), bx_ref_energy=npy(ref_energy), bx_mc2=npy(mc2), bx_bmad=npy(bm), bx_p0c=npy(p0c),
+                  bx_back=npy(back), bx_e_back=npy(e_back))
+    save("special.npz", **arrays)
+    print({k: v.shape for k, v in arrays.items() if k.endswith("_grad") or k in ("kde_2d", "bx_bmad")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad", "parameter_cavity_grad", "sc_grad", "kde"]
+    which = sys.argv[1:] or ["special", "dkd", "second_order", "aperture", "ares", "beam_utils", "cavity_grad", "nonlinear_grad", "parameter_cavity_grad", "sc_grad", "kde"]
     for w in which:
         globals()["gen_" + w]()

@@ -119,3 +119,63 @@ def test_track_methods_wrappers_and_aliases():
     assert grid.shape == (4, 4) and float(grid.sum()) == pytest.approx(3.0)
     pb = ca.ParameterBeam.from_parameters(sigma_x=t(1e-4), energy=E, **kw).linspaced(11)
     assert isinstance(pb, ca.ParticleBeam) and pb.num_particles == 11
+
+
+def test_submodule_layout_of_the_reference():
+    """Imports the reference's tests and user code make (tests/test_autograd.py:4, test_cloud_in_cell.py:5,
+    test_compare_bmad.py:8, test_segment.py:7, test_infix.py:3, test_rpn.py:3) resolve after switching packages."""
+    import importlib
+
+    for mod, names in {
+        "cheetah_amd.utils.autograd": ["log1pdiv", "si1mdiv", "sicos1mdiv", "sipsicos3mdiv", "sicoskuddelmuddel15mdiv",
+                                       "cossqrtmcosdivdiff", "simsidivdiff", "si2msi2divdiff", "sqrta2minusbdiva"],
+        "cheetah_amd.utils.bmadx": ["bmad_to_cheetah_z_pz", "cheetah_to_bmad_z_pz", "cheetah_to_bmad_coords",
+                                    "bmad_to_cheetah_coords"],
+        "cheetah_amd.utils.cloud_in_cell": ["cloud_in_cell_charge_deposition"],
+        "cheetah_amd.utils.kde": ["kde_histogram_1d", "kde_histogram_2d"],
+        "cheetah_amd.utils.statistics": ["unbiased_weighted_covariance", "unbiased_weighted_std", "match_distribution_moments"],
+        "cheetah_amd.utils.warnings": ["PhysicsWarning", "DirtyNameWarning", "UnknownElementWarning"],
+        "cheetah_amd.utils.physics": ["compute_relativistic_factors"],
+        "cheetah_amd.utils.names": ["UniqueNameGenerator", "merge_element_names"],
+        "cheetah_amd.utils.vector": ["squash_index_for_unavailable_dims"],
+        "cheetah_amd.utils.elementwise_linspace": ["elementwise_linspace"],
+        "cheetah_amd.converters.utils.infix": ["evaluate_expression"],
+        "cheetah_amd.converters.utils.rpn": ["evaluate_expression"],
+    }.items():
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
+    import cheetah_amd as ca
+
+    assert ca.utils.warnings.PhysicsWarning is ca.warnings.PhysicsWarning is ca.utils.PhysicsWarning
+    assert callable(ca.utils.elementwise_linspace) and callable(ca.utils.kde_histogram_2d)
+
+
+def test_special_functions_refuse_host_tensors():
+    """No CPU fallback: the element-wise special functions only run through chx_special."""
+    from cheetah_amd.utils.autograd import log1pdiv
+
+    with pytest.raises(Exception):
+        log1pdiv(torch.tensor([0.5], dtype=torch.float64))
+
+
+def test_infix_and_rpn_evaluators():
+    """The cases of the reference's tests/test_infix.py and tests/test_rpn.py."""
+    from cheetah_amd.converters.utils import infix, rpn
+
+    assert infix.evaluate_expression("2 + 3") == 5
+    assert infix.evaluate_expression("(10 * 2) + (4 ^ 2)") == 36
+    assert infix.evaluate_expression("a + b", {"a": 10, "b": 5}) == 15
+    for bad, ctx in (("2 +", None), ("a + b", {"a": 10})):
+        with pytest.raises(SyntaxError):
+            infix.evaluate_expression(bad, ctx)
+    nested = {"a": 10, "b": {"beep": 10, "boop": 100, "test": 5}, "test": 3}
+    assert rpn.evaluate_expression("2 3 +") == 5
+    assert rpn.evaluate_expression("10 2 * 4 2 ^ + sqrt") == 6
+    assert rpn.evaluate_expression("10 2 * 3 4 * + #should be valid") == 32
+    assert rpn.evaluate_expression("10 2 * pi 4 * +", {"pi": 3}) == 32
+    assert rpn.evaluate_expression("a b[test] - b[boop] *", nested) == 500
+    assert rpn.evaluate_expression("b[test] b[boop] *", nested) == 500
+    for bad in ("'2 3 +'", "ldsp2h +dldsp17h +lblxsph/2-lbxsph/2"):
+        with pytest.raises(SyntaxError):
+            rpn.evaluate_expression(bad)
