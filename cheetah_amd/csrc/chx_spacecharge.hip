@@ -174,25 +174,28 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
                     fl = fl > 2.0e9 ? 2.0e9 : (fl < -2.0e9 ? -2.0e9 : fl);
                     i0[d] = (int)fl;
                 }
+                // The eight corners are fetched first, each as one 16/32-byte access at a clamped (always valid) node,
+                // so all of them are in flight together; corners outside the grid get weight 0.
+                struct alignas(4 * sizeof(T)) Node { T x, y, z, pad; };
+                const Node* Fb = reinterpret_cast<const Node*>(F) + b * (int64_t)gx * gy * gz;
+                Node node[8];
+                double w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ix = i0[0] + (k >> 2), iy = i0[1] + ((k >> 1) & 1), iz = i0[2] + (k & 1);
+                    const bool valid = ix >= 0 && ix < g[0] && iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2];
+                    const int cx = min(max(ix, 0), g[0] - 1), cy = min(max(iy, 0), g[1] - 1), cz = min(max(iz, 0), g[2] - 1);
+                    node[k] = Fb[((int64_t)cx * g[1] + cy) * g[2] + cz];
+                    w[k] = valid ? (1.0 - fabs(u[0] - ix)) * (1.0 - fabs(u[1] - iy)) * (1.0 - fabs(u[2] - iz)) * kElementaryCharge
+                                 : 0.0;
+                }
                 double fx = 0.0, fy = 0.0, fz = 0.0;
-                const T* Fb = F + b * (int64_t)gx * gy * gz * 4;
 #pragma unroll
-                for (int ox = 0; ox < 2; ++ox)
-#pragma unroll
-                    for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-                        for (int oz = 0; oz < 2; ++oz) {
-                            const int ix = i0[0] + ox, iy = i0[1] + oy, iz = i0[2] + oz;
-                            const bool valid = ix >= 0 && ix < g[0] && iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2];
-                            if (valid) {
-                                const double w = (1.0 - fabs(u[0] - ix)) * (1.0 - fabs(u[1] - iy)) *
-                                                 (1.0 - fabs(u[2] - iz)) * kElementaryCharge;
-                                const T* f4 = Fb + (((int64_t)ix * g[1] + iy) * g[2] + iz) * 4;
-                                fx += w * (double)f4[0];
-                                fy += w * (double)f4[1];
-                                fz += w * (double)f4[2];
-                            }
-                        }
+                for (int k = 0; k < 8; ++k) {
+                    fx += w[k] * (double)node[k].x;
+                    fy += w[k] * (double)node[k].y;
+                    fz += w[k] * (double)node[k].z;
+                }
                 const double dtb = (double)dt[b];
                 s[1] += fx * dtb;
                 s[3] += fy * dtb;
