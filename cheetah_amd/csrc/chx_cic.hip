@@ -539,12 +539,15 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
 // ([wg][tile]) so every access below is coalesced across the 64 tiles of a workgroup; the 256 workgroup counts of
 // a tile are cut into 16 chunks of 16 (one lane each, 16 loads in flight) that meet through LDS.
 constexpr int kScanChunk = 16;
+constexpr int kScanTiles = 16;   // tiles per workgroup: 256-thread workgroups, nt / 16 of them (256 at 128^3) instead of
+                                 // nt / 64 with 1024 threads — they find free slots next to the Green-function chain
 static_assert(kSortWG == kScanChunk * 16, "scan decomposition");
-__global__ __launch_bounds__(1024) void cic_scan_tiles_kernel(int* __restrict__ counts, int* __restrict__ totals, int nt) {
-    __shared__ int part[16][64];
+__global__ __launch_bounds__(16 * kScanTiles) void cic_scan_tiles_kernel(int* __restrict__ counts, int* __restrict__ totals,
+                                                                        int nt) {
+    __shared__ int part[16][kScanTiles];
     const int64_t b = blockIdx.y;
-    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x % kScanTiles, c = threadIdx.x / kScanTiles;
+    const int t = blockIdx.x * kScanTiles + lane;
     int* cb = counts + b * kSortWG * (int64_t)nt;
     int v[kScanChunk];
     int run = 0;
@@ -835,7 +838,8 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
                        (const T*)p->charge, (const T*)p->survival, (const T*)p->extent, (const T*)p->scale,
                        (const T*)p->shift, counts, (const int*)totals, starts, recs, cap);
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cic_scan_tiles_kernel, dim3((g.nt + 63) / 64, (unsigned)a.B), dim3(1024), 0, s, counts, totals, g.nt);
+    hipLaunchKernelGGL(cic_scan_tiles_kernel, dim3((g.nt + kScanTiles - 1) / kScanTiles, (unsigned)a.B), dim3(16 * kScanTiles), 0, s,
+                       counts, totals, g.nt);
     CHX_CHECK_LAUNCH();
     hipLaunchKernelGGL((cic_sort_kernel<T, ND, true>), sgrid, dim3(kSortThreads), hist_bytes, s, a, g, (const T*)p->x,
                        (const T*)p->charge, (const T*)p->survival, (const T*)p->extent, (const T*)p->scale,
