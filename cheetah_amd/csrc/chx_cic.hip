@@ -571,9 +571,10 @@ __global__ __launch_bounds__(16 * kScanTiles) void cic_scan_tiles_kernel(int* __
 // pass 4a: one workgroup per (tile, batch row); LDS tile = exactly the owned cells. Takes the first kAccTileCap records
 // of its tile; what a hot tile holds beyond that is spread over many workgroups by pass 4b.
 constexpr int kAccThreads = 1024;  // a hot tile is latency-bound on its record stream: many waves per tile
+constexpr int kAccLightTile = 1024;  // average records per tile below which pass 4a uses 256-thread workgroups
 
-template <typename T, int ND>
-__global__ __launch_bounds__(kAccThreads) void cic_accumulate_kernel(CicDev a, TileGeom g,
+template <typename T, int ND, int THREADS>
+__global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileGeom g,
                                                                   const int* __restrict__ tile_start,
                                                                   const CicRec<T, ND>* __restrict__ recs,
                                                                   int64_t rec_cap, T* __restrict__ grid) {
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(kAccThreads) void cic_accumulate_kernel(CicDev a, T
         }
     }
     const int lcells = ld[0] * ld[1] * ld[2];
-    for (int i = threadIdx.x; i < lcells; i += kAccThreads) tile[i] = 0.0;
+    for (int i = threadIdx.x; i < lcells; i += THREADS) tile[i] = 0.0;
     __syncthreads();
     const CicRec<T, ND>* rb = recs + b * rec_cap;
     auto deposit = [&](const CicRec<T, ND>& rec) {
@@ -642,15 +643,15 @@ __global__ __launch_bounds__(kAccThreads) void cic_accumulate_kernel(CicDev a, T
     };
     int r = beg + threadIdx.x;
     // four record loads in flight per lane before the first ds_add depends on them
-    for (; r + 3 * kAccThreads < end; r += 4 * kAccThreads) {
-        const CicRec<T, ND> r0 = rb[r], r1 = rb[r + kAccThreads], r2 = rb[r + 2 * kAccThreads], r3 = rb[r + 3 * kAccThreads];
+    for (; r + 3 * THREADS < end; r += 4 * THREADS) {
+        const CicRec<T, ND> r0 = rb[r], r1 = rb[r + THREADS], r2 = rb[r + 2 * THREADS], r3 = rb[r + 3 * THREADS];
         deposit(r0); deposit(r1); deposit(r2); deposit(r3);
     }
-    for (; r < end; r += kAccThreads) deposit(rb[r]);
+    for (; r < end; r += THREADS) deposit(rb[r]);
     __syncthreads();
     // flush the owned cells: exclusive owner -> plain read-modify-write, last axis fastest (coalesced)
     T* gb = grid + b * a.gbatch;
-    for (int i = threadIdx.x; i < lcells; i += kAccThreads) {
+    for (int i = threadIdx.x; i < lcells; i += THREADS) {
         const double v = tile[i];
         if (v == 0.0) continue;
         int l[3];
@@ -847,8 +848,14 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
     CHX_CHECK_LAUNCH();
     size_t tile_bytes = sizeof(double);
     for (int d = 0; d < ND; ++d) tile_bytes *= (size_t)g.tdim[d];
-    hipLaunchKernelGGL((cic_accumulate_kernel<T, ND>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(kAccThreads), tile_bytes, s,
-                       a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
+    // Lightly filled tiles (a diffuse beam: ~250 records per 8^3 tile at N = 1e6 on 128^3) run as 256-thread workgroups,
+    // eight per CU instead of two, so the per-workgroup zero / flush latency overlaps; fuller tiles keep 1024 threads.
+    if (a.N / g.nt < kAccLightTile)
+        hipLaunchKernelGGL((cic_accumulate_kernel<T, ND, 256>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(256), tile_bytes, s,
+                           a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
+    else
+        hipLaunchKernelGGL((cic_accumulate_kernel<T, ND, kAccThreads>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(kAccThreads),
+                           tile_bytes, s, a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
     CHX_CHECK_LAUNCH();
     unsigned nchunks = (unsigned)((cap + kAccChunk - 1) / kAccChunk);
     if (nchunks > 1024) nchunks = 1024;  // chunk-strided inside the kernel
