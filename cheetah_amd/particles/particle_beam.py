@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import math
 
-import torch
 from torch import nn
 
 from .. import _ops
