@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import math
 
-from torch import nn
+import torch
 
 from .. import _ops
 from .beam import Beam
