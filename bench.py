@@ -2,18 +2,30 @@
 """bench.py — headline benchmark: particle-element-steps/s, 100-element FODO linac, 1e6 particles / GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a launcher re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` (one rank per GPU, RCCL); under a launcher (RANK / WORLD_SIZE set, the driver's form) it asserts
+that the world size equals N.
 
 Workload (BASELINE.json configs[1], "C2"): 25 x [Quad(0.2, +4.2), Drift(0.8), Quad(0.2, -4.2), Drift(0.8)],
-ParticleBeam.from_parameters defaults, fp32, 1e6 particles PER RANK (weak scaling: the particle axis
-shards with no data-path collective; only the global beam moments are all-reduced over RCCL).
+ParticleBeam.from_parameters defaults, fp32, 1e6 particles PER RANK (weak scaling: the particle axis shards with no
+data-path collective; only the global beam moments cross ranks — one all-gather of 29 doubles per rank).
 
-One timed "step" = `Segment.track_elementwise(beam)` — all 100 elements applied one after the other,
-one pass over HBM per element, NO map merging — followed by the global beam moments of the outgoing
-beam (2 reduction passes + 2 tiny all-reduces).  `value` = N_gpus * 1e6 * 100 / t_step.
-The reference's own semantics (`Segment.track`: merge the 100 maps, one pass) and the fused
-in-register variant are timed as well and reported under "modes" — N*E/t is not a bandwidth
-measure for those ("The metric is ill-posed under matrix merging").
+One timed "step" = `Segment.track_elementwise(beam)` — all 100 elements applied one after the other, one pass over HBM per
+element, NO map merging — followed by the global beam moments of the outgoing beam. `value` = N_gpus * 1e6 * 100 / t_step.
+The reference's own semantics (`Segment.track`: merge the 100 maps, one pass) and the fused in-register variant are timed as
+well ("modes") — N*E/t is not a bandwidth measure for those.
+
+`roofline`: the dominant kernel is apply_tile_kernel<float,2,0> (100 launches per step). Its average duration is measured
+live with HIP events recorded on the launch stream around the 100-launch run of EVERY timed step (so it includes the few
+hundred ns between back-to-back launches and must agree with the rocprofv3 kernel-trace average committed under profiles/);
+`achieved` = 56 B x 1e6 particles / that duration. `hbm_streaming` repeats the measurement at 1.6e7 particles, where the two
+448 MB buffers cannot live in the 256 MiB Infinity Cache.
+
+`configs` (1 GPU only): the other BASELINE.json configs at full size — C1 merged track, C3 k1 scan, C4 space-charge linac,
+C5 backward — each with its own algorithmic-byte accounting. `cpu_baseline` (rank 0, N = 1): the C oracle (OpenMP, pinned
+to the physical cores) and a plain PyTorch-CPU `(N,7) @ (7,7)` loop (the reference's element.py:182) on the same workload,
+timed in a subprocess with its own thread settings.
 
 Prints ONE JSON line on rank 0.
 """
@@ -21,8 +33,11 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import csv
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +47,9 @@ if ROOT not in sys.path:
 
 N_PARTICLES = 1_000_000
 N_CELLS = 25
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+APPLY_KERNEL = "apply_tile_kernel<float, 2, 0>"
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")
 
 
 def build_fodo(ca, torch, device, dtype):
@@ -67,13 +84,27 @@ def timed(torch, dist, fn, steps, warmup, world):
     return dt
 
 
-def cpu_baseline(n_elements):
-    """The CPU oracle (C restatement of the reference path, OpenMP over all host cores) on the same
-    workload and mode: element-by-element fp32 tracking of 1e6 particles, repeated until >= ~10 s."""
+# ---------------------------------------------------------------------------------------------------------------- CPU side
+def physical_cores() -> int:
+    try:
+        import psutil
+
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline_worker(n_elements: int) -> dict:
+    """Runs in a subprocess whose OMP_* environment pins one thread per physical core."""
     import numpy as np
+    import torch
 
     from oracle import chx_oracle as oracle
 
+    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
     E = 1e8
     f = np.float32
     cell = [oracle.build_rmatrix("quadrupole", [f(0.2), f(4.2), 0, 0, 0], E).astype(np.float32),
@@ -84,32 +115,245 @@ def cpu_baseline(n_elements):
     rng = np.random.default_rng(1234)
     x = (rng.standard_normal((N_PARTICLES, 7)) * [175e-6, 4e-6, 175e-6, 4e-6, 8e-6, 2e-3, 0]).astype(np.float32)
     x[..., 6] = 1.0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     out, tmp, x_par = np.empty_like(x), np.empty_like(x), np.empty_like(x)
     # first touch of every buffer happens inside the OpenMP loops (NUMA-local pages on a multi-socket host)
     oracle.track_elementwise(x, np.eye(7, dtype=np.float32)[None], x_par, tmp)
-    x = x_par
-    oracle.track_elementwise(x, maps, out, tmp)  # warm-up: page faults, OpenMP pool
+    xs = x_par
+    oracle.track_elementwise(xs, maps, out, tmp)  # warm-up: page faults, OpenMP pool
     reps, t0 = 0, time.perf_counter()
     while True:
-        oracle.track_elementwise(x, maps, out, tmp)
+        oracle.track_elementwise(xs, maps, out, tmp)
         reps += 1
         el = time.perf_counter() - t0
         if el >= 10.0 or reps >= 400:
             break
-    return {"value": N_PARTICLES * len(maps) * reps / el, "unit": "particle-element-steps/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{reps} x (1e6 particles x {len(maps)} elements, element-by-element, fp32 fma chain, "
-                      f"C oracle with OpenMP on {cores} host threads), {el:.1f} s"}
+    res = {"value": N_PARTICLES * len(maps) * reps / el, "unit": "particle-element-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} x (1e6 particles x {len(maps)} elements, element-by-element, fp32 fma chain, C oracle with "
+                     f"OpenMP, {cores} threads pinned to physical cores), {el:.1f} s"}
+    # like-for-like stand-in for the reference's CPU PyTorch path (element.py:182 `particles @ tm.mT`, one matmul per element).
+    # A (1e6, 7) @ (7, 7) product does not scale to every core of a large host, so the thread count is swept and the best kept.
+    xt = torch.from_numpy(x)
+    mt = [torch.from_numpy(np.ascontiguousarray(m)) for m in maps]
+    sweep = {}
+    for threads in sorted({8, 32, cores}):
+        if threads > cores:
+            continue
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            y = xt
+            for m in mt[:4]:
+                y = y @ m.mT
+            reps, t0 = 0, time.perf_counter()
+            while True:
+                y = xt
+                for m in mt:
+                    y = y @ m.mT
+                reps += 1
+                el = time.perf_counter() - t0
+                if el >= 3.0 or reps >= 100:
+                    break
+        sweep[threads] = (N_PARTICLES * len(mt) * reps / el, reps, el)
+    best = max(sweep, key=lambda k: sweep[k][0])
+    res["torch_cpu_matmul"] = {"value": sweep[best][0], "unit": "particle-element-steps/s", "threads": best,
+                               "torch": torch.__version__,
+                               "by_threads": {str(k): v[0] for k, v in sweep.items()},
+                               "sample": f"{sweep[best][1]} x (1e6 x 7 fp32) @ (7 x 7).mT over {len(mt)} elements, "
+                                         f"{sweep[best][2]:.1f} s, best of thread counts {sorted(sweep)}"}
+    return res
+
+
+def cpu_baseline(n_elements: int) -> dict:
+    cores = physical_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores", MKL_NUM_THREADS=str(cores),
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_elements)], env=env,
+                             capture_output=True, text=True, timeout=240)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as exc:  # the GPU numbers stand on their own; say why the baseline is missing
+        return {"value": None, "unit": "particle-element-steps/s", "cores": cores, "kind": "port",
+                "sample": f"cpu baseline failed: {type(exc).__name__}: {exc}"}
+
+
+# ---------------------------------------------------------------------------------------------------------------- launch
+def self_launch(args) -> None:
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node has {have}; "
+                         f"run with --gpus {max(have, 1)} or on a larger node\n")
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.execvpe(sys.executable, cmd, env)
+
+
+def rocprof_average_ms() -> float | None:
+    """Average duration of the apply kernel in the tracked rocprofv3 kernel-trace summary of this same command."""
+    try:
+        for row in csv.DictReader(open(PROFILE_CSV)):
+            if APPLY_KERNEL.replace(" ", "") in row["Name"].replace(" ", ""):
+                return float(row["AverageNs"]) * 1e-6
+    except Exception:
+        pass
+    return None
+
+
+def event_timed_elementwise(torch, seg, beam, steps, warmup):
+    """Average milliseconds of one `chx_track_elementwise` run (E launches) from HIP events on the launch stream."""
+    for _ in range(warmup):
+        seg.track_elementwise(beam, fused=False)
+    pairs = []
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        seg.track_elementwise(beam, fused=False)
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
+
+# ---------------------------------------------------------------------------------------------------------------- configs
+def other_configs(ca, torch, device) -> dict:
+    """C1 / C3 / C4 / C5 of BASELINE.json at full size on one GPU (seeded synthetic inputs), ms per call."""
+    from benchmarks import run_configs as rc
+
+    rc.DEV = device
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:  # a failing side config must not take the headline down with it
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+
+    def c1():
+        r = rc.c1()
+        return {"workload": "C1: ARES 13-element segment (README), 1e4 particles, fp64, Segment.track (maps merged)",
+                "ms_per_track": r["track_ms"], "ms_track_plus_cic_reading": r["track_plus_cic_reading_ms"],
+                "roofline": {"bound": "host launch", "algorithmic_bytes": 1e4 * 112.0,
+                             "note": "1.1 MB per track: floor 0.14 us of HBM time, the call is launch / host bound"}}
+
+    def c3():
+        r = rc.c3()
+        nbytes = r["output_GB"] * 1e9 + 2.8e6
+        return {"workload": "C3: k1 scan B=4096 x N=1e5 on the ARES EA subcell, fp32, shared beam, ONE GPU",
+                "ms_per_track": r["track_ms"], "ms_all_moments": r["all_moments_ms"],
+                "ms_track_moments_fused": r["fused_track_moments_ms"],
+                "particle_element_steps_per_s": r["steps_per_s"],
+                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["track_ms"] * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["track_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "28 B written per (setting, particle) + the 2.8 MB beam read once (SURVEY 8d)"}}
+
+    def c4():
+        r = rc.c4()
+        # SURVEY 8d per kick: 84 B per particle + ~1.6 GB of grid / dense-FFT traffic (the pruned solver moves ~0.35 GB)
+        per_kick = 84.0 * N_PARTICLES + 1.6e9
+        return {"workload": "C4: 50-element linac, 10 SpaceChargeKicks on 128^3, 1e6 particles, fp32",
+                "ms_per_track": r["track_ms"], "ms_per_kick": r["single_kick_ms"],
+                "particle_element_steps_per_s": r["steps_per_s"],
+                "roofline": {"bound": "hbm", "algorithmic_bytes_per_kick": per_kick,
+                             "achieved": per_kick / (r["single_kick_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": per_kick / (r["single_kick_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "byte count of SURVEY 8d (three dense 256^3 transforms); the pruned, symmetry-aware "
+                                     "solver built here moves about a fifth of it, so this fraction is an upper bound on "
+                                     "what the kernels sustain"}}
+
+    def c5():
+        r = rc.c5()
+        # forward: apply 56 B + moments 32 B; backward: moments_bwd 60 B + apply_bwd 84 B per particle
+        nbytes = 232.0 * N_PARTICLES
+        return {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
+                "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
+                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5)):
+        guarded(name, fn)
+    return out
+
+
+def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) -> dict:
+    """The other sharded workloads next to the weak-scaling headline (world > 1 only)."""
+    from benchmarks import run_configs as rc
+
+    rc.DEV = device
+    dtype = torch.float32
+    legs = {}
+    # strong scaling of C2: 1e6 particles in TOTAL, split over the ranks
+    seg = build_fodo(ca, torch, device, dtype)
+    lo, hi = sharding.shard_range(N_PARTICLES, rank, world)
+    torch.manual_seed(1234 + rank)
+    beam = ca.ParticleBeam.from_parameters(num_particles=hi - lo, dtype=dtype, device=device)
+
+    def strong():
+        out = seg.track_elementwise(beam, fused=False)
+        sharding.global_moments(out)
+
+    d = timed(torch, dist, strong, steps, warmup, world)
+    legs["c2_strong"] = {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_step": d / steps * 1e3,
+                         "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
+    # C3: the 4096 settings split over the ranks, beam replicated, no collective
+    B = 4096
+    b0, b1 = sharding.shard_range(B, rank, world)
+    k1 = torch.linspace(-30, 30, B, dtype=dtype, device=device)[b0:b1].contiguous()
+    seg3 = rc.ares_subcell(dtype, k1)
+    torch.manual_seed(99)
+    beam3 = ca.ParticleBeam.from_parameters(num_particles=100_000, dtype=dtype, device=device)
+    keep = {}
+    d = timed(torch, dist, lambda: keep.__setitem__("o", seg3.track(beam3)), 5, 2, world)
+    legs["c3_batch_shard"] = {"scaling": "strong", "settings_total": B, "settings_per_rank": b1 - b0, "ms_per_track": d / 5 * 1e3,
+                              "particle_element_steps_per_s": B * 100_000 * 13 * 5 / d, "collectives": "none"}
+    keep.clear()
+    torch.cuda.empty_cache()
+    # C4: particles split over the ranks; per kick one all-gather of 29 doubles and one all-reduce of the 8.4 MB grid
+    g = 128
+    kw = {"dtype": dtype, "device": device}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    els = []
+    for i in range(10):
+        els += [ca.Drift(t(0.1)), ca.SpaceChargeKick(t(0.2), grid_shape=(g, g, g), **kw), ca.Drift(t(0.1)),
+                ca.Quadrupole(t(0.1), k1=t(4.2 if i % 2 == 0 else -4.2), **kw), ca.Drift(t(0.1))]
+    seg4 = ca.Segment(els)
+    torch.manual_seed(7 + rank)
+    beam4 = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=hi - lo, total_charge=t(1e-9 * (hi - lo) / N_PARTICLES),
+                                                 energy=t(2.5e8), radius_x=t(1e-3), radius_y=t(1e-3), radius_tau=t(1e-3),
+                                                 sigma_px=t(1e-6), sigma_py=t(1e-6), sigma_p=t(1e-6), **kw)
+
+    def c4():
+        with sharding.particle_sharded():
+            seg4.track(beam4)
+
+    d = timed(torch, dist, c4, 3, 1, world)
+    legs["c4_particle_shard"] = {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_track": d / 3 * 1e3,
+                                 "particle_element_steps_per_s": N_PARTICLES * 50 * 3 / d,
+                                 "collectives": "per kick: all-gather 29 f64 per rank + all-reduce 8.4 MB grid (RCCL)"}
+    return legs
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1/C3/C4/C5 side timings (and the scaling legs)")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker(args.cpu_baseline_worker)))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # does not return
 
     import torch
     import torch.distributed as dist
@@ -117,14 +361,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE is {world})")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(device))
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus
 
     import cheetah_amd as ca
     from cheetah_amd import _ops, sharding
@@ -159,11 +403,9 @@ def main():
         modes[name] = {"ms_per_track": d / args.steps * 1e3,
                        "particle_element_steps_per_s": world * N_PARTICLES * E * args.steps / d}
 
-    # roofline of the dominant kernel (apply_tile_kernel<float>): HIP events on the launch stream
-    R = seg.elements[0].first_order_transfer_map(beam.energy, beam.species).reshape(1, 7, 7).contiguous()
-    x = beam.particles.reshape(1, N_PARTICLES, 7)
-    scratch = torch.empty_like(x)
-    ms_launch = _ops.time_apply_ms(x, R, scratch, 1, 1, 1, N_PARTICLES, 200)
+    # ---- roofline of the dominant kernel: HIP events on the launch stream around the E-launch run, every step
+    ms_run = event_timed_elementwise(torch, seg, beam, args.steps, args.warmup)
+    ms_launch = ms_run / E
     algo_bytes = 56.0 * N_PARTICLES  # 7 fp32 read + 7 fp32 written per particle per launch
     achieved = algo_bytes / (ms_launch * 1e-3) / 1e9
     traffic = None
@@ -173,10 +415,27 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "apply_tile_kernel<float,2,0>", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": ms_launch,
-                "note": "28 MB in + 28 MB out per launch fit the 256 MiB Infinity Cache; see DESIGN.md"}
+    ms_rocprof = rocprof_average_ms()
+    roofline = {"bound": "hbm", "kernel": APPLY_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_ms": ms_launch, "launches_per_step": E,
+                "avg_launch_ms_rocprof": ms_rocprof,
+                "frac_rocprof": (algo_bytes / (ms_rocprof * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_rocprof else None,
+                "note": "28 MB in + 28 MB out per launch fit the 256 MiB Infinity Cache; hbm_streaming is the same kernel "
+                        "on buffers that do not"}
+    # the same kernel streaming from HBM proper: 1.6e7 particles, 448 MB in + 448 MB out per launch
+    big_n = 16_000_000
+    try:
+        big = ca.ParticleBeam.from_parameters(num_particles=big_n, dtype=dtype, device=device)
+        seg10 = ca.Segment(list(seg.elements)[:10])
+        ms_big = event_timed_elementwise(torch, seg10, big, 10, 2) / 10
+        gbs = 56.0 * big_n / (ms_big * 1e-3) / 1e9
+        roofline["hbm_streaming"] = {"particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n, "avg_launch_ms": ms_big,
+                                     "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+        del big, seg10
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        roofline["hbm_streaming"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     result = {
         "metric": "particle-element-steps/sec at 1e6 particles, 100-elem linac",
@@ -187,8 +446,16 @@ def main():
                                "element-by-element tracking (no map merging) + global beam moments",
                    "elements": E, "particles_per_gpu": N_PARTICLES, "parallelism": f"particle-shard x{world}",
                    "sigma_x_out": sigma_x},
-        "modes": modes, "roofline": roofline,
+        "timed_region_s": dt, "modes": modes, "roofline": roofline,
     }
+    state.clear()
+    torch.cuda.empty_cache()
+    if not args.no_configs:
+        if world == 1:
+            result["configs"] = other_configs(ca, torch, device)
+        else:
+            result["scaling_legs"] = scaling_legs(ca, torch, dist, sharding, device, rank, world, min(args.steps, 50),
+                                                  min(args.warmup, 5))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(E)
     if rank == 0:

@@ -90,6 +90,7 @@ SIGNATURES = {
     "chx_cic_deposit": (c_int, [ctypes.POINTER(CicArgs), c_void_p]),
     "chx_cic_sorted_workspace_bytes": (c_size_t, [ctypes.POINTER(CicArgs)]),
     "chx_cic_deposit_sorted": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_size_t, c_void_p]),
+    "chx_cic_deposit_sorted_overwrite": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_size_t, c_void_p]),
     "chx_cic_indices": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_void_p, c_void_p]),
     "chx_cic_deposit_bwd": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_hist2d": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     "chx_sc_pruned_supported": (c_int, [c_i32_p, c_int]),
     "chx_sc_igf_table": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
     "chx_sc_green_workspace_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),
+    "chx_sc_green_fast_workspace_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),
+    "chx_sc_green_spectrum_fast": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_sc_green_spectrum": (c_int, [c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_sc_convolve_workspace_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),
     "chx_sc_convolve": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -140,6 +143,10 @@ SIGNATURES = {
     "chx_sc_gather_kick_bwd_partials_count": (c_i64, [c_i64, c_i64]),
     "chx_sc_gather_kick_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64,
                                        c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_sc_beam_geometry_workspace_bytes": (c_size_t, [c_i64, c_i64]),
+    "chx_sc_beam_geometry": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64,
+                                     c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_sc_kick_workspace_bytes": (c_size_t, [c_i64, c_i64, c_i32_p, c_int]),
     "chx_sc_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64,
                             c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

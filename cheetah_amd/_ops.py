@@ -687,11 +687,29 @@ def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Ten
     if survival is not None:
         w, _ = flat_bcast(survival.to(particles.dtype), batch_shape, 1)
         w = w.contiguous()
-    if x.requires_grad:
+    if w is not None and w.requires_grad and torch.is_grad_enabled():
+        # survival weights that carry a graph (an Aperture with differentiable edges upstream): chx_moments_bwd has no dW,
+        # so this rare case is written as device tensor expressions (statistics.py:4-48) — differentiable in x AND w
+        out = _moments_weight_grad(x, w, B)
+    elif x.requires_grad:
         out = Moments.apply(x, w, B)
     else:
         out = _moments_raw(x, w, B, N)
     return out.reshape(*batch_shape, MOM_NOUT)
+
+
+def _moments_weight_grad(x: torch.Tensor, w: torch.Tensor, B: int) -> torch.Tensor:
+    """[W, W2, mu(6), cov upper triangle (21)] in float64 as tensor expressions (particle_beam.py:1699-1717,
+    utils/statistics.py:4-48); only used when the survival probabilities require grad."""
+    xd = x.to(torch.float64).expand(B, -1, 7)[..., :6]
+    wd = w.to(torch.float64).expand(B, -1)
+    W = wd.sum(dim=-1)
+    W2 = (wd * wd).sum(dim=-1)
+    mu = (wd.unsqueeze(-1) * xd).sum(dim=-2) / W.unsqueeze(-1)
+    c = xd - mu.unsqueeze(-2)
+    cov = torch.einsum("bn,bni,bnj->bij", wd, c, c) / (W - W2 / W).reshape(B, 1, 1)
+    iu = torch.triu_indices(6, 6, device=x.device)
+    return torch.cat([W.unsqueeze(-1), W2.unsqueeze(-1), mu, cov[:, iu[0], iu[1]]], dim=-1)
 
 
 def aperture_mask(particles: torch.Tensor, survival: torch.Tensor, x_max: torch.Tensor, y_max: torch.Tensor,
@@ -1118,14 +1136,22 @@ def sc_pruned_supported(bins, dtype) -> bool:
     return bool(_lib.lib().chx_sc_pruned_supported(_bins3(bins), dtype_code(dtype)))
 
 
-def sc_green_spectrum(cell, gamma, bins) -> torch.Tensor:
-    """Real, even spectrum of the integrated Green function, (B, gx+1, gy+1, gz+1) (chx_sc_igf_table +
-    chx_sc_green_spectrum)."""
+def sc_green_spectrum(cell, gamma, bins, exact: bool = False) -> torch.Tensor:
+    """Real, even spectrum of the integrated Green function, (B, gx+1, gy+1, gz+1). Default: chx_sc_green_spectrum_fast
+    (fp32: far cells by the multipole expansion of the cell integral, see include/chx.h); `exact=True`: corner table
+    everywhere (chx_sc_igf_table + chx_sc_green_spectrum)."""
     B = cell.shape[0]
     lib = _lib.lib()
     b3 = _bins3(bins)
     dt = dtype_code(cell.dtype)
     n1 = (bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1)
+    if not exact:
+        ws_bytes = lib.chx_sc_green_fast_workspace_bytes(B, b3, dt)
+        ws = workspace(ws_bytes, cell.device)
+        Ghat = torch.empty((B, bins[0] + 1, bins[1] + 1, bins[2] + 1), dtype=cell.dtype, device=cell.device)
+        check(lib.chx_sc_green_spectrum_fast(ptr(cell), ptr(gamma), B, b3, dt, ptr(Ghat), ptr(ws), ws_bytes, stream_ptr()),
+              "chx_sc_green_spectrum_fast")
+        return Ghat
     table = torch.empty((B, n1), dtype=torch.float64, device=cell.device)
     check(lib.chx_sc_igf_table(ptr(cell), ptr(gamma), B, b3, dt, ptr(table), stream_ptr()), "chx_sc_igf_table")
     ws_bytes = lib.chx_sc_green_workspace_bytes(B, b3, dt)

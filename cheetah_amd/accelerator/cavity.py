@@ -61,12 +61,13 @@ class Cavity(Element):
     @property
     def is_active(self) -> bool:
         # host-side flag, refreshed only when the voltage tensor changes (one sync per change)
-        key = (id(self.voltage), self.voltage._version)
+        # (the tensor itself is kept in the entry: an `id` could be recycled by a later tensor)
+        v = self.voltage
         cached = self.__dict__.get("_active_cache")
-        if cached is None or cached[0] != key:
-            cached = (key, bool((self.voltage != 0).any().item()))
+        if cached is None or cached[0] is not v or cached[1] != v._version:
+            cached = (v, v._version, bool((v != 0).any().item()))
             self.__dict__["_active_cache"] = cached
-        return cached[1]
+        return cached[2]
 
     @property
     def is_skippable(self) -> bool:

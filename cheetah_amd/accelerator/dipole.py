@@ -111,9 +111,17 @@ class RBend(Dipole):
     def rbend_e1(self) -> torch.Tensor:
         return self._e1 - self.angle / 2
 
+    @rbend_e1.setter
+    def rbend_e1(self, value: torch.Tensor) -> None:  # rbend.py:107-110
+        self.dipole_e1 = value + self.angle / 2
+
     @property
     def rbend_e2(self) -> torch.Tensor:
         return self._e2 - self.angle / 2
+
+    @rbend_e2.setter
+    def rbend_e2(self, value: torch.Tensor) -> None:  # rbend.py:114-117
+        self.dipole_e2 = value + self.angle / 2
 
     @property
     def defining_features(self) -> list[str]:

@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import _ops
+from .._cache import TensorKey
 from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
@@ -111,14 +112,17 @@ class Element(nn.Module):
 
     # ---- cache (utils/cache.py) -----------------------------------------------------------------
     def _feature_key(self):
-        key = []
+        """(non-tensor features, defining tensors). The tensors are compared by identity / version / requires_grad against
+        a `TensorKey` that keeps them referenced (an `id` alone can be recycled by a later tensor)."""
+        static, tensors = [], []
         for name in self.defining_features:
             f = getattr(self, name)
             if isinstance(f, torch.Tensor):
-                key.append((id(f), f._version, f.requires_grad))
+                static.append(None)
+                tensors.append(f)
             else:
-                key.append(f if not isinstance(f, (list, dict)) else repr(f))
-        return tuple(key)
+                static.append(f if not isinstance(f, (list, dict)) else repr(f))
+        return tuple(static), tensors
 
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species) -> torch.Tensor:
         return self._cached_map("_map_cache", self._build_map, energy, species)
@@ -148,9 +152,9 @@ class Element(nn.Module):
         if energy.requires_grad or species.mass_eV.requires_grad or species.num_elementary_charges.requires_grad:
             return build(energy, species)
         cache = self.__dict__.get(slot)
-        fkey = self._feature_key()
-        if cache is not None and cache["fkey"] == fkey and cache["mass"] == species.mass_eV_float \
-                and cache["nq"] == species.num_elementary_charges_float:
+        fkey, ftensors = self._feature_key()
+        if cache is not None and cache["fkey"] == fkey and cache["tkey"].matches(ftensors) \
+                and cache["mass"] == species.mass_eV_float and cache["nq"] == species.num_elementary_charges_float:
             ce = cache["energy_ref"]
             if (ce is energy and cache["energy_version"] == energy._version) or (
                 ce.dtype == energy.dtype and ce.device == energy.device and ce.shape == energy.shape
@@ -161,7 +165,7 @@ class Element(nn.Module):
         if result.requires_grad:  # a graph-attached map must not outlive its backward pass
             return result
         self.__dict__[slot] = {
-            "fkey": fkey, "mass": species.mass_eV_float, "nq": species.num_elementary_charges_float,
+            "fkey": fkey, "tkey": TensorKey(ftensors), "mass": species.mass_eV_float, "nq": species.num_elementary_charges_float,
             "energy_ref": energy, "energy_version": energy._version, "energy_copy": energy.detach().clone(),
             "result": result,
         }
@@ -268,6 +272,7 @@ class Element(nn.Module):
         if "_revision" in self.__dict__ and not name.startswith("_"):
             self.__dict__["_revision"] += 1
             self.__dict__["_map_cache"] = None
+            self.__dict__["_tmap_cache"] = None
         return super().__setattr__(name, value)
 
     def register_buffer_or_parameter(self, name: str, value, persistent: bool = True) -> None:

@@ -76,7 +76,7 @@ class _Run:
     def current_token(self, energy, species):
         self._collect()
         return (id(energy), energy._version, species.mass_eV_float, species.num_elementary_charges_float, self.rev,
-                tuple([t._version for t in self.tensors]), tuple([p.requires_grad for p in self.params]))
+                tuple([t._version for t in self.tensors]), tuple([t.requires_grad for t in self.tensors]))
 
 
 class Segment(Element):

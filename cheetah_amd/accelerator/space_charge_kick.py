@@ -20,6 +20,7 @@ import math
 import torch
 
 from .. import _ops
+from .._cache import TensorKey
 from ..particles.particle_beam import ParticleBeam
 from .element import Element
 
@@ -82,13 +83,12 @@ class SpaceChargeKick(Element):
     def _grid_extent(self, dtype) -> torch.Tensor:
         """(Bext, 3) grid extents in sigmas, cached against the three buffers' identity / version."""
         parts = (self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau)
-        key = (dtype, tuple((id(p), p._version) for p in parts))
         cached = self.__dict__.get("_ext_cache")
-        if cached is None or cached[0] != key or any(p.requires_grad for p in parts):
+        if cached is None or cached[0] != dtype or not cached[1].matches(parts) or any(p.requires_grad for p in parts):
             ext = torch.stack(torch.broadcast_tensors(*parts), dim=-1).to(dtype).reshape(-1, 3).contiguous()
-            cached = (key, ext)
+            cached = (dtype, TensorKey(parts), ext)
             self.__dict__["_ext_cache"] = cached
-        return cached[1]
+        return cached[2]
 
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         assert isinstance(incoming, ParticleBeam), \

@@ -388,7 +388,8 @@ struct CicRec {
 };
 
 struct TileGeom {
-    int tdim[3];   // tile edge in cells per axis
+    int tdim[3];   // tile edge in cells per axis (a power of two)
+    int tshift[3]; // log2(tdim)
     int ntile[3];  // number of tiles per axis
     int nt;        // total tiles
 };
@@ -409,31 +410,82 @@ __host__ __device__ inline TileGeom tile_geom(int ndim, const int* bins) {
         if (g.nt <= 8192 || g.tdim[widest] >= 64) break;
         g.tdim[widest] *= 2;
     }
+    for (int d = 0; d < 3; ++d) {
+        g.tshift[d] = 0;
+        while ((1 << g.tshift[d]) < g.tdim[d]) ++g.tshift[d];
+    }
     return g;
 }
 
-constexpr int kAccTileCap = 8192;   // records of a tile handled by its owner workgroup (a +-3 sigma Gaussian stays below)
-constexpr int kSortWG = 256;       // workgroups of the count / scatter passes (per batch row)
-constexpr int kSortThreads = 1024;  // threads of those workgroups (latency-bound loops: many waves)
-
-// tiles touched per axis: [t0, t1] with t1 in {t0, t0 + 1}; cells outside the grid are never deposited
+// Per-axis constants of a batch row for the sort passes: wave-uniform, read once per workgroup (cic_locate re-reads the
+// extent and re-divides for every particle).
 template <typename T, int ND>
-__device__ __forceinline__ void tile_range(const CicDev& a, const TileGeom& g, const CicPoint<T>& pt,
-                                           int (&t0)[3], int (&t1)[3]) {
+struct SortAxes {
+    T l[ND], r[ND], bw[ND], sc[ND], sh[ND];
+    bool has_sc, has_sh;
+};
+
+template <typename T, int ND>
+__device__ __forceinline__ SortAxes<T, ND> sort_axes(const CicDev& a, const T* __restrict__ extent, const T* __restrict__ scale,
+                                                     const T* __restrict__ shift, int64_t b) {
+    SortAxes<T, ND> ax;
+    const T* ext = extent + (a.Be == 1 ? 0 : b) * ND * 2;
+    ax.has_sc = scale != nullptr;
+    ax.has_sh = shift != nullptr;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        ax.l[d] = ext[d * 2];
+        ax.r[d] = ext[d * 2 + 1];
+        ax.bw[d] = (ax.r[d] - ax.l[d]) / (T)a.bins[d];
+        ax.sc[d] = ax.has_sc ? scale[(a.Bsc == 1 ? 0 : b) * ND + d] : (T)1;
+        ax.sh[d] = ax.has_sh ? shift[(a.Bsh == 1 ? 0 : b) * ND + d] : (T)0;
+    }
+    return ax;
+}
+
+// The arithmetic of cic_locate (cloud_in_cell.py:150-172, bit for bit) in 32-bit integers: inside the extent floor(p) lies
+// in [-1, bins], so the conversion is exact, and p - (T)(long long)floor(p) == p - floor(p) for every integral floor(p);
+// particles outside the extent are skipped by the caller. Returns the in-extent mask.
+template <typename T, int ND>
+__device__ __forceinline__ bool sort_locate(const CicDev& a, const SortAxes<T, ND>& ax, const T* __restrict__ xrow, int (&i)[ND],
+                                            T (&f)[ND]) {
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        T v = xrow[a.cols[d]];
+        if (ax.has_sc) v = v * ax.sc[d];
+        if (ax.has_sh) v = v - ax.sh[d];
+        inside = inside && (v >= ax.l[d]) && (v <= ax.r[d]);
+        const T pb = (v - ax.l[d]) / ax.bw[d] - (T)0.5;
+        const T fl = floor(pb);
+        const T flc = fl < (T)-2 ? (T)-2 : (fl > (T)(a.bins[d] + 1) ? (T)(a.bins[d] + 1) : fl);
+        i[d] = (int)flc;
+        f[d] = pb - fl;
+    }
+    return inside;
+}
+
+// tiles touched per axis by the corners i, i + 1 (cells outside the grid are never deposited): [t0, t1], t1 in {t0, t0 + 1}
+template <int ND>
+__device__ __forceinline__ void sort_tile_range(const CicDev& a, const TileGeom& g, const int (&i)[ND], int (&t0)[3], int (&t1)[3]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (d < ND) {
-            long long lo = pt.i[d], hi = pt.i[d] + 1;
-            lo = lo < 0 ? 0 : lo;                               // corner -1 is invalid -> only cell 0 counts
-            hi = hi > a.bins[d] - 1 ? a.bins[d] - 1 : hi;       // corner n is invalid
+            int lo = i[d], hi = i[d] + 1;
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > a.bins[d] - 1 ? a.bins[d] - 1 : hi;
             if (lo > hi) lo = hi;
-            t0[d] = (int)(lo / g.tdim[d]);
-            t1[d] = (int)(hi / g.tdim[d]);
+            t0[d] = lo >> g.tshift[d];
+            t1[d] = hi >> g.tshift[d];
         } else {
             t0[d] = t1[d] = 0;
         }
     }
 }
+
+constexpr int kAccTileCap = 8192;   // records of a tile handled by its owner workgroup (a +-3 sigma Gaussian stays below)
+constexpr int kSortWG = 256;       // workgroups of the count / scatter passes (per batch row)
+constexpr int kSortThreads = 1024;  // threads of those workgroups (latency-bound loops: many waves)
 
 // exclusive prefix sum of v[0..n) in LDS by one workgroup of kSortThreads lanes; returns the total
 __device__ __forceinline__ int block_exclusive_scan(int* v, int n) {
@@ -508,16 +560,25 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
     __syncthreads();
     const int64_t per = (a.N + kSortWG - 1) / kSortWG;
     const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    const SortAxes<T, ND> ax = sort_axes<T, ND>(a, extent, scale, shift, b);
+    const T* __restrict__ xb = x + (a.Bx == 1 ? 0 : b) * a.N * 7;
+    const T* __restrict__ qb = q ? q + (a.Bq == 1 ? 0 : b) * a.N : nullptr;
+    const T* __restrict__ sb = s ? s + (a.Bs == 1 ? 0 : b) * a.N : nullptr;
+    CicRec<T, ND>* __restrict__ rb = recs + b * rec_cap;
     for (int64_t n = n0 + threadIdx.x; n < n1; n += kSortThreads) {
-        const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n);
-        if (!pt.inside) continue;
+        int pi[ND];
+        T pf[ND];
+        if (!sort_locate<T, ND>(a, ax, xb + n * 7, pi, pf)) continue;
         int t0[3], t1[3];
-        tile_range<T, ND>(a, g, pt, t0, t1);
+        sort_tile_range<ND>(a, g, pi, t0, t1);
         CicRec<T, ND> r;
         if (SCATTER) {
 #pragma unroll
-            for (int d = 0; d < ND; ++d) { r.i[d] = (int32_t)pt.i[d]; r.f[d] = pt.f[d]; }
-            r.c = cic_charge<T>(a, q, s, b, n);
+            for (int d = 0; d < ND; ++d) { r.i[d] = pi[d]; r.f[d] = pf[d]; }
+            T c = qb ? qb[n] : (T)1;
+            if (a.abs_charge) c = fabs(c);
+            if (sb) c = c * sb[n];
+            r.c = c;
         }
         for (int tx = t0[0]; tx <= t1[0]; ++tx)
             for (int ty = t0[1]; ty <= t1[1]; ++ty)
@@ -525,7 +586,7 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
                     const int tile = (tx * g.ntile[1] + ty) * g.ntile[2] + tz;
                     const int pos = atomicAdd(&hist[tile], 1);
                     if (SCATTER) {
-                        if (pos < rec_cap) recs[b * rec_cap + pos] = r;
+                        if (pos < rec_cap) rb[pos] = r;
                     }
                 }
     }
@@ -573,7 +634,9 @@ __global__ __launch_bounds__(16 * kScanTiles) void cic_scan_tiles_kernel(int* __
 constexpr int kAccThreads = 1024;  // a hot tile is latency-bound on its record stream: many waves per tile
 constexpr int kAccLightTile = 1024;  // average records per tile below which pass 4a uses 256-thread workgroups
 
-template <typename T, int ND, int THREADS>
+// OVERWRITE: the tile's cells are stored (zeros included, empty tiles too) instead of added to the grid — every grid cell
+// belongs to exactly one tile, so the caller needs no zero fill and the flush has no dependent load.
+template <typename T, int ND, int THREADS, bool OVERWRITE>
 __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileGeom g,
                                                                   const int* __restrict__ tile_start,
                                                                   const CicRec<T, ND>* __restrict__ recs,
@@ -588,7 +651,7 @@ __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileG
     int end = tile_start[b * (g.nt + 1) + t + 1];
     if (end > rec_cap) end = (int)rec_cap;
     if (end > beg + kAccTileCap) end = beg + kAccTileCap;
-    if (beg >= end) return;  // empty tile: nothing to add
+    if (!OVERWRITE && beg >= end) return;  // empty tile: nothing to add
     int ld[3], org[3];       // owned extents and cell origin
     {
         int rem = t;
@@ -653,11 +716,11 @@ __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileG
     T* gb = grid + b * a.gbatch;
     for (int i = threadIdx.x; i < lcells; i += THREADS) {
         const double v = tile[i];
-        if (v == 0.0) continue;
+        if (!OVERWRITE && v == 0.0) continue;
         int l[3];
         int rem = i;
-        l[2] = rem % ld[2]; rem /= ld[2];
-        l[1] = rem % ld[1]; rem /= ld[1];
+        l[2] = rem & (ld[2] - 1); rem >>= g.tshift[2];   // tile edges are powers of two
+        l[1] = rem & (ld[1] - 1); rem >>= g.tshift[1];
         l[0] = rem;
         bool in_grid = true;
         int64_t off = 0;
@@ -669,7 +732,7 @@ __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileG
                 off += (int64_t)cell * a.gstride[d];
             }
         }
-        if (in_grid) gb[off] = (T)((double)gb[off] + v);
+        if (in_grid) gb[off] = OVERWRITE ? (T)v : (T)((double)gb[off] + v);
     }
 }
 
@@ -821,7 +884,8 @@ size_t sorted_ws_bytes(const CicDev& a, const TileGeom& g) {
 }
 
 template <typename T, int ND>
-int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_t workspace_bytes, hipStream_t s) {
+int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_t workspace_bytes, hipStream_t s,
+                  bool overwrite) {
     const TileGeom g = tile_geom(a.ndim, a.bins);
     if (workspace_bytes < sorted_ws_bytes<T, ND>(a, g)) return CHX_ERR_WORKSPACE;
     if ((size_t)g.nt * sizeof(int) > 60 * 1024) return CHX_ERR_INVALID_ARG;
@@ -850,15 +914,17 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
     for (int d = 0; d < ND; ++d) tile_bytes *= (size_t)g.tdim[d];
     // Lightly filled tiles (a diffuse beam: ~250 records per 8^3 tile at N = 1e6 on 128^3) run as 256-thread workgroups,
     // eight per CU instead of two, so the per-workgroup zero / flush latency overlaps; fuller tiles keep 1024 threads.
-    if (a.N / g.nt < kAccLightTile)
-        hipLaunchKernelGGL((cic_accumulate_kernel<T, ND, 256>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(256), tile_bytes, s,
-                           a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
-    else
-        hipLaunchKernelGGL((cic_accumulate_kernel<T, ND, kAccThreads>), dim3((unsigned)g.nt, (unsigned)a.B), dim3(kAccThreads),
-                           tile_bytes, s, a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
+    const dim3 agrid((unsigned)g.nt, (unsigned)a.B);
+    const bool light = a.N / g.nt < kAccLightTile;
+#define CHX_ACC_LAUNCH(THREADS, OVER)                                                                                     \
+    hipLaunchKernelGGL((cic_accumulate_kernel<T, ND, THREADS, OVER>), agrid, dim3(THREADS), tile_bytes, s, a, g,          \
+                       (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid)
+    if (light) { if (overwrite) CHX_ACC_LAUNCH(256, true); else CHX_ACC_LAUNCH(256, false); }
+    else       { if (overwrite) CHX_ACC_LAUNCH(kAccThreads, true); else CHX_ACC_LAUNCH(kAccThreads, false); }
+#undef CHX_ACC_LAUNCH
     CHX_CHECK_LAUNCH();
     unsigned nchunks = (unsigned)((cap + kAccChunk - 1) / kAccChunk);
-    if (nchunks > 1024) nchunks = 1024;  // chunk-strided inside the kernel
+    if (nchunks > 256) nchunks = 256;  // chunk-strided inside the kernel; it returns at once unless a tile is hot
     hipLaunchKernelGGL((cic_accumulate_hot_kernel<T, ND>), dim3(nchunks, (unsigned)a.B), dim3(kAccThreads), tile_bytes, s,
                        a, g, (const int*)starts, (const CicRec<T, ND>*)recs, cap, (T*)p->grid);
     CHX_CHECK_LAUNCH();
@@ -988,7 +1054,7 @@ extern "C" size_t chx_cic_sorted_workspace_bytes(const chx_cic_args* p) {
     return a.ndim == 2 ? sorted_ws_bytes<double, 2>(a, g) : sorted_ws_bytes<double, 3>(a, g);
 }
 
-extern "C" int chx_cic_deposit_sorted(const chx_cic_args* p, void* workspace, size_t workspace_bytes, void* stream) {
+static int deposit_sorted(const chx_cic_args* p, void* workspace, size_t workspace_bytes, void* stream, bool overwrite) {
     CicDev a;
     int st = cic_prepare(p, a);
     if (st != CHX_OK) return st;
@@ -996,8 +1062,17 @@ extern "C" int chx_cic_deposit_sorted(const chx_cic_args* p, void* workspace, si
     if (!workspace) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (p->dtype == CHX_F32)
-        return a.ndim == 2 ? launch_sorted<float, 2>(a, p, workspace, workspace_bytes, s)
-                           : launch_sorted<float, 3>(a, p, workspace, workspace_bytes, s);
-    return a.ndim == 2 ? launch_sorted<double, 2>(a, p, workspace, workspace_bytes, s)
-                       : launch_sorted<double, 3>(a, p, workspace, workspace_bytes, s);
+        return a.ndim == 2 ? launch_sorted<float, 2>(a, p, workspace, workspace_bytes, s, overwrite)
+                           : launch_sorted<float, 3>(a, p, workspace, workspace_bytes, s, overwrite);
+    return a.ndim == 2 ? launch_sorted<double, 2>(a, p, workspace, workspace_bytes, s, overwrite)
+                       : launch_sorted<double, 3>(a, p, workspace, workspace_bytes, s, overwrite);
+}
+
+extern "C" int chx_cic_deposit_sorted(const chx_cic_args* p, void* workspace, size_t workspace_bytes, void* stream) {
+    return deposit_sorted(p, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int chx_cic_deposit_sorted_overwrite(const chx_cic_args* p, void* workspace, size_t workspace_bytes,
+                                                void* stream) {
+    return deposit_sorted(p, workspace, workspace_bytes, stream, true);
 }

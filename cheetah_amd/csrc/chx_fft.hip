@@ -12,6 +12,7 @@
 //     (g+1)^3 reals (8.6 MB instead of a 67 MB complex array); the spectral multiply looks it up by |k|.
 // Line lengths n = 2g must be powers of two (64 ... 1024); other grids use the hipFFT path (chx_sc_fft_exec).
 #include "chx_common.h"
+#include "chx_sc_math.h"
 
 namespace {
 
@@ -460,16 +461,140 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_compact_kernel(const double* __
     const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
     const double* tb = table + b * npts;
     const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
-    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < npts; idx += (int64_t)gridDim.x * CHX_BLOCK) {
-        const int k = (int)(idx % (gz + 1));
-        const int j = (int)((idx / (gz + 1)) % (gy + 1));
-        const int i = (int)(idx / sx);
+    // 32-bit index arithmetic: (g + 1)^3 <= 513^3 < 2^31 (64-bit integer division is ~100 instructions on this target and
+    // used to be most of this kernel's 38 us)
+    const unsigned n1u = (unsigned)(gz + 1), n2u = (unsigned)(gy + 1);
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)npts; idx += gridDim.x * CHX_BLOCK) {
+        const unsigned q1 = idx / n1u;
+        const int k = (int)(idx - q1 * n1u);
+        const unsigned q2 = q1 / n2u;
+        const int j = (int)(q1 - q2 * n2u);
+        const int i = (int)q2;
         double g = 0.0;
         if (i < gx && j < gy && k < gz) {
             const double* p = tb + i * sx + j * sy + k;
             g = p[sx + sy + 1] - p[sy + 1] - p[sx + 1] - p[sx + sy] + p[sx] + p[sy] + p[1] - p[0];
         }
         Gc[b * npts + idx] = (T)g;
+    }
+}
+
+// ---- far-field form of the integrated Green function (fp32 grids) ------------------------------------------------
+// G_ijk = integral of 1/r over the cell centred at R = (i dx, j dy, k dt) (space_charge_kick.py:170-236 evaluates it as
+// the signed 8-corner difference of the primitive F, 48 fp64 transcendentals per cell there, 6 per corner point here).
+// For |R| >= kFarRatio * max(dx, dy, dt) the Taylor expansion of 1/|R + s| about the cell centre, integrated over the
+// cell, is used instead (odd orders vanish by symmetry; with c_a = R_a^2 / R^2, e_a = h_a^2 / R^2):
+//   G = V / R * [ 1 + sum_a e_a (3 c_a - 1) / 24
+//                   + sum_a e_a^2 (105 c_a^2 - 90 c_a + 9) / 1920
+//                   + sum_{a<b} e_a e_b (105 c_a c_b - 15 (c_a + c_b) + 3) / 576 ]  + O(e^3)
+// Relative error <= 1e-8 at ratio 8 (checked against the 8-corner form in 80-bit arithmetic for isotropic and 1 : 1.3 : 440
+// cells) — six times below the fp32 rounding of the stored value, and smaller than the cancellation error of the
+// reference's own fp64 corner differences for stretched cells (5e-7 at 24 cells' distance for the 1 : 1.3 : 440 case).
+// Only the fp32 path uses it; fp64 grids keep the corner table everywhere.
+constexpr double kFarRatio = 8.0;
+
+struct FarGeom {
+    double dx, dy, dt, thr2;
+};
+
+template <typename T>
+__device__ __forceinline__ FarGeom far_geom(const T* __restrict__ cell, const T* __restrict__ gamma, int64_t b) {
+    FarGeom f;
+    f.dx = (double)cell[b * 3 + 0];
+    f.dy = (double)cell[b * 3 + 1];
+    f.dt = (double)(T)(cell[b * 3 + 2] * gamma[b]);   // space_charge_kick.py:170-176, product in the working dtype
+    const double hm = fmax(f.dx, fmax(f.dy, f.dt));
+    f.thr2 = (kFarRatio * hm) * (kFarRatio * hm);
+    return f;
+}
+
+// margin: the table keeps points up to 1.001 x the threshold, the compact kernel (fp32 test, 1.0001 x) calls a cell near
+// only well inside that — every corner a near cell reads is therefore in the table
+__device__ __forceinline__ bool far_for_table(const FarGeom& f, int i, int j, int k) {
+    const double x = i * f.dx, y = j * f.dy, z = k * f.dt;
+    return x * x + y * y + z * z >= f.thr2 * 1.001;
+}
+
+// Corner table restricted to the points a near cell needs: point (i, j, k) is a corner of the cells (i-1..i, j-1..j,
+// k-1..k); |R| grows with every index, so the point is needed iff its smallest adjacent cell is near. The thread index
+// runs fastest along the axis with the SMALLEST cell (the near region is longest there: for a relativistic bunch
+// dt = gamma * dz dominates and the near set is the slab k < 8): whole waves are skipped or kept.
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void igf_table_near_kernel(const T* __restrict__ cell, const T* __restrict__ gamma,
+                                                                  int gx, int gy, int gz, double* __restrict__ table) {
+    const int64_t b = blockIdx.y;
+    const FarGeom f = far_geom<T>(cell, gamma, b);
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    const int fast = (f.dx <= f.dy && f.dx <= f.dt) ? 0 : (f.dy <= f.dt ? 1 : 2);
+    const int n0 = gx + 1, n1 = gy + 1, n2 = gz + 1;
+    // extents in thread order (fast, mid, slow)
+    const int nf = fast == 0 ? n0 : (fast == 1 ? n1 : n2);
+    const int nm = fast == 0 ? n1 : n0;                       // mid = x unless x is the fast axis
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)npts; idx += gridDim.x * CHX_BLOCK) {
+        const unsigned q1 = idx / (unsigned)nf;
+        const int pf = (int)(idx - q1 * (unsigned)nf);
+        const unsigned q2 = q1 / (unsigned)nm;
+        const int pm = (int)(q1 - q2 * (unsigned)nm);
+        const int ps = (int)q2;
+        // fast 0: (x, y, z) = (pf, pm, ps); fast 1: (pm, pf, ps); fast 2: (pm, ps, pf)
+        const int i = fast == 0 ? pf : pm;
+        const int j = fast == 0 ? pm : (fast == 1 ? pf : ps);
+        const int k = fast == 2 ? pf : ps;
+        if (far_for_table(f, i > 0 ? i - 1 : 0, j > 0 ? j - 1 : 0, k > 0 ? k - 1 : 0)) continue;
+        table[b * npts + ((int64_t)i * n1 + j) * n2 + k] = igf_primitive<double>((i - 0.5) * f.dx, (j - 0.5) * f.dy, (k - 0.5) * f.dt);
+    }
+}
+
+// Compact Green function like igf_compact_kernel, far cells by the expansion above, near cells from the corner table.
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void igf_compact_far_kernel(const double* __restrict__ table, const T* __restrict__ cell,
+                                                                   const T* __restrict__ gamma, int gx, int gy, int gz,
+                                                                   T* __restrict__ Gc) {
+    const int64_t b = blockIdx.y;
+    const FarGeom f = far_geom<T>(cell, gamma, b);
+    const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
+    const double* tb = table + b * npts;
+    const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
+    // The far cells are evaluated in fp32 (this kernel only serves fp32 grids: the stored value is rounded to fp32 anyway):
+    // the leading term V / R comes from v_rsq_f32 refined by one Newton step, the bracket is 1 + O(1e-2) — about 1e-7
+    // relative in total, where the fp64 form (one division, one square root and ~70 flops per cell) cost 33 us next to the
+    // deposit kernels it shares the CUs with.
+    const float dxf = (float)f.dx, dyf = (float)f.dy, dtf = (float)f.dt;
+    const float Vf = (float)(f.dx * f.dy * f.dt), hx2 = dxf * dxf, hy2 = dyf * dyf, hz2 = dtf * dtf;
+    const float thr2f = (float)f.thr2;
+    // 32-bit index arithmetic: (g + 1)^3 <= 1025^3 < 2^31
+    const unsigned n1u = (unsigned)(gz + 1), n2u = (unsigned)(gy + 1);
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)npts; idx += gridDim.x * CHX_BLOCK) {
+        const unsigned q1 = idx / n1u;
+        const int k = (int)(idx - q1 * n1u);
+        const unsigned q2 = q1 / n2u;
+        const int j = (int)(q1 - q2 * n2u);
+        const int i = (int)q2;
+        T g = (T)0;
+        if (i < gx && j < gy && k < gz) {
+            const float x = (float)i * dxf, y = (float)j * dyf, z = (float)k * dtf;
+            const float x2 = x * x, y2 = y * y, z2 = z * z, R2 = x2 + y2 + z2;
+            // fp32 test with a 1.0001 margin; the table was filled up to 1.001 x the threshold (far_for_table), so every
+            // corner of a cell taken as near here is present
+            if (R2 >= thr2f * 1.0001f) {
+                float rinv = __frsqrt_rn(R2);
+                rinv = rinv * (1.5f - 0.5f * R2 * rinv * rinv);
+                const float inv = rinv * rinv;
+                const float cx = x2 * inv, cy = y2 * inv, cz = z2 * inv;
+                const float ex = hx2 * inv, ey = hy2 * inv, ez = hz2 * inv;
+                const float t2 = (ex * (3.0f * cx - 1.0f) + ey * (3.0f * cy - 1.0f) + ez * (3.0f * cz - 1.0f)) * (1.0f / 24.0f);
+                const float t4a = ex * ex * ((105.0f * cx - 90.0f) * cx + 9.0f) + ey * ey * ((105.0f * cy - 90.0f) * cy + 9.0f) +
+                                  ez * ez * ((105.0f * cz - 90.0f) * cz + 9.0f);
+                const float t4b = ex * ey * (105.0f * cx * cy - 15.0f * (cx + cy) + 3.0f) +
+                                  ex * ez * (105.0f * cx * cz - 15.0f * (cx + cz) + 3.0f) +
+                                  ey * ez * (105.0f * cy * cz - 15.0f * (cy + cz) + 3.0f);
+                g = (T)(Vf * rinv * (1.0f + t2 + t4a * (1.0f / 1920.0f) + t4b * (1.0f / 576.0f)));
+            } else {
+                const double* p = tb + i * sx + j * sy + k;
+                g = (T)(p[sx + sy + 1] - p[sy + 1] - p[sx + 1] - p[sx + sy] + p[sx] + p[sy] + p[1] - p[0]);
+            }
+        }
+        Gc[b * npts + idx] = g;
     }
 }
 
@@ -511,14 +636,20 @@ extern "C" size_t chx_sc_green_workspace_bytes(int64_t B, const int32_t* bins, i
     return (size_t)B * 2 * (size_t)(bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1) * esz;
 }
 
+// cell / gamma non-null: far-field compact kernel (the table then only holds the near points)
 template <typename T>
-static int green_spectrum_impl(const double* table, int64_t B, const int32_t* bins, T* Ghat, T* ws, hipStream_t s) {
+static int green_spectrum_impl(const double* table, const T* cell, const T* gamma, int64_t B, const int32_t* bins, T* Ghat,
+                               T* ws, hipStream_t s) {
     const int gx = bins[0], gy = bins[1], gz = bins[2];
     const int64_t n1 = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
     T* Gc = ws;
     T* H = ws + B * n1;
     int grid = chx_grid_for(n1, CHX_BLOCK, 4096);
-    hipLaunchKernelGGL(igf_compact_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, gx, gy, gz, Gc);
+    if (cell)
+        hipLaunchKernelGGL(igf_compact_far_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, cell,
+                           gamma, gx, gy, gz, Gc);
+    else
+        hipLaunchKernelGGL(igf_compact_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, gx, gy, gz, Gc);
     CHX_CHECK_LAUNCH();
     const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
     // z: lines (x, y), points contiguous; even extension in, real out (kz <= gz)           Gc -> H
@@ -544,8 +675,37 @@ extern "C" int chx_sc_green_spectrum(const double* table, int64_t B, const int32
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (!workspace || workspace_bytes < chx_sc_green_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == CHX_F32 ? green_spectrum_impl<float>(table, B, bins, (float*)Ghat, (float*)workspace, s)
-                            : green_spectrum_impl<double>(table, B, bins, (double*)Ghat, (double*)workspace, s);
+    return dtype == CHX_F32 ? green_spectrum_impl<float>(table, nullptr, nullptr, B, bins, (float*)Ghat, (float*)workspace, s)
+                            : green_spectrum_impl<double>(table, nullptr, nullptr, B, bins, (double*)Ghat, (double*)workspace, s);
+}
+
+// workspace of chx_sc_green_spectrum_fast: the corner table (double) followed by chx_sc_green_spectrum's workspace
+extern "C" size_t chx_sc_green_fast_workspace_bytes(int64_t B, const int32_t* bins, int dtype) {
+    if (B < 1 || !chx_sc_pruned_supported(bins, dtype)) return 0;
+    const size_t npts = (size_t)(bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1);
+    return (((size_t)B * npts * sizeof(double) + 255) & ~(size_t)255) + chx_sc_green_workspace_bytes(B, bins, dtype);
+}
+
+// Green spectrum straight from the cell sizes: chx_sc_igf_table + chx_sc_green_spectrum in one call. fp32 grids evaluate
+// the primitive only where the far-field expansion (above) is not accurate to fp32 rounding; fp64 grids are exact everywhere.
+extern "C" int chx_sc_green_spectrum_fast(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
+                                          void* Ghat, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!cell || !gamma || !Ghat || B < 1 || B > 65535 || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < chx_sc_green_fast_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npts = (size_t)(bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1);
+    double* table = (double*)workspace;
+    char* rest = (char*)workspace + (((size_t)B * npts * sizeof(double) + 255) & ~(size_t)255);
+    if (dtype == CHX_F64) {
+        int st = chx_sc_igf_table(cell, gamma, B, bins, dtype, table, stream);
+        if (st != CHX_OK) return st;
+        return green_spectrum_impl<double>(table, nullptr, nullptr, B, bins, (double*)Ghat, (double*)rest, s);
+    }
+    const int grid = chx_grid_for((int64_t)npts, CHX_BLOCK, 8192);
+    hipLaunchKernelGGL(igf_table_near_kernel<float>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, (const float*)cell,
+                       (const float*)gamma, bins[0], bins[1], bins[2], table);
+    CHX_CHECK_LAUNCH();
+    return green_spectrum_impl<float>(table, (const float*)cell, (const float*)gamma, B, bins, (float*)Ghat, (float*)rest, s);
 }
 
 // workspace of chx_sc_convolve per batch row: A [gx][gy][gz+1], Bf [gx][2gy][gz+1], C [2gx][2gy][gz+1] complex

@@ -8,7 +8,10 @@
 // the 4 waves -> per-workgroup partials in the caller's workspace -> a second tiny kernel sums the
 // partials in a fixed order (deterministic, no float atomics).
 // The same machinery gives dR = sum_n dY^T X for the apply backward.
+#include <cstdlib>
+
 #include "chx_common.h"
+#include "chx_sc_math.h"
 
 namespace {
 
@@ -25,16 +28,36 @@ __host__ __device__ inline int64_t red_nblk(int64_t B, int64_t N, int tile_rows)
     return tiles < cap ? tiles : cap;
 }
 
+// Workgroups of the one-pass moments kernel (per batch row). With the DPP block reduction the per-workgroup epilogue is
+// ~350 VALU instructions, so the grid is sized for latency hiding (4 workgroups per CU), not to minimise the number of
+// reductions. CHX_TUNE_MOMENTS_WGS overrides the total (benchmarks only; read once).
+inline int64_t onepass_total_wgs() {
+    static const int64_t v = [] {
+        const char* e = getenv("CHX_TUNE_MOMENTS_WGS");
+        const long n = e ? atol(e) : 0;
+        return (int64_t)(n >= 1 && n <= 1024 ? n : 1024);
+    }();
+    return v;
+}
+inline int64_t onepass_nblk(int64_t B, int64_t N, int tile_rows) {
+    const int64_t tiles = (N + tile_rows - 1) / tile_rows;
+    int64_t cap = onepass_total_wgs() / B;
+    if (cap < 1) cap = 1;
+    return tiles < cap ? tiles : cap;
+}
+
 // Generic reduction over the particles of batch row b = blockIdx.y. Each lane streams its own 28-/56-byte
 // rows straight from global memory (measured on MI355X: dword-strided row reads reach the same bandwidth as
 // LDS-staged float4 tiles, benchmarks/apply_variants.hip "direct dword"), 2 rows in flight per lane and
 // iteration, no barrier inside the loop; one block reduction at the end.
 // F::accumulate(x[7], w, n, acc[K]) is called once per particle.
-template <typename T, int K, typename F>
+// TRANSPOSED: the K block sums are written by K lanes to partial_out[k * out_stride] (partials laid out [k][block], so
+// that the finalize kernel reads them coalesced) after a DPP row reduction + one LDS exchange of 16 row sums.
+template <typename T, int K, typename F, bool TRANSPOSED = false>
 __device__ __forceinline__ void tiled_reduce(const T* __restrict__ x, const T* __restrict__ w,
                                              int64_t Bx, int64_t Bw, int64_t N, F& f,
-                                             double* __restrict__ partial_out /*[K]*/) {
-    __shared__ double red[4 * K];
+                                             double* __restrict__ partial_out /*[K]*/, int64_t out_stride = 1) {
+    __shared__ double red[(TRANSPOSED ? 16 : 4) * K];
     const int64_t b = blockIdx.y;
     const int64_t xrow = (Bx == 1) ? 0 : b, wrow = (Bw == 1) ? 0 : b;
     const T* __restrict__ xb = x + xrow * N * 7;
@@ -42,30 +65,49 @@ __device__ __forceinline__ void tiled_reduce(const T* __restrict__ x, const T* _
     double acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * CHX_BLOCK;
-    int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x;
-    for (; n + 3 * stride < N; n += 4 * stride) {  // four rows in flight per lane
+    // every workgroup owns a contiguous range of rows (a multiple of the block size); four rows in flight per lane and
+    // iteration, rows past the end of the range predicated off
+    const int64_t per = (((N + gridDim.x - 1) / gridDim.x + CHX_BLOCK - 1) / CHX_BLOCK) * CHX_BLOCK;
+    const int64_t n0 = (int64_t)blockIdx.x * per;
+    const int64_t n1 = (n0 + per < N) ? n0 + per : N;
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += 4 * CHX_BLOCK) {
         T r[4][7];
         double wv[4];
+        bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            const int64_t nn = n + u * CHX_BLOCK;
+            ok[u] = nn < n1;
+            const int64_t src = ok[u] ? nn : n;
 #pragma unroll
-            for (int j = 0; j < 7; ++j) r[u][j] = xb[(n + u * stride) * 7 + j];
-            wv[u] = wb ? (double)wb[n + u * stride] : 1.0;
+            for (int j = 0; j < 7; ++j) r[u][j] = xb[src * 7 + j];
+            wv[u] = wb ? (double)wb[src] : 1.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
             double xv[7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) xv[j] = (double)r[u][j];
-            f.accumulate(xv, wv[u], n + u * stride, acc);
+            f.accumulate(xv, wv[u], n + u * CHX_BLOCK, acc);
         }
     }
-    for (; n < N; n += stride) {
-        double xv[7];
+    if (TRANSPOSED) {
+        const int lane = threadIdx.x & 63, row = (threadIdx.x >> 6) * 4 + (lane >> 4);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xv[j] = (double)xb[n * 7 + j];
-        f.accumulate(xv, wb ? (double)wb[n] : 1.0, n, acc);
+        for (int k = 0; k < K; ++k) acc[k] = chx_row16_sum(acc[k]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[row * K + k] = acc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < K) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * K + threadIdx.x];
+            partial_out[threadIdx.x * out_stride] = t;
+        }
+        return;
     }
     chx_block_sum<K>(acc, red);
     if (threadIdx.x == 0) {
@@ -453,26 +495,42 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __r
     const T* x0 = x + ((Bx == 1) ? 0 : (int64_t)blockIdx.y) * N * 7;
 #pragma unroll
     for (int j = 0; j < 6; ++j) f.c[j] = (double)x0[j];
-    tiled_reduce<T, kTM, OnePassFn>(x, w, Bx, Bw, N, f, partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kTM);
+    // partials[b][k][blk]
+    tiled_reduce<T, kTM, OnePassFn, true>(x, w, Bx, Bw, N, f,
+                                          partials + (int64_t)blockIdx.y * kTM * gridDim.x + blockIdx.x, gridDim.x);
 }
 
-// One workgroup per batch row: wave k sums partial k over the blocks in a fixed order, then lanes 0..28 of wave 0
-// re-centre and normalise -> out[b][29]. Replaces reduce_partials x2 + finalize of the two-pass path.
+// One workgroup per batch row: lane t holds partial block t of all 29 sums (partials[b][k][blk]: coalesced loads, all in
+// flight at once), DPP row sums, one LDS exchange of the 64 row sums, then lanes 0..28 add them in a fixed order and lane 0
+// re-centres and normalises -> out[b][29]. Replaces reduce_partials x2 + finalize of the two-pass path.
 template <typename T>
 __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const double* __restrict__ partials, int nblk,
                                                                       const T* __restrict__ x, int64_t Bx, int64_t N,
                                                                       double* __restrict__ out) {
+    __shared__ double red[64 * kTM];
     __shared__ double tot[32];
     const int64_t b = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = wave; k < kTM; k += 16) {
-        const double* p = partials + b * nblk * kTM + k;
-        double s0 = 0.0, s1 = 0.0;
-        int i = lane;
-        for (; i + 64 < nblk; i += 128) { s0 += p[(int64_t)i * kTM]; s1 += p[(int64_t)(i + 64) * kTM]; }
-        for (; i < nblk; i += 64) s0 += p[(int64_t)i * kTM];
-        const double s = chx_wave_sum(s0 + s1);
-        if (lane == 0) tot[k] = s;
+    const double* pb = partials + b * kTM * (int64_t)nblk;
+    double a[kTM];
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) a[k] = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 1024) {
+#pragma unroll
+        for (int k = 0; k < kTM; ++k) a[k] += pb[(int64_t)k * nblk + i];
+    }
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) a[k] = chx_row16_sum(a[k]);
+    if ((threadIdx.x & 15) == 0) {
+        const int row = threadIdx.x >> 4;
+#pragma unroll
+        for (int k = 0; k < kTM; ++k) red[row * kTM + k] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kTM) {
+        double t = 0.0;
+        const int rows = (nblk + 15) / 16 < 64 ? (nblk + 15) / 16 : 64;
+        for (int r = 0; r < rows; ++r) t += red[r * kTM + threadIdx.x];
+        tot[threadIdx.x] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -487,6 +545,86 @@ __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const dou
         int k = 8;
         for (int i = 0; i < 6; ++i)
             for (int j = i; j < 6; ++j, ++k) o[k] = (tot[k] - W * m[i] * m[j]) / cf;
+    }
+}
+
+// ---- beam sizes for the space-charge grid (chx_sc_beam_geometry): the three variances SpaceChargeKick needs
+// (space_charge_kick.py:531-538: sigma_x, sigma_y, sigma_tau) with 8 accumulators instead of the 29 of chx_moments, and the
+// reduce / finalize step folded into the geometry kernel — two launches per kick instead of three, a third of the registers.
+constexpr int kSG = 8;   // W, W2, s_x, s_y, s_tau, m_xx, m_yy, m_tautau (shifted about the row's first particle)
+struct SigmaFn {
+    double c[3];
+    __device__ __forceinline__ void accumulate(const double (&x)[7], double w, int64_t, double (&a)[kSG]) {
+        const double d0 = x[0] - c[0], d1 = x[2] - c[1], d2 = x[4] - c[2];
+        a[0] += w;
+        a[1] += w * w;
+        const double w0 = w * d0, w1 = w * d1, w2 = w * d2;
+        a[2] += w0;
+        a[3] += w1;
+        a[4] += w2;
+        a[5] = fma(w0, d0, a[5]);
+        a[6] = fma(w1, d1, a[6]);
+        a[7] = fma(w2, d2, a[7]);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void sc_sigma_kernel(const T* __restrict__ x, const T* __restrict__ w, int64_t Bx,
+                                                            int64_t Bw, int64_t N, double* __restrict__ partials) {
+    SigmaFn f;
+    const T* x0 = x + ((Bx == 1) ? 0 : (int64_t)blockIdx.y) * N * 7;
+    f.c[0] = (double)x0[0];
+    f.c[1] = (double)x0[2];
+    f.c[2] = (double)x0[4];
+    // partials[b][k][blk]
+    tiled_reduce<T, kSG, SigmaFn, true>(x, w, Bx, Bw, N, f, partials + (int64_t)blockIdx.y * kSG * gridDim.x + blockIdx.x,
+                                        gridDim.x);
+}
+
+// one workgroup per batch row: sum the partial blocks (lane t holds block t, t + 256, ...), then lane 0 forms the variances
+// exactly like moments_reduce_finalize_kernel and writes the grid geometry
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
+    const double* __restrict__ partials, int nblk, const T* __restrict__ ext, const T* __restrict__ energy,
+    const T* __restrict__ length, double mass, double pot_factor, int64_t Bext, int64_t Be, int64_t Bl, int gx, int gy, int gz,
+    T* __restrict__ half, T* __restrict__ cell, T* __restrict__ gamma_out, T* __restrict__ dt, T* __restrict__ scale,
+    T* __restrict__ extent, double* __restrict__ pot_scale) {
+    __shared__ double red[16 * kSG];
+    __shared__ double tot[kSG];
+    const int64_t b = blockIdx.x;
+    const double* pb = partials + b * kSG * (int64_t)nblk;
+    double a[kSG];
+#pragma unroll
+    for (int k = 0; k < kSG; ++k) a[k] = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CHX_BLOCK) {
+#pragma unroll
+        for (int k = 0; k < kSG; ++k) a[k] += pb[(int64_t)k * nblk + i];
+    }
+#pragma unroll
+    for (int k = 0; k < kSG; ++k) a[k] = chx_row16_sum(a[k]);
+    if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < kSG; ++k) red[(threadIdx.x >> 4) * kSG + k] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kSG) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r * kSG + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double W = tot[0], W2 = tot[1];
+        const double cf = W - W2 / W;
+        double var[3];
+        for (int d = 0; d < 3; ++d) {
+            const double m = tot[2 + d] / W;
+            var[d] = (tot[5 + d] - W * m * m) / cf;
+        }
+        sc_geometry_row<T>(var, ext + ((Bext == 1) ? 0 : b) * 3, energy[(Be == 1) ? 0 : b], length[(Bl == 1) ? 0 : b], mass,
+                           pot_factor, gx, gy, gz, half + b * 3, cell + b * 3, gamma_out + b, dt + b, scale + b * 3,
+                           extent + b * 6, pot_scale + b);
     }
 }
 
@@ -547,7 +685,9 @@ inline int tile_rows(int dtype) { return dtype == CHX_F32 ? 512 : 256; }
 
 static size_t partials_bytes(int64_t B, int64_t N) {
     // worst case over dtypes (fp64 tiles are 256 rows -> more tiles)
-    const int64_t nblk = red_nblk(B, N, 256);
+    int64_t nblk = red_nblk(B, N, 256);
+    const int64_t nblk1 = onepass_nblk(B, N, 256);
+    if (nblk1 > nblk) nblk = nblk1;
     return (size_t)(B * nblk * 29 * sizeof(double));  // 29 = one-pass accumulators (two-pass passes need 8 / 21)
 }
 
@@ -627,7 +767,7 @@ extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, 
     if (!w) Bw = 1;
     // one sweep over the particles + one reduce/finalize launch (the split two-pass entry points above remain for
     // the multi-GPU path, where the means are all-reduced between the passes)
-    const int64_t nblk = red_nblk(B, N, tile_rows(dtype));
+    const int64_t nblk = onepass_nblk(B, N, tile_rows(dtype));
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)workspace;
     dim3 grid((unsigned)nblk, (unsigned)B);
@@ -643,6 +783,47 @@ extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, 
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(moments_reduce_finalize_kernel<double>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
                            (const double*)x, Bx, N, out);
+    }
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" size_t chx_sc_beam_geometry_workspace_bytes(int64_t B, int64_t N) {
+    if (B < 1 || N < 1) return 0;
+    return (size_t)(B * onepass_nblk(B, N, 256) * kSG * sizeof(double));
+}
+
+extern "C" int chx_sc_beam_geometry(const void* x, const void* w, const void* grid_extent, const void* energy,
+                                    const void* length, double mass_eV, double pot_factor, int64_t B, int64_t Bx, int64_t Bw,
+                                    int64_t Bext, int64_t Be, int64_t Bl, int64_t N, const int32_t* bins, int dtype, void* half,
+                                    void* cell, void* gamma, void* dt, void* scale, void* extent, double* pot_scale,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!grid_extent || !energy || !length || !half || !cell || !gamma || !dt || !scale || !extent || !pot_scale || !bins)
+        return CHX_ERR_INVALID_ARG;
+    int st = check_red(x, B, Bx, w ? Bw : 1, N, dtype);
+    if (st != CHX_OK) return st;
+    if (!chx_bcast_ok(Bext, B) || !chx_bcast_ok(Be, B) || !chx_bcast_ok(Bl, B)) return CHX_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < chx_sc_beam_geometry_workspace_bytes(B, N)) return CHX_ERR_WORKSPACE;
+    if (!w) Bw = 1;
+    const int64_t nblk = onepass_nblk(B, N, tile_rows(dtype));
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    const dim3 grid((unsigned)nblk, (unsigned)B);
+    if (dtype == CHX_F32) {
+        hipLaunchKernelGGL(sc_sigma_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x, (const float*)w, Bx, Bw, N, part);
+        CHX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sc_geometry_partials_kernel<float>, dim3((unsigned)B), dim3(CHX_BLOCK), 0, s, part, (int)nblk,
+                           (const float*)grid_extent, (const float*)energy, (const float*)length, mass_eV, pot_factor, Bext, Be,
+                           Bl, bins[0], bins[1], bins[2], (float*)half, (float*)cell, (float*)gamma, (float*)dt, (float*)scale,
+                           (float*)extent, pot_scale);
+    } else {
+        hipLaunchKernelGGL(sc_sigma_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x, (const double*)w, Bx, Bw, N,
+                           part);
+        CHX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sc_geometry_partials_kernel<double>, dim3((unsigned)B), dim3(CHX_BLOCK), 0, s, part, (int)nblk,
+                           (const double*)grid_extent, (const double*)energy, (const double*)length, mass_eV, pot_factor, Bext,
+                           Be, Bl, bins[0], bins[1], bins[2], (double*)half, (double*)cell, (double*)gamma, (double*)dt,
+                           (double*)scale, (double*)extent, pot_scale);
     }
     CHX_CHECK_LAUNCH();
     return CHX_OK;

@@ -18,7 +18,7 @@ constexpr int64_t kSortedMinParticles = 65536;  // below this the direct deposit
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t mom_ws, mom, geo, pot, rho, dep_ws, table, green_ws, ghat, conv_ws, phi, force, total;
+    size_t mom_ws, mom, geo, pot, rho, dep_ws, table, green_ws, ghat, conv_ws, phi, force, total;  // table: end of dep_ws
 };
 
 chx_cic_args deposit_args(int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t N, const int32_t* bins, int dtype) {
@@ -44,8 +44,8 @@ Layout layout(int64_t B, int64_t N, const int32_t* bins, int dtype) {
     Layout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += align256(bytes); return at; };
-    L.mom_ws = take(chx_moments_workspace_bytes(B, N));
-    L.mom = take((size_t)B * CHX_MOM_NOUT * sizeof(double));
+    L.mom_ws = take(chx_sc_beam_geometry_workspace_bytes(B, N));
+    L.mom = take(0);
     L.geo = take((size_t)B * 17 * esz);          // half 3, cell 3, gamma 1, dt 1, scale 3, extent 6
     L.pot = take((size_t)B * sizeof(double));
     L.rho = take((size_t)B * ncell * esz);
@@ -53,8 +53,8 @@ Layout layout(int64_t B, int64_t N, const int32_t* bins, int dtype) {
     // the workspace query only reads shapes; it needs non-null x / extent pointers to pass validation
     a.x = &a; a.extent = &a;
     L.dep_ws = take(N >= kSortedMinParticles ? chx_cic_sorted_workspace_bytes(&a) : 0);
-    L.table = take((size_t)B * npts * sizeof(double));
-    L.green_ws = take(chx_sc_green_workspace_bytes(B, bins, dtype));
+    L.table = take(0);
+    L.green_ws = take(chx_sc_green_fast_workspace_bytes(B, bins, dtype));   // corner table + compact Green function
     L.ghat = take((size_t)B * npts * esz);
     L.conv_ws = take(chx_sc_convolve_workspace_bytes(B, bins, dtype));
     L.phi = take((size_t)B * ncell * esz);
@@ -84,7 +84,6 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     hipStream_t main = (hipStream_t)stream;
     hipStream_t side = side_stream ? (hipStream_t)side_stream : main;
 
-    double* mom = (double*)(ws + L.mom);
     char* geo = ws + L.geo;
     void* half = geo;
     void* cell = geo + (size_t)B * 3 * esz;
@@ -94,19 +93,17 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     void* extent = geo + (size_t)B * 11 * esz;
     double* pot_scale = (double*)(ws + L.pot);
     void* rho = ws + L.rho;
-    double* table = (double*)(ws + L.table);
     void* ghat = ws + L.ghat;
     void* phi = ws + L.phi;
     void* force = ws + L.force;
 
     // beam sizes -> grid geometry (space_charge_kick.py:531-550); the unnormalised inverse FFT's 1 / (8 g^3) goes into
     // the potential factor
-    int st = chx_moments(x_in, survival, B, Bx, Bs, N, dtype, mom, ws + L.mom_ws, L.mom - L.mom_ws, main);
-    if (st != CHX_OK) return st;
     const double n_padded = 8.0 * bins[0] * bins[1] * bins[2];
     const double pot_factor = 1.0 / (4.0 * M_PI * kEpsilon0) / n_padded;
-    st = chx_sc_geometry(mom, grid_extent, energy, length, mass_eV, pot_factor, B, B, Bext, B, B, bins, dtype, half, cell,
-                         gamma, dt, scale, extent, pot_scale, main);
+    int st = chx_sc_beam_geometry(x_in, survival, grid_extent, energy, length, mass_eV, pot_factor, B, Bx, Bs, Bext, B, B, N,
+                                  bins, dtype, half, cell, gamma, dt, scale, extent, pot_scale, ws + L.mom_ws,
+                                  L.mom - L.mom_ws, main);
     if (st != CHX_OK) return st;
 
     // Green-function chain on the side stream while the main stream deposits the charge
@@ -119,19 +116,20 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
         (void)hipEventRecord(fork, main);
         (void)hipStreamWaitEvent(side, fork, 0);
     }
-    st = chx_sc_igf_table(cell, gamma, B, bins, dtype, table, side);
-    if (st == CHX_OK)
-        st = chx_sc_green_spectrum(table, B, bins, dtype, ghat, ws + L.green_ws, L.ghat - L.green_ws, side);
+    st = chx_sc_green_spectrum_fast(cell, gamma, B, bins, dtype, ghat, ws + L.green_ws, L.ghat - L.green_ws, side);
     if (forked) (void)hipEventRecord(join, side);
 
-    if (st == CHX_OK && hipMemsetAsync(rho, 0, (size_t)B * bins[0] * bins[1] * bins[2] * esz, main) != hipSuccess)
+    // the sorted deposit stores every cell of rho itself; the direct one adds into a zeroed grid
+    const bool sorted = N >= kSortedMinParticles;
+    if (st == CHX_OK && !sorted &&
+        hipMemsetAsync(rho, 0, (size_t)B * bins[0] * bins[1] * bins[2] * esz, main) != hipSuccess)
         st = CHX_ERR_LAUNCH;
     if (st == CHX_OK) {
         chx_cic_args a = deposit_args(B, Bx, Bq, Bs, N, bins, dtype);
         a.x = x_in; a.charge = charge; a.survival = survival; a.extent = extent; a.scale = scale; a.shift = nullptr;
         a.grid = rho;
-        st = N >= kSortedMinParticles ? chx_cic_deposit_sorted(&a, ws + L.dep_ws, L.table - L.dep_ws, main)
-                                      : chx_cic_deposit(&a, main);
+        st = sorted ? chx_cic_deposit_sorted_overwrite(&a, ws + L.dep_ws, L.table - L.dep_ws, main)
+                    : chx_cic_deposit(&a, main);
     }
     if (forked) {
         (void)hipStreamWaitEvent(main, join, 0);

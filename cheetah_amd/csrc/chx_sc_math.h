@@ -19,6 +19,40 @@ __device__ __forceinline__ S igf_primitive(S x, S y, S t) {
            x * t * m_asinh(y / m_sqrt(x * x + t * t)) + x * y * m_asinh(t / m_sqrt(x * x + y * y));
 }
 
+// Grid geometry of one kick from the three beam variances (space_charge_kick.py:531-550). Every step is rounded in T in
+// the order the reference's tensor expressions round (sigma = sqrt(cov) cast to T, half = extent * sigma,
+// cell = 2 half / g, gamma = E / m, beta, dt = L / (c beta)).
+template <typename T>
+__device__ __forceinline__ void sc_geometry_row(const double (&var)[3], const T* __restrict__ ext3, T energy, T length,
+                                                double mass, double pot_factor, int gx, int gy, int gz,
+                                                T* __restrict__ half3, T* __restrict__ cell3, T* __restrict__ gamma_out,
+                                                T* __restrict__ dt, T* __restrict__ scale3, T* __restrict__ extent6,
+                                                double* __restrict__ pot_scale) {
+    const T g[3] = {(T)gx, (T)gy, (T)gz};
+    double vol = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const T sig = (T)sqrt(var[d]);
+        const T h = ext3[d] * sig;
+        const T c = ((T)2 * h) / g[d];
+        half3[d] = h;
+        cell3[d] = c;
+        extent6[d * 2 + 0] = -h;
+        extent6[d * 2 + 1] = h;
+        vol *= (double)c;
+    }
+    const T gam = energy / (T)mass;
+    const T ig2 = (T)1 / (gam * gam);
+    T one_minus = (T)1 - ig2;
+    if (one_minus < (T)0) one_minus = (T)0;
+    const T beta = (fabs((double)gam) > 0.0) ? (T)sqrt(one_minus) : (T)1;
+    *gamma_out = gam;
+    *dt = length / ((T)299792458.0 * beta);
+    scale3[0] = (T)1;
+    scale3[1] = (T)1;
+    scale3[2] = -beta;
+    *pot_scale = (1.0 / vol) * pot_factor;
+}
+
 template <typename S>
 struct RefFrame {
     S gamma, beta, p0;  // reference gamma / beta, p0 = gamma beta m c

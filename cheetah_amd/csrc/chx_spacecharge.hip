@@ -36,11 +36,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_table_kernel(const T* __restric
     // longitudinal cell scaled by gamma (space_charge_kick.py:170-176); the product is formed in
     // the working dtype like the reference's `cell_size[..., 2] * beam.relativistic_gamma`
     const double dt = (double)(T)(cell[b * 3 + 2] * gamma[b]);
-    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < npts;
-         idx += (int64_t)gridDim.x * CHX_BLOCK) {
-        const int k = (int)(idx % (gz + 1));
-        const int j = (int)((idx / (gz + 1)) % (gy + 1));
-        const int i = (int)(idx / ((int64_t)(gz + 1) * (gy + 1)));
+    // 32-bit index arithmetic ((g + 1)^3 < 2^31): 64-bit integer division costs ~100 instructions here
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)npts; idx += gridDim.x * CHX_BLOCK) {
+        const unsigned q1 = idx / (unsigned)(gz + 1), q2 = q1 / (unsigned)(gy + 1);
+        const int k = (int)(idx - q1 * (unsigned)(gz + 1)), j = (int)(q1 - q2 * (unsigned)(gy + 1)), i = (int)q2;
         table[b * npts + idx] = igf_primitive<double>((i - 0.5) * dx, (j - 0.5) * dy, (k - 0.5) * dt);
     }
 }
@@ -57,11 +56,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_fill_kernel(const double* __res
     const int64_t GX = 2 * gx, GY = 2 * gy, GZ = ldz;
     const int64_t GZlog = 2 * gz;
     T* Gb = G + b * GX * GY * GZ;
-    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ncell;
-         idx += (int64_t)gridDim.x * CHX_BLOCK) {
-        const int k = (int)(idx % gz);
-        const int j = (int)((idx / gz) % gy);
-        const int i = (int)(idx / ((int64_t)gz * gy));
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)ncell; idx += gridDim.x * CHX_BLOCK) {
+        const unsigned q1 = idx / (unsigned)gz, q2 = q1 / (unsigned)gy;
+        const int k = (int)(idx - q1 * (unsigned)gz), j = (int)(q1 - q2 * (unsigned)gy), i = (int)q2;
         const double* p = tb + i * sx + j * sy + k;
         // +F(+,+,+) -F(-,+,+) -F(+,-,+) -F(+,+,-) +F(+,-,-) +F(-,+,-) +F(-,-,+) -F(-,-,-)
         const double g = p[sx + sy + 1] - p[sy + 1] - p[sx + 1] - p[sx + sy] + p[sx] + p[sy] + p[1] - p[0];
@@ -113,11 +110,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void gradient_kernel(const T* __restrict
     const T hx = (T)0.5 * ((T)1 / cell[b * 3 + 0]);
     const T hy = (T)0.5 * ((T)1 / cell[b * 3 + 1]);
     const T hz = (T)0.5 * ((T)1 / cell[b * 3 + 2]);
-    for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ncell;
-         idx += (int64_t)gridDim.x * CHX_BLOCK) {
-        const int k = (int)(idx % gz);
-        const int j = (int)((idx / gz) % gy);
-        const int i = (int)(idx / ((int64_t)gz * gy));
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)ncell; idx += gridDim.x * CHX_BLOCK) {
+        const unsigned q1 = idx / (unsigned)gz, q2 = q1 / (unsigned)gy;
+        const int k = (int)(idx - q1 * (unsigned)gz), j = (int)(q1 - q2 * (unsigned)gy), i = (int)q2;
         const int64_t c = ((int64_t)i * GY + j) * GZ + k;
         T fx = (T)0, fy = (T)0, fz = (T)0;
         if (i > 0 && i < gx - 1) fx = (pb[c + GY * GZ] - pb[c - GY * GZ]) * hx;
@@ -235,29 +230,9 @@ __global__ void sc_geometry_kernel(const double* __restrict__ mom, const T* __re
     if (b >= B) return;
     const double* m = mom + ((Bm == 1) ? 0 : b) * CHX_MOM_NOUT;
     const double var[3] = {m[8], m[8 + 11], m[8 + 18]};  // cov_xx, cov_yy, cov_tautau
-    const T g[3] = {(T)gx, (T)gy, (T)gz};
-    double vol = 1.0;
-    for (int d = 0; d < 3; ++d) {
-        const T sig = (T)sqrt(var[d]);
-        const T h = ext[((Bext == 1) ? 0 : b) * 3 + d] * sig;
-        const T c = ((T)2 * h) / g[d];
-        half[b * 3 + d] = h;
-        cell[b * 3 + d] = c;
-        extent[(b * 3 + d) * 2 + 0] = -h;
-        extent[(b * 3 + d) * 2 + 1] = h;
-        vol *= (double)c;
-    }
-    const T gam = energy[(Be == 1) ? 0 : b] / (T)mass;
-    const T ig2 = (T)1 / (gam * gam);
-    T one_minus = (T)1 - ig2;
-    if (one_minus < (T)0) one_minus = (T)0;
-    const T beta = (fabs((double)gam) > 0.0) ? (T)sqrt(one_minus) : (T)1;
-    gamma_out[b] = gam;
-    dt[b] = length[(Bl == 1) ? 0 : b] / ((T)299792458.0 * beta);
-    scale[b * 3 + 0] = (T)1;
-    scale[b * 3 + 1] = (T)1;
-    scale[b * 3 + 2] = -beta;
-    pot_scale[b] = (1.0 / vol) * pot_factor;
+    sc_geometry_row<T>(var, ext + ((Bext == 1) ? 0 : b) * 3, energy[(Be == 1) ? 0 : b], length[(Bl == 1) ? 0 : b], mass,
+                       pot_factor, gx, gy, gz, half + b * 3, cell + b * 3, gamma_out + b, dt + b, scale + b * 3,
+                       extent + b * 6, pot_scale + b);
 }
 
 bool bins_ok(const int32_t* bins) {

@@ -15,6 +15,7 @@ import math
 import torch
 
 from .. import _ops
+from .._cache import TensorKey
 from .beam import Beam
 from .species import Species
 
@@ -254,12 +255,11 @@ class ParticleBeam(Beam):
     # ------------------------------------------------------------------ moments (HIP, cached)
     def _moments(self) -> torch.Tensor:
         p, w = self.particles, self.survival_probabilities
-        key = (id(p), p._version, id(w), w._version)
         cached = self.__dict__.get("_moment_cache")
-        if cached is not None and cached[0] == key and not p.requires_grad:
+        if cached is not None and cached[0].matches((p, w)) and not p.requires_grad and not w.requires_grad:
             return cached[1]
         out = _ops.moments(p, w)
-        self.__dict__["_moment_cache"] = (key, out)
+        self.__dict__["_moment_cache"] = (TensorKey((p, w)), out)
         return out
 
     def as_parameter_beam(self):

@@ -63,10 +63,10 @@ class Species(nn.Module):
         buffers, params = self._buffers, self._parameters
         m = buffers["mass_eV"] if "mass_eV" in buffers else params["mass_eV"]
         q = buffers["num_elementary_charges"] if "num_elementary_charges" in buffers else params["num_elementary_charges"]
-        key = (id(m), m._version, id(q), q._version)
         cached = self.__dict__.get("_scalar_cache")
-        if cached is None or cached[0] != key:
-            cached = (key, float(m.detach().double().reshape(-1)[0].item()),
+        if cached is None or cached[0][0] is not m or cached[0][1] != m._version or cached[0][2] is not q \
+                or cached[0][3] != q._version:
+            cached = ((m, m._version, q, q._version), float(m.detach().double().reshape(-1)[0].item()),
                       float(q.detach().double().reshape(-1)[0].item()))
             self.__dict__["_scalar_cache"] = cached
         return cached[1], cached[2]

@@ -211,6 +211,10 @@ int chx_cic_deposit(const chx_cic_args* args, void* stream);
  * instead of 2^ndim global float atomics per particle (which saturate at ~21 G atomics/s on MI355X). */
 size_t chx_cic_sorted_workspace_bytes(const chx_cic_args* args);
 int chx_cic_deposit_sorted(const chx_cic_args* args, void* workspace, size_t workspace_bytes, void* stream);
+/* The same deposit with grid = deposit instead of grid += deposit: every cell of every grid row is stored by the tile
+ * that owns it (zeros included), so the caller does not zero the grid first and the flush carries no dependent load.
+ * Used by chx_sc_kick (space_charge_kick.py:556-563 deposits into a fresh zero tensor). */
+int chx_cic_deposit_sorted_overwrite(const chx_cic_args* args, void* workspace, size_t workspace_bytes, void* stream);
 /* Test/diagnostic twin: writes the integer cell index i_d=floor(p_d) (int32 [B][N][ndim])
  * and fractional part f_d (dtype [B][N][ndim]) instead of depositing. */
 int chx_cic_indices(const chx_cic_args* args, int32_t* idx_out, void* frac_out, void* stream);
@@ -292,6 +296,13 @@ int chx_sc_pruned_supported(const int32_t* bins, int dtype);
 int chx_sc_igf_table(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype, double* table,
                      void* stream);
 size_t chx_sc_green_workspace_bytes(int64_t B, const int32_t* bins, int dtype);
+/* chx_sc_igf_table + chx_sc_green_spectrum in one call from cell[B][3] / gamma[B] (dtype). fp32 grids evaluate the
+ * 6-transcendental primitive (space_charge_kick.py:103-123) only for cells closer than 8 x the largest cell edge and use
+ * the 4th-order multipole expansion of the cell integral of 1/r beyond (relative error <= 1e-8, below fp32 rounding);
+ * fp64 grids are exact everywhere. */
+size_t chx_sc_green_fast_workspace_bytes(int64_t B, const int32_t* bins, int dtype);
+int chx_sc_green_spectrum_fast(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype, void* Ghat,
+                               void* workspace, size_t workspace_bytes, void* stream);
 int chx_sc_green_spectrum(const double* table, int64_t B, const int32_t* bins, int dtype, void* Ghat, void* workspace,
                           size_t workspace_bytes, void* stream);
 size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins, int dtype);
@@ -323,6 +334,14 @@ int chx_sc_gather_kick(const void* x_in, const void* F, const void* half, const 
                        const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
                        int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
                        void* stream);
+/* chx_moments + chx_sc_geometry for the kick: only the three variances the grid needs (sigma_x, sigma_y, sigma_tau;
+ * space_charge_kick.py:531-538) are accumulated (8 fp64 sums per lane instead of 29, same shifted one-pass formulas and
+ * rounding), and the partial sums are finalised inside the geometry kernel: two launches. Outputs as chx_sc_geometry. */
+size_t chx_sc_beam_geometry_workspace_bytes(int64_t B, int64_t N);
+int chx_sc_beam_geometry(const void* x, const void* w, const void* grid_extent, const void* energy, const void* length,
+                         double mass_eV, double pot_factor, int64_t B, int64_t Bx, int64_t Bw, int64_t Bext, int64_t Be,
+                         int64_t Bl, int64_t N, const int32_t* bins, int dtype, void* half, void* cell, void* gamma, void* dt,
+                         void* scale, void* extent, double* pot_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* A whole SpaceChargeKick.track in ONE call (space_charge_kick.py:477-586) for grids chx_sc_pruned_supported() accepts:
  * chx_moments -> chx_sc_geometry -> [side stream: chx_sc_igf_table, chx_sc_green_spectrum] -> zero + chx_cic_deposit
  * (sorted for N >= 65536) -> chx_sc_convolve -> chx_sc_gradient -> chx_sc_gather_kick, all intermediates in `workspace`

@@ -87,17 +87,75 @@ def test_segment_partitioning_and_names():
 
 def test_revision_and_feature_keys_track_changes():
     import cheetah_amd as ca
+    from cheetah_amd._cache import TensorKey
 
     q = ca.Quadrupole(torch.tensor(0.2), k1=torch.tensor(4.2))
-    r0, k0 = q.__dict__["_revision"], q._feature_key()
+    r0 = q.__dict__["_revision"]
+    static0, tensors0 = q._feature_key()
+    key0 = TensorKey(tensors0)
+    assert key0.matches(q._feature_key()[1])
     q.k1 = torch.tensor(1.0)
-    assert q.__dict__["_revision"] > r0 and q._feature_key() != k0
-    k1 = q._feature_key()
+    assert q.__dict__["_revision"] > r0 and not key0.matches(q._feature_key()[1])
+    key1 = TensorKey(q._feature_key()[1])
     q.k1.add_(1.0)
-    assert q._feature_key() != k1
+    assert not key1.matches(q._feature_key()[1])            # in-place edit: _version moved
     q.k1 = torch.nn.Parameter(torch.tensor(2.0))
-    assert any(f[2] for f in q._feature_key() if isinstance(f, tuple))
+    assert any(t.requires_grad for t in q._feature_key()[1])
     assert [n for n, _ in q.named_parameters()] == ["k1"]
+    key2 = TensorKey(q._feature_key()[1])
+    q.k1.requires_grad_(False)
+    assert not key2.matches(q._feature_key()[1])            # requires_grad is part of the key
+    assert q._feature_key()[0] == static0                   # the non-tensor features did not change
+
+
+def test_caches_are_not_fooled_by_recycled_tensor_ids():
+    """caches keyed on id(tensor) served stale entries when CPython reused the id of a freed tensor
+    (Cavity.is_active stale in 49 of 200 trials). The keys now hold the tensors and compare with `is`."""
+    import cheetah_amd as ca
+
+    stale = 0
+    for _ in range(300):
+        c = ca.Cavity(torch.tensor(1.0), voltage=torch.tensor(0.0), phase=torch.tensor(0.0), frequency=torch.tensor(1.3e9))
+        assert not c.is_active
+        c.voltage = torch.tensor(1e6)   # replaces (and frees) the tensor the flag was cached for
+        c.voltage = torch.tensor(2e6)   # may receive the freed tensor's id
+        stale += not c.is_active
+    assert stale == 0
+    # the map cache key: same hazard on defining tensors
+    from cheetah_amd._cache import TensorKey
+
+    q = ca.Quadrupole(torch.tensor(0.2), k1=torch.tensor(4.2))
+    for _ in range(300):
+        key = TensorKey(q._feature_key()[1])
+        q.k1 = torch.tensor(1.0)
+        q.k1 = torch.tensor(2.0)
+        assert not key.matches(q._feature_key()[1])
+    # a Segment run's token records requires_grad of buffers too (ADVICE r1, low)
+    from cheetah_amd.accelerator.segment import _Run
+
+    run = _Run([q])
+    e = torch.tensor(1e8)
+    sp = ca.Species("electron")
+    tok = run.current_token(e, sp)
+    q.k1.requires_grad_(True)
+    assert run.current_token(e, sp) != tok
+
+
+def test_rbend_edge_setters():
+    """rbend.py:107-117: assigning rbend_e1 / rbend_e2 updates the dipole pole-face angles."""
+    import cheetah_amd as ca
+
+    r = ca.RBend(torch.tensor(1.0), angle=torch.tensor(0.2), rbend_e1=torch.tensor(0.01), rbend_e2=torch.tensor(0.02))
+    assert float(r.dipole_e1) == pytest.approx(0.11) and float(r.dipole_e2) == pytest.approx(0.12)
+    rev = r.__dict__["_revision"]
+    r.rbend_e1 = torch.tensor(0.05)
+    r.rbend_e2 = torch.tensor(-0.03)
+    assert float(r.dipole_e1) == pytest.approx(0.15) and float(r.dipole_e2) == pytest.approx(0.07)
+    assert float(r.rbend_e1) == pytest.approx(0.05) and float(r.rbend_e2) == pytest.approx(-0.03)
+    assert r.__dict__["_revision"] > rev
+    seg = ca.Segment([r])
+    seg.set_attrs_on_every_element(rbend_e1=torch.tensor(0.0))
+    assert float(r.dipole_e1) == pytest.approx(0.1)
 
 
 def test_flat_bcast_helper():

@@ -1,0 +1,339 @@
+"""Full-size parity of the BASELINE.json configs C3, C4 and C5 through the product's default kernels (`-m gpu`).
+
+The other GPU tests check every kernel against the reference's goldens at fixture size (N of a few thousand); those sizes take
+different code paths from the benchmark sizes (direct instead of sorted deposit, hipFFT instead of the pruned register FFT,
+one `grid.y` chunk of the shared-input apply). Here the configs run at the sizes BASELINE.json names:
+
+* C4 — 50-element linac, 10 SpaceChargeKicks on 128^3, 1e6 particles, fp64 and fp32, `Segment.track` through
+  `chx_sc_kick` (sorted deposit + far-field Green function + pruned FFTs + gather): compared with the REAL reference's fp64
+  run of the same lattice on the same particles (tests/golden/fullsize_c4.npz: beam statistics and a 3985-particle sample
+  after the first kick and at the end, written by tests/golden/generate_golden_fullsize.py) and, for the first kick, with
+  the CPU oracle on the same inputs (total charge, max |phi|, sampled kicks).
+  Matches /root/reference/tests/test_space_charge_kick.py:14-71.
+* C3 — k1 scan B = 4096 x N = 1e5 on the ARES EA subcell, fp32, one shared beam (11.5 GB of output): sampled rows
+  bit-exact against the oracle's fma chain, beam sizes of ALL rows against the oracle's moments / the exact linear
+  transport of the covariance. Matches /root/reference/tests/test_vectorized.py:186-211.
+* C5 — d sigma_x(screen) / d k1 and / d L over 1e6 particles, backward through the HIP kernels, against finite differences of
+  the oracle's fp64 maps (-3.688e-05 for the reference's own beam).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import fullsize_inputs as fi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    import cheetah_amd
+
+    cheetah_amd._lib.lib()  # fail loudly if libchx.so is missing
+    return cheetah_amd
+
+
+def tdt(tag):
+    return torch.float64 if tag == "f64" else torch.float32
+
+
+def beam_stats(p: torch.Tensor) -> np.ndarray:
+    p = p[:, :6].double()
+    return np.concatenate([p.mean(dim=0).cpu().numpy(), p.std(dim=0).cpu().numpy()])
+
+
+# ------------------------------------------------------------------------------------------------------------ C4
+def c4_segment(ca, dt):
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for cell in range(fi.C4_CELLS):
+        els += [ca.Drift(t(0.1), **kw), ca.SpaceChargeKick(t(0.2), grid_shape=fi.C4_GRID, **kw), ca.Drift(t(0.1), **kw),
+                ca.Quadrupole(t(0.1), k1=t(fi.c4_quad_k1(cell)), **kw), ca.Drift(t(0.1), **kw)]
+    return ca.Segment(els)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_c4_full_size_vs_reference_and_oracle(ca, golden, oracle, tag):
+    from cheetah_amd import _ops
+    from cheetah_amd.accelerator.space_charge_kick import epsilon_0
+
+    g = golden("fullsize_c4.npz")
+    dt = tdt(tag)
+    x_np = fi.c4_particles()
+    q_np = fi.c4_charges()
+    assert np.allclose(beam_stats(torch.from_numpy(x_np)), g["in_stats"], rtol=1e-12, atol=1e-18)  # same particles
+    sp = ca.Species("electron", dtype=dt, device="cuda")
+    beam = ca.ParticleBeam(torch.from_numpy(x_np).to(dt).cuda(), torch.tensor(fi.C4_ENERGY, dtype=dt, device="cuda"),
+                           particle_charges=torch.from_numpy(q_np).to(dt).cuda(), species=sp)
+    seg = c4_segment(ca, dt)
+    sl = slice(None, None, fi.C4_SAMPLE_STRIDE)
+
+    # ---- first kick alone, through Segment's own element objects: [Drift, SpaceChargeKick]
+    b1 = seg.elements[0].track(beam)
+    k1_in = b1.particles
+    b2 = seg.elements[1].track(b1)
+    torch.cuda.synchronize()
+    got_in = k1_in[sl].double().cpu().numpy()
+    got_out = b2.particles[sl].double().cpu().numpy()
+    ref_in, ref_out = g["kick1_in_sample"], g["kick1_out_sample"]
+    eps = np.finfo(np.float64 if tag == "f64" else np.float32).eps
+    assert np.max(np.abs(got_in - ref_in)) <= 4 * eps * np.max(np.abs(ref_in))
+    kick = np.max(np.abs(ref_out - ref_in), axis=0)
+    err = np.max(np.abs((got_out - got_in) - (ref_out - ref_in)), axis=0)
+    # tolerance as a fraction of the kick amplitude: fp64 1e-6 (test_gpu_parity.py::test_space_charge_kick_vs_reference);
+    # fp32 2e-2 against the fp64 reference (the reference's own fp32 kick is noisier than that)
+    tol = 1e-6 if tag == "f64" else 2e-2
+    for c in (1, 3, 5):
+        assert err[c] < tol * kick[c], (tag, c, err[c], kick[c])
+    assert kick[1] > 0 and kick[3] > 0 and kick[5] > 0
+    st = beam_stats(b2.particles)
+    assert np.allclose(st[6:], g["kick1_stats"][6:], rtol=1e-9 if tag == "f64" else 2e-6)
+
+    # ---- intermediates of the first kick by the same kernels chx_sc_kick strings together (sorted deposit is the N >= 65536
+    # default; far-field Green function is the default of sc_green_spectrum): total charge, max |phi|, lines of rho / phi
+    grid = fi.C4_GRID
+    xk = k1_in.reshape(1, -1, 7).contiguous()
+    N = xk.shape[1]
+    w = torch.ones(1, N, dtype=dt, device="cuda")
+    q = beam.particle_charges.reshape(1, N)
+    en = torch.full((1,), fi.C4_ENERGY, dtype=dt, device="cuda")
+    L = torch.full((1,), 0.2, dtype=dt, device="cuda")
+    ext = torch.full((1, 3), 3.0, dtype=dt, device="cuda")
+    mom = _ops.moments(xk, w)
+    pot_factor = 1.0 / (4 * np.pi * epsilon_0) / float(8 * grid[0] * grid[1] * grid[2])
+    half, cell, gamma, dtk, scale, extent, pot_scale = _ops.sc_geometry(mom.reshape(1, -1).contiguous(), ext, en, L,
+                                                                         sp.mass_eV_float, pot_factor, 1, grid)
+    assert np.allclose(half.double().cpu().numpy(), g["kick1_half"], rtol=1e-9 if tag == "f64" else 1e-6)
+    rho = torch.zeros((1, *grid), dtype=dt, device="cuda")
+    _ops.cic_deposit_into(rho, (grid[1] * grid[2], grid[2], 1), grid[0] * grid[1] * grid[2], xk, (0, 2, 4), grid, extent,
+                          charge=q, survival=w, scale=scale, mode="sorted")
+    green = _ops.sc_green_spectrum(cell, gamma, grid)
+    phi = _ops.sc_convolve(rho, green, pot_scale, grid)
+    torch.cuda.synchronize()
+    vol = float(cell.double().prod())
+    rho_ref_sum, rho_ref_max = float(g["kick1_rho_sum"]), float(g["kick1_rho_max"])   # reference rho = charge / cell volume
+    rtol_grid = 1e-9 if tag == "f64" else 2e-5
+    assert float(rho.double().sum()) / vol == pytest.approx(rho_ref_sum, rel=rtol_grid)
+    assert float(rho.double().abs().max()) / vol == pytest.approx(rho_ref_max, rel=1e-6 if tag == "f64" else 1e-3)
+    line = rho[0, :, grid[1] // 2, grid[2] // 2].double().cpu().numpy() / vol
+    assert np.max(np.abs(line - g["kick1_rho_line"])) <= (1e-9 if tag == "f64" else 2e-4) * rho_ref_max
+    phi_ref_max = float(g["kick1_phi_absmax"])
+    ptol = 1e-9 if tag == "f64" else 2e-5
+    assert float(phi.double().abs().max()) == pytest.approx(phi_ref_max, rel=ptol)
+    pl = phi[0, :, grid[1] // 2, grid[2] // 2].double().cpu().numpy()
+    assert np.max(np.abs(pl - g["kick1_phi_line"])) <= ptol * phi_ref_max
+    pdiag = np.asarray([float(phi[0, i, i, i]) for i in range(0, grid[0], 4)])
+    assert np.max(np.abs(pdiag - g["kick1_phi_diag"])) <= ptol * phi_ref_max
+
+    # ---- the oracle on the same first-kick inputs (fp64 grid solve; restates space_charge_kick.py:477-586)
+    xo = k1_in.cpu().numpy()[None]
+    o_out, det = oracle.space_charge_kick(xo, fi.C4_ENERGY, q_np.astype(xo.dtype), np.ones(N, xo.dtype), 0.2,
+                                          grid_shape=grid, details=True)
+    o_kick = (o_out[0, sl].astype(np.float64) - got_in)
+    h_kick = got_out - got_in
+    for c in (1, 3, 5):
+        assert np.max(np.abs(h_kick[:, c] - o_kick[:, c])) < (tol if tag == "f32" else 1e-6) * kick[c]
+    assert float(rho.double().sum()) == pytest.approx(float(det["rho"].astype(np.float64).sum()), rel=rtol_grid)
+    assert float(phi.double().abs().max()) == pytest.approx(float(np.abs(det["phi"]).max()), rel=ptol)
+
+    # ---- the whole lattice: 10 kicks; sigma growth and the sampled particles against the reference
+    out = seg.track(beam)
+    torch.cuda.synchronize()
+    st = beam_stats(out.particles)
+    growth_ref = g["out_stats"][6:] / g["in_stats"][6:]
+    growth = st[6:] / g["in_stats"][6:]
+    assert growth_ref[0] > 1.0001 or growth_ref[2] > 1.0001   # space charge blew the beam up measurably
+    # the reference's sigma growth ratios (x, px, y, py, tau, p)
+    assert np.allclose(growth, growth_ref, rtol=1e-7 if tag == "f64" else 2e-4), (growth, growth_ref)
+    got = out.particles[sl].double().cpu().numpy()
+    ref = g["out_sample"]
+    scale_c = np.max(np.abs(ref), axis=0)
+    errc = np.max(np.abs(got - ref), axis=0)
+    for c in range(6):
+        assert errc[c] < (1e-7 if tag == "f64" else 5e-4) * scale_c[c], (tag, c, errc[c], scale_c[c])
+
+
+def test_sorted_deposit_meets_reference_golden_directly(ca, golden):
+    """The sorted / LDS-privatised deposit (N >= 65536 default) forced at the fixture size, against the REFERENCE's rho of
+    tests/golden/space_charge.npz (16^3 and 32x24x20, N = 4000) — not against the direct kernel."""
+    from cheetah_amd import _ops
+
+    g = golden("space_charge.npz")
+    for gi in (0, 1):
+        for tag in ("f64", "f32"):
+            k = f"g{gi}_{tag}"
+            dt = tdt(tag)
+            grid = tuple(int(v) for v in g[f"{k}_grid"])
+            x = torch.from_numpy(g[f"{k}_in"]).to(dt).cuda().reshape(1, -1, 7)
+            half = torch.from_numpy(g[f"{k}_half"]).to(dt).cuda().reshape(1, 3)
+            cell = g[f"{k}_cell"].astype(np.float64).reshape(3)
+            extent = torch.stack([-half, half], dim=-1)
+            gamma = float(g["energy"]) / 510998.95069
+            beta = np.sqrt(1 - 1 / gamma**2)
+            scale = torch.tensor([[1.0, 1.0, -beta]], dtype=dt, device="cuda")
+            q = torch.from_numpy(g[f"{k}_charges"]).to(dt).cuda().reshape(1, -1)
+            w = torch.from_numpy(g[f"{k}_survival"]).to(dt).cuda().reshape(1, -1)
+            rho = torch.zeros((1, *grid), dtype=dt, device="cuda")
+            _ops.cic_deposit_into(rho, (grid[1] * grid[2], grid[2], 1), grid[0] * grid[1] * grid[2], x, (0, 2, 4), grid, extent,
+                                  charge=q, survival=w, scale=scale, mode="sorted")
+            got = rho[0].double().cpu().numpy() / np.prod(cell)
+            ref = g[f"{k}_rho"].astype(np.float64)
+            tol = 1e-11 if tag == "f64" else 2e-5
+            assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (k, np.max(np.abs(got - ref)), np.max(np.abs(ref)))
+            assert (got != 0).sum() == (ref != 0).sum()
+
+
+# ------------------------------------------------------------------------------------------------------------ C3
+def c3_segment(ca, dt, k1_scan):
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for kind, args in fi.c3_lattice_spec():
+        cls = getattr(ca, kind)
+        if kind == "Marker":
+            els.append(cls(**kw))
+            continue
+        a = {k: (t(v) if v is not None else k1_scan) for k, v in args.items()}
+        length = a.pop("length")
+        els.append(cls(length, **a, **kw))
+    return ca.Segment(els)
+
+
+def c3_oracle_maps(oracle, k1_scan_np, rows, energy=1e8):
+    f = np.float32
+    maps = []
+    for b in rows:
+        per = []
+        for kind, args in fi.c3_lattice_spec():
+            if kind == "Marker":
+                continue
+            if kind == "Drift":
+                per.append(oracle.build_rmatrix("drift", [f(args["length"])], energy))
+            elif kind == "Quadrupole":
+                k1 = k1_scan_np[b] if args["k1"] is None else f(args["k1"])
+                per.append(oracle.build_rmatrix("quadrupole", [f(args["length"]), k1, 0, 0, 0], energy))
+            elif kind == "VerticalCorrector":
+                per.append(oracle.build_rmatrix("vcor", [f(args["length"]), f(args["angle"])], energy))
+            elif kind == "HorizontalCorrector":
+                per.append(oracle.build_rmatrix("hcor", [f(args["length"]), f(args["angle"])], energy))
+        maps.append(oracle.compose(per)[0])
+    return np.stack(maps)
+
+
+def test_c3_full_size_k1_scan(ca, oracle):
+    dt = torch.float32
+    x_np = fi.gaussian_particles(fi.C3_N, seed=31)
+    k1_np = fi.c3_k1_scan()
+    k1 = torch.from_numpy(k1_np).cuda()
+    seg = c3_segment(ca, dt, k1)
+    beam = ca.ParticleBeam(torch.from_numpy(x_np).to(dt).cuda(), torch.tensor(1e8, dtype=dt, device="cuda"),
+                           species=ca.Species("electron", dtype=dt, device="cuda"))
+    out = seg.track(beam)
+    torch.cuda.synchronize()
+    assert out.particles.shape == (fi.C3_B, fi.C3_N, 7)
+    R = seg.first_order_transfer_map(beam.energy, beam.species)
+    assert R.shape == (fi.C3_B, 7, 7)
+    rows = list(fi.C3_SAMPLE_ROWS)
+    R_rows = R[rows].cpu().numpy()
+
+    # the composed maps of the sampled settings against the oracle's builder + composition (fp64 inside, fp32 parameters)
+    R_or = c3_oracle_maps(oracle, k1_np, rows)
+    scale_R = np.maximum(np.abs(R_or), 1e-3 * np.abs(R_or).max(axis=(1, 2), keepdims=True))
+    assert np.max(np.abs(R_rows - R_or) / scale_R) < 2e-6
+
+    # sampled particles of the sampled rows: bit-exact against the oracle's fma chain with the SAME fp32 map
+    n_s = np.r_[0:512, fi.C3_N - 512:fi.C3_N]
+    x_s = x_np[n_s].astype(np.float32)
+    for j, b in enumerate(rows):
+        want = oracle.apply(x_s[None], R_rows[j:j + 1].astype(np.float32), mode=1)[0]
+        got = out.particles[b, torch.from_numpy(n_s).cuda()].cpu().numpy()
+        assert np.array_equal(got, want), (b, np.max(np.abs(got - want)))
+
+    # beam sizes of ALL 4096 outgoing beams: the engine's moments of the 11.5 GB array ...
+    mom = out._moments()                                                               # (4096, 29) float64
+    sig = mom[:, [8, 19]].sqrt().cpu().numpy()                                         # sigma_x, sigma_y (fp64)
+    mu = mom[:, [2, 4]].cpu().numpy()
+    assert torch.allclose(out.sigma_x.double(), mom[:, 8].sqrt(), rtol=2e-7, atol=0)   # the property is the fp32 cast of it
+    assert sig.shape == (fi.C3_B, 2)
+    # ... against the exact linear transport of the incoming moments with the engine's own fp32 maps (fp64 arithmetic on the
+    # host): Sigma' = R Sigma R^T, mu' = R (mu, 1). The tracked particles are fp32-rounded per coordinate, hence 2e-6.
+    m = oracle.moments(x_np[None].astype(np.float32))
+    S = np.zeros((7, 7))
+    S[:6, :6] = m["cov"][0]
+    mu7 = np.r_[m["mu"][0], 1.0]
+    R64 = R.double().cpu().numpy()
+    S_out = R64 @ S @ np.swapaxes(R64, 1, 2)
+    mu_out = R64 @ mu7
+    assert np.allclose(sig[:, 0], np.sqrt(S_out[:, 0, 0]), rtol=2e-6)
+    assert np.allclose(sig[:, 1], np.sqrt(S_out[:, 2, 2]), rtol=2e-6)
+    assert np.allclose(mu, mu_out[:, [0, 2]], rtol=1e-5, atol=2e-6 * np.abs(sig).max())
+    # ... and against the oracle's two-pass moments of the sampled rows' full 1e5-particle output
+    for b in rows[::3]:
+        mo = oracle.moments(out.particles[b].cpu().numpy()[None])
+        assert sig[b, 0] == pytest.approx(np.sqrt(mo["cov"][0, 0, 0]), rel=1e-9)
+        assert sig[b, 1] == pytest.approx(np.sqrt(mo["cov"][0, 2, 2]), rel=1e-9)
+
+    # observables-only path (chx_track_moments: no (B, N, 7) output) gives the same beam sizes
+    pb = seg.track_moments(beam)
+    assert np.allclose(pb.sigma_x.double().cpu().numpy(), sig[:, 0], rtol=1e-6)
+    assert np.allclose(pb.sigma_y.double().cpu().numpy(), sig[:, 1], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------ C5
+def test_c5_full_size_backward(ca, oracle):
+    dt = torch.float32
+    N = 1_000_000
+    x_np = fi.gaussian_particles(N, seed=55)
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    k1 = torch.nn.Parameter(t(3.142))
+    L = torch.nn.Parameter(t(0.2))
+    seg = ca.Segment([ca.Drift(t(1.0), **kw), ca.Quadrupole(L, k1=k1, **kw), ca.Drift(t(1.0), **kw),
+                      ca.Screen(is_active=True, name="scr", **kw)])
+    beam = ca.ParticleBeam(torch.from_numpy(x_np).to(dt).cuda(), t(1e8), species=ca.Species("electron", **kw))
+    seg.track(beam)
+    sx = seg.scr.get_read_beam().sigma_x
+    sx.backward()
+    torch.cuda.synchronize()
+
+    # independent fp64 value on the host: sigma_x'^2 = (R Sigma R^T)_00 with the oracle's maps and the oracle's moments
+    m = oracle.moments(x_np[None].astype(np.float32))
+    S = m["cov"][0]
+
+    def sigma_x(k1v, Lv):
+        R = oracle.compose([oracle.build_rmatrix("drift", [1.0], 1e8), oracle.build_rmatrix("quadrupole", [Lv, k1v, 0, 0, 0], 1e8),
+                            oracle.build_rmatrix("drift", [1.0], 1e8)])[0][:6, :6]
+        return np.sqrt((R @ S @ R.T)[0, 0])
+
+    k0, L0 = float(np.float32(3.142)), float(np.float32(0.2))
+    h = 1e-4
+    dk = (sigma_x(k0 + h, L0) - sigma_x(k0 - h, L0)) / (2 * h)
+    dL = (sigma_x(k0, L0 + h) - sigma_x(k0, L0 - h)) / (2 * h)
+    assert float(sx) == pytest.approx(sigma_x(k0, L0), rel=2e-5)
+    assert abs(dk) > 1e-6   # -3.69e-05 for this lattice
+    assert float(k1.grad) == pytest.approx(dk, rel=1e-3)
+    assert float(L.grad) == pytest.approx(dL, rel=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------ Green function
+@pytest.mark.parametrize("aspect", [(1.0, 1.0, 1.0), (1.0, 1.3, 440.0), (3.0, 1.0, 0.2)])
+@pytest.mark.parametrize("g", [32, 128])
+def test_far_field_green_function_vs_corner_table(ca, aspect, g):
+    """fp32 Green spectrum with the multipole far field (default) against the corner table everywhere (`exact=True`):
+    the difference must stay below fp32 rounding of the spectrum's scale."""
+    from cheetah_amd import _ops
+
+    cell = torch.tensor([[1e-5 * aspect[0], 1e-5 * aspect[1], 1e-5]], dtype=torch.float32, device="cuda")
+    gamma = torch.tensor([aspect[2]], dtype=torch.float32, device="cuda")   # dt = cell_z * gamma
+    grid = (g, g, g)
+    fast = _ops.sc_green_spectrum(cell, gamma, grid).double()
+    exact = _ops.sc_green_spectrum(cell, gamma, grid, exact=True).double()
+    # fp64 corner table of the same cells as the yardstick for fp32 rounding
+    exact64 = _ops.sc_green_spectrum(cell.double(), gamma.double(), grid, exact=True)
+    scale = float(exact64.abs().max())
+    err_fast = float((fast - exact64).abs().max()) / scale
+    err_exact = float((exact - exact64).abs().max()) / scale
+    assert err_fast < 2e-6, (err_fast, err_exact)
+    assert err_fast < 4 * err_exact + 1e-7, (err_fast, err_exact)
