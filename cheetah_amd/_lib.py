@@ -72,6 +72,12 @@ SIGNATURES = {
     "chx_build_rmatrix": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_build_rmatrix_vjp": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_compose_maps": (c_int, [c_vpp, c_u8_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_compose_prefix": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_run_state_bytes": (c_size_t, [c_i64]),
+    "chx_run_map": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                            c_void_p]),
+    "chx_run_track": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                              c_void_p, c_i64, c_void_p]),
     "chx_apply_affine7": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "chx_apply_bwd_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "chx_apply_affine7_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_size_t, c_void_p]),
@@ -88,6 +94,7 @@ SIGNATURES = {
     "chx_moments": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_moments_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_cic_deposit": (c_int, [ctypes.POINTER(CicArgs), c_void_p]),
+    "chx_cic_deposit_mapped": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_i64, c_void_p]),
     "chx_cic_sorted_workspace_bytes": (c_size_t, [ctypes.POINTER(CicArgs)]),
     "chx_cic_deposit_sorted": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_size_t, c_void_p]),
     "chx_cic_deposit_sorted_overwrite": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_size_t, c_void_p]),
@@ -154,7 +161,6 @@ SIGNATURES = {
                                c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, c_int, c_void_p, c_void_p]),
     "chx_merge_moments": (c_int, [c_void_p, ctypes.c_int32, c_i64, c_void_p, c_void_p]),
     "chx_build_rmatrix_scalars": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p]),
-    "chx_time_apply_ms": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_void_p, c_double_p]),
 }
 
 _lib = None

@@ -768,12 +768,12 @@ def track_moments(particles: torch.Tensor, survival: torch.Tensor | None, tm: to
 # ---------------------------------------------------------------------------------------------
 # cloud in cell / histogram
 def _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs_charge, grid=None,
-              grid_strides=None, grid_batch_stride=0):
+              grid_strides=None, grid_batch_stride=0, extra_batch=()):
     require_device(particles, extent)
     dt = particles.dtype
     N = particles.shape[-2]
     nd = len(cols)
-    shapes = [particles.shape[:-2], extent.shape[:-2]]
+    shapes = [particles.shape[:-2], extent.shape[:-2], tuple(extra_batch)]
     for t, k in ((charge, 1), (survival, 1), (scale, 1), (shift, 1)):
         if t is not None:
             shapes.append(t.shape[:-1])
@@ -925,6 +925,43 @@ def _cic_deposit_raw(particles, cols, bins, extent, charge, survival, scale, shi
         out_shape = tuple(bins)
     _launch_cic(a, N, len(bins), particles.device, mode)
     return grid.reshape(*batch_shape, *out_shape)
+
+
+def cic_deposit_mapped(particles, tm, cols, bins, extent, charge=None, survival=None, shift=None, abs_charge=False,
+                       transpose_2d=False) -> torch.Tensor:
+    """Deposit of the TRACKED beam `particles @ tm.mT` without forming it (chx_cic_deposit_mapped): the (…,N,7) output of a
+    scan of lattice settings is never written, one image per setting comes back. Same cell indices and addends as
+    `cic_deposit(apply_map(particles, tm), …)`."""
+    require_device(particles, tm)
+    if tm.dtype != particles.dtype:
+        raise RuntimeError(f"transfer map dtype {tm.dtype} does not match particle dtype {particles.dtype}")
+    bins = [int(b) for b in bins]
+    a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, charge, survival, None, shift, abs_charge,
+                                           extra_batch=tm.shape[:-2])
+    R, BR = flat_bcast(tm, batch_shape, 2)
+    R = R.contiguous()
+    total = numel(bins)
+    grid = torch.zeros((B, total), dtype=particles.dtype, device=particles.device)
+    a.grid = ptr(grid)
+    if transpose_2d:
+        assert len(bins) == 2
+        a.grid_strides[0], a.grid_strides[1] = 1, bins[0]
+        a.grid_batch_stride = total
+        out_shape = (bins[1], bins[0])
+    else:
+        out_shape = tuple(bins)
+    check(_lib.lib().chx_cic_deposit_mapped(ctypes.byref(a), ptr(R), BR, stream_ptr()), "chx_cic_deposit_mapped")
+    return grid.reshape(*batch_shape, *out_shape)
+
+
+def compose_prefix(stack: torch.Tensor) -> torch.Tensor:
+    """(E, Bm, 7, 7) per-element maps -> (E, Bm, 7, 7) prefix products M_e ... M_0 (chx_compose_prefix)."""
+    E, Bm = stack.shape[0], stack.shape[1]
+    stack = stack.contiguous()
+    out = torch.empty_like(stack)
+    check(_lib.lib().chx_compose_prefix(ptr(stack), E, Bm, Bm, dtype_code(stack.dtype), ptr(out), stream_ptr()),
+          "chx_compose_prefix")
+    return out
 
 
 def cic_deposit_into(grid: torch.Tensor, grid_strides, grid_batch_stride, particles, cols, bins, extent,
@@ -1454,13 +1491,6 @@ def screen_gaussian(mu, cov, shift, geom, width: int, height: int) -> torch.Tens
     check(_lib.lib().chx_screen_gaussian(ptr(m), ptr(c), ptr(sh), ptr(geom), B, Bm, Bc, Bsh, width, height, pos_f32,
                                          dtype_code(mu.dtype), ptr(img), stream_ptr()), "chx_screen_gaussian")
     return img.reshape(*batch_shape, height, width)
-
-
-def time_apply_ms(x, R, out, B, Bx, BR, N, iters) -> float:
-    ms = ctypes.c_double(0.0)
-    check(_lib.lib().chx_time_apply_ms(ptr(x), ptr(R), ptr(out), B, Bx, BR, N, dtype_code(x.dtype), iters,
-                                       stream_ptr(), ctypes.byref(ms)), "chx_time_apply_ms")
-    return ms.value
 
 
 # ---------------------------------------------------------------------------------------------

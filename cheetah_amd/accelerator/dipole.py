@@ -49,8 +49,7 @@ class Dipole(Element):
     @dipole_e1.setter
     def dipole_e1(self, value) -> None:
         self._e1 = value
-        self.__dict__["_revision"] += 1
-        self.__dict__["_map_cache"] = None
+        self._touch()
 
     @property
     def dipole_e2(self) -> torch.Tensor:
@@ -59,8 +58,7 @@ class Dipole(Element):
     @dipole_e2.setter
     def dipole_e2(self, value) -> None:
         self._e2 = value
-        self.__dict__["_revision"] += 1
-        self.__dict__["_map_cache"] = None
+        self._touch()
 
     def _builder_params(self):
         # NB: like the reference (dipole.py:453-459) the exit face uses `gap`, not `gap_exit`

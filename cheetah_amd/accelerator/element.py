@@ -53,6 +53,8 @@ class Element(nn.Module):
     _chx_kind: int | None = None
     #: True when `is_skippable` depends on non-tensor attributes only (those bump `_revision` when set)
     _static_skippable = True
+    #: process-wide count of attribute assignments on any element (see `_touch`)
+    _epoch = 0
 
     def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         super().__init__()
@@ -246,6 +248,11 @@ class Element(nn.Module):
             species=incoming.species,
         )
 
+    def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
+        """`track` as called from inside `Segment.track`: pass-through elements override it to hand the incoming tensors on
+        without the deep copy their public `track` makes (the segment un-aliases once, at its end)."""
+        return self.track(incoming)
+
     def forward(self, incoming: ParticleBeam) -> ParticleBeam:
         return self.track(incoming)
 
@@ -270,10 +277,23 @@ class Element(nn.Module):
 
     def __setattr__(self, name: str, value: Any) -> None:
         if "_revision" in self.__dict__ and not name.startswith("_"):
-            self.__dict__["_revision"] += 1
-            self.__dict__["_map_cache"] = None
-            self.__dict__["_tmap_cache"] = None
+            self._touch()
         return super().__setattr__(name, value)
+
+    def _apply(self, fn, recurse=True):
+        # .to() / .double() / .cuda() replace the buffers without going through __setattr__
+        out = super()._apply(fn, recurse)
+        if "_revision" in self.__dict__:
+            self._touch()
+        return out
+
+    def _touch(self) -> None:
+        """An attribute of this element was (re)assigned: drop its cached maps, move its revision and the process-wide
+        epoch (`Segment` re-validates a run's persistent device plan only when the epoch moved — an O(1) check per track)."""
+        self.__dict__["_revision"] += 1
+        self.__dict__["_map_cache"] = None
+        self.__dict__["_tmap_cache"] = None
+        Element._epoch += 1
 
     def register_buffer_or_parameter(self, name: str, value, persistent: bool = True) -> None:
         if isinstance(value, nn.Parameter):

@@ -1,5 +1,9 @@
 """Pass-through elements (mirror of cheetah/accelerator/marker.py:45-57, bpm.py:66-87,
-aperture.py:79-135): identity map, skippable unless active."""
+aperture.py:79-135): identity map, skippable unless active.
+
+`track` keeps the reference's contract — the returned beam is a deep copy (`incoming.clone()`, marker.py:52-53, bpm.py:87):
+editing it in place never reaches the incoming beam. `Segment.track` walks its elements through `_track_internal`, which
+hands the same tensors on (nothing inside the walk edits a beam in place), and un-aliases once at the end (segment.py)."""
 
 from __future__ import annotations
 
@@ -10,14 +14,27 @@ from ..particles.particle_beam import ParticleBeam
 from .element import Element
 
 
+def _unaliased(outgoing, incoming):
+    """`outgoing` if it carries its own coordinate tensor, else a deep copy (the reference's `incoming.clone()`). The
+    pass-through elements hand on the very tensor object (`Beam._view`), so identity is the test."""
+    a = outgoing.particles if isinstance(outgoing, ParticleBeam) else getattr(outgoing, "mu", None)
+    b = incoming.particles if isinstance(incoming, ParticleBeam) else getattr(incoming, "mu", None)
+    if outgoing is incoming or (a is not None and a is b):
+        return outgoing.clone()
+    return outgoing
+
+
 class Marker(Element):
     _chx_kind = _ops.KIND["identity"]
 
     def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, device=device, dtype=dtype)
 
-    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+    def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         return incoming._view()
+
+    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        return _unaliased(self._track_internal(incoming), incoming)
 
     @property
     def is_skippable(self) -> bool:
@@ -41,7 +58,7 @@ class BPM(Marker):
     def is_skippable(self) -> bool:
         return not self.is_active
 
-    def track(self, incoming: ParticleBeam) -> ParticleBeam:
+    def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if self.is_active:
             # both means come out of one fused chx_moments call (bpm.py:77-85)
             self.reading = torch.stack([incoming.mu_x - self.misalignment[..., 0],
@@ -72,6 +89,11 @@ class Aperture(Marker):
         return not self.is_active
 
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        if self.is_active:   # aperture.py:129-135: a new beam that shares the particle tensor, new survival probabilities
+            return self._track_internal(incoming)
+        return _unaliased(self._track_internal(incoming), incoming)
+
+    def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if not self.is_active:
             return incoming._view()
         if not isinstance(incoming, ParticleBeam):  # aperture.py:94-100

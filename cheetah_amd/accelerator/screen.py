@@ -101,6 +101,11 @@ class Screen(Element):
         return ((ex[1:] + ex[:-1]) / 2, (ey[1:] + ey[:-1]) / 2)
 
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        from .marker import _unaliased
+
+        return _unaliased(self._track_internal(incoming), incoming)   # screen.py:239 `return incoming.clone()`
+
+    def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if self.is_active:
             # a snapshot of the unshifted beam is recorded (screen.py:190: later in-place edits of the incoming or
             # outgoing beam must not change the reading); the misalignment is applied inside the image kernels

@@ -14,22 +14,131 @@ Host-side cost matters here (the merged pass is a ~10 us kernel), so unlike the 
    against a token made of the `_version` counters of the run's tensors (in-place updates), the
    `requires_grad` flags of its parameters and the identity/version of the beam energy.
 
+ * a run whose elements all take device scalars (the usual control loop) keeps a persistent device plan (`_FastRun`,
+   `chx_run_track`): the device itself checks whether any setting changed since the stored map was composed, the host
+   only compares one process-wide epoch counter that every attribute assignment on an element moves. One C call per
+   run and track, no per-tensor Python work.
+
 `track_elementwise` is the merge-free variant (`for e in elements: beam = e.track(beam)`): the E maps
 are applied back to back by `chx_track_elementwise` / `chx_track_fused` from a single C call.
 """
 
 from __future__ import annotations
 
+import ctypes
 from copy import deepcopy
 
 import torch
 from torch import nn
 
-from .. import _ops
+from .. import _lib, _ops
 from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
 from .element import Element
+
+
+def _any_requires_grad_py(*tensors) -> bool:
+    for t in tensors:
+        if t.requires_grad:
+            return True
+    return False
+
+
+#: one C call over the tensors of a run (half the cost of the Python loop; 250 tensors for the 100-element FODO lattice)
+_any_requires_grad = getattr(torch._C, "_any_requires_grad", _any_requires_grad_py)
+
+
+class _ElementList(nn.ModuleList):
+    """The element list of a Segment: any change of the list moves the process-wide epoch (Element._touch), so that plans
+    derived from it are rebuilt."""
+
+    def _moved(self):
+        Element._epoch += 1
+
+    def __setitem__(self, idx, module):
+        self._moved()
+        return super().__setitem__(idx, module)
+
+    def __delitem__(self, idx):
+        self._moved()
+        return super().__delitem__(idx)
+
+    def __iadd__(self, modules):
+        self._moved()
+        return super().__iadd__(modules)
+
+    def insert(self, index, module):
+        self._moved()
+        return super().insert(index, module)
+
+    def append(self, module):
+        self._moved()
+        return super().append(module)
+
+    def extend(self, modules):
+        self._moved()
+        return super().extend(modules)
+
+    def pop(self, key=-1):
+        self._moved()
+        return super().pop(key)
+
+
+class _FastRun:
+    """Persistent device plan of a run (`chx_run_track`): packed kinds / parameter pointers (host arrays, forwarded by
+    value) and the device state buffer that remembers the settings the stored map was built from. Valid while
+    `Element._epoch` stands still; a changed VALUE of a setting (in-place edit, optimiser step) is found by the device."""
+
+    __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code")
+
+    def __init__(self, run, dtype, device, previous=None):
+        self.epoch = Element._epoch
+        self.ok = False
+        self.dtype, self.device = dtype, device
+        identity = _ops.KIND["identity"]
+        kinds, pointers, tensors = [], [], []
+        for e in run.elements:
+            if not e._static_skippable or e._parameters:
+                return                      # data-dependent skippability (Cavity, sub-Segment) or trainable parameters
+            kind = e._chx_kind
+            if kind is None:
+                return
+            if kind == identity:
+                continue
+            row = [None] * _ops.MAX_PARAMS
+            for k, (t, index) in enumerate(e._builder_scalar_refs()):
+                if t.dtype != dtype or t.device != device or t.requires_grad:
+                    return
+                if index is None:
+                    if t.dim() != 0:
+                        return
+                    row[k] = t.data_ptr()
+                else:
+                    if t.dim() != 1 or not t.is_contiguous():
+                        return
+                    row[k] = t.data_ptr() + index * t.element_size()
+                tensors.append(t)
+            kinds.append(kind)
+            pointers += row
+        E = len(kinds)
+        if E == 0 or E > 192 or len(tensors) > 400:
+            return
+        self.E = E
+        self.kinds = (ctypes.c_int32 * E)(*kinds)
+        self.ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*pointers)
+        # kept alive: the plan holds their addresses (each tensor once: `misalignment` feeds two parameters)
+        self.tensors = tuple({id(t): t for t in tensors}.values())
+        self.code = _ops.dtype_code(dtype)
+        if previous is not None and previous.ok and previous.dtype == dtype and previous.device == device \
+                and list(previous.kinds) == kinds:
+            # same elements, some setting re-assigned (a control loop): the remembered VALUES are still those the stored
+            # map was built from, whatever tensor they now live in — keep the state, the device compares values
+            self.state, self.state_bytes = previous.state, previous.state_bytes
+        else:
+            self.state_bytes = _lib.lib().chx_run_state_bytes(E)
+            self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=device)
+        self.ok = True
 
 
 class _Run:
@@ -38,7 +147,7 @@ class _Run:
     settings that changed — the tensor lists of the untouched elements, the summed length — is not redone."""
 
     __slots__ = ("elements", "modules", "rev", "per_module", "tensors", "params", "token", "tm", "stack", "length",
-                 "length_key", "energy_ref", "s_cache")
+                 "length_key", "energy_ref", "s_cache", "fast")
 
     def __init__(self, elements):
         self.elements = elements
@@ -54,6 +163,7 @@ class _Run:
         self.length_key = None
         self.energy_ref = None
         self.s_cache = None
+        self.fast = None
         self._collect()
 
     def _collect(self):
@@ -88,7 +198,7 @@ class Segment(Element):
                  dtype=None) -> None:
         super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, device=device, dtype=dtype)
         del self._buffers["length"]  # `length` is a derived property here (segment.py:54-58)
-        self.elements = nn.ModuleList(elements)
+        self.elements = _ElementList(elements)
         by_name: dict[str, list[Element]] = {}
         for e in elements:
             by_name.setdefault(e.name, []).append(e)
@@ -124,10 +234,13 @@ class Segment(Element):
     def _plan(self):
         """[(kind, payload)] with kind 'run' (payload _Run) or 'element' (payload Element). Depends on the element list
         and on which elements are skippable — not on their settings."""
+        cached = self.__dict__["_plan_cache"]
+        if cached is not None and cached[2] == Element._epoch and cached[3] is None:
+            return cached[1]     # nothing was assigned anywhere since, and no element's skippability depends on tensor values
         elements = list(self.elements)
         key = (tuple([id(e) for e in elements]), tuple([e.is_skippable for e in elements]))
-        cached = self.__dict__["_plan_cache"]
         if cached is not None and cached[0] == key:
+            self.__dict__["_plan_cache"] = (key, cached[1], Element._epoch, cached[3])
             return cached[1]
         plan, run = [], []
         for e in elements:
@@ -140,7 +253,10 @@ class Segment(Element):
                 plan.append(("element", e))
         if run:
             plan.append(("run", _Run(run)))
-        self.__dict__["_plan_cache"] = (key, plan)
+        # elements whose skippability is a function of tensor VALUES (Cavity voltage, nested segments): the list must be
+        # re-examined on every call while there are any
+        dynamic = [m for m in self.modules() if isinstance(m, Element) and m is not self and not m._static_skippable] or None
+        self.__dict__["_plan_cache"] = (key, plan, Element._epoch, dynamic)
         return plan
 
     # ---- per-run products ------------------------------------------------------------------------------
@@ -219,6 +335,34 @@ class Segment(Element):
             run.stack = stack
         return stack
 
+    @staticmethod
+    def _run_apply_fast(run: _Run, incoming: ParticleBeam):
+        """Tracked particles of `incoming` through `run` by ONE C call (chx_run_track), or None when the run or the beam
+        does not qualify (vectorised / trainable settings, a vectorised beam, gradients) and the general path is taken."""
+        p = incoming.particles
+        if p.dim() != 2 or not p.is_cuda:
+            return None
+        fr = run.fast
+        if fr is None or fr.epoch != Element._epoch or fr.dtype != p.dtype or fr.device != p.device:
+            fr = run.fast = _FastRun(run, p.dtype, p.device, previous=fr)
+        if not fr.ok:
+            return None
+        e = incoming.energy
+        if e.dim() != 0 or e.dtype != fr.dtype or e.device != fr.device:
+            return None
+        sp = incoming.species
+        if torch.is_grad_enabled():
+            if p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad:
+                return None
+            if _any_requires_grad(*fr.tensors):   # a buffer switched with requires_grad_(True) in place moves no counter
+                return None
+        x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
+        out = torch.empty_like(x)
+        _ops.check(_lib.lib().chx_run_track(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
+                                            sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
+                                            x.data_ptr(), out.data_ptr(), x.shape[0], _ops.stream_ptr()), "chx_run_track")
+        return out
+
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species):
         plan = self._plan()
         if len(plan) == 1 and plan[0][0] == "run":
@@ -229,6 +373,13 @@ class Segment(Element):
 
     # ---- tracking ---------------------------------------------------------------------------------------
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        from .marker import _unaliased
+
+        # the walk hands tensors from element to element without copies; if nothing on the way produced new coordinates
+        # (markers, inactive diagnostics only) the result is copied once here, like the reference's `incoming.clone()`
+        return _unaliased(self._track_internal(incoming), incoming)
+
+    def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if isinstance(incoming, ParameterBeam):
             for kind, item in self._plan():
                 if kind == "run":
@@ -237,27 +388,36 @@ class Segment(Element):
                     incoming = ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge,
                                              s=self._run_s(item, incoming.s), species=incoming.species)
                 else:
-                    incoming = item.track(incoming)
+                    incoming = item._track_internal(incoming)
             return incoming
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
         for kind, item in self._plan():
             if kind == "run":
-                tm = self._run_map(item, incoming.energy, incoming.species)
-                new_particles = _ops.apply_map(incoming.particles, tm)
+                new_particles = self._run_apply_fast(item, incoming)
+                if new_particles is None:
+                    tm = self._run_map(item, incoming.energy, incoming.species)
+                    new_particles = _ops.apply_map(incoming.particles, tm)
                 incoming = ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
                                         survival_probabilities=incoming.survival_probabilities,
                                         s=self._run_s(item, incoming.s), species=incoming.species)
             else:
-                incoming = item.track(incoming)
+                incoming = item._track_internal(incoming)
         return incoming
 
-    def track_moments(self, incoming: ParticleBeam) -> ParameterBeam:
+    def track_moments(self, incoming: ParticleBeam, exact: bool = True) -> ParameterBeam:
         """Track a `ParticleBeam` and return only the outgoing beam's moments as a `ParameterBeam` (mu, cov,
         energy, total_charge, s). Same numbers as `self.track(incoming).as_parameter_beam()`, but the last run
         of linear elements is fused with the moment reduction (`chx_track_moments`): the tracked particles of
         that run are never written — for a scan of B lattice settings over one shared beam that is the
-        (B, N, 7) array (11.5 GB at B = 4096, N = 1e5)."""
+        (B, N, 7) array (11.5 GB at B = 4096, N = 1e5).
+
+        `exact=False` transports the moments of the beam entering the last run algebraically instead, mu' = R mu,
+        Sigma' = R Sigma R^T (one `chx_moments` pass of the SHARED beam + one B-wide 7x7 kernel, `chx_parameter_track`):
+        no per-setting pass over the particles at all. A linear map transports first and second moments exactly; what
+        differs from `exact=True` is only that the tracked particles the reference would reduce are rounded to the beam dtype
+        coordinate by coordinate — relative differences of ~1e-7 of a sigma in fp32 (1e-4 of a sigma is the bound asserted
+        in tests/test_gpu_parity.py for strongly focused rows, where sigma itself is a small difference), 1e-15 in fp64."""
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
         plan = self._plan()
@@ -276,10 +436,52 @@ class Segment(Element):
             out.s = incoming.s
             return out
         tm = self._run_map(last_run, incoming.energy, incoming.species)
+        if not exact:
+            entering = incoming.as_parameter_beam()
+            mu, cov = _ops.parameter_track(entering.mu, entering.cov, tm)
+            return ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge,
+                                 s=self._run_s(last_run, incoming.s), species=incoming.species)
         mom = _ops.track_moments(incoming.particles, incoming.survival_probabilities, tm)
         return ParameterBeam._from_moment_vector(mom, incoming.particles.dtype, incoming.energy,
                                                  total_charge=incoming.total_charge,
                                                  s=self._run_s(last_run, incoming.s), species=incoming.species)
+
+    def track_screen_reading(self, incoming: ParticleBeam) -> torch.Tensor:
+        """Track a `ParticleBeam` and return the image of the segment's FINAL element, an active cloud-in-cell `Screen`
+        — same numbers as `self.track(incoming); screen.reading`, but the last run of linear elements is fused with the
+        deposit (`chx_cic_deposit_mapped`): for every (setting, particle) only x' and y' are evaluated (rows 0 and 2 of
+        R x, the apply kernel's fma chain) and deposited straight into that setting's image. The (B, N, 7) tracked array
+        is never written and the Screen's read beam is not recorded (the screen's own `reading` / `get_read_beam()` keep
+        what the last `track` left there). Falls back to `track` + `reading` when the lattice does not end in
+        [run of linear elements, active cloud-in-cell Screen] (screen.py:187-239, 327-339)."""
+        from .screen import Screen
+
+        if not isinstance(incoming, ParticleBeam):
+            raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+        plan = self._plan()
+        screen = plan[-1][1] if plan and plan[-1][0] == "element" else None
+        fused = (isinstance(screen, Screen) and screen.is_active and screen.method == "cloud-in-cell" and len(plan) >= 2
+                 and plan[-2][0] == "run" and not incoming.particles.requires_grad)
+        if not fused:
+            self.track(incoming)
+            last = self.elements[-1]
+            if not isinstance(last, Screen):
+                raise ValueError("track_screen_reading needs a Screen as the last element of the segment")
+            return last.reading
+        for kind, item in plan[:-2]:
+            if kind == "run":
+                tm = self._run_map(item, incoming.energy, incoming.species)
+                incoming = ParticleBeam(_ops.apply_map(incoming.particles, tm), incoming.energy,
+                                        particle_charges=incoming.particle_charges,
+                                        survival_probabilities=incoming.survival_probabilities,
+                                        s=self._run_s(item, incoming.s), species=incoming.species)
+            else:
+                incoming = item._track_internal(incoming)
+        tm = self._run_map(plan[-2][1], incoming.energy, incoming.species)
+        w, h = screen.effective_resolution
+        return _ops.cic_deposit_mapped(incoming.particles, tm, (0, 2), (w, h), screen.extent.reshape(2, 2),
+                                       charge=incoming.particle_charges, survival=incoming.survival_probabilities,
+                                       shift=screen.misalignment, abs_charge=True, transpose_2d=True)
 
     def track_elementwise(self, incoming: ParticleBeam, fused: bool = False) -> ParticleBeam:
         """Track element by element WITHOUT merging transfer maps (every element is a real pass over
@@ -320,11 +522,65 @@ class Segment(Element):
         """Beam attributes (every moment of a beam comes out of one fused `chx_moments` call per position) along the
         segment, stacked on a new axis in front of the attribute's own dims (segment.py:658-700)."""
         names = attr_names if isinstance(attr_names, tuple) else (attr_names,)
+        if resolution is not None:
+            return self.__class__(elements=self.split(resolution),
+                                  name=f"{self.name}_split").get_beam_attrs_along_segment(attr_names, incoming)
+        fast = self._attrs_along_fused(names, incoming)
+        if fast is not None:
+            return fast if isinstance(attr_names, tuple) else fast[0]
         per_beam = [tuple(getattr(beam, n) for n in names)
                     for beam in self.beam_along_segment_generator(incoming, resolution=resolution)]
         results = tuple(torch.stack(torch.broadcast_tensors(*[vals[i] for vals in per_beam]),
                                     dim=-(self._ATTR_DIMS.get(n, 0) + 1)) for i, n in enumerate(names))
         return results if isinstance(attr_names, tuple) else results[0]
+
+    #: beam attributes that are functions of the first and second moments (plus energy / s / charge): available from ONE
+    #: fused pass over the particles for all positions at once
+    _MOMENT_ATTRS = frozenset(
+        [f"mu_{c}" for c in ("x", "px", "y", "py", "tau", "p")] + [f"sigma_{c}" for c in ("x", "px", "y", "py", "tau", "p")]
+        + ["cov_xpx", "cov_ypy", "cov_taup", "cov_xp", "cov_pxp", "cov_yp", "cov_pyp", "emittance_x", "emittance_y",
+           "normalized_emittance_x", "normalized_emittance_y", "projected_emittance_x", "projected_emittance_y", "beta_x",
+           "beta_y", "alpha_x", "alpha_y", "gamma_x", "gamma_y", "dispersion_x", "dispersion_px", "dispersion_y",
+           "dispersion_py", "mu", "cov", "energy", "s", "total_charge", "relativistic_gamma", "relativistic_beta", "p0c"])
+
+    def _attrs_along_fused(self, names, incoming):
+        """Moment attributes after every element of an all-linear lattice from ONE pass over the particles: the prefix
+        products R_e = M_e ... M_0 (`chx_compose_prefix`) go through `chx_track_moments` as a batch of E + 1 maps on the
+        shared beam, instead of E tracking passes and E x len(names) reductions (segment.py:658-700). Returns None when the
+        request does not qualify (other attributes, a vectorised or differentiable beam, non-linear or active elements)."""
+        if not isinstance(incoming, ParticleBeam) or not all(n in self._MOMENT_ATTRS for n in names):
+            return None
+        if not all(hasattr(ParameterBeam, n) or n in ("mu", "cov", "energy", "s", "total_charge") for n in names):
+            return None
+        p = incoming.particles
+        if p.dim() != 2 or incoming.energy.dim() != 0 or incoming.survival_probabilities.dim() != 1 \
+                or incoming.particle_charges.dim() != 1 or p.requires_grad or not p.is_cuda:
+            return None
+        elements = list(self.elements)
+        plan = self._plan()
+        if len(plan) != 1 or plan[0][0] != "run" or len(plan[0][1].elements) != len(elements) or not elements:
+            return None
+        run = plan[0][1]
+        lengths = [e.length for e in elements]
+        if any(t.dim() != 0 or t.requires_grad for t in lengths):
+            return None
+        stack = self._run_stack(run, incoming.energy, incoming.species)          # (E, Bm, 7, 7)
+        if stack.shape[1] != 1 or stack.requires_grad:
+            return None
+        eye = torch.eye(7, dtype=stack.dtype, device=stack.device).reshape(1, 1, 7, 7)
+        prefix = torch.cat([eye, _ops.compose_prefix(stack)], dim=0).reshape(-1, 7, 7)        # position 0 = the incoming beam
+        mom = _ops.track_moments(p, incoming.survival_probabilities, prefix)                   # (E + 1, 29)
+        s_along = incoming.s + torch.cat([torch.zeros_like(lengths[0]).reshape(1), torch.stack(lengths).cumsum(0)])
+        along = ParameterBeam._from_moment_vector(mom, p.dtype, incoming.energy, total_charge=incoming.total_charge, s=s_along,
+                                                  species=incoming.species)
+        n_pos = prefix.shape[0]
+        out = []
+        for n in names:
+            v = getattr(along, n)
+            if v.dim() == 0 or v.shape[0] != n_pos:      # energy, total_charge: the same at every position
+                v = v.expand(n_pos, *v.shape) if v.dim() else v.expand(n_pos)
+            out.append(v)
+        return tuple(out)
 
     def set_attrs_on_every_element(self, filter_type=None, is_recursive: bool = True, **kwargs) -> None:
         """segment.py:702-724"""

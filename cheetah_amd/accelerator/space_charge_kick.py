@@ -1,16 +1,16 @@
 """SpaceChargeKick (mirror of cheetah/accelerator/space_charge_kick.py:54-609).
 
-Pipeline per kick, all on the caller's stream, no host synchronisation:
-  chx_moments           sigma_x / sigma_y / sigma_tau -> grid half widths, cell sizes (tiny tensor ops)
-  chx_cic_deposit       3-D cloud-in-cell deposit of (x, y, z = -beta tau) straight into the zero-padded
-                        (2g)^3 Hockney array (no separate pad copy; cell-volume scaling is folded into the
-                        spectral multiply)
-  chx_sc_igf            integrated Green function, fp64 inside
-  torch.fft.rfftn x2    hipFFT (library FFT, as allowed by the scope contract)
-  chx_sc_spectral_mul   rho_hat *= G_hat / (4 pi eps0 dV)
-  torch.fft.irfftn      hipFFT
-  chx_sc_gradient       E + v x B field on the g^3 grid, packed (Fx,Fy,Fz,0)
-  chx_sc_gather_kick    SI conversion + trilinear gather + momentum kick + back-conversion, fused
+One kick, all on the caller's stream, no host synchronisation:
+
+* power-of-two grids (16 ... 512 per axis): ONE C call, `chx_sc_kick` — beam sizes and grid geometry
+  (`chx_sc_beam_geometry`), sorted LDS-privatised cloud-in-cell deposit, Green spectrum on a side stream
+  (`chx_sc_green_spectrum_fast`), libchx's pruned line-FFT convolution (`chx_sc_convolve`), field gradient, fused
+  SI conversion + trilinear gather + momentum kick + back-conversion;
+* other grids: the same stages with dense in-place hipFFT plans owned by libchx (`chx_sc_fft_*`) on the zero-padded
+  (2g)^3 Hockney arrays, the Green-function chain on a side stream;
+* a beam whose particles are spread over the ranks of a process group (`sharding.particle_sharded`): the staged form
+  with the two exchanges in between (global beam moments, summed charge grid);
+* anything that requires grad: the differentiable stages of `_track_differentiable`.
 """
 
 from __future__ import annotations
@@ -31,16 +31,6 @@ speed_of_light = 299792458.0
 class SpaceChargeKick(Element):
     """Applies the effect of space charge over `effect_length` as an instantaneous momentum kick."""
 
-    #: axis-by-axis pruned FFTs (class-level switch so both variants can be timed, benchmarks/sc_fft_ab.py).
-    #: Measured on MI355X: SLOWER than the two full (2g)^3 hipFFT transforms (1.44 vs 1.16 ms per kick at
-    #: 128^3, 0.64 vs 0.60 ms at 32^3) — the strided 1-D passes through torch.fft cost more than the pruned
-    #: butterflies save — so the full transforms stay the default.
-    pruned_fft = False
-    #: "pruned": libchx's own pruned / symmetry-aware line FFTs (chx_sc_convolve, power-of-two grids; other grids fall
-    #:           back to "hipfft");
-    #: "hipfft": dense in-place hipFFT plans owned by libchx (chx_sc_fft_*), Green-function chain on a side stream;
-    #: "torch": torch.fft.rfftn / irfftn (out of place, defensive copies around every transform) — kept for A/B timing
-    fft_backend = "pruned"
     _plans: dict = {}
     _side_streams: dict = {}
 
@@ -117,7 +107,7 @@ class SpaceChargeKick(Element):
         group = sharding.active_group()
         if group is not None:
             return self._track_particle_sharded(incoming, group, x, q, w, energy, L, out_shape, B, N)
-        if self.fft_backend == "pruned" and _ops.sc_pruned_supported(g, dtype):
+        if _ops.sc_pruned_supported(g, dtype):
             # the whole kick in one C call (chx_sc_kick): moments, geometry, deposit, libchx's own pruned line FFTs with
             # the Green-function chain on a side stream, gradient, gather + kick
             out = _ops.sc_kick(x, q.to(dtype).contiguous(), w.to(dtype).contiguous(), energy, L.contiguous(),
@@ -136,62 +126,29 @@ class SpaceChargeKick(Element):
         half, cell, gamma, dt, scale, extent, pot_scale = _ops.sc_geometry(
             mom, self._grid_extent(dtype), energy, L.contiguous(), incoming.species.mass_eV_float, pot_factor, B, g)
 
-        if self.fft_backend in ("hipfft", "pruned"):
-            # in-place hipFFT on the padded layout [2gx][2gy][2gz+2]; the Green-function chain (fp64-bound table,
-            # fill, forward FFT) runs on a side stream while the main stream deposits and transforms the charge
-            plan = self._fft_plan(B, g, dtype)
-            ldz = G2[2] + 2
-            main = torch.cuda.current_stream(device)
-            side = self._side_stream(device)
-            fork = torch.cuda.Event()
-            fork.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(fork)
-                green = _ops.sc_igf(cell, gamma, g, padded=True)
-                plan.forward(green, which=1)
-                join = torch.cuda.Event()
-                join.record(side)
-            rho = torch.zeros((B, G2[0], G2[1], ldz), dtype=dtype, device=device)
-            _ops.cic_deposit_into(rho, (G2[1] * ldz, ldz, 1), G2[0] * G2[1] * ldz, x, (0, 2, 4), g, extent,
-                                  charge=q, survival=w, scale=scale)
-            plan.forward(rho, which=0)
-            main.wait_event(join)
-            green.record_stream(main)
-            _ops.sc_spectral_mul(rho, green, pot_scale)
-            plan.inverse(rho)
-            phi = rho
-            force = _ops.sc_gradient(phi, cell, gamma, g)
-            out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
-            return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,
-                                particle_charges=incoming.particle_charges,
-                                survival_probabilities=incoming.survival_probabilities, s=incoming.s,
-                                species=incoming.species)
-
-        green = _ops.sc_igf(cell, gamma, g)
-        green_hat = torch.fft.rfftn(green, dim=[1, 2, 3])
-        if self.pruned_fft:
-            # Hockney zero padding, pruned: the charge only occupies the first octant of the doubled array, so
-            # the forward transform pads one axis at a time (z lines of the g x g block, then y, then x) and the
-            # inverse crops one axis at a time — 58 % of the butterflies of the two full (2g)^3 transforms and no
-            # 8x zero-filled copy of rho.
-            rho = torch.zeros((B, *g), dtype=dtype, device=device)
-            _ops.cic_deposit_into(rho, (g[1] * g[2], g[2], 1), g[0] * g[1] * g[2], x, (0, 2, 4), g, extent,
-                                  charge=q, survival=w, scale=scale)
-            rho_hat = torch.fft.rfft(rho, n=G2[2], dim=3)
-            rho_hat = torch.fft.fft(rho_hat, n=G2[1], dim=2)
-            rho_hat = torch.fft.fft(rho_hat, n=G2[0], dim=1).contiguous()
-            _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
-            phi = torch.fft.ifft(rho_hat, dim=1, norm="forward")[:, : g[0]]
-            phi = torch.fft.ifft(phi, dim=2, norm="forward")[:, :, : g[1]]
-            phi = torch.fft.irfft(phi, n=G2[2], dim=3, norm="forward")[..., : g[2]].contiguous()
-        else:
-            rho = torch.zeros((B, *G2), dtype=dtype, device=device)
-            _ops.cic_deposit_into(rho, (G2[1] * G2[2], G2[2], 1), G2[0] * G2[1] * G2[2], x, (0, 2, 4), g, extent,
-                                  charge=q, survival=w, scale=scale)
-            rho_hat = torch.fft.rfftn(rho, dim=[1, 2, 3])
-            _ops.sc_spectral_mul(rho_hat, green_hat, pot_scale)
-            phi = torch.fft.irfftn(rho_hat, s=G2, dim=[1, 2, 3], norm="forward")
-
+        # in-place hipFFT on the padded layout [2gx][2gy][2gz+2]; the Green-function chain (fp64-bound table,
+        # fill, forward FFT) runs on a side stream while the main stream deposits and transforms the charge
+        plan = self._fft_plan(B, g, dtype)
+        ldz = G2[2] + 2
+        main = torch.cuda.current_stream(device)
+        side = self._side_stream(device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            green = _ops.sc_igf(cell, gamma, g, padded=True)
+            plan.forward(green, which=1)
+            join = torch.cuda.Event()
+            join.record(side)
+        rho = torch.zeros((B, G2[0], G2[1], ldz), dtype=dtype, device=device)
+        _ops.cic_deposit_into(rho, (G2[1] * ldz, ldz, 1), G2[0] * G2[1] * ldz, x, (0, 2, 4), g, extent,
+                              charge=q, survival=w, scale=scale)
+        plan.forward(rho, which=0)
+        main.wait_event(join)
+        green.record_stream(main)
+        _ops.sc_spectral_mul(rho, green, pot_scale)
+        plan.inverse(rho)
+        phi = rho
         force = _ops.sc_gradient(phi, cell, gamma, g)
         out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
         return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy,

@@ -355,26 +355,3 @@ extern "C" int chx_cavity_track(const void* x_in, const void* R, const double* c
     return dtype == CHX_F32 ? launch_tiles<float, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s)
                             : launch_tiles<double, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s);
 }
-
-extern "C" int chx_time_apply_ms(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
-                                 int64_t BR, int64_t N, int dtype, int iters, void* stream,
-                                 double* ms_out) {
-    if (!ms_out || iters < 1) return CHX_ERR_INVALID_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CHX_ERR_LAUNCH;
-    int st = chx_apply_affine7(x_in, R, x_out, B, Bx, BR, N, dtype, stream);  // warm
-    if (st == CHX_OK) {
-        (void)hipEventRecord(e0, s);
-        for (int i = 0; i < iters && st == CHX_OK; ++i)
-            st = chx_apply_affine7(x_in, R, x_out, B, Bx, BR, N, dtype, stream);
-        (void)hipEventRecord(e1, s);
-        if (hipEventSynchronize(e1) != hipSuccess) st = CHX_ERR_LAUNCH;
-        float ms = 0.f;
-        if (st == CHX_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *ms_out = (double)ms / iters;
-        else if (st == CHX_OK) st = CHX_ERR_LAUNCH;
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return st;
-}

@@ -387,25 +387,25 @@ struct ComposeArgs {
     uint8_t bcast[kComposeChunk];
 };
 
-template <typename T>
-__global__ __launch_bounds__(CHX_BLOCK) void compose_kernel(ComposeArgs args, int E, int has_init,
-                                                           T* __restrict__ R_out) {
+// The composition of one batch row by one 256-thread workgroup; `map_of(e)` returns element e's 49 entries (row-major).
+// Shared by compose_kernel and run_map_kernel so that both associate the products identically (bit-identical results).
+template <typename T, typename MapOf>
+__device__ __forceinline__ void compose_block(MapOf map_of, int E, int has_init, T* __restrict__ R_row) {
     __shared__ double cur[4][49];
     __shared__ double nxt[4][49];
-    const int64_t b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane / 7, j = lane - 7 * i;
     const int per = (E + 3) / 4;
     const int e0 = wave * per, e1 = (e0 + per < E) ? e0 + per : E;
     double acc = (lane < 49) ? ((i == j) ? 1.0 : 0.0) : 0.0;
     // a follow-up launch continues from the product accumulated so far (wave 0 only)
-    if (has_init && wave == 0 && lane < 49) acc = (double)R_out[b * 49 + lane];
+    if (has_init && wave == 0 && lane < 49) acc = (double)R_row[lane];
     if (lane < 49) cur[wave][lane] = acc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int e = e0; e < e1; ++e) {
-        const T* Re = (const T*)args.ptr[e] + (args.bcast[e] ? 0 : b * 49);
+        const T* Re = map_of(e);
         if (lane < 49) nxt[wave][lane] = (double)Re[lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -440,8 +440,16 @@ __global__ __launch_bounds__(CHX_BLOCK) void compose_kernel(ComposeArgs args, in
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (lane < 49) R_out[b * 49 + lane] = (T)acc;
+        if (lane < 49) R_row[lane] = (T)acc;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void compose_kernel(ComposeArgs args, int E, int has_init,
+                                                           T* __restrict__ R_out) {
+    const int64_t b = blockIdx.x;
+    compose_block<T>([&](int e) { return (const T*)args.ptr[e] + (args.bcast[e] ? 0 : b * 49); }, E, has_init,
+                     R_out + b * 49);
 }
 
 // ---- cavity track coefficients (cavity.py:100-226) -------------------------------------------
@@ -1042,6 +1050,154 @@ extern "C" int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const
         CHX_CHECK_LAUNCH();
     }
     return CHX_OK;
+}
+
+// ---- prefix products of a run (Segment.get_beam_attrs_along_segment, segment.py:658-700): out[e] = M_e ... M_1 M_0 for
+// every e, fp64 accumulation carried from element to element, each prefix rounded to T once. One wave per batch row.
+template <typename T>
+__global__ __launch_bounds__(64) void compose_prefix_kernel(const T* __restrict__ maps, int E, int64_t B, int64_t Bm,
+                                                            T* __restrict__ out) {
+    __shared__ double cur[49];
+    __shared__ double nxt[49];
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = lane / 7, j = lane - 7 * i;
+    double acc = (lane < 49) ? ((i == j) ? 1.0 : 0.0) : 0.0;
+    for (int e = 0; e < E; ++e) {
+        const T* Me = maps + ((int64_t)e * Bm + (Bm == 1 ? 0 : b)) * 49;
+        if (lane < 49) { cur[lane] = acc; nxt[lane] = (double)Me[lane]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 49) {
+            double s = nxt[i * 7] * cur[j];
+            for (int k = 1; k < 7; ++k) s = fma(nxt[i * 7 + k], cur[k * 7 + j], s);
+            acc = s;
+            out[((int64_t)e * B + b) * 49 + lane] = (T)acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+extern "C" int chx_compose_prefix(const void* maps, int64_t E, int64_t B, int64_t Bm, int dtype, void* out, void* stream) {
+    if (!maps || !out || E < 1 || B < 1 || B > 0x7fffffffLL || !chx_bcast_ok(Bm, B)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(compose_prefix_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, (const float*)maps, (int)E, B, Bm,
+                           (float*)out);
+    else
+        hipLaunchKernelGGL(compose_prefix_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)maps, (int)E, B, Bm,
+                           (double*)out);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+// ---- persistent map of a run of scalar-parameter elements (Segment.track's steady state) ---------------------------
+// A control loop tracks the same lattice again and again, usually with unchanged settings. Instead of the host proving
+// that nothing changed (one Python attribute read per tensor of the run) the device does: ONE workgroup reads every
+// parameter where it lives, compares it with the value the stored map was built from and returns at once when all are
+// equal; otherwise it rebuilds the element maps (rounded to T like chx_build_rmatrix_scalars) and composes them with the
+// association of chx_compose_maps — bit-identical to build + compose. The pointers travel by value in the kernel
+// arguments (packed: only the parameters each kind has), the state lives in a caller-owned device buffer.
+constexpr int kRunMaxE = 192;      // one compose launch (kComposeChunk)
+constexpr int kRunMaxPtr = 400;    // 3.2 KB of the 4 KB kernel-argument space
+struct RunArgs {
+    const void* ptr[kRunMaxPtr];
+    uint16_t off[kRunMaxE];        // first pointer of element e
+    uint8_t kind[kRunMaxE];
+};
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void run_map_kernel(RunArgs a, int E, int nptr, const T* __restrict__ energy,
+                                                           double mass, double nq, double* __restrict__ seen /*[nptr + 3]*/,
+                                                           T* __restrict__ maps /*[E][49]*/, T* __restrict__ R /*[49]*/) {
+    // 1. anything different from what R was built from? (NaN-initialised state: the first call is always dirty)
+    int dirty = 0;
+    for (int q = threadIdx.x; q < nptr + 3; q += CHX_BLOCK) {
+        const double v = q < nptr ? (double)*(const T*)a.ptr[q] : (q == nptr ? (double)energy[0] : (q == nptr + 1 ? mass : nq));
+        if (!(v == seen[q])) dirty = 1;
+    }
+    if (!__syncthreads_or(dirty)) return;
+    // 2. element maps, fp64 inside, rounded to T (chx_build_rmatrix_scalars)
+    for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
+        const int kind = a.kind[e];
+        const int P = kind_num_params(kind);
+        double p[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) p[k] = (double)*(const T*)a.ptr[a.off[e] + k];
+        Mat7<double> M;
+        build_kind<double>(kind, p, (double)energy[0], mass, nq, M);
+        for (int q = 0; q < 49; ++q) maps[e * 49 + q] = (T)M.m[q];
+    }
+    for (int q = threadIdx.x; q < nptr + 3; q += CHX_BLOCK)
+        seen[q] = q < nptr ? (double)*(const T*)a.ptr[q] : (q == nptr ? (double)energy[0] : (q == nptr + 1 ? mass : nq));
+    __syncthreads();
+    // 3. R = M_{E-1} ... M_0 (chx_compose_maps)
+    if (E == 1) {
+        if (threadIdx.x < 49) R[threadIdx.x] = maps[threadIdx.x];
+        return;
+    }
+    compose_block<T>([&](int e) { return (const T*)maps + e * 49; }, E, 0, R);
+}
+
+extern "C" size_t chx_run_state_bytes(int64_t E) {
+    if (E < 1 || E > kRunMaxE) return 0;
+    // seen[kRunMaxPtr + 3] doubles, maps[E][49] and R[49] as doubles (room for either dtype)
+    return (size_t)(kRunMaxPtr + 4 + (E + 1) * 49) * sizeof(double);
+}
+
+static int run_args(const int32_t* kinds, const void* const* param_ptrs, int64_t E, RunArgs& a, int& nptr) {
+    if (!kinds || !param_ptrs || E < 1 || E > kRunMaxE) return CHX_ERR_INVALID_ARG;
+    nptr = 0;
+    for (int e = 0; e < (int)E; ++e) {
+        const int P = kind_num_params(kinds[e]);
+        if (P < 0 || nptr + P > kRunMaxPtr) return CHX_ERR_INVALID_ARG;
+        a.kind[e] = (uint8_t)kinds[e];
+        a.off[e] = (uint16_t)nptr;
+        for (int k = 0; k < P; ++k) {
+            const void* q = param_ptrs[(size_t)e * CHX_MAX_PARAMS + k];
+            if (!q) return CHX_ERR_INVALID_ARG;
+            a.ptr[nptr++] = q;
+        }
+    }
+    for (int e = (int)E; e < kRunMaxE; ++e) { a.kind[e] = 0; a.off[e] = 0; }
+    for (int q = nptr; q < kRunMaxPtr; ++q) a.ptr[q] = nullptr;
+    return CHX_OK;
+}
+
+extern "C" int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                           double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, void* stream) {
+    if (!energy || !state) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    RunArgs a;
+    int nptr = 0;
+    int st = run_args(kinds, param_ptrs, E, a, nptr);
+    if (st != CHX_OK) return st;
+    if (state_bytes < chx_run_state_bytes(E)) return CHX_ERR_WORKSPACE;
+    double* seen = (double*)state;
+    double* maps = seen + kRunMaxPtr + 4;
+    double* R = maps + E * 49;
+    if (R_out) *R_out = R;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(run_map_kernel<float>, dim3(1), dim3(CHX_BLOCK), 0, s, a, (int)E, nptr, (const float*)energy, mass_eV,
+                           n_charges, seen, (float*)maps, (float*)R);
+    else
+        hipLaunchKernelGGL(run_map_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s, a, (int)E, nptr, (const double*)energy,
+                           mass_eV, n_charges, seen, maps, R);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                             double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out,
+                             int64_t N, void* stream) {
+    void* R = nullptr;
+    int st = chx_run_map(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, state, state_bytes, &R, stream);
+    if (st != CHX_OK) return st;
+    return chx_apply_affine7(x_in, R, x_out, 1, 1, 1, N, dtype, stream);
 }
 
 extern "C" int chx_compose_maps(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B,

@@ -30,19 +30,36 @@ struct CicPoint {
 };
 
 // cloud_in_cell.py:150-172 (1-D), :262-311 (3-D): in-extent mask, bin-space position, floor, frac
+// Rmap (optional): a 7x7 map applied to the particle on the fly — coordinate cols[d] of R x, evaluated as the fma chain of
+// chx_apply_affine7 (bit-identical to tracking first and depositing afterwards), without the tracked particles ever
+// being written (chx_cic_deposit_mapped: Screen images of a scan of lattice settings).
 template <typename T>
 __device__ __forceinline__ CicPoint<T> cic_locate(const CicDev& a, const T* __restrict__ x,
                                                   const T* __restrict__ extent,
                                                   const T* __restrict__ scale,
-                                                  const T* __restrict__ shift, int64_t b, int64_t n) {
+                                                  const T* __restrict__ shift, int64_t b, int64_t n,
+                                                  const T* __restrict__ Rmap = nullptr) {
     CicPoint<T> r;
     r.inside = true;
     const int64_t xrow = (a.Bx == 1 ? 0 : b) * a.N + n;
     const T* ext = extent + (a.Be == 1 ? 0 : b) * a.ndim * 2;
+    T row[7];
+    if (Rmap) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) row[j] = x[xrow * 7 + j];
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (d < a.ndim) {
-            T v = x[xrow * 7 + a.cols[d]];
+            T v;
+            if (Rmap) {
+                const T* Rr = Rmap + a.cols[d] * 7;
+                v = Rr[0] * row[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) v = fma(Rr[j], row[j], v);
+            } else {
+                v = x[xrow * 7 + a.cols[d]];
+            }
             if (scale) v = v * scale[(a.Bsc == 1 ? 0 : b) * a.ndim + d];
             if (shift) v = v - shift[(a.Bsh == 1 ? 0 : b) * a.ndim + d];
             const T l = ext[d * 2], rgt = ext[d * 2 + 1];
@@ -122,16 +139,18 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_deposit_kernel(CicDev a, const 
                                                                const T* __restrict__ extent,
                                                                const T* __restrict__ scale,
                                                                const T* __restrict__ shift,
-                                                               T* __restrict__ grid) {
+                                                               T* __restrict__ grid,
+                                                               const T* __restrict__ Rmaps, int64_t BR) {
     __shared__ long long keys[kCombSlots];
     __shared__ double vals[kCombSlots];
     const int64_t b = blockIdx.y;
     CombTable<T> table;
     table.init(keys, vals, grid + b * a.gbatch);
     auto add = [&](int64_t off, T v) { table.add(off, v); };
+    const T* Rb = Rmaps ? Rmaps + (BR == 1 ? 0 : b) * 49 : nullptr;
     for (int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; n < a.N;
          n += (int64_t)gridDim.x * CHX_BLOCK) {
-        const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n);
+        const CicPoint<T> pt = cic_locate<T>(a, x, extent, scale, shift, b, n, Rb);
         if (!pt.inside) continue;  // masked_charges == 0 (cloud_in_cell.py:150-156)
         const T c = cic_charge<T>(a, q, s, b, n);
         T wf[3][2];
@@ -933,23 +952,31 @@ int launch_sorted(const CicDev& a, const chx_cic_args* p, void* workspace, size_
 
 }  // namespace
 
-extern "C" int chx_cic_deposit(const chx_cic_args* p, void* stream) {
+static int deposit_direct(const chx_cic_args* p, const void* R, int64_t BR, void* stream) {
     CicDev a;
     int st = cic_prepare(p, a);
     if (st != CHX_OK) return st;
     if (!p->grid) return CHX_ERR_INVALID_ARG;
+    if (R && !chx_bcast_ok(BR, a.B)) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid = combine_grid(a.N, a.B);
     if (p->dtype == CHX_F32)
         hipLaunchKernelGGL(cic_deposit_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, a, (const float*)p->x,
                            (const float*)p->charge, (const float*)p->survival, (const float*)p->extent,
-                           (const float*)p->scale, (const float*)p->shift, (float*)p->grid);
+                           (const float*)p->scale, (const float*)p->shift, (float*)p->grid, (const float*)R, BR);
     else
         hipLaunchKernelGGL(cic_deposit_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, a, (const double*)p->x,
                            (const double*)p->charge, (const double*)p->survival, (const double*)p->extent,
-                           (const double*)p->scale, (const double*)p->shift, (double*)p->grid);
+                           (const double*)p->scale, (const double*)p->shift, (double*)p->grid, (const double*)R, BR);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
+}
+
+extern "C" int chx_cic_deposit(const chx_cic_args* p, void* stream) { return deposit_direct(p, nullptr, 1, stream); }
+
+extern "C" int chx_cic_deposit_mapped(const chx_cic_args* p, const void* R, int64_t BR, void* stream) {
+    if (!R) return CHX_ERR_INVALID_ARG;
+    return deposit_direct(p, R, BR, stream);
 }
 
 extern "C" int chx_cic_indices(const chx_cic_args* p, int32_t* idx_out, void* frac_out, void* stream) {

@@ -94,6 +94,25 @@ int chx_build_rmatrix_vjp(int kind, const void* params, const void* energy, doub
  * packed tensor, an allocation and a launch per element). */
 int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
                               double mass_eV, double n_charges, int dtype, void* R_out, void* stream);
+/* Persistent map of a run of scalar-parameter elements (Segment.track's steady state, segment.py:545-574): `state`
+ * (chx_run_state_bytes(E) bytes of device memory owned by the caller, filled with 0xFF bytes once) remembers the parameter
+ * values, the element maps and the composed map R of the last call. chx_run_map launches ONE workgroup that re-reads every
+ * parameter through its pointer and returns at once if none changed, else rebuilds and recomposes — bit-identical to
+ * chx_build_rmatrix_scalars + chx_compose_maps. *R_out (if not NULL) receives the device address of R[7][7] inside `state`.
+ * chx_run_track = chx_run_map + chx_apply_affine7(x_in, R, x_out) for one beam of N particles: a whole merged
+ * Segment.track in one call, with no host-side validation of the settings. E <= 192 elements, <= 400 parameters in total
+ * (CHX_ERR_INVALID_ARG beyond: use the two-call form). Identity elements are left out by the caller. */
+/* Prefix products of a run: out[e][b] = maps[e][b] ... maps[1][b] maps[0][b] for every e (maps[E][Bm][7][7], Bm in {1, B};
+ * out[E][B][7][7]); fp64 accumulation carried along, each prefix rounded once. With chx_track_moments on the E prefixes the
+ * beam moments after every element of a lattice (segment.py:658-700 `get_beam_attrs_along_segment`) cost one pass over the
+ * particles instead of E tracking passes and E reductions. */
+int chx_compose_prefix(const void* maps, int64_t E, int64_t B, int64_t Bm, int dtype, void* out, void* stream);
+size_t chx_run_state_bytes(int64_t E);
+int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, void* stream);
+int chx_run_track(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                  double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
+                  void* stream);
 /* ---- segment composition (a2; segment.py:534-543): R_out[b] = R_{E-1}[b] ... R_1[b] R_0[b].
  * R_ptrs is a HOST array of E device pointers, one map buffer per element (each element owns
  * its cached map); buffer e is [1][7][7] if bcast[e] (HOST array) else [B][7][7]. The pointers are
@@ -206,6 +225,11 @@ typedef struct chx_cic_args {
     void* grid;           /* [B] grids, dtype, accumulated into (caller zeroes) */
 } chx_cic_args;
 int chx_cic_deposit(const chx_cic_args* args, void* stream);
+/* Fused "track, then deposit" (SURVEY section 8 row f2): the position of particle n in batch row b is taken from R[b] x
+ * (R[BR][7][7], BR in {1, B}; coordinate cols[d] of the product, the fma chain of chx_apply_affine7 — bit-identical to
+ * chx_apply_affine7 followed by chx_cic_deposit) without the (B, N, 7) tracked array ever being written: Screen images
+ * for a scan of B lattice settings over one shared beam (element.py:180-191 + screen.py:327-339). */
+int chx_cic_deposit_mapped(const chx_cic_args* args, const void* R, int64_t BR, void* stream);
 /* Same result as chx_cic_deposit (identical addends, different summation order) for ndim 2 or 3 and large
  * N: particles are counting-sorted by grid tile, accumulated in LDS (ds_add) and flushed once per tile,
  * instead of 2^ndim global float atomics per particle (which saturate at ~21 G atomics/s on MI355X). */
@@ -449,12 +473,6 @@ int chx_apply_second_order_bwd(const void* x_in, const void* T, const void* dY, 
 enum chx_aperture_shape { CHX_APERTURE_RECTANGULAR = 0, CHX_APERTURE_ELLIPTICAL = 1 };
 int chx_aperture_mask(const void* x_in, const void* survival_in, const void* limits, int shape, int64_t B, int64_t Bx,
                       int64_t Bs, int64_t Bl, int64_t N, int dtype, void* survival_out, void* stream);
-
-/* ---- instrumentation: average duration (ms) of `iters` back-to-back launches of the apply
- * kernel on `stream`, measured with hipEvents recorded on that stream. Used by bench.py for
- * roofline.achieved. Synchronises the stream (the only entry point that does). */
-int chx_time_apply_ms(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
-                      int64_t BR, int64_t N, int dtype, int iters, void* stream, double* ms_out);
 
 #ifdef __cplusplus
 }

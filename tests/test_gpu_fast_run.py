@@ -1,0 +1,165 @@
+"""The persistent device plan of a run of scalar-parameter elements (`chx_run_track`, `Segment._run_apply_fast`): one C
+call per merged `Segment.track`, the device decides whether the stored map is still valid. Results must be bit-identical
+to the general path (per-element maps -> chx_compose_maps -> chx_apply_affine7) and follow every kind of change of the
+settings (in-place edit, re-assignment, dtype move, vectorised or trainable settings falling back to the general path).
+Reference behaviour: /root/reference/cheetah/accelerator/segment.py:534-574, utils/cache.py:29-52."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available()
+    import cheetah_amd
+
+    cheetah_amd._lib.lib()
+    return cheetah_amd
+
+
+def lattice(ca, dt):
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    return ca.Segment([
+        ca.Marker(**kw), ca.Drift(t(0.175), **kw), ca.Quadrupole(t(0.122), k1=t(8.2), name="q1", **kw), ca.Drift(t(0.428), **kw),
+        ca.Quadrupole(t(0.122), k1=t(-14.3), tilt=t(0.01), misalignment=t([1e-4, -2e-4]), name="q2", **kw),
+        ca.VerticalCorrector(t(0.02), angle=t(9e-5), name="cv", **kw), ca.Dipole(t(0.3), angle=t(0.05), dipole_e1=t(0.01), name="d", **kw),
+        ca.HorizontalCorrector(t(0.02), angle=t(-1e-4), name="ch", **kw), ca.Solenoid(t(0.1), k=t(0.3), **kw),
+        ca.BPM(**kw), ca.Drift(t(0.45), **kw), ca.Screen(name="scr", **kw),
+    ])
+
+
+def general_path(ca, seg, beam):
+    """Per-element maps composed and applied without the persistent plan."""
+    from cheetah_amd import _ops
+
+    # identity elements (Marker, inactive BPM / Screen) are left out of the product, as Segment does: the association of the
+    # fp64 products — and with it the last bit of an fp64 map — depends on the number of factors
+    maps = [e.first_order_transfer_map(beam.energy, beam.species) for e in seg.elements
+            if e._chx_kind != _ops.KIND["identity"]]
+    tm = _ops.compose_maps(maps, (), maps[0].dtype, maps[0].device)
+    return _ops.apply_map(beam.particles, tm)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_fast_run_is_bit_identical_and_follows_setting_changes(ca, dt):
+    seg = lattice(ca, dt)
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_000, dtype=dt, device="cuda")
+    out = seg.track(beam)
+    run = seg._plan()[0][1]
+    assert run.fast is not None and run.fast.ok, "the all-scalar lattice must take the persistent plan"
+    assert torch.equal(out.particles, general_path(ca, seg, beam))
+    assert torch.equal(seg.track(beam).particles, out.particles)            # unchanged settings: stored map reused
+    # in-place edit of a setting: no host-side counter is consulted, the device notices the new value
+    seg.q1.k1.add_(1.5)
+    out2 = seg.track(beam)
+    assert not torch.equal(out2.particles, out.particles)
+    assert torch.equal(out2.particles, general_path(ca, seg, beam))
+    seg.q2.misalignment[0] = 3e-4
+    assert torch.equal(seg.track(beam).particles, general_path(ca, seg, beam))
+    # re-assignment (new tensor, new address): the epoch moves, the plan is rebuilt
+    old_plan = run.fast
+    seg.cv.angle = torch.tensor(-2e-5, dtype=dt, device="cuda")
+    out3 = seg.track(beam)
+    assert seg._plan()[0][1].fast is not old_plan
+    assert torch.equal(out3.particles, general_path(ca, seg, beam))
+    # another beam energy / species: part of the device-side comparison
+    beam2 = ca.ParticleBeam(beam.particles, torch.tensor(2.3e9, dtype=dt, device="cuda"), species=ca.Species("proton", dtype=dt, device="cuda"))
+    assert torch.equal(seg.track(beam2).particles, general_path(ca, seg, beam2))
+    assert torch.equal(seg.track(beam).particles, general_path(ca, seg, beam))
+    # s and the other beam attributes as in the general path
+    assert float(out3.s) == pytest.approx(float(seg.length), rel=1e-6)
+
+
+def test_fast_run_falls_back_where_it_must(ca):
+    dt = torch.float32
+    seg = lattice(ca, dt)
+    beam = ca.ParticleBeam.from_parameters(num_particles=4096, dtype=dt, device="cuda")
+    seg.track(beam)
+    # vectorised setting -> general path, vectorised result
+    seg.q1.k1 = torch.linspace(-5, 5, 3, dtype=dt, device="cuda")
+    out = seg.track(beam)
+    assert out.particles.shape == (3, 4096, 7)
+    assert not seg._plan()[0][1].fast.ok
+    # trainable setting -> general path with gradients
+    seg.q1.k1 = torch.nn.Parameter(torch.tensor(4.2, dtype=dt, device="cuda"))
+    out = seg.track(beam)
+    out.particles[:, 0].square().mean().backward()
+    assert seg.q1.k1.grad is not None and float(seg.q1.k1.grad.abs()) > 0
+    # a buffer switched to requires_grad in place moves no counter: still found
+    seg = lattice(ca, dt)     # (a registered Parameter cannot be re-assigned a plain tensor: fresh lattice)
+    seg.track(beam)
+    assert seg._plan()[0][1].fast.ok
+    seg.q2.k1.requires_grad_(True)
+    out = seg.track(beam)
+    assert out.particles.requires_grad
+    seg.q2.k1.requires_grad_(False)
+    with torch.no_grad():
+        assert not seg.track(beam).particles.requires_grad
+    # particles that require grad
+    b2 = ca.ParticleBeam(beam.particles.clone().requires_grad_(True), beam.energy, species=beam.species)
+    assert seg.track(b2).particles.requires_grad
+    # the lattice moved to another dtype after tracking
+    seg64 = seg.double()
+    beam64 = ca.ParticleBeam(beam.particles.double(), beam.energy.double(), species=ca.Species("electron", dtype=torch.float64, device="cuda"))
+    o64 = seg64.track(beam64)
+    assert o64.particles.dtype == torch.float64
+    assert torch.equal(o64.particles, general_path(ca, seg64, beam64))
+    # changing the element list
+    seg64.elements.append(ca.Drift(torch.tensor(1.0, dtype=torch.float64, device="cuda"), dtype=torch.float64, device="cuda"))
+    o2 = seg64.track(beam64)
+    assert torch.equal(o2.particles, general_path(ca, seg64, beam64)) and not torch.equal(o2.particles, o64.particles)
+    # an active element in the middle splits the lattice into two runs, each with its own plan
+    seg64.scr.is_active = True
+    o3 = seg64.track(beam64)
+    plan = seg64._plan()
+    assert [k for k, _ in plan] == ["run", "element", "run"] and all(item.fast.ok for k, item in plan if k == "run")
+    # two passes (each rounding the coordinates once) instead of one merged pass: equal to rounding, not bit for bit
+    assert torch.allclose(o3.particles, o2.particles, rtol=1e-12, atol=1e-18)
+
+
+def test_c_abi_run_map_against_build_and_compose(ca):
+    """chx_run_map through the C-ABI: NaN-filled state -> map; same call again -> unchanged; a changed value -> new map
+    equal to chx_build_rmatrix_scalars + chx_compose_maps."""
+    import ctypes
+
+    from cheetah_amd import _lib, _ops
+
+    lib = _lib.lib()
+    dt = torch.float64
+    vals = [torch.tensor(v, dtype=dt, device="cuda") for v in (0.3, 0.2, 4.2, 0.0, 0.0, 0.0, 0.8)]
+    kinds = [_ops.KIND["drift"], _ops.KIND["quadrupole"], _ops.KIND["drift"]]
+    rows = [[vals[0]], [vals[1], vals[2], vals[3], vals[4], vals[5]], [vals[6]]]
+    ptrs = []
+    for r in rows:
+        ptrs += [t.data_ptr() for t in r] + [None] * (_ops.MAX_PARAMS - len(r))
+    E = 3
+    energy = torch.tensor(1e8, dtype=dt, device="cuda")
+    nbytes = lib.chx_run_state_bytes(E)
+    assert nbytes > 0 and lib.chx_run_state_bytes(0) == 0 and lib.chx_run_state_bytes(193) == 0
+    state = torch.full((nbytes // 8,), float("nan"), dtype=torch.float64, device="cuda")
+    R_addr = ctypes.c_void_p()
+    karr, parr = (ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs)
+
+    def run():
+        _ops.check(lib.chx_run_map(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), nbytes,
+                                   ctypes.byref(R_addr), _ops.stream_ptr()), "chx_run_map")
+        off = (R_addr.value - state.data_ptr()) // 8
+        return state[off:off + 49].reshape(7, 7).clone()
+
+    def two_call():
+        maps = torch.empty((E, 7, 7), dtype=dt, device="cuda")
+        _ops.check(lib.chx_build_rmatrix_scalars(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, maps.data_ptr(),
+                                                 _ops.stream_ptr()), "build")
+        return _ops.compose_maps([maps[0], maps[1], maps[2]], (), dt, maps.device)
+
+    R1 = run()
+    assert torch.equal(R1, two_call())
+    assert torch.equal(run(), R1)
+    vals[2].fill_(-3.3)
+    R2 = run()
+    assert not torch.equal(R2, R1) and torch.equal(R2, two_call())
+    assert lib.chx_run_map(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), 16, None, None) == -5
+    assert lib.chx_run_map(karr, parr, 0, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), nbytes, None, None) == -1

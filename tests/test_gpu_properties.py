@@ -193,3 +193,45 @@ def test_space_charge_cold_uniform_beam_doubles(ca, energy, dt):
     out = seg.track(incoming)
     for n in ("sigma_x", "sigma_y", "sigma_tau"):
         assert float(getattr(out, n)) == pytest.approx(2 * float(getattr(incoming, n)), rel=2e-2), n
+
+
+def test_pass_through_elements_return_independent_beams(ca):
+    """marker.py:52-53, bpm.py:87, screen.py:239 return `incoming.clone()`: editing the outgoing beam in place must not
+    reach the incoming beam (and vice versa), for single elements and for segments made only of pass-through elements; the
+    Screen reading survives edits of both (/root/reference/tests/test_screen.py:198-240)."""
+    for make in (lambda: ca.Marker(dtype=f64, device="cuda"), lambda: ca.BPM(is_active=True, dtype=f64, device="cuda"),
+                 lambda: ca.BPM(dtype=f64, device="cuda"), lambda: ca.Screen(dtype=f64, device="cuda"),
+                 lambda: ca.Screen(is_active=True, dtype=f64, device="cuda"),
+                 lambda: ca.Aperture(is_active=False, dtype=f64, device="cuda"),
+                 lambda: ca.Segment([ca.Marker(dtype=f64, device="cuda"), ca.BPM(dtype=f64, device="cuda")])):
+        el = make()
+        b = beam(ca)
+        before = {k: getattr(b, k).clone() for k in ("particles", "energy", "particle_charges", "survival_probabilities")}
+        out = el.track(b)
+        assert out is not b and torch.equal(out.particles, b.particles)
+        out.particles.mul_(0.7)
+        out.energy.mul_(0.5)
+        out.particle_charges.mul_(0.3)
+        out.survival_probabilities.mul_(0.1)
+        for k, v in before.items():
+            if isinstance(el, ca.Segment) and k != "particles":
+                continue   # a segment of skippable elements is one linear map: like the reference's _track_first_order
+                           # (element.py:184-191) the new beam shares energy / charges / survival with the incoming one
+            assert torch.equal(getattr(b, k), v), (type(el).__name__, k)
+    # a segment that ends in pass-through elements after a real map: new coordinates, no extra copy needed, still independent
+    b = beam(ca)
+    seg = ca.Segment([ca.Drift(t(0.3)), ca.Marker(dtype=f64, device="cuda"), ca.Screen(is_active=True, name="scr", dtype=f64, device="cuda")])
+    before = b.particles.clone()
+    out = seg.track(b)
+    read = seg.scr.get_read_beam().particles.clone()
+    img = seg.scr.reading.clone()
+    out.particles.mul_(2.0)
+    b.particles.mul_(3.0)
+    assert torch.equal(seg.scr.get_read_beam().particles, read) and torch.equal(seg.scr.reading, img)
+    assert torch.equal(b.particles, 3.0 * before)
+    # ParameterBeam through a marker
+    pb = ca.ParameterBeam.from_parameters(dtype=f64, device="cuda")
+    mu0 = pb.mu.clone()
+    o = ca.Marker(dtype=f64, device="cuda").track(pb)
+    o.mu.mul_(2.0)
+    assert torch.equal(pb.mu, mu0)
