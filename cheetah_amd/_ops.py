@@ -773,21 +773,35 @@ def _cic_args(particles, cols, bins, extent, charge, survival, scale, shift, abs
     dt = particles.dtype
     N = particles.shape[-2]
     nd = len(cols)
-    shapes = [particles.shape[:-2], extent.shape[:-2], tuple(extra_batch)]
-    for t, k in ((charge, 1), (survival, 1), (scale, 1), (shift, 1)):
-        if t is not None:
-            shapes.append(t.shape[:-1])
-    batch_shape = torch.broadcast_shapes(*shapes)
-    B = numel(batch_shape)
     keep = []
+    # no vector dimension anywhere (one beam on one screen / grid: the control-loop case): nothing to broadcast
+    plain = (particles.dim() == 2 and extent.dim() == 2 and not extra_batch
+             and all(t is None or t.dim() == 1 for t in (charge, survival, scale, shift)))
+    if plain:
+        batch_shape, B = (), 1
 
-    def prep(t, n_tail):
-        if t is None:
-            return None, 1
-        f, Bt = flat_bcast(t.to(dt), batch_shape, n_tail)
-        f = f.contiguous()
-        keep.append(f)
-        return f, Bt
+        def prep(t, n_tail):
+            if t is None:
+                return None, 1
+            f = t if t.dtype == dt else t.to(dt)
+            f = f if f.is_contiguous() else f.contiguous()
+            keep.append(f)
+            return f, 1
+    else:
+        shapes = [particles.shape[:-2], extent.shape[:-2], tuple(extra_batch)]
+        for t, k in ((charge, 1), (survival, 1), (scale, 1), (shift, 1)):
+            if t is not None:
+                shapes.append(t.shape[:-1])
+        batch_shape = torch.broadcast_shapes(*shapes)
+        B = numel(batch_shape)
+
+        def prep(t, n_tail):
+            if t is None:
+                return None, 1
+            f, Bt = flat_bcast(t.to(dt), batch_shape, n_tail)
+            f = f.contiguous()
+            keep.append(f)
+            return f, Bt
 
     x, Bx = prep(particles, 2)
     ext, Be = prep(extent, 2)

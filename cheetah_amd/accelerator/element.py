@@ -276,8 +276,16 @@ class Element(nn.Module):
         raise NotImplementedError
 
     def __setattr__(self, name: str, value: Any) -> None:
-        if "_revision" in self.__dict__ and not name.startswith("_"):
+        d = self.__dict__
+        if "_revision" in d and name[0] != "_":
             self._touch()
+            # a plain tensor assigned to a registered buffer (a control loop's `quad.k1 = new_value`): nn.Module.__setattr__
+            # ends up doing exactly this after ~4 us of isinstance checks on Parameter / Module
+            if type(value) is torch.Tensor:
+                buffers = d.get("_buffers")
+                if buffers is not None and name in buffers:
+                    buffers[name] = value
+                    return
         return super().__setattr__(name, value)
 
     def _apply(self, fn, recurse=True):

@@ -88,56 +88,102 @@ class _ElementList(nn.ModuleList):
 class _FastRun:
     """Persistent device plan of a run (`chx_run_track`): packed kinds / parameter pointers (host arrays, forwarded by
     value) and the device state buffer that remembers the settings the stored map was built from. Valid while
-    `Element._epoch` stands still; a changed VALUE of a setting (in-place edit, optimiser step) is found by the device."""
+    `Element._epoch` stands still; a changed VALUE of a setting (in-place edit, optimiser step) is found by the device.
 
-    __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code")
+    A control loop re-assigns a few settings per step, which moves the epoch: `refresh` then re-reads only the elements
+    whose own revision moved, patches their pointers into the existing host arrays and keeps the device state (it
+    remembers VALUES, whatever tensor they live in)."""
 
-    def __init__(self, run, dtype, device, previous=None):
+    __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
+                 "elements", "revs", "rows", "per_tensors")
+
+    def __init__(self, run, dtype, device):
+        self.dtype, self.device = dtype, device
+        self.elements = [e for e in run.elements]
+        self.revs = [None] * len(self.elements)
+        self.rows = [None] * len(self.elements)          # per element: (kind, [pointers]) or "identity"
+        self.per_tensors = [()] * len(self.elements)
+        self.state = None
+        self.kinds = None
+        self.code = _ops.dtype_code(dtype)
+        self.refresh()
+
+    def _read(self, e):
+        """(kind, pointers, tensors) of one element, "identity", or None when the element rules the plan out."""
+        if not e._static_skippable or e._parameters:
+            return None                     # data-dependent skippability (Cavity, sub-Segment) or trainable parameters
+        kind = e._chx_kind
+        if kind is None:
+            return None
+        if kind == _ops.KIND["identity"]:
+            return "identity"
+        row, tensors = [None] * _ops.MAX_PARAMS, []
+        dtype, device = self.dtype, self.device
+        for k, (t, index) in enumerate(e._builder_scalar_refs()):
+            if t.dtype != dtype or t.device != device or t.requires_grad:
+                return None
+            if index is None:
+                if t.dim() != 0:
+                    return None
+                row[k] = t.data_ptr()
+            else:
+                if t.dim() != 1 or not t.is_contiguous():
+                    return None
+                row[k] = t.data_ptr() + index * t.element_size()
+            tensors.append(t)
+        return kind, row, tensors
+
+    def refresh(self) -> None:
         self.epoch = Element._epoch
         self.ok = False
-        self.dtype, self.device = dtype, device
-        identity = _ops.KIND["identity"]
-        kinds, pointers, tensors = [], [], []
-        for e in run.elements:
-            if not e._static_skippable or e._parameters:
-                return                      # data-dependent skippability (Cavity, sub-Segment) or trainable parameters
-            kind = e._chx_kind
-            if kind is None:
-                return
-            if kind == identity:
-                continue
-            row = [None] * _ops.MAX_PARAMS
-            for k, (t, index) in enumerate(e._builder_scalar_refs()):
-                if t.dtype != dtype or t.device != device or t.requires_grad:
+        changed = []
+        for i, e in enumerate(self.elements):
+            rev = e.__dict__["_revision"]
+            if rev != self.revs[i]:
+                got = self._read(e)
+                self.revs[i] = rev
+                if got is None:
+                    self.rows[i] = None
+                    self.revs[i] = None     # look again next time
                     return
-                if index is None:
-                    if t.dim() != 0:
-                        return
-                    row[k] = t.data_ptr()
-                else:
-                    if t.dim() != 1 or not t.is_contiguous():
-                        return
-                    row[k] = t.data_ptr() + index * t.element_size()
-                tensors.append(t)
-            kinds.append(kind)
-            pointers += row
+                self.rows[i] = got if got == "identity" else (got[0], got[1])
+                self.per_tensors[i] = () if got == "identity" else tuple(got[2])
+                changed.append(i)
+            elif self.rows[i] is None:
+                return
+        kinds = [r[0] for r in self.rows if r != "identity"]
         E = len(kinds)
-        if E == 0 or E > 192 or len(tensors) > 400:
+        if E == 0 or E > 192:
             return
-        self.E = E
-        self.kinds = (ctypes.c_int32 * E)(*kinds)
-        self.ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*pointers)
-        # kept alive: the plan holds their addresses (each tensor once: `misalignment` feeds two parameters)
-        self.tensors = tuple({id(t): t for t in tensors}.values())
-        self.code = _ops.dtype_code(dtype)
-        if previous is not None and previous.ok and previous.dtype == dtype and previous.device == device \
-                and list(previous.kinds) == kinds:
-            # same elements, some setting re-assigned (a control loop): the remembered VALUES are still those the stored
-            # map was built from, whatever tensor they now live in — keep the state, the device compares values
-            self.state, self.state_bytes = previous.state, previous.state_bytes
+        if self.kinds is not None and len(self.kinds) == E and list(self.kinds) == kinds:
+            # same kinds in the same places: patch the pointers of the elements that changed
+            slot = 0
+            for i, r in enumerate(self.rows):
+                if r == "identity":
+                    continue
+                if i in changed:
+                    base = slot * _ops.MAX_PARAMS
+                    for k, v in enumerate(r[1]):
+                        self.ptrs[base + k] = v
+                slot += 1
         else:
+            pointers = []
+            for r in self.rows:
+                if r != "identity":
+                    pointers += r[1]
+            self.E = E
+            self.kinds = (ctypes.c_int32 * E)(*kinds)
+            self.ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*pointers)
             self.state_bytes = _lib.lib().chx_run_state_bytes(E)
-            self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=device)
+            self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=self.device)
+        # kept alive: the plan holds their addresses (each tensor once: `misalignment` feeds two parameters)
+        seen = {}
+        for ts in self.per_tensors:
+            for t in ts:
+                seen[id(t)] = t
+        if len(seen) > 400:
+            return
+        self.tensors = tuple(seen.values())
         self.ok = True
 
 
@@ -343,8 +389,10 @@ class Segment(Element):
         if p.dim() != 2 or not p.is_cuda:
             return None
         fr = run.fast
-        if fr is None or fr.epoch != Element._epoch or fr.dtype != p.dtype or fr.device != p.device:
-            fr = run.fast = _FastRun(run, p.dtype, p.device, previous=fr)
+        if fr is None or fr.dtype != p.dtype or fr.device != p.device:
+            fr = run.fast = _FastRun(run, p.dtype, p.device)
+        elif fr.epoch != Element._epoch:
+            fr.refresh()
         if not fr.ok:
             return None
         e = incoming.energy

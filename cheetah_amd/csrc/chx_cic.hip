@@ -466,12 +466,12 @@ __device__ __forceinline__ SortAxes<T, ND> sort_axes(const CicDev& a, const T* _
 // in [-1, bins], so the conversion is exact, and p - (T)(long long)floor(p) == p - floor(p) for every integral floor(p);
 // particles outside the extent are skipped by the caller. Returns the in-extent mask.
 template <typename T, int ND>
-__device__ __forceinline__ bool sort_locate(const CicDev& a, const SortAxes<T, ND>& ax, const T* __restrict__ xrow, int (&i)[ND],
+__device__ __forceinline__ bool sort_locate(const CicDev& a, const SortAxes<T, ND>& ax, const T (&raw)[ND], int (&i)[ND],
                                             T (&f)[ND]) {
     bool inside = true;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-        T v = xrow[a.cols[d]];
+        T v = raw[d];
         if (ax.has_sc) v = v * ax.sc[d];
         if (ax.has_sh) v = v - ax.sh[d];
         inside = inside && (v >= ax.l[d]) && (v <= ax.r[d]);
@@ -505,6 +505,7 @@ __device__ __forceinline__ void sort_tile_range(const CicDev& a, const TileGeom&
 constexpr int kAccTileCap = 8192;   // records of a tile handled by its owner workgroup (a +-3 sigma Gaussian stays below)
 constexpr int kSortWG = 256;       // workgroups of the count / scatter passes (per batch row)
 constexpr int kSortThreads = 1024;  // threads of those workgroups (latency-bound loops: many waves)
+constexpr int kSortBatch = 4;       // particles per lane fetched together
 
 // exclusive prefix sum of v[0..n) in LDS by one workgroup of kSortThreads lanes; returns the total
 __device__ __forceinline__ int block_exclusive_scan(int* v, int n) {
@@ -549,6 +550,31 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
     const int64_t b = blockIdx.y;
     const int wg = blockIdx.x;
     int* cnt = counts + (b * kSortWG + wg) * (int64_t)g.nt;
+    // The workgroup's particles are fetched FIRST — kSortBatch per lane, all loads in flight at once — so that their
+    // latency overlaps the cursor set-up below (zero fill, or the scan of the 4096 tile totals), and one memory round trip
+    // serves the whole chunk at the benchmark size (1e6 particles / 256 workgroups / 1024 lanes = 3.8 per lane).
+    const int64_t per = (a.N + kSortWG - 1) / kSortWG;
+    const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    const T* __restrict__ xb = x + (a.Bx == 1 ? 0 : b) * a.N * 7;
+    const T* __restrict__ qb = q ? q + (a.Bq == 1 ? 0 : b) * a.N : nullptr;
+    const T* __restrict__ sb = s ? s + (a.Bs == 1 ? 0 : b) * a.N : nullptr;
+    T raw[kSortBatch][ND], craw[kSortBatch];
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int u = 0; u < kSortBatch; ++u) {
+            const int64_t n = base + (int64_t)u * kSortThreads;
+            const int64_t src = n < n1 ? n : (n1 > n0 ? n1 - 1 : 0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) raw[u][d] = xb[src * 7 + a.cols[d]];
+            if (SCATTER) {
+                T c = qb ? qb[src] : (T)1;
+                if (a.abs_charge) c = fabs(c);
+                if (sb) c = c * sb[src];
+                craw[u] = c;
+            }
+        }
+    };
+    if (n1 > n0) fetch(n0 + threadIdx.x);
     if (!SCATTER) {
         for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] = 0;
     } else {
@@ -577,37 +603,35 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
         for (int t = threadIdx.x; t < g.nt; t += kSortThreads) hist[t] += cnt[t];
     }
     __syncthreads();
-    const int64_t per = (a.N + kSortWG - 1) / kSortWG;
-    const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
     const SortAxes<T, ND> ax = sort_axes<T, ND>(a, extent, scale, shift, b);
-    const T* __restrict__ xb = x + (a.Bx == 1 ? 0 : b) * a.N * 7;
-    const T* __restrict__ qb = q ? q + (a.Bq == 1 ? 0 : b) * a.N : nullptr;
-    const T* __restrict__ sb = s ? s + (a.Bs == 1 ? 0 : b) * a.N : nullptr;
     CicRec<T, ND>* __restrict__ rb = recs + b * rec_cap;
-    for (int64_t n = n0 + threadIdx.x; n < n1; n += kSortThreads) {
-        int pi[ND];
-        T pf[ND];
-        if (!sort_locate<T, ND>(a, ax, xb + n * 7, pi, pf)) continue;
-        int t0[3], t1[3];
-        sort_tile_range<ND>(a, g, pi, t0, t1);
-        CicRec<T, ND> r;
-        if (SCATTER) {
+    for (int64_t base = n0 + threadIdx.x; base < n1; base += (int64_t)kSortBatch * kSortThreads) {
+        if (base != n0 + threadIdx.x) fetch(base);
 #pragma unroll
-            for (int d = 0; d < ND; ++d) { r.i[d] = pi[d]; r.f[d] = pf[d]; }
-            T c = qb ? qb[n] : (T)1;
-            if (a.abs_charge) c = fabs(c);
-            if (sb) c = c * sb[n];
-            r.c = c;
-        }
-        for (int tx = t0[0]; tx <= t1[0]; ++tx)
-            for (int ty = t0[1]; ty <= t1[1]; ++ty)
-                for (int tz = t0[2]; tz <= t1[2]; ++tz) {
-                    const int tile = (tx * g.ntile[1] + ty) * g.ntile[2] + tz;
-                    const int pos = atomicAdd(&hist[tile], 1);
-                    if (SCATTER) {
-                        if (pos < rec_cap) rb[pos] = r;
+        for (int u = 0; u < kSortBatch; ++u) {
+            const int64_t n = base + (int64_t)u * kSortThreads;
+            if (n >= n1) break;
+            int pi[ND];
+            T pf[ND];
+            if (!sort_locate<T, ND>(a, ax, raw[u], pi, pf)) continue;
+            int t0[3], t1[3];
+            sort_tile_range<ND>(a, g, pi, t0, t1);
+            CicRec<T, ND> r;
+            if (SCATTER) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { r.i[d] = pi[d]; r.f[d] = pf[d]; }
+                r.c = craw[u];
+            }
+            for (int tx = t0[0]; tx <= t1[0]; ++tx)
+                for (int ty = t0[1]; ty <= t1[1]; ++ty)
+                    for (int tz = t0[2]; tz <= t1[2]; ++tz) {
+                        const int tile = (tx * g.ntile[1] + ty) * g.ntile[2] + tz;
+                        const int pos = atomicAdd(&hist[tile], 1);
+                        if (SCATTER) {
+                            if (pos < rec_cap) rb[pos] = r;
+                        }
                     }
-                }
+        }
     }
     if (!SCATTER) {
         __syncthreads();
@@ -665,7 +689,21 @@ __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileG
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);
     const int64_t b = blockIdx.y;
-    const int t = blockIdx.x;
+    // Workgroups are dispatched in blockIdx order: the tiles are visited from the middle of the grid outwards, so that the
+    // full tiles of a centred beam (thousands of records, a dozen dependent memory round trips) start in the first wave of
+    // workgroups and the nearly empty ones at the grid's edge fill in behind them.
+    int t;
+    {
+        int rem = blockIdx.x, tc[3];
+        for (int d = 2; d >= 0; --d) {
+            const int n = d < ND ? g.ntile[d] : 1;
+            const int k = rem % n;
+            rem /= n;
+            const int c = (n - 1) / 2;
+            tc[d] = (k & 1) ? c + (k + 1) / 2 : c - k / 2;
+        }
+        t = (tc[0] * (ND > 1 ? g.ntile[1] : 1) + (ND > 1 ? tc[1] : 0)) * (ND > 2 ? g.ntile[2] : 1) + (ND > 2 ? tc[2] : 0);
+    }
     const int beg = tile_start[b * (g.nt + 1) + t];
     int end = tile_start[b * (g.nt + 1) + t + 1];
     if (end > rec_cap) end = (int)rec_cap;

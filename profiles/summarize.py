@@ -22,7 +22,7 @@ rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.c
 with open(os.path.join(out, f"{rnd}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows[:25]:
+    for r in rows[:45]:
         name = r["Name"]
         if len(name) > 160:
             name = name[:157] + "..."

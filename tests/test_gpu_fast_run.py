@@ -59,12 +59,18 @@ def test_fast_run_is_bit_identical_and_follows_setting_changes(ca, dt):
     assert torch.equal(out2.particles, general_path(ca, seg, beam))
     seg.q2.misalignment[0] = 3e-4
     assert torch.equal(seg.track(beam).particles, general_path(ca, seg, beam))
-    # re-assignment (new tensor, new address): the epoch moves, the plan is rebuilt
-    old_plan = run.fast
+    # re-assignment (new tensor, new address): the epoch moves, the plan re-reads that element and patches its pointers
+    epoch = run.fast.epoch
     seg.cv.angle = torch.tensor(-2e-5, dtype=dt, device="cuda")
     out3 = seg.track(beam)
-    assert seg._plan()[0][1].fast is not old_plan
+    assert seg._plan()[0][1].fast.epoch != epoch and seg._plan()[0][1].fast.ok
     assert torch.equal(out3.particles, general_path(ca, seg, beam))
+    # a control loop: new tensors for several settings every step, old ones freed in between
+    for step in range(20):
+        seg.q1.k1 = torch.tensor(1.0 + step, dtype=dt, device="cuda")
+        seg.ch.angle = torch.tensor(1e-5 * step, dtype=dt, device="cuda")
+        seg.q2.misalignment = torch.tensor([1e-5 * step, -2e-5], dtype=dt, device="cuda")
+        assert torch.equal(seg.track(beam).particles, general_path(ca, seg, beam))
     # another beam energy / species: part of the device-side comparison
     beam2 = ca.ParticleBeam(beam.particles, torch.tensor(2.3e9, dtype=dt, device="cuda"), species=ca.Species("proton", dtype=dt, device="cuda"))
     assert torch.equal(seg.track(beam2).particles, general_path(ca, seg, beam2))
