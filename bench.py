@@ -342,7 +342,7 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1/C3/C4/C5 side timings (and the scaling legs)")

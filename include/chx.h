@@ -367,8 +367,8 @@ int chx_sc_beam_geometry(const void* x, const void* w, const void* grid_extent, 
                          int64_t Bl, int64_t N, const int32_t* bins, int dtype, void* half, void* cell, void* gamma, void* dt,
                          void* scale, void* extent, double* pot_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* A whole SpaceChargeKick.track in ONE call (space_charge_kick.py:477-586) for grids chx_sc_pruned_supported() accepts:
- * chx_moments -> chx_sc_geometry -> [side stream: chx_sc_igf_table, chx_sc_green_spectrum] -> zero + chx_cic_deposit
- * (sorted for N >= 65536) -> chx_sc_convolve -> chx_sc_gradient -> chx_sc_gather_kick, all intermediates in `workspace`
+ * chx_sc_beam_geometry -> [side stream: chx_sc_green_spectrum_fast] -> chx_cic_deposit_sorted_overwrite (N >= 65536; zero +
+ * chx_cic_deposit below) -> chx_sc_convolve -> chx_sc_gradient -> chx_sc_gather_kick, all intermediates in `workspace`
  * (chx_sc_kick_workspace_bytes). x_in[Bx][N][7], charge[Bq][N], survival[Bs][N], energy[B], length[B],
  * grid_extent[Bext][3] (in sigmas) -> x_out[B][N][7]. `side_stream` may be NULL (everything on `stream`); two events are
  * created and destroyed per call, nothing else is allocated. Saves ~20 foreign-function calls per kick: at the
