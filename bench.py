@@ -298,44 +298,66 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
         out = seg.track_elementwise(beam, fused=False)
         sharding.global_moments(out)
 
-    d = timed(torch, dist, strong, steps, warmup, world)
-    legs["c2_strong"] = {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_step": d / steps * 1e3,
-                         "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
-    # C3: the 4096 settings split over the ranks, beam replicated, no collective
-    B = 4096
-    b0, b1 = sharding.shard_range(B, rank, world)
-    k1 = torch.linspace(-30, 30, B, dtype=dtype, device=device)[b0:b1].contiguous()
-    seg3 = rc.ares_subcell(dtype, k1)
-    torch.manual_seed(99)
-    beam3 = ca.ParticleBeam.from_parameters(num_particles=100_000, dtype=dtype, device=device)
-    keep = {}
-    d = timed(torch, dist, lambda: keep.__setitem__("o", seg3.track(beam3)), 5, 2, world)
-    legs["c3_batch_shard"] = {"scaling": "strong", "settings_total": B, "settings_per_rank": b1 - b0, "ms_per_track": d / 5 * 1e3,
-                              "particle_element_steps_per_s": B * 100_000 * 13 * 5 / d, "collectives": "none"}
-    keep.clear()
-    torch.cuda.empty_cache()
-    # C4: particles split over the ranks; per kick one all-gather of 29 doubles and one all-reduce of the 8.4 MB grid
-    g = 128
-    kw = {"dtype": dtype, "device": device}
-    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
-    els = []
-    for i in range(10):
-        els += [ca.Drift(t(0.1)), ca.SpaceChargeKick(t(0.2), grid_shape=(g, g, g), **kw), ca.Drift(t(0.1)),
-                ca.Quadrupole(t(0.1), k1=t(4.2 if i % 2 == 0 else -4.2), **kw), ca.Drift(t(0.1))]
-    seg4 = ca.Segment(els)
-    torch.manual_seed(7 + rank)
-    beam4 = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=hi - lo, total_charge=t(1e-9 * (hi - lo) / N_PARTICLES),
-                                                 energy=t(2.5e8), radius_x=t(1e-3), radius_y=t(1e-3), radius_tau=t(1e-3),
-                                                 sigma_px=t(1e-6), sigma_py=t(1e-6), sigma_p=t(1e-6), **kw)
+    def guarded(name, fn):
+        """A leg that fails on this rank must not take the headline line down: the error is recorded; every rank reaches
+        the barrier below either way (a failure inside a collective would still hang the others until the process-group
+        timeout set in main())."""
+        try:
+            legs[name] = fn()
+        except Exception as exc:
+            legs[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.empty_cache()
 
-    def c4():
-        with sharding.particle_sharded():
-            seg4.track(beam4)
+    def leg_strong():
+        d = timed(torch, dist, strong, steps, warmup, world)
+        return {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_step": d / steps * 1e3,
+                "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
 
-    d = timed(torch, dist, c4, 3, 1, world)
-    legs["c4_particle_shard"] = {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_track": d / 3 * 1e3,
-                                 "particle_element_steps_per_s": N_PARTICLES * 50 * 3 / d,
-                                 "collectives": "per kick: all-gather 29 f64 per rank + all-reduce 8.4 MB grid (RCCL)"}
+    guarded("c2_strong", leg_strong)
+
+    def leg_c3():
+        # C3: the 4096 settings split over the ranks, beam replicated, no collective
+        B = 4096
+        b0, b1 = sharding.shard_range(B, rank, world)
+        k1 = torch.linspace(-30, 30, B, dtype=dtype, device=device)[b0:b1].contiguous()
+        seg3 = rc.ares_subcell(dtype, k1)
+        torch.manual_seed(99)
+        beam3 = ca.ParticleBeam.from_parameters(num_particles=100_000, dtype=dtype, device=device)
+        keep = {}
+        d = timed(torch, dist, lambda: keep.__setitem__("o", seg3.track(beam3)), 5, 2, world)
+        keep.clear()
+        return {"scaling": "strong", "settings_total": B, "settings_per_rank": b1 - b0, "ms_per_track": d / 5 * 1e3,
+                "particle_element_steps_per_s": B * 100_000 * 13 * 5 / d, "collectives": "none"}
+
+    guarded("c3_batch_shard", leg_c3)
+
+    def leg_c4():
+        # C4: particles split over the ranks; per kick one all-gather of 29 doubles and one all-reduce of the 8.4 MB grid
+        g = 128
+        kw = {"dtype": dtype, "device": device}
+        t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+        els = []
+        for i in range(10):
+            els += [ca.Drift(t(0.1)), ca.SpaceChargeKick(t(0.2), grid_shape=(g, g, g), **kw), ca.Drift(t(0.1)),
+                    ca.Quadrupole(t(0.1), k1=t(4.2 if i % 2 == 0 else -4.2), **kw), ca.Drift(t(0.1))]
+        seg4 = ca.Segment(els)
+        torch.manual_seed(7 + rank)
+        beam4 = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=hi - lo, total_charge=t(1e-9 * (hi - lo) / N_PARTICLES),
+                                                     energy=t(2.5e8), radius_x=t(1e-3), radius_y=t(1e-3), radius_tau=t(1e-3),
+                                                     sigma_px=t(1e-6), sigma_py=t(1e-6), sigma_p=t(1e-6), **kw)
+
+        def c4():
+            with sharding.particle_sharded():
+                seg4.track(beam4)
+
+        d = timed(torch, dist, c4, 3, 1, world)
+        return {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_track": d / 3 * 1e3,
+                "particle_element_steps_per_s": N_PARTICLES * 50 * 3 / d,
+                "collectives": "per kick: all-gather 29 f64 per rank + all-reduce 8.4 MB grid (RCCL)"}
+
+    guarded("c4_particle_shard", leg_c4)
     return legs
 
 
@@ -347,6 +369,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1/C3/C4/C5 side timings (and the scaling legs)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    # smoke test of the multi-rank code path on a ONE-GPU box: every rank on cuda:0, collectives over gloo (RCCL refuses two
+    # ranks on one device). Not a measurement.
+    ap.add_argument("--one-device-gloo", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.cpu_baseline_worker:
@@ -363,12 +388,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    if args.one_device_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
-        assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus
+        import datetime
+
+        # a rank that dies inside a collective must not park the others for the default 10 minutes
+        if args.one_device_gloo:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=240))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device), timeout=datetime.timedelta(seconds=240))
+            assert dist.get_backend() == "nccl"
+        assert dist.get_world_size() == args.gpus
 
     import cheetah_amd as ca
     from cheetah_amd import _ops, sharding
