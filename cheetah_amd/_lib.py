@@ -118,6 +118,8 @@ SIGNATURES = {
     "chx_sc_spectral_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_i64, c_int, c_void_p, c_void_p]),
     "chx_sc_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_sc_gather_kick_mapped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64,
+                                          c_i64, c_i32_p, c_int, c_void_p, c_i64, c_void_p, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_parameter_track": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
@@ -156,7 +158,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_sc_kick_workspace_bytes": (c_size_t, [c_i64, c_i64, c_i32_p, c_int]),
     "chx_sc_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64,
-                            c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+                            c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_i64]),
     "chx_kde_values": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_i64,
                                c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, c_int, c_void_p, c_void_p]),
     "chx_merge_moments": (c_int, [c_void_p, ctypes.c_int32, c_i64, c_void_p, c_void_p]),
@@ -181,7 +183,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 2:  # CHX_ABI_VERSION of include/chx.h
+        if handle.chx_abi_version() != 3:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib

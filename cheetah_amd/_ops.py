@@ -1276,8 +1276,10 @@ def sc_gradient(phi, cell, gamma, bins) -> torch.Tensor:
     return F
 
 
-def sc_kick(x, q, w, energy, length, grid_extent, mass_eV, B, N, bins, side_stream=None) -> torch.Tensor:
-    """One chx_sc_kick call: x (Bx,N,7), q (Bq,N), w (Bs,N), energy (B,), length (B,), grid_extent (Bext,3) -> (B,N,7)."""
+def sc_kick(x, q, w, energy, length, grid_extent, mass_eV, B, N, bins, side_stream=None, post_map_ptr=None) -> torch.Tensor:
+    """One chx_sc_kick call: x (Bx,N,7), q (Bq,N), w (Bs,N), energy (B,), length (B,), grid_extent (Bext,3) -> (B,N,7).
+    `post_map_ptr`: device address of a (7,7) map of the beam dtype applied to the kicked particles in the same pass (the
+    linear run that follows the kick in a Segment)."""
     lib = _lib.lib()
     b3 = _bins3(bins)
     dt = dtype_code(x.dtype)
@@ -1286,7 +1288,7 @@ def sc_kick(x, q, w, energy, length, grid_extent, mass_eV, B, N, bins, side_stre
     out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
     check(lib.chx_sc_kick(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, B, x.shape[0],
                           q.shape[0], w.shape[0], grid_extent.shape[0], N, b3, dt, ptr(out), ptr(ws), ws_bytes, stream_ptr(),
-                          side_stream.cuda_stream if side_stream is not None else None), "chx_sc_kick")
+                          side_stream.cuda_stream if side_stream is not None else None, post_map_ptr, 1), "chx_sc_kick")
     return out
 
 

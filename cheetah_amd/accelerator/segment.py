@@ -36,6 +36,7 @@ from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
 from .element import Element
+from .space_charge_kick import SpaceChargeKick
 
 
 def _any_requires_grad_py(*tensors) -> bool:
@@ -440,7 +441,10 @@ class Segment(Element):
             return incoming
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
-        for kind, item in self._plan():
+        plan = self._plan()
+        i, n_items = 0, len(plan)
+        while i < n_items:
+            kind, item = plan[i]
             if kind == "run":
                 new_particles = self._run_apply_fast(item, incoming)
                 if new_particles is None:
@@ -450,8 +454,46 @@ class Segment(Element):
                                         survival_probabilities=incoming.survival_probabilities,
                                         s=self._run_s(item, incoming.s), species=incoming.species)
             else:
+                if i + 1 < n_items and plan[i + 1][0] == "run" and isinstance(item, SpaceChargeKick):
+                    # [SpaceChargeKick, run of linear elements]: the run's map is applied inside the kick's particle kernel
+                    fused = self._kick_then_run(item, plan[i + 1][1], incoming)
+                    if fused is not None:
+                        incoming = fused
+                        i += 2
+                        continue
                 incoming = item._track_internal(incoming)
+            i += 1
         return incoming
+
+    def _kick_then_run(self, kick, run: _Run, incoming: ParticleBeam):
+        """One particle pass for a SpaceChargeKick and the run of linear elements behind it (`chx_run_map` refreshes the run's
+        stored map on the device, `chx_sc_kick` applies it to the kicked particles in registers): bit-identical to tracking
+        the two one after the other. None when either side does not qualify."""
+        p = incoming.particles
+        if p.dim() != 2 or not p.is_cuda:
+            return None
+        fr = run.fast
+        if fr is None or fr.dtype != p.dtype or fr.device != p.device:
+            fr = run.fast = _FastRun(run, p.dtype, p.device)
+        elif fr.epoch != Element._epoch:
+            fr.refresh()
+        e = incoming.energy
+        if not fr.ok or e.dim() != 0 or e.dtype != fr.dtype or e.device != fr.device:
+            return None
+        sp = incoming.species
+        if torch.is_grad_enabled() and (e.requires_grad or sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad
+                                        or _any_requires_grad(*fr.tensors)):
+            return None
+        R_addr = ctypes.c_void_p()
+        _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float,
+                                          fr.code, fr.state.data_ptr(), fr.state_bytes, ctypes.byref(R_addr), _ops.stream_ptr()),
+                   "chx_run_map")
+        out = kick._track_then_map(incoming, R_addr.value)
+        if out is None:
+            return None
+        return ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=self._run_s(run, incoming.s),
+                            species=incoming.species)
 
     def track_moments(self, incoming: ParticleBeam, exact: bool = True) -> ParameterBeam:
         """Track a `ParticleBeam` and return only the outgoing beam's moments as a `ParameterBeam` (mu, cov,

@@ -156,6 +156,34 @@ class SpaceChargeKick(Element):
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s,
                             species=incoming.species)
 
+    def _track_then_map(self, incoming: ParticleBeam, post_map_ptr: int):
+        """The kick followed by a linear map (device address of a (7,7) array of the beam dtype) in the SAME particle pass
+        (`chx_sc_kick` with `post_map`): what `Segment.track` uses when a run of linear elements follows the kick. Returns the
+        tracked particle tensor, or None when the one-call kick does not apply (vectorised beam, gradients, a grid that is not
+        a power of two, a particle-sharded beam) and the caller tracks kick and run separately."""
+        from .. import sharding
+
+        parts = incoming.particles
+        dtype, device = parts.dtype, parts.device
+        g = self.grid_shape
+        if parts.dim() != 2 or incoming.energy.dim() != 0 or incoming.particle_charges.dim() != 1 \
+                or incoming.survival_probabilities.dim() != 1 or self.effect_length.dim() != 0:
+            return None
+        if sharding.active_group() is not None or not _ops.sc_pruned_supported(g, dtype):
+            return None
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (
+                parts, incoming.particle_charges, incoming.survival_probabilities, incoming.energy, self.effect_length,
+                self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau)):
+            return None
+        N = parts.shape[0]
+        x = _ops.aligned(parts).reshape(1, N, 7)
+        out = _ops.sc_kick(x, incoming.particle_charges.to(dtype).reshape(1, N).contiguous(),
+                           incoming.survival_probabilities.to(dtype).reshape(1, N).contiguous(),
+                           incoming.energy.to(dtype).reshape(1), self.effect_length.to(dtype).reshape(1), self._grid_extent(dtype),
+                           incoming.species.mass_eV_float, 1, N, g, side_stream=self._side_stream(device),
+                           post_map_ptr=post_map_ptr)
+        return out.reshape(N, 7)
+
     def _track_particle_sharded(self, incoming, group, x, q, w, energy, L, out_shape, B, N) -> ParticleBeam:
         """The kick for a beam whose particles are spread over the ranks of `group` (sharding.particle_sharded): the same
         stages as `chx_sc_kick`, issued one by one so that the two exchanges fit in between — the beam moments (grid

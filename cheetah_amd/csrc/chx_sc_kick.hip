@@ -73,7 +73,8 @@ extern "C" size_t chx_sc_kick_workspace_bytes(int64_t B, int64_t N, const int32_
 extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* survival, const void* energy,
                            const void* length, const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq,
                            int64_t Bs, int64_t Bext, int64_t N, const int32_t* bins, int dtype, void* x_out,
-                           void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
+                           void* workspace, size_t workspace_bytes, void* stream, void* side_stream, const void* post_map,
+                           int64_t BR) {
     if (!x_in || !charge || !survival || !energy || !length || !grid_extent || !x_out || !workspace)
         return CHX_ERR_INVALID_ARG;
     if (B < 1 || N < 1 || !bins || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
@@ -142,5 +143,8 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     if (st != CHX_OK) return st;
     st = chx_sc_gradient(phi, cell, gamma, B, bins, 0, 0, dtype, force, main);
     if (st != CHX_OK) return st;
+    if (post_map)
+        return chx_sc_gather_kick_mapped(x_in, force, half, cell, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, post_map, BR,
+                                         x_out, main);
     return chx_sc_gather_kick(x_in, force, half, cell, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, x_out, main);
 }

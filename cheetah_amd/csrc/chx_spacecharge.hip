@@ -132,7 +132,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
     const T* __restrict__ x_in, const T* __restrict__ F, const T* __restrict__ half,
     const T* __restrict__ cell, const T* __restrict__ energy, const T* __restrict__ dt,
     double mass_eV, int64_t Bx, int64_t Be, int64_t N, int gx, int gy, int gz,
-    T* __restrict__ x_out) {
+    T* __restrict__ x_out, const T* __restrict__ post_map, int64_t BR) {
     constexpr int PPT = 1;
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
@@ -196,8 +196,25 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
                 s[3] += fy * dtb;
                 s[5] += fz * dtb;
                 from_si(rf, s, v);
+                if (post_map) {
+                    // the linear run that follows the kick, applied while the particle is still in registers: the same fma
+                    // chain as chx_apply_affine7 on the kicked coordinates ROUNDED TO T first, i.e. bit-identical to writing
+                    // the kicked beam and tracking it through the run in a second pass
+                    const T* __restrict__ R = post_map + ((BR == 1) ? 0 : b) * 49;
+                    T xk[7];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)v[j];
+                    for (int j = 0; j < 7; ++j) xk[j] = (T)v[j];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        T acc = R[i * 7] * xk[0];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) acc = fma(R[i * 7 + j], xk[j], acc);
+                        lds[p * 7 + i] = acc;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)v[j];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) lds[p * 7 + j] = (T)s[j];
@@ -437,7 +454,7 @@ template <int MODE>
 static int launch_particle(const void* x_in, const void* F, const void* half, const void* cell,
                            const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
                            int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
-                           void* stream) {
+                           void* stream, const void* post_map = nullptr, int64_t BR = 1) {
     if (!x_in || !x_out || !energy || B < 1 || N < 1 || B > 65535) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -448,11 +465,11 @@ static int launch_particle(const void* x_in, const void* F, const void* half, co
     if (dtype == CHX_F32)
         hipLaunchKernelGGL((sc_particle_kernel<float, MODE>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
                            (const float*)F, (const float*)half, (const float*)cell, (const float*)energy,
-                           (const float*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (float*)x_out);
+                           (const float*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (float*)x_out, (const float*)post_map, BR);
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL((sc_particle_kernel<double, MODE>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
                            (const double*)F, (const double*)half, (const double*)cell, (const double*)energy,
-                           (const double*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (double*)x_out);
+                           (const double*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (double*)x_out, (const double*)post_map, BR);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();
@@ -465,6 +482,14 @@ extern "C" int chx_sc_gather_kick(const void* x_in, const void* F, const void* h
                                   void* x_out, void* stream) {
     if (!F || !half || !cell || !dt || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
     return launch_particle<0>(x_in, F, half, cell, energy, dt, mass_eV, B, Bx, Be, N, bins, dtype, x_out, stream);
+}
+
+extern "C" int chx_sc_gather_kick_mapped(const void* x_in, const void* F, const void* half, const void* cell,
+                                         const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
+                                         int64_t Be, int64_t N, const int32_t* bins, int dtype, const void* post_map,
+                                         int64_t BR, void* x_out, void* stream) {
+    if (!F || !half || !cell || !dt || !bins_ok(bins) || !post_map || !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    return launch_particle<0>(x_in, F, half, cell, energy, dt, mass_eV, B, Bx, Be, N, bins, dtype, x_out, stream, post_map, BR);
 }
 
 extern "C" int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 2 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient */
+#define CHX_ABI_VERSION 3 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick */
 
 typedef enum chx_status {
     CHX_OK = 0,
@@ -358,6 +358,13 @@ int chx_sc_gather_kick(const void* x_in, const void* F, const void* half, const 
                        const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
                        int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
                        void* stream);
+/* chx_sc_gather_kick followed by chx_apply_affine7 with post_map[BR][7][7] (BR in {1, B}) in ONE pass: the linear run that
+ * follows a SpaceChargeKick inside a Segment (segment.py:545-574) is applied while the kicked particle is still in registers
+ * (the kicked coordinates are rounded to dtype first, then the apply kernel's fma chain: bit-identical to the two passes).
+ * chx_sc_kick takes the same optional map as its last arguments (NULL = kick only). */
+int chx_sc_gather_kick_mapped(const void* x_in, const void* F, const void* half, const void* cell, const void* energy,
+                              const void* dt, double mass_eV, int64_t B, int64_t Bx, int64_t Be, int64_t N, const int32_t* bins,
+                              int dtype, const void* post_map, int64_t BR, void* x_out, void* stream);
 /* chx_moments + chx_sc_geometry for the kick: only the three variances the grid needs (sigma_x, sigma_y, sigma_tau;
  * space_charge_kick.py:531-538) are accumulated (8 fp64 sums per lane instead of 29, same shifted one-pass formulas and
  * rounding), and the partial sums are finalised inside the geometry kernel: two launches. Outputs as chx_sc_geometry. */
@@ -375,9 +382,9 @@ int chx_sc_beam_geometry(const void* x, const void* w, const void* grid_extent, 
  * reference's default 32^3 grid the host, not the GPU, was the limit. */
 size_t chx_sc_kick_workspace_bytes(int64_t B, int64_t N, const int32_t* bins, int dtype);
 int chx_sc_kick(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
-                const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext,
-                int64_t N, const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes,
-                void* stream, void* side_stream);
+                const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
+                const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
+                void* side_stream, const void* post_map /*[BR][7][7] or NULL*/, int64_t BR);
 /* SI conversion on its own (particle_beam.py:1262-1346), used by to_xyz_pxpypz/from_xyz_pxpypz */
 int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B, int64_t Bx,
                       int64_t Be, int64_t N, int dtype, void* xp_out, void* stream);

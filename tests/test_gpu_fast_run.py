@@ -169,3 +169,76 @@ def test_c_abi_run_map_against_build_and_compose(ca):
     assert not torch.equal(R2, R1) and torch.equal(R2, two_call())
     assert lib.chx_run_map(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), 16, None, None) == -5
     assert lib.chx_run_map(karr, parr, 0, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), nbytes, None, None) == -1
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_kick_then_run_in_one_pass_is_bit_identical(ca, dt):
+    """[SpaceChargeKick, run of linear elements] inside a Segment: the run's map is applied in the kick's particle kernel
+    (`chx_sc_kick` with post_map). Must equal tracking the kick and the elements one after the other, bit for bit."""
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    torch.manual_seed(3)
+    beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=70_000, total_charge=t(1e-9), energy=t(2.5e8), radius_x=t(1e-3),
+                                                radius_y=t(1e-3), radius_tau=t(1e-4), sigma_px=t(1e-5), sigma_py=t(1e-5),
+                                                sigma_p=t(1e-5), **kw)
+    els = [ca.Drift(t(0.1), **kw), ca.SpaceChargeKick(t(0.2), grid_shape=(32, 32, 32), **kw), ca.Drift(t(0.1), **kw),
+           ca.Quadrupole(t(0.1), k1=t(4.2), **kw), ca.Drift(t(0.1), **kw), ca.SpaceChargeKick(t(0.2), grid_shape=(32, 32, 32), **kw),
+           ca.Marker(**kw), ca.Drift(t(0.3), **kw)]
+    seg = ca.Segment(els)
+    out = seg.track(beam)
+    plan = seg._plan()
+    assert [k for k, _ in plan] == ["run", "element", "run", "element", "run"]
+    assert all(item.fast is not None and item.fast.ok for k, item in plan[2::2] if k == "run")
+    # reference order: one element after the other through their public track methods, maps merged per run like Segment does
+    from cheetah_amd import _ops
+
+    b = beam
+    for kind, item in plan:
+        if kind == "run":
+            maps = [e.first_order_transfer_map(b.energy, b.species) for e in item.elements if e._chx_kind != _ops.KIND["identity"]]
+            tm = _ops.compose_maps(maps, (), dt, maps[0].device) if len(maps) > 1 else maps[0]
+            b = ca.ParticleBeam(_ops.apply_map(b.particles, tm), b.energy, particle_charges=b.particle_charges,
+                                survival_probabilities=b.survival_probabilities, species=b.species)
+        else:
+            b = item.track(b)
+    # two evaluations of a kick differ in the last bits (the order of the LDS atomics of the deposit is not fixed), so the
+    # end-to-end comparison is to rounding; the bit-exactness of the fused map is checked on a fixed field below
+    scale = b.particles.abs().amax(dim=0).clamp_min(1e-30)
+    assert float(((out.particles - b.particles).abs() / scale).max()) < (2e-6 if dt == torch.float32 else 1e-10)
+    assert float(out.s) == pytest.approx(float(seg.length), rel=1e-6)
+    # chx_sc_gather_kick_mapped == chx_sc_gather_kick followed by chx_apply_affine7, bit for bit (deterministic inputs)
+    from cheetah_amd import _lib
+
+    lib = _lib.lib()
+    g3 = (16, 16, 16)
+    N = 5000
+    x = (torch.randn(1, N, 7, dtype=dt, device="cuda") * 3e-4).contiguous()
+    x[..., 6] = 1
+    F = torch.randn(1, 16 * 16 * 16, 4, dtype=dt, device="cuda") * 1e3
+    half = torch.tensor([[1e-3, 1e-3, 1e-3]], dtype=dt, device="cuda")
+    cell = half * 2 / 16
+    energy = torch.tensor([2.5e8], dtype=dt, device="cuda")
+    dtk = torch.tensor([1e-9], dtype=dt, device="cuda")
+    R = (torch.eye(7, dtype=dt, device="cuda") + 0.05 * torch.randn(7, 7, dtype=dt, device="cuda")).reshape(1, 7, 7).contiguous()
+    R[0, 6] = 0
+    R[0, 6, 6] = 1
+    b3 = _ops._bins3(g3)
+    code = _ops.dtype_code(dt)
+    kicked, both, fused = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    _ops.check(lib.chx_sc_gather_kick(x.data_ptr(), F.data_ptr(), half.data_ptr(), cell.data_ptr(), energy.data_ptr(), dtk.data_ptr(),
+                                      510998.95069, 1, 1, 1, N, b3, code, kicked.data_ptr(), _ops.stream_ptr()), "gather")
+    _ops.check(lib.chx_apply_affine7(kicked.data_ptr(), R.data_ptr(), both.data_ptr(), 1, 1, 1, N, code, _ops.stream_ptr()), "apply")
+    _ops.check(lib.chx_sc_gather_kick_mapped(x.data_ptr(), F.data_ptr(), half.data_ptr(), cell.data_ptr(), energy.data_ptr(),
+                                             dtk.data_ptr(), 510998.95069, 1, 1, 1, N, b3, code, R.data_ptr(), 1, fused.data_ptr(),
+                                             _ops.stream_ptr()), "gather mapped")
+    assert torch.equal(fused, both) and not torch.equal(kicked, x)
+    # a setting of the fused run changed in place: picked up by the device-side validation inside the fused path as well
+    els[3].k1.fill_(-2.0)
+    out2 = seg.track(beam)
+    assert not torch.equal(out2.particles, out.particles)
+    b = beam
+    for e in els:
+        b = e.track(b)
+    # element by element (three rounded passes) vs merged (one): equal to rounding, relative to each coordinate's spread
+    scale = b.particles.abs().amax(dim=0).clamp_min(1e-30)
+    assert float(((out2.particles - b.particles).abs() / scale).max()) < (1e-4 if dt == torch.float32 else 1e-10)
