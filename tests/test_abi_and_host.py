@@ -193,3 +193,54 @@ def test_beam_factories_shapes_and_defaults():
     assert float(r2.max()) <= 1.0 + 1e-5
     sp = ca.Species("proton")
     assert sp.mass_eV_float == pytest.approx(938272089.43) and sp.num_elementary_charges_float == 1.0
+
+
+def test_persistent_run_plan_host_logic():
+    """`_FastRun` (the host half of chx_run_track): eligibility, the process-wide epoch, incremental refresh that patches only the
+    pointers of re-assigned settings and keeps the device state. No kernel is launched here."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+    from cheetah_amd.accelerator.element import Element
+    from cheetah_amd.accelerator.segment import _FastRun
+
+    t = torch.tensor
+    q1 = ca.Quadrupole(t(0.2), k1=t(4.2), name="q1")
+    seg = ca.Segment([ca.Marker(), ca.Drift(t(0.5)), q1, ca.HorizontalCorrector(t(0.02), angle=t(1e-4), name="ch"), ca.BPM()])
+    run = seg._plan()[0][1]
+    fr = _FastRun(run, torch.float32, torch.device("cpu"))
+    assert fr.ok and fr.E == 3                       # Marker and BPM are identity maps: left out
+    assert list(fr.kinds) == [_ops.KIND["drift"], _ops.KIND["quadrupole"], _ops.KIND["hcor"]]
+    state, ptrs = fr.state, fr.ptrs
+    assert fr.ptrs[1 * _ops.MAX_PARAMS + 1] == q1.k1.data_ptr()
+    # an in-place edit moves nothing on the host
+    epoch = Element._epoch
+    q1.k1.add_(1.0)
+    assert Element._epoch == epoch and fr.epoch == epoch
+    # a re-assignment moves the epoch; refresh patches that one pointer and keeps arrays and state
+    new_k1 = t(-3.0)
+    q1.k1 = new_k1
+    assert Element._epoch > epoch
+    fr.refresh()
+    assert fr.ok and fr.state is state and fr.ptrs is ptrs and fr.ptrs[1 * _ops.MAX_PARAMS + 1] == new_k1.data_ptr()
+    assert any(x is new_k1 for x in fr.tensors)
+    # vectorised or trainable settings, other dtypes: not eligible, and eligible again afterwards
+    q1.k1 = t([1.0, 2.0])
+    fr.refresh()
+    assert not fr.ok
+    q1.k1 = t(1.0)
+    fr.refresh()
+    assert fr.ok
+    q2 = ca.Quadrupole(t(0.2), k1=torch.nn.Parameter(t(1.0)))
+    assert not _FastRun(ca.Segment([q2])._plan()[0][1], torch.float32, torch.device("cpu")).ok
+    assert not _FastRun(run, torch.float64, torch.device("cpu")).ok
+    # a cavity's skippability depends on a tensor VALUE: a run containing one is never planned persistently
+    cav = ca.Cavity(t(1.0), voltage=t(0.0), phase=t(0.0), frequency=t(1.3e9))
+    assert not _FastRun(ca.Segment([ca.Drift(t(1.0)), cav])._plan()[0][1], torch.float32, torch.device("cpu")).ok
+    # editing the element list moves the epoch too
+    e0 = Element._epoch
+    seg.elements.append(ca.Drift(t(0.1)))
+    assert Element._epoch > e0 and len(seg._plan()[0][1].elements) == 6
+    # .to() replaces buffers behind __setattr__'s back: the elements are touched all the same
+    e1, rev = Element._epoch, q1.__dict__["_revision"]
+    seg.double()
+    assert Element._epoch > e1 and q1.__dict__["_revision"] > rev and q1.k1.dtype == torch.float64
