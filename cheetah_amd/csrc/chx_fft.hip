@@ -12,6 +12,7 @@
 //     (g+1)^3 reals (8.6 MB instead of a 67 MB complex array); the spectral multiply looks it up by |k|.
 // Line lengths n = 2g must be powers of two (64 ... 1024); other grids use the hipFFT path (chx_sc_fft_exec).
 #include "chx_common.h"
+#include "chx_fft_reg.h"
 #include "chx_sc_math.h"
 
 namespace {
@@ -153,61 +154,62 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_kernel(const T* __restric
 // ---- register-resident variant for n = 16 * M, M in {2, 4, 8, 16} ------------------------------------------------
 // Cooley-Tukey split n = 16 x M: a thread runs a whole 16-point FFT in registers on the points (c + M j1), multiplies
 // by W_n^(c k1), and after one exchange through LDS a thread runs the M-point FFT over c for its k1 and stores
-// X[k1 + 16 k2]. 256 threads = 16 lines x 16 columns: one barrier instead of log2(n), ~3x fewer instructions than the
-// LDS radix-2 kernel above (which stays for n = 512, 1024).
-template <typename T, int R>
-__device__ __forceinline__ void fft_reg(cplx<T> (&x)[R], int inverse) {
-    // bit-reversal permutation (compile-time indices after unrolling)
-    constexpr int LOG = (R == 2) ? 1 : (R == 4) ? 2 : (R == 8) ? 3 : 4;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        int r = 0;
-#pragma unroll
-        for (int b = 0; b < LOG; ++b) r |= ((i >> b) & 1) << (LOG - 1 - b);
-        if (r > i) { const cplx<T> t = x[i]; x[i] = x[r]; x[r] = t; }
-    }
-    // cos / sin of 2 pi k / 16, k = 0..7
-    constexpr double C16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
-                               0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
-    constexpr double S16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
-                               1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
-#pragma unroll
-    for (int s = 0; s < LOG; ++s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int bf = 0; bf < R / 2; ++bf) {
-            const int j = bf & (half - 1);
-            const int i0 = ((bf >> s) << (s + 1)) + j, i1 = i0 + half;
-            const int tk = (j * (R / 2 / half)) * (16 / R);  // index into the 16-point table
-            const T wr = (T)C16[tk];
-            const T wi = inverse ? (T)S16[tk] : (T)(-S16[tk]);
-            cplx<T> t;
-            t.re = x[i1].re * wr - x[i1].im * wi;
-            t.im = x[i1].re * wi + x[i1].im * wr;
-            const cplx<T> a = x[i0];
-            x[i0].re = a.re + t.re; x[i0].im = a.im + t.im;
-            x[i1].re = a.re - t.re; x[i1].im = a.im - t.im;
-        }
+// X[k1 + 16 k2]. 256 threads = 16 lines x 16 columns: one barrier instead of log2(n); the butterflies are the packed
+// radix-4 ones of chx_fft_reg.h (the LDS radix-2 kernel above stays for n = 512, 1024).
+//   ZP ("zero padded"): exactly the first n / 2 input points exist — the loads of the upper half and the first butterfly
+//                       layer on it are removed at compile time; otherwise complex / real inputs have all n points
+//   KH ("keep half"):   exactly the first n / 2 output points are kept — the stores (and, by dead-code elimination, the
+//                       arithmetic) of the upper half are removed at compile time
+// Lines of a tile beyond L are computed on the tile's first line and not stored: no load is predicated on it.
+using chx_fft::cmul;
+using chx_fft::cmul_conj;
+using chx_fft::fft16;
+using chx_fft::fft_small;
+
+template <typename T, int M>
+struct RegTile {
+    static constexpr int n = 16 * M;
+    static constexpr int LP = kTL + 1;           // line pitch
+    static constexpr int KP = M * LP + 1;        // pitch between k1 slabs (odd: spreads the banks)
+    static constexpr size_t shmem = ((size_t)16 * KP + n) * sizeof(vec2<T>);
+};
+
+template <typename T, int M>
+__device__ __forceinline__ void fill_twiddles(vec2<T>* tw, bool inverse) {
+    for (int k = threadIdx.x; k < 16 * M; k += CHX_BLOCK) {
+        T s, c;
+        sincos_2pi<T>(k, 16 * M, s, c);
+        tw[k] = vec2<T>{c, inverse ? s : -s};
     }
 }
 
-template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M>
+// 16-point transforms of x, twiddle W_n^(c k1), into the exchange buffer
+template <typename T, int M, bool INV, bool ZP>
+__device__ __forceinline__ void pass1_to_lds(vec2<T> (&x)[16], vec2<T>* xch, const vec2<T>* tw, int c, int line) {
+    using RT = RegTile<T, M>;
+    fft16<T, INV, ZP>(x);
+    xch[c * RT::LP + line] = x[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) xch[k1 * RT::KP + c * RT::LP + line] = cmul(x[k1], tw[(c * k1) & (RT::n - 1)]);
+}
+
+template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
 __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __restrict__ in, T* __restrict__ out, int n_valid,
                                                                  int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                                                                 LineLayout lo, int inverse) {
-    constexpr int n = 16 * M;
-    constexpr int LP = kTL + 1;                 // line pitch
-    constexpr int KP = M * LP + 1;              // pitch between k1 slabs (odd: spreads the banks)
+                                                                 LineLayout lo) {
+    using RT = RegTile<T, M>;
+    constexpr int n = RT::n;
+    constexpr bool kCplxIn = LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cplx<T>* xch = reinterpret_cast<cplx<T>*>(smem_raw);  // [k1][c][line], 16 * KP elements
-    cplx<T>* tw = xch + 16 * KP;                           // exp(-+2 pi i k / n), n elements
+    vec2<T>* xch = reinterpret_cast<vec2<T>*>(smem_raw);  // [k1][c][line], 16 * KP elements
+    vec2<T>* tw = xch + 16 * RT::KP;                       // exp(-+2 pi i k / n), n elements
     __shared__ int64_t in_base[kTL], out_base[kTL];
 
     const int tid = threadIdx.x;
     const int64_t l0 = (int64_t)blockIdx.x * kTL;
     const int nl = (int)((L - l0 < kTL) ? (L - l0) : kTL);
     const int64_t b = blockIdx.y;
-    const T* inb = in + b * li.batch_stride * ((LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN) ? 2 : 1);
+    const T* inb = in + b * li.batch_stride * (kCplxIn ? 2 : 1);
     T* outb = out + b * lo.batch_stride * ((STOREM == STORE_COMPLEX) ? 2 : 1);
     if (tid < kTL) {
         const int64_t l = l0 + (tid < nl ? tid : 0);
@@ -215,225 +217,182 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
         in_base[tid] = outer * li.outer_stride + inner * li.inner_stride;
         out_base[tid] = outer * lo.outer_stride + inner * lo.inner_stride;
     }
-    for (int k = tid; k < n; k += CHX_BLOCK) {
-        T s, c;
-        sincos_2pi<T>(k, n, s, c);
-        tw[k].re = c;
-        tw[k].im = inverse ? s : -s;
-    }
+    fill_twiddles<T, M>(tw, INV);
     __syncthreads();
     const int line = POINT_FAST ? (tid >> 4) : (tid & 15);
     const int c = POINT_FAST ? (tid & 15) : (tid >> 4);
     // ---- pass 1: 16-point FFTs over j1 for column c (< M), then the twiddle W_n^(c k1) --------------------------
     if (c < M) {
-        cplx<T> x[16];
-        const bool live = line < nl;
+        vec2<T> x[16];
         const int64_t base = in_base[line];
+        const vec2<T>* qc = reinterpret_cast<const vec2<T>*>(inb) + base;
+        const T* qr = inb + base;
 #pragma unroll
         for (int j1 = 0; j1 < 16; ++j1) {
             const int p = c + M * j1;
-            x[j1].re = (T)0;
-            x[j1].im = (T)0;
-            if (live) {
-                if (LOADM == LOAD_COMPLEX) {
-                    if (p < n_valid) x[j1] = reinterpret_cast<const cplx<T>*>(inb)[base + (int64_t)p * li.point_stride];
-                } else if (LOADM == LOAD_REAL) {
-                    if (p < n_valid) x[j1].re = inb[base + (int64_t)p * li.point_stride];
-                } else if (LOADM == LOAD_HERMITIAN) {
-                    const int ps = (p <= n / 2) ? p : n - p;
-                    x[j1] = reinterpret_cast<const cplx<T>*>(inb)[base + (int64_t)ps * li.point_stride];
-                    if (p > n / 2) x[j1].im = -x[j1].im;
-                } else {
-                    const int ps = (p <= n / 2) ? p : n - p;
-                    x[j1].re = inb[base + (int64_t)ps * li.point_stride];
-                }
+            x[j1] = vec2<T>{(T)0, (T)0};
+            if (LOADM == LOAD_COMPLEX) {
+                if (!ZP || j1 < 8) x[j1] = qc[(int64_t)p * li.point_stride];
+            } else if (LOADM == LOAD_REAL) {
+                if (!ZP || j1 < 8) x[j1].x = qr[(int64_t)p * li.point_stride];
+            } else if (LOADM == LOAD_HERMITIAN) {   // half spectrum 0..n/2 given: X[n-k] = conj X[k]
+                const bool lower = j1 < 8 || (j1 == 8 && c == 0);
+                x[j1] = qc[(int64_t)(lower ? p : n - p) * li.point_stride];
+                if (!lower) x[j1].y = -x[j1].y;
+            } else {                                // LOAD_EVEN_REAL: x[n-p] = x[p], values 0..n/2 given
+                const bool lower = j1 < 8 || (j1 == 8 && c == 0);
+                x[j1].x = qr[(int64_t)(lower ? p : n - p) * li.point_stride];
             }
         }
-        fft_reg<T, 16>(x, inverse);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) {
-            const cplx<T> w = tw[(c * k1) & (n - 1)];
-            cplx<T> y;
-            y.re = x[k1].re * w.re - x[k1].im * w.im;
-            y.im = x[k1].re * w.im + x[k1].im * w.re;
-            xch[k1 * KP + c * LP + line] = y;
-        }
+        pass1_to_lds<T, M, INV, ZP>(x, xch, tw, c, line);
     }
     __syncthreads();
     // ---- pass 2: M-point FFT over c for k1 = c (16 of them), output index k1 + 16 k2 ----------------------------
     {
         const int k1 = c;
-        cplx<T> y[M];
+        vec2<T> y[M];
 #pragma unroll
-        for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * KP + j2 * LP + line];
-        fft_reg<T, M>(y, inverse);
+        for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * RT::KP + j2 * RT::LP + line];
+        fft_small<T, M, INV>(y);
         if (line < nl) {
             const int64_t base = out_base[line];
 #pragma unroll
             for (int k2 = 0; k2 < M; ++k2) {
                 const int p = k1 + 16 * k2;
-                if (p < n_keep) {
-                    if (STOREM == STORE_COMPLEX) {
-                        reinterpret_cast<cplx<T>*>(outb)[base + (int64_t)p * lo.point_stride] = y[k2];
-                    } else {
-                        outb[base + (int64_t)p * lo.point_stride] = y[k2].re;
-                    }
+                if (KH ? (k2 < M / 2) : (p < n_keep)) {
+                    if (STOREM == STORE_COMPLEX) reinterpret_cast<vec2<T>*>(outb)[base + (int64_t)p * lo.point_stride] = y[k2];
+                    else outb[base + (int64_t)p * lo.point_stride] = y[k2].x;
                 }
             }
         }
     }
 }
 
-template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M>
+template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
 int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                     LineLayout lo, int inverse, int64_t B, hipStream_t s) {
+                     LineLayout lo, int64_t B, hipStream_t s) {
     dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
-    constexpr size_t shmem = ((size_t)16 * (M * (kTL + 1) + 1) + 16 * M) * sizeof(cplx<T>);
-    auto kern = fft_lines_reg_kernel<T, LOADM, STOREM, POINT_FAST, M>;
+    constexpr size_t shmem = RegTile<T, M>::shmem;
+    auto kern = fft_lines_reg_kernel<T, LOADM, STOREM, POINT_FAST, M, INV, ZP, KH>;
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
             hipSuccess)
             return CHX_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n_valid, n_keep, L, inner_count, li, lo,
-                       inverse);
+    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n_valid, n_keep, L, inner_count, li, lo);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
 
-// ---- x pass of the convolution, fused: forward FFT -> multiply by the Green spectrum -> inverse FFT, in place -------------
-// The x lines of the half-transformed charge (x < g valid, implicit zeros above) are transformed, multiplied by the real,
-// even Green spectrum and transformed back without leaving the CU: the [2g][2g][g+1] complex array C of the three-kernel
-// form (forward x, multiply, inverse x: 34 MB written + 68 MB read-modify-written + 34 MB read at g = 128) never exists.
+// ---- middle pass of the convolution, fused: forward FFT -> multiply by the Green spectrum -> inverse FFT, in place ---------
+// The z lines of the twice-transformed charge data[kx <= gx][ky < 2 gy][z < gz] (z >= gz: implicit zeros) are transformed,
+// multiplied by the real, even Green spectrum and transformed back without leaving the CU: the full [gx+1][2gy][2gz] complex
+// spectrum of the three-kernel form (forward, multiply, inverse) never exists. Line l = kx * ny + ky is contiguous;
+// consecutive lanes walk along it, so every access is a whole 128-byte (M = 16) run.
 // The inverse runs the forward factorisation backwards — inverse M-point FFTs over k2 in the thread that holds
 // X[k1 + 16 k2], conjugate twiddle, one LDS exchange, inverse 16-point FFTs — so no re-ordering pass is needed:
 //   X[k1 + 16 k2] = sum_c W_M^(c k2) W_n^(c k1) sum_j1 x[c + M j1] W_16^(j1 k1)
 //   x[c + M j1]   = sum_k1 W_16^(-j1 k1) W_n^(-c k1) sum_k2 X[k1 + 16 k2] W_M^(-c k2)
 template <typename T, int M>
-__global__ __launch_bounds__(CHX_BLOCK) void fft_x_fused_kernel(T* __restrict__ data, const T* __restrict__ gh,
-                                                               const double* __restrict__ scale, int n_valid, int64_t L,
-                                                               int ny, int nzc, int64_t point_stride, int64_t batch_stride) {
-    constexpr int n = 16 * M;
-    constexpr int LP = kTL + 1;
-    constexpr int KP = M * LP + 1;
+__global__ __launch_bounds__(CHX_BLOCK) void fft_z_fused_kernel(T* __restrict__ data, const T* __restrict__ gh,
+                                                               const double* __restrict__ scale, int64_t L, int ny, int gx) {
+    using RT = RegTile<T, M>;
+    constexpr int n = RT::n, gz = n / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cplx<T>* xch = reinterpret_cast<cplx<T>*>(smem_raw);  // [k1][c][line]
-    cplx<T>* tw = xch + 16 * KP;                           // exp(-2 pi i k / n)
-    __shared__ int64_t g_base[kTL];
+    vec2<T>* xch = reinterpret_cast<vec2<T>*>(smem_raw);  // [k1][c][line]
+    vec2<T>* tw = xch + 16 * RT::KP;                       // exp(-2 pi i k / n)
+    __shared__ int g_base[kTL];
 
     const int tid = threadIdx.x;
     const int64_t l0 = (int64_t)blockIdx.x * kTL;
     const int nl = (int)((L - l0 < kTL) ? (L - l0) : kTL);
     const int64_t b = blockIdx.y;
-    T* db = data + 2 * b * batch_stride;
-    const int gx1 = n / 2 + 1, gy1 = ny / 2 + 1;
-    const T* gb = gh + b * (int64_t)gx1 * gy1 * nzc;
+    const int gy1 = ny / 2 + 1;
+    vec2<T>* db = reinterpret_cast<vec2<T>*>(data) + b * L * gz;
+    const T* gb = gh + b * (int64_t)(gx + 1) * gy1 * (gz + 1);
     const T sc = (T)scale[b];
     if (tid < kTL) {
-        const int64_t l = l0 + (tid < nl ? tid : 0);     // l = ky * nzc + kz
-        const int ky = (int)(l / nzc), kz = (int)(l - (int64_t)ky * nzc);
-        const int syk = (ky <= ny / 2) ? ky : ny - ky;
-        g_base[tid] = (int64_t)syk * nzc + kz;
+        const int64_t l = l0 + (tid < nl ? tid : 0);        // l = kx * ny + ky -> Ghat[kx][|ky|][.]
+        const int kx = (int)(l / ny), ky = (int)(l - (int64_t)kx * ny);
+        g_base[tid] = (kx * gy1 + ((ky <= ny / 2) ? ky : ny - ky)) * (gz + 1);
     }
-    for (int k = tid; k < n; k += CHX_BLOCK) {
-        T sn, cs;
-        sincos_2pi<T>(k, n, sn, cs);
-        tw[k].re = cs;
-        tw[k].im = -sn;
-    }
+    fill_twiddles<T, M>(tw, false);
     __syncthreads();
-    const int line = tid & 15, c = tid >> 4;
+    const int line = tid >> 4, c = tid & 15;
     const bool live = line < nl;
-    const int64_t base = l0 + line;                       // element (complex) offset of point 0 of this line
-    // ---- forward, pass 1
+    vec2<T>* q = db + (l0 + (live ? line : 0)) * gz + c;    // point c of this line
+    // ---- forward, pass 1 (points c + M j1, j1 < 8 exist)
     if (c < M) {
-        cplx<T> x[16];
+        vec2<T> x[16];
 #pragma unroll
-        for (int j1 = 0; j1 < 16; ++j1) {
-            const int p = c + M * j1;
-            x[j1].re = (T)0;
-            x[j1].im = (T)0;
-            if (live && p < n_valid) x[j1] = reinterpret_cast<const cplx<T>*>(db)[base + (int64_t)p * point_stride];
-        }
-        fft_reg<T, 16>(x, 0);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) {
-            const cplx<T> w = tw[(c * k1) & (n - 1)];
-            cplx<T> y;
-            y.re = x[k1].re * w.re - x[k1].im * w.im;
-            y.im = x[k1].re * w.im + x[k1].im * w.re;
-            xch[k1 * KP + c * LP + line] = y;
-        }
+        for (int j1 = 0; j1 < 16; ++j1) x[j1] = j1 < 8 ? q[M * j1] : vec2<T>{(T)0, (T)0};
+        pass1_to_lds<T, M, false, true>(x, xch, tw, c, line);
     }
     __syncthreads();
     // ---- forward pass 2, multiply, inverse pass 1 (all in the registers of the thread that owns k1)
     {
         const int k1 = c;
-        cplx<T> y[M];
+        vec2<T> y[M];
 #pragma unroll
-        for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * KP + j2 * LP + line];
-        fft_reg<T, M>(y, 0);
-        const int64_t gl = g_base[line];
+        for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * RT::KP + j2 * RT::LP + line];
+        fft_small<T, M, false>(y);
+        const T* gl = gb + g_base[line];
 #pragma unroll
         for (int k2 = 0; k2 < M; ++k2) {
-            const int p = k1 + 16 * k2;
-            const int sxk = (p <= n / 2) ? p : n - p;
-            const T g = live ? gb[(int64_t)sxk * gy1 * nzc + gl] * sc : (T)0;
-            y[k2].re *= g;
-            y[k2].im *= g;
+            const int p = k1 + 16 * k2;                     // p <= n/2  <=>  k2 < M/2 or (k2 == M/2 and k1 == 0)
+            const int sk = (k2 < M / 2 || (k2 == M / 2 && k1 == 0)) ? p : n - p;
+            const T g = gl[sk] * sc;
+            y[k2] *= vec2<T>{g, g};
         }
-        fft_reg<T, M>(y, 1);
+        fft_small<T, M, true>(y);
+        xch[k1 * RT::KP + line] = y[0];
 #pragma unroll
-        for (int cc = 0; cc < M; ++cc) {
-            const cplx<T> w = tw[(cc * k1) & (n - 1)];   // conjugate twiddle W_n^(-c k1)
-            cplx<T> z;
-            z.re = y[cc].re * w.re + y[cc].im * w.im;
-            z.im = y[cc].im * w.re - y[cc].re * w.im;
-            xch[k1 * KP + cc * LP + line] = z;            // this thread's own slab: nobody else reads or writes it
-        }
+        for (int cc = 1; cc < M; ++cc)                       // conjugate twiddle W_n^(-c k1); this thread's own slab
+            xch[k1 * RT::KP + cc * RT::LP + line] = cmul_conj(y[cc], tw[(cc * k1) & (n - 1)]);
     }
     __syncthreads();
-    // ---- inverse pass 2: 16-point inverse FFTs over k1, outputs x[c + M j1] for the points that are kept
+    // ---- inverse pass 2: 16-point inverse FFTs over k1, outputs x[c + M j1], j1 < 8 kept
     if (c < M) {
-        cplx<T> x[16];
+        vec2<T> x[16];
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) x[k1] = xch[k1 * KP + c * LP + line];
-        fft_reg<T, 16>(x, 1);
+        for (int k1 = 0; k1 < 16; ++k1) x[k1] = xch[k1 * RT::KP + c * RT::LP + line];
+        fft16<T, true>(x);
         if (live) {
 #pragma unroll
-            for (int j1 = 0; j1 < 16; ++j1) {
-                const int p = c + M * j1;
-                if (p < n_valid) reinterpret_cast<cplx<T>*>(db)[base + (int64_t)p * point_stride] = x[j1];
-            }
+            for (int j1 = 0; j1 < 8; ++j1) q[M * j1] = x[j1];
         }
     }
 }
 
+// z lines of data[kx <= gx][ky < ny][z < gz] (complex), Green spectrum gh[(gx+1)][(gy+1)][(gz+1)]
 template <typename T, int M>
-int launch_x_fused(void* data, const void* gh, const double* scale, int n_valid, int64_t L, int ny, int nzc, int64_t point_stride,
-                   int64_t batch_stride, int64_t B, hipStream_t s) {
+int launch_z_fused(void* data, const void* gh, const double* scale, int gx, int gy, int64_t B, hipStream_t s) {
+    const int ny = 2 * gy;
+    const int64_t L = (int64_t)(gx + 1) * ny;
     dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
-    constexpr size_t shmem = ((size_t)16 * (M * (kTL + 1) + 1) + 16 * M) * sizeof(cplx<T>);
-    auto kern = fft_x_fused_kernel<T, M>;
+    constexpr size_t shmem = RegTile<T, M>::shmem;
+    auto kern = fft_z_fused_kernel<T, M>;
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
             hipSuccess)
             return CHX_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (T*)data, (const T*)gh, scale, n_valid, L, ny, nzc, point_stride,
-                       batch_stride);
+    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (T*)data, (const T*)gh, scale, L, ny, gx);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
 
-template <typename T, int LOADM, int STOREM, bool POINT_FAST>
+// ZP / KH are promises of the call site about n_valid / n_keep (checked here)
+template <typename T, int LOADM, int STOREM, bool POINT_FAST, bool INV, bool ZP = false, bool KH = false>
 int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                 LineLayout lo, int inverse, int64_t B, hipStream_t s) {
+                 LineLayout lo, int64_t B, hipStream_t s) {
+    if ((ZP && 2 * n_valid != n) || (KH && 2 * n_keep != n)) return CHX_ERR_INVALID_ARG;
+    if ((LOADM == LOAD_COMPLEX || LOADM == LOAD_REAL) && !ZP && n_valid != n) return CHX_ERR_INVALID_ARG;
     switch (n) {
-        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
-        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
-        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
-        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16>(in, out, n_valid, n_keep, L, inner_count, li, lo, inverse, B, s);
+        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
+        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
+        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
+        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
         default: break;
     }
     int log2n = 0;
@@ -447,7 +406,7 @@ int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int6
     }
     dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
     hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n, log2n, n_valid, n_keep, L, inner_count,
-                       li, lo, inverse);
+                       li, lo, INV ? 1 : 0);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -598,22 +557,22 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_compact_far_kernel(const double
     }
 }
 
-// rho_hat[b][kx][ky][kz] *= Ghat[b][min(kx, nx-kx)][min(ky, ny-ky)][kz] * scale[b]
+// rho_hat[b][kx <= gx][ky][kz] *= Ghat[b][kx][min(ky, ny-ky)][min(kz, nz-kz)] * scale[b]
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void spectral_mul_sym_kernel(T* __restrict__ a, const T* __restrict__ gh,
-                                                                    const double* __restrict__ scale, int nx, int ny, int nzc) {
+                                                                    const double* __restrict__ scale, int nxc, int ny, int nz) {
     const int64_t b = blockIdx.y;
-    const int64_t ntot = (int64_t)nx * ny * nzc;
+    const int64_t ntot = (int64_t)nxc * ny * nz;
     const T sc = (T)scale[b];
     T* ab = a + b * ntot * 2;
-    const int gx1 = nx / 2 + 1, gy1 = ny / 2 + 1;
-    const T* gb = gh + b * (int64_t)gx1 * gy1 * nzc;
+    const int gy1 = ny / 2 + 1, gz1 = nz / 2 + 1;
+    const T* gb = gh + b * (int64_t)nxc * gy1 * gz1;
     for (int64_t idx = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; idx < ntot; idx += (int64_t)gridDim.x * CHX_BLOCK) {
-        const int kz = (int)(idx % nzc);
-        const int ky = (int)((idx / nzc) % ny);
-        const int kx = (int)(idx / ((int64_t)nzc * ny));
-        const int sxk = (kx <= nx / 2) ? kx : nx - kx, syk = (ky <= ny / 2) ? ky : ny - ky;
-        const T g = gb[((int64_t)sxk * gy1 + syk) * nzc + kz] * sc;
+        const int kz = (int)(idx % nz);
+        const int ky = (int)((idx / nz) % ny);
+        const int kx = (int)(idx / ((int64_t)nz * ny));
+        const int syk = (ky <= ny / 2) ? ky : ny - ky, szk = (kz <= nz / 2) ? kz : nz - kz;
+        const T g = gb[((int64_t)kx * gy1 + syk) * gz1 + szk] * sc;
         ab[2 * idx] *= g;
         ab[2 * idx + 1] *= g;
     }
@@ -654,17 +613,17 @@ static int green_spectrum_impl(const double* table, const T* cell, const T* gamm
     const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
     // z: lines (x, y), points contiguous; even extension in, real out (kz <= gz)           Gc -> H
     LineLayout lz{1, sy, sx, n1};
-    int st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, true>(Gc, H, 2 * gz, gz + 1, gz + 1, (int64_t)(gx + 1) * (gy + 1), gy + 1,
-                                                               lz, lz, 0, B, s);
+    int st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, true, false>(Gc, H, 2 * gz, gz + 1, gz + 1,
+                                                                      (int64_t)(gx + 1) * (gy + 1), gy + 1, lz, lz, B, s);
     if (st != CHX_OK) return st;
     // y: lines (x, kz), point stride sy                                                    H -> Gc
     LineLayout ly{sy, 1, sx, n1};
-    st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false>(H, Gc, 2 * gy, gy + 1, gy + 1, (int64_t)(gx + 1) * (gz + 1), gz + 1, ly,
-                                                            ly, 0, B, s);
+    st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false, false>(H, Gc, 2 * gy, gy + 1, gy + 1,
+                                                                   (int64_t)(gx + 1) * (gz + 1), gz + 1, ly, ly, B, s);
     if (st != CHX_OK) return st;
     // x: lines (ky, kz) = one contiguous index, point stride sx                            Gc -> Ghat
     LineLayout lx{sx, 1, 0, n1};
-    return launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false>(Gc, Ghat, 2 * gx, gx + 1, gx + 1, sx, sx, lx, lx, 0, B, s);
+    return launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false, false>(Gc, Ghat, 2 * gx, gx + 1, gx + 1, sx, sx, lx, lx, B, s);
 }
 
 // Real, even spectrum of the integrated Green function on the doubled grid, stored on (gx+1)(gy+1)(gz+1) points.
@@ -708,66 +667,65 @@ extern "C" int chx_sc_green_spectrum_fast(const void* cell, const void* gamma, i
     return green_spectrum_impl<float>(table, (const float*)cell, (const float*)gamma, B, bins, (float*)Ghat, (float*)rest, s);
 }
 
-// workspace of chx_sc_convolve per batch row: A [gx][gy][gz+1], Bf [gx][2gy][gz+1], C [2gx][2gy][gz+1] complex
+// workspace of chx_sc_convolve per batch row: A [gx+1][gy][gz], Bf [gx+1][2gy][gz] complex, and for line lengths the fused
+// middle pass does not cover (2 gz > 256) the full z spectrum C [gx+1][2gy][2gz]
+static bool z_fused_ok(int gz) { return 2 * gz <= 256; }
+
 extern "C" size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins, int dtype) {
     if (B < 1 || !chx_sc_pruned_supported(bins, dtype)) return 0;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    const size_t gx = bins[0], gy = bins[1], nzc = bins[2] + 1;
-    return (size_t)B * 2 * esz * (gx * gy * nzc + gx * 2 * gy * nzc + 2 * gx * 2 * gy * nzc);
+    const size_t nxc = bins[0] + 1, gy = bins[1], gz = bins[2];
+    return (size_t)B * 2 * esz * (nxc * gy * gz + nxc * 2 * gy * gz + (z_fused_ok(bins[2]) ? 0 : nxc * 2 * gy * 2 * gz));
 }
 
+// Pass order x (real -> half spectrum), y, z: the half-spectrum axis (g + 1 planes, an odd count) is the SLOWEST one, so every
+// strided pass moves 16-line tiles that are whole, 128-byte aligned cache lines (gz is a multiple of 16), and the heaviest pass
+// — forward z, multiply, inverse z — runs in place along the contiguous axis.
 template <typename T>
 static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64_t B, const int32_t* bins, T* phi, T* ws,
                          hipStream_t s) {
     const int gx = bins[0], gy = bins[1], gz = bins[2];
-    const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nzc = gz + 1;
-    const int64_t nA = (int64_t)gx * gy * nzc, nB = (int64_t)gx * ny * nzc, nC = (int64_t)nx * ny * nzc;  // complex elements
+    const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nxc = gx + 1;
+    const int64_t nA = (int64_t)nxc * gy * gz, nB = (int64_t)nxc * ny * gz, nC = (int64_t)nxc * ny * nz;  // complex elements
     T* A = ws;
     T* Bf = A + 2 * B * nA;
     T* C = Bf + 2 * B * nB;
-    const int64_t g3 = (int64_t)gx * gy * gz;
-    // forward z: rho[x][y][z<gz] real -> A[x][y][kz<=gz]
-    LineLayout rz{1, gz, (int64_t)gy * gz, g3};
-    LineLayout az{1, nzc, (int64_t)gy * nzc, nA};
-    int st = launch_lines<T, LOAD_REAL, STORE_COMPLEX, true>(rho, A, nz, gz, nzc, (int64_t)gx * gy, gy, rz, az, 0, B, s);
+    const int64_t g3 = (int64_t)gx * gy * gz, yz = (int64_t)gy * gz;
+    // forward x: rho[x < gx][y][z] real, lines (y, z) -> A[kx <= gx][y][z]
+    LineLayout rx{yz, 1, 0, g3};
+    LineLayout ax{yz, 1, 0, nA};
+    int st = launch_lines<T, LOAD_REAL, STORE_COMPLEX, false, false, true>(rho, A, nx, gx, nxc, yz, yz, rx, ax, B, s);
     if (st != CHX_OK) return st;
-    // forward y: A lines (x, kz), y < gy valid -> Bf[x][ky < ny][kz]
-    LineLayout ay{nzc, 1, (int64_t)gy * nzc, nA};
-    LineLayout by{nzc, 1, (int64_t)ny * nzc, nB};
-    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(A, Bf, ny, gy, ny, (int64_t)gx * nzc, nzc, ay, by, 0, B, s);
+    // forward y: A lines (kx, z), y < gy valid -> Bf[kx][ky < ny][z]
+    LineLayout ay{gz, 1, yz, nA};
+    LineLayout by{gz, 1, (int64_t)ny * gz, nB};
+    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false, false, true>(A, Bf, ny, gy, ny, (int64_t)nxc * gz, gz, ay, by, B, s);
     if (st != CHX_OK) return st;
-    const int64_t plane = (int64_t)ny * nzc;
-    int fused = CHX_ERR_INVALID_ARG;
-    switch (nx) {   // x pass fused with the spectral multiply, in place on Bf (register-resident line FFTs)
-        case 32: fused = launch_x_fused<T, 2>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
-        case 64: fused = launch_x_fused<T, 4>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
-        case 128: fused = launch_x_fused<T, 8>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
-        case 256: fused = launch_x_fused<T, 16>(Bf, Ghat, scale, gx, plane, ny, nzc, plane, nB, B, s); break;
-        default: break;
-    }
-    if (fused == CHX_ERR_LAUNCH) return fused;
-    if (fused != CHX_OK) {
-        // forward x: Bf lines (ky, kz), x < gx valid -> C[kx < nx][ky][kz]
-        LineLayout bx{plane, 1, 0, nB};
-        LineLayout cx{plane, 1, 0, nC};
-        st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, C, nx, gx, nx, plane, plane, bx, cx, 0, B, s);
-        if (st != CHX_OK) return st;
-        // spectral multiply with the real, even Green spectrum
-        {
-            int grid = chx_grid_for(nC, CHX_BLOCK * 4, 8192);
+    // z: forward, multiply by the Green spectrum, inverse, z < gz kept — in place on Bf
+    switch (nz) {
+        case 32: st = launch_z_fused<T, 2>(Bf, Ghat, scale, gx, gy, B, s); break;
+        case 64: st = launch_z_fused<T, 4>(Bf, Ghat, scale, gx, gy, B, s); break;
+        case 128: st = launch_z_fused<T, 8>(Bf, Ghat, scale, gx, gy, B, s); break;
+        case 256: st = launch_z_fused<T, 16>(Bf, Ghat, scale, gx, gy, B, s); break;
+        default: {
+            const int64_t L = (int64_t)nxc * ny;
+            LineLayout bz{1, gz, 0, nB};
+            LineLayout cz{1, nz, 0, nC};
+            st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, true, false, true>(Bf, C, nz, gz, nz, L, L, bz, cz, B, s);
+            if (st != CHX_OK) return st;
+            const int grid = chx_grid_for(nC, CHX_BLOCK * 4, 8192);
             hipLaunchKernelGGL(spectral_mul_sym_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, C, Ghat, scale,
-                               nx, ny, nzc);
+                               nxc, ny, nz);
             CHX_CHECK_LAUNCH();
+            st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, true, true, false, true>(C, Bf, nz, nz, gz, L, L, cz, bz, B, s);
         }
-        // inverse x: C -> Bf[x < gx][ky][kz]
-        st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(C, Bf, nx, nx, gx, plane, plane, cx, bx, 1, B, s);
-        if (st != CHX_OK) return st;
     }
-    // inverse y: Bf -> A[x][y < gy][kz]
-    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false>(Bf, A, ny, ny, gy, (int64_t)gx * nzc, nzc, by, ay, 1, B, s);
     if (st != CHX_OK) return st;
-    // inverse z: A half spectra -> phi[x][y][z < gz] real
-    return launch_lines<T, LOAD_HERMITIAN, STORE_REAL, true>(A, phi, nz, nzc, gz, (int64_t)gx * gy, gy, az, rz, 1, B, s);
+    // inverse y: Bf -> A[kx][y < gy][z]
+    st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false, true, false, true>(Bf, A, ny, ny, gy, (int64_t)nxc * gz, gz, by, ay, B, s);
+    if (st != CHX_OK) return st;
+    // inverse x: half spectra A[kx <= gx] -> phi[x < gx][y][z] real
+    return launch_lines<T, LOAD_HERMITIAN, STORE_REAL, false, true, false, true>(A, phi, nx, nxc, gx, yz, yz, ax, rx, B, s);
 }
 
 // phi[B][gx][gy][gz] = crop( ifft( fft(pad(rho)) * Ghat * scale ) ), unnormalised transforms (fold 1/(8 gx gy gz) into

@@ -244,3 +244,20 @@ def test_persistent_run_plan_host_logic():
     e1, rev = Element._epoch, q1.__dict__["_revision"]
     seg.double()
     assert Element._epoch > e1 and q1.__dict__["_revision"] > rev and q1.k1.dtype == torch.float64
+
+
+def test_register_fft_butterflies_on_the_host(tmp_path):
+    """csrc/chx_fft_reg.h (the packed radix-4 butterflies of the line-FFT kernels) is host-callable: every transform
+    size and direction against a direct DFT in long double, compiled for the host only (no GPU, no HIP runtime call)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "fft_reg_check"
+    subprocess.run([hipcc, "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "cheetah_amd", "csrc"),
+                    "-o", str(exe), os.path.join(ROOT, "tests", "host", "fft_reg_check.hip")], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "f32: ok" in out.stdout and "f64: ok" in out.stdout

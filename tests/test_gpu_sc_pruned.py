@@ -25,13 +25,16 @@ def _dense(rho, cell, gamma, scale, g):
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-@pytest.mark.parametrize("g", [(32, 32, 32), (16, 32, 64), (64, 64, 64), (128, 128, 128), (256, 16, 32)])
+@pytest.mark.parametrize("g", [(32, 32, 32), (16, 32, 64), (64, 64, 64), (128, 128, 128), (256, 16, 32), (16, 32, 256)])
 def test_pruned_convolution_matches_dense_fft(tag, g):
     from cheetah_amd import _ops
 
     dt = torch.float32 if tag == "f32" else torch.float64
-    # line lengths 32 ... 256 run the register-resident kernel, 512 the LDS radix-2 kernel
-    assert _ops.sc_pruned_supported(g, dt)
+    # line lengths 32 ... 256 run the register-resident kernels, 512 the LDS radix-2 kernel (along x: (256, 16, 32); along z,
+    # where it replaces the fused forward-multiply-inverse pass by three kernels: (16, 32, 256))
+    if not _ops.sc_pruned_supported(g, dt):
+        assert dt == torch.float64 and max(g) == 256
+        pytest.skip("fp64 lines of 512 points do not fit the LDS tile")
     B = 2
     torch.manual_seed(0)
     rho = torch.rand((B, *g), dtype=dt, device="cuda") ** 4
