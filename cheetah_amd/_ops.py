@@ -1227,6 +1227,22 @@ def sc_convolve(rho, Ghat, scale, bins) -> torch.Tensor:
     return phi
 
 
+def sc_convolve_halo(rho, Ghat, scale, bins) -> torch.Tensor:
+    """The potential of sc_convolve stored inside a halo of 2 nodes, (B,gx+4,gy+4,gz+4); the halo is not written
+    (chx_sc_convolve_halo). Input of sc_gather_kick_phi."""
+    B = rho.shape[0]
+    lib = _lib.lib()
+    b3 = _bins3(bins)
+    dt = dtype_code(rho.dtype)
+    ws_bytes = lib.chx_sc_convolve_workspace_bytes(B, b3, dt)
+    ws = workspace(ws_bytes, rho.device)
+    phi = torch.empty((B, bins[0] + 4, bins[1] + 4, bins[2] + 4), dtype=rho.dtype, device=rho.device)
+    assert phi.numel() == lib.chx_sc_phi_halo_elements(B, b3)
+    check(lib.chx_sc_convolve_halo(ptr(rho), ptr(Ghat), ptr(scale), B, b3, dt, ptr(phi), ptr(ws), ws_bytes, stream_ptr()),
+          "chx_sc_convolve_halo")
+    return phi
+
+
 class ScFftPlan:
     """hipFFT plans of the Hockney convolution for one (B, grid, dtype) (chx_sc_fft_plan_*): in-place, unnormalised
     real <-> complex 3-D transforms on the padded layout (B,2gx,2gy,2gz+2)."""
@@ -1297,6 +1313,18 @@ def sc_gather_kick(x, F, half, cell, energy, dt, mass_eV, B, N, bins) -> torch.T
     check(_lib.lib().chx_sc_gather_kick(ptr(x), ptr(F), ptr(half), ptr(cell), ptr(energy), ptr(dt), mass_eV, B,
                                         x.shape[0], energy.shape[0], N, _bins3(bins), dtype_code(x.dtype),
                                         ptr(out), stream_ptr()), "chx_sc_gather_kick")
+    return out
+
+
+def sc_gather_kick_phi(x, phi_halo, half, cell, gamma, energy, dt, mass_eV, B, N, bins, post_map=None) -> torch.Tensor:
+    """sc_gradient + sc_gather_kick (+ the linear run post_map) in one pass from the potential with a halo
+    (chx_sc_gather_kick_phi): no force grid."""
+    out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
+    check(_lib.lib().chx_sc_gather_kick_phi(ptr(x), ptr(phi_halo), ptr(half), ptr(cell), ptr(gamma), ptr(energy), ptr(dt), mass_eV,
+                                            B, x.shape[0], energy.shape[0], N, _bins3(bins), dtype_code(x.dtype),
+                                            ptr(post_map) if post_map is not None else None,
+                                            post_map.shape[0] if post_map is not None else 1, ptr(out), stream_ptr()),
+          "chx_sc_gather_kick_phi")
     return out
 
 

@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int kTL = 16;        // lines per tile
+constexpr int kHalo = 2;       // chx_sc_convolve_halo: nodes of halo around phi (chx_spacecharge.hip reads i-1 .. i+2 of cell i >= -1)
 constexpr int kPad = kTL + 1;  // LDS row pitch (complex elements): breaks the power-of-two bank pattern
 
 enum LoadMode { LOAD_COMPLEX = 0, LOAD_REAL = 1, LOAD_HERMITIAN = 2, LOAD_EVEN_REAL = 3 };
@@ -683,7 +684,7 @@ extern "C" size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins
 // — forward z, multiply, inverse z — runs in place along the contiguous axis.
 template <typename T>
 static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64_t B, const int32_t* bins, T* phi, T* ws,
-                         hipStream_t s) {
+                         hipStream_t s, bool halo) {
     const int gx = bins[0], gy = bins[1], gz = bins[2];
     const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nxc = gx + 1;
     const int64_t nA = (int64_t)nxc * gy * gz, nB = (int64_t)nxc * ny * gz, nC = (int64_t)nxc * ny * nz;  // complex elements
@@ -724,8 +725,12 @@ static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64
     // inverse y: Bf -> A[kx][y < gy][z]
     st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false, true, false, true>(Bf, A, ny, ny, gy, (int64_t)nxc * gz, gz, by, ay, B, s);
     if (st != CHX_OK) return st;
-    // inverse x: half spectra A[kx <= gx] -> phi[x < gx][y][z] real
-    return launch_lines<T, LOAD_HERMITIAN, STORE_REAL, false, true, false, true>(A, phi, nx, nxc, gx, yz, yz, ax, rx, B, s);
+    // inverse x: half spectra A[kx <= gx], lines (y, z) -> phi[x < gx][y][z] real, compact or inside a halo of kHalo nodes
+    const int64_t pz = gz + (halo ? 2 * kHalo : 0), py = (gy + (halo ? 2 * kHalo : 0)) * pz;
+    LineLayout ai{yz, 1, gz, nA};
+    LineLayout po{py, 1, pz, (gx + (halo ? 2 * kHalo : 0)) * py};
+    T* origin = phi + (halo ? (kHalo * py + kHalo * pz + kHalo) : 0);
+    return launch_lines<T, LOAD_HERMITIAN, STORE_REAL, false, true, false, true>(A, origin, nx, nxc, gx, yz, gz, ai, po, B, s);
 }
 
 // phi[B][gx][gy][gz] = crop( ifft( fft(pad(rho)) * Ghat * scale ) ), unnormalised transforms (fold 1/(8 gx gy gz) into
@@ -737,7 +742,27 @@ extern "C" int chx_sc_convolve(const void* rho, const void* Ghat, const double* 
     if (!workspace || workspace_bytes < chx_sc_convolve_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     return dtype == CHX_F32 ? convolve_impl<float>((const float*)rho, (const float*)Ghat, scale, B, bins, (float*)phi,
-                                                   (float*)workspace, s)
+                                                   (float*)workspace, s, false)
                             : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi,
-                                                    (double*)workspace, s);
+                                                    (double*)workspace, s, false);
+}
+
+// The same convolution with phi stored inside a halo of 2 nodes: phi_halo[B][gx+4][gy+4][gz+4], node (i, j, k) at
+// [i+2][j+2][k+2]. The halo is NOT written (its content is undefined): chx_sc_gather_kick_phi reads it only where the
+// result is discarded. Same workspace as chx_sc_convolve.
+extern "C" size_t chx_sc_phi_halo_elements(int64_t B, const int32_t* bins) {
+    if (B < 1 || !bins) return 0;
+    return (size_t)B * (bins[0] + 2 * kHalo) * (bins[1] + 2 * kHalo) * (bins[2] + 2 * kHalo);
+}
+
+extern "C" int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,
+                                    int dtype, void* phi_halo, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!rho || !Ghat || !scale || !phi_halo || B < 1 || B > 65535 || !chx_sc_pruned_supported(bins, dtype))
+        return CHX_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < chx_sc_convolve_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == CHX_F32 ? convolve_impl<float>((const float*)rho, (const float*)Ghat, scale, B, bins, (float*)phi_halo,
+                                                   (float*)workspace, s, true)
+                            : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi_halo,
+                                                    (double*)workspace, s, true);
 }

@@ -18,7 +18,7 @@ constexpr int64_t kSortedMinParticles = 65536;  // below this the direct deposit
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t mom_ws, mom, geo, pot, rho, dep_ws, table, green_ws, ghat, conv_ws, phi, force, total;  // table: end of dep_ws
+    size_t mom_ws, mom, geo, pot, rho, dep_ws, table, green_ws, ghat, conv_ws, phi, total;  // table: end of dep_ws
 };
 
 chx_cic_args deposit_args(int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t N, const int32_t* bins, int dtype) {
@@ -57,8 +57,7 @@ Layout layout(int64_t B, int64_t N, const int32_t* bins, int dtype) {
     L.green_ws = take(chx_sc_green_fast_workspace_bytes(B, bins, dtype));   // corner table + compact Green function
     L.ghat = take((size_t)B * npts * esz);
     L.conv_ws = take(chx_sc_convolve_workspace_bytes(B, bins, dtype));
-    L.phi = take((size_t)B * ncell * esz);
-    L.force = take((size_t)B * ncell * 4 * esz);
+    L.phi = take(chx_sc_phi_halo_elements(B, bins) * esz);
     L.total = off;
     return L;
 }
@@ -96,7 +95,6 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     void* rho = ws + L.rho;
     void* ghat = ws + L.ghat;
     void* phi = ws + L.phi;
-    void* force = ws + L.force;
 
     // beam sizes -> grid geometry (space_charge_kick.py:531-550); the unnormalised inverse FFT's 1 / (8 g^3) goes into
     // the potential factor
@@ -139,12 +137,10 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     }
     if (st != CHX_OK) return st;
 
-    st = chx_sc_convolve(rho, ghat, pot_scale, B, bins, dtype, phi, ws + L.conv_ws, L.phi - L.conv_ws, main);
+    // potential inside a halo; the field (central differences, space_charge_kick.py:324-385) is formed per particle in the
+    // gather: the 33.5 MB force grid of the four-kernel form is neither written nor read
+    st = chx_sc_convolve_halo(rho, ghat, pot_scale, B, bins, dtype, phi, ws + L.conv_ws, L.phi - L.conv_ws, main);
     if (st != CHX_OK) return st;
-    st = chx_sc_gradient(phi, cell, gamma, B, bins, 0, 0, dtype, force, main);
-    if (st != CHX_OK) return st;
-    if (post_map)
-        return chx_sc_gather_kick_mapped(x_in, force, half, cell, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, post_map, BR,
-                                         x_out, main);
-    return chx_sc_gather_kick(x_in, force, half, cell, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, x_out, main);
+    return chx_sc_gather_kick_phi(x_in, phi, half, cell, gamma, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, post_map, BR,
+                                  x_out, main);
 }

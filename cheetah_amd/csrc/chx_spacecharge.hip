@@ -126,13 +126,25 @@ __global__ __launch_bounds__(CHX_BLOCK) void gradient_kernel(const T* __restrict
     }
 }
 
+// Force components at node (I, J, K) from the potential with a halo (chx_sc_convolve_halo): exactly gradient_kernel's
+// arithmetic, evaluated where it is needed. `q` points at the node, `lo`/`hi` are the neighbours along the axis.
+template <typename T>
+__device__ __forceinline__ T node_force(T lo, T hi, T h, T neg_ig2, bool interior) {
+    const T f = interior ? (hi - lo) * h : (T)0;
+    return neg_ig2 * f;
+}
+
+template <typename T, int N>
+struct alignas(sizeof(T)) Run { T v[N]; };   // N consecutive grid values at element (not vector) alignment
+
 // MODE 0: gather + kick (full SpaceChargeKick particle step); 1: to_xyz only; 2: from_xyz only
-template <typename T, int MODE>
+// FROM_PHI (MODE 0): F is the potential with a halo instead of the force grid; the central differences are taken here
+template <typename T, int MODE, bool FROM_PHI = false>
 __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
     const T* __restrict__ x_in, const T* __restrict__ F, const T* __restrict__ half,
     const T* __restrict__ cell, const T* __restrict__ energy, const T* __restrict__ dt,
     double mass_eV, int64_t Bx, int64_t Be, int64_t N, int gx, int gy, int gz,
-    T* __restrict__ x_out, const T* __restrict__ post_map, int64_t BR) {
+    T* __restrict__ x_out, const T* __restrict__ post_map, int64_t BR, const T* __restrict__ gamma) {
     constexpr int PPT = 1;
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
@@ -172,15 +184,57 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
                 // The eight corners are fetched first, each as one 16/32-byte access at a clamped (always valid) node,
                 // so all of them are in flight together; corners outside the grid get weight 0.
                 struct alignas(4 * sizeof(T)) Node { T x, y, z, pad; };
-                const Node* Fb = reinterpret_cast<const Node*>(F) + b * (int64_t)gx * gy * gz;
                 Node node[8];
                 double w[8];
+                if (FROM_PHI) {
+                    // 32 potential values around the cell — z runs of 4 on the four central rows, z pairs on the rows one
+                    // step out in x and in y — from a grid a quarter of the force grid's size (it stays in L2)
+                    const int pz = gz + 4, py = (gy + 4) * pz;   // halo of 2: every index below is in bounds
+                    const int ci = min(max(i0[0], -1), g[0] - 1), cj = min(max(i0[1], -1), g[1] - 1),
+                              ck = min(max(i0[2], -1), g[2] - 1);
+                    const T* q = F + b * (int64_t)(gx + 4) * py + ((int64_t)(ci + 2) * py + (cj + 2) * pz + (ck + 2));
+                    Run<T, 4> zr[2][2];
+                    Run<T, 2> xr[2][2], yr[2][2];          // [outer side: 0 = -1, 1 = +2][the other in-cell index]
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            zr[a][c2] = *reinterpret_cast<const Run<T, 4>*>(q + a * py + c2 * pz - 1);
+                            xr[a][c2] = *reinterpret_cast<const Run<T, 2>*>(q + (a ? 2 : -1) * py + c2 * pz);
+                            yr[a][c2] = *reinterpret_cast<const Run<T, 2>*>(q + c2 * py + (a ? 2 : -1) * pz);
+                        }
+                    }
+                    const T gm = gamma[b];
+                    const T nig2 = -((gm != (T)0) ? (T)1 / (gm * gm) : (T)0);
+                    const T hx = (T)0.5 * ((T)1 / cell[b * 3 + 0]);
+                    const T hy = (T)0.5 * ((T)1 / cell[b * 3 + 1]);
+                    const T hz = (T)0.5 * ((T)1 / cell[b * 3 + 2]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int a = k >> 2, c2 = (k >> 1) & 1, e = k & 1;    // node (ci + a, cj + c2, ck + e)
+                        const int I = ci + a, J = cj + c2, K = ck + e;
+                        // neighbours along x: a = 0 -> (ci - 1, ci + 1), a = 1 -> (ci, ci + 2); value at (., cj + c2, ck + e)
+                        const T xlo = a ? zr[0][c2].v[1 + e] : xr[0][c2].v[e];
+                        const T xhi = a ? xr[1][c2].v[e] : zr[1][c2].v[1 + e];
+                        const T ylo = c2 ? zr[a][0].v[1 + e] : yr[0][a].v[e];
+                        const T yhi = c2 ? yr[1][a].v[e] : zr[a][1].v[1 + e];
+                        const T zlo = zr[a][c2].v[e], zhi = zr[a][c2].v[e + 2];
+                        node[k].x = node_force(xlo, xhi, hx, nig2, I > 0 && I < g[0] - 1);
+                        node[k].y = node_force(ylo, yhi, hy, nig2, J > 0 && J < g[1] - 1);
+                        node[k].z = node_force(zlo, zhi, hz, nig2, K > 0 && K < g[2] - 1);
+                    }
+                }
+                const Node* Fb = reinterpret_cast<const Node*>(F) + b * (int64_t)gx * gy * gz;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int ix = i0[0] + (k >> 2), iy = i0[1] + ((k >> 1) & 1), iz = i0[2] + (k & 1);
                     const bool valid = ix >= 0 && ix < g[0] && iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2];
-                    const int cx = min(max(ix, 0), g[0] - 1), cy = min(max(iy, 0), g[1] - 1), cz = min(max(iz, 0), g[2] - 1);
-                    node[k] = Fb[((int64_t)cx * g[1] + cy) * g[2] + cz];
+                    if (!FROM_PHI) {
+                        const int cx = min(max(ix, 0), g[0] - 1), cy = min(max(iy, 0), g[1] - 1), cz = min(max(iz, 0), g[2] - 1);
+                        node[k] = Fb[((int64_t)cx * g[1] + cy) * g[2] + cz];
+                    } else if (!valid) {
+                        node[k].x = node[k].y = node[k].z = (T)0;   // built from halo values, which are undefined
+                    }
                     w[k] = valid ? (1.0 - fabs(u[0] - ix)) * (1.0 - fabs(u[1] - iy)) * (1.0 - fabs(u[2] - iz)) * kElementaryCharge
                                  : 0.0;
                 }
@@ -450,11 +504,11 @@ extern "C" int chx_sc_fft_exec(void* plan, int direction, void* data, void* stre
     return r == HIPFFT_SUCCESS ? CHX_OK : CHX_ERR_LAUNCH;
 }
 
-template <int MODE>
+template <int MODE, bool FROM_PHI = false>
 static int launch_particle(const void* x_in, const void* F, const void* half, const void* cell,
                            const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
                            int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
-                           void* stream, const void* post_map = nullptr, int64_t BR = 1) {
+                           void* stream, const void* post_map = nullptr, int64_t BR = 1, const void* gamma = nullptr) {
     if (!x_in || !x_out || !energy || B < 1 || N < 1 || B > 65535) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -463,13 +517,15 @@ static int launch_particle(const void* x_in, const void* F, const void* half, co
     dim3 grid((unsigned)tiles, (unsigned)B);
     const int gx = bins ? bins[0] : 0, gy = bins ? bins[1] : 0, gz = bins ? bins[2] : 0;
     if (dtype == CHX_F32)
-        hipLaunchKernelGGL((sc_particle_kernel<float, MODE>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+        hipLaunchKernelGGL((sc_particle_kernel<float, MODE, FROM_PHI>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
                            (const float*)F, (const float*)half, (const float*)cell, (const float*)energy,
-                           (const float*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (float*)x_out, (const float*)post_map, BR);
+                           (const float*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (float*)x_out, (const float*)post_map, BR,
+                           (const float*)gamma);
     else if (dtype == CHX_F64)
-        hipLaunchKernelGGL((sc_particle_kernel<double, MODE>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
+        hipLaunchKernelGGL((sc_particle_kernel<double, MODE, FROM_PHI>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,
                            (const double*)F, (const double*)half, (const double*)cell, (const double*)energy,
-                           (const double*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (double*)x_out, (const double*)post_map, BR);
+                           (const double*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (double*)x_out, (const double*)post_map, BR,
+                           (const double*)gamma);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();
@@ -490,6 +546,18 @@ extern "C" int chx_sc_gather_kick_mapped(const void* x_in, const void* F, const 
                                          int64_t BR, void* x_out, void* stream) {
     if (!F || !half || !cell || !dt || !bins_ok(bins) || !post_map || !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
     return launch_particle<0>(x_in, F, half, cell, energy, dt, mass_eV, B, Bx, Be, N, bins, dtype, x_out, stream, post_map, BR);
+}
+
+// Gather + kick straight from the potential with a halo (chx_sc_convolve_halo): the central differences of chx_sc_gradient
+// are taken per particle, bit-identical to chx_sc_gradient + chx_sc_gather_kick(_mapped); post_map may be null.
+extern "C" int chx_sc_gather_kick_phi(const void* x_in, const void* phi_halo, const void* half, const void* cell,
+                                      const void* gamma, const void* energy, const void* dt, double mass_eV, int64_t B,
+                                      int64_t Bx, int64_t Be, int64_t N, const int32_t* bins, int dtype, const void* post_map,
+                                      int64_t BR, void* x_out, void* stream) {
+    if (!phi_halo || !half || !cell || !gamma || !dt || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    if (post_map && !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    return launch_particle<0, true>(x_in, phi_halo, half, cell, energy, dt, mass_eV, B, Bx, Be, N, bins, dtype, x_out, stream,
+                                    post_map, post_map ? BR : 1, gamma);
 }
 
 extern "C" int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B,

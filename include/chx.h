@@ -332,6 +332,12 @@ int chx_sc_green_spectrum(const double* table, int64_t B, const int32_t* bins, i
 size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins, int dtype);
 int chx_sc_convolve(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
                     void* phi, void* workspace, size_t workspace_bytes, void* stream);
+/* The same convolution with the potential stored inside a halo of 2 nodes: phi_halo[B][gx+4][gy+4][gz+4] (dtype,
+ * chx_sc_phi_halo_elements() elements), node (i, j, k) at [i+2][j+2][k+2]. The halo itself is NOT written; its content is
+ * undefined and chx_sc_gather_kick_phi reads it only where the value is discarded. Workspace as chx_sc_convolve. */
+size_t chx_sc_phi_halo_elements(int64_t B, const int32_t* bins);
+int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
+                         void* phi_halo, void* workspace, size_t workspace_bytes, void* stream);
 /* Grid geometry of a kick from the beam moments (space_charge_kick.py:531-550,110-130), one launch instead of ~25
  * tensor ops: moments[Bm][29] (chx_moments layout), grid_extent[Bext][3] (in sigmas), energy[Be], length[Bl] ->
  * half[B][3] = extent*sigma, cell[B][3] = 2 half / bins, gamma[B], dt[B] = L/(c beta), scale[B][3] = (1, 1, -beta),
@@ -365,6 +371,14 @@ int chx_sc_gather_kick(const void* x_in, const void* F, const void* half, const 
 int chx_sc_gather_kick_mapped(const void* x_in, const void* F, const void* half, const void* cell, const void* energy,
                               const void* dt, double mass_eV, int64_t B, int64_t Bx, int64_t Be, int64_t N, const int32_t* bins,
                               int dtype, const void* post_map, int64_t BR, void* x_out, void* stream);
+/* chx_sc_gradient + chx_sc_gather_kick(_mapped) in ONE pass, without the force grid: every particle takes the central
+ * differences of chx_sc_gradient (space_charge_kick.py:324-385; zero normal component on the boundary nodes) on the 32
+ * potential values around its cell — phi_halo from chx_sc_convolve_halo, gamma[B] and cell[B][3] as for chx_sc_gradient —
+ * in the same arithmetic and order, then interpolates and kicks: bit-identical to the two-kernel form, which writes and
+ * re-reads a [g^3][4] force grid four times the size of the potential. post_map may be NULL (kick only). */
+int chx_sc_gather_kick_phi(const void* x_in, const void* phi_halo, const void* half, const void* cell, const void* gamma,
+                           const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx, int64_t Be, int64_t N,
+                           const int32_t* bins, int dtype, const void* post_map, int64_t BR, void* x_out, void* stream);
 /* chx_moments + chx_sc_geometry for the kick: only the three variances the grid needs (sigma_x, sigma_y, sigma_tau;
  * space_charge_kick.py:531-538) are accumulated (8 fp64 sums per lane instead of 29, same shifted one-pass formulas and
  * rounding), and the partial sums are finalised inside the geometry kernel: two launches. Outputs as chx_sc_geometry. */
@@ -375,7 +389,7 @@ int chx_sc_beam_geometry(const void* x, const void* w, const void* grid_extent, 
                          void* scale, void* extent, double* pot_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* A whole SpaceChargeKick.track in ONE call (space_charge_kick.py:477-586) for grids chx_sc_pruned_supported() accepts:
  * chx_sc_beam_geometry -> [side stream: chx_sc_green_spectrum_fast] -> chx_cic_deposit_sorted_overwrite (N >= 65536; zero +
- * chx_cic_deposit below) -> chx_sc_convolve -> chx_sc_gradient -> chx_sc_gather_kick, all intermediates in `workspace`
+ * chx_cic_deposit below) -> chx_sc_convolve_halo -> chx_sc_gather_kick_phi, all intermediates in `workspace`
  * (chx_sc_kick_workspace_bytes). x_in[Bx][N][7], charge[Bq][N], survival[Bs][N], energy[B], length[B],
  * grid_extent[Bext][3] (in sigmas) -> x_out[B][N][7]. `side_stream` may be NULL (everything on `stream`); two events are
  * created and destroyed per call, nothing else is allocated. Saves ~20 foreign-function calls per kick: at the
