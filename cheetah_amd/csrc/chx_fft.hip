@@ -21,8 +21,10 @@ constexpr int kTL = 16;        // lines per tile
 constexpr int kHalo = 2;       // chx_sc_convolve_halo: nodes of halo around phi (chx_spacecharge.hip reads i-1 .. i+2 of cell i >= -1)
 constexpr int kPad = kTL + 1;  // LDS row pitch (complex elements): breaks the power-of-two bank pattern
 
-enum LoadMode { LOAD_COMPLEX = 0, LOAD_REAL = 1, LOAD_HERMITIAN = 2, LOAD_EVEN_REAL = 3 };
-enum StoreMode { STORE_COMPLEX = 0, STORE_REAL = 1 };
+// LOAD_EVEN_REAL_PAIR / STORE_REAL_PAIR (register kernels only): TWO real, even lines ride one complex transform as a + i b —
+// the spectrum of a real even sequence is real, so Re and Im of the result are the two spectra, exactly; a tile is 32 lines
+enum LoadMode { LOAD_COMPLEX = 0, LOAD_REAL = 1, LOAD_HERMITIAN = 2, LOAD_EVEN_REAL = 3, LOAD_EVEN_REAL_PAIR = 4 };
+enum StoreMode { STORE_COMPLEX = 0, STORE_REAL = 1, STORE_REAL_PAIR = 2 };
 
 struct LineLayout {
     int64_t point_stride;   // elements between consecutive points of a line
@@ -201,18 +203,21 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
     using RT = RegTile<T, M>;
     constexpr int n = RT::n;
     constexpr bool kCplxIn = LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN;
+    constexpr bool kPair = LOADM == LOAD_EVEN_REAL_PAIR;
+    static_assert(kPair == (STOREM == STORE_REAL_PAIR), "paired lines are loaded and stored as pairs");
+    constexpr int kLines = kPair ? 2 * kTL : kTL;          // lines of the arrays per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     vec2<T>* xch = reinterpret_cast<vec2<T>*>(smem_raw);  // [k1][c][line], 16 * KP elements
     vec2<T>* tw = xch + 16 * RT::KP;                       // exp(-+2 pi i k / n), n elements
-    __shared__ int64_t in_base[kTL], out_base[kTL];
+    __shared__ int64_t in_base[kLines], out_base[kLines];
 
     const int tid = threadIdx.x;
-    const int64_t l0 = (int64_t)blockIdx.x * kTL;
-    const int nl = (int)((L - l0 < kTL) ? (L - l0) : kTL);
+    const int64_t l0 = (int64_t)blockIdx.x * kLines;
+    const int nl = (int)((L - l0 < kLines) ? (L - l0) : kLines);
     const int64_t b = blockIdx.y;
     const T* inb = in + b * li.batch_stride * (kCplxIn ? 2 : 1);
     T* outb = out + b * lo.batch_stride * ((STOREM == STORE_COMPLEX) ? 2 : 1);
-    if (tid < kTL) {
+    if (tid < kLines) {
         const int64_t l = l0 + (tid < nl ? tid : 0);
         const int64_t outer = l / inner_count, inner = l - outer * inner_count;
         in_base[tid] = outer * li.outer_stride + inner * li.inner_stride;
@@ -222,12 +227,14 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
     __syncthreads();
     const int line = POINT_FAST ? (tid >> 4) : (tid & 15);
     const int c = POINT_FAST ? (tid & 15) : (tid >> 4);
+    const int la = kPair ? 2 * line : line;                // first (or only) array line of this transform
     // ---- pass 1: 16-point FFTs over j1 for column c (< M), then the twiddle W_n^(c k1) --------------------------
     if (c < M) {
         vec2<T> x[16];
-        const int64_t base = in_base[line];
+        const int64_t base = in_base[la];
         const vec2<T>* qc = reinterpret_cast<const vec2<T>*>(inb) + base;
         const T* qr = inb + base;
+        const T* qr2 = inb + in_base[kPair ? la + 1 : la];
 #pragma unroll
         for (int j1 = 0; j1 < 16; ++j1) {
             const int p = c + M * j1;
@@ -240,9 +247,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
                 const bool lower = j1 < 8 || (j1 == 8 && c == 0);
                 x[j1] = qc[(int64_t)(lower ? p : n - p) * li.point_stride];
                 if (!lower) x[j1].y = -x[j1].y;
-            } else {                                // LOAD_EVEN_REAL: x[n-p] = x[p], values 0..n/2 given
+            } else {                                // even, real: x[n-p] = x[p], values 0..n/2 given
                 const bool lower = j1 < 8 || (j1 == 8 && c == 0);
-                x[j1].x = qr[(int64_t)(lower ? p : n - p) * li.point_stride];
+                const int64_t off = (int64_t)(lower ? p : n - p) * li.point_stride;
+                x[j1].x = qr[off];
+                if (kPair) x[j1].y = qr2[off];
             }
         }
         pass1_to_lds<T, M, INV, ZP>(x, xch, tw, c, line);
@@ -255,14 +264,20 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
 #pragma unroll
         for (int j2 = 0; j2 < M; ++j2) y[j2] = xch[k1 * RT::KP + j2 * RT::LP + line];
         fft_small<T, M, INV>(y);
-        if (line < nl) {
-            const int64_t base = out_base[line];
+        if (la < nl) {
+            const int64_t base = out_base[la];
+            const int64_t base2 = out_base[kPair ? la + 1 : la];
+            const bool second = kPair && la + 1 < nl;
 #pragma unroll
             for (int k2 = 0; k2 < M; ++k2) {
                 const int p = k1 + 16 * k2;
                 if (KH ? (k2 < M / 2) : (p < n_keep)) {
-                    if (STOREM == STORE_COMPLEX) reinterpret_cast<vec2<T>*>(outb)[base + (int64_t)p * lo.point_stride] = y[k2];
-                    else outb[base + (int64_t)p * lo.point_stride] = y[k2].x;
+                    if (STOREM == STORE_COMPLEX) {
+                        reinterpret_cast<vec2<T>*>(outb)[base + (int64_t)p * lo.point_stride] = y[k2];
+                    } else {
+                        outb[base + (int64_t)p * lo.point_stride] = y[k2].x;
+                        if (second) outb[base2 + (int64_t)p * lo.point_stride] = y[k2].y;
+                    }
                 }
             }
         }
@@ -272,7 +287,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
 template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
 int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
                      LineLayout lo, int64_t B, hipStream_t s) {
-    dim3 grid((unsigned)((L + kTL - 1) / kTL), (unsigned)B);
+    constexpr int lines = LOADM == LOAD_EVEN_REAL_PAIR ? 2 * kTL : kTL;
+    dim3 grid((unsigned)((L + lines - 1) / lines), (unsigned)B);
     constexpr size_t shmem = RegTile<T, M>::shmem;
     auto kern = fft_lines_reg_kernel<T, LOADM, STOREM, POINT_FAST, M, INV, ZP, KH>;
     if (shmem > 64 * 1024) {
@@ -399,7 +415,10 @@ int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int6
     int log2n = 0;
     while ((1 << log2n) < n) ++log2n;
     const size_t shmem = ((size_t)n * kPad + n / 2) * sizeof(cplx<T>);
-    auto kern = fft_lines_kernel<T, LOADM, STOREM, POINT_FAST>;
+    // the LDS radix-2 kernel (n = 512, 1024) transforms the lines of a pair one by one
+    constexpr int LM = LOADM == LOAD_EVEN_REAL_PAIR ? (int)LOAD_EVEN_REAL : LOADM;
+    constexpr int SM = STOREM == STORE_REAL_PAIR ? (int)STORE_REAL : STOREM;
+    auto kern = fft_lines_kernel<T, LM, SM, POINT_FAST>;
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
             hipSuccess)
@@ -614,17 +633,17 @@ static int green_spectrum_impl(const double* table, const T* cell, const T* gamm
     const int64_t sy = gz + 1, sx = (int64_t)(gy + 1) * (gz + 1);
     // z: lines (x, y), points contiguous; even extension in, real out (kz <= gz)           Gc -> H
     LineLayout lz{1, sy, sx, n1};
-    int st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, true, false>(Gc, H, 2 * gz, gz + 1, gz + 1,
+    int st = launch_lines<T, LOAD_EVEN_REAL_PAIR, STORE_REAL_PAIR, true, false>(Gc, H, 2 * gz, gz + 1, gz + 1,
                                                                       (int64_t)(gx + 1) * (gy + 1), gy + 1, lz, lz, B, s);
     if (st != CHX_OK) return st;
     // y: lines (x, kz), point stride sy                                                    H -> Gc
     LineLayout ly{sy, 1, sx, n1};
-    st = launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false, false>(H, Gc, 2 * gy, gy + 1, gy + 1,
+    st = launch_lines<T, LOAD_EVEN_REAL_PAIR, STORE_REAL_PAIR, false, false>(H, Gc, 2 * gy, gy + 1, gy + 1,
                                                                    (int64_t)(gx + 1) * (gz + 1), gz + 1, ly, ly, B, s);
     if (st != CHX_OK) return st;
     // x: lines (ky, kz) = one contiguous index, point stride sx                            Gc -> Ghat
     LineLayout lx{sx, 1, 0, n1};
-    return launch_lines<T, LOAD_EVEN_REAL, STORE_REAL, false, false>(Gc, Ghat, 2 * gx, gx + 1, gx + 1, sx, sx, lx, lx, B, s);
+    return launch_lines<T, LOAD_EVEN_REAL_PAIR, STORE_REAL_PAIR, false, false>(Gc, Ghat, 2 * gx, gx + 1, gx + 1, sx, sx, lx, lx, B, s);
 }
 
 // Real, even spectrum of the integrated Green function on the doubled grid, stored on (gx+1)(gy+1)(gz+1) points.
