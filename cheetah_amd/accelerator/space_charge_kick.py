@@ -4,8 +4,9 @@ One kick, all on the caller's stream, no host synchronisation:
 
 * power-of-two grids (16 ... 512 per axis): ONE C call, `chx_sc_kick` — beam sizes and grid geometry
   (`chx_sc_beam_geometry`), sorted LDS-privatised cloud-in-cell deposit, Green spectrum on a side stream
-  (`chx_sc_green_spectrum_fast`), libchx's pruned line-FFT convolution (`chx_sc_convolve`), field gradient, fused
-  SI conversion + trilinear gather + momentum kick + back-conversion;
+  (`chx_sc_green_spectrum_fast`), libchx's pruned line-FFT convolution into a potential with a halo
+  (`chx_sc_convolve_halo`), and one particle pass that takes the field's central differences on the potential around the
+  particle's cell, interpolates, kicks and converts to SI and back (`chx_sc_gather_kick_phi`; no force grid);
 * other grids: the same stages with dense in-place hipFFT plans owned by libchx (`chx_sc_fft_*`) on the zero-padded
   (2g)^3 Hockney arrays, the Green-function chain on a side stream;
 * a beam whose particles are spread over the ranks of a process group (`sharding.particle_sharded`): the staged form
@@ -109,7 +110,7 @@ class SpaceChargeKick(Element):
             return self._track_particle_sharded(incoming, group, x, q, w, energy, L, out_shape, B, N)
         if _ops.sc_pruned_supported(g, dtype):
             # the whole kick in one C call (chx_sc_kick): moments, geometry, deposit, libchx's own pruned line FFTs with
-            # the Green-function chain on a side stream, gradient, gather + kick
+            # the Green-function chain on a side stream, field + gather + kick in one particle pass
             out = _ops.sc_kick(x, q.to(dtype).contiguous(), w.to(dtype).contiguous(), energy, L.contiguous(),
                                self._grid_extent(dtype),
                                incoming.species.mass_eV_float, B, N, g, side_stream=self._side_stream(device))
@@ -205,9 +206,8 @@ class SpaceChargeKick(Element):
         _ops.cic_deposit_into(rho, (g[1] * g[2], g[2], 1), g[0] * g[1] * g[2], x, (0, 2, 4), g, extent, charge=q, survival=w,
                               scale=scale)
         sharding.allreduce_grid(rho, group)
-        phi = _ops.sc_convolve(rho, green_hat, pot_scale, g)
-        force = _ops.sc_gradient(phi, cell, gamma, g)
-        out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, incoming.species.mass_eV_float, B, N, g)
+        phi = _ops.sc_convolve_halo(rho, green_hat, pot_scale, g)
+        out = _ops.sc_gather_kick_phi(x, phi, half, cell, gamma, energy, dt, incoming.species.mass_eV_float, B, N, g)
         return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s,
                             species=incoming.species)
