@@ -166,6 +166,9 @@ SIGNATURES = {
     "chx_kde_values": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_i64,
                                c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, c_int, c_void_p, c_void_p]),
     "chx_merge_moments": (c_int, [c_void_p, ctypes.c_int32, c_i64, c_void_p, c_void_p]),
+    "chx_run_vjp_workspace_bytes": (c_size_t, [c_i64]),
+    "chx_run_vjp": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_size_t, c_void_p]),
     "chx_build_rmatrix_scalars": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p]),
 }
 

@@ -162,15 +162,11 @@ def build_rmatrix(kind: int, params, energy, mass_eV, n_charges, B) -> torch.Ten
 MAX_PARAMS = 9  # CHX_MAX_PARAMS
 
 
-def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_charges: float):
-    """Composed (7,7) map of a run of elements whose builder parameters are all device scalars of the energy's dtype
-    (chx_build_rmatrix_scalars + chx_compose_maps: two C calls whatever the number of elements). Returns None when the
-    run does not qualify (vectorised or mixed-dtype parameters, gradients, elements without a builder kind) and the
-    caller takes the general per-element path; the result is bit-identical either way."""
+def _scalar_run_tables(elements, energy: torch.Tensor):
+    """(kinds, refs) of a run whose builder parameters are all device scalars of the energy's dtype, identity elements left
+    out: refs[e] = [(tensor, index or None)] per parameter. None when the run does not qualify."""
     dtype, device = energy.dtype, energy.device
-    if energy.dim() != 0 or not energy.is_cuda or energy.requires_grad:
-        return None
-    kinds, pointers, keep = [], [], []
+    kinds, refs_all = [], []
     identity = KIND["identity"]
     for e in elements:
         kind = e._chx_kind
@@ -179,37 +175,122 @@ def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_char
         if kind == identity:
             continue
         refs = e._builder_scalar_refs()
-        row = [None] * MAX_PARAMS
-        for k, (t, index) in enumerate(refs):
-            if t.dtype != dtype or t.requires_grad or t.device != device:
+        for t, index in refs:
+            if t.dtype != dtype or t.device != device:
                 return None
             if index is None:
                 if t.dim() != 0:
                     return None
-                row[k] = t.data_ptr()
-            else:
-                if t.dim() != 1 or not t.is_contiguous():
-                    return None
-                row[k] = t.data_ptr() + index * t.element_size()
+            elif t.dim() != 1 or not t.is_contiguous():
+                return None
         kinds.append(kind)
+        refs_all.append(refs)
+    return kinds, refs_all
+
+
+def _scalar_run_pointers(refs_all):
+    pointers = []
+    for refs in refs_all:
+        row = [None] * MAX_PARAMS
+        for k, (t, index) in enumerate(refs):
+            row[k] = t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()
         pointers += row
-        keep.append(refs)     # the tensors must outlive the launch
+    return (ctypes.c_void_p * len(pointers))(*pointers)
+
+
+def _build_compose_raw(kinds, pointers, energy, mass_eV, n_charges):
+    """(element maps (E,7,7), composed map (7,7)) by chx_build_rmatrix_scalars + chx_compose_maps."""
     E = len(kinds)
-    if E == 0:
-        return torch.eye(7, dtype=dtype, device=device)
+    dtype, device = energy.dtype, energy.device
     lib = _lib.lib()
     code = dtype_code(dtype)
     maps = torch.empty((E, 7, 7), dtype=dtype, device=device)
-    check(lib.chx_build_rmatrix_scalars((ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * MAX_PARAMS))(*pointers), E,
-                                        ptr(energy), mass_eV, n_charges, code, ptr(maps), stream_ptr()),
-          "chx_build_rmatrix_scalars")
+    check(lib.chx_build_rmatrix_scalars((ctypes.c_int32 * E)(*kinds), pointers, E, ptr(energy), mass_eV, n_charges, code,
+                                        ptr(maps), stream_ptr()), "chx_build_rmatrix_scalars")
     if E == 1:
-        return maps[0]
+        return maps, maps[0]
     base, step = maps.data_ptr(), 49 * maps.element_size()
     out = torch.empty((7, 7), dtype=dtype, device=device)
     check(lib.chx_compose_maps((ctypes.c_void_p * E)(*[base + e * step for e in range(E)]), (ctypes.c_uint8 * E)(*([1] * E)),
                                E, 1, code, ptr(out), stream_ptr()), "chx_compose_maps")
-    return out
+    return maps, out
+
+
+class RunMapScalars(torch.autograd.Function):
+    """Composed map of a run of scalar-parameter elements WITH gradients: forward = the two C calls of the no-grad path,
+    backward = chx_run_vjp (compose backward + dual-number builders, two launches) — one autograd node for the whole run
+    instead of a BuildMap node per element and a matmul node per product."""
+
+    @staticmethod
+    def forward(ctx, meta, energy, *tensors):
+        kinds, slots, mass_eV, n_charges = meta           # slots[e][k] = (position in `tensors`, index or None)
+        refs_all = [[(tensors[pos], index) for pos, index in row] for row in slots]
+        pointers = _scalar_run_pointers(refs_all)
+        maps, out = _build_compose_raw(kinds, pointers, energy, mass_eV, n_charges)
+        ctx.meta = meta
+        ctx.save_for_backward(energy, maps, *tensors)
+        return out if len(kinds) > 1 else out.clone()
+
+    @staticmethod
+    def backward(ctx, dT):
+        kinds, slots, mass_eV, n_charges = ctx.meta
+        energy, maps, *tensors = ctx.saved_tensors
+        E = len(kinds)
+        refs_all = [[(tensors[pos], index) for pos, index in row] for row in slots]
+        pointers = _scalar_run_pointers(refs_all)
+        lib = _lib.lib()
+        ws_bytes = lib.chx_run_vjp_workspace_bytes(E)
+        ws = workspace(ws_bytes, energy.device)
+        dT = dT.to(energy.dtype).contiguous()
+        d = torch.empty((E, MAX_PARAMS + 1), dtype=energy.dtype, device=energy.device)
+        check(lib.chx_run_vjp((ctypes.c_int32 * E)(*kinds), pointers, E, ptr(energy), mass_eV, n_charges, dtype_code(energy.dtype),
+                              ptr(maps), ptr(dT), ptr(d), ptr(ws), ws_bytes, stream_ptr()), "chx_run_vjp")
+        grads = [None] * len(tensors)
+        for e, row in enumerate(slots):
+            for k, (pos, index) in enumerate(row):
+                if not ctx.needs_input_grad[2 + pos]:
+                    continue
+                t = tensors[pos]
+                g = d[e, k]
+                if index is not None:
+                    full = grads[pos] if grads[pos] is not None else torch.zeros_like(t)
+                    full[index] += g
+                    grads[pos] = full
+                else:
+                    grads[pos] = g if grads[pos] is None else grads[pos] + g
+        d_energy = d[:, MAX_PARAMS].sum() if ctx.needs_input_grad[1] else None
+        return (None, d_energy, *grads)
+
+
+def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_charges: float):
+    """Composed (7,7) map of a run of elements whose builder parameters are all device scalars of the energy's dtype
+    (chx_build_rmatrix_scalars + chx_compose_maps: two C calls whatever the number of elements; with gradients one autograd
+    node, RunMapScalars). Returns None when the run does not qualify (vectorised or mixed-dtype parameters, elements without
+    a builder kind) and the caller takes the general per-element path; without gradients the result is bit-identical either
+    way."""
+    if energy.dim() != 0 or not energy.is_cuda:
+        return None
+    tables = _scalar_run_tables(elements, energy)
+    if tables is None:
+        return None
+    kinds, refs_all = tables
+    if not kinds:
+        return torch.eye(7, dtype=energy.dtype, device=energy.device)
+    wants_grad = torch.is_grad_enabled() and (energy.requires_grad or any(t.requires_grad for refs in refs_all for t, _ in refs))
+    if not wants_grad:
+        with torch.no_grad():
+            return _build_compose_raw(kinds, _scalar_run_pointers(refs_all), energy, mass_eV, n_charges)[1]
+    tensors, where, slots = [], {}, []
+    for refs in refs_all:
+        row = []
+        for t, index in refs:
+            pos = where.get(id(t))
+            if pos is None:
+                pos = where[id(t)] = len(tensors)
+                tensors.append(t)
+            row.append((pos, index))
+        slots.append(row)
+    return RunMapScalars.apply((kinds, slots, mass_eV, n_charges), energy, *tensors)
 
 
 def compose_maps(maps: list[torch.Tensor], batch_shape, dtype, device) -> torch.Tensor:

@@ -33,6 +33,10 @@ class Screen(Element):
             "pixel_size", pixel_size if pixel_size is not None else torch.tensor((1e-3, 1e-3), **fk))
         self.register_buffer_or_parameter(
             "misalignment", misalignment if misalignment is not None else torch.tensor((0.0, 0.0), **fk))
+        if misalignment is None:
+            # known to be (0, 0) for as long as this very tensor is in place and unmodified: get_read_beam() then has
+            # nothing to shift (a value test would need a device -> host read)
+            self.__dict__["_zero_misalignment"] = (self.misalignment, self.misalignment._version)
         self.register_buffer_or_parameter(
             "kde_bandwidth", kde_bandwidth if kde_bandwidth is not None else self.pixel_size[0].clone().detach())
         self.resolution = tuple(resolution)
@@ -180,6 +184,12 @@ class Screen(Element):
         """The beam as seen by the screen, i.e. with x, y relative to the screen centre (screen.py:196-214)."""
         if self.__dict__.get("_read_beam") is None and self.__dict__.get("_incoming") is not None:
             inc = self.__dict__["_incoming"]
+            zero = self.__dict__.get("_zero_misalignment")
+            if zero is not None and zero[0] is self.misalignment and zero[1] == zero[0]._version \
+                    and not isinstance(inc, ParameterBeam) and inc.particles.dtype == zero[0].dtype:
+                # centred screen: x - 0 = x bit for bit; the recorded snapshot already is a private copy
+                self.__dict__["_read_beam"] = inc
+                return inc
             ref = inc.mu if isinstance(inc, ParameterBeam) else inc.particles
             tm = torch.eye(7, dtype=ref.dtype, device=ref.device).repeat(*self.misalignment.shape[:-1], 1, 1)
             tm[..., 0, 6] = -self.misalignment[..., 0]

@@ -355,8 +355,9 @@ class Segment(Element):
         if cacheable and run.tm is not None:
             return run.tm
         tm = None
-        if cacheable:
-            # all-scalar runs (the usual control loop): every element's map and their product in two C calls
+        if cacheable or not species.mass_eV.requires_grad:
+            # all-scalar runs (the usual control loop, and gradient-based tuning of scalar settings): every element's map and
+            # their product in two C calls — with gradients ONE autograd node for the run (_ops.RunMapScalars)
             tm = _ops.build_compose_scalars(run.elements, energy, species.mass_eV_float, species.num_elementary_charges_float)
         if tm is None:
             maps = [e.first_order_transfer_map(energy, species) for e in run.elements]

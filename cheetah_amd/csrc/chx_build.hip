@@ -1052,6 +1052,126 @@ extern "C" int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const
     return CHX_OK;
 }
 
+// ---- backward of chx_build_rmatrix_scalars + chx_compose_maps (a run of scalar-parameter elements, gradients wanted) -----
+// T = R_{E-1} ... R_0. With P_e = R_{e-1} ... R_0 and G_e = (R_{E-1} ... R_{e+1})^T dT:  dL/dR_e = G_e P_e^T,
+// G_{e-1} = R_e^T G_e. One wave: a forward sweep leaves the prefixes in `ws`, the backward sweep replaces them by dL/dR_e
+// (fp64 throughout). A second launch contracts dL/dR_e with the builders' derivatives (dual numbers, one thread per
+// (element, input) like build_vjp_kernel): autograd through a whole run costs two launches instead of ~3 nodes per element.
+template <typename T>
+__global__ __launch_bounds__(64) void compose_scalars_bwd_kernel(const T* __restrict__ maps, int E, const T* __restrict__ dT,
+                                                                 double* __restrict__ ws) {
+    __shared__ double P[49], R[49], G[49];
+    const int lane = threadIdx.x, i = lane / 7, j = lane - 7 * i;
+    const bool on = lane < 49;
+    if (on) P[lane] = (i == j) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+        if (on) {
+            ws[e * 49 + lane] = P[lane];
+            R[lane] = (double)maps[e * 49 + lane];
+        }
+        __syncthreads();
+        double acc = 0.0;
+        if (on) {
+            acc = R[i * 7] * P[j];
+            for (int k = 1; k < 7; ++k) acc = fma(R[i * 7 + k], P[k * 7 + j], acc);
+        }
+        __syncthreads();
+        if (on) P[lane] = acc;
+        __syncthreads();
+    }
+    if (on) G[lane] = (double)dT[lane];
+    __syncthreads();
+    for (int e = E - 1; e >= 0; --e) {
+        if (on) {
+            P[lane] = ws[e * 49 + lane];
+            R[lane] = (double)maps[e * 49 + lane];
+        }
+        __syncthreads();
+        double dr = 0.0, gn = 0.0;
+        if (on) {
+            for (int k = 0; k < 7; ++k) {
+                dr = fma(G[i * 7 + k], P[j * 7 + k], dr);
+                gn = fma(R[k * 7 + i], G[k * 7 + j], gn);
+            }
+            ws[e * 49 + lane] = dr;
+        }
+        __syncthreads();
+        if (on) G[lane] = gn;
+        __syncthreads();
+    }
+}
+
+// one thread per (element, slot k): slots 0 .. P-1 are the element's parameters, slot CHX_MAX_PARAMS the energy, the rest
+// are written as zeros. out[e][CHX_MAX_PARAMS + 1]
+template <typename T>
+__global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs args, int n, const T* __restrict__ energy,
+                                                               double mass, double nq, const double* __restrict__ dR,
+                                                               T* __restrict__ out) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int e = idx / (CHX_MAX_PARAMS + 1), k = idx - e * (CHX_MAX_PARAMS + 1);
+    if (e >= n) return;
+    const int kind = args.kind[e];
+    const int P = kind_num_params(kind);
+    const bool is_energy = k == CHX_MAX_PARAMS;
+    T* o = out + e * (CHX_MAX_PARAMS + 1);
+    if (!is_energy && k >= P) {
+        o[k] = (T)0;
+        return;
+    }
+    Dual p[CHX_MAX_PARAMS];
+    for (int q = 0; q < P; ++q) p[q] = mk((double)*(const T*)args.par[e][q], (!is_energy && q == k) ? 1.0 : 0.0);
+    const Dual en = mk((double)energy[0], is_energy ? 1.0 : 0.0);
+    Mat7<Dual> R;
+    build_kind<Dual>(kind, p, en, mass, nq, R);
+    double acc = 0.0;
+    for (int q = 0; q < 49; ++q) acc += dR[e * 49 + q] * R.m[q].d;
+    o[k] = (T)acc;
+}
+
+extern "C" size_t chx_run_vjp_workspace_bytes(int64_t E) { return E < 1 ? 0 : (size_t)E * 49 * sizeof(double); }
+
+extern "C" int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                           double n_charges, int dtype, const void* maps, const void* dT, void* dinputs, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (!kinds || !param_ptrs || !energy || !maps || !dT || !dinputs || E < 1 || E > 65535) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!workspace || workspace_bytes < chx_run_vjp_workspace_bytes(E)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(compose_scalars_bwd_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)maps, (int)E, (const float*)dT, ws);
+    else
+        hipLaunchKernelGGL(compose_scalars_bwd_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)maps, (int)E, (const double*)dT,
+                           ws);
+    CHX_CHECK_LAUNCH();
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    for (int64_t done = 0; done < E; done += kBuildChunk) {
+        BuildScalarsArgs a;
+        const int n = (int)((E - done < kBuildChunk) ? (E - done) : kBuildChunk);
+        for (int e = 0; e < kBuildChunk; ++e) {
+            const int kind = e < n ? kinds[done + e] : 0;
+            const int P = kind_num_params(kind);
+            if (P < 0) return CHX_ERR_INVALID_ARG;
+            a.kind[e] = (uint8_t)kind;
+            for (int k = 0; k < CHX_MAX_PARAMS; ++k) {
+                a.par[e][k] = (e < n && k < P) ? param_ptrs[(done + e) * CHX_MAX_PARAMS + k] : nullptr;
+                if (e < n && k < P && !a.par[e][k]) return CHX_ERR_INVALID_ARG;
+            }
+        }
+        char* out = (char*)dinputs + (size_t)done * (CHX_MAX_PARAMS + 1) * esz;
+        const unsigned blocks = (unsigned)((n * (CHX_MAX_PARAMS + 1) + 63) / 64);
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(build_scalars_vjp_kernel<float>, dim3(blocks), dim3(64), 0, s, a, n, (const float*)energy, mass_eV,
+                               n_charges, ws + done * 49, (float*)out);
+        else
+            hipLaunchKernelGGL(build_scalars_vjp_kernel<double>, dim3(blocks), dim3(64), 0, s, a, n, (const double*)energy, mass_eV,
+                               n_charges, ws + done * 49, (double*)out);
+        CHX_CHECK_LAUNCH();
+    }
+    return CHX_OK;
+}
+
 // ---- prefix products of a run (Segment.get_beam_attrs_along_segment, segment.py:658-700): out[e] = M_e ... M_1 M_0 for
 // every e, fp64 accumulation carried from element to element, each prefix rounded to T once. One wave per batch row.
 template <typename T>

@@ -107,6 +107,15 @@ int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const* param_ptr
  * beam moments after every element of a lattice (segment.py:658-700 `get_beam_attrs_along_segment`) cost one pass over the
  * particles instead of E tracking passes and E reductions. */
 int chx_compose_prefix(const void* maps, int64_t E, int64_t B, int64_t Bm, int dtype, void* out, void* stream);
+/* Backward of chx_build_rmatrix_scalars + chx_compose_maps for a run whose settings carry gradients (autograd through
+ * segment.py:534-574 for scalar parameters): given the element maps maps[E][7][7] of the forward call and dT[7][7] =
+ * dL/d(composed map) (both `dtype`), writes dinputs[E][CHX_MAX_PARAMS + 1] (`dtype`): column k < P_e is dL/d(parameter k of
+ * element e), column CHX_MAX_PARAMS is element e's contribution to dL/d(energy), the other columns are zero. Two launches
+ * (a one-wave prefix / suffix sweep in fp64, then dual-number builders), workspace chx_run_vjp_workspace_bytes(E). */
+size_t chx_run_vjp_workspace_bytes(int64_t E);
+int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                double n_charges, int dtype, const void* maps, const void* dT, void* dinputs, void* workspace,
+                size_t workspace_bytes, void* stream);
 size_t chx_run_state_bytes(int64_t E);
 int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                 double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, void* stream);

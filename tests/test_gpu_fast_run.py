@@ -242,3 +242,70 @@ def test_kick_then_run_in_one_pass_is_bit_identical(ca, dt):
     # element by element (three rounded passes) vs merged (one): equal to rounding, relative to each coordinate's spread
     scale = b.particles.abs().amax(dim=0).clamp_min(1e-30)
     assert float(((out2.particles - b.particles).abs() / scale).max()) < (1e-4 if dt == torch.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_run_of_scalar_settings_with_gradients_is_one_autograd_node(dt):
+    """A run whose scalar settings (and the beam energy) carry gradients goes through `_ops.RunMapScalars` (forward: the two C
+    calls of the no-grad path; backward: chx_run_vjp). Gradients against the element-by-element path (a BuildMap node per
+    element, torch matmuls in between) and, in fp64, against central differences."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+
+    def lattice(vals):
+        k1, ang, tilt, mis, bend, L = vals
+        return [ca.Drift(L, **kw), ca.Quadrupole(t(0.2), k1=k1, tilt=tilt, misalignment=mis, **kw), ca.Marker(),
+                ca.HorizontalCorrector(t(0.05), angle=ang, **kw), ca.Dipole(t(0.5), angle=bend, dipole_e1=t(0.02), **kw),
+                ca.Quadrupole(t(0.2), k1=k1, **kw), ca.Drift(t(0.3), **kw)]          # k1 is shared by two quadrupoles
+
+    def fresh():
+        return [torch.nn.Parameter(t(v)) for v in (4.2, 1e-3, 0.1)] + [torch.nn.Parameter(t([1e-4, -2e-4])),
+                                                                       torch.nn.Parameter(t(0.05)), torch.nn.Parameter(t(0.7))]
+
+    torch.manual_seed(5)
+    beam0 = ca.ParticleBeam.from_parameters(num_particles=20_000, energy=t(1.2e8), sigma_x=t(2e-4), sigma_y=t(1e-4), **kw)
+
+    def loss_of(out):
+        p = out.particles
+        return (p[:, 0].square().mean() * 3e6 + p[:, 2].mean() * 2e3 + p[:, 3].square().mean() * 1e7 + p[:, 4].var() * 1e9
+                + p[:, 1].mean() * 1e3)
+
+    def run(merged: bool, vals, energy):
+        beam = ca.ParticleBeam(beam0.particles, energy, particle_charges=beam0.particle_charges, species=beam0.species)
+        els = lattice(vals)
+        if merged:
+            return loss_of(ca.Segment(els).track(beam))
+        for e in els:
+            beam = e.track(beam)
+        return loss_of(beam)
+
+    calls = []
+    orig = _ops.RunMapScalars.apply
+    try:
+        _ops.RunMapScalars.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+        va, ea = fresh(), torch.nn.Parameter(t(1.2e8))
+        la = run(True, va, ea)
+        la.backward()
+    finally:
+        _ops.RunMapScalars.apply = orig
+    assert calls, "the merged run did not take the one-node path"
+    vb, eb = fresh(), torch.nn.Parameter(t(1.2e8))
+    lb = run(False, vb, eb)
+    lb.backward()
+    rtol = 2e-3 if dt == torch.float32 else 1e-8
+    assert float(la.detach()) == pytest.approx(float(lb.detach()), rel=1e-4 if dt == torch.float32 else 1e-10)
+    for a, b in zip(va + [ea], vb + [eb]):
+        assert a.grad is not None and torch.isfinite(a.grad).all()
+        scale = float(b.grad.abs().max())
+        assert float((a.grad - b.grad).abs().max()) <= rtol * scale + 1e-30, (a.grad, b.grad)
+    if dt == torch.float64:
+        with torch.no_grad():
+            for i, h in enumerate((1e-5, 1e-8, 1e-6)):
+                up, dn = fresh(), fresh()
+                up[i].add_(h)
+                dn[i].sub_(h)
+                fd = (float(run(True, up, t(1.2e8))) - float(run(True, dn, t(1.2e8)))) / (2 * h)
+                assert float(va[i].grad) == pytest.approx(fd, rel=2e-5, abs=1e-12)

@@ -229,6 +229,23 @@ def test_pass_through_elements_return_independent_beams(ca):
     b.particles.mul_(3.0)
     assert torch.equal(seg.scr.get_read_beam().particles, read) and torch.equal(seg.scr.reading, img)
     assert torch.equal(b.particles, 3.0 * before)
+    # a centred screen hands out its snapshot (nothing to shift); the shortcut ends with the first edit of the misalignment,
+    # in place or by assignment
+    b = beam(ca)
+    scr = ca.Screen(is_active=True, dtype=f64, device="cuda")
+    scr.track(b)
+    assert torch.equal(scr.get_read_beam().particles, b.particles)
+    scr.misalignment.add_(torch.tensor([1e-3, -2e-3], dtype=f64, device="cuda"))
+    scr.track(b)
+    rb = scr.get_read_beam().particles
+    assert torch.equal(rb[:, 0], b.particles[:, 0] - 1e-3) and torch.equal(rb[:, 2], b.particles[:, 2] + 2e-3)
+    scr2 = ca.Screen(is_active=True, dtype=f64, device="cuda")
+    scr2.misalignment = torch.tensor([5e-4, 0.0], dtype=f64, device="cuda")
+    scr2.track(b)
+    assert torch.equal(scr2.get_read_beam().particles[:, 0], b.particles[:, 0] - 5e-4)
+    scr3 = ca.Screen(is_active=True, dtype=torch.float32, device="cuda").double()    # moved: general path, still no shift
+    scr3.track(b)
+    assert torch.equal(scr3.get_read_beam().particles, b.particles)
     # ParameterBeam through a marker
     pb = ca.ParameterBeam.from_parameters(dtype=f64, device="cuda")
     mu0 = pb.mu.clone()
