@@ -134,7 +134,7 @@ def c5(N=1_000_000):
         seg.track(beam)
         loss = seg.scr.get_read_beam().sigma_x
         loss.backward()
-        res["sigma_x"], res["dk1"] = float(loss), float(k1.grad)
+        res["sigma_x"], res["dk1"] = float(loss.detach()), float(k1.grad)
 
     ms = timeit(f, 10, 2)
     return {"config": f"C5 d sigma_x(screen)/d k1, N={N}, fp32, forward+backward", "fwd_bwd_ms": ms, **res}
