@@ -161,15 +161,17 @@ def elegant_to_cheetah_coordinates(elegant_coordinates: torch.Tensor, p_central:
 
 
 def convert_beam(file_path: Path, device=None, dtype=None):
-    """Elegant SDDS particle file -> (particles, reference energy, charges). Needs the `sdds` package like the
-    reference (elegant.py:454-520)."""
+    """Elegant SDDS particle file -> (particles, reference energy, charges) (elegant.py:454-520). The file is read by the
+    `sdds` package when it is installed (as the reference does) and by `converters.sdds_file` otherwise."""
+    kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
     try:
         import sdds
     except ImportError:
-        raise ImportError("The soliday.sdds package is required to convert Elegant beam. Please install it via pip "
-                          "(`pip install soliday.sdds`) and try again.")
-    kw = {"device": device or torch.get_default_device(), "dtype": dtype or torch.get_default_dtype()}
-    data = sdds.load(str(file_path))
+        from . import sdds_file
+
+        data = sdds_file.load(file_path)
+    else:
+        data = sdds.load(str(file_path))
     columns = list(data.columnName[:6])
     if columns == ["r", "pz", "pr", "pphi", "t", "q"]:
         raise ValueError("The beam distribution is stored in the spiffe format, which is not currently supported. Use "

@@ -231,8 +231,8 @@ def test_elegant_coordinates_and_openpmd_group():
     assert np.allclose(out.numpy(), g["elegant_out"], rtol=1e-13, atol=1e-20)
     two_pages = elegant_to_cheetah_coordinates(torch.tensor(g["elegant_in"]).repeat(2, 1, 1), torch.tensor([199.5, 199.5], **F64))
     assert torch.equal(two_pages[0], two_pages[1]) and torch.allclose(two_pages[0], out[0])
-    with pytest.raises(ImportError, match="sdds"):
-        ca.ParticleBeam.from_elegant("nonexistent.sdds")
+    with pytest.raises(FileNotFoundError):
+        ca.ParticleBeam.from_elegant("nonexistent.sdds")     # read by converters.sdds_file when `sdds` is not installed
 
     group = types.SimpleNamespace(species="electron", **{k: g["pmd_" + k] for k in ("x", "y", "px", "py", "t", "energy",
                                                                                     "weight", "status")})
@@ -249,3 +249,199 @@ def test_elegant_coordinates_and_openpmd_group():
         ca.ParticleBeam.from_openpmd_file("x.h5", torch.tensor(5e7))
     with pytest.raises(ImportError, match="openPMD"):
         beam.save_as_openpmd_h5("x.h5")
+
+
+# ---- SDDS container (Elegant particle files) ------------------------------------------------------------------------------
+_SDDS_STRUCT = {"short": "h", "ushort": "H", "long": "i", "ulong": "I", "long64": "q", "ulong64": "Q", "float": "f", "double": "d"}
+
+
+def write_sdds(file, parameters, columns, pages, mode="ascii", endian="<", column_major=False, fixed=None, declare_endian="comment"):
+    """Minimal SDDS writer for the tests. parameters / columns: [(name, type)]; pages: [(parameter values, rows)], a row is a
+    tuple of column values; fixed: {parameter name: text} written as fixed_value (those take no value in the pages)."""
+    import struct
+
+    fixed = fixed or {}
+    head = ["SDDS1" if not column_major else "SDDS3"]
+    if mode == "binary" and declare_endian == "comment":
+        head.append("!# little-endian" if endian == "<" else "!# big-endian")
+    head.append('&description text="test beam, made by tests/test_converters.py", contents="phase space" &end')
+    for name, t in parameters:
+        extra = f', fixed_value={fixed[name]}' if name in fixed else ""
+        head.append(f'&parameter name={name}, type={t}, description="parameter {name}, with a comma"{extra} &end')
+    for name, t in columns:
+        head.append(f"&column name={name}, type={t},\n    units=arb &end")          # a command over two lines
+    data_cmd = f"&data mode={mode}"
+    if column_major:
+        data_cmd += ", column_major_order=1"
+    if mode == "binary" and declare_endian == "field":
+        data_cmd += ", endian=" + ("little" if endian == "<" else "big")
+    head.append(data_cmd + " &end")
+    out = ("\n".join(head) + "\n").encode("latin-1")
+    free = [(n, t) for n, t in parameters if n not in fixed]
+    if mode == "ascii":
+        text = ""
+        for values, rows in pages:
+            text += "! page\n"
+            for (n, t), v in zip(free, values):
+                text += (f'"{v}"' if t == "string" and " " in v else str(v) if t != "double" else repr(float(v))) + "\n"
+            if columns:
+                text += f"{len(rows)}\n"
+                for row in rows:
+                    text += " ".join(f'"{v}"' if t == "string" else (repr(float(v)) if t in ("double", "float") else str(v))
+                                     for (n, t), v in zip(columns, row)) + "\n"
+        out += text.encode("latin-1")
+    else:
+        def pack(t, v):
+            if t == "string":
+                b = v.encode("latin-1")
+                return struct.pack(endian + "i", len(b)) + b
+            if t == "character":
+                return v.encode("latin-1")
+            return struct.pack(endian + _SDDS_STRUCT[t], v)
+
+        for values, rows in pages:
+            out += struct.pack(endian + "i", len(rows))
+            for (n, t), v in zip(free, values):
+                out += pack(t, v)
+            if column_major:
+                for c, (n, t) in enumerate(columns):
+                    for row in rows:
+                        out += pack(t, row[c])
+            else:
+                for row in rows:
+                    for (n, t), v in zip(columns, row):
+                        out += pack(t, v)
+    with open(file, "wb") as f:
+        f.write(out)
+
+
+def _sdds_case():
+    rng = np.random.default_rng(11)
+    parameters = [("Step", "long"), ("pCentral", "double"), ("Label", "string"), ("Particles", "long64"), ("Flag", "character")]
+    columns = [("x", "double"), ("xp", "double"), ("y", "double"), ("yp", "double"), ("t", "double"), ("p", "double"),
+               ("dt", "float"), ("particleID", "ulong"), ("tag", "string"), ("kind", "short")]
+    pages = []
+    for page, n in enumerate((5, 0, 3)):
+        rows = [(*(rng.normal(size=4) * 1e-4), 1e-9 + 1e-13 * rng.normal(), 200.0 + rng.normal(), float(np.float32(rng.normal())),
+                 int(rng.integers(0, 2**32 - 1)), f"particle {i} of page {page}", int(rng.integers(-300, 300))) for i in range(n)]
+        pages.append(((page + 1, 199.5 + page, f"bunch number {page}", 10**12 + page, "ab"[page % 2]), rows))
+    return parameters, columns, pages
+
+
+@pytest.mark.parametrize("variant", ["ascii", "binary-le", "binary-be", "binary-le-colmajor", "binary-be-field", "ascii-fixed"])
+def test_sdds_reader_round_trips_every_layout(tmp_path, variant):
+    from cheetah_amd.converters import sdds_file
+
+    parameters, columns, pages = _sdds_case()
+    file = os.path.join(tmp_path, "beam.sdds")
+    fixed = {"pCentral": "199.5"} if variant == "ascii-fixed" else None
+    kw = {"ascii": {}, "binary-le": {"mode": "binary"}, "binary-be": {"mode": "binary", "endian": ">"},
+          "binary-le-colmajor": {"mode": "binary", "column_major": True},
+          "binary-be-field": {"mode": "binary", "endian": ">", "declare_endian": "field"}, "ascii-fixed": {"fixed": fixed}}[variant]
+    pages_written = pages
+    if fixed:
+        pages_written = [(tuple(v for (n, t), v in zip(parameters, values) if n not in fixed), rows) for values, rows in pages]
+    write_sdds(file, parameters, columns, pages_written, **kw)
+    data = sdds_file.load(file)
+    assert data.parameterName == [n for n, _ in parameters] and data.columnName == [n for n, _ in columns]
+    assert data.loaded_pages == 3 and data.mode == ("ascii" if variant.startswith("ascii") else "binary")
+    assert data.description["contents"] == "phase space" and "tests/test_converters.py" in data.description["text"]
+    assert data.parameterDefinition[1]["description"] == "parameter pCentral, with a comma"
+    assert data.columnDefinition[0]["units"] == "arb"
+    for i, (name, t) in enumerate(parameters):
+        want = [199.5] * 3 if fixed and name in fixed else [values[i] for values, _ in pages]
+        assert data.getParameterValueList(name) == want, name
+    for c, (name, t) in enumerate(columns):
+        got = data.getColumnValueLists(name)
+        assert [len(g) for g in got] == [5, 0, 3]
+        for page, (_, rows) in enumerate(pages):
+            assert got[page] == [row[c] for row in rows], (name, page)      # exact: repr() round-trips doubles
+
+
+def test_sdds_header_quirks_and_errors(tmp_path):
+    from cheetah_amd.converters import sdds_file
+
+    file = os.path.join(tmp_path, "quirks.sdds")
+    text = (
+        "SDDS2\n"
+        "! a comment line\n"
+        '&description text="elegant output: \\"watch\\" file & more", contents="x, y" &end\n'
+        "&parameter name=Charge, symbol=\"Q\", units=C, type=double,\n"
+        "   ! a comment inside a command\n"
+        '   description="Beam charge" &end\n'
+        "&parameter name=Comment, type=string &end\n"
+        "&associate filename=lattice.lte, path=., contents=lattice, sdds=0 &end\n"
+        "&column name=x, units=m, type=double &end\n"
+        "&column name=n, type=long &end\n"
+        "&data mode=ascii, lines_per_row=2, no_row_counts=1, additional_header_lines=1 &end\n"
+        "this header line is skipped\n"
+        "  1.5e-9\n"
+        "a comment, unquoted\n"
+        " 1e-3\n 7\n"
+        "! comment between rows\n"
+        " -2e-3\n 8\n"
+        "\n"
+        "2.5e-9\n"
+        '"second page"\n'
+        "\n")
+    with open(file, "w") as f:
+        f.write(text)
+    data = sdds_file.load(file)
+    assert data.description["text"] == 'elegant output: "watch" file & more'
+    assert data.parameterDefinition[0]["symbol"] == "Q" and data.parameterDefinition[0]["units"] == "C"
+    assert data.getParameterValueList("Charge") == [1.5e-9, 2.5e-9]
+    assert data.getParameterValueList("Comment") == ["a comment, unquoted", "second page"]
+    assert data.getColumnValueLists("x") == [[1e-3, -2e-3], []] and data.getColumnValueLists("n") == [[7, 8], []]
+
+    def load_text(body):
+        with open(file, "w") as f:
+            f.write(body)
+        return sdds_file.load(file)
+
+    with pytest.raises(ValueError, match="not an SDDS file"):
+        load_text("# something else\n")
+    with pytest.raises(ValueError, match="without a &data"):
+        load_text("SDDS1\n&column name=x, type=double &end\n")
+    with pytest.raises(NotImplementedError, match="array"):
+        load_text("SDDS1\n&array name=a, type=double &end\n&data mode=ascii &end\n")
+    with pytest.raises(ValueError, match="unknown type"):
+        load_text("SDDS1\n&column name=x, type=quad &end\n&data mode=ascii &end\n")
+    with pytest.raises(ValueError, match="ends after 1 of 3 rows"):
+        load_text("SDDS1\n&column name=x, type=double &end\n&data mode=ascii &end\n3\n1.0\n")
+    with open(file, "wb") as f:
+        f.write(b"SDDS1\n&column name=x, type=double &end\n&data mode=binary &end\n" + b"\x02\x00\x00\x00" + b"\x00" * 8)
+    with pytest.raises(ValueError, match="ends inside a page"):
+        sdds_file.load(file)
+
+
+@pytest.mark.parametrize("mode", ["ascii", "binary"])
+def test_particle_beam_from_an_elegant_sdds_file(tmp_path, mode):
+    import cheetah_amd as ca
+    from cheetah_amd.converters.elegant import ELECTRON_MASS_EV, elegant_to_cheetah_coordinates
+
+    rng = np.random.default_rng(3)
+    n = 64
+    rows6 = np.stack([rng.normal(size=n) * 2e-4, rng.normal(size=n) * 1e-5, rng.normal(size=n) * 1e-4, rng.normal(size=n) * 2e-5,
+                      1e-9 + rng.normal(size=n) * 1e-13, 195.7 * (1 + rng.normal(size=n) * 1e-3)], axis=1)
+    q = np.full(n, 2.5e-13)
+    file = os.path.join(tmp_path, "bunch.sdds")
+    columns = [(c, "double") for c in ("x", "xp", "y", "yp", "t", "p")] + [("particleID", "ulong"), ("q", "double")]
+    rows = [(*map(float, r), i + 1, float(qi)) for i, (r, qi) in enumerate(zip(rows6, q))]
+    write_sdds(file, [("Step", "long"), ("pCentral", "double"), ("Particles", "long")], columns, [((1, 195.7, n), rows)], mode=mode)
+    beam = ca.ParticleBeam.from_elegant(file, **F64)
+    want = elegant_to_cheetah_coordinates(torch.tensor(rows6[None], **F64), torch.tensor([195.7], **F64))
+    assert beam.particles.shape == (1, n, 7) and torch.equal(beam.particles, want)
+    assert torch.equal(beam.particle_charges, torch.tensor(q[None], **F64))
+    assert float(beam.energy[0]) == pytest.approx(np.sqrt((195.7 * ELECTRON_MASS_EV) ** 2 + ELECTRON_MASS_EV ** 2), rel=1e-15)
+    assert beam.species.name == "electron"
+    # no pCentral parameter, no charge column: the first particle is the reference, unit charges (elegant.py:500-519)
+    write_sdds(file, [("Step", "long")], columns[:6], [((1,), [r[:6] for r in rows])], mode=mode)
+    beam2 = ca.ParticleBeam.from_elegant(file, **F64)
+    assert float(beam2.particles[0, 0, 5]) == 0.0 and torch.all(beam2.particle_charges == 1.0)
+    # other conventions are refused like the reference does
+    write_sdds(file, [], [(c, "double") for c in ("r", "pz", "pr", "pphi", "t", "q")], [((), [(0.0,) * 6])], mode=mode)
+    with pytest.raises(ValueError, match="spiffe"):
+        ca.ParticleBeam.from_elegant(file)
+    write_sdds(file, [], [(c, "double") for c in ("x", "y", "z")], [((), [(0.0,) * 3])], mode=mode)
+    with pytest.raises(ValueError, match="Elegant beam convention"):
+        ca.ParticleBeam.from_elegant(file)
