@@ -106,6 +106,22 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+def clone_many(tensors):
+    """Copies of up to 8 device tensors by ONE launch (chx_copy_arrays) instead of one `clone()` kernel each; tensors that
+    carry gradients (under autograd), are not contiguous or do not live on a ROCm device are cloned the ordinary way."""
+    plain = [t.is_cuda and t.is_contiguous() and not (t.requires_grad and torch.is_grad_enabled()) for t in tensors]
+    out = [torch.empty_like(t) if ok else t.clone() for t, ok in zip(tensors, plain)]
+    pairs = [(t, o) for t, o, ok in zip(tensors, out, plain) if ok and t.numel()]
+    for lo in range(0, len(pairs), 8):
+        chunk = pairs[lo:lo + 8]
+        n = len(chunk)
+        check(_lib.lib().chx_copy_arrays((ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in chunk]),
+                                         (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in chunk]),
+                                         (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in chunk]), n, stream_ptr()),
+              "chx_copy_arrays")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # map builders
 def build_rmatrix_raw(kind: int, params, energy, mass_eV: float, n_charges: float, B: int) -> torch.Tensor:

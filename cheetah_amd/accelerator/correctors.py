@@ -22,6 +22,9 @@ class HorizontalCorrector(Element):
     def _builder_params(self):
         return [self.length, self.angle]
 
+    def _builder_scalar_refs(self):
+        return [(t, None) for t in self._settings("length", "angle")]
+
     @property
     def is_skippable(self) -> bool:
         return True
@@ -54,6 +57,9 @@ class CombinedCorrector(Element):
 
     def _builder_params(self):
         return [self.length, self.horizontal_angle, self.vertical_angle]
+
+    def _builder_scalar_refs(self):
+        return [(t, None) for t in self._settings("length", "horizontal_angle", "vertical_angle")]
 
     @property
     def is_skippable(self) -> bool:

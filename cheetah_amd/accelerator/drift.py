@@ -23,6 +23,9 @@ class Drift(Element):
     def _builder_params(self):
         return [self.length]
 
+    def _builder_scalar_refs(self):
+        return [(t, None) for t in self._settings("length")]
+
     @property
     def is_skippable(self) -> bool:
         return self.tracking_method == "linear"

@@ -84,6 +84,15 @@ class Element(nn.Module):
     def _builder_params(self) -> list[torch.Tensor]:
         return []
 
+    def _settings(self, *names):
+        """The named settings, straight from the buffer dictionary when none of them is a Parameter (nn.Module's
+        `__getattr__` costs ~0.4 us per name, and the run plan reads every setting of every touched element per control step)."""
+        b = self.__dict__["_buffers"]
+        try:
+            return [b[n] for n in names]
+        except KeyError:
+            return [getattr(self, n) for n in names]
+
     def _builder_scalar_refs(self):
         """The builder parameters as (tensor, index) pairs for the all-scalar fast path (`_ops.build_compose_scalars`):
         index None = the 0-d tensor itself, an integer = that entry of a 1-d tensor (no view object is created)."""

@@ -32,8 +32,8 @@ class Quadrupole(Element):
         return [self.length, self.k1, self.tilt, self.misalignment[..., 0], self.misalignment[..., 1]]
 
     def _builder_scalar_refs(self):
-        m = self.misalignment
-        return [(self.length, None), (self.k1, None), (self.tilt, None), (m, 0), (m, 1)]
+        length, k1, tilt, m = self._settings("length", "k1", "tilt", "misalignment")
+        return [(length, None), (k1, None), (tilt, None), (m, 0), (m, 1)]
 
     def _dkd_options(self):
         return int(self.num_steps), 3

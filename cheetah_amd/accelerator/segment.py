@@ -86,6 +86,9 @@ class _ElementList(nn.ModuleList):
         return super().pop(key)
 
 
+_IDENTITY = _ops.KIND["identity"]
+
+
 class _FastRun:
     """Persistent device plan of a run (`chx_run_track`): packed kinds / parameter pointers (host arrays, forwarded by
     value) and the device state buffer that remembers the settings the stored map was built from. Valid while
@@ -96,7 +99,7 @@ class _FastRun:
     remembers VALUES, whatever tensor they live in)."""
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
-                 "elements", "revs", "rows", "per_tensors")
+                 "elements", "revs", "rows", "per_tensors", "slots")
 
     def __init__(self, run, dtype, device):
         self.dtype, self.device = dtype, device
@@ -106,21 +109,31 @@ class _FastRun:
         self.per_tensors = [()] * len(self.elements)
         self.state = None
         self.kinds = None
+        self.slots = None
         self.code = _ops.dtype_code(dtype)
         self.refresh()
 
-    def _read(self, e):
-        """(kind, pointers, tensors) of one element, "identity", or None when the element rules the plan out."""
+    def _read(self, e, i):
+        """(kind, pointers, tensors) of element number i, "identity", or None when the element rules the plan out. A setting
+        that still is the tensor OBJECT read last time keeps its slot unexamined (same dtype, device, shape and address): a
+        control step that re-assigns one strength of a quadrupole re-checks one tensor, not five."""
         if not e._static_skippable or e._parameters:
             return None                     # data-dependent skippability (Cavity, sub-Segment) or trainable parameters
         kind = e._chx_kind
         if kind is None:
             return None
-        if kind == _ops.KIND["identity"]:
+        if kind == _IDENTITY:
             return "identity"
-        row, tensors = [None] * _ops.MAX_PARAMS, []
+        refs = e._builder_scalar_refs()
+        old_row, old_tensors = self.rows[i], self.per_tensors[i]
+        reuse = old_row is not None and old_row != "identity" and old_row[0] == kind and len(old_tensors) == len(refs)
+        row = list(old_row[1]) if reuse else [None] * _ops.MAX_PARAMS
+        tensors = []
         dtype, device = self.dtype, self.device
-        for k, (t, index) in enumerate(e._builder_scalar_refs()):
+        for k, (t, index) in enumerate(refs):
+            tensors.append(t)
+            if reuse and t is old_tensors[k]:
+                continue
             if t.dtype != dtype or t.device != device or t.requires_grad:
                 return None
             if index is None:
@@ -131,60 +144,63 @@ class _FastRun:
                 if t.dim() != 1 or not t.is_contiguous():
                     return None
                 row[k] = t.data_ptr() + index * t.element_size()
-            tensors.append(t)
         return kind, row, tensors
 
     def refresh(self) -> None:
         self.epoch = Element._epoch
         self.ok = False
-        changed = []
+        revs, rows = self.revs, self.rows
+        changed, same_layout = [], self.kinds is not None
         for i, e in enumerate(self.elements):
             rev = e.__dict__["_revision"]
-            if rev != self.revs[i]:
-                got = self._read(e)
-                self.revs[i] = rev
+            if rev != revs[i]:
+                got = self._read(e, i)
                 if got is None:
-                    self.rows[i] = None
-                    self.revs[i] = None     # look again next time
+                    rows[i] = None
+                    revs[i] = None     # look again next time
+                    self.kinds = None  # whatever is patched later starts from a full rebuild
                     return
-                self.rows[i] = got if got == "identity" else (got[0], got[1])
-                self.per_tensors[i] = () if got == "identity" else tuple(got[2])
+                old = rows[i]
+                if got == "identity":
+                    same_layout = same_layout and old == "identity"
+                    rows[i], self.per_tensors[i] = got, ()
+                else:
+                    same_layout = same_layout and old is not None and old != "identity" and old[0] == got[0]
+                    rows[i], self.per_tensors[i] = (got[0], got[1]), tuple(got[2])
+                revs[i] = rev
                 changed.append(i)
-            elif self.rows[i] is None:
+            elif rows[i] is None:
                 return
-        kinds = [r[0] for r in self.rows if r != "identity"]
-        E = len(kinds)
-        if E == 0 or E > 192:
-            return
-        if self.kinds is not None and len(self.kinds) == E and list(self.kinds) == kinds:
-            # same kinds in the same places: patch the pointers of the elements that changed
-            slot = 0
-            for i, r in enumerate(self.rows):
-                if r == "identity":
-                    continue
-                if i in changed:
-                    base = slot * _ops.MAX_PARAMS
-                    for k, v in enumerate(r[1]):
-                        self.ptrs[base + k] = v
-                slot += 1
-        else:
-            pointers = []
-            for r in self.rows:
+        if same_layout:
+            # same kinds in the same places (the usual control step): patch the pointers of the elements that changed
+            ptrs, slots = self.ptrs, self.slots
+            for i in changed:
+                r = rows[i]
                 if r != "identity":
+                    base = slots[i] * _ops.MAX_PARAMS
+                    for k, v in enumerate(r[1]):
+                        ptrs[base + k] = v
+        else:
+            kinds, pointers, slots = [], [], [None] * len(rows)
+            for i, r in enumerate(rows):
+                if r != "identity":
+                    slots[i] = len(kinds)
+                    kinds.append(r[0])
                     pointers += r[1]
-            self.E = E
+            E = len(kinds)
+            if E == 0 or E > 192:
+                self.kinds = None
+                return
+            self.E, self.slots = E, slots
             self.kinds = (ctypes.c_int32 * E)(*kinds)
             self.ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*pointers)
             self.state_bytes = _lib.lib().chx_run_state_bytes(E)
             self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=self.device)
-        # kept alive: the plan holds their addresses (each tensor once: `misalignment` feeds two parameters)
-        seen = {}
-        for ts in self.per_tensors:
-            for t in ts:
-                seen[id(t)] = t
-        if len(seen) > 400:
+        # kept alive: the plan holds their addresses (a tensor may appear more than once: `misalignment` feeds two parameters)
+        tensors = tuple([t for ts in self.per_tensors for t in ts])
+        if len(tensors) > 400:
             return
-        self.tensors = tuple(seen.values())
+        self.tensors = tensors
         self.ok = True
 
 
@@ -285,9 +301,21 @@ class Segment(Element):
         if cached is not None and cached[2] == Element._epoch and cached[3] is None:
             return cached[1]     # nothing was assigned anywhere since, and no element's skippability depends on tensor values
         elements = list(self.elements)
-        key = (tuple([id(e) for e in elements]), tuple([e.is_skippable for e in elements]))
+        ids = tuple([id(e) for e in elements])
+        revs = [e.__dict__["_revision"] for e in elements]
+        if cached is not None and cached[3] is None and cached[0][0] == ids:
+            # the same element objects, none with value-dependent skippability (Cavity voltage, nested segments): only an
+            # element whose own revision moved can have changed its skippability
+            skippable = list(cached[0][1])
+            for i, (rev, old) in enumerate(zip(revs, cached[4])):
+                if rev != old:
+                    skippable[i] = elements[i].is_skippable
+            skippable = tuple(skippable)
+        else:
+            skippable = tuple([e.is_skippable for e in elements])
+        key = (ids, skippable)
         if cached is not None and cached[0] == key:
-            self.__dict__["_plan_cache"] = (key, cached[1], Element._epoch, cached[3])
+            self.__dict__["_plan_cache"] = (key, cached[1], Element._epoch, cached[3], revs)
             return cached[1]
         plan, run = [], []
         for e in elements:
@@ -303,7 +331,7 @@ class Segment(Element):
         # elements whose skippability is a function of tensor VALUES (Cavity voltage, nested segments): the list must be
         # re-examined on every call while there are any
         dynamic = [m for m in self.modules() if isinstance(m, Element) and m is not self and not m._static_skippable] or None
-        self.__dict__["_plan_cache"] = (key, plan, Element._epoch, dynamic)
+        self.__dict__["_plan_cache"] = (key, plan, Element._epoch, dynamic, revs)
         return plan
 
     # ---- per-run products ------------------------------------------------------------------------------

@@ -355,3 +355,55 @@ extern "C" int chx_cavity_track(const void* x_in, const void* R, const double* c
     return dtype == CHX_F32 ? launch_tiles<float, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s)
                             : launch_tiles<double, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s);
 }
+
+// ---- several device arrays copied by ONE launch -----------------------------------------------------------------------
+// A Screen records a copy of the incoming beam (screen.py:190 `incoming.clone()`): five tensors, two of them scalars — five
+// launches of a framework copy kernel, or one of this. Arrays travel by value in the kernel arguments; blockIdx.y picks the
+// array, 16-byte chunks when source and destination allow, bytes otherwise.
+namespace {
+constexpr int kCopyMax = 8;
+struct CopyArgs {
+    const void* src[kCopyMax];
+    void* dst[kCopyMax];
+    int64_t bytes[kCopyMax];
+};
+
+__global__ __launch_bounds__(CHX_BLOCK) void copy_arrays_kernel(CopyArgs a) {
+    const int k = blockIdx.y;
+    const char* __restrict__ s = (const char*)a.src[k];
+    char* __restrict__ d = (char*)a.dst[k];
+    const int64_t n = a.bytes[k];
+    const int64_t tid = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x, nthreads = (int64_t)gridDim.x * CHX_BLOCK;
+    int64_t done = 0;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const int64_t n16 = n >> 4;
+        const float4* __restrict__ s4 = (const float4*)s;
+        float4* __restrict__ d4 = (float4*)d;
+        for (int64_t i = tid; i < n16; i += nthreads) d4[i] = s4[i];
+        done = n16 << 4;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int chx_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream) {
+    if (!src || !dst || !bytes || n < 1 || n > kCopyMax) return CHX_ERR_INVALID_ARG;
+    CopyArgs a;
+    int64_t most = 0;
+    for (int k = 0; k < kCopyMax; ++k) {
+        a.src[k] = k < n ? src[k] : nullptr;
+        a.dst[k] = k < n ? dst[k] : nullptr;
+        a.bytes[k] = k < n ? bytes[k] : 0;
+        if (k < n) {
+            if (bytes[k] < 0 || (bytes[k] > 0 && (!src[k] || !dst[k]))) return CHX_ERR_INVALID_ARG;
+            most = bytes[k] > most ? bytes[k] : most;
+        }
+    }
+    if (most == 0) return CHX_OK;
+    // 64 bytes per lane and pass: a 28 MB particle array gets 1709 workgroups, a scalar one
+    int64_t blocks = (most + CHX_BLOCK * 64 - 1) / (CHX_BLOCK * 64);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_arrays_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(CHX_BLOCK), 0, (hipStream_t)stream, a);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}

@@ -466,10 +466,8 @@ class ParticleBeam(Beam):
     def _snapshot(self) -> "ParticleBeam":
         """Copy of the tensor state (autograd-connected) sharing the species object: what a Screen records, so that
         later in-place edits of this beam do not reach the reading. Cheaper than `clone()` (no new Species tensors)."""
-        return self.__class__(particles=self.particles.clone(), energy=self.energy.clone(),
-                              particle_charges=self.particle_charges.clone(),
-                              survival_probabilities=self.survival_probabilities.clone(), s=self.s.clone(),
-                              species=self.species)
+        p, e, q, w, s = _ops.clone_many((self.particles, self.energy, self.particle_charges, self.survival_probabilities, self.s))
+        return self.__class__(particles=p, energy=e, particle_charges=q, survival_probabilities=w, s=s, species=self.species)
 
     def _view(self) -> "ParticleBeam":
         """New beam object sharing this beam's tensors (zero-copy). Pass-through elements return this

@@ -408,6 +408,9 @@ int chx_sc_kick(const void* x_in, const void* charge, const void* survival, cons
                 const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
                 const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
                 void* side_stream, const void* post_map /*[BR][7][7] or NULL*/, int64_t BR);
+/* n <= 8 device arrays copied by one launch: dst[k][0 .. bytes[k]) = src[k][...] (host arrays of device pointers and byte
+ * counts). What a Screen's record of the incoming beam costs (screen.py:190 `incoming.clone()`: five tensors). */
+int chx_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
 /* SI conversion on its own (particle_beam.py:1262-1346), used by to_xyz_pxpypz/from_xyz_pxpypz */
 int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B, int64_t Bx,
                       int64_t Be, int64_t N, int dtype, void* xp_out, void* stream);

@@ -43,3 +43,29 @@ def test_derived_beams_match_reference(golden):
     assert sub.num_particles == 100 and float(sub.total_charge) == pytest.approx(float(beam.total_charge), rel=1e-12)
     rows = {tuple(r) for r in beam.particles.cpu().numpy().round(15).tolist()}
     assert all(tuple(r) in rows for r in sub.particles.cpu().numpy().round(15).tolist())
+
+
+def test_clone_many_copies_every_array_in_one_launch():
+    """_ops.clone_many (chx_copy_arrays): sizes from one scalar to a particle array, unaligned views, dtypes mixed, an empty
+    tensor, a non-contiguous one and one that carries gradients (those two fall back to `clone()`)."""
+    import torch
+
+    from cheetah_amd import _ops
+
+    torch.manual_seed(0)
+    big = torch.randn(100_003, 7, device="cuda")
+    base = torch.randn(1000, device="cuda", dtype=torch.float64)
+    g = torch.randn(5, device="cuda", requires_grad=True)
+    tensors = [big, torch.tensor(3.5, device="cuda"), base[1:], torch.empty(0, device="cuda"), big[:, ::2], g,
+               torch.arange(17, device="cuda", dtype=torch.int32), base[3:4], torch.randn(33, device="cuda", dtype=torch.float16),
+               torch.randn(9, device="cuda")]
+    copies = _ops.clone_many(tensors)
+    assert len(copies) == len(tensors)
+    for t, c in zip(tensors, copies):
+        assert c.shape == t.shape and c.dtype == t.dtype and torch.equal(c, t)
+        assert t.numel() == 0 or c.data_ptr() != t.data_ptr()
+    assert copies[5].requires_grad and copies[5].grad_fn is not None        # still connected to the graph
+    with torch.no_grad():
+        assert not _ops.clone_many([g])[0].requires_grad
+    big.add_(1.0)
+    assert not torch.equal(copies[0], big)
