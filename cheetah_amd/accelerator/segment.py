@@ -99,7 +99,7 @@ class _FastRun:
     remembers VALUES, whatever tensor they live in)."""
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
-                 "elements", "revs", "rows", "per_tensors", "slots")
+                 "elements", "revs", "rows", "per_tensors", "slots", "R_view")
 
     def __init__(self, run, dtype, device):
         self.dtype, self.device = dtype, device
@@ -110,6 +110,7 @@ class _FastRun:
         self.state = None
         self.kinds = None
         self.slots = None
+        self.R_view = None
         self.code = _ops.dtype_code(dtype)
         self.refresh()
 
@@ -196,6 +197,7 @@ class _FastRun:
             self.ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*pointers)
             self.state_bytes = _lib.lib().chx_run_state_bytes(E)
             self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=self.device)
+            self.R_view = None
         # kept alive: the plan holds their addresses (a tensor may appear more than once: `misalignment` feeds two parameters)
         tensors = tuple([t for ts in self.per_tensors for t in ts])
         if len(tensors) > 400:
@@ -441,6 +443,33 @@ class Segment(Element):
                                             x.data_ptr(), out.data_ptr(), x.shape[0], _ops.stream_ptr()), "chx_run_track")
         return out
 
+    @staticmethod
+    def _run_map_fast(run: _Run, ref: torch.Tensor, energy: torch.Tensor, species: Species):
+        """The run's composed map as a (7, 7) tensor living inside the persistent plan's device state (chx_run_map: one
+        launch that re-validates the settings and rebuilds only if one changed), or None when the run does not qualify.
+        `ref` gives dtype and device. The tensor is overwritten by the next call: for immediate use on the same stream."""
+        if not ref.is_cuda or energy.dim() != 0:
+            return None
+        fr = run.fast
+        if fr is None or fr.dtype != ref.dtype or fr.device != ref.device:
+            fr = run.fast = _FastRun(run, ref.dtype, ref.device)
+        elif fr.epoch != Element._epoch:
+            fr.refresh()
+        if not fr.ok or energy.dtype != fr.dtype or energy.device != fr.device:
+            return None
+        if torch.is_grad_enabled() and (energy.requires_grad or species.mass_eV.requires_grad
+                                        or species.num_elementary_charges.requires_grad or _any_requires_grad(*fr.tensors)):
+            return None
+        R_addr = ctypes.c_void_p()
+        _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, energy.data_ptr(), species.mass_eV_float,
+                                          species.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
+                                          ctypes.byref(R_addr), _ops.stream_ptr()), "chx_run_map")
+        view = fr.R_view
+        if view is None or view.data_ptr() != R_addr.value:
+            off = R_addr.value - fr.state.data_ptr()
+            view = fr.R_view = fr.state.view(torch.uint8)[off:off + 49 * ref.element_size()].view(ref.dtype).view(7, 7)
+        return view
+
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species):
         plan = self._plan()
         if len(plan) == 1 and plan[0][0] == "run":
@@ -461,7 +490,11 @@ class Segment(Element):
         if isinstance(incoming, ParameterBeam):
             for kind, item in self._plan():
                 if kind == "run":
-                    tm = self._run_map(item, incoming.energy, incoming.species)
+                    tm = None
+                    if not (torch.is_grad_enabled() and (incoming.mu.requires_grad or incoming.cov.requires_grad)):
+                        tm = self._run_map_fast(item, incoming.mu, incoming.energy, incoming.species)
+                    if tm is None:
+                        tm = self._run_map(item, incoming.energy, incoming.species)
                     mu, cov = _ops.parameter_track(incoming.mu, incoming.cov, tm)
                     incoming = ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge,
                                              s=self._run_s(item, incoming.s), species=incoming.species)

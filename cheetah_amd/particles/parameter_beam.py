@@ -25,14 +25,18 @@ class ParameterBeam(Beam):
         dtype = dtype if dtype is not None else mu.dtype
         fk = {"device": device, "dtype": dtype}
         assert mu.shape[-1] == 7 and cov.shape[-2:] == (7, 7), "mu must be (…, 7) and cov (…, 7, 7)"
-        self.species = species if species is not None else Species("electron", **fk)
+        self._modules["species"] = species if species is not None else Species("electron", **fk)
+        # a new beam object per tracked run and per diagnostic: the state tensors are entered into the module's dictionaries
+        # directly (same result as five `register_buffer` / `register_parameter` calls, ~15 us cheaper) and read back through
+        # the class-level properties installed below instead of nn.Module.__getattr__
+        buffers, parameters = self._buffers, self._parameters
         for name, value in (("mu", mu), ("cov", cov), ("energy", energy),
                             ("total_charge", total_charge if total_charge is not None else torch.tensor(0.0, **fk)),
                             ("s", s if s is not None else torch.tensor(0.0, **fk))):
             if isinstance(value, torch.nn.Parameter):
-                self.register_parameter(name, value)
+                parameters[name] = value
             else:
-                self.register_buffer(name, value)
+                buffers[name] = value
 
     # ------------------------------------------------------------------ factories
     @classmethod
@@ -183,8 +187,8 @@ class ParameterBeam(Beam):
         return cls(mu.to(dtype), cov.to(dtype), energy, total_charge=total_charge, s=s, species=species)
 
     def _snapshot(self) -> "ParameterBeam":
-        return self.__class__(self.mu.clone(), self.cov.clone(), self.energy.clone(), total_charge=self.total_charge.clone(),
-                              s=self.s.clone(), species=self.species)
+        mu, cov, energy, q, s = _ops.clone_many((self.mu, self.cov, self.energy, self.total_charge, self.s))
+        return self.__class__(mu, cov, energy, total_charge=q, s=s, species=self.species)
 
     def _view(self) -> "ParameterBeam":
         return self.__class__(self.mu, self.cov, self.energy, total_charge=self.total_charge, s=self.s,
@@ -209,3 +213,33 @@ def _install_moment_properties() -> None:
 
 
 _install_moment_properties()
+
+
+def _install_state_accessors() -> None:
+    """Class-level data descriptors for the five state tensors and the species (see ParticleBeam): reads are one or two
+    dictionary lookups instead of nn.Module.__getattr__; a tensor assigned later lands where nn.Module would put it."""
+    for name in ("mu", "cov", "energy", "total_charge", "s"):
+        def getter(self, name=name):
+            v = self._buffers.get(name)
+            return v if v is not None else self._parameters[name]
+
+        def setter(self, value, name=name):
+            if isinstance(value, torch.nn.Parameter):
+                self._buffers.pop(name, None)
+                self._parameters[name] = value
+            else:
+                self._parameters.pop(name, None)
+                self._buffers[name] = value
+
+        setattr(ParameterBeam, name, property(getter, setter))
+
+    def get_species(self):
+        return self._modules["species"]
+
+    def set_species(self, value):
+        self._modules["species"] = value
+
+    ParameterBeam.species = property(get_species, set_species)
+
+
+_install_state_accessors()

@@ -309,3 +309,48 @@ def test_run_of_scalar_settings_with_gradients_is_one_autograd_node(dt):
                 dn[i].sub_(h)
                 fd = (float(run(True, up, t(1.2e8))) - float(run(True, dn, t(1.2e8)))) / (2 * h)
                 assert float(va[i].grad) == pytest.approx(fd, rel=2e-5, abs=1e-12)
+
+
+def test_parameter_beam_takes_the_persistent_plan_too():
+    """ParameterBeam through a run of scalar settings: the map comes from the persistent device plan (chx_run_map); the
+    result equals the general path (maps built and composed per call) bit for bit, and follows in-place edits and
+    re-assignments of the settings."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator.segment import Segment
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    q1 = ca.Quadrupole(t(0.2), k1=t(4.2), name="q1", **kw)
+    seg = ca.Segment([ca.Drift(t(0.4), **kw), q1, ca.Marker(), ca.HorizontalCorrector(t(0.03), angle=t(2e-4), **kw),
+                      ca.Drift(t(0.6), **kw), ca.Quadrupole(t(0.2), k1=t(-3.0), **kw)])
+    beam = ca.ParameterBeam.from_twiss(beta_x=t(3.0), beta_y=t(8.0), energy=t(1.5e8), **kw)
+
+    def general():
+        run = seg._plan()[0][1]
+        maps = [e.first_order_transfer_map(beam.energy, beam.species) for e in run.elements]
+        from cheetah_amd import _ops
+
+        tm = _ops.compose_maps([m for m, e in zip(maps, run.elements) if e._chx_kind != _ops.KIND["identity"]], (), dt, maps[0].device)
+        return _ops.parameter_track(beam.mu, beam.cov, tm)
+
+    calls = []
+    orig, descriptor = Segment._run_map_fast, Segment.__dict__["_run_map_fast"]
+    Segment._run_map_fast = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        out = seg.track(beam)
+    finally:
+        Segment._run_map_fast = descriptor
+    assert calls and seg._plan()[0][1].fast is not None and seg._plan()[0][1].fast.ok
+    mu, cov = general()
+    assert torch.equal(out.mu, mu.reshape(out.mu.shape)) and torch.equal(out.cov, cov.reshape(out.cov.shape))
+    q1.k1.fill_(-1.5)                                   # in place: found by the device
+    out2 = seg.track(beam)
+    mu, cov = general()
+    assert torch.equal(out2.mu, mu.reshape(out2.mu.shape)) and not torch.equal(out2.cov, out.cov)
+    q1.k1 = t(7.0)                                      # re-assigned: pointer patched on the host
+    out3 = seg.track(beam)
+    mu, cov = general()
+    assert torch.equal(out3.cov, cov.reshape(out3.cov.shape)) and not torch.equal(out3.cov, out2.cov)
+    assert torch.equal(out.cov, out.cov.clone())        # earlier results are separate tensors, not views of the plan's state
+    assert float(out3.s) == pytest.approx(1.43, rel=1e-6)
