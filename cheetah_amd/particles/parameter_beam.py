@@ -221,7 +221,11 @@ def _install_state_accessors() -> None:
     for name in ("mu", "cov", "energy", "total_charge", "s"):
         def getter(self, name=name):
             v = self._buffers.get(name)
-            return v if v is not None else self._parameters[name]
+            if v is None:
+                v = self._parameters.get(name)
+                if v is None:     # nn.Module.__setattr__ probes with hasattr() while it moves a name between the dictionaries
+                    raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+            return v
 
         def setter(self, value, name=name):
             if isinstance(value, torch.nn.Parameter):
