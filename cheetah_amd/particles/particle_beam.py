@@ -515,9 +515,15 @@ def _install_buffer_accessors() -> None:
     through nn.Module.__setattr__, which stores tensors into `_buffers`."""
     for name in ("particles", "energy", "particle_charges", "survival_probabilities", "s"):
         def getter(self, name=name):
-            return self._buffers[name]
+            v = self._buffers.get(name)
+            if v is None:
+                v = self._parameters.get(name)
+                if v is None:     # nn.Module.__setattr__ probes with hasattr() while it moves a name between the dictionaries
+                    raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+            return v
 
         def setter(self, value, name=name):
+            self._parameters.pop(name, None)
             self._buffers[name] = value
 
         setattr(ParticleBeam, name, property(getter, setter))

@@ -261,3 +261,25 @@ def test_register_fft_butterflies_on_the_host(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "f32: ok" in out.stdout and "f64: ok" in out.stdout
+
+
+def test_beam_state_can_become_a_parameter():
+    """The state tensors of both beam classes are read through class-level properties; assigning an nn.Parameter (a beam
+    that is optimised) must move the name into `_parameters` like nn.Module does — and, like any nn.Module, refuse a plain
+    tensor for that name afterwards."""
+    import cheetah_amd as ca
+
+    b = ca.ParticleBeam(torch.zeros(10, 7), torch.tensor(1e8))
+    b.particles = torch.nn.Parameter(torch.ones(10, 7))
+    assert isinstance(b.particles, torch.nn.Parameter) and "particles" in b._parameters and "particles" not in b._buffers
+    assert [n for n, _ in b.named_parameters()] == ["particles"]
+    with pytest.raises(TypeError, match="cannot assign"):
+        b.particles = torch.full((10, 7), 2.0)
+    b.energy = torch.tensor(2e8)                       # a buffer stays a buffer
+    assert "energy" in b._buffers and float(b.energy) == 2e8
+    p = ca.ParameterBeam(torch.zeros(7), torch.eye(7), torch.tensor(1e8))
+    p.mu = torch.nn.Parameter(torch.ones(7))
+    assert isinstance(p.mu, torch.nn.Parameter) and "mu" in p._parameters and "mu" not in p._buffers
+    p.cov = 2 * torch.eye(7)
+    assert "cov" in p._buffers and float(p.cov[0, 0]) == 2.0
+    assert not hasattr(ca.ParticleBeam.__new__(ca.ParticleBeam), "nonexistent_attribute")
