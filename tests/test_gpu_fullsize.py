@@ -337,3 +337,59 @@ def test_far_field_green_function_vs_corner_table(ca, aspect, g):
     err_exact = float((exact - exact64).abs().max()) / scale
     assert err_fast < 2e-6, (err_fast, err_exact)
     assert err_fast < 4 * err_exact + 1e-7, (err_fast, err_exact)
+
+
+def test_more_than_two_to_the_31_elements(ca, oracle):
+    """3.2e8 particles: 2.24e9 coordinates, 9 GB per array — past 2^31 elements and 2^32 bytes, where a 32-bit row or byte
+    offset would wrap. The apply kernel on sampled rows (including the last ones) bit for bit against the oracle, the
+    one-pass moments against a float64 reduction of column slices, and a Screen image that conserves the charge."""
+    from cheetah_amd import _ops
+
+    N = 320_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip("needs 40 GB of free device memory")
+    dt = torch.float32
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.empty((N, 7), dtype=dt, device="cuda")
+    chunk = 40_000_000
+    for lo in range(0, N, chunk):          # filled in pieces: the generator's scratch stays small
+        x[lo:lo + chunk].normal_(0.0, 1e-3, generator=gen)
+    x[:, 6] = 1.0
+    R = torch.eye(7, dtype=dt, device="cuda") + 0.1 * torch.randn(7, 7, dtype=dt, device="cuda", generator=gen)
+    R[6] = 0.0
+    R[6, 6] = 1.0
+    R[:6, 6] = torch.randn(6, dtype=dt, device="cuda", generator=gen) * 1e-4
+    y = _ops.apply_map(x, R)
+    assert y.shape == (N, 7)
+    rows = torch.cat([torch.arange(0, 4096, device="cuda"), torch.randint(0, N, (8192,), device="cuda", generator=gen),
+                      torch.arange(2**31 // 7 - 2048, 2**31 // 7 + 2048, device="cuda"),          # around element 2^31
+                      torch.arange(2**32 // 28 - 2048, 2**32 // 28 + 2048, device="cuda"),        # around byte 2^32
+                      torch.arange(N - 4096, N, device="cuda")])
+    want = oracle.apply(x[rows].cpu().numpy()[None], R.cpu().numpy()[None], mode=1)[0]      # mode 1: the kernel's fma chain
+    assert np.array_equal(y[rows].cpu().numpy(), want)
+    # moments: weights on, so that the weight column is addressed past 2^31 as well
+    w = torch.ones(N, dtype=dt, device="cuda")
+    w[::3] = 0.5
+    mom = _ops.moments(y, w).reshape(-1).cpu().numpy()                    # [W, W2, mu(6), cov upper triangle(21)]
+    W = 0.0
+    mu = np.zeros(2)
+    m2 = np.zeros(2)
+    for lo in range(0, N, chunk):
+        wc = w[lo:lo + chunk].double()
+        c = y[lo:lo + chunk, [0, 5]].double()
+        W += float(wc.sum())
+        mu += (c * wc[:, None]).sum(dim=0).cpu().numpy()
+        m2 += (c * c * wc[:, None]).sum(dim=0).cpu().numpy()
+    mu /= W
+    assert mom[0] == pytest.approx(W, rel=1e-12)
+    assert mom[2] == pytest.approx(mu[0], rel=1e-9, abs=1e-15) and mom[7] == pytest.approx(mu[1], rel=1e-9, abs=1e-15)
+    W2 = float((w.double() ** 2).sum())
+    var_x = (m2[0] - W * mu[0] ** 2) / (W - W2 / W)
+    assert mom[8] == pytest.approx(var_x, rel=1e-8)
+    del x
+    # Screen image of all 3.2e8 particles: every particle lands on the (generous) screen, the charge is conserved
+    q = torch.full((N,), 1e-18, dtype=dt, device="cuda")
+    ext = torch.tensor([[-0.05, 0.05], [-0.05, 0.05]], dtype=dt, device="cuda")
+    img = _ops.cic_deposit(y, (0, 2), (512, 512), ext, charge=q, survival=w, abs_charge=True, transpose_2d=True)
+    assert float(img.double().sum()) == pytest.approx(W * 1e-18, rel=1e-5)
