@@ -393,3 +393,24 @@ def test_more_than_two_to_the_31_elements(ca, oracle):
     ext = torch.tensor([[-0.05, 0.05], [-0.05, 0.05]], dtype=dt, device="cuda")
     img = _ops.cic_deposit(y, (0, 2), (512, 512), ext, charge=q, survival=w, abs_charge=True, transpose_2d=True)
     assert float(img.double().sum()) == pytest.approx(W * 1e-18, rel=1e-5)
+
+
+def test_space_charge_kick_of_fifty_million_particles(ca):
+    """One kick of 5e7 particles on 128^3 (sorted deposit with 7e7 records, 1.4 GB of them): finite, and — same bunch charge,
+    same distribution — the same mean kick as 1e6 particles to the sampling noise."""
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    stats = {}
+    for n in (1_000_000, 50_000_000):
+        torch.manual_seed(1)
+        beam = ca.ParticleBeam.from_parameters(num_particles=n, total_charge=t(1e-9), energy=t(1e8), sigma_x=t(2e-4), sigma_y=t(2e-4),
+                                               sigma_tau=t(1e-4), **kw)
+        out = ca.SpaceChargeKick(t(0.5), grid_shape=(128, 128, 128), **kw).track(beam)
+        assert bool(torch.isfinite(out.particles).all())
+        d = out.particles - beam.particles
+        assert float(d[:, [0, 2, 6]].abs().max()) == 0.0
+        stats[n] = [float(d[:, c].abs().mean()) for c in (1, 3, 5)]
+        del beam, out, d
+    for a, b in zip(stats[1_000_000], stats[50_000_000]):
+        assert a > 0 and b == pytest.approx(a, rel=0.02)
