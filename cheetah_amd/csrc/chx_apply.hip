@@ -188,6 +188,81 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_tile_kernel(
     tile_store<T, TP>(gout, lds, np * 7, out_vec, true);
 }
 
+// ---- one map per batch row, wave-private staging (MODE 0 only) ------------------------------------------------------------
+// The kernel above stages a tile per WORKGROUP: two barriers per tile. Here every wave owns 64 * PPT consecutive rows —
+// a whole number of 16-byte chunks — loads them into its own LDS slice, applies the map and streams them out: no workgroup
+// barrier at all, the four waves of a workgroup run independently. Needs 16-byte aligned batch rows on both sides.
+template <typename T, int PPT>
+__global__ __launch_bounds__(CHX_BLOCK) void apply_wave_kernel(const T* __restrict__ x_in, const T* __restrict__ R,
+                                                               T* __restrict__ x_out, int64_t B, int64_t Bx, int64_t BR,
+                                                               int64_t N) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    constexpr int TP = PPT * CHX_BLOCK;
+    constexpr int WP = PPT * 64, WE = WP * 7, WV = WE / VN;
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    const int64_t tiles_per_row = (N + TP - 1) / TP;
+    const int64_t b = blockIdx.x / tiles_per_row;
+    const int64_t t = blockIdx.x - b * tiles_per_row;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n0 = t * TP + wave * WP;                 // first row of this wave
+    if (n0 >= N) return;
+    const int valid = (int)((N - n0 < WP) ? (N - n0) : WP);
+    const int vchunks = valid * 7 / VN;
+    const int64_t in_row = (Bx == 1) ? 0 : b;
+    const T* __restrict__ gin = x_in + (in_row * N + n0) * 7;
+    T* __restrict__ gout = x_out + (b * N + n0) * 7;
+    T* wl = lds + wave * WE;
+    const bool nt_in = !(Bx == 1 && B > 1);
+    {
+        const V* __restrict__ gv = reinterpret_cast<const V*>(gin);
+        V* lv = reinterpret_cast<V*>(wl);
+#pragma unroll
+        for (int c = 0; c < (WV + 63) / 64; ++c) {
+            const int v = c * 64 + lane;
+            if (v < vchunks) lv[v] = nt_in ? chx_nt_load(gv + v) : gv[v];
+        }
+        for (int e = vchunks * VN + lane; e < valid * 7; e += 64) wl[e] = gin[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const T* __restrict__ Rb = R + ((BR == 1) ? 0 : b) * 49;
+    T y[PPT][7];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = k * 64 + lane;
+        T x[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) x[j] = (p < valid) ? wl[p * 7 + j] : (T)0;
+        apply7<T>(Rb, x, y[k]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = k * 64 + lane;
+        if (p < valid) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) wl[p * 7 + j] = y[k][j];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        V* __restrict__ gv = reinterpret_cast<V*>(gout);
+        const V* lv = reinterpret_cast<const V*>(wl);
+#pragma unroll
+        for (int c = 0; c < (WV + 63) / 64; ++c) {
+            const int v = c * 64 + lane;
+            if (v < vchunks) chx_nt_store(lv[v], gv + v);
+        }
+        for (int e = vchunks * VN + lane; e < valid * 7; e += 64) gout[e] = wl[e];
+    }
+}
+
 // ---- shared-input kernel (Bx == 1, B > 1): one x tile, many maps ---------------------------
 // grid = (tiles over N, batch chunks). Each block keeps its particles in registers and loops
 // over its chunk of batch rows; writes dominate (28 B per (batch, particle) in fp32).
@@ -233,6 +308,69 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_shared_kernel(
     }
 }
 
+// The same with wave-private staging: every wave keeps 64 * PPT consecutive particles, writes its outgoing rows into its own
+// LDS slice and streams them out as 16-byte chunks (64 rows of 28 / 56 bytes are a whole number of chunks) — no workgroup
+// barrier per batch row, so the four waves of a workgroup drift apart and their stores overlap the others' arithmetic.
+// Requires every batch row of the output to start on a 16-byte boundary (N * 7 * sizeof(T) % 16 == 0, aligned base).
+template <typename T, int PPT>
+__global__ __launch_bounds__(CHX_BLOCK) void apply_shared_wave_kernel(
+    const T* __restrict__ x_in, const T* __restrict__ R, T* __restrict__ x_out, int64_t B,
+    int64_t N, int64_t rows_per_chunk, int in_vec_ok) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    constexpr int TP = PPT * CHX_BLOCK;
+    constexpr int WP = PPT * 64;                 // particles per wave
+    constexpr int WE = WP * 7;                   // elements per wave
+    constexpr int WV = WE / VN;                  // 16-byte chunks per wave
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t b1 = (b0 + rows_per_chunk < B) ? b0 + rows_per_chunk : B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    tile_load<T, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0);
+    __syncthreads();
+    T x[PPT][7];
+    T* wl = lds + wave * WE;                      // this wave's slice: rows wave * WP + [0, WP)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = wave * WP + k * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? wl[(k * 64 + lane) * 7 + j] : (T)0;
+    }
+    // from here on a wave touches only its own slice
+    const int valid = (np - wave * WP < 0) ? 0 : ((np - wave * WP < WP) ? (np - wave * WP) : WP);   // rows of this wave that exist
+    const int vchunks = valid * 7 / VN;           // whole chunks inside the valid rows
+    for (int64_t b = b0; b < b1; ++b) {
+        const T* __restrict__ Rb = R + b * 49;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            T y[7];
+            apply7<T>(Rb, x[k], y);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) wl[(k * 64 + lane) * 7 + j] = y[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T* __restrict__ gout = x_out + (b * N + n0 + wave * WP) * 7;
+        V* __restrict__ gv = reinterpret_cast<V*>(gout);
+        const V* lv = reinterpret_cast<const V*>(wl);
+#pragma unroll
+        for (int c = 0; c < (WV + 63) / 64; ++c) {
+            const int v = c * 64 + lane;
+            if (v < vchunks) chx_nt_store(lv[v], gv + v);
+        }
+        if (vchunks < WV) {                       // the last tile of a row: a few elements beyond the last whole chunk
+            for (int e = vchunks * VN + lane; e < valid * 7; e += 64) gout[e] = wl[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <typename T> struct tile_cfg;
 template <> struct tile_cfg<float> { static constexpr int PPT = 2; };   // 512 rows, 14 KiB LDS
 template <> struct tile_cfg<double> { static constexpr int PPT = 1; };  // 256 rows, 14 KiB LDS
@@ -253,12 +391,30 @@ int launch_tiles_ppt(const void* x_in, const void* R, void* x_out, const double*
 // Tile size: measured on MI355X (benchmarks/apply_variants.hip, fp32): 512-row tiles win while the
 // working set is Infinity-Cache resident (5.76 vs 5.71 TB/s at N = 1e6), 256-row tiles win once the
 // launch streams from HBM (5.74 vs 5.42 TB/s at N = 1.6e7; a float4 copy of the same bytes: 5.83 TB/s).
+template <typename T, int PPT>
+int launch_wave(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx, int64_t BR, int64_t N, hipStream_t s) {
+    constexpr int TP = PPT * CHX_BLOCK;
+    const int64_t tiles = ((N + TP - 1) / TP) * B;
+    if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL((apply_wave_kernel<T, PPT>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const T*)x_in, (const T*)R,
+                       (T*)x_out, B, Bx, BR, N);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 template <typename T, int MODE>
 int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coeffs, int64_t B,
                  int64_t Bx, int64_t BR, int64_t N, int E, hipStream_t s) {
     constexpr int PPT = tile_cfg<T>::PPT;
-    if (PPT > 1 && MODE == 0 && B * N * 7 * (int64_t)sizeof(T) > (int64_t)96 * 1024 * 1024)
-        return launch_tiles_ppt<T, 1, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
+    if (MODE == 0 && B * N * 7 * (int64_t)sizeof(T) > (int64_t)96 * 1024 * 1024) {
+        // the launch streams from HBM: 256-row tiles (above), and no workgroup barriers when the batch rows are 16-byte
+        // aligned on both sides — measured at N = 1.6e7, fp32: 156.1 -> 150.0 us (5.74 -> 5.97 TB/s). While the working set
+        // is Infinity-Cache resident (N = 1e6) the workgroup-staged tiles are faster (9.0 us against 9.3 - 10.9 us).
+        const bool rows_aligned = chx_aligned16(x_in) && chx_aligned16(x_out) &&
+                                  ((N * 7 * (int64_t)sizeof(T)) % 16 == 0 || B == 1);
+        if (rows_aligned) return launch_wave<T, 1>(x_in, R, x_out, B, Bx, BR, N, s);
+        if (PPT > 1) return launch_tiles_ppt<T, 1, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
+    }
     // fused run: VALU-bound; 4 rows per lane amortise each map's scalar loads over 4 x 49 FMAs
     if (MODE == 1 && E >= 4 && N >= 4 * CHX_BLOCK * 64)
         return launch_tiles_ppt<T, 2 * PPT, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
@@ -278,9 +434,25 @@ int launch_shared(const void* x_in, const void* R, void* x_out, int64_t B, int64
     if (rows < 8 && B >= 8) rows = 8;
     chunks = (B + rows - 1) / rows;
     if (tiles > 0x7fffffffLL || chunks > 65535) return CHX_ERR_INVALID_ARG;
-    hipLaunchKernelGGL((apply_shared_kernel<T, PPT>), dim3((unsigned)tiles, (unsigned)chunks),
-                       dim3(CHX_BLOCK), 0, s, (const T*)x_in, (const T*)R, (T*)x_out, B, N, rows,
-                       (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+    if (chx_aligned16(x_out) && (N * 7 * (int64_t)sizeof(T)) % 16 == 0) {
+        // every batch row of the output starts on a 16-byte boundary: wave-private staging, 16 bytes per lane and row in
+        // flight (measured at B = 4096 x N = 1e5, fp32: rows per lane 1 / 2 / 4 / 8 -> 2.06 / 2.03 / 1.99 / 1.98 ms with
+        // ~8192 workgroups, against 2.25 ms for the workgroup-staged kernel below)
+        constexpr int WPPT = 16 / (int)sizeof(T);
+        constexpr int WTP = WPPT * CHX_BLOCK;
+        const int64_t wtiles = (N + WTP - 1) / WTP;
+        int64_t wchunks = (8192 + wtiles - 1) / wtiles;
+        if (wchunks > B) wchunks = B;
+        int64_t wrows = (B + wchunks - 1) / wchunks;
+        if (wrows < 8 && B >= 8) wrows = 8;
+        wchunks = (B + wrows - 1) / wrows;
+        if (wtiles > 0x7fffffffLL || wchunks > 65535) return CHX_ERR_INVALID_ARG;
+        hipLaunchKernelGGL((apply_shared_wave_kernel<T, WPPT>), dim3((unsigned)wtiles, (unsigned)wchunks), dim3(CHX_BLOCK), 0, s,
+                           (const T*)x_in, (const T*)R, (T*)x_out, B, N, wrows, (int)chx_aligned16(x_in));
+    } else
+        hipLaunchKernelGGL((apply_shared_kernel<T, PPT>), dim3((unsigned)tiles, (unsigned)chunks),
+                           dim3(CHX_BLOCK), 0, s, (const T*)x_in, (const T*)R, (T*)x_out, B, N, rows,
+                           (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

@@ -158,3 +158,49 @@ def test_vectorized_aperture_broadcasting(shape):
         assert np.allclose(frac, [0.0235, 0.42, 0.552], atol=7e-3)
     else:
         assert frac[0] < frac[1] < frac[2] < 1.0
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("B,N", [(16, 2048), (16, 2049), (3, 1001), (37, 70_003), (9, 1024 * 5 + 64), (1025, 4), (64, 1)])
+def test_shared_beam_apply_every_alignment(oracle, tag, B, N):
+    """One beam, B maps (`chx_apply_affine7` with Bx = 1): the wave-staged kernel when every output row starts on a 16-byte
+    boundary (N * 7 * sizeof % 16 == 0), the workgroup-staged one otherwise; ragged last tiles, fewer rows than a chunk,
+    tiles with idle waves. Bit for bit against the oracle's fma chain."""
+    import numpy as np
+    import torch
+
+    from cheetah_amd import _ops
+
+    dt = torch.float32 if tag == "f32" else torch.float64
+    rng = np.random.default_rng(B * 1000 + N)
+    x = rng.normal(size=(N, 7)).astype(np.float32 if tag == "f32" else np.float64) * 1e-3
+    x[:, 6] = 1.0
+    R = np.tile(np.eye(7), (B, 1, 1)) + 0.1 * rng.normal(size=(B, 7, 7))
+    R[:, 6] = 0.0
+    R[:, 6, 6] = 1.0
+    R = R.astype(x.dtype)
+    got = _ops.apply_map(torch.tensor(x, device="cuda"), torch.tensor(R, device="cuda"))
+    assert got.shape == (B, N, 7) and got.dtype == dt
+    want = oracle.apply(x[None], R, mode=1)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B,N", [(1, 4_000_001), (3, 1_500_004), (3, 1_500_001), (2, 2_000_000)])
+def test_streaming_size_apply_paths(oracle, B, N):
+    """Launches of more than 96 MB (they stream from HBM) take the barrier-free wave-staged kernel when the batch rows are
+    16-byte aligned — including a ragged last wave and the few elements behind the last whole 16-byte chunk of a single
+    row — and 256-row workgroup tiles otherwise. Per-row beams and maps, bit for bit against the oracle."""
+    import numpy as np
+    import torch
+
+    from cheetah_amd import _ops
+
+    rng = np.random.default_rng(N)
+    x = (rng.normal(size=(B, N, 7)) * 1e-3).astype(np.float32)
+    x[..., 6] = 1.0
+    R = (np.tile(np.eye(7), (B, 1, 1)) + 0.1 * rng.normal(size=(B, 7, 7))).astype(np.float32)
+    R[:, 6] = 0.0
+    R[:, 6, 6] = 1.0
+    got = _ops.apply_map(torch.tensor(x, device="cuda"), torch.tensor(R, device="cuda")).cpu().numpy()
+    want = oracle.apply(x, R, mode=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
