@@ -144,6 +144,57 @@ __device__ __forceinline__ void tile_store(T* __restrict__ g, const T* __restric
     }
 }
 
+// ---- the same staging per WAVE: a wave moves its own rows between global memory and its own LDS slice (64 rows of 28 / 56
+// bytes are a whole number of 16-byte chunks), so no workgroup barrier is needed around the transfer — chx_wave_sync()
+// orders the wave's LDS accesses — and the waves of a workgroup run independently.
+__device__ __forceinline__ void chx_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+__device__ __forceinline__ void wave_tile_load(const T* __restrict__ g, T* __restrict__ wl, int n_elem, bool vec_ok,
+                                                bool nt = false) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    const int lane = threadIdx.x & 63;
+    if (vec_ok) {
+        const int nvec = n_elem / VN;
+        const V* __restrict__ gv = reinterpret_cast<const V*>(g);
+        V* lv = reinterpret_cast<V*>(wl);
+        if (nt) {
+            for (int v = lane; v < nvec; v += 64) lv[v] = chx_nt_load(gv + v);
+        } else {
+            for (int v = lane; v < nvec; v += 64) lv[v] = gv[v];
+        }
+        for (int e = nvec * VN + lane; e < n_elem; e += 64) wl[e] = g[e];
+    } else {
+        for (int e = lane; e < n_elem; e += 64) wl[e] = g[e];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void wave_tile_store(T* __restrict__ g, const T* __restrict__ wl, int n_elem, bool vec_ok,
+                                                 bool nt = false) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    const int lane = threadIdx.x & 63;
+    if (vec_ok) {
+        const int nvec = n_elem / VN;
+        V* __restrict__ gv = reinterpret_cast<V*>(g);
+        const V* lv = reinterpret_cast<const V*>(wl);
+        if (nt) {
+            for (int v = lane; v < nvec; v += 64) chx_nt_store(lv[v], gv + v);
+        } else {
+            for (int v = lane; v < nvec; v += 64) gv[v] = lv[v];
+        }
+        for (int e = nvec * VN + lane; e < n_elem; e += 64) g[e] = wl[e];
+    } else {
+        for (int e = lane; e < n_elem; e += 64) g[e] = wl[e];
+    }
+}
+
 static inline int chx_grid_for(int64_t work_items, int per_block, int cap) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -154,8 +154,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
     const int64_t xrow = (Bx == 1) ? 0 : b;
     const bool vin = chx_aligned16(x_in) && (((xrow * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
     const bool vout = chx_aligned16(x_out) && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
-    tile_load<T, TP>(x_in + (xrow * N + n0) * 7, lds, np * 7, vin, Bx != 1 || gridDim.y == 1);
-    __syncthreads();
+    // staged per wave: no workgroup barrier, the four waves of a workgroup run independently through the long particle step
+    const int wrow = (threadIdx.x >> 6) * 64;                       // first row of this wave inside the tile
+    const int wvalid = (np - wrow < 0) ? 0 : ((np - wrow < 64) ? (np - wrow) : 64);
+    wave_tile_load<T>(x_in + (xrow * N + n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vin, Bx != 1 || gridDim.y == 1);
+    chx_wave_sync();
     const RefFrame<double> rf = ref_frame<double>((double)energy[Be == 1 ? 0 : b], mass_eV);
     const int p = threadIdx.x;
     if (p < np) {
@@ -275,8 +278,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
             }
         }
     }
-    __syncthreads();
-    tile_store<T, TP>(x_out + (b * N + n0) * 7, lds, np * 7, vout, true);
+    chx_wave_sync();
+    wave_tile_store<T>(x_out + (b * N + n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vout, true);
 }
 
 inline dim3 cell_grid(int64_t n, int64_t B) {
