@@ -256,7 +256,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
         }
         pass1_to_lds<T, M, INV, ZP>(x, xch, tw, c, line);
     }
-    __syncthreads();
+    // POINT_FAST: a wave holds 4 whole lines (every column and every k1 of each), the exchange never leaves the wave
+    if (POINT_FAST) chx_wave_sync();
+    else __syncthreads();
     // ---- pass 2: M-point FFT over c for k1 = c (16 of them), output index k1 + 16 k2 ----------------------------
     {
         const int k1 = c;
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_z_fused_kernel(T* __restrict__ 
         for (int j1 = 0; j1 < 16; ++j1) x[j1] = j1 < 8 ? q[M * j1] : vec2<T>{(T)0, (T)0};
         pass1_to_lds<T, M, false, true>(x, xch, tw, c, line);
     }
-    __syncthreads();
+    // a wave holds 4 whole lines (all 16 columns c and all 16 k1 of each): both exchanges stay inside the wave, so the waves
+    // of a workgroup need no barrier between them and drift apart (loads of one overlap the butterflies of another)
+    chx_wave_sync();
     // ---- forward pass 2, multiply, inverse pass 1 (all in the registers of the thread that owns k1)
     {
         const int k1 = c;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_z_fused_kernel(T* __restrict__ 
         for (int cc = 1; cc < M; ++cc)                       // conjugate twiddle W_n^(-c k1); this thread's own slab
             xch[k1 * RT::KP + cc * RT::LP + line] = cmul_conj(y[cc], tw[(cc * k1) & (n - 1)]);
     }
-    __syncthreads();
+    chx_wave_sync();
     // ---- inverse pass 2: 16-point inverse FFTs over k1, outputs x[c + M j1], j1 < 8 kept
     if (c < M) {
         vec2<T> x[16];
