@@ -192,13 +192,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_tile_kernel(
 // The kernel above stages a tile per WORKGROUP: two barriers per tile. Here every wave owns 64 * PPT consecutive rows —
 // a whole number of 16-byte chunks — loads them into its own LDS slice, applies the map and streams them out: no workgroup
 // barrier at all, the four waves of a workgroup run independently. Needs 16-byte aligned batch rows on both sides.
-template <typename T, int PPT>
-__global__ __launch_bounds__(CHX_BLOCK) void apply_wave_kernel(const T* __restrict__ x_in, const T* __restrict__ R,
+template <typename T, int PPT, int THREADS = CHX_BLOCK>
+__global__ __launch_bounds__(THREADS) void apply_wave_kernel(const T* __restrict__ x_in, const T* __restrict__ R,
                                                                T* __restrict__ x_out, int64_t B, int64_t Bx, int64_t BR,
                                                                int64_t N) {
     using V = typename chx_vec16<T>::type;
     constexpr int VN = chx_vec16<T>::n;
-    constexpr int TP = PPT * CHX_BLOCK;
+    constexpr int TP = PPT * THREADS;
     constexpr int WP = PPT * 64, WE = WP * 7, WV = WE / VN;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     const int64_t tiles_per_row = (N + TP - 1) / TP;
@@ -391,12 +391,12 @@ int launch_tiles_ppt(const void* x_in, const void* R, void* x_out, const double*
 // Tile size: measured on MI355X (benchmarks/apply_variants.hip, fp32): 512-row tiles win while the
 // working set is Infinity-Cache resident (5.76 vs 5.71 TB/s at N = 1e6), 256-row tiles win once the
 // launch streams from HBM (5.74 vs 5.42 TB/s at N = 1.6e7; a float4 copy of the same bytes: 5.83 TB/s).
-template <typename T, int PPT>
+template <typename T, int PPT, int THREADS = CHX_BLOCK>
 int launch_wave(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx, int64_t BR, int64_t N, hipStream_t s) {
-    constexpr int TP = PPT * CHX_BLOCK;
+    constexpr int TP = PPT * THREADS;
     const int64_t tiles = ((N + TP - 1) / TP) * B;
     if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
-    hipLaunchKernelGGL((apply_wave_kernel<T, PPT>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const T*)x_in, (const T*)R,
+    hipLaunchKernelGGL((apply_wave_kernel<T, PPT, THREADS>), dim3((unsigned)tiles), dim3(THREADS), 0, s, (const T*)x_in, (const T*)R,
                        (T*)x_out, B, Bx, BR, N);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
@@ -407,12 +407,13 @@ int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coe
                  int64_t Bx, int64_t BR, int64_t N, int E, hipStream_t s) {
     constexpr int PPT = tile_cfg<T>::PPT;
     if (MODE == 0 && B * N * 7 * (int64_t)sizeof(T) > (int64_t)96 * 1024 * 1024) {
-        // the launch streams from HBM: 256-row tiles (above), and no workgroup barriers when the batch rows are 16-byte
-        // aligned on both sides — measured at N = 1.6e7, fp32: 156.1 -> 150.0 us (5.74 -> 5.97 TB/s). While the working set
-        // is Infinity-Cache resident (N = 1e6) the workgroup-staged tiles are faster (9.0 us against 9.3 - 10.9 us).
+        // the launch streams from HBM: single-wave workgroups of 64 rows, no barriers, when the batch rows are 16-byte aligned
+        // on both sides — measured at N = 1.6e7, fp32: 156.1 us (256-row workgroup tiles) -> 150.0 (four independent waves
+        // per workgroup) -> 146.6 (one wave per workgroup): 5.74 -> 6.11 TB/s. While the working set is Infinity-Cache
+        // resident (N = 1e6) the workgroup-staged 512-row tiles are faster (9.1 us against 9.3 - 11.0 us for every variant).
         const bool rows_aligned = chx_aligned16(x_in) && chx_aligned16(x_out) &&
                                   ((N * 7 * (int64_t)sizeof(T)) % 16 == 0 || B == 1);
-        if (rows_aligned) return launch_wave<T, 1>(x_in, R, x_out, B, Bx, BR, N, s);
+        if (rows_aligned) return launch_wave<T, 1, 64>(x_in, R, x_out, B, Bx, BR, N, s);
         if (PPT > 1) return launch_tiles_ppt<T, 1, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
     }
     // fused run: VALU-bound; 4 rows per lane amortise each map's scalar loads over 4 x 49 FMAs
