@@ -31,7 +31,7 @@ with open(os.path.join(out, f"{rnd}_kernel_stats.csv"), "w", newline="") as f:
 agg = collections.defaultdict(list)
 for which in ("fetch", "write"):
     for r in csv.DictReader(open(os.path.join(src, f"pmc_{which}", "probe_counter_collection.csv"))):
-        if "apply_tile_kernel" in r["Kernel_Name"]:
+        if "apply_tile_kernel" in r["Kernel_Name"] or "apply_wave_kernel" in r["Kernel_Name"]:
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             # rows per lane = PPT template argument: apply_tile_kernel<T, PPT, MODE>
             ppt = int(r["Kernel_Name"].split("<")[1].split(",")[1])
@@ -47,7 +47,7 @@ for (grid, cname, ppt), vals in sorted(agg.items()):
     lines.append(f"| {grid} | {n_part} | {cname} | {raw:.2f} | {corr:.4e} | {algo:.4e} | {corr / algo:.4f} |")
     traffic.setdefault(n_part, {})[cname] = corr
 with open(os.path.join(out, f"{rnd}_pmc_apply.md"), "w") as f:
-    f.write(f"# HBM traffic of apply_tile_kernel<float,2,0> ({rnd})\n\n"
+    f.write(f"# HBM traffic of apply_tile_kernel<float,2,0> (1e6 rows) and apply_wave_kernel<float,1,64> (1.6e7 rows) ({rnd})\n\n"
             "Source: `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) over\n"
             "`profiles/traffic_probe.py` (20 launches per size). Corrections per MI355X_MICROARCH.md section HBM: counters are\n"
             "in KiB; on gfx950 FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced read stream -> x2.\n"
