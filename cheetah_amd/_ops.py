@@ -31,6 +31,13 @@ def dtype_code(dtype: torch.dtype) -> int:
     raise TypeError(f"cheetah_amd supports float32 and float64 beams, got {dtype}")
 
 
+try:  # raw C accessors: ~0.3 us instead of ~4 us for torch.cuda.current_stream().cuda_stream (called per launch)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _current_device = torch._C._cuda_getDevice
+except AttributeError:  # pragma: no cover - torch build without the private accessors
+    _raw_stream = None
+
+
 def require_device(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -38,13 +45,15 @@ def require_device(*tensors: torch.Tensor) -> None:
                 "cheetah_amd tracks on the GPU only (HIP kernels, no CPU fallback): move the beam "
                 "and the lattice to a ROCm device first, e.g. `.to('cuda')`."
             )
+    check_current_device(tensors[0].device if tensors and tensors[0] is not None else None)
 
 
-try:  # raw C accessors: ~0.3 us instead of ~4 us for torch.cuda.current_stream().cuda_stream (called per launch)
-    _raw_stream = torch._C._cuda_getCurrentRawStream
-    _current_device = torch._C._cuda_getDevice
-except AttributeError:  # pragma: no cover - torch build without the private accessors
-    _raw_stream = None
+def check_current_device(device) -> None:
+    """The kernels are launched on the CURRENT device's stream (one process per GPU is the design): tensors that live on
+    another GPU of the same process must be tracked under `torch.cuda.device(...)`. Loud instead of a cross-device launch."""
+    if device is not None and _raw_stream is not None and device.index is not None and device.index != _current_device():
+        raise RuntimeError(f"the tensors live on {device} but the current device is cuda:{_current_device()}: "
+                           f"run the call under `with torch.cuda.device({device.index}):`")
 
 
 def stream_ptr() -> int:

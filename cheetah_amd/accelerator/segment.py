@@ -438,6 +438,7 @@ class Segment(Element):
                 return None
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         out = torch.empty_like(x)
+        _ops.check_current_device(fr.device)
         _ops.check(_lib.lib().chx_run_track(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
                                             sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
                                             x.data_ptr(), out.data_ptr(), x.shape[0], _ops.stream_ptr()), "chx_run_track")

@@ -283,3 +283,15 @@ def test_beam_state_can_become_a_parameter():
     p.cov = 2 * torch.eye(7)
     assert "cov" in p._buffers and float(p.cov[0, 0]) == 2.0
     assert not hasattr(ca.ParticleBeam.__new__(ca.ParticleBeam), "nonexistent_attribute")
+
+
+def test_cross_device_launch_is_refused(monkeypatch):
+    """Kernels go to the current device's stream: tensors of another GPU of the same process must not be launched on it."""
+    from cheetah_amd import _ops
+
+    monkeypatch.setattr(_ops, "_raw_stream", lambda index: 0)
+    monkeypatch.setattr(_ops, "_current_device", lambda: 1)
+    _ops.check_current_device(torch.device("cuda:1"))
+    _ops.check_current_device(None)
+    with pytest.raises(RuntimeError, match=r"live on cuda:0 but the current device is cuda:1"):
+        _ops.check_current_device(torch.device("cuda:0"))
