@@ -332,6 +332,16 @@ class Element(nn.Module):
                    else deepcopy(getattr(self, f))) for f in self.defining_features},
             metadata=deepcopy(self.metadata), sanitize_name=False)
 
+    def plot(self, *args, **kwargs):
+        """element.py:318-331 — drawing is outside this tracking engine."""
+        raise NotImplementedError(f"{type(self).__name__}.plot: plotting and 3-D meshes are outside this tracking engine; "
+                                  "write the lattice with `to_lattice_json` and draw it with the reference")
+
+    def to_mesh(self, *args, **kwargs):
+        """element.py:333-362 — see `plot`."""
+        raise NotImplementedError(f"{type(self).__name__}.to_mesh: plotting and 3-D meshes are outside this tracking engine; "
+                                  "write the lattice with `to_lattice_json` and draw it with the reference")
+
     def split(self, resolution: torch.Tensor) -> list["Element"]:
         """Slices no longer than `resolution` (element.py:338-347); elements that cannot be split return [self]."""
         return [self]

@@ -833,6 +833,13 @@ class Segment(Element):
         merged_elements.append(current)
         return self.__class__(elements=merged_elements, name=self.name, metadata=deepcopy(self.metadata))
 
+    def _no_plot(self, *args, **kwargs):
+        raise NotImplementedError("Segment.plot_*: plotting is outside this tracking engine (SURVEY.md section 2); "
+                                  "`get_beam_attrs_along_segment` gives the numbers the reference's plots draw")
+
+    plot_beam_attrs = plot_beam_attrs_over_lattice = plot_mean_and_std = plot_overview = plot_twiss = _no_plot
+    plot_twiss_over_lattice = _no_plot
+
     def split(self, resolution) -> list[Element]:
         return [part for element in self.elements for part in element.split(resolution)]
 

@@ -8,8 +8,30 @@ import torch
 from torch import nn
 
 
+_OUT_OF_SCOPE = ("{} is plotting / visualisation, outside this tracking engine (SURVEY.md section 2): move the data to the host "
+                 "(`.cpu()`) and plot it there, or hand it to the reference's plotting helpers")
+
+
+def _abstract(name):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__}.{name} is provided by ParticleBeam and ParameterBeam")
+
+    method.__name__ = name
+    return method
+
+
 class Beam(nn.Module):
-    """Common interface of the two beam representations."""
+    """Common interface of the two beam representations (beam.py:17-592: the abstract surface is declared here too, so that
+    `hasattr(Beam, ...)` and subclass checks of user code see the same names)."""
+
+    UNVECTORIZED_NUM_ATTR_DIMS: dict = {}          # beam.py:36: dimensions of each tensor attribute without vector dims
+
+    def register_buffer_or_parameter(self, name: str, value) -> None:
+        """beam.py:574-589"""
+        if isinstance(value, nn.Parameter):
+            self.register_parameter(name, value)
+        else:
+            self.register_buffer(name, value)
 
     # reference frame (beam.py:323-341)
     @property
@@ -87,3 +109,16 @@ class Beam(nn.Module):
     @property
     def dispersion_py(self) -> torch.Tensor:
         return self.cov_pyp / self.sigma_p.square()
+
+
+# the abstract part of the reference's interface (beam.py:38-321, 343-430): implemented by the two subclasses
+for _name in ("from_parameters", "from_twiss", "from_astra", "from_ocelot"):
+    setattr(Beam, _name, classmethod(_abstract(_name)))
+for _name in ("transformed_to", "clone"):
+    setattr(Beam, _name, _abstract(_name))
+for _name in (["defining_features"] + [f"mu_{c}" for c in ("x", "px", "y", "py", "tau", "p")]
+              + [f"sigma_{c}" for c in ("x", "px", "y", "py", "tau", "p")]
+              + ["cov_xpx", "cov_ypy", "cov_taup", "cov_xp", "cov_pxp", "cov_yp", "cov_pyp", "cov_xy", "cov_xpy", "cov_xtau",
+                 "cov_pxy", "cov_pxpy", "cov_pxtau", "cov_ytau", "cov_pytau"]):
+    setattr(Beam, _name, property(_abstract(_name)))
+del _name

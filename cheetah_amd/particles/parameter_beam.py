@@ -19,6 +19,8 @@ _COORDS = ["x", "px", "y", "py", "tau", "p"]
 class ParameterBeam(Beam):
     """Gaussian beam given by `mu` and `cov`."""
 
+    UNVECTORIZED_NUM_ATTR_DIMS = Beam.UNVECTORIZED_NUM_ATTR_DIMS | {"mu": 1, "cov": 2}
+
     def __init__(self, mu, cov, energy, total_charge=None, s=None, species=None, device=None, dtype=None) -> None:
         super().__init__()
         device = device if device is not None else mu.device

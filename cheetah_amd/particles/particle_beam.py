@@ -32,6 +32,17 @@ def _tri(i: int, j: int) -> int:
 class ParticleBeam(Beam):
     """Beam of macro-particles, each a 7-vector (x, px, y, py, tau, p, 1)."""
 
+    PRETTY_DIMENSION_LABELS = {"x": r"$x$", "px": r"$p_x$", "y": r"$y$", "py": r"$p_y$", "tau": r"$\tau$", "p": r"$\delta$"}
+    UNVECTORIZED_NUM_ATTR_DIMS = Beam.UNVECTORIZED_NUM_ATTR_DIMS | {
+        "particles": 2, "particle_charges": 1, "survival_probabilities": 1, "x": 1, "px": 1, "y": 1, "py": 1, "tau": 1, "p": 1}
+
+    def _no_plot(self, *args, **kwargs):
+        from .beam import _OUT_OF_SCOPE
+
+        raise NotImplementedError(_OUT_OF_SCOPE.format("ParticleBeam.plot_*"))
+
+    plot_1d_distribution = plot_2d_distribution = plot_distribution = plot_point_cloud = _no_plot
+
     def __init__(self, particles, energy, particle_charges=None, survival_probabilities=None, s=None,
                  species=None, device=None, dtype=None) -> None:
         super().__init__()

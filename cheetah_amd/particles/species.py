@@ -21,6 +21,13 @@ eV_to_kg = 1.7826619216278975e-36
 class Species(nn.Module):
     """Named particle species defined by charge and mass."""
 
+    def register_buffer_or_parameter(self, name: str, value) -> None:
+        """species.py:118-131"""
+        if isinstance(value, nn.Parameter):
+            self.register_parameter(name, value)
+        else:
+            self.register_buffer(name, value)
+
     known = {
         "electron": {"num_elementary_charges": -1, "mass_eV": electron_mass_eV},
         "positron": {"num_elementary_charges": 1, "mass_eV": electron_mass_eV},

@@ -179,3 +179,25 @@ def test_infix_and_rpn_evaluators():
     for bad in ("'2 3 +'", "ldsp2h +dldsp17h +lblxsph/2-lbxsph/2"):
         with pytest.raises(SyntaxError):
             rpn.evaluate_expression(bad)
+
+
+def test_public_attribute_names_of_the_reference():
+    """Every public attribute name of every class the reference exports (tests/golden/api_surface.json, written by
+    generate_golden_api_surface.py from the imported reference) exists on the class of the same name here. Plotting and
+    mesh methods exist as well, but only to say that drawing is outside this engine."""
+    import json
+    import os
+
+    import cheetah_amd as ca
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_surface.json")) as f:
+        surface = json.load(f)
+    assert len(surface) >= 25
+    for cls_name, names in surface.items():
+        cls = getattr(ca, cls_name)
+        missing = [n for n in names if not hasattr(cls, n)]
+        assert not missing, (cls_name, missing)
+    seg = ca.Segment([ca.Drift(torch.tensor(1.0))])
+    for call in (seg.plot_overview, seg.elements[0].plot, seg.elements[0].to_mesh):
+        with pytest.raises(NotImplementedError, match="outside this tracking engine"):
+            call()
