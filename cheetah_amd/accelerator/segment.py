@@ -930,12 +930,12 @@ class Segment(Element):
 
         return load_cheetah_model(filepath, device=device, dtype=dtype)
 
-    def to_lattice_json(self, filepath: str, title: str | None = None, info: str | None = None) -> None:
+    def to_lattice_json(self, filepath: str, title: str | None = None,
+                        info: str = "This is a placeholder lattice description") -> None:
         """Save as LatticeJSON (segment.py:386-402)."""
         from ..latticejson import save_cheetah_model
 
-        kwargs = {} if info is None else {"info": info}
-        save_cheetah_model(self, filepath, title, **kwargs)
+        save_cheetah_model(self, filepath, title, info)
 
     def clone(self) -> "Segment":
         return self.__class__(elements=[e.clone() for e in self.elements], name=self.name,
