@@ -756,3 +756,31 @@ def test_one_call_kick_on_non_cubic_grids_vs_oracle(ca, golden, tag, grid, n):
     for c in (1, 3, 5):
         assert kick[c] > 0 and err[c] < tol * kick[c] + 2 * np.finfo(ndt(tag)).eps * np.max(np.abs(truth[:, c])), (c, err[c], kick[c])
     assert np.array_equal(got[:, 0], inp[:, 0]) and np.array_equal(got[:, 2], inp[:, 2])
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_map_builders_vs_reference_on_a_random_sweep(ca, golden, tag):
+    """The HIP builders on the 340 drawn settings of maps_random.npz (one batched call per element kind, per-row species
+    grouped), against the reference's matrices."""
+    from cheetah_amd import _ops
+
+    g = golden("maps_random.npz")
+    for kind_name in sorted(k[2:] for k in g.files if k.startswith("R_")):
+        kind = _ops.KIND[kind_name]
+        P, E, S, Rref = g[f"params_{kind_name}"], g[f"energy_{kind_name}"], g[f"species_{kind_name}"], g[f"R_{kind_name}"]
+        for mass, nq in {tuple(row) for row in S}:
+            rows = np.nonzero((S[:, 0] == mass) & (S[:, 1] == nq))[0]
+            R = _ops.build_rmatrix(kind, dev(P[rows], tdt(tag)), dev(E[rows], tdt(tag)), float(mass), float(nq), len(rows)).cpu().numpy()
+            for j, i in enumerate(rows):
+                denom = np.maximum(np.abs(Rref[i]), 1e-3 * np.max(np.abs(Rref[i])))
+                err = np.max(np.abs(R[j] - Rref[i]) / denom)
+                if tag == "f64":
+                    assert err < 1e-11, (kind_name, i, P[i], E[i], err)
+                else:
+                    # fp32: the reference value is for fp64 inputs; inputs rounded to fp32 move the entries by the map's
+                    # sensitivity to them (phase advance k L up to ~30 here), so compare with the fp64 map of the rounded inputs
+                    R64 = _ops.build_rmatrix(kind, dev(P[i:i + 1].astype(np.float32).astype(np.float64)),
+                                             dev(E[i:i + 1].astype(np.float32).astype(np.float64)), float(mass), float(nq), 1)
+                    R64 = R64.cpu().numpy()[0]
+                    d64 = np.maximum(np.abs(R64), 1e-3 * np.max(np.abs(R64)))
+                    assert np.max(np.abs(R[j] - R64) / d64) < 4e-7, (kind_name, i, P[i], E[i])

@@ -322,3 +322,18 @@ def test_si_roundtrip(golden, oracle):
     assert rel_err(xp[0, :256], g["g0_f64_xp"]) < 1e-14
     back = oracle.from_xyz_pxpypz(xp, g["energy"])
     assert np.allclose(back, x, rtol=1e-9, atol=1e-14)
+
+
+def test_maps_match_reference_on_a_random_sweep(golden, oracle):
+    """340 drawn settings (tests/golden/generate_golden_random_maps.py: magnitudes over several decades, exact zeros mixed in,
+    electrons and protons, 5 MeV ... 20 GeV) of every map builder against the reference's own matrices."""
+    g = golden("maps_random.npz")
+    kinds = sorted(k[2:] for k in g.files if k.startswith("R_"))
+    assert kinds == ["cavity_sw", "cavity_tw", "ccor", "dipole", "drift", "hcor", "quadrupole", "solenoid", "vcor"]
+    for kind in kinds:
+        P, E, S, R = g[f"params_{kind}"], g[f"energy_{kind}"], g[f"species_{kind}"], g[f"R_{kind}"]
+        assert len(R) >= 25
+        for i in range(len(R)):
+            Ro = oracle.build_rmatrix(kind, P[i], E[i], S[i][0], S[i][1])[0]
+            denom = np.maximum(np.abs(R[i]), 1e-3 * np.max(np.abs(R[i])))
+            assert np.max(np.abs(Ro - R[i]) / denom) < 2e-10, (kind, i, P[i], E[i])
