@@ -2,7 +2,8 @@
 """Random lattices tracked by the reference -> tests/golden/lattices_random.npz: for each of 12 drawn beamlines (6-14 elements:
 drifts, quadrupoles with tilt / misalignment, dipoles and rectangular bends with faces, correctors, solenoids, standing- and
 travelling-wave cavities on and off, markers, BPMs, inactive screens, apertures on and off) the element list as JSON, 96
-incoming particles and what `Segment.track` makes of them in float64 (particles, survival probabilities, energy, s).
+incoming particles and what `Segment.track` makes of them in float64 (particles, survival probabilities, energy, s), and the same for a ParameterBeam
+(mu, cov, energy).
 Run in the build container:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden_random_lattices.py
 """
 import json
@@ -86,6 +87,15 @@ for i in range(12):
                                                 sigma_p=torch.tensor(2e-3, **f64), **f64)
     out = build(cheetah, spec).track(beam)
     assert torch.isfinite(out.particles).all()
+    # the same beamline with a ParameterBeam (apertures do not act on it)
+    pbeam = cheetah.ParameterBeam.from_twiss(beta_x=torch.tensor(u(1.0, 20.0), **f64), alpha_x=torch.tensor(u(-1.5, 1.5), **f64),
+                                             beta_y=torch.tensor(u(1.0, 20.0), **f64), alpha_y=torch.tensor(u(-1.5, 1.5), **f64),
+                                             emittance_x=torch.tensor(2e-9, **f64), emittance_y=torch.tensor(3e-9, **f64),
+                                             energy=torch.tensor(energy, **f64), **f64)
+    pout = build(cheetah, spec).track(pbeam)
+    arrays[f"pmu_in_{i}"], arrays[f"pcov_in_{i}"] = pbeam.mu.numpy(), pbeam.cov.numpy()
+    arrays[f"pmu_out_{i}"], arrays[f"pcov_out_{i}"] = pout.mu.numpy(), pout.cov.numpy()
+    arrays[f"penergy_out_{i}"] = pout.energy.numpy()
     arrays[f"spec_{i}"] = np.asarray(json.dumps(spec))
     arrays[f"in_{i}"] = beam.particles.numpy()
     arrays[f"energy_{i}"] = np.asarray(energy)

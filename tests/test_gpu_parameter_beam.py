@@ -124,3 +124,37 @@ def test_beam_types_agree(ca):
     a, b = seg.track(pb), seg.track(particles)
     for n in ("mu_x", "mu_y", "sigma_x", "sigma_px", "sigma_y", "sigma_py", "sigma_tau", "sigma_p"):
         assert float(getattr(b, n)) == pytest.approx(float(getattr(a, n)), rel=1e-6, abs=1e-12), n
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_parameter_beam_through_random_lattices_vs_reference(golden, tag):
+    """The drawn beamlines of lattices_random.npz with a ParameterBeam: mu, cov and energy behind each against the reference
+    (cavities on: the cavity's moment update; apertures: transparent for a ParameterBeam)."""
+    import json
+
+    import numpy as np
+    import torch
+
+    import cheetah_amd as ca
+
+    g = golden("lattices_random.npz")
+    dt = torch.float64 if tag == "f64" else torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    for i in range(int(g["n_lattices"])):
+        spec = json.loads(str(g[f"spec_{i}"]))
+        elements = []
+        for kind, args in spec:
+            targs = {k: (torch.tensor(v, **kw) if isinstance(v, (float, list)) else v) for k, v in args.items()}
+            elements.append(getattr(ca, kind)(**targs, **kw))
+        beam = ca.ParameterBeam(torch.tensor(g[f"pmu_in_{i}"], **kw), torch.tensor(g[f"pcov_in_{i}"], **kw),
+                                torch.tensor(float(g[f"energy_{i}"]), **kw), species=ca.Species("electron", **kw))
+        out = ca.Segment(elements).track(beam)
+        mu, cov = out.mu.cpu().numpy().astype(np.float64), out.cov.cpu().numpy().astype(np.float64)
+        rmu, rcov = g[f"pmu_out_{i}"], g[f"pcov_out_{i}"]
+        sig = np.sqrt(np.abs(np.diag(rcov)[:6]))
+        tol = 1e-9 if tag == "f64" else 2e-3
+        assert np.all(np.abs(mu[:6] - rmu[:6]) <= tol * (sig + np.abs(rmu[:6])) + 1e-30), (i, [k for k, _ in spec])
+        # entries of the tiny tau block (sigma_tau ~ 4e-13 for this beam) carry the rounding of the large ones
+        floor = (1e-14 if tag == "f64" else 1e-6) * np.abs(rcov).max()
+        assert np.all(np.abs(cov[:6, :6] - rcov[:6, :6]) <= tol * np.outer(sig, sig) + floor), (i, [k for k, _ in spec])
+        assert float(out.energy) == pytest.approx(float(g[f"penergy_out_{i}"]), rel=1e-12 if tag == "f64" else 1e-6)
