@@ -829,3 +829,32 @@ def test_random_lattices_vs_reference(ca, golden, tag):
                 b = e.track(b)
             seq = b.particles.cpu().numpy().astype(np.float64)
             assert (np.abs(seq - got) / scale).max() < (1e-11 if tag == "f64" else 1e-4), i
+
+
+def test_space_charge_kick_on_drawn_configurations_vs_reference(ca, golden, oracle):
+    """Six drawn SpaceChargeKick set-ups (space_charge_random.npz: non-cubic grids, powers of two and not, grid extents of 2 to
+    4.5 sigma per axis, gamma from 5 to 340, flat and long bunches, unequal charges, dead particles) against the reference in
+    float64, and the oracle against the same fixture."""
+    g = golden("space_charge_random.npz")
+    dt = torch.float64
+    kw = {"dtype": dt, "device": "cuda"}
+    for i in range(int(g["n_cases"])):
+        grid = tuple(int(v) for v in g[f"grid_{i}"])
+        ext = g[f"extent_{i}"]
+        beam = ca.ParticleBeam(dev(g[f"in_{i}"]), torch.tensor(float(g[f"energy_{i}"]), **kw), particle_charges=dev(g[f"charges_{i}"]),
+                               survival_probabilities=dev(g[f"survival_{i}"]), species=ca.Species("electron", **kw))
+        sc = ca.SpaceChargeKick(effect_length=torch.tensor(float(g[f"length_{i}"]), **kw), grid_shape=grid,
+                                grid_extent_x=torch.tensor(float(ext[0]), **kw), grid_extent_y=torch.tensor(float(ext[1]), **kw),
+                                grid_extent_tau=torch.tensor(float(ext[2]), **kw), **kw)
+        got = sc.track(beam).particles.cpu().numpy()
+        inp, truth = g[f"in_{i}"], g[f"out_{i}"]
+        kick = np.max(np.abs(truth - inp), axis=0)
+        err = np.max(np.abs(got - truth), axis=0)
+        for c in (1, 3, 5):
+            assert kick[c] > 0 and err[c] < 1e-6 * kick[c] + 4e-16 * np.max(np.abs(truth[:, c])), (i, grid, c, err[c], kick[c])
+        assert np.array_equal(got[:, 0], inp[:, 0]) and np.array_equal(got[:, 2], inp[:, 2])
+        o = oracle.space_charge_kick(inp[None], float(g[f"energy_{i}"]), g[f"charges_{i}"], g[f"survival_{i}"], float(g[f"length_{i}"]),
+                                     grid_shape=grid, grid_extent=tuple(float(v) for v in ext))[0]
+        oerr = np.max(np.abs(o - truth), axis=0)
+        for c in (1, 3, 5):
+            assert oerr[c] < 1e-6 * kick[c] + 4e-16 * np.max(np.abs(truth[:, c])), ("oracle", i, grid, c)
