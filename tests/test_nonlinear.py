@@ -278,3 +278,37 @@ def test_nonlinear_entry_points_reject_bad_arguments():
     assert lib.chx_dkd_track(1, *args, 1, 3, 1, 1, 1, 1, 4, 5, x.data_ptr(), None, None) == -2      # dtype
     assert lib.chx_dkd_track(1, *args, 1, 3, 2, 3, 1, 1, 4, 0, x.data_ptr(), None, None) == -1      # broadcast
     assert lib.chx_apply_second_order(x.data_ptr(), None, x.data_ptr(), 1, 1, 1, 4, 0, None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_random_nonlinear_lattices_vs_reference(tag):
+    """Ten drawn beamlines (tests/golden/generate_golden_random_nonlinear.py) in which every element takes a drawn tracking
+    method out of the ones it supports — linear, second_order, drift_kick_drift with `num_steps`, fringe fields at either end —
+    plus sextupoles and transverse deflecting cavities, rebuilt from JSON and tracked here against the reference (float64)."""
+    import json
+    import os
+
+    import cheetah_amd as ca
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lattices_random_nonlinear.npz"))
+    dt = torch.float64 if tag == "f64" else torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    for i in range(int(g["n_lattices"])):
+        spec = json.loads(str(g[f"spec_{i}"]))
+        elements = []
+        for kind, args in spec:
+            targs = {k: (torch.tensor(v, **kw) if isinstance(v, (float, list)) else v) for k, v in args.items()}
+            elements.append(getattr(ca, kind)(**targs, **kw))
+        beam = ca.ParticleBeam(torch.tensor(g[f"in_{i}"], **kw), torch.tensor(float(g[f"energy_{i}"]), **kw),
+                               species=ca.Species("electron", **kw))
+        out = ca.Segment(elements).track(beam)
+        ref = g[f"out_{i}"]
+        got = out.particles.cpu().numpy().astype(np.float64)
+        scale = np.maximum(np.abs(ref).max(axis=0), 1e-30)
+        err = (np.abs(got - ref) / scale).max()
+        # fp64: the Bmad-X element maps are evaluated with series for the cancelling forms here (more accurate than the
+        # reference's direct formulas, whose own tolerance against Bmad-X is 1e-14 absolute); fp32: fp64 arithmetic on
+        # fp32-rounded coordinates and settings
+        assert err < (1e-11 if tag == "f64" else 1e-3), (i, [(k, a.get("tracking_method")) for k, a in spec], err)   # measured: 1e-12 / 3e-4
+        assert float(out.energy) == pytest.approx(float(g[f"energy_out_{i}"]), rel=1e-12 if tag == "f64" else 1e-6)
