@@ -185,8 +185,9 @@ def test_shared_beam_apply_every_alignment(oracle, tag, B, N):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("tag", ["f32", "f64"])
 @pytest.mark.parametrize("B,N", [(1, 4_000_001), (3, 1_500_004), (3, 1_500_001), (2, 2_000_000)])
-def test_streaming_size_apply_paths(oracle, B, N):
+def test_streaming_size_apply_paths(oracle, B, N, tag):
     """Launches of more than 96 MB (they stream from HBM) take the barrier-free wave-staged kernel when the batch rows are
     16-byte aligned — including a ragged last wave and the few elements behind the last whole 16-byte chunk of a single
     row — and 256-row workgroup tiles otherwise. Per-row beams and maps, bit for bit against the oracle."""
@@ -196,9 +197,10 @@ def test_streaming_size_apply_paths(oracle, B, N):
     from cheetah_amd import _ops
 
     rng = np.random.default_rng(N)
-    x = (rng.normal(size=(B, N, 7)) * 1e-3).astype(np.float32)
+    ndt = np.float32 if tag == "f32" else np.float64
+    x = (rng.normal(size=(B, N, 7)) * 1e-3).astype(ndt)
     x[..., 6] = 1.0
-    R = (np.tile(np.eye(7), (B, 1, 1)) + 0.1 * rng.normal(size=(B, 7, 7))).astype(np.float32)
+    R = (np.tile(np.eye(7), (B, 1, 1)) + 0.1 * rng.normal(size=(B, 7, 7))).astype(ndt)
     R[:, 6] = 0.0
     R[:, 6, 6] = 1.0
     got = _ops.apply_map(torch.tensor(x, device="cuda"), torch.tensor(R, device="cuda")).cpu().numpy()
