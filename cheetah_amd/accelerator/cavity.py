@@ -9,9 +9,11 @@ passes over the particle array, cavity.py:112-226).
 
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
-from .. import _ops
+from .. import _lib, _ops
 from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from .element import Element
@@ -98,6 +100,9 @@ class Cavity(Element):
             return self._track_parameter_beam(incoming)
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+        fast = self._track_scalars(incoming)
+        if fast is not None:
+            return fast
         dtype = incoming.particles.dtype
         tm = self.first_order_transfer_map(incoming.energy, incoming.species)
         tensors = [t.to(dtype) for t in self._builder_params()]
@@ -124,6 +129,36 @@ class Cavity(Element):
         return ParticleBeam(out.reshape(*batch_shape, N, 7), e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length,
                             species=incoming.species)
+
+    def _track_scalars(self, incoming: ParticleBeam):
+        """One beam through a cavity whose settings are device scalars of the beam's dtype: the whole element — map,
+        coefficients, outgoing energy, particle pass — in ONE C call (chx_cavity_track_scalars, two launches), bit-identical to
+        the general path below. None when that does not apply (vectorised beam or settings, mixed dtypes, gradients)."""
+        p, e = incoming.particles, incoming.energy
+        if p.dim() != 2 or not p.is_cuda or e.dim() != 0 or e.dtype != p.dtype or e.device != p.device:
+            return None
+        settings = self._settings("length", "voltage", "phase", "frequency")
+        for t in settings:
+            if t.dim() != 0 or t.dtype != p.dtype or t.device != p.device:
+                return None
+        sp = incoming.species
+        if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
+                                        or sp.num_elementary_charges.requires_grad or any(t.requires_grad for t in settings)):
+            return None
+        lib = _lib.lib()
+        x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
+        out = torch.empty_like(x)
+        e_out = torch.empty((), dtype=p.dtype, device=p.device)
+        ws_bytes = lib.chx_cavity_track_scalars_workspace_bytes()
+        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=p.device)
+        _ops.check_current_device(p.device)
+        kind = _ops.KIND["cavity_sw" if self.cavity_type == "standing_wave" else "cavity_tw"]
+        _ops.check(lib.chx_cavity_track_scalars(x.data_ptr(), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in settings]), e.data_ptr(),
+                                                kind, sp.mass_eV_float, sp.num_elementary_charges_float, x.shape[0],
+                                                _ops.dtype_code(p.dtype), out.data_ptr(), e_out.data_ptr(), ws.data_ptr(),
+                                                ws.numel() * 8, _ops.stream_ptr()), "chx_cavity_track_scalars")
+        return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length, species=sp)
 
     @property
     def defining_features(self) -> list[str]:

@@ -529,6 +529,23 @@ extern "C" int chx_cavity_track(const void* x_in, const void* R, const double* c
                             : launch_tiles<double, 2>(x_in, R, x_out, coeffs, B, Bx, B, N, 1, s);
 }
 
+// Cavity.track for one beam and a cavity whose settings are device scalars, in ONE call: chx_cavity_prepare_scalars (map,
+// coefficients, outgoing energy: one thread) + the particle pass of chx_cavity_track. workspace: 49 dtype values + 8 doubles.
+extern "C" size_t chx_cavity_track_scalars_workspace_bytes(void) { return 49 * sizeof(double) + 8 + CHX_CAV_NCOEF * sizeof(double); }
+
+extern "C" int chx_cavity_track_scalars(const void* x_in, const void* const* param_ptrs, const void* energy, int kind,
+                                        double mass_eV, double n_charges, int64_t N, int dtype, void* x_out, void* energy_out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_in || !x_out || !workspace || workspace_bytes < chx_cavity_track_scalars_workspace_bytes() || N < 1)
+        return CHX_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return CHX_ERR_MISALIGNED;
+    void* R = workspace;
+    double* coeffs = reinterpret_cast<double*>((char*)workspace + 49 * sizeof(double) + 8);
+    int st = chx_cavity_prepare_scalars(param_ptrs, energy, kind, mass_eV, n_charges, dtype, R, coeffs, energy_out, stream);
+    if (st != CHX_OK) return st;
+    return chx_cavity_track(x_in, R, coeffs, x_out, 1, 1, N, dtype, stream);
+}
+
 // ---- several device arrays copied by ONE launch -----------------------------------------------------------------------
 // A Screen records a copy of the incoming beam (screen.py:190 `incoming.clone()`): five tensors, two of them scalars — five
 // launches of a framework copy kernel, or one of this. Arrays travel by value in the kernel arguments; blockIdx.y picks the

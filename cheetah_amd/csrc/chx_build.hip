@@ -453,8 +453,41 @@ __global__ __launch_bounds__(CHX_BLOCK) void compose_kernel(ComposeArgs args, in
 }
 
 // ---- cavity track coefficients (cavity.py:100-226) -------------------------------------------
-// Single workgroup; pass 1 evaluates `any(delta_energy > 0)` over the batch (cavity.py:157),
-// pass 2 writes [a, b, k*beta0, phi, cos phi, T566, T556, T555] and the outgoing energy.
+// One row: [a, b, k*beta0, phi, cos phi, T566, T556, T555] and the outgoing energy; `gain` = any(delta_energy > 0) over the
+// batch (cavity.py:157 switches the second-order path-length terms for the whole batch at once).
+__device__ __forceinline__ double cavity_coeff_row(double L, double V, double phi_deg, double freq, double E0, double mass, double nq,
+                                                   bool gain, double* __restrict__ c) {
+    const double phi = phi_deg * (kPi / 180.0);
+    const double g0 = E0 / mass, ig2 = 1.0 / (g0 * g0), b0 = sqrt(1.0 - ig2);
+    const double cphi = cos(phi), sphi = sin(phi);
+    const double dEn = V * cphi * nq * -1.0;
+    const double E1 = E0 + dEn;
+    const double g1 = E1 / mass, b1 = sqrt(1.0 - 1.0 / (g1 * g1));
+    const double k = 2.0 * kPi * freq / kSpeedOfLight;
+    double T566 = 1.5 * L * ig2 / (b0 * b0 * b0), T556 = 0.0, T555 = 0.0;
+    if (gain) {
+        const double dg = V / mass;
+        const double b03 = b0 * b0 * b0, b13 = b1 * b1 * b1, g03 = g0 * g0 * g0, g13 = g1 * g1 * g1;
+        const double gd = g0 - g1;
+        T566 = L * (b03 * g03 - b13 * g13) / (2.0 * b0 * b13 * g0 * gd * g13);
+        T556 = b0 * k * L * dg * g0 * (b13 * g13 + b0 * (g0 - g13)) * sphi / (b13 * g13 * gd * gd);
+        T555 = b0 * b0 * k * k * L * dg / 2.0 *
+               (dg * (2.0 * g0 * g13 * (b0 * b13 - 1.0) + g0 * g0 + 3.0 * g1 * g1 - 2.0) /
+                    (b13 * g13 * gd * gd * gd) * sphi * sphi -
+                (g1 * g0 * (b1 * b0 - 1.0) + 1.0) / (b1 * g1 * gd * gd) * cphi);
+    }
+    c[0] = E0 * b0 / (E1 * b1);
+    c[1] = V * b0 / (E1 * b1);
+    c[2] = b0 * k;
+    c[3] = phi;
+    c[4] = cphi;
+    c[5] = T566;
+    c[6] = T556;
+    c[7] = T555;
+    return E1;
+}
+
+// Single workgroup; pass 1 evaluates `any(delta_energy > 0)` over the batch, pass 2 writes the rows.
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void cavity_coeff_kernel(const T* __restrict__ params,
                                                                 const T* __restrict__ energy,
@@ -477,38 +510,27 @@ __global__ __launch_bounds__(CHX_BLOCK) void cavity_coeff_kernel(const T* __rest
     const bool gain = any_gain != 0;
     for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
         const T* p = params + (Bp == 1 ? 0 : b) * 4;
-        const double L = (double)p[0], V = (double)p[1], phi = (double)p[2] * (kPi / 180.0),
-                     freq = (double)p[3];
-        const double E0 = (double)energy[Be == 1 ? 0 : b];
-        const double g0 = E0 / mass, ig2 = 1.0 / (g0 * g0), b0 = sqrt(1.0 - ig2);
-        const double cphi = cos(phi), sphi = sin(phi);
-        const double dEn = V * cphi * nq * -1.0;
-        const double E1 = E0 + dEn;
-        const double g1 = E1 / mass, b1 = sqrt(1.0 - 1.0 / (g1 * g1));
-        const double k = 2.0 * kPi * freq / kSpeedOfLight;
-        double T566 = 1.5 * L * ig2 / (b0 * b0 * b0), T556 = 0.0, T555 = 0.0;
-        if (gain) {
-            const double dg = V / mass;
-            const double b03 = b0 * b0 * b0, b13 = b1 * b1 * b1, g03 = g0 * g0 * g0, g13 = g1 * g1 * g1;
-            const double gd = g0 - g1;
-            T566 = L * (b03 * g03 - b13 * g13) / (2.0 * b0 * b13 * g0 * gd * g13);
-            T556 = b0 * k * L * dg * g0 * (b13 * g13 + b0 * (g0 - g13)) * sphi / (b13 * g13 * gd * gd);
-            T555 = b0 * b0 * k * k * L * dg / 2.0 *
-                   (dg * (2.0 * g0 * g13 * (b0 * b13 - 1.0) + g0 * g0 + 3.0 * g1 * g1 - 2.0) /
-                        (b13 * g13 * gd * gd * gd) * sphi * sphi -
-                    (g1 * g0 * (b1 * b0 - 1.0) + 1.0) / (b1 * g1 * gd * gd) * cphi);
-        }
-        double* c = coeffs + b * CHX_CAV_NCOEF;
-        c[0] = E0 * b0 / (E1 * b1);
-        c[1] = V * b0 / (E1 * b1);
-        c[2] = b0 * k;
-        c[3] = phi;
-        c[4] = cphi;
-        c[5] = T566;
-        c[6] = T556;
-        c[7] = T555;
+        const double E1 = cavity_coeff_row((double)p[0], (double)p[1], (double)p[2], (double)p[3], (double)energy[Be == 1 ? 0 : b],
+                                           mass, nq, gain, coeffs + b * CHX_CAV_NCOEF);
         energy_out[b] = (T)E1;
     }
+}
+
+// A cavity whose four settings are device scalars, for one beam: its map (chx_build_rmatrix), its coefficient row and the
+// outgoing energy by ONE thread of one launch — what Cavity.track needs before the particle pass.
+template <typename T>
+__global__ void cavity_prepare_scalars_kernel(const T* __restrict__ L, const T* __restrict__ V, const T* __restrict__ ph,
+                                              const T* __restrict__ fr, const T* __restrict__ energy, int kind, double mass,
+                                              double nq, T* __restrict__ R_out, double* __restrict__ coeffs,
+                                              T* __restrict__ energy_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double p[4] = {(double)*L, (double)*V, (double)*ph, (double)*fr};
+    const double E0 = (double)*energy;
+    Mat7<double> R;
+    build_kind<double>(kind, p, E0, mass, nq, R);
+    for (int q = 0; q < 49; ++q) R_out[q] = (T)R.m[q];
+    const double dEn = p[1] * cos(p[2] * (kPi / 180.0)) * nq * -1.0;
+    *energy_out = (T)cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, dEn > 0.0, coeffs);
 }
 
 // ---- second-order transfer tensors (track_methods.py:80-296, MAD convention) ------------------
@@ -986,6 +1008,28 @@ extern "C" int chx_cavity_coeffs(const void* params, const void* energy, double 
         hipLaunchKernelGGL(cavity_coeff_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s,
                            (const double*)params, (const double*)energy, mass_eV, n_charges, B, Bp,
                            Be, coeffs, (double*)energy_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_cavity_prepare_scalars(const void* const* param_ptrs, const void* energy, int kind, double mass_eV,
+                                          double n_charges, int dtype, void* R_out, double* coeffs, void* energy_out,
+                                          void* stream) {
+    if (!param_ptrs || !energy || !R_out || !coeffs || !energy_out) return CHX_ERR_INVALID_ARG;
+    if (kind != CHX_CAVITY_SW && kind != CHX_CAVITY_TW) return CHX_ERR_INVALID_ARG;
+    for (int k = 0; k < 4; ++k)
+        if (!param_ptrs[k]) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(cavity_prepare_scalars_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)param_ptrs[0],
+                           (const float*)param_ptrs[1], (const float*)param_ptrs[2], (const float*)param_ptrs[3],
+                           (const float*)energy, kind, mass_eV, n_charges, (float*)R_out, coeffs, (float*)energy_out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(cavity_prepare_scalars_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)param_ptrs[0],
+                           (const double*)param_ptrs[1], (const double*)param_ptrs[2], (const double*)param_ptrs[3],
+                           (const double*)energy, kind, mass_eV, n_charges, (double*)R_out, coeffs, (double*)energy_out);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

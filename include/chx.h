@@ -408,6 +408,18 @@ int chx_sc_kick(const void* x_in, const void* charge, const void* survival, cons
                 const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
                 const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
                 void* side_stream, const void* post_map /*[BR][7][7] or NULL*/, int64_t BR);
+/* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
+ * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
+ * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),
+ * the coefficient row coeffs[CHX_CAV_NCOEF] (as chx_cavity_coeffs) and the outgoing energy with one thread of one launch;
+ * chx_cavity_track_scalars adds the particle pass of chx_cavity_track: the whole element in one call, two launches,
+ * bit-identical to chx_build_rmatrix + chx_cavity_coeffs + chx_cavity_track. */
+int chx_cavity_prepare_scalars(const void* const* param_ptrs, const void* energy, int kind, double mass_eV, double n_charges,
+                               int dtype, void* R_out, double* coeffs, void* energy_out, void* stream);
+size_t chx_cavity_track_scalars_workspace_bytes(void);
+int chx_cavity_track_scalars(const void* x_in, const void* const* param_ptrs, const void* energy, int kind, double mass_eV,
+                             double n_charges, int64_t N, int dtype, void* x_out, void* energy_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* n <= 8 device arrays copied by one launch: dst[k][0 .. bytes[k]) = src[k][...] (host arrays of device pointers and byte
  * counts). What a Screen's record of the incoming beam costs (screen.py:190 `incoming.clone()`: five tensors). */
 int chx_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);

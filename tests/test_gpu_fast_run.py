@@ -354,3 +354,40 @@ def test_parameter_beam_takes_the_persistent_plan_too():
     assert torch.equal(out3.cov, cov.reshape(out3.cov.shape)) and not torch.equal(out3.cov, out2.cov)
     assert torch.equal(out.cov, out.cov.clone())        # earlier results are separate tensors, not views of the plan's state
     assert float(out3.s) == pytest.approx(1.43, rel=1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("cavity_type", ["standing_wave", "traveling_wave"])
+def test_scalar_cavity_in_one_call_is_bit_identical(dt, cavity_type):
+    """Cavity.track for one beam and scalar settings goes through chx_cavity_track_scalars (map, coefficients, outgoing energy
+    by one thread + the particle pass: one C call). Same bits as the general path (chx_build_rmatrix, chx_cavity_coeffs,
+    chx_cavity_track from packed tensors) for accelerating, decelerating and switched-off cavities."""
+    import cheetah_amd as ca
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(2)
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_007, energy=t(6e7), sigma_tau=t(2e-4), sigma_p=t(3e-3), **kw)
+    for voltage, phase in ((18e6, -12.0), (-7e6, 30.0), (0.0, 0.0), (5e6, 95.0)):
+        cav = ca.Cavity(t(1.0377), voltage=t(voltage), phase=t(phase), frequency=t(1.3e9), cavity_type=cavity_type, **kw)
+        calls = []
+        orig = ca.Cavity._track_scalars
+        ca.Cavity._track_scalars = lambda self, b: (calls.append(1), orig(self, b))[1]
+        try:
+            fast = cav.track(beam)
+        finally:
+            ca.Cavity._track_scalars = orig
+        assert calls and fast.particles.shape == beam.particles.shape
+        ca.Cavity._track_scalars = lambda self, b: None          # the general path
+        try:
+            slow = cav.track(beam)
+        finally:
+            ca.Cavity._track_scalars = orig
+        assert torch.equal(fast.particles, slow.particles), (voltage, phase)
+        assert torch.equal(fast.energy, slow.energy) and fast.energy.shape == slow.energy.shape == ()
+        assert torch.equal(fast.s, slow.s)
+        assert not torch.equal(fast.particles, beam.particles)
+    # a vectorised voltage or a trainable one takes the general path
+    assert ca.Cavity(t(1.0), voltage=t([1e6, 2e6]), phase=t(0.0), frequency=t(1.3e9), **kw)._track_scalars(beam) is None
+    vp = torch.nn.Parameter(t(1e6))
+    assert ca.Cavity(t(1.0), voltage=vp, phase=t(0.0), frequency=t(1.3e9), **kw)._track_scalars(beam) is None
