@@ -16,7 +16,7 @@ import torch
 from .. import _lib, _ops
 from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
-from .element import Element
+from .element import Element, tracking_call
 
 
 def _narrow_to(t: torch.Tensor, shape) -> torch.Tensor:
@@ -95,6 +95,7 @@ class Cavity(Element):
         e_out = _narrow_to(e_out.reshape(batch_shape), self._energy_shape(energy))
         return incoming._tracked(tm, self.length, cavity_coeffs=coeffs, energy=e_out, batch_shape=batch_shape)
 
+    @tracking_call
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         if isinstance(incoming, ParameterBeam):
             return self._track_parameter_beam(incoming)

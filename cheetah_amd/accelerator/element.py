@@ -44,6 +44,24 @@ def _unique_name() -> str:
     return f"unnamed_element_{_name_counter}"
 
 
+_TRACK_DEPTH = [0]   # > 0 while a tracking call is running: map caches then never compare energies by value (see _cached_map)
+
+
+def tracking_call(fn):
+    """Marks a method as a tracking entry point (`_TRACK_DEPTH`)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        _TRACK_DEPTH[0] += 1
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            _TRACK_DEPTH[0] -= 1
+
+    return wrapper
+
+
 class Element(nn.Module):
     """Base class of all beamline elements."""
 
@@ -167,10 +185,14 @@ class Element(nn.Module):
         if cache is not None and cache["fkey"] == fkey and cache["tkey"].matches(ftensors) \
                 and cache["mass"] == species.mass_eV_float and cache["nq"] == species.num_elementary_charges_float:
             ce = cache["energy_ref"]
-            if (ce is energy and cache["energy_version"] == energy._version) or (
-                ce.dtype == energy.dtype and ce.device == energy.device and ce.shape == energy.shape
-                and torch.equal(cache["energy_copy"], energy)
-            ):
+            if ce is energy and cache["energy_version"] == energy._version:
+                return cache["result"]
+            # Another tensor: the reference compares the VALUE (utils/cache.py:47-52, `torch.equal`), which reads the device
+            # back — 24 us and a pipeline stall, measured in a linac where every cavity hands on a new energy tensor. A direct
+            # call keeps that behaviour (the same map OBJECT for an equal energy); inside a tracking call the map is simply
+            # rebuilt, one small launch and no host synchronisation.
+            if _TRACK_DEPTH[0] == 0 and ce.dtype == energy.dtype and ce.device == energy.device and ce.shape == energy.shape \
+                    and torch.equal(cache["energy_copy"], energy):
                 return cache["result"]
         result = build(energy, species)
         if result.requires_grad:  # a graph-attached map must not outlive its backward pass
@@ -183,6 +205,7 @@ class Element(nn.Module):
         return result
 
     # ---- tracking ---------------------------------------------------------------------------------
+    @tracking_call
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
         method = self._tracking_method
         if method == "linear":

@@ -35,7 +35,7 @@ from .. import _lib, _ops
 from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
-from .element import Element
+from .element import Element, tracking_call
 from .space_charge_kick import SpaceChargeKick
 
 
@@ -487,6 +487,7 @@ class Segment(Element):
         # (markers, inactive diagnostics only) the result is copied once here, like the reference's `incoming.clone()`
         return _unaliased(self._track_internal(incoming), incoming)
 
+    @tracking_call
     def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if isinstance(incoming, ParameterBeam):
             for kind, item in self._plan():
@@ -558,6 +559,7 @@ class Segment(Element):
                             survival_probabilities=incoming.survival_probabilities, s=self._run_s(run, incoming.s),
                             species=incoming.species)
 
+    @tracking_call
     def track_moments(self, incoming: ParticleBeam, exact: bool = True) -> ParameterBeam:
         """Track a `ParticleBeam` and return only the outgoing beam's moments as a `ParameterBeam` (mu, cov,
         energy, total_charge, s). Same numbers as `self.track(incoming).as_parameter_beam()`, but the last run
@@ -599,6 +601,7 @@ class Segment(Element):
                                                  total_charge=incoming.total_charge,
                                                  s=self._run_s(last_run, incoming.s), species=incoming.species)
 
+    @tracking_call
     def track_screen_reading(self, incoming: ParticleBeam) -> torch.Tensor:
         """Track a `ParticleBeam` and return the image of the segment's FINAL element, an active cloud-in-cell `Screen`
         — same numbers as `self.track(incoming); screen.reading`, but the last run of linear elements is fused with the
