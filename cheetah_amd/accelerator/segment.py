@@ -305,12 +305,12 @@ class Segment(Element):
         elements = list(self.elements)
         ids = tuple([id(e) for e in elements])
         revs = [e.__dict__["_revision"] for e in elements]
-        if cached is not None and cached[3] is None and cached[0][0] == ids:
-            # the same element objects, none with value-dependent skippability (Cavity voltage, nested segments): only an
-            # element whose own revision moved can have changed its skippability
+        if cached is not None and cached[0][0] == ids:
+            # the same element objects: only an element whose own revision moved, or one whose skippability depends on
+            # tensor VALUES (Cavity voltage, nested segments), can have changed its skippability
             skippable = list(cached[0][1])
             for i, (rev, old) in enumerate(zip(revs, cached[4])):
-                if rev != old:
+                if rev != old or not elements[i]._static_skippable:
                     skippable[i] = elements[i].is_skippable
             skippable = tuple(skippable)
         else:
