@@ -206,3 +206,41 @@ def test_streaming_size_apply_paths(oracle, B, N, tag):
     got = _ops.apply_map(torch.tensor(x, device="cuda"), torch.tensor(R, device="cuda")).cpu().numpy()
     want = oracle.apply(x, R, mode=1)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_random_vectorised_lattices_vs_reference(tag):
+    """Eight drawn beamlines whose settings carry vector dimensions of shapes (3,), (2, 1), (2, 3) (tests/golden/
+    generate_golden_random_vectorized.py), a shared or a vectorised incoming beam: the SHAPES of the outgoing particles,
+    energy and survival probabilities are the reference's, and so are the values."""
+    import json
+    import os
+
+    import numpy as np
+    import torch
+
+    import cheetah_amd as ca
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lattices_random_vectorized.npz"))
+    dt = torch.float64 if tag == "f64" else torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    for i in range(int(g["n_lattices"])):
+        spec = json.loads(str(g[f"spec_{i}"]))
+        elements = []
+        for kind, args in spec:
+            targs = {k: (torch.tensor(v, **kw) if isinstance(v, (float, list)) else v) for k, v in args.items()}
+            elements.append(getattr(ca, kind)(**targs, **kw))
+        beam = ca.ParticleBeam(torch.tensor(g[f"in_{i}"], **kw), torch.tensor(g[f"energy_{i}"], **kw),
+                               particle_charges=torch.tensor(g[f"charges_{i}"], **kw), species=ca.Species("electron", **kw))
+        out = ca.Segment(elements).track(beam)
+        ref = g[f"out_{i}"]
+        names = [k for k, _ in spec]
+        assert tuple(out.particles.shape) == ref.shape, (i, names)
+        assert tuple(out.energy.shape) == g[f"energy_out_{i}"].shape, (i, names)
+        assert tuple(out.survival_probabilities.shape) == g[f"survival_{i}"].shape, (i, names)
+        got = out.particles.cpu().numpy().astype(np.float64)
+        scale = np.maximum(np.abs(ref).reshape(-1, 7).max(axis=0), 1e-30)
+        assert (np.abs(got - ref) / scale).max() < (1e-10 if tag == "f64" else 3e-4), (i, names)
+        assert np.allclose(out.energy.cpu().numpy(), g[f"energy_out_{i}"], rtol=1e-12 if tag == "f64" else 1e-6)
+        surv = out.survival_probabilities.cpu().numpy()
+        assert np.sum(surv != g[f"survival_{i}"]) <= (0 if tag == "f64" else 2), (i, names)
