@@ -858,3 +858,32 @@ def test_space_charge_kick_on_drawn_configurations_vs_reference(ca, golden, orac
         oerr = np.max(np.abs(o - truth), axis=0)
         for c in (1, 3, 5):
             assert oerr[c] < 1e-6 * kick[c] + 4e-16 * np.max(np.abs(truth[:, c])), ("oracle", i, grid, c)
+
+
+def test_screen_readings_on_drawn_setups_vs_reference(ca, golden):
+    """Ten drawn screens (screens_random.npz: non-square resolutions, binning 1 / 2 / 4, misalignments, both methods, both
+    dtypes, particles on pixel edges and beyond the screen, dead particles). Histogram images must be EQUAL — every charge is
+    the same power of two, so equal images mean identical pixel indices for every particle; cloud-in-cell images to rounding."""
+    g = golden("screens_random.npz")
+    for i in range(int(g["n_cases"])):
+        w, h, binning, cic, f32 = (int(v) for v in g[f"meta_{i}"])
+        dt = torch.float32 if f32 else torch.float64
+        kw = {"dtype": dt, "device": "cuda"}
+        xy = g[f"xy_{i}"]
+        n = xy.shape[0]
+        parts = torch.zeros((n, 7), **kw)
+        parts[:, 0], parts[:, 2], parts[:, 6] = torch.tensor(xy[:, 0], **kw), torch.tensor(xy[:, 1], **kw), 1.0
+        beam = ca.ParticleBeam(parts, torch.tensor(1e8, **kw), particle_charges=torch.full((n,), 2.0 ** -70, **kw),
+                               survival_probabilities=torch.tensor(g[f"survival_{i}"], **kw), species=ca.Species("electron", **kw))
+        screen = ca.Screen(resolution=(w, h), pixel_size=torch.tensor(g[f"pixel_size_{i}"], **kw), binning=binning,
+                           misalignment=torch.tensor(g[f"misalignment_{i}"], **kw), method="cloud-in-cell" if cic else "histogram",
+                           is_active=True, **kw)
+        screen.track(beam)
+        img = screen.reading.cpu().numpy()
+        ref = g[f"image_{i}"]
+        assert img.shape == ref.shape == (h // binning, w // binning) and img.dtype == ref.dtype, i
+        if not cic:
+            assert np.array_equal(img, ref), (i, int((img != ref).sum()))
+        else:
+            assert np.allclose(img, ref, rtol=0, atol=(1e-12 if not f32 else 2e-6) * ref.max()), i
+        assert img.sum() == pytest.approx(ref.sum(), rel=1e-12 if not f32 else 1e-6)
