@@ -391,3 +391,53 @@ def test_scalar_cavity_in_one_call_is_bit_identical(dt, cavity_type):
     assert ca.Cavity(t(1.0), voltage=t([1e6, 2e6]), phase=t(0.0), frequency=t(1.3e9), **kw)._track_scalars(beam) is None
     vp = torch.nn.Parameter(t(1e6))
     assert ca.Cavity(t(1.0), voltage=vp, phase=t(0.0), frequency=t(1.3e9), **kw)._track_scalars(beam) is None
+
+
+@pytest.mark.parametrize("trainable_beam", [False, True])
+def test_gradients_through_random_lattices_vs_reference(trainable_beam):
+    """Eight drawn beamlines (tests/golden/generate_golden_random_grads.py) with up to four trainable scalar settings each:
+    loss and d loss / d setting against the reference's autograd in float64 — through the one-node run path (RunMapScalars /
+    chx_run_vjp) when only settings are trainable, and through the general per-element path when the incoming particles
+    and the beam energy are trainable as well (then those gradients are compared too)."""
+    import json
+    import os
+
+    import numpy as np
+
+    import cheetah_amd as ca
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lattices_random_grads.npz"))
+    kw = {"dtype": torch.float64, "device": "cuda"}
+    for i in range(int(g["n_lattices"])):
+        spec = json.loads(str(g[f"spec_{i}"]))
+        trainable = json.loads(str(g[f"trainable_{i}"]))
+        elements, params = [], []
+        for e, (kind, args) in enumerate(spec):
+            targs = {}
+            for k, v in args.items():
+                if isinstance(v, float):
+                    t = torch.tensor(v, **kw)
+                    if [e, k] in trainable:
+                        t = torch.nn.Parameter(t)
+                        params.append(t)
+                    targs[k] = t
+                else:
+                    targs[k] = v
+            elements.append(getattr(ca, kind)(**targs, **kw))
+        x = torch.tensor(g[f"in_{i}"], **kw)
+        en = torch.tensor(float(g[f"energy_{i}"]), **kw)
+        if trainable_beam:
+            x, en = torch.nn.Parameter(x), torch.nn.Parameter(en)
+        out = ca.Segment(elements).track(ca.ParticleBeam(x, en, species=ca.Species("electron", **kw)))
+        w1, w2 = torch.tensor(g[f"w1_{i}"], **kw), torch.tensor(g[f"w2_{i}"], **kw)
+        loss = (out.particles[:, :6] * w1).sum(dim=1).mean() + (out.particles[:, :6].square() * w2).sum(dim=1).mean()
+        loss.backward()
+        names = [k for k, _ in spec]
+        assert float(loss.detach()) == pytest.approx(float(g[f"loss_{i}"]), rel=1e-10), (i, names)
+        ref = g[f"grads_{i}"]
+        got = np.array([float(p.grad) for p in params])
+        assert np.allclose(got, ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max()), (i, names, trainable, got, ref)
+        if trainable_beam:
+            assert float(en.grad) == pytest.approx(float(g[f"grad_energy_{i}"]), rel=1e-6, abs=1e-12 * abs(float(g[f"loss_{i}"])))
+            gp = g[f"grad_particles_{i}"]
+            assert np.allclose(x.grad.cpu().numpy(), gp, rtol=1e-8, atol=1e-10 * np.abs(gp).max()), (i, names)
