@@ -47,7 +47,7 @@ x = beam.particles
 out = torch.empty_like(x)
 sp = beam.species
 args = (fr.kinds, fr.ptrs, fr.E, beam.energy.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float, fr.code,
-        fr.state.data_ptr(), fr.state_bytes, x.data_ptr(), out.data_ptr(), x.shape[0])
+        fr.state.data_ptr(), fr.state_bytes, x.data_ptr(), out.data_ptr(), x.shape[0], None, None)
 print(f"chx_run_track only          {wall(lambda: lib.chx_run_track(*args, _ops.stream_ptr())):7.1f} us")
 R = seg.first_order_transfer_map(beam.energy, beam.species).contiguous()
 print(f"chx_apply_affine7 only      "

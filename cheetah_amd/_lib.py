@@ -75,9 +75,9 @@ SIGNATURES = {
     "chx_compose_prefix": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_run_state_bytes": (c_size_t, [c_i64]),
     "chx_run_map": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
-                            c_void_p]),
+                            c_void_p, c_void_p, c_void_p]),
     "chx_run_track": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
-                              c_void_p, c_i64, c_void_p]),
+                              c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "chx_apply_affine7": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "chx_apply_bwd_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "chx_apply_affine7_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_size_t, c_void_p]),
@@ -195,7 +195,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 3:  # CHX_ABI_VERSION of include/chx.h
+        if handle.chx_abi_version() != 4:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib

@@ -371,10 +371,11 @@ class Segment(Element):
     def _run_s(run: _Run, s_in: torch.Tensor) -> torch.Tensor:
         """`incoming.s + length` of the run; the sum is reused while the same incoming `s` tensor is
         tracked again (the usual RL loop re-tracks one incoming beam), saving a device op per track."""
+        length = Segment._run_length(run)      # re-validated on every call (and resets s_cache when a length changed)
         c = run.s_cache
         if c is not None and c[0] is s_in and c[1] == s_in._version and not s_in.requires_grad:
             return c[2]
-        s_out = s_in + Segment._run_length(run)
+        s_out = s_in + length
         if not s_out.requires_grad:
             run.s_cache = (s_in, s_in._version, s_out)
         return s_out
@@ -439,16 +440,21 @@ class Segment(Element):
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         out = torch.empty_like(x)
         _ops.check_current_device(fr.device)
+        s_in = incoming.s
+        s_out = Segment._device_s(fr, s_in)
         _ops.check(_lib.lib().chx_run_track(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
                                             sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
-                                            x.data_ptr(), out.data_ptr(), x.shape[0], _ops.stream_ptr()), "chx_run_track")
-        return out
+                                            x.data_ptr(), out.data_ptr(), x.shape[0], s_in.data_ptr() if s_out is not None else None,
+                                            s_out.data_ptr() if s_out is not None else None, _ops.stream_ptr()), "chx_run_track")
+        # the path length comes from the same launch that validates the settings (no host copy of the lengths to go stale)
+        return out, (s_out if s_out is not None else Segment._run_s(run, s_in))
 
     @staticmethod
-    def _run_map_fast(run: _Run, ref: torch.Tensor, energy: torch.Tensor, species: Species):
-        """The run's composed map as a (7, 7) tensor living inside the persistent plan's device state (chx_run_map: one
-        launch that re-validates the settings and rebuilds only if one changed), or None when the run does not qualify.
-        `ref` gives dtype and device. The tensor is overwritten by the next call: for immediate use on the same stream."""
+    def _run_map_fast(run: _Run, ref: torch.Tensor, energy: torch.Tensor, species: Species, s_in: torch.Tensor):
+        """(map, s_out): the run's composed map as a (7, 7) tensor living inside the persistent plan's device state (chx_run_map:
+        one launch that re-validates the settings and rebuilds only if one changed) and the path length behind the run from
+        the same launch — or None when the run does not qualify. `ref` gives dtype and device. The map tensor is overwritten
+        by the next call: for immediate use on the same stream."""
         if not ref.is_cuda or energy.dim() != 0:
             return None
         fr = run.fast
@@ -462,14 +468,24 @@ class Segment(Element):
                                         or species.num_elementary_charges.requires_grad or _any_requires_grad(*fr.tensors)):
             return None
         R_addr = ctypes.c_void_p()
+        s_out = Segment._device_s(fr, s_in)
         _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, energy.data_ptr(), species.mass_eV_float,
                                           species.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
-                                          ctypes.byref(R_addr), _ops.stream_ptr()), "chx_run_map")
+                                          ctypes.byref(R_addr), s_in.data_ptr() if s_out is not None else None,
+                                          s_out.data_ptr() if s_out is not None else None, _ops.stream_ptr()), "chx_run_map")
         view = fr.R_view
         if view is None or view.data_ptr() != R_addr.value:
             off = R_addr.value - fr.state.data_ptr()
             view = fr.R_view = fr.state.view(torch.uint8)[off:off + 49 * ref.element_size()].view(ref.dtype).view(7, 7)
-        return view
+        return view, (s_out if s_out is not None else Segment._run_s(run, s_in))
+
+    @staticmethod
+    def _device_s(fr: _FastRun, s_in: torch.Tensor):
+        """A fresh scalar for the path length behind the run when the plan's launch can write it (one value of the plan's
+        dtype on its device, no graph), else None (the caller adds the validated lengths on the host side)."""
+        if s_in.dim() == 0 and s_in.dtype == fr.dtype and s_in.device == fr.device and not s_in.requires_grad:
+            return torch.empty_like(s_in)
+        return None
 
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species):
         plan = self._plan()
@@ -492,14 +508,16 @@ class Segment(Element):
         if isinstance(incoming, ParameterBeam):
             for kind, item in self._plan():
                 if kind == "run":
-                    tm = None
+                    fast = None
                     if not (torch.is_grad_enabled() and (incoming.mu.requires_grad or incoming.cov.requires_grad)):
-                        tm = self._run_map_fast(item, incoming.mu, incoming.energy, incoming.species)
-                    if tm is None:
-                        tm = self._run_map(item, incoming.energy, incoming.species)
+                        fast = self._run_map_fast(item, incoming.mu, incoming.energy, incoming.species, incoming.s)
+                    if fast is None:
+                        tm, s_out = self._run_map(item, incoming.energy, incoming.species), self._run_s(item, incoming.s)
+                    else:
+                        tm, s_out = fast
                     mu, cov = _ops.parameter_track(incoming.mu, incoming.cov, tm)
-                    incoming = ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge,
-                                             s=self._run_s(item, incoming.s), species=incoming.species)
+                    incoming = ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge, s=s_out,
+                                             species=incoming.species)
                 else:
                     incoming = item._track_internal(incoming)
             return incoming
@@ -510,13 +528,14 @@ class Segment(Element):
         while i < n_items:
             kind, item = plan[i]
             if kind == "run":
-                new_particles = self._run_apply_fast(item, incoming)
-                if new_particles is None:
+                fast = self._run_apply_fast(item, incoming)
+                if fast is None:
                     tm = self._run_map(item, incoming.energy, incoming.species)
-                    new_particles = _ops.apply_map(incoming.particles, tm)
+                    new_particles, s_out = _ops.apply_map(incoming.particles, tm), self._run_s(item, incoming.s)
+                else:
+                    new_particles, s_out = fast
                 incoming = ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
-                                        survival_probabilities=incoming.survival_probabilities,
-                                        s=self._run_s(item, incoming.s), species=incoming.species)
+                                        survival_probabilities=incoming.survival_probabilities, s=s_out, species=incoming.species)
             else:
                 if i + 1 < n_items and plan[i + 1][0] == "run" and isinstance(item, SpaceChargeKick):
                     # [SpaceChargeKick, run of linear elements]: the run's map is applied inside the kick's particle kernel
@@ -549,15 +568,18 @@ class Segment(Element):
                                         or _any_requires_grad(*fr.tensors)):
             return None
         R_addr = ctypes.c_void_p()
+        s_in = incoming.s
+        s_out = self._device_s(fr, s_in)
         _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float,
-                                          fr.code, fr.state.data_ptr(), fr.state_bytes, ctypes.byref(R_addr), _ops.stream_ptr()),
-                   "chx_run_map")
+                                          fr.code, fr.state.data_ptr(), fr.state_bytes, ctypes.byref(R_addr),
+                                          s_in.data_ptr() if s_out is not None else None,
+                                          s_out.data_ptr() if s_out is not None else None, _ops.stream_ptr()), "chx_run_map")
         out = kick._track_then_map(incoming, R_addr.value)
         if out is None:
             return None
         return ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities, s=self._run_s(run, incoming.s),
-                            species=incoming.species)
+                            survival_probabilities=incoming.survival_probabilities,
+                            s=s_out if s_out is not None else self._run_s(run, s_in), species=incoming.species)
 
     @tracking_call
     def track_moments(self, incoming: ParticleBeam, exact: bool = True) -> ParameterBeam:

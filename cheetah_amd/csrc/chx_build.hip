@@ -1277,14 +1277,29 @@ struct RunArgs {
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void run_map_kernel(RunArgs a, int E, int nptr, const T* __restrict__ energy,
                                                            double mass, double nq, double* __restrict__ seen /*[nptr + 3]*/,
-                                                           T* __restrict__ maps /*[E][49]*/, T* __restrict__ R /*[49]*/) {
+                                                           T* __restrict__ maps /*[E][49]*/, T* __restrict__ R /*[49]*/,
+                                                           const T* __restrict__ s_in, T* __restrict__ s_out) {
     // 1. anything different from what R was built from? (NaN-initialised state: the first call is always dirty)
     int dirty = 0;
     for (int q = threadIdx.x; q < nptr + 3; q += CHX_BLOCK) {
         const double v = q < nptr ? (double)*(const T*)a.ptr[q] : (q == nptr ? (double)energy[0] : (q == nptr + 1 ? mass : nq));
         if (!(v == seen[q])) dirty = 1;
     }
-    if (!__syncthreads_or(dirty)) return;
+    // 1b. path length behind the run, s + (((L_0 + L_1) + L_2) + ...) in T like the reference's `incoming.s + segment.length`
+    // (segment.py:54-58, element.py:189): the first parameter of every kind is its length. Read from the settings on every
+    // call — the host keeps no copy that an in-place edit of a length could leave stale. All lengths are fetched in parallel,
+    // lane 0 adds them in element order.
+    __shared__ T lens[kRunMaxE];
+    if (s_out) {
+        for (int e = threadIdx.x; e < E; e += CHX_BLOCK) lens[e] = *(const T*)a.ptr[a.off[e]];
+    }
+    dirty = __syncthreads_or(dirty);
+    if (threadIdx.x == 0 && s_out) {
+        T total = lens[0];
+        for (int e = 1; e < E; ++e) total = total + lens[e];
+        *s_out = *s_in + total;
+    }
+    if (!dirty) return;
     // 2. element maps, fp64 inside, rounded to T (chx_build_rmatrix_scalars)
     for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
         const int kind = a.kind[e];
@@ -1332,8 +1347,9 @@ static int run_args(const int32_t* kinds, const void* const* param_ptrs, int64_t
 }
 
 extern "C" int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
-                           double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, void* stream) {
-    if (!energy || !state) return CHX_ERR_INVALID_ARG;
+                           double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, const void* s_in,
+                           void* s_out, void* stream) {
+    if (!energy || !state || ((s_in == nullptr) != (s_out == nullptr))) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     RunArgs a;
     int nptr = 0;
@@ -1347,19 +1363,19 @@ extern "C" int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(run_map_kernel<float>, dim3(1), dim3(CHX_BLOCK), 0, s, a, (int)E, nptr, (const float*)energy, mass_eV,
-                           n_charges, seen, (float*)maps, (float*)R);
+                           n_charges, seen, (float*)maps, (float*)R, (const float*)s_in, (float*)s_out);
     else
         hipLaunchKernelGGL(run_map_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s, a, (int)E, nptr, (const double*)energy,
-                           mass_eV, n_charges, seen, maps, R);
+                           mass_eV, n_charges, seen, maps, R, (const double*)s_in, (double*)s_out);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
 
 extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                              double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out,
-                             int64_t N, void* stream) {
+                             int64_t N, const void* s_in, void* s_out, void* stream) {
     void* R = nullptr;
-    int st = chx_run_map(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, state, state_bytes, &R, stream);
+    int st = chx_run_map(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, state, state_bytes, &R, s_in, s_out, stream);
     if (st != CHX_OK) return st;
     return chx_apply_affine7(x_in, R, x_out, 1, 1, 1, N, dtype, stream);
 }

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 3 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick */
+#define CHX_ABI_VERSION 4 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
+                             4: s_in / s_out arguments of chx_run_map / chx_run_track */
 
 typedef enum chx_status {
     CHX_OK = 0,
@@ -101,7 +102,10 @@ int chx_build_rmatrix_scalars(const int32_t* kinds, const void* const* param_ptr
  * chx_build_rmatrix_scalars + chx_compose_maps. *R_out (if not NULL) receives the device address of R[7][7] inside `state`.
  * chx_run_track = chx_run_map + chx_apply_affine7(x_in, R, x_out) for one beam of N particles: a whole merged
  * Segment.track in one call, with no host-side validation of the settings. E <= 192 elements, <= 400 parameters in total
- * (CHX_ERR_INVALID_ARG beyond: use the two-call form). Identity elements are left out by the caller. */
+ * (CHX_ERR_INVALID_ARG beyond: use the two-call form). Identity elements are left out by the caller.
+ * s_in / s_out (both NULL or both device pointers to one `dtype` value): the path length behind the run,
+ * *s_out = *s_in + (((L_0 + L_1) + L_2) + ...) with the lengths read from the settings on every call (the first parameter of
+ * every kind), like `incoming.s + segment.length` (segment.py:54-58): no host copy that an edited length could leave stale. */
 /* Prefix products of a run: out[e][b] = maps[e][b] ... maps[1][b] maps[0][b] for every e (maps[E][Bm][7][7], Bm in {1, B};
  * out[E][B][7][7]); fp64 accumulation carried along, each prefix rounded once. With chx_track_moments on the E prefixes the
  * beam moments after every element of a lattice (segment.py:658-700 `get_beam_attrs_along_segment`) cost one pass over the
@@ -118,10 +122,11 @@ int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, 
                 size_t workspace_bytes, void* stream);
 size_t chx_run_state_bytes(int64_t E);
 int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
-                double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, void* stream);
+                double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, const void* s_in, void* s_out,
+                void* stream);
 int chx_run_track(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                   double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
-                  void* stream);
+                  const void* s_in, void* s_out, void* stream);
 /* ---- segment composition (a2; segment.py:534-543): R_out[b] = R_{E-1}[b] ... R_1[b] R_0[b].
  * R_ptrs is a HOST array of E device pointers, one map buffer per element (each element owns
  * its cached map); buffer e is [1][7][7] if bcast[e] (HOST array) else [B][7][7]. The pointers are

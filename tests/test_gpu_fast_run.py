@@ -151,7 +151,7 @@ def test_c_abi_run_map_against_build_and_compose(ca):
 
     def run():
         _ops.check(lib.chx_run_map(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), nbytes,
-                                   ctypes.byref(R_addr), _ops.stream_ptr()), "chx_run_map")
+                                   ctypes.byref(R_addr), None, None, _ops.stream_ptr()), "chx_run_map")
         off = (R_addr.value - state.data_ptr()) // 8
         return state[off:off + 49].reshape(7, 7).clone()
 
@@ -167,8 +167,8 @@ def test_c_abi_run_map_against_build_and_compose(ca):
     vals[2].fill_(-3.3)
     R2 = run()
     assert not torch.equal(R2, R1) and torch.equal(R2, two_call())
-    assert lib.chx_run_map(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), 16, None, None) == -5
-    assert lib.chx_run_map(karr, parr, 0, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), nbytes, None, None) == -1
+    assert lib.chx_run_map(karr, parr, E, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), 16, None, None, None, None) == -5
+    assert lib.chx_run_map(karr, parr, 0, energy.data_ptr(), 510998.95069, -1.0, 1, state.data_ptr(), nbytes, None, None, None, None) == -1
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
@@ -441,3 +441,50 @@ def test_gradients_through_random_lattices_vs_reference(trainable_beam):
             assert float(en.grad) == pytest.approx(float(g[f"grad_energy_{i}"]), rel=1e-6, abs=1e-12 * abs(float(g[f"loss_{i}"])))
             gp = g[f"grad_particles_{i}"]
             assert np.allclose(x.grad.cpu().numpy(), gp, rtol=1e-8, atol=1e-10 * np.abs(gp).max()), (i, names)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_path_length_follows_every_edit_of_a_length(dt):
+    """`s` behind a run is `incoming.s + (L_0 + L_1 + ...)` (segment.py:54-58). The persistent plan computes it in the launch
+    that validates the settings, so a length that was re-assigned or edited IN PLACE shows up at once — for a ParticleBeam, a
+    ParameterBeam, behind a SpaceChargeKick and on the general path (regression: the fast path used to hand out a cached sum)."""
+    import cheetah_amd as ca
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    d = ca.Drift(t(1.0), **kw)
+    q = ca.Quadrupole(t(0.2), k1=t(1.0), **kw)
+    seg = ca.Segment([d, ca.Marker(), q])
+    beam = ca.ParticleBeam.from_parameters(num_particles=2000, **kw)
+    pbeam = ca.ParameterBeam.from_parameters(**kw)
+
+    def expect(total, s0=0.0):
+        want = float(t(s0) + (t(total[0]) + t(total[1])))          # the reference's association, in dtype
+        for b in (beam, pbeam):
+            if s0:
+                b = b.clone()
+                b.s = t(s0)
+            out = seg.track(b)
+            assert float(out.s) == want, (type(b).__name__, float(out.s), want)
+            assert out.s is not b.s
+
+    expect((1.0, 0.2))
+    expect((1.0, 0.2))                      # steady state (nothing changed)
+    d.length = t(2.0)
+    expect((2.0, 0.2))
+    d.length.add_(1.0)                      # in place: no host counter moves
+    expect((3.0, 0.2))
+    q.length.mul_(2.0)
+    expect((3.0, 0.4), s0=5.0)
+    # behind a kick, the run's map and its length are folded into the kick's pass
+    sc_seg = ca.Segment([ca.Drift(t(0.1), **kw), ca.SpaceChargeKick(t(0.25), grid_shape=(16, 16, 16), **kw), d, q])
+    big = ca.ParticleBeam.from_parameters(num_particles=20_000, total_charge=t(1e-10), **kw)
+    s1 = float(sc_seg.track(big).s)
+    d.length.add_(0.5)
+    s2 = float(sc_seg.track(big).s)
+    assert s1 == pytest.approx(0.1 + 3.4, rel=1e-6) and s2 == pytest.approx(s1 + 0.5, rel=1e-6)   # the kick itself is thin
+    # the general path (a vectorised setting rules the plan out) validates the lengths as well
+    q.k1 = t([1.0, 2.0])
+    assert float(seg.track(beam).s) == pytest.approx(3.9, rel=1e-6)
+    d.length.sub_(1.0)
+    assert float(seg.track(beam).s) == pytest.approx(2.9, rel=1e-6)
