@@ -124,10 +124,11 @@ SIGNATURES = {
     "chx_sc_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
     "chx_sc_gather_kick_mapped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64,
                                           c_i64, c_i32_p, c_int, c_void_p, c_i64, c_void_p, c_void_p]),
-    "chx_cavity_prepare_scalars": (c_int, [c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_cavity_prepare_scalars": (c_int, [c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p]),
     "chx_cavity_track_scalars_workspace_bytes": (c_size_t, []),
     "chx_cavity_track_scalars": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_i64, c_int, c_void_p, c_void_p,
-                                         c_void_p, c_size_t, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_copy_arrays": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int32, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),

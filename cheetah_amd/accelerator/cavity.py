@@ -150,16 +150,26 @@ class Cavity(Element):
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         out = torch.empty_like(x)
         e_out = torch.empty((), dtype=p.dtype, device=p.device)
-        ws_bytes = lib.chx_cavity_track_scalars_workspace_bytes()
-        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=p.device)
+        # map and coefficients live in a workspace that belongs to this element (consumed by the launch that follows on the
+        # same stream; elements, like the reference's caches, are not re-entrant)
+        ws = self.__dict__.get("_scalar_ws")
+        if ws is None or ws.device != p.device:
+            ws = self.__dict__["_scalar_ws"] = torch.empty(lib.chx_cavity_track_scalars_workspace_bytes() // 8 + 1,
+                                                           dtype=torch.float64, device=p.device)
         _ops.check_current_device(p.device)
         kind = _ops.KIND["cavity_sw" if self.cavity_type == "standing_wave" else "cavity_tw"]
+        s_in = incoming.s
+        s_out = torch.empty_like(s_in) if (s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device
+                                           and not s_in.requires_grad) else None
         _ops.check(lib.chx_cavity_track_scalars(x.data_ptr(), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in settings]), e.data_ptr(),
                                                 kind, sp.mass_eV_float, sp.num_elementary_charges_float, x.shape[0],
-                                                _ops.dtype_code(p.dtype), out.data_ptr(), e_out.data_ptr(), ws.data_ptr(),
-                                                ws.numel() * 8, _ops.stream_ptr()), "chx_cavity_track_scalars")
+                                                _ops.dtype_code(p.dtype), out.data_ptr(), e_out.data_ptr(),
+                                                s_in.data_ptr() if s_out is not None else None,
+                                                s_out.data_ptr() if s_out is not None else None, ws.data_ptr(), ws.numel() * 8,
+                                                _ops.stream_ptr()), "chx_cavity_track_scalars")
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length, species=sp)
+                            survival_probabilities=incoming.survival_probabilities,
+                            s=s_out if s_out is not None else s_in + self.length, species=sp)
 
     @property
     def defining_features(self) -> list[str]:

@@ -535,13 +535,14 @@ extern "C" size_t chx_cavity_track_scalars_workspace_bytes(void) { return 49 * s
 
 extern "C" int chx_cavity_track_scalars(const void* x_in, const void* const* param_ptrs, const void* energy, int kind,
                                         double mass_eV, double n_charges, int64_t N, int dtype, void* x_out, void* energy_out,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        const void* s_in, void* s_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x_in || !x_out || !workspace || workspace_bytes < chx_cavity_track_scalars_workspace_bytes() || N < 1)
         return CHX_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return CHX_ERR_MISALIGNED;
     void* R = workspace;
     double* coeffs = reinterpret_cast<double*>((char*)workspace + 49 * sizeof(double) + 8);
-    int st = chx_cavity_prepare_scalars(param_ptrs, energy, kind, mass_eV, n_charges, dtype, R, coeffs, energy_out, stream);
+    int st = chx_cavity_prepare_scalars(param_ptrs, energy, kind, mass_eV, n_charges, dtype, R, coeffs, energy_out, s_in, s_out,
+                                        stream);
     if (st != CHX_OK) return st;
     return chx_cavity_track(x_in, R, coeffs, x_out, 1, 1, N, dtype, stream);
 }

@@ -522,8 +522,9 @@ template <typename T>
 __global__ void cavity_prepare_scalars_kernel(const T* __restrict__ L, const T* __restrict__ V, const T* __restrict__ ph,
                                               const T* __restrict__ fr, const T* __restrict__ energy, int kind, double mass,
                                               double nq, T* __restrict__ R_out, double* __restrict__ coeffs,
-                                              T* __restrict__ energy_out) {
+                                              T* __restrict__ energy_out, const T* __restrict__ s_in, T* __restrict__ s_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (s_out) *s_out = *s_in + *L;          // incoming.s + length (cavity.py:228-251), in T
     const double p[4] = {(double)*L, (double)*V, (double)*ph, (double)*fr};
     const double E0 = (double)*energy;
     Mat7<double> R;
@@ -1016,8 +1017,9 @@ extern "C" int chx_cavity_coeffs(const void* params, const void* energy, double 
 
 extern "C" int chx_cavity_prepare_scalars(const void* const* param_ptrs, const void* energy, int kind, double mass_eV,
                                           double n_charges, int dtype, void* R_out, double* coeffs, void* energy_out,
-                                          void* stream) {
-    if (!param_ptrs || !energy || !R_out || !coeffs || !energy_out) return CHX_ERR_INVALID_ARG;
+                                          const void* s_in, void* s_out, void* stream) {
+    if (!param_ptrs || !energy || !R_out || !coeffs || !energy_out || ((s_in == nullptr) != (s_out == nullptr)))
+        return CHX_ERR_INVALID_ARG;
     if (kind != CHX_CAVITY_SW && kind != CHX_CAVITY_TW) return CHX_ERR_INVALID_ARG;
     for (int k = 0; k < 4; ++k)
         if (!param_ptrs[k]) return CHX_ERR_INVALID_ARG;
@@ -1025,11 +1027,13 @@ extern "C" int chx_cavity_prepare_scalars(const void* const* param_ptrs, const v
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(cavity_prepare_scalars_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)param_ptrs[0],
                            (const float*)param_ptrs[1], (const float*)param_ptrs[2], (const float*)param_ptrs[3],
-                           (const float*)energy, kind, mass_eV, n_charges, (float*)R_out, coeffs, (float*)energy_out);
+                           (const float*)energy, kind, mass_eV, n_charges, (float*)R_out, coeffs, (float*)energy_out,
+                           (const float*)s_in, (float*)s_out);
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL(cavity_prepare_scalars_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)param_ptrs[0],
                            (const double*)param_ptrs[1], (const double*)param_ptrs[2], (const double*)param_ptrs[3],
-                           (const double*)energy, kind, mass_eV, n_charges, (double*)R_out, coeffs, (double*)energy_out);
+                           (const double*)energy, kind, mass_eV, n_charges, (double*)R_out, coeffs, (double*)energy_out,
+                           (const double*)s_in, (double*)s_out);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

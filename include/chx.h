@@ -420,11 +420,12 @@ int chx_sc_kick(const void* x_in, const void* charge, const void* survival, cons
  * chx_cavity_track_scalars adds the particle pass of chx_cavity_track: the whole element in one call, two launches,
  * bit-identical to chx_build_rmatrix + chx_cavity_coeffs + chx_cavity_track. */
 int chx_cavity_prepare_scalars(const void* const* param_ptrs, const void* energy, int kind, double mass_eV, double n_charges,
-                               int dtype, void* R_out, double* coeffs, void* energy_out, void* stream);
+                               int dtype, void* R_out, double* coeffs, void* energy_out, const void* s_in /*may be NULL*/,
+                               void* s_out /*NULL iff s_in is: *s_out = *s_in + length*/, void* stream);
 size_t chx_cavity_track_scalars_workspace_bytes(void);
 int chx_cavity_track_scalars(const void* x_in, const void* const* param_ptrs, const void* energy, int kind, double mass_eV,
-                             double n_charges, int64_t N, int dtype, void* x_out, void* energy_out, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             double n_charges, int64_t N, int dtype, void* x_out, void* energy_out, const void* s_in,
+                             void* s_out, void* workspace, size_t workspace_bytes, void* stream);
 /* n <= 8 device arrays copied by one launch: dst[k][0 .. bytes[k]) = src[k][...] (host arrays of device pointers and byte
  * counts). What a Screen's record of the incoming beam costs (screen.py:190 `incoming.clone()`: five tensors). */
 int chx_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
