@@ -399,12 +399,42 @@ inline dim3 particle_grid(int64_t N, int64_t B) {
 //                     plain, coalesced `grid += tile` (no halo exchange); the overflow of hot tiles (beams focused
 //                     into a few cells) is load-balanced over chunks of the record array by pass 4b
 // The index / weight arithmetic is the one of cic_locate / cic_deposit_kernel above (bit-identical addends).
+// A record lives in the slot range of ONE tile, so its base cell is stored relative to that tile's origin: 7 bits per
+// axis (i - origin + 2 in [0, 66] for tile edges up to 64) in one word. fp32: 16 bytes in 2-D (one dwordx4 per record),
+// 20 bytes in 3-D (dwordx4 + dword at element alignment) instead of 20 / 28 with full indices — the scatter pass issues
+// one line request per store instruction and lane, so the record's instruction count is its price.
 template <typename T, int ND>
-struct CicRec {
-    int32_t i[ND];
+struct alignas((ND == 2 && sizeof(T) == 4) ? 16 : sizeof(T)) CicRec {
     T f[ND];
     T c;
+    uint32_t cell;
 };
+constexpr int kRecBits = 7, kRecBias = 2;
+
+template <typename T, int ND>
+__device__ __forceinline__ void rec_store(CicRec<T, ND>* __restrict__ dst, const CicRec<T, ND>& r) {
+    if constexpr (ND == 3 && sizeof(T) == 4) {
+        struct alignas(4) Quad { float v[4]; };
+        *reinterpret_cast<Quad*>(dst) = Quad{{r.f[0], r.f[1], r.f[2], r.c}};
+        dst->cell = r.cell;
+    } else {
+        *dst = r;
+    }
+}
+
+template <typename T, int ND>
+__device__ __forceinline__ CicRec<T, ND> rec_load(const CicRec<T, ND>* __restrict__ src) {
+    if constexpr (ND == 3 && sizeof(T) == 4) {
+        struct alignas(4) Quad { float v[4]; };
+        const Quad q = *reinterpret_cast<const Quad*>(src);
+        CicRec<T, ND> r;
+        r.f[0] = q.v[0]; r.f[1] = q.v[1]; r.f[2] = q.v[2]; r.c = q.v[3];
+        r.cell = src->cell;
+        return r;
+    } else {
+        return *src;
+    }
+}
 
 struct TileGeom {
     int tdim[3];   // tile edge in cells per axis (a power of two)
@@ -619,7 +649,7 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
             CicRec<T, ND> r;
             if (SCATTER) {
 #pragma unroll
-                for (int d = 0; d < ND; ++d) { r.i[d] = pi[d]; r.f[d] = pf[d]; }
+                for (int d = 0; d < ND; ++d) r.f[d] = pf[d];
                 r.c = craw[u];
             }
             for (int tx = t0[0]; tx <= t1[0]; ++tx)
@@ -628,7 +658,13 @@ __global__ __launch_bounds__(kSortThreads) void cic_sort_kernel(CicDev a, TileGe
                         const int tile = (tx * g.ntile[1] + ty) * g.ntile[2] + tz;
                         const int pos = atomicAdd(&hist[tile], 1);
                         if (SCATTER) {
-                            if (pos < rec_cap) rb[pos] = r;
+                            const int tt[3] = {tx, ty, tz};
+                            uint32_t cell = 0;
+#pragma unroll
+                            for (int d = 0; d < ND; ++d)
+                                cell |= (uint32_t)(pi[d] - (tt[d] << g.tshift[d]) + kRecBias) << (kRecBits * d);
+                            r.cell = cell;
+                            if (pos < rec_cap) rec_store<T, ND>(rb + pos, r);
                         }
                     }
         }
@@ -732,8 +768,8 @@ __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileG
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
                 if (d < ND) {
-                    const int id = rec.i[d] + o;
-                    const int l = id - org[d];
+                    const int l = (int)((rec.cell >> (kRecBits * d)) & ((1u << kRecBits) - 1)) - kRecBias + o;
+                    const int id = l + org[d];
                     // valid grid cell AND owned by this tile
                     ok[d][o] = (id >= 0) && (id < a.bins[d]) && (l >= 0) && (l < ld[d]);
                     li[d][o] = l;
@@ -764,10 +800,11 @@ __global__ __launch_bounds__(THREADS) void cic_accumulate_kernel(CicDev a, TileG
     int r = beg + threadIdx.x;
     // four record loads in flight per lane before the first ds_add depends on them
     for (; r + 3 * THREADS < end; r += 4 * THREADS) {
-        const CicRec<T, ND> r0 = rb[r], r1 = rb[r + THREADS], r2 = rb[r + 2 * THREADS], r3 = rb[r + 3 * THREADS];
+        const CicRec<T, ND> r0 = rec_load<T, ND>(rb + r), r1 = rec_load<T, ND>(rb + r + THREADS),
+                            r2 = rec_load<T, ND>(rb + r + 2 * THREADS), r3 = rec_load<T, ND>(rb + r + 3 * THREADS);
         deposit(r0); deposit(r1); deposit(r2); deposit(r3);
     }
-    for (; r < end; r += THREADS) deposit(rb[r]);
+    for (; r < end; r += THREADS) deposit(rec_load<T, ND>(rb + r));
     __syncthreads();
     // flush the owned cells: exclusive owner -> plain read-modify-write, last axis fastest (coalesced)
     T* gb = grid + b * a.gbatch;
@@ -862,8 +899,8 @@ __global__ __launch_bounds__(kAccThreads) void cic_accumulate_hot_kernel(CicDev 
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     if (d < ND) {
-                        const int id = rec.i[d] + o;
-                        const int l = id - org[d];
+                        const int l = (int)((rec.cell >> (kRecBits * d)) & ((1u << kRecBits) - 1)) - kRecBias + o;
+                        const int id = l + org[d];
                         // valid grid cell AND owned by this tile
                         ok[d][o] = (id >= 0) && (id < a.bins[d]) && (l >= 0) && (l < ld[d]);
                         li[d][o] = l;
@@ -894,10 +931,10 @@ __global__ __launch_bounds__(kAccThreads) void cic_accumulate_hot_kernel(CicDev 
         int r = beg + threadIdx.x;
         // two record loads in flight per lane before the first ds_add depends on them
         for (; r + kAccThreads < end; r += 2 * kAccThreads) {
-            const CicRec<T, ND> ra = rb[r], rc = rb[r + kAccThreads];
+            const CicRec<T, ND> ra = rec_load<T, ND>(rb + r), rc = rec_load<T, ND>(rb + r + kAccThreads);
             deposit(ra); deposit(rc);
         }
-        for (; r < end; r += kAccThreads) deposit(rb[r]);
+        for (; r < end; r += kAccThreads) deposit(rec_load<T, ND>(rb + r));
         __syncthreads();
         // add the tile to the grid (pass 4a may be writing the same cells: atomics)
         for (int i = threadIdx.x; i < lcells; i += kAccThreads) {
