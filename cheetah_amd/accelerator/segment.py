@@ -584,7 +584,7 @@ class Segment(Element):
     @tracking_call
     def track_moments(self, incoming: ParticleBeam, exact: bool = True) -> ParameterBeam:
         """Track a `ParticleBeam` and return only the outgoing beam's moments as a `ParameterBeam` (mu, cov,
-        energy, total_charge, s). Same numbers as `self.track(incoming).as_parameter_beam()`, but the last run
+        energy, total_charge, s, species). Same moments as `self.track(incoming).as_parameter_beam()`, but the last run
         of linear elements is fused with the moment reduction (`chx_track_moments`): the tracked particles of
         that run are never written — for a scan of B lattice settings over one shared beam that is the
         (B, N, 7) array (11.5 GB at B = 4096, N = 1e5).
@@ -609,12 +609,10 @@ class Segment(Element):
             else:
                 incoming = item.track(incoming)
         if last_run is None:
-            out = incoming.as_parameter_beam()
-            out.s = incoming.s
-            return out
+            return incoming._as_parameter_beam_same_species()
         tm = self._run_map(last_run, incoming.energy, incoming.species)
         if not exact:
-            entering = incoming.as_parameter_beam()
+            entering = incoming._as_parameter_beam_same_species()
             mu, cov = _ops.parameter_track(entering.mu, entering.cov, tm)
             return ParameterBeam(mu, cov, incoming.energy, total_charge=incoming.total_charge,
                                  s=self._run_s(last_run, incoming.s), species=incoming.species)

@@ -278,9 +278,17 @@ class ParticleBeam(Beam):
         chx_moments call instead of 27 separate reductions."""
         from .parameter_beam import ParameterBeam
 
-        # like the reference (particle_beam.py:1168-1178) `s` restarts at 0; the species is kept
+        # like the reference (particle_beam.py:1168-1178) neither `s` nor the species is passed on: `s` restarts at 0 and the
+        # result is an ELECTRON beam whatever this beam's species is (a quirk that is kept: same results on the same calls)
         return ParameterBeam._from_moment_vector(self._moments(), self.particles.dtype, self.energy,
-                                                 total_charge=self.total_charge, species=self.species)
+                                                 total_charge=self.total_charge)
+
+    def _as_parameter_beam_same_species(self):
+        """`as_parameter_beam` with this beam's species and path length (for the engine's own fused observables)."""
+        from .parameter_beam import ParameterBeam
+
+        return ParameterBeam._from_moment_vector(self._moments(), self.particles.dtype, self.energy,
+                                                 total_charge=self.total_charge, s=self.s, species=self.species)
 
     def _mu(self, i: int) -> torch.Tensor:
         return self._moments()[..., 2 + i].to(self.particles.dtype)
