@@ -69,3 +69,52 @@ def test_clone_many_copies_every_array_in_one_launch():
         assert not _ops.clone_many([g])[0].requires_grad
     big.add_(1.0)
     assert not torch.equal(copies[0], big)
+
+
+@pytest.mark.gpu
+def test_every_beam_property_on_drawn_beams_vs_reference(golden):
+    """beam_properties_random.npz (tests/golden/generate_golden_random_beam_properties.py): all derived properties of the
+    reference's Beam / ParticleBeam / ParameterBeam classes on eight drawn beams — correlated coordinates, unequal and negative
+    charges, survival probabilities with exact zeros, four species, gamma 1.3 … 1e4, vector shapes on the particles and / or the
+    energy — value and shape, in float64. Properties the reference itself cannot evaluate for a shape (`energies` of shared
+    particles with a vectorised energy) are not in the fixture and not asserted."""
+    import cheetah_amd as ca
+
+    g = golden("beam_properties_random.npz")
+    kw = {"dtype": torch.float64, "device": "cuda"}
+    base, moments, ponly = [str(v) for v in g["base"]], [str(v) for v in g["moments"]], [str(v) for v in g["particle_only"]]
+
+    def check(obj, name, ref, what):
+        got = getattr(obj, name)
+        got = got.cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+        assert got.shape == ref.shape, (what, name, got.shape, ref.shape)
+        # second moments of 200-700 weighted particles: differences of products, 1e-9 of the reference's own scale is the
+        # cancellation in its two-pass formula; the dispersions divide two such numbers
+        scale = np.maximum(np.abs(ref), 1e-12 * max(np.abs(ref).max(), 1e-300))
+        assert np.all(np.abs(got - ref) <= 2e-9 * scale + 1e-300), (what, name, got, ref)
+
+    for i in range(int(g["n_beams"])):
+        name = str(g[f"species_{i}"])
+        sp = (ca.Species("ion", num_elementary_charges=torch.tensor(6.0, **kw), mass_eV=torch.tensor(1.1178e10, **kw)) if name == "ion"
+              else ca.Species(name, **kw))
+        beam = ca.ParticleBeam(torch.tensor(g[f"particles_{i}"], **kw), torch.tensor(g[f"energy_{i}"], **kw),
+                               particle_charges=torch.tensor(g[f"charges_{i}"], **kw),
+                               survival_probabilities=torch.tensor(g[f"survival_{i}"], **kw), species=sp)
+        for prop in base + moments + ponly:
+            if f"pb_{prop}_{i}" in g.files:
+                check(beam, prop, g[f"pb_{prop}_{i}"], f"ParticleBeam {i}")
+        assert beam.num_particles == int(g[f"pb_num_particles_{i}"])
+        conv = beam.as_parameter_beam()
+        mu_ref, cov_ref = g[f"mu_{i}"], g[f"cov_{i}"]
+        assert conv.mu.shape == mu_ref.shape and conv.cov.shape == cov_ref.shape
+        sig = np.sqrt(np.abs(np.diagonal(cov_ref, axis1=-2, axis2=-1)))[..., :6]
+        assert np.abs(conv.mu.cpu().numpy() - mu_ref).max() <= 1e-12 * np.abs(mu_ref).max()
+        cov = conv.cov.cpu().numpy()
+        assert (np.abs(cov - cov_ref)[..., :6, :6] / (sig[..., :, None] * sig[..., None, :])).max() < 1e-9
+        # the affine coordinate has no spread: exactly 0 here, rounding noise of the reference's weighted two-pass formula there
+        assert np.abs(cov[..., 6, :]).max() == 0.0 and np.abs(cov[..., :, 6]).max() == 0.0 and np.abs(cov_ref[..., 6, :]).max() < 1e-18
+        par = ca.ParameterBeam(torch.tensor(mu_ref, **kw), torch.tensor(cov_ref, **kw), torch.tensor(g[f"energy_{i}"], **kw),
+                               total_charge=beam.total_charge, species=sp)
+        for prop in base + moments:
+            if f"par_{prop}_{i}" in g.files:
+                check(par, prop, g[f"par_{prop}_{i}"], f"ParameterBeam {i}")
