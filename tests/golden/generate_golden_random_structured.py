@@ -4,7 +4,8 @@ element lists contain nested Segments (two levels), Superimposed elements (a zer
 middle of a drift or quadrupole), Undulators, CustomTransferMaps, linear Sextupoles, active cavities and one small
 SpaceChargeKick followed by a run of linear elements — for electrons, positrons, protons and a custom ion. Stored per lattice:
 the recursive element list as JSON, the species, 128 incoming particles and what `Segment.track` makes of them in float64
-(particles, survival probabilities, energy, s), plus mu / cov of a ParameterBeam for the lattices without space charge.
+(particles, survival probabilities, energy, s), plus mu / cov of a ParameterBeam for the lattices without space charge, and
+the LatticeJSON text the reference writes for each lattice with the reference's tracking result after reading it back.
 Run in the build container:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden_random_structured.py
 """
 import json
@@ -147,6 +148,13 @@ if __name__ == "__main__":
         arrays[f"s_out_{i}"] = out.s.numpy()
         arrays[f"length_{i}"] = seg.length.numpy()
         arrays[f"n_flat_{i}"] = np.asarray(len(seg.flattened().elements))
+        # the lattice as the reference writes it to LatticeJSON, and what the reference tracks after reading that file back in
+        # float64 (the file keeps ~17 digits; a default-dtype load would round every setting to float32)
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(), "lattice.json")
+        seg.to_lattice_json(path)
+        arrays[f"json_{i}"] = np.asarray(open(path).read())
+        arrays[f"out_json_{i}"] = cheetah.Segment.from_lattice_json(path, **f64).track(beam).particles.numpy()
         if not with_sc:
             # NOT beam.as_parameter_beam(): the reference's conversion drops the species (particle_beam.py:1168-1178 passes none,
             # so a proton beam becomes an electron ParameterBeam); the moments are the same, the species is passed on here

@@ -9,6 +9,8 @@ Tolerances (stated per test):
  * images / grids (float atomics, order dependent): rtol 1e-5 fp32, 1e-11 fp64.
 """
 import json
+import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -882,6 +884,27 @@ def test_random_structured_lattices_vs_reference(ca, golden, tag):
         if tag == "f64":
             again = flat.track(beam).particles.cpu().numpy()
             assert (np.abs(again - got) / scale).max() < 1e-11, i
+        if tag == "f64":
+            # LatticeJSON, both ways: the file the reference wrote for this lattice, read here, tracks to what the reference got
+            # after reading it back; and the file written here holds the reference's entries (element names, which come from a
+            # process-wide counter, replaced by their order of appearance)
+            path = os.path.join(tempfile.mkdtemp(), "lattice.json")
+            with open(path, "w") as f:
+                f.write(str(g[f"json_{i}"]))
+            loaded = ca.Segment.from_lattice_json(path, **kw)
+            assert (np.abs(loaded.track(beam).particles.cpu().numpy() - g[f"out_json_{i}"]) / scale).max() < (1e-9 if has_sc else 1e-10), i
+            seg.to_lattice_json(path)
+
+            def canonical(text):
+                doc = json.loads(text)
+                names = {n: f"e{k}" for k, n in enumerate(list(doc["elements"]) + list(doc["lattices"]))}
+                swap = lambda v: (names.get(v, v) if isinstance(v, str) else [swap(x) for x in v] if isinstance(v, list)  # noqa: E731
+                                  else {k: swap(x) for k, x in v.items()} if isinstance(v, dict) else v)
+                return {"version": doc["version"], "root": names[doc["root"]],
+                        "elements": {names[n]: [e[0], swap(e[1])] for n, e in doc["elements"].items()},
+                        "lattices": {names[n]: swap(e) for n, e in doc["lattices"].items()}}
+
+            assert canonical(open(path).read()) == canonical(str(g[f"json_{i}"])), i
         if f"pmu_in_{i}" in g.files and tag == "f64":
             # the reference's conversion passes no species on (particle_beam.py:1168-1178): a proton beam converts to an electron
             # ParameterBeam; mirrored, and the fixture's ParameterBeam was given the species explicitly
