@@ -889,9 +889,11 @@ class Segment(Element):
         merged, run = [], []
         beam = incoming_beam
 
-        def flush():
+        def flush(last=False):
             nonlocal run, beam
-            if len(run) > 1:
+            # a single skippable element between two others stays what it is; at the END of the lattice the reference wraps
+            # even a single one into a CustomTransferMap (segment.py:221-226) — kept
+            if len(run) > 1 or (last and run):
                 merged.append(CustomTransferMap.from_merging_elements(run, beam))
             elif run:
                 merged.append(run[0])
@@ -906,7 +908,7 @@ class Segment(Element):
                 flush()
                 merged.append(e)
                 beam = e.track(beam)
-        flush()
+        flush(last=True)
         return Segment(merged, name=self.name)
 
     @classmethod
