@@ -45,13 +45,20 @@ class Cavity(Element):
         self.register_buffer_or_parameter("voltage", z(voltage))
         self.register_buffer_or_parameter("phase", z(phase))
         self.register_buffer_or_parameter("frequency", z(frequency))
-        if cavity_type not in ("standing_wave", "traveling_wave"):
-            raise ValueError(f"Invalid cavity type: {cavity_type}")
-        self.cavity_type = cavity_type
+        self.cavity_type = cavity_type   # not validated here: like the reference, an unknown type fails when its map is needed
 
     @property
     def _chx_kind(self) -> int:
-        return _ops.KIND["cavity_sw" if self.cavity_type == "standing_wave" else "cavity_tw"]
+        return _ops.KIND[self._kind_name()]
+
+    def _kind_name(self) -> str:
+        if self.cavity_type == "standing_wave":
+            return "cavity_sw"
+        if self.cavity_type == "traveling_wave":
+            return "cavity_tw"
+        if not self.is_active:
+            return "cavity_sw"       # switched off: the drift-like map, whatever the type says (cavity.py:253-262)
+        raise ValueError(f"Invalid cavity type: {self.cavity_type}")   # cavity.py:337
 
     def _builder_params(self):
         return [self.length, self.voltage, self.phase, self.frequency]
@@ -157,7 +164,7 @@ class Cavity(Element):
             ws = self.__dict__["_scalar_ws"] = torch.empty(lib.chx_cavity_track_scalars_workspace_bytes() // 8 + 1,
                                                            dtype=torch.float64, device=p.device)
         _ops.check_current_device(p.device)
-        kind = _ops.KIND["cavity_sw" if self.cavity_type == "standing_wave" else "cavity_tw"]
+        kind = _ops.KIND[self._kind_name()]
         s_in = incoming.s
         s_out = torch.empty_like(s_in) if (s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device
                                            and not s_in.requires_grad) else None

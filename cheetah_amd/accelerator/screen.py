@@ -27,8 +27,9 @@ class Screen(Element):
                  sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         fk = {"device": device, "dtype": dtype}
         super().__init__(name=name, sanitize_name=sanitize_name, metadata=metadata, **fk)
-        if method not in ("histogram", "kde", "cloud-in-cell"):   # screen.py:84-87
-            raise ValueError(f"Invalid method {method}. Must be either 'histogram', 'kde' or 'cloud-in-cell'.")
+        assert isinstance(resolution, (tuple, list)) and len(resolution) == 2, "Invalid resolution. Must be a tuple of 2 integers."
+        assert method in ("histogram", "kde", "cloud-in-cell"), \
+            f"Invalid method {method}. Must be 'histogram', 'kde', or 'cloud-in-cell'."   # screen.py:84-91
         self.register_buffer_or_parameter(
             "pixel_size", pixel_size if pixel_size is not None else torch.tensor((1e-3, 1e-3), **fk))
         self.register_buffer_or_parameter(

@@ -54,6 +54,9 @@ class _ElementList(nn.ModuleList):
     """The element list of a Segment: any change of the list moves the process-wide epoch (Element._touch), so that plans
     derived from it are rebuilt."""
 
+    def _get_name(self):
+        return "ModuleList"      # prints like the reference's element list
+
     def _moved(self):
         Element._epoch += 1
 
@@ -971,4 +974,12 @@ class Segment(Element):
         return super().defining_features + ["elements"]
 
     def __repr__(self) -> str:
-        return f"Segment(elements={list(self.elements)!r}, name={self.name!r})"
+        # segment.py:1061-1082: the element list as torch prints a ModuleList; beyond five elements the first and last two
+        n = len(self.elements)
+        if n <= 5:
+            listed = repr(self.elements)
+        else:
+            rows = [f"({i}): {self.elements[i]!r}" for i in (0, 1, n - 2, n - 1)]
+            rows.insert(2, " \u22ee")
+            listed = "ModuleList(\n  {0}\n)".format("\n  ".join(rows))
+        return f"{self.__class__.__name__}(elements={listed}, name={self.name!r})"

@@ -295,3 +295,34 @@ def test_cross_device_launch_is_refused(monkeypatch):
     _ops.check_current_device(None)
     with pytest.raises(RuntimeError, match=r"live on cuda:0 but the current device is cuda:1"):
         _ops.check_current_device(torch.device("cuda:0"))
+
+
+def test_constructor_error_behaviour_mirrors_the_reference():
+    """What the reference raises (or does not raise) for invalid constructor arguments, observed by running it:
+    Screen asserts on the method and the resolution (screen.py:84-91); a Cavity accepts any `cavity_type` and fails with
+    ValueError only when the map of an ACTIVE cavity is needed (cavity.py:337); an Aperture accepts any shape; Species and
+    Superimposed assert; Segment look-ups raise ValueError."""
+    import cheetah_amd as ca
+
+    with pytest.raises(AssertionError, match="Invalid method"):
+        ca.Screen(method="bogus")
+    with pytest.raises(AssertionError, match="Invalid resolution"):
+        ca.Screen(resolution=(1, 2, 3))
+    off = ca.Cavity(length=torch.tensor(1.0), cavity_type="bogus")
+    assert off.cavity_type == "bogus" and off._kind_name() == "cavity_sw"       # switched off: drift-like map
+    on = ca.Cavity(length=torch.tensor(1.0), voltage=torch.tensor(1e6), frequency=torch.tensor(1.3e9), cavity_type="bogus")
+    with pytest.raises(ValueError, match="Invalid cavity type: bogus"):
+        on._kind_name()
+    assert ca.Aperture(shape="bogus").shape == "bogus"
+    with pytest.raises(AssertionError, match="zero length"):
+        ca.Superimposed(ca.Drift(length=torch.tensor(1.0)), ca.Drift(length=torch.tensor(0.1)))
+    seg = ca.Segment([ca.Drift(length=torch.tensor(0.1 * i), name=f"d{i}") for i in range(8)], name="long")
+    for call in (lambda: seg.subcell(start="nope"), lambda: seg.subcell(end="nope"), lambda: seg.element_index("nope"),
+                 lambda: seg.partition_at("nope")):
+        with pytest.raises(ValueError):
+            call()
+    assert len(seg.subcell(start="d3", end="d2").elements) == 0
+    # printed like the reference (segment.py:1061-1082): a ModuleList, beyond five elements the first and last two
+    text = repr(seg)
+    assert text.startswith("Segment(elements=ModuleList(\n  (0): Drift(name='d0'") and "\n   ⋮\n" in text and text.endswith("name='long')")
+    assert repr(ca.Segment([ca.Marker(name="m")], name="s")) == "Segment(elements=ModuleList(\n  (0): Marker(name='m')\n), name='s')"

@@ -67,5 +67,5 @@ def test_kde_chunked_accumulation(monkeypatch):
     monkeypatch.setattr(_ops, "KDE_CHUNK", 1024)
     scr.track(beam)
     assert torch.allclose(scr.reading, whole, rtol=1e-4, atol=1e-6 * float(whole.max()))
-    with pytest.raises(ValueError, match="Invalid method"):
+    with pytest.raises(AssertionError, match="Invalid method"):      # the reference asserts (screen.py:87-91)
         ca.Screen(method="nearest")
