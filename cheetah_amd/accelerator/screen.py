@@ -70,8 +70,19 @@ class Screen(Element):
             cache = {"key": key, "pixel_size_ref": ps}
             self.__dict__["_geom_cache"] = cache
         if what not in cache:
-            cache[what] = self._compute_extent() if what == "extent" else self._compute_edges()
+            cache[what] = (self._compute_extent() if what == "extent" else self._compute_edges() if what == "edges"
+                           else self._compute_sample_counts())
         return cache[what]
+
+    def _compute_sample_counts(self) -> tuple[int, int]:
+        """Number of density samples per axis of a ParameterBeam image: the reference samples on
+        `torch.arange(left, right, step)` (screen.py:283-287), whose length is ceil((right - left) / step) evaluated in double
+        from the tensors' values — one more than `effective_resolution` whenever the quotient rounds above the integer (one
+        host read per screen geometry, cached with it)."""
+        import math
+
+        v = torch.cat([self._compute_extent().detach(), (self.pixel_size * self.binning).detach()]).tolist()
+        return (int(math.ceil((v[1] - v[0]) / v[4])), int(math.ceil((v[3] - v[2]) / v[5])))
 
     def _compute_extent(self) -> torch.Tensor:
         return torch.stack([
@@ -154,7 +165,8 @@ class Screen(Element):
             # bivariate normal density sampled at the pixel origins (screen.py:255-291)
             ext = self.extent
             geom = torch.stack([ext[0], self.pixel_size[0] * self.binning, ext[2], self.pixel_size[1] * self.binning])
-            image = _ops.screen_gaussian(beam.mu, beam.cov, self.misalignment, geom, int(w), int(h))
+            nx, ny = self._compute_sample_counts() if self.pixel_size.requires_grad else self._geometry("sample_counts")
+            image = _ops.screen_gaussian(beam.mu, beam.cov, self.misalignment, geom, nx, ny)
         elif self.method == "histogram":
             if beam.particles.dim() > 2 or beam.particle_charges.dim() > 1 or beam.energy.dim() > 0:
                 raise NotImplementedError("The 'histogram' method of Screen does not support vectorization. "
