@@ -947,6 +947,31 @@ def test_space_charge_kick_on_drawn_configurations_vs_reference(ca, golden, orac
             assert oerr[c] < 1e-6 * kick[c] + 4e-16 * np.max(np.abs(truth[:, c])), ("oracle", i, grid, c)
 
 
+def test_vectorised_space_charge_kicks_vs_reference(ca, golden):
+    """Five drawn VECTORISED set-ups of space_charge_random.npz — vector dimensions on the particles, on the energy (shared
+    particles), on particles + effect length, on everything at once, on particles + survival probabilities — against the
+    reference in float64: the shape of the outgoing particles and energy, and every row's kick to 1e-6 of its size."""
+    g = golden("space_charge_random.npz")
+    kw = {"dtype": torch.float64, "device": "cuda"}
+    for i in range(int(g["n_vectorised"])):
+        grid = tuple(int(v) for v in g[f"v_grid_{i}"])
+        beam = ca.ParticleBeam(dev(g[f"v_in_{i}"]), torch.tensor(g[f"v_energy_{i}"], **kw), particle_charges=dev(g[f"v_charges_{i}"]),
+                               survival_probabilities=dev(g[f"v_survival_{i}"]), species=ca.Species("electron", **kw))
+        sc = ca.SpaceChargeKick(effect_length=torch.tensor(g[f"v_length_{i}"], **kw), grid_shape=grid, **kw)
+        out = sc.track(beam)
+        truth = g[f"v_out_{i}"]
+        assert tuple(out.particles.shape) == truth.shape, (i, out.particles.shape, truth.shape)
+        assert tuple(out.energy.shape) == g[f"v_energy_out_{i}"].shape, (i, out.energy.shape)
+        got = out.particles.cpu().numpy()
+        inp = np.broadcast_to(g[f"v_in_{i}"], truth.shape)
+        for b in np.ndindex(truth.shape[:-2]):
+            kick = np.max(np.abs(truth[b] - inp[b]), axis=0)
+            err = np.max(np.abs(got[b] - truth[b]), axis=0)
+            for c in (1, 3, 5):
+                assert kick[c] > 0 and err[c] < 1e-6 * kick[c] + 4e-16 * np.max(np.abs(truth[b][:, c])), (i, b, c, err[c], kick[c])
+            assert np.array_equal(got[b][:, 0], inp[b][:, 0]) and np.array_equal(got[b][:, 2], inp[b][:, 2])
+
+
 def test_screen_readings_on_drawn_setups_vs_reference(ca, golden):
     """Ten drawn screens (screens_random.npz: non-square resolutions, binning 1 / 2 / 4, misalignments, both methods, both
     dtypes, particles on pixel edges and beyond the screen, dead particles). Histogram images must be EQUAL — every charge is
