@@ -196,7 +196,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 4:  # CHX_ABI_VERSION of include/chx.h
+        if handle.chx_abi_version() != 5:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib

@@ -35,8 +35,9 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 4 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
-                             4: s_in / s_out arguments of chx_run_map / chx_run_track */
+#define CHX_ABI_VERSION 5 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
+                             4: s_in / s_out arguments of chx_run_map / chx_run_track;
+                             5: s_in / s_out arguments of chx_cavity_prepare_scalars / chx_cavity_track_scalars */
 
 typedef enum chx_status {
     CHX_OK = 0,
