@@ -11,6 +11,7 @@ import torch
 
 from .. import _ops
 from ..particles.particle_beam import ParticleBeam
+from .._cache import TensorKey
 from .element import Element
 
 
@@ -104,7 +105,13 @@ class Aperture(Marker):
             warnings.warn("Aperture tracking is currently only supported for `ParticleBeam`.", PhysicsWarning,
                           stacklevel=2)
             return incoming
-        assert bool((self.x_max >= 0).all()) and bool((self.y_max >= 0).all())
+        # aperture.py:72-73 asserts non-negative half-widths on every track; here the (host-synchronising) check runs once
+        # per value of the two tensors
+        limits = (self.x_max, self.y_max)
+        checked = self.__dict__.get("_limits_checked")
+        if checked is None or not checked.matches(limits):
+            assert bool((self.x_max >= 0).all()) and bool((self.y_max >= 0).all())
+            self.__dict__["_limits_checked"] = TensorKey(limits)
         assert self.shape in ["rectangular", "elliptical"], f"Unknown aperture shape {self.shape}"
         # one streaming kernel (chx_aperture_mask): strict `<` for the rectangle, `<= 1` for the ellipse
         survival = _ops.aperture_mask(incoming.particles, incoming.survival_probabilities, self.x_max, self.y_max,

@@ -234,7 +234,11 @@ class SpaceChargeKick(Element):
         mom = _ops.moments(x, w.contiguous())                                   # (B, 29) float64, differentiable
         sigma = mom[:, [8, 19, 26]].sqrt().to(dtype)                            # sigma_x, sigma_y, sigma_tau
         half = self._grid_extent(dtype) * sigma                                 # (B, 3)
-        gt = torch.tensor([float(v) for v in g], dtype=dtype, device=device)
+        gt = self.__dict__.get("_grid_tensor")       # the three grid sizes on the device, made once (a host-to-device copy)
+        if gt is None or gt[0] != (tuple(g), dtype, device):
+            gt = self.__dict__["_grid_tensor"] = ((tuple(g), dtype, device),
+                                                  torch.tensor([float(v) for v in g], dtype=dtype, device=device))
+        gt = gt[1]
         cell = 2 * half / gt
         gamma = energy / incoming.species.mass_eV_float
         ig2 = 1 / (gamma * gamma)

@@ -197,8 +197,10 @@ class ParameterBeam(Beam):
                               species=self.species)
 
     def clone(self) -> "ParameterBeam":
-        return self.__class__(mu=self.mu.clone(), cov=self.cov.clone(), energy=self.energy.clone(),
-                              total_charge=self.total_charge.clone(), s=self.s.clone(), species=self.species.clone())
+        sp = self.species
+        mu, cov, energy, q, s, nq, m = _ops.clone_many((self.mu, self.cov, self.energy, self.total_charge, self.s,
+                                                        sp.num_elementary_charges, sp.mass_eV))
+        return self.__class__(mu=mu, cov=cov, energy=energy, total_charge=q, s=s, species=sp._from_tensors(sp.name, nq, m))
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(mu={self.mu!r}, cov={self.cov!r}, energy={self.energy!r}, "

@@ -477,10 +477,13 @@ class ParticleBeam(Beam):
         return ["particles", "energy", "particle_charges", "survival_probabilities", "s", "species"]
 
     def clone(self) -> "ParticleBeam":
-        return self.__class__(particles=self.particles.clone(), energy=self.energy.clone(),
-                              particle_charges=self.particle_charges.clone(),
-                              survival_probabilities=self.survival_probabilities.clone(), s=self.s.clone(),
-                              species=self.species.clone())
+        """particle_beam.py `clone`: every tensor of the beam and of its species copied — by ONE launch (`clone_many`) where no
+        gradient has to flow through the copy."""
+        sp = self.species
+        p, e, q, w, s, nq, m = _ops.clone_many((self.particles, self.energy, self.particle_charges, self.survival_probabilities,
+                                                self.s, sp.num_elementary_charges, sp.mass_eV))
+        return self.__class__(particles=p, energy=e, particle_charges=q, survival_probabilities=w, s=s,
+                              species=sp._from_tensors(sp.name, nq, m))
 
     def _snapshot(self) -> "ParticleBeam":
         """Copy of the tensor state (autograd-connected) sharing the species object: what a Screen records, so that

@@ -95,10 +95,21 @@ class Species(nn.Module):
         return self.num_elementary_charges * elementary_charge
 
     def clone(self) -> "Species":
-        if self.name in self.known:
-            return self.__class__(name=self.name, device=self.mass_eV.device, dtype=self.mass_eV.dtype)
-        return self.__class__(name=self.name, num_elementary_charges=self.num_elementary_charges.clone(),
-                              mass_eV=self.mass_eV.clone())
+        """species.py:133-149. Charge and mass are copied on their device (the reference re-creates a known species from its
+        constants, which on a GPU would be two synchronous host-to-device transfers per cloned beam; the values are the same)."""
+        from .. import _ops
+
+        nq, m = _ops.clone_many((self.num_elementary_charges, self.mass_eV))
+        return self._from_tensors(self.name, nq, m)
+
+    @classmethod
+    def _from_tensors(cls, name: str, num_elementary_charges: torch.Tensor, mass_eV: torch.Tensor) -> "Species":
+        sp = cls.__new__(cls)
+        nn.Module.__init__(sp)
+        sp.name = name
+        sp._register("num_elementary_charges", num_elementary_charges)
+        sp._register("mass_eV", mass_eV)
+        return sp
 
     def __repr__(self) -> str:
         return (f"Species(name={self.name!r}, num_elementary_charges={self.num_elementary_charges!r}, "
