@@ -118,6 +118,8 @@ SIGNATURES = {
     "chx_sc_spectral_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "chx_sc_phi_halo_elements": (c_size_t, [c_i64, c_i32_p]),
     "chx_sc_convolve_halo": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_sc_convolve_halo_after": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                           c_void_p]),
     "chx_sc_gather_kick_phi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64,
                                        c_i64, c_i64, c_i32_p, c_int, c_void_p, c_i64, c_void_p, c_void_p]),
     "chx_sc_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_i64, c_int, c_void_p, c_void_p]),

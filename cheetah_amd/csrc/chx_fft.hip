@@ -707,7 +707,7 @@ extern "C" size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins
 // — forward z, multiply, inverse z — runs in place along the contiguous axis.
 template <typename T>
 static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64_t B, const int32_t* bins, T* phi, T* ws,
-                         hipStream_t s, bool halo) {
+                         hipStream_t s, bool halo, hipEvent_t ghat_ready = nullptr) {
     const int gx = bins[0], gy = bins[1], gz = bins[2];
     const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nxc = gx + 1;
     const int64_t nA = (int64_t)nxc * gy * gz, nB = (int64_t)nxc * ny * gz, nC = (int64_t)nxc * ny * nz;  // complex elements
@@ -725,7 +725,11 @@ static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64
     LineLayout by{gz, 1, (int64_t)ny * gz, nB};
     st = launch_lines<T, LOAD_COMPLEX, STORE_COMPLEX, false, false, true>(A, Bf, ny, gy, ny, (int64_t)nxc * gz, gz, ay, by, B, s);
     if (st != CHX_OK) return st;
-    // z: forward, multiply by the Green spectrum, inverse, z < gz kept — in place on Bf
+    // z: forward, multiply by the Green spectrum, inverse, z < gz kept — in place on Bf. The spectrum is first needed HERE: a
+    // caller that computes it on another stream hands over its completion event, and the two forward passes above run
+    // without waiting for it (a cross-queue dependency costs ~13 us to resolve on MI355X: waiting before the first pass
+    // left the main queue idle for 17 us per kick)
+    if (ghat_ready && hipStreamWaitEvent(s, ghat_ready, 0) != hipSuccess) return CHX_ERR_LAUNCH;
     switch (nz) {
         case 32: st = launch_z_fused<T, 2>(Bf, Ghat, scale, gx, gy, B, s); break;
         case 64: st = launch_z_fused<T, 4>(Bf, Ghat, scale, gx, gy, B, s); break;
@@ -778,14 +782,21 @@ extern "C" size_t chx_sc_phi_halo_elements(int64_t B, const int32_t* bins) {
     return (size_t)B * (bins[0] + 2 * kHalo) * (bins[1] + 2 * kHalo) * (bins[2] + 2 * kHalo);
 }
 
-extern "C" int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,
-                                    int dtype, void* phi_halo, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int chx_sc_convolve_halo_after(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,
+                                          int dtype, void* phi_halo, void* workspace, size_t workspace_bytes, void* stream,
+                                          void* ghat_ready_event) {
     if (!rho || !Ghat || !scale || !phi_halo || B < 1 || B > 65535 || !chx_sc_pruned_supported(bins, dtype))
         return CHX_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < chx_sc_convolve_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev = (hipEvent_t)ghat_ready_event;
     return dtype == CHX_F32 ? convolve_impl<float>((const float*)rho, (const float*)Ghat, scale, B, bins, (float*)phi_halo,
-                                                   (float*)workspace, s, true)
+                                                   (float*)workspace, s, true, ev)
                             : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi_halo,
-                                                    (double*)workspace, s, true);
+                                                    (double*)workspace, s, true, ev);
+}
+
+extern "C" int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,
+                                    int dtype, void* phi_halo, void* workspace, size_t workspace_bytes, void* stream) {
+    return chx_sc_convolve_halo_after(rho, Ghat, scale, B, bins, dtype, phi_halo, workspace, workspace_bytes, stream, nullptr);
 }

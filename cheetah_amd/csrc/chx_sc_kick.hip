@@ -130,16 +130,18 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
         st = sorted ? chx_cic_deposit_sorted_overwrite(&a, ws + L.dep_ws, L.table - L.dep_ws, main)
                     : chx_cic_deposit(&a, main);
     }
+    // potential inside a halo; the field (central differences, space_charge_kick.py:324-385) is formed per particle in the
+    // gather: the 33.5 MB force grid of the four-kernel form is neither written nor read. The main stream joins the side
+    // stream where the Green spectrum is first read (in front of the z pass), not in front of the whole convolution.
+    if (st == CHX_OK)
+        st = chx_sc_convolve_halo_after(rho, ghat, pot_scale, B, bins, dtype, phi, ws + L.conv_ws, L.phi - L.conv_ws, main,
+                                        forked ? (void*)join : nullptr);
+    else if (forked)
+        (void)hipStreamWaitEvent(main, join, 0);     // an error path still rejoins the side stream
     if (forked) {
-        (void)hipStreamWaitEvent(main, join, 0);
         (void)hipEventDestroy(fork);
         (void)hipEventDestroy(join);
     }
-    if (st != CHX_OK) return st;
-
-    // potential inside a halo; the field (central differences, space_charge_kick.py:324-385) is formed per particle in the
-    // gather: the 33.5 MB force grid of the four-kernel form is neither written nor read
-    st = chx_sc_convolve_halo(rho, ghat, pot_scale, B, bins, dtype, phi, ws + L.conv_ws, L.phi - L.conv_ws, main);
     if (st != CHX_OK) return st;
     return chx_sc_gather_kick_phi(x_in, phi, half, cell, gamma, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, post_map, BR,
                                   x_out, main);
