@@ -2,7 +2,8 @@
 """Random beamlines with the non-linear tracking methods, tracked by the reference -> tests/golden/lattices_random_nonlinear.npz:
 ten drawn lines of 5-10 elements — drifts, quadrupoles (with `num_steps`), dipoles / rectangular bends (fringe fields at
 either or both ends), sextupoles and transverse deflecting cavities — every element with a drawn `tracking_method` out of
-the ones it supports (linear, second_order, drift_kick_drift), 64 particles in, the tracked particles out, float64.
+the ones it supports (linear, second_order, drift_kick_drift), 64 particles in, the tracked particles out, float64;
+plus six lines with VECTORISED settings ((3,), (2, 1), (2,)) and / or vectorised particles, for electrons, positrons and protons.
 Run in the build container:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden_random_nonlinear.py
 """
 import json
@@ -92,6 +93,34 @@ for i in range(n_lat):
     arrays[f"out_{i}"] = out.particles.numpy()
     arrays[f"energy_out_{i}"] = out.energy.numpy()
     print(i, [(k, a.get("tracking_method", "-")) for k, a in spec])
+# ---- vectorised settings / beams and other species (drawn after the lattices above, which keep their draws)
+VEC_KEYS = {"Quadrupole": "k1", "Dipole": "angle", "RBend": "angle", "Sextupole": "k2", "TransverseDeflectingCavity": "voltage",
+            "Drift": "length"}
+CASES = [("electron", (3,), ()), ("proton", (2, 1), ()), ("positron", (), (3,)), ("electron", (2,), (2,)), ("proton", (), ()),
+         ("electron", (3,), ())]
+arrays["n_vectorised"] = np.asarray(len(CASES))
+for i, (sp_name, setting_shape, beam_shape) in enumerate(CASES):
+    spec = [draw_element() for _ in range(int(rng.integers(4, 8)))]
+    hit = 0
+    for kind, kw in spec:
+        if setting_shape and (hit == 0 or rng.random() < 0.3):
+            key = VEC_KEYS[kind]
+            kw[key] = (kw[key] * rng.uniform(0.6, 1.4, setting_shape)).tolist()
+            hit += 1
+    sp = cheetah.Species(sp_name, **f64)
+    gamma = float(np.exp(rng.uniform(np.log(3.0 if sp_name == "proton" else 60.0), np.log(40.0 if sp_name == "proton" else 6000.0))))
+    energy = gamma * float(sp.mass_eV)
+    x = rng.standard_normal((*beam_shape, 48, 7)) * np.array([3e-4, 2e-5, 2e-4, 3e-5, 1e-4, 2e-3, 0.0])
+    x[..., 6] = 1.0
+    beam = cheetah.ParticleBeam(torch.tensor(x), torch.tensor(energy, **f64), species=sp, **f64)
+    out = build(cheetah, spec).track(beam)
+    assert torch.isfinite(out.particles).all(), spec
+    arrays[f"v_spec_{i}"] = np.asarray(json.dumps(spec))
+    arrays[f"v_species_{i}"] = np.asarray(sp_name)
+    arrays[f"v_in_{i}"], arrays[f"v_energy_{i}"] = x, np.asarray(energy)
+    arrays[f"v_out_{i}"], arrays[f"v_energy_out_{i}"] = out.particles.numpy(), out.energy.numpy()
+    print("vectorised", i, sp_name, setting_shape, beam_shape, "->", tuple(out.particles.shape),
+          [(k, a.get("tracking_method", "-")) for k, a in spec])
 path = os.path.join(OUT, "lattices_random_nonlinear.npz")
 np.savez_compressed(path, **arrays)
 print("->", path, f"{os.path.getsize(path) / 1024:.1f} KiB")

@@ -312,3 +312,34 @@ def test_random_nonlinear_lattices_vs_reference(tag):
         # fp32-rounded coordinates and settings
         assert err < (1e-11 if tag == "f64" else 1e-3), (i, [(k, a.get("tracking_method")) for k, a in spec], err)   # measured: 1e-12 / 3e-4
         assert float(out.energy) == pytest.approx(float(g[f"energy_out_{i}"]), rel=1e-12 if tag == "f64" else 1e-6)
+
+
+@pytest.mark.gpu
+def test_vectorised_nonlinear_lattices_vs_reference():
+    """Six drawn lines of lattices_random_nonlinear.npz with VECTORISED settings ((3,), (2, 1), (2,)) on elements of every
+    tracking method and / or vectorised particles, for electrons, positrons and protons: the shape of the outgoing particles
+    and every vector entry's coordinates against the reference in float64."""
+    import json
+    import os
+
+    import cheetah_amd as ca
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lattices_random_nonlinear.npz"))
+    kw = {"dtype": torch.float64, "device": "cuda"}
+    for i in range(int(g["n_vectorised"])):
+        spec = json.loads(str(g[f"v_spec_{i}"]))
+        elements = []
+        for kind, args in spec:
+            targs = {k: (torch.tensor(v, **kw) if isinstance(v, (float, list)) else v) for k, v in args.items()}
+            elements.append(getattr(ca, kind)(**targs, **kw))
+        beam = ca.ParticleBeam(torch.tensor(g[f"v_in_{i}"], **kw), torch.tensor(float(g[f"v_energy_{i}"]), **kw),
+                               species=ca.Species(str(g[f"v_species_{i}"]), **kw))
+        out = ca.Segment(elements).track(beam)
+        ref = g[f"v_out_{i}"]
+        assert tuple(out.particles.shape) == ref.shape, (i, out.particles.shape, ref.shape)
+        assert tuple(out.energy.shape) == g[f"v_energy_out_{i}"].shape, (i, out.energy.shape)
+        got = out.particles.cpu().numpy()
+        scale = np.maximum(np.abs(ref).reshape(-1, 7).max(axis=0), 1e-30)
+        err = (np.abs(got - ref) / scale).max()
+        assert err < 1e-11, (i, str(g[f"v_species_{i}"]), [(k, a.get("tracking_method")) for k, a in spec], err)
+        assert np.allclose(out.energy.cpu().numpy(), g[f"v_energy_out_{i}"], rtol=1e-12)
