@@ -29,6 +29,29 @@ def _tri(i: int, j: int) -> int:
     return 8 + i * 6 - (i * (i - 1)) // 2 + (j - i)
 
 
+class _MomentEntry(torch.autograd.Function):
+    """mom[..., index] (or its square root) cast to `dtype`; backward scatters the incoming gradient into that entry."""
+
+    @staticmethod
+    def forward(ctx, mom, index, take_sqrt, dtype):
+        v = mom[..., index]
+        if take_sqrt:
+            v = v.sqrt()
+            ctx.save_for_backward(v)
+        ctx.index, ctx.take_sqrt, ctx.mom_shape = index, take_sqrt, mom.shape
+        return v.to(dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = grad.to(torch.float64)
+        if ctx.take_sqrt:
+            (v,) = ctx.saved_tensors
+            g = g * 0.5 / v                      # d sqrt(x) / dx, infinite at x = 0 like torch.sqrt's own backward
+        d = g.new_zeros(ctx.mom_shape)
+        d[..., ctx.index] = g
+        return d, None, None, None
+
+
 class ParticleBeam(Beam):
     """Beam of macro-particles, each a 7-vector (x, px, y, py, tau, p, 1)."""
 
@@ -290,14 +313,24 @@ class ParticleBeam(Beam):
         return ParameterBeam._from_moment_vector(self._moments(), self.particles.dtype, self.energy,
                                                  total_charge=self.total_charge, s=self.s, species=self.species)
 
+    def _entry(self, index: int, take_sqrt: bool = False) -> torch.Tensor:
+        """One entry of the moment vector (optionally its square root) in the beam's dtype. Under autograd this is ONE node
+        (`_MomentEntry`) instead of select -> sqrt -> to, whose three backward nodes cost more host time than the moment
+        kernels themselves in an optimisation loop."""
+        mom = self._moments()
+        if mom.requires_grad and torch.is_grad_enabled():
+            return _MomentEntry.apply(mom, index, take_sqrt, self.particles.dtype)
+        v = mom[..., index]
+        return (v.sqrt() if take_sqrt else v).to(self.particles.dtype)
+
     def _mu(self, i: int) -> torch.Tensor:
-        return self._moments()[..., 2 + i].to(self.particles.dtype)
+        return self._entry(2 + i)
 
     def _cov(self, i: int, j: int) -> torch.Tensor:
-        return self._moments()[..., _tri(i, j)].to(self.particles.dtype)
+        return self._entry(_tri(i, j))
 
     def _sigma(self, i: int) -> torch.Tensor:
-        return self._moments()[..., _tri(i, i)].sqrt().to(self.particles.dtype)
+        return self._entry(_tri(i, i), take_sqrt=True)
 
     @property
     def total_charge(self) -> torch.Tensor:
