@@ -248,6 +248,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_particle_kernel(
                     fy += w[k] * (double)node[k].y;
                     fz += w[k] * (double)node[k].z;
                 }
+                // a grid without extent along an axis (all particles in one plane or point: sigma = 0, cell = 0) gives the
+                // reference 0 / 0 or x / 0 cell positions and NaN momenta for every particle; the clamped indices above would
+                // hide that as "outside the grid, no kick"
+                if (!(isfinite(u[0]) && isfinite(u[1]) && isfinite(u[2]))) fx = fy = fz = __builtin_nan("");
                 const double dtb = (double)dt[b];
                 s[1] += fx * dtb;
                 s[3] += fy * dtb;

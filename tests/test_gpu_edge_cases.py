@@ -58,3 +58,53 @@ def test_degenerate_inputs_vs_reference():
             assert (np.isnan(v) and np.isnan(r)) or (np.isinf(v) and np.isinf(r) and np.sign(v) == np.sign(r)) \
                 or v == pytest.approx(r, rel=1e-7, abs=1e-16 if s == "emittance_x" else 1e-300), (name, s, v, r)
             # (emittance: sqrt of a difference of products that is exactly zero for two particles — rounding residue 1e-23)
+
+
+def test_degenerate_screen_and_space_charge_inputs_vs_reference():
+    """edge_cases_diagnostics.npz: screens the beam misses, NaN / inf coordinates on a screen, a binning that does not divide the
+    resolution, dead particles only, one particle, particles exactly on pixel edges (both methods); space-charge kicks without
+    charge, of one / two particles, of dead particles only, of a beam collapsed into a point or a plane (the reference returns
+    NaN momenta there: grid cells of zero size), of mixed charge signs, at gamma = 1.001. Images: same shape, histogram counts
+    equal, cloud-in-cell to rounding (a non-finite coordinate: see below); kicks: same non-finite pattern, finite values to 1e-6 of the kick."""
+    import cheetah_amd as ca
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "edge_cases_diagnostics.npz"))
+    kw = {"dtype": torch.float64, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    for name in [str(n) for n in g["names"]]:
+        assert str(g[f"{name}_raises"]) == "", name
+        ref = g[f"{name}_result"]
+        x = torch.tensor(g[f"{name}_x"], **kw)
+        surv = torch.tensor(g[f"{name}_survival"], **kw)
+        if name.startswith("screen"):
+            beam = ca.ParticleBeam(x, t(1e8), particle_charges=torch.full((x.shape[0],), 1e-15, **kw), survival_probabilities=surv,
+                                   species=ca.Species("electron", **kw))
+            scr = ca.Screen(resolution=tuple(int(v) for v in g[f"{name}_resolution"]), pixel_size=t([2e-5, 2e-5]),
+                            binning=int(g[f"{name}_binning"]), misalignment=t([float(v) for v in g[f"{name}_misalignment"]]),
+                            method=str(g[f"{name}_method"]), is_active=True, **kw)
+            scr.track(beam)
+            img = scr.reading.cpu().numpy()
+            assert img.shape == ref.shape, (name, img.shape, ref.shape)
+            assert np.isfinite(img).all(), name
+            if str(g[f"{name}_method"]) == "histogram":
+                # every charge is 1e-15: equal images mean every particle sits in the reference's pixel
+                assert np.array_equal(np.rint(img / 1e-15), np.rint(ref / 1e-15)), (name, np.abs(img - ref).max())
+            else:
+                # A particle with a NaN / inf coordinate deposits nothing here. The reference converts its NaN cell position to
+                # an integer (undefined in C; INT64_MIN on its CPU path), clamps it to the border and adds NaN weights there:
+                # two to four border pixels of its image are NaN — not mirrored; every other pixel is compared.
+                ok = np.isfinite(ref)
+                assert (~ok).sum() <= 4 and (ok.all() or "nan" in name or "inf" in name), (name, int((~ok).sum()))
+                assert np.abs(img - ref)[ok].max() <= 1e-9 * max(ref[ok].max(), 1e-30), (name, np.abs(img - ref)[ok].max())
+        else:
+            beam = ca.ParticleBeam(x, t(float(g[f"{name}_energy"])), particle_charges=torch.tensor(g[f"{name}_charges"], **kw),
+                                   survival_probabilities=surv, species=ca.Species("electron", **kw))
+            out = ca.SpaceChargeKick(effect_length=t(0.3), grid_shape=tuple(int(v) for v in g[f"{name}_grid"]), **kw).track(beam)
+            got = out.particles.cpu().numpy()
+            assert got.shape == ref.shape, name
+            assert np.array_equal(np.isfinite(got), np.isfinite(ref)), (name, int((~np.isfinite(got)).sum()), int((~np.isfinite(ref)).sum()))
+            fin = np.isfinite(ref)
+            inp = g[f"{name}_x"]
+            kick = np.abs(np.where(fin, ref - inp, 0.0)).max(axis=0)
+            err = np.abs(np.where(fin, got - ref, 0.0)).max(axis=0)
+            assert np.all(err <= 1e-6 * kick + 1e-14 * np.abs(np.where(fin, ref, 0.0)).max(axis=0) + 1e-15), (name, err, kick)   # the SI round trip: delta = p / p0 - 1 is exact to an eps of 1
