@@ -1579,6 +1579,10 @@ def from_xyz_pxpypz(xp, energy, mass_eV):
 def parameter_track(mu, cov, tm, cavity_coeffs=None, batch_shape=None):
     """mu (…,7), cov (…,7,7), tm (…,7,7) -> (mu', cov') = (tm mu, tm cov tm^T) (element.py:167-179)."""
     require_device(mu, cov, tm)
+    if tm.dtype != mu.dtype:
+        # element.py:170 `tm @ mu`: torch refuses a float32 map on float64 moments (and the other way round)
+        raise RuntimeError(f"expected m1 and m2 to have the same dtype, but got: {tm.dtype} != {mu.dtype} "
+                           "(transfer map vs beam moments)")
     if mu.requires_grad or cov.requires_grad or tm.requires_grad or (
             cavity_coeffs is not None and cavity_coeffs.requires_grad):
         # gradient path (tests/test_differentiable.py:58-75): B tiny 7x7 products, left to autograd like compose_maps

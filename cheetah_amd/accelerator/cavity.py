@@ -104,6 +104,11 @@ class Cavity(Element):
 
     @tracking_call
     def track(self, incoming: ParticleBeam) -> ParticleBeam:
+        ref = incoming.mu if isinstance(incoming, ParameterBeam) else getattr(incoming, "particles", None)
+        if ref is not None and ref.dtype != self.length.dtype:
+            # cavity.py:108-111 multiplies the beam by the element's map: torch refuses mixed float32 / float64 operands
+            raise RuntimeError(f"expected m1 and m2 to have the same dtype, but got: {ref.dtype} != {self.length.dtype} "
+                               "(beam vs cavity settings)")
         if isinstance(incoming, ParameterBeam):
             return self._track_parameter_beam(incoming)
         if not isinstance(incoming, ParticleBeam):

@@ -246,14 +246,19 @@ class Element(nn.Module):
         kernel pass (chx_dkd_track); the outgoing energy is the reference energy recomputed from p0c."""
         assert isinstance(incoming, ParticleBeam), \
             "Drift-kick-drift tracking is currently only supported for `ParticleBeam`."
-        dtype = incoming.particles.dtype
+        # the reference's Bmad-X expressions mix the particles with the element's settings: the result is promoted to the wider
+        # of the two dtypes (a float64 element gives float64 particles from a float32 beam; the energy keeps the beam's dtype)
+        dtype = torch.promote_types(incoming.particles.dtype, self.length.dtype)
         params, pshape = _ops.stack_params(self._dkd_params(), dtype, incoming.particles.device)
         energy = incoming.energy.to(dtype) if incoming.energy.dtype != dtype else incoming.energy
         num_steps, fringe = self._dkd_options()
         species = incoming.species
-        particles, ref_energy = _ops.dkd_track(self._dkd_kind, incoming.particles, params, pshape, energy,
+        x = incoming.particles if incoming.particles.dtype == dtype else incoming.particles.to(dtype)
+        particles, ref_energy = _ops.dkd_track(self._dkd_kind, x, params, pshape, energy,
                                                species.mass_eV_float, species.num_elementary_charges_float, num_steps,
                                                fringe)
+        if ref_energy.dtype != incoming.energy.dtype:
+            ref_energy = ref_energy.to(incoming.energy.dtype)
         return ParticleBeam(
             particles,
             ref_energy,

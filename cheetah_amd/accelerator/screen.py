@@ -127,6 +127,7 @@ class Screen(Element):
             # outgoing beam must not change the reading); the misalignment is applied inside the image kernels
             # and lazily in get_read_beam()
             self.__dict__["_incoming"] = incoming._snapshot()
+            self.__dict__["_placed"] = (self.misalignment.dtype, self.misalignment.device)
             self.__dict__["_read_beam"] = None
             self.__dict__["_cached_reading"] = None
         if self.is_active and self.is_blocking:
@@ -142,22 +143,31 @@ class Screen(Element):
     @property
     def reading(self) -> torch.Tensor:
         """Image of shape (…, height, width)."""
+        # Was the screen moved with .to() / .double() / .cuda() since the beam was recorded? Then the recorded beam and a cached
+        # image follow it, like the reference's read beam, which is a sub-module of the screen (test_screen.py:137-159). A beam
+        # whose dtype merely differs from the screen's is left alone: the reference's image then has the BEAM's dtype.
+        now = (self.misalignment.dtype, self.misalignment.device)
+        placed = self.__dict__.get("_placed", now)
+        moved = placed != now
+        if moved:
+            self.__dict__["_placed"] = now
         cached = self.__dict__.get("_cached_reading")
         if cached is not None:
-            if cached.dtype != self.misalignment.dtype or cached.device != self.misalignment.device:
-                # the element was moved with .to() / .double() after the image was made (test_screen.py:137-159)
-                cached = cached.to(device=self.misalignment.device, dtype=self.misalignment.dtype)
+            if moved:
+                cached = cached.to(device=now[1], dtype=now[0])
                 self.__dict__["_cached_reading"] = cached
             return cached
         beam = self.__dict__.get("_incoming")
-        if beam is not None:
-            ref = beam.mu if isinstance(beam, ParameterBeam) else beam.particles
-            if ref.dtype != self.misalignment.dtype or ref.device != self.misalignment.device:
-                # the screen was moved with .to() / .double() after tracking: the recorded beam follows it, like the
-                # reference's read beam, which is a sub-module of the screen
-                beam = beam.to(device=self.misalignment.device, dtype=self.misalignment.dtype)
-                self.__dict__["_incoming"] = beam
-                self.__dict__["_read_beam"] = None
+        if beam is not None and moved:
+            beam = beam.to(device=now[1], dtype=now[0])
+            self.__dict__["_incoming"] = beam
+            self.__dict__["_read_beam"] = None
+        if (beam is not None and not isinstance(beam, ParameterBeam) and self.method == "cloud-in-cell"
+                and torch.promote_types(beam.particles.dtype, now[0]) != beam.particles.dtype):
+            # cloud_in_cell.py: positions normalised with the screen's (wider) extent are scattered with the beam's (narrower)
+            # charges — torch refuses the mixed scatter; the same combination raises here
+            raise RuntimeError("scatter(): Expected self.dtype to be equal to src.dtype "
+                               f"(screen {now[0]}, beam {beam.particles.dtype})")
         w, h = self.effective_resolution
         if beam is None:
             image = self.misalignment.new_zeros((int(h), int(w)))
@@ -217,6 +227,7 @@ class Screen(Element):
         return self.__dict__.get("_read_beam")
 
     def set_read_beam(self, value) -> None:
+        self.__dict__["_placed"] = (self.misalignment.dtype, self.misalignment.device)
         self.__dict__["_incoming"] = value
         self.__dict__["_read_beam"] = value
         self.__dict__["_cached_reading"] = None
