@@ -63,6 +63,14 @@ class Cavity(Element):
     def _builder_params(self):
         return [self.length, self.voltage, self.phase, self.frequency]
 
+    def _energy_graph(self, e_out: torch.Tensor, energy: torch.Tensor) -> torch.Tensor:
+        """The outgoing energy is `energy + voltage * cos(phase) * q` (cavity.py:113-122): it carries a graph only through
+        those three. The coefficient expressions are evaluated on the stacked settings, where a trainable length or frequency
+        would otherwise mark it as well."""
+        if e_out.requires_grad and not (energy.requires_grad or self.voltage.requires_grad or self.phase.requires_grad):
+            return e_out.detach()
+        return e_out
+
     def _energy_shape(self, energy: torch.Tensor):
         """Shape of the outgoing energy: `incoming.energy + voltage * cos(phase) * ...` (cavity.py:113-122)."""
         return torch.broadcast_shapes(self.voltage.shape, self.phase.shape, energy.shape)
@@ -99,7 +107,7 @@ class Cavity(Element):
         e = energy.reshape(1) if energy.dim() == 0 else energy.expand(batch_shape).reshape(B).contiguous()
         sp = incoming.species
         coeffs, e_out = _ops.cavity_coeffs(params.contiguous(), e, sp.mass_eV_float, sp.num_elementary_charges_float, B)
-        e_out = _narrow_to(e_out.reshape(batch_shape), self._energy_shape(energy))
+        e_out = _narrow_to(self._energy_graph(e_out, energy).reshape(batch_shape), self._energy_shape(energy))
         return incoming._tracked(tm, self.length, cavity_coeffs=coeffs, energy=e_out, batch_shape=batch_shape)
 
     @tracking_call
@@ -138,7 +146,7 @@ class Cavity(Element):
         R = R.expand(B, 7, 7).contiguous()
         out = _ops.cavity_track(_ops.aligned(x), R, coeffs, B, N)
         # outgoing energy has the broadcast shape of (voltage, phase, energy) — not of the length or the particles
-        e_out = _narrow_to(e_out.reshape(batch_shape), self._energy_shape(energy))
+        e_out = _narrow_to(self._energy_graph(e_out, energy).reshape(batch_shape), self._energy_shape(energy))
         return ParticleBeam(out.reshape(*batch_shape, N, 7), e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length,
                             species=incoming.species)

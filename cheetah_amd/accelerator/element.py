@@ -259,6 +259,8 @@ class Element(nn.Module):
                                                fringe)
         if ref_energy.dtype != incoming.energy.dtype:
             ref_energy = ref_energy.to(incoming.energy.dtype)
+        if ref_energy.requires_grad and not incoming.energy.requires_grad:
+            ref_energy = ref_energy.detach()     # recomputed from the incoming reference momentum alone (e.g. drift.py:141-152)
         return ParticleBeam(
             particles,
             ref_energy,

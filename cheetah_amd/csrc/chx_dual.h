@@ -66,4 +66,6 @@ __device__ __forceinline__ double m_asinh(double x) { return asinh(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ Dual m_atan(Dual x) { return mk(atan(x.v), x.d / (1.0 + x.v * x.v)); }
 __device__ __forceinline__ Dual m_asinh(Dual x) { return mk(asinh(x.v), x.d / sqrt(1.0 + x.v * x.v)); }
-__device__ __forceinline__ Dual m_abs(Dual x) { return x.v < 0.0 ? mk(-x.v, -x.d) : x; }
+// d|x| = sign(x) dx with sign(0) = 0: torch's convention for `abs` (the reference's trilinear weights are 1 - |u - i|,
+// space_charge_kick.py:413-415, so a particle sitting exactly on a grid node gets this sub-gradient there)
+__device__ __forceinline__ Dual m_abs(Dual x) { return x.v < 0.0 ? mk(-x.v, -x.d) : (x.v > 0.0 ? x : mk(0.0, 0.0)); }
