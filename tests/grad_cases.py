@@ -14,7 +14,7 @@ SETTINGS = {
     "Sextupole": {"length": 0.2, "k2": 5.0},
     "Undulator": {"length": 0.3},
     "Aperture": {"x_max": 1e-3, "y_max": 2e-3},
-    "SpaceChargeKick": {"effect_length": 0.2},
+    "SpaceChargeKick": {"effect_length": 0.2, "grid_extent_x": 3.0, "grid_extent_y": 2.7, "grid_extent_tau": 3.4},
     "TransverseDeflectingCavity": {"length": 0.3, "voltage": 1e6, "phase": 20.0, "frequency": 2.9e9},
 }
 EXTRA = {"Aperture": {"is_active": True}, "SpaceChargeKick": {"grid_shape": (16, 16, 16)}, "Sextupole": {"tracking_method": "linear"}}
