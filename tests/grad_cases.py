@@ -18,6 +18,12 @@ SETTINGS = {
     "TransverseDeflectingCavity": {"length": 0.3, "voltage": 1e6, "phase": 20.0, "frequency": 2.9e9},
 }
 EXTRA = {"Aperture": {"is_active": True}, "SpaceChargeKick": {"grid_shape": (16, 16, 16)}, "Sextupole": {"tracking_method": "linear"}}
+# the non-linear tracking methods: "Kind@method" builds Kind with that tracking_method
+for _kind, _methods in (("Drift", ("second_order", "drift_kick_drift")), ("Quadrupole", ("second_order", "drift_kick_drift")),
+                        ("Dipole", ("second_order", "drift_kick_drift")), ("Sextupole", ("second_order",))):
+    for _m in _methods:
+        SETTINGS[f"{_kind}@{_m}"] = {k: v for k, v in SETTINGS[_kind].items() if not (_kind == "Dipole" and _m == "drift_kick_drift" and k == "k1")}
+        EXTRA[f"{_kind}@{_m}"] = {"tracking_method": _m}
 
 
 def cases():
@@ -36,7 +42,7 @@ def run(module, kind, trainable, beam_kind, dev):
         if name == trainable:
             tns = leaf = torch.nn.Parameter(tns)
         args[name] = tns
-    el = getattr(module, kind)(**args, **EXTRA.get(kind, {}), **kw)
+    el = getattr(module, kind.split("@")[0])(**args, **EXTRA.get(kind, {}), **kw)
     n = 48
     # deterministic, but not on a regular lattice: evenly spaced coordinates put particles exactly on the nodes of a grid whose
     # extent is a multiple of the beam size, where the trilinear weights have a kink and the side taken depends on the last bit
