@@ -181,7 +181,7 @@ def self_launch(args) -> None:
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not args.one_device_gloo:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node has {have}; "
                          f"run with --gpus {max(have, 1)} or on a larger node\n")
         sys.exit(2)
