@@ -353,7 +353,8 @@ int chx_sc_convolve(const void* rho, const void* Ghat, const double* scale, int6
 size_t chx_sc_phi_halo_elements(int64_t B, const int32_t* bins);
 int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
                          void* phi_halo, void* workspace, size_t workspace_bytes, void* stream);
-/* The same, for a Green spectrum that another stream is still computing: `ghat_ready_event` (a hipEvent_t recorded on that
+/* The same convolution (space_charge_kick.py:262-322: FFT of the padded charge, product with the Green spectrum, inverse FFT,
+ * crop), for a Green spectrum that another stream is still computing: `ghat_ready_event` (a hipEvent_t recorded on that
  * stream behind the spectrum, or NULL) is waited for on `stream` in front of the pass that first reads Ghat — the forward
  * x and y passes of rho do not wait. */
 int chx_sc_convolve_halo_after(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
