@@ -104,6 +104,7 @@ SIGNATURES = {
     "chx_hist2d_indices": (c_int, [ctypes.POINTER(Hist2dArgs), c_void_p, c_void_p]),
     "chx_sc_igf_workspace_bytes": (c_size_t, [c_i64, c_i32_p]),
     "chx_sc_igf": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
+    "chx_sc_igf_from_table": (c_int, [c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_i64, c_void_p]),
     "chx_sc_pruned_supported": (c_int, [c_i32_p, c_int]),
     "chx_sc_igf_table": (c_int, [c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
     "chx_sc_green_workspace_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),

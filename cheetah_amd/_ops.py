@@ -1483,6 +1483,63 @@ class ScPoisson(torch.autograd.Function):
         return d_rho, d_cell, d_gamma, d_scale, None
 
 
+class ScPoissonDense(torch.autograd.Function):
+    """The Poisson stage on ANY grid: the same operator as ScPoisson, with hipFFT plans owned by libchx (ScFftPlan) on the
+    zero-padded (2g)^3 arrays instead of the pruned power-of-two transforms. Self-adjoint like ScPoisson; the cell / gamma
+    derivatives convolve rho with the doubled arrays of the derivative tables (chx_sc_igf_table_grad + chx_sc_igf_from_table)."""
+
+    @staticmethod
+    def _convolve(rho, Ghat, pot_scale, bins, plan):
+        B, (gx, gy, gz) = rho.shape[0], bins
+        work = torch.zeros((B, 2 * gx, 2 * gy, 2 * gz + 2), dtype=rho.dtype, device=rho.device)
+        work[:, :gx, :gy, :gz] = rho
+        plan.forward(work, which=0)
+        sc_spectral_mul(work, Ghat, pot_scale)
+        plan.inverse(work)
+        return work[:, :gx, :gy, :gz].contiguous()
+
+    @staticmethod
+    def forward(ctx, rho, cell, gamma, pot_scale, bins, plan):
+        Ghat = sc_igf(cell, gamma, bins, padded=True)
+        plan.forward(Ghat, which=1)
+        phi = ScPoissonDense._convolve(rho, Ghat, pot_scale, bins, plan)
+        ctx.save_for_backward(rho, cell, gamma, pot_scale, Ghat, phi)
+        ctx.bins, ctx.plan = tuple(bins), plan
+        return phi
+
+    @staticmethod
+    def backward(ctx, dphi):
+        rho, cell, gamma, pot_scale, Ghat, phi = ctx.saved_tensors
+        bins, plan = ctx.bins, ctx.plan
+        B = rho.shape[0]
+        dphi = dphi.contiguous()
+        d_rho = d_cell = d_gamma = d_scale = None
+        if ctx.needs_input_grad[0]:
+            d_rho = ScPoissonDense._convolve(dphi, Ghat, pot_scale, bins, plan)
+        if ctx.needs_input_grad[3]:
+            d_scale = (dphi.double() * phi.double()).sum(dim=(1, 2, 3)) / pot_scale
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            lib = _lib.lib()
+            b3 = _bins3(bins)
+            dt = dtype_code(cell.dtype)
+            n1 = (bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1)
+            tables = torch.empty((3, B, n1), dtype=torch.float64, device=cell.device)
+            check(lib.chx_sc_igf_table_grad(ptr(cell), ptr(gamma), B, b3, dt, ptr(tables), stream_ptr()), "chx_sc_igf_table_grad")
+            sens = []
+            for d in range(3):
+                Gd = torch.empty_like(Ghat)
+                check(lib.chx_sc_igf_from_table(ptr(tables[d]), B, b3, dt, ptr(Gd), Ghat.shape[-1], stream_ptr()),
+                      "chx_sc_igf_from_table")
+                plan.forward(Gd, which=1)
+                phi_d = ScPoissonDense._convolve(rho, Gd, pot_scale, bins, plan)
+                sens.append((dphi.double() * phi_d.double()).sum(dim=(1, 2, 3)))
+            if ctx.needs_input_grad[1]:     # third table: derivative with respect to cell_z * gamma
+                d_cell = torch.stack([sens[0], sens[1], sens[2] * gamma.double()], dim=-1).to(cell.dtype)
+            if ctx.needs_input_grad[2]:
+                d_gamma = (sens[2] * cell[:, 2].double()).to(gamma.dtype)
+        return d_rho, d_cell, d_gamma, d_scale, None, None
+
+
 class ScGradient(torch.autograd.Function):
     """F = -(1/gamma^2) grad phi, packed (B, gx, gy, gz, 4) (chx_sc_gradient / chx_sc_gradient_bwd)."""
 

@@ -219,8 +219,7 @@ class SpaceChargeKick(Element):
         parts = incoming.particles
         dtype, device = parts.dtype, parts.device
         g = self.grid_shape
-        if not _ops.sc_pruned_supported(g, dtype):
-            raise NotImplementedError(f"gradients through SpaceChargeKick need a power-of-two grid (16..512), got {g}")
+        pruned = _ops.sc_pruned_supported(g, dtype)     # else: the dense hipFFT plans of the forward-only path (ScPoissonDense)
         N = parts.shape[-2]
         out_shape = _ops.bshapes(parts.shape[:-2], incoming.energy.shape, incoming.particle_charges.shape[:-1],
                                  incoming.survival_probabilities.shape[:-1], self.effect_length.shape)
@@ -251,7 +250,11 @@ class SpaceChargeKick(Element):
         pot_scale = pot_factor / cell.double().prod(dim=-1)
 
         rho = _ops.cic_deposit(x, (0, 2, 4), g, extent, charge=q, survival=w, scale=scale)
-        phi = _ops.ScPoisson.apply(rho.reshape(B, *g).contiguous(), cell.contiguous(), gamma.contiguous(), pot_scale, g)
+        if pruned:
+            phi = _ops.ScPoisson.apply(rho.reshape(B, *g).contiguous(), cell.contiguous(), gamma.contiguous(), pot_scale, g)
+        else:
+            phi = _ops.ScPoissonDense.apply(rho.reshape(B, *g).contiguous(), cell.contiguous(), gamma.contiguous(), pot_scale, g,
+                                            self._fft_plan(B, g, dtype))
         force = _ops.ScGradient.apply(phi, cell.contiguous(), gamma.contiguous(), g)
         out = _ops.ScGatherKick.apply(_ops.aligned(x), force, half.contiguous(), cell.contiguous(), energy, dt.contiguous(),
                                       incoming.species.mass_eV_float, B, N, g)

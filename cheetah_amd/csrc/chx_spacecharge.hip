@@ -383,6 +383,28 @@ extern "C" int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const 
     return CHX_OK;
 }
 
+// The doubled, mirrored Green array of chx_sc_igf from a corner table that is already there (e.g. one of the derivative tables
+// of chx_sc_igf_table_grad: the backward pass of the Poisson stage on grids the pruned transforms do not cover).
+extern "C" int chx_sc_igf_from_table(const double* table, int64_t B, const int32_t* bins, int dtype, void* G_out, int64_t ldz,
+                                     void* stream) {
+    if (!table || !G_out || B < 1 || B > 65535 || !bins_ok(bins)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = bins[0], gy = bins[1], gz = bins[2];
+    if (ldz == 0) ldz = 2 * gz;
+    if (ldz < 2 * gz) return CHX_ERR_INVALID_ARG;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    if (hipMemsetAsync(G_out, 0, (size_t)B * 4 * (size_t)gx * gy * (size_t)ldz * esz, s) != hipSuccess) return CHX_ERR_LAUNCH;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(igf_fill_kernel<float>, cell_grid((int64_t)gx * gy * gz, B), dim3(CHX_BLOCK), 0, s, table, gx, gy, gz,
+                           ldz, (float*)G_out);
+    else
+        hipLaunchKernelGGL(igf_fill_kernel<double>, cell_grid((int64_t)gx * gy * gz, B), dim3(CHX_BLOCK), 0, s, table, gx, gy, gz,
+                           ldz, (double*)G_out);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 // Only the corner table of the primitive (the input of chx_sc_green_spectrum, chx_fft.hip).
 extern "C" int chx_sc_igf_table(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
                                 double* table, void* stream) {

@@ -317,6 +317,9 @@ size_t chx_sc_igf_workspace_bytes(int64_t B, const int32_t* bins);
 int chx_sc_igf(const void* cell, const void* gamma, int64_t B, const int32_t* bins, int dtype,
                void* G_out /*[B][2gx][2gy][ldz]*/, int64_t ldz, void* workspace, size_t workspace_bytes,
                void* stream);
+/* The same doubled array from a corner table that already exists (chx_sc_igf_table, or one of the three derivative tables of
+ * chx_sc_igf_table_grad — the backward pass of the Poisson stage on grids outside chx_sc_pruned_supported). */
+int chx_sc_igf_from_table(const double* table, int64_t B, const int32_t* bins, int dtype, void* G_out, int64_t ldz, void* stream);
 /* 3-D FFTs of the Hockney convolution (space_charge_kick.py:306-314) through hipFFT, in place on the padded real
  * layout [B][2gx][2gy][2gz + 2] (= complex [B][2gx][2gy][gz + 1]), unnormalised. direction 0 / 1: forward with
  * plan 0 / 1 (two plans, so rho and the Green function can be transformed concurrently on two streams),

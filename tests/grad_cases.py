@@ -18,6 +18,9 @@ SETTINGS = {
     "TransverseDeflectingCavity": {"length": 0.3, "voltage": 1e6, "phase": 20.0, "frequency": 2.9e9},
 }
 EXTRA = {"Aperture": {"is_active": True}, "SpaceChargeKick": {"grid_shape": (16, 16, 16)}, "Sextupole": {"tracking_method": "linear"}}
+# a grid outside the pruned power-of-two transforms: gradients through the dense hipFFT plans (ScPoissonDense)
+SETTINGS["SpaceChargeKick@odd_grid"] = dict(SETTINGS["SpaceChargeKick"])
+EXTRA["SpaceChargeKick@odd_grid"] = {"grid_shape": (12, 10, 14)}
 # the non-linear tracking methods: "Kind@method" builds Kind with that tracking_method
 for _kind, _methods in (("Drift", ("second_order", "drift_kick_drift")), ("Quadrupole", ("second_order", "drift_kick_drift")),
                         ("Dipole", ("second_order", "drift_kick_drift")), ("Sextupole", ("second_order",))):
