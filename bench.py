@@ -63,21 +63,22 @@ def build_fodo(ca, torch, device, dtype):
 
 
 def timed(torch, dist, fn, steps, warmup, world):
+    multi = world > 1 or (dist.is_available() and dist.is_initialized())   # a one-rank group (forced collectives) as well
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -282,7 +283,9 @@ def other_configs(ca, torch, device) -> dict:
 
 
 def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) -> dict:
-    """The other sharded workloads next to the weak-scaling headline (world > 1 only)."""
+    """The other sharded workloads next to the weak-scaling headline. World > 1: RCCL over xGMI. World == 1: the same code
+    on a one-rank RCCL group with `sharding.force_collectives` (every all-gather / all-reduce / chx_merge_moments executes;
+    a one-rank exchange returns its input), so the legs are exercised by every single-GPU run of the driver."""
     from benchmarks import run_configs as rc
 
     rc.DEV = device
@@ -368,6 +371,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1/C3/C4/C5 side timings (and the scaling legs)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1: open the one-rank RCCL group BEFORE the headline, so that its step runs the moments "
+                         "all-gather + chx_merge_moments too (default: only the scaling legs, after the headline)")
+    ap.add_argument("--no-scaling-legs", action="store_true", help="N = 1: skip the one-rank RCCL run of the scaling legs")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     # smoke test of the multi-rank code path on a ONE-GPU box: every rank on cuda:0, collectives over gloo (RCCL refuses two
     # ranks on one device). Not a measurement.
@@ -406,6 +413,24 @@ def main():
 
     import cheetah_amd as ca
     from cheetah_amd import _ops, sharding
+
+    def open_single_rank_group():
+        """A process group of this one rank on RCCL + the force switch: every exchange takes its collective branch."""
+        import datetime
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device),
+                                timeout=datetime.timedelta(seconds=240))
+        assert dist.get_backend() == "nccl"
+        sharding.force_collectives(True)
+
+    if world == 1 and args.force_collectives:
+        open_single_rank_group()
 
     dtype = torch.float32
     seg = build_fodo(ca, torch, device, dtype)
@@ -495,14 +520,24 @@ def main():
     if not args.no_configs:
         if world == 1:
             result["configs"] = other_configs(ca, torch, device)
-        else:
-            result["scaling_legs"] = scaling_legs(ca, torch, dist, sharding, device, rank, world, min(args.steps, 50),
-                                                  min(args.warmup, 5))
+        if world > 1 or not args.no_scaling_legs:
+            try:
+                if world == 1 and not dist.is_initialized():
+                    open_single_rank_group()
+                legs = scaling_legs(ca, torch, dist, sharding, device, rank, world, min(args.steps, 50), min(args.warmup, 5))
+                legs["n_gpus"] = world
+                if world == 1:
+                    legs["note"] = ("one-rank RCCL group with forced collectives: all_gather_into_tensor -> chx_merge_moments "
+                                    "and the device all-reduce of the charge grid execute; not a scaling measurement")
+                result["scaling_legs"] = legs
+            except Exception as exc:   # the headline stands on its own
+                result["scaling_legs"] = {"n_gpus": world, "error": f"{type(exc).__name__}: {exc}"}
+    result["collectives_forced_in_headline"] = bool(world == 1 and args.force_collectives)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(E)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1093,6 +1093,27 @@ def cic_deposit_into(grid: torch.Tensor, grid_strides, grid_batch_stride, partic
     _launch_cic(a, N, len(bins), particles.device, mode)
 
 
+def sc_deposit_overwrite(x, q, w, extent, scale, B: int, N: int, bins) -> torch.Tensor:
+    """The charge grid (B, gx, gy, gz) of a kick from x (Bx,N,7), charges, survival weights and the geometry kernel's
+    extent (B,3,2) / scale (B,3), as `chx_sc_kick` deposits it: `chx_cic_deposit_sorted_overwrite` (every cell stored by the
+    tile that owns it, no zero-fill) from 65536 particles on, below that a zeroed grid + the direct deposit."""
+    g = [int(b) for b in bins]
+    total = g[0] * g[1] * g[2]
+    rho = torch.empty((B, *g), dtype=x.dtype, device=x.device)
+    a, keep, _, _, _ = _cic_args(x, (0, 2, 4), g, extent, q, w, scale, None, False, grid=rho,
+                                 grid_strides=(g[1] * g[2], g[2], 1), grid_batch_stride=total)
+    lib = _lib.lib()
+    if N >= SORTED_CIC_MIN_PARTICLES:
+        nbytes = lib.chx_cic_sorted_workspace_bytes(ctypes.byref(a))
+        ws = workspace(nbytes, x.device)
+        check(lib.chx_cic_deposit_sorted_overwrite(ctypes.byref(a), ptr(ws), nbytes, stream_ptr()),
+              "chx_cic_deposit_sorted_overwrite")
+    else:
+        rho.zero_()
+        check(lib.chx_cic_deposit(ctypes.byref(a), stream_ptr()), "chx_cic_deposit")
+    return rho
+
+
 def cic_indices(particles, cols, bins, extent, scale=None, shift=None):
     a, keep, batch_shape, B, N = _cic_args(particles, cols, bins, extent, None, None, scale, shift, False)
     idx = torch.empty((B, N, len(cols)), dtype=torch.int32, device=particles.device)

@@ -640,7 +640,23 @@ class Segment(Element):
         plan = self._plan()
         screen = plan[-1][1] if plan and plan[-1][0] == "element" else None
         fused = (isinstance(screen, Screen) and screen.is_active and screen.method == "cloud-in-cell" and len(plan) >= 2
-                 and plan[-2][0] == "run" and not incoming.particles.requires_grad)
+                 and plan[-2][0] == "run")
+        if fused:
+            from .. import sharding
+
+            # `chx_cic_deposit_mapped` has no backward and deposits this rank's particles only: whenever anything that
+            # reaches the image carries a graph (beam, charges, survival, the screen's geometry, any lattice setting) or
+            # the beam is particle-sharded, `track` + `reading` is taken — it propagates gradients through CicDeposit and
+            # sums the image over the ranks
+            if sharding.active_group() is not None:
+                fused = False
+            elif torch.is_grad_enabled():
+                sp = incoming.species
+                fused = not (_any_requires_grad_py(incoming.particles, incoming.particle_charges,
+                                                   incoming.survival_probabilities, incoming.energy, sp.mass_eV,
+                                                   sp.num_elementary_charges, screen.pixel_size, screen.misalignment)
+                             or any(p.requires_grad for p in self.parameters())
+                             or any(b.requires_grad for b in self.buffers()))
         if not fused:
             self.track(incoming)
             last = self.elements[-1]

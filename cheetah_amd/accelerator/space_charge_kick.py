@@ -189,25 +189,53 @@ class SpaceChargeKick(Element):
         """The kick for a beam whose particles are spread over the ranks of `group` (sharding.particle_sharded): the same
         stages as `chx_sc_kick`, issued one by one so that the two exchanges fit in between — the beam moments (grid
         geometry from the GLOBAL sigmas) and the charge grid (sum over the shards). Every rank then solves the same
-        Poisson problem and kicks its own particles."""
+        Poisson problem and kicks its own particles. Any grid shape: power-of-two grids take libchx's pruned line FFTs,
+        the others the dense hipFFT plans of the single-GPU path (space_charge_kick.py:57,125-161)."""
         from .. import sharding
 
         dtype, device = x.dtype, x.device
         g = self.grid_shape
-        if not _ops.sc_pruned_supported(g, dtype):
-            raise NotImplementedError(f"a particle-sharded SpaceChargeKick needs a power-of-two grid (16..512), got {g}")
+        pruned = _ops.sc_pruned_supported(g, dtype)     # else: dense hipFFT plans on the zero-padded (2g)^3 arrays, any grid
+        mass = incoming.species.mass_eV_float
+        # exchange 1: beam moments (29 doubles per rank and batch row, one all-gather + chx_merge_moments)
         mom = _ops.moments(x, w.to(dtype).contiguous()).reshape(-1, _ops.MOM_NOUT)
         mom = sharding.gather_merge_moments(mom, group).contiguous()
         pot_factor = 1.0 / (4 * math.pi * epsilon_0) / float(8 * g[0] * g[1] * g[2])
         half, cell, gamma, dt, scale, extent, pot_scale = _ops.sc_geometry(
-            mom, self._grid_extent(dtype), energy, L.contiguous(), incoming.species.mass_eV_float, pot_factor, B, g)
-        green_hat = _ops.sc_green_spectrum(cell, gamma, g)
-        rho = torch.zeros((B, *g), dtype=dtype, device=device)
-        _ops.cic_deposit_into(rho, (g[1] * g[2], g[2], 1), g[0] * g[1] * g[2], x, (0, 2, 4), g, extent, charge=q, survival=w,
-                              scale=scale)
+            mom, self._grid_extent(dtype), energy, L.contiguous(), mass, pot_factor, B, g)
+        # the Green-function chain depends on the geometry only: it runs on the side stream UNDER the deposit and the grid
+        # all-reduce (the main stream joins it in front of the convolution)
+        main = torch.cuda.current_stream(device)
+        side = self._side_stream(device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            if pruned:
+                green = _ops.sc_green_spectrum(cell, gamma, g)
+            else:
+                plan = self._fft_plan(B, g, dtype)
+                green = _ops.sc_igf(cell, gamma, g, padded=True)
+                plan.forward(green, which=1)
+            join = torch.cuda.Event()
+            join.record(side)
+        # local charge: the tile-sorted deposit stores every cell of the compact grid itself (no zero-fill pass)
+        rho = _ops.sc_deposit_overwrite(x, q, w, extent, scale, B, N, g)
+        # exchange 2: the charge grid summed over the shards (g^3 values; 8.4 MB at 128^3 fp32)
         sharding.allreduce_grid(rho, group)
-        phi = _ops.sc_convolve_halo(rho, green_hat, pot_scale, g)
-        out = _ops.sc_gather_kick_phi(x, phi, half, cell, gamma, energy, dt, incoming.species.mass_eV_float, B, N, g)
+        main.wait_event(join)
+        green.record_stream(main)
+        if pruned:
+            phi = _ops.sc_convolve_halo(rho, green, pot_scale, g)
+            out = _ops.sc_gather_kick_phi(x, phi, half, cell, gamma, energy, dt, mass, B, N, g)
+        else:
+            work = torch.zeros((B, 2 * g[0], 2 * g[1], 2 * g[2] + 2), dtype=dtype, device=device)
+            work[:, :g[0], :g[1], :g[2]] = rho
+            plan.forward(work, which=0)
+            _ops.sc_spectral_mul(work, green, pot_scale)
+            plan.inverse(work)
+            force = _ops.sc_gradient(work, cell, gamma, g)
+            out = _ops.sc_gather_kick(x, force, half, cell, energy, dt, mass, B, N, g)
         return ParticleBeam(out.reshape(*out_shape, N, 7), incoming.energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=incoming.s,
                             species=incoming.species)

@@ -18,21 +18,44 @@ over gloo in the CPU tests (tests/test_sharding_gloo.py, world_size 2, partials 
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Callable
 
 import torch
 import torch.distributed as dist
 
-_ACTIVE_GROUP: list = []   # stack of process groups inside `particle_sharded(...)`
+_ACTIVE_GROUP: list = []   # stack of (process group, force_collectives) inside `particle_sharded(...)`
+_FORCE: list = [os.environ.get("CHX_FORCE_COLLECTIVES", "0") == "1"]   # process-wide default of `force_collectives`
+
+
+def force_collectives(on: bool = True) -> bool:
+    """Process-wide switch (also the environment variable CHX_FORCE_COLLECTIVES=1): take the collective branch of every
+    exchange below even in a group of ONE rank. A one-rank all-gather / all-reduce returns its input, so results are
+    bit-identical to the un-sharded ones — the point is that the RCCL calls, their stream ordering against libchx's own
+    streams and `chx_merge_moments` execute on a single-GPU box (tests, `bench.py --force-collectives`). Returns the
+    previous setting."""
+    old, _FORCE[0] = _FORCE[0], bool(on)
+    return old
+
+
+def collectives_on(group=None) -> bool:
+    """Does an exchange over `group` go through torch.distributed? More than one rank, or forced (see above)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    if dist.get_world_size(group) > 1:
+        return True
+    return _ACTIVE_GROUP[-1][1] if _ACTIVE_GROUP else _FORCE[0]
 
 
 @contextlib.contextmanager
-def particle_sharded(group=None):
+def particle_sharded(group=None, force_collectives=None):
     """Inside this context every rank of `group` holds a SLICE of the particles of one beam. Elements whose physics couples
     the particles exchange what they need: a `SpaceChargeKick` takes its grid from the global beam moments (one
     all-gather of 29 doubles per rank) and sums the deposited charge over the ranks (one all-reduce of the g^3 grid), a
-    `Screen` sums its image. Linear maps, cavities and apertures need nothing."""
-    _ACTIVE_GROUP.append(group if group is not None else (dist.group.WORLD if dist.is_initialized() else None))
+    `Screen` sums its image. Linear maps, cavities and apertures need nothing. `force_collectives` (default: the
+    process-wide switch): run the exchanges even when the group has a single rank."""
+    force = _FORCE[0] if force_collectives is None else bool(force_collectives)
+    _ACTIVE_GROUP.append((group if group is not None else (dist.group.WORLD if dist.is_initialized() else None), force))
     try:
         yield
     finally:
@@ -40,11 +63,12 @@ def particle_sharded(group=None):
 
 
 def active_group():
-    """The process group of the innermost `particle_sharded` context, or None outside / without more than one rank."""
+    """The process group of the innermost `particle_sharded` context, or None outside of one / when there is nothing to
+    exchange (a single rank and collectives not forced)."""
     if not _ACTIVE_GROUP or not (dist.is_available() and dist.is_initialized()):
         return None
-    group = _ACTIVE_GROUP[-1]
-    return group if dist.get_world_size(group) > 1 else None
+    group, force = _ACTIVE_GROUP[-1]
+    return group if (dist.get_world_size(group) > 1 or force) else None
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -63,10 +87,11 @@ def allreduce_moments(local_sums: torch.Tensor, centred_fn: Callable[[torch.Tens
     finalize_fn (global_sums, global_m2) -> (B,29) [W, W2, mu(6), unbiased cov upper triangle (21)]
     """
     sums = local_sums.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    on = collectives_on(group)
+    if on:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     m2 = centred_fn(sums).clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if on:
         dist.all_reduce(m2, op=dist.ReduceOp.SUM, group=group)
     return finalize_fn(sums, m2)
 
@@ -94,7 +119,7 @@ def merge_moments(per_rank: torch.Tensor) -> torch.Tensor:
 
 def gather_merge_moments(local: torch.Tensor, group=None) -> torch.Tensor:
     """Global moments from this rank's local (B,29) moments: one all-gather + exact merge."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not collectives_on(group):
         return local
     staged = local.contiguous()
     if staged.is_cuda and dist.get_backend(group) == "gloo":
@@ -128,6 +153,6 @@ def global_moments(beam, group=None) -> torch.Tensor:
 
 def allreduce_grid(grid: torch.Tensor, group=None) -> torch.Tensor:
     """Sum a locally deposited charge grid / screen image over the particle shards (in place)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         dist.all_reduce(grid, op=dist.ReduceOp.SUM, group=group)
     return grid

@@ -139,3 +139,44 @@ def test_gather_merge_moments_three_ranks_gloo(oracle):
         for j in range(i, 6):
             assert np.all(np.abs(out[:, k] - ref[:, k]) <= 1e-11 * sig[:, i] * sig[:, j]), (i, j)
             k += 1
+
+
+def test_force_collectives_on_one_rank_gloo():
+    """`force_collectives` / CHX_FORCE_COLLECTIVES: a group of ONE rank still goes through all_gather / all_reduce (what the
+    `-m gpu` test tests/test_gpu_rccl_single_rank.py runs on RCCL); without the switch the exchanges are skipped."""
+    from cheetah_amd import sharding
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = {"gather": 0, "reduce": 0}
+    real_gather, real_reduce = dist.all_gather, dist.all_reduce
+    dist.all_gather = lambda *a, **k: (calls.__setitem__("gather", calls["gather"] + 1), real_gather(*a, **k))[1]
+    dist.all_reduce = lambda *a, **k: (calls.__setitem__("reduce", calls["reduce"] + 1), real_reduce(*a, **k))[1]
+    try:
+        rng = np.random.default_rng(3)
+        local = torch.from_numpy(np.abs(rng.standard_normal((2, 29))) + 1.0)
+        local[:, 1] = local[:, 0] ** 2 / 50.0                       # W2 < W^2: a valid weight pair
+        grid = torch.full((3, 3), 2.0, dtype=torch.float64)
+        assert not sharding.collectives_on() and sharding.active_group() is None
+        with sharding.particle_sharded():
+            assert sharding.active_group() is None                   # one rank, not forced: nothing to exchange
+            assert sharding.gather_merge_moments(local) is local
+        assert calls == {"gather": 0, "reduce": 0}
+        with sharding.particle_sharded(force_collectives=True):
+            assert sharding.active_group() is not None and sharding.collectives_on()
+            merged = sharding.gather_merge_moments(local)
+            sharding.allreduce_grid(grid)
+        assert calls == {"gather": 1, "reduce": 1}
+        assert torch.allclose(merged, local, rtol=1e-14, atol=0) and torch.equal(grid, torch.full((3, 3), 2.0, dtype=torch.float64))
+        old = sharding.force_collectives(True)                       # the process-wide switch (bench.py --force-collectives)
+        try:
+            assert sharding.collectives_on()
+            with sharding.particle_sharded():
+                assert sharding.active_group() is not None
+            with sharding.particle_sharded(force_collectives=False):
+                assert sharding.active_group() is None
+        finally:
+            sharding.force_collectives(old)
+    finally:
+        dist.all_gather, dist.all_reduce = real_gather, real_reduce
+        dist.destroy_process_group()
