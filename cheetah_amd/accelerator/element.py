@@ -9,6 +9,7 @@ the `chx_apply_affine7` kernel (element.py:180-191).
 
 from __future__ import annotations
 
+import threading
 import warnings
 from copy import deepcopy
 from typing import Any
@@ -44,7 +45,15 @@ def _unique_name() -> str:
     return f"unnamed_element_{_name_counter}"
 
 
-_TRACK_DEPTH = [0]   # > 0 while a tracking call is running: map caches then never compare energies by value (see _cached_map)
+class _TrackDepth(threading.local):
+    """> 0 while a tracking call is running ON THIS THREAD: map caches then never compare energies by value (see
+    `_cached_map`). Thread-local: a track in one thread must not change the cache semantics of a direct
+    `first_order_transfer_map` call in another."""
+
+    value = 0
+
+
+_TRACK_DEPTH = _TrackDepth()
 
 
 def tracking_call(fn):
@@ -53,11 +62,12 @@ def tracking_call(fn):
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        _TRACK_DEPTH[0] += 1
+        depth = _TRACK_DEPTH
+        depth.value += 1
         try:
             return fn(*args, **kwargs)
         finally:
-            _TRACK_DEPTH[0] -= 1
+            depth.value -= 1
 
     return wrapper
 
@@ -191,7 +201,7 @@ class Element(nn.Module):
             # back — 24 us and a pipeline stall, measured in a linac where every cavity hands on a new energy tensor. A direct
             # call keeps that behaviour (the same map OBJECT for an equal energy); inside a tracking call the map is simply
             # rebuilt, one small launch and no host synchronisation.
-            if _TRACK_DEPTH[0] == 0 and ce.dtype == energy.dtype and ce.device == energy.device and ce.shape == energy.shape \
+            if _TRACK_DEPTH.value == 0 and ce.dtype == energy.dtype and ce.device == energy.device and ce.shape == energy.shape \
                     and torch.equal(cache["energy_copy"], energy):
                 return cache["result"]
         result = build(energy, species)
@@ -326,6 +336,20 @@ class Element(nn.Module):
                     buffers[name] = value
                     return
         return super().__setattr__(name, value)
+
+    #: derived caches kept in `__dict__`: run plans with raw device addresses (ctypes arrays: not picklable, and a copy would
+    #: address the ORIGINAL's tensors), memoised maps / geometry, scratch buffers. A copy or an unpickled element starts
+    #: without them and rebuilds on first use.
+    _DERIVED_STATE = ("_plan_cache", "_flat_elements", "_map_cache", "_tmap_cache", "_scalar_ws", "_ext_cache",
+                      "_grid_tensor", "_geom_cache", "_limits_checked")
+
+    def __getstate__(self):
+        """State for `copy.deepcopy`, `pickle` and `torch.save`: everything but the derived caches."""
+        state = self.__dict__.copy()
+        for key in self._DERIVED_STATE:
+            if key in state:
+                state[key] = None
+        return state
 
     def _apply(self, fn, recurse=True):
         # .to() / .double() / .cuda() replace the buffers without going through __setattr__

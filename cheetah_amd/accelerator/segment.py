@@ -26,6 +26,7 @@ are applied back to back by `chx_track_elementwise` / `chx_track_fused` from a s
 from __future__ import annotations
 
 import ctypes
+import os
 from copy import deepcopy
 
 import torch
@@ -99,7 +100,14 @@ class _FastRun:
 
     A control loop re-assigns a few settings per step, which moves the epoch: `refresh` then re-reads only the elements
     whose own revision moved, patches their pointers into the existing host arrays and keeps the device state (it
-    remembers VALUES, whatever tensor they live in)."""
+    remembers VALUES, whatever tensor they live in).
+
+    Contract: a setting changes by ASSIGNMENT (`quad.k1 = t`, moves the epoch) or by an in-place op on its tensor (same
+    storage, the device sees the new value). Swapping the storage under an unchanged tensor object without an assignment
+    (`buf.data = other`, `set_`, `resize_`) moves no counter the host looks at; the plan then still holds the old address.
+    `CHX_CHECK_PLANS=1` re-derives every address on every track and raises on a mismatch (debug aid, ~25 us per track of a
+    100-element run). The device state (`state`, `R_view`) is per run, not per stream: one lattice object is tracked from
+    one stream at a time, like the reference's non-reentrant element caches (utils/cache.py:23-27)."""
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
                  "elements", "revs", "rows", "per_tensors", "slots", "R_view")
@@ -137,7 +145,9 @@ class _FastRun:
         for k, (t, index) in enumerate(refs):
             tensors.append(t)
             if reuse and t is old_tensors[k]:
-                continue
+                # the same tensor OBJECT: its storage may still have been swapped (`t.data = ...`, `set_`, `resize_`)
+                if row[k] == (t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()):
+                    continue
             if t.dtype != dtype or t.device != device or t.requires_grad:
                 return None
             if index is None:
@@ -207,6 +217,24 @@ class _FastRun:
             return
         self.tensors = tensors
         self.ok = True
+
+
+    def verify(self) -> None:
+        """CHX_CHECK_PLANS=1: every stored address against the tensor it was read from."""
+        k = 0
+        for i, e in enumerate(self.elements):
+            r = self.rows[i]
+            if r is None or r == "identity":
+                continue
+            for j, (t, index) in enumerate(e._builder_scalar_refs()):
+                want = t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()
+                if self.ptrs[self.slots[i] * _ops.MAX_PARAMS + j] != want:
+                    raise RuntimeError(f"run plan of element {e.name!r}: the storage of setting {j} was replaced without an "
+                                       "attribute assignment (`.data = ...`, `set_`, `resize_`); assign the tensor instead")
+                k += 1
+
+
+_CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
 
 
 class _Run:
@@ -431,6 +459,8 @@ class Segment(Element):
             fr.refresh()
         if not fr.ok:
             return None
+        if _CHECK_PLANS:
+            fr.verify()
         e = incoming.energy
         if e.dim() != 0 or e.dtype != fr.dtype or e.device != fr.device:
             return None

@@ -326,3 +326,58 @@ def test_constructor_error_behaviour_mirrors_the_reference():
     text = repr(seg)
     assert text.startswith("Segment(elements=ModuleList(\n  (0): Drift(name='d0'") and "\n   ⋮\n" in text and text.endswith("name='long')")
     assert repr(ca.Segment([ca.Marker(name="m")], name="s")) == "Segment(elements=ModuleList(\n  (0): Marker(name='m')\n), name='s')"
+
+
+def test_segment_with_a_device_plan_can_be_copied_and_pickled(tmp_path):
+    """A Segment whose runs carry a persistent device plan (`_FastRun`: ctypes pointer arrays) deep-copies, pickles and
+    `torch.save`s like the reference's plain nn.Module (segment.py:45-71): derived caches are left out of the state, the copy
+    plans again on first use and addresses its OWN tensors."""
+    import copy
+    import io
+    import pickle
+
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator.segment import _FastRun
+
+    t = torch.tensor
+    seg = ca.Segment([ca.Drift(t(0.5)), ca.Quadrupole(t(0.2), k1=t(4.2), name="q1"), ca.Drift(t(0.3)),
+                      ca.SpaceChargeKick(t(0.1)), ca.Drift(t(0.2)), ca.Screen(name="scr", is_active=True)])
+    for kind, item in seg._plan():
+        if kind == "run":
+            item.fast = _FastRun(item, torch.float32, torch.device("cpu"))   # what a GPU track leaves behind
+            assert item.fast.ok
+    assert seg.__dict__["_plan_cache"] is not None
+    dup = copy.deepcopy(seg)
+    assert dup.__dict__["_plan_cache"] is None and seg.__dict__["_plan_cache"] is not None
+    assert dup.q1 is not seg.q1 and dup.q1.k1.data_ptr() != seg.q1.k1.data_ptr() and dup.elements[1] is dup.q1
+    plan = dup._plan()
+    fr = _FastRun(plan[0][1], torch.float32, torch.device("cpu"))
+    assert fr.ok and fr.ptrs[1 * 9 + 1] == dup.q1.k1.data_ptr()                # the copy's plan points at the copy's tensors
+    blob = pickle.dumps(seg)
+    back = pickle.loads(blob)
+    assert [type(e).__name__ for e in back.elements] == [type(e).__name__ for e in seg.elements]
+    assert torch.equal(back.q1.k1, seg.q1.k1) and back.__dict__["_plan_cache"] is None
+    buf = io.BytesIO()
+    torch.save(seg, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert torch.equal(again.q1.k1, seg.q1.k1) and len(again._plan()) == len(seg._plan())
+
+
+def test_storage_swap_under_a_planned_tensor_is_seen_when_its_element_is_reread():
+    from cheetah_amd.accelerator.segment import _FastRun
+    import cheetah_amd as ca
+
+    t = torch.tensor
+    q1 = ca.Quadrupole(t(0.2), k1=t(4.2), name="q1")
+    seg = ca.Segment([ca.Drift(t(0.5)), q1])
+    fr = _FastRun(seg._plan()[0][1], torch.float32, torch.device("cpu"))
+    k1 = q1.k1
+    old = k1.data_ptr()
+    k1.data = t(-1.0)                       # same tensor object, new storage, no assignment
+    with pytest.raises(RuntimeError, match="storage of setting"):
+        fr.verify()                         # what CHX_CHECK_PLANS=1 runs per track
+    q1.length = t(0.25)                     # any assignment on the element re-reads it: the swapped address is picked up
+    fr.refresh()
+    assert fr.ok and fr.ptrs[1 * 9 + 1] == k1.data_ptr() != old
+    fr.verify()

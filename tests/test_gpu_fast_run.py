@@ -488,3 +488,62 @@ def test_path_length_follows_every_edit_of_a_length(dt):
     assert float(seg.track(beam).s) == pytest.approx(3.9, rel=1e-6)
     d.length.sub_(1.0)
     assert float(seg.track(beam).s) == pytest.approx(2.9, rel=1e-6)
+
+
+def test_deepcopy_and_pickle_after_a_gpu_track(ca):
+    """the persistent plan (ctypes pointer arrays in `Segment.__dict__`) must not leak into copies — a copy plans
+    again and follows ITS OWN settings (the reference's Segment is a plain nn.Module and deep-copies, segment.py:45-71)."""
+    import copy
+    import pickle
+
+    dt = torch.float32
+    seg = lattice(ca, dt)
+    torch.manual_seed(4)
+    beam = ca.ParticleBeam.from_parameters(num_particles=5000, dtype=dt, device="cuda")
+    out = seg.track(beam).particles.clone()
+    assert seg._plan()[0][1].fast is not None and seg._plan()[0][1].fast.ok
+    dup = copy.deepcopy(seg)
+    back = pickle.loads(pickle.dumps(seg))
+    assert torch.equal(dup.track(beam).particles, out) and torch.equal(back.track(beam).particles, out)
+    dup.q1.k1 = torch.tensor(-2.5, dtype=dt, device="cuda")         # assignment on the copy
+    back.q1.k1.fill_(-2.5)                                            # in-place edit on the unpickled one
+    fresh = lattice(ca, dt)
+    fresh.q1.k1 = torch.tensor(-2.5, dtype=dt, device="cuda")
+    want = fresh.track(beam).particles
+    assert torch.equal(dup.track(beam).particles, want) and torch.equal(back.track(beam).particles, want)
+    assert torch.equal(seg.track(beam).particles, out)               # the original never noticed
+
+
+def test_fused_screen_reading_keeps_gradients_of_lattice_settings(ca):
+    """`track_screen_reading` must not hand back a detached image when a lattice setting / the charges / the
+    screen geometry carry a graph — it then takes `track` + `reading` (CicDeposit has a backward, the fused deposit none)."""
+    dt = torch.float64
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(8)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, sigma_x=t(2e-4), sigma_y=t(2e-4), **kw)
+
+    def build(k1):
+        return ca.Segment([ca.Drift(t(0.3), **kw), ca.Quadrupole(t(0.2), k1=k1, **kw), ca.Drift(t(0.8), **kw),
+                           ca.Screen(resolution=(32, 24), pixel_size=t([8e-5, 9e-5]), is_active=True, name="scr", **kw)])
+
+    weights = torch.linspace(0.0, 1.0, 32 * 24, **kw).reshape(24, 32)
+    k1a = torch.nn.Parameter(t(2.0))
+    img = build(k1a).track_screen_reading(beam)
+    assert img.requires_grad
+    (img * weights).sum().backward()
+    k1b = torch.nn.Parameter(t(2.0))
+    seg = build(k1b)
+    seg.track(beam)
+    (seg.scr.reading * weights).sum().backward()
+    assert k1a.grad is not None and torch.allclose(k1a.grad, k1b.grad, rtol=1e-12, atol=0)
+    # without any graph the fused deposit is taken and gives the same image
+    with torch.no_grad():
+        plain = build(t(2.0)).track_screen_reading(beam)
+    assert torch.allclose(plain, img.detach(), rtol=1e-10, atol=1e-30)
+    # charges that require grad: same rule
+    q = beam.particle_charges.clone().requires_grad_(True)
+    beam_q = ca.ParticleBeam(beam.particles, beam.energy, particle_charges=q, species=beam.species)
+    img_q = build(t(2.0)).track_screen_reading(beam_q)
+    img_q.sum().backward()
+    assert q.grad is not None and float(q.grad.abs().sum()) > 0
