@@ -270,8 +270,9 @@ def other_configs(ca, torch, device) -> dict:
 
     def c5():
         r = rc.c5()
-        # forward: apply 56 B + moments 32 B; backward: moments_bwd 60 B + apply_bwd 84 B per particle
-        nbytes = 232.0 * N_PARTICLES
+        # forward: apply 56 B + the Screen's snapshot of the beam 56 B + moments 32 B per particle; backward: 7x7 algebra on the
+        # incoming beam's (memoised) moments — no particle pass (the particle-sized backward moved 144 B more)
+        nbytes = 144.0 * N_PARTICLES
         return {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
                 "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
                 "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,

@@ -93,6 +93,10 @@ SIGNATURES = {
     "chx_moment_finalize": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "chx_moments": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_moments_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_moments_mapped_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_moment_entry": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "chx_moment_entry_mapped_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int,
+                                            c_void_p, c_int, c_void_p]),
     "chx_cic_deposit": (c_int, [ctypes.POINTER(CicArgs), c_void_p]),
     "chx_cic_deposit_mapped": (c_int, [ctypes.POINTER(CicArgs), c_void_p, c_i64, c_void_p]),
     "chx_cic_sorted_workspace_bytes": (c_size_t, [ctypes.POINTER(CicArgs)]),
@@ -178,6 +182,10 @@ SIGNATURES = {
     "chx_run_vjp_workspace_bytes": (c_size_t, [c_i64]),
     "chx_run_vjp": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_size_t, c_void_p]),
+    "chx_run_vjp_masked": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_run_build_compose": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p,
+                                      c_void_p]),
     "chx_build_rmatrix_scalars": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p]),
 }
 

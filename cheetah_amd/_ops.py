@@ -120,6 +120,13 @@ def clone_many(tensors):
     carry gradients (under autograd), are not contiguous or do not live on a ROCm device are cloned the ordinary way."""
     plain = [t.is_cuda and t.is_contiguous() and not (t.requires_grad and torch.is_grad_enabled()) for t in tensors]
     out = [torch.empty_like(t) if ok else t.clone() for t, ok in zip(tensors, plain)]
+    for t, o in zip(tensors, out):
+        # provenance (see `_LinearSource` / `_origin`): a copy of a linearly tracked array still IS R x; a copy of a weight
+        # array still holds the values of its source
+        lin = getattr(t, "_chx_lin", None)
+        if lin is not None and lin.version == t._version:
+            o._chx_lin = lin.rebound(o)
+        o._chx_origin = (t, t._version, o._version)
     pairs = [(t, o) for t, o, ok in zip(tensors, out, plain) if ok and t.numel()]
     for lo in range(0, len(pairs), 8):
         chunk = pairs[lo:lo + 8]
@@ -287,6 +294,71 @@ class RunMapScalars(torch.autograd.Function):
         return (None, d_energy, *grads)
 
 
+class RunMapPlanned(torch.autograd.Function):
+    """RunMapScalars on a persistent plan (`segment._FastRun(..., allow_grad=True)`): the packed kinds / pointer arrays and
+    the (tensor -> slots) table are read once per change of the lattice, every step is ONE C call forward
+    (chx_run_build_compose) and ONE backward (chx_run_vjp_masked: only the dual-number builders of the settings that want a
+    gradient are evaluated)."""
+
+    @staticmethod
+    def forward(ctx, plan, energy, mass_eV, n_charges, *tensors):
+        E = plan.E
+        maps = torch.empty((E, 7, 7), dtype=energy.dtype, device=energy.device)
+        out = torch.empty((7, 7), dtype=energy.dtype, device=energy.device)
+        check(_lib.lib().chx_run_build_compose(plan.kinds, plan.ptrs, E, energy.data_ptr(), mass_eV, n_charges, plan.code,
+                                               maps.data_ptr(), out.data_ptr(), stream_ptr()), "chx_run_build_compose")
+        ctx.plan, ctx.consts = plan, (mass_eV, n_charges, plan.kinds, plan.ptrs, plan.grad_slots, plan.epoch)
+        ctx.save_for_backward(energy, maps, *tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dT):
+        mass_eV, n_charges, kinds, ptrs, grad_slots, epoch = ctx.consts
+        energy, maps, *tensors = ctx.saved_tensors
+        E = maps.shape[0]
+        lib = _lib.lib()
+        if ctx.plan.epoch != epoch:
+            # the plan was refreshed since the forward pass (a setting re-assigned before backward): its pointer array may
+            # address other tensors by now — the addresses of THIS graph come from the saved tensors
+            ptrs = (ctypes.c_void_p * (E * MAX_PARAMS))()
+            for pos, slots in enumerate(grad_slots):
+                t = tensors[pos]
+                for e, k, index in slots:
+                    ptrs[e * MAX_PARAMS + k] = t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()
+        needs = ctx.needs_input_grad
+        need_energy = needs[1]
+        mask = [0] * E
+        for pos, slots in enumerate(grad_slots):
+            if needs[4 + pos]:
+                for e, k, _ in slots:
+                    mask[e] |= 1 << k
+        if need_energy:
+            mask = [m | (1 << MAX_PARAMS) for m in mask]
+        ws_bytes = lib.chx_run_vjp_workspace_bytes(E)
+        ws = workspace(ws_bytes, energy.device)
+        dT = dT.to(energy.dtype).contiguous()
+        d = torch.empty((E, MAX_PARAMS + 1), dtype=energy.dtype, device=energy.device)
+        check(lib.chx_run_vjp_masked(kinds, ptrs, E, energy.data_ptr(), mass_eV, n_charges, dtype_code(energy.dtype), ptr(maps),
+                                     ptr(dT), (ctypes.c_uint16 * E)(*mask), ptr(d), ptr(ws), ws_bytes, stream_ptr()),
+              "chx_run_vjp_masked")
+        grads = [None] * len(tensors)
+        for pos, slots in enumerate(grad_slots):
+            if not needs[4 + pos]:
+                continue
+            t = tensors[pos]
+            if t.dim() == 0:
+                g = d[slots[0][0], slots[0][1]]
+                for e, k, _ in slots[1:]:
+                    g = g + d[e, k]
+            else:
+                g = torch.zeros_like(t)
+                for e, k, index in slots:
+                    g[index] += d[e, k]
+            grads[pos] = g
+        d_energy = d[:, MAX_PARAMS].sum() if need_energy else None
+        return (None, d_energy, None, None, *grads)
+
+
 def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_charges: float):
     """Composed (7,7) map of a run of elements whose builder parameters are all device scalars of the energy's dtype
     (chx_build_rmatrix_scalars + chx_compose_maps: two C calls whatever the number of elements; with gradients one autograd
@@ -383,6 +455,30 @@ class Apply(torch.autograd.Function):
         return dX, dR, None
 
 
+class _LinearSource:
+    """Provenance of a tracked particle array y = R x whose only differentiable input is the MAP (the particles x carry no
+    graph): what `moments` needs to differentiate a moment of y algebraically (mu' = A mu + b, cov' = A C A^T) instead of
+    through two passes over the particles. Attached to the tensor object `apply_map` returns (`_chx_lin`); valid while that
+    tensor's version counter stands still."""
+
+    __slots__ = ("owner", "x", "R", "batch_shape", "version")
+
+    def __init__(self, owner, x, R, batch_shape, version):
+        self.owner, self.x, self.R, self.batch_shape, self.version = owner, x, R, batch_shape, version
+
+    def rebound(self, copy_: torch.Tensor) -> "_LinearSource":
+        return _LinearSource(self.owner, self.x, self.R, self.batch_shape, copy_._version)
+
+
+def _origin(t: torch.Tensor) -> torch.Tensor:
+    """The tensor `t` is an unmodified copy of (clone_many), followed through chains of copies; `t` itself otherwise."""
+    while True:
+        tag = getattr(t, "_chx_origin", None)
+        if tag is None or tag[2] != t._version or tag[0]._version != tag[1]:
+            return t
+        t = tag[0]
+
+
 def apply_map(particles: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
     """`particles @ tm.mT` (element.py:182) with torch broadcasting of the vector dims."""
     require_device(particles, tm)
@@ -395,9 +491,11 @@ def apply_map(particles: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
     R, _ = flat_bcast(tm, batch_shape, 2)
     x, R = aligned(x), R.contiguous()
     if x.requires_grad or R.requires_grad:
-        out = Apply.apply(x, R, B)
-    else:
-        out = _apply_raw(x, R, B, x.shape[0], R.shape[0], N)
+        out = Apply.apply(x, R, B).reshape(*batch_shape, N, 7)
+        if not x.requires_grad and torch.is_grad_enabled():
+            out._chx_lin = _LinearSource(_origin(particles), x, R, batch_shape, out._version)
+        return out
+    out = _apply_raw(x, R, B, x.shape[0], R.shape[0], N)
     return out.reshape(*batch_shape, N, 7)
 
 
@@ -780,6 +878,109 @@ class Moments(torch.autograd.Function):
         return dX, None, None
 
 
+def _memo_moments(owner: torch.Tensor, x: torch.Tensor, w, survival, B: int) -> torch.Tensor:
+    """chx_moments (B,29) of the flat, gradient-free x (Bx,N,7) / w (Bw,N), memoised on the tensor OBJECT `owner` the values
+    belong to, against (its version, the weight tensor — followed to the array it is an unmodified copy of — and that
+    array's version, the data address). An optimisation loop tracks one incoming beam again and again: reduced once."""
+    w_src = None if survival is None else _origin(survival)
+    cached = getattr(owner, "_chx_mom", None)
+    if cached is not None and cached[0] == owner._version and cached[1] is w_src \
+            and (w_src is None or cached[2] == w_src._version) and cached[3] == x.data_ptr() and cached[4].shape[0] == B:
+        return cached[4]
+    mom = _moments_raw(x, w, B, x.shape[1])
+    owner._chx_mom = (owner._version, w_src, None if w_src is None else w_src._version, x.data_ptr(), mom)
+    return mom
+
+
+def _incoming_moments(lin: "_LinearSource", survival, w, B: int) -> torch.Tensor:
+    """chx_moments (Bm,29) of the beam that ENTERED the linear map, with the weights the outgoing moment was taken with."""
+    x = lin.x
+    return _memo_moments(lin.owner, x, w, survival, max(x.shape[0], 1 if w is None else w.shape[0]))
+
+
+class MomentsMapped(torch.autograd.Function):
+    """out = chx_moments(y) for y = R x with x free of gradients: forward reduces the tracked particles like `Moments`
+    (same numbers), backward = chx_moments_mapped_bwd — 7x7 algebra on the INCOMING beam's moments, no pass over y or x."""
+
+    @staticmethod
+    def forward(ctx, R, y, w, source, B):
+        out = _moments_raw(y, w, B, y.shape[1])
+        ctx.save_for_backward(R, source[0].x, *(() if w is None else (w,)))
+        ctx.meta = (source, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        R, x, *rest = ctx.saved_tensors
+        (lin, survival), B = ctx.meta
+        w = rest[0] if rest else None
+        mom_x = _incoming_moments(lin, survival, w, B)
+        d_out = d_out.contiguous().to(torch.float64)
+        dR = torch.empty((B, 49), dtype=torch.float64, device=R.device)
+        check(_lib.lib().chx_moments_mapped_bwd(ptr(d_out), ptr(R), ptr(mom_x), B, R.shape[0], mom_x.shape[0],
+                                                dtype_code(R.dtype), ptr(dR), stream_ptr()), "chx_moments_mapped_bwd")
+        dR = dR.reshape(B, 7, 7)
+        if R.shape[0] == 1 and B > 1:
+            dR = dR.sum(dim=0, keepdim=True)
+        return dR.to(R.dtype), None, None, None, None
+
+
+class MomentEntryMapped(torch.autograd.Function):
+    """One beam property (mu_*, sigma_*, cov_*) of a linearly tracked beam as ONE autograd node hanging on the map:
+    forward = chx_moment_entry on the (memoised) moment vector of the tracked particles, backward = chx_moment_entry_mapped_bwd
+    (scalar gradient -> dR in one launch, from the incoming beam's memoised moments)."""
+
+    @staticmethod
+    def forward(ctx, R, mom_y, source, index, take_sqrt, B):
+        out = torch.empty((B,), dtype=R.dtype, device=R.device)
+        check(_lib.lib().chx_moment_entry(ptr(mom_y), B, index, int(take_sqrt), dtype_code(R.dtype), ptr(out), stream_ptr()),
+              "chx_moment_entry")
+        lin, survival, w = source
+        ctx.save_for_backward(R, mom_y, lin.x, *(() if w is None else (w,)))
+        ctx.meta = (lin, survival, index, take_sqrt, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        R, mom_y, x, *rest = ctx.saved_tensors
+        lin, survival, index, take_sqrt, B = ctx.meta
+        mom_x = _incoming_moments(lin, survival, rest[0] if rest else None, B)
+        grad = grad.contiguous()
+        BR = R.shape[0]
+        direct = BR == B
+        dR = torch.empty((B, 7, 7), dtype=R.dtype if direct else torch.float64, device=R.device)
+        check(_lib.lib().chx_moment_entry_mapped_bwd(ptr(grad), ptr(mom_y), index, int(take_sqrt), ptr(R), ptr(mom_x), B, BR,
+                                                     mom_x.shape[0], dtype_code(R.dtype), ptr(dR), 0 if direct else 1,
+                                                     stream_ptr()), "chx_moment_entry_mapped_bwd")
+        if not direct:
+            dR = dR.sum(dim=0, keepdim=True).to(R.dtype)
+        return dR, None, None, None, None, None
+
+
+def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool):
+    """`moments(particles, survival)[..., index]` (or its square root) in the particle dtype for a linearly tracked beam
+    whose particles carry no graph of their own (`_LinearSource`), as one autograd node on the map; None when that does not
+    apply and the caller takes `moments`."""
+    lin = getattr(particles, "_chx_lin", None)
+    if lin is None or lin.version != particles._version or not lin.R.requires_grad or not torch.is_grad_enabled():
+        return None
+    if survival is not None and survival.requires_grad:
+        return None
+    sshape = survival.shape[:-1] if survival is not None else ()
+    batch_shape = bshapes(particles.shape[:-2], sshape)
+    if tuple(batch_shape) != tuple(lin.batch_shape):
+        return None
+    B = numel(batch_shape)
+    y, _ = flat_bcast(particles.detach(), batch_shape, 2)
+    y = aligned(y)
+    w = None
+    if survival is not None:
+        w, _ = flat_bcast(survival if survival.dtype == particles.dtype else survival.to(particles.dtype), batch_shape, 1)
+        w = w.contiguous()
+    mom_y = _memo_moments(particles, y, w, survival, B)
+    return MomentEntryMapped.apply(lin.R, mom_y, (lin, survival, w), index, take_sqrt, B).reshape(batch_shape)
+
+
 def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Tensor:
     """(…,29) float64: [W, W2, mu(6), cov upper triangle (21)] for every vector entry."""
     require_device(particles)
@@ -793,7 +994,14 @@ def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Ten
     if survival is not None:
         w, _ = flat_bcast(survival.to(particles.dtype), batch_shape, 1)
         w = w.contiguous()
-    if w is not None and w.requires_grad and torch.is_grad_enabled():
+    lin = getattr(particles, "_chx_lin", None)
+    if lin is not None and torch.is_grad_enabled() and lin.version == particles._version and x.requires_grad \
+            and not (w is not None and w.requires_grad) and tuple(lin.batch_shape) == tuple(batch_shape) \
+            and lin.R.requires_grad:
+        # a moment of a linearly tracked beam whose particles carry no graph: the gradient reaches the map through
+        # mu' = A mu + b, cov' = A C A^T (MomentsMapped) — no particle-sized backward pass
+        out = MomentsMapped.apply(lin.R, x.detach(), w, (lin, survival), B)
+    elif w is not None and w.requires_grad and torch.is_grad_enabled():
         # survival weights that carry a graph (an Aperture with differentiable edges upstream): chx_moments_bwd has no dW,
         # so this rare case is written as device tensor expressions (statistics.py:4-48) — differentiable in x AND w
         out = _moments_weight_grad(x, w, B)

@@ -110,9 +110,13 @@ class _FastRun:
     one stream at a time, like the reference's non-reentrant element caches (utils/cache.py:23-27)."""
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
-                 "elements", "revs", "rows", "per_tensors", "slots", "R_view")
+                 "elements", "revs", "rows", "per_tensors", "slots", "R_view", "allow_grad", "distinct", "grad_slots")
 
-    def __init__(self, run, dtype, device):
+    def __init__(self, run, dtype, device, allow_grad=False):
+        # allow_grad: the plan of the DIFFERENTIABLE run map (_ops.RunMapPlanned) — trainable parameters and settings that
+        # require grad qualify; `distinct` / `grad_slots` then say which slots every distinct setting tensor feeds
+        self.allow_grad = allow_grad
+        self.distinct, self.grad_slots = (), ()
         self.dtype, self.device = dtype, device
         self.elements = [e for e in run.elements]
         self.revs = [None] * len(self.elements)
@@ -129,7 +133,7 @@ class _FastRun:
         """(kind, pointers, tensors) of element number i, "identity", or None when the element rules the plan out. A setting
         that still is the tensor OBJECT read last time keeps its slot unexamined (same dtype, device, shape and address): a
         control step that re-assigns one strength of a quadrupole re-checks one tensor, not five."""
-        if not e._static_skippable or e._parameters:
+        if not e._static_skippable or (e._parameters and not self.allow_grad):
             return None                     # data-dependent skippability (Cavity, sub-Segment) or trainable parameters
         kind = e._chx_kind
         if kind is None:
@@ -148,7 +152,7 @@ class _FastRun:
                 # the same tensor OBJECT: its storage may still have been swapped (`t.data = ...`, `set_`, `resize_`)
                 if row[k] == (t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()):
                     continue
-            if t.dtype != dtype or t.device != device or t.requires_grad:
+            if t.dtype != dtype or t.device != device or (t.requires_grad and not self.allow_grad):
                 return None
             if index is None:
                 if t.dim() != 0:
@@ -208,14 +212,28 @@ class _FastRun:
             self.E, self.slots = E, slots
             self.kinds = (ctypes.c_int32 * E)(*kinds)
             self.ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*pointers)
-            self.state_bytes = _lib.lib().chx_run_state_bytes(E)
-            self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=self.device)
+            if not self.allow_grad:
+                self.state_bytes = _lib.lib().chx_run_state_bytes(E)
+                self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=self.device)
             self.R_view = None
         # kept alive: the plan holds their addresses (a tensor may appear more than once: `misalignment` feeds two parameters)
         tensors = tuple([t for ts in self.per_tensors for t in ts])
         if len(tensors) > 400:
             return
         self.tensors = tensors
+        if self.allow_grad:
+            where, distinct, grad_slots = {}, [], []
+            for i, e in enumerate(self.elements):
+                if rows[i] == "identity":
+                    continue
+                for k, (t, index) in enumerate(e._builder_scalar_refs()):
+                    pos = where.get(id(t))
+                    if pos is None:
+                        pos = where[id(t)] = len(distinct)
+                        distinct.append(t)
+                        grad_slots.append([])
+                    grad_slots[pos].append((self.slots[i], k, index))
+            self.distinct, self.grad_slots = tuple(distinct), tuple(tuple(g) for g in grad_slots)
         self.ok = True
 
 
@@ -243,7 +261,7 @@ class _Run:
     settings that changed — the tensor lists of the untouched elements, the summed length — is not redone."""
 
     __slots__ = ("elements", "modules", "rev", "per_module", "tensors", "params", "token", "tm", "stack", "length",
-                 "length_key", "energy_ref", "s_cache", "fast")
+                 "length_key", "energy_ref", "s_cache", "fast", "gfast")
 
     def __init__(self, elements):
         self.elements = elements
@@ -260,6 +278,7 @@ class _Run:
         self.energy_ref = None
         self.s_cache = None
         self.fast = None
+        self.gfast = None
         self._collect()
 
     def _collect(self):
@@ -412,7 +431,30 @@ class Segment(Element):
         return s_out
 
     @staticmethod
+    def _run_map_grad(run: _Run, energy, species):
+        """The run's composed map WITH a graph from the persistent differentiable plan (`_ops.RunMapPlanned`: one C call
+        forward, one backward), or None when nothing requires grad / the run does not qualify (vectorised settings or energy,
+        a species whose mass carries a gradient)."""
+        if energy.dim() != 0 or not energy.is_cuda or species.mass_eV.requires_grad \
+                or species.num_elementary_charges.requires_grad:
+            return None
+        fr = run.gfast
+        if fr is None or fr.dtype != energy.dtype or fr.device != energy.device:
+            fr = run.gfast = _FastRun(run, energy.dtype, energy.device, allow_grad=True)
+        elif fr.epoch != Element._epoch:
+            fr.refresh()
+        if not fr.ok or not (energy.requires_grad or _any_requires_grad(*fr.distinct)):
+            return None
+        if _CHECK_PLANS:
+            fr.verify()
+        return _ops.RunMapPlanned.apply(fr, energy, species.mass_eV_float, species.num_elementary_charges_float, *fr.distinct)
+
+    @staticmethod
     def _run_map(run: _Run, energy, species) -> torch.Tensor:
+        if torch.is_grad_enabled():
+            tm = Segment._run_map_grad(run, energy, species)
+            if tm is not None:
+                return tm
         cacheable = Segment._refresh(run, energy, species)
         if cacheable and run.tm is not None:
             return run.tm

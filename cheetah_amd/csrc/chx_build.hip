@@ -1049,6 +1049,7 @@ constexpr int kBuildChunk = 40;  // 40 x (9 pointers + 1 kind byte) = 2.9 KiB of
 struct BuildScalarsArgs {
     const void* par[kBuildChunk][CHX_MAX_PARAMS];
     uint8_t kind[kBuildChunk];
+    uint16_t need[kBuildChunk];   // backward only: bit k = slot k of element e is wanted (bit CHX_MAX_PARAMS: the energy)
 };
 
 template <typename T>
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs 
     const int P = kind_num_params(kind);
     const bool is_energy = k == CHX_MAX_PARAMS;
     T* o = out + e * (CHX_MAX_PARAMS + 1);
-    if (!is_energy && k >= P) {
+    if ((!is_energy && k >= P) || !((args.need[e] >> k) & 1)) {
         o[k] = (T)0;
         return;
     }
@@ -1177,11 +1178,39 @@ __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs 
     o[k] = (T)acc;
 }
 
+// forward of a run whose settings carry gradients, one call: element maps into maps[E][7][7] (kept for the backward pass) and
+// their product into R_out[7][7] — chx_build_rmatrix_scalars + chx_compose_maps, bit-identical to the two calls
+extern "C" int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                                     double mass_eV, double n_charges, int dtype, void* maps, void* R_out, void* stream) {
+    if (!maps || !R_out || E < 1 || E > 4096) return CHX_ERR_INVALID_ARG;
+    int st = chx_build_rmatrix_scalars(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, stream);
+    if (st != CHX_OK) return st;
+    const size_t step = 49 * (dtype == CHX_F32 ? 4 : 8);
+    if (E == 1) {
+        if (hipMemcpyAsync(R_out, maps, step, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return CHX_ERR_LAUNCH;
+        return CHX_OK;
+    }
+    const void* ptrs[4096];
+    uint8_t bc[4096];
+    for (int64_t e = 0; e < E; ++e) {
+        ptrs[e] = (const char*)maps + e * step;
+        bc[e] = 1;
+    }
+    return chx_compose_maps(ptrs, bc, E, 1, dtype, R_out, stream);
+}
+
 extern "C" size_t chx_run_vjp_workspace_bytes(int64_t E) { return E < 1 ? 0 : (size_t)E * 49 * sizeof(double); }
 
 extern "C" int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                            double n_charges, int dtype, const void* maps, const void* dT, void* dinputs, void* workspace,
                            size_t workspace_bytes, void* stream) {
+    return chx_run_vjp_masked(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, dT, nullptr, dinputs, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int chx_run_vjp_masked(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                                  double mass_eV, double n_charges, int dtype, const void* maps, const void* dT,
+                                  const uint16_t* need, void* dinputs, void* workspace, size_t workspace_bytes, void* stream) {
     if (!kinds || !param_ptrs || !energy || !maps || !dT || !dinputs || E < 1 || E > 65535) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (!workspace || workspace_bytes < chx_run_vjp_workspace_bytes(E)) return CHX_ERR_WORKSPACE;
@@ -1202,6 +1231,7 @@ extern "C" int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, 
             const int P = kind_num_params(kind);
             if (P < 0) return CHX_ERR_INVALID_ARG;
             a.kind[e] = (uint8_t)kind;
+            a.need[e] = (e < n) ? (need ? need[done + e] : (uint16_t)0xffff) : (uint16_t)0;
             for (int k = 0; k < CHX_MAX_PARAMS; ++k) {
                 a.par[e][k] = (e < n && k < P) ? param_ptrs[(done + e) * CHX_MAX_PARAMS + k] : nullptr;
                 if (e < n && k < P && !a.par[e][k]) return CHX_ERR_INVALID_ARG;

@@ -1057,3 +1057,132 @@ extern "C" int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, d
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
+
+// ---- moments of a linearly tracked beam: backward with respect to the MAP, without touching a particle -------------------
+// y_n = R x_n (x_6 = 1) with weights w_n: mu' = A mu + b, cov' = A C A^T with A = R[:6,:6], b = R[:6,6], (mu, C) the moments of
+// the INCOMING beam (element.py:180-191 followed by statistics.py:4-62). Given d_out[B][29] of chx_moments(y) this is
+//   dA = 2 G A C + g_mu mu^T,  db = g_mu,   G = the symmetric matrix whose upper triangle carries d_out[8:29]
+//   (off-diagonal entries halved: cov'_ij and cov'_ji are one output).
+// Exactly what autograd gives through chx_moments_bwd + chx_apply_affine7_bwd's dR reduction (sum_n dY_n x_n^T) when the
+// particles carry no gradient of their own — 32 B/particle (one pass for mu, C, cacheable across steps) instead of 232.
+namespace {
+// dR (49 doubles) of one batch row from the gradient g[29] of its outgoing moments, its map Rb (T) and the incoming moments m[29]
+template <typename T>
+__device__ __forceinline__ void mapped_bwd_row(const double* g, const T* __restrict__ Rb, const double* __restrict__ m, double* o) {
+    double G[6][6], C[6][6], A[6][6];
+    int k = 8;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j, ++k) {
+            G[i][j] = G[j][i] = (i == j) ? g[k] : 0.5 * g[k];
+            C[i][j] = C[j][i] = m[k];
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) A[i][j] = (double)Rb[i * 7 + j];
+    double AC[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+            for (int l = 0; l < 6; ++l) acc += A[i][l] * C[l][j];
+            AC[i][j] = acc;
+        }
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+            for (int l = 0; l < 6; ++l) acc += G[i][l] * AC[l][j];
+            o[i * 7 + j] = 2.0 * acc + g[2 + i] * m[2 + j];
+        }
+        o[i * 7 + 6] = g[2 + i];
+    }
+    for (int j = 0; j < 7; ++j) o[42 + j] = 0.0;
+}
+
+template <typename T>
+__global__ void moments_mapped_bwd_kernel(const double* __restrict__ d_out, const T* __restrict__ R, int64_t BR,
+                                          const double* __restrict__ mom_x, int64_t Bm, int64_t B, double* __restrict__ dR) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double o[49];
+    mapped_bwd_row<T>(d_out + b * CHX_MOM_NOUT, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, o);
+    for (int q = 0; q < 49; ++q) dR[b * 49 + q] = o[q];
+}
+
+// one ENTRY of the moment vector (optionally its square root) in the beam dtype, and its backward straight to dR: the node a
+// scalar loss like sigma_x(screen) hangs on (particle_beam.py:1672-1943 properties)
+template <typename T>
+__global__ void moment_entry_kernel(const double* __restrict__ mom, int64_t B, int index, int take_sqrt, T* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double v = mom[b * CHX_MOM_NOUT + index];
+    out[b] = (T)(take_sqrt ? sqrt(v) : v);
+}
+
+template <typename T, typename TO>
+__global__ void moment_entry_mapped_bwd_kernel(const T* __restrict__ grad, const double* __restrict__ mom_y, int index,
+                                               int take_sqrt, const T* __restrict__ R, int64_t BR,
+                                               const double* __restrict__ mom_x, int64_t Bm, int64_t B, TO* __restrict__ dR) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double g[CHX_MOM_NOUT];
+    for (int q = 0; q < CHX_MOM_NOUT; ++q) g[q] = 0.0;
+    double gv = (double)grad[b];
+    if (take_sqrt) gv = gv * 0.5 / sqrt(mom_y[b * CHX_MOM_NOUT + index]);   // infinite at 0 like torch.sqrt's own backward
+    g[index] = gv;
+    double o[49];
+    mapped_bwd_row<T>(g, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, o);
+    for (int q = 0; q < 49; ++q) dR[b * 49 + q] = (TO)o[q];
+}
+}  // namespace
+
+extern "C" int chx_moments_mapped_bwd(const double* d_out, const void* R, const double* mom_x, int64_t B, int64_t BR,
+                                      int64_t Bm, int dtype, double* dR, void* stream) {
+    if (!d_out || !R || !mom_x || !dR || B < 1 || (BR != 1 && BR != B) || (Bm != 1 && Bm != B)) return CHX_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(moments_mapped_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, d_out, (const float*)R, BR,
+                           mom_x, Bm, B, dR);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(moments_mapped_bwd_kernel<double>, grid, block, 0, (hipStream_t)stream, d_out, (const double*)R, BR,
+                           mom_x, Bm, B, dR);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_moment_entry(const double* mom, int64_t B, int index, int take_sqrt, int dtype, void* out, void* stream) {
+    if (!mom || !out || B < 1 || index < 0 || index >= CHX_MOM_NOUT) return CHX_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(moment_entry_kernel<float>, grid, block, 0, (hipStream_t)stream, mom, B, index, take_sqrt, (float*)out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(moment_entry_kernel<double>, grid, block, 0, (hipStream_t)stream, mom, B, index, take_sqrt, (double*)out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_moment_entry_mapped_bwd(const void* grad, const double* mom_y, int index, int take_sqrt, const void* R,
+                                           const double* mom_x, int64_t B, int64_t BR, int64_t Bm, int dtype, void* dR,
+                                           int dR_is_double, void* stream) {
+    if (!grad || !mom_y || !R || !mom_x || !dR || B < 1 || (BR != 1 && BR != B) || (Bm != 1 && Bm != B) || index < 2 ||
+        index >= CHX_MOM_NOUT)
+        return CHX_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32) {
+        if (dR_is_double)
+            hipLaunchKernelGGL((moment_entry_mapped_bwd_kernel<float, double>), grid, block, 0, s, (const float*)grad, mom_y, index,
+                               take_sqrt, (const float*)R, BR, mom_x, Bm, B, (double*)dR);
+        else
+            hipLaunchKernelGGL((moment_entry_mapped_bwd_kernel<float, float>), grid, block, 0, s, (const float*)grad, mom_y, index,
+                               take_sqrt, (const float*)R, BR, mom_x, Bm, B, (float*)dR);
+    } else if (dtype == CHX_F64) {
+        hipLaunchKernelGGL((moment_entry_mapped_bwd_kernel<double, double>), grid, block, 0, s, (const double*)grad, mom_y, index,
+                           take_sqrt, (const double*)R, BR, mom_x, Bm, B, (double*)dR);
+    } else {
+        return CHX_ERR_DTYPE;
+    }
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}

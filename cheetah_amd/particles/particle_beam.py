@@ -317,6 +317,12 @@ class ParticleBeam(Beam):
         """One entry of the moment vector (optionally its square root) in the beam's dtype. Under autograd this is ONE node
         (`_MomentEntry`) instead of select -> sqrt -> to, whose three backward nodes cost more host time than the moment
         kernels themselves in an optimisation loop."""
+        p = self.particles
+        if p.requires_grad and getattr(p, "_chx_lin", None) is not None:
+            # a linearly tracked beam whose only differentiable input is the map: one node, algebraic backward
+            v = _ops.moment_entry(p, self.survival_probabilities, index, take_sqrt)
+            if v is not None:
+                return v
         mom = self._moments()
         if mom.requires_grad and torch.is_grad_enabled():
             return _MomentEntry.apply(mom, index, take_sqrt, self.particles.dtype)

@@ -121,6 +121,16 @@ size_t chx_run_vjp_workspace_bytes(int64_t E);
 int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                 double n_charges, int dtype, const void* maps, const void* dT, void* dinputs, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* The same with a mask: need[E] (NULL = everything), bit k of need[e] set = slot k of element e is wanted (bit
+ * CHX_MAX_PARAMS: the energy); unwanted slots are written as zeros without evaluating their dual-number builder (a loss on
+ * ONE quadrupole strength of a 100-element run evaluates one builder, not 250). */
+int chx_run_vjp_masked(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                       double n_charges, int dtype, const void* maps, const void* dT, const uint16_t* need, void* dinputs,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* Forward of the same run in one call: chx_build_rmatrix_scalars into maps[E][7][7] (kept for chx_run_vjp) followed by
+ * chx_compose_maps of that stack into R_out[7][7]; bit-identical to the two calls (segment.py:534-543). E <= 4096. */
+int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                          double n_charges, int dtype, void* maps, void* R_out, void* stream);
 size_t chx_run_state_bytes(int64_t E);
 int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                 double n_charges, int dtype, void* state, size_t state_bytes, void** R_out, const void* s_in, void* s_out,
@@ -205,6 +215,20 @@ int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, double* out,
 /* backward of chx_moments wrt x: given d_out[B][29] (double; entries 0,1 ignored) */
 int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,
                     int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX, void* stream);
+/* Backward of chx_moments(y), y_n = R x_n, with respect to the MAP R[BR][7][7] (dtype) when the particles x carry no
+ * gradient: mu' = A mu + b, cov' = A C A^T (element.py:180-191 + utils/statistics.py:4-62), so
+ * dR[B][7][7] (double) = [2 G A C + g_mu mu^T | g_mu; 0] from d_out[B][29] and the INCOMING beam's chx_moments
+ * mom_x[Bm][29] alone — no pass over the particles (tests/test_differentiable.py:10-32: d sigma_x(screen) / d k1). */
+int chx_moments_mapped_bwd(const double* d_out, const void* R, const double* mom_x, int64_t B, int64_t BR, int64_t Bm,
+                           int dtype, double* dR, void* stream);
+/* One entry of the moment vector as a beam property reads it (particle_beam.py:1672-1943: mu_*, sigma_* = sqrt of the
+ * variance, cov_*): out[b] (dtype) = mom[b][index] or its square root — and its backward for a linearly tracked beam in one
+ * launch: grad[B] (dtype) of that entry -> dR[B][7][7] (double, or dtype when dR_is_double = 0) through
+ * chx_moments_mapped_bwd's algebra; mom_y[B][29] = chx_moments of the tracked beam (for the square root). */
+int chx_moment_entry(const double* mom, int64_t B, int index, int take_sqrt, int dtype, void* out, void* stream);
+int chx_moment_entry_mapped_bwd(const void* grad, const double* mom_y, int index, int take_sqrt, const void* R,
+                                const double* mom_x, int64_t B, int64_t BR, int64_t Bm, int dtype, void* dR, int dR_is_double,
+                                void* stream);
 /* Fused observables: out[b] = chx_moments of the tracked beam R[b] x without ever
  * writing it (element.py:180-191 followed by particle_beam.py:1672-1943), e.g. sigma_x(k1) over a scan of B
  * settings on one shared beam. One pass; second moments are accumulated about c_b = R[b] centre, where

@@ -246,8 +246,8 @@ def test_kick_then_run_in_one_pass_is_bit_identical(ca, dt):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 def test_run_of_scalar_settings_with_gradients_is_one_autograd_node(dt):
-    """A run whose scalar settings (and the beam energy) carry gradients goes through `_ops.RunMapScalars` (forward: the two C
-    calls of the no-grad path; backward: chx_run_vjp). Gradients against the element-by-element path (a BuildMap node per
+    """A run whose scalar settings (and the beam energy) carry gradients goes through `_ops.RunMapPlanned` (forward:
+    chx_run_build_compose on the persistent plan; backward: chx_run_vjp_masked) or, without a plan, `_ops.RunMapScalars`. Gradients against the element-by-element path (a BuildMap node per
     element, torch matmuls in between) and, in fp64, against central differences."""
     import cheetah_amd as ca
     from cheetah_amd import _ops
@@ -283,15 +283,29 @@ def test_run_of_scalar_settings_with_gradients_is_one_autograd_node(dt):
         return loss_of(beam)
 
     calls = []
-    orig = _ops.RunMapScalars.apply
+    orig = _ops.RunMapPlanned.apply
     try:
-        _ops.RunMapScalars.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+        _ops.RunMapPlanned.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
         va, ea = fresh(), torch.nn.Parameter(t(1.2e8))
         la = run(True, va, ea)
         la.backward()
     finally:
-        _ops.RunMapScalars.apply = orig
-    assert calls, "the merged run did not take the one-node path"
+        _ops.RunMapPlanned.apply = orig
+    assert calls, "the merged run did not take the one-node path (persistent differentiable plan)"
+    # the plan-less form of the same node (RunMapScalars: runs beyond the plan's size) gives the same numbers
+    from cheetah_amd.accelerator.segment import Segment
+
+    planned = Segment._run_map_grad
+    try:
+        Segment._run_map_grad = staticmethod(lambda *a: None)
+        vc, ec = fresh(), torch.nn.Parameter(t(1.2e8))
+        lc = run(True, vc, ec)
+        lc.backward()
+    finally:
+        Segment._run_map_grad = planned
+    assert float(lc.detach()) == float(la.detach())
+    for a, c in zip(va + [ea], vc + [ec]):
+        assert torch.allclose(a.grad, c.grad, rtol=1e-6 if dt == torch.float32 else 1e-13, atol=0), (a.grad, c.grad)
     vb, eb = fresh(), torch.nn.Parameter(t(1.2e8))
     lb = run(False, vb, eb)
     lb.backward()

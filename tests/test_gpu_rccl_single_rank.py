@@ -87,6 +87,7 @@ def _worker(port, queue):
             try:
                 with sharding.particle_sharded(force_collectives=True):
                     staged = seg.track(beam).particles.clone()
+                    staged2 = seg.track(beam).particles.clone()
             finally:
                 dist.all_gather_into_tensor, dist.all_reduce = counting_gather, counting_reduce
             local = _ops.moments(beam.particles, beam.survival_probabilities)
@@ -97,6 +98,8 @@ def _worker(port, queue):
                 "staged_vs_forced_max": float((forced - staged).abs().max()),
                 "staged_vs_forced_rel": float(((forced - staged).abs() / (kick + 1e-30)).max()),
                 "sorted_deposit": n >= _ops.SORTED_CIC_MIN_PARTICLES,
+                "run_to_run_max": float((staged2 - staged).abs().max()),     # atomics anywhere on the path (direct deposit,
+                "run_to_run_rel": float(((staged2 - staged).abs() / (kick + 1e-30)).max()),   # hot tiles of the sorted one)
                 "forced_vs_whole": float(((forced - whole).abs() / (kick + 1e-30)).max()),
             }
         # Screen image summed over the (one) rank: bit-identical to the plain reading
@@ -143,10 +146,11 @@ def test_rccl_exchanges_on_one_rank():
         r = report[name]
         # three kicks: one all-gather (moments) and one all-reduce (grid) each, plus the all-gather of global_moments
         assert r["used"] == {"all_gather": 4, "all_reduce": 3}, (name, r)
-        if r["sorted_deposit"]:
+        if r["run_to_run_max"] == 0.0:
             assert r["staged_vs_forced_max"] == 0.0, (name, r)       # a one-rank exchange is the identity, bit for bit
-        else:   # below 65536 particles the deposit adds with global atomics: the summation order differs from run to run
-            assert r["staged_vs_forced_rel"] < (1e-4 if name.startswith("f32") else 1e-11), (name, r)
+        else:   # the path itself is not bit-reproducible (float atomics: direct deposit below 65536 particles, hot tiles of
+                # the sorted one): the exchanges must add nothing beyond that run-to-run noise
+            assert r["staged_vs_forced_rel"] <= 4 * r["run_to_run_rel"] + (1e-6 if name.startswith("f32") else 1e-13), (name, r)
         assert r["merge_rel"] < 1e-12, (name, r)
         # staged (chx_moments + merge + chx_sc_geometry, separate launches) vs the one-call kick (chx_sc_kick): the same
         # arithmetic up to the rounding of the three sigmas and the summation order of the charge grid
