@@ -176,6 +176,21 @@ SIGNATURES = {
     "chx_sc_kick_workspace_bytes": (c_size_t, [c_i64, c_i64, c_i32_p, c_int]),
     "chx_sc_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64,
                             c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_i64]),
+    "chx_sc_tile_state_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),
+    "chx_sc_kick_sorted_workspace_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),
+    "chx_sc_kick_sorted": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i32_p, c_int,
+                                   c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_sc_beam_geometry_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64,
+                                           c_i64, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
+    "chx_sc_geometry_from_partials": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_double, c_double, c_i32_p, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_sc_tile_sort": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
+    "chx_sc_tile_deposit": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                    c_void_p]),
+    "chx_sc_tile_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64,
+                                        c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "chx_kde_values": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_i64,
                                c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, c_int, c_void_p, c_void_p]),
     "chx_merge_moments": (c_int, [c_void_p, ctypes.c_int32, c_i64, c_void_p, c_void_p]),

@@ -1643,6 +1643,29 @@ def sc_kick(x, q, w, energy, length, grid_extent, mass_eV, B, N, bins, side_stre
     return out
 
 
+def sc_tile_state(N: int, bins, dtype: torch.dtype, device) -> torch.Tensor | None:
+    """State buffer of a chain of tile-ordered kicks (chx_sc_tile_state_bytes), or None when the grid has no tile layout
+    (tile edges beyond 16 cells)."""
+    nbytes = _lib.lib().chx_sc_tile_state_bytes(N, _bins3(bins), dtype_code(dtype))
+    return workspace(nbytes, device) if nbytes else None
+
+
+def sc_kick_sorted(x, q, w, energy, length, grid_extent, mass_eV, N, bins, state, first: bool, last: bool, side_stream=None,
+                   post_map_ptr=None) -> torch.Tensor:
+    """One kick of a chain on the tile-ordered beam (chx_sc_kick_sorted): x (N,7); q, w (N,) only read when `first`;
+    energy, length (1,); grid_extent (1,3). Returns (N,7) in tile order, or in the caller's order when `last`."""
+    lib = _lib.lib()
+    b3 = _bins3(bins)
+    dt = dtype_code(x.dtype)
+    ws_bytes = lib.chx_sc_kick_sorted_workspace_bytes(N, b3, dt)
+    ws = workspace(ws_bytes, x.device)
+    out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
+    check(lib.chx_sc_kick_sorted(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, N, b3, dt, ptr(out),
+                                 ptr(ws), ws_bytes, ptr(state), state.numel(), (1 if first else 0) | (2 if last else 0), stream_ptr(),
+                                 side_stream.cuda_stream if side_stream is not None else None, post_map_ptr), "chx_sc_kick_sorted")
+    return out
+
+
 def sc_gather_kick(x, F, half, cell, energy, dt, mass_eV, B, N, bins) -> torch.Tensor:
     out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
     check(_lib.lib().chx_sc_gather_kick(ptr(x), ptr(F), ptr(half), ptr(cell), ptr(energy), ptr(dt), mass_eV, B,

@@ -600,8 +600,23 @@ class Segment(Element):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
         plan = self._plan()
         i, n_items = 0, len(plan)
+        chain = None    # state buffer of a running chain of tile-ordered SpaceChargeKicks: `incoming` is then in TILE order
         while i < n_items:
             kind, item = plan[i]
+            if kind == "element" and isinstance(item, SpaceChargeKick) and (chain is not None or self._chain_starts(plan, i, incoming)):
+                # [kick, linear run, kick, ...]: the particle rows are sorted by deposit tile once, every kick of the chain works
+                # on the ordered rows (chx_sc_kick_sorted) and the last one restores the caller's particle order
+                first = chain is None
+                if first:
+                    chain = _ops.sc_tile_state(incoming.particles.shape[0], item.grid_shape, incoming.particles.dtype,
+                                               incoming.particles.device)
+                last = self._next_chain_kick(plan, i, item, incoming.particles.dtype) is None
+                incoming, step = self._chain_kick(item, plan[i + 1][1] if i + 1 < n_items and plan[i + 1][0] == "run" else None,
+                                                  incoming, chain, first, last)
+                if last:
+                    chain = None
+                i += step
+                continue
             if kind == "run":
                 fast = self._run_apply_fast(item, incoming)
                 if fast is None:
@@ -622,6 +637,57 @@ class Segment(Element):
                 incoming = item._track_internal(incoming)
             i += 1
         return incoming
+
+    @staticmethod
+    def _next_chain_kick(plan, i: int, kick, dtype):
+        """Index of the SpaceChargeKick that follows plan[i] through at most one run of linear elements and can continue its
+        chain (same grid, chainable settings), else None."""
+        j = i + 1
+        if j < len(plan) and plan[j][0] == "run":
+            j += 1
+        if j < len(plan) and plan[j][0] == "element" and isinstance(plan[j][1], SpaceChargeKick) \
+                and plan[j][1].grid_shape == kick.grid_shape and plan[j][1]._chain_settings_ok(dtype):
+            return j
+        return None
+
+    def _chain_starts(self, plan, i: int, incoming: ParticleBeam) -> bool:
+        kick = plan[i][1]
+        dtype = incoming.particles.dtype
+        return (kick._chain_settings_ok(dtype) and kick._chain_beam_ok(incoming)
+                and self._next_chain_kick(plan, i, kick, dtype) is not None
+                and _lib.lib().chx_sc_tile_state_bytes(incoming.particles.shape[0], _ops._bins3(kick.grid_shape),
+                                                       _ops.dtype_code(dtype)) > 0)
+
+    def _chain_kick(self, kick, run, incoming: ParticleBeam, state, first: bool, last: bool):
+        """One link of a chain: the kick and, when the run behind it has a persistent device plan, that run in the same particle
+        pass. Returns (beam, number of plan items consumed)."""
+        R_addr, s_out, fused = None, None, False
+        if run is not None:
+            p = incoming.particles
+            fr = run.fast
+            if fr is None or fr.dtype != p.dtype or fr.device != p.device:
+                fr = run.fast = _FastRun(run, p.dtype, p.device)
+            elif fr.epoch != Element._epoch:
+                fr.refresh()
+            e, sp = incoming.energy, incoming.species
+            if fr.ok and e.dtype == fr.dtype and e.device == fr.device and not (
+                    torch.is_grad_enabled() and (sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad
+                                                 or _any_requires_grad(*fr.tensors))):
+                addr = ctypes.c_void_p()
+                s_in = incoming.s
+                s_out = self._device_s(fr, s_in)
+                _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
+                                                  sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
+                                                  ctypes.byref(addr), s_in.data_ptr() if s_out is not None else None,
+                                                  s_out.data_ptr() if s_out is not None else None, _ops.stream_ptr()), "chx_run_map")
+                R_addr, fused = addr.value, True
+                if s_out is None:
+                    s_out = self._run_s(run, s_in)
+        out = kick._track_in_chain(incoming, state, first, last, R_addr)
+        beam = ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=s_out if fused else incoming.s,
+                            species=incoming.species)
+        return beam, (2 if fused else 1)
 
     def _kick_then_run(self, kick, run: _Run, incoming: ParticleBeam):
         """One particle pass for a SpaceChargeKick and the run of linear elements behind it (`chx_run_map` refreshes the run's

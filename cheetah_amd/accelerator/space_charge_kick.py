@@ -185,6 +185,43 @@ class SpaceChargeKick(Element):
                            post_map_ptr=post_map_ptr)
         return out.reshape(N, 7)
 
+    def _chain_settings_ok(self, dtype) -> bool:
+        """Can this element be a link of a chain of tile-ordered kicks (`Segment.track`)? Scalar settings without gradients
+        on a grid libchx's pruned solver takes."""
+        if self.effect_length.dim() != 0 or not _ops.sc_pruned_supported(self.grid_shape, dtype):
+            return False
+        return not (torch.is_grad_enabled() and any(t.requires_grad for t in (
+            self.effect_length, self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau)))
+
+    def _chain_beam_ok(self, incoming: ParticleBeam) -> bool:
+        """One plain beam (no vector dims, no gradients, not particle-sharded) that is large enough for the tile sort."""
+        from .. import sharding
+
+        parts = incoming.particles
+        if parts.dim() != 2 or incoming.energy.dim() != 0 or incoming.particle_charges.dim() != 1 \
+                or incoming.survival_probabilities.dim() != 1 or parts.shape[0] < _ops.SORTED_CIC_MIN_PARTICLES:
+            return False
+        if sharding.active_group() is not None:
+            return False
+        return not (torch.is_grad_enabled() and any(t.requires_grad for t in (
+            parts, incoming.particle_charges, incoming.survival_probabilities, incoming.energy)))
+
+    def _track_in_chain(self, incoming: ParticleBeam, state: torch.Tensor, first: bool, last: bool, post_map_ptr=None):
+        """This kick as a link of a chain (`chx_sc_kick_sorted`): the first link sorts the particle rows by deposit tile into
+        `state`, later links work on the ordered rows, the last one returns the rows in the caller's order. Returns the
+        particle tensor (in tile order unless `last`)."""
+        parts = incoming.particles
+        dtype, device = parts.dtype, parts.device
+        N = parts.shape[0]
+        x = _ops.aligned(parts)
+        q = w = None
+        if first:
+            q = incoming.particle_charges.to(dtype).contiguous()
+            w = incoming.survival_probabilities.to(dtype).contiguous()
+        return _ops.sc_kick_sorted(x, q, w, incoming.energy.to(dtype).reshape(1), self.effect_length.to(dtype).reshape(1),
+                                   self._grid_extent(dtype), incoming.species.mass_eV_float, N, self.grid_shape, state, first, last,
+                                   side_stream=self._side_stream(device), post_map_ptr=post_map_ptr)
+
     def _track_particle_sharded(self, incoming, group, x, q, w, energy, L, out_shape, B, N) -> ParticleBeam:
         """The kick for a beam whose particles are spread over the ranks of `group` (sharding.particle_sharded): the same
         stages as `chx_sc_kick`, issued one by one so that the two exchanges fit in between — the beam moments (grid

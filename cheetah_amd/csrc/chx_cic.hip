@@ -1178,3 +1178,419 @@ extern "C" int chx_cic_deposit_sorted_overwrite(const chx_cic_args* p, void* wor
                                                 void* stream) {
     return deposit_sorted(p, workspace, workspace_bytes, stream, true);
 }
+
+// =====================================================================================================================
+// Tile-ordered beam of a chain of SpaceChargeKicks (chx_sc_tiles.h): counting sort of the particle ROWS by deposit tile
+// (first kick of the chain), deposit straight from the ordered rows, and the bookkeeping that lets the gather pass re-order the
+// rows when too many particles have left their tile. The index / weight arithmetic is sort_locate's
+// (cloud_in_cell.py:150-172, 262-311): identical addends to chx_cic_deposit.
+#include "chx_sc_tiles.h"
+
+namespace {
+
+static_assert(kScSortThreads == kSortThreads && kScSortWG == kSortWG, "block_exclusive_scan / scan decomposition are shared");
+
+__device__ __forceinline__ int sc_home_tile(const CicDev& a, const ScTileGeom& g, const int (&pi)[3]) {
+    int t = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int c = pi[d] < 0 ? 0 : (pi[d] > a.bins[d] - 1 ? a.bins[d] - 1 : pi[d]);
+        t = t * g.ntile[d] + (c >> g.tshift[d]);
+    }
+    return t;
+}
+
+// first kick, pass 1: per-workgroup histogram of home tiles (one tile per particle)
+template <typename T>
+__global__ __launch_bounds__(kScSortThreads) void sc_tile_count_kernel(CicDev a, ScTileGeom g, const T* __restrict__ x,
+                                                                      const T* __restrict__ extent, const T* __restrict__ scale,
+                                                                      int* __restrict__ counts) {
+    extern __shared__ int hist[];
+    const int wg = blockIdx.x;
+    const int64_t per = (a.N + kScSortWG - 1) / kScSortWG;
+    const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    for (int t = threadIdx.x; t < g.nt; t += kScSortThreads) hist[t] = 0;
+    __syncthreads();
+    const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += kScSortThreads) {
+        const T raw[3] = {x[n * 7 + a.cols[0]], x[n * 7 + a.cols[1]], x[n * 7 + a.cols[2]]};
+        int pi[3];
+        T pf[3];
+        sort_locate<T, 3>(a, ax, raw, pi, pf);
+        atomicAdd(&hist[sc_home_tile(a, g, pi)], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.nt; t += kScSortThreads) counts[(int64_t)wg * g.nt + t] = hist[t];
+}
+
+// first kick, pass 3 (pass 2 is cic_scan_tiles_kernel): rows, weights, charges and the identity permutation into their tile's
+// slot range
+template <typename T>
+__global__ __launch_bounds__(kScSortThreads) void sc_tile_scatter_kernel(
+    CicDev a, ScTileGeom g, const T* __restrict__ x, const T* __restrict__ q_in, const T* __restrict__ w_in,
+    const T* __restrict__ extent, const T* __restrict__ scale, const int* __restrict__ counts, const int* __restrict__ totals,
+    int* __restrict__ tile_start, T* __restrict__ rows_out, T* __restrict__ ws_out, T* __restrict__ cs_out, int* __restrict__ perm_out) {
+    extern __shared__ int hist[];
+    const int wg = blockIdx.x;
+    const int64_t per = (a.N + kScSortWG - 1) / kScSortWG;
+    const int64_t n0 = (int64_t)wg * per, n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    for (int t = threadIdx.x; t < g.nt; t += kScSortThreads) hist[t] = totals[t];
+    __syncthreads();
+    const int sum = block_exclusive_scan(hist, g.nt);
+    if (wg == 0) {
+        for (int t = threadIdx.x; t < g.nt; t += kScSortThreads) tile_start[t] = hist[t];
+        if (threadIdx.x == 0) tile_start[g.nt] = sum;
+    }
+    for (int t = threadIdx.x; t < g.nt; t += kScSortThreads) hist[t] += counts[(int64_t)wg * g.nt + t];
+    __syncthreads();
+    const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += kScSortThreads) {
+        T row[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) row[j] = x[n * 7 + j];
+        const T raw[3] = {row[a.cols[0]], row[a.cols[1]], row[a.cols[2]]};
+        int pi[3];
+        T pf[3];
+        sort_locate<T, 3>(a, ax, raw, pi, pf);
+        const int pos = atomicAdd(&hist[sc_home_tile(a, g, pi)], 1);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rows_out[(int64_t)pos * 7 + j] = row[j];
+        const T w = w_in ? w_in[n] : (T)1;
+        T c = q_in ? q_in[n] : (T)1;
+        if (w_in) c = c * w;                       // charges = q * survival (space_charge_kick.py:556-563)
+        ws_out[pos] = w;
+        cs_out[pos] = c;
+        perm_out[pos] = (int)n;
+    }
+}
+
+// The crosser list is appended to through a per-workgroup LDS buffer: atomics on ONE global counter cost ~5-8 ns each on
+// MI355X however they are spread over the chip (measured: 4 000 of them added 20 us to the deposit pass), so a workgroup
+// reserves its whole batch with one.
+constexpr int kScCrossBuf = 1024;
+
+// deposit, pass 1: one workgroup per tile over its slot range. LDS block = the tile's cells plus the +1 layer (fp64, ds_add:
+// see cic_accumulate_kernel). Owned cells are STORED (every grid cell belongs to one tile: no zero fill), the +1 layer goes to
+// the tile's face buffer; misfiled particles (and what a tile holds beyond kScTileCap) are listed for pass 3. On the way every
+// particle's CURRENT home tile is recorded (home[], newcount[]): what the gather pass needs to re-order the rows.
+template <typename T>
+__global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
+                                                             const int* __restrict__ tile_start2 /*[2][nt+1]*/,
+                                                             const T* __restrict__ src, const T* __restrict__ cs2 /*[2][N]*/,
+                                                             const T* __restrict__ extent, const T* __restrict__ scale,
+                                                             T* __restrict__ grid, T* __restrict__ faces, int* __restrict__ crossers,
+                                                             uint16_t* __restrict__ home, int* __restrict__ newcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* blk = reinterpret_cast<double*>(smem);
+    __shared__ int nstay;
+    __shared__ int ncr, cr_base;
+    __shared__ int crbuf[kScCrossBuf];
+    const int par = hdr->parity;
+    const int* __restrict__ tile_start = tile_start2 + (int64_t)par * (g.nt + 1);
+    const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
+    const int t = blockIdx.x;
+    const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
+    const int BY = TZ + 1, BX = (TY + 1) * BY, ncell = (TX + 1) * BX;
+    int org[3];
+    {
+        int rem = t;
+        org[2] = (rem % g.ntile[2]) << g.tshift[2]; rem /= g.ntile[2];
+        org[1] = (rem % g.ntile[1]) << g.tshift[1]; rem /= g.ntile[1];
+        org[0] = rem << g.tshift[0];
+    }
+    const int beg = tile_start[t], end = tile_start[t + 1];
+    const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
+    for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
+    if (threadIdx.x == 0) { nstay = 0; ncr = 0; }
+    __syncthreads();
+    const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
+    int stay = 0;
+    for (int r0 = beg; r0 < end; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        bool push = false;
+        if (r < end) {
+            const T raw[3] = {src[(int64_t)r * 7 + a.cols[0]], src[(int64_t)r * 7 + a.cols[1]], src[(int64_t)r * 7 + a.cols[2]]};
+            const T c = cs[r];
+            int pi[3];
+            T pf[3];
+            const bool inside = sort_locate<T, 3>(a, ax, raw, pi, pf);
+            const int h = sc_home_tile(a, g, pi);
+            home[r] = (uint16_t)h;
+            if (h == t) ++stay; else atomicAdd(&newcount[h], 1);
+            const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
+            const bool in_tile = lx >= 0 && lx < TX && ly >= 0 && ly < TY && lz >= 0 && lz < TZ;
+            // misfiled (pass 3 deposits it if it lies inside the extent, and the gather's slow pass finds its potential), or
+            // the overflow of a hot tile
+            push = !in_tile || (inside && r >= lim);
+            if (inside && !push) {                      // outside the extent: no charge (cloud_in_cell.py:289-311)
+                {
+                    const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                            for (int oz = 0; oz < 2; ++oz) {
+                                // pi >= org >= 0; the upper corner may leave the grid at its far end (weight dropped like the
+                                // reference's in-range mask)
+                                if (pi[0] + ox < a.bins[0] && pi[1] + oy < a.bins[1] && pi[2] + oz < a.bins[2])
+                                    unsafeAtomicAdd(&blk[(lx + ox) * BX + (ly + oy) * BY + (lz + oz)],
+                                                    (double)(c * (wx[ox] * wy[oy] * wz[oz])));
+                            }
+                }
+            }
+        }
+        if (push) {
+            const int k = atomicAdd(&ncr, 1);
+            if (k < kScCrossBuf) crbuf[k] = r;
+            else crossers[atomicAdd(&hdr->ncross, 1)] = r;       // beyond the buffer (a hot or thoroughly stale tile)
+        }
+    }
+    if (stay) atomicAdd(&nstay, stay);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (nstay) atomicAdd(&newcount[t], nstay);
+        const int m = ncr < kScCrossBuf ? ncr : kScCrossBuf;
+        cr_base = m ? atomicAdd(&hdr->ncross, m) : 0;
+        ncr = m;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncr; k += 256) crossers[cr_base + k] = crbuf[k];
+    T* __restrict__ fb = faces + (int64_t)t * sc_face_cells(g);
+    const bool occupied = end > beg;                  // an empty slot range leaves no +1 layer: pass 2 skips the tile
+    for (int i = threadIdx.x; i < ncell; i += 256) {
+        const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
+        const T v = (T)blk[i];
+        if (lx < TX && ly < TY && lz < TZ)
+            grid[(int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] + (int64_t)(org[2] + lz) * a.gstride[2]] = v;
+        else if (occupied)
+            fb[sc_face_index(g, lx, ly, lz)] = v;
+    }
+}
+
+// deposit, pass 2: every tile adds what its seven lower neighbours deposited into its low boundary cells (their +1 layers);
+// neighbours with an empty slot range have nothing to give
+template <typename T>
+__global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom g, const ScTileHeader* __restrict__ hdr,
+                                                           const int* __restrict__ tile_start2, const T* __restrict__ faces,
+                                                           T* __restrict__ grid) {
+    const int* __restrict__ tile_start = tile_start2 + (int64_t)hdr->parity * (g.nt + 1);
+    const int t = blockIdx.x;
+    const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
+    int tc[3];
+    {
+        int rem = t;
+        tc[2] = rem % g.ntile[2]; rem /= g.ntile[2];
+        tc[1] = rem % g.ntile[1]; rem /= g.ntile[1];
+        tc[0] = rem;
+    }
+    int nb[8];          // neighbour (dx, dy, dz) = bits of k: tile index, or -1 (outside the grid / empty)
+    bool any = false;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const int nx = tc[0] - (k & 1), ny = tc[1] - ((k >> 1) & 1), nz = tc[2] - ((k >> 2) & 1);
+        int id = -1;
+        if (nx >= 0 && ny >= 0 && nz >= 0) {
+            id = (nx * g.ntile[1] + ny) * g.ntile[2] + nz;
+            if (tile_start[id + 1] <= tile_start[id]) id = -1;
+        }
+        nb[k] = id;
+        any = any || id >= 0;
+    }
+    if (!any) return;
+    const int nf = sc_face_cells(g);
+    auto face = [&](int k, int lx, int ly, int lz) -> T {
+        return nb[k] < 0 ? (T)0 : faces[(int64_t)nb[k] * nf + sc_face_index(g, lx, ly, lz)];
+    };
+    // the low boundary cells only: planes lx = 0, ly = 0 (lx > 0), lz = 0 (lx, ly > 0)
+    const int nX = TY * TZ, nY = (TX - 1) * TZ, nZ = (TX - 1) * (TY - 1);
+    for (int i = threadIdx.x; i < nX + nY + nZ; i += 256) {
+        int lx, ly, lz;
+        if (i < nX) { lx = 0; ly = i / TZ; lz = i % TZ; }
+        else if (i < nX + nY) { const int j = i - nX; lx = 1 + j / TZ; ly = 0; lz = j % TZ; }
+        else { const int j = i - nX - nY; lx = 1 + j / (TY - 1); ly = 1 + j % (TY - 1); lz = 0; }
+        T add = (T)0;
+        if (lx == 0) add += face(1, TX, ly, lz);
+        if (ly == 0) add += face(2, lx, TY, lz);
+        if (lz == 0) add += face(4, lx, ly, TZ);
+        if (lx == 0 && ly == 0) add += face(3, TX, TY, lz);
+        if (lx == 0 && lz == 0) add += face(5, TX, ly, TZ);
+        if (ly == 0 && lz == 0) add += face(6, lx, TY, TZ);
+        if (lx == 0 && ly == 0 && lz == 0) add += face(7, TX, TY, TZ);
+        if (add == (T)0) continue;
+        const int64_t off = (int64_t)((tc[0] << g.tshift[0]) + lx) * a.gstride[0] + (int64_t)((tc[1] << g.tshift[1]) + ly) * a.gstride[1] +
+                            (int64_t)((tc[2] << g.tshift[2]) + lz) * a.gstride[2];
+        grid[off] += add;
+    }
+}
+
+// deposit, pass 3: the listed particles with global float atomics (the arithmetic of cic_deposit_kernel). The last workgroup to
+// finish decides whether the rows are re-ordered by this kick's gather pass (more than 1/16 of the beam misfiled, and a later
+// kick to profit from it) and, if so, turns the new tile populations into the slot cursors and the next tile starts.
+template <typename T>
+__global__ __launch_bounds__(256) void sc_tile_crossers_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
+                                                              const int* __restrict__ crossers, const T* __restrict__ src,
+                                                              const T* __restrict__ cs2, const T* __restrict__ extent,
+                                                              const T* __restrict__ scale, T* __restrict__ grid,
+                                                              int* __restrict__ newcount, int* __restrict__ cursor,
+                                                              int* __restrict__ tile_start2, int allow_reorder) {
+    __shared__ int is_last;
+    __shared__ int part[256];
+    const int par = hdr->parity;
+    const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
+    const int n = hdr->ncross;
+    const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = crossers[i];
+        const T raw[3] = {src[(int64_t)r * 7 + a.cols[0]], src[(int64_t)r * 7 + a.cols[1]], src[(int64_t)r * 7 + a.cols[2]]};
+        const T c = cs[r];
+        int pi[3];
+        T pf[3];
+        if (!sort_locate<T, 3>(a, ax, raw, pi, pf)) continue;
+        const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int oz = 0; oz < 2; ++oz) {
+                    const int ix = pi[0] + ox, iy = pi[1] + oy, iz = pi[2] + oz;
+                    if (ix >= 0 && ix < a.bins[0] && iy >= 0 && iy < a.bins[1] && iz >= 0 && iz < a.bins[2])
+                        unsafeAtomicAdd(grid + (int64_t)ix * a.gstride[0] + (int64_t)iy * a.gstride[1] + (int64_t)iz * a.gstride[2],
+                                        c * (wx[ox] * wy[oy] * wz[oz]));
+                }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(&hdr->ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
+    // exclusive scan of the new tile populations (all deposit workgroups are done: this kernel runs behind them)
+    const int per = (g.nt + 255) / 256;
+    const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
+    int sum = 0;
+    if (reorder)
+        for (int t = lo; t < hi; ++t) sum += newcount[t];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int k = 0; k < (int)threadIdx.x; ++k) run += part[k];
+    int* __restrict__ ts_next = tile_start2 + (int64_t)(par ^ 1) * (g.nt + 1);
+    for (int t = lo; t < hi; ++t) {
+        const int c = newcount[t];
+        if (reorder) {
+            cursor[t] = run;
+            ts_next[t] = run;
+            run += c;
+        }
+        newcount[t] = 0;                            // ready for the next kick
+    }
+    if (threadIdx.x == 255 && reorder) ts_next[g.nt] = run;
+    if (threadIdx.x == 0) {
+        hdr->last_ncross = n;
+        hdr->ticket = 0;
+        if (reorder) {
+            hdr->scatter_now = 1;
+            hdr->n_sorts += 1;
+        }
+    }
+}
+
+int sc_tile_prepare(int64_t N, const int32_t* bins, int dtype, CicDev& a, ScTileGeom& g) {
+    if (N < 1 || N > 0x7fffffffLL / 8 || !bins) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    g = sc_tile_geom(bins);
+    for (int d = 0; d < 3; ++d)
+        if (bins[d] < 8 || (bins[d] & (g.tdim[d] - 1)) || g.tdim[d] != kScTdim) return CHX_ERR_INVALID_ARG;
+    if ((size_t)g.nt * sizeof(int) > 60 * 1024 || g.nt > 65535) return CHX_ERR_INVALID_ARG;
+    a.ndim = 3;
+    a.cols[0] = 0; a.cols[1] = 2; a.cols[2] = 4;
+    for (int d = 0; d < 3; ++d) a.bins[d] = bins[d];
+    a.gstride[0] = (int64_t)bins[1] * bins[2];
+    a.gstride[1] = bins[2];
+    a.gstride[2] = 1;
+    a.gbatch = (int64_t)bins[0] * bins[1] * bins[2];
+    a.B = a.Bx = a.Bq = a.Bs = a.Be = a.Bsc = a.Bsh = 1;
+    a.N = N;
+    a.abs_charge = 0;
+    return CHX_OK;
+}
+
+template <typename T>
+int sc_tile_sort_launch(const CicDev& a, const ScTileGeom& g, const ScTileLayout& L, char* st, const void* x_in, const void* charge,
+                        const void* survival, const void* extent, const void* scale, hipStream_t s) {
+    int* counts = (int*)(st + L.counts);
+    int* totals = (int*)(st + L.totals);
+    const size_t hist_bytes = (size_t)g.nt * sizeof(int);
+    if (hipMemsetAsync(st + L.hdr, 0, L.zero_bytes, s) != hipSuccess) return CHX_ERR_LAUNCH;     // header, newcount
+    hipLaunchKernelGGL(sc_tile_count_kernel<T>, dim3(kScSortWG), dim3(kScSortThreads), hist_bytes, s, a, g, (const T*)x_in,
+                       (const T*)extent, (const T*)scale, counts);
+    CHX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cic_scan_tiles_kernel, dim3((g.nt + kScanTiles - 1) / kScanTiles, 1), dim3(16 * kScanTiles), 0, s, counts, totals,
+                       g.nt);
+    CHX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sc_tile_scatter_kernel<T>, dim3(kScSortWG), dim3(kScSortThreads), hist_bytes, s, a, g, (const T*)x_in,
+                       (const T*)charge, (const T*)survival, (const T*)extent, (const T*)scale, counts, totals,
+                       (int*)(st + L.tile_start[0]), (T*)(st + L.rows_tmp), (T*)(st + L.ws[0]), (T*)(st + L.cs[0]), (int*)(st + L.perm[0]));
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+template <typename T>
+int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLayout& L, char* st, const void* rows, const void* extent,
+                           const void* scale, void* grid, int allow_reorder, hipStream_t s) {
+    ScTileHeader* hdr = (ScTileHeader*)(st + L.hdr);
+    const size_t blk_bytes = (size_t)(g.tdim[0] + 1) * (g.tdim[1] + 1) * (g.tdim[2] + 1) * sizeof(double);
+    hipLaunchKernelGGL(sc_tile_deposit_kernel<T>, dim3((unsigned)g.nt), dim3(256), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
+                       (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)grid, (T*)(st + L.faces),
+                       (int*)(st + L.crossers), (uint16_t*)(st + L.home), (int*)(st + L.newcount));
+    CHX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sc_tile_merge_kernel<T>, dim3((unsigned)g.nt), dim3(256), 0, s, a, g, (const ScTileHeader*)hdr,
+                       (const int*)(st + L.tile_start[0]), (const T*)(st + L.faces), (T*)grid);
+    CHX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sc_tile_crossers_kernel<T>, dim3(128), dim3(256), 0, s, a, g, hdr, (const int*)(st + L.crossers), (const T*)rows,
+                       (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)grid, (int*)(st + L.newcount), (int*)(st + L.cursor),
+                       (int*)(st + L.tile_start[0]), allow_reorder);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t chx_sc_tile_state_bytes(int64_t N, const int32_t* bins, int dtype) {
+    CicDev a;
+    ScTileGeom g;
+    if (sc_tile_prepare(N, bins, dtype, a, g) != CHX_OK) return 0;
+    return sc_tile_layout(N, bins, dtype).total;
+}
+
+extern "C" int chx_sc_tile_sort(const void* x_in, const void* charge, const void* survival, const void* extent, const void* scale,
+                                int64_t N, const int32_t* bins, int dtype, void* state, size_t state_bytes, void* stream) {
+    CicDev a;
+    ScTileGeom g;
+    int st = sc_tile_prepare(N, bins, dtype, a, g);
+    if (st != CHX_OK) return st;
+    if (!x_in || !extent || !state) return CHX_ERR_INVALID_ARG;
+    const ScTileLayout L = sc_tile_layout(N, bins, dtype);
+    if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
+    return dtype == CHX_F32 ? sc_tile_sort_launch<float>(a, g, L, (char*)state, x_in, charge, survival, extent, scale, (hipStream_t)stream)
+                            : sc_tile_sort_launch<double>(a, g, L, (char*)state, x_in, charge, survival, extent, scale, (hipStream_t)stream);
+}
+
+extern "C" int chx_sc_tile_deposit(const void* rows, const void* extent, const void* scale, int64_t N, const int32_t* bins, int dtype,
+                                   void* state, size_t state_bytes, void* grid, int allow_reorder, void* stream) {
+    CicDev a;
+    ScTileGeom g;
+    int st = sc_tile_prepare(N, bins, dtype, a, g);
+    if (st != CHX_OK) return st;
+    if (!extent || !state || !grid) return CHX_ERR_INVALID_ARG;
+    const ScTileLayout L = sc_tile_layout(N, bins, dtype);
+    if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
+    if (!rows) rows = (char*)state + L.rows_tmp;       // the rows the sort of the first kick wrote
+    return dtype == CHX_F32 ? sc_tile_deposit_launch<float>(a, g, L, (char*)state, rows, extent, scale, grid, allow_reorder, (hipStream_t)stream)
+                            : sc_tile_deposit_launch<double>(a, g, L, (char*)state, rows, extent, scale, grid, allow_reorder, (hipStream_t)stream);
+}

@@ -599,7 +599,11 @@ struct SigmaFn {
 
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void sc_sigma_kernel(const T* __restrict__ x, const T* __restrict__ w, int64_t Bx,
-                                                            int64_t Bw, int64_t N, double* __restrict__ partials) {
+                                                            int64_t Bw, int64_t N, double* __restrict__ partials,
+                                                            const int* __restrict__ tile_hdr) {
+    // chain of tile-ordered kicks (chx_sc_tiles.h): `w` is copy 0 of the ordered weights, the copy in force is
+    // header.parity ^ header.scatter_now (the flip itself happens in the geometry kernel behind this one)
+    if (tile_hdr && ((tile_hdr[0] ^ tile_hdr[1]) & 1)) w += N;
     SigmaFn f;
     const T* x0 = x + ((Bx == 1) ? 0 : (int64_t)blockIdx.y) * N * 7;
     f.c[0] = (double)x0[0];
@@ -617,8 +621,17 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
     const double* __restrict__ partials, int nblk, const T* __restrict__ ext, const T* __restrict__ energy,
     const T* __restrict__ length, double mass, double pot_factor, int64_t Bext, int64_t Be, int64_t Bl, int gx, int gy, int gz,
     T* __restrict__ half, T* __restrict__ cell, T* __restrict__ gamma_out, T* __restrict__ dt, T* __restrict__ scale,
-    T* __restrict__ extent, double* __restrict__ pot_scale) {
+    T* __restrict__ extent, double* __restrict__ pot_scale, int* __restrict__ tile_hdr, int tile_first) {
     __shared__ double red[16 * kSG];
+    // chain of tile-ordered kicks (chx_sc_tiles.h): this single-workgroup kernel runs before the deposit / gather kernels of the
+    // kick, so it is where the header rolls over: header = {parity, scatter_now, ncross, ...}
+    if (tile_hdr && !tile_first && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (tile_hdr[1]) {          // the previous kick's gather wrote its rows in a new tile order: its arrays are in force now
+            tile_hdr[0] ^= 1;
+            tile_hdr[1] = 0;
+        }
+        tile_hdr[2] = 0;            // crosser list of the kick that starts here
+    }
     __shared__ double tot[kSG];
     const int64_t b = blockIdx.x;
     const double* pb = partials + b * kSG * (int64_t)nblk;
@@ -827,6 +840,17 @@ extern "C" int chx_sc_beam_geometry(const void* x, const void* w, const void* gr
                                     int64_t Bext, int64_t Be, int64_t Bl, int64_t N, const int32_t* bins, int dtype, void* half,
                                     void* cell, void* gamma, void* dt, void* scale, void* extent, double* pot_scale,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return chx_sc_beam_geometry_tiles(x, w, grid_extent, energy, length, mass_eV, pot_factor, B, Bx, Bw, Bext, Be, Bl, N, bins,
+                                      dtype, half, cell, gamma, dt, scale, extent, pot_scale, workspace, workspace_bytes, nullptr,
+                                      0, stream);
+}
+
+extern "C" int chx_sc_beam_geometry_tiles(const void* x, const void* w, const void* grid_extent, const void* energy,
+                                          const void* length, double mass_eV, double pot_factor, int64_t B, int64_t Bx,
+                                          int64_t Bw, int64_t Bext, int64_t Be, int64_t Bl, int64_t N, const int32_t* bins,
+                                          int dtype, void* half, void* cell, void* gamma, void* dt, void* scale, void* extent,
+                                          double* pot_scale, void* workspace, size_t workspace_bytes, void* tile_header,
+                                          int tile_first, void* stream) {
     if (!grid_extent || !energy || !length || !half || !cell || !gamma || !dt || !scale || !extent || !pot_scale || !bins)
         return CHX_ERR_INVALID_ARG;
     int st = check_red(x, B, Bx, w ? Bw : 1, N, dtype);
@@ -839,21 +863,48 @@ extern "C" int chx_sc_beam_geometry(const void* x, const void* w, const void* gr
     double* part = (double*)workspace;
     const dim3 grid((unsigned)nblk, (unsigned)B);
     if (dtype == CHX_F32) {
-        hipLaunchKernelGGL(sc_sigma_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x, (const float*)w, Bx, Bw, N, part);
+        hipLaunchKernelGGL(sc_sigma_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x, (const float*)w, Bx, Bw, N, part,
+                           tile_first ? (const int*)nullptr : (const int*)tile_header);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(sc_geometry_partials_kernel<float>, dim3((unsigned)B), dim3(CHX_BLOCK), 0, s, part, (int)nblk,
                            (const float*)grid_extent, (const float*)energy, (const float*)length, mass_eV, pot_factor, Bext, Be,
                            Bl, bins[0], bins[1], bins[2], (float*)half, (float*)cell, (float*)gamma, (float*)dt, (float*)scale,
-                           (float*)extent, pot_scale);
+                           (float*)extent, pot_scale, (int*)tile_header, tile_first);
     } else {
         hipLaunchKernelGGL(sc_sigma_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x, (const double*)w, Bx, Bw, N,
-                           part);
+                           part, tile_first ? (const int*)nullptr : (const int*)tile_header);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(sc_geometry_partials_kernel<double>, dim3((unsigned)B), dim3(CHX_BLOCK), 0, s, part, (int)nblk,
                            (const double*)grid_extent, (const double*)energy, (const double*)length, mass_eV, pot_factor, Bext,
                            Be, Bl, bins[0], bins[1], bins[2], (double*)half, (double*)cell, (double*)gamma, (double*)dt,
-                           (double*)scale, (double*)extent, pot_scale);
+                           (double*)scale, (double*)extent, pot_scale, (int*)tile_header, tile_first);
     }
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+// the geometry kernel alone, from partial sums some other kernel left behind (the gather pass of the previous kick of a chain
+// accumulates them over the rows it writes: chx_sc_tile_gather_kick) — layout partials[kSG][nblk]
+extern "C" int chx_sc_geometry_from_partials(const double* partials, int64_t nblk, const void* grid_extent, const void* energy,
+                                             const void* length, double mass_eV, double pot_factor, const int32_t* bins, int dtype,
+                                             void* half, void* cell, void* gamma, void* dt, void* scale, void* extent,
+                                             double* pot_scale, void* tile_header, void* stream) {
+    if (!partials || nblk < 1 || nblk > 0x7fffffff || !grid_extent || !energy || !length || !half || !cell || !gamma || !dt || !scale ||
+        !extent || !pot_scale || !bins)
+        return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(sc_geometry_partials_kernel<float>, dim3(1), dim3(CHX_BLOCK), 0, s, partials, (int)nblk,
+                           (const float*)grid_extent, (const float*)energy, (const float*)length, mass_eV, pot_factor, 1, 1, 1, bins[0],
+                           bins[1], bins[2], (float*)half, (float*)cell, (float*)gamma, (float*)dt, (float*)scale, (float*)extent,
+                           pot_scale, (int*)tile_header, 0);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(sc_geometry_partials_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s, partials, (int)nblk,
+                           (const double*)grid_extent, (const double*)energy, (const double*)length, mass_eV, pot_factor, 1, 1, 1,
+                           bins[0], bins[1], bins[2], (double*)half, (double*)cell, (double*)gamma, (double*)dt, (double*)scale,
+                           (double*)extent, pot_scale, (int*)tile_header, 0);
+    else
+        return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

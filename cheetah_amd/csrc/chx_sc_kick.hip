@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "chx.h"
+#include "chx_sc_tiles.h"
 
 namespace {
 
@@ -145,4 +146,90 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     if (st != CHX_OK) return st;
     return chx_sc_gather_kick_phi(x_in, phi, half, cell, gamma, energy, dt, mass_eV, B, Bx, B, N, bins, dtype, post_map, BR,
                                   x_out, main);
+}
+
+// ---- a kick of a CHAIN of kicks on the tile-ordered beam (chx_sc_tiles.h) -------------------------------------------------
+// flags bit 0 (CHX_SC_FIRST): x_in is in the caller's particle order, charge / survival are the caller's arrays; the kick sorts
+//   the rows by deposit tile into `state` and leaves x_out in tile order. Without it x_in must be the x_out (possibly tracked
+//   through linear maps) of the previous kick of the same chain with the same `state`.
+// flags bit 1 (CHX_SC_LAST): x_out is written in the caller's particle order (the stored permutation is undone).
+extern "C" size_t chx_sc_kick_sorted_workspace_bytes(int64_t N, const int32_t* bins, int dtype) {
+    return chx_sc_kick_workspace_bytes(1, N, bins, dtype);
+}
+
+extern "C" int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                                  const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins, int dtype, void* x_out,
+                                  void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags, void* stream,
+                                  void* side_stream, const void* post_map) {
+    if (!x_in || !energy || !length || !grid_extent || !x_out || !workspace || !state) return CHX_ERR_INVALID_ARG;
+    if (N < 1 || !bins || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
+    const bool first = flags & 1, last = flags & 2;
+    if (first && (!charge || !survival)) return CHX_ERR_INVALID_ARG;
+    const size_t need_state = chx_sc_tile_state_bytes(N, bins, dtype);
+    if (need_state == 0) return CHX_ERR_INVALID_ARG;
+    if (state_bytes < need_state) return CHX_ERR_WORKSPACE;
+    const Layout L = layout(1, N, bins, dtype);
+    if (workspace_bytes < L.total) return CHX_ERR_WORKSPACE;
+    const ScTileLayout T = sc_tile_layout(N, bins, dtype);
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    char* ws = (char*)workspace;
+    char* st = (char*)state;
+    hipStream_t main = (hipStream_t)stream;
+    hipStream_t side = side_stream ? (hipStream_t)side_stream : main;
+
+    char* geo = ws + L.geo;
+    void* half = geo;
+    void* cell = geo + (size_t)3 * esz;
+    void* gamma = geo + (size_t)6 * esz;
+    void* dt = geo + (size_t)7 * esz;
+    void* scale = geo + (size_t)8 * esz;
+    void* extent = geo + (size_t)11 * esz;
+    double* pot_scale = (double*)(ws + L.pot);
+    void* rho = ws + L.rho;
+    void* ghat = ws + L.ghat;
+    void* phi = ws + L.phi;
+
+    const double n_padded = 8.0 * bins[0] * bins[1] * bins[2];
+    const double pot_factor = 1.0 / (4.0 * M_PI * kEpsilon0) / n_padded;
+    // beam sizes -> grid geometry. First kick: the two launches of chx_sc_beam_geometry on the caller's arrays. Later kicks: the
+    // gather pass of the previous kick left the partial sums of the rows it wrote (= this kick's x_in) in the state: one launch.
+    int rc;
+    if (first)
+        rc = chx_sc_beam_geometry_tiles(x_in, survival, grid_extent, energy, length, mass_eV, pot_factor, 1, 1, 1, 1, 1, 1, N, bins,
+                                        dtype, half, cell, gamma, dt, scale, extent, pot_scale, ws + L.mom_ws, L.mom - L.mom_ws,
+                                        st + T.hdr, 1, main);
+    else
+        rc = chx_sc_geometry_from_partials((const double*)(st + T.sigma), T.sigma_blocks, grid_extent, energy, length, mass_eV,
+                                           pot_factor, bins, dtype, half, cell, gamma, dt, scale, extent, pot_scale, st + T.hdr, main);
+    if (rc != CHX_OK) return rc;
+
+    hipEvent_t fork = nullptr, join = nullptr;
+    const bool forked = side != main;
+    if (forked) {
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess)
+            return CHX_ERR_LAUNCH;
+        (void)hipEventRecord(fork, main);
+        (void)hipStreamWaitEvent(side, fork, 0);
+    }
+    rc = chx_sc_green_spectrum_fast(cell, gamma, 1, bins, dtype, ghat, ws + L.green_ws, L.ghat - L.green_ws, side);
+    if (forked) (void)hipEventRecord(join, side);
+
+    // first kick of the chain: order the rows by deposit tile (into the state's row buffer); every kick: deposit from the ordered
+    // rows (the crosser pass decides on the device whether this kick's gather re-orders them for the kicks that follow)
+    const void* rows = first ? nullptr : x_in;             // nullptr = the state's row buffer
+    if (rc == CHX_OK && first) rc = chx_sc_tile_sort(x_in, charge, survival, extent, scale, N, bins, dtype, state, state_bytes, main);
+    if (rc == CHX_OK) rc = chx_sc_tile_deposit(rows, extent, scale, N, bins, dtype, state, state_bytes, rho, last ? 0 : 1, main);
+    if (rc == CHX_OK)
+        rc = chx_sc_convolve_halo_after(rho, ghat, pot_scale, 1, bins, dtype, phi, ws + L.conv_ws, L.phi - L.conv_ws, main,
+                                        forked ? (void*)join : nullptr);
+    else if (forked)
+        (void)hipStreamWaitEvent(main, join, 0);
+    if (forked) {
+        (void)hipEventDestroy(fork);
+        (void)hipEventDestroy(join);
+    }
+    if (rc != CHX_OK) return rc;
+    return chx_sc_tile_gather_kick(rows, phi, half, cell, gamma, energy, dt, mass_eV, N, bins, dtype, post_map, state, state_bytes,
+                                   last ? 1 : 0, x_out, main);
 }

@@ -1,0 +1,118 @@
+// chx_sc_tiles.h — the tile-ordered beam of a chain of SpaceChargeKicks (chx_sc_kick_sorted; space_charge_kick.py:477-586).
+//
+// Inside one Segment.track the particles barely move against the space-charge grid between two kicks (the grid follows the
+// beam: its extent is a multiple of the beam sigmas), so the counting sort by 8^3 deposit tile that a kick needs is done ONCE:
+// the first kick of a chain writes the particle rows in tile order and every later kick works on them in place —
+//   * deposit: one workgroup per tile accumulates its own slot range in an LDS block of (tile + 1)^3 cells (no records, no
+//     duplication of particles over neighbouring tiles), stores the cells it owns and hands the +1 layer to its neighbours
+//     through a small per-tile face buffer (merged by a second, tiny kernel);
+//   * gather: the per-particle kernel of the untiled path on the ordered rows — the lanes of a wave sit in one tile, so the 12
+//     line requests per particle for the 32 potential values around its cell hit the CU's vector cache (63 -> 33 us at 1e6
+//     particles on 128^3); it also accumulates the beam sizes the next kick's grid needs over the rows it writes;
+//   * a particle that has left the tile of its slot ("crosser", ~1 % per kick) is still handled exactly — global float atomics
+//     for its eight corners (the gather reads the potential from global memory anyway); when more than 1/16 of the beam is misfiled the gather pass of
+//     that very kick writes its rows in the new tile order (the deposit pass counted the new tile populations on the way): a
+//     device-side decision, no host synchronisation and no extra launch.
+// The permutation back to the caller's particle order is carried along and applied by the last kick of the chain.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "chx.h"
+
+// device-resident control block at the start of the state buffer
+struct ScTileHeader {
+    int parity;        // which copy of tile_start / perm / ws / cs is current
+    int scatter_now;   // this kick's gather writes its rows in a NEW tile order (decided by the crosser pass of the same kick);
+                       // the geometry kernel of the next kick then flips `parity` and clears the flag
+    int ncross;        // crosser list length of the running kick (reset by the geometry kernel of the next one)
+    int ticket;        // workgroups of the crosser pass that are done
+    int last_ncross;   // diagnostics: crosser count of the last finished deposit ...
+    int n_sorts;       // ... and how many times the chain (re)ordered its rows so far
+    int pad[2];
+};
+
+constexpr int kScSortWG = 256;       // workgroups of the count / scatter passes
+constexpr int kScSortThreads = 1024;
+constexpr int kScTileCap = 8192;     // particles of one tile deposited through LDS by its workgroup; the rest take the slow way
+constexpr int kScChunk = 256;        // slots per workgroup of the gather pass (four waves of 64 rows, each on its own)
+constexpr int kScTdim = 8;           // the tile edge the kernels are written for (grids whose tile rule gives larger tiles — more
+                                     // than 8192 tiles of 8^3 — keep the untiled path)
+
+struct ScTileGeom {
+    int tdim[3];    // tile edge in cells (a power of two)
+    int tshift[3];  // log2(tdim)
+    int ntile[3];
+    int nt;
+};
+
+// same rule as the generic sorted deposit (chx_cic.hip tile_geom, 3-D): 8^3 tiles, edges doubled until nt <= 8192
+static __host__ __device__ inline ScTileGeom sc_tile_geom(const int* bins) {
+    ScTileGeom g;
+    for (int d = 0; d < 3; ++d) g.tdim[d] = 8;
+    for (;;) {
+        g.nt = 1;
+        int widest = 0;
+        for (int d = 0; d < 3; ++d) {
+            g.ntile[d] = (bins[d] + g.tdim[d] - 1) / g.tdim[d];
+            g.nt *= g.ntile[d];
+            if (g.ntile[d] > g.ntile[widest]) widest = d;
+        }
+        if (g.nt <= 8192 || g.tdim[widest] >= 64) break;
+        g.tdim[widest] *= 2;
+    }
+    for (int d = 0; d < 3; ++d) {
+        g.tshift[d] = 0;
+        while ((1 << g.tshift[d]) < g.tdim[d]) ++g.tshift[d];
+    }
+    return g;
+}
+
+// cells of the +1 layer of a tile's LDS block: faces X (lx = TX), Y (ly = TY, lx < TX), Z (lz = TZ, lx < TX, ly < TY)
+static __host__ __device__ inline int sc_face_cells(const ScTileGeom& g) {
+    return (g.tdim[1] + 1) * (g.tdim[2] + 1) + g.tdim[0] * (g.tdim[2] + 1) + g.tdim[0] * g.tdim[1];
+}
+static __host__ __device__ inline int sc_face_index(const ScTileGeom& g, int lx, int ly, int lz) {
+    const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
+    if (lx == TX) return ly * (TZ + 1) + lz;
+    if (ly == TY) return (TY + 1) * (TZ + 1) + lx * (TZ + 1) + lz;
+    return (TY + 1) * (TZ + 1) + TX * (TZ + 1) + lx * TY + ly;   // lz == TZ
+}
+
+// byte offsets of the pieces of the state buffer (B = 1); [2] = one copy per parity
+struct ScTileLayout {
+    size_t hdr, newcount, cursor, tile_start[2], counts, totals, perm[2], ws[2], cs[2], home, rows_tmp, faces, crossers, sigma, total;
+    int64_t sigma_blocks;   // workgroups of the gather pass = partial sums per moment handed to the next kick's geometry kernel
+    size_t zero_bytes;   // header + newcount: cleared by the first kick of a chain
+};
+
+static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dtype) {
+    const ScTileGeom g = sc_tile_geom(bins);
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    ScTileLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    L.hdr = take(sizeof(ScTileHeader));
+    L.newcount = take((size_t)g.nt * sizeof(int));
+    L.zero_bytes = off;
+    L.cursor = take((size_t)g.nt * sizeof(int));
+    // the two copies of a double-buffered array are contiguous: copy p starts p * (element count) elements behind copy 0
+    L.tile_start[0] = take((size_t)2 * (g.nt + 1) * sizeof(int));
+    L.tile_start[1] = L.tile_start[0] + (size_t)(g.nt + 1) * sizeof(int);
+    L.counts = take((size_t)kScSortWG * g.nt * sizeof(int));
+    L.totals = take((size_t)g.nt * sizeof(int));
+    L.perm[0] = take((size_t)2 * N * sizeof(int));
+    L.perm[1] = L.perm[0] + (size_t)N * sizeof(int);
+    L.ws[0] = take((size_t)2 * N * esz);
+    L.ws[1] = L.ws[0] + (size_t)N * esz;
+    L.cs[0] = take((size_t)2 * N * esz);
+    L.cs[1] = L.cs[0] + (size_t)N * esz;
+    L.home = take((size_t)N * sizeof(uint16_t));
+    L.rows_tmp = take((size_t)N * 7 * esz);
+    L.faces = take((size_t)g.nt * sc_face_cells(g) * esz);
+    L.crossers = take((size_t)N * sizeof(int));
+    L.sigma_blocks = (N + 255) / 256;
+    L.sigma = take((size_t)8 * L.sigma_blocks * sizeof(double));
+    L.total = off;
+    return L;
+}

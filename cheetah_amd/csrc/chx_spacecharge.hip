@@ -21,6 +21,7 @@
 
 #include "chx_common.h"
 #include "chx_sc_math.h"
+#include "chx_sc_tiles.h"
 
 namespace {
 
@@ -587,6 +588,274 @@ extern "C" int chx_sc_gather_kick_phi(const void* x_in, const void* phi_halo, co
     if (post_map && !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
     return launch_particle<0, true>(x_in, phi_halo, half, cell, energy, dt, mass_eV, B, Bx, Be, N, bins, dtype, x_out, stream,
                                     post_map, post_map ? BR : 1, gamma);
+}
+
+// ---- gather + kick on the tile-ordered beam of a chain of kicks (chx_sc_tiles.h) ----------------------------------------
+// The arithmetic per particle IS sc_particle_kernel's (MODE 0, FROM_PHI): same values from the same nodes, bit-identical
+// result. What the tile order buys is locality: the lanes of a wave sit in one 8^3 tile, so the 12 line requests per particle for
+// the 32 potential values around its cell hit the CU's vector cache instead of the L2 — measured at 1e6 particles on 128^3
+// (benchmarks/tile_gather_bench.py): 63.1 us on rows in the caller's order, 33.1 us on the same rows in tile order. (Staging
+// each tile's 12^3 potential block in LDS explicitly was slower in every variant tried: 134 us with one block per workgroup
+// and a barrier per tile segment, 179-195 us with one block per wave — the binary search for the tile, the staging and the
+// spills of the fp64 particle step under a 128-VGPR cap cost more than the cache already gives for free.)
+// Destination of a row: its own slot; the caller's particle index (perm) for the last kick of a chain; or, when the deposit of
+// this kick found the order stale (header.scatter_now), a slot of the particle's CURRENT home tile taken from the cursors the
+// crosser pass prepared — the rows, weights, charges and the permutation then move to the other copy of the state arrays.
+namespace {
+
+template <typename T>
+struct alignas(4 * sizeof(T)) PhiNode { T x, y, z, pad; };
+
+// force components at the eight nodes (ci + a, cj + c2, ck + e) of a cell from the potential around it; q points at node
+// (ci, cj, ck), py / pz are the x / y strides of the array q lives in (global halo array or LDS block)
+template <typename T>
+__device__ __forceinline__ void phi_cell_forces(const T* q, int py, int pz, int ci, int cj, int ck, const int (&g)[3], T hx, T hy,
+                                                T hz, T nig2, PhiNode<T> (&node)[8]) {
+    Run<T, 4> zr[2][2];
+    Run<T, 2> xr[2][2], yr[2][2];          // [outer side: 0 = -1, 1 = +2][the other in-cell index]
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            zr[a][c2] = *reinterpret_cast<const Run<T, 4>*>(q + a * py + c2 * pz - 1);
+            xr[a][c2] = *reinterpret_cast<const Run<T, 2>*>(q + (a ? 2 : -1) * py + c2 * pz);
+            yr[a][c2] = *reinterpret_cast<const Run<T, 2>*>(q + c2 * py + (a ? 2 : -1) * pz);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int a = k >> 2, c2 = (k >> 1) & 1, e = k & 1;    // node (ci + a, cj + c2, ck + e)
+        const int I = ci + a, J = cj + c2, K = ck + e;
+        const T xlo = a ? zr[0][c2].v[1 + e] : xr[0][c2].v[e];
+        const T xhi = a ? xr[1][c2].v[e] : zr[1][c2].v[1 + e];
+        const T ylo = c2 ? zr[a][0].v[1 + e] : yr[0][a].v[e];
+        const T yhi = c2 ? yr[1][a].v[e] : zr[a][1].v[1 + e];
+        const T zlo = zr[a][c2].v[e], zhi = zr[a][c2].v[e + 2];
+        node[k].x = node_force(xlo, xhi, hx, nig2, I > 0 && I < g[0] - 1);
+        node[k].y = node_force(ylo, yhi, hy, nig2, J > 0 && J < g[1] - 1);
+        node[k].z = node_force(zlo, zhi, hz, nig2, K > 0 && K < g[2] - 1);
+    }
+}
+
+template <typename T>
+struct ScKickCtx {
+    RefFrame<double> rf;
+    T nig2, hx, hy, hz;
+    double halfd[3], celld[3], dtb;
+    int g[3];
+    const T* post_map;
+};
+
+template <typename T>
+__device__ __forceinline__ ScKickCtx<T> sc_kick_ctx(const T* half, const T* cell, const T* energy, const T* dt, const T* gamma,
+                                                    double mass_eV, int gx, int gy, int gz, const T* post_map) {
+    ScKickCtx<T> c;
+    c.rf = ref_frame<double>((double)energy[0], mass_eV);
+    const T gm = gamma[0];
+    c.nig2 = -((gm != (T)0) ? (T)1 / (gm * gm) : (T)0);
+    c.hx = (T)0.5 * ((T)1 / cell[0]);
+    c.hy = (T)0.5 * ((T)1 / cell[1]);
+    c.hz = (T)0.5 * ((T)1 / cell[2]);
+    for (int d = 0; d < 3; ++d) { c.halfd[d] = (double)half[d]; c.celld[d] = (double)cell[d]; }
+    c.dtb = (double)dt[0];
+    c.g[0] = gx; c.g[1] = gy; c.g[2] = gz;
+    c.post_map = post_map;
+    return c;
+}
+
+// SI coordinates, cell position and the clamped base node of a row
+template <typename T>
+__device__ __forceinline__ void sc_kick_locate(const ScKickCtx<T>& c, const double (&v)[7], double (&s)[7], double (&u)[3],
+                                               int (&i0)[3], int (&cn)[3]) {
+    to_si(c.rf, v, s);
+    const double posd[3] = {s[0], s[2], s[4]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        u[d] = (posd[d] + c.halfd[d]) / c.celld[d];
+        double fl = floor(u[d]);
+        fl = fl > 2.0e9 ? 2.0e9 : (fl < -2.0e9 ? -2.0e9 : fl);
+        i0[d] = (int)fl;
+        cn[d] = min(max(i0[d], -1), c.g[d] - 1);
+    }
+}
+
+// interpolation, kick, back to Cheetah coordinates, optional linear map; out in T
+template <typename T>
+__device__ __forceinline__ void sc_kick_finish(const ScKickCtx<T>& c, double (&s)[7], const double (&u)[3], const int (&i0)[3],
+                                               PhiNode<T> (&node)[8], T (&out)[7]) {
+    double w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int ix = i0[0] + (k >> 2), iy = i0[1] + ((k >> 1) & 1), iz = i0[2] + (k & 1);
+        const bool valid = ix >= 0 && ix < c.g[0] && iy >= 0 && iy < c.g[1] && iz >= 0 && iz < c.g[2];
+        if (!valid) node[k].x = node[k].y = node[k].z = (T)0;   // built from halo values, which are undefined
+        w[k] = valid ? (1.0 - fabs(u[0] - ix)) * (1.0 - fabs(u[1] - iy)) * (1.0 - fabs(u[2] - iz)) * kElementaryCharge : 0.0;
+    }
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        fx += w[k] * (double)node[k].x;
+        fy += w[k] * (double)node[k].y;
+        fz += w[k] * (double)node[k].z;
+    }
+    if (!(isfinite(u[0]) && isfinite(u[1]) && isfinite(u[2]))) fx = fy = fz = __builtin_nan("");
+    s[1] += fx * c.dtb;
+    s[3] += fy * c.dtb;
+    s[5] += fz * c.dtb;
+    double v[7];
+    from_si(c.rf, s, v);
+    if (c.post_map) {
+        T xk[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xk[j] = (T)v[j];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            T acc = c.post_map[i * 7] * xk[0];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) acc = fma(c.post_map[i * 7 + j], xk[j], acc);
+            out[i] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) out[j] = (T)v[j];
+    }
+}
+
+// where a finished row goes (see the header of this section); `active` lanes have a row. Wave-uniform control flow.
+template <typename T>
+__device__ __forceinline__ int64_t sc_row_dest(bool active, int64_t r, int mode /*0 slot, 1 perm, 2 scatter*/, int par, int64_t N,
+                                               const int* perm2, const uint16_t* __restrict__ home, int* __restrict__ cursor,
+                                               T* ws2, T* cs2, int* perm2w) {
+    if (mode == 0) return r;
+    if (mode == 1) return active ? (int64_t)perm2[(int64_t)par * N + r] : 0;
+    // scatter: lanes of the wave that go to the same tile share one atomic on its cursor
+    const int lane = threadIdx.x & 63;
+    const int h = active ? (int)home[r] : -1;
+    int64_t dst = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int h0 = __shfl(h, leader, 64);
+        const unsigned long long same = __ballot(active && h == h0) & todo;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[h0], __popcll(same));
+        base = __shfl(base, leader, 64);
+        if ((same >> lane) & 1ull) dst = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (active) {
+        const int64_t from = (int64_t)par * N + r, to = (int64_t)(par ^ 1) * N + dst;
+        perm2w[to] = perm2[from];
+        ws2[to] = ws2[from];
+        cs2[to] = cs2[from];
+    }
+    return dst;
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
+    const T* __restrict__ src, const ScTileHeader* __restrict__ hdr, int* perm2, T* ws2, T* cs2, const uint16_t* __restrict__ home,
+    int* __restrict__ cursor, const T* __restrict__ phi, const T* __restrict__ half, const T* __restrict__ cell,
+    const T* __restrict__ energy, const T* __restrict__ dt, const T* __restrict__ gamma, double mass_eV, int64_t N, int gx, int gy,
+    int gz, T* __restrict__ x_out, const T* __restrict__ post_map, int unpermute, double* __restrict__ sigma_partials) {
+    __shared__ __attribute__((aligned(16))) T lds[CHX_BLOCK * 7];
+    __shared__ double red[4 * 8];
+    const int par = hdr->parity;
+    const int mode = hdr->scatter_now ? 2 : (unpermute ? 1 : 0);
+    const int64_t n0 = (int64_t)blockIdx.x * CHX_BLOCK;
+    const int np = (int)((N - n0 < CHX_BLOCK) ? (N - n0) : CHX_BLOCK);
+    // staged per wave like sc_particle_kernel: no workgroup barrier
+    const int wrow = (threadIdx.x >> 6) * 64;
+    const int wvalid = (np - wrow < 0) ? 0 : ((np - wrow < 64) ? (np - wrow) : 64);
+    const bool vin = chx_aligned16(src), vout = chx_aligned16(x_out);
+    wave_tile_load<T>(src + (n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vin, true);
+    chx_wave_sync();
+    const ScKickCtx<T> ctx = sc_kick_ctx<T>(half, cell, energy, dt, gamma, mass_eV, gx, gy, gz, post_map);
+    const int pz = gz + 4, py = (gy + 4) * pz;            // halo of 2: every index below is in bounds
+    const int p = threadIdx.x;
+    const bool active = p < np;
+    T out[7];
+    if (active) {
+        double v[7], s[7], u[3];
+        int i0[3], cn[3];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[j] = (double)lds[p * 7 + j];
+        sc_kick_locate<T>(ctx, v, s, u, i0, cn);
+        PhiNode<T> node[8];
+        phi_cell_forces<T>(phi + ((int64_t)(cn[0] + 2) * py + (cn[1] + 2) * pz + (cn[2] + 2)), py, pz, cn[0], cn[1], cn[2], ctx.g, ctx.hx,
+                           ctx.hy, ctx.hz, ctx.nig2, node);
+        sc_kick_finish<T>(ctx, s, u, i0, node, out);
+    }
+    if (sigma_partials) {
+        // the rows written here are the beam the NEXT kick of the chain sees: its three variances (space_charge_kick.py:531-538)
+        // are accumulated on the way — the sums of sc_sigma_kernel about the origin instead of about the first particle
+        double a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = 0.0;
+        if (active) {
+            const double w = (double)ws2[(int64_t)par * N + n0 + p];
+            const double d0 = (double)out[0], d1 = (double)out[2], d2 = (double)out[4];
+            a[0] = w;
+            a[1] = w * w;
+            const double w0 = w * d0, w1 = w * d1, w2 = w * d2;
+            a[2] = w0; a[3] = w1; a[4] = w2;
+            a[5] = w0 * d0; a[6] = w1 * d1; a[7] = w2 * d2;
+        }
+        chx_block_sum<8>(a, red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sigma_partials[(int64_t)k * gridDim.x + blockIdx.x] = a[k];
+        }
+    }
+    if (mode == 0) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = out[j];
+        }
+        chx_wave_sync();
+        wave_tile_store<T>(x_out + (n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vout, true);
+    } else {
+        const int64_t dst = sc_row_dest<T>(active, n0 + p, mode, par, N, perm2, home, cursor, ws2, cs2, perm2);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) x_out[dst * 7 + j] = out[j];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
+                                       const void* energy, const void* dt, double mass_eV, int64_t N, const int32_t* bins, int dtype,
+                                       const void* post_map, void* state, size_t state_bytes, int unpermute, void* x_out,
+                                       void* stream) {
+    if (!phi_halo || !half || !cell || !gamma || !energy || !dt || !state || !x_out || !bins_ok(bins) || N < 1)
+        return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    const ScTileGeom tg = sc_tile_geom(bins);
+    for (int d = 0; d < 3; ++d)
+        if (tg.tdim[d] != kScTdim || (bins[d] & (tg.tdim[d] - 1))) return CHX_ERR_INVALID_ARG;
+    const ScTileLayout L = sc_tile_layout(N, bins, dtype);
+    if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
+    char* st = (char*)state;
+    if (!rows) rows = st + L.rows_tmp;                    // the rows the sort of the first kick wrote
+    const unsigned nwg = (unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    const ScTileHeader* hdr = (const ScTileHeader*)(st + L.hdr);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(sc_tile_particle_kernel<float>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const float*)rows, hdr, (int*)(st + L.perm[0]),
+                           (float*)(st + L.ws[0]), (float*)(st + L.cs[0]), (const uint16_t*)(st + L.home), (int*)(st + L.cursor),
+                           (const float*)phi_halo, (const float*)half, (const float*)cell, (const float*)energy, (const float*)dt,
+                           (const float*)gamma, mass_eV, N, bins[0], bins[1], bins[2], (float*)x_out, (const float*)post_map, unpermute,
+                           unpermute ? nullptr : (double*)(st + L.sigma));
+    else
+        hipLaunchKernelGGL(sc_tile_particle_kernel<double>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const double*)rows, hdr,
+                           (int*)(st + L.perm[0]), (double*)(st + L.ws[0]), (double*)(st + L.cs[0]), (const uint16_t*)(st + L.home),
+                           (int*)(st + L.cursor), (const double*)phi_halo, (const double*)half, (const double*)cell,
+                           (const double*)energy, (const double*)dt, (const double*)gamma, mass_eV, N, bins[0], bins[1], bins[2],
+                           (double*)x_out, (const double*)post_map, unpermute, unpermute ? nullptr : (double*)(st + L.sigma));
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
 }
 
 extern "C" int chx_to_xyz_pxpypz(const void* x_in, const void* energy, double mass_eV, int64_t B,

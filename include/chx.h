@@ -447,6 +447,49 @@ int chx_sc_kick(const void* x_in, const void* charge, const void* survival, cons
                 const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
                 const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
                 void* side_stream, const void* post_map /*[BR][7][7] or NULL*/, int64_t BR);
+/* A CHAIN of kicks inside one Segment.track on a tile-ordered beam (csrc/chx_sc_tiles.h; space_charge_kick.py:477-586 per kick):
+ * between two kicks the particles barely move against the grid (its extent follows the beam sigmas), so the counting sort by
+ * 8^3 deposit tile is done by the FIRST kick only; every kick then deposits straight from the ordered rows (LDS block per tile,
+ * +1 layer handed to the neighbours through per-tile face buffers) and gathers with the potential block of each tile staged in
+ * LDS; particles that left the tile of their slot are handled exactly on a slow path (float atomics / global loads), and when more
+ * than 1/16 of the beam is misfiled the gather of that kick writes its rows in the new tile order (device-side decision, no host
+ * synchronisation, no extra launch). B = 1 (one beam), grids as chx_sc_kick.
+ *  - state: chx_sc_tile_state_bytes() bytes that live as long as the chain (header, tile starts, permutation, ordered
+ *    weights / charges, row buffer, face buffers, crosser list); workspace: per-kick scratch, chx_sc_kick_sorted_workspace_bytes();
+ *  - flags: CHX_SC_FIRST (1) x_in, charge, survival are the caller's arrays in the caller's order — sort; otherwise x_in is the
+ *    x_out of the previous kick of the chain (possibly mapped through linear elements) and charge / survival are ignored;
+ *    CHX_SC_LAST (2) x_out is written in the caller's particle order (else in tile order);
+ *  - post_map (may be NULL): the linear run behind the kick, applied in the same particle pass (as chx_sc_kick).
+ * The pieces are entry points of their own: chx_sc_beam_geometry_tiles (= chx_sc_beam_geometry + the header update),
+ * chx_sc_tile_sort, chx_sc_tile_deposit (rho[gx][gy][gz], every cell stored: no zero fill), chx_sc_tile_gather_kick. */
+#define CHX_SC_FIRST 1
+#define CHX_SC_LAST 2
+size_t chx_sc_tile_state_bytes(int64_t N, const int32_t* bins, int dtype);
+size_t chx_sc_kick_sorted_workspace_bytes(int64_t N, const int32_t* bins, int dtype);
+int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                       const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins, int dtype, void* x_out,
+                       void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags, void* stream,
+                       void* side_stream, const void* post_map);
+int chx_sc_beam_geometry_tiles(const void* x, const void* w, const void* grid_extent, const void* energy, const void* length,
+                               double mass_eV, double pot_factor, int64_t B, int64_t Bx, int64_t Bw, int64_t Bext, int64_t Be,
+                               int64_t Bl, int64_t N, const int32_t* bins, int dtype, void* half, void* cell, void* gamma, void* dt,
+                               void* scale, void* extent, double* pot_scale, void* workspace, size_t workspace_bytes,
+                               void* tile_header, int tile_first, void* stream);
+/* the geometry kernel of chx_sc_beam_geometry alone, from partial sums partials[8][nblk] (double) that chx_sc_tile_gather_kick
+ * accumulated over the rows it wrote (B = 1) */
+int chx_sc_geometry_from_partials(const double* partials, int64_t nblk, const void* grid_extent, const void* energy,
+                                  const void* length, double mass_eV, double pot_factor, const int32_t* bins, int dtype, void* half,
+                                  void* cell, void* gamma, void* dt, void* scale, void* extent, double* pot_scale, void* tile_header,
+                                  void* stream);
+int chx_sc_tile_sort(const void* x_in, const void* charge, const void* survival, const void* extent, const void* scale, int64_t N,
+                     const int32_t* bins, int dtype, void* state, size_t state_bytes, void* stream);
+/* rows: the tile-ordered rows (NULL = the state's own row buffer, which chx_sc_tile_sort filled); allow_reorder: may the crosser
+ * pass order a re-sort by this kick's gather (0 for the last kick of a chain, which restores the caller's order instead). */
+int chx_sc_tile_deposit(const void* rows, const void* extent, const void* scale, int64_t N, const int32_t* bins, int dtype,
+                        void* state, size_t state_bytes, void* grid, int allow_reorder, void* stream);
+int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
+                            const void* energy, const void* dt, double mass_eV, int64_t N, const int32_t* bins, int dtype,
+                            const void* post_map, void* state, size_t state_bytes, int unpermute, void* x_out, void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),

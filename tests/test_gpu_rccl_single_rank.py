@@ -102,7 +102,7 @@ def _worker(port, queue):
                 "run_to_run_rel": float(((staged2 - staged).abs() / (kick + 1e-30)).max()),   # hot tiles of the sorted one)
                 "forced_vs_whole": float(((forced - whole).abs() / (kick + 1e-30)).max()),
             }
-        # Screen image summed over the (one) rank: bit-identical to the plain reading
+        # Screen image summed over the (one) rank: the plain reading
         kw = {"dtype": torch.float32, "device": "cuda"}
         beam = _beam(ca, torch.float32, 150_000)
         screen = ca.Screen(resolution=(64, 48), pixel_size=torch.tensor([6e-5, 8e-5], **kw), is_active=True, **kw)
@@ -112,7 +112,8 @@ def _worker(port, queue):
         with sharding.particle_sharded(force_collectives=True):
             screen.track(beam)
             summed = screen.reading.clone()
-        report["screen"] = {"equal": bool(torch.equal(plain, summed)), "all_reduce": calls["all_reduce"] - before}
+        # (the image itself is an LDS-atomic sum: its last bit can differ between two runs of the same deposit)
+        report["screen"] = {"equal": bool(torch.allclose(plain, summed, rtol=1e-5, atol=0)), "all_reduce": calls["all_reduce"] - before}
         # batch shard of a vectorised scan (no collective): the union of the per-"rank" slices equals the whole scan
         k1 = torch.linspace(-30, 30, 64, **kw)
         t = lambda v: torch.tensor(v, **kw)  # noqa: E731
