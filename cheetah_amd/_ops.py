@@ -857,6 +857,9 @@ def _moments_raw(x, w, B, N):
 
 
 class Moments(torch.autograd.Function):
+    """out = chx_moments(x, w); backward = chx_moments_bwd_w: gradients of the particles AND of the weights (the reference's
+    weighted statistics are differentiable in both, utils/statistics.py:4-62) in one pass."""
+
     @staticmethod
     def forward(ctx, x, w, B):
         out = _moments_raw(x, w, B, x.shape[1])
@@ -868,14 +871,17 @@ class Moments(torch.autograd.Function):
     def backward(ctx, d_out):
         x, w, out = ctx.saved_tensors
         B, N = ctx.B, x.shape[1]
+        need_x, need_w = ctx.needs_input_grad[0], w is not None and ctx.needs_input_grad[1]
         d_out = d_out.contiguous().to(torch.float64)
-        dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
-        check(_lib.lib().chx_moments_bwd(ptr(x), ptr(w), ptr(out), ptr(d_out), B, x.shape[0],
-                                         1 if w is None else w.shape[0], N, dtype_code(x.dtype), ptr(dX),
-                                         stream_ptr()), "chx_moments_bwd")
-        if x.shape[0] == 1 and B > 1:
+        dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_x else None
+        dW = torch.empty((B, N), dtype=x.dtype, device=x.device) if need_w else None
+        check(_lib.lib().chx_moments_bwd_w(ptr(x), ptr(w), ptr(out), ptr(d_out), B, x.shape[0], 1 if w is None else w.shape[0], N,
+                                           dtype_code(x.dtype), ptr(dX), ptr(dW), stream_ptr()), "chx_moments_bwd_w")
+        if need_x and x.shape[0] == 1 and B > 1:
             dX = dX.sum(dim=0, keepdim=True)
-        return dX, None, None
+        if need_w and w.shape[0] == 1 and B > 1:
+            dW = dW.sum(dim=0, keepdim=True)
+        return dX, dW, None
 
 
 def _memo_moments(owner: torch.Tensor, x: torch.Tensor, w, survival, B: int) -> torch.Tensor:
@@ -1001,29 +1007,11 @@ def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Ten
         # a moment of a linearly tracked beam whose particles carry no graph: the gradient reaches the map through
         # mu' = A mu + b, cov' = A C A^T (MomentsMapped) — no particle-sized backward pass
         out = MomentsMapped.apply(lin.R, x.detach(), w, (lin, survival), B)
-    elif w is not None and w.requires_grad and torch.is_grad_enabled():
-        # survival weights that carry a graph (an Aperture with differentiable edges upstream): chx_moments_bwd has no dW,
-        # so this rare case is written as device tensor expressions (statistics.py:4-48) — differentiable in x AND w
-        out = _moments_weight_grad(x, w, B)
-    elif x.requires_grad:
+    elif torch.is_grad_enabled() and (x.requires_grad or (w is not None and w.requires_grad)):
         out = Moments.apply(x, w, B)
     else:
         out = _moments_raw(x, w, B, N)
     return out.reshape(*batch_shape, MOM_NOUT)
-
-
-def _moments_weight_grad(x: torch.Tensor, w: torch.Tensor, B: int) -> torch.Tensor:
-    """[W, W2, mu(6), cov upper triangle (21)] in float64 as tensor expressions (particle_beam.py:1699-1717,
-    utils/statistics.py:4-48); only used when the survival probabilities require grad."""
-    xd = x.to(torch.float64).expand(B, -1, 7)[..., :6]
-    wd = w.to(torch.float64).expand(B, -1)
-    W = wd.sum(dim=-1)
-    W2 = (wd * wd).sum(dim=-1)
-    mu = (wd.unsqueeze(-1) * xd).sum(dim=-2) / W.unsqueeze(-1)
-    c = xd - mu.unsqueeze(-2)
-    cov = torch.einsum("bn,bni,bnj->bij", wd, c, c) / (W - W2 / W).reshape(B, 1, 1)
-    iu = torch.triu_indices(6, 6, device=x.device)
-    return torch.cat([W.unsqueeze(-1), W2.unsqueeze(-1), mu, cov[:, iu[0], iu[1]]], dim=-1)
 
 
 def aperture_mask(particles: torch.Tensor, survival: torch.Tensor, x_max: torch.Tensor, y_max: torch.Tensor,

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_bwd_kernel(const T* __restr
                                                                const double* __restrict__ out,
                                                                const double* __restrict__ d_out,
                                                                int64_t Bx, int64_t Bw, int64_t N,
-                                                               T* __restrict__ dX) {
+                                                               T* __restrict__ dX, T* __restrict__ dWt) {
     constexpr int PPT = red_cfg<T>::PPT;
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
@@ -228,10 +228,16 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_bwd_kernel(const T* __restr
                 else { G[i][j] = v; G[j][i] = v; }
             }
     }
+    // weights: with S = sum_{a<=b} g_ab cov_ab and k = 1 + W2 / W^2,
+    //   dW[n] = g_W + 2 w_n g_W2 + (g_mu . d_n) / W + (1/cf) ( d_n^T Gsym d_n / 2 - S (k - 2 w_n / W) )
+    // (dM_ab / dw_n = d_na d_nb: the shift of the mean drops out because sum_m w_m d_m = 0; d cf / d w_n = k - 2 w_n / W)
+    double S = 0.0;
+    for (int k = 0; k < 21; ++k) S += g[8 + k] * o[8 + k];
+    const double kcf = 1.0 + W2 / (W * W);
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
     const bool vin = chx_aligned16(x) && (((xrow * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
-    const bool vout = chx_aligned16(dX) && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
+    const bool vout = dX && chx_aligned16(dX) && (((b * N * 7 * (int64_t)sizeof(T)) & 15) == 0);
     tile_load<T, TP>(x + (xrow * N + n0) * 7, lds, np * 7, vin);
     __syncthreads();
 #pragma unroll
@@ -242,18 +248,22 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_bwd_kernel(const T* __restr
 #pragma unroll
             for (int j = 0; j < 6; ++j) d[j] = (double)lds[p * 7 + j] - o[2 + j];
             const double wv = w ? (double)w[wrow * N + n0 + p] : 1.0;
+            double quad = 0.0, lin = 0.0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 double s = 0.0;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) s += G[a][c] * d[c];
+                quad += d[a] * s;
+                lin += g[2 + a] * d[a];
                 lds[p * 7 + a] = (T)(wv * (g[2 + a] / W + icf * s));
             }
             lds[p * 7 + 6] = (T)0;
+            if (dWt) dWt[b * N + n0 + p] = (T)(g[0] + 2.0 * wv * g[1] + lin / W + icf * (0.5 * quad - S * (kcf - 2.0 * wv / W)));
         }
     }
     __syncthreads();
-    tile_store<T, TP>(dX + (b * N + n0) * 7, lds, np * 7, vout);
+    if (dX) tile_store<T, TP>(dX + (b * N + n0) * 7, lds, np * 7, vout);
 }
 
 // dR[i][j] = sum_n dY[n][i] X[n][j]   (49 fp64 accumulators per lane)
@@ -1000,18 +1010,24 @@ extern "C" int chx_track_moments(const void* x_in, const void* w, const void* R,
 extern "C" int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,
                                int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX,
                                void* stream) {
+    if (!dX) return CHX_ERR_INVALID_ARG;
+    return chx_moments_bwd_w(x, w, out, d_out, B, Bx, Bw, N, dtype, dX, nullptr, stream);
+}
+
+extern "C" int chx_moments_bwd_w(const void* x, const void* w, const double* out, const double* d_out, int64_t B, int64_t Bx,
+                                 int64_t Bw, int64_t N, int dtype, void* dX, void* dW, void* stream) {
     int st = check_red(x, B, Bx, Bw, N, dtype);
     if (st != CHX_OK) return st;
-    if (!out || !d_out || !dX) return CHX_ERR_INVALID_ARG;
+    if (!out || !d_out || (!dX && !dW)) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int tr = tile_rows(dtype);
     dim3 grid((unsigned)((N + tr - 1) / tr), (unsigned)B);
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(moments_bwd_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x,
-                           (const float*)w, out, d_out, Bx, Bw, N, (float*)dX);
+                           (const float*)w, out, d_out, Bx, Bw, N, (float*)dX, (float*)dW);
     else
         hipLaunchKernelGGL(moments_bwd_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
-                           (const double*)w, out, d_out, Bx, Bw, N, (double*)dX);
+                           (const double*)w, out, d_out, Bx, Bw, N, (double*)dX, (double*)dW);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

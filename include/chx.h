@@ -215,6 +215,11 @@ int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, double* out,
 /* backward of chx_moments wrt x: given d_out[B][29] (double; entries 0,1 ignored) */
 int chx_moments_bwd(const void* x, const void* w, const double* out, const double* d_out,
                     int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX, void* stream);
+/* The same with the gradient of the WEIGHTS as well (utils/statistics.py:4-62 is differentiable in the survival
+ * probabilities: an Aperture with trainable edges upstream): dW[B][N] (dtype; the caller sums the rows of a broadcast weight
+ * array), dX and dW may each be NULL. d_out entries 0 (W) and 1 (sum w^2) are honoured here. */
+int chx_moments_bwd_w(const void* x, const void* w, const double* out, const double* d_out, int64_t B, int64_t Bx, int64_t Bw,
+                      int64_t N, int dtype, void* dX, void* dW, void* stream);
 /* Backward of chx_moments(y), y_n = R x_n, with respect to the MAP R[BR][7][7] (dtype) when the particles x carry no
  * gradient: mu' = A mu + b, cov' = A C A^T (element.py:180-191 + utils/statistics.py:4-62), so
  * dR[B][7][7] (double) = [2 G A C + g_mu mu^T | g_mu; 0] from d_out[B][29] and the INCOMING beam's chx_moments
