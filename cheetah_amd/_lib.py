@@ -72,6 +72,8 @@ SIGNATURES = {
     "chx_build_rmatrix": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_build_rmatrix_vjp": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_compose_maps": (c_int, [c_vpp, c_u8_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "chx_compose_maps_vjp_workspace_bytes": (c_size_t, [c_i64, c_i64]),
+    "chx_compose_maps_vjp": (c_int, [c_vpp, c_u8_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_compose_prefix": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_run_state_bytes": (c_size_t, [c_i64]),
     "chx_run_map": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,

@@ -390,28 +390,68 @@ def build_compose_scalars(elements, energy: torch.Tensor, mass_eV: float, n_char
     return RunMapScalars.apply((kinds, slots, mass_eV, n_charges), energy, *tensors)
 
 
+COMPOSE_VJP_MAX = 192  # kComposeChunk: element maps per chx_compose_maps_vjp call
+
+
+def _compose_raw(flat, bcast, B, dtype, device):
+    E = len(flat)
+    bc = (ctypes.c_uint8 * E)(*bcast)
+    ptrs = (ctypes.c_void_p * E)(*[f.data_ptr() for f in flat])
+    out = torch.empty((B, 7, 7), dtype=dtype, device=device)
+    check(_lib.lib().chx_compose_maps(ptrs, bc, E, B, dtype_code(dtype), ptr(out), stream_ptr()), "chx_compose_maps")
+    return out
+
+
+class ComposeMaps(torch.autograd.Function):
+    """R = M_E ... M_1 per batch row (chx_compose_maps); backward = chx_compose_maps_vjp (one wave per row, fp64 prefix /
+    suffix sweep) — one autograd node for the whole product instead of a matmul node per element."""
+
+    @staticmethod
+    def forward(ctx, B, *flat):
+        bcast = [1 if f.shape[0] == 1 else 0 for f in flat]
+        ctx.save_for_backward(*flat)
+        ctx.meta = (B, bcast)
+        return _compose_raw(flat, bcast, B, flat[0].dtype, flat[0].device)
+
+    @staticmethod
+    def backward(ctx, dT):
+        flat = ctx.saved_tensors
+        B, bcast = ctx.meta
+        E = len(flat)
+        dtype, device = flat[0].dtype, flat[0].device
+        lib = _lib.lib()
+        dT = dT.to(dtype).contiguous()
+        ws_bytes = lib.chx_compose_maps_vjp_workspace_bytes(E, B)
+        ws = workspace(ws_bytes, device)
+        dM = torch.empty((E, B, 7, 7), dtype=dtype, device=device)
+        check(lib.chx_compose_maps_vjp((ctypes.c_void_p * E)(*[f.data_ptr() for f in flat]), (ctypes.c_uint8 * E)(*bcast), E, B,
+                                       dtype_code(dtype), ptr(dT), ptr(dM), ptr(ws), ws_bytes, stream_ptr()), "chx_compose_maps_vjp")
+        grads = []
+        for e, f in enumerate(flat):
+            if not ctx.needs_input_grad[1 + e]:
+                grads.append(None)
+            elif bcast[e] and B > 1:
+                grads.append(dM[e].sum(dim=0, keepdim=True))
+            else:
+                grads.append(dM[e])
+        return (None, *grads)
+
+
 def compose_maps(maps: list[torch.Tensor], batch_shape, dtype, device) -> torch.Tensor:
     """maps: per-element (…,7,7) tensors -> composed (*batch_shape,7,7) = R_E … R_1 (segment.py:534-543)."""
     B = numel(batch_shape)
-    if any(m.requires_grad for m in maps):
-        # gradient path: a handful of 7x7 products, let autograd see them
-        tm = torch.eye(7, dtype=dtype, device=device)
-        for m in maps:
-            tm = m.to(dtype) @ tm
-        return tm.expand(*batch_shape, 7, 7)
-    E = len(maps)
     flat = []
-    bc = (ctypes.c_uint8 * E)()
-    ptrs = (ctypes.c_void_p * E)()
-    for e, m in enumerate(maps):
+    for m in maps:
         f, Bm = flat_bcast(m if m.dtype == dtype else m.to(dtype), batch_shape, 2)
-        f = f.contiguous()
-        flat.append(f)  # keep alive until the launch is enqueued
-        bc[e] = 1 if Bm == 1 else 0
-        ptrs[e] = f.data_ptr()
-    out = torch.empty((B, 7, 7), dtype=dtype, device=device)
-    check(_lib.lib().chx_compose_maps(ptrs, bc, E, B, dtype_code(dtype), ptr(out), stream_ptr()),
-          "chx_compose_maps")
+        flat.append(f.contiguous())
+    if torch.is_grad_enabled() and any(f.requires_grad for f in flat):
+        # longer products are folded in chunks of 192 maps (the kernel's by-value pointer table), each chunk one node
+        out = None
+        for lo in range(0, len(flat), COMPOSE_VJP_MAX - 1):
+            chunk = flat[lo:lo + COMPOSE_VJP_MAX - 1]
+            out = ComposeMaps.apply(B, *(chunk if out is None else [out] + chunk))
+        return out.reshape(*batch_shape, 7, 7)
+    out = _compose_raw(flat, [1 if f.shape[0] == 1 else 0 for f in flat], B, dtype, device)
     return out.reshape(*batch_shape, 7, 7)
 
 

@@ -1151,6 +1151,56 @@ __global__ __launch_bounds__(64) void compose_scalars_bwd_kernel(const T* __rest
     }
 }
 
+// The same sweep for VECTORISED maps (chx_compose_maps with gradients: segment.py:534-543 under autograd): one wave per batch
+// row, element maps through the by-value pointer table of compose_kernel, dM[e][b] = G_e P_e^T in T. ws: [B][E][49] doubles.
+template <typename T>
+__global__ __launch_bounds__(64) void compose_vjp_kernel(ComposeArgs args, int E, const T* __restrict__ dT, double* __restrict__ ws,
+                                                         T* __restrict__ dM /*[E][B][49]*/) {
+    __shared__ double P[49], R[49], G[49];
+    const int64_t b = blockIdx.x, B = gridDim.x;
+    const int lane = threadIdx.x, i = lane / 7, j = lane - 7 * i;
+    const bool on = lane < 49;
+    double* wb = ws + b * (int64_t)E * 49;
+    auto map_of = [&](int e) { return (const T*)args.ptr[e] + (args.bcast[e] ? 0 : b * 49); };
+    if (on) P[lane] = (i == j) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+        if (on) {
+            wb[e * 49 + lane] = P[lane];
+            R[lane] = (double)map_of(e)[lane];
+        }
+        __syncthreads();
+        double acc = 0.0;
+        if (on) {
+            acc = R[i * 7] * P[j];
+            for (int k = 1; k < 7; ++k) acc = fma(R[i * 7 + k], P[k * 7 + j], acc);
+        }
+        __syncthreads();
+        if (on) P[lane] = acc;
+        __syncthreads();
+    }
+    if (on) G[lane] = (double)dT[b * 49 + lane];
+    __syncthreads();
+    for (int e = E - 1; e >= 0; --e) {
+        if (on) {
+            P[lane] = wb[e * 49 + lane];
+            R[lane] = (double)map_of(e)[lane];
+        }
+        __syncthreads();
+        double dr = 0.0, gn = 0.0;
+        if (on) {
+            for (int k = 0; k < 7; ++k) {
+                dr = fma(G[i * 7 + k], P[j * 7 + k], dr);
+                gn = fma(R[k * 7 + i], G[k * 7 + j], gn);
+            }
+            dM[((int64_t)e * B + b) * 49 + lane] = (T)dr;
+        }
+        __syncthreads();
+        if (on) G[lane] = gn;
+        __syncthreads();
+    }
+}
+
 // one thread per (element, slot k): slots 0 .. P-1 are the element's parameters, slot CHX_MAX_PARAMS the energy, the rest
 // are written as zeros. out[e][CHX_MAX_PARAMS + 1]
 template <typename T>
@@ -1412,6 +1462,32 @@ extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs
     int st = chx_run_map(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, state, state_bytes, &R, s_in, s_out, stream);
     if (st != CHX_OK) return st;
     return chx_apply_affine7(x_in, R, x_out, 1, 1, 1, N, dtype, stream);
+}
+
+extern "C" size_t chx_compose_maps_vjp_workspace_bytes(int64_t E, int64_t B) {
+    return (E < 1 || B < 1) ? 0 : (size_t)E * B * 49 * sizeof(double);
+}
+
+extern "C" int chx_compose_maps_vjp(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B, int dtype, const void* dT,
+                                    void* dM, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!R_ptrs || !bcast || !dT || !dM || E < 1 || E > kComposeChunk || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!workspace || workspace_bytes < chx_compose_maps_vjp_workspace_bytes(E, B)) return CHX_ERR_WORKSPACE;
+    ComposeArgs a;
+    for (int e = 0; e < kComposeChunk; ++e) {
+        a.ptr[e] = e < E ? R_ptrs[e] : nullptr;
+        a.bcast[e] = e < E ? bcast[e] : 1;
+        if (e < E && !a.ptr[e]) return CHX_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(compose_vjp_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, a, (int)E, (const float*)dT, (double*)workspace,
+                           (float*)dM);
+    else
+        hipLaunchKernelGGL(compose_vjp_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, a, (int)E, (const double*)dT,
+                           (double*)workspace, (double*)dM);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
 }
 
 extern "C" int chx_compose_maps(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B,

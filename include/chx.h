@@ -145,6 +145,12 @@ int chx_run_track(const int32_t* kinds, const void* const* param_ptrs, int64_t E
  * rounded once to dtype. */
 int chx_compose_maps(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B,
                      int dtype, void* R_out, void* stream);
+/* Backward of chx_compose_maps (autograd through segment.py:534-543 for vectorised maps): given dT[B][7][7] = dL/d(composed map)
+ * writes dM[E][B][7][7] = dL/d(element map e of batch row b) (dtype; the caller sums the rows of a broadcast map). One wave per
+ * batch row, fp64 prefix / suffix sweep. E <= 192; workspace chx_compose_maps_vjp_workspace_bytes(E, B). */
+size_t chx_compose_maps_vjp_workspace_bytes(int64_t E, int64_t B);
+int chx_compose_maps_vjp(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B, int dtype, const void* dT, void* dM,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- linear apply (a1; element.py:180-191): x_out[b][n][:] = R[b] . x_in[b][n][:]. */
 int chx_apply_affine7(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx,
