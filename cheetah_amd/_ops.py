@@ -675,8 +675,8 @@ def cavity_track(x, R, coeffs, B, N):
 # non-linear tracking (drift_kick_drift, second_order)
 DKD_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "tdc": 3}
 DKD_NUM_PARAMS = [1, 5, 9, 7]
-T_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "sextupole": 3}
-T_NUM_PARAMS = [1, 5, 9, 5]
+T_KIND = {"drift": 0, "quadrupole": 1, "dipole": 2, "sextupole": 3, "general": 4}
+T_NUM_PARAMS = [1, 5, 9, 5, 4]
 FRINGE_AT = {"neither": 0, "entrance": 1, "exit": 2, "both": 3}
 
 

@@ -560,9 +560,9 @@ __device__ S ttensor_H(S u, S C, S Sn) {
 }
 
 #define TT(i, j, k) T[((i) * 7 + (j)) * 7 + (k)]
-// T must be zero-filled by the caller. Every jc/js/jd/jf term below carries a factor k2, and the reference's
-// elements only combine k2 != 0 with k1 = hx = 0 (Sextupole), where the divided differences sit at their
-// a == b == 0 limits; elsewhere they are multiplied by zero, so the plain difference quotients suffice.
+// T must be zero-filled by the caller. Every jc/js/jd/jf term below carries a factor k2; the reference's own elements only
+// combine k2 != 0 with k1 = hx = 0 (Sextupole), custom elements written against track_methods.base_ttensor may combine
+// all three (CHX_T_GENERAL).
 template <typename S>
 __device__ void base_ttensor(S L, S k1, S k2, S hx, S energy, double mass, S* T) {
     S g, ig2, beta;
@@ -577,17 +577,32 @@ __device__ void base_ttensor(S L, S k1, S k2, S hx, S energy, double mass, S* T)
     const S sx = Sx * L, sy = Sy * L;
     const S dx = L2 * Gx;                 // 0.5 L^2 sinc^2(kx L / 2), no hx factor here (track_methods.py:120)
     const S fx = L3 * Fx;                 // si1mdiv
-    const S f2y = L3 * 4.0 * F4;          // sicos1mdiv(v) = (1 - S(v) C(v)) / v = 4 F(4v)
+    // sicos1mdiv(v) = (1 - S(v) C(v)) / v = 4 F(4v). At exactly v == 0 the reference substitutes 1/6 (utils/autograd.py
+    // `SiCos1MDiv.forward`: `.where(x != 0, 1.0 / 6.0)`) although the limit is 2/3; parity means taking what it takes. The
+    // value only reaches a tensor entry through jf when k1 == 0 exactly while k2 != 0 and hx != 0 (CHX_T_GENERAL).
+    const S f2y = (val(b) != 0.0) ? L3 * 4.0 * F4 : L3 * (1.0 / 6.0);
     const S j1 = fx;
     const S j2 = L3 * ttensor_E<S>(a, cx, Sx);
     const S L7 = L3 * L3 * L;
     const S j3 = (val(kx2) != 0.0) ? L7 * ttensor_H<S>(a, cx, Sx) / 6.0 : L7 / 56.0;
     const S jden = kx2 - 4.0 * ky2;
     const bool same = val(a) == val(b), bzero = val(b) == 0.0;
-    const S jc = L2 * (!same ? (cy - cx) / (a - b) : 0.5 * Sx);
-    const S js = L3 * (!same ? (Sx - Sy) / (b - a) : (!bzero ? 0.5 * (Sy - cy) / b : cst<S>(1.0 / 6.0)));
-    const S jd =
-        L2 * L2 * (!same ? (Sy * Sy - Sx * Sx) / (a - b) : (!bzero ? (1.0 - cy * cy - b * Sy * cy) / (b * b) : cst<S>(1.0 / 3.0)));
+    // The divided differences (utils/autograd.py `cossqrtmcosdivdiff`, `simsidivdiff`, `si2msi2divdiff`). On the diagonal
+    // a == b the reference substitutes the limit and gives BOTH arguments the same partial derivative (its backward passes,
+    // autograd.py:395-405, 452-470, 560-585): the value below is that limit, and its tangent is limit' * (da + db) — a
+    // one-variable expression in `a` alone would have the wrong tangent whenever da != db (general k1, k2, hx).
+    const double vb = val(b), vcy = val(cy), vSy = val(Sy);
+    const S dab = (a + b) - (val(a) + val(b));      // value 0, tangent da + db
+    const S jc = L2 * (!same ? (cy - cx) / (a - b)
+                              : 0.5 * val(Sx) + dab * (!bzero ? (vcy - vSy) / (8.0 * vb) : -1.0 / 24.0));
+    const S js = L3 * (!same ? (Sx - Sy) / (b - a)
+                              : (!bzero ? 0.5 * (vSy - vcy) / vb : 1.0 / 6.0) +
+                                    dab * (!bzero ? (3.0 * vcy + (vb - 3.0) * vSy) / (8.0 * vb * vb) : -1.0 / 120.0));
+    const S jd = L2 * L2 *
+                 (!same ? (Sy * Sy - Sx * Sx) / (a - b)
+                        : (!bzero ? (1.0 - vcy * vcy - vb * vSy * vcy) / (vb * vb) : 1.0 / 3.0) +
+                              dab * (!bzero ? (5.0 * vb * vSy * vcy - (vb - 2.0) * (2.0 * vcy * vcy - 1.0) - 2.0) / (4.0 * vb * vb * vb)
+                                            : -2.0 / 45.0));
     const S jf = (val(jden) != 0.0) ? (f2y - fx) / jden : L2 * L3 / 120.0;
     const S khk = k2 + 2.0 * hx * k1;
     const S b2 = beta * beta, b3 = b2 * beta, hx2 = hx * hx, hx3 = hx2 * hx, dx2 = dx * dx;
@@ -694,6 +709,9 @@ __device__ void ttensor_fill(int kind, const S* p, S en, double mass, S* Ts, S* 
     } else if (kind == CHX_T_SEXTUPOLE) {
         base_ttensor<S>(p[0], zero, p[1], zero, en, mass, Ts);
         drift_map<S>(p[0], en, mass, R);
+    } else if (kind == CHX_T_GENERAL) {  // [L, k1, k2, hx]: the bare tensor of track_methods.base_ttensor, no first-order block
+        base_ttensor<S>(p[0], p[1], p[2], p[3], en, mass, Ts);
+        return;
     } else {  // CHX_T_DIPOLE: [L, angle, k1, e1, e2, tilt, fint, fint_exit, gap]
         const S hx = p[1] / p[0];
         base_ttensor<S>(p[0], p[2], zero, hx, en, mass, Ts);
@@ -751,7 +769,7 @@ __global__ __launch_bounds__(kTBlock) void ttensor_kernel(int kind, const T* __r
         for (int k = 0; k < P; ++k) p[k] = (double)params[(Bp == 1 ? 0 : b) * P + k];
         ttensor_fill<double>(kind, p, (double)energy[Be == 1 ? 0 : b], mass, Ts, X1, E1, X2, E2);
     }
-    if (kind != CHX_T_DRIFT) ttensor_contract<double>(Ts, As, X1, E1);
+    if (kind != CHX_T_DRIFT && kind != CHX_T_GENERAL) ttensor_contract<double>(Ts, As, X1, E1);
     if (kind == CHX_T_DIPOLE) ttensor_contract<double>(Ts, As, X2, E2);
     __syncthreads();
     if (id < 343) T_out[b * 343 + id] = (T)Ts[id];
@@ -777,7 +795,7 @@ __global__ __launch_bounds__(kTBlock) void ttensor_vjp_kernel(int kind, const T*
         const Dual en = mk((double)energy[Be == 1 ? 0 : b], k == P ? 1.0 : 0.0);
         ttensor_fill<Dual>(kind, p, en, mass, Ts, X1, E1, X2, E2);
     }
-    if (kind != CHX_T_DRIFT) ttensor_contract<Dual>(Ts, As, X1, E1);
+    if (kind != CHX_T_DRIFT && kind != CHX_T_GENERAL) ttensor_contract<Dual>(Ts, As, X1, E1);
     if (kind == CHX_T_DIPOLE) ttensor_contract<Dual>(Ts, As, X2, E2);
     __syncthreads();
     double acc = (id < 343) ? (double)dT[b * 343 + id] * Ts[id].d : 0.0;
@@ -892,6 +910,7 @@ extern "C" int chx_t_num_params(int kind) {
         case CHX_T_QUADRUPOLE: return 5;
         case CHX_T_DIPOLE: return 9;
         case CHX_T_SEXTUPOLE: return 5;
+        case CHX_T_GENERAL: return 4;
     }
     return -1;
 }

@@ -36,20 +36,12 @@ def base_rmatrix(length, k1, hx, species: Species, energy: torch.Tensor | None =
 
 
 def base_ttensor(length, k1, k2, hx, species: Species, energy: torch.Tensor | None = None) -> torch.Tensor:
-    """Second-order tensor without the first-order block (track_methods.py:80-281). The builder kernel knows the two
-    families the reference's elements use: k2 = 0 (Drift / Quadrupole / Dipole) and k1 = hx = 0 (Sextupole)."""
+    """Second-order tensor without the first-order block (track_methods.py:80-281) for any combination of quadrupole,
+    sextupole strength and curvature: `chx_build_ttensor` kind CHX_T_GENERAL [length, k1, k2, hx] (differentiable in all
+    four and in the energy through chx_build_ttensor_vjp)."""
     energy = energy if energy is not None else length.new_zeros(())
-    zero = length.new_zeros(())
-    if not torch.any(k2 != 0):
-        values, kind = [length, hx * length, k1, zero, zero, zero, zero, zero, zero], _ops.T_KIND["dipole"]
-    elif not (torch.any(k1 != 0) or torch.any(hx != 0)):
-        values, kind = [length, k2, zero, zero, zero], _ops.T_KIND["sextupole"]
-    else:
-        raise NotImplementedError("base_ttensor with k2 != 0 together with k1 or hx != 0 is not available")
-    params, pshape = _ops.stack_params(values, length.dtype, length.device)
-    T = _ops.build_ttensor(kind, params, pshape, energy.to(length.dtype), species.mass_eV_float).clone()
-    T[..., :, 6, :] = 0.0      # the elements put their first-order map here (drift.py:79-82)
-    return T
+    params, pshape = _ops.stack_params([length, k1, k2, hx], length.dtype, length.device)
+    return _ops.build_ttensor(_ops.T_KIND["general"], params, pshape, energy.to(length.dtype), species.mass_eV_float)
 
 
 def rotation_matrix(angle: torch.Tensor) -> torch.Tensor:

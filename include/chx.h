@@ -587,8 +587,10 @@ int chx_special(int kind, const void* a, const void* b, int64_t n, int dtype, vo
  * dipole.py:397-428, sextupole.py:91-116). params[Bp][P] (dtype):
  *   CHX_T_DRIFT [length]   CHX_T_QUADRUPOLE [length, k1, tilt, mx, my]   CHX_T_SEXTUPOLE [length, k2, tilt, mx, my]
  *   CHX_T_DIPOLE = the CHX_DIPOLE vector [length, angle, k1, e1, e2, tilt, fint, fint_exit, gap]
+ *   CHX_T_GENERAL [length, k1, k2, hx]: the bare tensor of track_methods.base_ttensor (track_methods.py:80-281) for any
+ *   combination of the three strengths, without a first-order block and without dressing (custom elements)
  * T_out[B][7][7][7] (dtype). */
-enum chx_t_kind { CHX_T_DRIFT = 0, CHX_T_QUADRUPOLE = 1, CHX_T_DIPOLE = 2, CHX_T_SEXTUPOLE = 3 };
+enum chx_t_kind { CHX_T_DRIFT = 0, CHX_T_QUADRUPOLE = 1, CHX_T_DIPOLE = 2, CHX_T_SEXTUPOLE = 3, CHX_T_GENERAL = 4 };
 int chx_t_num_params(int kind);
 int chx_build_ttensor(int kind, const void* params, const void* energy, double mass_eV, int64_t B, int64_t Bp,
                       int64_t Be, int dtype, void* T_out, void* stream);

@@ -268,7 +268,7 @@ def test_nonlinear_entry_points_reject_bad_arguments():
 
     lib = _lib.lib()
     assert [lib.chx_dkd_num_params(k) for k in range(5)] == [1, 5, 9, 7, -1]
-    assert [lib.chx_t_num_params(k) for k in range(5)] == [1, 5, 9, 5, -1]
+    assert [lib.chx_t_num_params(k) for k in range(6)] == [1, 5, 9, 5, 4, -1]
     x = torch.zeros(4, 7, device="cuda")
     p = torch.ones(1, 5, device="cuda")
     e = torch.full((1,), 1e8, device="cuda")
