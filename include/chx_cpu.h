@@ -1,0 +1,35 @@
+/* chx_cpu.h — host twins of the core libchx entry points ("each entry point has a *_cpu twin with
+ * identical signature (host pointers)").
+ *
+ * For downstream projects that want to link and test their binding of the C-ABI on a machine WITHOUT a GPU: every function here
+ * has the argument list of its include/chx.h namesake, takes host pointers, ignores `stream` / `workspace`, and runs the CPU
+ * restatement of the reference (oracle/chx_oracle.c, compiled into oracle/libchx_cpu.so by oracle/chx_oracle.py
+ * `build_cpu_abi()`). This is test / CI infrastructure like the oracle itself: the cheetah_amd package never loads it, and
+ * there is no fallback from the GPU library to it.
+ *
+ *   chx_build_rmatrix_cpu   chx_build_rmatrix   track_methods.py:17-77,284-382, dipole.py:372-466, cavity.py:253-358
+ *   chx_compose_maps_cpu    chx_compose_maps    segment.py:534-543
+ *   chx_apply_affine7_cpu   chx_apply_affine7   element.py:180-191 (the kernels' fma chain: bit-identical results)
+ *   chx_moments_cpu         chx_moments         particle_beam.py:1699-1717, utils/statistics.py:4-48
+ *   chx_cic_deposit_cpu     chx_cic_deposit     utils/cloud_in_cell.py:8-451 (row-major grids only)
+ */
+#ifndef CHX_CPU_H
+#define CHX_CPU_H
+#include "chx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int chx_abi_version_cpu(void);
+int chx_build_rmatrix_cpu(int kind, const void* params, const void* energy, double mass_eV, double n_charges, int64_t B,
+                          int64_t Bp, int64_t Be, int dtype, void* R_out, void* stream);
+int chx_compose_maps_cpu(const void* const* R_ptrs, const uint8_t* bcast, int64_t E, int64_t B, int dtype, void* R_out,
+                         void* stream);
+int chx_apply_affine7_cpu(const void* x_in, const void* R, void* x_out, int64_t B, int64_t Bx, int64_t BR, int64_t N, int dtype,
+                          void* stream);
+int chx_moments_cpu(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, double* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int chx_cic_deposit_cpu(const chx_cic_args* args, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -24,7 +24,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef CHXO_API
 #define CHXO_API __attribute__((visibility("default")))
+#endif
 
 static const double kC = 299792458.0;             /* scipy.constants.speed_of_light */
 static const double kE = 1.602176634e-19;         /* scipy.constants.elementary_charge */

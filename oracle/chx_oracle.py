@@ -56,6 +56,21 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+_CPU_ABI_SO = os.path.join(_HERE, "libchx_cpu.so")
+
+
+def build_cpu_abi(force: bool = False) -> str:
+    """Compile the host twins of the core C-ABI entry points (include/chx_cpu.h; oracle/chx_cpu_abi.c includes the oracle's C)
+    into oracle/libchx_cpu.so: what a downstream project links to exercise its binding without a GPU."""
+    srcs = [os.path.join(_HERE, n) for n in ("chx_cpu_abi.c", "chx_oracle.c", "chx_oracle_nonlinear.inc")]
+    hdrs = [os.path.join(_HERE, "..", "include", n) for n in ("chx.h", "chx_cpu.h")]
+    newest = max(os.path.getmtime(f) for f in srcs + hdrs)
+    if force or not os.path.exists(_CPU_ABI_SO) or os.path.getmtime(_CPU_ABI_SO) < newest:
+        subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-fPIC", "-shared", "-fopenmp", "-fvisibility=hidden",
+                               "-ffp-contract=off", "-o", _CPU_ABI_SO, srcs[0], "-lm"])
+    return _CPU_ABI_SO
+
+
 _lib = None
 
 

@@ -1,0 +1,97 @@
+"""include/chx_cpu.h: the host twins of the core C-ABI entry points (oracle/libchx_cpu.so, compiled from the oracle's C) — every
+declared symbol is exported with the argument list of its chx.h namesake, and gives the oracle's numbers (which the golden
+fixtures pin to the reference: tests/test_oracle_golden.py). Runs without a GPU: that is the point of the twins."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+i64, vp, dbl = ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+
+
+def _lib():
+    from oracle import chx_oracle
+
+    return ctypes.CDLL(chx_oracle.build_cpu_abi())
+
+
+def _decls(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return {m.group(2): re.sub(r"\s+", " ", m.group(3)).strip()
+            for m in re.finditer(r"\b(int|size_t|int64_t)\s+(chx_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(vp)
+
+
+def test_every_twin_is_exported_with_the_signature_of_its_namesake():
+    lib = _lib()
+    twins, abi = _decls("chx_cpu.h"), _decls("chx.h")
+    assert set(twins) == {"chx_abi_version_cpu", "chx_build_rmatrix_cpu", "chx_compose_maps_cpu", "chx_apply_affine7_cpu",
+                          "chx_moments_cpu", "chx_cic_deposit_cpu"}
+    norm = lambda sig: re.sub(r"\s*/\*.*?\*/", "", sig).replace(" ,", ",")  # noqa: E731
+    for name, sig in twins.items():
+        assert hasattr(lib, name), name
+        base = name[:-4]
+        assert base in abi, base
+        assert norm(sig) == norm(abi[base]), (name, sig, abi[base])
+    exported = os.popen(f"nm -D --defined-only {os.path.join(ROOT, 'oracle', 'libchx_cpu.so')}").read()
+    assert "chxo_" not in exported                      # the oracle's own entry points stay internal
+    assert lib.chx_abi_version_cpu() == int(re.search(r"#define CHX_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "chx.h")).read()).group(1))
+
+
+def test_twins_give_the_oracles_numbers(oracle):
+    lib = _lib()
+    rng = np.random.default_rng(7)
+    # maps: quadrupole with tilt + misalignment, fp32 and fp64 storage
+    for dtype, code in ((np.float64, 1), (np.float32, 0)):
+        params = np.array([[0.2, 4.2, 0.1, 1e-4, -2e-4], [0.3, -3.0, 0.0, 0.0, 0.0]], dtype=dtype)
+        energy = np.array([1e8], dtype=dtype)
+        R = np.empty((2, 7, 7), dtype=dtype)
+        assert lib.chx_build_rmatrix_cpu(2, _ptr(params), _ptr(energy), dbl(oracle.ELECTRON_MASS_EV), dbl(-1.0), i64(2), i64(2), i64(1),
+                                         code, _ptr(R), None) == 0
+        ref = oracle.build_rmatrix("quadrupole", params.astype(np.float64), energy.astype(np.float64))
+        assert np.allclose(R, ref.astype(dtype), rtol=0, atol=0)
+        # compose (one shared map, one per row)
+        drift = oracle.build_rmatrix("drift", [0.8], 1e8).astype(dtype)
+        ptrs = (vp * 3)(_ptr(R).value, _ptr(drift).value, _ptr(R).value)
+        bc = (ctypes.c_uint8 * 3)(0, 1, 0)
+        out = np.empty((2, 7, 7), dtype=dtype)
+        assert lib.chx_compose_maps_cpu(ptrs, bc, i64(3), i64(2), code, _ptr(out), None) == 0
+        want = np.stack([R[b].astype(np.float64) @ drift[0].astype(np.float64) @ R[b].astype(np.float64) for b in range(2)])
+        assert np.allclose(out, want, rtol=1e-6 if code == 0 else 1e-14)
+        # apply: the kernels' fma chain (bit-identical to the oracle's mode 1)
+        x = (rng.standard_normal((1, 1000, 7)) * 1e-3).astype(dtype)
+        x[..., 6] = 1
+        y = np.empty((2, 1000, 7), dtype=dtype)
+        assert lib.chx_apply_affine7_cpu(_ptr(x), _ptr(out), _ptr(y), i64(2), i64(1), i64(2), i64(1000), code, None) == 0
+        assert np.array_equal(y, oracle.apply(x, out, mode=1))
+        # moments
+        w = rng.random((2, 1000)).astype(dtype)
+        mom = np.empty((2, 29))
+        assert lib.chx_moments_cpu(_ptr(y), _ptr(w), i64(2), i64(2), i64(2), i64(1000), code, _ptr(mom), None, ctypes.c_size_t(0), None) == 0
+        assert np.allclose(mom, oracle.moments(y, w)["raw"], rtol=1e-13, atol=0)
+    # cloud in cell through the struct of the ABI
+    from cheetah_amd._lib import CicArgs
+
+    x = (rng.standard_normal((1, 4000, 7)) * [1e-3, 0, 2e-3, 0, 0, 0, 0]).astype(np.float32)
+    q = rng.random((1, 4000)).astype(np.float32)
+    extent = np.array([[[-3e-3, 3e-3], [-5e-3, 5e-3]]], dtype=np.float32)
+    grid = np.zeros((1, 16, 24), dtype=np.float32)
+    a = CicArgs()
+    a.ndim = 2
+    a.cols[0], a.cols[1] = 0, 2
+    a.bins[0], a.bins[1] = 16, 24
+    a.B = a.Bx = a.Bq = a.Be = a.Bs = a.Bsc = a.Bsh = 1
+    a.N, a.dtype, a.abs_charge = 4000, 0, 0
+    a.x, a.charge, a.extent, a.grid = _ptr(x).value, _ptr(q).value, _ptr(extent).value, _ptr(grid).value
+    assert lib.chx_cic_deposit_cpu(ctypes.byref(a), None) == 0
+    ref = oracle.cic_deposit(x, (0, 2), (16, 24), extent[0], charge=q)
+    assert np.array_equal(grid, ref.reshape(grid.shape))
+    # argument checking like the GPU library: negative status, no exception across the ABI
+    assert lib.chx_apply_affine7_cpu(None, _ptr(out), _ptr(y), i64(2), i64(1), i64(2), i64(1000), 0, None) == -1
+    assert lib.chx_moments_cpu(_ptr(y), None, i64(2), i64(2), i64(1), i64(1000), 7, _ptr(mom), None, ctypes.c_size_t(0), None) == -2
