@@ -46,6 +46,18 @@ def main():
             "dkd tdc": lambda: _ops.dkd_track(3, x, t(1.0, 1e7, 0.2, 1e9, 0.0, 0.0, 0.0), torch.Size(()), E, m, nq),
             "second_order apply": lambda: _ops.apply_second_order(x, T),
         }
+        if dt == torch.float32:   # the float32-arithmetic variants (Element.dkd_precision = "storage")
+            cases.update({
+                "dkd drift, fp32 arith": lambda: _ops.dkd_track(0, x, t(1.0), torch.Size(()), E, m, nq, storage_precision=True),
+                "dkd quadrupole 1 step, fp32 arith": lambda: _ops.dkd_track(1, x, t(0.2, 4.2, 0.0, 0.0, 0.0), torch.Size(()), E, m, nq, 1,
+                                                                            storage_precision=True),
+                "dkd quadrupole 10 steps, fp32 arith": lambda: _ops.dkd_track(1, x, t(0.2, 4.2, 0.1, 1e-4, -1e-4), torch.Size(()), E, m, nq,
+                                                                              10, storage_precision=True),
+                "dkd dipole, fp32 arith": lambda: _ops.dkd_track(2, x, t(0.5, 0.35, 0.17, 0.17, 0.1, 0.5, 0.5, 0.05, 0.05), torch.Size(()), E,
+                                                                 m, nq, 1, 3, storage_precision=True),
+                "dkd tdc, fp32 arith": lambda: _ops.dkd_track(3, x, t(1.0, 1e7, 0.2, 1e9, 0.0, 0.0, 0.0), torch.Size(()), E, m, nq,
+                                                              storage_precision=True),
+            })
         R = torch.eye(7, device="cuda", dtype=dt)
         R[0, 1] = 1.0
         T = _ops.build_ttensor(1, t(0.2, 4.2, 0.1, 1e-4, -1e-4), torch.Size(()), E, m)
@@ -53,7 +65,21 @@ def main():
         for name, fn in cases.items():
             us = timed(fn)
             gbs = N * 14 * esz / us * 1e-3
-            print(f"{name:28s} {us:9.1f} us   {gbs:8.1f} GB/s   {N / us:8.1f} Mparticles/s")
+            print(f"{name:36s} {us:9.1f} us   {gbs:8.1f} GB/s   {N / us:8.1f} Mparticles/s")
+        if dt == torch.float32:
+            # error of the two arithmetic widths against the float64 kernel on the same (float32-representable) input, in units of
+            # the largest absolute value of each coordinate
+            x64, E64 = x.double(), E.double()
+            t64 = lambda *v: torch.tensor([list(v)], device="cuda", dtype=torch.float64)  # noqa: E731
+            for name, kind, par, extra in (("drift", 0, (1.0,), ()), ("quadrupole", 1, (0.2, 4.2, 0.1, 1e-4, -1e-4), (10,)),
+                                           ("dipole", 2, (0.5, 0.35, 0.17, 0.17, 0.1, 0.5, 0.5, 0.05, 0.05), (1, 3)),
+                                           ("tdc", 3, (1.0, 1e7, 0.2, 1e9, 0.0, 0.0, 0.0), ())):
+                ref = _ops.dkd_track(kind, x64, t64(*par), torch.Size(()), E64, m, nq, *extra)[0]
+                scale = ref.abs().max(dim=0).values[:6]
+                for label, flag in (("fp64 arith", False), ("fp32 arith", True)):
+                    got = _ops.dkd_track(kind, x, t(*par), torch.Size(()), E, m, nq, *extra, storage_precision=flag)[0]
+                    err = ((got.double() - ref).abs().max(dim=0).values[:6] / scale).tolist()
+                    print(f"error vs float64 kernel, {name:10s} {label}: " + " ".join(f"{v:.1e}" for v in err))
         us = timed(lambda: _ops.build_ttensor(1, t(0.2, 4.2, 0.1, 1e-4, -1e-4), torch.Size(()), E, m))
         print(f"{'build_ttensor (1 row)':28s} {us:9.1f} us")
 

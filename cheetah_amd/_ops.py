@@ -688,12 +688,12 @@ def stack_params(values, dtype, device) -> tuple[torch.Tensor, torch.Size]:
     return torch.stack([v.to(dtype).expand(shape) for v in values], dim=-1).reshape(-1, len(values)), shape
 
 
-def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N):
+def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, storage_precision=False):
     out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
     e_out = torch.empty((B,), dtype=x.dtype, device=x.device)
-    check(_lib.lib().chx_dkd_track(kind, ptr(x), ptr(p), ptr(e), mass_eV, n_charges, num_steps, fringe_at, B, x.shape[0],
-                                   p.shape[0], e.shape[0], N, dtype_code(x.dtype), ptr(out), ptr(e_out), stream_ptr()),
-          "chx_dkd_track")
+    check(_lib.lib().chx_dkd_track_p(kind, ptr(x), ptr(p), ptr(e), mass_eV, n_charges, num_steps, fringe_at, B, x.shape[0],
+                                     p.shape[0], e.shape[0], N, dtype_code(x.dtype), 1 if storage_precision else 0, ptr(out),
+                                     ptr(e_out), stream_ptr()), "chx_dkd_track_p")
     return out, e_out
 
 
@@ -738,9 +738,11 @@ class DkdTrack(torch.autograd.Function):
 
 
 def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float, n_charges: float, num_steps: int = 1,
-              fringe_at: int = 3):
-    """One drift-kick-drift element (chx_dkd_track): particles (..., N, 7), params (Bp, P) with vector shape
-    `param_shape`, energy (...). Returns (particles_out (*batch, N, 7), ref_energy (*energy/param batch))."""
+              fringe_at: int = 3, storage_precision: bool = False):
+    """One drift-kick-drift element (chx_dkd_track_p): particles (..., N, 7), params (Bp, P) with vector shape
+    `param_shape`, energy (...). Returns (particles_out (*batch, N, 7), ref_energy (*energy/param batch)).
+    `storage_precision`: evaluate float32 beams in float32 (the reference's arithmetic width) instead of float64; the
+    differentiable path always runs in float64 (dual numbers)."""
     require_device(particles, params, energy)
     N = particles.shape[-2]
     eb_shape = bshapes(param_shape, energy.shape)           # batch shape of the outgoing energy
@@ -753,7 +755,7 @@ def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float,
     if torch.is_grad_enabled() and (x.requires_grad or p.requires_grad or e.requires_grad):
         out, e_out = DkdTrack.apply(x, p, e, kind, mass_eV, n_charges, num_steps, fringe_at, B, N)
     else:
-        out, e_out = _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N)
+        out, e_out = _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, storage_precision)
     # the outgoing reference energy has the INCOMING energy's shape (bmadx.py:49: it only depends on p0c)
     if energy.numel() == 1:
         e_out = e_out[:1].reshape(energy.shape)

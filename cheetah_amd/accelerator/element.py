@@ -240,6 +240,11 @@ class Element(nn.Module):
             species=incoming.species,
         )
 
+    #: arithmetic of the drift-kick-drift (Bmad-X) kernels for float32 beams: "double" (default) evaluates every particle in
+    #: float64 and rounds once — Bmad-X to ~1e-7 of a coordinate, fp64-VALU bound; "storage" evaluates in float32 like the
+    #: reference's own tensor code (cheetah/utils/bmadx.py runs in the beam dtype) — one HBM-bound pass, measured errors in
+    #: DESIGN.md section 5. Set on an element (`quad.dkd_precision = "storage"`) or on the class for a whole lattice.
+    dkd_precision = "double"
     #: chx_dkd_kind / chx_t_kind of the element (include/chx.h); None = method not available
     _dkd_kind: int | None = None
     _t_kind: int | None = None
@@ -264,9 +269,11 @@ class Element(nn.Module):
         num_steps, fringe = self._dkd_options()
         species = incoming.species
         x = incoming.particles if incoming.particles.dtype == dtype else incoming.particles.to(dtype)
+        if self.dkd_precision not in ("double", "storage"):
+            raise ValueError(f"dkd_precision must be 'double' or 'storage', got {self.dkd_precision!r}")
         particles, ref_energy = _ops.dkd_track(self._dkd_kind, x, params, pshape, energy,
                                                species.mass_eV_float, species.num_elementary_charges_float, num_steps,
-                                               fringe)
+                                               fringe, storage_precision=self.dkd_precision == "storage")
         if ref_energy.dtype != incoming.energy.dtype:
             ref_energy = ref_energy.to(incoming.energy.dtype)
         if ref_energy.requires_grad and not incoming.energy.requires_grad:

@@ -69,3 +69,43 @@ __device__ __forceinline__ Dual m_asinh(Dual x) { return mk(asinh(x.v), x.d / sq
 // d|x| = sign(x) dx with sign(0) = 0: torch's convention for `abs` (the reference's trilinear weights are 1 - |u - i|,
 // space_charge_kick.py:413-415, so a particle sitting exactly on a grid node gets this sub-gradient there)
 __device__ __forceinline__ Dual m_abs(Dual x) { return x.v < 0.0 ? mk(-x.v, -x.d) : (x.v > 0.0 ? x : mk(0.0, 0.0)); }
+
+// ---- F32: the same closed forms evaluated in float32 (opt-in `precision="storage"` of the drift-kick-drift kernels: the
+// reference's Bmad-X arithmetic runs in the storage dtype, cheetah/utils/bmadx.py). A wrapper instead of plain `float` so that
+// the double literals of the templates (1.0 + x, 0.5 * x, kPi / 2.0 ...) are rounded to float and the operation itself is a
+// float operation — `1.0 + x` with a plain float would be promoted to a v_add_f64.
+struct F32 {
+    float v;
+};
+__device__ __forceinline__ F32 mkf(float v) { F32 r; r.v = v; return r; }
+__device__ __forceinline__ F32 operator+(F32 a, F32 b) { return mkf(a.v + b.v); }
+__device__ __forceinline__ F32 operator-(F32 a, F32 b) { return mkf(a.v - b.v); }
+__device__ __forceinline__ F32 operator*(F32 a, F32 b) { return mkf(a.v * b.v); }
+// divisions and square roots through the hardware approximations (v_rcp_f32, v_sqrt_f32: 1 ulp) instead of the IEEE-exact
+// expansions (~10 instructions each): this type exists to be HBM-bound, and its results carry the rounding of a float32
+// evaluation of the whole map anyway
+__device__ __forceinline__ F32 operator/(F32 a, F32 b) { return mkf(a.v * __builtin_amdgcn_rcpf(b.v)); }
+__device__ __forceinline__ F32 operator-(F32 a) { return mkf(-a.v); }
+__device__ __forceinline__ F32 operator+(F32 a, double b) { return mkf(a.v + (float)b); }
+__device__ __forceinline__ F32 operator+(double a, F32 b) { return mkf((float)a + b.v); }
+__device__ __forceinline__ F32 operator-(F32 a, double b) { return mkf(a.v - (float)b); }
+__device__ __forceinline__ F32 operator-(double a, F32 b) { return mkf((float)a - b.v); }
+__device__ __forceinline__ F32 operator*(F32 a, double b) { return mkf(a.v * (float)b); }
+__device__ __forceinline__ F32 operator*(double a, F32 b) { return mkf((float)a * b.v); }
+__device__ __forceinline__ F32 operator/(F32 a, double b) { return mkf(a.v * __builtin_amdgcn_rcpf((float)b)); }
+__device__ __forceinline__ F32 operator/(double a, F32 b) { return mkf((float)a * __builtin_amdgcn_rcpf(b.v)); }
+__device__ __forceinline__ double val(F32 x) { return (double)x.v; }
+__device__ __forceinline__ double tan_of(F32 x) { return 0.0 * x.v; }
+template <> __device__ __forceinline__ F32 cst<F32>(double c) { return mkf((float)c); }
+__device__ __forceinline__ F32 m_sqrt(F32 x) { return mkf(__builtin_amdgcn_sqrtf(x.v)); }
+__device__ __forceinline__ F32 m_sin(F32 x) { return mkf(sinf(x.v)); }
+__device__ __forceinline__ F32 m_cos(F32 x) { return mkf(cosf(x.v)); }
+__device__ __forceinline__ F32 m_tan(F32 x) { return mkf(tanf(x.v)); }
+__device__ __forceinline__ F32 m_sinh(F32 x) { return mkf(sinhf(x.v)); }
+__device__ __forceinline__ F32 m_cosh(F32 x) { return mkf(coshf(x.v)); }
+__device__ __forceinline__ F32 m_log1p(F32 x) { return mkf(log1pf(x.v)); }
+__device__ __forceinline__ F32 m_asin(F32 x) { return mkf(asinf(x.v)); }
+__device__ __forceinline__ F32 m_atan2(F32 y, F32 x) { return mkf(atan2f(y.v, x.v)); }
+__device__ __forceinline__ F32 m_atan(F32 x) { return mkf(atanf(x.v)); }
+__device__ __forceinline__ F32 m_asinh(F32 x) { return mkf(asinhf(x.v)); }
+__device__ __forceinline__ F32 m_abs(F32 x) { return mkf(fabsf(x.v)); }

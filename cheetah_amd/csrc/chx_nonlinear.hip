@@ -126,6 +126,9 @@ __device__ __forceinline__ QuadCoef<S> quad_coefficients(S k1, S len, S rel_p) {
 __device__ __forceinline__ double sqrta2minusbdiva(double a, double b) {
     return b != 0.0 ? (sqrt(a * a + b) - a) / b : 1.0 / (2.0 * a);
 }
+__device__ __forceinline__ F32 sqrta2minusbdiva(F32 a, F32 b) {
+    return b.v != 0.0f ? mkf((sqrtf(a.v * a.v + b.v) - a.v) / b.v) : mkf(1.0f / (2.0f * a.v));
+}
 __device__ __forceinline__ Dual sqrta2minusbdiva(Dual a, Dual b) {
     if (b.v != 0.0) return (m_sqrt(a * a + b) - a) / b;
     return mk(1.0 / (2.0 * a.v), -a.d / (2.0 * a.v * a.v) - b.d / (8.0 * a.v * a.v * a.v));
@@ -274,7 +277,19 @@ __device__ __forceinline__ void dkd_map(const S* c, const S (&in)[6], double mc2
     from_bmad<S>(q.z, q.pz, c[C_P0C], mc2, out[4], out[5]);
 }
 
-template <typename T, int KIND>
+// C: the scalar the per-particle map is evaluated in — double (default, whatever the storage dtype) or F32 (float32 beams with
+// `precision = storage`: the reference's own arithmetic width, HBM-bound instead of fp64-VALU-bound).
+template <typename C> struct dkd_scalar;
+template <> struct dkd_scalar<double> {
+    __device__ static __forceinline__ double from(double v) { return v; }
+    __device__ static __forceinline__ double to(double v) { return v; }
+};
+template <> struct dkd_scalar<F32> {
+    __device__ static __forceinline__ F32 from(double v) { return mkf((float)v); }
+    __device__ static __forceinline__ double to(F32 v) { return (double)v.v; }
+};
+
+template <typename T, int KIND, typename C = double>
 __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_in, const T* __restrict__ params,
                                                         const T* __restrict__ energy, double mc2, double nq,
                                                         int num_steps, int fringe, int P, int64_t B, int64_t Bx,
@@ -283,6 +298,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
     constexpr int TP = CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     __shared__ double cst_[C_N + 1];
+    __shared__ C cstc_[C_N + 1];
 
     const int64_t tiles_per_row = (N + TP - 1) / TP;
     const int64_t b = blockIdx.x / tiles_per_row;
@@ -297,7 +313,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
         const T Eb = energy[(Be == 1) ? 0 : b];
         double par[CHX_MAX_PARAMS];
         for (int k = 0; k < P; ++k) par[k] = (double)params[((Bp == 1) ? 0 : b) * P + k];
-        dkd_constants<double>(KIND, par, (double)Eb, mc2, nq, fringe, cst_);
+        dkd_constants<double>(KIND, par, (double)Eb, mc2, nq, fringe, cst_);      // per-row constants: always in double
+        for (int k = 0; k <= C_N; ++k) cstc_[k] = dkd_scalar<C>::from(cst_[k]);
         if (t == 0 && energy_out) {
             // ref_energy of bmad_to_cheetah_z_pz (bmadx.py:49), in the storage dtype like the reference
             const T m = (T)mc2;
@@ -310,12 +327,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
 
     const int p = threadIdx.x;
     if (p < np) {
-        double in[6], out[6];
+        C in[6], out[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) in[j] = (double)lds[p * 7 + j];
-        dkd_map<KIND, double>(cst_, in, mc2, num_steps, out);
+        for (int j = 0; j < 6; ++j) in[j] = dkd_scalar<C>::from((double)lds[p * 7 + j]);
+        dkd_map<KIND, C>(cstc_, in, mc2, num_steps, out);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) lds[p * 7 + j] = (T)out[j];
+        for (int j = 0; j < 6; ++j) lds[p * 7 + j] = (T)dkd_scalar<C>::to(out[j]);
         lds[p * 7 + 6] = (T)1;
     }
     __syncthreads();
@@ -406,36 +423,36 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_bwd_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, typename C = double>
 int launch_dkd(const void* x_in, const void* params, const void* energy, double mc2, double nq, int num_steps,
                int fringe, int P, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N, void* x_out,
                void* energy_out, hipStream_t s) {
     const int64_t tiles = ((N + CHX_BLOCK - 1) / CHX_BLOCK) * B;
     if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
-    hipLaunchKernelGGL((dkd_kernel<T, KIND>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const T*)x_in,
+    hipLaunchKernelGGL((dkd_kernel<T, KIND, C>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const T*)x_in,
                        (const T*)params, (const T*)energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be, N,
                        (T*)x_out, (T*)energy_out, (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
 
-template <typename T>
+template <typename T, typename C = double>
 int dispatch_dkd(int kind, const void* x_in, const void* params, const void* energy, double mc2, double nq,
                  int num_steps, int fringe, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N,
                  void* x_out, void* energy_out, hipStream_t s) {
     const int P = chx_dkd_num_params(kind);
     switch (kind) {
         case CHX_DKD_DRIFT:
-            return launch_dkd<T, CHX_DKD_DRIFT>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be,
+            return launch_dkd<T, CHX_DKD_DRIFT, C>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be,
                                                 N, x_out, energy_out, s);
         case CHX_DKD_QUADRUPOLE:
-            return launch_dkd<T, CHX_DKD_QUADRUPOLE>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp,
+            return launch_dkd<T, CHX_DKD_QUADRUPOLE, C>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp,
                                                      Be, N, x_out, energy_out, s);
         case CHX_DKD_DIPOLE:
-            return launch_dkd<T, CHX_DKD_DIPOLE>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be,
+            return launch_dkd<T, CHX_DKD_DIPOLE, C>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be,
                                                  N, x_out, energy_out, s);
         case CHX_DKD_TDC:
-            return launch_dkd<T, CHX_DKD_TDC>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be, N,
+            return launch_dkd<T, CHX_DKD_TDC, C>(x_in, params, energy, mc2, nq, num_steps, fringe, P, B, Bx, Bp, Be, N,
                                               x_out, energy_out, s);
     }
     return CHX_ERR_INVALID_ARG;
@@ -457,6 +474,14 @@ extern "C" int chx_dkd_track(int kind, const void* x_in, const void* params, con
                              double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx,
                              int64_t Bp, int64_t Be, int64_t N, int dtype, void* x_out, void* energy_out,
                              void* stream) {
+    return chx_dkd_track_p(kind, x_in, params, energy, mass_eV, n_charges, num_steps, fringe_at, B, Bx, Bp, Be, N, dtype, 0, x_out,
+                           energy_out, stream);
+}
+
+extern "C" int chx_dkd_track_p(int kind, const void* x_in, const void* params, const void* energy, double mass_eV,
+                               double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp,
+                               int64_t Be, int64_t N, int dtype, int storage_precision, void* x_out, void* energy_out,
+                               void* stream) {
     if (chx_dkd_num_params(kind) < 0) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (B < 0 || N < 0) return CHX_ERR_INVALID_ARG;
@@ -466,6 +491,9 @@ extern "C" int chx_dkd_track(int kind, const void* x_in, const void* params, con
     if (kind == CHX_DKD_QUADRUPOLE && num_steps < 1) return CHX_ERR_INVALID_ARG;
     if (fringe_at < 0 || fringe_at > 3) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32 && storage_precision)
+        return dispatch_dkd<float, F32>(kind, x_in, params, energy, mass_eV, n_charges, num_steps, fringe_at, B, Bx, Bp, Be, N, x_out,
+                                        energy_out, s);
     return dtype == CHX_F32 ? dispatch_dkd<float>(kind, x_in, params, energy, mass_eV, n_charges, num_steps, fringe_at,
                                                   B, Bx, Bp, Be, N, x_out, energy_out, s)
                             : dispatch_dkd<double>(kind, x_in, params, energy, mass_eV, n_charges, num_steps,

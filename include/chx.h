@@ -554,6 +554,13 @@ int chx_dkd_num_params(int kind);
 int chx_dkd_track(int kind, const void* x_in, const void* params, const void* energy, double mass_eV,
                   double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp,
                   int64_t Be, int64_t N, int dtype, void* x_out, void* energy_out, void* stream);
+/* The same with the arithmetic width as an argument: storage_precision = 0 evaluates the per-particle map in float64 whatever
+ * the storage dtype (chx_dkd_track: agreement with Bmad-X to 1e-14 in float64, ~1e-7 of a coordinate in float32, but fp64-VALU
+ * bound: 20-42 us per element at 1e6 particles); 1 evaluates float32 beams in float32 like the reference's own tensor code
+ * (cheetah/utils/bmadx.py runs in the beam dtype) — one HBM-bound pass. float64 beams ignore the flag. */
+int chx_dkd_track_p(int kind, const void* x_in, const void* params, const void* energy, double mass_eV, double n_charges,
+                    int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N, int dtype,
+                    int storage_precision, void* x_out, void* energy_out, void* stream);
 /* Backward of chx_dkd_track (the reference gets it from torch autograd through utils/bmadx.py): forward-mode dual
  * numbers on device, one seeded evaluation per input. dx[B][N][7] (dtype, may be NULL) = dY . d x_out / d x_in;
  * partials (may be NULL) = chx_dkd_bwd_partials_count() doubles laid out [B][ceil(N/256)][P + 1]: per workgroup

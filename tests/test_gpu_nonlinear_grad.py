@@ -166,3 +166,55 @@ def test_vectorised_dipole_gradients_equal_separate_runs(method):
         assert torch.allclose(xv.grad[b], x1.grad, rtol=1e-9, atol=1e-12 * float(x1.grad.abs().max()))
         length_total += float(l1.grad)
     assert float(lv.grad) == pytest.approx(length_total, rel=1e-9)      # a shared parameter collects all rows
+
+
+@pytest.mark.parametrize("kind,params,extra", [
+    ("drift", (1.0,), ()), ("quadrupole", (0.2, 4.2, 0.1, 1e-4, -1e-4), (10,)),
+    ("dipole", (0.5, 0.35, 0.17, 0.17, 0.1, 0.5, 0.5, 0.05, 0.05), (1, 3)), ("tdc", (1.0, 1e7, 0.2, 1e9, 0.0, 0.0, 0.0), ())])
+def test_storage_precision_dkd_stays_within_float32_rounding_of_the_float64_map(kind, params, extra):
+    """`Element.dkd_precision = "storage"` (chx_dkd_track_p): float32 beams evaluated in float32 like the reference's Bmad-X
+    tensor code (/root/reference/cheetah/utils/bmadx.py runs in the beam dtype). The float64 kernel on the same input is the
+    yardstick: errors of a few float32 ulps of each coordinate's scale; the default (float64 arithmetic) is at the rounding of the
+    store."""
+    import cheetah_amd  # noqa: F401
+    from cheetah_amd import _ops
+
+    torch.manual_seed(0)
+    N = 50_000
+    x = torch.randn(N, 7, device="cuda") * torch.tensor([2e-4, 4e-6, 2e-4, 4e-6, 8e-6, 2e-3, 0.0], device="cuda")
+    x[:, 6] = 1.0
+    E = torch.tensor(1e8, device="cuda")
+    k = _ops.DKD_KIND[kind]
+    p32 = torch.tensor([list(params)], device="cuda")
+    ref = _ops.dkd_track(k, x.double(), p32.double(), torch.Size(()), E.double(), 510998.95069, -1.0, *extra)[0]
+    scale = ref.abs().max(dim=0).values[:6]
+    errs = {}
+    for flag in (False, True):
+        got, e_out = _ops.dkd_track(k, x, p32, torch.Size(()), E, 510998.95069, -1.0, *extra, storage_precision=flag)
+        assert got.dtype == torch.float32 and torch.all(got[:, 6] == 1)
+        errs[flag] = (got.double() - ref).abs().max(dim=0).values[:6] / scale
+    assert float(errs[False].max()) < 2e-7           # one rounding of the stored float32
+    # float32 arithmetic through the whole map: a few ulps on the transverse coordinates; tau and delta go through the
+    # Cheetah <-> Bmad conversion (bmadx.py:7-56), whose energy differences cancel five digits of a float32 — the price of the
+    # reference's own arithmetic width (measured: delta 2.4e-5, tau up to 2.6e-4 of the coordinate's scale)
+    # the dipole body (dipole.py:246-336: asin, atan2 and differences of nearly equal lengths) loses more: 1.3e-4 on px
+    bound = torch.tensor([2e-4, 5e-4, 2e-4, 5e-4, 3e-3, 2e-4] if kind == "dipole" else [5e-6, 5e-6, 5e-6, 5e-6, 1e-3, 1e-4],
+                         dtype=torch.float64, device="cuda")
+    assert torch.all(errs[True] < bound), errs[True]
+
+
+def test_dkd_precision_attribute_reaches_the_kernel():
+    import cheetah_amd as ca
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, **kw)
+    quad = ca.Quadrupole(t(0.2), k1=t(4.2), tracking_method="drift_kick_drift", **kw)
+    a = quad.track(beam).particles
+    quad.dkd_precision = "storage"
+    b = quad.track(beam).particles
+    scale = a.abs().max(dim=0).values[:6]
+    assert not torch.equal(a, b) and torch.all((a - b).abs().max(dim=0).values[:6] <= 2e-3 * scale)
+    quad.dkd_precision = "half"
+    with pytest.raises(ValueError):
+        quad.track(beam)
