@@ -238,3 +238,22 @@ def check(status: int, what: str = "libchx") -> None:
     if status != 0:
         msg = lib().chx_status_string(status).decode()
         raise ChxError(f"{what} failed: {msg} (status {status})")
+
+
+_host = None
+
+
+def host():
+    """`cheetah_amd._chxhost` (csrc/chx_host.c), bound to libchx's chx_run_track: the host step of a merged Segment.track in C.
+    Built by the same Makefile as libchx.so; missing = a broken build, there is no slower stand-in."""
+    global _host
+    if _host is None:
+        try:
+            from . import _chxhost
+        except ImportError as exc:  # pragma: no cover - broken build
+            raise ImportError("cheetah_amd._chxhost is not built: run `make -C cheetah_amd/csrc` "
+                              "(or `python -c 'import __graft_entry__ as g; g.build()'`)") from exc
+        fn = lib().chx_run_track
+        _chxhost.bind(ctypes.cast(fn, ctypes.c_void_p).value, torch.empty_like, torch._C._cuda_getCurrentRawStream, ChxError)
+        _host = _chxhost
+    return _host

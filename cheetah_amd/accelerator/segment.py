@@ -110,13 +110,14 @@ class _FastRun:
     one stream at a time, like the reference's non-reentrant element caches (utils/cache.py:23-27)."""
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
-                 "elements", "revs", "rows", "per_tensors", "slots", "R_view", "allow_grad", "distinct", "grad_slots")
+                 "elements", "revs", "rows", "per_tensors", "slots", "R_view", "allow_grad", "distinct", "grad_slots", "capsule")
 
     def __init__(self, run, dtype, device, allow_grad=False):
         # allow_grad: the plan of the DIFFERENTIABLE run map (_ops.RunMapPlanned) — trainable parameters and settings that
         # require grad qualify; `distinct` / `grad_slots` then say which slots every distinct setting tensor feeds
         self.allow_grad = allow_grad
         self.distinct, self.grad_slots = (), ()
+        self.capsule = None
         self.dtype, self.device = dtype, device
         self.elements = [e for e in run.elements]
         self.revs = [None] * len(self.elements)
@@ -215,6 +216,9 @@ class _FastRun:
             if not self.allow_grad:
                 self.state_bytes = _lib.lib().chx_run_state_bytes(E)
                 self.state = torch.full((self.state_bytes // 8,), float("nan"), dtype=torch.float64, device=self.device)
+                # the plan as the C host step sees it (cheetah_amd._chxhost): addresses of the two arrays above and of the state
+                self.capsule = _lib.host().plan(ctypes.addressof(self.kinds), ctypes.addressof(self.ptrs), E,
+                                                self.state.data_ptr(), self.state_bytes, self.code) if self.state.is_cuda else None
             self.R_view = None
         # kept alive: the plan holds their addresses (a tensor may appear more than once: `misalignment` feeds two parameters)
         tensors = tuple([t for ts in self.per_tensors for t in ts])
@@ -253,6 +257,19 @@ class _FastRun:
 
 
 _CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
+
+
+class _HostProxy:
+    """`cheetah_amd._chxhost`, loaded (and bound to libchx) at first use."""
+
+    def __getattr__(self, name):
+        h = _lib.host()
+        global _HOST
+        _HOST = h
+        return getattr(h, name)
+
+
+_HOST = _HostProxy()
 
 
 class _Run:
@@ -513,15 +530,13 @@ class Segment(Element):
             if _any_requires_grad(*fr.tensors):   # a buffer switched with requires_grad_(True) in place moves no counter
                 return None
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
-        out = torch.empty_like(x)
         _ops.check_current_device(fr.device)
         s_in = incoming.s
-        s_out = Segment._device_s(fr, s_in)
-        _ops.check(_lib.lib().chx_run_track(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
-                                            sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
-                                            x.data_ptr(), out.data_ptr(), x.shape[0], s_in.data_ptr() if s_out is not None else None,
-                                            s_out.data_ptr() if s_out is not None else None, _ops.stream_ptr()), "chx_run_track")
-        # the path length comes from the same launch that validates the settings (no host copy of the lengths to go stale)
+        on_device = s_in.dim() == 0 and s_in.dtype == fr.dtype and s_in.device == fr.device and not s_in.requires_grad
+        # the C host step (csrc/chx_host.c): output tensors, stream, chx_run_track — one call, no ctypes marshalling. The path
+        # length comes from the same launch that validates the settings (no host copy of the lengths to go stale)
+        out, s_out = _HOST.run_track(fr.capsule, x, x.shape[0], e, s_in if on_device else None, sp.mass_eV_float,
+                                     sp.num_elementary_charges_float, fr.device.index)
         return out, (s_out if s_out is not None else Segment._run_s(run, s_in))
 
     @staticmethod
