@@ -399,7 +399,9 @@ __device__ __forceinline__ void tm_centre(const T (&R)[42], const double* __rest
 #pragma unroll
             for (int j = 0; j < 6; ++j) s += (double)R[i * 7 + j] * centre[j];
         }
-        c[i] = s;
+        // float32 beams: a float32 shift point (any point near the mean serves), so that kernels which subtract it in float32
+        // and the finalize kernel, which adds it back in float64, mean the same number
+        c[i] = sizeof(T) == 4 ? (double)(float)s : s;
     }
 }
 
@@ -439,6 +441,95 @@ __global__ __launch_bounds__(CHX_BLOCK) void track_moments_rows_kernel(const T* 
 #pragma unroll
             for (int j = 0; j < 7; ++j) xv[j] = xs[i * 7 + j];
             tm_accumulate<T>(R, xv, (double)ws[i], c, acc);
+        }
+    }
+    if (b < B) {
+        double* p = partials + ((int64_t)blockIdx.y * B + b) * kTM;
+#pragma unroll
+        for (int k = 0; k < kTM; ++k) p[k] = acc[k];
+    }
+}
+
+// The same for float32 beams with the products in PACKED float32 and float64 only for the running sums: a lane handles two
+// particles at a time (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on {particle 2i, particle 2i + 1}), keeps 29 packed float32
+// partial sums over kTMFlush pairs and adds them to its float64 accumulators once per flush. The all-float64 kernel above is
+// fp64-VALU bound (41 float64 operations per (setting, particle) behind the 42 float32 FMAs of the map: 1.0 ms for
+// 4096 x 1e5); here a pair costs ~83 packed operations and 3.6 float64 operations per particle.
+// Rounding: y is the float32 the apply kernels store; d = y - c in float32 (c rounded to float32, see tm_centre) and
+// w d_i d_j in float32 carry ~6e-8 relative error each, independent from particle to particle; 32 of them are summed in
+// float32 before the float64 add (kTMFlush pairs) — the moments agree with the float64 accumulation to ~1e-7 relative
+// (tests/test_gpu_track_moments.py, profiles/r03_track_moments_rows.md).
+constexpr int kTMFlush = 32;   // pairs between two float64 updates
+
+__global__ __launch_bounds__(CHX_BLOCK) void track_moments_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                          const float* __restrict__ Rm,
+                                                                          const double* __restrict__ centre, int64_t B, int64_t N,
+                                                                          int64_t per_chunk, double* __restrict__ partials) {
+    constexpr int kChunk = 1024, kPairs = kChunk / 2;
+    __shared__ __attribute__((aligned(16))) chx_v2f xs[kPairs * 7];   // [pair][coordinate] = {x of the even, x of the odd particle}
+    __shared__ __attribute__((aligned(8))) chx_v2f ws[kPairs];
+    const int64_t b = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x;
+    const int64_t bb = b < B ? b : B - 1;
+    float R[42];
+#pragma unroll
+    for (int k = 0; k < 42; ++k) R[k] = Rm[bb * 49 + k];
+    double c[6], acc[kTM];
+    tm_centre<float>(R, centre, c);
+    float cf[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cf[i] = (float)c[i];               // exact: tm_centre<float> returns float32 values
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) acc[k] = 0.0;
+    const int64_t n_begin = (int64_t)blockIdx.y * per_chunk;
+    const int64_t n_end = (n_begin + per_chunk < N) ? n_begin + per_chunk : N;
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += kChunk) {
+        const int np = (int)((n_end - n0 < kChunk) ? (n_end - n0) : kChunk);
+        const int npairs = (np + 1) / 2;
+        __syncthreads();
+        // stage the chunk pairwise; a missing odd partner gets weight 0 (and finite coordinates)
+        float* xf = reinterpret_cast<float*>(xs);
+        for (int e = threadIdx.x; e < npairs * 14; e += CHX_BLOCK) {
+            const int pr = e / 14, r = e - pr * 14, j = r >> 1, odd = r & 1;
+            const int i = 2 * pr + odd;
+            xf[e] = i < np ? x[(n0 + i) * 7 + j] : 0.0f;
+        }
+        float* wf = reinterpret_cast<float*>(ws);
+        for (int i = threadIdx.x; i < npairs * 2; i += CHX_BLOCK) wf[i] = i < np ? (w ? w[n0 + i] : 1.0f) : 0.0f;
+        __syncthreads();
+        for (int p0 = 0; p0 < npairs; p0 += kTMFlush) {
+            const int p1 = p0 + kTMFlush < npairs ? p0 + kTMFlush : npairs;
+            chx_v2f a[kTM];
+#pragma unroll
+            for (int k = 0; k < kTM; ++k) a[k] = chx_v2f{0.0f, 0.0f};
+            for (int p = p0; p < p1; ++p) {
+                chx_v2f xv[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) xv[j] = xs[p * 7 + j];
+                const chx_v2f wv = ws[p];
+                chx_v2f d[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    chx_v2f y = xv[0] * R[i * 7];                  // the fma chain of chx_apply_affine7, two particles wide
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) {
+                        const chx_v2f r = {R[i * 7 + j], R[i * 7 + j]};
+                        y = __builtin_elementwise_fma(r, xv[j], y);
+                    }
+                    d[i] = y - chx_v2f{cf[i], cf[i]};
+                }
+                a[0] = a[0] + wv;
+                a[1] = __builtin_elementwise_fma(wv, wv, a[1]);
+                int k = 8;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const chx_v2f wd = wv * d[i];
+                    a[2 + i] = a[2 + i] + wd;
+#pragma unroll
+                    for (int j = i; j < 6; ++j, ++k) a[k] = __builtin_elementwise_fma(wd, d[j], a[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kTM; ++k) acc[k] += (double)a[k].x + (double)a[k].y;
         }
     }
     if (b < B) {
@@ -981,7 +1072,7 @@ extern "C" int chx_track_moments(const void* x_in, const void* w, const void* R,
         const int64_t per_chunk = (N + chunks - 1) / chunks;
         dim3 grid((unsigned)((B + CHX_BLOCK - 1) / CHX_BLOCK), (unsigned)chunks);
         if (dtype == CHX_F32)
-            hipLaunchKernelGGL(track_moments_rows_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+            hipLaunchKernelGGL(track_moments_rows_f32_kernel, grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
                                (const float*)w, (const float*)R, centre, B, N, per_chunk, part);
         else
             hipLaunchKernelGGL(track_moments_rows_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in,

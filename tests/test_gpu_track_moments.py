@@ -33,16 +33,20 @@ def _maps(B, dt, seed):
     return O.compose([q, d, h]).astype(dt)
 
 
-def _check(raw, ora, tag):
-    """raw (B,29) from the device vs oracle moments dict of the tracked particles."""
+def _check(raw, ora, tag, packed=False):
+    """raw (B,29) from the device vs oracle moments dict of the tracked particles. `packed`: the float32 rows kernel forms its
+    products in packed float32 and sums 32 particles in float32 before every float64 add (csrc/chx_moments.hip
+    track_moments_rows_f32_kernel): ~1e-7 relative instead of float64 rounding — still two decades below what the reference's
+    own float32 reductions give."""
     ref = ora["raw"]
-    assert np.allclose(raw[:, :2], ref[:, :2], rtol=1e-13, atol=0)
+    t_w, t_mu, t_cov = (1e-6, 3e-7, 2e-6) if packed else (1e-13, 1e-12, 1e-11)
+    assert np.allclose(raw[:, :2], ref[:, :2], rtol=t_w, atol=0)
     sig6 = np.sqrt(np.stack([ora["cov"][:, j, j] for j in range(6)], axis=-1))
-    assert np.all(np.abs(raw[:, 2:8] - ref[:, 2:8]) <= 1e-12 * (sig6 + np.abs(ref[:, 2:8])))
+    assert np.all(np.abs(raw[:, 2:8] - ref[:, 2:8]) <= t_mu * (sig6 + np.abs(ref[:, 2:8])))
     k = 8
     for i in range(6):
         for j in range(i, 6):
-            assert np.all(np.abs(raw[:, k] - ref[:, k]) <= 1e-11 * sig6[:, i] * sig6[:, j]), (tag, i, j)
+            assert np.all(np.abs(raw[:, k] - ref[:, k]) <= t_cov * sig6[:, i] * sig6[:, j]), (tag, i, j)
             k += 1
 
 
@@ -59,12 +63,13 @@ def test_rows_path_shared_beam(oracle, tag, B, N, weighted):
     raw = _ops.track_moments(tx, tw, tR).cpu().numpy()
     y = oracle.apply(x[None], R, mode=1)
     ora = oracle.moments(y, w if weighted else None)
-    _check(raw, ora, tag)
+    packed = tag == "f32"
+    _check(raw, ora, tag, packed=packed)
     # and against the product's own two-step path (bit-identical tracked particles)
     two = _ops.moments(_ops.apply_map(tx, tR), tw).cpu().numpy()
     sig = np.sqrt(np.abs(two[:, [8, 14, 19, 23, 26, 28]]))
-    assert np.all(np.abs(raw[:, 2:8] - two[:, 2:8]) <= 1e-12 * (sig + np.abs(two[:, 2:8])))
-    assert np.allclose(raw[:, [8, 14, 19, 23, 26, 28]], two[:, [8, 14, 19, 23, 26, 28]], rtol=1e-10, atol=0)
+    assert np.all(np.abs(raw[:, 2:8] - two[:, 2:8]) <= (3e-7 if packed else 1e-12) * (sig + np.abs(two[:, 2:8])))
+    assert np.allclose(raw[:, [8, 14, 19, 23, 26, 28]], two[:, [8, 14, 19, 23, 26, 28]], rtol=2e-6 if packed else 1e-10, atol=0)
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
