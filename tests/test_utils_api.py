@@ -203,6 +203,7 @@ def test_public_attribute_names_of_the_reference():
             call()
 
 
+@pytest.mark.gpu
 def test_general_ttensor_vs_reference_golden():
     """`track_methods.base_ttensor` with k2 together with k1 and / or hx (CHX_T_GENERAL) against the reference
     (/root/reference/cheetah/track_methods.py:80-281) on 48 drawn and special settings (tests/golden/ttensor_general.npz):
