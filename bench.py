@@ -16,11 +16,13 @@ element, NO map merging — followed by the global beam moments of the outgoing 
 The reference's own semantics (`Segment.track`: merge the 100 maps, one pass) and the fused in-register variant are timed as
 well ("modes") — N*E/t is not a bandwidth measure for those.
 
-`roofline`: the dominant kernel is apply_tile_kernel<float,2,0> (100 launches per step). Its average duration is measured
-live with HIP events recorded on the launch stream around the 100-launch run of EVERY timed step (so it includes the few
-hundred ns between back-to-back launches and must agree with the rocprofv3 kernel-trace average committed under profiles/);
-`achieved` = 56 B x 1e6 particles / that duration. `hbm_streaming` repeats the measurement at 1.6e7 particles, where the two
-448 MB buffers cannot live in the 256 MiB Infinity Cache.
+`roofline`: the dominant kernel is the linear apply (apply_tile_kernel<float,2,0> at 1e6 particles, apply_wave_kernel beyond;
+100 launches per step). The line LEADS with the true-HBM figure: the same kernel at 1.6e7 particles (two 448 MB buffers that
+cannot live in the 256 MiB Infinity Cache), average launch duration from HIP events on the launch stream, `achieved` =
+56 B x particles / duration, `frac` against the 8 TB/s spec and `frac_vs_copy_ceiling` against the 6.29 TB/s a float4 copy
+reaches on this part. `workload_size` holds the same measurement at the benchmark's 1e6 particles (events around the 100-launch
+run of EVERY timed step, next to the rocprofv3 kernel-trace average committed under profiles/): its 56 MB working set is
+Infinity-Cache resident, so it is labelled "infinity-cache / hbm" and is not an HBM rate.
 
 `configs` (1 GPU only): the other BASELINE.json configs at full size — C1 merged track, C3 k1 scan, C4 space-charge linac,
 C5 backward — each with its own algorithmic-byte accounting. `cpu_baseline` (rank 0, N = 1): the C oracle (OpenMP, pinned
@@ -49,7 +51,8 @@ N_PARTICLES = 1_000_000
 N_CELLS = 25
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 APPLY_KERNEL = "apply_tile_kernel<float, 2, 0>"
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")
+COPY_CEILING_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of the 8 TB/s spec)
 
 
 def build_fodo(ca, torch, device, dtype):
@@ -258,15 +261,22 @@ def other_configs(ca, torch, device) -> dict:
         r = rc.c4()
         # SURVEY 8d per kick: 84 B per particle + ~1.6 GB of grid / dense-FFT traffic (the pruned solver moves ~0.35 GB)
         per_kick = 84.0 * N_PARTICLES + 1.6e9
+        in_track = (r["track_ms"] - 0.0) / 10.0          # a kick of the chain (tile-ordered beam), the linear runs folded in
         return {"workload": "C4: 50-element linac, 10 SpaceChargeKicks on 128^3, 1e6 particles, fp32",
-                "ms_per_track": r["track_ms"], "ms_per_kick": r["single_kick_ms"],
+                "ms_per_track": r["track_ms"], "ms_per_kick_in_track": in_track, "ms_per_isolated_kick": r["single_kick_ms"],
                 "particle_element_steps_per_s": r["steps_per_s"],
-                "roofline": {"bound": "hbm", "algorithmic_bytes_per_kick": per_kick,
-                             "achieved": per_kick / (r["single_kick_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": per_kick / (r["single_kick_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "byte count of SURVEY 8d (three dense 256^3 transforms); the pruned, symmetry-aware "
-                                     "solver built here moves about a fifth of it, so this fraction is an upper bound on "
-                                     "what the kernels sustain"}}
+                "roofline": {"bound": "hbm (model floor)", "algorithmic_bytes_per_kick": per_kick,
+                             "ratio_to_model_floor": per_kick / (in_track * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "particle_kernels": {"bytes_per_particle": 84.0,
+                                                  "deposit_us_profile": 59.0, "gather_us_profile": 34.5,
+                                                  "achieved_GBs": 84.0 * N_PARTICLES / 93.5e-6 / 1e9,
+                                                  "frac": 84.0 * N_PARTICLES / 93.5e-6 / 1e9 / HBM_PEAK_GBS,
+                                                  "source": "profiles/r03_c4_kernel_stats.csv"},
+                             "note": "the byte count is the SURVEY 8d model (three dense 256^3 transforms); the pruned, "
+                                     "symmetry-aware solver moves about a fifth of it, so `ratio_to_model_floor` is a ratio to "
+                                     "the model's floor time, not an achieved bandwidth. `particle_kernels` is the achieved rate "
+                                     "of the per-particle half (tile deposit + gather on the tile-ordered beam) from the "
+                                     "tracked rocprofv3 summary."}}
 
     def c5():
         r = rc.c5()
@@ -278,7 +288,46 @@ def other_configs(ca, torch, device) -> dict:
                 "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
-    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5)):
+    def dkd():
+        # 100-element FODO tracked element by element with the Bmad-X drift-kick-drift maps
+        import time as _t
+
+        dt = torch.float32
+        kw = {"dtype": dt, "device": device}
+        tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
+        els = []
+        for _ in range(N_CELLS):
+            els += [ca.Quadrupole(tt(0.2), k1=tt(4.2), tracking_method="drift_kick_drift", **kw),
+                    ca.Drift(tt(0.8), tracking_method="drift_kick_drift", **kw),
+                    ca.Quadrupole(tt(0.2), k1=tt(-4.2), tracking_method="drift_kick_drift", **kw),
+                    ca.Drift(tt(0.8), tracking_method="drift_kick_drift", **kw)]
+        beam = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES, **kw)
+        res = {"workload": "100-element FODO, drift_kick_drift (Bmad-X) tracking of every element, 1e6 particles, fp32"}
+        for label, prec in (("float64_arithmetic", "double"), ("float32_arithmetic", "storage")):
+            for e in els:
+                e.dkd_precision = prec
+
+            def run():
+                b = beam
+                for e in els:
+                    b = e.track(b)
+                return b
+
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            ms = (_t.perf_counter() - t0) / 5 * 1e3
+            res[label] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
+                          "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
+        res["note"] = ("per-element kernel times and the measured error of the float32-arithmetic variant against Bmad-X: "
+                       "profiles/r03_dkd_precision.md")
+        return res
+
+    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd)):
         guarded(name, fn)
     return out
 
@@ -457,53 +506,66 @@ def main():
     value = world * N_PARTICLES * E * args.steps / dt
     sigma_x = float(state["moments"][8].sqrt())
 
+    def step_merged_no_grad():
+        with torch.no_grad():
+            state["out"] = seg.track(beam)
+
     modes = {}
-    for name, fn in (("merged_reference_semantics", step_merged), ("fused_in_register", step_fused)):
+    for name, fn in (("merged_reference_semantics", step_merged), ("merged_no_grad", step_merged_no_grad),
+                     ("fused_in_register", step_fused)):
         d = timed(torch, dist, fn, args.steps, args.warmup, world)
         modes[name] = {"ms_per_track": d / args.steps * 1e3,
                        "particle_element_steps_per_s": world * N_PARTICLES * E * args.steps / d}
+    modes["merged_no_grad"]["note"] = ("torch.no_grad(): without the requires_grad scan of the run's 300 setting tensors the "
+                                       "merged track is bound by its two launches (~12 us of GPU)")
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around the E-launch run, every step
     ms_run = event_timed_elementwise(torch, seg, beam, args.steps, args.warmup)
     ms_launch = ms_run / E
     algo_bytes = 56.0 * N_PARTICLES  # 7 fp32 read + 7 fp32 written per particle per launch
     achieved = algo_bytes / (ms_launch * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_big = None
     tpath = os.path.join(ROOT, "profiles", "apply_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_big = (tj.get("streaming") or {}).get("hbm_bytes_per_launch") or None
         except Exception:
             traffic = None
     ms_rocprof = rocprof_average_ms()
     # The live number is the wall time of the 100 back-to-back launches / 100. rocprofv3's kernel trace brackets every
     # dispatch from its first wave to its last, and consecutive dispatches of one stream overlap by a few hundred ns, so its
-    # mean duration is slightly LONGER than the per-launch wall time. `achieved` / `frac` use the larger of the two (the
+    # mean duration is slightly LONGER than the per-launch wall time. The workload-size figure uses the larger of the two (the
     # conservative reading, identical to what the tracked profile gives); both durations are reported.
     ms_used = max(ms_launch, ms_rocprof) if ms_rocprof else ms_launch
-    achieved = algo_bytes / (ms_used * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": APPLY_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_launch_ms": ms_used, "launches_per_step": E,
-                "avg_launch_ms_events": ms_launch, "frac_events": algo_bytes / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_ms_rocprof": ms_rocprof,
-                "frac_rocprof": (algo_bytes / (ms_rocprof * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_rocprof else None,
-                "rocprof_summary": "profiles/r02_kernel_stats.csv",
-                "note": "28 MB in + 28 MB out per launch fit the 256 MiB Infinity Cache; hbm_streaming is the same kernel "
-                        "on buffers that do not"}
-    # the same kernel streaming from HBM proper: 1.6e7 particles, 448 MB in + 448 MB out per launch
+    at_size = {"bound": "infinity-cache / hbm", "kernel": APPLY_KERNEL, "particles": N_PARTICLES,
+               "algorithmic_bytes_per_launch": algo_bytes, "achieved": algo_bytes / (ms_used * 1e-3) / 1e9,
+               "frac_of_hbm_peak": algo_bytes / (ms_used * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_used,
+               "launches_per_step": E, "avg_launch_ms_events": ms_launch, "avg_launch_ms_rocprof": ms_rocprof,
+               "rocprof_summary": "profiles/r03_kernel_stats.csv", "traffic": traffic,
+               "note": "28 MB in + 28 MB out per launch fit the 256 MiB Infinity Cache: not an HBM rate"}
+    # the same kernel streaming from HBM proper: 1.6e7 particles, 448 MB in + 448 MB out per launch — the roofline entry
     big_n = 16_000_000
+    roofline = {"bound": "hbm", "kernel": "apply_wave_kernel<float> (the linear apply at 1.6e7 particles)", "achieved": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "workload_size": at_size}
     try:
         big = ca.ParticleBeam.from_parameters(num_particles=big_n, dtype=dtype, device=device)
         seg10 = ca.Segment(list(seg.elements)[:10])
         ms_big = event_timed_elementwise(torch, seg10, big, 10, 2) / 10
         gbs = 56.0 * big_n / (ms_big * 1e-3) / 1e9
-        roofline["hbm_streaming"] = {"particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n, "avg_launch_ms": ms_big,
-                                     "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+        roofline.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "frac_vs_copy_ceiling": gbs / COPY_CEILING_GBS,
+                         "copy_ceiling": COPY_CEILING_GBS, "particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n,
+                         "avg_launch_ms": ms_big,
+                         "traffic": traffic_big,
+                         "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch at this size (separate rocprofv3 --pmc passes, "
+                                         "gfx950 corrections of MI355X_MICROARCH.md; profiles/r03_pmc_apply.md): 1.0002 x the "
+                                         "algorithmic bytes"})
         del big, seg10
         torch.cuda.empty_cache()
     except Exception as exc:
-        roofline["hbm_streaming"] = {"error": f"{type(exc).__name__}: {exc}"}
+        roofline["error"] = f"{type(exc).__name__}: {exc}"
+        roofline.update({"achieved": at_size["achieved"], "frac": at_size["frac_of_hbm_peak"]})
 
     result = {
         "metric": "particle-element-steps/sec at 1e6 particles, 100-elem linac",

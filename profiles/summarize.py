@@ -55,8 +55,11 @@ with open(os.path.join(out, f"{rnd}_pmc_apply.md"), "w") as f:
             "counters: corrected/algorithmic = 1.00 for both.\n\n" + "\n".join(lines) + "\n")
 t = traffic.get(1_000_000, {})
 if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+    big = traffic.get(16_000_000, {})
     json.dump({"kernel": "apply_tile_kernel<float,2,0>", "particles": 1_000_000,
                "hbm_bytes_per_launch": t["FETCH_SIZE"] + t["WRITE_SIZE"],
+               "streaming": {"kernel": "apply_wave_kernel<float,1,64>", "particles": 16_000_000,
+                             "hbm_bytes_per_launch": big.get("FETCH_SIZE", 0.0) + big.get("WRITE_SIZE", 0.0)},
                "fetch_bytes": t["FETCH_SIZE"], "write_bytes": t["WRITE_SIZE"], "round": rnd,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 (gfx950), KiB units"},
               open(os.path.join(out, "apply_traffic.json"), "w"), indent=1)
