@@ -83,8 +83,9 @@ def test_c4_full_size_vs_reference_and_oracle(ca, golden, oracle, tag):
     kick = np.max(np.abs(ref_out - ref_in), axis=0)
     err = np.max(np.abs((got_out - got_in) - (ref_out - ref_in)), axis=0)
     # tolerance as a fraction of the kick amplitude: fp64 1e-6 (test_gpu_parity.py::test_space_charge_kick_vs_reference);
-    # fp32 2e-2 against the fp64 reference (the reference's own fp32 kick is noisier than that)
-    tol = 1e-6 if tag == "f64" else 2e-2
+    # fp32 5e-4 against the fp64 reference — measured 2.2e-5 max / 5.6e-6 rms (benchmarks/sc_fp32_error.py, DESIGN.md
+    # section 5); the reference's own fp32 kick is noisier than that
+    tol = 1e-6 if tag == "f64" else 5e-4
     for c in (1, 3, 5):
         assert err[c] < tol * kick[c], (tag, c, err[c], kick[c])
     assert kick[1] > 0 and kick[3] > 0 and kick[5] > 0
