@@ -243,7 +243,7 @@ class Element(nn.Module):
     #: arithmetic of the drift-kick-drift (Bmad-X) kernels for float32 beams: "double" (default) evaluates every particle in
     #: float64 and rounds once — Bmad-X to ~1e-7 of a coordinate, fp64-VALU bound; "storage" evaluates in float32 like the
     #: reference's own tensor code (cheetah/utils/bmadx.py runs in the beam dtype) — one HBM-bound pass, measured errors in
-    #: DESIGN.md section 5. Set on an element (`quad.dkd_precision = "storage"`) or on the class for a whole lattice.
+    #: DESIGN.md section 6. Set on an element (`quad.dkd_precision = "storage"`) or on the class for a whole lattice.
     dkd_precision = "double"
     #: chx_dkd_kind / chx_t_kind of the element (include/chx.h); None = method not available
     _dkd_kind: int | None = None
