@@ -1264,189 +1264,57 @@ __global__ __launch_bounds__(kScSortThreads) void sc_tile_scatter_kernel(
     }
 }
 
-// The crosser list is appended to through a per-workgroup LDS buffer: atomics on ONE global counter cost ~5-8 ns each on
-// MI355X however they are spread over the chip (measured: 4 000 of them added 20 us to the deposit pass), so a workgroup
-// reserves its whole batch with one.
-constexpr int kScCrossBuf = 1024;
-
 // deposit, pass 1: one workgroup per tile over its slot range. LDS block = the tile's cells plus the +1 layer (fp64, ds_add:
 // see cic_accumulate_kernel). Owned cells are STORED (every grid cell belongs to one tile: no zero fill), the +1 layer goes to
-// the tile's face buffer; misfiled particles (and what a tile holds beyond kScTileCap) are listed for pass 3. On the way every
-// particle's CURRENT home tile is recorded (home[], newcount[]): what the gather pass needs to re-order the rows.
+// the tile's face buffer. A misfiled particle (and what a tile holds beyond kScTileCap) adds the corners that still fall into
+// this tile's block there and the others to the `cross` grid with global atomics right here — 4096 workgroups' worth of
+// parallelism for them; a list + a pass of its own behind this kernel cost 7 us at 1 % misfiled and 59 us at 17 % (C4's last
+// kick). On the way every particle's CURRENT home tile is recorded (home[], newcount[] — movers to the 26 neighbours are
+// counted in LDS first: their global atomics would pile up on a few lines). Slots are read four at a time per thread: the pass
+// is bound by the load -> ds_add chain of its fullest tiles.
+// Measured and dropped: an LDS queue for the misfiled particles with a dense pass (one lane per corner) behind the loop, with
+// and without the global atomics moved behind the last barrier — no faster at 1 % misfiled, 1.6 x slower at 25 %.
+constexpr int kScDepUnroll = 4;
+
 template <typename T>
 __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
                                                              const int* __restrict__ tile_start2 /*[2][nt+1]*/,
                                                              const T* __restrict__ src, const T* __restrict__ cs2 /*[2][N]*/,
                                                              const T* __restrict__ extent, const T* __restrict__ scale,
-                                                             T* __restrict__ grid, T* __restrict__ faces, int* __restrict__ crossers,
+                                                             T* __restrict__ grid, T* __restrict__ faces, T* __restrict__ cross,
                                                              uint16_t* __restrict__ home, int* __restrict__ newcount) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
-    __shared__ int nstay;
-    __shared__ int ncr, cr_base;
-    __shared__ int crbuf[kScCrossBuf];
+    __shared__ int nbr[27];
+    __shared__ int nstay, nmis;
     const int par = hdr->parity;
     const int* __restrict__ tile_start = tile_start2 + (int64_t)par * (g.nt + 1);
     const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
     const int t = blockIdx.x;
     const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
     const int BY = TZ + 1, BX = (TY + 1) * BY, ncell = (TX + 1) * BX;
-    int org[3];
-    {
-        int rem = t;
-        org[2] = (rem % g.ntile[2]) << g.tshift[2]; rem /= g.ntile[2];
-        org[1] = (rem % g.ntile[1]) << g.tshift[1]; rem /= g.ntile[1];
-        org[0] = rem << g.tshift[0];
-    }
-    const int beg = tile_start[t], end = tile_start[t + 1];
-    const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
-    for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
-    if (threadIdx.x == 0) { nstay = 0; ncr = 0; }
-    __syncthreads();
-    const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
-    int stay = 0;
-    for (int r0 = beg; r0 < end; r0 += 256) {
-        const int r = r0 + threadIdx.x;
-        bool push = false;
-        if (r < end) {
-            const T raw[3] = {src[(int64_t)r * 7 + a.cols[0]], src[(int64_t)r * 7 + a.cols[1]], src[(int64_t)r * 7 + a.cols[2]]};
-            const T c = cs[r];
-            int pi[3];
-            T pf[3];
-            const bool inside = sort_locate<T, 3>(a, ax, raw, pi, pf);
-            const int h = sc_home_tile(a, g, pi);
-            home[r] = (uint16_t)h;
-            if (h == t) ++stay; else atomicAdd(&newcount[h], 1);
-            const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
-            const bool in_tile = lx >= 0 && lx < TX && ly >= 0 && ly < TY && lz >= 0 && lz < TZ;
-            // misfiled (pass 3 deposits it if it lies inside the extent, and the gather's slow pass finds its potential), or
-            // the overflow of a hot tile
-            push = !in_tile || (inside && r >= lim);
-            if (inside && !push) {                      // outside the extent: no charge (cloud_in_cell.py:289-311)
-                {
-                    const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
-#pragma unroll
-                    for (int ox = 0; ox < 2; ++ox)
-#pragma unroll
-                        for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-                            for (int oz = 0; oz < 2; ++oz) {
-                                // pi >= org >= 0; the upper corner may leave the grid at its far end (weight dropped like the
-                                // reference's in-range mask)
-                                if (pi[0] + ox < a.bins[0] && pi[1] + oy < a.bins[1] && pi[2] + oz < a.bins[2])
-                                    unsafeAtomicAdd(&blk[(lx + ox) * BX + (ly + oy) * BY + (lz + oz)],
-                                                    (double)(c * (wx[ox] * wy[oy] * wz[oz])));
-                            }
-                }
-            }
-        }
-        if (push) {
-            const int k = atomicAdd(&ncr, 1);
-            if (k < kScCrossBuf) crbuf[k] = r;
-            else crossers[atomicAdd(&hdr->ncross, 1)] = r;       // beyond the buffer (a hot or thoroughly stale tile)
-        }
-    }
-    if (stay) atomicAdd(&nstay, stay);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (nstay) atomicAdd(&newcount[t], nstay);
-        const int m = ncr < kScCrossBuf ? ncr : kScCrossBuf;
-        cr_base = m ? atomicAdd(&hdr->ncross, m) : 0;
-        ncr = m;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < ncr; k += 256) crossers[cr_base + k] = crbuf[k];
-    T* __restrict__ fb = faces + (int64_t)t * sc_face_cells(g);
-    const bool occupied = end > beg;                  // an empty slot range leaves no +1 layer: pass 2 skips the tile
-    for (int i = threadIdx.x; i < ncell; i += 256) {
-        const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
-        const T v = (T)blk[i];
-        if (lx < TX && ly < TY && lz < TZ)
-            grid[(int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] + (int64_t)(org[2] + lz) * a.gstride[2]] = v;
-        else if (occupied)
-            fb[sc_face_index(g, lx, ly, lz)] = v;
-    }
-}
-
-// deposit, pass 2: every tile adds what its seven lower neighbours deposited into its low boundary cells (their +1 layers);
-// neighbours with an empty slot range have nothing to give
-template <typename T>
-__global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom g, const ScTileHeader* __restrict__ hdr,
-                                                           const int* __restrict__ tile_start2, const T* __restrict__ faces,
-                                                           T* __restrict__ grid) {
-    const int* __restrict__ tile_start = tile_start2 + (int64_t)hdr->parity * (g.nt + 1);
-    const int t = blockIdx.x;
-    const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
-    int tc[3];
+    int tc[3], org[3];
     {
         int rem = t;
         tc[2] = rem % g.ntile[2]; rem /= g.ntile[2];
         tc[1] = rem % g.ntile[1]; rem /= g.ntile[1];
         tc[0] = rem;
-    }
-    int nb[8];          // neighbour (dx, dy, dz) = bits of k: tile index, or -1 (outside the grid / empty)
-    bool any = false;
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        const int nx = tc[0] - (k & 1), ny = tc[1] - ((k >> 1) & 1), nz = tc[2] - ((k >> 2) & 1);
-        int id = -1;
-        if (nx >= 0 && ny >= 0 && nz >= 0) {
-            id = (nx * g.ntile[1] + ny) * g.ntile[2] + nz;
-            if (tile_start[id + 1] <= tile_start[id]) id = -1;
-        }
-        nb[k] = id;
-        any = any || id >= 0;
+        for (int d = 0; d < 3; ++d) org[d] = tc[d] << g.tshift[d];
     }
-    if (!any) return;
-    const int nf = sc_face_cells(g);
-    auto face = [&](int k, int lx, int ly, int lz) -> T {
-        return nb[k] < 0 ? (T)0 : faces[(int64_t)nb[k] * nf + sc_face_index(g, lx, ly, lz)];
-    };
-    // the low boundary cells only: planes lx = 0, ly = 0 (lx > 0), lz = 0 (lx, ly > 0)
-    const int nX = TY * TZ, nY = (TX - 1) * TZ, nZ = (TX - 1) * (TY - 1);
-    for (int i = threadIdx.x; i < nX + nY + nZ; i += 256) {
-        int lx, ly, lz;
-        if (i < nX) { lx = 0; ly = i / TZ; lz = i % TZ; }
-        else if (i < nX + nY) { const int j = i - nX; lx = 1 + j / TZ; ly = 0; lz = j % TZ; }
-        else { const int j = i - nX - nY; lx = 1 + j / (TY - 1); ly = 1 + j % (TY - 1); lz = 0; }
-        T add = (T)0;
-        if (lx == 0) add += face(1, TX, ly, lz);
-        if (ly == 0) add += face(2, lx, TY, lz);
-        if (lz == 0) add += face(4, lx, ly, TZ);
-        if (lx == 0 && ly == 0) add += face(3, TX, TY, lz);
-        if (lx == 0 && lz == 0) add += face(5, TX, ly, TZ);
-        if (ly == 0 && lz == 0) add += face(6, lx, TY, TZ);
-        if (lx == 0 && ly == 0 && lz == 0) add += face(7, TX, TY, TZ);
-        if (add == (T)0) continue;
-        const int64_t off = (int64_t)((tc[0] << g.tshift[0]) + lx) * a.gstride[0] + (int64_t)((tc[1] << g.tshift[1]) + ly) * a.gstride[1] +
-                            (int64_t)((tc[2] << g.tshift[2]) + lz) * a.gstride[2];
-        grid[off] += add;
-    }
-}
-
-// deposit, pass 3: the listed particles with global float atomics (the arithmetic of cic_deposit_kernel). The last workgroup to
-// finish decides whether the rows are re-ordered by this kick's gather pass (more than 1/16 of the beam misfiled, and a later
-// kick to profit from it) and, if so, turns the new tile populations into the slot cursors and the next tile starts.
-template <typename T>
-__global__ __launch_bounds__(256) void sc_tile_crossers_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
-                                                              const int* __restrict__ crossers, const T* __restrict__ src,
-                                                              const T* __restrict__ cs2, const T* __restrict__ extent,
-                                                              const T* __restrict__ scale, T* __restrict__ grid,
-                                                              int* __restrict__ newcount, int* __restrict__ cursor,
-                                                              int* __restrict__ tile_start2, int allow_reorder) {
-    __shared__ int is_last;
-    __shared__ int part[256];
-    const int par = hdr->parity;
-    const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
-    const int n = hdr->ncross;
+    const int beg = tile_start[t], end = tile_start[t + 1];
+    const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
+    for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
+    if (threadIdx.x < 27) nbr[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { nstay = 0; nmis = 0; }
+    __syncthreads();
     const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int r = crossers[i];
-        const T raw[3] = {src[(int64_t)r * 7 + a.cols[0]], src[(int64_t)r * 7 + a.cols[1]], src[(int64_t)r * 7 + a.cols[2]]};
-        const T c = cs[r];
-        int pi[3];
-        T pf[3];
-        if (!sort_locate<T, 3>(a, ax, raw, pi, pf)) continue;
+    int stay = 0, mis = 0;
+    // corners of a particle outside this tile's cells: those that still fall into the tile's block go there (a particle one cell
+    // beyond a face keeps half of its corners out of the global atomics), the others to `cross` — the arithmetic of
+    // cic_deposit_kernel
+    auto slow_corners = [&](const int (&pi)[3], const T (&pf)[3], T c, bool lds_ok) {
+        const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
         const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)
@@ -1455,48 +1323,201 @@ __global__ __launch_bounds__(256) void sc_tile_crossers_kernel(CicDev a, ScTileG
 #pragma unroll
                 for (int oz = 0; oz < 2; ++oz) {
                     const int ix = pi[0] + ox, iy = pi[1] + oy, iz = pi[2] + oz;
-                    if (ix >= 0 && ix < a.bins[0] && iy >= 0 && iy < a.bins[1] && iz >= 0 && iz < a.bins[2])
-                        unsafeAtomicAdd(grid + (int64_t)ix * a.gstride[0] + (int64_t)iy * a.gstride[1] + (int64_t)iz * a.gstride[2],
-                                        c * (wx[ox] * wy[oy] * wz[oz]));
+                    if (!(ix >= 0 && ix < a.bins[0] && iy >= 0 && iy < a.bins[1] && iz >= 0 && iz < a.bins[2])) continue;
+                    const T v = c * (wx[ox] * wy[oy] * wz[oz]);
+                    const int bx = lx + ox, by = ly + oy, bz = lz + oz;
+                    if (lds_ok && bx >= 0 && bx <= TX && by >= 0 && by <= TY && bz >= 0 && bz <= TZ)
+                        unsafeAtomicAdd(&blk[bx * BX + by * BY + bz], (double)v);
+                    else
+                        unsafeAtomicAdd(cross + (int64_t)ix * a.gstride[0] + (int64_t)iy * a.gstride[1] + (int64_t)iz * a.gstride[2], v);
                 }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(&hdr->ticket, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
-    // exclusive scan of the new tile populations (all deposit workgroups are done: this kernel runs behind them)
-    const int per = (g.nt + 255) / 256;
-    const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
-    int sum = 0;
-    if (reorder)
-        for (int t = lo; t < hi; ++t) sum += newcount[t];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    int run = 0;
-    for (int k = 0; k < (int)threadIdx.x; ++k) run += part[k];
-    int* __restrict__ ts_next = tile_start2 + (int64_t)(par ^ 1) * (g.nt + 1);
-    for (int t = lo; t < hi; ++t) {
-        const int c = newcount[t];
-        if (reorder) {
-            cursor[t] = run;
-            ts_next[t] = run;
-            run += c;
+    };
+    for (int r0 = beg; r0 < end; r0 += 256 * kScDepUnroll) {
+        T raw[kScDepUnroll][3], cq[kScDepUnroll];
+#pragma unroll
+        for (int u = 0; u < kScDepUnroll; ++u) {
+            const int r = r0 + u * 256 + (int)threadIdx.x;
+            const int rr = r < end ? r : beg;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) raw[u][d] = src[(int64_t)rr * 7 + a.cols[d]];
+            cq[u] = cs[rr];
         }
-        newcount[t] = 0;                            // ready for the next kick
-    }
-    if (threadIdx.x == 255 && reorder) ts_next[g.nt] = run;
-    if (threadIdx.x == 0) {
-        hdr->last_ncross = n;
-        hdr->ticket = 0;
-        if (reorder) {
-            hdr->scatter_now = 1;
-            hdr->n_sorts += 1;
+#pragma unroll
+        for (int u = 0; u < kScDepUnroll; ++u) {
+            const int r = r0 + u * 256 + (int)threadIdx.x;
+            if (r >= end) continue;
+            int pi[3];
+            T pf[3];
+            const bool inside = sort_locate<T, 3>(a, ax, raw[u], pi, pf);
+            int hc[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                hc[d] = (pi[d] < 0 ? 0 : (pi[d] > a.bins[d] - 1 ? a.bins[d] - 1 : pi[d])) >> g.tshift[d];   // = sc_home_tile
+            const int h = (hc[0] * g.ntile[1] + hc[1]) * g.ntile[2] + hc[2];
+            home[r] = (uint16_t)h;
+            if (h == t) ++stay;
+            else {
+                const int dx = hc[0] - tc[0], dy = hc[1] - tc[1], dz = hc[2] - tc[2];
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) atomicAdd(&nbr[(dx + 1) * 9 + (dy + 1) * 3 + dz + 1], 1);
+                else atomicAdd(&newcount[h], 1);
+            }
+            const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
+            const bool in_tile = lx >= 0 && lx < TX && ly >= 0 && ly < TY && lz >= 0 && lz < TZ;
+            if (!in_tile) ++mis;
+            if (!inside) continue;                      // outside the extent: no charge (cloud_in_cell.py:289-311)
+            const T c = cq[u];
+            if (in_tile && r < lim) {
+                const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                        for (int oz = 0; oz < 2; ++oz) {
+                            // pi >= org >= 0; the upper corner may leave the grid at its far end (weight dropped like the
+                            // reference's in-range mask)
+                            if (pi[0] + ox < a.bins[0] && pi[1] + oy < a.bins[1] && pi[2] + oz < a.bins[2])
+                                unsafeAtomicAdd(&blk[(lx + ox) * BX + (ly + oy) * BY + (lz + oz)], (double)(c * (wx[ox] * wy[oy] * wz[oz])));
+                        }
+            } else {                                     // misfiled, or the overflow of a hot tile
+                slow_corners(pi, pf, c, r < lim);
+            }
         }
+    }
+    if (stay) atomicAdd(&nstay, stay);
+    if (mis) atomicAdd(&nmis, mis);
+    __syncthreads();
+    if (threadIdx.x < 27 && nbr[threadIdx.x]) {        // a counted neighbour holds the particle's clamped cell: it exists
+        const int k = threadIdx.x;
+        const int nb = ((tc[0] + k / 9 - 1) * g.ntile[1] + (tc[1] + (k / 3) % 3 - 1)) * g.ntile[2] + (tc[2] + k % 3 - 1);
+        atomicAdd(&newcount[nb], nbr[k]);
+    }
+    if (threadIdx.x == 32 && nstay) atomicAdd(&newcount[t], nstay);
+    T* __restrict__ fb = faces + (int64_t)t * sc_face_cells(g);
+    for (int i = threadIdx.x; i < ncell; i += 256) {
+        const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
+        const T v = (T)blk[i];
+        if (lx < TX && ly < TY && lz < TZ)
+            grid[(int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] + (int64_t)(org[2] + lz) * a.gstride[2]] = v;
+        else
+            fb[sc_face_index(g, lx, ly, lz)] = v;      // (zeros from an empty tile: pass 2 reads every face unconditionally)
+    }
+    if (threadIdx.x == 64 && nmis) atomicAdd(&hdr->ncross, nmis);   // (reset by the geometry kernel of the next kick)
+}
+
+// deposit, pass 2: every cell takes what the misfiled particles left for it in `cross` (cleared on the way) and, on the low
+// boundary planes of its tile, what the seven lower neighbour tiles deposited into their +1 layers. One extra workgroup decides
+// whether the rows are re-ordered by this kick's gather pass (more than 1/16 of the beam misfiled, and a later kick to profit
+// from it) and, if so, turns the new tile populations into the slot cursors and the next tile starts. (A ticket at the end of
+// pass 1 instead needs a device-scope release per workgroup: 4096 L2 write-backs took that kernel from 30 to 500 us.)
+template <typename T>
+__global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr, const T* __restrict__ faces,
+                                                           T* __restrict__ cross, T* __restrict__ grid, int* __restrict__ newcount,
+                                                           int* __restrict__ cursor, int* __restrict__ tile_start2, int allow_reorder) {
+    const int t = blockIdx.x;
+    if (t == (int)gridDim.x - 1) {
+        __shared__ int part[256];
+        const int n = hdr->ncross;
+        const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
+        const int per = (g.nt + 255) / 256;
+        const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
+        int sum = 0;
+        for (int k = lo; k < hi; ++k) sum += newcount[k];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {        // inclusive Hillis-Steele over the 256 partial sums
+            const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int run = part[threadIdx.x] - sum;
+        int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
+        for (int k = lo; k < hi; ++k) {
+            const int c = newcount[k];
+            if (reorder) {
+                cursor[k] = run;
+                ts_next[k] = run;
+                run += c;
+            }
+            newcount[k] = 0;                            // ready for the next kick
+        }
+        if (threadIdx.x == 255 && reorder) ts_next[g.nt] = part[255];
+        if (threadIdx.x == 0) {
+            hdr->last_ncross = n;
+            if (reorder) {
+                hdr->scatter_now = 1;
+                hdr->n_sorts += 1;
+            }
+        }
+        return;
+    }
+    // four tiles per workgroup, one thread per z-row of 8 cells (tiles are 8^3: sc_tile_prepare), every load issued before
+    // the first use: the pass is a chain of load latencies, not of bytes
+    constexpr int TX = kScTdim, TY = kScTdim, TZ = kScTdim;
+    const int tile = t * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= g.nt) return;
+    const int lx = (threadIdx.x >> 3) & 7, ly = threadIdx.x & 7;
+    int tc[3];
+    {
+        int rem = tile;
+        tc[2] = rem % g.ntile[2]; rem /= g.ntile[2];
+        tc[1] = rem % g.ntile[1]; rem /= g.ntile[1];
+        tc[0] = rem;
+    }
+    const int nf = sc_face_cells(g);
+    // neighbour (dx, dy, dz) = bits of k: its face buffer, or null (outside the grid)
+    auto fbuf = [&](int k) -> const T* {
+        const int nx = tc[0] - (k & 1), ny = tc[1] - ((k >> 1) & 1), nz = tc[2] - ((k >> 2) & 1);
+        return (nx >= 0 && ny >= 0 && nz >= 0) ? faces + (int64_t)((nx * g.ntile[1] + ny) * g.ntile[2] + nz) * nf : nullptr;
+    };
+    const int64_t off = (int64_t)(tc[0] * TX + lx) * a.gstride[0] + (int64_t)(tc[1] * TY + ly) * a.gstride[1] + (int64_t)(tc[2] * TZ);
+    T cr[TZ], gv[TZ], add[TZ];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) {
+        cr[z] = cross[off + z];
+        gv[z] = grid[off + z];
+        add[z] = (T)0;
+    }
+    if (const T* f = fbuf(4)) add[0] += f[sc_face_index(g, lx, ly, TZ)];
+    if (lx == 0) {
+        if (const T* f = fbuf(1)) {
+            const T* row = f + sc_face_index(g, TX, ly, 0);
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) add[z] += row[z];
+        }
+        if (const T* f = fbuf(5)) add[0] += f[sc_face_index(g, TX, ly, TZ)];
+    }
+    if (ly == 0) {
+        if (const T* f = fbuf(2)) {
+            const T* row = f + sc_face_index(g, lx, TY, 0);
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) add[z] += row[z];
+        }
+        if (const T* f = fbuf(6)) add[0] += f[sc_face_index(g, lx, TY, TZ)];
+    }
+    if (lx == 0 && ly == 0) {
+        if (const T* f = fbuf(3)) {
+            const T* row = f + sc_face_index(g, TX, TY, 0);
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) add[z] += row[z];
+        }
+        if (const T* f = fbuf(7)) add[0] += f[sc_face_index(g, TX, TY, TZ)];
+    }
+    bool any_cr = false, any = false;
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) {
+        any_cr = any_cr || cr[z] != (T)0;
+        add[z] += cr[z];
+        any = any || add[z] != (T)0;
+    }
+    if (any_cr) {
+#pragma unroll
+        for (int z = 0; z < TZ; ++z) cross[off + z] = (T)0;
+    }
+    if (any) {
+#pragma unroll
+        for (int z = 0; z < TZ; ++z) grid[off + z] = gv[z] + add[z];
     }
 }
 
@@ -1547,14 +1568,10 @@ int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLay
     const size_t blk_bytes = (size_t)(g.tdim[0] + 1) * (g.tdim[1] + 1) * (g.tdim[2] + 1) * sizeof(double);
     hipLaunchKernelGGL(sc_tile_deposit_kernel<T>, dim3((unsigned)g.nt), dim3(256), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
                        (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)grid, (T*)(st + L.faces),
-                       (int*)(st + L.crossers), (uint16_t*)(st + L.home), (int*)(st + L.newcount));
+                       (T*)(st + L.cross), (uint16_t*)(st + L.home), (int*)(st + L.newcount));
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sc_tile_merge_kernel<T>, dim3((unsigned)g.nt), dim3(256), 0, s, a, g, (const ScTileHeader*)hdr,
-                       (const int*)(st + L.tile_start[0]), (const T*)(st + L.faces), (T*)grid);
-    CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sc_tile_crossers_kernel<T>, dim3(128), dim3(256), 0, s, a, g, hdr, (const int*)(st + L.crossers), (const T*)rows,
-                       (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)grid, (int*)(st + L.newcount), (int*)(st + L.cursor),
-                       (int*)(st + L.tile_start[0]), allow_reorder);
+    hipLaunchKernelGGL(sc_tile_merge_kernel<T>, dim3((unsigned)(g.nt + 3) / 4 + 1), dim3(256), 0, s, a, g, hdr, (const T*)(st + L.faces),
+                       (T*)(st + L.cross), (T*)grid, (int*)(st + L.newcount), (int*)(st + L.cursor), (int*)(st + L.tile_start[0]), allow_reorder);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

@@ -509,11 +509,23 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_table_near_kernel(const T* __re
     const FarGeom f = far_geom<T>(cell, gamma, b);
     const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
     const int fast = (f.dx <= f.dy && f.dx <= f.dt) ? 0 : (f.dy <= f.dt ? 1 : 2);
-    const int n0 = gx + 1, n1 = gy + 1, n2 = gz + 1;
+    const int n1 = gy + 1, n2 = gz + 1;
+    // bounding box of the needed points: point p is needed only if (p - 1) h < 1.001^(1/2) x threshold along its axis (the
+    // threads run over the box, not over the (g + 1)^3 points: for a relativistic bunch it is the slab k <= 9 of 129)
+    const double reach = sqrt(f.thr2 * 1.001);
+    const double h[3] = {f.dx, f.dy, f.dt};
+    const int full[3] = {gx + 1, gy + 1, gz + 1};
+    int box[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double m = reach / h[d] + 2.0;
+        box[d] = m < (double)full[d] ? (int)m : full[d];
+    }
     // extents in thread order (fast, mid, slow)
-    const int nf = fast == 0 ? n0 : (fast == 1 ? n1 : n2);
-    const int nm = fast == 0 ? n1 : n0;                       // mid = x unless x is the fast axis
-    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)npts; idx += gridDim.x * CHX_BLOCK) {
+    const int nf = box[fast];
+    const int nm = fast == 0 ? box[1] : box[0];                       // mid = x unless x is the fast axis
+    const unsigned nbox = (unsigned)box[0] * (unsigned)box[1] * (unsigned)box[2];
+    for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < nbox; idx += gridDim.x * CHX_BLOCK) {
         const unsigned q1 = idx / (unsigned)nf;
         const int pf = (int)(idx - q1 * (unsigned)nf);
         const unsigned q2 = q1 / (unsigned)nm;
@@ -532,6 +544,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_table_near_kernel(const T* __re
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void igf_compact_far_kernel(const double* __restrict__ table, const T* __restrict__ cell,
                                                                    const T* __restrict__ gamma, int gx, int gy, int gz,
+                                                                   unsigned long long magic_z, unsigned long long magic_y,
                                                                    T* __restrict__ Gc) {
     const int64_t b = blockIdx.y;
     const FarGeom f = far_geom<T>(cell, gamma, b);
@@ -545,12 +558,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void igf_compact_far_kernel(const double
     const float dxf = (float)f.dx, dyf = (float)f.dy, dtf = (float)f.dt;
     const float Vf = (float)(f.dx * f.dy * f.dt), hx2 = dxf * dxf, hy2 = dyf * dyf, hz2 = dtf * dtf;
     const float thr2f = (float)f.thr2;
-    // 32-bit index arithmetic: (g + 1)^3 <= 1025^3 < 2^31
+    // index arithmetic: (g + 1)^3 <= 513^3 < 2^28, and idx / d = (idx * (2^38 / d + 1)) >> 38 exactly for idx < 2^28, d < 2^10
+    // (two unsigned divisions by run-time values were half of this kernel's 10 us)
     const unsigned n1u = (unsigned)(gz + 1), n2u = (unsigned)(gy + 1);
     for (unsigned idx = blockIdx.x * CHX_BLOCK + threadIdx.x; idx < (unsigned)npts; idx += gridDim.x * CHX_BLOCK) {
-        const unsigned q1 = idx / n1u;
+        const unsigned q1 = (unsigned)(((unsigned long long)idx * magic_z) >> 38);
         const int k = (int)(idx - q1 * n1u);
-        const unsigned q2 = q1 / n2u;
+        const unsigned q2 = (unsigned)(((unsigned long long)q1 * magic_y) >> 38);
         const int j = (int)(q1 - q2 * n2u);
         const int i = (int)q2;
         T g = (T)0;
@@ -630,7 +644,7 @@ static int green_spectrum_impl(const double* table, const T* cell, const T* gamm
     int grid = chx_grid_for(n1, CHX_BLOCK, 4096);
     if (cell)
         hipLaunchKernelGGL(igf_compact_far_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, cell,
-                           gamma, gx, gy, gz, Gc);
+                           gamma, gx, gy, gz, (1ull << 38) / (unsigned)(gz + 1) + 1, (1ull << 38) / (unsigned)(gy + 1) + 1, Gc);
     else
         hipLaunchKernelGGL(igf_compact_kernel<T>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, gx, gy, gz, Gc);
     CHX_CHECK_LAUNCH();
@@ -684,7 +698,7 @@ extern "C" int chx_sc_green_spectrum_fast(const void* cell, const void* gamma, i
         if (st != CHX_OK) return st;
         return green_spectrum_impl<double>(table, nullptr, nullptr, B, bins, (double*)Ghat, (double*)rest, s);
     }
-    const int grid = chx_grid_for((int64_t)npts, CHX_BLOCK, 8192);
+    const int grid = chx_grid_for((int64_t)npts, CHX_BLOCK, 2048);
     hipLaunchKernelGGL(igf_table_near_kernel<float>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, (const float*)cell,
                        (const float*)gamma, bins[0], bins[1], bins[2], table);
     CHX_CHECK_LAUNCH();

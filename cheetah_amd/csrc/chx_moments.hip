@@ -739,9 +739,19 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
     double a[kSG];
 #pragma unroll
     for (int k = 0; k < kSG; ++k) a[k] = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += CHX_BLOCK) {
+    // four blocks per lane and step, all 32 loads in flight together (one workgroup: the kernel is a chain of load latencies)
+    for (int i0 = threadIdx.x; i0 < nblk; i0 += 4 * CHX_BLOCK) {
+        double v[4][kSG];
 #pragma unroll
-        for (int k = 0; k < kSG; ++k) a[k] += pb[(int64_t)k * nblk + i];
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * CHX_BLOCK;
+#pragma unroll
+            for (int k = 0; k < kSG; ++k) v[u][k] = i < nblk ? pb[(int64_t)k * nblk + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < kSG; ++k) a[k] += v[u][k];
     }
 #pragma unroll
     for (int k = 0; k < kSG; ++k) a[k] = chx_row16_sum(a[k]);

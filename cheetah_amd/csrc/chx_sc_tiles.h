@@ -9,10 +9,12 @@
 //   * gather: the per-particle kernel of the untiled path on the ordered rows — the lanes of a wave sit in one tile, so the 12
 //     line requests per particle for the 32 potential values around its cell hit the CU's vector cache (63 -> 33 us at 1e6
 //     particles on 128^3); it also accumulates the beam sizes the next kick's grid needs over the rows it writes;
-//   * a particle that has left the tile of its slot ("crosser", ~1 % per kick) is still handled exactly — global float atomics
-//     for its eight corners (the gather reads the potential from global memory anyway); when more than 1/16 of the beam is misfiled the gather pass of
-//     that very kick writes its rows in the new tile order (the deposit pass counted the new tile populations on the way): a
-//     device-side decision, no host synchronisation and no extra launch.
+//   * a particle that has left the tile of its slot ("crosser": 1 % of the beam per kick in a smooth channel, 10-20 % where the
+//     beam goes through a focus) is still handled exactly — the deposit workgroup adds its eight corners with global float
+//     atomics to a second, otherwise zero grid that the face-merge pass folds in (and clears); the gather reads the potential
+//     from global memory anyway. When more than 1/16 of the beam is misfiled the gather pass of that very kick writes its rows
+//     in the new tile order (the deposit pass counted the new tile populations on the way): a device-side decision (one extra workgroup
+//     of the face-merge pass), no host synchronisation and no extra launch.
 // The permutation back to the caller's particle order is carried along and applied by the last kick of the chain.
 #pragma once
 #include <stddef.h>
@@ -25,12 +27,13 @@ struct ScTileHeader {
     int parity;        // which copy of tile_start / perm / ws / cs is current
     int scatter_now;   // this kick's gather writes its rows in a NEW tile order (decided by the crosser pass of the same kick);
                        // the geometry kernel of the next kick then flips `parity` and clears the flag
-    int ncross;        // crosser list length of the running kick (reset by the geometry kernel of the next one)
-    int ticket;        // workgroups of the crosser pass that are done
-    int last_ncross;   // diagnostics: crosser count of the last finished deposit ...
+    int ncross;        // misfiled particles found by the running deposit pass (reset by the geometry kernel of the next kick)
+    int reserved;
+    int last_ncross;   // diagnostics: that count for the last finished deposit ...
     int n_sorts;       // ... and how many times the chain (re)ordered its rows so far
     int pad[2];
 };
+static_assert(sizeof(ScTileHeader) == 32, "the host reads the header as eight ints");
 
 constexpr int kScSortWG = 256;       // workgroups of the count / scatter passes
 constexpr int kScSortThreads = 1024;
@@ -81,9 +84,9 @@ static __host__ __device__ inline int sc_face_index(const ScTileGeom& g, int lx,
 
 // byte offsets of the pieces of the state buffer (B = 1); [2] = one copy per parity
 struct ScTileLayout {
-    size_t hdr, newcount, cursor, tile_start[2], counts, totals, perm[2], ws[2], cs[2], home, rows_tmp, faces, crossers, sigma, total;
+    size_t hdr, newcount, cross, cursor, tile_start[2], counts, totals, perm[2], ws[2], cs[2], home, rows_tmp, faces, sigma, total;
     int64_t sigma_blocks;   // workgroups of the gather pass = partial sums per moment handed to the next kick's geometry kernel
-    size_t zero_bytes;   // header + newcount: cleared by the first kick of a chain
+    size_t zero_bytes;   // header + newcount + the crossers' grid: cleared by the first kick of a chain
 };
 
 static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dtype) {
@@ -94,6 +97,7 @@ static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dt
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     L.hdr = take(sizeof(ScTileHeader));
     L.newcount = take((size_t)g.nt * sizeof(int));
+    L.cross = take((size_t)bins[0] * bins[1] * bins[2] * esz);   // what misfiled particles deposit; all zero between two kicks
     L.zero_bytes = off;
     L.cursor = take((size_t)g.nt * sizeof(int));
     // the two copies of a double-buffered array are contiguous: copy p starts p * (element count) elements behind copy 0
@@ -110,7 +114,6 @@ static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dt
     L.home = take((size_t)N * sizeof(uint16_t));
     L.rows_tmp = take((size_t)N * 7 * esz);
     L.faces = take((size_t)g.nt * sc_face_cells(g) * esz);
-    L.crossers = take((size_t)N * sizeof(int));
     L.sigma_blocks = (N + 255) / 256;
     L.sigma = take((size_t)8 * L.sigma_blocks * sizeof(double));
     L.total = off;
