@@ -14,7 +14,7 @@ from cheetah_amd import _lib, _ops  # noqa: E402
 dt = torch.float32
 kw = {"dtype": dt, "device": "cuda"}
 t = lambda v: torch.tensor(v, **kw)  # noqa: E731
-N, bins = 1_000_000, (128, 128, 128)
+N, bins = int(os.environ.get("NPART", "1000000")), (128, 128, 128)
 lib = _lib.lib()
 beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=N, total_charge=t(1e-9), energy=t(2.5e8), radius_x=t(1e-3), radius_y=t(1e-3),
                                             radius_tau=t(1e-3), sigma_px=t(1e-6), sigma_py=t(1e-6), sigma_p=t(1e-6), **kw)

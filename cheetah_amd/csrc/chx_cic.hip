@@ -1275,6 +1275,7 @@ __global__ __launch_bounds__(kScSortThreads) void sc_tile_scatter_kernel(
 // Measured and dropped: an LDS queue for the misfiled particles with a dense pass (one lane per corner) behind the loop, with
 // and without the global atomics moved behind the last barrier — no faster at 1 % misfiled, 1.6 x slower at 25 %.
 constexpr int kScDepUnroll = 4;
+constexpr int kScCrossQ = 512;
 
 template <typename T>
 __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
@@ -1282,11 +1283,14 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
                                                              const T* __restrict__ src, const T* __restrict__ cs2 /*[2][N]*/,
                                                              const T* __restrict__ extent, const T* __restrict__ scale,
                                                              T* __restrict__ grid, T* __restrict__ faces, T* __restrict__ cross,
-                                                             uint16_t* __restrict__ home, int* __restrict__ newcount) {
+                                                             uint16_t* __restrict__ home, int* __restrict__ newcount,
+                                                             int* __restrict__ tile_mis) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
-    __shared__ int nstay, nmis;
+    __shared__ int nstay, nmis, nq;
+    __shared__ int qcell[kScCrossQ];
+    __shared__ T qf[kScCrossQ * 4];
     const int par = hdr->parity;
     const int* __restrict__ tile_start = tile_start2 + (int64_t)par * (g.nt + 1);
     const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
@@ -1306,14 +1310,14 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
     const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
     for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
     if (threadIdx.x < 27) nbr[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { nstay = 0; nmis = 0; }
+    if (threadIdx.x == 0) { nstay = 0; nmis = 0; nq = 0; }
     __syncthreads();
     const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
     int stay = 0, mis = 0;
     // corners of a particle outside this tile's cells: those that still fall into the tile's block go there (a particle one cell
     // beyond a face keeps half of its corners out of the global atomics), the others to `cross` — the arithmetic of
     // cic_deposit_kernel
-    auto slow_corners = [&](const int (&pi)[3], const T (&pf)[3], T c, bool lds_ok) {
+    auto slow_corners = [&](const int (&pi)[3], const T (&pf)[3], T c, bool lds_ok, int part /*1 block, 2 cross*/) {
         const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
         const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
 #pragma unroll
@@ -1326,9 +1330,9 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
                     if (!(ix >= 0 && ix < a.bins[0] && iy >= 0 && iy < a.bins[1] && iz >= 0 && iz < a.bins[2])) continue;
                     const T v = c * (wx[ox] * wy[oy] * wz[oz]);
                     const int bx = lx + ox, by = ly + oy, bz = lz + oz;
-                    if (lds_ok && bx >= 0 && bx <= TX && by >= 0 && by <= TY && bz >= 0 && bz <= TZ)
-                        unsafeAtomicAdd(&blk[bx * BX + by * BY + bz], (double)v);
-                    else
+                    if (lds_ok && bx >= 0 && bx <= TX && by >= 0 && by <= TY && bz >= 0 && bz <= TZ) {
+                        if (part & 1) unsafeAtomicAdd(&blk[bx * BX + by * BY + bz], (double)v);
+                    } else if (part & 2)
                         unsafeAtomicAdd(cross + (int64_t)ix * a.gstride[0] + (int64_t)iy * a.gstride[1] + (int64_t)iz * a.gstride[2], v);
                 }
     };
@@ -1379,8 +1383,14 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
                             if (pi[0] + ox < a.bins[0] && pi[1] + oy < a.bins[1] && pi[2] + oz < a.bins[2])
                                 unsafeAtomicAdd(&blk[(lx + ox) * BX + (ly + oy) * BY + (lz + oz)], (double)(c * (wx[ox] * wy[oy] * wz[oz])));
                         }
-            } else {                                     // misfiled, or the overflow of a hot tile
-                slow_corners(pi, pf, c, r < lim);
+            } else {                                     // misfiled, or the overflow of a hot tile: block corners now, the global
+                slow_corners(pi, pf, c, r < lim, 1);     // atomics behind the last barrier (queued; inline once the queue is full)
+                const int k = atomicAdd(&nq, 1);
+                if (k < kScCrossQ) {
+                    qcell[k] = (pi[0] + 2) | ((pi[1] + 2) << 10) | ((pi[2] + 2) << 20) | (r < lim ? (1 << 30) : 0);
+                    qf[k * 4 + 0] = pf[0]; qf[k * 4 + 1] = pf[1]; qf[k * 4 + 2] = pf[2]; qf[k * 4 + 3] = c;
+                } else
+                    slow_corners(pi, pf, c, r < lim, 2);
             }
         }
     }
@@ -1402,7 +1412,16 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
         else
             fb[sc_face_index(g, lx, ly, lz)] = v;      // (zeros from an empty tile: pass 2 reads every face unconditionally)
     }
-    if (threadIdx.x == 64 && nmis) atomicAdd(&hdr->ncross, nmis);   // (reset by the geometry kernel of the next kick)
+    if (threadIdx.x == 64) tile_mis[t] = nmis;   // summed by pass 2 (one atomic per workgroup on a header word instead: 1000 of them
+                                                 // on one address, 5-8 ns each, were the 8 us this kernel lost at 1 % misfiled)
+    // the queued global atomics: nothing in this workgroup waits for them any more
+    const int nqv = nq < kScCrossQ ? nq : kScCrossQ;
+    for (int k = threadIdx.x; k < nqv; k += 256) {
+        const int cell = qcell[k];
+        const int pi[3] = {(cell & 1023) - 2, ((cell >> 10) & 1023) - 2, ((cell >> 20) & 1023) - 2};
+        const T pf[3] = {qf[k * 4 + 0], qf[k * 4 + 1], qf[k * 4 + 2]};
+        slow_corners(pi, pf, qf[k * 4 + 3], (cell >> 30) & 1, 2);
+    }
 }
 
 // deposit, pass 2: every cell takes what the misfiled particles left for it in `cross` (cleared on the way) and, on the low
@@ -1413,18 +1432,26 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
 template <typename T>
 __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr, const T* __restrict__ faces,
                                                            T* __restrict__ cross, T* __restrict__ grid, int* __restrict__ newcount,
-                                                           int* __restrict__ cursor, int* __restrict__ tile_start2, int allow_reorder) {
+                                                           const int* __restrict__ tile_mis, int* __restrict__ cursor,
+                                                           int* __restrict__ tile_start2, int allow_reorder) {
     const int t = blockIdx.x;
     if (t == (int)gridDim.x - 1) {
         __shared__ int part[256];
-        const int n = hdr->ncross;
-        const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
+        __shared__ int n_mis;
         const int per = (g.nt + 255) / 256;
         const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
-        int sum = 0;
-        for (int k = lo; k < hi; ++k) sum += newcount[k];
+        int sum = 0, m = 0;
+        for (int k = lo; k < hi; ++k) {
+            sum += newcount[k];
+            m += tile_mis[k];
+        }
+        if (threadIdx.x == 0) n_mis = 0;
+        __syncthreads();
+        if (m) atomicAdd(&n_mis, m);
         part[threadIdx.x] = sum;
         __syncthreads();
+        const int n = n_mis;
+        const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
         for (int off = 1; off < 256; off <<= 1) {        // inclusive Hillis-Steele over the 256 partial sums
             const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
             __syncthreads();
@@ -1444,6 +1471,7 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
         }
         if (threadIdx.x == 255 && reorder) ts_next[g.nt] = part[255];
         if (threadIdx.x == 0) {
+            hdr->ncross = n;
             hdr->last_ncross = n;
             if (reorder) {
                 hdr->scatter_now = 1;
@@ -1568,10 +1596,11 @@ int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLay
     const size_t blk_bytes = (size_t)(g.tdim[0] + 1) * (g.tdim[1] + 1) * (g.tdim[2] + 1) * sizeof(double);
     hipLaunchKernelGGL(sc_tile_deposit_kernel<T>, dim3((unsigned)g.nt), dim3(256), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
                        (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)grid, (T*)(st + L.faces),
-                       (T*)(st + L.cross), (uint16_t*)(st + L.home), (int*)(st + L.newcount));
+                       (T*)(st + L.cross), (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.totals));
     CHX_CHECK_LAUNCH();
     hipLaunchKernelGGL(sc_tile_merge_kernel<T>, dim3((unsigned)(g.nt + 3) / 4 + 1), dim3(256), 0, s, a, g, hdr, (const T*)(st + L.faces),
-                       (T*)(st + L.cross), (T*)grid, (int*)(st + L.newcount), (int*)(st + L.cursor), (int*)(st + L.tile_start[0]), allow_reorder);
+                       (T*)(st + L.cross), (T*)grid, (int*)(st + L.newcount), (const int*)(st + L.totals), (int*)(st + L.cursor),
+                       (int*)(st + L.tile_start[0]), allow_reorder);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

@@ -27,7 +27,7 @@ struct ScTileHeader {
     int parity;        // which copy of tile_start / perm / ws / cs is current
     int scatter_now;   // this kick's gather writes its rows in a NEW tile order (decided by the crosser pass of the same kick);
                        // the geometry kernel of the next kick then flips `parity` and clears the flag
-    int ncross;        // misfiled particles found by the running deposit pass (reset by the geometry kernel of the next kick)
+    int ncross;        // misfiled particles found by the last deposit pass
     int reserved;
     int last_ncross;   // diagnostics: that count for the last finished deposit ...
     int n_sorts;       // ... and how many times the chain (re)ordered its rows so far
@@ -104,7 +104,7 @@ static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dt
     L.tile_start[0] = take((size_t)2 * (g.nt + 1) * sizeof(int));
     L.tile_start[1] = L.tile_start[0] + (size_t)(g.nt + 1) * sizeof(int);
     L.counts = take((size_t)kScSortWG * g.nt * sizeof(int));
-    L.totals = take((size_t)g.nt * sizeof(int));
+    L.totals = take((size_t)g.nt * sizeof(int));   // sort: tile totals; afterwards: misfiled particles per tile (deposit -> merge)
     L.perm[0] = take((size_t)2 * N * sizeof(int));
     L.perm[1] = L.perm[0] + (size_t)N * sizeof(int);
     L.ws[0] = take((size_t)2 * N * esz);
