@@ -1275,7 +1275,6 @@ __global__ __launch_bounds__(kScSortThreads) void sc_tile_scatter_kernel(
 // Measured and dropped: an LDS queue for the misfiled particles with a dense pass (one lane per corner) behind the loop, with
 // and without the global atomics moved behind the last barrier — no faster at 1 % misfiled, 1.6 x slower at 25 %.
 constexpr int kScDepUnroll = 4;
-constexpr int kScCrossQ = 512;
 
 template <typename T>
 __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
@@ -1288,9 +1287,7 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
-    __shared__ int nstay, nmis, nq;
-    __shared__ int qcell[kScCrossQ];
-    __shared__ T qf[kScCrossQ * 4];
+    __shared__ int nstay, nmis;
     const int par = hdr->parity;
     const int* __restrict__ tile_start = tile_start2 + (int64_t)par * (g.nt + 1);
     const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
@@ -1310,32 +1307,10 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
     const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
     for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
     if (threadIdx.x < 27) nbr[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { nstay = 0; nmis = 0; nq = 0; }
+    if (threadIdx.x == 0) { nstay = 0; nmis = 0; }
     __syncthreads();
     const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
     int stay = 0, mis = 0;
-    // corners of a particle outside this tile's cells: those that still fall into the tile's block go there (a particle one cell
-    // beyond a face keeps half of its corners out of the global atomics), the others to `cross` — the arithmetic of
-    // cic_deposit_kernel
-    auto slow_corners = [&](const int (&pi)[3], const T (&pf)[3], T c, bool lds_ok, int part /*1 block, 2 cross*/) {
-        const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
-        const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
-#pragma unroll
-        for (int ox = 0; ox < 2; ++ox)
-#pragma unroll
-            for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-                for (int oz = 0; oz < 2; ++oz) {
-                    const int ix = pi[0] + ox, iy = pi[1] + oy, iz = pi[2] + oz;
-                    if (!(ix >= 0 && ix < a.bins[0] && iy >= 0 && iy < a.bins[1] && iz >= 0 && iz < a.bins[2])) continue;
-                    const T v = c * (wx[ox] * wy[oy] * wz[oz]);
-                    const int bx = lx + ox, by = ly + oy, bz = lz + oz;
-                    if (lds_ok && bx >= 0 && bx <= TX && by >= 0 && by <= TY && bz >= 0 && bz <= TZ) {
-                        if (part & 1) unsafeAtomicAdd(&blk[bx * BX + by * BY + bz], (double)v);
-                    } else if (part & 2)
-                        unsafeAtomicAdd(cross + (int64_t)ix * a.gstride[0] + (int64_t)iy * a.gstride[1] + (int64_t)iz * a.gstride[2], v);
-                }
-    };
     for (int r0 = beg; r0 < end; r0 += 256 * kScDepUnroll) {
         T raw[kScDepUnroll][3], cq[kScDepUnroll];
 #pragma unroll
@@ -1365,33 +1340,38 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
                 if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) atomicAdd(&nbr[(dx + 1) * 9 + (dy + 1) * 3 + dz + 1], 1);
                 else atomicAdd(&newcount[h], 1);
             }
-            const int lx = pi[0] - org[0], ly = pi[1] - org[1], lz = pi[2] - org[2];
-            const bool in_tile = lx >= 0 && lx < TX && ly >= 0 && ly < TY && lz >= 0 && lz < TZ;
-            if (!in_tile) ++mis;
+            const int l[3] = {pi[0] - org[0], pi[1] - org[1], pi[2] - org[2]};
+            if (!(l[0] >= 0 && l[0] < TX && l[1] >= 0 && l[1] < TY && l[2] >= 0 && l[2] < TZ)) ++mis;
             if (!inside) continue;                      // outside the extent: no charge (cloud_in_cell.py:289-311)
+            // ONE code path for filed and misfiled particles (a branch for the latter cost every wave that held a single one of
+            // them the whole detour: +9 us on the kernel at 1 % misfiled). Per corner: in the grid? (the reference's in-range
+            // mask) -> in this tile's block? -> LDS, else the `cross` grid with a global atomic (the arithmetic of
+            // cic_deposit_kernel); the overflow of a hot tile (r >= lim) goes to `cross` altogether.
             const T c = cq[u];
-            if (in_tile && r < lim) {
-                const T wx[2] = {(T)1.0 - pf[0], pf[0]}, wy[2] = {(T)1.0 - pf[1], pf[1]}, wz[2] = {(T)1.0 - pf[2], pf[2]};
+            const T wgt[3][2] = {{(T)1.0 - pf[0], pf[0]}, {(T)1.0 - pf[1], pf[1]}, {(T)1.0 - pf[2], pf[2]}};
+            bool ok[3][2], inb[3][2];
 #pragma unroll
-                for (int ox = 0; ox < 2; ++ox)
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-                    for (int oy = 0; oy < 2; ++oy)
+                for (int o = 0; o < 2; ++o) {
+                    ok[d][o] = pi[d] + o >= 0 && pi[d] + o < a.bins[d];
+                    inb[d][o] = l[d] + o >= 0 && l[d] + o <= TX;         // tiles are cubes (sc_tile_prepare)
+                }
+            const bool lds_ok = r < lim;
 #pragma unroll
-                        for (int oz = 0; oz < 2; ++oz) {
-                            // pi >= org >= 0; the upper corner may leave the grid at its far end (weight dropped like the
-                            // reference's in-range mask)
-                            if (pi[0] + ox < a.bins[0] && pi[1] + oy < a.bins[1] && pi[2] + oz < a.bins[2])
-                                unsafeAtomicAdd(&blk[(lx + ox) * BX + (ly + oy) * BY + (lz + oz)], (double)(c * (wx[ox] * wy[oy] * wz[oz])));
-                        }
-            } else {                                     // misfiled, or the overflow of a hot tile: block corners now, the global
-                slow_corners(pi, pf, c, r < lim, 1);     // atomics behind the last barrier (queued; inline once the queue is full)
-                const int k = atomicAdd(&nq, 1);
-                if (k < kScCrossQ) {
-                    qcell[k] = (pi[0] + 2) | ((pi[1] + 2) << 10) | ((pi[2] + 2) << 20) | (r < lim ? (1 << 30) : 0);
-                    qf[k * 4 + 0] = pf[0]; qf[k * 4 + 1] = pf[1]; qf[k * 4 + 2] = pf[2]; qf[k * 4 + 3] = c;
-                } else
-                    slow_corners(pi, pf, c, r < lim, 2);
-            }
+            for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int oz = 0; oz < 2; ++oz) {
+                        if (!(ok[0][ox] && ok[1][oy] && ok[2][oz])) continue;
+                        const T v = c * (wgt[0][ox] * wgt[1][oy] * wgt[2][oz]);
+                        if (lds_ok && inb[0][ox] && inb[1][oy] && inb[2][oz])
+                            unsafeAtomicAdd(&blk[(l[0] + ox) * BX + (l[1] + oy) * BY + (l[2] + oz)], (double)v);
+                        else
+                            unsafeAtomicAdd(cross + (int64_t)(pi[0] + ox) * a.gstride[0] + (int64_t)(pi[1] + oy) * a.gstride[1] +
+                                                (int64_t)(pi[2] + oz) * a.gstride[2], v);
+                    }
         }
     }
     if (stay) atomicAdd(&nstay, stay);
@@ -1412,16 +1392,7 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
         else
             fb[sc_face_index(g, lx, ly, lz)] = v;      // (zeros from an empty tile: pass 2 reads every face unconditionally)
     }
-    if (threadIdx.x == 64) tile_mis[t] = nmis;   // summed by pass 2 (one atomic per workgroup on a header word instead: 1000 of them
-                                                 // on one address, 5-8 ns each, were the 8 us this kernel lost at 1 % misfiled)
-    // the queued global atomics: nothing in this workgroup waits for them any more
-    const int nqv = nq < kScCrossQ ? nq : kScCrossQ;
-    for (int k = threadIdx.x; k < nqv; k += 256) {
-        const int cell = qcell[k];
-        const int pi[3] = {(cell & 1023) - 2, ((cell >> 10) & 1023) - 2, ((cell >> 20) & 1023) - 2};
-        const T pf[3] = {qf[k * 4 + 0], qf[k * 4 + 1], qf[k * 4 + 2]};
-        slow_corners(pi, pf, qf[k * 4 + 3], (cell >> 30) & 1, 2);
-    }
+    if (threadIdx.x == 64) tile_mis[t] = nmis;   // summed by pass 2
 }
 
 // deposit, pass 2: every cell takes what the misfiled particles left for it in `cross` (cleared on the way) and, on the low
@@ -1438,13 +1409,19 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
     if (t == (int)gridDim.x - 1) {
         __shared__ int part[256];
         __shared__ int n_mis;
+        constexpr int kPer = 32;                         // nt <= 8192 (sc_tile_geom): at most 32 tiles per thread
         const int per = (g.nt + 255) / 256;
-        const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
+        const int lo = threadIdx.x * per;
+        int cnt[kPer];
         int sum = 0, m = 0;
-        for (int k = lo; k < hi; ++k) {
-            sum += newcount[k];
-            m += tile_mis[k];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {                 // every load in flight at once: one workgroup, a chain of latencies
+            const bool on = k < per && lo + k < g.nt;
+            cnt[k] = on ? newcount[lo + k] : 0;
+            m += on ? tile_mis[lo + k] : 0;
         }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) sum += cnt[k];
         if (threadIdx.x == 0) n_mis = 0;
         __syncthreads();
         if (m) atomicAdd(&n_mis, m);
@@ -1460,14 +1437,15 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
         }
         int run = part[threadIdx.x] - sum;
         int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
-        for (int k = lo; k < hi; ++k) {
-            const int c = newcount[k];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (!(k < per && lo + k < g.nt)) continue;
             if (reorder) {
-                cursor[k] = run;
-                ts_next[k] = run;
-                run += c;
+                cursor[lo + k] = run;
+                ts_next[lo + k] = run;
+                run += cnt[k];
             }
-            newcount[k] = 0;                            // ready for the next kick
+            newcount[lo + k] = 0;                       // ready for the next kick
         }
         if (threadIdx.x == 255 && reorder) ts_next[g.nt] = part[255];
         if (threadIdx.x == 0) {
