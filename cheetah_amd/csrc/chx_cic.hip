@@ -1405,23 +1405,17 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
                                                            T* __restrict__ cross, T* __restrict__ grid, int* __restrict__ newcount,
                                                            const int* __restrict__ tile_mis, int* __restrict__ cursor,
                                                            int* __restrict__ tile_start2, int allow_reorder) {
-    const int t = blockIdx.x;
-    if (t == (int)gridDim.x - 1) {
-        __shared__ int part[256];
+    const int t = (int)blockIdx.x - 1;
+    if (t < 0) {                                      // (the FIRST workgroup: dispatched first, its chain of dependent steps
+        __shared__ int part[256];                     // runs under the others instead of behind them)
         __shared__ int n_mis;
-        constexpr int kPer = 32;                         // nt <= 8192 (sc_tile_geom): at most 32 tiles per thread
         const int per = (g.nt + 255) / 256;
-        const int lo = threadIdx.x * per;
-        int cnt[kPer];
+        const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
         int sum = 0, m = 0;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {                 // every load in flight at once: one workgroup, a chain of latencies
-            const bool on = k < per && lo + k < g.nt;
-            cnt[k] = on ? newcount[lo + k] : 0;
-            m += on ? tile_mis[lo + k] : 0;
+        for (int k = lo; k < hi; ++k) {
+            sum += newcount[k];
+            m += tile_mis[k];
         }
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) sum += cnt[k];
         if (threadIdx.x == 0) n_mis = 0;
         __syncthreads();
         if (m) atomicAdd(&n_mis, m);
@@ -1437,15 +1431,14 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
         }
         int run = part[threadIdx.x] - sum;
         int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            if (!(k < per && lo + k < g.nt)) continue;
+        for (int k = lo; k < hi; ++k) {
+            const int c = newcount[k];
             if (reorder) {
-                cursor[lo + k] = run;
-                ts_next[lo + k] = run;
-                run += cnt[k];
+                cursor[k] = run;
+                ts_next[k] = run;
+                run += c;
             }
-            newcount[lo + k] = 0;                       // ready for the next kick
+            newcount[k] = 0;                            // ready for the next kick
         }
         if (threadIdx.x == 255 && reorder) ts_next[g.nt] = part[255];
         if (threadIdx.x == 0) {
