@@ -257,6 +257,27 @@ def other_configs(ca, torch, device) -> dict:
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["track_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "28 B written per (setting, particle) + the 2.8 MB beam read once (SURVEY 8d)"}}
 
+    def c4_particle_kernels():
+        # average durations of the chain's per-particle kernels in the tracked rocprofv3 summary (run under the profiler with the
+        # Green chain on the side stream: durations include what the overlap costs them)
+        import csv
+        path = os.path.join(ROOT, "profiles", "r03_c4_kernel_stats.csv")
+        avg = {}
+        try:
+            for row in csv.DictReader(open(path)):
+                for key in ("sc_tile_deposit_kernel", "sc_tile_merge_kernel", "sc_tile_particle_kernel"):
+                    if key in row["Name"]:
+                        avg[key] = float(row["AverageNs"]) * 1e-3
+        except OSError:
+            return None
+        if len(avg) < 3:
+            return None
+        dep = avg["sc_tile_deposit_kernel"] + avg["sc_tile_merge_kernel"]
+        gat = avg["sc_tile_particle_kernel"]
+        rate = 84.0 * N_PARTICLES / ((dep + gat) * 1e-6) / 1e9
+        return {"bytes_per_particle": 84.0, "deposit_us_profile": dep, "gather_us_profile": gat, "achieved_GBs": rate,
+                "frac": rate / HBM_PEAK_GBS, "source": "profiles/r03_c4_kernel_stats.csv"}
+
     def c4():
         r = rc.c4()
         # SURVEY 8d per kick: 84 B per particle + ~1.6 GB of grid / dense-FFT traffic (the pruned solver moves ~0.35 GB)
@@ -267,11 +288,7 @@ def other_configs(ca, torch, device) -> dict:
                 "particle_element_steps_per_s": r["steps_per_s"],
                 "roofline": {"bound": "hbm (model floor)", "algorithmic_bytes_per_kick": per_kick,
                              "ratio_to_model_floor": per_kick / (in_track * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "particle_kernels": {"bytes_per_particle": 84.0,
-                                                  "deposit_us_profile": 59.0, "gather_us_profile": 34.5,
-                                                  "achieved_GBs": 84.0 * N_PARTICLES / 93.5e-6 / 1e9,
-                                                  "frac": 84.0 * N_PARTICLES / 93.5e-6 / 1e9 / HBM_PEAK_GBS,
-                                                  "source": "profiles/r03_c4_kernel_stats.csv"},
+                             "particle_kernels": c4_particle_kernels(),
                              "note": "the byte count is the SURVEY 8d model (three dense 256^3 transforms); the pruned, "
                                      "symmetry-aware solver moves about a fifth of it, so `ratio_to_model_floor` is a ratio to "
                                      "the model's floor time, not an achieved bandwidth. `particle_kernels` is the achieved rate "

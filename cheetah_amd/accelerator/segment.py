@@ -336,6 +336,7 @@ class Segment(Element):
             by_name.setdefault(e.name, []).append(e)
         self.__dict__["_by_name"] = by_name
         self.__dict__["_plan_cache"] = None
+        self.__dict__["_chain_guard_state"] = None
 
     def __getattr__(self, name: str):
         by_name = self.__dict__.get("_by_name")
@@ -629,6 +630,7 @@ class Segment(Element):
                 incoming, step = self._chain_kick(item, plan[i + 1][1] if i + 1 < n_items and plan[i + 1][0] == "run" else None,
                                                   incoming, chain, first, last)
                 if last:
+                    self._chain_report(plan, chain)
                     chain = None
                 i += step
                 continue
@@ -665,10 +667,46 @@ class Segment(Element):
             return j
         return None
 
+    #: a chain pays off while the beam keeps its deposit-tile order from kick to kick. The device counts the particles each
+    #: deposit finds outside their slot's tile; the header with the running mean comes back ASYNCHRONOUSLY after the first
+    #: tracks of a plan (pinned copy + event, polled at the next track: no synchronisation), and a plan whose beam reshuffles
+    #: (a phase advance of tens of degrees between kicks) goes back to the kick-by-kick path, where the deposit sorts from
+    #: scratch: at 25 % misfiled the two cost the same, at 100 % the chain's deposit is 350 us against 72.
+    _CHAIN_MAX_MISFILED_PERMILLE = 250
+    _CHAIN_SAMPLES = 3
+
+    def _chain_guard(self, plan) -> dict:
+        guard = self.__dict__.get("_chain_guard_state")
+        if guard is None or guard["plan"] is not plan:
+            guard = self.__dict__["_chain_guard_state"] = {"plan": plan, "off": False, "samples": 0, "pending": None}
+        return guard
+
+    def _chain_allowed(self, plan) -> bool:
+        guard = self._chain_guard(plan)
+        pending = guard["pending"]
+        if pending is not None and pending[1].query():
+            header = pending[0]
+            if int(header[6]) > 0 and int(header[3]) > self._CHAIN_MAX_MISFILED_PERMILLE * int(header[6]):
+                guard["off"] = True
+            guard["pending"] = None
+        return not guard["off"]
+
+    def _chain_report(self, plan, state) -> None:
+        """Behind the last kick of a chain: fetch the chain's header for `_chain_allowed` (the first tracks of a plan only)."""
+        guard = self._chain_guard(plan)
+        if guard["off"] or guard["pending"] is not None or guard["samples"] >= self._CHAIN_SAMPLES:
+            return
+        guard["samples"] += 1
+        host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+        host.copy_(state[:32].view(torch.int32), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        guard["pending"] = (host, done)
+
     def _chain_starts(self, plan, i: int, incoming: ParticleBeam) -> bool:
         kick = plan[i][1]
         dtype = incoming.particles.dtype
-        return (kick._chain_settings_ok(dtype) and kick._chain_beam_ok(incoming)
+        return (self._chain_allowed(plan) and kick._chain_settings_ok(dtype) and kick._chain_beam_ok(incoming)
                 and self._next_chain_kick(plan, i, kick, dtype) is not None
                 and _lib.lib().chx_sc_tile_state_bytes(incoming.particles.shape[0], _ops._bins3(kick.grid_shape),
                                                        _ops.dtype_code(dtype)) > 0)

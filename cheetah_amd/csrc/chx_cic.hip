@@ -1444,6 +1444,8 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
         if (threadIdx.x == 0) {
             hdr->ncross = n;
             hdr->last_ncross = n;
+            hdr->misfiled_permille += (int)((int64_t)n * 1000 / a.N);   // over the chain so far: what the host's guard reads
+            hdr->n_deposits += 1;
             if (reorder) {
                 hdr->scatter_now = 1;
                 hdr->n_sorts += 1;

@@ -25,13 +25,16 @@
 // device-resident control block at the start of the state buffer
 struct ScTileHeader {
     int parity;        // which copy of tile_start / perm / ws / cs is current
-    int scatter_now;   // this kick's gather writes its rows in a NEW tile order (decided by the crosser pass of the same kick);
+    int scatter_now;   // this kick's gather writes its rows in a NEW tile order (decided by the merge pass of the same kick);
                        // the geometry kernel of the next kick then flips `parity` and clears the flag
     int ncross;        // misfiled particles found by the last deposit pass
-    int reserved;
-    int last_ncross;   // diagnostics: that count for the last finished deposit ...
-    int n_sorts;       // ... and how many times the chain (re)ordered its rows so far
-    int pad[2];
+    int misfiled_permille;   // sum over the chain's deposit passes of 1000 * misfiled / N ...
+    int last_ncross;   // (= ncross)
+    int n_sorts;       // how many times the chain (re)ordered its rows so far
+    int n_deposits;    // ... and the number of those passes: a host that reads the header after a track (asynchronously) learns
+                       // whether the beam keeps its tile order between kicks; where it does not (mean share above ~1/4) the
+                       // kick-by-kick path with the generic sorted deposit is the faster one (cheetah_amd Segment does that)
+    int pad;
 };
 static_assert(sizeof(ScTileHeader) == 32, "the host reads the header as eight ints");
 

@@ -132,6 +132,53 @@ def test_strong_mixing_takes_the_slow_paths_and_resorts(ca):
     assert flags[-1] >= 2, flags
 
 
+def test_reshuffling_beam_turns_the_chain_off_and_a_laminar_one_keeps_it(ca):
+    """The host's guard (Segment._chain_allowed): the chain's header — the mean share of particles each deposit found outside
+    their slot's tile — comes back asynchronously after a track; a lattice whose beam is imaged upside down between kicks goes
+    back to kick-by-kick tracking (same results), the laminar linac keeps its chain."""
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    from cheetah_amd import _ops
+
+    calls, orig = [], _ops.sc_kick_sorted
+    _ops.sc_kick_sorted = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        els = []
+        for i in range(5):
+            els += [ca.SpaceChargeKick(t(0.05), grid_shape=(32, 32, 32), **kw),
+                    ca.Quadrupole(t(0.2), k1=t(14.0 if i % 2 == 0 else -12.0), **kw), ca.Drift(t(0.9), **kw)]
+        mixing, beam = ca.Segment(els), _beam(ca, dt, 120_000, gaussian=True)
+        first = mixing.track(beam)
+        assert len(calls) == 5                                   # chained
+        torch.cuda.synchronize()                                  # (the guard itself never waits: it polls an event)
+        second = mixing.track(beam)
+        assert len(calls) == 5, "the second track still took the chain"
+        guard = mixing._chain_guard(mixing._plan())
+        assert guard["off"] and guard["pending"] is None
+        ref = _unchained(mixing, beam)
+        effect = (ref.particles - _one_by_one(_no_charge(ca, mixing), beam).particles).abs().max(dim=0).values
+        ulp = 4 * torch.finfo(dt).eps * ref.particles.abs().max(dim=0).values
+        # (`second` took the very path of `ref`; its hot tiles use float atomics, so not bit for bit)
+        assert torch.all((second.particles - ref.particles).abs().max(dim=0).values <= 1e-5 * effect + ulp)
+        assert torch.all((first.particles - ref.particles).abs().max(dim=0).values <= 1e-3 * effect + ulp)
+        # a copy of the lattice starts without the verdict (derived state)
+        import copy
+
+        assert copy.deepcopy(mixing).__dict__["_chain_guard_state"] is None
+        # the laminar linac: a few per cent misfiled per kick -> stays chained, and stops sampling after three tracks
+        calls.clear()
+        linac, beam = _linac(ca, dt, (64, 64, 64), 4), _beam(ca, dt, 200_000)
+        for _ in range(5):
+            linac.track(beam)
+            torch.cuda.synchronize()
+        assert len(calls) == 20
+        guard = linac._chain_guard(linac._plan())
+        assert not guard["off"] and guard["samples"] == 3
+    finally:
+        _ops.sc_kick_sorted = orig
+
+
 def _tile_pieces(ca, x, q, w, extent, scale, bins):
     """chx_sc_tile_sort + chx_sc_tile_deposit on x; returns (rho, state)."""
     from cheetah_amd import _lib, _ops
