@@ -155,6 +155,6 @@ def test_rccl_exchanges_on_one_rank():
         assert r["merge_rel"] < 1e-12, (name, r)
         # staged (chx_moments + merge + chx_sc_geometry, separate launches) vs the one-call kick (chx_sc_kick): the same
         # arithmetic up to the rounding of the three sigmas and the summation order of the charge grid
-        assert r["forced_vs_whole"] < (2e-3 if name.startswith("f32") else 1e-9), (name, r)
+        assert r["forced_vs_whole"] < (2e-4 if name.startswith("f32") else 1e-9), (name, r)
     assert report["screen"] == {"equal": True, "all_reduce": 1}
     assert report["batch_shard_equal"]

@@ -78,7 +78,7 @@ def test_particle_sharded_space_charge_equals_single_process(dtype):
         assert p.exitcode == 0
     joined = torch.cat([torch.from_numpy(results[0][0]), torch.from_numpy(results[1][0])], dim=0)
     kick = (ref - x).abs().max(dim=0).values                   # size of the effect per coordinate
-    tol = 1e-9 if dtype == torch.float64 else 2e-3             # fp32: the charge sum order differs between the runs
+    tol = 1e-9 if dtype == torch.float64 else 2e-4             # fp32: the charge sum order differs between the runs (measured 3e-5)
     assert torch.all((joined - ref).abs() <= tol * kick + 1e-30), ((joined - ref).abs().max(dim=0).values / kick)
     kw = {"dtype": dtype, "device": "cuda"}
     screen = ca.Screen(resolution=(64, 48), pixel_size=torch.tensor([4e-5, 5e-5], **kw), is_active=True, **kw)
