@@ -252,6 +252,7 @@ def other_configs(ca, torch, device) -> dict:
         return {"workload": "C3: k1 scan B=4096 x N=1e5 on the ARES EA subcell, fp32, shared beam, ONE GPU",
                 "ms_per_track": r["track_ms"], "ms_all_moments": r["all_moments_ms"],
                 "ms_track_moments_fused": r["fused_track_moments_ms"],
+                "ms_track_moments_algebraic": r["algebraic_track_moments_ms"],
                 "particle_element_steps_per_s": r["steps_per_s"],
                 "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["track_ms"] * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["track_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,

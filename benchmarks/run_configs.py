@@ -95,8 +95,9 @@ def c3(B=4096, N=100_000):
     gbytes = B * N * 28 / 1e9
     del o, out["b"]
     ms_fused = timeit(lambda: seg.track_moments(beam), 5, 2)  # chx_track_moments: no (B, N, 7) output at all
+    ms_alg = timeit(lambda: seg.track_moments(beam, exact=False), 20, 3)   # one pass over the shared beam + 7x7 algebra per setting
     return {"config": f"C3 k1 scan B={B} x N={N}, fp32, shared beam", "track_ms": ms, "all_moments_ms": ms_sig,
-            "fused_track_moments_ms": ms_fused, "output_GB": gbytes, "write_GBps": gbytes / (ms * 1e-3),
+            "fused_track_moments_ms": ms_fused, "algebraic_track_moments_ms": ms_alg, "output_GB": gbytes, "write_GBps": gbytes / (ms * 1e-3),
             "steps_per_s": B * N * 13 / (ms * 1e-3), "fused_steps_per_s": B * N * 13 / (ms_fused * 1e-3)}
 
 

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void track_moments_rows_kernel(const T* 
 // w d_i d_j in float32 carry ~6e-8 relative error each, independent from particle to particle; 32 of them are summed in
 // float32 before the float64 add (kTMFlush pairs) — the moments agree with the float64 accumulation to ~1e-7 relative
 // (tests/test_gpu_track_moments.py, profiles/r03_track_moments_rows.md).
-constexpr int kTMFlush = 32;   // pairs between two float64 updates
+constexpr int kTMFlush = 64;   // pairs between two float64 updates
 
 __global__ __launch_bounds__(CHX_BLOCK) void track_moments_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                           const float* __restrict__ Rm,
