@@ -144,6 +144,8 @@ SIGNATURES = {
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_parameter_track": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_parameter_track_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "chx_screen_gaussian": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, ctypes.c_int32, ctypes.c_int32, c_int, c_int, c_void_p, c_void_p]),
     "chx_track_moments_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "chx_track_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int,

@@ -1915,6 +1915,48 @@ def from_xyz_pxpypz(xp, energy, mass_eV):
 
 # ---------------------------------------------------------------------------------------------
 # ParameterBeam path
+class ParameterTrack(torch.autograd.Function):
+    """(mu', cov') = (R mu, R cov R^T) per batch row (chx_parameter_track without cavity coefficients) with a HIP backward
+    (chx_parameter_track_bwd) — one node instead of the three matmul nodes of element.py:167-179."""
+
+    @staticmethod
+    def forward(ctx, mu, cov, tm, batch_shape):
+        B = numel(batch_shape)
+        m, Bm = flat_bcast(mu, batch_shape, 1)
+        c, Bc = flat_bcast(cov, batch_shape, 2)
+        R, BR = flat_bcast(tm, batch_shape, 2)
+        m, c, R = m.contiguous(), c.contiguous(), R.contiguous()
+        mu_out = torch.empty((B, 7), dtype=mu.dtype, device=mu.device)
+        cov_out = torch.empty((B, 7, 7), dtype=mu.dtype, device=mu.device)
+        check(_lib.lib().chx_parameter_track(ptr(m), ptr(c), ptr(R), None, B, Bm, Bc, BR, dtype_code(mu.dtype), ptr(mu_out),
+                                             ptr(cov_out), stream_ptr()), "chx_parameter_track")
+        ctx.save_for_backward(m, c, R)
+        ctx.meta = (tuple(batch_shape), B, Bm, Bc, BR, mu.shape, cov.shape, tm.shape)
+        return mu_out.reshape(*batch_shape, 7), cov_out.reshape(*batch_shape, 7, 7)
+
+    @staticmethod
+    def backward(ctx, g_mu, g_cov):
+        m, c, R = ctx.saved_tensors
+        batch_shape, B, Bm, Bc, BR, mu_shape, cov_shape, tm_shape = ctx.meta
+        need = ctx.needs_input_grad
+        dt, dev = m.dtype, m.device
+        gm = g_mu.to(dt).reshape(B, 7).contiguous() if g_mu is not None else None
+        gc = g_cov.to(dt).reshape(B, 7, 7).contiguous() if g_cov is not None else None
+        d_mu = torch.empty((B, 7), dtype=dt, device=dev) if need[0] else None
+        d_cov = torch.empty((B, 7, 7), dtype=dt, device=dev) if need[1] else None
+        d_R = torch.empty((B, 7, 7), dtype=dt, device=dev) if need[2] else None
+        check(_lib.lib().chx_parameter_track_bwd(ptr(gm), ptr(gc), ptr(m), ptr(c), ptr(R), B, Bm, Bc, BR, dtype_code(dt), ptr(d_mu),
+                                                 ptr(d_cov), ptr(d_R), stream_ptr()), "chx_parameter_track_bwd")
+        # one gradient row per batch row: fold the rows of a broadcast input
+        if d_mu is not None:
+            d_mu = d_mu.reshape(*batch_shape, 7).sum_to_size(mu_shape)
+        if d_cov is not None:
+            d_cov = d_cov.reshape(*batch_shape, 7, 7).sum_to_size(cov_shape)
+        if d_R is not None:
+            d_R = d_R.reshape(*batch_shape, 7, 7).sum_to_size(tm_shape)
+        return d_mu, d_cov, d_R, None
+
+
 def parameter_track(mu, cov, tm, cavity_coeffs=None, batch_shape=None):
     """mu (…,7), cov (…,7,7), tm (…,7,7) -> (mu', cov') = (tm mu, tm cov tm^T) (element.py:167-179)."""
     require_device(mu, cov, tm)
@@ -1924,15 +1966,14 @@ def parameter_track(mu, cov, tm, cavity_coeffs=None, batch_shape=None):
                            "(transfer map vs beam moments)")
     if mu.requires_grad or cov.requires_grad or tm.requires_grad or (
             cavity_coeffs is not None and cavity_coeffs.requires_grad):
-        # gradient path (tests/test_differentiable.py:58-75): B tiny 7x7 products, left to autograd like compose_maps
-        tm_ = tm.to(mu.dtype)
-        mu_out, cov_out = (tm_ @ mu.unsqueeze(-1)).squeeze(-1), tm_ @ cov @ tm_.mT
+        # gradient path (tests/test_differentiable.py:58-75): one node with a HIP backward
+        if batch_shape is None:
+            batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], tm.shape[:-2])
+        mu_out, cov_out = ParameterTrack.apply(mu, cov.to(mu.dtype), tm, tuple(batch_shape))
         if cavity_coeffs is None:
             return mu_out, cov_out
         # active cavity: the moment updates of parameter_track_kernel as (B,)-sized tensor expressions
         # (cavity.py:127-133, 202-218); cf = [a, b, k beta0, phi, cos phi, T566, T556, T555] in fp64
-        if batch_shape is None:
-            batch_shape = bshapes(mu.shape[:-1], cov.shape[:-2], tm.shape[:-2])
         cf = cavity_coeffs.reshape(*batch_shape, cavity_coeffs.shape[-1])
         dt = mu.dtype
         mu4, mu5 = mu[..., 4].double(), mu[..., 5].double()

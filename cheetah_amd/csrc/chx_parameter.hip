@@ -53,6 +53,58 @@ __global__ __launch_bounds__(64) void parameter_track_kernel(const T* __restrict
     if (lane < 7) mu_out[b * 7 + lane] = (T)mu_i;
 }
 
+// backward of mu' = R mu, cov' = R cov R^T for one batch row per wavefront (lane (i, j) owns one entry): with g = dL/dmu',
+// G = dL/dcov':  d_mu = R^T g,  d_cov = R^T G R,  d_R = g mu^T + G R cov^T + G^T R cov   (fp64 inside, like the forward)
+template <typename T>
+__global__ __launch_bounds__(64) void parameter_track_bwd_kernel(const T* __restrict__ g_mu, const T* __restrict__ g_cov,
+                                                                const T* __restrict__ mu, const T* __restrict__ cov,
+                                                                const T* __restrict__ R, int64_t Bmu, int64_t Bcov, int64_t BR,
+                                                                T* __restrict__ d_mu, T* __restrict__ d_cov, T* __restrict__ d_R) {
+    __shared__ double r[49], c[49], m[7], G[49], g[7], rc[49], rct[49], gr[49];
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = lane / 7, j = lane - 7 * i;
+    if (lane < 49) {
+        r[lane] = (double)R[(BR == 1 ? 0 : b) * 49 + lane];
+        c[lane] = (double)cov[(Bcov == 1 ? 0 : b) * 49 + lane];
+        G[lane] = g_cov ? (double)g_cov[b * 49 + lane] : 0.0;
+    }
+    if (lane < 7) {
+        m[lane] = (double)mu[(Bmu == 1 ? 0 : b) * 7 + lane];
+        g[lane] = g_mu ? (double)g_mu[b * 7 + lane] : 0.0;
+    }
+    __syncthreads();
+    if (lane < 49) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int k = 0; k < 7; ++k) {
+            s1 = fma(r[i * 7 + k], c[k * 7 + j], s1);      // R cov
+            s2 = fma(r[i * 7 + k], c[j * 7 + k], s2);      // R cov^T
+            s3 = fma(G[i * 7 + k], r[k * 7 + j], s3);      // G R
+        }
+        rc[lane] = s1;
+        rct[lane] = s2;
+        gr[lane] = s3;
+    }
+    __syncthreads();
+    if (lane < 49) {
+        if (d_R) {
+            double s = g[i] * m[j];
+            for (int k = 0; k < 7; ++k) s = fma(G[i * 7 + k], rct[k * 7 + j], fma(G[k * 7 + i], rc[k * 7 + j], s));
+            d_R[b * 49 + lane] = (T)s;
+        }
+        if (d_cov) {
+            double s = 0.0;
+            for (int k = 0; k < 7; ++k) s = fma(r[k * 7 + i], gr[k * 7 + j], s);
+            d_cov[b * 49 + lane] = (T)s;
+        }
+    }
+    if (lane < 7 && d_mu) {
+        double s = 0.0;
+        for (int k = 0; k < 7; ++k) s = fma(r[k * 7 + lane], g[k], s);
+        d_mu[b * 7 + lane] = (T)s;
+    }
+}
+
 // image[b][iy][ix] = N2(pos; mu_xy, cov_xy) at pos = (left + ix hstep, bottom + iy vstep)  (screen.py:277-291)
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __restrict__ mu, const T* __restrict__ cov,
@@ -102,6 +154,25 @@ extern "C" int chx_parameter_track(const void* mu, const void* cov, const void* 
         hipLaunchKernelGGL(parameter_track_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)mu,
                            (const double*)cov, (const double*)R, cavity_coeffs, Bmu, Bcov, BR, (double*)mu_out,
                            (double*)cov_out);
+    else
+        return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_parameter_track_bwd(const void* g_mu, const void* g_cov, const void* mu, const void* cov, const void* R, int64_t B,
+                                       int64_t Bmu, int64_t Bcov, int64_t BR, int dtype, void* d_mu, void* d_cov, void* d_R,
+                                       void* stream) {
+    if ((!g_mu && !g_cov) || !mu || !cov || !R || (!d_mu && !d_cov && !d_R) || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B) || !chx_bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(parameter_track_bwd_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, (const float*)g_mu, (const float*)g_cov,
+                           (const float*)mu, (const float*)cov, (const float*)R, Bmu, Bcov, BR, (float*)d_mu, (float*)d_cov, (float*)d_R);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(parameter_track_bwd_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)g_mu,
+                           (const double*)g_cov, (const double*)mu, (const double*)cov, (const double*)R, Bmu, Bcov, BR,
+                           (double*)d_mu, (double*)d_cov, (double*)d_R);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

@@ -530,6 +530,13 @@ int chx_from_xyz_pxpypz(const void* xp_in, const void* energy, double mass_eV, i
 int chx_parameter_track(const void* mu, const void* cov, const void* R, const double* cavity_coeffs, int64_t B,
                         int64_t Bmu, int64_t Bcov, int64_t BR, int dtype, void* mu_out, void* cov_out,
                         void* stream);
+/* Backward of the linear part (no cavity coefficients): g_mu[B][7], g_cov[B][7][7] (dtype; either may be NULL = zero) ->
+ * d_mu[B][7] = R^T g, d_cov[B][7][7] = R^T G R, d_R[B][7][7] = g mu^T + G R cov^T + G^T R cov, one row per batch row (the
+ * caller sums the rows of a broadcast input); each output may be NULL. What autograd derives from element.py:167-179
+ * (tests/test_differentiable.py:58-75). */
+int chx_parameter_track_bwd(const void* g_mu, const void* g_cov, const void* mu, const void* cov, const void* R, int64_t B,
+                            int64_t Bmu, int64_t Bcov, int64_t BR, int dtype, void* d_mu, void* d_cov, void* d_R,
+                            void* stream);
 /* Screen reading of a ParameterBeam: bivariate normal density of (x - shift_x, y - shift_y) sampled at
  * (left + ix*hstep, bottom + iy*vstep); geom = [left, hstep, bottom, vstep] (dtype, device);
  * positions_fp32 != 0 rounds the sample positions to fp32 (the reference's torch.arange grid is created in
