@@ -47,8 +47,16 @@ def _any_requires_grad_py(*tensors) -> bool:
     return False
 
 
-#: one C call over the tensors of a run (half the cost of the Python loop; 250 tensors for the 100-element FODO lattice)
-_any_requires_grad = getattr(torch._C, "_any_requires_grad", _any_requires_grad_py)
+#: one C call over the tensors of a run: `cheetah_amd._chxtorch` (csrc/chx_torch_probe.cpp) reads the flag straight from the
+#: tensor objects — 0.9 us for the 300 setting tensors of the 100-element FODO where torch._C._any_requires_grad's argument
+#: parser takes 7-13 us; without the extension (a torch upgrade without a rebuild) torch's own function, then the Python loop
+try:
+    from .._chxtorch import any_requires_grad as _scan_requires_grad
+
+    def _any_requires_grad(*tensors) -> bool:
+        return _scan_requires_grad(tensors)
+except ImportError:  # pragma: no cover - stale build
+    _any_requires_grad = getattr(torch._C, "_any_requires_grad", _any_requires_grad_py)
 
 
 class _ElementList(nn.ModuleList):

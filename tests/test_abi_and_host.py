@@ -381,3 +381,22 @@ def test_storage_swap_under_a_planned_tensor_is_seen_when_its_element_is_reread(
     fr.refresh()
     assert fr.ok and fr.ptrs[1 * 9 + 1] == k1.data_ptr() != old
     fr.verify()
+
+
+def test_requires_grad_scan_extension():
+    """cheetah_amd._chxtorch (csrc/chx_torch_probe.cpp): the flag scan the host layer runs over a run's setting tensors."""
+    import torch
+
+    from cheetah_amd import _chxtorch
+    from cheetah_amd.accelerator import segment
+
+    ts = tuple(torch.zeros(2) for _ in range(50))
+    assert _chxtorch.any_requires_grad(ts) is False and _chxtorch.any_requires_grad(()) is False
+    assert _chxtorch.any_requires_grad(ts + (torch.nn.Parameter(torch.zeros(1)),)) is True
+    ts[7].requires_grad_(True)                     # in place: no counter moves — the reason the scan runs on every track
+    assert _chxtorch.any_requires_grad(ts) is True
+    assert _chxtorch.any_requires_grad((None, 1.0, "k1")) is False
+    with pytest.raises(TypeError):
+        _chxtorch.any_requires_grad(list(ts))
+    assert segment._any_requires_grad(*ts) is True and segment._any_requires_grad() is False
+    assert segment._any_requires_grad.__module__ == "cheetah_amd.accelerator.segment"      # the extension, not torch._C's parser
