@@ -38,6 +38,23 @@ elif which == "c2":
 
     def step():
         return seg.track(beam)
+elif which == "dkd":
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for _ in range(25):
+        els += [ca.Quadrupole(rc.t(0.2, dt), k1=rc.t(4.2, dt), tracking_method="drift_kick_drift", **kw),
+                ca.Drift(rc.t(0.8, dt), tracking_method="drift_kick_drift", **kw),
+                ca.Quadrupole(rc.t(0.2, dt), k1=rc.t(-4.2, dt), tracking_method="drift_kick_drift", **kw),
+                ca.Drift(rc.t(0.8, dt), tracking_method="drift_kick_drift", **kw)]
+    for e in els:
+        e.dkd_precision = "storage"
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_000, dtype=dt, device="cuda")
+
+    def step():
+        b = beam
+        for e in els[:10]:
+            b = e.track(b)
+        return b
 else:
     kw = {"dtype": dt, "device": "cuda"}
     k1 = torch.nn.Parameter(rc.t(3.142, dt))

@@ -256,11 +256,50 @@ class Element(nn.Module):
         """(num_steps, fringe_at bits) for chx_dkd_track."""
         return 1, 3
 
+    def _dkd_params_stacked(self, dtype, device):
+        """The (1, P) parameter array of chx_dkd_track for an element whose settings are all device scalars of `dtype` that
+        carry no gradient — kept between tracks (one `torch.stack` = one launch + 6 us of host time per element and track
+        otherwise). The key holds the element's revision (any assignment) and the settings' version counters (in-place edits).
+        None when the element does not qualify."""
+        if type(self)._dkd_params is not Element._dkd_params:
+            return None
+        refs = self._builder_scalar_refs()
+        key = [self.__dict__["_revision"], dtype, device]
+        grad = torch.is_grad_enabled()
+        for t, index in refs:
+            if t.dim() != (0 if index is None else 1) or t.dtype != dtype or t.device != device or (grad and t.requires_grad):
+                return None
+            key.append(t._version)
+        cached = self.__dict__.get("_dkd_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        with torch.no_grad():
+            stacked = torch.stack([t if index is None else t[index] for t, index in refs]).reshape(1, len(refs))
+        self.__dict__["_dkd_cache"] = (key, stacked)
+        return stacked
+
     def _track_drift_kick_drift(self, incoming: ParticleBeam) -> ParticleBeam:
         """Bmad-X tracking (e.g. drift.py:106-154): Cheetah -> Bmad coordinates, the element's map and back in one
         kernel pass (chx_dkd_track); the outgoing energy is the reference energy recomputed from p0c."""
         assert isinstance(incoming, ParticleBeam), \
             "Drift-kick-drift tracking is currently only supported for `ParticleBeam`."
+        if self.dkd_precision not in ("double", "storage"):
+            raise ValueError(f"dkd_precision must be 'double' or 'storage', got {self.dkd_precision!r}")
+        x, energy = incoming.particles, incoming.energy
+        if x.dim() == 2 and x.is_cuda and energy.dim() == 0 and energy.dtype == x.dtype and energy.device == x.device and not (
+                torch.is_grad_enabled() and (x.requires_grad or energy.requires_grad)):
+            # one plain beam, scalar settings, no graph: the kernel call without the broadcasting / autograd preparations
+            params = self._dkd_params_stacked(x.dtype, x.device)
+            if params is not None:
+                num_steps, fringe = self._dkd_options()
+                species = incoming.species
+                N = x.shape[0]
+                out, e_out = _ops._dkd_raw(self._dkd_kind, _ops.aligned(x).reshape(1, N, 7), params, energy.reshape(1),
+                                           species.mass_eV_float, species.num_elementary_charges_float, num_steps, fringe, 1, N,
+                                           self.dkd_precision == "storage")
+                return ParticleBeam(out.reshape(N, 7), e_out.reshape(()), particle_charges=incoming.particle_charges,
+                                    survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length,
+                                    species=species)
         # the reference's Bmad-X expressions mix the particles with the element's settings: the result is promoted to the wider
         # of the two dtypes (a float64 element gives float64 particles from a float32 beam; the energy keeps the beam's dtype)
         dtype = torch.promote_types(incoming.particles.dtype, self.length.dtype)
@@ -269,8 +308,6 @@ class Element(nn.Module):
         num_steps, fringe = self._dkd_options()
         species = incoming.species
         x = incoming.particles if incoming.particles.dtype == dtype else incoming.particles.to(dtype)
-        if self.dkd_precision not in ("double", "storage"):
-            raise ValueError(f"dkd_precision must be 'double' or 'storage', got {self.dkd_precision!r}")
         particles, ref_energy = _ops.dkd_track(self._dkd_kind, x, params, pshape, energy,
                                                species.mass_eV_float, species.num_elementary_charges_float, num_steps,
                                                fringe, storage_precision=self.dkd_precision == "storage")
@@ -348,7 +385,7 @@ class Element(nn.Module):
     #: address the ORIGINAL's tensors), memoised maps / geometry, scratch buffers. A copy or an unpickled element starts
     #: without them and rebuilds on first use.
     _DERIVED_STATE = ("_plan_cache", "_flat_elements", "_map_cache", "_tmap_cache", "_scalar_ws", "_ext_cache",
-                      "_grid_tensor", "_geom_cache", "_limits_checked", "_chain_guard_state")
+                      "_grid_tensor", "_geom_cache", "_limits_checked", "_chain_guard_state", "_dkd_cache")
 
     def __getstate__(self):
         """State for `copy.deepcopy`, `pickle` and `torch.save`: everything but the derived caches."""

@@ -1,0 +1,66 @@
+"""The short drift-kick-drift path (Element._track_drift_kick_drift for one plain beam and scalar settings: cached parameter
+array + chx_dkd_track_p) against the general path (_ops.dkd_track), and the invalidation of the cached array
+(reference behaviour: /root/reference/cheetah/accelerator/quadrupole.py:174-240, drift.py:106-154 re-read their settings on
+every call)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _general(el, beam):
+    """The same element through the general path (the cached array switched off)."""
+    orig = type(el)._dkd_params_stacked
+    type(el)._dkd_params_stacked = lambda self, dtype, device: None
+    try:
+        return el.track(beam)
+    finally:
+        type(el)._dkd_params_stacked = orig
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("precision", ["double", "storage"])
+def test_short_path_equals_general_path_and_follows_the_settings(dt, precision):
+    import cheetah_amd as ca
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(2)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, sigma_x=t(2e-4), sigma_px=t(3e-5), sigma_p=t(1e-3), energy=t(8e7), **kw)
+    quad = ca.Quadrupole(t(0.3), k1=t(2.5), misalignment=t([1e-4, -2e-4]), tilt=t(0.1), num_steps=3, tracking_method="drift_kick_drift", **kw)
+    drift = ca.Drift(t(0.7), tracking_method="drift_kick_drift", **kw)
+    for el in (quad, drift):
+        el.dkd_precision = precision
+        a, b = el.track(beam), _general(el, beam)
+        assert el.__dict__["_dkd_cache"] is not None
+        assert torch.equal(a.particles, b.particles) and torch.equal(a.energy, b.energy) and torch.equal(a.s, b.s)
+        assert a.particles.shape == beam.particles.shape and a.energy.shape == beam.energy.shape
+    first = quad.track(beam).particles.clone()
+    # in-place edit (version counter), re-assignment (revision), both seen
+    quad.k1.fill_(-1.0)
+    edited = quad.track(beam)
+    assert not torch.equal(edited.particles, first) and torch.equal(edited.particles, _general(quad, beam).particles)
+    quad.k1 = t(2.5)
+    assert torch.equal(quad.track(beam).particles, first)
+    quad.misalignment[1] = 5e-4
+    assert torch.equal(quad.track(beam).particles, _general(quad, beam).particles)
+    # a setting that wants a gradient takes the differentiable path, and gets one
+    quad.k1 = torch.nn.Parameter(t(2.5))
+    out = quad.track(beam)
+    out.particles[:, 1].square().sum().backward()
+    assert quad.k1.grad is not None and float(quad.k1.grad.abs()) > 0
+    with torch.no_grad():
+        assert torch.isfinite(quad.track(beam).particles).all()
+    # a copy starts without the cached array (derived state) and tracks the same
+    clone = copy.deepcopy(drift)
+    assert clone.__dict__["_dkd_cache"] is None
+    assert torch.equal(clone.track(beam).particles, drift.track(beam).particles)
+    # vector settings, a float64 element on a float32 beam: the general path as before
+    wide = ca.Quadrupole(t(0.3), k1=t([1.0, 2.0]), tracking_method="drift_kick_drift", **kw)
+    assert wide.track(beam).particles.shape == (2, 20_000, 7) and wide.__dict__.get("_dkd_cache") is None
+    if dt == torch.float32:
+        d64 = ca.Drift(torch.tensor(0.7, dtype=torch.float64, device="cuda"), tracking_method="drift_kick_drift",
+                       dtype=torch.float64, device="cuda")
+        assert d64.track(beam).particles.dtype == torch.float64
