@@ -1288,10 +1288,12 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
     __shared__ int nstay, nmis;
-    const int par = hdr->parity;
-    const int* __restrict__ tile_start = tile_start2 + (int64_t)par * (g.nt + 1);
-    const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
     const int t = blockIdx.x;
+    // the slot range of both parities is fetched next to the parity itself: one round trip instead of two in front of everything
+    // this workgroup does (a workgroup of an empty tile is two round trips long otherwise)
+    const int b0 = tile_start2[t], e0 = tile_start2[t + 1], b1 = tile_start2[g.nt + 1 + t], e1 = tile_start2[g.nt + 2 + t];
+    const int par = hdr->parity;
+    const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
     const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
     const int BY = TZ + 1, BX = (TY + 1) * BY, ncell = (TX + 1) * BX;
     int tc[3], org[3];
@@ -1303,8 +1305,20 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
 #pragma unroll
         for (int d = 0; d < 3; ++d) org[d] = tc[d] << g.tshift[d];
     }
-    const int beg = tile_start[t], end = tile_start[t + 1];
+    const int beg = par ? b1 : b0, end = par ? e1 : e0;
     const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
+    if (end <= beg) {                                   // no slots (3/4 of the tiles of a 3-sigma grid): zeros, no LDS, no barrier
+        T* __restrict__ fz = faces + (int64_t)t * sc_face_cells(g);
+        for (int i = threadIdx.x; i < ncell; i += 256) {
+            const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
+            if (lx < TX && ly < TY && lz < TZ)
+                grid[(int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] + (int64_t)(org[2] + lz) * a.gstride[2]] = (T)0;
+            else
+                fz[sc_face_index(g, lx, ly, lz)] = (T)0;
+        }
+        if (threadIdx.x == 64) tile_mis[t] = 0;
+        return;
+    }
     for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
     if (threadIdx.x < 27) nbr[threadIdx.x] = 0;
     if (threadIdx.x == 0) { nstay = 0; nmis = 0; }
