@@ -1433,17 +1433,23 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
         if (threadIdx.x == 0) n_mis = 0;
         __syncthreads();
         if (m) atomicAdd(&n_mis, m);
-        part[threadIdx.x] = sum;
-        __syncthreads();
-        const int n = n_mis;
-        const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
-        for (int off = 1; off < 256; off <<= 1) {        // inclusive Hillis-Steele over the 256 partial sums
-            const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
+        // inclusive scan of the 256 partial sums: inside each wave by shuffles, the four wave totals through LDS (one barrier;
+        // this workgroup is a chain of dependent steps the other workgroups of the pass run beside)
+        int incl = sum;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
         }
-        int run = part[threadIdx.x] - sum;
+        if (lane == 63) part[wv] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int k = 0; k < wv; ++k) before += part[k];
+        const int total = part[0] + part[1] + part[2] + part[3];
+        int run = before + incl - sum;
+        const int n = n_mis;                             // (complete: the barrier above is behind every lane's atomic)
+        const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
         int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
         for (int k = lo; k < hi; ++k) {
             const int c = newcount[k];
@@ -1454,7 +1460,7 @@ __global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom
             }
             newcount[k] = 0;                            // ready for the next kick
         }
-        if (threadIdx.x == 255 && reorder) ts_next[g.nt] = part[255];
+        if (threadIdx.x == 255 && reorder) ts_next[g.nt] = total;
         if (threadIdx.x == 0) {
             hdr->ncross = n;
             hdr->last_ncross = n;
