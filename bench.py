@@ -320,27 +320,35 @@ def other_configs(ca, torch, device) -> dict:
                     ca.Quadrupole(tt(0.2), k1=tt(-4.2), tracking_method="drift_kick_drift", **kw),
                     ca.Drift(tt(0.8), tracking_method="drift_kick_drift", **kw)]
         beam = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES, **kw)
-        res = {"workload": "100-element FODO, drift_kick_drift (Bmad-X) tracking of every element, 1e6 particles, fp32"}
+        res = {"workload": "100-element FODO, drift_kick_drift (Bmad-X) tracking of every element, 1e6 particles, fp32: "
+                           "Segment.track (no element of this lattice can be merged with another: 100 particle passes, issued by "
+                           "one chx_dkd_chain call) and the elements' own track() one after the other"}
+        seg = ca.Segment(els)
+
+        def by_segment():
+            return seg.track(beam)
+
+        def one_by_one():
+            b = beam
+            for e in els:
+                b = e.track(b)
+            return b
+
         for label, prec in (("float64_arithmetic", "double"), ("float32_arithmetic", "storage")):
             for e in els:
                 e.dkd_precision = prec
-
-            def run():
-                b = beam
-                for e in els:
-                    b = e.track(b)
-                return b
-
-            for _ in range(2):
-                run()
-            torch.cuda.synchronize()
-            t0 = _t.perf_counter()
-            for _ in range(5):
-                run()
-            torch.cuda.synchronize()
-            ms = (_t.perf_counter() - t0) / 5 * 1e3
-            res[label] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
-                          "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
+            res[label] = {}
+            for how, run in (("segment_track", by_segment), ("element_by_element", one_by_one)):
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                t0 = _t.perf_counter()
+                for _ in range(5):
+                    run()
+                torch.cuda.synchronize()
+                ms = (_t.perf_counter() - t0) / 5 * 1e3
+                res[label][how] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
+                                   "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
         res["note"] = ("per-element kernel times and the measured error of the float32-arithmetic variant against Bmad-X: "
                        "profiles/r03_dkd_precision.md")
         return res

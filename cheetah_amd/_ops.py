@@ -697,6 +697,22 @@ def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, stor
     return out, e_out
 
 
+def dkd_chain(kinds, params, num_steps, fringe, storage, x, energy, s, mass_eV, n_charges):
+    """A run of drift-kick-drift elements on one plain beam (chx_dkd_chain): x (N, 7), energy and s 0-d of x's dtype, params =
+    the elements' (1, P) parameter arrays. Returns (particles (N, 7), energy 0-d, s 0-d) behind the last element."""
+    E, N = len(kinds), x.shape[0]
+    x = aligned(x)
+    out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
+    tmp = torch.empty((N, 7), dtype=x.dtype, device=x.device) if E > 1 else None
+    scalars = torch.empty((E + 1,), dtype=x.dtype, device=x.device)       # the elements' outgoing energies, then s
+    i32 = ctypes.c_int32 * E
+    check(_lib.lib().chx_dkd_chain(i32(*kinds), (ctypes.c_void_p * E)(*[p.data_ptr() for p in params]), i32(*num_steps), i32(*fringe),
+                                   i32(*storage), E, ptr(x), ptr(energy), mass_eV, n_charges, N, dtype_code(x.dtype), ptr(out),
+                                   ptr(tmp), ptr(scalars), ptr(s), scalars.data_ptr() + E * scalars.element_size(), stream_ptr()),
+          "chx_dkd_chain")
+    return out, scalars[E - 1], scalars[E]
+
+
 class DkdTrack(torch.autograd.Function):
     """(x_out, ref_energy) = chx_dkd_track(x, params, energy); backward = chx_dkd_track_bwd (dual numbers on device)."""
 

@@ -501,6 +501,62 @@ extern "C" int chx_dkd_track_p(int kind, const void* x_in, const void* params, c
 }
 
 namespace {
+constexpr int kDkdSChunk = 64;
+struct DkdLengthPtrs {
+    const void* p[kDkdSChunk];
+};
+// s_out = (((s_in + l_0) + l_1) + ...) in T: the additions the reference makes one element at a time (element.py `s=incoming.s +
+// self.length`), so that the path length carries the same rounding
+template <typename T>
+__global__ void dkd_path_length_kernel(DkdLengthPtrs args, int n, const T* __restrict__ s_in, T* __restrict__ s_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    T s = *s_in;
+    for (int e = 0; e < n; ++e) s = s + *(const T*)args.p[e];
+    *s_out = s;
+}
+}  // namespace
+
+// A run of drift-kick-drift elements on ONE beam with scalar settings: E launches of chx_dkd_track_p from one call. The reference
+// energy is handed from element to element on the device (energies[e] = what element e leaves), the particle rows ping-pong
+// between x_out and x_tmp so that the last element writes x_out. Same results as E separate calls, bit for bit.
+extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, const int32_t* num_steps, const int32_t* fringe_at,
+                             const int32_t* storage_precision, int64_t E, const void* x_in, const void* energy_in, double mass_eV,
+                             double n_charges, int64_t N, int dtype, void* x_out, void* x_tmp, void* energies, const void* s_in,
+                             void* s_out, void* stream) {
+    if (!kinds || !params || !num_steps || !fringe_at || !storage_precision || E < 1 || E > 65535) return CHX_ERR_INVALID_ARG;
+    if ((s_in == nullptr) != (s_out == nullptr)) return CHX_ERR_INVALID_ARG;
+    if (!x_in || !energy_in || !x_out || !energies || (E > 1 && !x_tmp) || N < 1) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    const void* src = x_in;
+    const void* e_src = energy_in;
+    for (int64_t e = 0; e < E; ++e) {
+        void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;          // the last element lands in x_out
+        void* e_dst = (char*)energies + (size_t)e * esz;
+        const int st = chx_dkd_track_p(kinds[e], src, params[e], e_src, mass_eV, n_charges, num_steps[e], fringe_at[e], 1, 1, 1, 1, N,
+                                       dtype, storage_precision[e], dst, e_dst, stream);
+        if (st != CHX_OK) return st;
+        src = dst;
+        e_src = e_dst;
+    }
+    // the path length behind the run: every kind's first parameter is its length
+    for (int64_t done = 0; s_out && done < E; done += kDkdSChunk) {
+        DkdLengthPtrs a;
+        const int n = (int)((E - done < kDkdSChunk) ? (E - done) : kDkdSChunk);
+        for (int e = 0; e < kDkdSChunk; ++e) a.p[e] = e < n ? params[done + e] : nullptr;
+        const void* from = done == 0 ? s_in : s_out;
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(dkd_path_length_kernel<float>, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, (const float*)from, (float*)s_out);
+        else
+            hipLaunchKernelGGL(dkd_path_length_kernel<double>, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, (const double*)from,
+                               (double*)s_out);
+        CHX_CHECK_LAUNCH();
+    }
+    return CHX_OK;
+}
+
+namespace {
 template <typename T, int KIND>
 int launch_dkd_bwd(const void* x_in, const void* params, const void* energy, const void* dY, double mc2, double nq,
                    int num_steps, int fringe, int P, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N, void* dx,

@@ -568,6 +568,17 @@ int chx_dkd_track(int kind, const void* x_in, const void* params, const void* en
 int chx_dkd_track_p(int kind, const void* x_in, const void* params, const void* energy, double mass_eV, double n_charges,
                     int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N, int dtype,
                     int storage_precision, void* x_out, void* energy_out, void* stream);
+/* A run of E drift-kick-drift elements (a lattice tracked with tracking_method = "drift_kick_drift": every element is its own,
+ * non-mergeable map, e.g. quadrupole.py:174-240) on one beam x_in[N][7] with scalar settings: HOST arrays kinds[E],
+ * params[E] (device pointers to each element's parameter array), num_steps[E], fringe_at[E], storage_precision[E]; the
+ * reference energy travels from element to element on the device (energies[E] (dtype): what each element leaves; energy_in one
+ * scalar). x_tmp[N][7] is scratch (may be NULL for E = 1); x_out receives the last element's particles. E launches, one call.
+ * s_in / s_out (one scalar of dtype each, both or neither): the path length, s_out = (((s_in + l_0) + l_1) + ...) with the
+ * lengths added one by one in dtype like the reference's `s=incoming.s + self.length` per element. */
+int chx_dkd_chain(const int32_t* kinds, const void* const* params, const int32_t* num_steps, const int32_t* fringe_at,
+                  const int32_t* storage_precision, int64_t E, const void* x_in, const void* energy_in, double mass_eV,
+                  double n_charges, int64_t N, int dtype, void* x_out, void* x_tmp, void* energies, const void* s_in, void* s_out,
+                  void* stream);
 /* Backward of chx_dkd_track (the reference gets it from torch autograd through utils/bmadx.py): forward-mode dual
  * numbers on device, one seeded evaluation per input. dx[B][N][7] (dtype, may be NULL) = dY . d x_out / d x_in;
  * partials (may be NULL) = chx_dkd_bwd_partials_count() doubles laid out [B][ceil(N/256)][P + 1]: per workgroup

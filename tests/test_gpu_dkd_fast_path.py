@@ -64,3 +64,56 @@ def test_short_path_equals_general_path_and_follows_the_settings(dt, precision):
         d64 = ca.Drift(torch.tensor(0.7, dtype=torch.float64, device="cuda"), tracking_method="drift_kick_drift",
                        dtype=torch.float64, device="cuda")
         assert d64.track(beam).particles.dtype == torch.float64
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_segment_tracks_a_drift_kick_drift_run_in_one_call(dt):
+    """Segment.track hands consecutive drift-kick-drift elements to chx_dkd_chain: same particles, energy and s — bit for bit —
+    as the elements tracked one after the other; elements that do not qualify (a vectorised setting, a Marker, a linear
+    element, a setting that wants a gradient) end a run and are tracked as before."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(4)
+    beam = ca.ParticleBeam.from_parameters(num_particles=30_001, sigma_x=t(2e-4), sigma_px=t(3e-5), sigma_p=t(1e-3), energy=t(8e7), **kw)
+    dkd = {"tracking_method": "drift_kick_drift"}
+    els = [ca.Drift(t(0.31), **dkd, **kw), ca.Quadrupole(t(0.2), k1=t(3.1), num_steps=4, **dkd, **kw), ca.Drift(t(0.77), **dkd, **kw),
+           ca.Quadrupole(t(0.2), k1=t(-2.9), tilt=t(0.2), misalignment=t([1e-4, 2e-4]), **dkd, **kw),
+           ca.Dipole(t(0.5), angle=t(0.02), **dkd, **kw), ca.Drift(t(0.13), **dkd, **kw),
+           ca.Marker(name="m"), ca.Drift(t(0.4), **kw),                      # a pass-through element and a linear one
+           ca.Drift(t(0.21), **dkd, **kw), ca.Quadrupole(t(0.1), k1=t(1.0), **dkd, **kw), ca.Drift(t(0.5), **dkd, **kw)]
+    els[1].dkd_precision = "storage"
+    seg = ca.Segment(els)
+    calls, orig = [], _ops.dkd_chain
+    _ops.dkd_chain = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
+    try:
+        out = seg.track(beam)
+    finally:
+        _ops.dkd_chain = orig
+    assert calls == [4, 3], calls            # (the Dipole brings its own parameter list: tracked on its own, like the Drift behind it)
+    ref = beam
+    for e in els:
+        ref = e.track(ref)
+    assert torch.equal(out.particles, ref.particles) and torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+    assert out.energy.shape == () and out.s.shape == ()
+    # a vectorised setting in the middle: the run stops in front of it
+    els[2].length = t([0.7, 0.8])
+    calls.clear()
+    _ops.dkd_chain = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
+    try:
+        out = seg.track(beam)
+    finally:
+        _ops.dkd_chain = orig
+    assert calls == [2], calls                                    # (behind it the beam is vectorised: no run)
+    ref = beam
+    for e in els:
+        ref = e.track(ref)
+    assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s)
+    els[2].length = t(0.77)
+    # gradients: the differentiable path, same value
+    els[1].k1 = torch.nn.Parameter(t(3.1))
+    out = seg.track(beam)
+    out.particles[:, 0].square().mean().backward()
+    assert els[1].k1.grad is not None and float(els[1].k1.grad.abs()) > 0
