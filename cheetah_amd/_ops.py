@@ -1948,7 +1948,13 @@ class ParameterTrack(torch.autograd.Function):
                                              ptr(cov_out), stream_ptr()), "chx_parameter_track")
         ctx.save_for_backward(m, c, R)
         ctx.meta = (tuple(batch_shape), B, Bm, Bc, BR, mu.shape, cov.shape, tm.shape)
-        return mu_out.reshape(*batch_shape, 7), cov_out.reshape(*batch_shape, 7, 7)
+        mu_out, cov_out = mu_out.reshape(*batch_shape, 7), cov_out.reshape(*batch_shape, 7, 7)
+        # the graph flags of the reference's two expressions: mu' hangs on (mu, tm), cov' on (cov, tm)
+        need_mu, need_cov, need_tm = ctx.needs_input_grad[:3]
+        dead = [t for t, alive in ((mu_out, need_mu or need_tm), (cov_out, need_cov or need_tm)) if not alive]
+        if dead:
+            ctx.mark_non_differentiable(*dead)
+        return mu_out, cov_out
 
     @staticmethod
     def backward(ctx, g_mu, g_cov):

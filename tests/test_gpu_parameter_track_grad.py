@@ -52,3 +52,16 @@ def test_only_the_wanted_gradients_are_formed():
     ref_c = tm @ cov @ tm.mT
     (r,) = torch.autograd.grad(ref_c[..., 0, 0].sqrt().sum(), (tm,))
     assert torch.allclose(g, r, rtol=1e-12, atol=1e-14)
+
+
+def test_graph_flags_follow_the_two_expressions():
+    """mu' = R mu hangs on (mu, R), cov' = R cov R^T on (cov, R): an input that only feeds one of them must not put the other
+    output into the graph (the reference's flags, tests/golden/grad_flags.json)."""
+    from cheetah_amd import _ops
+
+    mu, cov, tm = _inputs(torch.float64, (), (), ())
+    for req in ((True, False, False), (False, True, False), (False, False, True)):
+        for t, r in zip((mu, cov, tm), req):
+            t.requires_grad_(r)
+        mo, co = _ops.parameter_track(mu, cov, tm)
+        assert mo.requires_grad == (req[0] or req[2]) and co.requires_grad == (req[1] or req[2]), req
