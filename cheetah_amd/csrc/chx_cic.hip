@@ -1270,11 +1270,11 @@ __global__ __launch_bounds__(kScSortThreads) void sc_tile_scatter_kernel(
 // this tile's block there and the others to the `cross` grid with global atomics right here — 4096 workgroups' worth of
 // parallelism for them; a list + a pass of its own behind this kernel cost 7 us at 1 % misfiled and 59 us at 17 % (C4's last
 // kick). On the way every particle's CURRENT home tile is recorded (home[], newcount[] — movers to the 26 neighbours are
-// counted in LDS first: their global atomics would pile up on a few lines). Slots are read four at a time per thread: the pass
+// counted in LDS first: their global atomics would pile up on a few lines). Slots are read eight at a time per thread: the pass
 // is bound by the load -> ds_add chain of its fullest tiles.
 // Measured and dropped: an LDS queue for the misfiled particles with a dense pass (one lane per corner) behind the loop, with
 // and without the global atomics moved behind the last barrier — no faster at 1 % misfiled, 1.6 x slower at 25 %.
-constexpr int kScDepUnroll = 4;
+constexpr int kScDepUnroll = 8;
 
 template <typename T>
 __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
