@@ -9,12 +9,14 @@
 //   * gather: the per-particle kernel of the untiled path on the ordered rows — the lanes of a wave sit in one tile, so the 12
 //     line requests per particle for the 32 potential values around its cell hit the CU's vector cache (63 -> 33 us at 1e6
 //     particles on 128^3); it also accumulates the beam sizes the next kick's grid needs over the rows it writes;
-//   * a particle that has left the tile of its slot ("crosser": 1 % of the beam per kick in a smooth channel, 10-20 % where the
-//     beam goes through a focus) is still handled exactly — the deposit workgroup adds its eight corners with global float
-//     atomics to a second, otherwise zero grid that the face-merge pass folds in (and clears); the gather reads the potential
-//     from global memory anyway. When more than 1/16 of the beam is misfiled the gather pass of that very kick writes its rows
-//     in the new tile order (the deposit pass counted the new tile populations on the way): a device-side decision (one extra workgroup
-//     of the face-merge pass), no host synchronisation and no extra launch.
+//   * a particle that has left the tile of its slot ("misfiled": 1 % of the beam per kick in a smooth channel, 10-20 % where
+//     the beam goes through a focus) is still handled exactly, by the same code path: a corner that still falls into the
+//     tile's block goes there, any other takes a global float atomic into a second, otherwise zero grid that the face-merge
+//     pass folds in (and clears); the gather reads the potential from global memory anyway. When more than 1/16 of the beam
+//     is misfiled the gather pass of that very kick writes its rows in the new tile order (the deposit pass counted the new
+//     tile populations on the way): a device-side decision (one extra workgroup of the face-merge pass), no host
+//     synchronisation and no extra launch. The header keeps the running share of misfiled particles for the host (see
+//     ScTileHeader): a beam that reshuffles between kicks is better served by the kick-by-kick path.
 // The permutation back to the caller's particle order is carried along and applied by the last kick of the chain.
 #pragma once
 #include <stddef.h>
