@@ -74,6 +74,16 @@ def test_steady_state_tracking_calls_do_not_synchronise():
     vec = ca.Segment([ca.Drift(t(1.0), **kw), ca.Quadrupole(t(0.2), k1=torch.linspace(-3, 3, 8, **kw), **kw), ca.Drift(t(1.0), **kw)])
     flows["vectorised track"] = lambda: vec.track(beam)
     flows["track_moments"] = lambda: vec.track_moments(beam)
+    # the chain of tile-ordered space-charge kicks incl. its guard (pinned copy of the chain's header + event poll, first tracks
+    # of a plan) and a run of drift-kick-drift elements in one call
+    big = ca.ParticleBeam.from_parameters(num_particles=100_000, **kw)
+    chain = ca.Segment([el for i in range(3) for el in (ca.SpaceChargeKick(t(0.1), grid_shape=(32, 32, 32), **kw), ca.Drift(t(0.2), **kw),
+                                                        ca.Quadrupole(t(0.1), k1=t(2.0 if i % 2 else -2.0), **kw))])
+    flows["space-charge chain"] = lambda: chain.track(big)
+    dkd = ca.Segment([ca.Drift(t(0.2), tracking_method="drift_kick_drift", **kw),
+                      ca.Quadrupole(t(0.1), k1=t(2.0), tracking_method="drift_kick_drift", **kw),
+                      ca.Drift(t(0.2), tracking_method="drift_kick_drift", **kw)])
+    flows["drift-kick-drift run"] = lambda: dkd.track(beam)
     for name, fn in flows.items():
         hits = sync_warnings(fn)
         assert not hits, (name, [(w.filename, w.lineno) for w in hits])
