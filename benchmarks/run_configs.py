@@ -112,7 +112,7 @@ def c4(N=1_000_000, g=128):
     beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=N, total_charge=t(1e-9, dt), energy=t(2.5e8, dt),
                                                 radius_x=t(1e-3, dt), radius_y=t(1e-3, dt), radius_tau=t(1e-3, dt),
                                                 sigma_px=t(1e-6, dt), sigma_py=t(1e-6, dt), sigma_p=t(1e-6, dt), **kw)
-    ms = timeit(lambda: seg.track(beam), 3, 1)
+    ms = timeit(lambda: seg.track(beam), 10, 4)
     sc = els[1]
     ms_kick = timeit(lambda: sc.track(beam), 5, 2)
     return {"config": f"C4 50-element linac, 10 SpaceChargeKicks {g}^3, N={N}, fp32", "track_ms": ms,

@@ -729,7 +729,7 @@ class Segment(Element):
     def _chain_guard(self, plan) -> dict:
         guard = self.__dict__.get("_chain_guard_state")
         if guard is None or guard["plan"] is not plan:
-            guard = self.__dict__["_chain_guard_state"] = {"plan": plan, "off": False, "samples": 0, "pending": None}
+            guard = self.__dict__["_chain_guard_state"] = {"plan": plan, "off": False, "samples": 0, "pending": None, "host": None}
         return guard
 
     def _chain_allowed(self, plan) -> bool:
@@ -748,7 +748,9 @@ class Segment(Element):
         if guard["off"] or guard["pending"] is not None or guard["samples"] >= self._CHAIN_SAMPLES:
             return
         guard["samples"] += 1
-        host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+        host = guard["host"]
+        if host is None:                                   # one page-locked buffer per plan (its allocation is the slow part)
+            host = guard["host"] = torch.empty(8, dtype=torch.int32, pin_memory=True)
         host.copy_(state[:32].view(torch.int32), non_blocking=True)
         done = torch.cuda.Event()
         done.record()
