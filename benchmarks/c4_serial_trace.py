@@ -28,4 +28,5 @@ for _ in range(3):
     log.clear()
     seg.track(beam)
     torch.cuda.synchronize()
-print("header (parity, scatter_now, ncross, ticket, last_ncross, n_sorts) after the track:", log[-1][:32].view(torch.int32).tolist()[:6])
+print("header (parity, scatter_now, misfiled, sum of misfiled permille, misfiled, n_sorts, n_deposits) after the track:",
+      log[-1][:32].view(torch.int32).tolist()[:7])

@@ -725,13 +725,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
     T* __restrict__ extent, double* __restrict__ pot_scale, int* __restrict__ tile_hdr, int tile_first) {
     __shared__ double red[16 * kSG];
     // chain of tile-ordered kicks (chx_sc_tiles.h): this single-workgroup kernel runs before the deposit / gather kernels of the
-    // kick, so it is where the header rolls over: header = {parity, scatter_now, ncross, ...}
+    // kick, so it is where the header rolls over: header = {parity, scatter_now, ...}
     if (tile_hdr && !tile_first && blockIdx.x == 0 && threadIdx.x == 0) {
         if (tile_hdr[1]) {          // the previous kick's gather wrote its rows in a new tile order: its arrays are in force now
             tile_hdr[0] ^= 1;
             tile_hdr[1] = 0;
         }
-        tile_hdr[2] = 0;            // crosser list of the kick that starts here
     }
     __shared__ double tot[kSG];
     const int64_t b = blockIdx.x;

@@ -216,7 +216,7 @@ extern "C" int chx_sc_kick_sorted(const void* x_in, const void* charge, const vo
     if (forked) (void)hipEventRecord(join, side);
 
     // first kick of the chain: order the rows by deposit tile (into the state's row buffer); every kick: deposit from the ordered
-    // rows (the crosser pass decides on the device whether this kick's gather re-orders them for the kicks that follow)
+    // rows (the merge pass decides on the device whether this kick's gather re-orders them for the kicks that follow)
     const void* rows = first ? nullptr : x_in;             // nullptr = the state's row buffer
     if (rc == CHX_OK && first) rc = chx_sc_tile_sort(x_in, charge, survival, extent, scale, N, bins, dtype, state, state_bytes, main);
     if (rc == CHX_OK) rc = chx_sc_tile_deposit(rows, extent, scale, N, bins, dtype, state, state_bytes, rho, last ? 0 : 1, main);

@@ -600,7 +600,7 @@ extern "C" int chx_sc_gather_kick_phi(const void* x_in, const void* phi_halo, co
 // spills of the fp64 particle step under a 128-VGPR cap cost more than the cache already gives for free.)
 // Destination of a row: its own slot; the caller's particle index (perm) for the last kick of a chain; or, when the deposit of
 // this kick found the order stale (header.scatter_now), a slot of the particle's CURRENT home tile taken from the cursors the
-// crosser pass prepared — the rows, weights, charges and the permutation then move to the other copy of the state arrays.
+// merge pass prepared — the rows, weights, charges and the permutation then move to the other copy of the state arrays.
 namespace {
 
 template <typename T>

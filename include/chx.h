@@ -466,7 +466,7 @@ int chx_sc_kick(const void* x_in, const void* charge, const void* survival, cons
  * than 1/16 of the beam is misfiled the gather of that kick writes its rows in the new tile order (device-side decision, no host
  * synchronisation, no extra launch). B = 1 (one beam), grids as chx_sc_kick.
  *  - state: chx_sc_tile_state_bytes() bytes that live as long as the chain (header, tile starts, permutation, ordered
- *    weights / charges, row buffer, face buffers, crosser list); workspace: per-kick scratch, chx_sc_kick_sorted_workspace_bytes();
+ *    weights / charges, row buffer, face buffers, the misfiled particles' grid); workspace: per-kick scratch, chx_sc_kick_sorted_workspace_bytes();
  *  - flags: CHX_SC_FIRST (1) x_in, charge, survival are the caller's arrays in the caller's order — sort; otherwise x_in is the
  *    x_out of the previous kick of the chain (possibly mapped through linear elements) and charge / survival are ignored;
  *    CHX_SC_LAST (2) x_out is written in the caller's particle order (else in tile order);

@@ -97,7 +97,7 @@ def _no_charge(ca, seg):
 
 def test_strong_mixing_takes_the_slow_paths_and_resorts(ca):
     """Quadrupoles strong enough to turn the beam inside out between kicks: most particles leave the tile of their slot
-    (crosser list, global atomics / global potential loads), and the device re-sorts on the next kick."""
+    (global atomics into the second grid / global potential loads), and the device re-sorts on the next kick."""
     dt = torch.float32
     kw = {"dtype": dt, "device": "cuda"}
     t = lambda v: torch.tensor(v, **kw)  # noqa: E731
