@@ -771,10 +771,13 @@ class Segment(Element):
         if run is not None:
             p = incoming.particles
             fr = run.fast
+            fresh = False          # the plan's device buffers were (re)written on the main stream just now
             if fr is None or fr.dtype != p.dtype or fr.device != p.device:
                 fr = run.fast = _FastRun(run, p.dtype, p.device)
+                fresh = True
             elif fr.epoch != Element._epoch:
                 fr.refresh()
+                fresh = True
             e, sp = incoming.energy, incoming.species
             if fr.ok and e.dtype == fr.dtype and e.device == fr.device and not (
                     torch.is_grad_enabled() and (sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad
@@ -782,10 +785,21 @@ class Segment(Element):
                 addr = ctypes.c_void_p()
                 s_in = incoming.s
                 s_out = self._device_s(fr, s_in)
+                # The run's map (and path length) is built on the kick's SIDE stream, in front of the Green-function chain the
+                # kick puts there: it depends on nothing the chain computes (settings, the reference energy), and the main stream
+                # joins the side stream before the gather pass that applies the map. Off the main stream's critical path: 5 us
+                # per kick. The side stream first waits for what the main stream did before the chain (first link: settings edited in
+                # place, the beam) or to the plan's buffers (a plan built or refreshed in this very call).
+                side = kick._side_stream(p.device)
+                stream = _ops.stream_ptr()
+                if side is not None:
+                    if first or fresh:
+                        side.wait_stream(torch.cuda.current_stream(p.device))
+                    stream = side.cuda_stream
                 _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
                                                   sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
                                                   ctypes.byref(addr), s_in.data_ptr() if s_out is not None else None,
-                                                  s_out.data_ptr() if s_out is not None else None, _ops.stream_ptr()), "chx_run_map")
+                                                  s_out.data_ptr() if s_out is not None else None, stream), "chx_run_map")
                 R_addr, fused = addr.value, True
                 if s_out is None:
                     s_out = self._run_s(run, s_in)
