@@ -75,15 +75,22 @@ struct Mat7 {
 
 template <typename S>
 __device__ void eye7(Mat7<S>& M) {
+#pragma unroll
     for (int k = 0; k < 49; ++k) M.m[k] = cst<S>(0.0);
+#pragma unroll
     for (int i = 0; i < 7; ++i) M(i, i) = cst<S>(1.0);
 }
 
+// fully unrolled: every index is a constant, so the matrices of the dual-number instantiation (98 doubles each: they live in
+// scratch) are read in batches instead of one dependent load per multiply-add
 template <typename S>
 __device__ void matmul7(const Mat7<S>& A, const Mat7<S>& Bm, Mat7<S>& Cm) {
+#pragma unroll
     for (int i = 0; i < 7; ++i)
+#pragma unroll
         for (int j = 0; j < 7; ++j) {
             S acc = A(i, 0) * Bm(0, j);
+#pragma unroll
             for (int k = 1; k < 7; ++k) acc = acc + A(i, k) * Bm(k, j);
             Cm(i, j) = acc;
         }
@@ -149,7 +156,9 @@ __device__ void rotation_map(S angle, Mat7<S>& R) {
 
 template <typename S>
 __device__ void transpose7(const Mat7<S>& A, Mat7<S>& At) {
+#pragma unroll
     for (int i = 0; i < 7; ++i)
+#pragma unroll
         for (int j = 0; j < 7; ++j) At(i, j) = A(j, i);
 }
 
