@@ -73,6 +73,50 @@ struct Mat7 {
     __device__ __forceinline__ const S& operator()(int i, int j) const { return m[i * 7 + j]; }
 };
 
+// The dual-number matrices of the builders' VJP kernels live in LDS and are SHARED by the lanes of a wave: a VJP kernel runs one
+// wave per (element, input) pair, every lane executes the builder's scalar code redundantly (identical values: the redundant
+// stores to a shared matrix all carry the same value), and the dense 7x7 products are split over the lanes (matmul7<Dual>
+// below: lane 7 i + j forms entry (i, j)). One lane doing everything — matrices in its stack, i.e. scratch memory, 2.7 KB of it,
+// or in a private LDS slab — took 32-35 us for ONE quadrupole: ~700 dependent dual-number multiply-adds in a single thread.
+// The matrices are handed out from the workgroup's slab in stack order as the builders' locals come and go (every lane keeps its
+// own, identical, depth counter). ttensor_vjp_kernel fills its tensors from thread 0 alone: it never calls matmul7.
+constexpr int kDualArenaLanes = 64;
+constexpr int kDualArenaMats = 8;     // deepest nesting: dipole_map's seven locals + the caller's result
+
+__device__ __forceinline__ Dual* dual_arena_slab(int*& depth) {
+    __shared__ Dual arena[kDualArenaMats * 49];
+    __shared__ int depths[kDualArenaLanes];
+    depth = &depths[threadIdx.x];
+    return arena;
+}
+// at the entry of a kernel whose threads build dual-number maps (threadIdx.x < kDualArenaLanes)
+__device__ __forceinline__ void dual_arena_reset() {
+    int* depth;
+    dual_arena_slab(depth);
+    *depth = 0;
+}
+
+template <>
+struct Mat7<Dual> {
+    Dual* m;
+    __device__ __forceinline__ Mat7() {
+        int* depth;
+        Dual* slab = dual_arena_slab(depth);
+        if (threadIdx.x >= kDualArenaLanes || *depth >= kDualArenaMats) __builtin_trap();
+        m = slab + *depth * 49;
+        *depth += 1;
+    }
+    __device__ __forceinline__ ~Mat7() {
+        int* depth;
+        dual_arena_slab(depth);
+        *depth -= 1;
+    }
+    Mat7(const Mat7&) = delete;
+    Mat7& operator=(const Mat7&) = delete;
+    __device__ __forceinline__ Dual& operator()(int i, int j) { return m[i * 7 + j]; }
+    __device__ __forceinline__ const Dual& operator()(int i, int j) const { return m[i * 7 + j]; }
+};
+
 template <typename S>
 __device__ void eye7(Mat7<S>& M) {
 #pragma unroll
@@ -94,6 +138,20 @@ __device__ void matmul7(const Mat7<S>& A, const Mat7<S>& Bm, Mat7<S>& Cm) {
             for (int k = 1; k < 7; ++k) acc = acc + A(i, k) * Bm(k, j);
             Cm(i, j) = acc;
         }
+}
+
+// C = A B for the wave-shared dual-number matrices (see Mat7<Dual>): lane 7 i + j forms entry (i, j); A, B, C are distinct
+template <>
+__device__ __forceinline__ void matmul7<Dual>(const Mat7<Dual>& A, const Mat7<Dual>& Bm, Mat7<Dual>& Cm) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 49) {
+        const int i = lane / 7, j = lane - 7 * i;
+        Dual acc = A(i, 0) * Bm(0, j);
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = acc + A(i, k) * Bm(k, j);
+        Cm.m[lane] = acc;
+    }
+    chx_wave_sync();          // the other lanes read these entries next
 }
 
 template <typename S>
@@ -363,14 +421,14 @@ __global__ void build_kernel(int kind, const T* __restrict__ params, const T* __
     for (int k = 0; k < 49; ++k) R_out[b * 49 + k] = (T)R.m[k];
 }
 
-// one thread per (b, input k) with k in [0, P] (k == P is the energy)
+// one WAVE per (b, input k) with k in [0, P] (k == P is the energy): see Mat7<Dual>
 template <typename T>
-__global__ void build_vjp_kernel(int kind, const T* __restrict__ params, const T* __restrict__ energy,
-                                 double mass, double nq, const T* __restrict__ dR, int64_t B,
-                                 int64_t Bp, int64_t Be, int P, T* __restrict__ dparams,
-                                 T* __restrict__ denergy) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * (P + 1)) return;
+__global__ __launch_bounds__(64) void build_vjp_kernel(int kind, const T* __restrict__ params, const T* __restrict__ energy,
+                                                       double mass, double nq, const T* __restrict__ dR, int64_t B,
+                                                       int64_t Bp, int64_t Be, int P, T* __restrict__ dparams,
+                                                       T* __restrict__ denergy) {
+    const int64_t idx = blockIdx.x;
+    dual_arena_reset();
     const int64_t b = idx / (P + 1);
     const int k = (int)(idx - b * (P + 1));
     Dual p[CHX_MAX_PARAMS];
@@ -378,10 +436,14 @@ __global__ void build_vjp_kernel(int kind, const T* __restrict__ params, const T
     const Dual en = mk((double)energy[Be == 1 ? 0 : b], k == P ? 1.0 : 0.0);
     Mat7<Dual> R;
     build_kind<Dual>(kind, p, en, mass, nq, R);
-    double acc = 0.0;
-    for (int q = 0; q < 49; ++q) acc += (double)dR[b * 49 + q] * R.m[q].d;
-    if (k < P) dparams[b * P + k] = (T)acc;
-    else denergy[b] = (T)acc;
+    chx_wave_sync();
+    const int lane = threadIdx.x;
+    double acc = lane < 49 ? (double)dR[b * 49 + lane] * R.m[lane].d : 0.0;
+    acc = chx_wave_sum(acc);
+    if (lane == 0) {
+        if (k < P) dparams[b * P + k] = (T)acc;
+        else denergy[b] = (T)acc;
+    }
 }
 
 // ---- composition (segment.py:534-543): tm = R_e @ tm for e = 0..E-1 -------------------------
@@ -799,6 +861,7 @@ __global__ __launch_bounds__(kTBlock) void ttensor_vjp_kernel(int kind, const T*
     if (id < 343) Ts[id] = mk(0.0, 0.0);
     __syncthreads();
     if (id == 0) {
+        dual_arena_reset();
         Dual p[CHX_MAX_PARAMS];
         for (int j = 0; j < P; ++j) p[j] = mk((double)params[(Bp == 1 ? 0 : b) * P + j], j == k ? 1.0 : 0.0);
         const Dual en = mk((double)energy[Be == 1 ? 0 : b], k == P ? 1.0 : 0.0);
@@ -1007,7 +1070,8 @@ extern "C" int chx_build_rmatrix_vjp(int kind, const void* params, const void* e
         return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bp, B) || !chx_bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
     const int64_t work = B * (P + 1);
-    const int grid = (int)((work + 63) / 64);
+    if (work > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    const int grid = (int)work;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(build_vjp_kernel<float>, dim3(grid), dim3(64), 0, s, kind,
@@ -1229,31 +1293,34 @@ __global__ __launch_bounds__(64) void compose_vjp_kernel(ComposeArgs args, int E
     }
 }
 
-// one thread per (element, slot k): slots 0 .. P-1 are the element's parameters, slot CHX_MAX_PARAMS the energy, the rest
-// are written as zeros. out[e][CHX_MAX_PARAMS + 1]
+// one WAVE per (element, slot k) (see Mat7<Dual>): slots 0 .. P-1 are the element's parameters, slot CHX_MAX_PARAMS the energy,
+// the rest are written as zeros. out[e][CHX_MAX_PARAMS + 1]
 template <typename T>
 __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs args, int n, const T* __restrict__ energy,
                                                                double mass, double nq, const double* __restrict__ dR,
                                                                T* __restrict__ out) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int idx = blockIdx.x;
     const int e = idx / (CHX_MAX_PARAMS + 1), k = idx - e * (CHX_MAX_PARAMS + 1);
     if (e >= n) return;
+    const int lane = threadIdx.x;
     const int kind = args.kind[e];
     const int P = kind_num_params(kind);
     const bool is_energy = k == CHX_MAX_PARAMS;
     T* o = out + e * (CHX_MAX_PARAMS + 1);
     if ((!is_energy && k >= P) || !((args.need[e] >> k) & 1)) {
-        o[k] = (T)0;
+        if (lane == 0) o[k] = (T)0;
         return;
     }
+    dual_arena_reset();
     Dual p[CHX_MAX_PARAMS];
     for (int q = 0; q < P; ++q) p[q] = mk((double)*(const T*)args.par[e][q], (!is_energy && q == k) ? 1.0 : 0.0);
     const Dual en = mk((double)energy[0], is_energy ? 1.0 : 0.0);
     Mat7<Dual> R;
     build_kind<Dual>(kind, p, en, mass, nq, R);
-    double acc = 0.0;
-    for (int q = 0; q < 49; ++q) acc += dR[e * 49 + q] * R.m[q].d;
-    o[k] = (T)acc;
+    chx_wave_sync();
+    double acc = lane < 49 ? dR[e * 49 + lane] * R.m[lane].d : 0.0;
+    acc = chx_wave_sum(acc);
+    if (lane == 0) o[k] = (T)acc;
 }
 
 // forward of a run whose settings carry gradients, one call: element maps into maps[E][7][7] (kept for the backward pass) and
@@ -1316,7 +1383,7 @@ extern "C" int chx_run_vjp_masked(const int32_t* kinds, const void* const* param
             }
         }
         char* out = (char*)dinputs + (size_t)done * (CHX_MAX_PARAMS + 1) * esz;
-        const unsigned blocks = (unsigned)((n * (CHX_MAX_PARAMS + 1) + 63) / 64);
+        const unsigned blocks = (unsigned)(n * (CHX_MAX_PARAMS + 1));
         if (dtype == CHX_F32)
             hipLaunchKernelGGL(build_scalars_vjp_kernel<float>, dim3(blocks), dim3(64), 0, s, a, n, (const float*)energy, mass_eV,
                                n_charges, ws + done * 49, (float*)out);
