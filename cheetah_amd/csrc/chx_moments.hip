@@ -1233,44 +1233,53 @@ extern "C" int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, d
 // Exactly what autograd gives through chx_moments_bwd + chx_apply_affine7_bwd's dR reduction (sum_n dY_n x_n^T) when the
 // particles carry no gradient of their own — 32 B/particle (one pass for mu, C, cacheable across steps) instead of 232.
 namespace {
-// dR (49 doubles) of one batch row from the gradient g[29] of its outgoing moments, its map Rb (T) and the incoming moments m[29]
-template <typename T>
-__device__ __forceinline__ void mapped_bwd_row(const double* g, const T* __restrict__ Rb, const double* __restrict__ m, double* o) {
-    double G[6][6], C[6][6], A[6][6];
-    int k = 8;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j, ++k) {
-            G[i][j] = G[j][i] = (i == j) ? g[k] : 0.5 * g[k];
-            C[i][j] = C[j][i] = m[k];
-        }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) A[i][j] = (double)Rb[i * 7 + j];
-    double AC[6][6];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            double acc = 0.0;
-            for (int l = 0; l < 6; ++l) acc += A[i][l] * C[l][j];
-            AC[i][j] = acc;
-        }
-    for (int i = 0; i < 6; ++i) {
-        for (int j = 0; j < 6; ++j) {
-            double acc = 0.0;
-            for (int l = 0; l < 6; ++l) acc += G[i][l] * AC[l][j];
-            o[i * 7 + j] = 2.0 * acc + g[2 + i] * m[2 + j];
-        }
-        o[i * 7 + 6] = g[2 + i];
+// dR (49 values) of one batch row from the gradient g[29] of its outgoing moments, its map Rb (T) and the incoming moments
+// m[29], by ONE WAVE: lane 6 i + j (i, j < 6) owns entry (i, j) of the 6x6 products, which pass through LDS (a single thread
+// doing the two dense products took 14 us). g, m: anywhere readable by every lane; lds: 3 * 36 doubles of this wave.
+template <typename T, typename TO>
+__device__ __forceinline__ void mapped_bwd_row_wave(const double* g, const T* __restrict__ Rb, const double* __restrict__ m,
+                                                    double* lds, TO* __restrict__ o) {
+    const int lane = threadIdx.x & 63;
+    double* G = lds;
+    double* AC = lds + 36;
+    double* C = lds + 72;
+    const int i = lane / 6, j = lane - 6 * i;
+    if (lane < 36) {
+        // index of (min, max) in the upper-triangle listing that starts at 8
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int k = 8 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+        G[lane] = (i == j) ? g[k] : 0.5 * g[k];
+        C[lane] = m[k];
     }
-    for (int j = 0; j < 7; ++j) o[42 + j] = 0.0;
+    chx_wave_sync();
+    if (lane < 36) {
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) acc += (double)Rb[i * 7 + l] * C[l * 6 + j];
+        AC[lane] = acc;
+    }
+    chx_wave_sync();
+    if (lane < 36) {
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) acc += G[i * 6 + l] * AC[l * 6 + j];
+        o[i * 7 + j] = (TO)(2.0 * acc + g[2 + i] * m[2 + j]);
+    } else if (lane < 42) {
+        o[(lane - 36) * 7 + 6] = (TO)g[2 + (lane - 36)];
+    } else if (lane < 49) {
+        o[42 + (lane - 42)] = (TO)0;
+    }
 }
 
+// one wave per batch row
 template <typename T>
-__global__ void moments_mapped_bwd_kernel(const double* __restrict__ d_out, const T* __restrict__ R, int64_t BR,
-                                          const double* __restrict__ mom_x, int64_t Bm, int64_t B, double* __restrict__ dR) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double o[49];
-    mapped_bwd_row<T>(d_out + b * CHX_MOM_NOUT, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, o);
-    for (int q = 0; q < 49; ++q) dR[b * 49 + q] = o[q];
+__global__ __launch_bounds__(64) void moments_mapped_bwd_kernel(const double* __restrict__ d_out, const T* __restrict__ R, int64_t BR,
+                                                                const double* __restrict__ mom_x, int64_t Bm, int64_t B,
+                                                                double* __restrict__ dR) {
+    __shared__ double lds[3 * 36];
+    const int64_t b = blockIdx.x;
+    mapped_bwd_row_wave<T, double>(d_out + b * CHX_MOM_NOUT, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, lds,
+                                   dR + b * 49);
 }
 
 // one ENTRY of the moment vector (optionally its square root) in the beam dtype, and its backward straight to dR: the node a
@@ -1284,26 +1293,31 @@ __global__ void moment_entry_kernel(const double* __restrict__ mom, int64_t B, i
 }
 
 template <typename T, typename TO>
-__global__ void moment_entry_mapped_bwd_kernel(const T* __restrict__ grad, const double* __restrict__ mom_y, int index,
-                                               int take_sqrt, const T* __restrict__ R, int64_t BR,
-                                               const double* __restrict__ mom_x, int64_t Bm, int64_t B, TO* __restrict__ dR) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double g[CHX_MOM_NOUT];
-    for (int q = 0; q < CHX_MOM_NOUT; ++q) g[q] = 0.0;
-    double gv = (double)grad[b];
-    if (take_sqrt) gv = gv * 0.5 / sqrt(mom_y[b * CHX_MOM_NOUT + index]);   // infinite at 0 like torch.sqrt's own backward
-    g[index] = gv;
-    double o[49];
-    mapped_bwd_row<T>(g, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, o);
-    for (int q = 0; q < 49; ++q) dR[b * 49 + q] = (TO)o[q];
+__global__ __launch_bounds__(64) void moment_entry_mapped_bwd_kernel(const T* __restrict__ grad, const double* __restrict__ mom_y,
+                                                                     int index, int take_sqrt, const T* __restrict__ R, int64_t BR,
+                                                                     const double* __restrict__ mom_x, int64_t Bm, int64_t B,
+                                                                     TO* __restrict__ dR) {
+    __shared__ double lds[3 * 36];
+    __shared__ double g[CHX_MOM_NOUT];
+    const int64_t b = blockIdx.x;
+    if (threadIdx.x < CHX_MOM_NOUT) {
+        double gv = 0.0;
+        if ((int)threadIdx.x == index) {
+            gv = (double)grad[b];
+            if (take_sqrt) gv = gv * 0.5 / sqrt(mom_y[b * CHX_MOM_NOUT + index]);   // infinite at 0 like torch.sqrt's own backward
+        }
+        g[threadIdx.x] = gv;
+    }
+    chx_wave_sync();
+    mapped_bwd_row_wave<T, TO>(g, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, lds, dR + b * 49);
 }
 }  // namespace
 
 extern "C" int chx_moments_mapped_bwd(const double* d_out, const void* R, const double* mom_x, int64_t B, int64_t BR,
                                       int64_t Bm, int dtype, double* dR, void* stream) {
-    if (!d_out || !R || !mom_x || !dR || B < 1 || (BR != 1 && BR != B) || (Bm != 1 && Bm != B)) return CHX_ERR_INVALID_ARG;
-    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    if (!d_out || !R || !mom_x || !dR || B < 1 || B > 0x7fffffffLL || (BR != 1 && BR != B) || (Bm != 1 && Bm != B))
+        return CHX_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)B), block(64);
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(moments_mapped_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, d_out, (const float*)R, BR,
                            mom_x, Bm, B, dR);
@@ -1332,10 +1346,10 @@ extern "C" int chx_moment_entry(const double* mom, int64_t B, int index, int tak
 extern "C" int chx_moment_entry_mapped_bwd(const void* grad, const double* mom_y, int index, int take_sqrt, const void* R,
                                            const double* mom_x, int64_t B, int64_t BR, int64_t Bm, int dtype, void* dR,
                                            int dR_is_double, void* stream) {
-    if (!grad || !mom_y || !R || !mom_x || !dR || B < 1 || (BR != 1 && BR != B) || (Bm != 1 && Bm != B) || index < 2 ||
-        index >= CHX_MOM_NOUT)
+    if (!grad || !mom_y || !R || !mom_x || !dR || B < 1 || B > 0x7fffffffLL || (BR != 1 && BR != B) || (Bm != 1 && Bm != B) ||
+        index < 2 || index >= CHX_MOM_NOUT)
         return CHX_ERR_INVALID_ARG;
-    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    const dim3 grid((unsigned)B), block(64);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CHX_F32) {
         if (dR_is_double)
