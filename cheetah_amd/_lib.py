@@ -94,6 +94,8 @@ SIGNATURES = {
     "chx_moment_centred": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_moment_finalize": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "chx_moments": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_moments_entry": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
     "chx_moments_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_moments_bwd_w": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p,
                                   c_void_p]),

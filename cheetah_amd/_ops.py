@@ -115,18 +115,25 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+class _CloneInto(torch.autograd.Function):
+    """`t.clone()` whose copy is made by someone else (clone_many's one launch for all tensors): forward hands out the
+    uninitialised destination, backward is the identity like CloneBackward."""
+
+    @staticmethod
+    def forward(ctx, t, dst):
+        return dst.view_as(dst)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
 def clone_many(tensors):
-    """Copies of up to 8 device tensors by ONE launch (chx_copy_arrays) instead of one `clone()` kernel each; tensors that
-    carry gradients (under autograd), are not contiguous or do not live on a ROCm device are cloned the ordinary way."""
-    plain = [t.is_cuda and t.is_contiguous() and not (t.requires_grad and torch.is_grad_enabled()) for t in tensors]
+    """Copies of up to 8 device tensors by ONE launch (chx_copy_arrays) instead of one `clone()` kernel each — also for tensors
+    that carry a graph (their copies are attached to it by an identity node); tensors that are not contiguous or do not live on
+    a ROCm device are cloned the ordinary way."""
+    plain = [t.is_cuda and t.is_contiguous() for t in tensors]
     out = [torch.empty_like(t) if ok else t.clone() for t, ok in zip(tensors, plain)]
-    for t, o in zip(tensors, out):
-        # provenance (see `_LinearSource` / `_origin`): a copy of a linearly tracked array still IS R x; a copy of a weight
-        # array still holds the values of its source
-        lin = getattr(t, "_chx_lin", None)
-        if lin is not None and lin.version == t._version:
-            o._chx_lin = lin.rebound(o)
-        o._chx_origin = (t, t._version, o._version)
     pairs = [(t, o) for t, o, ok in zip(tensors, out, plain) if ok and t.numel()]
     for lo in range(0, len(pairs), 8):
         chunk = pairs[lo:lo + 8]
@@ -135,6 +142,17 @@ def clone_many(tensors):
                                          (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in chunk]),
                                          (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in chunk]), n, stream_ptr()),
               "chx_copy_arrays")
+    if torch.is_grad_enabled():
+        for i, (t, ok) in enumerate(zip(tensors, plain)):
+            if ok and t.requires_grad:
+                out[i] = _CloneInto.apply(t, out[i])
+    for t, o in zip(tensors, out):
+        # provenance (see `_LinearSource` / `_origin`): a copy of a linearly tracked array still IS R x; a copy of a weight
+        # array still holds the values of its source
+        lin = getattr(t, "_chx_lin", None)
+        if lin is not None and lin.version == t._version:
+            o._chx_lin = lin.rebound(o)
+        o._chx_origin = (t, t._version, o._version)
     return out
 
 
@@ -904,14 +922,21 @@ def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor
 
 # ---------------------------------------------------------------------------------------------
 # moments
-def _moments_raw(x, w, B, N):
+def _moments_raw(x, w, B, N, entry=None):
+    """chx_moments; with entry = (index, take_sqrt) also that entry of every row in x's dtype (chx_moments_entry: the same two
+    launches) -> (moments, entries)."""
     lib = _lib.lib()
     ws_bytes = lib.chx_moments_workspace_bytes(B, N)
     ws = workspace(ws_bytes, x.device)
     out = torch.empty((B, MOM_NOUT), dtype=torch.float64, device=x.device)
-    check(lib.chx_moments(ptr(x), ptr(w), B, x.shape[0], 1 if w is None else w.shape[0], N, dtype_code(x.dtype),
-                          ptr(out), ptr(ws), ws_bytes, stream_ptr()), "chx_moments")
-    return out
+    if entry is None:
+        check(lib.chx_moments(ptr(x), ptr(w), B, x.shape[0], 1 if w is None else w.shape[0], N, dtype_code(x.dtype),
+                              ptr(out), ptr(ws), ws_bytes, stream_ptr()), "chx_moments")
+        return out
+    picked = torch.empty((B,), dtype=x.dtype, device=x.device)
+    check(lib.chx_moments_entry(ptr(x), ptr(w), B, x.shape[0], 1 if w is None else w.shape[0], N, dtype_code(x.dtype), ptr(out),
+                                entry[0], int(entry[1]), ptr(picked), ptr(ws), ws_bytes, stream_ptr()), "chx_moments_entry")
+    return out, picked
 
 
 class Moments(torch.autograd.Function):
@@ -942,18 +967,21 @@ class Moments(torch.autograd.Function):
         return dX, dW, None
 
 
-def _memo_moments(owner: torch.Tensor, x: torch.Tensor, w, survival, B: int) -> torch.Tensor:
+def _memo_moments(owner: torch.Tensor, x: torch.Tensor, w, survival, B: int, entry=None):
     """chx_moments (B,29) of the flat, gradient-free x (Bx,N,7) / w (Bw,N), memoised on the tensor OBJECT `owner` the values
     belong to, against (its version, the weight tensor — followed to the array it is an unmodified copy of — and that
-    array's version, the data address). An optimisation loop tracks one incoming beam again and again: reduced once."""
+    array's version, the data address). An optimisation loop tracks one incoming beam again and again: reduced once.
+    With entry = (index, take_sqrt): returns (moments, that entry per row in x's dtype — or None on a memo hit, the caller then
+    picks it with chx_moment_entry)."""
     w_src = None if survival is None else _origin(survival)
     cached = getattr(owner, "_chx_mom", None)
     if cached is not None and cached[0] == owner._version and cached[1] is w_src \
             and (w_src is None or cached[2] == w_src._version) and cached[3] == x.data_ptr() and cached[4].shape[0] == B:
-        return cached[4]
-    mom = _moments_raw(x, w, B, x.shape[1])
+        return cached[4] if entry is None else (cached[4], None)
+    res = _moments_raw(x, w, B, x.shape[1], entry)
+    mom = res if entry is None else res[0]
     owner._chx_mom = (owner._version, w_src, None if w_src is None else w_src._version, x.data_ptr(), mom)
-    return mom
+    return res
 
 
 def _incoming_moments(lin: "_LinearSource", survival, w, B: int) -> torch.Tensor:
@@ -995,10 +1023,13 @@ class MomentEntryMapped(torch.autograd.Function):
     (scalar gradient -> dR in one launch, from the incoming beam's memoised moments)."""
 
     @staticmethod
-    def forward(ctx, R, mom_y, source, index, take_sqrt, B):
-        out = torch.empty((B,), dtype=R.dtype, device=R.device)
-        check(_lib.lib().chx_moment_entry(ptr(mom_y), B, index, int(take_sqrt), dtype_code(R.dtype), ptr(out), stream_ptr()),
-              "chx_moment_entry")
+    def forward(ctx, R, mom_y, source, index, take_sqrt, B, picked=None):
+        if picked is not None:                      # came with the reduction (chx_moments_entry)
+            out = picked
+        else:
+            out = torch.empty((B,), dtype=R.dtype, device=R.device)
+            check(_lib.lib().chx_moment_entry(ptr(mom_y), B, index, int(take_sqrt), dtype_code(R.dtype), ptr(out), stream_ptr()),
+                  "chx_moment_entry")
         lin, survival, w = source
         ctx.save_for_backward(R, mom_y, lin.x, *(() if w is None else (w,)))
         ctx.meta = (lin, survival, index, take_sqrt, B)
@@ -1018,7 +1049,7 @@ class MomentEntryMapped(torch.autograd.Function):
                                                      stream_ptr()), "chx_moment_entry_mapped_bwd")
         if not direct:
             dR = dR.sum(dim=0, keepdim=True).to(R.dtype)
-        return dR, None, None, None, None, None
+        return dR, None, None, None, None, None, None
 
 
 def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool):
@@ -1041,8 +1072,10 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
     if survival is not None:
         w, _ = flat_bcast(survival if survival.dtype == particles.dtype else survival.to(particles.dtype), batch_shape, 1)
         w = w.contiguous()
-    mom_y = _memo_moments(particles, y, w, survival, B)
-    return MomentEntryMapped.apply(lin.R, mom_y, (lin, survival, w), index, take_sqrt, B).reshape(batch_shape)
+    mom_y, picked = _memo_moments(particles, y, w, survival, B, (index, take_sqrt))
+    if picked is not None and picked.dtype != lin.R.dtype:
+        picked = None
+    return MomentEntryMapped.apply(lin.R, mom_y, (lin, survival, w), index, take_sqrt, B, picked).reshape(batch_shape)
 
 
 def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Tensor:

@@ -1295,10 +1295,61 @@ __global__ __launch_bounds__(64) void compose_vjp_kernel(ComposeArgs args, int E
 
 // one WAVE per (element, slot k) (see Mat7<Dual>): slots 0 .. P-1 are the element's parameters, slot CHX_MAX_PARAMS the energy,
 // the rest are written as zeros. out[e][CHX_MAX_PARAMS + 1]
+// dL/dR_e of compose_scalars_bwd_kernel for ONE element, by the calling wave alone (the same products in the same order: prefix
+// P_e = R_{e-1} ... R_0, G_e = (R_{E-1} ... R_{e+1})^T dT, dL/dR_e = G_e P_e^T): E - 1 cooperative 7x7 products instead of a
+// launch of its own in front of the VJP kernel — for the short runs of an optimisation loop (E <= kRunVjpFuseE) the launch costs
+// more than the sweep. dRl: 49 doubles of LDS; tmp: 3 * 49 doubles of LDS.
+constexpr int kRunVjpFuseE = 16;
+
+template <typename T>
+__device__ __forceinline__ void wave_element_cotangent(const T* __restrict__ maps, int E, int e, const T* __restrict__ dT, double* tmp,
+                                                       double* dRl) {
+    double* P = tmp;
+    double* R = tmp + 49;
+    double* G = tmp + 98;
+    const int lane = threadIdx.x & 63, i = lane / 7, j = lane - 7 * i;
+    const bool on = lane < 49;
+    if (on) P[lane] = (i == j) ? 1.0 : 0.0;
+    chx_wave_sync();
+    for (int q = 0; q < e; ++q) {
+        if (on) R[lane] = (double)maps[q * 49 + lane];
+        chx_wave_sync();
+        double acc = 0.0;
+        if (on) {
+            acc = R[i * 7] * P[j];
+            for (int k = 1; k < 7; ++k) acc = fma(R[i * 7 + k], P[k * 7 + j], acc);
+        }
+        chx_wave_sync();
+        if (on) P[lane] = acc;
+        chx_wave_sync();
+    }
+    if (on) G[lane] = (double)dT[lane];
+    chx_wave_sync();
+    for (int q = E - 1; q > e; --q) {
+        if (on) R[lane] = (double)maps[q * 49 + lane];
+        chx_wave_sync();
+        double gn = 0.0;
+        if (on)
+            for (int k = 0; k < 7; ++k) gn = fma(R[k * 7 + i], G[k * 7 + j], gn);
+        chx_wave_sync();
+        if (on) G[lane] = gn;
+        chx_wave_sync();
+    }
+    if (on) {
+        double dr = 0.0;
+        for (int k = 0; k < 7; ++k) dr = fma(G[i * 7 + k], P[j * 7 + k], dr);
+        dRl[lane] = dr;
+    }
+    chx_wave_sync();
+}
+
+// dR: dL/dR_e of every element ([n][49], from compose_scalars_bwd_kernel), or NULL: formed here from maps / dT (fused form)
 template <typename T>
 __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs args, int n, const T* __restrict__ energy,
                                                                double mass, double nq, const double* __restrict__ dR,
+                                                               const T* __restrict__ maps, const T* __restrict__ dT,
                                                                T* __restrict__ out) {
+    __shared__ double cot[4 * 49];
     const int idx = blockIdx.x;
     const int e = idx / (CHX_MAX_PARAMS + 1), k = idx - e * (CHX_MAX_PARAMS + 1);
     if (e >= n) return;
@@ -1318,30 +1369,11 @@ __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs 
     Mat7<Dual> R;
     build_kind<Dual>(kind, p, en, mass, nq, R);
     chx_wave_sync();
-    double acc = lane < 49 ? dR[e * 49 + lane] * R.m[lane].d : 0.0;
+    const double* dRe = dR ? dR + e * 49 : cot + 147;
+    if (!dR) wave_element_cotangent<T>(maps, n, e, dT, cot, cot + 147);
+    double acc = lane < 49 ? dRe[lane] * R.m[lane].d : 0.0;
     acc = chx_wave_sum(acc);
     if (lane == 0) o[k] = (T)acc;
-}
-
-// forward of a run whose settings carry gradients, one call: element maps into maps[E][7][7] (kept for the backward pass) and
-// their product into R_out[7][7] — chx_build_rmatrix_scalars + chx_compose_maps, bit-identical to the two calls
-extern "C" int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
-                                     double mass_eV, double n_charges, int dtype, void* maps, void* R_out, void* stream) {
-    if (!maps || !R_out || E < 1 || E > 4096) return CHX_ERR_INVALID_ARG;
-    int st = chx_build_rmatrix_scalars(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, stream);
-    if (st != CHX_OK) return st;
-    const size_t step = 49 * (dtype == CHX_F32 ? 4 : 8);
-    if (E == 1) {
-        if (hipMemcpyAsync(R_out, maps, step, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return CHX_ERR_LAUNCH;
-        return CHX_OK;
-    }
-    const void* ptrs[4096];
-    uint8_t bc[4096];
-    for (int64_t e = 0; e < E; ++e) {
-        ptrs[e] = (const char*)maps + e * step;
-        bc[e] = 1;
-    }
-    return chx_compose_maps(ptrs, bc, E, 1, dtype, R_out, stream);
 }
 
 extern "C" size_t chx_run_vjp_workspace_bytes(int64_t E) { return E < 1 ? 0 : (size_t)E * 49 * sizeof(double); }
@@ -1361,12 +1393,16 @@ extern "C" int chx_run_vjp_masked(const int32_t* kinds, const void* const* param
     if (!workspace || workspace_bytes < chx_run_vjp_workspace_bytes(E)) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* ws = (double*)workspace;
-    if (dtype == CHX_F32)
-        hipLaunchKernelGGL(compose_scalars_bwd_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)maps, (int)E, (const float*)dT, ws);
-    else
-        hipLaunchKernelGGL(compose_scalars_bwd_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)maps, (int)E, (const double*)dT,
-                           ws);
-    CHX_CHECK_LAUNCH();
+    const bool fused = E <= kRunVjpFuseE && E <= kBuildChunk;      // every wave forms its element's cotangent itself
+    if (!fused) {
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(compose_scalars_bwd_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)maps, (int)E, (const float*)dT,
+                               ws);
+        else
+            hipLaunchKernelGGL(compose_scalars_bwd_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)maps, (int)E,
+                               (const double*)dT, ws);
+        CHX_CHECK_LAUNCH();
+    }
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
     for (int64_t done = 0; done < E; done += kBuildChunk) {
         BuildScalarsArgs a;
@@ -1386,10 +1422,12 @@ extern "C" int chx_run_vjp_masked(const int32_t* kinds, const void* const* param
         const unsigned blocks = (unsigned)(n * (CHX_MAX_PARAMS + 1));
         if (dtype == CHX_F32)
             hipLaunchKernelGGL(build_scalars_vjp_kernel<float>, dim3(blocks), dim3(64), 0, s, a, n, (const float*)energy, mass_eV,
-                               n_charges, ws + done * 49, (float*)out);
+                               n_charges, fused ? (const double*)nullptr : ws + done * 49, (const float*)maps, (const float*)dT,
+                               (float*)out);
         else
             hipLaunchKernelGGL(build_scalars_vjp_kernel<double>, dim3(blocks), dim3(64), 0, s, a, n, (const double*)energy, mass_eV,
-                               n_charges, ws + done * 49, (double*)out);
+                               n_charges, fused ? (const double*)nullptr : ws + done * 49, (const double*)maps, (const double*)dT,
+                               (double*)out);
         CHX_CHECK_LAUNCH();
     }
     return CHX_OK;
@@ -1459,8 +1497,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void run_map_kernel(RunArgs a, int E, in
                                                            T* __restrict__ maps /*[E][49]*/, T* __restrict__ R /*[49]*/,
                                                            const T* __restrict__ s_in, T* __restrict__ s_out) {
     // 1. anything different from what R was built from? (NaN-initialised state: the first call is always dirty)
-    int dirty = 0;
-    for (int q = threadIdx.x; q < nptr + 3; q += CHX_BLOCK) {
+    // (seen == NULL: no stored state, the maps are always built — chx_run_build_compose)
+    int dirty = seen ? 0 : 1;
+    for (int q = threadIdx.x; seen && q < nptr + 3; q += CHX_BLOCK) {
         const double v = q < nptr ? (double)*(const T*)a.ptr[q] : (q == nptr ? (double)energy[0] : (q == nptr + 1 ? mass : nq));
         if (!(v == seen[q])) dirty = 1;
     }
@@ -1489,7 +1528,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void run_map_kernel(RunArgs a, int E, in
         build_kind<double>(kind, p, (double)energy[0], mass, nq, M);
         for (int q = 0; q < 49; ++q) maps[e * 49 + q] = (T)M.m[q];
     }
-    for (int q = threadIdx.x; q < nptr + 3; q += CHX_BLOCK)
+    for (int q = threadIdx.x; seen && q < nptr + 3; q += CHX_BLOCK)
         seen[q] = q < nptr ? (double)*(const T*)a.ptr[q] : (q == nptr ? (double)energy[0] : (q == nptr + 1 ? mass : nq));
     __syncthreads();
     // 3. R = M_{E-1} ... M_0 (chx_compose_maps)
@@ -1549,6 +1588,46 @@ extern "C" int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, 
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
+
+// forward of a run whose settings carry gradients, one call: element maps into maps[E][7][7] (kept for the backward pass) and
+// their product into R_out[7][7] — chx_build_rmatrix_scalars + chx_compose_maps, bit-identical to the two calls
+extern "C" int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                                     double mass_eV, double n_charges, int dtype, void* maps, void* R_out, void* stream) {
+    if (!maps || !R_out || !energy || E < 1 || E > 4096) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    {   // a run that fits the persistent-plan kernel: element maps and their product in ONE launch (run_map_kernel without stored
+        // state; the same arithmetic, bit for bit, as the two launches below)
+        RunArgs a;
+        int nptr = 0;
+        if (E <= kRunMaxE && run_args(kinds, param_ptrs, E, a, nptr) == CHX_OK) {
+            hipStream_t s = (hipStream_t)stream;
+            if (dtype == CHX_F32)
+                hipLaunchKernelGGL(run_map_kernel<float>, dim3(1), dim3(CHX_BLOCK), 0, s, a, (int)E, nptr, (const float*)energy, mass_eV,
+                                   n_charges, (double*)nullptr, (float*)maps, (float*)R_out, (const float*)nullptr, (float*)nullptr);
+            else
+                hipLaunchKernelGGL(run_map_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s, a, (int)E, nptr, (const double*)energy,
+                                   mass_eV, n_charges, (double*)nullptr, (double*)maps, (double*)R_out, (const double*)nullptr,
+                                   (double*)nullptr);
+            CHX_CHECK_LAUNCH();
+            return CHX_OK;
+        }
+    }
+    int st = chx_build_rmatrix_scalars(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, stream);
+    if (st != CHX_OK) return st;
+    const size_t step = 49 * (dtype == CHX_F32 ? 4 : 8);
+    if (E == 1) {
+        if (hipMemcpyAsync(R_out, maps, step, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return CHX_ERR_LAUNCH;
+        return CHX_OK;
+    }
+    const void* ptrs[4096];
+    uint8_t bc[4096];
+    for (int64_t e = 0; e < E; ++e) {
+        ptrs[e] = (const char*)maps + e * step;
+        bc[e] = 1;
+    }
+    return chx_compose_maps(ptrs, bc, E, 1, dtype, R_out, stream);
+}
+
 
 extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                              double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out,

@@ -636,7 +636,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __r
 template <typename T>
 __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const double* __restrict__ partials, int nblk,
                                                                       const T* __restrict__ x, int64_t Bx, int64_t N,
-                                                                      double* __restrict__ out) {
+                                                                      double* __restrict__ out, int entry /*-1: none*/,
+                                                                      int entry_sqrt, T* __restrict__ entry_out) {
     __shared__ double red[64 * kTM];
     __shared__ double tot[32];
     const int64_t b = blockIdx.x;
@@ -675,6 +676,10 @@ __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const dou
         int k = 8;
         for (int i = 0; i < 6; ++i)
             for (int j = i; j < 6; ++j, ++k) o[k] = (tot[k] - W * m[i] * m[j]) / cf;
+        if (entry >= 0) {                                   // chx_moments_entry: the one beam property the caller reads
+            const double v = o[entry];
+            entry_out[b] = (T)(entry_sqrt ? sqrt(v) : v);
+        }
     }
 }
 
@@ -907,7 +912,14 @@ extern "C" int chx_moment_finalize(const double* sums, const double* m2, int64_t
 extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
                            int dtype, double* out, void* workspace, size_t workspace_bytes,
                            void* stream) {
+    return chx_moments_entry(x, w, B, Bx, Bw, N, dtype, out, -1, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int chx_moments_entry(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, double* out,
+                                 int index, int take_sqrt, void* entry_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!out) return CHX_ERR_INVALID_ARG;
+    if (index >= CHX_MOM_NOUT || (index >= 0 && !entry_out)) return CHX_ERR_INVALID_ARG;
+    if (index < 0) index = -1;
     // out doubles as scratch for sums (first 8 of each 29-row are rewritten by finalize):
     // keep sums and m2 at the tail of the workspace instead.
     if (B < 1 || N < 1) return CHX_ERR_INVALID_ARG;
@@ -928,13 +940,13 @@ extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, 
                            Bx, Bw, N, part);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(moments_reduce_finalize_kernel<float>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
-                           (const float*)x, Bx, N, out);
+                           (const float*)x, Bx, N, out, index, take_sqrt, (float*)entry_out);
     } else {
         hipLaunchKernelGGL(moments_onepass_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
                            (const double*)w, Bx, Bw, N, part);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(moments_reduce_finalize_kernel<double>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
-                           (const double*)x, Bx, N, out);
+                           (const double*)x, Bx, N, out, index, take_sqrt, (double*)entry_out);
     }
     CHX_CHECK_LAUNCH();
     return CHX_OK;

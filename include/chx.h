@@ -215,6 +215,11 @@ int chx_moment_finalize(const double* sums, const double* m2, int64_t B, double*
 /* convenience: the three calls above on one stream */
 int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
                 int dtype, double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* chx_moments plus ONE entry of the vector in the beam dtype — what a beam property reads (particle_beam.py:1672-1943: mu_*,
+ * sigma_* = sqrt of the variance, cov_*): entry_out[B] (dtype) = out[b][index] or its square root, written by the same finalize
+ * launch (index < 0: plain chx_moments). */
+int chx_moments_entry(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, double* out,
+                      int index, int take_sqrt, void* entry_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Multi-GPU: exact merge of the chx_moments outputs of R particle shards, per_rank[R][B][29] -> out[B][29] (the reference's
  * weighted statistics over the union of the shards, utils/statistics.py:30-48; shards with zero weight are skipped). */
 int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, double* out, void* stream);
