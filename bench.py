@@ -301,10 +301,34 @@ def other_configs(ca, torch, device) -> dict:
         # forward: apply 56 B + the Screen's snapshot of the beam 56 B + moments 32 B per particle; backward: 7x7 algebra on the
         # incoming beam's (memoised) moments — no particle pass (the particle-sized backward moved 144 B more)
         nbytes = 144.0 * N_PARTICLES
-        return {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
-                "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
-                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        res = {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
+               "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
+               "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "eager step: bound by ~0.25 ms of Python / autograd bookkeeping around 8 launches"}}
+        # The same step captured once into a device graph (torch.cuda.CUDAGraph = hipGraph) and replayed: what an optimisation loop
+        # that keeps its tensors in place can run. In a process of its own: a capture needs Parameters that have never seen a
+        # backward pass on the default stream, and a failed capture must not take this line down.
+        import subprocess
+
+        try:
+            proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "c5_graph.py")], capture_output=True, text=True,
+                                  timeout=300, cwd=ROOT)
+            line = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"c5_graph"')]
+            if proc.returncode != 0 or not line:
+                raise RuntimeError(f"rc {proc.returncode}: {proc.stderr[-300:]}")
+            g = json.loads(line[-1])["c5_graph"]
+            ms = g["graph_replay_us"] * 1e-3
+            res["graph_replay"] = {"ms_fwd_bwd": ms, "ms_fwd_bwd_eager_same_process": g["eager_us"] * 1e-3,
+                                   "loss_equals_eager": abs(g["loss"] - g["loss_eager"]) <= 1e-6 * abs(g["loss_eager"]),
+                                   "grad_equals_eager": abs(g["grad"] - g["grad_eager"]) <= 1e-5 * abs(g["grad_eager"]),
+                                   "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9,
+                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                   "note": "benchmarks/c5_graph.py: forward + backward captured after a warm-up on a side stream; k1 "
+                                           "is updated in place between replays and the replayed kernels read it through its pointer"}
+        except Exception as exc:  # noqa: BLE001
+            res["graph_replay"] = {"error": str(exc)[:300]}
+        return res
 
     def dkd():
         # 100-element FODO tracked element by element with the Bmad-X drift-kick-drift maps

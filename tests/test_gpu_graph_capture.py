@@ -1,0 +1,27 @@
+"""Forward + backward of config C5 captured into a device graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed: libchx's
+launches are plain launches on the current stream, its workspaces come from torch's allocator and nothing on the path synchronises,
+so a whole optimisation step can be captured; the replay follows in-place updates of the trainable setting (the kernels read it
+through its pointer) and gives the eager numbers (/root/reference/tests/test_differentiable.py:10-32 is the eager step). Run in a
+process of its own: the capture must come before any backward pass on the default stream touches the Parameter."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c5_step_replays_from_a_graph_with_the_eager_numbers():
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "c5_graph.py")], capture_output=True, text=True, timeout=600,
+                          cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"c5_graph"')]
+    assert line, proc.stdout[-1000:]
+    g = json.loads(line[-1])["c5_graph"]
+    # after k1 was set to 2.5 in place: the replayed step and the eager step agree
+    assert g["loss"] == pytest.approx(g["loss_eager"], rel=1e-6) and g["grad"] == pytest.approx(g["grad_eager"], rel=1e-5)
+    assert g["loss"] == pytest.approx(8.05307e-05, rel=1e-3)                 # sigma_x at the screen for k1 = 2.5
+    assert g["graph_replay_us"] < g["eager_us"]
