@@ -569,6 +569,22 @@ def main():
     modes["merged_no_grad"]["note"] = ("torch.no_grad(): without the requires_grad scan of the run's 300 setting tensors the "
                                        "merged track is bound by its two launches (~12 us of GPU)")
 
+    # ---- small-beam workloads replayed from a device graph (rank 0 of a single-GPU run; each in a process of its own)
+    if world == 1:
+        modes["graph_replay"] = {"note": "torch.cuda.CUDAGraph (hipGraph) capture of the whole step, benchmarks/graph_modes.py: the "
+                                         "README segment's track + screen reading, and the control step with its five settings "
+                                         "written in place (the replay follows them); eager times of the same process beside"}
+        for which in ("c1", "control"):
+            try:
+                proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "graph_modes.py"), which], capture_output=True,
+                                      text=True, timeout=300, cwd=ROOT)
+                line = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"graph_mode"')]
+                if proc.returncode != 0 or not line:
+                    raise RuntimeError(f"rc {proc.returncode}: {proc.stderr[-300:]}")
+                modes["graph_replay"][which] = json.loads(line[-1])["graph_mode"]
+            except Exception as exc:  # noqa: BLE001
+                modes["graph_replay"][which] = {"error": str(exc)[:300]}
+
     # ---- roofline of the dominant kernel: HIP events on the launch stream around the E-launch run, every step
     ms_run = event_timed_elementwise(torch, seg, beam, args.steps, args.warmup)
     ms_launch = ms_run / E

@@ -25,3 +25,17 @@ def test_c5_step_replays_from_a_graph_with_the_eager_numbers():
     assert g["loss"] == pytest.approx(g["loss_eager"], rel=1e-6) and g["grad"] == pytest.approx(g["grad_eager"], rel=1e-5)
     assert g["loss"] == pytest.approx(8.05307e-05, rel=1e-3)                 # sigma_x at the screen for k1 = 2.5
     assert g["graph_replay_us"] < g["eager_us"]
+
+
+@pytest.mark.parametrize("which", ["c1", "control"])
+def test_small_beam_steps_replay_from_a_graph(which):
+    """Track + screen reading of the README segment, and the control step whose five settings are written in place: captured,
+    replayed, equal to the eager step; the replay follows new settings."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "graph_modes.py"), which], capture_output=True, text=True,
+                          timeout=600, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    g = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"graph_mode"')][-1])["graph_mode"]
+    assert g["replay_equals_eager"] is True
+    if which == "control":
+        assert g["replay_follows_in_place_settings"] is True
+    assert g["graph_replay_us"] < g["eager_us"]
