@@ -44,17 +44,13 @@ def eager(n=200):
 
 # capture (the recipe of torch's CUDA-graphs notes: warm up on a side stream, then capture forward + backward). The capture comes
 # BEFORE any backward pass on the default stream: a Parameter whose AccumulateGrad node was created there breaks the capture.
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(3):
-        k1.grad = None
-        step()
-torch.cuda.current_stream().wait_stream(side)
-graph = torch.cuda.CUDAGraph()
-k1.grad = None
-with torch.cuda.graph(graph):
-    static_loss = step()
+def clean_step():
+    k1.grad = None
+    return step()
+
+
+captured = ca.graph.capture(clean_step)
+graph, static_loss = captured.graph, captured.outputs
 static_grad = k1.grad
 graph.replay()
 torch.cuda.synchronize()

@@ -65,16 +65,9 @@ else:
 with torch.no_grad():
     eager_us = timed(step, reps, 20 if which != "c4" else 6)       # (also takes the chain guard past its sampling tracks)
     ref = step().clone()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = step()
-    graph.replay()
+    captured = ca.graph.capture(step)
+    graph, out = captured.graph, captured.outputs
+    captured()
     torch.cuda.synchronize()
     same = bool(torch.allclose(out, ref, rtol=1e-4 if which == "c4" else 1e-6, atol=0.0 if which != "c4" else 1e-9))
     follows = None

@@ -31,7 +31,7 @@ from .accelerator import (  # noqa: F401
     VerticalCorrector,
 )
 from .particles import ParameterBeam, ParticleBeam, Species  # noqa: F401
-from . import converters, latticejson, track_methods, utils  # noqa: F401,E402
+from . import converters, graph, latticejson, track_methods, utils  # noqa: F401,E402
 from .particles.beam import Beam  # noqa: F401,E402
 from .warnings import (  # noqa: F401,E402
     DefaultParameterWarning,
