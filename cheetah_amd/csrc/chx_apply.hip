@@ -570,7 +570,20 @@ __global__ __launch_bounds__(CHX_BLOCK) void copy_arrays_kernel(CopyArgs a) {
         const int64_t n16 = n >> 4;
         const float4* __restrict__ s4 = (const float4*)s;
         float4* __restrict__ d4 = (float4*)d;
-        for (int64_t i = tid; i < n16; i += nthreads) d4[i] = s4[i];
+        // four independent 16-byte loads per lane in flight before the first store, streaming (nontemporal) both ways: the
+        // copy of a 28 MB particle array went from 4.0 to the apply kernels' rate
+        int64_t i = tid;
+        const chx_v4f* __restrict__ sv = reinterpret_cast<const chx_v4f*>(s);
+        chx_v4f* __restrict__ dv = reinterpret_cast<chx_v4f*>(d);
+        for (; i + 3 * nthreads < n16; i += 4 * nthreads) {
+            const chx_v4f v0 = __builtin_nontemporal_load(sv + i), v1 = __builtin_nontemporal_load(sv + i + nthreads),
+                          v2 = __builtin_nontemporal_load(sv + i + 2 * nthreads), v3 = __builtin_nontemporal_load(sv + i + 3 * nthreads);
+            __builtin_nontemporal_store(v0, dv + i);
+            __builtin_nontemporal_store(v1, dv + i + nthreads);
+            __builtin_nontemporal_store(v2, dv + i + 2 * nthreads);
+            __builtin_nontemporal_store(v3, dv + i + 3 * nthreads);
+        }
+        for (; i < n16; i += nthreads) d4[i] = s4[i];
         done = n16 << 4;
     }
     for (int64_t i = done + tid; i < n; i += nthreads) d[i] = s[i];
