@@ -574,7 +574,7 @@ def main():
         modes["graph_replay"] = {"note": "torch.cuda.CUDAGraph (hipGraph) capture of the whole step, benchmarks/graph_modes.py: the "
                                          "README segment's track + screen reading, and the control step with its five settings "
                                          "written in place (the replay follows them); eager times of the same process beside"}
-        for which in ("c1", "control"):
+        for which in ("c1", "control", "control_parameter_beam"):
             try:
                 proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "graph_modes.py"), which], capture_output=True,
                                       text=True, timeout=300, cwd=ROOT)

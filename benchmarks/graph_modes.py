@@ -2,6 +2,7 @@
 """Small-beam workloads replayed from a device graph (torch.cuda.CUDAGraph = hipGraph): the host side of a step is one graph launch.
   c1       README segment (13 elements, 1e4 particles, fp64): track + cloud-in-cell screen reading
   control  the control loop on that segment (fp32): five magnet settings written IN PLACE from an action tensor, track, screen reading
+  control_parameter_beam  the same with a ParameterBeam (moments only: the reading is the bivariate normal image)
   c4       50-element linac with 10 space-charge kicks (128^3, 1e6 particles): the chain with its side stream as graph edges
 usage: python benchmarks/graph_modes.py c1|control|c4   -> one JSON line {"graph_mode": {...}}"""
 import json
@@ -29,17 +30,20 @@ def timed(fn, reps, warm):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
-if which in ("c1", "control"):
+if which in ("c1", "control", "control_parameter_beam"):
     dt = torch.float64 if which == "c1" else torch.float32
     seg = rc.ares_subcell(dt, rc.t(8.2, dt))
     seg.AREABSCR1.is_active = True
-    beam = ca.ParticleBeam.from_twiss(beta_x=rc.t(3.14, dt), beta_y=rc.t(42.0, dt), num_particles=10_000, dtype=dt, device="cuda")
+    if which == "control_parameter_beam":
+        beam = ca.ParameterBeam.from_twiss(beta_x=rc.t(3.14, dt), beta_y=rc.t(42.0, dt), dtype=dt, device="cuda")
+    else:
+        beam = ca.ParticleBeam.from_twiss(beta_x=rc.t(3.14, dt), beta_y=rc.t(42.0, dt), num_particles=10_000, dtype=dt, device="cuda")
     action = torch.randn(5, device="cuda", dtype=dt)
     scale = torch.tensor([10.0, 10.0, 1e-4, 10.0, 1e-4], device="cuda", dtype=dt)
     settings = [seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle]
 
     def step():
-        if which == "control":
+        if which != "c1":
             scaled = action * scale
             for i, target in enumerate(settings):
                 target.copy_(scaled[i])                       # in place: the lattice's tensors (and their addresses) stay
@@ -71,7 +75,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     same = bool(torch.allclose(out, ref, rtol=1e-4 if which == "c4" else 1e-6, atol=0.0 if which != "c4" else 1e-9))
     follows = None
-    if which == "control":
+    if which != "c1":
         action.copy_(torch.tensor([0.3, -0.2, 0.5, 0.1, -0.4], device="cuda", dtype=dt))
         graph.replay()
         torch.cuda.synchronize()
