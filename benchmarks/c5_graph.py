@@ -49,7 +49,7 @@ def clean_step():
     return step()
 
 
-captured = ca.graph.capture(clean_step)
+captured = ca.graph.capture(clean_step, constant_beam=True)      # an optimisation over k1: the incoming beam stays
 graph, static_loss = captured.graph, captured.outputs
 static_grad = k1.grad
 graph.replay()

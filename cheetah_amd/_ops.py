@@ -111,6 +111,15 @@ def flat_bcast(t: torch.Tensor, batch_shape, n_tail: int):
     return t.expand(*batch_shape, *tail).reshape(B, *tail), B
 
 
+#: > 0 while a tracking step is being recorded into a device graph (`cheetah_amd.graph.capture`): the host-side caches that
+#: skip a launch because "the values have not changed since" (maps keyed on version counters, stacked parameter arrays, memoised
+#: moments) are bypassed — a replay re-runs the recorded launches against whatever the tensors hold THEN, so every kernel that
+#: derives something from a setting must be part of the recording
+CAPTURING = [0]
+#: (with `capture(..., constant_beam=True)`: the moments of the beam entering the step may stay memoised)
+CAPTURE_KEEPS_BEAM_MOMENTS = [False]
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -974,7 +983,7 @@ def _memo_moments(owner: torch.Tensor, x: torch.Tensor, w, survival, B: int, ent
     With entry = (index, take_sqrt): returns (moments, that entry per row in x's dtype — or None on a memo hit, the caller then
     picks it with chx_moment_entry)."""
     w_src = None if survival is None else _origin(survival)
-    cached = getattr(owner, "_chx_mom", None)
+    cached = getattr(owner, "_chx_mom", None) if (not CAPTURING[0] or CAPTURE_KEEPS_BEAM_MOMENTS[0]) else None
     if cached is not None and cached[0] == owner._version and cached[1] is w_src \
             and (w_src is None or cached[2] == w_src._version) and cached[3] == x.data_ptr() and cached[4].shape[0] == B:
         return cached[4] if entry is None else (cached[4], None)

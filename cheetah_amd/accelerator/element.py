@@ -188,7 +188,8 @@ class Element(nn.Module):
         return _ops.build_ttensor(self._t_kind, params, pshape, energy, species.mass_eV_float)
 
     def _cached_map(self, slot: str, build, energy: torch.Tensor, species: Species) -> torch.Tensor:
-        if energy.requires_grad or species.mass_eV.requires_grad or species.num_elementary_charges.requires_grad:
+        if energy.requires_grad or species.mass_eV.requires_grad or species.num_elementary_charges.requires_grad \
+                or _ops.CAPTURING[0]:
             return build(energy, species)
         cache = self.__dict__.get(slot)
         fkey, ftensors = self._feature_key()
@@ -271,7 +272,7 @@ class Element(nn.Module):
                 return None
             key.append(t._version)
         cached = self.__dict__.get("_dkd_cache")
-        if cached is not None and cached[0] == key:
+        if cached is not None and cached[0] == key and not _ops.CAPTURING[0]:
             return cached[1]
         with torch.no_grad():
             stacked = torch.stack([t if index is None else t[index] for t, index in refs]).reshape(1, len(refs))

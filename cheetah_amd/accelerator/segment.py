@@ -416,7 +416,7 @@ class Segment(Element):
     @staticmethod
     def _refresh(run: _Run, energy, species) -> bool:
         """Invalidate the run's caches when its token changed. Returns whether caching is allowed."""
-        if energy.requires_grad or species.mass_eV.requires_grad:
+        if energy.requires_grad or species.mass_eV.requires_grad or _ops.CAPTURING[0]:
             run.token = run.tm = run.stack = None
             return False
         token = run.current_token(energy, species)

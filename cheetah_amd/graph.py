@@ -31,16 +31,31 @@ class CapturedStep:
         return self.outputs
 
 
-def capture(fn, warmup: int = 3) -> CapturedStep:
-    """Run `fn` `warmup` times on a side stream (allocations, plans, memoised moments, the space-charge chain's guard settle
-    there), then once more under capture. `fn` must be free of host synchronisation and keep the tensors it reads in place."""
+def capture(fn, warmup: int = 3, constant_beam: bool = False) -> CapturedStep:
+    """Run `fn` `warmup` times on a side stream (allocations, plans, the space-charge chain's guard settle there), then once more
+    under capture. `fn` must be free of host synchronisation and keep the tensors it reads in place.
+
+    While recording, the host-side caches that would skip a launch because "nothing changed since the last call" are off
+    (`_ops.CAPTURING`): every kernel that derives something from a setting is part of the graph, so the replay follows in-place
+    changes of ANY tensor the step reads. `constant_beam=True` keeps one of them: the memoised moments of the beam that enters
+    the step (used by the backward pass of a beam property of a linearly tracked beam) — one particle pass less per replay for
+    an optimisation over lattice settings with a fixed incoming beam; the beam must then not be edited between replays."""
+    from . import _ops
+
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(int(warmup), 1)):
-            fn()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        outputs = fn()
+    _ops.CAPTURING[0] += 1
+    keep = _ops.CAPTURE_KEEPS_BEAM_MOMENTS[0]
+    _ops.CAPTURE_KEEPS_BEAM_MOMENTS[0] = bool(constant_beam)
+    try:
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outputs = fn()
+    finally:
+        _ops.CAPTURING[0] -= 1
+        _ops.CAPTURE_KEEPS_BEAM_MOMENTS[0] = keep
     return CapturedStep(graph, outputs)

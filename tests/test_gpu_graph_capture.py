@@ -39,3 +39,40 @@ def test_small_beam_steps_replay_from_a_graph(which):
     if which != "c1":
         assert g["replay_follows_in_place_settings"] is True
     assert g["graph_replay_us"] < g["eager_us"]
+
+
+def test_replay_follows_settings_changed_outside_the_step_on_cached_paths():
+    """Paths whose maps are cached on the host against version counters (a vectorised setting, elements tracked on their own, a
+    drift-kick-drift element's parameter array): while `capture` records, those caches are off, so the kernels that derive the
+    maps from the settings are part of the graph and a replay sees a setting that was edited in place BETWEEN replays."""
+    import torch
+
+    import cheetah_amd as ca
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(0)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, sigma_x=t(2e-4), sigma_px=t(2e-5), energy=t(1e8), **kw)
+    k1 = torch.linspace(-3.0, 3.0, 4, **kw)
+    quad = ca.Quadrupole(t(0.2), k1=k1, **kw)                               # vectorised: no persistent device plan
+    lone = ca.Quadrupole(t(0.3), k1=t(1.5), **kw)                           # tracked on its own: Element._cached_map
+    dkd = ca.Quadrupole(t(0.2), k1=t(2.0), tracking_method="drift_kick_drift", **kw)
+    seg = ca.Segment([ca.Drift(t(0.5), **kw), quad, ca.Drift(t(0.5), **kw)])
+
+    def step():
+        return seg.track(beam).sigma_x, lone.track(beam).sigma_x, dkd.track(beam).sigma_x
+
+    with torch.no_grad():
+        for _ in range(3):
+            step()                                                          # the host caches are warm ...
+        captured = ca.graph.capture(step)                                   # ... and must not be used by the recording
+        first = [v.clone() for v in captured()]
+        quad.k1.mul_(-1.0)
+        lone.k1.fill_(-4.0)
+        dkd.k1.fill_(-6.0)
+        replayed = [v.clone() for v in captured()]
+        eager = step()
+    for a, b, c in zip(replayed, eager, first):
+        assert torch.allclose(a, b, rtol=1e-6), (a, b)
+        assert not torch.allclose(a, c, rtol=1e-3), "the replay did not follow the edited setting"
