@@ -76,3 +76,14 @@ def test_replay_follows_settings_changed_outside_the_step_on_cached_paths():
     for a, b, c in zip(replayed, eager, first):
         assert torch.allclose(a, b, rtol=1e-6), (a, b)
         assert not torch.allclose(a, c, rtol=1e-3), "the replay did not follow the edited setting"
+
+
+def test_space_charge_chain_is_capturable():
+    """The chain of tile-ordered kicks with its side stream (fork / join events become graph edges), the device-side re-ordering
+    decision and the host guard's pinned copy: recorded and replayed with the eager result. (The replay is no faster than the
+    eager track on this platform — bench.py does not use it — but a captured optimisation step may contain such a lattice.)"""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "graph_modes.py"), "c4"], capture_output=True, text=True,
+                          timeout=600, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    g = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"graph_mode"')][-1])["graph_mode"]
+    assert g["replay_equals_eager"] is True
