@@ -431,7 +431,7 @@ class Segment(Element):
         kept referenced by the key, so that an `is` comparison cannot be fooled by a recycled object id."""
         lengths = [e.length for e in run.elements]
         key = run.length_key
-        same = (key is not None and run.length is not None and not run.length.requires_grad
+        same = (key is not None and run.length is not None and not run.length.requires_grad and not _ops.CAPTURING[0]
                 and all(a is b and a._version == v for a, (b, v) in zip(lengths, key)))
         if not same:
             total = None
@@ -449,7 +449,7 @@ class Segment(Element):
         tracked again (the usual RL loop re-tracks one incoming beam), saving a device op per track."""
         length = Segment._run_length(run)      # re-validated on every call (and resets s_cache when a length changed)
         c = run.s_cache
-        if c is not None and c[0] is s_in and c[1] == s_in._version and not s_in.requires_grad:
+        if c is not None and c[0] is s_in and c[1] == s_in._version and not s_in.requires_grad and not _ops.CAPTURING[0]:
             return c[2]
         s_out = s_in + length
         if not s_out.requires_grad:
