@@ -43,7 +43,7 @@ if which in ("c1", "control", "control_parameter_beam"):
     settings = [seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle]
 
     def step():
-        if which != "c1":
+        if which.startswith("control"):
             scaled = action * scale
             for i, target in enumerate(settings):
                 target.copy_(scaled[i])                       # in place: the lattice's tensors (and their addresses) stay
@@ -75,7 +75,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     same = bool(torch.allclose(out, ref, rtol=1e-4 if which == "c4" else 1e-6, atol=0.0 if which != "c4" else 1e-9))
     follows = None
-    if which != "c1":
+    if which.startswith("control"):
         action.copy_(torch.tensor([0.3, -0.2, 0.5, 0.1, -0.4], device="cuda", dtype=dt))
         graph.replay()
         torch.cuda.synchronize()
