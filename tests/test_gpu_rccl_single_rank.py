@@ -151,13 +151,15 @@ def test_rccl_exchanges_on_one_rank():
             assert r["staged_vs_forced_max"] == 0.0, (name, r)       # a one-rank exchange is the identity, bit for bit
         else:   # the path itself is not bit-reproducible (float atomics: direct deposit below 65536 particles, hot tiles of
                 # the sorted one): the exchanges must add nothing beyond that run-to-run noise
-            # (two independent samples of that noise: an order of magnitude of room, and a floor of a few ulp of the kick)
-            floor = 1e-6 if name.startswith("f32") else 1e-13
-            assert r["staged_vs_forced_rel"] <= 10 * max(r["run_to_run_rel"], floor), (name, r)
+            # (two independent samples of that noise — over six repeats of this worker, benchmarks/_rccl_noise.py: up to 1.1e-6
+            # of the kick in float32 and 1.0e-10 in float64, while a single pair of runs can happen to agree to 1e-15 — so an
+            # order of magnitude of room over the sample and a floor above the largest noise seen)
+            floor = 2e-5 if name.startswith("f32") else 1e-9
+            assert r["staged_vs_forced_rel"] <= max(10 * r["run_to_run_rel"], floor), (name, r)
         assert r["merge_rel"] < 1e-12, (name, r)
         # staged (chx_moments + merge + chx_sc_geometry, separate launches) vs the one-call kick (chx_sc_kick): the same
         # arithmetic up to the rounding of the three sigmas and the summation order of the charge grid
-        # (fp32: measured 3e-5 typical, 1.5e-4 at most over repeated runs — float atomics in hot tiles)
-        assert r["forced_vs_whole"] < (1e-3 if name.startswith("f32") else 1e-9), (name, r)
+        # (measured over six repeats: 1.1e-6 in float32, 1.0e-10 in float64)
+        assert r["forced_vs_whole"] < (2e-4 if name.startswith("f32") else 1e-9), (name, r)
     assert report["screen"] == {"equal": True, "all_reduce": 1}
     assert report["batch_shard_equal"]
