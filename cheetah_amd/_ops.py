@@ -138,10 +138,13 @@ class _CloneInto(torch.autograd.Function):
 
 
 def clone_many(tensors):
-    """Copies of up to 8 device tensors by ONE launch (chx_copy_arrays) instead of one `clone()` kernel each — also for tensors
-    that carry a graph (their copies are attached to it by an identity node); tensors that are not contiguous or do not live on
-    a ROCm device are cloned the ordinary way."""
-    plain = [t.is_cuda and t.is_contiguous() for t in tensors]
+    """Copies of up to 8 device tensors by ONE launch (chx_copy_arrays) instead of one `clone()` kernel each — while a device
+    graph records also for tensors that carry an autograd graph (their copies are attached to it by an identity node); tensors
+    that are not contiguous or do not live on a ROCm device are cloned the ordinary way."""
+    # (a graph-carrying tensor joins the shared launch only while a device graph records — one kernel less in the replay; in
+    # eager mode torch's own clone() is the cheaper call on the host, which is what bounds an eager step)
+    graphs = torch.is_grad_enabled() and not CAPTURING[0]
+    plain = [t.is_cuda and t.is_contiguous() and not (graphs and t.requires_grad) for t in tensors]
     out = [torch.empty_like(t) if ok else t.clone() for t, ok in zip(tensors, plain)]
     pairs = [(t, o) for t, o, ok in zip(tensors, out, plain) if ok and t.numel()]
     for lo in range(0, len(pairs), 8):
