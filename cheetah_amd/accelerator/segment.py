@@ -747,6 +747,8 @@ class Segment(Element):
         guard = self._chain_guard(plan)
         if guard["off"] or guard["pending"] is not None or guard["samples"] >= self._CHAIN_SAMPLES:
             return
+        if torch.cuda.is_current_stream_capturing():        # an event recorded into a graph cannot be polled later
+            return
         guard["samples"] += 1
         host = guard["host"]
         if host is None:                                   # one page-locked buffer per plan (its allocation is the slow part)
