@@ -735,7 +735,7 @@ class Segment(Element):
     def _chain_allowed(self, plan) -> bool:
         guard = self._chain_guard(plan)
         pending = guard["pending"]
-        if pending is not None and pending[1].query():
+        if pending is not None and not torch.cuda.is_current_stream_capturing() and pending[1].query():   # (no polling inside a recording)
             header = pending[0]
             if int(header[6]) > 0 and int(header[3]) > self._CHAIN_MAX_MISFILED_PERMILLE * int(header[6]):
                 guard["off"] = True

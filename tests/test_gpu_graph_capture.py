@@ -87,3 +87,27 @@ def test_space_charge_chain_is_capturable():
     assert proc.returncode == 0, proc.stderr[-2000:]
     g = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"graph_mode"')][-1])["graph_mode"]
     assert g["replay_equals_eager"] is True
+
+
+def test_chain_capture_with_a_single_warm_up_track():
+    """The chain's host guard samples the first tracks of a plan (pinned copy + event): a recording that starts before the
+    sampling is over must not put that event into the graph."""
+    import torch
+
+    import cheetah_amd as ca
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(1)
+    beam = ca.ParticleBeam.from_parameters(num_particles=120_000, sigma_x=t(3e-4), sigma_y=t(2e-4), sigma_tau=t(1e-4), energy=t(5e7),
+                                           total_charge=t(1e-9), **kw)
+    seg = ca.Segment([el for i in range(3) for el in (ca.SpaceChargeKick(t(0.1), grid_shape=(32, 32, 32), **kw), ca.Drift(t(0.2), **kw),
+                                                      ca.Quadrupole(t(0.1), k1=t(2.0 if i % 2 else -2.0), **kw))])
+    with torch.no_grad():
+        step = ca.graph.capture(lambda: seg.track(beam).particles, warmup=1)
+        replayed = step().clone()
+        eager = seg.track(beam).particles
+    scale = eager.abs().max(dim=0).values
+    assert torch.all((replayed - eager).abs().max(dim=0).values <= 1e-5 * scale + 1e-12)
+    assert torch.isfinite(replayed).all()
