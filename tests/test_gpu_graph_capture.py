@@ -111,3 +111,38 @@ def test_chain_capture_with_a_single_warm_up_track():
     scale = eager.abs().max(dim=0).values
     assert torch.all((replayed - eager).abs().max(dim=0).values <= 1e-5 * scale + 1e-12)
     assert torch.isfinite(replayed).all()
+
+
+def test_a_lattice_of_many_element_types_is_capturable():
+    """Drift, quadrupole, corrector, marker, active cavity, aperture, BPM, a second-order quadrupole, a drift-kick-drift dipole and
+    a screen in one Segment: recorded once; the replay follows in-place changes of a quadrupole strength and of the cavity phase
+    and gives the eager step's image, beam moments, BPM reading and energy."""
+    import torch
+
+    import cheetah_amd as ca
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)
+    beam = ca.ParticleBeam.from_parameters(num_particles=50_000, energy=t(1e8), **kw)
+    screen = ca.Screen(resolution=(200, 100), pixel_size=t([1e-5, 1e-5]), is_active=True, name="screen", **kw)
+    quad = ca.Quadrupole(t(0.2), k1=t(3.0), name="quad", **kw)
+    cav = ca.Cavity(t(1.0), voltage=t(1e7), phase=t(5.0), frequency=t(1.3e9), **kw)
+    seg = ca.Segment([ca.Drift(t(0.5), **kw), quad, ca.HorizontalCorrector(t(0.1), angle=t(1e-4), **kw), ca.Marker(**kw), cav, ca.Drift(t(0.5), **kw),
+                      ca.Aperture(x_max=t(5e-3), y_max=t(5e-3), is_active=True, **kw), ca.BPM(is_active=True, name="bpm", **kw),
+                      ca.Quadrupole(t(0.2), k1=t(1.0), tracking_method="second_order", **kw),
+                      ca.Dipole(t(0.5), angle=t(0.02), tracking_method="drift_kick_drift", **kw), screen])
+    def step():
+        out = seg.track(beam)
+        return screen.reading, out.sigma_x, out.mu_y, seg.bpm.reading, out.energy
+    with torch.no_grad():
+        cap = ca.graph.capture(step)
+        a = [v.clone() for v in cap()]
+        quad.k1.fill_(-2.0); cav.phase.fill_(20.0)
+        b = [v.clone() for v in cap()]
+        c = step()
+    names = ("image", "sigma_x", "mu_y", "bpm", "energy")
+    for name, x, y, z in zip(names, b, c, a):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7 * float(y.abs().max())), name
+        if name in ("sigma_x", "energy"):
+            assert float((x - z).abs().max()) > 0, name          # the replay saw the new settings
