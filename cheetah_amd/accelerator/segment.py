@@ -652,6 +652,11 @@ class Segment(Element):
                 incoming = ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
                                         survival_probabilities=incoming.survival_probabilities, s=s_out, species=incoming.species)
             else:
+                if item._tracking_method == "second_order":
+                    done = self._second_order_run(plan, i, incoming)      # like the drift-kick-drift run below
+                    if done is not None:
+                        incoming, i = done
+                        continue
                 if item._tracking_method == "drift_kick_drift":
                     # a lattice tracked with the Bmad-X maps: consecutive elements go to the device in ONE call
                     # (chx_dkd_chain; the per-element Python path costs ~25 us where the kernels take 12-29)
@@ -669,6 +674,39 @@ class Segment(Element):
                 incoming = item._track_internal(incoming)
             i += 1
         return incoming
+
+    def _second_order_run(self, plan, i: int, incoming: ParticleBeam):
+        """plan[i] and the second-order elements behind it as one `chx_second_order_chain` call: (outgoing beam, index behind
+        the run), or None when fewer than two elements qualify (one plain beam without a graph, (7, 7, 7) maps and scalar
+        lengths of the beam's dtype without gradients, the stock `track`)."""
+        x, energy, s = incoming.particles, incoming.energy, incoming.s
+        if x.dim() != 2 or not x.is_cuda or energy.dim() != 0 or s.dim() != 0 or s.dtype != x.dtype or s.device != x.device or (
+                torch.is_grad_enabled() and (x.requires_grad or energy.requires_grad or s.requires_grad)):
+            return None
+        grad = torch.is_grad_enabled()
+        species = incoming.species
+        maps, lengths = [], []
+        j = i
+        while j < len(plan) and plan[j][0] == "element":
+            e = plan[j][1]
+            cls = type(e)
+            if e._tracking_method != "second_order" or e._t_kind is None or cls.track is not Element.track \
+                    or cls._track_second_order is not Element._track_second_order or cls._track_internal is not Element._track_internal:
+                break
+            length = e.length
+            if length.dim() != 0 or length.dtype != x.dtype or length.device != x.device or (grad and length.requires_grad):
+                break
+            T = e.second_order_transfer_map(energy, species)
+            if T.dim() != 3 or T.dtype != x.dtype or T.device != x.device or (grad and T.requires_grad):
+                break
+            maps.append(T if T.is_contiguous() else T.contiguous())
+            lengths.append(length)
+            j += 1
+        if j - i < 2:
+            return None
+        out, s_out = _ops.second_order_chain(maps, lengths, x, s)
+        return ParticleBeam(out, energy, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), j
 
     def _dkd_run(self, plan, i: int, incoming: ParticleBeam):
         """plan[i] and the drift-kick-drift elements behind it as one `chx_dkd_chain` call: (outgoing beam, index behind the

@@ -556,6 +556,40 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     return CHX_OK;
 }
 
+// A run of elements tracked with their second-order maps (element.py:195-228) on ONE beam: E launches of chx_apply_second_order
+// from one call, rows ping-ponging between x_out and x_tmp so that the last element writes x_out; the path length like
+// chx_dkd_chain (lengths[E]: device pointers to the elements' length scalars). Same results as E separate calls, bit for bit.
+extern "C" int chx_second_order_chain(const void* const* T_maps, const void* const* lengths, int64_t E, const void* x_in, int64_t N,
+                                      int dtype, void* x_out, void* x_tmp, const void* s_in, void* s_out, void* stream) {
+    if (!T_maps || E < 1 || E > 65535 || !x_in || !x_out || (E > 1 && !x_tmp) || N < 1) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if ((s_in == nullptr) != (s_out == nullptr) || (s_out && !lengths)) return CHX_ERR_INVALID_ARG;
+    if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
+    const void* src = x_in;
+    for (int64_t e = 0; e < E; ++e) {
+        if (!T_maps[e]) return CHX_ERR_INVALID_ARG;
+        void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;
+        const int st = chx_apply_second_order(src, T_maps[e], dst, 1, 1, 1, N, dtype, stream);
+        if (st != CHX_OK) return st;
+        src = dst;
+    }
+    for (int64_t done = 0; s_out && done < E; done += kDkdSChunk) {
+        DkdLengthPtrs a;
+        const int n = (int)((E - done < kDkdSChunk) ? (E - done) : kDkdSChunk);
+        for (int e = 0; e < kDkdSChunk; ++e) a.p[e] = e < n ? lengths[done + e] : nullptr;
+        for (int e = 0; e < n; ++e)
+            if (!a.p[e]) return CHX_ERR_INVALID_ARG;
+        const void* from = done == 0 ? s_in : s_out;
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(dkd_path_length_kernel<float>, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, (const float*)from, (float*)s_out);
+        else
+            hipLaunchKernelGGL(dkd_path_length_kernel<double>, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, (const double*)from,
+                               (double*)s_out);
+        CHX_CHECK_LAUNCH();
+    }
+    return CHX_OK;
+}
+
 namespace {
 template <typename T, int KIND>
 int launch_dkd_bwd(const void* x_in, const void* params, const void* energy, const void* dY, double mc2, double nq,

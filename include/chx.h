@@ -626,6 +626,12 @@ int chx_build_ttensor(int kind, const void* params, const void* energy, double m
                       int64_t Be, int dtype, void* T_out, void* stream);
 int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t B, int64_t Bx, int64_t BT,
                            int64_t N, int dtype, void* stream);
+/* A run of E elements tracked with their second-order maps on one beam x_in[N][7] (a lattice with tracking_method =
+ * "second_order": element.py:195-228 once per element): HOST arrays T_maps[E] (device pointers to each element's [7][7][7] map)
+ * and lengths[E] (device pointers to the elements' length scalars, only read when s_in / s_out are given: s_out = (((s_in +
+ * l_0) + l_1) + ...) in dtype). x_tmp[N][7] is scratch (may be NULL for E = 1); E launches, one call. */
+int chx_second_order_chain(const void* const* T_maps, const void* const* lengths, int64_t E, const void* x_in, int64_t N, int dtype,
+                           void* x_out, void* x_tmp, const void* s_in, void* s_out, void* stream);
 /* Derivatives of the two calls above (reference: torch autograd through track_methods.py:80-296 and the einsum).
  * chx_build_ttensor_vjp: dparams[B][P], denergy[B] (dtype) = dT[B][343] . dT/dtheta (dual numbers, one workgroup
  * per (row, input)); rows are NOT reduced when params / energy are broadcast (Bp or Be = 1) — the caller sums.
