@@ -377,7 +377,34 @@ def other_configs(ca, torch, device) -> dict:
                        "profiles/r03_dkd_precision.md")
         return res
 
-    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd)):
+    def second_order():
+        # the same FODO with every element's second-order map (element.py:195-228): consecutive elements in one chx_second_order_chain
+        import time as _t
+
+        dt = torch.float32
+        kw = {"dtype": dt, "device": device}
+        tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
+        so = {"tracking_method": "second_order"}
+        els = []
+        for _ in range(N_CELLS):
+            els += [ca.Quadrupole(tt(0.2), k1=tt(4.2), **so, **kw), ca.Drift(tt(0.8), **so, **kw),
+                    ca.Quadrupole(tt(0.2), k1=tt(-4.2), **so, **kw), ca.Drift(tt(0.8), **so, **kw)]
+        seg = ca.Segment(els)
+        beam = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES, **kw)
+        with torch.no_grad():
+            for _ in range(3):
+                seg.track(beam)
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(10):
+                seg.track(beam)
+            torch.cuda.synchronize()
+        ms = (_t.perf_counter() - t0) / 10 * 1e3
+        return {"workload": "100-element FODO, second_order tracking of every element, 1e6 particles, fp32, Segment.track",
+                "ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
+                "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
+
+    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order)):
         guarded(name, fn)
     return out
 
