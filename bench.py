@@ -599,9 +599,10 @@ def main():
     # ---- small-beam workloads replayed from a device graph (rank 0 of a single-GPU run; each in a process of its own)
     if world == 1:
         modes["graph_replay"] = {"note": "torch.cuda.CUDAGraph (hipGraph) capture of the whole step, benchmarks/graph_modes.py: the "
-                                         "README segment's track + screen reading, and the control step with its five settings "
-                                         "written in place (the replay follows them); eager times of the same process beside"}
-        for which in ("c1", "control", "control_parameter_beam"):
+                                         "README segment's track + screen reading, the control step with its five settings "
+                                         "written in place (the replay follows them), a 16-cell linac with active cavities; "
+                                         "eager times of the same process beside"}
+        for which in ("c1", "control", "control_parameter_beam", "linac"):
             try:
                 proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "graph_modes.py"), which], capture_output=True,
                                       text=True, timeout=300, cwd=ROOT)

@@ -3,8 +3,9 @@
   c1       README segment (13 elements, 1e4 particles, fp64): track + cloud-in-cell screen reading
   control  the control loop on that segment (fp32): five magnet settings written IN PLACE from an action tensor, track, screen reading
   control_parameter_beam  the same with a ParameterBeam (moments only: the reading is the bivariate normal image)
+  linac    16 cells [Drift, Quadrupole, active Cavity] (1e4 particles, fp32): every cavity is a map of the energy it receives
   c4       50-element linac with 10 space-charge kicks (128^3, 1e6 particles): the chain with its side stream as graph edges
-usage: python benchmarks/graph_modes.py c1|control|c4   -> one JSON line {"graph_mode": {...}}"""
+usage: python benchmarks/graph_modes.py c1|control|control_parameter_beam|linac|c4   -> one JSON line {"graph_mode": {...}}"""
 import json
 import os
 import sys
@@ -50,6 +51,19 @@ if which in ("c1", "control", "control_parameter_beam"):
         seg.track(beam)
         return seg.AREABSCR1.reading
     reps = 2000
+elif which == "linac":
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for i in range(16):
+        els += [ca.Drift(rc.t(0.3, dt), **kw), ca.Quadrupole(rc.t(0.2, dt), k1=rc.t(3.0 if i % 2 else -3.0, dt), **kw),
+                ca.Cavity(rc.t(1.0377, dt), voltage=rc.t(18e6, dt), phase=rc.t(-10.0, dt), frequency=rc.t(1.3e9, dt), **kw)]
+    seg = ca.Segment(els)
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_000, energy=rc.t(1e8, dt), **kw)
+
+    def step():
+        return seg.track(beam).particles
+    reps = 300
 else:
     dt = torch.float32
     kw = {"dtype": dt, "device": "cuda"}

@@ -27,7 +27,7 @@ def test_c5_step_replays_from_a_graph_with_the_eager_numbers():
     assert g["graph_replay_us"] < g["eager_us"]
 
 
-@pytest.mark.parametrize("which", ["c1", "control", "control_parameter_beam"])
+@pytest.mark.parametrize("which", ["c1", "control", "control_parameter_beam", "linac"])
 def test_small_beam_steps_replay_from_a_graph(which):
     """Track + screen reading of the README segment, and the control step whose five settings are written in place: captured,
     replayed, equal to the eager step; the replay follows new settings."""
@@ -36,7 +36,7 @@ def test_small_beam_steps_replay_from_a_graph(which):
     assert proc.returncode == 0, proc.stderr[-2000:]
     g = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"graph_mode"')][-1])["graph_mode"]
     assert g["replay_equals_eager"] is True
-    if which != "c1":
+    if which.startswith("control"):
         assert g["replay_follows_in_place_settings"] is True
     assert g["graph_replay_us"] < g["eager_us"]
 
