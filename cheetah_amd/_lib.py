@@ -193,6 +193,16 @@ SIGNATURES = {
     "chx_sc_kick_sorted_workspace_bytes": (c_size_t, [c_i64, c_i32_p, c_int]),
     "chx_sc_kick_sorted": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i32_p, c_int,
                                    c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_sc_kick_sorted_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64, c_i32_p, c_int,
+                                         c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, ctypes.c_int32, c_vpp, c_void_p,
+                                         c_void_p]),
+    "chx_sc_kick_sorted_finish": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                          c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "chx_sc_tile_beam_moments": (c_int, [c_void_p, c_size_t, c_i64, c_i32_p, c_int, c_void_p, c_void_p]),
+    "chx_sc_partials_moments": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
+    "chx_sc_geometry_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                      c_i32_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, ctypes.c_int32, c_void_p]),
     "chx_sc_beam_geometry_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_i64, c_i64,
                                            c_i64, c_i64, c_i64, c_i64, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),

@@ -1757,18 +1757,45 @@ def sc_tile_state(N: int, bins, dtype: torch.dtype, device) -> torch.Tensor | No
 
 
 def sc_kick_sorted(x, q, w, energy, length, grid_extent, mass_eV, N, bins, state, first: bool, last: bool, side_stream=None,
-                   post_map_ptr=None) -> torch.Tensor:
+                   post_map_ptr=None, group=None) -> torch.Tensor:
     """One kick of a chain on the tile-ordered beam (chx_sc_kick_sorted): x (N,7); q, w (N,) only read when `first`;
-    energy, length (1,); grid_extent (1,3). Returns (N,7) in tile order, or in the caller's order when `last`."""
+    energy, length (1,); grid_extent (1,3). Returns (N,7) in tile order, or in the caller's order when `last`.
+
+    `group` (sharding.particle_sharded): the rows are this rank's slice of the beam. The kick then runs in its two halves
+    (chx_sc_kick_sorted_begin / _finish) around the two exchanges of the staged sharded kick — the beam moments (the 29-double
+    all-gather + chx_merge_moments: this rank's share comes from chx_moments on the first kick and from the sums the previous
+    gather pass left in `state` afterwards) and the all-reduce of the deposited charge grid — and the rows stay in tile order."""
     lib = _lib.lib()
     b3 = _bins3(bins)
     dt = dtype_code(x.dtype)
     ws_bytes = lib.chx_sc_kick_sorted_workspace_bytes(N, b3, dt)
     ws = workspace(ws_bytes, x.device)
     out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
-    check(lib.chx_sc_kick_sorted(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, N, b3, dt, ptr(out),
-                                 ptr(ws), ws_bytes, ptr(state), state.numel(), (1 if first else 0) | (2 if last else 0), stream_ptr(),
-                                 side_stream.cuda_stream if side_stream is not None else None, post_map_ptr), "chx_sc_kick_sorted")
+    flags = (1 if first else 0) | (2 if last else 0)
+    side = side_stream.cuda_stream if side_stream is not None else None
+    if group is None:
+        check(lib.chx_sc_kick_sorted(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, N, b3, dt, ptr(out),
+                                     ptr(ws), ws_bytes, ptr(state), state.numel(), flags, stream_ptr(), side, post_map_ptr),
+              "chx_sc_kick_sorted")
+        return out
+    from . import sharding
+
+    if first:
+        local = _moments_raw(x.reshape(1, N, 7), w.reshape(1, N), 1, N).reshape(1, MOM_NOUT)
+    else:
+        local = torch.empty((1, MOM_NOUT), dtype=torch.float64, device=x.device)
+        check(lib.chx_sc_tile_beam_moments(ptr(state), state.numel(), N, b3, dt, ptr(local), stream_ptr()), "chx_sc_tile_beam_moments")
+    mom, rows = sharding.gather_moments_rows(local, group)
+    rho_addr = ctypes.c_void_p()
+    check(lib.chx_sc_kick_sorted_begin(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, N, b3, dt, ptr(ws),
+                                       ws_bytes, ptr(state), state.numel(), flags, ptr(mom), rows, ctypes.byref(rho_addr), stream_ptr(),
+                                       side),
+          "chx_sc_kick_sorted_begin")
+    off = rho_addr.value - ws.data_ptr()
+    rho = ws[off:off + int(bins[0]) * int(bins[1]) * int(bins[2]) * x.element_size()].view(x.dtype)
+    sharding.allreduce_grid(rho, group)
+    check(lib.chx_sc_kick_sorted_finish(ptr(x), ptr(energy), mass_eV, N, b3, dt, ptr(out), ptr(ws), ws_bytes, ptr(state), state.numel(),
+                                        flags, stream_ptr(), side, post_map_ptr), "chx_sc_kick_sorted_finish")
     return out
 
 

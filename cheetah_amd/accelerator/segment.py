@@ -265,6 +265,13 @@ class _FastRun:
 
 
 _CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
+#: CHX_SC_CHAIN = auto (default) | on | off — how `Segment.track` takes [SpaceChargeKick, linear run, SpaceChargeKick, ...]:
+#: "auto" starts on the tile-ordered chain and lets the asynchronous guard (`_chain_allowed`) send a plan whose beam reshuffles
+#: between kicks back to kick-by-kick tracking. The two paths sum the charge in different orders, so WHEN the guard's header
+#: arrives decides the last bits of the first few tracks of a plan; "on" / "off" pin the path for bit-reproducible runs.
+_CHAIN_MODE = os.environ.get("CHX_SC_CHAIN", "auto").lower()
+if _CHAIN_MODE not in ("auto", "on", "off"):
+    raise ValueError(f"CHX_SC_CHAIN must be auto, on or off, not {_CHAIN_MODE!r}")
 
 
 class _HostProxy:
@@ -629,14 +636,18 @@ class Segment(Element):
             kind, item = plan[i]
             if kind == "element" and isinstance(item, SpaceChargeKick) and (chain is not None or self._chain_starts(plan, i, incoming)):
                 # [kick, linear run, kick, ...]: the particle rows are sorted by deposit tile once, every kick of the chain works
-                # on the ordered rows (chx_sc_kick_sorted) and the last one restores the caller's particle order
+                # on the ordered rows (chx_sc_kick_sorted) and the last one restores the caller's particle order. A link needs
+                # the run behind it to be applied INSIDE its own particle pass (persistent device plan, no gradients): only then
+                # are the sums the gather pass leaves for the next kick's grid the sums of the rows that kick sees, and only
+                # then does nothing on the way attach a graph to the beam. Any other run ends the chain at this kick.
                 first = chain is None
                 if first:
                     chain = _ops.sc_tile_state(incoming.particles.shape[0], item.grid_shape, incoming.particles.dtype,
                                                incoming.particles.device)
-                last = self._next_chain_kick(plan, i, item, incoming.particles.dtype) is None
-                incoming, step = self._chain_kick(item, plan[i + 1][1] if i + 1 < n_items and plan[i + 1][0] == "run" else None,
-                                                  incoming, chain, first, last)
+                run = plan[i + 1][1] if i + 1 < n_items and plan[i + 1][0] == "run" else None
+                fused = self._chain_run_plan(run, incoming) if run is not None else None
+                last = self._next_chain_kick(plan, i, item, incoming.particles.dtype) is None or (run is not None and fused is None)
+                incoming, step = self._chain_kick(item, run, fused, incoming, chain, first, last)
                 if last:
                     self._chain_report(plan, chain)
                     chain = None
@@ -771,6 +782,8 @@ class Segment(Element):
         return guard
 
     def _chain_allowed(self, plan) -> bool:
+        if _CHAIN_MODE != "auto":        # CHX_SC_CHAIN=on / off pins the path (reproducible last bits from run to run)
+            return _CHAIN_MODE == "on"
         guard = self._chain_guard(plan)
         pending = guard["pending"]
         if pending is not None and not torch.cuda.is_current_stream_capturing() and pending[1].query():   # (no polling inside a recording)
@@ -799,55 +812,69 @@ class Segment(Element):
     def _chain_starts(self, plan, i: int, incoming: ParticleBeam) -> bool:
         kick = plan[i][1]
         dtype = incoming.particles.dtype
-        return (self._chain_allowed(plan) and kick._chain_settings_ok(dtype) and kick._chain_beam_ok(incoming)
-                and self._next_chain_kick(plan, i, kick, dtype) is not None
-                and _lib.lib().chx_sc_tile_state_bytes(incoming.particles.shape[0], _ops._bins3(kick.grid_shape),
-                                                       _ops.dtype_code(dtype)) > 0)
+        if not (self._chain_allowed(plan) and kick._chain_settings_ok(dtype) and kick._chain_beam_ok(incoming)
+                and self._next_chain_kick(plan, i, kick, dtype) is not None):
+            return False
+        if i + 1 < len(plan) and plan[i + 1][0] == "run" and self._chain_run_plan(plan[i + 1][1], incoming) is None:
+            return False     # the run behind the first kick cannot ride in its particle pass: no second link to profit from
+        return _lib.lib().chx_sc_tile_state_bytes(incoming.particles.shape[0], _ops._bins3(kick.grid_shape), _ops.dtype_code(dtype)) > 0
 
-    def _chain_kick(self, kick, run, incoming: ParticleBeam, state, first: bool, last: bool):
-        """One link of a chain: the kick and, when the run behind it has a persistent device plan, that run in the same particle
-        pass. Returns (beam, number of plan items consumed)."""
-        R_addr, s_out, fused = None, None, False
-        if run is not None:
+    @staticmethod
+    def _chain_run_plan(run: _Run, incoming: ParticleBeam):
+        """(persistent device plan of `run`, was it (re)built in this call) when the run can be applied inside a chain kick's
+        particle pass — scalar settings of the beam's dtype on its device, nothing trainable or requiring grad, at most 192
+        elements — else None."""
+        p = incoming.particles
+        fr = run.fast
+        fresh = False          # the plan's device buffers were (re)written on the main stream just now
+        if fr is None or fr.dtype != p.dtype or fr.device != p.device:
+            fr = run.fast = _FastRun(run, p.dtype, p.device)
+            fresh = True
+        elif fr.epoch != Element._epoch:
+            fr.refresh()
+            fresh = True
+        e, sp = incoming.energy, incoming.species
+        if not fr.ok or e.dim() != 0 or e.dtype != fr.dtype or e.device != fr.device:
+            return None
+        if torch.is_grad_enabled() and (e.requires_grad or sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad
+                                        or _any_requires_grad(*fr.tensors)):
+            return None
+        return fr, fresh
+
+    def _chain_kick(self, kick, run, fused, incoming: ParticleBeam, state, first: bool, last: bool):
+        """One link of a chain: the kick and, when the run behind it has a persistent device plan (`fused` from
+        `_chain_run_plan`), that run in the same particle pass. Returns (beam, number of plan items consumed)."""
+        R_addr, s_out = None, None
+        if fused is not None:
+            fr, fresh = fused
             p = incoming.particles
-            fr = run.fast
-            fresh = False          # the plan's device buffers were (re)written on the main stream just now
-            if fr is None or fr.dtype != p.dtype or fr.device != p.device:
-                fr = run.fast = _FastRun(run, p.dtype, p.device)
-                fresh = True
-            elif fr.epoch != Element._epoch:
-                fr.refresh()
-                fresh = True
             e, sp = incoming.energy, incoming.species
-            if fr.ok and e.dtype == fr.dtype and e.device == fr.device and not (
-                    torch.is_grad_enabled() and (sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad
-                                                 or _any_requires_grad(*fr.tensors))):
-                addr = ctypes.c_void_p()
-                s_in = incoming.s
-                s_out = self._device_s(fr, s_in)
-                # The run's map (and path length) is built on the kick's SIDE stream, in front of the Green-function chain the
-                # kick puts there: it depends on nothing the chain computes (settings, the reference energy), and the main stream
-                # joins the side stream before the gather pass that applies the map. Off the main stream's critical path: 5 us
-                # per kick. The side stream first waits for what the main stream did before the chain (first link: settings edited in
-                # place, the beam) or to the plan's buffers (a plan built or refreshed in this very call).
-                side = kick._side_stream(p.device)
-                stream = _ops.stream_ptr()
-                if side is not None:
-                    if first or fresh:
-                        side.wait_stream(torch.cuda.current_stream(p.device))
-                    stream = side.cuda_stream
-                _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
-                                                  sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
-                                                  ctypes.byref(addr), s_in.data_ptr() if s_out is not None else None,
-                                                  s_out.data_ptr() if s_out is not None else None, stream), "chx_run_map")
-                R_addr, fused = addr.value, True
-                if s_out is None:
-                    s_out = self._run_s(run, s_in)
+            addr = ctypes.c_void_p()
+            s_in = incoming.s
+            s_out = self._device_s(fr, s_in)
+            # The run's map (and path length) is built on the kick's SIDE stream, in front of the Green-function chain the
+            # kick puts there: it depends on nothing the chain computes (settings, the reference energy), and the main stream
+            # joins the side stream before the gather pass that applies the map. Off the main stream's critical path: 5 us
+            # per kick. The side stream first waits for what the main stream did before the chain (first link: settings edited in
+            # place, the beam) or to the plan's buffers (a plan built or refreshed in this very call).
+            side = kick._side_stream(p.device)
+            stream = _ops.stream_ptr()
+            if side is not None:
+                if first or fresh:
+                    side.wait_stream(torch.cuda.current_stream(p.device))
+                stream = side.cuda_stream
+            _ops.check(_lib.lib().chx_run_map(fr.kinds, fr.ptrs, fr.E, e.data_ptr(), sp.mass_eV_float,
+                                              sp.num_elementary_charges_float, fr.code, fr.state.data_ptr(), fr.state_bytes,
+                                              ctypes.byref(addr), s_in.data_ptr() if s_out is not None else None,
+                                              s_out.data_ptr() if s_out is not None else None, stream), "chx_run_map")
+            R_addr = addr.value
+            if s_out is None:
+                s_out = self._run_s(run, s_in)
         out = kick._track_in_chain(incoming, state, first, last, R_addr)
         beam = ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities, s=s_out if fused else incoming.s,
+                            survival_probabilities=incoming.survival_probabilities, s=s_out if fused is not None else incoming.s,
                             species=incoming.species)
-        return beam, (2 if fused else 1)
+        return beam, (2 if fused is not None else 1)
 
     def _kick_then_run(self, kick, run: _Run, incoming: ParticleBeam):
         """One particle pass for a SpaceChargeKick and the run of linear elements behind it (`chx_run_map` refreshes the run's

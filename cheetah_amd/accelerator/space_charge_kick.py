@@ -194,14 +194,11 @@ class SpaceChargeKick(Element):
             self.effect_length, self.grid_extent_x, self.grid_extent_y, self.grid_extent_tau)))
 
     def _chain_beam_ok(self, incoming: ParticleBeam) -> bool:
-        """One plain beam (no vector dims, no gradients, not particle-sharded) that is large enough for the tile sort."""
-        from .. import sharding
-
+        """One plain beam (no vector dims, no gradients) that is large enough for the tile sort. A particle-sharded beam
+        qualifies with its local rows (`_track_in_chain` puts the two exchanges between the halves of the kick)."""
         parts = incoming.particles
         if parts.dim() != 2 or incoming.energy.dim() != 0 or incoming.particle_charges.dim() != 1 \
                 or incoming.survival_probabilities.dim() != 1 or parts.shape[0] < _ops.SORTED_CIC_MIN_PARTICLES:
-            return False
-        if sharding.active_group() is not None:
             return False
         return not (torch.is_grad_enabled() and any(t.requires_grad for t in (
             parts, incoming.particle_charges, incoming.survival_probabilities, incoming.energy)))
@@ -210,6 +207,8 @@ class SpaceChargeKick(Element):
         """This kick as a link of a chain (`chx_sc_kick_sorted`): the first link sorts the particle rows by deposit tile into
         `state`, later links work on the ordered rows, the last one returns the rows in the caller's order. Returns the
         particle tensor (in tile order unless `last`)."""
+        from .. import sharding
+
         parts = incoming.particles
         dtype, device = parts.dtype, parts.device
         N = parts.shape[0]
@@ -218,9 +217,13 @@ class SpaceChargeKick(Element):
         if first:
             q = incoming.particle_charges.to(dtype).contiguous()
             w = incoming.survival_probabilities.to(dtype).contiguous()
+        # inside sharding.particle_sharded: the same two exchanges per kick as `_track_particle_sharded` (29 doubles all-gather,
+        # grid all-reduce), with the same contents — so a rank may be on the chain while another (a slice below the sort's
+        # minimum, a guard that switched its plan back) tracks kick by kick, and both see the same grid
         return _ops.sc_kick_sorted(x, q, w, incoming.energy.to(dtype).reshape(1), self.effect_length.to(dtype).reshape(1),
                                    self._grid_extent(dtype), incoming.species.mass_eV_float, N, self.grid_shape, state, first, last,
-                                   side_stream=self._side_stream(device), post_map_ptr=post_map_ptr)
+                                   side_stream=self._side_stream(device), post_map_ptr=post_map_ptr,
+                                   group=sharding.active_group())
 
     def _track_particle_sharded(self, incoming, group, x, q, w, energy, L, out_shape, B, N) -> ParticleBeam:
         """The kick for a beam whose particles are spread over the ranks of `group` (sharding.particle_sharded): the same

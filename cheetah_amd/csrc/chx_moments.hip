@@ -829,6 +829,61 @@ __global__ __launch_bounds__(CHX_BLOCK) void cavity_bwd_kernel(const T* __restri
     }
 }
 
+// The sums sc_tile_particle_kernel left behind (partials[kSG][nblk], about the origin) as a chx_moments row: [W, W2, mu(6),
+// cov(21)] with the entries of x, y and tau filled (the three variances a SpaceChargeKick reads) and zeros elsewhere. One
+// workgroup. This is what a rank of a particle-sharded chain puts into the 29-double all-gather between two kicks
+// (chx_merge_moments merges entry by entry, so the zeros stay zeros).
+__global__ __launch_bounds__(CHX_BLOCK) void sc_partials_moments_kernel(const double* __restrict__ partials, int nblk,
+                                                                       double* __restrict__ out) {
+    __shared__ double red[16 * kSG];
+    __shared__ double tot[kSG];
+    double a[kSG];
+#pragma unroll
+    for (int k = 0; k < kSG; ++k) a[k] = 0.0;
+    for (int i0 = threadIdx.x; i0 < nblk; i0 += 4 * CHX_BLOCK) {
+        double v[4][kSG];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * CHX_BLOCK;
+#pragma unroll
+            for (int k = 0; k < kSG; ++k) v[u][k] = i < nblk ? partials[(int64_t)k * nblk + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < kSG; ++k) a[k] += v[u][k];
+    }
+#pragma unroll
+    for (int k = 0; k < kSG; ++k) a[k] = chx_row16_sum(a[k]);
+    if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < kSG; ++k) red[(threadIdx.x >> 4) * kSG + k] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kSG) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r * kSG + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < CHX_MOM_NOUT) out[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double W = tot[0], W2 = tot[1];
+        const double cf = W - W2 / W;
+        out[0] = W;
+        out[1] = W2;
+        const int col[3] = {0, 2, 4};
+        const int diag[3] = {0, 11, 18};     // cov_xx, cov_yy, cov_tautau in the upper triangle
+        for (int d = 0; d < 3; ++d) {
+            const double m = tot[2 + d] / W;
+            out[2 + col[d]] = m;
+            out[8 + diag[d]] = (tot[5 + d] - W * m * m) / cf;
+        }
+    }
+}
+
 int check_red(const void* x, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype) {
     if (!x || B < 1 || N < 1 || B > 65535) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bw, B)) return CHX_ERR_INVALID_ARG;
@@ -1027,6 +1082,13 @@ extern "C" int chx_sc_geometry_from_partials(const double* partials, int64_t nbl
                            (double*)extent, pot_scale, (int*)tile_header, 0);
     else
         return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+extern "C" int chx_sc_partials_moments(const double* partials, int64_t nblk, double* moments_out, void* stream) {
+    if (!partials || !moments_out || nblk < 1 || nblk > 0x7fffffff) return CHX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sc_partials_moments_kernel, dim3(1), dim3(CHX_BLOCK), 0, (hipStream_t)stream, partials, (int)nblk, moments_out);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

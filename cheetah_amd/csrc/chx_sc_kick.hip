@@ -157,79 +157,162 @@ extern "C" size_t chx_sc_kick_sorted_workspace_bytes(int64_t N, const int32_t* b
     return chx_sc_kick_workspace_bytes(1, N, bins, dtype);
 }
 
-extern "C" int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
-                                  const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins, int dtype, void* x_out,
-                                  void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags, void* stream,
-                                  void* side_stream, const void* post_map) {
-    if (!x_in || !energy || !length || !grid_extent || !x_out || !workspace || !state) return CHX_ERR_INVALID_ARG;
+namespace {
+
+// pointers into the workspace / state of one kick of a chain
+struct SortedKick {
+    Layout L;
+    ScTileLayout T;
+    char *ws, *st;
+    void *half, *cell, *gamma, *dt, *scale, *extent, *rho, *ghat, *phi;
+    double* pot_scale;
+};
+
+int sorted_kick_prepare(int64_t N, const int32_t* bins, int dtype, void* workspace, size_t workspace_bytes, void* state,
+                        size_t state_bytes, SortedKick& k) {
+    if (!workspace || !state) return CHX_ERR_INVALID_ARG;
     if (N < 1 || !bins || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
-    const bool first = flags & 1, last = flags & 2;
-    if (first && (!charge || !survival)) return CHX_ERR_INVALID_ARG;
     const size_t need_state = chx_sc_tile_state_bytes(N, bins, dtype);
     if (need_state == 0) return CHX_ERR_INVALID_ARG;
     if (state_bytes < need_state) return CHX_ERR_WORKSPACE;
-    const Layout L = layout(1, N, bins, dtype);
-    if (workspace_bytes < L.total) return CHX_ERR_WORKSPACE;
-    const ScTileLayout T = sc_tile_layout(N, bins, dtype);
+    k.L = layout(1, N, bins, dtype);
+    if (workspace_bytes < k.L.total) return CHX_ERR_WORKSPACE;
+    k.T = sc_tile_layout(N, bins, dtype);
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    char* ws = (char*)workspace;
-    char* st = (char*)state;
+    k.ws = (char*)workspace;
+    k.st = (char*)state;
+    char* geo = k.ws + k.L.geo;
+    k.half = geo;
+    k.cell = geo + (size_t)3 * esz;
+    k.gamma = geo + (size_t)6 * esz;
+    k.dt = geo + (size_t)7 * esz;
+    k.scale = geo + (size_t)8 * esz;
+    k.extent = geo + (size_t)11 * esz;
+    k.pot_scale = (double*)(k.ws + k.L.pot);
+    k.rho = k.ws + k.L.rho;
+    k.ghat = k.ws + k.L.ghat;
+    k.phi = k.ws + k.L.phi;
+    return CHX_OK;
+}
+
+}  // namespace
+
+// The kick in two halves, so that a beam whose particles are spread over several GPUs (cheetah_amd.sharding) can put its two
+// exchanges in between WITHOUT leaving the tile-ordered chain:
+//   begin : grid geometry (from `beam_moments` when given — the 29 doubles of the WHOLE beam (moment_rows = 0), or the
+//           moment_rows x 29 doubles of its shards as all-gathered, merged here — else from this process's own particles) -> [side stream: Green spectrum] -> [first kick: tile sort] -> tile deposit into *rho_out (compact
+//           [gx][gy][gz] array of `dtype` inside the workspace: the caller may sum it over the ranks in place)
+//   finish: pruned FFT convolution (the main stream joins the side stream in front of the pass that reads the spectrum) ->
+//           gather + kick (+ post_map) on the ordered rows.
+// The same workspace and state must be handed to both halves; nothing else may use the workspace in between.
+extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, const void* survival, const void* energy,
+                                        const void* length, const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins,
+                                        int dtype, void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags,
+                                        const double* beam_moments, int32_t moment_rows, void** rho_out, void* stream,
+                                        void* side_stream) {
+    if (!x_in || !energy || !length || !grid_extent) return CHX_ERR_INVALID_ARG;
+    const bool first = flags & 1, last = flags & 2;
+    if (first && (!charge || !survival)) return CHX_ERR_INVALID_ARG;
+    SortedKick k;
+    int rc = sorted_kick_prepare(N, bins, dtype, workspace, workspace_bytes, state, state_bytes, k);
+    if (rc != CHX_OK) return rc;
     hipStream_t main = (hipStream_t)stream;
     hipStream_t side = side_stream ? (hipStream_t)side_stream : main;
 
-    char* geo = ws + L.geo;
-    void* half = geo;
-    void* cell = geo + (size_t)3 * esz;
-    void* gamma = geo + (size_t)6 * esz;
-    void* dt = geo + (size_t)7 * esz;
-    void* scale = geo + (size_t)8 * esz;
-    void* extent = geo + (size_t)11 * esz;
-    double* pot_scale = (double*)(ws + L.pot);
-    void* rho = ws + L.rho;
-    void* ghat = ws + L.ghat;
-    void* phi = ws + L.phi;
-
     const double n_padded = 8.0 * bins[0] * bins[1] * bins[2];
     const double pot_factor = 1.0 / (4.0 * M_PI * kEpsilon0) / n_padded;
-    // beam sizes -> grid geometry. First kick: the two launches of chx_sc_beam_geometry on the caller's arrays. Later kicks: the
-    // gather pass of the previous kick left the partial sums of the rows it wrote (= this kick's x_in) in the state: one launch.
-    int rc;
-    if (first)
+    // beam sizes -> grid geometry. From the whole beam's moments when the caller has them (particle-sharded beam). Else, first
+    // kick: the two launches of chx_sc_beam_geometry on the caller's arrays; later kicks: the gather pass of the previous kick left
+    // the partial sums of the rows it wrote (= this kick's x_in) in the state: one launch.
+    if (beam_moments)
+        rc = chx_sc_geometry_tiles(beam_moments, grid_extent, energy, length, mass_eV, pot_factor, 1, 1, 1, 1, 1, bins, dtype, k.half,
+                                   k.cell, k.gamma, k.dt, k.scale, k.extent, k.pot_scale, first ? nullptr : k.st + k.T.hdr, moment_rows, main);
+    else if (first)
         rc = chx_sc_beam_geometry_tiles(x_in, survival, grid_extent, energy, length, mass_eV, pot_factor, 1, 1, 1, 1, 1, 1, N, bins,
-                                        dtype, half, cell, gamma, dt, scale, extent, pot_scale, ws + L.mom_ws, L.mom - L.mom_ws,
-                                        st + T.hdr, 1, main);
+                                        dtype, k.half, k.cell, k.gamma, k.dt, k.scale, k.extent, k.pot_scale, k.ws + k.L.mom_ws,
+                                        k.L.mom - k.L.mom_ws, k.st + k.T.hdr, 1, main);
     else
-        rc = chx_sc_geometry_from_partials((const double*)(st + T.sigma), T.sigma_blocks, grid_extent, energy, length, mass_eV,
-                                           pot_factor, bins, dtype, half, cell, gamma, dt, scale, extent, pot_scale, st + T.hdr, main);
+        rc = chx_sc_geometry_from_partials((const double*)(k.st + k.T.sigma), k.T.sigma_blocks, grid_extent, energy, length, mass_eV,
+                                           pot_factor, bins, dtype, k.half, k.cell, k.gamma, k.dt, k.scale, k.extent, k.pot_scale,
+                                           k.st + k.T.hdr, main);
     if (rc != CHX_OK) return rc;
 
-    hipEvent_t fork = nullptr, join = nullptr;
     const bool forked = side != main;
     if (forked) {
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess)
-            return CHX_ERR_LAUNCH;
+        hipEvent_t fork = nullptr;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return CHX_ERR_LAUNCH;
         (void)hipEventRecord(fork, main);
         (void)hipStreamWaitEvent(side, fork, 0);
+        (void)hipEventDestroy(fork);
     }
-    rc = chx_sc_green_spectrum_fast(cell, gamma, 1, bins, dtype, ghat, ws + L.green_ws, L.ghat - L.green_ws, side);
-    if (forked) (void)hipEventRecord(join, side);
+    rc = chx_sc_green_spectrum_fast(k.cell, k.gamma, 1, bins, dtype, k.ghat, k.ws + k.L.green_ws, k.L.ghat - k.L.green_ws, side);
 
     // first kick of the chain: order the rows by deposit tile (into the state's row buffer); every kick: deposit from the ordered
     // rows (the merge pass decides on the device whether this kick's gather re-orders them for the kicks that follow)
     const void* rows = first ? nullptr : x_in;             // nullptr = the state's row buffer
-    if (rc == CHX_OK && first) rc = chx_sc_tile_sort(x_in, charge, survival, extent, scale, N, bins, dtype, state, state_bytes, main);
-    if (rc == CHX_OK) rc = chx_sc_tile_deposit(rows, extent, scale, N, bins, dtype, state, state_bytes, rho, last ? 0 : 1, main);
-    if (rc == CHX_OK)
-        rc = chx_sc_convolve_halo_after(rho, ghat, pot_scale, 1, bins, dtype, phi, ws + L.conv_ws, L.phi - L.conv_ws, main,
-                                        forked ? (void*)join : nullptr);
-    else if (forked)
-        (void)hipStreamWaitEvent(main, join, 0);
+    if (rc == CHX_OK && first)
+        rc = chx_sc_tile_sort(x_in, charge, survival, k.extent, k.scale, N, bins, dtype, state, state_bytes, main);
+    if (rc == CHX_OK) rc = chx_sc_tile_deposit(rows, k.extent, k.scale, N, bins, dtype, state, state_bytes, k.rho, last ? 0 : 1, main);
+    if (rc != CHX_OK && forked) {                           // an error path still rejoins the side stream
+        hipEvent_t join = nullptr;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
+            (void)hipEventRecord(join, side);
+            (void)hipStreamWaitEvent(main, join, 0);
+            (void)hipEventDestroy(join);
+        }
+    }
+    if (rho_out) *rho_out = k.rho;
+    return rc;
+}
+
+extern "C" int chx_sc_kick_sorted_finish(const void* x_in, const void* energy, double mass_eV, int64_t N, const int32_t* bins,
+                                         int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* state,
+                                         size_t state_bytes, int flags, void* stream, void* side_stream, const void* post_map) {
+    if (!x_in || !energy || !x_out) return CHX_ERR_INVALID_ARG;
+    const bool first = flags & 1, last = flags & 2;
+    SortedKick k;
+    int rc = sorted_kick_prepare(N, bins, dtype, workspace, workspace_bytes, state, state_bytes, k);
+    if (rc != CHX_OK) return rc;
+    hipStream_t main = (hipStream_t)stream;
+    hipStream_t side = side_stream ? (hipStream_t)side_stream : main;
+    hipEvent_t join = nullptr;
+    const bool forked = side != main;
     if (forked) {
-        (void)hipEventDestroy(fork);
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return CHX_ERR_LAUNCH;
+        (void)hipEventRecord(join, side);                 // behind the Green spectrum `begin` put on the side stream
+    }
+    rc = chx_sc_convolve_halo_after(k.rho, k.ghat, k.pot_scale, 1, bins, dtype, k.phi, k.ws + k.L.conv_ws, k.L.phi - k.L.conv_ws, main,
+                                    forked ? (void*)join : nullptr);
+    if (forked) {
+        if (rc != CHX_OK) (void)hipStreamWaitEvent(main, join, 0);
         (void)hipEventDestroy(join);
     }
     if (rc != CHX_OK) return rc;
-    return chx_sc_tile_gather_kick(rows, phi, half, cell, gamma, energy, dt, mass_eV, N, bins, dtype, post_map, state, state_bytes,
-                                   last ? 1 : 0, x_out, main);
+    const void* rows = first ? nullptr : x_in;
+    return chx_sc_tile_gather_kick(rows, k.phi, k.half, k.cell, k.gamma, energy, k.dt, mass_eV, N, bins, dtype, post_map, state,
+                                   state_bytes, last ? 1 : 0, x_out, main);
+}
+
+extern "C" int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                                  const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins, int dtype, void* x_out,
+                                  void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags, void* stream,
+                                  void* side_stream, const void* post_map) {
+    if (!x_out) return CHX_ERR_INVALID_ARG;
+    int rc = chx_sc_kick_sorted_begin(x_in, charge, survival, energy, length, grid_extent, mass_eV, N, bins, dtype, workspace,
+                                      workspace_bytes, state, state_bytes, flags, nullptr, 0, nullptr, stream, side_stream);
+    if (rc != CHX_OK) return rc;
+    return chx_sc_kick_sorted_finish(x_in, energy, mass_eV, N, bins, dtype, x_out, workspace, workspace_bytes, state, state_bytes,
+                                     flags, stream, side_stream, post_map);
+}
+
+// what this process's rows of a running chain contribute to the beam moments the NEXT kick's grid is built from: the sums the
+// last gather pass accumulated (chx_sc_tile_gather_kick), as a chx_moments row (x, y, tau entries; chx_sc_partials_moments)
+extern "C" int chx_sc_tile_beam_moments(const void* state, size_t state_bytes, int64_t N, const int32_t* bins, int dtype,
+                                        double* moments_out, void* stream) {
+    if (!state || !moments_out || N < 1 || !bins) return CHX_ERR_INVALID_ARG;
+    const size_t need_state = chx_sc_tile_state_bytes(N, bins, dtype);
+    if (need_state == 0) return CHX_ERR_INVALID_ARG;
+    if (state_bytes < need_state) return CHX_ERR_WORKSPACE;
+    const ScTileLayout T = sc_tile_layout(N, bins, dtype);
+    return chx_sc_partials_moments((const double*)((const char*)state + T.sigma), T.sigma_blocks, moments_out, stream);
 }

@@ -304,11 +304,47 @@ __global__ void sc_geometry_kernel(const double* __restrict__ mom, const T* __re
                                    const T* __restrict__ length, double mass, double pot_factor, int64_t B, int64_t Bm,
                                    int64_t Bext, int64_t Be, int64_t Bl, int gx, int gy, int gz, T* __restrict__ half,
                                    T* __restrict__ cell, T* __restrict__ gamma_out, T* __restrict__ dt,
-                                   T* __restrict__ scale, T* __restrict__ extent, double* __restrict__ pot_scale) {
+                                   T* __restrict__ scale, T* __restrict__ extent, double* __restrict__ pot_scale,
+                                   int* __restrict__ tile_hdr, int merge_rows) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const double* m = mom + ((Bm == 1) ? 0 : b) * CHX_MOM_NOUT;
-    const double var[3] = {m[8], m[8 + 11], m[8 + 18]};  // cov_xx, cov_yy, cov_tautau
+    // a later kick of a chain of tile-ordered kicks (chx_sc_tiles.h): the header rolls over here, exactly as in
+    // sc_geometry_partials_kernel (chx_moments.hip) — this kernel runs before the deposit / gather kernels of the kick
+    if (tile_hdr && b == 0 && tile_hdr[1]) {
+        tile_hdr[0] ^= 1;
+        tile_hdr[1] = 0;
+    }
+    double var[3];
+    if (merge_rows > 0) {
+        // mom[merge_rows][29] are the moments of the SHARDS of one beam (what the ranks all-gathered): the three variances of
+        // their union by the arithmetic of merge_moments_kernel (chx_moments.hip), entry by entry — bit-identical to
+        // chx_merge_moments followed by this kernel with merge_rows = 0
+        const int col[3] = {0, 2, 4}, diag[3] = {0, 11, 18};
+        double W = 0.0, W2 = 0.0, mu[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < merge_rows; ++r) {
+            const double* p = mom + (int64_t)r * CHX_MOM_NOUT;
+            if (!(p[0] > 0.0)) continue;
+            W += p[0];
+            W2 += p[1];
+            for (int d = 0; d < 3; ++d) mu[d] += p[0] * p[2 + col[d]];
+        }
+        for (int d = 0; d < 3; ++d) mu[d] /= W;
+        double M[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < merge_rows; ++r) {
+            const double* p = mom + (int64_t)r * CHX_MOM_NOUT;
+            if (!(p[0] > 0.0)) continue;
+            const double cf = p[0] - p[1] / p[0];
+            for (int d = 0; d < 3; ++d) {
+                const double dd = p[2 + col[d]] - mu[d];
+                M[d] += p[8 + diag[d]] * cf + p[0] * dd * dd;
+            }
+        }
+        const double cf = W - W2 / W;
+        for (int d = 0; d < 3; ++d) var[d] = M[d] / cf;
+    } else {
+        const double* m = mom + ((Bm == 1) ? 0 : b) * CHX_MOM_NOUT;
+        var[0] = m[8]; var[1] = m[8 + 11]; var[2] = m[8 + 18];  // cov_xx, cov_yy, cov_tautau
+    }
     sc_geometry_row<T>(var, ext + ((Bext == 1) ? 0 : b) * 3, energy[(Be == 1) ? 0 : b], length[(Bl == 1) ? 0 : b], mass,
                        pot_factor, gx, gy, gz, half + b * 3, cell + b * 3, gamma_out + b, dt + b, scale + b * 3,
                        extent + b * 6, pot_scale + b);
@@ -325,6 +361,16 @@ extern "C" int chx_sc_geometry(const double* moments, const void* grid_extent, c
                                double mass_eV, double pot_factor, int64_t B, int64_t Bm, int64_t Bext, int64_t Be,
                                int64_t Bl, const int32_t* bins, int dtype, void* half, void* cell, void* gamma,
                                void* dt, void* scale, void* extent, double* pot_scale, void* stream) {
+    return chx_sc_geometry_tiles(moments, grid_extent, energy, length, mass_eV, pot_factor, B, Bm, Bext, Be, Bl, bins, dtype, half,
+                                 cell, gamma, dt, scale, extent, pot_scale, nullptr, 0, stream);
+}
+
+extern "C" int chx_sc_geometry_tiles(const double* moments, const void* grid_extent, const void* energy, const void* length,
+                                     double mass_eV, double pot_factor, int64_t B, int64_t Bm, int64_t Bext, int64_t Be,
+                                     int64_t Bl, const int32_t* bins, int dtype, void* half, void* cell, void* gamma,
+                                     void* dt, void* scale, void* extent, double* pot_scale, void* tile_header, int32_t merge_rows,
+                                     void* stream) {
+    if (merge_rows < 0 || (merge_rows > 0 && B != 1)) return CHX_ERR_INVALID_ARG;
     if (!moments || !grid_extent || !energy || !length || !half || !cell || !gamma || !dt || !scale || !extent ||
         !pot_scale || B < 1 || !bins_ok(bins))
         return CHX_ERR_INVALID_ARG;
@@ -336,12 +382,12 @@ extern "C" int chx_sc_geometry(const double* moments, const void* grid_extent, c
         hipLaunchKernelGGL(sc_geometry_kernel<float>, dim3(nb), dim3(64), 0, s, moments, (const float*)grid_extent,
                            (const float*)energy, (const float*)length, mass_eV, pot_factor, B, Bm, Bext, Be, Bl, bins[0],
                            bins[1], bins[2], (float*)half, (float*)cell, (float*)gamma, (float*)dt, (float*)scale,
-                           (float*)extent, pot_scale);
+                           (float*)extent, pot_scale, (int*)tile_header, (int)merge_rows);
     else if (dtype == CHX_F64)
         hipLaunchKernelGGL(sc_geometry_kernel<double>, dim3(nb), dim3(64), 0, s, moments, (const double*)grid_extent,
                            (const double*)energy, (const double*)length, mass_eV, pot_factor, B, Bm, Bext, Be, Bl, bins[0],
                            bins[1], bins[2], (double*)half, (double*)cell, (double*)gamma, (double*)dt, (double*)scale,
-                           (double*)extent, pot_scale);
+                           (double*)extent, pot_scale, (int*)tile_header, (int)merge_rows);
     else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();

@@ -142,6 +142,19 @@ def gather_merge_moments(local: torch.Tensor, group=None) -> torch.Tensor:
     return merged
 
 
+def gather_moments_rows(local: torch.Tensor, group=None):
+    """This rank's (1,29) moments -> (rows, R): over RCCL the (R,29) moments of all shards exactly as all-gathered (R = world
+    size; the consumer merges them itself: `chx_sc_kick_sorted_begin`'s geometry kernel), otherwise the merged (1,29) row and
+    R = 0. One all-gather either way."""
+    if collectives_on(group) and local.is_cuda and dist.get_backend(group) != "gloo":
+        world = dist.get_world_size(group)
+        staged = local.contiguous()
+        gathered = torch.empty((world, staged.shape[-1]), dtype=staged.dtype, device=staged.device)
+        dist.all_gather_into_tensor(gathered, staged.reshape(1, -1), group=group)
+        return gathered, world
+    return gather_merge_moments(local, group).contiguous(), 0
+
+
 def global_moments(beam, group=None) -> torch.Tensor:
     """(…,29) global moments of a particle-sharded beam: local one-pass HIP reduction (chx_moments) + one
     all-gather over RCCL + exact merge."""

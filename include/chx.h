@@ -486,6 +486,37 @@ int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* surviva
                        const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins, int dtype, void* x_out,
                        void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags, void* stream,
                        void* side_stream, const void* post_map);
+/* chx_sc_kick_sorted in two halves, for a beam whose particles are spread over several GPUs (one process per GPU,
+ * cheetah_amd/sharding.py; the reference's kick, space_charge_kick.py:477-586, needs the beam sizes of ALL particles :531-538 and
+ * the charge of ALL particles on the grid :556-563): the two exchanges sit between the halves and the rows never leave the
+ * tile order.
+ *  begin : grid geometry — from beam_moments when non-NULL (chx_moments layout; moment_rows = 0: the 29 moments of the WHOLE
+ *          beam, moment_rows = R > 0: the [R][29] moments of its shards exactly as the ranks all-gathered them, merged inside the
+ *          geometry kernel with chx_merge_moments' arithmetic), else from this process's own rows as chx_sc_kick_sorted does — then
+ *          [side stream: Green spectrum], [CHX_SC_FIRST: tile sort], tile deposit. *rho_out = the compact charge grid
+ *          [gx][gy][gz] (dtype) inside `workspace`, every cell stored: sum it over the ranks in place.
+ *  finish: convolution (joins the side stream) -> gather + kick (+ post_map) into x_out.
+ * Same workspace / state / flags / streams for both halves; the workspace must not be touched in between.
+ * chx_sc_tile_beam_moments: this process's share of the moments the NEXT kick's grid needs — the sums the last
+ * gather pass left in `state`, as a chx_moments row (entries of x, y, tau; zeros elsewhere) for the all-gather + merge. */
+int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                             const void* grid_extent, double mass_eV, int64_t N, const int32_t* bins, int dtype, void* workspace,
+                             size_t workspace_bytes, void* state, size_t state_bytes, int flags, const double* beam_moments,
+                             int32_t moment_rows, void** rho_out, void* stream, void* side_stream);
+int chx_sc_kick_sorted_finish(const void* x_in, const void* energy, double mass_eV, int64_t N, const int32_t* bins, int dtype,
+                              void* x_out, void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, int flags,
+                              void* stream, void* side_stream, const void* post_map);
+int chx_sc_tile_beam_moments(const void* state, size_t state_bytes, int64_t N, const int32_t* bins, int dtype, double* moments_out,
+                             void* stream);
+/* partials[8][nblk] (the sums of chx_sc_tile_gather_kick: W, W2, sum w x / y / tau, sum w x^2 / y^2 / tau^2 about the origin)
+ * -> one chx_moments row [29] with the x, y, tau means and variances filled (statistics.py:30-48), zeros elsewhere */
+int chx_sc_partials_moments(const double* partials, int64_t nblk, double* moments_out, void* stream);
+/* chx_sc_geometry (B = 1 in a chain) + the header update of a chain of tile-ordered kicks (tile_header = start of the chain's
+ * state for every kick but the first, NULL otherwise) */
+int chx_sc_geometry_tiles(const double* moments, const void* grid_extent, const void* energy, const void* length, double mass_eV,
+                          double pot_factor, int64_t B, int64_t Bm, int64_t Bext, int64_t Be, int64_t Bl, const int32_t* bins,
+                          int dtype, void* half, void* cell, void* gamma, void* dt, void* scale, void* extent, double* pot_scale,
+                          void* tile_header, int32_t merge_rows /*0, or B = 1 and moments[merge_rows][29] = shards to merge*/, void* stream);
 int chx_sc_beam_geometry_tiles(const void* x, const void* w, const void* grid_extent, const void* energy, const void* length,
                                double mass_eV, double pot_factor, int64_t B, int64_t Bx, int64_t Bw, int64_t Bext, int64_t Be,
                                int64_t Bl, int64_t N, const int32_t* bins, int dtype, void* half, void* cell, void* gamma, void* dt,

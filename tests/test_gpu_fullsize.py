@@ -312,10 +312,20 @@ def test_c5_full_size_backward(ca, oracle):
     h = 1e-4
     dk = (sigma_x(k0 + h, L0) - sigma_x(k0 - h, L0)) / (2 * h)
     dL = (sigma_x(k0, L0 + h) - sigma_x(k0, L0 - h)) / (2 * h)
-    assert float(sx) == pytest.approx(sigma_x(k0, L0), rel=2e-5)
+    # the finite differences themselves: Richardson-extrapolated central differences (error O(h^4)) so that the comparison
+    # measures the device's gradient, not the step of the difference
+    dk2 = (sigma_x(k0 + 2 * h, L0) - sigma_x(k0 - 2 * h, L0)) / (4 * h)
+    dL2 = (sigma_x(k0, L0 + 2 * h) - sigma_x(k0, L0 - 2 * h)) / (4 * h)
+    dk, dL = (4 * dk - dk2) / 3, (4 * dL - dL2) / 3
+    e_v = abs(float(sx.detach()) / sigma_x(k0, L0) - 1)
+    e_k, e_L = abs(float(k1.grad) / dk - 1), abs(float(L.grad) / dL - 1)
+    print(f"\nC5 full size: sigma_x {e_v:.2e}, d/dk1 {e_k:.2e}, d/dL {e_L:.2e} (relative)")
+    # MEASURED on the MI355X: value 1.6e-7 (fp32 particles, fp64 moments), d sigma_x / d k1 6.7e-9, d sigma_x / d L 2.9e-8 relative
+    # (the backward is 7x7 algebra in fp64 on the memoised moments; the maps are fp32). Bounds 4x measured.
+    assert e_v < 6.4e-7
     assert abs(dk) > 1e-6   # -3.69e-05 for this lattice
-    assert float(k1.grad) == pytest.approx(dk, rel=1e-3)
-    assert float(L.grad) == pytest.approx(dL, rel=1e-3)
+    assert e_k < 2.7e-8
+    assert e_L < 1.2e-7
 
 
 # ------------------------------------------------------------------------------------------------------------ Green function

@@ -286,15 +286,25 @@ def test_c2_fodo100(ca, golden, tag):
                     mass_eV=torch.tensor(mass, dtype=torch.float64, device="cuda"))
     beam = ca.ParticleBeam(dev(g[f"in_{tag}"]), dev(g[f"energy_{tag}"]), species=sp)
     R = seg.first_order_transfer_map(beam.energy, beam.species).cpu().numpy()
-    assert relmax(R, g[f"R_{tag}"]) < (1e-10 if tag == "f64" else 2e-4)
+    e_R = relmax(R, g[f"R_{tag}"])
     out = seg.track(beam).particles.cpu().numpy()
     scale = np.max(np.abs(g[f"out_merged_{tag}"]), axis=0)
-    assert np.max(np.abs(out - g[f"out_merged_{tag}"]) / scale) < (1e-11 if tag == "f64" else 5e-4)
-    tol = np.full(7, 1e-11 if tag == "f64" else 5e-4)
-    tol[4] = max(tol[4], 1e-7)  # reference species.clone() quirk, see tests/test_oracle_golden.py
+    e_merged = np.max(np.abs(out - g[f"out_merged_{tag}"]) / scale)
+    e_ew = []
     for fused in (False, True):
         ew = seg.track_elementwise(beam, fused=fused).particles.cpu().numpy()
-        assert (np.max(np.abs(ew - g[f"out_elementwise_{tag}"]) / scale, axis=0) < tol).all()
+        e_ew.append(np.max(np.abs(ew - g[f"out_elementwise_{tag}"]) / scale, axis=0))
+    print(f"\nC2 {tag}: map {e_R:.2e}, merged track {e_merged:.2e}, elementwise {np.max(e_ew[0][:4]):.2e} (tau {e_ew[0][4]:.2e})")
+    # MEASURED (MI355X, against the reference's own run, in units of a coordinate's scale) -> bound = 4x:
+    #   fp64: map 2.1e-15, merged track 5.3e-15, element by element 7.8e-15
+    #   fp32: map 4.1e-6 (the reference composes its 100 float32 maps in float32; here the product is accumulated in float64 and
+    #         rounded once), merged track 5.4e-6, element by element 5.7e-6 (100 fp32 steps on both sides, different sum order)
+    assert e_R < (8.4e-15 if tag == "f64" else 1.7e-5)
+    assert e_merged < (2.2e-14 if tag == "f64" else 2.2e-5)
+    tol = np.full(7, 3.2e-14 if tag == "f64" else 2.3e-5)
+    tol[4] = max(tol[4], 1e-7)  # reference species.clone() quirk, see tests/test_oracle_golden.py
+    for e in e_ew:
+        assert (e < tol).all(), e
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])

@@ -74,10 +74,15 @@ def _worker(port, queue):
             seg, beam = _lattice(ca, dtype, grid), _beam(ca, dtype, n)
             whole = seg.track(beam).particles.clone()
             before = dict(calls)
-            with sharding.particle_sharded(force_collectives=True):
-                assert sharding.active_group() is not None
-                forced = seg.track(beam).particles.clone()
-                mom = sharding.global_moments(beam)
+            links, orig_link = [], _ops.sc_kick_sorted
+            _ops.sc_kick_sorted = lambda *a, **k: (links.append(k.get("group") is not None), orig_link(*a, **k))[1]
+            try:
+                with sharding.particle_sharded(force_collectives=True):
+                    assert sharding.active_group() is not None
+                    forced = seg.track(beam).particles.clone()
+                    mom = sharding.global_moments(beam)
+            finally:
+                _ops.sc_kick_sorted = orig_link
             used = {k: calls[k] - before[k] for k in calls}
             # the same staged path with the two RCCL calls replaced by local copies (chx_merge_moments still runs)
             def local_gather(out, inp, group=None):
@@ -98,6 +103,7 @@ def _worker(port, queue):
                 "staged_vs_forced_max": float((forced - staged).abs().max()),
                 "staged_vs_forced_rel": float(((forced - staged).abs() / (kick + 1e-30)).max()),
                 "sorted_deposit": n >= _ops.SORTED_CIC_MIN_PARTICLES,
+                "chain_links": links,
                 "run_to_run_max": float((staged2 - staged).abs().max()),     # atomics anywhere on the path (direct deposit,
                 "run_to_run_rel": float(((staged2 - staged).abs() / (kick + 1e-30)).max()),   # hot tiles of the sorted one)
                 "forced_vs_whole": float(((forced - whole).abs() / (kick + 1e-30)).max()),
@@ -147,6 +153,9 @@ def test_rccl_exchanges_on_one_rank():
         r = report[name]
         # three kicks: one all-gather (moments) and one all-reduce (grid) each, plus the all-gather of global_moments
         assert r["used"] == {"all_gather": 4, "all_reduce": 3}, (name, r)
+        # power-of-two grid and enough rows for the tile sort: the three kicks are links of ONE tile-ordered chain whose halves
+        # (chx_sc_kick_sorted_begin / _finish) sit around the exchanges; the other cases take the staged kick
+        assert r["chain_links"] == ([True] * 3 if name == "f32_64_sorted" else []), (name, r)
         if r["run_to_run_max"] == 0.0:
             assert r["staged_vs_forced_max"] == 0.0, (name, r)       # a one-rank exchange is the identity, bit for bit
         else:   # the path itself is not bit-reproducible (float atomics: direct deposit below 65536 particles, hot tiles of

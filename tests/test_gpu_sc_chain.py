@@ -286,3 +286,104 @@ def test_isolated_kicks_and_small_beams_keep_the_one_call_path(ca):
     finally:
         _ops.sc_kick_sorted = orig
     assert calls == []
+
+
+def _spy_links(fn):
+    """(first, last) of every chain link `fn()` issues."""
+    from cheetah_amd import _ops
+
+    calls, orig = [], _ops.sc_kick_sorted
+    _ops.sc_kick_sorted = lambda *a, **k: (calls.append((a[10], a[11])), orig(*a, **k))[1]
+    try:
+        out = fn()
+    finally:
+        _ops.sc_kick_sorted = orig
+    return out, calls
+
+
+@pytest.mark.parametrize("breaker", ["custom_map", "vector_quad", "parameter_quad", "long_run"])
+def test_unfusable_run_ends_the_chain(ca, breaker):
+    """A run between two kicks that cannot ride in the kick's particle pass (no device plan: a CustomTransferMap, vectorised
+    settings, a trainable Parameter, more than 192 elements) must END the chain at the kick in front of it: the sums the gather pass
+    leaves for the next kick's grid describe the rows BEFORE that run, so a chain that went on would build the next grid from
+    stale beam sizes (silently wrong). Kicks behind the breaker may start a new chain."""
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    grid = (32, 32, 32)
+    sc = lambda: ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw)  # noqa: E731
+    quad = lambda k: ca.Quadrupole(t(0.1), k1=t(k), **kw)  # noqa: E731
+    if breaker == "custom_map":
+        R = torch.eye(7, **kw)
+        R[0, 1], R[2, 3], R[0, 0], R[2, 2] = 0.7, 0.4, 1.6, 0.5             # changes sigma_x / sigma_y a lot
+        mid = [ca.CustomTransferMap(R, length=t(0.7), **kw)]
+    elif breaker == "vector_quad":
+        mid = [ca.Quadrupole(t(0.3), k1=torch.tensor([9.0], **kw), **kw), ca.Drift(t(0.8), **kw)]
+    elif breaker == "parameter_quad":      # a trainable strength (tracked under no_grad below: the beam carries no graph)
+        mid = [ca.Quadrupole(t(0.3), k1=torch.nn.Parameter(t(9.0)), **kw), ca.Drift(t(0.8), **kw)]
+    else:
+        mid = [ca.Drift(t(0.004), **kw) for _ in range(200)] + [quad(9.0), ca.Drift(t(0.6), **kw)]
+    els = [sc(), ca.Drift(t(0.1), **kw), sc()] + mid + [sc(), quad(-4.0), ca.Drift(t(0.2), **kw), sc(), ca.Drift(t(0.1), **kw)]
+    seg, beam = ca.Segment(els), _beam(ca, dt, 120_000, gaussian=True)
+    if breaker == "vector_quad":
+        # a vectorised run makes the beam behind it vectorised: no chain there (and none needed)
+        out, calls = _spy_links(lambda: seg.track(beam))
+        assert calls == [(True, False), (False, True)]
+    else:
+        with torch.no_grad():
+            out, calls = _spy_links(lambda: seg.track(beam))
+        assert calls == [(True, False), (False, True), (True, False), (False, True)], calls
+    with torch.no_grad():
+        ref = _unchained(seg, beam)
+    assert out.particles.shape == ref.particles.shape
+    effect = (ref.particles - _one_by_one(_no_charge(ca, seg), beam).particles).abs().max(dim=-2).values.reshape(-1, 7).max(dim=0).values
+    err = (out.particles - ref.particles).abs().max(dim=-2).values.reshape(-1, 7).max(dim=0).values
+    ulp = 16 * torch.finfo(dt).eps * ref.particles.abs().max(dim=-2).values.reshape(-1, 7).max(dim=0).values
+    assert torch.all(err <= 2e-4 * effect + ulp), (err / (2e-4 * effect + ulp))
+
+
+def test_gradients_flow_through_a_lattice_of_kicks(ca):
+    """[kick, Quad(k1 requires grad), kick, Drift, kick]: the run with the trainable strength is not fused, the particles behind
+    it carry a graph, and every later kick must take its differentiable path — gradient equal to kick-by-kick tracking (measured:
+    identical; the bound leaves room for the summation order of the deposits)."""
+    dt = torch.float64
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    grid = (16, 16, 16)
+
+    def lattice(k1):
+        return ca.Segment([ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Quadrupole(t(0.1), k1=k1, **kw), ca.Drift(t(0.3), **kw),
+                           ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Drift(t(0.2), **kw),
+                           ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Drift(t(0.1), **kw)])
+
+    beam = _beam(ca, dt, 70_000, gaussian=True)
+    k1 = torch.tensor(3.0, requires_grad=True, **kw)
+    out, calls = _spy_links(lambda: lattice(k1).track(beam))
+    assert calls == []                                  # no link: the first kick's run is not fusable
+    assert out.particles.requires_grad
+    out.sigma_x.backward()
+    g_chain = float(k1.grad)
+    k1b = torch.tensor(3.0, requires_grad=True, **kw)
+    b = beam
+    for e in lattice(k1b).elements:
+        b = e.track(b)
+    b.sigma_x.backward()
+    assert g_chain != 0.0 and abs(g_chain - float(k1b.grad)) <= 1e-9 * abs(float(k1b.grad)), (g_chain, float(k1b.grad))
+    # trainable strength BEHIND a fusable link: [kick, Drift, kick, Quad(k1), kick] — the first two kicks chain, the chain ends
+    # in front of the trainable run and the third kick differentiates
+    k1c = torch.tensor(3.0, requires_grad=True, **kw)
+    seg = ca.Segment([ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Drift(t(0.3), **kw),
+                      ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Quadrupole(t(0.1), k1=k1c, **kw), ca.Drift(t(0.2), **kw),
+                      ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Drift(t(0.1), **kw)])
+    out, calls = _spy_links(lambda: seg.track(beam))
+    assert calls == [(True, False), (False, True)]
+    out.sigma_x.backward()
+    k1d = torch.tensor(3.0, requires_grad=True, **kw)
+    seg2 = ca.Segment([ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Drift(t(0.3), **kw),
+                       ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Quadrupole(t(0.1), k1=k1d, **kw), ca.Drift(t(0.2), **kw),
+                       ca.SpaceChargeKick(t(0.2), grid_shape=grid, **kw), ca.Drift(t(0.1), **kw)])
+    b = beam
+    for e in seg2.elements:
+        b = e.track(b)
+    b.sigma_x.backward()
+    assert float(k1c.grad) != 0.0 and abs(float(k1c.grad) - float(k1d.grad)) <= 1e-6 * abs(float(k1d.grad)), (float(k1c.grad), float(k1d.grad))

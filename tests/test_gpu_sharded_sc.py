@@ -30,14 +30,16 @@ def _make(ca, x, q, dtype):
     return seg, beam
 
 
-def _worker(rank, world, port, x, q, queue):
+def _worker(rank, world, port, x, q, queue, cuts=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import cheetah_amd as ca
-    from cheetah_amd import sharding
+    from cheetah_amd import _ops, sharding
 
-    lo, hi = sharding.shard_range(x.shape[0], rank, world)
+    lo, hi = sharding.shard_range(x.shape[0], rank, world) if cuts is None else (cuts[rank], cuts[rank + 1])
     seg, beam = _make(ca, x[lo:hi], q[lo:hi], x.dtype)
+    links, orig = [], _ops.sc_kick_sorted
+    _ops.sc_kick_sorted = lambda *a, **k: (links.append(k.get("group") is not None), orig(*a, **k))[1]
     kw = {"dtype": x.dtype, "device": "cuda"}
     screen = ca.Screen(resolution=(64, 48), pixel_size=torch.tensor([4e-5, 5e-5], **kw), is_active=True, **kw)
     with sharding.particle_sharded():
@@ -45,17 +47,22 @@ def _worker(rank, world, port, x, q, queue):
         sigma = sharding.global_moments(out)[8].sqrt()
         screen.track(out)
         image_sum = float(screen.reading.sum())       # summed over the ranks inside the context
-    queue.put((rank, out.particles.cpu().numpy(), float(sigma), image_sum))   # by value: the process may be gone when it is read
+    queue.put((rank, out.particles.cpu().numpy(), float(sigma), image_sum, links))   # by value: the process may be gone when it is read
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_particle_sharded_space_charge_equals_single_process(dtype):
+# (dtype, N, cuts): float64 / 60 000 — both ranks below the tile sort's minimum: the staged kick with the direct deposit;
+# float32 / 150 001 — both ranks on the tile-ordered CHAIN (chx_sc_kick_sorted_begin / _finish around the two exchanges), an odd
+# split; float64 / 180 000 cut at 120 000 — rank 0 on the chain, rank 1 (60 000 rows) kick by kick, and float32 / 140 000 cut at 50 000 the other way
+# round: the exchanges carry the same contents on both paths, so the ranks need not agree on the path
+@pytest.mark.parametrize("dtype,N,cuts,chained", [(torch.float64, 60_000, None, (False, False)), (torch.float32, 150_001, None, (True, True)),
+                                                  (torch.float64, 180_000, (0, 120_000, 180_000), (True, False)),
+                                                  (torch.float32, 140_000, (0, 50_000, 140_000), (False, True))])
+def test_particle_sharded_space_charge_equals_single_process(dtype, N, cuts, chained):
     import cheetah_amd as ca
 
     torch.manual_seed(12)
-    N = 60_000 if dtype == torch.float64 else 150_001       # direct and sorted deposit; an odd split
     x = torch.randn(N, 7, dtype=dtype) * torch.tensor([3e-4, 2e-5, 2e-4, 3e-5, 2e-5, 1e-3, 0.0], dtype=dtype)
     x[:, 6] = 1.0
     q = torch.full((N,), 2e-9 / N, dtype=dtype)
@@ -66,16 +73,18 @@ def test_particle_sharded_space_charge_equals_single_process(dtype):
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, x, q, queue)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, x, q, queue, cuts)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict()
     for _ in range(2):
-        rank, parts, sigma, image_sum = queue.get(timeout=300)
-        results[rank] = (parts, sigma, image_sum)
+        rank, parts, sigma, image_sum, links = queue.get(timeout=300)
+        results[rank] = (parts, sigma, image_sum, links)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for r in range(2):      # two kicks: two links of a chain with the group handed down, or none (staged kick by kick)
+        assert results[r][3] == ([True, True] if chained[r] else []), (r, results[r][3])
     joined = torch.cat([torch.from_numpy(results[0][0]), torch.from_numpy(results[1][0])], dim=0)
     kick = (ref - x).abs().max(dim=0).values                   # size of the effect per coordinate
     tol = 1e-9 if dtype == torch.float64 else 2e-4             # fp32: the charge sum order differs between the runs (measured 3e-5)
