@@ -53,6 +53,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 APPLY_KERNEL = "apply_tile_kernel<float, 2, 0>"
 PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")
 COPY_CEILING_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of the 8 TB/s spec)
+#: sigma_x behind the 100 elements of the beam of rank 0 (torch.manual_seed(1234), from_parameters defaults, 1e6 particles, fp32):
+#: the same digits in every driver run since round 1 (BENCH_r01..r03). bench.py refuses to print a line when its step no longer
+#: produces it.
+EXPECTED_SIGMA_X_RANK0 = 1.9558527096402663e-4
 
 
 def build_fodo(ca, torch, device, dtype):
@@ -89,92 +93,166 @@ def timed(torch, dist, fn, steps, warmup, world):
 
 
 # ---------------------------------------------------------------------------------------------------------------- CPU side
-def physical_cores() -> int:
+def usable_cores() -> int:
+    """Cores this process may actually keep busy: physical cores, capped by the affinity mask and by the container's CPU quota
+    (cgroup cpu.max / cfs_quota). The GPU boxes of this pool show 256 logical CPUs behind a 16-CPU quota: a thread per core there
+    is throttled to a crawl (measured with benchmarks/cpu_probe.py: the C port drops from 1.9e9 steps/s at 16 threads to 6.5e8 at
+    128 and 8e6 at 256)."""
     try:
         import psutil
 
-        n = psutil.cpu_count(logical=False)
-        if n:
-            return int(n)
+        n = psutil.cpu_count(logical=False) or 0
+    except Exception:
+        n = 0
+    if not n:
+        n = max(1, (os.cpu_count() or 2) // 2)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    return max(1, (os.cpu_count() or 2) // 2)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
 
 
-def cpu_baseline_worker(n_elements: int) -> dict:
-    """Runs in a subprocess whose OMP_* environment pins one thread per physical core."""
+def cpu_baseline_worker(spec: str) -> dict:
+    """One leg of the CPU baseline, in a process of its own whose OMP_NUM_THREADS is the leg's thread count.
+    spec = "<port|torch>:<elementwise|merged>:<n_elements>:<seconds>"."""
     import numpy as np
-    import torch
 
+    which, mode, n_elements, seconds = spec.split(":")
+    n_elements, seconds = int(n_elements), float(seconds)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     from oracle import chx_oracle as oracle
 
-    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
     E = 1e8
     f = np.float32
-    cell = [oracle.build_rmatrix("quadrupole", [f(0.2), f(4.2), 0, 0, 0], E).astype(np.float32),
-            oracle.build_rmatrix("drift", [f(0.8)], E).astype(np.float32),
-            oracle.build_rmatrix("quadrupole", [f(0.2), f(-4.2), 0, 0, 0], E).astype(np.float32),
-            oracle.build_rmatrix("drift", [f(0.8)], E).astype(np.float32)]
-    maps = np.concatenate((cell * N_CELLS)[:n_elements])
+    cell = [oracle.build_rmatrix("quadrupole", [f(0.2), f(4.2), 0, 0, 0], E), oracle.build_rmatrix("drift", [f(0.8)], E),
+            oracle.build_rmatrix("quadrupole", [f(0.2), f(-4.2), 0, 0, 0], E), oracle.build_rmatrix("drift", [f(0.8)], E)]
+    maps64 = (cell * N_CELLS)[:n_elements]
+    maps = np.concatenate([m.astype(np.float32) for m in maps64])
     rng = np.random.default_rng(1234)
     x = (rng.standard_normal((N_PARTICLES, 7)) * [175e-6, 4e-6, 175e-6, 4e-6, 8e-6, 2e-3, 0]).astype(np.float32)
     x[..., 6] = 1.0
-    out, tmp, x_par = np.empty_like(x), np.empty_like(x), np.empty_like(x)
-    # first touch of every buffer happens inside the OpenMP loops (NUMA-local pages on a multi-socket host)
-    oracle.track_elementwise(x, np.eye(7, dtype=np.float32)[None], x_par, tmp)
-    xs = x_par
-    oracle.track_elementwise(xs, maps, out, tmp)  # warm-up: page faults, OpenMP pool
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.track_elementwise(xs, maps, out, tmp)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= 10.0 or reps >= 400:
-            break
-    res = {"value": N_PARTICLES * len(maps) * reps / el, "unit": "particle-element-steps/s", "cores": cores, "kind": "port",
-           "sample": f"{reps} x (1e6 particles x {len(maps)} elements, element-by-element, fp32 fma chain, C oracle with "
-                     f"OpenMP, {cores} threads pinned to physical cores), {el:.1f} s"}
-    # like-for-like stand-in for the reference's CPU PyTorch path (element.py:182 `particles @ tm.mT`, one matmul per element).
-    # A (1e6, 7) @ (7, 7) product does not scale to every core of a large host, so the thread count is swept and the best kept.
-    xt = torch.from_numpy(x)
-    mt = [torch.from_numpy(np.ascontiguousarray(m)) for m in maps]
-    sweep = {}
-    for threads in sorted({8, 32, cores}):
-        if threads > cores:
-            continue
+    reps = 0
+    if which == "port":
+        out, tmp, xs = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+        # first touch of every buffer happens inside the OpenMP loops (NUMA-local pages on a multi-socket host)
+        oracle.track_elementwise(x, np.eye(7, dtype=np.float32)[None], xs, tmp)
+        if mode == "elementwise":
+            step = lambda: oracle.track_elementwise(xs, maps, out, tmp)  # noqa: E731
+        else:   # the reference's own semantics (segment.py:534-547): compose the E maps, ONE pass over the particles
+            step = lambda: oracle.track_elementwise(xs, oracle.compose(maps64).astype(np.float32), out, tmp)  # noqa: E731
+        step()
+        t0 = time.perf_counter()
+        while True:
+            step()
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                break
+    else:
+        import torch
+
         torch.set_num_threads(threads)
+        xt = torch.from_numpy(x)
+        mt = [torch.from_numpy(np.ascontiguousarray(m)) for m in maps]
         with torch.no_grad():
-            y = xt
-            for m in mt[:4]:
-                y = y @ m.mT
-            reps, t0 = 0, time.perf_counter()
-            while True:
+            def elementwise():          # element.py:182 `particles @ tm.mT`, one matmul (and one fresh output) per element
                 y = xt
                 for m in mt:
                     y = y @ m.mT
+                return y
+
+            def merged():               # segment.py:534-547: the 7x7 product first, one matmul over the particles
+                tm = mt[0]
+                for m in mt[1:]:
+                    tm = m @ tm
+                return xt @ tm.mT
+
+            step = elementwise if mode == "elementwise" else merged
+            step()
+            step()
+            t0 = time.perf_counter()
+            while True:
+                step()
                 reps += 1
                 el = time.perf_counter() - t0
-                if el >= 3.0 or reps >= 100:
+                if el >= seconds:
                     break
-        sweep[threads] = (N_PARTICLES * len(mt) * reps / el, reps, el)
-    best = max(sweep, key=lambda k: sweep[k][0])
-    res["torch_cpu_matmul"] = {"value": sweep[best][0], "unit": "particle-element-steps/s", "threads": best,
-                               "torch": torch.__version__,
-                               "by_threads": {str(k): v[0] for k, v in sweep.items()},
-                               "sample": f"{sweep[best][1]} x (1e6 x 7 fp32) @ (7 x 7).mT over {len(mt)} elements, "
-                                         f"{sweep[best][2]:.1f} s, best of thread counts {sorted(sweep)}"}
-    return res
+    return {"value": N_PARTICLES * n_elements * reps / el, "threads": threads, "reps": reps, "seconds": el}
 
 
 def cpu_baseline(n_elements: int) -> dict:
-    cores = physical_cores()
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores", MKL_NUM_THREADS=str(cores),
-               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    """The CPU figures of the line (rank 0, N = 1), each leg in its own subprocess: the C oracle (OpenMP) and a plain PyTorch-CPU
+    restatement of the reference's tensor code, both element by element (the headline's semantics) and merged (the reference's
+    `Segment.track`: BASELINE.md section 2 reports both modes). Thread counts are swept up to the cores this process may use
+    (`usable_cores`: the container's CPU quota, not the host's core count); the best of each leg is reported. ~25 s in total."""
+    cores = usable_cores()
+
+    def leg(which, mode, threads, seconds, bind):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="",
+                   CUDA_VISIBLE_DEVICES="")
+        env.pop("OMP_PROC_BIND", None)
+        env.pop("OMP_PLACES", None)
+        if bind:
+            env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", f"{which}:{mode}:{n_elements}:{seconds}"],
+                             env=env, capture_output=True, text=True, timeout=180)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if not line:
+            raise RuntimeError(out.stderr[-300:])
+        return json.loads(line[-1])
+
+    def best(which, mode, counts, seconds, bind=False):
+        runs = {}
+        for threads in counts:
+            try:
+                runs[threads] = leg(which, mode, threads, seconds, bind)
+            except Exception as exc:  # noqa: BLE001
+                runs[threads] = {"value": 0.0, "error": f"{type(exc).__name__}: {exc}"[:200]}
+        top = max(runs, key=lambda k: runs[k]["value"])
+        return top, runs
+
+    counts = sorted({max(1, cores // 2), cores, 2 * cores})
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_elements)], env=env,
-                             capture_output=True, text=True, timeout=240)
-        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
-        return json.loads(line)
+        t_port, port = best("port", "elementwise", counts, 4.0)
+        res = {"value": port[t_port]["value"], "unit": "particle-element-steps/s", "cores": t_port, "kind": "port",
+               "usable_cores": cores, "host_logical_cpus": os.cpu_count(),
+               "by_threads": {str(k): v["value"] for k, v in port.items()},
+               "sample": f"{port[t_port].get('reps')} x (1e6 particles x {n_elements} elements, element by element, fp32 fma chain, C "
+                         f"oracle with OpenMP, {t_port} threads — best of {counts}; the container's CPU quota is {cores} of the "
+                         f"host's {os.cpu_count()} logical CPUs), {port[t_port].get('seconds', 0):.1f} s"}
+        _, merged = best("port", "merged", [t_port], 2.0)
+        res["merged"] = {"value": merged[t_port]["value"], "unit": "particle-element-steps/s", "threads": t_port,
+                         "sample": "the reference's Segment.track semantics: the 100 maps composed, ONE pass over the 1e6 particles "
+                                   "(N*E/t is not a bandwidth measure in this mode)"}
+        tcounts = sorted({max(1, cores // 2), cores})
+        t_t, tor = best("torch", "elementwise", tcounts, 3.0)
+        _, tmerged = best("torch", "merged", [t_t], 2.0)
+        import torch
+
+        res["torch_cpu_matmul"] = {"value": tor[t_t]["value"], "unit": "particle-element-steps/s", "threads": t_t,
+                                   "torch": torch.__version__, "by_threads": {str(k): v["value"] for k, v in tor.items()},
+                                   "merged": tmerged[t_t]["value"],
+                                   "sample": f"(1e6 x 7 fp32) @ (7 x 7).mT per element over {n_elements} elements (element.py:182) and "
+                                             f"merged (segment.py:534-547), best of thread counts {tcounts}; torch's MKL sgemm on "
+                                             "this host — BASELINE.md section 2 has the reference itself on an 8-core Intel "
+                                             "container: 1.3e9 element by element, 3.1e10 merged"}
+        return res
     except Exception as exc:  # the GPU numbers stand on their own; say why the baseline is missing
         return {"value": None, "unit": "particle-element-steps/s", "cores": cores, "kind": "port",
                 "sample": f"cpu baseline failed: {type(exc).__name__}: {exc}"}
@@ -442,8 +520,41 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
 
     def leg_strong():
         d = timed(torch, dist, strong, steps, warmup, world)
-        return {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_step": d / steps * 1e3,
-                "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
+        res = {"scaling": "strong", "particles_total": N_PARTICLES, "particles_per_rank": hi - lo, "ms_per_step": d / steps * 1e3,
+               "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
+        # The same step with its 100 apply launches replayed from ONE device graph (hipGraph of chx_track_elementwise's launches;
+        # the moments exchange stays outside the graph). MEASURED NEGATIVE on ROCm 7.2: a replayed kernel node costs ~9 us of
+        # scheduling against ~2.5 us for a launch issued from the C loop, so the eager leg is the faster one at every size
+        # (1e6 particles: 1.86 vs 1.03 ms; see also `one_eighth`). Kept in the line as evidence, not used.
+        def graph_pair(beam_):
+            from cheetah_amd import graph as chx_graph
+
+            with torch.no_grad():
+                replay = chx_graph.capture(lambda: seg.track_elementwise(beam_, fused=False))
+
+            def stepg():
+                sharding.global_moments(replay())
+
+            def stepe():
+                sharding.global_moments(seg.track_elementwise(beam_, fused=False))
+
+            stepg()
+            same = bool(torch.equal(replay.outputs.particles, seg.track_elementwise(beam_, fused=False).particles))
+            dg = timed(torch, dist, stepg, steps, warmup, world)
+            de = timed(torch, dist, stepe, steps, warmup, world)
+            return {"eager_ms_per_step": de / steps * 1e3, "graph_replay_ms_per_step": dg / steps * 1e3, "graph_equals_eager": same}
+
+        try:
+            res["graph_replay"] = graph_pair(beam)
+            if world == 1:
+                # what ONE rank of an 8-GPU strong run holds: 1.25e5 particles. Launch-bound: 100 launches x ~2.5 us
+                torch.manual_seed(4321)
+                small = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES // 8, dtype=dtype, device=device)
+                res["one_eighth"] = dict(graph_pair(small), particles=N_PARTICLES // 8,
+                                         note="the per-rank share of an 8-rank strong run, timed on this one GPU")
+        except Exception as exc:  # noqa: BLE001
+            res["graph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        return res
 
     guarded("c2_strong", leg_strong)
 
@@ -463,8 +574,7 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
 
     guarded("c3_batch_shard", leg_c3)
 
-    def leg_c4():
-        # C4: particles split over the ranks; per kick one all-gather of 29 doubles and one all-reduce of the 8.4 MB grid
+    def c4_lattice(n_local, total, seed):
         g = 128
         kw = {"dtype": dtype, "device": device}
         t = lambda v: torch.tensor(v, **kw)  # noqa: E731
@@ -472,22 +582,45 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
         for i in range(10):
             els += [ca.Drift(t(0.1)), ca.SpaceChargeKick(t(0.2), grid_shape=(g, g, g), **kw), ca.Drift(t(0.1)),
                     ca.Quadrupole(t(0.1), k1=t(4.2 if i % 2 == 0 else -4.2), **kw), ca.Drift(t(0.1))]
-        seg4 = ca.Segment(els)
-        torch.manual_seed(7 + rank)
-        beam4 = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=hi - lo, total_charge=t(1e-9 * (hi - lo) / N_PARTICLES),
+        torch.manual_seed(seed)
+        beam4 = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=n_local, total_charge=t(1e-9 * n_local / total),
                                                      energy=t(2.5e8), radius_x=t(1e-3), radius_y=t(1e-3), radius_tau=t(1e-3),
                                                      sigma_px=t(1e-6), sigma_py=t(1e-6), sigma_p=t(1e-6), **kw)
+        return ca.Segment(els), beam4
+
+    C4_COLLECTIVES = ("per kick: all-gather of 29 f64 per rank (beam moments; merged inside the geometry kernel) + all-reduce of the "
+                      "8.4 MB charge grid (RCCL), between the two halves of the tile-ordered chain kick "
+                      "(chx_sc_kick_sorted_begin / _finish)")
+
+    def leg_c4():
+        # C4 strong: 1e6 particles in TOTAL split over the ranks; every rank keeps its rows in deposit-tile order across the ten
+        # kicks exactly as the un-sharded track does
+        seg4, beam4 = c4_lattice(hi - lo, N_PARTICLES, 7 + rank)
 
         def c4():
             with sharding.particle_sharded():
                 seg4.track(beam4)
 
-        d = timed(torch, dist, c4, 3, 1, world)
-        return {"scaling": "strong", "particles_total": N_PARTICLES, "ms_per_track": d / 3 * 1e3,
-                "particle_element_steps_per_s": N_PARTICLES * 50 * 3 / d,
-                "collectives": "per kick: all-gather 29 f64 per rank + all-reduce 8.4 MB grid (RCCL)"}
+        d = timed(torch, dist, c4, 5, 2, world)
+        return {"scaling": "strong", "particles_total": N_PARTICLES, "particles_per_rank": hi - lo, "ms_per_track": d / 5 * 1e3,
+                "particle_element_steps_per_s": N_PARTICLES * 50 * 5 / d, "collectives": C4_COLLECTIVES}
+
+    def leg_c4_weak():
+        # C4 weak: 1e6 particles PER RANK (the particle half of a kick — deposit + gather, ~95 us — stays what it is on one GPU,
+        # the replicated Poisson solve and the two exchanges are the overhead that grows with the ranks)
+        seg4, beam4 = c4_lattice(N_PARTICLES, N_PARTICLES * world, 70 + rank)
+
+        def c4():
+            with sharding.particle_sharded():
+                seg4.track(beam4)
+
+        d = timed(torch, dist, c4, 5, 2, world)
+        return {"scaling": "weak", "particles_per_rank": N_PARTICLES, "particles_total": N_PARTICLES * world,
+                "ms_per_track": d / 5 * 1e3, "particle_element_steps_per_s": world * N_PARTICLES * 50 * 5 / d,
+                "collectives": C4_COLLECTIVES}
 
     guarded("c4_particle_shard", leg_c4)
+    guarded("c4_particle_shard_weak", leg_c4_weak)
     return legs
 
 
@@ -502,7 +635,7 @@ def main():
                     help="N = 1: open the one-rank RCCL group BEFORE the headline, so that its step runs the moments "
                          "all-gather + chx_merge_moments too (default: only the scaling legs, after the headline)")
     ap.add_argument("--no-scaling-legs", action="store_true", help="N = 1: skip the one-rank RCCL run of the scaling legs")
-    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker", type=str, default="", help=argparse.SUPPRESS)
     # smoke test of the multi-rank code path on a ONE-GPU box: every rank on cuda:0, collectives over gloo (RCCL refuses two
     # ranks on one device). Not a measurement.
     ap.add_argument("--one-device-gloo", action="store_true", help=argparse.SUPPRESS)
@@ -633,33 +766,45 @@ def main():
     # mean duration is slightly LONGER than the per-launch wall time. The workload-size figure uses the larger of the two (the
     # conservative reading, identical to what the tracked profile gives); both durations are reported.
     ms_used = max(ms_launch, ms_rocprof) if ms_rocprof else ms_launch
-    at_size = {"bound": "infinity-cache / hbm", "kernel": APPLY_KERNEL, "particles": N_PARTICLES,
-               "algorithmic_bytes_per_launch": algo_bytes, "achieved": algo_bytes / (ms_used * 1e-3) / 1e9,
-               "frac_of_hbm_peak": algo_bytes / (ms_used * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_used,
-               "launches_per_step": E, "avg_launch_ms_events": ms_launch, "avg_launch_ms_rocprof": ms_rocprof,
-               "rocprof_summary": "profiles/r03_kernel_stats.csv", "traffic": traffic,
-               "note": "28 MB in + 28 MB out per launch fit the 256 MiB Infinity Cache: not an HBM rate"}
-    # the same kernel streaming from HBM proper: 1.6e7 particles, 448 MB in + 448 MB out per launch — the roofline entry
+    # Top level = the kernel the METRIC times, at the workload's own launch shape: apply_tile_kernel<float,2,0> on 1e6 particles.
+    # Its 28 MB in + 28 MB out per launch live in the 256 MiB Infinity Cache between launches, so the bound is labelled
+    # "infinity-cache" and `frac` (against the 8 TB/s HBM spec, as the contract asks) is not an HBM rate; `hbm_streaming` is the
+    # same arithmetic streaming from HBM proper (1.6e7 particles, 448 MB in + 448 MB out per launch: apply_wave_kernel).
+    roofline = {"bound": "infinity-cache", "kernel": APPLY_KERNEL, "particles": N_PARTICLES,
+                "achieved": algo_bytes / (ms_used * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": algo_bytes / (ms_used * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": ms_used, "launches_per_step": E,
+                "avg_launch_ms_events": ms_launch, "avg_launch_ms_rocprof": ms_rocprof,
+                "rocprof_summary": os.path.relpath(PROFILE_CSV, ROOT),
+                "note": "56 B x 1e6 particles per launch / the LARGER of the live HIP-event average (100 back-to-back launches / "
+                        "100) and the rocprofv3 kernel-trace average of the tracked summary; working set 56 MB = Infinity-Cache "
+                        "resident, `traffic` (PMC, HBM side) is therefore below the algorithmic bytes"}
     big_n = 16_000_000
-    roofline = {"bound": "hbm", "kernel": "apply_wave_kernel<float> (the linear apply at 1.6e7 particles)", "achieved": None,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "workload_size": at_size}
+    stream = {"bound": "hbm", "kernel": "apply_wave_kernel<float, 1, 64>", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": None, "traffic": None}
     try:
         big = ca.ParticleBeam.from_parameters(num_particles=big_n, dtype=dtype, device=device)
         seg10 = ca.Segment(list(seg.elements)[:10])
         ms_big = event_timed_elementwise(torch, seg10, big, 10, 2) / 10
         gbs = 56.0 * big_n / (ms_big * 1e-3) / 1e9
-        roofline.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "frac_vs_copy_ceiling": gbs / COPY_CEILING_GBS,
-                         "copy_ceiling": COPY_CEILING_GBS, "particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n,
-                         "avg_launch_ms": ms_big,
-                         "traffic": traffic_big,
-                         "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch at this size (separate rocprofv3 --pmc passes, "
-                                         "gfx950 corrections of MI355X_MICROARCH.md; profiles/r03_pmc_apply.md): 1.0002 x the "
-                                         "algorithmic bytes"})
+        stream.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "frac_vs_copy_ceiling": gbs / COPY_CEILING_GBS,
+                       "copy_ceiling": COPY_CEILING_GBS, "particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n,
+                       "avg_launch_ms": ms_big, "traffic": traffic_big,
+                       "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch at this size (separate rocprofv3 --pmc passes, "
+                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r03_pmc_apply.md): 1.0002 x the "
+                                       "algorithmic bytes"})
         del big, seg10
         torch.cuda.empty_cache()
     except Exception as exc:
-        roofline["error"] = f"{type(exc).__name__}: {exc}"
-        roofline.update({"achieved": at_size["achieved"], "frac": at_size["frac_of_hbm_peak"]})
+        stream["error"] = f"{type(exc).__name__}: {exc}"
+    roofline["hbm_streaming"] = stream
+
+    # the tracked beam itself is checked, not only timed: sigma_x of the outgoing beam of rank 0's seed against the committed value
+    # (tests/test_gpu_bench_parity.py holds the bit-exact comparison of this very step with the oracle)
+    sigma_ok = abs(sigma_x / EXPECTED_SIGMA_X_RANK0 - 1.0) < 1e-9 if rank == 0 else None
+    if rank == 0 and not sigma_ok:
+        raise SystemExit(f"bench.py: sigma_x of the tracked beam is {sigma_x!r}, expected {EXPECTED_SIGMA_X_RANK0!r}: the step "
+                         "does not compute what it is timed for")
 
     result = {
         "metric": "particle-element-steps/sec at 1e6 particles, 100-elem linac",
@@ -669,7 +814,7 @@ def main():
         "config": {"workload": "C2: 100-element Drift+Quadrupole FODO, 1e6 particles per GPU, fp32, "
                                "element-by-element tracking (no map merging) + global beam moments",
                    "elements": E, "particles_per_gpu": N_PARTICLES, "parallelism": f"particle-shard x{world}",
-                   "sigma_x_out": sigma_x},
+                   "sigma_x_out": sigma_x, "sigma_x_expected": EXPECTED_SIGMA_X_RANK0, "sigma_x_checked": sigma_ok},
         "timed_region_s": dt, "modes": modes, "roofline": roofline,
     }
     state.clear()
