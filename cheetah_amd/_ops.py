@@ -8,6 +8,7 @@ arithmetic on particle-sized or map-sized data happens inside libchx.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 

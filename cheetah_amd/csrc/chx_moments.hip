@@ -35,7 +35,7 @@ inline int64_t onepass_total_wgs() {
     static const int64_t v = [] {
         const char* e = getenv("CHX_TUNE_MOMENTS_WGS");
         const long n = e ? atol(e) : 0;
-        return (int64_t)(n >= 1 && n <= 1024 ? n : 1024);
+        return (int64_t)(n >= 1 && n <= 1024 ? n : 512);
     }();
     return v;
 }
@@ -617,17 +617,101 @@ struct OnePassFn {
     }
 };
 
+// The provisional centre of the one-pass sums: the weighted mean of the row's first 16 particles, not particle 0 alone — one
+// far outlier in slot 0 (|x0 - mu| = r sigma costs r^2 of the fp64 headroom of sum w d d^T) no longer matters, and a zero-weight
+// one does not enter the centre at all. Every wave forms the same c from the same 16 rows (448 bytes: cache hits) under its own
+// row requests: 16 lanes load, four DPP steps sum the row of lanes, one reciprocal, v_readfirstlane hands the result to the wave
+// (the 64-row / ds_bpermute / six-division form of this cost 2.5 us of the 9 us sweep). No weight in those rows (or a non-finite
+// mean, e.g. 0 * inf of a dead outlier): particle 0 — any finite centre is exact algebra, only the headroom differs.
+template <typename T>
+__device__ __forceinline__ void first_wave_centre(const T* __restrict__ xb, const T* __restrict__ wb, int64_t N, double (&c)[6]) {
+    const int lane = threadIdx.x & 63;
+    const bool ok = lane < 16 && lane < N;
+    double wv = 0.0, xv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xv[j] = ok ? (double)xb[(int64_t)lane * 7 + j] : 0.0;
+    if (ok) wv = wb ? (double)wb[lane] : 1.0;
+    const double W = chx_row16_sum(wv);
+    const double inv = 1.0 / W;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double m = chx_row16_sum(wv * xv[j]) * inv;
+        const double pick = (W > 0.0 && isfinite(m)) ? m : xv[j];       // lane 0: row 0
+        c[j] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(pick)), __builtin_amdgcn_readfirstlane(__double2loint(pick)));
+    }
+}
+
+// The sweep: every lane streams its own rows straight from global memory (dword-strided row reads), kMomUnroll rows in flight per
+// lane and iteration; with 512 workgroups a lane of the 1e6-particle case holds all its 8 rows in ONE batch of requests, i.e. the
+// kernel is a single memory round trip long. (Measured and dropped, round 4: per-wave LDS staging with 14 KB of 16-byte loads in
+// flight per wave — 12.0 us against 9.3 for this form at 1e6 particles; the sweep is a latency chain, not a bandwidth problem,
+// and the LDS detour lengthens the chain.) partials[b][k][blk]; centre_out[b][6] (workgroup 0).
+constexpr int kMomUnroll = 8;
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                    int64_t Bx, int64_t Bw, int64_t N,
-                                                                   double* __restrict__ partials) {
+                                                                   double* __restrict__ partials, double* __restrict__ centre_out) {
+    constexpr int U = kMomUnroll;
+    __shared__ double red[16 * kTM];
+    const int64_t b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* __restrict__ xb = x + ((Bx == 1) ? 0 : b) * N * 7;
+    const T* __restrict__ wb = w ? w + ((Bw == 1) ? 0 : b) * N : nullptr;
+    const int64_t per = (((N + gridDim.x - 1) / gridDim.x + CHX_BLOCK - 1) / CHX_BLOCK) * CHX_BLOCK;
+    const int64_t n0 = (int64_t)blockIdx.x * per;
+    const int64_t n1 = (n0 + per < N) ? n0 + per : N;
     OnePassFn f;
-    const T* x0 = x + ((Bx == 1) ? 0 : (int64_t)blockIdx.y) * N * 7;
+    double acc[kTM];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) f.c[j] = (double)x0[j];
-    // partials[b][k][blk]
-    tiled_reduce<T, kTM, OnePassFn, true>(x, w, Bx, Bw, N, f,
-                                          partials + (int64_t)blockIdx.y * kTM * gridDim.x + blockIdx.x, gridDim.x);
+    for (int k = 0; k < kTM; ++k) acc[k] = 0.0;
+    bool have_c = false;
+    // (the loop bounds are the same for every lane of the workgroup: the DPP sums of first_wave_centre need whole rows of lanes)
+    for (int64_t nb = n0; nb < n1; nb += U * CHX_BLOCK) {
+        const int64_t n = nb + threadIdx.x;
+        T r[U][7];
+        double wv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t nn = n + u * CHX_BLOCK;
+            ok[u] = nn < n1;
+            const int64_t src = ok[u] ? nn : nb;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) r[u][j] = xb[src * 7 + j];
+            wv[u] = wb ? (double)wb[src] : 1.0;
+        }
+        if (!have_c) {              // (formed under the row requests above)
+            first_wave_centre<T>(xb, wb, N, f.c);
+            have_c = true;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            double xv[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xv[j] = (double)r[u][j];
+            f.accumulate(xv, wv[u], n + u * CHX_BLOCK, acc);
+        }
+    }
+    if (!have_c) first_wave_centre<T>(xb, wb, N, f.c);      // (a lane without rows still takes part in the reduction)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) centre_out[b * 6 + j] = f.c[j];
+    }
+    const int row = wave * 4 + (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) acc[k] = chx_row16_sum(acc[k]);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < kTM; ++k) red[row * kTM + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kTM) {
+        double t = 0.0;
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) t += red[r2 * kTM + threadIdx.x];
+        partials[(b * kTM + threadIdx.x) * (int64_t)gridDim.x + blockIdx.x] = t;
+    }
 }
 
 // One workgroup per batch row: lane t holds partial block t of all 29 sums (partials[b][k][blk]: coalesced loads, all in
@@ -635,7 +719,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __r
 // re-centres and normalises -> out[b][29]. Replaces reduce_partials x2 + finalize of the two-pass path.
 template <typename T>
 __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const double* __restrict__ partials, int nblk,
-                                                                      const T* __restrict__ x, int64_t Bx, int64_t N,
+                                                                      const double* __restrict__ centre,
                                                                       double* __restrict__ out, int entry /*-1: none*/,
                                                                       int entry_sqrt, T* __restrict__ entry_out) {
     __shared__ double red[64 * kTM];
@@ -649,37 +733,40 @@ __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const dou
 #pragma unroll
         for (int k = 0; k < kTM; ++k) a[k] += pb[(int64_t)k * nblk + i];
     }
+    const int rows = (nblk + 15) / 16 < 64 ? (nblk + 15) / 16 : 64;
+    if ((int)(threadIdx.x >> 4) < rows) {       // (whole waves beyond the partial blocks hold zeros: nothing to reduce)
 #pragma unroll
-    for (int k = 0; k < kTM; ++k) a[k] = chx_row16_sum(a[k]);
-    if ((threadIdx.x & 15) == 0) {
-        const int row = threadIdx.x >> 4;
+        for (int k = 0; k < kTM; ++k) a[k] = chx_row16_sum(a[k]);
+        if ((threadIdx.x & 15) == 0) {
+            const int row = threadIdx.x >> 4;
 #pragma unroll
-        for (int k = 0; k < kTM; ++k) red[row * kTM + k] = a[k];
+            for (int k = 0; k < kTM; ++k) red[row * kTM + k] = a[k];
+        }
     }
     __syncthreads();
     if (threadIdx.x < kTM) {
         double t = 0.0;
-        const int rows = (nblk + 15) / 16 < 64 ? (nblk + 15) / 16 : 64;
         for (int r = 0; r < rows; ++r) t += red[r * kTM + threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const T* x0 = x + ((Bx == 1) ? 0 : b) * N * 7;
+    // out[b][k], one lane per entry (the 27 divisions side by side instead of one after the other on lane 0)
+    if (threadIdx.x < kTM) {
+        const int k = threadIdx.x;
         const double W = tot[0], W2 = tot[1];
-        double* o = out + b * CHX_MOM_NOUT;
-        o[0] = W;
-        o[1] = W2;
-        double m[6];
-        for (int j = 0; j < 6; ++j) { m[j] = tot[2 + j] / W; o[2 + j] = (double)x0[j] + m[j]; }
-        const double cf = W - W2 / W;
-        int k = 8;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j, ++k) o[k] = (tot[k] - W * m[i] * m[j]) / cf;
-        if (entry >= 0) {                                   // chx_moments_entry: the one beam property the caller reads
-            const double v = o[entry];
-            entry_out[b] = (T)(entry_sqrt ? sqrt(v) : v);
+        double v;
+        if (k == 0) v = W;
+        else if (k == 1) v = W2;
+        else if (k < 8) v = centre[b * 6 + (k - 2)] + tot[k] / W;
+        else {
+            int i = 0, rem = k - 8;
+            while (rem >= 6 - i) { rem -= 6 - i; ++i; }
+            const int j = i + rem;
+            const double mi = tot[2 + i] / W, mj = tot[2 + j] / W;
+            v = (tot[k] - W * mi * mj) / (W - W2 / W);
         }
+        out[b * CHX_MOM_NOUT + k] = v;
+        if (k == entry) entry_out[b] = (T)(entry_sqrt ? sqrt(v) : v);   // chx_moments_entry: the one beam property the caller reads
     }
 }
 
@@ -989,19 +1076,20 @@ extern "C" int chx_moments_entry(const void* x, const void* w, int64_t B, int64_
     const int64_t nblk = onepass_nblk(B, N, tile_rows(dtype));
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)workspace;
+    double* centre = (double*)((char*)workspace + need);      // [B][6] in the tail behind the partial sums
     dim3 grid((unsigned)nblk, (unsigned)B);
     if (dtype == CHX_F32) {
         hipLaunchKernelGGL(moments_onepass_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x, (const float*)w,
-                           Bx, Bw, N, part);
+                           Bx, Bw, N, part, centre);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(moments_reduce_finalize_kernel<float>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
-                           (const float*)x, Bx, N, out, index, take_sqrt, (float*)entry_out);
+                           centre, out, index, take_sqrt, (float*)entry_out);
     } else {
         hipLaunchKernelGGL(moments_onepass_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
-                           (const double*)w, Bx, Bw, N, part);
+                           (const double*)w, Bx, Bw, N, part, centre);
         CHX_CHECK_LAUNCH();
         hipLaunchKernelGGL(moments_reduce_finalize_kernel<double>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
-                           (const double*)x, Bx, N, out, index, take_sqrt, (double*)entry_out);
+                           centre, out, index, take_sqrt, (double*)entry_out);
     }
     CHX_CHECK_LAUNCH();
     return CHX_OK;
