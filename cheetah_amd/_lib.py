@@ -212,6 +212,9 @@ SIGNATURES = {
                                  c_void_p]),
     "chx_sc_tile_deposit": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                     c_void_p]),
+    "chx_sc_tile_deposit_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_size_t, c_int, c_vpp, c_void_p]),
+    "chx_sc_convolve_halo_consume": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                             c_void_p]),
     "chx_sc_tile_gather_kick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_i64,
                                         c_i32_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "chx_kde_values": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_i64,

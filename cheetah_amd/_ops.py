@@ -1792,8 +1792,8 @@ def sc_kick_sorted(x, q, w, energy, length, grid_extent, mass_eV, N, bins, state
                                        ws_bytes, ptr(state), state.numel(), flags, ptr(mom), rows, ctypes.byref(rho_addr), stream_ptr(),
                                        side),
           "chx_sc_kick_sorted_begin")
-    off = rho_addr.value - ws.data_ptr()
-    rho = ws[off:off + int(bins[0]) * int(bins[1]) * int(bins[2]) * x.element_size()].view(x.dtype)
+    off = rho_addr.value - state.data_ptr()         # the chain's accumulation grid, inside the state buffer
+    rho = state[off:off + int(bins[0]) * int(bins[1]) * int(bins[2]) * x.element_size()].view(x.dtype)
     sharding.allreduce_grid(rho, group)
     check(lib.chx_sc_kick_sorted_finish(ptr(x), ptr(energy), mass_eV, N, b3, dt, ptr(out), ptr(ws), ws_bytes, ptr(state), state.numel(),
                                         flags, stream_ptr(), side, post_map_ptr), "chx_sc_kick_sorted_finish")

@@ -7,6 +7,8 @@
 // order (this file is compiled with -ffp-contract=off, IEEE division) so that cell indices are
 // bit-identical, and the 2^d weighted adds go out as hardware float atomics
 // (global_atomic_add_f32 / _f64).
+#include <cstdlib>
+
 #include "chx_common.h"
 
 namespace {
@@ -1264,26 +1266,29 @@ __global__ __launch_bounds__(kScSortThreads) void sc_tile_scatter_kernel(
     }
 }
 
-// deposit, pass 1: one workgroup per tile over its slot range. LDS block = the tile's cells plus the +1 layer (fp64, ds_add:
-// see cic_accumulate_kernel). Owned cells are STORED (every grid cell belongs to one tile: no zero fill), the +1 layer goes to
-// the tile's face buffer. A misfiled particle (and what a tile holds beyond kScTileCap) adds the corners that still fall into
-// this tile's block there and the others to the `cross` grid with global atomics right here — 4096 workgroups' worth of
-// parallelism for them; a list + a pass of its own behind this kernel cost 7 us at 1 % misfiled and 59 us at 17 % (C4's last
-// kick). On the way every particle's CURRENT home tile is recorded (home[], newcount[] — movers to the 26 neighbours are
-// counted in LDS first: their global atomics would pile up on a few lines). Slots are read eight at a time per thread: the pass
-// is bound by the load -> ds_add chain of its fullest tiles.
+// deposit: one workgroup per tile over its slot range. LDS block = the tile's cells plus the +1 layer (fp64, ds_add: see
+// cic_accumulate_kernel), flushed with one float atomic per NON-ZERO cell into the chain's accumulation grid `acc` (state; all
+// zero between two kicks: whoever consumes it — the first FFT pass of the convolution, or chx_sc_tile_deposit's collect pass —
+// writes the zeros back). A tile without slots (3/4 of the tiles of a 3-sigma grid) returns at once: nothing to zero-fill,
+// nothing to hand to neighbours. (Round 3 stored the owned cells, handed the +1 layer over through per-tile face buffers and
+// merged them in a second kernel: 46 + 15 us at 1e6 particles on 128^3; the zero stores of the empty tiles alone were 16 us.)
+// A misfiled particle (and what a tile holds beyond kScTileCap) adds the corners that still fall into this tile's block there
+// and the others to `acc` with global atomics right here — 4096 workgroups' worth of parallelism for them; a list + a pass of
+// its own behind this kernel cost 7 us at 1 % misfiled and 59 us at 17 % (C4's last kick). On the way every particle's CURRENT
+// home tile is recorded (home[], newcount[] — movers to the 26 neighbours are counted in LDS first: their global atomics would
+// pile up on a few lines). Slots are read eight at a time per thread: the pass is bound by the load -> ds_add chain of its
+// fullest tiles.
 // Measured and dropped: an LDS queue for the misfiled particles with a dense pass (one lane per corner) behind the loop, with
 // and without the global atomics moved behind the last barrier — no faster at 1 % misfiled, 1.6 x slower at 25 %.
 constexpr int kScDepUnroll = 8;
 
-template <typename T>
-__global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
+template <typename T, int TH>
+__global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr,
                                                              const int* __restrict__ tile_start2 /*[2][nt+1]*/,
                                                              const T* __restrict__ src, const T* __restrict__ cs2 /*[2][N]*/,
                                                              const T* __restrict__ extent, const T* __restrict__ scale,
-                                                             T* __restrict__ grid, T* __restrict__ faces, T* __restrict__ cross,
-                                                             uint16_t* __restrict__ home, int* __restrict__ newcount,
-                                                             int* __restrict__ tile_mis) {
+                                                             T* __restrict__ cross /* = acc */, uint16_t* __restrict__ home,
+                                                             int* __restrict__ newcount, int* __restrict__ mis_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
@@ -1307,29 +1312,18 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
     }
     const int beg = par ? b1 : b0, end = par ? e1 : e0;
     const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
-    if (end <= beg) {                                   // no slots (3/4 of the tiles of a 3-sigma grid): zeros, no LDS, no barrier
-        T* __restrict__ fz = faces + (int64_t)t * sc_face_cells(g);
-        for (int i = threadIdx.x; i < ncell; i += 256) {
-            const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
-            if (lx < TX && ly < TY && lz < TZ)
-                grid[(int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] + (int64_t)(org[2] + lz) * a.gstride[2]] = (T)0;
-            else
-                fz[sc_face_index(g, lx, ly, lz)] = (T)0;
-        }
-        if (threadIdx.x == 64) tile_mis[t] = 0;
-        return;
-    }
-    for (int i = threadIdx.x; i < ncell; i += 256) blk[i] = 0.0;
+    if (end <= beg) return;                             // no slots (3/4 of the tiles of a 3-sigma grid)
+    for (int i = threadIdx.x; i < ncell; i += TH) blk[i] = 0.0;
     if (threadIdx.x < 27) nbr[threadIdx.x] = 0;
     if (threadIdx.x == 0) { nstay = 0; nmis = 0; }
     __syncthreads();
     const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
     int stay = 0, mis = 0;
-    for (int r0 = beg; r0 < end; r0 += 256 * kScDepUnroll) {
+    for (int r0 = beg; r0 < end; r0 += TH * kScDepUnroll) {
         T raw[kScDepUnroll][3], cq[kScDepUnroll];
 #pragma unroll
         for (int u = 0; u < kScDepUnroll; ++u) {
-            const int r = r0 + u * 256 + (int)threadIdx.x;
+            const int r = r0 + u * TH + (int)threadIdx.x;
             const int rr = r < end ? r : beg;
 #pragma unroll
             for (int d = 0; d < 3; ++d) raw[u][d] = src[(int64_t)rr * 7 + a.cols[d]];
@@ -1337,7 +1331,7 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
         }
 #pragma unroll
         for (int u = 0; u < kScDepUnroll; ++u) {
-            const int r = r0 + u * 256 + (int)threadIdx.x;
+            const int r = r0 + u * TH + (int)threadIdx.x;
             if (r >= end) continue;
             int pi[3];
             T pf[3];
@@ -1397,148 +1391,86 @@ __global__ __launch_bounds__(256) void sc_tile_deposit_kernel(CicDev a, ScTileGe
         atomicAdd(&newcount[nb], nbr[k]);
     }
     if (threadIdx.x == 32 && nstay) atomicAdd(&newcount[t], nstay);
-    T* __restrict__ fb = faces + (int64_t)t * sc_face_cells(g);
-    for (int i = threadIdx.x; i < ncell; i += 256) {
-        const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
+    for (int i = threadIdx.x; i < ncell; i += TH) {
         const T v = (T)blk[i];
-        if (lx < TX && ly < TY && lz < TZ)
-            grid[(int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] + (int64_t)(org[2] + lz) * a.gstride[2]] = v;
-        else
-            fb[sc_face_index(g, lx, ly, lz)] = v;      // (zeros from an empty tile: pass 2 reads every face unconditionally)
+        if (v == (T)0) continue;                        // (cells of the +1 layer beyond the grid edge never receive anything)
+        const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
+        unsafeAtomicAdd(cross + (int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] +
+                            (int64_t)(org[2] + lz) * a.gstride[2], v);
     }
-    if (threadIdx.x == 64) tile_mis[t] = nmis;   // summed by pass 2
+    if (threadIdx.x == 64 && nmis) atomicAdd(&mis_slots[t & (kScMisSlots - 1)], nmis);   // the beam's misfiled particles (-> schedule kernel)
 }
 
-// deposit, pass 2: every cell takes what the misfiled particles left for it in `cross` (cleared on the way) and, on the low
-// boundary planes of its tile, what the seven lower neighbour tiles deposited into their +1 layers. One extra workgroup decides
-// whether the rows are re-ordered by this kick's gather pass (more than 1/16 of the beam misfiled, and a later kick to profit
-// from it) and, if so, turns the new tile populations into the slot cursors and the next tile starts. (A ticket at the end of
-// pass 1 instead needs a device-scope release per workgroup: 4096 L2 write-backs took that kernel from 30 to 500 us.)
+// deposit, the bookkeeping behind the pass (ONE workgroup): decides whether the rows are re-ordered by this kick's gather pass
+// (more than 1/16 of the beam misfiled, and a later kick to profit from it) and, if so, turns the new tile populations into the
+// slot cursors and the next tile starts; updates the header. The counters (newcount[], mis[]) are put back to zero by
+// the gather pass of the same kick (chx_sc_tile_gather_kick), which runs behind this kernel and in front of the next deposit. (A ticket at the end of
+// the deposit kernel instead needs a device-scope release per workgroup: 4096 L2 write-backs took that kernel from 30 to
+// 500 us.)
+__global__ __launch_bounds__(256) void sc_tile_schedule_kernel(ScTileGeom g, int64_t N, ScTileHeader* __restrict__ hdr,
+                                                              const int* __restrict__ newcount, const int* __restrict__ mis,
+                                                              int* __restrict__ cursor, int* __restrict__ tile_start2, int allow_reorder) {
+    __shared__ int part[256];
+    __shared__ int n_sh;
+    if (threadIdx.x < 64) {                          // the deposit kernel's counters (zero before a chain and after every gather)
+        int v = threadIdx.x < kScMisSlots ? mis[threadIdx.x] : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0) n_sh = v;
+    }
+    __syncthreads();
+    const int n = n_sh;
+    const bool reorder = allow_reorder && (int64_t)n * 16 > N;
+    if (threadIdx.x == 0) {
+        hdr->ncross = n;
+        hdr->last_ncross = n;
+        hdr->misfiled_permille += (int)((int64_t)n * 1000 / N);   // over the chain so far: what the host's guard reads
+        hdr->n_deposits += 1;
+        if (reorder) {
+            hdr->scatter_now = 1;
+            hdr->n_sorts += 1;
+        }
+    }
+    if (!reorder) return;                            // the usual case: this kernel is one round trip long
+    // new tile populations -> slot cursors and the next tile starts (exclusive scan over the tiles)
+    const int per = (g.nt + 255) / 256;
+    const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += newcount[k];
+    int incl = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < wv; ++k) before += part[k];
+    const int total = part[0] + part[1] + part[2] + part[3];
+    int run = before + incl - sum;
+    int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
+    for (int k = lo; k < hi; ++k) {
+        cursor[k] = run;
+        ts_next[k] = run;
+        run += newcount[k];
+    }
+    if (threadIdx.x == 255) ts_next[g.nt] = total;
+}
+
+// chx_sc_tile_deposit as an entry point of its own: move the accumulated charge into the caller's grid and leave zeros behind
+// (inside chx_sc_kick_sorted the first FFT pass of the convolution reads `acc` itself and writes the zeros back)
 template <typename T>
-__global__ __launch_bounds__(256) void sc_tile_merge_kernel(CicDev a, ScTileGeom g, ScTileHeader* __restrict__ hdr, const T* __restrict__ faces,
-                                                           T* __restrict__ cross, T* __restrict__ grid, int* __restrict__ newcount,
-                                                           const int* __restrict__ tile_mis, int* __restrict__ cursor,
-                                                           int* __restrict__ tile_start2, int allow_reorder) {
-    const int t = (int)blockIdx.x - 1;
-    if (t < 0) {                                      // (the FIRST workgroup: dispatched first, its chain of dependent steps
-        __shared__ int part[256];                     // runs under the others instead of behind them)
-        __shared__ int n_mis;
-        const int per = (g.nt + 255) / 256;
-        const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
-        int sum = 0, m = 0;
-        for (int k = lo; k < hi; ++k) {
-            sum += newcount[k];
-            m += tile_mis[k];
-        }
-        if (threadIdx.x == 0) n_mis = 0;
-        __syncthreads();
-        if (m) atomicAdd(&n_mis, m);
-        // inclusive scan of the 256 partial sums: inside each wave by shuffles, the four wave totals through LDS (one barrier;
-        // this workgroup is a chain of dependent steps the other workgroups of the pass run beside)
-        int incl = sum;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) part[wv] = incl;
-        __syncthreads();
-        int before = 0;
-        for (int k = 0; k < wv; ++k) before += part[k];
-        const int total = part[0] + part[1] + part[2] + part[3];
-        int run = before + incl - sum;
-        const int n = n_mis;                             // (complete: the barrier above is behind every lane's atomic)
-        const bool reorder = allow_reorder && (int64_t)n * 16 > a.N;
-        int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
-        for (int k = lo; k < hi; ++k) {
-            const int c = newcount[k];
-            if (reorder) {
-                cursor[k] = run;
-                ts_next[k] = run;
-                run += c;
-            }
-            newcount[k] = 0;                            // ready for the next kick
-        }
-        if (threadIdx.x == 255 && reorder) ts_next[g.nt] = total;
-        if (threadIdx.x == 0) {
-            hdr->ncross = n;
-            hdr->last_ncross = n;
-            hdr->misfiled_permille += (int)((int64_t)n * 1000 / a.N);   // over the chain so far: what the host's guard reads
-            hdr->n_deposits += 1;
-            if (reorder) {
-                hdr->scatter_now = 1;
-                hdr->n_sorts += 1;
-            }
-        }
-        return;
-    }
-    // four tiles per workgroup, one thread per z-row of 8 cells (tiles are 8^3: sc_tile_prepare), every load issued before
-    // the first use: the pass is a chain of load latencies, not of bytes
-    constexpr int TX = kScTdim, TY = kScTdim, TZ = kScTdim;
-    const int tile = t * 4 + (int)(threadIdx.x >> 6);
-    if (tile >= g.nt) return;
-    const int lx = (threadIdx.x >> 3) & 7, ly = threadIdx.x & 7;
-    int tc[3];
-    {
-        int rem = tile;
-        tc[2] = rem % g.ntile[2]; rem /= g.ntile[2];
-        tc[1] = rem % g.ntile[1]; rem /= g.ntile[1];
-        tc[0] = rem;
-    }
-    const int nf = sc_face_cells(g);
-    // neighbour (dx, dy, dz) = bits of k: its face buffer, or null (outside the grid)
-    auto fbuf = [&](int k) -> const T* {
-        const int nx = tc[0] - (k & 1), ny = tc[1] - ((k >> 1) & 1), nz = tc[2] - ((k >> 2) & 1);
-        return (nx >= 0 && ny >= 0 && nz >= 0) ? faces + (int64_t)((nx * g.ntile[1] + ny) * g.ntile[2] + nz) * nf : nullptr;
-    };
-    const int64_t off = (int64_t)(tc[0] * TX + lx) * a.gstride[0] + (int64_t)(tc[1] * TY + ly) * a.gstride[1] + (int64_t)(tc[2] * TZ);
-    T cr[TZ], gv[TZ], add[TZ];
-#pragma unroll
-    for (int z = 0; z < TZ; ++z) {
-        cr[z] = cross[off + z];
-        gv[z] = grid[off + z];
-        add[z] = (T)0;
-    }
-    if (const T* f = fbuf(4)) add[0] += f[sc_face_index(g, lx, ly, TZ)];
-    if (lx == 0) {
-        if (const T* f = fbuf(1)) {
-            const T* row = f + sc_face_index(g, TX, ly, 0);
-#pragma unroll
-            for (int z = 0; z < TZ; ++z) add[z] += row[z];
-        }
-        if (const T* f = fbuf(5)) add[0] += f[sc_face_index(g, TX, ly, TZ)];
-    }
-    if (ly == 0) {
-        if (const T* f = fbuf(2)) {
-            const T* row = f + sc_face_index(g, lx, TY, 0);
-#pragma unroll
-            for (int z = 0; z < TZ; ++z) add[z] += row[z];
-        }
-        if (const T* f = fbuf(6)) add[0] += f[sc_face_index(g, lx, TY, TZ)];
-    }
-    if (lx == 0 && ly == 0) {
-        if (const T* f = fbuf(3)) {
-            const T* row = f + sc_face_index(g, TX, TY, 0);
-#pragma unroll
-            for (int z = 0; z < TZ; ++z) add[z] += row[z];
-        }
-        if (const T* f = fbuf(7)) add[0] += f[sc_face_index(g, TX, TY, TZ)];
-    }
-    bool any_cr = false, any = false;
-#pragma unroll
-    for (int z = 0; z < TZ; ++z) {
-        any_cr = any_cr || cr[z] != (T)0;
-        add[z] += cr[z];
-        any = any || add[z] != (T)0;
-    }
-    if (any_cr) {
-#pragma unroll
-        for (int z = 0; z < TZ; ++z) cross[off + z] = (T)0;
-    }
-    if (any) {
-#pragma unroll
-        for (int z = 0; z < TZ; ++z) grid[off + z] = gv[z] + add[z];
+__global__ __launch_bounds__(256) void sc_tile_collect_kernel(T* __restrict__ acc, T* __restrict__ grid, int64_t n,
+                                                             int* __restrict__ newcount, int nt, int* __restrict__ mis) {
+    // (the counters the gather pass of a chain kick would put back to zero)
+    for (int k = (int)blockIdx.x * 256 + threadIdx.x; k < nt; k += (int)gridDim.x * 256) newcount[k] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kScMisSlots) mis[threadIdx.x] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T v = acc[i];
+        grid[i] = v;
+        if (v != (T)0) acc[i] = (T)0;
     }
 }
 
@@ -1584,17 +1516,26 @@ int sc_tile_sort_launch(const CicDev& a, const ScTileGeom& g, const ScTileLayout
 
 template <typename T>
 int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLayout& L, char* st, const void* rows, const void* extent,
-                           const void* scale, void* grid, int allow_reorder, hipStream_t s) {
+                           const void* scale, void* grid /*nullptr: leave the charge in the state's accumulation grid*/,
+                           int allow_reorder, hipStream_t s) {
     ScTileHeader* hdr = (ScTileHeader*)(st + L.hdr);
     const size_t blk_bytes = (size_t)(g.tdim[0] + 1) * (g.tdim[1] + 1) * (g.tdim[2] + 1) * sizeof(double);
-    hipLaunchKernelGGL(sc_tile_deposit_kernel<T>, dim3((unsigned)g.nt), dim3(256), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
-                       (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)grid, (T*)(st + L.faces),
-                       (T*)(st + L.cross), (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.totals));
+    // threads per tile: CHX_TUNE_DEPOSIT_THREADS (benchmarks only) picks 256 / 512 / 1024
+    static const int th = [] { const char* e = getenv("CHX_TUNE_DEPOSIT_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 256; }();
+    auto kern = th == 1024 ? sc_tile_deposit_kernel<T, 1024> : th == 512 ? sc_tile_deposit_kernel<T, 512> : sc_tile_deposit_kernel<T, 256>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.nt), dim3(th), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
+                       (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)(st + L.cross),
+                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis));
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sc_tile_merge_kernel<T>, dim3((unsigned)(g.nt + 3) / 4 + 1), dim3(256), 0, s, a, g, hdr, (const T*)(st + L.faces),
-                       (T*)(st + L.cross), (T*)grid, (int*)(st + L.newcount), (const int*)(st + L.totals), (int*)(st + L.cursor),
-                       (int*)(st + L.tile_start[0]), allow_reorder);
+    hipLaunchKernelGGL(sc_tile_schedule_kernel, dim3(1), dim3(256), 0, s, g, a.N, hdr, (const int*)(st + L.newcount),
+                       (const int*)(st + L.mis), (int*)(st + L.cursor), (int*)(st + L.tile_start[0]), allow_reorder);
     CHX_CHECK_LAUNCH();
+    if (grid) {
+        const int64_t n = a.gbatch;
+        hipLaunchKernelGGL(sc_tile_collect_kernel<T>, dim3((unsigned)chx_grid_for(n, 256 * 8, 4096)), dim3(256), 0, s, (T*)(st + L.cross),
+                           (T*)grid, n, (int*)(st + L.newcount), g.nt, (int*)(st + L.mis));
+        CHX_CHECK_LAUNCH();
+    }
     return CHX_OK;
 }
 
@@ -1632,4 +1573,21 @@ extern "C" int chx_sc_tile_deposit(const void* rows, const void* extent, const v
     if (!rows) rows = (char*)state + L.rows_tmp;       // the rows the sort of the first kick wrote
     return dtype == CHX_F32 ? sc_tile_deposit_launch<float>(a, g, L, (char*)state, rows, extent, scale, grid, allow_reorder, (hipStream_t)stream)
                             : sc_tile_deposit_launch<double>(a, g, L, (char*)state, rows, extent, scale, grid, allow_reorder, (hipStream_t)stream);
+}
+
+// the same deposit, the charge left in the chain's own accumulation grid (*acc_out: [gx][gy][gz] of `dtype` inside `state`): the
+// consumer must leave zeros behind (chx_sc_convolve_halo_consume does)
+extern "C" int chx_sc_tile_deposit_acc(const void* rows, const void* extent, const void* scale, int64_t N, const int32_t* bins, int dtype,
+                                       void* state, size_t state_bytes, int allow_reorder, void** acc_out, void* stream) {
+    CicDev a;
+    ScTileGeom g;
+    int st = sc_tile_prepare(N, bins, dtype, a, g);
+    if (st != CHX_OK) return st;
+    if (!extent || !state) return CHX_ERR_INVALID_ARG;
+    const ScTileLayout L = sc_tile_layout(N, bins, dtype);
+    if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
+    if (!rows) rows = (char*)state + L.rows_tmp;
+    if (acc_out) *acc_out = (char*)state + L.cross;
+    return dtype == CHX_F32 ? sc_tile_deposit_launch<float>(a, g, L, (char*)state, rows, extent, scale, nullptr, allow_reorder, (hipStream_t)stream)
+                            : sc_tile_deposit_launch<double>(a, g, L, (char*)state, rows, extent, scale, nullptr, allow_reorder, (hipStream_t)stream);
 }

@@ -197,9 +197,10 @@ __device__ __forceinline__ void pass1_to_lds(vec2<T> (&x)[16], vec2<T>* xch, con
 }
 
 template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
-__global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __restrict__ in, T* __restrict__ out, int n_valid,
+__global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* in, T* __restrict__ out, int n_valid,
                                                                  int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                                                                 LineLayout lo) {
+                                                                 LineLayout lo, T* consume /*LOAD_REAL: = in, zeros are written
+                                                                 behind the loads (null: the input is left alone)*/) {
     using RT = RegTile<T, M>;
     constexpr int n = RT::n;
     constexpr bool kCplxIn = LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN;
@@ -254,6 +255,14 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
                 if (kPair) x[j1].y = qr2[off];
             }
         }
+        if (LOADM == LOAD_REAL && consume && la < nl) {
+            // the accumulation grid of a chain of space-charge kicks: every cell is read exactly once, by this pass — leave it
+            // zeroed for the next kick's deposit (only cells that held charge are written)
+            T* zr = consume + b * li.batch_stride + base;
+#pragma unroll
+            for (int j1 = 0; j1 < (ZP ? 8 : 16); ++j1)
+                if (x[j1].x != (T)0) zr[(int64_t)(c + M * j1) * li.point_stride] = (T)0;
+        }
         pass1_to_lds<T, M, INV, ZP>(x, xch, tw, c, line);
     }
     // POINT_FAST: a wave holds 4 whole lines (every column and every k1 of each), the exchange never leaves the wave
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* __res
 
 template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
 int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                     LineLayout lo, int64_t B, hipStream_t s) {
+                     LineLayout lo, int64_t B, hipStream_t s, void* consume = nullptr) {
     constexpr int lines = LOADM == LOAD_EVEN_REAL_PAIR ? 2 * kTL : kTL;
     dim3 grid((unsigned)((L + lines - 1) / lines), (unsigned)B);
     constexpr size_t shmem = RegTile<T, M>::shmem;
@@ -298,7 +307,8 @@ int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t
             hipSuccess)
             return CHX_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n_valid, n_keep, L, inner_count, li, lo);
+    hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n_valid, n_keep, L, inner_count, li, lo,
+                       (T*)consume);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -406,14 +416,14 @@ int launch_z_fused(void* data, const void* gh, const double* scale, int gx, int 
 // ZP / KH are promises of the call site about n_valid / n_keep (checked here)
 template <typename T, int LOADM, int STOREM, bool POINT_FAST, bool INV, bool ZP = false, bool KH = false>
 int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                 LineLayout lo, int64_t B, hipStream_t s) {
+                 LineLayout lo, int64_t B, hipStream_t s, void* consume = nullptr) {
     if ((ZP && 2 * n_valid != n) || (KH && 2 * n_keep != n)) return CHX_ERR_INVALID_ARG;
     if ((LOADM == LOAD_COMPLEX || LOADM == LOAD_REAL) && !ZP && n_valid != n) return CHX_ERR_INVALID_ARG;
     switch (n) {
-        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
-        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
-        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
-        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s);
+        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
+        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
+        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
+        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
         default: break;
     }
     int log2n = 0;
@@ -721,7 +731,7 @@ extern "C" size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins
 // — forward z, multiply, inverse z — runs in place along the contiguous axis.
 template <typename T>
 static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64_t B, const int32_t* bins, T* phi, T* ws,
-                         hipStream_t s, bool halo, hipEvent_t ghat_ready = nullptr) {
+                         hipStream_t s, bool halo, hipEvent_t ghat_ready = nullptr, bool consume_rho = false) {
     const int gx = bins[0], gy = bins[1], gz = bins[2];
     const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nxc = gx + 1;
     const int64_t nA = (int64_t)nxc * gy * gz, nB = (int64_t)nxc * ny * gz, nC = (int64_t)nxc * ny * nz;  // complex elements
@@ -732,8 +742,12 @@ static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64
     // forward x: rho[x < gx][y][z] real, lines (y, z) -> A[kx <= gx][y][z]
     LineLayout rx{yz, 1, 0, g3};
     LineLayout ax{yz, 1, 0, nA};
-    int st = launch_lines<T, LOAD_REAL, STORE_COMPLEX, false, false, true>(rho, A, nx, gx, nxc, yz, yz, rx, ax, B, s);
+    // consume_rho: rho is the accumulation grid of a chain of kicks — the pass that reads it leaves zeros behind
+    const bool in_pass = consume_rho && nx <= 256;
+    int st = launch_lines<T, LOAD_REAL, STORE_COMPLEX, false, false, true>(rho, A, nx, gx, nxc, yz, yz, rx, ax, B, s,
+                                                                           in_pass ? (void*)rho : nullptr);
     if (st != CHX_OK) return st;
+    if (consume_rho && !in_pass && hipMemsetAsync((void*)rho, 0, (size_t)B * g3 * sizeof(T), s) != hipSuccess) return CHX_ERR_LAUNCH;
     // forward y: A lines (kx, z), y < gy valid -> Bf[kx][ky < ny][z]
     LineLayout ay{gz, 1, yz, nA};
     LineLayout by{gz, 1, (int64_t)ny * gz, nB};
@@ -808,6 +822,22 @@ extern "C" int chx_sc_convolve_halo_after(const void* rho, const void* Ghat, con
                                                    (float*)workspace, s, true, ev)
                             : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi_halo,
                                                     (double*)workspace, s, true, ev);
+}
+
+// chx_sc_convolve_halo_after for a charge grid that is an accumulation buffer (chx_sc_tile_deposit_acc): rho is all zeros when
+// the call has run
+extern "C" int chx_sc_convolve_halo_consume(void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
+                                            void* phi_halo, void* workspace, size_t workspace_bytes, void* stream,
+                                            void* ghat_ready_event) {
+    if (!rho || !Ghat || !scale || !phi_halo || B < 1 || B > 65535 || !chx_sc_pruned_supported(bins, dtype))
+        return CHX_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < chx_sc_convolve_workspace_bytes(B, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev = (hipEvent_t)ghat_ready_event;
+    return dtype == CHX_F32 ? convolve_impl<float>((const float*)rho, (const float*)Ghat, scale, B, bins, (float*)phi_halo,
+                                                   (float*)workspace, s, true, ev, true)
+                            : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi_halo,
+                                                    (double*)workspace, s, true, ev, true);
 }
 
 extern "C" int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,

@@ -252,7 +252,8 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
     const void* rows = first ? nullptr : x_in;             // nullptr = the state's row buffer
     if (rc == CHX_OK && first)
         rc = chx_sc_tile_sort(x_in, charge, survival, k.extent, k.scale, N, bins, dtype, state, state_bytes, main);
-    if (rc == CHX_OK) rc = chx_sc_tile_deposit(rows, k.extent, k.scale, N, bins, dtype, state, state_bytes, k.rho, last ? 0 : 1, main);
+    void* acc = nullptr;
+    if (rc == CHX_OK) rc = chx_sc_tile_deposit_acc(rows, k.extent, k.scale, N, bins, dtype, state, state_bytes, last ? 0 : 1, &acc, main);
     if (rc != CHX_OK && forked) {                           // an error path still rejoins the side stream
         hipEvent_t join = nullptr;
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
@@ -261,7 +262,7 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
             (void)hipEventDestroy(join);
         }
     }
-    if (rho_out) *rho_out = k.rho;
+    if (rho_out) *rho_out = acc;
     return rc;
 }
 
@@ -281,8 +282,9 @@ extern "C" int chx_sc_kick_sorted_finish(const void* x_in, const void* energy, d
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return CHX_ERR_LAUNCH;
         (void)hipEventRecord(join, side);                 // behind the Green spectrum `begin` put on the side stream
     }
-    rc = chx_sc_convolve_halo_after(k.rho, k.ghat, k.pot_scale, 1, bins, dtype, k.phi, k.ws + k.L.conv_ws, k.L.phi - k.L.conv_ws, main,
-                                    forked ? (void*)join : nullptr);
+    // the charge sits in the chain's accumulation grid (state); the convolution's first pass leaves it zeroed for the next kick
+    rc = chx_sc_convolve_halo_consume(k.st + k.T.cross, k.ghat, k.pot_scale, 1, bins, dtype, k.phi, k.ws + k.L.conv_ws,
+                                      k.L.phi - k.L.conv_ws, main, forked ? (void*)join : nullptr);
     if (forked) {
         if (rc != CHX_OK) (void)hipStreamWaitEvent(main, join, 0);
         (void)hipEventDestroy(join);

@@ -4,17 +4,17 @@
 // beam: its extent is a multiple of the beam sigmas), so the counting sort by 8^3 deposit tile that a kick needs is done ONCE:
 // the first kick of a chain writes the particle rows in tile order and every later kick works on them in place —
 //   * deposit: one workgroup per tile accumulates its own slot range in an LDS block of (tile + 1)^3 cells (no records, no
-//     duplication of particles over neighbouring tiles), stores the cells it owns and hands the +1 layer to its neighbours
-//     through a small per-tile face buffer (merged by a second, tiny kernel);
+//     duplication of particles over neighbouring tiles) and adds the non-zero cells of the block to the chain's accumulation
+//     grid with one float atomic each; the first FFT pass of the convolution reads that grid and writes the zeros back;
 //   * gather: the per-particle kernel of the untiled path on the ordered rows — the lanes of a wave sit in one tile, so the 12
 //     line requests per particle for the 32 potential values around its cell hit the CU's vector cache (63 -> 33 us at 1e6
 //     particles on 128^3); it also accumulates the beam sizes the next kick's grid needs over the rows it writes;
 //   * a particle that has left the tile of its slot ("misfiled": 1 % of the beam per kick in a smooth channel, 10-20 % where
 //     the beam goes through a focus) is still handled exactly, by the same code path: a corner that still falls into the
-//     tile's block goes there, any other takes a global float atomic into a second, otherwise zero grid that the face-merge
-//     pass folds in (and clears); the gather reads the potential from global memory anyway. When more than 1/16 of the beam
+//     tile's block goes there, any other takes a global float atomic into the same accumulation grid; the gather reads the
+//     potential from global memory anyway. When more than 1/16 of the beam
 //     is misfiled the gather pass of that very kick writes its rows in the new tile order (the deposit pass counted the new
-//     tile populations on the way): a device-side decision (one extra workgroup of the face-merge pass), no host
+//     tile populations on the way): a device-side decision (a one-workgroup kernel behind the deposit), no host
 //     synchronisation and no extra launch. The header keeps the running share of misfiled particles for the host (see
 //     ScTileHeader): a beam that reshuffles between kicks is better served by the kick-by-kick path.
 // The permutation back to the caller's particle order is carried along and applied by the last kick of the chain.
@@ -44,6 +44,7 @@ constexpr int kScSortWG = 256;       // workgroups of the count / scatter passes
 constexpr int kScSortThreads = 1024;
 constexpr int kScTileCap = 8192;     // particles of one tile deposited through LDS by its workgroup; the rest take the slow way
 constexpr int kScChunk = 256;        // slots per workgroup of the gather pass (four waves of 64 rows, each on its own)
+constexpr int kScMisSlots = 64;     // (one counter would serialise a thousand atomics on one address: +4 us on the deposit)
 constexpr int kScTdim = 8;           // the tile edge the kernels are written for (grids whose tile rule gives larger tiles — more
                                      // than 8192 tiles of 8^3 — keep the untiled path)
 
@@ -76,20 +77,9 @@ static __host__ __device__ inline ScTileGeom sc_tile_geom(const int* bins) {
     return g;
 }
 
-// cells of the +1 layer of a tile's LDS block: faces X (lx = TX), Y (ly = TY, lx < TX), Z (lz = TZ, lx < TX, ly < TY)
-static __host__ __device__ inline int sc_face_cells(const ScTileGeom& g) {
-    return (g.tdim[1] + 1) * (g.tdim[2] + 1) + g.tdim[0] * (g.tdim[2] + 1) + g.tdim[0] * g.tdim[1];
-}
-static __host__ __device__ inline int sc_face_index(const ScTileGeom& g, int lx, int ly, int lz) {
-    const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
-    if (lx == TX) return ly * (TZ + 1) + lz;
-    if (ly == TY) return (TY + 1) * (TZ + 1) + lx * (TZ + 1) + lz;
-    return (TY + 1) * (TZ + 1) + TX * (TZ + 1) + lx * TY + ly;   // lz == TZ
-}
-
 // byte offsets of the pieces of the state buffer (B = 1); [2] = one copy per parity
 struct ScTileLayout {
-    size_t hdr, newcount, cross, cursor, tile_start[2], counts, totals, perm[2], ws[2], cs[2], home, rows_tmp, faces, sigma, total;
+    size_t hdr, newcount, mis, cross, cursor, tile_start[2], counts, totals, perm[2], ws[2], cs[2], home, rows_tmp, sigma, total;
     int64_t sigma_blocks;   // workgroups of the gather pass = partial sums per moment handed to the next kick's geometry kernel
     size_t zero_bytes;   // header + newcount + the crossers' grid: cleared by the first kick of a chain
 };
@@ -102,7 +92,8 @@ static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dt
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     L.hdr = take(sizeof(ScTileHeader));
     L.newcount = take((size_t)g.nt * sizeof(int));
-    L.cross = take((size_t)bins[0] * bins[1] * bins[2] * esz);   // what misfiled particles deposit; all zero between two kicks
+    L.mis = take((size_t)kScMisSlots * sizeof(int));              // misfiled particles of the last deposit, spread over a few counters
+    L.cross = take((size_t)bins[0] * bins[1] * bins[2] * esz);   // the accumulation grid of the deposits; all zero between two kicks
     L.zero_bytes = off;
     L.cursor = take((size_t)g.nt * sizeof(int));
     // the two copies of a double-buffered array are contiguous: copy p starts p * (element count) elements behind copy 0
@@ -118,7 +109,6 @@ static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dt
     L.cs[1] = L.cs[0] + (size_t)N * esz;
     L.home = take((size_t)N * sizeof(uint16_t));
     L.rows_tmp = take((size_t)N * 7 * esz);
-    L.faces = take((size_t)g.nt * sc_face_cells(g) * esz);
     L.sigma_blocks = (N + 255) / 256;
     L.sigma = take((size_t)8 * L.sigma_blocks * sizeof(double));
     L.total = off;

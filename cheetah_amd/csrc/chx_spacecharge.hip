@@ -803,11 +803,15 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
     const T* __restrict__ src, const ScTileHeader* __restrict__ hdr, int* perm2, T* ws2, T* cs2, const uint16_t* __restrict__ home,
     int* __restrict__ cursor, const T* __restrict__ phi, const T* __restrict__ half, const T* __restrict__ cell,
     const T* __restrict__ energy, const T* __restrict__ dt, const T* __restrict__ gamma, double mass_eV, int64_t N, int gx, int gy,
-    int gz, T* __restrict__ x_out, const T* __restrict__ post_map, int unpermute, double* __restrict__ sigma_partials) {
+    int gz, T* __restrict__ x_out, const T* __restrict__ post_map, int unpermute, double* __restrict__ sigma_partials,
+    int* __restrict__ newcount, int nt, int* __restrict__ mis) {
     __shared__ __attribute__((aligned(16))) T lds[CHX_BLOCK * 7];
     __shared__ double red[4 * 8];
     const int par = hdr->parity;
     const int mode = hdr->scatter_now ? 2 : (unpermute ? 1 : 0);
+    // the deposit's counters (read by the schedule kernel in front of this pass) go back to zero for the next kick's deposit
+    for (int k = (int)blockIdx.x * CHX_BLOCK + threadIdx.x; k < nt; k += (int)gridDim.x * CHX_BLOCK) newcount[k] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kScMisSlots) mis[threadIdx.x] = 0;
     const int64_t n0 = (int64_t)blockIdx.x * CHX_BLOCK;
     const int np = (int)((N - n0 < CHX_BLOCK) ? (N - n0) : CHX_BLOCK);
     // staged per wave like sc_particle_kernel: no workgroup barrier
@@ -893,13 +897,14 @@ extern "C" int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, c
                            (float*)(st + L.ws[0]), (float*)(st + L.cs[0]), (const uint16_t*)(st + L.home), (int*)(st + L.cursor),
                            (const float*)phi_halo, (const float*)half, (const float*)cell, (const float*)energy, (const float*)dt,
                            (const float*)gamma, mass_eV, N, bins[0], bins[1], bins[2], (float*)x_out, (const float*)post_map, unpermute,
-                           unpermute ? nullptr : (double*)(st + L.sigma));
+                           unpermute ? nullptr : (double*)(st + L.sigma), (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis));
     else
         hipLaunchKernelGGL(sc_tile_particle_kernel<double>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const double*)rows, hdr,
                            (int*)(st + L.perm[0]), (double*)(st + L.ws[0]), (double*)(st + L.cs[0]), (const uint16_t*)(st + L.home),
                            (int*)(st + L.cursor), (const double*)phi_halo, (const double*)half, (const double*)cell,
                            (const double*)energy, (const double*)dt, (const double*)gamma, mass_eV, N, bins[0], bins[1], bins[2],
-                           (double*)x_out, (const double*)post_map, unpermute, unpermute ? nullptr : (double*)(st + L.sigma));
+                           (double*)x_out, (const double*)post_map, unpermute, unpermute ? nullptr : (double*)(st + L.sigma),
+                           (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis));
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

@@ -494,7 +494,7 @@ int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* surviva
  *          beam, moment_rows = R > 0: the [R][29] moments of its shards exactly as the ranks all-gathered them, merged inside the
  *          geometry kernel with chx_merge_moments' arithmetic), else from this process's own rows as chx_sc_kick_sorted does — then
  *          [side stream: Green spectrum], [CHX_SC_FIRST: tile sort], tile deposit. *rho_out = the compact charge grid
- *          [gx][gy][gz] (dtype) inside `workspace`, every cell stored: sum it over the ranks in place.
+ *          [gx][gy][gz] (dtype) inside `state` (the chain's accumulation grid): sum it over the ranks in place.
  *  finish: convolution (joins the side stream) -> gather + kick (+ post_map) into x_out.
  * Same workspace / state / flags / streams for both halves; the workspace must not be touched in between.
  * chx_sc_tile_beam_moments: this process's share of the moments the NEXT kick's grid needs — the sums the last
@@ -534,6 +534,13 @@ int chx_sc_tile_sort(const void* x_in, const void* charge, const void* survival,
  * pass order a re-sort by this kick's gather (0 for the last kick of a chain, which restores the caller's order instead). */
 int chx_sc_tile_deposit(const void* rows, const void* extent, const void* scale, int64_t N, const int32_t* bins, int dtype,
                         void* state, size_t state_bytes, void* grid, int allow_reorder, void* stream);
+/* chx_sc_tile_deposit with the charge LEFT in the chain's accumulation grid (*acc_out: [gx][gy][gz] of dtype inside `state`, all
+ * zero between two kicks): what chx_sc_kick_sorted uses. Whoever consumes the grid must leave zeros behind —
+ * chx_sc_convolve_halo_consume (= chx_sc_convolve_halo_after whose first FFT pass writes zeros behind its loads) does. */
+int chx_sc_tile_deposit_acc(const void* rows, const void* extent, const void* scale, int64_t N, const int32_t* bins, int dtype,
+                            void* state, size_t state_bytes, int allow_reorder, void** acc_out, void* stream);
+int chx_sc_convolve_halo_consume(void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins, int dtype,
+                                 void* phi_halo, void* workspace, size_t workspace_bytes, void* stream, void* ghat_ready_event);
 int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
                             const void* energy, const void* dt, double mass_eV, int64_t N, const int32_t* bins, int dtype,
                             const void* post_map, void* state, size_t state_bytes, int unpermute, void* x_out, void* stream);
