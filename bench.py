@@ -801,7 +801,8 @@ def main():
 
     # the tracked beam itself is checked, not only timed: sigma_x of the outgoing beam of rank 0's seed against the committed value
     # (tests/test_gpu_bench_parity.py holds the bit-exact comparison of this very step with the oracle)
-    sigma_ok = abs(sigma_x / EXPECTED_SIGMA_X_RANK0 - 1.0) < 1e-9 if rank == 0 else None
+    # (N > 1: the moments are those of the union of the ranks' beams — other seeds, the same distribution: 5e-3)
+    sigma_ok = abs(sigma_x / EXPECTED_SIGMA_X_RANK0 - 1.0) < (1e-9 if world == 1 else 5e-3) if rank == 0 else None
     if rank == 0 and not sigma_ok:
         raise SystemExit(f"bench.py: sigma_x of the tracked beam is {sigma_x!r}, expected {EXPECTED_SIGMA_X_RANK0!r}: the step "
                          "does not compute what it is timed for")

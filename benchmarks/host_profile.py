@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""cProfile of the host side of the small-beam paths: python benchmarks/host_profile.py [rl|c1|c2|c5]"""
+"""cProfile of the host side of the small-beam paths: python benchmarks/host_profile.py [rl|c1|linac|c2|dkd|c5]"""
 import cProfile
 import os
 import pstats
@@ -28,6 +28,18 @@ if which in ("rl", "c1"):
             seg.AREAMQZM3.k1, seg.AREAMCHM1.angle = a[3] * 10, a[4] * 1e-4
         seg.track(beam)
         return seg.AREABSCR1.reading
+elif which == "linac":
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for i in range(16):
+        els += [ca.Drift(rc.t(0.3, dt), **kw), ca.Quadrupole(rc.t(0.2, dt), k1=rc.t(3.0 if i % 2 else -3.0, dt), **kw),
+                ca.Cavity(rc.t(1.0377, dt), voltage=rc.t(18e6, dt), phase=rc.t(-10.0, dt), frequency=rc.t(1.3e9, dt), **kw)]
+    seg = ca.Segment(els)
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_000, energy=rc.t(1e8, dt), **kw)
+
+    def step():
+        with torch.no_grad():
+            return seg.track(beam).particles
 elif which == "c2":
     kw = {"dtype": dt, "device": "cuda"}
     els = []

@@ -142,6 +142,11 @@ SIGNATURES = {
     "chx_cavity_track_scalars_workspace_bytes": (c_size_t, []),
     "chx_cavity_track_scalars": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_i64, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_lattice_state_bytes": (c_size_t, [c_i64, c_i64]),
+    "chx_lattice_prepare": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
+    "chx_lattice_track": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                                  c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_copy_arrays": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int32, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
@@ -275,5 +280,6 @@ def host():
                               "(or `python -c 'import __graft_entry__ as g; g.build()'`)") from exc
         fn = lib().chx_run_track
         _chxhost.bind(ctypes.cast(fn, ctypes.c_void_p).value, torch.empty_like, torch._C._cuda_getCurrentRawStream, ChxError)
+        _chxhost.bind_lattice(ctypes.cast(lib().chx_lattice_track, ctypes.c_void_p).value)
         _host = _chxhost
     return _host

@@ -35,6 +35,7 @@ class Cavity(Element):
     """Accelerating RF cavity (standing or traveling wave)."""
 
     _static_skippable = False  # `voltage != 0` is a tensor-value dependent flag
+    _is_cavity = True
 
     def __init__(self, length, voltage=None, phase=None, frequency=None, cavity_type="standing_wave", name=None,
                  sanitize_name=None, metadata=None, device=None, dtype=None) -> None:

@@ -264,6 +264,91 @@ class _FastRun:
                 k += 1
 
 
+class _LatticePlan:
+    """Persistent device plan of a STRETCH of lattice — [run of skippable elements | active Cavity]+ with scalar settings — for
+    `chx_lattice_track`: the whole stretch is two launches (every map, coefficient row, energy and the path length in one, every
+    particle through all items in registers in the other) and one C call of the host step, where the element-by-element walk
+    (segment.py:545-574 of the reference) costs two launches and ~20-30 us of host time per item. The table holds device
+    ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
+    `Element._epoch` stands still and is re-derived after any attribute assignment."""
+
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code")
+
+    def __init__(self, items, dtype, device):
+        self.items, self.dtype, self.device = items, dtype, device
+        self.code = _ops.dtype_code(dtype)
+        self.table = self.state = self.capsule = None
+        self.tensors = ()
+        self.count = 0          # leading items the table covers (the stretch ends in front of the first item it cannot take)
+        self.refresh()
+
+    def refresh(self) -> None:
+        from .cavity import Cavity
+
+        self.epoch = Element._epoch
+        self.ok = False
+        lib = _lib.lib()
+        dtype, device = self.dtype, self.device
+        rows, elem_kind, elem_poff, ptrs, tensors = [], [], [], [], []
+        count = cavities = 0
+        for kind, item in self.items:
+            if kind == "run":
+                fr = item.fast
+                if fr is None or fr.dtype != dtype or fr.device != device:
+                    fr = item.fast = _FastRun(item, dtype, device)
+                elif fr.epoch != Element._epoch:
+                    fr.refresh()
+                if not fr.ok:
+                    break
+                row_ptrs = []
+                for e in range(fr.E):
+                    base = e * _ops.MAX_PARAMS
+                    row_ptrs.append([fr.ptrs[base + j] for j in range(lib.chx_kind_num_params(fr.kinds[e]))])
+                if any(q is None for r in row_ptrs for q in r):
+                    break
+                rows += [0, fr.E, len(elem_kind), 0]
+                for e, r in enumerate(row_ptrs):
+                    elem_kind.append(fr.kinds[e])
+                    elem_poff.append(len(ptrs))
+                    ptrs += r
+                tensors += fr.tensors
+            else:
+                if type(item).track is not Cavity.track or item._parameters:
+                    break
+                settings = item._settings("length", "voltage", "phase", "frequency")
+                if any(t.dim() != 0 or t.dtype != dtype or t.device != device or t.requires_grad for t in settings):
+                    break
+                rows += [1, 1, len(elem_kind), 0]
+                elem_kind.append(_ops.KIND[item._kind_name()])
+                elem_poff.append(len(ptrs))
+                ptrs += [t.data_ptr() for t in settings]
+                tensors += settings
+                cavities += 1
+            count += 1
+        # (a trailing run stays in the stretch: it rides in the same particle pass)
+        self.count = count
+        if count < 2 or cavities == 0:
+            return
+        n_items, n_elems, n_ptrs = count, len(elem_kind), len(ptrs)
+        state_bytes = lib.chx_lattice_state_bytes(n_items, n_elems)
+        if state_bytes == 0:
+            return
+        # host -> device without a synchronisation: page-locked staging buffer (torch's caching host allocator keeps it alive
+        # until the copy has run), asynchronous copy on the current stream
+        words = rows + elem_kind + elem_poff + ptrs
+        staging = torch.empty(len(words), dtype=torch.int64, pin_memory=True)
+        staging.copy_(torch.tensor(words, dtype=torch.int64))
+        if self.table is None or self.table.numel() != len(words):
+            self.table = torch.empty(len(words), dtype=torch.int64, device=device)
+        self.table.copy_(staging, non_blocking=True)
+        if self.state is None or self.state.numel() * 8 < state_bytes:
+            self.state = torch.empty(state_bytes // 8 + 1, dtype=torch.float64, device=device)
+        self.capsule = _lib.host().lattice_plan(self.table.data_ptr(), n_items, n_elems, n_ptrs, self.state.data_ptr(),
+                                                self.state.numel() * 8, self.code)
+        self.tensors = tuple(tensors)       # kept alive: the table holds their addresses
+        self.ok = True
+
+
 _CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
 #: CHX_SC_CHAIN = auto (default) | on | off — how `Segment.track` takes [SpaceChargeKick, linear run, SpaceChargeKick, ...]:
 #: "auto" starts on the tile-ordered chain and lets the asynchronous guard (`_chain_allowed`) send a plan whose beam reshuffles
@@ -653,6 +738,11 @@ class Segment(Element):
                     chain = None
                 i += step
                 continue
+            if (kind == "run" or item._is_cavity) and n_items - i >= 2:
+                done = self._lattice_stretch(plan, i, incoming)
+                if done is not None:
+                    incoming, i = done
+                    continue
             if kind == "run":
                 fast = self._run_apply_fast(item, incoming)
                 if fast is None:
@@ -685,6 +775,54 @@ class Segment(Element):
                 incoming = item._track_internal(incoming)
             i += 1
         return incoming
+
+    def _lattice_stretch(self, plan, i: int, incoming: ParticleBeam):
+        """plan[i] and the items behind it as ONE `chx_lattice_track` call when they form a stretch [run | active Cavity]+ (at
+        least two items, at least one cavity) of scalar settings and the beam is one plain beam without a graph: (outgoing beam,
+        index behind the stretch), else None. Same numbers, bit for bit, as the walk item by item."""
+        cache = self.__dict__.get("_lattice_cache")
+        if cache is None or cache[0] is not plan:
+            cache = self.__dict__["_lattice_cache"] = (plan, {})
+        p = incoming.particles
+        key = (i, p.dtype, p.device)
+        entry = cache[1].get(key)
+        if entry is None:
+            j, cavities = i, 0
+            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity):
+                cavities += plan[j][0] != "run"
+                j += 1
+            entry = cache[1][key] = False if (j - i < 2 or cavities == 0 or not p.is_cuda) else [j, None]
+        if entry is False:
+            return None
+        if p.dim() != 2 or not p.is_cuda:
+            return None
+        e, s_in, sp = incoming.energy, incoming.s, incoming.species
+        if e.dim() != 0 or e.dtype != p.dtype or e.device != p.device:
+            return None
+        lp = entry[1]
+        if lp is None or lp.epoch != Element._epoch:
+            if torch.cuda.is_current_stream_capturing():
+                return None     # (the table's upload is not part of a recording: the walk item by item is capturable as it is)
+            if lp is None:
+                lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device)
+            else:
+                lp.refresh()
+        if not lp.ok:
+            return None
+        if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
+                                        or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
+            return None
+        x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
+        _ops.check_current_device(lp.device)
+        on_device = s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device and not s_in.requires_grad
+        out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, x.shape[0], e, s_in if on_device else None, sp.mass_eV_float,
+                                                sp.num_elementary_charges_float, lp.device.index)
+        if s_out is None:
+            s_out = s_in
+            for kind, item in lp.items[:lp.count]:
+                s_out = s_out + (self._run_length(item) if kind == "run" else item.length)
+        return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
+                            survival_probabilities=incoming.survival_probabilities, s=s_out, species=sp), i + lp.count
 
     def _second_order_run(self, plan, i: int, incoming: ParticleBeam):
         """plan[i] and the second-order elements behind it as one `chx_second_order_chain` call: (outgoing beam, index behind

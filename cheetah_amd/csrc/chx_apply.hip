@@ -547,6 +547,78 @@ extern "C" int chx_cavity_track_scalars(const void* x_in, const void* const* par
     return chx_cavity_track(x_in, R, coeffs, x_out, 1, 1, N, dtype, stream);
 }
 
+// ---- a stretch of lattice, every particle through all its items in registers (see lattice_prepare_kernel, chx_build.hip) ----
+// items: [n_items][4] int64 = {type 0 linear run / 1 active cavity, ...}; Rs[n_items][49] (T in double-sized slots);
+// coeffs[n_items][8]. Per item the arithmetic of apply_tile_kernel MODE 0 / MODE 2 on coordinates rounded to T — what storing
+// the beam behind every element and loading it again gives: bit-identical to element-by-element tracking.
+namespace {
+template <typename T, int PPT>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in, T* x_out, const int64_t* __restrict__ items, int n_items,
+                                                                 const double* __restrict__ Rs, const double* __restrict__ coeffs,
+                                                                 int64_t N, int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = PPT * CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    tile_load<T, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
+    __syncthreads();
+    T x[PPT][7];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + k * CHX_BLOCK;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? lds[p * 7 + j] : (T)0;
+    }
+    for (int i = 0; i < n_items; ++i) {
+        const T* __restrict__ R = reinterpret_cast<const T*>(Rs + (int64_t)i * 49);
+        const bool cavity = items[i * 4] == 1;
+        const double* __restrict__ c = coeffs + (int64_t)i * CHX_CAV_NCOEF;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            T y[7];
+            apply7<T>(R, x[k], y);
+            if (cavity) cavity_epilogue<T>(c, x[k], y);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = threadIdx.x + k * CHX_BLOCK;
+        if (p < np) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x[k][j];
+        }
+    }
+    __syncthreads();
+    tile_store<T, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
+}
+}  // namespace
+
+extern "C" int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                 double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
+                                 void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, void* stream) {
+    if (!x_in || !x_out || N < 1) return CHX_ERR_INVALID_ARG;
+    int st = chx_lattice_prepare(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, energy_out,
+                                 s_in, s_out, stream);
+    if (st != CHX_OK) return st;
+    const double* Rs = (const double*)state;
+    const double* coeffs = Rs + n_items * 49;
+    hipStream_t s = (hipStream_t)stream;
+    const int iv = chx_aligned16(x_in) ? 1 : 0, ov = chx_aligned16(x_out) ? 1 : 0;
+    // one particle per lane: a stretch is tracked on small beams (a few dozen tiles), two per lane only halve the waves in flight
+    const unsigned grid = (unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK);
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL((lattice_apply_kernel<float, 1>), dim3(grid), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
+                           (int)n_items, Rs, coeffs, N, iv, ov);
+    else
+        hipLaunchKernelGGL((lattice_apply_kernel<double, 1>), dim3(grid), dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out, table,
+                           (int)n_items, Rs, coeffs, N, iv, ov);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 // ---- several device arrays copied by ONE launch -----------------------------------------------------------------------
 // A Screen records a copy of the incoming beam (screen.py:190 `incoming.clone()`): five tensors, two of them scalars — five
 // launches of a framework copy kernel, or one of this. Arrays travel by value in the kernel arguments; blockIdx.y picks the

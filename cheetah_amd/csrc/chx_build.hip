@@ -1638,6 +1638,124 @@ extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs
     return chx_apply_affine7(x_in, R, x_out, 1, 1, 1, N, dtype, stream);
 }
 
+// ---- a whole stretch of lattice in two launches (chx_lattice_track, chx_apply.hip) --------------------------------------
+// Segment.track (segment.py:545-574) walks [run of skippable elements, active Cavity, run, Cavity, ...] element by element; each
+// item costs two launches here (map / coefficients, then the particle pass) and ~4 us of host time per launch, so a 16-cell
+// linac on a 1e4-particle beam is 64 launches = 0.6 ms of host for ~60 us of kernels. The items of such a stretch depend on one
+// another only through the REFERENCE ENERGY (every cavity hands E + V cos(phi) q on, cavity.py:113-122) and the path length —
+// both scalars. So: ONE launch with a workgroup per item prepares every map (each workgroup first walks the energy through the
+// cavities in front of its item: a few cosines), and ONE launch carries every particle through all items in registers
+// (lattice_apply_kernel). The arithmetic per item is that of run_map_kernel / cavity_prepare_scalars_kernel — bit-identical maps,
+// coefficients, energies and path length.
+//   table (int64 words, device): items[n_items][4] = {type 0 run / 1 cavity, E, first element, -}, elem_kind[n_elems],
+//   elem_poff[n_elems] (first pointer of the element), ptrs[n_ptrs] (device addresses of the scalar settings, kind order)
+//   state: R[n_items][49] (T, in double-sized slots), coeffs[n_items][8] double, emaps[n_elems][49] (T, double-sized slots)
+constexpr int kLatticeMaxItems = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_t* __restrict__ items, const int64_t* __restrict__ elem_kind,
+                                                                   const int64_t* __restrict__ elem_poff, const int64_t* __restrict__ ptrs,
+                                                                   int n_items, const T* __restrict__ energy, double mass, double nq,
+                                                                   double* __restrict__ Rs, double* __restrict__ coeffs,
+                                                                   double* __restrict__ emaps, T* __restrict__ energy_out,
+                                                                   const T* __restrict__ s_in, T* __restrict__ s_out) {
+    __shared__ double e_in_sh;
+    const int b = blockIdx.x;
+    const int type = (int)items[b * 4], E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
+    auto setting = [&](int64_t q) { return *(const T*)ptrs[q]; };
+    if (threadIdx.x == 0) {
+        // the reference energy this item sees: through the cavities in front of it, rounded to T after each (the energy is a
+        // tensor of the beam's dtype between two elements)
+        double e = (double)energy[0];
+        for (int i = 0; i < b; ++i) {
+            if (items[i * 4] != 1) continue;
+            const int64_t po = elem_poff[items[i * 4 + 2]];
+            const double dEn = (double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0;
+            e = (double)(T)(e + dEn);
+        }
+        e_in_sh = e;
+    }
+    if (b == n_items - 1 && threadIdx.x == 64 && s_out) {
+        // path length behind the stretch: s + run length (((L0 + L1) + L2) + ...) / + cavity length, item by item, in T
+        T sv = *s_in;
+        for (int i = 0; i < n_items; ++i) {
+            const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
+            T total = setting(elem_poff[e0]);
+            for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
+            sv = sv + total;
+        }
+        *s_out = sv;
+    }
+    __syncthreads();
+    const double E0 = e_in_sh;
+    T* R = reinterpret_cast<T*>(Rs + (int64_t)b * 49);
+    if (type == 1) {
+        if (threadIdx.x == 0) {
+            const int64_t po = elem_poff[elem0];
+            const double p[4] = {(double)setting(po), (double)setting(po + 1), (double)setting(po + 2), (double)setting(po + 3)};
+            Mat7<double> M;
+            build_kind<double>((int)elem_kind[elem0], p, E0, mass, nq, M);
+            for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
+            const double dEn = p[1] * cos(p[2] * (kPi / 180.0)) * nq * -1.0;
+            const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, dEn > 0.0, coeffs + (int64_t)b * CHX_CAV_NCOEF);
+            if (b == n_items - 1) *energy_out = (T)E1;
+        }
+        return;
+    }
+    if (b == n_items - 1 && threadIdx.x == 0) *energy_out = (T)E0;
+    T* maps = reinterpret_cast<T*>(emaps + (int64_t)elem0 * 49);
+    for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
+        const int kind = (int)elem_kind[elem0 + e];
+        const int P = kind_num_params(kind);
+        const int64_t po = elem_poff[elem0 + e];
+        double p[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) p[k] = (double)setting(po + k);
+        Mat7<double> M;
+        build_kind<double>(kind, p, E0, mass, nq, M);
+        for (int q = 0; q < 49; ++q) maps[e * 49 + q] = (T)M.m[q];
+    }
+    __syncthreads();
+    if (E == 1) {
+        if (threadIdx.x < 49) R[threadIdx.x] = maps[threadIdx.x];
+        return;
+    }
+    compose_block<T>([&](int e) { return (const T*)maps + e * 49; }, E, 0, R);
+}
+
+extern "C" size_t chx_lattice_state_bytes(int64_t n_items, int64_t n_elems) {
+    if (n_items < 1 || n_items > kLatticeMaxItems || n_elems < n_items) return 0;
+    return (size_t)(n_items * (49 + CHX_CAV_NCOEF) + n_elems * 49) * sizeof(double);
+}
+
+extern "C" int chx_lattice_prepare(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                   double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, void* energy_out,
+                                   const void* s_in, void* s_out, void* stream) {
+    if (!table || !energy || !state || !energy_out || ((s_in == nullptr) != (s_out == nullptr)) || n_ptrs < n_elems)
+        return CHX_ERR_INVALID_ARG;
+    const size_t need = chx_lattice_state_bytes(n_items, n_elems);
+    if (need == 0) return CHX_ERR_INVALID_ARG;
+    if (state_bytes < need) return CHX_ERR_WORKSPACE;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    const int64_t* items = table;
+    const int64_t* elem_kind = items + n_items * 4;
+    const int64_t* elem_poff = elem_kind + n_elems;
+    const int64_t* ptrs = elem_poff + n_elems;
+    double* Rs = (double*)state;
+    double* coeffs = Rs + n_items * 49;
+    double* emaps = coeffs + n_items * CHX_CAV_NCOEF;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(lattice_prepare_kernel<float>, dim3((unsigned)n_items), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
+                           (int)n_items, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
+                           (const float*)s_in, (float*)s_out);
+    else
+        hipLaunchKernelGGL(lattice_prepare_kernel<double>, dim3((unsigned)n_items), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
+                           ptrs, (int)n_items, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
+                           (const double*)s_in, (double*)s_out);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 extern "C" size_t chx_compose_maps_vjp_workspace_bytes(int64_t E, int64_t B) {
     return (E < 1 || B < 1) ? 0 : (size_t)E * B * 49 * sizeof(double);
 }

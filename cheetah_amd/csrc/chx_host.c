@@ -113,7 +113,89 @@ static PyObject* host_run_track(PyObject* self, PyObject* const* args, Py_ssize_
     return res;
 }
 
+/* ---- a stretch of lattice ([run | active cavity]+) in ONE C call: chx_lattice_track (two launches for the whole stretch) ------ */
+typedef int (*lattice_track_fn)(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
+                                void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, void* stream);
+static lattice_track_fn p_lattice_track = NULL;
+
+typedef struct {
+    const int64_t* table;
+    int64_t n_items, n_elems, n_ptrs;
+    void* state;
+    size_t state_bytes;
+    int code;
+} lattice_plan;
+
+static void lattice_free(PyObject* cap) { free(PyCapsule_GetPointer(cap, "chx.lattice_plan")); }
+
+static PyObject* host_bind_lattice(PyObject* self, PyObject* args) {
+    unsigned long long addr;
+    if (!PyArg_ParseTuple(args, "K", &addr)) return NULL;
+    p_lattice_track = (lattice_track_fn)(uintptr_t)addr;
+    Py_RETURN_NONE;
+}
+
+/* lattice_plan(table address (device), n_items, n_elems, n_ptrs, state address, state bytes, dtype code) -> capsule */
+static PyObject* host_lattice_plan(PyObject* self, PyObject* args) {
+    unsigned long long table, state, state_bytes;
+    long long n_items, n_elems, n_ptrs;
+    int code;
+    if (!PyArg_ParseTuple(args, "KLLLKKi", &table, &n_items, &n_elems, &n_ptrs, &state, &state_bytes, &code)) return NULL;
+    lattice_plan* p = (lattice_plan*)malloc(sizeof(lattice_plan));
+    if (!p) return PyErr_NoMemory();
+    p->table = (const int64_t*)(uintptr_t)table;
+    p->n_items = n_items; p->n_elems = n_elems; p->n_ptrs = n_ptrs;
+    p->state = (void*)(uintptr_t)state;
+    p->state_bytes = (size_t)state_bytes;
+    p->code = code;
+    return PyCapsule_New(p, "chx.lattice_plan", lattice_free);
+}
+
+/* lattice_track(plan, x, N, energy, s_in | None, mass_eV, n_charges, device_index) -> (out, energy_out, s_out | None) */
+static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+    if (nargs != 8) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8 arguments"); return NULL; }
+    if (!p_lattice_track) { PyErr_SetString(PyExc_RuntimeError, "cheetah_amd._chxhost is not bound to chx_lattice_track"); return NULL; }
+    lattice_plan* p = (lattice_plan*)PyCapsule_GetPointer(args[0], "chx.lattice_plan");
+    if (!p) return NULL;
+    PyObject *x = args[1], *energy = args[3], *s_in = args[4];
+    const long long N = PyLong_AsLongLong(args[2]);
+    const double mass = PyFloat_AsDouble(args[5]), nq = PyFloat_AsDouble(args[6]);
+    if (PyErr_Occurred()) return NULL;
+    void *xp, *ep, *sp = NULL, *op, *eop, *sop = NULL, *stream;
+    if (tensor_ptr(x, &xp) || tensor_ptr(energy, &ep)) return NULL;
+    PyObject* out = PyObject_CallOneArg(g_empty_like, x);
+    if (!out) return NULL;
+    PyObject* e_out = PyObject_CallOneArg(g_empty_like, energy);
+    if (!e_out) { Py_DECREF(out); return NULL; }
+    PyObject* s_out = Py_None;
+    if (s_in != Py_None) {
+        s_out = PyObject_CallOneArg(g_empty_like, s_in);
+        if (!s_out || tensor_ptr(s_in, &sp) || tensor_ptr(s_out, &sop)) { Py_DECREF(out); Py_DECREF(e_out); Py_XDECREF(s_out); return NULL; }
+    } else {
+        Py_INCREF(Py_None);
+    }
+    PyObject* st = PyObject_CallOneArg(g_raw_stream, args[7]);
+    if (!st || tensor_ptr(out, &op) || tensor_ptr(e_out, &eop)) { Py_XDECREF(st); Py_DECREF(out); Py_DECREF(e_out); Py_DECREF(s_out); return NULL; }
+    stream = PyLong_AsVoidPtr(st);
+    Py_DECREF(st);
+    const int rc = p_lattice_track(p->table, p->n_items, p->n_elems, p->n_ptrs, ep, mass, nq, p->code, p->state, p->state_bytes, xp, op,
+                                   (int64_t)N, eop, sp, sop, stream);
+    if (rc != 0) {
+        Py_DECREF(out); Py_DECREF(e_out); Py_DECREF(s_out);
+        PyErr_Format(g_error ? g_error : PyExc_RuntimeError, "chx_lattice_track failed with status %d", rc);
+        return NULL;
+    }
+    PyObject* res = PyTuple_Pack(3, out, e_out, s_out);
+    Py_DECREF(out); Py_DECREF(e_out); Py_DECREF(s_out);
+    return res;
+}
+
 static PyMethodDef methods[] = {
+    {"bind_lattice", host_bind_lattice, METH_VARARGS, "bind_lattice(chx_lattice_track address)"},
+    {"lattice_plan", host_lattice_plan, METH_VARARGS, "lattice_plan(table addr, n_items, n_elems, n_ptrs, state addr, state bytes, dtype code) -> capsule"},
+    {"lattice_track", (PyCFunction)(void (*)(void))host_lattice_track, METH_FASTCALL,
+     "lattice_track(plan, x, N, energy, s_in | None, mass_eV, n_charges, device index) -> (out, energy_out, s_out | None)"},
     {"bind", host_bind, METH_VARARGS, "bind(chx_run_track address, torch.empty_like, raw stream getter, error class)"},
     {"plan", host_plan_new, METH_VARARGS, "plan(kinds addr, pointer-table addr, E, state addr, state bytes, dtype code) -> capsule"},
     {"run_track", (PyCFunction)(void (*)(void))host_run_track, METH_FASTCALL,

@@ -544,6 +544,24 @@ int chx_sc_convolve_halo_consume(void* rho, const void* Ghat, const double* scal
 int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
                             const void* energy, const void* dt, double mass_eV, int64_t N, const int32_t* bins, int dtype,
                             const void* post_map, void* state, size_t state_bytes, int unpermute, void* x_out, void* stream);
+/* A STRETCH of lattice — [run of skippable elements | active Cavity]+ with scalar device settings, ONE beam — in two launches:
+ * what Segment.track's element-by-element walk (segment.py:545-574; cavity.py:100-251 per cavity) does with two launches and
+ * ~8 us of host time per item. Launch 1 (chx_lattice_prepare, a workgroup per item): every run's composed map, every cavity's
+ * map and coefficient row for the reference energy it receives (walked through the cavities in front of it), the outgoing
+ * energy and path length. Launch 2: every particle through all items in registers. Bit-identical to tracking the items one by
+ * one with chx_run_track / chx_cavity_track_scalars.
+ *  table (device, int64 words): items[n_items][4] = {0 run | 1 cavity, elements E, first element, 0}, elem_kind[n_elems],
+ *    elem_poff[n_elems] (index of the element's first pointer), ptrs[n_ptrs] (device addresses of the settings, each kind's
+ *    parameters in chx_build_rmatrix order; a cavity: length, voltage, phase, frequency);
+ *  state: chx_lattice_state_bytes(n_items, n_elems) bytes of device scratch that belong to the plan;
+ *  energy, energy_out, s_in, s_out: one value of `dtype` each (s_in / s_out may both be NULL). */
+size_t chx_lattice_state_bytes(int64_t n_items, int64_t n_elems);
+int chx_lattice_prepare(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
+                        double n_charges, int dtype, void* state, size_t state_bytes, void* energy_out, const void* s_in, void* s_out,
+                        void* stream);
+int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
+                      double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
+                      void* energy_out, const void* s_in, void* s_out, void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),

@@ -38,7 +38,12 @@ def test_small_beam_steps_replay_from_a_graph(which):
     assert g["replay_equals_eager"] is True
     if which.startswith("control"):
         assert g["replay_follows_in_place_settings"] is True
-    assert g["graph_replay_us"] < g["eager_us"]
+    if which == "linac":
+        # the eager step of this lattice is ONE chx_lattice_track call (two launches; Segment._lattice_stretch): 40 us against the
+        # 600 us of the element-by-element walk — a replayed graph (44 us) has nothing left to win
+        assert g["eager_us"] < 120 and g["graph_replay_us"] < 120
+    else:
+        assert g["graph_replay_us"] < g["eager_us"]
 
 
 def test_replay_follows_settings_changed_outside_the_step_on_cached_paths():

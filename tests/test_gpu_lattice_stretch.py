@@ -1,0 +1,155 @@
+"""`Segment.track` hands a stretch [run of skippable elements | active Cavity]+ with scalar settings to the device in ONE call
+(chx_lattice_track: two launches for the whole stretch; Segment._lattice_stretch) — particles, energy and path length must
+equal, BIT FOR BIT, the reference's walk element by element (/root/reference/cheetah/accelerator/segment.py:545-574,
+cavity.py:100-251), i.e. this package's own per-element path; the reference values themselves: tests/golden/cavity.npz and the
+linac of tests/golden (test_gpu_parity.py). Elements that do not qualify end a stretch and are tracked as before."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _spy():
+    from cheetah_amd.accelerator import segment
+
+    calls = []
+    host = segment._lib.host()
+
+    class Spy:
+        def __getattr__(self, name):
+            fn = getattr(host, name)
+            if name != "lattice_track":
+                return fn
+            return lambda *a: (calls.append(a[2]), fn(*a))[1]
+
+    return calls, Spy()
+
+
+def _walk(seg, beam):
+    """`Segment.track` item by item (merged runs through chx_run_track, cavities through chx_cavity_track_scalars): the path the
+    stretch replaces."""
+    from cheetah_amd.accelerator.segment import Segment
+
+    orig = Segment._lattice_stretch
+    Segment._lattice_stretch = lambda self, plan, i, incoming: None
+    try:
+        return seg.track(beam)
+    finally:
+        Segment._lattice_stretch = orig
+
+
+def _linac(ca, dt, cells, cavity_type="standing_wave", phase=-10.0):
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    els = []
+    for i in range(cells):
+        els += [ca.Drift(t(0.3), **kw), ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw),
+                ca.HorizontalCorrector(t(0.05), angle=t(1e-4 * (i + 1)), **kw),
+                ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(phase + 3 * i), frequency=t(1.3e9), cavity_type=cavity_type, **kw)]
+    return els
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("cavity_type", ["standing_wave", "traveling_wave"])
+def test_stretch_equals_element_by_element(dt, cavity_type):
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(3)
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_007, energy=t(6e6), sigma_p=t(1e-3), sigma_tau=t(1e-4), **kw)
+    els = _linac(ca, dt, 6, cavity_type)
+    els += [ca.Drift(t(0.4), **kw)]                              # a run behind the last cavity
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(beam)
+        assert calls == [10_007], calls                            # ONE stretch call for the 25 elements
+        with torch.no_grad():
+            ref = _walk(seg, beam)
+            one_by_one = beam
+            for e in els:
+                one_by_one = e.track(one_by_one)
+        assert torch.equal(out.particles, ref.particles)
+        # (element by element WITHOUT merging the runs differs by the rounding of the merged maps, like the reference's own
+        # Segment.track does from its elements tracked one after the other)
+        scale = one_by_one.particles.abs().amax(dim=0)
+        assert ((out.particles - one_by_one.particles).abs().amax(dim=0) / scale).max() < (1e-5 if dt == torch.float32 else 1e-13)
+        assert torch.equal(out.energy, ref.energy) and out.energy.shape == ()
+        assert torch.equal(out.s, ref.s)
+        assert float(out.energy) > 1e8                             # six cavities of 18 MV
+        # deceleration (the other branch of cavity.py:157) and an in-place edit of a setting: the device reads the settings
+        els[15].phase.fill_(170.0)                                  # (the fourth cavity: the beam has 60 MeV by then)
+        els[7].voltage.mul_(0.5)
+        calls.clear()
+        with torch.no_grad():
+            out2 = seg.track(beam)
+            ref2 = _walk(seg, beam)
+        assert calls == [10_007]
+        assert torch.isfinite(out2.particles).all() and float(out2.energy) < float(out.energy) - 3e7
+        assert torch.equal(out2.particles, ref2.particles) and torch.equal(out2.energy, ref2.energy)
+        assert not torch.equal(out2.particles, out.particles)
+        # a new tensor assigned to a setting (moves the epoch: the table is re-derived)
+        els[1].k1 = t(5.5)
+        calls.clear()
+        with torch.no_grad():
+            out3 = seg.track(beam)
+            ref3 = _walk(seg, beam)
+        assert calls == [10_007] and torch.equal(out3.particles, ref3.particles)
+    finally:
+        segment._HOST = old
+
+
+def test_what_ends_a_stretch():
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(4)
+    beam = ca.ParticleBeam.from_parameters(num_particles=5_000, energy=t(5e7), **kw)
+    els = _linac(ca, dt, 2)
+    els += [ca.Screen(is_active=True, name="scr", **kw)]           # records the beam: the stretch ends in front of it
+    els += _linac(ca, dt, 2)
+    els += [ca.Quadrupole(t(0.2), k1=torch.tensor([1.0, 2.0], **kw), **kw)]   # vectorised: general path
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(beam)
+        assert calls == [5_000, 5_000], calls
+        read = seg.scr.get_read_beam().particles.clone()
+        with torch.no_grad():
+            ref = _walk(seg, beam)
+        assert out.particles.shape == (2, 5_000, 7) and torch.equal(out.particles, ref.particles)
+        assert torch.equal(read, seg.scr.get_read_beam().particles)
+        # a switched-off cavity is a skippable element (cavity.py:253-262): part of a run the device plan does not take -> the
+        # element-by-element path, same numbers
+        els[3].voltage = t(0.0)
+        calls.clear()
+        with torch.no_grad():
+            out2 = seg.track(beam)
+            ref2 = _walk(seg, beam)
+        assert torch.equal(out2.particles, ref2.particles)
+        # gradients: a trainable voltage keeps the differentiable path
+        els[3].voltage = t(18e6)
+        els[7].voltage = torch.nn.Parameter(t(18e6))
+        calls.clear()
+        out3 = seg.track(beam)
+        out3.particles[..., 5].square().mean().backward()
+        assert els[7].voltage.grad is not None and float(els[7].voltage.grad.abs()) > 0
+        # a float64 cavity in a float32 lattice raises like the reference's matmul does
+        bad = ca.Cavity(torch.tensor(1.0, dtype=torch.float64, device="cuda"), voltage=torch.tensor(1e6, dtype=torch.float64, device="cuda"),
+                        frequency=torch.tensor(1.3e9, dtype=torch.float64, device="cuda"), dtype=torch.float64, device="cuda")
+        with pytest.raises(RuntimeError):
+            with torch.no_grad():
+                ca.Segment(_linac(ca, dt, 1) + [bad]).track(beam)
+    finally:
+        segment._HOST = old

@@ -87,7 +87,10 @@ def test_segment_utilities_on_drawn_lattices_vs_reference(golden):
                 ref = g[f"{k}_along{tag}_{a}"]
                 v = v.cpu().numpy()
                 assert v.shape == ref.shape, (k, tag, a, v.shape, ref.shape)
-                assert np.allclose(v, ref, rtol=1e-8, atol=1e-9 * np.abs(ref).max()), (k, tag, a)
+                # beta_x = sigma_x^2 / emittance_x with emittance^2 = sigma_x^2 sigma_px^2 - cov_xpx^2: behind a long drift
+                # (beta of kilometres) the difference cancels ~1e6-fold, and the 1e-14 of the one-pass moments shows up as
+                # MEASURED 3.2e-8 at beta_x = 3684 m of lattice l3 (every other entry <= 1e-9): bound 4x for beta, 1e-8 otherwise
+                assert np.allclose(v, ref, rtol=1.3e-7 if a == "beta_x" else 1e-8, atol=1e-9 * np.abs(ref).max()), (k, tag, a)
         seg2 = build(ca, root)
         seg2.set_attrs_on_every_element(ca.Quadrupole, k1=torch.tensor(1.25, **KW))
         seg2.set_attrs_on_every_element(ca.Drift, is_recursive=False, length=torch.tensor(0.123, **KW))
