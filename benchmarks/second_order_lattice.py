@@ -1,37 +1,60 @@
 #!/usr/bin/env python3
-"""100-element FODO tracked with the second-order maps (tracking_method="second_order"), 1e6 and 1e4 float32 particles: wall time per
-Segment.track and the kernel time of one element (HIP events around 50 back-to-back applications)."""
-import os, sys, time
+"""100-element FODO tracked with second-order maps (bench.py's SECOND_ORDER_FODO100) and the two kernels per element kind:
+ms per track and us per element pass at 1e6 particles; A/B of builds inside one gpurun call."""
+import os
+import sys
+import time
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import cheetah_amd as ca
+import cheetah_amd as ca  # noqa: E402
+
 dt = torch.float32
 kw = {"dtype": dt, "device": "cuda"}
-t = lambda v: torch.tensor(v, **kw)
+tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
 so = {"tracking_method": "second_order"}
 els = []
 for _ in range(25):
-    els += [ca.Quadrupole(t(0.2), k1=t(4.2), **so, **kw), ca.Drift(t(0.8), **so, **kw), ca.Quadrupole(t(0.2), k1=t(-4.2), **so, **kw),
-            ca.Drift(t(0.8), **so, **kw)]
+    els += [ca.Quadrupole(tt(0.2), k1=tt(4.2), **so, **kw), ca.Drift(tt(0.8), **so, **kw),
+            ca.Quadrupole(tt(0.2), k1=tt(-4.2), **so, **kw), ca.Drift(tt(0.8), **so, **kw)]
 seg = ca.Segment(els)
-for n in (1_000_000, 10_000):
-    beam = ca.ParticleBeam.from_parameters(num_particles=n, **kw)
-    with torch.no_grad():
-        for _ in range(3):
-            seg.track(beam)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+beam = ca.ParticleBeam.from_parameters(num_particles=1_000_000, **kw)
+lin = ca.Segment([ca.Quadrupole(tt(0.2), k1=tt(4.2), **kw) if i % 2 == 0 else ca.Drift(tt(0.8), **kw) for i in range(100)])
+with torch.no_grad():
+    for _ in range(3):
+        lin.track_elementwise(beam)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        lin.track_elementwise(beam)
+    torch.cuda.synchronize()
+    print(f"calibration: linear apply, 100 passes: {(time.perf_counter() - t0) / 10 / 100 * 1e6:.2f} us per pass on this box")
+with torch.no_grad():
+    for _ in range(3):
+        seg.track(beam)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
         for _ in range(10):
             seg.track(beam)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 10 * 1e3
+        best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+    print(f"second-order FODO100, 1e6 particles: {best:.3f} ms per track = {best * 10:.2f} us per element pass "
+          f"({56e6 * 100 / (best * 1e-3) / 1e12:.2f} TB/s)")
+    for name, e in (("quadrupole", els[0]), ("drift", els[1]), ("dipole", ca.Dipole(tt(0.5), angle=tt(0.03), **so, **kw)),
+                    ("sextupole", ca.Sextupole(tt(0.15), k2=tt(25.0), **so, **kw))):
+        for _ in range(3):
+            e.track(beam)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        T = els[0].second_order_transfer_map(beam.energy, beam.species)
-        x = beam.particles
+        T = e.second_order_transfer_map(beam.energy, beam.species)
         from cheetah_amd import _ops
-        for _ in range(5):
-            _ops.apply_second_order(x, T)
+        torch.cuda.synchronize()
         e0.record()
         for _ in range(50):
-            _ops.apply_second_order(x, T)
-        e1.record(); torch.cuda.synchronize()
-    print(f"N={n}: Segment.track {ms:.3f} ms per track ({ms * 10:.1f} us per element); apply_second_order kernel {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
+            _ops.apply_second_order(beam.particles, T)
+        e1.record()
+        torch.cuda.synchronize()
+        nnz = int((T != 0).sum())
+        print(f"  {name:10s}: {e0.elapsed_time(e1) / 50 * 1e3:6.2f} us per pass, {nnz} non-zero entries of T")

@@ -10,6 +10,8 @@
 // Both are one streaming pass over particles[B][N][7] (56 B/particle fp32, 112 B fp64) through the same
 // LDS tile staging as chx_apply.hip; the per-particle arithmetic runs in fp64 whatever the storage
 // dtype is (transcendental-heavy but far below the HBM time of the pass on 256 CUs).
+#include <cstdlib>
+
 #include "chx_common.h"
 #include "chx_dual.h"
 
@@ -720,12 +722,20 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_kernel(const T* __rest
 
 
 // float32: TWO particles per lane in packed arithmetic (v_pk_mul_f32 / v_pk_fma_f32 on {particle p, particle p + 256}): every
-// coefficient fetched from LDS serves two particles and every instruction two multiply-adds — the one-particle kernel above
-// issues 196 LDS reads + 224 arithmetic instructions per particle and sits at 19 us for 1e6 particles (2.9 TB/s); per-lane
-// IEEE fma on both halves, so the results are bit-identical to it.
-__global__ __launch_bounds__(CHX_BLOCK) void second_order_pk_kernel(const float* __restrict__ x_in, const float* __restrict__ Tt,
-                                                                    float* __restrict__ x_out, int64_t B, int64_t Bx, int64_t BT,
-                                                                    int64_t N, int in_vec_ok, int out_vec_ok) {
+// coefficient fetched from LDS serves two particles and every instruction two multiply-adds; per-lane IEEE fma on both halves,
+// the same products in the same order as the one-particle kernel above.
+// Round 4 (profiles/r04_second_order.md; kernel trace at 1e6 particles, the linear apply = 9.1 us): the round-3 form of this
+// kernel took 17.9 us — 6 of them arithmetic, 1.8 the coefficient fill in FRONT of the tile loads (its two dependent global
+// loads stalled every workgroup before it had requested a single row), ~2.6 the lower occupancy (74 VGPRs: the 28 products of
+// both particles were kept in registers) and a third barrier. Now: the rows are requested first and the coefficients folded
+// while they fly; the products x_j x_k are formed where they are used (same rounding: a product, then an fma), which brings the
+// kernel to the apply kernel's 8 waves per SIMD; groups of four coefficients that are all zero are skipped (a drift's tensor has
+// 15 non-zero entries of 343, a quadrupole's 27: track_methods.py:80-296) — wave-uniform jumps over a ds_read_b128, four packed
+// products and four packed FMAs; a lane overwrites the rows it has read itself, so two barriers suffice. (Wave-private staging
+// without any workgroup barrier was measured slower, 19.4 us: as for the linear apply at this size.)
+__global__ __launch_bounds__(CHX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void second_order_pk_kernel(const float* __restrict__ x_in, const float* __restrict__ Tt, float* __restrict__ x_out, int64_t B,
+                            int64_t Bx, int64_t BT, int64_t N, int in_vec_ok, int out_vec_ok) {
     constexpr int TP = 2 * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) float lds[TP * 7];
     __shared__ __attribute__((aligned(16))) float U[7 * 28];   // rows of 28 = seven 16-byte groups: read as ds_read_b128
@@ -737,7 +747,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_pk_kernel(const float*
     const int64_t in_row = (Bx == 1) ? 0 : b;
     const bool in_vec = in_vec_ok && (((in_row * N * 7 * (int64_t)sizeof(float)) & 15) == 0);
     const bool out_vec = out_vec_ok && (((b * N * 7 * (int64_t)sizeof(float)) & 15) == 0);
+    tile_load<float, TP>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec, !(Bx == 1 && B > 1));
     if (threadIdx.x < 7 * 28) {
+        // U[i][(j,k)], j <= k: T_ijk + T_ikj folded (element.py:207-217 sums over all j, k)
         const int i = threadIdx.x / 28;
         int r = threadIdx.x - i * 28, j = 0;
         while (r >= 7 - j) { r -= 7 - j; ++j; }
@@ -745,36 +757,49 @@ __global__ __launch_bounds__(CHX_BLOCK) void second_order_pk_kernel(const float*
         const float* Tb = Tt + ((BT == 1) ? 0 : b) * 343 + i * 49;
         U[threadIdx.x] = (j == k) ? Tb[j * 7 + k] : Tb[j * 7 + k] + Tb[k * 7 + j];
     }
-    tile_load<float, TP>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec, !(Bx == 1 && B > 1));
     __syncthreads();
+    unsigned long long groups;
+    {
+        const int lane = threadIdx.x & 63;
+        bool nz = false;
+        if (lane < 49) {
+            const chx_v4f u = *reinterpret_cast<const chx_v4f*>(&U[4 * lane]);
+            nz = u[0] != 0.0f || u[1] != 0.0f || u[2] != 0.0f || u[3] != 0.0f;
+        }
+        groups = __ballot(nz);
+    }
     const int p0 = threadIdx.x, p1 = threadIdx.x + CHX_BLOCK;
     const bool on0 = p0 < np, on1 = p1 < np;
-    chx_v2f x[7], q[28], y[7];
+    chx_v2f x[7], y[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) x[j] = chx_v2f{on0 ? lds[p0 * 7 + j] : 0.0f, on1 ? lds[p1 * 7 + j] : 0.0f};
-    {
-        int c = 0;
+    // The products that are skipped are exact zeros for finite coordinates; a non-finite coordinate makes EVERY output NaN in the
+    // dense sum (0 * inf, 0 * nan in each row): restored explicitly. (An overflow of x_j x_k at finite coordinates of ~1e19 is not.)
+    bool bad0 = false, bad1 = false;
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
-#pragma unroll
-            for (int k = j; k < 7; ++k) q[c++] = x[j] * x[k];
+    for (int j = 0; j < 7; ++j) {
+        bad0 = bad0 || !isfinite(x[j].x);
+        bad1 = bad1 || !isfinite(x[j].y);
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         chx_v2f acc = chx_v2f{0.0f, 0.0f};
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
+            if (!((groups >> (i * 7 + m)) & 1ull)) continue;           // wave-uniform
             const chx_v4f u = *reinterpret_cast<const chx_v4f*>(&U[i * 28 + 4 * m]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                constexpr int kJ[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
+                constexpr int kK[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
                 const int c = 4 * m + e;
                 const chx_v2f uu = {u[e], u[e]};
-                acc = c == 0 ? uu * q[0] : __builtin_elementwise_fma(uu, q[c], acc);   // (the first term is a product, as above)
+                const chx_v2f q = x[kJ[c]] * x[kK[c]];
+                acc = __builtin_elementwise_fma(uu, q, acc);
             }
         }
-        y[i] = acc;
+        y[i] = chx_v2f{bad0 ? __builtin_nanf("") : acc.x, bad1 ? __builtin_nanf("") : acc.y};
     }
-    __syncthreads();                       // (every lane has read its rows: the tile is overwritten in place)
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         if (on0) lds[p0 * 7 + j] = y[j].x;
