@@ -43,6 +43,24 @@ with torch.no_grad():
         best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
     print(f"second-order FODO100, 1e6 particles: {best:.3f} ms per track = {best * 10:.2f} us per element pass "
           f"({56e6 * 100 / (best * 1e-3) / 1e12:.2f} TB/s)")
+    dkd = {"tracking_method": "drift_kick_drift"}
+    for prec in ("double", "mixed", "storage"):
+        els2 = []
+        for _ in range(25):
+            els2 += [ca.Quadrupole(tt(0.2), k1=tt(4.2), **dkd, **kw), ca.Drift(tt(0.8), **dkd, **kw),
+                     ca.Quadrupole(tt(0.2), k1=tt(-4.2), **dkd, **kw), ca.Drift(tt(0.8), **dkd, **kw)]
+        for e in els2:
+            e.dkd_precision = prec
+        seg2 = ca.Segment(els2)
+        for _ in range(3):
+            seg2.track(beam)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            seg2.track(beam)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        print(f"drift-kick-drift FODO100 [{prec}]: {ms:.3f} ms per track ({56e6 * 100 / (ms * 1e-3) / 1e12:.2f} TB/s)")
     for name, e in (("quadrupole", els[0]), ("drift", els[1]), ("dipole", ca.Dipole(tt(0.5), angle=tt(0.03), **so, **kw)),
                     ("sextupole", ca.Sextupole(tt(0.15), k2=tt(25.0), **so, **kw))):
         for _ in range(3):

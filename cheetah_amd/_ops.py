@@ -719,11 +719,15 @@ def stack_params(values, dtype, device) -> tuple[torch.Tensor, torch.Size]:
     return torch.stack([v.to(dtype).expand(shape) for v in values], dim=-1).reshape(-1, len(values)), shape
 
 
-def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, storage_precision=False):
+#: `Element.dkd_precision` -> the `storage_precision` code of chx_dkd_track_p (0 float64 arithmetic, 1 float32, 2 mixed)
+DKD_PRECISION = {"double": 0, "storage": 1, "mixed": 2}
+
+
+def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, storage_precision=0):
     out = torch.empty((B, N, 7), dtype=x.dtype, device=x.device)
     e_out = torch.empty((B,), dtype=x.dtype, device=x.device)
     check(_lib.lib().chx_dkd_track_p(kind, ptr(x), ptr(p), ptr(e), mass_eV, n_charges, num_steps, fringe_at, B, x.shape[0],
-                                     p.shape[0], e.shape[0], N, dtype_code(x.dtype), 1 if storage_precision else 0, ptr(out),
+                                     p.shape[0], e.shape[0], N, dtype_code(x.dtype), int(storage_precision), ptr(out),
                                      ptr(e_out), stream_ptr()), "chx_dkd_track_p")
     return out, e_out
 
@@ -785,11 +789,12 @@ class DkdTrack(torch.autograd.Function):
 
 
 def dkd_track(kind: int, particles, params, param_shape, energy, mass_eV: float, n_charges: float, num_steps: int = 1,
-              fringe_at: int = 3, storage_precision: bool = False):
+              fringe_at: int = 3, storage_precision: int = 0):
     """One drift-kick-drift element (chx_dkd_track_p): particles (..., N, 7), params (Bp, P) with vector shape
     `param_shape`, energy (...). Returns (particles_out (*batch, N, 7), ref_energy (*energy/param batch)).
-    `storage_precision`: evaluate float32 beams in float32 (the reference's arithmetic width) instead of float64; the
-    differentiable path always runs in float64 (dual numbers)."""
+    `storage_precision` (DKD_PRECISION): float32 beams in float64 arithmetic (0), in float32 like the reference's own tensor code
+    (1), or mixed (2: the longitudinal pair in float64, the rest in float32; Drift and Quadrupole); the differentiable path always
+    runs in float64 (dual numbers)."""
     require_device(particles, params, energy)
     N = particles.shape[-2]
     eb_shape = bshapes(param_shape, energy.shape)           # batch shape of the outgoing energy

@@ -242,11 +242,16 @@ class Element(nn.Module):
             species=incoming.species,
         )
 
-    #: arithmetic of the drift-kick-drift (Bmad-X) kernels for float32 beams: "double" (default) evaluates every particle in
-    #: float64 and rounds once — Bmad-X to ~1e-7 of a coordinate, fp64-VALU bound; "storage" evaluates in float32 like the
-    #: reference's own tensor code (cheetah/utils/bmadx.py runs in the beam dtype) — one HBM-bound pass, measured errors in
-    #: DESIGN.md section 6. Set on an element (`quad.dkd_precision = "storage"`) or on the class for a whole lattice.
-    dkd_precision = "double"
+    #: arithmetic of the drift-kick-drift (Bmad-X) kernels for float32 beams (float64 beams are evaluated in float64):
+    #:  "mixed" (default)  the longitudinal pair — the (tau, delta) <-> (z, pz) conversions, the z accumulator, the low-energy
+    #:                     correction — and the misalignment shift in float64, everything else in float32 (Drift, Quadrupole;
+    #:                     Dipole and TransverseDeflectingCavity are evaluated in float64). tau and delta as accurate as
+    #:                     "double", the transverse coordinates to one float32 rounding per element;
+    #:  "double"           every particle in float64, rounded once per element — 1.5 x the time of "mixed" (fp64-VALU bound);
+    #:  "storage"          everything in float32 like the reference's own tensor code (cheetah/utils/bmadx.py runs in the beam
+    #:                     dtype) — 0.9 x the time, tau / delta lose three to four digits over a lattice.
+    #: Measured errors: DESIGN.md section 6. Set on an element (`quad.dkd_precision = "double"`) or on the class for a lattice.
+    dkd_precision = "mixed"
     #: chx_dkd_kind / chx_t_kind of the element (include/chx.h); None = method not available
     _dkd_kind: int | None = None
     _t_kind: int | None = None
@@ -285,8 +290,8 @@ class Element(nn.Module):
         kernel pass (chx_dkd_track); the outgoing energy is the reference energy recomputed from p0c."""
         assert isinstance(incoming, ParticleBeam), \
             "Drift-kick-drift tracking is currently only supported for `ParticleBeam`."
-        if self.dkd_precision not in ("double", "storage"):
-            raise ValueError(f"dkd_precision must be 'double' or 'storage', got {self.dkd_precision!r}")
+        if self.dkd_precision not in _ops.DKD_PRECISION:
+            raise ValueError(f"dkd_precision must be 'double', 'mixed' or 'storage', got {self.dkd_precision!r}")
         x, energy = incoming.particles, incoming.energy
         if x.dim() == 2 and x.is_cuda and energy.dim() == 0 and energy.dtype == x.dtype and energy.device == x.device and not (
                 torch.is_grad_enabled() and (x.requires_grad or energy.requires_grad)):
@@ -298,7 +303,7 @@ class Element(nn.Module):
                 N = x.shape[0]
                 out, e_out = _ops._dkd_raw(self._dkd_kind, _ops.aligned(x).reshape(1, N, 7), params, energy.reshape(1),
                                            species.mass_eV_float, species.num_elementary_charges_float, num_steps, fringe, 1, N,
-                                           self.dkd_precision == "storage")
+                                           _ops.DKD_PRECISION[self.dkd_precision])
                 return ParticleBeam(out.reshape(N, 7), e_out.reshape(()), particle_charges=incoming.particle_charges,
                                     survival_probabilities=incoming.survival_probabilities, s=incoming.s + self.length,
                                     species=species)
@@ -312,7 +317,7 @@ class Element(nn.Module):
         x = incoming.particles if incoming.particles.dtype == dtype else incoming.particles.to(dtype)
         particles, ref_energy = _ops.dkd_track(self._dkd_kind, x, params, pshape, energy,
                                                species.mass_eV_float, species.num_elementary_charges_float, num_steps,
-                                               fringe, storage_precision=self.dkd_precision == "storage")
+                                               fringe, storage_precision=_ops.DKD_PRECISION[self.dkd_precision])
         if ref_energy.dtype != incoming.energy.dtype:
             ref_energy = ref_energy.to(incoming.energy.dtype)
         if ref_energy.requires_grad and not incoming.energy.requires_grad:

@@ -873,7 +873,7 @@ class Segment(Element):
             cls = type(e)
             if e._tracking_method != "drift_kick_drift" or e._dkd_kind is None or cls.track is not Element.track \
                     or cls._track_drift_kick_drift is not Element._track_drift_kick_drift \
-                    or cls._track_internal is not Element._track_internal or e.dkd_precision not in ("double", "storage"):
+                    or cls._track_internal is not Element._track_internal or e.dkd_precision not in _ops.DKD_PRECISION:
                 break
             p = e._dkd_params_stacked(x.dtype, x.device)
             if p is None:
@@ -883,7 +883,7 @@ class Segment(Element):
             params.append(p)
             steps.append(n)
             fringes.append(f)
-            storage.append(1 if e.dkd_precision == "storage" else 0)
+            storage.append(_ops.DKD_PRECISION[e.dkd_precision])
             j += 1
         if j - i < 2:
             return None

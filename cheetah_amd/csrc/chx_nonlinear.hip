@@ -341,6 +341,129 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
     tile_store<T, TP>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec, true);
 }
 
+// ---- float32 beams, MIXED arithmetic (Drift, Quadrupole): the default of float32 beams --------------------------------------
+// Where does a float32 evaluation of the Bmad-X maps lose its digits? Not in the transverse map (x, px, y, py move by parts in
+// 1e3 per element; seven significant digits of each step are what the float32 STORAGE keeps anyway) — in the longitudinal pair:
+// pz = (p - p0c) / p0c and delta = (E - E_ref) / p0c subtract numbers that agree to three or four digits (bmadx.py:7-56), the
+// low-energy correction subtracts beta - beta0 ~ 1e-8 (bmadx.py:184-216), and z collects increments of 1e-9 into a value of
+// 1e-5. Measured over the 100 elements of the benchmark lattice: tau off by 1e-2 of its scale, delta by 4e-4 in float32
+// arithmetic (the reference's own float32 run: 8e-3 / 4e-5), 5e-7 / 7e-14 in float64 arithmetic — at 2-3 times the kernel time,
+// because then the per-particle cos / sin / cosh / sinh of the quadrupole and five square roots run in fp64 as well.
+// Here: the (tau, delta) <-> (z, pz) conversions, the z accumulator, the low-energy correction and the misalignment shift run in
+// fp64 — one square root and three divisions per particle (delta' is formed from the particle's own energy: pz does not change
+// inside these two elements, so the round trip through p is the identity) — everything else in float32, including the
+// increments of z (a RELATIVE error of 1e-7 on an increment is 1e-16 of z's scale).
+template <int KIND>
+__global__ __launch_bounds__(CHX_BLOCK) void dkd_mixed_kernel(const float* __restrict__ x_in, const float* __restrict__ params,
+                                                              const float* __restrict__ energy, double mc2, double nq, int num_steps,
+                                                              int P, int64_t B, int64_t Bx, int64_t Bp, int64_t Be, int64_t N,
+                                                              float* __restrict__ x_out, float* __restrict__ energy_out,
+                                                              int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    __shared__ double cst_[C_N + 4];
+    enum { C_ETOT = C_N + 1, C_BETA0, C_ME2 };
+    const int64_t tiles_per_row = (N + TP - 1) / TP;
+    const int64_t b = blockIdx.x / tiles_per_row;
+    const int64_t t = blockIdx.x - b * tiles_per_row;
+    const int64_t n0 = t * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const int64_t in_row = (Bx == 1) ? 0 : b;
+    const bool in_vec = in_vec_ok && (((in_row * N * 7 * (int64_t)sizeof(float)) & 15) == 0);
+    const bool out_vec = out_vec_ok && (((b * N * 7 * (int64_t)sizeof(float)) & 15) == 0);
+    tile_load<float, TP>(x_in + (in_row * N + n0) * 7, lds, np * 7, in_vec, !(Bx == 1 && B > 1));   // rows first: the constants
+    if (threadIdx.x == 0) {                                                                          // are formed under the loads
+        const float Eb = energy[(Be == 1) ? 0 : b];
+        double par[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) par[k] = (double)params[((Bp == 1) ? 0 : b) * P + k];
+        dkd_constants<double>(KIND, par, (double)Eb, mc2, nq, 3, cst_);
+        const double p0c = cst_[C_P0C];
+        const double e_tot = sqrt(p0c * p0c + mc2 * mc2);
+        cst_[C_ETOT] = e_tot;
+        cst_[C_BETA0] = p0c / e_tot;
+        cst_[C_ME2] = (mc2 / e_tot) * (mc2 / e_tot);
+        if (t == 0 && energy_out) {
+            const float m = (float)mc2;
+            const float p0 = sqrtf(Eb * Eb - m * m);
+            energy_out[b] = sqrtf(p0 * p0 + m * m);
+        }
+    }
+    __syncthreads();
+    const int p = threadIdx.x;
+    if (p < np) {
+        const double E = cst_[C_E], p0c = cst_[C_P0C];
+        float x = lds[p * 7], px = lds[p * 7 + 1], y = lds[p * 7 + 2], py = lds[p * 7 + 3];
+        const double tau = (double)lds[p * 7 + 4], delta = (double)lds[p * 7 + 5];
+        // (tau, delta) -> (z, pz), bmadx.py:7-31, fp64
+        const double en = E + delta * p0c;
+        const double pc = sqrt(en * en - mc2 * mc2);
+        const double beta = pc / en;
+        double z = -beta * tau;
+        const double pz = (pc - p0c) / p0c;
+        const float pzf = (float)pz, mc2f = (float)mc2, p0cf = (float)p0c;
+        const float relp = 1.0f + pzf;
+        if (KIND == CHX_DKD_DRIFT) {                                  // bmadx.py:263-298
+            const float L = (float)cst_[C_A];
+            const float ir = __builtin_amdgcn_rcpf(relp);
+            const float Px = px * ir, Py = py * ir;
+            const float Pxy2 = Px * Px + Py * Py;
+            const float Pl = __builtin_amdgcn_sqrtf(1.0f - Pxy2);
+            const float iPl = __builtin_amdgcn_rcpf(Pl);
+            const float pcf = p0cf * relp, m2 = mc2f * mc2f;
+            const float a = (m2 * (2.0f * pzf + pzf * pzf)) * __builtin_amdgcn_rcpf(pcf * pcf + m2);
+            const float so_a = a * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(1.0f + a) + 1.0f);          // sqrt_one(a)
+            const float so_b = -Pxy2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(1.0f - Pxy2) + 1.0f);   // sqrt_one(-Pxy2)
+            x = x + L * Px * iPl;
+            y = y + L * Py * iPl;
+            z = z + (double)(L * (so_a + so_b * iPl));
+        } else {                                                      // quadrupole.py:168-251, bmadx.py:219-252
+            const double xo = cst_[C_XO], yo = cst_[C_YO], sn = cst_[C_SIN], cs = cst_[C_COS];
+            {   // offset_set: the shift by the misalignment in fp64 (it may be hundreds of beam sizes), the rotation with it
+                const double xi = (double)x - xo, yi = (double)y - yo;
+                const float xr = (float)(xi * cs + yi * sn), yr = (float)(-xi * sn + yi * cs);
+                const float pxr = (float)((double)px * cs + (double)py * sn), pyr = (float)(-(double)px * sn + (double)py * cs);
+                x = xr; y = yr; px = pxr; py = pyr;
+            }
+            const float L = (float)cst_[C_A], b1 = (float)cst_[C_B];
+            const float step = L / (float)num_steps;
+            const F32 k1 = mkf(b1 * __builtin_amdgcn_rcpf(L * relp));
+            const QuadCoef<F32> tx = quad_coefficients<F32>(-k1, mkf(step), mkf(relp));
+            const QuadCoef<F32> ty = quad_coefficients<F32>(k1, mkf(step), mkf(relp));
+            // low_energy_z_correction (bmadx.py:184-216) in fp64: beta - beta0 cancels to 1e-8
+            double dzc;
+            {
+                const double e_tot = cst_[C_ETOT], beta0 = cst_[C_BETA0], me2 = cst_[C_ME2];
+                const double b0pz = beta0 * pz, b02 = beta0 * beta0, ds = (double)step;
+                if (mc2 * (b0pz * b0pz) < 3e-7 * e_tot)
+                    dzc = ds * pz * (1.0 - 3.0 * (pz * b02) / 2.0 + pz * pz * b02 * (2.0 * b02 - me2 / 2.0)) * me2;
+                else
+                    dzc = ds * (beta - beta0) / beta0;                // (beta of this particle: pc / en above)
+            }
+            for (int s = 0; s < num_steps; ++s) {
+                const float dz = tx.c1.v * (x * x) + tx.c2.v * x * px + tx.c3.v * (px * px) + ty.c1.v * (y * y) + ty.c2.v * y * py +
+                                 ty.c3.v * (py * py);
+                const float xn = tx.a11.v * x + tx.a12.v * px, pxn = tx.a21.v * x + tx.a22.v * px;
+                const float yn = ty.a11.v * y + ty.a12.v * py, pyn = ty.a21.v * y + ty.a22.v * py;
+                x = xn; px = pxn; y = yn; py = pyn;
+                z = z + (double)dz + dzc;
+            }
+            {   // offset_unset
+                const double xi = (double)x * cs - (double)y * sn, yi = (double)x * sn + (double)y * cs;
+                const float pxr = (float)((double)px * cs - (double)py * sn), pyr = (float)((double)px * sn + (double)py * cs);
+                x = (float)(xi + xo); y = (float)(yi + yo); px = pxr; py = pyr;
+            }
+        }
+        // (z, pz) -> (tau, delta), bmadx.py:34-56: pz is unchanged, so p = pc and the particle's energy is `en` again
+        const double ref = cst_[C_ETOT];
+        lds[p * 7] = x; lds[p * 7 + 1] = px; lds[p * 7 + 2] = y; lds[p * 7 + 3] = py;
+        lds[p * 7 + 4] = (float)(-z / beta);
+        lds[p * 7 + 5] = (float)((en - ref) / p0c);
+        lds[p * 7 + 6] = 1.0f;
+    }
+    __syncthreads();
+    tile_store<float, TP>(x_out + (b * N + n0) * 7, lds, np * 7, out_vec, true);
+}
+
 // Backward of the above. dx[n][m] = sum_i dY[n][i] d out_i / d in_m (six passes, coordinate m seeded), and per
 // parameter k (then the energy) the workgroup's sum over its particles of dY . d out / d theta_k, written to
 // partials[b][tile][k] — summed by the caller (no atomics: deterministic, and 10 same-address atomics per workgroup
@@ -493,7 +616,23 @@ extern "C" int chx_dkd_track_p(int kind, const void* x_in, const void* params, c
     if (kind == CHX_DKD_QUADRUPOLE && num_steps < 1) return CHX_ERR_INVALID_ARG;
     if (fringe_at < 0 || fringe_at > 3) return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == CHX_F32 && storage_precision)
+    if (dtype == CHX_F32 && storage_precision == 2 && (kind == CHX_DKD_DRIFT || kind == CHX_DKD_QUADRUPOLE)) {
+        // mixed arithmetic (see dkd_mixed_kernel); the other kinds keep the fp64 evaluation
+        const int64_t tiles = ((N + CHX_BLOCK - 1) / CHX_BLOCK) * B;
+        if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+        const int P = chx_dkd_num_params(kind);
+        if (kind == CHX_DKD_DRIFT)
+            hipLaunchKernelGGL(dkd_mixed_kernel<CHX_DKD_DRIFT>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+                               (const float*)params, (const float*)energy, mass_eV, n_charges, num_steps, P, B, Bx, Bp, Be, N,
+                               (float*)x_out, (float*)energy_out, (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+        else
+            hipLaunchKernelGGL(dkd_mixed_kernel<CHX_DKD_QUADRUPOLE>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+                               (const float*)params, (const float*)energy, mass_eV, n_charges, num_steps, P, B, Bx, Bp, Be, N,
+                               (float*)x_out, (float*)energy_out, (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+        CHX_CHECK_LAUNCH();
+        return CHX_OK;
+    }
+    if (dtype == CHX_F32 && storage_precision == 1)
         return dispatch_dkd<float, F32>(kind, x_in, params, energy, mass_eV, n_charges, num_steps, fringe_at, B, Bx, Bp, Be, N, x_out,
                                         energy_out, s);
     return dtype == CHX_F32 ? dispatch_dkd<float>(kind, x_in, params, energy, mass_eV, n_charges, num_steps, fringe_at,

@@ -218,3 +218,43 @@ def test_dkd_precision_attribute_reaches_the_kernel():
     quad.dkd_precision = "half"
     with pytest.raises(ValueError):
         quad.track(beam)
+
+
+@pytest.mark.parametrize("kind,params,extra", [
+    ("drift", (1.0,), ()), ("quadrupole", (0.2, 4.2, 0.1, 1e-4, -1e-4), (10,)), ("quadrupole", (0.2, -4.2, 0.0, 0.0, 0.0), (1,)),
+    ("quadrupole", (1.0, 10.0, 0.5, 0.01, -0.02), (10,)), ("quadrupole", (0.3, 0.0, 0.0, 0.0, 0.0), (3,))])
+def test_mixed_precision_dkd_is_float64_grade_in_tau_and_delta(kind, params, extra):
+    """`Element.dkd_precision = "mixed"`, the default of float32 beams (dkd_mixed_kernel): the longitudinal pair in float64, the
+    transverse map in float32. Yardstick: the float64 kernel on the same float32 input (itself pinned to Bmad-X at 1e-14,
+    tests/test_nonlinear.py). tau and delta must come out at the rounding of the float32 store like the float64 arithmetic
+    does; x, px, y, py within a few float32 ulps of the coordinate's scale."""
+    import cheetah_amd  # noqa: F401
+    from cheetah_amd import _ops
+
+    torch.manual_seed(0)
+    N = 50_000
+    x = torch.randn(N, 7, device="cuda") * torch.tensor([2e-4, 4e-6, 2e-4, 4e-6, 8e-6, 2e-3, 0.0], device="cuda")
+    x[:, 6] = 1.0
+    E = torch.tensor(1e8, device="cuda")
+    k = _ops.DKD_KIND[kind]
+    p32 = torch.tensor([list(params)], device="cuda")
+    ref = _ops.dkd_track(k, x.double(), p32.double(), torch.Size(()), E.double(), 510998.95069, -1.0, *extra)[0]
+    scale = ref.abs().max(dim=0).values[:6]
+    got, e_mixed = _ops.dkd_track(k, x, p32, torch.Size(()), E, 510998.95069, -1.0, *extra, storage_precision=2)
+    dbl, e_double = _ops.dkd_track(k, x, p32, torch.Size(()), E, 510998.95069, -1.0, *extra, storage_precision=0)
+    assert got.dtype == torch.float32 and torch.all(got[:, 6] == 1) and torch.equal(e_mixed, e_double)
+    err = (got.double() - ref).abs().max(dim=0).values[:6] / scale
+    print(f"\nmixed {kind} {params}: " + " ".join(f"{float(v):.1e}" for v in err))
+    # MEASURED (units of the coordinate's scale; the float64 arithmetic gives 6e-8 = the rounding of the float32 store):
+    #   drift                                   x, y 3.5e-8, tau 5.1e-8, delta 4.4e-14
+    #   quadrupole, one step, on the axis       x ... py 1.8e-7, tau 5.0e-8, delta 4.4e-14
+    #   quadrupole, 10 steps, shifted by half a beam size: x ... py 6.2e-7 (ten float32 maps), tau 3.7e-8
+    #   quadrupole, 10 steps, k1 = 10, shifted by 100 beam sizes (the element of the reference's Bmad-X test): x ... py 1.2e-6,
+    #   tau 2.2e-6 — the path-length terms k1 x^2 L / 4 of the SHIFTED coordinate are 30 times tau's scale there and carry the
+    #   1e-7 of their float32 coefficients; `dkd_precision = "double"` is the setting for such a lattice
+    # Bounds 4x measured.
+    far_off_axis = kind == "quadrupole" and abs(params[3]) >= 1e-3
+    steps = extra[0] if extra else 1
+    assert float(err[5]) < 2e-13, err
+    assert float(err[4]) < (9e-6 if far_off_axis else 2.4e-7), err
+    assert float(err[:4].max()) < (5e-6 if far_off_axis else 2.5e-6 if steps > 1 else 7.2e-7), err
