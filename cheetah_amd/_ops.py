@@ -8,6 +8,7 @@ arithmetic on particle-sized or map-sized data happens inside libchx.
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 
 import torch
@@ -131,7 +132,10 @@ class _CloneInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, dst):
-        return dst.view_as(dst)
+        # the destination itself (declared modified in place), not a view of it: an in-place edit of the copy under autograd
+        # must not trip over "a view was created inside a custom Function"
+        ctx.mark_dirty(dst)
+        return dst
 
     @staticmethod
     def backward(ctx, grad):
@@ -165,7 +169,10 @@ def clone_many(tensors):
         lin = getattr(t, "_chx_lin", None)
         if lin is not None and lin.version == t._version:
             o._chx_lin = lin.rebound(o)
-        o._chx_origin = (t, t._version, o._version)
+        # (the ROOT of a chain of copies, held weakly: a copy of a copy must not keep every array in between — or its source
+        # — alive for as long as it lives itself)
+        root = _origin(t)
+        o._chx_origin = (weakref.ref(root), root._version, o._version)
     return out
 
 
@@ -545,9 +552,12 @@ def _origin(t: torch.Tensor) -> torch.Tensor:
     """The tensor `t` is an unmodified copy of (clone_many), followed through chains of copies; `t` itself otherwise."""
     while True:
         tag = getattr(t, "_chx_origin", None)
-        if tag is None or tag[2] != t._version or tag[0]._version != tag[1]:
+        if tag is None or tag[2] != t._version:
             return t
-        t = tag[0]
+        src = tag[0]()
+        if src is None or src._version != tag[1]:
+            return t
+        t = src
 
 
 def apply_map(particles: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
