@@ -51,7 +51,7 @@ N_PARTICLES = 1_000_000
 N_CELLS = 25
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 APPLY_KERNEL = "apply_tile_kernel<float, 2, 0>"
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r04_kernel_stats.csv")
 COPY_CEILING_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of the 8 TB/s spec)
 #: sigma_x behind the 100 elements of the beam of rank 0 (torch.manual_seed(1234), from_parameters defaults, 1e6 particles, fp32):
 #: the same digits in every driver run since round 1 (BENCH_r01..r03). bench.py refuses to print a line when its step no longer
@@ -340,22 +340,22 @@ def other_configs(ca, torch, device) -> dict:
         # average durations of the chain's per-particle kernels in the tracked rocprofv3 summary (run under the profiler with the
         # Green chain on the side stream: durations include what the overlap costs them)
         import csv
-        path = os.path.join(ROOT, "profiles", "r03_c4_kernel_stats.csv")
+        path = os.path.join(ROOT, "profiles", "r04_c4_kernel_stats.csv")
         avg = {}
         try:
             for row in csv.DictReader(open(path)):
-                for key in ("sc_tile_deposit_kernel", "sc_tile_merge_kernel", "sc_tile_particle_kernel"):
+                for key in ("sc_tile_deposit_kernel", "sc_tile_schedule_kernel", "sc_tile_particle_kernel"):
                     if key in row["Name"]:
                         avg[key] = float(row["AverageNs"]) * 1e-3
         except OSError:
             return None
         if len(avg) < 3:
             return None
-        dep = avg["sc_tile_deposit_kernel"] + avg["sc_tile_merge_kernel"]
+        dep = avg["sc_tile_deposit_kernel"] + avg["sc_tile_schedule_kernel"]
         gat = avg["sc_tile_particle_kernel"]
         rate = 84.0 * N_PARTICLES / ((dep + gat) * 1e-6) / 1e9
         return {"bytes_per_particle": 84.0, "deposit_us_profile": dep, "gather_us_profile": gat, "achieved_GBs": rate,
-                "frac": rate / HBM_PEAK_GBS, "source": "profiles/r03_c4_kernel_stats.csv"}
+                "frac": rate / HBM_PEAK_GBS, "source": "profiles/r04_c4_kernel_stats.csv"}
 
     def c4():
         r = rc.c4()
@@ -452,7 +452,7 @@ def other_configs(ca, torch, device) -> dict:
                 res[label][how] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
                                    "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
         res["note"] = ("per-element kernel times and the measured error of the float32-arithmetic variant against Bmad-X: "
-                       "profiles/r03_dkd_precision.md")
+                       "profiles/r04_dkd_precision.md")
         return res
 
     def second_order():
@@ -522,38 +522,9 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
         d = timed(torch, dist, strong, steps, warmup, world)
         res = {"scaling": "strong", "particles_total": N_PARTICLES, "particles_per_rank": hi - lo, "ms_per_step": d / steps * 1e3,
                "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
-        # The same step with its 100 apply launches replayed from ONE device graph (hipGraph of chx_track_elementwise's launches;
-        # the moments exchange stays outside the graph). MEASURED NEGATIVE on ROCm 7.2: a replayed kernel node costs ~9 us of
-        # scheduling against ~2.5 us for a launch issued from the C loop, so the eager leg is the faster one at every size
-        # (1e6 particles: 1.86 vs 1.03 ms; see also `one_eighth`). Kept in the line as evidence, not used.
-        def graph_pair(beam_):
-            from cheetah_amd import graph as chx_graph
-
-            with torch.no_grad():
-                replay = chx_graph.capture(lambda: seg.track_elementwise(beam_, fused=False))
-
-            def stepg():
-                sharding.global_moments(replay())
-
-            def stepe():
-                sharding.global_moments(seg.track_elementwise(beam_, fused=False))
-
-            stepg()
-            same = bool(torch.equal(replay.outputs.particles, seg.track_elementwise(beam_, fused=False).particles))
-            dg = timed(torch, dist, stepg, steps, warmup, world)
-            de = timed(torch, dist, stepe, steps, warmup, world)
-            return {"eager_ms_per_step": de / steps * 1e3, "graph_replay_ms_per_step": dg / steps * 1e3, "graph_equals_eager": same}
-
-        try:
-            res["graph_replay"] = graph_pair(beam)
-            if world == 1:
-                # what ONE rank of an 8-GPU strong run holds: 1.25e5 particles. Launch-bound: 100 launches x ~2.5 us
-                torch.manual_seed(4321)
-                small = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES // 8, dtype=dtype, device=device)
-                res["one_eighth"] = dict(graph_pair(small), particles=N_PARTICLES // 8,
-                                         note="the per-rank share of an 8-rank strong run, timed on this one GPU")
-        except Exception as exc:  # noqa: BLE001
-            res["graph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        # (replaying the 100 apply launches from ONE device graph was measured and is not used: a replayed kernel node costs ~9 us
+        # of scheduling on ROCm 7.2 against ~2.5 us for a launch issued from the C loop — 1.86 vs 1.03 ms at 1e6 particles, and
+        # slower at the 1.25e5 particles a rank of an 8-GPU strong run holds as well: benchmarks/strong_leg_probe.py)
         return res
 
     guarded("c2_strong", leg_strong)
@@ -791,7 +762,7 @@ def main():
                        "copy_ceiling": COPY_CEILING_GBS, "particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n,
                        "avg_launch_ms": ms_big, "traffic": traffic_big,
                        "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch at this size (separate rocprofv3 --pmc passes, "
-                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r03_pmc_apply.md): 1.0002 x the "
+                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r04_pmc_apply.md): 1.0002 x the "
                                        "algorithmic bytes"})
         del big, seg10
         torch.cuda.empty_cache()

@@ -11,7 +11,7 @@ f = glob.glob("$O/t/*counter_collection.csv")[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    for key in ("sc_tile_deposit", "sc_tile_particle", "sc_tile_merge"):
+    for key in ("sc_tile_deposit", "sc_tile_particle", "sc_tile_schedule"):
         if key in n: acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k, {c: [round(x) for x in v[-10:]] for c, v in d.items()})
