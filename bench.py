@@ -436,7 +436,7 @@ def other_configs(ca, torch, device) -> dict:
                 b = e.track(b)
             return b
 
-        for label, prec in (("float64_arithmetic", "double"), ("float32_arithmetic", "storage")):
+        for label, prec in (("mixed_arithmetic_default", "mixed"), ("float64_arithmetic", "double"), ("float32_arithmetic", "storage")):
             for e in els:
                 e.dkd_precision = prec
             res[label] = {}
@@ -451,8 +451,9 @@ def other_configs(ca, torch, device) -> dict:
                 ms = (_t.perf_counter() - t0) / 5 * 1e3
                 res[label][how] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
                                    "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
-        res["note"] = ("per-element kernel times and the measured error of the float32-arithmetic variant against Bmad-X: "
-                       "profiles/r04_dkd_precision.md")
+        res["note"] = ("dkd_precision: mixed (default of float32 beams: tau / delta in fp64, the rest in float32), double, storage; "
+                       "per-element kernel times and measured errors against the reference's float64 run: "
+                       "profiles/r04_dkd_precision.md, tests/test_gpu_bench_parity.py")
         return res
 
     def second_order():
