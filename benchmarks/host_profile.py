@@ -13,14 +13,22 @@ import cheetah_amd as ca  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "rl"
 dt = torch.float32
-if which in ("rl", "c1"):
+if which in ("rl", "c1", "control"):
     seg = rc.ares_subcell(dt, rc.t(8.2, dt))
     seg.AREABSCR1.is_active = True
     beam = ca.ParticleBeam.from_twiss(beta_x=rc.t(3.14, dt), beta_y=rc.t(42.0, dt), num_particles=10_000, dtype=dt, device="cuda")
     actions = torch.randn(300, 5, device="cuda", dtype=dt)
     counter = [0]
 
+    scale = torch.tensor([10.0, 10.0, 1e-4, 10.0, 1e-4], device="cuda", dtype=dt)
+    settings = [seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle]
+
     def step():
+        if which == "control":
+            scaled = actions[counter[0] % 300] * scale
+            counter[0] += 1
+            for i, target in enumerate(settings):
+                target.copy_(scaled[i])
         if which == "rl":
             a = actions[counter[0] % 300]
             counter[0] += 1
@@ -95,4 +103,4 @@ for _ in range(500):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(int(os.environ.get("TOP", "28")))

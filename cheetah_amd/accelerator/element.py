@@ -244,8 +244,8 @@ class Element(nn.Module):
 
     #: arithmetic of the drift-kick-drift (Bmad-X) kernels for float32 beams (float64 beams are evaluated in float64):
     #:  "mixed" (default)  the longitudinal pair — the (tau, delta) <-> (z, pz) conversions, the z accumulator, the low-energy
-    #:                     correction — and the misalignment shift in float64, everything else in float32 (Drift, Quadrupole;
-    #:                     Dipole and TransverseDeflectingCavity are evaluated in float64). tau and delta as accurate as
+    #:                     correction — in float64, everything else in float32 (Drift, Quadrupole on its axis; a
+    #:                     misaligned Quadrupole, Dipole and TransverseDeflectingCavity are evaluated in float64). tau and delta as accurate as
     #:                     "double", the transverse coordinates to one float32 rounding per element;
     #:  "double"           every particle in float64, rounded once per element — 1.5 x the time of "mixed" (fp64-VALU bound);
     #:  "storage"          everything in float32 like the reference's own tensor code (cheetah/utils/bmadx.py runs in the beam

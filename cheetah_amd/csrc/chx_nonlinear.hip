@@ -390,7 +390,20 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_mixed_kernel(const float* __res
     }
     __syncthreads();
     const int p = threadIdx.x;
-    if (p < np) {
+    // A quadrupole that is shifted off the axis (quadrupole.py:199-215 subtracts the misalignment before its map): the shifted
+    // coordinate may be hundreds of beam sizes, float32 steps on it lose digits of the BEAM's scale and its path-length terms
+    // dwarf tau — such an element is evaluated in float64 like dkd_kernel<float, ., double> (workgroup-uniform decision).
+    if (KIND == CHX_DKD_QUADRUPOLE && (cst_[C_XO] != 0.0 || cst_[C_YO] != 0.0)) {
+        if (p < np) {
+            double in[6], out[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) in[j] = (double)lds[p * 7 + j];
+            dkd_map<CHX_DKD_QUADRUPOLE, double>(cst_, in, mc2, num_steps, out);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) lds[p * 7 + j] = (float)out[j];
+            lds[p * 7 + 6] = 1.0f;
+        }
+    } else if (p < np) {
         const double E = cst_[C_E], p0c = cst_[C_P0C];
         float x = lds[p * 7], px = lds[p * 7 + 1], y = lds[p * 7 + 2], py = lds[p * 7 + 3];
         const double tau = (double)lds[p * 7 + 4], delta = (double)lds[p * 7 + 5];
