@@ -180,3 +180,63 @@ def test_force_collectives_on_one_rank_gloo():
     finally:
         dist.all_gather, dist.all_reduce = real_gather, real_reduce
         dist.destroy_process_group()
+
+
+def _worker_chain_rows(rank, world, port, x, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cheetah_amd.sharding import gather_moments_rows, shard_range
+    from oracle import chx_oracle
+
+    lo, hi = shard_range(x.shape[0], rank, world)
+    xs, ws = x[lo:hi].astype(np.float64), w[lo:hi].astype(np.float64)
+    if rank == 0:
+        # a rank on the staged kick-by-kick path: the full moments of its shard (chx_moments)
+        local = chx_oracle.moments(xs[None], ws[None])["raw"]
+    else:
+        # a rank on the tile-ordered chain: what chx_sc_partials_moments makes of the sums the gather pass left behind — W, W2,
+        # the means and variances of x, y, tau from sums about the ORIGIN; zeros elsewhere
+        W, W2 = ws.sum(), (ws * ws).sum()
+        local = np.zeros((1, 29))
+        local[0, 0], local[0, 1] = W, W2
+        for col, diag in ((0, 0), (2, 11), (4, 18)):
+            m = (ws * xs[:, col]).sum() / W
+            local[0, 2 + col] = m
+            local[0, 8 + diag] = ((ws * xs[:, col] ** 2).sum() - W * m * m) / (W - W2 / W)
+    rows, n = gather_moments_rows(torch.from_numpy(local))
+    q.put((rank, rows.numpy(), n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chain_and_staged_ranks_exchange_compatible_moment_rows(oracle):
+    """Inside `sharding.particle_sharded` a SpaceChargeKick needs sigma_x, sigma_y, sigma_tau of ALL particles
+    (space_charge_kick.py:531-538). A rank on the tile-ordered chain contributes a row with only those three entries filled
+    (from the sums its gather pass accumulated), a rank on the staged path its full chx_moments row: both go through the same
+    29-double all-gather, and the merged x / y / tau entries must be the whole beam's — on every rank."""
+    rng = np.random.default_rng(21)
+    N = 30_001
+    x = rng.standard_normal((N, 7)) * [3e-4, 1e-5, 2e-4, 1e-5, 5e-5, 1e-3, 0] + [2e-4, 0, -1e-4, 0, 3e-5, 0, 1]
+    x[:12_000, 0] += 4e-4                      # the two shards have different means
+    w = rng.random(N)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chain_rows, args=(r, 2, port, x, w, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, rows, n = q.get()
+        got[rank] = (rows, n)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = oracle.moments(x[None], w[None])["raw"][0]
+    for rank in (0, 1):
+        rows, n = got[rank]
+        assert n == 0 and rows.shape == (1, 29)           # gloo / CPU: merged on the host (RCCL hands the rows to the kernel)
+        for col, diag in ((0, 0), (2, 11), (4, 18)):
+            assert abs(rows[0, 2 + col] - ref[2 + col]) <= 1e-12 * np.sqrt(ref[8 + diag])
+            assert rows[0, 8 + diag] == __import__("pytest").approx(ref[8 + diag], rel=1e-11)
+    assert np.array_equal(got[0][0], got[1][0])            # bit-identical on both ranks: the same grid geometry everywhere
