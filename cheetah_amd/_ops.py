@@ -948,19 +948,21 @@ def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor
     return out.reshape(*batch_shape, N, 7)
 
 
-def second_order_chain(T_maps, lengths, x, s):
+def second_order_chain(T_maps, lengths, x, s, ptrs=None):
     """A run of second-order elements on one plain beam (chx_second_order_chain): x (N, 7); T_maps = the elements' (7, 7, 7)
-    maps, lengths their 0-d length tensors, s the 0-d path length — all of x's dtype. Returns (particles (N, 7), s)."""
+    maps, lengths their 0-d length tensors, s the 0-d path length — all of x's dtype. Returns (particles (N, 7), s, ptrs);
+    `ptrs` (the two address arrays) can be handed back in while T_maps and lengths are the same tensors."""
     E, N = len(T_maps), x.shape[0]
     x = aligned(x)
     out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
     tmp = torch.empty((N, 7), dtype=x.dtype, device=x.device) if E > 1 else None
     s_out = torch.empty((), dtype=x.dtype, device=x.device)
-    ptrs = ctypes.c_void_p * E
-    check(_lib.lib().chx_second_order_chain(ptrs(*[t.data_ptr() for t in T_maps]), ptrs(*[t.data_ptr() for t in lengths]), E, ptr(x), N,
-                                            dtype_code(x.dtype), ptr(out), ptr(tmp), ptr(s), ptr(s_out), stream_ptr()),
-          "chx_second_order_chain")
-    return out, s_out
+    if ptrs is None:
+        arr = ctypes.c_void_p * E
+        ptrs = (arr(*[t.data_ptr() for t in T_maps]), arr(*[t.data_ptr() for t in lengths]))
+    check(_lib.lib().chx_second_order_chain(ptrs[0], ptrs[1], E, ptr(x), N, dtype_code(x.dtype), ptr(out), ptr(tmp), ptr(s),
+                                            ptr(s_out), stream_ptr()), "chx_second_order_chain")
+    return out, s_out, ptrs
 
 
 # ---------------------------------------------------------------------------------------------

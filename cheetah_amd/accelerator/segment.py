@@ -834,7 +834,22 @@ class Segment(Element):
             return None
         grad = torch.is_grad_enabled()
         species = incoming.species
-        maps, lengths = [], []
+        # the run as it was found last time stands while no attribute of any element was assigned (`Element._epoch`), the
+        # energy is the same tensor at the same version and no setting was edited in place: O(1) + one version sweep instead
+        # of ~2.5 us of cache look-ups per element
+        cache = self.__dict__.get("_so_run_cache")
+        if cache is None or cache[0] is not plan:
+            cache = self.__dict__["_so_run_cache"] = (plan, {})
+        ent = cache[1].get(i)
+        if ent is not None and ent["epoch"] == Element._epoch and ent["energy"] is energy and ent["energy_version"] == energy._version \
+                and ent["dtype"] == x.dtype and ent["device"] == x.device and ent["mass"] == species.mass_eV_float \
+                and ent["nq"] == species.num_elementary_charges_float \
+                and [t._version for t in ent["tensors"]] == ent["versions"] \
+                and not (grad and any(t.requires_grad for t in ent["tensors"])):
+            out, s_out, _ = _ops.second_order_chain(ent["maps"], ent["lengths"], x, s, ent["ptrs"])
+            return ParticleBeam(out, energy, particle_charges=incoming.particle_charges,
+                                survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), ent["end"]
+        maps, lengths, tensors = [], [], []
         j = i
         while j < len(plan) and plan[j][0] == "element":
             e = plan[j][1]
@@ -850,10 +865,17 @@ class Segment(Element):
                 break
             maps.append(T if T.is_contiguous() else T.contiguous())
             lengths.append(length)
+            tensors += e._feature_key()[1]
             j += 1
         if j - i < 2:
             return None
-        out, s_out = _ops.second_order_chain(maps, lengths, x, s)
+        out, s_out, ptrs = _ops.second_order_chain(maps, lengths, x, s)
+        if not _ops.CAPTURING[0] and not any(t.requires_grad for t in tensors) and not energy.requires_grad:
+            # (maps of tensors that carry gradients are rebuilt on every track, Element._cached_map: nothing to keep)
+            cache[1][i] = {"epoch": Element._epoch, "energy": energy, "energy_version": energy._version, "dtype": x.dtype,
+                           "device": x.device, "mass": species.mass_eV_float, "nq": species.num_elementary_charges_float,
+                           "tensors": tensors, "versions": [t._version for t in tensors], "maps": maps, "lengths": lengths,
+                           "ptrs": ptrs, "end": j}
         return ParticleBeam(out, energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), j
 

@@ -710,8 +710,164 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     return CHX_OK;
 }
 
-// A run of elements tracked with their second-order maps (element.py:195-228) on ONE beam: E launches of chx_apply_second_order
-// from one call, rows ping-ponging between x_out and x_tmp so that the last element writes x_out; the path length like
+namespace {
+// ---- a RUN of second-order elements on one float32 beam, particles kept in registers (chx_second_order_chain) ---------------
+// E launches of second_order_pk_kernel move 56 B per particle and element through HBM for ~50 useful multiply-adds; a run of
+// elements needs none of that traffic: Segment.track only hands out the beam behind the run. Two launches for the whole run:
+//   so_chain_coeff_kernel  (a workgroup per element) folds T_ijk + T_ikj of every element into its 7 x 28 coefficients, finds
+//                          which of them are non-zero and files the element under one of three evaluation schemes;
+//   so_chain_kernel        every lane carries two particles through all elements; the coefficients are wave-uniform and come
+//                          through scalar loads: no LDS, no barrier inside the loop.
+// The schemes differ only in WHICH exact zeros are skipped (a skipped term is 0 * q, an exact no-op on a finite beam), never in
+// the order of the remaining multiply-adds: per element the result is second_order_pk_kernel's, value for value.
+//   scheme 0: the 27 coefficients an upright Quadrupole can have (a Drift's 15 are among them): 13 products + 27 multiply-adds;
+//   scheme 1: the 55 of upright Dipoles (edges, gradient), RBends and Sextupoles: 22 products + 55 multiply-adds;
+//   scheme 2: anything else (tilted, misaligned, custom maps): groups of four coefficients, skipped when all four are zero.
+constexpr int kSoChainMax = 448;           // T pointers per launch (kernel-argument space)
+constexpr int kSoCoefStride = 200;         // floats per element in the scratch: 196 coefficients, 2 group-mask words, the scheme
+struct SoChainPtrs {
+    const void* T[kSoChainMax];
+};
+// bit c of row i = coefficient (i, c) of the folded map, c = the pair (j <= k) in the order 00 01 .. 06 11 12 .. 66
+struct SoPatternQuad {
+    static constexpr unsigned int rows[7] = {0x1860u, 0x1860u, 0x330000u, 0x330000u, 0x7046083u, 0x4000000u, 0x8000000u};
+};
+struct SoPatternBend {
+    static constexpr unsigned int rows[7] = {0x60478e3u, 0x60478e3u, 0x33030cu, 0x33030cu, 0x70478e3u, 0x4000000u, 0x8000000u};
+};
+constexpr int kSoJ[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
+constexpr int kSoK[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
+
+__global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs maps, float* __restrict__ coef) {
+    const int e = blockIdx.x;
+    const float* Tt = (const float*)maps.T[e];
+    float* out = coef + (int64_t)e * kSoCoefStride;
+    float u = 0.0f;
+    int i = 0, c = 0;
+    if (threadIdx.x < 7 * 28) {
+        i = threadIdx.x / 28;
+        c = threadIdx.x - i * 28;
+        const int j = kSoJ[c], k = kSoK[c];
+        const float* Tb = Tt + i * 49;
+        u = (j == k) ? Tb[j * 7 + k] : Tb[j * 7 + k] + Tb[k * 7 + j];
+        out[threadIdx.x] = u;
+    }
+    __shared__ unsigned int any4[64];          // group g = coefficients 4g .. 4g + 3
+    __shared__ unsigned int outside[2];        // a non-zero coefficient outside pattern 0 / 1
+    if (threadIdx.x < 64) any4[threadIdx.x] = 0u;
+    if (threadIdx.x < 2) outside[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x < 7 * 28 && u != 0.0f) {
+        atomicOr(&any4[threadIdx.x >> 2], 1u);
+        if (!((SoPatternQuad::rows[i] >> c) & 1u)) atomicOr(&outside[0], 1u);
+        if (!((SoPatternBend::rows[i] >> c) & 1u)) atomicOr(&outside[1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const unsigned long long m = __ballot(threadIdx.x < 49 && any4[threadIdx.x] != 0u);
+        if (threadIdx.x == 0) {
+            unsigned int* w = reinterpret_cast<unsigned int*>(out);
+            w[196] = (unsigned int)(m & 0xffffffffull);
+            w[197] = (unsigned int)(m >> 32);
+            w[198] = outside[0] == 0u ? 0u : (outside[1] == 0u ? 1u : 2u);
+            w[199] = 0u;
+        }
+    }
+}
+
+// one element, coefficients of a fixed pattern: every product once, every row its multiply-adds in ascending c
+template <class P>
+__device__ __forceinline__ void so_step_pattern(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
+    constexpr unsigned int cols = P::rows[0] | P::rows[1] | P::rows[2] | P::rows[3] | P::rows[4] | P::rows[5] | P::rows[6];
+    chx_v2f q[28];
+#pragma unroll
+    for (int c = 0; c < 28; ++c)
+        if ((cols >> c) & 1u) q[c] = x[kSoJ[c]] * x[kSoK[c]];
+    chx_v2f y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        chx_v2f acc = probe;
+#pragma unroll
+        for (int c = 0; c < 28; ++c)
+            if ((P::rows[i] >> c) & 1u) {
+                const float u = U[i * 28 + c];
+                acc = __builtin_elementwise_fma(chx_v2f{u, u}, q[c], acc);
+            }
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+
+__device__ __forceinline__ void so_step_groups(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
+    const unsigned long long g = (unsigned long long)reinterpret_cast<const unsigned int*>(U)[196] |
+                                 ((unsigned long long)reinterpret_cast<const unsigned int*>(U)[197] << 32);
+    chx_v2f y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        chx_v2f acc = probe;
+        if ((g >> (i * 7)) & 0x7full) {                            // wave-uniform: a row without coefficients is skipped whole
+            float u[28];
+#pragma unroll
+            for (int c = 0; c < 28; ++c) u[c] = U[i * 28 + c];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                if (!((g >> (i * 7 + m)) & 1ull)) continue;       // wave-uniform
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c = 4 * m + q4;
+                    const chx_v2f q = x[kSoJ[c]] * x[kSoK[c]];
+                    acc = __builtin_elementwise_fma(chx_v2f{u[c], u[c]}, q, acc);
+                }
+            }
+        }
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+
+__global__ __launch_bounds__(CHX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void so_chain_kernel(const float* __restrict__ x_in, const float* __restrict__ coef, int E, float* __restrict__ x_out, int64_t N,
+                     int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = 2 * CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    tile_load<float, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
+    __syncthreads();
+    const int p0 = threadIdx.x, p1 = threadIdx.x + CHX_BLOCK;
+    const bool on0 = p0 < np, on1 = p1 < np;
+    chx_v2f x[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = chx_v2f{on0 ? lds[p0 * 7 + j] : 0.0f, on1 ? lds[p1 * 7 + j] : 0.0f};
+    for (int e = 0; e < E; ++e) {
+        const float* __restrict__ U = coef + (int64_t)e * kSoCoefStride;
+        const unsigned int scheme = reinterpret_cast<const unsigned int*>(U)[198];
+        // 0 * x is NaN exactly for a non-finite x and +0 otherwise: every row's sum STARTS from this value, so a particle that
+        // left the finite range comes out as NaN in all seven coordinates (second_order_pk_kernel's rule) and nothing changes
+        // for the others (+0 + a = a)
+        chx_v2f probe = chx_v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) probe = __builtin_elementwise_fma(chx_v2f{0.0f, 0.0f}, x[j], probe);
+        if (scheme == 0u) so_step_pattern<SoPatternQuad>(U, x, probe);
+        else if (scheme == 1u) so_step_pattern<SoPatternBend>(U, x, probe);
+        else so_step_groups(U, x, probe);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if (on0) lds[p0 * 7 + j] = x[j].x;
+        if (on1) lds[p1 * 7 + j] = x[j].y;
+    }
+    __syncthreads();
+    tile_store<float, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
+}
+
+}  // namespace
+
+// A run of elements tracked with their second-order maps (element.py:195-228) on ONE beam. float32: the particles stay in
+// registers for the whole run (so_chain_kernel, two launches; x_tmp holds the folded coefficients). Otherwise E launches of
+// chx_apply_second_order, rows ping-ponging between x_out and x_tmp so that the last element writes x_out; the path length like
 // chx_dkd_chain (lengths[E]: device pointers to the elements' length scalars). Same results as E separate calls, bit for bit.
 extern "C" int chx_second_order_chain(const void* const* T_maps, const void* const* lengths, int64_t E, const void* x_in, int64_t N,
                                       int dtype, void* x_out, void* x_tmp, const void* s_in, void* s_out, void* stream) {
@@ -719,13 +875,30 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if ((s_in == nullptr) != (s_out == nullptr) || (s_out && !lengths)) return CHX_ERR_INVALID_ARG;
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
-    const void* src = x_in;
-    for (int64_t e = 0; e < E; ++e) {
+    for (int64_t e = 0; e < E; ++e)
         if (!T_maps[e]) return CHX_ERR_INVALID_ARG;
-        void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;
-        const int st = chx_apply_second_order(src, T_maps[e], dst, 1, 1, 1, N, dtype, stream);
-        if (st != CHX_OK) return st;
-        src = dst;
+    // float32, a run that fits one argument block and a scratch of 800 bytes per element inside x_tmp: the particles stay in
+    // registers for the whole run (so_chain_kernel) — two launches instead of E passes over HBM, the same bits
+    static const bool fused_off = [] { const char* v = getenv("CHX_SO_CHAIN_FUSED"); return v && v[0] == '0'; }();
+    if (!fused_off && dtype == CHX_F32 && E >= 2 && E <= kSoChainMax && (int64_t)E * kSoCoefStride <= N * 7) {
+        SoChainPtrs maps;
+        for (int e = 0; e < kSoChainMax; ++e) maps.T[e] = e < E ? T_maps[e] : nullptr;
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(so_chain_coeff_kernel, dim3((unsigned)E), dim3(CHX_BLOCK), 0, s, maps, (float*)x_tmp);
+        CHX_CHECK_LAUNCH();
+        const int64_t tiles = (N + 2 * CHX_BLOCK - 1) / (2 * CHX_BLOCK);
+        if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(so_chain_kernel, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const float*)x_tmp, (int)E,
+                           (float*)x_out, N, (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
+        CHX_CHECK_LAUNCH();
+    } else {
+        const void* src = x_in;
+        for (int64_t e = 0; e < E; ++e) {
+            void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;
+            const int st = chx_apply_second_order(src, T_maps[e], dst, 1, 1, 1, N, dtype, stream);
+            if (st != CHX_OK) return st;
+            src = dst;
+        }
     }
     for (int64_t done = 0; s_out && done < E; done += kDkdSChunk) {
         DkdLengthPtrs a;

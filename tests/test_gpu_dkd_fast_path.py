@@ -161,3 +161,53 @@ def test_segment_tracks_a_second_order_run_in_one_call(dt):
         assert els[1].k1.grad is not None and float(els[1].k1.grad.abs()) > 0
     finally:
         _ops.second_order_chain = orig
+
+
+def test_second_order_run_cache_follows_every_kind_of_change():
+    """A second-order run is looked up once and reused while nothing changed (Segment._second_order_run). What can change —
+    a setting edited in place, an attribute assigned, a setting that starts to require a gradient, another energy tensor, another
+    species — must be seen: every track equals the elements tracked one after the other (element.py:195-228), bit for bit."""
+    import cheetah_amd as ca
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(8)
+    beam = ca.ParticleBeam.from_parameters(num_particles=30_011, sigma_x=t(3e-4), sigma_px=t(4e-5), sigma_p=t(2e-3), energy=t(6e7), **kw)
+    so = {"tracking_method": "second_order"}
+    els = [ca.Drift(t(0.4), **so, **kw), ca.Quadrupole(t(0.2), k1=t(3.3), **so, **kw), ca.Drift(t(0.6), **so, **kw),
+           ca.Dipole(t(0.5), angle=t(0.03), **so, **kw), ca.Quadrupole(t(0.2), k1=t(-2.0), **so, **kw), ca.Drift(t(0.3), **so, **kw)]
+    seg = ca.Segment(els)
+
+    def check(b):
+        out = seg.track(b)
+        ref = b
+        for e in els:
+            ref = e.track(ref)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s) and torch.equal(out.energy, ref.energy)
+        return out
+
+    first = check(beam)
+    again = check(beam)                                   # from the cache
+    assert torch.equal(first.particles, again.particles)
+    assert seg.__dict__["_so_run_cache"][1], "the run was not kept"
+    els[1].k1.mul_(1.5)                                   # in place
+    edited = check(beam)
+    assert not torch.equal(edited.particles, first.particles)
+    els[2].length.add_(0.25)
+    check(beam)
+    els[4].k1 = t(-1.0)                                   # assigned
+    check(beam)
+    other = ca.ParticleBeam(beam.particles.clone(), t(7.5e7), particle_charges=beam.particle_charges, species=beam.species, **kw)
+    check(other)                                          # another energy tensor
+    check(beam)
+    beam.energy.mul_(1.1)                                 # the same tensor, another value
+    check(beam)
+    protons = ca.ParticleBeam(beam.particles.clone(), t(2e9), particle_charges=beam.particle_charges, species=ca.Species("proton"), **kw)
+    check(protons)
+    check(beam)
+    els[1].k1.requires_grad_(True)                        # no assignment, no version change: the differentiable path must take over
+    out = seg.track(beam)
+    out.particles[:, 0].square().mean().backward()
+    assert els[1].k1.grad is not None and float(els[1].k1.grad.abs()) > 0
+    with torch.no_grad():
+        check(beam)
