@@ -742,20 +742,22 @@ def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, stor
     return out, e_out
 
 
-def dkd_chain(kinds, params, num_steps, fringe, storage, x, energy, s, mass_eV, n_charges):
+def dkd_chain(kinds, params, num_steps, fringe, storage, x, energy, s, mass_eV, n_charges, arrays=None):
     """A run of drift-kick-drift elements on one plain beam (chx_dkd_chain): x (N, 7), energy and s 0-d of x's dtype, params =
-    the elements' (1, P) parameter arrays. Returns (particles (N, 7), energy 0-d, s 0-d) behind the last element."""
+    the elements' (1, P) parameter arrays. Returns (particles (N, 7), energy 0-d, s 0-d, arrays) behind the last element;
+    `arrays` (the five argument arrays) can be handed back in while the run and its parameter arrays are the same."""
     E, N = len(kinds), x.shape[0]
     x = aligned(x)
     out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
     tmp = torch.empty((N, 7), dtype=x.dtype, device=x.device) if E > 1 else None
     scalars = torch.empty((E + 1,), dtype=x.dtype, device=x.device)       # the elements' outgoing energies, then s
-    i32 = ctypes.c_int32 * E
-    check(_lib.lib().chx_dkd_chain(i32(*kinds), (ctypes.c_void_p * E)(*[p.data_ptr() for p in params]), i32(*num_steps), i32(*fringe),
-                                   i32(*storage), E, ptr(x), ptr(energy), mass_eV, n_charges, N, dtype_code(x.dtype), ptr(out),
-                                   ptr(tmp), ptr(scalars), ptr(s), scalars.data_ptr() + E * scalars.element_size(), stream_ptr()),
-          "chx_dkd_chain")
-    return out, scalars[E - 1], scalars[E]
+    if arrays is None:
+        i32 = ctypes.c_int32 * E
+        arrays = (i32(*kinds), (ctypes.c_void_p * E)(*[p.data_ptr() for p in params]), i32(*num_steps), i32(*fringe), i32(*storage))
+    check(_lib.lib().chx_dkd_chain(arrays[0], arrays[1], arrays[2], arrays[3], arrays[4], E, ptr(x), ptr(energy), mass_eV, n_charges, N,
+                                   dtype_code(x.dtype), ptr(out), ptr(tmp), ptr(scalars), ptr(s),
+                                   scalars.data_ptr() + E * scalars.element_size(), stream_ptr()), "chx_dkd_chain")
+    return out, scalars[E - 1], scalars[E], arrays
 
 
 class DkdTrack(torch.autograd.Function):

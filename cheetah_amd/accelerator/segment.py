@@ -350,6 +350,8 @@ class _LatticePlan:
 
 
 _CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
+#: drift-kick-drift kinds chx_dkd_chain carries through a run in registers (float32 beams)
+_DKD_IN_REGISTERS = (_ops.DKD_KIND["drift"], _ops.DKD_KIND["quadrupole"])
 #: CHX_SC_CHAIN = auto (default) | on | off — how `Segment.track` takes [SpaceChargeKick, linear run, SpaceChargeKick, ...]:
 #: "auto" starts on the tile-ordered chain and lets the asynchronous guard (`_chain_allowed`) send a plan whose beam reshuffles
 #: between kicks back to kick-by-kick tracking. The two paths sum the charge in different orders, so WHEN the guard's header
@@ -888,7 +890,22 @@ class Segment(Element):
                 or s.dim() != 0 or s.dtype != x.dtype or s.device != x.device or (
                     torch.is_grad_enabled() and (x.requires_grad or energy.requires_grad or s.requires_grad)):
             return None
-        kinds, params, steps, fringes, storage = [], [], [], [], []
+        grad = torch.is_grad_enabled()
+        species = incoming.species
+        # the run as it was found last time stands while no attribute of any element was assigned (`Element._epoch`) and no
+        # setting was edited in place (one sweep over the version counters instead of ~3 us of look-ups per element)
+        cache = self.__dict__.get("_dkd_run_cache")
+        if cache is None or cache[0] is not plan:
+            cache = self.__dict__["_dkd_run_cache"] = (plan, {})
+        ent = cache[1].get(i)
+        if ent is not None and ent["epoch"] == Element._epoch and ent["dtype"] == x.dtype and ent["device"] == x.device \
+                and [t._version for t in ent["tensors"]] == ent["versions"] and not _ops.CAPTURING[0] \
+                and not (grad and any(t.requires_grad for t in ent["tensors"])):
+            out, e_out, s_out, _ = _ops.dkd_chain(ent["kinds"], ent["params"], None, None, None, x, energy, s, species.mass_eV_float,
+                                                  species.num_elementary_charges_float, ent["arrays"])
+            return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
+                                survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), ent["end"]
+        kinds, params, steps, fringes, storage, tensors = [], [], [], [], [], []
         j = i
         while j < len(plan) and plan[j][0] == "element":
             e = plan[j][1]
@@ -906,12 +923,32 @@ class Segment(Element):
             steps.append(n)
             fringes.append(f)
             storage.append(_ops.DKD_PRECISION[e.dkd_precision])
+            tensors.append([t for t, _ in e._builder_scalar_refs()])
             j += 1
+        # float32 Drifts and Quadrupoles of one arithmetic mode go through the device with the particles in registers
+        # (chx_dkd_chain's two-launch form): the run is cut so that such a stretch is a call of its own
+        if x.dtype == torch.float32:
+            fusable = [storage[k] if kinds[k] in _DKD_IN_REGISTERS else -1 for k in range(j - i)]
+            n = len(fusable)
+            if n >= 2 and fusable[0] >= 0 and fusable[1] == fusable[0]:
+                k = 2
+                while k < n and fusable[k] == fusable[0]:
+                    k += 1
+            else:
+                k = 1
+                while k < n and not (fusable[k] >= 0 and k + 1 < n and fusable[k + 1] == fusable[k]):
+                    k += 1
+            if k < n:
+                j = i + k
+                kinds, params, steps, fringes, storage, tensors = kinds[:k], params[:k], steps[:k], fringes[:k], storage[:k], tensors[:k]
         if j - i < 2:
             return None
-        species = incoming.species
-        out, e_out, s_out = _ops.dkd_chain(kinds, params, steps, fringes, storage, x, energy, s, species.mass_eV_float,
-                                           species.num_elementary_charges_float)
+        out, e_out, s_out, arrays = _ops.dkd_chain(kinds, params, steps, fringes, storage, x, energy, s, species.mass_eV_float,
+                                                   species.num_elementary_charges_float)
+        flat = [t for ts in tensors for t in ts]
+        if not _ops.CAPTURING[0]:
+            cache[1][i] = {"epoch": Element._epoch, "dtype": x.dtype, "device": x.device, "tensors": flat,
+                           "versions": [t._version for t in flat], "kinds": kinds, "params": params, "arrays": arrays, "end": j}
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), j
 

@@ -353,6 +353,99 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
 // fp64 — one square root and three divisions per particle (delta' is formed from the particle's own energy: pz does not change
 // inside these two elements, so the round trip through p is the identity) — everything else in float32, including the
 // increments of z (a RELATIVE error of 1e-7 on an increment is 1e-16 of z's scale).
+enum { C_ETOT = C_N + 1, C_BETA0, C_ME2, C_MIXED_N };
+// the three extra constants of the mixed evaluation, behind dkd_constants' (lane 0 of a workgroup / of a prepare kernel)
+__device__ __forceinline__ void dkd_mixed_constants(double* cst_, double mc2) {
+    const double p0c = cst_[C_P0C];
+    const double e_tot = sqrt(p0c * p0c + mc2 * mc2);
+    cst_[C_ETOT] = e_tot;
+    cst_[C_BETA0] = p0c / e_tot;
+    cst_[C_ME2] = (mc2 / e_tot) * (mc2 / e_tot);
+}
+// one particle through one element, v = (x, px, y, py, tau, delta) in float32 before and after
+template <int KIND>
+__device__ __forceinline__ void dkd_mixed_particle(const double* __restrict__ cst_, double mc2, int num_steps, float (&v)[6]) {
+    // A quadrupole that is shifted off the axis (quadrupole.py:199-215 subtracts the misalignment before its map): the shifted
+    // coordinate may be hundreds of beam sizes, float32 steps on it lose digits of the BEAM's scale and its path-length terms
+    // dwarf tau — such an element is evaluated in float64 like dkd_kernel<float, ., double> (workgroup-uniform decision).
+    if (KIND == CHX_DKD_QUADRUPOLE && (cst_[C_XO] != 0.0 || cst_[C_YO] != 0.0)) {
+        double in[6], out[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) in[j] = (double)v[j];
+        dkd_map<CHX_DKD_QUADRUPOLE, double>(cst_, in, mc2, num_steps, out);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = (float)out[j];
+        return;
+    }
+    const double E = cst_[C_E], p0c = cst_[C_P0C];
+    float x = v[0], px = v[1], y = v[2], py = v[3];
+    const double tau = (double)v[4], delta = (double)v[5];
+    // (tau, delta) -> (z, pz), bmadx.py:7-31, fp64
+    const double en = E + delta * p0c;
+    const double pc = sqrt(en * en - mc2 * mc2);
+    const double beta = pc / en;
+    double z = -beta * tau;
+    const double pz = (pc - p0c) / p0c;
+    const float pzf = (float)pz, mc2f = (float)mc2, p0cf = (float)p0c;
+    const float relp = 1.0f + pzf;
+    if (KIND == CHX_DKD_DRIFT) {                                  // bmadx.py:263-298
+        const float L = (float)cst_[C_A];
+        const float ir = __builtin_amdgcn_rcpf(relp);
+        const float Px = px * ir, Py = py * ir;
+        const float Pxy2 = Px * Px + Py * Py;
+        const float Pl = __builtin_amdgcn_sqrtf(1.0f - Pxy2);
+        const float iPl = __builtin_amdgcn_rcpf(Pl);
+        const float pcf = p0cf * relp, m2 = mc2f * mc2f;
+        const float a = (m2 * (2.0f * pzf + pzf * pzf)) * __builtin_amdgcn_rcpf(pcf * pcf + m2);
+        const float so_a = a * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(1.0f + a) + 1.0f);          // sqrt_one(a)
+        const float so_b = -Pxy2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(1.0f - Pxy2) + 1.0f);   // sqrt_one(-Pxy2)
+        x = x + L * Px * iPl;
+        y = y + L * Py * iPl;
+        z = z + (double)(L * (so_a + so_b * iPl));
+    } else {                                                      // quadrupole.py:168-251, bmadx.py:219-252
+        const double xo = cst_[C_XO], yo = cst_[C_YO], sn = cst_[C_SIN], cs = cst_[C_COS];
+        {   // offset_set: the shift by the misalignment in fp64 (it may be hundreds of beam sizes), the rotation with it
+            const double xi = (double)x - xo, yi = (double)y - yo;
+            const float xr = (float)(xi * cs + yi * sn), yr = (float)(-xi * sn + yi * cs);
+            const float pxr = (float)((double)px * cs + (double)py * sn), pyr = (float)(-(double)px * sn + (double)py * cs);
+            x = xr; y = yr; px = pxr; py = pyr;
+        }
+        const float L = (float)cst_[C_A], b1 = (float)cst_[C_B];
+        const float step = L / (float)num_steps;
+        const F32 k1 = mkf(b1 * __builtin_amdgcn_rcpf(L * relp));
+        const QuadCoef<F32> tx = quad_coefficients<F32>(-k1, mkf(step), mkf(relp));
+        const QuadCoef<F32> ty = quad_coefficients<F32>(k1, mkf(step), mkf(relp));
+        // low_energy_z_correction (bmadx.py:184-216) in fp64: beta - beta0 cancels to 1e-8
+        double dzc;
+        {
+            const double e_tot = cst_[C_ETOT], beta0 = cst_[C_BETA0], me2 = cst_[C_ME2];
+            const double b0pz = beta0 * pz, b02 = beta0 * beta0, ds = (double)step;
+            if (mc2 * (b0pz * b0pz) < 3e-7 * e_tot)
+                dzc = ds * pz * (1.0 - 3.0 * (pz * b02) / 2.0 + pz * pz * b02 * (2.0 * b02 - me2 / 2.0)) * me2;
+            else
+                dzc = ds * (beta - beta0) / beta0;                // (beta of this particle: pc / en above)
+        }
+        for (int s = 0; s < num_steps; ++s) {
+            const float dz = tx.c1.v * (x * x) + tx.c2.v * x * px + tx.c3.v * (px * px) + ty.c1.v * (y * y) + ty.c2.v * y * py +
+                             ty.c3.v * (py * py);
+            const float xn = tx.a11.v * x + tx.a12.v * px, pxn = tx.a21.v * x + tx.a22.v * px;
+            const float yn = ty.a11.v * y + ty.a12.v * py, pyn = ty.a21.v * y + ty.a22.v * py;
+            x = xn; px = pxn; y = yn; py = pyn;
+            z = z + (double)dz + dzc;
+        }
+        {   // offset_unset
+            const double xi = (double)x * cs - (double)y * sn, yi = (double)x * sn + (double)y * cs;
+            const float pxr = (float)((double)px * cs - (double)py * sn), pyr = (float)((double)px * sn + (double)py * cs);
+            x = (float)(xi + xo); y = (float)(yi + yo); px = pxr; py = pyr;
+        }
+    }
+    // (z, pz) -> (tau, delta), bmadx.py:34-56: pz is unchanged, so p = pc and the particle's energy is `en` again
+    const double ref = cst_[C_ETOT];
+    v[0] = x; v[1] = px; v[2] = y; v[3] = py;
+    v[4] = (float)(-z / beta);
+    v[5] = (float)((en - ref) / p0c);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(CHX_BLOCK) void dkd_mixed_kernel(const float* __restrict__ x_in, const float* __restrict__ params,
                                                               const float* __restrict__ energy, double mc2, double nq, int num_steps,
@@ -361,8 +454,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_mixed_kernel(const float* __res
                                                               int in_vec_ok, int out_vec_ok) {
     constexpr int TP = CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) float lds[TP * 7];
-    __shared__ double cst_[C_N + 4];
-    enum { C_ETOT = C_N + 1, C_BETA0, C_ME2 };
+    __shared__ double cst_[C_MIXED_N];
     const int64_t tiles_per_row = (N + TP - 1) / TP;
     const int64_t b = blockIdx.x / tiles_per_row;
     const int64_t t = blockIdx.x - b * tiles_per_row;
@@ -377,11 +469,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_mixed_kernel(const float* __res
         double par[CHX_MAX_PARAMS];
         for (int k = 0; k < P; ++k) par[k] = (double)params[((Bp == 1) ? 0 : b) * P + k];
         dkd_constants<double>(KIND, par, (double)Eb, mc2, nq, 3, cst_);
-        const double p0c = cst_[C_P0C];
-        const double e_tot = sqrt(p0c * p0c + mc2 * mc2);
-        cst_[C_ETOT] = e_tot;
-        cst_[C_BETA0] = p0c / e_tot;
-        cst_[C_ME2] = (mc2 / e_tot) * (mc2 / e_tot);
+        dkd_mixed_constants(cst_, mc2);
         if (t == 0 && energy_out) {
             const float m = (float)mc2;
             const float p0 = sqrtf(Eb * Eb - m * m);
@@ -390,87 +478,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_mixed_kernel(const float* __res
     }
     __syncthreads();
     const int p = threadIdx.x;
-    // A quadrupole that is shifted off the axis (quadrupole.py:199-215 subtracts the misalignment before its map): the shifted
-    // coordinate may be hundreds of beam sizes, float32 steps on it lose digits of the BEAM's scale and its path-length terms
-    // dwarf tau — such an element is evaluated in float64 like dkd_kernel<float, ., double> (workgroup-uniform decision).
-    if (KIND == CHX_DKD_QUADRUPOLE && (cst_[C_XO] != 0.0 || cst_[C_YO] != 0.0)) {
-        if (p < np) {
-            double in[6], out[6];
+    if (p < np) {
+        float v[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) in[j] = (double)lds[p * 7 + j];
-            dkd_map<CHX_DKD_QUADRUPOLE, double>(cst_, in, mc2, num_steps, out);
+        for (int j = 0; j < 6; ++j) v[j] = lds[p * 7 + j];
+        dkd_mixed_particle<KIND>(cst_, mc2, num_steps, v);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) lds[p * 7 + j] = (float)out[j];
-            lds[p * 7 + 6] = 1.0f;
-        }
-    } else if (p < np) {
-        const double E = cst_[C_E], p0c = cst_[C_P0C];
-        float x = lds[p * 7], px = lds[p * 7 + 1], y = lds[p * 7 + 2], py = lds[p * 7 + 3];
-        const double tau = (double)lds[p * 7 + 4], delta = (double)lds[p * 7 + 5];
-        // (tau, delta) -> (z, pz), bmadx.py:7-31, fp64
-        const double en = E + delta * p0c;
-        const double pc = sqrt(en * en - mc2 * mc2);
-        const double beta = pc / en;
-        double z = -beta * tau;
-        const double pz = (pc - p0c) / p0c;
-        const float pzf = (float)pz, mc2f = (float)mc2, p0cf = (float)p0c;
-        const float relp = 1.0f + pzf;
-        if (KIND == CHX_DKD_DRIFT) {                                  // bmadx.py:263-298
-            const float L = (float)cst_[C_A];
-            const float ir = __builtin_amdgcn_rcpf(relp);
-            const float Px = px * ir, Py = py * ir;
-            const float Pxy2 = Px * Px + Py * Py;
-            const float Pl = __builtin_amdgcn_sqrtf(1.0f - Pxy2);
-            const float iPl = __builtin_amdgcn_rcpf(Pl);
-            const float pcf = p0cf * relp, m2 = mc2f * mc2f;
-            const float a = (m2 * (2.0f * pzf + pzf * pzf)) * __builtin_amdgcn_rcpf(pcf * pcf + m2);
-            const float so_a = a * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(1.0f + a) + 1.0f);          // sqrt_one(a)
-            const float so_b = -Pxy2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(1.0f - Pxy2) + 1.0f);   // sqrt_one(-Pxy2)
-            x = x + L * Px * iPl;
-            y = y + L * Py * iPl;
-            z = z + (double)(L * (so_a + so_b * iPl));
-        } else {                                                      // quadrupole.py:168-251, bmadx.py:219-252
-            const double xo = cst_[C_XO], yo = cst_[C_YO], sn = cst_[C_SIN], cs = cst_[C_COS];
-            {   // offset_set: the shift by the misalignment in fp64 (it may be hundreds of beam sizes), the rotation with it
-                const double xi = (double)x - xo, yi = (double)y - yo;
-                const float xr = (float)(xi * cs + yi * sn), yr = (float)(-xi * sn + yi * cs);
-                const float pxr = (float)((double)px * cs + (double)py * sn), pyr = (float)(-(double)px * sn + (double)py * cs);
-                x = xr; y = yr; px = pxr; py = pyr;
-            }
-            const float L = (float)cst_[C_A], b1 = (float)cst_[C_B];
-            const float step = L / (float)num_steps;
-            const F32 k1 = mkf(b1 * __builtin_amdgcn_rcpf(L * relp));
-            const QuadCoef<F32> tx = quad_coefficients<F32>(-k1, mkf(step), mkf(relp));
-            const QuadCoef<F32> ty = quad_coefficients<F32>(k1, mkf(step), mkf(relp));
-            // low_energy_z_correction (bmadx.py:184-216) in fp64: beta - beta0 cancels to 1e-8
-            double dzc;
-            {
-                const double e_tot = cst_[C_ETOT], beta0 = cst_[C_BETA0], me2 = cst_[C_ME2];
-                const double b0pz = beta0 * pz, b02 = beta0 * beta0, ds = (double)step;
-                if (mc2 * (b0pz * b0pz) < 3e-7 * e_tot)
-                    dzc = ds * pz * (1.0 - 3.0 * (pz * b02) / 2.0 + pz * pz * b02 * (2.0 * b02 - me2 / 2.0)) * me2;
-                else
-                    dzc = ds * (beta - beta0) / beta0;                // (beta of this particle: pc / en above)
-            }
-            for (int s = 0; s < num_steps; ++s) {
-                const float dz = tx.c1.v * (x * x) + tx.c2.v * x * px + tx.c3.v * (px * px) + ty.c1.v * (y * y) + ty.c2.v * y * py +
-                                 ty.c3.v * (py * py);
-                const float xn = tx.a11.v * x + tx.a12.v * px, pxn = tx.a21.v * x + tx.a22.v * px;
-                const float yn = ty.a11.v * y + ty.a12.v * py, pyn = ty.a21.v * y + ty.a22.v * py;
-                x = xn; px = pxn; y = yn; py = pyn;
-                z = z + (double)dz + dzc;
-            }
-            {   // offset_unset
-                const double xi = (double)x * cs - (double)y * sn, yi = (double)x * sn + (double)y * cs;
-                const float pxr = (float)((double)px * cs - (double)py * sn), pyr = (float)((double)px * sn + (double)py * cs);
-                x = (float)(xi + xo); y = (float)(yi + yo); px = pxr; py = pyr;
-            }
-        }
-        // (z, pz) -> (tau, delta), bmadx.py:34-56: pz is unchanged, so p = pc and the particle's energy is `en` again
-        const double ref = cst_[C_ETOT];
-        lds[p * 7] = x; lds[p * 7 + 1] = px; lds[p * 7 + 2] = y; lds[p * 7 + 3] = py;
-        lds[p * 7 + 4] = (float)(-z / beta);
-        lds[p * 7 + 5] = (float)((en - ref) / p0c);
+        for (int j = 0; j < 6; ++j) lds[p * 7 + j] = v[j];
         lds[p * 7 + 6] = 1.0f;
     }
     __syncthreads();
@@ -668,11 +682,113 @@ __global__ void dkd_path_length_kernel(DkdLengthPtrs args, int n, const T* __res
     for (int e = 0; e < n; ++e) s = s + *(const T*)args.p[e];
     *s_out = s;
 }
+
+// ---- a RUN of Drifts and Quadrupoles on one float32 beam, particles kept in registers (chx_dkd_chain) -----------------------
+// The per-element kernels above are bound by their arithmetic (a quadrupole in mixed arithmetic: ~450 instructions per particle),
+// yet every one of them also moves its 56 bytes per particle through HBM and waits for them at both ends. A run of E elements of
+// one arithmetic mode is two launches:
+//   dkd_chain_prepare_kernel  a workgroup per element: its reference energy (the float32 round trip of bmadx.py:49 applied once
+//                             per element in front of it, as the element-by-element kernels hand it on), dkd_constants in fp64,
+//                             the energy it leaves (`energies[e]`);
+//   dkd_chain_kernel<MODE>    a particle per lane through all elements; the element's constants are wave-uniform scalar loads;
+//                             between two elements the coordinates are rounded to float32 — exactly what the store and the
+//                             load of two separate launches do: the same bits as E calls of chx_dkd_track_p.
+constexpr int kDkdChainMax = 320;          // elements per launch pair (kernel-argument space: 12 bytes each)
+constexpr int kDkdCstStride = 24;          // doubles per element: C_MIXED_N constants, then kind and step count as two ints
+struct DkdChainArgs {
+    const void* params[kDkdChainMax];
+    int32_t meta[kDkdChainMax];            // kind | num_steps << 4
+};
+
+__device__ __forceinline__ float dkd_energy_round_trip(float E, float m) {       // ref_energy of bmadx.py:49, storage dtype
+    const float p0 = sqrtf(E * E - m * m);
+    return sqrtf(p0 * p0 + m * m);
+}
+
+__global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const float* __restrict__ energy_in, double mc2, double nq,
+                                         double* __restrict__ cst, float* __restrict__ energies) {
+    const int e = blockIdx.x;
+    if (threadIdx.x != 0 || e >= E) return;
+    const float m = (float)mc2;
+    float Ee = *energy_in;
+    for (int k = 0; k < e; ++k) Ee = dkd_energy_round_trip(Ee, m);
+    const int kind = args.meta[e] & 15, steps = args.meta[e] >> 4;
+    const int P = kind == CHX_DKD_DRIFT ? 1 : 5;
+    double par[CHX_MAX_PARAMS];
+    const float* pe = (const float*)args.params[e];
+    for (int k = 0; k < P; ++k) par[k] = (double)pe[k];
+    double c[kDkdCstStride];
+    for (int k = 0; k < kDkdCstStride; ++k) c[k] = 0.0;
+    dkd_constants<double>(kind, par, (double)Ee, mc2, nq, 3, c);
+    dkd_mixed_constants(c, mc2);
+    double* out = cst + (int64_t)e * kDkdCstStride;
+    for (int k = 0; k < C_MIXED_N; ++k) out[k] = c[k];
+    int32_t* w = reinterpret_cast<int32_t*>(out + C_MIXED_N);
+    w[0] = kind;
+    w[1] = steps;
+    energies[e] = dkd_energy_round_trip(Ee, m);
+}
+
+// MODE: chx_dkd_track_p's storage_precision — 0 fp64 evaluation, 1 float32 evaluation, 2 mixed
+template <int MODE, int KIND>
+__device__ __forceinline__ void dkd_chain_step(const double* __restrict__ c, double mc2, int num_steps, float (&v)[6]) {
+    if (MODE == 2) {
+        dkd_mixed_particle<KIND>(c, mc2, num_steps, v);
+    } else if (MODE == 0) {
+        double in[6], out[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) in[j] = (double)v[j];
+        dkd_map<KIND, double>(c, in, mc2, num_steps, out);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = (float)out[j];
+    } else {
+        F32 cf[C_N + 1], in[6], out[6];
+#pragma unroll
+        for (int k = 0; k <= C_N; ++k) cf[k] = dkd_scalar<F32>::from(c[k]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) in[j] = mkf(v[j]);
+        dkd_map<KIND, F32>(cf, in, mc2, num_steps, out);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = out[j].v;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* __restrict__ x_in, const double* __restrict__ cst, int E,
+                                                              double mc2, float* __restrict__ x_out, int64_t N, int in_vec_ok,
+                                                              int out_vec_ok) {
+    constexpr int TP = CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    tile_load<float, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
+    __syncthreads();
+    const int p = threadIdx.x;
+    float v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] = p < np ? lds[p * 7 + j] : 0.0f;
+    for (int e = 0; e < E; ++e) {
+        const double* __restrict__ c = cst + (int64_t)e * kDkdCstStride;
+        const int32_t* w = reinterpret_cast<const int32_t*>(c + C_MIXED_N);
+        const int kind = w[0], steps = w[1];
+        if (kind == CHX_DKD_DRIFT) dkd_chain_step<MODE, CHX_DKD_DRIFT>(c, mc2, steps, v);
+        else dkd_chain_step<MODE, CHX_DKD_QUADRUPOLE>(c, mc2, steps, v);
+    }
+    if (p < np) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) lds[p * 7 + j] = v[j];
+        lds[p * 7 + 6] = 1.0f;
+    }
+    __syncthreads();
+    tile_store<float, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
+}
 }  // namespace
 
-// A run of drift-kick-drift elements on ONE beam with scalar settings: E launches of chx_dkd_track_p from one call. The reference
-// energy is handed from element to element on the device (energies[e] = what element e leaves), the particle rows ping-pong
-// between x_out and x_tmp so that the last element writes x_out. Same results as E separate calls, bit for bit.
+// A run of drift-kick-drift elements on ONE beam with scalar settings. float32 Drifts and Quadrupoles of one arithmetic mode: two
+// launches, the particles in registers for the whole run (dkd_chain_kernel; x_tmp holds the elements' constants). Otherwise E
+// launches of chx_dkd_track_p from one call: the reference energy is handed from element to element on the device (energies[e] =
+// what element e leaves), the particle rows ping-pong between x_out and x_tmp so that the last element writes x_out. Either way
+// the same results as E separate calls, bit for bit.
 extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, const int32_t* num_steps, const int32_t* fringe_at,
                              const int32_t* storage_precision, int64_t E, const void* x_in, const void* energy_in, double mass_eV,
                              double n_charges, int64_t N, int dtype, void* x_out, void* x_tmp, void* energies, const void* s_in,
@@ -683,16 +799,50 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    const void* src = x_in;
-    const void* e_src = energy_in;
-    for (int64_t e = 0; e < E; ++e) {
-        void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;          // the last element lands in x_out
-        void* e_dst = (char*)energies + (size_t)e * esz;
-        const int st = chx_dkd_track_p(kinds[e], src, params[e], e_src, mass_eV, n_charges, num_steps[e], fringe_at[e], 1, 1, 1, 1, N,
-                                       dtype, storage_precision[e], dst, e_dst, stream);
-        if (st != CHX_OK) return st;
-        src = dst;
-        e_src = e_dst;
+    // float32 Drifts and Quadrupoles of one arithmetic mode, a run that fits one argument block and whose constants (192 bytes
+    // per element) fit x_tmp: the particles stay in registers (dkd_chain_kernel), two launches, the same bits
+    static const bool fused_off = [] { const char* v = getenv("CHX_DKD_CHAIN_FUSED"); return v && v[0] == '0'; }();
+    bool fuse = !fused_off && dtype == CHX_F32 && E >= 2 && E <= kDkdChainMax &&
+                (int64_t)E * kDkdCstStride * (int64_t)sizeof(double) <= N * 7 * (int64_t)sizeof(float) && chx_aligned16(x_tmp);
+    for (int64_t e = 0; fuse && e < E; ++e)
+        fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE) && storage_precision[e] == storage_precision[0] &&
+               storage_precision[e] >= 0 && storage_precision[e] <= 2 && num_steps[e] >= 1 && num_steps[e] < (1 << 27) && params[e];
+    if (fuse) {
+        DkdChainArgs a;
+        for (int e = 0; e < kDkdChainMax; ++e) {
+            a.params[e] = e < E ? params[e] : nullptr;
+            a.meta[e] = e < E ? (kinds[e] | (num_steps[e] << 4)) : 0;
+        }
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(dkd_chain_prepare_kernel, dim3((unsigned)E), dim3(64), 0, s, a, (int)E, (const float*)energy_in, mass_eV,
+                           n_charges, (double*)x_tmp, (float*)energies);
+        CHX_CHECK_LAUNCH();
+        const int64_t tiles = (N + CHX_BLOCK - 1) / CHX_BLOCK;
+        if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+        const int in_ok = (int)chx_aligned16(x_in), out_ok = (int)chx_aligned16(x_out);
+        const int mode = storage_precision[0];
+        if (mode == 2)
+            hipLaunchKernelGGL(dkd_chain_kernel<2>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp,
+                               (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok);
+        else if (mode == 1)
+            hipLaunchKernelGGL(dkd_chain_kernel<1>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp,
+                               (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok);
+        else
+            hipLaunchKernelGGL(dkd_chain_kernel<0>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp,
+                               (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok);
+        CHX_CHECK_LAUNCH();
+    } else {
+        const void* src = x_in;
+        const void* e_src = energy_in;
+        for (int64_t e = 0; e < E; ++e) {
+            void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;          // the last element lands in x_out
+            void* e_dst = (char*)energies + (size_t)e * esz;
+            const int st = chx_dkd_track_p(kinds[e], src, params[e], e_src, mass_eV, n_charges, num_steps[e], fringe_at[e], 1, 1, 1, 1,
+                                           N, dtype, storage_precision[e], dst, e_dst, stream);
+            if (st != CHX_OK) return st;
+            src = dst;
+            e_src = e_dst;
+        }
     }
     // the path length behind the run: every kind's first parameter is its length
     for (int64_t done = 0; s_out && done < E; done += kDkdSChunk) {

@@ -92,7 +92,9 @@ def test_segment_tracks_a_drift_kick_drift_run_in_one_call(dt):
         out = seg.track(beam)
     finally:
         _ops.dkd_chain = orig
-    assert calls == [4, 3], calls            # (the Dipole brings its own parameter list: tracked on its own, like the Drift behind it)
+    # (the Dipole brings its own parameter list: tracked on its own, like the Drift behind it; a float32 run is cut where a
+    # stretch of Drifts and Quadrupoles of one arithmetic mode begins: that stretch keeps its particles in registers)
+    assert calls == ([2, 2, 3] if dt == torch.float32 else [4, 3]), calls
     ref = beam
     for e in els:
         ref = e.track(ref)
@@ -206,6 +208,99 @@ def test_second_order_run_cache_follows_every_kind_of_change():
     check(protons)
     check(beam)
     els[1].k1.requires_grad_(True)                        # no assignment, no version change: the differentiable path must take over
+    out = seg.track(beam)
+    out.particles[:, 0].square().mean().backward()
+    assert els[1].k1.grad is not None and float(els[1].k1.grad.abs()) > 0
+    with torch.no_grad():
+        check(beam)
+
+
+@pytest.mark.parametrize("precision", ["mixed", "double", "storage"])
+def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(precision):
+    """A float32 run of Drifts and Quadrupoles of one arithmetic mode is two launches with the particles in registers
+    (chx_dkd_chain -> dkd_chain_kernel): particles, energy and s equal the elements tracked one after the other (drift.py:106-154,
+    quadrupole.py:174-240) bit for bit — low energy (the reference energy's float32 round trip matters), several steps, a tilted
+    and a shifted quadrupole, a tile that is not full."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(12)
+    dkd = {"tracking_method": "drift_kick_drift"}
+    for energy, n in ((4.2e6, 20_011), (1.3e9, 777)):
+        beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(2e-4), sigma_px=t(3e-5), sigma_y=t(1e-4), sigma_py=t(2e-5),
+                                               sigma_tau=t(1e-4), sigma_p=t(2e-3), energy=t(energy), **kw)
+        els = []
+        for c in range(6):
+            els += [ca.Quadrupole(t(0.2), k1=t(3.0 + 0.1 * c), num_steps=1 + c % 3, **dkd, **kw), ca.Drift(t(0.5 + 0.01 * c), **dkd, **kw),
+                    ca.Quadrupole(t(0.15), k1=t(-2.5), tilt=t(0.05 * c), **dkd, **kw), ca.Drift(t(0.3), **dkd, **kw)]
+        els[6] = ca.Quadrupole(t(0.2), k1=t(1.5), misalignment=t([2e-4, -1e-4]), **dkd, **kw)
+        els[10] = ca.Quadrupole(t(0.2), k1=t(0.0), **dkd, **kw)
+        for e in els:
+            e.dkd_precision = precision
+        seg = ca.Segment(els)
+        calls, orig = [], _ops.dkd_chain
+        _ops.dkd_chain = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
+        try:
+            out = seg.track(beam)
+            again = seg.track(beam)                    # the run from Segment's cache
+        finally:
+            _ops.dkd_chain = orig
+        assert calls == [24, 24], calls
+        ref = beam
+        for e in els:
+            ref = e.track(ref)
+        for o in (out, again):
+            assert torch.equal(o.particles, ref.particles) and torch.equal(o.energy, ref.energy) and torch.equal(o.s, ref.s)
+        assert torch.isfinite(out.particles).all()
+
+
+def test_drift_kick_drift_run_cache_follows_every_kind_of_change():
+    """Segment keeps a drift-kick-drift run as it found it (Segment._dkd_run) while nothing changed. A setting edited in place,
+    an attribute assigned (a setting, the arithmetic mode, the step count), a setting that starts to require a gradient, another
+    energy or species: every track still equals the elements tracked one after the other (the reference re-reads its settings on
+    every call, quadrupole.py:174-240)."""
+    import cheetah_amd as ca
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(13)
+    dkd = {"tracking_method": "drift_kick_drift"}
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_007, sigma_x=t(2e-4), sigma_px=t(3e-5), sigma_p=t(1e-3), energy=t(9e7), **kw)
+    els = [ca.Drift(t(0.3), **dkd, **kw), ca.Quadrupole(t(0.2), k1=t(3.1), **dkd, **kw), ca.Drift(t(0.7), **dkd, **kw),
+           ca.Quadrupole(t(0.2), k1=t(-2.9), **dkd, **kw), ca.Drift(t(0.2), **dkd, **kw)]
+    seg = ca.Segment(els)
+
+    def check(b):
+        out = seg.track(b)
+        ref = b
+        for e in els:
+            ref = e.track(ref)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s) and torch.equal(out.energy, ref.energy)
+        return out
+
+    first = check(beam)
+    assert torch.equal(check(beam).particles, first.particles)
+    assert seg.__dict__["_dkd_run_cache"][1], "the run was not kept"
+    els[1].k1.mul_(1.5)                                   # in place
+    assert not torch.equal(check(beam).particles, first.particles)
+    els[2].length.add_(0.25)
+    check(beam)
+    els[3].k1 = t(-1.0)                                   # assigned
+    check(beam)
+    els[3].num_steps = 3
+    check(beam)
+    els[1].dkd_precision = "double"                       # the run is cut differently now
+    check(beam)
+    els[1].dkd_precision = "mixed"
+    check(beam)
+    other = ca.ParticleBeam(beam.particles.clone(), t(7.5e7), particle_charges=beam.particle_charges, species=beam.species, **kw)
+    check(other)
+    protons = ca.ParticleBeam(beam.particles.clone(), t(2e9), particle_charges=beam.particle_charges, species=ca.Species("proton"), **kw)
+    check(protons)
+    check(beam)
+    els[1].k1.requires_grad_(True)                        # no assignment, no version change: the differentiable path takes over
     out = seg.track(beam)
     out.particles[:, 0].square().mean().backward()
     assert els[1].k1.grad is not None and float(els[1].k1.grad.abs()) > 0
