@@ -350,17 +350,36 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_kernel(const T* __restrict__ x_
 // arithmetic (the reference's own float32 run: 8e-3 / 4e-5), 5e-7 / 7e-14 in float64 arithmetic — at 2-3 times the kernel time,
 // because then the per-particle cos / sin / cosh / sinh of the quadrupole and five square roots run in fp64 as well.
 // Here: the (tau, delta) <-> (z, pz) conversions, the z accumulator, the low-energy correction and the misalignment shift run in
-// fp64 — one square root and three divisions per particle (delta' is formed from the particle's own energy: pz does not change
-// inside these two elements, so the round trip through p is the identity) — everything else in float32, including the
-// increments of z (a RELATIVE error of 1e-7 on an increment is 1e-16 of z's scale).
-enum { C_ETOT = C_N + 1, C_BETA0, C_ME2, C_MIXED_N };
-// the three extra constants of the mixed evaluation, behind dkd_constants' (lane 0 of a workgroup / of a prepare kernel)
+// fp64 — one square root and one reciprocal per particle, both from the hardware seeds (delta' is formed from the particle's
+// own energy: pz does not change inside these two elements, so the round trip through p is the identity) — everything else in
+// float32, including the increments of z (a RELATIVE error of 1e-7 on an increment is 1e-16 of z's scale).
+enum { C_ETOT = C_N + 1, C_BETA0, C_ME2, C_INVP0C, C_INVBETA0, C_MIXED_N };
+// the extra constants of the mixed evaluation, behind dkd_constants' (lane 0 of a workgroup / of a prepare kernel)
 __device__ __forceinline__ void dkd_mixed_constants(double* cst_, double mc2) {
     const double p0c = cst_[C_P0C];
     const double e_tot = sqrt(p0c * p0c + mc2 * mc2);
     cst_[C_ETOT] = e_tot;
     cst_[C_BETA0] = p0c / e_tot;
     cst_[C_ME2] = (mc2 / e_tot) * (mc2 / e_tot);
+    cst_[C_INVP0C] = 1.0 / p0c;
+    cst_[C_INVBETA0] = e_tot / p0c;
+}
+// fp64 square root and reciprocal from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-26) and Newton steps in fused multiply-adds:
+// a few ulp of a double, a third of the instructions of the correctly rounded library forms. What they feed is rounded to float32
+// at the end of the element (2^-24): the extra 2^-51 is invisible there.
+__device__ __forceinline__ double dkd_sqrt_fast(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    y = y * fma(-0.5 * a, y * y, 1.5);
+    y = y * fma(-0.5 * a, y * y, 1.5);
+    double s = a * y;
+    s = fma(0.5 * y, fma(-s, s, a), s);
+    return a == 0.0 ? 0.0 : s;
+}
+__device__ __forceinline__ double dkd_rcp_fast(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
 }
 // one particle through one element, v = (x, px, y, py, tau, delta) in float32 before and after
 template <int KIND>
@@ -381,11 +400,13 @@ __device__ __forceinline__ void dkd_mixed_particle(const double* __restrict__ cs
     float x = v[0], px = v[1], y = v[2], py = v[3];
     const double tau = (double)v[4], delta = (double)v[5];
     // (tau, delta) -> (z, pz), bmadx.py:7-31, fp64
+    const double inv_p0c = cst_[C_INVP0C];
     const double en = E + delta * p0c;
-    const double pc = sqrt(en * en - mc2 * mc2);
-    const double beta = pc / en;
+    const double pc = dkd_sqrt_fast(en * en - mc2 * mc2);
+    const double r = dkd_rcp_fast(pc * en);
+    const double beta = (pc * pc) * r, inv_beta = (en * en) * r;          // pc / en and en / pc from one reciprocal
     double z = -beta * tau;
-    const double pz = (pc - p0c) / p0c;
+    const double pz = (pc - p0c) * inv_p0c;
     const float pzf = (float)pz, mc2f = (float)mc2, p0cf = (float)p0c;
     const float relp = 1.0f + pzf;
     if (KIND == CHX_DKD_DRIFT) {                                  // bmadx.py:263-298
@@ -404,7 +425,10 @@ __device__ __forceinline__ void dkd_mixed_particle(const double* __restrict__ cs
         z = z + (double)(L * (so_a + so_b * iPl));
     } else {                                                      // quadrupole.py:168-251, bmadx.py:219-252
         const double xo = cst_[C_XO], yo = cst_[C_YO], sn = cst_[C_SIN], cs = cst_[C_COS];
-        {   // offset_set: the shift by the misalignment in fp64 (it may be hundreds of beam sizes), the rotation with it
+        // (here xo = yo = 0.) An upright quadrupole — sin(tilt) = 0, cos(tilt) = 1 — is rotated by the identity: x * 1 + y * 0 is
+        // x again, so the two rotations are left out (wave-uniform), value for value the same result
+        const bool upright = sn == 0.0 && cs == 1.0;
+        if (!upright) {   // offset_set: the shift by the misalignment in fp64 (it may be hundreds of beam sizes), the rotation with it
             const double xi = (double)x - xo, yi = (double)y - yo;
             const float xr = (float)(xi * cs + yi * sn), yr = (float)(-xi * sn + yi * cs);
             const float pxr = (float)((double)px * cs + (double)py * sn), pyr = (float)(-(double)px * sn + (double)py * cs);
@@ -423,7 +447,7 @@ __device__ __forceinline__ void dkd_mixed_particle(const double* __restrict__ cs
             if (mc2 * (b0pz * b0pz) < 3e-7 * e_tot)
                 dzc = ds * pz * (1.0 - 3.0 * (pz * b02) / 2.0 + pz * pz * b02 * (2.0 * b02 - me2 / 2.0)) * me2;
             else
-                dzc = ds * (beta - beta0) / beta0;                // (beta of this particle: pc / en above)
+                dzc = ds * (beta - beta0) * cst_[C_INVBETA0];     // (beta of this particle: pc / en above)
         }
         for (int s = 0; s < num_steps; ++s) {
             const float dz = tx.c1.v * (x * x) + tx.c2.v * x * px + tx.c3.v * (px * px) + ty.c1.v * (y * y) + ty.c2.v * y * py +
@@ -433,7 +457,7 @@ __device__ __forceinline__ void dkd_mixed_particle(const double* __restrict__ cs
             x = xn; px = pxn; y = yn; py = pyn;
             z = z + (double)dz + dzc;
         }
-        {   // offset_unset
+        if (!upright) {   // offset_unset
             const double xi = (double)x * cs - (double)y * sn, yi = (double)x * sn + (double)y * cs;
             const float pxr = (float)((double)px * cs - (double)py * sn), pyr = (float)((double)px * sn + (double)py * cs);
             x = (float)(xi + xo); y = (float)(yi + yo); px = pxr; py = pyr;
@@ -442,8 +466,8 @@ __device__ __forceinline__ void dkd_mixed_particle(const double* __restrict__ cs
     // (z, pz) -> (tau, delta), bmadx.py:34-56: pz is unchanged, so p = pc and the particle's energy is `en` again
     const double ref = cst_[C_ETOT];
     v[0] = x; v[1] = px; v[2] = y; v[3] = py;
-    v[4] = (float)(-z / beta);
-    v[5] = (float)((en - ref) / p0c);
+    v[4] = (float)(-z * inv_beta);
+    v[5] = (float)((en - ref) * inv_p0c);
 }
 
 template <int KIND>
@@ -821,15 +845,13 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
         if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
         const int in_ok = (int)chx_aligned16(x_in), out_ok = (int)chx_aligned16(x_out);
         const int mode = storage_precision[0];
-        if (mode == 2)
-            hipLaunchKernelGGL(dkd_chain_kernel<2>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp,
-                               (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok);
-        else if (mode == 1)
-            hipLaunchKernelGGL(dkd_chain_kernel<1>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp,
-                               (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok);
-        else
-            hipLaunchKernelGGL(dkd_chain_kernel<0>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp,
-                               (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok);
+#define CHX_DKD_CHAIN_LAUNCH(M)                                                                                                  \
+    hipLaunchKernelGGL(dkd_chain_kernel<M>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp, \
+                       (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok)
+        if (mode == 2) CHX_DKD_CHAIN_LAUNCH(2);
+        else if (mode == 1) CHX_DKD_CHAIN_LAUNCH(1);
+        else CHX_DKD_CHAIN_LAUNCH(0);
+#undef CHX_DKD_CHAIN_LAUNCH
         CHX_CHECK_LAUNCH();
     } else {
         const void* src = x_in;
