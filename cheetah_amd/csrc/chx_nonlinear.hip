@@ -778,9 +778,9 @@ __device__ __forceinline__ void dkd_chain_step(const double* __restrict__ c, dou
 }
 
 template <int MODE>
-__global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* __restrict__ x_in, const double* __restrict__ cst, int E,
-                                                              double mc2, float* __restrict__ x_out, int64_t N, int in_vec_ok,
-                                                              int out_vec_ok) {
+__global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* x_in, const double* __restrict__ cst, int E, double mc2,
+                                                              float* x_out, int64_t N, int in_vec_ok, int out_vec_ok) {
+    // (x_out may be x_in: a tile is read whole before it is written)
     constexpr int TP = CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) float lds[TP * 7];
     const int64_t n0 = (int64_t)blockIdx.x * TP;
@@ -823,36 +823,43 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    // float32 Drifts and Quadrupoles of one arithmetic mode, a run that fits one argument block and whose constants (192 bytes
-    // per element) fit x_tmp: the particles stay in registers (dkd_chain_kernel), two launches, the same bits
+    // float32 Drifts and Quadrupoles of one arithmetic mode, the constants (192 bytes per element) in x_tmp: the particles stay
+    // in registers (dkd_chain_kernel), two launches per 320 elements, the same bits
     static const bool fused_off = [] { const char* v = getenv("CHX_DKD_CHAIN_FUSED"); return v && v[0] == '0'; }();
-    bool fuse = !fused_off && dtype == CHX_F32 && E >= 2 && E <= kDkdChainMax &&
-                (int64_t)E * kDkdCstStride * (int64_t)sizeof(double) <= N * 7 * (int64_t)sizeof(float) && chx_aligned16(x_tmp);
+    // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
+    // before it writes)
+    const int64_t per_pass = std::min<int64_t>(kDkdChainMax, N * 7 * (int64_t)sizeof(float) / (kDkdCstStride * (int64_t)sizeof(double)));
+    bool fuse = !fused_off && dtype == CHX_F32 && E >= 2 && per_pass >= 2 && chx_aligned16(x_tmp);
     for (int64_t e = 0; fuse && e < E; ++e)
         fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE) && storage_precision[e] == storage_precision[0] &&
                storage_precision[e] >= 0 && storage_precision[e] <= 2 && num_steps[e] >= 1 && num_steps[e] < (1 << 27) && params[e];
     if (fuse) {
-        DkdChainArgs a;
-        for (int e = 0; e < kDkdChainMax; ++e) {
-            a.params[e] = e < E ? params[e] : nullptr;
-            a.meta[e] = e < E ? (kinds[e] | (num_steps[e] << 4)) : 0;
-        }
         hipStream_t s = (hipStream_t)stream;
-        hipLaunchKernelGGL(dkd_chain_prepare_kernel, dim3((unsigned)E), dim3(64), 0, s, a, (int)E, (const float*)energy_in, mass_eV,
-                           n_charges, (double*)x_tmp, (float*)energies);
-        CHX_CHECK_LAUNCH();
         const int64_t tiles = (N + CHX_BLOCK - 1) / CHX_BLOCK;
         if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
-        const int in_ok = (int)chx_aligned16(x_in), out_ok = (int)chx_aligned16(x_out);
         const int mode = storage_precision[0];
-#define CHX_DKD_CHAIN_LAUNCH(M)                                                                                                  \
-    hipLaunchKernelGGL(dkd_chain_kernel<M>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const double*)x_tmp, \
-                       (int)E, mass_eV, (float*)x_out, N, in_ok, out_ok)
-        if (mode == 2) CHX_DKD_CHAIN_LAUNCH(2);
-        else if (mode == 1) CHX_DKD_CHAIN_LAUNCH(1);
-        else CHX_DKD_CHAIN_LAUNCH(0);
+        for (int64_t done = 0; done < E; done += per_pass) {
+            const int n = (int)std::min<int64_t>(per_pass, E - done);
+            DkdChainArgs a;
+            for (int e = 0; e < kDkdChainMax; ++e) {
+                a.params[e] = e < n ? params[done + e] : nullptr;
+                a.meta[e] = e < n ? (kinds[done + e] | (num_steps[done + e] << 4)) : 0;
+            }
+            const float* e_from = done == 0 ? (const float*)energy_in : (const float*)energies + (done - 1);
+            hipLaunchKernelGGL(dkd_chain_prepare_kernel, dim3((unsigned)n), dim3(64), 0, s, a, n, e_from, mass_eV, n_charges, (double*)x_tmp,
+                               (float*)energies + done);
+            CHX_CHECK_LAUNCH();
+            const void* src = done == 0 ? x_in : x_out;
+            const int in_ok = (int)chx_aligned16(src), out_ok = (int)chx_aligned16(x_out);
+#define CHX_DKD_CHAIN_LAUNCH(M)                                                                                                    \
+    hipLaunchKernelGGL(dkd_chain_kernel<M>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const double*)x_tmp, n, \
+                       mass_eV, (float*)x_out, N, in_ok, out_ok)
+            if (mode == 2) CHX_DKD_CHAIN_LAUNCH(2);
+            else if (mode == 1) CHX_DKD_CHAIN_LAUNCH(1);
+            else CHX_DKD_CHAIN_LAUNCH(0);
 #undef CHX_DKD_CHAIN_LAUNCH
-        CHX_CHECK_LAUNCH();
+            CHX_CHECK_LAUNCH();
+        }
     } else {
         const void* src = x_in;
         const void* e_src = energy_in;
@@ -1000,8 +1007,8 @@ __device__ __forceinline__ void so_step_groups(const float* __restrict__ U, chx_
 }
 
 __global__ __launch_bounds__(CHX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void so_chain_kernel(const float* __restrict__ x_in, const float* __restrict__ coef, int E, float* __restrict__ x_out, int64_t N,
-                     int in_vec_ok, int out_vec_ok) {
+void so_chain_kernel(const float* x_in, const float* __restrict__ coef, int E, float* x_out, int64_t N, int in_vec_ok,
+                     int out_vec_ok) {                  // (x_out may be x_in: a tile is read whole before it is written)
     constexpr int TP = 2 * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) float lds[TP * 7];
     const int64_t n0 = (int64_t)blockIdx.x * TP;
@@ -1049,20 +1056,27 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     for (int64_t e = 0; e < E; ++e)
         if (!T_maps[e]) return CHX_ERR_INVALID_ARG;
-    // float32, a run that fits one argument block and a scratch of 800 bytes per element inside x_tmp: the particles stay in
-    // registers for the whole run (so_chain_kernel) — two launches instead of E passes over HBM, the same bits
+    // float32 and a scratch of 800 bytes per element inside x_tmp: the particles stay in registers for the whole run
+    // (so_chain_kernel) — two launches per 448 elements instead of E passes over HBM, the same bits
     static const bool fused_off = [] { const char* v = getenv("CHX_SO_CHAIN_FUSED"); return v && v[0] == '0'; }();
-    if (!fused_off && dtype == CHX_F32 && E >= 2 && E <= kSoChainMax && (int64_t)E * kSoCoefStride <= N * 7) {
-        SoChainPtrs maps;
-        for (int e = 0; e < kSoChainMax; ++e) maps.T[e] = e < E ? T_maps[e] : nullptr;
+    // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
+    // before it writes)
+    const int64_t per_pass = std::min<int64_t>(kSoChainMax, N * 7 / kSoCoefStride);
+    if (!fused_off && dtype == CHX_F32 && E >= 2 && per_pass >= 2) {
         hipStream_t s = (hipStream_t)stream;
-        hipLaunchKernelGGL(so_chain_coeff_kernel, dim3((unsigned)E), dim3(CHX_BLOCK), 0, s, maps, (float*)x_tmp);
-        CHX_CHECK_LAUNCH();
         const int64_t tiles = (N + 2 * CHX_BLOCK - 1) / (2 * CHX_BLOCK);
         if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
-        hipLaunchKernelGGL(so_chain_kernel, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const float*)x_tmp, (int)E,
-                           (float*)x_out, N, (int)chx_aligned16(x_in), (int)chx_aligned16(x_out));
-        CHX_CHECK_LAUNCH();
+        for (int64_t done = 0; done < E; done += per_pass) {
+            const int n = (int)std::min<int64_t>(per_pass, E - done);
+            SoChainPtrs maps;
+            for (int e = 0; e < kSoChainMax; ++e) maps.T[e] = e < n ? T_maps[done + e] : nullptr;
+            hipLaunchKernelGGL(so_chain_coeff_kernel, dim3((unsigned)n), dim3(CHX_BLOCK), 0, s, maps, (float*)x_tmp);
+            CHX_CHECK_LAUNCH();
+            const void* src = done == 0 ? x_in : x_out;
+            hipLaunchKernelGGL(so_chain_kernel, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const float*)x_tmp, n,
+                               (float*)x_out, N, (int)chx_aligned16(src), (int)chx_aligned16(x_out));
+            CHX_CHECK_LAUNCH();
+        }
     } else {
         const void* src = x_in;
         for (int64_t e = 0; e < E; ++e) {

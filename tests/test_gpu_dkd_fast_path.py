@@ -220,7 +220,7 @@ def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(preci
     """A float32 run of Drifts and Quadrupoles of one arithmetic mode is two launches with the particles in registers
     (chx_dkd_chain -> dkd_chain_kernel): particles, energy and s equal the elements tracked one after the other (drift.py:106-154,
     quadrupole.py:174-240) bit for bit — low energy (the reference energy's float32 round trip matters), several steps, a tilted
-    and a shifted quadrupole, a tile that is not full."""
+    and a shifted quadrupole, a tile that is not full, a beam so small that the elements' constants need several passes."""
     import cheetah_amd as ca
     from cheetah_amd import _ops
 
@@ -228,7 +228,7 @@ def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(preci
     t = lambda v: torch.tensor(v, **kw)  # noqa: E731
     torch.manual_seed(12)
     dkd = {"tracking_method": "drift_kick_drift"}
-    for energy, n in ((4.2e6, 20_011), (1.3e9, 777)):
+    for energy, n in ((4.2e6, 20_011), (1.3e9, 777), (6e7, 70)):       # (70 particles: the run goes through in three passes)
         beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(2e-4), sigma_px=t(3e-5), sigma_y=t(1e-4), sigma_py=t(2e-5),
                                                sigma_tau=t(1e-4), sigma_p=t(2e-3), energy=t(energy), **kw)
         els = []
@@ -306,3 +306,24 @@ def test_drift_kick_drift_run_cache_follows_every_kind_of_change():
     assert els[1].k1.grad is not None and float(els[1].k1.grad.abs()) > 0
     with torch.no_grad():
         check(beam)
+
+
+def test_long_second_order_run_on_a_small_beam_goes_through_in_several_passes():
+    """chx_second_order_chain keeps the folded coefficients of a run in the scratch rows of the beam (800 bytes per element): 60
+    particles hold two elements per pass, later passes run in place. Same bits as the elements one by one (element.py:195-228)."""
+    import cheetah_amd as ca
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(21)
+    so = {"tracking_method": "second_order"}
+    for n in (60, 9):                                   # (9 particles: no room for two elements — element by element)
+        beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(3e-4), sigma_px=t(4e-5), sigma_p=t(2e-3), energy=t(6e7), **kw)
+        els = [ca.Drift(t(0.4), **so, **kw), ca.Quadrupole(t(0.2), k1=t(3.3), **so, **kw), ca.Drift(t(0.6), **so, **kw),
+               ca.Dipole(t(0.5), angle=t(0.03), **so, **kw), ca.Quadrupole(t(0.2), k1=t(-2.0), tilt=t(0.3), **so, **kw),
+               ca.Drift(t(0.3), **so, **kw), ca.Sextupole(t(0.1), k2=t(12.0), **so, **kw)]
+        out = ca.Segment(els).track(beam)
+        ref = beam
+        for e in els:
+            ref = e.track(ref)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s)
