@@ -423,8 +423,9 @@ def other_configs(ca, torch, device) -> dict:
                     ca.Drift(tt(0.8), tracking_method="drift_kick_drift", **kw)]
         beam = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES, **kw)
         res = {"workload": "100-element FODO, drift_kick_drift (Bmad-X) tracking of every element, 1e6 particles, fp32: "
-                           "Segment.track (no element of this lattice can be merged with another: 100 particle passes, issued by "
-                           "one chx_dkd_chain call) and the elements' own track() one after the other"}
+                           "Segment.track (no element of this lattice can be merged with another; one chx_dkd_chain call carries "
+                           "every particle through the 100 maps in registers: one read and one write of the beam) and the "
+                           "elements' own track() one after the other (100 passes over HBM)"}
         seg = ca.Segment(els)
 
         def by_segment():
@@ -449,8 +450,12 @@ def other_configs(ca, torch, device) -> dict:
                     run()
                 torch.cuda.synchronize()
                 ms = (_t.perf_counter() - t0) / 5 * 1e3
-                res[label][how] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
-                                   "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
+                res[label][how] = {"ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3)}
+                if how == "element_by_element":          # 56 B per particle and element through HBM
+                    res[label][how]["achieved_GBs"] = 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9
+                else:                                    # 56 B per particle and TRACK: bound by the maps' arithmetic
+                    res[label][how]["hbm_bytes_per_track"] = 56.0 * N_PARTICLES
+                    res[label][how]["bound"] = "valu (particles in registers across the run)"
         res["note"] = ("dkd_precision: mixed (default of float32 beams: tau / delta in fp64, the rest in float32), double, storage; "
                        "per-element kernel times and measured errors against the reference's float64 run: "
                        "profiles/r04_dkd_precision.md, tests/test_gpu_bench_parity.py")
@@ -470,18 +475,32 @@ def other_configs(ca, torch, device) -> dict:
                     ca.Quadrupole(tt(0.2), k1=tt(-4.2), **so, **kw), ca.Drift(tt(0.8), **so, **kw)]
         seg = ca.Segment(els)
         beam = ca.ParticleBeam.from_parameters(num_particles=N_PARTICLES, **kw)
+
+        def one_by_one():
+            b = beam
+            for e in els:
+                b = e.track(b)
+            return b
+
+        times = {}
         with torch.no_grad():
-            for _ in range(3):
-                seg.track(beam)
-            torch.cuda.synchronize()
-            t0 = _t.perf_counter()
-            for _ in range(10):
-                seg.track(beam)
-            torch.cuda.synchronize()
-        ms = (_t.perf_counter() - t0) / 10 * 1e3
-        return {"workload": "100-element FODO, second_order tracking of every element, 1e6 particles, fp32, Segment.track",
+            for how, run in (("segment_track", lambda: seg.track(beam)), ("element_by_element", one_by_one)):
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                t0 = _t.perf_counter()
+                for _ in range(10):
+                    run()
+                torch.cuda.synchronize()
+                times[how] = (_t.perf_counter() - t0) / 10 * 1e3
+        ms = times["segment_track"]
+        return {"workload": "100-element FODO, second_order tracking of every element, 1e6 particles, fp32: Segment.track (one "
+                            "chx_second_order_chain call: every particle through the 100 maps in registers, one read and one write "
+                            "of the beam) and the elements' own track() one after the other (100 passes over HBM)",
                 "ms_per_track": ms, "particle_element_steps_per_s": N_PARTICLES * len(els) / (ms * 1e-3),
-                "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (ms * 1e-3) / 1e9}
+                "hbm_bytes_per_track": 56.0 * N_PARTICLES, "bound": "valu (particles in registers across the run)",
+                "element_by_element": {"ms_per_track": times["element_by_element"],
+                                       "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (times["element_by_element"] * 1e-3) / 1e9}}
 
     for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order)):
         guarded(name, fn)

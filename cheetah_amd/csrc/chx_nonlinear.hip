@@ -730,12 +730,29 @@ __device__ __forceinline__ float dkd_energy_round_trip(float E, float m) {      
 }
 
 __global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const float* __restrict__ energy_in, double mc2, double nq,
-                                         double* __restrict__ cst, float* __restrict__ energies) {
+                                         double* __restrict__ cst, float* __restrict__ energies, const float* s_in, float* s_out) {
     const int e = blockIdx.x;
-    if (threadIdx.x != 0 || e >= E) return;
+    if (e == E) {
+        // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in float32 like the reference's
+        // element-by-element additions (every kind's first parameter is its length; s_out may be s_in)
+        __shared__ float len[kDkdChainMax];
+        for (int k = threadIdx.x; k < E; k += blockDim.x) len[k] = ((const float*)args.params[k])[0];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sum = *s_in;
+            for (int k = 0; k < E; ++k) sum = sum + len[k];
+            *s_out = sum;
+        }
+        return;
+    }
+    if (threadIdx.x != 0) return;
     const float m = (float)mc2;
     float Ee = *energy_in;
-    for (int k = 0; k < e; ++k) Ee = dkd_energy_round_trip(Ee, m);
+    for (int k = 0; k < e; ++k) {
+        const float En = dkd_energy_round_trip(Ee, m);
+        if (En == Ee) break;              // a fixed point: every later round trip returns it again
+        Ee = En;
+    }
     const int kind = args.meta[e] & 15, steps = args.meta[e] >> 4;
     const int P = kind == CHX_DKD_DRIFT ? 1 : 5;
     double par[CHX_MAX_PARAMS];
@@ -846,8 +863,9 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
                 a.meta[e] = e < n ? (kinds[done + e] | (num_steps[done + e] << 4)) : 0;
             }
             const float* e_from = done == 0 ? (const float*)energy_in : (const float*)energies + (done - 1);
-            hipLaunchKernelGGL(dkd_chain_prepare_kernel, dim3((unsigned)n), dim3(64), 0, s, a, n, e_from, mass_eV, n_charges, (double*)x_tmp,
-                               (float*)energies + done);
+            hipLaunchKernelGGL(dkd_chain_prepare_kernel, dim3((unsigned)(n + (s_out ? 1 : 0))), dim3(64), 0, s, a, n, e_from, mass_eV,
+                               n_charges, (double*)x_tmp, (float*)energies + done, (const float*)(done == 0 ? s_in : s_out),
+                               (float*)s_out);
             CHX_CHECK_LAUNCH();
             const void* src = done == 0 ? x_in : x_out;
             const int in_ok = (int)chx_aligned16(src), out_ok = (int)chx_aligned16(x_out);
@@ -873,8 +891,8 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
             e_src = e_dst;
         }
     }
-    // the path length behind the run: every kind's first parameter is its length
-    for (int64_t done = 0; s_out && done < E; done += kDkdSChunk) {
+    // the path length behind the run: every kind's first parameter is its length (the fused form has it from its first launch)
+    for (int64_t done = 0; s_out && !fuse && done < E; done += kDkdSChunk) {
         DkdLengthPtrs a;
         const int n = (int)((E - done < kDkdSChunk) ? (E - done) : kDkdSChunk);
         for (int e = 0; e < kDkdSChunk; ++e) a.p[e] = e < n ? params[done + e] : nullptr;
@@ -902,10 +920,12 @@ namespace {
 //   scheme 0: the 27 coefficients an upright Quadrupole can have (a Drift's 15 are among them): 13 products + 27 multiply-adds;
 //   scheme 1: the 55 of upright Dipoles (edges, gradient), RBends and Sextupoles: 22 products + 55 multiply-adds;
 //   scheme 2: anything else (tilted, misaligned, custom maps): groups of four coefficients, skipped when all four are zero.
-constexpr int kSoChainMax = 448;           // T pointers per launch (kernel-argument space)
-constexpr int kSoCoefStride = 200;         // floats per element in the scratch: 196 coefficients, 2 group-mask words, the scheme
+constexpr int kSoChainMax = 224;           // elements per launch pair (kernel-argument space: a map and a length pointer each)
+constexpr int kSoCoefStride = 256;         // floats per element in the scratch: 196 coefficients, 2 group-mask words, the scheme,
+constexpr int kSoPacked = 200;             // one unused; from kSoPacked on the coefficients of the element's pattern, back to back
 struct SoChainPtrs {
     const void* T[kSoChainMax];
+    const void* length[kSoChainMax];
 };
 // bit c of row i = coefficient (i, c) of the folded map, c = the pair (j <= k) in the order 00 01 .. 06 11 12 .. 66
 struct SoPatternQuad {
@@ -917,8 +937,23 @@ struct SoPatternBend {
 constexpr int kSoJ[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
 constexpr int kSoK[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
 
-__global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs maps, float* __restrict__ coef) {
+__global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs maps, int E, float* __restrict__ coef, const float* s_in,
+                                                                   float* s_out) {
     const int e = blockIdx.x;
+    if (e == E) {
+        // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in float32 like the reference's
+        // element-by-element additions (s_out may be s_in)
+        static_assert(kSoChainMax <= CHX_BLOCK, "one lane per length");
+        __shared__ float len[kSoChainMax];
+        if (threadIdx.x < E) len[threadIdx.x] = *(const float*)maps.length[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sum = *s_in;
+            for (int k = 0; k < E; ++k) sum = sum + len[k];
+            *s_out = sum;
+        }
+        return;
+    }
     const float* Tt = (const float*)maps.T[e];
     float* out = coef + (int64_t)e * kSoCoefStride;
     float u = 0.0f;
@@ -952,30 +987,61 @@ __global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs m
             w[199] = 0u;
         }
     }
+    // the pattern's coefficients back to back (row by row, ascending c): three or four wide scalar loads per element and wave
+    // instead of seventeen narrow ones — the scalar memory path of a CU serves its 32 waves one request at a time
+    if (threadIdx.x < 7 * 28 && outside[1] == 0u) {
+        const unsigned int* rows = outside[0] == 0u ? SoPatternQuad::rows : SoPatternBend::rows;
+        if ((rows[i] >> c) & 1u) {
+            int n = __popc(rows[i] & ((1u << c) - 1u));
+            for (int r = 0; r < i; ++r) n += __popc(rows[r]);
+            out[kSoPacked + n] = u;
+        }
+    }
 }
 
 // one element, coefficients of a fixed pattern: every product once, every row its multiply-adds in ascending c
 template <class P>
-__device__ __forceinline__ void so_step_pattern(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
+struct SoPatternSize {
+    static constexpr int count() {
+        int n = 0;
+        for (int i = 0; i < 7; ++i)
+            for (int c = 0; c < 28; ++c) n += (P::rows[i] >> c) & 1u;
+        return n;
+    }
+};
+template <class P>
+__device__ __forceinline__ void so_load_pattern(const float* __restrict__ U, float (&u)[SoPatternSize<P>::count()]) {
+#pragma unroll
+    for (int n = 0; n < SoPatternSize<P>::count(); ++n) u[n] = U[kSoPacked + n];
+}
+template <class P>
+__device__ __forceinline__ void so_eval_pattern(const float (&u)[SoPatternSize<P>::count()], chx_v2f (&x)[7], chx_v2f probe) {
     constexpr unsigned int cols = P::rows[0] | P::rows[1] | P::rows[2] | P::rows[3] | P::rows[4] | P::rows[5] | P::rows[6];
     chx_v2f q[28];
 #pragma unroll
     for (int c = 0; c < 28; ++c)
         if ((cols >> c) & 1u) q[c] = x[kSoJ[c]] * x[kSoK[c]];
     chx_v2f y[7];
+    int n = 0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         chx_v2f acc = probe;
 #pragma unroll
         for (int c = 0; c < 28; ++c)
             if ((P::rows[i] >> c) & 1u) {
-                const float u = U[i * 28 + c];
-                acc = __builtin_elementwise_fma(chx_v2f{u, u}, q[c], acc);
+                const float uu = u[n++];
+                acc = __builtin_elementwise_fma(chx_v2f{uu, uu}, q[c], acc);
             }
         y[i] = acc;
     }
 #pragma unroll
     for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+template <class P>
+__device__ __forceinline__ void so_step_pattern(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
+    float u[SoPatternSize<P>::count()];
+    so_load_pattern<P>(U, u);
+    so_eval_pattern<P>(u, x, probe);
 }
 
 __device__ __forceinline__ void so_step_groups(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
@@ -1056,21 +1122,27 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     for (int64_t e = 0; e < E; ++e)
         if (!T_maps[e]) return CHX_ERR_INVALID_ARG;
-    // float32 and a scratch of 800 bytes per element inside x_tmp: the particles stay in registers for the whole run
-    // (so_chain_kernel) — two launches per 448 elements instead of E passes over HBM, the same bits
+    // float32 and a scratch of 1 KiB per element inside x_tmp: the particles stay in registers for the whole run
+    // (so_chain_kernel) — two launches per 224 elements instead of E passes over HBM, the same bits
     static const bool fused_off = [] { const char* v = getenv("CHX_SO_CHAIN_FUSED"); return v && v[0] == '0'; }();
     // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
     // before it writes)
     const int64_t per_pass = std::min<int64_t>(kSoChainMax, N * 7 / kSoCoefStride);
-    if (!fused_off && dtype == CHX_F32 && E >= 2 && per_pass >= 2) {
+    const bool fuse = !fused_off && dtype == CHX_F32 && E >= 2 && per_pass >= 2;
+    if (fuse) {
         hipStream_t s = (hipStream_t)stream;
         const int64_t tiles = (N + 2 * CHX_BLOCK - 1) / (2 * CHX_BLOCK);
         if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
         for (int64_t done = 0; done < E; done += per_pass) {
             const int n = (int)std::min<int64_t>(per_pass, E - done);
             SoChainPtrs maps;
-            for (int e = 0; e < kSoChainMax; ++e) maps.T[e] = e < n ? T_maps[done + e] : nullptr;
-            hipLaunchKernelGGL(so_chain_coeff_kernel, dim3((unsigned)n), dim3(CHX_BLOCK), 0, s, maps, (float*)x_tmp);
+            for (int e = 0; e < kSoChainMax; ++e) {
+                maps.T[e] = e < n ? T_maps[done + e] : nullptr;
+                maps.length[e] = e < n ? lengths[done + e] : nullptr;
+                if (s_out && e < n && !maps.length[e]) return CHX_ERR_INVALID_ARG;
+            }
+            hipLaunchKernelGGL(so_chain_coeff_kernel, dim3((unsigned)(n + (s_out ? 1 : 0))), dim3(CHX_BLOCK), 0, s, maps, n, (float*)x_tmp,
+                               (const float*)(done == 0 ? s_in : s_out), (float*)s_out);
             CHX_CHECK_LAUNCH();
             const void* src = done == 0 ? x_in : x_out;
             hipLaunchKernelGGL(so_chain_kernel, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const float*)x_tmp, n,
@@ -1086,7 +1158,7 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
             src = dst;
         }
     }
-    for (int64_t done = 0; s_out && done < E; done += kDkdSChunk) {
+    for (int64_t done = 0; s_out && !fuse && done < E; done += kDkdSChunk) {      // (the fused form has s from its first launch)
         DkdLengthPtrs a;
         const int n = (int)((E - done < kDkdSChunk) ? (E - done) : kDkdSChunk);
         for (int e = 0; e < kDkdSChunk; ++e) a.p[e] = e < n ? lengths[done + e] : nullptr;

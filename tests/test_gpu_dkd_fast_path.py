@@ -309,15 +309,15 @@ def test_drift_kick_drift_run_cache_follows_every_kind_of_change():
 
 
 def test_long_second_order_run_on_a_small_beam_goes_through_in_several_passes():
-    """chx_second_order_chain keeps the folded coefficients of a run in the scratch rows of the beam (800 bytes per element): 60
-    particles hold two elements per pass, later passes run in place. Same bits as the elements one by one (element.py:195-228)."""
+    """chx_second_order_chain keeps the folded coefficients of a run in the scratch rows of the beam (1 KiB per element): 150
+    particles hold four elements per pass, later passes run in place. Same bits as the elements one by one (element.py:195-228)."""
     import cheetah_amd as ca
 
     kw = {"dtype": torch.float32, "device": "cuda"}
     t = lambda v: torch.tensor(v, **kw)  # noqa: E731
     torch.manual_seed(21)
     so = {"tracking_method": "second_order"}
-    for n in (60, 9):                                   # (9 particles: no room for two elements — element by element)
+    for n in (150, 9):                                  # (9 particles: no room for two elements — element by element)
         beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(3e-4), sigma_px=t(4e-5), sigma_p=t(2e-3), energy=t(6e7), **kw)
         els = [ca.Drift(t(0.4), **so, **kw), ca.Quadrupole(t(0.2), k1=t(3.3), **so, **kw), ca.Drift(t(0.6), **so, **kw),
                ca.Dipole(t(0.5), angle=t(0.03), **so, **kw), ca.Quadrupole(t(0.2), k1=t(-2.0), tilt=t(0.3), **so, **kw),
