@@ -925,10 +925,12 @@ class Segment(Element):
             storage.append(_ops.DKD_PRECISION[e.dkd_precision])
             tensors.append([t for t, _ in e._builder_scalar_refs()])
             j += 1
-        # float32 Drifts and Quadrupoles of one arithmetic mode go through the device with the particles in registers
+        # Drifts and Quadrupoles of one arithmetic mode go through the device with the particles in registers
         # (chx_dkd_chain's two-launch form): the run is cut so that such a stretch is a call of its own
-        if x.dtype == torch.float32:
-            fusable = [storage[k] if kinds[k] in _DKD_IN_REGISTERS else -1 for k in range(j - i)]
+        if x.dtype in (torch.float32, torch.float64):
+            # (float64 beams are evaluated in fp64 whatever `dkd_precision` says: one class)
+            single = x.dtype == torch.float64
+            fusable = [(0 if single else storage[k]) if kinds[k] in _DKD_IN_REGISTERS else -1 for k in range(j - i)]
             n = len(fusable)
             if n >= 2 and fusable[0] >= 0 and fusable[1] == fusable[0]:
                 k = 2

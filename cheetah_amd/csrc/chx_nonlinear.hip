@@ -724,39 +724,41 @@ struct DkdChainArgs {
     int32_t meta[kDkdChainMax];            // kind | num_steps << 4
 };
 
-__device__ __forceinline__ float dkd_energy_round_trip(float E, float m) {       // ref_energy of bmadx.py:49, storage dtype
-    const float p0 = sqrtf(E * E - m * m);
-    return sqrtf(p0 * p0 + m * m);
+template <typename T>
+__device__ __forceinline__ T dkd_energy_round_trip(T E, T m) {       // ref_energy of bmadx.py:49, storage dtype
+    const T p0 = sqrt(E * E - m * m);
+    return sqrt(p0 * p0 + m * m);
 }
 
-__global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const float* __restrict__ energy_in, double mc2, double nq,
-                                         double* __restrict__ cst, float* __restrict__ energies, const float* s_in, float* s_out) {
+template <typename T>
+__global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const T* __restrict__ energy_in, double mc2, double nq,
+                                         double* __restrict__ cst, T* __restrict__ energies, const T* s_in, T* s_out) {
     const int e = blockIdx.x;
     if (e == E) {
-        // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in float32 like the reference's
-        // element-by-element additions (every kind's first parameter is its length; s_out may be s_in)
-        __shared__ float len[kDkdChainMax];
-        for (int k = threadIdx.x; k < E; k += blockDim.x) len[k] = ((const float*)args.params[k])[0];
+        // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in the beam's dtype like the
+        // reference's element-by-element additions (every kind's first parameter is its length; s_out may be s_in)
+        __shared__ T len[kDkdChainMax];
+        for (int k = threadIdx.x; k < E; k += blockDim.x) len[k] = ((const T*)args.params[k])[0];
         __syncthreads();
         if (threadIdx.x == 0) {
-            float sum = *s_in;
+            T sum = *s_in;
             for (int k = 0; k < E; ++k) sum = sum + len[k];
             *s_out = sum;
         }
         return;
     }
     if (threadIdx.x != 0) return;
-    const float m = (float)mc2;
-    float Ee = *energy_in;
+    const T m = (T)mc2;
+    T Ee = *energy_in;
     for (int k = 0; k < e; ++k) {
-        const float En = dkd_energy_round_trip(Ee, m);
+        const T En = dkd_energy_round_trip<T>(Ee, m);
         if (En == Ee) break;              // a fixed point: every later round trip returns it again
         Ee = En;
     }
     const int kind = args.meta[e] & 15, steps = args.meta[e] >> 4;
     const int P = kind == CHX_DKD_DRIFT ? 1 : 5;
     double par[CHX_MAX_PARAMS];
-    const float* pe = (const float*)args.params[e];
+    const T* pe = (const T*)args.params[e];
     for (int k = 0; k < P; ++k) par[k] = (double)pe[k];
     double c[kDkdCstStride];
     for (int k = 0; k < kDkdCstStride; ++k) c[k] = 0.0;
@@ -767,7 +769,7 @@ __global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const float* 
     int32_t* w = reinterpret_cast<int32_t*>(out + C_MIXED_N);
     w[0] = kind;
     w[1] = steps;
-    energies[e] = dkd_energy_round_trip(Ee, m);
+    energies[e] = dkd_energy_round_trip<T>(Ee, m);
 }
 
 // MODE: chx_dkd_track_p's storage_precision — 0 fp64 evaluation, 1 float32 evaluation, 2 mixed
@@ -823,6 +825,38 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* x_in,
     __syncthreads();
     tile_store<float, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
 }
+
+// float64 beams: the map in fp64 like dkd_kernel<double, ., double>, a particle per lane
+__global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel_f64(const double* x_in, const double* __restrict__ cst, int E, double mc2,
+                                                                  double* x_out, int64_t N, int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = CHX_BLOCK;              // (x_out may be x_in: a tile is read whole before it is written)
+    __shared__ __attribute__((aligned(16))) double lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    tile_load<double, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
+    __syncthreads();
+    const int p = threadIdx.x;
+    double v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] = p < np ? lds[p * 7 + j] : 0.0;
+    for (int e = 0; e < E; ++e) {
+        const double* __restrict__ c = cst + (int64_t)e * kDkdCstStride;
+        const int32_t* w = reinterpret_cast<const int32_t*>(c + C_MIXED_N);
+        const int kind = w[0], steps = w[1];
+        double out[6];
+        if (kind == CHX_DKD_DRIFT) dkd_map<CHX_DKD_DRIFT, double>(c, v, mc2, steps, out);
+        else dkd_map<CHX_DKD_QUADRUPOLE, double>(c, v, mc2, steps, out);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = out[j];
+    }
+    if (p < np) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) lds[p * 7 + j] = v[j];
+        lds[p * 7 + 6] = 1.0;
+    }
+    __syncthreads();
+    tile_store<double, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
+}
 }  // namespace
 
 // A run of drift-kick-drift elements on ONE beam with scalar settings. float32 Drifts and Quadrupoles of one arithmetic mode: two
@@ -840,16 +874,17 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    // float32 Drifts and Quadrupoles of one arithmetic mode, the constants (192 bytes per element) in x_tmp: the particles stay
-    // in registers (dkd_chain_kernel), two launches per 320 elements, the same bits
+    // Drifts and Quadrupoles (float32: of one arithmetic mode), the constants (192 bytes per element) in x_tmp: the particles stay
+    // in registers (dkd_chain_kernel, dkd_chain_kernel_f64), two launches per 320 elements, the same bits
     static const bool fused_off = [] { const char* v = getenv("CHX_DKD_CHAIN_FUSED"); return v && v[0] == '0'; }();
     // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
     // before it writes)
-    const int64_t per_pass = std::min<int64_t>(kDkdChainMax, N * 7 * (int64_t)sizeof(float) / (kDkdCstStride * (int64_t)sizeof(double)));
-    bool fuse = !fused_off && dtype == CHX_F32 && E >= 2 && per_pass >= 2 && chx_aligned16(x_tmp);
-    for (int64_t e = 0; fuse && e < E; ++e)
-        fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE) && storage_precision[e] == storage_precision[0] &&
-               storage_precision[e] >= 0 && storage_precision[e] <= 2 && num_steps[e] >= 1 && num_steps[e] < (1 << 27) && params[e];
+    const int64_t per_pass = std::min<int64_t>(kDkdChainMax, N * 7 * (int64_t)esz / (kDkdCstStride * (int64_t)sizeof(double)));
+    bool fuse = !fused_off && E >= 2 && per_pass >= 2 && chx_aligned16(x_tmp);
+    for (int64_t e = 0; fuse && e < E; ++e)        // (float64 beams ignore storage_precision, like chx_dkd_track_p)
+        fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE) &&
+               (dtype == CHX_F64 || (storage_precision[e] == storage_precision[0] && storage_precision[e] >= 0 && storage_precision[e] <= 2)) &&
+               num_steps[e] >= 1 && num_steps[e] < (1 << 27) && params[e];
     if (fuse) {
         hipStream_t s = (hipStream_t)stream;
         const int64_t tiles = (N + CHX_BLOCK - 1) / CHX_BLOCK;
@@ -862,13 +897,24 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
                 a.params[e] = e < n ? params[done + e] : nullptr;
                 a.meta[e] = e < n ? (kinds[done + e] | (num_steps[done + e] << 4)) : 0;
             }
-            const float* e_from = done == 0 ? (const float*)energy_in : (const float*)energies + (done - 1);
-            hipLaunchKernelGGL(dkd_chain_prepare_kernel, dim3((unsigned)(n + (s_out ? 1 : 0))), dim3(64), 0, s, a, n, e_from, mass_eV,
-                               n_charges, (double*)x_tmp, (float*)energies + done, (const float*)(done == 0 ? s_in : s_out),
-                               (float*)s_out);
-            CHX_CHECK_LAUNCH();
+            const void* e_from = done == 0 ? energy_in : (const void*)((const char*)energies + (size_t)(done - 1) * esz);
+            void* e_to = (char*)energies + (size_t)done * esz;
+            const void* s_from = done == 0 ? s_in : s_out;
+            const unsigned blocks = (unsigned)(n + (s_out ? 1 : 0));
             const void* src = done == 0 ? x_in : x_out;
             const int in_ok = (int)chx_aligned16(src), out_ok = (int)chx_aligned16(x_out);
+            if (dtype == CHX_F64) {
+                hipLaunchKernelGGL(dkd_chain_prepare_kernel<double>, dim3(blocks), dim3(64), 0, s, a, n, (const double*)e_from, mass_eV,
+                                   n_charges, (double*)x_tmp, (double*)e_to, (const double*)s_from, (double*)s_out);
+                CHX_CHECK_LAUNCH();
+                hipLaunchKernelGGL(dkd_chain_kernel_f64, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const double*)src,
+                                   (const double*)x_tmp, n, mass_eV, (double*)x_out, N, in_ok, out_ok);
+                CHX_CHECK_LAUNCH();
+                continue;
+            }
+            hipLaunchKernelGGL(dkd_chain_prepare_kernel<float>, dim3(blocks), dim3(64), 0, s, a, n, (const float*)e_from, mass_eV,
+                               n_charges, (double*)x_tmp, (float*)e_to, (const float*)s_from, (float*)s_out);
+            CHX_CHECK_LAUNCH();
 #define CHX_DKD_CHAIN_LAUNCH(M)                                                                                                    \
     hipLaunchKernelGGL(dkd_chain_kernel<M>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const double*)x_tmp, n, \
                        mass_eV, (float*)x_out, N, in_ok, out_ok)
@@ -937,32 +983,32 @@ struct SoPatternBend {
 constexpr int kSoJ[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
 constexpr int kSoK[28] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
 
-__global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs maps, int E, float* __restrict__ coef, const float* s_in,
-                                                                   float* s_out) {
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs maps, int E, T* __restrict__ coef, const T* s_in, T* s_out) {
     const int e = blockIdx.x;
     if (e == E) {
-        // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in float32 like the reference's
+        // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in the beam's dtype like the reference's
         // element-by-element additions (s_out may be s_in)
         static_assert(kSoChainMax <= CHX_BLOCK, "one lane per length");
-        __shared__ float len[kSoChainMax];
-        if (threadIdx.x < E) len[threadIdx.x] = *(const float*)maps.length[threadIdx.x];
+        __shared__ T len[kSoChainMax];
+        if (threadIdx.x < E) len[threadIdx.x] = *(const T*)maps.length[threadIdx.x];
         __syncthreads();
         if (threadIdx.x == 0) {
-            float sum = *s_in;
+            T sum = *s_in;
             for (int k = 0; k < E; ++k) sum = sum + len[k];
             *s_out = sum;
         }
         return;
     }
-    const float* Tt = (const float*)maps.T[e];
-    float* out = coef + (int64_t)e * kSoCoefStride;
-    float u = 0.0f;
+    const T* Tt = (const T*)maps.T[e];
+    T* out = coef + (int64_t)e * kSoCoefStride;
+    T u = (T)0;
     int i = 0, c = 0;
     if (threadIdx.x < 7 * 28) {
         i = threadIdx.x / 28;
         c = threadIdx.x - i * 28;
         const int j = kSoJ[c], k = kSoK[c];
-        const float* Tb = Tt + i * 49;
+        const T* Tb = Tt + i * 49;
         u = (j == k) ? Tb[j * 7 + k] : Tb[j * 7 + k] + Tb[k * 7 + j];
         out[threadIdx.x] = u;
     }
@@ -971,7 +1017,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs m
     if (threadIdx.x < 64) any4[threadIdx.x] = 0u;
     if (threadIdx.x < 2) outside[threadIdx.x] = 0u;
     __syncthreads();
-    if (threadIdx.x < 7 * 28 && u != 0.0f) {
+    if (threadIdx.x < 7 * 28 && u != (T)0) {
         atomicOr(&any4[threadIdx.x >> 2], 1u);
         if (!((SoPatternQuad::rows[i] >> c) & 1u)) atomicOr(&outside[0], 1u);
         if (!((SoPatternBend::rows[i] >> c) & 1u)) atomicOr(&outside[1], 1u);
@@ -980,11 +1026,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs m
     if (threadIdx.x < 64) {
         const unsigned long long m = __ballot(threadIdx.x < 49 && any4[threadIdx.x] != 0u);
         if (threadIdx.x == 0) {
-            unsigned int* w = reinterpret_cast<unsigned int*>(out);
-            w[196] = (unsigned int)(m & 0xffffffffull);
-            w[197] = (unsigned int)(m >> 32);
-            w[198] = outside[0] == 0u ? 0u : (outside[1] == 0u ? 1u : 2u);
-            w[199] = 0u;
+            unsigned int* w = reinterpret_cast<unsigned int*>(out + 196);        // three 32-bit words behind the coefficients
+            w[0] = (unsigned int)(m & 0xffffffffull);
+            w[1] = (unsigned int)(m >> 32);
+            w[2] = outside[0] == 0u ? 0u : (outside[1] == 0u ? 1u : 2u);
+            w[3] = 0u;
         }
     }
     // the pattern's coefficients back to back (row by row, ascending c): three or four wide scalar loads per element and wave
@@ -1045,8 +1091,8 @@ __device__ __forceinline__ void so_step_pattern(const float* __restrict__ U, chx
 }
 
 __device__ __forceinline__ void so_step_groups(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
-    const unsigned long long g = (unsigned long long)reinterpret_cast<const unsigned int*>(U)[196] |
-                                 ((unsigned long long)reinterpret_cast<const unsigned int*>(U)[197] << 32);
+    const unsigned long long g = (unsigned long long)reinterpret_cast<const unsigned int*>(U + 196)[0] |
+                                 ((unsigned long long)reinterpret_cast<const unsigned int*>(U + 196)[1] << 32);
     chx_v2f y[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -1088,7 +1134,7 @@ void so_chain_kernel(const float* x_in, const float* __restrict__ coef, int E, f
     for (int j = 0; j < 7; ++j) x[j] = chx_v2f{on0 ? lds[p0 * 7 + j] : 0.0f, on1 ? lds[p1 * 7 + j] : 0.0f};
     for (int e = 0; e < E; ++e) {
         const float* __restrict__ U = coef + (int64_t)e * kSoCoefStride;
-        const unsigned int scheme = reinterpret_cast<const unsigned int*>(U)[198];
+        const unsigned int scheme = reinterpret_cast<const unsigned int*>(U + 196)[2];
         // 0 * x is NaN exactly for a non-finite x and +0 otherwise: every row's sum STARTS from this value, so a particle that
         // left the finite range comes out as NaN in all seven coordinates (second_order_pk_kernel's rule) and nothing changes
         // for the others (+0 + a = a)
@@ -1108,6 +1154,83 @@ void so_chain_kernel(const float* x_in, const float* __restrict__ coef, int E, f
     tile_store<float, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
 }
 
+
+// ---- the same for float64 beams: one particle per lane, fp64 multiply-adds. second_order_kernel<double> sums a row densely
+// (U_i0 q_0, then 27 multiply-adds); leaving out the terms whose coefficient is an exact zero changes no value of a finite beam
+// (fma(0, q, acc) = acc), a non-finite coordinate turns the whole particle into NaN there (0 * inf) and here (the probe).
+template <class P>
+__device__ __forceinline__ void so_step_pattern_f64(const double* __restrict__ U, double (&x)[7], double probe) {
+    constexpr unsigned int cols = P::rows[0] | P::rows[1] | P::rows[2] | P::rows[3] | P::rows[4] | P::rows[5] | P::rows[6];
+    double q[28];
+#pragma unroll
+    for (int c = 0; c < 28; ++c)
+        if ((cols >> c) & 1u) q[c] = x[kSoJ[c]] * x[kSoK[c]];
+    double y[7];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double acc = probe;
+#pragma unroll
+        for (int c = 0; c < 28; ++c)
+            if ((P::rows[i] >> c) & 1u) acc = fma(U[kSoPacked + n++], q[c], acc);
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+
+__device__ __forceinline__ void so_step_groups_f64(const double* __restrict__ U, double (&x)[7], double probe) {
+    const unsigned long long g = (unsigned long long)reinterpret_cast<const unsigned int*>(U + 196)[0] |
+                                 ((unsigned long long)reinterpret_cast<const unsigned int*>(U + 196)[1] << 32);
+    double y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double acc = probe;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            if (!((g >> (i * 7 + m)) & 1ull)) continue;           // wave-uniform
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 4 * m + q4;
+                acc = fma(U[i * 28 + c], x[kSoJ[c]] * x[kSoK[c]], acc);
+            }
+        }
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+
+__global__ __launch_bounds__(CHX_BLOCK) void so_chain_kernel_f64(const double* x_in, const double* __restrict__ coef, int E, double* x_out,
+                                                                 int64_t N, int in_vec_ok, int out_vec_ok) {
+    constexpr int TP = CHX_BLOCK;              // (x_out may be x_in: a tile is read whole before it is written)
+    __shared__ __attribute__((aligned(16))) double lds[TP * 7];
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    tile_load<double, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
+    __syncthreads();
+    const int p = threadIdx.x;
+    double x[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = p < np ? lds[p * 7 + j] : 0.0;
+    for (int e = 0; e < E; ++e) {
+        const double* __restrict__ U = coef + (int64_t)e * kSoCoefStride;
+        const unsigned int scheme = reinterpret_cast<const unsigned int*>(U + 196)[2];
+        double probe = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) probe = fma(0.0, x[j], probe);
+        if (scheme == 0u) so_step_pattern_f64<SoPatternQuad>(U, x, probe);
+        else if (scheme == 1u) so_step_pattern_f64<SoPatternBend>(U, x, probe);
+        else so_step_groups_f64(U, x, probe);
+    }
+    if (p < np) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x[j];
+    }
+    __syncthreads();
+    tile_store<double, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
+}
+
 }  // namespace
 
 // A run of elements tracked with their second-order maps (element.py:195-228) on ONE beam. float32: the particles stay in
@@ -1122,16 +1245,17 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     for (int64_t e = 0; e < E; ++e)
         if (!T_maps[e]) return CHX_ERR_INVALID_ARG;
-    // float32 and a scratch of 1 KiB per element inside x_tmp: the particles stay in registers for the whole run
-    // (so_chain_kernel) — two launches per 224 elements instead of E passes over HBM, the same bits
+    // a scratch of 256 coefficients per element inside x_tmp: the particles stay in registers for the whole run (so_chain_kernel,
+    // so_chain_kernel_f64) — two launches per 224 elements instead of E passes over HBM, the same values
     static const bool fused_off = [] { const char* v = getenv("CHX_SO_CHAIN_FUSED"); return v && v[0] == '0'; }();
     // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
     // before it writes)
     const int64_t per_pass = std::min<int64_t>(kSoChainMax, N * 7 / kSoCoefStride);
-    const bool fuse = !fused_off && dtype == CHX_F32 && E >= 2 && per_pass >= 2;
+    const bool fuse = !fused_off && E >= 2 && per_pass >= 2;
     if (fuse) {
         hipStream_t s = (hipStream_t)stream;
-        const int64_t tiles = (N + 2 * CHX_BLOCK - 1) / (2 * CHX_BLOCK);
+        const int per_tile = dtype == CHX_F32 ? 2 * CHX_BLOCK : CHX_BLOCK;
+        const int64_t tiles = (N + per_tile - 1) / per_tile;
         if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
         for (int64_t done = 0; done < E; done += per_pass) {
             const int n = (int)std::min<int64_t>(per_pass, E - done);
@@ -1141,12 +1265,22 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
                 maps.length[e] = e < n ? lengths[done + e] : nullptr;
                 if (s_out && e < n && !maps.length[e]) return CHX_ERR_INVALID_ARG;
             }
-            hipLaunchKernelGGL(so_chain_coeff_kernel, dim3((unsigned)(n + (s_out ? 1 : 0))), dim3(CHX_BLOCK), 0, s, maps, n, (float*)x_tmp,
-                               (const float*)(done == 0 ? s_in : s_out), (float*)s_out);
-            CHX_CHECK_LAUNCH();
             const void* src = done == 0 ? x_in : x_out;
-            hipLaunchKernelGGL(so_chain_kernel, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const float*)x_tmp, n,
-                               (float*)x_out, N, (int)chx_aligned16(src), (int)chx_aligned16(x_out));
+            const void* s_from = done == 0 ? s_in : s_out;
+            const unsigned blocks = (unsigned)(n + (s_out ? 1 : 0));
+            if (dtype == CHX_F32) {
+                hipLaunchKernelGGL(so_chain_coeff_kernel<float>, dim3(blocks), dim3(CHX_BLOCK), 0, s, maps, n, (float*)x_tmp,
+                                   (const float*)s_from, (float*)s_out);
+                CHX_CHECK_LAUNCH();
+                hipLaunchKernelGGL(so_chain_kernel, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const float*)x_tmp, n,
+                                   (float*)x_out, N, (int)chx_aligned16(src), (int)chx_aligned16(x_out));
+            } else {
+                hipLaunchKernelGGL(so_chain_coeff_kernel<double>, dim3(blocks), dim3(CHX_BLOCK), 0, s, maps, n, (double*)x_tmp,
+                                   (const double*)s_from, (double*)s_out);
+                CHX_CHECK_LAUNCH();
+                hipLaunchKernelGGL(so_chain_kernel_f64, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const double*)src,
+                                   (const double*)x_tmp, n, (double*)x_out, N, (int)chx_aligned16(src), (int)chx_aligned16(x_out));
+            }
             CHX_CHECK_LAUNCH();
         }
     } else {

@@ -633,9 +633,9 @@ int chx_dkd_track_p(int kind, const void* x_in, const void* params, const void* 
  * non-mergeable map, e.g. quadrupole.py:174-240) on one beam x_in[N][7] with scalar settings: HOST arrays kinds[E],
  * params[E] (device pointers to each element's parameter array), num_steps[E], fringe_at[E], storage_precision[E]; the
  * reference energy travels from element to element on the device (energies[E] (dtype): what each element leaves; energy_in one
- * scalar). x_tmp[N][7] is scratch (may be NULL for E = 1); x_out receives the last element's particles. float32 Drifts and
- * Quadrupoles of one storage_precision: two launches per 320 elements, the particles in registers across the run (x_tmp holds
- * the elements' constants); otherwise E launches. Either way one call and the bits of E separate chx_dkd_track_p calls.
+ * scalar). x_tmp[N][7] is scratch (may be NULL for E = 1); x_out receives the last element's particles. Drifts and Quadrupoles
+ * (float32 beams: of one storage_precision): two launches per 320 elements, the particles in registers across the run (x_tmp
+ * holds the elements' constants); otherwise E launches. Either way one call and the bits of E separate chx_dkd_track_p calls.
  * s_in / s_out (one scalar of dtype each, both or neither): the path length, s_out = (((s_in + l_0) + l_1) + ...) with the
  * lengths added one by one in dtype like the reference's `s=incoming.s + self.length` per element. */
 int chx_dkd_chain(const int32_t* kinds, const void* const* params, const int32_t* num_steps, const int32_t* fringe_at,
@@ -687,9 +687,9 @@ int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t
 /* A run of E elements tracked with their second-order maps on one beam x_in[N][7] (a lattice with tracking_method =
  * "second_order": element.py:195-228 once per element): HOST arrays T_maps[E] (device pointers to each element's [7][7][7] map)
  * and lengths[E] (device pointers to the elements' length scalars, only read when s_in / s_out are given: s_out = (((s_in +
- * l_0) + l_1) + ...) in dtype). x_tmp[N][7] is scratch (may be NULL for E = 1). float32: two launches per 224 elements, the
- * particles in registers across the run (x_tmp holds the folded coefficients, 1 KiB per element); float64, or a beam too small
- * for that scratch: E launches. Either way one call and the bits of E separate chx_apply_second_order calls. */
+ * l_0) + l_1) + ...) in dtype). x_tmp[N][7] is scratch (may be NULL for E = 1). Two launches per 224 elements, the particles in
+ * registers across the run (x_tmp holds the folded coefficients, 256 per element); a beam too small for that scratch: E
+ * launches. Either way one call and the values of E separate chx_apply_second_order calls (an exact zero may differ in sign). */
 int chx_second_order_chain(const void* const* T_maps, const void* const* lengths, int64_t E, const void* x_in, int64_t N, int dtype,
                            void* x_out, void* x_tmp, const void* s_in, void* s_out, void* stream);
 /* Derivatives of the two calls above (reference: torch autograd through track_methods.py:80-296 and the einsum).

@@ -165,13 +165,14 @@ def test_segment_tracks_a_second_order_run_in_one_call(dt):
         _ops.second_order_chain = orig
 
 
-def test_second_order_run_cache_follows_every_kind_of_change():
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_second_order_run_cache_follows_every_kind_of_change(dt):
     """A second-order run is looked up once and reused while nothing changed (Segment._second_order_run). What can change —
     a setting edited in place, an attribute assigned, a setting that starts to require a gradient, another energy tensor, another
     species — must be seen: every track equals the elements tracked one after the other (element.py:195-228), bit for bit."""
     import cheetah_amd as ca
 
-    kw = {"dtype": torch.float32, "device": "cuda"}
+    kw = {"dtype": dt, "device": "cuda"}
     t = lambda v: torch.tensor(v, **kw)  # noqa: E731
     torch.manual_seed(8)
     beam = ca.ParticleBeam.from_parameters(num_particles=30_011, sigma_x=t(3e-4), sigma_px=t(4e-5), sigma_p=t(2e-3), energy=t(6e7), **kw)
@@ -215,16 +216,17 @@ def test_second_order_run_cache_follows_every_kind_of_change():
         check(beam)
 
 
-@pytest.mark.parametrize("precision", ["mixed", "double", "storage"])
-def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(precision):
-    """A float32 run of Drifts and Quadrupoles of one arithmetic mode is two launches with the particles in registers
+@pytest.mark.parametrize("precision,dt", [("mixed", torch.float32), ("double", torch.float32), ("storage", torch.float32),
+                                          ("mixed", torch.float64)])
+def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(precision, dt):
+    """A run of Drifts and Quadrupoles (float32 beams: of one arithmetic mode) is two launches with the particles in registers
     (chx_dkd_chain -> dkd_chain_kernel): particles, energy and s equal the elements tracked one after the other (drift.py:106-154,
     quadrupole.py:174-240) bit for bit — low energy (the reference energy's float32 round trip matters), several steps, a tilted
     and a shifted quadrupole, a tile that is not full, a beam so small that the elements' constants need several passes."""
     import cheetah_amd as ca
     from cheetah_amd import _ops
 
-    kw = {"dtype": torch.float32, "device": "cuda"}
+    kw = {"dtype": dt, "device": "cuda"}
     t = lambda v: torch.tensor(v, **kw)  # noqa: E731
     torch.manual_seed(12)
     dkd = {"tracking_method": "drift_kick_drift"}
@@ -308,12 +310,13 @@ def test_drift_kick_drift_run_cache_follows_every_kind_of_change():
         check(beam)
 
 
-def test_long_second_order_run_on_a_small_beam_goes_through_in_several_passes():
-    """chx_second_order_chain keeps the folded coefficients of a run in the scratch rows of the beam (1 KiB per element): 150
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_long_second_order_run_on_a_small_beam_goes_through_in_several_passes(dt):
+    """chx_second_order_chain keeps the folded coefficients of a run in the scratch rows of the beam (256 coefficients per element): 150
     particles hold four elements per pass, later passes run in place. Same bits as the elements one by one (element.py:195-228)."""
     import cheetah_amd as ca
 
-    kw = {"dtype": torch.float32, "device": "cuda"}
+    kw = {"dtype": dt, "device": "cuda"}
     t = lambda v: torch.tensor(v, **kw)  # noqa: E731
     torch.manual_seed(21)
     so = {"tracking_method": "second_order"}
