@@ -70,6 +70,9 @@ class Dipole(Element):
         return [self.length, self.angle, self._e1, self._e2, self.tilt, self.fringe_integral,
                 self.fringe_integral_exit, self.gap, self.gap_exit]
 
+    def _dkd_scalar_refs(self):
+        return [(t, None) for t in self._dkd_params()]       # (buffers of the element, RBend's derived face angles included)
+
     def _dkd_options(self):
         return 1, _ops.FRINGE_AT[self.fringe_at]
 

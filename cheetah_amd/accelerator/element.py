@@ -263,14 +263,22 @@ class Element(nn.Module):
         """(num_steps, fringe_at bits) for chx_dkd_track."""
         return 1, 3
 
+    def _dkd_scalar_refs(self):
+        """The drift-kick-drift parameters as (tensor, index) pairs like `_builder_scalar_refs`, for elements whose parameters
+        are persistent tensors of the element (their version counters tell an edit); None for an element with its own
+        `_dkd_params` list that does not say so."""
+        if type(self)._dkd_params is not Element._dkd_params:
+            return None
+        return self._builder_scalar_refs()
+
     def _dkd_params_stacked(self, dtype, device):
         """The (1, P) parameter array of chx_dkd_track for an element whose settings are all device scalars of `dtype` that
         carry no gradient — kept between tracks (one `torch.stack` = one launch + 6 us of host time per element and track
         otherwise). The key holds the element's revision (any assignment) and the settings' version counters (in-place edits).
         None when the element does not qualify."""
-        if type(self)._dkd_params is not Element._dkd_params:
+        refs = self._dkd_scalar_refs()
+        if refs is None:
             return None
-        refs = self._builder_scalar_refs()
         key = [self.__dict__["_revision"], dtype, device]
         grad = torch.is_grad_enabled()
         for t, index in refs:

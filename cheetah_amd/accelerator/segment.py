@@ -350,8 +350,8 @@ class _LatticePlan:
 
 
 _CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
-#: drift-kick-drift kinds chx_dkd_chain carries through a run in registers (float32 beams)
-_DKD_IN_REGISTERS = (_ops.DKD_KIND["drift"], _ops.DKD_KIND["quadrupole"])
+#: drift-kick-drift kinds chx_dkd_chain carries through a run in registers
+_DKD_IN_REGISTERS = (_ops.DKD_KIND["drift"], _ops.DKD_KIND["quadrupole"], _ops.DKD_KIND["dipole"])
 #: CHX_SC_CHAIN = auto (default) | on | off — how `Segment.track` takes [SpaceChargeKick, linear run, SpaceChargeKick, ...]:
 #: "auto" starts on the tile-ordered chain and lets the asynchronous guard (`_chain_allowed`) send a plan whose beam reshuffles
 #: between kicks back to kick-by-kick tracking. The two paths sum the charge in different orders, so WHEN the guard's header
@@ -923,7 +923,7 @@ class Segment(Element):
             steps.append(n)
             fringes.append(f)
             storage.append(_ops.DKD_PRECISION[e.dkd_precision])
-            tensors.append([t for t, _ in e._builder_scalar_refs()])
+            tensors.append([t for t, _ in e._dkd_scalar_refs()])
             j += 1
         # Drifts and Quadrupoles of one arithmetic mode go through the device with the particles in registers
         # (chx_dkd_chain's two-launch form): the run is cut so that such a stretch is a call of its own

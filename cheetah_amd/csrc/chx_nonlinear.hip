@@ -707,7 +707,7 @@ __global__ void dkd_path_length_kernel(DkdLengthPtrs args, int n, const T* __res
     *s_out = s;
 }
 
-// ---- a RUN of Drifts and Quadrupoles on one float32 beam, particles kept in registers (chx_dkd_chain) -----------------------
+// ---- a RUN of Drifts, Quadrupoles and Dipoles on one beam, particles kept in registers (chx_dkd_chain) ---------------------
 // The per-element kernels above are bound by their arithmetic (a quadrupole in mixed arithmetic: ~450 instructions per particle),
 // yet every one of them also moves its 56 bytes per particle through HBM and waits for them at both ends. A run of E elements of
 // one arithmetic mode is two launches:
@@ -721,7 +721,7 @@ constexpr int kDkdChainMax = 320;          // elements per launch pair (kernel-a
 constexpr int kDkdCstStride = 24;          // doubles per element: C_MIXED_N constants, then kind and step count as two ints
 struct DkdChainArgs {
     const void* params[kDkdChainMax];
-    int32_t meta[kDkdChainMax];            // kind | num_steps << 4
+    int32_t meta[kDkdChainMax];            // kind | fringe_at << 4 | num_steps << 6
 };
 
 template <typename T>
@@ -755,14 +755,14 @@ __global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const T* __re
         if (En == Ee) break;              // a fixed point: every later round trip returns it again
         Ee = En;
     }
-    const int kind = args.meta[e] & 15, steps = args.meta[e] >> 4;
-    const int P = kind == CHX_DKD_DRIFT ? 1 : 5;
+    const int kind = args.meta[e] & 15, fringe = (args.meta[e] >> 4) & 3, steps = args.meta[e] >> 6;
+    const int P = kind == CHX_DKD_DRIFT ? 1 : (kind == CHX_DKD_QUADRUPOLE ? 5 : 9);
     double par[CHX_MAX_PARAMS];
     const T* pe = (const T*)args.params[e];
     for (int k = 0; k < P; ++k) par[k] = (double)pe[k];
     double c[kDkdCstStride];
     for (int k = 0; k < kDkdCstStride; ++k) c[k] = 0.0;
-    dkd_constants<double>(kind, par, (double)Ee, mc2, nq, 3, c);
+    dkd_constants<double>(kind, par, (double)Ee, mc2, nq, fringe, c);
     dkd_mixed_constants(c, mc2);
     double* out = cst + (int64_t)e * kDkdCstStride;
     for (int k = 0; k < C_MIXED_N; ++k) out[k] = c[k];
@@ -775,9 +775,9 @@ __global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const T* __re
 // MODE: chx_dkd_track_p's storage_precision — 0 fp64 evaluation, 1 float32 evaluation, 2 mixed
 template <int MODE, int KIND>
 __device__ __forceinline__ void dkd_chain_step(const double* __restrict__ c, double mc2, int num_steps, float (&v)[6]) {
-    if (MODE == 2) {
+    if (MODE == 2 && KIND != CHX_DKD_DIPOLE) {          // (a Dipole in mixed mode: the fp64 evaluation, as chx_dkd_track_p does)
         dkd_mixed_particle<KIND>(c, mc2, num_steps, v);
-    } else if (MODE == 0) {
+    } else if (MODE == 0 || MODE == 2) {
         double in[6], out[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) in[j] = (double)v[j];
@@ -796,7 +796,8 @@ __device__ __forceinline__ void dkd_chain_step(const double* __restrict__ c, dou
     }
 }
 
-template <int MODE>
+// BEND: the run contains Dipoles (their body — asin, atan2, a dozen square roots — costs registers the other runs keep)
+template <int MODE, bool BEND>
 __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* x_in, const double* __restrict__ cst, int E, double mc2,
                                                               float* x_out, int64_t N, int in_vec_ok, int out_vec_ok) {
     // (x_out may be x_in: a tile is read whole before it is written)
@@ -815,7 +816,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* x_in,
         const int32_t* w = reinterpret_cast<const int32_t*>(c + C_MIXED_N);
         const int kind = w[0], steps = w[1];
         if (kind == CHX_DKD_DRIFT) dkd_chain_step<MODE, CHX_DKD_DRIFT>(c, mc2, steps, v);
-        else dkd_chain_step<MODE, CHX_DKD_QUADRUPOLE>(c, mc2, steps, v);
+        else if (!BEND || kind == CHX_DKD_QUADRUPOLE) dkd_chain_step<MODE, CHX_DKD_QUADRUPOLE>(c, mc2, steps, v);
+        else dkd_chain_step<MODE, CHX_DKD_DIPOLE>(c, mc2, steps, v);
     }
     if (p < np) {
 #pragma unroll
@@ -827,6 +829,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* x_in,
 }
 
 // float64 beams: the map in fp64 like dkd_kernel<double, ., double>, a particle per lane
+template <bool BEND>
 __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel_f64(const double* x_in, const double* __restrict__ cst, int E, double mc2,
                                                                   double* x_out, int64_t N, int in_vec_ok, int out_vec_ok) {
     constexpr int TP = CHX_BLOCK;              // (x_out may be x_in: a tile is read whole before it is written)
@@ -845,7 +848,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel_f64(const double* 
         const int kind = w[0], steps = w[1];
         double out[6];
         if (kind == CHX_DKD_DRIFT) dkd_map<CHX_DKD_DRIFT, double>(c, v, mc2, steps, out);
-        else dkd_map<CHX_DKD_QUADRUPOLE, double>(c, v, mc2, steps, out);
+        else if (!BEND || kind == CHX_DKD_QUADRUPOLE) dkd_map<CHX_DKD_QUADRUPOLE, double>(c, v, mc2, steps, out);
+        else dkd_map<CHX_DKD_DIPOLE, double>(c, v, mc2, steps, out);
 #pragma unroll
         for (int j = 0; j < 6; ++j) v[j] = out[j];
     }
@@ -874,17 +878,20 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    // Drifts and Quadrupoles (float32: of one arithmetic mode), the constants (192 bytes per element) in x_tmp: the particles stay
+    // Drifts, Quadrupoles and Dipoles (float32: of one arithmetic mode), the constants (192 bytes per element) in x_tmp: the particles stay
     // in registers (dkd_chain_kernel, dkd_chain_kernel_f64), two launches per 320 elements, the same bits
     static const bool fused_off = [] { const char* v = getenv("CHX_DKD_CHAIN_FUSED"); return v && v[0] == '0'; }();
     // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
     // before it writes)
     const int64_t per_pass = std::min<int64_t>(kDkdChainMax, N * 7 * (int64_t)esz / (kDkdCstStride * (int64_t)sizeof(double)));
     bool fuse = !fused_off && E >= 2 && per_pass >= 2 && chx_aligned16(x_tmp);
-    for (int64_t e = 0; fuse && e < E; ++e)        // (float64 beams ignore storage_precision, like chx_dkd_track_p)
-        fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE) &&
+    bool bend = false;
+    for (int64_t e = 0; fuse && e < E; ++e) {      // (float64 beams ignore storage_precision, like chx_dkd_track_p)
+        fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE || kinds[e] == CHX_DKD_DIPOLE) &&
                (dtype == CHX_F64 || (storage_precision[e] == storage_precision[0] && storage_precision[e] >= 0 && storage_precision[e] <= 2)) &&
-               num_steps[e] >= 1 && num_steps[e] < (1 << 27) && params[e];
+               num_steps[e] >= 1 && num_steps[e] < (1 << 25) && fringe_at[e] >= 0 && fringe_at[e] <= 3 && params[e];
+        bend = bend || kinds[e] == CHX_DKD_DIPOLE;
+    }
     if (fuse) {
         hipStream_t s = (hipStream_t)stream;
         const int64_t tiles = (N + CHX_BLOCK - 1) / CHX_BLOCK;
@@ -895,7 +902,7 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
             DkdChainArgs a;
             for (int e = 0; e < kDkdChainMax; ++e) {
                 a.params[e] = e < n ? params[done + e] : nullptr;
-                a.meta[e] = e < n ? (kinds[done + e] | (num_steps[done + e] << 4)) : 0;
+                a.meta[e] = e < n ? (kinds[done + e] | (fringe_at[done + e] << 4) | (num_steps[done + e] << 6)) : 0;
             }
             const void* e_from = done == 0 ? energy_in : (const void*)((const char*)energies + (size_t)(done - 1) * esz);
             void* e_to = (char*)energies + (size_t)done * esz;
@@ -907,20 +914,27 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
                 hipLaunchKernelGGL(dkd_chain_prepare_kernel<double>, dim3(blocks), dim3(64), 0, s, a, n, (const double*)e_from, mass_eV,
                                    n_charges, (double*)x_tmp, (double*)e_to, (const double*)s_from, (double*)s_out);
                 CHX_CHECK_LAUNCH();
-                hipLaunchKernelGGL(dkd_chain_kernel_f64, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const double*)src,
-                                   (const double*)x_tmp, n, mass_eV, (double*)x_out, N, in_ok, out_ok);
+                if (bend)
+                    hipLaunchKernelGGL(dkd_chain_kernel_f64<true>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const double*)src,
+                                       (const double*)x_tmp, n, mass_eV, (double*)x_out, N, in_ok, out_ok);
+                else
+                    hipLaunchKernelGGL(dkd_chain_kernel_f64<false>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const double*)src,
+                                       (const double*)x_tmp, n, mass_eV, (double*)x_out, N, in_ok, out_ok);
                 CHX_CHECK_LAUNCH();
                 continue;
             }
             hipLaunchKernelGGL(dkd_chain_prepare_kernel<float>, dim3(blocks), dim3(64), 0, s, a, n, (const float*)e_from, mass_eV,
                                n_charges, (double*)x_tmp, (float*)e_to, (const float*)s_from, (float*)s_out);
             CHX_CHECK_LAUNCH();
-#define CHX_DKD_CHAIN_LAUNCH(M)                                                                                                    \
-    hipLaunchKernelGGL(dkd_chain_kernel<M>, dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const double*)x_tmp, n, \
-                       mass_eV, (float*)x_out, N, in_ok, out_ok)
-            if (mode == 2) CHX_DKD_CHAIN_LAUNCH(2);
-            else if (mode == 1) CHX_DKD_CHAIN_LAUNCH(1);
-            else CHX_DKD_CHAIN_LAUNCH(0);
+#define CHX_DKD_CHAIN_LAUNCH(M, B)                                                                                                \
+    hipLaunchKernelGGL((dkd_chain_kernel<M, B>), dim3((unsigned)tiles), dim3(CHX_BLOCK), 0, s, (const float*)src, (const double*)x_tmp, \
+                       n, mass_eV, (float*)x_out, N, in_ok, out_ok)
+            if (mode == 2 && bend) CHX_DKD_CHAIN_LAUNCH(2, true);
+            else if (mode == 2) CHX_DKD_CHAIN_LAUNCH(2, false);
+            else if (mode == 1 && bend) CHX_DKD_CHAIN_LAUNCH(1, true);
+            else if (mode == 1) CHX_DKD_CHAIN_LAUNCH(1, false);
+            else if (bend) CHX_DKD_CHAIN_LAUNCH(0, true);
+            else CHX_DKD_CHAIN_LAUNCH(0, false);
 #undef CHX_DKD_CHAIN_LAUNCH
             CHX_CHECK_LAUNCH();
         }

@@ -633,8 +633,8 @@ int chx_dkd_track_p(int kind, const void* x_in, const void* params, const void* 
  * non-mergeable map, e.g. quadrupole.py:174-240) on one beam x_in[N][7] with scalar settings: HOST arrays kinds[E],
  * params[E] (device pointers to each element's parameter array), num_steps[E], fringe_at[E], storage_precision[E]; the
  * reference energy travels from element to element on the device (energies[E] (dtype): what each element leaves; energy_in one
- * scalar). x_tmp[N][7] is scratch (may be NULL for E = 1); x_out receives the last element's particles. Drifts and Quadrupoles
- * (float32 beams: of one storage_precision): two launches per 320 elements, the particles in registers across the run (x_tmp
+ * scalar). x_tmp[N][7] is scratch (may be NULL for E = 1); x_out receives the last element's particles. Drifts, Quadrupoles and
+ * Dipoles (float32 beams: of one storage_precision): two launches per 320 elements, the particles in registers across the run (x_tmp
  * holds the elements' constants); otherwise E launches. Either way one call and the bits of E separate chx_dkd_track_p calls.
  * s_in / s_out (one scalar of dtype each, both or neither): the path length, s_out = (((s_in + l_0) + l_1) + ...) with the
  * lengths added one by one in dtype like the reference's `s=incoming.s + self.length` per element. */

@@ -92,9 +92,8 @@ def test_segment_tracks_a_drift_kick_drift_run_in_one_call(dt):
         out = seg.track(beam)
     finally:
         _ops.dkd_chain = orig
-    # (the Dipole brings its own parameter list: tracked on its own, like the Drift behind it; a float32 run is cut where a
-    # stretch of Drifts and Quadrupoles of one arithmetic mode begins: that stretch keeps its particles in registers)
-    assert calls == ([2, 2, 3] if dt == torch.float32 else [4, 3]), calls
+    # (a float32 run is cut where a stretch of one arithmetic mode begins: that stretch keeps its particles in registers)
+    assert calls == ([2, 4, 3] if dt == torch.float32 else [6, 3]), calls
     ref = beam
     for e in els:
         ref = e.track(ref)
@@ -219,9 +218,9 @@ def test_second_order_run_cache_follows_every_kind_of_change(dt):
 @pytest.mark.parametrize("precision,dt", [("mixed", torch.float32), ("double", torch.float32), ("storage", torch.float32),
                                           ("mixed", torch.float64)])
 def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(precision, dt):
-    """A run of Drifts and Quadrupoles (float32 beams: of one arithmetic mode) is two launches with the particles in registers
+    """A run of Drifts, Quadrupoles and Dipoles (float32 beams: of one arithmetic mode) is two launches with the particles in registers
     (chx_dkd_chain -> dkd_chain_kernel): particles, energy and s equal the elements tracked one after the other (drift.py:106-154,
-    quadrupole.py:174-240) bit for bit — low energy (the reference energy's float32 round trip matters), several steps, a tilted
+    quadrupole.py:174-240, dipole.py:183-370) bit for bit — low energy (the reference energy's float32 round trip matters), several steps, a tilted
     and a shifted quadrupole, a tile that is not full, a beam so small that the elements' constants need several passes."""
     import cheetah_amd as ca
     from cheetah_amd import _ops
@@ -239,6 +238,10 @@ def test_drifts_and_quadrupoles_in_registers_equal_the_elements_one_by_one(preci
                     ca.Quadrupole(t(0.15), k1=t(-2.5), tilt=t(0.05 * c), **dkd, **kw), ca.Drift(t(0.3), **dkd, **kw)]
         els[6] = ca.Quadrupole(t(0.2), k1=t(1.5), misalignment=t([2e-4, -1e-4]), **dkd, **kw)
         els[10] = ca.Quadrupole(t(0.2), k1=t(0.0), **dkd, **kw)
+        els[14] = ca.Dipole(t(0.4), angle=t(0.05), dipole_e1=t(0.01), dipole_e2=t(0.02), fringe_integral=t(0.5), gap=t(0.02),
+                            **dkd, **kw)
+        els[18] = ca.Dipole(t(0.3), angle=t(-0.03), tilt=t(0.2), fringe_at="entrance", **dkd, **kw)
+        els[19] = ca.RBend(t(0.3), angle=t(0.02), rbend_e1=t(0.004), **dkd, **kw)
         for e in els:
             e.dkd_precision = precision
         seg = ca.Segment(els)
