@@ -173,6 +173,8 @@ SIGNATURES = {
     "chx_build_ttensor": (c_int, [c_int, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_apply_second_order": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "chx_second_order_chain": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_second_order_chain_mixed": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p]),
     "chx_dkd_bwd_partials_count": (c_i64, [c_int, c_i64, c_i64]),
     "chx_dkd_track_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, ctypes.c_int32,
                                   ctypes.c_int32, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),

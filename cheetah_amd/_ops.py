@@ -950,10 +950,12 @@ def apply_second_order(particles: torch.Tensor, T: torch.Tensor) -> torch.Tensor
     return out.reshape(*batch_shape, N, 7)
 
 
-def second_order_chain(T_maps, lengths, x, s, ptrs=None):
-    """A run of second-order elements on one plain beam (chx_second_order_chain): x (N, 7); T_maps = the elements' (7, 7, 7)
-    maps, lengths their 0-d length tensors, s the 0-d path length — all of x's dtype. Returns (particles (N, 7), s, ptrs);
-    `ptrs` (the two address arrays) can be handed back in while T_maps and lengths are the same tensors."""
+def second_order_chain(T_maps, lengths, x, s, ptrs=None, linear=None):
+    """A run of second-order elements on one plain beam (chx_second_order_chain_mixed): x (N, 7); T_maps = the elements' (7, 7, 7)
+    maps, lengths their 0-d length tensors, s the 0-d path length — all of x's dtype. `linear` (a list of 0 / 1, optional) marks
+    entries of T_maps that are (7, 7) first-order maps of merged linear runs in between (their `lengths` entry: the run's summed
+    length). Returns (particles (N, 7), s, ptrs); `ptrs` (the argument arrays) can be handed back in while T_maps and lengths are
+    the same tensors."""
     E, N = len(T_maps), x.shape[0]
     x = aligned(x)
     out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
@@ -961,9 +963,10 @@ def second_order_chain(T_maps, lengths, x, s, ptrs=None):
     s_out = torch.empty((), dtype=x.dtype, device=x.device)
     if ptrs is None:
         arr = ctypes.c_void_p * E
-        ptrs = (arr(*[t.data_ptr() for t in T_maps]), arr(*[t.data_ptr() for t in lengths]))
-    check(_lib.lib().chx_second_order_chain(ptrs[0], ptrs[1], E, ptr(x), N, dtype_code(x.dtype), ptr(out), ptr(tmp), ptr(s),
-                                            ptr(s_out), stream_ptr()), "chx_second_order_chain")
+        flags = (ctypes.c_int32 * E)(*linear) if linear is not None and any(linear) else None
+        ptrs = (arr(*[t.data_ptr() for t in T_maps]), arr(*[t.data_ptr() for t in lengths]), flags)
+    check(_lib.lib().chx_second_order_chain_mixed(ptrs[0], ptrs[2], ptrs[1], E, ptr(x), N, dtype_code(x.dtype), ptr(out), ptr(tmp),
+                                                  ptr(s), ptr(s_out), stream_ptr()), "chx_second_order_chain_mixed")
     return out, s_out, ptrs
 
 

@@ -745,6 +745,11 @@ class Segment(Element):
                 if done is not None:
                     incoming, i = done
                     continue
+            if kind == "run" and i + 1 < n_items and plan[i + 1][0] == "element" and plan[i + 1][1]._tracking_method == "second_order":
+                done = self._second_order_run(plan, i, incoming)          # the run rides in the second-order elements' pass
+                if done is not None:
+                    incoming, i = done
+                    continue
             if kind == "run":
                 fast = self._run_apply_fast(item, incoming)
                 if fast is None:
@@ -827,16 +832,18 @@ class Segment(Element):
                             survival_probabilities=incoming.survival_probabilities, s=s_out, species=sp), i + lp.count
 
     def _second_order_run(self, plan, i: int, incoming: ParticleBeam):
-        """plan[i] and the second-order elements behind it as one `chx_second_order_chain` call: (outgoing beam, index behind
-        the run), or None when fewer than two elements qualify (one plain beam without a graph, (7, 7, 7) maps and scalar
-        lengths of the beam's dtype without gradients, the stock `track`)."""
+        """plan[i] and what follows it as one `chx_second_order_chain_mixed` call — second-order elements and the merged runs of
+        linear elements between them (a lattice whose drifts are linear and whose magnets second order): (outgoing beam, index
+        behind the stretch), or None when fewer than two items or no second-order element qualify (one plain beam without a
+        graph, (7, 7, 7) maps and scalar lengths of the beam's dtype without gradients, the stock `track`; runs with scalar
+        settings). Same numbers as the walk item by item."""
         x, energy, s = incoming.particles, incoming.energy, incoming.s
         if x.dim() != 2 or not x.is_cuda or energy.dim() != 0 or s.dim() != 0 or s.dtype != x.dtype or s.device != x.device or (
                 torch.is_grad_enabled() and (x.requires_grad or energy.requires_grad or s.requires_grad)):
             return None
         grad = torch.is_grad_enabled()
         species = incoming.species
-        # the run as it was found last time stands while no attribute of any element was assigned (`Element._epoch`), the
+        # the stretch as it was found last time stands while no attribute of any element was assigned (`Element._epoch`), the
         # energy is the same tensor at the same version and no setting was edited in place: O(1) + one version sweep instead
         # of ~2.5 us of cache look-ups per element
         cache = self.__dict__.get("_so_run_cache")
@@ -851,27 +858,48 @@ class Segment(Element):
             out, s_out, _ = _ops.second_order_chain(ent["maps"], ent["lengths"], x, s, ent["ptrs"])
             return ParticleBeam(out, energy, particle_charges=incoming.particle_charges,
                                 survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), ent["end"]
-        maps, lengths, tensors = [], [], []
-        j = i
-        while j < len(plan) and plan[j][0] == "element":
-            e = plan[j][1]
-            cls = type(e)
-            if e._tracking_method != "second_order" or e._t_kind is None or cls.track is not Element.track \
-                    or cls._track_second_order is not Element._track_second_order or cls._track_internal is not Element._track_internal:
+        maps, lengths, linear, tensors = [], [], [], []
+        j, last_so = i, None
+        while j < len(plan):
+            kind, e = plan[j]
+            if kind == "run":
+                # a merged run of linear elements: its composed map (chx_run_map, one launch now, none while the stretch stands)
+                # in a tensor of its own — the plan's state is shared with every other way this run can be tracked
+                if j + 1 < len(plan) and plan[j + 1][0] == "element" and plan[j + 1][1]._is_cavity:
+                    break                                      # that run belongs to the cavity's stretch (chx_lattice_track)
+                zero = self.__dict__.get("_zero_s")
+                if zero is None or zero.dtype != x.dtype or zero.device != x.device:
+                    zero = self.__dict__["_zero_s"] = torch.zeros((), dtype=x.dtype, device=x.device)
+                got = self._run_map_fast(e, x, energy, species, zero)
+                if got is None or got[1].dim() != 0 or got[1].dtype != x.dtype or got[1].device != x.device:
+                    break
+                maps.append(got[0].clone())
+                lengths.append(got[1])                         # 0 + (l_0 + l_1 + ...): the run's length as the walk adds it
+                linear.append(1)
+                tensors += e.fast.tensors
+            elif kind == "element":
+                cls = type(e)
+                if e._tracking_method != "second_order" or e._t_kind is None or cls.track is not Element.track \
+                        or cls._track_second_order is not Element._track_second_order \
+                        or cls._track_internal is not Element._track_internal:
+                    break
+                length = e.length
+                if length.dim() != 0 or length.dtype != x.dtype or length.device != x.device or (grad and length.requires_grad):
+                    break
+                T = e.second_order_transfer_map(energy, species)
+                if T.dim() != 3 or T.dtype != x.dtype or T.device != x.device or (grad and T.requires_grad):
+                    break
+                maps.append(T if T.is_contiguous() else T.contiguous())
+                lengths.append(length)
+                linear.append(0)
+                tensors += e._feature_key()[1]
+                last_so = j
+            else:
                 break
-            length = e.length
-            if length.dim() != 0 or length.dtype != x.dtype or length.device != x.device or (grad and length.requires_grad):
-                break
-            T = e.second_order_transfer_map(energy, species)
-            if T.dim() != 3 or T.dtype != x.dtype or T.device != x.device or (grad and T.requires_grad):
-                break
-            maps.append(T if T.is_contiguous() else T.contiguous())
-            lengths.append(length)
-            tensors += e._feature_key()[1]
             j += 1
-        if j - i < 2:
+        if last_so is None or j - i < 2:
             return None
-        out, s_out, ptrs = _ops.second_order_chain(maps, lengths, x, s)
+        out, s_out, ptrs = _ops.second_order_chain(maps, lengths, x, s, linear=linear)
         if not _ops.CAPTURING[0] and not any(t.requires_grad for t in tensors) and not energy.requires_grad:
             # (maps of tensors that carry gradients are rebuilt on every track, Element._cached_map: nothing to keep)
             cache[1][i] = {"epoch": Element._epoch, "energy": energy, "energy_version": energy._version, "dtype": x.dtype,

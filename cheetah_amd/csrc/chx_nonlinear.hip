@@ -986,6 +986,7 @@ constexpr int kSoPacked = 200;             // one unused; from kSoPacked on the 
 struct SoChainPtrs {
     const void* T[kSoChainMax];
     const void* length[kSoChainMax];
+    unsigned char linear[kSoChainMax];     // 1: T[e] is a 7 x 7 first-order map (a merged run of linear elements between two others)
 };
 // bit c of row i = coefficient (i, c) of the folded map, c = the pair (j <= k) in the order 00 01 .. 06 11 12 .. 66
 struct SoPatternQuad {
@@ -1016,6 +1017,14 @@ __global__ __launch_bounds__(CHX_BLOCK) void so_chain_coeff_kernel(SoChainPtrs m
     }
     const T* Tt = (const T*)maps.T[e];
     T* out = coef + (int64_t)e * kSoCoefStride;
+    if (maps.linear[e]) {                      // scheme 3: the 49 entries of a first-order map, applied like chx_apply_affine7
+        if (threadIdx.x < 49) out[kSoPacked + threadIdx.x] = Tt[threadIdx.x];
+        if (threadIdx.x == 0) {
+            unsigned int* w = reinterpret_cast<unsigned int*>(out + 196);
+            w[0] = 0u; w[1] = 0u; w[2] = 3u; w[3] = 0u;
+        }
+        return;
+    }
     T u = (T)0;
     int i = 0, c = 0;
     if (threadIdx.x < 7 * 28) {
@@ -1104,6 +1113,24 @@ __device__ __forceinline__ void so_step_pattern(const float* __restrict__ U, chx
     so_eval_pattern<P>(u, x, probe);
 }
 
+// a first-order map between two second-order elements: apply7's order (R_i0 x_0, then six multiply-adds), both particles of
+// the lane at once — the values chx_apply_affine7 writes
+__device__ __forceinline__ void so_step_linear(const float* __restrict__ U, chx_v2f (&x)[7]) {
+    float r[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) r[k] = U[kSoPacked + k];
+    chx_v2f y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        chx_v2f acc = x[0] * r[i * 7];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) acc = __builtin_elementwise_fma(chx_v2f{r[i * 7 + j], r[i * 7 + j]}, x[j], acc);
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+
 __device__ __forceinline__ void so_step_groups(const float* __restrict__ U, chx_v2f (&x)[7], chx_v2f probe) {
     const unsigned long long g = (unsigned long long)reinterpret_cast<const unsigned int*>(U + 196)[0] |
                                  ((unsigned long long)reinterpret_cast<const unsigned int*>(U + 196)[1] << 32);
@@ -1157,6 +1184,7 @@ void so_chain_kernel(const float* x_in, const float* __restrict__ coef, int E, f
         for (int j = 0; j < 7; ++j) probe = __builtin_elementwise_fma(chx_v2f{0.0f, 0.0f}, x[j], probe);
         if (scheme == 0u) so_step_pattern<SoPatternQuad>(U, x, probe);
         else if (scheme == 1u) so_step_pattern<SoPatternBend>(U, x, probe);
+        else if (scheme == 3u) so_step_linear(U, x);
         else so_step_groups(U, x, probe);
     }
 #pragma unroll
@@ -1215,6 +1243,19 @@ __device__ __forceinline__ void so_step_groups_f64(const double* __restrict__ U,
     for (int j = 0; j < 7; ++j) x[j] = y[j];
 }
 
+__device__ __forceinline__ void so_step_linear_f64(const double* __restrict__ U, double (&x)[7]) {
+    double y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double acc = U[kSoPacked + i * 7] * x[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) acc = fma(U[kSoPacked + i * 7 + j], x[j], acc);
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = y[j];
+}
+
 __global__ __launch_bounds__(CHX_BLOCK) void so_chain_kernel_f64(const double* x_in, const double* __restrict__ coef, int E, double* x_out,
                                                                  int64_t N, int in_vec_ok, int out_vec_ok) {
     constexpr int TP = CHX_BLOCK;              // (x_out may be x_in: a tile is read whole before it is written)
@@ -1235,6 +1276,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void so_chain_kernel_f64(const double* x
         for (int j = 0; j < 7; ++j) probe = fma(0.0, x[j], probe);
         if (scheme == 0u) so_step_pattern_f64<SoPatternQuad>(U, x, probe);
         else if (scheme == 1u) so_step_pattern_f64<SoPatternBend>(U, x, probe);
+        else if (scheme == 3u) so_step_linear_f64(U, x);
         else so_step_groups_f64(U, x, probe);
     }
     if (p < np) {
@@ -1253,6 +1295,15 @@ __global__ __launch_bounds__(CHX_BLOCK) void so_chain_kernel_f64(const double* x
 // chx_dkd_chain (lengths[E]: device pointers to the elements' length scalars). Same results as E separate calls, bit for bit.
 extern "C" int chx_second_order_chain(const void* const* T_maps, const void* const* lengths, int64_t E, const void* x_in, int64_t N,
                                       int dtype, void* x_out, void* x_tmp, const void* s_in, void* s_out, void* stream) {
+    return chx_second_order_chain_mixed(T_maps, nullptr, lengths, E, x_in, N, dtype, x_out, x_tmp, s_in, s_out, stream);
+}
+
+// The same run with first-order maps in between: linear[e] != 0 marks T_maps[e] as a [7][7] map (a merged run of linear elements
+// that stands between second-order elements, applied like chx_apply_affine7) — a lattice whose drifts are tracked linearly and
+// whose magnets to second order is still ONE pass over the beam.
+extern "C" int chx_second_order_chain_mixed(const void* const* T_maps, const int32_t* linear, const void* const* lengths, int64_t E,
+                                            const void* x_in, int64_t N, int dtype, void* x_out, void* x_tmp, const void* s_in,
+                                            void* s_out, void* stream) {
     if (!T_maps || E < 1 || E > 65535 || !x_in || !x_out || (E > 1 && !x_tmp) || N < 1) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if ((s_in == nullptr) != (s_out == nullptr) || (s_out && !lengths)) return CHX_ERR_INVALID_ARG;
@@ -1276,7 +1327,8 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
             SoChainPtrs maps;
             for (int e = 0; e < kSoChainMax; ++e) {
                 maps.T[e] = e < n ? T_maps[done + e] : nullptr;
-                maps.length[e] = e < n ? lengths[done + e] : nullptr;
+                maps.length[e] = e < n && lengths ? lengths[done + e] : nullptr;
+                maps.linear[e] = (e < n && linear && linear[done + e]) ? 1 : 0;
                 if (s_out && e < n && !maps.length[e]) return CHX_ERR_INVALID_ARG;
             }
             const void* src = done == 0 ? x_in : x_out;
@@ -1301,7 +1353,8 @@ extern "C" int chx_second_order_chain(const void* const* T_maps, const void* con
         const void* src = x_in;
         for (int64_t e = 0; e < E; ++e) {
             void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;
-            const int st = chx_apply_second_order(src, T_maps[e], dst, 1, 1, 1, N, dtype, stream);
+            const int st = (linear && linear[e]) ? chx_apply_affine7(src, T_maps[e], dst, 1, 1, 1, N, dtype, stream)
+                                                 : chx_apply_second_order(src, T_maps[e], dst, 1, 1, 1, N, dtype, stream);
             if (st != CHX_OK) return st;
             src = dst;
         }

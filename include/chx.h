@@ -692,6 +692,12 @@ int chx_apply_second_order(const void* x_in, const void* T, void* x_out, int64_t
  * launches. Either way one call and the values of E separate chx_apply_second_order calls (an exact zero may differ in sign). */
 int chx_second_order_chain(const void* const* T_maps, const void* const* lengths, int64_t E, const void* x_in, int64_t N, int dtype,
                            void* x_out, void* x_tmp, const void* s_in, void* s_out, void* stream);
+/* The same run with first-order maps in between: linear[E] (HOST array, may be NULL) marks T_maps[e] as a [7][7] map — a merged
+ * run of linear elements between second-order ones (segment.py:545-574 tracks it with its composed map) — applied with the
+ * arithmetic of chx_apply_affine7; lengths[e] is then the run's summed length. One pass over the beam for the whole stretch. */
+int chx_second_order_chain_mixed(const void* const* T_maps, const int32_t* linear, const void* const* lengths, int64_t E,
+                                 const void* x_in, int64_t N, int dtype, void* x_out, void* x_tmp, const void* s_in, void* s_out,
+                                 void* stream);
 /* Derivatives of the two calls above (reference: torch autograd through track_methods.py:80-296 and the einsum).
  * chx_build_ttensor_vjp: dparams[B][P], denergy[B] (dtype) = dT[B][343] . dT/dtheta (dual numbers, one workgroup
  * per (row, input)); rows are NOT reduced when params / energy are broadcast (Bp or Be = 1) — the caller sums.

@@ -333,3 +333,55 @@ def test_long_second_order_run_on_a_small_beam_goes_through_in_several_passes(dt
         for e in els:
             ref = e.track(ref)
         assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_linear_runs_between_second_order_elements_ride_in_the_same_pass(dt):
+    """A lattice whose drifts are tracked linearly (the default) and whose magnets to second order: the merged runs of linear
+    elements between the second-order elements go through `chx_second_order_chain_mixed` with them — one pass over the beam.
+    Same particles and s as the walk piece by piece (segment.py:545-574: a run of skippable elements is tracked with its composed
+    map; element.py:195-228 for the others), also after edits of a linear element's setting and of a magnet's."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(31)
+    so = {"tracking_method": "second_order"}
+    beam = ca.ParticleBeam.from_parameters(num_particles=40_009, sigma_x=t(3e-4), sigma_px=t(4e-5), sigma_p=t(2e-3), energy=t(6e7), **kw)
+    pieces = [[ca.Drift(t(0.4), **kw), ca.Quadrupole(t(0.1), k1=t(0.7), **kw), ca.Drift(t(0.2), **kw)],      # a linear run of three
+              [ca.Quadrupole(t(0.2), k1=t(3.3), **so, **kw)],
+              [ca.Drift(t(0.6), **kw)],
+              [ca.Sextupole(t(0.15), k2=t(25.0), **so, **kw)],
+              [ca.Dipole(t(0.5), angle=t(0.03), **so, **kw)],
+              [ca.Drift(t(0.3), **kw), ca.HorizontalCorrector(t(0.1), angle=t(1e-4), **kw)],
+              [ca.Quadrupole(t(0.2), k1=t(-2.0), tilt=t(0.2), **so, **kw)],
+              [ca.Drift(t(0.25), **kw)]]
+    els = [e for piece in pieces for e in piece]
+    seg = ca.Segment(els)
+    subs = [ca.Segment(piece) if len(piece) > 1 or piece[0].tracking_method == "linear" else piece[0] for piece in pieces]
+    calls, orig = [], _ops.second_order_chain
+    _ops.second_order_chain = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
+
+    def check():
+        out = seg.track(beam)
+        ref = beam
+        for piece in subs:
+            ref = piece.track(ref)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s) and torch.equal(out.energy, ref.energy)
+        return out
+
+    try:
+        first = check()
+        assert calls == [8], calls                       # every piece in ONE call
+        check()                                          # the stretch from Segment's cache
+        pieces[0][1].k1.mul_(2.0)                        # a linear element inside a run, in place
+        assert not torch.equal(check().particles, first.particles)
+        pieces[2][0].length = t(0.9)                     # assigned
+        check()
+        pieces[3][0].k2.mul_(0.5)                        # a second-order magnet, in place
+        check()
+        with torch.no_grad():
+            check()
+    finally:
+        _ops.second_order_chain = orig
