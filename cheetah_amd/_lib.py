@@ -169,6 +169,9 @@ SIGNATURES = {
                                 c_i64, c_i64, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_dkd_chain": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_double, c_double, c_i64,
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_dkd_chain_mixed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_double,
+                                    c_double, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_dkd_energy_chain": (c_int, [c_void_p, c_i64, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "chx_t_num_params": (c_int, [c_int]),
     "chx_build_ttensor": (c_int, [c_int, c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_apply_second_order": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),

@@ -742,10 +742,15 @@ def _dkd_raw(kind, x, p, e, mass_eV, n_charges, num_steps, fringe_at, B, N, stor
     return out, e_out
 
 
-def dkd_chain(kinds, params, num_steps, fringe, storage, x, energy, s, mass_eV, n_charges, arrays=None):
-    """A run of drift-kick-drift elements on one plain beam (chx_dkd_chain): x (N, 7), energy and s 0-d of x's dtype, params =
-    the elements' (1, P) parameter arrays. Returns (particles (N, 7), energy 0-d, s 0-d, arrays) behind the last element;
-    `arrays` (the five argument arrays) can be handed back in while the run and its parameter arrays are the same."""
+DKD_LINEAR = 4      # chx_dkd_chain_mixed: a merged run of linear elements between drift-kick-drift elements
+
+
+def dkd_chain(kinds, params, num_steps, fringe, storage, x, energy, s, mass_eV, n_charges, arrays=None, lengths=None):
+    """A run of drift-kick-drift elements on one plain beam (chx_dkd_chain_mixed): x (N, 7), energy and s 0-d of x's dtype, params
+    = the elements' (1, P) parameter arrays. Items of kind DKD_LINEAR are merged runs of linear elements in between: their
+    `params` entry is the run's (7, 7) map, their `lengths` entry its 0-d summed length (None for the other items). Returns
+    (particles (N, 7), energy 0-d, s 0-d, arrays) behind the last item; `arrays` (the argument arrays) can be handed back in
+    while the run and its tensors are the same."""
     E, N = len(kinds), x.shape[0]
     x = aligned(x)
     out = torch.empty((N, 7), dtype=x.dtype, device=x.device)
@@ -753,11 +758,24 @@ def dkd_chain(kinds, params, num_steps, fringe, storage, x, energy, s, mass_eV, 
     scalars = torch.empty((E + 1,), dtype=x.dtype, device=x.device)       # the elements' outgoing energies, then s
     if arrays is None:
         i32 = ctypes.c_int32 * E
-        arrays = (i32(*kinds), (ctypes.c_void_p * E)(*[p.data_ptr() for p in params]), i32(*num_steps), i32(*fringe), i32(*storage))
-    check(_lib.lib().chx_dkd_chain(arrays[0], arrays[1], arrays[2], arrays[3], arrays[4], E, ptr(x), ptr(energy), mass_eV, n_charges, N,
-                                   dtype_code(x.dtype), ptr(out), ptr(tmp), ptr(scalars), ptr(s),
-                                   scalars.data_ptr() + E * scalars.element_size(), stream_ptr()), "chx_dkd_chain")
+        vp = ctypes.c_void_p * E
+        lens = vp(*[None if t is None else t.data_ptr() for t in lengths]) if lengths is not None else None
+        arrays = (i32(*kinds), vp(*[p.data_ptr() for p in params]), i32(*num_steps), i32(*fringe), i32(*storage), lens)
+    check(_lib.lib().chx_dkd_chain_mixed(arrays[0], arrays[1], arrays[5], arrays[2], arrays[3], arrays[4], E, ptr(x), ptr(energy), mass_eV,
+                                         n_charges, N, dtype_code(x.dtype), ptr(out), ptr(tmp), ptr(scalars), ptr(s),
+                                         scalars.data_ptr() + E * scalars.element_size(), stream_ptr()), "chx_dkd_chain_mixed")
     return out, scalars[E - 1], scalars[E], arrays
+
+
+def dkd_energy_chain(kinds, energy, mass_eV):
+    """(E,) reference energies behind the items of a drift-kick-drift run (chx_dkd_energy_chain): a drift-kick-drift element
+    leaves the round trip of what it received in the beam's dtype (bmadx.py:49), a DKD_LINEAR item hands its energy on."""
+    E = len(kinds)
+    out = torch.empty((E,), dtype=energy.dtype, device=energy.device)
+    scratch = torch.empty((E,), dtype=torch.int32, device=energy.device)
+    check(_lib.lib().chx_dkd_energy_chain((ctypes.c_int32 * E)(*kinds), E, ptr(energy), mass_eV, dtype_code(energy.dtype), ptr(out),
+                                          ptr(scratch), stream_ptr()), "chx_dkd_energy_chain")
+    return out
 
 
 class DkdTrack(torch.autograd.Function):

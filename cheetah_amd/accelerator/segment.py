@@ -745,8 +745,13 @@ class Segment(Element):
                 if done is not None:
                     incoming, i = done
                     continue
-            if kind == "run" and i + 1 < n_items and plan[i + 1][0] == "element" and plan[i + 1][1]._tracking_method == "second_order":
-                done = self._second_order_run(plan, i, incoming)          # the run rides in the second-order elements' pass
+            if kind == "run" and i + 1 < n_items and plan[i + 1][0] == "element":
+                method = plan[i + 1][1]._tracking_method
+                done = None
+                if method == "second_order":
+                    done = self._second_order_run(plan, i, incoming)      # the run rides in the second-order elements' pass
+                elif method == "drift_kick_drift":
+                    done = self._dkd_run(plan, i, incoming)               # ... in the drift-kick-drift elements' pass
                 if done is not None:
                     incoming, i = done
                     continue
@@ -831,6 +836,12 @@ class Segment(Element):
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=s_out, species=sp), i + lp.count
 
+    @staticmethod
+    def _identity_run(run) -> bool:
+        """A run of pass-through elements only (Markers, inactive BPMs / Screens between two non-linear elements): nothing to
+        apply, zero length."""
+        return all(e._chx_kind == _IDENTITY and e._static_skippable and not e._parameters for e in run.elements)
+
     def _second_order_run(self, plan, i: int, incoming: ParticleBeam):
         """plan[i] and what follows it as one `chx_second_order_chain_mixed` call — second-order elements and the merged runs of
         linear elements between them (a lattice whose drifts are linear and whose magnets second order): (outgoing beam, index
@@ -867,6 +878,9 @@ class Segment(Element):
                 # in a tensor of its own — the plan's state is shared with every other way this run can be tracked
                 if j + 1 < len(plan) and plan[j + 1][0] == "element" and plan[j + 1][1]._is_cavity:
                     break                                      # that run belongs to the cavity's stretch (chx_lattice_track)
+                if self._identity_run(e):
+                    j += 1                                     # Markers between two magnets: nothing to apply, s + 0
+                    continue
                 zero = self.__dict__.get("_zero_s")
                 if zero is None or zero.dtype != x.dtype or zero.device != x.device:
                     zero = self.__dict__["_zero_s"] = torch.zeros((), dtype=x.dtype, device=x.device)
@@ -897,7 +911,7 @@ class Segment(Element):
             else:
                 break
             j += 1
-        if last_so is None or j - i < 2:
+        if last_so is None or len(maps) < 2:
             return None
         out, s_out, ptrs = _ops.second_order_chain(maps, lengths, x, s, linear=linear)
         if not _ops.CAPTURING[0] and not any(t.requires_grad for t in tensors) and not energy.requires_grad:
@@ -909,10 +923,26 @@ class Segment(Element):
         return ParticleBeam(out, energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), j
 
+    @staticmethod
+    def _stable_energy(ent: dict, energy: torch.Tensor, mass: float, e_out: torch.Tensor) -> torch.Tensor:
+        """The reference energy behind a cached drift-kick-drift stretch as the SAME tensor object from track to track while the
+        incoming energy is the same tensor at the same version (then the value is the same): what stands downstream and depends
+        on the energy — run maps of a later stretch, second-order maps — recognises it by identity and keeps its own products.
+        A tensor somebody edited in place since is not handed out again."""
+        last = ent.get("e_out")
+        if last is not None and ent["e_in"] is energy and ent["e_in_version"] == energy._version and ent["e_mass"] == mass \
+                and last._version == ent["e_out_version"]:
+            return last
+        ent["e_in"], ent["e_in_version"], ent["e_mass"], ent["e_out"], ent["e_out_version"] = energy, energy._version, mass, e_out, \
+            e_out._version
+        return e_out
+
     def _dkd_run(self, plan, i: int, incoming: ParticleBeam):
-        """plan[i] and the drift-kick-drift elements behind it as one `chx_dkd_chain` call: (outgoing beam, index behind the
-        run), or None when fewer than two elements qualify (one plain beam without a graph; scalar settings of the beam's
-        dtype that carry no gradient; the stock `track`) — then `Element.track` takes each of them as before."""
+        """plan[i] and the drift-kick-drift elements behind it as one `chx_dkd_chain_mixed` call: (outgoing beam, index behind
+        the run), or None when fewer than two items qualify (one plain beam without a graph; scalar settings of the beam's
+        dtype that carry no gradient; the stock `track`) — then `Element.track` takes each of them as before. Drifts,
+        Quadrupoles and Dipoles of one arithmetic mode keep the particles in registers, and the merged runs of linear elements
+        between them (a lattice whose drifts are linear and whose magnets drift-kick-drift) ride in the same pass."""
         x, energy, s = incoming.particles, incoming.energy, incoming.s
         if x.dim() != 2 or not x.is_cuda or energy.dim() != 0 or energy.dtype != x.dtype or energy.device != x.device \
                 or s.dim() != 0 or s.dtype != x.dtype or s.device != x.device or (
@@ -921,66 +951,131 @@ class Segment(Element):
         grad = torch.is_grad_enabled()
         species = incoming.species
         # the run as it was found last time stands while no attribute of any element was assigned (`Element._epoch`) and no
-        # setting was edited in place (one sweep over the version counters instead of ~3 us of look-ups per element)
+        # setting was edited in place (one sweep over the version counters instead of ~3 us of look-ups per element); with
+        # linear runs inside also: the same energy tensor at the same version, the same species (their maps depend on both)
         cache = self.__dict__.get("_dkd_run_cache")
         if cache is None or cache[0] is not plan:
             cache = self.__dict__["_dkd_run_cache"] = (plan, {})
         ent = cache[1].get(i)
         if ent is not None and ent["epoch"] == Element._epoch and ent["dtype"] == x.dtype and ent["device"] == x.device \
                 and [t._version for t in ent["tensors"]] == ent["versions"] and not _ops.CAPTURING[0] \
-                and not (grad and any(t.requires_grad for t in ent["tensors"])):
+                and not (grad and any(t.requires_grad for t in ent["tensors"])) \
+                and (ent["energy"] is None or (ent["energy"] is energy and ent["energy_version"] == energy._version
+                                               and ent["mass"] == species.mass_eV_float
+                                               and ent["nq"] == species.num_elementary_charges_float)):
             out, e_out, s_out, _ = _ops.dkd_chain(ent["kinds"], ent["params"], None, None, None, x, energy, s, species.mass_eV_float,
                                                   species.num_elementary_charges_float, ent["arrays"])
+            e_out = self._stable_energy(ent, energy, species.mass_eV_float, e_out)
             return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                                 survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), ent["end"]
-        kinds, params, steps, fringes, storage, tensors = [], [], [], [], [], []
+        # what stands at plan[i:]: drift-kick-drift elements that qualify (with their argument set) and runs of linear elements
+        seq, after = [], []                                    # after[k]: the plan index behind item k (and the Markers behind it)
         j = i
-        while j < len(plan) and plan[j][0] == "element":
-            e = plan[j][1]
-            cls = type(e)
-            if e._tracking_method != "drift_kick_drift" or e._dkd_kind is None or cls.track is not Element.track \
-                    or cls._track_drift_kick_drift is not Element._track_drift_kick_drift \
-                    or cls._track_internal is not Element._track_internal or e.dkd_precision not in _ops.DKD_PRECISION:
-                break
-            p = e._dkd_params_stacked(x.dtype, x.device)
-            if p is None:
-                break
-            n, f = e._dkd_options()
-            kinds.append(e._dkd_kind)
-            params.append(p)
-            steps.append(n)
-            fringes.append(f)
-            storage.append(_ops.DKD_PRECISION[e.dkd_precision])
-            tensors.append([t for t, _ in e._dkd_scalar_refs()])
-            j += 1
-        # Drifts and Quadrupoles of one arithmetic mode go through the device with the particles in registers
-        # (chx_dkd_chain's two-launch form): the run is cut so that such a stretch is a call of its own
-        if x.dtype in (torch.float32, torch.float64):
-            # (float64 beams are evaluated in fp64 whatever `dkd_precision` says: one class)
-            single = x.dtype == torch.float64
-            fusable = [(0 if single else storage[k]) if kinds[k] in _DKD_IN_REGISTERS else -1 for k in range(j - i)]
-            n = len(fusable)
-            if n >= 2 and fusable[0] >= 0 and fusable[1] == fusable[0]:
-                k = 2
-                while k < n and fusable[k] == fusable[0]:
-                    k += 1
+        while j < len(plan):
+            kind, e = plan[j]
+            if kind == "run":
+                if j + 1 < len(plan) and plan[j + 1][0] == "element" and plan[j + 1][1]._is_cavity:
+                    break                                      # that run belongs to the cavity's stretch (chx_lattice_track)
+                if self._identity_run(e):
+                    j += 1                                     # Markers between two magnets: nothing to apply, s + 0
+                    if after:
+                        after[-1] = j
+                    continue
+                seq.append((e, None))
+            elif kind == "element":
+                cls = type(e)
+                if e._tracking_method != "drift_kick_drift" or e._dkd_kind is None or cls.track is not Element.track \
+                        or cls._track_drift_kick_drift is not Element._track_drift_kick_drift \
+                        or cls._track_internal is not Element._track_internal or e.dkd_precision not in _ops.DKD_PRECISION:
+                    break
+                p = e._dkd_params_stacked(x.dtype, x.device)
+                if p is None:
+                    break
+                n, f = e._dkd_options()
+                seq.append((e, (e._dkd_kind, p, n, f, _ops.DKD_PRECISION[e.dkd_precision], [t for t, _ in e._dkd_scalar_refs()])))
             else:
-                k = 1
-                while k < n and not (fusable[k] >= 0 and k + 1 < n and fusable[k + 1] == fusable[k]):
-                    k += 1
-            if k < n:
-                j = i + k
-                kinds, params, steps, fringes, storage, tensors = kinds[:k], params[:k], steps[:k], fringes[:k], storage[:k], tensors[:k]
-        if j - i < 2:
+                break
+            j += 1
+            after.append(j)
+        # the arithmetic class of every item: a linear run goes with any (None); Drifts, Quadrupoles and Dipoles with their
+        # `dkd_precision` (float64 beams are evaluated in fp64 whatever it says: one class); anything else has none (-1)
+        single = x.dtype == torch.float64
+        classes = [None if a is None else ((0 if single else a[4]) if a[0] in _DKD_IN_REGISTERS and x.dtype in (torch.float32, torch.float64)
+                                           else -1) for _, a in seq]
+        first = next((k for k, c in enumerate(classes) if c is not None), None)
+        if first is None:
             return None
-        out, e_out, s_out, arrays = _ops.dkd_chain(kinds, params, steps, fringes, storage, x, energy, s, species.mass_eV_float,
+        k = 0
+        if classes[first] >= 0:
+            while k < len(seq) and classes[k] in (None, classes[first]):
+                k += 1
+        while k >= 2:
+            # a stretch whose particles stay in registers: seq[:k]
+            kinds = [_ops.DKD_LINEAR if a is None else a[0] for _, a in seq[:k]]
+            has_runs = _ops.DKD_LINEAR in kinds
+            params, lengths, steps, fringes, storage, tensors = [], [], [], [], [], []
+            energies = _ops.dkd_energy_chain(kinds, energy, species.mass_eV_float) if has_runs else None
+            failed = None
+            for r, (obj, a) in enumerate(seq[:k]):
+                if a is None:
+                    # the run's composed map for the energy in front of it (chx_run_map: one launch now, none while the stretch
+                    # stands) in a tensor of its own — the plan's state is shared with every other way this run can be tracked
+                    zero = self.__dict__.get("_zero_s")
+                    if zero is None or zero.dtype != x.dtype or zero.device != x.device:
+                        zero = self.__dict__["_zero_s"] = torch.zeros((), dtype=x.dtype, device=x.device)
+                    got = self._run_map_fast(obj, x, energy if r == 0 else energies[r - 1], species, zero)
+                    if got is None or got[1].dim() != 0 or got[1].dtype != x.dtype or got[1].device != x.device:
+                        failed = r
+                        break
+                    params.append(got[0].clone())
+                    lengths.append(got[1])                     # 0 + (l_0 + l_1 + ...): the run's length as the walk adds it
+                    steps.append(1)
+                    fringes.append(0)
+                    storage.append(0)
+                    tensors += obj.fast.tensors
+                else:
+                    params.append(a[1])
+                    lengths.append(None)
+                    steps.append(a[2])
+                    fringes.append(a[3])
+                    storage.append(a[4])
+                    tensors += a[5]
+            if failed is not None:
+                k = failed                                     # the stretch ends in front of the run that does not qualify
+                continue
+            if not any(a is not None for _, a in seq[:k]):
+                return None
+            out, e_out, s_out, arrays = _ops.dkd_chain(kinds, params, steps, fringes, storage, x, energy, s, species.mass_eV_float,
+                                                       species.num_elementary_charges_float, lengths=lengths if has_runs else None)
+            if not _ops.CAPTURING[0]:
+                cache[1][i] = {"epoch": Element._epoch, "dtype": x.dtype, "device": x.device, "tensors": tensors,
+                               "versions": [t._version for t in tensors], "kinds": kinds, "params": params, "lengths": lengths,
+                               "arrays": arrays, "end": after[k - 1], "energy": energy if has_runs else None,
+                               "energy_version": energy._version, "mass": species.mass_eV_float,
+                               "nq": species.num_elementary_charges_float}
+            return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
+                                survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), after[k - 1]
+        # no such stretch starts here: consecutive drift-kick-drift elements (no runs) in one call, element passes, up to where
+        # a stretch could start
+        if seq[0][1] is None:
+            return None
+        k = 1
+        while k < len(seq) and seq[k][1] is not None and not (
+                classes[k] >= 0 and k + 1 < len(seq) and classes[k + 1] in (None, classes[k])):
+            k += 1
+        if k < 2:
+            return None
+        kinds, params = [a[0] for _, a in seq[:k]], [a[1] for _, a in seq[:k]]
+        tensors = [t for _, a in seq[:k] for t in a[5]]
+        out, e_out, s_out, arrays = _ops.dkd_chain(kinds, params, [a[2] for _, a in seq[:k]], [a[3] for _, a in seq[:k]],
+                                                   [a[4] for _, a in seq[:k]], x, energy, s, species.mass_eV_float,
                                                    species.num_elementary_charges_float)
-        flat = [t for ts in tensors for t in ts]
         if not _ops.CAPTURING[0]:
-            cache[1][i] = {"epoch": Element._epoch, "dtype": x.dtype, "device": x.device, "tensors": flat,
-                           "versions": [t._version for t in flat], "kinds": kinds, "params": params, "arrays": arrays, "end": j}
+            cache[1][i] = {"epoch": Element._epoch, "dtype": x.dtype, "device": x.device, "tensors": tensors,
+                           "versions": [t._version for t in tensors], "kinds": kinds, "params": params, "arrays": arrays,
+                           "end": after[k - 1], "energy": None}
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), j
+                            survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), after[k - 1]
 
     @staticmethod
     def _next_chain_kick(plan, i: int, kick, dtype):

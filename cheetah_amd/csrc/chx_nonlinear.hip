@@ -717,10 +717,13 @@ __global__ void dkd_path_length_kernel(DkdLengthPtrs args, int n, const T* __res
 //   dkd_chain_kernel<MODE>    a particle per lane through all elements; the element's constants are wave-uniform scalar loads;
 //                             between two elements the coordinates are rounded to float32 — exactly what the store and the
 //                             load of two separate launches do: the same bits as E calls of chx_dkd_track_p.
-constexpr int kDkdChainMax = 320;          // elements per launch pair (kernel-argument space: 12 bytes each)
-constexpr int kDkdCstStride = 24;          // doubles per element: C_MIXED_N constants, then kind and step count as two ints
+constexpr int kDkdChainMax = 192;          // elements per launch pair (kernel-argument space: 20 bytes each)
+constexpr int kDkdCstStride = 56;          // doubles per element: C_MIXED_N constants — or the 49 entries of a first-order map in the
+constexpr int kDkdMeta = 54;               // beam's dtype —, and at kDkdMeta the kind and the step count as two ints
+constexpr int kDkdLinear = 4;              // CHX_DKD_LINEAR: a merged run of linear elements between two others
 struct DkdChainArgs {
-    const void* params[kDkdChainMax];
+    const void* params[kDkdChainMax];      // (a linear run: its composed map R[7][7])
+    const void* length[kDkdChainMax];      // the item's length if it is not the first parameter (a linear run's summed length), else null
     int32_t meta[kDkdChainMax];            // kind | fringe_at << 4 | num_steps << 6
 };
 
@@ -738,7 +741,7 @@ __global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const T* __re
         // one workgroup more: the path length behind the run, s = ((s_in + l_0) + l_1) + ... in the beam's dtype like the
         // reference's element-by-element additions (every kind's first parameter is its length; s_out may be s_in)
         __shared__ T len[kDkdChainMax];
-        for (int k = threadIdx.x; k < E; k += blockDim.x) len[k] = ((const T*)args.params[k])[0];
+        for (int k = threadIdx.x; k < E; k += blockDim.x) len[k] = args.length[k] ? *(const T*)args.length[k] : ((const T*)args.params[k])[0];
         __syncthreads();
         if (threadIdx.x == 0) {
             T sum = *s_in;
@@ -747,29 +750,58 @@ __global__ void dkd_chain_prepare_kernel(DkdChainArgs args, int E, const T* __re
         }
         return;
     }
+    const int kind = args.meta[e] & 15, fringe = (args.meta[e] >> 4) & 3, steps = args.meta[e] >> 6;
+    double* out = cst + (int64_t)e * kDkdCstStride;
+    if (kind == kDkdLinear && threadIdx.x < 49) reinterpret_cast<T*>(out)[threadIdx.x] = ((const T*)args.params[e])[threadIdx.x];
     if (threadIdx.x != 0) return;
+    // the reference energy in front of element e: every drift-kick-drift element in front of it leaves the float round trip of
+    // what it received (bmadx.py:49); a linear run hands its energy on
     const T m = (T)mc2;
     T Ee = *energy_in;
     for (int k = 0; k < e; ++k) {
+        if ((args.meta[k] & 15) == kDkdLinear) continue;
         const T En = dkd_energy_round_trip<T>(Ee, m);
         if (En == Ee) break;              // a fixed point: every later round trip returns it again
         Ee = En;
     }
-    const int kind = args.meta[e] & 15, fringe = (args.meta[e] >> 4) & 3, steps = args.meta[e] >> 6;
+    int32_t* w = reinterpret_cast<int32_t*>(out + kDkdMeta);
+    w[0] = kind;
+    w[1] = steps;
+    if (kind == kDkdLinear) {
+        energies[e] = Ee;
+        return;
+    }
     const int P = kind == CHX_DKD_DRIFT ? 1 : (kind == CHX_DKD_QUADRUPOLE ? 5 : 9);
     double par[CHX_MAX_PARAMS];
     const T* pe = (const T*)args.params[e];
     for (int k = 0; k < P; ++k) par[k] = (double)pe[k];
-    double c[kDkdCstStride];
-    for (int k = 0; k < kDkdCstStride; ++k) c[k] = 0.0;
+    double c[C_MIXED_N];
+    for (int k = 0; k < C_MIXED_N; ++k) c[k] = 0.0;
     dkd_constants<double>(kind, par, (double)Ee, mc2, nq, fringe, c);
     dkd_mixed_constants(c, mc2);
-    double* out = cst + (int64_t)e * kDkdCstStride;
     for (int k = 0; k < C_MIXED_N; ++k) out[k] = c[k];
-    int32_t* w = reinterpret_cast<int32_t*>(out + C_MIXED_N);
-    w[0] = kind;
-    w[1] = steps;
     energies[e] = dkd_energy_round_trip<T>(Ee, m);
+}
+
+struct DkdKindsBlock {
+    int32_t k[256];
+};
+__global__ void dkd_store_kinds_kernel(DkdKindsBlock b, int n, int32_t* __restrict__ out) {
+    if ((int)threadIdx.x < n) out[threadIdx.x] = b.k[threadIdx.x];
+}
+
+// energies[e] = the reference energy behind item e of such a run, nothing else (chx_dkd_energy_chain: a caller that builds the
+// maps of the linear runs in between needs the energy in front of each of them)
+template <typename T>
+__global__ void dkd_energy_chain_kernel(const int32_t* __restrict__ kinds_dev, int E, const T* __restrict__ energy_in, double mc2,
+                                        T* __restrict__ energies) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const T m = (T)mc2;
+    T Ee = *energy_in;
+    for (int e = 0; e < E; ++e) {
+        if (kinds_dev[e] != kDkdLinear) Ee = dkd_energy_round_trip<T>(Ee, m);
+        energies[e] = Ee;
+    }
 }
 
 // MODE: chx_dkd_track_p's storage_precision — 0 fp64 evaluation, 1 float32 evaluation, 2 mixed
@@ -808,21 +840,39 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel(const float* x_in,
     tile_load<float, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
     __syncthreads();
     const int p = threadIdx.x;
-    float v[6];
+    float v[6], v6 = p < np ? lds[p * 7 + 6] : 1.0f;       // (the drift-kick-drift kernels write 1 into the seventh column)
 #pragma unroll
     for (int j = 0; j < 6; ++j) v[j] = p < np ? lds[p * 7 + j] : 0.0f;
     for (int e = 0; e < E; ++e) {
         const double* __restrict__ c = cst + (int64_t)e * kDkdCstStride;
-        const int32_t* w = reinterpret_cast<const int32_t*>(c + C_MIXED_N);
+        const int32_t* w = reinterpret_cast<const int32_t*>(c + kDkdMeta);
         const int kind = w[0], steps = w[1];
+        if (kind == kDkdLinear) {
+            // a merged run of linear elements: apply7's arithmetic on all seven coordinates, as chx_apply_affine7 does it
+            const float* __restrict__ R = reinterpret_cast<const float*>(c);
+            const float x[7] = {v[0], v[1], v[2], v[3], v[4], v[5], v6};
+            float y[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                float acc = R[i * 7] * x[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) acc = fmaf(R[i * 7 + j], x[j], acc);
+                y[i] = acc;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = y[j];
+            v6 = y[6];
+            continue;
+        }
         if (kind == CHX_DKD_DRIFT) dkd_chain_step<MODE, CHX_DKD_DRIFT>(c, mc2, steps, v);
         else if (!BEND || kind == CHX_DKD_QUADRUPOLE) dkd_chain_step<MODE, CHX_DKD_QUADRUPOLE>(c, mc2, steps, v);
         else dkd_chain_step<MODE, CHX_DKD_DIPOLE>(c, mc2, steps, v);
+        v6 = 1.0f;
     }
     if (p < np) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) lds[p * 7 + j] = v[j];
-        lds[p * 7 + 6] = 1.0f;
+        lds[p * 7 + 6] = v6;
     }
     __syncthreads();
     tile_store<float, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
@@ -839,24 +889,40 @@ __global__ __launch_bounds__(CHX_BLOCK) void dkd_chain_kernel_f64(const double* 
     tile_load<double, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
     __syncthreads();
     const int p = threadIdx.x;
-    double v[6];
+    double v[6], v6 = p < np ? lds[p * 7 + 6] : 1.0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) v[j] = p < np ? lds[p * 7 + j] : 0.0;
     for (int e = 0; e < E; ++e) {
         const double* __restrict__ c = cst + (int64_t)e * kDkdCstStride;
-        const int32_t* w = reinterpret_cast<const int32_t*>(c + C_MIXED_N);
+        const int32_t* w = reinterpret_cast<const int32_t*>(c + kDkdMeta);
         const int kind = w[0], steps = w[1];
         double out[6];
+        if (kind == kDkdLinear) {
+            const double x[7] = {v[0], v[1], v[2], v[3], v[4], v[5], v6};
+            double y[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                double acc = c[i * 7] * x[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) acc = fma(c[i * 7 + j], x[j], acc);
+                y[i] = acc;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = y[j];
+            v6 = y[6];
+            continue;
+        }
         if (kind == CHX_DKD_DRIFT) dkd_map<CHX_DKD_DRIFT, double>(c, v, mc2, steps, out);
         else if (!BEND || kind == CHX_DKD_QUADRUPOLE) dkd_map<CHX_DKD_QUADRUPOLE, double>(c, v, mc2, steps, out);
         else dkd_map<CHX_DKD_DIPOLE, double>(c, v, mc2, steps, out);
 #pragma unroll
         for (int j = 0; j < 6; ++j) v[j] = out[j];
+        v6 = 1.0;
     }
     if (p < np) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) lds[p * 7 + j] = v[j];
-        lds[p * 7 + 6] = 1.0;
+        lds[p * 7 + 6] = v6;
     }
     __syncthreads();
     tile_store<double, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
@@ -872,37 +938,86 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
                              const int32_t* storage_precision, int64_t E, const void* x_in, const void* energy_in, double mass_eV,
                              double n_charges, int64_t N, int dtype, void* x_out, void* x_tmp, void* energies, const void* s_in,
                              void* s_out, void* stream) {
+    return chx_dkd_chain_mixed(kinds, params, nullptr, num_steps, fringe_at, storage_precision, E, x_in, energy_in, mass_eV, n_charges, N,
+                               dtype, x_out, x_tmp, energies, s_in, s_out, stream);
+}
+
+// energies[e] (dtype) = the reference energy behind item e of a run: a drift-kick-drift element leaves the round trip E ->
+// sqrt(p0c^2 + m^2) of what it received in dtype (bmadx.py:49), an item of kind CHX_DKD_LINEAR hands its energy on. One launch.
+extern "C" int chx_dkd_energy_chain(const int32_t* kinds, int64_t E, const void* energy_in, double mass_eV, int dtype, void* energies,
+                                    void* kinds_scratch, void* stream) {
+    if (!kinds || E < 1 || E > 65535 || !energy_in || !energies || !kinds_scratch) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    // the kinds travel as kernel arguments in blocks (no host buffer has to outlive the call)
+    for (int64_t done = 0; done < E; done += 256) {
+        DkdKindsBlock b;
+        const int n = (int)std::min<int64_t>(256, E - done);
+        for (int e = 0; e < 256; ++e) b.k[e] = e < n ? kinds[done + e] : 0;
+        hipLaunchKernelGGL(dkd_store_kinds_kernel, dim3(1), dim3(256), 0, s, b, n, (int32_t*)kinds_scratch + done);
+        CHX_CHECK_LAUNCH();
+    }
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(dkd_energy_chain_kernel<float>, dim3(1), dim3(1), 0, s, (const int32_t*)kinds_scratch, (int)E,
+                           (const float*)energy_in, mass_eV, (float*)energies);
+    else
+        hipLaunchKernelGGL(dkd_energy_chain_kernel<double>, dim3(1), dim3(1), 0, s, (const int32_t*)kinds_scratch, (int)E,
+                           (const double*)energy_in, mass_eV, (double*)energies);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+// The same run with merged runs of linear elements in between: kinds[e] = CHX_DKD_LINEAR marks params[e] as a [7][7] first-order
+// map (dtype) applied with the arithmetic of chx_apply_affine7, lengths[e] as the device scalar with that run's summed length
+// (lengths may be NULL when no item is linear; an entry of a drift-kick-drift element may be NULL: its first parameter). A lattice
+// whose drifts are tracked linearly and whose magnets with the Bmad-X maps is still one pass over the beam.
+extern "C" int chx_dkd_chain_mixed(const int32_t* kinds, const void* const* params, const void* const* lengths, const int32_t* num_steps,
+                                   const int32_t* fringe_at, const int32_t* storage_precision, int64_t E, const void* x_in,
+                                   const void* energy_in, double mass_eV, double n_charges, int64_t N, int dtype, void* x_out,
+                                   void* x_tmp, void* energies, const void* s_in, void* s_out, void* stream) {
     if (!kinds || !params || !num_steps || !fringe_at || !storage_precision || E < 1 || E > 65535) return CHX_ERR_INVALID_ARG;
     if ((s_in == nullptr) != (s_out == nullptr)) return CHX_ERR_INVALID_ARG;
     if (!x_in || !energy_in || !x_out || !energies || (E > 1 && !x_tmp) || N < 1) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (x_out == x_in || x_tmp == x_in || x_tmp == x_out) return CHX_ERR_INVALID_ARG;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    // Drifts, Quadrupoles and Dipoles (float32: of one arithmetic mode), the constants (192 bytes per element) in x_tmp: the particles stay
-    // in registers (dkd_chain_kernel, dkd_chain_kernel_f64), two launches per 320 elements, the same bits
+    int64_t first = -1;                               // the first drift-kick-drift element: its arithmetic mode is the run's
+    for (int64_t e = 0; e < E; ++e) {
+        if (!params[e]) return CHX_ERR_INVALID_ARG;
+        if (kinds[e] == kDkdLinear) {
+            if (s_out && !(lengths && lengths[e])) return CHX_ERR_INVALID_ARG;
+        } else if (first < 0) {
+            first = e;
+        }
+    }
+    // Drifts, Quadrupoles, Dipoles (float32: of one arithmetic mode) and linear runs, the constants (448 bytes per item) in x_tmp:
+    // the particles stay in registers (dkd_chain_kernel, dkd_chain_kernel_f64), two launches per 192 items, the same bits
     static const bool fused_off = [] { const char* v = getenv("CHX_DKD_CHAIN_FUSED"); return v && v[0] == '0'; }();
     // (a longer run takes several such pairs, the later ones in place on x_out: a workgroup holds its whole tile in registers
     // before it writes)
     const int64_t per_pass = std::min<int64_t>(kDkdChainMax, N * 7 * (int64_t)esz / (kDkdCstStride * (int64_t)sizeof(double)));
-    bool fuse = !fused_off && E >= 2 && per_pass >= 2 && chx_aligned16(x_tmp);
+    bool fuse = !fused_off && E >= 2 && per_pass >= 2 && chx_aligned16(x_tmp) && first >= 0;
     bool bend = false;
     for (int64_t e = 0; fuse && e < E; ++e) {      // (float64 beams ignore storage_precision, like chx_dkd_track_p)
+        if (kinds[e] == kDkdLinear) continue;
         fuse = (kinds[e] == CHX_DKD_DRIFT || kinds[e] == CHX_DKD_QUADRUPOLE || kinds[e] == CHX_DKD_DIPOLE) &&
-               (dtype == CHX_F64 || (storage_precision[e] == storage_precision[0] && storage_precision[e] >= 0 && storage_precision[e] <= 2)) &&
-               num_steps[e] >= 1 && num_steps[e] < (1 << 25) && fringe_at[e] >= 0 && fringe_at[e] <= 3 && params[e];
+               (dtype == CHX_F64 || (storage_precision[e] == storage_precision[first] && storage_precision[e] >= 0 && storage_precision[e] <= 2)) &&
+               num_steps[e] >= 1 && num_steps[e] < (1 << 25) && fringe_at[e] >= 0 && fringe_at[e] <= 3;
         bend = bend || kinds[e] == CHX_DKD_DIPOLE;
     }
     if (fuse) {
         hipStream_t s = (hipStream_t)stream;
         const int64_t tiles = (N + CHX_BLOCK - 1) / CHX_BLOCK;
         if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
-        const int mode = storage_precision[0];
+        const int mode = storage_precision[first];
         for (int64_t done = 0; done < E; done += per_pass) {
             const int n = (int)std::min<int64_t>(per_pass, E - done);
             DkdChainArgs a;
             for (int e = 0; e < kDkdChainMax; ++e) {
+                const bool lin = e < n && kinds[done + e] == kDkdLinear;
                 a.params[e] = e < n ? params[done + e] : nullptr;
-                a.meta[e] = e < n ? (kinds[done + e] | (fringe_at[done + e] << 4) | (num_steps[done + e] << 6)) : 0;
+                a.length[e] = e < n && lengths ? lengths[done + e] : nullptr;
+                a.meta[e] = e >= n ? 0 : (lin ? kDkdLinear : (kinds[done + e] | (fringe_at[done + e] << 4) | (num_steps[done + e] << 6)));
             }
             const void* e_from = done == 0 ? energy_in : (const void*)((const char*)energies + (size_t)(done - 1) * esz);
             void* e_to = (char*)energies + (size_t)done * esz;
@@ -944,8 +1059,15 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
         for (int64_t e = 0; e < E; ++e) {
             void* dst = ((E - 1 - e) & 1) ? x_tmp : x_out;          // the last element lands in x_out
             void* e_dst = (char*)energies + (size_t)e * esz;
-            const int st = chx_dkd_track_p(kinds[e], src, params[e], e_src, mass_eV, n_charges, num_steps[e], fringe_at[e], 1, 1, 1, 1,
-                                           N, dtype, storage_precision[e], dst, e_dst, stream);
+            int st;
+            if (kinds[e] == kDkdLinear) {
+                st = chx_apply_affine7(src, params[e], dst, 1, 1, 1, N, dtype, stream);
+                if (st == CHX_OK && hipMemcpyAsync(e_dst, e_src, esz, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                    st = CHX_ERR_LAUNCH;
+            } else {
+                st = chx_dkd_track_p(kinds[e], src, params[e], e_src, mass_eV, n_charges, num_steps[e], fringe_at[e], 1, 1, 1, 1, N, dtype,
+                                     storage_precision[e], dst, e_dst, stream);
+            }
             if (st != CHX_OK) return st;
             src = dst;
             e_src = e_dst;
@@ -955,7 +1077,8 @@ extern "C" int chx_dkd_chain(const int32_t* kinds, const void* const* params, co
     for (int64_t done = 0; s_out && !fuse && done < E; done += kDkdSChunk) {
         DkdLengthPtrs a;
         const int n = (int)((E - done < kDkdSChunk) ? (E - done) : kDkdSChunk);
-        for (int e = 0; e < kDkdSChunk; ++e) a.p[e] = e < n ? params[done + e] : nullptr;
+        for (int e = 0; e < kDkdSChunk; ++e)
+            a.p[e] = e >= n ? nullptr : ((lengths && lengths[done + e]) ? lengths[done + e] : params[done + e]);
         const void* from = done == 0 ? s_in : s_out;
         if (dtype == CHX_F32)
             hipLaunchKernelGGL(dkd_path_length_kernel<float>, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, (const float*)from, (float*)s_out);

@@ -617,7 +617,8 @@ int chx_screen_gaussian(const void* mu, const void* cov, const void* shift, cons
  *                       (+ fringe_at: bit 0 = entrance, bit 1 = exit; linear_edge fringe)
  *   CHX_DKD_TDC         [length, voltage, phase, frequency, tilt, misalignment_x, misalignment_y]
  * energy_out[B] (may be NULL) receives the reference energy recomputed from p0c (bmadx.py:49). */
-enum chx_dkd_kind { CHX_DKD_DRIFT = 0, CHX_DKD_QUADRUPOLE = 1, CHX_DKD_DIPOLE = 2, CHX_DKD_TDC = 3 };
+enum chx_dkd_kind { CHX_DKD_DRIFT = 0, CHX_DKD_QUADRUPOLE = 1, CHX_DKD_DIPOLE = 2, CHX_DKD_TDC = 3,
+                    CHX_DKD_LINEAR = 4 /* only in chx_dkd_chain_mixed / chx_dkd_energy_chain: a merged run of linear elements */ };
 int chx_dkd_num_params(int kind);
 int chx_dkd_track(int kind, const void* x_in, const void* params, const void* energy, double mass_eV,
                   double n_charges, int32_t num_steps, int32_t fringe_at, int64_t B, int64_t Bx, int64_t Bp,
@@ -642,6 +643,19 @@ int chx_dkd_chain(const int32_t* kinds, const void* const* params, const int32_t
                   const int32_t* storage_precision, int64_t E, const void* x_in, const void* energy_in, double mass_eV,
                   double n_charges, int64_t N, int dtype, void* x_out, void* x_tmp, void* energies, const void* s_in, void* s_out,
                   void* stream);
+/* The same run with merged runs of linear elements in between (a lattice whose drifts are tracked linearly and whose magnets with
+ * the Bmad-X maps; segment.py:545-574 tracks such a run with its composed map): kinds[e] = CHX_DKD_LINEAR marks params[e] as a
+ * [7][7] first-order map (dtype), applied with the arithmetic of chx_apply_affine7, and lengths[e] as the device scalar holding
+ * that run's summed length (lengths may be NULL when no item is linear; the entry of a drift-kick-drift element may be NULL: its
+ * first parameter). The reference energy passes a linear run unchanged. One pass over the beam for the whole stretch. */
+int chx_dkd_chain_mixed(const int32_t* kinds, const void* const* params, const void* const* lengths, const int32_t* num_steps,
+                        const int32_t* fringe_at, const int32_t* storage_precision, int64_t E, const void* x_in, const void* energy_in,
+                        double mass_eV, double n_charges, int64_t N, int dtype, void* x_out, void* x_tmp, void* energies,
+                        const void* s_in, void* s_out, void* stream);
+/* energies[E] (dtype) = the reference energy behind every item of such a run without tracking anything (a caller that builds the
+ * maps of the linear runs needs the energy in front of each of them). kinds_scratch: E int32 of device memory. One or two launches. */
+int chx_dkd_energy_chain(const int32_t* kinds, int64_t E, const void* energy_in, double mass_eV, int dtype, void* energies,
+                         void* kinds_scratch, void* stream);
 /* Backward of chx_dkd_track (the reference gets it from torch autograd through utils/bmadx.py): forward-mode dual
  * numbers on device, one seeded evaluation per input. dx[B][N][7] (dtype, may be NULL) = dY . d x_out / d x_in;
  * partials (may be NULL) = chx_dkd_bwd_partials_count() doubles laid out [B][ceil(N/256)][P + 1]: per workgroup

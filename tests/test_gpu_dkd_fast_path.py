@@ -92,8 +92,9 @@ def test_segment_tracks_a_drift_kick_drift_run_in_one_call(dt):
         out = seg.track(beam)
     finally:
         _ops.dkd_chain = orig
-    # (a float32 run is cut where a stretch of one arithmetic mode begins: that stretch keeps its particles in registers)
-    assert calls == ([2, 4, 3] if dt == torch.float32 else [6, 3]), calls
+    # (a float32 run is cut where a stretch of one arithmetic mode begins: that stretch keeps its particles in registers, and
+    # the run [Marker, linear Drift] rides in it)
+    assert calls == ([2, 8] if dt == torch.float32 else [10]), calls
     ref = beam
     for e in els:
         ref = e.track(ref)
@@ -141,7 +142,7 @@ def test_segment_tracks_a_second_order_run_in_one_call(dt):
     _ops.second_order_chain = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
     try:
         out = seg.track(beam)
-        assert calls == [6, 2], calls
+        assert calls == [8], calls                        # (the Marker between two of them does not end the stretch)
         ref = beam
         for e in els:
             ref = e.track(ref)
@@ -385,3 +386,61 @@ def test_linear_runs_between_second_order_elements_ride_in_the_same_pass(dt):
             check()
     finally:
         _ops.second_order_chain = orig
+
+
+@pytest.mark.parametrize("dt,precision", [(torch.float32, "mixed"), (torch.float32, "storage"), (torch.float64, "mixed")])
+def test_linear_runs_between_drift_kick_drift_elements_ride_in_the_same_pass(dt, precision):
+    """A lattice whose drifts are tracked linearly (the default) and whose magnets with the Bmad-X maps: the merged runs of linear
+    elements between them go through `chx_dkd_chain_mixed` with them — one pass over the beam; each run's map is built for the
+    reference energy in front of it (every drift-kick-drift element hands on the float round trip of its own, bmadx.py:49).
+    Same particles, energy and s as the walk piece by piece (segment.py:545-574), also after edits; a lone Marker between two
+    magnets does not end the stretch."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(33)
+    dkd = {"tracking_method": "drift_kick_drift"}
+    beam = ca.ParticleBeam.from_parameters(num_particles=30_011, sigma_x=t(3e-4), sigma_px=t(4e-5), sigma_p=t(2e-3), energy=t(4.7e6), **kw)
+    pieces = [[ca.Drift(t(0.4), **kw), ca.Quadrupole(t(0.1), k1=t(0.7), **kw), ca.Drift(t(0.2), **kw)],      # a linear run of three
+              [ca.Quadrupole(t(0.2), k1=t(3.3), num_steps=3, **dkd, **kw)],
+              [ca.Drift(t(0.6), **kw)],
+              [ca.Dipole(t(0.5), angle=t(0.03), dipole_e1=t(0.01), **dkd, **kw)],
+              [ca.Marker(name="between")],
+              [ca.Quadrupole(t(0.2), k1=t(-2.0), tilt=t(0.2), **dkd, **kw)],
+              [ca.Drift(t(0.3), **kw), ca.VerticalCorrector(t(0.1), angle=t(1e-4), **kw)],
+              [ca.Drift(t(0.25), **dkd, **kw)],
+              [ca.Drift(t(0.15), **kw)]]
+    els = [e for piece in pieces for e in piece]
+    for e in els:
+        e.dkd_precision = precision
+    seg = ca.Segment(els)
+    subs = [ca.Segment(piece) if len(piece) > 1 or piece[0].tracking_method == "linear" else piece[0] for piece in pieces]
+    calls, orig = [], _ops.dkd_chain
+    _ops.dkd_chain = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
+
+    def check():
+        out = seg.track(beam)
+        ref = beam
+        for piece in subs:
+            ref = piece.track(ref)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s) and torch.equal(out.energy, ref.energy)
+        return out
+
+    try:
+        first = check()
+        assert calls == [8], calls                       # every piece but the Marker, in ONE call
+        check()                                          # the stretch from Segment's cache
+        pieces[0][1].k1.mul_(2.0)                        # a linear element inside a run, in place
+        assert not torch.equal(check().particles, first.particles)
+        pieces[2][0].length = t(0.9)                     # assigned
+        check()
+        pieces[1][0].k1.mul_(0.5)                        # a magnet, in place
+        check()
+        beam.energy.mul_(1.5)                            # the linear maps depend on it
+        check()
+        with torch.no_grad():
+            check()
+    finally:
+        _ops.dkd_chain = orig
