@@ -864,7 +864,7 @@ class Segment(Element):
         if ent is not None and ent["epoch"] == Element._epoch and ent["energy"] is energy and ent["energy_version"] == energy._version \
                 and ent["dtype"] == x.dtype and ent["device"] == x.device and ent["mass"] == species.mass_eV_float \
                 and ent["nq"] == species.num_elementary_charges_float \
-                and [t._version for t in ent["tensors"]] == ent["versions"] \
+                and [t._version for t in ent["tensors"]] == ent["versions"] and not _ops.CAPTURING[0] \
                 and not (grad and any(t.requires_grad for t in ent["tensors"])):
             out, s_out, _ = _ops.second_order_chain(ent["maps"], ent["lengths"], x, s, ent["ptrs"])
             return ParticleBeam(out, energy, particle_charges=incoming.particle_charges,

@@ -444,3 +444,38 @@ def test_linear_runs_between_drift_kick_drift_elements_ride_in_the_same_pass(dt,
             check()
     finally:
         _ops.dkd_chain = orig
+
+
+@pytest.mark.parametrize("method", ["second_order", "drift_kick_drift"])
+def test_mixed_stretches_on_tiny_beams_and_behind_each_other(method):
+    """(a) A beam too small to hold the stretch's constants in its scratch rows takes the element passes inside the same C call
+    (chx_apply_affine7 for the linear runs, the energy handed on by a copy): same numbers. (b) Two stretches with an active Screen
+    between them: the second one's linear maps are built for the energy the first one leaves; tracked repeatedly (the stretches
+    come from Segment's cache, the first hands the same energy tensor on while its input stands) and after the beam energy was
+    edited in place, the result equals the walk piece by piece (segment.py:545-574)."""
+    import cheetah_amd as ca
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(41)
+    nl = {"tracking_method": method}
+
+    def cell(k):
+        return [[ca.Drift(t(0.3 + 0.01 * k), **kw)], [ca.Quadrupole(t(0.2), k1=t(2.0 + 0.1 * k), **nl, **kw)],
+                [ca.Drift(t(0.4), **kw), ca.HorizontalCorrector(t(0.05), angle=t(1e-4), **kw)], [ca.Quadrupole(t(0.2), k1=t(-2.2), **nl, **kw)]]
+
+    screen = ca.Screen(resolution=(64, 48), pixel_size=t([2e-5, 2e-5]), is_active=True, name="mid", **kw)
+    pieces = cell(0) + cell(1) + [[screen]] + cell(2) + cell(3) + [[ca.Drift(t(0.2), **kw)]]
+    seg = ca.Segment([e for piece in pieces for e in piece])
+    subs = [ca.Segment(piece) if len(piece) > 1 or piece[0].tracking_method == "linear" and piece[0] is not screen else piece[0]
+            for piece in pieces]
+    for n in (9, 20_003):
+        beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(2e-4), sigma_px=t(3e-5), sigma_p=t(1e-3), energy=t(5.1e6), **kw)
+        for repeat in range(4):
+            if repeat == 3:
+                beam.energy.mul_(1.3)
+            out = seg.track(beam)
+            ref = beam
+            for piece in subs:
+                ref = piece.track(ref)
+            assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s) and torch.equal(out.energy, ref.energy), (n, repeat)

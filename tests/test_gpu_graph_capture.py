@@ -151,3 +151,41 @@ def test_a_lattice_of_many_element_types_is_capturable():
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-7 * float(y.abs().max())), name
         if name in ("sigma_x", "energy"):
             assert float((x - z).abs().max()) > 0, name          # the replay saw the new settings
+
+
+@pytest.mark.parametrize("method", ["second_order", "drift_kick_drift"])
+def test_a_stretch_of_non_linear_elements_and_linear_runs_is_capturable(method):
+    """Linear drifts between second-order / drift-kick-drift magnets go through the device in one pass (Segment._second_order_run /
+    _dkd_run; the maps of the linear runs are kept while nothing changed). While `capture` records, nothing is kept: the launches
+    that derive every map from the settings are part of the graph, and a replay follows a magnet's strength, a linear element's
+    setting and the beam energy edited in place between replays — same numbers as the eager step."""
+    import torch
+
+    import cheetah_amd as ca
+
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(5)
+    nl = {"tracking_method": method}
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, energy=t(5e7), **kw)
+    lin_quad = ca.Quadrupole(t(0.1), k1=t(0.5), **kw)
+    magnet = ca.Quadrupole(t(0.2), k1=t(3.0), **nl, **kw)
+    seg = ca.Segment([ca.Drift(t(0.5), **kw), lin_quad, magnet, ca.Drift(t(0.4), **kw), ca.Marker(**kw),
+                      ca.Quadrupole(t(0.2), k1=t(-2.5), **nl, **kw), ca.Drift(t(0.3), **kw)])
+
+    def step():
+        out = seg.track(beam)
+        return out.particles, out.energy, out.s
+
+    with torch.no_grad():
+        eager0 = [v.clone() for v in step()]
+        cap = ca.graph.capture(step)
+        a = [v.clone() for v in cap()]
+        for x, y in zip(a, eager0):
+            assert torch.equal(x, y)
+        magnet.k1.fill_(-1.0); lin_quad.k1.fill_(2.0); beam.energy.mul_(1.2)
+        b = [v.clone() for v in cap()]
+        c = step()
+    for x, y in zip(b, c):
+        assert torch.equal(x, y)
+    assert not torch.equal(a[0], b[0])
