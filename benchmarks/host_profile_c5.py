@@ -52,4 +52,4 @@ for _ in range(300):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats(os.environ.get("SORT", "cumulative")).print_stats(45)

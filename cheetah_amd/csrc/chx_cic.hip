@@ -1288,12 +1288,16 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
                                                              const T* __restrict__ src, const T* __restrict__ cs2 /*[2][N]*/,
                                                              const T* __restrict__ extent, const T* __restrict__ scale,
                                                              T* __restrict__ cross /* = acc */, uint16_t* __restrict__ home,
-                                                             int* __restrict__ newcount, int* __restrict__ mis_slots) {
+                                                             int* __restrict__ newcount, int* __restrict__ mis_slots,
+                                                             int parts_shift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
     __shared__ int nstay, nmis;
-    const int t = blockIdx.x;
+    // 2^parts_shift workgroups share a tile (dense tiles — few tiles, many particles: the reference's default 32^3 grid with 1e6
+    // particles has 64 tiles of 15 000 slots on average, 60 000 in the occupied ones): each takes a contiguous share of the
+    // tile's slot range; everything a workgroup leaves behind is a sum (charge, counters), so the shares simply add up
+    const int t = (int)(blockIdx.x >> parts_shift), part = (int)(blockIdx.x & ((1u << parts_shift) - 1u));
     // the slot range of both parities is fetched next to the parity itself: one round trip instead of two in front of everything
     // this workgroup does (a workgroup of an empty tile is two round trips long otherwise)
     const int b0 = tile_start2[t], e0 = tile_start2[t + 1], b1 = tile_start2[g.nt + 1 + t], e1 = tile_start2[g.nt + 2 + t];
@@ -1310,7 +1314,12 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
 #pragma unroll
         for (int d = 0; d < 3; ++d) org[d] = tc[d] << g.tshift[d];
     }
-    const int beg = par ? b1 : b0, end = par ? e1 : e0;
+    int beg = par ? b1 : b0, end = par ? e1 : e0;
+    if (parts_shift) {
+        const int share = (end - beg + (1 << parts_shift) - 1) >> parts_shift;
+        beg += part * share;
+        end = (beg + share < end) ? beg + share : end;
+    }
     const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
     if (end <= beg) return;                             // no slots (3/4 of the tiles of a 3-sigma grid)
     for (int i = threadIdx.x; i < ncell; i += TH) blk[i] = 0.0;
@@ -1523,9 +1532,13 @@ int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLay
     // threads per tile: CHX_TUNE_DEPOSIT_THREADS (benchmarks only) picks 256 / 512 / 1024
     static const int th = [] { const char* e = getenv("CHX_TUNE_DEPOSIT_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 256; }();
     auto kern = th == 1024 ? sc_tile_deposit_kernel<T, 1024> : th == 512 ? sc_tile_deposit_kernel<T, 512> : sc_tile_deposit_kernel<T, 256>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)g.nt), dim3(th), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
+    // workgroups per tile: an occupied tile of a 3-sigma grid holds ~4 N / nt slots; shares of at most ~2048 slots
+    // (benchmarks/sc_chain_density.py: one workgroup per tile costs 841 us per kick at 1e6 particles on 32^3)
+    int parts_shift = 0;
+    while (parts_shift < 6 && ((a.N * 4 / g.nt) >> parts_shift) > 2048) ++parts_shift;
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.nt << parts_shift), dim3(th), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
                        (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)(st + L.cross),
-                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis));
+                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis), parts_shift);
     CHX_CHECK_LAUNCH();
     hipLaunchKernelGGL(sc_tile_schedule_kernel, dim3(1), dim3(256), 0, s, g, a.N, hdr, (const int*)(st + L.newcount),
                        (const int*)(st + L.mis), (int*)(st + L.cursor), (int*)(st + L.tile_start[0]), allow_reorder);

@@ -64,7 +64,10 @@ def _unchained(seg, beam):
 
 
 @pytest.mark.parametrize("dt,grid,n,gaussian", [(torch.float32, (64, 64, 64), 200_000, False), (torch.float64, (32, 32, 32), 100_000, True),
-                                                (torch.float32, (128, 64, 32), 150_001, True)])
+                                                (torch.float32, (128, 64, 32), 150_001, True),
+                                                # dense tiles (the reference's default 32^3 grid under a large beam): the deposit
+                                                # splits every tile's slots over 16 / 32 workgroups
+                                                (torch.float32, (32, 32, 32), 400_000, False), (torch.float32, (16, 16, 64), 300_001, True)])
 def test_chain_equals_kick_by_kick(ca, dt, grid, n, gaussian):
     seg, beam = _linac(ca, dt, grid, 4), _beam(ca, dt, n, gaussian=gaussian)
     calls = []
