@@ -990,10 +990,24 @@ def second_order_chain(T_maps, lengths, x, s, ptrs=None, linear=None):
 
 # ---------------------------------------------------------------------------------------------
 # moments
+#: the batch (vector) index of the reductions and deposits is `blockIdx.y`: at most 65 535 rows per launch
+MAX_GRID_ROWS = 65535
+
+
 def _moments_raw(x, w, B, N, entry=None):
     """chx_moments; with entry = (index, take_sqrt) also that entry of every row in x's dtype (chx_moments_entry: the same two
     launches) -> (moments, entries)."""
     lib = _lib.lib()
+    if B > MAX_GRID_ROWS:
+        # more vector rows than one launch takes (the batch index is a grid dimension of 65 535): row slices, one call each
+        outs = []
+        for b0 in range(0, B, MAX_GRID_ROWS):
+            b1 = min(B, b0 + MAX_GRID_ROWS)
+            outs.append(_moments_raw(x if x.shape[0] == 1 else x[b0:b1], w if w is None or w.shape[0] == 1 else w[b0:b1],
+                                     b1 - b0, N, entry))
+        if entry is None:
+            return torch.cat(outs)
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     ws_bytes = lib.chx_moments_workspace_bytes(B, N)
     ws = workspace(ws_bytes, x.device)
     out = torch.empty((B, MOM_NOUT), dtype=torch.float64, device=x.device)

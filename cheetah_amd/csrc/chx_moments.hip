@@ -717,8 +717,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __r
 // One workgroup per batch row: lane t holds partial block t of all 29 sums (partials[b][k][blk]: coalesced loads, all in
 // flight at once), DPP row sums, one LDS exchange of the 64 row sums, then lanes 0..28 add them in a fixed order and lane 0
 // re-centres and normalises -> out[b][29]. Replaces reduce_partials x2 + finalize of the two-pass path.
-template <typename T>
-__global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const double* __restrict__ partials, int nblk,
+// TH = threads of the workgroup: 1024 for long rows; a row with at most 256 / 64 partial blocks (a vectorised beam of many
+// short rows: 4096 x 1000 particles) takes 256 / 64 — the lanes beyond the blocks only added zeros, so the sums are the same
+// bits, and a thousand-thread workgroup per row of ONE block cost 42 us where 64 threads cost 6.
+template <typename T, int TH>
+__global__ __launch_bounds__(TH) void moments_reduce_finalize_kernel(const double* __restrict__ partials, int nblk,
                                                                       const double* __restrict__ centre,
                                                                       double* __restrict__ out, int entry /*-1: none*/,
                                                                       int entry_sqrt, T* __restrict__ entry_out) {
@@ -729,11 +732,11 @@ __global__ __launch_bounds__(1024) void moments_reduce_finalize_kernel(const dou
     double a[kTM];
 #pragma unroll
     for (int k = 0; k < kTM; ++k) a[k] = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 1024) {
+    for (int i = threadIdx.x; i < nblk; i += TH) {
 #pragma unroll
         for (int k = 0; k < kTM; ++k) a[k] += pb[(int64_t)k * nblk + i];
     }
-    const int rows = (nblk + 15) / 16 < 64 ? (nblk + 15) / 16 : 64;
+    const int rows = (nblk + 15) / 16 < TH / 16 ? (nblk + 15) / 16 : TH / 16;
     if ((int)(threadIdx.x >> 4) < rows) {       // (whole waves beyond the partial blocks hold zeros: nothing to reduce)
 #pragma unroll
         for (int k = 0; k < kTM; ++k) a[k] = chx_row16_sum(a[k]);
@@ -1051,6 +1054,20 @@ extern "C" int chx_moment_finalize(const double* sums, const double* m2, int64_t
     return CHX_OK;
 }
 
+template <typename T>
+static void launch_reduce_finalize(int64_t B, int64_t nblk, const double* part, const double* centre, double* out, int index,
+                                   int take_sqrt, void* entry_out, hipStream_t s) {
+    if (nblk <= 64)
+        hipLaunchKernelGGL((moments_reduce_finalize_kernel<T, 64>), dim3((unsigned)B), dim3(64), 0, s, part, (int)nblk, centre, out,
+                           index, take_sqrt, (T*)entry_out);
+    else if (nblk <= 256)
+        hipLaunchKernelGGL((moments_reduce_finalize_kernel<T, 256>), dim3((unsigned)B), dim3(256), 0, s, part, (int)nblk, centre, out,
+                           index, take_sqrt, (T*)entry_out);
+    else
+        hipLaunchKernelGGL((moments_reduce_finalize_kernel<T, 1024>), dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk, centre,
+                           out, index, take_sqrt, (T*)entry_out);
+}
+
 extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
                            int dtype, double* out, void* workspace, size_t workspace_bytes,
                            void* stream) {
@@ -1082,14 +1099,12 @@ extern "C" int chx_moments_entry(const void* x, const void* w, int64_t B, int64_
         hipLaunchKernelGGL(moments_onepass_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, (const float*)x, (const float*)w,
                            Bx, Bw, N, part, centre);
         CHX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(moments_reduce_finalize_kernel<float>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
-                           centre, out, index, take_sqrt, (float*)entry_out);
+        launch_reduce_finalize<float>(B, nblk, part, centre, out, index, take_sqrt, entry_out, s);
     } else {
         hipLaunchKernelGGL(moments_onepass_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, (const double*)x,
                            (const double*)w, Bx, Bw, N, part, centre);
         CHX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(moments_reduce_finalize_kernel<double>, dim3((unsigned)B), dim3(1024), 0, s, part, (int)nblk,
-                           centre, out, index, take_sqrt, (double*)entry_out);
+        launch_reduce_finalize<double>(B, nblk, part, centre, out, index, take_sqrt, entry_out, s);
     }
     CHX_CHECK_LAUNCH();
     return CHX_OK;

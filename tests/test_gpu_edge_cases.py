@@ -163,3 +163,25 @@ def test_moments_of_beams_with_outliers_vs_reference():
                     err = abs(got - ref) / (sig[a] * sig[b])
                 assert err < (1e-9 if tag == "f64" else 5e-2 if name == "offset_beam" else 2e-4), (name, tag, p, got, ref, err)
     print("\nmoments vs oracle: " + ", ".join(f"{k[0]}/{k[1]} mu {v[0]:.1e} cov {v[1]:.1e}" for k, v in worst.items()))
+
+
+@pytest.mark.gpu
+def test_beam_properties_of_more_vector_rows_than_one_launch_takes():
+    """70 000 vector rows x 16 particles: the reductions index the batch with blockIdx.y (65 535 rows per launch) — the rows
+    go through in slices; tracking such a beam is one flat launch anyway. Against torch's own statistics of the rows
+    (utils/statistics.py:4-62 with unit weights = the unbiased variance)."""
+    import cheetah_amd as ca
+
+    torch.manual_seed(3)
+    B, N = 70_000, 16
+    p = torch.randn(B, N, 7, device="cuda", dtype=torch.float32) * 1e-3
+    p[..., 6] = 1.0
+    beam = ca.ParticleBeam(p, energy=torch.tensor(1e8, device="cuda"), dtype=torch.float32, device="cuda")
+    quad = ca.Quadrupole(torch.tensor(0.2, device="cuda"), k1=torch.linspace(-5.0, 5.0, B, device="cuda"), device="cuda", dtype=torch.float32)
+    out = ca.Segment([ca.Drift(torch.tensor(0.5, device="cuda"), device="cuda", dtype=torch.float32), quad]).track(beam)
+    assert out.particles.shape == (B, N, 7)
+    want_sigma = out.particles[..., 0].double().std(dim=1)
+    want_mu = out.particles[..., 2].double().mean(dim=1)
+    assert out.sigma_x.shape == (B,)
+    assert torch.allclose(out.sigma_x.double(), want_sigma, rtol=2e-6, atol=0.0)
+    assert torch.allclose(out.mu_y.double(), want_mu, rtol=0.0, atol=2e-10)
