@@ -561,3 +561,48 @@ def test_fused_screen_reading_keeps_gradients_of_lattice_settings(ca):
     img_q = build(t(2.0)).track_screen_reading(beam_q)
     img_q.sum().backward()
     assert q.grad is not None and float(q.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_run_longer_than_one_device_plan_goes_through_in_pieces(ca, dt):
+    """600 mergeable elements between the ends of a beamline: one persistent device plan holds 192 elements / 400 setting
+    tensors, so the run's map is the product of its PIECES' maps (`Segment._run_map_parts`: a `chx_run_map` call per piece, one
+    `chx_compose_maps`) instead of a host walk over every element. Against the product of all element maps (fp64: rounding of
+    the association; fp32: the piece maps are rounded where the element maps were — measured 1.5e-7 of a coordinate's scale)."""
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for i in range(150):
+        els += [ca.Quadrupole(t(0.2), k1=t(1.1 if i % 2 == 0 else -1.1), misalignment=t([1e-5 * (i % 7), -2e-5]), tilt=t(1e-3 * (i % 3)), **kw),
+                ca.Drift(t(0.8), **kw), ca.HorizontalCorrector(t(0.02), angle=t(1e-6 * (i % 5)), **kw),
+                ca.Dipole(t(0.1), angle=t(1e-3), dipole_e1=t(5e-4), **kw) if i % 10 == 0 else ca.Drift(t(0.1), **kw)]
+    seg = ca.Segment(els)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, dtype=dt, device="cuda")
+    with torch.no_grad():
+        out = seg.track(beam)
+        run = seg._plan()[0][1]
+        assert run.parts is not None and len(run.parts) >= 4 and all(p.fast is not None and p.fast.ok for p in run.parts)
+        ref = general_path(ca, seg, beam)
+        scale = ref.abs().amax(dim=0)
+        err = ((out.particles - ref).abs() / scale).max()
+        assert err < (6e-7 if dt == torch.float32 else 1e-12), float(err)
+        assert float(out.s) == pytest.approx(float(sum(float(e.length) for e in els)), rel=1e-6 if dt == torch.float32 else 1e-12)
+        # an in-place edit inside the third piece is followed (the device compares the values), and so is a re-assignment
+        els[300].k1.add_(0.5)
+        out2 = seg.track(beam)
+        ref2 = general_path(ca, seg, beam)
+        assert not torch.equal(out2.particles, out.particles)
+        assert ((out2.particles - ref2).abs() / scale).max() < (6e-7 if dt == torch.float32 else 1e-12)
+        els[10].k1 = t(-0.7)
+        ref3 = general_path(ca, seg, beam)
+        assert ((seg.track(beam).particles - ref3).abs() / scale).max() < (6e-7 if dt == torch.float32 else 1e-12)
+        # ParameterBeam: the same pieces
+        pb = ca.ParameterBeam.from_parameters(dtype=dt, device="cuda")
+        got = seg.track(pb)
+        tm = ca._ops.compose_maps([e.first_order_transfer_map(pb.energy, pb.species) for e in els], (), dt, torch.device("cuda"))
+        want_mu = tm @ pb.mu
+        assert torch.allclose(got.mu, want_mu, rtol=0, atol=float(want_mu.abs().max()) * (2e-6 if dt == torch.float32 else 1e-12))
+    # a trainable setting anywhere in the run: the differentiable path, as before
+    els[4].k1 = torch.nn.Parameter(t(0.3))
+    seg.track(beam).sigma_x.backward()
+    assert els[4].k1.grad is not None and torch.isfinite(els[4].k1.grad) and float(els[4].k1.grad) != 0.0
