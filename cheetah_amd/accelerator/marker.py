@@ -45,6 +45,8 @@ class Marker(Element):
 class BPM(Marker):
     """Beam position monitor: reads (mu_x, mu_y) of the passing beam when active (bpm.py:77-87)."""
 
+    _is_bpm = True
+
     def __init__(self, is_active=False, name=None, misalignment=None, sanitize_name=None, metadata=None, device=None,
                  dtype=None):
         fk = {"device": device, "dtype": dtype}
@@ -61,9 +63,17 @@ class BPM(Marker):
 
     def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if self.is_active:
-            # both means come out of one fused chx_moments call (bpm.py:77-85)
-            self.reading = torch.stack([incoming.mu_x - self.misalignment[..., 0],
-                                        incoming.mu_y - self.misalignment[..., 1]], dim=-1)
+            # both means come out of one fused chx_moments call (bpm.py:77-85). The reading is an OUTPUT of tracking, not a
+            # setting: it goes straight into the buffer table — an attribute assignment would move the process-wide epoch and
+            # have every persistent run plan of the lattice re-validate on its next use (25 active BPMs in a 100-element lattice:
+            # 92 us per BPM and track)
+            p = getattr(incoming, "particles", None)
+            if p is not None and not (torch.is_grad_enabled() and (p.requires_grad or incoming.survival_probabilities.requires_grad)):
+                # entries 2 and 4 of the moment vector = (mu_x, mu_y): one strided view, one cast, one subtraction
+                xy = incoming._moments()[..., 2:5:2].to(p.dtype)
+            else:
+                xy = torch.stack([incoming.mu_x, incoming.mu_y], dim=-1)
+            self.__dict__["_buffers"]["reading"] = xy - self.misalignment
         return incoming._view()
 
     @property

@@ -153,3 +153,80 @@ def test_what_ends_a_stretch():
                 ca.Segment(_linac(ca, dt, 1) + [bad]).track(beam)
     finally:
         segment._HOST = old
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("with_cavities", [False, True])
+def test_active_bpms_ride_in_the_stretch(dt, with_cavities):
+    """A lattice with an active BPM in every cell: ONE stretch call (chx_lattice_track_bpm: prepare, particle pass with the
+    weighted sums of x and y at every monitor, one finalize launch) — particles, energy and path length bit for bit as the walk
+    item by item; every reading = (mu_x, mu_y) of the beam AT that monitor minus its misalignment (bpm.py:77-87), equal to the
+    walk's reading to the rounding of the mean (fp64 sums in another order, then one rounding to the beam's dtype)."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(5)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_011, energy=t(6e7), mu_x=t(2e-4), mu_y=t(-1e-4), sigma_p=t(1e-3), **kw)
+    # some particles lost upstream: the means are weighted with the survival probabilities
+    w = torch.ones(20_011, **kw)
+    w[::7] = 0.25
+    w[5] = 0.0
+    beam = ca.ParticleBeam(beam.particles, beam.energy, particle_charges=beam.particle_charges, survival_probabilities=w, **kw)
+    els, bpms = [], []
+    for i in range(12):
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -2e-5 * i]), name=f"bpm{i}", **kw)
+        bpms.append(bpm)
+        els += [ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw), ca.Drift(t(0.5), **kw),
+                ca.VerticalCorrector(t(0.05), angle=t(2e-5 * (i + 1)), **kw), bpm, ca.Drift(t(0.2), **kw)]
+        if with_cavities and i % 4 == 1:
+            els += [ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw)]
+    els += [ca.BPM(is_active=True, name="last", **kw)]            # a monitor at the very end reads the outgoing beam
+    bpms.append(els[-1])
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(beam)
+            got = torch.stack([b.reading.clone() for b in bpms])
+        assert calls == [20_011], calls                            # one call for the whole lattice
+        with torch.no_grad():
+            ref = _walk(seg, beam)
+            want = torch.stack([b.reading.clone() for b in bpms])
+        assert calls == [20_011] or not with_cavities              # (the walk's cavities take their own path)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+        assert got.shape == (13, 2) and torch.isfinite(got).all()
+        eps = torch.finfo(dt).eps
+        # one unit in the last place of the MEAN in the beam's dtype (the reading is the mean minus the misalignment) + the
+        # rounding of fp64 sums over 20 011 coordinates of a few mm taken in another order (measured: 5.4e-20 m)
+        mean_scale = (want + torch.stack([b.misalignment for b in bpms])).abs()
+        order = 8 * torch.finfo(torch.float64).eps * 5e-3
+        assert torch.all((got - want).abs() <= 2 * eps * mean_scale + order), ((got - want).abs() / (eps * mean_scale)).max()
+        assert (got[1] - got[0]).abs().max() > 1e-6                # the monitors see different beams
+        # the last monitor: the outgoing beam
+        assert torch.allclose(got[-1, 0], out.mu_x, rtol=4 * eps, atol=order) and torch.allclose(got[-1, 1], out.mu_y, rtol=4 * eps, atol=order)
+        # an in-place edit of a corrector and of a monitor's misalignment is followed; tracking does not move the epoch
+        epoch = ca.Element._epoch
+        els[2].angle.fill_(5e-4)
+        bpms[3].misalignment[0] = 7e-4
+        calls.clear()
+        with torch.no_grad():
+            out2 = seg.track(beam)
+            got2 = torch.stack([b.reading.clone() for b in bpms])
+            ref2 = _walk(seg, beam)
+            want2 = torch.stack([b.reading.clone() for b in bpms])
+        assert ca.Element._epoch == epoch
+        assert torch.equal(out2.particles, ref2.particles)
+        mean_scale2 = (want2 + torch.stack([b.misalignment for b in bpms])).abs()
+        assert torch.all((got2 - want2).abs() <= 2 * eps * mean_scale2 + order)
+        assert (got2[1] - got[1]).abs().max() > 1e-7             # (the kick shows at the NEXT monitor)
+        # an inactive monitor is a pass-through element of its run; a monitor with a gradient-carrying misalignment ends the stretch
+        bpms[5].is_active = False
+        with torch.no_grad():
+            out3, ref3 = seg.track(beam), _walk(seg, beam)
+        assert torch.equal(out3.particles, ref3.particles)
+    finally:
+        segment._HOST = old
