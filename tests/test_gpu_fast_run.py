@@ -606,3 +606,51 @@ def test_run_longer_than_one_device_plan_goes_through_in_pieces(ca, dt):
     els[4].k1 = torch.nn.Parameter(t(0.3))
     seg.track(beam).sigma_x.backward()
     assert els[4].k1.grad is not None and torch.isfinite(els[4].k1.grad) and float(els[4].k1.grad) != 0.0
+
+
+def test_nested_segments_are_planned_through(ca):
+    """A lattice of cells of cells (what lattice files give): the plain nested Segments' elements join the parent's runs — ONE run
+    plan for 25 cells of 4 elements, the same numbers as the flattened lattice bit for bit (same elements in the same order);
+    a nested segment holding an active Screen still records its beam; a SUBCLASS of Segment stays an element of its own."""
+    dt = torch.float32
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+
+    def cell(i):
+        return [ca.Quadrupole(t(0.2), k1=t(4.2 if i % 2 == 0 else -4.2), **kw), ca.Drift(t(0.8), **kw)]
+
+    cells = [ca.Segment(cell(2 * i) + [ca.Segment(cell(2 * i + 1), name=f"inner{i}")], name=f"cell{i}") for i in range(25)]
+    nested = ca.Segment(cells)
+    flat = nested.flattened()
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_000, **kw)
+    with torch.no_grad():
+        out, ref = nested.track(beam), flat.track(beam)
+    plan = nested._plan()
+    assert len(plan) == 1 and plan[0][0] == "run" and len(plan[0][1].elements) == 100 and plan[0][1].fast.ok
+    assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s)
+    # O(1) re-validation: nothing in the plan depends on tensor values any more
+    assert nested.__dict__["_plan_cache"][3] is None
+    # an edit deep inside is followed
+    cells[3].elements[2].elements[0].k1 = t(1.5)
+    with torch.no_grad():
+        assert torch.equal(nested.track(beam).particles, flat.track(beam).particles)
+    # an active screen inside a nested segment records the beam at its place
+    scr = ca.Screen(resolution=(32, 32), is_active=True, name="scr", **kw)
+    cells[10].elements.append(scr)
+    flat2 = nested.flattened()
+    with torch.no_grad():
+        out2 = nested.track(beam)
+        read = scr.get_read_beam().particles.clone()
+        ref2 = flat2.track(beam)
+    assert torch.equal(out2.particles, ref2.particles) and torch.equal(read, scr.get_read_beam().particles)
+    assert [k for k, _ in nested._plan()] == ["run", "element", "run"]
+
+    class MySegment(ca.Segment):
+        def track(self, incoming):
+            return super().track(incoming)
+
+    own = ca.Segment([MySegment(cell(0)), ca.Drift(t(0.1), **kw)])
+    assert any(isinstance(e, MySegment) for _, item in own._plan() for e in (item.elements if _ == "run" else [item]))
+    with torch.no_grad():       # (its map enters the run as ONE factor: the same product in another association)
+        a, b = own.track(beam).particles, own.flattened().track(beam).particles
+    assert ((a - b).abs().amax(dim=0) / b.abs().amax(dim=0)).max() < 1e-6
