@@ -147,10 +147,10 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     "chx_lattice_track": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                   c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "chx_lattice_bpm_workspace_bytes": (c_size_t, [c_i64, c_i64]),
-    "chx_lattice_track_bpm": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
-                                      c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_size_t,
-                                      c_void_p]),
+    "chx_lattice_diag_workspace_bytes": (c_size_t, [c_i64, c_i64]),
+    "chx_lattice_track_diag": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                                       c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "chx_copy_arrays": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int32, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
@@ -289,6 +289,6 @@ def host():
                               "(or `python -c 'import __graft_entry__ as g; g.build()'`)") from exc
         fn = lib().chx_run_track
         _chxhost.bind(ctypes.cast(fn, ctypes.c_void_p).value, torch.empty_like, torch._C._cuda_getCurrentRawStream, ChxError)
-        _chxhost.bind_lattice(ctypes.cast(lib().chx_lattice_track_bpm, ctypes.c_void_p).value)
+        _chxhost.bind_lattice(ctypes.cast(lib().chx_lattice_track_diag, ctypes.c_void_p).value)
         _host = _chxhost
     return _host

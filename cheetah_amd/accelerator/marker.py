@@ -85,6 +85,8 @@ class Aperture(Marker):
     """Aperture: when active, zeroes the survival probability of particles outside
     (aperture.py:90-135). The mask is a per-particle elementwise torch op on the device."""
 
+    _is_aperture = True
+
     def __init__(self, x_max=None, y_max=None, shape="rectangular", is_active=True, name=None, sanitize_name=None,
                  metadata=None, device=None, dtype=None):
         fk = {"device": device, "dtype": dtype}
@@ -104,6 +106,14 @@ class Aperture(Marker):
             return self._track_internal(incoming)
         return _unaliased(self._track_internal(incoming), incoming)
 
+    def _check_limits(self) -> None:
+        limits = (self.x_max, self.y_max)
+        checked = self.__dict__.get("_limits_checked")
+        if checked is None or not checked.matches(limits):
+            assert bool((self.x_max >= 0).all()) and bool((self.y_max >= 0).all())
+            self.__dict__["_limits_checked"] = TensorKey(limits)
+        assert self.shape in ["rectangular", "elliptical"], f"Unknown aperture shape {self.shape}"
+
     def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if not self.is_active:
             return incoming._view()
@@ -117,12 +127,7 @@ class Aperture(Marker):
             return incoming
         # aperture.py:72-73 asserts non-negative half-widths on every track; here the (host-synchronising) check runs once
         # per value of the two tensors
-        limits = (self.x_max, self.y_max)
-        checked = self.__dict__.get("_limits_checked")
-        if checked is None or not checked.matches(limits):
-            assert bool((self.x_max >= 0).all()) and bool((self.y_max >= 0).all())
-            self.__dict__["_limits_checked"] = TensorKey(limits)
-        assert self.shape in ["rectangular", "elliptical"], f"Unknown aperture shape {self.shape}"
+        self._check_limits()
         # one streaming kernel (chx_aperture_mask): strict `<` for the rectangle, `<= 1` for the ellipse
         survival = _ops.aperture_mask(incoming.particles, incoming.survival_probabilities, self.x_max, self.y_max,
                                       self.shape)

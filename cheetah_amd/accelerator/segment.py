@@ -272,7 +272,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures")
 
     def __init__(self, items, dtype, device):
         self.items, self.dtype, self.device = items, dtype, device
@@ -280,6 +280,7 @@ class _LatticePlan:
         self.table = self.state = self.capsule = None
         self.tensors = ()
         self.bpms = ()          # the active BPMs of the stretch, in reading-slot order
+        self.apertures = ()     # its active apertures
         self.count = 0          # leading items the table covers (the stretch ends in front of the first item it cannot take)
         self.refresh()
 
@@ -290,9 +291,24 @@ class _LatticePlan:
         self.ok = False
         lib = _lib.lib()
         dtype, device = self.dtype, self.device
-        rows, elem_kind, elem_poff, ptrs, tensors, bpms = [], [], [], [], [], []
+        rows, elem_kind, elem_poff, ptrs, tensors, bpms, apertures = [], [], [], [], [], [], []
         count = cavities = 0
         for kind, item in self.items:
+            if kind != "run" and item._is_aperture:
+                # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
+                from .marker import Aperture
+
+                limits = (item.x_max, item.y_max)
+                if type(item)._track_internal is not Aperture._track_internal or item._parameters or not item.is_active \
+                        or item.shape not in ("rectangular", "elliptical") \
+                        or any(t.dim() != 0 or t.dtype != dtype or t.device != device or t.requires_grad for t in limits):
+                    break
+                rows += [3, 1 if item.shape == "elliptical" else 0, len(ptrs), 0]
+                ptrs += [t.data_ptr() for t in limits]
+                tensors += limits
+                apertures.append(item)
+                count += 1
+                continue
             if kind != "run" and item._is_bpm:
                 # an active beam position monitor: {2, 0, where its misalignment's address sits in ptrs, reading slot}
                 from .marker import BPM
@@ -342,8 +358,8 @@ class _LatticePlan:
             count += 1
         # (a trailing run stays in the stretch: it rides in the same particle pass; a trailing BPM reads the outgoing beam)
         self.count = count
-        self.bpms = tuple(bpms)
-        if count < 2 or (cavities == 0 and not bpms) or not elem_kind:
+        self.bpms, self.apertures = tuple(bpms), tuple(apertures)
+        if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = count, len(elem_kind), len(ptrs)
         state_bytes = lib.chx_lattice_state_bytes(n_items, n_elems)
@@ -813,7 +829,7 @@ class Segment(Element):
                     chain = None
                 i += step
                 continue
-            if (kind == "run" or item._is_cavity or item._is_bpm) and n_items - i >= 2:
+            if (kind == "run" or item._is_cavity or item._is_bpm or item._is_aperture) and n_items - i >= 2:
                 done = self._lattice_stretch(plan, i, incoming)
                 if done is not None:
                     incoming, i = done
@@ -880,8 +896,8 @@ class Segment(Element):
         entry = cache[1].get(key)
         if entry is None:
             j, cavities = i, 0
-            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm):
-                cavities += plan[j][0] != "run"          # (cavities and active BPMs: what makes a stretch worth one call)
+            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm or plan[j][1]._is_aperture):
+                cavities += plan[j][0] != "run"          # (cavities, active BPMs and apertures: what makes a stretch worth one call)
                 j += 1
             entry = cache[1][key] = False if (j - i < 2 or cavities == 0 or not p.is_cuda) else [j, None]
         if entry is False:
@@ -907,20 +923,30 @@ class Segment(Element):
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         _ops.check_current_device(lp.device)
         on_device = s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device and not s_in.requires_grad
-        if lp.bpms:
-            # active BPMs in the stretch: the particle pass leaves the weighted sums of x and y at each of them, one more launch
-            # forms every reading (chx_lattice_track_bpm) — three launches for the lattice instead of six per monitor
+        w_out = incoming.survival_probabilities
+        if lp.bpms or lp.apertures:
+            # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
+            # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —
+            # three launches for the lattice instead of six per monitor and a stop per aperture
             w = incoming.survival_probabilities
             N = x.shape[0]
             if w.shape != (N,) or w.dtype != p.dtype or w.device != p.device or not w.is_contiguous() or (
                     torch.is_grad_enabled() and w.requires_grad):
                 return None
+            for ap in lp.apertures:
+                ap._check_limits()           # (aperture.py:72-73; a host read once per value of the two limits)
             n_bpm = len(lp.bpms)
-            readings = torch.empty((n_bpm, 2), dtype=p.dtype, device=p.device)
-            ws_bytes = _lib.lib().chx_lattice_bpm_workspace_bytes(N, n_bpm)
-            ws = _ops.workspace(ws_bytes, p.device)
+            readings = ws = None
+            ws_bytes = 0
+            if n_bpm:
+                readings = torch.empty((n_bpm, 2), dtype=p.dtype, device=p.device)
+                ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, n_bpm)
+                ws = _ops.workspace(ws_bytes, p.device)
+            if lp.apertures:
+                w_out = torch.empty_like(w)
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, N, e, s_in if on_device else None, sp.mass_eV_float,
-                                                    sp.num_elementary_charges_float, lp.device.index, w, n_bpm, readings, ws, ws_bytes)
+                                                    sp.num_elementary_charges_float, lp.device.index, w,
+                                                    w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes)
             for k, bpm in enumerate(lp.bpms):
                 bpm.__dict__["_buffers"]["reading"] = readings[k]
         else:
@@ -929,10 +955,10 @@ class Segment(Element):
         if s_out is None:
             s_out = s_in
             for kind, item in lp.items[:lp.count]:
-                if kind == "run" or not item._is_bpm:          # (a monitor has no length)
+                if kind == "run" or item._is_cavity:           # (monitors and apertures have no length)
                     s_out = s_out + (self._run_length(item) if kind == "run" else item.length)
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
-                            survival_probabilities=incoming.survival_probabilities, s=s_out, species=sp), i + lp.count
+                            survival_probabilities=w_out, s=s_out, species=sp), i + lp.count
 
     @staticmethod
     def _identity_run(run) -> bool:

@@ -553,13 +553,17 @@ extern "C" int chx_cavity_track_scalars(const void* x_in, const void* const* par
 // the beam behind every element and loading it again gives: bit-identical to element-by-element tracking.
 namespace {
 // An item of type 2 is an active beam position monitor (bpm.py:77-87): it reads the weighted means of x and y of the beam AT
-// that point of the lattice and lets the beam pass. Every wave leaves its sums of w x and w y there (fp64, slot by slot) and
-// its sum of w once; lattice_bpm_finalize_kernel forms reading = (T)(sum / W) - misalignment for all monitors of the stretch.
+// that point of the lattice and lets the beam pass. Every wave leaves its sums of w, w x and w y there (fp64, slot by slot);
+// lattice_bpm_finalize_kernel forms reading = (T)(sum / W) - misalignment for all monitors of the stretch.
+// An item of type 3 is an active aperture (aperture.py:90-135): survival *= inside(x, y) in T, the arithmetic of
+// aperture_kernel (chx_aperture.hip) — the weights of the monitors behind it are the reduced ones, and the pass writes the
+// outgoing survival probabilities.
 template <typename T, int PPT>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in, T* x_out, const int64_t* __restrict__ items, int n_items,
                                                                  const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                                  int64_t N, int in_vec_ok, int out_vec_ok,
-                                                                 const T* __restrict__ survival, double* __restrict__ bpm_ws, int n_bpm) {
+                                                                 const T* __restrict__ survival, double* __restrict__ bpm_ws, int diag,
+                                                                 const int64_t* __restrict__ ptrs, T* __restrict__ survival_out) {
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     const int64_t n0 = (int64_t)blockIdx.x * TP;
@@ -573,36 +577,56 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
 #pragma unroll
         for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? lds[p * 7 + j] : (T)0;
     }
-    // weights of this lane's particles (0 beyond the beam) and this wave's share of W = sum w
-    double w[PPT];
+    // survival probabilities of this lane's particles (0 beyond the beam): the monitors' weights, what the apertures reduce
+    T sv[PPT];
     const int64_t nw = (int64_t)gridDim.x * (CHX_BLOCK / 64);
     const int64_t wslot = (int64_t)blockIdx.x * (CHX_BLOCK / 64) + (threadIdx.x >> 6);
-    if (n_bpm > 0) {
-        double wsum = 0.0;
+    if (diag) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int p = threadIdx.x + k * CHX_BLOCK;
-            w[k] = (p < np) ? (survival ? (double)survival[n0 + p] : 1.0) : 0.0;
-            wsum += w[k];
+            sv[k] = (p < np) ? (survival ? survival[n0 + p] : (T)1) : (T)0;
         }
-        wsum = chx_wave_sum(wsum);
-        if ((threadIdx.x & 63) == 0) bpm_ws[wslot] = wsum;
     }
     for (int i = 0; i < n_items; ++i) {
         const int type = (int)items[i * 4];
         if (type == 2) {
-            double sx = 0.0, sy = 0.0;
+            double sw = 0.0, sx = 0.0, sy = 0.0;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                sx = fma(w[k], (double)x[k][0], sx);
-                sy = fma(w[k], (double)x[k][2], sy);
+                const double w = (double)sv[k];
+                sw += w;
+                sx = fma(w, (double)x[k][0], sx);
+                sy = fma(w, (double)x[k][2], sy);
             }
+            sw = chx_wave_sum(sw);
             sx = chx_wave_sum(sx);
             sy = chx_wave_sum(sy);
             if ((threadIdx.x & 63) == 0) {
-                double* part = bpm_ws + nw + ((int64_t)items[i * 4 + 3] * nw + wslot) * 2;
-                part[0] = sx;
-                part[1] = sy;
+                double* part = bpm_ws + ((int64_t)items[i * 4 + 3] * nw + wslot) * 3;
+                part[0] = sw;
+                part[1] = sx;
+                part[2] = sy;
+            }
+            continue;
+        }
+        if (type == 3) {
+            const int64_t q = items[i * 4 + 2];
+            const T x_max = *(const T*)ptrs[q], y_max = *(const T*)ptrs[q + 1];
+            const bool elliptical = items[i * 4 + 1] != 0;
+            const T x_max2 = x_max * x_max, y_max2 = y_max * y_max;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const T px = x[k][0], py = x[k][2];
+                bool inside;
+                if (elliptical) {
+                    const T a = (px * px) / x_max2;
+                    const T c = (py * py) / y_max2;
+                    inside = (a + c) <= (T)1;
+                } else {
+                    inside = (px > -x_max) && (px < x_max) && (py > -y_max) && (py < y_max);
+                }
+                sv[k] = sv[k] * (inside ? (T)1 : (T)0);
             }
             continue;
         }
@@ -616,6 +640,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             if (cavity) cavity_epilogue<T>(c, x[k], y);
 #pragma unroll
             for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+        }
+    }
+    if (survival_out) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * CHX_BLOCK;
+            if (p < np) survival_out[n0 + p] = sv[k];
         }
     }
     __syncthreads();
@@ -639,12 +670,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_bpm_finalize_kernel(const i
                                                                         int64_t nw, T* __restrict__ readings) {
     __shared__ double red[4 * 3];
     const int slot = blockIdx.x;
-    const double* part = ws + nw + (int64_t)slot * nw * 2;
+    const double* part = ws + (int64_t)slot * nw * 3;
     double v[3] = {0.0, 0.0, 0.0};
     for (int64_t i = threadIdx.x; i < nw; i += CHX_BLOCK) {
-        v[0] += ws[i];
-        v[1] += part[i * 2];
-        v[2] += part[i * 2 + 1];
+        v[0] += part[i * 3];
+        v[1] += part[i * 3 + 1];
+        v[2] += part[i * 3 + 2];
     }
     chx_block_sum<3>(v, red);
     if (threadIdx.x == 0) {
@@ -657,19 +688,20 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_bpm_finalize_kernel(const i
 }
 }  // namespace
 
-extern "C" size_t chx_lattice_bpm_workspace_bytes(int64_t N, int64_t n_bpm) {
+extern "C" size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t n_bpm) {
     if (N < 1 || n_bpm < 0) return 0;
     const int64_t nw = ((N + CHX_BLOCK - 1) / CHX_BLOCK) * (CHX_BLOCK / 64);
-    return (size_t)(nw * (1 + 2 * n_bpm)) * sizeof(double);
+    return (size_t)(nw * 3 * n_bpm) * sizeof(double);
 }
 
-extern "C" int chx_lattice_track_bpm(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
-                                     double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
-                                     void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, const void* survival,
-                                     int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                      double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
+                                      void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, const void* survival,
+                                      void* survival_out, int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
     if (!x_in || !x_out || N < 1 || n_bpm < 0 || n_bpm > n_items) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && (!readings || !workspace)) return CHX_ERR_INVALID_ARG;
-    if (n_bpm > 0 && workspace_bytes < chx_lattice_bpm_workspace_bytes(N, n_bpm)) return CHX_ERR_WORKSPACE;
+    if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, n_bpm)) return CHX_ERR_WORKSPACE;
     int st = chx_lattice_prepare(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, energy_out,
                                  s_in, s_out, stream);
     if (st != CHX_OK) return st;
@@ -681,16 +713,19 @@ extern "C" int chx_lattice_track_bpm(const int64_t* table, int64_t n_items, int6
     const unsigned grid = (unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK);
     const int64_t nw = (int64_t)grid * (CHX_BLOCK / 64);
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
+    const int diag = (n_bpm > 0 || survival_out) ? 1 : 0;
     if (dtype == CHX_F32) {
         hipLaunchKernelGGL((lattice_apply_kernel<float, 1>), dim3(grid), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
-                           (int)n_items, Rs, coeffs, N, iv, ov, (const float*)survival, (double*)workspace, (int)n_bpm);
+                           (int)n_items, Rs, coeffs, N, iv, ov, (const float*)survival, (double*)workspace, diag, ptrs,
+                           (float*)survival_out);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
             hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
                                (const double*)workspace, nw, (float*)readings);
     } else {
         hipLaunchKernelGGL((lattice_apply_kernel<double, 1>), dim3(grid), dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out, table,
-                           (int)n_items, Rs, coeffs, N, iv, ov, (const double*)survival, (double*)workspace, (int)n_bpm);
+                           (int)n_items, Rs, coeffs, N, iv, ov, (const double*)survival, (double*)workspace, diag, ptrs,
+                           (double*)survival_out);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
             hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
@@ -703,8 +738,8 @@ extern "C" int chx_lattice_track_bpm(const int64_t* table, int64_t n_items, int6
 extern "C" int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                  double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                                  void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, void* stream) {
-    return chx_lattice_track_bpm(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, x_in, x_out, N,
-                                 energy_out, s_in, s_out, nullptr, 0, nullptr, nullptr, 0, stream);
+    return chx_lattice_track_diag(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, x_in, x_out, N,
+                                  energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 // ---- several device arrays copied by ONE launch -----------------------------------------------------------------------

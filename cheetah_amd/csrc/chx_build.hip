@@ -1648,7 +1648,8 @@ extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs
 // (lattice_apply_kernel). The arithmetic per item is that of run_map_kernel / cavity_prepare_scalars_kernel — bit-identical maps,
 // coefficients, energies and path length.
 //   table (int64 words, device): items[n_items][4] = {type 0 run / 1 cavity, E, first element, -} or {2 active BPM, 0, index of
-//   its misalignment's address in ptrs, reading slot}, elem_kind[n_elems],
+//   its misalignment's address in ptrs, reading slot} or {3 active aperture, 0 rectangular / 1 elliptical, index of the addresses
+//   of x_max and y_max in ptrs, -}, elem_kind[n_elems],
 //   elem_poff[n_elems] (first pointer of the element), ptrs[n_ptrs] (device addresses of the scalar settings, kind order)
 //   state: R[n_items][49] (T, in double-sized slots), coeffs[n_items][8] double, emaps[n_elems][49] (T, double-sized slots)
 constexpr int kLatticeMaxItems = 1024;
@@ -1680,7 +1681,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
         // path length behind the stretch: s + run length (((L0 + L1) + L2) + ...) / + cavity length, item by item, in T
         T sv = *s_in;
         for (int i = 0; i < n_items; ++i) {
-            if (items[i * 4] == 2) continue;               // a beam position monitor: no length
+            if (items[i * 4] >= 2) continue;               // a beam position monitor / an aperture: no length
             const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
             T total = setting(elem_poff[e0]);
             for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
@@ -1691,7 +1692,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     __syncthreads();
     const double E0 = e_in_sh;
     T* R = reinterpret_cast<T*>(Rs + (int64_t)b * 49);
-    if (type == 2) {                                       // an active BPM: nothing to build (lattice_apply_kernel reads the beam there)
+    if (type >= 2) {                                       // an active BPM / aperture: nothing to build (lattice_apply_kernel acts there)
         if (b == n_items - 1 && threadIdx.x == 0) *energy_out = (T)E0;
         return;
     }

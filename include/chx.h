@@ -38,7 +38,7 @@ extern "C" {
 #define CHX_ABI_VERSION 6 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
                              4: s_in / s_out arguments of chx_run_map / chx_run_track;
                              5: s_in / s_out arguments of chx_cavity_prepare_scalars / chx_cavity_track_scalars;
-                             6: chx_lattice_track_bpm (items of type 2 in the table of a lattice stretch) */
+                             6: chx_lattice_track_diag (items of type 2 / 3 in the table of a lattice stretch) */
 
 typedef enum chx_status {
     CHX_OK = 0,
@@ -551,8 +551,8 @@ int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* 
  * map and coefficient row for the reference energy it receives (walked through the cavities in front of it), the outgoing
  * energy and path length. Launch 2: every particle through all items in registers. Bit-identical to tracking the items one by
  * one with chx_run_track / chx_cavity_track_scalars.
- *  table (device, int64 words): items[n_items][4] = {0 run | 1 cavity, elements E, first element, 0} (| 2: see
- *    chx_lattice_track_bpm), elem_kind[n_elems],
+ *  table (device, int64 words): items[n_items][4] = {0 run | 1 cavity, elements E, first element, 0} (| 2, 3: see
+ *    chx_lattice_track_diag), elem_kind[n_elems],
  *    elem_poff[n_elems] (index of the element's first pointer), ptrs[n_ptrs] (device addresses of the settings, each kind's
  *    parameters in chx_build_rmatrix order; a cavity: length, voltage, phase, frequency);
  *  state: chx_lattice_state_bytes(n_items, n_elems) bytes of device scratch that belong to the plan;
@@ -564,17 +564,20 @@ int chx_lattice_prepare(const int64_t* table, int64_t n_items, int64_t n_elems, 
 int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
                       double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
                       void* energy_out, const void* s_in, void* s_out, void* stream);
-/* The same stretch with ACTIVE beam position monitors in it (bpm.py:77-87: reading = (mu_x, mu_y) of the passing beam minus the
- * monitor's misalignment; the beam passes unchanged): an item {2, 0, index in ptrs of the address of the monitor's misalignment
- * [2], reading slot 0 .. n_bpm-1}. The particle pass leaves every wave's sums of w x and w y at each monitor (fp64; w =
- * survival[N] of `dtype`, or 1 when NULL), one more launch forms readings[n_bpm][2] = (dtype)(sum / sum w) - misalignment. A lattice
- * with a monitor in every cell is three launches instead of six per cell (segment.py:545-574 walks it element by element).
- * workspace: chx_lattice_bpm_workspace_bytes(N, n_bpm) bytes; n_bpm = 0: chx_lattice_track. */
-size_t chx_lattice_bpm_workspace_bytes(int64_t N, int64_t n_bpm);
-int chx_lattice_track_bpm(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
-                          double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
-                          void* energy_out, const void* s_in, void* s_out, const void* survival, int64_t n_bpm, void* readings,
-                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same stretch with ACTIVE beam position monitors and apertures in it — elements that read or thin the beam and let the
+ * particles pass, each of which costs the element-by-element walk (segment.py:545-574) a stop and several launches:
+ *  {2, 0, q, slot}: a BPM (bpm.py:77-87): ptrs[q] = address of its misalignment [2]; readings[slot] = (dtype)(sum w x / sum w,
+ *     sum w y / sum w) - misalignment of the beam AT that point (fp64 sums per wave in the particle pass, one more launch);
+ *  {3, 0 rectangular | 1 elliptical, q, 0}: an aperture (aperture.py:90-135): ptrs[q], ptrs[q + 1] = addresses of x_max, y_max;
+ *     survival *= inside(x, y), the arithmetic of chx_aperture_mask; monitors behind it weigh with the reduced probabilities.
+ * survival: [N] of `dtype` or NULL (= 1); survival_out: [N], required when the stretch holds an aperture, else NULL;
+ * readings[n_bpm][2]; workspace: chx_lattice_diag_workspace_bytes(N, n_bpm) bytes. Particles, energy and path length are those
+ * of chx_lattice_track bit for bit. */
+size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t n_bpm);
+int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
+                           double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
+                           void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out, int64_t n_bpm,
+                           void* readings, void* workspace, size_t workspace_bytes, void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),

@@ -230,3 +230,63 @@ def test_active_bpms_ride_in_the_stretch(dt, with_cavities):
         assert torch.equal(out3.particles, ref3.particles)
     finally:
         segment._HOST = old
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", ["rectangular", "elliptical"])
+def test_active_apertures_ride_in_the_stretch(dt, shape):
+    """Active apertures between the cells (aperture.py:90-135: survival *= inside(x, y)) and monitors behind them: one stretch
+    call; outgoing particles AND survival probabilities bit for bit as the walk item by item (a particle on the boundary falls on
+    the same side: the comparison is evaluated operation by operation in the beam's dtype), readings weighted with the thinned
+    probabilities."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(6)
+    beam = ca.ParticleBeam.from_parameters(num_particles=30_001, energy=t(6e7), sigma_x=t(4e-4), sigma_y=t(3e-4), mu_x=t(1e-4), **kw)
+    w = torch.rand(30_001, **kw)
+    beam = ca.ParticleBeam(beam.particles, beam.energy, particle_charges=beam.particle_charges, survival_probabilities=w, **kw)
+    els, bpms, aps = [], [], []
+    for i in range(8):
+        ap = ca.Aperture(x_max=t(6e-4 + 1e-4 * i), y_max=t(5e-4), shape=shape, name=f"ap{i}", **kw)
+        bpm = ca.BPM(is_active=True, name=f"bpm{i}", **kw)
+        aps.append(ap)
+        bpms.append(bpm)
+        els += [ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw), ca.Drift(t(0.5), **kw), ap, bpm, ca.Drift(t(0.2), **kw)]
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(beam)
+            got = torch.stack([b.reading.clone() for b in bpms])
+        assert calls == [30_001], calls
+        with torch.no_grad():
+            ref = _walk(seg, beam)
+            want = torch.stack([b.reading.clone() for b in bpms])
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.s, ref.s)
+        assert torch.equal(out.survival_probabilities, ref.survival_probabilities)
+        lost = int((out.survival_probabilities == 0).sum())
+        assert 1000 < lost < 29_000, lost                            # the apertures do cut
+        assert out.survival_probabilities is not beam.survival_probabilities and torch.equal(beam.survival_probabilities, w)
+        eps = torch.finfo(dt).eps
+        order = 8 * torch.finfo(torch.float64).eps * 5e-3
+        assert torch.all((got - want).abs() <= 2 * eps * want.abs() + order), (got - want).abs().max()
+        # a particle exactly on the boundary of the first aperture: same side as the element-by-element kernel
+        aps[0].x_max.copy_(ref.particles[0, 0].abs())
+        with torch.no_grad():
+            out2, ref2 = seg.track(beam), _walk(seg, beam)
+        assert torch.equal(out2.survival_probabilities, ref2.survival_probabilities)
+        # a negative half-width is refused like on the walk (aperture.py:72-73)
+        aps[3].x_max.fill_(-1.0)
+        with pytest.raises(AssertionError):
+            seg.track(beam)
+        aps[3].x_max.fill_(1e-3)
+        # a ParameterBeam passes (with the reference's warning) as before
+        with pytest.warns(Warning), torch.no_grad():
+            seg.track(ca.ParameterBeam.from_parameters(**kw))
+    finally:
+        segment._HOST = old
