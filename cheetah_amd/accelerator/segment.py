@@ -731,41 +731,65 @@ class Segment(Element):
     #: a persistent device plan (`_FastRun`) holds at most 192 elements and 400 setting tensors; a longer run is cut into pieces
     _PART_ELEMENTS = 128
     _PART_TENSORS = 380
+    #: runs shorter than this keep the general path when their one plan declines (its host walk is a few microseconds)
+    _PART_MIN_RUN = 16
 
     @staticmethod
     def _run_map_parts(run: _Run, ref: torch.Tensor, energy: torch.Tensor, species: Species, s_in: torch.Tensor):
-        """(map, s_out) of a run that is too long for one persistent device plan — a beamline of a thousand elements between two
-        screens — from the plans of its PIECES: every piece's composed map comes from its own plan (`chx_run_map`: the device
-        re-validates the piece's settings and rebuilds its map only when one changed), the K piece maps are composed by one more
-        launch. Host work per track: K calls instead of a walk over every element's tensors (~0.85 us per element: 0.85 ms for
-        1000 elements, 3.4 ms for 5000). None when a piece does not qualify (vectorised or trainable settings, gradients)."""
-        if len(run.elements) <= Segment._PART_ELEMENTS and run.fast is not None and run.fast.kinds is not None:
-            return None                       # short enough for one plan, which declined for another reason
-        if not ref.is_cuda or energy.dim() != 0:
+        """(map, s_out) of a run that ONE persistent device plan does not take — a beamline of a thousand elements between two
+        screens, or a run with a CustomTransferMap / one vectorised or trainable magnet in it — from its PIECES: stretches of
+        elements a plan takes (at most 128 elements / 380 setting tensors each: their composed map comes from `chx_run_map`, the
+        device re-validates the piece's settings and rebuilds its map only when one changed) and, one by one, the elements a plan
+        cannot take (their map through the general path, cached per element). The K piece maps are composed by one more launch.
+        Host work per track: K calls instead of a walk over every element's tensors (~0.85 us per element: 0.85 ms for 1000
+        elements, 3.4 ms for 5000; 100 us for 100 elements around one CustomTransferMap). None when that would not pay."""
+        if len(run.elements) < Segment._PART_MIN_RUN or not ref.is_cuda or energy.dim() != 0:
             return None
-        parts = run.parts
-        if parts is None:
+        built = run.parts
+        if built is None or built[0] is None:
+            # the partition: elements whose settings are device scalars without a graph go into the plans' stretches. It is redone
+            # (at most once per epoch) when a stretch's plan declines after all — a setting became vectorised or trainable since
             parts, piece, refs = [], [], 0
+            dtype, device = ref.dtype, ref.device
             for e in run.elements:
-                n = len(e._builder_scalar_refs()) if getattr(e, "_chx_kind", None) is not None and e._static_skippable else 0
+                takes = getattr(e, "_chx_kind", None) is not None and e._static_skippable and not e._parameters
+                settings = e._builder_scalar_refs() if takes else ()
+                if takes and any(t.dtype != dtype or t.device != device or t.requires_grad or t.dim() != (0 if index is None else 1)
+                                 for t, index in settings):
+                    takes = False
+                if not takes:
+                    if piece:
+                        parts.append((_Run(piece), True))
+                        piece, refs = [], 0
+                    parts.append((_Run([e]), False))
+                    continue
+                n = len(settings)
                 if piece and (len(piece) >= Segment._PART_ELEMENTS or refs + n > Segment._PART_TENSORS):
-                    parts.append(_Run(piece))
+                    parts.append((_Run(piece), True))
                     piece, refs = [], 0
                 piece.append(e)
                 refs += n
             if piece:
-                parts.append(_Run(piece))
-            run.parts = parts
-        if len(parts) < 2:
+                parts.append((_Run(piece), True))
+            if len(parts) < 2 or not any(cand and len(part.elements) >= 8 for part, cand in parts):
+                parts = ()
+            built = run.parts = (parts, Element._epoch if built is None else built[1])
+        parts = built[0]
+        if not parts:
             return None
         maps, s = [], s_in
-        for part in parts:
-            got = Segment._run_map_fast(part, ref, energy, species, s)
-            if got is None:
-                return None
-            maps.append(got[0])
-            s = got[1]
-        return _ops.compose_maps(maps, (), ref.dtype, ref.device), s
+        for part, candidate in parts:
+            got = Segment._run_map_fast(part, ref, energy, species, s) if candidate else None
+            if got is None:             # (a vectorised or gradient-carrying setting: this piece through the general path)
+                if candidate and built[1] != Element._epoch:
+                    run.parts = (None, Element._epoch)       # partition again on the next track (once per epoch)
+                maps.append(Segment._run_map(part, energy, species))
+                s = Segment._run_s(part, s)
+            else:
+                maps.append(got[0])
+                s = got[1]
+        batch_shape = torch.broadcast_shapes(*[m.shape[:-2] for m in maps])
+        return _ops.compose_maps(maps, batch_shape, ref.dtype, ref.device), s
 
     def first_order_transfer_map(self, energy: torch.Tensor, species: Species):
         plan = self._plan()
@@ -791,7 +815,7 @@ class Segment(Element):
                     fast = None
                     if not (torch.is_grad_enabled() and (incoming.mu.requires_grad or incoming.cov.requires_grad)):
                         fast = self._run_map_fast(item, incoming.mu, incoming.energy, incoming.species, incoming.s)
-                        if fast is None and len(item.elements) > self._PART_ELEMENTS and incoming.mu.dim() == 1:
+                        if fast is None and len(item.elements) >= self._PART_MIN_RUN:
                             fast = self._run_map_parts(item, incoming.mu, incoming.energy, incoming.species, incoming.s)
                     if fast is None:
                         tm, s_out = self._run_map(item, incoming.energy, incoming.species), self._run_s(item, incoming.s)
@@ -848,8 +872,7 @@ class Segment(Element):
                 fast = self._run_apply_fast(item, incoming)
                 if fast is None:
                     long_run = None
-                    if len(item.elements) > self._PART_ELEMENTS and incoming.particles.dim() == 2 and not (
-                            torch.is_grad_enabled() and incoming.particles.requires_grad):
+                    if len(item.elements) >= self._PART_MIN_RUN and not (torch.is_grad_enabled() and incoming.particles.requires_grad):
                         long_run = self._run_map_parts(item, incoming.particles, incoming.energy, incoming.species, incoming.s)
                     if long_run is None:
                         tm, s_out = self._run_map(item, incoming.energy, incoming.species), self._run_s(item, incoming.s)

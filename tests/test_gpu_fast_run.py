@@ -581,7 +581,7 @@ def test_run_longer_than_one_device_plan_goes_through_in_pieces(ca, dt):
     with torch.no_grad():
         out = seg.track(beam)
         run = seg._plan()[0][1]
-        assert run.parts is not None and len(run.parts) >= 4 and all(p.fast is not None and p.fast.ok for p in run.parts)
+        assert run.parts and len(run.parts[0]) >= 4 and all(c and p.fast is not None and p.fast.ok for p, c in run.parts[0])
         ref = general_path(ca, seg, beam)
         scale = ref.abs().amax(dim=0)
         err = ((out.particles - ref).abs() / scale).max()
@@ -654,3 +654,45 @@ def test_nested_segments_are_planned_through(ca):
     with torch.no_grad():       # (its map enters the run as ONE factor: the same product in another association)
         a, b = own.track(beam).particles, own.flattened().track(beam).particles
     assert ((a - b).abs().amax(dim=0) / b.abs().amax(dim=0)).max() < 1e-6
+
+
+def test_run_with_elements_no_device_plan_takes_goes_through_in_pieces(ca):
+    """100 elements around a CustomTransferMap, a quadrupole with 8 strengths and (then) a trainable corrector: the stretches a
+    persistent plan takes come from `chx_run_map`, the three odd elements from the general path, one `chx_compose_maps` puts
+    them together — the product of all element maps (vectorised over the 8 strengths), with a gradient where one is asked for."""
+    dt = torch.float32
+    t = lambda v: torch.tensor(v, dtype=dt, device="cuda")  # noqa: E731
+    kw = {"dtype": dt, "device": "cuda"}
+    els = []
+    for i in range(50):
+        els += [ca.Quadrupole(t(0.2), k1=t(2.2 if i % 2 == 0 else -2.2), **kw), ca.Drift(t(0.8), **kw)]
+    R = torch.eye(7, **kw)
+    R[0, 1], R[2, 3], R[0, 6] = 0.3, 0.3, 1e-5
+    els[31] = ca.CustomTransferMap(R, length=t(0.3), **kw)
+    els[60] = ca.Quadrupole(t(0.2), k1=torch.linspace(-3.0, 3.0, 8, **kw), **kw)
+    seg = ca.Segment(els)
+    beam = ca.ParticleBeam.from_parameters(num_particles=5_000, **kw)
+    with torch.no_grad():
+        out = seg.track(beam)
+        run = seg._plan()[0][1]
+        assert run.parts and [c for _, c in run.parts[0]] == [True, False, True, False, True]
+        maps = [e.first_order_transfer_map(beam.energy, beam.species) for e in els]
+        tm = ca._ops.compose_maps(maps, (8,), dt, torch.device("cuda"))
+        ref = ca._ops.apply_map(beam.particles, tm)
+    assert out.particles.shape == (8, 5_000, 7)
+    scale = ref.abs().amax(dim=(0, 1))
+    assert ((out.particles - ref).abs().amax(dim=(0, 1)) / scale).max() < 1e-6
+    assert float(out.s) == pytest.approx(sum(float(e.length) for e in els), rel=1e-6)
+    # a trainable setting in one of the plan's stretches: that stretch takes the differentiable path, the product keeps the graph
+    els[5] = ca.HorizontalCorrector(t(0.1), angle=torch.nn.Parameter(t(1e-4)), **kw)
+    seg = ca.Segment(els)
+    loss = seg.track(beam).mu_x.sum()
+    loss.backward()
+    g = els[5].angle.grad
+    assert g is not None and torch.isfinite(g) and float(g) != 0.0
+    # against finite differences of the same lattice
+    with torch.no_grad():
+        h = 1e-5
+        els[5].angle.add_(h); up = float(seg.track(beam).mu_x.sum())
+        els[5].angle.sub_(2 * h); dn = float(seg.track(beam).mu_x.sum())
+    assert float(g) == pytest.approx((up - dn) / (2 * h), rel=2e-2)
