@@ -660,8 +660,8 @@ class Segment(Element):
         """Tracked particles of `incoming` through `run` by ONE C call (chx_run_track), or None when the run or the beam
         does not qualify (vectorised / trainable settings, a vectorised beam, gradients) and the general path is taken."""
         p = incoming.particles
-        if p.dim() != 2 or not p.is_cuda:
-            return None
+        if p.dim() < 2 or not p.is_cuda or (p.dim() > 2 and not p.is_contiguous()):
+            return None                    # (B beams in one ParticleBeam under scalar settings: one flat beam of B N particles)
         fr = run.fast
         if fr is None or fr.dtype != p.dtype or fr.device != p.device:
             fr = run.fast = _FastRun(run, p.dtype, p.device)
@@ -681,6 +681,8 @@ class Segment(Element):
             if _any_requires_grad(*fr.tensors):   # a buffer switched with requires_grad_(True) in place moves no counter
                 return None
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
+        if x.dim() > 2:
+            x = x.reshape(-1, 7)
         _ops.check_current_device(fr.device)
         s_in = incoming.s
         on_device = s_in.dim() == 0 and s_in.dtype == fr.dtype and s_in.device == fr.device and not s_in.requires_grad
@@ -688,6 +690,8 @@ class Segment(Element):
         # length comes from the same launch that validates the settings (no host copy of the lengths to go stale)
         out, s_out = _HOST.run_track(fr.capsule, x, x.shape[0], e, s_in if on_device else None, sp.mass_eV_float,
                                      sp.num_elementary_charges_float, fr.device.index)
+        if p.dim() > 2:
+            out = out.reshape(p.shape)
         return out, (s_out if s_out is not None else Segment._run_s(run, s_in))
 
     @staticmethod
@@ -925,8 +929,8 @@ class Segment(Element):
             entry = cache[1][key] = False if (j - i < 2 or cavities == 0 or not p.is_cuda) else [j, None]
         if entry is False:
             return None
-        if p.dim() != 2 or not p.is_cuda:
-            return None
+        if p.dim() < 2 or not p.is_cuda or (p.dim() > 2 and not p.is_contiguous()):
+            return None                    # (B beams in one ParticleBeam: blockIdx.y of the particle pass)
         e, s_in, sp = incoming.energy, incoming.s, incoming.species
         if e.dim() != 0 or e.dtype != p.dtype or e.device != p.device:
             return None
@@ -947,31 +951,45 @@ class Segment(Element):
         _ops.check_current_device(lp.device)
         on_device = s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device and not s_in.requires_grad
         w_out = incoming.survival_probabilities
-        if lp.bpms or lp.apertures:
+        lead, N = tuple(p.shape[:-2]), p.shape[-2]
+        B = 1
+        for d in lead:
+            B *= d
+        if B < 1 or B > 65535:
+            return None
+        if lp.bpms or lp.apertures or lead:
             # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
             # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —
             # three launches for the lattice instead of six per monitor and a stop per aperture
-            w = incoming.survival_probabilities
-            N = x.shape[0]
-            if w.shape != (N,) or w.dtype != p.dtype or w.device != p.device or not w.is_contiguous() or (
-                    torch.is_grad_enabled() and w.requires_grad):
-                return None
+            w = None
+            if lp.bpms or lp.apertures:
+                w = incoming.survival_probabilities
+                if w.dtype != p.dtype or w.device != p.device or (torch.is_grad_enabled() and w.requires_grad) \
+                        or w.shape[-1] != N or w.dim() > len(lead) + 1:
+                    return None
+                if tuple(w.shape) != lead + (N,):
+                    try:
+                        w = w.expand(*lead, N)
+                    except RuntimeError:
+                        return None
+                if not w.is_contiguous():
+                    w = w.contiguous()
             for ap in lp.apertures:
                 ap._check_limits()           # (aperture.py:72-73; a host read once per value of the two limits)
             n_bpm = len(lp.bpms)
             readings = ws = None
             ws_bytes = 0
             if n_bpm:
-                readings = torch.empty((n_bpm, 2), dtype=p.dtype, device=p.device)
-                ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, n_bpm)
+                readings = torch.empty((n_bpm, B, 2), dtype=p.dtype, device=p.device)
+                ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, B, n_bpm)
                 ws = _ops.workspace(ws_bytes, p.device)
             if lp.apertures:
                 w_out = torch.empty_like(w)
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, N, e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index, w,
-                                                    w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes)
+                                                    w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B)
             for k, bpm in enumerate(lp.bpms):
-                bpm.__dict__["_buffers"]["reading"] = readings[k]
+                bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(*lead, 2)
         else:
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, x.shape[0], e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index)

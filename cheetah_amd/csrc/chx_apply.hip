@@ -566,9 +566,14 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                                                                  const int64_t* __restrict__ ptrs, T* __restrict__ survival_out) {
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
-    const int64_t n0 = (int64_t)blockIdx.x * TP;
-    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
-    tile_load<T, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0, true);
+    // blockIdx.y = beam (a vectorised ParticleBeam of gridDim.y beams of N particles under ONE lattice setting and energy: the
+    // same maps for all of them); tiles do not straddle beams, so a wave's sums at a monitor belong to one beam
+    const int64_t beam = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * TP;
+    const int64_t n0 = beam * N + t0;                      // first flat particle of this tile
+    const int np = (int)((N - t0 < TP) ? (N - t0) : TP);
+    const bool row_vec = ((beam * N * 7 * (int64_t)sizeof(T)) & 15) == 0;
+    tile_load<T, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0 && row_vec, true);
     __syncthreads();
     T x[PPT][7];
 #pragma unroll
@@ -579,8 +584,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
     }
     // survival probabilities of this lane's particles (0 beyond the beam): the monitors' weights, what the apertures reduce
     T sv[PPT];
-    const int64_t nw = (int64_t)gridDim.x * (CHX_BLOCK / 64);
-    const int64_t wslot = (int64_t)blockIdx.x * (CHX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (CHX_BLOCK / 64);            // waves per beam
+    const int64_t wslot = beam * nw + (int64_t)blockIdx.x * (CHX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nw_all = nw * gridDim.y;
     if (diag) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             sx = chx_wave_sum(sx);
             sy = chx_wave_sum(sy);
             if ((threadIdx.x & 63) == 0) {
-                double* part = bpm_ws + ((int64_t)items[i * 4 + 3] * nw + wslot) * 3;
+                double* part = bpm_ws + ((int64_t)items[i * 4 + 3] * nw_all + wslot) * 3;
                 part[0] = sw;
                 part[1] = sx;
                 part[2] = sy;
@@ -659,10 +665,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
         }
     }
     __syncthreads();
-    tile_store<T, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0, true);
+    tile_store<T, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0 && row_vec, true);
 }
 
-// one workgroup per monitor: W and the two sums over the waves' shares (fixed order: thread t takes shares t, t + 256, ...),
+// one workgroup per monitor and beam: W and the two sums over the waves' shares (fixed order: thread t takes shares t, t + 256, ...),
 // reading = (T)(sum / W) - misalignment, the subtraction in T like `incoming.mu_x - self.misalignment[..., 0]` (bpm.py:80-85)
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_bpm_finalize_kernel(const int64_t* __restrict__ items, int n_items,
@@ -670,7 +676,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_bpm_finalize_kernel(const i
                                                                         int64_t nw, T* __restrict__ readings) {
     __shared__ double red[4 * 3];
     const int slot = blockIdx.x;
-    const double* part = ws + (int64_t)slot * nw * 3;
+    const int64_t beam = blockIdx.y;                       // nw = waves per beam; readings[slot][beam][2]
+    const double* part = ws + ((int64_t)slot * gridDim.y + beam) * nw * 3;
     double v[3] = {0.0, 0.0, 0.0};
     for (int64_t i = threadIdx.x; i < nw; i += CHX_BLOCK) {
         v[0] += part[i * 3];
@@ -682,26 +689,27 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_bpm_finalize_kernel(const i
         const T* mis = nullptr;
         for (int i = 0; i < n_items; ++i)
             if (items[i * 4] == 2 && (int)items[i * 4 + 3] == slot) mis = (const T*)ptrs[items[i * 4 + 2]];
-        readings[slot * 2 + 0] = (T)(v[1] / v[0]) - mis[0];
-        readings[slot * 2 + 1] = (T)(v[2] / v[0]) - mis[1];
+        T* r = readings + ((int64_t)slot * gridDim.y + beam) * 2;
+        r[0] = (T)(v[1] / v[0]) - mis[0];
+        r[1] = (T)(v[2] / v[0]) - mis[1];
     }
 }
 }  // namespace
 
-extern "C" size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t n_bpm) {
-    if (N < 1 || n_bpm < 0) return 0;
+extern "C" size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t B, int64_t n_bpm) {
+    if (N < 1 || B < 1 || n_bpm < 0) return 0;
     const int64_t nw = ((N + CHX_BLOCK - 1) / CHX_BLOCK) * (CHX_BLOCK / 64);
-    return (size_t)(nw * 3 * n_bpm) * sizeof(double);
+    return (size_t)(nw * B * 3 * n_bpm) * sizeof(double);
 }
 
 extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                       double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
-                                      void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, const void* survival,
-                                      void* survival_out, int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
-    if (!x_in || !x_out || N < 1 || n_bpm < 0 || n_bpm > n_items) return CHX_ERR_INVALID_ARG;
+                                      void* x_out, int64_t N, int64_t B, void* energy_out, const void* s_in, void* s_out,
+                                      const void* survival, void* survival_out, int64_t n_bpm, void* readings, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    if (!x_in || !x_out || N < 1 || B < 1 || B > 65535 || n_bpm < 0 || n_bpm > n_items) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && (!readings || !workspace)) return CHX_ERR_INVALID_ARG;
-    if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, n_bpm)) return CHX_ERR_WORKSPACE;
+    if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, B, n_bpm)) return CHX_ERR_WORKSPACE;
     int st = chx_lattice_prepare(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, energy_out,
                                  s_in, s_out, stream);
     if (st != CHX_OK) return st;
@@ -710,25 +718,25 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
     hipStream_t s = (hipStream_t)stream;
     const int iv = chx_aligned16(x_in) ? 1 : 0, ov = chx_aligned16(x_out) ? 1 : 0;
     // one particle per lane: a stretch is tracked on small beams (a few dozen tiles), two per lane only halve the waves in flight
-    const unsigned grid = (unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK);
-    const int64_t nw = (int64_t)grid * (CHX_BLOCK / 64);
+    const dim3 grid((unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK), (unsigned)B);
+    const int64_t nw = (int64_t)grid.x * (CHX_BLOCK / 64);
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
     const int diag = (n_bpm > 0 || survival_out) ? 1 : 0;
     if (dtype == CHX_F32) {
-        hipLaunchKernelGGL((lattice_apply_kernel<float, 1>), dim3(grid), dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
+        hipLaunchKernelGGL((lattice_apply_kernel<float, 1>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
                            (int)n_items, Rs, coeffs, N, iv, ov, (const float*)survival, (double*)workspace, diag, ptrs,
                            (float*)survival_out);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
-            hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
+            hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
                                (const double*)workspace, nw, (float*)readings);
     } else {
-        hipLaunchKernelGGL((lattice_apply_kernel<double, 1>), dim3(grid), dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out, table,
+        hipLaunchKernelGGL((lattice_apply_kernel<double, 1>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out, table,
                            (int)n_items, Rs, coeffs, N, iv, ov, (const double*)survival, (double*)workspace, diag, ptrs,
                            (double*)survival_out);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
-            hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
+            hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
                                (const double*)workspace, nw, (double*)readings);
     }
     CHX_CHECK_LAUNCH();
@@ -739,7 +747,7 @@ extern "C" int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t 
                                  double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                                  void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, void* stream) {
     return chx_lattice_track_diag(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, x_in, x_out, N,
-                                  energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+                                  1, energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 // ---- several device arrays copied by ONE launch -----------------------------------------------------------------------

@@ -117,8 +117,9 @@ static PyObject* host_run_track(PyObject* self, PyObject* const* args, Py_ssize_
 /* chx_lattice_track_diag (include/chx.h); without monitors / apertures: survival = survival_out = readings = workspace = NULL */
 typedef int (*lattice_track_fn)(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                 double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
-                                void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, const void* survival,
-                                void* survival_out, int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream);
+                                void* x_out, int64_t N, int64_t B, void* energy_out, const void* s_in, void* s_out,
+                                const void* survival, void* survival_out, int64_t n_bpm, void* readings, void* workspace,
+                                size_t workspace_bytes, void* stream);
 static lattice_track_fn p_lattice_track = NULL;
 
 typedef struct {
@@ -155,18 +156,19 @@ static PyObject* host_lattice_plan(PyObject* self, PyObject* args) {
 }
 
 /* lattice_track(plan, x, N, energy, s_in | None, mass_eV, n_charges, device_index
- *               [, survival | None, survival_out | None, n_bpm, readings | None, workspace | None, workspace bytes])
+ *               [, survival | None, survival_out | None, n_bpm, readings | None, workspace | None, workspace bytes, B])
  *   -> (out, energy_out, s_out | None)
- * the six optional arguments: a stretch with active BPMs / apertures — survival_out (N,), readings (n_bpm, 2) and the workspace
- * are the caller's tensors */
+ * the seven optional arguments: B beams of N particles (x: (B, N, 7) contiguous) and / or a stretch with active BPMs / apertures —
+ * survival_out (B, N), readings (n_bpm, B, 2) and the workspace are the caller's tensors */
 static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
-    if (nargs != 8 && nargs != 14) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8 or 14 arguments"); return NULL; }
+    if (nargs != 8 && nargs != 15) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8 or 15 arguments"); return NULL; }
     void *surv = NULL, *surv_out = NULL, *readings = NULL, *bws = NULL;
-    long long n_bpm = 0;
+    long long n_bpm = 0, beams = 1;
     unsigned long long bws_bytes = 0;
-    if (nargs == 14) {
+    if (nargs == 15) {
         n_bpm = PyLong_AsLongLong(args[10]);
         bws_bytes = PyLong_AsUnsignedLongLong(args[13]);
+        beams = PyLong_AsLongLong(args[14]);
         if (PyErr_Occurred()) return NULL;
         if ((args[8] != Py_None && tensor_ptr(args[8], &surv)) || (args[9] != Py_None && tensor_ptr(args[9], &surv_out)) ||
             (args[11] != Py_None && tensor_ptr(args[11], &readings)) || (args[12] != Py_None && tensor_ptr(args[12], &bws)))
@@ -197,7 +199,7 @@ static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ss
     stream = PyLong_AsVoidPtr(st);
     Py_DECREF(st);
     const int rc = p_lattice_track(p->table, p->n_items, p->n_elems, p->n_ptrs, ep, mass, nq, p->code, p->state, p->state_bytes, xp, op,
-                                   (int64_t)N, eop, sp, sop, surv, surv_out, (int64_t)n_bpm, readings, bws, (size_t)bws_bytes, stream);
+                                   (int64_t)N, (int64_t)beams, eop, sp, sop, surv, surv_out, (int64_t)n_bpm, readings, bws, (size_t)bws_bytes, stream);
     if (rc != 0) {
         Py_DECREF(out); Py_DECREF(e_out); Py_DECREF(s_out);
         PyErr_Format(g_error ? g_error : PyExc_RuntimeError, "chx_lattice_track failed with status %d", rc);
@@ -212,7 +214,7 @@ static PyMethodDef methods[] = {
     {"bind_lattice", host_bind_lattice, METH_VARARGS, "bind_lattice(chx_lattice_track_diag address)"},
     {"lattice_plan", host_lattice_plan, METH_VARARGS, "lattice_plan(table addr, n_items, n_elems, n_ptrs, state addr, state bytes, dtype code) -> capsule"},
     {"lattice_track", (PyCFunction)(void (*)(void))host_lattice_track, METH_FASTCALL,
-     "lattice_track(plan, x, N, energy, s_in | None, mass_eV, n_charges, device index[, survival | None, survival_out | None, n_bpm, readings | None, workspace | None, workspace bytes]) -> (out, energy_out, s_out | None)"},
+     "lattice_track(plan, x, N, energy, s_in | None, mass_eV, n_charges, device index[, survival | None, survival_out | None, n_bpm, readings | None, workspace | None, workspace bytes, B]) -> (out, energy_out, s_out | None)"},
     {"bind", host_bind, METH_VARARGS, "bind(chx_run_track address, torch.empty_like, raw stream getter, error class)"},
     {"plan", host_plan_new, METH_VARARGS, "plan(kinds addr, pointer-table addr, E, state addr, state bytes, dtype code) -> capsule"},
     {"run_track", (PyCFunction)(void (*)(void))host_run_track, METH_FASTCALL,

@@ -570,14 +570,15 @@ int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, in
  *     sum w y / sum w) - misalignment of the beam AT that point (fp64 sums per wave in the particle pass, one more launch);
  *  {3, 0 rectangular | 1 elliptical, q, 0}: an aperture (aperture.py:90-135): ptrs[q], ptrs[q + 1] = addresses of x_max, y_max;
  *     survival *= inside(x, y), the arithmetic of chx_aperture_mask; monitors behind it weigh with the reduced probabilities.
- * survival: [N] of `dtype` or NULL (= 1); survival_out: [N], required when the stretch holds an aperture, else NULL;
- * readings[n_bpm][2]; workspace: chx_lattice_diag_workspace_bytes(N, n_bpm) bytes. Particles, energy and path length are those
- * of chx_lattice_track bit for bit. */
-size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t n_bpm);
+ * B beams of N particles each (x_in / x_out [B][N][7]: a vectorised ParticleBeam under ONE lattice setting and energy — the same
+ * maps for all beams; chx_lattice_track: B = 1). survival: [B][N] of `dtype` or NULL (= 1); survival_out: [B][N], required when
+ * the stretch holds an aperture, else NULL; readings[n_bpm][B][2]; workspace: chx_lattice_diag_workspace_bytes(N, B, n_bpm)
+ * bytes. Particles, energy and path length are those of chx_lattice_track bit for bit. */
+size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t B, int64_t n_bpm);
 int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
                            double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
-                           void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out, int64_t n_bpm,
-                           void* readings, void* workspace, size_t workspace_bytes, void* stream);
+                           int64_t B, void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
+                           int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),

