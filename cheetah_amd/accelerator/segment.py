@@ -272,7 +272,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape")
 
     def __init__(self, items, dtype, device):
         self.items, self.dtype, self.device = items, dtype, device
@@ -377,6 +377,7 @@ class _LatticePlan:
             self.state = torch.empty(state_bytes // 8 + 1, dtype=torch.float64, device=device)
         self.capsule = _lib.host().lattice_plan(self.table.data_ptr(), n_items, n_elems, n_ptrs, self.state.data_ptr(),
                                                 self.state.numel() * 8, self.code)
+        self.shape = (n_items, n_elems, n_ptrs)
         self.tensors = tuple(tensors)       # kept alive: the table holds their addresses
         self.ok = True
 
@@ -814,7 +815,16 @@ class Segment(Element):
     @tracking_call
     def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if isinstance(incoming, ParameterBeam):
-            for kind, item in self._plan():
+            plan = self._plan()
+            i, n_items = 0, len(plan)
+            while i < n_items:
+                kind, item = plan[i]
+                i += 1
+                if (kind == "run" or item._is_cavity or item._is_bpm) and n_items - i >= 1:
+                    done = self._lattice_stretch_parameter(plan, i - 1, incoming)
+                    if done is not None:
+                        incoming, i = done
+                        continue
                 if kind == "run":
                     fast = None
                     if not (torch.is_grad_enabled() and (incoming.mu.requires_grad or incoming.cov.requires_grad)):
@@ -1000,6 +1010,71 @@ class Segment(Element):
                     s_out = s_out + (self._run_length(item) if kind == "run" else item.length)
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=w_out, s=s_out, species=sp), i + lp.count
+
+    def _lattice_stretch_parameter(self, plan, i: int, incoming: ParameterBeam):
+        """The stretch of `_lattice_stretch` for a ParameterBeam (`chx_parameter_lattice_track`: the same preparation launch, then
+        one wavefront per batch row walks the items): (outgoing beam, index behind the stretch) or None. The walk item by item
+        costs ~80-160 us of host time per cavity / monitor cell for 49 numbers of beam state."""
+        mu, cov = incoming.mu, incoming.cov
+        if not mu.is_cuda or cov.dtype != mu.dtype or cov.device != mu.device:
+            return None
+        cache = self.__dict__.get("_lattice_cache")
+        if cache is None or cache[0] is not plan:
+            cache = self.__dict__["_lattice_cache"] = (plan, {})
+        key = (i, mu.dtype, mu.device)
+        entry = cache[1].get(key)
+        if entry is None:
+            j, special = i, 0
+            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm or plan[j][1]._is_aperture):
+                special += plan[j][0] != "run"
+                j += 1
+            entry = cache[1][key] = False if (j - i < 2 or special == 0) else [j, None]
+        if entry is False:
+            return None
+        e, s_in, sp = incoming.energy, incoming.s, incoming.species
+        if e.dim() != 0 or e.dtype != mu.dtype or e.device != mu.device:
+            return None
+        lp = entry[1]
+        if lp is None or lp.epoch != Element._epoch:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            if lp is None:
+                lp = entry[1] = _LatticePlan(plan[i:entry[0]], mu.dtype, mu.device)
+            else:
+                lp.refresh()
+        if not lp.ok or lp.apertures:                # (an aperture only warns for a ParameterBeam: the walk does that)
+            return None
+        if torch.is_grad_enabled() and (mu.requires_grad or cov.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
+                                        or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
+            return None
+        lead = torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2])
+        B = _ops.numel(lead)
+        m2 = mu.reshape(-1, 7) if mu.is_contiguous() else mu.reshape(-1, 7).contiguous()
+        c2 = cov.reshape(-1, 49) if cov.is_contiguous() else cov.reshape(-1, 49).contiguous()
+        if m2.shape[0] not in (1, B) or c2.shape[0] not in (1, B):
+            return None
+        _ops.check_current_device(lp.device)
+        on_device = s_in.dim() == 0 and s_in.dtype == mu.dtype and s_in.device == mu.device and not s_in.requires_grad
+        mu_out = torch.empty((*lead, 7), dtype=mu.dtype, device=mu.device)
+        cov_out = torch.empty((*lead, 7, 7), dtype=mu.dtype, device=mu.device)
+        e_out = torch.empty_like(e)
+        s_out = torch.empty_like(s_in) if on_device else None
+        n_bpm = len(lp.bpms)
+        readings = torch.empty((n_bpm, B, 2), dtype=mu.dtype, device=mu.device) if n_bpm else None
+        n_items, n_elems, n_ptrs = lp.shape
+        _ops.check(_lib.lib().chx_parameter_lattice_track(
+            lp.table.data_ptr(), n_items, n_elems, n_ptrs, e.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float, lp.code,
+            lp.state.data_ptr(), lp.state.numel() * 8, m2.data_ptr(), c2.data_ptr(), B, m2.shape[0], c2.shape[0], mu_out.data_ptr(),
+            cov_out.data_ptr(), e_out.data_ptr(), s_in.data_ptr() if on_device else None, s_out.data_ptr() if on_device else None,
+            n_bpm, readings.data_ptr() if n_bpm else None, _ops.stream_ptr()), "chx_parameter_lattice_track")
+        for k, bpm in enumerate(lp.bpms):
+            bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(*lead, 2)
+        if s_out is None:
+            s_out = s_in
+            for kind, item in lp.items[:lp.count]:
+                if kind == "run" or item._is_cavity:
+                    s_out = s_out + (self._run_length(item) if kind == "run" else item.length)
+        return ParameterBeam(mu_out, cov_out, e_out, total_charge=incoming.total_charge, s=s_out, species=sp), i + lp.count
 
     @staticmethod
     def _identity_run(run) -> bool:

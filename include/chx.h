@@ -579,6 +579,14 @@ int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elem
                            double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
                            int64_t B, void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
                            int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream);
+/* The same stretch for a ParameterBeam (element.py:167-179, cavity.py:127-133,202-218, bpm.py:77-87): mu [Bmu][7], cov [Bcov][49]
+ * (Bmu, Bcov in {1, B}) through [run | active Cavity | active BPM]+ by one wavefront per batch row after the same preparation
+ * launch — mu' = R mu, cov' = R cov R^T item by item (fp64 inside, rounded to `dtype` between items like chx_parameter_track), a
+ * cavity's moment updates, readings[n_bpm][B][2] = (mu_x, mu_y) - misalignment at every monitor. Items of type 3 are skipped. */
+int chx_parameter_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* mu,
+                                const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, void* mu_out, void* cov_out, void* energy_out,
+                                const void* s_in, void* s_out, int64_t n_bpm, void* readings, void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),
