@@ -502,7 +502,49 @@ def other_configs(ca, torch, device) -> dict:
                 "element_by_element": {"ms_per_track": times["element_by_element"],
                                        "achieved_GBs": 56.0 * N_PARTICLES * len(els) / (times["element_by_element"] * 1e-3) / 1e9}}
 
-    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order)):
+    def diagnostics():
+        # lattices with things between the magnets that read or thin the beam: active BPMs, apertures, cavities — one stretch call
+        # each (chx_lattice_track_diag / chx_parameter_lattice_track), ParticleBeam of 1e5 particles and ParameterBeam
+        import time as _t
+
+        dt = torch.float32
+        kw = {"dtype": dt, "device": device}
+        tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
+
+        def timed_us(fn, reps=30):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (_t.perf_counter() - t0) / reps * 1e6
+
+        bpm_cells, ap_cells, linac = [], [], []
+        for i in range(25):
+            q = lambda: ca.Quadrupole(tt(0.2), k1=tt(4.2 if i % 2 == 0 else -4.2), **kw)  # noqa: E731
+            bpm_cells += [q(), ca.Drift(tt(0.8), **kw), ca.BPM(is_active=True, **kw), ca.Drift(tt(0.2), **kw)]
+            ap_cells += [q(), ca.Drift(tt(0.8), **kw), ca.Aperture(x_max=tt(5e-3), y_max=tt(5e-3), **kw), ca.Drift(tt(0.2), **kw)]
+        for i in range(16):
+            linac += [ca.Drift(tt(0.3), **kw), ca.Quadrupole(tt(0.2), k1=tt(3.0 if i % 2 else -3.0), **kw),
+                      ca.Cavity(tt(1.0377), voltage=tt(18e6), phase=tt(-10.0), frequency=tt(1.3e9), **kw)]
+        beam = ca.ParticleBeam.from_parameters(num_particles=100_000, energy=tt(1e8), **kw)
+        pbeam = ca.ParameterBeam.from_parameters(energy=tt(1e8), **kw)
+        many = ca.ParticleBeam(beam.particles[:10_000].unsqueeze(0).repeat(16, 1, 1).contiguous(), beam.energy, **kw)
+        res = {"workload": "100-element lattices with 25 active BPMs / 25 active apertures and a 16-cell cavity linac, fp32: us per "
+                           "Segment.track (ParticleBeam of 1e5 particles; ParameterBeam; 16 beams of 1e4 particles in one ParticleBeam)"}
+        with torch.no_grad():
+            for name, els in (("bpm_lattice", bpm_cells), ("aperture_lattice", ap_cells), ("cavity_linac", linac)):
+                seg = ca.Segment(els)
+                res[name] = {"particle_beam_us": timed_us(lambda: seg.track(beam)),
+                             "sixteen_beams_us": timed_us(lambda: seg.track(many))}
+                if name != "aperture_lattice":      # (an aperture only warns for a ParameterBeam)
+                    res[name]["parameter_beam_us"] = timed_us(lambda: seg.track(pbeam))
+        return res
+
+    for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order),
+                     ("DIAGNOSTICS_LATTICES", diagnostics)):
         guarded(name, fn)
     return out
 
