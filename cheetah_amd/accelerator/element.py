@@ -403,7 +403,7 @@ class Element(nn.Module):
     #: without them and rebuilds on first use.
     _DERIVED_STATE = ("_plan_cache", "_flat_elements", "_map_cache", "_tmap_cache", "_scalar_ws", "_ext_cache",
                       "_grid_tensor", "_geom_cache", "_limits_checked", "_chain_guard_state", "_dkd_cache", "_lattice_cache",
-                      "_so_run_cache", "_dkd_run_cache", "_zero_s")
+                      "_so_run_cache", "_dkd_run_cache", "_zero_s", "_along_cache")
 
     def __getstate__(self):
         """State for `copy.deepcopy`, `pickle` and `torch.save`: everything but the derived caches."""

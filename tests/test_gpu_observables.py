@@ -152,3 +152,75 @@ def test_mapped_deposit_is_bit_identical_to_track_then_deposit(ca):
         assert got.shape == want.shape == (5, 16, 12, 10)
         assert torch.equal(got != 0, want != 0)
         assert torch.allclose(got, want, rtol=1e-12 if dt == torch.float64 else 1e-5, atol=0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_beam_attrs_along_segment_parameter_beam_and_nested_cells(ca, dt):
+    """A ParameterBeam and a lattice of nested cells take the fused path too (prefix maps through chx_parameter_track /
+    chx_track_moments); against the walk element by element (segment.py:658-700): positions are the ends of the segment's OWN
+    elements, a nested cell counts once."""
+    from cheetah_amd.accelerator.segment import Segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+
+    def cell(i):
+        return [ca.Quadrupole(t(0.2), k1=t(2.2 if i % 2 == 0 else -2.2), **kw), ca.Drift(t(0.8), **kw),
+                ca.HorizontalCorrector(t(0.05), angle=t(1e-5 * i), **kw)]
+
+    flat = ca.Segment([e for i in range(12) for e in cell(i)])
+    nested = ca.Segment([ca.Segment(cell(2 * i) + cell(2 * i + 1)) for i in range(6)] + [ca.Drift(t(0.3), **kw)])
+    names = ("beta_x", "alpha_y", "sigma_x", "mu_x", "emittance_y", "s", "energy")
+    pbeam = ca.ParameterBeam.from_twiss(beta_x=t(3.14), beta_y=t(12.0), alpha_x=t(0.4), energy=t(1e8), **kw)
+    beam = ca.ParticleBeam.from_twiss(beta_x=t(3.14), beta_y=t(12.0), alpha_x=t(0.4), energy=t(1e8), num_particles=20_000, **kw)
+    tol = 2e-4 if dt == torch.float32 else 1e-9
+    for seg, incoming, n_pos in ((flat, pbeam, 37), (nested, pbeam, 8), (nested, beam, 8)):
+        with torch.no_grad():
+            assert seg._attrs_along_fused(names, incoming) is not None
+            got = seg.get_beam_attrs_along_segment(names, incoming)
+            orig = Segment._attrs_along_fused
+            Segment._attrs_along_fused = lambda self, names, incoming: None
+            try:
+                want = seg.get_beam_attrs_along_segment(names, incoming)
+            finally:
+                Segment._attrs_along_fused = orig
+        for n, g, w in zip(names, got, want):
+            assert g.shape == w.shape == (n_pos,), (n, g.shape, w.shape)
+            scale = w.abs().max().clamp_min(1e-30)
+            assert ((g - w).abs().max() / scale) < tol, (n, float((g - w).abs().max() / scale))
+
+
+def test_beam_attrs_along_segment_with_active_bpms(ca):
+    """Active BPMs let the beam pass: the fused path takes them as identities and leaves their readings (the means at their
+    position minus the misalignment), like the walk element by element does."""
+    from cheetah_amd.accelerator.segment import Segment
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    els, bpms = [], []
+    for i in range(10):
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -1e-5]), **kw)
+        bpms.append(bpm)
+        els += [ca.Quadrupole(t(0.2), k1=t(2.2 if i % 2 == 0 else -2.2), **kw), ca.Drift(t(0.8), **kw),
+                ca.VerticalCorrector(t(0.05), angle=t(2e-5 * i), **kw), bpm]
+    seg = ca.Segment(els)
+    names = ("beta_x", "sigma_y", "mu_y", "s")
+    for incoming in (ca.ParticleBeam.from_twiss(beta_x=t(3.14), beta_y=t(12.0), energy=t(1e8), num_particles=20_000, **kw),
+                     ca.ParameterBeam.from_twiss(beta_x=t(3.14), beta_y=t(12.0), energy=t(1e8), **kw)):
+        with torch.no_grad():
+            assert seg._attrs_along_fused(names, incoming) is not None
+            got = seg.get_beam_attrs_along_segment(names, incoming)
+            got_r = torch.stack([b.reading.clone() for b in bpms])
+            orig = Segment._attrs_along_fused
+            Segment._attrs_along_fused = lambda self, names, incoming: None
+            try:
+                want = seg.get_beam_attrs_along_segment(names, incoming)
+                want_r = torch.stack([b.reading.clone() for b in bpms])
+            finally:
+                Segment._attrs_along_fused = orig
+        for n, g, w in zip(names, got, want):
+            assert g.shape == w.shape == (41,)
+            assert ((g - w).abs().max() / w.abs().max().clamp_min(1e-30)) < 2e-4, n
+        assert got_r.shape == (10, 2) and torch.allclose(got_r, want_r, rtol=1e-4, atol=2e-9)
+        assert (got_r[5] - got_r[1]).abs().max() > 1e-6
