@@ -998,7 +998,7 @@ def _moments_raw(x, w, B, N, entry=None):
     """chx_moments; with entry = (index, take_sqrt) also that entry of every row in x's dtype (chx_moments_entry: the same two
     launches) -> (moments, entries)."""
     lib = _lib.lib()
-    if B > MAX_GRID_ROWS:
+    if B > MAX_GRID_ROWS and N > 2048:     # (short rows: one wave per row, the rows are blockIdx.x)
         # more vector rows than one launch takes (the batch index is a grid dimension of 65 535): row slices, one call each
         outs = []
         for b0 in range(0, B, MAX_GRID_ROWS):

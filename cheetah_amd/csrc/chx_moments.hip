@@ -714,6 +714,88 @@ __global__ __launch_bounds__(CHX_BLOCK) void moments_onepass_kernel(const T* __r
     }
 }
 
+// Many SHORT rows (a vectorised beam: 4096 beams of 1000 particles): one WAVE per batch row does the whole of chx_moments — the
+// sweep (rows lane, lane + 64, ...; four in flight per lane), the wave-wide sums and the finalize arithmetic of
+// moments_reduce_finalize_kernel on lanes 0..28 — in one launch without partial sums. The workgroup form above holds 29
+// accumulators and eight rows per lane (~200 VGPRs: two workgroups per CU) and needs eight rounds of workgroups plus a second
+// launch for 4096 rows: 47 + 6 us against ~10 us here. Same statistics, the fp64 sums in another order.
+constexpr int kRowWaveUnroll = 4;
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void moments_rows_wave_kernel(const T* __restrict__ x, const T* __restrict__ w, int64_t B,
+                                                                     int64_t Bx, int64_t Bw, int64_t N, double* __restrict__ out,
+                                                                     int entry, int entry_sqrt, T* __restrict__ entry_out) {
+    constexpr int U = kRowWaveUnroll;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (CHX_BLOCK / 64) + (threadIdx.x >> 6);
+    if (b >= B) return;                                    // (whole waves: nothing below synchronises the workgroup)
+    const T* __restrict__ xb = x + ((Bx == 1) ? 0 : b) * N * 7;
+    const T* __restrict__ wb = w ? w + ((Bw == 1) ? 0 : b) * N : nullptr;
+    OnePassFn f;
+    double acc[kTM];
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) acc[k] = 0.0;
+    bool have_c = false;
+    for (int64_t nb = 0; nb < N; nb += U * 64) {
+        T r[U][7];
+        double wv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t nn = nb + lane + u * 64;
+            ok[u] = nn < N;
+            const int64_t src = ok[u] ? nn : nb;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) r[u][j] = xb[src * 7 + j];
+            wv[u] = wb ? (double)wb[src] : 1.0;
+        }
+        if (!have_c) {
+            first_wave_centre<T>(xb, wb, N, f.c);
+            have_c = true;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            double xv[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xv[j] = (double)r[u][j];
+            f.accumulate(xv, wv[u], nb + lane + u * 64, acc);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTM; ++k) acc[k] = chx_wave_sum(acc[k]);
+    if (lane < kTM) {
+        // lane k forms out[b][k] (the arithmetic of moments_reduce_finalize_kernel); operands picked without indexing registers
+        const int k = lane;
+        int i = 0, j = 0;
+        if (k >= 8) {
+            int rem = k - 8;
+            while (rem >= 6 - i) { rem -= 6 - i; ++i; }
+            j = i + rem;
+        }
+        double tk = 0.0, si = 0.0, sj = 0.0, ck = 0.0;
+#pragma unroll
+        for (int q = 0; q < kTM; ++q)
+            if (q == k) tk = acc[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (q == i) si = acc[2 + q];
+            if (q == j) sj = acc[2 + q];
+            if (q == k - 2) ck = f.c[q];
+        }
+        const double W = acc[0], W2 = acc[1];
+        double v;
+        if (k == 0) v = W;
+        else if (k == 1) v = W2;
+        else if (k < 8) v = ck + tk / W;
+        else {
+            const double mi = si / W, mj = sj / W;
+            v = (tk - W * mi * mj) / (W - W2 / W);
+        }
+        out[b * CHX_MOM_NOUT + k] = v;
+        if (k == entry) entry_out[b] = (T)(entry_sqrt ? sqrt(v) : v);
+    }
+}
+
 // One workgroup per batch row: lane t holds partial block t of all 29 sums (partials[b][k][blk]: coalesced loads, all in
 // flight at once), DPP row sums, one LDS exchange of the 64 row sums, then lanes 0..28 add them in a fixed order and lane 0
 // re-centres and normalises -> out[b][29]. Replaces reduce_partials x2 + finalize of the two-pass path.
@@ -1085,6 +1167,20 @@ extern "C" int chx_moments_entry(const void* x, const void* w, int64_t B, int64_
     const size_t need = partials_bytes(B, N);
     const size_t tail = (size_t)B * (CHX_MOM_NSUMS + CHX_MOM_NM2) * sizeof(double);
     if (!workspace || workspace_bytes < need + tail) return CHX_ERR_WORKSPACE;
+    hipStream_t s0 = (hipStream_t)stream;
+    if (B >= 64 && N <= 2048 && x && (dtype == CHX_F32 || dtype == CHX_F64) && chx_bcast_ok(Bx, B) && chx_bcast_ok(w ? Bw : 1, B) &&
+        B <= 0x7fffffffLL) {
+        // many short rows: one wave per row, one launch (and no 65 535-row limit: the rows are blockIdx.x)
+        const unsigned grid = (unsigned)((B + CHX_BLOCK / 64 - 1) / (CHX_BLOCK / 64));
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(moments_rows_wave_kernel<float>, dim3(grid), dim3(CHX_BLOCK), 0, s0, (const float*)x, (const float*)w, B, Bx,
+                               w ? Bw : 1, N, out, index, take_sqrt, (float*)entry_out);
+        else
+            hipLaunchKernelGGL(moments_rows_wave_kernel<double>, dim3(grid), dim3(CHX_BLOCK), 0, s0, (const double*)x, (const double*)w, B,
+                               Bx, w ? Bw : 1, N, out, index, take_sqrt, (double*)entry_out);
+        CHX_CHECK_LAUNCH();
+        return CHX_OK;
+    }
     int st = check_red(x, B, Bx, w ? Bw : 1, N, dtype);
     if (st != CHX_OK) return st;
     if (!w) Bw = 1;
