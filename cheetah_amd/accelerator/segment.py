@@ -324,6 +324,9 @@ class _LatticePlan:
                 count += 1
                 continue
             if kind == "run":
+                if Segment._identity_run(item):
+                    count += 1          # Markers / inactive diagnostics between two monitors: nothing to apply, no length
+                    continue
                 fr = item.fast
                 if fr is None or fr.dtype != dtype or fr.device != device:
                     fr = item.fast = _FastRun(item, dtype, device)
@@ -361,7 +364,7 @@ class _LatticePlan:
         self.bpms, self.apertures = tuple(bpms), tuple(apertures)
         if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
-        n_items, n_elems, n_ptrs = count, len(elem_kind), len(ptrs)
+        n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
         state_bytes = lib.chx_lattice_state_bytes(n_items, n_elems)
         if state_bytes == 0:
             return
