@@ -696,3 +696,46 @@ def test_run_with_elements_no_device_plan_takes_goes_through_in_pieces(ca):
         els[5].angle.add_(h); up = float(seg.track(beam).mu_x.sum())
         els[5].angle.sub_(2 * h); dn = float(seg.track(beam).mu_x.sum())
     assert float(g) == pytest.approx((up - dn) / (2 * h), rel=2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_long_lattice_vs_reference(ca, dt):
+    """700 mergeable elements around a CustomTransferMap — more than one persistent device plan takes: the run's map is composed
+    from its pieces — against the REFERENCE's own float64 run (tests/golden/long_lattice.npz, generator
+    tests/golden/generate_golden_long_lattice.py; segment.py:534-574): ParticleBeam, ParameterBeam, three beams in one ParticleBeam.
+    Measured on the MI355X, relative to a coordinate's scale: float64 particles 8.8e-15, ParameterBeam 2.6e-14, three beams 7.3e-15;
+    float32 1.2e-6 / 2.7e-6 / 1.2e-6 — bounds = 4 x those."""
+    import json
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "long_lattice.npz"))
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda a: torch.tensor(np.asarray(a), **fk)  # noqa: E731
+    els = []
+    for kind, kw in json.loads(str(g["spec"])):
+        args = {k: (torch.tensor(v, **fk) if isinstance(v, (float, list)) else v) for k, v in kw.items()}
+        els.append(getattr(ca, kind)(**args, **fk))
+    seg = ca.Segment(els)
+    beam = ca.ParticleBeam(t(g["in"]), t(g["energy"]), **fk)
+    with torch.no_grad():
+        out = seg.track(beam)
+        run = seg._plan()[0][1]
+        assert len(seg._plan()) == 1 and run.parts and len(run.parts[0]) >= 6       # pieces around the CustomTransferMap
+        pout = seg.track(ca.ParameterBeam(t(g["pb_mu_in"]), t(g["pb_cov_in"]), t(g["energy"]), **fk))
+        parts = t(g["in"]).unsqueeze(0) * torch.tensor([0.5, 1.0, 1.5], **fk).reshape(3, 1, 1)
+        parts[..., 6] = 1.0
+        many = seg.track(ca.ParticleBeam(parts.contiguous(), t(g["energy"]), **fk))
+    tol = 3.6e-14 if dt == torch.float64 else 5e-6
+    ref = g["out"]
+    err = (np.abs(out.particles.double().cpu().numpy() - ref).max(axis=0) / np.abs(ref).max(axis=0)).max()
+    assert err < tol, err
+    assert float(out.s) == pytest.approx(float(g["s_out"]), rel=1e-12 if dt == torch.float64 else 2e-6)
+    e_mu = np.abs(pout.mu.double().cpu().numpy() - g["pb_mu"]).max() / np.abs(g["pb_mu"][:6]).max()
+    e_cov = np.abs(pout.cov.double().cpu().numpy() - g["pb_cov"]).max() / np.abs(g["pb_cov"]).max()
+    assert max(e_mu, e_cov) < 3 * tol, (e_mu, e_cov)
+    mref = g["many_out"]
+    merr = (np.abs(many.particles.double().cpu().numpy() - mref).max(axis=(0, 1)) / np.abs(mref).max(axis=(0, 1))).max()
+    assert merr < tol, merr
+    print(f"long lattice vs reference ({dt}): particles {err:.2e}, parameter beam {max(e_mu, e_cov):.2e}, three beams {merr:.2e}")
