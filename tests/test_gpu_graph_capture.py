@@ -189,3 +189,48 @@ def test_a_stretch_of_non_linear_elements_and_linear_runs_is_capturable(method):
     for x, y in zip(b, c):
         assert torch.equal(x, y)
     assert not torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("beam_kind", ["particles", "parameters"])
+def test_a_lattice_with_monitors_apertures_and_cavities_replays_from_a_graph(beam_kind):
+    """The diagnostics stretch (chx_lattice_track_diag / chx_parameter_lattice_track) inside a captured step: the replay equals the
+    eager step, follows correctors written in place, and the monitors' reading tensors are the capture's static tensors."""
+    import torch
+
+    import cheetah_amd as ca
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    els, bpms, cors = [], [], []
+    for i in range(6):
+        bpm = ca.BPM(is_active=True, **kw)
+        cor = ca.HorizontalCorrector(t(0.05), angle=t(1e-5 * i), **kw)
+        bpms.append(bpm)
+        cors.append(cor)
+        els += [ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw), cor, ca.Drift(t(0.5), **kw), bpm]
+        if i == 2 and beam_kind == "particles":
+            els += [ca.Aperture(x_max=t(8e-4), y_max=t(8e-4), **kw)]
+        if i % 3 == 1:
+            els += [ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw)]
+    seg = ca.Segment(els)
+    if beam_kind == "particles":
+        beam = ca.ParticleBeam.from_parameters(num_particles=10_000, energy=t(6e7), sigma_x=t(3e-4), **kw)
+        state = lambda b: b.particles  # noqa: E731
+    else:
+        beam = ca.ParameterBeam.from_parameters(energy=t(6e7), sigma_x=t(3e-4), **kw)
+        state = lambda b: b.mu  # noqa: E731
+
+    def step():
+        out = seg.track(beam)
+        return torch.cat([state(out).reshape(-1)[:70], torch.stack([b.reading for b in bpms]).reshape(-1)])
+
+    with torch.no_grad():
+        eager = step().clone()
+        captured = ca.graph.capture(step)
+        assert torch.equal(captured().clone(), eager)
+        for c in cors:
+            c.angle.mul_(-3.0).add_(2e-5)
+        replayed = captured().clone()
+        now = step().clone()
+        assert torch.equal(replayed, now) and not torch.equal(replayed, eager)
