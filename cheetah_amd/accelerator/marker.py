@@ -68,7 +68,14 @@ class BPM(Marker):
             # have every persistent run plan of the lattice re-validate on its next use (25 active BPMs in a 100-element lattice:
             # 92 us per BPM and track)
             p = getattr(incoming, "particles", None)
-            if p is not None and not (torch.is_grad_enabled() and (p.requires_grad or incoming.survival_probabilities.requires_grad)):
+            from .. import sharding
+
+            group = sharding.active_group() if p is not None else None
+            if group is not None:
+                # the beam's particles are spread over the ranks of a process group (sharding.particle_sharded): the monitor reads
+                # the mean of ALL of them — this rank's one-pass moments, one all-gather of 29 doubles, the exact merge
+                xy = sharding.global_moments(incoming, group)[..., 2:5:2].to(p.dtype)
+            elif p is not None and not (torch.is_grad_enabled() and (p.requires_grad or incoming.survival_probabilities.requires_grad)):
                 # entries 2 and 4 of the moment vector = (mu_x, mu_y): one strided view, one cast, one subtraction
                 xy = incoming._moments()[..., 2:5:2].to(p.dtype)
             else:

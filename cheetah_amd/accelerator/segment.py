@@ -963,6 +963,11 @@ class Segment(Element):
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         _ops.check_current_device(lp.device)
         on_device = s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device and not s_in.requires_grad
+        if lp.bpms:
+            from .. import sharding
+
+            if sharding.active_group() is not None:
+                return None            # a particle-sharded beam: the monitors read GLOBAL means (BPM._track_internal exchanges them)
         w_out = incoming.survival_probabilities
         lead, N = tuple(p.shape[:-2]), p.shape[-2]
         B = 1

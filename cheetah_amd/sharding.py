@@ -52,7 +52,8 @@ def particle_sharded(group=None, force_collectives=None):
     """Inside this context every rank of `group` holds a SLICE of the particles of one beam. Elements whose physics couples
     the particles exchange what they need: a `SpaceChargeKick` takes its grid from the global beam moments (one
     all-gather of 29 doubles per rank) and sums the deposited charge over the ranks (one all-reduce of the g^3 grid), a
-    `Screen` sums its image. Linear maps, cavities and apertures need nothing. `force_collectives` (default: the
+    `Screen` sums its image, an active `BPM` reads the mean of all shards (the same 29-double all-gather). Linear maps, cavities
+    and apertures need nothing. `force_collectives` (default: the
     process-wide switch): run the exchanges even when the group has a single rank."""
     force = _FORCE[0] if force_collectives is None else bool(force_collectives)
     _ACTIVE_GROUP.append((group if group is not None else (dist.group.WORLD if dist.is_initialized() else None), force))

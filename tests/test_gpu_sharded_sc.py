@@ -118,3 +118,71 @@ def test_merge_moments_kernel_equals_tensor_formula():
     out = torch.empty((B, 29), dtype=torch.float64, device="cuda")
     _ops.check(_lib.lib().chx_merge_moments(per_rank.data_ptr(), R, B, out.data_ptr(), _ops.stream_ptr()), "chx_merge_moments")
     assert torch.allclose(out, ref, rtol=1e-12, atol=1e-300)
+
+
+def _bpm_worker(rank, world, port, x, w, queue):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cheetah_amd as ca
+    from cheetah_amd import sharding
+
+    lo, hi = sharding.shard_range(x.shape[0], rank, world)
+    seg, bpms = _bpm_lattice(ca)
+    beam = ca.ParticleBeam(x[lo:hi].to("cuda"), torch.tensor(1e8, device="cuda"), survival_probabilities=w[lo:hi].to("cuda"), device="cuda",
+                           dtype=torch.float32)
+    with sharding.particle_sharded(), torch.no_grad():
+        out = seg.track(beam)
+    queue.put((rank, out.particles.cpu().numpy(), torch.stack([b.reading for b in bpms]).cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _bpm_lattice(ca):
+    kw = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    els, bpms = [], []
+    for i in range(5):
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -1e-5]), **kw)
+        bpms.append(bpm)
+        els += [ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw), ca.Drift(t(0.5), **kw),
+                ca.Aperture(x_max=t(1.5e-3), y_max=t(1.5e-3), **kw), bpm]
+    return ca.Segment(els), bpms
+
+
+def test_particle_sharded_bpms_read_the_means_of_all_shards():
+    """Two ranks hold the halves of one beam: inside sharding.particle_sharded an active BPM reads the GLOBAL weighted means (this
+    rank's one-pass moments, the 29-double all-gather, the exact merge) — the single-process readings, to rounding — while the
+    particles of each half are tracked as before."""
+    import cheetah_amd as ca
+
+    torch.manual_seed(21)
+    N = 40_001
+    x = torch.randn(N, 7) * torch.tensor([5e-4, 2e-5, 4e-4, 3e-5, 2e-5, 1e-3, 0.0])
+    x[:, 0] += 2e-4
+    x[:, 6] = 1.0
+    w = torch.rand(N)
+    seg, bpms = _bpm_lattice(ca)
+    with torch.no_grad():
+        whole = seg.track(ca.ParticleBeam(x.to("cuda"), torch.tensor(1e8, device="cuda"), survival_probabilities=w.to("cuda"), device="cuda",
+                                          dtype=torch.float32))
+    want = torch.stack([b.reading for b in bpms]).cpu().numpy()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bpm_worker, args=(r, 2, port, x, w, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in range(2):
+        rank, parts, readings = queue.get(timeout=180)
+        results[rank] = (parts, readings)
+    for p in procs:
+        p.join(timeout=60)
+    import numpy as np
+
+    union = np.concatenate([results[0][0], results[1][0]])
+    assert np.array_equal(union, whole.particles.cpu().numpy())
+    for r in (0, 1):
+        assert np.allclose(results[r][1], want, rtol=2e-6, atol=2e-10), np.abs(results[r][1] - want).max()
+    assert np.array_equal(results[0][1], results[1][1])                 # every rank holds the same global readings
+    assert np.abs(want[:, 0]).min() > 1e-5
