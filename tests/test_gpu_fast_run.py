@@ -739,3 +739,23 @@ def test_long_lattice_vs_reference(ca, dt):
     merr = (np.abs(many.particles.double().cpu().numpy() - mref).max(axis=(0, 1)) / np.abs(mref).max(axis=(0, 1))).max()
     assert merr < tol, merr
     print(f"long lattice vs reference ({dt}): particles {err:.2e}, parameter beam {max(e_mu, e_cov):.2e}, three beams {merr:.2e}")
+
+
+def test_settings_that_are_views_of_one_tensor(ca):
+    """Several magnets' settings as 0-dim views of ONE tensor (a control loop writes them all with one `copy_`): the device plan
+    holds their addresses and follows the write."""
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    settings = torch.tensor([3.0, -3.0, 1e-4], **kw)
+    seg = ca.Segment([ca.Quadrupole(t(0.2), k1=settings[0], **kw), ca.Drift(t(0.5), **kw), ca.Quadrupole(t(0.2), k1=settings[1], **kw),
+                      ca.HorizontalCorrector(t(0.05), angle=settings[2], **kw), ca.Drift(t(0.5), **kw)])
+    beam = ca.ParticleBeam.from_parameters(num_particles=4_000, **kw)
+    with torch.no_grad():
+        a = seg.track(beam).particles.clone()
+        assert seg._plan()[0][1].fast.ok
+        assert torch.equal(a, general_path(ca, seg, beam))
+        epoch = ca.Element._epoch
+        settings.copy_(torch.tensor([1.5, -2.0, -3e-4], **kw))
+        b = seg.track(beam).particles
+        assert ca.Element._epoch == epoch and not torch.equal(a, b) and torch.equal(b, general_path(ca, seg, beam))
