@@ -631,7 +631,9 @@ class Segment(Element):
         if cacheable and run.tm is not None:
             return run.tm
         tm = None
-        if cacheable or not species.mass_eV.requires_grad:
+        if not (torch.is_grad_enabled() and (energy.requires_grad or species.mass_eV.requires_grad)):
+            tm = Segment._run_map_vector(run, energy, species)
+        if tm is None and (cacheable or not species.mass_eV.requires_grad):
             # all-scalar runs (the usual control loop, and gradient-based tuning of scalar settings): every element's map and
             # their product in two C calls — with gradients ONE autograd node for the run (_ops.RunMapScalars)
             tm = _ops.build_compose_scalars(run.elements, energy, species.mass_eV_float, species.num_elementary_charges_float)
@@ -642,6 +644,59 @@ class Segment(Element):
         if cacheable and not tm.requires_grad:
             run.tm = tm
         return tm
+
+    @staticmethod
+    def _run_map_vector(run: _Run, energy, species):
+        """The composed maps (*shape, 7, 7) of a run whose settings are vectorised over a batch of lattice settings — some
+        parameters tensors of ONE common shape, the others scalars; scalar energy and lengths — by one launch
+        (`chx_run_map_batched`: a workgroup per batch row builds and composes the row's maps), or None when the run does not
+        qualify (no vectorised setting at all, mixed shapes, gradients, a vectorised length or vector component). The general
+        path builds every vectorised element's maps on its own: ~100 us of host time per element and step, whatever the batch."""
+        if energy.dim() != 0 or not energy.is_cuda or len(run.elements) > 192:
+            return None
+        dtype, device = energy.dtype, energy.device
+        grad = torch.is_grad_enabled()
+        kinds, ptrs, flags, keep, shape = [], [], [], [], None
+        for e in run.elements:
+            kind = getattr(e, "_chx_kind", None)
+            if kind is None or not e._static_skippable or e._parameters:
+                return None
+            if kind == _IDENTITY:
+                continue
+            row, fl = [None] * _ops.MAX_PARAMS, [0] * _ops.MAX_PARAMS
+            for k, (t, index) in enumerate(e._builder_scalar_refs()):
+                if t.dtype != dtype or t.device != device or (grad and t.requires_grad):
+                    return None
+                if index is not None:                      # a component of a vector-valued setting (misalignment[..., i])
+                    if t.dim() != 1 or not t.is_contiguous():
+                        return None
+                    row[k] = t.data_ptr() + index * t.element_size()
+                elif t.dim() == 0:
+                    row[k] = t.data_ptr()
+                else:
+                    if k == 0 or not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
+                        return None
+                    shape = tuple(t.shape)
+                    row[k], fl[k] = t.data_ptr(), 1
+                keep.append(t)
+            kinds.append(kind)
+            ptrs += row
+            flags += fl
+        E = len(kinds)
+        if shape is None or E == 0:
+            return None
+        B = _ops.numel(shape)
+        lib = _lib.lib()
+        code = _ops.dtype_code(dtype)
+        ws_bytes = lib.chx_run_map_batched_workspace_bytes(E, B, code)
+        ws = _ops.workspace(ws_bytes, device) if ws_bytes else None
+        R = torch.empty((*shape, 7, 7), dtype=dtype, device=device)
+        _ops.check(lib.chx_run_map_batched((ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs),
+                                           (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), E, B, energy.data_ptr(),
+                                           species.mass_eV_float, species.num_elementary_charges_float, code,
+                                           ws.data_ptr() if ws is not None else None, ws_bytes, R.data_ptr(), _ops.stream_ptr()),
+                   "chx_run_map_batched")
+        return R
 
     @staticmethod
     def _run_stack(run: _Run, energy, species) -> torch.Tensor:

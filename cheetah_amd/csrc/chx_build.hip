@@ -1589,6 +1589,79 @@ extern "C" int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, 
     return CHX_OK;
 }
 
+// ---- a run whose settings are VECTORISED over B lattice settings (a k1 scan, a batched environment, an orbit-response measurement:
+// some parameters are (B,) tensors, the others scalars; the energy and every length scalar): all B composed maps in ONE launch — a
+// workgroup per batch row builds the row's element maps (fp64 inside, rounded to T like chx_build_rmatrix) and composes them with
+// the association of chx_compose_maps: bit-identical to the per-element builds + chx_compose_maps of the general path, which cost
+// ~100 us of host time per vectorised element and step. A pointer with its lowest bit set addresses a (B,) array (element b of
+// it belongs to row b), any other a scalar. No stored state: such settings change with every step.
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void run_map_batched_kernel(RunArgs a, int E, const T* __restrict__ energy, double mass,
+                                                                   double nq, T* __restrict__ maps_ws, T* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char run_lds[];
+    const int64_t b = blockIdx.x;
+    T* maps = maps_ws ? maps_ws + b * E * 49 : reinterpret_cast<T*>(run_lds);
+    for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
+        const int kind = a.kind[e];
+        const int P = kind_num_params(kind);
+        double p[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) {
+            const uintptr_t q = reinterpret_cast<uintptr_t>(a.ptr[a.off[e] + k]);
+            const T* base = reinterpret_cast<const T*>(q & ~(uintptr_t)1);
+            p[k] = (double)((q & 1) ? base[b] : base[0]);
+        }
+        Mat7<double> M;
+        build_kind<double>(kind, p, (double)energy[0], mass, nq, M);
+        for (int q = 0; q < 49; ++q) maps[e * 49 + q] = (T)M.m[q];
+    }
+    __syncthreads();
+    T* Rb = R + b * 49;
+    if (E == 1) {
+        if (threadIdx.x < 49) Rb[threadIdx.x] = maps[threadIdx.x];
+        return;
+    }
+    compose_block<T>([&](int e) { return (const T*)maps + e * 49; }, E, 0, Rb);
+}
+
+extern "C" size_t chx_run_map_batched_workspace_bytes(int64_t E, int64_t B, int dtype) {
+    if (E < 1 || E > kRunMaxE || B < 1) return 0;
+    const size_t per_row = (size_t)E * 49 * (dtype == CHX_F32 ? 4 : 8);
+    return per_row <= 48 * 1024 ? 0 : per_row * (size_t)B;     // rows whose element maps fit the LDS need no scratch
+}
+
+extern "C" int chx_run_map_batched(const int32_t* kinds, const void* const* param_ptrs, const uint8_t* batched, int64_t E, int64_t B,
+                                   const void* energy, double mass_eV, double n_charges, int dtype, void* workspace,
+                                   size_t workspace_bytes, void* R_out, void* stream) {
+    if (!energy || !R_out || !batched || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    RunArgs a;
+    int nptr = 0;
+    int st = run_args(kinds, param_ptrs, E, a, nptr);
+    if (st != CHX_OK) return st;
+    for (int e = 0, q = 0; e < (int)E; ++e) {
+        const int P = kind_num_params(kinds[e]);
+        for (int k = 0; k < P; ++k, ++q) {
+            if (reinterpret_cast<uintptr_t>(a.ptr[q]) & 1) return CHX_ERR_MISALIGNED;
+            if (batched[(size_t)e * CHX_MAX_PARAMS + k]) {
+                if (k == 0) return CHX_ERR_INVALID_ARG;             // (a vectorised length: the path length is per row — not here)
+                a.ptr[q] = reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(a.ptr[q]) | 1);
+            }
+        }
+    }
+    const size_t need = chx_run_map_batched_workspace_bytes(E, B, dtype);
+    if (need && (!workspace || workspace_bytes < need)) return CHX_ERR_WORKSPACE;
+    const size_t lds = need ? 0 : (size_t)E * 49 * (dtype == CHX_F32 ? 4 : 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(run_map_batched_kernel<float>, dim3((unsigned)B), dim3(CHX_BLOCK), lds, s, a, (int)E, (const float*)energy, mass_eV,
+                           n_charges, need ? (float*)workspace : (float*)nullptr, (float*)R_out);
+    else
+        hipLaunchKernelGGL(run_map_batched_kernel<double>, dim3((unsigned)B), dim3(CHX_BLOCK), lds, s, a, (int)E, (const double*)energy,
+                           mass_eV, n_charges, need ? (double*)workspace : (double*)nullptr, (double*)R_out);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 // forward of a run whose settings carry gradients, one call: element maps into maps[E][7][7] (kept for the backward pass) and
 // their product into R_out[7][7] — chx_build_rmatrix_scalars + chx_compose_maps, bit-identical to the two calls
 extern "C" int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,

@@ -128,6 +128,15 @@ int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, 
 int chx_run_vjp_masked(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                        double n_charges, int dtype, const void* maps, const void* dT, const uint16_t* need, void* dinputs,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* A merged run whose settings are VECTORISED over B lattice settings (segment.py:534-547 with (B,) parameters: a k1 scan, a batched
+ * environment, an orbit response): all B composed maps R_out[B][7][7] in one launch — per row the element maps of chx_build_rmatrix
+ * and the product of chx_compose_maps, bit-identical to those calls. batched[E][CHX_MAX_PARAMS]: 1 = the pointer addresses a
+ * contiguous (B,) array of `dtype`, 0 = a scalar; the energy and every length (parameter 0) are scalars.
+ * workspace: chx_run_map_batched_workspace_bytes(E, B, dtype) bytes (0 when a row's element maps fit the LDS). */
+size_t chx_run_map_batched_workspace_bytes(int64_t E, int64_t B, int dtype);
+int chx_run_map_batched(const int32_t* kinds, const void* const* param_ptrs, const uint8_t* batched, int64_t E, int64_t B,
+                        const void* energy, double mass_eV, double n_charges, int dtype, void* workspace, size_t workspace_bytes,
+                        void* R_out, void* stream);
 /* Forward of the same run in one call: chx_build_rmatrix_scalars into maps[E][7][7] (kept for chx_run_vjp) followed by
  * chx_compose_maps of that stack into R_out[7][7]; bit-identical to the two calls (segment.py:534-543). E <= 4096. */
 int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,

@@ -759,3 +759,57 @@ def test_settings_that_are_views_of_one_tensor(ca):
         settings.copy_(torch.tensor([1.5, -2.0, -3e-4], **kw))
         b = seg.track(beam).particles
         assert ca.Element._epoch == epoch and not torch.equal(a, b) and torch.equal(b, general_path(ca, seg, beam))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_vectorised_settings_of_a_run_in_one_launch(ca, dt):
+    """A run whose settings are vectorised over a batch of lattice settings (k1 scans, batched environments): the composed maps of
+    all rows from ONE launch (chx_run_map_batched) — bit for bit the per-element builds + chx_compose_maps of the general path
+    (which tests/golden/lattices_random_vectorized.npz pins against the reference); runs that do not qualify keep that path."""
+    from cheetah_amd import _ops
+    from cheetah_amd.accelerator.segment import Segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(5)
+    for shape in ((7,), (3, 2)):
+        els = [ca.Marker(**kw), ca.Drift(t(0.175), **kw), ca.Quadrupole(t(0.122), k1=torch.randn(shape, **kw) * 8, **kw), ca.Drift(t(0.428), **kw),
+               ca.Quadrupole(t(0.122), k1=t(-14.3), tilt=torch.randn(shape, **kw) * 0.05, misalignment=t([1e-4, -2e-4]), **kw),
+               ca.VerticalCorrector(t(0.02), angle=torch.randn(shape, **kw) * 1e-4, **kw),
+               ca.Dipole(t(0.3), angle=torch.randn(shape, **kw) * 0.02, dipole_e1=t(0.01), **kw), ca.Solenoid(t(0.1), k=t(0.3), **kw),
+               ca.HorizontalCorrector(t(0.02), angle=t(-1e-4), **kw), ca.Drift(t(0.45), **kw)]
+        seg = ca.Segment(els)
+        beam = ca.ParticleBeam.from_parameters(num_particles=3_000, **kw)
+        calls = []
+        orig = Segment._run_map_vector
+        Segment._run_map_vector = staticmethod(lambda run, energy, species: (calls.append(1), orig(run, energy, species))[1])
+        try:
+            with torch.no_grad():
+                out = seg.track(beam)
+        finally:
+            Segment._run_map_vector = orig
+        assert calls and out.particles.shape == (*shape, 3_000, 7)
+        maps = [e.first_order_transfer_map(beam.energy, beam.species) for e in els if e._chx_kind != _ops.KIND["identity"]]
+        tm = _ops.compose_maps(maps, shape, dt, torch.device("cuda"))
+        run = seg._plan()[0][1]
+        got = Segment._run_map_vector(run, beam.energy, beam.species)
+        assert got is not None and got.shape == (*shape, 7, 7) and torch.equal(got, tm)
+        with torch.no_grad():
+            assert torch.equal(out.particles, _ops.apply_map(beam.particles, tm))
+        # a ParameterBeam takes the same maps
+        pb = ca.ParameterBeam.from_parameters(**kw)
+        with torch.no_grad():
+            pout = seg.track(pb)
+            mu, cov = _ops.parameter_track(pb.mu, pb.cov, tm)
+        assert torch.equal(pout.mu, mu) and torch.equal(pout.cov, cov)
+    # what does not qualify: a vectorised length, two different batch shapes, a setting that requires grad
+    assert Segment._run_map_vector(ca.Segment([ca.Drift(torch.tensor([0.1, 0.2], **kw), **kw), ca.Quadrupole(t(0.1), k1=t(1.0), **kw)])._plan()[0][1],
+                                   beam.energy, beam.species) is None
+    mixed = ca.Segment([ca.Quadrupole(t(0.1), k1=torch.randn(3, **kw), **kw), ca.Quadrupole(t(0.1), k1=torch.randn(3, 1, **kw), **kw)])
+    assert Segment._run_map_vector(mixed._plan()[0][1], beam.energy, beam.species) is None
+    with torch.no_grad():
+        assert mixed.track(beam).particles.shape == (3, 3, 3_000, 7)
+    k = torch.randn(4, **kw).requires_grad_(True)
+    gseg = ca.Segment([ca.Quadrupole(t(0.1), k1=k, **kw), ca.Drift(t(0.5), **kw)])
+    gseg.track(beam).sigma_x.sum().backward()
+    assert k.grad is not None and torch.isfinite(k.grad).all()
