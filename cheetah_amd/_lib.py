@@ -151,9 +151,14 @@ SIGNATURES = {
     "chx_lattice_track_diag": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                        c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
+    "chx_lattice_state_bytes_batched": (c_size_t, [c_i64, c_i64, c_i64]),
+    "chx_lattice_prepare_batched": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chx_lattice_prepare_rows": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_double, c_double, c_int, c_void_p,
+                                         c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_parameter_lattice_track": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t,
-                                            c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_i64, c_void_p, c_void_p]),
+                                            c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_i64, c_void_p, c_void_p]),
     "chx_copy_arrays": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int32, c_void_p]),
     "chx_to_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "chx_from_xyz_pxpypz": (c_int, [c_void_p, c_void_p, c_double, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]),

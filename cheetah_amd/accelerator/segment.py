@@ -272,15 +272,17 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec")
 
-    def __init__(self, items, dtype, device):
+    def __init__(self, items, dtype, device, allow_vector=False):
         self.items, self.dtype, self.device = items, dtype, device
+        self.allow_vector = allow_vector       # a ParameterBeam's stretch takes runs with vectorised settings; particles end there
         self.code = _ops.dtype_code(dtype)
         self.table = self.state = self.capsule = None
         self.tensors = ()
         self.bpms = ()          # the active BPMs of the stretch, in reading-slot order
         self.apertures = ()     # its active apertures
+        self.vshape = None      # batch shape of vectorised settings inside the stretch (a ParameterBeam's stretch takes them)
         self.count = 0          # leading items the table covers (the stretch ends in front of the first item it cannot take)
         self.refresh()
 
@@ -292,7 +294,8 @@ class _LatticePlan:
         lib = _lib.lib()
         dtype, device = self.dtype, self.device
         rows, elem_kind, elem_poff, ptrs, tensors, bpms, apertures = [], [], [], [], [], [], []
-        count = cavities = 0
+        count = cavities = longest_run = 0
+        vshape, bpm_vec = None, []
         for kind, item in self.items:
             if kind != "run" and item._is_aperture:
                 # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
@@ -321,6 +324,7 @@ class _LatticePlan:
                 ptrs.append(mis.data_ptr())
                 tensors.append(mis)
                 bpms.append(item)
+                bpm_vec.append(vshape is not None)     # does a run with vectorised settings sit in front of this monitor?
                 count += 1
                 continue
             if kind == "run":
@@ -332,20 +336,34 @@ class _LatticePlan:
                     fr = item.fast = _FastRun(item, dtype, device)
                 elif fr.epoch != Element._epoch:
                     fr.refresh()
-                if not fr.ok:
+                if fr.ok:
+                    run_kinds = [fr.kinds[e] for e in range(fr.E)]
+                    row_ptrs = []
+                    for e in range(fr.E):
+                        base = e * _ops.MAX_PARAMS
+                        row_ptrs.append([fr.ptrs[base + j] for j in range(lib.chx_kind_num_params(fr.kinds[e]))])
+                    run_tensors = fr.tensors
+                else:
+                    # settings vectorised over a batch of lattice settings: addresses tagged with their lowest bit (a (rows,) array);
+                    # one batch shape for the whole stretch
+                    got = Segment._vector_run_rows(item, dtype, device) if self.allow_vector else None
+                    # (one workgroup per item and row prepares the maps: beyond a few hundred rows the walk item by item is cheaper)
+                    if got is None or got[4] is None or (vshape is not None and got[4] != vshape) or len(got[0]) > 192 \
+                            or _ops.numel(got[4]) > 65535:
+                        break
+                    run_kinds, vrows, vflags, run_tensors, vshape = got
+                    if any(len(r) != lib.chx_kind_num_params(k) for r, k in zip(vrows, run_kinds)):
+                        break
+                    row_ptrs = [[q | f for q, f in zip(r, fl)] for r, fl in zip(vrows, vflags)]
+                if not run_kinds or any(q is None for r in row_ptrs for q in r):
                     break
-                row_ptrs = []
-                for e in range(fr.E):
-                    base = e * _ops.MAX_PARAMS
-                    row_ptrs.append([fr.ptrs[base + j] for j in range(lib.chx_kind_num_params(fr.kinds[e]))])
-                if any(q is None for r in row_ptrs for q in r):
-                    break
-                rows += [0, fr.E, len(elem_kind), 0]
+                longest_run = max(longest_run, len(run_kinds))
+                rows += [0, len(run_kinds), len(elem_kind), 0]
                 for e, r in enumerate(row_ptrs):
-                    elem_kind.append(fr.kinds[e])
+                    elem_kind.append(run_kinds[e])
                     elem_poff.append(len(ptrs))
                     ptrs += r
-                tensors += fr.tensors
+                tensors += run_tensors
             else:
                 if type(item).track is not Cavity.track or item._parameters:
                     break
@@ -361,11 +379,17 @@ class _LatticePlan:
             count += 1
         # (a trailing run stays in the stretch: it rides in the same particle pass; a trailing BPM reads the outgoing beam)
         self.count = count
-        self.bpms, self.apertures = tuple(bpms), tuple(apertures)
+        self.bpms, self.apertures, self.bpm_vec = tuple(bpms), tuple(apertures), tuple(bpm_vec)
         if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
-        state_bytes = lib.chx_lattice_state_bytes(n_items, n_elems)
+        self.vshape = vshape
+        # a wave per (item, row) prepares a stretch without cavities and with short runs; else a workgroup does, which pays up to a
+        # few hundred rows of vectorised settings only
+        self.small_runs = 1 if (cavities == 0 and longest_run <= 64) else 0
+        if vshape is not None and not self.small_runs and _ops.numel(vshape) > Segment._STRETCH_MAX_ROWS:
+            return
+        state_bytes = lib.chx_lattice_state_bytes_batched(n_items, n_elems, _ops.numel(vshape) if vshape is not None else 1)
         if state_bytes == 0:
             return
         # host -> device without a synchronisation: page-locked staging buffer (torch's caching host allocator keeps it alive
@@ -646,6 +670,43 @@ class Segment(Element):
         return tm
 
     @staticmethod
+    def _vector_run_rows(run: _Run, dtype, device):
+        """(kinds, per-element setting addresses, per-element flags (1 = a tensor of the common batch shape), tensors, batch shape) of
+        a run whose elements all have a device builder and settings that are device scalars or contiguous tensors of ONE shape — or
+        None (a vectorised length, mixed shapes, another dtype / device, gradients, trainable parameters)."""
+        grad = torch.is_grad_enabled()
+        kinds, rows, flags, keep, shape = [], [], [], [], None
+        for e in run.elements:
+            kind = getattr(e, "_chx_kind", None)
+            if kind is None or not e._static_skippable or e._parameters:
+                return None
+            if kind == _IDENTITY:
+                continue
+            row, fl = [], []
+            for k, (t, index) in enumerate(e._builder_scalar_refs()):
+                if t.dtype != dtype or t.device != device or (grad and t.requires_grad):
+                    return None
+                if index is not None:                      # a component of a vector-valued setting (misalignment[..., i])
+                    if t.dim() != 1 or not t.is_contiguous():
+                        return None
+                    row.append(t.data_ptr() + index * t.element_size())
+                    fl.append(0)
+                elif t.dim() == 0:
+                    row.append(t.data_ptr())
+                    fl.append(0)
+                else:
+                    if k == 0 or not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
+                        return None
+                    shape = tuple(t.shape)
+                    row.append(t.data_ptr())
+                    fl.append(1)
+                keep.append(t)
+            kinds.append(kind)
+            rows.append(row)
+            flags.append(fl)
+        return kinds, rows, flags, keep, shape
+
+    @staticmethod
     def _run_map_vector(run: _Run, energy, species):
         """The composed maps (*shape, 7, 7) of a run whose settings are vectorised over a batch of lattice settings — some
         parameters tensors of ONE common shape, the others scalars; scalar energy and lengths — by one launch
@@ -654,34 +715,15 @@ class Segment(Element):
         path builds every vectorised element's maps on its own: ~100 us of host time per element and step, whatever the batch."""
         if energy.dim() != 0 or not energy.is_cuda or len(run.elements) > 192:
             return None
+        got = Segment._vector_run_rows(run, energy.dtype, energy.device)
+        if got is None:
+            return None
+        kinds, rows, row_flags, keep, shape = got
         dtype, device = energy.dtype, energy.device
-        grad = torch.is_grad_enabled()
-        kinds, ptrs, flags, keep, shape = [], [], [], [], None
-        for e in run.elements:
-            kind = getattr(e, "_chx_kind", None)
-            if kind is None or not e._static_skippable or e._parameters:
-                return None
-            if kind == _IDENTITY:
-                continue
-            row, fl = [None] * _ops.MAX_PARAMS, [0] * _ops.MAX_PARAMS
-            for k, (t, index) in enumerate(e._builder_scalar_refs()):
-                if t.dtype != dtype or t.device != device or (grad and t.requires_grad):
-                    return None
-                if index is not None:                      # a component of a vector-valued setting (misalignment[..., i])
-                    if t.dim() != 1 or not t.is_contiguous():
-                        return None
-                    row[k] = t.data_ptr() + index * t.element_size()
-                elif t.dim() == 0:
-                    row[k] = t.data_ptr()
-                else:
-                    if k == 0 or not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
-                        return None
-                    shape = tuple(t.shape)
-                    row[k], fl[k] = t.data_ptr(), 1
-                keep.append(t)
-            kinds.append(kind)
-            ptrs += row
-            flags += fl
+        ptrs, flags = [], []
+        for r, f in zip(rows, row_flags):
+            ptrs += r + [None] * (_ops.MAX_PARAMS - len(r))
+            flags += f + [0] * (_ops.MAX_PARAMS - len(f))
         E = len(kinds)
         if shape is None or E == 0:
             return None
@@ -790,6 +832,12 @@ class Segment(Element):
         if s_in.dim() == 0 and s_in.dtype == fr.dtype and s_in.device == fr.device and not s_in.requires_grad:
             return torch.empty_like(s_in)
         return None
+
+    #: rows of vectorised lattice settings a ParameterBeam's stretch call takes when a WORKGROUP per (item, row) prepares the maps
+    #: (cavities, or runs of more than 64 elements; above: the walk item by item, whose cost does not depend on the rows —
+    #: benchmarks/response_matrix_probe.py: 64 rows 1.4 -> 0.14 ms, 4096 rows 1.4 -> 6.4 ms). Without cavities and with short runs a
+    #: wave per (item, row) does and any number of rows up to 65 535 goes
+    _STRETCH_MAX_ROWS = 512
 
     #: a persistent device plan (`_FastRun`) holds at most 192 elements and 400 setting tensors; a longer run is cut into pieces
     _PART_ELEMENTS = 128
@@ -1010,7 +1058,7 @@ class Segment(Element):
                 lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device)
             else:
                 lp.refresh()
-        if not lp.ok:
+        if not lp.ok or lp.vshape is not None:       # (vectorised settings: the ParameterBeam's stretch takes them; particles walk)
             return None
         if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
@@ -1084,7 +1132,7 @@ class Segment(Element):
         cache = self.__dict__.get("_lattice_cache")
         if cache is None or cache[0] is not plan:
             cache = self.__dict__["_lattice_cache"] = (plan, {})
-        key = (i, mu.dtype, mu.device)
+        key = (i, mu.dtype, mu.device, "moments")
         entry = cache[1].get(key)
         if entry is None:
             j, special = i, 0
@@ -1102,7 +1150,7 @@ class Segment(Element):
             if torch.cuda.is_current_stream_capturing():
                 return None
             if lp is None:
-                lp = entry[1] = _LatticePlan(plan[i:entry[0]], mu.dtype, mu.device)
+                lp = entry[1] = _LatticePlan(plan[i:entry[0]], mu.dtype, mu.device, allow_vector=True)
             else:
                 lp.refresh()
         if not lp.ok or lp.apertures:                # (an aperture only warns for a ParameterBeam: the walk does that)
@@ -1110,8 +1158,14 @@ class Segment(Element):
         if torch.is_grad_enabled() and (mu.requires_grad or cov.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
             return None
-        lead = torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2])
+        try:
+            lead = torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2], lp.vshape if lp.vshape is not None else ())
+        except RuntimeError:
+            return None
         B = _ops.numel(lead)
+        Bm = _ops.numel(lp.vshape) if lp.vshape is not None else 1
+        if Bm not in (1, B) or (Bm > 1 and tuple(lp.vshape) != tuple(lead)):
+            return None
         m2 = mu.reshape(-1, 7) if mu.is_contiguous() else mu.reshape(-1, 7).contiguous()
         c2 = cov.reshape(-1, 49) if cov.is_contiguous() else cov.reshape(-1, 49).contiguous()
         if m2.shape[0] not in (1, B) or c2.shape[0] not in (1, B):
@@ -1127,11 +1181,20 @@ class Segment(Element):
         n_items, n_elems, n_ptrs = lp.shape
         _ops.check(_lib.lib().chx_parameter_lattice_track(
             lp.table.data_ptr(), n_items, n_elems, n_ptrs, e.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float, lp.code,
-            lp.state.data_ptr(), lp.state.numel() * 8, m2.data_ptr(), c2.data_ptr(), B, m2.shape[0], c2.shape[0], mu_out.data_ptr(),
+            lp.state.data_ptr(), lp.state.numel() * 8, m2.data_ptr(), c2.data_ptr(), B, m2.shape[0], c2.shape[0], Bm, lp.small_runs,
+            mu_out.data_ptr(),
             cov_out.data_ptr(), e_out.data_ptr(), s_in.data_ptr() if on_device else None, s_out.data_ptr() if on_device else None,
             n_bpm, readings.data_ptr() if n_bpm else None, _ops.stream_ptr()), "chx_parameter_lattice_track")
+        in_lead = tuple(torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2]))
         for k, bpm in enumerate(lp.bpms):
-            bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(*lead, 2)
+            r = readings[k].reshape(*lead, 2)
+            if lp.vshape is not None and not lp.bpm_vec[k] and in_lead != tuple(lead):
+                # a monitor in FRONT of the first vectorised element sees the beam before it was spread over the lattice settings:
+                # the rows are equal there, the reading has the incoming beam's shape (like the walk's)
+                from .cavity import _narrow_to
+
+                r = _narrow_to(r, (*in_lead, 2))
+            bpm.__dict__["_buffers"]["reading"] = r
         if s_out is None:
             s_out = s_in
             for kind, item in lp.items[:lp.count]:

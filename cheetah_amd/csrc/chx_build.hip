@@ -1730,14 +1730,22 @@ constexpr int kLatticeMaxItems = 1024;
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_t* __restrict__ items, const int64_t* __restrict__ elem_kind,
                                                                    const int64_t* __restrict__ elem_poff, const int64_t* __restrict__ ptrs,
-                                                                   int n_items, const T* __restrict__ energy, double mass, double nq,
+                                                                   int n_items, int n_elems, const T* __restrict__ energy, double mass, double nq,
                                                                    double* __restrict__ Rs, double* __restrict__ coeffs,
                                                                    double* __restrict__ emaps, T* __restrict__ energy_out,
                                                                    const T* __restrict__ s_in, T* __restrict__ s_out) {
     __shared__ double e_in_sh;
     const int b = blockIdx.x;
+    // blockIdx.y = row of a batch of lattice settings (gridDim.y = 1: scalar settings): a pointer with its lowest bit set addresses
+    // a (rows,) array whose element `row` belongs to this row (chx_run_map_batched's convention), any other a scalar. The maps and
+    // coefficient rows of row r sit behind those of the rows before it: Rs[(item * rows + r)], emaps[r][element].
+    const int64_t row = blockIdx.y, rows = gridDim.y;
     const int type = (int)items[b * 4], E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
-    auto setting = [&](int64_t q) { return *(const T*)ptrs[q]; };
+    auto setting = [&](int64_t q) {
+        const uintptr_t a = (uintptr_t)ptrs[q];
+        const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
+        return (a & 1) ? base[row] : base[0];
+    };
     if (threadIdx.x == 0) {
         // the reference energy this item sees: through the cavities in front of it, rounded to T after each (the energy is a
         // tensor of the beam's dtype between two elements)
@@ -1750,7 +1758,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
         }
         e_in_sh = e;
     }
-    if (b == n_items - 1 && threadIdx.x == 64 && s_out) {
+    if (b == n_items - 1 && threadIdx.x == 64 && s_out && row == 0) {
         // path length behind the stretch: s + run length (((L0 + L1) + L2) + ...) / + cavity length, item by item, in T
         T sv = *s_in;
         for (int i = 0; i < n_items; ++i) {
@@ -1764,9 +1772,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     }
     __syncthreads();
     const double E0 = e_in_sh;
-    T* R = reinterpret_cast<T*>(Rs + (int64_t)b * 49);
+    T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
     if (type >= 2) {                                       // an active BPM / aperture: nothing to build (lattice_apply_kernel acts there)
-        if (b == n_items - 1 && threadIdx.x == 0) *energy_out = (T)E0;
+        if (b == n_items - 1 && threadIdx.x == 0 && row == 0) *energy_out = (T)E0;
         return;
     }
     if (type == 1) {
@@ -1777,13 +1785,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
             build_kind<double>((int)elem_kind[elem0], p, E0, mass, nq, M);
             for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
             const double dEn = p[1] * cos(p[2] * (kPi / 180.0)) * nq * -1.0;
-            const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, dEn > 0.0, coeffs + (int64_t)b * CHX_CAV_NCOEF);
-            if (b == n_items - 1) *energy_out = (T)E1;
+            const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, dEn > 0.0, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
+            if (b == n_items - 1 && row == 0) *energy_out = (T)E1;
         }
         return;
     }
-    if (b == n_items - 1 && threadIdx.x == 0) *energy_out = (T)E0;
-    T* maps = reinterpret_cast<T*>(emaps + (int64_t)elem0 * 49);
+    if (b == n_items - 1 && threadIdx.x == 0 && row == 0) *energy_out = (T)E0;
+    T* maps = reinterpret_cast<T*>(emaps + (row * (int64_t)n_elems + elem0) * 49);
     for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
         const int kind = (int)elem_kind[elem0 + e];
         const int P = kind_num_params(kind);
@@ -1802,17 +1810,129 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     compose_block<T>([&](int e) { return (const T*)maps + e * 49; }, E, 0, R);
 }
 
-extern "C" size_t chx_lattice_state_bytes(int64_t n_items, int64_t n_elems) {
-    if (n_items < 1 || n_items > kLatticeMaxItems || n_elems < 1) return 0;      // (BPM items hold no element)
-    return (size_t)(n_items * (49 + CHX_CAV_NCOEF) + n_elems * 49) * sizeof(double);
+// The same preparation for MANY rows of vectorised settings (an orbit response over thousands of corrector settings): one WAVE per
+// (item, row) instead of one workgroup — a run between two monitors holds two or three elements, and 75 items x 4096 rows are
+// 300 000 workgroups of 256 mostly idle threads (6.4 ms) otherwise. For stretches without cavities (one reference energy) whose
+// runs hold at most 64 elements: lane e builds element e, the wave composes the maps with the association of compose_block (four
+// chunk products from the identity, then P3 P2 P1 P0) — the same bits.
+template <typename T, typename MapOf>
+__device__ __forceinline__ void compose_wave(MapOf map_of, int E, T* __restrict__ R_row, double* cur4 /*[4][49]*/, double* nxt /*[49]*/) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane / 7, j = lane - 7 * i;
+    const int per = (E + 3) / 4;
+    double acc = 0.0;
+    for (int w = 0; w < 4; ++w) {
+        const int e0 = w * per, e1 = (e0 + per < E) ? e0 + per : E;
+        double* cur = cur4 + w * 49;
+        acc = (lane < 49) ? ((i == j) ? 1.0 : 0.0) : 0.0;
+        if (lane < 49) cur[lane] = acc;
+        chx_wave_sync();
+        for (int e = e0; e < e1; ++e) {
+            const T* Re = map_of(e);
+            if (lane < 49) nxt[lane] = (double)Re[lane];
+            chx_wave_sync();
+            if (lane < 49) {
+                double s = nxt[i * 7] * cur[j];
+                for (int k = 1; k < 7; ++k) s = fma(nxt[i * 7 + k], cur[k * 7 + j], s);
+                acc = s;
+            }
+            chx_wave_sync();
+            if (lane < 49) cur[lane] = acc;
+            chx_wave_sync();
+        }
+    }
+    for (int w = 1; w < 4; ++w) {
+        if (lane < 49) {
+            double s = cur4[w * 49 + i * 7] * cur4[j];
+            for (int k = 1; k < 7; ++k) s = fma(cur4[w * 49 + i * 7 + k], cur4[k * 7 + j], s);
+            acc = s;
+        }
+        chx_wave_sync();
+        if (lane < 49) cur4[lane] = acc;
+        chx_wave_sync();
+    }
+    if (lane < 49) R_row[lane] = (T)acc;
 }
 
-extern "C" int chx_lattice_prepare(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
-                                   double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, void* energy_out,
-                                   const void* s_in, void* s_out, void* stream) {
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_rows_kernel(const int64_t* __restrict__ items, const int64_t* __restrict__ elem_kind,
+                                                                        const int64_t* __restrict__ elem_poff, const int64_t* __restrict__ ptrs,
+                                                                        int n_items, int n_elems, int64_t rows, const T* __restrict__ energy,
+                                                                        double mass, double nq, double* __restrict__ Rs,
+                                                                        double* __restrict__ emaps, T* __restrict__ energy_out,
+                                                                        const T* __restrict__ s_in, T* __restrict__ s_out) {
+    __shared__ double lds[CHX_BLOCK / 64][5 * 49];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pid = (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave;
+    if (pid >= (int64_t)n_items * rows) return;             // (whole waves; nothing below synchronises the workgroup)
+    const int b = (int)(pid / rows);
+    const int64_t row = pid - (int64_t)b * rows;
+    auto setting = [&](int64_t q) {
+        const uintptr_t a = (uintptr_t)ptrs[q];
+        const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
+        return (a & 1) ? base[row] : base[0];
+    };
+    if (pid == 0 && lane == 0) {
+        *energy_out = energy[0];                            // (no cavity in the stretch)
+        if (s_out) {
+            T sv = *s_in;
+            for (int i = 0; i < n_items; ++i) {
+                if (items[i * 4] != 0) continue;
+                const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
+                T total = setting(elem_poff[e0]);
+                for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
+                sv = sv + total;
+            }
+            *s_out = sv;
+        }
+    }
+    if (items[b * 4] != 0) return;
+    const int E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
+    const double E0 = (double)energy[0];
+    T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
+    T* maps = reinterpret_cast<T*>(emaps + (row * (int64_t)n_elems + elem0) * 49);
+    if (lane < E) {
+        const int kind = (int)elem_kind[elem0 + lane];
+        const int P = kind_num_params(kind);
+        const int64_t po = elem_poff[elem0 + lane];
+        double p[CHX_MAX_PARAMS];
+        for (int k = 0; k < P; ++k) p[k] = (double)setting(po + k);
+        Mat7<double> M;
+        build_kind<double>(kind, p, E0, mass, nq, M);
+        for (int q = 0; q < 49; ++q) maps[lane * 49 + q] = (T)M.m[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (E == 1) {
+        if (lane < 49) R[lane] = maps[lane];
+        return;
+    }
+    compose_wave<T>([&](int e) { return (const T*)maps + e * 49; }, E, R, &lds[wave][0], &lds[wave][4 * 49]);
+}
+
+extern "C" size_t chx_lattice_state_bytes_batched(int64_t n_items, int64_t n_elems, int64_t rows) {
+    if (n_items < 1 || n_items > kLatticeMaxItems || n_elems < 1 || rows < 1 || rows > 65535) return 0;      // (BPM items hold no element)
+    return (size_t)(n_items * (49 + CHX_CAV_NCOEF) + n_elems * 49) * (size_t)rows * sizeof(double);
+}
+
+extern "C" size_t chx_lattice_state_bytes(int64_t n_items, int64_t n_elems) { return chx_lattice_state_bytes_batched(n_items, n_elems, 1); }
+
+extern "C" int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows,
+                                           const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
+                                           void* energy_out, const void* s_in, void* s_out, void* stream) {
+    return chx_lattice_prepare_rows(table, n_items, n_elems, n_ptrs, rows, 0, energy, mass_eV, n_charges, dtype, state, state_bytes,
+                                    energy_out, s_in, s_out, stream);
+}
+
+// small_runs != 0: the caller vouches that the stretch holds NO cavity and that every run has at most 64 elements — the
+// wave-per-(item, row) kernel prepares it (same results)
+extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
+                                        const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
+                                        void* energy_out, const void* s_in, void* s_out, void* stream) {
     if (!table || !energy || !state || !energy_out || ((s_in == nullptr) != (s_out == nullptr)) || n_ptrs < n_elems)
         return CHX_ERR_INVALID_ARG;
-    const size_t need = chx_lattice_state_bytes(n_items, n_elems);
+    const size_t need = chx_lattice_state_bytes_batched(n_items, n_elems, rows);
     if (need == 0) return CHX_ERR_INVALID_ARG;
     if (state_bytes < need) return CHX_ERR_WORKSPACE;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
@@ -1821,19 +1941,41 @@ extern "C" int chx_lattice_prepare(const int64_t* table, int64_t n_items, int64_
     const int64_t* elem_poff = elem_kind + n_elems;
     const int64_t* ptrs = elem_poff + n_elems;
     double* Rs = (double*)state;
-    double* coeffs = Rs + n_items * 49;
-    double* emaps = coeffs + n_items * CHX_CAV_NCOEF;
+    double* coeffs = Rs + n_items * rows * 49;
+    double* emaps = coeffs + n_items * rows * CHX_CAV_NCOEF;
     hipStream_t s = (hipStream_t)stream;
+    if (small_runs && rows > 1) {
+        const int64_t pairs = n_items * rows;
+        const unsigned g = (unsigned)((pairs + CHX_BLOCK / 64 - 1) / (CHX_BLOCK / 64));
+        if (dtype == CHX_F32)
+            hipLaunchKernelGGL(lattice_prepare_rows_kernel<float>, dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs, (int)n_items,
+                               (int)n_elems, rows, (const float*)energy, mass_eV, n_charges, Rs, emaps, (float*)energy_out,
+                               (const float*)s_in, (float*)s_out);
+        else
+            hipLaunchKernelGGL(lattice_prepare_rows_kernel<double>, dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
+                               (int)n_items, (int)n_elems, rows, (const double*)energy, mass_eV, n_charges, Rs, emaps, (double*)energy_out,
+                               (const double*)s_in, (double*)s_out);
+        CHX_CHECK_LAUNCH();
+        return CHX_OK;
+    }
+    const dim3 grid((unsigned)n_items, (unsigned)rows);
     if (dtype == CHX_F32)
-        hipLaunchKernelGGL(lattice_prepare_kernel<float>, dim3((unsigned)n_items), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
-                           (int)n_items, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
+        hipLaunchKernelGGL(lattice_prepare_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
+                           (int)n_items, (int)n_elems, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
                            (const float*)s_in, (float*)s_out);
     else
-        hipLaunchKernelGGL(lattice_prepare_kernel<double>, dim3((unsigned)n_items), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
-                           ptrs, (int)n_items, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
+        hipLaunchKernelGGL(lattice_prepare_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
+                           ptrs, (int)n_items, (int)n_elems, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
                            (const double*)s_in, (double*)s_out);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
+}
+
+extern "C" int chx_lattice_prepare(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                   double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, void* energy_out,
+                                   const void* s_in, void* s_out, void* stream) {
+    return chx_lattice_prepare_batched(table, n_items, n_elems, n_ptrs, 1, energy, mass_eV, n_charges, dtype, state, state_bytes,
+                                       energy_out, s_in, s_out, stream);
 }
 
 extern "C" size_t chx_compose_maps_vjp_workspace_bytes(int64_t E, int64_t B) {

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __r
 // loading it again gives: bit-identical to the walk item by item); a monitor reads (mu_x, mu_y) - misalignment there.
 template <typename T>
 __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restrict__ mu, const T* __restrict__ cov, int64_t Bmu,
-                                                              int64_t Bcov, const int64_t* __restrict__ items, int n_items,
+                                                              int64_t Bcov, int64_t Bm /*rows of lattice settings: 1 or B*/,
+                                                              const int64_t* __restrict__ items, int n_items,
                                                               const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                               const int64_t* __restrict__ ptrs, T* __restrict__ mu_out,
                                                               T* __restrict__ cov_out, T* __restrict__ readings) {
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restri
             continue;
         }
         if (type != 0 && type != 1) continue;
-        if (lane < 49) r[lane] = (double)reinterpret_cast<const T*>(Rs + (int64_t)it * 49)[lane];
+        const int64_t mrow = (int64_t)it * Bm + (Bm == 1 ? 0 : b);         // this row's map of the item (vectorised settings)
+        if (lane < 49) r[lane] = (double)reinterpret_cast<const T*>(Rs + mrow * 49)[lane];
         __syncthreads();
         if (lane < 49) {  // tmp = R cov
             double s = 0.0;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restri
             for (int k = 0; k < 7; ++k) mu_i = fma(r[lane * 7 + k], m[k], mu_i);
         }
         if (type == 1) {      // cavity moment updates with the INCOMING moments (cavity.py:127-133, 202-218)
-            const double* cf = coeffs + (int64_t)it * CHX_CAV_NCOEF;
+            const double* cf = coeffs + mrow * CHX_CAV_NCOEF;
             const double mu4 = m[4], mu5 = m[5], c44 = c[4 * 7 + 4], c45 = c[4 * 7 + 5], c55 = c[5 * 7 + 5];
             if (lane == 5) mu_i = mu5 * cf[0] + cf[1] * (cos(-mu4 * cf[2] + cf[3]) - cf[4]);
             if (lane == 4) mu_i = mu_i + (cf[5] * mu5 * mu5 + cf[6] * mu4 * mu5 + cf[7] * mu4 * mu4);
@@ -222,25 +224,25 @@ extern "C" int chx_parameter_track(const void* mu, const void* cov, const void* 
 
 extern "C" int chx_parameter_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                            double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
-                                           const void* mu, const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, void* mu_out,
-                                           void* cov_out, void* energy_out, const void* s_in, void* s_out, int64_t n_bpm,
-                                           void* readings, void* stream) {
+                                           const void* mu, const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, int64_t Bm,
+                                           int small_runs, void* mu_out, void* cov_out, void* energy_out, const void* s_in,
+                                           void* s_out, int64_t n_bpm, void* readings, void* stream) {
     if (!mu || !cov || !mu_out || !cov_out || B < 1 || B > 0x7fffffffLL || n_bpm < 0 || (n_bpm > 0 && !readings))
         return CHX_ERR_INVALID_ARG;
-    if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B)) return CHX_ERR_INVALID_ARG;
-    int st = chx_lattice_prepare(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, energy_out,
-                                 s_in, s_out, stream);
+    if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B) || !chx_bcast_ok(Bm, B)) return CHX_ERR_INVALID_ARG;
+    int st = chx_lattice_prepare_rows(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
+                                      state_bytes, energy_out, s_in, s_out, stream);
     if (st != CHX_OK) return st;
     const double* Rs = (const double*)state;
-    const double* coeffs = Rs + n_items * 49;
+    const double* coeffs = Rs + n_items * Bm * 49;
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(parameter_lattice_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, (const float*)mu, (const float*)cov, Bmu,
-                           Bcov, table, (int)n_items, Rs, coeffs, ptrs, (float*)mu_out, (float*)cov_out, (float*)readings);
+                           Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (float*)mu_out, (float*)cov_out, (float*)readings);
     else
         hipLaunchKernelGGL(parameter_lattice_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)mu, (const double*)cov,
-                           Bmu, Bcov, table, (int)n_items, Rs, coeffs, ptrs, (double*)mu_out, (double*)cov_out, (double*)readings);
+                           Bmu, Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (double*)mu_out, (double*)cov_out, (double*)readings);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

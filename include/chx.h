@@ -592,10 +592,23 @@ int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elem
  * (Bmu, Bcov in {1, B}) through [run | active Cavity | active BPM]+ by one wavefront per batch row after the same preparation
  * launch — mu' = R mu, cov' = R cov R^T item by item (fp64 inside, rounded to `dtype` between items like chx_parameter_track), a
  * cavity's moment updates, readings[n_bpm][B][2] = (mu_x, mu_y) - misalignment at every monitor. Items of type 3 are skipped. */
+/* Bm = rows of lattice settings (1, or B: the settings are vectorised — ptrs entries with the lowest bit set address (B,) arrays of
+ * `dtype`, like chx_run_map_batched; lengths, cavity settings and the energy stay scalars): row b of the beam goes through row b of
+ * the lattice; state: chx_lattice_state_bytes_batched(n_items, n_elems, Bm) bytes (chx_lattice_prepare_batched fills it). */
+size_t chx_lattice_state_bytes_batched(int64_t n_items, int64_t n_elems, int64_t rows);
+int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, const void* energy,
+                                double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, void* energy_out,
+                                const void* s_in, void* s_out, void* stream);
+/* small_runs != 0: the caller vouches that the stretch holds no cavity and no run of more than 64 elements — a wave per (item, row)
+ * prepares the maps instead of a workgroup (300 000 of them for 75 items x 4096 rows); the same results. */
+int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
+                             const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
+                             void* energy_out, const void* s_in, void* s_out, void* stream);
 int chx_parameter_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                 double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* mu,
-                                const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, void* mu_out, void* cov_out, void* energy_out,
-                                const void* s_in, void* s_out, int64_t n_bpm, void* readings, void* stream);
+                                const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, int64_t Bm, int small_runs, void* mu_out,
+                                void* cov_out, void* energy_out, const void* s_in, void* s_out, int64_t n_bpm, void* readings,
+                                void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),

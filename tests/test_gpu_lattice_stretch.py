@@ -435,3 +435,62 @@ def test_parameter_beam_takes_the_stretch(dt):
         finally:
             Segment._lattice_stretch_parameter = orig
     assert torch.equal(out2.mu, ref2.mu) and torch.equal(out2.cov, ref2.cov) and not torch.equal(out2.mu, out.mu[0] if out.mu.dim() > 1 else out.mu)
+
+
+@pytest.mark.parametrize("B,with_cavity", [(37, True), (600, False)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_parameter_beam_stretch_with_vectorised_settings(dt, B, with_cavity):
+    """An orbit-response measurement: every corrector's angle (and one quadrupole's strength) a (B,) tensor, a monitor in every cell,
+    a cavity with scalar settings in between — ONE call for all B lattice settings (the preparation launch builds row b's maps from
+    element b of the vectorised settings); mu, cov and the (B, 2) readings bit for bit as the walk item by item."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator.segment import Segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(9)
+    els, bpms = [], []        # (37 rows and a cavity: a workgroup per (item, row) prepares the maps; 600 rows without: a wave does)
+    for i in range(9):
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -1e-5]), **kw)
+        bpms.append(bpm)
+        k1 = torch.randn(B, **kw) * 3 if i == 4 else t(3.0 if i % 2 else -3.0)
+        els += [ca.Quadrupole(t(0.2), k1=k1, **kw), ca.HorizontalCorrector(t(0.05), angle=1e-4 * torch.randn(B, **kw), **kw), ca.Drift(t(0.6), **kw),
+                ca.VerticalCorrector(t(0.05), angle=t(2e-5 * i), **kw), bpm]
+        if i == 5 and with_cavity:
+            els += [ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw)]
+    seg = ca.Segment(els)
+    pb = ca.ParameterBeam.from_parameters(energy=t(6e7), mu_x=t(1e-4), sigma_p=t(1e-3), **kw)
+    orig = Segment._lattice_stretch_parameter
+    calls = []
+    Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: (lambda r: (calls.append(r is not None), r)[1])(orig(self, plan, i, incoming))
+    try:
+        with torch.no_grad():
+            out = seg.track(pb)
+            got = torch.stack([b.reading.clone() for b in bpms])
+        assert calls == [True], calls
+    finally:
+        Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: None
+    try:
+        with torch.no_grad():
+            ref = seg.track(pb)
+            want = torch.stack([b.reading.clone() for b in bpms])
+    finally:
+        Segment._lattice_stretch_parameter = orig
+    assert out.mu.shape == (B, 7) and out.cov.shape == (B, 7, 7) and got.shape == (9, B, 2)
+    assert torch.equal(out.mu, ref.mu) and torch.equal(out.cov, ref.cov) and torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+    assert torch.equal(got, want)
+    assert (got[8, 0] - got[8, 1]).abs().max() > 1e-7                     # the rows see different lattices
+    # the settings written in place: followed; a ParticleBeam on the same lattice walks (and agrees with its own walk)
+    els[1].angle.mul_(-2.0)
+    with torch.no_grad():
+        out2 = seg.track(pb)
+        Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: None
+        try:
+            ref2 = seg.track(pb)
+        finally:
+            Segment._lattice_stretch_parameter = orig
+        assert torch.equal(out2.mu, ref2.mu) and not torch.equal(out2.mu, out.mu)
+        beam = ca.ParticleBeam.from_parameters(num_particles=2_000, energy=t(6e7), **kw)
+        a = seg.track(beam)
+        assert a.particles.shape == (B, 2_000, 7)
+        assert torch.equal(a.particles, _walk(seg, beam).particles)
