@@ -272,7 +272,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec")
 
     def __init__(self, items, dtype, device, allow_vector=False):
         self.items, self.dtype, self.device = items, dtype, device
@@ -295,7 +295,7 @@ class _LatticePlan:
         dtype, device = self.dtype, self.device
         rows, elem_kind, elem_poff, ptrs, tensors, bpms, apertures = [], [], [], [], [], [], []
         count = cavities = longest_run = 0
-        vshape, bpm_vec = None, []
+        vshape, bpm_vec, ap_vec = None, [], []
         for kind, item in self.items:
             if kind != "run" and item._is_aperture:
                 # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
@@ -310,6 +310,7 @@ class _LatticePlan:
                 ptrs += [t.data_ptr() for t in limits]
                 tensors += limits
                 apertures.append(item)
+                ap_vec.append(vshape is not None)
                 count += 1
                 continue
             if kind != "run" and item._is_bpm:
@@ -379,7 +380,7 @@ class _LatticePlan:
             count += 1
         # (a trailing run stays in the stretch: it rides in the same particle pass; a trailing BPM reads the outgoing beam)
         self.count = count
-        self.bpms, self.apertures, self.bpm_vec = tuple(bpms), tuple(apertures), tuple(bpm_vec)
+        self.bpms, self.apertures, self.bpm_vec, self.ap_vec = tuple(bpms), tuple(apertures), tuple(bpm_vec), tuple(ap_vec)
         if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
@@ -1055,10 +1056,10 @@ class Segment(Element):
             if torch.cuda.is_current_stream_capturing():
                 return None     # (the table's upload is not part of a recording: the walk item by item is capturable as it is)
             if lp is None:
-                lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device)
+                lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device, allow_vector=True)
             else:
                 lp.refresh()
-        if not lp.ok or lp.vshape is not None:       # (vectorised settings: the ParameterBeam's stretch takes them; particles walk)
+        if not lp.ok:
             return None
         if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
@@ -1072,10 +1073,20 @@ class Segment(Element):
             if sharding.active_group() is not None:
                 return None            # a particle-sharded beam: the monitors read GLOBAL means (BPM._track_internal exchanges them)
         w_out = incoming.survival_probabilities
-        lead, N = tuple(p.shape[:-2]), p.shape[-2]
-        B = 1
-        for d in lead:
-            B *= d
+        lead_x, N = tuple(p.shape[:-2]), p.shape[-2]
+        lead, Bm = lead_x, 1
+        if lp.vshape is not None:
+            # settings vectorised over a scan of the lattice: row b of the outgoing beams = the beam (ONE shared beam, or its own
+            # row b) through row b of the settings — the preparation launch forms the maps of every row, the particle pass picks
+            # its row's by blockIdx.y
+            try:
+                lead = tuple(torch.broadcast_shapes(lead_x, lp.vshape))
+            except RuntimeError:
+                return None
+            if tuple(lp.vshape) != lead or (_ops.numel(lead_x) != 1 and lead_x != lead):
+                return None
+            Bm = _ops.numel(lead)
+        B, Bx = _ops.numel(lead), _ops.numel(lead_x)
         if B < 1 or B > 65535:
             return None
         if lp.bpms or lp.apertures or lead:
@@ -1106,11 +1117,24 @@ class Segment(Element):
                 ws = _ops.workspace(ws_bytes, p.device)
             if lp.apertures:
                 w_out = torch.empty_like(w)
+            out = None if lead == lead_x else torch.empty((*lead, N, 7), dtype=p.dtype, device=p.device)
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, N, e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index, w,
-                                                    w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B)
+                                                    w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B,
+                                                    Bx, Bm, lp.small_runs, out)
             for k, bpm in enumerate(lp.bpms):
-                bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(*lead, 2)
+                r = readings[k].reshape(*lead, 2)
+                if lead != lead_x and not lp.bpm_vec[k]:
+                    # a monitor in FRONT of the first vectorised element reads the beam before it was spread over the scan: equal
+                    # rows, the reading has the incoming beam's shape (like the walk's)
+                    from .cavity import _narrow_to
+
+                    r = _narrow_to(r, (*lead_x, 2))
+                bpm.__dict__["_buffers"]["reading"] = r
+            if lp.apertures and lead != lead_x and not any(lp.ap_vec):
+                from .cavity import _narrow_to
+
+                w_out = _narrow_to(w_out, (*lead_x, N))     # (every aperture sits in front of the scan: equal rows)
         else:
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, x.shape[0], e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index)

@@ -563,7 +563,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                                                                  const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                                  int64_t N, int in_vec_ok, int out_vec_ok,
                                                                  const T* __restrict__ survival, double* __restrict__ bpm_ws, int diag,
-                                                                 const int64_t* __restrict__ ptrs, T* __restrict__ survival_out) {
+                                                                 const int64_t* __restrict__ ptrs, T* __restrict__ survival_out,
+                                                                 int shared_in /*x_in is ONE beam of N particles for all rows*/,
+                                                                 int64_t Bm /*rows of lattice settings: 1, or gridDim.y*/) {
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     // blockIdx.y = beam (a vectorised ParticleBeam of gridDim.y beams of N particles under ONE lattice setting and energy: the
@@ -573,7 +575,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
     const int64_t n0 = beam * N + t0;                      // first flat particle of this tile
     const int np = (int)((N - t0 < TP) ? (N - t0) : TP);
     const bool row_vec = ((beam * N * 7 * (int64_t)sizeof(T)) & 15) == 0;
-    tile_load<T, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0 && row_vec, true);
+    // (a beam shared by the rows of a scan of lattice settings is re-read by every row: no streaming hint then)
+    tile_load<T, TP>(x_in + (shared_in ? t0 : n0) * 7, lds, np * 7, in_vec_ok != 0 && (shared_in || row_vec), !shared_in);
     __syncthreads();
     T x[PPT][7];
 #pragma unroll
@@ -636,9 +639,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             }
             continue;
         }
-        const T* __restrict__ R = reinterpret_cast<const T*>(Rs + (int64_t)i * 49);
+        const int64_t mrow = (int64_t)i * Bm + (Bm == 1 ? 0 : beam);       // this row's map of the item (vectorised settings)
+        const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
         const bool cavity = type == 1;
-        const double* __restrict__ c = coeffs + (int64_t)i * CHX_CAV_NCOEF;
+        const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             T y[7];
@@ -704,17 +708,19 @@ extern "C" size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t B, int64_t
 
 extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                       double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
-                                      void* x_out, int64_t N, int64_t B, void* energy_out, const void* s_in, void* s_out,
-                                      const void* survival, void* survival_out, int64_t n_bpm, void* readings, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+                                      void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int small_runs, void* energy_out,
+                                      const void* s_in, void* s_out, const void* survival, void* survival_out, int64_t n_bpm,
+                                      void* readings, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x_in || !x_out || N < 1 || B < 1 || B > 65535 || n_bpm < 0 || n_bpm > n_items) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bm, B)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && (!readings || !workspace)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, B, n_bpm)) return CHX_ERR_WORKSPACE;
-    int st = chx_lattice_prepare(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, energy_out,
-                                 s_in, s_out, stream);
+    int st = chx_lattice_prepare_rows(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
+                                      state_bytes, energy_out, s_in, s_out, stream);
     if (st != CHX_OK) return st;
     const double* Rs = (const double*)state;
-    const double* coeffs = Rs + n_items * 49;
+    const double* coeffs = Rs + n_items * Bm * 49;
+    const int shared_in = (Bx == 1 && B > 1) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int iv = chx_aligned16(x_in) ? 1 : 0, ov = chx_aligned16(x_out) ? 1 : 0;
     // one particle per lane: a stretch is tracked on small beams (a few dozen tiles), two per lane only halve the waves in flight
@@ -725,7 +731,7 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
     if (dtype == CHX_F32) {
         hipLaunchKernelGGL((lattice_apply_kernel<float, 1>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
                            (int)n_items, Rs, coeffs, N, iv, ov, (const float*)survival, (double*)workspace, diag, ptrs,
-                           (float*)survival_out);
+                           (float*)survival_out, shared_in, Bm);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
             hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
@@ -733,7 +739,7 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
     } else {
         hipLaunchKernelGGL((lattice_apply_kernel<double, 1>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out, table,
                            (int)n_items, Rs, coeffs, N, iv, ov, (const double*)survival, (double*)workspace, diag, ptrs,
-                           (double*)survival_out);
+                           (double*)survival_out, shared_in, Bm);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
             hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
@@ -747,7 +753,7 @@ extern "C" int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t 
                                  double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                                  void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, void* stream) {
     return chx_lattice_track_diag(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, x_in, x_out, N,
-                                  1, energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+                                  1, 1, 1, 0, energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 // ---- several device arrays copied by ONE launch -----------------------------------------------------------------------

@@ -494,3 +494,77 @@ def test_parameter_beam_stretch_with_vectorised_settings(dt, B, with_cavity):
         a = seg.track(beam)
         assert a.particles.shape == (B, 2_000, 7)
         assert torch.equal(a.particles, _walk(seg, beam).particles)
+
+
+@pytest.mark.parametrize("B,with_cavity,own_rows", [(5, True, False), (70, False, False), (6, True, True)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_particle_beam_stretch_with_vectorised_settings(dt, B, with_cavity, own_rows):
+    """A scan of lattice settings tracked with particles: corrector angles and one quadrupole strength (B,) tensors, monitors and
+    apertures in front of and behind the first vectorised element, a cavity with scalar settings — ONE stretch call; row b of the
+    (B, N, 7) result = the beam (one shared beam, or row b of a (B, N, 7) beam) through row b of the settings, bit for bit as the
+    walk item by item; readings to the rounding of the mean; a monitor / aperture in front of the scan keeps the incoming shape."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(21)
+    N = 3_001
+    beam = ca.ParticleBeam.from_parameters(num_particles=N, energy=t(6e7), mu_x=t(2e-4), sigma_x=t(4e-4), sigma_y=t(4e-4), sigma_p=t(1e-3), **kw)
+    if own_rows:
+        parts = beam.particles.unsqueeze(0).repeat(B, 1, 1)
+        parts[..., :6] *= 1 + 0.1 * torch.rand(B, 1, 1, **kw)
+        beam = ca.ParticleBeam(parts, beam.energy, particle_charges=beam.particle_charges, **kw)
+    front_bpm = ca.BPM(is_active=True, misalignment=t([3e-5, -1e-5]), **kw)
+    front_ap = ca.Aperture(x_max=t(1.2e-3), y_max=t(1.5e-3), shape="elliptical", **kw)
+    els = [ca.Drift(t(0.4), **kw), front_ap, ca.Quadrupole(t(0.2), k1=t(2.0), **kw), front_bpm]
+    bpms = []
+    for i in range(6):
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -1e-5]), **kw)
+        bpms.append(bpm)
+        k1 = torch.randn(B, **kw) * 3 if i == 3 else t(3.0 if i % 2 else -3.0)
+        els += [ca.Quadrupole(t(0.2), k1=k1, **kw), ca.HorizontalCorrector(t(0.05), angle=2e-4 * torch.randn(B, **kw), **kw),
+                ca.Drift(t(0.6), **kw), bpm]
+        if i == 2:
+            els += [ca.Aperture(x_max=t(1.5e-3), y_max=t(1.5e-3), shape="rectangular", **kw)]
+        if i == 4 and with_cavity:
+            els += [ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw)]
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(beam)
+            got, got_front = torch.stack([b.reading.clone() for b in bpms]), front_bpm.reading.clone()
+        assert calls == [N], calls
+        with torch.no_grad():
+            ref = _walk(seg, beam)
+            want, want_front = torch.stack([b.reading.clone() for b in bpms]), front_bpm.reading.clone()
+    finally:
+        segment._HOST = old
+    assert out.particles.shape == (B, N, 7) == ref.particles.shape
+    assert torch.equal(out.particles, ref.particles) and torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+    assert out.survival_probabilities.shape == ref.survival_probabilities.shape == (B, N)
+    assert torch.equal(out.survival_probabilities, ref.survival_probabilities)
+    lost = (out.survival_probabilities == 0).sum(dim=-1)
+    assert lost.min() > 0 and lost.max() < N and (own_rows or len(set(lost.tolist())) > 1)     # the rows lose different particles
+    assert got.shape == want.shape == (6, B, 2)
+    assert got_front.shape == want_front.shape == ((B, 2) if own_rows else (2,))
+    eps = torch.finfo(dt).eps
+    order = 8 * torch.finfo(torch.float64).eps * 5e-3
+    mis = torch.stack([b.misalignment for b in bpms]).unsqueeze(1)
+    assert torch.all((got - want).abs() <= 2 * eps * (want + mis).abs() + order)
+    assert torch.all((got_front - want_front).abs() <= 2 * eps * (want_front + front_bpm.misalignment).abs() + order)
+    assert (got[5, 0] - got[5, 1]).abs().max() > 1e-6
+    # settings written in place are followed by the next track
+    els[5].angle.mul_(-1.5)
+    with torch.no_grad():
+        out2, ref2 = seg.track(beam), _walk(seg, beam)
+    assert torch.equal(out2.particles, ref2.particles) and not torch.equal(out2.particles, out.particles)
+    # only apertures in FRONT of the scan: the survival probabilities keep the incoming beam's shape, like the walk's
+    els[16].is_active = False
+    with torch.no_grad():
+        out3, ref3 = seg.track(beam), _walk(seg, beam)
+    assert out3.survival_probabilities.shape == ref3.survival_probabilities.shape
+    assert torch.equal(out3.survival_probabilities, ref3.survival_probabilities) and torch.equal(out3.particles, ref3.particles)
