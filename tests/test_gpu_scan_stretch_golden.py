@@ -1,0 +1,104 @@
+"""SCANS of lattice settings tracked with particles against the REFERENCE's own run (tests/golden/scan_stretch.npz, generator
+tests/golden/generate_golden_scan_stretch.py): six drawn lattices with active monitors, apertures and cavities, about a third of the
+quadrupole strengths and corrector angles (4,) tensors. Each is ONE stretch call here (chx_lattice_track_diag with Bm = 4 rows of
+maps and one shared incoming beam; chx_parameter_lattice_track for the ParameterBeam): the (4, 1200, 7) outgoing particles, survival
+probabilities and their SHAPE, energy, s and every monitor's reading with the reference's shape — (2,) in front of the first
+vectorised element, (4, 2) behind (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
+(worst of the six lattices): float64 particles 5.8e-15, readings 6.8e-17, ParameterBeam 4.6e-16; float32 4.1e-7 / 1.3e-8 / 3.2e-7;
+the bounds are those of test_gpu_diagnostics_stretch_golden.py."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scan_stretch.npz")
+
+
+def _build(ca, spec, fk):
+    kind, kw = spec
+    args = {k: (torch.tensor(v, **fk) if isinstance(v, (float, list)) else v) for k, v in kw.items()}
+    return getattr(ca, kind)(**args, **fk)
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_scans_with_particles_vs_reference(dt):
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    g = np.load(GOLDEN)
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda a: torch.tensor(np.asarray(a), **fk)  # noqa: E731
+    stretch_calls = []
+    host = segment._lib.host()
+
+    class Spy:
+        def __getattr__(self, name):
+            fn = getattr(host, name)
+            return fn if name != "lattice_track" else (lambda *a: (stretch_calls.append(len(a)), fn(*a))[1])
+
+    f64 = dt == torch.float64
+    worst = {"particles": 0.0, "readings": 0.0, "pb": 0.0}
+    old = segment._HOST
+    segment._HOST = Spy()
+    try:
+        for i in range(int(g["n_lattices"])):
+            specs = json.loads(str(g[f"lat{i}_spec"]))
+            seg = ca.Segment([_build(ca, s, fk) for s in specs])
+            bpms = [e for e in seg.elements if isinstance(e, ca.BPM)]
+            assert len(bpms) == int(g[f"lat{i}_n_bpms"])
+            beam = ca.ParticleBeam(t(g[f"lat{i}_in"]), t(g[f"lat{i}_energy"]), particle_charges=t(g[f"lat{i}_q"]),
+                                   survival_probabilities=t(g[f"lat{i}_w"]), **fk)
+            stretch_calls.clear()
+            with torch.no_grad():
+                out = seg.track(beam)
+            assert stretch_calls == [19], (i, stretch_calls)          # the whole scan is one stretch call
+            ref = g[f"lat{i}_out"]
+            assert tuple(out.particles.shape) == ref.shape
+            scale = np.abs(ref).max(axis=(0, 1))
+            err = (np.abs(out.particles.double().cpu().numpy() - ref) / scale).max()
+            worst["particles"] = max(worst["particles"], err)
+            assert err < (1e-13 if f64 else 3e-6), (i, err)
+            w_ref = g[f"lat{i}_w_out"]
+            w_got = out.survival_probabilities.double().cpu().numpy()
+            assert w_got.shape == w_ref.shape, (i, w_got.shape, w_ref.shape)
+            if f64:
+                assert np.array_equal(w_got, w_ref), (i, int((w_got != w_ref).sum()))
+            else:       # a float32 coordinate may fall on the other side of an aperture edge
+                assert (np.abs(w_got - w_ref) > 1e-6).sum() <= 8, (i, int((np.abs(w_got - w_ref) > 1e-6).sum()))
+            assert float(out.energy) == pytest.approx(float(g[f"lat{i}_energy_out"]), rel=1e-13 if f64 else 1e-6)
+            assert float(out.s) == pytest.approx(float(g[f"lat{i}_s_out"]), rel=1e-13 if f64 else 1e-6)
+            size = np.abs(ref[..., [0, 2]]).max()
+            for k, b in enumerate(bpms):
+                r_ref = g[f"lat{i}_reading{k}"]
+                r_got = b.reading.double().cpu().numpy()
+                assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                live = np.isfinite(r_ref)
+                assert np.array_equal(np.isfinite(r_got), live)
+                if live.any():
+                    e = np.abs(r_got[live] - r_ref[live]).max() / (size + np.abs(r_ref[live]).max())
+                    worst["readings"] = max(worst["readings"], e)
+                    assert e < (1e-15 if f64 else 3e-7), (i, k, e)
+            # the same scan for a ParameterBeam
+            pb = ca.ParameterBeam(t(g[f"lat{i}_pb_mu_in"]), t(g[f"lat{i}_pb_cov_in"]), t(g[f"lat{i}_energy"]), **fk)
+            with warnings.catch_warnings(), torch.no_grad():
+                warnings.simplefilter("ignore")
+                pout = seg.track(pb)
+            mu_ref, cov_ref = g[f"lat{i}_pb_mu"], g[f"lat{i}_pb_cov"]
+            assert tuple(pout.mu.shape) == mu_ref.shape and tuple(pout.cov.shape) == cov_ref.shape
+            e_mu = np.abs(pout.mu.double().cpu().numpy() - mu_ref).max() / np.abs(mu_ref[..., :6]).max()
+            e_cov = np.abs(pout.cov.double().cpu().numpy() - cov_ref).max() / np.abs(cov_ref).max()
+            worst["pb"] = max(worst["pb"], e_mu, e_cov)
+            assert max(e_mu, e_cov) < (5e-15 if f64 else 1.5e-6), (i, e_mu, e_cov)
+            for k, b in enumerate(bpms):
+                r_ref = g[f"lat{i}_pb_reading{k}"]
+                r_got = b.reading.double().cpu().numpy()
+                assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                assert np.abs(r_got - r_ref).max() < (5e-15 if f64 else 1.5e-6) * (np.abs(mu_ref[..., :6]).max() + np.abs(r_ref).max())
+    finally:
+        segment._HOST = old
+    print(f"scans vs reference ({dt}): worst particles {worst['particles']:.2e}, readings {worst['readings']:.2e}, "
+          f"parameter beam {worst['pb']:.2e}")
