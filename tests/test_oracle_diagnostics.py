@@ -1,4 +1,4 @@
-"""The CPU oracle walks the lattices of tests/golden/diagnostics_stretch.npz and long_lattice.npz element by element — maps
+"""The CPU oracle walks the lattices of tests/golden/diagnostics_stretch.npz, scan_stretch.npz and long_lattice.npz element by element — maps
 (chxo_build_rmatrix), `x @ R.mT`, Cavity.track, the weighted means a BPM reads (bpm.py:77-87), the aperture mask
 (aperture.py:104-128) — and must reproduce the REFERENCE's float64 run: the third side of the triangle reference / oracle / HIP
 (the HIP path against the same files: tests/test_gpu_diagnostics_stretch_golden.py, tests/test_gpu_fast_run.py)."""
@@ -84,3 +84,28 @@ def test_oracle_walks_the_long_lattice_like_the_reference(oracle):
     many = oracle.apply(g["in"][None] * np.array([0.5, 1.0, 1.5]).reshape(3, 1, 1) * np.array([1, 1, 1, 1, 1, 1, 0.0]) + np.array([0, 0, 0, 0, 0, 0, 1.0]), R)
     mref = g["many_out"]
     assert (np.abs(many - mref).max(axis=(0, 1)) / np.abs(mref).max(axis=(0, 1))).max() < 1e-11
+
+
+def test_oracle_walks_the_scans_row_by_row_like_the_reference(oracle):
+    """tests/golden/scan_stretch.npz: four lattice settings in one reference track = four scalar walks of the oracle, one per row of
+    the (4,) settings; a monitor in front of the first vectorised element holds ONE reading, equal for all rows."""
+    g = np.load(os.path.join(GOLDEN, "scan_stretch.npz"))
+    rows = int(g["rows"])
+    for i in range(int(g["n_lattices"])):
+        specs = json.loads(str(g[f"lat{i}_spec"]))
+        ref, w_ref = g[f"lat{i}_out"], g[f"lat{i}_w_out"]
+        for b in range(rows):
+            row = [[k, {q: (v[b] if isinstance(v, list) and len(v) == rows and q in ("k1", "angle") else v) for q, v in kw.items()}] for k, kw in specs]
+            x, w, E, s, readings = _walk(oracle, row, g[f"lat{i}_in"], g[f"lat{i}_w"], float(g[f"lat{i}_energy"]))
+            err = (np.abs(x - ref[b]).max(axis=0) / np.abs(ref[b]).max(axis=0)).max()
+            assert err < 1e-11, (i, b, err)
+            assert np.array_equal(w, w_ref[b] if w_ref.ndim == 2 else w_ref), (i, b)
+            assert E == pytest.approx(float(g[f"lat{i}_energy_out"]), rel=1e-13) and s == pytest.approx(float(g[f"lat{i}_s_out"]), rel=1e-12)
+            size = np.abs(ref[b][:, [0, 2]]).max()
+            for k in range(int(g[f"lat{i}_n_bpms"])):
+                r_ref = g[f"lat{i}_reading{k}"]
+                r_ref = r_ref[b] if r_ref.ndim == 2 else r_ref
+                if np.isfinite(r_ref).all():
+                    assert np.abs(readings[k] - r_ref).max() / (size + np.abs(r_ref).max()) < 1e-12, (i, b, k)
+                else:
+                    assert not np.isfinite(readings[k]).all()
