@@ -149,7 +149,7 @@ SIGNATURES = {
                                   c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chx_lattice_diag_workspace_bytes": (c_size_t, [c_i64, c_i64, c_i64]),
     "chx_lattice_track_diag": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
-                                       c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_lattice_state_bytes_batched": (c_size_t, [c_i64, c_i64, c_i64]),
     "chx_lattice_prepare_batched": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t,

@@ -1099,7 +1099,10 @@ class Segment(Element):
                 if w.dtype != p.dtype or w.device != p.device or (torch.is_grad_enabled() and w.requires_grad) \
                         or w.shape[-1] != N or w.dim() > len(lead) + 1:
                     return None
-                if tuple(w.shape) != lead + (N,):
+                Bw = B
+                if w.numel() == N and B > 1:
+                    w, Bw = w.reshape(N), 1             # one row of weights for all beams: read as it is, not spread over the rows
+                elif tuple(w.shape) != lead + (N,):
                     try:
                         w = w.expand(*lead, N)
                     except RuntimeError:
@@ -1116,12 +1119,12 @@ class Segment(Element):
                 ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, B, n_bpm)
                 ws = _ops.workspace(ws_bytes, p.device)
             if lp.apertures:
-                w_out = torch.empty_like(w)
+                w_out = torch.empty((*lead, N), dtype=p.dtype, device=p.device)
             out = None if lead == lead_x else torch.empty((*lead, N, 7), dtype=p.dtype, device=p.device)
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, N, e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index, w,
                                                     w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B,
-                                                    Bx, Bm, lp.small_runs, out)
+                                                    Bx, Bm, Bw if w is not None else B, lp.small_runs, out)
             for k, bpm in enumerate(lp.bpms):
                 r = readings[k].reshape(*lead, 2)
                 if lead != lead_x and not lp.bpm_vec[k]:

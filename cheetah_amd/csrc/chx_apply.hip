@@ -565,7 +565,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                                                                  const T* __restrict__ survival, double* __restrict__ bpm_ws, int diag,
                                                                  const int64_t* __restrict__ ptrs, T* __restrict__ survival_out,
                                                                  int shared_in /*x_in is ONE beam of N particles for all rows*/,
-                                                                 int64_t Bm /*rows of lattice settings: 1, or gridDim.y*/) {
+                                                                 int64_t Bm /*rows of lattice settings: 1, or gridDim.y*/,
+                                                                 int shared_sv /*survival is ONE row of N weights for all rows*/) {
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     // blockIdx.y = beam (a vectorised ParticleBeam of gridDim.y beams of N particles under ONE lattice setting and energy: the
@@ -594,24 +595,33 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int p = threadIdx.x + k * CHX_BLOCK;
-            sv[k] = (p < np) ? (survival ? survival[n0 + p] : (T)1) : (T)0;
+            sv[k] = (p < np) ? (survival ? survival[(shared_sv ? t0 : n0) + p] : (T)1) : (T)0;
         }
     }
+    // the wave's sum of weights stands from monitor to monitor until an aperture thins them (a wave sum of doubles is ~100
+    // cycles: at 4e8 particle rows the monitors, not HBM, bound the pass)
+    bool sw_known = false;
+    double sw = 0.0;
     for (int i = 0; i < n_items; ++i) {
         const int type = (int)items[i * 4];
         if (type == 2) {
-            double sw = 0.0, sx = 0.0, sy = 0.0;
+            double sx = 0.0, sy = 0.0;
+            if (!sw_known) {
+                sw = 0.0;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) sw += (double)sv[k];
+                sw = chx_wave_sum_lane63(sw);
+                sw_known = true;
+            }
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const double w = (double)sv[k];
-                sw += w;
                 sx = fma(w, (double)x[k][0], sx);
                 sy = fma(w, (double)x[k][2], sy);
             }
-            sw = chx_wave_sum(sw);
-            sx = chx_wave_sum(sx);
-            sy = chx_wave_sum(sy);
-            if ((threadIdx.x & 63) == 0) {
+            sx = chx_wave_sum_lane63(sx);        // (the totals land in lane 63: DPP row broadcasts instead of ds_bpermute)
+            sy = chx_wave_sum_lane63(sy);
+            if ((threadIdx.x & 63) == 63) {
                 double* part = bpm_ws + ((int64_t)items[i * 4 + 3] * nw_all + wslot) * 3;
                 part[0] = sw;
                 part[1] = sx;
@@ -637,19 +647,53 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                 }
                 sv[k] = sv[k] * (inside ? (T)1 : (T)0);
             }
+            sw_known = false;
             continue;
         }
         const int64_t mrow = (int64_t)i * Bm + (Bm == 1 ? 0 : beam);       // this row's map of the item (vectorised settings)
         const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
         const bool cavity = type == 1;
         const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
+        if constexpr (std::is_same<T, float>::value && PPT == 2) {
+            // the lane's two particles in one register pair: every step of apply7's fmaf chain is ONE v_pk_fma_f32 for both
+            // (same per-particle order -> same bits; at 4e8 particle rows the maps of a stretch are VALU time, not HBM time)
+            chx_v2f xp[7], y[7];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            T y[7];
-            apply7<T>(R, x[k], y);
-            if (cavity) cavity_epilogue<T>(c, x[k], y);
+            for (int j = 0; j < 7; ++j) xp[j] = chx_v2f{x[0][j], x[1][j]};
 #pragma unroll
-            for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+            for (int r = 0; r < 7; ++r) {
+                chx_v2f acc = xp[0] * R[r * 7];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) {
+                    const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
+                    acc = __builtin_elementwise_fma(m, xp[j], acc);
+                }
+                y[r] = acc;
+            }
+            T y0[7], y1[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                y0[j] = y[j].x;
+                y1[j] = y[j].y;
+            }
+            if (cavity) {
+                cavity_epilogue<T>(c, x[0], y0);
+                cavity_epilogue<T>(c, x[1], y1);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                x[0][j] = y0[j];
+                x[1][j] = y1[j];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                T y[7];
+                apply7<T>(R, x[k], y);
+                if (cavity) cavity_epilogue<T>(c, x[k], y);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+            }
         }
     }
     if (survival_out) {
@@ -708,11 +752,11 @@ extern "C" size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t B, int64_t
 
 extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                       double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
-                                      void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int small_runs, void* energy_out,
-                                      const void* s_in, void* s_out, const void* survival, void* survival_out, int64_t n_bpm,
-                                      void* readings, void* workspace, size_t workspace_bytes, void* stream) {
+                                      void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
+                                      void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
+                                      int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x_in || !x_out || N < 1 || B < 1 || B > 65535 || n_bpm < 0 || n_bpm > n_items) return CHX_ERR_INVALID_ARG;
-    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bm, B)) return CHX_ERR_INVALID_ARG;
+    if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bm, B) || !chx_bcast_ok(Bw, B)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && (!readings || !workspace)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, B, n_bpm)) return CHX_ERR_WORKSPACE;
     int st = chx_lattice_prepare_rows(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
@@ -720,31 +764,37 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
     if (st != CHX_OK) return st;
     const double* Rs = (const double*)state;
     const double* coeffs = Rs + n_items * Bm * 49;
-    const int shared_in = (Bx == 1 && B > 1) ? 1 : 0;
+    const int shared_in = (Bx == 1 && B > 1) ? 1 : 0, shared_sv = (Bw == 1 && B > 1) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int iv = chx_aligned16(x_in) ? 1 : 0, ov = chx_aligned16(x_out) ? 1 : 0;
-    // one particle per lane: a stretch is tracked on small beams (a few dozen tiles), two per lane only halve the waves in flight
-    const dim3 grid((unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK), (unsigned)B);
+    // one particle per lane on small beams (a few dozen tiles: two per lane only halve the waves in flight); two per lane from 4e6
+    // particle rows on (half the waves: half the wave sums at the monitors, half the scalar loads of the maps)
+    const int ppt = (N * B >= ((int64_t)1 << 22)) ? 2 : 1;
+    const int64_t tile = (int64_t)CHX_BLOCK * ppt;
+    const dim3 grid((unsigned)((N + tile - 1) / tile), (unsigned)B);
     const int64_t nw = (int64_t)grid.x * (CHX_BLOCK / 64);
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
     const int diag = (n_bpm > 0 || survival_out) ? 1 : 0;
+#define CHX_LATTICE_APPLY(T, PPT)                                                                                                   \
+    hipLaunchKernelGGL((lattice_apply_kernel<T, PPT>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out, table, (int)n_items, \
+                       Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs, (T*)survival_out, shared_in, Bm,  \
+                       shared_sv)
     if (dtype == CHX_F32) {
-        hipLaunchKernelGGL((lattice_apply_kernel<float, 1>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
-                           (int)n_items, Rs, coeffs, N, iv, ov, (const float*)survival, (double*)workspace, diag, ptrs,
-                           (float*)survival_out, shared_in, Bm);
+        if (ppt == 2) CHX_LATTICE_APPLY(float, 2);
+        else CHX_LATTICE_APPLY(float, 1);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
             hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
                                (const double*)workspace, nw, (float*)readings);
     } else {
-        hipLaunchKernelGGL((lattice_apply_kernel<double, 1>), grid, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out, table,
-                           (int)n_items, Rs, coeffs, N, iv, ov, (const double*)survival, (double*)workspace, diag, ptrs,
-                           (double*)survival_out, shared_in, Bm);
+        if (ppt == 2) CHX_LATTICE_APPLY(double, 2);
+        else CHX_LATTICE_APPLY(double, 1);
         CHX_CHECK_LAUNCH();
         if (n_bpm > 0)
             hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table, (int)n_items, ptrs,
                                (const double*)workspace, nw, (double*)readings);
     }
+#undef CHX_LATTICE_APPLY
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -753,7 +803,7 @@ extern "C" int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t 
                                  double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                                  void* x_out, int64_t N, void* energy_out, const void* s_in, void* s_out, void* stream) {
     return chx_lattice_track_diag(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, x_in, x_out, N,
-                                  1, 1, 1, 0, energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+                                  1, 1, 1, 1, 0, energy_out, s_in, s_out, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 // ---- several device arrays copied by ONE launch -----------------------------------------------------------------------

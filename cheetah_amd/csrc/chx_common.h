@@ -46,6 +46,26 @@ __device__ __forceinline__ double chx_wave_sum(double v) {
     return v;
 }
 
+// The same sum, bit for bit, delivered in lane 63 ONLY (the other lanes hold partial sums): the two steps across rows as DPP
+// row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of four dependent ds_bpermute —
+// for passes that take many wave sums per wave and let one lane write them (the monitors of lattice_apply_kernel).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double chx_dpp_add_rows(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double chx_wave_sum_lane63(double v) {
+    v = chx_dpp_add<0xB1>(v);
+    v = chx_dpp_add<0x4E>(v);
+    v = chx_dpp_add<0x141>(v);
+    v = chx_dpp_add<0x140>(v);
+    v = chx_dpp_add_rows<0x142, 0xA>(v);   // row_bcast:15 -> rows 1 and 3: r1 + r0, r3 + r2
+    v = chx_dpp_add_rows<0x143, 0xC>(v);   // row_bcast:31 -> rows 2 and 3: (r3 + r2) + (r1 + r0)
+    return v;
+}
+
 // Sum over each row of 16 lanes only (every lane of a row receives its row's total): the DPP part of chx_wave_sum.
 __device__ __forceinline__ double chx_row16_sum(double v) {
     v = chx_dpp_add<0xB1>(v);

@@ -117,9 +117,9 @@ static PyObject* host_run_track(PyObject* self, PyObject* const* args, Py_ssize_
 /* chx_lattice_track_diag (include/chx.h); without monitors / apertures: survival = survival_out = readings = workspace = NULL */
 typedef int (*lattice_track_fn)(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                 double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
-                                void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int small_runs, void* energy_out,
-                                const void* s_in, void* s_out, const void* survival, void* survival_out, int64_t n_bpm,
-                                void* readings, void* workspace, size_t workspace_bytes, void* stream);
+                                void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
+                                void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
+                                int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream);
 static lattice_track_fn p_lattice_track = NULL;
 
 typedef struct {
@@ -161,17 +161,18 @@ static PyObject* host_lattice_plan(PyObject* self, PyObject* args) {
  * the seven optional arguments: B beams of N particles (x: (B, N, 7) contiguous) and / or a stretch with active BPMs / apertures —
  * survival_out (B, N), readings (n_bpm, B, 2) and the workspace are the caller's tensors */
 static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
-    if (nargs != 8 && nargs != 15 && nargs != 19) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8, 15 or 19 arguments"); return NULL; }
+    if (nargs != 8 && nargs != 15 && nargs != 20) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8, 15 or 20 arguments"); return NULL; }
     void *surv = NULL, *surv_out = NULL, *readings = NULL, *bws = NULL;
-    long long n_bpm = 0, beams = 1, bx = -1, bm = 1, small_runs = 0;
+    long long n_bpm = 0, beams = 1, bx = -1, bm = 1, bw = -1, small_runs = 0;
     unsigned long long bws_bytes = 0;
     PyObject* out_given = NULL;
-    if (nargs == 19) {           /* ..., Bx, Bm, small_runs, out: vectorised lattice settings / one beam shared by the rows */
+    if (nargs == 20) {           /* ..., Bx, Bm, Bw, small_runs, out: vectorised lattice settings / one beam shared by the rows */
         bx = PyLong_AsLongLong(args[15]);
         bm = PyLong_AsLongLong(args[16]);
-        small_runs = PyLong_AsLongLong(args[17]);
+        bw = PyLong_AsLongLong(args[17]);
+        small_runs = PyLong_AsLongLong(args[18]);
         if (PyErr_Occurred()) return NULL;
-        if (args[18] != Py_None) out_given = args[18];
+        if (args[19] != Py_None) out_given = args[19];
     }
     if (nargs >= 15) {
         n_bpm = PyLong_AsLongLong(args[10]);
@@ -209,7 +210,7 @@ static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ss
     stream = PyLong_AsVoidPtr(st);
     Py_DECREF(st);
     const int rc = p_lattice_track(p->table, p->n_items, p->n_elems, p->n_ptrs, ep, mass, nq, p->code, p->state, p->state_bytes, xp, op,
-                                   (int64_t)N, (int64_t)beams, (int64_t)(bx < 0 ? beams : bx), (int64_t)bm, (int)small_runs, eop, sp, sop, surv, surv_out,
+                                   (int64_t)N, (int64_t)beams, (int64_t)(bx < 0 ? beams : bx), (int64_t)bm, (int64_t)(bw < 0 ? beams : bw), (int)small_runs, eop, sp, sop, surv, surv_out,
                                    (int64_t)n_bpm, readings, bws, (size_t)bws_bytes, stream);
     if (rc != 0) {
         Py_DECREF(out); Py_DECREF(e_out); Py_DECREF(s_out);

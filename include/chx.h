@@ -582,14 +582,15 @@ int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, in
  * B beams of N particles each (x_in / x_out [B][N][7]: a vectorised ParticleBeam under ONE lattice setting and energy — the same
  * maps for all beams; chx_lattice_track: B = 1). Bx = 1: x_in is ONE beam [N][7] shared by the B rows; Bm = B: the lattice
  * settings are vectorised over the rows (tagged addresses, state of chx_lattice_state_bytes_batched(.., Bm); small_runs as for
- * chx_lattice_prepare_rows): row b of the output = the beam through row b of the settings. survival: [B][N] of `dtype` or NULL (= 1); survival_out: [B][N], required when
+ * chx_lattice_prepare_rows): row b of the output = the beam through row b of the settings. survival: [Bw][N] (Bw = 1: one row of weights for
+ * all rows), survival_out [B][N] of `dtype` or NULL (= 1); survival_out: [B][N], required when
  * the stretch holds an aperture, else NULL; readings[n_bpm][B][2]; workspace: chx_lattice_diag_workspace_bytes(N, B, n_bpm)
  * bytes. Particles, energy and path length are those of chx_lattice_track bit for bit. */
 size_t chx_lattice_diag_workspace_bytes(int64_t N, int64_t B, int64_t n_bpm);
 int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy, double mass_eV,
                            double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in, void* x_out, int64_t N,
-                           int64_t B, int64_t Bx, int64_t Bm, int small_runs, void* energy_out, const void* s_in, void* s_out,
-                           const void* survival, void* survival_out, int64_t n_bpm, void* readings, void* workspace,
+                           int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs, void* energy_out, const void* s_in,
+                           void* s_out, const void* survival, void* survival_out, int64_t n_bpm, void* readings, void* workspace,
                            size_t workspace_bytes, void* stream);
 /* The same stretch for a ParameterBeam (element.py:167-179, cavity.py:127-133,202-218, bpm.py:77-87): mu [Bmu][7], cov [Bcov][49]
  * (Bmu, Bcov in {1, B}) through [run | active Cavity | active BPM]+ by one wavefront per batch row after the same preparation

@@ -55,7 +55,7 @@ def test_scans_with_particles_vs_reference(dt):
             stretch_calls.clear()
             with torch.no_grad():
                 out = seg.track(beam)
-            assert stretch_calls == [19], (i, stretch_calls)          # the whole scan is one stretch call
+            assert stretch_calls == [20], (i, stretch_calls)          # the whole scan is one stretch call
             ref = g[f"lat{i}_out"]
             assert tuple(out.particles.shape) == ref.shape
             scale = np.abs(ref).max(axis=(0, 1))
