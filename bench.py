@@ -533,7 +533,8 @@ def other_configs(ca, torch, device) -> dict:
         pbeam = ca.ParameterBeam.from_parameters(energy=tt(1e8), **kw)
         many = ca.ParticleBeam(beam.particles[:10_000].unsqueeze(0).repeat(16, 1, 1).contiguous(), beam.energy, **kw)
         res = {"workload": "100-element lattices with 25 active BPMs / 25 active apertures and a 16-cell cavity linac, fp32: us per "
-                           "Segment.track (ParticleBeam of 1e5 particles; ParameterBeam; 16 beams of 1e4 particles in one ParticleBeam)"}
+                           "Segment.track (ParticleBeam of 1e5 particles; ParameterBeam; 16 beams of 1e4 particles in one ParticleBeam); an orbit "
+                           "response of 25 cells, each corrector angle a (64,) tensor (ParameterBeam; one 1e4-particle beam shared by the rows)"}
         with torch.no_grad():
             for name, els in (("bpm_lattice", bpm_cells), ("aperture_lattice", ap_cells), ("cavity_linac", linac)):
                 seg = ca.Segment(els)
@@ -541,6 +542,18 @@ def other_configs(ca, torch, device) -> dict:
                              "sixteen_beams_us": timed_us(lambda: seg.track(many))}
                 if name != "aperture_lattice":      # (an aperture only warns for a ParameterBeam)
                     res[name]["parameter_beam_us"] = timed_us(lambda: seg.track(pbeam))
+            # an orbit response: every corrector's angle a (64,) tensor, 25 monitors; all 64 settings in one stretch call, for a
+            # ParameterBeam and for ONE ParticleBeam of 1e4 particles shared by the settings
+            scan = []
+            torch.manual_seed(77)
+            for i in range(25):
+                scan += [ca.Quadrupole(tt(0.2), k1=tt(4.2 if i % 2 == 0 else -4.2), **kw),
+                         ca.HorizontalCorrector(tt(0.05), angle=1e-5 * torch.randn(64, **kw), **kw), ca.Drift(tt(0.8), **kw),
+                         ca.BPM(is_active=True, **kw)]
+            seg = ca.Segment(scan)
+            small = ca.ParticleBeam(beam.particles[:10_000].contiguous(), beam.energy, **kw)
+            res["orbit_response_64_settings"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
+                                                 "particle_beam_1e4_us": timed_us(lambda: seg.track(small))}
         return res
 
     for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order),
