@@ -64,6 +64,12 @@ class Cavity(Element):
     def _builder_params(self):
         return [self.length, self.voltage, self.phase, self.frequency]
 
+    def _plannable(self) -> bool:
+        # a switched-off cavity inside a run (Segment._plan re-examines `is_active` on every track and re-partitions the lattice
+        # when the voltage comes back): its drift-like map is built on the device from the four settings like any magnet's —
+        # a linac with two of sixteen cavities off was 241 us per track instead of 49
+        return not self.is_active
+
     def _energy_graph(self, e_out: torch.Tensor, energy: torch.Tensor) -> torch.Tensor:
         """The outgoing energy is `energy + voltage * cos(phase) * q` (cavity.py:113-122): it carries a graph only through
         those three. The coefficient expressions are evaluated on the stacked settings, where a trainable length or frequency

@@ -124,6 +124,11 @@ class Element(nn.Module):
         except KeyError:
             return [getattr(self, n) for n in names]
 
+    def _plannable(self) -> bool:
+        """May this element, standing in a run of skippable elements, go into the run's persistent device plan? Elements whose
+        skippability depends on tensor VALUES say no by default."""
+        return self._static_skippable
+
     def _builder_scalar_refs(self):
         """The builder parameters as (tensor, index) pairs for the all-scalar fast path (`_ops.build_compose_scalars`):
         index None = the 0-d tensor itself, an integer = that entry of a 1-d tensor (no view object is created)."""
@@ -403,7 +408,7 @@ class Element(nn.Module):
     #: without them and rebuilds on first use.
     _DERIVED_STATE = ("_plan_cache", "_flat_elements", "_map_cache", "_tmap_cache", "_scalar_ws", "_ext_cache",
                       "_grid_tensor", "_geom_cache", "_limits_checked", "_chain_guard_state", "_dkd_cache", "_lattice_cache",
-                      "_so_run_cache", "_dkd_run_cache", "_zero_s", "_along_cache")
+                      "_so_run_cache", "_dkd_run_cache", "_zero_s", "_along_cache", "_plan_store", "_lattice_store")
 
     def __getstate__(self):
         """State for `copy.deepcopy`, `pickle` and `torch.save`: everything but the derived caches."""

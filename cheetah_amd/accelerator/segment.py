@@ -142,8 +142,8 @@ class _FastRun:
         """(kind, pointers, tensors) of element number i, "identity", or None when the element rules the plan out. A setting
         that still is the tensor OBJECT read last time keeps its slot unexamined (same dtype, device, shape and address): a
         control step that re-assigns one strength of a quadrupole re-checks one tensor, not five."""
-        if not e._static_skippable or (e._parameters and not self.allow_grad):
-            return None                     # data-dependent skippability (Cavity, sub-Segment) or trainable parameters
+        if not e._plannable() or (e._parameters and not self.allow_grad):
+            return None                     # data-dependent skippability (an active Cavity, a sub-Segment) or trainable parameters
         kind = e._chx_kind
         if kind is None:
             return None
@@ -566,6 +566,13 @@ class Segment(Element):
         if cached is not None and cached[0] == key:
             self.__dict__["_plan_cache"] = (key, cached[1], Element._epoch, cached[3], revs)
             return cached[1]
+        # a partition seen before (a cavity switched off and on again, a diagnostic toggled): its runs come back with their
+        # persistent plans, which re-validate against the epoch — rebuilding every plan of a 16-cell linac costs ~0.9 ms
+        store = self.__dict__.setdefault("_plan_store", {})
+        known = store.get(key)
+        if known is not None:
+            self.__dict__["_plan_cache"] = (key, known[0], Element._epoch, known[1], revs)
+            return known[0]
         plan, run = [], []
         for e in elements:
             if e.is_skippable:
@@ -581,7 +588,22 @@ class Segment(Element):
         # re-examined on every call while there are any
         dynamic = [m for e in elements for m in e.modules() if isinstance(m, Element) and not m._static_skippable] or None
         self.__dict__["_plan_cache"] = (key, plan, Element._epoch, dynamic, revs)
+        if len(store) >= 8:
+            store.clear()
+            self.__dict__.pop("_lattice_store", None)
+        store[key] = (plan, dynamic)
         return plan
+
+    def _lattice_cache_for(self, plan):
+        """The stretch plans of `plan` (one table per partition of the lattice that `_plan` keeps)."""
+        store = self.__dict__.setdefault("_lattice_store", {})
+        cache = store.get(id(plan))
+        if cache is None or cache[0] is not plan:
+            if len(store) >= 8:
+                store.clear()
+            cache = store[id(plan)] = (plan, {})
+        self.__dict__["_lattice_cache"] = cache
+        return cache
 
     # ---- per-run products ------------------------------------------------------------------------------
     @staticmethod
@@ -679,7 +701,7 @@ class Segment(Element):
         kinds, rows, flags, keep, shape = [], [], [], [], None
         for e in run.elements:
             kind = getattr(e, "_chx_kind", None)
-            if kind is None or not e._static_skippable or e._parameters:
+            if kind is None or not e._plannable() or e._parameters:
                 return None
             if kind == _IDENTITY:
                 continue
@@ -864,7 +886,7 @@ class Segment(Element):
             parts, piece, refs = [], [], 0
             dtype, device = ref.dtype, ref.device
             for e in run.elements:
-                takes = getattr(e, "_chx_kind", None) is not None and e._static_skippable and not e._parameters
+                takes = getattr(e, "_chx_kind", None) is not None and e._plannable() and not e._parameters
                 settings = e._builder_scalar_refs() if takes else ()
                 if takes and any(t.dtype != dtype or t.device != device or t.requires_grad or t.dim() != (0 if index is None else 1)
                                  for t, index in settings):
@@ -1034,7 +1056,7 @@ class Segment(Element):
         index behind the stretch), else None. Same numbers, bit for bit, as the walk item by item."""
         cache = self.__dict__.get("_lattice_cache")
         if cache is None or cache[0] is not plan:
-            cache = self.__dict__["_lattice_cache"] = (plan, {})
+            cache = self._lattice_cache_for(plan)
         p = incoming.particles
         key = (i, p.dtype, p.device)
         entry = cache[1].get(key)
@@ -1158,7 +1180,7 @@ class Segment(Element):
             return None
         cache = self.__dict__.get("_lattice_cache")
         if cache is None or cache[0] is not plan:
-            cache = self.__dict__["_lattice_cache"] = (plan, {})
+            cache = self._lattice_cache_for(plan)
         key = (i, mu.dtype, mu.device, "moments")
         entry = cache[1].get(key)
         if entry is None:

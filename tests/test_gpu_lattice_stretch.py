@@ -622,3 +622,64 @@ def test_big_stretch_two_particles_per_lane(dt, B, N):
     mis = mis.unsqueeze(1) if B else mis
     assert got.shape == want.shape == (5, *lead, 2)
     assert torch.all((got - want).abs() <= 2 * eps * (want + mis).abs() + order), ((got - want).abs()).max()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("cavity_type", ["standing_wave", "traveling_wave"])
+def test_switched_off_cavities_ride_in_the_runs(dt, cavity_type):
+    """A linac with some cavities at voltage 0 (skippable, drift-like: cavity.py:253-262): they are elements of the runs' persistent
+    plans, the whole linac stays ONE stretch call — the same bits as with the cavities kept out of the plans (the per-element
+    builders + chx_compose_maps), for particles and for a ParameterBeam. Switching a cavity off and on again between tracks
+    re-partitions the lattice; a partition seen before comes back with its plans."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+    from cheetah_amd.accelerator.cavity import Cavity
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(8)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_003, energy=t(5e7), sigma_p=t(1e-3), **kw)
+    pbeam = ca.ParameterBeam.from_parameters(energy=t(5e7), sigma_p=t(1e-3), **kw)
+    els = _linac(ca, dt, 8, cavity_type)
+    cavities = [e for e in els if isinstance(e, Cavity)]
+    for k in (2, 5):
+        cavities[k].voltage = t(0.0)
+    seg = ca.Segment(els)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg.track(beam)
+            pout = seg.track(pbeam)
+        assert calls == [20_003], calls
+        orig = Cavity._plannable
+        Cavity._plannable = lambda self: False
+        try:
+            ca.Element._epoch += 1                       # (the plans look at their elements again)
+            with torch.no_grad():
+                ref = seg.track(beam)
+                pref = seg.track(pbeam)
+        finally:
+            Cavity._plannable = orig
+            ca.Element._epoch += 1
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+        assert torch.equal(pout.mu, pref.mu) and torch.equal(pout.cov, pref.cov) and torch.equal(pout.energy, pref.energy)
+        # the voltage comes back (assignment), goes away again (in place): every partition tracks like a fresh lattice
+        plan_off = seg._plan()
+        cavities[2].voltage = t(18e6)
+        with torch.no_grad():
+            out_on = seg.track(beam)
+        assert seg._plan() is not plan_off
+        fresh = _linac(ca, dt, 8, cavity_type)
+        [e for e in fresh if isinstance(e, Cavity)][5].voltage = t(0.0)
+        with torch.no_grad():
+            want_on = ca.Segment(fresh).track(beam)
+        assert torch.equal(out_on.particles, want_on.particles) and torch.equal(out_on.energy, want_on.energy)
+        cavities[2].voltage.zero_()
+        with torch.no_grad():
+            out_off = seg.track(beam)
+        assert seg._plan() is plan_off                  # the partition seen before, with its plans
+        assert torch.equal(out_off.particles, out.particles) and torch.equal(out_off.energy, out.energy)
+    finally:
+        segment._HOST = old
