@@ -568,7 +568,9 @@ class Segment(Element):
             return cached[1]
         # a partition seen before (a cavity switched off and on again, a diagnostic toggled): its runs come back with their
         # persistent plans, which re-validate against the epoch — rebuilding every plan of a 16-cell linac costs ~0.9 ms
-        store = self.__dict__.setdefault("_plan_store", {})
+        store = self.__dict__.get("_plan_store")
+        if store is None:                    # (never planned, or a copy: derived state does not travel)
+            store = self.__dict__["_plan_store"] = {}
         known = store.get(key)
         if known is not None:
             self.__dict__["_plan_cache"] = (key, known[0], Element._epoch, known[1], revs)
@@ -596,7 +598,9 @@ class Segment(Element):
 
     def _lattice_cache_for(self, plan):
         """The stretch plans of `plan` (one table per partition of the lattice that `_plan` keeps)."""
-        store = self.__dict__.setdefault("_lattice_store", {})
+        store = self.__dict__.get("_lattice_store")
+        if store is None:
+            store = self.__dict__["_lattice_store"] = {}
         cache = store.get(id(plan))
         if cache is None or cache[0] is not plan:
             if len(store) >= 8:

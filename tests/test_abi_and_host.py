@@ -233,9 +233,19 @@ def test_persistent_run_plan_host_logic():
     q2 = ca.Quadrupole(t(0.2), k1=torch.nn.Parameter(t(1.0)))
     assert not _FastRun(ca.Segment([q2])._plan()[0][1], torch.float32, torch.device("cpu")).ok
     assert not _FastRun(run, torch.float64, torch.device("cpu")).ok
-    # a cavity's skippability depends on a tensor VALUE: a run containing one is never planned persistently
+    # a cavity's skippability depends on a tensor VALUE: switched off it is an element of its run's plan (four settings, the
+    # standing-wave builder); when the voltage comes back `_plan` re-partitions — the cavity is an item of its own, the partition
+    # seen before returns with its plans when it is switched off again
     cav = ca.Cavity(t(1.0), voltage=t(0.0), phase=t(0.0), frequency=t(1.3e9))
-    assert not _FastRun(ca.Segment([ca.Drift(t(1.0)), cav])._plan()[0][1], torch.float32, torch.device("cpu")).ok
+    lin = ca.Segment([ca.Drift(t(1.0)), cav])
+    plan_off = lin._plan()
+    fr_cav = _FastRun(plan_off[0][1], torch.float32, torch.device("cpu"))
+    assert fr_cav.ok and fr_cav.E == 2 and fr_cav.kinds[1] == _ops.KIND["cavity_sw"] and fr_cav.ptrs[_ops.MAX_PARAMS + 1] == cav.voltage.data_ptr()
+    cav.voltage.fill_(1e6)
+    plan_on = lin._plan()
+    assert [k for k, _ in plan_on] == ["run", "element"] and plan_on[1][1] is cav and not cav._plannable()
+    cav.voltage.zero_()
+    assert lin._plan() is plan_off and cav._plannable()
     # editing the element list moves the epoch too
     e0 = Element._epoch
     seg.elements.append(ca.Drift(t(0.1)))
