@@ -65,3 +65,29 @@ for name, mk in makers.items():
         except Exception as exc:  # noqa: BLE001
             b = float("nan")
     print(f"10 x {name:30s}: ParticleBeam {a:9.1f} us   ParameterBeam {b:9.1f} us", flush=True)
+
+# ---- the same plain lattice with its SETTINGS in other states ---------------------------------------------------------------
+print("settings states (100-element FODO, 1e5 particles / ParameterBeam, us per track under no_grad):")
+
+
+def fodo(k1_of):
+    els = []
+    for i in range(50):
+        els += [ca.Quadrupole(t(0.2), k1=k1_of(i), **kw), ca.Drift(t(0.8), **kw)]
+    return ca.Segment(els)
+
+
+states = {
+    "plain scalars": lambda i: t(4.2 if i % 2 == 0 else -4.2),
+    "one nn.Parameter strength": lambda i: torch.nn.Parameter(t(4.2)) if i == 7 else t(4.2 if i % 2 == 0 else -4.2),
+    "every strength an nn.Parameter": lambda i: torch.nn.Parameter(t(4.2 if i % 2 == 0 else -4.2)),
+    "one strength requires_grad (buffer)": lambda i: t(4.2).requires_grad_() if i == 7 else t(4.2 if i % 2 == 0 else -4.2),
+    "one strength of shape (1,)": lambda i: t([4.2]) if i == 7 else t(4.2 if i % 2 == 0 else -4.2),
+    "strengths views of one settings tensor": (lambda base: (lambda i: base[i]))(torch.randn(50, **kw)),
+}
+for name, k1_of in states.items():
+    seg = fodo(k1_of)
+    with torch.no_grad():
+        a = timeit(lambda: seg.track(beam), reps=10)
+        b = timeit(lambda: seg.track(pbeam), reps=10)
+    print(f"   {name:42s}: ParticleBeam {a:9.1f} us   ParameterBeam {b:9.1f} us", flush=True)

@@ -142,8 +142,11 @@ class _FastRun:
         """(kind, pointers, tensors) of element number i, "identity", or None when the element rules the plan out. A setting
         that still is the tensor OBJECT read last time keeps its slot unexamined (same dtype, device, shape and address): a
         control step that re-assigns one strength of a quadrupole re-checks one tensor, not five."""
-        if not e._plannable() or (e._parameters and not self.allow_grad):
-            return None                     # data-dependent skippability (an active Cavity, a sub-Segment) or trainable parameters
+        if not e._plannable():
+            return None                     # data-dependent skippability (an active Cavity, a sub-Segment)
+        # (trainable parameters and settings that require grad are read like any other: whether a track may USE this plan is
+        # decided per call — every user asks `torch.is_grad_enabled() and _any_requires_grad(*plan.tensors)` — so a model with
+        # nn.Parameter strengths evaluated under no_grad keeps its plans: 75 -> 22 us for a 100-element lattice)
         kind = e._chx_kind
         if kind is None:
             return None
@@ -161,7 +164,7 @@ class _FastRun:
                 # the same tensor OBJECT: its storage may still have been swapped (`t.data = ...`, `set_`, `resize_`)
                 if row[k] == (t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()):
                     continue
-            if t.dtype != dtype or t.device != device or (t.requires_grad and not self.allow_grad):
+            if t.dtype != dtype or t.device != device:
                 return None
             if index is None:
                 if t.dim() != 0:
@@ -302,9 +305,9 @@ class _LatticePlan:
                 from .marker import Aperture
 
                 limits = (item.x_max, item.y_max)
-                if type(item)._track_internal is not Aperture._track_internal or item._parameters or not item.is_active \
+                if type(item)._track_internal is not Aperture._track_internal or not item.is_active \
                         or item.shape not in ("rectangular", "elliptical") \
-                        or any(t.dim() != 0 or t.dtype != dtype or t.device != device or t.requires_grad for t in limits):
+                        or any(t.dim() != 0 or t.dtype != dtype or t.device != device for t in limits):
                     break
                 rows += [3, 1 if item.shape == "elliptical" else 0, len(ptrs), 0]
                 ptrs += [t.data_ptr() for t in limits]
@@ -318,8 +321,8 @@ class _LatticePlan:
                 from .marker import BPM
 
                 mis = item.misalignment
-                if type(item)._track_internal is not BPM._track_internal or item._parameters or not item.is_active \
-                        or mis.shape != (2,) or mis.dtype != dtype or mis.device != device or mis.requires_grad or not mis.is_contiguous():
+                if type(item)._track_internal is not BPM._track_internal or not item.is_active \
+                        or mis.shape != (2,) or mis.dtype != dtype or mis.device != device or not mis.is_contiguous():
                     break
                 rows += [2, 0, len(ptrs), len(bpms)]
                 ptrs.append(mis.data_ptr())
@@ -366,10 +369,10 @@ class _LatticePlan:
                     ptrs += r
                 tensors += run_tensors
             else:
-                if type(item).track is not Cavity.track or item._parameters:
+                if type(item).track is not Cavity.track:
                     break
                 settings = item._settings("length", "voltage", "phase", "frequency")
-                if any(t.dim() != 0 or t.dtype != dtype or t.device != device or t.requires_grad for t in settings):
+                if any(t.dim() != 0 or t.dtype != dtype or t.device != device for t in settings):
                     break
                 rows += [1, 1, len(elem_kind), 0]
                 elem_kind.append(_ops.KIND[item._kind_name()])

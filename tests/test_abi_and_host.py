@@ -201,6 +201,7 @@ def test_persistent_run_plan_host_logic():
     import cheetah_amd as ca
     from cheetah_amd import _ops
     from cheetah_amd.accelerator.element import Element
+    from cheetah_amd.accelerator import segment
     from cheetah_amd.accelerator.segment import _FastRun
 
     t = torch.tensor
@@ -230,8 +231,11 @@ def test_persistent_run_plan_host_logic():
     q1.k1 = t(1.0)
     fr.refresh()
     assert fr.ok
+    # a trainable strength is read like any other setting: whether a track may USE the plan is asked per call
+    # (`torch.is_grad_enabled() and _any_requires_grad(*plan.tensors)`), so a model evaluated under no_grad keeps its plans
     q2 = ca.Quadrupole(t(0.2), k1=torch.nn.Parameter(t(1.0)))
-    assert not _FastRun(ca.Segment([q2])._plan()[0][1], torch.float32, torch.device("cpu")).ok
+    fr2 = _FastRun(ca.Segment([q2])._plan()[0][1], torch.float32, torch.device("cpu"))
+    assert fr2.ok and any(x is q2.k1 for x in fr2.tensors) and segment._any_requires_grad(*fr2.tensors)
     assert not _FastRun(run, torch.float64, torch.device("cpu")).ok
     # a cavity's skippability depends on a tensor VALUE: switched off it is an element of its run's plan (four settings, the
     # standing-wave builder); when the voltage comes back `_plan` re-partitions — the cavity is an item of its own, the partition

@@ -683,3 +683,63 @@ def test_switched_off_cavities_ride_in_the_runs(dt, cavity_type):
         assert torch.equal(out_off.particles, out.particles) and torch.equal(out_off.energy, out.energy)
     finally:
         segment._HOST = old
+
+
+def test_trainable_settings_keep_their_plans_under_no_grad():
+    """A lattice whose strengths, cavity voltage and a monitor's misalignment are nn.Parameters: evaluated under `torch.no_grad()`
+    it is ONE stretch call with the numbers of the same lattice built from plain tensors; with gradients enabled the very same
+    Segment takes the differentiable path (every parameter receives a gradient) and, after an optimiser step edited the parameters
+    in place, the next no_grad evaluation follows the new values."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(12)
+    beam = ca.ParticleBeam.from_parameters(num_particles=10_000, energy=t(5e7), sigma_p=t(1e-3), **kw)
+
+    def lattice(wrap):
+        els = []
+        for i in range(6):
+            els += [ca.Drift(t(0.3), **kw), ca.Quadrupole(t(0.2), k1=wrap(t(3.0 if i % 2 else -3.0)), **kw),
+                    ca.Cavity(t(1.0377), voltage=wrap(t(18e6)) if i == 2 else t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw),
+                    ca.BPM(is_active=True, misalignment=wrap(t([1e-5, -2e-5])) if i == 3 else t([0.0, 0.0]), **kw)]
+        return ca.Segment(els)
+
+    trainable, plain = lattice(torch.nn.Parameter), lattice(lambda v: v)
+    params = list(trainable.parameters())
+    assert len(params) == 8
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = trainable.track(beam)
+            assert calls == [10_000], calls
+            ref = plain.track(beam)
+        assert torch.equal(out.particles, ref.particles) and torch.equal(out.energy, ref.energy)
+        assert torch.equal(trainable.elements[15].reading, plain.elements[15].reading)
+        # gradients: the same Segment, the differentiable path
+        calls.clear()
+        got = trainable.track(beam)
+        assert calls == [] and got.particles.requires_grad
+        assert torch.allclose(got.particles, out.particles, rtol=1e-4, atol=1e-9)
+        loss = got.particles[:, 0].square().mean() + got.energy * 1e-20 + trainable.elements[15].reading.square().sum()
+        loss.backward()
+        assert all(p.grad is not None and bool(p.grad.abs().sum() > 0) for p in params), [p.grad for p in params]
+        # an optimiser step edits the parameters in place: the plans read the new values
+        with torch.no_grad():
+            for p in params:
+                p.mul_(1.01)
+            calls.clear()
+            out2 = trainable.track(beam)
+            assert calls == [10_000]
+            for e_t, e_p in zip(trainable.elements, plain.elements):
+                for name in ("k1", "voltage", "misalignment"):
+                    if hasattr(e_p, name) and isinstance(getattr(e_t, name), torch.nn.Parameter):
+                        setattr(e_p, name, getattr(e_t, name).detach().clone())
+            ref2 = plain.track(beam)
+        assert torch.equal(out2.particles, ref2.particles) and not torch.equal(out2.particles, out.particles)
+    finally:
+        segment._HOST = old

@@ -307,7 +307,7 @@ def _spy_links(fn):
 @pytest.mark.parametrize("breaker", ["custom_map", "vector_quad", "parameter_quad", "long_run"])
 def test_unfusable_run_ends_the_chain(ca, breaker):
     """A run between two kicks that cannot ride in the kick's particle pass (no device plan: a CustomTransferMap, vectorised
-    settings, a trainable Parameter, more than 192 elements) must END the chain at the kick in front of it: the sums the gather pass
+    settings, a trainable Parameter while gradients are enabled, more than 192 elements) must END the chain at the kick in front of it: the sums the gather pass
     leaves for the next kick's grid describe the rows BEFORE that run, so a chain that went on would build the next grid from
     stale beam sizes (silently wrong). Kicks behind the breaker may start a new chain."""
     dt = torch.float32
@@ -322,7 +322,7 @@ def test_unfusable_run_ends_the_chain(ca, breaker):
         mid = [ca.CustomTransferMap(R, length=t(0.7), **kw)]
     elif breaker == "vector_quad":
         mid = [ca.Quadrupole(t(0.3), k1=torch.tensor([9.0], **kw), **kw), ca.Drift(t(0.8), **kw)]
-    elif breaker == "parameter_quad":      # a trainable strength (tracked under no_grad below: the beam carries no graph)
+    elif breaker == "parameter_quad":      # a trainable strength
         mid = [ca.Quadrupole(t(0.3), k1=torch.nn.Parameter(t(9.0)), **kw), ca.Drift(t(0.8), **kw)]
     else:
         mid = [ca.Drift(t(0.004), **kw) for _ in range(200)] + [quad(9.0), ca.Drift(t(0.6), **kw)]
@@ -332,6 +332,14 @@ def test_unfusable_run_ends_the_chain(ca, breaker):
         # a vectorised run makes the beam behind it vectorised: no chain there (and none needed)
         out, calls = _spy_links(lambda: seg.track(beam))
         assert calls == [(True, False), (False, True)]
+    elif breaker == "parameter_quad":
+        # with gradients enabled the run with the trainable strength has no plan a track may use: the chain ends in front of it
+        _, calls = _spy_links(lambda: seg.track(beam))
+        assert calls[:2] == [(True, False), (False, True)], calls
+        # under no_grad a trainable strength is a setting like any other (the plans read its value): ONE chain of four links
+        with torch.no_grad():
+            out, calls = _spy_links(lambda: seg.track(beam))
+        assert calls == [(True, False), (False, False), (False, False), (False, True)], calls
     else:
         with torch.no_grad():
             out, calls = _spy_links(lambda: seg.track(beam))
