@@ -248,7 +248,7 @@ SIGNATURES = {
     "chx_run_vjp_masked": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_run_map_batched_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int]),
-    "chx_run_map_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t,
+    "chx_run_map_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_double, c_double, c_int, c_void_p, c_size_t,
                                     c_void_p, c_void_p]),
     "chx_run_build_compose": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p,
                                       c_void_p]),

@@ -275,7 +275,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after")
 
     def __init__(self, items, dtype, device, allow_vector=False):
         self.items, self.dtype, self.device = items, dtype, device
@@ -299,6 +299,7 @@ class _LatticePlan:
         rows, elem_kind, elem_poff, ptrs, tensors, bpms, apertures = [], [], [], [], [], [], []
         count = cavities = longest_run = 0
         vshape, bpm_vec, ap_vec = None, [], []
+        bpm_after, ap_after, maps_seen = [], [], False   # does a run / cavity (a map) sit in front of the monitor / aperture?
         for kind, item in self.items:
             if kind != "run" and item._is_aperture:
                 # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
@@ -314,6 +315,7 @@ class _LatticePlan:
                 tensors += limits
                 apertures.append(item)
                 ap_vec.append(vshape is not None)
+                ap_after.append(maps_seen)
                 count += 1
                 continue
             if kind != "run" and item._is_bpm:
@@ -329,6 +331,7 @@ class _LatticePlan:
                 tensors.append(mis)
                 bpms.append(item)
                 bpm_vec.append(vshape is not None)     # does a run with vectorised settings sit in front of this monitor?
+                bpm_after.append(maps_seen)
                 count += 1
                 continue
             if kind == "run":
@@ -362,6 +365,7 @@ class _LatticePlan:
                 if not run_kinds or any(q is None for r in row_ptrs for q in r):
                     break
                 longest_run = max(longest_run, len(run_kinds))
+                maps_seen = True
                 rows += [0, len(run_kinds), len(elem_kind), 0]
                 for e, r in enumerate(row_ptrs):
                     elem_kind.append(run_kinds[e])
@@ -380,10 +384,12 @@ class _LatticePlan:
                 ptrs += [t.data_ptr() for t in settings]
                 tensors += settings
                 cavities += 1
+                maps_seen = True
             count += 1
         # (a trailing run stays in the stretch: it rides in the same particle pass; a trailing BPM reads the outgoing beam)
         self.count = count
         self.bpms, self.apertures, self.bpm_vec, self.ap_vec = tuple(bpms), tuple(apertures), tuple(bpm_vec), tuple(ap_vec)
+        self.bpm_after, self.ap_after = tuple(bpm_after), tuple(ap_after)
         if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
@@ -411,6 +417,20 @@ class _LatticePlan:
         self.shape = (n_items, n_elems, n_ptrs)
         self.tensors = tuple(tensors)       # kept alive: the table holds their addresses
         self.ok = True
+
+
+    def ensure_rows(self, rows: int) -> bool:
+        """Room for `rows` rows of maps in the device state (a scan of beam energies brings its rows with the BEAM, not with the
+        lattice): the state grows when needed and the C host step's capsule follows it."""
+        n_items, n_elems, n_ptrs = self.shape
+        need = _lib.lib().chx_lattice_state_bytes_batched(n_items, n_elems, rows)
+        if need == 0:
+            return False
+        if self.state.numel() * 8 < need:
+            self.state = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
+            self.capsule = _lib.host().lattice_plan(self.table.data_ptr(), n_items, n_elems, n_ptrs, self.state.data_ptr(),
+                                                    self.state.numel() * 8, self.code)
+        return True
 
 
 _CHECK_PLANS = os.environ.get("CHX_CHECK_PLANS", "0") == "1"
@@ -444,11 +464,12 @@ class _Run:
     settings that changed — the tensor lists of the untouched elements, the summed length — is not redone."""
 
     __slots__ = ("elements", "modules", "rev", "per_module", "tensors", "params", "token", "tm", "stack", "length",
-                 "length_key", "energy_ref", "s_cache", "fast", "gfast", "parts")
+                 "length_key", "energy_ref", "s_cache", "fast", "gfast", "parts", "vrows")
 
     def __init__(self, elements):
         self.elements = elements
         self.parts = None         # a run too long for ONE persistent device plan: its pieces (Segment._run_map_parts)
+        self.vrows = None         # the packed tables of Segment._run_map_vector, valid while the epoch stands still
         self.modules = [m for e in elements for m in e.modules() if isinstance(m, Element)]
         self.rev = None
         self.per_module = [None] * len(self.modules)   # (revision, buffers + parameters, parameters) per module
@@ -703,18 +724,18 @@ class Segment(Element):
     def _vector_run_rows(run: _Run, dtype, device):
         """(kinds, per-element setting addresses, per-element flags (1 = a tensor of the common batch shape), tensors, batch shape) of
         a run whose elements all have a device builder and settings that are device scalars or contiguous tensors of ONE shape — or
-        None (a vectorised length, mixed shapes, another dtype / device, gradients, trainable parameters)."""
-        grad = torch.is_grad_enabled()
+        None (a vectorised length, mixed shapes, another dtype / device). Whether a setting requires grad is asked by the caller,
+        per call (`_any_requires_grad(*tensors)`)."""
         kinds, rows, flags, keep, shape = [], [], [], [], None
         for e in run.elements:
             kind = getattr(e, "_chx_kind", None)
-            if kind is None or not e._plannable() or e._parameters:
+            if kind is None or not e._plannable():
                 return None
             if kind == _IDENTITY:
                 continue
             row, fl = [], []
             for k, (t, index) in enumerate(e._builder_scalar_refs()):
-                if t.dtype != dtype or t.device != device or (grad and t.requires_grad):
+                if t.dtype != dtype or t.device != device:
                     return None
                 if index is not None:                      # a component of a vector-valued setting (misalignment[..., i])
                     if t.dim() != 1 or not t.is_contiguous():
@@ -743,18 +764,36 @@ class Segment(Element):
         (`chx_run_map_batched`: a workgroup per batch row builds and composes the row's maps), or None when the run does not
         qualify (no vectorised setting at all, mixed shapes, gradients, a vectorised length or vector component). The general
         path builds every vectorised element's maps on its own: ~100 us of host time per element and step, whatever the batch."""
-        if energy.dim() != 0 or not energy.is_cuda or len(run.elements) > 192:
+        if not energy.is_cuda or len(run.elements) > 192 or (energy.dim() != 0 and not energy.is_contiguous()):
             return None
-        got = Segment._vector_run_rows(run, energy.dtype, energy.device)
-        if got is None:
+        # the packed tables stand while no attribute of any element was assigned (the addresses of the settings; their VALUES are
+        # read by the device on every call): building them anew is ~3 us per element and step
+        c = run.vrows
+        if c is None or c[0] != Element._epoch or c[1] != energy.dtype or c[2] != energy.device:
+            got = Segment._vector_run_rows(run, energy.dtype, energy.device)
+            if got is not None:
+                kinds, rows, row_flags, keep, shape = got
+                ptrs, flags = [], []
+                for r, f in zip(rows, row_flags):
+                    ptrs += r + [None] * (_ops.MAX_PARAMS - len(r))
+                    flags += f + [0] * (_ops.MAX_PARAMS - len(f))
+                E = len(kinds)
+                got = (E, (ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs),
+                       (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), tuple(keep), shape)
+            c = run.vrows = (Element._epoch, energy.dtype, energy.device, got)
+        if c[3] is None:
             return None
-        kinds, rows, row_flags, keep, shape = got
+        E, kinds_arr, ptrs_arr, flags_arr, keep, shape = c[3]
+        if torch.is_grad_enabled() and _any_requires_grad(*keep):
+            return None
+        if energy.dim() != 0:
+            # a scan of BEAM ENERGIES (with scalar settings, or settings vectorised over the same shape): row b's maps are built
+            # for energy b. Element by element that is one builder call per element and step — every cavity in front hands on a
+            # new energy tensor, so nothing is ever cached: 48 elements of a linac 4.7 ms
+            if shape is not None and tuple(energy.shape) != tuple(shape):
+                return None
+            shape = tuple(energy.shape)
         dtype, device = energy.dtype, energy.device
-        ptrs, flags = [], []
-        for r, f in zip(rows, row_flags):
-            ptrs += r + [None] * (_ops.MAX_PARAMS - len(r))
-            flags += f + [0] * (_ops.MAX_PARAMS - len(f))
-        E = len(kinds)
         if shape is None or E == 0:
             return None
         B = _ops.numel(shape)
@@ -763,9 +802,8 @@ class Segment(Element):
         ws_bytes = lib.chx_run_map_batched_workspace_bytes(E, B, code)
         ws = _ops.workspace(ws_bytes, device) if ws_bytes else None
         R = torch.empty((*shape, 7, 7), dtype=dtype, device=device)
-        _ops.check(lib.chx_run_map_batched((ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs),
-                                           (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), E, B, energy.data_ptr(),
-                                           species.mass_eV_float, species.num_elementary_charges_float, code,
+        _ops.check(lib.chx_run_map_batched(kinds_arr, ptrs_arr, flags_arr, E, B, energy.data_ptr(),
+                                           1 if energy.dim() != 0 else 0, species.mass_eV_float, species.num_elementary_charges_float, code,
                                            ws.data_ptr() if ws is not None else None, ws_bytes, R.data_ptr(), _ops.stream_ptr()),
                    "chx_run_map_batched")
         return R
@@ -1078,8 +1116,9 @@ class Segment(Element):
         if p.dim() < 2 or not p.is_cuda or (p.dim() > 2 and not p.is_contiguous()):
             return None                    # (B beams in one ParticleBeam: blockIdx.y of the particle pass)
         e, s_in, sp = incoming.energy, incoming.s, incoming.species
-        if e.dim() != 0 or e.dtype != p.dtype or e.device != p.device:
+        if e.dtype != p.dtype or e.device != p.device or (e.dim() != 0 and not e.is_contiguous()):
             return None
+        energy_rows = e.dim() != 0          # a scan of beam energies: row b of the maps is built for energy b
         lp = entry[1]
         if lp is None or lp.epoch != Element._epoch:
             if torch.cuda.is_current_stream_capturing():
@@ -1104,20 +1143,26 @@ class Segment(Element):
         w_out = incoming.survival_probabilities
         lead_x, N = tuple(p.shape[:-2]), p.shape[-2]
         lead, Bm = lead_x, 1
-        if lp.vshape is not None:
-            # settings vectorised over a scan of the lattice: row b of the outgoing beams = the beam (ONE shared beam, or its own
-            # row b) through row b of the settings — the preparation launch forms the maps of every row, the particle pass picks
-            # its row's by blockIdx.y
+        if lp.vshape is not None or energy_rows:
+            # settings vectorised over a scan of the lattice (and / or a scan of beam energies): row b of the outgoing beams = the
+            # beam (ONE shared beam, or its own row b) through row b of the settings at energy b — the preparation launch forms
+            # the maps of every row, the particle pass picks its row's by blockIdx.y
             try:
-                lead = tuple(torch.broadcast_shapes(lead_x, lp.vshape))
+                lead = tuple(torch.broadcast_shapes(lead_x, lp.vshape if lp.vshape is not None else (), e.shape))
             except RuntimeError:
                 return None
-            if tuple(lp.vshape) != lead or (_ops.numel(lead_x) != 1 and lead_x != lead):
+            if (lp.vshape is not None and tuple(lp.vshape) != lead) or (energy_rows and tuple(e.shape) != lead) \
+                    or (_ops.numel(lead_x) != 1 and lead_x != lead):
                 return None
             Bm = _ops.numel(lead)
+            if Bm > 1 and not lp.small_runs and Bm > Segment._STRETCH_MAX_ROWS:
+                return None       # (a workgroup per (item, row) prepares a stretch with cavities: beyond a few hundred rows the walk)
+            if not lp.ensure_rows(Bm):
+                return None
         B, Bx = _ops.numel(lead), _ops.numel(lead_x)
         if B < 1 or B > 65535:
             return None
+        flags = lp.small_runs | (2 if energy_rows else 0)
         if lp.bpms or lp.apertures or lead:
             # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
             # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —
@@ -1153,17 +1198,17 @@ class Segment(Element):
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, N, e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index, w,
                                                     w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B,
-                                                    Bx, Bm, Bw if w is not None else B, lp.small_runs, out)
+                                                    Bx, Bm, Bw if w is not None else B, flags, out)
             for k, bpm in enumerate(lp.bpms):
                 r = readings[k].reshape(*lead, 2)
-                if lead != lead_x and not lp.bpm_vec[k]:
+                if lead != lead_x and not (lp.bpm_vec[k] or (energy_rows and lp.bpm_after[k])):
                     # a monitor in FRONT of the first vectorised element reads the beam before it was spread over the scan: equal
                     # rows, the reading has the incoming beam's shape (like the walk's)
                     from .cavity import _narrow_to
 
                     r = _narrow_to(r, (*lead_x, 2))
                 bpm.__dict__["_buffers"]["reading"] = r
-            if lp.apertures and lead != lead_x and not any(lp.ap_vec):
+            if lp.apertures and lead != lead_x and not any(lp.ap_vec) and not (energy_rows and any(lp.ap_after)):
                 from .cavity import _narrow_to
 
                 w_out = _narrow_to(w_out, (*lead_x, N))     # (every aperture sits in front of the scan: equal rows)
@@ -1199,8 +1244,9 @@ class Segment(Element):
         if entry is False:
             return None
         e, s_in, sp = incoming.energy, incoming.s, incoming.species
-        if e.dim() != 0 or e.dtype != mu.dtype or e.device != mu.device:
+        if e.dtype != mu.dtype or e.device != mu.device or (e.dim() != 0 and not e.is_contiguous()):
             return None
+        energy_rows = e.dim() != 0          # a scan of beam energies: row b of the maps is built for energy b
         lp = entry[1]
         if lp is None or lp.epoch != Element._epoch:
             if torch.cuda.is_current_stream_capturing():
@@ -1215,12 +1261,16 @@ class Segment(Element):
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
             return None
         try:
-            lead = torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2], lp.vshape if lp.vshape is not None else ())
+            lead = torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2], lp.vshape if lp.vshape is not None else (), e.shape)
         except RuntimeError:
             return None
         B = _ops.numel(lead)
-        Bm = _ops.numel(lp.vshape) if lp.vshape is not None else 1
-        if Bm not in (1, B) or (Bm > 1 and tuple(lp.vshape) != tuple(lead)):
+        if (lp.vshape is not None and tuple(lp.vshape) != tuple(lead)) or (energy_rows and tuple(e.shape) != tuple(lead)):
+            return None
+        Bm = B if (lp.vshape is not None or energy_rows) else 1
+        if Bm > 1 and not lp.small_runs and Bm > Segment._STRETCH_MAX_ROWS:
+            return None
+        if Bm > 1 and not lp.ensure_rows(Bm):
             return None
         m2 = mu.reshape(-1, 7) if mu.is_contiguous() else mu.reshape(-1, 7).contiguous()
         c2 = cov.reshape(-1, 49) if cov.is_contiguous() else cov.reshape(-1, 49).contiguous()
@@ -1237,14 +1287,15 @@ class Segment(Element):
         n_items, n_elems, n_ptrs = lp.shape
         _ops.check(_lib.lib().chx_parameter_lattice_track(
             lp.table.data_ptr(), n_items, n_elems, n_ptrs, e.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float, lp.code,
-            lp.state.data_ptr(), lp.state.numel() * 8, m2.data_ptr(), c2.data_ptr(), B, m2.shape[0], c2.shape[0], Bm, lp.small_runs,
+            lp.state.data_ptr(), lp.state.numel() * 8, m2.data_ptr(), c2.data_ptr(), B, m2.shape[0], c2.shape[0], Bm,
+            lp.small_runs | (2 if energy_rows else 0),
             mu_out.data_ptr(),
             cov_out.data_ptr(), e_out.data_ptr(), s_in.data_ptr() if on_device else None, s_out.data_ptr() if on_device else None,
             n_bpm, readings.data_ptr() if n_bpm else None, _ops.stream_ptr()), "chx_parameter_lattice_track")
         in_lead = tuple(torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2]))
         for k, bpm in enumerate(lp.bpms):
             r = readings[k].reshape(*lead, 2)
-            if lp.vshape is not None and not lp.bpm_vec[k] and in_lead != tuple(lead):
+            if not (lp.bpm_vec[k] or (energy_rows and lp.bpm_after[k])) and in_lead != tuple(lead):
                 # a monitor in FRONT of the first vectorised element sees the beam before it was spread over the lattice settings:
                 # the rows are equal there, the reading has the incoming beam's shape (like the walk's)
                 from .cavity import _narrow_to

@@ -1597,7 +1597,8 @@ extern "C" int chx_run_map(const int32_t* kinds, const void* const* param_ptrs, 
 // it belongs to row b), any other a scalar. No stored state: such settings change with every step.
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void run_map_batched_kernel(RunArgs a, int E, const T* __restrict__ energy, double mass,
-                                                                   double nq, T* __restrict__ maps_ws, T* __restrict__ R) {
+                                                                   double nq, T* __restrict__ maps_ws, T* __restrict__ R,
+                                                                   int energy_rows /*energy is a (B,) array: a scan of beam energies*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char run_lds[];
     const int64_t b = blockIdx.x;
     T* maps = maps_ws ? maps_ws + b * E * 49 : reinterpret_cast<T*>(run_lds);
@@ -1611,7 +1612,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void run_map_batched_kernel(RunArgs a, i
             p[k] = (double)((q & 1) ? base[b] : base[0]);
         }
         Mat7<double> M;
-        build_kind<double>(kind, p, (double)energy[0], mass, nq, M);
+        build_kind<double>(kind, p, (double)energy[energy_rows ? b : 0], mass, nq, M);
         for (int q = 0; q < 49; ++q) maps[e * 49 + q] = (T)M.m[q];
     }
     __syncthreads();
@@ -1630,7 +1631,7 @@ extern "C" size_t chx_run_map_batched_workspace_bytes(int64_t E, int64_t B, int 
 }
 
 extern "C" int chx_run_map_batched(const int32_t* kinds, const void* const* param_ptrs, const uint8_t* batched, int64_t E, int64_t B,
-                                   const void* energy, double mass_eV, double n_charges, int dtype, void* workspace,
+                                   const void* energy, int energy_rows, double mass_eV, double n_charges, int dtype, void* workspace,
                                    size_t workspace_bytes, void* R_out, void* stream) {
     if (!energy || !R_out || !batched || B < 1 || B > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
@@ -1654,10 +1655,10 @@ extern "C" int chx_run_map_batched(const int32_t* kinds, const void* const* para
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(run_map_batched_kernel<float>, dim3((unsigned)B), dim3(CHX_BLOCK), lds, s, a, (int)E, (const float*)energy, mass_eV,
-                           n_charges, need ? (float*)workspace : (float*)nullptr, (float*)R_out);
+                           n_charges, need ? (float*)workspace : (float*)nullptr, (float*)R_out, energy_rows ? 1 : 0);
     else
         hipLaunchKernelGGL(run_map_batched_kernel<double>, dim3((unsigned)B), dim3(CHX_BLOCK), lds, s, a, (int)E, (const double*)energy,
-                           mass_eV, n_charges, need ? (double*)workspace : (double*)nullptr, (double*)R_out);
+                           mass_eV, n_charges, need ? (double*)workspace : (double*)nullptr, (double*)R_out, energy_rows ? 1 : 0);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -1733,7 +1734,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
                                                                    int n_items, int n_elems, const T* __restrict__ energy, double mass, double nq,
                                                                    double* __restrict__ Rs, double* __restrict__ coeffs,
                                                                    double* __restrict__ emaps, T* __restrict__ energy_out,
-                                                                   const T* __restrict__ s_in, T* __restrict__ s_out) {
+                                                                   const T* __restrict__ s_in, T* __restrict__ s_out,
+                                                                   int energy_rows /*energy and energy_out are (rows,) arrays*/) {
     __shared__ double e_in_sh;
     const int b = blockIdx.x;
     // blockIdx.y = row of a batch of lattice settings (gridDim.y = 1: scalar settings): a pointer with its lowest bit set addresses
@@ -1749,7 +1751,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     if (threadIdx.x == 0) {
         // the reference energy this item sees: through the cavities in front of it, rounded to T after each (the energy is a
         // tensor of the beam's dtype between two elements)
-        double e = (double)energy[0];
+        double e = (double)energy[energy_rows ? row : 0];
         for (int i = 0; i < b; ++i) {
             if (items[i * 4] != 1) continue;
             const int64_t po = elem_poff[items[i * 4 + 2]];
@@ -1774,7 +1776,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     const double E0 = e_in_sh;
     T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
     if (type >= 2) {                                       // an active BPM / aperture: nothing to build (lattice_apply_kernel acts there)
-        if (b == n_items - 1 && threadIdx.x == 0 && row == 0) *energy_out = (T)E0;
+        if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_rows)) energy_out[energy_rows ? row : 0] = (T)E0;
         return;
     }
     if (type == 1) {
@@ -1786,11 +1788,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
             for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
             const double dEn = p[1] * cos(p[2] * (kPi / 180.0)) * nq * -1.0;
             const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, dEn > 0.0, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
-            if (b == n_items - 1 && row == 0) *energy_out = (T)E1;
+            if (b == n_items - 1 && (row == 0 || energy_rows)) energy_out[energy_rows ? row : 0] = (T)E1;
         }
         return;
     }
-    if (b == n_items - 1 && threadIdx.x == 0 && row == 0) *energy_out = (T)E0;
+    if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_rows)) energy_out[energy_rows ? row : 0] = (T)E0;
     T* maps = reinterpret_cast<T*>(emaps + (row * (int64_t)n_elems + elem0) * 49);
     for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
         const int kind = (int)elem_kind[elem0 + e];
@@ -1860,7 +1862,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_rows_kernel(const i
                                                                         int n_items, int n_elems, int64_t rows, const T* __restrict__ energy,
                                                                         double mass, double nq, double* __restrict__ Rs,
                                                                         double* __restrict__ emaps, T* __restrict__ energy_out,
-                                                                        const T* __restrict__ s_in, T* __restrict__ s_out) {
+                                                                        const T* __restrict__ s_in, T* __restrict__ s_out,
+                                                                        int energy_rows /*energy and energy_out are (rows,) arrays*/) {
     __shared__ double lds[CHX_BLOCK / 64][5 * 49];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pid = (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave;
@@ -1872,8 +1875,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_rows_kernel(const i
         const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
         return (a & 1) ? base[row] : base[0];
     };
+    if (energy_rows && b == 0 && lane == 0) energy_out[row] = energy[row];       // (no cavity in the stretch)
     if (pid == 0 && lane == 0) {
-        *energy_out = energy[0];                            // (no cavity in the stretch)
+        if (!energy_rows) *energy_out = energy[0];
         if (s_out) {
             T sv = *s_in;
             for (int i = 0; i < n_items; ++i) {
@@ -1888,7 +1892,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_rows_kernel(const i
     }
     if (items[b * 4] != 0) return;
     const int E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
-    const double E0 = (double)energy[0];
+    const double E0 = (double)energy[energy_rows ? row : 0];
     T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
     T* maps = reinterpret_cast<T*>(emaps + (row * (int64_t)n_elems + elem0) * 49);
     if (lane < E) {
@@ -1932,6 +1936,8 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
                                         void* energy_out, const void* s_in, void* s_out, void* stream) {
     if (!table || !energy || !state || !energy_out || ((s_in == nullptr) != (s_out == nullptr)) || n_ptrs < n_elems)
         return CHX_ERR_INVALID_ARG;
+    const int energy_rows = (small_runs & CHX_LATTICE_ENERGY_ROWS) ? 1 : 0;   // bit 1: energy / energy_out are (rows,) arrays
+    small_runs &= 1;
     const size_t need = chx_lattice_state_bytes_batched(n_items, n_elems, rows);
     if (need == 0) return CHX_ERR_INVALID_ARG;
     if (state_bytes < need) return CHX_ERR_WORKSPACE;
@@ -1950,11 +1956,11 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
         if (dtype == CHX_F32)
             hipLaunchKernelGGL(lattice_prepare_rows_kernel<float>, dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs, (int)n_items,
                                (int)n_elems, rows, (const float*)energy, mass_eV, n_charges, Rs, emaps, (float*)energy_out,
-                               (const float*)s_in, (float*)s_out);
+                               (const float*)s_in, (float*)s_out, energy_rows);
         else
             hipLaunchKernelGGL(lattice_prepare_rows_kernel<double>, dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
                                (int)n_items, (int)n_elems, rows, (const double*)energy, mass_eV, n_charges, Rs, emaps, (double*)energy_out,
-                               (const double*)s_in, (double*)s_out);
+                               (const double*)s_in, (double*)s_out, energy_rows);
         CHX_CHECK_LAUNCH();
         return CHX_OK;
     }
@@ -1962,11 +1968,11 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(lattice_prepare_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
                            (int)n_items, (int)n_elems, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
-                           (const float*)s_in, (float*)s_out);
+                           (const float*)s_in, (float*)s_out, energy_rows);
     else
         hipLaunchKernelGGL(lattice_prepare_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
                            ptrs, (int)n_items, (int)n_elems, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
-                           (const double*)s_in, (double*)s_out);
+                           (const double*)s_in, (double*)s_out, energy_rows);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

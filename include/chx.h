@@ -131,12 +131,13 @@ int chx_run_vjp_masked(const int32_t* kinds, const void* const* param_ptrs, int6
 /* A merged run whose settings are VECTORISED over B lattice settings (segment.py:534-547 with (B,) parameters: a k1 scan, a batched
  * environment, an orbit response): all B composed maps R_out[B][7][7] in one launch — per row the element maps of chx_build_rmatrix
  * and the product of chx_compose_maps, bit-identical to those calls. batched[E][CHX_MAX_PARAMS]: 1 = the pointer addresses a
- * contiguous (B,) array of `dtype`, 0 = a scalar; the energy and every length (parameter 0) are scalars.
+ * contiguous (B,) array of `dtype`, 0 = a scalar; every length (parameter 0) is a scalar; energy_rows != 0: `energy` is a (B,)
+ * array as well (a scan of beam energies, with or without vectorised settings), else a scalar.
  * workspace: chx_run_map_batched_workspace_bytes(E, B, dtype) bytes (0 when a row's element maps fit the LDS). */
 size_t chx_run_map_batched_workspace_bytes(int64_t E, int64_t B, int dtype);
 int chx_run_map_batched(const int32_t* kinds, const void* const* param_ptrs, const uint8_t* batched, int64_t E, int64_t B,
-                        const void* energy, double mass_eV, double n_charges, int dtype, void* workspace, size_t workspace_bytes,
-                        void* R_out, void* stream);
+                        const void* energy, int energy_rows, double mass_eV, double n_charges, int dtype, void* workspace,
+                        size_t workspace_bytes, void* R_out, void* stream);
 /* Forward of the same run in one call: chx_build_rmatrix_scalars into maps[E][7][7] (kept for chx_run_vjp) followed by
  * chx_compose_maps of that stack into R_out[7][7]; bit-identical to the two calls (segment.py:534-543). E <= 4096. */
 int chx_run_build_compose(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
@@ -603,8 +604,14 @@ size_t chx_lattice_state_bytes_batched(int64_t n_items, int64_t n_elems, int64_t
 int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, const void* energy,
                                 double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, void* energy_out,
                                 const void* s_in, void* s_out, void* stream);
-/* small_runs != 0: the caller vouches that the stretch holds no cavity and no run of more than 64 elements — a wave per (item, row)
- * prepares the maps instead of a workgroup (300 000 of them for 75 items x 4096 rows); the same results. */
+/* small_runs is a set of flags. Bit 0 (CHX_LATTICE_SMALL_RUNS): the caller vouches that the stretch holds no cavity and no run of
+ * more than 64 elements — a wave per (item, row) prepares the maps instead of a workgroup (300 000 of them for 75 items x 4096
+ * rows); the same results. Bit 1 (CHX_LATTICE_ENERGY_ROWS): `energy` and `energy_out` are (rows,) arrays — a scan of BEAM ENERGIES,
+ * row r of the maps, coefficient rows and outgoing energies belongs to energy r (cavity.py:113-122 per row; the second-order
+ * path-length switch of cavity.py:157 depends on the cavity's settings only, which are scalars here). The same flags travel through
+ * the `small_runs` argument of chx_lattice_track_diag and chx_parameter_lattice_track. */
+#define CHX_LATTICE_SMALL_RUNS 1
+#define CHX_LATTICE_ENERGY_ROWS 2
 int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                              const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
                              void* energy_out, const void* s_in, void* s_out, void* stream);

@@ -813,3 +813,52 @@ def test_vectorised_settings_of_a_run_in_one_launch(ca, dt):
     gseg = ca.Segment([ca.Quadrupole(t(0.1), k1=k, **kw), ca.Drift(t(0.5), **kw)])
     gseg.track(beam).sigma_x.sum().backward()
     assert k.grad is not None and torch.isfinite(k.grad).all()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("with_vector_settings", [False, True])
+def test_energy_scan_maps_in_one_launch(dt, with_vector_settings):
+    """A scan of BEAM ENERGIES — `energy` a (B,) tensor, lattice settings scalar or vectorised over the same shape: the composed maps
+    of a run for all B energies from one launch (chx_run_map_batched with energy_rows), bit for bit the per-element builders +
+    chx_compose_maps of the general path; a ParticleBeam and a ParameterBeam tracked through both agree bit for bit, a fresh energy
+    tensor per track included (nothing to cache)."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator.segment import Segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(17)
+    B = 37
+    els = []
+    for i in range(30):
+        k1 = torch.randn(B, **kw) * 4 if (with_vector_settings and i % 7 == 3) else t(4.2 if i % 2 == 0 else -4.2)
+        els += [ca.Quadrupole(t(0.2), k1=k1, misalignment=t([1e-4, -2e-4]) if i == 5 else None, **kw), ca.Drift(t(0.8), **kw)]
+        if i % 10 == 4:
+            els += [ca.Dipole(t(0.3), angle=t(0.02), dipole_e1=t(0.01), **kw), ca.HorizontalCorrector(t(0.05), angle=t(1e-4), **kw)]
+    seg = ca.Segment(els)
+    energy = torch.linspace(6e7, 1.4e8, B, **kw)
+    beam = ca.ParticleBeam.from_parameters(num_particles=2_000, energy=energy, **kw)
+    pbeam = ca.ParameterBeam.from_parameters(energy=energy, sigma_p=t(1e-3), **kw)
+    run = seg._plan()[0][1]
+    calls = []
+    orig = Segment._run_map_vector
+    try:
+        Segment._run_map_vector = staticmethod(lambda run, energy, species: (lambda r: (calls.append(r is not None), r)[1])(orig(run, energy, species)))
+        with torch.no_grad():
+            out, pout = seg.track(beam), seg.track(pbeam)
+            fresh = seg.track(ca.ParticleBeam(beam.particles, energy.clone(), particle_charges=beam.particle_charges, **kw))
+        assert calls and all(calls), calls
+        got = orig(run, energy, beam.species)
+        Segment._run_map_vector = staticmethod(lambda run, energy, species: None)
+        ca.Element._epoch += 1
+        run.token = run.tm = None
+        with torch.no_grad():
+            ref, pref = seg.track(beam), seg.track(pbeam)
+            want = Segment._run_map(run, energy.clone(), beam.species)
+    finally:
+        Segment._run_map_vector = orig
+        ca.Element._epoch += 1
+    assert got.shape == want.shape == (B, 7, 7) and torch.equal(got, want)
+    assert out.particles.shape == (B, 2_000, 7) and torch.equal(out.particles, ref.particles) and torch.equal(fresh.particles, ref.particles)
+    assert torch.equal(pout.mu, pref.mu) and torch.equal(pout.cov, pref.cov)
+    assert (out.particles[0] - out.particles[-1]).abs().max() > 1e-6          # the rows see different energies
