@@ -5,7 +5,7 @@ quadrupole strengths and corrector angles are (4,) tensors — four lattice sett
 list as JSON (a vectorised setting is a list of four numbers), 1200 incoming particles with drawn survival probabilities and what
 the reference leaves in float64: the (4, 1200, 7) outgoing particles, the survival probabilities (whatever shape they have),
 energy, s and EVERY monitor's reading with its own shape ((2,) in front of the first vectorised element, (4, 2) behind); the same
-scan for a ParameterBeam.
+scan for a ParameterBeam; and both once more with a (4,) BEAM ENERGY on top (`lat*_escan_*`: a scan of energies through the cavities).
 Run in the build container:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden_scan_stretch.py
 """
 import json
@@ -64,6 +64,7 @@ def build(module, spec, fk):
 
 if __name__ == "__main__":
     arrays = {"n_lattices": np.asarray(6), "rows": np.asarray(ROWS)}
+    torch.manual_seed(299)          # (from_parameters draws from torch's generator: lattice 0 too starts from a fixed state)
     for i in range(6):
         with_cav, with_ap = i % 2 == 1, i >= 3
         specs = [["Drift", {"length": u(0.1, 0.5)}], ["BPM", {"is_active": True, "misalignment": [1e-4, -1e-4]}]]   # a monitor in front of the scan
@@ -111,6 +112,25 @@ if __name__ == "__main__":
         arrays[f"lat{i}_pb_cov"] = pout.cov.numpy()
         for k, b in enumerate(bpms):
             arrays[f"lat{i}_pb_reading{k}"] = b.reading.numpy()
+        # the same lattice under a scan of BEAM ENERGIES (a (4,) energy on top of the vectorised settings), particles and moments
+        escan = torch.tensor([float(energy) * f for f in (0.7, 0.9, 1.15, 1.4)], **f64)
+        ebeam = cheetah.ParticleBeam(beam.particles, escan, particle_charges=beam.particle_charges, survival_probabilities=w, **f64)
+        eout = seg.track(ebeam)
+        arrays[f"lat{i}_escan_energy"] = escan.numpy()
+        arrays[f"lat{i}_escan_out"] = eout.particles.numpy()
+        arrays[f"lat{i}_escan_w_out"] = eout.survival_probabilities.numpy()
+        arrays[f"lat{i}_escan_energy_out"] = eout.energy.numpy()
+        for k, b in enumerate(bpms):
+            arrays[f"lat{i}_escan_reading{k}"] = b.reading.numpy()
+        epb = cheetah.ParameterBeam(pb.mu, pb.cov, escan, **f64)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            epout = seg.track(epb)
+        arrays[f"lat{i}_escan_pb_mu"] = epout.mu.numpy()
+        arrays[f"lat{i}_escan_pb_cov"] = epout.cov.numpy()
+        arrays[f"lat{i}_escan_pb_energy"] = epout.energy.numpy()
+        for k, b in enumerate(bpms):
+            arrays[f"lat{i}_escan_pb_reading{k}"] = b.reading.numpy()
         print(i, len(specs), "elements,", len(bpms), "monitors, w_out", tuple(out.survival_probabilities.shape),
               "lost per row", (out.survival_probabilities == 0).sum(dim=-1).tolist(), "readings", [tuple(b.reading.shape) for b in bpms])
     np.savez_compressed(os.path.join(OUT, "scan_stretch.npz"), **arrays)

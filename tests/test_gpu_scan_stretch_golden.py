@@ -3,7 +3,7 @@ tests/golden/generate_golden_scan_stretch.py): six drawn lattices with active mo
 quadrupole strengths and corrector angles (4,) tensors. Each is ONE stretch call here (chx_lattice_track_diag with Bm = 4 rows of
 maps and one shared incoming beam; chx_parameter_lattice_track for the ParameterBeam): the (4, 1200, 7) outgoing particles, survival
 probabilities and their SHAPE, energy, s and every monitor's reading with the reference's shape — (2,) in front of the first
-vectorised element, (4, 2) behind (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
+vectorised element, (4, 2) behind; and both once more under a (4,) BEAM ENERGY (`lat*_escan_*`) (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
 (worst of the six lattices): float64 particles 5.8e-15, readings 6.8e-17, ParameterBeam 4.6e-16; float32 4.1e-7 / 1.3e-8 / 3.2e-7;
 the bounds are those of test_gpu_diagnostics_stretch_golden.py."""
 import json
@@ -98,7 +98,49 @@ def test_scans_with_particles_vs_reference(dt):
                 r_got = b.reading.double().cpu().numpy()
                 assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
                 assert np.abs(r_got - r_ref).max() < (5e-15 if f64 else 1.5e-6) * (np.abs(mu_ref[..., :6]).max() + np.abs(r_ref).max())
+            # a (4,) BEAM ENERGY on top of the vectorised settings: row b at energy b through the cavities
+            escan = t(g[f"lat{i}_escan_energy"])
+            ebeam = ca.ParticleBeam(t(g[f"lat{i}_in"]), escan, particle_charges=t(g[f"lat{i}_q"]), survival_probabilities=t(g[f"lat{i}_w"]), **fk)
+            stretch_calls.clear()
+            with torch.no_grad():
+                eout = seg.track(ebeam)
+            assert stretch_calls == [20], (i, stretch_calls)
+            eref = g[f"lat{i}_escan_out"]
+            assert tuple(eout.particles.shape) == eref.shape
+            err = (np.abs(eout.particles.double().cpu().numpy() - eref) / np.abs(eref).max(axis=(0, 1))).max()
+            worst["escan"] = max(worst.get("escan", 0.0), err)
+            assert err < (1e-13 if f64 else 3e-6), (i, err)
+            ew_ref, ew_got = g[f"lat{i}_escan_w_out"], eout.survival_probabilities.double().cpu().numpy()
+            assert ew_got.shape == ew_ref.shape
+            if f64:
+                assert np.array_equal(ew_got, ew_ref)
+            e_ref = g[f"lat{i}_escan_energy_out"]
+            assert tuple(eout.energy.shape) == e_ref.shape and np.allclose(eout.energy.double().cpu().numpy(), e_ref, rtol=1e-13 if f64 else 1e-6, atol=0)
+            esize = np.abs(eref[..., [0, 2]]).max()
+            for k, b in enumerate(bpms):
+                r_ref, r_got = g[f"lat{i}_escan_reading{k}"], b.reading.double().cpu().numpy()
+                assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                live = np.isfinite(r_ref)
+                assert np.array_equal(np.isfinite(r_got), live)
+                if live.any():
+                    assert np.abs(r_got[live] - r_ref[live]).max() / (esize + np.abs(r_ref[live]).max()) < (1e-15 if f64 else 3e-7), (i, k)
+            epb = ca.ParameterBeam(t(g[f"lat{i}_pb_mu_in"]), t(g[f"lat{i}_pb_cov_in"]), escan, **fk)
+            with warnings.catch_warnings(), torch.no_grad():
+                warnings.simplefilter("ignore")
+                epout = seg.track(epb)
+            emu, ecov = g[f"lat{i}_escan_pb_mu"], g[f"lat{i}_escan_pb_cov"]
+            assert tuple(epout.mu.shape) == emu.shape and tuple(epout.cov.shape) == ecov.shape
+            e1 = np.abs(epout.mu.double().cpu().numpy() - emu).max() / np.abs(emu[..., :6]).max()
+            e2 = np.abs(epout.cov.double().cpu().numpy() - ecov).max() / np.abs(ecov).max()
+            worst["escan_pb"] = max(worst.get("escan_pb", 0.0), e1, e2)
+            assert max(e1, e2) < (5e-15 if f64 else 1.5e-6), (i, e1, e2)
+            assert np.allclose(epout.energy.double().cpu().numpy(), g[f"lat{i}_escan_pb_energy"], rtol=1e-13 if f64 else 1e-6, atol=0)
+            for k, b in enumerate(bpms):
+                r_ref, r_got = g[f"lat{i}_escan_pb_reading{k}"], b.reading.double().cpu().numpy()
+                assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                assert np.abs(r_got - r_ref).max() < (5e-15 if f64 else 1.5e-6) * (np.abs(emu[..., :6]).max() + np.abs(r_ref).max())
     finally:
         segment._HOST = old
+    print(f"energy scans vs reference ({dt}): worst particles {worst.get('escan', 0):.2e}, parameter beam {worst.get('escan_pb', 0):.2e}")
     print(f"scans vs reference ({dt}): worst particles {worst['particles']:.2e}, readings {worst['readings']:.2e}, "
           f"parameter beam {worst['pb']:.2e}")

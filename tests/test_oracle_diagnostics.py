@@ -109,3 +109,26 @@ def test_oracle_walks_the_scans_row_by_row_like_the_reference(oracle):
                     assert np.abs(readings[k] - r_ref).max() / (size + np.abs(r_ref).max()) < 1e-12, (i, b, k)
                 else:
                     assert not np.isfinite(readings[k]).all()
+
+
+def test_oracle_walks_the_energy_scans_row_by_row_like_the_reference(oracle):
+    """The `lat*_escan_*` arrays of tests/golden/scan_stretch.npz: a (4,) beam energy on top of the (4,) settings = four scalar walks
+    of the oracle, each at its own energy (the outgoing energies through the cavities included)."""
+    g = np.load(os.path.join(GOLDEN, "scan_stretch.npz"))
+    rows = int(g["rows"])
+    for i in range(int(g["n_lattices"])):
+        specs = json.loads(str(g[f"lat{i}_spec"]))
+        ref, w_ref, e_ref = g[f"lat{i}_escan_out"], g[f"lat{i}_escan_w_out"], g[f"lat{i}_escan_energy_out"]
+        for b in range(rows):
+            row = [[k, {q: (v[b] if isinstance(v, list) and len(v) == rows and q in ("k1", "angle") else v) for q, v in kw.items()}] for k, kw in specs]
+            x, w, E, s, readings = _walk(oracle, row, g[f"lat{i}_in"], g[f"lat{i}_w"], float(g[f"lat{i}_escan_energy"][b]))
+            err = (np.abs(x - ref[b]).max(axis=0) / np.abs(ref[b]).max(axis=0)).max()
+            assert err < 1e-11, (i, b, err)
+            assert np.array_equal(w, w_ref[b] if w_ref.ndim == 2 else w_ref), (i, b)
+            assert E == pytest.approx(float(e_ref[b]), rel=1e-13)
+            size = np.abs(ref[b][:, [0, 2]]).max()
+            for k in range(int(g[f"lat{i}_n_bpms"])):
+                r_ref = g[f"lat{i}_escan_reading{k}"]
+                r_ref = r_ref[b] if r_ref.ndim == 2 else r_ref
+                if np.isfinite(r_ref).all():
+                    assert np.abs(readings[k] - r_ref).max() / (size + np.abs(r_ref).max()) < 1e-12, (i, b, k)
