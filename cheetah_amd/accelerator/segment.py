@@ -275,7 +275,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows")
 
     def __init__(self, items, dtype, device, allow_vector=False):
         self.items, self.dtype, self.device = items, dtype, device
@@ -300,6 +300,7 @@ class _LatticePlan:
         count = cavities = longest_run = 0
         vshape, bpm_vec, ap_vec = None, [], []
         bpm_after, ap_after, maps_seen = [], [], False   # does a run / cavity (a map) sit in front of the monitor / aperture?
+        e_out_rows = False       # a cavity with a vectorised voltage or phase: the outgoing energy has the batch shape
         for kind, item in self.items:
             if kind != "run" and item._is_aperture:
                 # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
@@ -376,12 +377,29 @@ class _LatticePlan:
                 if type(item).track is not Cavity.track:
                     break
                 settings = item._settings("length", "voltage", "phase", "frequency")
-                if any(t.dim() != 0 or t.dtype != dtype or t.device != device for t in settings):
+                if any(t.dtype != dtype or t.device != device for t in settings):
                     break
+                # a PHASE (voltage, frequency) scan: the setting is a tensor of the stretch's one batch shape, its address tagged
+                # like a vectorised magnet strength; the cavity then hands on one energy per row
+                cav_ptrs, cav_shape, fits = [], vshape, True
+                for k, t in enumerate(settings):
+                    if t.dim() == 0:
+                        cav_ptrs.append(t.data_ptr())
+                    elif not self.allow_vector or k == 0 or not t.is_contiguous() or (cav_shape is not None and tuple(t.shape) != tuple(cav_shape)) \
+                            or _ops.numel(t.shape) > 65535:
+                        fits = False
+                        break
+                    else:
+                        cav_shape = tuple(t.shape)
+                        cav_ptrs.append(t.data_ptr() | 1)
+                        e_out_rows = e_out_rows or k in (1, 2)
+                if not fits:
+                    break
+                vshape = cav_shape
                 rows += [1, 1, len(elem_kind), 0]
                 elem_kind.append(_ops.KIND[item._kind_name()])
                 elem_poff.append(len(ptrs))
-                ptrs += [t.data_ptr() for t in settings]
+                ptrs += cav_ptrs
                 tensors += settings
                 cavities += 1
                 maps_seen = True
@@ -390,6 +408,7 @@ class _LatticePlan:
         self.count = count
         self.bpms, self.apertures, self.bpm_vec, self.ap_vec = tuple(bpms), tuple(apertures), tuple(bpm_vec), tuple(ap_vec)
         self.bpm_after, self.ap_after = tuple(bpm_after), tuple(ap_after)
+        self.e_out_rows = e_out_rows
         if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
@@ -1162,7 +1181,7 @@ class Segment(Element):
         B, Bx = _ops.numel(lead), _ops.numel(lead_x)
         if B < 1 or B > 65535:
             return None
-        flags = lp.small_runs | (2 if energy_rows else 0)
+        flags = lp.small_runs | (2 if energy_rows else 0) | (4 if lp.e_out_rows else 0)
         if lp.bpms or lp.apertures or lead:
             # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
             # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —
@@ -1198,7 +1217,8 @@ class Segment(Element):
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, N, e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index, w,
                                                     w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B,
-                                                    Bx, Bm, Bw if w is not None else B, flags, out)
+                                                    Bx, Bm, Bw if w is not None else B, flags, out,
+                                                    torch.empty(lead, dtype=p.dtype, device=p.device) if (lp.e_out_rows and not energy_rows) else None)
             for k, bpm in enumerate(lp.bpms):
                 r = readings[k].reshape(*lead, 2)
                 if lead != lead_x and not (lp.bpm_vec[k] or (energy_rows and lp.bpm_after[k])):
@@ -1280,7 +1300,7 @@ class Segment(Element):
         on_device = s_in.dim() == 0 and s_in.dtype == mu.dtype and s_in.device == mu.device and not s_in.requires_grad
         mu_out = torch.empty((*lead, 7), dtype=mu.dtype, device=mu.device)
         cov_out = torch.empty((*lead, 7, 7), dtype=mu.dtype, device=mu.device)
-        e_out = torch.empty_like(e)
+        e_out = torch.empty(tuple(lead), dtype=e.dtype, device=e.device) if (lp.e_out_rows and not energy_rows) else torch.empty_like(e)
         s_out = torch.empty_like(s_in) if on_device else None
         n_bpm = len(lp.bpms)
         readings = torch.empty((n_bpm, B, 2), dtype=mu.dtype, device=mu.device) if n_bpm else None
@@ -1288,7 +1308,7 @@ class Segment(Element):
         _ops.check(_lib.lib().chx_parameter_lattice_track(
             lp.table.data_ptr(), n_items, n_elems, n_ptrs, e.data_ptr(), sp.mass_eV_float, sp.num_elementary_charges_float, lp.code,
             lp.state.data_ptr(), lp.state.numel() * 8, m2.data_ptr(), c2.data_ptr(), B, m2.shape[0], c2.shape[0], Bm,
-            lp.small_runs | (2 if energy_rows else 0),
+            lp.small_runs | (2 if energy_rows else 0) | (4 if lp.e_out_rows else 0),
             mu_out.data_ptr(),
             cov_out.data_ptr(), e_out.data_ptr(), s_in.data_ptr() if on_device else None, s_out.data_ptr() if on_device else None,
             n_bpm, readings.data_ptr() if n_bpm else None, _ops.stream_ptr()), "chx_parameter_lattice_track")

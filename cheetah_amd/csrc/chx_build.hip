@@ -1735,7 +1735,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
                                                                    double* __restrict__ Rs, double* __restrict__ coeffs,
                                                                    double* __restrict__ emaps, T* __restrict__ energy_out,
                                                                    const T* __restrict__ s_in, T* __restrict__ s_out,
-                                                                   int energy_rows /*energy and energy_out are (rows,) arrays*/) {
+                                                                   int energy_rows /*energy is a (rows,) array*/,
+                                                                   int energy_out_rows /*energy_out is a (rows,) array*/) {
     __shared__ double e_in_sh;
     const int b = blockIdx.x;
     // blockIdx.y = row of a batch of lattice settings (gridDim.y = 1: scalar settings): a pointer with its lowest bit set addresses
@@ -1743,11 +1744,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     // coefficient rows of row r sit behind those of the rows before it: Rs[(item * rows + r)], emaps[r][element].
     const int64_t row = blockIdx.y, rows = gridDim.y;
     const int type = (int)items[b * 4], E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
-    auto setting = [&](int64_t q) {
+    auto setting_of = [&](int64_t q, int64_t r) {
         const uintptr_t a = (uintptr_t)ptrs[q];
         const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
-        return (a & 1) ? base[row] : base[0];
+        return (a & 1) ? base[r] : base[0];
     };
+    auto setting = [&](int64_t q) { return setting_of(q, row); };
     if (threadIdx.x == 0) {
         // the reference energy this item sees: through the cavities in front of it, rounded to T after each (the energy is a
         // tensor of the beam's dtype between two elements)
@@ -1776,10 +1778,24 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     const double E0 = e_in_sh;
     T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
     if (type >= 2) {                                       // an active BPM / aperture: nothing to build (lattice_apply_kernel acts there)
-        if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_rows)) energy_out[energy_rows ? row : 0] = (T)E0;
+        if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E0;
         return;
     }
     if (type == 1) {
+        // cavity.py:157 switches the second-order path-length terms on for the WHOLE batch when ANY row gains energy: with a
+        // vectorised voltage or phase the rows of this cavity are looked at together (uniform branch: one item per workgroup)
+        int gains = 0;
+        {
+            const int64_t po = elem_poff[elem0];
+            const bool vec = (((uintptr_t)ptrs[po + 1]) | ((uintptr_t)ptrs[po + 2])) & 1;
+            if (vec) {
+                for (int64_t r = threadIdx.x; r < rows; r += CHX_BLOCK)
+                    gains |= ((double)setting_of(po + 1, r) * cos((double)setting_of(po + 2, r) * (kPi / 180.0)) * nq * -1.0) > 0.0;
+                gains = __syncthreads_or(gains);
+            } else {
+                gains = ((double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0) > 0.0;
+            }
+        }
         if (threadIdx.x == 0) {
             const int64_t po = elem_poff[elem0];
             const double p[4] = {(double)setting(po), (double)setting(po + 1), (double)setting(po + 2), (double)setting(po + 3)};
@@ -1787,12 +1803,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
             build_kind<double>((int)elem_kind[elem0], p, E0, mass, nq, M);
             for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
             const double dEn = p[1] * cos(p[2] * (kPi / 180.0)) * nq * -1.0;
-            const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, dEn > 0.0, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
-            if (b == n_items - 1 && (row == 0 || energy_rows)) energy_out[energy_rows ? row : 0] = (T)E1;
+            (void)dEn;
+            const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, gains != 0, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
+            if (b == n_items - 1 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E1;
         }
         return;
     }
-    if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_rows)) energy_out[energy_rows ? row : 0] = (T)E0;
+    if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E0;
     T* maps = reinterpret_cast<T*>(emaps + (row * (int64_t)n_elems + elem0) * 49);
     for (int e = threadIdx.x; e < E; e += CHX_BLOCK) {
         const int kind = (int)elem_kind[elem0 + e];
@@ -1937,6 +1954,9 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
     if (!table || !energy || !state || !energy_out || ((s_in == nullptr) != (s_out == nullptr)) || n_ptrs < n_elems)
         return CHX_ERR_INVALID_ARG;
     const int energy_rows = (small_runs & CHX_LATTICE_ENERGY_ROWS) ? 1 : 0;   // bit 1: energy / energy_out are (rows,) arrays
+    // bit 2: energy_out alone is a (rows,) array (a cavity with a vectorised voltage or phase behind a scalar incoming energy)
+    const int energy_out_rows = (energy_rows || (small_runs & CHX_LATTICE_ENERGY_OUT_ROWS)) ? 1 : 0;
+    if (energy_out_rows != energy_rows && (small_runs & 1)) return CHX_ERR_INVALID_ARG;       // (no cavity in a small-runs stretch)
     small_runs &= 1;
     const size_t need = chx_lattice_state_bytes_batched(n_items, n_elems, rows);
     if (need == 0) return CHX_ERR_INVALID_ARG;
@@ -1968,11 +1988,11 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(lattice_prepare_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
                            (int)n_items, (int)n_elems, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
-                           (const float*)s_in, (float*)s_out, energy_rows);
+                           (const float*)s_in, (float*)s_out, energy_rows, energy_out_rows);
     else
         hipLaunchKernelGGL(lattice_prepare_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
                            ptrs, (int)n_items, (int)n_elems, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
-                           (const double*)s_in, (double*)s_out, energy_rows);
+                           (const double*)s_in, (double*)s_out, energy_rows, energy_out_rows);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

@@ -161,12 +161,13 @@ static PyObject* host_lattice_plan(PyObject* self, PyObject* args) {
  * the seven optional arguments: B beams of N particles (x: (B, N, 7) contiguous) and / or a stretch with active BPMs / apertures —
  * survival_out (B, N), readings (n_bpm, B, 2) and the workspace are the caller's tensors */
 static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
-    if (nargs != 8 && nargs != 15 && nargs != 20) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8, 15 or 20 arguments"); return NULL; }
+    if (nargs != 8 && nargs != 15 && nargs != 20 && nargs != 21) { PyErr_SetString(PyExc_TypeError, "lattice_track takes 8, 15, 20 or 21 arguments"); return NULL; }
     void *surv = NULL, *surv_out = NULL, *readings = NULL, *bws = NULL;
     long long n_bpm = 0, beams = 1, bx = -1, bm = 1, bw = -1, small_runs = 0;
     unsigned long long bws_bytes = 0;
-    PyObject* out_given = NULL;
-    if (nargs == 20) {           /* ..., Bx, Bm, Bw, small_runs, out: vectorised lattice settings / one beam shared by the rows */
+    PyObject *out_given = NULL, *e_out_given = NULL;   /* (21st: the outgoing energies, when their shape is not the incoming one's) */
+    if (nargs == 21 && args[20] != Py_None) e_out_given = args[20];
+    if (nargs >= 20) {           /* ..., Bx, Bm, Bw, small_runs, out: vectorised lattice settings / one beam shared by the rows */
         bx = PyLong_AsLongLong(args[15]);
         bm = PyLong_AsLongLong(args[16]);
         bw = PyLong_AsLongLong(args[17]);
@@ -196,7 +197,9 @@ static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ss
     if (out_given) { out = out_given; Py_INCREF(out); }
     else out = PyObject_CallOneArg(g_empty_like, x);
     if (!out) return NULL;
-    PyObject* e_out = PyObject_CallOneArg(g_empty_like, energy);
+    PyObject* e_out;
+    if (e_out_given) { e_out = e_out_given; Py_INCREF(e_out); }
+    else e_out = PyObject_CallOneArg(g_empty_like, energy);
     if (!e_out) { Py_DECREF(out); return NULL; }
     PyObject* s_out = Py_None;
     if (s_in != Py_None) {

@@ -609,9 +609,12 @@ int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items, int64_t n
  * rows); the same results. Bit 1 (CHX_LATTICE_ENERGY_ROWS): `energy` and `energy_out` are (rows,) arrays — a scan of BEAM ENERGIES,
  * row r of the maps, coefficient rows and outgoing energies belongs to energy r (cavity.py:113-122 per row; the second-order
  * path-length switch of cavity.py:157 depends on the cavity's settings only, which are scalars here). The same flags travel through
- * the `small_runs` argument of chx_lattice_track_diag and chx_parameter_lattice_track. */
+ * the `small_runs` argument of chx_lattice_track_diag and chx_parameter_lattice_track. Bit 2 (CHX_LATTICE_ENERGY_OUT_ROWS):
+ * `energy_out` alone is a (rows,) array — a cavity whose voltage or phase is vectorised (tagged addresses) hands on one energy per
+ * row; cavity.py:157's `(delta_energy > 0).any()` is then taken over the rows of that cavity. */
 #define CHX_LATTICE_SMALL_RUNS 1
 #define CHX_LATTICE_ENERGY_ROWS 2
+#define CHX_LATTICE_ENERGY_OUT_ROWS 4
 int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                              const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
                              void* energy_out, const void* s_in, void* s_out, void* stream);

@@ -810,3 +810,77 @@ def test_energy_scan_rides_in_the_stretch(dt, with_vector_settings, with_cavitie
         assert torch.all((g - w).abs() <= 2 * eps * (w + bpms[k].misalignment).abs() + order), k
         assert torch.equal(pg, pw), k
     assert (out.particles[0] - out.particles[-1]).abs().max() > 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("scanned", ["phase_of_one", "phase_and_voltage_of_all", "frequency_of_one", "decelerating_rows"])
+def test_cavity_scans_ride_in_the_stretch(dt, scanned):
+    """A PHASE / voltage / frequency scan of cavities — the setting a (B,) tensor — stays ONE stretch call: row b of the beam through
+    row b of the cavity's settings, the outgoing energy one per row (cavity.py:113-122), `(delta_energy > 0).any()` of cavity.py:157
+    taken over the rows of that cavity (rows that lose energy next to rows that gain it). Particles, moments, energies, s bit for bit
+    as the walk item by item; readings with the walk's shapes ((2,) in front of the first scanned cavity)."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+    from cheetah_amd.accelerator.segment import Segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    torch.manual_seed(52)
+    B, N = 19, 3_000
+    els, bpms = [], []
+    for i in range(6):
+        phase, voltage, freq = t(-10.0 + 3 * i), t(18e6), t(1.3e9)
+        if scanned == "phase_of_one" and i == 2:
+            phase = torch.linspace(-40.0, 40.0, B, **kw)
+        elif scanned == "phase_and_voltage_of_all":
+            phase, voltage = torch.linspace(-30.0, 30.0, B, **kw) + i, 1.5e7 + 5e6 * torch.rand(B, **kw)
+        elif scanned == "frequency_of_one" and i == 3:
+            freq = torch.linspace(1.2e9, 1.4e9, B, **kw)
+        elif scanned == "decelerating_rows" and i == 1:
+            phase = torch.linspace(0.0, 180.0, B, **kw)          # half of the rows lose energy in this cavity
+        bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -1e-5]), **kw)
+        bpms.append(bpm)
+        els += [ca.Drift(t(0.3), **kw), ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw), ca.HorizontalCorrector(t(0.05), angle=t(1e-4), **kw), bpm,
+                ca.Cavity(t(1.0377), voltage=voltage, phase=phase, frequency=freq, cavity_type="standing_wave" if i % 2 else "traveling_wave", **kw)]
+    seg = ca.Segment(els)
+    beam = ca.ParticleBeam.from_parameters(num_particles=N, energy=t(9e7), mu_x=t(1e-4), sigma_p=t(1e-3), **kw)
+    pbeam = ca.ParameterBeam.from_parameters(energy=t(9e7), mu_x=t(1e-4), sigma_p=t(1e-3), **kw)
+    calls, spy = _spy()
+    pcalls = []
+    orig_p = Segment._lattice_stretch_parameter
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: (lambda r: (pcalls.append(r is not None), r)[1])(orig_p(self, plan, i, incoming))
+        with torch.no_grad():
+            out = seg.track(beam)
+            got = [b.reading.clone() for b in bpms]
+            pout = seg.track(pbeam)
+            pgot = [b.reading.clone() for b in bpms]
+        assert calls == [N] and pcalls == [True], (calls, pcalls)
+        Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: None
+        with torch.no_grad():
+            ref = _walk(seg, beam)
+            want = [b.reading.clone() for b in bpms]
+            pref = seg.track(pbeam)
+            pwant = [b.reading.clone() for b in bpms]
+    finally:
+        segment._HOST = old
+        Segment._lattice_stretch_parameter = orig_p
+    # (the row at exactly 90 degrees gains nothing: the reference's formulas give 0 / 0 there, NaN in the walk and in the stretch alike)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1234.5), torch.nan_to_num(b, nan=1234.5))  # noqa: E731
+    assert out.particles.shape == ref.particles.shape == (B, N, 7) and same(out.particles, ref.particles)
+    assert int(torch.isnan(out.particles).any(dim=-1).any(dim=-1).sum()) <= (1 if scanned == "decelerating_rows" else 0)
+    assert out.energy.shape == ref.energy.shape and torch.equal(out.energy, ref.energy) and torch.equal(out.s, ref.s)
+    assert out.energy.shape == (() if scanned == "frequency_of_one" else (B,))
+    assert pout.mu.shape == pref.mu.shape and same(pout.mu, pref.mu) and same(pout.cov, pref.cov)
+    assert pout.energy.shape == pref.energy.shape and torch.equal(pout.energy, pref.energy) and torch.equal(pout.s, pref.s)
+    eps = torch.finfo(dt).eps
+    order = 8 * torch.finfo(torch.float64).eps * 5e-3
+    for k, (g, w, pg, pw) in enumerate(zip(got, want, pgot, pwant)):
+        assert g.shape == w.shape and pg.shape == pw.shape, (k, g.shape, w.shape, pg.shape, pw.shape)
+        live = torch.isfinite(w)
+        assert torch.equal(torch.isfinite(g), live) and torch.all(((g - w).abs() <= 2 * eps * (w + bpms[k].misalignment).abs() + order)[live]), k
+        assert same(pg, pw), k
+    assert got[0].shape == (2,) and got[-1].shape == (B, 2)
+    assert (out.particles[0] - out.particles[-1]).abs().max() > 1e-7

@@ -55,7 +55,7 @@ def test_scans_with_particles_vs_reference(dt):
             stretch_calls.clear()
             with torch.no_grad():
                 out = seg.track(beam)
-            assert stretch_calls == [20], (i, stretch_calls)          # the whole scan is one stretch call
+            assert stretch_calls == [21], (i, stretch_calls)          # the whole scan is one stretch call
             ref = g[f"lat{i}_out"]
             assert tuple(out.particles.shape) == ref.shape
             scale = np.abs(ref).max(axis=(0, 1))
@@ -104,7 +104,7 @@ def test_scans_with_particles_vs_reference(dt):
             stretch_calls.clear()
             with torch.no_grad():
                 eout = seg.track(ebeam)
-            assert stretch_calls == [20], (i, stretch_calls)
+            assert stretch_calls == [21], (i, stretch_calls)
             eref = g[f"lat{i}_escan_out"]
             assert tuple(eout.particles.shape) == eref.shape
             err = (np.abs(eout.particles.double().cpu().numpy() - eref) / np.abs(eref).max(axis=(0, 1))).max()
