@@ -5,7 +5,8 @@ quadrupole strengths and corrector angles are (4,) tensors — four lattice sett
 list as JSON (a vectorised setting is a list of four numbers), 1200 incoming particles with drawn survival probabilities and what
 the reference leaves in float64: the (4, 1200, 7) outgoing particles, the survival probabilities (whatever shape they have),
 energy, s and EVERY monitor's reading with its own shape ((2,) in front of the first vectorised element, (4, 2) behind); the same
-scan for a ParameterBeam; and both once more with a (4,) BEAM ENERGY on top (`lat*_escan_*`: a scan of energies through the cavities).
+scan for a ParameterBeam; and both once more with a (4,) BEAM ENERGY on top (`lat*_escan_*`: a scan of energies through the cavities); for the lattices with cavities a PHASE scan of every cavity plus a
+voltage scan of the first (`lat*_cscan_*`), some rows losing energy.
 Run in the build container:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden_scan_stretch.py
 """
 import json
@@ -131,6 +132,33 @@ if __name__ == "__main__":
         arrays[f"lat{i}_escan_pb_energy"] = epout.energy.numpy()
         for k, b in enumerate(bpms):
             arrays[f"lat{i}_escan_pb_reading{k}"] = b.reading.numpy()
+        if with_cav:
+            # a PHASE scan of every cavity (and a voltage scan of the first) on top: (4,) cavity settings, some rows LOSE energy in
+            # some cavities (cavity.py:157 looks at the whole batch)
+            crng = np.random.default_rng(5000 + i)
+            cspecs, first = json.loads(json.dumps(specs)), True
+            for sp in cspecs:
+                if sp[0] == "Cavity":
+                    sp[1]["phase"] = [float(crng.uniform(-60.0, 60.0)) for _ in range(ROWS - 1)] + [float(crng.uniform(120.0, 170.0))]
+                    if first:
+                        sp[1]["voltage"] = [float(crng.uniform(2e6, 1.5e7)) for _ in range(ROWS)]
+                        first = False
+            cseg = cheetah.Segment([build(cheetah, sp, f64) for sp in cspecs])
+            cbpms = [e for e in cseg.elements if isinstance(e, cheetah.BPM)]
+            cout = cseg.track(beam)
+            arrays[f"lat{i}_cscan_spec"] = np.asarray(json.dumps(cspecs))
+            arrays[f"lat{i}_cscan_out"] = cout.particles.numpy()
+            arrays[f"lat{i}_cscan_w_out"] = cout.survival_probabilities.numpy()
+            arrays[f"lat{i}_cscan_energy_out"] = cout.energy.numpy()
+            for k, b in enumerate(cbpms):
+                arrays[f"lat{i}_cscan_reading{k}"] = b.reading.numpy()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cpout = cseg.track(pb)
+            arrays[f"lat{i}_cscan_pb_mu"] = cpout.mu.numpy()
+            arrays[f"lat{i}_cscan_pb_cov"] = cpout.cov.numpy()
+            arrays[f"lat{i}_cscan_pb_energy"] = cpout.energy.numpy()
+            print("   cavity scan: energies out", cout.energy.numpy(), "NaNs", int(np.isnan(cout.particles.numpy()).sum()))
         print(i, len(specs), "elements,", len(bpms), "monitors, w_out", tuple(out.survival_probabilities.shape),
               "lost per row", (out.survival_probabilities == 0).sum(dim=-1).tolist(), "readings", [tuple(b.reading.shape) for b in bpms])
     np.savez_compressed(os.path.join(OUT, "scan_stretch.npz"), **arrays)

@@ -3,7 +3,7 @@ tests/golden/generate_golden_scan_stretch.py): six drawn lattices with active mo
 quadrupole strengths and corrector angles (4,) tensors. Each is ONE stretch call here (chx_lattice_track_diag with Bm = 4 rows of
 maps and one shared incoming beam; chx_parameter_lattice_track for the ParameterBeam): the (4, 1200, 7) outgoing particles, survival
 probabilities and their SHAPE, energy, s and every monitor's reading with the reference's shape — (2,) in front of the first
-vectorised element, (4, 2) behind; and both once more under a (4,) BEAM ENERGY (`lat*_escan_*`) (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
+vectorised element, (4, 2) behind; and both once more under a (4,) BEAM ENERGY (`lat*_escan_*`) and, for the lattices with cavities, under a phase scan of every cavity (`lat*_cscan_*`) (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
 (worst of the six lattices): float64 particles 5.8e-15, readings 6.8e-17, ParameterBeam 4.6e-16; float32 4.1e-7 / 1.3e-8 / 3.2e-7;
 the bounds are those of test_gpu_diagnostics_stretch_golden.py."""
 import json
@@ -139,8 +139,46 @@ def test_scans_with_particles_vs_reference(dt):
                 r_ref, r_got = g[f"lat{i}_escan_pb_reading{k}"], b.reading.double().cpu().numpy()
                 assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
                 assert np.abs(r_got - r_ref).max() < (5e-15 if f64 else 1.5e-6) * (np.abs(emu[..., :6]).max() + np.abs(r_ref).max())
+            # a PHASE scan of every cavity + a voltage scan of the first, some rows losing energy (cavity.py:157 over the batch)
+            if f"lat{i}_cscan_spec" in g.files:
+                cspecs = json.loads(str(g[f"lat{i}_cscan_spec"]))
+                cseg = ca.Segment([_build(ca, sp, fk) for sp in cspecs])
+                cbpms = [e for e in cseg.elements if isinstance(e, ca.BPM)]
+                stretch_calls.clear()
+                with torch.no_grad():
+                    cout = cseg.track(beam)
+                assert stretch_calls == [21], (i, stretch_calls)
+                cref = g[f"lat{i}_cscan_out"]
+                assert tuple(cout.particles.shape) == cref.shape
+                err = (np.abs(cout.particles.double().cpu().numpy() - cref) / np.abs(cref).max(axis=(0, 1))).max()
+                worst["cscan"] = max(worst.get("cscan", 0.0), err)
+                assert err < (1e-13 if f64 else 3e-6), (i, err)
+                ce_ref = g[f"lat{i}_cscan_energy_out"]
+                assert tuple(cout.energy.shape) == ce_ref.shape == (4,)
+                assert np.allclose(cout.energy.double().cpu().numpy(), ce_ref, rtol=1e-13 if f64 else 1e-6, atol=0)
+                cw_ref, cw_got = g[f"lat{i}_cscan_w_out"], cout.survival_probabilities.double().cpu().numpy()
+                assert cw_got.shape == cw_ref.shape and (not f64 or np.array_equal(cw_got, cw_ref))
+                csize = np.abs(cref[..., [0, 2]]).max()
+                for k, b in enumerate(cbpms):
+                    r_ref, r_got = g[f"lat{i}_cscan_reading{k}"], b.reading.double().cpu().numpy()
+                    assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                    live = np.isfinite(r_ref)
+                    assert np.array_equal(np.isfinite(r_got), live)
+                    if live.any():
+                        assert np.abs(r_got[live] - r_ref[live]).max() / (csize + np.abs(r_ref[live]).max()) < (1e-15 if f64 else 3e-7), (i, k)
+                with warnings.catch_warnings(), torch.no_grad():
+                    warnings.simplefilter("ignore")
+                    cpout = cseg.track(pb)
+                cmu, ccov = g[f"lat{i}_cscan_pb_mu"], g[f"lat{i}_cscan_pb_cov"]
+                assert tuple(cpout.mu.shape) == cmu.shape and tuple(cpout.cov.shape) == ccov.shape
+                e1 = np.abs(cpout.mu.double().cpu().numpy() - cmu).max() / np.abs(cmu[..., :6]).max()
+                e2 = np.abs(cpout.cov.double().cpu().numpy() - ccov).max() / np.abs(ccov).max()
+                worst["cscan_pb"] = max(worst.get("cscan_pb", 0.0), e1, e2)
+                assert max(e1, e2) < (5e-15 if f64 else 1.5e-6), (i, e1, e2)
+                assert np.allclose(cpout.energy.double().cpu().numpy(), g[f"lat{i}_cscan_pb_energy"], rtol=1e-13 if f64 else 1e-6, atol=0)
     finally:
         segment._HOST = old
+    print(f"cavity scans vs reference ({dt}): worst particles {worst.get('cscan', 0):.2e}, parameter beam {worst.get('cscan_pb', 0):.2e}")
     print(f"energy scans vs reference ({dt}): worst particles {worst.get('escan', 0):.2e}, parameter beam {worst.get('escan_pb', 0):.2e}")
     print(f"scans vs reference ({dt}): worst particles {worst['particles']:.2e}, readings {worst['readings']:.2e}, "
           f"parameter beam {worst['pb']:.2e}")
