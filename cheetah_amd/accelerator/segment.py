@@ -777,6 +777,25 @@ class Segment(Element):
         return kinds, rows, flags, keep, shape
 
     @staticmethod
+    def _vector_tables(run: _Run, dtype, device):
+        """(E, kinds, addresses, flags, tensors, batch shape) of `_vector_run_rows` packed for `chx_run_map_batched`, kept while the
+        epoch stands still — or None."""
+        c = run.vrows
+        if c is None or c[0] != Element._epoch or c[1] != dtype or c[2] != device:
+            got = Segment._vector_run_rows(run, dtype, device) if len(run.elements) <= 192 else None
+            if got is not None:
+                kinds, rows, row_flags, keep, shape = got
+                ptrs, flags = [], []
+                for r, f in zip(rows, row_flags):
+                    ptrs += r + [None] * (_ops.MAX_PARAMS - len(r))
+                    flags += f + [0] * (_ops.MAX_PARAMS - len(f))
+                E = len(kinds)
+                got = (E, (ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs),
+                       (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), tuple(keep), shape)
+            c = run.vrows = (Element._epoch, dtype, device, got)
+        return c[3]
+
+    @staticmethod
     def _run_map_vector(run: _Run, energy, species):
         """The composed maps (*shape, 7, 7) of a run whose settings are vectorised over a batch of lattice settings — some
         parameters tensors of ONE common shape, the others scalars; scalar energy and lengths — by one launch
@@ -787,22 +806,10 @@ class Segment(Element):
             return None
         # the packed tables stand while no attribute of any element was assigned (the addresses of the settings; their VALUES are
         # read by the device on every call): building them anew is ~3 us per element and step
-        c = run.vrows
-        if c is None or c[0] != Element._epoch or c[1] != energy.dtype or c[2] != energy.device:
-            got = Segment._vector_run_rows(run, energy.dtype, energy.device)
-            if got is not None:
-                kinds, rows, row_flags, keep, shape = got
-                ptrs, flags = [], []
-                for r, f in zip(rows, row_flags):
-                    ptrs += r + [None] * (_ops.MAX_PARAMS - len(r))
-                    flags += f + [0] * (_ops.MAX_PARAMS - len(f))
-                E = len(kinds)
-                got = (E, (ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs),
-                       (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), tuple(keep), shape)
-            c = run.vrows = (Element._epoch, energy.dtype, energy.device, got)
-        if c[3] is None:
+        tables = Segment._vector_tables(run, energy.dtype, energy.device)
+        if tables is None:
             return None
-        E, kinds_arr, ptrs_arr, flags_arr, keep, shape = c[3]
+        E, kinds_arr, ptrs_arr, flags_arr, keep, shape = tables
         if torch.is_grad_enabled() and _any_requires_grad(*keep):
             return None
         if energy.dim() != 0:
@@ -943,6 +950,12 @@ class Segment(Element):
         elements, 3.4 ms for 5000; 100 us for 100 elements around one CustomTransferMap). None when that would not pay."""
         if len(run.elements) < Segment._PART_MIN_RUN or not ref.is_cuda or energy.dim() != 0:
             return None
+        if len(run.elements) <= 192:
+            tables = Segment._vector_tables(run, ref.dtype, ref.device)
+            if tables is not None and tables[5] is not None and tables[0] > 0:
+                # settings vectorised over ONE batch shape: `_run_map` has all rows' maps from one launch (`_run_map_vector`), and
+                # keeps them while no setting changes — the pieces would cost a call each
+                return None
         built = run.parts
         if built is None or built[0] is None:
             # the partition: elements whose settings are device scalars without a graph go into the plans' stretches. It is redone
