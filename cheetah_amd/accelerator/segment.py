@@ -669,18 +669,26 @@ class Segment(Element):
     def _run_length(run: _Run):
         """Summed length of the run, redone only when a length tensor was replaced or modified. The previous tensors are
         kept referenced by the key, so that an `is` comparison cannot be fooled by a recycled object id."""
-        lengths = [e.length for e in run.elements]
         key = run.length_key
+        if key is not None and key[0] == Element._epoch and run.length is not None and not _ops.CAPTURING[0]:
+            # no attribute of any element was assigned since the sum was formed and every length is a tensor the element itself
+            # holds (not a derived property): the same tensor objects — only an in-place edit can have changed them (100
+            # `nn.Module.__getattr__` look-ups, ~20 us, for a 100-element run otherwise)
+            if all(t._version == v for t, v in key[1]):
+                return run.length
+        lengths = [e.length for e in run.elements]
         same = (key is not None and run.length is not None and not run.length.requires_grad and not _ops.CAPTURING[0]
-                and all(a is b and a._version == v for a, (b, v) in zip(lengths, key)))
+                and len(key[1]) == len(lengths) and all(a is b and a._version == v for a, (b, v) in zip(lengths, key[1])))
+        plain = all(("length" in e._buffers) or ("length" in e._parameters) for e in run.elements)
         if not same:
             total = None
             for t in lengths:
                 total = t if total is None else total + t
             run.length = total
             # derived lengths (a sub-segment's sum is a fresh tensor every time) never compare identical: recomputed
-            run.length_key = [(t, t._version) for t in lengths]
             run.s_cache = None
+        # (the epoch shortcut above only for sums without a graph over lengths the elements hold themselves)
+        run.length_key = (Element._epoch if (plain and not run.length.requires_grad) else None, [(t, t._version) for t in lengths])
         return run.length
 
     @staticmethod
