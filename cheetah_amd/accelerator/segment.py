@@ -275,7 +275,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc")
 
     def __init__(self, items, dtype, device, allow_vector=False):
         self.items, self.dtype, self.device = items, dtype, device
@@ -301,6 +301,29 @@ class _LatticePlan:
         vshape, bpm_vec, ap_vec = None, [], []
         bpm_after, ap_after, maps_seen = [], [], False   # does a run / cavity (a map) sit in front of the monitor / aperture?
         e_out_rows = False       # a cavity with a vectorised voltage or phase: the outgoing energy has the batch shape
+        # the ONE batch shape of the stretch: what every vectorised setting in it broadcasts to ((8, 1) and (1, 8) of a grid scan:
+        # (8, 8)); `acc`: what the settings in front of an item broadcast to — the batch shape the beam has there in the walk
+        common, acc, expanded, bpm_acc, ap_acc = None, None, [], [], []
+        e_acc = None             # what the vectorised voltages and phases broadcast to: the batch shape of the outgoing energy
+        if self.allow_vector:
+            found = []
+            for kind, item in self.items:
+                if kind == "run":
+                    for e in item.elements:
+                        if getattr(e, "_chx_kind", None) is None:
+                            continue
+                        found += [tuple(t.shape) for t, index in e._builder_scalar_refs() if index is None and t.dim() != 0]
+                elif item._is_cavity:
+                    found += [tuple(t.shape) for t in item._settings("voltage", "phase", "frequency") if t.dim() != 0]
+            if found:
+                try:
+                    common = tuple(torch.broadcast_shapes(*found))
+                except RuntimeError:
+                    common = None           # (shapes that do not broadcast: the walk raises like the reference)
+
+        def grown(a, b):
+            return b if a is None else a if b is None else tuple(torch.broadcast_shapes(a, b))
+
         for kind, item in self.items:
             if kind != "run" and item._is_aperture:
                 # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
@@ -317,6 +340,7 @@ class _LatticePlan:
                 apertures.append(item)
                 ap_vec.append(vshape is not None)
                 ap_after.append(maps_seen)
+                ap_acc.append(acc)
                 count += 1
                 continue
             if kind != "run" and item._is_bpm:
@@ -333,6 +357,7 @@ class _LatticePlan:
                 bpms.append(item)
                 bpm_vec.append(vshape is not None)     # does a run with vectorised settings sit in front of this monitor?
                 bpm_after.append(maps_seen)
+                bpm_acc.append(acc)
                 count += 1
                 continue
             if kind == "run":
@@ -354,12 +379,14 @@ class _LatticePlan:
                 else:
                     # settings vectorised over a batch of lattice settings: addresses tagged with their lowest bit (a (rows,) array);
                     # one batch shape for the whole stretch
-                    got = Segment._vector_run_rows(item, dtype, device) if self.allow_vector else None
+                    got = Segment._vector_run_rows(item, dtype, device, common) if self.allow_vector else None
                     # (one workgroup per item and row prepares the maps: beyond a few hundred rows the walk item by item is cheaper)
                     if got is None or got[4] is None or (vshape is not None and got[4] != vshape) or len(got[0]) > 192 \
                             or _ops.numel(got[4]) > 65535:
                         break
-                    run_kinds, vrows, vflags, run_tensors, vshape = got
+                    run_kinds, vrows, vflags, run_tensors, vshape, run_expanded, own = got
+                    expanded += run_expanded
+                    acc = grown(acc, own)
                     if any(len(r) != lib.chx_kind_num_params(k) for r, k in zip(vrows, run_kinds)):
                         break
                     row_ptrs = [[q | f for q, f in zip(r, fl)] for r, fl in zip(vrows, vflags)]
@@ -381,21 +408,30 @@ class _LatticePlan:
                     break
                 # a PHASE (voltage, frequency) scan: the setting is a tensor of the stretch's one batch shape, its address tagged
                 # like a vectorised magnet strength; the cavity then hands on one energy per row
-                cav_ptrs, cav_shape, fits = [], vshape, True
+                cav_ptrs, cav_shape, fits, cav_expanded = [], vshape, True, []
                 for k, t in enumerate(settings):
                     if t.dim() == 0:
                         cav_ptrs.append(t.data_ptr())
-                    elif not self.allow_vector or k == 0 or not t.is_contiguous() or (cav_shape is not None and tuple(t.shape) != tuple(cav_shape)) \
-                            or _ops.numel(t.shape) > 65535:
+                    elif not self.allow_vector or k == 0 or not t.is_contiguous() or common is None or _ops.numel(common) > 65535:
                         fits = False
                         break
                     else:
-                        cav_shape = tuple(t.shape)
-                        cav_ptrs.append(t.data_ptr() | 1)
-                        e_out_rows = e_out_rows or k in (1, 2)
+                        cav_shape = common
+                        if tuple(t.shape) != common:           # (a phase of shape (8, 1) in a grid scan: an expanded copy)
+                            with torch.no_grad():
+                                copy = t.expand(common).contiguous()
+                            cav_expanded.append((t, copy, [t._version]))
+                            tensors.append(copy)
+                            cav_ptrs.append(copy.data_ptr() | 1)
+                        else:
+                            cav_ptrs.append(t.data_ptr() | 1)
+                        acc = grown(acc, tuple(t.shape))
+                        if k in (1, 2):
+                            e_out_rows, e_acc = True, grown(e_acc, tuple(t.shape))
                 if not fits:
                     break
                 vshape = cav_shape
+                expanded += cav_expanded
                 rows += [1, 1, len(elem_kind), 0]
                 elem_kind.append(_ops.KIND[item._kind_name()])
                 elem_poff.append(len(ptrs))
@@ -409,6 +445,7 @@ class _LatticePlan:
         self.bpms, self.apertures, self.bpm_vec, self.ap_vec = tuple(bpms), tuple(apertures), tuple(bpm_vec), tuple(ap_vec)
         self.bpm_after, self.ap_after = tuple(bpm_after), tuple(ap_after)
         self.e_out_rows = e_out_rows
+        self.expanded, self.bpm_acc, self.ap_acc, self.e_acc = tuple(expanded), tuple(bpm_acc), tuple(ap_acc), e_acc
         if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
@@ -639,6 +676,12 @@ class Segment(Element):
         store[key] = (plan, dynamic)
         return plan
 
+    @staticmethod
+    def _lead_at(lead_in, acc, energy_shape) -> tuple:
+        """Batch shape of a beam at a point of a stretch: what it came in with, spread over the vectorised settings in front of
+        that point (`acc`) and over the beam energies once a map was applied."""
+        return tuple(torch.broadcast_shapes(tuple(lead_in), acc if acc is not None else (), tuple(energy_shape)))
+
     def _lattice_cache_for(self, plan):
         """The stretch plans of `plan` (one table per partition of the lattice that `_plan` keeps)."""
         store = self.__dict__.get("_lattice_store")
@@ -748,58 +791,94 @@ class Segment(Element):
         return tm
 
     @staticmethod
-    def _vector_run_rows(run: _Run, dtype, device):
-        """(kinds, per-element setting addresses, per-element flags (1 = a tensor of the common batch shape), tensors, batch shape) of
-        a run whose elements all have a device builder and settings that are device scalars or contiguous tensors of ONE shape — or
-        None (a vectorised length, mixed shapes, another dtype / device). Whether a setting requires grad is asked by the caller,
-        per call (`_any_requires_grad(*tensors)`)."""
-        kinds, rows, flags, keep, shape = [], [], [], [], None
+    def _vector_run_rows(run: _Run, dtype, device, common=None):
+        """(kinds, per-element setting addresses, per-element flags (1 = a tensor of the batch shape), tensors, batch shape, expanded,
+        own shape) of a run whose elements all have a device builder and settings that are device scalars or contiguous tensors that
+        BROADCAST to one batch shape (`common` when given — the shape of the whole stretch) — or None (a vectorised length, shapes
+        that do not broadcast, another dtype / device). A setting whose own shape is not the batch shape — (8, 1) against (1, 8) in
+        a grid scan — is addressed through an expanded contiguous COPY: `expanded` = [(setting, copy, [version])], refreshed by the
+        user of the tables when the setting's version moved (`_refresh_expanded`). `own shape`: what the run's own settings
+        broadcast to (the batch shape a beam has BEHIND this run in the walk). Whether a setting requires grad is asked by the
+        caller, per call (`_any_requires_grad(*tensors)`)."""
+        kinds, refs_all, shapes = [], [], []
         for e in run.elements:
             kind = getattr(e, "_chx_kind", None)
             if kind is None or not e._plannable():
                 return None
             if kind == _IDENTITY:
                 continue
-            row, fl = [], []
-            for k, (t, index) in enumerate(e._builder_scalar_refs()):
+            refs = e._builder_scalar_refs()
+            for k, (t, index) in enumerate(refs):
                 if t.dtype != dtype or t.device != device:
                     return None
                 if index is not None:                      # a component of a vector-valued setting (misalignment[..., i])
                     if t.dim() != 1 or not t.is_contiguous():
                         return None
+                elif t.dim() != 0:
+                    if k == 0 or not t.is_contiguous():
+                        return None
+                    shapes.append(tuple(t.shape))
+            kinds.append(kind)
+            refs_all.append(refs)
+        shape = own = None
+        if shapes:
+            try:
+                own = tuple(torch.broadcast_shapes(*shapes))
+                shape = tuple(torch.broadcast_shapes(own, tuple(common))) if common is not None else own
+            except RuntimeError:
+                return None
+            if common is not None and shape != tuple(common):
+                return None
+        rows, flags, keep, expanded = [], [], [], []
+        for refs in refs_all:
+            row, fl = [], []
+            for t, index in refs:
+                if index is not None:
                     row.append(t.data_ptr() + index * t.element_size())
                     fl.append(0)
                 elif t.dim() == 0:
                     row.append(t.data_ptr())
                     fl.append(0)
                 else:
-                    if k == 0 or not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
-                        return None
-                    shape = tuple(t.shape)
-                    row.append(t.data_ptr())
+                    if tuple(t.shape) != shape:
+                        with torch.no_grad():
+                            copy = t.expand(shape).contiguous()
+                        expanded.append((t, copy, [t._version]))
+                        keep.append(copy)
+                        row.append(copy.data_ptr())
+                    else:
+                        row.append(t.data_ptr())
                     fl.append(1)
                 keep.append(t)
-            kinds.append(kind)
             rows.append(row)
             flags.append(fl)
-        return kinds, rows, flags, keep, shape
+        return kinds, rows, flags, keep, shape, expanded, own
+
+    @staticmethod
+    def _refresh_expanded(expanded) -> None:
+        """The expanded copies of settings whose own shape is not the batch shape follow in-place edits of the settings."""
+        for src, copy, version in expanded:
+            if src._version != version[0]:
+                with torch.no_grad():
+                    copy.copy_(src.expand(copy.shape))
+                version[0] = src._version
 
     @staticmethod
     def _vector_tables(run: _Run, dtype, device):
-        """(E, kinds, addresses, flags, tensors, batch shape) of `_vector_run_rows` packed for `chx_run_map_batched`, kept while the
+        """(E, kinds, addresses, flags, tensors, batch shape, expanded copies) of `_vector_run_rows` packed for `chx_run_map_batched`, kept while the
         epoch stands still — or None."""
         c = run.vrows
         if c is None or c[0] != Element._epoch or c[1] != dtype or c[2] != device:
             got = Segment._vector_run_rows(run, dtype, device) if len(run.elements) <= 192 else None
             if got is not None:
-                kinds, rows, row_flags, keep, shape = got
+                kinds, rows, row_flags, keep, shape, expanded, _ = got
                 ptrs, flags = [], []
                 for r, f in zip(rows, row_flags):
                     ptrs += r + [None] * (_ops.MAX_PARAMS - len(r))
                     flags += f + [0] * (_ops.MAX_PARAMS - len(f))
                 E = len(kinds)
                 got = (E, (ctypes.c_int32 * E)(*kinds), (ctypes.c_void_p * (E * _ops.MAX_PARAMS))(*ptrs),
-                       (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), tuple(keep), shape)
+                       (ctypes.c_uint8 * (E * _ops.MAX_PARAMS))(*flags), tuple(keep), shape, tuple(expanded))
             c = run.vrows = (Element._epoch, dtype, device, got)
         return c[3]
 
@@ -817,9 +896,11 @@ class Segment(Element):
         tables = Segment._vector_tables(run, energy.dtype, energy.device)
         if tables is None:
             return None
-        E, kinds_arr, ptrs_arr, flags_arr, keep, shape = tables
+        E, kinds_arr, ptrs_arr, flags_arr, keep, shape, expanded = tables
         if torch.is_grad_enabled() and _any_requires_grad(*keep):
             return None
+        if expanded:
+            Segment._refresh_expanded(expanded)
         if energy.dim() != 0:
             # a scan of BEAM ENERGIES (with scalar settings, or settings vectorised over the same shape): row b's maps are built
             # for energy b. Element by element that is one builder call per element and step — every cavity in front hands on a
@@ -1203,6 +1284,9 @@ class Segment(Element):
         if B < 1 or B > 65535:
             return None
         flags = lp.small_runs | (2 if energy_rows else 0) | (4 if lp.e_out_rows else 0)
+        if lp.expanded:
+            Segment._refresh_expanded(lp.expanded)
+        w_lead = tuple(incoming.survival_probabilities.shape[:-1])
         if lp.bpms or lp.apertures or lead:
             # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
             # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —
@@ -1240,19 +1324,30 @@ class Segment(Element):
                                                     w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes, B,
                                                     Bx, Bm, Bw if w is not None else B, flags, out,
                                                     torch.empty(lead, dtype=p.dtype, device=p.device) if (lp.e_out_rows and not energy_rows) else None)
-            for k, bpm in enumerate(lp.bpms):
-                r = readings[k].reshape(*lead, 2)
-                if lead != lead_x and not (lp.bpm_vec[k] or (energy_rows and lp.bpm_after[k])):
-                    # a monitor in FRONT of the first vectorised element reads the beam before it was spread over the scan: equal
-                    # rows, the reading has the incoming beam's shape (like the walk's)
+            if lp.e_out_rows and not energy_rows:
+                here = self._lead_at(e.shape, lp.e_acc, ())
+                if here != lead:                 # (only some axes of a grid scan reach the cavities' voltages and phases)
                     from .cavity import _narrow_to
 
-                    r = _narrow_to(r, (*lead_x, 2))
-                bpm.__dict__["_buffers"]["reading"] = r
-            if lp.apertures and lead != lead_x and not any(lp.ap_vec) and not (energy_rows and any(lp.ap_after)):
-                from .cavity import _narrow_to
+                    e_out = _narrow_to(e_out, here)
+            for k, bpm in enumerate(lp.bpms):
+                r = readings[k].reshape(*lead, 2)
+                if lead != lead_x:
+                    # the beam AT the monitor is spread over the settings in front of it only (and over the energies once a map was
+                    # applied): equal rows beyond that, the reading has the shape the walk's has — (2,) in front of the scan,
+                    # (8, 1, 2) behind the first axis of a grid scan
+                    here = self._lead_at(lead_x, lp.bpm_acc[k], e.shape if (energy_rows and lp.bpm_after[k]) else ())
+                    if here != lead:
+                        from .cavity import _narrow_to
 
-                w_out = _narrow_to(w_out, (*lead_x, N))     # (every aperture sits in front of the scan: equal rows)
+                        r = _narrow_to(r, (*here, 2))
+                bpm.__dict__["_buffers"]["reading"] = r
+            if lp.apertures and lead != lead_x:
+                here = self._lead_at(torch.broadcast_shapes(lead_x, w_lead), lp.ap_acc[-1], e.shape if (energy_rows and lp.ap_after[-1]) else ())
+                if here != lead:
+                    from .cavity import _narrow_to
+
+                    w_out = _narrow_to(w_out, (*here, N))     # (the beam at the LAST aperture is not spread over the whole scan yet)
         else:
             out, e_out, s_out = _HOST.lattice_track(lp.capsule, x, x.shape[0], e, s_in if on_device else None, sp.mass_eV_float,
                                                     sp.num_elementary_charges_float, lp.device.index)
@@ -1313,6 +1408,8 @@ class Segment(Element):
             return None
         if Bm > 1 and not lp.ensure_rows(Bm):
             return None
+        if lp.expanded:
+            Segment._refresh_expanded(lp.expanded)
         m2 = mu.reshape(-1, 7) if mu.is_contiguous() else mu.reshape(-1, 7).contiguous()
         c2 = cov.reshape(-1, 49) if cov.is_contiguous() else cov.reshape(-1, 49).contiguous()
         if m2.shape[0] not in (1, B) or c2.shape[0] not in (1, B):
@@ -1334,14 +1431,21 @@ class Segment(Element):
             cov_out.data_ptr(), e_out.data_ptr(), s_in.data_ptr() if on_device else None, s_out.data_ptr() if on_device else None,
             n_bpm, readings.data_ptr() if n_bpm else None, _ops.stream_ptr()), "chx_parameter_lattice_track")
         in_lead = tuple(torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2]))
-        for k, bpm in enumerate(lp.bpms):
-            r = readings[k].reshape(*lead, 2)
-            if not (lp.bpm_vec[k] or (energy_rows and lp.bpm_after[k])) and in_lead != tuple(lead):
-                # a monitor in FRONT of the first vectorised element sees the beam before it was spread over the lattice settings:
-                # the rows are equal there, the reading has the incoming beam's shape (like the walk's)
+        if lp.e_out_rows and not energy_rows:
+            here = self._lead_at(e.shape, lp.e_acc, ())
+            if here != tuple(lead):
                 from .cavity import _narrow_to
 
-                r = _narrow_to(r, (*in_lead, 2))
+                e_out = _narrow_to(e_out, here)
+        for k, bpm in enumerate(lp.bpms):
+            r = readings[k].reshape(*lead, 2)
+            here = self._lead_at(in_lead, lp.bpm_acc[k], e.shape if (energy_rows and lp.bpm_after[k]) else ())
+            if here != tuple(lead):
+                # the beam at the monitor is spread over the settings in FRONT of it only: equal rows beyond that, the reading has
+                # the shape the walk's has
+                from .cavity import _narrow_to
+
+                r = _narrow_to(r, (*here, 2))
             bpm.__dict__["_buffers"]["reading"] = r
         if s_out is None:
             s_out = s_in

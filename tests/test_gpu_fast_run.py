@@ -802,11 +802,21 @@ def test_vectorised_settings_of_a_run_in_one_launch(ca, dt):
             pout = seg.track(pb)
             mu, cov = _ops.parameter_track(pb.mu, pb.cov, tm)
         assert torch.equal(pout.mu, mu) and torch.equal(pout.cov, cov)
-    # what does not qualify: a vectorised length, two different batch shapes, a setting that requires grad
+    # what does not qualify: a vectorised length, batch shapes that do not broadcast, a setting that requires grad
     assert Segment._run_map_vector(ca.Segment([ca.Drift(torch.tensor([0.1, 0.2], **kw), **kw), ca.Quadrupole(t(0.1), k1=t(1.0), **kw)])._plan()[0][1],
                                    beam.energy, beam.species) is None
-    mixed = ca.Segment([ca.Quadrupole(t(0.1), k1=torch.randn(3, **kw), **kw), ca.Quadrupole(t(0.1), k1=torch.randn(3, 1, **kw), **kw)])
-    assert Segment._run_map_vector(mixed._plan()[0][1], beam.energy, beam.species) is None
+    clash = ca.Segment([ca.Quadrupole(t(0.1), k1=torch.randn(3, **kw), **kw), ca.Quadrupole(t(0.1), k1=torch.randn(2, **kw), **kw)])
+    assert Segment._run_map_vector(clash._plan()[0][1], beam.energy, beam.species) is None
+    # two shapes that BROADCAST ((3,) against (3, 1): a grid scan): one launch over the (3, 3) grid through expanded copies of the
+    # settings, bit for bit the per-element builders + chx_compose_maps; an in-place edit of a setting is followed
+    kb = torch.randn(3, 1, **kw)
+    mixed = ca.Segment([ca.Quadrupole(t(0.1), k1=torch.randn(3, **kw), **kw), ca.Quadrupole(t(0.1), k1=kb, **kw)])
+    for _ in range(2):
+        got = Segment._run_map_vector(mixed._plan()[0][1], beam.energy, beam.species)
+        maps = [e.first_order_transfer_map(beam.energy, beam.species) for e in mixed.elements]
+        want = _ops.compose_maps(maps, (3, 3), dt, maps[0].device)
+        assert got.shape == (3, 3, 7, 7) and torch.equal(got, want)
+        kb.mul_(-1.5)
     with torch.no_grad():
         assert mixed.track(beam).particles.shape == (3, 3, 3_000, 7)
     k = torch.randn(4, **kw).requires_grad_(True)
