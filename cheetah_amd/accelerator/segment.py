@@ -680,7 +680,14 @@ class Segment(Element):
     def _lead_at(lead_in, acc, energy_shape) -> tuple:
         """Batch shape of a beam at a point of a stretch: what it came in with, spread over the vectorised settings in front of
         that point (`acc`) and over the beam energies once a map was applied."""
-        return tuple(torch.broadcast_shapes(tuple(lead_in), acc if acc is not None else (), tuple(energy_shape)))
+        # (plain tuples, right-aligned: `torch.broadcast_shapes` costs ~6 us a call, and a lattice has a monitor per cell)
+        out = tuple(lead_in)
+        for other in (acc, tuple(energy_shape)):
+            if not other or other == out:
+                continue
+            a, b = ((1,) * (len(other) - len(out)) + out, tuple(other)) if len(other) > len(out) else (out, (1,) * (len(out) - len(other)) + tuple(other))
+            out = tuple(x if y == 1 else y for x, y in zip(a, b))
+        return out
 
     def _lattice_cache_for(self, plan):
         """The stretch plans of `plan` (one table per partition of the lattice that `_plan` keeps)."""
@@ -1336,7 +1343,7 @@ class Segment(Element):
                     # the beam AT the monitor is spread over the settings in front of it only (and over the energies once a map was
                     # applied): equal rows beyond that, the reading has the shape the walk's has — (2,) in front of the scan,
                     # (8, 1, 2) behind the first axis of a grid scan
-                    here = self._lead_at(lead_x, lp.bpm_acc[k], e.shape if (energy_rows and lp.bpm_after[k]) else ())
+                    here = lead if lp.bpm_acc[k] == lead else self._lead_at(lead_x, lp.bpm_acc[k], e.shape if (energy_rows and lp.bpm_after[k]) else ())
                     if here != lead:
                         from .cavity import _narrow_to
 
@@ -1430,7 +1437,8 @@ class Segment(Element):
             mu_out.data_ptr(),
             cov_out.data_ptr(), e_out.data_ptr(), s_in.data_ptr() if on_device else None, s_out.data_ptr() if on_device else None,
             n_bpm, readings.data_ptr() if n_bpm else None, _ops.stream_ptr()), "chx_parameter_lattice_track")
-        in_lead = tuple(torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2]))
+        in_lead = tuple(torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2])) if (mu.dim() > 1 or cov.dim() > 2) else ()
+        lead_t = tuple(lead)
         if lp.e_out_rows and not energy_rows:
             here = self._lead_at(e.shape, lp.e_acc, ())
             if here != tuple(lead):
@@ -1439,8 +1447,11 @@ class Segment(Element):
                 e_out = _narrow_to(e_out, here)
         for k, bpm in enumerate(lp.bpms):
             r = readings[k].reshape(*lead, 2)
+            if in_lead == lead_t or lp.bpm_acc[k] == lead_t:
+                bpm.__dict__["_buffers"]["reading"] = r         # (nothing to narrow: the usual case, no shape arithmetic per monitor)
+                continue
             here = self._lead_at(in_lead, lp.bpm_acc[k], e.shape if (energy_rows and lp.bpm_after[k]) else ())
-            if here != tuple(lead):
+            if here != lead_t:
                 # the beam at the monitor is spread over the settings in FRONT of it only: equal rows beyond that, the reading has
                 # the shape the walk's has
                 from .cavity import _narrow_to
