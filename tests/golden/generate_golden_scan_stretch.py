@@ -6,7 +6,8 @@ list as JSON (a vectorised setting is a list of four numbers), 1200 incoming par
 the reference leaves in float64: the (4, 1200, 7) outgoing particles, the survival probabilities (whatever shape they have),
 energy, s and EVERY monitor's reading with its own shape ((2,) in front of the first vectorised element, (4, 2) behind); the same
 scan for a ParameterBeam; and both once more with a (4,) BEAM ENERGY on top (`lat*_escan_*`: a scan of energies through the cavities); for the lattices with cavities a PHASE scan of every cavity plus a
-voltage scan of the first (`lat*_cscan_*`), some rows losing energy.
+voltage scan of the first (`lat*_cscan_*`), some rows losing energy; and a 2-D GRID scan written by broadcasting — strengths of shape
+(3, 1) and (1, 2) — on the lattice with otherwise scalar settings (`lat*_gscan_*`).
 Run in the build container:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden_scan_stretch.py
 """
 import json
@@ -159,6 +160,40 @@ if __name__ == "__main__":
             arrays[f"lat{i}_cscan_pb_cov"] = cpout.cov.numpy()
             arrays[f"lat{i}_cscan_pb_energy"] = cpout.energy.numpy()
             print("   cavity scan: energies out", cout.energy.numpy(), "NaNs", int(np.isnan(cout.particles.numpy()).sum()))
+        # a 2-D GRID scan by broadcasting: the lattice with scalar settings, then one quadrupole strength of shape (3, 1) and a later
+        # one of shape (1, 2) (and, with cavities, the last cavity's phase (1, 2))
+        grng = np.random.default_rng(7000 + i)
+        gspecs = json.loads(json.dumps(specs))
+        for sp in gspecs:
+            for q, v in sp[1].items():
+                if isinstance(v, list) and len(v) == ROWS and q in ("k1", "angle"):
+                    sp[1][q] = v[0]
+        quads = [sp for sp in gspecs if sp[0] == "Quadrupole"]
+        if len(quads) >= 2:
+            quads[0][1]["k1"] = [[float(grng.uniform(-8.0, 8.0))] for _ in range(3)]
+            quads[-1][1]["k1"] = [[float(grng.uniform(-8.0, 8.0)) for _ in range(2)]]
+            cavs = [sp for sp in gspecs if sp[0] == "Cavity"]
+            if cavs:
+                cavs[-1][1]["phase"] = [[float(grng.uniform(-50.0, 50.0)) for _ in range(2)]]
+            gseg = cheetah.Segment([build(cheetah, sp, f64) for sp in gspecs])
+            gbpms = [e for e in gseg.elements if isinstance(e, cheetah.BPM)]
+            gout = gseg.track(beam)
+            arrays[f"lat{i}_gscan_spec"] = np.asarray(json.dumps(gspecs))
+            arrays[f"lat{i}_gscan_out"] = gout.particles.numpy()
+            arrays[f"lat{i}_gscan_w_out"] = gout.survival_probabilities.numpy()
+            arrays[f"lat{i}_gscan_energy_out"] = gout.energy.numpy()
+            for k, b in enumerate(gbpms):
+                arrays[f"lat{i}_gscan_reading{k}"] = b.reading.numpy()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                gpout = gseg.track(pb)
+            arrays[f"lat{i}_gscan_pb_mu"] = gpout.mu.numpy()
+            arrays[f"lat{i}_gscan_pb_cov"] = gpout.cov.numpy()
+            arrays[f"lat{i}_gscan_pb_energy"] = gpout.energy.numpy()
+            for k, b in enumerate(gbpms):
+                arrays[f"lat{i}_gscan_pb_reading{k}"] = b.reading.numpy()
+            print("   grid scan: out", tuple(gout.particles.shape), "w", tuple(gout.survival_probabilities.shape), "energy", tuple(gout.energy.shape),
+                  "readings", sorted({tuple(b.reading.shape) for b in gbpms}))
         print(i, len(specs), "elements,", len(bpms), "monitors, w_out", tuple(out.survival_probabilities.shape),
               "lost per row", (out.survival_probabilities == 0).sum(dim=-1).tolist(), "readings", [tuple(b.reading.shape) for b in bpms])
     np.savez_compressed(os.path.join(OUT, "scan_stretch.npz"), **arrays)

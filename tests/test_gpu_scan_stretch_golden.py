@@ -3,7 +3,7 @@ tests/golden/generate_golden_scan_stretch.py): six drawn lattices with active mo
 quadrupole strengths and corrector angles (4,) tensors. Each is ONE stretch call here (chx_lattice_track_diag with Bm = 4 rows of
 maps and one shared incoming beam; chx_parameter_lattice_track for the ParameterBeam): the (4, 1200, 7) outgoing particles, survival
 probabilities and their SHAPE, energy, s and every monitor's reading with the reference's shape — (2,) in front of the first
-vectorised element, (4, 2) behind; and both once more under a (4,) BEAM ENERGY (`lat*_escan_*`) and, for the lattices with cavities, under a phase scan of every cavity (`lat*_cscan_*`) (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
+vectorised element, (4, 2) behind; and both once more under a (4,) BEAM ENERGY (`lat*_escan_*`) and, for the lattices with cavities, under a phase scan of every cavity (`lat*_cscan_*`); and a 2-D grid scan by broadcasting (`lat*_gscan_*`: shapes (3, 1) and (1, 2)) (segment.py:545-574, bpm.py:77-87, aperture.py:90-135, cavity.py:100-251). Measured on the MI355X
 (worst of the six lattices): float64 particles 5.8e-15, readings 6.8e-17, ParameterBeam 4.6e-16; float32 4.1e-7 / 1.3e-8 / 3.2e-7;
 the bounds are those of test_gpu_diagnostics_stretch_golden.py."""
 import json
@@ -176,8 +176,52 @@ def test_scans_with_particles_vs_reference(dt):
                 worst["cscan_pb"] = max(worst.get("cscan_pb", 0.0), e1, e2)
                 assert max(e1, e2) < (5e-15 if f64 else 1.5e-6), (i, e1, e2)
                 assert np.allclose(cpout.energy.double().cpu().numpy(), g[f"lat{i}_cscan_pb_energy"], rtol=1e-13 if f64 else 1e-6, atol=0)
+            # a 2-D GRID scan written by broadcasting: strengths of shape (3, 1) and (1, 2) (and a cavity phase of shape (1, 2))
+            if f"lat{i}_gscan_spec" in g.files:
+                gspecs = json.loads(str(g[f"lat{i}_gscan_spec"]))
+                gseg = ca.Segment([_build(ca, sp, fk) for sp in gspecs])
+                gbpms = [e for e in gseg.elements if isinstance(e, ca.BPM)]
+                stretch_calls.clear()
+                with torch.no_grad():
+                    gout = gseg.track(beam)
+                assert stretch_calls == [21], (i, stretch_calls)
+                gref = g[f"lat{i}_gscan_out"]
+                assert tuple(gout.particles.shape) == gref.shape == (3, 2, 1200, 7)
+                err = (np.abs(gout.particles.double().cpu().numpy() - gref) / np.abs(gref).max(axis=(0, 1, 2))).max()
+                worst["gscan"] = max(worst.get("gscan", 0.0), err)
+                assert err < (1e-13 if f64 else 3e-6), (i, err)
+                ge_ref = g[f"lat{i}_gscan_energy_out"]
+                assert tuple(gout.energy.shape) == ge_ref.shape, (i, gout.energy.shape, ge_ref.shape)
+                assert np.allclose(gout.energy.double().cpu().numpy(), ge_ref, rtol=1e-13 if f64 else 1e-6, atol=0)
+                gw_ref, gw_got = g[f"lat{i}_gscan_w_out"], gout.survival_probabilities.double().cpu().numpy()
+                assert gw_got.shape == gw_ref.shape, (i, gw_got.shape, gw_ref.shape)
+                if f64:
+                    assert np.array_equal(gw_got, gw_ref)
+                gsize = np.abs(gref[..., [0, 2]]).max()
+                for k, b in enumerate(gbpms):
+                    r_ref, r_got = g[f"lat{i}_gscan_reading{k}"], b.reading.double().cpu().numpy()
+                    assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                    live = np.isfinite(r_ref)
+                    assert np.array_equal(np.isfinite(r_got), live)
+                    if live.any():
+                        assert np.abs(r_got[live] - r_ref[live]).max() / (gsize + np.abs(r_ref[live]).max()) < (1e-15 if f64 else 3e-7), (i, k)
+                with warnings.catch_warnings(), torch.no_grad():
+                    warnings.simplefilter("ignore")
+                    gpout = gseg.track(pb)
+                gmu, gcov = g[f"lat{i}_gscan_pb_mu"], g[f"lat{i}_gscan_pb_cov"]
+                assert tuple(gpout.mu.shape) == gmu.shape and tuple(gpout.cov.shape) == gcov.shape
+                e1 = np.abs(gpout.mu.double().cpu().numpy() - gmu).max() / np.abs(gmu[..., :6]).max()
+                e2 = np.abs(gpout.cov.double().cpu().numpy() - gcov).max() / np.abs(gcov).max()
+                worst["gscan_pb"] = max(worst.get("gscan_pb", 0.0), e1, e2)
+                assert max(e1, e2) < (5e-15 if f64 else 1.5e-6), (i, e1, e2)
+                assert tuple(gpout.energy.shape) == g[f"lat{i}_gscan_pb_energy"].shape
+                for k, b in enumerate(gbpms):
+                    r_ref, r_got = g[f"lat{i}_gscan_pb_reading{k}"], b.reading.double().cpu().numpy()
+                    assert r_got.shape == r_ref.shape, (i, k, r_got.shape, r_ref.shape)
+                    assert np.abs(r_got - r_ref).max() < (5e-15 if f64 else 1.5e-6) * (np.abs(gmu[..., :6]).max() + np.abs(r_ref).max())
     finally:
         segment._HOST = old
+    print(f"grid scans vs reference ({dt}): worst particles {worst.get('gscan', 0):.2e}, parameter beam {worst.get('gscan_pb', 0):.2e}")
     print(f"cavity scans vs reference ({dt}): worst particles {worst.get('cscan', 0):.2e}, parameter beam {worst.get('cscan_pb', 0):.2e}")
     print(f"energy scans vs reference ({dt}): worst particles {worst.get('escan', 0):.2e}, parameter beam {worst.get('escan_pb', 0):.2e}")
     print(f"scans vs reference ({dt}): worst particles {worst['particles']:.2e}, readings {worst['readings']:.2e}, "
