@@ -863,9 +863,12 @@ class Segment(Element):
 
     @staticmethod
     def _refresh_expanded(expanded) -> None:
-        """The expanded copies of settings whose own shape is not the batch shape follow in-place edits of the settings."""
+        """The expanded copies of settings whose own shape is not the batch shape follow in-place edits of the settings. While a
+        device graph records, the copy is made unconditionally: it becomes a node of the graph, so a replay follows settings that
+        were written between two replays (a version counter is host state the replay does not see)."""
+        recording = torch.cuda.is_current_stream_capturing()
         for src, copy, version in expanded:
-            if src._version != version[0]:
+            if recording or src._version != version[0]:
                 with torch.no_grad():
                     copy.copy_(src.expand(copy.shape))
                 version[0] = src._version

@@ -234,3 +234,43 @@ def test_a_lattice_with_monitors_apertures_and_cavities_replays_from_a_graph(bea
         replayed = captured().clone()
         now = step().clone()
         assert torch.equal(replayed, now) and not torch.equal(replayed, eager)
+
+
+@pytest.mark.parametrize("beam_kind", ["particles", "parameters"])
+def test_a_grid_scan_by_broadcasting_replays_from_a_graph(beam_kind):
+    """A grid scan whose settings have shapes (3, 1) and (1, 4): the stretch reads them through expanded copies. Inside a recording
+    the copies are made as nodes of the graph, so a replay follows strengths written in place BETWEEN two replays, like every other
+    setting."""
+    import torch
+
+    import cheetah_amd as ca
+
+    dt = torch.float32
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    ka = torch.linspace(-3.0, 3.0, 3, **kw).reshape(3, 1).contiguous()
+    kb = torch.linspace(-2.0, 2.0, 4, **kw).reshape(1, 4).contiguous()
+    bpms = [ca.BPM(is_active=True, **kw) for _ in range(3)]
+    seg = ca.Segment([ca.Drift(t(0.3), **kw), ca.Quadrupole(t(0.2), k1=ka, **kw), ca.Drift(t(0.5), **kw), bpms[0],
+                      ca.Cavity(t(1.0377), voltage=t(18e6), phase=t(-10.0), frequency=t(1.3e9), **kw), bpms[1],
+                      ca.Quadrupole(t(0.2), k1=kb, **kw), ca.Drift(t(0.4), **kw), bpms[2]])
+    if beam_kind == "particles":
+        beam = ca.ParticleBeam.from_parameters(num_particles=5_000, energy=t(6e7), mu_x=t(1e-4), **kw)
+        state = lambda b: b.particles  # noqa: E731
+    else:
+        beam = ca.ParameterBeam.from_parameters(energy=t(6e7), mu_x=t(1e-4), **kw)
+        state = lambda b: b.mu  # noqa: E731
+
+    def step():
+        out = seg.track(beam)
+        return torch.cat([state(out).reshape(-1)[:140], torch.cat([b.reading.reshape(-1) for b in bpms])])
+
+    with torch.no_grad():
+        eager = step().clone()
+        captured = ca.graph.capture(step)
+        assert torch.equal(captured().clone(), eager)
+        ka.mul_(-1.7)
+        kb.add_(0.3)
+        replayed = captured().clone()
+        now = step().clone()
+        assert torch.equal(replayed, now) and not torch.equal(replayed, eager)
