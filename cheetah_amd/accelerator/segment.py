@@ -483,6 +483,8 @@ class _LatticePlan:
         if need == 0:
             return False
         if self.state.numel() * 8 < need:
+            if torch.cuda.is_current_stream_capturing():
+                return False          # (persistent state is not allocated from a recording's private pool: the walk is capturable)
             self.state = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
             self.capsule = _lib.host().lattice_plan(self.table.data_ptr(), n_items, n_elems, n_ptrs, self.state.data_ptr(),
                                                     self.state.numel() * 8, self.code)
