@@ -881,6 +881,8 @@ class Segment(Element):
         epoch stands still — or None."""
         c = run.vrows
         if c is None or c[0] != Element._epoch or c[1] != dtype or c[2] != device:
+            if torch.cuda.is_current_stream_capturing():
+                return None       # (tables — and expanded copies — are not built inside a recording; the general path is capturable)
             got = Segment._vector_run_rows(run, dtype, device) if len(run.elements) <= 192 else None
             if got is not None:
                 kinds, rows, row_flags, keep, shape, expanded, _ = got
