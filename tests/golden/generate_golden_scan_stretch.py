@@ -25,6 +25,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 f64 = {"dtype": torch.float64}
 rng = np.random.default_rng(20261001)
 ROWS = 4
+SUB = 300       # particles whose outgoing coordinates are kept for the energy / cavity / grid scans (the readings see all 1200)
 
 
 def u(lo, hi):
@@ -119,8 +120,8 @@ if __name__ == "__main__":
         ebeam = cheetah.ParticleBeam(beam.particles, escan, particle_charges=beam.particle_charges, survival_probabilities=w, **f64)
         eout = seg.track(ebeam)
         arrays[f"lat{i}_escan_energy"] = escan.numpy()
-        arrays[f"lat{i}_escan_out"] = eout.particles.numpy()
-        arrays[f"lat{i}_escan_w_out"] = eout.survival_probabilities.numpy()
+        arrays[f"lat{i}_escan_out"] = eout.particles[..., :SUB, :].numpy()
+        arrays[f"lat{i}_escan_w_out"] = eout.survival_probabilities[..., :SUB].numpy()
         arrays[f"lat{i}_escan_energy_out"] = eout.energy.numpy()
         for k, b in enumerate(bpms):
             arrays[f"lat{i}_escan_reading{k}"] = b.reading.numpy()
@@ -148,8 +149,8 @@ if __name__ == "__main__":
             cbpms = [e for e in cseg.elements if isinstance(e, cheetah.BPM)]
             cout = cseg.track(beam)
             arrays[f"lat{i}_cscan_spec"] = np.asarray(json.dumps(cspecs))
-            arrays[f"lat{i}_cscan_out"] = cout.particles.numpy()
-            arrays[f"lat{i}_cscan_w_out"] = cout.survival_probabilities.numpy()
+            arrays[f"lat{i}_cscan_out"] = cout.particles[..., :SUB, :].numpy()
+            arrays[f"lat{i}_cscan_w_out"] = cout.survival_probabilities[..., :SUB].numpy()
             arrays[f"lat{i}_cscan_energy_out"] = cout.energy.numpy()
             for k, b in enumerate(cbpms):
                 arrays[f"lat{i}_cscan_reading{k}"] = b.reading.numpy()
@@ -179,8 +180,8 @@ if __name__ == "__main__":
             gbpms = [e for e in gseg.elements if isinstance(e, cheetah.BPM)]
             gout = gseg.track(beam)
             arrays[f"lat{i}_gscan_spec"] = np.asarray(json.dumps(gspecs))
-            arrays[f"lat{i}_gscan_out"] = gout.particles.numpy()
-            arrays[f"lat{i}_gscan_w_out"] = gout.survival_probabilities.numpy()
+            arrays[f"lat{i}_gscan_out"] = gout.particles[..., :SUB, :].numpy()
+            arrays[f"lat{i}_gscan_w_out"] = gout.survival_probabilities[..., :SUB].numpy()
             arrays[f"lat{i}_gscan_energy_out"] = gout.energy.numpy()
             for k, b in enumerate(gbpms):
                 arrays[f"lat{i}_gscan_reading{k}"] = b.reading.numpy()

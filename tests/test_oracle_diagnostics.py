@@ -122,9 +122,10 @@ def test_oracle_walks_the_energy_scans_row_by_row_like_the_reference(oracle):
         for b in range(rows):
             row = [[k, {q: (v[b] if isinstance(v, list) and len(v) == rows and q in ("k1", "angle") else v) for q, v in kw.items()}] for k, kw in specs]
             x, w, E, s, readings = _walk(oracle, row, g[f"lat{i}_in"], g[f"lat{i}_w"], float(g[f"lat{i}_escan_energy"][b]))
-            err = (np.abs(x - ref[b]).max(axis=0) / np.abs(ref[b]).max(axis=0)).max()
+            sub = ref.shape[-2]                                   # (the file keeps the first `sub` particles of every row)
+            err = (np.abs(x[:sub] - ref[b]).max(axis=0) / np.abs(ref[b]).max(axis=0)).max()
             assert err < 1e-11, (i, b, err)
-            assert np.array_equal(w, w_ref[b] if w_ref.ndim == 2 else w_ref), (i, b)
+            assert np.array_equal(w[:sub], w_ref[b] if w_ref.ndim == 2 else w_ref), (i, b)
             assert E == pytest.approx(float(e_ref[b]), rel=1e-13)
             size = np.abs(ref[b][:, [0, 2]]).max()
             for k in range(int(g[f"lat{i}_n_bpms"])):
