@@ -534,7 +534,8 @@ def other_configs(ca, torch, device) -> dict:
         many = ca.ParticleBeam(beam.particles[:10_000].unsqueeze(0).repeat(16, 1, 1).contiguous(), beam.energy, **kw)
         res = {"workload": "100-element lattices with 25 active BPMs / 25 active apertures and a 16-cell cavity linac, fp32: us per "
                            "Segment.track (ParticleBeam of 1e5 particles; ParameterBeam; 16 beams of 1e4 particles in one ParticleBeam); an orbit "
-                           "response of 25 cells, each corrector angle a (64,) tensor (ParameterBeam; one 1e4-particle beam shared by the rows)"}
+                           "response of 25 cells, each corrector angle a (64,) tensor (ParameterBeam; one 1e4-particle beam shared by the rows); the "
+                           "cavity linac at 64 beam energies, with the phase of every cavity a (64,) tensor, and with two cavities switched off"}
         with torch.no_grad():
             for name, els in (("bpm_lattice", bpm_cells), ("aperture_lattice", ap_cells), ("cavity_linac", linac)):
                 seg = ca.Segment(els)
@@ -554,6 +555,27 @@ def other_configs(ca, torch, device) -> dict:
             small = ca.ParticleBeam(beam.particles[:10_000].contiguous(), beam.energy, **kw)
             res["orbit_response_64_settings"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
                                                  "particle_beam_1e4_us": timed_us(lambda: seg.track(small))}
+            # the 16-cell cavity linac under scans and with cavities switched off: 64 beam energies; the phase of every cavity a
+            # (64,) tensor; two cavities at voltage 0 (skippable, drift-like) — each one stretch call
+            def cav_linac(phase_of, off=()):
+                out = []
+                for i in range(16):
+                    out += [ca.Drift(tt(0.3), **kw), ca.Quadrupole(tt(0.2), k1=tt(3.0 if i % 2 else -3.0), **kw),
+                            ca.Cavity(tt(1.0377), voltage=tt(0.0 if i in off else 18e6), phase=phase_of(i), frequency=tt(1.3e9), **kw)]
+                return ca.Segment(out)
+
+            energies = torch.linspace(8e7, 1.2e8, 64, **kw)
+            e_pb = ca.ParameterBeam.from_parameters(energy=energies, **kw)
+            e_beam = ca.ParticleBeam(small.particles, energies, **kw)
+            seg = cav_linac(lambda i: tt(-10.0))
+            res["linac_64_energies"] = {"parameter_beam_us": timed_us(lambda: seg.track(e_pb)),
+                                        "particle_beam_1e4_us": timed_us(lambda: seg.track(e_beam))}
+            seg = cav_linac(lambda i: torch.linspace(-30.0, 30.0, 64, **kw))
+            res["linac_64_phases_of_every_cavity"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
+                                                      "particle_beam_1e4_us": timed_us(lambda: seg.track(small))}
+            seg = cav_linac(lambda i: tt(-10.0), off=(5, 9))
+            res["linac_two_cavities_off"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
+                                             "particle_beam_us": timed_us(lambda: seg.track(beam))}
         return res
 
     for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order),
