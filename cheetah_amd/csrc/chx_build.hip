@@ -1750,29 +1750,63 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
         return (a & 1) ? base[r] : base[0];
     };
     auto setting = [&](int64_t q) { return setting_of(q, row); };
-    if (threadIdx.x == 0) {
+    {
         // the reference energy this item sees: through the cavities in front of it, rounded to T after each (the energy is a
-        // tensor of the beam's dtype between two elements)
+        // tensor of the beam's dtype between two elements). The energy gains of the cavities in front are LOADED side by side (one
+        // thread per item: four dependent loads each — item, element, address, value — 60 in a row for the last item of a 16-cell
+        // linac when one thread walks them, ~60 us of a 105 us launch at 64 rows) and then summed in order by one thread.
+        __shared__ double gain_sh[CHX_BLOCK];
+        __shared__ int is_cavity_sh[CHX_BLOCK];
         double e = (double)energy[energy_rows ? row : 0];
-        for (int i = 0; i < b; ++i) {
-            if (items[i * 4] != 1) continue;
-            const int64_t po = elem_poff[items[i * 4 + 2]];
-            const double dEn = (double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0;
-            e = (double)(T)(e + dEn);
+        for (int base = 0; base < b; base += CHX_BLOCK) {
+            const int i = base + (int)threadIdx.x;
+            int cav = 0;
+            double dEn = 0.0;
+            if (i < b && items[i * 4] == 1) {
+                const int64_t po = elem_poff[items[i * 4 + 2]];
+                dEn = (double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0;
+                cav = 1;
+            }
+            gain_sh[threadIdx.x] = dEn;
+            is_cavity_sh[threadIdx.x] = cav;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int n = (b - base < CHX_BLOCK) ? (b - base) : CHX_BLOCK;
+                for (int j = 0; j < n; ++j)
+                    if (is_cavity_sh[j]) e = (double)(T)(e + gain_sh[j]);
+            }
+            __syncthreads();
         }
-        e_in_sh = e;
+        if (threadIdx.x == 0) e_in_sh = e;
     }
-    if (b == n_items - 1 && threadIdx.x == 64 && s_out && row == 0) {
-        // path length behind the stretch: s + run length (((L0 + L1) + L2) + ...) / + cavity length, item by item, in T
+    if (b == n_items - 1 && s_out && row == 0) {           // (uniform over the workgroup)
+        // path length behind the stretch: s + run length (((L0 + L1) + L2) + ...) / + cavity length, item by item, in T. Every
+        // item's own length is summed by a thread of its own (its loads wait side by side with the other items'), one thread then
+        // adds the items in order.
+        __shared__ T total_sh[CHX_BLOCK];
+        __shared__ int has_length_sh[CHX_BLOCK];
         T sv = *s_in;
-        for (int i = 0; i < n_items; ++i) {
-            if (items[i * 4] >= 2) continue;               // a beam position monitor / an aperture: no length
-            const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
-            T total = setting(elem_poff[e0]);
-            for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
-            sv = sv + total;
+        for (int base = 0; base < n_items; base += CHX_BLOCK) {
+            const int i = base + (int)threadIdx.x;
+            int has = 0;
+            T total = (T)0;
+            if (i < n_items && items[i * 4] < 2) {         // (a beam position monitor / an aperture: no length)
+                const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
+                total = setting(elem_poff[e0]);
+                for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
+                has = 1;
+            }
+            total_sh[threadIdx.x] = total;
+            has_length_sh[threadIdx.x] = has;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int n = (n_items - base < CHX_BLOCK) ? (n_items - base) : CHX_BLOCK;
+                for (int j = 0; j < n; ++j)
+                    if (has_length_sh[j]) sv = sv + total_sh[j];
+            }
+            __syncthreads();
         }
-        *s_out = sv;
+        if (threadIdx.x == 0) *s_out = sv;
     }
     __syncthreads();
     const double E0 = e_in_sh;
