@@ -53,6 +53,17 @@ class CicArgs(ctypes.Structure):
     ]
 
 
+class LatticeScreen(ctypes.Structure):
+    """struct chx_lattice_screen (include/chx.h): one active Screen's output buffers of a stretch call."""
+
+    _fields_ = [
+        ("rows", c_void_p), ("charges", c_void_p), ("survival", c_void_p), ("energy", c_void_p), ("s", c_void_p),
+        ("image", c_void_p), ("image_bytes", c_i64),
+        ("mu", c_void_p), ("cov", c_void_p), ("geom", c_void_p), ("shift", c_void_p), ("total_charge", c_void_p),
+        ("total_charge_out", c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+    ]
+
+
 class Hist2dArgs(ctypes.Structure):
     """struct chx_hist2d_args (include/chx.h)."""
 
@@ -151,6 +162,15 @@ SIGNATURES = {
     "chx_lattice_track_diag": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                        c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "chx_lattice_track_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                                          c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_i64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_i64, c_void_p]),
+    "chx_lattice_prepare_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_double, c_double, c_int, c_void_p,
+                                            c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "chx_screen_extent": (c_int, [c_void_p, ctypes.c_int32, ctypes.c_int32, c_int, c_void_p, c_void_p]),
+    "chx_parameter_lattice_track_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t,
+                                                    c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
     "chx_lattice_state_bytes_batched": (c_size_t, [c_i64, c_i64, c_i64]),
     "chx_lattice_prepare_batched": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -273,7 +293,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 6:  # CHX_ABI_VERSION of include/chx.h
+        if handle.chx_abi_version() != 7:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib
@@ -303,3 +323,24 @@ def host():
         _chxhost.bind_lattice(ctypes.cast(lib().chx_lattice_track_diag, ctypes.c_void_p).value)
         _host = _chxhost
     return _host
+
+
+_torch_host = None
+
+
+def torch_host():
+    """`cheetah_amd._chxtorch` (csrc/chx_torch_host.cpp), bound to libchx's stretch entry points: the host step of a stretch with
+    active Screens in C++ against ATen. Built by the same Makefile as libchx.so; missing = a broken build."""
+    global _torch_host
+    if _torch_host is None:
+        try:
+            from . import _chxtorch
+        except ImportError as exc:  # pragma: no cover - broken build
+            raise ImportError("cheetah_amd._chxtorch is not built: run `make -C cheetah_amd/csrc` "
+                              "(or `python -c 'import __graft_entry__ as g; g.build()'`)") from exc
+        h = lib()
+        _chxtorch.bind(ctypes.cast(h.chx_lattice_track_screens, ctypes.c_void_p).value,
+                       ctypes.cast(h.chx_parameter_lattice_track_screens, ctypes.c_void_p).value,
+                       torch._C._cuda_getCurrentRawStream, ChxError)
+        _torch_host = _chxtorch
+    return _torch_host

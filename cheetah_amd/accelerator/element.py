@@ -82,6 +82,7 @@ class Element(nn.Module):
     _is_cavity = False            # Cavity: may join a stretch of `chx_lattice_track` (Segment._lattice_stretch)
     _is_bpm = False               # BPM (when active): likewise, as an item that reads the beam and lets it pass
     _is_aperture = False          # Aperture (when active): likewise, as an item that thins the survival probabilities
+    _is_screen = False            # Screen (when active): likewise, as an item that records the beam (and its image) and lets it pass
     #: True when `is_skippable` depends on non-tensor attributes only (those bump `_revision` when set)
     _static_skippable = True
     #: process-wide count of attribute assignments on any element (see `_touch`)

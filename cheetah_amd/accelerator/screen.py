@@ -21,6 +21,12 @@ class Screen(Element):
     """Diagnostic screen."""
 
     _chx_kind = _ops.KIND["identity"]
+    _is_screen = True
+
+    #: beams of at most this many particles get their cloud-in-cell image deposited by the stretch call that tracks them
+    #: (`Segment._lattice_stretch`: no further launch, and `reading` has nothing left to do); larger beams are recorded only and the
+    #: image is formed when it is asked for — the deposit's atomics then cost more than the launch they save
+    _EAGER_IMAGE_PARTICLES = 262_144
 
     def __init__(self, resolution=(1024, 1024), pixel_size=None, binning=1, misalignment=None,
                  method="cloud-in-cell", kde_bandwidth=None, is_blocking=False, is_active=False, name=None,
@@ -71,8 +77,13 @@ class Screen(Element):
             self.__dict__["_geom_cache"] = cache
         if what not in cache:
             cache[what] = (self._compute_extent() if what == "extent" else self._compute_edges() if what == "edges"
-                           else self._compute_sample_counts())
+                           else self._compute_gauss_geom() if what == "gauss_geom" else self._compute_sample_counts())
         return cache[what]
+
+    def _compute_gauss_geom(self) -> torch.Tensor:
+        """[left, hstep, bottom, vstep] of the sample grid of a ParameterBeam's image (screen.py:276-287)."""
+        ext = self.extent
+        return torch.stack([ext[0], self.pixel_size[0] * self.binning, ext[2], self.pixel_size[1] * self.binning])
 
     def _compute_sample_counts(self) -> tuple[int, int]:
         """Number of density samples per axis of a ParameterBeam image: the reference samples on
@@ -121,12 +132,54 @@ class Screen(Element):
 
         return _unaliased(self._track_internal(incoming), incoming)   # screen.py:239 `return incoming.clone()`
 
+    def _image_key(self) -> tuple:
+        """What an image deposited ahead of its first reading depends on besides the recorded beam: the reference forms the image
+        when it is first asked for (screen.py:241-244), with the screen's settings of THAT moment."""
+        b = self._buffers
+        ps, mis = b.get("pixel_size"), b.get("misalignment")
+        if ps is None or mis is None:
+            return ()                                   # (trainable geometry: never deposited ahead)
+        return (self.resolution, self.binning, self.method, id(ps), ps._version, id(mis), mis._version, mis.dtype, mis.device)
+
+    def _record_stretch(self, record, n: int, species, image, kind: str = "particles") -> None:
+        """Called by the stretch call of `Segment.track` (`chx_lattice_track_screens` / `chx_parameter_lattice_track_screens`):
+        `record` is ONE tensor holding the copy of the beam that reached this screen ([rows | charges | survival | energy | s] of
+        n particles, or [mu | cov | energy | s | total charge]), `image` the reading deposited by the same call (or None). The
+        beam object is built when somebody asks for it."""
+        d = self.__dict__
+        d["_incoming"] = None
+        d["_record"] = (record, n, species, kind)
+        d["_read_beam"] = None
+        mis = self._buffers["misalignment"]
+        d["_placed"] = (mis.dtype, mis.device)
+        d["_cached_reading"] = image
+        d["_eager"] = None if image is None else (self._image_key(), self._buffers["pixel_size"], mis)
+
+    def _incoming_beam(self):
+        """The recorded (unshifted) beam; a stretch call's record becomes a beam object here, on first use."""
+        d = self.__dict__
+        beam = d.get("_incoming")
+        if beam is None:
+            rec = d.get("_record")
+            if rec is not None:
+                t, n, species, kind = rec
+                if kind == "particles":
+                    beam = ParticleBeam(t[:7 * n].view(n, 7), t[9 * n], particle_charges=t[7 * n:8 * n],
+                                        survival_probabilities=t[8 * n:9 * n], s=t[9 * n + 1], species=species)
+                else:
+                    beam = ParameterBeam(t[:7], t[7:56].view(7, 7), t[56], total_charge=t[58], s=t[57], species=species)
+                d["_incoming"] = beam
+                d["_record"] = None
+        return beam
+
     def _track_internal(self, incoming: ParticleBeam) -> ParticleBeam:
         if self.is_active:
             # a snapshot of the unshifted beam is recorded (screen.py:190: later in-place edits of the incoming or
             # outgoing beam must not change the reading); the misalignment is applied inside the image kernels
             # and lazily in get_read_beam()
             self.__dict__["_incoming"] = incoming._snapshot()
+            self.__dict__["_record"] = None
+            self.__dict__["_eager"] = None
             self.__dict__["_placed"] = (self.misalignment.dtype, self.misalignment.device)
             self.__dict__["_read_beam"] = None
             self.__dict__["_cached_reading"] = None
@@ -143,6 +196,14 @@ class Screen(Element):
     @property
     def reading(self) -> torch.Tensor:
         """Image of shape (…, height, width)."""
+        d = self.__dict__
+        eager = d.get("_eager")
+        if eager is not None:
+            # the image the tracking call deposited: valid if the screen still is what it was then
+            d["_eager"] = None
+            if eager[0] == self._image_key():
+                return d["_cached_reading"]
+            d["_cached_reading"] = None
         # Was the screen moved with .to() / .double() / .cuda() since the beam was recorded? Then the recorded beam and a cached
         # image follow it, like the reference's read beam, which is a sub-module of the screen (test_screen.py:137-159). A beam
         # whose dtype merely differs from the screen's is left alone: the reference's image then has the BEAM's dtype.
@@ -157,7 +218,7 @@ class Screen(Element):
                 cached = cached.to(device=now[1], dtype=now[0])
                 self.__dict__["_cached_reading"] = cached
             return cached
-        beam = self.__dict__.get("_incoming")
+        beam = self._incoming_beam()
         if beam is not None and moved:
             beam = beam.to(device=now[1], dtype=now[0])
             self.__dict__["_incoming"] = beam
@@ -173,8 +234,7 @@ class Screen(Element):
             image = self.misalignment.new_zeros((int(h), int(w)))
         elif isinstance(beam, ParameterBeam):
             # bivariate normal density sampled at the pixel origins (screen.py:255-291)
-            ext = self.extent
-            geom = torch.stack([ext[0], self.pixel_size[0] * self.binning, ext[2], self.pixel_size[1] * self.binning])
+            geom = self._compute_gauss_geom() if self.pixel_size.requires_grad else self._geometry("gauss_geom")
             nx, ny = self._compute_sample_counts() if self.pixel_size.requires_grad else self._geometry("sample_counts")
             image = _ops.screen_gaussian(beam.mu, beam.cov, self.misalignment, geom, nx, ny)
         elif self.method == "histogram":
@@ -205,7 +265,7 @@ class Screen(Element):
 
     def get_read_beam(self) -> ParticleBeam | None:
         """The beam as seen by the screen, i.e. with x, y relative to the screen centre (screen.py:196-214)."""
-        if self.__dict__.get("_read_beam") is None and self.__dict__.get("_incoming") is not None:
+        if self.__dict__.get("_read_beam") is None and self._incoming_beam() is not None:
             inc = self.__dict__["_incoming"]
             zero = self.__dict__.get("_zero_misalignment")
             if zero is not None and zero[0] is self.misalignment and zero[1] == zero[0]._version \
@@ -229,6 +289,8 @@ class Screen(Element):
     def set_read_beam(self, value) -> None:
         self.__dict__["_placed"] = (self.misalignment.dtype, self.misalignment.device)
         self.__dict__["_incoming"] = value
+        self.__dict__["_record"] = None
+        self.__dict__["_eager"] = None
         self.__dict__["_read_beam"] = value
         self.__dict__["_cached_reading"] = None
 

@@ -47,7 +47,7 @@ def _any_requires_grad_py(*tensors) -> bool:
     return False
 
 
-#: one C call over the tensors of a run: `cheetah_amd._chxtorch` (csrc/chx_torch_probe.cpp) reads the flag straight from the
+#: one C call over the tensors of a run: `cheetah_amd._chxtorch` (csrc/chx_torch_host.cpp) reads the flag straight from the
 #: tensor objects — 0.9 us for the 300 setting tensors of the 100-element FODO where torch._C._any_requires_grad's argument
 #: parser takes 7-13 us; without the extension (a torch upgrade without a rebuild) torch's own function, then the Python loop
 try:
@@ -275,11 +275,14 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc", "screens", "allow_screens", "capsule_s")
 
-    def __init__(self, items, dtype, device, allow_vector=False):
+    def __init__(self, items, dtype, device, allow_vector=False, allow_screens=False):
         self.items, self.dtype, self.device = items, dtype, device
         self.allow_vector = allow_vector       # a ParameterBeam's stretch takes runs with vectorised settings; particles end there
+        self.allow_screens = allow_screens     # ONE plain beam under scalar settings: active Screens are items of the stretch
+        self.screens = ()                      # the active screens of the stretch, in record-slot order
+        self.capsule_s = None
         self.code = _ops.dtype_code(dtype)
         self.table = self.state = self.capsule = None
         self.tensors = ()
@@ -297,6 +300,7 @@ class _LatticePlan:
         lib = _lib.lib()
         dtype, device = self.dtype, self.device
         rows, elem_kind, elem_poff, ptrs, tensors, bpms, apertures = [], [], [], [], [], [], []
+        screens, screen_shapes = [], []
         count = cavities = longest_run = 0
         vshape, bpm_vec, ap_vec = None, [], []
         bpm_after, ap_after, maps_seen = [], [], False   # does a run / cavity (a map) sit in front of the monitor / aperture?
@@ -325,6 +329,28 @@ class _LatticePlan:
             return b if a is None else a if b is None else tuple(torch.broadcast_shapes(a, b))
 
         for kind, item in self.items:
+            if kind != "run" and item._is_screen:
+                # an active screen: {4, flags, where the addresses of its misalignment and pixel size (and its resolution and
+                # image shape) sit in ptrs, record slot} — it records the beam that reaches it (and deposits its cloud-in-cell
+                # image from the particle pass) and lets the beam pass (screen.py:187-239)
+                from .screen import Screen
+
+                b = item.__dict__["_buffers"]
+                mis, ps = b.get("misalignment"), b.get("pixel_size")
+                if not self.allow_screens or vshape is not None or len(screens) >= 4 \
+                        or type(item)._track_internal is not Screen._track_internal or type(item).reading is not Screen.reading \
+                        or not item.is_active or item.is_blocking or mis is None or ps is None \
+                        or any(t.shape != (2,) or t.dtype != dtype or t.device != device or not t.is_contiguous() for t in (mis, ps)):
+                    break
+                res, bins = item.resolution, item.effective_resolution
+                deposit = 1 if item.method == "cloud-in-cell" else 0
+                rows += [4, deposit, len(ptrs), len(screens)]
+                ptrs += [mis.data_ptr(), ps.data_ptr(), int(res[0]), int(res[1]), int(bins[0]), int(bins[1])]
+                tensors += [mis, ps]
+                screens.append(item)
+                screen_shapes.append((deposit, int(bins[0]), int(bins[1])))
+                count += 1
+                continue
             if kind != "run" and item._is_aperture:
                 # an active aperture: {3, shape, where the addresses of x_max and y_max sit in ptrs, -}
                 from .marker import Aperture
@@ -379,7 +405,7 @@ class _LatticePlan:
                 else:
                     # settings vectorised over a batch of lattice settings: addresses tagged with their lowest bit (a (rows,) array);
                     # one batch shape for the whole stretch
-                    got = Segment._vector_run_rows(item, dtype, device, common) if self.allow_vector else None
+                    got = Segment._vector_run_rows(item, dtype, device, common) if (self.allow_vector and not screens) else None
                     # (one workgroup per item and row prepares the maps: beyond a few hundred rows the walk item by item is cheaper)
                     if got is None or got[4] is None or (vshape is not None and got[4] != vshape) or len(got[0]) > 192 \
                             or _ops.numel(got[4]) > 65535:
@@ -412,7 +438,7 @@ class _LatticePlan:
                 for k, t in enumerate(settings):
                     if t.dim() == 0:
                         cav_ptrs.append(t.data_ptr())
-                    elif not self.allow_vector or k == 0 or not t.is_contiguous() or common is None or _ops.numel(common) > 65535:
+                    elif not self.allow_vector or screens or k == 0 or not t.is_contiguous() or common is None or _ops.numel(common) > 65535:
                         fits = False
                         break
                     else:
@@ -446,7 +472,8 @@ class _LatticePlan:
         self.bpm_after, self.ap_after = tuple(bpm_after), tuple(ap_after)
         self.e_out_rows = e_out_rows
         self.expanded, self.bpm_acc, self.ap_acc, self.e_acc = tuple(expanded), tuple(bpm_acc), tuple(ap_acc), e_acc
-        if count < 2 or (cavities == 0 and not bpms and not apertures) or not elem_kind:
+        self.screens, self.capsule_s = tuple(screens), None
+        if count < 2 or (cavities == 0 and not bpms and not apertures and not screens) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
         self.vshape = vshape
@@ -470,6 +497,10 @@ class _LatticePlan:
             self.state = torch.empty(state_bytes // 8 + 1, dtype=torch.float64, device=device)
         self.capsule = _lib.host().lattice_plan(self.table.data_ptr(), n_items, n_elems, n_ptrs, self.state.data_ptr(),
                                                 self.state.numel() * 8, self.code)
+        if screens:
+            # the same plan as the C++ host step sees it (cheetah_amd._chxtorch): with the screens' image shapes
+            self.capsule_s = _lib.torch_host().stretch_plan(self.table.data_ptr(), n_items, n_elems, n_ptrs, self.state.data_ptr(),
+                                                            self.state.numel() * 8, self.code, tuple(screen_shapes))
         self.shape = (n_items, n_elems, n_ptrs)
         self.tensors = tuple(tensors)       # kept alive: the table holds their addresses
         self.ok = True
@@ -514,6 +545,19 @@ class _HostProxy:
 
 
 _HOST = _HostProxy()
+
+
+class _TorchHostProxy:
+    """`cheetah_amd._chxtorch`, loaded (and bound to libchx) at first use."""
+
+    def __getattr__(self, name):
+        h = _lib.torch_host()
+        global _TORCH_HOST
+        _TORCH_HOST = h
+        return getattr(h, name)
+
+
+_TORCH_HOST = _TorchHostProxy()
 
 
 class _Run:
@@ -1030,6 +1074,10 @@ class Segment(Element):
             return torch.empty_like(s_in)
         return None
 
+    #: active Screens as items of the stretch call (False: a screen ends the stretch and is tracked on its own — the walk the
+    #: tests compare the stretch with)
+    _STRETCH_SCREENS = True
+
     #: rows of vectorised lattice settings a ParameterBeam's stretch call takes when a WORKGROUP per (item, row) prepares the maps
     #: (cavities, or runs of more than 64 elements; above: the walk item by item, whose cost does not depend on the rows —
     #: benchmarks/response_matrix_probe.py: 64 rows 1.4 -> 0.14 ms, 4096 rows 1.4 -> 6.4 ms). Without cavities and with short runs a
@@ -1129,7 +1177,7 @@ class Segment(Element):
             while i < n_items:
                 kind, item = plan[i]
                 i += 1
-                if (kind == "run" or item._is_cavity or item._is_bpm) and n_items - i >= 1:
+                if (kind == "run" or item._is_cavity or item._is_bpm or item._is_screen) and n_items - i >= 1:
                     done = self._lattice_stretch_parameter(plan, i - 1, incoming)
                     if done is not None:
                         incoming, i = done
@@ -1176,7 +1224,7 @@ class Segment(Element):
                     chain = None
                 i += step
                 continue
-            if (kind == "run" or item._is_cavity or item._is_bpm or item._is_aperture) and n_items - i >= 2:
+            if (kind == "run" or item._is_cavity or item._is_bpm or item._is_aperture or item._is_screen) and n_items - i >= 2:
                 done = self._lattice_stretch(plan, i, incoming)
                 if done is not None:
                     incoming, i = done
@@ -1238,19 +1286,24 @@ class Segment(Element):
         if cache is None or cache[0] is not plan:
             cache = self._lattice_cache_for(plan)
         p = incoming.particles
-        key = (i, p.dtype, p.device)
+        e = incoming.energy
+        # ONE plain beam at one energy: active Screens are items of the stretch too (their record and image come from the same two
+        # launches); a vectorised beam's stretch ends in front of a screen as before
+        with_screens = Segment._STRETCH_SCREENS and p.dim() == 2 and e.dim() == 0
+        key = (i, p.dtype, p.device, with_screens)
         entry = cache[1].get(key)
         if entry is None:
             j, cavities = i, 0
-            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm or plan[j][1]._is_aperture):
-                cavities += plan[j][0] != "run"          # (cavities, active BPMs and apertures: what makes a stretch worth one call)
+            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm or plan[j][1]._is_aperture
+                                     or (with_screens and plan[j][1]._is_screen)):
+                cavities += plan[j][0] != "run"          # (cavities, active BPMs, apertures, screens: what makes a stretch worth one call)
                 j += 1
             entry = cache[1][key] = False if (j - i < 2 or cavities == 0 or not p.is_cuda) else [j, None]
         if entry is False:
             return None
         if p.dim() < 2 or not p.is_cuda or (p.dim() > 2 and not p.is_contiguous()):
             return None                    # (B beams in one ParticleBeam: blockIdx.y of the particle pass)
-        e, s_in, sp = incoming.energy, incoming.s, incoming.species
+        s_in, sp = incoming.s, incoming.species
         if e.dtype != p.dtype or e.device != p.device or (e.dim() != 0 and not e.is_contiguous()):
             return None
         energy_rows = e.dim() != 0          # a scan of beam energies: row b of the maps is built for energy b
@@ -1259,7 +1312,7 @@ class Segment(Element):
             if torch.cuda.is_current_stream_capturing():
                 return None     # (the table's upload is not part of a recording: the walk item by item is capturable as it is)
             if lp is None:
-                lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device, allow_vector=True)
+                lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device, allow_vector=True, allow_screens=with_screens)
             else:
                 lp.refresh()
         if not lp.ok:
@@ -1270,11 +1323,12 @@ class Segment(Element):
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         _ops.check_current_device(lp.device)
         on_device = s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device and not s_in.requires_grad
-        if lp.bpms:
+        if lp.bpms or lp.screens:
             from .. import sharding
 
             if sharding.active_group() is not None:
-                return None            # a particle-sharded beam: the monitors read GLOBAL means (BPM._track_internal exchanges them)
+                return None            # a particle-sharded beam: the monitors read GLOBAL means (BPM._track_internal exchanges them),
+                #                        a screen sums its image over the ranks
         w_out = incoming.survival_probabilities
         lead_x, N = tuple(p.shape[:-2]), p.shape[-2]
         lead, Bm = lead_x, 1
@@ -1301,6 +1355,36 @@ class Segment(Element):
         if lp.expanded:
             Segment._refresh_expanded(lp.expanded)
         w_lead = tuple(incoming.survival_probabilities.shape[:-1])
+        if lp.screens:
+            # [run | cavity | monitor | aperture | active Screen]+ on one plain beam: the C++ host step (cheetah_amd._chxtorch)
+            # allocates the outgoing beam, every screen's record and image and enqueues the two launches
+            q, w = incoming.particle_charges, incoming.survival_probabilities
+            N = p.shape[0]
+            if lead or Bm != 1 or not on_device or q.shape != (N,) or w.shape != (N,) or q.dtype != p.dtype or w.dtype != p.dtype \
+                    or q.device != p.device or w.device != p.device or not q.is_contiguous() or not w.is_contiguous() \
+                    or (torch.is_grad_enabled() and (q.requires_grad or w.requires_grad)):
+                return None       # (charges or weights the screens' host step does not take: the walk, as before)
+            for ap in lp.apertures:
+                ap._check_limits()
+            n_bpm = len(lp.bpms)
+            readings = ws = None
+            ws_bytes = 0
+            if n_bpm:
+                readings = torch.empty((n_bpm, 1, 2), dtype=p.dtype, device=p.device)
+                ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, 1, n_bpm)
+                ws = _ops.workspace(ws_bytes, p.device)
+            if lp.apertures:
+                w_out = torch.empty((N,), dtype=p.dtype, device=p.device)
+            from .screen import Screen
+
+            out, e_out, s_out, records, images = _TORCH_HOST.lattice_track_screens(
+                lp.capsule_s, x, e, s_in, q, w, sp.mass_eV_float, sp.num_elementary_charges_float, lp.device.index,
+                Screen._EAGER_IMAGE_PARTICLES, w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes)
+            for k, bpm in enumerate(lp.bpms):
+                bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(2)
+            for screen, record, image in zip(lp.screens, records, images):
+                screen._record_stretch(record, N, sp, image)
+            return ParticleBeam(out, e_out, particle_charges=q, survival_probabilities=w_out, s=s_out, species=sp), i + lp.count
         if lp.bpms or lp.apertures or lead:
             # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
             # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —
@@ -1383,17 +1467,20 @@ class Segment(Element):
         cache = self.__dict__.get("_lattice_cache")
         if cache is None or cache[0] is not plan:
             cache = self._lattice_cache_for(plan)
-        key = (i, mu.dtype, mu.device, "moments")
+        e = incoming.energy
+        with_screens = Segment._STRETCH_SCREENS and mu.dim() == 1 and cov.dim() == 2 and e.dim() == 0       # (one beam: active Screens are items of the stretch)
+        key = (i, mu.dtype, mu.device, "moments", with_screens)
         entry = cache[1].get(key)
         if entry is None:
             j, special = i, 0
-            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm or plan[j][1]._is_aperture):
+            while j < len(plan) and (plan[j][0] == "run" or plan[j][1]._is_cavity or plan[j][1]._is_bpm or plan[j][1]._is_aperture
+                                     or (with_screens and plan[j][1]._is_screen)):
                 special += plan[j][0] != "run"
                 j += 1
             entry = cache[1][key] = False if (j - i < 2 or special == 0) else [j, None]
         if entry is False:
             return None
-        e, s_in, sp = incoming.energy, incoming.s, incoming.species
+        s_in, sp = incoming.s, incoming.species
         if e.dtype != mu.dtype or e.device != mu.device or (e.dim() != 0 and not e.is_contiguous()):
             return None
         energy_rows = e.dim() != 0          # a scan of beam energies: row b of the maps is built for energy b
@@ -1402,7 +1489,7 @@ class Segment(Element):
             if torch.cuda.is_current_stream_capturing():
                 return None
             if lp is None:
-                lp = entry[1] = _LatticePlan(plan[i:entry[0]], mu.dtype, mu.device, allow_vector=True)
+                lp = entry[1] = _LatticePlan(plan[i:entry[0]], mu.dtype, mu.device, allow_vector=True, allow_screens=with_screens)
             else:
                 lp.refresh()
         if not lp.ok or lp.apertures:                # (an aperture only warns for a ParameterBeam: the walk does that)
@@ -1410,6 +1497,30 @@ class Segment(Element):
         if torch.is_grad_enabled() and (mu.requires_grad or cov.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
             return None
+        if lp.screens:
+            # one ParameterBeam through [run | cavity | monitor | active Screen]+: the C++ host step allocates the outgoing moments,
+            # every screen's record and its image (the bivariate normal density, screen.py:255-291) and enqueues the launches
+            q = incoming.total_charge
+            on_device = s_in.dim() == 0 and s_in.dtype == mu.dtype and s_in.device == mu.device and not s_in.requires_grad
+            if not on_device or not mu.is_contiguous() or not cov.is_contiguous() or q.dim() != 0 or q.dtype != mu.dtype \
+                    or q.device != mu.device or e.dtype != mu.dtype or e.device != mu.device \
+                    or (torch.is_grad_enabled() and q.requires_grad):
+                return None
+            _ops.check_current_device(lp.device)
+            geoms = []
+            for screen in lp.screens:
+                nx, ny = screen._geometry("sample_counts")
+                geoms.append((screen._geometry("gauss_geom"), screen.__dict__["_buffers"]["misalignment"], nx, ny))
+            n_bpm = len(lp.bpms)
+            readings = torch.empty((n_bpm, 1, 2), dtype=mu.dtype, device=mu.device) if n_bpm else None
+            mu_out, cov_out, e_out, s_out, records, images = _TORCH_HOST.parameter_lattice_track_screens(
+                lp.capsule_s, mu, cov, e, s_in, q, sp.mass_eV_float, sp.num_elementary_charges_float, lp.device.index, tuple(geoms),
+                n_bpm, readings)
+            for k, bpm in enumerate(lp.bpms):
+                bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(2)
+            for screen, record, image in zip(lp.screens, records, images):
+                screen._record_stretch(record, 0, sp, image, "moments")
+            return ParameterBeam(mu_out, cov_out, e_out, total_charge=q, s=s_out, species=sp), i + lp.count
         try:
             lead = torch.broadcast_shapes(mu.shape[:-1], cov.shape[:-2], lp.vshape if lp.vshape is not None else (), e.shape)
         except RuntimeError:

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "chx_common.h"
+#include "chx_cic_dev.h"
 
 namespace {
 
@@ -558,7 +559,16 @@ namespace {
 // An item of type 3 is an active aperture (aperture.py:90-135): survival *= inside(x, y) in T, the arithmetic of
 // aperture_kernel (chx_aperture.hip) — the weights of the monitors behind it are the reduced ones, and the pass writes the
 // outgoing survival probabilities.
-template <typename T, int PPT>
+// An item of type 4 is an active Screen (screen.py:187-239, 241-344): the rows, charges and survival probabilities of the beam AT
+// that point are recorded (the screen's copy of the beam, unshifted) and — flag bit 0 — every particle adds |q| w to its four
+// pixels of the image, which the preparation launch zeroed: the arithmetic of cic_deposit_kernel on (x - misalignment) through the
+// same per-workgroup combining table, the extent derived from the pixel size (screen_extent_axis).
+struct ApplyScreens {
+    chx_lattice_screen s[CHX_LATTICE_MAX_SCREENS];
+    const void* charge;      // [N] or NULL (= 1)
+};
+
+template <typename T, int PPT, bool SCREENS>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in, T* x_out, const int64_t* __restrict__ items, int n_items,
                                                                  const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                                  int64_t N, int in_vec_ok, int out_vec_ok,
@@ -566,7 +576,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                                                                  const int64_t* __restrict__ ptrs, T* __restrict__ survival_out,
                                                                  int shared_in /*x_in is ONE beam of N particles for all rows*/,
                                                                  int64_t Bm /*rows of lattice settings: 1, or gridDim.y*/,
-                                                                 int shared_sv /*survival is ONE row of N weights for all rows*/) {
+                                                                 int shared_sv /*survival is ONE row of N weights for all rows*/,
+                                                                 ApplyScreens scr) {
     constexpr int TP = PPT * CHX_BLOCK;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     // blockIdx.y = beam (a vectorised ParticleBeam of gridDim.y beams of N particles under ONE lattice setting and energy: the
@@ -628,6 +639,80 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                 part[2] = sy;
             }
             continue;
+        }
+        if constexpr (SCREENS) {
+            if (type == 4) {
+                __shared__ long long comb_keys[kCombSlots];
+                __shared__ double comb_vals[kCombSlots];
+                const int64_t q = items[i * 4 + 2];
+                const chx_lattice_screen& so = scr.s[(int)items[i * 4 + 3]];
+                const T* __restrict__ charge = (const T*)scr.charge;
+                T* rows = (T*)so.rows;
+                if (rows) {
+                    __syncthreads();                   // (the tile is free: its rows sit in registers)
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int p = threadIdx.x + k * CHX_BLOCK;
+                        if (p < np) {
+#pragma unroll
+                            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x[k][j];
+                        }
+                    }
+                    __syncthreads();
+                    tile_store<T, TP>(rows + n0 * 7, lds, np * 7, chx_aligned16(rows) && row_vec, false);
+                }
+                T* sv_rec = (T*)so.survival;
+                T* q_rec = (T*)so.charges;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int p = threadIdx.x + k * CHX_BLOCK;
+                    if (p < np) {
+                        if (sv_rec) sv_rec[n0 + p] = sv[k];
+                        if (q_rec) q_rec[n0 + p] = charge ? charge[t0 + p] : (T)1;
+                    }
+                }
+                if ((items[i * 4 + 1] & 1) && so.image) {
+                    const T* mis = (const T*)ptrs[q];
+                    const T* ps = (const T*)ptrs[q + 1];
+                    const int bins_x = (int)ptrs[q + 4], bins_y = (int)ptrs[q + 5];
+                    T lx, rx, ly, ry;
+                    screen_extent_axis<T>((int)ptrs[q + 2], ps[0], lx, rx);
+                    screen_extent_axis<T>((int)ptrs[q + 3], ps[1], ly, ry);
+                    const T mx = mis[0], my = mis[1];
+                    CombTable<T> table;
+                    table.init(comb_keys, comb_vals, (T*)so.image);
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int p = threadIdx.x + k * CHX_BLOCK;
+                        if (p >= np) continue;
+                        const T vx = x[k][0] - mx, vy = x[k][2] - my;      // screen.py:200-212: positions relative to the screen
+                        long long ix, iy;
+                        T fx, fy, bw;
+                        bool inside = cic_axis<T>(vx, lx, rx, bins_x, ix, fx, bw);
+                        inside = cic_axis<T>(vy, ly, ry, bins_y, iy, fy, bw) && inside;
+                        if (!inside) continue;
+                        T c = charge ? charge[t0 + p] : (T)1;
+                        c = fabs(c);
+                        c = c * sv[k];
+#pragma unroll
+                        for (int oy = 0; oy < 2; ++oy) {
+                            const long long jy = iy + oy;
+                            if (jy < 0 || jy >= bins_y) continue;
+                            const T wy = oy ? fy : ((T)1.0 - fy);
+#pragma unroll
+                            for (int ox = 0; ox < 2; ++ox) {
+                                const long long jx = ix + ox;
+                                if (jx < 0 || jx >= bins_x) continue;
+                                const T wx = ox ? fx : ((T)1.0 - fx);
+                                table.add((int64_t)jx + (int64_t)jy * bins_x, c * wx * wy);
+                            }
+                        }
+                    }
+                    table.flush();
+                    __syncthreads();                   // (the table is free for the next screen of the stretch)
+                }
+                continue;
+            }
         }
         if (type == 3) {
             const int64_t q = items[i * 4 + 2];
@@ -755,13 +840,28 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
                                       void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
                                       void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
                                       int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, void* stream) {
+    return chx_lattice_track_screens(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, x_in, x_out,
+                                     N, B, Bx, Bm, Bw, small_runs, energy_out, s_in, s_out, survival, survival_out, n_bpm, readings,
+                                     workspace, workspace_bytes, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                         double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
+                                         void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
+                                         void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
+                                         int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, const void* charge,
+                                         const chx_lattice_screen* screens, int64_t n_screens, void* stream) {
     if (!x_in || !x_out || N < 1 || B < 1 || B > 65535 || n_bpm < 0 || n_bpm > n_items) return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bm, B) || !chx_bcast_ok(Bw, B)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && (!readings || !workspace)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, B, n_bpm)) return CHX_ERR_WORKSPACE;
-    int st = chx_lattice_prepare_rows(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
-                                      state_bytes, energy_out, s_in, s_out, stream);
+    if (n_screens < 0 || n_screens > CHX_LATTICE_MAX_SCREENS || (n_screens > 0 && (!screens || B != 1))) return CHX_ERR_INVALID_ARG;
+    int st = chx_lattice_prepare_screens(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
+                                         state_bytes, energy_out, s_in, s_out, screens, n_screens, stream);
     if (st != CHX_OK) return st;
+    ApplyScreens scr;
+    for (int k = 0; k < CHX_LATTICE_MAX_SCREENS; ++k) scr.s[k] = k < n_screens ? screens[k] : chx_lattice_screen{};
+    scr.charge = charge;
     const double* Rs = (const double*)state;
     const double* coeffs = Rs + n_items * Bm * 49;
     const int shared_in = (Bx == 1 && B > 1) ? 1 : 0, shared_sv = (Bw == 1 && B > 1) ? 1 : 0;
@@ -775,11 +875,16 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
     const dim3 grid((unsigned)((N + tile - 1) / tile), (unsigned)B);
     const int64_t nw = (int64_t)grid.x * (CHX_BLOCK / 64);
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
-    const int diag = (n_bpm > 0 || survival_out) ? 1 : 0;
-#define CHX_LATTICE_APPLY(T, PPT)                                                                                                   \
-    hipLaunchKernelGGL((lattice_apply_kernel<T, PPT>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out, table, (int)n_items, \
-                       Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs, (T*)survival_out, shared_in, Bm,  \
-                       shared_sv)
+    const int diag = (n_bpm > 0 || survival_out || n_screens > 0) ? 1 : 0;
+#define CHX_LATTICE_APPLY_S(T, PPT, SCR)                                                                                            \
+    hipLaunchKernelGGL((lattice_apply_kernel<T, PPT, SCR>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out, table,          \
+                       (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs, (T*)survival_out,   \
+                       shared_in, Bm, shared_sv, scr)
+#define CHX_LATTICE_APPLY(T, PPT)                  \
+    do {                                           \
+        if (n_screens > 0) CHX_LATTICE_APPLY_S(T, PPT, true); \
+        else CHX_LATTICE_APPLY_S(T, PPT, false);   \
+    } while (0)
     if (dtype == CHX_F32) {
         if (ppt == 2) CHX_LATTICE_APPLY(float, 2);
         else CHX_LATTICE_APPLY(float, 1);
@@ -796,6 +901,7 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
                                (const double*)workspace, nw, (double*)readings);
     }
 #undef CHX_LATTICE_APPLY
+#undef CHX_LATTICE_APPLY_S
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -868,6 +974,31 @@ extern "C" int chx_copy_arrays(const void* const* src, void* const* dst, const i
     int64_t blocks = (most + CHX_BLOCK * 64 - 1) / (CHX_BLOCK * 64);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(copy_arrays_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(CHX_BLOCK), 0, (hipStream_t)stream, a);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
+// ---- the extent a stretch derives from a Screen's pixel size (screen.py:139-148), for checking it against the tensor expression ----
+namespace {
+template <typename T>
+__global__ void screen_extent_kernel(const T* __restrict__ ps, int rx, int ry, T* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        screen_extent_axis<T>(rx, ps[0], out[0], out[1]);
+        screen_extent_axis<T>(ry, ps[1], out[2], out[3]);
+    }
+}
+}  // namespace
+
+extern "C" int chx_screen_extent(const void* pixel_size, int32_t resolution_x, int32_t resolution_y, int dtype, void* out, void* stream) {
+    if (!pixel_size || !out) return CHX_ERR_INVALID_ARG;
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(screen_extent_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)pixel_size, resolution_x,
+                           resolution_y, (float*)out);
+    else if (dtype == CHX_F64)
+        hipLaunchKernelGGL(screen_extent_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)pixel_size, resolution_x,
+                           resolution_y, (double*)out);
+    else
+        return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

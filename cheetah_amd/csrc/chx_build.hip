@@ -1728,6 +1728,34 @@ extern "C" int chx_run_track(const int32_t* kinds, const void* const* param_ptrs
 //   state: R[n_items][49] (T, in double-sized slots), coeffs[n_items][8] double, emaps[n_elems][49] (T, double-sized slots)
 constexpr int kLatticeMaxItems = 1024;
 
+// Active Screens of the stretch (items of type 4, chx_lattice_track_screens): this call's output buffers by value, and where each
+// screen's image starts among the spare workgroups that zero the images (kScreenZeroBytes each) — the memset launch of an image
+// rides in the preparation launch.
+constexpr int64_t kScreenZeroBytes = 16384;
+struct LatticeScreens {
+    chx_lattice_screen s[CHX_LATTICE_MAX_SCREENS];
+    int64_t zero_first[CHX_LATTICE_MAX_SCREENS + 1];
+    int n;
+};
+
+__device__ __forceinline__ void lattice_zero_images(const LatticeScreens& scr, int64_t z) {
+    int slot = 0;
+    while (slot + 1 < scr.n && z >= scr.zero_first[slot + 1]) ++slot;
+    char* base = (char*)scr.s[slot].image;
+    const int64_t lo = (z - scr.zero_first[slot]) * kScreenZeroBytes;
+    int64_t hi = lo + kScreenZeroBytes;
+    if (hi > scr.s[slot].image_bytes) hi = scr.s[slot].image_bytes;
+    if (!base || lo >= hi) return;
+    if ((((uintptr_t)base) & 15) == 0) {
+        const int64_t n16 = (hi - lo) >> 4;
+        float4* d = (float4*)(base + lo);
+        for (int64_t i = threadIdx.x; i < n16; i += CHX_BLOCK) d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = lo + (n16 << 4) + threadIdx.x * 4; i < hi; i += CHX_BLOCK * 4) *(uint32_t*)(base + i) = 0u;
+    } else {
+        for (int64_t i = lo + threadIdx.x * 4; i < hi; i += CHX_BLOCK * 4) *(uint32_t*)(base + i) = 0u;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_t* __restrict__ items, const int64_t* __restrict__ elem_kind,
                                                                    const int64_t* __restrict__ elem_poff, const int64_t* __restrict__ ptrs,
@@ -1736,8 +1764,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
                                                                    double* __restrict__ emaps, T* __restrict__ energy_out,
                                                                    const T* __restrict__ s_in, T* __restrict__ s_out,
                                                                    int energy_rows /*energy is a (rows,) array*/,
-                                                                   int energy_out_rows /*energy_out is a (rows,) array*/) {
+                                                                   int energy_out_rows /*energy_out is a (rows,) array*/,
+                                                                   LatticeScreens scr) {
     __shared__ double e_in_sh;
+    if ((int)blockIdx.x >= n_items) {                      // (spare workgroups: the screens' images start from zero)
+        lattice_zero_images(scr, (int64_t)blockIdx.x - n_items);
+        return;
+    }
     const int b = blockIdx.x;
     // blockIdx.y = row of a batch of lattice settings (gridDim.y = 1: scalar settings): a pointer with its lowest bit set addresses
     // a (rows,) array whose element `row` belongs to this row (chx_run_map_batched's convention), any other a scalar. The maps and
@@ -1790,19 +1823,24 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
             const int i = base + (int)threadIdx.x;
             int has = 0;
             T total = (T)0;
-            if (i < n_items && items[i * 4] < 2) {         // (a beam position monitor / an aperture: no length)
+            if (i < n_items && items[i * 4] < 2) {         // (a beam position monitor / an aperture / a screen: no length)
                 const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
                 total = setting(elem_poff[e0]);
                 for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
                 has = 1;
+            } else if (i < n_items && items[i * 4] == 4) {
+                has = 2 + (int)items[i * 4 + 3];           // an active screen: its record takes the path length up to here
             }
             total_sh[threadIdx.x] = total;
             has_length_sh[threadIdx.x] = has;
             __syncthreads();
             if (threadIdx.x == 0) {
                 const int n = (n_items - base < CHX_BLOCK) ? (n_items - base) : CHX_BLOCK;
-                for (int j = 0; j < n; ++j)
-                    if (has_length_sh[j]) sv = sv + total_sh[j];
+                for (int j = 0; j < n; ++j) {
+                    if (has_length_sh[j] == 1) sv = sv + total_sh[j];
+                    else if (has_length_sh[j] >= 2 && has_length_sh[j] - 2 < scr.n && scr.s[has_length_sh[j] - 2].s)
+                        *(T*)scr.s[has_length_sh[j] - 2].s = sv;
+                }
             }
             __syncthreads();
         }
@@ -1811,8 +1849,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     __syncthreads();
     const double E0 = e_in_sh;
     T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
-    if (type >= 2) {                                       // an active BPM / aperture: nothing to build (lattice_apply_kernel acts there)
+    if (type >= 2) {                                       // an active BPM / aperture / screen: nothing to build (lattice_apply_kernel acts there)
         if (b == n_items - 1 && threadIdx.x == 0 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E0;
+        if (type == 4 && threadIdx.x == 0 && row == 0) {
+            const int slot = (int)items[b * 4 + 3];
+            if (slot < scr.n && scr.s[slot].energy) *(T*)scr.s[slot].energy = (T)E0;
+        }
         return;
     }
     if (type == 1) {
@@ -1985,8 +2027,34 @@ extern "C" int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items
 extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                                         const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
                                         void* energy_out, const void* s_in, void* s_out, void* stream) {
+    return chx_lattice_prepare_screens(table, n_items, n_elems, n_ptrs, rows, small_runs, energy, mass_eV, n_charges, dtype, state,
+                                       state_bytes, energy_out, s_in, s_out, nullptr, 0, stream);
+}
+
+extern "C" int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
+                                           const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
+                                           void* energy_out, const void* s_in, void* s_out, const chx_lattice_screen* screens,
+                                           int64_t n_screens, void* stream) {
     if (!table || !energy || !state || !energy_out || ((s_in == nullptr) != (s_out == nullptr)) || n_ptrs < n_elems)
         return CHX_ERR_INVALID_ARG;
+    if (n_screens < 0 || n_screens > CHX_LATTICE_MAX_SCREENS || (n_screens > 0 && (!screens || rows != 1))) return CHX_ERR_INVALID_ARG;
+    LatticeScreens scr;
+    scr.n = (int)n_screens;
+    int64_t zero_blocks = 0;
+    for (int k = 0; k < CHX_LATTICE_MAX_SCREENS; ++k) {
+        scr.zero_first[k] = zero_blocks;
+        if (k < n_screens) {
+            scr.s[k] = screens[k];
+            if (screens[k].image) {
+                if (screens[k].image_bytes < 0 || (screens[k].image_bytes & 3)) return CHX_ERR_INVALID_ARG;
+                zero_blocks += (screens[k].image_bytes + kScreenZeroBytes - 1) / kScreenZeroBytes;
+            }
+        } else {
+            scr.s[k] = chx_lattice_screen{};
+        }
+    }
+    scr.zero_first[CHX_LATTICE_MAX_SCREENS] = zero_blocks;
+    if (zero_blocks > 1000000) return CHX_ERR_INVALID_ARG;
     const int energy_rows = (small_runs & CHX_LATTICE_ENERGY_ROWS) ? 1 : 0;   // bit 1: energy / energy_out are (rows,) arrays
     // bit 2: energy_out alone is a (rows,) array (a cavity with a vectorised voltage or phase behind a scalar incoming energy)
     const int energy_out_rows = (energy_rows || (small_runs & CHX_LATTICE_ENERGY_OUT_ROWS)) ? 1 : 0;
@@ -2018,15 +2086,15 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
         CHX_CHECK_LAUNCH();
         return CHX_OK;
     }
-    const dim3 grid((unsigned)n_items, (unsigned)rows);
+    const dim3 grid((unsigned)(n_items + zero_blocks), (unsigned)rows);
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(lattice_prepare_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
                            (int)n_items, (int)n_elems, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
-                           (const float*)s_in, (float*)s_out, energy_rows, energy_out_rows);
+                           (const float*)s_in, (float*)s_out, energy_rows, energy_out_rows, scr);
     else
         hipLaunchKernelGGL(lattice_prepare_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
                            ptrs, (int)n_items, (int)n_elems, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
-                           (const double*)s_in, (double*)s_out, energy_rows, energy_out_rows);
+                           (const double*)s_in, (double*)s_out, energy_rows, energy_out_rows, scr);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }

@@ -142,13 +142,21 @@ __global__ __launch_bounds__(CHX_BLOCK) void screen_gaussian_kernel(const T* __r
 // (chx_build.hip: one map per item, a coefficient row per cavity) — one wavefront per batch row walks the items: per item the
 // arithmetic of parameter_track_kernel on moments rounded to T in between (what storing the beam behind every element and
 // loading it again gives: bit-identical to the walk item by item); a monitor reads (mu_x, mu_y) - misalignment there.
+struct ParameterScreens {
+    void* mu[CHX_LATTICE_MAX_SCREENS];
+    void* cov[CHX_LATTICE_MAX_SCREENS];
+    const void* q[CHX_LATTICE_MAX_SCREENS];
+    void* q_out[CHX_LATTICE_MAX_SCREENS];
+    int n;
+};
+
 template <typename T>
 __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restrict__ mu, const T* __restrict__ cov, int64_t Bmu,
                                                               int64_t Bcov, int64_t Bm /*rows of lattice settings: 1 or B*/,
                                                               const int64_t* __restrict__ items, int n_items,
                                                               const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                               const int64_t* __restrict__ ptrs, T* __restrict__ mu_out,
-                                                              T* __restrict__ cov_out, T* __restrict__ readings) {
+                                                              T* __restrict__ cov_out, T* __restrict__ readings, ParameterScreens scr) {
     __shared__ double r[49], c[49], m[7], tmp[49];
     const int64_t b = blockIdx.x, B = gridDim.x;
     const int lane = threadIdx.x;
@@ -162,6 +170,17 @@ __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restri
             if (lane < 2) {
                 const T* mis = (const T*)ptrs[items[it * 4 + 2]];
                 readings[((int64_t)items[it * 4 + 3] * B + b) * 2 + lane] = (T)m[lane == 0 ? 0 : 2] - mis[lane];
+            }
+            continue;
+        }
+        if (type == 4) {
+            // an active screen (screen.py:187-214): the moments that reach it are its record (unshifted; the image kernel and
+            // the caller's get_read_beam subtract the misalignment)
+            const int slot = (int)items[it * 4 + 3];
+            if (slot < scr.n && b == 0) {
+                if (scr.mu[slot] && lane < 7) ((T*)scr.mu[slot])[lane] = (T)m[lane];
+                if (scr.cov[slot] && lane < 49) ((T*)scr.cov[slot])[lane] = (T)c[lane];
+                if (scr.q[slot] && scr.q_out[slot] && lane == 63) *(T*)scr.q_out[slot] = *(const T*)scr.q[slot];
             }
             continue;
         }
@@ -227,11 +246,38 @@ extern "C" int chx_parameter_lattice_track(const int64_t* table, int64_t n_items
                                            const void* mu, const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, int64_t Bm,
                                            int small_runs, void* mu_out, void* cov_out, void* energy_out, const void* s_in,
                                            void* s_out, int64_t n_bpm, void* readings, void* stream) {
+    return chx_parameter_lattice_track_screens(table, n_items, n_elems, n_ptrs, energy, mass_eV, n_charges, dtype, state, state_bytes, mu,
+                                               cov, B, Bmu, Bcov, Bm, small_runs, mu_out, cov_out, energy_out, s_in, s_out, n_bpm,
+                                               readings, nullptr, 0, stream);
+}
+
+extern "C" int chx_parameter_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs,
+                                                   const void* energy, double mass_eV, double n_charges, int dtype, void* state,
+                                                   size_t state_bytes, const void* mu, const void* cov, int64_t B, int64_t Bmu,
+                                                   int64_t Bcov, int64_t Bm, int small_runs, void* mu_out, void* cov_out,
+                                                   void* energy_out, const void* s_in, void* s_out, int64_t n_bpm, void* readings,
+                                                   const chx_lattice_screen* screens, int64_t n_screens, void* stream) {
     if (!mu || !cov || !mu_out || !cov_out || B < 1 || B > 0x7fffffffLL || n_bpm < 0 || (n_bpm > 0 && !readings))
         return CHX_ERR_INVALID_ARG;
     if (!chx_bcast_ok(Bmu, B) || !chx_bcast_ok(Bcov, B) || !chx_bcast_ok(Bm, B)) return CHX_ERR_INVALID_ARG;
-    int st = chx_lattice_prepare_rows(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
-                                      state_bytes, energy_out, s_in, s_out, stream);
+    if (n_screens < 0 || n_screens > CHX_LATTICE_MAX_SCREENS || (n_screens > 0 && (!screens || B != 1))) return CHX_ERR_INVALID_ARG;
+    ParameterScreens scr;
+    scr.n = (int)n_screens;
+    chx_lattice_screen prep[CHX_LATTICE_MAX_SCREENS];
+    for (int k = 0; k < CHX_LATTICE_MAX_SCREENS; ++k) {
+        scr.mu[k] = k < n_screens ? screens[k].mu : nullptr;
+        scr.cov[k] = k < n_screens ? screens[k].cov : nullptr;
+        scr.q[k] = k < n_screens ? screens[k].total_charge : nullptr;
+        scr.q_out[k] = k < n_screens ? screens[k].total_charge_out : nullptr;
+        if (k < n_screens) {
+            prep[k] = screens[k];
+            prep[k].image = nullptr;           // (the gaussian image writes every pixel: nothing to zero)
+            prep[k].image_bytes = 0;
+            if (screens[k].image && (!screens[k].mu || !screens[k].cov || !screens[k].geom)) return CHX_ERR_INVALID_ARG;
+        }
+    }
+    int st = chx_lattice_prepare_screens(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
+                                         state_bytes, energy_out, s_in, s_out, n_screens > 0 ? prep : nullptr, n_screens, stream);
     if (st != CHX_OK) return st;
     const double* Rs = (const double*)state;
     const double* coeffs = Rs + n_items * Bm * 49;
@@ -239,11 +285,17 @@ extern "C" int chx_parameter_lattice_track(const int64_t* table, int64_t n_items
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(parameter_lattice_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, (const float*)mu, (const float*)cov, Bmu,
-                           Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (float*)mu_out, (float*)cov_out, (float*)readings);
+                           Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (float*)mu_out, (float*)cov_out, (float*)readings, scr);
     else
         hipLaunchKernelGGL(parameter_lattice_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)mu, (const double*)cov,
-                           Bmu, Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (double*)mu_out, (double*)cov_out, (double*)readings);
+                           Bmu, Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (double*)mu_out, (double*)cov_out, (double*)readings, scr);
     CHX_CHECK_LAUNCH();
+    for (int64_t k = 0; k < n_screens; ++k) {
+        if (!screens[k].image) continue;
+        st = chx_screen_gaussian(screens[k].mu, screens[k].cov, screens[k].shift, screens[k].geom, 1, 1, 1, 1, screens[k].width,
+                                 screens[k].height, 0, dtype, screens[k].image, stream);
+        if (st != CHX_OK) return st;
+    }
     return CHX_OK;
 }
 

@@ -35,10 +35,11 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 6 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
+#define CHX_ABI_VERSION 7 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
                              4: s_in / s_out arguments of chx_run_map / chx_run_track;
                              5: s_in / s_out arguments of chx_cavity_prepare_scalars / chx_cavity_track_scalars;
-                             6: chx_lattice_track_diag (items of type 2 / 3 in the table of a lattice stretch) */
+                             6: chx_lattice_track_diag (items of type 2 / 3 in the table of a lattice stretch);
+                             7: chx_lattice_track_screens / chx_parameter_lattice_track_screens (items of type 4: active Screens) */
 
 typedef enum chx_status {
     CHX_OK = 0,
@@ -593,6 +594,58 @@ int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int64_t n_elem
                            int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs, void* energy_out, const void* s_in,
                            void* s_out, const void* survival, void* survival_out, int64_t n_bpm, void* readings, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The same stretch with ACTIVE SCREENS in it (screen.py:187-239: the screen records a copy of the beam that reaches it and lets
+ * the beam pass; screen.py:241-344: its image). An RL control step is `Segment.track` on a small beam followed by the screen's
+ * reading: element by element that is the merged track, a copy of five tensors, a memset and the deposit — four launches and
+ * ~50 us of host time around ~10 us of work. Here the screen is an item of the stretch:
+ *  {4, flags, q, slot}: ptrs[q] = address of its misalignment [2], ptrs[q + 1] = address of its pixel_size [2] (both `dtype`),
+ *     ptrs[q + 2 .. q + 5] = the integers resolution_x, resolution_y, bins_x, bins_y (bins = resolution // binning);
+ *     flags bit 0: deposit the cloud-in-cell image (screen.py:327-339) in the particle pass.
+ * screens[slot] (HOST array, read before the call returns) holds this call's output buffers of the screen:
+ *  rows [N][7], charges [N], survival [N]: the record of the beam AT the screen (the coordinates UNSHIFTED: the misalignment is
+ *     subtracted where the image is formed and by the caller's `get_read_beam`), written by the particle pass; each may be NULL;
+ *  energy, s: one value of `dtype` each — the reference energy and path length at the screen, written by the preparation launch;
+ *  image [bins_y][bins_x] (`dtype`; NULL = none) of image_bytes bytes: ZEROED by the preparation launch (spare workgroups: no
+ *     memset launch), then every particle adds |charge| * survival to its four pixels with the index arithmetic of
+ *     chx_cic_deposit on (x - misalignment_x, y - misalignment_y) and the extent (-+ resolution * pixel_size / 2) evaluated from
+ *     the pixel size as torch evaluates screen.py:139-148 — the same cells, fractions and addends as
+ *     chx_apply_affine7 + chx_cic_deposit on the recorded rows (float atomics: the same sum to the order of the additions);
+ *  ParameterBeam variant (chx_parameter_lattice_track_screens): mu [7], cov [49] = the moments at the screen; image
+ *     [height][width] = chx_screen_gaussian of them (geom: [left, hstep, bottom, vstep], shift: the misalignment; one more launch).
+ * One beam, scalar settings (B = Bx = Bm = Bw = 1) when n_screens > 0; `charge` [N] (may be NULL = 1) feeds the image weights
+ * and the record. */
+#define CHX_LATTICE_MAX_SCREENS 4
+typedef struct chx_lattice_screen {
+    void* rows;
+    void* charges;
+    void* survival;
+    void* energy;
+    void* s;
+    void* image;
+    int64_t image_bytes;
+    /* ParameterBeam variant only */
+    void* mu;
+    void* cov;
+    const void* geom;
+    const void* shift;      /* the screen's misalignment [2] (`dtype`, device) */
+    const void* total_charge; /* the beam's total charge (one value of `dtype`) and where the record's copy of it goes */
+    void* total_charge_out;
+    int32_t width, height;
+} chx_lattice_screen;
+int chx_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                              double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
+                              void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
+                              void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
+                              int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, const void* charge,
+                              const chx_lattice_screen* screens, int64_t n_screens, void* stream);
+/* chx_lattice_prepare_rows that also writes screens[slot].energy / .s and zeroes screens[slot].image (rows = 1 when n_screens > 0) */
+int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
+                                const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
+                                void* energy_out, const void* s_in, void* s_out, const chx_lattice_screen* screens,
+                                int64_t n_screens, void* stream);
+/* out[4] (`dtype`, device) = the extent (left, right, bottom, top) the stretch kernels derive from pixel_size[2] (`dtype`, device)
+ * and the resolution — for checking it bit for bit against the reference's tensor expression (screen.py:139-148) */
+int chx_screen_extent(const void* pixel_size, int32_t resolution_x, int32_t resolution_y, int dtype, void* out, void* stream);
 /* The same stretch for a ParameterBeam (element.py:167-179, cavity.py:127-133,202-218, bpm.py:77-87): mu [Bmu][7], cov [Bcov][49]
  * (Bmu, Bcov in {1, B}) through [run | active Cavity | active BPM]+ by one wavefront per batch row after the same preparation
  * launch — mu' = R mu, cov' = R cov R^T item by item (fp64 inside, rounded to `dtype` between items like chx_parameter_track), a
@@ -623,6 +676,11 @@ int chx_parameter_lattice_track(const int64_t* table, int64_t n_items, int64_t n
                                 const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, int64_t Bm, int small_runs, void* mu_out,
                                 void* cov_out, void* energy_out, const void* s_in, void* s_out, int64_t n_bpm, void* readings,
                                 void* stream);
+int chx_parameter_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
+                                        double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* mu,
+                                        const void* cov, int64_t B, int64_t Bmu, int64_t Bcov, int64_t Bm, int small_runs, void* mu_out,
+                                        void* cov_out, void* energy_out, const void* s_in, void* s_out, int64_t n_bpm, void* readings,
+                                        const chx_lattice_screen* screens, int64_t n_screens, void* stream);
 /* Cavity.track (cavity.py:100-251) for ONE beam and a cavity whose four settings are device scalars of `dtype`:
  * param_ptrs[4] = device pointers to length, voltage, phase [deg], frequency; energy = device pointer to one value;
  * kind = CHX_CAVITY_SW / CHX_CAVITY_TW. chx_cavity_prepare_scalars writes the map R_out[7][7] (dtype, as chx_build_rmatrix),

@@ -1,0 +1,378 @@
+"""Active Screens as items of the one-call lattice stretch (chx_lattice_track_screens / chx_parameter_lattice_track_screens;
+screen.py:187-344, segment.py:545-574): the screen's record of the beam and its image come out of the same two launches that track
+the beam.
+
+ * against the REFERENCE's own run (tests/golden/screen_stretch.npz, generator tests/golden/generate_golden_screen_stretch.py): six
+   drawn lattices with two or three active screens each (mid-lattice and last; cloud-in-cell and histogram; misaligned; binning 2)
+   between monitors, apertures and cavities — outgoing beam, every screen's read beam and image, for particles and a ParameterBeam;
+   and the README's control step at three sets of magnet settings;
+ * against this engine's own walk element by element (`Segment._STRETCH_SCREENS = False`): records bit for bit, images to the
+   order of the float atomics;
+ * the extent the kernels derive from the pixel size against the reference's tensor expression, bit for bit;
+ * the screen's semantics around the record: in-place edits of the beams afterwards, settings changed between track and reading,
+   beams above the eager-image size.
+Measured on the MI355X (worst case over the lattices; relative to the coordinate's scale / the image's maximum): float64 read beams
+and outgoing particles 6.0e-15, images 1.1e-14, ParameterBeam moments 4.7e-16, its images 1.2e-7 (the reference samples the density
+at float32-rounded positions); float32 1.4e-6 / 4.7e-6 / 3.7e-7 / 4.2e-7 — the bounds below are >= 4 x those."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "screen_stretch.npz")
+
+
+def _build(ca, spec, fk):
+    kind, kw = spec
+    args = {}
+    for k, v in kw.items():
+        if k == "resolution":
+            args[k] = tuple(v)
+        elif isinstance(v, (float, list)):
+            args[k] = torch.tensor(v, **fk)
+        else:
+            args[k] = v
+    return getattr(ca, kind)(**args, **fk)
+
+
+class _Spy:
+    """Counts the calls of one function of a host module."""
+
+    def __init__(self, host, name, calls):
+        self._host, self._name, self._calls = host, name, calls
+
+    def __getattr__(self, name):
+        fn = getattr(self._host, name)
+        if name != self._name:
+            return fn
+        return lambda *a: (self._calls.append(len(a)), fn(*a))[1]
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_screen_lattices_vs_reference(dt):
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    g = np.load(GOLDEN)
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda a: torch.tensor(np.asarray(a), **fk)  # noqa: E731
+    f64 = dt == torch.float64
+    calls, pcalls = [], []
+    th = segment._lib.torch_host()
+    old = segment._TORCH_HOST
+    worst = {"rows": 0.0, "image": 0.0, "pb": 0.0, "pb_image": 0.0}
+    try:
+        for i in range(int(g["n_lattices"])):
+            specs = json.loads(str(g[f"lat{i}_spec"]))
+            seg = ca.Segment([_build(ca, s, fk) for s in specs])
+            screens = [e for e in seg.elements if isinstance(e, ca.Screen)]
+            bpms = [e for e in seg.elements if isinstance(e, ca.BPM)]
+            beam = ca.ParticleBeam(t(g[f"lat{i}_in"]), t(g[f"lat{i}_energy"]), particle_charges=t(g[f"lat{i}_q"]),
+                                   survival_probabilities=t(g[f"lat{i}_w"]), **fk)
+            calls.clear()
+            segment._TORCH_HOST = _Spy(th, "lattice_track_screens", calls)
+            with torch.no_grad():
+                out = seg.track(beam)
+            assert len(calls) == 1, (i, calls)            # the whole lattice, screens included, is ONE stretch call
+            ref = g[f"lat{i}_out"]
+            scale = np.abs(ref).max(axis=0)
+            err = (np.abs(out.particles.double().cpu().numpy() - ref) / scale).max()
+            worst["rows"] = max(worst["rows"], err)
+            assert err < (1e-13 if f64 else 6e-6), (i, err)
+            assert float(out.energy) == pytest.approx(float(g[f"lat{i}_energy_out"]), rel=1e-13 if f64 else 1e-6)
+            assert float(out.s) == pytest.approx(float(g[f"lat{i}_s_out"]), rel=1e-13 if f64 else 1e-6)
+            w_ref, w_got = g[f"lat{i}_w_out"], out.survival_probabilities.double().cpu().numpy()
+            assert (np.abs(w_got - w_ref) > 1e-6).sum() <= (0 if f64 else 4), i
+            if bpms:
+                got_r = torch.stack([b.reading for b in bpms]).double().cpu().numpy()
+                ref_r = g[f"lat{i}_readings"]
+                live = np.isfinite(ref_r).all(axis=1)
+                assert np.abs(got_r[live] - ref_r[live]).max() < (1e-15 if f64 else 3e-7) * (np.abs(ref[:, [0, 2]]).max() + np.abs(ref_r[live]).max())
+            for k, scr in enumerate(screens):
+                rb = scr.get_read_beam()
+                rows_ref = g[f"lat{i}_scr{k}_rows"]
+                sc = np.abs(rows_ref).max(axis=0)
+                e_rows = (np.abs(rb.particles.double().cpu().numpy() - rows_ref) / sc).max()
+                worst["rows"] = max(worst["rows"], e_rows)
+                assert e_rows < (1e-13 if f64 else 6e-6), (i, k, e_rows)
+                assert np.allclose(rb.particle_charges.double().cpu().numpy(), g[f"lat{i}_scr{k}_q"], rtol=1e-15 if f64 else 1e-7, atol=0)
+                w_at = rb.survival_probabilities.double().cpu().numpy()
+                assert (np.abs(w_at - g[f"lat{i}_scr{k}_w"]) > 1e-6).sum() <= (0 if f64 else 4), (i, k)
+                assert float(rb.energy) == pytest.approx(float(g[f"lat{i}_scr{k}_energy"]), rel=1e-13 if f64 else 1e-6)
+                assert float(rb.s) == pytest.approx(float(g[f"lat{i}_scr{k}_s"]), rel=1e-13 if f64 else 1e-6, abs=1e-12)
+                img, img_ref = scr.reading.double().cpu().numpy(), g[f"lat{i}_scr{k}_image"]
+                assert img.shape == img_ref.shape, (i, k, img.shape, img_ref.shape)
+                if scr.method == "cloud-in-cell" or f64:
+                    e_img = np.abs(img - img_ref).max() / img_ref.max()
+                    worst["image"] = max(worst["image"], e_img)
+                    assert e_img < (1e-13 if f64 else 2e-5), (i, k, e_img)
+                else:       # a float32 coordinate may fall into the neighbouring histogram bin
+                    assert np.abs(img - img_ref).sum() <= 8 * np.abs(g[f"lat{i}_scr{k}_q"]).max(), (i, k)
+                assert np.isclose(img.sum(), img_ref.sum(), rtol=1e-12 if f64 else 1e-5)
+            if f"lat{i}_pb_mu" not in g.files:
+                continue
+            pb = ca.ParameterBeam(t(g[f"lat{i}_pb_mu_in"]), t(g[f"lat{i}_pb_cov_in"]), t(g[f"lat{i}_energy"]),
+                                  total_charge=t(2e-10), **fk)
+            pcalls.clear()
+            segment._TORCH_HOST = _Spy(th, "parameter_lattice_track_screens", pcalls)
+            with warnings.catch_warnings(), torch.no_grad():
+                warnings.simplefilter("ignore")
+                pout = seg.track(pb)
+            assert len(pcalls) == 1, (i, pcalls)
+            size = np.sqrt(np.abs(np.diag(g[f"lat{i}_pb_cov"])))[:6].max()
+            e_pb = max(np.abs(pout.mu.double().cpu().numpy() - g[f"lat{i}_pb_mu"])[:6].max() / size,
+                       np.abs(pout.cov.double().cpu().numpy() - g[f"lat{i}_pb_cov"])[:6, :6].max() / size ** 2)
+            worst["pb"] = max(worst["pb"], e_pb)
+            assert e_pb < (1e-13 if f64 else 3e-6), (i, e_pb)
+            assert float(pout.energy) == pytest.approx(float(g[f"lat{i}_pb_energy"]), rel=1e-13 if f64 else 1e-6)
+            assert float(pout.s) == pytest.approx(float(g[f"lat{i}_pb_s"]), rel=1e-13 if f64 else 1e-6)
+            for k, scr in enumerate(screens):
+                rb = scr.get_read_beam()
+                mu_ref, cov_ref = g[f"lat{i}_pb_scr{k}_mu"], g[f"lat{i}_pb_scr{k}_cov"]
+                sz = np.sqrt(np.abs(np.diag(cov_ref)))[:6].max() + np.abs(mu_ref[:6]).max()
+                assert np.abs(rb.mu.double().cpu().numpy() - mu_ref)[:6].max() / sz < (1e-13 if f64 else 3e-6), (i, k)
+                assert np.abs(rb.cov.double().cpu().numpy() - cov_ref)[:6, :6].max() / sz ** 2 < (1e-13 if f64 else 3e-6), (i, k)
+                assert float(rb.energy) == pytest.approx(float(g[f"lat{i}_pb_scr{k}_energy"]), rel=1e-13 if f64 else 1e-6)
+                assert float(rb.s) == pytest.approx(float(g[f"lat{i}_pb_scr{k}_s"]), rel=1e-13 if f64 else 1e-6, abs=1e-12)
+                assert float(rb.total_charge) == pytest.approx(2e-10, rel=1e-7)
+                img, img_ref = scr.reading.double().cpu().numpy(), g[f"lat{i}_pb_scr{k}_image"]
+                if f64:
+                    assert img.shape == img_ref.shape, (i, k, img.shape, img_ref.shape)
+                else:
+                    # the number of samples is ceil((right - left) / step) of the TENSORS' values (screen.py:283-287): float32
+                    # geometry may round the quotient above the integer, one more row or column than the float64 fixture
+                    assert all(0 <= a - b <= 1 for a, b in zip(img.shape, img_ref.shape)), (i, k, img.shape, img_ref.shape)
+                    img = img[:img_ref.shape[0], :img_ref.shape[1]]
+                # (the reference samples the density at float32-rounded positions, screen.py:283-287; see test_gpu_parameter_beam.py)
+                e_img = np.abs(img - img_ref).max() / img_ref.max()
+                worst["pb_image"] = max(worst["pb_image"], e_img)
+                assert e_img < (5e-7 if f64 else 2e-6), (i, k, e_img)
+    finally:
+        segment._TORCH_HOST = old
+    print("screen stretch vs reference", dt, worst)
+
+
+def _ares(ca, fk, res=(306, 255)):
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    return ca.Segment([
+        ca.Marker(name="AREASOLA1"), ca.Drift(t(0.17504), **fk),
+        ca.Quadrupole(t(0.122), k1=t(8.2), name="AREAMQZM1", **fk), ca.Drift(t(0.428), **fk),
+        ca.Quadrupole(t(0.122), k1=t(-14.3), name="AREAMQZM2", **fk), ca.Drift(t(0.204), **fk),
+        ca.VerticalCorrector(t(0.02), angle=t(9e-5), name="AREAMCVM1", **fk), ca.Drift(t(0.204), **fk),
+        ca.Quadrupole(t(0.122), k1=t(3.142), name="AREAMQZM3", **fk), ca.Drift(t(0.179), **fk),
+        ca.HorizontalCorrector(t(0.02), angle=t(-1e-4), name="AREAMCHM1", **fk), ca.Drift(t(0.45), **fk),
+        ca.Screen(resolution=res, pixel_size=t([2.8390e-5, 2.0002e-5]), is_active=True, method="cloud-in-cell", name="AREABSCR1", **fk)])
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_control_step_vs_reference(dt):
+    """README.md:43-88: five magnet settings written IN PLACE, track, the screen's image — the reference's numbers."""
+    import cheetah_amd as ca
+
+    g = np.load(GOLDEN)
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda a: torch.tensor(np.asarray(a), **fk)  # noqa: E731
+    f64 = dt == torch.float64
+    seg = _ares(ca, fk)
+    beam = ca.ParticleBeam(t(g["control_in"]), t(g["control_energy"]), particle_charges=t(g["control_q"]), **fk)
+    pb = ca.ParameterBeam(t(g["control_pb_mu_in"]), t(g["control_pb_cov_in"]), t(g["control_energy"]), **fk)
+    settings = [seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle]
+    with torch.no_grad():
+        for k, a in enumerate(g["control_actions"]):
+            for target, v in zip(settings, a):
+                target.copy_(t(v))
+            out = seg.track(beam)
+            ref = g[f"control{k}_out"]
+            err = (np.abs(out.particles.double().cpu().numpy() - ref) / np.abs(ref).max(axis=0)).max()
+            assert err < (1e-13 if f64 else 6e-6), (k, err)
+            img, img_ref = seg.AREABSCR1.reading.double().cpu().numpy(), g[f"control{k}_image"]
+            assert img.shape == img_ref.shape
+            assert np.abs(img - img_ref).max() / img_ref.max() < (1e-12 if f64 else 5e-3), k
+            assert np.isclose(img.sum(), img_ref.sum(), rtol=1e-12 if f64 else 1e-5)
+            pout = seg.track(pb)
+            cov_ref = g[f"control{k}_pb_cov"]
+            size = np.sqrt(np.abs(np.diag(cov_ref)))[:6].max()
+            assert np.abs(pout.mu.double().cpu().numpy() - g[f"control{k}_pb_mu"])[:6].max() / size < (1e-12 if f64 else 3e-6), k
+            assert np.abs(pout.cov.double().cpu().numpy() - cov_ref)[:6, :6].max() / size ** 2 < (1e-12 if f64 else 3e-6), k
+            got_shape, ref_shape = tuple(seg.AREABSCR1.reading.shape), g[f"control{k}_pb_image"].shape
+            assert got_shape == ref_shape if f64 else all(0 <= a - b <= 1 for a, b in zip(got_shape, ref_shape)), (got_shape, ref_shape)
+
+
+def test_screen_extent_bits():
+    """The extent the stretch kernels derive from the pixel size = the reference's tensor expression (screen.py:139-148), bit for
+    bit: the image's cell indices rest on it."""
+    import cheetah_amd as ca
+    from cheetah_amd import _lib, _ops
+
+    rng = np.random.default_rng(5)
+    for dt in (torch.float32, torch.float64):
+        for _ in range(200):
+            res = (int(rng.integers(1, 5000)), int(rng.integers(1, 5000)))
+            ps = torch.tensor(10.0 ** rng.uniform(-7, -2, size=2), dtype=dt, device="cuda")
+            scr = ca.Screen(resolution=res, pixel_size=ps, dtype=dt, device="cuda")
+            out = torch.empty(4, dtype=dt, device="cuda")
+            _ops.check(_lib.lib().chx_screen_extent(ps.data_ptr(), res[0], res[1], _ops.dtype_code(dt), out.data_ptr(), _ops.stream_ptr()),
+                       "chx_screen_extent")
+            assert torch.equal(out, scr._compute_extent()), (dt, res, ps)
+
+
+def _drawn_lattice(ca, fk, seed):
+    rng = np.random.default_rng(seed)
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    els = []
+    for k in range(4):
+        els += [ca.Drift(t(rng.uniform(0.1, 0.5)), **fk), ca.Quadrupole(t(0.15), k1=t(rng.uniform(-8, 8)), **fk),
+                ca.HorizontalCorrector(t(0.05), angle=t(rng.uniform(-1e-4, 1e-4)), **fk)]
+        if k == 1:
+            els.append(ca.Cavity(t(0.6), voltage=t(8e6), phase=t(-12.0), frequency=t(1.3e9), **fk))
+            els.append(ca.BPM(is_active=True, **fk))
+        if k == 2:
+            els.append(ca.Aperture(x_max=t(9e-4), y_max=t(7e-4), shape="elliptical", is_active=True, **fk))
+        els.append(ca.Screen(resolution=(80, 60), pixel_size=t([6e-5, 5e-5]), misalignment=t([1e-4 * (k - 1), -5e-5 * k]),
+                             binning=2 if k == 3 else 1, method="histogram" if k == 2 else "cloud-in-cell", is_active=True,
+                             name=f"s{k}", **fk))
+    els.append(ca.Drift(t(0.2), **fk))
+    return ca.Segment(els)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_stretch_equals_walk(dt):
+    """Four screens (mid-lattice, behind a cavity and an aperture, one histogram, one binned) in one stretch call against the walk
+    element by element: outgoing beam, records and monitor readings bit for bit; images to the order of the atomics."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator.segment import Segment
+
+    fk = {"dtype": dt, "device": "cuda"}
+    torch.manual_seed(3)
+    beam = ca.ParticleBeam.from_parameters(num_particles=30_000, sigma_x=torch.tensor(3e-4, **fk), sigma_y=torch.tensor(2e-4, **fk),
+                                           energy=torch.tensor(8e7, **fk), **fk)
+    beam.survival_probabilities = torch.rand(30_000, **fk)
+    seg = _drawn_lattice(ca, fk, 11)
+    with torch.no_grad():
+        out = seg.track(beam)
+        got = [(s.get_read_beam(), s.reading) for s in seg.elements if isinstance(s, ca.Screen)]
+        bpm_got = [b.reading.clone() for b in seg.elements if isinstance(b, ca.BPM)]
+        Segment._STRETCH_SCREENS = False
+        try:
+            seg2 = _drawn_lattice(ca, fk, 11)
+            ref_out = seg2.track(beam)
+            ref = [(s.get_read_beam(), s.reading) for s in seg2.elements if isinstance(s, ca.Screen)]
+            bpm_ref = [b.reading.clone() for b in seg2.elements if isinstance(b, ca.BPM)]
+        finally:
+            Segment._STRETCH_SCREENS = True
+    assert torch.equal(out.particles, ref_out.particles) and torch.equal(out.survival_probabilities, ref_out.survival_probabilities)
+    assert torch.equal(out.energy, ref_out.energy) and torch.equal(out.s, ref_out.s)
+    for a, b in zip(bpm_got, bpm_ref):
+        assert torch.allclose(a, b, rtol=1e-6 if dt == torch.float32 else 1e-13, atol=0)
+    assert len(got) == len(ref) == 4
+    for (rb, img), (rb2, img2) in zip(got, ref):
+        assert torch.equal(rb.particles, rb2.particles)
+        assert torch.equal(rb.particle_charges, rb2.particle_charges) and torch.equal(rb.survival_probabilities, rb2.survival_probabilities)
+        assert torch.equal(rb.energy, rb2.energy) and torch.equal(rb.s, rb2.s)
+        assert img.shape == img2.shape
+        assert torch.allclose(img, img2, rtol=1e-4 if dt == torch.float32 else 1e-11, atol=float(img2.max()) * (1e-6 if dt == torch.float32 else 1e-13))
+
+
+def test_record_is_private_and_lazy():
+    """screen.py:190 / tests/test_screen.py:198-240 of the reference: editing the incoming or outgoing beam in place afterwards does
+    not reach the screen; a setting changed between `track` and the first `reading` is honoured (the reference forms the image when
+    it is asked for); beams above the eager-image size are recorded and read on demand."""
+    import cheetah_amd as ca
+
+    fk = {"dtype": torch.float32, "device": "cuda"}
+    seg = _ares(ca, fk)
+    torch.manual_seed(0)
+    beam = ca.ParticleBeam.from_twiss(beta_x=torch.tensor(3.14, **fk), beta_y=torch.tensor(42.0, **fk), num_particles=5000, **fk)
+    scr = seg.AREABSCR1
+    with torch.no_grad():
+        out = seg.track(beam)
+        assert scr.__dict__["_eager"] is not None and scr.__dict__["_incoming"] is None       # deposited by the stretch call
+        img = scr.reading.clone()
+        rows = scr.get_read_beam().particles.clone()
+        charges = scr.get_read_beam().particle_charges.clone()
+        out.particles.mul_(0.7)
+        out.energy.mul_(0.5)
+        beam.particle_charges.mul_(4.0)
+        beam.survival_probabilities.mul_(0.9)
+        rb = scr.get_read_beam()
+        assert torch.equal(rb.particles, rows) and torch.equal(rb.particle_charges, charges)
+        assert float(rb.survival_probabilities.min()) == 1.0 and torch.equal(scr.reading, img)
+        beam.particle_charges.div_(4.0)
+        beam.survival_probabilities.fill_(1.0)
+        # a setting changed before the first reading
+        seg.track(beam)
+        scr.binning = 3
+        img3 = scr.reading
+        assert img3.shape == (255 // 3, 306 // 3)
+        assert torch.allclose(img3.sum(), img.sum(), rtol=1e-5)
+        scr.binning = 1
+        seg.track(beam)
+        scr.pixel_size.mul_(2.0)            # in place: no epoch, the image key sees the version
+        wide = scr.reading
+        scr.pixel_size.div_(2.0)
+        ref = ca.Screen(resolution=(306, 255), pixel_size=scr.pixel_size * 2.0, is_active=True, **fk)
+        ref.track(seg.track(beam))
+        assert torch.allclose(wide, ref.reading, rtol=1e-4, atol=1e-6 * float(ref.reading.max()))
+        # the kernels follow an in-place change of the pixel size on the NEXT track
+        scr.pixel_size.mul_(2.0)
+        seg.track(beam)
+        assert scr.__dict__["_eager"] is not None
+        assert torch.allclose(scr.reading, ref.reading, rtol=1e-4, atol=1e-6 * float(ref.reading.max()))
+        scr.pixel_size.div_(2.0)
+        # a large beam: recorded, the image on demand
+        old = ca.Screen._EAGER_IMAGE_PARTICLES
+        ca.Screen._EAGER_IMAGE_PARTICLES = 1000
+        try:
+            seg.track(beam)
+            assert scr.__dict__["_eager"] is None and scr.__dict__["_cached_reading"] is None
+            assert torch.allclose(scr.reading, img, rtol=1e-4, atol=1e-6 * float(img.max()))
+        finally:
+            ca.Screen._EAGER_IMAGE_PARTICLES = old
+
+
+def test_screen_stretch_declines():
+    """What does not ride in the stretch call keeps the walk's results: gradients, a blocking screen, a vectorised beam, a
+    particle-sharded beam."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    fk = {"dtype": torch.float32, "device": "cuda"}
+    calls = []
+    th = segment._lib.torch_host()
+    old = segment._TORCH_HOST
+    segment._TORCH_HOST = _Spy(th, "lattice_track_screens", calls)
+    try:
+        seg = _ares(ca, fk, res=(64, 48))
+        torch.manual_seed(0)
+        beam = ca.ParticleBeam.from_twiss(beta_x=torch.tensor(3.14, **fk), beta_y=torch.tensor(42.0, **fk), num_particles=3000, **fk)
+        with torch.no_grad():
+            seg.track(beam)
+        assert len(calls) == 1
+        plain = seg.AREABSCR1.reading.clone()
+        # a blocking screen
+        seg.AREABSCR1.is_blocking = True
+        with torch.no_grad():
+            out = seg.track(beam)
+        assert len(calls) == 1 and float(out.survival_probabilities.abs().max()) == 0.0
+        assert torch.allclose(seg.AREABSCR1.reading, plain, rtol=1e-4, atol=1e-6 * float(plain.max()))
+        seg.AREABSCR1.is_blocking = False
+        # gradients through a setting
+        seg.AREAMQZM1.k1 = torch.nn.Parameter(torch.tensor(8.2, **fk))
+        out = seg.track(beam)
+        assert len(calls) == 1 and out.particles.requires_grad
+        seg.AREABSCR1.get_read_beam().sigma_x.backward()
+        assert seg.AREAMQZM1.k1.grad is not None
+        with torch.no_grad():
+            seg.track(beam)                                   # ... and the plan is back under no_grad
+        assert len(calls) == 2
+        # three beams in one ParticleBeam
+        many = ca.ParticleBeam(beam.particles.unsqueeze(0).repeat(3, 1, 1), beam.energy, particle_charges=beam.particle_charges, **fk)
+        with torch.no_grad():
+            seg.track(many)
+        assert len(calls) == 2 and seg.AREABSCR1.reading.shape == (3, 48, 64)
+    finally:
+        segment._TORCH_HOST = old
