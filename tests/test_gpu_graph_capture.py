@@ -43,7 +43,9 @@ def test_small_beam_steps_replay_from_a_graph(which):
         # 600 us of the element-by-element walk — a replayed graph (44 us) has nothing left to win
         assert g["eager_us"] < 120 and g["graph_replay_us"] < 120
     else:
-        assert g["graph_replay_us"] < g["eager_us"]
+        # round 5: the eager step is ONE stretch call as well (active Screens are items of it: two launches, the C++ host step) —
+        # 27 / 53 / 57 us where round 4 measured 70 / 127 / 152, about what the replay of its graph costs (31 / 35 / 47 us)
+        assert g["eager_us"] < 90 and g["graph_replay_us"] < 90
 
 
 def test_replay_follows_settings_changed_outside_the_step_on_cached_paths():

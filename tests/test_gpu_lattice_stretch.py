@@ -114,18 +114,37 @@ def test_what_ends_a_stretch():
     torch.manual_seed(4)
     beam = ca.ParticleBeam.from_parameters(num_particles=5_000, energy=t(5e7), **kw)
     els = _linac(ca, dt, 2)
-    els += [ca.Screen(is_active=True, name="scr", **kw)]           # records the beam: the stretch ends in front of it
+    els += [ca.Screen(is_active=True, name="scr", **kw)]           # records the beam and lets it pass: an item of the stretch (round 5)
     els += _linac(ca, dt, 2)
     els += [ca.Quadrupole(t(0.2), k1=torch.tensor([1.0, 2.0], **kw), **kw)]   # vectorised: general path
     seg = ca.Segment(els)
     calls, spy = _spy()
     old = segment._HOST
     segment._HOST = spy
+    tcalls = []
+    th = segment._lib.torch_host()
+
+    class TorchSpy:
+        def __getattr__(self, name):
+            fn = getattr(th, name)
+            return fn if name != "lattice_track_screens" else (lambda *a: (tcalls.append(a[1].shape[0]), fn(*a))[1])
+
+    old_t = segment._TORCH_HOST
+    segment._TORCH_HOST = TorchSpy()
     try:
         with torch.no_grad():
             out = seg.track(beam)
-        assert calls == [5_000, 5_000], calls
+        assert calls == [] and tcalls == [5_000], (calls, tcalls)      # both linacs and the screen between them: ONE call
         read = seg.scr.get_read_beam().particles.clone()
+        # with screens kept out of the stretches (the walk the screen tests compare with) the screen ends the first stretch
+        segment.Segment._STRETCH_SCREENS = False
+        try:
+            with torch.no_grad():
+                out_b = seg.track(beam)
+            assert calls == [5_000, 5_000] and tcalls == [5_000], (calls, tcalls)
+            assert torch.equal(out_b.particles, out.particles) and torch.equal(seg.scr.get_read_beam().particles, read)
+        finally:
+            segment.Segment._STRETCH_SCREENS = True
         with torch.no_grad():
             ref = _walk(seg, beam)
         assert out.particles.shape == (2, 5_000, 7) and torch.equal(out.particles, ref.particles)
@@ -153,6 +172,7 @@ def test_what_ends_a_stretch():
                 ca.Segment(_linac(ca, dt, 1) + [bad]).track(beam)
     finally:
         segment._HOST = old
+        segment._TORCH_HOST = old_t
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])

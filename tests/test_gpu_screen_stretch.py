@@ -195,7 +195,7 @@ def test_control_step_vs_reference(dt):
             assert np.isclose(img.sum(), img_ref.sum(), rtol=1e-12 if f64 else 1e-5)
             pout = seg.track(pb)
             cov_ref = g[f"control{k}_pb_cov"]
-            size = np.sqrt(np.abs(np.diag(cov_ref)))[:6].max()
+            size = np.sqrt(np.abs(np.diag(cov_ref)))[:6].max() + np.abs(g[f"control{k}_pb_mu"][:6]).max()
             assert np.abs(pout.mu.double().cpu().numpy() - g[f"control{k}_pb_mu"])[:6].max() / size < (1e-12 if f64 else 3e-6), k
             assert np.abs(pout.cov.double().cpu().numpy() - cov_ref)[:6, :6].max() / size ** 2 < (1e-12 if f64 else 3e-6), k
             got_shape, ref_shape = tuple(seg.AREABSCR1.reading.shape), g[f"control{k}_pb_image"].shape
