@@ -58,7 +58,7 @@ class LatticeScreen(ctypes.Structure):
 
     _fields_ = [
         ("rows", c_void_p), ("charges", c_void_p), ("survival", c_void_p), ("energy", c_void_p), ("s", c_void_p),
-        ("image", c_void_p), ("image_bytes", c_i64),
+        ("image", c_void_p), ("image_bytes", c_i64), ("map", c_void_p),
         ("mu", c_void_p), ("cov", c_void_p), ("geom", c_void_p), ("shift", c_void_p), ("total_charge", c_void_p),
         ("total_charge_out", c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
     ]
@@ -339,8 +339,9 @@ def torch_host():
             raise ImportError("cheetah_amd._chxtorch is not built: run `make -C cheetah_amd/csrc` "
                               "(or `python -c 'import __graft_entry__ as g; g.build()'`)") from exc
         h = lib()
-        _chxtorch.bind(ctypes.cast(h.chx_lattice_track_screens, ctypes.c_void_p).value,
-                       ctypes.cast(h.chx_parameter_lattice_track_screens, ctypes.c_void_p).value,
-                       torch._C._cuda_getCurrentRawStream, ChxError)
+        names = ("chx_lattice_track_screens", "chx_parameter_lattice_track_screens", "chx_run_build_compose", "chx_run_vjp_masked",
+                 "chx_run_vjp_workspace_bytes", "chx_apply_affine7_bwd", "chx_apply_bwd_workspace_bytes", "chx_moments_entry",
+                 "chx_moments_workspace_bytes", "chx_moment_entry", "chx_moment_entry_mapped_bwd")
+        _chxtorch.bind({n: ctypes.cast(getattr(h, n), ctypes.c_void_p).value for n in names}, ChxError)
         _torch_host = _chxtorch
     return _torch_host

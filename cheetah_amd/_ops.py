@@ -1154,6 +1154,20 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
     if survival is not None:
         w, _ = flat_bcast(survival if survival.dtype == particles.dtype else survival.to(particles.dtype), batch_shape, 1)
         w = w.contiguous()
+    if B == 1 and lin.R.shape[0] == 1 and lin.R.dtype == y.dtype and lin.x.shape[0] == 1:
+        # one beam through one map: the node in C++ (cheetah_amd._chxtorch MomentEntryMappedNode: no Python frame in the forward
+        # call's autograd bookkeeping and none at all in the backward pass)
+        mom_x = _incoming_moments(lin, survival, w, B)
+        w_src = None if survival is None else _origin(survival)
+        cached = getattr(particles, "_chx_mom", None) if (not CAPTURING[0] or CAPTURE_KEEPS_BEAM_MOMENTS[0]) else None
+        known = None
+        if cached is not None and cached[0] == particles._version and cached[1] is w_src \
+                and (w_src is None or cached[2] == w_src._version) and cached[3] == y.data_ptr() and cached[4].shape[0] == 1:
+            known = cached[4]
+        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, y, w, mom_x, known, index, take_sqrt)
+        if known is None:
+            particles._chx_mom = (particles._version, w_src, None if w_src is None else w_src._version, y.data_ptr(), mom_y)
+        return out.reshape(batch_shape)
     mom_y, picked = _memo_moments(particles, y, w, survival, B, (index, take_sqrt))
     if picked is not None and picked.dtype != lin.R.dtype:
         picked = None

@@ -118,7 +118,7 @@ class _FastRun:
     one stream at a time, like the reference's non-reentrant element caches (utils/cache.py:23-27)."""
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
-                 "elements", "revs", "rows", "per_tensors", "slots", "R_view", "allow_grad", "distinct", "grad_slots", "capsule")
+                 "elements", "revs", "rows", "per_tensors", "slots", "R_view", "allow_grad", "distinct", "grad_slots", "capsule", "grad_meta")
 
     def __init__(self, run, dtype, device, allow_grad=False):
         # allow_grad: the plan of the DIFFERENTIABLE run map (_ops.RunMapPlanned) — trainable parameters and settings that
@@ -126,6 +126,7 @@ class _FastRun:
         self.allow_grad = allow_grad
         self.distinct, self.grad_slots = (), ()
         self.capsule = None
+        self.grad_meta = None
         self.dtype, self.device = dtype, device
         self.elements = [e for e in run.elements]
         self.revs = [None] * len(self.elements)
@@ -249,6 +250,13 @@ class _FastRun:
                         grad_slots.append([])
                     grad_slots[pos].append((self.slots[i], k, index))
             self.distinct, self.grad_slots = tuple(distinct), tuple(tuple(g) for g in grad_slots)
+            # the same plan as the C++ node reads it (cheetah_amd._chxtorch RunScreenTrack): one list of integers
+            meta = [self.E, self.code, len(distinct)] + [int(k) for k in self.kinds] + [int(v or 0) for v in self.ptrs]
+            for g in grad_slots:
+                meta.append(len(g))
+                for e, k, index in g:
+                    meta += [e, k, -1 if index is None else index]
+            self.grad_meta = meta
         self.ok = True
 
 
@@ -1317,9 +1325,14 @@ class Segment(Element):
                 lp.refresh()
         if not lp.ok:
             return None
+        grad_run = None
         if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
-            return None
+            # gradients: [run of scalar settings | one active Screen] on a beam without a graph is ONE differentiable node
+            # (cheetah_amd._chxtorch RunScreenTrack); anything else takes the general differentiable path
+            grad_run = self._stretch_grad_run(lp, incoming)
+            if grad_run is None:
+                return None
         x = p if p.is_contiguous() and p.data_ptr() % 16 == 0 else _ops.aligned(p)
         _ops.check_current_device(lp.device)
         on_device = s_in.dim() == 0 and s_in.dtype == p.dtype and s_in.device == p.device and not s_in.requires_grad
@@ -1364,6 +1377,14 @@ class Segment(Element):
                     or q.device != p.device or w.device != p.device or not q.is_contiguous() or not w.is_contiguous() \
                     or (torch.is_grad_enabled() and (q.requires_grad or w.requires_grad)):
                 return None       # (charges or weights the screens' host step does not take: the walk, as before)
+            if grad_run is not None:
+                run, fr = grad_run
+                out, rows, C, rest = _TORCH_HOST.run_screen_track(lp.capsule_s, x, e, s_in, q, w, fr.distinct, fr.grad_meta,
+                                                                  sp.mass_eV_float, sp.num_elementary_charges_float)
+                x1, origin = x.reshape(1, N, 7), _ops._origin(p)
+                out._chx_lin = _ops._LinearSource(origin, x1, C, (), out._version)
+                lp.screens[0]._record_stretch((rows, rest, x1, C, origin), N, sp, None, "particles_grad")
+                return ParticleBeam(out, e, particle_charges=q, survival_probabilities=w, s=self._run_s(run, s_in), species=sp), i + lp.count
             for ap in lp.apertures:
                 ap._check_limits()
             n_bpm = len(lp.bpms)
@@ -1456,6 +1477,31 @@ class Segment(Element):
                     s_out = s_out + (self._run_length(item) if kind == "run" else item.length)
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=w_out, s=s_out, species=sp), i + lp.count
+
+    @staticmethod
+    def _stretch_grad_run(lp, incoming: ParticleBeam):
+        """(run, its differentiable plan) when the stretch `lp` is [run of scalar settings | one active Screen] and the only
+        things that carry a graph are settings of the run (a beam, an energy, a species or a screen geometry with a graph: None)."""
+        p, e, sp = incoming.particles, incoming.energy, incoming.species
+        if p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad or sp.num_elementary_charges.requires_grad:
+            return None
+        if lp.count != 2 or len(lp.screens) != 1 or lp.bpms or lp.apertures or lp.vshape is not None or lp.items[0][0] != "run" \
+                or lp.items[1][1] is not lp.screens[0] or p.dim() != 2 or e.dim() != 0:
+            return None
+        b = lp.screens[0].__dict__["_buffers"]
+        if b["misalignment"].requires_grad or b["pixel_size"].requires_grad:
+            return None
+        run = lp.items[0][1]
+        fr = run.gfast
+        if fr is None or fr.dtype != p.dtype or fr.device != p.device:
+            fr = run.gfast = _FastRun(run, p.dtype, p.device, allow_grad=True)
+        elif fr.epoch != Element._epoch:
+            fr.refresh()
+        if not fr.ok or fr.grad_meta is None:
+            return None
+        if _CHECK_PLANS:
+            fr.verify()
+        return run, fr
 
     def _lattice_stretch_parameter(self, plan, i: int, incoming: ParameterBeam):
         """The stretch of `_lattice_stretch` for a ParameterBeam (`chx_parameter_lattice_track`: the same preparation launch, then

@@ -1898,11 +1898,21 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
         for (int q = 0; q < 49; ++q) maps[e * 49 + q] = (T)M.m[q];
     }
     __syncthreads();
+    // a screen right behind this run may want the run's composed map (chx_lattice_screen.map)
+    T* map_out = nullptr;
+    if (b + 1 < n_items && items[(b + 1) * 4] == 4 && row == 0) {
+        const int slot = (int)items[(b + 1) * 4 + 3];
+        if (slot < scr.n) map_out = (T*)scr.s[slot].map;
+    }
     if (E == 1) {
-        if (threadIdx.x < 49) R[threadIdx.x] = maps[threadIdx.x];
+        if (threadIdx.x < 49) {
+            R[threadIdx.x] = maps[threadIdx.x];
+            if (map_out) map_out[threadIdx.x] = maps[threadIdx.x];
+        }
         return;
     }
     compose_block<T>([&](int e) { return (const T*)maps + e * 49; }, E, 0, R);
+    if (map_out && threadIdx.x < 49) map_out[threadIdx.x] = R[threadIdx.x];       // (thread t of wave 0 wrote R[t] itself)
 }
 
 // The same preparation for MANY rows of vectorised settings (an orbit response over thousands of corrector settings): one WAVE per

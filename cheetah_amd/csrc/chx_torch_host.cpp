@@ -13,9 +13,12 @@
 #include <Python.h>
 
 #include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/csrc/autograd/python_variable.h>
 
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "chx.h"
@@ -27,8 +30,22 @@ using parameter_screens_fn = decltype(&chx_parameter_lattice_track_screens);
 
 track_screens_fn p_track = nullptr;
 parameter_screens_fn p_parameter = nullptr;
-PyObject* g_raw_stream = nullptr;   // torch._C._cuda_getCurrentRawStream
+// what the differentiable nodes below call (bound by name, `bind`)
+decltype(&chx_run_build_compose) p_run_build_compose = nullptr;
+decltype(&chx_run_vjp_masked) p_run_vjp_masked = nullptr;
+decltype(&chx_run_vjp_workspace_bytes) p_run_vjp_workspace_bytes = nullptr;
+decltype(&chx_apply_affine7_bwd) p_apply_bwd = nullptr;
+decltype(&chx_apply_bwd_workspace_bytes) p_apply_bwd_workspace_bytes = nullptr;
+decltype(&chx_moments_entry) p_moments_entry = nullptr;
+decltype(&chx_moments_workspace_bytes) p_moments_workspace_bytes = nullptr;
+decltype(&chx_moment_entry) p_moment_entry = nullptr;
+decltype(&chx_moment_entry_mapped_bwd) p_moment_entry_mapped_bwd = nullptr;
 PyObject* g_error = nullptr;        // cheetah_amd._lib.ChxError
+
+// the stream torch's kernels of this thread go to on the tensor's device (also inside a backward pass: the engine restores the
+// forward's stream) — libchx enqueues on the caller's stream
+inline void* stream_of(const at::Tensor& t) { return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
+inline int code_of(const at::Tensor& t) { return t.scalar_type() == at::kDouble ? CHX_F64 : CHX_F32; }
 
 struct ScreenShape {
     int deposit;          // the particle pass may deposit the cloud-in-cell image of this screen
@@ -59,18 +76,30 @@ PyObject* any_requires_grad(PyObject*, PyObject* seq) {
     Py_RETURN_FALSE;
 }
 
-// bind(chx_lattice_track_screens address, chx_parameter_lattice_track_screens address, raw-stream getter, error class)
+// bind({symbol name: address}, error class): the libchx entry points this module calls
 PyObject* host_bind(PyObject*, PyObject* args) {
-    unsigned long long a, b;
-    PyObject *rs, *err;
-    if (!PyArg_ParseTuple(args, "KKOO", &a, &b, &rs, &err)) return nullptr;
-    p_track = reinterpret_cast<track_screens_fn>(static_cast<uintptr_t>(a));
-    p_parameter = reinterpret_cast<parameter_screens_fn>(static_cast<uintptr_t>(b));
-    Py_XDECREF(g_raw_stream);
+    PyObject *table, *err;
+    if (!PyArg_ParseTuple(args, "O!O", &PyDict_Type, &table, &err)) return nullptr;
+    auto take = [&](const char* name, auto& slot) -> bool {
+        PyObject* v = PyDict_GetItemString(table, name);
+        if (!v) {
+            PyErr_Format(PyExc_KeyError, "bind: no address for %s", name);
+            return false;
+        }
+        const unsigned long long a = PyLong_AsUnsignedLongLong(v);
+        if (PyErr_Occurred()) return false;
+        slot = reinterpret_cast<std::remove_reference_t<decltype(slot)>>(static_cast<uintptr_t>(a));
+        return true;
+    };
+    if (!take("chx_lattice_track_screens", p_track) || !take("chx_parameter_lattice_track_screens", p_parameter) ||
+        !take("chx_run_build_compose", p_run_build_compose) || !take("chx_run_vjp_masked", p_run_vjp_masked) ||
+        !take("chx_run_vjp_workspace_bytes", p_run_vjp_workspace_bytes) || !take("chx_apply_affine7_bwd", p_apply_bwd) ||
+        !take("chx_apply_bwd_workspace_bytes", p_apply_bwd_workspace_bytes) || !take("chx_moments_entry", p_moments_entry) ||
+        !take("chx_moments_workspace_bytes", p_moments_workspace_bytes) || !take("chx_moment_entry", p_moment_entry) ||
+        !take("chx_moment_entry_mapped_bwd", p_moment_entry_mapped_bwd))
+        return nullptr;
     Py_XDECREF(g_error);
-    Py_INCREF(rs);
     Py_INCREF(err);
-    g_raw_stream = rs;
     g_error = err;
     Py_RETURN_NONE;
 }
@@ -99,14 +128,6 @@ PyObject* host_plan(PyObject*, PyObject* args) {
         p->screens.push_back(ScreenShape{deposit, bx, by});
     }
     return PyCapsule_New(p, "chx.stretch_plan", plan_free);
-}
-
-bool current_stream(PyObject* device_index, void** stream) {
-    PyObject* st = PyObject_CallOneArg(g_raw_stream, device_index);
-    if (!st) return false;
-    *stream = PyLong_AsVoidPtr(st);
-    Py_DECREF(st);
-    return !(*stream == nullptr && PyErr_Occurred());
 }
 
 inline const at::Tensor& unpack(PyObject* o) { return THPVariable_Unpack(o); }
@@ -146,8 +167,7 @@ PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     void* survival_out = args[10] == Py_None ? nullptr : unpack(args[10]).data_ptr();
     void* readings = args[12] == Py_None ? nullptr : unpack(args[12]).data_ptr();
     void* workspace = args[13] == Py_None ? nullptr : unpack(args[13]).data_ptr();
-    void* stream;
-    if (!current_stream(args[8], &stream)) return nullptr;
+    void* stream = stream_of(x);
     const int64_t N = x.size(0);
     const auto opts = x.options();
     at::Tensor out = at::empty_like(x);
@@ -231,8 +251,7 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     const long long n_bpm = PyLong_AsLongLong(args[10]);
     if (PyErr_Occurred()) return nullptr;
     void* readings = args[11] == Py_None ? nullptr : unpack(args[11]).data_ptr();
-    void* stream;
-    if (!current_stream(args[8], &stream)) return nullptr;
+    void* stream = stream_of(mu);
     PyObject* geoms = args[9];
     const size_t n_screens = p->screens.size();
     if (!PyTuple_Check(geoms) || static_cast<size_t>(PyTuple_GET_SIZE(geoms)) != n_screens) {
@@ -301,9 +320,247 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     return res;
 }
 
+// ---- differentiable nodes in C++ -----------------------------------------------------------------------------------------------
+// d(screen sigma_x) / d(quadrupole strength) (tests/test_differentiable.py:10-32 of the reference; BASELINE config C5) is, per step,
+// eight launches of ~70 us — and was ~0.25 ms of Python around them: four `torch.autograd.Function.apply` calls forward, their
+// `backward` methods called back from the engine's device thread. The two nodes below do the same work from C++ (no GIL, no
+// Python frames in the backward pass):
+//  RunScreenTrack   [run of linear elements with scalar settings | active Screen]: the stretch call of the forward pass (two
+//                   launches: the run's map, the particle pass with the screen's record) as ONE node with outputs (outgoing rows,
+//                   the screen's record, the run's composed map C); backward: dC (+ the particle-sized terms dY x^T only when a
+//                   gradient arrives through the rows) -> chx_run_build_compose + chx_run_vjp_masked -> the settings' gradients
+//                   (element.py:180-191, segment.py:545-574, screen.py:187-214);
+//  MomentEntryMapped one beam property (mu_*, sigma_*, cov_*; particle_beam.py:1672-1943) of y = C x as a node on C: forward
+//                   chx_moments_entry of y, backward chx_moment_entry_mapped_bwd from the INCOMING beam's moments — no
+//                   particle-sized backward pass.
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+inline void chx_check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed with status ", rc); }
+
+// meta (int64 words): [E, code, n_distinct, kinds[E], ptrs[E * CHX_MAX_PARAMS], then per distinct setting tensor: n, (element,
+// slot, index | -1) x n]; mass_eV and n_charges travel as doubles
+struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& energy, const at::Tensor& s_in,
+                                 const at::Tensor& charges, const at::Tensor& survival, at::TensorList settings, int64_t plan_addr,
+                                 std::vector<int64_t> meta, double mass, double nq) {
+        auto* p = reinterpret_cast<StretchPlan*>(static_cast<uintptr_t>(plan_addr));
+        TORCH_CHECK(p->screens.size() == 1, "RunScreenTrack: a stretch [run | one active Screen]");
+        const int64_t N = x.size(0);
+        const auto opts = x.options();
+        at::Tensor out = at::empty_like(x), e_out = at::empty_like(energy), s_out = at::empty_like(s_in);
+        // the screen's record: the rows (differentiable: a loss on the image reaches the map through them) and, in one more tensor,
+        // [charges N | survival N | energy | s] (constants of this node)
+        at::Tensor rows = at::empty({N, 7}, opts), rest = at::empty({2 * N + 2}, opts), C = at::empty({1, 7, 7}, opts);
+        const size_t esize = x.element_size();
+        chx_lattice_screen scr = {};
+        char* base = static_cast<char*>(rest.data_ptr());
+        scr.rows = rows.data_ptr();
+        scr.charges = base;
+        scr.survival = base + N * esize;
+        scr.energy = base + 2 * N * esize;
+        scr.s = base + (2 * N + 1) * esize;
+        scr.map = C.data_ptr();
+        chx_check(p_track(p->table, p->n_items, p->n_elems, p->n_ptrs, energy.data_ptr(), mass, nq, p->code, p->state, p->state_bytes,
+                          x.data_ptr(), out.data_ptr(), N, 1, 1, 1, 1, 0, e_out.data_ptr(), s_in.data_ptr(), s_out.data_ptr(),
+                          survival.data_ptr(), nullptr, 0, nullptr, nullptr, 0, charges.data_ptr(), &scr, 1, stream_of(x)),
+                  "chx_lattice_track_screens");
+        variable_list saved = {x, energy, C};
+        for (const at::Tensor& t : settings) saved.push_back(t);
+        ctx->save_for_backward(saved);
+        ctx->saved_data["meta"] = meta;
+        ctx->saved_data["mass"] = mass;
+        ctx->saved_data["nq"] = nq;
+        ctx->mark_non_differentiable({e_out, s_out, rest});
+        return {out, rows, C, e_out, s_out, rest};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const variable_list saved = ctx->get_saved_variables();
+        const at::Tensor &x = saved[0], &energy = saved[1], &C = saved[2];
+        const std::vector<int64_t> meta = ctx->saved_data["meta"].toIntVector();
+        const double mass = ctx->saved_data["mass"].toDouble(), nq = ctx->saved_data["nq"].toDouble();
+        const int64_t E = meta[0], n_distinct = meta[2];
+        const int code = static_cast<int>(meta[1]);
+        const int64_t N = x.size(0);
+        void* stream = stream_of(x);
+        const auto opts = x.options();
+        // dL/dC: what came through C itself (beam properties of the tracked rows) plus sum_n dY_n x_n^T for the rows
+        at::Tensor dC = grads[2].defined() ? grads[2].to(opts.dtype()).contiguous() : at::Tensor();
+        auto add_rows = [&](const at::Tensor& dY) {
+            const size_t ws_bytes = p_apply_bwd_workspace_bytes(1, N);
+            at::Tensor ws = at::empty({static_cast<int64_t>(ws_bytes)}, opts.dtype(at::kByte));
+            at::Tensor dR = at::empty({49}, opts.dtype(at::kDouble));
+            at::Tensor g = dY.contiguous();
+            chx_check(p_apply_bwd(g.data_ptr(), C.data_ptr(), x.data_ptr(), nullptr, static_cast<double*>(dR.data_ptr()), 1, 1, 1, N, code,
+                                  ws.data_ptr(), ws_bytes, stream),
+                      "chx_apply_affine7_bwd");
+            at::Tensor part = dR.to(opts.dtype()).reshape({1, 7, 7});
+            dC = dC.defined() ? dC + part : part;
+        };
+        if (grads[0].defined()) add_rows(grads[0]);
+        if (grads[1].defined()) add_rows(grads[1]);
+        variable_list result(9 + n_distinct);        // x, energy, s_in, charges, survival, settings..., plan, meta, mass, nq
+        if (!dC.defined()) return result;
+        // the element maps again (the forward pass kept none: ~5 us of launch against E x 49 values per graph), then the VJP of the
+        // builders the wanted settings feed
+        std::vector<int32_t> kinds(E);
+        std::vector<const void*> ptrs(E * CHX_MAX_PARAMS);
+        for (int64_t e = 0; e < E; ++e) kinds[e] = static_cast<int32_t>(meta[3 + e]);
+        for (int64_t k = 0; k < E * CHX_MAX_PARAMS; ++k) ptrs[k] = reinterpret_cast<const void*>(static_cast<uintptr_t>(meta[3 + E + k]));
+        at::Tensor maps = at::empty({E, 7, 7}, opts), Rtmp = at::empty({7, 7}, opts);
+        chx_check(p_run_build_compose(kinds.data(), ptrs.data(), E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), Rtmp.data_ptr(), stream),
+                  "chx_run_build_compose");
+        std::vector<uint16_t> need(E, 0);
+        const bool need_energy = ctx->needs_input_grad(1);
+        size_t at = 3 + E + E * CHX_MAX_PARAMS;
+        std::vector<size_t> slot_at(n_distinct);
+        for (int64_t pos = 0; pos < n_distinct; ++pos) {
+            slot_at[pos] = at;
+            const int64_t n = meta[at];
+            if (ctx->needs_input_grad(5 + pos))
+                for (int64_t i = 0; i < n; ++i) need[meta[at + 1 + 3 * i]] |= static_cast<uint16_t>(1u << meta[at + 2 + 3 * i]);
+            at += 1 + 3 * n;
+        }
+        if (need_energy)
+            for (auto& m : need) m |= static_cast<uint16_t>(1u << CHX_MAX_PARAMS);
+        const size_t ws_bytes = p_run_vjp_workspace_bytes(E);
+        at::Tensor ws = at::empty({static_cast<int64_t>(ws_bytes)}, opts.dtype(at::kByte));
+        at::Tensor d = at::empty({E, CHX_MAX_PARAMS + 1}, opts);
+        chx_check(p_run_vjp_masked(kinds.data(), ptrs.data(), E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), dC.data_ptr(), need.data(),
+                                   d.data_ptr(), ws.data_ptr(), ws_bytes, stream),
+                  "chx_run_vjp_masked");
+        for (int64_t pos = 0; pos < n_distinct; ++pos) {
+            if (!ctx->needs_input_grad(5 + pos)) continue;
+            const at::Tensor& t = saved[3 + pos];
+            const size_t a = slot_at[pos];
+            const int64_t n = meta[a];
+            at::Tensor g;
+            if (t.dim() == 0) {
+                g = d.select(0, meta[a + 1]).select(0, meta[a + 2]);
+                for (int64_t i = 1; i < n; ++i) g = g + d.select(0, meta[a + 1 + 3 * i]).select(0, meta[a + 2 + 3 * i]);
+            } else {
+                g = at::zeros_like(t);
+                for (int64_t i = 0; i < n; ++i)
+                    g.select(0, meta[a + 3 + 3 * i]).add_(d.select(0, meta[a + 1 + 3 * i]).select(0, meta[a + 2 + 3 * i]));
+            }
+            result[5 + pos] = g;
+        }
+        if (need_energy) result[1] = d.select(1, CHX_MAX_PARAMS).sum();
+        return result;
+    }
+};
+
+struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappedNode> {
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& C, const at::Tensor& y, const std::optional<at::Tensor>& w,
+                                 const at::Tensor& mom_x, const std::optional<at::Tensor>& mom_y_in, int64_t index, bool take_sqrt) {
+        const int64_t N = y.size(-2);
+        const auto opts = y.options();
+        const int code = code_of(y);
+        void* stream = stream_of(y);
+        at::Tensor picked = at::empty({}, opts);
+        at::Tensor mom_y;
+        if (mom_y_in.has_value() && mom_y_in->defined()) {
+            mom_y = *mom_y_in;
+            chx_check(p_moment_entry(static_cast<const double*>(mom_y.data_ptr()), 1, static_cast<int>(index), take_sqrt ? 1 : 0, code,
+                                     picked.data_ptr(), stream),
+                      "chx_moment_entry");
+        } else {
+            mom_y = at::empty({1, 29}, opts.dtype(at::kDouble));
+            const size_t ws_bytes = p_moments_workspace_bytes(1, N);
+            at::Tensor ws = at::empty({static_cast<int64_t>(ws_bytes)}, opts.dtype(at::kByte));
+            chx_check(p_moments_entry(y.data_ptr(), w.has_value() && w->defined() ? w->data_ptr() : nullptr, 1, 1, 1, N, code,
+                                      static_cast<double*>(mom_y.data_ptr()), static_cast<int>(index), take_sqrt ? 1 : 0, picked.data_ptr(),
+                                      ws.data_ptr(), ws_bytes, stream),
+                      "chx_moments_entry");
+        }
+        ctx->save_for_backward({C, mom_y, mom_x});
+        ctx->saved_data["index"] = index;
+        ctx->saved_data["sqrt"] = take_sqrt;
+        ctx->mark_non_differentiable({mom_y});
+        return {picked, mom_y};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const variable_list saved = ctx->get_saved_variables();
+        const at::Tensor &C = saved[0], &mom_y = saved[1], &mom_x = saved[2];
+        variable_list result(7);
+        if (!grads[0].defined()) return result;
+        at::Tensor g = grads[0].to(C.scalar_type()).contiguous();
+        at::Tensor dR = at::empty_like(C);
+        chx_check(p_moment_entry_mapped_bwd(g.data_ptr(), static_cast<const double*>(mom_y.data_ptr()),
+                                            static_cast<int>(ctx->saved_data["index"].toInt()), ctx->saved_data["sqrt"].toBool() ? 1 : 0,
+                                            C.data_ptr(), static_cast<const double*>(mom_x.data_ptr()), 1, 1, mom_x.size(0), code_of(C),
+                                            dR.data_ptr(), 0, stream_of(C)),
+                  "chx_moment_entry_mapped_bwd");
+        result[0] = dR;
+        return result;
+    }
+};
+
+// run_screen_track(plan, x, energy, s_in, charges, survival, settings tuple, meta (list of ints), mass_eV, n_charges)
+//   -> (out, rows at the screen, C (1, 7, 7), [charges | survival | energy | s] at the screen)   [the first three differentiable in
+//      the settings and the energy]
+PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    if (nargs != 10) {
+        PyErr_SetString(PyExc_TypeError, "run_screen_track takes 10 arguments");
+        return nullptr;
+    }
+    auto* p = static_cast<StretchPlan*>(PyCapsule_GetPointer(args[0], "chx.stretch_plan"));
+    if (!p) return nullptr;
+    if (!PyTuple_Check(args[6]) || !PyList_Check(args[7])) {
+        PyErr_SetString(PyExc_TypeError, "run_screen_track: settings as a tuple of tensors, meta as a list of ints");
+        return nullptr;
+    }
+    std::vector<at::Tensor> settings;
+    for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(args[6]); ++i) settings.push_back(unpack(PyTuple_GET_ITEM(args[6], i)));
+    std::vector<int64_t> meta(PyList_GET_SIZE(args[7]));
+    for (Py_ssize_t i = 0; i < PyList_GET_SIZE(args[7]); ++i) meta[i] = static_cast<int64_t>(PyLong_AsUnsignedLongLongMask(PyList_GET_ITEM(args[7], i)));
+    const double mass = PyFloat_AsDouble(args[8]), nq = PyFloat_AsDouble(args[9]);
+    if (PyErr_Occurred()) return nullptr;
+    try {
+        variable_list r = RunScreenTrack::apply(unpack(args[1]), unpack(args[2]), unpack(args[3]), unpack(args[4]), unpack(args[5]),
+                                                at::TensorList(settings), static_cast<int64_t>(reinterpret_cast<uintptr_t>(p)), meta, mass, nq);
+        PyObject* res = PyTuple_New(4);
+        if (!res) return nullptr;
+        for (int i = 0; i < 3; ++i) PyTuple_SET_ITEM(res, i, THPVariable_Wrap(r[i]));
+        PyTuple_SET_ITEM(res, 3, THPVariable_Wrap(r[5]));
+        return res;
+    } catch (const std::exception& e) {
+        PyErr_SetString(g_error ? g_error : PyExc_RuntimeError, e.what());
+        return nullptr;
+    }
+}
+
+// moment_entry_mapped(C, y, w | None, mom_x, mom_y | None, index, take_sqrt) -> (entry, mom_y)
+PyObject* host_moment_entry_mapped(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    if (nargs != 7) {
+        PyErr_SetString(PyExc_TypeError, "moment_entry_mapped takes 7 arguments");
+        return nullptr;
+    }
+    const long long index = PyLong_AsLongLong(args[5]);
+    const int take_sqrt = PyObject_IsTrue(args[6]);
+    if (PyErr_Occurred()) return nullptr;
+    try {
+        std::optional<at::Tensor> w, mom_y;
+        if (args[2] != Py_None) w = unpack(args[2]);
+        if (args[4] != Py_None) mom_y = unpack(args[4]);
+        variable_list r = MomentEntryMappedNode::apply(unpack(args[0]), unpack(args[1]), w, unpack(args[3]), mom_y, static_cast<int64_t>(index),
+                                                       take_sqrt != 0);
+        PyObject* res = PyTuple_New(2);
+        if (!res) return nullptr;
+        PyTuple_SET_ITEM(res, 0, THPVariable_Wrap(r[0]));
+        PyTuple_SET_ITEM(res, 1, THPVariable_Wrap(r[1]));
+        return res;
+    } catch (const std::exception& e) {
+        PyErr_SetString(g_error ? g_error : PyExc_RuntimeError, e.what());
+        return nullptr;
+    }
+}
+
 PyMethodDef methods[] = {
     {"any_requires_grad", any_requires_grad, METH_O, "any_requires_grad(tuple_of_tensors) -> bool (non-tensor items count as False)"},
-    {"bind", host_bind, METH_VARARGS, "bind(chx_lattice_track_screens address, chx_parameter_lattice_track_screens address, raw stream getter, error class)"},
+    {"bind", host_bind, METH_VARARGS, "bind({libchx symbol: address}, error class)"},
     {"stretch_plan", host_plan, METH_VARARGS, "stretch_plan(table addr, n_items, n_elems, n_ptrs, state addr, state bytes, dtype code, screens) -> capsule"},
     {"lattice_track_screens", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_track)), METH_FASTCALL,
      "lattice_track_screens(plan, x, energy, s_in, charges, survival | None, mass_eV, n_charges, device index, image_limit, survival_out | None, "
@@ -311,6 +568,11 @@ PyMethodDef methods[] = {
     {"parameter_lattice_track_screens", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_parameter)), METH_FASTCALL,
      "parameter_lattice_track_screens(plan, mu, cov, energy, s_in, total_charge, mass_eV, n_charges, device index, geometries, n_bpm, "
      "readings | None) -> (mu_out, cov_out, energy_out, s_out, records, images)"},
+    {"run_screen_track", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_run_screen_track)), METH_FASTCALL,
+     "run_screen_track(plan, x, energy, s_in, charges, survival, settings, meta, mass_eV, n_charges) -> (out, rows, C, rest): the stretch "
+     "[run | active Screen] as one differentiable node"},
+    {"moment_entry_mapped", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_moment_entry_mapped)), METH_FASTCALL,
+     "moment_entry_mapped(C, y, w | None, mom_x, mom_y | None, index, take_sqrt) -> (entry, mom_y): one beam property of y = C x as a node on C"},
     {nullptr, nullptr, 0, nullptr}};
 
 struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_chxtorch", "torch-side host step of cheetah_amd (see chx_torch_host.cpp)", -1, methods};

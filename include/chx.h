@@ -623,6 +623,8 @@ typedef struct chx_lattice_screen {
     void* s;
     void* image;
     int64_t image_bytes;
+    void* map;              /* [7][7] (`dtype`) or NULL: the composed map of the RUN right in front of the screen, as the particle
+                               pass applies it (what a differentiable caller hangs the screen's beam properties on) */
     /* ParameterBeam variant only */
     void* mu;
     void* cov;

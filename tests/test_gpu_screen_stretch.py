@@ -376,3 +376,91 @@ def test_screen_stretch_declines():
         assert len(calls) == 2 and seg.AREABSCR1.reading.shape == (3, 48, 64)
     finally:
         segment._TORCH_HOST = old
+
+
+def _trainable_lattice(ca, fk, values):
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    k1a, k1b, ang = (torch.nn.Parameter(t(v)) for v in values)
+    seg = ca.Segment([
+        ca.Drift(t(0.6), **fk), ca.Quadrupole(t(0.2), k1=k1a, misalignment=t([1e-4, -5e-5]), **fk), ca.Drift(t(0.4), **fk),
+        ca.HorizontalCorrector(t(0.05), angle=ang, **fk), ca.Quadrupole(t(0.15), k1=k1b, tilt=t(0.05), **fk), ca.Drift(t(0.8), **fk),
+        ca.Screen(resolution=(64, 48), pixel_size=t([8e-5, 8e-5]), misalignment=t([5e-5, 0.0]), is_active=True, name="scr", **fk)])
+    return seg, (k1a, k1b, ang)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_differentiable_stretch_equals_general_path(dt):
+    """[run with trainable settings | active Screen] as ONE differentiable node (cheetah_amd._chxtorch RunScreenTrack +
+    MomentEntryMappedNode) against the general differentiable path (RunMapPlanned / Apply / clone / MomentEntryMapped): the same
+    losses and gradients for beam properties of the read beam and of the outgoing beam (algebraic backward), for a loss on the
+    image and on the outgoing particles (particle-sized backward), and with two forward passes before the backward passes."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    fk = {"dtype": dt, "device": "cuda"}
+    torch.manual_seed(1)
+    beam = ca.ParticleBeam.from_parameters(num_particles=20_000, sigma_x=torch.tensor(2e-4, **fk), sigma_y=torch.tensor(1.5e-4, **fk),
+                                           sigma_px=torch.tensor(2e-5, **fk), sigma_py=torch.tensor(2e-5, **fk), energy=torch.tensor(9e7, **fk), **fk)
+    beam.survival_probabilities = 0.5 + 0.5 * torch.rand(20_000, **fk)
+    calls = []
+    th = segment._lib.torch_host()
+    old = segment._TORCH_HOST
+    segment._TORCH_HOST = _Spy(th, "run_screen_track", calls)
+
+    def losses(seg):
+        out = seg.track(beam)
+        rb = seg.scr.get_read_beam()
+        weights = torch.linspace(0.0, 1.0, 64 * 48, **fk).reshape(48, 64)
+        return [rb.sigma_x, rb.sigma_y + 3.0 * rb.mu_x, rb.cov_xpx * 1e4 + out.sigma_x, out.mu_y * 2.0 + rb.sigma_px,
+                (seg.scr.reading * weights).sum() * 1e12, out.particles[:, :4].square().mean() * 1e6]
+
+    rel = 2e-4 if dt == torch.float32 else 1e-9
+    try:
+        values = (4.0, -6.0, 8e-5)
+        n_losses = 6
+        for which in range(n_losses):
+            seg_a, params_a = _trainable_lattice(ca, fk, values)
+            calls.clear()
+            la = losses(seg_a)[which]
+            assert len(calls) == 1, (which, calls)                      # the one-node path was taken
+            la.backward()
+            segment.Segment._STRETCH_SCREENS = False
+            try:
+                seg_b, params_b = _trainable_lattice(ca, fk, values)
+                lb = losses(seg_b)[which]
+                lb.backward()
+            finally:
+                segment.Segment._STRETCH_SCREENS = True
+            assert len(calls) == 1
+            assert float(la) == pytest.approx(float(lb), rel=rel), which
+            for pa, pb in zip(params_a, params_b):
+                assert pa.grad is not None and pb.grad is not None, which
+                assert float(pa.grad) == pytest.approx(float(pb.grad), rel=10 * rel, abs=1e-12 * abs(float(lb))), (which, float(pa.grad), float(pb.grad))
+        # two forward passes (another beam in between) before the backward passes: every node keeps its own state
+        seg, params = _trainable_lattice(ca, fk, values)
+        other = ca.ParticleBeam(beam.particles * 1.5, beam.energy, particle_charges=beam.particle_charges, **fk)
+        seg.track(beam)
+        l1 = seg.scr.get_read_beam().sigma_x
+        seg.track(other)
+        l2 = seg.scr.get_read_beam().sigma_x
+        l1.backward()
+        g1 = [float(p.grad) for p in params]
+        for p in params:
+            p.grad = None
+        l2.backward()
+        g2 = [float(p.grad) for p in params]
+        seg_c, params_c = _trainable_lattice(ca, fk, values)
+        seg_c.track(beam)
+        seg_c.scr.get_read_beam().sigma_x.backward()
+        for a, c in zip(g1, [float(p.grad) for p in params_c]):
+            assert a == pytest.approx(c, rel=1e-6)
+        assert any(abs(a - b) > 1e-3 * abs(a) for a, b in zip(g1, g2))
+        # a setting edited in place between forward and backward is refused like any saved tensor
+        seg.track(beam)
+        loss = seg.scr.get_read_beam().sigma_x
+        with torch.no_grad():
+            params[0].add_(0.5)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            loss.backward()
+    finally:
+        segment._TORCH_HOST = old
