@@ -58,7 +58,7 @@ class LatticeScreen(ctypes.Structure):
 
     _fields_ = [
         ("rows", c_void_p), ("charges", c_void_p), ("survival", c_void_p), ("energy", c_void_p), ("s", c_void_p),
-        ("image", c_void_p), ("image_bytes", c_i64), ("map", c_void_p),
+        ("image", c_void_p), ("image_bytes", c_i64), ("map", c_void_p), ("element_maps", c_void_p),
         ("mu", c_void_p), ("cov", c_void_p), ("geom", c_void_p), ("shift", c_void_p), ("total_charge", c_void_p),
         ("total_charge_out", c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
     ]

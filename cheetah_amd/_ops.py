@@ -1143,6 +1143,30 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
         return None
     if survival is not None and survival.requires_grad:
         return None
+    if particles.dim() == 2 and lin.batch_shape == () and lin.R.shape[0] == 1 and lin.R.dtype == particles.dtype and lin.x.shape[0] == 1 \
+            and (survival is None or (survival.dim() == 1 and survival.dtype == particles.dtype and survival.is_contiguous())) \
+            and particles.is_contiguous() and particles.data_ptr() % 16 == 0:
+        # the plain case — one beam through one map, an optimisation loop's every step — without the broadcasting preparations:
+        # the memoised moments of the incoming beam, the node in C++ (cheetah_amd._chxtorch MomentEntryMappedNode)
+        memo = not CAPTURING[0] or CAPTURE_KEEPS_BEAM_MOMENTS[0]
+        w_src = None if survival is None else _origin(survival)
+        w_ver = None if w_src is None else w_src._version
+        owner, mom_x = lin.owner, None
+        cached = getattr(owner, "_chx_mom", None) if memo else None
+        if cached is not None and cached[0] == owner._version and cached[1] is w_src and cached[2] == w_ver \
+                and cached[3] == lin.x.data_ptr() and cached[4].shape[0] == 1:
+            mom_x = cached[4]
+        else:
+            mom_x = _memo_moments(owner, lin.x, None if survival is None else survival.reshape(1, -1), survival, 1)
+        cached = getattr(particles, "_chx_mom", None) if memo else None
+        known = None
+        if cached is not None and cached[0] == particles._version and cached[1] is w_src and cached[2] == w_ver \
+                and cached[3] == particles.data_ptr() and cached[4].shape[0] == 1:
+            known = cached[4]
+        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, particles.detach(), survival, mom_x, known, index, take_sqrt)
+        if known is None:
+            particles._chx_mom = (particles._version, w_src, w_ver, particles.data_ptr(), mom_y)
+        return out
     sshape = survival.shape[:-1] if survival is not None else ()
     batch_shape = bshapes(particles.shape[:-2], sshape)
     if tuple(batch_shape) != tuple(lin.batch_shape):

@@ -169,10 +169,9 @@ class Screen(Element):
                 elif kind == "particles_grad":
                     # the differentiable stretch (cheetah_amd._chxtorch RunScreenTrack): the rows are an output of the node, y = C x
                     # with x free of gradients — a beam property of them hangs on C (`_LinearSource`)
-                    rows, rest, x, C, origin = t
+                    rows, q, w, e, s_at, x, C, origin = t
                     rows._chx_lin = _ops._LinearSource(origin, x, C, (), rows._version)
-                    beam = ParticleBeam(rows, rest[2 * n], particle_charges=rest[:n], survival_probabilities=rest[n:2 * n],
-                                        s=rest[2 * n + 1], species=species)
+                    beam = ParticleBeam(rows, e, particle_charges=q, survival_probabilities=w, s=s_at, species=species)
                 else:
                     beam = ParameterBeam(t[:7], t[7:56].view(7, 7), t[56], total_charge=t[58], s=t[57], species=species)
                 d["_incoming"] = beam

@@ -1379,11 +1379,11 @@ class Segment(Element):
                 return None       # (charges or weights the screens' host step does not take: the walk, as before)
             if grad_run is not None:
                 run, fr = grad_run
-                out, rows, C, rest = _TORCH_HOST.run_screen_track(lp.capsule_s, x, e, s_in, q, w, fr.distinct, fr.grad_meta,
-                                                                  sp.mass_eV_float, sp.num_elementary_charges_float)
+                out, rows, C, q_at, w_at, e_at, s_at = _TORCH_HOST.run_screen_track(
+                    lp.capsule_s, x, e, s_in, q, w, fr.distinct, fr.grad_meta, sp.mass_eV_float, sp.num_elementary_charges_float)
                 x1, origin = x.reshape(1, N, 7), _ops._origin(p)
                 out._chx_lin = _ops._LinearSource(origin, x1, C, (), out._version)
-                lp.screens[0]._record_stretch((rows, rest, x1, C, origin), N, sp, None, "particles_grad")
+                lp.screens[0]._record_stretch((rows, q_at, w_at, e_at, s_at, x1, C, origin), N, sp, None, "particles_grad")
                 return ParticleBeam(out, e, particle_charges=q, survival_probabilities=w, s=self._run_s(run, s_in), species=sp), i + lp.count
             for ap in lp.apertures:
                 ap._check_limits()
@@ -1497,7 +1497,7 @@ class Segment(Element):
             fr = run.gfast = _FastRun(run, p.dtype, p.device, allow_grad=True)
         elif fr.epoch != Element._epoch:
             fr.refresh()
-        if not fr.ok or fr.grad_meta is None:
+        if not fr.ok or fr.grad_meta is None or fr.E != lp.shape[1]:
             return None
         if _CHECK_PLANS:
             fr.verify()

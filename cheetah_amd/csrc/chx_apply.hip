@@ -568,7 +568,9 @@ struct ApplyScreens {
     const void* charge;      // [N] or NULL (= 1)
 };
 
-template <typename T, int PPT, bool SCREENS>
+// SCREENS: 0 = no screen items, 1 = screens that record only (no image buffer in this call: none of the combining table's 32 KiB
+// of LDS, which would leave four workgroups per CU), 2 = screens with images
+template <typename T, int PPT, int SCREENS>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in, T* x_out, const int64_t* __restrict__ items, int n_items,
                                                                  const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                                  int64_t N, int in_vec_ok, int out_vec_ok,
@@ -640,10 +642,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             }
             continue;
         }
-        if constexpr (SCREENS) {
+        if constexpr (SCREENS != 0) {
             if (type == 4) {
-                __shared__ long long comb_keys[kCombSlots];
-                __shared__ double comb_vals[kCombSlots];
                 const int64_t q = items[i * 4 + 2];
                 const chx_lattice_screen& so = scr.s[(int)items[i * 4 + 3]];
                 const T* __restrict__ charge = (const T*)scr.charge;
@@ -671,7 +671,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                         if (q_rec) q_rec[n0 + p] = charge ? charge[t0 + p] : (T)1;
                     }
                 }
-                if ((items[i * 4 + 1] & 1) && so.image) {
+                if constexpr (SCREENS == 2) {
+                  if ((items[i * 4 + 1] & 1) && so.image) {
+                    __shared__ long long comb_keys[kCombSlots];
+                    __shared__ double comb_vals[kCombSlots];
                     const T* mis = (const T*)ptrs[q];
                     const T* ps = (const T*)ptrs[q + 1];
                     const int bins_x = (int)ptrs[q + 4], bins_y = (int)ptrs[q + 5];
@@ -710,6 +713,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     }
                     table.flush();
                     __syncthreads();                   // (the table is free for the next screen of the stretch)
+                  }
                 }
                 continue;
             }
@@ -880,10 +884,13 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
     hipLaunchKernelGGL((lattice_apply_kernel<T, PPT, SCR>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out, table,          \
                        (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs, (T*)survival_out,   \
                        shared_in, Bm, shared_sv, scr)
+    bool images = false;
+    for (int64_t k = 0; k < n_screens; ++k) images = images || screens[k].image != nullptr;
 #define CHX_LATTICE_APPLY(T, PPT)                  \
     do {                                           \
-        if (n_screens > 0) CHX_LATTICE_APPLY_S(T, PPT, true); \
-        else CHX_LATTICE_APPLY_S(T, PPT, false);   \
+        if (n_screens > 0 && images) CHX_LATTICE_APPLY_S(T, PPT, 2); \
+        else if (n_screens > 0) CHX_LATTICE_APPLY_S(T, PPT, 1);      \
+        else CHX_LATTICE_APPLY_S(T, PPT, 0);       \
     } while (0)
     if (dtype == CHX_F32) {
         if (ppt == 2) CHX_LATTICE_APPLY(float, 2);

@@ -1902,7 +1902,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
     T* map_out = nullptr;
     if (b + 1 < n_items && items[(b + 1) * 4] == 4 && row == 0) {
         const int slot = (int)items[(b + 1) * 4 + 3];
-        if (slot < scr.n) map_out = (T*)scr.s[slot].map;
+        if (slot < scr.n) {
+            map_out = (T*)scr.s[slot].map;
+            T* emaps_out = (T*)scr.s[slot].element_maps;
+            if (emaps_out)
+                for (int q = threadIdx.x; q < E * 49; q += CHX_BLOCK) emaps_out[q] = maps[q];
+        }
     }
     if (E == 1) {
         if (threadIdx.x < 49) {

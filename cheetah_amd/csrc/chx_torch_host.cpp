@@ -346,12 +346,15 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
                                  std::vector<int64_t> meta, double mass, double nq) {
         auto* p = reinterpret_cast<StretchPlan*>(static_cast<uintptr_t>(plan_addr));
         TORCH_CHECK(p->screens.size() == 1, "RunScreenTrack: a stretch [run | one active Screen]");
+        ctx->set_materialize_grads(false);       // (an output nobody differentiates arrives undefined, not as N x 7 zeros)
         const int64_t N = x.size(0);
         const auto opts = x.options();
         at::Tensor out = at::empty_like(x), e_out = at::empty_like(energy), s_out = at::empty_like(s_in);
         // the screen's record: the rows (differentiable: a loss on the image reaches the map through them) and, in one more tensor,
         // [charges N | survival N | energy | s] (constants of this node)
+        const int64_t E = meta[0];
         at::Tensor rows = at::empty({N, 7}, opts), rest = at::empty({2 * N + 2}, opts), C = at::empty({1, 7, 7}, opts);
+        at::Tensor maps = at::empty({E, 7, 7}, opts);
         const size_t esize = x.element_size();
         chx_lattice_screen scr = {};
         char* base = static_cast<char*>(rest.data_ptr());
@@ -361,11 +364,12 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
         scr.energy = base + 2 * N * esize;
         scr.s = base + (2 * N + 1) * esize;
         scr.map = C.data_ptr();
+        scr.element_maps = maps.data_ptr();
         chx_check(p_track(p->table, p->n_items, p->n_elems, p->n_ptrs, energy.data_ptr(), mass, nq, p->code, p->state, p->state_bytes,
                           x.data_ptr(), out.data_ptr(), N, 1, 1, 1, 1, 0, e_out.data_ptr(), s_in.data_ptr(), s_out.data_ptr(),
                           survival.data_ptr(), nullptr, 0, nullptr, nullptr, 0, charges.data_ptr(), &scr, 1, stream_of(x)),
                   "chx_lattice_track_screens");
-        variable_list saved = {x, energy, C};
+        variable_list saved = {x, energy, C, maps};
         for (const at::Tensor& t : settings) saved.push_back(t);
         ctx->save_for_backward(saved);
         ctx->saved_data["meta"] = meta;
@@ -377,7 +381,7 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const variable_list saved = ctx->get_saved_variables();
-        const at::Tensor &x = saved[0], &energy = saved[1], &C = saved[2];
+        const at::Tensor &x = saved[0], &energy = saved[1], &C = saved[2], &maps = saved[3];
         const std::vector<int64_t> meta = ctx->saved_data["meta"].toIntVector();
         const double mass = ctx->saved_data["mass"].toDouble(), nq = ctx->saved_data["nq"].toDouble();
         const int64_t E = meta[0], n_distinct = meta[2];
@@ -402,15 +406,11 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
         if (grads[1].defined()) add_rows(grads[1]);
         variable_list result(9 + n_distinct);        // x, energy, s_in, charges, survival, settings..., plan, meta, mass, nq
         if (!dC.defined()) return result;
-        // the element maps again (the forward pass kept none: ~5 us of launch against E x 49 values per graph), then the VJP of the
-        // builders the wanted settings feed
+        // the VJP of the builders the wanted settings feed, from the element maps the forward pass's preparation launch left
         std::vector<int32_t> kinds(E);
         std::vector<const void*> ptrs(E * CHX_MAX_PARAMS);
         for (int64_t e = 0; e < E; ++e) kinds[e] = static_cast<int32_t>(meta[3 + e]);
         for (int64_t k = 0; k < E * CHX_MAX_PARAMS; ++k) ptrs[k] = reinterpret_cast<const void*>(static_cast<uintptr_t>(meta[3 + E + k]));
-        at::Tensor maps = at::empty({E, 7, 7}, opts), Rtmp = at::empty({7, 7}, opts);
-        chx_check(p_run_build_compose(kinds.data(), ptrs.data(), E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), Rtmp.data_ptr(), stream),
-                  "chx_run_build_compose");
         std::vector<uint16_t> need(E, 0);
         const bool need_energy = ctx->needs_input_grad(1);
         size_t at = 3 + E + E * CHX_MAX_PARAMS;
@@ -432,7 +432,7 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
                   "chx_run_vjp_masked");
         for (int64_t pos = 0; pos < n_distinct; ++pos) {
             if (!ctx->needs_input_grad(5 + pos)) continue;
-            const at::Tensor& t = saved[3 + pos];
+            const at::Tensor& t = saved[4 + pos];
             const size_t a = slot_at[pos];
             const int64_t n = meta[a];
             at::Tensor g;
@@ -454,6 +454,7 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
 struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappedNode> {
     static variable_list forward(AutogradContext* ctx, const at::Tensor& C, const at::Tensor& y, const std::optional<at::Tensor>& w,
                                  const at::Tensor& mom_x, const std::optional<at::Tensor>& mom_y_in, int64_t index, bool take_sqrt) {
+        ctx->set_materialize_grads(false);
         const int64_t N = y.size(-2);
         const auto opts = y.options();
         const int code = code_of(y);
@@ -499,8 +500,8 @@ struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappe
 };
 
 // run_screen_track(plan, x, energy, s_in, charges, survival, settings tuple, meta (list of ints), mass_eV, n_charges)
-//   -> (out, rows at the screen, C (1, 7, 7), [charges | survival | energy | s] at the screen)   [the first three differentiable in
-//      the settings and the energy]
+//   -> (out, rows at the screen, C (1, 7, 7), charges, survival, energy, s at the screen)   [the first three differentiable in the
+//      settings and the energy; the last four are views of one allocation]
 PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     if (nargs != 10) {
         PyErr_SetString(PyExc_TypeError, "run_screen_track takes 10 arguments");
@@ -521,10 +522,16 @@ PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nar
     try {
         variable_list r = RunScreenTrack::apply(unpack(args[1]), unpack(args[2]), unpack(args[3]), unpack(args[4]), unpack(args[5]),
                                                 at::TensorList(settings), static_cast<int64_t>(reinterpret_cast<uintptr_t>(p)), meta, mass, nq);
-        PyObject* res = PyTuple_New(4);
+        PyObject* res = PyTuple_New(7);
         if (!res) return nullptr;
         for (int i = 0; i < 3; ++i) PyTuple_SET_ITEM(res, i, THPVariable_Wrap(r[i]));
-        PyTuple_SET_ITEM(res, 3, THPVariable_Wrap(r[5]));
+        // the constants of the record as the beam's tensors (views of one allocation, made here: ~0.5 us each against ~2 us from Python)
+        const at::Tensor& rest = r[5];
+        const int64_t N = r[1].size(0);
+        PyTuple_SET_ITEM(res, 3, THPVariable_Wrap(rest.narrow(0, 0, N)));
+        PyTuple_SET_ITEM(res, 4, THPVariable_Wrap(rest.narrow(0, N, N)));
+        PyTuple_SET_ITEM(res, 5, THPVariable_Wrap(rest.select(0, 2 * N)));
+        PyTuple_SET_ITEM(res, 6, THPVariable_Wrap(rest.select(0, 2 * N + 1)));
         return res;
     } catch (const std::exception& e) {
         PyErr_SetString(g_error ? g_error : PyExc_RuntimeError, e.what());

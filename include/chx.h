@@ -625,6 +625,7 @@ typedef struct chx_lattice_screen {
     int64_t image_bytes;
     void* map;              /* [7][7] (`dtype`) or NULL: the composed map of the RUN right in front of the screen, as the particle
                                pass applies it (what a differentiable caller hangs the screen's beam properties on) */
+    void* element_maps;     /* [E][7][7] (`dtype`) or NULL: that run's element maps in tracking order (what chx_run_vjp_masked takes) */
     /* ParameterBeam variant only */
     void* mu;
     void* cov;

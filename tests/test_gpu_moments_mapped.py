@@ -88,13 +88,15 @@ def test_incoming_moments_are_reduced_once_per_beam(ca):
         first, _ = _grads(ca, beam, dt, True, names=("sigma_x",))
         n_first = calls["n"]                      # forward reduction of y + the incoming moments
         again, _ = _grads(ca, beam, dt, True, names=("sigma_x",))
-        assert calls["n"] - n_first == 1          # forward reduction only
+        # forward reduction only — and that one inside the C++ node (cheetah_amd._chxtorch MomentEntryMappedNode) when one beam
+        # goes through one map: the incoming beam is not reduced again either way
+        assert calls["n"] - n_first in (0, 1)
         assert torch.equal(first["sigma_x"][1][0], again["sigma_x"][1][0])
         with torch.no_grad():
             beam.particles[:, 0] *= 2.0           # version moves
         n0 = calls["n"]
         changed, _ = _grads(ca, beam, dt, True, names=("sigma_x",))
-        assert calls["n"] - n0 == 2
+        assert calls["n"] - n0 in (1, 2)          # the incoming beam again (+ the forward reduction when Python launches it)
         assert float(changed["sigma_x"][0]) > 1.5 * float(first["sigma_x"][0])
     finally:
         _ops._moments_raw = real
