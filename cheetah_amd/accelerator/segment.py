@@ -1147,7 +1147,7 @@ class Segment(Element):
         parts = built[0]
         if not parts:
             return None
-        maps, s = [], s_in
+        maps, s, views = [], s_in, []
         for part, candidate in parts:
             got = Segment._run_map_fast(part, ref, energy, species, s) if candidate else None
             if got is None:             # (a vectorised or gradient-carrying setting: this piece through the general path)
@@ -1156,8 +1156,15 @@ class Segment(Element):
                 maps.append(Segment._run_map(part, energy, species))
                 s = Segment._run_s(part, s)
             else:
+                views.append(len(maps))
                 maps.append(got[0])
                 s = got[1]
+        if torch.is_grad_enabled() and any(m.requires_grad for m in maps):
+            # `ComposeMaps` saves its inputs for the backward pass: a piece map that is a VIEW of its plan's device state would be
+            # overwritten by the next forward pass (another beam energy, an in-place edit of a setting) without any version
+            # counter moving — the product's backward pass needs the values of THIS forward pass
+            for k in views:
+                maps[k] = maps[k].clone()
         batch_shape = torch.broadcast_shapes(*[m.shape[:-2] for m in maps])
         return _ops.compose_maps(maps, batch_shape, ref.dtype, ref.device), s
 
@@ -1752,6 +1759,7 @@ class Segment(Element):
         ent = cache[1].get(i)
         if ent is not None and ent["epoch"] == Element._epoch and ent["dtype"] == x.dtype and ent["device"] == x.device \
                 and [t._version for t in ent["tensors"]] == ent["versions"] and not _ops.CAPTURING[0] \
+                and [e.dkd_precision for e in ent["dkd"]] == ent["precisions"] \
                 and not (grad and any(t.requires_grad for t in ent["tensors"])) \
                 and (ent["energy"] is None or (ent["energy"] is energy and ent["energy_version"] == energy._version
                                                and ent["mass"] == species.mass_eV_float
@@ -1845,7 +1853,10 @@ class Segment(Element):
                                "versions": [t._version for t in tensors], "kinds": kinds, "params": params, "lengths": lengths,
                                "arrays": arrays, "end": after[k - 1], "energy": energy if has_runs else None,
                                "energy_version": energy._version, "mass": species.mass_eV_float,
-                               "nq": species.num_elementary_charges_float}
+                               "nq": species.num_elementary_charges_float,
+                               # (`dkd_precision` may be set on the CLASS, which moves no epoch: compared on every hit)
+                               "dkd": [obj for obj, a in seq[:k] if a is not None],
+                               "precisions": [obj.dkd_precision for obj, a in seq[:k] if a is not None]}
             return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                                 survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), after[k - 1]
         # no such stretch starts here: consecutive drift-kick-drift elements (no runs) in one call, element passes, up to where
@@ -1866,7 +1877,8 @@ class Segment(Element):
         if not _ops.CAPTURING[0]:
             cache[1][i] = {"epoch": Element._epoch, "dtype": x.dtype, "device": x.device, "tensors": tensors,
                            "versions": [t._version for t in tensors], "kinds": kinds, "params": params, "arrays": arrays,
-                           "end": after[k - 1], "energy": None}
+                           "end": after[k - 1], "energy": None, "dkd": [obj for obj, _ in seq[:k]],
+                           "precisions": [obj.dkd_precision for obj, _ in seq[:k]]}
         return ParticleBeam(out, e_out, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=s_out, species=species), after[k - 1]
 
@@ -2223,6 +2235,11 @@ class Segment(Element):
                 cached = self.__dict__["_along_cache"] = (plan, _Run(leaves))
             run = cached[1]
             bpms = [(k, e) for k, e in enumerate(run.elements) if e._is_bpm and e.is_active]
+            if bpms:
+                from .. import sharding
+
+                if sharding.active_group() is not None:
+                    return None       # (a particle-sharded beam: the monitors read GLOBAL means, BPM._track_internal exchanges them)
         # where the segment's own elements end in the run's list of leaves
         ends, n_leaves = [], 0
         for e in elements:

@@ -65,6 +65,7 @@ def build(module, spec, fk):
 
 if __name__ == "__main__":
     arrays = {"n_lattices": np.asarray(8)}
+    torch.manual_seed(99)            # (lattice 0's beam is drawn before the first per-lattice seed below)
     for i in range(8):
         with_cav, with_ap = i % 2 == 1, i >= 4
         specs = [draw(with_cav, with_ap) for _ in range(int(rng.integers(18, 41)))]
