@@ -303,8 +303,8 @@ def event_timed_elementwise(torch, seg, beam, steps, warmup):
 
 
 # ---------------------------------------------------------------------------------------------------------------- configs
-def other_configs(ca, torch, device) -> dict:
-    """C1 / C3 / C4 / C5 of BASELINE.json at full size on one GPU (seeded synthetic inputs), ms per call."""
+def other_configs(ca, torch, device, only=None) -> dict:
+    """C1 / C3 / C4 / C5 of BASELINE.json at full size on one GPU (seeded synthetic inputs), ms per call. `only`: names to run."""
     from benchmarks import run_configs as rc
 
     rc.DEV = device
@@ -504,12 +504,19 @@ def other_configs(ca, torch, device) -> dict:
 
     def diagnostics():
         # lattices with things between the magnets that read or thin the beam: active BPMs, apertures, cavities — one stretch call
-        # each (chx_lattice_track_diag / chx_parameter_lattice_track), ParticleBeam of 1e5 particles and ParameterBeam
+        # each (chx_lattice_track_diag / chx_parameter_lattice_track), ParticleBeam of 1e5 particles and ParameterBeam. Lattices and
+        # beams are DATA drawn on the host from fixed seeds (benchmarks/diagnostics_inputs.py); every entry is checked against the
+        # REFERENCE's float64 run of the same data (tests/golden/bench_diagnostics.json) before its time is reported.
         import time as _t
+
+        from benchmarks import diagnostics_inputs as di
 
         dt = torch.float32
         kw = {"dtype": dt, "device": device}
         tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
+        with open(os.path.join(ROOT, "tests", "golden", "bench_diagnostics.json")) as fh:
+            expected = json.load(fh)
+        checks = {"entries": 0, "values": 0, "worst_relative_error": 0.0}
 
         def timed_us(fn, reps=30):
             for _ in range(5):
@@ -521,66 +528,92 @@ def other_configs(ca, torch, device) -> dict:
             torch.cuda.synchronize()
             return (_t.perf_counter() - t0) / reps * 1e6
 
-        bpm_cells, ap_cells, linac = [], [], []
-        for i in range(25):
-            q = lambda: ca.Quadrupole(tt(0.2), k1=tt(4.2 if i % 2 == 0 else -4.2), **kw)  # noqa: E731
-            bpm_cells += [q(), ca.Drift(tt(0.8), **kw), ca.BPM(is_active=True, **kw), ca.Drift(tt(0.2), **kw)]
-            ap_cells += [q(), ca.Drift(tt(0.8), **kw), ca.Aperture(x_max=tt(5e-3), y_max=tt(5e-3), **kw), ca.Drift(tt(0.2), **kw)]
-        for i in range(16):
-            linac += [ca.Drift(tt(0.3), **kw), ca.Quadrupole(tt(0.2), k1=tt(3.0 if i % 2 else -3.0), **kw),
-                      ca.Cavity(tt(1.0377), voltage=tt(18e6), phase=tt(-10.0), frequency=tt(1.3e9), **kw)]
-        beam = ca.ParticleBeam.from_parameters(num_particles=100_000, energy=tt(1e8), **kw)
-        pbeam = ca.ParameterBeam.from_parameters(energy=tt(1e8), **kw)
-        many = ca.ParticleBeam(beam.particles[:10_000].unsqueeze(0).repeat(16, 1, 1).contiguous(), beam.energy, **kw)
+        def check(entry, variant, seg, out, rows=None):
+            """sigma_x, sigma_y, energy, the surviving weight and the last monitor's reading of what was just tracked against the
+            reference's numbers: float32 tracking of ~100 elements against float64 — 2e-4 of a beam size, 1e-6 of the energy."""
+            want = expected[entry][variant]
+            bpms = [e for e in seg.elements if isinstance(e, ca.BPM)]
+            got = {}
+            for tag, b in ([("", None)] if rows is None else [(f"_row{r}", r) for r in rows]):
+                pick = lambda t: float(t if (b is None or t.dim() == 0) else t[b])  # noqa: E731
+                got["sigma_x" + tag], got["sigma_y" + tag], got["energy" + tag] = pick(out.sigma_x), pick(out.sigma_y), pick(out.energy)
+                if bpms:
+                    r = bpms[-1].reading
+                    got["last_reading_x" + tag] = float(r[..., 0] if b is None or r.dim() == 1 else r[b, 0])
+            if isinstance(out, ca.ParticleBeam):
+                w = out.survival_probabilities
+                got["survived"] = float(w.sum() if w.dim() == 1 else w[0].sum())
+            assert set(got) == set(want), (entry, variant, sorted(set(got) ^ set(want)))
+            for key, v in want.items():
+                if key.startswith("last_reading"):
+                    scale, tol = max(abs(v), want["sigma_x" + key[len("last_reading_x"):]]), 2e-4      # (a mean: against the beam size)
+                elif key.startswith("energy") or key == "survived":
+                    scale, tol = abs(v), 1e-6
+                else:
+                    scale, tol = abs(v), 2e-4
+                err = abs(got[key] - v) / scale
+                checks["worst_relative_error"] = max(checks["worst_relative_error"], err)
+                checks["values"] += 1
+                if not err < tol:
+                    raise AssertionError(f"DIAGNOSTICS_LATTICES {entry}/{variant}: {key} = {got[key]!r}, the reference has {v!r}")
+            checks["entries"] += 1
+
+        x = di.particles().to(device)
+        E0 = tt(1e8)
+        beam = ca.ParticleBeam(x, E0, **kw)
+        small = ca.ParticleBeam(x[:di.N_SMALL].contiguous(), E0, **kw)
+        mu, cov = di.parameter_beam_moments()
+        pbeam = ca.ParameterBeam(mu.to(**kw), cov.to(**kw), E0, **kw)
+        many = ca.ParticleBeam(x[:di.N_SMALL].unsqueeze(0).repeat(16, 1, 1).contiguous(), E0, **kw)
         res = {"workload": "100-element lattices with 25 active BPMs / 25 active apertures and a 16-cell cavity linac, fp32: us per "
                            "Segment.track (ParticleBeam of 1e5 particles; ParameterBeam; 16 beams of 1e4 particles in one ParticleBeam); an orbit "
                            "response of 25 cells, each corrector angle a (64,) tensor (ParameterBeam; one 1e4-particle beam shared by the rows); the "
-                           "cavity linac at 64 beam energies, with the phase of every cavity a (64,) tensor, and with two cavities switched off"}
+                           "cavity linac at 64 beam energies, with the phase of every cavity a (64,) tensor, and with two cavities switched off. "
+                           "Every entry's outgoing beam (sigma_x, sigma_y, energy, surviving weight, last monitor reading) is compared with the "
+                           "REFERENCE's float64 run of the same seeded data (tests/golden/bench_diagnostics.json) before its time is reported"}
         with torch.no_grad():
-            for name, els in (("bpm_lattice", bpm_cells), ("aperture_lattice", ap_cells), ("cavity_linac", linac)):
-                seg = ca.Segment(els)
+            for name, specs in (("bpm_lattice", di.bpm_lattice()), ("aperture_lattice", di.aperture_lattice()), ("cavity_linac", di.cavity_linac())):
+                seg = di.segment(ca, specs, kw)
+                check(name, "particle_beam", seg, seg.track(beam))
                 res[name] = {"particle_beam_us": timed_us(lambda: seg.track(beam)),
                              "sixteen_beams_us": timed_us(lambda: seg.track(many))}
                 if name != "aperture_lattice":      # (an aperture only warns for a ParameterBeam)
+                    check(name, "parameter_beam", seg, seg.track(pbeam))
                     res[name]["parameter_beam_us"] = timed_us(lambda: seg.track(pbeam))
             # an orbit response: every corrector's angle a (64,) tensor, 25 monitors; all 64 settings in one stretch call, for a
             # ParameterBeam and for ONE ParticleBeam of 1e4 particles shared by the settings
-            scan = []
-            torch.manual_seed(77)
-            for i in range(25):
-                scan += [ca.Quadrupole(tt(0.2), k1=tt(4.2 if i % 2 == 0 else -4.2), **kw),
-                         ca.HorizontalCorrector(tt(0.05), angle=1e-5 * torch.randn(64, **kw), **kw), ca.Drift(tt(0.8), **kw),
-                         ca.BPM(is_active=True, **kw)]
-            seg = ca.Segment(scan)
-            small = ca.ParticleBeam(beam.particles[:10_000].contiguous(), beam.energy, **kw)
+            seg = di.segment(ca, di.orbit_response(), kw)
+            check("orbit_response_64_settings", "parameter_beam", seg, seg.track(pbeam), rows=(0, 63))
+            check("orbit_response_64_settings", "particle_beam_1e4", seg, seg.track(small), rows=(0, 63))
             res["orbit_response_64_settings"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
                                                  "particle_beam_1e4_us": timed_us(lambda: seg.track(small))}
             # the 16-cell cavity linac under scans and with cavities switched off: 64 beam energies; the phase of every cavity a
             # (64,) tensor; two cavities at voltage 0 (skippable, drift-like) — each one stretch call
-            def cav_linac(phase_of, off=()):
-                out = []
-                for i in range(16):
-                    out += [ca.Drift(tt(0.3), **kw), ca.Quadrupole(tt(0.2), k1=tt(3.0 if i % 2 else -3.0), **kw),
-                            ca.Cavity(tt(1.0377), voltage=tt(0.0 if i in off else 18e6), phase=phase_of(i), frequency=tt(1.3e9), **kw)]
-                return ca.Segment(out)
-
-            energies = torch.linspace(8e7, 1.2e8, 64, **kw)
-            e_pb = ca.ParameterBeam.from_parameters(energy=energies, **kw)
+            energies = tt(di.energies())
+            e_pb = ca.ParameterBeam(mu.to(**kw), cov.to(**kw), energies, **kw)
             e_beam = ca.ParticleBeam(small.particles, energies, **kw)
-            seg = cav_linac(lambda i: tt(-10.0))
+            seg = di.segment(ca, di.cavity_linac(), kw)
+            check("linac_64_energies", "parameter_beam", seg, seg.track(e_pb), rows=(0, 63))
+            check("linac_64_energies", "particle_beam_1e4", seg, seg.track(e_beam), rows=(0, 63))
             res["linac_64_energies"] = {"parameter_beam_us": timed_us(lambda: seg.track(e_pb)),
                                         "particle_beam_1e4_us": timed_us(lambda: seg.track(e_beam))}
-            seg = cav_linac(lambda i: torch.linspace(-30.0, 30.0, 64, **kw))
+            seg = di.segment(ca, di.cavity_linac(phase=di.phases()), kw)
+            check("linac_64_phases_of_every_cavity", "parameter_beam", seg, seg.track(pbeam), rows=(0, 63))
+            check("linac_64_phases_of_every_cavity", "particle_beam_1e4", seg, seg.track(small), rows=(0, 63))
             res["linac_64_phases_of_every_cavity"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
                                                       "particle_beam_1e4_us": timed_us(lambda: seg.track(small))}
-            seg = cav_linac(lambda i: tt(-10.0), off=(5, 9))
+            seg = di.segment(ca, di.cavity_linac(off=(5, 9)), kw)
+            check("linac_two_cavities_off", "parameter_beam", seg, seg.track(pbeam))
+            check("linac_two_cavities_off", "particle_beam", seg, seg.track(beam))
             res["linac_two_cavities_off"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
                                              "particle_beam_us": timed_us(lambda: seg.track(beam))}
+        res["checked_against_reference"] = checks
         return res
 
     for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order),
                      ("DIAGNOSTICS_LATTICES", diagnostics)):
-        guarded(name, fn)
+        if only is None or name in only:
+            guarded(name, fn)
     return out
 
 
