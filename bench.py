@@ -648,10 +648,19 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
         dist.barrier()
         torch.cuda.empty_cache()
 
+    def strong_fused():
+        out = seg.track_elementwise(beam, fused=True)      # the same maps, the same bits: every particle through the 100 maps in registers
+        sharding.global_moments(out)
+
     def leg_strong():
         d = timed(torch, dist, strong, steps, warmup, world)
         res = {"scaling": "strong", "particles_total": N_PARTICLES, "particles_per_rank": hi - lo, "ms_per_step": d / steps * 1e3,
                "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / d}
+        # beside the 100 launches: ONE launch that keeps the particles in registers across the elements (chx_track_fused,
+        # bit-identical results) — what a strong-scaling user would run once a rank's share is launch-bound (below ~5e5
+        # particles a launch costs its ~3.7 us floor whatever it moves: benchmarks/strong_leg_trace.py)
+        df = timed(torch, dist, strong_fused, steps, warmup, world)
+        res["fused_in_register"] = {"ms_per_step": df / steps * 1e3, "particle_element_steps_per_s": N_PARTICLES * len(seg.elements) * steps / df}
         # (replaying the 100 apply launches from ONE device graph was measured and is not used: a replayed kernel node costs ~9 us
         # of scheduling on ROCm 7.2 against ~2.5 us for a launch issued from the C loop — 1.86 vs 1.03 ms at 1e6 particles, and
         # slower at the 1.25e5 particles a rank of an 8-GPU strong run holds as well: benchmarks/strong_leg_probe.py)
@@ -937,6 +946,19 @@ def main():
             except Exception as exc:   # the headline stands on its own
                 result["scaling_legs"] = {"n_gpus": world, "error": f"{type(exc).__name__}: {exc}"}
     result["collectives_forced_in_headline"] = bool(world == 1 and args.force_collectives)
+    # who ran: the process group as torch.distributed sees it and the device every rank computed on (for the driver to check that
+    # RCCL saw N ranks on N distinct GPUs)
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": torch.cuda.current_device(),
+          "device_name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    result["distributed"] = {"initialized": bool(dist.is_available() and dist.is_initialized()),
+                             "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                             "backend": dist.get_backend() if dist.is_initialized() else None,
+                             "distinct_devices": len({(r["device_index"], r["pci_bus_id"], r["uuid"]) for r in ranks}), "ranks": ranks}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(E)
     if rank == 0:

@@ -14,6 +14,7 @@
 //    scalar cache (s_load), only tiles straddling a batch boundary fall back to per-lane loads;
 //  * fp32 rows are evaluated as an fmaf chain in the order j=0..6 (same sequence in the single
 //    pass, element-wise and fused kernels, so those agree bit for bit).
+#include <cstdlib>
 #include <type_traits>
 
 #include "chx_common.h"
@@ -416,6 +417,16 @@ int launch_tiles(const void* x_in, const void* R, void* x_out, const double* coe
                                   ((N * 7 * (int64_t)sizeof(T)) % 16 == 0 || B == 1);
         if (rows_aligned) return launch_wave<T, 1, 64>(x_in, R, x_out, B, Bx, BR, N, s);
         if (PPT > 1) return launch_tiles_ppt<T, 1, MODE>(x_in, R, x_out, coeffs, B, Bx, BR, N, E, s);
+    }
+    if (MODE == 0 && B * N * 7 * (int64_t)sizeof(T) <= (int64_t)14 * 1024 * 1024 + 700 * 1024) {
+        // a small beam (what a rank of a strong-scaling run holds: 1.25e5 - 5e5 particles): a few hundred workgroup tiles leave
+        // most CUs with one dependent load -> barrier -> store chain; four independent waves per workgroup, each staging its own
+        // 64 rows, overlap them. Measured, 100 launches back to back (benchmarks/strong_leg_trace.py): 3e5 particles 0.459 ->
+        // 0.411 ms, 4e5 0.619 -> 0.520; from 6e5 on the workgroup tiles win (0.668 vs 0.690; 1e6: 0.899 vs 1.092). Below ~1.5e5
+        // the step sits on the launch floor either way (3.7 - 3.8 us per launch)
+        const bool rows_aligned = chx_aligned16(x_in) && chx_aligned16(x_out) &&
+                                  ((N * 7 * (int64_t)sizeof(T)) % 16 == 0 || B == 1);
+        if (rows_aligned) return launch_wave<T, 1, 256>(x_in, R, x_out, B, Bx, BR, N, s);
     }
     // fused run: VALU-bound; 4 rows per lane amortise each map's scalar loads over 4 x 49 FMAs
     if (MODE == 1 && E >= 4 && N >= 4 * CHX_BLOCK * 64)

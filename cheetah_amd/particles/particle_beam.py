@@ -16,6 +16,7 @@ import torch
 
 from .. import _ops
 from .._cache import TensorKey
+from ..sharding import _ACTIVE_GROUP as _SHARDING_STACK       # non-empty inside `sharding.particle_sharded(...)`
 from .beam import Beam
 from .species import Species
 
@@ -289,11 +290,39 @@ class ParticleBeam(Beam):
     # ------------------------------------------------------------------ moments (HIP, cached)
     def _moments(self) -> torch.Tensor:
         p, w = self.particles, self.survival_probabilities
+        if _SHARDING_STACK:
+            from .. import sharding
+
+            group = sharding.active_group()
+            if group is not None:
+                return self._global_moments(group)
         cached = self.__dict__.get("_moment_cache")
         if cached is not None and cached[0].matches((p, w)) and not p.requires_grad and not w.requires_grad:
             return cached[1]
         out = _ops.moments(p, w)
         self.__dict__["_moment_cache"] = (TensorKey((p, w)), out)
+        return out
+
+    def _global_moments(self, group) -> torch.Tensor:
+        """The moments of ALL shards of a particle-sharded beam (inside `sharding.particle_sharded`): this rank's one-pass reduction,
+        ONE all-gather of 29 doubles per rank and batch row, the exact merge (`chx_merge_moments`; utils/statistics.py:4-62 over the
+        union of the shards) — once per version of the beam's tensors, whatever number of properties is read
+        (particle_beam.py:1699-1943: `sigma_x`, `mu_*`, `cov_*`, emittances, Twiss). A COLLECTIVE: every rank of the group must
+        read a property of its shard at the same point of the program. Gradients do not cross the exchange."""
+        from .. import sharding
+
+        p, w = self.particles, self.survival_probabilities
+        if torch.is_grad_enabled() and (p.requires_grad or w.requires_grad):
+            raise NotImplementedError("beam properties of a particle-sharded beam are global statistics exchanged between the ranks: "
+                                      "they carry no autograd graph (read them under torch.no_grad(), or differentiate per shard "
+                                      "outside sharding.particle_sharded)")
+        cached = self.__dict__.get("_global_moment_cache")
+        if cached is not None and cached[0].matches((p, w)) and cached[1] is group:
+            return cached[2]
+        with torch.no_grad():
+            local = _ops.moments(p, w)
+            out = sharding.gather_merge_moments(local.reshape(-1, _ops.MOM_NOUT), group).reshape(local.shape)
+        self.__dict__["_global_moment_cache"] = (TensorKey((p, w)), group, out)
         return out
 
     def as_parameter_beam(self):
@@ -318,6 +347,8 @@ class ParticleBeam(Beam):
         (`_MomentEntry`) instead of select -> sqrt -> to, whose three backward nodes cost more host time than the moment
         kernels themselves in an optimisation loop."""
         p = self.particles
+        if _SHARDING_STACK and p.requires_grad:
+            self._moments()                 # (raises inside sharding.particle_sharded: global statistics carry no graph)
         if p.requires_grad and getattr(p, "_chx_lin", None) is not None:
             # a linearly tracked beam whose only differentiable input is the map: one node, algebraic backward
             v = _ops.moment_entry(p, self.survival_probabilities, index, take_sqrt)
@@ -340,7 +371,14 @@ class ParticleBeam(Beam):
 
     @property
     def total_charge(self) -> torch.Tensor:
-        return (self.particle_charges * self.survival_probabilities).sum(dim=-1)
+        q = (self.particle_charges * self.survival_probabilities).sum(dim=-1)
+        if _SHARDING_STACK:
+            from .. import sharding
+
+            group = sharding.active_group()
+            if group is not None:           # the charge of ALL shards (a collective, like the moment properties)
+                q = sharding.allreduce_grid(q.detach().clone().reshape(-1), group).reshape(q.shape)
+        return q
 
     @property
     def num_particles(self) -> int:
@@ -351,7 +389,14 @@ class ParticleBeam(Beam):
 
     @property
     def num_particles_survived(self) -> torch.Tensor:
-        return self.survival_probabilities.sum(dim=-1)
+        n = self.survival_probabilities.sum(dim=-1)
+        if _SHARDING_STACK:
+            from .. import sharding
+
+            group = sharding.active_group()
+            if group is not None:           # over ALL shards
+                n = sharding.allreduce_grid(n.detach().clone().reshape(-1), group).reshape(n.shape)
+        return n
 
     # reference frame (beam.py:323-341)
     @property

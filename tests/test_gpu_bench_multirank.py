@@ -36,3 +36,33 @@ def test_two_rank_bench_line_on_one_device():
     assert legs["c2_strong"]["particles_total"] == 1_000_000 and legs["c4_particle_shard"]["particles_total"] == 1_000_000
     # the global sigma_x of the sharded headline beam equals the single-rank one (exact merge of the ranks' moments)
     assert out["config"]["sigma_x_out"] == pytest.approx(1.9558527e-4, rel=2e-3)
+
+
+def test_eight_rank_bench_line_on_one_device():
+    """The driver's scaling run is --gpus 8: the same contract with EIGHT ranks (all on cuda:0, exchanges over gloo): one line
+    from rank 0, the whole-job aggregate, the 4096 settings of C3 split 8 x 512, the particles of C2 / C4 split 8 x 1.25e5, the
+    global sigma_x from the merge of eight ranks' moments, and the `distributed` block naming every rank's device."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--one-device-gloo"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "particle-shard x8" and out["config"]["particles_per_gpu"] == 1_000_000
+    assert out["value"] == pytest.approx(8 * 1e6 * 100 / (out["ms_per_step"] * 1e-3), rel=1e-6)
+    assert out["config"]["sigma_x_out"] == pytest.approx(1.9558527e-4, rel=2e-3) and out["config"]["sigma_x_checked"] is True
+    legs = out["scaling_legs"]
+    assert legs["n_gpus"] == 8
+    assert legs["c3_batch_shard"]["settings_per_rank"] == 512 and legs["c3_batch_shard"]["collectives"] == "none"
+    assert legs["c2_strong"]["particles_per_rank"] == 125_000 and legs["c2_strong"]["fused_in_register"]["ms_per_step"] > 0
+    assert legs["c4_particle_shard"]["particles_total"] == 1_000_000
+    d = out["distributed"]
+    assert d["initialized"] is True and d["world_size"] == 8 and d["backend"] == "gloo"
+    assert [r["rank"] for r in d["ranks"]] == list(range(8)) and d["distinct_devices"] == 1       # (one device: this box has one GPU)

@@ -120,6 +120,21 @@ def _worker(port, queue):
             summed = screen.reading.clone()
         # (the image itself is an LDS-atomic sum: its last bit can differ between two runs of the same deposit)
         report["screen"] = {"equal": bool(torch.allclose(plain, summed, rtol=1e-5, atol=0)), "all_reduce": calls["all_reduce"] - before}
+        # beam properties of a particle-sharded beam (particle_beam.py:1699-1943): ONE all_gather_into_tensor -> chx_merge_moments
+        # per version of the beam, whatever number of properties is read; total_charge / num_particles_survived: one all-reduce each
+        pbeam = _beam(ca, torch.float32, 120_000)
+        names = ("sigma_x", "sigma_y", "sigma_p", "mu_x", "cov_xpx", "emittance_x", "beta_x", "total_charge", "num_particles_survived")
+        with torch.no_grad():
+            local_vals = {n: float(getattr(pbeam, n)) for n in names}
+            before = dict(calls)
+            with sharding.particle_sharded(force_collectives=True):
+                global_vals = {n: float(getattr(pbeam, n)) for n in names}
+                used_props = {k: calls[k] - before[k] for k in calls}
+                pbeam.particles[:, 0] *= 2.0
+                doubled = float(pbeam.sigma_x)
+                used_after_edit = {k: calls[k] - before[k] for k in calls}
+        report["beam_properties"] = {"local": local_vals, "global": global_vals, "used": used_props, "used_after_edit": used_after_edit,
+                                     "doubled": doubled}
         # batch shard of a vectorised scan (no collective): the union of the per-"rank" slices equals the whole scan
         k1 = torch.linspace(-30, 30, 64, **kw)
         t = lambda v: torch.tensor(v, **kw)  # noqa: E731
@@ -172,3 +187,10 @@ def test_rccl_exchanges_on_one_rank():
         assert r["forced_vs_whole"] < (2e-4 if name.startswith("f32") else 1e-9), (name, r)
     assert report["screen"] == {"equal": True, "all_reduce": 1}
     assert report["batch_shard_equal"]
+
+    # a one-rank union is the rank's own beam: the merged properties equal the local ones; one all-gather served all moment properties
+    bp = report["beam_properties"]
+    for n, v in bp["local"].items():
+        assert bp["global"][n] == pytest.approx(v, rel=1e-12), n
+    assert bp["used"] == {"all_gather": 1, "all_reduce": 2}, bp
+    assert bp["used_after_edit"] == {"all_gather": 2, "all_reduce": 2} and bp["doubled"] == pytest.approx(2.0 * bp["local"]["sigma_x"], rel=1e-5)

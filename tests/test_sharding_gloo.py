@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -240,3 +241,151 @@ def test_chain_and_staged_ranks_exchange_compatible_moment_rows(oracle):
             assert abs(rows[0, 2 + col] - ref[2 + col]) <= 1e-12 * np.sqrt(ref[8 + diag])
             assert rows[0, 8 + diag] == __import__("pytest").approx(ref[8 + diag], rel=1e-11)
     assert np.array_equal(got[0][0], got[1][0])            # bit-identical on both ranks: the same grid geometry everywhere
+
+
+def _worker_beam_properties(rank, world, port, x, w, qc, q):
+    """A particle-sharded ParticleBeam's properties through the PRODUCT's classes. The local reduction is libchx's on the GPU box;
+    here (no GPU) `_ops.moments` is replaced by the oracle's, everything behind it — the cache, the exchange, the merge, the
+    property algebra — is the product's."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cheetah_amd as ca
+    from cheetah_amd import _ops, sharding
+    from oracle import chx_oracle
+
+    calls = {"n": 0}
+
+    def oracle_moments(particles, survival):
+        calls["n"] += 1
+        raw = chx_oracle.moments(particles.numpy()[None].astype(np.float64), survival.numpy()[None].astype(np.float64))["raw"]
+        return torch.from_numpy(raw).reshape(29)
+
+    _ops.moments = oracle_moments
+    lo, hi = sharding.shard_range(x.shape[0], rank, world)
+    beam = ca.ParticleBeam(torch.from_numpy(x[lo:hi]), torch.tensor(1e8, dtype=torch.float64), particle_charges=torch.from_numpy(qc[lo:hi]),
+                           survival_probabilities=torch.from_numpy(w[lo:hi]), dtype=torch.float64)
+    gathers = {"n": 0}
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (gathers.__setitem__("n", gathers["n"] + 1), real(*a, **k))[1]
+    with torch.no_grad(), sharding.particle_sharded():
+        names = ("sigma_x", "sigma_px", "sigma_y", "sigma_p", "mu_x", "mu_y", "mu_tau", "cov_xpx", "cov_taup", "emittance_x", "beta_y", "alpha_x",
+                 "total_charge", "num_particles_survived")
+        got = {n: float(getattr(beam, n)) for n in names}
+        assert calls["n"] == 1 and gathers["n"] == 1, (calls, gathers)          # ONE local reduction and ONE exchange for all of them
+        beam.particles[:, 0] *= 2.0                                               # a new version of the beam: reduced and exchanged again
+        got["sigma_x_doubled"] = float(beam.sigma_x)
+        assert calls["n"] == 2 and gathers["n"] == 2
+    local_sigma = float(beam.sigma_x)                                            # outside the context: this shard's own statistics
+    assert calls["n"] == 3 and gathers["n"] == 2
+    x_req = ca.ParticleBeam(torch.from_numpy(x[lo:hi]).requires_grad_(True), torch.tensor(1e8, dtype=torch.float64), dtype=torch.float64)
+    refused = False
+    with sharding.particle_sharded():
+        try:
+            x_req.sigma_x
+        except NotImplementedError:
+            refused = True
+    dist.all_gather = real
+    q.put((rank, got, local_sigma, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, target, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda t: t[0])
+
+
+def test_sharded_beam_properties_are_global_two_ranks_gloo(oracle):
+    """particle_beam.py:1699-1943 on a particle-sharded beam: inside `sharding.particle_sharded` every rank reads the statistics of
+    the UNION of the shards (the reference's weighted statistics, utils/statistics.py:4-62, over all particles) from one cached
+    exchange; outside the context a shard's own."""
+    rng = np.random.default_rng(21)
+    N = 15_001
+    x = rng.standard_normal((N, 7)) * [3e-4, 2e-5, 2e-4, 1e-5, 1e-4, 2e-3, 0] + [1e-4, 0, -2e-4, 0, 1e-5, 0, 1]
+    x[:, 1] += 0.05 * x[:, 0]                                        # x-px and x-p correlations: the optics functions are not trivial
+    x[:, 0] += 0.02 * x[:, 5]
+    x[:9000, 0] += 2e-4                                              # the shards have different means: the merge term matters
+    w = rng.random(N)
+    qc = rng.random(N) * 1e-15
+    res = _run(2, _worker_beam_properties, (x, w, qc))
+    mom = oracle.moments(x[None], w[None])
+    import cheetah_amd as ca
+
+    union = ca.ParameterBeam._from_moment_vector(torch.from_numpy(mom["raw"]).reshape(29), torch.float64, torch.tensor(1e8, dtype=torch.float64))
+    x2 = x.copy()
+    x2[:, 0] *= 2.0
+    sig2 = float(np.sqrt(oracle.moments(x2[None], w[None])["cov"][0, 0, 0]))
+    for rank, got, local_sigma, refused in res:
+        for name, v in got.items():
+            if name == "total_charge":
+                want = float((qc * w).sum())
+            elif name == "num_particles_survived":
+                want = float(w.sum())
+            elif name == "sigma_x_doubled":
+                want = sig2
+            else:
+                want = float(getattr(union, name))
+            assert v == pytest.approx(want, rel=1e-9, abs=1e-30), (rank, name, v, want)
+        lo, hi = (0, 7501) if rank == 0 else (7501, N)
+        own = x[lo:hi].copy()
+        own[:, 0] *= 2.0
+        assert local_sigma == pytest.approx(float(np.sqrt(oracle.moments(own[None], w[None, lo:hi])["cov"][0, 0, 0])), rel=1e-10)
+        assert refused
+
+
+def _worker_uneven(rank, world, port, x, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cheetah_amd import sharding
+    from oracle import chx_oracle
+
+    out = []
+    for n_total in (x.shape[0], 5, 8, 11):                # 5 < world: three EMPTY shards; 11: shards of 2 and 1
+        lo, hi = sharding.shard_range(n_total, rank, world)
+        if hi > lo:
+            local = np.nan_to_num(chx_oracle.moments(x[None, lo:hi], w[None, lo:hi])["raw"], nan=0.0, posinf=0.0, neginf=0.0)
+        else:
+            local = np.zeros((1, 29))                     # a rank without particles: no weight, contributes nothing
+        merged = sharding.gather_merge_moments(torch.from_numpy(local))
+        grid = torch.full((2, 3), float(hi - lo), dtype=torch.float64)
+        sharding.allreduce_grid(grid)
+        out.append((merged.numpy(), float(grid[0, 0]), (lo, hi)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_and_empty_shards_gloo(oracle):
+    """World 8 (the driver's scaling run): `shard_range` + all-gather + exact merge with shards of unequal size, shards of ONE
+    particle and EMPTY shards (fewer particles than ranks) — every rank ends with the moments of the union."""
+    rng = np.random.default_rng(8)
+    N, world = 1003, 8
+    x = rng.standard_normal((N, 7)) * [1e-3, 1e-5, 2e-3, 1e-5, 1e-4, 1e-3, 0] + [5e-3, 0, -1e-3, 0, 0, 2e-2, 1]
+    w = 0.25 + rng.random(N)
+    res = _run(world, _worker_uneven, (x, w))
+    for k, n_total in enumerate((N, 5, 8, 11)):
+        ref = oracle.moments(x[None, :n_total], w[None, :n_total])["raw"]
+        cuts = [r[1][k][2] for r in res]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n_total and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        if n_total == 5:
+            assert sum(1 for lo, hi in cuts if hi == lo) == 3
+        sig = np.sqrt(ref[0, [8, 14, 19, 23, 26, 28]])
+        for rank, per_case in res:
+            merged, count, _ = per_case[k]
+            assert count == float(n_total), (rank, n_total, count)
+            assert np.allclose(merged[0, :2], ref[0, :2], rtol=1e-13)
+            assert np.all(np.abs(merged[0, 2:8] - ref[0, 2:8]) <= 1e-12 * (sig + np.abs(ref[0, 2:8]))), (rank, n_total)
+            j = 8
+            for a in range(6):
+                for b in range(a, 6):
+                    assert abs(merged[0, j] - ref[0, j]) <= 1e-10 * sig[a] * sig[b], (rank, n_total, a, b)
+                    j += 1
