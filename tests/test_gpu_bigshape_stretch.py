@@ -135,7 +135,9 @@ def _row_specs(specs, b, rows):
 
 @pytest.mark.parametrize("dt,lattice,rows,n,check_rows", [
     (torch.float32, 3, 64, 70_001, (0, 3, 17, 63)), (torch.float32, 5, 64, 70_001, (1, 40)), (torch.float64, 5, 64, 70_001, (2, 63)),
-    (torch.float32, 1, 64, 70_001, (0, 33)), (torch.float32, 4, 4096, 100_000, (0, 3, 2047, 4095))])
+    (torch.float32, 1, 64, 70_001, (0, 33)), (torch.float32, 4, 4096, 100_000, (0, 3, 2047, 4095)),
+    # seven monitors, thousands of rows: the lanes keep their own sums over the tiles of a row (`lattice_apply_kernel<T, 2, 0, 1>`)
+    (torch.float32, 0, 4096, 100_000, (0, 1, 2047, 4095)), (torch.float64, 0, 1024, 50_003, (2, 1023))])
 def test_big_scans_vs_reference_and_oracle(dt, lattice, rows, n, check_rows, oracle):
     import cheetah_amd as ca
     from cheetah_amd.accelerator import segment
