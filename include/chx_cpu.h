@@ -12,6 +12,10 @@
  *   chx_apply_affine7_cpu   chx_apply_affine7   element.py:180-191 (the kernels' fma chain: bit-identical results)
  *   chx_moments_cpu         chx_moments         particle_beam.py:1699-1717, utils/statistics.py:4-48
  *   chx_cic_deposit_cpu     chx_cic_deposit     utils/cloud_in_cell.py:8-451 (row-major grids only)
+ *   chx_track_elementwise_cpu chx_track_elementwise segment.py:571-572 (`for e in elements: beam = e.track(beam)`: E fma-chain passes)
+ *   chx_cavity_coeffs_cpu   chx_cavity_coeffs   cavity.py:113-122,135-226 (coefficient rows + outgoing energy)
+ *   chx_cavity_track_cpu    chx_cavity_track    cavity.py:112,135-151,220-226 (x @ R.mT, then the per-particle delta / tau update)
+ *   chx_hist2d_cpu          chx_hist2d          screen.py:292-311 (torch.histogramdd on explicit edges, weight |q| * survival)
  */
 #ifndef CHX_CPU_H
 #define CHX_CPU_H
@@ -29,6 +33,16 @@ int chx_apply_affine7_cpu(const void* x_in, const void* R, void* x_out, int64_t 
 int chx_moments_cpu(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, double* out,
                     void* workspace, size_t workspace_bytes, void* stream);
 int chx_cic_deposit_cpu(const chx_cic_args* args, void* stream);
+int chx_track_elementwise_cpu(const void* x_in, const void* R /*[E][BR][7][7]*/, void* x_out,
+                              void* scratch, int64_t E, int64_t B, int64_t Bx, int64_t BR,
+                              int64_t N, int dtype, void* stream);
+int chx_cavity_coeffs_cpu(const void* params /*[Bp][4]*/, const void* energy /*[Be]*/, double mass_eV,
+                          double n_charges, int64_t B, int64_t Bp, int64_t Be, int dtype,
+                          double* coeffs /*[B][CHX_CAV_NCOEF]*/, void* energy_out /*[B] dtype*/,
+                          void* stream);
+int chx_cavity_track_cpu(const void* x_in, const void* R, const double* coeffs, void* x_out,
+                         int64_t B, int64_t Bx, int64_t N, int dtype, void* stream);
+int chx_hist2d_cpu(const chx_hist2d_args* args, void* stream);
 #ifdef __cplusplus
 }
 #endif

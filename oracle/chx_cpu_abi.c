@@ -90,3 +90,63 @@ CPU_API int chx_cic_deposit_cpu(const chx_cic_args* p, void* stream) {
     a.x = p->x; a.charge = p->charge; a.survival = p->survival; a.extent = p->extent; a.scale = p->scale; a.shift = p->shift;
     return chxo_cic_deposit(&a, p->grid) == 0 ? CHX_OK : CHX_ERR_INVALID_ARG;
 }
+
+/* chx_track_elementwise: E passes of the fma chain, pass 0 from x_in, the others on x_out (a row is loaded whole before it is
+ * stored, like the device's tile-local read-then-write) */
+CPU_API int chx_track_elementwise_cpu(const void* x_in, const void* R, void* x_out, void* scratch, int64_t E, int64_t B, int64_t Bx,
+                                      int64_t BR, int64_t N, int dtype, void* stream) {
+    (void)scratch; (void)stream;
+    if (!x_in || !R || !x_out || E < 1 || B < 1 || N < 1 || !bcast_ok(Bx, B) || !bcast_ok(BR, B) || x_in == x_out) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    void* tmp = malloc((size_t)B * (size_t)N * 7 * esz);
+    if (!tmp) return CHX_ERR_WORKSPACE;
+    const void* src = x_in;
+    int64_t src_B = Bx;
+    for (int64_t e = 0; e < E; ++e) {
+        void* dst = (((E - 1 - e) & 1) == 0) ? x_out : tmp;          /* ping-pong so that the last pass lands in x_out */
+        if (chxo_apply(src, (const char*)R + (size_t)e * (size_t)BR * 49 * esz, dst, B, src_B, BR, N, dtype, 1) != 0) { free(tmp); return CHX_ERR_INVALID_ARG; }
+        src = dst;
+        src_B = B;
+    }
+    free(tmp);
+    return CHX_OK;
+}
+
+CPU_API int chx_cavity_coeffs_cpu(const void* params, const void* energy, double mass_eV, double n_charges, int64_t B, int64_t Bp,
+                                  int64_t Be, int dtype, double* coeffs, void* energy_out, void* stream) {
+    (void)stream;
+    if (!params || !energy || !coeffs || !energy_out || B < 1 || !bcast_ok(Bp, B) || !bcast_ok(Be, B)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    double* p = (double*)malloc(sizeof(double) * (size_t)Bp * 4);
+    double* e = (double*)malloc(sizeof(double) * (size_t)Be);
+    double* eo = (double*)malloc(sizeof(double) * (size_t)B);
+    if (!p || !e || !eo) { free(p); free(e); free(eo); return CHX_ERR_WORKSPACE; }
+    for (int64_t i = 0; i < Bp * 4; ++i) p[i] = ld(params, dtype, i);
+    for (int64_t i = 0; i < Be; ++i) e[i] = ld(energy, dtype, i);
+    const int rc = chxo_cavity_coeffs(p, e, mass_eV, n_charges, B, Bp, Be, coeffs, eo);
+    if (rc == 0)
+        for (int64_t i = 0; i < B; ++i) st(energy_out, dtype, i, eo[i]);
+    free(p); free(e); free(eo);
+    return rc == 0 ? CHX_OK : CHX_ERR_INVALID_ARG;
+}
+
+CPU_API int chx_cavity_track_cpu(const void* x_in, const void* R, const double* coeffs, void* x_out, int64_t B, int64_t Bx, int64_t N,
+                                 int dtype, void* stream) {
+    (void)stream;
+    if (!x_in || !R || !coeffs || !x_out || B < 1 || N < 1 || !bcast_ok(Bx, B)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    return chxo_cavity_track(x_in, R, coeffs, x_out, B, Bx, N, dtype) == 0 ? CHX_OK : CHX_ERR_INVALID_ARG;
+}
+
+/* chx_hist2d: image[b][jy][jx] += |q| * survival of the particles inside the edges (the caller zeroes the image) */
+CPU_API int chx_hist2d_cpu(const chx_hist2d_args* p, void* stream) {
+    (void)stream;
+    if (!p || !p->x || !p->edges_x || !p->edges_y || !p->image || p->B < 1 || p->N < 1 || p->nx < 1 || p->ny < 1) return CHX_ERR_INVALID_ARG;
+    if (p->dtype != CHX_F32 && p->dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!bcast_ok(p->Bx, p->B) || (p->charge && !bcast_ok(p->Bq, p->B)) || (p->survival && !bcast_ok(p->Bs, p->B)) ||
+        (p->shift && !bcast_ok(p->Bsh, p->B)))
+        return CHX_ERR_INVALID_ARG;
+    return chxo_hist2d(p->x, p->charge, p->survival, p->shift, p->edges_x, p->edges_y, p->B, p->Bx, p->Bq, p->Bs, p->Bsh, p->N, p->nx,
+                       p->ny, p->dtype, p->image, NULL) == 0 ? CHX_OK : CHX_ERR_INVALID_ARG;
+}

@@ -32,7 +32,8 @@ def test_every_twin_is_exported_with_the_signature_of_its_namesake():
     lib = _lib()
     twins, abi = _decls("chx_cpu.h"), _decls("chx.h")
     assert set(twins) == {"chx_abi_version_cpu", "chx_build_rmatrix_cpu", "chx_compose_maps_cpu", "chx_apply_affine7_cpu",
-                          "chx_moments_cpu", "chx_cic_deposit_cpu"}
+                          "chx_moments_cpu", "chx_cic_deposit_cpu", "chx_track_elementwise_cpu", "chx_cavity_coeffs_cpu",
+                          "chx_cavity_track_cpu", "chx_hist2d_cpu"}
     norm = lambda sig: re.sub(r"\s*/\*.*?\*/", "", sig).replace(" ,", ",")  # noqa: E731
     for name, sig in twins.items():
         assert hasattr(lib, name), name
@@ -95,3 +96,53 @@ def test_twins_give_the_oracles_numbers(oracle):
     # argument checking like the GPU library: negative status, no exception across the ABI
     assert lib.chx_apply_affine7_cpu(None, _ptr(out), _ptr(y), i64(2), i64(1), i64(2), i64(1000), 0, None) == -1
     assert lib.chx_moments_cpu(_ptr(y), None, i64(2), i64(2), i64(1), i64(1000), 7, _ptr(mom), None, ctypes.c_size_t(0), None) == -2
+
+
+def test_tracking_cavity_and_histogram_twins_give_the_oracles_numbers(oracle):
+    """chx_track_elementwise_cpu / chx_cavity_coeffs_cpu / chx_cavity_track_cpu / chx_hist2d_cpu (segment.py:571-572,
+    cavity.py:100-251, screen.py:292-311) through the argument lists of their chx.h namesakes."""
+    from cheetah_amd._lib import Hist2dArgs
+
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    for dtype, code in ((np.float32, 0), (np.float64, 1)):
+        # element by element, no merging: 7 maps on a beam shared by two rows of settings (Bx = 1, BR = B = 2)
+        E, B, N = 7, 2, 1500
+        maps = np.stack([np.stack([oracle.build_rmatrix("quadrupole", [0.2, 4.2 * (-1) ** e * (1 + b), 0, 0, 0], 1e8)[0] if e % 2 == 0
+                                   else oracle.build_rmatrix("drift", [0.5 + 0.1 * b], 1e8)[0] for b in range(B)]) for e in range(E)]).astype(dtype)
+        x = (rng.standard_normal((1, N, 7)) * [2e-4, 1e-5, 2e-4, 1e-5, 1e-4, 1e-3, 0]).astype(dtype)
+        x[..., 6] = 1
+        out = np.empty((B, N, 7), dtype=dtype)
+        assert lib.chx_track_elementwise_cpu(_ptr(x), _ptr(maps), _ptr(out), None, i64(E), i64(B), i64(1), i64(B), i64(N), code, None) == 0
+        for b in range(B):
+            assert np.array_equal(out[b], oracle.track_elementwise(x[0], maps[:, b]))
+        assert lib.chx_track_elementwise_cpu(_ptr(out), _ptr(maps), _ptr(out), None, i64(E), i64(B), i64(B), i64(B), i64(N), code, None) == -1
+        # a cavity: coefficient rows and outgoing energies for two phases, then the particle update
+        params = np.array([[1.0377, 18e6, -10.0, 1.3e9], [1.0377, 18e6, 170.0, 1.3e9]], dtype=dtype)
+        energy = np.array([6e7], dtype=dtype)
+        coeffs, e_out = np.empty((2, 8)), np.empty(2, dtype=dtype)
+        assert lib.chx_cavity_coeffs_cpu(_ptr(params), _ptr(energy), dbl(oracle.ELECTRON_MASS_EV), dbl(-1.0), i64(2), i64(2), i64(1), code,
+                                         _ptr(coeffs), _ptr(e_out), None) == 0
+        c_ref, e_ref = oracle.cavity_coeffs(params.astype(np.float64), energy.astype(np.float64))
+        assert np.array_equal(coeffs, c_ref) and np.array_equal(e_out, e_ref.astype(dtype))
+        assert e_out[0] > 7.7e7 and e_out[1] < 4.3e7                                    # one row gains, the other loses energy
+        R = oracle.build_rmatrix("cavity_sw", params.astype(np.float64), energy.astype(np.float64)).astype(dtype)
+        y = np.empty((2, N, 7), dtype=dtype)
+        assert lib.chx_cavity_track_cpu(_ptr(x), _ptr(R), _ptr(coeffs), _ptr(y), i64(2), i64(1), i64(N), code, None) == 0
+        assert np.array_equal(y, oracle.cavity_track(x, R, coeffs))
+        # the screen histogram through the struct of the ABI (misaligned screen, |q| * survival weights)
+        edges_x, edges_y = np.linspace(-6e-4, 6e-4, 25).astype(dtype), np.linspace(-5e-4, 5e-4, 17).astype(dtype)
+        q = (rng.standard_normal((1, N)) * 1e-15).astype(dtype)
+        w = rng.random((1, N)).astype(dtype)
+        shift = np.array([[5e-5, -2e-5]], dtype=dtype)
+        image = np.zeros((1, 16, 24), dtype=dtype)
+        a = Hist2dArgs()
+        a.B = a.Bx = a.Bq = a.Bs = a.Bsh = 1
+        a.N, a.nx, a.ny, a.dtype = N, 24, 16, code
+        a.x, a.charge, a.survival, a.shift = _ptr(x).value, _ptr(q).value, _ptr(w).value, _ptr(shift).value
+        a.edges_x, a.edges_y, a.image = _ptr(edges_x).value, _ptr(edges_y).value, _ptr(image).value
+        assert lib.chx_hist2d_cpu(ctypes.byref(a), None) == 0
+        ref, _ = oracle.hist2d(x, edges_x, edges_y, charge=q, survival=w, shift=shift)
+        assert np.array_equal(image, ref) and image.sum() > 0
+        a.dtype = 5
+        assert lib.chx_hist2d_cpu(ctypes.byref(a), None) == -2
