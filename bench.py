@@ -51,7 +51,7 @@ N_PARTICLES = 1_000_000
 N_CELLS = 25
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 APPLY_KERNEL = "apply_tile_kernel<float, 2, 0>"
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r04_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")
 COPY_CEILING_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of the 8 TB/s spec)
 #: sigma_x behind the 100 elements of the beam of rank 0 (torch.manual_seed(1234), from_parameters defaults, 1e6 particles, fp32):
 #: the same digits in every driver run since round 1 (BENCH_r01..r03). bench.py refuses to print a line when its step no longer
@@ -901,7 +901,7 @@ def main():
                        "copy_ceiling": COPY_CEILING_GBS, "particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n,
                        "avg_launch_ms": ms_big, "traffic": traffic_big,
                        "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch at this size (separate rocprofv3 --pmc passes, "
-                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r04_pmc_apply.md): 1.0002 x the "
+                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r05_pmc_apply.md): 1.0002 x the "
                                        "algorithmic bytes"})
         del big, seg10
         torch.cuda.empty_cache()

@@ -36,6 +36,7 @@ from .. import _lib, _ops
 from ..particles.parameter_beam import ParameterBeam
 from ..particles.particle_beam import ParticleBeam
 from ..particles.species import Species
+from . import _planner
 from .element import Element, tracking_call
 from .space_charge_kick import SpaceChargeKick
 
@@ -283,7 +284,7 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc", "screens", "allow_screens", "capsule_s")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc", "screens", "allow_screens", "capsule_s", "words")
 
     def __init__(self, items, dtype, device, allow_vector=False, allow_screens=False):
         self.items, self.dtype, self.device = items, dtype, device
@@ -293,6 +294,7 @@ class _LatticePlan:
         self.capsule_s = None
         self.code = _ops.dtype_code(dtype)
         self.table = self.state = self.capsule = None
+        self.words = None
         self.tensors = ()
         self.bpms = ()          # the active BPMs of the stretch, in reading-slot order
         self.apertures = ()     # its active apertures
@@ -496,6 +498,7 @@ class _LatticePlan:
         # host -> device without a synchronisation: page-locked staging buffer (torch's caching host allocator keeps it alive
         # until the copy has run), asynchronous copy on the current stream
         words = rows + elem_kind + elem_poff + ptrs
+        self.words = words
         staging = torch.empty(len(words), dtype=torch.int64, pin_memory=True)
         staging.copy_(torch.tensor(words, dtype=torch.int64))
         if self.table is None or self.table.numel() != len(words):
@@ -513,6 +516,16 @@ class _LatticePlan:
         self.tensors = tuple(tensors)       # kept alive: the table holds their addresses
         self.ok = True
 
+
+    def verify(self) -> None:
+        """CHX_CHECK_PLANS=1: the table re-derived from the elements as they are now must be the table on the device (a storage
+        swapped under an unchanged tensor object — `.data = ...`, `set_`, `resize_` — moves no counter the host looks at)."""
+        if self.expanded or torch.cuda.is_current_stream_capturing():
+            return                  # (expanded copies of broadcast settings live in the plan itself: a fresh plan has other addresses)
+        fresh = _LatticePlan(self.items, self.dtype, self.device, allow_vector=self.allow_vector, allow_screens=self.allow_screens)
+        if fresh.ok != self.ok or (fresh.ok and fresh.words != self.words):
+            raise RuntimeError("lattice stretch plan: the storage of a setting was replaced without an attribute assignment "
+                               "(`.data = ...`, `set_`, `resize_`); assign the tensor instead")
 
     def ensure_rows(self, rows: int) -> bool:
         """Room for `rows` rows of maps in the device state (a scan of beam energies brings its rows with the BEAM, not with the
@@ -1215,83 +1228,9 @@ class Segment(Element):
             return incoming
         if not isinstance(incoming, ParticleBeam):
             raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
-        plan = self._plan()
-        i, n_items = 0, len(plan)
-        chain = None    # state buffer of a running chain of tile-ordered SpaceChargeKicks: `incoming` is then in TILE order
-        while i < n_items:
-            kind, item = plan[i]
-            if kind == "element" and isinstance(item, SpaceChargeKick) and (chain is not None or self._chain_starts(plan, i, incoming)):
-                # [kick, linear run, kick, ...]: the particle rows are sorted by deposit tile once, every kick of the chain works
-                # on the ordered rows (chx_sc_kick_sorted) and the last one restores the caller's particle order. A link needs
-                # the run behind it to be applied INSIDE its own particle pass (persistent device plan, no gradients): only then
-                # are the sums the gather pass leaves for the next kick's grid the sums of the rows that kick sees, and only
-                # then does nothing on the way attach a graph to the beam. Any other run ends the chain at this kick.
-                first = chain is None
-                if first:
-                    chain = _ops.sc_tile_state(incoming.particles.shape[0], item.grid_shape, incoming.particles.dtype,
-                                               incoming.particles.device)
-                run = plan[i + 1][1] if i + 1 < n_items and plan[i + 1][0] == "run" else None
-                fused = self._chain_run_plan(run, incoming) if run is not None else None
-                last = self._next_chain_kick(plan, i, item, incoming.particles.dtype) is None or (run is not None and fused is None)
-                incoming, step = self._chain_kick(item, run, fused, incoming, chain, first, last)
-                if last:
-                    self._chain_report(plan, chain)
-                    chain = None
-                i += step
-                continue
-            if (kind == "run" or item._is_cavity or item._is_bpm or item._is_aperture or item._is_screen) and n_items - i >= 2:
-                done = self._lattice_stretch(plan, i, incoming)
-                if done is not None:
-                    incoming, i = done
-                    continue
-            if kind == "run" and i + 1 < n_items and plan[i + 1][0] == "element":
-                method = plan[i + 1][1]._tracking_method
-                done = None
-                if method == "second_order":
-                    done = self._second_order_run(plan, i, incoming)      # the run rides in the second-order elements' pass
-                elif method == "drift_kick_drift":
-                    done = self._dkd_run(plan, i, incoming)               # ... in the drift-kick-drift elements' pass
-                if done is not None:
-                    incoming, i = done
-                    continue
-            if kind == "run":
-                fast = self._run_apply_fast(item, incoming)
-                if fast is None:
-                    long_run = None
-                    if len(item.elements) >= self._PART_MIN_RUN and not (torch.is_grad_enabled() and incoming.particles.requires_grad):
-                        long_run = self._run_map_parts(item, incoming.particles, incoming.energy, incoming.species, incoming.s)
-                    if long_run is None:
-                        tm, s_out = self._run_map(item, incoming.energy, incoming.species), self._run_s(item, incoming.s)
-                    else:
-                        tm, s_out = long_run
-                    new_particles = _ops.apply_map(incoming.particles, tm)
-                else:
-                    new_particles, s_out = fast
-                incoming = ParticleBeam(new_particles, incoming.energy, particle_charges=incoming.particle_charges,
-                                        survival_probabilities=incoming.survival_probabilities, s=s_out, species=incoming.species)
-            else:
-                if item._tracking_method == "second_order":
-                    done = self._second_order_run(plan, i, incoming)      # like the drift-kick-drift run below
-                    if done is not None:
-                        incoming, i = done
-                        continue
-                if item._tracking_method == "drift_kick_drift":
-                    # a lattice tracked with the Bmad-X maps: consecutive elements go to the device in ONE call
-                    # (chx_dkd_chain; the per-element Python path costs ~25 us where the kernels take 12-29)
-                    done = self._dkd_run(plan, i, incoming)
-                    if done is not None:
-                        incoming, i = done
-                        continue
-                if i + 1 < n_items and plan[i + 1][0] == "run" and isinstance(item, SpaceChargeKick):
-                    # [SpaceChargeKick, run of linear elements]: the run's map is applied inside the kick's particle kernel
-                    fused = self._kick_then_run(item, plan[i + 1][1], incoming)
-                    if fused is not None:
-                        incoming = fused
-                        i += 2
-                        continue
-                incoming = item._track_internal(incoming)
-            i += 1
-        return incoming
+        # every plan item through the first path of the planner's table that takes it (accelerator/_planner.py: the space-charge
+        # chain, the stretch call, runs ahead of / made of non-linear elements, the merged run, kick + run, the element's own track)
+        return _planner.walk_particles(self, self._plan(), incoming)
 
     def _lattice_stretch(self, plan, i: int, incoming: ParticleBeam):
         """plan[i] and the items behind it as ONE `chx_lattice_track` call when they form a stretch [run | active Cavity]+ (at
@@ -1332,6 +1271,8 @@ class Segment(Element):
                 lp.refresh()
         if not lp.ok:
             return None
+        if _CHECK_PLANS:
+            lp.verify()
         grad_run = None
         if torch.is_grad_enabled() and (p.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
@@ -1547,6 +1488,8 @@ class Segment(Element):
                 lp.refresh()
         if not lp.ok or lp.apertures:                # (an aperture only warns for a ParameterBeam: the walk does that)
             return None
+        if _CHECK_PLANS:
+            lp.verify()
         if torch.is_grad_enabled() and (mu.requires_grad or cov.requires_grad or e.requires_grad or sp.mass_eV.requires_grad
                                         or sp.num_elementary_charges.requires_grad or _any_requires_grad(*lp.tensors)):
             return None
