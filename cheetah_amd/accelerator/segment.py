@@ -522,6 +522,9 @@ class _LatticePlan:
         swapped under an unchanged tensor object — `.data = ...`, `set_`, `resize_` — moves no counter the host looks at)."""
         if self.expanded or torch.cuda.is_current_stream_capturing():
             return                  # (expanded copies of broadcast settings live in the plan itself: a fresh plan has other addresses)
+        for kind, item in self.items[:self.count]:
+            if kind == "run" and item.fast is not None and item.fast.ok:
+                item.fast.verify()  # (the table takes a run's addresses from its persistent plan)
         fresh = _LatticePlan(self.items, self.dtype, self.device, allow_vector=self.allow_vector, allow_screens=self.allow_screens)
         if fresh.ok != self.ok or (fresh.ok and fresh.words != self.words):
             raise RuntimeError("lattice stretch plan: the storage of a setting was replaced without an attribute assignment "
