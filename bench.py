@@ -376,14 +376,16 @@ def other_configs(ca, torch, device, only=None) -> dict:
 
     def c5():
         r = rc.c5()
-        # forward: apply 56 B + the Screen's snapshot of the beam 56 B + moments 32 B per particle; backward: 7x7 algebra on the
+        # forward: apply 56 B + the Screen's record of the beam 36 + 28 B (same pass) + moments 32 B per particle ~ 144 B; backward: 7x7 algebra on the
         # incoming beam's (memoised) moments — no particle pass (the particle-sized backward moved 144 B more)
         nbytes = 144.0 * N_PARTICLES
         res = {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
                "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "eager step: bound by ~0.25 ms of Python / autograd bookkeeping around 8 launches"}}
+                            "note": "eager step: [run | Screen] is one differentiable node and the beam property another, both in C++ "
+                                    "(cheetah_amd._chxtorch); bound by the host: ~80 us forward + the autograd engine (60 us for a "
+                                    "one-node graph on these hosts, benchmarks/c5_variants.py) + two backward launches"}}
         # The same step captured once into a device graph (torch.cuda.CUDAGraph = hipGraph) and replayed: what an optimisation loop
         # that keeps its tensors in place can run. In a process of its own: a capture needs Parameters that have never seen a
         # backward pass on the default stream, and a failed capture must not take this line down.
