@@ -464,3 +464,123 @@ def test_differentiable_stretch_equals_general_path(dt):
             loss.backward()
     finally:
         segment._TORCH_HOST = old
+
+
+def _walk_copy(build, beam, track=lambda seg, b: seg.track(b)):
+    """The same lattice built twice: tracked with screens as stretch items, and with screens kept out of the stretches (the walk)."""
+    from cheetah_amd.accelerator.segment import Segment
+
+    seg_a = build()
+    out_a = track(seg_a, beam)
+    Segment._STRETCH_SCREENS = False
+    try:
+        seg_b = build()
+        out_b = track(seg_b, beam)
+    finally:
+        Segment._STRETCH_SCREENS = True
+    return seg_a, out_a, seg_b, out_b
+
+
+def _same_screens(ca, seg_a, seg_b, dt):
+    sa = [e for e in seg_a.modules() if isinstance(e, ca.Screen) and e.is_active]
+    sb = [e for e in seg_b.modules() if isinstance(e, ca.Screen) and e.is_active]
+    assert len(sa) == len(sb) and sa
+    for a, b in zip(sa, sb):
+        ra, rb = a.get_read_beam(), b.get_read_beam()
+        assert torch.equal(ra.particles, rb.particles) and torch.equal(ra.particle_charges, rb.particle_charges)
+        assert torch.equal(ra.survival_probabilities, rb.survival_probabilities) and torch.equal(ra.energy, rb.energy) and torch.equal(ra.s, rb.s)
+        ia, ib = a.reading, b.reading
+        assert ia.shape == ib.shape
+        assert torch.allclose(ia, ib, rtol=1e-4 if dt == torch.float32 else 1e-11, atol=float(ib.max()) * (1e-6 if dt == torch.float32 else 1e-13))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 63, 257, 10_001])
+def test_screen_stretch_shapes_and_positions(dt, n):
+    """Screens first, last, back to back, six of them (more than one stretch call takes), inside a nested Segment, odd particle
+    counts (the record's parts start at every alignment): equal to the walk."""
+    import cheetah_amd as ca
+
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    torch.manual_seed(n)
+    full = ca.ParticleBeam.from_parameters(num_particles=max(n, 100), sigma_x=t(2e-4), sigma_y=t(2e-4), energy=t(1e8), **fk)
+    beam = ca.ParticleBeam(full.particles[:n].contiguous(), full.energy, particle_charges=full.particle_charges[:n].contiguous(),
+                           survival_probabilities=torch.rand(n, **fk), **fk)
+
+    def scr(k, **kw):
+        return ca.Screen(resolution=(40, 30), pixel_size=t([5e-5, 6e-5]), misalignment=t([2e-5 * k, -1e-5 * k]), is_active=True, name=f"s{k}",
+                         **kw, **fk)
+
+    def build():
+        inner = ca.Segment([ca.Drift(t(0.2), **fk), scr(3), ca.Quadrupole(t(0.1), k1=t(-5.0), **fk)], name="inner")
+        return ca.Segment([scr(0), ca.Drift(t(0.3), **fk), ca.Quadrupole(t(0.2), k1=t(6.0), **fk), scr(1), scr(2), ca.Drift(t(0.1), **fk), inner,
+                           ca.HorizontalCorrector(t(0.05), angle=t(1e-4), **fk), scr(4), ca.Drift(t(0.2), **fk), scr(5), ca.Drift(t(0.4), **fk),
+                           scr(6)])
+
+    with torch.no_grad():
+        seg_a, out_a, seg_b, out_b = _walk_copy(build, beam)
+        assert torch.equal(out_a.particles, out_b.particles) and torch.equal(out_a.s, out_b.s)
+        assert out_a.particles.data_ptr() != beam.particles.data_ptr()
+        _same_screens(ca, seg_a, seg_b, dt)
+        # tracked again (the plans exist now), and with a screen switched off in between
+        out_a2 = seg_a.track(beam)
+        assert torch.equal(out_a2.particles, out_b.particles)
+        seg_a.s1.is_active = False
+        seg_b.s1.is_active = False
+        out_a3 = seg_a.track(beam)
+        assert torch.equal(out_a3.particles, out_b.particles)
+        _same_screens(ca, seg_a, seg_b, dt)
+
+
+def test_screen_stretch_keeps_the_walks_errors_and_copies():
+    """A float64 screen under a float32 beam raises like the reference's scatter does; a trainable misalignment and a histogram / kde
+    screen keep working; a tracked lattice can be deep-copied, pickled and moved."""
+    import copy
+    import pickle
+
+    import cheetah_amd as ca
+
+    fk = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    torch.manual_seed(0)
+    beam = ca.ParticleBeam.from_parameters(num_particles=4000, sigma_x=t(2e-4), sigma_y=t(2e-4), **fk)
+    wide = ca.Screen(resolution=(32, 32), pixel_size=torch.tensor([1e-4, 1e-4], dtype=torch.float64, device="cuda"), is_active=True,
+                     dtype=torch.float64, device="cuda")
+    seg = ca.Segment([ca.Drift(t(0.5), **fk), wide])
+    with torch.no_grad():
+        seg.track(beam)
+        with pytest.raises(RuntimeError, match="scatter"):
+            wide.reading
+    for method in ("histogram", "kde"):
+        def build(method=method):
+            return ca.Segment([ca.Drift(t(0.5), **fk), ca.Quadrupole(t(0.2), k1=t(3.0), **fk),
+                               ca.Screen(resolution=(32, 24), pixel_size=t([1e-4, 1e-4]), method=method, is_active=True, name="scr", **fk)])
+
+        with torch.no_grad():
+            seg_a, out_a, seg_b, out_b = _walk_copy(build, beam)
+        assert torch.equal(out_a.particles, out_b.particles)
+        assert torch.allclose(seg_a.scr.reading, seg_b.scr.reading, rtol=1e-4, atol=1e-6 * float(seg_b.scr.reading.max()))
+    # trainable misalignment: the screen stays out of the stretch, the gradient reaches it through the image
+    mis = torch.nn.Parameter(t([1e-5, 2e-5]))
+    seg = ca.Segment([ca.Drift(t(0.5), **fk), ca.Screen(resolution=(32, 24), pixel_size=t([1e-4, 1e-4]), misalignment=mis, is_active=True,
+                                                       name="scr", **fk)])
+    seg.track(beam)
+    assert seg.scr.get_read_beam().particles.requires_grad
+    seg.scr.get_read_beam().mu_x.backward()
+    assert mis.grad is not None and float(mis.grad[0]) == pytest.approx(-1.0, rel=1e-4)
+    # copies of a tracked lattice
+    def build():
+        return ca.Segment([ca.Drift(t(0.5), **fk), ca.Screen(resolution=(32, 24), pixel_size=t([1e-4, 1e-4]), is_active=True, name="scr", **fk)])
+
+    with torch.no_grad():
+        seg = build()
+        seg.track(beam)
+        image = seg.scr.reading.clone()
+        for other in (copy.deepcopy(seg), pickle.loads(pickle.dumps(seg))):
+            assert torch.equal(other.scr.get_read_beam().particles, seg.scr.get_read_beam().particles)
+            assert torch.allclose(other.scr.reading, image)
+            other.track(beam)
+            assert torch.allclose(other.scr.reading, image, rtol=1e-4, atol=1e-6 * float(image.max()))
+        moved = copy.deepcopy(seg).double()
+        assert moved.scr.reading.dtype == torch.float64 and torch.allclose(moved.scr.reading.float(), image, rtol=1e-5)
