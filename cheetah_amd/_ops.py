@@ -1850,7 +1850,7 @@ def sc_tile_state(N: int, bins, dtype: torch.dtype, device) -> torch.Tensor | No
 
 
 def sc_kick_sorted(x, q, w, energy, length, grid_extent, mass_eV, N, bins, state, first: bool, last: bool, side_stream=None,
-                   post_map_ptr=None, group=None) -> torch.Tensor:
+                   post_map_ptr=None, group=None, index: int = 0) -> torch.Tensor:
     """One kick of a chain on the tile-ordered beam (chx_sc_kick_sorted): x (N,7); q, w (N,) only read when `first`;
     energy, length (1,); grid_extent (1,3). Returns (N,7) in tile order, or in the caller's order when `last`.
 
@@ -1867,6 +1867,9 @@ def sc_kick_sorted(x, q, w, energy, length, grid_extent, mass_eV, N, bins, state
     flags = (1 if first else 0) | (2 if last else 0)
     side = side_stream.cuda_stream if side_stream is not None else None
     if group is None:
+        # `index` (the kick's position in its chain; 0 for the first): from the second kick on the grid geometry and the deposit's
+        # bookkeeping are formed inside the kernels that need them (csrc/chx_sc_geom_dev.h) — two launches fewer per kick
+        flags |= (index & 0x7FFFFF) << 8
         check(lib.chx_sc_kick_sorted(ptr(x), ptr(q), ptr(w), ptr(energy), ptr(length), ptr(grid_extent), mass_eV, N, b3, dt, ptr(out),
                                      ptr(ws), ws_bytes, ptr(state), state.numel(), flags, stream_ptr(), side, post_map_ptr),
               "chx_sc_kick_sorted")

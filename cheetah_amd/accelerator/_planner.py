@@ -35,10 +35,11 @@ class Path(NamedTuple):
 class WalkState:
     """What a walk over the plan carries from item to item."""
 
-    __slots__ = ("chain",)
+    __slots__ = ("chain", "chain_index")
 
     def __init__(self):
         self.chain = None      # state buffer of a running chain of tile-ordered SpaceChargeKicks: the rows are then in TILE order
+        self.chain_index = 0   # position of the next kick in that chain
 
 
 # ---- [kick, linear run, kick, ...] on one grid: the tile-ordered chain (chx_sc_kick_sorted) ------------------------------------
@@ -54,10 +55,12 @@ def _launch_chain(seg, plan, i, kind, item, incoming, state):
     first = state.chain is None
     if first:
         state.chain = _ops.sc_tile_state(incoming.particles.shape[0], item.grid_shape, incoming.particles.dtype, incoming.particles.device)
+        state.chain_index = 0
     run = plan[i + 1][1] if i + 1 < len(plan) and plan[i + 1][0] == "run" else None
     fused = seg._chain_run_plan(run, incoming) if run is not None else None
     last = seg._next_chain_kick(plan, i, item, incoming.particles.dtype) is None or (run is not None and fused is None)
-    out, step = seg._chain_kick(item, run, fused, incoming, state.chain, first, last)
+    out, step = seg._chain_kick(item, run, fused, incoming, state.chain, first, last, state.chain_index)
+    state.chain_index += 1
     if last:
         seg._chain_report(plan, state.chain)
         state.chain = None

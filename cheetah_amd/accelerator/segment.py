@@ -1972,7 +1972,7 @@ class Segment(Element):
             return None
         return fr, fresh
 
-    def _chain_kick(self, kick, run, fused, incoming: ParticleBeam, state, first: bool, last: bool):
+    def _chain_kick(self, kick, run, fused, incoming: ParticleBeam, state, first: bool, last: bool, index: int = 0):
         """One link of a chain: the kick and, when the run behind it has a persistent device plan (`fused` from
         `_chain_run_plan`), that run in the same particle pass. Returns (beam, number of plan items consumed)."""
         R_addr, s_out = None, None
@@ -2001,7 +2001,7 @@ class Segment(Element):
             R_addr = addr.value
             if s_out is None:
                 s_out = self._run_s(run, s_in)
-        out = kick._track_in_chain(incoming, state, first, last, R_addr)
+        out = kick._track_in_chain(incoming, state, first, last, R_addr, index)
         beam = ParticleBeam(out, incoming.energy, particle_charges=incoming.particle_charges,
                             survival_probabilities=incoming.survival_probabilities, s=s_out if fused is not None else incoming.s,
                             species=incoming.species)

@@ -203,7 +203,7 @@ class SpaceChargeKick(Element):
         return not (torch.is_grad_enabled() and any(t.requires_grad for t in (
             parts, incoming.particle_charges, incoming.survival_probabilities, incoming.energy)))
 
-    def _track_in_chain(self, incoming: ParticleBeam, state: torch.Tensor, first: bool, last: bool, post_map_ptr=None):
+    def _track_in_chain(self, incoming: ParticleBeam, state: torch.Tensor, first: bool, last: bool, post_map_ptr=None, index: int = 0):
         """This kick as a link of a chain (`chx_sc_kick_sorted`): the first link sorts the particle rows by deposit tile into
         `state`, later links work on the ordered rows, the last one returns the rows in the caller's order. Returns the
         particle tensor (in tile order unless `last`)."""
@@ -223,7 +223,7 @@ class SpaceChargeKick(Element):
         return _ops.sc_kick_sorted(x, q, w, incoming.energy.to(dtype).reshape(1), self.effect_length.to(dtype).reshape(1),
                                    self._grid_extent(dtype), incoming.species.mass_eV_float, N, self.grid_shape, state, first, last,
                                    side_stream=self._side_stream(device), post_map_ptr=post_map_ptr,
-                                   group=sharding.active_group())
+                                   group=sharding.active_group(), index=index)
 
     def _track_particle_sharded(self, incoming, group, x, q, w, energy, L, out_shape, B, N) -> ParticleBeam:
         """The kick for a beam whose particles are spread over the ranks of `group` (sharding.particle_sharded): the same

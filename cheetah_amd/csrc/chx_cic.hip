@@ -1067,6 +1067,7 @@ extern "C" int chx_cic_deposit_sorted_overwrite(const chx_cic_args* p, void* wor
 // rows when too many particles have left their tile. The index / weight arithmetic is sort_locate's
 // (cloud_in_cell.py:150-172, 262-311): identical addends to chx_cic_deposit.
 #include "chx_sc_tiles.h"
+#include "chx_sc_geom_dev.h"
 
 namespace {
 
@@ -1169,11 +1170,13 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
                                                              const T* __restrict__ extent, const T* __restrict__ scale,
                                                              T* __restrict__ cross /* = acc */, uint16_t* __restrict__ home,
                                                              int* __restrict__ newcount, int* __restrict__ mis_slots,
-                                                             int parts_shift) {
+                                                             int parts_shift, ScGeoSums rider) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
     __shared__ int nstay, nmis;
+    __shared__ T geo_s[kScGeoValues];                    // rider: the geometry this workgroup formed (chx_sc_geom_dev.h)
+    __shared__ double pot_s[1];
     // 2^parts_shift workgroups share a tile (dense tiles — few tiles, many particles: the reference's default 32^3 grid with 1e6
     // particles has 64 tiles of 15 000 slots on average, 60 000 in the occupied ones): each takes a contiguous share of the
     // tile's slot range; everything a workgroup leaves behind is a sum (charge, counters), so the shares simply add up
@@ -1181,7 +1184,9 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
     // the slot range of both parities is fetched next to the parity itself: one round trip instead of two in front of everything
     // this workgroup does (a workgroup of an empty tile is two round trips long otherwise)
     const int b0 = tile_start2[t], e0 = tile_start2[t + 1], b1 = tile_start2[g.nt + 1 + t], e1 = tile_start2[g.nt + 2 + t];
-    const int par = hdr->parity;
+    // (a gather pass that re-ordered the rows leaves scatter_now set: its copy of the arrays is in force from this kick on; the flag
+    // itself is taken back by the bookkeeping step behind this pass, or by the geometry kernel in front of it where one runs)
+    const int par = (hdr->parity ^ hdr->scatter_now) & 1;
     const T* __restrict__ cs = cs2 + (int64_t)par * a.N;
     const int TX = g.tdim[0], TY = g.tdim[1], TZ = g.tdim[2];
     const int BY = TZ + 1, BX = (TY + 1) * BY, ncell = (TX + 1) * BX;
@@ -1201,12 +1206,16 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
         end = (beg + share < end) ? beg + share : end;
     }
     const int lim = (end - beg > kScTileCap) ? beg + kScTileCap : end;
+    // rider: this kick's grid geometry from the sums the previous gather pass left — every workgroup with particles, redundantly
+    // (the (TX + 1)^3 block is zeroed behind it: its first (TH / 16 + 1) * 8 doubles serve the reduction); workgroup 0, with or
+    // without particles, also leaves it behind for the kernels that follow on this stream
+    if (rider.sums && (blockIdx.x == 0 || end > beg)) sc_geo_from_sums<T, TH>(rider, blk, geo_s, pot_s, blockIdx.x == 0);
     if (end <= beg) return;                             // no slots (3/4 of the tiles of a 3-sigma grid)
-    for (int i = threadIdx.x; i < ncell; i += TH) blk[i] = 0.0;
     if (threadIdx.x < 27) nbr[threadIdx.x] = 0;
     if (threadIdx.x == 0) { nstay = 0; nmis = 0; }
+    for (int i = threadIdx.x; i < ncell; i += TH) blk[i] = 0.0;
     __syncthreads();
-    const SortAxes<T, 3> ax = sort_axes<T, 3>(a, extent, scale, nullptr, 0);
+    const SortAxes<T, 3> ax = rider.sums ? sort_axes<T, 3>(a, geo_s + 11, geo_s + 8, nullptr, 0) : sort_axes<T, 3>(a, extent, scale, nullptr, 0);
     int stay = 0, mis = 0;
     for (int r0 = beg; r0 < end; r0 += TH * kScDepUnroll) {
         T raw[kScDepUnroll][3], cq[kScDepUnroll];
@@ -1290,62 +1299,11 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
     if (threadIdx.x == 64 && nmis) atomicAdd(&mis_slots[t & (kScMisSlots - 1)], nmis);   // the beam's misfiled particles (-> schedule kernel)
 }
 
-// deposit, the bookkeeping behind the pass (ONE workgroup): decides whether the rows are re-ordered by this kick's gather pass
-// (more than 1/16 of the beam misfiled, and a later kick to profit from it) and, if so, turns the new tile populations into the
-// slot cursors and the next tile starts; updates the header. The counters (newcount[], mis[]) are put back to zero by
-// the gather pass of the same kick (chx_sc_tile_gather_kick), which runs behind this kernel and in front of the next deposit. (A ticket at the end of
-// the deposit kernel instead needs a device-scope release per workgroup: 4096 L2 write-backs took that kernel from 30 to
-// 500 us.)
-__global__ __launch_bounds__(256) void sc_tile_schedule_kernel(ScTileGeom g, int64_t N, ScTileHeader* __restrict__ hdr,
-                                                              const int* __restrict__ newcount, const int* __restrict__ mis,
-                                                              int* __restrict__ cursor, int* __restrict__ tile_start2, int allow_reorder) {
-    __shared__ int part[256];
-    __shared__ int n_sh;
-    if (threadIdx.x < 64) {                          // the deposit kernel's counters (zero before a chain and after every gather)
-        int v = threadIdx.x < kScMisSlots ? mis[threadIdx.x] : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (threadIdx.x == 0) n_sh = v;
-    }
-    __syncthreads();
-    const int n = n_sh;
-    const bool reorder = allow_reorder && (int64_t)n * 16 > N;
-    if (threadIdx.x == 0) {
-        hdr->ncross = n;
-        hdr->last_ncross = n;
-        hdr->misfiled_permille += (int)((int64_t)n * 1000 / N);   // over the chain so far: what the host's guard reads
-        hdr->n_deposits += 1;
-        if (reorder) {
-            hdr->scatter_now = 1;
-            hdr->n_sorts += 1;
-        }
-    }
-    if (!reorder) return;                            // the usual case: this kernel is one round trip long
-    // new tile populations -> slot cursors and the next tile starts (exclusive scan over the tiles)
-    const int per = (g.nt + 255) / 256;
-    const int lo = threadIdx.x * per, hi = (lo + per < g.nt) ? lo + per : g.nt;
-    int sum = 0;
-    for (int k = lo; k < hi; ++k) sum += newcount[k];
-    int incl = sum;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) part[wv] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int k = 0; k < wv; ++k) before += part[k];
-    const int total = part[0] + part[1] + part[2] + part[3];
-    int run = before + incl - sum;
-    int* __restrict__ ts_next = tile_start2 + (int64_t)(hdr->parity ^ 1) * (g.nt + 1);
-    for (int k = lo; k < hi; ++k) {
-        cursor[k] = run;
-        ts_next[k] = run;
-        run += newcount[k];
-    }
-    if (threadIdx.x == 255) ts_next[g.nt] = total;
+// deposit, the bookkeeping behind the pass (ONE workgroup): sc_tile_schedule_block (chx_sc_tiles.h) as a kernel of its own. Inside a
+// chain of kicks it rides in the first FFT pass of the convolution instead (chx_sc_convolve_halo_chain).
+__global__ __launch_bounds__(256) void sc_tile_schedule_kernel(ScScheduleArgs a) {
+    __shared__ int part[257];
+    sc_tile_schedule_block(a, part);
 }
 
 // chx_sc_tile_deposit as an entry point of its own: move the accumulated charge into the caller's grid and leave zeros behind
@@ -1403,10 +1361,23 @@ int sc_tile_sort_launch(const CicDev& a, const ScTileGeom& g, const ScTileLayout
     return CHX_OK;
 }
 
+ScScheduleArgs sc_schedule_args(const ScTileGeom& g, const ScTileLayout& L, char* st, int64_t N, int allow_reorder) {
+    ScScheduleArgs sa;
+    sa.g = g;
+    sa.N = N;
+    sa.hdr = (ScTileHeader*)(st + L.hdr);
+    sa.newcount = (const int*)(st + L.newcount);
+    sa.mis = (const int*)(st + L.mis);
+    sa.cursor = (int*)(st + L.cursor);
+    sa.tile_start2 = (int*)(st + L.tile_start[0]);
+    sa.allow_reorder = allow_reorder;
+    return sa;
+}
+
 template <typename T>
 int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLayout& L, char* st, const void* rows, const void* extent,
                            const void* scale, void* grid /*nullptr: leave the charge in the state's accumulation grid*/,
-                           int allow_reorder, hipStream_t s) {
+                           int allow_reorder, hipStream_t s, const ScGeoSums* rider = nullptr, bool schedule = true) {
     ScTileHeader* hdr = (ScTileHeader*)(st + L.hdr);
     const size_t blk_bytes = (size_t)(g.tdim[0] + 1) * (g.tdim[1] + 1) * (g.tdim[2] + 1) * sizeof(double);
     // threads per tile: CHX_TUNE_DEPOSIT_THREADS (benchmarks only) picks 256 / 512 / 1024
@@ -1416,13 +1387,19 @@ int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLay
     // (benchmarks/sc_chain_density.py: one workgroup per tile costs 841 us per kick at 1e6 particles on 32^3)
     int parts_shift = 0;
     while (parts_shift < 6 && ((a.N * 4 / g.nt) >> parts_shift) > 2048) ++parts_shift;
+    ScGeoSums rd = ScGeoSums();
+    if (rider) rd = *rider;
+    // (the rider's reduction borrows the tile block's LDS: (th / 16 + 1) * 8 doubles)
+    if (rd.sums && blk_bytes < (size_t)(th / 16 + 1) * 8 * sizeof(double)) return CHX_ERR_INVALID_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)g.nt << parts_shift), dim3(th), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
                        (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)(st + L.cross),
-                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis), parts_shift);
+                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis), parts_shift, rd);
     CHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sc_tile_schedule_kernel, dim3(1), dim3(256), 0, s, g, a.N, hdr, (const int*)(st + L.newcount),
-                       (const int*)(st + L.mis), (int*)(st + L.cursor), (int*)(st + L.tile_start[0]), allow_reorder);
-    CHX_CHECK_LAUNCH();
+    if (schedule) {
+        const ScScheduleArgs sa = sc_schedule_args(g, L, st, a.N, allow_reorder);
+        hipLaunchKernelGGL(sc_tile_schedule_kernel, dim3(1), dim3(256), 0, s, sa);
+        CHX_CHECK_LAUNCH();
+    }
     if (grid) {
         const int64_t n = a.gbatch;
         hipLaunchKernelGGL(sc_tile_collect_kernel<T>, dim3((unsigned)chx_grid_for(n, 256 * 8, 4096)), dim3(256), 0, s, (T*)(st + L.cross),
@@ -1483,4 +1460,32 @@ extern "C" int chx_sc_tile_deposit_acc(const void* rows, const void* extent, con
     if (acc_out) *acc_out = (char*)state + L.cross;
     return dtype == CHX_F32 ? sc_tile_deposit_launch<float>(a, g, L, (char*)state, rows, extent, scale, nullptr, allow_reorder, (hipStream_t)stream)
                             : sc_tile_deposit_launch<double>(a, g, L, (char*)state, rows, extent, scale, nullptr, allow_reorder, (hipStream_t)stream);
+}
+
+// chx_sc_tile_deposit_acc inside a chain kick (chx_sc_tiles.h)
+int chx_sc_tile_deposit_chain(const void* rows, const void* extent, const void* scale, int64_t N, const int32_t* bins, int dtype,
+                              void* state, size_t state_bytes, int allow_reorder, const ScGeoSums* rider, bool schedule, void* stream) {
+    CicDev a;
+    ScTileGeom g;
+    int st = sc_tile_prepare(N, bins, dtype, a, g);
+    if (st != CHX_OK) return st;
+    if ((!rider && !extent) || !state) return CHX_ERR_INVALID_ARG;
+    const ScTileLayout L = sc_tile_layout(N, bins, dtype);
+    if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
+    if (!rows) rows = (char*)state + L.rows_tmp;
+    return dtype == CHX_F32 ? sc_tile_deposit_launch<float>(a, g, L, (char*)state, rows, extent, scale, nullptr, allow_reorder, (hipStream_t)stream, rider, schedule)
+                            : sc_tile_deposit_launch<double>(a, g, L, (char*)state, rows, extent, scale, nullptr, allow_reorder, (hipStream_t)stream, rider, schedule);
+}
+
+// the bookkeeping step's arguments for a state buffer (chx_sc_convolve_halo_chain's rider)
+int chx_sc_schedule_args(int64_t N, const int32_t* bins, int dtype, void* state, size_t state_bytes, int allow_reorder, ScScheduleArgs* out) {
+    CicDev a;
+    ScTileGeom g;
+    int st = sc_tile_prepare(N, bins, dtype, a, g);
+    if (st != CHX_OK) return st;
+    if (!state || !out) return CHX_ERR_INVALID_ARG;
+    const ScTileLayout L = sc_tile_layout(N, bins, dtype);
+    if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
+    *out = sc_schedule_args(g, L, (char*)state, N, allow_reorder);
+    return CHX_OK;
 }

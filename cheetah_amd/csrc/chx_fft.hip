@@ -14,6 +14,8 @@
 #include "chx_common.h"
 #include "chx_fft_reg.h"
 #include "chx_sc_math.h"
+#include "chx_sc_tiles.h"
+#include "chx_sc_geom_dev.h"
 
 namespace {
 
@@ -196,11 +198,21 @@ __device__ __forceinline__ void pass1_to_lds(vec2<T> (&x)[16], vec2<T>* xch, con
     for (int k1 = 1; k1 < 16; ++k1) xch[k1 * RT::KP + c * RT::LP + line] = cmul(x[k1], tw[(c * k1) & (RT::n - 1)]);
 }
 
-template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
+// RIDER: the launch has ONE workgroup more than the lines need; it runs the bookkeeping step behind the tile deposit of a chain of
+// space-charge kicks (sc_tile_schedule_block, chx_sc_tiles.h) — a launch of its own otherwise, between the deposit and this pass.
+template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH, bool RIDER = false>
 __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* in, T* __restrict__ out, int n_valid,
                                                                  int n_keep, int64_t L, int64_t inner_count, LineLayout li,
                                                                  LineLayout lo, T* consume /*LOAD_REAL: = in, zeros are written
-                                                                 behind the loads (null: the input is left alone)*/) {
+                                                                 behind the loads (null: the input is left alone)*/,
+                                                                 ScScheduleArgs sched) {
+    if constexpr (RIDER) {
+        if (blockIdx.x == gridDim.x - 1) {
+            __shared__ int sched_part[257];
+            if (blockIdx.y == 0) sc_tile_schedule_block(sched, sched_part);
+            return;
+        }
+    }
     using RT = RegTile<T, M>;
     constexpr int n = RT::n;
     constexpr bool kCplxIn = LOADM == LOAD_COMPLEX || LOADM == LOAD_HERMITIAN;
@@ -297,18 +309,26 @@ __global__ __launch_bounds__(CHX_BLOCK) void fft_lines_reg_kernel(const T* in, T
 
 template <typename T, int LOADM, int STOREM, bool POINT_FAST, int M, bool INV, bool ZP, bool KH>
 int launch_lines_reg(const void* in, void* out, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                     LineLayout lo, int64_t B, hipStream_t s, void* consume = nullptr) {
+                     LineLayout lo, int64_t B, hipStream_t s, void* consume = nullptr, const ScScheduleArgs* sched = nullptr) {
     constexpr int lines = LOADM == LOAD_EVEN_REAL_PAIR ? 2 * kTL : kTL;
     dim3 grid((unsigned)((L + lines - 1) / lines), (unsigned)B);
     constexpr size_t shmem = RegTile<T, M>::shmem;
     auto kern = fft_lines_reg_kernel<T, LOADM, STOREM, POINT_FAST, M, INV, ZP, KH>;
+    if constexpr (LOADM == LOAD_REAL) {
+        if (sched) {
+            kern = fft_lines_reg_kernel<T, LOADM, STOREM, POINT_FAST, M, INV, ZP, KH, true>;
+            grid.x += 1;
+        }
+    } else if (sched) {
+        return CHX_ERR_INVALID_ARG;
+    }
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
             hipSuccess)
             return CHX_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kern, grid, dim3(CHX_BLOCK), shmem, s, (const T*)in, (T*)out, n_valid, n_keep, L, inner_count, li, lo,
-                       (T*)consume);
+                       (T*)consume, sched ? *sched : ScScheduleArgs());
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
@@ -416,16 +436,17 @@ int launch_z_fused(void* data, const void* gh, const double* scale, int gx, int 
 // ZP / KH are promises of the call site about n_valid / n_keep (checked here)
 template <typename T, int LOADM, int STOREM, bool POINT_FAST, bool INV, bool ZP = false, bool KH = false>
 int launch_lines(const void* in, void* out, int n, int n_valid, int n_keep, int64_t L, int64_t inner_count, LineLayout li,
-                 LineLayout lo, int64_t B, hipStream_t s, void* consume = nullptr) {
+                 LineLayout lo, int64_t B, hipStream_t s, void* consume = nullptr, const ScScheduleArgs* sched = nullptr) {
     if ((ZP && 2 * n_valid != n) || (KH && 2 * n_keep != n)) return CHX_ERR_INVALID_ARG;
     if ((LOADM == LOAD_COMPLEX || LOADM == LOAD_REAL) && !ZP && n_valid != n) return CHX_ERR_INVALID_ARG;
     switch (n) {
-        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
-        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
-        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
-        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume);
+        case 32: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 2, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume, sched);
+        case 64: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 4, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume, sched);
+        case 128: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 8, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume, sched);
+        case 256: return launch_lines_reg<T, LOADM, STOREM, POINT_FAST, 16, INV, ZP, KH>(in, out, n_valid, n_keep, L, inner_count, li, lo, B, s, consume, sched);
         default: break;
     }
+    if (sched) return CHX_ERR_INVALID_ARG;          // (chx_sc_convolve_carries_schedule: lines of at most 256 points)
     int log2n = 0;
     while ((1 << log2n) < n) ++log2n;
     const size_t shmem = ((size_t)n * kPad + n / 2) * sizeof(cplx<T>);
@@ -513,9 +534,19 @@ __device__ __forceinline__ bool far_for_table(const FarGeom& f, int i, int j, in
 // runs fastest along the axis with the SMALLEST cell (the near region is longest there: for a relativistic bunch
 // dt = gamma * dz dominates and the near set is the slab k < 8): whole waves are skipped or kept.
 template <typename T>
-__global__ __launch_bounds__(CHX_BLOCK) void igf_table_near_kernel(const T* __restrict__ cell, const T* __restrict__ gamma,
-                                                                  int gx, int gy, int gz, double* __restrict__ table) {
+__global__ __launch_bounds__(CHX_BLOCK) void igf_table_near_kernel(const T* cell, const T* gamma,
+                                                                  int gx, int gy, int gz, double* __restrict__ table, ScGeoSums rider) {
     const int64_t b = blockIdx.y;
+    // rider (chx_sc_geom_dev.h; B = 1): every workgroup forms the kick's geometry from the sums the previous gather pass left and takes
+    // cell / gamma from it; workgroup 0 stores it as the side stream's copy for the kernels behind this one
+    __shared__ double geo_red[(CHX_BLOCK / 16 + 1) * 8];
+    __shared__ T geo_s[kScGeoValues];
+    __shared__ double pot_s[1];
+    if (rider.sums) {
+        sc_geo_from_sums<T, CHX_BLOCK>(rider, geo_red, geo_s, pot_s, blockIdx.x == 0 && blockIdx.y == 0);
+        cell = geo_s + 3;
+        gamma = geo_s + 6;
+    }
     const FarGeom f = far_geom<T>(cell, gamma, b);
     const int64_t npts = (int64_t)(gx + 1) * (gy + 1) * (gz + 1);
     const int fast = (f.dx <= f.dy && f.dx <= f.dt) ? 0 : (f.dy <= f.dt ? 1 : 2);
@@ -710,9 +741,27 @@ extern "C" int chx_sc_green_spectrum_fast(const void* cell, const void* gamma, i
     }
     const int grid = chx_grid_for((int64_t)npts, CHX_BLOCK, 2048);
     hipLaunchKernelGGL(igf_table_near_kernel<float>, dim3((unsigned)grid, (unsigned)B), dim3(CHX_BLOCK), 0, s, (const float*)cell,
-                       (const float*)gamma, bins[0], bins[1], bins[2], table);
+                       (const float*)gamma, bins[0], bins[1], bins[2], table, ScGeoSums());
     CHX_CHECK_LAUNCH();
     return green_spectrum_impl<float>(table, (const float*)cell, (const float*)gamma, B, bins, (float*)Ghat, (float*)rest, s);
+}
+
+// chx_sc_green_spectrum_fast inside a chain kick (chx_sc_tiles.h): B = 1; with a rider the corner-table launch forms cell / gamma itself
+int chx_sc_green_spectrum_chain(const void* cell, const void* gamma, const int32_t* bins, int dtype, void* Ghat, void* workspace,
+                                size_t workspace_bytes, const ScGeoSums* rider, void* stream) {
+    if (!rider || !rider->sums) return chx_sc_green_spectrum_fast(cell, gamma, 1, bins, dtype, Ghat, workspace, workspace_bytes, stream);
+    if (dtype != CHX_F32 || !Ghat || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < chx_sc_green_fast_workspace_bytes(1, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npts = (size_t)(bins[0] + 1) * (bins[1] + 1) * (bins[2] + 1);
+    double* table = (double*)workspace;
+    char* rest = (char*)workspace + ((npts * sizeof(double) + 255) & ~(size_t)255);
+    const float* geo = (const float*)rider->geo_out;      // the kernels behind the corner table read the copy its workgroup 0 stores
+    const int grid = chx_grid_for((int64_t)npts, CHX_BLOCK, 2048);
+    hipLaunchKernelGGL(igf_table_near_kernel<float>, dim3((unsigned)grid, 1), dim3(CHX_BLOCK), 0, s, geo + 3, geo + 6, bins[0], bins[1],
+                       bins[2], table, *rider);
+    CHX_CHECK_LAUNCH();
+    return green_spectrum_impl<float>(table, geo + 3, geo + 6, 1, bins, (float*)Ghat, (float*)rest, s);
 }
 
 // workspace of chx_sc_convolve per batch row: A [gx+1][gy][gz], Bf [gx+1][2gy][gz] complex, and for line lengths the fused
@@ -731,7 +780,8 @@ extern "C" size_t chx_sc_convolve_workspace_bytes(int64_t B, const int32_t* bins
 // — forward z, multiply, inverse z — runs in place along the contiguous axis.
 template <typename T>
 static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64_t B, const int32_t* bins, T* phi, T* ws,
-                         hipStream_t s, bool halo, hipEvent_t ghat_ready = nullptr, bool consume_rho = false) {
+                         hipStream_t s, bool halo, hipEvent_t ghat_ready = nullptr, bool consume_rho = false,
+                         const ScScheduleArgs* sched = nullptr) {
     const int gx = bins[0], gy = bins[1], gz = bins[2];
     const int nx = 2 * gx, ny = 2 * gy, nz = 2 * gz, nxc = gx + 1;
     const int64_t nA = (int64_t)nxc * gy * gz, nB = (int64_t)nxc * ny * gz, nC = (int64_t)nxc * ny * nz;  // complex elements
@@ -745,7 +795,7 @@ static int convolve_impl(const T* rho, const T* Ghat, const double* scale, int64
     // consume_rho: rho is the accumulation grid of a chain of kicks — the pass that reads it leaves zeros behind
     const bool in_pass = consume_rho && nx <= 256;
     int st = launch_lines<T, LOAD_REAL, STORE_COMPLEX, false, false, true>(rho, A, nx, gx, nxc, yz, yz, rx, ax, B, s,
-                                                                           in_pass ? (void*)rho : nullptr);
+                                                                           in_pass ? (void*)rho : nullptr, sched);
     if (st != CHX_OK) return st;
     if (consume_rho && !in_pass && hipMemsetAsync((void*)rho, 0, (size_t)B * g3 * sizeof(T), s) != hipSuccess) return CHX_ERR_LAUNCH;
     // forward y: A lines (kx, z), y < gy valid -> Bf[kx][ky < ny][z]
@@ -838,6 +888,23 @@ extern "C" int chx_sc_convolve_halo_consume(void* rho, const void* Ghat, const d
                                                    (float*)workspace, s, true, ev, true)
                             : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, B, bins, (double*)phi_halo,
                                                     (double*)workspace, s, true, ev, true);
+}
+
+// chx_sc_convolve_halo_consume inside a chain kick (chx_sc_tiles.h): B = 1, the first pass carries the deposit's bookkeeping step
+int chx_sc_convolve_carries_schedule(const int32_t* bins) { return bins && 2 * bins[0] <= 256 && 2 * bins[0] >= 32; }
+
+int chx_sc_convolve_halo_chain(void* rho, const void* Ghat, const double* scale, const int32_t* bins, int dtype, void* phi_halo,
+                               void* workspace, size_t workspace_bytes, void* stream, void* ghat_ready_event,
+                               const ScScheduleArgs* schedule) {
+    if (!rho || !Ghat || !scale || !phi_halo || !chx_sc_pruned_supported(bins, dtype)) return CHX_ERR_INVALID_ARG;
+    if (schedule && !chx_sc_convolve_carries_schedule(bins)) return CHX_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < chx_sc_convolve_workspace_bytes(1, bins, dtype)) return CHX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev = (hipEvent_t)ghat_ready_event;
+    return dtype == CHX_F32 ? convolve_impl<float>((const float*)rho, (const float*)Ghat, scale, 1, bins, (float*)phi_halo,
+                                                   (float*)workspace, s, true, ev, true, schedule)
+                            : convolve_impl<double>((const double*)rho, (const double*)Ghat, scale, 1, bins, (double*)phi_halo,
+                                                    (double*)workspace, s, true, ev, true, schedule);
 }
 
 extern "C" int chx_sc_convolve_halo(const void* rho, const void* Ghat, const double* scale, int64_t B, const int32_t* bins,

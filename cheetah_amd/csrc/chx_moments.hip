@@ -894,13 +894,15 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_sigma_kernel(const T* __restrict
 
 // one workgroup per batch row: sum the partial blocks (lane t holds block t, t + 256, ...), then lane 0 forms the variances
 // exactly like moments_reduce_finalize_kernel and writes the grid geometry
-template <typename T>
-__global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
+// (TH = 1024 for the chain's ~4000 partial blocks: every lane's loads are in flight at once, the kernel is ONE memory round trip long
+// instead of four)
+template <typename T, int TH = CHX_BLOCK>
+__global__ __launch_bounds__(TH) void sc_geometry_partials_kernel(
     const double* __restrict__ partials, int nblk, const T* __restrict__ ext, const T* __restrict__ energy,
     const T* __restrict__ length, double mass, double pot_factor, int64_t Bext, int64_t Be, int64_t Bl, int gx, int gy, int gz,
     T* __restrict__ half, T* __restrict__ cell, T* __restrict__ gamma_out, T* __restrict__ dt, T* __restrict__ scale,
     T* __restrict__ extent, double* __restrict__ pot_scale, int* __restrict__ tile_hdr, int tile_first) {
-    __shared__ double red[16 * kSG];
+    __shared__ double red[(TH / 16) * kSG];
     // chain of tile-ordered kicks (chx_sc_tiles.h): this single-workgroup kernel runs before the deposit / gather kernels of the
     // kick, so it is where the header rolls over: header = {parity, scatter_now, ...}
     if (tile_hdr && !tile_first && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -916,11 +918,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
 #pragma unroll
     for (int k = 0; k < kSG; ++k) a[k] = 0.0;
     // four blocks per lane and step, all 32 loads in flight together (one workgroup: the kernel is a chain of load latencies)
-    for (int i0 = threadIdx.x; i0 < nblk; i0 += 4 * CHX_BLOCK) {
+    for (int i0 = threadIdx.x; i0 < nblk; i0 += 4 * TH) {
         double v[4][kSG];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * CHX_BLOCK;
+            const int i = i0 + u * TH;
 #pragma unroll
             for (int k = 0; k < kSG; ++k) v[u][k] = i < nblk ? pb[(int64_t)k * nblk + i] : 0.0;
         }
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_geometry_partials_kernel(
     if (threadIdx.x < kSG) {
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += red[r * kSG + threadIdx.x];
+        for (int r = 0; r < TH / 16; ++r) t += red[r * kSG + threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
@@ -1269,17 +1271,20 @@ extern "C" int chx_sc_geometry_from_partials(const double* partials, int64_t nbl
         !extent || !pot_scale || !bins)
         return CHX_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == CHX_F32)
-        hipLaunchKernelGGL(sc_geometry_partials_kernel<float>, dim3(1), dim3(CHX_BLOCK), 0, s, partials, (int)nblk,
+    const bool wide = nblk > 4 * CHX_BLOCK;
+    if (dtype == CHX_F32) {
+        auto kern = wide ? sc_geometry_partials_kernel<float, 1024> : sc_geometry_partials_kernel<float, CHX_BLOCK>;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(wide ? 1024 : CHX_BLOCK), 0, s, partials, (int)nblk,
                            (const float*)grid_extent, (const float*)energy, (const float*)length, mass_eV, pot_factor, 1, 1, 1, bins[0],
                            bins[1], bins[2], (float*)half, (float*)cell, (float*)gamma, (float*)dt, (float*)scale, (float*)extent,
                            pot_scale, (int*)tile_header, 0);
-    else if (dtype == CHX_F64)
-        hipLaunchKernelGGL(sc_geometry_partials_kernel<double>, dim3(1), dim3(CHX_BLOCK), 0, s, partials, (int)nblk,
+    } else if (dtype == CHX_F64) {
+        auto kern = wide ? sc_geometry_partials_kernel<double, 1024> : sc_geometry_partials_kernel<double, CHX_BLOCK>;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(wide ? 1024 : CHX_BLOCK), 0, s, partials, (int)nblk,
                            (const double*)grid_extent, (const double*)energy, (const double*)length, mass_eV, pot_factor, 1, 1, 1,
                            bins[0], bins[1], bins[2], (double*)half, (double*)cell, (double*)gamma, (double*)dt, (double*)scale,
                            (double*)extent, pot_scale, (int*)tile_header, 0);
-    else
+    } else
         return CHX_ERR_DTYPE;
     CHX_CHECK_LAUNCH();
     return CHX_OK;

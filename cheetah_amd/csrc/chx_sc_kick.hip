@@ -6,10 +6,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "chx.h"
 #include "chx_sc_tiles.h"
+#include "chx_sc_geom_dev.h"
 
 namespace {
 
@@ -168,6 +170,13 @@ struct SortedKick {
     double* pot_scale;
 };
 
+// does this kick of a chain form its geometry and run its bookkeeping inside the kernels that need them (chx_sc_geom_dev.h)?
+// CHX_SC_RIDERS=0 (benchmarks / bisecting) keeps the two one-workgroup launches.
+bool sorted_kick_rides(int flags, int dtype, const int32_t* bins) {
+    static const bool enabled = [] { const char* e = getenv("CHX_SC_RIDERS"); return !(e && e[0] == '0'); }();
+    return enabled && !(flags & 1) && (flags >> 8) > 0 && dtype == CHX_F32 && chx_sc_convolve_carries_schedule(bins);
+}
+
 int sorted_kick_prepare(int64_t N, const int32_t* bins, int dtype, void* workspace, size_t workspace_bytes, void* state,
                         size_t state_bytes, SortedKick& k) {
     if (!workspace || !state) return CHX_ERR_INVALID_ARG;
@@ -181,14 +190,16 @@ int sorted_kick_prepare(int64_t N, const int32_t* bins, int dtype, void* workspa
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
     k.ws = (char*)workspace;
     k.st = (char*)state;
-    char* geo = k.ws + k.L.geo;
+    // the kick's geometry lives in the chain's state (copy 0: the main stream's), not in the workspace: with riders
+    // (chx_sc_geom_dev.h) it is written by the first kernels of the kick and read until its last one
+    char* geo = k.st + k.T.geo[0];
     k.half = geo;
     k.cell = geo + (size_t)3 * esz;
     k.gamma = geo + (size_t)6 * esz;
     k.dt = geo + (size_t)7 * esz;
     k.scale = geo + (size_t)8 * esz;
     k.extent = geo + (size_t)11 * esz;
-    k.pot_scale = (double*)(k.ws + k.L.pot);
+    k.pot_scale = (double*)(geo + kScGeoPotOffset);
     k.rho = k.ws + k.L.rho;
     k.ghat = k.ws + k.L.ghat;
     k.phi = k.ws + k.L.phi;
@@ -224,7 +235,27 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
     // beam sizes -> grid geometry. From the whole beam's moments when the caller has them (particle-sharded beam). Else, first
     // kick: the two launches of chx_sc_beam_geometry on the caller's arrays; later kicks: the gather pass of the previous kick left
     // the partial sums of the rows it wrote (= this kick's x_in) in the state: one launch.
-    if (beam_moments)
+    // Riders (flags bits 8..: the kick's index in its chain, > 0; fp32; lines the first FFT pass can carry the bookkeeping on): no
+    // geometry launch at all — the workgroups of the deposit (main stream) and of the Green function's corner table (side stream)
+    // form it from the sums the previous gather pass added up, each launch for its own stream (chx_sc_geom_dev.h), and the
+    // bookkeeping step behind the deposit rides in the convolution's first pass: 12 launches per kick + the run's map instead of
+    // 15, none of them a one-workgroup kernel on the critical path.
+    if (beam_moments && (flags >> 8)) return CHX_ERR_INVALID_ARG;    // (an indexed kick takes its geometry from the chain's own sums)
+    const bool ride = sorted_kick_rides(flags, dtype, bins);
+    ScGeoSums riders[2];
+    if (ride) {
+        for (int c = 0; c < 2; ++c) {
+            ScGeoSums& r = riders[c];
+            r.sums = (const double*)(k.st + k.T.sums[((flags >> 8) - 1) & 1]);     // what the previous kick's gather pass added up
+            r.grid_extent = grid_extent;
+            r.energy = energy;
+            r.length = length;
+            r.mass = mass_eV;
+            r.pot_factor = pot_factor;
+            r.gx = bins[0]; r.gy = bins[1]; r.gz = bins[2];
+            r.geo_out = k.st + k.T.geo[c];
+        }
+    } else if (beam_moments)
         rc = chx_sc_geometry_tiles(beam_moments, grid_extent, energy, length, mass_eV, pot_factor, 1, 1, 1, 1, 1, bins, dtype, k.half,
                                    k.cell, k.gamma, k.dt, k.scale, k.extent, k.pot_scale, first ? nullptr : k.st + k.T.hdr, moment_rows, main);
     else if (first)
@@ -245,7 +276,8 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
         (void)hipStreamWaitEvent(side, fork, 0);
         (void)hipEventDestroy(fork);
     }
-    rc = chx_sc_green_spectrum_fast(k.cell, k.gamma, 1, bins, dtype, k.ghat, k.ws + k.L.green_ws, k.L.ghat - k.L.green_ws, side);
+    rc = chx_sc_green_spectrum_chain(k.cell, k.gamma, bins, dtype, k.ghat, k.ws + k.L.green_ws, k.L.ghat - k.L.green_ws,
+                                     ride ? &riders[forked ? 1 : 0] : nullptr, side);
 
     // first kick of the chain: order the rows by deposit tile (into the state's row buffer); every kick: deposit from the ordered
     // rows (the merge pass decides on the device whether this kick's gather re-orders them for the kicks that follow)
@@ -253,7 +285,12 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
     if (rc == CHX_OK && first)
         rc = chx_sc_tile_sort(x_in, charge, survival, k.extent, k.scale, N, bins, dtype, state, state_bytes, main);
     void* acc = nullptr;
-    if (rc == CHX_OK) rc = chx_sc_tile_deposit_acc(rows, k.extent, k.scale, N, bins, dtype, state, state_bytes, last ? 0 : 1, &acc, main);
+    if (rc == CHX_OK) {
+        acc = k.st + k.T.cross;
+        // (riders on ONE stream: the corner table's rider has published copy 0 in front of the deposit; the deposit reads it in place)
+        rc = chx_sc_tile_deposit_chain(rows, k.extent, k.scale, N, bins, dtype, state, state_bytes, last ? 0 : 1,
+                                       ride && forked ? &riders[0] : nullptr, !ride, main);
+    }
     if (rc != CHX_OK && forked) {                           // an error path still rejoins the side stream
         hipEvent_t join = nullptr;
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
@@ -283,16 +320,21 @@ extern "C" int chx_sc_kick_sorted_finish(const void* x_in, const void* energy, d
         (void)hipEventRecord(join, side);                 // behind the Green spectrum `begin` put on the side stream
     }
     // the charge sits in the chain's accumulation grid (state); the convolution's first pass leaves it zeroed for the next kick
-    rc = chx_sc_convolve_halo_consume(k.st + k.T.cross, k.ghat, k.pot_scale, 1, bins, dtype, k.phi, k.ws + k.L.conv_ws,
-                                      k.L.phi - k.L.conv_ws, main, forked ? (void*)join : nullptr);
+    ScScheduleArgs sched;
+    const bool ride = sorted_kick_rides(flags, dtype, bins);
+    if (ride) rc = chx_sc_schedule_args(N, bins, dtype, state, state_bytes, last ? 0 : 1, &sched);
+    if (rc == CHX_OK)
+        rc = chx_sc_convolve_halo_chain(k.st + k.T.cross, k.ghat, k.pot_scale, bins, dtype, k.phi, k.ws + k.L.conv_ws,
+                                        k.L.phi - k.L.conv_ws, main, forked ? (void*)join : nullptr, ride ? &sched : nullptr);
     if (forked) {
         if (rc != CHX_OK) (void)hipStreamWaitEvent(main, join, 0);
         (void)hipEventDestroy(join);
     }
     if (rc != CHX_OK) return rc;
     const void* rows = first ? nullptr : x_in;
-    return chx_sc_tile_gather_kick(rows, k.phi, k.half, k.cell, k.gamma, energy, k.dt, mass_eV, N, bins, dtype, post_map, state,
-                                   state_bytes, last ? 1 : 0, x_out, main);
+    // (the gather adds the beam-size sums of the rows it writes into set index & 1 for the next kick's riders)
+    return chx_sc_tile_gather_kick_chain(rows, k.phi, k.half, k.cell, k.gamma, energy, k.dt, mass_eV, N, bins, dtype, post_map, state,
+                                         state_bytes, last ? 1 : 0, x_out, (flags >> 8) & 1, main);
 }
 
 extern "C" int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,

@@ -804,7 +804,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
     int* __restrict__ cursor, const T* __restrict__ phi, const T* __restrict__ half, const T* __restrict__ cell,
     const T* __restrict__ energy, const T* __restrict__ dt, const T* __restrict__ gamma, double mass_eV, int64_t N, int gx, int gy,
     int gz, T* __restrict__ x_out, const T* __restrict__ post_map, int unpermute, double* __restrict__ sigma_partials,
-    int* __restrict__ newcount, int nt, int* __restrict__ mis) {
+    int* __restrict__ newcount, int nt, int* __restrict__ mis, double* __restrict__ sums_add /*[8][256] or null*/,
+    double* __restrict__ sums_clear) {
     __shared__ __attribute__((aligned(16))) T lds[CHX_BLOCK * 7];
     __shared__ double red[4 * 8];
     const int par = hdr->parity;
@@ -812,6 +813,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
     // the deposit's counters (read by the schedule kernel in front of this pass) go back to zero for the next kick's deposit
     for (int k = (int)blockIdx.x * CHX_BLOCK + threadIdx.x; k < nt; k += (int)gridDim.x * CHX_BLOCK) newcount[k] = 0;
     if (blockIdx.x == 0 && threadIdx.x < kScMisSlots) mis[threadIdx.x] = 0;
+    // ... and the set of beam-size sums the NEXT gather pass adds into (chx_sc_geom_dev.h; its last readers ran in front of this pass)
+    if (sums_clear && blockIdx.x < 8) sums_clear[blockIdx.x * 256 + threadIdx.x] = 0.0;
     const int64_t n0 = (int64_t)blockIdx.x * CHX_BLOCK;
     const int np = (int)((N - n0 < CHX_BLOCK) ? (N - n0) : CHX_BLOCK);
     // staged per wave like sc_particle_kernel: no workgroup barrier
@@ -855,6 +858,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) sigma_partials[(int64_t)k * gridDim.x + blockIdx.x] = a[k];
+            // the same sums folded into 256 rows with fp64 atomics: few enough for every workgroup of the next kick's first
+            // kernels to reduce them itself (chx_sc_geom_dev.h) — no launch between this pass and those kernels
+            if (sums_add) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) unsafeAtomicAdd(&sums_add[k * 256 + (blockIdx.x & 255)], a[k]);
+            }
         }
     }
     if (mode == 0) {
@@ -879,6 +888,14 @@ extern "C" int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, c
                                        const void* energy, const void* dt, double mass_eV, int64_t N, const int32_t* bins, int dtype,
                                        const void* post_map, void* state, size_t state_bytes, int unpermute, void* x_out,
                                        void* stream) {
+    return chx_sc_tile_gather_kick_chain(rows, phi_halo, half, cell, gamma, energy, dt, mass_eV, N, bins, dtype, post_map, state,
+                                         state_bytes, unpermute, x_out, -1, stream);
+}
+
+int chx_sc_tile_gather_kick_chain(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
+                                  const void* energy, const void* dt, double mass_eV, int64_t N, const int32_t* bins, int dtype,
+                                  const void* post_map, void* state, size_t state_bytes, int unpermute, void* x_out, int sums_set,
+                                  void* stream) {
     if (!phi_halo || !half || !cell || !gamma || !energy || !dt || !state || !x_out || !bins_ok(bins) || N < 1)
         return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
@@ -892,19 +909,23 @@ extern "C" int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, c
     const unsigned nwg = (unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK);
     hipStream_t s = (hipStream_t)stream;
     const ScTileHeader* hdr = (const ScTileHeader*)(st + L.hdr);
+    const bool with_sums = sums_set >= 0 && !unpermute;
+    double* sums_add = with_sums ? (double*)(st + L.sums[sums_set & 1]) : nullptr;
+    double* sums_clear = with_sums ? (double*)(st + L.sums[(sums_set & 1) ^ 1]) : nullptr;
     if (dtype == CHX_F32)
         hipLaunchKernelGGL(sc_tile_particle_kernel<float>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const float*)rows, hdr, (int*)(st + L.perm[0]),
                            (float*)(st + L.ws[0]), (float*)(st + L.cs[0]), (const uint16_t*)(st + L.home), (int*)(st + L.cursor),
                            (const float*)phi_halo, (const float*)half, (const float*)cell, (const float*)energy, (const float*)dt,
                            (const float*)gamma, mass_eV, N, bins[0], bins[1], bins[2], (float*)x_out, (const float*)post_map, unpermute,
-                           unpermute ? nullptr : (double*)(st + L.sigma), (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis));
+                           unpermute ? nullptr : (double*)(st + L.sigma), (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis), sums_add,
+                           sums_clear);
     else
         hipLaunchKernelGGL(sc_tile_particle_kernel<double>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const double*)rows, hdr,
                            (int*)(st + L.perm[0]), (double*)(st + L.ws[0]), (double*)(st + L.cs[0]), (const uint16_t*)(st + L.home),
                            (int*)(st + L.cursor), (const double*)phi_halo, (const double*)half, (const double*)cell,
                            (const double*)energy, (const double*)dt, (const double*)gamma, mass_eV, N, bins[0], bins[1], bins[2],
                            (double*)x_out, (const double*)post_map, unpermute, unpermute ? nullptr : (double*)(st + L.sigma),
-                           (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis));
+                           (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis), sums_add, sums_clear);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
