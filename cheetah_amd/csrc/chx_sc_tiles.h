@@ -43,7 +43,7 @@ static_assert(sizeof(ScTileHeader) == 32, "the host reads the header as eight in
 constexpr int kScSortWG = 256;       // workgroups of the count / scatter passes
 constexpr int kScSortThreads = 1024;
 constexpr int kScTileCap = 8192;     // particles of one tile deposited through LDS by its workgroup; the rest take the slow way
-constexpr int kScChunk = 256;        // slots per workgroup of the gather pass (four waves of 64 rows, each on its own)
+constexpr int kScGatherRows = 256;   // rows per workgroup of the gather pass (four waves of 64 rows, each on its own)
 constexpr int kScMisSlots = 64;     // (one counter would serialise a thousand atomics on one address: +4 us on the deposit)
 constexpr int kScTdim = 8;           // the tile edge the kernels are written for (grids whose tile rule gives larger tiles — more
                                      // than 8192 tiles of 8^3 — keep the untiled path)
@@ -117,7 +117,7 @@ static inline ScTileLayout sc_tile_layout(int64_t N, const int32_t* bins, int dt
     L.cs[1] = L.cs[0] + (size_t)N * esz;
     L.home = take((size_t)N * sizeof(uint16_t));
     L.rows_tmp = take((size_t)N * 7 * esz);
-    L.sigma_blocks = (N + 255) / 256;
+    L.sigma_blocks = (N + kScGatherRows - 1) / kScGatherRows;
     L.sigma = take((size_t)8 * L.sigma_blocks * sizeof(double));
     L.total = off;
     return L;

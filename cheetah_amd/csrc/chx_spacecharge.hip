@@ -798,7 +798,12 @@ __device__ __forceinline__ int64_t sc_row_dest(bool active, int64_t r, int mode 
     return dst;
 }
 
-template <typename T>
+// R segments of 64 rows per wave, one after the other. R = 1 is what runs. Measured with R = 4 and R = 2 (round 5; the idea: what a
+// lane does once per launch — the kick's constants, ~90 instructions; the eight float64 block sums of the beam sizes, 144 DPP
+// instructions and two barriers = 3.6 us of the 38 us pass, benchmarks/_gather_sigma_cost.sh — is shared by R rows): the constants
+// and the running sums stay live across the loop, the scalar registers overflow into vector registers, 114 -> 178 (R = 2) / 200
+// (R = 4) VGPRs, two waves per SIMD instead of four, 38 -> 48 us. Capped at 128 VGPRs the kernel spills 76 registers.
+template <typename T, int R>
 __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
     const T* __restrict__ src, const ScTileHeader* __restrict__ hdr, int* perm2, T* ws2, T* cs2, const uint16_t* __restrict__ home,
     int* __restrict__ cursor, const T* __restrict__ phi, const T* __restrict__ half, const T* __restrict__ cell,
@@ -814,46 +819,66 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
     for (int k = (int)blockIdx.x * CHX_BLOCK + threadIdx.x; k < nt; k += (int)gridDim.x * CHX_BLOCK) newcount[k] = 0;
     if (blockIdx.x == 0 && threadIdx.x < kScMisSlots) mis[threadIdx.x] = 0;
     // ... and the set of beam-size sums the NEXT gather pass adds into (chx_sc_geom_dev.h; its last readers ran in front of this pass)
-    if (sums_clear && blockIdx.x < 8) sums_clear[blockIdx.x * 256 + threadIdx.x] = 0.0;
-    const int64_t n0 = (int64_t)blockIdx.x * CHX_BLOCK;
-    const int np = (int)((N - n0 < CHX_BLOCK) ? (N - n0) : CHX_BLOCK);
-    // staged per wave like sc_particle_kernel: no workgroup barrier
-    const int wrow = (threadIdx.x >> 6) * 64;
-    const int wvalid = (np - wrow < 0) ? 0 : ((np - wrow < 64) ? (np - wrow) : 64);
+    if (sums_clear) {
+        for (int k = (int)blockIdx.x * CHX_BLOCK + threadIdx.x; k < 8 * 256; k += (int)gridDim.x * CHX_BLOCK) sums_clear[k] = 0.0;
+    }
     const bool vin = chx_aligned16(src), vout = chx_aligned16(x_out);
-    wave_tile_load<T>(src + (n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vin, true);
-    chx_wave_sync();
     const ScKickCtx<T> ctx = sc_kick_ctx<T>(half, cell, energy, dt, gamma, mass_eV, gx, gy, gz, post_map);
     const int pz = gz + 4, py = (gy + 4) * pz;            // halo of 2: every index below is in bounds
-    const int p = threadIdx.x;
-    const bool active = p < np;
-    T out[7];
-    if (active) {
-        double v[7], s[7], u[3];
-        int i0[3], cn[3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* wlds = lds + wave * 64 * 7;                        // staged per wave like sc_particle_kernel: no workgroup barrier
+    double a[8];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) v[j] = (double)lds[p * 7 + j];
-        sc_kick_locate<T>(ctx, v, s, u, i0, cn);
-        PhiNode<T> node[8];
-        phi_cell_forces<T>(phi + ((int64_t)(cn[0] + 2) * py + (cn[1] + 2) * pz + (cn[2] + 2)), py, pz, cn[0], cn[1], cn[2], ctx.g, ctx.hx,
-                           ctx.hy, ctx.hz, ctx.nig2, node);
-        sc_kick_finish<T>(ctx, s, u, i0, node, out);
+    for (int k = 0; k < 8; ++k) a[k] = 0.0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const ScKickCtx<T>& c = ctx;
+        const int64_t w0 = (((int64_t)blockIdx.x * 4 + wave) * R + r) * 64;      // first row of this wave's segment
+        const int wvalid = (N - w0 <= 0) ? 0 : (int)((N - w0 < 64) ? (N - w0) : 64);
+        if (wvalid == 0) break;                           // (wave-uniform)
+        wave_tile_load<T>(src + w0 * 7, wlds, wvalid * 7, vin, true);
+        chx_wave_sync();
+        const bool active = lane < wvalid;
+        T out[7];
+        if (active) {
+            double v[7], s[7], u[3];
+            int i0[3], cn[3];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = (double)wlds[lane * 7 + j];
+            sc_kick_locate<T>(c, v, s, u, i0, cn);
+            PhiNode<T> node[8];
+            phi_cell_forces<T>(phi + ((int64_t)(cn[0] + 2) * py + (cn[1] + 2) * pz + (cn[2] + 2)), py, pz, cn[0], cn[1], cn[2], c.g,
+                               c.hx, c.hy, c.hz, c.nig2, node);
+            sc_kick_finish<T>(c, s, u, i0, node, out);
+        }
+        if (sigma_partials && active) {
+            // the rows written here are the beam the NEXT kick of the chain sees: its three variances (space_charge_kick.py:531-538)
+            // are accumulated on the way — the sums of sc_sigma_kernel about the origin instead of about the first particle
+            const double w = (double)ws2[(int64_t)par * N + w0 + lane];
+            const double d0 = (double)out[0], d1 = (double)out[2], d2 = (double)out[4];
+            a[0] += w;
+            a[1] += w * w;
+            const double w0d = w * d0, w1d = w * d1, w2d = w * d2;
+            a[2] += w0d; a[3] += w1d; a[4] += w2d;
+            a[5] += w0d * d0; a[6] += w1d * d1; a[7] += w2d * d2;
+        }
+        if (mode == 0) {
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) wlds[lane * 7 + j] = out[j];
+            }
+            chx_wave_sync();
+            wave_tile_store<T>(x_out + w0 * 7, wlds, wvalid * 7, vout, true);
+            chx_wave_sync();
+        } else {
+            const int64_t dst = sc_row_dest<T>(active, w0 + lane, mode, par, N, perm2, home, cursor, ws2, cs2, perm2);
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) x_out[dst * 7 + j] = out[j];
+            }
+        }
     }
     if (sigma_partials) {
-        // the rows written here are the beam the NEXT kick of the chain sees: its three variances (space_charge_kick.py:531-538)
-        // are accumulated on the way — the sums of sc_sigma_kernel about the origin instead of about the first particle
-        double a[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = 0.0;
-        if (active) {
-            const double w = (double)ws2[(int64_t)par * N + n0 + p];
-            const double d0 = (double)out[0], d1 = (double)out[2], d2 = (double)out[4];
-            a[0] = w;
-            a[1] = w * w;
-            const double w0 = w * d0, w1 = w * d1, w2 = w * d2;
-            a[2] = w0; a[3] = w1; a[4] = w2;
-            a[5] = w0 * d0; a[6] = w1 * d1; a[7] = w2 * d2;
-        }
         chx_block_sum<8>(a, red);
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -864,20 +889,6 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
 #pragma unroll
                 for (int k = 0; k < 8; ++k) unsafeAtomicAdd(&sums_add[k * 256 + (blockIdx.x & 255)], a[k]);
             }
-        }
-    }
-    if (mode == 0) {
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = out[j];
-        }
-        chx_wave_sync();
-        wave_tile_store<T>(x_out + (n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vout, true);
-    } else {
-        const int64_t dst = sc_row_dest<T>(active, n0 + p, mode, par, N, perm2, home, cursor, ws2, cs2, perm2);
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) x_out[dst * 7 + j] = out[j];
         }
     }
 }
@@ -906,21 +917,22 @@ int chx_sc_tile_gather_kick_chain(const void* rows, const void* phi_halo, const 
     if (state_bytes < L.total) return CHX_ERR_WORKSPACE;
     char* st = (char*)state;
     if (!rows) rows = st + L.rows_tmp;                    // the rows the sort of the first kick wrote
-    const unsigned nwg = (unsigned)((N + CHX_BLOCK - 1) / CHX_BLOCK);
+    const unsigned nwg = (unsigned)L.sigma_blocks;        // kScGatherRows rows per workgroup
     hipStream_t s = (hipStream_t)stream;
     const ScTileHeader* hdr = (const ScTileHeader*)(st + L.hdr);
     const bool with_sums = sums_set >= 0 && !unpermute;
     double* sums_add = with_sums ? (double*)(st + L.sums[sums_set & 1]) : nullptr;
     double* sums_clear = with_sums ? (double*)(st + L.sums[(sums_set & 1) ^ 1]) : nullptr;
+    constexpr int R = kScGatherRows / CHX_BLOCK;
     if (dtype == CHX_F32)
-        hipLaunchKernelGGL(sc_tile_particle_kernel<float>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const float*)rows, hdr, (int*)(st + L.perm[0]),
+        hipLaunchKernelGGL((sc_tile_particle_kernel<float, R>), dim3(nwg), dim3(CHX_BLOCK), 0, s, (const float*)rows, hdr, (int*)(st + L.perm[0]),
                            (float*)(st + L.ws[0]), (float*)(st + L.cs[0]), (const uint16_t*)(st + L.home), (int*)(st + L.cursor),
                            (const float*)phi_halo, (const float*)half, (const float*)cell, (const float*)energy, (const float*)dt,
                            (const float*)gamma, mass_eV, N, bins[0], bins[1], bins[2], (float*)x_out, (const float*)post_map, unpermute,
                            unpermute ? nullptr : (double*)(st + L.sigma), (int*)(st + L.newcount), tg.nt, (int*)(st + L.mis), sums_add,
                            sums_clear);
     else
-        hipLaunchKernelGGL(sc_tile_particle_kernel<double>, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const double*)rows, hdr,
+        hipLaunchKernelGGL((sc_tile_particle_kernel<double, R>), dim3(nwg), dim3(CHX_BLOCK), 0, s, (const double*)rows, hdr,
                            (int*)(st + L.perm[0]), (double*)(st + L.ws[0]), (double*)(st + L.cs[0]), (const uint16_t*)(st + L.home),
                            (int*)(st + L.cursor), (const double*)phi_halo, (const double*)half, (const double*)cell,
                            (const double*)energy, (const double*)dt, (const double*)gamma, mass_eV, N, bins[0], bins[1], bins[2],

@@ -487,11 +487,18 @@ int chx_sc_kick(const void* x_in, const void* charge, const void* survival, cons
  *  - flags: CHX_SC_FIRST (1) x_in, charge, survival are the caller's arrays in the caller's order — sort; otherwise x_in is the
  *    x_out of the previous kick of the chain (possibly mapped through linear elements) and charge / survival are ignored;
  *    CHX_SC_LAST (2) x_out is written in the caller's particle order (else in tile order);
+ *    CHX_SC_INDEX(i) (bits 8..): the kick's position in its chain, 0 for the first. With it (fp32 beams, grid edges up to 128 along
+ *    x) the kicks from the second one on launch NO one-workgroup kernels: the grid geometry is formed inside the deposit and the
+ *    Green function's corner-table launches from sums the previous kick's gather pass adds up with fp64 atomics, and the deposit's
+ *    bookkeeping rides in the convolution's first FFT pass (csrc/chx_sc_geom_dev.h: 13 launches per kick instead of 15). The
+ *    sums' last bits depend on the order of the atomics, like the charge grid's. Without an index (0) every kick launches the
+ *    geometry and bookkeeping kernels. An indexed kick must not be handed beam_moments (chx_sc_kick_sorted_begin);
  *  - post_map (may be NULL): the linear run behind the kick, applied in the same particle pass (as chx_sc_kick).
  * The pieces are entry points of their own: chx_sc_beam_geometry_tiles (= chx_sc_beam_geometry + the header update),
  * chx_sc_tile_sort, chx_sc_tile_deposit (rho[gx][gy][gz], every cell stored: no zero fill), chx_sc_tile_gather_kick. */
 #define CHX_SC_FIRST 1
 #define CHX_SC_LAST 2
+#define CHX_SC_INDEX(i) ((int)(i) << 8)
 size_t chx_sc_tile_state_bytes(int64_t N, const int32_t* bins, int dtype);
 size_t chx_sc_kick_sorted_workspace_bytes(int64_t N, const int32_t* bins, int dtype);
 int chx_sc_kick_sorted(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
