@@ -816,6 +816,202 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
     tile_store<T, TP>(x_out + n0 * 7, lds, np * 7, out_vec_ok != 0 && row_vec, true);
 }
 
+// The same pass for a SCAN: B rows of lattice settings over ONE shared beam (x_in[N][7]; the maps of item i and row b at Rs[i * B + b]),
+// no screens. Built like apply_shared_wave_kernel: a workgroup keeps its PPT * 256 particles in registers and walks a chunk of rows;
+// every wave owns PPT * 64 consecutive particles, puts its outgoing rows into its own LDS slice and streams them out as 16-byte
+// chunks — no workgroup barrier per row, the four waves drift apart and their stores overlap the others' maps and monitor sums.
+// (lattice_apply_kernel takes one (tile, row) per workgroup: 8e5 short workgroups for 4096 x 1e5, each a load -> barrier -> maps ->
+// barrier -> store chain; 2.69 ms with one monitor where the plain shared-beam apply takes 2.07.) Needs every row of the output to
+// start on a 16-byte boundary. Per particle the arithmetic of lattice_apply_kernel, item by item; a monitor's per-wave sums cover
+// other particles than there (a wave = PPT * 64 consecutive particles), the finalize kernel adds them up all the same.
+template <typename T, int PPT>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* __restrict__ x_in, T* __restrict__ x_out,
+                                                                     const int64_t* __restrict__ items, int n_items,
+                                                                     const double* __restrict__ Rs, const double* __restrict__ coeffs,
+                                                                     int64_t N, int64_t B, int64_t rows_per_chunk, int in_vec_ok,
+                                                                     const T* __restrict__ survival, double* __restrict__ bpm_ws, int diag,
+                                                                     const int64_t* __restrict__ ptrs, T* __restrict__ survival_out,
+                                                                     int shared_sv) {
+    using V = typename chx_vec16<T>::type;
+    constexpr int VN = chx_vec16<T>::n;
+    constexpr int TP = PPT * CHX_BLOCK;
+    constexpr int WP = PPT * 64;                 // particles per wave
+    constexpr int WE = WP * 7;                   // elements per wave
+    constexpr int WV = WE / VN;                  // 16-byte chunks per wave
+    __shared__ __attribute__((aligned(16))) T lds[TP * 7];
+    const int64_t t0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - t0 < TP) ? (N - t0) : TP);
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t b1 = (b0 + rows_per_chunk < B) ? b0 + rows_per_chunk : B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    tile_load<T, TP>(x_in + t0 * 7, lds, np * 7, in_vec_ok != 0, false);      // (re-read by every chunk of rows: no streaming hint)
+    __syncthreads();
+    T x0[PPT][7];
+    T* wl = lds + wave * WE;                      // this wave's slice: particles t0 + wave * WP + [0, WP)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = wave * WP + k * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) x0[k][j] = (p < np) ? wl[(k * 64 + lane) * 7 + j] : (T)0;
+    }
+    T sv0[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = wave * WP + k * 64 + lane;
+        sv0[k] = (p < np) ? ((survival && shared_sv) ? survival[t0 + p] : (T)1) : (T)0;
+    }
+    // from here on a wave touches only its own slice
+    const int valid = (np - wave * WP < 0) ? 0 : ((np - wave * WP < WP) ? (np - wave * WP) : WP);   // particles of this wave that exist
+    const int vchunks = valid * 7 / VN;           // whole chunks inside the valid rows
+    const int64_t nw = (int64_t)gridDim.x * (CHX_BLOCK / 64);            // waves per row
+    const int64_t nw_all = nw * B;
+    for (int64_t b = b0; b < b1; ++b) {
+        T x[PPT][7], sv[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) x[k][j] = x0[k][j];
+            sv[k] = sv0[k];
+        }
+        if (diag && survival && !shared_sv) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = wave * WP + k * 64 + lane;
+                sv[k] = (p < np) ? survival[b * N + t0 + p] : (T)0;
+            }
+        }
+        const int64_t wslot = b * nw + (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave;
+        bool sw_known = false;
+        double sw = 0.0;
+        for (int i = 0; i < n_items; ++i) {
+            const int type = (int)items[i * 4];
+            if (type == 2) {                         // active monitor (bpm.py:77-87): the wave's sums of w, w x, w y
+                double sx = 0.0, sy = 0.0;
+                if (!sw_known) {
+                    sw = 0.0;
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) sw += (double)sv[k];
+                    sw = chx_wave_sum_lane63(sw);
+                    sw_known = true;
+                }
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const double w = (double)sv[k];
+                    sx = fma(w, (double)x[k][0], sx);
+                    sy = fma(w, (double)x[k][2], sy);
+                }
+                sx = chx_wave_sum_lane63(sx);
+                sy = chx_wave_sum_lane63(sy);
+                if (lane == 63) {
+                    double* part = bpm_ws + ((int64_t)items[i * 4 + 3] * nw_all + wslot) * 3;
+                    part[0] = sw;
+                    part[1] = sx;
+                    part[2] = sy;
+                }
+                continue;
+            }
+            if (type == 3) {                         // active aperture (aperture.py:90-135)
+                const int64_t q = items[i * 4 + 2];
+                const T x_max = *(const T*)ptrs[q], y_max = *(const T*)ptrs[q + 1];
+                const bool elliptical = items[i * 4 + 1] != 0;
+                const T x_max2 = x_max * x_max, y_max2 = y_max * y_max;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const T px = x[k][0], py = x[k][2];
+                    bool inside;
+                    if (elliptical) {
+                        const T a = (px * px) / x_max2;
+                        const T c = (py * py) / y_max2;
+                        inside = (a + c) <= (T)1;
+                    } else {
+                        inside = (px > -x_max) && (px < x_max) && (py > -y_max) && (py < y_max);
+                    }
+                    sv[k] = sv[k] * (inside ? (T)1 : (T)0);
+                }
+                sw_known = false;
+                continue;
+            }
+            const int64_t mrow = (int64_t)i * B + b;
+            const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
+            const bool cavity = type == 1;
+            const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
+            if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
+                // two of the lane's particles per register pair: every step of apply7's fmaf chain is ONE v_pk_fma_f32 for both
+#pragma unroll
+                for (int k = 0; k < PPT; k += 2) {
+                    chx_v2f xp[7], y[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) xp[j] = chx_v2f{x[k][j], x[k + 1][j]};
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) {
+                        chx_v2f acc = xp[0] * R[r * 7];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) {
+                            const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
+                            acc = __builtin_elementwise_fma(m, xp[j], acc);
+                        }
+                        y[r] = acc;
+                    }
+                    T y0[7], y1[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        y0[j] = y[j].x;
+                        y1[j] = y[j].y;
+                    }
+                    if (cavity) {
+                        cavity_epilogue<T>(c, x[k], y0);
+                        cavity_epilogue<T>(c, x[k + 1], y1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        x[k][j] = y0[j];
+                        x[k + 1][j] = y1[j];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    T y[7];
+                    apply7<T>(R, x[k], y);
+                    if (cavity) cavity_epilogue<T>(c, x[k], y);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+                }
+            }
+        }
+        if (survival_out) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = wave * WP + k * 64 + lane;
+                if (p < np) survival_out[b * N + t0 + p] = sv[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) wl[(k * 64 + lane) * 7 + j] = x[k][j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T* __restrict__ gout = x_out + (b * N + t0 + wave * WP) * 7;
+        V* __restrict__ gv = reinterpret_cast<V*>(gout);
+        const V* lv = reinterpret_cast<const V*>(wl);
+#pragma unroll
+        for (int cidx = 0; cidx < (WV + 63) / 64; ++cidx) {
+            const int v = cidx * 64 + lane;
+            if (v < vchunks) chx_nt_store(lv[v], gv + v);
+        }
+        if (vchunks < WV) {                       // the last tile of a row: a few elements beyond the last whole chunk
+            for (int e = vchunks * VN + lane; e < valid * 7; e += 64) gout[e] = wl[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // one workgroup per monitor and beam: W and the two sums over the waves' shares (fixed order: thread t takes shares t, t + 256, ...),
 // reading = (T)(sum / W) - misalignment, the subtraction in T like `incoming.mu_x - self.misalignment[..., 0]` (bpm.py:80-85)
 template <typename T>
@@ -891,6 +1087,44 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
     const int64_t nw = (int64_t)grid.x * (CHX_BLOCK / 64);
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
     const int diag = (n_bpm > 0 || survival_out || n_screens > 0) ? 1 : 0;
+    // a scan of lattice settings over one shared beam: workgroups that keep their particles and walk a chunk of rows, wave-private
+    // output staging (lattice_scan_wave_kernel) — when every row of the output starts on a 16-byte boundary
+    static const bool scan_wave = [] { const char* e = getenv("CHX_TUNE_SCAN_WAVE"); return !(e && e[0] == '0'); }();
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    if (scan_wave && shared_in && Bm == B && B >= 8 && n_screens == 0 && chx_aligned16(x_out) && (N * 7 * (int64_t)esz) % 16 == 0 &&
+        (dtype == CHX_F32 || dtype == CHX_F64)) {
+        const int wppt = 16 / (int)esz;
+        const int64_t wtp = (int64_t)wppt * CHX_BLOCK;
+        const int64_t wtiles = (N + wtp - 1) / wtp;
+        static const int64_t scan_wgs = [] { const char* e = getenv("CHX_TUNE_SCAN_WGS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 8192); }();
+        int64_t wchunks = (scan_wgs + wtiles - 1) / wtiles;
+        if (wchunks > B) wchunks = B;
+        int64_t wrows = (B + wchunks - 1) / wchunks;
+        if (wrows < 8) wrows = 8;
+        wchunks = (B + wrows - 1) / wrows;
+        if (wtiles > 0x7fffffffLL || wchunks > 65535) return CHX_ERR_INVALID_ARG;
+        const dim3 wgrid((unsigned)wtiles, (unsigned)wchunks);
+        const int64_t wnw = wtiles * (CHX_BLOCK / 64);
+        if (dtype == CHX_F32) {
+            hipLaunchKernelGGL((lattice_scan_wave_kernel<float, 4>), wgrid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
+                               (int)n_items, Rs, coeffs, N, B, wrows, iv, (const float*)survival, (double*)workspace, diag, ptrs,
+                               (float*)survival_out, shared_sv);
+            CHX_CHECK_LAUNCH();
+            if (n_bpm > 0)
+                hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table,
+                                   (int)n_items, ptrs, (const double*)workspace, wnw, (float*)readings);
+        } else {
+            hipLaunchKernelGGL((lattice_scan_wave_kernel<double, 2>), wgrid, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out,
+                               table, (int)n_items, Rs, coeffs, N, B, wrows, iv, (const double*)survival, (double*)workspace, diag, ptrs,
+                               (double*)survival_out, shared_sv);
+            CHX_CHECK_LAUNCH();
+            if (n_bpm > 0)
+                hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table,
+                                   (int)n_items, ptrs, (const double*)workspace, wnw, (double*)readings);
+        }
+        CHX_CHECK_LAUNCH();
+        return CHX_OK;
+    }
 #define CHX_LATTICE_APPLY_S(T, PPT, SCR)                                                                                            \
     hipLaunchKernelGGL((lattice_apply_kernel<T, PPT, SCR>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out, table,          \
                        (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs, (T*)survival_out,   \

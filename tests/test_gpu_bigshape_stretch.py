@@ -137,7 +137,12 @@ def _row_specs(specs, b, rows):
     (torch.float32, 3, 64, 70_001, (0, 3, 17, 63)), (torch.float32, 5, 64, 70_001, (1, 40)), (torch.float64, 5, 64, 70_001, (2, 63)),
     (torch.float32, 1, 64, 70_001, (0, 33)), (torch.float32, 4, 4096, 100_000, (0, 3, 2047, 4095)),
     # seven monitors, thousands of rows: the lanes keep their own sums over the tiles of a row (`lattice_apply_kernel<T, 2, 0, 1>`)
-    (torch.float32, 0, 4096, 100_000, (0, 1, 2047, 4095)), (torch.float64, 0, 1024, 50_003, (2, 1023))])
+    (torch.float32, 0, 4096, 100_000, (0, 1, 2047, 4095)), (torch.float64, 0, 1024, 50_003, (2, 1023)),
+    # rows that start on 16-byte boundaries take `lattice_scan_wave_kernel` (a workgroup keeps its particles and walks a chunk of
+    # rows, wave-private output staging): cavities + monitors + apertures, a last tile with 1 / 2 / 3 of a wave's 4 x 64 particles,
+    # float64 (two particles per lane), a chunk of rows that does not divide the scan
+    (torch.float32, 3, 64, 70_000, (0, 3, 17, 63)), (torch.float32, 5, 64, 70_084, (1, 40, 63)), (torch.float64, 5, 64, 70_002, (2, 63)),
+    (torch.float32, 1, 67, 70_212, (0, 33, 66)), (torch.float64, 0, 1024, 50_004, (2, 1023))])
 def test_big_scans_vs_reference_and_oracle(dt, lattice, rows, n, check_rows, oracle):
     import cheetah_amd as ca
     from cheetah_amd.accelerator import segment
