@@ -1089,10 +1089,14 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
     const int diag = (n_bpm > 0 || survival_out || n_screens > 0) ? 1 : 0;
     // a scan of lattice settings over one shared beam: workgroups that keep their particles and walk a chunk of rows, wave-private
     // output staging (lattice_scan_wave_kernel) — when every row of the output starts on a 16-byte boundary
-    static const bool scan_wave = [] { const char* e = getenv("CHX_TUNE_SCAN_WAVE"); return !(e && e[0] == '0'); }();
+    // From 8e6 particle rows on (benchmarks/scan_wave_crossover.py: 64 x 1e5 a tie, 1024 x 1e4 0.113 -> 0.100 ms, 64 x 1e6 0.64 -> 0.36;
+    // below, its 1024-particle workgroups are too few for a lattice with many items: a 16-cavity linac at 64 energies x 1e4 particles
+    // 154 -> 172 us). CHX_TUNE_SCAN_WAVE=0 / 2 (tests, benchmarks): never / whenever the layout allows.
+    const char* scan_env = getenv("CHX_TUNE_SCAN_WAVE");
+    const int scan_wave = scan_env ? atoi(scan_env) : 1;
     const size_t esz = dtype == CHX_F32 ? 4 : 8;
-    if (scan_wave && shared_in && Bm == B && B >= 8 && n_screens == 0 && chx_aligned16(x_out) && (N * 7 * (int64_t)esz) % 16 == 0 &&
-        (dtype == CHX_F32 || dtype == CHX_F64)) {
+    if (scan_wave != 0 && (scan_wave == 2 || B * N >= 8000000) && shared_in && Bm == B && B >= 8 && n_screens == 0 &&
+        chx_aligned16(x_out) && (N * 7 * (int64_t)esz) % 16 == 0 && (dtype == CHX_F32 || dtype == CHX_F64)) {
         const int wppt = 16 / (int)esz;
         const int64_t wtp = (int64_t)wppt * CHX_BLOCK;
         const int64_t wtiles = (N + wtp - 1) / wtp;
@@ -1100,7 +1104,8 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
         int64_t wchunks = (scan_wgs + wtiles - 1) / wtiles;
         if (wchunks > B) wchunks = B;
         int64_t wrows = (B + wchunks - 1) / wchunks;
-        if (wrows < 8) wrows = 8;
+        static const int64_t scan_min_rows = [] { const char* e = getenv("CHX_TUNE_SCAN_MIN_ROWS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 1); }();
+        if (wrows < scan_min_rows) wrows = scan_min_rows;
         wchunks = (B + wrows - 1) / wrows;
         if (wtiles > 0x7fffffffLL || wchunks > 65535) return CHX_ERR_INVALID_ARG;
         const dim3 wgrid((unsigned)wtiles, (unsigned)wchunks);
