@@ -824,7 +824,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
 // barrier -> store chain; 2.69 ms with one monitor where the plain shared-beam apply takes 2.07.) Needs every row of the output to
 // start on a 16-byte boundary. Per particle the arithmetic of lattice_apply_kernel, item by item; a monitor's per-wave sums cover
 // other particles than there (a wave = PPT * 64 consecutive particles), the finalize kernel adds them up all the same.
-template <typename T, int PPT>
+// CAV false: the caller vouches that the stretch holds no cavity (chx_lattice_prepare_rows' small_runs) — without the fp64 cosine of the
+// cavity epilogue the kernel keeps a map's 49 entries in scalar registers in one piece.
+template <typename T, int PPT, bool CAV>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* __restrict__ x_in, T* __restrict__ x_out,
                                                                      const int64_t* __restrict__ items, int n_items,
                                                                      const double* __restrict__ Rs, const double* __restrict__ coeffs,
@@ -934,39 +936,44 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
             }
             const int64_t mrow = (int64_t)i * B + b;
             const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
-            const bool cavity = type == 1;
+            const bool cavity = CAV && type == 1;
             const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
             if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
-                // two of the lane's particles per register pair: every step of apply7's fmaf chain is ONE v_pk_fma_f32 for both
+                // two of the lane's particles per register pair: every step of apply7's fmaf chain is ONE v_pk_fma_f32 for both; matrix
+                // row by matrix row over ALL pairs, so that a map entry is fetched once per item (pair by pair the compiler, short of
+                // scalar registers, fetched the 49 entries in four pieces per pair, each waited for on the spot)
+                chx_v2f xp[PPT / 2][7], y[PPT / 2][7];
 #pragma unroll
-                for (int k = 0; k < PPT; k += 2) {
-                    chx_v2f xp[7], y[7];
+                for (int pr = 0; pr < PPT / 2; ++pr)
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) xp[j] = chx_v2f{x[k][j], x[k + 1][j]};
+                    for (int j = 0; j < 7; ++j) xp[pr][j] = chx_v2f{x[2 * pr][j], x[2 * pr + 1][j]};
 #pragma unroll
-                    for (int r = 0; r < 7; ++r) {
-                        chx_v2f acc = xp[0] * R[r * 7];
+                for (int r = 0; r < 7; ++r) {
 #pragma unroll
-                        for (int j = 1; j < 7; ++j) {
-                            const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
-                            acc = __builtin_elementwise_fma(m, xp[j], acc);
-                        }
-                        y[r] = acc;
+                    for (int pr = 0; pr < PPT / 2; ++pr) y[pr][r] = xp[pr][0] * R[r * 7];
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) {
+                        const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
+#pragma unroll
+                        for (int pr = 0; pr < PPT / 2; ++pr) y[pr][r] = __builtin_elementwise_fma(m, xp[pr][j], y[pr][r]);
                     }
+                }
+#pragma unroll
+                for (int pr = 0; pr < PPT / 2; ++pr) {
                     T y0[7], y1[7];
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        y0[j] = y[j].x;
-                        y1[j] = y[j].y;
+                        y0[j] = y[pr][j].x;
+                        y1[j] = y[pr][j].y;
                     }
                     if (cavity) {
-                        cavity_epilogue<T>(c, x[k], y0);
-                        cavity_epilogue<T>(c, x[k + 1], y1);
+                        cavity_epilogue<T>(c, x[2 * pr], y0);
+                        cavity_epilogue<T>(c, x[2 * pr + 1], y1);
                     }
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        x[k][j] = y0[j];
-                        x[k + 1][j] = y1[j];
+                        x[2 * pr][j] = y0[j];
+                        x[2 * pr + 1][j] = y1[j];
                     }
                 }
             } else {
@@ -1109,9 +1116,14 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
         wchunks = (B + wrows - 1) / wrows;
         if (wtiles > 0x7fffffffLL || wchunks > 65535) return CHX_ERR_INVALID_ARG;
         const dim3 wgrid((unsigned)wtiles, (unsigned)wchunks);
+#define CHX_SCAN_LAUNCH(T, PPT, ...)                                                                        \
+    do {                                                                                                    \
+        if (small_runs) hipLaunchKernelGGL((lattice_scan_wave_kernel<T, PPT, false>), wgrid, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((lattice_scan_wave_kernel<T, PPT, true>), wgrid, __VA_ARGS__);              \
+    } while (0)
         const int64_t wnw = wtiles * (CHX_BLOCK / 64);
         if (dtype == CHX_F32) {
-            hipLaunchKernelGGL((lattice_scan_wave_kernel<float, 4>), wgrid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
+            CHX_SCAN_LAUNCH(float, 4, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
                                (int)n_items, Rs, coeffs, N, B, wrows, iv, (const float*)survival, (double*)workspace, diag, ptrs,
                                (float*)survival_out, shared_sv);
             CHX_CHECK_LAUNCH();
@@ -1119,7 +1131,7 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
                 hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table,
                                    (int)n_items, ptrs, (const double*)workspace, wnw, (float*)readings);
         } else {
-            hipLaunchKernelGGL((lattice_scan_wave_kernel<double, 2>), wgrid, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out,
+            CHX_SCAN_LAUNCH(double, 2, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out,
                                table, (int)n_items, Rs, coeffs, N, B, wrows, iv, (const double*)survival, (double*)workspace, diag, ptrs,
                                (double*)survival_out, shared_sv);
             CHX_CHECK_LAUNCH();
@@ -1128,6 +1140,7 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
                                    (int)n_items, ptrs, (const double*)workspace, wnw, (double*)readings);
         }
         CHX_CHECK_LAUNCH();
+#undef CHX_SCAN_LAUNCH
         return CHX_OK;
     }
 #define CHX_LATTICE_APPLY_S(T, PPT, SCR)                                                                                            \
