@@ -43,6 +43,12 @@ int chx_cavity_coeffs_cpu(const void* params /*[Bp][4]*/, const void* energy /*[
 int chx_cavity_track_cpu(const void* x_in, const void* R, const double* coeffs, void* x_out,
                          int64_t B, int64_t Bx, int64_t N, int dtype, void* stream);
 int chx_hist2d_cpu(const chx_hist2d_args* args, void* stream);
+/* chx_sc_kick on host pointers (stream / side_stream / workspace ignored; the Poisson solve in double like the oracle's) */
+size_t chx_sc_kick_workspace_bytes_cpu(int64_t B, int64_t N, const int32_t* bins, int dtype);
+int chx_sc_kick_cpu(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                    const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
+                    const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
+                    void* side_stream, const void* post_map /*[BR][7][7] or NULL*/, int64_t BR);
 #ifdef __cplusplus
 }
 #endif

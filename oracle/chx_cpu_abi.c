@@ -150,3 +150,163 @@ CPU_API int chx_hist2d_cpu(const chx_hist2d_args* p, void* stream) {
     return chxo_hist2d(p->x, p->charge, p->survival, p->shift, p->edges_x, p->edges_y, p->B, p->Bx, p->Bq, p->Bs, p->Bsh, p->N, p->nx,
                        p->ny, p->dtype, p->image, NULL) == 0 ? CHX_OK : CHX_ERR_INVALID_ARG;
 }
+
+/* ---- chx_sc_kick: SpaceChargeKick.track (space_charge_kick.py:477-586) on host pointers ---------------------------------------------
+ * beam sizes -> grid (:531-550) -> cloud-in-cell charge (:556-563) -> integrated Green function on the doubled grid (:163-291) ->
+ * cyclic convolution (:293-322; radix-2 transforms below, the grids are powers of two like the device path's) -> field (:324-385) ->
+ * trilinear gather + kick (:387-475, :548-584) -> optional linear map behind the kick (the device entry point's post_map). The steps
+ * and their working precisions are those of oracle/chx_oracle.py `space_charge_kick` (index / weight arithmetic of the deposit in the
+ * beam dtype, the Poisson solve in double). */
+static void fft1d(double* re, double* im, int n, int64_t stride, int inverse) {
+    for (int i = 1, j = 0; i < n; ++i) {                       /* bit reversal */
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i * stride]; re[i * stride] = re[j * stride]; re[j * stride] = t;
+            t = im[i * stride]; im[i * stride] = im[j * stride]; im[j * stride] = t;
+        }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = (inverse ? 2.0 : -2.0) * kPi / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * k), wi = sin(ang * k);
+                const int64_t a = (int64_t)(i + k) * stride, b = (int64_t)(i + k + len / 2) * stride;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+
+static void fft3d(double* re, double* im, int nx, int ny, int nz, int inverse) {
+    const int64_t sy = nz, sx = (int64_t)ny * nz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < ny; ++j) fft1d(re + i * sx + j * sy, im + i * sx + j * sy, nz, 1, inverse);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < nx; ++i)
+        for (int k = 0; k < nz; ++k) fft1d(re + i * sx + k, im + i * sx + k, ny, sy, inverse);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int j = 0; j < ny; ++j)
+        for (int k = 0; k < nz; ++k) fft1d(re + j * sy + k, im + j * sy + k, nx, sx, inverse);
+}
+
+static int pow2_grid(int g) { return g >= 16 && g <= 512 && (g & (g - 1)) == 0; }
+
+CPU_API size_t chx_sc_kick_workspace_bytes_cpu(int64_t B, int64_t N, const int32_t* bins, int dtype) {
+    (void)N;
+    return (B >= 1 && bins && (dtype == CHX_F32 || dtype == CHX_F64) && pow2_grid(bins[0]) && pow2_grid(bins[1]) && pow2_grid(bins[2])) ? 256 : 0;
+}
+
+CPU_API int chx_sc_kick_cpu(const void* x_in, const void* charge, const void* survival, const void* energy, const void* length,
+                            const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
+                            const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
+                            void* side_stream, const void* post_map, int64_t BR) {
+    (void)workspace; (void)workspace_bytes; (void)stream; (void)side_stream;
+    if (!x_in || !charge || !survival || !energy || !length || !grid_extent || !x_out || !bins) return CHX_ERR_INVALID_ARG;
+    if (B < 1 || N < 1 || !bcast_ok(Bx, B) || !bcast_ok(Bq, B) || !bcast_ok(Bs, B) || !bcast_ok(Bext, B)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (!pow2_grid(bins[0]) || !pow2_grid(bins[1]) || !pow2_grid(bins[2])) return CHX_ERR_INVALID_ARG;
+    if (post_map && !bcast_ok(BR, B)) return CHX_ERR_INVALID_ARG;
+    const int g[3] = {bins[0], bins[1], bins[2]};
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    const int64_t ncell = (int64_t)g[0] * g[1] * g[2], npad = 8 * ncell;
+    const int PX = 2 * g[0], PY = 2 * g[1], PZ = 2 * g[2];
+    int rc = CHX_ERR_WORKSPACE;
+    double* mom = (double*)malloc(sizeof(double) * (size_t)B * 29);
+    void* geo_T = malloc(esz * (size_t)B * 9);                 /* extent[B][3][2] | scale[B][3] in the beam dtype */
+    double* half = (double*)malloc(sizeof(double) * (size_t)B * 3);
+    double* cell = (double*)malloc(sizeof(double) * (size_t)B * 3);
+    double* cell_scaled = (double*)malloc(sizeof(double) * (size_t)B * 3);
+    double* gamma = (double*)malloc(sizeof(double) * (size_t)B);
+    double* en = (double*)malloc(sizeof(double) * (size_t)B);
+    double* dtk = (double*)malloc(sizeof(double) * (size_t)B);
+    void* rho = calloc((size_t)B * (size_t)ncell, esz);
+    double* G = (double*)malloc(sizeof(double) * (size_t)B * (size_t)npad);
+    double* gi = (double*)calloc((size_t)npad, sizeof(double));
+    double* pr = (double*)malloc(sizeof(double) * (size_t)npad);
+    double* pi = (double*)malloc(sizeof(double) * (size_t)npad);
+    double* phi = (double*)malloc(sizeof(double) * (size_t)B * (size_t)ncell);
+    double* F = (double*)malloc(sizeof(double) * (size_t)B * (size_t)ncell * 3);
+    void* kicked = post_map ? malloc(esz * (size_t)B * (size_t)N * 7) : NULL;
+    if (!mom || !geo_T || !half || !cell || !cell_scaled || !gamma || !en || !dtk || !rho || !G || !gi || !pr || !pi || !phi || !F ||
+        (post_map && !kicked))
+        goto done;
+    rc = CHX_ERR_INVALID_ARG;
+    if (chxo_moments(x_in, survival, B, Bx, Bs, N, dtype, mom) != 0) goto done;
+    for (int64_t b = 0; b < B; ++b) {
+        static const int diag[3] = {8, 19, 26};                /* cov_xx, cov_yy, cov_tautau in the [W, W2, mu(6), cov(21)] row */
+        en[b] = ld(energy, dtype, b);                            /* energy / length: one value per batch row */
+        gamma[b] = en[b] / mass_eV;
+        const double beta = sqrt(1.0 - 1.0 / (gamma[b] * gamma[b]));
+        dtk[b] = ld(length, dtype, b) / (kC * beta);           /* :548-550 */
+        for (int d = 0; d < 3; ++d) {
+            const double ext = ld(grid_extent, dtype, (Bext == 1 ? 0 : b) * 3 + d);
+            double h, c;
+            if (dtype == CHX_F32) {                               /* sigma, half, cell formed in the beam dtype (:531-547) */
+                const float sig = (float)sqrt(mom[b * 29 + diag[d]]);
+                const float hf = (float)ext * sig;
+                const float cf = (2.0f * hf) / (float)g[d];
+                h = hf; c = cf;
+            } else {
+                const double sig = sqrt(mom[b * 29 + diag[d]]);
+                h = ext * sig;
+                c = (2.0 * h) / (double)g[d];
+            }
+            half[b * 3 + d] = h;
+            cell[b * 3 + d] = c;
+            st(geo_T, dtype, b * 6 + d * 2, -h);
+            st(geo_T, dtype, b * 6 + d * 2 + 1, h);
+        }
+        for (int d = 0; d < 3; ++d) st((char*)geo_T + esz * (size_t)B * 6, dtype, b * 3 + d, d == 2 ? -beta : 1.0);   /* z = tau * -beta */
+        cell_scaled[b * 3] = cell[b * 3];
+        cell_scaled[b * 3 + 1] = cell[b * 3 + 1];
+        cell_scaled[b * 3 + 2] = dtype == CHX_F32 ? (double)((float)cell[b * 3 + 2] * (float)gamma[b]) : cell[b * 3 + 2] * gamma[b];   /* :170-176 */
+    }
+    {
+        chxo_cic_args a;
+        memset(&a, 0, sizeof(a));
+        a.ndim = 3;
+        a.cols[0] = 0; a.cols[1] = 2; a.cols[2] = 4;
+        for (int d = 0; d < 3; ++d) a.bins[d] = g[d];
+        a.B = B; a.Bx = Bx; a.Bq = Bq; a.Bs = Bs; a.Be = B; a.Bsc = B; a.Bsh = 1; a.N = N;
+        a.dtype = dtype; a.abs_charge = 0;
+        a.x = x_in; a.charge = charge; a.survival = survival; a.extent = geo_T; a.scale = (char*)geo_T + esz * (size_t)B * 6; a.shift = NULL;
+        if (chxo_cic_deposit(&a, rho) != 0) goto done;
+    }
+    if (chxo_sc_igf(cell_scaled, B, bins, G) != 0) goto done;
+    for (int64_t b = 0; b < B; ++b) {
+        const double inv_vol = 1.0 / (cell[b * 3] * cell[b * 3 + 1] * cell[b * 3 + 2]);      /* :144-146 */
+        memset(pr, 0, sizeof(double) * (size_t)npad);
+        memset(pi, 0, sizeof(double) * (size_t)npad);
+        for (int i = 0; i < g[0]; ++i)
+            for (int j = 0; j < g[1]; ++j)
+                for (int k = 0; k < g[2]; ++k)
+                    pr[((int64_t)i * PY + j) * PZ + k] = ld(rho, dtype, b * ncell + ((int64_t)i * g[1] + j) * g[2] + k) * inv_vol;
+        double* gr = G + b * npad;
+        memset(gi, 0, sizeof(double) * (size_t)npad);
+        fft3d(pr, pi, PX, PY, PZ, 0);
+        fft3d(gr, gi, PX, PY, PZ, 0);
+        for (int64_t q = 0; q < npad; ++q) {
+            const double ar = pr[q], ai = pi[q];
+            pr[q] = ar * gr[q] - ai * gi[q];
+            pi[q] = ar * gi[q] + ai * gr[q];
+        }
+        fft3d(pr, pi, PX, PY, PZ, 1);
+        const double norm = 1.0 / (double)npad / (4.0 * kPi * 8.8541878188e-12);             /* :306-316 */
+        for (int i = 0; i < g[0]; ++i)
+            for (int j = 0; j < g[1]; ++j)
+                for (int k = 0; k < g[2]; ++k)
+                    phi[b * ncell + ((int64_t)i * g[1] + j) * g[2] + k] = pr[((int64_t)i * PY + j) * PZ + k] * norm;
+    }
+    if (chxo_sc_gradient(phi, cell, gamma, B, bins, F) != 0) goto done;
+    if (chxo_sc_gather_kick(x_in, F, half, cell, en, dtk, mass_eV, B, Bx, B, N, bins, dtype, post_map ? kicked : x_out, NULL) != 0) goto done;
+    if (post_map && chxo_apply(kicked, post_map, x_out, B, B, BR, N, dtype, 1) != 0) goto done;
+    rc = CHX_OK;
+done:
+    free(mom); free(geo_T); free(half); free(cell); free(cell_scaled); free(gamma); free(en); free(dtk); free(rho); free(G); free(gi);
+    free(pr); free(pi); free(phi); free(F); free(kicked);
+    return rc;
+}

@@ -33,7 +33,7 @@ def test_every_twin_is_exported_with_the_signature_of_its_namesake():
     twins, abi = _decls("chx_cpu.h"), _decls("chx.h")
     assert set(twins) == {"chx_abi_version_cpu", "chx_build_rmatrix_cpu", "chx_compose_maps_cpu", "chx_apply_affine7_cpu",
                           "chx_moments_cpu", "chx_cic_deposit_cpu", "chx_track_elementwise_cpu", "chx_cavity_coeffs_cpu",
-                          "chx_cavity_track_cpu", "chx_hist2d_cpu"}
+                          "chx_cavity_track_cpu", "chx_hist2d_cpu", "chx_sc_kick_workspace_bytes_cpu", "chx_sc_kick_cpu"}
     norm = lambda sig: re.sub(r"\s*/\*.*?\*/", "", sig).replace(" ,", ",")  # noqa: E731
     for name, sig in twins.items():
         assert hasattr(lib, name), name
@@ -146,3 +146,52 @@ def test_tracking_cavity_and_histogram_twins_give_the_oracles_numbers(oracle):
         assert np.array_equal(image, ref) and image.sum() > 0
         a.dtype = 5
         assert lib.chx_hist2d_cpu(ctypes.byref(a), None) == -2
+
+
+def test_space_charge_kick_twin_gives_the_oracles_numbers(oracle):
+    """chx_sc_kick_cpu (space_charge_kick.py:477-586) through chx_sc_kick's argument list: the oracle's pipeline
+    (`chx_oracle.space_charge_kick`, pinned to the reference by tests/golden/space_charge*.npz in tests/test_oracle_golden.py) with the
+    cyclic convolution done by the twin's own radix-2 transforms instead of numpy.fft."""
+    lib = _lib()
+    lib.chx_sc_kick_workspace_bytes_cpu.restype = ctypes.c_size_t
+    rng = np.random.default_rng(21)
+    B, N, g = 2, 4000, (16, 16, 32)
+    bins = (ctypes.c_int32 * 3)(*g)
+    x64 = rng.standard_normal((B, N, 7)) * np.array([3e-4, 2e-5, 2e-4, 3e-5, 1e-4, 1e-3, 0.0])
+    x64[..., 6] = 1.0
+    x64[0, :20, 0] *= 8.0                                             # a few particles beyond the grid
+    q64 = np.full((B, N), -1e-9 / N)
+    w64 = np.where(rng.random((B, N)) < 0.1, 0.5, 1.0)
+    for dtype, code, tol in ((np.float64, 1, 1e-9), (np.float32, 0, 2e-5)):
+        x, q, w = x64.astype(dtype), q64.astype(dtype), w64.astype(dtype)
+        energy = np.array([5e7, 8e7], dtype=dtype)
+        length = np.array([0.2, 0.35], dtype=dtype)
+        ext = np.array([[3.0, 3.0, 3.0]], dtype=dtype)
+        ref = np.stack([oracle.space_charge_kick(x[b:b + 1], float(energy[b]), q[b:b + 1], w[b:b + 1], float(length[b]), grid_shape=g)[0]
+                        for b in range(B)])
+        assert lib.chx_sc_kick_workspace_bytes_cpu(i64(B), i64(N), bins, code) > 0
+        out = np.empty_like(x)
+        rc = lib.chx_sc_kick_cpu(_ptr(x), _ptr(q), _ptr(w), _ptr(energy), _ptr(length), _ptr(ext), dbl(oracle.ELECTRON_MASS_EV), i64(B), i64(B),
+                                 i64(B), i64(B), i64(1), i64(N), bins, code, _ptr(out), None, ctypes.c_size_t(0), None, None, None, i64(1))
+        assert rc == 0
+        kick_ref, kick = ref.astype(np.float64) - x, out.astype(np.float64) - x
+        scale = np.abs(kick_ref).max(axis=(0, 1))
+        assert scale[1] > 0 and scale[3] > 0 and scale[5] > 0           # the kick acts on px, py, delta
+        err = (np.abs(kick - kick_ref).max(axis=(0, 1))[[1, 3, 5]] / scale[[1, 3, 5]]).max()
+        assert err < tol, err
+        assert np.array_equal(out[..., [0, 2, 4, 6]], ref[..., [0, 2, 4, 6]])        # positions: the same round trip through SI units
+        # the linear run behind the kick, applied by the same call (fma chain of chx_apply_affine7_cpu)
+        R = (np.eye(7) + 0.05 * rng.standard_normal((7, 7))).astype(dtype)
+        R[6] = 0
+        R[6, 6] = 1
+        out2, chained = np.empty_like(x), np.empty_like(x)
+        assert lib.chx_sc_kick_cpu(_ptr(x), _ptr(q), _ptr(w), _ptr(energy), _ptr(length), _ptr(ext), dbl(oracle.ELECTRON_MASS_EV), i64(B), i64(B),
+                                   i64(B), i64(B), i64(1), i64(N), bins, code, _ptr(out2), None, ctypes.c_size_t(0), None, None, _ptr(R), i64(1)) == 0
+        assert lib.chx_apply_affine7_cpu(_ptr(out), _ptr(R), _ptr(chained), i64(B), i64(B), i64(1), i64(N), code, None) == 0
+        assert np.array_equal(out2, chained)
+    # argument checks of the namesake: a grid edge that is not a power of two >= 16, a dtype code that does not exist
+    bad = (ctypes.c_int32 * 3)(16, 24, 16)
+    assert lib.chx_sc_kick_cpu(_ptr(x), _ptr(q), _ptr(w), _ptr(energy), _ptr(length), _ptr(ext), dbl(oracle.ELECTRON_MASS_EV), i64(B), i64(B), i64(B),
+                               i64(B), i64(1), i64(N), bad, 0, _ptr(out), None, ctypes.c_size_t(0), None, None, None, i64(1)) == -1
+    assert lib.chx_sc_kick_cpu(_ptr(x), _ptr(q), _ptr(w), _ptr(energy), _ptr(length), _ptr(ext), dbl(oracle.ELECTRON_MASS_EV), i64(B), i64(B), i64(B),
+                               i64(B), i64(1), i64(N), bins, 7, _ptr(out), None, ctypes.c_size_t(0), None, None, None, i64(1)) == -2
