@@ -833,7 +833,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
                                                                      int64_t N, int64_t B, int64_t rows_per_chunk, int in_vec_ok,
                                                                      const T* __restrict__ survival, double* __restrict__ bpm_ws, int diag,
                                                                      const int64_t* __restrict__ ptrs, T* __restrict__ survival_out,
-                                                                     int shared_sv) {
+                                                                     int shared_sv, int transport /*monitors behind a linear prefix are
+                                                                     evaluated elsewhere (lattice_scan_bpm_transport_kernel)*/) {
     using V = typename chx_vec16<T>::type;
     constexpr int VN = chx_vec16<T>::n;
     constexpr int TP = PPT * CHX_BLOCK;
@@ -886,9 +887,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
         const int64_t wslot = b * nw + (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave;
         bool sw_known = false;
         double sw = 0.0;
+        bool linear = transport != 0;                // nothing but maps and monitors so far in this row's stretch
         for (int i = 0; i < n_items; ++i) {
             const int type = (int)items[i * 4];
+            if (type == 1 || type == 3) linear = false;
             if (type == 2) {                         // active monitor (bpm.py:77-87): the wave's sums of w, w x, w y
+                if (linear) continue;
                 double sx = 0.0, sy = 0.0;
                 if (!sw_known) {
                     sw = 0.0;
@@ -1019,14 +1023,101 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
     }
 }
 
+// ---- monitors behind a LINEAR prefix of a scan: readings by transporting the beam's first moments ------------------------------------
+// A monitor reads the weighted means of x and y AT its place (bpm.py:77-87). While everything in front of it in the stretch is linear
+// (runs of maps, other monitors: no cavity's cosine, no aperture's mask), the weighted mean of the tracked coordinates IS the
+// composed map applied to the weighted mean of the incoming beam (the 7th coordinate carries the affine part). For a scan of B rows
+// of settings over ONE shared float32 beam that replaces three fp64 wave sums per monitor, wave and row in the particle pass by
+// 8 sums over the shared beam, once, and one thread per row that takes the mean through the row's maps in fp64 — the maps the
+// particles see, float32-rounded — and evaluates every such monitor on the way.
+// What differs from summing the tracked float32 particles: their per-item rounding errors (0.5 ulp each, random in sign) are not in
+// the transported mean — ~1e-10 of the beam size after averaging over 1e5 particles, three orders below the float32 reading's own
+// resolution. float64 beams keep the particle sums (their readings are compared at 1e-15).
+constexpr int kScanSumBlocks = 64;
+
+// partials[kScanSumBlocks][8]: sum w, sum w x_j (j = 0..6) of the shared beam
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void scan_beam_sums_kernel(const T* __restrict__ x, const T* __restrict__ survival, int64_t N,
+                                                                  double* __restrict__ partials) {
+    __shared__ double red[4 * 8];
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * CHX_BLOCK) {
+        const double w = survival ? (double)survival[n] : 1.0;
+        a[0] += w;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a[1 + j] = fma(w, (double)x[n * 7 + j], a[1 + j]);
+    }
+    chx_block_sum<8>(a, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) partials[blockIdx.x * 8 + k] = a[k];
+    }
+}
+
+// one thread per row of settings: the beam's weighted mean through the row's maps item by item (fp64), the monitors evaluated on the
+// way while the prefix is linear
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_bpm_transport_kernel(const int64_t* __restrict__ items, int n_items,
+                                                                              const int64_t* __restrict__ ptrs, const double* __restrict__ Rs,
+                                                                              const double* __restrict__ partials, int nblk, int64_t B,
+                                                                              T* __restrict__ readings) {
+    __shared__ double mean[8];
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+        for (int k = 0; k < nblk; ++k) t += partials[k * 8 + threadIdx.x];
+        mean[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * CHX_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const double W = mean[0];
+    double v[7];                                   // the weighted mean of the beam at the current place of the row's lattice
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = mean[1 + j] / W;
+    for (int i = 0; i < n_items; ++i) {
+        const int type = (int)items[i * 4];
+        if (type == 1 || type == 3) return;        // a cavity / an aperture: the monitors behind it take the particle sums
+        if (type == 2) {
+            const T* mis = (const T*)ptrs[items[i * 4 + 2]];
+            T* r = readings + ((int64_t)items[i * 4 + 3] * B + b) * 2;
+            r[0] = (T)v[0] - mis[0];
+            r[1] = (T)v[2] - mis[1];
+            continue;
+        }
+        if (type != 0) continue;
+        const T* __restrict__ R = reinterpret_cast<const T*>(Rs + ((int64_t)i * B + b) * 49);
+        double y[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            double acc = (double)R[r * 7] * v[0];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) acc = fma((double)R[r * 7 + j], v[j], acc);
+            y[r] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[j] = y[j];
+    }
+}
+
 // one workgroup per monitor and beam: W and the two sums over the waves' shares (fixed order: thread t takes shares t, t + 256, ...),
 // reading = (T)(sum / W) - misalignment, the subtraction in T like `incoming.mu_x - self.misalignment[..., 0]` (bpm.py:80-85)
 template <typename T>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_bpm_finalize_kernel(const int64_t* __restrict__ items, int n_items,
                                                                         const int64_t* __restrict__ ptrs, const double* __restrict__ ws,
-                                                                        int64_t nw, T* __restrict__ readings) {
+                                                                        int64_t nw, T* __restrict__ readings, int transport = 0) {
     __shared__ double red[4 * 3];
     const int slot = blockIdx.x;
+    if (transport) {                                       // a monitor behind a linear prefix has its reading already
+        bool linear = true;
+        for (int i = 0; i < n_items; ++i) {
+            const int type = (int)items[i * 4];
+            if (type == 1 || type == 3) linear = false;
+            if (type == 2 && (int)items[i * 4 + 3] == slot) break;
+        }
+        if (linear) return;
+    }
     const int64_t beam = blockIdx.y;                       // nw = waves per beam; readings[slot][beam][2]
     const double* part = ws + ((int64_t)slot * gridDim.y + beam) * nw * 3;
     double v[3] = {0.0, 0.0, 0.0};
@@ -1116,6 +1207,18 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
         wchunks = (B + wrows - 1) / wrows;
         if (wtiles > 0x7fffffffLL || wchunks > 65535) return CHX_ERR_INVALID_ARG;
         const dim3 wgrid((unsigned)wtiles, (unsigned)wchunks);
+        // monitors behind a linear prefix by moment transport (float32, one shared row of weights): 8 sums over the shared beam in the
+        // part of the workspace the per-wave sums of this grid do not reach. CHX_TUNE_SCAN_TRANSPORT=0: particle sums everywhere.
+        static const bool transport_on = [] { const char* e = getenv("CHX_TUNE_SCAN_TRANSPORT"); return !(e && e[0] == '0'); }();
+        const int64_t ws_used = wtiles * (CHX_BLOCK / 64) * B * 3 * n_bpm;
+        const int transport = (transport_on && dtype == CHX_F32 && n_bpm > 0 && (!survival || shared_sv) &&
+                               workspace_bytes >= (size_t)(ws_used + kScanSumBlocks * 8) * sizeof(double)) ? 1 : 0;
+        double* sum_partials = (double*)workspace + ws_used;
+        if (transport) {
+            hipLaunchKernelGGL(scan_beam_sums_kernel<float>, dim3(kScanSumBlocks), dim3(CHX_BLOCK), 0, s, (const float*)x_in,
+                               (const float*)survival, N, sum_partials);
+            CHX_CHECK_LAUNCH();
+        }
 #define CHX_SCAN_LAUNCH(T, PPT, ...)                                                                        \
     do {                                                                                                    \
         if (small_runs) hipLaunchKernelGGL((lattice_scan_wave_kernel<T, PPT, false>), wgrid, __VA_ARGS__);  \
@@ -1125,15 +1228,20 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
         if (dtype == CHX_F32) {
             CHX_SCAN_LAUNCH(float, 4, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (float*)x_out, table,
                                (int)n_items, Rs, coeffs, N, B, wrows, iv, (const float*)survival, (double*)workspace, diag, ptrs,
-                               (float*)survival_out, shared_sv);
+                               (float*)survival_out, shared_sv, transport);
             CHX_CHECK_LAUNCH();
             if (n_bpm > 0)
                 hipLaunchKernelGGL(lattice_bpm_finalize_kernel<float>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table,
-                                   (int)n_items, ptrs, (const double*)workspace, wnw, (float*)readings);
+                                   (int)n_items, ptrs, (const double*)workspace, wnw, (float*)readings, transport);
+            if (transport) {
+                CHX_CHECK_LAUNCH();
+                hipLaunchKernelGGL(lattice_scan_bpm_transport_kernel<float>, dim3((unsigned)((B + CHX_BLOCK - 1) / CHX_BLOCK)), dim3(CHX_BLOCK), 0,
+                                   s, table, (int)n_items, ptrs, Rs, sum_partials, kScanSumBlocks, B, (float*)readings);
+            }
         } else {
             CHX_SCAN_LAUNCH(double, 2, dim3(CHX_BLOCK), 0, s, (const double*)x_in, (double*)x_out,
                                table, (int)n_items, Rs, coeffs, N, B, wrows, iv, (const double*)survival, (double*)workspace, diag, ptrs,
-                               (double*)survival_out, shared_sv);
+                               (double*)survival_out, shared_sv, 0);
             CHX_CHECK_LAUNCH();
             if (n_bpm > 0)
                 hipLaunchKernelGGL(lattice_bpm_finalize_kernel<double>, dim3((unsigned)n_bpm, (unsigned)B), dim3(CHX_BLOCK), 0, s, table,
