@@ -824,8 +824,27 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
 // barrier -> store chain; 2.69 ms with one monitor where the plain shared-beam apply takes 2.07.) Needs every row of the output to
 // start on a 16-byte boundary. Per particle the arithmetic of lattice_apply_kernel, item by item; a monitor's per-wave sums cover
 // other particles than there (a wave = PPT * 64 consecutive particles), the finalize kernel adds them up all the same.
+// A lane's PPT particles. float32 with an even PPT: two particles per 64-bit register pair (particle 2 p in .x, 2 p + 1 in .y) FROM
+// LOAD TO STORE, so that a map is 49 v_pk_fma_f32 per pair and nothing else (packed anew per item, as lattice_apply_kernel does, the
+// 28 + 28 register moves around every map were as many instructions as the map itself).
+template <typename T, int PPT, bool PAIRS = (std::is_same<T, float>::value && PPT % 2 == 0)>
+struct LaneRows {
+    T v[PPT][7];
+    __device__ __forceinline__ T get(int k, int j) const { return v[k][j]; }
+    __device__ __forceinline__ void set(int k, int j, T val) { v[k][j] = val; }
+};
+template <int PPT>
+struct LaneRows<float, PPT, true> {
+    chx_v2f v[PPT / 2][7];
+    __device__ __forceinline__ float get(int k, int j) const { return (k & 1) ? v[k >> 1][j].y : v[k >> 1][j].x; }
+    __device__ __forceinline__ void set(int k, int j, float val) {
+        if (k & 1) v[k >> 1][j].y = val;
+        else v[k >> 1][j].x = val;
+    }
+};
+
 // CAV false: the caller vouches that the stretch holds no cavity (chx_lattice_prepare_rows' small_runs) — without the fp64 cosine of the
-// cavity epilogue the kernel keeps a map's 49 entries in scalar registers in one piece.
+// cavity epilogue the kernel keeps a map's 49 entries in scalar registers in fewer pieces.
 template <typename T, int PPT, bool CAV>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* __restrict__ x_in, T* __restrict__ x_out,
                                                                      const int64_t* __restrict__ items, int n_items,
@@ -841,6 +860,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
     constexpr int WP = PPT * 64;                 // particles per wave
     constexpr int WE = WP * 7;                   // elements per wave
     constexpr int WV = WE / VN;                  // 16-byte chunks per wave
+    constexpr bool kPairs = std::is_same<T, float>::value && PPT % 2 == 0;
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     const int64_t t0 = (int64_t)blockIdx.x * TP;
     const int np = (int)((N - t0 < TP) ? (N - t0) : TP);
@@ -850,13 +870,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
 
     tile_load<T, TP>(x_in + t0 * 7, lds, np * 7, in_vec_ok != 0, false);      // (re-read by every chunk of rows: no streaming hint)
     __syncthreads();
-    T x0[PPT][7];
+    LaneRows<T, PPT> x0;
     T* wl = lds + wave * WE;                      // this wave's slice: particles t0 + wave * WP + [0, WP)
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = wave * WP + k * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) x0[k][j] = (p < np) ? wl[(k * 64 + lane) * 7 + j] : (T)0;
+        for (int j = 0; j < 7; ++j) x0.set(k, j, (p < np) ? wl[(k * 64 + lane) * 7 + j] : (T)0);
     }
     T sv0[PPT];
 #pragma unroll
@@ -870,13 +890,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
     const int64_t nw = (int64_t)gridDim.x * (CHX_BLOCK / 64);            // waves per row
     const int64_t nw_all = nw * B;
     for (int64_t b = b0; b < b1; ++b) {
-        T x[PPT][7], sv[PPT];
+        LaneRows<T, PPT> x = x0;
+        T sv[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) x[k][j] = x0[k][j];
-            sv[k] = sv0[k];
-        }
+        for (int k = 0; k < PPT; ++k) sv[k] = sv0[k];
         if (diag && survival && !shared_sv) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -904,8 +921,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const double w = (double)sv[k];
-                    sx = fma(w, (double)x[k][0], sx);
-                    sy = fma(w, (double)x[k][2], sy);
+                    sx = fma(w, (double)x.get(k, 0), sx);
+                    sy = fma(w, (double)x.get(k, 2), sy);
                 }
                 sx = chx_wave_sum_lane63(sx);
                 sy = chx_wave_sum_lane63(sy);
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
                 const T x_max2 = x_max * x_max, y_max2 = y_max * y_max;
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    const T px = x[k][0], py = x[k][2];
+                    const T px = x.get(k, 0), py = x.get(k, 2);
                     bool inside;
                     if (elliptical) {
                         const T a = (px * px) / x_max2;
@@ -942,52 +959,51 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
             const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
             const bool cavity = CAV && type == 1;
             const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
-            if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
-                // two of the lane's particles per register pair: every step of apply7's fmaf chain is ONE v_pk_fma_f32 for both; matrix
-                // row by matrix row over ALL pairs, so that a map entry is fetched once per item (pair by pair the compiler, short of
-                // scalar registers, fetched the 49 entries in four pieces per pair, each waited for on the spot)
-                chx_v2f xp[PPT / 2][7], y[PPT / 2][7];
-#pragma unroll
-                for (int pr = 0; pr < PPT / 2; ++pr)
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) xp[pr][j] = chx_v2f{x[2 * pr][j], x[2 * pr + 1][j]};
+            if constexpr (kPairs) {
+                // every step of apply7's fmaf chain is ONE v_pk_fma_f32 for the two particles of a pair (same per-particle order -> same
+                // bits); matrix row by matrix row over ALL pairs, so that a map entry is fetched once per item (pair by pair the compiler,
+                // short of scalar registers, fetched the 49 entries in four pieces per pair, each waited for on the spot)
+                chx_v2f y[PPT / 2][7];
 #pragma unroll
                 for (int r = 0; r < 7; ++r) {
 #pragma unroll
-                    for (int pr = 0; pr < PPT / 2; ++pr) y[pr][r] = xp[pr][0] * R[r * 7];
+                    for (int pr = 0; pr < PPT / 2; ++pr) y[pr][r] = x.v[pr][0] * R[r * 7];
 #pragma unroll
                     for (int j = 1; j < 7; ++j) {
                         const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
 #pragma unroll
-                        for (int pr = 0; pr < PPT / 2; ++pr) y[pr][r] = __builtin_elementwise_fma(m, xp[pr][j], y[pr][r]);
+                        for (int pr = 0; pr < PPT / 2; ++pr) y[pr][r] = __builtin_elementwise_fma(m, x.v[pr][j], y[pr][r]);
+                    }
+                }
+                if (cavity) {
+#pragma unroll
+                    for (int pr = 0; pr < PPT / 2; ++pr) {
+                        T xa[7], xb[7], ya[7], yb[7];
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) {
+                            xa[j] = x.v[pr][j].x; xb[j] = x.v[pr][j].y;
+                            ya[j] = y[pr][j].x; yb[j] = y[pr][j].y;
+                        }
+                        cavity_epilogue<T>(c, xa, ya);
+                        cavity_epilogue<T>(c, xb, yb);
+                        y[pr][4] = chx_v2f{ya[4], yb[4]};
+                        y[pr][5] = chx_v2f{ya[5], yb[5]};
                     }
                 }
 #pragma unroll
-                for (int pr = 0; pr < PPT / 2; ++pr) {
-                    T y0[7], y1[7];
+                for (int pr = 0; pr < PPT / 2; ++pr)
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        y0[j] = y[pr][j].x;
-                        y1[j] = y[pr][j].y;
-                    }
-                    if (cavity) {
-                        cavity_epilogue<T>(c, x[2 * pr], y0);
-                        cavity_epilogue<T>(c, x[2 * pr + 1], y1);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        x[2 * pr][j] = y0[j];
-                        x[2 * pr + 1][j] = y1[j];
-                    }
-                }
+                    for (int j = 0; j < 7; ++j) x.v[pr][j] = y[pr][j];
             } else {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    T y[7];
-                    apply7<T>(R, x[k], y);
-                    if (cavity) cavity_epilogue<T>(c, x[k], y);
+                    T xi[7], y[7];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+                    for (int j = 0; j < 7; ++j) xi[j] = x.get(k, j);
+                    apply7<T>(R, xi, y);
+                    if (cavity) cavity_epilogue<T>(c, xi, y);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) x.set(k, j, y[j]);
                 }
             }
         }
@@ -1001,7 +1017,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) wl[(k * 64 + lane) * 7 + j] = x[k][j];
+            for (int j = 0; j < 7; ++j) wl[(k * 64 + lane) * 7 + j] = x.get(k, j);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
