@@ -574,6 +574,25 @@ namespace {
 // that point are recorded (the screen's copy of the beam, unshifted) and — flag bit 0 — every particle adds |q| w to its four
 // pixels of the image, which the preparation launch zeroed: the arithmetic of cic_deposit_kernel on (x - misalignment) through the
 // same per-workgroup combining table, the extent derived from the pixel size (screen_extent_axis).
+// A lane's PPT particles. float32 with an even PPT: two particles per 64-bit register pair (particle 2 p in .x, 2 p + 1 in .y) FROM
+// LOAD TO STORE, so that a map is 49 v_pk_fma_f32 per pair and nothing else (packed anew per item, the 28 + 28 register moves
+// around every map were as many instructions as the map itself).
+template <typename T, int PPT, bool PAIRS = (std::is_same<T, float>::value && PPT % 2 == 0)>
+struct LaneRows {
+    T v[PPT][7];
+    __device__ __forceinline__ T get(int k, int j) const { return v[k][j]; }
+    __device__ __forceinline__ void set(int k, int j, T val) { v[k][j] = val; }
+};
+template <int PPT>
+struct LaneRows<float, PPT, true> {
+    chx_v2f v[PPT / 2][7];
+    __device__ __forceinline__ float get(int k, int j) const { return (k & 1) ? v[k >> 1][j].y : v[k >> 1][j].x; }
+    __device__ __forceinline__ void set(int k, int j, float val) {
+        if (k & 1) v[k >> 1][j].y = val;
+        else v[k >> 1][j].x = val;
+    }
+};
+
 struct ApplyScreens {
     chx_lattice_screen s[CHX_LATTICE_MAX_SCREENS];
     const void* charge;      // [N] or NULL (= 1)
@@ -603,12 +622,12 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
     // (a beam shared by the rows of a scan of lattice settings is re-read by every row: no streaming hint then)
     tile_load<T, TP>(x_in + (shared_in ? t0 : n0) * 7, lds, np * 7, in_vec_ok != 0 && (shared_in || row_vec), !shared_in);
     __syncthreads();
-    T x[PPT][7];
+    LaneRows<T, PPT> x;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = threadIdx.x + k * CHX_BLOCK;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? lds[p * 7 + j] : (T)0;
+        for (int j = 0; j < 7; ++j) x.set(k, j, (p < np) ? lds[p * 7 + j] : (T)0);
     }
     // survival probabilities of this lane's particles (0 beyond the beam): the monitors' weights, what the apertures reduce
     T sv[PPT];
@@ -640,8 +659,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const double w = (double)sv[k];
-                sx = fma(w, (double)x[k][0], sx);
-                sy = fma(w, (double)x[k][2], sy);
+                sx = fma(w, (double)x.get(k, 0), sx);
+                sy = fma(w, (double)x.get(k, 2), sy);
             }
             sx = chx_wave_sum_lane63(sx);        // (the totals land in lane 63: DPP row broadcasts instead of ds_bpermute)
             sy = chx_wave_sum_lane63(sy);
@@ -666,7 +685,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                         const int p = threadIdx.x + k * CHX_BLOCK;
                         if (p < np) {
 #pragma unroll
-                            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x[k][j];
+                            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x.get(k, j);
                         }
                     }
                     __syncthreads();
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     for (int k = 0; k < PPT; ++k) {
                         const int p = threadIdx.x + k * CHX_BLOCK;
                         if (p >= np) continue;
-                        const T vx = x[k][0] - mx, vy = x[k][2] - my;      // screen.py:200-212: positions relative to the screen
+                        const T vx = x.get(k, 0) - mx, vy = x.get(k, 2) - my;      // screen.py:200-212: positions relative to the screen
                         long long ix, iy;
                         T fx, fy, bw;
                         bool inside = cic_axis<T>(vx, lx, rx, bins_x, ix, fx, bw);
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             const T x_max2 = x_max * x_max, y_max2 = y_max * y_max;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const T px = x[k][0], py = x[k][2];
+                const T px = x.get(k, 0), py = x.get(k, 2);
                 bool inside;
                 if (elliptical) {
                     const T a = (px * px) / x_max2;
@@ -754,45 +773,48 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
         const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
         const bool cavity = type == 1;
         const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
-        if constexpr (std::is_same<T, float>::value && PPT == 2) {
-            // the lane's two particles in one register pair: every step of apply7's fmaf chain is ONE v_pk_fma_f32 for both
-            // (same per-particle order -> same bits; at 4e8 particle rows the maps of a stretch are VALU time, not HBM time)
-            chx_v2f xp[7], y[7];
+        if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
+            // the lane's particles two to a register pair, kept that way from load to store: every step of apply7's fmaf chain is ONE
+            // v_pk_fma_f32 for both (same per-particle order -> same bits; at 4e8 particle rows the maps of a stretch are VALU time,
+            // not HBM time)
 #pragma unroll
-            for (int j = 0; j < 7; ++j) xp[j] = chx_v2f{x[0][j], x[1][j]};
+            for (int pr = 0; pr < PPT / 2; ++pr) {
+                chx_v2f y[7];
 #pragma unroll
-            for (int r = 0; r < 7; ++r) {
-                chx_v2f acc = xp[0] * R[r * 7];
+                for (int r = 0; r < 7; ++r) {
+                    chx_v2f acc = x.v[pr][0] * R[r * 7];
 #pragma unroll
-                for (int j = 1; j < 7; ++j) {
-                    const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
-                    acc = __builtin_elementwise_fma(m, xp[j], acc);
+                    for (int j = 1; j < 7; ++j) {
+                        const chx_v2f m = {R[r * 7 + j], R[r * 7 + j]};
+                        acc = __builtin_elementwise_fma(m, x.v[pr][j], acc);
+                    }
+                    y[r] = acc;
                 }
-                y[r] = acc;
-            }
-            T y0[7], y1[7];
+                if (cavity) {
+                    T xa[7], xb[7], ya[7], yb[7];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                y0[j] = y[j].x;
-                y1[j] = y[j].y;
-            }
-            if (cavity) {
-                cavity_epilogue<T>(c, x[0], y0);
-                cavity_epilogue<T>(c, x[1], y1);
-            }
+                    for (int j = 0; j < 7; ++j) {
+                        xa[j] = x.v[pr][j].x; xb[j] = x.v[pr][j].y;
+                        ya[j] = y[j].x; yb[j] = y[j].y;
+                    }
+                    cavity_epilogue<T>(c, xa, ya);
+                    cavity_epilogue<T>(c, xb, yb);
+                    y[4] = chx_v2f{ya[4], yb[4]};
+                    y[5] = chx_v2f{ya[5], yb[5]};
+                }
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                x[0][j] = y0[j];
-                x[1][j] = y1[j];
+                for (int j = 0; j < 7; ++j) x.v[pr][j] = y[j];
             }
         } else {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                T y[7];
-                apply7<T>(R, x[k], y);
-                if (cavity) cavity_epilogue<T>(c, x[k], y);
+                T xi[7], y[7];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) x[k][j] = y[j];
+                for (int j = 0; j < 7; ++j) xi[j] = x.get(k, j);
+                apply7<T>(R, xi, y);
+                if (cavity) cavity_epilogue<T>(c, xi, y);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) x.set(k, j, y[j]);
             }
         }
     }
@@ -809,7 +831,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
         const int p = threadIdx.x + k * CHX_BLOCK;
         if (p < np) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x[k][j];
+            for (int j = 0; j < 7; ++j) lds[p * 7 + j] = x.get(k, j);
         }
     }
     __syncthreads();
@@ -824,25 +846,6 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
 // barrier -> store chain; 2.69 ms with one monitor where the plain shared-beam apply takes 2.07.) Needs every row of the output to
 // start on a 16-byte boundary. Per particle the arithmetic of lattice_apply_kernel, item by item; a monitor's per-wave sums cover
 // other particles than there (a wave = PPT * 64 consecutive particles), the finalize kernel adds them up all the same.
-// A lane's PPT particles. float32 with an even PPT: two particles per 64-bit register pair (particle 2 p in .x, 2 p + 1 in .y) FROM
-// LOAD TO STORE, so that a map is 49 v_pk_fma_f32 per pair and nothing else (packed anew per item, as lattice_apply_kernel does, the
-// 28 + 28 register moves around every map were as many instructions as the map itself).
-template <typename T, int PPT, bool PAIRS = (std::is_same<T, float>::value && PPT % 2 == 0)>
-struct LaneRows {
-    T v[PPT][7];
-    __device__ __forceinline__ T get(int k, int j) const { return v[k][j]; }
-    __device__ __forceinline__ void set(int k, int j, T val) { v[k][j] = val; }
-};
-template <int PPT>
-struct LaneRows<float, PPT, true> {
-    chx_v2f v[PPT / 2][7];
-    __device__ __forceinline__ float get(int k, int j) const { return (k & 1) ? v[k >> 1][j].y : v[k >> 1][j].x; }
-    __device__ __forceinline__ void set(int k, int j, float val) {
-        if (k & 1) v[k >> 1][j].y = val;
-        else v[k >> 1][j].x = val;
-    }
-};
-
 // CAV false: the caller vouches that the stretch holds no cavity (chx_lattice_prepare_rows' small_runs) — without the fp64 cosine of the
 // cavity epilogue the kernel keeps a map's 49 entries in scalar registers in fewer pieces.
 template <typename T, int PPT, bool CAV>
