@@ -585,7 +585,10 @@ int chx_lattice_track(const int64_t* table, int64_t n_items, int64_t n_elems, in
 /* The same stretch with ACTIVE beam position monitors and apertures in it — elements that read or thin the beam and let the
  * particles pass, each of which costs the element-by-element walk (segment.py:545-574) a stop and several launches:
  *  {2, 0, q, slot}: a BPM (bpm.py:77-87): ptrs[q] = address of its misalignment [2]; readings[slot] = (dtype)(sum w x / sum w,
- *     sum w y / sum w) - misalignment of the beam AT that point (fp64 sums per wave in the particle pass, one more launch);
+ *     sum w y / sum w) - misalignment of the beam AT that point (fp64 sums per wave in the particle pass, one more launch). In a big
+ *     float32 scan (Bx = 1, Bm = B >= 8, B * N >= 8e6, rows on 16-byte boundaries, one row of weights) a monitor with nothing but maps
+ *     and monitors in front of it is evaluated by taking the beam's weighted mean through the row's maps in fp64 instead — the same
+ *     number up to the per-item float32 rounding of the individual particles, which averages out (~1e-10 of the beam size);
  *  {3, 0 rectangular | 1 elliptical, q, 0}: an aperture (aperture.py:90-135): ptrs[q], ptrs[q + 1] = addresses of x_max, y_max;
  *     survival *= inside(x, y), the arithmetic of chx_aperture_mask; monitors behind it weigh with the reduced probabilities.
  * B beams of N particles each (x_in / x_out [B][N][7]: a vectorised ParticleBeam under ONE lattice setting and energy — the same
