@@ -1228,7 +1228,8 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
         const dim3 wgrid((unsigned)wtiles, (unsigned)wchunks);
         // monitors behind a linear prefix by moment transport (float32, one shared row of weights): 8 sums over the shared beam in the
         // part of the workspace the per-wave sums of this grid do not reach. CHX_TUNE_SCAN_TRANSPORT=0: particle sums everywhere.
-        static const bool transport_on = [] { const char* e = getenv("CHX_TUNE_SCAN_TRANSPORT"); return !(e && e[0] == '0'); }();
+        const char* transport_env = getenv("CHX_TUNE_SCAN_TRANSPORT");
+        const bool transport_on = !(transport_env && transport_env[0] == '0');
         const int64_t ws_used = wtiles * (CHX_BLOCK / 64) * B * 3 * n_bpm;
         const int transport = (transport_on && dtype == CHX_F32 && n_bpm > 0 && (!survival || shared_sv) &&
                                workspace_bytes >= (size_t)(ws_used + kScanSumBlocks * 8) * sizeof(double)) ? 1 : 0;
