@@ -265,6 +265,25 @@ __global__ __launch_bounds__(THREADS) void apply_wave_kernel(const T* __restrict
     }
 }
 
+// A lane's PPT particles. float32 with an even PPT: two particles per 64-bit register pair (particle 2 p in .x, 2 p + 1 in .y) FROM
+// LOAD TO STORE, so that a map is 49 v_pk_fma_f32 per pair and nothing else (packed anew per item, the 28 + 28 register moves
+// around every map were as many instructions as the map itself).
+template <typename T, int PPT, bool PAIRS = (std::is_same<T, float>::value && PPT % 2 == 0)>
+struct LaneRows {
+    T v[PPT][7];
+    __device__ __forceinline__ T get(int k, int j) const { return v[k][j]; }
+    __device__ __forceinline__ void set(int k, int j, T val) { v[k][j] = val; }
+};
+template <int PPT>
+struct LaneRows<float, PPT, true> {
+    chx_v2f v[PPT / 2][7];
+    __device__ __forceinline__ float get(int k, int j) const { return (k & 1) ? v[k >> 1][j].y : v[k >> 1][j].x; }
+    __device__ __forceinline__ void set(int k, int j, float val) {
+        if (k & 1) v[k >> 1][j].y = val;
+        else v[k >> 1][j].x = val;
+    }
+};
+
 // ---- shared-input kernel (Bx == 1, B > 1): one x tile, many maps ---------------------------
 // grid = (tiles over N, batch chunks). Each block keeps its particles in registers and loops
 // over its chunk of batch rows; writes dominate (28 B per (batch, particle) in fp32).
@@ -333,25 +352,48 @@ __global__ __launch_bounds__(CHX_BLOCK) void apply_shared_wave_kernel(
 
     tile_load<T, TP>(x_in + n0 * 7, lds, np * 7, in_vec_ok != 0);
     __syncthreads();
-    T x[PPT][7];
+    LaneRows<T, PPT> x;                           // (float32: two particles per register pair, the maps as packed FMAs)
     T* wl = lds + wave * WE;                      // this wave's slice: rows wave * WP + [0, WP)
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = wave * WP + k * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) x[k][j] = (p < np) ? wl[(k * 64 + lane) * 7 + j] : (T)0;
+        for (int j = 0; j < 7; ++j) x.set(k, j, (p < np) ? wl[(k * 64 + lane) * 7 + j] : (T)0);
     }
     // from here on a wave touches only its own slice
     const int valid = (np - wave * WP < 0) ? 0 : ((np - wave * WP < WP) ? (np - wave * WP) : WP);   // rows of this wave that exist
     const int vchunks = valid * 7 / VN;           // whole chunks inside the valid rows
     for (int64_t b = b0; b < b1; ++b) {
         const T* __restrict__ Rb = R + b * 49;
+        if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
+            // apply7's fmaf chain for the two particles of a pair in ONE v_pk_fma_f32 per step (same order per particle: same bits)
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            T y[7];
-            apply7<T>(Rb, x[k], y);
+            for (int r = 0; r < 7; ++r) {
+                chx_v2f y[PPT / 2];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) wl[(k * 64 + lane) * 7 + j] = y[j];
+                for (int pr = 0; pr < PPT / 2; ++pr) y[pr] = x.v[pr][0] * Rb[r * 7];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) {
+                    const chx_v2f m = {Rb[r * 7 + j], Rb[r * 7 + j]};
+#pragma unroll
+                    for (int pr = 0; pr < PPT / 2; ++pr) y[pr] = __builtin_elementwise_fma(m, x.v[pr][j], y[pr]);
+                }
+#pragma unroll
+                for (int pr = 0; pr < PPT / 2; ++pr) {
+                    wl[((2 * pr) * 64 + lane) * 7 + r] = y[pr].x;
+                    wl[((2 * pr + 1) * 64 + lane) * 7 + r] = y[pr].y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                T xi[7], y[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) xi[j] = x.get(k, j);
+                apply7<T>(Rb, xi, y);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) wl[(k * 64 + lane) * 7 + j] = y[j];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -574,25 +616,6 @@ namespace {
 // that point are recorded (the screen's copy of the beam, unshifted) and — flag bit 0 — every particle adds |q| w to its four
 // pixels of the image, which the preparation launch zeroed: the arithmetic of cic_deposit_kernel on (x - misalignment) through the
 // same per-workgroup combining table, the extent derived from the pixel size (screen_extent_axis).
-// A lane's PPT particles. float32 with an even PPT: two particles per 64-bit register pair (particle 2 p in .x, 2 p + 1 in .y) FROM
-// LOAD TO STORE, so that a map is 49 v_pk_fma_f32 per pair and nothing else (packed anew per item, the 28 + 28 register moves
-// around every map were as many instructions as the map itself).
-template <typename T, int PPT, bool PAIRS = (std::is_same<T, float>::value && PPT % 2 == 0)>
-struct LaneRows {
-    T v[PPT][7];
-    __device__ __forceinline__ T get(int k, int j) const { return v[k][j]; }
-    __device__ __forceinline__ void set(int k, int j, T val) { v[k][j] = val; }
-};
-template <int PPT>
-struct LaneRows<float, PPT, true> {
-    chx_v2f v[PPT / 2][7];
-    __device__ __forceinline__ float get(int k, int j) const { return (k & 1) ? v[k >> 1][j].y : v[k >> 1][j].x; }
-    __device__ __forceinline__ void set(int k, int j, float val) {
-        if (k & 1) v[k >> 1][j].y = val;
-        else v[k >> 1][j].x = val;
-    }
-};
-
 struct ApplyScreens {
     chx_lattice_screen s[CHX_LATTICE_MAX_SCREENS];
     const void* charge;      // [N] or NULL (= 1)
