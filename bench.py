@@ -572,7 +572,9 @@ def other_configs(ca, torch, device, only=None) -> dict:
                            "response of 25 cells, each corrector angle a (64,) tensor (ParameterBeam; one 1e4-particle beam shared by the rows); the "
                            "cavity linac at 64 beam energies, with the phase of every cavity a (64,) tensor, and with two cavities switched off. "
                            "Every entry's outgoing beam (sigma_x, sigma_y, energy, surviving weight, last monitor reading) is compared with the "
-                           "REFERENCE's float64 run of the same seeded data (tests/golden/bench_diagnostics.json) before its time is reported"}
+                           "REFERENCE's float64 run of the same seeded data (tests/golden/bench_diagnostics.json) before its time is reported. "
+                           "scan_4096_settings_x_1e5_shared_particles: C3's size through six cells with one / six active monitors, ms per "
+                           "Segment.track and GB/s of the (4096, 1e5, 7) result, rows 0 and 4095 checked against their own single-row track"}
         with torch.no_grad():
             for name, specs in (("bpm_lattice", di.bpm_lattice()), ("aperture_lattice", di.aperture_lattice()), ("cavity_linac", di.cavity_linac())):
                 seg = di.segment(ca, specs, kw)
@@ -609,6 +611,50 @@ def other_configs(ca, torch, device, only=None) -> dict:
             check("linac_two_cavities_off", "particle_beam", seg, seg.track(beam))
             res["linac_two_cavities_off"] = {"parameter_beam_us": timed_us(lambda: seg.track(pbeam)),
                                              "particle_beam_us": timed_us(lambda: seg.track(beam))}
+            # a scan at C3's size — 4096 rows of settings (a quadrupole strength and six corrector angles per row, drawn on the host
+            # from a fixed seed) over ONE shared beam of 1e5 particles, 11.5 GB of result — through six cells with one / six active
+            # monitors: one stretch call (lattice_scan_wave_kernel). Checked against THIS engine's own track of single rows (the scan's
+            # kernels are pinned to the reference and the oracle by tests/test_gpu_bigshape_stretch.py; the reference's float64 run of
+            # the whole scan would be a 23 GB fixture): particles of rows 0 and 4095 bit for bit, readings to a float32 reading's rounding.
+            import numpy as _np
+
+            rng = _np.random.default_rng(20260930)
+            B_scan = 4096
+            k1_rows = torch.tensor(rng.standard_normal(B_scan), **kw)
+            angle_rows = [torch.tensor(1e-5 * rng.standard_normal(B_scan), **kw) for _ in range(6)]
+
+            def scan_lattice(monitors, row=None):
+                pick = (lambda v: v) if row is None else (lambda v: v[row].clone())
+                els = []
+                for i in range(6):
+                    els += [ca.Quadrupole(tt(0.2), k1=(pick(k1_rows) if i == 0 else tt(4.2 if i % 2 == 0 else -4.2)), **kw),
+                            ca.HorizontalCorrector(tt(0.05), angle=pick(angle_rows[i]), **kw), ca.Drift(tt(0.8), **kw)]
+                    if i % (6 // monitors) == 6 // monitors - 1:
+                        els.append(ca.BPM(is_active=True, **kw))
+                return ca.Segment(els)
+
+            res["scan_4096_settings_x_1e5_shared_particles"] = {}
+            for monitors in (1, 6):
+                seg = scan_lattice(monitors)
+                out = seg.track(beam)
+                readings = torch.stack([e.reading for e in seg.elements if isinstance(e, ca.BPM)])          # (monitors, 4096, 2)
+                size = float(beam.particles[:, [0, 2]].abs().max())
+                for row in (0, B_scan - 1):
+                    one = scan_lattice(monitors, row)
+                    ref = one.track(beam)
+                    if not torch.equal(out.particles[row], ref.particles):
+                        raise AssertionError(f"DIAGNOSTICS_LATTICES scan with {monitors} monitors: row {row} differs from its own track")
+                    r1 = torch.stack([e.reading for e in one.elements if isinstance(e, ca.BPM)])
+                    err = float((readings[:, row].double() - r1.double()).abs().max()) / size
+                    checks["values"] += 1
+                    if not err < 2e-7:
+                        raise AssertionError(f"DIAGNOSTICS_LATTICES scan with {monitors} monitors: readings of row {row} off by {err:.2e} beam sizes")
+                del out
+                us = timed_us(lambda: seg.track(beam), reps=5)
+                res["scan_4096_settings_x_1e5_shared_particles"][f"{monitors}_monitor{'s' if monitors > 1 else ''}_ms"] = us / 1e3
+                res["scan_4096_settings_x_1e5_shared_particles"][f"{monitors}_monitor{'s' if monitors > 1 else ''}_result_GBps"] = \
+                    B_scan * beam.particles.shape[0] * 28 / (us * 1e-6) / 1e9
+                checks["entries"] += 1
         res["checked_against_reference"] = checks
         return res
 
