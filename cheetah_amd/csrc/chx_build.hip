@@ -1756,14 +1756,9 @@ __device__ __forceinline__ void lattice_zero_images(const LatticeScreens& scr, i
     }
 }
 
-// STAGED: every workgroup first copies the whole table (items | element kinds | first pointers | addresses: contiguous) into LDS and
-// then the settings of ALL elements — two rounds of loads side by side instead of the chains item -> element -> address -> value that
-// each of its three walks (reference energy, path length, its own elements) used to wait for one after the other: the launch is a
-// chain of ~4 memory round trips instead of ~12 (12 us -> 6 us for the 13 elements of C1; the launcher stages tables of up to 48 KB).
-template <typename T, bool STAGED>
-__global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_t* __restrict__ items_g, const int64_t* __restrict__ elem_kind_g,
-                                                                   const int64_t* __restrict__ elem_poff_g, const int64_t* __restrict__ ptrs_g,
-                                                                   int n_ptrs,
+template <typename T>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_t* __restrict__ items, const int64_t* __restrict__ elem_kind,
+                                                                   const int64_t* __restrict__ elem_poff, const int64_t* __restrict__ ptrs,
                                                                    int n_items, int n_elems, const T* __restrict__ energy, double mass, double nq,
                                                                    double* __restrict__ Rs, double* __restrict__ coeffs,
                                                                    double* __restrict__ emaps, T* __restrict__ energy_out,
@@ -1772,35 +1767,11 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
                                                                    int energy_out_rows /*energy_out is a (rows,) array*/,
                                                                    LatticeScreens scr) {
     __shared__ double e_in_sh;
-    extern __shared__ __attribute__((aligned(8))) unsigned char stage_raw[];
     if ((int)blockIdx.x >= n_items) {                      // (spare workgroups: the screens' images start from zero)
         lattice_zero_images(scr, (int64_t)blockIdx.x - n_items);
         return;
     }
     const int b = blockIdx.x;
-    // the table's four parts are one contiguous array of words (chx_lattice_prepare_rows)
-    const int64_t n_words = (int64_t)n_items * 4 + 2 * (int64_t)n_elems + n_ptrs;
-    int64_t* tab = reinterpret_cast<int64_t*>(stage_raw);
-    T* vals = reinterpret_cast<T*>(tab + (STAGED ? n_words : 0));                 // [n_ptrs]: the settings behind the addresses
-    const int64_t* items = STAGED ? tab : items_g;
-    const int64_t* elem_kind = STAGED ? tab + (int64_t)n_items * 4 : elem_kind_g;
-    const int64_t* elem_poff = STAGED ? tab + (int64_t)n_items * 4 + n_elems : elem_poff_g;
-    const int64_t* ptrs = STAGED ? tab + (int64_t)n_items * 4 + 2 * (int64_t)n_elems : ptrs_g;
-    if constexpr (STAGED) {
-        for (int64_t w = threadIdx.x; w < n_words; w += CHX_BLOCK) tab[w] = items_g[w];
-        __syncthreads();
-        // (only the words the element kinds name are addresses of settings: screens keep plain numbers among theirs)
-        for (int e = threadIdx.x; e < n_elems; e += CHX_BLOCK) {
-            const int P = kind_num_params((int)elem_kind[e]);
-            const int64_t po = elem_poff[e];
-            for (int kq = 0; kq < P; ++kq) {
-                const uintptr_t a = (uintptr_t)ptrs[po + kq];
-                const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
-                vals[po + kq] = (a & 1) ? base[blockIdx.y] : base[0];
-            }
-        }
-        __syncthreads();
-    }
     // blockIdx.y = row of a batch of lattice settings (gridDim.y = 1: scalar settings): a pointer with its lowest bit set addresses
     // a (rows,) array whose element `row` belongs to this row (chx_run_map_batched's convention), any other a scalar. The maps and
     // coefficient rows of row r sit behind those of the rows before it: Rs[(item * rows + r)], emaps[r][element].
@@ -1811,10 +1782,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
         const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
         return (a & 1) ? base[r] : base[0];
     };
-    auto setting = [&](int64_t q) {
-        if constexpr (STAGED) return vals[q];
-        else return setting_of(q, row);
-    };
+    auto setting = [&](int64_t q) { return setting_of(q, row); };
     {
         // the reference energy this item sees: through the cavities in front of it, rounded to T after each (the energy is a
         // tensor of the beam's dtype between two elements). The energy gains of the cavities in front are LOADED side by side (one
@@ -2134,23 +2102,14 @@ extern "C" int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items
         return CHX_OK;
     }
     const dim3 grid((unsigned)(n_items + zero_blocks), (unsigned)rows);
-    // table and settings staged in LDS when they fit 48 KB (CHX_TUNE_PREPARE_STAGED=0: the loads where they are needed)
-    static const bool stage_on = [] { const char* e = getenv("CHX_TUNE_PREPARE_STAGED"); return !(e && e[0] == '0'); }();
-    const size_t esz_v = dtype == CHX_F32 ? 4 : 8;
-    const size_t stage_bytes = (size_t)(n_items * 4 + 2 * n_elems + n_ptrs) * 8 + (size_t)n_ptrs * esz_v;
-    const bool staged = stage_on && stage_bytes <= 48 * 1024;
-#define CHX_PREPARE_LAUNCH(T, ST, SH)                                                                                                       \
-    hipLaunchKernelGGL((lattice_prepare_kernel<T, ST>), grid, dim3(CHX_BLOCK), SH, s, items, elem_kind, elem_poff, ptrs, (int)n_ptrs,        \
-                       (int)n_items, (int)n_elems, (const T*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (T*)energy_out, (const T*)s_in, \
-                       (T*)s_out, energy_rows, energy_out_rows, scr)
-    if (dtype == CHX_F32) {
-        if (staged) CHX_PREPARE_LAUNCH(float, true, stage_bytes);
-        else CHX_PREPARE_LAUNCH(float, false, 0);
-    } else {
-        if (staged) CHX_PREPARE_LAUNCH(double, true, stage_bytes);
-        else CHX_PREPARE_LAUNCH(double, false, 0);
-    }
-#undef CHX_PREPARE_LAUNCH
+    if (dtype == CHX_F32)
+        hipLaunchKernelGGL(lattice_prepare_kernel<float>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
+                           (int)n_items, (int)n_elems, (const float*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (float*)energy_out,
+                           (const float*)s_in, (float*)s_out, energy_rows, energy_out_rows, scr);
+    else
+        hipLaunchKernelGGL(lattice_prepare_kernel<double>, grid, dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff,
+                           ptrs, (int)n_items, (int)n_elems, (const double*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (double*)energy_out,
+                           (const double*)s_in, (double*)s_out, energy_rows, energy_out_rows, scr);
     CHX_CHECK_LAUNCH();
     return CHX_OK;
 }
