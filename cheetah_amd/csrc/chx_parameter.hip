@@ -150,17 +150,49 @@ struct ParameterScreens {
     int n;
 };
 
-template <typename T>
+// STAGED (stretches of at most kParamStagedItems items): the wave first brings the item table, every item's map, the cavities' coefficient
+// rows and the monitors' misalignments into LDS — one round of loads side by side — and then walks the items out of LDS. Read where they
+// are used, the item's type and its map are two dependent memory round trips in front of every item of a walk that is sequential by
+// nature (the moments are rounded to T behind every item): 26 - 30 us for the 50 items of a 100-element lattice with 25 monitors, of
+// which the arithmetic is a third.
+constexpr int kParamStagedItems = 96;
+
+template <typename T, bool STAGED>
 __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restrict__ mu, const T* __restrict__ cov, int64_t Bmu,
                                                               int64_t Bcov, int64_t Bm /*rows of lattice settings: 1 or B*/,
-                                                              const int64_t* __restrict__ items, int n_items,
+                                                              const int64_t* __restrict__ items_g, int n_items,
                                                               const double* __restrict__ Rs, const double* __restrict__ coeffs,
                                                               const int64_t* __restrict__ ptrs, T* __restrict__ mu_out,
                                                               T* __restrict__ cov_out, T* __restrict__ readings, ParameterScreens scr) {
     __shared__ double r[49], c[49], m[7], tmp[49];
+    extern __shared__ __attribute__((aligned(8))) unsigned char stage_raw[];
     const int64_t b = blockIdx.x, B = gridDim.x;
     const int lane = threadIdx.x;
     const int i = lane / 7, j = lane - 7 * i;
+    // staged copies: items[n_items][4] | coefficient rows [n_items][8] (double) | maps [n_items][49] (T) | misalignments [n_items][2] (T)
+    int64_t* items_s = reinterpret_cast<int64_t*>(stage_raw);
+    double* coeffs_s = reinterpret_cast<double*>(items_s + (STAGED ? n_items * 4 : 0));
+    T* maps_s = reinterpret_cast<T*>(coeffs_s + (STAGED ? n_items * CHX_CAV_NCOEF : 0));
+    T* mis_s = maps_s + (STAGED ? n_items * 49 : 0);
+    const int64_t* items = STAGED ? items_s : items_g;
+    if constexpr (STAGED) {
+        for (int w = lane; w < n_items * 4; w += 64) items_s[w] = items_g[w];
+        for (int w = lane; w < n_items * 49; w += 64) {
+            const int it = w / 49, q = w - it * 49;
+            maps_s[w] = reinterpret_cast<const T*>(Rs + ((int64_t)it * Bm + (Bm == 1 ? 0 : b)) * 49)[q];
+        }
+        for (int w = lane; w < n_items * CHX_CAV_NCOEF; w += 64) {
+            const int it = w / CHX_CAV_NCOEF, q = w - it * CHX_CAV_NCOEF;
+            coeffs_s[w] = coeffs[((int64_t)it * Bm + (Bm == 1 ? 0 : b)) * CHX_CAV_NCOEF + q];
+        }
+        for (int it = lane; it < n_items; it += 64) {
+            if (items_g[it * 4] == 2) {
+                const T* mis = (const T*)ptrs[items_g[it * 4 + 2]];
+                mis_s[it * 2] = mis[0];
+                mis_s[it * 2 + 1] = mis[1];
+            }
+        }
+    }
     if (lane < 49) c[lane] = (double)cov[(Bcov == 1 ? 0 : b) * 49 + lane];
     if (lane < 7) m[lane] = (double)mu[(Bmu == 1 ? 0 : b) * 7 + lane];
     __syncthreads();
@@ -168,8 +200,10 @@ __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restri
         const int type = (int)items[it * 4];
         if (type == 2) {
             if (lane < 2) {
-                const T* mis = (const T*)ptrs[items[it * 4 + 2]];
-                readings[((int64_t)items[it * 4 + 3] * B + b) * 2 + lane] = (T)m[lane == 0 ? 0 : 2] - mis[lane];
+                T mis_v;
+                if constexpr (STAGED) mis_v = mis_s[it * 2 + lane];
+                else mis_v = ((const T*)ptrs[items[it * 4 + 2]])[lane];
+                readings[((int64_t)items[it * 4 + 3] * B + b) * 2 + lane] = (T)m[lane == 0 ? 0 : 2] - mis_v;
             }
             continue;
         }
@@ -186,7 +220,10 @@ __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restri
         }
         if (type != 0 && type != 1) continue;
         const int64_t mrow = (int64_t)it * Bm + (Bm == 1 ? 0 : b);         // this row's map of the item (vectorised settings)
-        if (lane < 49) r[lane] = (double)reinterpret_cast<const T*>(Rs + mrow * 49)[lane];
+        if (lane < 49) {
+            if constexpr (STAGED) r[lane] = (double)maps_s[it * 49 + lane];
+            else r[lane] = (double)reinterpret_cast<const T*>(Rs + mrow * 49)[lane];
+        }
         __syncthreads();
         if (lane < 49) {  // tmp = R cov
             double s = 0.0;
@@ -202,7 +239,7 @@ __global__ __launch_bounds__(64) void parameter_lattice_kernel(const T* __restri
             for (int k = 0; k < 7; ++k) mu_i = fma(r[lane * 7 + k], m[k], mu_i);
         }
         if (type == 1) {      // cavity moment updates with the INCOMING moments (cavity.py:127-133, 202-218)
-            const double* cf = coeffs + mrow * CHX_CAV_NCOEF;
+            const double* cf = STAGED ? coeffs_s + it * CHX_CAV_NCOEF : coeffs + mrow * CHX_CAV_NCOEF;
             const double mu4 = m[4], mu5 = m[5], c44 = c[4 * 7 + 4], c45 = c[4 * 7 + 5], c55 = c[5 * 7 + 5];
             if (lane == 5) mu_i = mu5 * cf[0] + cf[1] * (cos(-mu4 * cf[2] + cf[3]) - cf[4]);
             if (lane == 4) mu_i = mu_i + (cf[5] * mu5 * mu5 + cf[6] * mu4 * mu5 + cf[7] * mu4 * mu4);
@@ -283,12 +320,22 @@ extern "C" int chx_parameter_lattice_track_screens(const int64_t* table, int64_t
     const double* coeffs = Rs + n_items * Bm * 49;
     const int64_t* ptrs = table + n_items * 4 + 2 * n_elems;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == CHX_F32)
-        hipLaunchKernelGGL(parameter_lattice_kernel<float>, dim3((unsigned)B), dim3(64), 0, s, (const float*)mu, (const float*)cov, Bmu,
-                           Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (float*)mu_out, (float*)cov_out, (float*)readings, scr);
-    else
-        hipLaunchKernelGGL(parameter_lattice_kernel<double>, dim3((unsigned)B), dim3(64), 0, s, (const double*)mu, (const double*)cov,
-                           Bmu, Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (double*)mu_out, (double*)cov_out, (double*)readings, scr);
+    // (CHX_TUNE_PARAMETER_STAGED=0: every item's table row and map read where they are used)
+    static const bool stage_on = [] { const char* e = getenv("CHX_TUNE_PARAMETER_STAGED"); return !(e && e[0] == '0'); }();
+    const size_t esz = dtype == CHX_F32 ? 4 : 8;
+    const bool staged = stage_on && n_items <= kParamStagedItems;
+    const size_t stage_bytes = staged ? (size_t)n_items * (4 * 8 + CHX_CAV_NCOEF * 8 + 49 * esz + 2 * esz) : 0;
+#define CHX_PARAM_LAUNCH(T, ST)                                                                                                        \
+    hipLaunchKernelGGL((parameter_lattice_kernel<T, ST>), dim3((unsigned)B), dim3(64), stage_bytes, s, (const T*)mu, (const T*)cov, Bmu, \
+                       Bcov, Bm, table, (int)n_items, Rs, coeffs, ptrs, (T*)mu_out, (T*)cov_out, (T*)readings, scr)
+    if (dtype == CHX_F32) {
+        if (staged) CHX_PARAM_LAUNCH(float, true);
+        else CHX_PARAM_LAUNCH(float, false);
+    } else {
+        if (staged) CHX_PARAM_LAUNCH(double, true);
+        else CHX_PARAM_LAUNCH(double, false);
+    }
+#undef CHX_PARAM_LAUNCH
     CHX_CHECK_LAUNCH();
     for (int64_t k = 0; k < n_screens; ++k) {
         if (!screens[k].image) continue;
