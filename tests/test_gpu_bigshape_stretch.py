@@ -10,7 +10,9 @@ kernel. Here the fixtures' beams and settings are PLACED INSIDE big problems (th
  * scans of 64 lattice settings over a shared beam of 70 001 particles with cavities, monitors and apertures, and of 4 096
    settings over 1e5 particles (11.5 GB of result) with monitors and apertures (tests/golden/scan_stretch.npz): rows 0-3 of the
    scan are the fixture's four settings, the beam's first 1 200 particles the fixture's -> that corner against the REFERENCE's
-   (4, 1200, 7) result, a handful of whole rows and their readings against the oracle's walk of that row.
+   (4, 1200, 7) result, a handful of whole rows and their readings against the oracle's walk of that row. Scans whose rows start on
+   16-byte boundaries take `lattice_scan_wave_kernel` (workgroups walk chunks of rows, particle pairs packed in registers, in float32
+   the monitors behind a linear prefix evaluated by moment transport): the 4096 x 1e5 shapes and five shapes of 64 - 1024 rows.
 Measured on the MI355X (relative to a coordinate's scale; worst case of the parametrisations): float32 4.5e-7 vs the reference, 1.0e-6
 vs the oracle over the rows that survive (5.1e-6 with the rows an aperture took, which fly on to 0.2 m), readings 6.1e-8; float64
 5.8e-15 / 1.0e-14 / 3.3e-15 — the bounds are 4 x those or the bounds of the small-shape tests, whichever is larger."""
