@@ -246,3 +246,32 @@ def test_transported_monitor_readings_equal_the_particle_sums(monkeypatch):
     print("transported vs summed readings, per monitor (of the beam size):", [f"{float(e):.1e}" for e in err])
     assert float(err[:4].max()) < 1.2e-7 and float(err[:4].max()) > 0.0       # transported: equal up to the particles' rounding, not identical
     assert float(err[4:].max()) == 0.0                                      # behind the aperture: the particle sums in both runs
+
+
+def test_scan_with_one_row_of_weights_per_setting(monkeypatch):
+    """A shared beam (N, 7) under (B,) settings whose survival probabilities are a (B, N) tensor — every row of the scan its own weights
+    (`Bx = 1`, `Bw = B`): the row-chunk kernel reads a row's weights at the head of that row and sums the monitors over the particles
+    (no moment transport: there is no single weighted mean of the beam). Against the one-(tile, row)-per-workgroup kernel on the same
+    call: particles and survival probabilities bit for bit, readings to the summation order."""
+    import cheetah_amd as ca
+
+    fk = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    torch.manual_seed(1)
+    B, N = 16, 40_000
+    els = [ca.Quadrupole(t(0.2), k1=torch.linspace(-4, 4, B, **fk), **fk), ca.Drift(t(0.5), **fk), ca.BPM(is_active=True, **fk),
+           ca.Aperture(x_max=t(1e-3), y_max=t(1e-3), is_active=True, **fk), ca.Drift(t(0.5), **fk), ca.BPM(is_active=True, **fk)]
+    seg = ca.Segment(els)
+    base = ca.ParticleBeam.from_parameters(num_particles=N, sigma_x=t(4e-4), sigma_y=t(4e-4), energy=t(1e8), **fk)
+    beam = ca.ParticleBeam(base.particles, base.energy, survival_probabilities=torch.rand(B, N, **fk), **fk)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CHX_TUNE_SCAN_WAVE", mode)
+        with torch.no_grad():
+            out = seg.track(beam)
+        res[mode] = (out.particles.clone(), out.survival_probabilities.clone(), torch.stack([e.reading for e in seg.elements if isinstance(e, ca.BPM)]))
+    assert tuple(res["2"][0].shape) == (B, N, 7) and tuple(res["2"][1].shape) == (B, N)
+    assert torch.equal(res["0"][0], res["2"][0]) and torch.equal(res["0"][1], res["2"][1])
+    assert float(res["2"][1].min()) == 0.0                                  # the aperture took particles
+    size = float(base.particles[:, [0, 2]].abs().max())
+    assert float((res["0"][2].double() - res["2"][2].double()).abs().max()) <= 1.2e-7 * size
