@@ -1749,7 +1749,8 @@ __device__ __forceinline__ void lattice_zero_images(const LatticeScreens& scr, i
     if ((((uintptr_t)base) & 15) == 0) {
         const int64_t n16 = (hi - lo) >> 4;
         float4* d = (float4*)(base + lo);
-        for (int64_t i = threadIdx.x; i < n16; i += CHX_BLOCK) d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (streaming stores: 40 MB of zeros for an ARES-sized float64 image should not pass through the L2 on their way out)
+        for (int64_t i = threadIdx.x; i < n16; i += CHX_BLOCK) chx_nt_store(make_float4(0.f, 0.f, 0.f, 0.f), d + i);
         for (int64_t i = lo + (n16 << 4) + threadIdx.x * 4; i < hi; i += CHX_BLOCK * 4) *(uint32_t*)(base + i) = 0u;
     } else {
         for (int64_t i = lo + threadIdx.x * 4; i < hi; i += CHX_BLOCK * 4) *(uint32_t*)(base + i) = 0u;
