@@ -1264,7 +1264,7 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
         }
 #define CHX_SCAN_LAUNCH(T, PPT, ...)                                                                        \
     do {                                                                                                    \
-        if (small_runs) hipLaunchKernelGGL((lattice_scan_wave_kernel<T, PPT, false>), wgrid, __VA_ARGS__);  \
+        if (small_runs & 1) hipLaunchKernelGGL((lattice_scan_wave_kernel<T, PPT, false>), wgrid, __VA_ARGS__); \
         else hipLaunchKernelGGL((lattice_scan_wave_kernel<T, PPT, true>), wgrid, __VA_ARGS__);              \
     } while (0)
         const int64_t wnw = wtiles * (CHX_BLOCK / 64);

@@ -1873,16 +1873,19 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
                 gains = ((double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0) > 0.0;
             }
         }
-        if (threadIdx.x == 0) {
+        // the cavity's map and its coefficient row are two long chains of float64 arithmetic on ONE lane each (a few thousand dependent
+        // instructions): on lanes of two different waves they run side by side (a 16-cell linac at 64 energies: 76 -> ? us per launch)
+        if (threadIdx.x == 0 || threadIdx.x == 64) {
             const int64_t po = elem_poff[elem0];
             const double p[4] = {(double)setting(po), (double)setting(po + 1), (double)setting(po + 2), (double)setting(po + 3)};
-            Mat7<double> M;
-            build_kind<double>((int)elem_kind[elem0], p, E0, mass, nq, M);
-            for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
-            const double dEn = p[1] * cos(p[2] * (kPi / 180.0)) * nq * -1.0;
-            (void)dEn;
-            const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, gains != 0, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
-            if (b == n_items - 1 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E1;
+            if (threadIdx.x == 0) {
+                Mat7<double> M;
+                build_kind<double>((int)elem_kind[elem0], p, E0, mass, nq, M);
+                for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
+            } else {
+                const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, gains != 0, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
+                if (b == n_items - 1 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E1;
+            }
         }
         return;
     }

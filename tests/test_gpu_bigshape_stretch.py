@@ -275,3 +275,41 @@ def test_scan_with_one_row_of_weights_per_setting(monkeypatch):
     assert float(res["2"][1].min()) == 0.0                                  # the aperture took particles
     size = float(base.particles[:, [0, 2]].abs().max())
     assert float((res["0"][2].double() - res["2"][2].double()).abs().max()) <= 1.2e-7 * size
+
+
+@pytest.mark.parametrize("what", ["energies", "phases"])
+def test_big_cavity_scans_through_both_scan_kernels(what, monkeypatch):
+    """A 6-cell linac [Drift, Quadrupole, active Cavity] with a monitor behind every second cell, scanned over 64 beam energies
+    (`small_runs` carries the energy-rows bit, not the no-cavity vouch) / over 64 phases of every cavity, one shared beam of 130 000
+    particles (8.3e6 particle rows: the row-chunk kernel WITH the cavity epilogue) against the one-(tile, row)-per-workgroup kernel on the
+    same call: particles, outgoing energies and readings bit for bit (every monitor sits behind a cavity: particle sums in both)."""
+    import cheetah_amd as ca
+
+    fk = {"dtype": torch.float32, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    torch.manual_seed(5)
+    B, N = 64, 130_000
+    els = []
+    for i in range(6):
+        ph = torch.linspace(-30.0, 30.0, B, **fk) if what == "phases" else t(-10.0 + i)
+        els += [ca.Drift(t(0.3), **fk), ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **fk),
+                ca.Cavity(t(1.0377), voltage=t(18e6), phase=ph, frequency=t(1.3e9), **fk)]
+        if i % 2 == 1:
+            els.append(ca.BPM(is_active=True, **fk))
+    seg = ca.Segment(els)
+    energy = torch.linspace(8e7, 1.6e8, B, **fk) if what == "energies" else t(1e8)
+    base = ca.ParticleBeam.from_parameters(num_particles=N, sigma_x=t(3e-4), sigma_y=t(3e-4), sigma_tau=t(1e-4), energy=t(1e8), **fk)
+    beam = ca.ParticleBeam(base.particles, energy, **fk)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CHX_TUNE_SCAN_WAVE", mode)
+        with torch.no_grad():
+            out = seg.track(beam)
+        res[mode] = (out.particles.clone(), out.energy.clone(), torch.stack([e.reading for e in seg.elements if isinstance(e, ca.BPM)]))
+    assert tuple(res["2"][0].shape) == (B, N, 7)
+    assert torch.equal(res["0"][0], res["2"][0]) and torch.equal(res["0"][1], res["2"][1])
+    assert float((res["2"][0][0] - res["2"][0][B - 1]).abs().max()) > 0           # the rows differ
+    # the cavities act on delta: the rows' outgoing energy spread follows the scan
+    assert float(res["2"][1].max() - res["2"][1].min()) > 1e6
+    size = float(base.particles[:, [0, 2]].abs().max())
+    assert float((res["0"][2].double() - res["2"][2].double()).abs().max()) <= 1.2e-7 * size
