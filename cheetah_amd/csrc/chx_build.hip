@@ -1874,7 +1874,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_kernel(const int64_
             }
         }
         // the cavity's map and its coefficient row are two long chains of float64 arithmetic on ONE lane each (a few thousand dependent
-        // instructions): on lanes of two different waves they run side by side (a 16-cell linac at 64 energies: 76 -> ? us per launch)
+        // instructions): on lanes of two different waves they run side by side (a 16-cell linac: 14.5 -> 13.6 us per launch; at 64 rows
+        // of settings the launch stays at 76 us — 2048 workgroups of four waves are several rounds of the chip, see below)
         if (threadIdx.x == 0 || threadIdx.x == 64) {
             const int64_t po = elem_poff[elem0];
             const double p[4] = {(double)setting(po), (double)setting(po + 1), (double)setting(po + 2), (double)setting(po + 3)};
