@@ -539,6 +539,8 @@ class _LatticePlan:
         # a wave per (item, row) prepares a stretch without cavities and with short runs; else a workgroup does, which pays up to a
         # few hundred rows of vectorised settings only
         self.small_runs = 1 if (cavities == 0 and longest_run <= 64) else 0
+        if longest_run <= 64:
+            self.small_runs |= 8      # CHX_LATTICE_SHORT_RUNS: a wave per (item, row) also with cavities
         if vshape is not None and not self.small_runs and _ops.numel(vshape) > Segment._STRETCH_MAX_ROWS:
             return
         state_bytes = lib.chx_lattice_state_bytes_batched(n_items, n_elems, _ops.numel(vshape) if vshape is not None else 1)

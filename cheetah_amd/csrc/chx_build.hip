@@ -1969,44 +1969,112 @@ __device__ __forceinline__ void compose_wave(MapOf map_of, int E, T* __restrict_
     if (lane < 49) R_row[lane] = (T)acc;
 }
 
-template <typename T>
+// CAV: the stretch may hold active cavities (lattice_prepare_kernel's arithmetic for them: the reference energy walked through the
+// cavities in front of the item and rounded to T behind each, the cavity's map on lane 0 and its coefficient row on lane 1, cavity.py:157's
+// batch-wide switch looked up over all rows). With a workgroup per (item, row) a 16-cell linac at 64 energies is 2048 workgroups of four
+// mostly idle waves — several rounds of the chip, 76 us; a wave per (item, row): one round.
+template <typename T, bool CAV>
 __global__ __launch_bounds__(CHX_BLOCK) void lattice_prepare_rows_kernel(const int64_t* __restrict__ items, const int64_t* __restrict__ elem_kind,
                                                                         const int64_t* __restrict__ elem_poff, const int64_t* __restrict__ ptrs,
                                                                         int n_items, int n_elems, int64_t rows, const T* __restrict__ energy,
                                                                         double mass, double nq, double* __restrict__ Rs,
-                                                                        double* __restrict__ emaps, T* __restrict__ energy_out,
-                                                                        const T* __restrict__ s_in, T* __restrict__ s_out,
-                                                                        int energy_rows /*energy and energy_out are (rows,) arrays*/) {
+                                                                        double* __restrict__ coeffs, double* __restrict__ emaps,
+                                                                        T* __restrict__ energy_out, const T* __restrict__ s_in,
+                                                                        T* __restrict__ s_out,
+                                                                        int energy_rows /*energy is a (rows,) array*/,
+                                                                        int energy_out_rows /*energy_out is a (rows,) array*/) {
     __shared__ double lds[CHX_BLOCK / 64][5 * 49];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pid = (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave;
     if (pid >= (int64_t)n_items * rows) return;             // (whole waves; nothing below synchronises the workgroup)
     const int b = (int)(pid / rows);
     const int64_t row = pid - (int64_t)b * rows;
-    auto setting = [&](int64_t q) {
+    auto setting_of = [&](int64_t q, int64_t r) {
         const uintptr_t a = (uintptr_t)ptrs[q];
         const T* base = reinterpret_cast<const T*>(a & ~(uintptr_t)1);
-        return (a & 1) ? base[row] : base[0];
+        return (a & 1) ? base[r] : base[0];
     };
-    if (energy_rows && b == 0 && lane == 0) energy_out[row] = energy[row];       // (no cavity in the stretch)
-    if (pid == 0 && lane == 0) {
-        if (!energy_rows) *energy_out = energy[0];
-        if (s_out) {
-            T sv = *s_in;
-            for (int i = 0; i < n_items; ++i) {
-                if (items[i * 4] != 0) continue;
-                const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
-                T total = setting(elem_poff[e0]);
-                for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
-                sv = sv + total;
+    auto setting = [&](int64_t q) { return setting_of(q, row); };
+    if (!CAV) {
+        if (energy_rows && b == 0 && lane == 0) energy_out[row] = energy[row];       // (no cavity in the stretch)
+        if (pid == 0 && lane == 0 && !energy_rows) *energy_out = energy[0];
+    }
+    if (pid == 0 && lane == 0 && s_out) {
+        T sv = *s_in;
+        for (int i = 0; i < n_items; ++i) {
+            if (items[i * 4] >= 2) continue;                // (monitors and apertures have no length)
+            const int Ei = (int)items[i * 4 + 1], e0 = (int)items[i * 4 + 2];
+            T total = setting(elem_poff[e0]);
+            for (int e = 1; e < Ei; ++e) total = total + setting(elem_poff[e0 + e]);
+            sv = sv + total;
+        }
+        *s_out = sv;
+    }
+    const int type = (int)items[b * 4];
+    double E0 = (double)energy[energy_rows ? row : 0];
+    if (CAV) {
+        // the reference energy this item sees: the gains of the cavities in front of it are evaluated side by side (lane i: item
+        // base + i), lane 0 adds them in item order, rounding to T behind every cavity like the tensor between two elements
+        double* gain = &lds[wave][0];
+        double* flag = &lds[wave][64];
+        for (int base = 0; base < b; base += 64) {
+            const int i = base + lane;
+            double dEn = 0.0, cav = 0.0;
+            if (i < b && items[i * 4] == 1) {
+                const int64_t po = elem_poff[items[i * 4 + 2]];
+                dEn = (double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0;
+                cav = 1.0;
             }
-            *s_out = sv;
+            gain[lane] = dEn;
+            flag[lane] = cav;
+            chx_wave_sync();
+            if (lane == 0) {
+                const int n = (b - base < 64) ? (b - base) : 64;
+                double e = E0;
+                for (int j = 0; j < n; ++j)
+                    if (flag[j] != 0.0) e = (double)(T)(e + gain[j]);
+                gain[128] = e;
+            }
+            chx_wave_sync();
+            E0 = gain[128];
+            chx_wave_sync();
         }
     }
-    if (items[b * 4] != 0) return;
-    const int E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
-    const double E0 = (double)energy[energy_rows ? row : 0];
     T* R = reinterpret_cast<T*>(Rs + ((int64_t)b * rows + row) * 49);
+    if (type >= 2) {
+        if (CAV && b == n_items - 1 && lane == 0 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E0;
+        return;
+    }
+    if (type == 1) {
+        if (!CAV) return;
+        const int elem0c = (int)items[b * 4 + 2];
+        const int64_t po = elem_poff[elem0c];
+        // cavity.py:157: the second-order path-length terms are on for the WHOLE batch when ANY row gains energy
+        bool gains;
+        const bool vec = (((uintptr_t)ptrs[po + 1]) | ((uintptr_t)ptrs[po + 2])) & 1;
+        if (vec) {
+            bool g = false;
+            for (int64_t r = lane; r < rows; r += 64)
+                g = g || ((double)setting_of(po + 1, r) * cos((double)setting_of(po + 2, r) * (kPi / 180.0)) * nq * -1.0) > 0.0;
+            gains = __ballot(g) != 0ull;
+        } else {
+            gains = ((double)setting(po + 1) * cos((double)setting(po + 2) * (kPi / 180.0)) * nq * -1.0) > 0.0;
+        }
+        if (lane < 2) {
+            const double p[4] = {(double)setting(po), (double)setting(po + 1), (double)setting(po + 2), (double)setting(po + 3)};
+            if (lane == 0) {
+                Mat7<double> M;
+                build_kind<double>((int)elem_kind[elem0c], p, E0, mass, nq, M);
+                for (int q = 0; q < 49; ++q) R[q] = (T)M.m[q];
+            } else {
+                const double E1 = cavity_coeff_row(p[0], p[1], p[2], p[3], E0, mass, nq, gains, coeffs + ((int64_t)b * rows + row) * CHX_CAV_NCOEF);
+                if (b == n_items - 1 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E1;
+            }
+        }
+        return;
+    }
+    if (CAV && b == n_items - 1 && lane == 0 && (row == 0 || energy_out_rows)) energy_out[energy_out_rows ? row : 0] = (T)E0;
+    const int E = (int)items[b * 4 + 1], elem0 = (int)items[b * 4 + 2];
     T* maps = reinterpret_cast<T*>(emaps + (row * (int64_t)n_elems + elem0) * 49);
     if (lane < E) {
         const int kind = (int)elem_kind[elem0 + lane];
@@ -2079,6 +2147,8 @@ extern "C" int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items
     // bit 2: energy_out alone is a (rows,) array (a cavity with a vectorised voltage or phase behind a scalar incoming energy)
     const int energy_out_rows = (energy_rows || (small_runs & CHX_LATTICE_ENERGY_OUT_ROWS)) ? 1 : 0;
     if (energy_out_rows != energy_rows && (small_runs & 1)) return CHX_ERR_INVALID_ARG;       // (no cavity in a small-runs stretch)
+    // bit 3: every run has at most 64 elements, cavities or not — the wave-per-(item, row) kernel with the cavity arithmetic
+    const int short_runs = (small_runs & CHX_LATTICE_SHORT_RUNS) ? 1 : 0;
     small_runs &= 1;
     const size_t need = chx_lattice_state_bytes_batched(n_items, n_elems, rows);
     if (need == 0) return CHX_ERR_INVALID_ARG;
@@ -2092,17 +2162,21 @@ extern "C" int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items
     double* coeffs = Rs + n_items * rows * 49;
     double* emaps = coeffs + n_items * rows * CHX_CAV_NCOEF;
     hipStream_t s = (hipStream_t)stream;
-    if (small_runs && rows > 1) {
+    if ((small_runs || short_runs) && rows > 1) {
         const int64_t pairs = n_items * rows;
         const unsigned g = (unsigned)((pairs + CHX_BLOCK / 64 - 1) / (CHX_BLOCK / 64));
-        if (dtype == CHX_F32)
-            hipLaunchKernelGGL(lattice_prepare_rows_kernel<float>, dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs, (int)n_items,
-                               (int)n_elems, rows, (const float*)energy, mass_eV, n_charges, Rs, emaps, (float*)energy_out,
-                               (const float*)s_in, (float*)s_out, energy_rows);
-        else
-            hipLaunchKernelGGL(lattice_prepare_rows_kernel<double>, dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs,
-                               (int)n_items, (int)n_elems, rows, (const double*)energy, mass_eV, n_charges, Rs, emaps, (double*)energy_out,
-                               (const double*)s_in, (double*)s_out, energy_rows);
+#define CHX_PREPARE_ROWS(T, CAV)                                                                                                          \
+    hipLaunchKernelGGL((lattice_prepare_rows_kernel<T, CAV>), dim3(g), dim3(CHX_BLOCK), 0, s, items, elem_kind, elem_poff, ptrs, (int)n_items, \
+                       (int)n_elems, rows, (const T*)energy, mass_eV, n_charges, Rs, coeffs, emaps, (T*)energy_out, (const T*)s_in,          \
+                       (T*)s_out, energy_rows, energy_out_rows)
+        if (dtype == CHX_F32) {
+            if (small_runs) CHX_PREPARE_ROWS(float, false);
+            else CHX_PREPARE_ROWS(float, true);
+        } else {
+            if (small_runs) CHX_PREPARE_ROWS(double, false);
+            else CHX_PREPARE_ROWS(double, true);
+        }
+#undef CHX_PREPARE_ROWS
         CHX_CHECK_LAUNCH();
         return CHX_OK;
     }

@@ -681,6 +681,9 @@ int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items, int64_t n
 #define CHX_LATTICE_SMALL_RUNS 1
 #define CHX_LATTICE_ENERGY_ROWS 2
 #define CHX_LATTICE_ENERGY_OUT_ROWS 4
+/* bit 3: the caller vouches that every run holds at most 64 elements (cavities allowed): with rows > 1 a wave per (item, row) prepares
+ * the stretch, cavity arithmetic included (a 16-cell linac at 64 energies: 2048 workgroups of four waves otherwise) */
+#define CHX_LATTICE_SHORT_RUNS 8
 int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                              const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
                              void* energy_out, const void* s_in, void* s_out, void* stream);
