@@ -623,9 +623,16 @@ struct ApplyScreens {
 
 // SCREENS: 0 = no screen items, 1 = screens that record only (no image buffer in this call: none of the combining table's 32 KiB
 // of LDS, which would leave four workgroups per CU), 2 = screens with images
-template <typename T, int PPT, int SCREENS>
-__global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in, T* x_out, const int64_t* __restrict__ items, int n_items,
-                                                                 const double* __restrict__ Rs, const double* __restrict__ coeffs,
+// STAGED (small beams, stretches of at most kApplyStagedItems items): the workgroup copies the item table, this row's maps and the
+// cavities' coefficient rows into LDS next to its particle tile — one round of loads — and walks the items out of LDS. A beam of 1e5
+// particles is one or two workgroups per CU: nothing hides the scalar loads in front of every item (its type, then its 49 map entries
+// in up to four pieces), and a 100-element lattice with 25 monitors is 51 items: 26 us of a pass whose arithmetic is a fifth of that.
+constexpr int kApplyStagedItems = 96;
+constexpr int kApplyMapStride = 52;
+
+template <typename T, int PPT, int SCREENS, bool STAGED>
+__global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in, T* x_out, const int64_t* __restrict__ items_g, int n_items,
+                                                                 const double* __restrict__ Rs, const double* __restrict__ coeffs_g,
                                                                  int64_t N, int in_vec_ok, int out_vec_ok,
                                                                  const T* __restrict__ survival, double* __restrict__ bpm_ws, int diag,
                                                                  const int64_t* __restrict__ ptrs, T* __restrict__ survival_out,
@@ -644,6 +651,23 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
     const bool row_vec = ((beam * N * 7 * (int64_t)sizeof(T)) & 15) == 0;
     // (a beam shared by the rows of a scan of lattice settings is re-read by every row: no streaming hint then)
     tile_load<T, TP>(x_in + (shared_in ? t0 : n0) * 7, lds, np * 7, in_vec_ok != 0 && (shared_in || row_vec), !shared_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
+    T* maps_s = reinterpret_cast<T*>(stage_raw);                                              // [n_items][kApplyMapStride]
+    double* coeffs_s = reinterpret_cast<double*>(maps_s + (STAGED ? n_items * kApplyMapStride : 0));   // [n_items][CHX_CAV_NCOEF]
+    int64_t* items_s = reinterpret_cast<int64_t*>(coeffs_s + (STAGED ? n_items * CHX_CAV_NCOEF : 0));  // [n_items][4]
+    const int64_t* items = STAGED ? items_s : items_g;
+    if constexpr (STAGED) {
+        const int64_t mrow0 = (Bm == 1 ? 0 : beam);
+        for (int w = threadIdx.x; w < n_items * 49; w += CHX_BLOCK) {
+            const int it = w / 49, q = w - it * 49;
+            maps_s[it * kApplyMapStride + q] = reinterpret_cast<const T*>(Rs + ((int64_t)it * Bm + mrow0) * 49)[q];
+        }
+        for (int w = threadIdx.x; w < n_items * CHX_CAV_NCOEF; w += CHX_BLOCK) {
+            const int it = w / CHX_CAV_NCOEF, q = w - it * CHX_CAV_NCOEF;
+            coeffs_s[w] = coeffs_g[((int64_t)it * Bm + mrow0) * CHX_CAV_NCOEF + q];
+        }
+        for (int w = threadIdx.x; w < n_items * 4; w += CHX_BLOCK) items_s[w] = items_g[w];
+    }
     __syncthreads();
     LaneRows<T, PPT> x;
 #pragma unroll
@@ -793,9 +817,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             continue;
         }
         const int64_t mrow = (int64_t)i * Bm + (Bm == 1 ? 0 : beam);       // this row's map of the item (vectorised settings)
-        const T* __restrict__ R = reinterpret_cast<const T*>(Rs + mrow * 49);
+        const T* __restrict__ R = STAGED ? maps_s + i * kApplyMapStride : reinterpret_cast<const T*>(Rs + mrow * 49);
         const bool cavity = type == 1;
-        const double* __restrict__ c = coeffs + mrow * CHX_CAV_NCOEF;
+        const double* __restrict__ c = STAGED ? coeffs_s + i * CHX_CAV_NCOEF : coeffs_g + mrow * CHX_CAV_NCOEF;
         if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
             // the lane's particles two to a register pair, kept that way from load to store: every step of apply7's fmaf chain is ONE
             // v_pk_fma_f32 for both (same per-particle order -> same bits; at 4e8 particle rows the maps of a stretch are VALU time,
@@ -1294,10 +1318,23 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
 #undef CHX_SCAN_LAUNCH
         return CHX_OK;
     }
+    // small beams walk their items out of LDS (CHX_TUNE_APPLY_STAGED=0: every item's type and map read where they are used)
+    static const bool stage_on = [] { const char* e = getenv("CHX_TUNE_APPLY_STAGED"); return !(e && e[0] == '0'); }();
+    // (at most 16 KB next to the particle tile and, with screens, the 32 KB combining table: inside the default 64 KB of a workgroup)
+    const size_t stage_need = (size_t)n_items * (kApplyMapStride * (dtype == CHX_F32 ? 4 : 8) + CHX_CAV_NCOEF * 8 + 4 * 8);
+    const bool staged = stage_on && ppt == 1 && n_items <= kApplyStagedItems && stage_need <= 16384;
+    const size_t stage_bytes = staged ? stage_need : 0;
 #define CHX_LATTICE_APPLY_S(T, PPT, SCR)                                                                                            \
-    hipLaunchKernelGGL((lattice_apply_kernel<T, PPT, SCR>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out, table,          \
-                       (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs, (T*)survival_out,   \
-                       shared_in, Bm, shared_sv, scr)
+    do {                                                                                                                            \
+        if (PPT == 1 && staged)                                                                                                     \
+            hipLaunchKernelGGL((lattice_apply_kernel<T, 1, SCR, true>), grid, dim3(CHX_BLOCK), stage_bytes, s, (const T*)x_in,      \
+                               (T*)x_out, table, (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, \
+                               ptrs, (T*)survival_out, shared_in, Bm, shared_sv, scr);                                              \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((lattice_apply_kernel<T, PPT, SCR, false>), grid, dim3(CHX_BLOCK), 0, s, (const T*)x_in, (T*)x_out,  \
+                               table, (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs,      \
+                               (T*)survival_out, shared_in, Bm, shared_sv, scr);                                                    \
+    } while (0)
     bool images = false;
     for (int64_t k = 0; k < n_screens; ++k) images = images || screens[k].image != nullptr;
 #define CHX_LATTICE_APPLY(T, PPT)                  \
