@@ -1322,7 +1322,11 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
     static const bool stage_on = [] { const char* e = getenv("CHX_TUNE_APPLY_STAGED"); return !(e && e[0] == '0'); }();
     // (at most 16 KB next to the particle tile and, with screens, the 32 KB combining table: inside the default 64 KB of a workgroup)
     const size_t stage_need = (size_t)n_items * (kApplyMapStride * (dtype == CHX_F32 ? 4 : 8) + CHX_CAV_NCOEF * 8 + 4 * 8);
-    const bool staged = stage_on && ppt == 1 && n_items <= kApplyStagedItems && stage_need <= 16384;
+    // Taken where it was measured to pay (kernel durations, rocprofv3, 1e4 particles): float64 maps — C1's pass with its screen 14.8 -> 8.3 us
+    // — and stretches with cavities — a 16-cell float32 linac 25.0 -> 19.0 us; a float32 stretch without cavities is level (100 elements,
+    // 25 monitors, 1e5 particles: 25.8 / 26.5 us) or loses (the control step's four items: 7.8 -> 9.7 us) and keeps its scalar loads.
+    const bool staged = stage_on && ppt == 1 && n_items <= kApplyStagedItems && stage_need <= 16384 &&
+                        (dtype == CHX_F64 || !(small_runs & 1));
     const size_t stage_bytes = staged ? stage_need : 0;
 #define CHX_LATTICE_APPLY_S(T, PPT, SCR)                                                                                            \
     do {                                                                                                                            \
