@@ -914,8 +914,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
     __shared__ __attribute__((aligned(16))) T lds[TP * 7];
     const int64_t t0 = (int64_t)blockIdx.x * TP;
     const int np = (int)((N - t0 < TP) ? (N - t0) : TP);
-    const int64_t b0 = (int64_t)blockIdx.y * rows_per_chunk;
-    const int64_t b1 = (b0 + rows_per_chunk < B) ? b0 + rows_per_chunk : B;
+    const int b0 = (int)blockIdx.y * (int)rows_per_chunk;                  // (B <= 65535)
+    const int b1 = (b0 + (int)rows_per_chunk < (int)B) ? b0 + (int)rows_per_chunk : (int)B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     tile_load<T, TP>(x_in + t0 * 7, lds, np * 7, in_vec_ok != 0, false);      // (re-read by every chunk of rows: no streaming hint)
@@ -937,9 +937,8 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
     // from here on a wave touches only its own slice
     const int valid = (np - wave * WP < 0) ? 0 : ((np - wave * WP < WP) ? (np - wave * WP) : WP);   // particles of this wave that exist
     const int vchunks = valid * 7 / VN;           // whole chunks inside the valid rows
-    const int64_t nw = (int64_t)gridDim.x * (CHX_BLOCK / 64);            // waves per row
-    const int64_t nw_all = nw * B;
-    for (int64_t b = b0; b < b1; ++b) {
+    const int nw = (int)gridDim.x * (CHX_BLOCK / 64);                    // waves per row
+    for (int b = b0; b < b1; ++b) {
         LaneRows<T, PPT> x = x0;
         T sv[PPT];
 #pragma unroll
@@ -948,10 +947,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int p = wave * WP + k * 64 + lane;
-                sv[k] = (p < np) ? survival[b * N + t0 + p] : (T)0;
+                sv[k] = (p < np) ? survival[(int64_t)b * N + t0 + p] : (T)0;
             }
         }
-        const int64_t wslot = b * nw + (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave;
+
         bool sw_known = false;
         double sw = 0.0;
         bool linear = transport != 0;                // nothing but maps and monitors so far in this row's stretch
@@ -977,7 +976,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
                 sx = chx_wave_sum_lane63(sx);
                 sy = chx_wave_sum_lane63(sy);
                 if (lane == 63) {
-                    double* part = bpm_ws + ((int64_t)items[i * 4 + 3] * nw_all + wslot) * 3;
+                    double* part = bpm_ws + (((int64_t)items[i * 4 + 3] * B + b) * nw + (int64_t)blockIdx.x * (CHX_BLOCK / 64) + wave) * 3;
                     part[0] = sw;
                     part[1] = sx;
                     part[2] = sy;
@@ -1061,7 +1060,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int p = wave * WP + k * 64 + lane;
-                if (p < np) survival_out[b * N + t0 + p] = sv[k];
+                if (p < np) survival_out[(int64_t)b * N + t0 + p] = sv[k];
             }
         }
 #pragma unroll
@@ -1072,7 +1071,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_scan_wave_kernel(const T* _
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        T* __restrict__ gout = x_out + (b * N + t0 + wave * WP) * 7;
+        T* __restrict__ gout = x_out + ((int64_t)b * N + t0 + wave * WP) * 7;
         V* __restrict__ gv = reinterpret_cast<V*>(gout);
         const V* lv = reinterpret_cast<const V*>(wl);
 #pragma unroll
