@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
                                                              const T* __restrict__ extent, const T* __restrict__ scale,
                                                              T* __restrict__ cross /* = acc */, uint16_t* __restrict__ home,
                                                              int* __restrict__ newcount, int* __restrict__ mis_slots,
-                                                             int parts_shift, ScGeoSums rider) {
+                                                             int parts_shift, ScGeoSums rider, int diag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* blk = reinterpret_cast<double*>(smem);
     __shared__ int nbr[27];
@@ -1239,16 +1239,16 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
             for (int d = 0; d < 3; ++d)
                 hc[d] = (pi[d] < 0 ? 0 : (pi[d] > a.bins[d] - 1 ? a.bins[d] - 1 : pi[d])) >> g.tshift[d];   // = sc_home_tile
             const int h = (hc[0] * g.ntile[1] + hc[1]) * g.ntile[2] + hc[2];
-            home[r] = (uint16_t)h;
+            if (!(diag & 4)) home[r] = (uint16_t)h;
             if (h == t) ++stay;
-            else {
+            else if (!(diag & 4)) {
                 const int dx = hc[0] - tc[0], dy = hc[1] - tc[1], dz = hc[2] - tc[2];
                 if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) atomicAdd(&nbr[(dx + 1) * 9 + (dy + 1) * 3 + dz + 1], 1);
                 else atomicAdd(&newcount[h], 1);
             }
             const int l[3] = {pi[0] - org[0], pi[1] - org[1], pi[2] - org[2]};
             if (!(l[0] >= 0 && l[0] < TX && l[1] >= 0 && l[1] < TY && l[2] >= 0 && l[2] < TZ)) ++mis;
-            if (!inside) continue;                      // outside the extent: no charge (cloud_in_cell.py:289-311)
+            if (!inside || (diag & 1)) continue;        // outside the extent: no charge (cloud_in_cell.py:289-311)
             // ONE code path for filed and misfiled particles (a branch for the latter cost every wave that held a single one of
             // them the whole detour: +9 us on the kernel at 1 % misfiled). Per corner: in the grid? (the reference's in-range
             // mask) -> in this tile's block? -> LDS, else the `cross` grid with a global atomic (the arithmetic of
@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(TH) void sc_tile_deposit_kernel(CicDev a, ScTileGeo
     if (threadIdx.x == 32 && nstay) atomicAdd(&newcount[t], nstay);
     for (int i = threadIdx.x; i < ncell; i += TH) {
         const T v = (T)blk[i];
-        if (v == (T)0) continue;                        // (cells of the +1 layer beyond the grid edge never receive anything)
+        if (v == (T)0 || (diag & 2)) continue;          // (cells of the +1 layer beyond the grid edge never receive anything)
         const int lz = i % BY, ly = (i / BY) % (TY + 1), lx = i / BX;
         unsafeAtomicAdd(cross + (int64_t)(org[0] + lx) * a.gstride[0] + (int64_t)(org[1] + ly) * a.gstride[1] +
                             (int64_t)(org[2] + lz) * a.gstride[2], v);
@@ -1385,15 +1385,18 @@ int sc_tile_deposit_launch(const CicDev& a, const ScTileGeom& g, const ScTileLay
     auto kern = th == 1024 ? sc_tile_deposit_kernel<T, 1024> : th == 512 ? sc_tile_deposit_kernel<T, 512> : sc_tile_deposit_kernel<T, 256>;
     // workgroups per tile: an occupied tile of a 3-sigma grid holds ~4 N / nt slots; shares of at most ~2048 slots
     // (benchmarks/sc_chain_density.py: one workgroup per tile costs 841 us per kick at 1e6 particles on 32^3)
+    static const int share = [] { const char* e = getenv("CHX_TUNE_DEPOSIT_SHARE"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 2048; }();
+    // CHX_TUNE_DEPOSIT_DIAG (timing experiments, WRONG results): 1 no LDS atomics, 2 no flush, 4 no home / neighbour counters
+    static const int diag = [] { const char* e = getenv("CHX_TUNE_DEPOSIT_DIAG"); return e ? atoi(e) : 0; }();
     int parts_shift = 0;
-    while (parts_shift < 6 && ((a.N * 4 / g.nt) >> parts_shift) > 2048) ++parts_shift;
+    while (parts_shift < 6 && ((a.N * 4 / g.nt) >> parts_shift) > share) ++parts_shift;
     ScGeoSums rd = ScGeoSums();
     if (rider) rd = *rider;
     // (the rider's reduction borrows the tile block's LDS: (th / 16 + 1) * 8 doubles)
     if (rd.sums && blk_bytes < (size_t)(th / 16 + 1) * 8 * sizeof(double)) return CHX_ERR_INVALID_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)g.nt << parts_shift), dim3(th), blk_bytes, s, a, g, hdr, (const int*)(st + L.tile_start[0]),
                        (const T*)rows, (const T*)(st + L.cs[0]), (const T*)extent, (const T*)scale, (T*)(st + L.cross),
-                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis), parts_shift, rd);
+                       (uint16_t*)(st + L.home), (int*)(st + L.newcount), (int*)(st + L.mis), parts_shift, rd, diag);
     CHX_CHECK_LAUNCH();
     if (schedule) {
         const ScScheduleArgs sa = sc_schedule_args(g, L, st, a.N, allow_reorder);

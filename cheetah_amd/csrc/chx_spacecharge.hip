@@ -138,6 +138,217 @@ __device__ __forceinline__ T node_force(T lo, T hi, T h, T neg_ig2, bool interio
 template <typename T, int N>
 struct alignas(sizeof(T)) Run { T v[N]; };   // N consecutive grid values at element (not vector) alignment
 
+// ---- the particle step of a float32 beam from the potential, in float32 (round 6) ------------------------------------------
+// space_charge_kick.py:387-475 (node-based trilinear gather of the force), :548-565 (p += F dt between to_xyz_pxpypz and
+// from_xyz_pxpypz, particle_beam.py:1262-1346). Until round 5 a float32 row went through the float64 step below (SI momenta,
+// 11 divisions and 5 square roots in fp64: 534 of the pass's ~1300 instructions per wave, the gather pass VALU-bound at 38 us per
+// 1e6 rows). The SI detour is not needed for the accuracy: in units of m c, with g = gamma0 (1 + delta beta0) the particle's
+// gamma and pn = (px, py) gamma0 beta0, pz = sqrt(g^2 - 1 - pn^2), the kick k = F e dt / (m c) gives
+//     px' = px + kx / (gamma0 beta0)                     (one rounding: the sum itself)
+//     g'^2 = g^2 + D,   D = 2 (pn . k) + k . k
+//     delta' = (g' - gamma0) / (gamma0 beta0) = delta + D / ((g' + g) gamma0 beta0)
+// — the same real-number map as the reference's, with the cancellation g' - gamma0 removed algebraically instead of carried in
+// fp64: every term is a float32 product with a relative error of ~1e-7 OF THE KICK, and x, y, tau pass through untouched
+// (the fp64 step returns them bit for bit as well). The potential is float32 to begin with. Measured against the reference's
+// float64 run: profiles/r06_c4_gather.md. Float64 beams keep the fp64 step (sc_kick_locate / sc_kick_finish below).
+struct ScKickCtx32 {
+    float gamma0, p0n, rp0n, nbeta;      // gamma0, gamma0 beta0, its reciprocal, -beta0
+    float r_hi[3], r_lo[3];              // 1 / cell as a sum of two floats (the cell coordinate keeps ~1e-7 of a cell, see below)
+    float h_hi[3], h_lo[3];              // half / cell likewise
+    float k[3];                          // (sum of weights x potential differences along d) -> kick in units of m c
+    int g[3];
+};
+
+// No division in here: a wave holds 64 rows, so what a lane does once per kick is paid per row (seven float32 divisions were ~80 of
+// the pass's instructions). v_rcp_f32 / v_sqrt_f32 are good to 1 ulp, which is what the terms they enter need.
+__device__ __forceinline__ ScKickCtx32 sc_kick_ctx32(const float* __restrict__ half, const float* __restrict__ cell,
+                                                     const float* __restrict__ energy, const float* __restrict__ dt,
+                                                     const float* __restrict__ gamma, float inv_mass, float c_over_m, int gx, int gy,
+                                                     int gz) {
+    ScKickCtx32 c;
+    const float g0 = energy[0] * inv_mass;                                // beam.py:323-326
+    c.gamma0 = g0;
+    c.p0n = __builtin_amdgcn_sqrtf((g0 - 1.0f) * (g0 + 1.0f));            // gamma0 beta0 = sqrt(gamma0^2 - 1), beam.py:328-336
+    c.rp0n = __builtin_amdgcn_rcpf(c.p0n);
+    c.nbeta = (fabsf(g0) > 0.0f) ? -(c.p0n * __builtin_amdgcn_rcpf(g0)) : -1.0f;
+    const float gm = gamma[0];
+    const float nig2 = -((gm != 0.0f) ? __builtin_amdgcn_rcpf(gm * gm) : 0.0f);   // space_charge_kick.py:367-372
+    const float kmom = dt[0] * c_over_m;                                  // e dt / (m c) = dt c / (m c^2 / e)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float cl = cell[d], hf = half[d];
+        const float r = __builtin_amdgcn_rcpf(cl);
+        c.r_hi[d] = r;
+        c.r_lo[d] = fmaf(-cl, r, 1.0f) * r;                               // 1 / cell - r to first order
+        c.h_hi[d] = hf * r;
+        c.h_lo[d] = fmaf(hf, r, -c.h_hi[d]) + hf * c.r_lo[d];
+        c.k[d] = (nig2 * (0.5f * r)) * kmom;                              // -(1 / gamma^2) / (2 h) x e dt / (m c)
+    }
+    c.g[0] = gx; c.g[1] = gy; c.g[2] = gz;
+    return c;
+}
+
+// one row: v (Cheetah coordinates) -> out (kicked, Cheetah coordinates); phi points at the first element of the potential's
+// array (node (0, 0, 0) sits at [2][2][2] inside its halo of 2), py / pz are the array's x / y strides; the array has less than
+// 2^30 elements (32-bit element offsets from a wave-uniform base: scalar base + vector offset addressing)
+__device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float (&v)[7], const float* __restrict__ phi, int py,
+                                              int pz, float (&out)[7], int diag = 0) {
+    const float pos[3] = {v[0], v[2], v[4] * c.nbeta};
+    float f[3];
+    int i0[3], cn[3];
+    bool finite = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        // cell coordinate u = (pos + half) / cell (space_charge_kick.py:405-411). A float32 u near the far end of a 128-node axis
+        // resolves 8e-6 of a cell; its fraction f = u - floor(u) is therefore formed again around the integer with the low parts
+        // of 1 / cell and half / cell (two more FMAs per axis) and keeps ~1e-7 of a cell. floor(u) itself may land on the wrong
+        // side of a node for a row within 1e-5 cells of it: f is then just below 0 or above 1 and the trilinear form, which is
+        // continuous across nodes, extrapolates by that much.
+        const float u = fmaf(pos[d], c.r_hi[d], c.h_hi[d]);
+        finite = finite && (fabsf(u) <= 3.0e38f);                         // false for inf and NaN (a grid without extent)
+        float fl = floorf(u);
+        f[d] = fmaf(pos[d], c.r_hi[d], c.h_hi[d] - fl) + fmaf(pos[d], c.r_lo[d], c.h_lo[d]);
+        fl = fl > 2.0e9f ? 2.0e9f : (fl < -2.0e9f ? -2.0e9f : fl);
+        i0[d] = (int)fl;
+        cn[d] = min(max(i0[d], -1), c.g[d] - 1);
+    }
+    // the 32 potential values around the cell (see phi_cell_forces): z runs of 4 on the four central rows, z pairs one step out
+    unsigned o = 4u * (unsigned)((cn[0] + 2) * py + (cn[1] + 2) * pz + (cn[2] + 2));   // byte offset of the cell's first node
+    if (diag & 1) o = 4u * (unsigned)(2 * py + 2 * pz + 2);   // (timing experiments only: every lane reads the same cell)
+    const char* __restrict__ pb = reinterpret_cast<const char*>(phi);
+    Run<float, 4> zr[2][2];
+    Run<float, 2> xr[2][2], yr[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            zr[a][b] = *reinterpret_cast<const Run<float, 4>*>(pb + (o + 4u * (unsigned)(a * py + b * pz - 1)));
+            xr[a][b] = *reinterpret_cast<const Run<float, 2>*>(pb + (o + 4u * (unsigned)((a ? 2 : -1) * py + b * pz)));
+            yr[a][b] = *reinterpret_cast<const Run<float, 2>*>(pb + (o + 4u * (unsigned)(b * py + (a ? 2 : -1) * pz)));
+        }
+    }
+    // per axis and corner: is the node inside the grid (its weight counts), is it an interior node (its central difference
+    // along that axis exists; boundary nodes carry force 0, space_charge_kick.py:340-365)
+    bool in[3][2], inner[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int n = i0[d] + a;
+            in[d][a] = n >= 0 && n < c.g[d];
+            inner[d][a] = n > 0 && n < c.g[d] - 1;
+        }
+    }
+    const float wx[2] = {1.0f - f[0], f[0]}, wy[2] = {1.0f - f[1], f[1]}, wz[2] = {1.0f - f[2], f[2]};
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float wab = wx[a] * wy[b];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                // differences along x / y / z at node (cn0 + a, cn1 + b, cn2 + e); a value outside the grid or a difference that
+                // reaches into the halo (whose content is undefined, possibly NaN) is replaced by 0, not multiplied by 0
+                const float xlo = a ? zr[0][b].v[1 + e] : xr[0][b].v[e];
+                const float xhi = a ? xr[1][b].v[e] : zr[1][b].v[1 + e];
+                const float ylo = b ? zr[a][0].v[1 + e] : yr[0][a].v[e];
+                const float yhi = b ? yr[1][a].v[e] : zr[a][1].v[1 + e];
+                const float zlo = zr[a][b].v[e], zhi = zr[a][b].v[e + 2];
+                const bool node_in = in[0][a] && in[1][b] && in[2][e];
+                const float w = wab * wz[e];
+                sx = fmaf(w, (node_in && inner[0][a]) ? xhi - xlo : 0.0f, sx);
+                sy = fmaf(w, (node_in && inner[1][b]) ? yhi - ylo : 0.0f, sy);
+                sz = fmaf(w, (node_in && inner[2][e]) ? zhi - zlo : 0.0f, sz);
+            }
+        }
+    }
+    float kx = sx * c.k[0], ky = sy * c.k[1], kz = sz * c.k[2];
+    if (!finite) kx = ky = kz = __builtin_nanf("");
+    const float g = fmaf(c.p0n, v[5], c.gamma0);
+    const float pxn = v[1] * c.p0n, pyn = v[3] * c.p0n;
+    const float pzn = __builtin_amdgcn_sqrtf(fmaf(g - 1.0f, g + 1.0f, -fmaf(pxn, pxn, pyn * pyn)));
+    const float D = fmaf(2.0f, fmaf(pxn, kx, fmaf(pyn, ky, pzn * kz)), fmaf(kx, kx, fmaf(ky, ky, kz * kz)));
+    const float g1 = __builtin_amdgcn_sqrtf(fmaf(g, g, D));
+    out[0] = v[0];
+    out[1] = fmaf(kx, c.rp0n, v[1]);
+    out[2] = v[2];
+    out[3] = fmaf(ky, c.rp0n, v[3]);
+    out[4] = v[4];
+    out[5] = fmaf(D, __builtin_amdgcn_rcpf((g1 + g) * c.p0n), v[5]);
+    out[6] = v[6];
+}
+
+// the linear run behind a kick on the kicked row, the fma chain of chx_apply_affine7 (bit-identical to a second pass)
+__device__ __forceinline__ void sc_post_map32(const float* __restrict__ R, float (&x)[7]) {
+    float y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        float acc = R[i * 7] * x[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) acc = fmaf(R[i * 7 + j], x[j], acc);
+        y[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = y[i];
+}
+
+// CHX_SC_GATHER_FP64=1: float32 beams take the float64 particle step of rounds 1-5 again (A/B runs, bisecting)
+static bool sc_gather_fp64() {
+    static const bool on = [] {
+        const char* e = getenv("CHX_SC_GATHER_FP64");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
+// CHX_TUNE_GATHER_DIAG (timing experiments, WRONG results): 1 every lane reads the potential around one cell, 2 no beam-size sums
+static int sc_gather_diag() {
+    static const int v = [] { const char* e = getenv("CHX_TUNE_GATHER_DIAG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+// sc_kick_row32 addresses the potential with 32-bit element offsets
+static bool sc_phi_offsets_fit32(const int32_t* bins) {
+    return bins && (int64_t)(bins[0] + 4) * (bins[1] + 4) * (bins[2] + 4) < (1LL << 30);
+}
+
+// chx_sc_gather_kick_phi on a float32 beam: the float32 particle step above, rows staged per wave like sc_particle_kernel below;
+// inv_mass = (float)(1 / mass_eV), c_over_m = (float)(c / mass_eV) from the host
+__global__ __launch_bounds__(CHX_BLOCK) void sc_particle32_kernel(
+    const float* __restrict__ x_in, const float* __restrict__ phi, const float* __restrict__ half, const float* __restrict__ cell,
+    const float* __restrict__ energy, const float* __restrict__ dt, float inv_mass, float c_over_m, int64_t Bx, int64_t Be, int64_t N,
+    int gx, int gy, int gz, float* __restrict__ x_out, const float* __restrict__ post_map, int64_t BR,
+    const float* __restrict__ gamma) {
+    constexpr int TP = CHX_BLOCK;
+    __shared__ __attribute__((aligned(16))) float lds[TP * 7];
+    const int64_t b = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const int np = (int)((N - n0 < TP) ? (N - n0) : TP);
+    const int64_t xrow = (Bx == 1) ? 0 : b;
+    const bool vin = chx_aligned16(x_in) && (((xrow * N * 7 * (int64_t)sizeof(float)) & 15) == 0);
+    const bool vout = chx_aligned16(x_out) && (((b * N * 7 * (int64_t)sizeof(float)) & 15) == 0);
+    const int wrow = (threadIdx.x >> 6) * 64;
+    const int wvalid = (np - wrow < 0) ? 0 : ((np - wrow < 64) ? (np - wrow) : 64);
+    wave_tile_load<float>(x_in + (xrow * N + n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vin, Bx != 1 || gridDim.y == 1);
+    chx_wave_sync();
+    const ScKickCtx32 c = sc_kick_ctx32(half + b * 3, cell + b * 3, energy + (Be == 1 ? 0 : b), dt + b, gamma + b, inv_mass, c_over_m,
+                                        gx, gy, gz);
+    const int pzs = gz + 4, pys = (gy + 4) * pzs;
+    const int p = threadIdx.x;
+    if (p < np) {
+        float v[7], out[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[j] = lds[p * 7 + j];
+        sc_kick_row32(c, v, phi + b * (int64_t)(gx + 4) * pys, pys, pzs, out);
+        if (post_map) sc_post_map32(post_map + ((BR == 1) ? 0 : b) * 49, out);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) lds[p * 7 + j] = out[j];
+    }
+    chx_wave_sync();
+    wave_tile_store<float>(x_out + (b * N + n0 + wrow) * 7, lds + wrow * 7, wvalid * 7, vout, true);
+}
+
 // MODE 0: gather + kick (full SpaceChargeKick particle step); 1: to_xyz only; 2: from_xyz only
 // FROM_PHI (MODE 0): F is the potential with a halo instead of the force grid; the central differences are taken here
 template <typename T, int MODE, bool FROM_PHI = false>
@@ -592,7 +803,11 @@ static int launch_particle(const void* x_in, const void* F, const void* half, co
     if (tiles > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
     dim3 grid((unsigned)tiles, (unsigned)B);
     const int gx = bins ? bins[0] : 0, gy = bins ? bins[1] : 0, gz = bins ? bins[2] : 0;
-    if (dtype == CHX_F32)
+    if (dtype == CHX_F32 && MODE == 0 && FROM_PHI && !sc_gather_fp64() && sc_phi_offsets_fit32(bins))
+        hipLaunchKernelGGL(sc_particle32_kernel, grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in, (const float*)F, (const float*)half,
+                           (const float*)cell, (const float*)energy, (const float*)dt, (float)(1.0 / mass_eV), (float)(kC / mass_eV), Bx, Be, N,
+                           gx, gy, gz, (float*)x_out, (const float*)post_map, BR, (const float*)gamma);
+    else if (dtype == CHX_F32)
         hipLaunchKernelGGL((sc_particle_kernel<float, MODE, FROM_PHI>), grid, dim3(CHX_BLOCK), 0, s, (const float*)x_in,
                            (const float*)F, (const float*)half, (const float*)cell, (const float*)energy,
                            (const float*)dt, mass_eV, Bx, Be, N, gx, gy, gz, (float*)x_out, (const float*)post_map, BR,
@@ -893,6 +1108,80 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle_kernel(
     }
 }
 
+// The float32 beam's pass: the float32 particle step (sc_kick_row32), everything else as above.
+__global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle32_kernel(
+    const float* __restrict__ src, const ScTileHeader* __restrict__ hdr, int* perm2, float* ws2, float* cs2,
+    const uint16_t* __restrict__ home, int* __restrict__ cursor, const float* __restrict__ phi, const float* __restrict__ half,
+    const float* __restrict__ cell, const float* __restrict__ energy, const float* __restrict__ dt, const float* __restrict__ gamma,
+    float inv_mass, float c_over_m, int64_t N, int gx, int gy, int gz, float* __restrict__ x_out, const float* __restrict__ post_map,
+    int unpermute, double* __restrict__ sigma_partials, int* __restrict__ newcount, int nt, int* __restrict__ mis,
+    double* __restrict__ sums_add /*[8][256] or null*/, double* __restrict__ sums_clear, int diag) {
+    __shared__ __attribute__((aligned(16))) float lds[CHX_BLOCK * 7];
+    __shared__ double red[16 * 8];
+    if (diag & 2) sigma_partials = nullptr;
+    const int par = hdr->parity;
+    const int mode = hdr->scatter_now ? 2 : (unpermute ? 1 : 0);
+    for (int k = (int)blockIdx.x * CHX_BLOCK + threadIdx.x; k < nt; k += (int)gridDim.x * CHX_BLOCK) newcount[k] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kScMisSlots) mis[threadIdx.x] = 0;
+    if (sums_clear) {
+        for (int k = (int)blockIdx.x * CHX_BLOCK + threadIdx.x; k < 8 * 256; k += (int)gridDim.x * CHX_BLOCK) sums_clear[k] = 0.0;
+    }
+    const bool vin = chx_aligned16(src), vout = chx_aligned16(x_out);
+    const int pz = gz + 4, py = (gy + 4) * pz;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* wlds = lds + wave * 64 * 7;
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wave) * 64;             // first row of this wave's segment
+    const int wvalid = (N - w0 <= 0) ? 0 : (int)((N - w0 < 64) ? (N - w0) : 64);
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.0;
+    if (wvalid > 0) {                                                     // (wave-uniform)
+        wave_tile_load<float>(src + w0 * 7, wlds, wvalid * 7, vin, true);
+        const float wgt = (sigma_partials && lane < wvalid) ? ws2[(int64_t)par * N + w0 + lane] : 0.0f;
+        const ScKickCtx32 c = sc_kick_ctx32(half, cell, energy, dt, gamma, inv_mass, c_over_m, gx, gy, gz);
+        chx_wave_sync();
+        const bool active = lane < wvalid;
+        float out[7];
+        if (active) {
+            float v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = wlds[lane * 7 + j];
+            sc_kick_row32(c, v, phi, py, pz, out, diag);
+            if (post_map) sc_post_map32(post_map, out);
+        }
+        if (sigma_partials && active) {
+            // the rows written here are the beam the NEXT kick of the chain sees (space_charge_kick.py:531-538): its sums about the origin
+            const double w = (double)wgt;
+            const double d0 = (double)out[0], d1 = (double)out[2], d2 = (double)out[4];
+            const double w0d = w * d0, w1d = w * d1, w2d = w * d2;
+            a[0] = w; a[1] = w * w;
+            a[2] = w0d; a[3] = w1d; a[4] = w2d;
+            a[5] = w0d * d0; a[6] = w1d * d1; a[7] = w2d * d2;
+        }
+        if (mode == 0) {
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) wlds[lane * 7 + j] = out[j];
+            }
+            chx_wave_sync();
+            wave_tile_store<float>(x_out + w0 * 7, wlds, wvalid * 7, vout, true);
+        } else {
+            const int64_t dst = sc_row_dest<float>(active, w0 + lane, mode, par, N, perm2, home, cursor, ws2, cs2, perm2);
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) x_out[dst * 7 + j] = out[j];
+            }
+        }
+    }
+    if (sigma_partials) {
+        chx_block_sum8_folded(a, red);
+        if (threadIdx.x < 8) {                            // thread k holds the workgroup's total of sum k
+            sigma_partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = a[0];
+            if (sums_add) unsafeAtomicAdd(&sums_add[threadIdx.x * 256 + (blockIdx.x & 255)], a[0]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
@@ -924,7 +1213,15 @@ int chx_sc_tile_gather_kick_chain(const void* rows, const void* phi_halo, const 
     double* sums_add = with_sums ? (double*)(st + L.sums[sums_set & 1]) : nullptr;
     double* sums_clear = with_sums ? (double*)(st + L.sums[(sums_set & 1) ^ 1]) : nullptr;
     constexpr int R = kScGatherRows / CHX_BLOCK;
-    if (dtype == CHX_F32)
+    static_assert(R == 1, "sc_tile_particle32_kernel walks one segment of 64 rows per wave");
+    if (dtype == CHX_F32 && !sc_gather_fp64() && sc_phi_offsets_fit32(bins))
+        hipLaunchKernelGGL(sc_tile_particle32_kernel, dim3(nwg), dim3(CHX_BLOCK), 0, s, (const float*)rows, hdr, (int*)(st + L.perm[0]),
+                           (float*)(st + L.ws[0]), (float*)(st + L.cs[0]), (const uint16_t*)(st + L.home), (int*)(st + L.cursor),
+                           (const float*)phi_halo, (const float*)half, (const float*)cell, (const float*)energy, (const float*)dt,
+                           (const float*)gamma, (float)(1.0 / mass_eV), (float)(kC / mass_eV), N, bins[0], bins[1], bins[2], (float*)x_out,
+                           (const float*)post_map, unpermute, unpermute ? nullptr : (double*)(st + L.sigma), (int*)(st + L.newcount),
+                           tg.nt, (int*)(st + L.mis), sums_add, sums_clear, sc_gather_diag());
+    else if (dtype == CHX_F32)
         hipLaunchKernelGGL((sc_tile_particle_kernel<float, R>), dim3(nwg), dim3(CHX_BLOCK), 0, s, (const float*)rows, hdr, (int*)(st + L.perm[0]),
                            (float*)(st + L.ws[0]), (float*)(st + L.cs[0]), (const uint16_t*)(st + L.home), (int*)(st + L.cursor),
                            (const float*)phi_halo, (const float*)half, (const float*)cell, (const float*)energy, (const float*)dt,

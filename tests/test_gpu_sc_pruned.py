@@ -70,6 +70,12 @@ def test_unsupported_grids_are_reported():
     assert _ops.sc_pruned_supported((512, 32, 32), torch.float32) and not _ops.sc_pruned_supported((512, 32, 32), torch.float64)
 
 
+# float32 particle step against the float64 one, as a fraction of the largest kick of the coordinate: measured <= 5.1e-6 on MI355X
+# on this test's rough potential (uniform noise to the fourth power: neighbouring nodes differ by the full amplitude, so the eight
+# corner terms cancel; on C4's smooth potential the two steps agree to 1e-7 of the kick, benchmarks/sc_fp32_error.py), bound 4 x that
+FP32_STEP_BOUND = 2.0e-5
+
+
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 @pytest.mark.parametrize("g", [(16, 16, 16), (32, 16, 64), (128, 128, 128)])
 def test_gather_from_the_potential_is_bit_identical_to_gradient_then_gather(tag, g):
@@ -120,11 +126,23 @@ def test_gather_from_the_potential_is_bit_identical_to_gradient_then_gather(tag,
     _ops.check(lib.chx_from_xyz_pxpypz(xyz.data_ptr(), energy.data_ptr(), 510998.95069, B, B, B, N, code, x.data_ptr(), _ops.stream_ptr()),
                "from_xyz")
     dtk = torch.tensor([1e-9, 3e-9], dtype=dt, device="cuda")
+
+    def same(a, b, before):
+        # float64 rows: one arithmetic on both routes, bit for bit. float32 rows (round 6): chx_sc_gather_kick_phi evaluates the
+        # particle step in float32 (csrc/chx_spacecharge.hip, sc_kick_row32), the force-grid route in float64 — the same real-number
+        # map, so they agree to a few 1e-7 of the kick plus the last bit of the coordinate. Measured on MI355X: see FP32_STEP_BOUND.
+        if tag == "f64":
+            assert torch.equal(a, b)
+            return
+        kick = (b - before).abs().amax(dim=1, keepdim=True)
+        excess = ((a - b).abs() - 2 * torch.finfo(dt).eps * b.abs()).clamp_min(0) / kick.clamp_min(1e-30)
+        assert (excess <= FP32_STEP_BOUND).all(), excess.amax(dim=1)
+
     F = _ops.sc_gradient(phi, cell, gamma, g)
     want = _ops.sc_gather_kick(x, F, half, cell, energy, dtk, 510998.95069, B, N, g)
     got = _ops.sc_gather_kick_phi(x, halo, half, cell, gamma, energy, dtk, 510998.95069, B, N, g)
     assert not torch.isnan(got).any()
-    assert torch.equal(got, want)
+    same(got, want, x)
     assert not torch.equal(want, x)
     # with the linear run folded in, per batch row
     R = (torch.eye(7, dtype=dt, device="cuda") + 0.05 * torch.randn(B, 7, 7, dtype=dt, device="cuda")).contiguous()
@@ -135,4 +153,11 @@ def test_gather_from_the_potential_is_bit_identical_to_gradient_then_gather(tag,
                                              dtk.data_ptr(), 510998.95069, B, B, B, N, b3, code, R.data_ptr(), B, want_m.data_ptr(),
                                              _ops.stream_ptr()), "gather mapped")
     got_m = _ops.sc_gather_kick_phi(x, halo, half, cell, gamma, energy, dtk, 510998.95069, B, N, g, post_map=R)
-    assert torch.equal(got_m, want_m)
+    if tag == "f64":
+        assert torch.equal(got_m, want_m)
+    else:
+        # the kicked row goes through R: a difference of FP32_STEP_BOUND kicks in px, py, delta reaches every coordinate
+        kick = (want - x).abs().amax(dim=1, keepdim=True)                                   # (B, 1, 7)
+        reach = (R.abs() @ kick.transpose(1, 2)).transpose(1, 2)                            # (B, 1, 7)
+        lim = FP32_STEP_BOUND * reach + 4 * torch.finfo(dt).eps * want_m.abs().amax(dim=1, keepdim=True)
+        assert ((got_m - want_m).abs() <= lim).all(), ((got_m - want_m).abs() / lim).amax(dim=1)
