@@ -37,6 +37,7 @@ from __future__ import annotations
 import argparse
 import csv
 import json
+import math
 import os
 import socket
 import subprocess
@@ -340,12 +341,13 @@ def other_configs(ca, torch, device, only=None) -> dict:
         # average durations of the chain's per-particle kernels in the tracked rocprofv3 summary (run under the profiler with the
         # Green chain on the side stream: durations include what the overlap costs them)
         import csv
-        path = os.path.join(ROOT, "profiles", "r05_c4_kernel_stats.csv")
+        path = os.path.join(ROOT, "profiles", "r06_c4_kernel_stats.csv")
         avg = {}
         try:
             for row in csv.DictReader(open(path)):
-                for key in ("sc_tile_deposit_kernel", "sc_tile_schedule_kernel", "sc_tile_particle_kernel"):
-                    if key in row["Name"]:
+                for key, name in (("sc_tile_deposit_kernel", "sc_tile_deposit_kernel"), ("sc_tile_schedule_kernel", "sc_tile_schedule_kernel"),
+                                  ("sc_tile_particle_kernel", "sc_tile_particle32_kernel")):   # (round 6: the float32 beam's gather pass)
+                    if name in row["Name"]:
                         avg[key] = float(row["AverageNs"]) * 1e-3
         except OSError:
             return None
@@ -356,9 +358,40 @@ def other_configs(ca, torch, device, only=None) -> dict:
         gat = avg["sc_tile_particle_kernel"]
         rate = 84.0 * N_PARTICLES / ((dep + gat) * 1e-6) / 1e9
         return {"bytes_per_particle": 84.0, "deposit_us_profile": dep, "gather_us_profile": gat, "achieved_GBs": rate,
-                "frac": rate / HBM_PEAK_GBS, "source": "profiles/r05_c4_kernel_stats.csv",
+                "frac": rate / HBM_PEAK_GBS, "source": "profiles/r06_c4_kernel_stats.csv",
                 "launches_per_kick": 13, "note_launches": "deposit, five charge-FFT passes, gather on the main stream; corner table, far "
                 "field, three Green FFT passes and the next run's map on the side stream (profiles/r05_c4_timeline.txt)"}
+
+    def c4_fp32_kick_error():
+        # the float32 kick of C4's first SpaceChargeKick against the reference's float64 run of the same particles (committed sample,
+        # tests/golden/fullsize_c4.npz): max / rms error per momentum coordinate as a fraction of the kick amplitude — a drift of
+        # the kernels' arithmetic shows up here (tests/test_gpu_fullsize.py bounds it at 5e-4)
+        try:
+            import numpy as np
+
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import fullsize_inputs as fi
+
+            g = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_c4.npz"))
+            dt = torch.float32
+            kw = {"dtype": dt, "device": device}
+            tt = lambda v: torch.tensor(v, **kw)  # noqa: E731
+            beam = ca.ParticleBeam(torch.from_numpy(fi.c4_particles()).to(dt).to(device), tt(fi.C4_ENERGY),
+                                   particle_charges=torch.from_numpy(fi.c4_charges()).to(dt).to(device), species=ca.Species("electron", **kw))
+            b1 = ca.Drift(tt(0.1), **kw).track(beam)
+            b2 = ca.SpaceChargeKick(tt(0.2), grid_shape=fi.C4_GRID, **kw).track(b1)
+            sl = slice(None, None, fi.C4_SAMPLE_STRIDE)
+            got = (b2.particles[sl].double() - b1.particles[sl].double()).cpu().numpy()
+            ref = g["kick1_out_sample"] - g["kick1_in_sample"]
+            kick = np.max(np.abs(ref), axis=0)
+            err = np.max(np.abs(got - ref), axis=0) / kick
+            rms = np.sqrt(np.mean((got - ref) ** 2, axis=0)) / kick
+            return {"max_over_kick_amplitude": {"px": float(err[1]), "py": float(err[3]), "delta": float(err[5])},
+                    "rms_over_kick_amplitude": {"px": float(rms[1]), "py": float(rms[3]), "delta": float(rms[5])},
+                    "against": "the reference's float64 kick of the same 1e6 particles (tests/golden/fullsize_c4.npz, every "
+                               f"{fi.C4_SAMPLE_STRIDE}th particle)", "test_bound": 5e-4}
+        except Exception as exc:  # noqa: BLE001
+            return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     def c4():
         r = rc.c4()
@@ -367,7 +400,7 @@ def other_configs(ca, torch, device, only=None) -> dict:
         in_track = (r["track_ms"] - 0.0) / 10.0          # a kick of the chain (tile-ordered beam), the linear runs folded in
         return {"workload": "C4: 50-element linac, 10 SpaceChargeKicks on 128^3, 1e6 particles, fp32",
                 "ms_per_track": r["track_ms"], "ms_per_kick_in_track": in_track, "ms_per_isolated_kick": r["single_kick_ms"],
-                "particle_element_steps_per_s": r["steps_per_s"],
+                "particle_element_steps_per_s": r["steps_per_s"], "fp32_kick_error": c4_fp32_kick_error(),
                 "roofline": {"bound": "hbm (model floor)", "algorithmic_bytes_per_kick": per_kick,
                              "ratio_to_model_floor": per_kick / (in_track * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "particle_kernels": c4_particle_kernels(),
@@ -876,6 +909,12 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * N_PARTICLES * E * args.steps / dt
     sigma_x = float(state["moments"][8].sqrt())
+    # the same step once more over a longer sample (>= 0.25 s of steps): the driver's --steps 20 is 19 ms of GPU work, and the
+    # box-to-box scatter of so short a sample should be visible next to it. `steps` / `ms_per_step` above stay exactly as asked.
+    long_steps = max(args.steps, int(math.ceil(250.0 / max(ms_per_step, 1e-3))))
+    dt_long = timed(torch, dist, step_elementwise, long_steps, 0, world)
+    headline_long = {"steps": long_steps, "ms_per_step": dt_long / long_steps * 1e3, "timed_region_s": dt_long,
+                     "value": world * N_PARTICLES * E * long_steps / dt_long}
 
     def step_merged_no_grad():
         with torch.no_grad():
@@ -977,7 +1016,7 @@ def main():
                                "element-by-element tracking (no map merging) + global beam moments",
                    "elements": E, "particles_per_gpu": N_PARTICLES, "parallelism": f"particle-shard x{world}",
                    "sigma_x_out": sigma_x, "sigma_x_expected": EXPECTED_SIGMA_X_RANK0, "sigma_x_checked": sigma_ok},
-        "timed_region_s": dt, "modes": modes, "roofline": roofline,
+        "timed_region_s": dt, "headline_long": headline_long, "modes": modes, "roofline": roofline,
     }
     state.clear()
     torch.cuda.empty_cache()

@@ -1021,13 +1021,36 @@ def _moments_raw(x, w, B, N, entry=None):
     return out, picked
 
 
+def _moments_bwd_raw(x, w, out, d_out, B, need_x, need_w):
+    """chx_moments_bwd_w: (dX | None, dW | None) of d_out . moments for the rows x (Bx, N, 7) / weights w (Bw, N) given the
+    moment vector `out` the cotangent belongs to. The kernel forms every term from `out` (W, W2, mu, cov) and the row itself, so
+    with the moments of ALL shards of a particle-sharded beam in `out` it returns the gradient of the GLOBAL statistics with
+    respect to this rank's rows (utils/statistics.py:4-62 over the union of the shards)."""
+    N = x.shape[1]
+    dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_x else None
+    dW = torch.empty((B, N), dtype=x.dtype, device=x.device) if need_w else None
+    check(_lib.lib().chx_moments_bwd_w(ptr(x), ptr(w), ptr(out), ptr(d_out), B, x.shape[0], 1 if w is None else w.shape[0], N,
+                                       dtype_code(x.dtype), ptr(dX), ptr(dW), stream_ptr()), "chx_moments_bwd_w")
+    return dX, dW
+
+
 class Moments(torch.autograd.Function):
     """out = chx_moments(x, w); backward = chx_moments_bwd_w: gradients of the particles AND of the weights (the reference's
-    weighted statistics are differentiable in both, utils/statistics.py:4-62) in one pass."""
+    weighted statistics are differentiable in both, utils/statistics.py:4-62) in one pass.
+
+    With a process `group` (a particle-sharded beam, `sharding.particle_sharded`): forward = this rank's one-pass moments, ONE
+    all-gather of 29 doubles per rank and row, the exact merge — the statistics of the union of the shards; backward = the same
+    kernel on THIS rank's rows with the GLOBAL moments: no collective. Every rank evaluates the same loss of the global
+    statistics, so what a rank's backward pass accumulates on a replicated setting is its shard's share of the gradient:
+    `sharding.all_reduce_gradients` (or any data-parallel wrapper) sums the shares."""
 
     @staticmethod
-    def forward(ctx, x, w, B):
+    def forward(ctx, x, w, B, group=None):
         out = _moments_raw(x, w, B, x.shape[1])
+        if group is not None:
+            from . import sharding
+
+            out = sharding.gather_merge_moments(out, group)
         ctx.save_for_backward(x, w, out)
         ctx.B = B
         return out
@@ -1035,18 +1058,15 @@ class Moments(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         x, w, out = ctx.saved_tensors
-        B, N = ctx.B, x.shape[1]
+        B = ctx.B
         need_x, need_w = ctx.needs_input_grad[0], w is not None and ctx.needs_input_grad[1]
         d_out = d_out.contiguous().to(torch.float64)
-        dX = torch.empty((B, N, 7), dtype=x.dtype, device=x.device) if need_x else None
-        dW = torch.empty((B, N), dtype=x.dtype, device=x.device) if need_w else None
-        check(_lib.lib().chx_moments_bwd_w(ptr(x), ptr(w), ptr(out), ptr(d_out), B, x.shape[0], 1 if w is None else w.shape[0], N,
-                                           dtype_code(x.dtype), ptr(dX), ptr(dW), stream_ptr()), "chx_moments_bwd_w")
+        dX, dW = _moments_bwd_raw(x, w, out, d_out, B, need_x, need_w)
         if need_x and x.shape[0] == 1 and B > 1:
             dX = dX.sum(dim=0, keepdim=True)
         if need_w and w.shape[0] == 1 and B > 1:
             dW = dW.sum(dim=0, keepdim=True)
-        return dX, dW, None
+        return dX, dW, None, None
 
 
 def _memo_moments(owner: torch.Tensor, x: torch.Tensor, w, survival, B: int, entry=None):
@@ -1198,8 +1218,9 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
     return MomentEntryMapped.apply(lin.R, mom_y, (lin, survival, w), index, take_sqrt, B, picked).reshape(batch_shape)
 
 
-def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Tensor:
-    """(…,29) float64: [W, W2, mu(6), cov upper triangle (21)] for every vector entry."""
+def moments(particles: torch.Tensor, survival: torch.Tensor | None, group=None) -> torch.Tensor:
+    """(…,29) float64: [W, W2, mu(6), cov upper triangle (21)] for every vector entry. `group`: the particles are one rank's
+    shard of a beam spread over that process group — the moments are those of ALL shards (a collective; see `Moments`)."""
     require_device(particles)
     N = particles.shape[-2]
     sshape = survival.shape[:-1] if survival is not None else ()
@@ -1212,7 +1233,16 @@ def moments(particles: torch.Tensor, survival: torch.Tensor | None) -> torch.Ten
         w, _ = flat_bcast(survival.to(particles.dtype), batch_shape, 1)
         w = w.contiguous()
     lin = getattr(particles, "_chx_lin", None)
-    if lin is not None and torch.is_grad_enabled() and lin.version == particles._version and x.requires_grad \
+    if group is not None:
+        # (the algebraic backward of a linearly tracked beam would hand every rank the WHOLE gradient of the map; the rows'
+        # backward pass hands it its shard's share, like every other differentiable path of a sharded beam)
+        if torch.is_grad_enabled() and (x.requires_grad or (w is not None and w.requires_grad)):
+            out = Moments.apply(x, w, B, group)
+        else:
+            from . import sharding
+
+            out = sharding.gather_merge_moments(_moments_raw(x, w, B, N), group)
+    elif lin is not None and torch.is_grad_enabled() and lin.version == particles._version and x.requires_grad \
             and not (w is not None and w.requires_grad) and tuple(lin.batch_shape) == tuple(batch_shape) \
             and lin.R.requires_grad:
         # a moment of a linearly tracked beam whose particles carry no graph: the gradient reaches the map through
@@ -1607,10 +1637,11 @@ KDE_CHUNK = 131072  # particles per GEMM slab: bounds the (N, bins) kernel-value
 
 
 def kde_histogram_2d(particles, centres_x, centres_y, bandwidth, charge=None, survival=None, shift=None,
-                     epsilon: float = 1e-10) -> torch.Tensor:
+                     epsilon: float = 1e-10, group=None) -> torch.Tensor:
     """Screen "kde" image (…, H, W) (utils/kde.py:137-204 + the `.mT` of screen.py:326): chx_kde_values for the two
     sets of Gaussian kernel values, their GEMM over the particle axis (rocBLAS through torch.matmul), normalised to a
-    pdf. With gradient tracking the kernel values are tensor expressions instead, so autograd sees them."""
+    pdf. With gradient tracking the kernel values are tensor expressions instead, so autograd sees them. `group`: the particles
+    are one rank's shard of a beam (`sharding.particle_sharded`): the kernel sums are added over the ranks before the normalisation."""
     require_device(particles, centres_x, centres_y, bandwidth)
     dt = particles.dtype
     N = particles.shape[-2]
@@ -1655,6 +1686,11 @@ def kde_histogram_2d(particles, centres_x, centres_y, bandwidth, charge=None, su
             check(lib.chx_kde_values(ptr(x), None, None, ptr(sh), ptr(cy), ptr(sg), 2, B, Bx, 1, 1, Bsh, N, n0, nc, H_,
                                      dtype_code(dt), ptr(k2), stream_ptr()), "chx_kde_values")
         joint = joint + k1.mT @ k2
+    if group is not None:
+        # a particle-sharded beam: the kernel sums of ALL shards, then the normalisation (the pdf of the union, not of a shard)
+        from . import sharding
+
+        joint = sharding.sum_over_ranks(joint, group)
     pdf = joint / (joint.sum(dim=(-2, -1), keepdim=True) + epsilon)
     return pdf.mT.reshape(*batch_shape, H_, W_)
 

@@ -74,7 +74,11 @@ class BPM(Marker):
             if group is not None:
                 # the beam's particles are spread over the ranks of a process group (sharding.particle_sharded): the monitor reads
                 # the mean of ALL of them — this rank's one-pass moments, one all-gather of 29 doubles, the exact merge
-                xy = incoming._global_moments(group)[..., 2:5:2].to(p.dtype)     # (cached per version of the beam: shared with its properties)
+                # (cached per version of the beam: shared with its properties). The stored reading carries no graph — the
+                # exchange runs under no_grad whatever the beam carries (a differentiable track through an active BPM
+                # must not need one)
+                with torch.no_grad():
+                    xy = incoming._global_moments(group)[..., 2:5:2].to(p.dtype)
             elif p is not None and not (torch.is_grad_enabled() and (p.requires_grad or incoming.survival_probabilities.requires_grad)):
                 # entries 2 and 4 of the moment vector = (mu_x, mu_y): one strided view, one cast, one subtraction
                 xy = incoming._moments()[..., 2:5:2].to(p.dtype)

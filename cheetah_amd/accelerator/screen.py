@@ -251,9 +251,12 @@ class Screen(Element):
             image = _ops.hist2d(beam.particles, ex, ey, charge=beam.particle_charges,
                                 survival=beam.survival_probabilities, shift=self.misalignment)
         elif self.method == "kde":
+            from .. import sharding
+
             cx, cy = self.pixel_bin_centers
             image = _ops.kde_histogram_2d(beam.particles, cx, cy, self.kde_bandwidth, charge=beam.particle_charges,
-                                          survival=beam.survival_probabilities, shift=self.misalignment)
+                                          survival=beam.survival_probabilities, shift=self.misalignment,
+                                          group=sharding.active_group())
         else:
             image = _ops.cic_deposit(beam.particles, (0, 2), (w, h), self.extent.reshape(2, 2),
                                      charge=beam.particle_charges, survival=beam.survival_probabilities,
@@ -261,11 +264,11 @@ class Screen(Element):
         from .. import sharding
 
         group = sharding.active_group()
-        if group is not None and beam is not None and not isinstance(beam, ParameterBeam):
-            if self.method == "kde":
-                raise NotImplementedError("the 'kde' image is normalised per process; use 'cloud-in-cell' or 'histogram' "
-                                          "for a particle-sharded beam")
-            image = sharding.allreduce_grid(image.contiguous(), group)   # every rank deposited its own particles
+        if group is not None and beam is not None and not isinstance(beam, ParameterBeam) and self.method != "kde":
+            # every rank deposited its own particles: the image of ALL shards (a collective; a graph on this rank's share is
+            # kept — the backward pass of the sum is the identity, sharding.sum_over_ranks). The 'kde' image sums its kernel
+            # values over the ranks in front of its normalisation (_ops.kde_histogram_2d).
+            image = sharding.sum_over_ranks(image.contiguous(), group)
         self.__dict__["_cached_reading"] = image
         return image
 

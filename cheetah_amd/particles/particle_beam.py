@@ -308,14 +308,16 @@ class ParticleBeam(Beam):
         ONE all-gather of 29 doubles per rank and batch row, the exact merge (`chx_merge_moments`; utils/statistics.py:4-62 over the
         union of the shards) — once per version of the beam's tensors, whatever number of properties is read
         (particle_beam.py:1699-1943: `sigma_x`, `mu_*`, `cov_*`, emittances, Twiss). A COLLECTIVE: every rank of the group must
-        read a property of its shard at the same point of the program. Gradients do not cross the exchange."""
+        read a property of its shard at the same point of the program. With gradients enabled and particles / weights that carry
+        a graph the result is differentiable (`_ops.Moments` with the group): every rank's backward pass works on its own rows."""
         from .. import sharding
 
         p, w = self.particles, self.survival_probabilities
         if torch.is_grad_enabled() and (p.requires_grad or w.requires_grad):
-            raise NotImplementedError("beam properties of a particle-sharded beam are global statistics exchanged between the ranks: "
-                                      "they carry no autograd graph (read them under torch.no_grad(), or differentiate per shard "
-                                      "outside sharding.particle_sharded)")
+            # differentiable: one node whose backward is chx_moments_bwd_w on this rank's rows with the GLOBAL moments (no
+            # collective); a rank's backward pass yields its shard's share of the gradient of a replicated setting
+            # (sharding.all_reduce_gradients sums the shares). Not cached: the result carries this call's graph.
+            return _ops.moments(p, w, group=group)
         cached = self.__dict__.get("_global_moment_cache")
         if cached is not None and cached[0].matches((p, w)) and cached[1] is group:
             return cached[2]
@@ -347,9 +349,12 @@ class ParticleBeam(Beam):
         (`_MomentEntry`) instead of select -> sqrt -> to, whose three backward nodes cost more host time than the moment
         kernels themselves in an optimisation loop."""
         p = self.particles
-        if _SHARDING_STACK and p.requires_grad:
-            self._moments()                 # (raises inside sharding.particle_sharded: global statistics carry no graph)
-        if p.requires_grad and getattr(p, "_chx_lin", None) is not None:
+        sharded = False
+        if _SHARDING_STACK:
+            from .. import sharding
+
+            sharded = sharding.active_group() is not None
+        if p.requires_grad and not sharded and getattr(p, "_chx_lin", None) is not None:
             # a linearly tracked beam whose only differentiable input is the map: one node, algebraic backward
             v = _ops.moment_entry(p, self.survival_probabilities, index, take_sqrt)
             if v is not None:
@@ -371,14 +376,22 @@ class ParticleBeam(Beam):
 
     @property
     def total_charge(self) -> torch.Tensor:
-        q = (self.particle_charges * self.survival_probabilities).sum(dim=-1)
+        """Sum of charge x survival probability. Inside `sharding.particle_sharded`: of ALL shards — a COLLECTIVE like the moment
+        properties (every rank reads it at the same point; `local_total_charge` is this rank's own); a graph on this rank's
+        charges / survival probabilities is kept (`sharding.sum_over_ranks`)."""
+        q = self.local_total_charge
         if _SHARDING_STACK:
             from .. import sharding
 
             group = sharding.active_group()
-            if group is not None:           # the charge of ALL shards (a collective, like the moment properties)
-                q = sharding.allreduce_grid(q.detach().clone().reshape(-1), group).reshape(q.shape)
+            if group is not None:
+                q = sharding.sum_over_ranks(q.reshape(-1), group).reshape(q.shape)
         return q
+
+    @property
+    def local_total_charge(self) -> torch.Tensor:
+        """The charge of THIS rank's particles, inside or outside `sharding.particle_sharded` (no exchange: safe to read on one rank)."""
+        return (self.particle_charges * self.survival_probabilities).sum(dim=-1)
 
     @property
     def num_particles(self) -> int:
@@ -394,8 +407,8 @@ class ParticleBeam(Beam):
             from .. import sharding
 
             group = sharding.active_group()
-            if group is not None:           # over ALL shards
-                n = sharding.allreduce_grid(n.detach().clone().reshape(-1), group).reshape(n.shape)
+            if group is not None:           # over ALL shards (a collective; keeps this rank's graph)
+                n = sharding.sum_over_ranks(n.reshape(-1), group).reshape(n.shape)
         return n
 
     # reference frame (beam.py:323-341)

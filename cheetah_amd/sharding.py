@@ -143,6 +143,53 @@ def gather_merge_moments(local: torch.Tensor, group=None) -> torch.Tensor:
     return merged
 
 
+class _SumOverRanks(torch.autograd.Function):
+    """y = the sum of x over the ranks of a group, delivered to every rank, as a differentiable node. Every rank evaluates the
+    SAME loss of y, so the cotangent that reaches rank r's x is the loss's own: backward is the identity and needs no exchange.
+    (torch.distributed.nn.all_reduce sums the cotangents instead: that is the rule for ranks with DIFFERENT losses.)"""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.detach().clone().contiguous()
+        if collectives_on(group):
+            staged = y.cpu() if (y.is_cuda and dist.get_backend(group) == "gloo") else y
+            dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=group)
+            if staged is not y:
+                y.copy_(staged)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def sum_over_ranks(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of `x` over the particle shards on every rank (total charge, surviving particles, a screen image); keeps the
+    autograd graph of this rank's contribution."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _SumOverRanks.apply(x, group)
+    return allreduce_grid(x.detach().clone().contiguous(), group)
+
+
+def all_reduce_gradients(tensors, group=None) -> None:
+    """Sum the `.grad` of replicated settings over the ranks (in place). Inside `particle_sharded` every rank evaluates the same
+    loss of the GLOBAL beam statistics, and its backward pass leaves on every replicated setting (a quadrupole strength, a
+    cavity phase) the share of the gradient that comes through ITS particles; the gradient of the loss is the sum of the shares
+    — one all-reduce per setting, after `backward()`. A setting a rank has no gradient for counts as zero."""
+    if group is None and _ACTIVE_GROUP:
+        group = _ACTIVE_GROUP[-1][0]
+    if not collectives_on(group):
+        return
+    for t in tensors:
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
+        g = t.grad
+        staged = g.cpu() if (g.is_cuda and dist.get_backend(group) == "gloo") else g
+        dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=group)
+        if staged is not g:
+            g.copy_(staged)
+
+
 def gather_moments_rows(local: torch.Tensor, group=None):
     """This rank's (1,29) moments -> (rows, R): over RCCL the (R,29) moments of all shards exactly as all-gathered (R = world
     size; the consumer merges them itself: `chx_sc_kick_sorted_begin`'s geometry kernel), otherwise the merged (1,29) row and

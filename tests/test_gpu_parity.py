@@ -506,16 +506,20 @@ def test_space_charge_kick_vs_reference(ca, golden, gi, tag):
         truth = oracle.space_charge_kick(inp[None], float(g["energy"]), g[f"{k}_charges"].astype(np.float64),
                                          g[f"{k}_survival"].astype(np.float64), float(g["effect_length"]),
                                          grid_shape=grid)[0]
-        tol = 2e-2
+        # measured on MI355X (benchmarks/sc_small_fp32_error.py, both fixture grids): 6.9e-6 of the kick amplitude at most
+        # (px, py; delta 7.3e-7) on top of the rounding of the stored coordinate (the eps term below) — bound 4 x that
+        tol = 3e-5
     kick = np.max(np.abs(truth - inp), axis=0)
     err = np.max(np.abs(got - truth), axis=0)
     for c in (1, 3, 5):
         assert err[c] < tol * kick[c] + 2 * np.finfo(ndt(tag)).eps * np.max(np.abs(truth[:, c])), (c, err[c], kick[c])
     if tag == "f32":
-        # and the reference's fp32 output agrees with ours at the level of its own noise
+        # and the reference's OWN fp32 output agrees with ours at the level of ITS noise: transverse 2.4e-5 of the kick measured
+        # (bound 1e-4); in delta its float32 detour through SI momenta (particle_beam.py:1262-1346: gamma - gamma0 with both
+        # ~ 2e2 in float32) leaves 1.1e-2 of the kick (bound 4e-2) — that column of the fixture is documented noise, not truth
         ref32 = g[f"{k}_out"].astype(np.float64)
-        for c in (1, 3, 5):
-            assert np.max(np.abs(got[:, c] - ref32[:, c])) < 0.2 * kick[c] + 4 * np.finfo(np.float32).eps * np.max(np.abs(truth[:, c]))
+        for c, lim in ((1, 1e-4), (3, 1e-4), (5, 4e-2)):
+            assert np.max(np.abs(got[:, c] - ref32[:, c])) < lim * kick[c] + 4 * np.finfo(np.float32).eps * np.max(np.abs(truth[:, c]))
     assert np.array_equal(got[:, 0], inp[:, 0]) and np.array_equal(got[:, 2], inp[:, 2])
     assert np.allclose(got[:, 4], inp[:, 4], rtol=4 * np.finfo(ndt(tag)).eps, atol=0)
 

@@ -135,6 +135,43 @@ def _worker(port, queue):
                 used_after_edit = {k: calls[k] - before[k] for k in calls}
         report["beam_properties"] = {"local": local_vals, "global": global_vals, "used": used_props, "used_after_edit": used_after_edit,
                                      "doubled": doubled}
+        # gradients across the exchange (round 6; utils/statistics.py:4-62 is differentiable for any particle layout): d(global
+        # sigma_x of the tracked beam + total charge) / d(k1, an aperture-like weight scale) inside the context — chx_moments ->
+        # all_gather_into_tensor -> chx_merge_moments forward, chx_moments_bwd_w on the local rows with the global moments
+        # backward — against the same loss outside of it
+        f64 = {"dtype": torch.float64, "device": "cuda"}
+        gbeam = _beam(ca, torch.float64, 60_000)
+
+        def loss_and_grads(sharded):
+            k1g = torch.tensor(4.2, requires_grad=True, **f64)
+            a = torch.tensor(1.3, requires_grad=True, **f64)
+            seg = ca.Segment([ca.Drift(torch.tensor(0.3, **f64), **f64), ca.Quadrupole(torch.tensor(0.2, **f64), k1=k1g, **f64),
+                              ca.Drift(torch.tensor(0.5, **f64), **f64)])
+            w = torch.sigmoid(a * (1.0 - (gbeam.particles[:, 0] / 8e-4) ** 2))
+            b = ca.ParticleBeam(gbeam.particles, gbeam.energy, particle_charges=gbeam.particle_charges, survival_probabilities=w,
+                                species=gbeam.species)
+            ctx_ = sharding.particle_sharded(force_collectives=True) if sharded else torch.enable_grad()
+            with ctx_:
+                out = seg.track(b)
+                loss = out.sigma_x * 1e3 + out.mu_px * 1e3 + out.total_charge * 1e9
+                loss.backward()
+                if sharded:
+                    sharding.all_reduce_gradients([k1g, a])
+            return float(loss.detach()), float(k1g.grad), float(a.grad)
+
+        before = dict(calls)
+        report["gradients"] = {"plain": loss_and_grads(False), "sharded": loss_and_grads(True),
+                               "used": None}
+        report["gradients"]["used"] = {k: calls[k] - before[k] for k in calls}
+        # the 'kde' image of a sharded beam: kernel sums over the ranks, then the normalisation
+        kscreen = ca.Screen(resolution=(32, 24), pixel_size=torch.tensor([1.2e-4, 1.6e-4], **kw), method="kde", is_active=True, **kw)
+        sbeam = _beam(ca, torch.float32, 20_000)
+        kscreen.track(sbeam)
+        kplain = kscreen.reading.clone()
+        with sharding.particle_sharded(force_collectives=True):
+            kscreen.track(sbeam)
+            ksum = kscreen.reading.clone()
+        report["kde"] = {"equal": bool(torch.allclose(kplain, ksum, rtol=1e-5, atol=0)), "sum": float(ksum.sum())}
         # batch shard of a vectorised scan (no collective): the union of the per-"rank" slices equals the whole scan
         k1 = torch.linspace(-30, 30, 64, **kw)
         t = lambda v: torch.tensor(v, **kw)  # noqa: E731
@@ -187,6 +224,14 @@ def test_rccl_exchanges_on_one_rank():
         assert r["forced_vs_whole"] < (2e-4 if name.startswith("f32") else 1e-9), (name, r)
     assert report["screen"] == {"equal": True, "all_reduce": 1}
     assert report["batch_shard_equal"]
+    g = report["gradients"]
+    assert g["sharded"][0] == pytest.approx(g["plain"][0], rel=1e-12)
+    assert g["sharded"][1] == pytest.approx(g["plain"][1], rel=1e-9) and g["sharded"][2] == pytest.approx(g["plain"][2], rel=1e-9), g
+    assert g["plain"][1] != 0.0 and g["plain"][2] != 0.0
+    # forward: one all-gather (the moments, one node for both properties would be one — sigma_x and mu_px are two reads of a
+    # graph-carrying beam: two nodes) and one all-reduce (total charge); all_reduce_gradients: one all-reduce per setting
+    assert g["used"]["all_gather"] == 2 and g["used"]["all_reduce"] == 3, g
+    assert report["kde"]["equal"] and report["kde"]["sum"] == pytest.approx(1.0, rel=1e-4)
 
     # a one-rank union is the rank's own beam: the merged properties equal the local ones; one all-gather served all moment properties
     bp = report["beam_properties"]

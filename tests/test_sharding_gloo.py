@@ -4,6 +4,7 @@ The per-rank partial reductions come from the CPU oracle here (on the GPU box th
 chx_moment_* kernels); what is under test is the sharding arithmetic and the two all-reduces."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -277,15 +278,8 @@ def _worker_beam_properties(rank, world, port, x, w, qc, q):
         assert calls["n"] == 2 and gathers["n"] == 2
     local_sigma = float(beam.sigma_x)                                            # outside the context: this shard's own statistics
     assert calls["n"] == 3 and gathers["n"] == 2
-    x_req = ca.ParticleBeam(torch.from_numpy(x[lo:hi]).requires_grad_(True), torch.tensor(1e8, dtype=torch.float64), dtype=torch.float64)
-    refused = False
-    with sharding.particle_sharded():
-        try:
-            x_req.sigma_x
-        except NotImplementedError:
-            refused = True
     dist.all_gather = real
-    q.put((rank, got, local_sigma, refused))
+    q.put((rank, got, local_sigma))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -297,7 +291,18 @@ def _run(world, target, args):
     procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get() for _ in range(world)]
+    out, deadline = [], time.monotonic() + 180
+    while len(out) < world:                       # (a worker that died must fail the test, not park it on the queue)
+        if not q.empty():
+            out.append(q.get())
+            continue
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        if dead or time.monotonic() > deadline:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+            raise AssertionError(f"worker exit codes {dead}" if dead else "workers timed out")
+        time.sleep(0.05)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -324,7 +329,7 @@ def test_sharded_beam_properties_are_global_two_ranks_gloo(oracle):
     x2 = x.copy()
     x2[:, 0] *= 2.0
     sig2 = float(np.sqrt(oracle.moments(x2[None], w[None])["cov"][0, 0, 0]))
-    for rank, got, local_sigma, refused in res:
+    for rank, got, local_sigma in res:
         for name, v in got.items():
             if name == "total_charge":
                 want = float((qc * w).sum())
@@ -339,7 +344,6 @@ def test_sharded_beam_properties_are_global_two_ranks_gloo(oracle):
         own = x[lo:hi].copy()
         own[:, 0] *= 2.0
         assert local_sigma == pytest.approx(float(np.sqrt(oracle.moments(own[None], w[None, lo:hi])["cov"][0, 0, 0])), rel=1e-10)
-        assert refused
 
 
 def _worker_uneven(rank, world, port, x, w, q):
@@ -389,3 +393,123 @@ def test_eight_ranks_uneven_and_empty_shards_gloo(oracle):
                 for b in range(a, 6):
                     assert abs(merged[0, j] - ref[0, j]) <= 1e-10 * sig[a] * sig[b], (rank, n_total, a, b)
                     j += 1
+
+
+# ---------------------------------------------------------------------------------------------- gradients across the shards
+def _cpu_moments_bwd(x, w, out, d_out, B, need_x, need_w):
+    """chx_moments_bwd_w restated in torch (csrc/chx_moments.hip moments_bwd_kernel): every term from the moment vector `out`
+    and the row itself — the property that makes the backward pass of a sharded beam local."""
+    o, g = out.reshape(B, 29), d_out.reshape(B, 29)
+    dX = torch.zeros(B, x.shape[1], 7, dtype=torch.float64) if need_x else None
+    dW = torch.zeros(B, x.shape[1], dtype=torch.float64) if need_w else None
+    for b in range(B):
+        xb = x[0 if x.shape[0] == 1 else b].double()
+        wb = torch.ones(xb.shape[0], dtype=torch.float64) if w is None else w[0 if w.shape[0] == 1 else b].double()
+        W, W2 = o[b, 0], o[b, 1]
+        icf = 1.0 / (W - W2 / W)
+        G = torch.zeros(6, 6, dtype=torch.float64)
+        k = 8
+        for i in range(6):
+            for j in range(i, 6):
+                if i == j:
+                    G[i, i] = 2.0 * g[b, k]
+                else:
+                    G[i, j] = G[j, i] = g[b, k]
+                k += 1
+        d = xb[:, :6] - o[b, 2:8]
+        s = d @ G.T
+        if need_x:
+            dX[b, :, :6] = wb[:, None] * (g[b, 2:8] / W + icf * s)
+        if need_w:
+            S = (g[b, 8:] * o[b, 8:]).sum()
+            kcf = 1.0 + W2 / (W * W)
+            dW[b] = g[b, 0] + 2.0 * wb * g[b, 1] + (d * g[b, 2:8]).sum(1) / W + icf * (0.5 * (d * s).sum(1) - S * (kcf - 2.0 * wb / W))
+    return (None if dX is None else dX.to(x.dtype)), (None if dW is None else dW.to(x.dtype))
+
+
+def _worker_sharded_gradients(rank, world, port, x, w, qc, q):
+    """d(loss of the GLOBAL statistics) / d(a replicated setting) through the product's classes on a particle-sharded beam. The two
+    libchx calls of the node — the local one-pass moments and chx_moments_bwd_w — are replaced by CPU restatements (no GPU here);
+    the node itself, the exchange, the merge, the property algebra, `total_charge` and `all_reduce_gradients` are the product's."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cheetah_amd as ca
+    from cheetah_amd import _ops, sharding
+    from oracle import chx_oracle
+
+    def cpu_moments_raw(xx, ww, B, N, entry=None):
+        xs = xx.detach().numpy().astype(np.float64)
+        ws = np.ones((1, N)) if ww is None else ww.detach().numpy().astype(np.float64)
+        xs, ws = np.broadcast_to(xs, (B, N, 7)), np.broadcast_to(ws, (B, N))
+        return torch.from_numpy(np.nan_to_num(chx_oracle.moments(xs, ws)["raw"], nan=0.0)).reshape(B, 29)
+
+    _ops._moments_raw = cpu_moments_raw
+    _ops._moments_bwd_raw = _cpu_moments_bwd
+    _ops.require_device = lambda *a: None
+    lo, hi = sharding.shard_range(x.shape[0], rank, world)
+    f64 = torch.float64
+    k = torch.tensor(0.7, dtype=f64, requires_grad=True)          # replicated "settings": a focusing strength ...
+    a = torch.tensor(1.3, dtype=f64, requires_grad=True)          # ... and an aperture-like weight scale
+    x0, w0, q0 = torch.from_numpy(x[lo:hi]), torch.from_numpy(w[lo:hi]), torch.from_numpy(qc[lo:hi])
+
+    def beam_of(xx, ww, qq):
+        R = torch.eye(7, dtype=f64)
+        R = R + k * torch.tensor([[0, 0.5, 0, 0, 0, 0, 0], [-0.8, 0, 0, 0, 0, 0.1, 0]] + [[0] * 7] * 5, dtype=f64)
+        weights = torch.sigmoid(a * (1.0 - (xx[:, 0] / 4e-4) ** 2)) * ww
+        return ca.ParticleBeam(xx @ R.T, torch.tensor(1e8, dtype=f64), particle_charges=qq, survival_probabilities=weights, dtype=f64)
+
+    def loss_of(beam):
+        return beam.sigma_x * 3e3 + beam.mu_px * 1e4 + beam.cov_xpx * 1e8 + beam.emittance_x * 1e9 + beam.total_charge * 1e12 \
+            + beam.num_particles_survived * 1e-4
+
+    with sharding.particle_sharded():
+        loss = loss_of(beam_of(x0, w0, q0))
+        loss.backward()
+        shares = (float(k.grad), float(a.grad))
+        sharding.all_reduce_gradients([k, a])
+        # an active BPM inside a differentiable track of a sharded beam: the reading is formed under no_grad, nothing raises
+        bpm = ca.BPM(is_active=True, dtype=f64)
+        bpm.track(beam_of(x0, w0, q0))
+        reading = bpm.reading.clone()
+    q.put((rank, float(loss.detach()), float(k.grad), float(a.grad), shares, reading.tolist(), bool(bpm.reading.requires_grad)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_beam_properties_are_differentiable_two_ranks_gloo(oracle):
+    """utils/statistics.py:4-62 and particle_beam.py:1699-1717 are differentiable whatever the layout of the particles: a loss
+    of the global beam statistics, back-propagated on every rank of a particle-sharded beam, gives shares that add up to the
+    single-process gradient (computed here with plain torch autograd on the union of the shards)."""
+    rng = np.random.default_rng(33)
+    N = 9_001
+    x = rng.standard_normal((N, 7)) * [3e-4, 2e-5, 2e-4, 1e-5, 1e-4, 2e-3, 0] + [1e-4, 0, -2e-4, 0, 1e-5, 0, 1]
+    x[:, 1] += 0.05 * x[:, 0]
+    x[:5000, 0] += 2e-4
+    w = 0.2 + 0.8 * rng.random(N)
+    qc = rng.random(N) * 1e-15
+    res = _run(2, _worker_sharded_gradients, (x, w, qc))
+    # the single-process truth: the same expressions on all particles, statistics written out in torch (utils/statistics.py:4-62)
+    f64 = torch.float64
+    k = torch.tensor(0.7, dtype=f64, requires_grad=True)
+    a = torch.tensor(1.3, dtype=f64, requires_grad=True)
+    xx, ww, qq = torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(qc)
+    R = torch.eye(7, dtype=f64) + k * torch.tensor([[0, 0.5, 0, 0, 0, 0, 0], [-0.8, 0, 0, 0, 0, 0.1, 0]] + [[0] * 7] * 5, dtype=f64)
+    y = xx @ R.T
+    wt = torch.sigmoid(a * (1.0 - (xx[:, 0] / 4e-4) ** 2)) * ww
+    W = wt.sum()
+    mean = lambda v: (wt * v).sum() / W  # noqa: E731
+    cov = lambda u, v: (wt * (u - mean(u)) * (v - mean(v))).sum() / (W - (wt * wt).sum() / W)  # noqa: E731
+    sxx, spp, sxp = cov(y[:, 0], y[:, 0]), cov(y[:, 1], y[:, 1]), cov(y[:, 0], y[:, 1])
+    sdd, sxd, spd = cov(y[:, 5], y[:, 5]), cov(y[:, 0], y[:, 5]), cov(y[:, 1], y[:, 5])
+    emit = ((sxx - sxd * sxd / sdd) * (spp - spd * spd / sdd) - (sxp - sxd * spd / sdd) ** 2).sqrt()     # beam.py:442-470 (dispersion corrected)
+    loss = sxx.sqrt() * 3e3 + mean(y[:, 1]) * 1e4 + sxp * 1e8 + emit * 1e9 + (qq * wt).sum() * 1e12 + W * 1e-4
+    loss.backward()
+    mu_xy = (float(mean(y[:, 0]).detach()), float(mean(y[:, 2]).detach()))
+    for rank, got_loss, gk, ga, shares, reading, reading_grad in res:
+        assert got_loss == pytest.approx(float(loss.detach()), rel=1e-10)
+        assert gk == pytest.approx(float(k.grad), rel=1e-8) and ga == pytest.approx(float(a.grad), rel=1e-8), (rank, gk, ga)
+        assert reading == pytest.approx(mu_xy, rel=1e-9) and not reading_grad
+    # the shares differ between the ranks (they come through different particles) and add up
+    assert res[0][4] != res[1][4]
+    assert res[0][4][0] + res[1][4][0] == pytest.approx(float(k.grad), rel=1e-8)
+    assert res[0][4][1] + res[1][4][1] == pytest.approx(float(a.grad), rel=1e-8)
