@@ -2321,21 +2321,20 @@ class Segment(Element):
             raise ValueError(f"Element {start} is not part of the segment.")
         if end is not None and end not in names:
             raise ValueError(f"Element {end} is not part of the segment.")
-        subcell = []
-        is_in_subcell = start is None
-        for element in self.elements:
-            if element.name == start:
-                is_in_subcell = True
-                if include_start:
-                    subcell.append(element)
-                continue
-            if element.name == end:
-                if include_end and is_in_subcell:
-                    subcell.append(element)
-                break
-            if is_in_subcell:
-                subcell.append(element)
-        return self.__class__(subcell)
+        # by position: the cut ends at the first element called `end` (one that is also called `start` opens the cut instead, as
+        # in the reference's walk), begins at the first element called `start` in front of it — or not at all when `start` only
+        # comes later — and leaves out elements called `start` when include_start is off
+        labels = [element.name for element in self.elements]
+        stop = len(labels)
+        if end is not None:
+            stop = next((i for i, label in enumerate(labels) if label == end and label != start), stop)
+        first = 0 if start is None else next((i for i in range(stop) if labels[i] == start), None)
+        if first is None:
+            return self.__class__([])
+        picked = [element for element in self.elements[first:stop] if include_start or element.name != start]
+        if include_end and stop < len(labels):
+            picked.append(self.elements[stop])
+        return self.__class__(picked)
 
     def flattened(self) -> "Segment":
         flat = []

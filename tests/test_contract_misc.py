@@ -132,3 +132,42 @@ def test_tracking_lengthless_elements_and_superimposed_map():
     off = ca.Undulator(length=t(1.0), **kw)                      # test_undulator.py: an undulator that is off is a drift
     assert not off.is_active
     assert torch.allclose(off.track(beam_in).particles, ca.Drift(length=t(1.0), **kw).track(beam_in).particles, atol=1e-7)
+
+
+def test_subcell_follows_the_reference_walk_for_any_names():
+    """Segment.subcell (segment.py:94-141 of the reference) is written by position here; the reference's walk — an element called
+    `start` opens the cut (and is skipped when include_start is off, every time it appears), the first other element called `end`
+    closes it, `start` behind `end` gives an empty segment — restated as the checker, over random lattices with repeated names."""
+    import itertools
+    import random
+
+    import cheetah_amd as ca
+
+    def walk(elements, start, end, include_start, include_end):
+        sub, inside = [], start is None
+        for e in elements:
+            if e.name == start:
+                inside = True
+                if include_start:
+                    sub.append(e)
+                continue
+            if e.name == end:
+                if include_end and inside:
+                    sub.append(e)
+                break
+            if inside:
+                sub.append(e)
+        return [id(e) for e in sub]
+
+    rng = random.Random(1)
+    checked = 0
+    for _ in range(60):
+        names = [rng.choice("abcde") + ("" if rng.random() < 0.4 else str(rng.randint(0, 3))) for _ in range(rng.randint(1, 7))]
+        seg = ca.Segment([ca.Marker(name=n) for n in names])
+        for start, end, i_s, i_e in itertools.product([None] + names, [None] + names, (True, False), (True, False)):
+            got = [id(e) for e in seg.subcell(start, end, include_start=i_s, include_end=i_e).elements]
+            assert got == walk(seg.elements, start, end, i_s, i_e), (names, start, end, i_s, i_e)
+            checked += 1
+    assert checked > 3000
+    with pytest.raises(ValueError):
+        seg.subcell(start="not there")
