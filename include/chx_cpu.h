@@ -16,6 +16,14 @@
  *   chx_cavity_coeffs_cpu   chx_cavity_coeffs   cavity.py:113-122,135-226 (coefficient rows + outgoing energy)
  *   chx_cavity_track_cpu    chx_cavity_track    cavity.py:112,135-151,220-226 (x @ R.mT, then the per-particle delta / tau update)
  *   chx_hist2d_cpu          chx_hist2d          screen.py:292-311 (torch.histogramdd on explicit edges, weight |q| * survival)
+ *   chx_sc_kick_cpu         chx_sc_kick         space_charge_kick.py:477-586 (the whole kick; radix-2 convolution in double)
+ *   chx_track_fused_cpu     chx_track_fused     segment.py:571-572 (the element-by-element numbers from one pass)
+ *   chx_apply_affine7_bwd_cpu chx_apply_affine7_bwd element.py:180-191 under autograd: dX = dY R, dR = sum_n dY_n x_n^T
+ *   chx_moments_bwd_cpu / chx_moments_bwd_w_cpu  chx_moments_bwd(_w)  the cotangent of utils/statistics.py:4-62 (rows and weights)
+ *   chx_cic_deposit_bwd_cpu chx_cic_deposit_bwd utils/cloud_in_cell.py under autograd: d / d(weights), d / d(positions)
+ *   chx_sc_gather_kick_cpu  chx_sc_gather_kick  space_charge_kick.py:387-475, 548-584 (trilinear gather + kick from a force grid)
+ * The remaining ~80 declarations of chx.h are plans, fused stretches and tuning forms of these: they are exercised by the `-m gpu`
+ * tests against the oracle directly and have no host twin.
  */
 #ifndef CHX_CPU_H
 #define CHX_CPU_H
@@ -49,6 +57,22 @@ int chx_sc_kick_cpu(const void* x_in, const void* charge, const void* survival, 
                     const void* grid_extent, double mass_eV, int64_t B, int64_t Bx, int64_t Bq, int64_t Bs, int64_t Bext, int64_t N,
                     const int32_t* bins, int dtype, void* x_out, void* workspace, size_t workspace_bytes, void* stream,
                     void* side_stream, const void* post_map /*[BR][7][7] or NULL*/, int64_t BR);
+int chx_track_fused_cpu(const void* x_in, const void* R /*[E][BR][7][7]*/, void* x_out, int64_t E,
+                        int64_t B, int64_t Bx, int64_t BR, int64_t N, int dtype, void* stream);
+size_t chx_apply_bwd_workspace_bytes_cpu(int64_t B, int64_t N);
+int chx_apply_affine7_bwd_cpu(const void* dY, const void* R, const void* X, void* dX, double* dR,
+                              int64_t B, int64_t Bx, int64_t BR, int64_t N, int dtype,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int chx_moments_bwd_cpu(const void* x, const void* w, const double* out, const double* d_out,
+                        int64_t B, int64_t Bx, int64_t Bw, int64_t N, int dtype, void* dX, void* stream);
+int chx_moments_bwd_w_cpu(const void* x, const void* w, const double* out, const double* d_out, int64_t B, int64_t Bx, int64_t Bw,
+                          int64_t N, int dtype, void* dX, void* dW, void* stream);
+int chx_cic_deposit_bwd_cpu(const chx_cic_args* args, const void* dgrid, void* dweight /*[B][N]*/,
+                            void* dpos /*[B][N][ndim]*/, void* stream);
+int chx_sc_gather_kick_cpu(const void* x_in, const void* F, const void* half, const void* cell,
+                           const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
+                           int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
+                           void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -310,3 +310,188 @@ done:
     free(pr); free(pi); free(phi); free(F); free(kicked);
     return rc;
 }
+
+/* ---- round 6: the rest of SURVEY 8(b)'s list — the fused track, the backward entry points, the gather ------------------------------ */
+
+/* chx_track_fused: the same rounding per element as chx_track_elementwise (the device keeps the row in registers; the numbers are
+ * those of E passes) */
+CPU_API int chx_track_fused_cpu(const void* x_in, const void* R, void* x_out, int64_t E, int64_t B, int64_t Bx, int64_t BR, int64_t N,
+                                int dtype, void* stream) {
+    return chx_track_elementwise_cpu(x_in, R, x_out, NULL, E, B, Bx, BR, N, dtype, stream);
+}
+
+/* chx_apply_affine7_bwd (element.py:180-191 under autograd): dX[b][n][j] = sum_i dY[b][n][i] R[b][i][j] (double accumulation,
+ * rounded once to dtype; a shared x_in, Bx == 1, still gets B rows of dX like the device entry point — the caller sums them),
+ * dR[b][i][j] = sum_n dY[b][n][i] X[b][n][j] in double */
+CPU_API size_t chx_apply_bwd_workspace_bytes_cpu(int64_t B, int64_t N) { (void)B; (void)N; return 0; }
+CPU_API int chx_apply_affine7_bwd_cpu(const void* dY, const void* R, const void* X, void* dX, double* dR, int64_t B, int64_t Bx,
+                                      int64_t BR, int64_t N, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes; (void)stream;
+    if (!dY || B < 1 || N < 1 || !bcast_ok(Bx, B) || !bcast_ok(BR, B) || (dX && !R) || (dR && !X)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    for (int64_t b = 0; b < B; ++b) {
+        double acc[49];
+        for (int k = 0; k < 49; ++k) acc[k] = 0.0;
+        for (int64_t n = 0; n < N; ++n) {
+            double g[7];
+            for (int i = 0; i < 7; ++i) g[i] = ld(dY, dtype, (b * N + n) * 7 + i);
+            if (dX)
+                for (int j = 0; j < 7; ++j) {
+                    double s = 0.0;
+                    for (int i = 0; i < 7; ++i) s += g[i] * ld(R, dtype, (BR == 1 ? 0 : b) * 49 + i * 7 + j);
+                    st(dX, dtype, (b * N + n) * 7 + j, s);
+                }
+            if (dR)
+                for (int i = 0; i < 7; ++i)
+                    for (int j = 0; j < 7; ++j) acc[i * 7 + j] += g[i] * ld(X, dtype, ((Bx == 1 ? 0 : b) * N + n) * 7 + j);
+        }
+        if (dR)
+            for (int k = 0; k < 49; ++k) dR[b * 49 + k] = acc[k];
+    }
+    return CHX_OK;
+}
+
+/* chx_moments_bwd(_w): the cotangent of utils/statistics.py:4-62 (csrc/chx_moments.hip moments_bwd_kernel restated): with
+ * cf = W - W2 / W, Gsym = g + g^T on the upper-triangular cotangent g of the covariances, d_n = x_n - mu,
+ *   dX[n][a] = w_n (g_mu[a] / W + (Gsym d_n)[a] / cf)
+ *   dW[n]    = g_W + 2 w_n g_W2 + (g_mu . d_n) / W + (d_n^T Gsym d_n / 2 - S (1 + W2 / W^2 - 2 w_n / W)) / cf,  S = sum g_ab cov_ab */
+CPU_API int chx_moments_bwd_w_cpu(const void* x, const void* w, const double* out, const double* d_out, int64_t B, int64_t Bx, int64_t Bw,
+                                  int64_t N, int dtype, void* dX, void* dW, void* stream) {
+    (void)stream;
+    if (!x || !out || !d_out || B < 1 || N < 1 || !bcast_ok(Bx, B) || (w && !bcast_ok(Bw, B))) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    for (int64_t b = 0; b < B; ++b) {
+        const double* o = out + b * 29;
+        const double* g = d_out + b * 29;
+        const double W = o[0], W2 = o[1], icf = 1.0 / (W - W2 / W), kcf = 1.0 + W2 / (W * W);
+        double G[6][6], S = 0.0;
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j, ++k) {
+                if (i == j) G[i][i] = 2.0 * g[8 + k];
+                else G[i][j] = G[j][i] = g[8 + k];
+                S += g[8 + k] * o[8 + k];
+            }
+        for (int64_t n = 0; n < N; ++n) {
+            double d[6], quad = 0.0, lin = 0.0;
+            for (int j = 0; j < 6; ++j) d[j] = ld(x, dtype, ((Bx == 1 ? 0 : b) * N + n) * 7 + j) - o[2 + j];
+            const double wv = w ? ld(w, dtype, (Bw == 1 ? 0 : b) * N + n) : 1.0;
+            for (int a = 0; a < 6; ++a) {
+                double s = 0.0;
+                for (int c = 0; c < 6; ++c) s += G[a][c] * d[c];
+                quad += d[a] * s;
+                lin += g[2 + a] * d[a];
+                if (dX) st(dX, dtype, (b * N + n) * 7 + a, wv * (g[2 + a] / W + icf * s));
+            }
+            if (dX) st(dX, dtype, (b * N + n) * 7 + 6, 0.0);
+            if (dW) st(dW, dtype, b * N + n, g[0] + 2.0 * wv * g[1] + lin / W + icf * (0.5 * quad - S * (kcf - 2.0 * wv / W)));
+        }
+    }
+    return CHX_OK;
+}
+
+CPU_API int chx_moments_bwd_cpu(const void* x, const void* w, const double* out, const double* d_out, int64_t B, int64_t Bx, int64_t Bw,
+                                int64_t N, int dtype, void* dX, void* stream) {
+    return chx_moments_bwd_w_cpu(x, w, out, d_out, B, Bx, Bw, N, dtype, dX, NULL, stream);
+}
+
+/* chx_cic_deposit_bwd (utils/cloud_in_cell.py under autograd; csrc/chx_cic.hip cic_bwd_kernel restated): a particle inside the
+ * extent receives dweight = sum over its in-grid corners of dgrid x corner weight, dpos[d] = charge x sum of dgrid x
+ * (+-1 along d) x the other axes' weights / bin width; a particle outside gets zeros. Cell index, fraction and charge are the
+ * oracle's dtype-faithful ones. Row-major grids. */
+CPU_API int chx_cic_deposit_bwd_cpu(const chx_cic_args* p, const void* dgrid, void* dweight, void* dpos, void* stream) {
+    (void)stream;
+    if (!p || !p->x || !p->extent || !dgrid || p->ndim < 1 || p->ndim > 3 || p->B < 1 || p->N < 1) return CHX_ERR_INVALID_ARG;
+    if (p->dtype != CHX_F32 && p->dtype != CHX_F64) return CHX_ERR_DTYPE;
+    int64_t total = 1, stride[3] = {0, 0, 0};
+    for (int d = p->ndim - 1; d >= 0; --d) { stride[d] = total; total *= p->bins[d]; }
+    for (int d = 0; d < p->ndim; ++d)
+        if (p->grid_strides[d] != 0 && p->grid_strides[d] != stride[d]) return CHX_ERR_INVALID_ARG;
+    chxo_cic_args a;
+    memset(&a, 0, sizeof(a));
+    a.ndim = p->ndim;
+    for (int d = 0; d < 3; ++d) { a.cols[d] = p->cols[d]; a.bins[d] = p->bins[d]; }
+    a.B = p->B; a.Bx = p->Bx; a.Bq = p->Bq; a.Bs = p->Bs; a.Be = p->Be; a.Bsc = p->Bsc; a.Bsh = p->Bsh; a.N = p->N;
+    a.dtype = p->dtype; a.abs_charge = p->abs_charge;
+    a.x = p->x; a.charge = p->charge; a.survival = p->survival; a.extent = p->extent; a.scale = p->scale; a.shift = p->shift;
+    const int nc = 1 << a.ndim;
+    for (int64_t b = 0; b < a.B; ++b)
+        for (int64_t n = 0; n < a.N; ++n) {
+            int64_t idx[3] = {0, 0, 0};
+            double f[3] = {0, 0, 0}, bw[3] = {1, 1, 1}, c;
+            int inside;
+            if (a.dtype == CHX_F32) {
+                float ff[3];
+                inside = cic_locate_f32(&a, b, n, idx, ff);
+                c = (double)cic_charge_f32(&a, b, n);
+                for (int d = 0; d < a.ndim; ++d) {
+                    f[d] = ff[d];
+                    const float* e = (const float*)a.extent + (a.Be == 1 ? 0 : b) * a.ndim * 2 + d * 2;
+                    bw[d] = (double)((e[1] - e[0]) / (float)a.bins[d]);
+                }
+            } else {
+                inside = cic_locate_f64(&a, b, n, idx, f);
+                c = cic_charge_f64(&a, b, n);
+                for (int d = 0; d < a.ndim; ++d) {
+                    const double* e = (const double*)a.extent + (a.Be == 1 ? 0 : b) * a.ndim * 2 + d * 2;
+                    bw[d] = (e[1] - e[0]) / (double)a.bins[d];
+                }
+            }
+            double dw = 0.0, dp[3] = {0.0, 0.0, 0.0};
+            for (int corner = 0; inside && corner < nc; ++corner) {
+                const int o[3] = {corner & 1, (corner >> 1) & 1, (corner >> 2) & 1};
+                int valid = 1;
+                int64_t off = 0;
+                double wf[3] = {1.0, 1.0, 1.0}, sg[3] = {0.0, 0.0, 0.0};
+                for (int d = 0; d < a.ndim; ++d) {
+                    const int64_t id = idx[d] + o[d];
+                    valid = valid && id >= 0 && id < a.bins[d];
+                    off += (id < 0 ? 0 : (id > a.bins[d] - 1 ? a.bins[d] - 1 : id)) * stride[d];
+                    wf[d] = o[d] ? f[d] : 1.0 - f[d];
+                    sg[d] = o[d] ? 1.0 : -1.0;
+                }
+                if (!valid) continue;
+                const double gv = ld(dgrid, a.dtype, b * total + off);
+                dw += gv * wf[0] * wf[1] * wf[2];
+                for (int d = 0; d < a.ndim; ++d) {
+                    double prod = sg[d];
+                    for (int e = 0; e < a.ndim; ++e)
+                        if (e != d) prod *= wf[e];
+                    dp[d] += c * gv * prod / bw[d];
+                }
+            }
+            if (dweight) st(dweight, a.dtype, b * a.N + n, dw);
+            if (dpos)
+                for (int d = 0; d < a.ndim; ++d) st(dpos, a.dtype, (b * a.N + n) * a.ndim + d, dp[d]);
+        }
+    return CHX_OK;
+}
+
+/* chx_sc_gather_kick (space_charge_kick.py:387-475, 548-584; particle_beam.py:1262-1346): F[B][gx][gy][gz][4] (x, y, z, pad) and
+ * half / cell / energy / dt of `dtype`, the particle step in double like the oracle's, rounded once */
+CPU_API int chx_sc_gather_kick_cpu(const void* x_in, const void* F, const void* half, const void* cell, const void* energy, const void* dt,
+                                   double mass_eV, int64_t B, int64_t Bx, int64_t Be, int64_t N, const int32_t* bins, int dtype,
+                                   void* x_out, void* stream) {
+    (void)stream;
+    if (!x_in || !F || !half || !cell || !energy || !dt || !x_out || !bins || B < 1 || N < 1 || !bcast_ok(Bx, B) || !bcast_ok(Be, B))
+        return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (bins[0] < 1 || bins[1] < 1 || bins[2] < 1) return CHX_ERR_INVALID_ARG;
+    const int64_t ncell = (int64_t)bins[0] * bins[1] * bins[2];
+    double* F3 = (double*)malloc(sizeof(double) * (size_t)B * (size_t)ncell * 3);
+    double* hd = (double*)malloc(sizeof(double) * (size_t)B * 3);
+    double* cd = (double*)malloc(sizeof(double) * (size_t)B * 3);
+    double* ed = (double*)malloc(sizeof(double) * (size_t)Be);
+    double* td = (double*)malloc(sizeof(double) * (size_t)B);
+    int rc = CHX_ERR_WORKSPACE;
+    if (F3 && hd && cd && ed && td) {
+        for (int64_t i = 0; i < B * ncell; ++i)
+            for (int d = 0; d < 3; ++d) F3[i * 3 + d] = ld(F, dtype, i * 4 + d);
+        for (int64_t i = 0; i < B * 3; ++i) { hd[i] = ld(half, dtype, i); cd[i] = ld(cell, dtype, i); }
+        for (int64_t i = 0; i < Be; ++i) ed[i] = ld(energy, dtype, i);
+        for (int64_t i = 0; i < B; ++i) td[i] = ld(dt, dtype, i);
+        rc = chxo_sc_gather_kick(x_in, F3, hd, cd, ed, td, mass_eV, B, Bx, Be, N, bins, dtype, x_out, NULL) == 0 ? CHX_OK : CHX_ERR_INVALID_ARG;
+    }
+    free(F3); free(hd); free(cd); free(ed); free(td);
+    return rc;
+}

@@ -33,7 +33,9 @@ def test_every_twin_is_exported_with_the_signature_of_its_namesake():
     twins, abi = _decls("chx_cpu.h"), _decls("chx.h")
     assert set(twins) == {"chx_abi_version_cpu", "chx_build_rmatrix_cpu", "chx_compose_maps_cpu", "chx_apply_affine7_cpu",
                           "chx_moments_cpu", "chx_cic_deposit_cpu", "chx_track_elementwise_cpu", "chx_cavity_coeffs_cpu",
-                          "chx_cavity_track_cpu", "chx_hist2d_cpu", "chx_sc_kick_workspace_bytes_cpu", "chx_sc_kick_cpu"}
+                          "chx_cavity_track_cpu", "chx_hist2d_cpu", "chx_sc_kick_workspace_bytes_cpu", "chx_sc_kick_cpu",
+                          "chx_track_fused_cpu", "chx_apply_bwd_workspace_bytes_cpu", "chx_apply_affine7_bwd_cpu", "chx_moments_bwd_cpu",
+                          "chx_moments_bwd_w_cpu", "chx_cic_deposit_bwd_cpu", "chx_sc_gather_kick_cpu"}
     norm = lambda sig: re.sub(r"\s*/\*.*?\*/", "", sig).replace(" ,", ",")  # noqa: E731
     for name, sig in twins.items():
         assert hasattr(lib, name), name
@@ -195,3 +197,113 @@ def test_space_charge_kick_twin_gives_the_oracles_numbers(oracle):
                                i64(B), i64(1), i64(N), bad, 0, _ptr(out), None, ctypes.c_size_t(0), None, None, None, i64(1)) == -1
     assert lib.chx_sc_kick_cpu(_ptr(x), _ptr(q), _ptr(w), _ptr(energy), _ptr(length), _ptr(ext), dbl(oracle.ELECTRON_MASS_EV), i64(B), i64(B), i64(B),
                                i64(B), i64(1), i64(N), bins, 7, _ptr(out), None, ctypes.c_size_t(0), None, None, None, i64(1)) == -2
+
+
+def test_backward_and_gather_twins_against_torch_autograd_and_the_oracle(oracle):
+    """The round-6 twins. The backward entry points are checked against torch autograd of the reference's own tensor expressions
+    (element.py:180-191, utils/statistics.py:4-62, utils/cloud_in_cell.py written out in float64) — independent of the C they test;
+    the fused track and the gather against the twins / the oracle call they must equal."""
+    import torch
+
+    from cheetah_amd._lib import CicArgs
+
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    B, N, E = 2, 700, 5
+    # ---- chx_track_fused_cpu == chx_track_elementwise_cpu, bit for bit (float32 storage: the rounding between elements matters)
+    x = (rng.standard_normal((B, N, 7)) * 1e-3).astype(np.float32)
+    x[..., 6] = 1
+    R = (np.eye(7) + 0.05 * rng.standard_normal((E, B, 7, 7))).astype(np.float32)
+    R[..., 6, :] = [0, 0, 0, 0, 0, 0, 1]
+    a, b = np.empty_like(x), np.empty_like(x)
+    assert lib.chx_track_elementwise_cpu(_ptr(x), _ptr(R), _ptr(a), None, i64(E), i64(B), i64(B), i64(B), i64(N), 0, None) == 0
+    assert lib.chx_track_fused_cpu(_ptr(x), _ptr(R), _ptr(b), i64(E), i64(B), i64(B), i64(B), i64(N), 0, None) == 0
+    assert np.array_equal(a, b) and not np.array_equal(a, x)
+    # ---- chx_apply_affine7_bwd_cpu: y = x @ R.mT under autograd
+    xt = torch.from_numpy(rng.standard_normal((B, N, 7))).requires_grad_(True)
+    Rt = torch.from_numpy(np.eye(7) + 0.1 * rng.standard_normal((B, 7, 7))).requires_grad_(True)
+    dY = torch.from_numpy(rng.standard_normal((B, N, 7)))
+    (xt @ Rt.mT).backward(dY)
+    dX, dR = np.empty((B, N, 7)), np.empty((B, 49))
+    assert lib.chx_apply_affine7_bwd_cpu(_ptr(dY.numpy()), _ptr(Rt.detach().numpy()), _ptr(xt.detach().numpy()), _ptr(dX), _ptr(dR), i64(B), i64(B),
+                                         i64(B), i64(N), 1, None, ctypes.c_size_t(0), None) == 0
+    assert np.allclose(dX, xt.grad.numpy(), rtol=1e-13, atol=1e-15) and np.allclose(dR.reshape(B, 7, 7), Rt.grad.numpy(), rtol=1e-12, atol=1e-13)
+    assert lib.chx_apply_bwd_workspace_bytes_cpu(i64(B), i64(N)) == 0
+    # ---- chx_moments_bwd_w_cpu: the reference's weighted statistics (utils/statistics.py:4-62) under autograd
+    xs = torch.from_numpy(rng.standard_normal((B, N, 7)) * [1e-3, 1e-5, 2e-3, 1e-5, 1e-4, 1e-3, 0] + [5e-3, 0, -1e-3, 0, 0, 0, 1]).requires_grad_(True)
+    ws = torch.from_numpy(0.1 + rng.random((B, N))).requires_grad_(True)
+    W, W2 = ws.sum(-1), ws.square().sum(-1)
+    mu = (ws.unsqueeze(-1) * xs[..., :6]).sum(-2) / W.unsqueeze(-1)
+    d = xs[..., :6] - mu.unsqueeze(-2)
+    cov = torch.einsum("bn,bni,bnj->bij", ws, d, d) / (W - W2 / W)[:, None, None]
+    iu = torch.triu_indices(6, 6)
+    out_t = torch.cat([W[:, None], W2[:, None], mu, cov[:, iu[0], iu[1]]], dim=-1)          # the 29-vector of chx_moments
+    g = torch.from_numpy(rng.standard_normal((B, 29)))
+    out_t.backward(g)
+    mom = np.empty((B, 29))
+    assert lib.chx_moments_cpu(_ptr(xs.detach().numpy()), _ptr(ws.detach().numpy()), i64(B), i64(B), i64(B), i64(N), 1, _ptr(mom), None,
+                               ctypes.c_size_t(0), None) == 0
+    assert np.allclose(mom, out_t.detach().numpy(), rtol=1e-10, atol=1e-22)
+    dXm, dWm = np.empty((B, N, 7)), np.empty((B, N))
+    assert lib.chx_moments_bwd_w_cpu(_ptr(xs.detach().numpy()), _ptr(ws.detach().numpy()), _ptr(mom), _ptr(g.numpy()), i64(B), i64(B), i64(B),
+                                     i64(N), 1, _ptr(dXm), _ptr(dWm), None) == 0
+    scale = np.abs(xs.grad.numpy()).max(axis=1, keepdims=True) + 1e-300
+    assert np.max(np.abs(dXm - xs.grad.numpy()) / scale) < 1e-9 and np.all(dXm[..., 6] == 0)
+    assert np.max(np.abs(dWm - ws.grad.numpy())) < 1e-9 * np.abs(ws.grad.numpy()).max()
+    dXo = np.empty((B, N, 7))
+    assert lib.chx_moments_bwd_cpu(_ptr(xs.detach().numpy()), _ptr(ws.detach().numpy()), _ptr(mom), _ptr(g.numpy()), i64(B), i64(B), i64(B), i64(N),
+                                   1, _ptr(dXo), None) == 0
+    assert np.array_equal(dXo, dXm)
+    # ---- chx_cic_deposit_bwd_cpu: the 2-D cloud-in-cell deposit (utils/cloud_in_cell.py:178-239) under autograd
+    n2, bins = 900, (12, 10)
+    pos = torch.from_numpy(rng.standard_normal((n2, 2)) * [1.2e-3, 2.0e-3]).requires_grad_(True)      # some land outside the extent
+    qq = torch.from_numpy(rng.random(n2)).requires_grad_(True)
+    ext = torch.tensor([[-3e-3, 3e-3], [-4e-3, 4e-3]], dtype=torch.float64)
+    bw = (ext[:, 1] - ext[:, 0]) / torch.tensor(bins, dtype=torch.float64)
+    pb = (pos - ext[:, 0]) / bw - 0.5
+    i0 = pb.detach().floor().long()
+    f = pb - i0
+    inside = ((pos >= ext[:, 0]) & (pos <= ext[:, 1])).all(-1).to(torch.float64).detach()
+    grid_t = torch.zeros(bins[0] * bins[1], dtype=torch.float64)
+    for ox in (0, 1):
+        for oy in (0, 1):
+            ix, iy = i0[:, 0] + ox, i0[:, 1] + oy
+            ok = ((ix >= 0) & (ix < bins[0]) & (iy >= 0) & (iy < bins[1])).to(torch.float64)
+            wgt = (f[:, 0] if ox else 1 - f[:, 0]) * (f[:, 1] if oy else 1 - f[:, 1])
+            grid_t = grid_t.scatter_add(0, ix.clamp(0, bins[0] - 1) * bins[1] + iy.clamp(0, bins[1] - 1), qq * inside * ok * wgt)
+    dgrid = torch.from_numpy(rng.standard_normal(bins[0] * bins[1]))
+    grid_t.backward(dgrid)
+    x7 = np.zeros((1, n2, 7))
+    x7[0, :, 0], x7[0, :, 2] = pos.detach().numpy()[:, 0], pos.detach().numpy()[:, 1]
+    qn, en = np.ascontiguousarray(qq.detach().numpy()[None]), np.ascontiguousarray(ext.numpy()[None])
+    a = CicArgs()
+    a.ndim = 2
+    a.cols[0], a.cols[1] = 0, 2
+    a.bins[0], a.bins[1] = bins
+    a.B = a.Bx = a.Bq = a.Be = a.Bs = a.Bsc = a.Bsh = 1
+    a.N, a.dtype, a.abs_charge = n2, 1, 0
+    gridn = np.zeros((1, *bins))
+    a.x, a.charge, a.extent, a.grid = _ptr(x7).value, _ptr(qn).value, _ptr(en).value, _ptr(gridn).value
+    assert lib.chx_cic_deposit_cpu(ctypes.byref(a), None) == 0
+    assert np.allclose(gridn.reshape(-1), grid_t.detach().numpy(), rtol=1e-12, atol=1e-18)         # same forward first
+    dwt, dps = np.empty((1, n2)), np.empty((1, n2, 2))
+    assert lib.chx_cic_deposit_bwd_cpu(ctypes.byref(a), _ptr(dgrid.numpy()), _ptr(dwt), _ptr(dps), None) == 0
+    assert np.allclose(dwt[0], qq.grad.numpy(), rtol=1e-11, atol=1e-16)
+    assert np.allclose(dps[0], pos.grad.numpy(), rtol=1e-11, atol=1e-12 * np.abs(pos.grad.numpy()).max())
+    assert (inside == 0).any() and np.all(dwt[0][inside.numpy() == 0] == 0)
+    # ---- chx_sc_gather_kick_cpu: the oracle's own gather on the oracle's own force grid (the last step of its space_charge_kick)
+    n3 = 3000
+    xk = (rng.standard_normal((1, n3, 7)) * [2e-4, 3e-6, 2e-4, 3e-6, 1e-5, 1e-3, 0]).astype(np.float64)
+    xk[..., 6] = 1
+    qk, wk = np.full((1, n3), 1e-13), np.ones((1, n3))
+    want, det = oracle.space_charge_kick(xk, 1e8, qk, wk, 0.3, grid_shape=(16, 16, 16), details=True)
+    F4 = np.zeros((1, 16, 16, 16, 4))
+    F4[..., :3] = det["F"]
+    got = np.empty_like(xk)
+    b3 = (ctypes.c_int32 * 3)(16, 16, 16)
+    assert lib.chx_sc_gather_kick_cpu(_ptr(xk), _ptr(F4), _ptr(np.ascontiguousarray(det["half"].astype(np.float64))),
+                                      _ptr(np.ascontiguousarray(det["cell"].astype(np.float64))), _ptr(np.array([1e8])),
+                                      _ptr(np.ascontiguousarray(det["dt"])), dbl(oracle.ELECTRON_MASS_EV), i64(1), i64(1), i64(1), i64(n3), b3, 1,
+                                      _ptr(got), None) == 0
+    assert np.array_equal(got, want) and not np.array_equal(got, xk)
+    assert lib.chx_sc_gather_kick_cpu(_ptr(xk), None, None, None, None, None, dbl(1.0), i64(1), i64(1), i64(1), i64(n3), b3, 1, _ptr(got), None) == -1
