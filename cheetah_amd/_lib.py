@@ -61,6 +61,7 @@ class LatticeScreen(ctypes.Structure):
         ("image", c_void_p), ("image_bytes", c_i64), ("map", c_void_p), ("element_maps", c_void_p),
         ("mu", c_void_p), ("cov", c_void_p), ("geom", c_void_p), ("shift", c_void_p), ("total_charge", c_void_p),
         ("total_charge_out", c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("mom_partials", c_void_p),
     ]
 
 
@@ -165,6 +166,8 @@ SIGNATURES = {
     "chx_lattice_track_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                           c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_i64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_i64, c_void_p]),
+    "chx_lattice_moment_blocks": (c_i64, [c_i64, c_i64]),
+    "chx_lattice_screen_moments": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "chx_lattice_prepare_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_double, c_double, c_int, c_void_p,
                                             c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "chx_screen_extent": (c_int, [c_void_p, ctypes.c_int32, ctypes.c_int32, c_int, c_void_p, c_void_p]),
@@ -293,7 +296,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 7:  # CHX_ABI_VERSION of include/chx.h
+        if handle.chx_abi_version() != 8:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib
@@ -341,7 +344,8 @@ def torch_host():
         h = lib()
         names = ("chx_lattice_track_screens", "chx_parameter_lattice_track_screens", "chx_run_build_compose", "chx_run_vjp_masked",
                  "chx_run_vjp_workspace_bytes", "chx_apply_affine7_bwd", "chx_apply_bwd_workspace_bytes", "chx_moments_entry",
-                 "chx_moments_workspace_bytes", "chx_moment_entry", "chx_moment_entry_mapped_bwd")
+                 "chx_moments_workspace_bytes", "chx_moment_entry", "chx_moment_entry_mapped_bwd", "chx_lattice_moment_blocks",
+                 "chx_lattice_screen_moments")
         _chxtorch.bind({n: ctypes.cast(getattr(h, n), ctypes.c_void_p).value for n in names}, ChxError)
         _torch_host = _chxtorch
     return _torch_host

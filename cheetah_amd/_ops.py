@@ -548,6 +548,13 @@ class _LinearSource:
         return _LinearSource(self.owner, self.x, self.R, self.batch_shape, copy_._version)
 
 
+def mark_copy_of(copy: torch.Tensor, source: torch.Tensor) -> None:
+    """Declare `copy` an unmodified copy of `source` as both stand now (what clone_many records for its own copies): `_origin`
+    follows the tag while neither tensor has been written to since."""
+    root = _origin(source)
+    copy._chx_origin = (weakref.ref(root), root._version, copy._version)
+
+
 def _origin(t: torch.Tensor) -> torch.Tensor:
     """The tensor `t` is an unmodified copy of (clone_many), followed through chains of copies; `t` itself otherwise."""
     while True:
@@ -1183,7 +1190,12 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
         if cached is not None and cached[0] == particles._version and cached[1] is w_src and cached[2] == w_ver \
                 and cached[3] == particles.data_ptr() and cached[4].shape[0] == 1:
             known = cached[4]
-        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, particles.detach(), survival, mom_x, known, index, take_sqrt)
+        partials = None
+        if known is None:
+            tag = getattr(particles, "_chx_partials", None)      # (sums, version of the rows, the weights they were taken with)
+            if tag is not None and tag[1] == particles._version and tag[2] is survival:
+                partials = tag[0]
+        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, particles.detach(), survival, mom_x, known, index, take_sqrt, partials)
         if known is None:
             particles._chx_mom = (particles._version, w_src, w_ver, particles.data_ptr(), mom_y)
         return out
@@ -1208,7 +1220,7 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
         if cached is not None and cached[0] == particles._version and cached[1] is w_src \
                 and (w_src is None or cached[2] == w_src._version) and cached[3] == y.data_ptr() and cached[4].shape[0] == 1:
             known = cached[4]
-        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, y, w, mom_x, known, index, take_sqrt)
+        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, y, w, mom_x, known, index, take_sqrt, None)
         if known is None:
             particles._chx_mom = (particles._version, w_src, None if w_src is None else w_src._version, y.data_ptr(), mom_y)
         return out.reshape(batch_shape)

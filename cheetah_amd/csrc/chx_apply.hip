@@ -622,12 +622,15 @@ struct ApplyScreens {
 };
 
 // SCREENS: 0 = no screen items, 1 = screens that record only (no image buffer in this call: none of the combining table's 32 KiB
-// of LDS, which would leave four workgroups per CU), 2 = screens with images
+// of LDS, which would leave four workgroups per CU), 2 = screens with images, 3 = record + the one-pass sums of the recorded
+// beam's moments (chx_lattice_screen.mom_partials: a beam property of the screen's beam then needs no pass over its rows —
+// d sigma_x(screen) / d k1, BASELINE config C5: one launch less per step, 32 MB less to read)
 // STAGED (small beams, stretches of at most kApplyStagedItems items): the workgroup copies the item table, this row's maps and the
 // cavities' coefficient rows into LDS next to its particle tile — one round of loads — and walks the items out of LDS. A beam of 1e5
 // particles is one or two workgroups per CU: nothing hides the scalar loads in front of every item (its type, then its 49 map entries
 // in up to four pieces), and a 100-element lattice with 25 monitors is 51 items: 26 us of a pass whose arithmetic is a fifth of that.
 constexpr int kApplyStagedItems = 96;
+constexpr int kMomSlots = 64;       // sets of moment sums a screen's particle pass adds into (chx_lattice_screen.mom_partials)
 constexpr int kApplyMapStride = 52;
 
 template <typename T, int PPT, int SCREENS, bool STAGED>
@@ -688,6 +691,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
             sv[k] = (p < np) ? (survival ? survival[(shared_sv ? t0 : n0) + p] : (T)1) : (T)0;
         }
     }
+    // SCREENS == 3: the beam's first row rides along (every lane the same values): the common centre of the moment sums at a screen
+    T x0[7];
+    if constexpr (SCREENS == 3) {
+        const T* r0 = x_in + (shared_in ? 0 : beam * N) * 7;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) x0[j] = r0[j];
+    }
     // the wave's sum of weights stands from monitor to monitor until an aperture thins them (a wave sum of doubles is ~100
     // cycles: at 4e8 particle rows the monitors, not HBM, bound the pass)
     bool sw_known = false;
@@ -746,6 +756,69 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     if (p < np) {
                         if (sv_rec) sv_rec[n0 + p] = sv[k];
                         if (q_rec) q_rec[n0 + p] = charge ? charge[t0 + p] : (T)1;
+                    }
+                }
+                if constexpr (SCREENS == 3) {
+                    double* mp = (double*)so.mom_partials;
+                    if (mp) {
+                        // sums about the beam's FIRST row as it stands at this screen (carried through the items next to the lane's
+                        // own rows: the same value in every workgroup, a particle of the beam — |x - c| stays beam-sized), added
+                        // into kMomSlots sets with fp64 atomics (the preparation launch zeroed them)
+                        __shared__ double mom_red[16 * 32];
+                        __syncthreads();                 // (a second screen of the stretch: the array is free again)
+                        double c0[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) c0[j] = isfinite((double)x0[j]) ? (double)x0[j] : 0.0;
+                        // two halves of 16 accumulators (all 32 at once held the pass at three waves per SIMD): {W, W2, s[6], m_0*[6]},
+                        // then {m_1*[5], m_2*[4], m_3*[3], m_4*[2], m_55}; mom_red column of value k: k (k < 14), k + 2 (k >= 14)
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            __builtin_amdgcn_sched_barrier(0);      // (the halves' live ranges must not overlap: that is their point)
+                            double acc[16];
+#pragma unroll
+                            for (int k2 = 0; k2 < 16; ++k2) acc[k2] = 0.0;
+#pragma unroll
+                            for (int k = 0; k < PPT; ++k) {
+                                const int p = threadIdx.x + k * CHX_BLOCK;
+                                if (p >= np) continue;
+                                const double w = (double)sv[k];
+                                double d[6];
+#pragma unroll
+                                for (int j = 0; j < 6; ++j) d[j] = (double)x.get(k, j) - c0[j];
+                                if (half == 0) {
+                                    acc[0] += w;
+                                    acc[1] += w * w;
+                                    const double wd0 = w * d[0];
+#pragma unroll
+                                    for (int a = 0; a < 6; ++a) {
+                                        acc[2 + a] = fma(w, d[a], acc[2 + a]);
+                                        acc[8 + a] = fma(wd0, d[a], acc[8 + a]);
+                                    }
+                                } else {
+                                    int k2 = 0;
+#pragma unroll
+                                    for (int a = 1; a < 6; ++a) {
+                                        const double wd = w * d[a];
+#pragma unroll
+                                        for (int b2 = a; b2 < 6; ++b2) { acc[k2] = fma(wd, d[b2], acc[k2]); ++k2; }
+                                    }
+                                }
+                            }
+                            chx_row16_sum16_folded(acc, mom_red + half * 16, 32);
+                        }
+                        __syncthreads();
+                        const int nslots = (int)((gridDim.x < (unsigned)kMomSlots) ? gridDim.x : (unsigned)kMomSlots);
+                        const int64_t stride = (int64_t)nslots * gridDim.y, slot = beam * nslots + (int)(blockIdx.x % (unsigned)nslots);
+                        if (threadIdx.x < CHX_MOM_NOUT) {
+                            const int col = threadIdx.x < 14 ? threadIdx.x : threadIdx.x + 2;
+                            double t = 0.0;
+#pragma unroll
+                            for (int r2 = 0; r2 < 16; ++r2) t += mom_red[r2 * 32 + col];
+                            unsafeAtomicAdd(&mp[(int64_t)threadIdx.x * stride + slot], t);
+                        } else if (threadIdx.x < CHX_MOM_NOUT + 6 && blockIdx.x == 0) {
+                            // the sums' centre, behind the 29 rows of sets: [29 * sets + j] of this beam's block
+                            mp[(int64_t)CHX_MOM_NOUT * stride + beam * 6 + (threadIdx.x - CHX_MOM_NOUT)] = c0[threadIdx.x - CHX_MOM_NOUT];
+                        }
                     }
                 }
                 if constexpr (SCREENS == 2) {
@@ -820,6 +893,13 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
         const T* __restrict__ R = STAGED ? maps_s + i * kApplyMapStride : reinterpret_cast<const T*>(Rs + mrow * 49);
         const bool cavity = type == 1;
         const double* __restrict__ c = STAGED ? coeffs_s + i * CHX_CAV_NCOEF : coeffs_g + mrow * CHX_CAV_NCOEF;
+        if constexpr (SCREENS == 3) {
+            T y0[7];
+            apply7<T>(R, x0, y0);
+            if (cavity) cavity_epilogue<T>(c, x0, y0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) x0[j] = y0[j];
+        }
         if constexpr (std::is_same<T, float>::value && PPT % 2 == 0) {
             // the lane's particles two to a register pair, kept that way from load to store: every step of apply7's fmaf chain is ONE
             // v_pk_fma_f32 for both (same per-particle order -> same bits; at 4e8 particle rows the maps of a stretch are VALU time,
@@ -1219,6 +1299,29 @@ extern "C" int chx_lattice_track_diag(const int64_t* table, int64_t n_items, int
                                      workspace, workspace_bytes, nullptr, nullptr, 0, stream);
 }
 
+// the particle pass's grid.x: one particle per lane on small beams, two from 1e6 particle rows on (see chx_lattice_track_screens)
+static inline int lattice_ppt(int64_t N, int64_t B) { return (N * B >= 1000000) ? 2 : 1; }
+
+extern "C" int64_t chx_lattice_moment_blocks(int64_t N, int64_t B) {
+    if (N < 1 || B < 1) return 0;
+    const int64_t tile = (int64_t)CHX_BLOCK * lattice_ppt(N, B);
+    const int64_t wgs = (N + tile - 1) / tile;
+    return (wgs < kMomSlots ? wgs : kMomSlots) * B;
+}
+
+// (chx_moments.hip) partials[29][n_sets] + centre[6] -> out[29] (+ one entry): the second launch of chx_moments_entry on its own
+int chx_moments_finalize_sets(const double* partials, int64_t n_sets, const double* centre, int dtype, double* out, int index, int take_sqrt,
+                              void* entry_out, void* stream);
+
+extern "C" int chx_lattice_screen_moments(const double* mom_partials, int64_t n_blocks, int dtype, double* out, int index, int take_sqrt,
+                                          void* entry_out, void* stream) {
+    if (!mom_partials || !out || n_blocks < 1 || n_blocks > 0x7fffffffLL || index >= CHX_MOM_NOUT || (index >= 0 && !entry_out))
+        return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    if (n_blocks > kMomSlots) return CHX_ERR_INVALID_ARG;
+    return chx_moments_finalize_sets(mom_partials, n_blocks, mom_partials + CHX_MOM_NOUT * n_blocks, dtype, out, index, take_sqrt, entry_out, stream);
+}
+
 extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                                          double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                                          void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
@@ -1244,7 +1347,7 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
     // one particle per lane on small beams (a few dozen tiles: two per lane only halve the waves in flight); two per lane from 1e6
     // particle rows on (half the waves: half the wave sums at the monitors, half the scalar loads of the maps; measured: a
     // 16-cavity linac 0.132 -> 0.124 ms at 1e6, 0.418 -> 0.371 at 4e6, no gain at 3e5)
-    const int ppt = (N * B >= 1000000) ? 2 : 1;
+    const int ppt = lattice_ppt(N, B);
     const int64_t tile = (int64_t)CHX_BLOCK * ppt;
     const dim3 grid((unsigned)((N + tile - 1) / tile), (unsigned)B);
     const int64_t nw = (int64_t)grid.x * (CHX_BLOCK / 64);
@@ -1338,11 +1441,16 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
                                table, (int)n_items, Rs, coeffs, N, iv, ov, (const T*)survival, (double*)workspace, diag, ptrs,      \
                                (T*)survival_out, shared_in, Bm, shared_sv, scr);                                                    \
     } while (0)
-    bool images = false;
-    for (int64_t k = 0; k < n_screens; ++k) images = images || screens[k].image != nullptr;
+    bool images = false, sums = false;
+    for (int64_t k = 0; k < n_screens; ++k) {
+        images = images || screens[k].image != nullptr;
+        sums = sums || screens[k].mom_partials != nullptr;
+    }
+    if (images && sums) return CHX_ERR_INVALID_ARG;     // (one or the other per call: the combining table and the sums' LDS)
 #define CHX_LATTICE_APPLY(T, PPT)                  \
     do {                                           \
         if (n_screens > 0 && images) CHX_LATTICE_APPLY_S(T, PPT, 2); \
+        else if (n_screens > 0 && sums) CHX_LATTICE_APPLY_S(T, PPT, 3); \
         else if (n_screens > 0) CHX_LATTICE_APPLY_S(T, PPT, 1);      \
         else CHX_LATTICE_APPLY_S(T, PPT, 0);       \
     } while (0)

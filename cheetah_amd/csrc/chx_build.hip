@@ -2133,9 +2133,15 @@ extern "C" int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items
         scr.zero_first[k] = zero_blocks;
         if (k < n_screens) {
             scr.s[k] = screens[k];
-            if (screens[k].image) {
-                if (screens[k].image_bytes < 0 || (screens[k].image_bytes & 3)) return CHX_ERR_INVALID_ARG;
-                zero_blocks += (screens[k].image_bytes + kScreenZeroBytes - 1) / kScreenZeroBytes;
+            if (!screens[k].image && screens[k].mom_partials) {
+                // the sets of moment sums the particle pass adds into start from zero like an image does (this kernel reads
+                // `image` for nothing else)
+                scr.s[k].image = screens[k].mom_partials;
+                scr.s[k].image_bytes = CHX_LATTICE_MOMENT_DOUBLES * (int64_t)sizeof(double);
+            }
+            if (scr.s[k].image) {
+                if (scr.s[k].image_bytes < 0 || (scr.s[k].image_bytes & 3)) return CHX_ERR_INVALID_ARG;
+                zero_blocks += (scr.s[k].image_bytes + kScreenZeroBytes - 1) / kScreenZeroBytes;
             }
         } else {
             scr.s[k] = chx_lattice_screen{};

@@ -138,6 +138,58 @@ __device__ __forceinline__ void chx_block_sum8_folded(double (&v)[8], double* sm
     }
 }
 
+// THIRTY-TWO doubles per thread summed over the workgroup's rows of 16 lanes, folded the same way: after lane ^ 1 a lane carries 16
+// of the values, after lane ^ 2 eight, and those eight are summed over the four quads of its row (row_ror:8, row_ror:4): ~216
+// instructions per wave against 32 x 12 for full row sums. Lane p < 4 of a row ends with the row totals of values
+// 16 (p & 1) + 8 (p >> 1) + j, j < 8, and stores them to smem[row][32] (row = wave * 4 + lane / 16). No barrier in here.
+__device__ __forceinline__ void chx_row16_sum32_folded(double (&v)[32], double* smem /* [rows][32] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    double t[16], u[8];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double mine = b0 ? v[j + 16] : v[j], give = b0 ? v[j] : v[j + 16];
+        t[j] = mine + chx_dpp_get<0xB1>(give);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double mine = b1 ? t[j + 8] : t[j], give = b1 ? t[j] : t[j + 8];
+        u[j] = mine + chx_dpp_get<0x4E>(give);
+        u[j] += chx_dpp_get<0x128>(u[j]);
+        u[j] += chx_dpp_get<0x124>(u[j]);
+    }
+    if ((lane & 15) < 4) {
+        double* dst = smem + (wave * 4 + (lane >> 4)) * 32 + 16 * (lane & 1) + 4 * (lane & 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = u[j];
+    }
+}
+
+// SIXTEEN doubles per thread, the same folding (~108 instructions per wave): lane p < 4 of a row ends with the row totals of values
+// 8 (p & 1) + 4 (p >> 1) + j, j < 4, and stores them to smem[row * stride + j...]. No barrier in here.
+__device__ __forceinline__ void chx_row16_sum16_folded(double (&v)[16], double* smem /* [rows][stride] */, int stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    double t[8], u[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double mine = b0 ? v[j + 8] : v[j], give = b0 ? v[j] : v[j + 8];
+        t[j] = mine + chx_dpp_get<0xB1>(give);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double mine = b1 ? t[j + 4] : t[j], give = b1 ? t[j] : t[j + 4];
+        u[j] = mine + chx_dpp_get<0x4E>(give);
+        u[j] += chx_dpp_get<0x128>(u[j]);
+        u[j] += chx_dpp_get<0x124>(u[j]);
+    }
+    if ((lane & 15) < 4) {
+        double* dst = smem + (wave * 4 + (lane >> 4)) * stride + 8 * (lane & 1) + 2 * (lane & 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = u[j];
+    }
+}
+
 // ---- LDS tile staging: contiguous 16-byte vector transfers between global memory and an LDS
 // tile (coalesced global_load/store_dwordx4); scalar fallback when the tile start is unaligned.
 // Non-temporal 16-byte accesses (the `nt` cache policy of global_load/store_dwordx4): a streaming pass reads every

@@ -1152,6 +1152,17 @@ static void launch_reduce_finalize(int64_t B, int64_t nblk, const double* part, 
                            out, index, take_sqrt, (T*)entry_out);
 }
 
+// the second launch of chx_moments_entry on partial sums some other pass left (chx_lattice_screen.mom_partials): B = 1
+int chx_moments_finalize_sets(const double* partials, int64_t n_sets, const double* centre, int dtype, double* out, int index, int take_sqrt,
+                              void* entry_out, void* stream) {
+    if (!partials || !centre || !out || n_sets < 1 || n_sets > 0x7fffffffLL) return CHX_ERR_INVALID_ARG;
+    if (dtype == CHX_F32) launch_reduce_finalize<float>(1, n_sets, partials, centre, out, index, take_sqrt, entry_out, (hipStream_t)stream);
+    else if (dtype == CHX_F64) launch_reduce_finalize<double>(1, n_sets, partials, centre, out, index, take_sqrt, entry_out, (hipStream_t)stream);
+    else return CHX_ERR_DTYPE;
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 extern "C" int chx_moments(const void* x, const void* w, int64_t B, int64_t Bx, int64_t Bw, int64_t N,
                            int dtype, double* out, void* workspace, size_t workspace_bytes,
                            void* stream) {

@@ -40,6 +40,8 @@ decltype(&chx_moments_entry) p_moments_entry = nullptr;
 decltype(&chx_moments_workspace_bytes) p_moments_workspace_bytes = nullptr;
 decltype(&chx_moment_entry) p_moment_entry = nullptr;
 decltype(&chx_moment_entry_mapped_bwd) p_moment_entry_mapped_bwd = nullptr;
+decltype(&chx_lattice_moment_blocks) p_moment_blocks = nullptr;
+decltype(&chx_lattice_screen_moments) p_screen_moments = nullptr;
 PyObject* g_error = nullptr;        // cheetah_amd._lib.ChxError
 
 // the stream torch's kernels of this thread go to on the tensor's device (also inside a backward pass: the engine restores the
@@ -96,7 +98,8 @@ PyObject* host_bind(PyObject*, PyObject* args) {
         !take("chx_run_vjp_workspace_bytes", p_run_vjp_workspace_bytes) || !take("chx_apply_affine7_bwd", p_apply_bwd) ||
         !take("chx_apply_bwd_workspace_bytes", p_apply_bwd_workspace_bytes) || !take("chx_moments_entry", p_moments_entry) ||
         !take("chx_moments_workspace_bytes", p_moments_workspace_bytes) || !take("chx_moment_entry", p_moment_entry) ||
-        !take("chx_moment_entry_mapped_bwd", p_moment_entry_mapped_bwd))
+        !take("chx_moment_entry_mapped_bwd", p_moment_entry_mapped_bwd) || !take("chx_lattice_moment_blocks", p_moment_blocks) ||
+        !take("chx_lattice_screen_moments", p_screen_moments))
         return nullptr;
     Py_XDECREF(g_error);
     Py_INCREF(err);
@@ -365,6 +368,10 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
         scr.s = base + (2 * N + 1) * esize;
         scr.map = C.data_ptr();
         scr.element_maps = maps.data_ptr();
+        // the one-pass sums of the recorded beam's moments, a set per workgroup of the particle pass (chx_lattice_screen.mom_partials):
+        // a beam property of the screen's beam (MomentEntryMappedNode) is then one small launch instead of a pass over the rows
+        at::Tensor sums = at::empty({CHX_LATTICE_MOMENT_DOUBLES}, opts.dtype(at::kDouble));      // (zeroed by the preparation launch)
+        scr.mom_partials = sums.data_ptr();
         chx_check(p_track(p->table, p->n_items, p->n_elems, p->n_ptrs, energy.data_ptr(), mass, nq, p->code, p->state, p->state_bytes,
                           x.data_ptr(), out.data_ptr(), N, 1, 1, 1, 1, 0, e_out.data_ptr(), s_in.data_ptr(), s_out.data_ptr(),
                           survival.data_ptr(), nullptr, 0, nullptr, nullptr, 0, charges.data_ptr(), &scr, 1, stream_of(x)),
@@ -375,8 +382,8 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
         ctx->saved_data["meta"] = meta;
         ctx->saved_data["mass"] = mass;
         ctx->saved_data["nq"] = nq;
-        ctx->mark_non_differentiable({e_out, s_out, rest});
-        return {out, rows, C, e_out, s_out, rest};
+        ctx->mark_non_differentiable({e_out, s_out, rest, sums});
+        return {out, rows, C, e_out, s_out, rest, sums};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -453,7 +460,8 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
 
 struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappedNode> {
     static variable_list forward(AutogradContext* ctx, const at::Tensor& C, const at::Tensor& y, const std::optional<at::Tensor>& w,
-                                 const at::Tensor& mom_x, const std::optional<at::Tensor>& mom_y_in, int64_t index, bool take_sqrt) {
+                                 const at::Tensor& mom_x, const std::optional<at::Tensor>& mom_y_in, int64_t index, bool take_sqrt,
+                                 const std::optional<at::Tensor>& partials) {
         ctx->set_materialize_grads(false);
         const int64_t N = y.size(-2);
         const auto opts = y.options();
@@ -466,6 +474,13 @@ struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappe
             chx_check(p_moment_entry(static_cast<const double*>(mom_y.data_ptr()), 1, static_cast<int>(index), take_sqrt ? 1 : 0, code,
                                      picked.data_ptr(), stream),
                       "chx_moment_entry");
+        } else if (partials.has_value() && partials->defined()) {
+            // y's one-pass sums came out of the particle pass that wrote it (RunScreenTrack): re-centre, add, finalise, pick
+            mom_y = at::empty({1, 29}, opts.dtype(at::kDouble));
+            chx_check(p_screen_moments(static_cast<const double*>(partials->data_ptr()), p_moment_blocks(N, 1), code,
+                                       static_cast<double*>(mom_y.data_ptr()), static_cast<int>(index), take_sqrt ? 1 : 0, picked.data_ptr(),
+                                       stream),
+                      "chx_lattice_screen_moments");
         } else {
             mom_y = at::empty({1, 29}, opts.dtype(at::kDouble));
             const size_t ws_bytes = p_moments_workspace_bytes(1, N);
@@ -485,7 +500,7 @@ struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappe
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const variable_list saved = ctx->get_saved_variables();
         const at::Tensor &C = saved[0], &mom_y = saved[1], &mom_x = saved[2];
-        variable_list result(7);
+        variable_list result(8);
         if (!grads[0].defined()) return result;
         at::Tensor g = grads[0].to(C.scalar_type()).contiguous();
         at::Tensor dR = at::empty_like(C);
@@ -500,8 +515,8 @@ struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappe
 };
 
 // run_screen_track(plan, x, energy, s_in, charges, survival, settings tuple, meta (list of ints), mass_eV, n_charges)
-//   -> (out, rows at the screen, C (1, 7, 7), charges, survival, energy, s at the screen)   [the first three differentiable in the
-//      settings and the energy; the last four are views of one allocation]
+//   -> (out, rows at the screen, C (1, 7, 7), charges, survival, energy, s at the screen, moment sums of the rows)   [the first
+//      three differentiable in the settings and the energy; the next four are views of one allocation; the last: mom_partials]
 PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     if (nargs != 10) {
         PyErr_SetString(PyExc_TypeError, "run_screen_track takes 10 arguments");
@@ -522,9 +537,10 @@ PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nar
     try {
         variable_list r = RunScreenTrack::apply(unpack(args[1]), unpack(args[2]), unpack(args[3]), unpack(args[4]), unpack(args[5]),
                                                 at::TensorList(settings), static_cast<int64_t>(reinterpret_cast<uintptr_t>(p)), meta, mass, nq);
-        PyObject* res = PyTuple_New(7);
+        PyObject* res = PyTuple_New(8);
         if (!res) return nullptr;
         for (int i = 0; i < 3; ++i) PyTuple_SET_ITEM(res, i, THPVariable_Wrap(r[i]));
+        PyTuple_SET_ITEM(res, 7, THPVariable_Wrap(r[6]));
         // the constants of the record as the beam's tensors (views of one allocation, made here: ~0.5 us each against ~2 us from Python)
         const at::Tensor& rest = r[5];
         const int64_t N = r[1].size(0);
@@ -541,19 +557,20 @@ PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nar
 
 // moment_entry_mapped(C, y, w | None, mom_x, mom_y | None, index, take_sqrt) -> (entry, mom_y)
 PyObject* host_moment_entry_mapped(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
-    if (nargs != 7) {
-        PyErr_SetString(PyExc_TypeError, "moment_entry_mapped takes 7 arguments");
+    if (nargs != 8) {
+        PyErr_SetString(PyExc_TypeError, "moment_entry_mapped takes 8 arguments");
         return nullptr;
     }
     const long long index = PyLong_AsLongLong(args[5]);
     const int take_sqrt = PyObject_IsTrue(args[6]);
     if (PyErr_Occurred()) return nullptr;
     try {
-        std::optional<at::Tensor> w, mom_y;
+        std::optional<at::Tensor> w, mom_y, partials;
         if (args[2] != Py_None) w = unpack(args[2]);
         if (args[4] != Py_None) mom_y = unpack(args[4]);
+        if (args[7] != Py_None) partials = unpack(args[7]);
         variable_list r = MomentEntryMappedNode::apply(unpack(args[0]), unpack(args[1]), w, unpack(args[3]), mom_y, static_cast<int64_t>(index),
-                                                       take_sqrt != 0);
+                                                       take_sqrt != 0, partials);
         PyObject* res = PyTuple_New(2);
         if (!res) return nullptr;
         PyTuple_SET_ITEM(res, 0, THPVariable_Wrap(r[0]));
@@ -579,7 +596,7 @@ PyMethodDef methods[] = {
      "run_screen_track(plan, x, energy, s_in, charges, survival, settings, meta, mass_eV, n_charges) -> (out, rows, C, rest): the stretch "
      "[run | active Screen] as one differentiable node"},
     {"moment_entry_mapped", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_moment_entry_mapped)), METH_FASTCALL,
-     "moment_entry_mapped(C, y, w | None, mom_x, mom_y | None, index, take_sqrt) -> (entry, mom_y): one beam property of y = C x as a node on C"},
+     "moment_entry_mapped(C, y, w | None, mom_x, mom_y | None, index, take_sqrt, partial sums | None) -> (entry, mom_y): one beam property of y = C x as a node on C"},
     {nullptr, nullptr, 0, nullptr}};
 
 struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_chxtorch", "torch-side host step of cheetah_amd (see chx_torch_host.cpp)", -1, methods};

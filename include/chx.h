@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 7 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
+#define CHX_ABI_VERSION 8 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
                              4: s_in / s_out arguments of chx_run_map / chx_run_track;
                              5: s_in / s_out arguments of chx_cavity_prepare_scalars / chx_cavity_track_scalars;
                              6: chx_lattice_track_diag (items of type 2 / 3 in the table of a lattice stretch);
@@ -644,7 +644,22 @@ typedef struct chx_lattice_screen {
     const void* total_charge; /* the beam's total charge (one value of `dtype`) and where the record's copy of it goes */
     void* total_charge_out;
     int32_t width, height;
+    /* ParticleBeam variant, round 6 (ABI 8): the particle pass also adds the one-pass sums of the recorded beam's 29 moments
+     * (particle_beam.py:1699-1717; utils/statistics.py:4-62) — about the beam's first row as it stands at the screen — into
+     * mom_partials: CHX_LATTICE_MOMENT_DOUBLES doubles = n sets (n = chx_lattice_moment_blocks(N, B) <= 64) of {W, W2, s[6], m[21]} as
+     * [29][n], the centre[6] behind them; the preparation launch zeroes the buffer — or NULL. chx_lattice_screen_moments
+     * adds the sets and finalises: a beam property of the screen's beam costs one small launch, no pass over its rows.
+     * Not together with `image` in one call. */
+    void* mom_partials;
 } chx_lattice_screen;
+#define CHX_LATTICE_MOMENT_DOUBLES (29 * 64 + 6)
+/* the sets of partial sums the particle pass of chx_lattice_track_screens uses for N particles x B beams (at most 64 per beam) */
+int64_t chx_lattice_moment_blocks(int64_t N, int64_t B);
+/* mom_partials (n_blocks = chx_lattice_moment_blocks sets) -> out[29] = {W, W2, mu[6], cov[21]} (what chx_moments gives for the
+ * recorded rows, to the rounding of another summation order) and, index >= 0, entry_out[1] (`dtype`) = out[index] or its square
+ * root (chx_moments_entry). */
+int chx_lattice_screen_moments(const double* mom_partials, int64_t n_blocks, int dtype, double* out, int index, int take_sqrt,
+                               void* entry_out, void* stream);
 int chx_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                               double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                               void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,

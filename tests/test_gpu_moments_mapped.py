@@ -60,7 +60,10 @@ def test_algebraic_backward_equals_particle_backward(ca, dt, weights, vector):
     par, _ = _grads(ca, beam, dt, False, vector=vector)
     rtol = 1e-9 if dt == torch.float64 else 2e-4     # fp32: the particle path differentiates through rounded y = R x
     for name in alg:
-        assert torch.equal(alg[name][0], par[name][0]), name               # the forward reduction is the same kernel
+        # the same statistic forward: the algebraic route reads the one-pass sums the particle pass of the [run | Screen] stretch left
+        # (round 6, chx_lattice_screen.mom_partials), the particle route runs chx_moments over the rows — two summation orders
+        ftol = 1e-12 if dt == torch.float64 else 2e-7
+        assert torch.allclose(alg[name][0], par[name][0], rtol=ftol, atol=ftol * float(alg["sigma_x"][0].abs().max()) ** (2 if name.startswith("cov") else 1)), name
         # a setting the moment does not depend on has gradient 0 algebraically and rounding noise on the particle path:
         # errors are measured in units of the moment's largest sensitivity, every setting weighted with its own size
         sizes = [3.142, 0.2, 2e-4]

@@ -584,3 +584,53 @@ def test_screen_stretch_keeps_the_walks_errors_and_copies():
             assert torch.allclose(other.scr.reading, image, rtol=1e-4, atol=1e-6 * float(image.max()))
         moved = copy.deepcopy(seg).double()
         assert moved.scr.reading.dtype == torch.float64 and torch.allclose(moved.scr.reading.float(), image, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [700, 40_001, 1_000_003])
+def test_moment_sums_of_the_recorded_beam(dt, n):
+    """Round 6: the particle pass of the differentiable [run | Screen] stretch leaves the one-pass sums of the recorded beam's 29
+    moments about the beam's first row as it stands at the screen, added into at most 64 sets (chx_lattice_screen.mom_partials);
+    chx_lattice_screen_moments adds the sets and finalises. Against chx_moments of the recorded rows (pinned to the reference's weighted statistics,
+    utils/statistics.py:4-62, by tests/golden/moment_outliers.npz): beams off axis by many sigma, rows with zero weight, a far
+    outlier in a workgroup's first slot; one (n < 1e6) and two particles per lane; n not a multiple of the tile."""
+    import cheetah_amd as ca
+    from cheetah_amd import _lib, _ops
+
+    fk = {"dtype": dt, "device": "cuda"}
+    torch.manual_seed(n)
+    beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=torch.tensor(2e-4, **fk), sigma_y=torch.tensor(1.5e-4, **fk),
+                                           mu_x=torch.tensor(3e-2, **fk), mu_y=torch.tensor(-5e-3, **fk), energy=torch.tensor(9e7, **fk), **fk)
+    w = 0.25 + 0.75 * torch.rand(n, **fk)
+    w[::7] = 0.0
+    beam.survival_probabilities = w
+    if n > 600:
+        beam.particles[512, 2] -= 0.3                              # far outliers (not the first row: that one is the sums' centre)
+        beam.particles[256, 4] += 0.2
+    seg, params = _trainable_lattice(ca, fk, (4.0, -6.0, 8e-5))
+    seg.track(beam)
+    rb = seg.scr._incoming_beam()            # the screen's record (the read beam of this lattice is shifted by its misalignment)
+    rows, wr = rb.particles, rb.survival_probabilities
+    tag = getattr(rows, "_chx_partials", None)
+    assert tag is not None and tag[1] == rows._version and tag[2] is wr
+    nblk = _lib.lib().chx_lattice_moment_blocks(n, 1)
+    assert tag[0].numel() == 29 * 64 + 6 and nblk == min(64, -(-n // (512 if n >= 1_000_000 else 256)))
+    got = torch.empty(29, dtype=torch.float64, device="cuda")
+    picked = torch.empty((), **fk)
+    _ops.check(_lib.lib().chx_lattice_screen_moments(tag[0].data_ptr(), nblk, _ops.dtype_code(dt), got.data_ptr(), 8, 1, picked.data_ptr(),
+                                                     _ops.stream_ptr()), "chx_lattice_screen_moments")
+    want = _ops._moments_raw(rows.detach().reshape(1, n, 7).contiguous(), wr.reshape(1, n).contiguous(), 1, n).reshape(29)
+    sig = want[[8, 14, 19, 23, 26, 28]].sqrt()
+    assert torch.equal(got[:2], want[:2]) or torch.allclose(got[:2], want[:2], rtol=1e-14, atol=0)
+    assert ((got[2:8] - want[2:8]).abs() <= 1e-12 * (sig + want[2:8].abs())).all()
+    k = 8
+    for i in range(6):
+        for j in range(i, 6):
+            assert abs(float(got[k] - want[k])) <= 1e-11 * float(sig[i] * sig[j]), (i, j, float(got[k]), float(want[k]))
+            k += 1
+    assert float(picked) == pytest.approx(float(want[8].sqrt()), rel=2e-7 if dt == torch.float32 else 1e-12)
+    # and the property itself goes that way: same value as the sums', gradient as the general path's
+    sx = rb.sigma_x
+    assert float(sx) == float(picked)
+    sx.backward()
+    assert all(p.grad is not None for p in params)
