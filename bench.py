@@ -934,8 +934,10 @@ def main():
         modes["graph_replay"] = {"note": "torch.cuda.CUDAGraph (hipGraph) capture of the whole step, benchmarks/graph_modes.py: the "
                                          "README segment's track + screen reading, the control step with its five settings "
                                          "written in place (the replay follows them), a 16-cell linac with active cavities; "
-                                         "eager times of the same process beside"}
-        for which in ("c1", "control", "control_parameter_beam", "linac"):
+                                         "eager times of the same process beside. control_assigned*: the README's own style, the "
+                                         "five settings ASSIGNED as new tensors every step (eager only), beside the in-place step "
+                                         "of the same process"}
+        for which in ("c1", "control", "control_parameter_beam", "control_assigned", "control_assigned_parameter_beam", "linac"):
             try:
                 proc = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "graph_modes.py"), which], capture_output=True,
                                       text=True, timeout=300, cwd=ROOT)

@@ -3,6 +3,8 @@
   c1       README segment (13 elements, 1e4 particles, fp64): track + cloud-in-cell screen reading
   control  the control loop on that segment (fp32): five magnet settings written IN PLACE from an action tensor, track, screen reading
   control_parameter_beam  the same with a ParameterBeam (moments only: the reading is the bivariate normal image)
+  control_assigned / control_assigned_parameter_beam  the README's style (README.md:73-77 of the reference): the five settings ASSIGNED as
+           new tensors every step (`seg.AREAMQZM1.k1 = scaled[0]`) — eager only: a recording holds addresses, new tensors have new ones
   linac    16 cells [Drift, Quadrupole, active Cavity] (1e4 particles, fp32): every cavity is a map of the energy it receives
   c4       50-element linac with 10 space-charge kicks (128^3, 1e6 particles): the chain with its side stream as graph edges
 usage: python benchmarks/graph_modes.py c1|control|control_parameter_beam|linac|c4   -> one JSON line {"graph_mode": {...}}"""
@@ -30,6 +32,42 @@ def timed(fn, reps, warm):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e6
 
+
+if which in ("control_assigned", "control_assigned_parameter_beam"):
+    dt = torch.float32
+    seg = rc.ares_subcell(dt, rc.t(8.2, dt))
+    seg.AREABSCR1.is_active = True
+    if which.endswith("parameter_beam"):
+        beam = ca.ParameterBeam.from_twiss(beta_x=rc.t(3.14, dt), beta_y=rc.t(42.0, dt), dtype=dt, device="cuda")
+    else:
+        beam = ca.ParticleBeam.from_twiss(beta_x=rc.t(3.14, dt), beta_y=rc.t(42.0, dt), num_particles=10_000, dtype=dt, device="cuda")
+    action = torch.randn(5, device="cuda", dtype=dt)
+    scale = torch.tensor([10.0, 10.0, 1e-4, 10.0, 1e-4], device="cuda", dtype=dt)
+    settings = [seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle]
+
+    def assigned():
+        scaled = (action * scale).unbind(0)                   # the caller's ops: one multiply, five views
+        seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle = scaled
+        seg.track(beam)
+        return seg.AREABSCR1.reading
+
+    def in_place():
+        scaled = action * scale
+        for i, target in enumerate(settings):
+            target.copy_(scaled[i])
+        seg.track(beam)
+        return seg.AREABSCR1.reading
+
+    with torch.no_grad():
+        a_us = timed(assigned, 2000, 50)
+        img_a = assigned().clone()
+        seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle = [t.clone() for t in (action * scale).unbind(0)]
+        settings = [seg.AREAMQZM1.k1, seg.AREAMQZM2.k1, seg.AREAMCVM1.angle, seg.AREAMQZM3.k1, seg.AREAMCHM1.angle]
+        p_us = timed(in_place, 2000, 50)
+        img_p = in_place()
+        same = bool(torch.allclose(img_a, img_p, rtol=1e-5, atol=1e-6 * float(img_p.max())))
+    print(json.dumps({"graph_mode": {"workload": which, "eager_assigned_us": a_us, "eager_in_place_us": p_us, "readings_equal": same}}))
+    sys.exit(0)
 
 if which in ("c1", "control", "control_parameter_beam"):
     dt = torch.float64 if which == "c1" else torch.float32

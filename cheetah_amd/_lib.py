@@ -166,6 +166,8 @@ SIGNATURES = {
     "chx_lattice_track_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                           c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_i64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_i64, c_void_p]),
+    "chx_table_store_max_words": (c_i64, []),
+    "chx_table_store": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
     "chx_lattice_moment_blocks": (c_i64, [c_i64, c_i64]),
     "chx_lattice_screen_moments": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "chx_lattice_prepare_screens": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_double, c_double, c_int, c_void_p,
@@ -324,6 +326,7 @@ def host():
         fn = lib().chx_run_track
         _chxhost.bind(ctypes.cast(fn, ctypes.c_void_p).value, torch.empty_like, torch._C._cuda_getCurrentRawStream, ChxError)
         _chxhost.bind_lattice(ctypes.cast(lib().chx_lattice_track_diag, ctypes.c_void_p).value)
+        _chxhost.bind_table_store(ctypes.cast(lib().chx_table_store, ctypes.c_void_p).value, int(lib().chx_table_store_max_words()))
         _host = _chxhost
     return _host
 

@@ -87,6 +87,12 @@ class Element(nn.Module):
     _static_skippable = True
     #: process-wide count of attribute assignments on any element (see `_touch`)
     _epoch = 0
+    #: the epoch of the last assignment that may have changed more than an ADDRESS: anything but a plain tensor put in the place
+    #: of a registered buffer of the same dtype, device and shape, neither of them carrying a graph (`__setattr__`). What depends
+    #: on the lattice's structure only (which elements are skippable, `Segment._plan`) stands while this one stands still; plans
+    #: that hold addresses are patched on the spot where they registered for it (`_hooks`, segment._FastRun.absorb) — the control
+    #: loop that assigns its actions as new tensors every step (README.md:73-77 of the reference) re-derives nothing.
+    _hard_epoch = 0
 
     def __init__(self, name=None, sanitize_name=None, metadata=None, device=None, dtype=None) -> None:
         super().__init__()
@@ -394,22 +400,50 @@ class Element(nn.Module):
     def __setattr__(self, name: str, value: Any) -> None:
         d = self.__dict__
         if "_revision" in d and name[0] != "_":
-            self._touch()
             # a plain tensor assigned to a registered buffer (a control loop's `quad.k1 = new_value`): nn.Module.__setattr__
             # ends up doing exactly this after ~4 us of isinstance checks on Parameter / Module
             if type(value) is torch.Tensor:
                 buffers = d.get("_buffers")
                 if buffers is not None and name in buffers:
+                    old = buffers[name]
                     buffers[name] = value
+                    if type(old) is torch.Tensor and old.dtype == value.dtype and old.shape == value.shape and old.device == value.device \
+                            and not value.requires_grad and not old.requires_grad and self._static_skippable:
+                        # only an address changed: the lattice's structure stands (`_hard_epoch` stays), and the plans that
+                        # registered for this element take the new address now instead of re-reading the element at the next track
+                        before = Element._epoch
+                        self._touch(soft=True)
+                        hooks = d.get("_hooks")
+                        if hooks:
+                            self._absorb(hooks, value, before)
+                    else:
+                        self._touch()
                     return
+            self._touch()
         return super().__setattr__(name, value)
+
+    def _absorb(self, hooks: list, value: torch.Tensor, before: int) -> None:
+        """Hand the freshly assigned setting tensor to the plans that hold this element's addresses (`_hooks`: weak references
+        left by segment._FastRun.refresh). A plan that was valid at epoch `before` and takes the patch is valid at the new epoch."""
+        refs = self._builder_scalar_refs()
+        slots = [k for k, (t, index) in enumerate(refs) if t is value]
+        rev = self.__dict__["_revision"]
+        alive = False
+        for ref, i in hooks:
+            plan = ref()
+            if plan is None:
+                continue
+            alive = True
+            plan.absorb(self, i, refs, slots, rev, before)
+        if not alive:
+            self.__dict__["_hooks"] = None
 
     #: derived caches kept in `__dict__`: run plans with raw device addresses (ctypes arrays: not picklable, and a copy would
     #: address the ORIGINAL's tensors), memoised maps / geometry, scratch buffers. A copy or an unpickled element starts
     #: without them and rebuilds on first use.
     _DERIVED_STATE = ("_plan_cache", "_flat_elements", "_map_cache", "_tmap_cache", "_scalar_ws", "_ext_cache",
                       "_grid_tensor", "_geom_cache", "_limits_checked", "_chain_guard_state", "_dkd_cache", "_lattice_cache",
-                      "_so_run_cache", "_dkd_run_cache", "_zero_s", "_along_cache", "_plan_store", "_lattice_store")
+                      "_so_run_cache", "_dkd_run_cache", "_zero_s", "_along_cache", "_plan_store", "_lattice_store", "_hooks")
 
     def __getstate__(self):
         """State for `copy.deepcopy`, `pickle` and `torch.save`: everything but the derived caches."""
@@ -426,13 +460,16 @@ class Element(nn.Module):
             self._touch()
         return out
 
-    def _touch(self) -> None:
+    def _touch(self, soft: bool = False) -> None:
         """An attribute of this element was (re)assigned: drop its cached maps, move its revision and the process-wide
-        epoch (`Segment` re-validates a run's persistent device plan only when the epoch moved — an O(1) check per track)."""
+        epoch (`Segment` re-validates a run's persistent device plan only when the epoch moved — an O(1) check per track).
+        `soft`: nothing but the address of a setting changed (see `_hard_epoch`)."""
         self.__dict__["_revision"] += 1
         self.__dict__["_map_cache"] = None
         self.__dict__["_tmap_cache"] = None
         Element._epoch += 1
+        if not soft:
+            Element._hard_epoch = Element._epoch
 
     def register_buffer_or_parameter(self, name: str, value, persistent: bool = True) -> None:
         if isinstance(value, nn.Parameter):

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from copy import deepcopy
 
 import torch
@@ -69,6 +70,7 @@ class _ElementList(nn.ModuleList):
 
     def _moved(self):
         Element._epoch += 1
+        Element._hard_epoch = Element._epoch
 
     def __setitem__(self, idx, module):
         self._moved()
@@ -120,7 +122,7 @@ class _FastRun:
 
     __slots__ = ("epoch", "ok", "dtype", "device", "kinds", "ptrs", "E", "state", "state_bytes", "tensors", "code",
                  "elements", "revs", "rows", "per_tensors", "slots", "R_view", "allow_grad", "distinct", "grad_slots", "capsule", "grad_meta",
-                 "layout")
+                 "layout", "hooked", "__weakref__")
 
     def __init__(self, run, dtype, device, allow_grad=False):
         # allow_grad: the plan of the DIFFERENTIABLE run map (_ops.RunMapPlanned) — trainable parameters and settings that
@@ -130,6 +132,7 @@ class _FastRun:
         self.capsule = None
         self.grad_meta = None
         self.layout = 0           # moves whenever the packed arrays are rebuilt (other kinds / another number of elements)
+        self.hooked = False       # the elements know this plan (Element._hooks): re-assigned settings are patched in on the spot
         self.dtype, self.device = dtype, device
         self.elements = [e for e in run.elements]
         self.revs = [None] * len(self.elements)
@@ -262,7 +265,45 @@ class _FastRun:
                     meta += [e, k, -1 if index is None else index]
             self.grad_meta = meta
         self.ok = True
+        if not self.allow_grad and not self.hooked:
+            # the elements hand re-assigned setting tensors to this plan on the spot (Element._absorb -> absorb below)
+            me = weakref.ref(self)
+            for i, e in enumerate(self.elements):
+                if rows[i] != "identity":
+                    d = e.__dict__
+                    hooks = d.get("_hooks")
+                    if hooks is None:
+                        hooks = d["_hooks"] = []
+                    elif len(hooks) > 8:
+                        hooks[:] = [h for h in hooks if h[0]() is not None]     # (plans of lattices that are gone)
+                    hooks.append((me, i))
+            self.hooked = True
 
+    def absorb(self, e, i: int, refs, slots, rev: int, before: int) -> None:
+        """Element number `i` (`e`) had the setting tensor behind its parameter slots `slots` replaced by one of the same dtype,
+        device and shape (Element.__setattr__, a "soft" assignment at epoch `before` + 1): patch the addresses in place. A plan
+        that was valid before the assignment stays valid; any other one re-reads its elements at the next track as before."""
+        row = self.rows[i]
+        if not self.ok or self.elements[i] is not e or self.revs[i] != rev - 1 or row is None or row == "identity" \
+                or len(refs) != len(self.per_tensors[i]):
+            return          # (a plan that has not seen this element's previous revision re-reads it at its next refresh)
+        base = self.slots[i] * _ops.MAX_PARAMS
+        ptrs, addresses = self.ptrs, row[1]
+        tensors = list(self.per_tensors[i])
+        for k in slots:
+            t, index = refs[k]
+            a = t.data_ptr() if index is None else t.data_ptr() + index * t.element_size()
+            ptrs[base + k] = a
+            addresses[k] = a
+            tensors[k] = t
+        self.per_tensors[i] = tuple(tensors)
+        self.revs[i] = rev
+        if self.epoch == before:
+            self.epoch = before + 1      # valid before the assignment: valid after it
+        # (else: something else moved the epoch since this plan's last refresh — another lattice being built, say; the next
+        # refresh compares revisions, finds this element up to date and re-reads only what it has not seen)
+        # (users ask `_any_requires_grad(*plan.tensors)` per track: the list must name the tensors the plan addresses NOW)
+        self.tensors = tuple([t for ts in self.per_tensors for t in ts])
 
     def verify(self) -> None:
         """CHX_CHECK_PLANS=1: every stored address against the tensor it was read from."""
@@ -324,9 +365,12 @@ class _LatticePlan:
                 return False
             self.words_np[dst] = view[src]
             kept += fr.tensors
-        staging = torch.empty(self.words_np.shape[0], dtype=torch.int64, pin_memory=True)
-        staging.numpy()[:] = self.words_np
-        self.table.copy_(staging, non_blocking=True)
+        # (a table of up to 448 words rides in the arguments of a one-workgroup launch, chx_table_store: no page-locked staging
+        # tensor, no copy call — ~12 us of a control step's host time)
+        if not _HOST.table_store(self.words_np, self.table.data_ptr(), self.device.index or 0):
+            staging = torch.empty(self.words_np.shape[0], dtype=torch.int64, pin_memory=True)
+            staging.numpy()[:] = self.words_np
+            self.table.copy_(staging, non_blocking=True)
         self.tensors = tuple(kept) + self.other_tensors
         self.words = None                          # (verify() compares against a fresh derivation: the list form is rebuilt there)
         self.epoch = Element._epoch
@@ -753,8 +797,10 @@ class Segment(Element):
         """[(kind, payload)] with kind 'run' (payload _Run) or 'element' (payload Element). Depends on the element list
         and on which elements are skippable — not on their settings."""
         cached = self.__dict__["_plan_cache"]
-        if cached is not None and cached[2] == Element._epoch and cached[3] is None:
-            return cached[1]     # nothing was assigned anywhere since, and no element's skippability depends on tensor values
+        if cached is not None and cached[2] >= Element._hard_epoch and cached[3] is None:
+            # nothing but addresses of settings was assigned anywhere since (Element._hard_epoch), and no element's skippability
+            # depends on tensor values
+            return cached[1]
         # plain nested Segments are planned THROUGH: their elements join the parent's runs, stretches and chains (the reference
         # tracks a nested segment as one element, merged or walked by its own `track` — the same maps in another association).
         # A lattice file's cells-of-cells would otherwise be 25 non-static "elements" walked one by one: 625 us instead of 28

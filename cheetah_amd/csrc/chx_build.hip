@@ -2119,6 +2119,30 @@ extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, i
                                        state_bytes, energy_out, s_in, s_out, nullptr, 0, stream);
 }
 
+// ---- a stretch's table from HOST memory to the device without a staging buffer: the words ride in the kernel arguments ------------
+// A control loop that ASSIGNS new tensors to a few settings per step (`quad.k1 = action[0]`, README.md:73-77 of the reference) leaves
+// the lattice's layout alone and changes a handful of addresses in the table; re-uploading it through a page-locked staging tensor and
+// an asynchronous copy cost ~12 us of host time per step (allocation, two torch calls). Kernel arguments are copied at launch: no
+// staging buffer to keep alive, no race with a launch still in flight, stream-ordered in front of the preparation launch.
+namespace {
+constexpr int kTableStoreWords = 448;            // 3.5 KB of the kernel-argument segment
+struct TableWords { int64_t w[kTableStoreWords]; };
+__global__ __launch_bounds__(CHX_BLOCK) void table_store_kernel(TableWords t, int n, int64_t* __restrict__ dst) {
+    for (int i = threadIdx.x; i < n; i += CHX_BLOCK) dst[i] = t.w[i];
+}
+}  // namespace
+
+extern "C" int64_t chx_table_store_max_words(void) { return kTableStoreWords; }
+
+extern "C" int chx_table_store(const int64_t* host_words, int64_t n, void* table, void* stream) {
+    if (!host_words || !table || n < 1 || n > kTableStoreWords) return CHX_ERR_INVALID_ARG;
+    TableWords t;
+    for (int64_t i = 0; i < n; ++i) t.w[i] = host_words[i];
+    hipLaunchKernelGGL(table_store_kernel, dim3(1), dim3(CHX_BLOCK), 0, (hipStream_t)stream, t, (int)n, (int64_t*)table);
+    CHX_CHECK_LAUNCH();
+    return CHX_OK;
+}
+
 extern "C" int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                                            const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
                                            void* energy_out, const void* s_in, void* s_out, const chx_lattice_screen* screens,

@@ -225,7 +225,49 @@ static PyObject* host_lattice_track(PyObject* self, PyObject* const* args, Py_ss
     return res;
 }
 
+/* ---- a stretch's table from a host buffer to the device: chx_table_store (the words ride in a launch's arguments) ---------------- */
+typedef int (*table_store_fn)(const int64_t* host_words, int64_t n, void* table, void* stream);
+static table_store_fn p_table_store = NULL;
+static long long g_table_store_max = 0;
+
+static PyObject* host_bind_table_store(PyObject* self, PyObject* args) {
+    unsigned long long addr;
+    long long max_words;
+    if (!PyArg_ParseTuple(args, "KL", &addr, &max_words)) return NULL;
+    p_table_store = (table_store_fn)(uintptr_t)addr;
+    g_table_store_max = max_words;
+    Py_RETURN_NONE;
+}
+
+/* table_store(words (a contiguous buffer of int64: a numpy array), table address (device), device index) -> True, or False when the
+ * table has more words than one launch carries (the caller then uploads it through a staging tensor as before) */
+static PyObject* host_table_store(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+    if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "table_store takes 3 arguments"); return NULL; }
+    if (!p_table_store) { PyErr_SetString(PyExc_RuntimeError, "cheetah_amd._chxhost is not bound to chx_table_store"); return NULL; }
+    Py_buffer view;
+    if (PyObject_GetBuffer(args[0], &view, PyBUF_C_CONTIGUOUS) != 0) return NULL;
+    const long long n = (long long)(view.len / 8);
+    if (view.len % 8 != 0 || n < 1) { PyBuffer_Release(&view); PyErr_SetString(PyExc_ValueError, "table_store: a buffer of int64 words"); return NULL; }
+    if (n > g_table_store_max) { PyBuffer_Release(&view); Py_RETURN_FALSE; }
+    void* table = PyLong_AsVoidPtr(args[1]);
+    if (!table && PyErr_Occurred()) { PyBuffer_Release(&view); return NULL; }
+    PyObject* st = PyObject_CallOneArg(g_raw_stream, args[2]);
+    if (!st) { PyBuffer_Release(&view); return NULL; }
+    void* stream = PyLong_AsVoidPtr(st);
+    Py_DECREF(st);
+    const int rc = p_table_store((const int64_t*)view.buf, (int64_t)n, table, stream);
+    PyBuffer_Release(&view);
+    if (rc != 0) {
+        PyErr_Format(g_error ? g_error : PyExc_RuntimeError, "chx_table_store failed with status %d", rc);
+        return NULL;
+    }
+    Py_RETURN_TRUE;
+}
+
 static PyMethodDef methods[] = {
+    {"bind_table_store", host_bind_table_store, METH_VARARGS, "bind_table_store(chx_table_store address, words per launch)"},
+    {"table_store", (PyCFunction)(void (*)(void))host_table_store, METH_FASTCALL,
+     "table_store(int64 words buffer, device table address, device index) -> bool (False: too many words for one launch)"},
     {"bind_lattice", host_bind_lattice, METH_VARARGS, "bind_lattice(chx_lattice_track_diag address)"},
     {"lattice_plan", host_lattice_plan, METH_VARARGS, "lattice_plan(table addr, n_items, n_elems, n_ptrs, state addr, state bytes, dtype code) -> capsule"},
     {"lattice_track", (PyCFunction)(void (*)(void))host_lattice_track, METH_FASTCALL,

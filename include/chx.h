@@ -666,6 +666,12 @@ int chx_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_e
                               void* energy_out, const void* s_in, void* s_out, const void* survival, void* survival_out,
                               int64_t n_bpm, void* readings, void* workspace, size_t workspace_bytes, const void* charge,
                               const chx_lattice_screen* screens, int64_t n_screens, void* stream);
+/* A stretch's table (the `table` argument of the chx_lattice_* calls: device memory) written from HOST words without a staging
+ * buffer — the words travel in the arguments of a one-workgroup launch on `stream`, in front of the preparation launch that reads
+ * them: n <= chx_table_store_max_words(). For a host whose control loop assigns new setting tensors every step (README.md:73-77):
+ * the table's layout stands, a few addresses change. */
+int64_t chx_table_store_max_words(void);
+int chx_table_store(const int64_t* host_words, int64_t n, void* table, void* stream);
 /* chx_lattice_prepare_rows that also writes screens[slot].energy / .s and zeroes screens[slot].image (rows = 1 when n_screens > 0) */
 int chx_lattice_prepare_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                                 const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
