@@ -694,8 +694,76 @@ def other_configs(ca, torch, device, only=None) -> dict:
         res["checked_against_reference"] = checks
         return res
 
+    def ares_speed_guard():
+        # The reference's own speed guard (tests/test_speed.py:21-35): the ARES experimental-area section AREASOLA1 -> AREABSCR1 of the
+        # lattice file with its screen switched on (method 'histogram', the file's default), 1e5 particles, `segment.track` +
+        # `AREABSCR1.reading` — the reference asserts < 0.1 s. Checked against the reference's float64 run of the same beam
+        # (tests/golden/ares_speed.json, generate_golden_ares_speed.py) before it is timed; no plan item may take the per-element
+        # fallback, and the step's launches are counted with the profiler.
+        import time as _t
+
+        from benchmarks import diagnostics_inputs as di
+        from cheetah_amd.accelerator import _planner
+
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", "ares_speed.json")))
+        dt = torch.float32
+        kw = {"dtype": dt, "device": device}
+        full = ca.Segment.from_lattice_json(os.path.join(ROOT, "tests", "golden", "ares_lattice.json"), **kw)
+        seg = full.subcell("AREASOLA1", "AREABSCR1")
+        seg.AREABSCR1.is_active = True
+        assert [type(e).__name__ for e in seg.elements] == want["elements"] and seg.AREABSCR1.method == want["method"]
+        beam = ca.ParticleBeam(di.particles().to(device), torch.tensor(1e8, **kw), **kw)
+
+        def step():
+            out = seg.track(beam)
+            return out, seg.AREABSCR1.reading
+
+        with torch.no_grad():
+            out, img = step()
+            taken0 = dict(_planner.TAKEN)
+            out, img = step()
+            taken = {k: v - taken0[k] for k, v in _planner.TAKEN.items() if v != taken0[k]}
+            h, w = img.shape
+            got = {"sigma_x": float(out.sigma_x), "sigma_y": float(out.sigma_y), "image_sum": float(img.double().sum()),
+                   "image_centre_x": float((img.double().sum(0) * torch.arange(w, dtype=torch.float64, device=device)).sum() / img.double().sum()),
+                   "image_centre_y": float((img.double().sum(1) * torch.arange(h, dtype=torch.float64, device=device)).sum() / img.double().sum()),
+                   "lit_pixels": int((img != 0).sum())}
+            # float32 tracking against float64: 2e-4 of a beam size; a particle on a pixel's edge may fall to either side: the image's
+            # sum exactly (the same particles inside the screen), its centre to a hundredth of a pixel, the lit pixels to 1 %
+            assert [h, w] == want["image_shape"]
+            for key, tol in (("sigma_x", 2e-4), ("sigma_y", 2e-4), ("image_sum", 1e-6), ("lit_pixels", 1e-2)):
+                if not abs(got[key] / want[key] - 1.0) < tol:
+                    raise AssertionError(f"ARES_EA_SPEED_GUARD: {key} = {got[key]!r}, the reference has {want[key]!r}")
+            for key in ("image_centre_x", "image_centre_y"):
+                if not abs(got[key] - want[key]) < 1e-2:
+                    raise AssertionError(f"ARES_EA_SPEED_GUARD: {key} = {got[key]!r}, the reference has {want[key]!r}")
+            if taken.get("element", 0) != 0:
+                raise AssertionError(f"ARES_EA_SPEED_GUARD: {taken} — a plan item took the per-element fallback")
+            launches = None
+            try:
+                from torch.profiler import ProfilerActivity, profile
+
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    step()
+                    torch.cuda.synchronize()
+                launches = sum(1 for ev in prof.events() if ev.device_type is not None and "cuda" in str(ev.device_type).lower())
+            except Exception:   # noqa: BLE001  (the count is a diagnostic; the timing below stands without it)
+                launches = None
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(200):
+                step()
+            torch.cuda.synchronize()
+            ms = (_t.perf_counter() - t0) / 200 * 1e3
+        return {"workload": "ARES experimental area AREASOLA1 -> AREABSCR1 from tests/golden/ares_lattice.json, screen active (histogram), "
+                            "1e5 particles, fp32: segment.track + AREABSCR1.reading (the reference's tests/test_speed.py:21-35, bound 100 ms)",
+                "ms_per_step": ms, "reference_bound_ms": 100.0, "paths_taken": taken, "device_launches_per_step": launches,
+                "checked_against_reference": {k: got[k] for k in got}, "particle_element_steps_per_s": 1e5 * len(seg.elements) / (ms * 1e-3)}
+
     for name, fn in (("C1", c1), ("C3", c3), ("C4", c4), ("C5", c5), ("DKD_FODO100", dkd), ("SECOND_ORDER_FODO100", second_order),
-                     ("DIAGNOSTICS_LATTICES", diagnostics)):
+                     ("DIAGNOSTICS_LATTICES", diagnostics), ("ARES_EA_SPEED_GUARD", ares_speed_guard)):
         if only is None or name in only:
             guarded(name, fn)
     return out

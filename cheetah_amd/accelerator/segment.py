@@ -328,13 +328,14 @@ class _LatticePlan:
     ADDRESSES of the settings (read by the device on every track: in-place edits are followed); like `_FastRun` it is valid while
     `Element._epoch` stands still and is re-derived after any attribute assignment."""
 
-    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc", "screens", "allow_screens", "capsule_s", "words", "patch", "others", "other_tensors", "words_np")
+    __slots__ = ("items", "count", "dtype", "device", "epoch", "ok", "table", "state", "capsule", "tensors", "code", "bpms", "apertures", "shape", "vshape", "allow_vector", "small_runs", "bpm_vec", "ap_vec", "bpm_after", "ap_after", "e_out_rows", "expanded", "bpm_acc", "ap_acc", "e_acc", "screens", "allow_screens", "capsule_s", "words", "patch", "others", "other_tensors", "words_np", "edge_keys")
 
     def __init__(self, items, dtype, device, allow_vector=False, allow_screens=False):
         self.items, self.dtype, self.device = items, dtype, device
         self.allow_vector = allow_vector       # a ParameterBeam's stretch takes runs with vectorised settings; particles end there
         self.allow_screens = allow_screens     # ONE plain beam under scalar settings: active Screens are items of the stretch
         self.screens = ()                      # the active screens of the stretch, in record-slot order
+        self.edge_keys = ()                    # histogram screens: (screen, pixel-size tensor, its version) the edge arrays were formed from
         self.capsule_s = None
         self.code = _ops.dtype_code(dtype)
         self.table = self.state = self.capsule = None
@@ -388,7 +389,7 @@ class _LatticePlan:
         dtype, device = self.dtype, self.device
         patch, others, other_tensors, patchable = [], [], [], True
         rows, elem_kind, elem_poff, ptrs, tensors, bpms, apertures = [], [], [], [], [], [], []
-        screens, screen_shapes = [], []
+        screens, screen_shapes, edge_keys = [], [], []
         count = cavities = longest_run = 0
         vshape, bpm_vec, ap_vec = None, [], []
         bpm_after, ap_after, maps_seen = [], [], False   # does a run / cavity (a map) sit in front of the monitor / aperture?
@@ -431,12 +432,23 @@ class _LatticePlan:
                         or any(t.shape != (2,) or t.dtype != dtype or t.device != device or not t.is_contiguous() for t in (mis, ps)):
                     break
                 res, bins = item.resolution, item.effective_resolution
-                deposit = 1 if item.method == "cloud-in-cell" else 0
+                # the particle pass deposits the image: 1 cloud-in-cell (the extent derived on the device from the pixel size), 2
+                # histogram (torch.histogramdd's bins on the edges torch.linspace gives: the edge arrays are formed here, on the
+                # host's side of the call, and their addresses ride behind the screen's other entries)
+                deposit = 1 if item.method == "cloud-in-cell" else 2 if item.method == "histogram" else 0
                 rows += [4, deposit, len(ptrs), len(screens)]
                 ptrs += [mis.data_ptr(), ps.data_ptr(), int(res[0]), int(res[1]), int(bins[0]), int(bins[1])]
                 tensors += [mis, ps]
                 others.append((item, item.__dict__["_revision"]))
                 other_tensors += [mis, ps]
+                if deposit == 2:
+                    ex, ey = item.pixel_bin_edges
+                    if ex.dtype != dtype or ey.dtype != dtype or not ex.is_contiguous() or not ey.is_contiguous():
+                        break
+                    ptrs += [ex.data_ptr(), ey.data_ptr()]
+                    tensors += [ex, ey]
+                    other_tensors += [ex, ey]
+                    edge_keys.append((item, ps, ps._version))          # (an in-place edit of the pixel size: other edges)
                 screens.append(item)
                 screen_shapes.append((deposit, int(bins[0]), int(bins[1])))
                 count += 1
@@ -576,6 +588,7 @@ class _LatticePlan:
         self.e_out_rows = e_out_rows
         self.expanded, self.bpm_acc, self.ap_acc, self.e_acc = tuple(expanded), tuple(bpm_acc), tuple(ap_acc), e_acc
         self.screens, self.capsule_s = tuple(screens), None
+        self.edge_keys = tuple(edge_keys)
         if count < 2 or (cavities == 0 and not bpms and not apertures and not screens) or not elem_kind:
             return
         n_items, n_elems, n_ptrs = len(rows) // 4, len(elem_kind), len(ptrs)      # (identity runs hold no row)
@@ -1378,6 +1391,16 @@ class Segment(Element):
                 lp = entry[1] = _LatticePlan(plan[i:entry[0]], p.dtype, p.device, allow_vector=True, allow_screens=with_screens)
             else:
                 lp.refresh()
+        if lp.edge_keys:
+            # a histogram screen's bin edges sit in the table as arrays formed from its pixel size: an in-place edit of that tensor
+            # moves no epoch — re-derive the stretch (the cloud-in-cell extent is derived on the device and follows by itself)
+            for screen, ps, version in lp.edge_keys:
+                if ps._version != version:
+                    if torch.cuda.is_current_stream_capturing():
+                        return None
+                    lp.patch = None
+                    lp.refresh()
+                    break
         if not lp.ok:
             return None
         if _CHECK_PLANS:

@@ -822,9 +822,9 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     }
                 }
                 if constexpr (SCREENS == 2) {
+                  __shared__ long long comb_keys[kCombSlots];        // (one table for either kind of image)
+                  __shared__ double comb_vals[kCombSlots];
                   if ((items[i * 4 + 1] & 1) && so.image) {
-                    __shared__ long long comb_keys[kCombSlots];
-                    __shared__ double comb_vals[kCombSlots];
                     const T* mis = (const T*)ptrs[q];
                     const T* ps = (const T*)ptrs[q + 1];
                     const int bins_x = (int)ptrs[q + 4], bins_y = (int)ptrs[q + 5];
@@ -863,6 +863,30 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     }
                     table.flush();
                     __syncthreads();                   // (the table is free for the next screen of the stretch)
+                  } else if ((items[i * 4 + 1] & 2) && so.image) {
+                    // the 'histogram' image (screen.py:292-311: torch.histogramdd on the edges torch.linspace gave, weight |q| w):
+                    // hist2d_kernel's arithmetic from registers — x - misalignment in T, ATen's bin search on the edge arrays the
+                    // host formed (their addresses behind the screen's other entries in ptrs) — through the same combining table
+                    const T* mis = (const T*)ptrs[q];
+                    const int bins_x = (int)ptrs[q + 4], bins_y = (int)ptrs[q + 5];
+                    const T* __restrict__ ex = (const T*)ptrs[q + 6];
+                    const T* __restrict__ ey = (const T*)ptrs[q + 7];
+                    const T mx = mis[0], my = mis[1];
+                    CombTable<T> table;
+                    table.init(comb_keys, comb_vals, (T*)so.image);
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int p = threadIdx.x + k * CHX_BLOCK;
+                        if (p >= np) continue;
+                        const T vx = x.get(k, 0) - mx, vy = x.get(k, 2) - my;
+                        const int jx = hist_bin<T>(ex, bins_x, vx), jy = hist_bin<T>(ey, bins_y, vy);
+                        if (jx < 0 || jy < 0) continue;
+                        T c = charge ? fabs(charge[t0 + p]) : (T)1;
+                        c = c * sv[k];
+                        table.add((int64_t)jy * bins_x + jx, c);
+                    }
+                    table.flush();
+                    __syncthreads();
                   }
                 }
                 continue;

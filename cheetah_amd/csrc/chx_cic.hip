@@ -152,22 +152,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void cic_bwd_kernel(CicDev a, const T* _
     }
 }
 
-// ---- Screen histogram (screen.py:305-311; ATen histogramdd with explicit edges:
-// skip if v < e_0 or e_last < v; pos = upper_bound(edges, v) - 1; pos == nbins -> nbins - 1) ----
-template <typename T>
-__device__ __forceinline__ int hist_bin(const T* __restrict__ edges, int nbins, T v) {
-    if (!(v >= edges[0]) || !(v <= edges[nbins])) return -1;
-    int lo = 0, hi = nbins + 1;  // first index with edges[idx] > v
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (edges[mid] > v) hi = mid;
-        else lo = mid + 1;
-    }
-    int pos = lo - 1;
-    if (pos == nbins) pos -= 1;
-    return pos;
-}
-
+// ---- Screen histogram (screen.py:305-311): hist_bin (chx_cic_dev.h) is ATen histogramdd's bin search on explicit edges ----
 struct HistDev {
     int64_t B, Bx, Bq, Bs, Bsh, N;
     int nx, ny;

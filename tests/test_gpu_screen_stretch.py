@@ -634,3 +634,45 @@ def test_moment_sums_of_the_recorded_beam(dt, n):
     assert float(sx) == float(picked)
     sx.backward()
     assert all(p.grad is not None for p in params)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_histogram_screen_rides_in_the_particle_pass(dt):
+    """Round 6: the 'histogram' image (the ARES lattice file's default method; screen.py:292-311) is deposited by the stretch's
+    particle pass like the cloud-in-cell one — torch.histogramdd's bin search on the edges torch.linspace gives (chx_hist2d's
+    arithmetic, bit-identical pixel indices) — instead of a memset and a deposit launch at the first reading. Equal to the reading
+    formed from the record (the walk's path); an in-place edit of the pixel size, which changes the edges, is followed."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    seg = ca.Segment([ca.Drift(t(0.3), **fk), ca.Quadrupole(t(0.15), k1=t(5.0), **fk), ca.Drift(t(0.4), **fk),
+                      ca.Screen(resolution=(96, 64), pixel_size=t([2.5e-5, 3.0e-5]), misalignment=t([4e-5, -2e-5]), binning=2,
+                                method="histogram", is_active=True, name="scr", **fk), ca.Drift(t(0.1), **fk)])
+    torch.manual_seed(5)
+    beam = ca.ParticleBeam.from_parameters(num_particles=40_000, sigma_x=t(2e-4), sigma_y=t(2.5e-4), **fk)
+    beam.survival_probabilities = torch.rand(40_000, **fk)
+    # particles exactly on bin edges and on the outer edges (right-inclusive last bin), just outside, far outside
+    ex, ey = seg.scr.pixel_bin_edges
+    with torch.no_grad():
+        seg.track(beam)
+        assert seg.scr.__dict__["_eager"] is not None            # deposited by the stretch call
+        img = seg.scr.reading.clone()
+        rb = seg.scr.get_read_beam()
+        want = _ops.hist2d(seg.scr._incoming_beam().particles, ex, ey, charge=beam.particle_charges, survival=beam.survival_probabilities,
+                           shift=seg.scr.misalignment)
+        assert img.shape == want.shape == (32, 48)
+        assert torch.allclose(img, want, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=0)
+        assert float(img.sum()) > 0 and int((img != 0).sum()) == int((want != 0).sum())      # the same pixels are lit
+        # pixel size edited in place: other edges on the next track
+        seg.scr.pixel_size.mul_(1.5)
+        seg.track(beam)
+        ex2, ey2 = seg.scr.pixel_bin_edges
+        assert not torch.equal(ex2, ex)
+        want2 = _ops.hist2d(seg.scr._incoming_beam().particles, ex2, ey2, charge=beam.particle_charges,
+                            survival=beam.survival_probabilities, shift=seg.scr.misalignment)
+        assert seg.scr.__dict__["_eager"] is not None
+        assert torch.allclose(seg.scr.reading, want2, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=0)
+        assert float((want2 - want).abs().max()) > 0.1 * float(want.max())      # (other edges: another image)
+    assert rb.particles.shape == (40_000, 7)
