@@ -52,7 +52,7 @@ N_PARTICLES = 1_000_000
 N_CELLS = 25
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 APPLY_KERNEL = "apply_tile_kernel<float, 2, 0>"
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r06_kernel_stats.csv")
 COPY_CEILING_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of the 8 TB/s spec)
 #: sigma_x behind the 100 elements of the beam of rank 0 (torch.manual_seed(1234), from_parameters defaults, 1e6 particles, fp32):
 #: the same digits in every driver run since round 1 (BENCH_r01..r03). bench.py refuses to print a line when its step no longer
@@ -360,7 +360,8 @@ def other_configs(ca, torch, device, only=None) -> dict:
         return {"bytes_per_particle": 84.0, "deposit_us_profile": dep, "gather_us_profile": gat, "achieved_GBs": rate,
                 "frac": rate / HBM_PEAK_GBS, "source": "profiles/r06_c4_kernel_stats.csv",
                 "launches_per_kick": 13, "note_launches": "deposit, five charge-FFT passes, gather on the main stream; corner table, far "
-                "field, three Green FFT passes and the next run's map on the side stream (profiles/r05_c4_timeline.txt)"}
+                "field, three Green FFT passes and the next run's map on the side stream (profiles/r05_c4_timeline.txt); round 6: the "
+                "gather pass evaluates a float32 beam's particle step in float32 (sc_tile_particle32_kernel, profiles/r06_c4_gather.md)"}
 
     def c4_fp32_kick_error():
         # the float32 kick of C4's first SpaceChargeKick against the reference's float64 run of the same particles (committed sample,
@@ -1061,7 +1062,7 @@ def main():
                        "copy_ceiling": COPY_CEILING_GBS, "particles": big_n, "algorithmic_bytes_per_launch": 56.0 * big_n,
                        "avg_launch_ms": ms_big, "traffic": traffic_big,
                        "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch at this size (separate rocprofv3 --pmc passes, "
-                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r05_pmc_apply.md): 1.0002 x the "
+                                       "gfx950 corrections of MI355X_MICROARCH.md; profiles/r06_pmc_apply.md): 1.0002 x the "
                                        "algorithmic bytes"})
         del big, seg10
         torch.cuda.empty_cache()
