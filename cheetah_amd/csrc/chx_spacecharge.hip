@@ -188,15 +188,14 @@ __device__ __forceinline__ ScKickCtx32 sc_kick_ctx32(const float* __restrict__ h
     return c;
 }
 
-// one row: v (Cheetah coordinates) -> out (kicked, Cheetah coordinates); phi points at the first element of the potential's
-// array (node (0, 0, 0) sits at [2][2][2] inside its halo of 2), py / pz are the array's x / y strides; the array has less than
-// 2^30 elements (32-bit element offsets from a wave-uniform base: scalar base + vector offset addressing)
-__device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float (&v)[7], const float* __restrict__ phi, int py,
-                                              int pz, float (&out)[7], int diag = 0) {
+// The row step in three pieces (locate, the three sums, the kick); phi points at the first element of the potential's array (node (0, 0, 0) at
+// [2][2][2] inside its halo of 2), py / pz are the array's x / y strides; the array has less than 2^30 elements (32-bit offsets from
+// a wave-uniform base: scalar base + vector offset addressing)
+// a row's cell: fraction f, floor i0 (clamped to +-2e9), node cn clamped into the halo array, `finite` false for a grid without extent
+__device__ __forceinline__ void sc_row32_locate(const ScKickCtx32& c, const float (&v)[7], float (&f)[3], int (&i0)[3], int (&cn)[3],
+                                                bool& finite) {
     const float pos[3] = {v[0], v[2], v[4] * c.nbeta};
-    float f[3];
-    int i0[3], cn[3];
-    bool finite = true;
+    finite = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         // cell coordinate u = (pos + half) / cell (space_charge_kick.py:405-411). A float32 u near the far end of a 128-node axis
@@ -212,6 +211,13 @@ __device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float 
         i0[d] = (int)fl;
         cn[d] = min(max(i0[d], -1), c.g[d] - 1);
     }
+}
+
+// sums over the cell's eight nodes of weight x central difference of the potential along x / y / z, the potential read from its
+// global array (phi: first element; node (0, 0, 0) at [2][2][2] inside its halo of 2; less than 2^30 elements)
+__device__ __forceinline__ void sc_row32_sums_global(const ScKickCtx32& c, const float (&f)[3], const int (&i0)[3], const int (&cn)[3],
+                                                     const float* __restrict__ phi, int py, int pz, float& sx, float& sy, float& sz,
+                                                     int diag) {
     // the 32 potential values around the cell (see phi_cell_forces): z runs of 4 on the four central rows, z pairs one step out
     unsigned o = 4u * (unsigned)((cn[0] + 2) * py + (cn[1] + 2) * pz + (cn[2] + 2));   // byte offset of the cell's first node
     if (diag & 1) o = 4u * (unsigned)(2 * py + 2 * pz + 2);   // (timing experiments only: every lane reads the same cell)
@@ -240,7 +246,7 @@ __device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float 
         }
     }
     const float wx[2] = {1.0f - f[0], f[0]}, wy[2] = {1.0f - f[1], f[1]}, wz[2] = {1.0f - f[2], f[2]};
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    sx = sy = sz = 0.0f;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -263,6 +269,11 @@ __device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float 
             }
         }
     }
+}
+
+// the kick from the three sums: see the header of this section
+__device__ __forceinline__ void sc_row32_finish(const ScKickCtx32& c, const float (&v)[7], float sx, float sy, float sz, bool finite,
+                                                float (&out)[7]) {
     float kx = sx * c.k[0], ky = sy * c.k[1], kz = sz * c.k[2];
     if (!finite) kx = ky = kz = __builtin_nanf("");
     const float g = fmaf(c.p0n, v[5], c.gamma0);
@@ -277,6 +288,17 @@ __device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float 
     out[4] = v[4];
     out[5] = fmaf(D, __builtin_amdgcn_rcpf((g1 + g) * c.p0n), v[5]);
     out[6] = v[6];
+}
+
+// one row: v (Cheetah coordinates) -> out (kicked, Cheetah coordinates), the potential from its global array
+__device__ __forceinline__ void sc_kick_row32(const ScKickCtx32& c, const float (&v)[7], const float* __restrict__ phi, int py,
+                                              int pz, float (&out)[7], int diag = 0) {
+    float f[3], sx, sy, sz;
+    int i0[3], cn[3];
+    bool finite;
+    sc_row32_locate(c, v, f, i0, cn, finite);
+    sc_row32_sums_global(c, f, i0, cn, phi, py, pz, sx, sy, sz, diag);
+    sc_row32_finish(c, v, sx, sy, sz, finite, out);
 }
 
 // the linear run behind a kick on the kicked row, the fma chain of chx_apply_affine7 (bit-identical to a second pass)
@@ -1182,6 +1204,10 @@ __global__ __launch_bounds__(CHX_BLOCK) void sc_tile_particle32_kernel(
     }
 }
 
+// (Round 6, measured and dropped — profiles/r06_c4_gather.md: one workgroup per (tile, share) with the central differences of the
+// potential at the tile's 10^3 nodes staged once in LDS, the rows of the share read from it with eight 16-byte reads each, bit-identical
+// results: 74.7 us for 1e6 rows on 128^3 against 27.4 for the pass above. A share is 3-4 dependent load -> table -> store rounds per
+// wave at 127 VGPRs; one wave per 64 rows at 70 VGPRs keeps seven such chains in flight per SIMD and lets the vector cache do the rest.)
 }  // namespace
 
 extern "C" int chx_sc_tile_gather_kick(const void* rows, const void* phi_halo, const void* half, const void* cell, const void* gamma,
