@@ -2110,8 +2110,9 @@ extern "C" int chx_lattice_prepare_batched(const int64_t* table, int64_t n_items
                                     energy_out, s_in, s_out, stream);
 }
 
-// small_runs != 0: the caller vouches that the stretch holds NO cavity and that every run has at most 64 elements — the
-// wave-per-(item, row) kernel prepares it (same results)
+// small_runs bit 0: the caller vouches that the stretch holds NO cavity and that every run has at most 64 elements; bit 3
+// (CHX_LATTICE_SHORT_RUNS): every run has at most 64 elements, cavities or not — either way the wave-per-(item, row) kernel prepares
+// it (same results; with cavities every wave walks the energy through the cavities in front of its item), for any number of rows
 extern "C" int chx_lattice_prepare_rows(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, int64_t rows, int small_runs,
                                         const void* energy, double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes,
                                         void* energy_out, const void* s_in, void* s_out, void* stream) {

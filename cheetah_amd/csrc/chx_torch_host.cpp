@@ -13,6 +13,7 @@
 #include <Python.h>
 
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/csrc/autograd/python_variable.h>
@@ -135,6 +136,33 @@ PyObject* host_plan(PyObject*, PyObject* args) {
 
 inline const at::Tensor& unpack(PyObject* o) { return THPVariable_Unpack(o); }
 
+// What the Python caller promises, checked where a mismatch would otherwise write out of bounds on the device: `t` is a tensor on a
+// ROCm device, contiguous, of the plan's dtype, with exactly `numel` elements (numel < 0: any). Sets a Python error and returns false.
+bool tensor_ok(PyObject* o, const char* what, int code, int64_t numel, const at::Tensor* same_device_as = nullptr) {
+    if (!THPVariable_Check(o)) {
+        PyErr_Format(PyExc_TypeError, "%s: a tensor is expected", what);
+        return false;
+    }
+    const at::Tensor& t = THPVariable_Unpack(o);
+    const bool dtype_ok = code == CHX_F64 ? t.scalar_type() == at::kDouble : t.scalar_type() == at::kFloat;
+    if (!t.is_cuda() || !t.is_contiguous() || !dtype_ok || (numel >= 0 && t.numel() != numel) ||
+        (same_device_as && t.device() != same_device_as->device())) {
+        PyErr_Format(PyExc_ValueError, "%s: a contiguous %s tensor of %lld elements on the beam's device is expected (got %lld elements, %s)", what,
+                     code == CHX_F64 ? "float64" : "float32", static_cast<long long>(numel), static_cast<long long>(t.numel()),
+                     t.is_cuda() ? (t.is_contiguous() ? "dtype or device differ" : "not contiguous") : "not on a ROCm device");
+        return false;
+    }
+    return true;
+}
+
+// a tuple slot from a tensor; a failed wrap (out of memory) leaves the Python error set and the slot NULL (the tuple's destructor copes)
+inline bool set_wrapped(PyObject* tuple, Py_ssize_t i, const at::Tensor& t) {
+    PyObject* w = THPVariable_Wrap(t);
+    if (!w) return false;
+    PyTuple_SET_ITEM(tuple, i, w);
+    return true;
+}
+
 PyObject* fail(int rc, const char* what) {
     PyErr_Format(g_error ? g_error : PyExc_RuntimeError, "%s failed with status %d", what, rc);
     return nullptr;
@@ -157,21 +185,41 @@ PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     }
     auto* p = static_cast<StretchPlan*>(PyCapsule_GetPointer(args[0], "chx.stretch_plan"));
     if (!p) return nullptr;
+    if (!tensor_ok(args[1], "x", p->code, -1)) return nullptr;
     const at::Tensor& x = unpack(args[1]);
+    if (x.dim() != 2 || x.size(1) != 7 || x.size(0) < 1) {
+        PyErr_SetString(PyExc_ValueError, "x: an (N, 7) tensor is expected");
+        return nullptr;
+    }
+    const int64_t N = x.size(0);
+    const long long n_bpm = PyLong_AsLongLong(args[11]);
+    if (PyErr_Occurred()) return nullptr;
+    if (!tensor_ok(args[2], "energy", p->code, 1, &x) || !tensor_ok(args[3], "s", p->code, 1, &x) ||
+        !tensor_ok(args[4], "particle_charges", p->code, N, &x) || (args[5] != Py_None && !tensor_ok(args[5], "survival_probabilities", p->code, N, &x)) ||
+        (args[10] != Py_None && !tensor_ok(args[10], "survival_out", p->code, N, &x)) ||
+        (args[12] != Py_None && !tensor_ok(args[12], "readings", p->code, 2 * n_bpm, &x)))
+        return nullptr;
+    if ((n_bpm > 0) != (args[12] != Py_None) || (args[13] != Py_None && (!THPVariable_Check(args[13]) || !unpack(args[13]).is_cuda()))) {
+        PyErr_SetString(PyExc_ValueError, "readings / workspace: device tensors for every active monitor of the plan (and only then)");
+        return nullptr;
+    }
     const at::Tensor& energy = unpack(args[2]);
     const at::Tensor& s_in = unpack(args[3]);
     const at::Tensor& charges = unpack(args[4]);
     const double mass = PyFloat_AsDouble(args[6]), nq = PyFloat_AsDouble(args[7]);
     const long long image_limit = PyLong_AsLongLong(args[9]);
-    const long long n_bpm = PyLong_AsLongLong(args[11]);
     const unsigned long long ws_bytes = PyLong_AsUnsignedLongLong(args[14]);
     if (PyErr_Occurred()) return nullptr;
+    if (args[13] != Py_None && static_cast<unsigned long long>(unpack(args[13]).nbytes()) < ws_bytes) {
+        PyErr_SetString(PyExc_ValueError, "workspace: smaller than the byte count handed over with it");
+        return nullptr;
+    }
+    const c10::hip::HIPGuard device_guard(x.device());      // (allocations and the stream below belong to the beam's device)
     const void* survival = args[5] == Py_None ? nullptr : unpack(args[5]).data_ptr();
     void* survival_out = args[10] == Py_None ? nullptr : unpack(args[10]).data_ptr();
     void* readings = args[12] == Py_None ? nullptr : unpack(args[12]).data_ptr();
     void* workspace = args[13] == Py_None ? nullptr : unpack(args[13]).data_ptr();
     void* stream = stream_of(x);
-    const int64_t N = x.size(0);
     const auto opts = x.options();
     at::Tensor out = at::empty_like(x);
     at::Tensor e_out = at::empty_like(energy);
@@ -206,26 +254,29 @@ PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
         Py_XDECREF(img_t);
         return nullptr;
     }
+    bool wrapped = true;
     for (size_t k = 0; k < n_screens; ++k) {
-        PyTuple_SET_ITEM(rec_t, k, THPVariable_Wrap(recs[k]));
+        wrapped = set_wrapped(rec_t, k, recs[k]) && wrapped;
         if (images[k].defined()) {
-            PyTuple_SET_ITEM(img_t, k, THPVariable_Wrap(images[k]));
+            wrapped = set_wrapped(img_t, k, images[k]) && wrapped;
         } else {
             Py_INCREF(Py_None);
             PyTuple_SET_ITEM(img_t, k, Py_None);
         }
     }
     PyObject* res = PyTuple_New(5);
-    if (!res) {
+    if (!res || !wrapped) {
+        Py_XDECREF(res);
         Py_DECREF(rec_t);
         Py_DECREF(img_t);
         return nullptr;
     }
-    PyTuple_SET_ITEM(res, 0, THPVariable_Wrap(out));
-    PyTuple_SET_ITEM(res, 1, THPVariable_Wrap(e_out));
-    PyTuple_SET_ITEM(res, 2, THPVariable_Wrap(s_out));
     PyTuple_SET_ITEM(res, 3, rec_t);
     PyTuple_SET_ITEM(res, 4, img_t);
+    if (!set_wrapped(res, 0, out) || !set_wrapped(res, 1, e_out) || !set_wrapped(res, 2, s_out)) {
+        Py_DECREF(res);
+        return nullptr;
+    }
     return res;
 }
 
@@ -245,14 +296,24 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     }
     auto* p = static_cast<StretchPlan*>(PyCapsule_GetPointer(args[0], "chx.stretch_plan"));
     if (!p) return nullptr;
+    const long long n_bpm = PyLong_AsLongLong(args[10]);
+    if (PyErr_Occurred()) return nullptr;
+    if (!tensor_ok(args[1], "mu", p->code, 7)) return nullptr;
     const at::Tensor& mu = unpack(args[1]);
+    if (!tensor_ok(args[2], "cov", p->code, 49, &mu) || !tensor_ok(args[3], "energy", p->code, 1, &mu) || !tensor_ok(args[4], "s", p->code, 1, &mu) ||
+        !tensor_ok(args[5], "total_charge", p->code, 1, &mu) || (args[11] != Py_None && !tensor_ok(args[11], "readings", p->code, 2 * n_bpm, &mu)))
+        return nullptr;
+    if ((n_bpm > 0) != (args[11] != Py_None)) {
+        PyErr_SetString(PyExc_ValueError, "readings: a device tensor for every active monitor of the plan (and only then)");
+        return nullptr;
+    }
     const at::Tensor& cov = unpack(args[2]);
     const at::Tensor& energy = unpack(args[3]);
     const at::Tensor& s_in = unpack(args[4]);
     const at::Tensor& q = unpack(args[5]);
     const double mass = PyFloat_AsDouble(args[6]), nq = PyFloat_AsDouble(args[7]);
-    const long long n_bpm = PyLong_AsLongLong(args[10]);
     if (PyErr_Occurred()) return nullptr;
+    const c10::hip::HIPGuard device_guard(mu.device());
     void* readings = args[11] == Py_None ? nullptr : unpack(args[11]).data_ptr();
     void* stream = stream_of(mu);
     PyObject* geoms = args[9];
@@ -280,6 +341,8 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
             PyObject *geom, *shift;
             int width, height;
             if (!PyArg_ParseTuple(g, "OOii", &geom, &shift, &width, &height)) return nullptr;
+            if (width < 1 || height < 1 || !tensor_ok(geom, "screen geometry", p->code, 4, &mu) || !tensor_ok(shift, "screen misalignment", p->code, 2, &mu))
+                return nullptr;
             images[k] = at::empty({height, width}, opts);
             scr[k].image = images[k].data_ptr();
             scr[k].geom = unpack(geom).data_ptr();
@@ -299,27 +362,29 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
         Py_XDECREF(img_t);
         return nullptr;
     }
+    bool wrapped = true;
     for (size_t k = 0; k < n_screens; ++k) {
-        PyTuple_SET_ITEM(rec_t, k, THPVariable_Wrap(recs[k]));
+        wrapped = set_wrapped(rec_t, k, recs[k]) && wrapped;
         if (images[k].defined()) {
-            PyTuple_SET_ITEM(img_t, k, THPVariable_Wrap(images[k]));
+            wrapped = set_wrapped(img_t, k, images[k]) && wrapped;
         } else {
             Py_INCREF(Py_None);
             PyTuple_SET_ITEM(img_t, k, Py_None);
         }
     }
     PyObject* res = PyTuple_New(6);
-    if (!res) {
+    if (!res || !wrapped) {
+        Py_XDECREF(res);
         Py_DECREF(rec_t);
         Py_DECREF(img_t);
         return nullptr;
     }
-    PyTuple_SET_ITEM(res, 0, THPVariable_Wrap(mu_out));
-    PyTuple_SET_ITEM(res, 1, THPVariable_Wrap(cov_out));
-    PyTuple_SET_ITEM(res, 2, THPVariable_Wrap(e_out));
-    PyTuple_SET_ITEM(res, 3, THPVariable_Wrap(s_out));
     PyTuple_SET_ITEM(res, 4, rec_t);
     PyTuple_SET_ITEM(res, 5, img_t);
+    if (!set_wrapped(res, 0, mu_out) || !set_wrapped(res, 1, cov_out) || !set_wrapped(res, 2, e_out) || !set_wrapped(res, 3, s_out)) {
+        Py_DECREF(res);
+        return nullptr;
+    }
     return res;
 }
 
@@ -349,6 +414,16 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
                                  std::vector<int64_t> meta, double mass, double nq) {
         auto* p = reinterpret_cast<StretchPlan*>(static_cast<uintptr_t>(plan_addr));
         TORCH_CHECK(p->screens.size() == 1, "RunScreenTrack: a stretch [run | one active Screen]");
+        const auto want = p->code == CHX_F64 ? at::kDouble : at::kFloat;
+        TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.size(1) == 7 && x.size(0) >= 1 && x.is_contiguous() && x.scalar_type() == want,
+                    "RunScreenTrack: x must be a contiguous (N, 7) device tensor of the plan's dtype");
+        for (const at::Tensor* t : {&energy, &s_in})
+            TORCH_CHECK(t->numel() == 1 && t->scalar_type() == want && t->device() == x.device(), "RunScreenTrack: energy / s: one value of x's dtype on its device");
+        for (const at::Tensor* t : {&charges, &survival})
+            TORCH_CHECK(t->numel() == x.size(0) && t->is_contiguous() && t->scalar_type() == want && t->device() == x.device(),
+                        "RunScreenTrack: charges / survival probabilities: contiguous (N,) tensors of x's dtype on its device");
+        TORCH_CHECK(meta.size() >= 3 && meta[0] >= 1 && static_cast<int64_t>(meta.size()) >= 3 + meta[0] * (1 + CHX_MAX_PARAMS), "RunScreenTrack: malformed plan description");
+        const c10::hip::HIPGuard device_guard(x.device());
         ctx->set_materialize_grads(false);       // (an output nobody differentiates arrives undefined, not as N x 7 zeros)
         const int64_t N = x.size(0);
         const auto opts = x.options();
@@ -539,15 +614,15 @@ PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nar
                                                 at::TensorList(settings), static_cast<int64_t>(reinterpret_cast<uintptr_t>(p)), meta, mass, nq);
         PyObject* res = PyTuple_New(8);
         if (!res) return nullptr;
-        for (int i = 0; i < 3; ++i) PyTuple_SET_ITEM(res, i, THPVariable_Wrap(r[i]));
-        PyTuple_SET_ITEM(res, 7, THPVariable_Wrap(r[6]));
         // the constants of the record as the beam's tensors (views of one allocation, made here: ~0.5 us each against ~2 us from Python)
         const at::Tensor& rest = r[5];
         const int64_t N = r[1].size(0);
-        PyTuple_SET_ITEM(res, 3, THPVariable_Wrap(rest.narrow(0, 0, N)));
-        PyTuple_SET_ITEM(res, 4, THPVariable_Wrap(rest.narrow(0, N, N)));
-        PyTuple_SET_ITEM(res, 5, THPVariable_Wrap(rest.select(0, 2 * N)));
-        PyTuple_SET_ITEM(res, 6, THPVariable_Wrap(rest.select(0, 2 * N + 1)));
+        if (!set_wrapped(res, 0, r[0]) || !set_wrapped(res, 1, r[1]) || !set_wrapped(res, 2, r[2]) || !set_wrapped(res, 7, r[6]) ||
+            !set_wrapped(res, 3, rest.narrow(0, 0, N)) || !set_wrapped(res, 4, rest.narrow(0, N, N)) || !set_wrapped(res, 5, rest.select(0, 2 * N)) ||
+            !set_wrapped(res, 6, rest.select(0, 2 * N + 1))) {
+            Py_DECREF(res);
+            return nullptr;
+        }
         return res;
     } catch (const std::exception& e) {
         PyErr_SetString(g_error ? g_error : PyExc_RuntimeError, e.what());
@@ -573,8 +648,10 @@ PyObject* host_moment_entry_mapped(PyObject*, PyObject* const* args, Py_ssize_t 
                                                        take_sqrt != 0, partials);
         PyObject* res = PyTuple_New(2);
         if (!res) return nullptr;
-        PyTuple_SET_ITEM(res, 0, THPVariable_Wrap(r[0]));
-        PyTuple_SET_ITEM(res, 1, THPVariable_Wrap(r[1]));
+        if (!set_wrapped(res, 0, r[0]) || !set_wrapped(res, 1, r[1])) {
+            Py_DECREF(res);
+            return nullptr;
+        }
         return res;
     } catch (const std::exception& e) {
         PyErr_SetString(g_error ? g_error : PyExc_RuntimeError, e.what());

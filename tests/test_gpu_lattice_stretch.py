@@ -981,3 +981,76 @@ def test_grid_scan_by_broadcasting_rides_in_the_stretch(dt, with_cavity):
     out2, _, pout2, _, ref2, _, pref2, _ = both()
     assert torch.equal(out2.particles, ref2.particles) and not torch.equal(out2.particles, out.particles)
     assert torch.equal(pout2.mu, pref2.mu) and not torch.equal(pout2.mu, pout.mu)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_cavity_stretch_with_thousands_of_rows(dt):
+    """`small_runs` bit 3 (CHX_LATTICE_SHORT_RUNS: a WAVE per (item, row) prepares a stretch WITH cavities when its runs hold
+    at most 64 elements) lifts the `_STRETCH_MAX_ROWS` cap — on purpose. 4096 beam energies through a 12-cavity linac with monitors
+    (a ParameterBeam: 4096 rows of moments), one stretch call, against the walk item by item: moments, (4096,) outgoing energies and
+    every reading bit for bit; and 1500 rows of a cavity phase for 500 shared particles."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+    from cheetah_amd.accelerator.segment import Segment
+
+    kw = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **kw)  # noqa: E731
+    B = 4096
+    assert B > Segment._STRETCH_MAX_ROWS
+    energy = torch.linspace(4e7, 9e7, B, **kw)
+
+    def lattice(phase_rows=None):
+        els, bpms = [], []
+        for i in range(12):
+            bpm = ca.BPM(is_active=True, misalignment=t([1e-5 * i, -1e-5]), **kw)
+            bpms.append(bpm)
+            phase = t(-10.0 + 3 * i) if (phase_rows is None or i != 5) else phase_rows
+            els += [ca.Drift(t(0.3), **kw), ca.Quadrupole(t(0.2), k1=t(3.0 if i % 2 else -3.0), **kw),
+                    ca.Cavity(t(1.0377), voltage=t(18e6), phase=phase, frequency=t(1.3e9),
+                              cavity_type="standing_wave" if i % 2 else "traveling_wave", **kw), bpm]
+        return ca.Segment(els), bpms
+
+    seg, bpms = lattice()
+    pbeam = ca.ParameterBeam.from_parameters(energy=energy, mu_x=t(1e-4), sigma_p=t(1e-3), **kw)
+    pcalls = []
+    orig_p = Segment._lattice_stretch_parameter
+    try:
+        Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: (lambda r: (pcalls.append(r is not None), r)[1])(orig_p(self, plan, i, incoming))
+        with torch.no_grad():
+            pout = seg.track(pbeam)
+            pgot = [b.reading.clone() for b in bpms]
+        assert pcalls == [True], pcalls                              # ONE stretch call took all 4096 rows
+        Segment._lattice_stretch_parameter = lambda self, plan, i, incoming: None
+        with torch.no_grad():
+            pref = seg.track(pbeam)
+            pwant = [b.reading.clone() for b in bpms]
+    finally:
+        Segment._lattice_stretch_parameter = orig_p
+    assert pout.mu.shape == pref.mu.shape == (B, 7) and torch.equal(pout.mu, pref.mu) and torch.equal(pout.cov, pref.cov)
+    assert pout.energy.shape == (B,) and torch.equal(pout.energy, pref.energy) and torch.equal(pout.s, pref.s)
+    assert float((pout.energy - energy).min()) > 1e8
+    for g, w in zip(pgot, pwant):
+        assert g.shape == w.shape == (B, 2) and torch.equal(g, w)
+    # particles: 1500 phases of one cavity over 500 shared particles
+    rows = torch.linspace(-40.0, 40.0, 1500, **kw)
+    seg2, bpms2 = lattice(rows)
+    beam = ca.ParticleBeam.from_parameters(num_particles=500, energy=t(6e7), mu_x=t(1e-4), sigma_p=t(1e-3), **kw)
+    calls, spy = _spy()
+    old = segment._HOST
+    segment._HOST = spy
+    try:
+        with torch.no_grad():
+            out = seg2.track(beam)
+            got = [b.reading.clone() for b in bpms2]
+        assert calls == [500], calls
+        with torch.no_grad():
+            ref = _walk(seg2, beam)
+            want = [b.reading.clone() for b in bpms2]
+    finally:
+        segment._HOST = old
+    assert out.particles.shape == ref.particles.shape == (1500, 500, 7) and torch.equal(out.particles, ref.particles)
+    assert torch.equal(out.energy, ref.energy) and out.energy.shape == (1500,)
+    eps = torch.finfo(dt).eps
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape
+        assert torch.all((g - w).abs() <= 2 * eps * (w + bpms2[k].misalignment).abs() + 1e-17), k

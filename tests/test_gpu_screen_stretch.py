@@ -676,3 +676,61 @@ def test_histogram_screen_rides_in_the_particle_pass(dt):
         assert torch.allclose(seg.scr.reading, want2, rtol=1e-5 if dt == torch.float32 else 1e-12, atol=0)
         assert float((want2 - want).abs().max()) > 0.1 * float(want.max())      # (other edges: another image)
     assert rb.particles.shape == (40_000, 7)
+
+
+def test_host_step_checks_what_python_hands_it():
+    """cheetah_amd._chxtorch trusts its caller for nothing that would write out of bounds on the device: shapes, lengths, dtypes,
+    contiguity and devices of the tensors of a stretch call are checked against the plan — a real call's arguments,
+    replayed with one of them spoiled, raise instead of launching."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import segment
+
+    fk = {"dtype": torch.float32, "device": "cuda"}
+    seg = _ares(ca, fk)
+    beam = ca.ParticleBeam.from_twiss(beta_x=torch.tensor(3.14, **fk), beta_y=torch.tensor(42.0, **fk), num_particles=2000, **fk)
+    pbeam = ca.ParameterBeam.from_twiss(beta_x=torch.tensor(3.14, **fk), beta_y=torch.tensor(42.0, **fk), **fk)
+    th = segment._lib.torch_host()
+    seen = {}
+
+    class Recorder:
+        def __getattr__(self, name):
+            fn = getattr(th, name)
+
+            def call(*a):
+                seen[name] = a
+                return fn(*a)
+            return call
+
+    old = segment._TORCH_HOST
+    segment._TORCH_HOST = Recorder()
+    try:
+        with torch.no_grad():
+            seg.track(beam)
+            seg.track(pbeam)
+    finally:
+        segment._TORCH_HOST = old
+    a = list(seen["lattice_track_screens"])
+    good = th.lattice_track_screens(*a)
+    assert good[0].shape == (2000, 7)
+    x, energy, charges = a[1], a[2], a[4]
+    spoiled = [
+        (1, x[:, :6].contiguous()), (1, x.double()), (1, x.t().contiguous().t()), (1, x.cpu()), (1, x.reshape(-1)),
+        (2, torch.stack([energy, energy])), (2, energy.double()), (4, charges[:-1]), (4, charges.double()), (4, charges[::2]),
+        (5, torch.ones(1999, **fk)),
+    ]
+    for index, bad in spoiled:
+        b = list(a)
+        b[index] = bad
+        with pytest.raises((ValueError, TypeError)):
+            th.lattice_track_screens(*b)
+    b = list(a)
+    b[1] = "not a tensor"
+    with pytest.raises(TypeError):
+        th.lattice_track_screens(*b)
+    pa = list(seen["parameter_lattice_track_screens"])
+    assert th.parameter_lattice_track_screens(*pa)[0].shape == (7,)
+    for index, bad in ((1, pa[1][:6]), (2, pa[2][:6]), (2, pa[2].double()), (3, pa[3].double()), (1, pa[1].cpu())):
+        b = list(pa)
+        b[index] = bad
+        with pytest.raises((ValueError, TypeError)):
+            th.parameter_lattice_track_screens(*b)
