@@ -13,7 +13,7 @@
 #include <Python.h>
 
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/csrc/autograd/python_variable.h>
@@ -174,7 +174,7 @@ PyObject* fail(int rc, const char* what) {
 // record of screen k: ONE tensor of 9 N + 2 values [rows N x 7 | charges N | survival N | energy | s] of the beam AT the screen;
 // image: (bins_y, bins_x), deposited by the particle pass when the screen allows it and N <= image_limit (else None: the caller
 // forms it from the record when it is asked for).
-PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+PyObject* host_track_impl(PyObject* const* args, Py_ssize_t nargs) {
     if (nargs != 15) {
         PyErr_SetString(PyExc_TypeError, "lattice_track_screens takes 15 arguments");
         return nullptr;
@@ -214,7 +214,8 @@ PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
         PyErr_SetString(PyExc_ValueError, "workspace: smaller than the byte count handed over with it");
         return nullptr;
     }
-    const c10::hip::HIPGuard device_guard(x.device());      // (allocations and the stream below belong to the beam's device)
+    const c10::DeviceGuard device_guard(x.device());      // (allocations and the stream below belong to the beam's device; PyTorch-ROCm
+    // tensors carry the CUDA device type: the generic guard dispatches to the registered implementation)
     const void* survival = args[5] == Py_None ? nullptr : unpack(args[5]).data_ptr();
     void* survival_out = args[10] == Py_None ? nullptr : unpack(args[10]).data_ptr();
     void* readings = args[12] == Py_None ? nullptr : unpack(args[12]).data_ptr();
@@ -285,7 +286,7 @@ PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
 //   -> (mu_out, cov_out, energy_out, s_out, (record, ...), (image | None, ...))
 // record of screen k: ONE tensor of 59 values [mu 7 | cov 49 | energy | s | total charge] of the beam AT the screen; image
 // (height, width): the bivariate normal density of the recorded moments (screen.py:255-291), when geometry is given.
-PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+PyObject* host_parameter_impl(PyObject* const* args, Py_ssize_t nargs) {
     if (nargs != 12) {
         PyErr_SetString(PyExc_TypeError, "parameter_lattice_track_screens takes 12 arguments");
         return nullptr;
@@ -313,7 +314,7 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     const at::Tensor& q = unpack(args[5]);
     const double mass = PyFloat_AsDouble(args[6]), nq = PyFloat_AsDouble(args[7]);
     if (PyErr_Occurred()) return nullptr;
-    const c10::hip::HIPGuard device_guard(mu.device());
+    const c10::DeviceGuard device_guard(mu.device());
     void* readings = args[11] == Py_None ? nullptr : unpack(args[11]).data_ptr();
     void* stream = stream_of(mu);
     PyObject* geoms = args[9];
@@ -388,6 +389,19 @@ PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     return res;
 }
 
+// (no C++ exception may cross into the interpreter: an allocation failure or a failed check inside ATen becomes a Python error)
+template <typename F>
+PyObject* guarded(F&& body) {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        PyErr_SetString(g_error ? g_error : PyExc_RuntimeError, e.what());
+        return nullptr;
+    }
+}
+PyObject* host_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) { return guarded([&] { return host_track_impl(args, nargs); }); }
+PyObject* host_parameter(PyObject*, PyObject* const* args, Py_ssize_t nargs) { return guarded([&] { return host_parameter_impl(args, nargs); }); }
+
 // ---- differentiable nodes in C++ -----------------------------------------------------------------------------------------------
 // d(screen sigma_x) / d(quadrupole strength) (tests/test_differentiable.py:10-32 of the reference; BASELINE config C5) is, per step,
 // eight launches of ~70 us — and was ~0.25 ms of Python around them: four `torch.autograd.Function.apply` calls forward, their
@@ -423,7 +437,7 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
             TORCH_CHECK(t->numel() == x.size(0) && t->is_contiguous() && t->scalar_type() == want && t->device() == x.device(),
                         "RunScreenTrack: charges / survival probabilities: contiguous (N,) tensors of x's dtype on its device");
         TORCH_CHECK(meta.size() >= 3 && meta[0] >= 1 && static_cast<int64_t>(meta.size()) >= 3 + meta[0] * (1 + CHX_MAX_PARAMS), "RunScreenTrack: malformed plan description");
-        const c10::hip::HIPGuard device_guard(x.device());
+        const c10::DeviceGuard device_guard(x.device());
         ctx->set_materialize_grads(false);       // (an output nobody differentiates arrives undefined, not as N x 7 zeros)
         const int64_t N = x.size(0);
         const auto opts = x.options();
