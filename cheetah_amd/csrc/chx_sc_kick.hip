@@ -177,6 +177,14 @@ bool sorted_kick_rides(int flags, int dtype, const int32_t* bins) {
     return enabled && !(flags & 1) && (flags >> 8) > 0 && dtype == CHX_F32 && chx_sc_convolve_carries_schedule(bins);
 }
 
+// The bookkeeping step behind the deposit alone (sc_tile_schedule_block as one extra workgroup of the convolution's first pass) does
+// not depend on how the kick's geometry was formed: a kick that is not the first of its chain rides it also when its geometry came
+// from exchanged moments (a particle-sharded beam) or from the partial sums — one launch less on the main stream.
+bool sorted_kick_rides_schedule(int flags, int dtype, const int32_t* bins) {
+    static const bool enabled = [] { const char* e = getenv("CHX_SC_RIDERS"); return !(e && e[0] == '0'); }();
+    return enabled && !(flags & 1) && dtype == CHX_F32 && chx_sc_convolve_carries_schedule(bins);
+}
+
 int sorted_kick_prepare(int64_t N, const int32_t* bins, int dtype, void* workspace, size_t workspace_bytes, void* state,
                         size_t state_bytes, SortedKick& k) {
     if (!workspace || !state) return CHX_ERR_INVALID_ARG;
@@ -289,7 +297,7 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
         acc = k.st + k.T.cross;
         // (riders on ONE stream: the corner table's rider has published copy 0 in front of the deposit; the deposit reads it in place)
         rc = chx_sc_tile_deposit_chain(rows, k.extent, k.scale, N, bins, dtype, state, state_bytes, last ? 0 : 1,
-                                       ride && forked ? &riders[0] : nullptr, !ride, main);
+                                       ride && forked ? &riders[0] : nullptr, !(ride || sorted_kick_rides_schedule(flags, dtype, bins)), main);
     }
     if (rc != CHX_OK && forked) {                           // an error path still rejoins the side stream
         hipEvent_t join = nullptr;
@@ -321,7 +329,7 @@ extern "C" int chx_sc_kick_sorted_finish(const void* x_in, const void* energy, d
     }
     // the charge sits in the chain's accumulation grid (state); the convolution's first pass leaves it zeroed for the next kick
     ScScheduleArgs sched;
-    const bool ride = sorted_kick_rides(flags, dtype, bins);
+    const bool ride = sorted_kick_rides(flags, dtype, bins) || sorted_kick_rides_schedule(flags, dtype, bins);
     if (ride) rc = chx_sc_schedule_args(N, bins, dtype, state, state_bytes, last ? 0 : 1, &sched);
     if (rc == CHX_OK)
         rc = chx_sc_convolve_halo_chain(k.st + k.T.cross, k.ghat, k.pot_scale, bins, dtype, k.phi, k.ws + k.L.conv_ws,
