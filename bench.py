@@ -864,9 +864,9 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
             with sharding.particle_sharded():
                 seg4.track(beam4)
 
-        d = timed(torch, dist, c4, 5, 2, world)
-        return {"scaling": "strong", "particles_total": N_PARTICLES, "particles_per_rank": hi - lo, "ms_per_track": d / 5 * 1e3,
-                "particle_element_steps_per_s": N_PARTICLES * 50 * 5 / d, "collectives": C4_COLLECTIVES}
+        d = timed(torch, dist, c4, 20, 4, world)
+        return {"scaling": "strong", "particles_total": N_PARTICLES, "particles_per_rank": hi - lo, "ms_per_track": d / 20 * 1e3,
+                "particle_element_steps_per_s": N_PARTICLES * 50 * 20 / d, "collectives": C4_COLLECTIVES}
 
     def leg_c4_weak():
         # C4 weak: 1e6 particles PER RANK (the particle half of a kick — deposit + gather, ~95 us — stays what it is on one GPU,
@@ -877,9 +877,9 @@ def scaling_legs(ca, torch, dist, sharding, device, rank, world, steps, warmup) 
             with sharding.particle_sharded():
                 seg4.track(beam4)
 
-        d = timed(torch, dist, c4, 5, 2, world)
+        d = timed(torch, dist, c4, 20, 4, world)     # (20 tracks: the 5 of earlier rounds scattered by +-0.1 ms from run to run)
         return {"scaling": "weak", "particles_per_rank": N_PARTICLES, "particles_total": N_PARTICLES * world,
-                "ms_per_track": d / 5 * 1e3, "particle_element_steps_per_s": world * N_PARTICLES * 50 * 5 / d,
+                "ms_per_track": d / 20 * 1e3, "particle_element_steps_per_s": world * N_PARTICLES * 50 * 20 / d,
                 "collectives": C4_COLLECTIVES}
 
     guarded("c4_particle_shard", leg_c4)
