@@ -288,6 +288,54 @@ def rocprof_average_ms() -> float | None:
     return None
 
 
+def live_pmc_traffic() -> dict | None:
+    """HBM bytes per launch of the apply kernel measured IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE: separate
+    `--pmc` passes with the kernel trace only, as MI355X_MICROARCH.md prescribes) over profiles/traffic_probe.py in subprocesses,
+    counters in KiB, FETCH_SIZE x 2 for wide coalesced reads on gfx950. None when rocprofv3 is missing, fails or is switched off
+    (CHX_BENCH_NO_PMC=1); the tracked figure of profiles/apply_traffic.json stands then."""
+    import shutil
+    import tempfile
+
+    if os.environ.get("CHX_BENCH_NO_PMC", "0") == "1" or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None     # (switched off, or this process itself runs under the profiler: no nested sessions)
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory(prefix="chx_pmc_", dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                proc = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "probe", "--",
+                                       sys.executable, os.path.join(ROOT, "profiles", "traffic_probe.py")], capture_output=True, text=True,
+                                      timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"})
+                if proc.returncode != 0:
+                    return None
+                found = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+                if not found:
+                    return None
+                per = {}
+                for row in csv.DictReader(open(found[0])):
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] != counter or not ("apply_tile_kernel" in name or "apply_wave_kernel" in name):
+                        continue
+                    ppt = int(name.split("<")[1].split(",")[1])
+                    grid = int(row["Grid_Size"])
+                    n_part = 1_000_000 if (grid, ppt) == (500224, 2) else grid * ppt
+                    per.setdefault(n_part, []).append(float(row["Counter_Value"]))
+                for n_part, vals in per.items():
+                    out.setdefault(n_part, {})[counter] = sum(vals) / len(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+    except Exception:   # noqa: BLE001  (a diagnostic: the timing stands without it)
+        return None
+    small, big = out.get(1_000_000, {}), out.get(16_000_000, {})
+    if "FETCH_SIZE" not in small or "WRITE_SIZE" not in small:
+        return None
+    res = {"hbm_bytes_per_launch": small["FETCH_SIZE"] + small["WRITE_SIZE"], "fetch_bytes": small["FETCH_SIZE"], "write_bytes": small["WRITE_SIZE"]}
+    if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
+        res["streaming_hbm_bytes_per_launch"] = big["FETCH_SIZE"] + big["WRITE_SIZE"]
+    return res
+
+
 def event_timed_elementwise(torch, seg, beam, steps, warmup):
     """Average milliseconds of one `chx_track_elementwise` run (E launches) from HIP events on the launch stream."""
     for _ in range(warmup):
@@ -1031,6 +1079,14 @@ def main():
             traffic_big = (tj.get("streaming") or {}).get("hbm_bytes_per_launch") or None
         except Exception:
             traffic = None
+    traffic_source = "profiles/apply_traffic.json (this round's rocprofv3 --pmc passes, builder session)"
+    if world == 1 and rank == 0:
+        live = live_pmc_traffic()
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            traffic_big = live.get("streaming_hbm_bytes_per_launch", traffic_big)
+            traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                              "profiles/traffic_probe.py in subprocesses; KiB units, FETCH x 2 (gfx950)")
     ms_rocprof = rocprof_average_ms()
     # The live number is the wall time of the 100 back-to-back launches / 100. rocprofv3's kernel trace brackets every
     # dispatch from its first wave to its last, and consecutive dispatches of one stream overlap by a few hundred ns, so its
@@ -1043,7 +1099,7 @@ def main():
     # same arithmetic streaming from HBM proper (1.6e7 particles, 448 MB in + 448 MB out per launch: apply_wave_kernel).
     roofline = {"bound": "infinity-cache", "kernel": APPLY_KERNEL, "particles": N_PARTICLES,
                 "achieved": algo_bytes / (ms_used * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algo_bytes / (ms_used * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": algo_bytes / (ms_used * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": ms_used, "launches_per_step": E,
                 "avg_launch_ms_events": ms_launch, "avg_launch_ms_rocprof": ms_rocprof,
                 "rocprof_summary": os.path.relpath(PROFILE_CSV, ROOT),

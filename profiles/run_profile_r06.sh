@@ -7,7 +7,7 @@ OUT=$REPO/gpurun_out/prof_r06
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python $REPO/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-scaling-legs > $OUT/bench_under_profiler.json 2> $OUT/trace.log
+    env CHX_BENCH_NO_PMC=1 python $REPO/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-scaling-legs > $OUT/bench_under_profiler.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o probe -- \
     python $REPO/profiles/traffic_probe.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o probe -- \
