@@ -14,21 +14,28 @@ package is optional here: `converters.elegant.convert_beam` uses it when it is i
           [column_major_order=1], [endian=little|big] &end
     <pages>
 
-ASCII page: one line per parameter that has no fixed value, then (if there are columns) the row count and the rows.
-Binary page: int32 row count, the parameters (strings as int32 length + bytes), then the table row by row, or column by
-column with `column_major_order=1`.
+    &array name=..., type=..., [dimensions=N] &end
 
-Supported: parameters and columns of every scalar type (short, ushort, long, ulong, long64, ulong64, float, double,
-character, string), ASCII and binary, both byte orders, any number of pages. Not supported (NotImplementedError): `&array`,
-`&include`, `longdouble`.
+ASCII page: one line per parameter that has no fixed value, then each array (a line with its `dimensions` sizes, then its
+elements over as many lines as they take), then (if there are columns) the row count and the rows.
+Binary page: int32 row count, the parameters (strings as int32 length + bytes), the arrays (int32 size per dimension, then
+the elements), then the table row by row, or column by column with `column_major_order=1`.
+
+Supported: parameters, arrays and columns of every type (short, ushort, long, ulong, long64, ulong64, float, double,
+longdouble, character, string), ASCII and binary, both byte orders, any number of pages. `longdouble` in binary data is read
+as the x86 80-bit extended format in 16 bytes (what SDDS writes on the machines Elegant runs on) and rounded to a Python
+float; in big-endian binary data its layout depends on the writing machine and it raises NotImplementedError, as does
+`&include`.
 
 `load(path)` returns an `SddsData` with the attributes the converter reads from the `sdds` package's object:
 `parameterName`, `columnName`, `columnData[column][page][row]`, `parameterData[parameter][page]`,
-`getParameterValueList(name)`, `getColumnValueLists(name)`.
+`getParameterValueList(name)`, `getColumnValueLists(name)`; arrays are `arrayName`, `arrayDimensions[array][page]` and
+`arrayData[array][page]` (the elements in file order, last dimension fastest).
 """
 
 from __future__ import annotations
 
+import math
 import re
 import struct
 from pathlib import Path
@@ -38,6 +45,23 @@ _NUMERIC = {  # SDDS type -> (struct code, size)
     "float": ("f", 4), "double": ("d", 8),
 }
 _INTEGER = {"short", "ushort", "long", "ulong", "long64", "ulong64"}
+_LONGDOUBLE_BYTES = 16
+
+
+def _extended_to_float(chunk: bytes) -> float:
+    """x86 extended precision, little endian: 64-bit significand with an explicit leading bit, then sign + 15-bit exponent."""
+    significand, = struct.unpack_from("<Q", chunk, 0)
+    tail, = struct.unpack_from("<H", chunk, 8)
+    sign = -1.0 if tail & 0x8000 else 1.0
+    exponent = tail & 0x7FFF
+    if exponent == 0x7FFF:
+        return sign * math.inf if significand << 1 & (2**64 - 1) == 0 else math.nan
+    if exponent == 0:
+        exponent = 1            # subnormals share the smallest exponent
+    try:
+        return sign * math.ldexp(float(significand), exponent - 16383 - 63)
+    except OverflowError:
+        return sign * math.inf
 
 
 class SddsData:
@@ -51,13 +75,19 @@ class SddsData:
         self.columnName: list[str] = []
         self.columnDefinition: list[dict[str, str]] = []
         self.columnData: list[list[list]] = []
+        self.arrayName: list[str] = []
+        self.arrayDefinition: list[dict[str, str]] = []
+        self.arrayDimensions: list[list[list[int]]] = []
+        self.arrayData: list[list[list]] = []
         self.mode = "ascii"
 
     @property
     def loaded_pages(self) -> int:
         if self.columnData:
             return len(self.columnData[0])
-        return len(self.parameterData[0]) if self.parameterData else 0
+        if self.parameterData:
+            return len(self.parameterData[0])
+        return len(self.arrayData[0]) if self.arrayData else 0
 
     def getParameterValueList(self, name: str) -> list:
         return self.parameterData[self.parameterName.index(name)]
@@ -148,7 +178,7 @@ def _read_header(raw: bytes):
 def _convert(token: str, sdds_type: str):
     if sdds_type in _INTEGER:
         return int(token)
-    if sdds_type in ("float", "double"):
+    if sdds_type in ("float", "double", "longdouble"):
         return float(token)
     if sdds_type == "character":
         return token[:1] if not token.startswith("\\") else chr(int(token[1:], 8))
@@ -185,7 +215,9 @@ def _read_ascii(data: SddsData, text: str, fixed: dict, opts: dict) -> None:
             pos += 1
         return pos >= len(lines)
 
-    if not data.parameterName and not ctypes:
+    atypes = [d["type"] for d in data.arrayDefinition]
+    adims = [int(d.get("dimensions", 1) or 1) for d in data.arrayDefinition]
+    if not data.parameterName and not ctypes and not atypes:
         return
     while not at_end():      # a page starts with its first non-blank line
         page_params = []
@@ -201,6 +233,21 @@ def _read_ascii(data: SddsData, text: str, fixed: dict, opts: dict) -> None:
                 page_params.append(tok[0] if len(tok) == 1 and ln.strip().startswith('"') else ln.strip())
             else:
                 page_params.append(_convert(_tokens(ln)[0], t))
+        page_arrays = []
+        for name, t, nd in zip(data.arrayName, atypes, adims):
+            ln = next_line(True)
+            if ln is None:
+                raise ValueError(f"SDDS ASCII data ends before the dimensions of array {name}")
+            sizes = [int(tok) for tok in _tokens(ln)[:nd]]
+            if len(sizes) != nd or min(sizes) < 0:
+                raise ValueError(f"SDDS ASCII array {name}: expected {nd} sizes, found {ln.strip()[:40]!r}")
+            total, values = math.prod(sizes), []
+            while len(values) < total:
+                ln = next_line(True)
+                if ln is None:
+                    raise ValueError(f"SDDS ASCII data ends after {len(values)} of {total} elements of array {name}")
+                values += [_convert(tok, t) for tok in _tokens(ln)]
+            page_arrays.append((sizes, values[:total]))
         rows_of = [[] for _ in ctypes]
         if ctypes:
             if no_row_counts:
@@ -231,6 +278,9 @@ def _read_ascii(data: SddsData, text: str, fixed: dict, opts: dict) -> None:
                 done += 1
         for i, v in enumerate(page_params):
             data.parameterData[i].append(v)
+        for i, (sizes, values) in enumerate(page_arrays):
+            data.arrayDimensions[i].append(sizes)
+            data.arrayData[i].append(values)
         for c, col in enumerate(rows_of):
             data.columnData[c].append(col)
 
@@ -258,8 +308,21 @@ class _Cursor:
             return s
         if sdds_type == "character":
             return self.take("c", 1)[0].decode("latin-1")
-        code, size = _NUMERIC[sdds_type]
-        return self.take(code, size)[0]
+        return self.values(sdds_type, 1)[0]
+
+    def values(self, sdds_type: str, count: int) -> list:
+        if sdds_type == "longdouble":
+            if self.endian != "<":
+                raise NotImplementedError("SDDS type longdouble in big-endian binary data is not supported")
+            end = self.pos + _LONGDOUBLE_BYTES * count
+            if end > len(self.raw):
+                raise ValueError("SDDS binary data ends inside a page")
+            out = [_extended_to_float(self.raw[at:at + 10]) for at in range(self.pos, end, _LONGDOUBLE_BYTES)]
+            self.pos = end
+            return out
+        if sdds_type in _NUMERIC:
+            return list(self.take(*_NUMERIC[sdds_type], count))
+        return [self.value(sdds_type) for _ in range(count)]
 
 
 def _read_binary(data: SddsData, raw: bytes, pos: int, endian: str, fixed: dict, opts: dict) -> None:
@@ -279,14 +342,17 @@ def _read_binary(data: SddsData, raw: bytes, pos: int, endian: str, fixed: dict,
                 data.parameterData[i].append(_convert(fixed[name], t) if t != "string" else fixed[name])
             else:
                 data.parameterData[i].append(cur.value(t))
+        for i, definition in enumerate(data.arrayDefinition):
+            sizes = list(cur.take("i", 4, int(definition.get("dimensions", 1) or 1)))
+            if min(sizes) < 0:
+                raise ValueError(f"SDDS binary data: array {definition['name']} has sizes {sizes}")
+            data.arrayDimensions[i].append(sizes)
+            data.arrayData[i].append(cur.values(definition["type"], math.prod(sizes)))
         cols = [[] for _ in ctypes]
         if ctypes and count:
             if column_major:
                 for c, t in enumerate(ctypes):
-                    if t in _NUMERIC:
-                        cols[c] = list(cur.take(*_NUMERIC[t], count))
-                    else:
-                        cols[c] = [cur.value(t) for _ in range(count)]
+                    cols[c] = cur.values(t, count)
             elif all_numeric:
                 fmt = endian + "".join(_NUMERIC[t][0] for t in ctypes)
                 size = struct.calcsize(fmt)
@@ -313,13 +379,11 @@ def load(path) -> SddsData:
     for name, fields in commands:
         if name == "description":
             data.description = fields
-        elif name in ("parameter", "column"):
+        elif name in ("parameter", "column", "array"):
             if "name" not in fields:
                 raise ValueError(f"SDDS header: &{name} without a name")
             t = fields.get("type", "").lower()
-            if t == "longdouble":
-                raise NotImplementedError("SDDS type longdouble is not supported")
-            if t not in _NUMERIC and t not in ("string", "character"):
+            if t not in _NUMERIC and t not in ("string", "character", "longdouble"):
                 raise ValueError(f"SDDS header: &{name} {fields['name']} has unknown type {t!r}")
             fields["type"] = t
             if name == "parameter":
@@ -328,12 +392,17 @@ def load(path) -> SddsData:
                 data.parameterData.append([])
                 if "fixed_value" in fields:
                     fixed[fields["name"]] = fields["fixed_value"]
-            else:
+            elif name == "column":
                 data.columnName.append(fields["name"])
                 data.columnDefinition.append(fields)
                 data.columnData.append([])
-        elif name in ("array", "include"):
-            raise NotImplementedError(f"SDDS &{name} commands are not supported")
+            else:
+                data.arrayName.append(fields["name"])
+                data.arrayDefinition.append(fields)
+                data.arrayDimensions.append([])
+                data.arrayData.append([])
+        elif name == "include":
+            raise NotImplementedError("SDDS &include commands are not supported")
         elif name == "data":
             opts = fields
         # &associate and unknown commands carry no data: ignored

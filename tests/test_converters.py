@@ -402,8 +402,10 @@ def test_sdds_header_quirks_and_errors(tmp_path):
         load_text("# something else\n")
     with pytest.raises(ValueError, match="without a &data"):
         load_text("SDDS1\n&column name=x, type=double &end\n")
-    with pytest.raises(NotImplementedError, match="array"):
-        load_text("SDDS1\n&array name=a, type=double &end\n&data mode=ascii &end\n")
+    with pytest.raises(NotImplementedError, match="include"):
+        load_text("SDDS1\n&include filename=other.sdds &end\n&data mode=ascii &end\n")
+    with pytest.raises(ValueError, match="2 of 3 elements of array a"):
+        load_text("SDDS1\n&array name=a, type=double &end\n&data mode=ascii &end\n3\n1.0 2.0\n")
     with pytest.raises(ValueError, match="unknown type"):
         load_text("SDDS1\n&column name=x, type=quad &end\n&data mode=ascii &end\n")
     with pytest.raises(ValueError, match="ends after 1 of 3 rows"):
@@ -412,6 +414,75 @@ def test_sdds_header_quirks_and_errors(tmp_path):
         f.write(b"SDDS1\n&column name=x, type=double &end\n&data mode=binary &end\n" + b"\x02\x00\x00\x00" + b"\x00" * 8)
     with pytest.raises(ValueError, match="ends inside a page"):
         sdds_file.load(file)
+
+
+def _extended(v: float) -> bytes:
+    """x86 80-bit extended precision in 16 bytes, as SDDS writes a longdouble."""
+    import math
+    import struct
+
+    if v == 0.0:
+        return bytes(16)
+    m, e = math.frexp(abs(v))
+    return struct.pack("<QH", int(m * 2.0**64), (e - 1 + 16383) | (0x8000 if v < 0 else 0)) + bytes(6)
+
+
+@pytest.mark.parametrize("mode", ["ascii", "binary"])
+def test_sdds_reader_arrays_and_longdouble(tmp_path, mode):
+    """`&array` blocks sit between the parameters and the table of every page; `longdouble` is the 16-byte x86 extended
+    format in binary data and a plain number in ASCII data."""
+    import struct
+
+    from cheetah_amd.converters import sdds_file
+
+    file = os.path.join(tmp_path, "arrays.sdds")
+    head = ("SDDS5\n!# little-endian\n&parameter name=Step, type=long &end\n&parameter name=Precise, type=longdouble &end\n"
+            "&array name=Grid, type=double, dimensions=2 &end\n&array name=Names, type=string &end\n"
+            "&array name=Wide, type=longdouble &end\n"
+            "&column name=x, type=double &end\n&column name=w, type=longdouble &end\n"
+            f"&data mode={mode} &end\n").encode("latin-1")
+    pages = [
+        (1, 0.1, [2, 3], [1.5, -2.5, 3.25, 4.0, 5.0, 6.0], ["first name", "b"], [1e300, -2.0 ** -1030, 0.0], [(0.25, 1.0 / 3.0), (-4.0, 2.5e-7)]),
+        (2, -7.75, [0, 3], [], [], [3.0], []),
+    ]
+    if mode == "ascii":
+        body = ""
+        for step, precise, dims, grid, names, wide, rows in pages:
+            body += f"{step}\n{precise!r}\n{dims[0]} {dims[1]}\n"
+            body += "".join(" ".join(repr(v) for v in grid[i:i + 4]) + "\n" for i in range(0, len(grid), 4))      # 4 per line
+            body += f"{len(names)}\n" + (" ".join(f'"{n}"' for n in names) + "\n" if names else "")
+            body += f"{len(wide)}\n" + " ".join(repr(v) for v in wide) + "\n"
+            body += f"{len(rows)}\n" + "".join(f"{x!r} {w!r}\n" for x, w in rows)
+        raw = head + body.encode("latin-1")
+    else:
+        raw = head
+        for step, precise, dims, grid, names, wide, rows in pages:
+            raw += struct.pack("<i", len(rows)) + struct.pack("<i", step) + _extended(precise)
+            raw += struct.pack("<2i", *dims) + struct.pack(f"<{len(grid)}d", *grid)
+            raw += struct.pack("<i", len(names)) + b"".join(struct.pack("<i", len(n)) + n.encode() for n in names)
+            raw += struct.pack("<i", len(wide)) + b"".join(_extended(v) for v in wide)
+            raw += b"".join(struct.pack("<d", x) + _extended(w) for x, w in rows)
+    with open(file, "wb") as f:
+        f.write(raw)
+    data = sdds_file.load(file)
+    assert data.loaded_pages == 2 and data.arrayName == ["Grid", "Names", "Wide"]
+    assert data.getParameterValueList("Step") == [1, 2]
+    assert data.getParameterValueList("Precise") == [0.1, -7.75]
+    assert data.arrayDimensions[0] == [[2, 3], [0, 3]] and data.arrayDimensions[1] == [[2], [0]]
+    assert data.arrayData[0] == [pages[0][3], []]
+    assert data.arrayData[1] == [["first name", "b"], []]
+    assert data.arrayData[2] == [pages[0][5], [3.0]]                 # subnormal-in-double and large values survive
+    assert data.getColumnValueLists("x") == [[0.25, -4.0], []]
+    assert data.getColumnValueLists("w") == [[1.0 / 3.0, 2.5e-7], []]
+
+    if mode == "binary":                                              # the layout of a big-endian longdouble is machine dependent
+        with open(file, "wb") as f:
+            f.write(raw.replace(b"little-endian", b"big-endian"))
+        with pytest.raises(NotImplementedError, match="longdouble"):
+            sdds_file.load(file)
+        inf = sdds_file._extended_to_float(struct.pack("<QH", 1 << 63, 0xFFFF))
+        assert inf == -float("inf") and np.isnan(sdds_file._extended_to_float(struct.pack("<QH", 3 << 62, 0x7FFF)))
+        assert sdds_file._extended_to_float(struct.pack("<QH", 1 << 63, 0x7FFE)) == float("inf")     # beyond double range
 
 
 @pytest.mark.parametrize("mode", ["ascii", "binary"])
