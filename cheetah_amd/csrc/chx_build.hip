@@ -220,12 +220,51 @@ __device__ void transpose7(const Mat7<S>& A, Mat7<S>& At) {
         for (int j = 0; j < 7; ++j) At(i, j) = A(j, i);
 }
 
+// exactly zero, and constant with respect to the input a dual-number build differentiates
+__device__ __forceinline__ bool plain_zero(double x) { return x == 0.0; }
+__device__ __forceinline__ bool plain_zero(Dual x) { return x.v == 0.0 && x.d == 0.0; }
+__device__ __forceinline__ bool finite_entry(double x) { return isfinite(x); }
+__device__ __forceinline__ bool finite_entry(Dual x) { return isfinite(x.v) && isfinite(x.d); }
+
+template <typename S>
+__device__ bool all_finite7(const Mat7<S>& A) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 49; ++k) ok = ok && finite_entry(A.m[k]);
+    return ok;
+}
+template <>
+__device__ __forceinline__ bool all_finite7<Dual>(const Mat7<Dual>& A) {     // (wave-shared matrix: a lane per entry)
+    const int lane = threadIdx.x & 63;
+    return !__any(lane < 49 && !finite_entry(A.m[lane]));
+}
+template <typename S>
+__device__ void copy7(const Mat7<S>& A, Mat7<S>& B) {
+#pragma unroll
+    for (int k = 0; k < 49; ++k) B.m[k] = A.m[k];
+}
+template <>
+__device__ __forceinline__ void copy7<Dual>(const Mat7<Dual>& A, Mat7<Dual>& B) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 49) B.m[lane] = A.m[lane];
+    chx_wave_sync();
+}
+
 // quadrupole.py:93-110 with track_methods.py:345-382
 template <typename S>
 __device__ void quadrupole_map(const S* p, S energy, double mass, Mat7<S>& R) {
     const S L = p[0], k1 = p[1], tilt = p[2], mx = p[3], my = p[4];
     Mat7<S> base, entry, exitm, tmp;
     base_rmatrix<S>(L, k1, cst<S>(0.0), energy, mass, base);
+    // An upright, centred quadrupole — nearly every one of a lattice: the rotation in front is the identity with a column of zeros,
+    // the one behind its transpose, and exit (base entry) returns base's entries as they are (products with 1 and sums with 0 are
+    // exact; a zero may change its sign) when all of them are finite. The two dense products and the four sines and cosines are
+    // two thirds of this builder's time — 4.7 of the 10.9 us a wave spends on the dual-number form in the backward pass of an
+    // optimisation step, 700 dependent multiply-adds on the one lane that builds the map in the forward pass.
+    if (plain_zero(tilt) && plain_zero(mx) && plain_zero(my) && all_finite7(base)) {
+        copy7(base, R);
+        return;
+    }
     rotation_map<S>(tilt, entry);
     transpose7(entry, exitm);  // tm_exit = tm_entry.clone().mT (before the misalignment is added)
     const S cs = m_cos(tilt), sn = m_sin(tilt);
@@ -261,6 +300,10 @@ __device__ void dipole_map(const S* p, S energy, double mass, Mat7<S>& R) {
     }
     matmul7(base, enter, t1);
     matmul7(exitm, t1, t2);
+    if (plain_zero(tilt) && all_finite7(t2)) {      // an upright dipole: rot^T (t2 rot) returns t2's entries (see quadrupole_map)
+        copy7(t2, R);
+        return;
+    }
     rotation_map<S>(tilt, rot);
     transpose7(rot, rotT);
     matmul7(t2, rot, t1);

@@ -153,6 +153,44 @@ def test_map_builder_fp32_equals_fp64_of_rounded_inputs(ca, oracle):
     assert np.max(np.abs(R32 - Ro.astype(np.float32))) <= 2 * np.finfo(np.float32).eps * np.max(np.abs(Ro))
 
 
+def test_upright_elements_take_the_short_way_to_the_same_map(ca, oracle):
+    """An upright, centred quadrupole (tilt = 0, no misalignment) and an upright dipole skip the rotation products in the builders
+    (csrc/chx_build.hip quadrupole_map / dipole_map): exit (base entry) with entry = identity returns base's entries as they are.
+    Against the oracle, which forms the full product (quadrupole.py:93-110, dipole.py:372-394): the same entries (zeros and NaNs exactly, the rest to 1e-12) —
+    also when a setting is not finite (then the builders take the long way and the NaNs land where the reference's land) — and
+    the derivatives of the short way equal those of a tilt of 1e-300 (the long way)."""
+    from cheetah_amd import _ops
+
+    mass = oracle.ELECTRON_MASS_EV
+    e = np.array([1e8, 6e6, 1e8, 1e8])
+    quads = np.array([[0.2, 4.2, 0.0, 0.0, 0.0], [0.3, -11.0, 0.0, 0.0, 0.0], [0.2, np.nan, 0.0, 0.0, 0.0], [0.2, np.inf, 0.0, 0.0, 0.0]])
+    with np.errstate(all="ignore"):
+        want = oracle.build_rmatrix("quadrupole", quads, e)
+    got = _ops.build_rmatrix(_ops.KIND["quadrupole"], dev(quads), dev(e), mass, -1.0, 4).cpu().numpy()
+    # (1e-12: the device's and the host's sines and cosines, as in test_map_builders_vs_reference_goldens; zeros and NaNs exactly)
+    assert np.allclose(got, want, rtol=1e-12, atol=0, equal_nan=True)
+    assert np.isnan(got[2]).sum() == np.isnan(want[2]).sum() > 13                       # (the NaN went through the products)
+    #                 length angle k1   e1   e2  tilt fint fint_exit gap
+    dips = np.array([[0.5, 0.2, 0.0, 0.05, -0.02, 0.0, 0.4, 0.3, 0.02], [1.1, -0.3, 0.7, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+                     [0.5, np.nan, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], [0.5, 0.2, 0.0, 0.05, -0.02, 0.3, 0.4, 0.3, 0.02]])
+    with np.errstate(all="ignore"):
+        want = oracle.build_rmatrix("dipole", dips, e)
+    got = _ops.build_rmatrix(_ops.KIND["dipole"], dev(dips), dev(e), mass, -1.0, 4).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=0, equal_nan=True)
+    # dual-number form (the backward pass): d / d(length, k1, energy) of an upright quadrupole the short way == with a tilt that is
+    # not zero but changes nothing
+    for tilt in (0.0, 1e-300):
+        p = torch.tensor([[0.2, 4.2, tilt, 0.0, 0.0]], dtype=torch.float64, device="cuda", requires_grad=True)
+        en = torch.tensor([1e8], dtype=torch.float64, device="cuda", requires_grad=True)
+        R = _ops.build_rmatrix(_ops.KIND["quadrupole"], p, en, mass, -1.0, 1)
+        W = torch.arange(49, dtype=torch.float64, device="cuda").reshape(1, 7, 7).cos()
+        (R * W).sum().backward()
+        if tilt == 0.0:
+            first = (p.grad.clone(), en.grad.clone())
+    assert torch.equal(first[0][:, :2], p.grad[:, :2]) and torch.equal(first[1], en.grad)
+    assert torch.allclose(first[0][:, 2:], p.grad[:, 2:], rtol=1e-14, atol=0)          # (tilt, misalignment: the long way both times)
+
+
 def test_compose_vs_oracle(ca, oracle):
     from cheetah_amd import _ops
 
