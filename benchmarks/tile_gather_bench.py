@@ -19,6 +19,9 @@ lib = _lib.lib()
 beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=N, total_charge=t(1e-9), energy=t(2.5e8), radius_x=t(1e-3), radius_y=t(1e-3),
                                             radius_tau=t(1e-3), sigma_px=t(1e-6), sigma_py=t(1e-6), sigma_p=t(1e-6), **kw)
 x = beam.particles.contiguous()
+if os.environ.get("GAUSS"):          # C4's shape: a Gaussian bunch (the ellipsoid is uniform)
+    x = ca.ParticleBeam.from_parameters(num_particles=N, sigma_x=t(1e-3), sigma_y=t(1e-3), sigma_tau=t(1e-3), energy=t(2.5e8), **kw).particles.contiguous()
+    beam = ca.ParticleBeam(x, t(2.5e8), particle_charges=beam.particle_charges, **kw)
 energy = torch.tensor([2.5e8], **kw)
 gamma = energy / 510998.95069
 beta = (1 - 1 / gamma**2).sqrt()
@@ -27,6 +30,16 @@ half = (3.0 * sig).contiguous()
 cell = (2 * half / 128.0).contiguous()
 extent = torch.stack([-half[0], half[0]], dim=-1).reshape(1, 3, 2).contiguous()
 scale = torch.stack([torch.ones_like(beta), torch.ones_like(beta), -beta], dim=-1).contiguous()
+if os.environ.get("PRESORT"):
+    # experiment: rows handed over in CELL order (the tile sort keeps the order of its input inside a tile, coarsely): what would a
+    # cell-ordered beam buy the deposit (equal-cell neighbours) and the gather (fewer distinct lines per load)?
+    pos = torch.stack([x[:, 0], x[:, 2], -beta * x[:, 4]], dim=1)
+    idx = ((pos + half) / cell).floor().clamp(0, 127).long()
+    key = (idx[:, 0] * 128 + idx[:, 1]) * 128 + idx[:, 2]
+    order = key.argsort()
+    if os.environ["PRESORT"] == "shuffle":
+        order = torch.randperm(N, device=x.device)
+    x = x[order].contiguous()
 dtt = torch.tensor([0.2 / 299792458.0], **kw)
 phi = torch.randn(1, 132, 132, 132, **kw) * 1e3
 q = beam.particle_charges.contiguous()
