@@ -270,6 +270,9 @@ SIGNATURES = {
     "chx_run_vjp_workspace_bytes": (c_size_t, [c_i64]),
     "chx_run_vjp": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_size_t, c_void_p]),
+    "chx_run_vjp_entry_workspace_bytes": (c_size_t, [c_i64]),
+    "chx_run_vjp_entry": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_run_vjp_masked": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "chx_run_map_batched_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int]),
@@ -298,7 +301,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.chx_abi_version() != 8:  # CHX_ABI_VERSION of include/chx.h
+        if handle.chx_abi_version() != 9:  # CHX_ABI_VERSION of include/chx.h
             raise ImportError("libchx.so ABI version mismatch; rebuild the library")
         _lib = handle
     return _lib
@@ -345,7 +348,8 @@ def torch_host():
             raise ImportError("cheetah_amd._chxtorch is not built: run `make -C cheetah_amd/csrc` "
                               "(or `python -c 'import __graft_entry__ as g; g.build()'`)") from exc
         h = lib()
-        names = ("chx_lattice_track_screens", "chx_parameter_lattice_track_screens", "chx_run_build_compose", "chx_run_vjp_masked",
+        names = ("chx_lattice_track_screens", "chx_parameter_lattice_track_screens", "chx_run_build_compose", "chx_run_vjp_masked", "chx_run_vjp_entry",
+                 "chx_run_vjp_entry_workspace_bytes",
                  "chx_run_vjp_workspace_bytes", "chx_apply_affine7_bwd", "chx_apply_bwd_workspace_bytes", "chx_moments_entry",
                  "chx_moments_workspace_bytes", "chx_moment_entry", "chx_moment_entry_mapped_bwd", "chx_lattice_moment_blocks",
                  "chx_lattice_screen_moments")

@@ -1161,6 +1161,11 @@ class MomentEntryMapped(torch.autograd.Function):
         return dR, None, None, None, None, None, None
 
 
+#: a property of a [run | Screen] stretch's record as ONE node on the run's settings (False: on the run's composed map, whose own node
+#: carries the gradient on to the settings — the two-node form; tests compare the two)
+ONE_NODE_PROPERTY = [True]
+
+
 def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool):
     """`moments(particles, survival)[..., index]` (or its square root) in the particle dtype for a linearly tracked beam
     whose particles carry no graph of their own (`_LinearSource`), as one autograd node on the map; None when that does not
@@ -1190,12 +1195,19 @@ def moment_entry(particles: torch.Tensor, survival, index: int, take_sqrt: bool)
         if cached is not None and cached[0] == particles._version and cached[1] is w_src and cached[2] == w_ver \
                 and cached[3] == particles.data_ptr() and cached[4].shape[0] == 1:
             known = cached[4]
-        partials = None
-        if known is None:
-            tag = getattr(particles, "_chx_partials", None)      # (sums, version of the rows, the weights they were taken with)
-            if tag is not None and tag[1] == particles._version and tag[2] is survival:
-                partials = tag[0]
-        out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, particles.detach(), survival, mom_x, known, index, take_sqrt, partials)
+        # (sums, version of the rows, the weights they were taken with, the run the rows came through): what the particle pass of a
+        # differentiable [run | Screen] stretch left on its record
+        tag = getattr(particles, "_chx_partials", None)
+        partials = tag[0] if tag is not None and tag[1] == particles._version and tag[2] is survival else None
+        run = tag[3] if partials is not None and len(tag) > 3 else None
+        if run is not None and run[0] is lin.R and index >= 2 and ONE_NODE_PROPERTY[0]:
+            # the rows are the record of a [run | Screen] stretch: the property hangs on the run's SETTINGS, one node whose backward
+            # is one launch (cheetah_amd._chxtorch RunMomentEntry); the map is a constant of that node
+            _, energy, distinct, meta, mass, nq, maps = run
+            out, mom_y = _lib.torch_host().run_moment_entry(energy, distinct, lin.R.detach(), mom_x, partials, known, maps, meta, mass, nq,
+                                                            index, take_sqrt, particles.shape[0])
+        else:
+            out, mom_y = _lib.torch_host().moment_entry_mapped(lin.R, particles.detach(), survival, mom_x, known, index, take_sqrt, partials)
         if known is None:
             particles._chx_mom = (particles._version, w_src, w_ver, particles.data_ptr(), mom_y)
         return out

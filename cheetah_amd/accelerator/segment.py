@@ -850,14 +850,15 @@ class Segment(Element):
                 return None       # (charges or weights the screens' host step does not take: the walk, as before)
             if grad_run is not None:
                 run, fr = grad_run
-                out, rows, C, q_at, w_at, e_at, s_at, sums = _TORCH_HOST.run_screen_track(
+                out, rows, C, q_at, w_at, e_at, s_at, sums, maps = _TORCH_HOST.run_screen_track(
                     lp.capsule_s, x, e, s_in, q, w, fr.distinct, fr.grad_meta, sp.mass_eV_float, sp.num_elementary_charges_float)
                 x1, origin = x.reshape(1, N, 7), _ops._origin(p)
                 # the recorded survival probabilities are the incoming ones (no aperture in a [run | Screen] stretch): tagged as
                 # their copy, so that the incoming beam's memoised moments are found again on the next step of a loop; the one-pass
                 # sums of the recorded rows ride on the rows (a beam property of them: one small launch, _ops.moment_entry)
                 _ops.mark_copy_of(w_at, w)
-                rows._chx_partials = (sums, rows._version, w_at)
+                rows._chx_partials = (sums, rows._version, w_at,
+                                      (C, e, fr.distinct, fr.grad_meta, sp.mass_eV_float, sp.num_elementary_charges_float, maps))
                 out._chx_lin = _ops._LinearSource(origin, x1, C, (), out._version)
                 lp.screens[0]._record_stretch((rows, q_at, w_at, e_at, s_at, x1, C, origin), N, sp, None, "particles_grad")
                 return ParticleBeam(out, e, particle_charges=q, survival_probabilities=w, s=self._run_s(run, s_in), species=sp), i + lp.count

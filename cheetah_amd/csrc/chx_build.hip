@@ -18,6 +18,7 @@
 // incoming cotangent, which replaces torch autograd through ~40 tiny ops per element.
 #include "chx_common.h"
 #include "chx_dual.h"
+#include "chx_moments_dev.h"
 
 namespace {
 
@@ -1387,12 +1388,25 @@ __device__ __forceinline__ void wave_element_cotangent(const T* __restrict__ map
 }
 
 // dR: dL/dR_e of every element ([n][49], from compose_scalars_bwd_kernel), or NULL: formed here from maps / dT (fused form)
+// entry.grad set (chx_run_vjp_entry): dT is not given but formed by every wave itself — the cotangent the composed map C receives
+// from ONE property of the beam y = C x (its moments mom_y, the incoming beam's mom_x; chx_moment_entry_mapped_bwd's arithmetic,
+// rounded to T like the tensor that launch would have written): the backward pass of d sigma_x(screen) / d k1 in one launch.
+struct VjpEntry {
+    const void* grad;        // one value of T, or NULL
+    const double* mom_y;
+    const double* mom_x;
+    const void* C;           // [49] of T
+    int index, take_sqrt;
+};
+
 template <typename T>
 __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs args, int n, const T* __restrict__ energy,
                                                                double mass, double nq, const double* __restrict__ dR,
                                                                const T* __restrict__ maps, const T* __restrict__ dT,
-                                                               T* __restrict__ out) {
+                                                               T* __restrict__ out, VjpEntry entry) {
     __shared__ double cot[4 * 49];
+    __shared__ double entry_lds[3 * 36 + CHX_MOM_NOUT];
+    __shared__ T dT_own[49];
     const int idx = blockIdx.x;
     const int e = idx / (CHX_MAX_PARAMS + 1), k = idx - e * (CHX_MAX_PARAMS + 1);
     if (e >= n) return;
@@ -1413,6 +1427,12 @@ __global__ __launch_bounds__(64) void build_scalars_vjp_kernel(BuildScalarsArgs 
     build_kind<Dual>(kind, p, en, mass, nq, R);
     chx_wave_sync();
     const double* dRe = dR ? dR + e * 49 : cot + 147;
+    if (!dR && entry.grad) {
+        moment_entry_gradient((double)*(const T*)entry.grad, entry.mom_y, entry.index, entry.take_sqrt, entry_lds + 108);
+        mapped_bwd_row_wave<T, T>(entry_lds + 108, (const T*)entry.C, entry.mom_x, entry_lds, dT_own);
+        chx_wave_sync();
+        dT = dT_own;
+    }
     if (!dR) wave_element_cotangent<T>(maps, n, e, dT, cot, cot + 147);
     double acc = lane < 49 ? dRe[lane] * R.m[lane].d : 0.0;
     acc = chx_wave_sum(acc);
@@ -1428,10 +1448,55 @@ extern "C" int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, 
                               workspace_bytes, stream);
 }
 
+static int run_vjp_launch(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                          double n_charges, int dtype, const void* maps, const void* dT, const uint16_t* need, void* dinputs,
+                          void* workspace, size_t workspace_bytes, void* stream, const VjpEntry& entry);
+
 extern "C" int chx_run_vjp_masked(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
                                   double mass_eV, double n_charges, int dtype, const void* maps, const void* dT,
                                   const uint16_t* need, void* dinputs, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!kinds || !param_ptrs || !energy || !maps || !dT || !dinputs || E < 1 || E > 65535) return CHX_ERR_INVALID_ARG;
+    if (!dT) return CHX_ERR_INVALID_ARG;
+    return run_vjp_launch(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, dT, need, dinputs, workspace, workspace_bytes,
+                          stream, VjpEntry{});
+}
+
+extern "C" int chx_moment_entry_mapped_bwd(const void* grad, const double* mom_y, int index, int take_sqrt, const void* R,
+                                           const double* mom_x, int64_t B, int64_t BR, int64_t Bm, int dtype, void* dR,
+                                           int dR_is_double, void* stream);
+
+extern "C" int chx_run_vjp_entry(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                                 double n_charges, int dtype, const void* maps, const uint16_t* need, const void* grad,
+                                 const double* mom_y, int index, int take_sqrt, const void* C, const double* mom_x, void* dinputs,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!grad || !mom_y || !mom_x || !C || index < 2 || index >= CHX_MOM_NOUT) return CHX_ERR_INVALID_ARG;
+    if (E >= 1 && E <= kRunVjpFuseE && E <= kBuildChunk) {
+        VjpEntry entry;
+        entry.grad = grad;
+        entry.mom_y = mom_y;
+        entry.mom_x = mom_x;
+        entry.C = C;
+        entry.index = index;
+        entry.take_sqrt = take_sqrt;
+        return run_vjp_launch(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, nullptr, need, dinputs, workspace,
+                              workspace_bytes, stream, entry);
+    }
+    // a long run: the cotangent as a launch of its own, at the head of the workspace's spare 49 values (chx_run_vjp_entry_workspace_bytes)
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    const size_t base = chx_run_vjp_workspace_bytes(E);
+    if (!workspace || E < 1 || workspace_bytes < base + 49 * sizeof(double)) return CHX_ERR_WORKSPACE;
+    void* dT = (char*)workspace + base;
+    const int rc = chx_moment_entry_mapped_bwd(grad, mom_y, index, take_sqrt, C, mom_x, 1, 1, 1, dtype, dT, 0, stream);
+    if (rc != CHX_OK) return rc;
+    return run_vjp_launch(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps, dT, need, dinputs, workspace, base, stream,
+                          VjpEntry{});
+}
+
+extern "C" size_t chx_run_vjp_entry_workspace_bytes(int64_t E) { return E < 1 ? 0 : chx_run_vjp_workspace_bytes(E) + 49 * sizeof(double); }
+
+static int run_vjp_launch(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                          double n_charges, int dtype, const void* maps, const void* dT, const uint16_t* need, void* dinputs,
+                          void* workspace, size_t workspace_bytes, void* stream, const VjpEntry& entry) {
+    if (!kinds || !param_ptrs || !energy || !maps || (!dT && !entry.grad) || !dinputs || E < 1 || E > 65535) return CHX_ERR_INVALID_ARG;
     if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
     if (!workspace || workspace_bytes < chx_run_vjp_workspace_bytes(E)) return CHX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -1466,11 +1531,11 @@ extern "C" int chx_run_vjp_masked(const int32_t* kinds, const void* const* param
         if (dtype == CHX_F32)
             hipLaunchKernelGGL(build_scalars_vjp_kernel<float>, dim3(blocks), dim3(64), 0, s, a, n, (const float*)energy, mass_eV,
                                n_charges, fused ? (const double*)nullptr : ws + done * 49, (const float*)maps, (const float*)dT,
-                               (float*)out);
+                               (float*)out, entry);
         else
             hipLaunchKernelGGL(build_scalars_vjp_kernel<double>, dim3(blocks), dim3(64), 0, s, a, n, (const double*)energy, mass_eV,
                                n_charges, fused ? (const double*)nullptr : ws + done * 49, (const double*)maps, (const double*)dT,
-                               (double*)out);
+                               (double*)out, entry);
         CHX_CHECK_LAUNCH();
     }
     return CHX_OK;

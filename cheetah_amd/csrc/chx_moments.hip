@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "chx_common.h"
+#include "chx_moments_dev.h"
 #include "chx_sc_math.h"
 
 namespace {
@@ -1522,44 +1523,6 @@ extern "C" int chx_merge_moments(const double* per_rank, int32_t R, int64_t B, d
 // Exactly what autograd gives through chx_moments_bwd + chx_apply_affine7_bwd's dR reduction (sum_n dY_n x_n^T) when the
 // particles carry no gradient of their own — 32 B/particle (one pass for mu, C, cacheable across steps) instead of 232.
 namespace {
-// dR (49 values) of one batch row from the gradient g[29] of its outgoing moments, its map Rb (T) and the incoming moments
-// m[29], by ONE WAVE: lane 6 i + j (i, j < 6) owns entry (i, j) of the 6x6 products, which pass through LDS (a single thread
-// doing the two dense products took 14 us). g, m: anywhere readable by every lane; lds: 3 * 36 doubles of this wave.
-template <typename T, typename TO>
-__device__ __forceinline__ void mapped_bwd_row_wave(const double* g, const T* __restrict__ Rb, const double* __restrict__ m,
-                                                    double* lds, TO* __restrict__ o) {
-    const int lane = threadIdx.x & 63;
-    double* G = lds;
-    double* AC = lds + 36;
-    double* C = lds + 72;
-    const int i = lane / 6, j = lane - 6 * i;
-    if (lane < 36) {
-        // index of (min, max) in the upper-triangle listing that starts at 8
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const int k = 8 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
-        G[lane] = (i == j) ? g[k] : 0.5 * g[k];
-        C[lane] = m[k];
-    }
-    chx_wave_sync();
-    if (lane < 36) {
-        double acc = 0.0;
-#pragma unroll
-        for (int l = 0; l < 6; ++l) acc += (double)Rb[i * 7 + l] * C[l * 6 + j];
-        AC[lane] = acc;
-    }
-    chx_wave_sync();
-    if (lane < 36) {
-        double acc = 0.0;
-#pragma unroll
-        for (int l = 0; l < 6; ++l) acc += G[i * 6 + l] * AC[l * 6 + j];
-        o[i * 7 + j] = (TO)(2.0 * acc + g[2 + i] * m[2 + j]);
-    } else if (lane < 42) {
-        o[(lane - 36) * 7 + 6] = (TO)g[2 + (lane - 36)];
-    } else if (lane < 49) {
-        o[42 + (lane - 42)] = (TO)0;
-    }
-}
-
 // one wave per batch row
 template <typename T>
 __global__ __launch_bounds__(64) void moments_mapped_bwd_kernel(const double* __restrict__ d_out, const T* __restrict__ R, int64_t BR,
@@ -1589,15 +1552,7 @@ __global__ __launch_bounds__(64) void moment_entry_mapped_bwd_kernel(const T* __
     __shared__ double lds[3 * 36];
     __shared__ double g[CHX_MOM_NOUT];
     const int64_t b = blockIdx.x;
-    if (threadIdx.x < CHX_MOM_NOUT) {
-        double gv = 0.0;
-        if ((int)threadIdx.x == index) {
-            gv = (double)grad[b];
-            if (take_sqrt) gv = gv * 0.5 / sqrt(mom_y[b * CHX_MOM_NOUT + index]);   // infinite at 0 like torch.sqrt's own backward
-        }
-        g[threadIdx.x] = gv;
-    }
-    chx_wave_sync();
+    moment_entry_gradient((double)grad[b], mom_y + b * CHX_MOM_NOUT, index, take_sqrt, g);
     mapped_bwd_row_wave<T, TO>(g, R + (BR == 1 ? 0 : b) * 49, mom_x + (Bm == 1 ? 0 : b) * CHX_MOM_NOUT, lds, dR + b * 49);
 }
 }  // namespace

@@ -35,6 +35,8 @@ parameter_screens_fn p_parameter = nullptr;
 decltype(&chx_run_build_compose) p_run_build_compose = nullptr;
 decltype(&chx_run_vjp_masked) p_run_vjp_masked = nullptr;
 decltype(&chx_run_vjp_workspace_bytes) p_run_vjp_workspace_bytes = nullptr;
+decltype(&chx_run_vjp_entry) p_run_vjp_entry = nullptr;
+decltype(&chx_run_vjp_entry_workspace_bytes) p_run_vjp_entry_workspace_bytes = nullptr;
 decltype(&chx_apply_affine7_bwd) p_apply_bwd = nullptr;
 decltype(&chx_apply_bwd_workspace_bytes) p_apply_bwd_workspace_bytes = nullptr;
 decltype(&chx_moments_entry) p_moments_entry = nullptr;
@@ -100,7 +102,8 @@ PyObject* host_bind(PyObject*, PyObject* args) {
         !take("chx_apply_bwd_workspace_bytes", p_apply_bwd_workspace_bytes) || !take("chx_moments_entry", p_moments_entry) ||
         !take("chx_moments_workspace_bytes", p_moments_workspace_bytes) || !take("chx_moment_entry", p_moment_entry) ||
         !take("chx_moment_entry_mapped_bwd", p_moment_entry_mapped_bwd) || !take("chx_lattice_moment_blocks", p_moment_blocks) ||
-        !take("chx_lattice_screen_moments", p_screen_moments))
+        !take("chx_lattice_screen_moments", p_screen_moments) || !take("chx_run_vjp_entry", p_run_vjp_entry) ||
+        !take("chx_run_vjp_entry_workspace_bytes", p_run_vjp_entry_workspace_bytes))
         return nullptr;
     Py_XDECREF(g_error);
     Py_INCREF(err);
@@ -422,6 +425,61 @@ inline void chx_check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " f
 
 // meta (int64 words): [E, code, n_distinct, kinds[E], ptrs[E * CHX_MAX_PARAMS], then per distinct setting tensor: n, (element,
 // slot, index | -1) x n]; mass_eV and n_charges travel as doubles
+struct RunDescription {
+    int64_t E = 0, n_distinct = 0;
+    std::vector<int32_t> kinds;
+    std::vector<const void*> ptrs;
+    std::vector<size_t> slot_at;        // where distinct setting `pos` starts in meta
+    std::vector<uint16_t> need;         // per element: the slots whose derivative is wanted (bit CHX_MAX_PARAMS: the energy)
+
+    // wanted(pos): does distinct setting `pos` need a gradient?
+    template <typename Wanted>
+    RunDescription(const std::vector<int64_t>& meta, Wanted wanted, bool need_energy) {
+        TORCH_CHECK(meta.size() >= 3 && meta[0] >= 1 && static_cast<int64_t>(meta.size()) >= 3 + meta[0] * (1 + CHX_MAX_PARAMS),
+                    "malformed plan description");
+        E = meta[0];
+        n_distinct = meta[2];
+        kinds.resize(E);
+        ptrs.resize(E * CHX_MAX_PARAMS);
+        need.assign(E, 0);
+        slot_at.resize(n_distinct);
+        for (int64_t e = 0; e < E; ++e) kinds[e] = static_cast<int32_t>(meta[3 + e]);
+        for (int64_t k = 0; k < E * CHX_MAX_PARAMS; ++k) ptrs[k] = reinterpret_cast<const void*>(static_cast<uintptr_t>(meta[3 + E + k]));
+        size_t at = 3 + E + E * CHX_MAX_PARAMS;
+        for (int64_t pos = 0; pos < n_distinct; ++pos) {
+            TORCH_CHECK(at < meta.size(), "malformed plan description");
+            slot_at[pos] = at;
+            const int64_t n = meta[at];
+            TORCH_CHECK(n >= 0 && at + 1 + 3 * static_cast<size_t>(n) <= meta.size(), "malformed plan description");
+            if (wanted(pos))
+                for (int64_t i = 0; i < n; ++i) {
+                    const int64_t e = meta[at + 1 + 3 * i], k = meta[at + 2 + 3 * i];
+                    TORCH_CHECK(e >= 0 && e < E && k >= 0 && k < CHX_MAX_PARAMS, "malformed plan description");
+                    need[e] |= static_cast<uint16_t>(1u << k);
+                }
+            at += 1 + 3 * n;
+        }
+        if (need_energy)
+            for (auto& m : need) m |= static_cast<uint16_t>(1u << CHX_MAX_PARAMS);
+    }
+
+    // the gradient of distinct setting `pos` (the tensor t) out of d[E][CHX_MAX_PARAMS + 1]
+    at::Tensor setting_gradient(const std::vector<int64_t>& meta, int64_t pos, const at::Tensor& t, const at::Tensor& d) const {
+        const size_t a = slot_at[pos];
+        const int64_t n = meta[a];
+        at::Tensor g;
+        if (t.dim() == 0) {
+            g = d.select(0, meta[a + 1]).select(0, meta[a + 2]);
+            for (int64_t i = 1; i < n; ++i) g = g + d.select(0, meta[a + 1 + 3 * i]).select(0, meta[a + 2 + 3 * i]);
+        } else {
+            g = at::zeros_like(t);
+            for (int64_t i = 0; i < n; ++i)
+                g.select(0, meta[a + 3 + 3 * i]).add_(d.select(0, meta[a + 1 + 3 * i]).select(0, meta[a + 2 + 3 * i]));
+        }
+        return g;
+    }
+};
+
 struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
     static variable_list forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& energy, const at::Tensor& s_in,
                                  const at::Tensor& charges, const at::Tensor& survival, at::TensorList settings, int64_t plan_addr,
@@ -471,8 +529,8 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
         ctx->saved_data["meta"] = meta;
         ctx->saved_data["mass"] = mass;
         ctx->saved_data["nq"] = nq;
-        ctx->mark_non_differentiable({e_out, s_out, rest, sums});
-        return {out, rows, C, e_out, s_out, rest, sums};
+        ctx->mark_non_differentiable({e_out, s_out, rest, sums, maps});
+        return {out, rows, C, e_out, s_out, rest, sums, maps};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -503,45 +561,16 @@ struct RunScreenTrack : public torch::autograd::Function<RunScreenTrack> {
         variable_list result(9 + n_distinct);        // x, energy, s_in, charges, survival, settings..., plan, meta, mass, nq
         if (!dC.defined()) return result;
         // the VJP of the builders the wanted settings feed, from the element maps the forward pass's preparation launch left
-        std::vector<int32_t> kinds(E);
-        std::vector<const void*> ptrs(E * CHX_MAX_PARAMS);
-        for (int64_t e = 0; e < E; ++e) kinds[e] = static_cast<int32_t>(meta[3 + e]);
-        for (int64_t k = 0; k < E * CHX_MAX_PARAMS; ++k) ptrs[k] = reinterpret_cast<const void*>(static_cast<uintptr_t>(meta[3 + E + k]));
-        std::vector<uint16_t> need(E, 0);
         const bool need_energy = ctx->needs_input_grad(1);
-        size_t at = 3 + E + E * CHX_MAX_PARAMS;
-        std::vector<size_t> slot_at(n_distinct);
-        for (int64_t pos = 0; pos < n_distinct; ++pos) {
-            slot_at[pos] = at;
-            const int64_t n = meta[at];
-            if (ctx->needs_input_grad(5 + pos))
-                for (int64_t i = 0; i < n; ++i) need[meta[at + 1 + 3 * i]] |= static_cast<uint16_t>(1u << meta[at + 2 + 3 * i]);
-            at += 1 + 3 * n;
-        }
-        if (need_energy)
-            for (auto& m : need) m |= static_cast<uint16_t>(1u << CHX_MAX_PARAMS);
+        const RunDescription run(meta, [&](int64_t pos) { return ctx->needs_input_grad(5 + pos); }, need_energy);
         const size_t ws_bytes = p_run_vjp_workspace_bytes(E);
         at::Tensor ws = at::empty({static_cast<int64_t>(ws_bytes)}, opts.dtype(at::kByte));
         at::Tensor d = at::empty({E, CHX_MAX_PARAMS + 1}, opts);
-        chx_check(p_run_vjp_masked(kinds.data(), ptrs.data(), E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), dC.data_ptr(), need.data(),
-                                   d.data_ptr(), ws.data_ptr(), ws_bytes, stream),
+        chx_check(p_run_vjp_masked(run.kinds.data(), run.ptrs.data(), E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), dC.data_ptr(),
+                                   run.need.data(), d.data_ptr(), ws.data_ptr(), ws_bytes, stream),
                   "chx_run_vjp_masked");
-        for (int64_t pos = 0; pos < n_distinct; ++pos) {
-            if (!ctx->needs_input_grad(5 + pos)) continue;
-            const at::Tensor& t = saved[4 + pos];
-            const size_t a = slot_at[pos];
-            const int64_t n = meta[a];
-            at::Tensor g;
-            if (t.dim() == 0) {
-                g = d.select(0, meta[a + 1]).select(0, meta[a + 2]);
-                for (int64_t i = 1; i < n; ++i) g = g + d.select(0, meta[a + 1 + 3 * i]).select(0, meta[a + 2 + 3 * i]);
-            } else {
-                g = at::zeros_like(t);
-                for (int64_t i = 0; i < n; ++i)
-                    g.select(0, meta[a + 3 + 3 * i]).add_(d.select(0, meta[a + 1 + 3 * i]).select(0, meta[a + 2 + 3 * i]));
-            }
-            result[5 + pos] = g;
-        }
+        for (int64_t pos = 0; pos < n_distinct; ++pos)
+            if (ctx->needs_input_grad(5 + pos)) result[5 + pos] = run.setting_gradient(meta, pos, saved[4 + pos], d);
         if (need_energy) result[1] = d.select(1, CHX_MAX_PARAMS).sum();
         return result;
     }
@@ -603,9 +632,95 @@ struct MomentEntryMappedNode : public torch::autograd::Function<MomentEntryMappe
     }
 };
 
+// One beam property of the screen's beam as ONE node on the run's settings: the record's rows are y = C x with C
+// the run's composed map, so the property depends on the settings through C alone. MomentEntryMappedNode hangs it on C and leaves the
+// way from C to the settings to RunScreenTrack's backward — two nodes, two launches. This node takes the settings themselves: forward
+// = the property out of the particle pass's moment sums (or the memoised moments); backward = chx_run_vjp_entry, the builders' VJP
+// whose waves form dL/dC from the property's gradient themselves: one node, one launch. C, the element maps and the moments are
+// constants of the node (C is a function of the settings and the energy only: there is no other way a gradient could take).
+struct RunMomentEntry : public torch::autograd::Function<RunMomentEntry> {
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& energy, at::TensorList settings, const at::Tensor& C,
+                                 const at::Tensor& mom_x, const std::optional<at::Tensor>& partials, const std::optional<at::Tensor>& mom_y_in,
+                                 const at::Tensor& maps, std::vector<int64_t> meta, double mass, double nq, int64_t index, bool take_sqrt,
+                                 int64_t N) {
+        ctx->set_materialize_grads(false);
+        const auto opts = C.options();
+        const int code = code_of(C);
+        TORCH_CHECK(C.is_cuda() && C.numel() == 49 && C.is_contiguous() && (code == CHX_F64 || C.scalar_type() == at::kFloat),
+                    "run_moment_entry: C as a contiguous (1, 7, 7) device tensor of float32 / float64");
+        TORCH_CHECK(meta.size() >= 3 && meta[0] >= 1 && meta[1] == code, "run_moment_entry: malformed plan description");
+        TORCH_CHECK(maps.is_contiguous() && maps.numel() == meta[0] * 49 && maps.scalar_type() == C.scalar_type() && maps.device() == C.device(),
+                    "run_moment_entry: the run's element maps as (E, 7, 7) of C's dtype");
+        TORCH_CHECK(mom_x.scalar_type() == at::kDouble && mom_x.is_contiguous() && mom_x.numel() == 29 && mom_x.device() == C.device(),
+                    "run_moment_entry: the incoming beam's moments as 29 doubles");
+        TORCH_CHECK(energy.numel() == 1 && energy.scalar_type() == C.scalar_type() && energy.device() == C.device(),
+                    "run_moment_entry: energy as one value of C's dtype");
+        TORCH_CHECK(index >= 2 && index < 29 && N >= 1, "run_moment_entry: entry ", index, " of the 29 moments");
+        const c10::DeviceGuard device_guard(C.device());
+        void* stream = stream_of(C);
+        at::Tensor picked = at::empty({}, opts);
+        at::Tensor mom_y;
+        if (mom_y_in.has_value() && mom_y_in->defined()) {
+            mom_y = *mom_y_in;
+            TORCH_CHECK(mom_y.scalar_type() == at::kDouble && mom_y.is_contiguous() && mom_y.numel() == 29 && mom_y.device() == C.device(),
+                        "run_moment_entry: the beam's moments as 29 doubles");
+            chx_check(p_moment_entry(static_cast<const double*>(mom_y.data_ptr()), 1, static_cast<int>(index), take_sqrt ? 1 : 0, code,
+                                     picked.data_ptr(), stream),
+                      "chx_moment_entry");
+        } else {
+            TORCH_CHECK(partials.has_value() && partials->defined() && partials->scalar_type() == at::kDouble && partials->is_contiguous() &&
+                            partials->numel() == CHX_LATTICE_MOMENT_DOUBLES && partials->device() == C.device(),
+                        "run_moment_entry: the particle pass's moment sums (chx_lattice_screen.mom_partials)");
+            mom_y = at::empty({1, 29}, opts.dtype(at::kDouble));
+            chx_check(p_screen_moments(static_cast<const double*>(partials->data_ptr()), p_moment_blocks(N, 1), code,
+                                       static_cast<double*>(mom_y.data_ptr()), static_cast<int>(index), take_sqrt ? 1 : 0, picked.data_ptr(),
+                                       stream),
+                      "chx_lattice_screen_moments");
+        }
+        variable_list saved = {energy, C, mom_y, mom_x, maps};
+        for (const at::Tensor& t : settings) saved.push_back(t);
+        ctx->save_for_backward(saved);
+        ctx->saved_data["meta"] = meta;
+        ctx->saved_data["mass"] = mass;
+        ctx->saved_data["nq"] = nq;
+        ctx->saved_data["index"] = index;
+        ctx->saved_data["sqrt"] = take_sqrt;
+        ctx->mark_non_differentiable({mom_y});
+        return {picked, mom_y};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const variable_list saved = ctx->get_saved_variables();
+        const at::Tensor &energy = saved[0], &C = saved[1], &mom_y = saved[2], &mom_x = saved[3], &maps = saved[4];
+        const std::vector<int64_t> meta = ctx->saved_data["meta"].toIntVector();
+        const int64_t n_distinct = meta[2], E = meta[0];
+        variable_list result(1 + n_distinct + 11);   // energy, settings..., C, mom_x, partials, mom_y, maps, meta, mass, nq, index, sqrt, N
+        if (!grads[0].defined()) return result;
+        const c10::DeviceGuard device_guard(C.device());
+        const auto opts = C.options();
+        const bool need_energy = ctx->needs_input_grad(0);
+        const RunDescription run(meta, [&](int64_t pos) { return ctx->needs_input_grad(1 + pos); }, need_energy);
+        at::Tensor g = grads[0].to(C.scalar_type()).contiguous();
+        const size_t ws_bytes = p_run_vjp_entry_workspace_bytes(E);
+        at::Tensor ws = at::empty({static_cast<int64_t>(ws_bytes)}, opts.dtype(at::kByte));
+        at::Tensor d = at::empty({E, CHX_MAX_PARAMS + 1}, opts);
+        chx_check(p_run_vjp_entry(run.kinds.data(), run.ptrs.data(), E, energy.data_ptr(), ctx->saved_data["mass"].toDouble(),
+                                  ctx->saved_data["nq"].toDouble(), code_of(C), maps.data_ptr(), run.need.data(), g.data_ptr(),
+                                  static_cast<const double*>(mom_y.data_ptr()), static_cast<int>(ctx->saved_data["index"].toInt()),
+                                  ctx->saved_data["sqrt"].toBool() ? 1 : 0, C.data_ptr(), static_cast<const double*>(mom_x.data_ptr()),
+                                  d.data_ptr(), ws.data_ptr(), ws_bytes, stream_of(C)),
+                  "chx_run_vjp_entry");
+        for (int64_t pos = 0; pos < n_distinct; ++pos)
+            if (ctx->needs_input_grad(1 + pos)) result[1 + pos] = run.setting_gradient(meta, pos, saved[5 + pos], d);
+        if (need_energy) result[0] = d.select(1, CHX_MAX_PARAMS).sum();
+        return result;
+    }
+};
+
 // run_screen_track(plan, x, energy, s_in, charges, survival, settings tuple, meta (list of ints), mass_eV, n_charges)
-//   -> (out, rows at the screen, C (1, 7, 7), charges, survival, energy, s at the screen, moment sums of the rows)   [the first
-//      three differentiable in the settings and the energy; the next four are views of one allocation; the last: mom_partials]
+//   -> (out, rows at the screen, C (1, 7, 7), charges, survival, energy, s at the screen, moment sums of the rows, element maps)
+//      [the first three differentiable in the settings and the energy; the next four are views of one allocation; then mom_partials
+//      and the run's (E, 7, 7) element maps: what run_moment_entry takes]
 PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     if (nargs != 10) {
         PyErr_SetString(PyExc_TypeError, "run_screen_track takes 10 arguments");
@@ -626,12 +741,13 @@ PyObject* host_run_screen_track(PyObject*, PyObject* const* args, Py_ssize_t nar
     try {
         variable_list r = RunScreenTrack::apply(unpack(args[1]), unpack(args[2]), unpack(args[3]), unpack(args[4]), unpack(args[5]),
                                                 at::TensorList(settings), static_cast<int64_t>(reinterpret_cast<uintptr_t>(p)), meta, mass, nq);
-        PyObject* res = PyTuple_New(8);
+        PyObject* res = PyTuple_New(9);
         if (!res) return nullptr;
         // the constants of the record as the beam's tensors (views of one allocation, made here: ~0.5 us each against ~2 us from Python)
         const at::Tensor& rest = r[5];
         const int64_t N = r[1].size(0);
         if (!set_wrapped(res, 0, r[0]) || !set_wrapped(res, 1, r[1]) || !set_wrapped(res, 2, r[2]) || !set_wrapped(res, 7, r[6]) ||
+            !set_wrapped(res, 8, r[7]) ||
             !set_wrapped(res, 3, rest.narrow(0, 0, N)) || !set_wrapped(res, 4, rest.narrow(0, N, N)) || !set_wrapped(res, 5, rest.select(0, 2 * N)) ||
             !set_wrapped(res, 6, rest.select(0, 2 * N + 1))) {
             Py_DECREF(res);
@@ -673,6 +789,54 @@ PyObject* host_moment_entry_mapped(PyObject*, PyObject* const* args, Py_ssize_t 
     }
 }
 
+// run_moment_entry(energy, settings tuple, C, mom_x, partial sums | None, mom_y | None, element maps, meta, mass_eV, n_charges, index,
+//                  take_sqrt, N) -> (entry, mom_y)
+PyObject* host_run_moment_entry(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    if (nargs != 13) {
+        PyErr_SetString(PyExc_TypeError, "run_moment_entry takes 13 arguments");
+        return nullptr;
+    }
+    if (!PyTuple_Check(args[1]) || !PyList_Check(args[7])) {
+        PyErr_SetString(PyExc_TypeError, "run_moment_entry: settings as a tuple of tensors, meta as a list of ints");
+        return nullptr;
+    }
+    for (const int k : {0, 2, 3, 4, 5, 6})
+        if (!(THPVariable_Check(args[k]) || ((k == 4 || k == 5) && args[k] == Py_None))) {
+            PyErr_Format(PyExc_TypeError, "run_moment_entry: argument %d: a tensor is expected", k);
+            return nullptr;
+        }
+    for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(args[1]); ++i)
+        if (!THPVariable_Check(PyTuple_GET_ITEM(args[1], i))) {
+            PyErr_SetString(PyExc_TypeError, "run_moment_entry: settings as a tuple of tensors");
+            return nullptr;
+        }
+    return guarded([&]() -> PyObject* {
+        std::vector<at::Tensor> settings;
+        for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(args[1]); ++i) settings.push_back(unpack(PyTuple_GET_ITEM(args[1], i)));
+        std::vector<int64_t> meta(PyList_GET_SIZE(args[7]));
+        for (Py_ssize_t i = 0; i < PyList_GET_SIZE(args[7]); ++i) meta[i] = static_cast<int64_t>(PyLong_AsUnsignedLongLongMask(PyList_GET_ITEM(args[7], i)));
+        const double mass = PyFloat_AsDouble(args[8]), nq = PyFloat_AsDouble(args[9]);
+        const long long index = PyLong_AsLongLong(args[10]);
+        const int take_sqrt = PyObject_IsTrue(args[11]);
+        const long long N = PyLong_AsLongLong(args[12]);
+        if (PyErr_Occurred()) return nullptr;
+        TORCH_CHECK(static_cast<int64_t>(settings.size()) == (meta.size() >= 3 ? meta[2] : -1), "run_moment_entry: one tensor per distinct setting");
+        std::optional<at::Tensor> partials, mom_y;
+        if (args[4] != Py_None) partials = unpack(args[4]);
+        if (args[5] != Py_None) mom_y = unpack(args[5]);
+        variable_list r = RunMomentEntry::apply(unpack(args[0]), at::TensorList(settings), unpack(args[2]), unpack(args[3]), partials, mom_y,
+                                                unpack(args[6]), meta, mass, nq, static_cast<int64_t>(index), take_sqrt != 0,
+                                                static_cast<int64_t>(N));
+        PyObject* res = PyTuple_New(2);
+        if (!res) return nullptr;
+        if (!set_wrapped(res, 0, r[0]) || !set_wrapped(res, 1, r[1])) {
+            Py_DECREF(res);
+            return nullptr;
+        }
+        return res;
+    });
+}
+
 PyMethodDef methods[] = {
     {"any_requires_grad", any_requires_grad, METH_O, "any_requires_grad(tuple_of_tensors) -> bool (non-tensor items count as False)"},
     {"bind", host_bind, METH_VARARGS, "bind({libchx symbol: address}, error class)"},
@@ -688,6 +852,9 @@ PyMethodDef methods[] = {
      "[run | active Screen] as one differentiable node"},
     {"moment_entry_mapped", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_moment_entry_mapped)), METH_FASTCALL,
      "moment_entry_mapped(C, y, w | None, mom_x, mom_y | None, index, take_sqrt, partial sums | None) -> (entry, mom_y): one beam property of y = C x as a node on C"},
+    {"run_moment_entry", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(host_run_moment_entry)), METH_FASTCALL,
+     "run_moment_entry(energy, settings, C, mom_x, partial sums | None, mom_y | None, element maps, meta, mass_eV, n_charges, index, take_sqrt, N) "
+     "-> (entry, mom_y): one property of the screen's beam as ONE node on the run's settings"},
     {nullptr, nullptr, 0, nullptr}};
 
 struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_chxtorch", "torch-side host step of cheetah_amd (see chx_torch_host.cpp)", -1, methods};

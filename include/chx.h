@@ -35,11 +35,12 @@
 extern "C" {
 #endif
 
-#define CHX_ABI_VERSION 8 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
+#define CHX_ABI_VERSION 9 /* 2: ldz argument of chx_sc_igf / chx_sc_gradient; 3: post_map arguments of chx_sc_kick;
                              4: s_in / s_out arguments of chx_run_map / chx_run_track;
                              5: s_in / s_out arguments of chx_cavity_prepare_scalars / chx_cavity_track_scalars;
                              6: chx_lattice_track_diag (items of type 2 / 3 in the table of a lattice stretch);
-                             7: chx_lattice_track_screens / chx_parameter_lattice_track_screens (items of type 4: active Screens) */
+                             7: chx_lattice_track_screens / chx_parameter_lattice_track_screens (items of type 4: active Screens);
+                             8: chx_lattice_screen.mom_partials, chx_table_store; 9: chx_run_vjp_entry */
 
 typedef enum chx_status {
     CHX_OK = 0,
@@ -129,6 +130,17 @@ int chx_run_vjp(const int32_t* kinds, const void* const* param_ptrs, int64_t E, 
 int chx_run_vjp_masked(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
                        double n_charges, int dtype, const void* maps, const void* dT, const uint16_t* need, void* dinputs,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* ABI 9. The same when dL/d(composed map) comes from ONE property of the beam y = C x the run's map produced — entry `index` (2..28)
+ * of chx_moments(y) = mom_y[29], or its square root (`take_sqrt`), with the gradient grad[1] (`dtype`) — instead of a tensor dT:
+ * every wave of the builders' launch forms chx_moment_entry_mapped_bwd's 49 values itself (C[7][7] `dtype`: the composed map,
+ * mom_x[29]: the incoming beam's moments), rounded to `dtype` as that call writes them. The backward pass of
+ * d sigma_x(screen) / d k1 (tests/test_differentiable.py:10-32; screen.py:187-239, particle_beam.py:1672-1943) is then ONE launch.
+ * Runs of more than 16 elements fall back to the two launches. Workspace: chx_run_vjp_entry_workspace_bytes(E). */
+size_t chx_run_vjp_entry_workspace_bytes(int64_t E);
+int chx_run_vjp_entry(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                      double n_charges, int dtype, const void* maps, const uint16_t* need, const void* grad, const double* mom_y,
+                      int index, int take_sqrt, const void* C, const double* mom_x, void* dinputs, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* A merged run whose settings are VECTORISED over B lattice settings (segment.py:534-547 with (B,) parameters: a k1 scan, a batched
  * environment, an orbit response): all B composed maps R_out[B][7][7] in one launch — per row the element maps of chx_build_rmatrix
  * and the product of chx_compose_maps, bit-identical to those calls. batched[E][CHX_MAX_PARAMS]: 1 = the pointer addresses a

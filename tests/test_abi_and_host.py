@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
     exported = set(re.findall(r" T (chx_[a-z0-9_]+)", out))
     assert set(syms) <= exported, sorted(set(syms) - exported)
     assert set(syms) == set(L.SIGNATURES), (sorted(set(syms) ^ set(L.SIGNATURES)))
-    assert lib.chx_abi_version() == 8
+    assert lib.chx_abi_version() == 9
     assert lib.chx_kind_num_params(2) == 5 and lib.chx_kind_num_params(3) == 9 and lib.chx_kind_num_params(99) == -1
     assert lib.chx_status_string(-3) == b"misaligned buffer"
     # pure host-side queries (no device needed)

@@ -637,6 +637,53 @@ def test_moment_sums_of_the_recorded_beam(dt, n):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_property_of_the_record_is_one_node_on_the_settings(dt):
+    """Round 6: a beam property of the record of a [run | Screen] stretch hangs on the run's SETTINGS as one autograd node whose
+    backward is one launch (cheetah_amd._chxtorch RunMomentEntry -> chx_run_vjp_entry: the builders' VJP forms dL/dC from the
+    property's gradient itself) instead of on the composed map, whose node carried the gradient on (two nodes, two launches).
+    Same values, same gradients — a strength shared by two quadrupoles, a tilted one, a corrector angle; a second
+    property read from the memoised moments; a run longer than the fused kernel takes (two launches behind the same entry point)."""
+    import cheetah_amd as ca
+    from cheetah_amd import _ops
+
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    torch.manual_seed(3)
+    for extra_drifts in (0, 20):
+        k1, ang = torch.nn.Parameter(t(4.0)), torch.nn.Parameter(t(6e-5))
+        els = [ca.Drift(t(0.6), **fk), ca.Quadrupole(t(0.2), k1=k1, **fk), ca.Drift(t(0.4), **fk), ca.HorizontalCorrector(t(0.05), angle=ang, **fk),
+               ca.Quadrupole(t(0.15), k1=k1, tilt=t(0.05), misalignment=t([1e-4, -5e-5]), **fk), ca.Drift(t(0.8), **fk)]
+        els += [ca.Drift(t(0.01), **fk) for _ in range(extra_drifts)]
+        seg = ca.Segment(els + [ca.Screen(resolution=(64, 48), pixel_size=t([8e-5, 8e-5]), is_active=True, name="scr", **fk)])
+        base = ca.ParticleBeam.from_parameters(num_particles=30_000, sigma_x=t(2e-4), sigma_y=t(1.5e-4), sigma_px=t(2e-5), sigma_py=t(2e-5),
+                                               mu_x=t(1e-4), energy=t(9e7), **fk)
+        beam = base
+        got = {}
+        for one_node in (True, False):
+            _ops.ONE_NODE_PROPERTY[0] = one_node
+            try:
+                for prop in ("sigma_x", "sigma_y", "mu_x", "sigma_tau", "sigma_px"):
+                    for p in (k1, ang):
+                        p.grad = None
+                    seg.track(beam)
+                    rb = seg.scr.get_read_beam()
+                    v = getattr(rb, prop)
+                    assert ("RunMomentEntry" in v.grad_fn.name()) == one_node, v.grad_fn.name()
+                    second = rb.sigma_y if prop == "sigma_x" else None          # (from the memoised moments of the same record)
+                    (v if second is None else v + 2.0 * second).backward()
+                    got[(one_node, prop)] = (v.detach().clone(), k1.grad.clone(), ang.grad.clone())
+            finally:
+                _ops.ONE_NODE_PROPERTY[0] = True
+        rel = 1e-5 if dt == torch.float32 else 1e-11
+        for prop in ("sigma_x", "sigma_y", "mu_x", "sigma_tau", "sigma_px"):
+            a, b = got[(True, prop)], got[(False, prop)]
+            assert torch.equal(a[0], b[0]), prop
+            for ga, gb, name in zip(a[1:], b[1:], ("k1", "angle")):
+                assert torch.isfinite(ga).all() and abs(float(ga - gb)) <= rel * abs(float(gb)) + 1e-30, (extra_drifts, prop, name, float(ga), float(gb))
+            assert float(a[1]) != 0.0 or prop in ("sigma_tau",)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 def test_histogram_screen_rides_in_the_particle_pass(dt):
     """Round 6: the 'histogram' image (the ARES lattice file's default method; screen.py:292-311) is deposited by the stretch's
     particle pass like the cloud-in-cell one — torch.histogramdd's bin search on the edges torch.linspace gives (chx_hist2d's
