@@ -462,15 +462,20 @@ def other_configs(ca, torch, device, only=None) -> dict:
     def c5():
         r = rc.c5()
         # forward: apply 56 B + the Screen's record of the beam 36 + 28 B (same pass) + moments 32 B per particle ~ 144 B; backward: 7x7 algebra on the
-        # incoming beam's (memoised) moments — no particle pass (the particle-sized backward moved 144 B more)
+        # incoming beam's (memoised) moments — no particle pass (the particle-sized backward moved 144 B more). 144 B is the model every
+        # round's fraction was quoted on; since round 6 the record's moments come out of the particle pass itself, so the step MOVES
+        # 100 B per particle (rows 28 + charges, weights 8 in; rows 28, record 28 + 8 out): `moved_bytes` / `frac_of_moved_bytes`
         nbytes = 144.0 * N_PARTICLES
+        moved = 100.0 * N_PARTICLES
         res = {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
                "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "eager step: [run | Screen] is one differentiable node and the beam property another, both in C++ "
-                                    "(cheetah_amd._chxtorch); bound by the host: ~80 us forward + the autograd engine (60 us for a "
-                                    "one-node graph on these hosts, benchmarks/c5_variants.py) + two backward launches"}}
+                            "moved_bytes": moved, "frac_of_moved_bytes": moved / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "eager step: four launches (preparation, particle pass + the record's moment sums, finalize; backward: "
+                                    "the builders' VJP forming dL/dC itself) and ONE autograd node from sigma_x to k1, in C++ "
+                                    "(cheetah_amd._chxtorch RunMomentEntry); bound by the host: ~80 us forward + the autograd engine "
+                                    "(60 us for a one-node graph on these hosts, benchmarks/c5_variants.py)"}}
         # The same step captured once into a device graph (torch.cuda.CUDAGraph = hipGraph) and replayed: what an optimisation loop
         # that keeps its tensors in place can run. In a process of its own: a capture needs Parameters that have never seen a
         # backward pass on the default stream, and a failed capture must not take this line down.
@@ -488,7 +493,8 @@ def other_configs(ca, torch, device, only=None) -> dict:
                                    "loss_equals_eager": abs(g["loss"] - g["loss_eager"]) <= 1e-6 * abs(g["loss_eager"]),
                                    "grad_equals_eager": abs(g["grad"] - g["grad_eager"]) <= 1e-5 * abs(g["grad_eager"]),
                                    "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9,
-                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "moved_bytes": moved, "frac_of_moved_bytes": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                                    "note": "benchmarks/c5_graph.py: forward + backward captured after a warm-up on a side stream; k1 "
                                            "is updated in place between replays and the replayed kernels read it through its pointer"}
         except Exception as exc:  # noqa: BLE001
