@@ -1456,7 +1456,7 @@ class Segment(Element):
             # joins the side stream before the gather pass that applies the map. Off the main stream's critical path: 5 us
             # per kick. The side stream first waits for what the main stream did before the chain (first link: settings edited in
             # place, the beam) or to the plan's buffers (a plan built or refreshed in this very call).
-            side = kick._side_stream(p.device)
+            side = kick._chain_side_stream(p.device)
             stream = _ops.stream_ptr()
             if side is not None:
                 if first or fresh:

@@ -25,6 +25,10 @@ from .._cache import TensorKey
 from ..particles.particle_beam import ParticleBeam
 from .element import Element
 
+import os as _os
+
+_CHAIN_SIDE_STREAM = _os.environ.get("CHX_SC_CHAIN_SIDE_STREAM", "1") != "0"
+
 epsilon_0 = 8.8541878188e-12  # scipy.constants.epsilon_0 (CODATA 2022)
 speed_of_light = 299792458.0
 
@@ -44,6 +48,12 @@ class SpaceChargeKick(Element):
                 cls._plans.pop(next(iter(cls._plans)))
             plan = cls._plans[key] = _ops.ScFftPlan(B, g, dtype)
         return plan
+
+    @classmethod
+    def _chain_side_stream(cls, device):
+        """The stream a CHAIN kick puts its Green-function kernels (and the next run's map) on; None = the caller's own
+        (CHX_SC_CHAIN_SIDE_STREAM=0: an A/B switch, benchmarks/_c4_side_stream_ab.sh)."""
+        return cls._side_stream(device) if _CHAIN_SIDE_STREAM else None
 
     @classmethod
     def _side_stream(cls, device):
@@ -222,7 +232,7 @@ class SpaceChargeKick(Element):
         # minimum, a guard that switched its plan back) tracks kick by kick, and both see the same grid
         return _ops.sc_kick_sorted(x, q, w, incoming.energy.to(dtype).reshape(1), self.effect_length.to(dtype).reshape(1),
                                    self._grid_extent(dtype), incoming.species.mass_eV_float, N, self.grid_shape, state, first, last,
-                                   side_stream=self._side_stream(device), post_map_ptr=post_map_ptr,
+                                   side_stream=self._chain_side_stream(device), post_map_ptr=post_map_ptr,
                                    group=sharding.active_group(), index=index)
 
     def _track_particle_sharded(self, incoming, group, x, q, w, energy, L, out_shape, B, N) -> ParticleBeam:

@@ -11,6 +11,22 @@
 
 #include "chx.h"
 #include "chx_sc_tiles.h"
+
+
+// Flags of the events that order the kick's two streams. Both streams belong to one device, the events are created, recorded, waited for
+// and destroyed inside one call and never inspected by the host, and what crosses between the streams is device memory written by
+// kernels that have ENDED (their own end-of-kernel release made it visible to the device; the waiting stream's next kernel acquires
+// at its start): the system-scope fence an event record carries by default — a cache write-back and invalidation in front of the
+// kernel that follows it — buys nothing here and cost 2.4 % of a C4 track (1.86-1.88 -> 1.82-1.84 ms, benchmarks/_c4_event_ab.sh).
+// CHX_TUNE_EVENT_FLAGS: 0 = the default system-scope fence, 1 = hipEventReleaseToDevice, 2 (default) = hipEventDisableSystemFence.
+static unsigned sc_event_flags() {
+    static const unsigned flags = [] {
+        const char* e = getenv("CHX_TUNE_EVENT_FLAGS");
+        const int v = e ? atoi(e) : 2;
+        return (unsigned)hipEventDisableTiming | (v == 1 ? (unsigned)hipEventReleaseToDevice : v == 2 ? (unsigned)hipEventDisableSystemFence : 0u);
+    }();
+    return flags;
+}
 #include "chx_sc_geom_dev.h"
 
 namespace {
@@ -112,8 +128,8 @@ extern "C" int chx_sc_kick(const void* x_in, const void* charge, const void* sur
     hipEvent_t fork = nullptr, join = nullptr;
     const bool forked = side != main;
     if (forked) {
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&fork, sc_event_flags()) != hipSuccess ||
+            hipEventCreateWithFlags(&join, sc_event_flags()) != hipSuccess)
             return CHX_ERR_LAUNCH;
         (void)hipEventRecord(fork, main);
         (void)hipStreamWaitEvent(side, fork, 0);
@@ -279,7 +295,7 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
     const bool forked = side != main;
     if (forked) {
         hipEvent_t fork = nullptr;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return CHX_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&fork, sc_event_flags()) != hipSuccess) return CHX_ERR_LAUNCH;
         (void)hipEventRecord(fork, main);
         (void)hipStreamWaitEvent(side, fork, 0);
         (void)hipEventDestroy(fork);
@@ -301,7 +317,7 @@ extern "C" int chx_sc_kick_sorted_begin(const void* x_in, const void* charge, co
     }
     if (rc != CHX_OK && forked) {                           // an error path still rejoins the side stream
         hipEvent_t join = nullptr;
-        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventCreateWithFlags(&join, sc_event_flags()) == hipSuccess) {
             (void)hipEventRecord(join, side);
             (void)hipStreamWaitEvent(main, join, 0);
             (void)hipEventDestroy(join);
@@ -324,7 +340,7 @@ extern "C" int chx_sc_kick_sorted_finish(const void* x_in, const void* energy, d
     hipEvent_t join = nullptr;
     const bool forked = side != main;
     if (forked) {
-        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return CHX_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&join, sc_event_flags()) != hipSuccess) return CHX_ERR_LAUNCH;
         (void)hipEventRecord(join, side);                 // behind the Green spectrum `begin` put on the side stream
     }
     // the charge sits in the chain's accumulation grid (state); the convolution's first pass leaves it zeroed for the next kick
