@@ -468,7 +468,8 @@ def other_configs(ca, torch, device, only=None) -> dict:
         nbytes = 144.0 * N_PARTICLES
         moved = 100.0 * N_PARTICLES
         res = {"workload": "C5: d sigma_x(screen)/d k1, [Drift, Quad(k1), Drift, Screen], 1e6 particles, fp32, fwd+bwd",
-               "ms_fwd_bwd": r["fwd_bwd_ms"], "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
+               "ms_fwd_bwd": r["fwd_bwd_ms"], "ms_fwd_bwd_first_50_steps": r.get("fwd_bwd_ms_first_50_steps"),
+               "steps_timed": r.get("steps_timed"), "sigma_x": r["sigma_x"], "dsigma_x_dk1": r["dk1"],
                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "moved_bytes": moved, "frac_of_moved_bytes": moved / (r["fwd_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
