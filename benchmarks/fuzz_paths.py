@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Differential fuzz of `Segment.track`'s fast paths: drawn flat lattices (linear elements with scalar or (B,) settings, upright and
+rotated quadrupoles, dipoles, correctors, solenoids, active cavities, active monitors, apertures and screens, second-order and
+drift-kick-drift elements) tracked by `Segment.track` — one-call stretches, merged runs, chains in registers — against the same
+elements tracked ONE BY ONE through their own `track` (the path the reference-generated goldens pin). Compared: outgoing particles,
+survival probabilities, energy, path length, every monitor's reading, every screen's reading.
+
+usage: python benchmarks/fuzz_paths.py [n_cases] [first_seed]        prints one line per failing case and a summary; exit code 1 on a failure
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cheetah_amd as ca  # noqa: E402
+
+
+def draw_lattice(rng, fk, B):
+    """(elements for Segment.track, a second, independent copy for the walk): B = 0: scalar settings, else some settings are (B,)."""
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+
+    def setting(lo, hi, vector_ok=True):
+        if B and vector_ok and rng.random() < 0.35:
+            return rng.uniform(lo, hi, size=B).tolist()
+        return float(rng.uniform(lo, hi))
+
+    specs = []
+    n = int(rng.integers(2, 14))
+    nonlinear = rng.random() < 0.25 and not B
+    with_cavity = rng.random() < 0.3
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.3:
+            specs.append(("Drift", {"length": float(rng.uniform(0.05, 1.0))}))
+        elif r < 0.55:
+            kw = {"length": float(rng.uniform(0.05, 0.4)), "k1": setting(-12.0, 12.0)}
+            if rng.random() < 0.3:
+                kw["tilt"] = setting(-0.3, 0.3)
+            if rng.random() < 0.3:
+                kw["misalignment"] = [float(rng.normal() * 1e-4), float(rng.normal() * 1e-4)]
+            if nonlinear and rng.random() < 0.5:
+                kw["tracking_method"] = str(rng.choice(["second_order", "drift_kick_drift"]))
+            specs.append(("Quadrupole", kw))
+        elif r < 0.63:
+            specs.append(("HorizontalCorrector", {"length": float(rng.uniform(0.02, 0.1)), "angle": setting(-2e-4, 2e-4)}))
+        elif r < 0.7:
+            specs.append(("VerticalCorrector", {"length": float(rng.uniform(0.02, 0.1)), "angle": setting(-2e-4, 2e-4)}))
+        elif r < 0.76:
+            kw = {"length": float(rng.uniform(0.2, 0.8)), "angle": float(rng.uniform(-0.2, 0.2))}
+            if rng.random() < 0.5:
+                kw.update(dipole_e1=float(rng.uniform(-0.1, 0.1)), dipole_e2=float(rng.uniform(-0.1, 0.1)))
+            if rng.random() < 0.3:
+                kw["tilt"] = float(rng.uniform(-0.2, 0.2))
+            specs.append(("Dipole", kw))
+        elif r < 0.8:
+            specs.append(("Solenoid", {"length": float(rng.uniform(0.1, 0.4)), "k": float(rng.uniform(-2.0, 2.0))}))
+        elif r < 0.86:
+            specs.append(("BPM", {"is_active": bool(rng.random() < 0.8)}))
+        elif r < 0.9:
+            specs.append(("Aperture", {"x_max": float(rng.uniform(2e-4, 2e-3)), "y_max": float(rng.uniform(2e-4, 2e-3)),
+                                       "shape": str(rng.choice(["rectangular", "elliptical"])), "is_active": bool(rng.random() < 0.8)}))
+        elif r < 0.95 and with_cavity:
+            specs.append(("Cavity", {"length": float(rng.uniform(0.3, 1.0)), "voltage": setting(1e6, 2e7), "phase": setting(-60.0, 60.0),
+                                     "frequency": 1.3e9, "cavity_type": str(rng.choice(["standing_wave", "traveling_wave"]))}))
+        else:
+            specs.append(("Marker", {}))
+    if rng.random() < 0.6 and not B:
+        specs.insert(int(rng.integers(1, len(specs) + 1)),
+                     ("Screen", {"resolution": [int(rng.integers(16, 80)), int(rng.integers(16, 80))], "pixel_size": [6e-5, 5e-5],
+                                 "method": str(rng.choice(["cloud-in-cell", "histogram"])), "is_active": True,
+                                 "misalignment": [float(rng.normal() * 5e-5), 0.0] if rng.random() < 0.3 else [0.0, 0.0]}))
+
+    def build():
+        out = []
+        for kind, kw in specs:
+            args = {}
+            for k, v in kw.items():
+                args[k] = t(v) if isinstance(v, (float, list)) and k not in ("resolution",) else v
+            cls = getattr(ca, kind)
+            out.append(cls(**args, **fk) if kind != "Drift" else cls(args["length"], **fk))
+        return out
+
+    return specs, build(), build()
+
+
+def compare(a, b, tol, what, fails, scale=None):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    if a.shape != b.shape:
+        fails.append(f"{what}: shapes {tuple(a.shape)} vs {tuple(b.shape)}")
+        return
+    a64, b64 = a.double(), b.double()
+    both_nan = torch.isnan(a64) & torch.isnan(b64)
+    ref = b64.abs().amax() if scale is None else scale
+    err = ((a64 - b64).abs().masked_fill(both_nan, 0.0) / (ref + 1e-300)).amax() if a.numel() else torch.tensor(0.0)
+    if not bool(err <= tol):
+        fails.append(f"{what}: {float(err):.3e} of the largest entry (allowed {tol:.1e})")
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    dt = torch.float64 if rng.random() < 0.5 else torch.float32
+    fk = {"dtype": dt, "device": "cuda"}
+    B = int(rng.choice([0, 0, 3, 17]))
+    specs, els_a, els_b = draw_lattice(rng, fk, B)
+    n = int(rng.choice([37, 1000, 4097, 30000]))
+    torch.manual_seed(seed)
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(3e-4), sigma_y=t(2e-4), sigma_px=t(3e-5), sigma_py=t(2e-5),
+                                           mu_x=t(float(rng.normal() * 1e-4)), energy=t(float(rng.uniform(2e7, 3e8))), **fk)
+    if rng.random() < 0.4:
+        beam.survival_probabilities = (0.2 + 0.8 * torch.rand(n, **fk))
+    if rng.random() < 0.25 and n <= 4097 and not any(k == "Screen" for k, _ in specs):
+        # a vectorised beam: (Bb, N, 7) particles (the lattice's (B,) settings broadcast against it), sometimes its own energies
+        Bb = B if B else 2
+        shift = torch.linspace(-1e-4, 1e-4, Bb, **fk).reshape(Bb, 1, 1) * torch.tensor([1.0, 0, 0.5, 0, 0, 0, 0], **fk)
+        energy = beam.energy * torch.linspace(0.9, 1.1, Bb, **fk) if rng.random() < 0.4 else beam.energy
+        beam = ca.ParticleBeam(beam.particles.unsqueeze(0) + shift, energy, particle_charges=beam.particle_charges,
+                               survival_probabilities=beam.survival_probabilities, **fk)
+    fails = []
+    seg = ca.Segment(els_a)
+    mode = rng.random()
+    if mode < 0.2 and not B:
+        gradients(rng, seg, els_a, els_b, beam, dt, fails)
+        return specs, dt, B, n, fails
+    if mode < 0.35 and not any(kw.get("tracking_method") for _, kw in specs):      # (non-linear methods refuse a ParameterBeam, as the reference's do)
+        moments_beam(seg, els_a, els_b, beam, dt, fails)
+        return specs, dt, B, n, fails
+    for round_ in range(int(rng.integers(1, 4))):
+        if round_:
+            mutate(rng, els_a, els_b, fk)
+        check(seg, els_a, els_b, beam, dt, fails, f"track {round_}: ")
+        if fails:
+            break
+    return specs, dt, B, n, fails
+
+
+def gradients(rng, seg, els_a, els_b, beam, dt, fails):
+    """Scalar settings as Parameters on both copies: a loss on the outgoing particles, on a beam property and (when there is one) on
+    the screen's image — the gradients of the two ways of tracking."""
+    pa, pb = [], []
+    for ea, eb in zip(els_a, els_b):
+        for name in ("k1", "angle", "voltage", "phase"):
+            if isinstance(ea, ca.Dipole) or not hasattr(ea, name) or getattr(ea, name).dim() != 0:
+                continue
+            if rng.random() < 0.6:
+                va = torch.nn.Parameter(getattr(ea, name).detach().clone())
+                vb = torch.nn.Parameter(va.detach().clone())
+                setattr(ea, name, va)
+                setattr(eb, name, vb)
+                pa.append(va)
+                pb.append(vb)
+    if not pa:
+        return
+    n = beam.particles.shape[-2]
+    W = torch.linspace(-1.0, 1.0, n * 7, dtype=dt, device="cuda").reshape(n, 7).cos()
+    which = rng.random()
+    screens = [(ea, eb) for ea, eb in zip(els_a, els_b) if isinstance(ea, ca.Screen)]
+
+    def loss_of(out, scr):
+        if which < 0.4:
+            return (out.particles * W).sum() / n
+        if which < 0.8 or not screens:
+            return (out.sigma_x + 0.5 * out.sigma_y + out.mu_x).sum()
+        return (scr.reading * scr.reading).sum() * 1e20 if scr.method == "cloud-in-cell" else scr.get_read_beam().sigma_x
+
+    la = loss_of(seg.track(beam), screens[0][0] if screens else None)
+    ref = beam
+    for e in els_b:
+        ref = e.track(ref)
+    lb = loss_of(ref, screens[0][1] if screens else None)
+    if la.requires_grad != lb.requires_grad:
+        fails.append(f"loss requires_grad {la.requires_grad} vs {lb.requires_grad}")
+        return
+    if not lb.requires_grad:                 # (every Parameter sits behind the screen the loss reads)
+        return
+    la.backward()
+    lb.backward()
+    rel = 1e-8 if dt == torch.float64 else 2e-3
+    eps = (1e-13 if dt == torch.float64 else 1e-5) * abs(float(lb.detach()))      # rounding of a gradient that is zero analytically
+    compare(la.detach(), lb.detach(), 1e-10 if dt == torch.float64 else 1e-4, "loss", fails)
+    gmax = max(float(p.grad.abs()) if p.grad is not None else 0.0 for p in pb) + 1e-300
+    for k, (va, vb) in enumerate(zip(pa, pb)):
+        ga = va.grad if va.grad is not None else torch.zeros_like(va)
+        gb = vb.grad if vb.grad is not None else torch.zeros_like(vb)
+        if not abs(float(ga) - float(gb)) <= rel * max(abs(float(gb)), 1e-3 * gmax) + eps / max(abs(float(vb.detach())), 1e-3):
+            fails.append(f"gradient {k}: {float(ga):.6e} vs {float(gb):.6e} (loss kind {which:.2f})")
+
+
+def moments_beam(seg, els_a, els_b, beam, dt, fails):
+    """The same lattice on a ParameterBeam: Segment.track against the elements one by one."""
+    pb = beam.as_parameter_beam()
+    out = seg.track(pb)
+    ref = pb
+    for e in els_b:
+        ref = e.track(ref)
+    tol = 1e-10 if dt == torch.float64 else 1e-4
+    compare(out.mu, ref.mu, tol, "mu", fails)
+    compare(out.cov, ref.cov, tol, "cov", fails)
+    compare(out.energy, ref.energy, 1e-12 if dt == torch.float64 else 2e-7, "energy", fails)
+    for ea, eb in zip(els_a, els_b):
+        if isinstance(ea, ca.BPM) and ea.is_active:
+            compare(ea.reading, eb.reading, tol, "BPM reading", fails, scale=torch.tensor(3e-4))
+        if isinstance(ea, ca.Screen):
+            compare(ea.reading, eb.reading, 1e-8 if dt == torch.float64 else 1e-3, "screen reading", fails)
+
+
+def mutate(rng, els_a, els_b, fk):
+    """Between two tracks of the same Segment: settings edited in place, assigned as new tensors, diagnostics switched — the same on
+    both copies (the plans `Segment.track` keeps must follow)."""
+    for ea, eb in zip(els_a, els_b):
+        r = rng.random()
+        if isinstance(ea, ca.Quadrupole) and r < 0.5:
+            f = float(rng.uniform(0.5, 1.5))
+            if rng.random() < 0.5:
+                with torch.no_grad():
+                    ea.k1.mul_(f)
+                    eb.k1.mul_(f)
+            else:
+                ea.k1 = ea.k1 * f
+                eb.k1 = eb.k1 * f
+        elif isinstance(ea, (ca.HorizontalCorrector, ca.VerticalCorrector)) and r < 0.5:
+            v = torch.tensor(float(rng.uniform(-2e-4, 2e-4)), **fk)
+            if ea.angle.dim() == 0:
+                ea.angle = v
+                eb.angle = v.clone()
+        elif isinstance(ea, ca.BPM) and r < 0.3:
+            ea.is_active = eb.is_active = not ea.is_active
+        elif isinstance(ea, ca.Cavity) and r < 0.4:
+            with torch.no_grad():
+                ea.phase.add_(5.0)
+                eb.phase.add_(5.0)
+        elif isinstance(ea, ca.Drift) and r < 0.1:
+            f = float(rng.uniform(0.8, 1.2))
+            ea.length = ea.length * f
+            eb.length = eb.length * f
+
+
+def check(seg, els_a, els_b, beam, dt, fails, tag):
+    n0 = len(fails)
+    out = seg.track(beam)
+    ref = beam
+    for e in els_b:
+        ref = e.track(ref)
+    tol = 2e-11 if dt == torch.float64 else 3e-5
+    cols = out.particles.double().abs().reshape(-1, 7).amax(dim=0)
+    if out.particles.shape != ref.particles.shape:
+        fails.append(f"particles: shapes {tuple(out.particles.shape)} vs {tuple(ref.particles.shape)}")
+    else:
+        d = (out.particles.double() - ref.particles.double()).abs().reshape(-1, 7).amax(dim=0) / (cols + 1e-300)
+        if not bool((d <= tol).all()):
+            fails.append(f"particles: per-column error {[f'{float(v):.2e}' for v in d]} (allowed {tol:.1e})")
+    compare(out.survival_probabilities, ref.survival_probabilities, tol, "survival", fails, scale=torch.tensor(1.0))
+    compare(out.energy, ref.energy, 1e-12 if dt == torch.float64 else 2e-7, "energy", fails)
+    compare(out.s, ref.s, 1e-12 if dt == torch.float64 else 1e-6, "s", fails)
+    for ea, eb in zip(els_a, els_b):
+        if isinstance(ea, ca.BPM) and ea.is_active:
+            compare(ea.reading, eb.reading, tol, "BPM reading", fails, scale=torch.tensor(3e-4))
+        if isinstance(ea, ca.Screen):
+            ra, rb = ea.reading, eb.reading
+            if ea.method == "histogram" and dt == torch.float32:
+                # a float32 row that lands within rounding of a bin edge falls into the neighbouring pixel on one of the two paths
+                # (a composed map against the elements' maps one by one): a few pixels may trade one particle
+                differing = int(((ra.double() - rb.double()).abs() > 2e-4 * rb.double().abs().amax()).sum())
+                if differing > 8 or abs(float(ra.double().sum() - rb.double().sum())) > 1e-5 * abs(float(rb.double().sum())):
+                    fails.append(f"histogram screen reading: {differing} pixels differ")
+            else:
+                compare(ra, rb, 1e-9 if dt == torch.float64 else 2e-4, "screen reading", fails)
+    fails[n0:] = [tag + f for f in fails[n0:]]
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    from cheetah_amd.accelerator import _planner
+
+    for seed in range(first, first + n_cases):
+        try:
+            specs, dt, B, n, fails = one_case(seed)
+        except Exception as exc:  # noqa: BLE001
+            specs, dt, B, n, fails = None, None, None, None, [f"raised {type(exc).__name__}: {str(exc)[:300]}"]
+        if fails:
+            bad += 1
+            print(f"seed {seed} dtype {dt} B {B} N {n}: " + "; ".join(fails))
+            if specs is not None:
+                print("   lattice: " + " ".join(k + (("[" + v.get("tracking_method", "") + "]") if v.get("tracking_method") else "") for k, v in specs))
+    print(f"{n_cases - bad} of {n_cases} cases agree; paths taken: { {k: v for k, v in _planner.TAKEN.items() if v} }")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
