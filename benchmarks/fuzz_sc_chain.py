@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the space-charge chain: drawn lattices [linear run, SpaceChargeKick]+ (strong and weak focusing: beams that keep
+their tile order and beams that reshuffle between kicks), tracked by `Segment.track` (the tile-ordered chain with its riders and
+re-ordering decisions) against the same elements tracked one by one (every kick an isolated `chx_sc_kick`). Compared: the outgoing
+particles, column by column, relative to the size of the change the lattice makes to that column.
+
+usage: python benchmarks/fuzz_sc_chain.py [n_cases] [first_seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cheetah_amd as ca  # noqa: E402
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    dt = torch.float32 if rng.random() < 0.7 else torch.float64
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+    g = int(rng.choice([16, 32, 64]))
+    grid = (g, g, g) if rng.random() < 0.7 else (g, int(rng.choice([16, 32])), int(rng.choice([32, 64])))
+    kicks = int(rng.integers(2, 7))
+    strength = float(rng.choice([0.5, 4.0, 25.0]))          # 25: the beam goes through a focus between kicks (rows change tiles)
+
+    def build():
+        els = []
+        for i in range(kicks):
+            els.append(ca.Drift(t(float(rng2.uniform(0.05, 0.3))), **fk))
+            if rng2.random() < 0.8:
+                els.append(ca.Quadrupole(t(float(rng2.uniform(0.05, 0.2))), k1=t(float(rng2.uniform(-1, 1)) * strength), **fk))
+            if rng2.random() < 0.3:
+                els.append(ca.HorizontalCorrector(t(0.05), angle=t(float(rng2.normal() * 1e-4)), **fk))
+            els.append(ca.SpaceChargeKick(t(float(rng2.uniform(0.05, 0.3))), grid_shape=grid, **fk))
+        if rng2.random() < 0.5:
+            els.append(ca.Drift(t(0.2), **fk))
+        return els
+
+    rng2 = np.random.default_rng(seed + 10**6)
+    els_a = build()
+    rng2 = np.random.default_rng(seed + 10**6)
+    els_b = build()
+    n = int(rng.choice([20_000, 100_000, 400_000]))
+    torch.manual_seed(seed)
+    if rng.random() < 0.5:
+        beam = ca.ParticleBeam.uniform_3d_ellipsoid(num_particles=n, total_charge=t(float(rng.uniform(1e-10, 2e-9))), energy=t(float(rng.uniform(5e6, 2.5e8))),
+                                                    radius_x=t(1e-3), radius_y=t(0.7e-3), radius_tau=t(1e-3), sigma_px=t(2e-6), sigma_py=t(2e-6),
+                                                    sigma_p=t(1e-6), **fk)
+    else:
+        beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(4e-4), sigma_y=t(3e-4), sigma_tau=t(5e-4), sigma_px=t(1e-5), sigma_py=t(1e-5),
+                                               total_charge=t(float(rng.uniform(1e-10, 2e-9))), energy=t(float(rng.uniform(5e6, 2.5e8))), **fk)
+    if rng.random() < 0.3:
+        beam.survival_probabilities = 0.3 + 0.7 * torch.rand(n, **fk)
+    fails = []
+    from cheetah_amd.accelerator import _planner
+
+    before = _planner.TAKEN["space_charge_chain"]
+    seg = ca.Segment(els_a)
+    out = None
+    for _ in range(int(rng.integers(1, 3))):              # (a second track: the chain's guard has seen the first one's header)
+        out = seg.track(beam)
+    chained = _planner.TAKEN["space_charge_chain"] - before
+    ref = beam
+    for e in els_b:
+        ref = e.track(ref)
+    x0, a, b = beam.particles.double(), out.particles.double(), ref.particles.double()
+    change = (b - x0).abs().amax(dim=0) + 1e-300
+    tol = 2e-3 if dt == torch.float32 else 1e-7
+    # (a column the lattice hardly changes — tau of a relativistic beam — may differ by a few roundings of its own values)
+    allowed = tol * change + 4 * torch.finfo(dt).eps * b.abs().amax(dim=0)
+    err = (a - b).abs().amax(dim=0) / change
+    if not bool(((a - b).abs().amax(dim=0) <= allowed).all()) or not bool(torch.isfinite(a).all()):
+        fails.append(f"columns {[f'{float(v):.1e}' for v in err]} of the lattice's change (allowed {tol:.0e}); chain links taken {chained}")
+    return (grid, kicks, strength, chained), dt, n, fails
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = chained_cases = 0
+    for seed in range(first, first + n_cases):
+        try:
+            info, dt, n, fails = one_case(seed)
+            chained_cases += info[3] > 0
+        except Exception as exc:  # noqa: BLE001
+            info, dt, n, fails = None, None, None, [f"raised {type(exc).__name__}: {str(exc)[:300]}"]
+        if fails:
+            bad += 1
+            print(f"seed {seed} {dt} N {n} {info}: " + "; ".join(fails))
+    print(f"{n_cases - bad} of {n_cases} cases agree ({chained_cases} of them took the chain)")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -27,3 +27,22 @@ def test_drawn_lattices_fast_paths_equal_the_walk(first):
             if fails:
                 bad.append((seed, str(dt), B, n, fails, [k for k, _ in specs]))
     assert not bad, bad
+
+
+def test_drawn_space_charge_lattices_chain_equals_the_walk():
+    """benchmarks/fuzz_sc_chain.py: [linear run, SpaceChargeKick]+ lattices — beams that keep their tile order and beams that go through
+    a focus between kicks — through `Segment.track` (the tile-ordered chain) and kick by kick (3600 seeds agreed in round 6)."""
+    import warnings
+
+    import fuzz_sc_chain
+
+    bad, chained = [], 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed in range(60):
+            info, dt, n, fails = fuzz_sc_chain.one_case(seed)
+            chained += info[3] > 0
+            if fails:
+                bad.append((seed, str(dt), n, info, fails))
+    assert not bad, bad
+    assert chained >= 20          # (the sweep is about the chain: most of its cases must take it)
