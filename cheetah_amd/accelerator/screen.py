@@ -141,14 +141,14 @@ class Screen(Element):
             return ()                                   # (trainable geometry: never deposited ahead)
         return (self.resolution, self.binning, self.method, id(ps), ps._version, id(mis), mis._version, mis.dtype, mis.device)
 
-    def _record_stretch(self, record, n: int, species, image, kind: str = "particles") -> None:
+    def _record_stretch(self, record, n: int, species, image, kind: str = "particles", lead: tuple = ()) -> None:
         """Called by the stretch call of `Segment.track` (`chx_lattice_track_screens` / `chx_parameter_lattice_track_screens`):
         `record` is ONE tensor holding the copy of the beam that reached this screen ([rows | charges | survival | energy | s] of
         n particles, or [mu | cov | energy | s | total charge]), `image` the reading deposited by the same call (or None). The
         beam object is built when somebody asks for it."""
         d = self.__dict__
         d["_incoming"] = None
-        d["_record"] = (record, n, species, kind)
+        d["_record"] = (record, n, species, kind, lead)      # (lead: the vector dims of a vectorised beam — its beams one behind the other)
         d["_read_beam"] = None
         mis = self._buffers["misalignment"]
         d["_placed"] = (mis.dtype, mis.device)
@@ -162,10 +162,11 @@ class Screen(Element):
         if beam is None:
             rec = d.get("_record")
             if rec is not None:
-                t, n, species, kind = rec
+                t, n, species, kind, lead = rec
                 if kind == "particles":
-                    beam = ParticleBeam(t[:7 * n].view(n, 7), t[9 * n], particle_charges=t[7 * n:8 * n],
-                                        survival_probabilities=t[8 * n:9 * n], s=t[9 * n + 1], species=species)
+                    m = n * _ops.numel(lead)
+                    beam = ParticleBeam(t[:7 * m].view(lead + (n, 7)), t[9 * m], particle_charges=t[7 * m:8 * m].view(lead + (n,)),
+                                        survival_probabilities=t[8 * m:9 * m].view(lead + (n,)), s=t[9 * m + 1], species=species)
                 elif kind == "particles_grad":
                     # the differentiable stretch (cheetah_amd._chxtorch RunScreenTrack): the rows are an output of the node, y = C x
                     # with x free of gradients — a beam property of them hangs on C (`_LinearSource`)

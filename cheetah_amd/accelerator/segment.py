@@ -745,7 +745,7 @@ class Segment(Element):
         # chain, the stretch call, runs ahead of / made of non-linear elements, the merged run, kick + run, the element's own track)
         return _planner.walk_particles(self, self._plan(), incoming)
 
-    def _lattice_stretch(self, plan, i: int, incoming: ParticleBeam):
+    def _lattice_stretch(self, plan, i: int, incoming: ParticleBeam, allow_screens: bool = True):
         """plan[i] and the items behind it as ONE `chx_lattice_track` call when they form a stretch [run | active Cavity]+ (at
         least two items, at least one cavity) of scalar settings and the beam is one plain beam without a graph: (outgoing beam,
         index behind the stretch), else None. Same numbers, bit for bit, as the walk item by item."""
@@ -754,9 +754,11 @@ class Segment(Element):
             cache = self._lattice_cache_for(plan)
         p = incoming.particles
         e = incoming.energy
-        # ONE plain beam at one energy: active Screens are items of the stretch too (their record and image come from the same two
-        # launches); a vectorised beam's stretch ends in front of a screen as before
-        with_screens = Segment._STRETCH_SCREENS and p.dim() == 2 and e.dim() == 0
+        # one energy: active Screens are items of the stretch too (their record and image come from the same two launches) — for one
+        # plain beam and for a vectorised one (B beams under the one lattice setting: every record and image holds B of them). Where
+        # the screens' host step does not apply after all (vectorised settings, charges per beam, ...) the stretch is taken again
+        # without them: it then ends in front of the first screen (`allow_screens` False)
+        with_screens = allow_screens and Segment._STRETCH_SCREENS and p.dim() >= 2 and e.dim() == 0
         key = (i, p.dtype, p.device, with_screens)
         entry = cache[1].get(key)
         if entry is None:
@@ -843,11 +845,12 @@ class Segment(Element):
             # [run | cavity | monitor | aperture | active Screen]+ on one plain beam: the C++ host step (cheetah_amd._chxtorch)
             # allocates the outgoing beam, every screen's record and image and enqueues the two launches
             q, w = incoming.particle_charges, incoming.survival_probabilities
-            N = p.shape[0]
-            if lead or Bm != 1 or not on_device or q.shape != (N,) or w.shape != (N,) or q.dtype != p.dtype or w.dtype != p.dtype \
-                    or q.device != p.device or w.device != p.device or not q.is_contiguous() or not w.is_contiguous() \
-                    or (torch.is_grad_enabled() and (q.requires_grad or w.requires_grad)):
-                return None       # (charges or weights the screens' host step does not take: the walk, as before)
+            if Bm != 1 or not on_device or q.shape != (N,) or (w.shape != (N,) and tuple(w.shape) != lead + (N,)) or q.dtype != p.dtype \
+                    or w.dtype != p.dtype or q.device != p.device or w.device != p.device or not q.is_contiguous() or not w.is_contiguous() \
+                    or (torch.is_grad_enabled() and (q.requires_grad or w.requires_grad)) or (lead and grad_run is not None) \
+                    or (lead and any(scr.method != "cloud-in-cell" for scr in lp.screens)):      # (screen.py:292-294: the others refuse vectorised beams)
+                # (settings, charges or weights the screens' host step does not take: the stretch without its screens)
+                return self._lattice_stretch(plan, i, incoming, allow_screens=False)
             if grad_run is not None:
                 run, fr = grad_run
                 out, rows, C, q_at, w_at, e_at, s_at, sums, maps = _TORCH_HOST.run_screen_track(
@@ -868,21 +871,25 @@ class Segment(Element):
             readings = ws = None
             ws_bytes = 0
             if n_bpm:
-                readings = torch.empty((n_bpm, 1, 2), dtype=p.dtype, device=p.device)
-                ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, 1, n_bpm)
+                readings = torch.empty((n_bpm, B, 2), dtype=p.dtype, device=p.device)
+                ws_bytes = _lib.lib().chx_lattice_diag_workspace_bytes(N, B, n_bpm)
                 ws = _ops.workspace(ws_bytes, p.device)
             if lp.apertures:
-                w_out = torch.empty((N,), dtype=p.dtype, device=p.device)
+                w_out = torch.empty(lead + (N,), dtype=p.dtype, device=p.device)
             from .screen import Screen
 
+            # (a vectorised beam goes in as (B, N, 7): the beams of a (2, 3, N, 7) array one behind the other)
             out, e_out, s_out, records, images = _TORCH_HOST.lattice_track_screens(
-                lp.capsule_s, x, e, s_in, q, w, sp.mass_eV_float, sp.num_elementary_charges_float, lp.device.index,
-                Screen._EAGER_IMAGE_PARTICLES, w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes)
+                lp.capsule_s, x.reshape(B, N, 7) if lead else x, e, s_in, q, w, sp.mass_eV_float, sp.num_elementary_charges_float,
+                lp.device.index, Screen._EAGER_IMAGE_PARTICLES, w_out if lp.apertures else None, n_bpm, readings, ws, ws_bytes)
             for k, bpm in enumerate(lp.bpms):
-                bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(2)
+                bpm.__dict__["_buffers"]["reading"] = readings[k].reshape(lead + (2,))
             for screen, record, image in zip(lp.screens, records, images):
-                screen._record_stretch(record, N, sp, image)
-            return ParticleBeam(out, e_out, particle_charges=q, survival_probabilities=w_out, s=s_out, species=sp), i + lp.count
+                if lead and image is not None:
+                    image = image.reshape(lead + tuple(image.shape[-2:]))
+                screen._record_stretch(record, N, sp, image, lead=lead)
+            return ParticleBeam(out.reshape(p.shape) if lead else out, e_out, particle_charges=q, survival_probabilities=w_out, s=s_out,
+                                species=sp), i + lp.count
         if lp.bpms or lp.apertures or lead:
             # active BPMs / apertures in the stretch (chx_lattice_track_diag): the particle pass leaves the weighted sums of x and
             # y at every monitor (one more launch forms all readings) and thins the survival probabilities at every aperture —

@@ -833,7 +833,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     screen_extent_axis<T>((int)ptrs[q + 3], ps[1], ly, ry);
                     const T mx = mis[0], my = mis[1];
                     CombTable<T> table;
-                    table.init(comb_keys, comb_vals, (T*)so.image);
+                    table.init(comb_keys, comb_vals, (T*)so.image + beam * ((int64_t)bins_x * bins_y));     // (beam b's image behind beam b - 1's)
 #pragma unroll
                     for (int k = 0; k < PPT; ++k) {
                         const int p = threadIdx.x + k * CHX_BLOCK;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(CHX_BLOCK) void lattice_apply_kernel(const T* x_in,
                     const T* __restrict__ ey = (const T*)ptrs[q + 7];
                     const T mx = mis[0], my = mis[1];
                     CombTable<T> table;
-                    table.init(comb_keys, comb_vals, (T*)so.image);
+                    table.init(comb_keys, comb_vals, (T*)so.image + beam * ((int64_t)bins_x * bins_y));     // (beam b's image behind beam b - 1's)
 #pragma unroll
                     for (int k = 0; k < PPT; ++k) {
                         const int p = threadIdx.x + k * CHX_BLOCK;
@@ -1356,7 +1356,12 @@ extern "C" int chx_lattice_track_screens(const int64_t* table, int64_t n_items, 
     if (!chx_bcast_ok(Bx, B) || !chx_bcast_ok(Bm, B) || !chx_bcast_ok(Bw, B)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && (!readings || !workspace)) return CHX_ERR_INVALID_ARG;
     if (n_bpm > 0 && workspace_bytes < chx_lattice_diag_workspace_bytes(N, B, n_bpm)) return CHX_ERR_WORKSPACE;
-    if (n_screens < 0 || n_screens > CHX_LATTICE_MAX_SCREENS || (n_screens > 0 && (!screens || B != 1))) return CHX_ERR_INVALID_ARG;
+    // screens of a VECTORISED beam (B > 1 beams of N particles under ONE lattice setting, Bm = 1): every record holds the B beams one
+    // behind the other ([B][N][7] rows, [B][N] charges and survival probabilities), every image B images; `charge` is ONE row of N
+    // charges shared by the beams (particle_beam.py: a vectorised beam's charges broadcast)
+    if (n_screens < 0 || n_screens > CHX_LATTICE_MAX_SCREENS || (n_screens > 0 && (!screens || (B != 1 && Bm != 1)))) return CHX_ERR_INVALID_ARG;
+    for (int64_t k = 0; k < n_screens; ++k)
+        if (B != 1 && screens[k].mom_partials) return CHX_ERR_INVALID_ARG;
     int st = chx_lattice_prepare_screens(table, n_items, n_elems, n_ptrs, Bm, small_runs, energy, mass_eV, n_charges, dtype, state,
                                          state_bytes, energy_out, s_in, s_out, screens, n_screens, stream);
     if (st != CHX_OK) return st;

@@ -174,8 +174,9 @@ PyObject* fail(int rc, const char* what) {
 // lattice_track_screens(plan, x (N, 7), energy, s_in, charges (N,), survival (N,) | None, mass_eV, n_charges, device index,
 //                       image_limit, survival_out | None, n_bpm, readings | None, workspace | None, workspace bytes)
 //   -> (out, energy_out, s_out, (record, ...), (image | None, ...))
-// record of screen k: ONE tensor of 9 N + 2 values [rows N x 7 | charges N | survival N | energy | s] of the beam AT the screen;
-// image: (bins_y, bins_x), deposited by the particle pass when the screen allows it and N <= image_limit (else None: the caller
+// record of screen k: ONE tensor of 9 M + 2 values [rows M x 7 | charges M | survival M | energy | s] of the beam AT the screen
+// (M = N, or B N for a vectorised beam x of shape (B, N, 7): the beams one behind the other);
+// image: (bins_y, bins_x) — (B, bins_y, bins_x) —, deposited by the particle pass when the screen allows it and N <= image_limit (else None: the caller
 // forms it from the record when it is asked for).
 PyObject* host_track_impl(PyObject* const* args, Py_ssize_t nargs) {
     if (nargs != 15) {
@@ -190,18 +191,28 @@ PyObject* host_track_impl(PyObject* const* args, Py_ssize_t nargs) {
     if (!p) return nullptr;
     if (!tensor_ok(args[1], "x", p->code, -1)) return nullptr;
     const at::Tensor& x = unpack(args[1]);
-    if (x.dim() != 2 || x.size(1) != 7 || x.size(0) < 1) {
-        PyErr_SetString(PyExc_ValueError, "x: an (N, 7) tensor is expected");
+    // (N, 7): one beam; (B, N, 7): a vectorised beam of B beams under the one lattice setting — every record and image then holds B of them
+    if ((x.dim() != 2 && x.dim() != 3) || x.size(-1) != 7 || x.size(-2) < 1 || x.size(0) < 1) {
+        PyErr_SetString(PyExc_ValueError, "x: an (N, 7) or (B, N, 7) tensor is expected");
         return nullptr;
     }
-    const int64_t N = x.size(0);
+    const int64_t N = x.size(-2), B = x.dim() == 3 ? x.size(0) : 1;
     const long long n_bpm = PyLong_AsLongLong(args[11]);
     if (PyErr_Occurred()) return nullptr;
     if (!tensor_ok(args[2], "energy", p->code, 1, &x) || !tensor_ok(args[3], "s", p->code, 1, &x) ||
-        !tensor_ok(args[4], "particle_charges", p->code, N, &x) || (args[5] != Py_None && !tensor_ok(args[5], "survival_probabilities", p->code, N, &x)) ||
-        (args[10] != Py_None && !tensor_ok(args[10], "survival_out", p->code, N, &x)) ||
-        (args[12] != Py_None && !tensor_ok(args[12], "readings", p->code, 2 * n_bpm, &x)))
+        !tensor_ok(args[4], "particle_charges", p->code, N, &x) || (args[5] != Py_None && !tensor_ok(args[5], "survival_probabilities", p->code, -1, &x)) ||
+        (args[10] != Py_None && !tensor_ok(args[10], "survival_out", p->code, B * N, &x)) ||
+        (args[12] != Py_None && !tensor_ok(args[12], "readings", p->code, 2 * n_bpm * B, &x)))
         return nullptr;
+    int64_t Bw = 1;
+    if (args[5] != Py_None) {
+        const int64_t nw = unpack(args[5]).numel();
+        if (nw != N && nw != B * N) {
+            PyErr_SetString(PyExc_ValueError, "survival_probabilities: N values shared by the beams or B x N");
+            return nullptr;
+        }
+        Bw = nw == N ? 1 : B;
+    }
     if ((n_bpm > 0) != (args[12] != Py_None) || (args[13] != Py_None && (!THPVariable_Check(args[13]) || !unpack(args[13]).is_cuda()))) {
         PyErr_SetString(PyExc_ValueError, "readings / workspace: device tensors for every active monitor of the plan (and only then)");
         return nullptr;
@@ -232,22 +243,24 @@ PyObject* host_track_impl(PyObject* const* args, Py_ssize_t nargs) {
     chx_lattice_screen scr[CHX_LATTICE_MAX_SCREENS] = {};
     at::Tensor recs[CHX_LATTICE_MAX_SCREENS], images[CHX_LATTICE_MAX_SCREENS];
     const size_t esize = x.element_size();
+    const int64_t M = B * N;          // rows of a record: the B beams one behind the other
     for (size_t k = 0; k < n_screens; ++k) {
-        recs[k] = at::empty({9 * N + 2}, opts);
+        recs[k] = at::empty({9 * M + 2}, opts);
         char* base = static_cast<char*>(recs[k].data_ptr());
         scr[k].rows = base;
-        scr[k].charges = base + 7 * N * esize;
-        scr[k].survival = base + 8 * N * esize;
-        scr[k].energy = base + 9 * N * esize;
-        scr[k].s = base + (9 * N + 1) * esize;
+        scr[k].charges = base + 7 * M * esize;
+        scr[k].survival = base + 8 * M * esize;
+        scr[k].energy = base + 9 * M * esize;
+        scr[k].s = base + (9 * M + 1) * esize;
         if (p->screens[k].deposit && N <= image_limit) {
-            images[k] = at::empty({p->screens[k].bins_y, p->screens[k].bins_x}, opts);
+            images[k] = x.dim() == 3 ? at::empty({B, p->screens[k].bins_y, p->screens[k].bins_x}, opts)
+                                     : at::empty({p->screens[k].bins_y, p->screens[k].bins_x}, opts);
             scr[k].image = images[k].data_ptr();
-            scr[k].image_bytes = static_cast<int64_t>(p->screens[k].bins_x * p->screens[k].bins_y * esize);
+            scr[k].image_bytes = static_cast<int64_t>(B * p->screens[k].bins_x * p->screens[k].bins_y * esize);
         }
     }
     const int rc = p_track(p->table, p->n_items, p->n_elems, p->n_ptrs, energy.data_ptr(), mass, nq, p->code, p->state, p->state_bytes,
-                           x.data_ptr(), out.data_ptr(), N, 1, 1, 1, 1, 0, e_out.data_ptr(), s_in.data_ptr(), s_out.data_ptr(), survival,
+                           x.data_ptr(), out.data_ptr(), N, B, B, 1, Bw, 0, e_out.data_ptr(), s_in.data_ptr(), s_out.data_ptr(), survival,
                            survival_out, n_bpm, readings, workspace, static_cast<size_t>(ws_bytes), charges.data_ptr(), scr,
                            static_cast<int64_t>(n_screens), stream);
     if (rc != 0) return fail(rc, "chx_lattice_track_screens");

@@ -672,6 +672,8 @@ int64_t chx_lattice_moment_blocks(int64_t N, int64_t B);
  * root (chx_moments_entry). */
 int chx_lattice_screen_moments(const double* mom_partials, int64_t n_blocks, int dtype, double* out, int index, int take_sqrt,
                                void* entry_out, void* stream);
+/* (ABI 9: B > 1 beams with screens when Bm == 1 — records [B][N][7] / [B][N] / [B][N], images [B][height][width], `charge` one row of N
+ * shared by the beams; mom_partials only with B == 1.) */
 int chx_lattice_track_screens(const int64_t* table, int64_t n_items, int64_t n_elems, int64_t n_ptrs, const void* energy,
                               double mass_eV, double n_charges, int dtype, void* state, size_t state_bytes, const void* x_in,
                               void* x_out, int64_t N, int64_t B, int64_t Bx, int64_t Bm, int64_t Bw, int small_runs,
