@@ -335,8 +335,8 @@ def test_record_is_private_and_lazy():
 
 
 def test_screen_stretch_declines():
-    """What does not ride in the stretch call keeps the walk's results: gradients, a blocking screen, a vectorised beam, a
-    particle-sharded beam."""
+    """What does not ride in the stretch call keeps the walk's results: gradients, a blocking screen (a vectorised beam rides since
+    round 6)."""
     import cheetah_amd as ca
     from cheetah_amd.accelerator import segment
 
@@ -369,11 +369,15 @@ def test_screen_stretch_declines():
         with torch.no_grad():
             seg.track(beam)                                   # ... and the plan is back under no_grad
         assert len(calls) == 2
-        # three beams in one ParticleBeam
+        # three beams in one ParticleBeam: a stretch call too since round 6 (test_screens_of_a_vectorised_beam_ride_in_the_stretch),
+        # every beam's image the plain beam's
         many = ca.ParticleBeam(beam.particles.unsqueeze(0).repeat(3, 1, 1), beam.energy, particle_charges=beam.particle_charges, **fk)
         with torch.no_grad():
             seg.track(many)
-        assert len(calls) == 2 and seg.AREABSCR1.reading.shape == (3, 48, 64)
+        images = seg.AREABSCR1.reading
+        assert len(calls) == 3 and images.shape == (3, 48, 64)
+        for b in range(3):
+            assert torch.allclose(images[b], plain, rtol=1e-4, atol=1e-6 * float(plain.max()))
     finally:
         segment._TORCH_HOST = old
 
@@ -781,3 +785,59 @@ def test_host_step_checks_what_python_hands_it():
         b[index] = bad
         with pytest.raises((ValueError, TypeError)):
             th.parameter_lattice_track_screens(*b)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("lead", [(3,), (2, 2)])
+def test_screens_of_a_vectorised_beam_ride_in_the_stretch(dt, lead):
+    """Round 6: a vectorised ParticleBeam (B beams of N particles under one lattice setting) through [run | monitor | aperture |
+    active Screen]+ is ONE stretch call too: every screen's record holds the B beams ((B, N, 7) rows, (B, N) charges and survival
+    probabilities), every cloud-in-cell image B images, the monitors' readings and the thinned survival probabilities carry the
+    beam's vector dims. Against the elements tracked one by one (screen.py:187-344, bpm.py:77-87, aperture.py:90-135). A 'histogram'
+    screen refuses vectorised beams like the reference's (screen.py:292-294): its stretch is taken without the screen."""
+    import cheetah_amd as ca
+    from cheetah_amd.accelerator import _planner
+
+    fk = {"dtype": dt, "device": "cuda"}
+    t = lambda v: torch.tensor(v, **fk)  # noqa: E731
+
+    def lattice(method):
+        return [ca.Drift(t(0.3), **fk), ca.Quadrupole(t(0.15), k1=t(5.0), **fk), ca.BPM(is_active=True, **fk), ca.Drift(t(0.4), **fk),
+                ca.Aperture(x_max=t(6e-4), y_max=t(5e-4), shape="elliptical", is_active=True, **fk),
+                ca.Quadrupole(t(0.15), k1=t(-4.0), tilt=t(0.1), **fk), ca.Drift(t(0.2), **fk),
+                ca.Screen(resolution=(48, 40), pixel_size=t([5e-5, 5e-5]), method=method, is_active=True, misalignment=t([4e-5, -2e-5]), **fk),
+                ca.HorizontalCorrector(t(0.05), angle=t(1e-4), **fk), ca.Drift(t(0.3), **fk)]
+
+    torch.manual_seed(5)
+    n, B = 5000, int(torch.tensor(lead).prod())
+    one = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(3e-4), sigma_y=t(2.5e-4), sigma_px=t(3e-5), sigma_py=t(2e-5), energy=t(8e7), **fk)
+    shifts = torch.linspace(-2e-4, 2e-4, B, **fk).reshape(lead + (1, 1)) * torch.tensor([1.0, 0, 0.4, 0, 0, 0, 0], **fk)
+    beam = ca.ParticleBeam(one.particles + shifts, one.energy, particle_charges=one.particle_charges,
+                           survival_probabilities=0.4 + 0.6 * torch.rand(lead + (n,), **fk), **fk)
+    els_a, els_b = lattice("cloud-in-cell"), lattice("cloud-in-cell")
+    before = dict(_planner.TAKEN)
+    out = ca.Segment(els_a).track(beam)
+    assert _planner.TAKEN["lattice_stretch"] == before["lattice_stretch"] + 1 and _planner.TAKEN["element"] == before["element"]
+    ref = beam
+    for e in els_b:
+        ref = e.track(ref)
+    tol = 1e-12 if dt == torch.float64 else 2e-6
+    assert out.particles.shape == lead + (n, 7) and out.survival_probabilities.shape == lead + (n,)
+    assert torch.allclose(out.particles, ref.particles, rtol=tol, atol=tol * 1e-3)
+    assert torch.equal(out.survival_probabilities, ref.survival_probabilities)
+    assert els_a[2].reading.shape == lead + (2,) and torch.allclose(els_a[2].reading, els_b[2].reading, rtol=1e-5, atol=1e-9)
+    img, want = els_a[7].reading, els_b[7].reading
+    assert img.shape == lead + (40, 48) and torch.allclose(img, want, rtol=1e-4 if dt == torch.float32 else 1e-10, atol=float(want.max()) * 1e-6)
+    assert float((img.reshape(B, -1)[0] - img.reshape(B, -1)[-1]).abs().max()) > 1e-2 * float(img.max())   # (the beams differ: so do their images)
+    rb, wb = els_a[7].get_read_beam(), els_b[7].get_read_beam()
+    assert rb.particles.shape == lead + (n, 7) and rb.particle_charges.shape[-1] == n
+    assert torch.allclose(rb.particles, wb.particles, rtol=tol, atol=tol * 1e-3)
+    assert torch.allclose(rb.sigma_x, wb.sigma_x, rtol=1e-5) and rb.sigma_x.shape == lead
+    # the 'histogram' method: no image for a vectorised beam, in the stretch as in the walk
+    els_h = lattice("histogram")
+    before = dict(_planner.TAKEN)
+    out_h = ca.Segment(els_h).track(beam)
+    assert _planner.TAKEN["lattice_stretch"] >= before["lattice_stretch"] + 1          # (the stretch without the screen, not the walk)
+    assert torch.allclose(out_h.particles, ref.particles, rtol=tol, atol=tol * 1e-3)
+    with pytest.raises(NotImplementedError, match="does not support vectorization"):
+        els_h[7].reading
