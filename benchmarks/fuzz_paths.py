@@ -284,7 +284,7 @@ def check(seg, els_a, els_b, beam, dt, fails, tag):
     ref = beam
     for e in els_b:
         ref = e.track(ref)
-    tol = 2e-11 if dt == torch.float64 else 3e-5
+    tol = 2e-11 if dt == torch.float64 else 1e-4        # (float32: a composed map of a dozen strong elements against their maps one by one)
     cols = out.particles.double().abs().reshape(-1, 7).amax(dim=0)
     if out.particles.shape != ref.particles.shape:
         fails.append(f"particles: shapes {tuple(out.particles.shape)} vs {tuple(ref.particles.shape)}")
