@@ -148,3 +148,73 @@ def test_full_size_dR_reduction_against_float64_torch(ca, dt):
     loss2 = mom2[0, 8].sqrt() + 3.0 * mom2[0, 4] + mom2[0, 8 + 7]
     dR_alg, = torch.autograd.grad(loss2, R)
     assert float((dR_alg[0].double() - dR_torch).abs().max() / scale) < (3e-4 if dt == torch.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("E", [3, 16, 23])
+def test_run_vjp_entry_equals_its_two_launches(dt, E):
+    """`chx_run_vjp_entry` (ABI 9) through the C-ABI: the builders' VJP that forms dL/d(composed map) from the gradient of ONE entry
+    of the tracked beam's moments itself, against the two calls it replaces — `chx_moment_entry_mapped_bwd` writing that cotangent
+    as a tensor, `chx_run_vjp_masked` reading it: the same bits, for runs the fused kernel takes (E <= 16: one launch) and for a
+    longer one (its fallback: the two launches behind the one entry point); every entry index, with and without the square root;
+    a mask that leaves settings out."""
+    import ctypes
+
+    from cheetah_amd import _lib, _ops
+
+    lib = _lib.lib()
+    dev = "cuda"
+    torch.manual_seed(E)
+    kinds_py, params = [], []
+    for e in range(E):
+        if e % 3 == 1:
+            kinds_py.append(_ops.KIND["quadrupole"])
+            params.append([0.1 + 0.01 * e, 3.0 * (-1) ** e, 0.05 * (e % 2), 1e-4 * (e % 3), -5e-5])
+        elif e % 3 == 2:
+            kinds_py.append(_ops.KIND["hcor"] if "hcor" in _ops.KIND else _ops.KIND["horizontal_corrector"])
+            params.append([0.05, 1e-4 * e])
+        else:
+            kinds_py.append(_ops.KIND["drift"])
+            params.append([0.2 + 0.01 * e])
+    tensors = [[torch.tensor(v, dtype=dt, device=dev) for v in p] for p in params]
+    ptrs = (ctypes.c_void_p * (E * _ops.MAX_PARAMS))()
+    for e, ts in enumerate(tensors):
+        for k, t in enumerate(ts):
+            ptrs[e * _ops.MAX_PARAMS + k] = t.data_ptr()
+    kinds = (ctypes.c_int32 * E)(*kinds_py)
+    energy = torch.tensor([1.2e8], dtype=dt, device=dev)
+    mass, nq, code = 510998.95069, -1.0, _ops.dtype_code(dt)
+    maps = torch.empty((E, 7, 7), dtype=dt, device=dev)
+    C = torch.empty((7, 7), dtype=dt, device=dev)
+    _ops.check(lib.chx_run_build_compose(kinds, ptrs, E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), C.data_ptr(), _ops.stream_ptr()),
+               "chx_run_build_compose")
+    x = torch.randn(1, 4000, 7, dtype=dt, device=dev) * torch.tensor([2e-4, 3e-5, 1.5e-4, 2e-5, 1e-4, 1e-3, 0.0], dtype=dt, device=dev)
+    x[..., 6] = 1.0
+    w = (0.3 + 0.7 * torch.rand(1, 4000, dtype=dt, device=dev))
+    mom_x = _ops._moments_raw(x, w, 1, 4000)
+    y = x @ C.T
+    mom_y = _ops._moments_raw(y.contiguous(), w, 1, 4000)
+    need = (ctypes.c_uint16 * E)(*[(0xFFFF if e % 4 else 0x0002) for e in range(E)])       # (every fourth element: its slot 1 only)
+    g = torch.tensor([0.7], dtype=dt, device=dev)
+    ws_bytes = lib.chx_run_vjp_entry_workspace_bytes(E)
+    assert ws_bytes == lib.chx_run_vjp_workspace_bytes(E) + 49 * 8
+    for index, take_sqrt in ((8, 1), (8, 0), (2, 0), (3, 0), (14, 1), (9, 0), (28, 1), (19, 0)):
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        got = torch.full((E, _ops.MAX_PARAMS + 1), float("nan"), dtype=dt, device=dev)
+        _ops.check(lib.chx_run_vjp_entry(kinds, ptrs, E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), need, g.data_ptr(), mom_y.data_ptr(),
+                                         index, take_sqrt, C.data_ptr(), mom_x.data_ptr(), got.data_ptr(), ws.data_ptr(), ws_bytes,
+                                         _ops.stream_ptr()), "chx_run_vjp_entry")
+        dC = torch.empty((7, 7), dtype=dt, device=dev)
+        _ops.check(lib.chx_moment_entry_mapped_bwd(g.data_ptr(), mom_y.data_ptr(), index, take_sqrt, C.data_ptr(), mom_x.data_ptr(), 1, 1, 1, code,
+                                                   dC.data_ptr(), 0, _ops.stream_ptr()), "chx_moment_entry_mapped_bwd")
+        want = torch.full_like(got, float("nan"))
+        ws2 = torch.empty(lib.chx_run_vjp_workspace_bytes(E), dtype=torch.uint8, device=dev)
+        _ops.check(lib.chx_run_vjp_masked(kinds, ptrs, E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), dC.data_ptr(), need, want.data_ptr(),
+                                          ws2.data_ptr(), ws2.numel(), _ops.stream_ptr()), "chx_run_vjp_masked")
+        assert torch.equal(got, want), (index, take_sqrt, (got - want).abs().max())
+        assert torch.isfinite(got).all() and (float(got.abs().max()) > 0.0 or index == 28)     # (sigma_p does not depend on a linear map's settings)
+    # argument checks: W / W2 have no gradient to a map; a missing workspace
+    assert lib.chx_run_vjp_entry(kinds, ptrs, E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), need, g.data_ptr(), mom_y.data_ptr(), 1, 0,
+                                 C.data_ptr(), mom_x.data_ptr(), got.data_ptr(), ws.data_ptr(), ws_bytes, _ops.stream_ptr()) == -1
+    assert lib.chx_run_vjp_entry(kinds, ptrs, E, energy.data_ptr(), mass, nq, code, maps.data_ptr(), need, g.data_ptr(), mom_y.data_ptr(), 8, 1,
+                                 C.data_ptr(), mom_x.data_ptr(), got.data_ptr(), None, 0, _ops.stream_ptr()) == -5
