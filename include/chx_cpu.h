@@ -22,7 +22,12 @@
  *   chx_moments_bwd_cpu / chx_moments_bwd_w_cpu  chx_moments_bwd(_w)  the cotangent of utils/statistics.py:4-62 (rows and weights)
  *   chx_cic_deposit_bwd_cpu chx_cic_deposit_bwd utils/cloud_in_cell.py under autograd: d / d(weights), d / d(positions)
  *   chx_sc_gather_kick_cpu  chx_sc_gather_kick  space_charge_kick.py:387-475, 548-584 (trilinear gather + kick from a force grid)
- * The remaining ~80 declarations of chx.h are plans, fused stretches and tuning forms of these: they are exercised by the `-m gpu`
+ *   chx_merge_moments_cpu   chx_merge_moments   the exact pooled statistics of R shards (Chan et al.; utils/statistics.py:4-62 on the union)
+ *   chx_moment_entry_cpu, chx_moments_mapped_bwd_cpu, chx_moment_entry_mapped_bwd_cpu   their namesakes: a beam property
+ *                           (particle_beam.py:1672-1943) of y = R x and its gradient with respect to R from the incoming beam's moments
+ *   chx_build_rmatrix_scalars_cpu, chx_run_build_compose_cpu   their namesakes: a run's element maps from scalars read where they live,
+ *                           and their product (segment.py:534-543)
+ * The remaining declarations of chx.h are plans, fused stretches and tuning forms of these: they are exercised by the `-m gpu`
  * tests against the oracle directly and have no host twin.
  */
 #ifndef CHX_CPU_H
@@ -73,6 +78,17 @@ int chx_sc_gather_kick_cpu(const void* x_in, const void* F, const void* half, co
                            const void* energy, const void* dt, double mass_eV, int64_t B, int64_t Bx,
                            int64_t Be, int64_t N, const int32_t* bins, int dtype, void* x_out,
                            void* stream);
+int chx_merge_moments_cpu(const double* per_rank, int32_t R, int64_t B, double* out, void* stream);
+int chx_moments_mapped_bwd_cpu(const double* d_out, const void* R, const double* mom_x, int64_t B, int64_t BR, int64_t Bm,
+                               int dtype, double* dR, void* stream);
+int chx_moment_entry_cpu(const double* mom, int64_t B, int index, int take_sqrt, int dtype, void* out, void* stream);
+int chx_moment_entry_mapped_bwd_cpu(const void* grad, const double* mom_y, int index, int take_sqrt, const void* R,
+                                    const double* mom_x, int64_t B, int64_t BR, int64_t Bm, int dtype, void* dR, int dR_is_double,
+                                    void* stream);
+int chx_build_rmatrix_scalars_cpu(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                                  double mass_eV, double n_charges, int dtype, void* R_out, void* stream);
+int chx_run_build_compose_cpu(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                              double n_charges, int dtype, void* maps, void* R_out, void* stream);
 #ifdef __cplusplus
 }
 #endif

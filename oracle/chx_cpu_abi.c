@@ -495,3 +495,152 @@ CPU_API int chx_sc_gather_kick_cpu(const void* x_in, const void* F, const void* 
     free(F3); free(hd); free(cd); free(ed); free(td);
     return rc;
 }
+
+
+/* ---- round 6, second batch: the algebra around a beam property (particle_beam.py:1672-1943) and the scalar-run builders ---- */
+
+/* chx_merge_moments (exact pooled statistics of R shards, Chan et al.): per_rank[R][B][29] -> out[B][29] */
+CPU_API int chx_merge_moments_cpu(const double* per_rank, int32_t R, int64_t B, double* out, void* stream) {
+    (void)stream;
+    if (!per_rank || !out || R < 1 || B < 1) return CHX_ERR_INVALID_ARG;
+    for (int64_t b = 0; b < B; ++b) {
+        double W = 0.0, W2 = 0.0, mu[6] = {0, 0, 0, 0, 0, 0}, M[21];
+        for (int r = 0; r < R; ++r) {
+            const double* p = per_rank + ((int64_t)r * B + b) * 29;
+            if (!(p[0] > 0.0)) continue;
+            W += p[0];
+            W2 += p[1];
+            for (int j = 0; j < 6; ++j) mu[j] += p[0] * p[2 + j];
+        }
+        for (int j = 0; j < 6; ++j) mu[j] /= W;
+        for (int k = 0; k < 21; ++k) M[k] = 0.0;
+        for (int r = 0; r < R; ++r) {
+            const double* p = per_rank + ((int64_t)r * B + b) * 29;
+            if (!(p[0] > 0.0)) continue;
+            const double cf = p[0] - p[1] / p[0];
+            int k = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 6; ++j, ++k) M[k] += p[8 + k] * cf + p[0] * (p[2 + i] - mu[i]) * (p[2 + j] - mu[j]);
+        }
+        double* o = out + b * 29;
+        o[0] = W;
+        o[1] = W2;
+        for (int j = 0; j < 6; ++j) o[2 + j] = mu[j];
+        for (int k = 0; k < 21; ++k) o[8 + k] = M[k] / (W - W2 / W);
+    }
+    return CHX_OK;
+}
+
+/* dR[49] of one batch row from the gradient g[29] of the moments of y = R x: mu' = A mu + b, cov' = A C A^T (element.py:180-191
+ * followed by statistics.py:4-62): dA = 2 G A C + g_mu mu^T, db = g_mu, G symmetric with the off-diagonal gradients halved */
+static void mapped_bwd_row(const double* g, const double* Rb, const double* m, double* o) {
+    double G[36], C[36], AC[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int k = 8 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+            G[i * 6 + j] = (i == j) ? g[k] : 0.5 * g[k];
+            C[i * 6 + j] = m[k];
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+            for (int l = 0; l < 6; ++l) acc += Rb[i * 7 + l] * C[l * 6 + j];
+            AC[i * 6 + j] = acc;
+        }
+    for (int k = 0; k < 49; ++k) o[k] = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+            for (int l = 0; l < 6; ++l) acc += G[i * 6 + l] * AC[l * 6 + j];
+            o[i * 7 + j] = 2.0 * acc + g[2 + i] * m[2 + j];
+        }
+        o[i * 7 + 6] = g[2 + i];
+    }
+}
+
+CPU_API int chx_moments_mapped_bwd_cpu(const double* d_out, const void* R, const double* mom_x, int64_t B, int64_t BR, int64_t Bm,
+                                       int dtype, double* dR, void* stream) {
+    (void)stream;
+    if (!d_out || !R || !mom_x || !dR || B < 1 || (BR != 1 && BR != B) || (Bm != 1 && Bm != B)) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    for (int64_t b = 0; b < B; ++b) {
+        double Rb[49];
+        for (int k = 0; k < 49; ++k) Rb[k] = ld(R, dtype, (BR == 1 ? 0 : b) * 49 + k);
+        mapped_bwd_row(d_out + b * 29, Rb, mom_x + (Bm == 1 ? 0 : b) * 29, dR + b * 49);
+    }
+    return CHX_OK;
+}
+
+CPU_API int chx_moment_entry_cpu(const double* mom, int64_t B, int index, int take_sqrt, int dtype, void* out, void* stream) {
+    (void)stream;
+    if (!mom || !out || B < 1 || index < 0 || index >= 29) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    for (int64_t b = 0; b < B; ++b) st(out, dtype, b, take_sqrt ? sqrt(mom[b * 29 + index]) : mom[b * 29 + index]);
+    return CHX_OK;
+}
+
+CPU_API int chx_moment_entry_mapped_bwd_cpu(const void* grad, const double* mom_y, int index, int take_sqrt, const void* R,
+                                            const double* mom_x, int64_t B, int64_t BR, int64_t Bm, int dtype, void* dR, int dR_is_double,
+                                            void* stream) {
+    (void)stream;
+    if (!grad || !mom_y || !R || !mom_x || !dR || B < 1 || (BR != 1 && BR != B) || (Bm != 1 && Bm != B) || index < 2 || index >= 29)
+        return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    for (int64_t b = 0; b < B; ++b) {
+        double g[29], Rb[49], o[49];
+        for (int k = 0; k < 29; ++k) g[k] = 0.0;
+        g[index] = ld(grad, dtype, b);
+        if (take_sqrt) g[index] = g[index] * 0.5 / sqrt(mom_y[b * 29 + index]);
+        for (int k = 0; k < 49; ++k) Rb[k] = ld(R, dtype, (BR == 1 ? 0 : b) * 49 + k);
+        mapped_bwd_row(g, Rb, mom_x + (Bm == 1 ? 0 : b) * 29, o);
+        for (int k = 0; k < 49; ++k) {
+            if (dR_is_double) ((double*)dR)[b * 49 + k] = o[k];
+            else st(dR, dtype, b * 49 + k, o[k]);
+        }
+    }
+    return CHX_OK;
+}
+
+/* chx_build_rmatrix_scalars / chx_run_build_compose: E elements whose parameters are scalars read where they live (host pointers
+ * here), each map rounded to `dtype`; the composed map accumulated in double from the ROUNDED element maps, rounded once */
+static int build_scalars(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                         double n_charges, int dtype, void* maps) {
+    if (!kinds || !param_ptrs || !energy || !maps || E < 1) return CHX_ERR_INVALID_ARG;
+    if (dtype != CHX_F32 && dtype != CHX_F64) return CHX_ERR_DTYPE;
+    const double e = ld(energy, dtype, 0);
+    for (int64_t i = 0; i < E; ++i) {
+        const int P = kind_np(kinds[i]);
+        if (P < 0) return CHX_ERR_INVALID_ARG;
+        double p[CHX_MAX_PARAMS], R[49];
+        for (int k = 0; k < P; ++k) {
+            if (!param_ptrs[i * CHX_MAX_PARAMS + k]) return CHX_ERR_INVALID_ARG;
+            p[k] = ld(param_ptrs[i * CHX_MAX_PARAMS + k], dtype, 0);
+        }
+        if (chxo_build_rmatrix(kinds[i], p, &e, mass_eV, n_charges, 1, 1, 1, R) != 0) return CHX_ERR_INVALID_ARG;
+        for (int k = 0; k < 49; ++k) st(maps, dtype, i * 49 + k, R[k]);
+    }
+    return CHX_OK;
+}
+
+CPU_API int chx_build_rmatrix_scalars_cpu(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy,
+                                          double mass_eV, double n_charges, int dtype, void* R_out, void* stream) {
+    (void)stream;
+    return build_scalars(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, R_out);
+}
+
+CPU_API int chx_run_build_compose_cpu(const int32_t* kinds, const void* const* param_ptrs, int64_t E, const void* energy, double mass_eV,
+                                      double n_charges, int dtype, void* maps, void* R_out, void* stream) {
+    (void)stream;
+    if (!R_out) return CHX_ERR_INVALID_ARG;
+    const int rc = build_scalars(kinds, param_ptrs, E, energy, mass_eV, n_charges, dtype, maps);
+    if (rc != CHX_OK) return rc;
+    double tm[49], m[49];
+    eye7(tm);
+    for (int64_t i = 0; i < E; ++i) {
+        for (int k = 0; k < 49; ++k) m[k] = ld(maps, dtype, i * 49 + k);
+        mm7(m, tm, tm);
+    }
+    for (int k = 0; k < 49; ++k) st(R_out, dtype, k, tm[k]);
+    return CHX_OK;
+}

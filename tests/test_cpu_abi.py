@@ -35,7 +35,9 @@ def test_every_twin_is_exported_with_the_signature_of_its_namesake():
                           "chx_moments_cpu", "chx_cic_deposit_cpu", "chx_track_elementwise_cpu", "chx_cavity_coeffs_cpu",
                           "chx_cavity_track_cpu", "chx_hist2d_cpu", "chx_sc_kick_workspace_bytes_cpu", "chx_sc_kick_cpu",
                           "chx_track_fused_cpu", "chx_apply_bwd_workspace_bytes_cpu", "chx_apply_affine7_bwd_cpu", "chx_moments_bwd_cpu",
-                          "chx_moments_bwd_w_cpu", "chx_cic_deposit_bwd_cpu", "chx_sc_gather_kick_cpu"}
+                          "chx_moments_bwd_w_cpu", "chx_cic_deposit_bwd_cpu", "chx_sc_gather_kick_cpu", "chx_merge_moments_cpu",
+                          "chx_moments_mapped_bwd_cpu", "chx_moment_entry_cpu", "chx_moment_entry_mapped_bwd_cpu",
+                          "chx_build_rmatrix_scalars_cpu", "chx_run_build_compose_cpu"}
     norm = lambda sig: re.sub(r"\s*/\*.*?\*/", "", sig).replace(" ,", ",")  # noqa: E731
     for name, sig in twins.items():
         assert hasattr(lib, name), name
@@ -307,3 +309,99 @@ def test_backward_and_gather_twins_against_torch_autograd_and_the_oracle(oracle)
                                       _ptr(got), None) == 0
     assert np.array_equal(got, want) and not np.array_equal(got, xk)
     assert lib.chx_sc_gather_kick_cpu(_ptr(xk), None, None, None, None, None, dbl(1.0), i64(1), i64(1), i64(1), i64(n3), b3, 1, _ptr(got), None) == -1
+
+
+def test_property_and_scalar_run_twins(oracle):
+    """The second round-6 batch: pooled moments of shards, a beam property of y = R x and its gradient with respect to R (checked
+    against torch autograd of the reference's statistics, utils/statistics.py:4-62, through y = x @ R.mT), the maps of a run whose
+    settings are scalars read where they live and their product (against the batched builder twin / the oracle)."""
+    import torch
+
+    lib = _lib()
+    rng = np.random.default_rng(23)
+    N = 900
+    x = rng.standard_normal((1, N, 7)) * [1e-3, 1e-5, 2e-3, 1e-5, 1e-4, 1e-3, 0] + [2e-3, 0, -1e-3, 0, 0, 0, 1]
+    w = 0.2 + rng.random((1, N))
+
+    def moments(xa, wa):
+        out = np.empty((xa.shape[0], 29))
+        assert lib.chx_moments_cpu(_ptr(np.ascontiguousarray(xa)), _ptr(np.ascontiguousarray(wa)), i64(xa.shape[0]), i64(xa.shape[0]), i64(xa.shape[0]),
+                                   i64(xa.shape[1]), 1, _ptr(out), None, ctypes.c_size_t(0), None) == 0
+        return out
+
+    # ---- chx_merge_moments_cpu: three unequal shards (one of them without weight) pool to the moments of the whole
+    whole = moments(x, w)
+    cuts = [(0, 250), (250, 251), (251, N)]
+    w_cut = w.copy()
+    w_cut[:, 250:251] = 0.0                                         # a shard whose particles are all lost
+    whole = moments(x, w_cut)
+    parts = np.stack([moments(x[:, a:b], w_cut[:, a:b]) for a, b in cuts])       # (R, B, 29)
+    merged = np.empty((1, 29))
+    assert lib.chx_merge_moments_cpu(_ptr(np.ascontiguousarray(parts)), ctypes.c_int32(3), i64(1), _ptr(merged), None) == 0
+    assert np.allclose(merged, whole, rtol=1e-11, atol=1e-24)
+    # ---- a property of y = R x and d / dR, against torch autograd of the statistics themselves
+    R = np.eye(7) + 0.2 * rng.standard_normal((1, 7, 7))
+    R[:, 6, :] = [0, 0, 0, 0, 0, 0, 1]
+    Rt = torch.from_numpy(R.copy()).requires_grad_(True)
+    xs, ws = torch.from_numpy(x), torch.from_numpy(w)
+    y = xs @ Rt.mT
+    W, W2 = ws.sum(-1), ws.square().sum(-1)
+    mu = (ws.unsqueeze(-1) * y[..., :6]).sum(-2) / W.unsqueeze(-1)
+    d = y[..., :6] - mu.unsqueeze(-2)
+    cov = torch.einsum("bn,bni,bnj->bij", ws, d, d) / (W - W2 / W)[:, None, None]
+    iu = torch.triu_indices(6, 6)
+    out_t = torch.cat([W[:, None], W2[:, None], mu, cov[:, iu[0], iu[1]]], dim=-1)
+    g = rng.standard_normal((1, 29))
+    out_t.backward(torch.from_numpy(g))
+    mom_x, mom_y = moments(x, w), moments(y.detach().numpy(), w)
+    dR = np.empty((1, 49))
+    assert lib.chx_moments_mapped_bwd_cpu(_ptr(g), _ptr(R), _ptr(mom_x), i64(1), i64(1), i64(1), 1, _ptr(dR), None) == 0
+    want = Rt.grad.numpy().reshape(1, 49)
+    assert np.allclose(dR, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+    for index, take_sqrt in ((8, 1), (3, 0), (19, 1), (10, 0)):
+        picked = np.empty(1)
+        assert lib.chx_moment_entry_cpu(_ptr(mom_y), i64(1), index, take_sqrt, 1, _ptr(picked), None) == 0
+        assert picked[0] == (np.sqrt(mom_y[0, index]) if take_sqrt else mom_y[0, index])
+        Rt.grad = None
+        y = xs @ Rt.mT
+        mu = (ws.unsqueeze(-1) * y[..., :6]).sum(-2) / W.unsqueeze(-1)
+        d = y[..., :6] - mu.unsqueeze(-2)
+        cov = torch.einsum("bn,bni,bnj->bij", ws, d, d) / (W - W2 / W)[:, None, None]
+        out_t = torch.cat([W[:, None], W2[:, None], mu, cov[:, iu[0], iu[1]]], dim=-1)
+        entry = out_t[0, index].sqrt() if take_sqrt else out_t[0, index]
+        (0.7 * entry).backward()
+        one = np.empty((1, 49))
+        assert lib.chx_moment_entry_mapped_bwd_cpu(_ptr(np.array([0.7])), _ptr(mom_y), index, take_sqrt, _ptr(R), _ptr(mom_x), i64(1), i64(1),
+                                                   i64(1), 1, _ptr(one), 1, None) == 0
+        want = Rt.grad.numpy().reshape(1, 49)
+        assert np.allclose(one, want, rtol=1e-8, atol=1e-11 * np.abs(want).max()), (index, take_sqrt)
+        as_f32 = np.empty((1, 49), dtype=np.float32)               # (dR in the beam dtype: the same values rounded)
+        R32, g32 = R.astype(np.float32), np.array([0.7], dtype=np.float32)
+        assert lib.chx_moment_entry_mapped_bwd_cpu(_ptr(g32), _ptr(mom_y), index, take_sqrt, _ptr(R32), _ptr(mom_x), i64(1), i64(1), i64(1), 0,
+                                                   _ptr(as_f32), 0, None) == 0
+        assert np.allclose(as_f32, one, rtol=2e-5, atol=1e-6 * np.abs(one).max())
+    assert lib.chx_moment_entry_mapped_bwd_cpu(_ptr(np.array([0.7])), _ptr(mom_y), 1, 0, _ptr(R), _ptr(mom_x), i64(1), i64(1), i64(1), 1,
+                                               _ptr(one), 1, None) == -1
+    # ---- the maps of a run of scalar settings and their product: the batched builder twin element by element, the compose twin
+    kinds = np.array([1, 2, 4, 1, 2], dtype=np.int32)              # drift, quadrupole, horizontal corrector, drift, quadrupole
+    params = [[0.3], [0.12, 4.2, 0.05, 1e-4, -2e-4], [0.05, 1.5e-4], [0.7], [0.12, -3.9, 0.0, 0.0, 0.0]]
+    for dtype, code in ((np.float64, 1), (np.float32, 0)):
+        scalars = [[np.array([v], dtype=dtype) for v in p] for p in params]
+        ptrs = (vp * (5 * 9))()
+        for e, row in enumerate(scalars):
+            for k, a in enumerate(row):
+                ptrs[e * 9 + k] = a.ctypes.data
+        energy = np.array([1.3e8], dtype=dtype)
+        maps, comp, maps2 = np.empty((5, 7, 7), dtype=dtype), np.empty((7, 7), dtype=dtype), np.empty((5, 7, 7), dtype=dtype)
+        assert lib.chx_run_build_compose_cpu(_ptr(kinds), ptrs, i64(5), _ptr(energy), dbl(oracle.ELECTRON_MASS_EV), dbl(-1.0), code, _ptr(maps),
+                                             _ptr(comp), None) == 0
+        assert lib.chx_build_rmatrix_scalars_cpu(_ptr(kinds), ptrs, i64(5), _ptr(energy), dbl(oracle.ELECTRON_MASS_EV), dbl(-1.0), code,
+                                                 _ptr(maps2), None) == 0
+        assert np.array_equal(maps, maps2)
+        for e, (kind, p) in enumerate(zip(("drift", "quadrupole", "hcor", "drift", "quadrupole"), params)):
+            want = oracle.build_rmatrix(kind, np.array([p], dtype=dtype).astype(np.float64), energy.astype(np.float64))[0]
+            assert np.array_equal(maps[e], want.astype(dtype)), (dtype, e)
+        prod = np.eye(7)
+        for e in range(5):
+            prod = maps[e].astype(np.float64) @ prod
+        assert np.allclose(comp, prod.astype(dtype), rtol=4 * np.finfo(dtype).eps, atol=1e-30)
