@@ -1185,11 +1185,20 @@ def main():
                              "distinct_devices": len({(r["device_index"], r["pci_bus_id"], r["uuid"]) for r in ranks}), "ranks": ranks}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(E)
-    if rank == 0:
-        print(json.dumps(result))
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # The ONE JSON line is the last thing on stdout: whatever native libraries still hold in C's stdio buffer (RCCL prints its
+        # library path there; into a pipe that buffer is only written out at process exit, i.e. behind Python's own) goes out first.
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
