@@ -681,7 +681,8 @@ def test_property_of_the_record_is_one_node_on_the_settings(dt):
         rel = 1e-5 if dt == torch.float32 else 1e-11
         for prop in ("sigma_x", "sigma_y", "mu_x", "sigma_tau", "sigma_px"):
             a, b = got[(True, prop)], got[(False, prop)]
-            assert torch.equal(a[0], b[0]), prop
+            # (two tracks: the particle pass adds its sums with atomics, whose order — hence the last bits in float64 — is not fixed)
+            assert torch.allclose(a[0], b[0], rtol=1e-12 if dt == torch.float64 else 2e-7, atol=0), prop
             for ga, gb, name in zip(a[1:], b[1:], ("k1", "angle")):
                 assert torch.isfinite(ga).all() and abs(float(ga - gb)) <= rel * abs(float(gb)) + 1e-30, (extra_drifts, prop, name, float(ga), float(gb))
             assert float(a[1]) != 0.0 or prop in ("sigma_tau",)
