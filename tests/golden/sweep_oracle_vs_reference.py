@@ -115,5 +115,47 @@ for _ in range(N):
     check_t("dipole", cheetah.Dipole(length=t(p[0]), angle=t(p[1]), k1=t(p[2]), dipole_e1=t(p[3]), dipole_e2=t(p[4]), tilt=t(p[5]),
                                      fringe_integral=t(p[6]), fringe_integral_exit=t(p[7]), gap=t(p[8]), **f64), p, E)
 
+# per-particle paths: an active cavity (cavity.py:100-251) and the Bmad-X drift-kick-drift maps of drifts and quadrupoles
+# (utils/bmadx.py, quadrupole.py:146-215) on a small drawn beam
+def beam_of(n, E):
+    return cheetah.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(mag(1e-5, 2e-3, 0, False)), sigma_y=t(mag(1e-5, 2e-3, 0, False)),
+                                                sigma_px=t(mag(1e-6, 2e-4, 0, False)), sigma_py=t(mag(1e-6, 2e-4, 0, False)),
+                                                sigma_tau=t(mag(1e-6, 1e-3, 0, False)), sigma_p=t(mag(1e-5, 1e-2, 0, False)),
+                                                mu_x=t(mag(1e-6, 1e-3)), mu_y=t(mag(1e-6, 1e-3)), energy=t(E), **f64)
+
+
+def note(key, got, want, params, energy):
+    scale = np.abs(want).max(axis=0) + 1e-300
+    err = float((np.abs(got - want) / scale).max())
+    if err > worst.get(key, (0.0,))[0]:
+        worst[key] = (err, params, energy)
+
+
+torch.manual_seed(3)
+for _ in range(max(N // 5, 50)):
+    E = float(np.exp(rng.uniform(np.log(5e6), np.log(5e9))))
+    L = mag(1e-2, 2.0, zero=0.0, signed=False)
+    b = beam_of(64, E)
+    x = b.particles.numpy()[None]
+    for ctype, kind in (("standing_wave", "cavity_sw"), ("traveling_wave", "cavity_tw")):
+        p = [L, mag(1e3, 0.4 * E if E < 1e9 else 5e7, zero=0.1), float(rng.uniform(-180.0, 180.0)), mag(1e8, 1.2e10, zero=0.0, signed=False)]
+        cav = cheetah.Cavity(length=t(p[0]), voltage=t(p[1]), phase=t(p[2]), frequency=t(p[3]), cavity_type=ctype, **f64)
+        out = cav.track(b)
+        if not torch.isfinite(out.particles).all():
+            continue
+        R = oracle.build_rmatrix(kind, [p], [E])
+        coeffs, e_out = oracle.cavity_coeffs([p], [E])
+        note("track_" + kind, oracle.cavity_track(x, R, coeffs)[0], out.particles.numpy(), p, E)
+        note("energy_" + kind, np.asarray(e_out).reshape(1, 1), out.energy.numpy().reshape(1, 1), p, E)
+    steps = int(rng.integers(1, 6))
+    p = [L, strength(L) if rng.random() < 0.9 else 0.0, mag(1e-6, 0.5, zero=0.4), mag(1e-7, 2e-3, zero=0.4), mag(1e-7, 2e-3, zero=0.4)]
+    q = cheetah.Quadrupole(length=t(p[0]), k1=t(p[1]), tilt=t(p[2]), misalignment=t([p[3], p[4]]), num_steps=steps,
+                           tracking_method="drift_kick_drift", **f64)
+    want = q.track(b).particles.numpy()
+    if np.isfinite(want).all():
+        note("dkd_quadrupole", oracle.dkd_track("quadrupole", x, [p], [E], num_steps=steps)[0][0], want, p + [steps], E)
+    d = cheetah.Drift(length=t(L), tracking_method="drift_kick_drift", **f64)
+    note("dkd_drift", oracle.dkd_track("drift", x, [[L]], [E])[0][0], d.track(b).particles.numpy(), [L], E)
+
 for kind, (err, params, energy) in sorted(worst.items()):
     print(f"{kind:12s} worst relative difference {err:.2e}  at params {params} energy {energy:.6g}")
