@@ -109,6 +109,8 @@ def one_case(seed):
     B = int(rng.choice([0, 0, 3, 17]))
     specs, els_a, els_b = draw_lattice(rng, fk, B)
     n = int(rng.choice([37, 1000, 4097, 30000]))
+    if n == 37 and any(k == "Aperture" and kw["is_active"] for k, kw in specs):
+        n = 1000          # (one or two survivors of 37: statistics that divide by ~0 are noise on either path)
     torch.manual_seed(seed)
     t = lambda v: torch.tensor(v, **fk)  # noqa: E731
     beam = ca.ParticleBeam.from_parameters(num_particles=n, sigma_x=t(3e-4), sigma_y=t(2e-4), sigma_px=t(3e-5), sigma_py=t(2e-5),
@@ -229,7 +231,8 @@ def observables(seg, els_b, beam, dt, fails):
         if got.mu.shape != want.mu.shape or got.cov.shape != want.cov.shape:
             fails.append(f"track_moments(exact={exact}): shapes {tuple(got.mu.shape)} {tuple(got.cov.shape)} vs {tuple(want.mu.shape)} {tuple(want.cov.shape)}")
             continue
-        if bool((torch.isnan(got.mu) != torch.isnan(want.mu)).any()) or bool((torch.isnan(got.cov) != torch.isnan(want.cov)).any()):
+        if bool((torch.isnan(got.mu[..., :6]) != torch.isnan(want.mu[..., :6])).any()) \
+                or bool((torch.isnan(got.cov[..., :6, :6]) != torch.isnan(want.cov[..., :6, :6])).any()):
             fails.append(f"track_moments(exact={exact}): NaNs in different places")
             continue
         dmu = torch.nan_to_num((got.mu[..., :6] - want.mu[..., :6]).abs() / (sig + want.mu[..., :6].abs() + 1e-300), nan=0.0).amax()
@@ -315,12 +318,13 @@ def check(seg, els_a, els_b, beam, dt, fails, tag):
                 if type(ra) is not type(rb):
                     fails.append(f"screen reading: {type(ra).__name__} vs {type(rb).__name__}")
                 continue
-            if ea.method == "histogram" and dt == torch.float32:
-                # a float32 row that lands within rounding of a bin edge falls into the neighbouring pixel on one of the two paths
-                # (a composed map against the elements' maps one by one): a few pixels may trade one particle
+            if dt == torch.float32:
+                # a float32 row that lands within rounding of a bin edge ('histogram') or of the screen's outer edge (either method:
+                # out-of-bounds particles contribute nothing) falls on the other side of it on one of the two paths (a composed map
+                # against the elements' maps one by one): a few pixels may differ by one particle's charge
                 differing = int(((ra.double() - rb.double()).abs() > 2e-4 * rb.double().abs().amax()).sum())
                 if differing > 8 or abs(float(ra.double().sum() - rb.double().sum())) > 1e-5 * abs(float(rb.double().sum())):
-                    fails.append(f"histogram screen reading: {differing} pixels differ")
+                    fails.append(f"screen reading ({ea.method}): {differing} pixels differ")
             else:
                 compare(ra, rb, 1e-9 if dt == torch.float64 else 2e-4, "screen reading", fails)
     fails[n0:] = [tag + f for f in fails[n0:]]
