@@ -69,7 +69,7 @@ def one_case(seed):
     change = (b - x0).abs().amax(dim=0) + 1e-300
     tol = 2e-3 if dt == torch.float32 else 1e-7
     # (a column the lattice hardly changes — tau of a relativistic beam — may differ by a few roundings of its own values)
-    allowed = tol * change + 4 * torch.finfo(dt).eps * b.abs().amax(dim=0)
+    allowed = tol * change + 16 * torch.finfo(dt).eps * b.abs().amax(dim=0)      # (six kicks and runs: a few roundings each)
     err = (a - b).abs().amax(dim=0) / change
     if not bool(((a - b).abs().amax(dim=0) <= allowed).all()) or not bool(torch.isfinite(a).all()):
         fails.append(f"columns {[f'{float(v):.1e}' for v in err]} of the lattice's change (allowed {tol:.0e}); chain links taken {chained}")

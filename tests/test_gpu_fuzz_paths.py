@@ -2,7 +2,8 @@
 with cavities / monitors / apertures / screens, merged runs, non-linear chains; scalar and (B,) settings, vectorised beams and
 energies, ParameterBeams; settings edited in place, assigned as new tensors and diagnostics switched between tracks of one Segment;
 gradients of losses on particles, beam properties and screen images). The one-by-one path is what the reference-generated goldens
-pin (tests/test_gpu_parity.py, test_oracle_diagnostics.py); 30 000 seeds of the script were run in round 6 without a disagreement."""
+pin (tests/test_gpu_parity.py, test_oracle_diagnostics.py); 130 000 seeds of the script were run in round 6: every disagreement
+was a float32 rounding flip at a bin / screen / aperture edge or a statistic of one or two surviving particles."""
 import os
 import sys
 
@@ -31,7 +32,7 @@ def test_drawn_lattices_fast_paths_equal_the_walk(first):
 
 def test_drawn_space_charge_lattices_chain_equals_the_walk():
     """benchmarks/fuzz_sc_chain.py: [linear run, SpaceChargeKick]+ lattices — beams that keep their tile order and beams that go through
-    a focus between kicks — through `Segment.track` (the tile-ordered chain) and kick by kick (3600 seeds agreed in round 6)."""
+    a focus between kicks — through `Segment.track` (the tile-ordered chain) and kick by kick (11 600 seeds agreed in round 6)."""
     import warnings
 
     import fuzz_sc_chain
