@@ -136,6 +136,9 @@ def one_case(seed):
     if mode < 0.45:
         observables(seg, els_b, beam, dt, fails)
         return specs, dt, B, n, fails
+    if mode < 0.55 and not B and beam.particles.dim() == 2:
+        record_property(rng, els_a, els_b, beam, dt, fk, fails)
+        return specs, dt, B, n, fails
     for round_ in range(int(rng.integers(1, 4))):
         if round_:
             mutate(rng, els_a, els_b, fk)
@@ -215,6 +218,61 @@ def moments_beam(seg, els_a, els_b, beam, dt, fails):
             compare(ea.reading, eb.reading, tol, "BPM reading", fails, scale=torch.tensor(3e-4))
         if isinstance(ea, ca.Screen):
             compare(ea.reading, eb.reading, 1e-8 if dt == torch.float64 else 1e-3, "screen reading", fails)
+
+
+def record_property(rng, els_a, els_b, beam, dt, fk, fails):
+    """[run of linear elements | active Screen]: the differentiable stretch (RunScreenTrack) and a property of its record as one
+    node on the run's settings (RunMomentEntry) against the walk — value and gradients of a drawn beam property of the read beam."""
+    linear = (ca.Drift, ca.Quadrupole, ca.HorizontalCorrector, ca.VerticalCorrector, ca.Dipole, ca.Solenoid)
+    keep = [k for k, e in enumerate(els_a) if isinstance(e, linear) and getattr(e, "tracking_method", "linear") == "linear"]
+    if not keep:
+        return
+    run_a, run_b = [els_a[k] for k in keep], [els_b[k] for k in keep]
+    pa, pb = [], []
+    for ea, eb in zip(run_a, run_b):
+        for name in ("k1", "angle", "tilt", "length"):
+            if not hasattr(ea, name) or getattr(ea, name).dim() != 0 or (name == "length" and not isinstance(ea, ca.Drift)):
+                continue
+            if rng.random() < 0.4:
+                va = torch.nn.Parameter(getattr(ea, name).detach().clone())
+                vb = torch.nn.Parameter(va.detach().clone())
+                setattr(ea, name, va)
+                setattr(eb, name, vb)
+                pa.append(va)
+                pb.append(vb)
+    if not pa:
+        return
+    mis = [float(rng.normal() * 5e-5), 0.0] if rng.random() < 0.3 else [0.0, 0.0]
+    sa = ca.Screen(resolution=(32, 32), pixel_size=torch.tensor([1e-4, 1e-4], **fk), is_active=True, misalignment=torch.tensor(mis, **fk), **fk)
+    sb = ca.Screen(resolution=(32, 32), pixel_size=torch.tensor([1e-4, 1e-4], **fk), is_active=True, misalignment=torch.tensor(mis, **fk), **fk)
+    seg = ca.Segment(run_a + [sa])
+    prop = str(rng.choice(["sigma_x", "sigma_y", "sigma_px", "mu_x", "mu_y", "sigma_tau", "sigma_p", "mu_px"]))
+    for step in range(int(rng.integers(1, 3))):          # (a second step: plans and memoised moments are reused)
+        for v in pa + pb:
+            v.grad = None
+        seg.track(beam)
+        la = getattr(sa.get_read_beam(), prop)
+        ref = beam
+        for e in run_b + [sb]:
+            ref = e.track(ref)
+        lb = getattr(sb.get_read_beam(), prop)
+        if la.requires_grad != lb.requires_grad:
+            fails.append(f"{prop}: requires_grad {la.requires_grad} vs {lb.requires_grad}")
+            return
+        compare(la.detach(), lb.detach(), 1e-10 if dt == torch.float64 else 2e-5, prop, fails, scale=lb.detach().abs() + 1e-7)
+        if not lb.requires_grad:
+            return
+        la.backward()
+        lb.backward()
+        rel = 1e-7 if dt == torch.float64 else 5e-3
+        gmax = max(float(v.grad.abs()) if v.grad is not None else 0.0 for v in pb) + 1e-300
+        for k, (va, vb) in enumerate(zip(pa, pb)):
+            ga = float(va.grad) if va.grad is not None else 0.0
+            gb = float(vb.grad) if vb.grad is not None else 0.0
+            if ga != ga and gb != gb:
+                continue
+            if not abs(ga - gb) <= rel * max(abs(gb), 1e-3 * gmax) + (1e-13 if dt == torch.float64 else 1e-5) * max(abs(float(lb.detach())), 1e-5) / max(abs(float(vb.detach())), 1e-3):
+                fails.append(f"d {prop} / d setting {k}: {ga:.6e} vs {gb:.6e} (step {step})")
 
 
 def observables(seg, els_b, beam, dt, fails):
