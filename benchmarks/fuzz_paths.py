@@ -259,7 +259,7 @@ def record_property(rng, els_a, els_b, beam, dt, fk, fails):
         if la.requires_grad != lb.requires_grad:
             fails.append(f"{prop}: requires_grad {la.requires_grad} vs {lb.requires_grad}")
             return
-        compare(la.detach(), lb.detach(), 1e-10 if dt == torch.float64 else 2e-5, prop, fails, scale=lb.detach().abs() + 1e-7)
+        compare(la.detach(), lb.detach(), 1e-10 if dt == torch.float64 else 5e-5, prop, fails, scale=lb.detach().abs() + 1e-7)
         if not lb.requires_grad:
             return
         la.backward()
