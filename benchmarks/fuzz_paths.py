@@ -94,6 +94,7 @@ def compare(a, b, tol, what, fails, scale=None):
     both_nan = torch.isnan(a64) & torch.isnan(b64)
     finite = b64[~torch.isnan(b64)]
     ref = (finite.abs().amax() if finite.numel() else torch.tensor(0.0, device=b64.device)) if scale is None else scale
+    ref = torch.as_tensor(ref).to(dtype=torch.float64, device=b64.device)      # (+ 1e-300 below must not underflow)
     if bool((torch.isnan(a64) != torch.isnan(b64)).any()):
         fails.append(f"{what}: NaNs in different places")
         return
@@ -138,6 +139,9 @@ def one_case(seed):
         return specs, dt, B, n, fails
     if mode < 0.55 and not B and beam.particles.dim() == 2:
         record_property(rng, els_a, els_b, beam, dt, fk, fails)
+        return specs, dt, B, n, fails
+    if mode < 0.62:
+        replayed(rng, seg, els_a, els_b, beam, dt, fails)
         return specs, dt, B, n, fails
     for round_ in range(int(rng.integers(1, 4))):
         if round_:
@@ -273,6 +277,61 @@ def record_property(rng, els_a, els_b, beam, dt, fk, fails):
                 continue
             if not abs(ga - gb) <= rel * max(abs(gb), 1e-3 * gmax) + (1e-13 if dt == torch.float64 else 1e-5) * max(abs(float(lb.detach())), 1e-5) / max(abs(float(vb.detach())), 1e-3):
                 fails.append(f"d {prop} / d setting {k}: {ga:.6e} vs {gb:.6e} (step {step})")
+
+
+def replayed(rng, seg, els_a, els_b, beam, dt, fails):
+    """The step (track + every monitor's and screen's reading) captured once into a device graph (cheetah_amd.graph.capture) and
+    replayed after the settings were edited IN PLACE: the replay against the walk with the edited settings."""
+    import cheetah_amd.graph as graph
+
+    def step():
+        out = seg.track(beam)
+        reads = [e.reading for e in els_a if (isinstance(e, ca.BPM) and e.is_active) or (isinstance(e, ca.Screen) and (e.method == "cloud-in-cell" or beam.particles.dim() == 2))]
+        return out.particles, out.survival_probabilities, out.energy, reads
+
+    with torch.no_grad():
+        try:
+            captured = graph.capture(step)
+        except NotImplementedError:
+            return                            # ('histogram' under a vectorised beam: refused like the reference's)
+        for _ in range(2):
+            for ea, eb in zip(els_a, els_b):          # in place, the same on both copies
+                if isinstance(ea, ca.Quadrupole) and rng.random() < 0.7:
+                    f = float(rng.uniform(0.6, 1.4))
+                    ea.k1.mul_(f)
+                    eb.k1.mul_(f)
+                elif isinstance(ea, (ca.HorizontalCorrector, ca.VerticalCorrector)) and rng.random() < 0.7:
+                    ea.angle.mul_(-0.5)
+                    eb.angle.mul_(-0.5)
+            particles, survival, energy, reads = captured()
+            ref = beam
+            for e in els_b:
+                ref = e.track(ref)
+            tol = 2e-11 if dt == torch.float64 else 1e-4
+            cols = ref.particles.double().abs().reshape(-1, 7).amax(dim=0) + 1e-300
+            if particles.shape != ref.particles.shape:
+                fails.append(f"replay: particle shapes {tuple(particles.shape)} vs {tuple(ref.particles.shape)}")
+                return
+            d = (particles.double() - ref.particles.double()).abs().reshape(-1, 7).amax(dim=0) / cols
+            if not bool((d <= tol).all()):
+                fails.append(f"replay: particles per-column error {[f'{float(v):.2e}' for v in d]}")
+            flips = int(((survival - ref.survival_probabilities).abs() > tol).sum()) if survival.shape == ref.survival_probabilities.shape else 99
+            if flips > (3 if dt == torch.float32 else 0):
+                fails.append(f"replay: survival differs in {flips} entries")
+            compare(energy, ref.energy, 1e-12 if dt == torch.float64 else 2e-7, "replay: energy", fails)
+            if flips:
+                return
+            want = [e.reading for e in els_b if (isinstance(e, ca.BPM) and e.is_active) or (isinstance(e, ca.Screen) and (e.method == "cloud-in-cell" or beam.particles.dim() == 2))]
+            for ra, rb in zip(reads, want):
+                if dt == torch.float32 and ra.dim() >= 2:
+                    differing = int(((ra.double() - rb.double()).abs() > 2e-4 * rb.double().abs().amax()).sum())
+                    if differing > 8:
+                        fails.append(f"replay: screen reading differs in {differing} pixels")
+                else:
+                    compare(ra, rb, 1e-9 if dt == torch.float64 else 3e-5, "replay: reading", fails,
+                            scale=torch.tensor(3e-4) if ra.shape[-1] == 2 and ra.dim() <= 2 else None)
+            if fails:
+                return
 
 
 def observables(seg, els_b, beam, dt, fails):
