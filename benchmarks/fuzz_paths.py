@@ -207,12 +207,40 @@ def gradients(rng, seg, els_a, els_b, beam, dt, fails):
 
 
 def moments_beam(seg, els_a, els_b, beam, dt, fails):
-    """The same lattice on a ParameterBeam: Segment.track against the elements one by one."""
+    """The same lattice on a ParameterBeam: Segment.track against the elements one by one; with scalar settings also the gradients of
+    a loss on the outgoing moments with respect to settings made Parameters."""
     pb = beam.as_parameter_beam()
+    pa, pbs = [], []
+    scalar = all(getattr(e, n).dim() == 0 for e in els_a for n in ("k1", "angle", "voltage", "phase") if hasattr(e, n) and not isinstance(e, ca.Dipole))
+    if scalar and pb.mu.dim() == 1:
+        for ea, eb in zip(els_a, els_b):
+            for name in ("k1", "angle"):
+                if isinstance(ea, ca.Dipole) or not hasattr(ea, name) or getattr(ea, name).dim() != 0:
+                    continue
+                va = torch.nn.Parameter(getattr(ea, name).detach().clone())
+                vb = torch.nn.Parameter(va.detach().clone())
+                setattr(ea, name, va)
+                setattr(eb, name, vb)
+                pa.append(va)
+                pbs.append(vb)
     out = seg.track(pb)
     ref = pb
     for e in els_b:
         ref = e.track(ref)
+    if pa and out.mu.requires_grad and ref.mu.requires_grad:
+        W = torch.linspace(0.3, 1.7, 49, dtype=dt, device="cuda").reshape(7, 7)
+        la = (out.cov * W).sum() * 1e6 + out.mu[:6].sum() * 1e2
+        lb = (ref.cov * W).sum() * 1e6 + ref.mu[:6].sum() * 1e2
+        la.backward()
+        lb.backward()
+        gmax = max(float(v.grad.abs()) if v.grad is not None else 0.0 for v in pbs) + 1e-300
+        rel = 1e-8 if dt == torch.float64 else 5e-3
+        for k, (va, vb) in enumerate(zip(pa, pbs)):
+            ga = float(va.grad) if va.grad is not None else 0.0
+            gb = float(vb.grad) if vb.grad is not None else 0.0
+            if not abs(ga - gb) <= rel * max(abs(gb), 1e-3 * gmax):
+                fails.append(f"ParameterBeam gradient {k}: {ga:.6e} vs {gb:.6e}")
+        out, ref = out.detach() if hasattr(out, "detach") else out, ref
     tol = 1e-10 if dt == torch.float64 else 1e-4
     compare(out.mu, ref.mu, tol, "mu", fails)
     compare(out.cov, ref.cov, tol, "cov", fails)

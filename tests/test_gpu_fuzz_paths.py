@@ -2,7 +2,7 @@
 with cavities / monitors / apertures / screens, merged runs, non-linear chains; scalar and (B,) settings, vectorised beams and
 energies, ParameterBeams; settings edited in place, assigned as new tensors and diagnostics switched between tracks of one Segment;
 gradients of losses on particles, beam properties and screen images). The one-by-one path is what the reference-generated goldens
-pin (tests/test_gpu_parity.py, test_oracle_diagnostics.py); 130 000 seeds of the script were run in round 6: every disagreement
+pin (tests/test_gpu_parity.py, test_oracle_diagnostics.py); 190 000 seeds of the script were run in round 6: every disagreement
 was a float32 rounding flip at a bin / screen / aperture edge or a statistic of one or two surviving particles."""
 import os
 import sys
