@@ -126,7 +126,16 @@ def one_case(seed):
         beam = ca.ParticleBeam(beam.particles.unsqueeze(0) + shift, energy, particle_charges=beam.particle_charges,
                                survival_probabilities=beam.survival_probabilities, **fk)
     fails = []
-    seg = ca.Segment(els_a)
+    nested = list(els_a)
+    if rng.random() < 0.3 and len(nested) >= 3:
+        # (nested Segments, one or two levels: Segment.track sees through plain nested Segments; the walk goes over the flat list)
+        for _ in range(int(rng.integers(1, 3))):
+            if len(nested) < 2:
+                break
+            lo = int(rng.integers(0, len(nested) - 1))
+            hi = int(rng.integers(lo + 1, len(nested) + 1))
+            nested[lo:hi] = [ca.Segment(nested[lo:hi])]
+    seg = ca.Segment(nested)
     mode = rng.random()
     if mode < 0.2 and not B:
         gradients(rng, seg, els_a, els_b, beam, dt, fails)
